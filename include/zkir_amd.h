@@ -1,0 +1,210 @@
+/* zkir_amd.h — C ABI of the MI355X-native ZKIR v3.4 execution-trace path.
+ *
+ * The reference (seceq/zkir) has NO FFI/plugin boundary: its only seam is the Rust API
+ *     VM::new(program, inputs, config) -> VM          zkir-runtime/src/vm.rs:138
+ *     VM::run(self) -> Result<ExecutionResult>        zkir-runtime/src/vm.rs:208
+ *     ExecutionResult::get_memory_trace()             zkir-runtime/src/vm.rs:85-94
+ * so this header defines the boundary a thin Rust shim would bind to replace that
+ * path.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Two layers:
+ *   1. zkir_exec / zkir_result_*  — drop-in for VM::new + VM::run: host interpreter -> delta log ->
+ *      HIP kernels that materialise the wide SoA trace in HBM.
+ *   2. zkir_interpret / zkir_*_launch — the same stages individually (host delta log; device kernels
+ *      on caller-owned device buffers and a caller-chosen HIP stream), used by bench.py and by
+ *      multi-GPU row sharding.
+ *
+ * Error codes mirror RuntimeError (zkir-runtime/src/error.rs:7-37) + program validation
+ * (zkir-spec/src/program.rs:147-167).  The message of the last failure on the calling thread is
+ * returned by zkir_last_error().
+ */
+#ifndef ZKIR_AMD_H
+#define ZKIR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------------------------- */
+enum {
+  ZKIR_OK = 0,
+  ZKIR_ERR_MISALIGNED = 1,      /* RuntimeError::MisalignedAccess      error.rs:15 */
+  ZKIR_ERR_INVALID_MEMORY = 2,  /* RuntimeError::InvalidMemoryAccess   error.rs:18 */
+  ZKIR_ERR_DIV_ZERO = 3,        /* RuntimeError::DivisionByZero        error.rs:21 */
+  ZKIR_ERR_INVALID_SYSCALL = 4, /* RuntimeError::InvalidSyscall        error.rs:24 */
+  ZKIR_ERR_DECODE = 5,          /* RuntimeError::Other("Decode error") vm.rs:376   */
+  ZKIR_ERR_OTHER = 6,           /* RuntimeError::Other                 error.rs:36 */
+  ZKIR_ERR_BAD_PROGRAM = 7,     /* ZkIrError header/size validation program.rs:147-167,318-346; debug-format
+                                   programs (vm.rs:141-147 panics) are reported here instead of aborting */
+  ZKIR_ERR_DEVICE = 8,          /* HIP failure / no device: the product path never falls back to the CPU */
+  ZKIR_ERR_ARGUMENT = 9
+};
+
+/* HaltReason, zkir-runtime/src/state.rs:8-15 */
+enum { ZKIR_HALT_EBREAK = 0, ZKIR_HALT_EXIT = 1, ZKIR_HALT_CYCLE_LIMIT = 2 };
+
+/* BoundSource tag, zkir-spec/src/bound.rs:82-93 (declaration order); payload meaning per tag */
+enum {
+  ZKIR_BOUND_PROGRAM_WIDTH = 0, /* payload 0 */
+  ZKIR_BOUND_TYPE_WIDTH = 1,    /* payload = bits */
+  ZKIR_BOUND_CRYPTO_OUTPUT = 2, /* payload = CryptoType: 0 Sha256, 1 Keccak256, 2 Poseidon2, 3 Blake3 (bound.rs:10-19) */
+  ZKIR_BOUND_COMPUTED = 3,      /* payload 0 */
+  ZKIR_BOUND_CONSTANT = 4       /* payload = the constant */
+};
+
+/* VMConfig, zkir-runtime/src/vm.rs:15-50 (defaults: 1_000_000, false, false, false, false) */
+typedef struct zkir_vm_config {
+  uint64_t max_cycles;
+  uint8_t trace;                  /* per-cycle eprintln; ignored */
+  uint8_t enable_range_checking;
+  uint8_t enable_execution_trace;
+  uint8_t enable_deferred_model;
+} zkir_vm_config;
+
+/* ---- delta log (host memory): what the sequential interpreter hands to the GPU ---------------- */
+
+/* One register write: the full (value, bound, storage-state) triple of register `reg`, visible in the
+ * pre-state of every row >= vis (TraceRow holds the state BEFORE its instruction, vm.rs:245-253).
+ * Events are ordered by vis; there is at most one event per (reg, vis).  The first 16 events are the
+ * initial snapshot (event r describes register r, vis = 0), so every register always has a writer. */
+typedef struct zkir_reg_event {
+  uint64_t value;     /* VMState.regs[reg] raw u64 (un-masked, state.rs:87-91) */
+  uint64_t payload;   /* BoundSource payload */
+  uint32_t max_bits;  /* ValueBound.max_bits */
+  uint32_t vis;       /* shard-relative row index from which the write is visible (= cycle + 1) */
+  uint8_t reg;        /* 0..15 */
+  uint8_t state;      /* RegisterState: 0 Normalized, 1 Accumulated (trace.rs:11-17) */
+  uint8_t tag;        /* ZKIR_BOUND_* */
+  uint8_t pad[5];
+} zkir_reg_event;     /* 32 bytes */
+
+/* One architectural data-memory access (MemoryOp, trace.rs:149-167); bound is always
+ * TypeWidth(8*width) (memory.rs:245) and is re-derived on the device. */
+typedef struct zkir_mem_event {
+  uint64_t address;
+  uint64_t value;
+  uint32_t row;       /* = timestamp = cycle */
+  uint8_t is_write;
+  uint8_t width;      /* 1, 2, 4, 8 */
+  uint16_t pad;
+} zkir_mem_event;     /* 24 bytes */
+
+/* A deferred range check flushed at a checkpoint (range_check.rs:59-66, 140-168) */
+typedef struct zkir_rc_event {
+  uint64_t value;     /* Value40::to_u64() */
+  uint64_t pc;
+} zkir_rc_event;      /* 16 bytes */
+
+/* An observation-point normalization (normalization_witness.rs:19-43), before expansion */
+typedef struct zkir_norm_event {
+  uint64_t cycle;
+  uint64_t pc;
+  uint64_t raw_value; /* register value before normalization */
+  uint8_t reg;
+  uint8_t state;      /* storage state before normalization (selects 20- or 30-bit unpacking, state.rs:202-220) */
+  uint8_t opcode;     /* triggering opcode byte */
+  uint8_t pad[5];
+} zkir_norm_event;    /* 32 bytes */
+
+/* A single-block SHA-256 syscall (input_len < 56): the padded 64-byte message block, big-endian words
+ * as parse_message_block produces them (crypto.rs:127-139), and the row it belongs to. */
+typedef struct zkir_sha_block {
+  uint32_t message_block[16];
+  uint64_t timestamp;
+} zkir_sha_block;     /* 72 bytes */
+
+typedef struct zkir_delta_log zkir_delta_log;   /* opaque, host memory */
+
+/* Run the program on the host interpreter (bit-exact to VM::run, vm.rs:208-358) and record the delta
+ * log.  tile_rows (power of two, 256..4096; 0 = default) fixes the granularity of the tile index.
+ * Returns ZKIR_OK or an error code (then *out is NULL). No device is touched. */
+int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
+                   const zkir_vm_config* cfg, uint32_t tile_rows, zkir_delta_log** out);
+void zkir_delta_log_free(zkir_delta_log* log);
+
+uint64_t zkir_delta_log_cycles(const zkir_delta_log*);        /* ExecutionResult.cycles */
+int zkir_delta_log_halt_kind(const zkir_delta_log*);          /* ZKIR_HALT_* */
+uint64_t zkir_delta_log_halt_code(const zkir_delta_log*);     /* Exit(code) */
+size_t zkir_delta_log_n_outputs(const zkir_delta_log*);
+const uint64_t* zkir_delta_log_outputs(const zkir_delta_log*);
+uint64_t zkir_delta_log_n_rows(const zkir_delta_log*);        /* 0 unless enable_execution_trace */
+uint32_t zkir_delta_log_tile_rows(const zkir_delta_log*);
+const uint64_t* zkir_delta_log_pc(const zkir_delta_log*);     /* [n_rows] TraceRow.pc          */
+const uint32_t* zkir_delta_log_inst(const zkir_delta_log*);   /* [n_rows] TraceRow.instruction */
+size_t zkir_delta_log_n_reg_events(const zkir_delta_log*);    /* includes the 16 snapshot events */
+const zkir_reg_event* zkir_delta_log_reg_events(const zkir_delta_log*);
+size_t zkir_delta_log_n_tiles(const zkir_delta_log*);
+const uint32_t* zkir_delta_log_tile_ev_off(const zkir_delta_log*); /* [n_tiles+1] first event with vis > tile start */
+const uint32_t* zkir_delta_log_tile_snap(const zkir_delta_log*);   /* [n_tiles][16] last event per register with vis <= tile start */
+size_t zkir_delta_log_n_mem_events(const zkir_delta_log*);
+const zkir_mem_event* zkir_delta_log_mem_events(const zkir_delta_log*);
+size_t zkir_delta_log_n_rc_events(const zkir_delta_log*);
+const zkir_rc_event* zkir_delta_log_rc_events(const zkir_delta_log*);
+size_t zkir_delta_log_n_rc_witnesses(const zkir_delta_log*);
+const uint64_t* zkir_delta_log_rc_offsets(const zkir_delta_log*);  /* [n_rc_witnesses+1] CSR over rc_events */
+uint32_t zkir_delta_log_rc_chunk_bits(const zkir_delta_log*);      /* header limb_bits / 2 (range_check.rs:29) */
+size_t zkir_delta_log_n_norm_events(const zkir_delta_log*);
+const zkir_norm_event* zkir_delta_log_norm_events(const zkir_delta_log*);
+size_t zkir_delta_log_n_sha_blocks(const zkir_delta_log*);
+const zkir_sha_block* zkir_delta_log_sha_blocks(const zkir_delta_log*);
+
+/* ---- device stage: kernels on caller-owned device memory ------------------------------------- */
+
+/* The wide execution trace in HBM, struct-of-arrays (one contiguous column per field per register;
+ * TraceRow schema zkir-spec/src/trace.rs:24-50).  Register-indexed arrays are [16][reg_stride]
+ * elements, column r starting at base + r*reg_stride. 372 bytes per row in total. */
+typedef struct zkir_trace_columns {
+  uint64_t* cycle;          /* [n_rows]                                        8 B/row  */
+  uint64_t* pc;             /* [n_rows]  (may alias the uploaded delta-log pc)  8 B/row  */
+  uint32_t* instruction;    /* [n_rows]  (may alias the uploaded delta-log inst)4 B/row  */
+  uint64_t* registers;      /* [16][reg_stride]                               128 B/row */
+  uint32_t* bound_bits;     /* [16][reg_stride]                                64 B/row */
+  uint8_t* bound_tag;       /* [16][reg_stride]                                16 B/row */
+  uint64_t* bound_payload;  /* [16][reg_stride]                               128 B/row */
+  uint8_t* reg_state;       /* [16][reg_stride]                                16 B/row */
+  uint64_t reg_stride;      /* elements between consecutive register columns (>= n_rows, multiple of 16) */
+} zkir_trace_columns;
+
+typedef struct zkir_trace_fill_args {
+  const zkir_reg_event* events;   /* device, [n_events] */
+  const uint32_t* tile_ev_off;    /* device, [n_tiles+1] */
+  const uint32_t* tile_snap;      /* device, [n_tiles][16] */
+  uint64_t n_rows;
+  uint64_t cycle_base;            /* TraceRow.cycle of row 0 (row-sharding across GPUs) */
+  uint32_t tile_rows;
+  uint32_t n_events;
+  zkir_trace_columns out;         /* device */
+} zkir_trace_fill_args;
+
+/* K1: expand the register-write log into the SoA trace columns (cycle, registers, bounds, states).
+ * Asynchronous on `hip_stream` (a hipStream_t; NULL = default stream). */
+int zkir_trace_fill_launch(const zkir_trace_fill_args* args, void* hip_stream);
+
+/* Algorithmic HBM bytes one zkir_trace_fill_launch moves: 360*n_rows written +
+ * 32*n_events + 68*n_tiles read. */
+uint64_t zkir_trace_fill_bytes(uint64_t n_rows, uint64_t n_events, uint64_t n_tiles);
+
+/* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
+typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */
+
+/* program_blob is Program::to_bytes() (program.rs:300-315).  On success the trace columns are resident
+ * on the current HIP device.  Fails with ZKIR_ERR_DEVICE if no GPU is usable (no CPU fallback). */
+int zkir_exec(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
+              const zkir_vm_config* cfg, zkir_result** out);
+void zkir_result_free(zkir_result* r);
+const zkir_delta_log* zkir_result_delta_log(const zkir_result* r);       /* host-side metadata */
+const zkir_trace_columns* zkir_result_trace(const zkir_result* r);       /* device pointers */
+/* copy one device column to host: field = 0 cycle,1 pc,2 instruction,3 registers,4 bound_bits,5 bound_tag,
+ * 6 bound_payload,7 reg_state; reg ignored for fields 0-2.  dst must hold n_rows elements. */
+int zkir_result_copy_column(const zkir_result* r, int field, int reg, void* dst);
+
+const char* zkir_last_error(void);
+const char* zkir_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKIR_AMD_H */

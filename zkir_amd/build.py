@@ -1,0 +1,57 @@
+"""Build libzkir_amd.so (host interpreter + HIP kernels + C ABI) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with gpurun.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libzkir_amd.so")
+OBJ = os.path.join(HERE, "build")
+
+HOST_SOURCES = ["interp.cpp", "hashes.cpp"]
+HIP_SOURCES = ["trace_fill.hip", "abi.hip"]
+HEADERS = ["host.h", os.path.join("..", "..", "include", "zkir_amd.h")]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(src: str, dst: str, deps) -> bool:
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in [src] + list(deps))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    deps = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs = []
+    for name in HOST_SOURCES + HIP_SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJ, name + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj, deps):
+            if name.endswith(".hip"):
+                cmd = [HIPCC, f"--offload-arch={ARCH}", *COMMON, "-c", src, "-o", obj]
+            else:
+                cmd = [HIPCC, "-x", "c++", *COMMON, "-march=x86-64-v2", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or any(_newer(o, OUT, []) for o in objs):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

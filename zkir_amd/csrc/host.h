@@ -1,0 +1,99 @@
+// host.h — internal host-side types of libzkir_amd (not part of the C ABI).
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zkir_amd.h"
+
+#define ZKIR_DEFAULT_TILE_ROWS 1024u
+
+namespace zkir {
+
+struct Status {
+  int code = ZKIR_OK;
+  std::string msg;
+  bool ok() const { return code == ZKIR_OK; }
+};
+
+struct BoundT {            // ValueBound, zkir-spec/src/bound.rs:116-121
+  uint32_t max_bits;
+  uint8_t tag;
+  uint64_t payload;
+};
+
+// Growable POD buffer backed by realloc (mremap for large blocks: growth neither copies nor re-faults).
+template <typename T>
+class Buf {
+ public:
+  Buf() = default;
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  ~Buf() { free(p_); }
+  void reserve(size_t n) {
+    if (n <= cap_) return;
+    void* q = realloc(p_, n * sizeof(T));
+    if (!q) throw std::bad_alloc();
+    p_ = (T*)q; cap_ = n;
+  }
+  inline void push(const T& v) {
+    if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024);
+    p_[n_++] = v;
+  }
+  size_t size() const { return n_; }
+  const T* data() const { return p_; }
+  T* data() { return p_; }
+  const T& operator[](size_t i) const { return p_[i]; }
+
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
+struct ProgramView {       // parsed Program blob (zkir-spec/src/program.rs:318-346); points into the caller's bytes
+  uint8_t limb_bits = 20, data_limbs = 2, addr_limbs = 2;
+  uint32_t entry_point = 0x1000;
+  const uint8_t* code = nullptr; uint64_t n_code_words = 0;
+  const uint8_t* data = nullptr; uint64_t n_data = 0;
+};
+
+}  // namespace zkir
+
+// The opaque C-ABI handle: everything the sequential interpreter produced, in host memory.
+struct zkir_delta_log {
+  uint64_t cycles = 0;
+  int halt_kind = ZKIR_HALT_EBREAK;
+  uint64_t halt_code = 0;
+  uint64_t n_rows = 0;
+  uint32_t tile_rows = ZKIR_DEFAULT_TILE_ROWS;
+  uint32_t rc_chunk_bits = 10;
+  std::vector<uint64_t> outputs;
+  zkir::Buf<uint64_t> pc;
+  zkir::Buf<uint32_t> inst;
+  zkir::Buf<zkir_reg_event> reg_events;
+  std::vector<uint32_t> tile_ev_off;
+  std::vector<uint32_t> tile_snap;
+  zkir::Buf<zkir_mem_event> mem_events;
+  zkir::Buf<zkir_rc_event> rc_events;
+  std::vector<uint64_t> rc_offsets;
+  zkir::Buf<zkir_norm_event> norm_events;
+  zkir::Buf<zkir_sha_block> sha_blocks;
+};
+
+namespace zkir {
+using DeltaLog = ::zkir_delta_log;
+
+Status parse_program(const uint8_t* blob, size_t len, ProgramView& pv);
+Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log);
+
+// hashes.cpp — the digests behind syscalls 3/5/6 (zkir-runtime/src/crypto.rs uses sha2 / sha3::Keccak256 / blake3)
+void sha256(const uint8_t* data, size_t len, uint32_t out_be_words[8]);
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
+void blake3(const uint8_t* data, size_t len, uint8_t out[32]);
+
+void set_last_error(const Status& st);
+}  // namespace zkir

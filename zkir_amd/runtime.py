@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's `zkir_runtime` API on top of the C ABI (include/zkir_amd.h).
+
+    reference (Rust)                                   here
+    -----------------------------------------------    ---------------------------------------------
+    VMConfig {max_cycles, trace, enable_* ..}          VMConfig                      vm.rs:15-50
+    VM::new(program, inputs, config)                   VM(program, inputs, config)   vm.rs:138
+    VM::run(self) -> Result<ExecutionResult>           VM.run() -> ExecutionResult   vm.rs:208
+    ExecutionResult.{cycles, outputs, halt_reason,     same attribute names          vm.rs:54-78
+       range_check_witnesses, execution_trace,
+       normalization_witnesses}
+    ExecutionResult::get_memory_trace()                ExecutionResult.get_memory_trace()   vm.rs:85-94
+    RuntimeError::{MisalignedAccess, ..}               RuntimeError(code, message)   error.rs:7-37
+    zkir_runtime::run(program, inputs)                 run(program, inputs)          lib.rs:59-62
+
+The wide execution trace stays resident in HBM (SoA columns); `execution_trace.column(...)` copies one
+column to the host, `execution_trace.rows()` reassembles reference-shaped TraceRow records (for tests).
+There is no CPU fallback: without the built HIP library or without a GPU, trace collection raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .spec import Program
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libzkir_amd.so")
+
+(ZKIR_OK, ERR_MISALIGNED, ERR_INVALID_MEMORY, ERR_DIV_ZERO, ERR_INVALID_SYSCALL, ERR_DECODE, ERR_OTHER, ERR_BAD_PROGRAM,
+ ERR_DEVICE, ERR_ARGUMENT) = range(10)
+HALT_EBREAK, HALT_EXIT, HALT_CYCLE_LIMIT = 0, 1, 2
+
+REG_EVENT_DTYPE = np.dtype([("value", "<u8"), ("payload", "<u8"), ("max_bits", "<u4"), ("vis", "<u4"), ("reg", "u1"),
+                            ("state", "u1"), ("tag", "u1"), ("pad", "u1", (5,))])
+MEM_EVENT_DTYPE = np.dtype([("address", "<u8"), ("value", "<u8"), ("row", "<u4"), ("is_write", "u1"), ("width", "u1"), ("pad", "<u2")])
+RC_EVENT_DTYPE = np.dtype([("value", "<u8"), ("pc", "<u8")])
+NORM_EVENT_DTYPE = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("raw_value", "<u8"), ("reg", "u1"), ("state", "u1"), ("opcode", "u1"),
+                             ("pad", "u1", (5,))])
+SHA_BLOCK_DTYPE = np.dtype([("message_block", "<u4", (16,)), ("timestamp", "<u8")])
+assert REG_EVENT_DTYPE.itemsize == 32 and MEM_EVENT_DTYPE.itemsize == 24 and NORM_EVENT_DTYPE.itemsize == 32 and SHA_BLOCK_DTYPE.itemsize == 72
+
+FIELD_CYCLE, FIELD_PC, FIELD_INSTRUCTION, FIELD_REGISTERS, FIELD_BOUND_BITS, FIELD_BOUND_TAG, FIELD_BOUND_PAYLOAD, FIELD_REG_STATE = range(8)
+_FIELD_DTYPE = {0: "<u8", 1: "<u8", 2: "<u4", 3: "<u8", 4: "<u4", 5: "u1", 6: "<u8", 7: "u1"}
+
+
+class RuntimeError(Exception):  # noqa: A001 - mirrors zkir_runtime::RuntimeError
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code, self.message = code, message
+
+
+class VmConfigC(C.Structure):
+    _fields_ = [("max_cycles", C.c_uint64), ("trace", C.c_uint8), ("enable_range_checking", C.c_uint8),
+                ("enable_execution_trace", C.c_uint8), ("enable_deferred_model", C.c_uint8)]
+
+
+class TraceColumnsC(C.Structure):
+    _fields_ = [("cycle", C.c_void_p), ("pc", C.c_void_p), ("instruction", C.c_void_p), ("registers", C.c_void_p),
+                ("bound_bits", C.c_void_p), ("bound_tag", C.c_void_p), ("bound_payload", C.c_void_p), ("reg_state", C.c_void_p),
+                ("reg_stride", C.c_uint64)]
+
+
+class TraceFillArgsC(C.Structure):
+    _fields_ = [("events", C.c_void_p), ("tile_ev_off", C.c_void_p), ("tile_snap", C.c_void_p), ("n_rows", C.c_uint64),
+                ("cycle_base", C.c_uint64), ("tile_rows", C.c_uint32), ("n_events", C.c_uint32), ("out", TraceColumnsC)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libzkir_amd.so; fails loudly if it has not been built (python -m zkir_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(f"{_SO} is missing: build it with `python zkir_amd/build.py` (hipcc --offload-arch=gfx950). "
+                          "zkir_amd has no pure-Python or CPU fallback.")
+    L = C.CDLL(_SO)
+    L.zkir_last_error.restype = C.c_char_p
+    L.zkir_version.restype = C.c_char_p
+    L.zkir_interpret.restype = C.c_int
+    L.zkir_interpret.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.c_uint32,
+                                 C.POINTER(C.c_void_p)]
+    L.zkir_delta_log_free.argtypes = [C.c_void_p]
+    L.zkir_delta_log_free.restype = None
+    for name, res in [("cycles", C.c_uint64), ("halt_kind", C.c_int), ("halt_code", C.c_uint64), ("n_outputs", C.c_size_t),
+                      ("outputs", C.c_void_p), ("n_rows", C.c_uint64), ("tile_rows", C.c_uint32), ("pc", C.c_void_p),
+                      ("inst", C.c_void_p), ("n_reg_events", C.c_size_t), ("reg_events", C.c_void_p), ("n_tiles", C.c_size_t),
+                      ("tile_ev_off", C.c_void_p), ("tile_snap", C.c_void_p), ("n_mem_events", C.c_size_t),
+                      ("mem_events", C.c_void_p), ("n_rc_events", C.c_size_t), ("rc_events", C.c_void_p),
+                      ("n_rc_witnesses", C.c_size_t), ("rc_offsets", C.c_void_p), ("rc_chunk_bits", C.c_uint32),
+                      ("n_norm_events", C.c_size_t), ("norm_events", C.c_void_p), ("n_sha_blocks", C.c_size_t),
+                      ("sha_blocks", C.c_void_p)]:
+        f = getattr(L, "zkir_delta_log_" + name)
+        f.restype = res
+        f.argtypes = [C.c_void_p]
+    L.zkir_trace_fill_launch.restype = C.c_int
+    L.zkir_trace_fill_launch.argtypes = [C.POINTER(TraceFillArgsC), C.c_void_p]
+    L.zkir_trace_fill_bytes.restype = C.c_uint64
+    L.zkir_trace_fill_bytes.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    L.zkir_exec.restype = C.c_int
+    L.zkir_exec.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.POINTER(C.c_void_p)]
+    L.zkir_result_free.argtypes = [C.c_void_p]
+    L.zkir_result_free.restype = None
+    L.zkir_result_delta_log.restype = C.c_void_p
+    L.zkir_result_delta_log.argtypes = [C.c_void_p]
+    L.zkir_result_trace.restype = C.POINTER(TraceColumnsC)
+    L.zkir_result_trace.argtypes = [C.c_void_p]
+    L.zkir_result_copy_column.restype = C.c_int
+    L.zkir_result_copy_column.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _raise(code: int):
+    raise RuntimeError(code, lib().zkir_last_error().decode())
+
+
+def _view(ptr, n, dtype) -> np.ndarray:
+    dtype = np.dtype(dtype)
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+@dataclass
+class VMConfig:
+    """vm.rs:15-50 (same defaults)."""
+    max_cycles: int = 1_000_000
+    trace: bool = False
+    enable_range_checking: bool = False
+    enable_execution_trace: bool = False
+    enable_deferred_model: bool = False
+
+    def _c(self) -> VmConfigC:
+        return VmConfigC(self.max_cycles, int(self.trace), int(self.enable_range_checking), int(self.enable_execution_trace),
+                         int(self.enable_deferred_model))
+
+
+@dataclass(frozen=True)
+class HaltReason:
+    """state.rs:8-15."""
+    kind: int
+    code: int = 0
+
+    @staticmethod
+    def Ebreak(): return HaltReason(HALT_EBREAK)
+    @staticmethod
+    def Exit(code: int): return HaltReason(HALT_EXIT, code)
+    @staticmethod
+    def CycleLimit(): return HaltReason(HALT_CYCLE_LIMIT)
+
+
+class DeltaLog:
+    """Owner of a zkir_delta_log handle with zero-copy numpy views (valid while this object lives)."""
+
+    def __init__(self, handle: int, owned: bool = True):
+        self._h, self._owned = handle, owned
+        L = lib()
+        h = handle
+        self.cycles = L.zkir_delta_log_cycles(h)
+        self.halt_reason = HaltReason(L.zkir_delta_log_halt_kind(h), L.zkir_delta_log_halt_code(h) if L.zkir_delta_log_halt_kind(h) == HALT_EXIT else 0)
+        self.outputs = _view(L.zkir_delta_log_outputs(h), L.zkir_delta_log_n_outputs(h), "<u8").tolist()
+        self.n_rows = L.zkir_delta_log_n_rows(h)
+        self.tile_rows = L.zkir_delta_log_tile_rows(h)
+        self.pc = _view(L.zkir_delta_log_pc(h), self.n_rows, "<u8")
+        self.inst = _view(L.zkir_delta_log_inst(h), self.n_rows, "<u4")
+        self.reg_events = _view(L.zkir_delta_log_reg_events(h), L.zkir_delta_log_n_reg_events(h), REG_EVENT_DTYPE)
+        self.n_tiles = L.zkir_delta_log_n_tiles(h)
+        self.tile_ev_off = _view(L.zkir_delta_log_tile_ev_off(h), self.n_tiles + 1 if self.n_rows else 0, "<u4")
+        self.tile_snap = _view(L.zkir_delta_log_tile_snap(h), self.n_tiles * 16, "<u4").reshape(-1, 16)
+        self.mem_events = _view(L.zkir_delta_log_mem_events(h), L.zkir_delta_log_n_mem_events(h), MEM_EVENT_DTYPE)
+        self.rc_events = _view(L.zkir_delta_log_rc_events(h), L.zkir_delta_log_n_rc_events(h), RC_EVENT_DTYPE)
+        self.rc_offsets = _view(L.zkir_delta_log_rc_offsets(h), L.zkir_delta_log_n_rc_witnesses(h) + 1, "<u8")
+        self.rc_chunk_bits = L.zkir_delta_log_rc_chunk_bits(h)
+        self.norm_events = _view(L.zkir_delta_log_norm_events(h), L.zkir_delta_log_n_norm_events(h), NORM_EVENT_DTYPE)
+        self.sha_blocks = _view(L.zkir_delta_log_sha_blocks(h), L.zkir_delta_log_n_sha_blocks(h), SHA_BLOCK_DTYPE)
+
+    def close(self):
+        if self._owned and self._h:
+            lib().zkir_delta_log_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def interpret(program: Program | bytes, inputs: Sequence[int] = (), config: Optional[VMConfig] = None, tile_rows: int = 0) -> DeltaLog:
+    """Host stage only (zkir_interpret): run the program, return the delta log.  Never touches a GPU."""
+    blob = program if isinstance(program, (bytes, bytearray)) else program.to_bytes()
+    cfg = (config or VMConfig())._c()
+    arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
+    out = C.c_void_p()
+    rc = lib().zkir_interpret(bytes(blob), len(blob), arr, len(inputs), C.byref(cfg), tile_rows, C.byref(out))
+    if rc != ZKIR_OK:
+        _raise(rc)
+    return DeltaLog(out.value)
+
+
+class ExecutionTrace:
+    """Device-resident SoA execution trace (TraceRow schema, trace.rs:24-50)."""
+
+    def __init__(self, result_handle: int, n_rows: int):
+        self._r, self.n_rows = result_handle, n_rows
+        self.columns = lib().zkir_result_trace(result_handle).contents if n_rows else None
+
+    def __len__(self):
+        return self.n_rows
+
+    def column(self, field: int, reg: int = 0) -> np.ndarray:
+        out = np.empty(self.n_rows, dtype=_FIELD_DTYPE[field])
+        if self.n_rows:
+            rc = lib().zkir_result_copy_column(self._r, field, reg, out.ctypes.data)
+            if rc != ZKIR_OK:
+                _raise(rc)
+        return out
+
+    def rows(self) -> np.ndarray:
+        """All rows as packed reference-shaped records (same dtype as the test oracle's rows)."""
+        dt = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("instruction", "<u4"), ("registers", "<u8", (16,)),
+                       ("bound_bits", "<u4", (16,)), ("bound_tag", "u1", (16,)), ("bound_payload", "<u8", (16,)), ("reg_state", "u1", (16,))])
+        out = np.zeros(self.n_rows, dtype=dt)
+        out["cycle"] = self.column(FIELD_CYCLE)
+        out["pc"] = self.column(FIELD_PC)
+        out["instruction"] = self.column(FIELD_INSTRUCTION)
+        for r in range(16):
+            out["registers"][:, r] = self.column(FIELD_REGISTERS, r)
+            out["bound_bits"][:, r] = self.column(FIELD_BOUND_BITS, r)
+            out["bound_tag"][:, r] = self.column(FIELD_BOUND_TAG, r)
+            out["bound_payload"][:, r] = self.column(FIELD_BOUND_PAYLOAD, r)
+            out["reg_state"][:, r] = self.column(FIELD_REG_STATE, r)
+        return out
+
+
+class ExecutionResult:
+    """vm.rs:54-78."""
+
+    def __init__(self, result_handle: Optional[int], log: DeltaLog):
+        self._r = result_handle
+        self._log = log
+        self.cycles: int = log.cycles
+        self.outputs: List[int] = log.outputs
+        self.halt_reason: HaltReason = log.halt_reason
+        self.execution_trace = ExecutionTrace(result_handle, log.n_rows) if result_handle else ExecutionTrace.__new__(ExecutionTrace)
+        if not result_handle:
+            self.execution_trace._r, self.execution_trace.n_rows, self.execution_trace.columns = None, 0, None
+        self.delta_log = log
+
+    def close(self):
+        if self._r:
+            lib().zkir_result_free(self._r)    # also frees the delta log it owns
+            self._r = None
+            self._log._h = None
+        else:
+            self._log.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VM:
+    """VM::new + VM::run (vm.rs:138-358).  `run()` consumes the VM, as in the reference."""
+
+    def __init__(self, program: Program | bytes, inputs: Sequence[int] = (), config: Optional[VMConfig] = None):
+        self._blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
+        self._inputs = [int(x) & (2**64 - 1) for x in inputs]
+        self._config = config or VMConfig()
+        self._consumed = False
+
+    def run(self) -> ExecutionResult:
+        if self._consumed:
+            raise ValueError("VM::run consumes the VM (vm.rs:208)")
+        self._consumed = True
+        L = lib()
+        cfg = self._config._c()
+        arr = (C.c_uint64 * max(1, len(self._inputs)))(*self._inputs)
+        if not self._config.enable_execution_trace:
+            # nothing to materialise on the device: host stage only
+            return ExecutionResult(None, interpret(self._blob, self._inputs, self._config))
+        out = C.c_void_p()
+        rc = L.zkir_exec(self._blob, len(self._blob), arr, len(self._inputs), C.byref(cfg), C.byref(out))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        log = DeltaLog(L.zkir_result_delta_log(out.value), owned=False)
+        return ExecutionResult(out.value, log)
+
+
+def run(program: Program | bytes, inputs: Sequence[int] = ()) -> List[int]:
+    """zkir_runtime::run (lib.rs:59-62): default config, outputs only."""
+    res = VM(program, inputs, VMConfig()).run()
+    try:
+        return list(res.outputs)
+    finally:
+        res.close()

@@ -1,0 +1,234 @@
+"""ZKIR v3.4 input contract, host side: opcodes, 32-bit encodings and the program blob.
+
+Mirrors (names and meaning) the reference's spec/encoder surface that feeds the hot path:
+  * Opcode                 zkir-spec/src/opcode.rs:24-144
+  * encode(...)            zkir-assembler/src/encoder.rs:18-151 (bit layout zkir-spec/src/encoding.rs:23-60)
+  * Config                 zkir-spec/src/config.rs:10-56
+  * ProgramHeader/Program  zkir-spec/src/program.rs:62-346 (32-byte LE header + code words + data)
+
+This is plain host logic (no device work): it only builds the byte blob that `zkir_exec`
+(include/zkir_amd.h) consumes.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from enum import IntEnum
+from typing import List, Sequence
+
+MAGIC = 0x52494B5A      # program.rs:37  ("ZKIR" little-endian)
+VERSION = 0x00030004    # program.rs:40
+CODE_BASE = 0x1000      # vm.rs:155
+NUM_REGISTERS = 16      # register.rs:10
+
+
+class Opcode(IntEnum):
+    """opcode.rs:24-144 (7-bit opcodes)."""
+    ADD = 0x00; SUB = 0x01; MUL = 0x02; MULH = 0x03; DIVU = 0x04; REMU = 0x05; DIV = 0x06; REM = 0x07; ADDI = 0x08
+    AND = 0x10; OR = 0x11; XOR = 0x12; ANDI = 0x13; ORI = 0x14; XORI = 0x15
+    SLL = 0x18; SRL = 0x19; SRA = 0x1A; SLLI = 0x1B; SRLI = 0x1C; SRAI = 0x1D
+    SLTU = 0x20; SGEU = 0x21; SLT = 0x22; SGE = 0x23; SEQ = 0x24; SNE = 0x25
+    CMOV = 0x26; CMOVZ = 0x27; CMOVNZ = 0x28
+    LB = 0x30; LBU = 0x31; LH = 0x32; LHU = 0x33; LW = 0x34; LD = 0x35
+    SB = 0x38; SH = 0x39; SW = 0x3A; SD = 0x3B
+    BEQ = 0x40; BNE = 0x41; BLT = 0x42; BGE = 0x43; BLTU = 0x44; BGEU = 0x45
+    JAL = 0x48; JALR = 0x49
+    ECALL = 0x50; EBREAK = 0x51
+
+
+R_TYPE = {Opcode.ADD, Opcode.SUB, Opcode.MUL, Opcode.MULH, Opcode.DIVU, Opcode.REMU, Opcode.DIV, Opcode.REM,
+          Opcode.AND, Opcode.OR, Opcode.XOR, Opcode.SLL, Opcode.SRL, Opcode.SRA,
+          Opcode.SLTU, Opcode.SGEU, Opcode.SLT, Opcode.SGE, Opcode.SEQ, Opcode.SNE,
+          Opcode.CMOV, Opcode.CMOVZ, Opcode.CMOVNZ}
+I_TYPE = {Opcode.ADDI, Opcode.ANDI, Opcode.ORI, Opcode.XORI, Opcode.LB, Opcode.LBU, Opcode.LH, Opcode.LHU,
+          Opcode.LW, Opcode.LD, Opcode.JALR}
+SHIFT_I = {Opcode.SLLI, Opcode.SRLI, Opcode.SRAI}
+S_TYPE = {Opcode.SB, Opcode.SH, Opcode.SW, Opcode.SD}
+B_TYPE = {Opcode.BEQ, Opcode.BNE, Opcode.BLT, Opcode.BGE, Opcode.BLTU, Opcode.BGEU}
+
+
+def _r(op: int, rd: int, rs1: int, rs2: int, funct: int = 0) -> int:      # encoder.rs:100-108
+    return (op & 0x7F) | ((rd & 0xF) << 7) | ((rs1 & 0xF) << 11) | ((rs2 & 0xF) << 15) | ((funct & 0x1FFF) << 19)
+
+
+def _i(op: int, rd: int, rs1: int, imm: int) -> int:                       # encoder.rs:112-119 (imm silently masked to 17 bits)
+    return (op & 0x7F) | ((rd & 0xF) << 7) | ((rs1 & 0xF) << 11) | ((imm & 0x1FFFF) << 15)
+
+
+def _j(op: int, rd: int, offset: int) -> int:                              # encoder.rs:145-151
+    return (op & 0x7F) | ((rd & 0xF) << 7) | ((offset & 0x1FFFFF) << 11)
+
+
+def encode(op: Opcode, rd: int = 0, rs1: int = 0, rs2: int = 0, imm: int = 0) -> int:
+    """encode(&Instruction) of zkir-assembler/src/encoder.rs:18-96.
+
+    Field meaning per format: R-type (rd, rs1, rs2); I-type (rd, rs1, imm); shift-immediate
+    (rd, rs1, imm=shamt); S-type and B-type (rs1, rs2, imm/offset) with rs1 in bits 10:7 and rs2 in
+    bits 14:11; JAL (rd, imm=offset)."""
+    op = Opcode(op)
+    if op in R_TYPE:
+        return _r(op, rd, rs1, rs2)
+    if op in I_TYPE:
+        return _i(op, rd, rs1, imm)
+    if op in SHIFT_I:
+        return _i(op, rd, rs1, imm & 0xFF)
+    if op in S_TYPE or op in B_TYPE:
+        return _i(op, rs1, rs2, imm)
+    if op == Opcode.JAL:
+        return _j(op, rd, imm)
+    return _i(op, 0, 0, 0)                                                  # ECALL / EBREAK
+
+
+# ----- convenience constructors in the reference's `Instruction::X { .. }` vocabulary -------------
+def add(rd, rs1, rs2): return encode(Opcode.ADD, rd, rs1, rs2)
+def sub(rd, rs1, rs2): return encode(Opcode.SUB, rd, rs1, rs2)
+def mul(rd, rs1, rs2): return encode(Opcode.MUL, rd, rs1, rs2)
+def addi(rd, rs1, imm): return encode(Opcode.ADDI, rd, rs1, imm=imm)
+def slli(rd, rs1, shamt): return encode(Opcode.SLLI, rd, rs1, imm=shamt)
+def lw(rd, rs1, imm): return encode(Opcode.LW, rd, rs1, imm=imm)
+def sw(rs1, rs2, imm): return encode(Opcode.SW, rs1=rs1, rs2=rs2, imm=imm)   # mem[rs1+imm] = rs2
+def beq(rs1, rs2, off): return encode(Opcode.BEQ, rs1=rs1, rs2=rs2, imm=off)
+def bne(rs1, rs2, off): return encode(Opcode.BNE, rs1=rs1, rs2=rs2, imm=off)
+def jal(rd, off): return encode(Opcode.JAL, rd, imm=off)
+def ecall(): return encode(Opcode.ECALL)
+def ebreak(): return encode(Opcode.EBREAK)
+
+
+@dataclass
+class Config:
+    """config.rs:10-56."""
+    limb_bits: int = 20
+    data_limbs: int = 2
+    addr_limbs: int = 2
+
+    def validate(self) -> None:                                             # config.rs:154-174
+        if not (16 <= self.limb_bits <= 30):
+            raise ValueError("InvalidLimbBits")
+        if self.limb_bits % 2:
+            raise ValueError("OddLimbBits")
+        if not (1 <= self.data_limbs <= 4):
+            raise ValueError("InvalidDataLimbs")
+        if not (1 <= self.addr_limbs <= 2):
+            raise ValueError("InvalidAddrLimbs")
+
+    def data_bits(self) -> int:
+        return self.limb_bits * self.data_limbs
+
+
+@dataclass
+class ProgramHeader:
+    """program.rs:62-214 (32 bytes, little-endian)."""
+    magic: int = MAGIC
+    version: int = VERSION
+    limb_bits: int = 20
+    data_limbs: int = 2
+    addr_limbs: int = 2
+    flags: int = 0
+    entry_point: int = CODE_BASE
+    code_size: int = 0
+    data_size: int = 0
+    bss_size: int = 0
+    stack_size: int = 1 << 20
+
+    SIZE = 32
+
+    def to_bytes(self) -> bytes:                                            # program.rs:170-186
+        return struct.pack("<IIBBBBIIIII", self.magic, self.version, self.limb_bits, self.data_limbs, self.addr_limbs,
+                           self.flags, self.entry_point, self.code_size, self.data_size, self.bss_size, self.stack_size)
+
+    @classmethod
+    def from_bytes(cls, b: bytes) -> "ProgramHeader":                       # program.rs:189-213
+        if len(b) < cls.SIZE:
+            raise ValueError(f"Invalid header size: expected 32 bytes, found {len(b)} bytes")
+        h = cls(*struct.unpack("<IIBBBBIIIII", b[:32]))
+        h.validate()
+        return h
+
+    def validate(self) -> None:                                             # program.rs:147-167
+        if self.magic != MAGIC:
+            raise ValueError(f"Invalid program magic: expected 0x5A4B4952, got {self.magic:#010x}")
+        if self.version != VERSION:
+            raise ValueError(f"Invalid program version: expected {VERSION:#010x}, found {self.version:#010x}")
+        Config(self.limb_bits, self.data_limbs, self.addr_limbs).validate()
+
+
+@dataclass
+class Program:
+    """program.rs:240-346."""
+    header: ProgramHeader = field(default_factory=ProgramHeader)
+    code: List[int] = field(default_factory=list)
+    data: bytes = b""
+
+    @classmethod
+    def from_code(cls, code: Sequence[int], data: bytes = b"", config: Config | None = None) -> "Program":
+        """The `create_program_from_instructions` helper pattern of the reference's tests (vm.rs:419-431),
+        additionally keeping header.data_size consistent so the blob passes Program::from_bytes."""
+        p = cls()
+        if config is not None:
+            config.validate()
+            p.header.limb_bits, p.header.data_limbs, p.header.addr_limbs = config.limb_bits, config.data_limbs, config.addr_limbs
+        p.code = [c & 0xFFFFFFFF for c in code]
+        p.data = bytes(data)
+        p.header.code_size = 4 * len(p.code)
+        p.header.data_size = len(p.data)
+        return p
+
+    def to_bytes(self) -> bytes:                                            # program.rs:300-315
+        return self.header.to_bytes() + b"".join(struct.pack("<I", w) for w in self.code) + self.data
+
+    @classmethod
+    def from_bytes(cls, b: bytes) -> "Program":                             # program.rs:318-346
+        h = ProgramHeader.from_bytes(b)
+        code_end = 32 + h.code_size
+        data_end = code_end + h.data_size
+        if len(b) < data_end:
+            raise ValueError(f"Invalid program size: expected {data_end} bytes, found {len(b)} bytes")
+        n = h.code_size // 4
+        code = list(struct.unpack(f"<{n}I", b[32:32 + 4 * n]))
+        if 4 * len(code) != h.code_size:
+            raise ValueError(f"Invalid code size: expected {h.code_size} bytes, found {4 * len(code)} bytes")
+        return cls(h, code, bytes(b[code_end:data_end]))
+
+
+# ----- workloads named by BASELINE.json / SURVEY.md §8(d) ----------------------------------------
+def fib_program(n: int) -> Program:
+    """v3.4 Fibonacci of tests/cross_module.rs:145-164 generalised: writes fib(n) then exits 0.
+    n >= 2; the loop counter n-1 must fit the 17-bit immediate (Q11), i.e. n <= 65536."""
+    assert 2 <= n <= 65536
+    return Program.from_code([
+        addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, n - 1),
+        add(4, 1, 2), addi(1, 2, 0), addi(2, 4, 0), addi(3, 3, -1), bne(3, 0, -16),
+        addi(11, 2, 0), addi(10, 0, 2), ecall(),
+        addi(10, 0, 0), addi(11, 0, 0), ecall(),
+    ])
+
+
+def fib_endless_program() -> Program:
+    """Same loop body, never exits: run with max_cycles = 2^k for exactly 2^k rows (halt = CycleLimit,
+    vm.rs:211-214).  The counter r3 just decrements mod 2^40 (first zero after 2^40 iterations)."""
+    return Program.from_code([
+        addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, 0),
+        add(4, 1, 2), addi(1, 2, 0), addi(2, 4, 0), addi(3, 3, -1), bne(3, 0, -16),
+        jal(0, -20),
+    ])
+
+
+def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
+    """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
+    The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).
+    Every ECALL row carries 32 byte-reads + 8 word-writes; run with max_cycles = 2^k (halt = CycleLimit)."""
+    assert len(seed) == 32
+    code = [
+        addi(5, 0, 0),                                   # [0] r5 = data base (patched below; data sits right after code, vm.rs:164-170)
+        addi(6, 0, 0x8000), slli(6, 6, 1),               # r6 = 0x10000
+        addi(7, 5, 32),                                  # r7 = end of seed
+        lw(8, 5, 0), sw(6, 8, 0), addi(5, 5, 4), addi(6, 6, 4), bne(5, 7, -16),   # [4..8] copy loop
+        addi(11, 0, 0x8000), slli(11, 11, 1),            # in  = 0x10000
+        addi(13, 11, 32),                                # out = 0x10020
+        addi(12, 0, 32),                                 # len = 32
+        addi(10, 0, 3), ecall(),                         # [13] L: SYS_SHA256
+        addi(9, 11, 0), addi(11, 13, 0), addi(13, 9, 0), # swap in/out
+        jal(0, -20),                                     # [18] -> L
+    ]
+    code[0] = addi(5, 0, CODE_BASE + 4 * len(code))
+    return Program.from_code(code, data=seed)
