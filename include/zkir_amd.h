@@ -125,6 +125,14 @@ int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t*
                    const zkir_vm_config* cfg, uint32_t tile_rows, zkir_delta_log** out);
 void zkir_delta_log_free(zkir_delta_log* log);
 
+/* Row sharding (multi-GPU): a self-contained delta log for rows [row_begin, row_end) of `log`
+ * (row_begin a multiple of tile_rows).  Its first 16 events are the register snapshot at row_begin, event
+ * `vis`, mem-event rows and the tile index are rebased to the shard, and zkir_delta_log_cycle_base()
+ * returns row_begin.  Side logs (range checks, normalizations, SHA blocks) are cut by the same cycle range.
+ * Outputs / halt reason / cycles stay those of the whole run. */
+int zkir_delta_log_shard(const zkir_delta_log* log, uint64_t row_begin, uint64_t row_end, zkir_delta_log** out);
+uint64_t zkir_delta_log_cycle_base(const zkir_delta_log*);
+
 uint64_t zkir_delta_log_cycles(const zkir_delta_log*);        /* ExecutionResult.cycles */
 int zkir_delta_log_halt_kind(const zkir_delta_log*);          /* ZKIR_HALT_* */
 uint64_t zkir_delta_log_halt_code(const zkir_delta_log*);     /* Exit(code) */

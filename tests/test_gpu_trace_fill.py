@@ -1,0 +1,115 @@
+"""GPU parity: the HIP trace-fill path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import api as oracle
+from zkir_amd import runtime as rt, spec
+
+import helpers
+import programs
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(blob, inputs=(), **cfg):
+    res = rt.VM(blob, inputs, rt.VMConfig(enable_execution_trace=True, **cfg)).run()
+    want = oracle.run(blob, inputs, enable_execution_trace=True, **cfg)
+    return res, want
+
+
+def _check(res, want):
+    assert res.cycles == want.cycles
+    assert (res.halt_reason.kind, res.halt_reason.code) == (want.halt_kind, want.halt_code if want.halt_kind == 1 else 0)
+    assert list(res.outputs) == list(want.outputs)
+    helpers.assert_rows_equal(res.execution_trace.rows(), want.rows)
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1023, 1024, 1025, 5000, 65536])
+def test_fib_cycle_limit_sizes(n):
+    """Ragged and exact tile multiples (tile = 1024 rows); halt = CycleLimit with exactly n rows (vm.rs:211-214)."""
+    res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=n)
+    assert res.cycles == n
+    _check(res, want)
+    res.close()
+
+
+def test_fib_n30_exit():
+    res, want = _run_both(spec.fib_program(30).to_bytes())
+    assert res.outputs == [832040] and res.cycles == 154
+    _check(res, want)
+    res.close()
+
+
+def test_empty_trace():
+    res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=0)
+    assert res.cycles == 0 and len(res.execution_trace) == 0
+    _check(res, want)
+    res.close()
+
+
+@pytest.mark.parametrize("name", sorted(programs.ALL))
+def test_program_suite(name):
+    blob, inputs, cfg = programs.ALL[name]()
+    res, want = _run_both(blob, inputs, **cfg)
+    _check(res, want)
+    res.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_programs(seed):
+    blob, inputs = programs.random_program(seed, n_instr=400)
+    for deferred in (False, True):
+        try:
+            want = oracle.run(blob, inputs, max_cycles=20000, enable_execution_trace=True, enable_deferred_model=deferred)
+        except oracle.OracleError as e:
+            with pytest.raises(rt.RuntimeError) as ei:
+                rt.VM(blob, inputs, rt.VMConfig(max_cycles=20000, enable_execution_trace=True, enable_deferred_model=deferred)).run()
+            assert ei.value.code == e.code
+            continue
+        res = rt.VM(blob, inputs, rt.VMConfig(max_cycles=20000, enable_execution_trace=True, enable_deferred_model=deferred)).run()
+        _check(res, want)
+        res.close()
+
+
+def test_full_size_2p20_properties():
+    """BASELINE configs[1] size (2^20 rows): bit-exact vs the oracle, plus size-independent properties."""
+    n = 1 << 20
+    blob = spec.fib_endless_program().to_bytes()
+    res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run()
+    tr = res.execution_trace
+    cyc = tr.column(rt.FIELD_CYCLE)
+    assert np.array_equal(cyc, np.arange(n, dtype=np.uint64))
+    # R0 is hard-wired zero with bound Constant(0) in every row
+    assert not tr.column(rt.FIELD_REGISTERS, 0).any() and not tr.column(rt.FIELD_BOUND_BITS, 0).any()
+    assert (tr.column(rt.FIELD_BOUND_TAG, 0) == 4).all()
+    # fib recurrence mod 2^40 on the rows where `add r4, r1, r2` executes: next row's r4 = r1 + r2
+    inst = tr.column(rt.FIELD_INSTRUCTION)
+    r1, r2, r4 = (tr.column(rt.FIELD_REGISTERS, r) for r in (1, 2, 4))
+    add_rows = np.nonzero(inst[:-1] == spec.add(4, 1, 2))[0]
+    assert len(add_rows) > n // 6
+    assert np.array_equal(r4[add_rows + 1], (r1[add_rows] + r2[add_rows]) & np.uint64((1 << 40) - 1))
+    want = oracle.run(blob, max_cycles=n, enable_execution_trace=True)
+    helpers.assert_rows_equal(tr.rows(), want.rows)
+    res.close()
+
+
+def test_sharded_fill_matches_unsharded():
+    """Row sharding (multi-GPU path) on one device: two shard launches reproduce the unsharded rows."""
+    import torch
+    from zkir_amd import pipeline as pl
+    n = 10 * 1024 + 300
+    blob = spec.fib_endless_program().to_bytes()
+    log = rt.interpret(blob, config=rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    want = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
+    cut = 4 * 1024
+    parts = []
+    for lo, hi in ((0, cut), (cut, n)):
+        sh = log.shard(lo, hi)
+        ddl = pl.upload(sh)
+        tr = pl.DeviceTrace(ddl)
+        pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        torch.cuda.synchronize()
+        parts.append(tr.rows())
+        sh.close()
+    helpers.assert_rows_equal(np.concatenate(parts), want)
+    log.close()

@@ -51,6 +51,46 @@ int zkir_interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size
 }
 void zkir_delta_log_free(zkir_delta_log* log) { delete log; }
 
+int zkir_delta_log_shard(const zkir_delta_log* src, uint64_t row_begin, uint64_t row_end, zkir_delta_log** out) {
+  if (!src || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  *out = nullptr;
+  const uint64_t T = src->tile_rows;
+  if (row_begin > row_end || row_end > src->n_rows || row_begin % T != 0 || src->cycle_base != 0) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: need 0 <= row_begin <= row_end <= n_rows, row_begin % tile_rows == 0, unsharded source"});
+    return ZKIR_ERR_ARGUMENT;
+  }
+  zkir_delta_log* d = new zkir_delta_log();
+  d->cycles = src->cycles; d->halt_kind = src->halt_kind; d->halt_code = src->halt_code; d->outputs = src->outputs;
+  d->tile_rows = src->tile_rows; d->rc_chunk_bits = src->rc_chunk_bits;
+  d->n_rows = row_end - row_begin; d->cycle_base = row_begin;
+  d->rc_offsets.push_back(0);
+  if (d->n_rows == 0) { d->tile_ev_off.push_back(0); *out = d; return ZKIR_OK; }
+  const uint64_t t0 = row_begin / T, t1 = (row_end + T - 1) / T;                   // tiles [t0, t1)
+  const uint32_t e0 = src->tile_ev_off[t0];
+  // events up to the end of the last tile; for an interior cut that is tile_ev_off[t1], for the run's tail all remaining
+  const uint32_t e1 = src->tile_ev_off[t1];
+  d->pc.append(src->pc.data() + row_begin, d->n_rows);
+  d->inst.append(src->inst.data() + row_begin, d->n_rows);
+  for (int r = 0; r < 16; r++) {                                                   // snapshot at row_begin
+    zkir_reg_event e = src->reg_events[src->tile_snap[t0 * 16 + r]];
+    e.vis = 0;
+    d->reg_events.push(e);
+  }
+  for (uint32_t k = e0; k < e1; k++) { zkir_reg_event e = src->reg_events[k]; e.vis -= (uint32_t)row_begin; d->reg_events.push(e); }
+  for (uint64_t t = t0; t <= t1; t++) d->tile_ev_off.push_back(src->tile_ev_off[t] - e0 + 16);
+  for (uint64_t t = t0; t < t1; t++)
+    for (int r = 0; r < 16; r++) { const uint32_t i = src->tile_snap[t * 16 + r]; d->tile_snap.push_back(i < e0 ? (uint32_t)r : i - e0 + 16); }
+  for (size_t k = 0; k < src->mem_events.size(); k++) {
+    zkir_mem_event m = src->mem_events[k];
+    if (m.row >= row_begin && m.row < row_end) { m.row -= (uint32_t)row_begin; d->mem_events.push(m); }
+  }
+  for (size_t k = 0; k < src->norm_events.size(); k++) if (src->norm_events[k].cycle >= row_begin && src->norm_events[k].cycle < row_end) d->norm_events.push(src->norm_events[k]);
+  for (size_t k = 0; k < src->sha_blocks.size(); k++) if (src->sha_blocks[k].timestamp >= row_begin && src->sha_blocks[k].timestamp < row_end) d->sha_blocks.push(src->sha_blocks[k]);
+  *out = d;
+  return ZKIR_OK;
+}
+uint64_t zkir_delta_log_cycle_base(const zkir_delta_log* l) { return l->cycle_base; }
+
 uint64_t zkir_delta_log_cycles(const zkir_delta_log* l) { return l->cycles; }
 int zkir_delta_log_halt_kind(const zkir_delta_log* l) { return l->halt_kind; }
 uint64_t zkir_delta_log_halt_code(const zkir_delta_log* l) { return l->halt_code; }

@@ -44,6 +44,12 @@ class Buf {
     if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024);
     p_[n_++] = v;
   }
+  void append(const T* src, size_t n) {
+    if (n == 0) return;
+    reserve(n_ + n);
+    memcpy(p_ + n_, src, n * sizeof(T));
+    n_ += n;
+  }
   size_t size() const { return n_; }
   const T* data() const { return p_; }
   T* data() { return p_; }
@@ -69,6 +75,7 @@ struct zkir_delta_log {
   int halt_kind = ZKIR_HALT_EBREAK;
   uint64_t halt_code = 0;
   uint64_t n_rows = 0;
+  uint64_t cycle_base = 0;       // TraceRow.cycle of row 0 (non-zero only for shards)
   uint32_t tile_rows = ZKIR_DEFAULT_TILE_ROWS;
   uint32_t rc_chunk_bits = 10;
   std::vector<uint64_t> outputs;

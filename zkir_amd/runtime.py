@@ -99,6 +99,10 @@ def lib() -> C.CDLL:
         f = getattr(L, "zkir_delta_log_" + name)
         f.restype = res
         f.argtypes = [C.c_void_p]
+    L.zkir_delta_log_shard.restype = C.c_int
+    L.zkir_delta_log_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.zkir_delta_log_cycle_base.restype = C.c_uint64
+    L.zkir_delta_log_cycle_base.argtypes = [C.c_void_p]
     L.zkir_trace_fill_launch.restype = C.c_int
     L.zkir_trace_fill_launch.argtypes = [C.POINTER(TraceFillArgsC), C.c_void_p]
     L.zkir_trace_fill_bytes.restype = C.c_uint64
@@ -168,6 +172,7 @@ class DeltaLog:
         self.halt_reason = HaltReason(L.zkir_delta_log_halt_kind(h), L.zkir_delta_log_halt_code(h) if L.zkir_delta_log_halt_kind(h) == HALT_EXIT else 0)
         self.outputs = _view(L.zkir_delta_log_outputs(h), L.zkir_delta_log_n_outputs(h), "<u8").tolist()
         self.n_rows = L.zkir_delta_log_n_rows(h)
+        self.cycle_base = L.zkir_delta_log_cycle_base(h)
         self.tile_rows = L.zkir_delta_log_tile_rows(h)
         self.pc = _view(L.zkir_delta_log_pc(h), self.n_rows, "<u8")
         self.inst = _view(L.zkir_delta_log_inst(h), self.n_rows, "<u4")
@@ -181,6 +186,14 @@ class DeltaLog:
         self.rc_chunk_bits = L.zkir_delta_log_rc_chunk_bits(h)
         self.norm_events = _view(L.zkir_delta_log_norm_events(h), L.zkir_delta_log_n_norm_events(h), NORM_EVENT_DTYPE)
         self.sha_blocks = _view(L.zkir_delta_log_sha_blocks(h), L.zkir_delta_log_n_sha_blocks(h), SHA_BLOCK_DTYPE)
+
+    def shard(self, row_begin: int, row_end: int) -> "DeltaLog":
+        """zkir_delta_log_shard: self-contained delta log of rows [row_begin, row_end) (multi-GPU row sharding)."""
+        out = C.c_void_p()
+        rc = lib().zkir_delta_log_shard(self._h, row_begin, row_end, C.byref(out))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        return DeltaLog(out.value)
 
     def close(self):
         if self._owned and self._h:
