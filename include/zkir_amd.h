@@ -119,7 +119,8 @@ typedef struct zkir_sha_block {
 typedef struct zkir_delta_log zkir_delta_log;   /* opaque, host memory */
 
 /* Run the program on the host interpreter (bit-exact to VM::run, vm.rs:208-358) and record the delta
- * log.  tile_rows (power of two, 256..4096; 0 = default) fixes the granularity of the tile index.
+ * log.  tile_rows (power of two, 256..4096; 0 = default: 256 when max_cycles <= 2^21, else 512) fixes
+ * the granularity of the tile index (one K1 workgroup per tile).
  * Returns ZKIR_OK or an error code (then *out is NULL). No device is touched. */
 int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
                    const zkir_vm_config* cfg, uint32_t tile_rows, zkir_delta_log** out);

@@ -560,7 +560,7 @@ Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t
   if (pv.entry_point < 0x1000) {                                      // vm.rs:141-147 panics; reported as an error here
     return {ZKIR_ERR_BAD_PROGRAM, "Program appears to be in debug format (entry_point=" + hexs(pv.entry_point) + "). Use release format (zkir-llvm without --debug) for execution."};
   }
-  if (tile_rows == 0) tile_rows = ZKIR_DEFAULT_TILE_ROWS;
+  if (tile_rows == 0) tile_rows = cfg.max_cycles <= (1ull << 21) ? 256u : 512u;   // measured best on MI355X (profiles/r01_sweep_trace_fill.txt)
   if (tile_rows < 256 || tile_rows > 4096 || (tile_rows & (tile_rows - 1))) return {ZKIR_ERR_ARGUMENT, "tile_rows must be a power of two in 256..4096"};
   log.tile_rows = tile_rows;
   if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 28)) { log.pc.reserve(cfg.max_cycles); log.inst.reserve(cfg.max_cycles); log.reg_events.reserve(cfg.max_cycles + 16); }

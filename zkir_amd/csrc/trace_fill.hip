@@ -31,18 +31,19 @@ using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
 struct alignas(16) U64x2 { uint64_t a, b; };
 struct alignas(16) U32x4 { uint32_t a, b, c, d; };
 
-template <typename V>
+template <bool NTS, typename V>
 __device__ __forceinline__ void store16(void* p, const V& v) {
   static_assert(sizeof(V) == 16, "16-byte store");
-  __builtin_nontemporal_store(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned int*>(&v),
-                              reinterpret_cast<__attribute__((ext_vector_type(4))) unsigned int*>(p));
+  using v4 = __attribute__((ext_vector_type(4))) unsigned int;
+  if constexpr (NTS) __builtin_nontemporal_store(*reinterpret_cast<const v4*>(&v), reinterpret_cast<v4*>(p));
+  else *reinterpret_cast<v4*>(p) = *reinterpret_cast<const v4*>(&v);
 }
 
 // LDS image of one event: same 32 bytes as zkir_reg_event, viewed as dwords.
 //   dw0-1 value, dw2-3 payload, dw4 max_bits, dw5 vis, dw6 = reg | state<<8 | tag<<16
 struct alignas(16) EvLds { uint32_t dw[8]; };
 
-template <int T, int NT, int EVCAP>
+template <int T, int NT, int EVCAP, bool NTS>
 __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __restrict__ events, const uint32_t* __restrict__ tile_ev_off,
                                                           const uint32_t* __restrict__ tile_snap, uint64_t cycle_base, uint64_t* __restrict__ col_cycle,
                                                           uint64_t* __restrict__ col_reg, uint32_t* __restrict__ col_bits, uint8_t* __restrict__ col_tag,
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __
   // cycle column
   for (int q = tid; q < T / 2; q += NT) {
     const uint64_t c = cycle_base + row0 + 2 * (uint64_t)q;
-    store16(col_cycle + row0 + 2 * q, U64x2{c, c + 1});
+    store16<NTS>(col_cycle + row0 + 2 * q, U64x2{c, c + 1});
   }
 #pragma unroll 1
   for (int r = 0; r < 16; r++) {
@@ -158,20 +159,20 @@ __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __
       const U32x4 bb{b, b, b, b};
       const uint32_t t4 = tg * 0x01010101u, s4 = st * 0x01010101u;
       const U32x4 tt{t4, t4, t4, t4}, ss{s4, s4, s4, s4};
-      for (int q = tid; q < T / 2; q += NT) { store16(creg + 2 * q, vv); store16(cpay + 2 * q, pp); }
-      for (int q = tid; q < T / 4; q += NT) store16(cbits + 4 * q, bb);
-      for (int q = tid; q < T / 16; q += NT) { store16(ctag + 16 * q, tt); store16(cst + 16 * q, ss); }
+      for (int q = tid; q < T / 2; q += NT) { store16<NTS>(creg + 2 * q, vv); store16<NTS>(cpay + 2 * q, pp); }
+      for (int q = tid; q < T / 4; q += NT) store16<NTS>(cbits + 4 * q, bb);
+      for (int q = tid; q < T / 16; q += NT) { store16<NTS>(ctag + 16 * q, tt); store16<NTS>(cst + 16 * q, ss); }
     } else {
       const unsigned short* row = idx + r * T;
       for (int q = tid; q < T / 2; q += NT) {
         const unsigned int pair = *reinterpret_cast<const unsigned int*>(row + 2 * q);
         const uint32_t s0 = pair & 0xFFFF, s1 = pair >> 16;
-        store16(creg + 2 * q, U64x2{ev_u64(s0, 0), ev_u64(s1, 0)});
-        store16(cpay + 2 * q, U64x2{ev_u64(s0, 2), ev_u64(s1, 2)});
+        store16<NTS>(creg + 2 * q, U64x2{ev_u64(s0, 0), ev_u64(s1, 0)});
+        store16<NTS>(cpay + 2 * q, U64x2{ev_u64(s0, 2), ev_u64(s1, 2)});
       }
       for (int q = tid; q < T / 4; q += NT) {
         const uint2 quad = *reinterpret_cast<const uint2*>(row + 4 * q);
-        store16(cbits + 4 * q, U32x4{ev_dw(quad.x & 0xFFFF, 4), ev_dw(quad.x >> 16, 4), ev_dw(quad.y & 0xFFFF, 4), ev_dw(quad.y >> 16, 4)});
+        store16<NTS>(cbits + 4 * q, U32x4{ev_dw(quad.x & 0xFFFF, 4), ev_dw(quad.x >> 16, 4), ev_dw(quad.y & 0xFFFF, 4), ev_dw(quad.y >> 16, 4)});
       }
       for (int q = tid; q < T / 16; q += NT) {
         const u16x8 s_lo = *reinterpret_cast<const u16x8*>(row + 16 * q), s_hi = *reinterpret_cast<const u16x8*>(row + 16 * q + 8);
@@ -182,24 +183,25 @@ __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __
           sw[k >> 2] |= ((meta >> 8) & 0xFF) << (8 * (k & 3));
           tw[k >> 2] |= ((meta >> 16) & 0xFF) << (8 * (k & 3));
         }
-        store16(ctag + 16 * q, U32x4{tw[0], tw[1], tw[2], tw[3]});
-        store16(cst + 16 * q, U32x4{sw[0], sw[1], sw[2], sw[3]});
+        store16<NTS>(ctag + 16 * q, U32x4{tw[0], tw[1], tw[2], tw[3]});
+        store16<NTS>(cst + 16 * q, U32x4{sw[0], sw[1], sw[2], sw[3]});
       }
     }
   }
 }
 
-template <int T>
+template <int T, int NT, bool NTS>
 int launch_tile(const zkir_trace_fill_args* a, uint32_t n_tiles, hipStream_t stream) {
-  constexpr int NT = 256;
   constexpr int EVCAP = 16 + T;
   constexpr size_t lds = sizeof(EvLds) * EVCAP + 2 * 16 * T + 16;
-  auto k = trace_fill_kernel<T, NT, EVCAP>;
+  auto k = trace_fill_kernel<T, NT, EVCAP, NTS>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(k, dim3(n_tiles), dim3(NT), lds, stream, a->events, a->tile_ev_off, a->tile_snap, a->cycle_base, a->out.cycle, a->out.registers,
                      a->out.bound_bits, a->out.bound_tag, a->out.bound_payload, a->out.reg_state, a->out.reg_stride);
-  return hipGetLastError() == hipSuccess ? ZKIR_OK : ZKIR_ERR_DEVICE;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("trace_fill launch failed: ") + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
+  return ZKIR_OK;
 }
 
 }  // namespace
@@ -215,14 +217,22 @@ extern "C" int zkir_trace_fill_launch(const zkir_trace_fill_args* a, void* hip_s
   }
   hipStream_t s = (hipStream_t)hip_stream;
   int rc;
+  // tuning knobs (benchmarking only): ZKIR_TF_THREADS = 256|512, ZKIR_TF_NT = 0|1
+  static const int threads_env = getenv("ZKIR_TF_THREADS") ? atoi(getenv("ZKIR_TF_THREADS")) : 0;
+  const int threads = threads_env ? threads_env : (T >= 512 ? 512 : 256);    // measured best on MI355X (profiles/r01_sweep_trace_fill.txt)
+  static const int nts = getenv("ZKIR_TF_NT") ? atoi(getenv("ZKIR_TF_NT")) : 1;
+#define ZKIR_TF_CASE(TT)                                                                          \
+  case TT:                                                                                        \
+    if (threads == 512) rc = nts ? launch_tile<TT, 512, true>(a, (uint32_t)n_tiles, s) : launch_tile<TT, 512, false>(a, (uint32_t)n_tiles, s); \
+    else rc = nts ? launch_tile<TT, 256, true>(a, (uint32_t)n_tiles, s) : launch_tile<TT, 256, false>(a, (uint32_t)n_tiles, s);               \
+    break;
   switch (T) {
-    case 256: rc = launch_tile<256>(a, (uint32_t)n_tiles, s); break;
-    case 512: rc = launch_tile<512>(a, (uint32_t)n_tiles, s); break;
-    case 1024: rc = launch_tile<1024>(a, (uint32_t)n_tiles, s); break;
-    case 2048: rc = launch_tile<2048>(a, (uint32_t)n_tiles, s); break;
+    ZKIR_TF_CASE(256)
+    ZKIR_TF_CASE(512)
+    ZKIR_TF_CASE(1024)
+    ZKIR_TF_CASE(2048)
     default: zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_trace_fill_launch: tile_rows must be 256, 512, 1024 or 2048"}); return ZKIR_ERR_ARGUMENT;
   }
-  if (rc != ZKIR_OK) zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("trace_fill launch failed: ") + hipGetErrorString(hipGetLastError())});
   return rc;
 }
 

@@ -80,6 +80,13 @@ def lib() -> C.CDLL:
     if not os.path.exists(_SO):
         raise ImportError(f"{_SO} is missing: build it with `python zkir_amd/build.py` (hipcc --offload-arch=gfx950). "
                           "zkir_amd has no pure-Python or CPU fallback.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so (soname libamdhip64.so.7, same as
+    # /opt/rocm's).  Importing torch first makes the loader resolve our DT_NEEDED to that already-loaded copy;
+    # loading ours first would give the process two runtimes, and whichever touches the device second fails.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     L.zkir_last_error.restype = C.c_char_p
     L.zkir_version.restype = C.c_char_p
