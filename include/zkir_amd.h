@@ -196,6 +196,48 @@ int zkir_trace_fill_launch(const zkir_trace_fill_args* args, void* hip_stream);
  * 32*n_events + 68*n_tiles read. */
 uint64_t zkir_trace_fill_bytes(uint64_t n_rows, uint64_t n_events, uint64_t n_tiles);
 
+/* ---- witness expansion kernels (witness.hip); every pointer is device memory, all launches async ----- */
+
+/* MemoryOp columns (trace.rs:149-167), 39 bytes per op; each array has n_ops elements */
+typedef struct zkir_memop_columns {
+  uint64_t* address;
+  uint64_t* value;
+  uint64_t* timestamp;
+  uint8_t* is_write;       /* MemOpType: 0 Read, 1 Write */
+  uint8_t* width;
+  uint32_t* bound_bits;    /* ValueBound::from_type_width(8*width), memory.rs:245 */
+  uint8_t* bound_tag;
+  uint64_t* bound_payload;
+} zkir_memop_columns;
+
+/* TraceRow.memory_ops flattened in row order */
+int zkir_memops_expand_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t cycle_base, const zkir_memop_columns* out, void* hip_stream);
+/* CSR: offsets[r] = number of ops whose row < r, r = 0..n_rows (n_rows+1 entries) */
+int zkir_memops_row_offsets_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t n_rows, uint64_t* offsets, void* hip_stream);
+/* ExecutionResult::get_memory_trace() (vm.rs:85-94): stable order by (timestamp, address, Read<Write).
+ * row_offsets from zkir_memops_row_offsets_launch; seg_scratch = n_rows bytes of device scratch. */
+int zkir_memops_sort_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t n_rows, uint64_t cycle_base, const uint64_t* row_offsets,
+                            uint8_t* seg_scratch, const zkir_memop_columns* out, void* hip_stream);
+
+/* RangeCheckWitness entries (range_check.rs:175-192,212): value[n], pc[n], chunks[4][chunk_stride] (u16) and, if
+ * multiplicity != NULL, the lookup multiplicities of all chunks: multiplicity[2^chunk_bits] (zeroed by the call). */
+int zkir_range_check_expand_launch(const zkir_rc_event* events, uint64_t n, uint32_t chunk_bits, uint64_t* value, uint64_t* pc,
+                                   uint16_t* chunks, uint64_t chunk_stride, uint32_t* multiplicity, void* hip_stream);
+
+/* NormalizationEvent columns (normalization_witness.rs:19-43; normalized_bits = 20, limb_bits = 30, cause = ObservationPoint) */
+typedef struct zkir_norm_columns {
+  uint64_t* cycle; uint64_t* pc; uint8_t* reg; uint8_t* opcode;
+  uint64_t* accumulated0; uint64_t* accumulated1;
+  uint32_t* normalized0; uint32_t* normalized1;
+  uint32_t* carry0; uint32_t* carry1;
+} zkir_norm_columns;
+int zkir_norm_expand_launch(const zkir_norm_event* events, uint64_t n, const zkir_norm_columns* out, void* hip_stream);
+
+/* SHA-256 chip (Sha256Witness, trace.rs:236-256; crypto.rs:142-207): out = 608 word-columns [608][stride] (u32):
+ * [0,16) message_block, [16,24) initial_state, [24,88) message_schedule, [88,600) round_states[64][8], [600,608) final_state;
+ * timestamps[n] optional. */
+int zkir_sha256_chip_launch(const zkir_sha_block* blocks, uint64_t n, uint32_t* out, uint64_t stride, uint64_t* timestamps, void* hip_stream);
+
 /* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
 typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */
 

@@ -1,0 +1,126 @@
+"""GPU parity for the witness-expansion kernels (witness.hip) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import api as oracle
+from zkir_amd import runtime as rt, spec
+
+import programs
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(blob, inputs, cfg):
+    cfg = dict(cfg, enable_execution_trace=True)
+    log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
+    want = oracle.run(blob, inputs, **cfg)
+    return log, want
+
+
+MEM_PROGRAMS = ["mem_sw_lw", "timestamps", "loads_stores", "q9_access_at_own_pc", "hashes_all", "blake3_multi_chunk", "sha_chain_small",
+                "sha256_hello", "deferred_negative_and_overflow", "fib30"]
+
+
+@pytest.mark.parametrize("name", MEM_PROGRAMS)
+def test_memory_ops_row_order_offsets_and_sorted(name):
+    from zkir_amd import pipeline as pl
+    blob, inputs, cfg = programs.ALL[name]()
+    log, want = _both(blob, inputs, cfg)
+    rows, offsets, srt = pl.memory_ops(log)
+    assert np.array_equal(rows.to_numpy(), want.memops)
+    assert np.array_equal(offsets.cpu().numpy().view(np.uint64), want.row_memop_offsets)
+    assert np.array_equal(srt.to_numpy(), want.sorted_memops)            # ExecutionResult::get_memory_trace, vm.rs:85-94
+
+
+def test_memory_sort_fallback_on_wrapping_addresses():
+    """A hash input that wraps around 2^64 breaks the ascending-run shape: the counting-rank path must still match."""
+    from zkir_amd import pipeline as pl
+    from zkir_amd.spec import Opcode as O, encode as E
+    A = programs.A
+    # LB keeps the 64-bit sign extension (Q1), which is the only way to get a raw register value near 2^64
+    code = [A(5, 0, 0x2000), A(9, 0, 0xF8), E(O.SB, rs1=5, rs2=9, imm=0), A(9, 0, 0xF0), E(O.SB, rs1=5, rs2=9, imm=1), A(9, 0, 0xFD),
+            E(O.SB, rs1=5, rs2=9, imm=2),
+            E(O.LB, 11, 5, imm=0), A(12, 0, 20), A(13, 0, 0x3000), A(10, 0, 5), programs.EC,            # keccak over [2^64-8, 2^64+12)
+            E(O.LB, 11, 5, imm=2), A(12, 0, 9), E(O.LB, 13, 5, imm=1), A(10, 0, 6), programs.EC,          # blake3, output wraps too
+            programs.EB]
+    blob = spec.Program.from_code(code).to_bytes()
+    log, want = _both(blob, [], {})
+    rows, offsets, srt = pl.memory_ops(log)
+    assert len(want.memops) == 6 + 20 + 32 + 9 + 32
+    assert want.memops["address"].max() > 2**63 and want.memops["address"].min() == 0     # the syscall rows really wrap
+    assert np.array_equal(rows.to_numpy(), want.memops)
+    assert np.array_equal(srt.to_numpy(), want.sorted_memops)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_program_witnesses(seed):
+    from zkir_amd import pipeline as pl
+    blob, inputs = programs.random_program(100 + seed, n_instr=500)
+    cfg = dict(max_cycles=20000, enable_range_checking=True, enable_deferred_model=bool(seed % 2))
+    try:
+        log, want = _both(blob, inputs, cfg)
+    except (oracle.OracleError, rt.RuntimeError):
+        pytest.skip("program errors out")
+    rows, offsets, srt = pl.memory_ops(log)
+    assert np.array_equal(rows.to_numpy(), want.memops) and np.array_equal(srt.to_numpy(), want.sorted_memops)
+    value, pc, chunks, mult = pl.range_checks(log)
+    assert np.array_equal(value.cpu().numpy().view(np.uint64), want.rc_checks["value"])
+    assert np.array_equal(pc.cpu().numpy().view(np.uint64), want.rc_checks["pc"])
+    assert np.array_equal(chunks.cpu().numpy().view(np.uint16).T, want.rc_checks["chunks"])
+    assert np.array_equal(pl.normalization_events(log), want.norm_events)
+
+
+@pytest.mark.parametrize("name", ["rc_doubling", "rc_many_pending", "rc_config_30bit", "deferred_fib"])
+def test_range_check_chunks_and_multiplicities(name):
+    from zkir_amd import pipeline as pl
+    blob, inputs, cfg = programs.ALL[name]()
+    log, want = _both(blob, inputs, cfg)
+    assert len(want.rc_checks) > 0
+    value, pc, chunks, mult = pl.range_checks(log)
+    assert np.array_equal(value.cpu().numpy().view(np.uint64), want.rc_checks["value"])
+    assert np.array_equal(pc.cpu().numpy().view(np.uint64), want.rc_checks["pc"])
+    assert np.array_equal(chunks.cpu().numpy().view(np.uint16).T, want.rc_checks["chunks"])
+    assert np.array_equal(log.rc_offsets, want.rc_offsets)
+    table = 1 << log.rc_chunk_bits
+    assert np.array_equal(mult.cpu().numpy().view(np.uint32), np.bincount(want.rc_checks["chunks"].reshape(-1), minlength=table).astype(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["deferred_add_branch", "deferred_chain_store", "deferred_add_sub_mix", "deferred_negative_and_overflow", "deferred_fib"])
+def test_normalization_events(name):
+    from zkir_amd import pipeline as pl
+    blob, inputs, cfg = programs.ALL[name]()
+    log, want = _both(blob, inputs, cfg)
+    assert len(want.norm_events) > 0
+    assert np.array_equal(pl.normalization_events(log), want.norm_events)
+
+
+def test_sha256_chip_matches_witness():
+    """K3 vs sha256_hash_with_witness (crypto.rs:223-297): all 608 words per block, every single-block length 0..55."""
+    from zkir_amd import pipeline as pl
+    msgs = [bytes((11 * i + n) & 0xFF for i in range(n)) for n in range(56)] + [b"hello", b"", b"abc"]
+    blocks = np.zeros(len(msgs), dtype=rt.SHA_BLOCK_DTYPE)
+    want = np.zeros((len(msgs), 608), dtype=np.uint32)
+    for k, m in enumerate(msgs):
+        w = oracle.sha256_witness(m, 1000 + k)
+        blocks[k]["message_block"] = w["message_block"]
+        blocks[k]["timestamp"] = 1000 + k
+        want[k] = w["flat"]
+    cols, ts = pl.sha256_chip(blocks)
+    assert np.array_equal(cols.cpu().numpy().view(np.uint32).T, want)
+    assert np.array_equal(ts.cpu().numpy(), 1000 + np.arange(len(msgs)))
+
+
+def test_sha256_chip_from_hash_chain_run():
+    """Config 5 shape: the blocks recorded by the host for a SHA-256 hash chain, expanded on the device."""
+    from zkir_amd import pipeline as pl
+    import hashlib
+    blob = spec.sha256_chain_program().to_bytes()
+    log = rt.interpret(blob, config=rt.VMConfig(max_cycles=1 << 14, enable_execution_trace=True))
+    assert len(log.sha_blocks) > 2000
+    cols, ts = pl.sha256_chip(log.sha_blocks)
+    got = cols.cpu().numpy().view(np.uint32)
+    for k in (0, 1, 777, len(log.sha_blocks) - 1):
+        blk = log.sha_blocks[k]["message_block"].astype(">u4").tobytes()[:32]      # 32-byte message
+        w = oracle.sha256_witness(blk, int(log.sha_blocks[k]["timestamp"]))
+        assert np.array_equal(got[:, k], w["flat"])
+        assert got[600:608, k].astype(">u4").tobytes() == hashlib.sha256(blk).digest()

@@ -1,0 +1,63 @@
+"""N>1 path on CPU: two gloo ranks shard the rows exactly as bench.py does on GPUs (rank g owns rows
+[g*n/2, (g+1)*n/2) with its own register snapshot, no data-path collective), expand their shard with the
+numpy stand-in for K1, and an all_gather of per-shard digests reproduces the unsharded trace."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zkir_amd import runtime as rt, spec
+
+import helpers
+
+N_ROWS = 8 * 256
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, blob, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = rt.interpret(blob, config=rt.VMConfig(max_cycles=N_ROWS, enable_execution_trace=True), tile_rows=256)
+    per = N_ROWS // world
+    sh = log.shard(rank * per, (rank + 1) * per)
+    rows = helpers.expand_delta_log(sh)
+    rows["cycle"] += np.uint64(sh.cycle_base)
+    digest = torch.tensor(list(hashlib.sha256(rows.tobytes()).digest()), dtype=torch.uint8)
+    gathered = [torch.zeros(32, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(gathered, digest)                       # the only collective of the path: 32 bytes per rank
+    n_ev = torch.tensor([len(sh.reg_events)], dtype=torch.int64)
+    dist.all_reduce(n_ev)
+    if rank == 0:
+        out_q.put(([bytes(g.tolist()) for g in gathered], int(n_ev.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_sharding_gloo():
+    blob = spec.sha256_chain_program().to_bytes()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, blob, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    digests, n_ev = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    log = rt.interpret(blob, config=rt.VMConfig(max_cycles=N_ROWS, enable_execution_trace=True), tile_rows=256)
+    full = helpers.expand_delta_log(log)
+    half = N_ROWS // 2
+    assert digests == [hashlib.sha256(full[:half].tobytes()).digest(), hashlib.sha256(full[half:].tobytes()).digest()]
+    assert n_ev >= len(log.reg_events)          # each shard carries its own 16 snapshot events

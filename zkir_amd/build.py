@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libzkir_amd.so")
 OBJ = os.path.join(HERE, "build")
 
 HOST_SOURCES = ["interp.cpp", "hashes.cpp"]
-HIP_SOURCES = ["trace_fill.hip", "abi.hip"]
+HIP_SOURCES = ["trace_fill.hip", "witness.hip", "abi.hip"]
 HEADERS = ["host.h", os.path.join("..", "..", "include", "zkir_amd.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

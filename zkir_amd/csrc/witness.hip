@@ -1,0 +1,247 @@
+// witness.hip — expansion of the host interpreter's side logs into the witness columns the reference's
+// ExecutionResult carries (gfx950).  All kernels are elementwise / small-segment integer work, HBM-bound,
+// written as coalesced SoA producers; none has a contraction (no MFMA).
+//
+//   memops_*      MemoryOp columns in row order + CSR row offsets (TraceRow.memory_ops, zkir-spec/src/trace.rs:149-167,
+//                 bound = TypeWidth(8*width) zkir-runtime/src/memory.rs:245) and ExecutionResult::get_memory_trace()
+//                 (zkir-runtime/src/vm.rs:85-94: stable sort by timestamp, address, Read<Write; Ord at trace.rs:210-223)
+//   range_check   RangeCheckWitness entries (value, chunks[4], pc) zkir-runtime/src/range_check.rs:175-192,212 plus the
+//                 lookup-table multiplicities of the chunks (table size 2^chunk_bits, config.rs:78-80)
+//   norm          NormalizationEvent columns, zkir-runtime/src/normalization_witness.rs:19-43, normalize.rs:133-153
+//   sha256_chip   Sha256Witness per single-block message, zkir-runtime/src/crypto.rs:142-207,223-297; trace.rs:236-256
+#include <hip/hip_runtime.h>
+
+#include "../../include/zkir_amd.h"
+#include "host.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline unsigned grid_for(uint64_t n, int per_block = NT) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ------------------------------------------------------------------------------------------------
+// memory ops
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_memop(const zkir_memop_columns& c, uint64_t at, const zkir_mem_event& e, uint64_t cycle_base) {
+  c.address[at] = e.address;
+  c.value[at] = e.value;
+  c.timestamp[at] = cycle_base + e.row;
+  c.is_write[at] = e.is_write;
+  c.width[at] = e.width;
+  c.bound_bits[at] = 8u * e.width;                 // ValueBound::from_type_width(width * 8)
+  c.bound_tag[at] = ZKIR_BOUND_TYPE_WIDTH;
+  c.bound_payload[at] = 8ull * e.width;
+}
+
+__global__ __launch_bounds__(NT) void memops_expand_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, uint64_t cycle_base, zkir_memop_columns c) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i < n) put_memop(c, i, ev[i], cycle_base);
+}
+
+// offsets[r] = number of ops with row < r  (ops are ordered by row); one thread per row, binary search
+__global__ __launch_bounds__(NT) void memops_row_offsets_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, uint64_t n_rows, uint64_t* __restrict__ offsets) {
+  const uint64_t r = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (r > n_rows) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if ((uint64_t)ev[mid].row < r) lo = mid + 1; else hi = mid;
+  }
+  offsets[r] = lo;
+}
+
+// A row's ops come from one instruction: a single load/store, or a hash syscall = [byte reads, ascending][writes, ascending].
+// Segments that keep that shape are merged by rank; any other shape (e.g. address wrap-around) is flagged here and
+// sorted by an always-correct counting rank.
+__global__ __launch_bounds__(NT) void memops_segment_check_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, unsigned char* __restrict__ seg_bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i == 0 || i >= n) return;
+  const zkir_mem_event a = ev[i - 1], b = ev[i];
+  if (a.row != b.row) return;
+  const bool bad = (b.is_write < a.is_write) || (b.is_write == a.is_write && b.address < a.address);
+  if (bad) seg_bad[b.row] = 1;
+}
+
+__device__ __forceinline__ bool memop_before(const zkir_mem_event& a, uint64_t ia, const zkir_mem_event& b, uint64_t ib) {
+  if (a.address != b.address) return a.address < b.address;     // same row: timestamp ties
+  if (a.is_write != b.is_write) return a.is_write < b.is_write;
+  return ia < ib;                                                // stable
+}
+
+__global__ __launch_bounds__(NT) void memops_sort_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, uint64_t cycle_base,
+                                                          const uint64_t* __restrict__ offsets, const unsigned char* __restrict__ seg_bad, zkir_memop_columns c) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const zkir_mem_event e = ev[i];
+  const uint64_t s = offsets[e.row], t = offsets[(uint64_t)e.row + 1];
+  uint64_t rank;
+  if (t - s == 1) {
+    rank = 0;
+  } else if (!seg_bad[e.row]) {
+    uint64_t lo = s, hi = t;                                     // nR: first write in the segment
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ev[mid].is_write) hi = mid; else lo = mid + 1; }
+    const uint64_t w0 = lo;
+    if (!e.is_write) {                                           // reads precede writes at equal address: count writes strictly below
+      uint64_t a = w0, b = t;
+      while (a < b) { const uint64_t mid = (a + b) >> 1; if (ev[mid].address < e.address) a = mid + 1; else b = mid; }
+      rank = (i - s) + (a - w0);
+    } else {                                                     // count reads at or below
+      uint64_t a = s, b = w0;
+      while (a < b) { const uint64_t mid = (a + b) >> 1; if (ev[mid].address <= e.address) a = mid + 1; else b = mid; }
+      rank = (i - w0) + (a - s);
+    }
+  } else {
+    rank = 0;
+    for (uint64_t j = s; j < t; j++) rank += memop_before(ev[j], j, e, i) ? 1 : 0;
+  }
+  put_memop(c, s + rank, e, cycle_base);
+}
+
+// ------------------------------------------------------------------------------------------------
+// range checks
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void range_check_kernel(const zkir_rc_event* __restrict__ ev, uint64_t n, uint32_t chunk_bits, uint64_t* __restrict__ value,
+                                                          uint64_t* __restrict__ pc, uint16_t* __restrict__ chunks, uint64_t stride, uint32_t* __restrict__ mult) {
+  extern __shared__ uint32_t hist[];                             // privatised multiplicity table
+  const uint32_t table = 1u << chunk_bits, mask = table - 1;
+  if (mult) { for (uint32_t k = threadIdx.x; k < table; k += NT) hist[k] = 0; __syncthreads(); }
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) {
+    const zkir_rc_event e = ev[i];
+    value[i] = e.value; pc[i] = e.pc;
+    const uint32_t l0 = (uint32_t)(e.value & 0xFFFFF), l1 = (uint32_t)((e.value >> 20) & 0xFFFFF);      // Value40 limbs (value.rs:592-596)
+    const uint32_t c0 = l0 & mask, c1 = (l0 >> chunk_bits) & mask, c2 = l1 & mask, c3 = (l1 >> chunk_bits) & mask;
+    chunks[i] = (uint16_t)c0; chunks[stride + i] = (uint16_t)c1; chunks[2 * stride + i] = (uint16_t)c2; chunks[3 * stride + i] = (uint16_t)c3;
+    if (mult) { atomicAdd(&hist[c0], 1u); atomicAdd(&hist[c1], 1u); atomicAdd(&hist[c2], 1u); atomicAdd(&hist[c3], 1u); }
+  }
+  if (mult) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < table; k += NT) if (hist[k]) atomicAdd(&mult[k], hist[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalization events
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void norm_kernel(const zkir_norm_event* __restrict__ ev, uint64_t n, zkir_norm_columns c) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const zkir_norm_event e = ev[i];
+  const unsigned bits = e.state == 0 ? 20 : 30;                  // read_reg_limbs_extended, state.rs:202-220
+  const uint64_t mask = (1ull << bits) - 1;
+  const uint64_t a0 = e.raw_value & mask, a1 = (e.raw_value >> bits) & mask;
+  const uint32_t c0 = (uint32_t)(a0 >> 20), n0 = (uint32_t)(a0 & 0xFFFFF);      // normalize.rs:138-145
+  const uint64_t t = a1 + c0;
+  const uint32_t c1 = (uint32_t)(t >> 20), n1 = (uint32_t)(t & 0xFFFFF);
+  c.cycle[i] = e.cycle; c.pc[i] = e.pc; c.reg[i] = e.reg; c.opcode[i] = e.opcode;
+  c.accumulated0[i] = a0; c.accumulated1[i] = a1;
+  c.normalized0[i] = n0; c.normalized1[i] = n1;
+  c.carry0[i] = c0; c.carry1[i] = c1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SHA-256 chip: one lane per single-block message; 608 word-columns, column-major so every store is coalesced
+// ------------------------------------------------------------------------------------------------
+__constant__ uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+// column ids: [0,16) message_block, [16,24) initial_state, [24,88) message_schedule, [88,600) round_states[64][8], [600,608) final_state
+__global__ __launch_bounds__(NT) void sha256_chip_kernel(const zkir_sha_block* __restrict__ blocks, uint64_t n, uint32_t* __restrict__ out, uint64_t stride,
+                                                          uint64_t* __restrict__ timestamps) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16];
+  const uint4* src = reinterpret_cast<const uint4*>(blocks + i);               // 72-byte records: 8-byte aligned only
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(blocks + i);
+  (void)src;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { w[k] = sw[k]; out[(uint64_t)k * stride + i] = w[k]; }
+  if (timestamps) timestamps[i] = blocks[i].timestamp;
+  const uint32_t H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+#pragma unroll
+  for (int k = 0; k < 8; k++) out[(uint64_t)(16 + k) * stride + i] = H0[k];
+  uint32_t a = H0[0], b = H0[1], c = H0[2], d = H0[3], e = H0[4], f = H0[5], g = H0[6], h = H0[7];
+#pragma unroll
+  for (int t = 0; t < 64; t++) {
+    uint32_t wt;
+    if (t < 16) wt = w[t];
+    else {                                                                     // crypto.rs:149-154, rolling 16-word window
+      const uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+      wt = (rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10)) + w[(t + 9) & 15] + (rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3)) + w[t & 15];
+      w[t & 15] = wt;
+    }
+    out[(uint64_t)(24 + t) * stride + i] = wt;
+    const uint32_t t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[t] + wt;       // crypto.rs:173-179
+    const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    uint32_t* o = out + (uint64_t)(88 + 8 * t) * stride + i;
+    o[0] = a; o[stride] = b; o[2 * stride] = c; o[3 * stride] = d; o[4 * stride] = e; o[5 * stride] = f; o[6 * stride] = g; o[7 * stride] = h;
+  }
+  uint32_t* o = out + 600ull * stride + i;
+  o[0] = H0[0] + a; o[stride] = H0[1] + b; o[2 * stride] = H0[2] + c; o[3 * stride] = H0[3] + d;
+  o[4 * stride] = H0[4] + e; o[5 * stride] = H0[5] + f; o[6 * stride] = H0[6] + g; o[7 * stride] = H0[7] + h;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
+  return ZKIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkir_memops_expand_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t cycle_base, const zkir_memop_columns* out, void* stream) {
+  if (n_ops == 0) return ZKIR_OK;
+  hipLaunchKernelGGL(memops_expand_kernel, dim3(grid_for(n_ops)), dim3(NT), 0, (hipStream_t)stream, ev, n_ops, cycle_base, *out);
+  return check_launch("memops_expand");
+}
+
+int zkir_memops_row_offsets_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t n_rows, uint64_t* offsets, void* stream) {
+  hipLaunchKernelGGL(memops_row_offsets_kernel, dim3(grid_for(n_rows + 1)), dim3(NT), 0, (hipStream_t)stream, ev, n_ops, n_rows, offsets);
+  return check_launch("memops_row_offsets");
+}
+
+int zkir_memops_sort_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t n_rows, uint64_t cycle_base, const uint64_t* row_offsets,
+                            uint8_t* seg_scratch, const zkir_memop_columns* out, void* stream) {
+  if (n_ops == 0) return ZKIR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(seg_scratch, 0, n_rows, s) != hipSuccess) return check_launch("memops_sort memset");
+  hipLaunchKernelGGL(memops_segment_check_kernel, dim3(grid_for(n_ops)), dim3(NT), 0, s, ev, n_ops, seg_scratch);
+  hipLaunchKernelGGL(memops_sort_kernel, dim3(grid_for(n_ops)), dim3(NT), 0, s, ev, n_ops, cycle_base, row_offsets, seg_scratch, *out);
+  return check_launch("memops_sort");
+}
+
+int zkir_range_check_expand_launch(const zkir_rc_event* ev, uint64_t n, uint32_t chunk_bits, uint64_t* value, uint64_t* pc, uint16_t* chunks,
+                                   uint64_t chunk_stride, uint32_t* multiplicity, void* stream) {
+  if (chunk_bits < 8 || chunk_bits > 15) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "chunk_bits must be in 8..15"}); return ZKIR_ERR_ARGUMENT; }
+  hipStream_t s = (hipStream_t)stream;
+  if (multiplicity && hipMemsetAsync(multiplicity, 0, sizeof(uint32_t) << chunk_bits, s) != hipSuccess) return check_launch("range_check memset");
+  if (n == 0) return ZKIR_OK;
+  unsigned g = grid_for(n);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(range_check_kernel, dim3(g), dim3(NT), multiplicity ? (sizeof(uint32_t) << chunk_bits) : 0, s, ev, n, chunk_bits, value, pc, chunks,
+                     chunk_stride, multiplicity);
+  return check_launch("range_check");
+}
+
+int zkir_norm_expand_launch(const zkir_norm_event* ev, uint64_t n, const zkir_norm_columns* out, void* stream) {
+  if (n == 0) return ZKIR_OK;
+  hipLaunchKernelGGL(norm_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, ev, n, *out);
+  return check_launch("norm_expand");
+}
+
+int zkir_sha256_chip_launch(const zkir_sha_block* blocks, uint64_t n, uint32_t* out, uint64_t stride, uint64_t* timestamps, void* stream) {
+  if (n == 0) return ZKIR_OK;
+  if (stride < n) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "sha256_chip: stride < n"}); return ZKIR_ERR_ARGUMENT; }
+  hipLaunchKernelGGL(sha256_chip_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, blocks, n, out, stride, timestamps);
+  return check_launch("sha256_chip");
+}
+
+}  // extern "C"

@@ -112,3 +112,104 @@ def trace_fill(args: rt.TraceFillArgsC, stream: Optional[torch.cuda.Stream] = No
 
 def trace_fill_bytes(ddl: DeviceDeltaLog) -> int:
     return int(rt.lib().zkir_trace_fill_bytes(ddl.n_rows, ddl.n_events, ddl.n_tiles))
+
+
+# ---- witness expansion (witness.hip) -----------------------------------------------------------------
+def _stream_ptr(stream):
+    return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+
+def _check(rc):
+    if rc != rt.ZKIR_OK:
+        rt._raise(rc)
+
+
+class MemopColumns:
+    """zkir_memop_columns backed by torch tensors."""
+    FIELDS = (("address", torch.int64), ("value", torch.int64), ("timestamp", torch.int64), ("is_write", torch.uint8), ("width", torch.uint8),
+              ("bound_bits", torch.int32), ("bound_tag", torch.uint8), ("bound_payload", torch.int64))
+
+    def __init__(self, n: int, device):
+        self.n = n
+        self.t = {name: torch.empty(max(n, 1), dtype=dt, device=device) for name, dt in self.FIELDS}
+        self.c = rt.MemopColumnsC(*[self.t[name].data_ptr() for name, _ in self.FIELDS])
+
+    def to_numpy(self) -> np.ndarray:
+        """Packed reference-shaped MemoryOp records (same dtype as the oracle's)."""
+        dt = np.dtype([("address", "<u8"), ("value", "<u8"), ("timestamp", "<u8"), ("is_write", "u1"), ("width", "u1"),
+                       ("bound_bits", "<u4"), ("bound_tag", "u1"), ("bound_payload", "<u8")])
+        out = np.zeros(self.n, dtype=dt)
+        for name, _ in self.FIELDS:
+            a = self.t[name][:self.n].cpu().numpy()
+            out[name] = a.view(dt[name]) if a.dtype.itemsize == dt[name].itemsize else a
+        return out
+
+
+def memory_ops(log: rt.DeltaLog, device=None, stream=None):
+    """Returns (row_order MemopColumns, row_offsets tensor[n_rows+1], sorted MemopColumns = get_memory_trace())."""
+    _require_gpu()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    L = rt.lib()
+    n, n_rows = len(log.mem_events), log.n_rows
+    ev = _to_dev(log.mem_events, device)
+    sp = _stream_ptr(stream)
+    row_cols, sorted_cols = MemopColumns(n, device), MemopColumns(n, device)
+    offsets = torch.empty(n_rows + 1, dtype=torch.int64, device=device)
+    scratch = torch.empty(max(n_rows, 1), dtype=torch.uint8, device=device)
+    _check(L.zkir_memops_row_offsets_launch(ev.data_ptr(), n, n_rows, offsets.data_ptr(), sp))
+    _check(L.zkir_memops_expand_launch(ev.data_ptr(), n, log.cycle_base, C.byref(row_cols.c), sp))
+    _check(L.zkir_memops_sort_launch(ev.data_ptr(), n, n_rows, log.cycle_base, offsets.data_ptr(), scratch.data_ptr(), C.byref(sorted_cols.c), sp))
+    torch.cuda.current_stream().synchronize()
+    return row_cols, offsets, sorted_cols
+
+
+def range_checks(log: rt.DeltaLog, device=None, stream=None):
+    """Returns (value[n], pc[n], chunks[4][n] u16 as int16 tensor, multiplicity[2^chunk_bits])."""
+    _require_gpu()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    n = len(log.rc_events)
+    ev = _to_dev(log.rc_events, device)
+    value = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    pc = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    chunks = torch.empty((4, max(n, 1)), dtype=torch.int16, device=device)
+    mult = torch.empty(1 << log.rc_chunk_bits, dtype=torch.int32, device=device)
+    _check(rt.lib().zkir_range_check_expand_launch(ev.data_ptr(), n, log.rc_chunk_bits, value.data_ptr(), pc.data_ptr(), chunks.data_ptr(),
+                                                    max(n, 1), mult.data_ptr(), _stream_ptr(stream)))
+    torch.cuda.current_stream().synchronize()
+    return value[:n], pc[:n], chunks[:, :n], mult
+
+
+def normalization_events(log: rt.DeltaLog, device=None, stream=None) -> np.ndarray:
+    """NormalizationEvent records (oracle NORM_DTYPE layout) computed on the device."""
+    _require_gpu()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    n = len(log.norm_events)
+    ev = _to_dev(log.norm_events, device)
+    spec_ = (("cycle", torch.int64), ("pc", torch.int64), ("reg", torch.uint8), ("opcode", torch.uint8), ("accumulated0", torch.int64),
+             ("accumulated1", torch.int64), ("normalized0", torch.int32), ("normalized1", torch.int32), ("carry0", torch.int32), ("carry1", torch.int32))
+    t = {k: torch.empty(max(n, 1), dtype=dt, device=device) for k, dt in spec_}
+    cols = rt.NormColumnsC(*[t[k].data_ptr() for k, _ in spec_])
+    _check(rt.lib().zkir_norm_expand_launch(ev.data_ptr(), n, C.byref(cols), _stream_ptr(stream)))
+    torch.cuda.current_stream().synchronize()
+    dt = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("reg", "u1"), ("accumulated", "<u8", (2,)), ("normalized", "<u4", (2,)),
+                   ("carries", "<u4", (2,)), ("normalized_bits", "u1"), ("limb_bits", "u1"), ("cause", "u1"), ("opcode", "u1")])
+    out = np.zeros(n, dtype=dt)
+    g = lambda k: t[k][:n].cpu().numpy()  # noqa: E731
+    out["cycle"] = g("cycle").view(np.uint64); out["pc"] = g("pc").view(np.uint64); out["reg"] = g("reg"); out["opcode"] = g("opcode")
+    out["accumulated"][:, 0] = g("accumulated0").view(np.uint64); out["accumulated"][:, 1] = g("accumulated1").view(np.uint64)
+    out["normalized"][:, 0] = g("normalized0").view(np.uint32); out["normalized"][:, 1] = g("normalized1").view(np.uint32)
+    out["carries"][:, 0] = g("carry0").view(np.uint32); out["carries"][:, 1] = g("carry1").view(np.uint32)
+    out["normalized_bits"] = 20; out["limb_bits"] = 30; out["cause"] = 0
+    return out
+
+
+def sha256_chip(blocks: np.ndarray, device=None, stream=None):
+    """K3: blocks = rt.SHA_BLOCK_DTYPE records -> (columns tensor int32 [608][n], timestamps int64[n])."""
+    _require_gpu()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    n = len(blocks)
+    ev = _to_dev(blocks, device)
+    out = torch.empty((608, max(n, 1)), dtype=torch.int32, device=device)
+    ts = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    _check(rt.lib().zkir_sha256_chip_launch(ev.data_ptr(), n, out.data_ptr(), max(n, 1), ts.data_ptr(), _stream_ptr(stream)))
+    return out[:, :n], ts[:n]

@@ -69,6 +69,15 @@ class TraceFillArgsC(C.Structure):
                 ("cycle_base", C.c_uint64), ("tile_rows", C.c_uint32), ("n_events", C.c_uint32), ("out", TraceColumnsC)]
 
 
+class MemopColumnsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("address", "value", "timestamp", "is_write", "width", "bound_bits", "bound_tag", "bound_payload")]
+
+
+class NormColumnsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cycle", "pc", "reg", "opcode", "accumulated0", "accumulated1", "normalized0", "normalized1",
+                                         "carry0", "carry1")]
+
+
 _lib = None
 
 
@@ -114,6 +123,16 @@ def lib() -> C.CDLL:
     L.zkir_trace_fill_launch.argtypes = [C.POINTER(TraceFillArgsC), C.c_void_p]
     L.zkir_trace_fill_bytes.restype = C.c_uint64
     L.zkir_trace_fill_bytes.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    V, U64, U32 = C.c_void_p, C.c_uint64, C.c_uint32
+    for name, args in [("zkir_memops_expand_launch", [V, U64, U64, C.POINTER(MemopColumnsC), V]),
+                       ("zkir_memops_row_offsets_launch", [V, U64, U64, V, V]),
+                       ("zkir_memops_sort_launch", [V, U64, U64, U64, V, V, C.POINTER(MemopColumnsC), V]),
+                       ("zkir_range_check_expand_launch", [V, U64, U32, V, V, V, U64, V, V]),
+                       ("zkir_norm_expand_launch", [V, U64, C.POINTER(NormColumnsC), V]),
+                       ("zkir_sha256_chip_launch", [V, U64, V, U64, V, V])]:
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = args
     L.zkir_exec.restype = C.c_int
     L.zkir_exec.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.POINTER(C.c_void_p)]
     L.zkir_result_free.argtypes = [C.c_void_p]
