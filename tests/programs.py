@@ -228,7 +228,12 @@ def deferred_fib():
     return spec.fib_program(40).to_bytes(), [], {"enable_deferred_model": True, "enable_range_checking": True}
 
 
-ALL = {f.__name__: f for f in (
+def fib_rc():
+    """fib with range checking: every ADD whose bound exceeds 40 bits defers and is flushed at the next BNE."""
+    return spec.fib_program(200).to_bytes(), [], {"enable_range_checking": True}
+
+
+ALL = {f.__name__: f for f in (fib_rc,
     exit_42, io_echo, echo5, jal_self_cycle_limit, basic_add_ebreak, mem_sw_lw, timestamps, beq_skip, sum_1_to_5, fib30, rc_doubling,
     rc_small_consts, rc_many_pending, rc_config_30bit, alu_all, loads_stores, jumps_and_links, q9_access_at_own_pc, self_modifying,
     cmov_false_keeps_bound, sha256_hello, hashes_all, blake3_multi_chunk, sha_chain_small, deferred_add_branch, deferred_chain_store,

@@ -70,7 +70,7 @@ def test_random_program_witnesses(seed):
     assert np.array_equal(pl.normalization_events(log), want.norm_events)
 
 
-@pytest.mark.parametrize("name", ["rc_doubling", "rc_many_pending", "rc_config_30bit", "deferred_fib"])
+@pytest.mark.parametrize("name", ["rc_doubling", "rc_many_pending", "rc_config_30bit", "fib_rc"])
 def test_range_check_chunks_and_multiplicities(name):
     from zkir_amd import pipeline as pl
     blob, inputs, cfg = programs.ALL[name]()
@@ -90,7 +90,8 @@ def test_normalization_events(name):
     from zkir_amd import pipeline as pl
     blob, inputs, cfg = programs.ALL[name]()
     log, want = _both(blob, inputs, cfg)
-    assert len(want.norm_events) > 0
+    # deferred_chain_store stores through rs1 = R0: norm_two! emits nothing for R0 and normalises rs2 silently (execute.rs:903-916)
+    assert len(want.norm_events) > 0 or name == "deferred_chain_store"
     assert np.array_equal(pl.normalization_events(log), want.norm_events)
 
 
