@@ -238,6 +238,23 @@ int zkir_norm_expand_launch(const zkir_norm_event* events, uint64_t n, const zki
  * timestamps[n] optional. */
 int zkir_sha256_chip_launch(const zkir_sha_block* blocks, uint64_t n, uint32_t* out, uint64_t stride, uint64_t* timestamps, void* hip_stream);
 
+/* ---- prover stages over Baby Bear (stark.hip) ----------------------------------------------------
+ * NOT in the reference (no prove(), no Plonky3: Cargo.toml:67-69) => self-defined
+ * ("ZKIR-STARK v0"), parity unpinned; spec = oracle/stark_oracle.cpp.  Field elements are canonical
+ * u32 (< p = 2^31 - 2^27 + 1) at rest; matrices are column-major [width][n]. */
+typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, coset powers, Poseidon2 constants) for 2^log_n rows */
+int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup /* must be 1 */, zkir_stark_ctx** out);
+void zkir_stark_ctx_free(zkir_stark_ctx* ctx);
+uint32_t zkir_main_trace_width(void);             /* 89 */
+/* trace columns (K1 output) -> main trace matrix out[89][n_rows] */
+int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_rows, uint32_t* out, void* hip_stream);
+/* per-column low-degree extension: in[width][N] (evaluations over <w_N>, natural order; CLOBBERED as scratch when N > 1024)
+ * -> out[width][2N] = evaluations over the coset 31*<w_2N>, natural order */
+int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);
+/* Poseidon2-12 Merkle tree over the n_leaves rows of mat[width][n_leaves]; tree = 4*(2*n_leaves-1) words,
+ * leaf digests first, root = last 4 words */
+int zkir_merkle_commit_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* hip_stream);
+
 /* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
 typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */
 

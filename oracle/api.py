@@ -41,8 +41,8 @@ class _Cfg(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "zkir_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("zkir_oracle.cpp", "stark_oracle.cpp", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

@@ -14,8 +14,8 @@ OUT = os.path.join(HERE, "libzkir_amd.so")
 OBJ = os.path.join(HERE, "build")
 
 HOST_SOURCES = ["interp.cpp", "hashes.cpp"]
-HIP_SOURCES = ["trace_fill.hip", "witness.hip", "abi.hip"]
-HEADERS = ["host.h", os.path.join("..", "..", "include", "zkir_amd.h")]
+HIP_SOURCES = ["trace_fill.hip", "witness.hip", "stark.hip", "abi.hip"]
+HEADERS = ["host.h", "babybear.h", "poseidon2.h", os.path.join("..", "..", "include", "zkir_amd.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

@@ -1,0 +1,93 @@
+// babybear.h — Baby Bear field (p = 2^31 - 2^27 + 1) and its quartic extension F[X]/(X^4 - 11), host + device.
+//
+// Self-defined prover stages (absent from the reference, parity unpinned).  Values at rest in HBM and
+// in proofs are CANONICAL (0 <= x < p).  Multiplication uses Montgomery reduction with R = 2^32:
+//     mont_mul(a, b) = a * b * R^-1 mod p
+// so a canonical value times a constant stored in Montgomery form (c*R) gives the canonical product directly, and
+// data*data products are done on values converted with to_mont()/from_mont() inside a kernel.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define BB_HD __host__ __device__ __forceinline__
+#else
+#define BB_HD inline
+#endif
+
+namespace bb {
+
+constexpr uint32_t P = 0x78000001u;          // 2013265921
+constexpr uint32_t NEG_PINV = 0x77FFFFFFu;   // -p^-1 mod 2^32
+constexpr uint32_t R1 = 0x0FFFFFFEu;         // 2^32 mod p   (Montgomery form of 1)
+constexpr uint32_t R2 = 0x45DDDDE3u;         // 2^64 mod p
+constexpr uint32_t GEN = 31u;                // multiplicative generator, LDE coset shift
+constexpr uint32_t ROOT27 = 0x1A427A41u;     // 31^15: primitive 2^27-th root of unity
+constexpr uint32_t W_EXT = 11u;              // X^4 = 11
+
+BB_HD uint32_t add(uint32_t a, uint32_t b) { const uint32_t s = a + b; return s >= P ? s - P : s; }
+BB_HD uint32_t sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
+BB_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+BB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
+BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
+  const uint64_t t = (uint64_t)a * b;
+  const uint32_t m = (uint32_t)t * NEG_PINV;
+  const uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);
+  return u >= P ? u - P : u;
+}
+BB_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2); }
+BB_HD uint32_t from_mont(uint32_t a) { return mont_mul(a, 1u); }
+// canonical * canonical -> canonical (two reductions; for cold paths)
+BB_HD uint32_t mul(uint32_t a, uint32_t b) { return mont_mul(mont_mul(a, b), R2); }
+BB_HD uint32_t pow(uint32_t a, uint64_t e) {          // canonical in/out
+  uint32_t r = R1, b = to_mont(a);
+  while (e) { if (e & 1) r = mont_mul(r, b); b = mont_mul(b, b); e >>= 1; }
+  return from_mont(r);
+}
+BB_HD uint32_t inv(uint32_t a) { return pow(a, P - 2); }
+BB_HD uint32_t root_of_unity(int log_n) { uint32_t w = ROOT27; for (int i = log_n; i < 27; i++) w = mul(w, w); return w; }
+
+// ---- quartic extension; every coefficient in the SAME form (all canonical or all Montgomery) ----------------
+struct E4 { uint32_t c[4]; };
+BB_HD E4 e_add(const E4& a, const E4& b) { return E4{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}}; }
+BB_HD E4 e_sub(const E4& a, const E4& b) { return E4{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}}; }
+// Montgomery-form product (inputs and output in Montgomery form).  w11m = 11*R mod p.
+BB_HD E4 e_mul_m(const E4& a, const E4& b) {
+  constexpr uint32_t W11M = (uint32_t)((11ull * R1) % P);
+  const uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3], b0 = b.c[0], b1 = b.c[1], b2 = b.c[2], b3 = b.c[3];
+  const uint32_t t4 = add(add(mont_mul(a1, b3), mont_mul(a2, b2)), mont_mul(a3, b1));
+  const uint32_t t5 = add(mont_mul(a2, b3), mont_mul(a3, b2));
+  const uint32_t t6 = mont_mul(a3, b3);
+  E4 r;
+  r.c[0] = add(mont_mul(a0, b0), mont_mul(W11M, t4));
+  r.c[1] = add(add(mont_mul(a0, b1), mont_mul(a1, b0)), mont_mul(W11M, t5));
+  r.c[2] = add(add(add(mont_mul(a0, b2), mont_mul(a1, b1)), mont_mul(a2, b0)), mont_mul(W11M, t6));
+  r.c[3] = add(add(mont_mul(a0, b3), mont_mul(a1, b2)), add(mont_mul(a2, b1), mont_mul(a3, b0)));
+  return r;
+}
+// E4 (any form) times a base-field scalar given in Montgomery form -> same form as `a`
+BB_HD E4 e_mul_fm(const E4& a, uint32_t bm) { return E4{{mont_mul(a.c[0], bm), mont_mul(a.c[1], bm), mont_mul(a.c[2], bm), mont_mul(a.c[3], bm)}}; }
+BB_HD E4 e_to_mont(const E4& a) { return E4{{to_mont(a.c[0]), to_mont(a.c[1]), to_mont(a.c[2]), to_mont(a.c[3])}}; }
+BB_HD E4 e_from_mont(const E4& a) { return E4{{from_mont(a.c[0]), from_mont(a.c[1]), from_mont(a.c[2]), from_mont(a.c[3])}}; }
+BB_HD E4 e_one_m() { return E4{{R1, 0, 0, 0}}; }
+BB_HD E4 e_zero() { return E4{{0, 0, 0, 0}}; }
+// inverse in Montgomery form via the norm to the quadratic subfield F[Y]/(Y^2 - 11), Y = X^2:
+//   a = A(Y) + X*B(Y), A = a0 + a2 Y, B = a1 + a3 Y;  a * (A - X B) = A^2 - Y B^2 =: N in F[Y]/(Y^2-11);  N^-1 = conj(N)/(n0^2 - 11 n1^2)
+BB_HD E4 e_inv_m(const E4& a) {
+  constexpr uint32_t W11M = (uint32_t)((11ull * R1) % P);
+  const uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+  // A^2 = (a0^2 + 11 a2^2) + (2 a0 a2) Y ;  B^2 = (a1^2 + 11 a3^2) + (2 a1 a3) Y ;  Y*B^2 = 11*(2 a1 a3) + (a1^2 + 11 a3^2) Y
+  const uint32_t A0 = add(mont_mul(a0, a0), mont_mul(W11M, mont_mul(a2, a2))), A1 = dbl(mont_mul(a0, a2));
+  const uint32_t B0 = add(mont_mul(a1, a1), mont_mul(W11M, mont_mul(a3, a3))), B1 = dbl(mont_mul(a1, a3));
+  const uint32_t n0 = sub(A0, mont_mul(W11M, B1)), n1 = sub(A1, B0);
+  const uint32_t d = sub(mont_mul(n0, n0), mont_mul(W11M, mont_mul(n1, n1)));          // norm to F, Montgomery form
+  // d^-1 in Montgomery form: pow over Montgomery values
+  uint32_t r = R1, b = d; uint32_t e = P - 2;
+  while (e) { if (e & 1) r = mont_mul(r, b); b = mont_mul(b, b); e >>= 1; }
+  const uint32_t i0 = mont_mul(n0, r), i1 = neg(mont_mul(n1, r));                       // N^-1 = (n0 - n1 Y) / d
+  // a^-1 = (A - X B) * N^-1, with (A - X B) = a0 - a1 X + a2 X^2 - a3 X^3 and N^-1 = i0 + i1 X^2
+  const E4 conj{{a0, neg(a1), a2, neg(a3)}};
+  const E4 ninv{{i0, 0, i1, 0}};
+  return e_mul_m(conj, ninv);
+}
+
+}  // namespace bb

@@ -1,0 +1,290 @@
+// stark.hip — self-defined prover stages over Baby Bear on gfx950 ("ZKIR-STARK v0").
+//
+// The reference has none of this (parity unpinned); the spec is oracle/stark_oracle.cpp and every
+// kernel here is checked bit-for-bit against it.  Stage A (this part): main-trace field columns, radix-2 NTT / coset LDE,
+// Poseidon2-12 Merkle commitment.
+//
+//   main_trace_kernel   372 B/row SoA trace -> 89 Baby Bear columns (limbs of pc / instruction fields / registers, state and
+//                       "changed" flags).  HBM-bound: ~744 B read (row + next row, second read L2-hot) + 356 B written per row.
+//   ntt passes          per column: inverse DIF NTT over H (natural -> bit-reversed), coset scale, zero-interleave, forward DIT
+//                       NTT over the 2N coset (bit-reversed -> natural).  LDS-staged radix-2^B passes: strided passes move
+//                       tiles of 2^B x 2^C elements (2^C consecutive words per row of the tile keep loads coalesced); the last
+//                       B_m inverse stages, the scaling and the first B_m+1 forward stages are fused in one contiguous-tile
+//                       kernel.  HBM-bound: 8 B/element per strided pass, 12 B/element for the fused middle.
+//   merkle kernels      Poseidon2 width-12 sponge over the rows of the LDE matrix (one lane per leaf, column reads coalesced
+//                       across lanes) + 2-to-1 compression layers.  ALU-bound (≈740 Montgomery multiplications per permutation);
+//                       no MFMA: 31-bit modular integer work, no dense contraction.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/zkir_amd.h"
+#include "babybear.h"
+#include "host.h"
+#include "poseidon2.h"
+
+namespace {
+
+constexpr int NT = 256;
+__constant__ p2::Consts d_p2;
+
+inline unsigned grid_for(uint64_t n, int per = NT) { return (unsigned)((n + per - 1) / per); }
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
+  return ZKIR_OK;
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits == 0 ? 0u : __brev(x) >> (32 - bits); }
+
+// ------------------------------------------------------------------------------------------------
+// main trace columns (oracle: so::main_trace)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, uint64_t n, uint32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  auto col = [&](int k) -> uint32_t& { return out[(uint64_t)k * n + i]; };
+  col(0) = (uint32_t)(t.cycle[i] % bb::P);
+  const uint64_t pc = t.pc[i];
+  col(1) = (uint32_t)(pc & 0xFFFFF); col(2) = (uint32_t)((pc >> 20) & 0xFFFFF); col(3) = (uint32_t)(pc >> 40);
+  const uint32_t w = t.instruction[i];
+  col(4) = w & 0x7F; col(5) = (w >> 7) & 0xF; col(6) = (w >> 11) & 0xF; col(7) = (w >> 15) & 0xF; col(8) = w >> 19;
+  const bool last = i + 1 >= n;
+#pragma unroll 4
+  for (int g = 0; g < 16; g++) {
+    const uint64_t o = (uint64_t)g * t.reg_stride + i;
+    const uint64_t v = t.registers[o];
+    const uint32_t st = t.reg_state[o];
+    const int bits = st ? 30 : 20;
+    const uint64_t mask = (1ull << bits) - 1;
+    col(9 + 3 * g) = (uint32_t)(v & mask); col(10 + 3 * g) = (uint32_t)((v >> bits) & mask); col(11 + 3 * g) = (uint32_t)(v >> (2 * bits));
+    col(57 + g) = st;
+    uint32_t ch = 0;
+    if (!last) ch = (t.registers[o + 1] != v) | (t.reg_state[o + 1] != st) | (t.bound_bits[o + 1] != t.bound_bits[o]) | (t.bound_tag[o + 1] != t.bound_tag[o]) |
+                    (t.bound_payload[o + 1] != t.bound_payload[o]);
+    col(73 + g) = ch;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT
+// ------------------------------------------------------------------------------------------------
+// tw[k] = w^k in Montgomery form, k < count; w canonical
+__global__ __launch_bounds__(NT) void powers_kernel(uint32_t w, uint32_t scale_m, uint32_t* __restrict__ tw, uint32_t count) {
+  const uint32_t k = blockIdx.x * NT + threadIdx.x;
+  if (k >= count) return;
+  uint32_t r = scale_m, b = bb::to_mont(w), e = k;
+  while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; }
+  tw[k] = r;
+}
+
+// One strided pass of B radix-2 stages over tiles of 2^B x 2^C elements, in place, one column per blockIdx.y.
+//   DIT == false: inverse DIF stages s0..s0+B-1 of a size-2^L transform (twiddles w_N^-k, table `tw` has N/2 entries)
+//   DIT == true : forward DIT stages s0..s0+B-1 (half-span 2^s)   (twiddles w_n^k,   table `tw` has n/2 entries)
+template <bool DIT>
+__global__ __launch_bounds__(NT) void ntt_strided_kernel(uint32_t* __restrict__ data, uint64_t col_stride, int L, int s0, int B, int C, const uint32_t* __restrict__ tw) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* x = data + (uint64_t)blockIdx.y * col_stride;
+  const uint32_t n = 1u << L;
+  const uint32_t stride_mid = DIT ? (1u << s0) : (n >> (s0 + B));
+  const uint32_t lo_tiles = stride_mid >> C;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t hi = tile / lo_tiles, lo0 = (tile % lo_tiles) << C;
+  const uint32_t base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
+  const uint32_t elems = 1u << (B + C), cmask = (1u << C) - 1;
+  for (uint32_t e = threadIdx.x; e < elems; e += NT) lds[e] = x[base + (e >> C) * stride_mid + (e & cmask)];
+  __syncthreads();
+  for (int b = 0; b < B; b++) {
+    const int hb = DIT ? b : (B - 1 - b);                     // log2 of the half-span in `mid` units
+    const uint32_t half_mid = 1u << hb;
+    const int s = s0 + b;
+    for (uint32_t q = threadIdx.x; q < (elems >> 1); q += NT) {
+      const uint32_t lo_l = q & cmask, r = q >> C;
+      const uint32_t mid_lo = r & (half_mid - 1), mid_hi = r >> hb;
+      const uint32_t ia = (((mid_hi << (hb + 1)) | mid_lo) << C) | lo_l, ib = ia + (half_mid << C);
+      const uint32_t j = mid_lo * stride_mid + lo0 + lo_l;
+      const uint32_t a = lds[ia], bv = lds[ib];
+      if (DIT) {
+        const uint32_t t = bb::mont_mul(bv, tw[j << (L - 1 - s)]);
+        lds[ia] = bb::add(a, t); lds[ib] = bb::sub(a, t);
+      } else {
+        lds[ia] = bb::add(a, bv); lds[ib] = bb::mont_mul(bb::sub(a, bv), tw[j << s]);
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < elems; e += NT) x[base + (e >> C) * stride_mid + (e & cmask)] = lds[e];
+}
+
+// Fused middle: last Bm inverse-DIF stages on a contiguous 2^Bm chunk of the size-N array `in`, scale by g^k / N
+// (k = bit-reversal of the position), zero-interleave, first Bm+1 forward-DIT stages, write the 2^(Bm+1) chunk of `out`.
+//   g_lo[k & 1023] * g_hi[k >> 10] = g^k * N^-1   (two-level power table, Montgomery form)
+__global__ __launch_bounds__(NT) void lde_middle_kernel(const uint32_t* __restrict__ in, uint64_t in_stride, uint32_t* __restrict__ out, uint64_t out_stride, int L,
+                                                         int Bm, const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ tw_fwd,
+                                                         const uint32_t* __restrict__ g_lo, const uint32_t* __restrict__ g_hi) {
+  extern __shared__ uint32_t lds[];                            // 2^(Bm+1) words
+  const uint32_t* x = in + (uint64_t)blockIdx.y * in_stride;
+  uint32_t* y = out + (uint64_t)blockIdx.y * out_stride;
+  const uint32_t chunk = 1u << Bm, base = blockIdx.x << Bm;
+  for (uint32_t e = threadIdx.x; e < chunk; e += NT) lds[e] = x[base + e];
+  __syncthreads();
+  for (int b = 0; b < Bm; b++) {                               // inverse DIF stages s = L-Bm+b, half = 2^(Bm-1-b)
+    const int hb = Bm - 1 - b, s = L - Bm + b;
+    const uint32_t half = 1u << hb;
+    for (uint32_t q = threadIdx.x; q < (chunk >> 1); q += NT) {
+      const uint32_t r_lo = q & (half - 1), r_hi = q >> hb;
+      const uint32_t ia = (r_hi << (hb + 1)) | r_lo, ib = ia + half;
+      const uint32_t a = lds[ia], bv = lds[ib];
+      lds[ia] = bb::add(a, bv); lds[ib] = bb::mont_mul(bb::sub(a, bv), tw_inv[r_lo << s]);
+    }
+    __syncthreads();
+  }
+  // scale + zero-interleave (in registers, then one barrier): position p holds coefficient k = bitrev_L(p); DIT stage 0 duplicates
+  uint32_t v[(1 << 11) / NT > 0 ? (1 << 11) / NT : 1];
+  int cnt = 0;
+  for (uint32_t e = threadIdx.x; e < chunk; e += NT) {
+    const uint32_t k = bitrev(base + e, L);
+    v[cnt++] = bb::mont_mul(bb::mont_mul(lds[e], g_lo[k & 1023]), g_hi[k >> 10]);
+  }
+  __syncthreads();
+  cnt = 0;
+  for (uint32_t e = threadIdx.x; e < chunk; e += NT) { lds[2 * e] = v[cnt]; lds[2 * e + 1] = v[cnt]; cnt++; }
+  __syncthreads();
+  const int L2 = L + 1;
+  for (int s = 1; s <= Bm; s++) {                              // forward DIT stages 1..Bm of the size-2N transform
+    const uint32_t half = 1u << s;
+    for (uint32_t q = threadIdx.x; q < chunk; q += NT) {
+      const uint32_t r_lo = q & (half - 1), r_hi = q >> s;
+      const uint32_t ia = (r_hi << (s + 1)) | r_lo, ib = ia + half;
+      const uint32_t a = lds[ia], t = bb::mont_mul(lds[ib], tw_fwd[r_lo << (L2 - 1 - s)]);
+      lds[ia] = bb::add(a, t); lds[ib] = bb::sub(a, t);
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < 2 * chunk; e += NT) y[2 * base + e] = lds[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Poseidon2 Merkle
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void leaf_hash_kernel(const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint64_t col_stride, uint32_t* __restrict__ digests) {
+  const uint64_t j = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (j >= n) return;
+  uint32_t s[p2::T];
+#pragma unroll
+  for (int i = 0; i < p2::T; i++) s[i] = 0;
+  for (uint32_t off = 0; off < width; off += p2::RATE) {
+#pragma unroll
+    for (int i = 0; i < p2::RATE; i++)
+      if (off + i < width) s[i] = bb::to_mont(mat[(uint64_t)(off + i) * col_stride + j]);
+    p2::permute(s, d_p2);
+  }
+  if (width == 0) p2::permute(s, d_p2);
+  uint4 d = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+  reinterpret_cast<uint4*>(digests)[j] = d;
+}
+
+__global__ __launch_bounds__(NT) void compress_kernel(const uint32_t* __restrict__ in, uint64_t n_out, uint32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n_out) return;
+  const uint4 l = reinterpret_cast<const uint4*>(in)[2 * i], r = reinterpret_cast<const uint4*>(in)[2 * i + 1];
+  uint32_t s[p2::T] = {bb::to_mont(l.x), bb::to_mont(l.y), bb::to_mont(l.z), bb::to_mont(l.w), bb::to_mont(r.x), bb::to_mont(r.y), bb::to_mont(r.z), bb::to_mont(r.w), 0, 0, 0, 0};
+  p2::permute(s, d_p2);
+  reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+}
+
+}  // namespace
+
+// ================================================================================================
+// context + C ABI
+// ================================================================================================
+struct zkir_stark_ctx {
+  uint32_t log_n = 0, log_blowup = 1;
+  uint32_t* d_tw_inv = nullptr;   // w_N^-k, k < N/2
+  uint32_t* d_tw_fwd = nullptr;   // w_{2N}^k, k < N
+  uint32_t* d_g_lo = nullptr;     // g^k / N, k < 1024
+  uint32_t* d_g_hi = nullptr;     // g^(1024 k)
+  p2::Consts consts;
+};
+
+extern "C" {
+
+uint32_t zkir_main_trace_width(void) { return 89; }
+
+int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** out) {
+  if (!out || log_n < 1 || log_n > 26 || log_blowup != 1) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_stark_ctx_create: need 1 <= log_n <= 26 and log_blowup == 1"}); return ZKIR_ERR_ARGUMENT; }
+  *out = nullptr;
+  zkir_stark_ctx* c = new zkir_stark_ctx();
+  c->log_n = log_n; c->log_blowup = log_blowup;
+  const uint32_t N = 1u << log_n;
+  const uint32_t n_inv = N >= 2 ? N / 2 : 1, n_hi = (N >> 10) + 1;
+  p2::generate(c->consts);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_p2), &c->consts, sizeof(p2::Consts));
+  if (e == hipSuccess) e = hipMalloc(&c->d_tw_inv, (size_t)n_inv * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_tw_fwd, (size_t)N * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_g_lo, 1024 * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_g_hi, (size_t)n_hi * 4);
+  if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("zkir_stark_ctx_create: ") + hipGetErrorString(e)}); zkir_stark_ctx_free(c); return ZKIR_ERR_DEVICE; }
+  const uint32_t wN = bb::root_of_unity(log_n), w2N = bb::root_of_unity(log_n + 1);
+  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_inv)), dim3(NT), 0, 0, bb::inv(wN), bb::R1, c->d_tw_inv, n_inv);
+  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(N)), dim3(NT), 0, 0, w2N, bb::R1, c->d_tw_fwd, N);
+  hipLaunchKernelGGL(powers_kernel, dim3(4), dim3(NT), 0, 0, bb::GEN, bb::to_mont(bb::inv(N % bb::P)), c->d_g_lo, 1024u);
+  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_hi)), dim3(NT), 0, 0, bb::pow(bb::GEN, 1024), bb::R1, c->d_g_hi, n_hi);
+  if (hipDeviceSynchronize() != hipSuccess || check_launch("stark ctx tables") != ZKIR_OK) { zkir_stark_ctx_free(c); return ZKIR_ERR_DEVICE; }
+  *out = c;
+  return ZKIR_OK;
+}
+
+void zkir_stark_ctx_free(zkir_stark_ctx* c) {
+  if (!c) return;
+  (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi);
+  delete c;
+}
+
+int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_rows, uint32_t* out, void* stream) {
+  if (n_rows == 0) return ZKIR_OK;
+  hipLaunchKernelGGL(main_trace_kernel, dim3(grid_for(n_rows)), dim3(NT), 0, (hipStream_t)stream, *trace, n_rows, out);
+  return check_launch("main_trace");
+}
+
+// in: [width][N] canonical evaluations over H (natural order; used as scratch and overwritten!), out: [width][2N]
+int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int L = (int)c->log_n;
+  const uint32_t N = 1u << L;
+  const int Bm = L < 10 ? L : 10;
+  // inverse DIF strided stages 0 .. L-Bm-1
+  for (int s0 = 0; s0 < L - Bm;) {
+    const int B = (L - Bm - s0) < 5 ? (L - Bm - s0) : 5;
+    int C = L - (s0 + B); if (C > 6) C = 6;                   // stride_mid = 2^(L-s0-B) >= 2^Bm
+    hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(N >> (B + C), width), dim3(NT), (4u << (B + C)), s, in, (uint64_t)N, L, s0, B, C, c->d_tw_inv);
+    s0 += B;
+  }
+  hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi);
+  // forward DIT strided stages Bm+1 .. L of the size-2N transform
+  const int L2 = L + 1;
+  for (int s0 = Bm + 1; s0 < L2;) {
+    const int B = (L2 - s0) < 5 ? (L2 - s0) : 5;
+    int C = s0 < 6 ? s0 : 6;
+    hipLaunchKernelGGL(ntt_strided_kernel<true>, dim3((2 * N) >> (B + C), width), dim3(NT), (4u << (B + C)), s, out, (uint64_t)2 * N, L2, s0, B, C, c->d_tw_fwd);
+    s0 += B;
+  }
+  return check_launch("lde");
+}
+
+// tree = [leaf digests (4*n)] [layer 1 (4*n/2)] ... [root (4)]  = 4*(2n-1) words; n_leaves a power of two
+int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* stream) {
+  (void)c;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle: n_leaves must be a power of two"}); return ZKIR_ERR_ARGUMENT; }
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, mat, width, n_leaves, n_leaves, tree);
+  uint32_t* cur = tree;
+  for (uint64_t m = n_leaves; m > 1; m >>= 1) {
+    uint32_t* nxt = cur + 4 * m;
+    hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cur, m / 2, nxt);
+    cur = nxt;
+  }
+  return check_launch("merkle_commit");
+}
+
+}  // extern "C"

@@ -133,6 +133,16 @@ def lib() -> C.CDLL:
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
+    L.zkir_stark_ctx_create.restype = C.c_int
+    L.zkir_stark_ctx_create.argtypes = [U32, U32, C.POINTER(V)]
+    L.zkir_stark_ctx_free.restype = None
+    L.zkir_stark_ctx_free.argtypes = [V]
+    L.zkir_main_trace_width.restype = U32
+    for name, args in [("zkir_main_trace_launch", [C.POINTER(TraceColumnsC), U64, V, V]), ("zkir_lde_launch", [V, V, U32, V, V]),
+                       ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V])]:
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = args
     L.zkir_exec.restype = C.c_int
     L.zkir_exec.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.POINTER(C.c_void_p)]
     L.zkir_result_free.argtypes = [C.c_void_p]

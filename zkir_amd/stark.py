@@ -1,0 +1,86 @@
+"""Driver for the self-defined prover stages (stark.hip) — Baby Bear LDE + Poseidon2-12 Merkle commitment.
+
+NOT in the reference (parity unpinned); spec = oracle/stark_oracle.cpp, DESIGN.md §8.
+PyTorch is plumbing (device buffers, streams); all arithmetic happens in the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import pipeline as pl
+from . import runtime as rt
+
+P = 2013265921
+W_MAIN = 89
+
+
+class StarkContext:
+    """zkir_stark_ctx: device tables for traces of 2^log_n rows (blow-up 2)."""
+
+    def __init__(self, log_n: int, log_blowup: int = 1):
+        pl._require_gpu()
+        self.log_n, self.log_blowup = log_n, log_blowup
+        h = C.c_void_p()
+        rc = rt.lib().zkir_stark_ctx_create(log_n, log_blowup, C.byref(h))
+        if rc != rt.ZKIR_OK:
+            rt._raise(rc)
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            rt.lib().zkir_stark_ctx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _sp(stream):
+    return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+
+def main_trace(trace: pl.DeviceTrace, stream=None) -> torch.Tensor:
+    """K4: SoA execution trace -> main trace matrix int32[89][n_rows] (canonical Baby Bear values)."""
+    n = trace.n_rows
+    out = torch.empty((W_MAIN, n), dtype=torch.int32, device=trace.cycle.device)
+    pl._check(rt.lib().zkir_main_trace_launch(C.byref(trace.c), n, out.data_ptr(), _sp(stream)))
+    return out
+
+
+def lde(ctx: StarkContext, mat: torch.Tensor, stream=None, clobber: bool = False) -> torch.Tensor:
+    """Per-column LDE of mat[width][N] to [width][2N] on the coset 31*<w_2N> (natural order)."""
+    width, n = mat.shape
+    assert n == 1 << ctx.log_n and mat.dtype == torch.int32 and mat.is_contiguous()
+    src = mat if clobber else mat.clone()
+    out = torch.empty((width, 2 * n), dtype=torch.int32, device=mat.device)
+    pl._check(rt.lib().zkir_lde_launch(ctx.handle, src.data_ptr(), width, out.data_ptr(), _sp(stream)))
+    return out
+
+
+def merkle_commit(ctx: StarkContext, mat: torch.Tensor, stream=None) -> torch.Tensor:
+    """Poseidon2-12 Merkle tree over the rows (positions) of mat[width][n]; returns the tree int32[4*(2n-1)], root = last 4."""
+    width, n = mat.shape
+    assert mat.dtype == torch.int32 and mat.is_contiguous()
+    tree = torch.empty(4 * (2 * n - 1), dtype=torch.int32, device=mat.device)
+    pl._check(rt.lib().zkir_merkle_commit_launch(ctx.handle, mat.data_ptr(), width, n, tree.data_ptr(), _sp(stream)))
+    return tree
+
+
+def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None):
+    """main trace -> LDE -> Merkle.  Returns (root np.uint32[4], lde matrix tensor, tree tensor)."""
+    m = main_trace(trace, stream)
+    L = lde(ctx, m, stream, clobber=True)
+    tree = merkle_commit(ctx, L, stream)
+    root = tree[-4:].cpu().numpy().view(np.uint32)
+    return root, L, tree
