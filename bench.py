@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — trace rows/sec of the MI355X execution-trace path on the BASELINE.json workload.
+"""bench.py — trace rows/sec of the MI355X prover hot path on BASELINE.json configs[1]:
+"2^20-cycle fib trace: BabyBear NTT/LDE + Poseidon2 Merkle on 1 MI355X".
 
-A "step" = one pass of the device hot path over one resident delta log: K1 `trace_fill`
-(zkir_amd/csrc/trace_fill.hip) expanding the 2^k-cycle Fibonacci run into the 372 B/row SoA trace.
-The delta log (events, tile index, pc/instruction columns) is resident in HBM before the timed region;
-the host interpreter that produced it is timed separately and reported as `host_interpret_rows_per_s`.
+A "step" = one pass of the device hot path over one resident delta log of a 2^k-cycle Fibonacci run:
+    K1 trace_fill (372 B/row SoA trace)  ->  main_trace (89 Baby Bear columns)  ->  LDE (blow-up 2, coset NTT)
+    ->  Poseidon2-12 Merkle commitment of the 2^(k+1) LDE rows.
+The delta log (register events, tile index, pc/instruction columns) is resident in HBM before the timed region; the
+sequential host interpreter that produced it is timed separately (`host_interpret_rows_per_s`).  `--stage trace_fill`
+times K1 alone.  The trace / LDE / Merkle stages after K1 have no counterpart in the reference (no prover there).
 
-N ranks = N row shards of one (N * 2^k)-cycle run (weak scaling, no data-path collective: each rank
-fills its own row range from its own register snapshot).  Launch: `python bench.py` (N=1) or
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+N ranks = N row shards of one (N * 2^k)-cycle run (weak scaling): each rank fills and commits its own row range from
+its own register snapshot with no data-path collective; the per-rank Merkle roots are all-gathered over RCCL (32 B... 16 B
+per rank) and rank 0 hashes the top levels.  Launch: `python bench.py` (N=1) or torch.distributed.run with --gpus N.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -21,16 +25,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+W = 89
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2-rows", type=int, default=20, help="rows per GPU = 2^k (BASELINE configs[1] = 20)")
     ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--stage", choices=["commit", "trace_fill"], default="commit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -38,7 +44,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from zkir_amd import pipeline as pl, runtime as rt, spec
+    from zkir_amd import pipeline as pl, runtime as rt, spec, stark
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -50,23 +56,41 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    rows_per_gpu = 1 << args.log2_rows
-    total_rows = rows_per_gpu * world
+    k = args.log2_rows
+    n = 1 << k
+    total_rows = n * world
     blob = spec.fib_endless_program().to_bytes()
+    lib = rt.lib()
 
     # ---- host stage (untimed for `value`; reported separately) ------------------------------------
     t0 = time.perf_counter()
     log = rt.interpret(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True), tile_rows=args.tile_rows)
     host_s = time.perf_counter() - t0
     assert log.n_rows == total_rows and log.halt_reason == rt.HaltReason.CycleLimit()
-    shard = log.shard(rank * rows_per_gpu, (rank + 1) * rows_per_gpu) if world > 1 else log
+    shard = log.shard(rank * n, (rank + 1) * n) if world > 1 else log
     t0 = time.perf_counter()
     ddl = pl.upload(shard)
     torch.cuda.synchronize()
     h2d_s = time.perf_counter() - t0
     trace = pl.DeviceTrace(ddl)
     fill_args = pl.trace_fill_args(ddl, trace)
-    step_bytes = pl.trace_fill_bytes(ddl)
+    commit = args.stage == "commit"
+    if commit:
+        ctx = stark.StarkContext(k)
+        m = torch.empty((W, n), dtype=torch.int32, device="cuda")
+        L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
+        tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
+    sp = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+
+    stages = [("trace_fill", lambda: pl.trace_fill(fill_args))]
+    if commit:
+        stages += [("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, m.data_ptr(), sp()))),
+                   ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
+                   ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
+
+    def step():
+        for _, f in stages:
+            f()
 
     def barrier():
         if world > 1:
@@ -75,68 +99,117 @@ def main():
 
     t_pre = time.perf_counter()                       # untimed pre-warm: let the GPU clocks settle (DVFS) before the W warmup steps
     while time.perf_counter() - t_pre < 0.3:
-        for _ in range(20):
-            pl.trace_fill(fill_args)
+        step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        pl.trace_fill(fill_args)
+        step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        pl.trace_fill(fill_args)          # launched on torch's current stream, the one the events are recorded on
-        b.record()
+    ev0.record()
+    for _ in range(args.steps):
+        step()                                        # every launch goes to torch's current stream
+    ev1.record()
     barrier()
     wall = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
-    # ---- parity spot check outside the timed region (full parity lives in tests/ -m gpu) ----------
-    n_chk = min(4096, rows_per_gpu)
+    # ---- per-stage kernel times with HIP events on the launch stream (outside the timed region) ----
+    stage_ms = {}
+    for name, f in stages:
+        ts = []
+        for _ in range(10):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); f(); b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        stage_ms[name] = float(np.mean(ts))
+
+    # ---- parity spot checks outside the timed region (full parity lives in tests/ -m gpu) ----------
+    n_chk = min(4096, n)
     got = trace.registers[:, :n_chk].cpu().numpy().view(np.uint64)
     ev_np = shard.reg_events
     for r in (1, 2, 3, 4):
         e = ev_np[ev_np["reg"] == r]
         pos = np.searchsorted(e["vis"], np.arange(n_chk), side="right") - 1
         assert np.array_equal(got[r], e["value"][pos]), "bench parity spot-check failed"
+    root = tree[-4:].cpu().numpy().view(np.uint32).tolist() if commit else None
+    roots = None
+    if commit and world > 1:                          # the only collective of the path: all-gather of per-GPU subtree roots
+        g = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(world)]
+        dist.all_gather(g, tree[-4:].contiguous())
+        roots = [x.cpu().numpy().view(np.uint32).tolist() for x in g]
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
         value = total_rows * args.steps / wall
-        achieved = step_bytes / (kernel_ms * 1e-3) / 1e9
+        fill_bytes = pl.trace_fill_bytes(ddl)
+        kernels = {"trace_fill": {"bound": "hbm", "bytes": fill_bytes, "ms": stage_ms["trace_fill"]}}
+        if commit:
+            #   main_trace: reads the 372 B/row trace once (+ the next-row re-read served by L2), writes 89 u32 columns
+            #   lde: per column 2 strided inverse passes (8 B/elem over N) + fused middle (4N read + 8N written)
+            #        + 2 strided forward passes (8 B/elem over 2N)   [k >= 16; fewer passes below]
+            #   merkle: reads the LDE matrix once, writes 16 B per node; ALU-bound (Poseidon2), bytes given for completeness
+            n_inv = -(-max(k - 10, 0) // 5)
+            kernels["main_trace"] = {"bound": "hbm", "bytes": (372 + 4 * W) * n, "ms": stage_ms["main_trace"]}
+            kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
+            perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
+            kernels["merkle"] = {"bound": "int-alu", "bytes": 4 * W * 2 * n + 16 * (4 * n - 1), "ms": stage_ms["merkle"],
+                                 "poseidon2_perms_per_s": perms / (stage_ms["merkle"] * 1e-3),
+                                 "mont_mul_per_s": perms * 736 / (stage_ms["merkle"] * 1e-3)}
+        for v in kernels.values():
+            v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
+        dom = max(kernels, key=lambda q: kernels[q]["ms"])
         traffic = None                                 # HBM bytes/launch from the committed rocprofv3 PMC passes of this exact workload
-        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_k{args.log2_rows}_t{ddl.tile_rows}.json")
+        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{dom}_k{k}.json")
         if os.path.exists(pmc):
-            d = json.load(open(pmc))
-            traffic = next(iter(d.values())).get("hbm_bytes_per_launch")
+            traffic = next(iter(json.load(open(pmc)).values())).get("hbm_bytes_per_launch")
         out = {
-            "metric": "trace rows/sec (2^20-cycle fib, device-resident delta log -> 372 B/row SoA execution trace)",
+            "metric": "trace rows/sec (2^20-cycle fib: execution-trace fill + BabyBear NTT/LDE + Poseidon2 Merkle commitment)"
+                      if commit else "trace rows/sec (2^20-cycle fib, execution-trace fill only)",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"fib_endless 2^{args.log2_rows} cycles per GPU (v3.4 fib loop of tests/cross_module.rs:145-164, max_cycles halt), "
-                                   "VMConfig{enable_execution_trace}, stage = K1 trace_fill",
-                       "rows_per_gpu": rows_per_gpu, "tile_rows": ddl.tile_rows, "reg_events_per_gpu": ddl.n_events,
+            "dtype": "u32 (Baby Bear, 31-bit modular) / u64 trace words" if commit else "u64", "data": "synthetic",
+            "config": {"workload": f"fib_endless 2^{k} cycles per GPU (v3.4 fib loop of tests/cross_module.rs:145-164, max_cycles halt), "
+                                   f"VMConfig{{enable_execution_trace}}; stages = {'+'.join(s for s, _ in stages)}; blow-up 2, Poseidon2 width 12",
+                       "rows_per_gpu": n, "tile_rows": ddl.tile_rows, "reg_events_per_gpu": ddl.n_events, "main_trace_width": W if commit else None,
                        "parallelism": f"row-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "trace_fill_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": step_bytes},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernels[dom]["ms"],
+                         "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
+                         "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (≈736 Montgomery multiplications per "
+                                  "permutation), not HBM- or MFMA-bound; see roofline_by_stage for its ALU rate and for the HBM-bound stages")
+                         if kernels[dom]["bound"] != "hbm" else None},
+            "roofline_by_stage": kernels,
+            "gpu_ms_per_step_hip_events": gpu_ms_per_step,
+            "merkle_root": root, "merkle_roots_all_ranks": roots,
             "host_interpret_rows_per_s": total_rows / host_s,
             "h2d_upload_s": h2d_s,
-            "end_to_end_rows_per_s_incl_host_and_pcie": rows_per_gpu / (host_s / world + h2d_s + kernel_ms * 1e-3),
+            "end_to_end_rows_per_s_incl_host_and_pcie": n / (host_s / world + h2d_s + gpu_ms_per_step * 1e-3),
         }
         if not args.no_cpu_baseline and world == 1:
-            from oracle import api as oracle
-            n_cpu = min(total_rows, 1 << 20)
+            from oracle import api as oracle, stark_api as so
             oracle.time_run(blob, 1 << 12)                      # warm the allocator / page cache
-            dt, n = oracle.time_run(blob, n_cpu)
+            n_cpu = min(total_rows, 1 << 22)
+            dt, nn = oracle.time_run(blob, n_cpu)
             dtf, nf = oracle.time_run(blob, 1 << 14, faithful=True)
-            out["cpu_baseline"] = {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-                                   "sample": f"oracle (C++ restatement of VM::run, linear mode) on the same fib program, {n} rows in {dt:.2f} s; "
-                                             f"faithful O(N^2) mode: {nf} rows in {dtf:.2f} s = {nf / dtf:.0f} rows/s"}
+            sample = (f"oracle (C++ restatement of VM::run, linear mode): {nn} rows in {dt:.2f} s = {nn / dt:.3g} rows/s; "
+                      f"faithful O(N^2) mode (vm.rs:287-298): {nf} rows in {dtf:.2f} s = {nf / dtf:.3g} rows/s")
+            cpu_value = nn / dt
+            if commit:
+                kc = 14
+                rows = oracle.run(blob, max_cycles=1 << kc, enable_execution_trace=True).rows
+                t0 = time.perf_counter()
+                so.commit_trace(rows, 1)
+                dtc = time.perf_counter() - t0
+                cpu_value = (1 << kc) / (dtc + (1 << kc) / (nn / dt))
+                sample += f"; oracle commit (main trace + LDE + Poseidon2 Merkle) of 2^{kc} rows in {dtc:.2f} s; value = rows/s of trace + commit at 2^{kc} rows"
+            out["cpu_baseline"] = {"value": cpu_value, "unit": "rows/s", "cores": 1, "kind": "port", "sample": sample}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -78,11 +78,14 @@ __global__ __launch_bounds__(NT) void powers_kernel(uint32_t w, uint32_t scale_m
   tw[k] = r;
 }
 
-// One strided pass of B radix-2 stages over tiles of 2^B x 2^C elements, in place, one column per blockIdx.y.
-//   DIT == false: inverse DIF stages s0..s0+B-1 of a size-2^L transform (twiddles w_N^-k, table `tw` has N/2 entries)
-//   DIT == true : forward DIT stages s0..s0+B-1 (half-span 2^s)   (twiddles w_n^k,   table `tw` has n/2 entries)
+// One strided pass of B (<= 5) radix-2 stages over tiles of 2^B x 2^C elements, in place, one column per blockIdx.y.
+//   DIT == false: inverse DIF stages s0..s0+B-1 of a size-2^L transform; DIT == true: forward DIT stages s0..s0+B-1.
+// Twiddles never come from a big strided table lookup per butterfly: the exponent splits into a per-lane part that only
+// depends on `lo` (one table read per thread per tile, then repeated squaring across the stages) and a root of unity of
+// order <= 2^B indexed by the position inside the tile (compact table `small` of order 2^log_small, L1-resident).
 template <bool DIT>
-__global__ __launch_bounds__(NT) void ntt_strided_kernel(uint32_t* __restrict__ data, uint64_t col_stride, int L, int s0, int B, int C, const uint32_t* __restrict__ tw) {
+__global__ __launch_bounds__(NT) void ntt_strided_kernel(uint32_t* __restrict__ data, uint64_t col_stride, int L, int s0, int B, int C, const uint32_t* __restrict__ tw,
+                                                          const uint32_t* __restrict__ small, int log_small) {
   extern __shared__ uint32_t lds[];
   uint32_t* x = data + (uint64_t)blockIdx.y * col_stride;
   const uint32_t n = 1u << L;
@@ -93,25 +96,40 @@ __global__ __launch_bounds__(NT) void ntt_strided_kernel(uint32_t* __restrict__ 
   const uint32_t base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
   const uint32_t elems = 1u << (B + C), cmask = (1u << C) - 1;
   for (uint32_t e = threadIdx.x; e < elems; e += NT) lds[e] = x[base + (e >> C) * stride_mid + (e & cmask)];
+  // per-lane twiddle powers (NT is a multiple of 2^C, so a thread always works on the same `lo`)
+  const uint32_t lo = lo0 + (threadIdx.x & cmask);
+  uint32_t tp[5];
+  if (DIT) {                                                   // stage b needs w^(lo << (L-1-s0-b)): finest at b = B-1, each coarser stage squares it
+    uint32_t u = tw[lo << (L - s0 - B)];
+#pragma unroll
+    for (int b = 4; b >= 0; b--) if (b < B) { tp[b] = u; u = bb::mont_mul(u, u); }
+  } else {                                                     // stage b needs w^-(lo << (s0+b))
+    uint32_t u = tw[lo << s0];
+#pragma unroll
+    for (int b = 0; b < 5; b++) if (b < B) { tp[b] = u; u = bb::mont_mul(u, u); }
+  }
   __syncthreads();
-  for (int b = 0; b < B; b++) {
-    const int hb = DIT ? b : (B - 1 - b);                     // log2 of the half-span in `mid` units
-    const uint32_t half_mid = 1u << hb;
-    const int s = s0 + b;
-    for (uint32_t q = threadIdx.x; q < (elems >> 1); q += NT) {
-      const uint32_t lo_l = q & cmask, r = q >> C;
-      const uint32_t mid_lo = r & (half_mid - 1), mid_hi = r >> hb;
-      const uint32_t ia = (((mid_hi << (hb + 1)) | mid_lo) << C) | lo_l, ib = ia + (half_mid << C);
-      const uint32_t j = mid_lo * stride_mid + lo0 + lo_l;
-      const uint32_t a = lds[ia], bv = lds[ib];
-      if (DIT) {
-        const uint32_t t = bb::mont_mul(bv, tw[j << (L - 1 - s)]);
-        lds[ia] = bb::add(a, t); lds[ib] = bb::sub(a, t);
-      } else {
-        lds[ia] = bb::add(a, bv); lds[ib] = bb::mont_mul(bb::sub(a, bv), tw[j << s]);
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    if (b < B) {
+      const int hb = DIT ? b : (B - 1 - b);                    // log2 of the half-span in `mid` units
+      const uint32_t half_mid = 1u << hb;
+      const int sh = log_small - (hb + 1);                     // small-root order 2^(hb+1)
+      for (uint32_t q = threadIdx.x; q < (elems >> 1); q += NT) {
+        const uint32_t lo_l = q & cmask, r = q >> C;
+        const uint32_t mid_lo = r & (half_mid - 1), mid_hi = r >> hb;
+        const uint32_t ia = (((mid_hi << (hb + 1)) | mid_lo) << C) | lo_l, ib = ia + (half_mid << C);
+        const uint32_t w = bb::mont_mul(tp[b], small[mid_lo << sh]);
+        const uint32_t a = lds[ia], bv = lds[ib];
+        if (DIT) {
+          const uint32_t t = bb::mont_mul(bv, w);
+          lds[ia] = bb::add(a, t); lds[ib] = bb::sub(a, t);
+        } else {
+          lds[ia] = bb::add(a, bv); lds[ib] = bb::mont_mul(bb::sub(a, bv), w);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   for (uint32_t e = threadIdx.x; e < elems; e += NT) x[base + (e >> C) * stride_mid + (e & cmask)] = lds[e];
 }
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(NT) void ntt_strided_kernel(uint32_t* __restrict__ 
 // (k = bit-reversal of the position), zero-interleave, first Bm+1 forward-DIT stages, write the 2^(Bm+1) chunk of `out`.
 //   g_lo[k & 1023] * g_hi[k >> 10] = g^k * N^-1   (two-level power table, Montgomery form)
 __global__ __launch_bounds__(NT) void lde_middle_kernel(const uint32_t* __restrict__ in, uint64_t in_stride, uint32_t* __restrict__ out, uint64_t out_stride, int L,
-                                                         int Bm, const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ tw_fwd,
+                                                         int Bm, const uint32_t* __restrict__ small_inv, const uint32_t* __restrict__ small_fwd,
                                                          const uint32_t* __restrict__ g_lo, const uint32_t* __restrict__ g_hi) {
   extern __shared__ uint32_t lds[];                            // 2^(Bm+1) words
   const uint32_t* x = in + (uint64_t)blockIdx.y * in_stride;
@@ -129,13 +147,13 @@ __global__ __launch_bounds__(NT) void lde_middle_kernel(const uint32_t* __restri
   for (uint32_t e = threadIdx.x; e < chunk; e += NT) lds[e] = x[base + e];
   __syncthreads();
   for (int b = 0; b < Bm; b++) {                               // inverse DIF stages s = L-Bm+b, half = 2^(Bm-1-b)
-    const int hb = Bm - 1 - b, s = L - Bm + b;
+    const int hb = Bm - 1 - b;
     const uint32_t half = 1u << hb;
     for (uint32_t q = threadIdx.x; q < (chunk >> 1); q += NT) {
       const uint32_t r_lo = q & (half - 1), r_hi = q >> hb;
       const uint32_t ia = (r_hi << (hb + 1)) | r_lo, ib = ia + half;
       const uint32_t a = lds[ia], bv = lds[ib];
-      lds[ia] = bb::add(a, bv); lds[ib] = bb::mont_mul(bb::sub(a, bv), tw_inv[r_lo << s]);
+      lds[ia] = bb::add(a, bv); lds[ib] = bb::mont_mul(bb::sub(a, bv), small_inv[r_lo << b]);   // w_N^-(r_lo << s) = w_{2^Bm}^-(r_lo << b)
     }
     __syncthreads();
   }
@@ -150,13 +168,12 @@ __global__ __launch_bounds__(NT) void lde_middle_kernel(const uint32_t* __restri
   cnt = 0;
   for (uint32_t e = threadIdx.x; e < chunk; e += NT) { lds[2 * e] = v[cnt]; lds[2 * e + 1] = v[cnt]; cnt++; }
   __syncthreads();
-  const int L2 = L + 1;
   for (int s = 1; s <= Bm; s++) {                              // forward DIT stages 1..Bm of the size-2N transform
     const uint32_t half = 1u << s;
     for (uint32_t q = threadIdx.x; q < chunk; q += NT) {
       const uint32_t r_lo = q & (half - 1), r_hi = q >> s;
       const uint32_t ia = (r_hi << (s + 1)) | r_lo, ib = ia + half;
-      const uint32_t a = lds[ia], t = bb::mont_mul(lds[ib], tw_fwd[r_lo << (L2 - 1 - s)]);
+      const uint32_t a = lds[ia], t = bb::mont_mul(lds[ib], small_fwd[r_lo << (Bm - s)]);    // w_2N^(r_lo << (L-s)) = w_{2^(Bm+1)}^(r_lo << (Bm-s))
       lds[ia] = bb::add(a, t); lds[ib] = bb::sub(a, t);
     }
     __syncthreads();
@@ -204,6 +221,8 @@ struct zkir_stark_ctx {
   uint32_t* d_tw_fwd = nullptr;   // w_{2N}^k, k < N
   uint32_t* d_g_lo = nullptr;     // g^k / N, k < 1024
   uint32_t* d_g_hi = nullptr;     // g^(1024 k)
+  uint32_t* d_small_inv = nullptr;  // w_{2^Bm}^-k, k < 2^(Bm-1)      (Bm = min(log_n, 10))
+  uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
   p2::Consts consts;
 };
 
@@ -224,12 +243,18 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_fwd, (size_t)N * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_lo, 1024 * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_hi, (size_t)n_hi * 4);
+  const int Bm = log_n < 10 ? (int)log_n : 10;
+  const uint32_t n_si = Bm >= 1 ? (1u << (Bm - 1)) : 1, n_sf = 1u << Bm;
+  if (e == hipSuccess) e = hipMalloc(&c->d_small_inv, (size_t)n_si * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_small_fwd, (size_t)n_sf * 4);
   if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("zkir_stark_ctx_create: ") + hipGetErrorString(e)}); zkir_stark_ctx_free(c); return ZKIR_ERR_DEVICE; }
   const uint32_t wN = bb::root_of_unity(log_n), w2N = bb::root_of_unity(log_n + 1);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_inv)), dim3(NT), 0, 0, bb::inv(wN), bb::R1, c->d_tw_inv, n_inv);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(N)), dim3(NT), 0, 0, w2N, bb::R1, c->d_tw_fwd, N);
   hipLaunchKernelGGL(powers_kernel, dim3(4), dim3(NT), 0, 0, bb::GEN, bb::to_mont(bb::inv(N % bb::P)), c->d_g_lo, 1024u);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_hi)), dim3(NT), 0, 0, bb::pow(bb::GEN, 1024), bb::R1, c->d_g_hi, n_hi);
+  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_si)), dim3(NT), 0, 0, bb::inv(bb::root_of_unity(Bm)), bb::R1, c->d_small_inv, n_si);
+  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_sf)), dim3(NT), 0, 0, bb::root_of_unity(Bm + 1), bb::R1, c->d_small_fwd, n_sf);
   if (hipDeviceSynchronize() != hipSuccess || check_launch("stark ctx tables") != ZKIR_OK) { zkir_stark_ctx_free(c); return ZKIR_ERR_DEVICE; }
   *out = c;
   return ZKIR_OK;
@@ -238,6 +263,7 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
 void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
   (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi);
+  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd);
   delete c;
 }
 
@@ -257,16 +283,16 @@ int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint3
   for (int s0 = 0; s0 < L - Bm;) {
     const int B = (L - Bm - s0) < 5 ? (L - Bm - s0) : 5;
     int C = L - (s0 + B); if (C > 6) C = 6;                   // stride_mid = 2^(L-s0-B) >= 2^Bm
-    hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(N >> (B + C), width), dim3(NT), (4u << (B + C)), s, in, (uint64_t)N, L, s0, B, C, c->d_tw_inv);
+    hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(N >> (B + C), width), dim3(NT), (4u << (B + C)), s, in, (uint64_t)N, L, s0, B, C, c->d_tw_inv, c->d_small_inv, Bm);
     s0 += B;
   }
-  hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi);
+  hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, c->d_small_inv, c->d_small_fwd, c->d_g_lo, c->d_g_hi);
   // forward DIT strided stages Bm+1 .. L of the size-2N transform
   const int L2 = L + 1;
   for (int s0 = Bm + 1; s0 < L2;) {
     const int B = (L2 - s0) < 5 ? (L2 - s0) : 5;
     int C = s0 < 6 ? s0 : 6;
-    hipLaunchKernelGGL(ntt_strided_kernel<true>, dim3((2 * N) >> (B + C), width), dim3(NT), (4u << (B + C)), s, out, (uint64_t)2 * N, L2, s0, B, C, c->d_tw_fwd);
+    hipLaunchKernelGGL(ntt_strided_kernel<true>, dim3((2 * N) >> (B + C), width), dim3(NT), (4u << (B + C)), s, out, (uint64_t)2 * N, L2, s0, B, C, c->d_tw_fwd, c->d_small_fwd, Bm + 1);
     s0 += B;
   }
   return check_launch("lde");
