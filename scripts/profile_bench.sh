@@ -1,0 +1,12 @@
+#!/bin/bash
+# rocprofv3 evidence for `python bench.py` (run on the GPU box via gpurun). Usage: profile_bench.sh <round-tag>
+export TMPDIR=/tmp
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+python $R/bench.py > $OUT/bench.json 2>$OUT/bench.err
+python $R/bench.py --stage trace_fill --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_trace_fill.json 2>>$OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o b -- python $R/bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pf.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pw.log 2>&1
+python $R/scripts/extract_prof.py $OUT $OUT/summary trace_fill main_trace lde_middle ntt_strided leaf_hash compress | cut -c1-150
+head -c 1500 $OUT/bench.json; echo; tail -3 $OUT/bench.err
