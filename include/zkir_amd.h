@@ -255,6 +255,15 @@ int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uin
  * leaf digests first, root = last 4 words */
 int zkir_merkle_commit_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* hip_stream);
 
+/* Full proof (execution-trace AIR of DESIGN.md §8.4: cycle counter, R0 = 0, boolean flags, untouched registers keep their
+ * limbs/state), blow-up 2, 24 FRI queries, final codeword of 8.  `trace` = K1 output for n_rows = 2^log_n rows.  *proof_out is a
+ * malloc'ed array of u32 words (little-endian canonical field elements; layout in oracle/stark_oracle.cpp so::prove), released
+ * with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries. */
+int zkir_prove(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint64_t n_rows, uint32_t** proof_out, uint64_t* proof_words,
+               float* stage_ms, void* hip_stream);
+void zkir_proof_free(uint32_t* proof);
+uint32_t zkir_proof_num_queries(void);
+
 /* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
 typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */
 

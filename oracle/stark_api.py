@@ -26,6 +26,12 @@ def lib():
                            ("so_main_trace", [V, SZ, V]), ("so_merkle", [V, I, SZ, V, V]), ("so_commit_trace", [V, SZ, I, V, V])]:
             f = getattr(L, name); f.restype = None; f.argtypes = args
         L.so_main_trace_width.restype = I
+        L.so_prove.restype = SZ; L.so_prove.argtypes = [V, SZ, V, SZ]
+        L.so_verify.restype = I; L.so_verify.argtypes = [V, SZ]
+        L.so_last_challenges.restype = None; L.so_last_challenges.argtypes = [V, V, V]
+        L.so_last_quotient.restype = None; L.so_last_quotient.argtypes = [V]
+        L.so_last_fri_layer.restype = SZ; L.so_last_fri_layer.argtypes = [I, V]
+        L.so_num_queries.restype = I; L.so_log_final.restype = I
         _bound = True
     return L
 
@@ -107,3 +113,40 @@ def commit_trace(rows: np.ndarray, log_blowup=1, want_lde=False):
     L = np.zeros((W_MAIN, n << log_blowup), np.uint32) if want_lde else None
     lib().so_commit_trace(rows.ctypes.data, n, log_blowup, root.ctypes.data, L.ctypes.data if want_lde else None)
     return (root, L) if want_lde else root
+
+
+# ---- stage B: prover + verifier ------------------------------------------------------------------
+def prove(rows: np.ndarray) -> np.ndarray:
+    """Full ZKIR-STARK v0 proof (u32 words) for a power-of-two number of packed reference rows."""
+    rows = np.ascontiguousarray(rows)
+    n = len(rows)
+    assert n & (n - 1) == 0 and n >= 8
+    size = lib().so_prove(rows.ctypes.data, n, None, 0)
+    out = np.zeros(size, np.uint32)
+    lib().so_prove(rows.ctypes.data, n, out.ctypes.data, size)
+    return out
+
+
+def verify(proof: np.ndarray) -> int:
+    """0 = accepted; otherwise the code of the first failed check."""
+    proof = _u32(proof)
+    return lib().so_verify(proof.ctypes.data, len(proof))
+
+
+def last_challenges():
+    a, z, g = np.zeros(4, np.uint32), np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+    lib().so_last_challenges(a.ctypes.data, z.ctypes.data, g.ctypes.data)
+    return a, z, g
+
+
+def last_quotient(n: int) -> np.ndarray:
+    out = np.zeros((4, 2 * n), np.uint32)
+    lib().so_last_quotient(out.ctypes.data)
+    return out
+
+
+def last_fri_layer(j: int) -> np.ndarray:
+    m = lib().so_last_fri_layer(j, None)
+    out = np.zeros((m, 4), np.uint32)
+    lib().so_last_fri_layer(j, out.ctypes.data)
+    return out

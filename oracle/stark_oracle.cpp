@@ -208,6 +208,323 @@ static void merkle_build(const std::vector<F>& mat, int width, size_t n, Merkle&
   }
 }
 
+
+// =================================================================================================
+// Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v0)
+// =================================================================================================
+static const int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103;
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 1;   // "ZKPF"
+
+// ---- duplex challenger over Poseidon2-12 (rate 8): overwrite-absorb, squeeze from the end of the rate ----
+struct Challenger {
+  F st[T]; std::vector<F> in, out;
+  Challenger() { memset(st, 0, sizeof st); }
+  void duplex() { for (size_t i = 0; i < in.size(); i++) st[i] = in[i]; in.clear(); permute(st); out.assign(st, st + RATE); }
+  void observe(F x) { out.clear(); in.push_back(x); if ((int)in.size() == RATE) duplex(); }
+  void observe_n(const F* x, size_t n) { for (size_t i = 0; i < n; i++) observe(x[i]); }
+  void observe_ext(const E& e) { observe_n(e.c, 4); }
+  F sample() { if (!in.empty() || out.empty()) duplex(); F v = out.back(); out.pop_back(); return v; }
+  E sample_ext() { E e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
+  uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
+};
+
+// ---- the AIR: Σ_c alpha^c C_c over one (local, next) row pair; generic over base / extension values ----
+// columns: 0 cycle | 1-3 pc limbs | 4-8 instruction fields | 9+3r.. register limbs | 57+r state | 73+r changed
+// row values as E (base-field rows are lifted); returns Σ alpha^c C_c
+static E constraints_sum(const E* loc, const E* nxt, const E& is_first, const E& is_trans, const E* ap) {
+  E acc = e_from(0); int c = 0;
+  auto push = [&](const E& v) { acc = eadd(acc, emul(ap[c], v)); c++; };
+  const E one = e_from(1);
+  push(emul(esub(esub(nxt[0], loc[0]), one), is_trans));                 // c0: cycle' = cycle + 1
+  push(emul(loc[0], is_first));                                          // c1: cycle[0] = 0
+  for (int r = 0; r < 16; r++) {
+    const E st = loc[57 + r], ch = loc[73 + r];
+    push(emul(st, esub(st, one)));                                       // state boolean
+    push(emul(ch, esub(ch, one)));                                       // changed boolean
+    const E keep = esub(one, ch);
+    for (int l = 0; l < 3; l++) push(emul(emul(keep, esub(nxt[9 + 3 * r + l], loc[9 + 3 * r + l])), is_trans));   // untouched registers keep their limbs
+    push(emul(emul(keep, esub(nxt[57 + r], st)), is_trans));             // ... and their storage state
+  }
+  push(loc[9]); push(loc[10]); push(loc[11]); push(loc[57]); push(loc[73]);   // R0 is hard-wired zero, Normalized, never written
+  return acc;
+}
+
+struct Proof { std::vector<uint32_t> w; };
+static void put_e(std::vector<uint32_t>& w, const E& e) { for (int i = 0; i < 4; i++) w.push_back(e.c[i]); }
+
+struct Tree { Merkle m; };
+static void merkle_path(const Merkle& t, size_t leaf, std::vector<uint32_t>& w) {
+  size_t j = leaf;
+  for (size_t lv = 0; lv + 1 < t.layers.size(); lv++) { const F* sib = &t.layers[lv][4 * (j ^ 1)]; for (int i = 0; i < 4; i++) w.push_back(sib[i]); j >>= 1; }
+}
+static E fold_pair(const E& a, const E& b, F x, const E& beta) {          // (a+b)/2 + beta (a-b)/(2x)
+  const F half = finv(2), inv2x = finv(fmul(2, x));
+  return eadd(emul_f(eadd(a, b), half), emul(beta, emul_f(esub(a, b), inv2x)));
+}
+static E horner_base(const std::vector<F>& coeffs, const E& z) { E acc = e_from(0); for (size_t k = coeffs.size(); k-- > 0;) acc = eadd(emul(acc, z), e_from(coeffs[k])); return acc; }
+
+struct ProverTrace {     // everything the oracle keeps for inspection by tests
+  std::vector<F> M, L, Qc;            // [W][N], [W][2N], [4][2N]
+  Merkle trace_tree, quot_tree;
+  std::vector<std::vector<E>> fri;    // codewords per layer (layer 0 = DEEP codeword, size 2N)
+  std::vector<Merkle> fri_trees;
+  E alpha, zeta, gamma; std::vector<E> betas; std::vector<uint32_t> queries;
+};
+
+static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt) {
+  int log_n = 0; while (((size_t)1 << log_n) < n) log_n++;
+  const size_t N = n, N2 = 2 * n;
+  const int Wm = W_MAIN;
+  main_trace(rows, n, pt.M);
+  pt.L.assign((size_t)Wm * N2, 0);
+  std::vector<std::vector<F>> coeffs(Wm);
+  for (int k = 0; k < Wm; k++) {
+    std::vector<F> e(pt.M.begin() + (size_t)k * N, pt.M.begin() + (size_t)(k + 1) * N), o;
+    lde(e, 1, coeffs[k], o);
+    memcpy(&pt.L[(size_t)k * N2], o.data(), N2 * 4);
+  }
+  merkle_build(pt.L, Wm, N2, pt.trace_tree);
+  Challenger ch;
+  ch.observe(log_n); ch.observe(Wm); ch.observe(NUM_QUERIES); ch.observe(LOG_FINAL);
+  ch.observe_n(pt.trace_tree.layers.back().data(), 4);
+  pt.alpha = ch.sample_ext();
+  std::vector<E> ap(N_CONSTRAINTS); ap[0] = e_from(1); for (int c = 1; c < N_CONSTRAINTS; c++) ap[c] = emul(ap[c - 1], pt.alpha);
+
+  // ---- quotient on the LDE coset: x_j = g * w_2N^j, next row = position j + 2 ----
+  const F w2n = root_of_unity(log_n + 1), wn_inv = finv(root_of_unity(log_n));
+  const F gN = fpow(GEN, N);
+  pt.Qc.assign(4 * N2, 0);
+  {
+    F x = GEN;
+    std::vector<E> loc(Wm), nxt(Wm);
+    for (size_t j = 0; j < N2; j++) {
+      for (int k = 0; k < Wm; k++) { loc[k] = e_from(pt.L[(size_t)k * N2 + j]); nxt[k] = e_from(pt.L[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      const F zh = fsub((j & 1) ? fneg(gN) : gN, 1);                      // x^N - 1, x^N = g^N (-1)^j
+      const F inv_zh = finv(zh);
+      const E is_first = e_from(fmul(zh, finv(fsub(x, 1))));
+      const E is_trans = e_from(fsub(x, wn_inv));
+      E q = emul_f(constraints_sum(loc.data(), nxt.data(), is_first, is_trans, ap.data()), inv_zh);
+      for (int i = 0; i < 4; i++) pt.Qc[(size_t)i * N2 + j] = q.c[i];
+      x = fmul(x, w2n);
+    }
+  }
+  merkle_build(pt.Qc, 4, N2, pt.quot_tree);
+  ch.observe_n(pt.quot_tree.layers.back().data(), 4);
+  pt.zeta = ch.sample_ext();
+  const E zeta_w = emul_f(pt.zeta, root_of_unity(log_n));
+
+  // ---- openings (oracle: Horner on coefficient vectors) ----
+  std::vector<E> t_z(Wm), t_zw(Wm), q_z(4);
+  for (int k = 0; k < Wm; k++) { t_z[k] = horner_base(coeffs[k], pt.zeta); t_zw[k] = horner_base(coeffs[k], zeta_w); }
+  for (int i = 0; i < 4; i++) {                                           // quotient columns: interpolate from the coset evaluations
+    std::vector<F> ev(pt.Qc.begin() + (size_t)i * N2, pt.Qc.begin() + (size_t)(i + 1) * N2);
+    ntt(ev, true);                                                        // coefficients of q_i(g x)
+    F ginv = finv(GEN), sc = 1;
+    for (size_t k2 = 0; k2 < N2; k2++) { ev[k2] = fmul(ev[k2], sc); sc = fmul(sc, ginv); }
+    q_z[i] = horner_base(ev, pt.zeta);
+  }
+  for (int k = 0; k < Wm; k++) ch.observe_ext(t_z[k]);
+  for (int k = 0; k < Wm; k++) ch.observe_ext(t_zw[k]);
+  for (int i = 0; i < 4; i++) ch.observe_ext(q_z[i]);
+  pt.gamma = ch.sample_ext();
+
+  // ---- DEEP codeword over the LDE coset ----
+  std::vector<E> gp(2 * Wm + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], pt.gamma);
+  E a0 = e_from(0), b0 = e_from(0);
+  for (int k = 0; k < Wm; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wm + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wm + i], q_z[i]));
+  std::vector<E> cw(N2);
+  {
+    F x = GEN;
+    for (size_t j = 0; j < N2; j++) {
+      E A = e_from(0), B = e_from(0);
+      for (int k = 0; k < Wm; k++) { const F v = pt.L[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[k], v)); B = eadd(B, emul_f(gp[Wm + k], v)); }
+      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wm + i], pt.Qc[(size_t)i * N2 + j]));
+      const E d1 = einv(esub(e_from(x), pt.zeta)), d2 = einv(esub(e_from(x), zeta_w));
+      cw[j] = eadd(emul(esub(A, a0), d1), emul(esub(B, b0), d2));
+      x = fmul(x, w2n);
+    }
+  }
+
+  // ---- FRI commit phase ----
+  pt.fri.clear(); pt.fri_trees.clear(); pt.betas.clear();
+  pt.fri.push_back(cw);
+  F shift = GEN; int log_m = log_n + 1;
+  while (log_m > LOG_FINAL) {
+    const std::vector<E>& c = pt.fri.back();
+    const size_t m = c.size(), h = m / 2;
+    std::vector<F> mat(8 * h);                                            // leaf i = (c[i], c[i+h]) as 8 base elements, column-major [8][h]
+    for (size_t i = 0; i < h; i++) for (int t = 0; t < 4; t++) { mat[(size_t)t * h + i] = c[i].c[t]; mat[(size_t)(4 + t) * h + i] = c[i + h].c[t]; }
+    Merkle tr; merkle_build(mat, 8, h, tr);
+    ch.observe_n(tr.layers.back().data(), 4);
+    const E beta = ch.sample_ext();
+    pt.betas.push_back(beta);
+    std::vector<E> nx(h);
+    const F wm = root_of_unity(log_m);
+    F x = shift;
+    for (size_t i = 0; i < h; i++) { nx[i] = fold_pair(c[i], c[i + h], x, beta); x = fmul(x, wm); }
+    pt.fri_trees.push_back(std::move(tr));
+    pt.fri.push_back(std::move(nx));
+    shift = fmul(shift, shift); log_m--;
+  }
+  const std::vector<E>& fin = pt.fri.back();
+  for (const E& e : fin) ch.observe_ext(e);
+  pt.queries.clear();
+  for (int t = 0; t < NUM_QUERIES; t++) pt.queries.push_back(ch.sample_bits(log_n));
+
+  // ---- serialize ----
+  std::vector<uint32_t>& w = proof.w; w.clear();
+  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(Wm); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL);
+  for (int i = 0; i < 4; i++) w.push_back(pt.trace_tree.layers.back()[i]);
+  for (int i = 0; i < 4; i++) w.push_back(pt.quot_tree.layers.back()[i]);
+  for (int k = 0; k < Wm; k++) put_e(w, t_z[k]);
+  for (int k = 0; k < Wm; k++) put_e(w, t_zw[k]);
+  for (int i = 0; i < 4; i++) put_e(w, q_z[i]);
+  w.push_back((uint32_t)pt.fri_trees.size());
+  for (auto& tr : pt.fri_trees) for (int i = 0; i < 4; i++) w.push_back(tr.layers.back()[i]);
+  for (const E& e : fin) put_e(w, e);
+  for (uint32_t q : pt.queries) {
+    w.push_back(q);
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wm; k++) w.push_back(pt.L[(size_t)k * N2 + pos]); merkle_path(pt.trace_tree, pos, w); }
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int i = 0; i < 4; i++) w.push_back(pt.Qc[(size_t)i * N2 + pos]); merkle_path(pt.quot_tree, pos, w); }
+    for (size_t j = 0; j < pt.fri_trees.size(); j++) {
+      const size_t h = pt.fri[j].size() / 2, idx = q & (h - 1);
+      put_e(w, pt.fri[j][idx]); put_e(w, pt.fri[j][idx + h]);
+      merkle_path(pt.fri_trees[j], idx, w);
+    }
+  }
+}
+
+// ---- verifier (N4): returns 0 if the proof is accepted, otherwise a non-zero code naming the failed check ----
+static bool check_path(const F* leaf_digest, size_t idx, const uint32_t* path, int depth, const F* root) {
+  F node[4]; memcpy(node, leaf_digest, 16);
+  for (int d = 0; d < depth; d++) { F nx[4]; if (idx & 1) compress(path + 4 * d, node, nx); else compress(node, path + 4 * d, nx); memcpy(node, nx, 16); idx >>= 1; }
+  return !memcmp(node, root, 16);
+}
+static int verify(const uint32_t* w, size_t len) {
+  size_t p = 0;
+  auto need = [&](size_t k) { return p + k <= len; };
+  if (!need(6) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
+  const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5]; p = 6;
+  if (Wm != W_MAIN || nq != NUM_QUERIES || log_final != LOG_FINAL || log_n < LOG_FINAL || log_n > 26) return 2;
+  const size_t N = (size_t)1 << log_n;
+  for (size_t i = 6; i < len; i++) if (w[i] >= P) return 3;   // every payload word must be canonical (query indices are < N < p)
+  if (!need(8)) return 4;
+  const F* troot = w + p; p += 4; const F* qroot = w + p; p += 4;
+  auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
+  if (!need((size_t)(2 * Wm + 4) * 4)) return 4;
+  std::vector<E> t_z(Wm), t_zw(Wm), q_z(4);
+  for (int k = 0; k < Wm; k++) { t_z[k] = get_e(p); p += 4; }
+  for (int k = 0; k < Wm; k++) { t_zw[k] = get_e(p); p += 4; }
+  for (int i = 0; i < 4; i++) { q_z[i] = get_e(p); p += 4; }
+  if (!need(1)) return 4;
+  const int n_layers = w[p++];
+  if (n_layers != log_n + 1 - LOG_FINAL) return 5;
+  if (!need((size_t)4 * n_layers + 4 * ((size_t)1 << LOG_FINAL))) return 4;
+  std::vector<const F*> lroots(n_layers);
+  for (int j = 0; j < n_layers; j++) { lroots[j] = w + p; p += 4; }
+  std::vector<E> fin((size_t)1 << LOG_FINAL);
+  for (auto& e : fin) { e = get_e(p); p += 4; }
+  // transcript
+  Challenger ch;
+  ch.observe(log_n); ch.observe(Wm); ch.observe(NUM_QUERIES); ch.observe(LOG_FINAL);
+  ch.observe_n(troot, 4);
+  const E alpha = ch.sample_ext();
+  ch.observe_n(qroot, 4);
+  const E zeta = ch.sample_ext();
+  for (int k = 0; k < Wm; k++) ch.observe_ext(t_z[k]);
+  for (int k = 0; k < Wm; k++) ch.observe_ext(t_zw[k]);
+  for (int i = 0; i < 4; i++) ch.observe_ext(q_z[i]);
+  const E gamma = ch.sample_ext();
+  std::vector<E> betas(n_layers);
+  for (int j = 0; j < n_layers; j++) { ch.observe_n(lroots[j], 4); betas[j] = ch.sample_ext(); }
+  for (const E& e : fin) ch.observe_ext(e);
+  // 1. constraints at zeta:  Σ alpha^c C_c(zeta) == Q(zeta) * Z_H(zeta)
+  {
+    std::vector<E> ap(N_CONSTRAINTS); ap[0] = e_from(1); for (int c = 1; c < N_CONSTRAINTS; c++) ap[c] = emul(ap[c - 1], alpha);
+    const E zN = epow(zeta, N), zh = esub(zN, e_from(1));
+    const E is_first = emul(zh, einv(esub(zeta, e_from(1))));
+    const E is_trans = esub(zeta, e_from(finv(root_of_unity(log_n))));
+    const E lhs = constraints_sum(t_z.data(), t_zw.data(), is_first, is_trans, ap.data());
+    E qz = e_from(0);
+    for (int i = 0; i < 4; i++) { E basis = e_from(0); basis.c[i] = 1; qz = eadd(qz, emul(basis, q_z[i])); }
+    if (!eeq(lhs, emul(qz, zh))) return 10;
+  }
+  // 2. final codeword is low degree: interpolate over shift_f * <w_8>, top half of the coefficients must vanish
+  {
+    F shift = GEN; for (int j = 0; j < n_layers; j++) shift = fmul(shift, shift);
+    const size_t m = fin.size();
+    for (int t = 0; t < 4; t++) {
+      std::vector<F> ev(m); for (size_t i = 0; i < m; i++) ev[i] = fin[i].c[t];
+      ntt(ev, true);                                                       // coefficients of f(shift * x): scaling by shift^-k keeps zeros zero
+      for (size_t k2 = m / 2; k2 < m; k2++) if (ev[k2] != 0) return 11;
+    }
+  }
+  // 3. queries
+  std::vector<E> gp(2 * Wm + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], gamma);
+  E a0 = e_from(0), b0 = e_from(0);
+  for (int k = 0; k < Wm; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wm + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wm + i], q_z[i]));
+  const E zeta_w = emul_f(zeta, root_of_unity(log_n));
+  const F w2n = root_of_unity(log_n + 1);
+  const int depth0 = log_n + 1;
+  for (int t = 0; t < nq; t++) {
+    const uint32_t q = ch.sample_bits(log_n);
+    if (!need(1) || w[p++] != q) return 20;
+    E deep[2];
+    const uint32_t* tl[2]; const uint32_t* ql[2];
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      if (!need((size_t)Wm + 4 * depth0)) return 4;
+      tl[s2] = w + p; p += Wm;
+      F dg[4]; hash_elems(tl[s2], Wm, dg);
+      if (!check_path(dg, pos, w + p, depth0, troot)) return 21;
+      p += 4 * depth0;
+    }
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      if (!need((size_t)4 + 4 * depth0)) return 4;
+      ql[s2] = w + p; p += 4;
+      F dg[4]; hash_elems(ql[s2], 4, dg);
+      if (!check_path(dg, pos, w + p, depth0, qroot)) return 22;
+      p += 4 * depth0;
+    }
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      const F x = fmul(GEN, fpow(w2n, pos));
+      E A = e_from(0), B = e_from(0);
+      for (int k = 0; k < Wm; k++) { A = eadd(A, emul_f(gp[k], tl[s2][k])); B = eadd(B, emul_f(gp[Wm + k], tl[s2][k])); }
+      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wm + i], ql[s2][i]));
+      deep[s2] = eadd(emul(esub(A, a0), einv(esub(e_from(x), zeta))), emul(esub(B, b0), einv(esub(e_from(x), zeta_w))));
+    }
+    // FRI layers
+    E expect_lo = deep[0], expect_hi = deep[1];
+    bool have_pair = true;                                                 // layer 0: both elements of the leaf are known from the trace/quotient openings
+    E carried = e_from(0); size_t carried_idx = 0;
+    F shift = GEN; int log_m = log_n + 1;
+    size_t idx_full = q;                                                   // position of the carried value in the current layer
+    for (int j = 0; j < n_layers; j++) {
+      const size_t h = (size_t)1 << (log_m - 1), idx = idx_full & (h - 1);
+      const int depth = log_m - 1;
+      if (!need((size_t)8 + 4 * depth)) return 4;
+      const E lo = get_e(p), hi = get_e(p + 4);
+      F dg[4]; hash_elems(w + p, 8, dg);
+      p += 8;
+      if (!check_path(dg, idx, w + p, depth, lroots[j])) return 23;
+      p += 4 * depth;
+      if (have_pair) { if (!eeq(lo, expect_lo) || !eeq(hi, expect_hi)) return 24; have_pair = false; }
+      else { const E& mine = (carried_idx < h) ? lo : hi; if (!eeq(mine, carried)) return 25; }
+      const F x = fmul(shift, fpow(root_of_unity(log_m), idx));
+      carried = fold_pair(lo, hi, x, betas[j]);
+      carried_idx = idx;                                                   // position in the next layer (size h)
+      idx_full = idx;
+      shift = fmul(shift, shift); log_m--;
+    }
+    if (!eeq(fin[carried_idx & (fin.size() - 1)], carried)) return 26;
+  }
+  if (p != len) return 30;
+  return 0;
+}
 }  // namespace so
 
 // =================================================================================================
@@ -260,4 +577,18 @@ void so_commit_trace(const void* packed_rows, size_t n, int log_blowup, uint32_t
   memcpy(root4, t.layers.back().data(), 16);
   if (lde_out) memcpy(lde_out, L.data(), L.size() * 4);
 }
+
+// ---- stage B C API ----
+static so::ProverTrace g_pt;   // last prover run (tests inspect intermediate objects)
+size_t so_prove(const void* packed_rows, size_t n, uint32_t* out, size_t cap) {
+  so::Proof pr; so::prove((const so::PackedRow*)packed_rows, n, pr, g_pt);
+  if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
+  return pr.w.size();
+}
+int so_verify(const uint32_t* proof, size_t len) { return so::verify(proof, len); }
+void so_last_challenges(uint32_t* alpha, uint32_t* zeta, uint32_t* gamma) { memcpy(alpha, g_pt.alpha.c, 16); memcpy(zeta, g_pt.zeta.c, 16); memcpy(gamma, g_pt.gamma.c, 16); }
+void so_last_quotient(uint32_t* out /* [4][2N] */) { memcpy(out, g_pt.Qc.data(), g_pt.Qc.size() * 4); }
+size_t so_last_fri_layer(int j, uint32_t* out /* [m][4] */) { if (j < 0 || (size_t)j >= g_pt.fri.size()) return 0; if (out) memcpy(out, g_pt.fri[j].data(), g_pt.fri[j].size() * 16); return g_pt.fri[j].size(); }
+int so_num_queries() { return so::NUM_QUERIES; }
+int so_log_final() { return so::LOG_FINAL; }
 }  // extern "C"

@@ -103,3 +103,46 @@ def test_commit_2p16_root_and_properties():
         off += 4 * mm; mm //= 2; j //= 2
     assert np.array_equal(node, root)
     ctx.close()
+
+
+@pytest.mark.parametrize("name,log_n", [("fib", 3), ("fib", 5), ("fib", 8), ("fib", 11), ("sha", 9), ("deferred", 10), ("fib", 13)])
+def test_proof_bytes_match_oracle_and_verify(name, log_n):
+    """End-to-end proof (quotient, openings, DEEP, FRI, queries): GPU proof words == oracle proof words, and the oracle's
+    verifier accepts them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on coefficients."""
+    from zkir_amd import stark
+    n = 1 << log_n
+    cfg = {}
+    if name == "fib":
+        blob = spec.fib_endless_program().to_bytes()
+    elif name == "sha":
+        blob = spec.sha256_chain_program().to_bytes()
+    else:
+        blob, cfg = spec.fib_endless_program().to_bytes(), {"enable_deferred_model": True}
+    log, tr = _device_trace(blob, n, **cfg)
+    ctx = stark.StarkContext(log_n)
+    proof, ms = stark.prove(ctx, tr, want_stage_ms=True)
+    assert so.verify(proof) == 0
+    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg).rows
+    want = so.prove(rows)
+    assert len(proof) == len(want)
+    if not np.array_equal(proof, want):
+        bad = np.nonzero(proof != want)[0]
+        raise AssertionError(f"proof differs at word {bad[0]} of {len(want)} ({len(bad)} words differ)")
+    # tampering is rejected
+    for pos in (8, 30, len(proof) // 2, len(proof) - 1):
+        t = proof.copy()
+        t[pos] = (int(t[pos]) + 1) % P
+        assert so.verify(t) != 0
+    ctx.close()
+
+
+def test_proof_2p16_verifies():
+    """Larger than the oracle prover comfortably handles: the oracle VERIFIER (cheap) accepts the GPU proof."""
+    from zkir_amd import stark
+    log_n = 16
+    log, tr = _device_trace(spec.fib_endless_program().to_bytes(), 1 << log_n)
+    ctx = stark.StarkContext(log_n)
+    proof = stark.prove(ctx, tr)
+    assert so.verify(proof) == 0
+    assert proof[2] == log_n and proof[3] == 89
+    ctx.close()

@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "build")
 
 HOST_SOURCES = ["interp.cpp", "hashes.cpp"]
 HIP_SOURCES = ["trace_fill.hip", "witness.hip", "stark.hip", "abi.hip"]
-HEADERS = ["host.h", "babybear.h", "poseidon2.h", os.path.join("..", "..", "include", "zkir_amd.h")]
+HEADERS = ["host.h", "babybear.h", "poseidon2.h", "stark_prove.inl", os.path.join("..", "..", "include", "zkir_amd.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

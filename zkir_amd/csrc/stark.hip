@@ -16,6 +16,8 @@
 //                       no MFMA: 31-bit modular integer work, no dense contraction.
 #include <hip/hip_runtime.h>
 
+#include <array>
+#include <cstddef>
 #include <vector>
 
 #include "../../include/zkir_amd.h"
@@ -314,3 +316,5 @@ int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
 }
 
 }  // extern "C"
+
+#include "stark_prove.inl"

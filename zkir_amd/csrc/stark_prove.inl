@@ -1,0 +1,401 @@
+// stark_prove.inl — stage B of the self-defined prover (included by stark.hip): AIR quotient on the LDE coset, barycentric
+// openings, DEEP combination, FRI commit/fold, query gathering, proof serialisation; host-side Fiat-Shamir transcript.
+// Spec: oracle/stark_oracle.cpp (so::prove / so::verify).  Parity unpinned vs the reference (it has no prover).
+//
+// Every kernel is one thread per evaluation point, column reads coalesced across lanes.  The quotient / DEEP kernels stream the
+// LDE matrix once each (HBM-bound: 4*W B read per point, 16 B written); FRI folds are geometric and negligible after layer 0.
+
+namespace {
+
+using bb::E4;
+
+struct ProveParams {            // constants of one proof, Montgomery form, uploaded once per phase
+  E4 alpha_pow[103];
+  E4 gamma_pow[2 * 89 + 4];
+  E4 zeta, zeta_w, a0, b0;
+};
+__constant__ ProveParams d_pp;
+
+constexpr int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103, WM = 89;
+
+__device__ __forceinline__ E4 e_from_base_m(uint32_t xm) { return E4{{xm, 0, 0, 0}}; }
+__device__ __forceinline__ E4 e_fma_base(const E4& acc, const E4& coef, uint32_t vm) {          // acc + coef * v   (all Montgomery)
+  return E4{{bb::add(acc.c[0], bb::mont_mul(coef.c[0], vm)), bb::add(acc.c[1], bb::mont_mul(coef.c[1], vm)), bb::add(acc.c[2], bb::mont_mul(coef.c[2], vm)),
+             bb::add(acc.c[3], bb::mont_mul(coef.c[3], vm))}};
+}
+
+// ---- quotient: Q(x_j) = (Σ_c alpha^c C_c(x_j)) / Z_H(x_j) on x_j = g w_2N^j;  next row = position j+2 -------------------
+__global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, uint32_t gN_m,
+                                                       uint32_t wn_inv_m, uint32_t* __restrict__ Q) {
+  const uint32_t N2 = 2u << log_n;
+  const uint32_t j = blockIdx.x * NT + threadIdx.x;
+  if (j >= N2) return;
+  const uint32_t jn = (j + 2) & (N2 - 1);
+  auto ld = [&](int k, uint32_t pos) { return bb::to_mont(L[(uint64_t)k * N2 + pos]); };
+  // x = g * w_2N^j (Montgomery): w^j = tw[j] for j < N, -tw[j-N] otherwise
+  const uint32_t N = N2 >> 1;
+  const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
+  const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
+  const uint32_t one = bb::R1;
+  const uint32_t zh = bb::sub((j & 1) ? bb::neg(gN_m) : gN_m, one);                                 // x^N - 1
+  // base-field inverses by exponentiation (two per point; negligible next to the 2*W loads)
+  auto inv_m = [](uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; };
+  const uint32_t inv_zh = inv_m(zh);
+  const uint32_t is_first = bb::mont_mul(zh, inv_m(bb::sub(x, one)));
+  const uint32_t is_trans = bb::sub(x, wn_inv_m);
+  E4 acc = bb::e_zero();
+  int c = 0;
+  const uint32_t cyc = ld(0, j);
+  acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(bb::sub(bb::sub(ld(0, jn), cyc), one), is_trans));
+  acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(cyc, is_first));
+#pragma unroll 1
+  for (int r = 0; r < 16; r++) {
+    const uint32_t st = ld(57 + r, j), ch = ld(73 + r, j);
+    acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(st, bb::sub(st, one)));
+    acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(ch, bb::sub(ch, one)));
+    const uint32_t keep_t = bb::mont_mul(bb::sub(one, ch), is_trans);
+#pragma unroll
+    for (int l = 0; l < 3; l++) acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(9 + 3 * r + l, jn), ld(9 + 3 * r + l, j))));
+    acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(57 + r, jn), st)));
+  }
+  acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(9, j)); acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(10, j)); acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(11, j));
+  acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(57, j)); acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(73, j));
+  const E4 q = bb::e_from_mont(bb::e_mul_fm(acc, inv_zh));
+#pragma unroll
+  for (int i = 0; i < 4; i++) Q[(uint64_t)i * N2 + j] = q.c[i];
+}
+
+// ---- barycentric weights over the LDE coset: e_j = x_j / (zeta - x_j)  (Montgomery E4, AoS) -------------------------------
+__global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const uint32_t* __restrict__ tw_fwd, E4* __restrict__ wts) {
+  const uint32_t N2 = 2u << log_n, N = N2 >> 1;
+  const uint32_t j = blockIdx.x * NT + threadIdx.x;
+  if (j >= N2) return;
+  const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
+  const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
+  E4 d = d_pp.zeta; d.c[0] = bb::sub(d.c[0], x);
+  wts[j] = bb::e_mul_fm(bb::e_inv_m(d), x);
+}
+
+// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}      (grid: chunks x columns)
+__global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, const E4* __restrict__ wts, E4* __restrict__ partial, uint32_t n_chunks) {
+  __shared__ E4 red[2][NT / 64];
+  const uint32_t col = blockIdx.y, chunk = blockIdx.x;
+  const uint64_t per = N2 / n_chunks, lo = (uint64_t)chunk * per;
+  const uint32_t* v = mat + (uint64_t)col * N2;
+  E4 s0 = bb::e_zero(), s1 = bb::e_zero();
+  for (uint64_t j = lo + threadIdx.x; j < lo + per; j += NT) {
+    const uint32_t vm = bb::to_mont(v[j]);
+    s0 = e_fma_base(s0, wts[j], vm);
+    s1 = e_fma_base(s1, wts[(j + N2 - 2) & (N2 - 1)], vm);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      s0.c[t] = bb::add(s0.c[t], __shfl_down(s0.c[t], off, 64));
+      s1.c[t] = bb::add(s1.c[t], __shfl_down(s1.c[t], off, 64));
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = s0; red[1][wv] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    E4 a = red[0][0], b = red[1][0];
+    for (int k = 1; k < NT / 64; k++) { a = bb::e_add(a, red[0][k]); b = bb::e_add(b, red[1][k]); }
+    partial[((uint64_t)col * n_chunks + chunk) * 2] = a;
+    partial[((uint64_t)col * n_chunks + chunk) * 2 + 1] = b;
+  }
+}
+
+// ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
+__global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ Q, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
+                                                   uint32_t* __restrict__ cw) {
+  const uint32_t N2 = 2u << log_n, N = N2 >> 1;
+  const uint32_t j = blockIdx.x * NT + threadIdx.x;
+  if (j >= N2) return;
+  E4 A = bb::e_zero(), B = bb::e_zero();
+#pragma unroll 4
+  for (int k = 0; k < WM; k++) {
+    const uint32_t vm = bb::to_mont(L[(uint64_t)k * N2 + j]);
+    A = e_fma_base(A, d_pp.gamma_pow[k], vm);
+    B = e_fma_base(B, d_pp.gamma_pow[WM + k], vm);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) A = e_fma_base(A, d_pp.gamma_pow[2 * WM + i], bb::to_mont(Q[(uint64_t)i * N2 + j]));
+  const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
+  const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
+  E4 d1 = d_pp.zeta, d2 = d_pp.zeta_w;                                        // x - zeta = -(zeta - x)
+  d1.c[0] = bb::sub(d1.c[0], x); d2.c[0] = bb::sub(d2.c[0], x);
+  const E4 t1 = bb::e_mul_m(bb::e_sub(d_pp.a0, A), bb::e_inv_m(d1));          // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
+  const E4 t2 = bb::e_mul_m(bb::e_sub(d_pp.b0, B), bb::e_inv_m(d2));
+  const E4 f = bb::e_from_mont(bb::e_add(t1, t2));
+#pragma unroll
+  for (int i = 0; i < 4; i++) cw[(uint64_t)i * N2 + j] = f.c[i];
+}
+
+// ---- FRI: leaf i of a layer of size m = (c[i], c[i+m/2]) = 8 base elements = one permutation -------------------------------
+__global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const uint32_t* __restrict__ c, uint64_t m, uint32_t* __restrict__ digests) {
+  const uint64_t h = m >> 1, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= h) return;
+  uint32_t s[p2::T];
+#pragma unroll
+  for (int t = 0; t < 4; t++) { s[t] = bb::to_mont(c[(uint64_t)t * m + i]); s[4 + t] = bb::to_mont(c[(uint64_t)t * m + h + i]); s[8 + t] = 0; }
+  p2::permute(s, d_p2);
+  reinterpret_cast<uint4*>(digests)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+}
+
+// c'[i] = (c[i] + c[i+h])/2 + beta (c[i] - c[i+h]) / (2 x_i),  x_i = shift * w_m^i
+__global__ __launch_bounds__(NT) void fri_fold_kernel(const uint32_t* __restrict__ c, uint32_t log_m, uint32_t log_2n, const uint32_t* __restrict__ tw_fwd, E4 beta_m,
+                                                       uint32_t half_shift_inv_m, uint32_t* __restrict__ out) {
+  const uint64_t m = 1ull << log_m, h = m >> 1, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= h) return;
+  E4 a, b;
+#pragma unroll
+  for (int t = 0; t < 4; t++) { a.c[t] = c[(uint64_t)t * m + i]; b.c[t] = c[(uint64_t)t * m + h + i]; }
+  // w_m^-i = w_2N^-(i << (log_2n - log_m)) ; w^-k = -w^(N-k) for 0 < k < N (w^N = -1), table holds w^k for k < N = 2^(log_2n-1)
+  const uint32_t N = 1u << (log_2n - 1);
+  const uint32_t k = (uint32_t)(i << (log_2n - log_m));
+  const uint32_t winv = k == 0 ? bb::R1 : bb::neg(tw_fwd[N - k]);
+  const uint32_t inv2x = bb::mont_mul(winv, half_shift_inv_m);                 // 1/(2 x_i), Montgomery
+  constexpr uint32_t HALF_M = (uint32_t)(((uint64_t)((bb::P + 1) / 2) * bb::R1) % bb::P);
+  const E4 sum = bb::e_mul_fm(bb::e_add(a, b), HALF_M);                        // canonical * mont = canonical
+  const E4 dif = bb::e_mul_fm(bb::e_sub(a, b), inv2x);                         // canonical
+  const E4 prod = bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(dif), beta_m));    // mont(dif) * mont(beta) = mont(dif * beta) -> canonical
+  const E4 res = bb::e_add(sum, prod);
+#pragma unroll
+  for (int t = 0; t < 4; t++) out[(uint64_t)t * h + i] = res.c[t];
+}
+
+// ---- query gathering: job = copy `count` words src[k * stride] -> dst[k] ------------------------------------------------------
+struct GatherJob { const uint32_t* src; uint64_t stride; uint32_t count; uint32_t dst; };
+__global__ void gather_kernel(const GatherJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ dst) {
+  const uint32_t jb = blockIdx.x;
+  if (jb >= n_jobs) return;
+  const GatherJob g = jobs[jb];
+  for (uint32_t k = threadIdx.x; k < g.count; k += blockDim.x) dst[g.dst + k] = g.src[(uint64_t)k * g.stride];
+}
+
+// ---- host-side duplex challenger (Montgomery state; canonical in/out) -------------------------------------------------------
+struct Challenger {
+  const p2::Consts& c;
+  uint32_t st[p2::T];
+  std::vector<uint32_t> in, out;
+  explicit Challenger(const p2::Consts& cc) : c(cc) { for (auto& v : st) v = 0; }
+  void duplex() { for (size_t i = 0; i < in.size(); i++) st[i] = bb::to_mont(in[i]); in.clear(); p2::permute(st, c); out.clear(); for (int i = 0; i < p2::RATE; i++) out.push_back(bb::from_mont(st[i])); }
+  void observe(uint32_t x) { out.clear(); in.push_back(x); if ((int)in.size() == p2::RATE) duplex(); }
+  void observe_n(const uint32_t* x, size_t n) { for (size_t i = 0; i < n; i++) observe(x[i]); }
+  uint32_t sample() { if (!in.empty() || out.empty()) duplex(); const uint32_t v = out.back(); out.pop_back(); return v; }
+  E4 sample_ext() { E4 e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
+  uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
+};
+
+E4 h_e_mul(const E4& a, const E4& b) { return bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(a), bb::e_to_mont(b))); }   // canonical in/out
+E4 h_e_pow(E4 a, uint64_t e) { E4 r{{1, 0, 0, 0}}; while (e) { if (e & 1) r = h_e_mul(r, a); a = h_e_mul(a, a); e >>= 1; } return r; }
+
+#define HIP_OK(expr)                                                                                         \
+  do { hipError_t _e = (expr); if (_e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)}); return ZKIR_ERR_DEVICE; } } while (0)
+
+struct DevBuf {                 // RAII device allocation
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+extern "C" {
+
+uint32_t zkir_proof_num_queries(void) { return NUM_QUERIES; }
+
+void zkir_proof_free(uint32_t* proof) { free(proof); }
+
+// Full proof for the trace whose main-trace LDE is produced from `trace` (n_rows = 2^ctx.log_n).  Phases are timed with HIP events
+// when stage_ms != NULL: [0] main trace, [1] LDE, [2] trace Merkle, [3] quotient (+Merkle), [4] openings, [5] DEEP, [6] FRI, [7] queries.
+int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_t n_rows, uint32_t** proof_out, uint64_t* proof_words, float* stage_ms, void* stream) {
+  if (!c || !trace || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  const uint32_t log_n = c->log_n;
+  const uint64_t N = 1ull << log_n, N2 = 2 * N;
+  if (n_rows != N || log_n < (uint32_t)LOG_FINAL) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: n_rows must equal 2^log_n of the context (>= 8)"}); return ZKIR_ERR_ARGUMENT; }
+  hipStream_t s = (hipStream_t)stream;
+  *proof_out = nullptr; *proof_words = 0;
+  const int depth0 = (int)log_n + 1;
+  const int n_layers = (int)log_n + 1 - LOG_FINAL;
+
+  DevBuf dM, dL, dTree, dQ, dQTree, dW, dPart, dCw[2], dJobs, dOut;
+  std::vector<DevBuf> fri_trees(n_layers), fri_layers(n_layers + 1);
+  HIP_OK(dM.alloc(WM * N * 4)); HIP_OK(dL.alloc(WM * N2 * 4)); HIP_OK(dTree.alloc(4 * (2 * N2 - 1) * 4));
+  HIP_OK(dQ.alloc(4 * N2 * 4)); HIP_OK(dQTree.alloc(4 * (2 * N2 - 1) * 4)); HIP_OK(dW.alloc(N2 * sizeof(E4)));
+  const uint32_t n_chunks = N2 >= 16 * NT ? 16 : 1;
+  HIP_OK(dPart.alloc((size_t)(WM + 4) * n_chunks * 2 * sizeof(E4)));
+
+  hipEvent_t ev[9];
+  if (stage_ms) for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+  auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(ev[i], s); };
+
+  // ---- 1. main trace, LDE, trace commitment ---------------------------------------------------------------------------------
+  mark(0);
+  int rc = zkir_main_trace_launch(trace, N, dM.as<uint32_t>(), s); if (rc) return rc;
+  mark(1);
+  rc = zkir_lde_launch(c, dM.as<uint32_t>(), WM, dL.as<uint32_t>(), s); if (rc) return rc;
+  mark(2);
+  rc = zkir_merkle_commit_launch(c, dL.as<uint32_t>(), WM, N2, dTree.as<uint32_t>(), s); if (rc) return rc;
+  uint32_t troot[4], qroot[4];
+  HIP_OK(hipMemcpyAsync(troot, dTree.as<uint32_t>() + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  mark(3);
+  Challenger ch(c->consts);
+  ch.observe(log_n); ch.observe(WM); ch.observe(NUM_QUERIES); ch.observe(LOG_FINAL);
+  ch.observe_n(troot, 4);
+  const E4 alpha = ch.sample_ext();
+
+  // ---- 2. quotient ------------------------------------------------------------------------------------------------------------
+  static ProveParams pp;                          // host staging (proofs are serialised per process; the ABI is single-proof-at-a-time per ctx)
+  {
+    E4 a{{1, 0, 0, 0}};
+    for (int k = 0; k < N_CONSTRAINTS; k++) { pp.alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
+    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp, sizeof(pp.alpha_pow), offsetof(ProveParams, alpha_pow), hipMemcpyHostToDevice, s));
+  }
+  const uint32_t gN_m = bb::to_mont(bb::pow(bb::GEN, N)), wn_inv_m = bb::to_mont(bb::inv(bb::root_of_unity((int)log_n)));
+  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), log_n, c->d_tw_fwd, gN_m, wn_inv_m, dQ.as<uint32_t>());
+  rc = zkir_merkle_commit_launch(c, dQ.as<uint32_t>(), 4, N2, dQTree.as<uint32_t>(), s); if (rc) return rc;
+  HIP_OK(hipMemcpyAsync(qroot, dQTree.as<uint32_t>() + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  mark(4);
+  ch.observe_n(qroot, 4);
+  const E4 zeta = ch.sample_ext();
+  const E4 zeta_w = bb::E4{{bb::mul(zeta.c[0], bb::root_of_unity((int)log_n)), bb::mul(zeta.c[1], bb::root_of_unity((int)log_n)),
+                            bb::mul(zeta.c[2], bb::root_of_unity((int)log_n)), bb::mul(zeta.c[3], bb::root_of_unity((int)log_n))}};
+
+  // ---- 3. openings by barycentric evaluation over the LDE coset ------------------------------------------------------------
+  pp.zeta = bb::e_to_mont(zeta); pp.zeta_w = bb::e_to_mont(zeta_w);
+  HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.zeta, 2 * sizeof(E4), offsetof(ProveParams, zeta), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dW.as<E4>());
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, WM), dim3(NT), 0, s, dL.as<uint32_t>(), N2, dW.as<E4>(), dPart.as<E4>(), n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 4), dim3(NT), 0, s, dQ.as<uint32_t>(), N2, dW.as<E4>(), dPart.as<E4>() + (size_t)WM * n_chunks * 2, n_chunks);
+  std::vector<E4> part((size_t)(WM + 4) * n_chunks * 2);
+  HIP_OK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  std::vector<E4> t_z(WM), t_zw(WM), q_z(4);
+  {
+    // scale = ((z/g)^2N - 1) / (2N);  for z = zeta*w the factor is the same because w^(2N) = 1
+    const E4 zg = bb::E4{{bb::mul(zeta.c[0], bb::inv(bb::GEN)), bb::mul(zeta.c[1], bb::inv(bb::GEN)), bb::mul(zeta.c[2], bb::inv(bb::GEN)), bb::mul(zeta.c[3], bb::inv(bb::GEN))}};
+    E4 sc = h_e_pow(zg, N2); sc.c[0] = bb::sub(sc.c[0], 1);
+    const uint32_t inv2n = bb::inv((uint32_t)(N2 % bb::P));
+    for (int t = 0; t < 4; t++) sc.c[t] = bb::mul(sc.c[t], inv2n);
+    const E4 sc_m = bb::e_to_mont(sc);
+    for (int k = 0; k < WM + 4; k++) {
+      E4 a = bb::e_zero(), b = bb::e_zero();
+      for (uint32_t q = 0; q < n_chunks; q++) { a = bb::e_add(a, part[((size_t)k * n_chunks + q) * 2]); b = bb::e_add(b, part[((size_t)k * n_chunks + q) * 2 + 1]); }
+      const E4 va = bb::e_from_mont(bb::e_mul_m(a, sc_m)), vb = bb::e_from_mont(bb::e_mul_m(b, sc_m));      // partial sums are Montgomery E4
+      if (k < WM) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WM] = va;
+    }
+  }
+  mark(5);
+  for (int k = 0; k < WM; k++) ch.observe_n(t_z[k].c, 4);
+  for (int k = 0; k < WM; k++) ch.observe_n(t_zw[k].c, 4);
+  for (int i = 0; i < 4; i++) ch.observe_n(q_z[i].c, 4);
+  const E4 gamma = ch.sample_ext();
+
+  // ---- 4. DEEP codeword ------------------------------------------------------------------------------------------------------
+  {
+    E4 g{{1, 0, 0, 0}}, a0 = bb::e_zero(), b0 = bb::e_zero();
+    for (int k = 0; k < 2 * WM + 4; k++) {
+      pp.gamma_pow[k] = bb::e_to_mont(g);
+      if (k < WM) a0 = bb::e_add(a0, h_e_mul(g, t_z[k]));
+      else if (k < 2 * WM) b0 = bb::e_add(b0, h_e_mul(g, t_zw[k - WM]));
+      else a0 = bb::e_add(a0, h_e_mul(g, q_z[k - 2 * WM]));
+      g = h_e_mul(g, gamma);
+    }
+    pp.a0 = bb::e_to_mont(a0); pp.b0 = bb::e_to_mont(b0);
+    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.gamma_pow, sizeof(pp.gamma_pow), offsetof(ProveParams, gamma_pow), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.a0, 2 * sizeof(E4), offsetof(ProveParams, a0), hipMemcpyHostToDevice, s));
+  }
+  HIP_OK(fri_layers[0].alloc(4 * N2 * 4));
+  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), dQ.as<uint32_t>(), log_n, c->d_tw_fwd, fri_layers[0].as<uint32_t>());
+  mark(6);
+
+  // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
+  std::vector<std::array<uint32_t, 4>> lroots(n_layers);
+  std::vector<E4> betas(n_layers);
+  {
+    uint32_t shift = bb::GEN;
+    int log_m = (int)log_n + 1;
+    for (int j = 0; j < n_layers; j++, log_m--) {
+      const uint64_t m = 1ull << log_m, h = m >> 1;
+      HIP_OK(fri_trees[j].alloc(4 * (2 * h - 1) * 4));
+      HIP_OK(fri_layers[j + 1].alloc(4 * h * 4));
+      uint32_t* tree = fri_trees[j].as<uint32_t>();
+      hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(h)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, tree);
+      uint32_t* cur = tree;
+      for (uint64_t q = h; q > 1; q >>= 1) { uint32_t* nxt = cur + 4 * q; hipLaunchKernelGGL(compress_kernel, dim3(grid_for(q / 2)), dim3(NT), 0, s, cur, q / 2, nxt); cur = nxt; }
+      HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * h - 2), 16, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      ch.observe_n(lroots[j].data(), 4);
+      betas[j] = ch.sample_ext();
+      const uint32_t half_shift_inv_m = bb::to_mont(bb::inv(bb::mul(2, shift)));
+      hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(h)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), (uint32_t)log_m, log_n + 1, c->d_tw_fwd, bb::e_to_mont(betas[j]),
+                         half_shift_inv_m, fri_layers[j + 1].as<uint32_t>());
+      shift = bb::mul(shift, shift);
+    }
+  }
+  const uint64_t fin_n = 1ull << LOG_FINAL;
+  uint32_t fin_cols[4 * 8];
+  HIP_OK(hipMemcpyAsync(fin_cols, fri_layers[n_layers].p, 4 * fin_n * 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  mark(7);
+  for (uint64_t i = 0; i < fin_n; i++) for (int t = 0; t < 4; t++) ch.observe(fin_cols[t * fin_n + i]);
+  std::vector<uint32_t> queries(NUM_QUERIES);
+  for (auto& q : queries) q = ch.sample_bits((int)log_n);
+
+  // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
+  std::vector<uint32_t> head;
+  head.insert(head.end(), {0x46504B5Au, 1u, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL});
+  head.insert(head.end(), troot, troot + 4); head.insert(head.end(), qroot, qroot + 4);
+  for (int k = 0; k < WM; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
+  for (int k = 0; k < WM; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);
+  for (int i = 0; i < 4; i++) head.insert(head.end(), q_z[i].c, q_z[i].c + 4);
+  head.push_back((uint32_t)n_layers);
+  for (auto& r : lroots) head.insert(head.end(), r.begin(), r.end());
+  for (uint64_t i = 0; i < fin_n; i++) for (int t = 0; t < 4; t++) head.push_back(fin_cols[t * fin_n + i]);
+
+  std::vector<GatherJob> jobs;
+  uint32_t off = 0;                                                           // offsets inside the query section
+  std::vector<uint32_t> qpos;                                                 // where each query's index word goes
+  auto path_jobs = [&](const uint32_t* tree, uint64_t n_leaves, uint64_t leaf) {
+    const uint32_t* layer = tree; uint64_t jdx = leaf;
+    for (uint64_t q = n_leaves; q > 1; q >>= 1) { jobs.push_back({layer + 4 * (jdx ^ 1), 1, 4, off}); off += 4; layer += 4 * q; jdx >>= 1; }
+  };
+  for (uint32_t q : queries) {
+    qpos.push_back(off); off += 1;
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dL.as<uint32_t>() + pos, N2, (uint32_t)WM, off}); off += WM; path_jobs(dTree.as<uint32_t>(), N2, pos); }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ.as<uint32_t>() + pos, N2, 4, off}); off += 4; path_jobs(dQTree.as<uint32_t>(), N2, pos); }
+    int log_m = (int)log_n + 1;
+    for (int j = 0; j < n_layers; j++, log_m--) {
+      const uint64_t m = 1ull << log_m, h = m >> 1, idx = q & (h - 1);
+      jobs.push_back({fri_layers[j].as<uint32_t>() + idx, m, 4, off}); off += 4;
+      jobs.push_back({fri_layers[j].as<uint32_t>() + idx + h, m, 4, off}); off += 4;
+      path_jobs(fri_trees[j].as<uint32_t>(), h, idx);
+    }
+  }
+  HIP_OK(dJobs.alloc(jobs.size() * sizeof(GatherJob))); HIP_OK(dOut.alloc((size_t)off * 4));
+  HIP_OK(hipMemcpyAsync(dJobs.p, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)jobs.size()), dim3(64), 0, s, dJobs.as<GatherJob>(), (uint32_t)jobs.size(), dOut.as<uint32_t>());
+  const uint64_t total = head.size() + off;
+  uint32_t* out = (uint32_t*)malloc(total * 4);
+  if (!out) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: out of host memory"}); return ZKIR_ERR_OTHER; }
+  memcpy(out, head.data(), head.size() * 4);
+  hipError_t e = hipMemcpyAsync(out + head.size(), dOut.p, (size_t)off * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess || check_launch("zkir_prove") != ZKIR_OK) { free(out); if (e != hipSuccess) zkir::set_last_error({ZKIR_ERR_DEVICE, hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
+  for (size_t t = 0; t < queries.size(); t++) out[head.size() + qpos[t]] = queries[t];
+  mark(8);
+  if (stage_ms) {
+    (void)hipEventSynchronize(ev[8]);
+    for (int i = 0; i < 8; i++) { (void)hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]); }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+  }
+  *proof_out = out; *proof_words = total;
+  return ZKIR_OK;
+}
+
+}  // extern "C"

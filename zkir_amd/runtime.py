@@ -143,6 +143,11 @@ def lib() -> C.CDLL:
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
+    L.zkir_prove.restype = C.c_int
+    L.zkir_prove.argtypes = [V, C.POINTER(TraceColumnsC), U64, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(U64), C.POINTER(C.c_float), V]
+    L.zkir_proof_free.restype = None
+    L.zkir_proof_free.argtypes = [C.POINTER(C.c_uint32)]
+    L.zkir_proof_num_queries.restype = U32
     L.zkir_exec.restype = C.c_int
     L.zkir_exec.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.POINTER(C.c_void_p)]
     L.zkir_result_free.argtypes = [C.c_void_p]

@@ -84,3 +84,14 @@ def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None):
     tree = merkle_commit(ctx, L, stream)
     root = tree[-4:].cpu().numpy().view(np.uint32)
     return root, L, tree
+
+
+def prove(ctx: StarkContext, trace: pl.DeviceTrace, stream=None, want_stage_ms: bool = False):
+    """zkir_prove: full ZKIR-STARK v0 proof for a 2^log_n-row device trace.  Returns np.uint32 proof words (and stage ms)."""
+    out = C.POINTER(C.c_uint32)()
+    n_words = C.c_uint64()
+    ms = (C.c_float * 8)()
+    pl._check(rt.lib().zkir_prove(ctx.handle, C.byref(trace.c), trace.n_rows, C.byref(out), C.byref(n_words), ms if want_stage_ms else None, _sp(stream)))
+    proof = np.ctypeslib.as_array(out, shape=(n_words.value,)).copy()
+    rt.lib().zkir_proof_free(out)
+    return (proof, list(ms)) if want_stage_ms else proof
