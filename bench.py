@@ -129,6 +129,16 @@ def main():
             ts.append(a.elapsed_time(b))
         stage_ms[name] = float(np.mean(ts))
 
+    # ---- end-to-end prove (BASELINE metric's "end-to-end prove ms"): AIR quotient + openings + DEEP + FRI on top of the commit ----
+    prove_ms, prove_stage_ms, proof_bytes = None, None, None
+    if commit and world == 1:                         # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
+        for _ in range(2):                            # first call allocates the context's workspace
+            t0 = time.perf_counter()
+            proof, pms = stark.prove(ctx, trace, want_stage_ms=True)
+            prove_ms = (time.perf_counter() - t0) * 1e3
+        prove_stage_ms = dict(zip(["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "openings", "deep", "fri", "queries"], pms))
+        proof_bytes = int(len(proof) * 4)
+
     # ---- parity spot checks outside the timed region (full parity lives in tests/ -m gpu) ----------
     n_chk = min(4096, n)
     got = trace.registers[:, :n_chk].cpu().numpy().view(np.uint64)
@@ -187,6 +197,7 @@ def main():
                          if kernels[dom]["bound"] != "hbm" else None},
             "roofline_by_stage": kernels,
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
+            "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes,
             "merkle_root": root, "merkle_roots_all_ranks": roots,
             "host_interpret_rows_per_s": total_rows / host_s,
             "h2d_upload_s": h2d_s,

@@ -159,3 +159,65 @@ def test_main_trace_columns_and_commit():
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
+
+
+# ---- stage B: prover + verifier ------------------------------------------------------------------------------------
+def _rows(n, prog="fib", **cfg):
+    blob = (spec.fib_endless_program() if prog == "fib" else spec.sha256_chain_program()).to_bytes()
+    return oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg).rows
+
+
+@pytest.mark.parametrize("log_n,prog", [(3, "fib"), (4, "fib"), (7, "fib"), (9, "sha"), (10, "fib")])
+def test_prove_verify_roundtrip(log_n, prog):
+    pr = so.prove(_rows(1 << log_n, prog))
+    assert pr[0] == 0x46504B5A and pr[2] == log_n and pr[3] == 89 and pr[4] == 24
+    assert (pr[6:] < P).all()
+    assert so.verify(pr) == 0
+    assert so.verify(pr[:-1]) != 0 and so.verify(np.concatenate([pr, [0]])) != 0           # length is checked
+    rng = np.random.default_rng(log_n)
+    for pos in rng.integers(6, len(pr), 40):                                               # any single-word change is rejected
+        t = pr.copy()
+        t[pos] = (int(t[pos]) + 1 + int(rng.integers(0, 1000))) % P
+        if t[pos] != pr[pos]:
+            assert so.verify(t) != 0, pos
+
+
+def test_quotient_is_low_degree_and_fri_layers_fold():
+    n = 64
+    so.prove(_rows(n))
+    Q = so.last_quotient(n)
+    for i in range(4):                                                                     # degree < N: upper half of the coset-coefficients vanish
+        c = so.ntt(Q[i], inverse=True)
+        assert not c[n:].any()
+    l0, l1 = so.last_fri_layer(0), so.last_fri_layer(1)
+    assert l0.shape == (2 * n, 4) and l1.shape == (n, 4)
+    # DEEP codeword has degree < N as well (each quotient (p(x)-p(z))/(x-z) drops one degree)
+    for t in range(4):
+        c = so.ntt(l0[:, t], inverse=True)
+        assert not c[n:].any()
+
+
+def test_invalid_traces_are_rejected():
+    rows = _rows(64).copy()
+    rows["cycle"][30] = 77                                   # cycle counter must increase by one
+    assert so.verify(so.prove(rows)) == 10
+    rows = _rows(64).copy()
+    rows["registers"][:, 0] = 1                              # R0 is hard-wired zero
+    assert so.verify(so.prove(rows)) == 10
+    rows = _rows(64).copy()
+    rows["reg_state"][10, 3] = 2                             # storage state is boolean
+    assert so.verify(so.prove(rows)) == 10
+    rows = _rows(64).copy()
+    rows["cycle"] += 5                                       # first row must be cycle 0
+    assert so.verify(so.prove(rows)) == 10
+
+
+def test_transcript_binds_everything():
+    a = so.prove(_rows(32))
+    al, ze, ga = so.last_challenges()
+    rows = _rows(32).copy()
+    rows["pc"][7] ^= 4
+    b = so.prove(rows)
+    al2, ze2, ga2 = so.last_challenges()
+    assert not np.array_equal(al, al2) and not np.array_equal(ze, ze2) and not np.array_equal(ga, ga2)
+    assert not np.array_equal(a[6:10], b[6:10])              # trace roots differ

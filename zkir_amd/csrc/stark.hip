@@ -226,6 +226,9 @@ struct zkir_stark_ctx {
   uint32_t* d_small_inv = nullptr;  // w_{2^Bm}^-k, k < 2^(Bm-1)      (Bm = min(log_n, 10))
   uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
   p2::Consts consts;
+  // prover workspace: one device allocation made on the first zkir_prove and reused (hipMalloc of GBs costs more than the kernels)
+  mutable unsigned char* arena = nullptr;
+  mutable size_t arena_size = 0, arena_off = 0;
 };
 
 extern "C" {
@@ -266,6 +269,7 @@ void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
   (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi);
   (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd);
+  if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
 

@@ -194,10 +194,18 @@ E4 h_e_pow(E4 a, uint64_t e) { E4 r{{1, 0, 0, 0}}; while (e) { if (e & 1) r = h_
 #define HIP_OK(expr)                                                                                         \
   do { hipError_t _e = (expr); if (_e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)}); return ZKIR_ERR_DEVICE; } } while (0)
 
-struct DevBuf {                 // RAII device allocation
+// Bump allocation out of the context's persistent workspace (reset at the start of every zkir_prove).
+thread_local const zkir_stark_ctx* g_arena_ctx = nullptr;
+struct DevBuf {
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+  hipError_t alloc(size_t bytes) {
+    const zkir_stark_ctx* c = g_arena_ctx;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (!c || c->arena_off + need > c->arena_size) return hipErrorOutOfMemory;
+    p = c->arena + c->arena_off;
+    c->arena_off += need;
+    return hipSuccess;
+  }
   template <typename T> T* as() { return (T*)p; }
 };
 
@@ -221,7 +229,18 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   const int depth0 = (int)log_n + 1;
   const int n_layers = (int)log_n + 1 - LOG_FINAL;
 
-  DevBuf dM, dL, dTree, dQ, dQTree, dW, dPart, dCw[2], dJobs, dOut;
+  {                                               // workspace: 12 W (M + L) + 320 (trees, quotient, weights, FRI) bytes per row, allocated once per context
+    const size_t want = (size_t)(12 * WM + 400) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
+    if (c->arena_size < want) {
+      if (c->arena) (void)hipFree(c->arena);
+      c->arena = nullptr; c->arena_size = 0;
+      HIP_OK(hipMalloc((void**)&c->arena, want));
+      c->arena_size = want;
+    }
+    c->arena_off = 0;
+    g_arena_ctx = c;
+  }
+  DevBuf dM, dL, dTree, dQ, dQTree, dW, dPart, dJobs, dOut;
   std::vector<DevBuf> fri_trees(n_layers), fri_layers(n_layers + 1);
   HIP_OK(dM.alloc(WM * N * 4)); HIP_OK(dL.alloc(WM * N2 * 4)); HIP_OK(dTree.alloc(4 * (2 * N2 - 1) * 4));
   HIP_OK(dQ.alloc(4 * N2 * 4)); HIP_OK(dQTree.alloc(4 * (2 * N2 - 1) * 4)); HIP_OK(dW.alloc(N2 * sizeof(E4)));
