@@ -168,9 +168,12 @@ def main():
             kernels["main_trace"] = {"bound": "hbm", "bytes": (372 + 4 * W) * n, "ms": stage_ms["main_trace"]}
             kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
             perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
+            modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
+            modmul = perms * 736 / (stage_ms["merkle"] * 1e-3)
             kernels["merkle"] = {"bound": "int-alu", "bytes": 4 * W * 2 * n + 16 * (4 * n - 1), "ms": stage_ms["merkle"],
                                  "poseidon2_perms_per_s": perms / (stage_ms["merkle"] * 1e-3),
-                                 "mont_mul_per_s": perms * 736 / (stage_ms["merkle"] * 1e-3)}
+                                 "mont_mul_per_s": modmul, "mont_mul_peak_per_s_measured": modmul_peak,
+                                 "frac_of_alu_peak": modmul / modmul_peak if modmul_peak else None}
         for v in kernels.values():
             v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS

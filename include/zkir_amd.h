@@ -246,6 +246,9 @@ typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, co
 int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup /* must be 1 */, zkir_stark_ctx** out);
 void zkir_stark_ctx_free(zkir_stark_ctx* ctx);
 uint32_t zkir_main_trace_width(void);             /* 89 */
+/* diagnostic: measured peak rate (per second) of independent Montgomery multiplications on the current device — the integer-ALU
+ * roofline the Poseidon2 kernels are priced against (they are ALU-bound, not HBM- or MFMA-bound) */
+double zkir_modmul_peak_per_s(void* hip_stream);
 /* trace columns (K1 output) -> main trace matrix out[89][n_rows] */
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_rows, uint32_t* out, void* hip_stream);
 /* per-column low-degree extension: in[width][N] (evaluations over <w_N>, natural order; CLOBBERED as scratch when N > 1024)

@@ -31,8 +31,9 @@ BB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
 BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
   const uint64_t t = (uint64_t)a * b;
   const uint32_t m = (uint32_t)t * NEG_PINV;
-  const uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);
-  return u >= P ? u - P : u;
+  const uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);     // < 2p
+  const uint32_t d = u - P;                                       // wraps above u when u < p
+  return d < u ? d : u;                                           // min(u, u - p): 32-bit ops only
 }
 BB_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2); }
 BB_HD uint32_t from_mont(uint32_t a) { return mont_mul(a, 1u); }

@@ -183,6 +183,76 @@ __global__ __launch_bounds__(NT) void lde_middle_kernel(const uint32_t* __restri
   for (uint32_t e = threadIdx.x; e < 2 * chunk; e += NT) y[2 * base + e] = lds[e];
 }
 
+// Same computation for Bm = 10, with register-resident radix-4 butterflies: every round does TWO radix-2 stages on 4 values held
+// in registers, so the 10 inverse + 10 forward stages need 10 LDS round trips / barriers instead of 21, each lane has 4-8
+// independent multiplications in flight, and only one twiddle per quad is read (the others are its square and its product with
+// a 4th root of unity).  A = LDS[0,1024): inverse part; Bf = LDS[1024, 3072): forward part (zero-interleaved, stage 0 = copy).
+__global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __restrict__ in, uint64_t in_stride, uint32_t* __restrict__ out, uint64_t out_stride, int L,
+                                                            const uint32_t* __restrict__ small_inv, const uint32_t* __restrict__ small_fwd,
+                                                            const uint32_t* __restrict__ g_lo, const uint32_t* __restrict__ g_hi, uint32_t j4_inv_m, uint32_t j4_fwd_m) {
+  constexpr int Bm = 10;
+  __shared__ uint32_t A[1024];
+  __shared__ uint32_t Bf[2048];
+  const uint32_t* x = in + (uint64_t)blockIdx.y * in_stride;
+  uint32_t* y = out + (uint64_t)blockIdx.y * out_stride;
+  const uint32_t base = blockIdx.x << Bm, q = threadIdx.x;
+  {
+    const uint4 v = reinterpret_cast<const uint4*>(x + base)[q];
+    reinterpret_cast<uint4*>(A)[q] = v;
+  }
+  __syncthreads();
+  // ---- inverse DIF, rounds r = 0..4: stages (2r, 2r+1), spans h1 = 2^(9-2r), h2 = h1/2 ----
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int lg = 8 - 2 * r;                                  // log2(h2)
+    const uint32_t h2 = 1u << lg, lo = q & (h2 - 1), hi = q >> lg;
+    const uint32_t i0 = (hi << (lg + 2)) | lo;
+    const uint32_t x0 = A[i0], x1 = A[i0 + h2], x2 = A[i0 + 2 * h2], x3 = A[i0 + 3 * h2];
+    const uint32_t wA = small_inv[lo << (2 * r)];              // w_1024^-(lo << 2r)
+    const uint32_t wB = bb::mont_mul(wA, j4_inv_m), w2 = bb::mont_mul(wA, wA);
+    const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub(x0, x2), wA);
+    const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub(x1, x3), wB);
+    uint32_t z0 = bb::add(y0, y1), z1 = bb::mont_mul(bb::sub(y0, y1), w2);
+    uint32_t z2 = bb::add(y2, y3), z3 = bb::mont_mul(bb::sub(y2, y3), w2);
+    if (r == 4) {                                              // last round (positions 4q..4q+3): fold in the coset scale g^k / N, k = bitrev_L(position)
+      const uint32_t p0 = base + i0;
+      const uint32_t k0 = bitrev(p0, L), k1 = bitrev(p0 + 1, L), k2 = bitrev(p0 + 2, L), k3 = bitrev(p0 + 3, L);
+      z0 = bb::mont_mul(bb::mont_mul(z0, g_lo[k0 & 1023]), g_hi[k0 >> 10]);
+      z1 = bb::mont_mul(bb::mont_mul(z1, g_lo[k1 & 1023]), g_hi[k1 >> 10]);
+      z2 = bb::mont_mul(bb::mont_mul(z2, g_lo[k2 & 1023]), g_hi[k2 >> 10]);
+      z3 = bb::mont_mul(bb::mont_mul(z3, g_lo[k3 & 1023]), g_hi[k3 >> 10]);
+    }
+    A[i0] = z0; A[i0 + h2] = z1; A[i0 + 2 * h2] = z2; A[i0 + 3 * h2] = z3;
+    __syncthreads();
+  }
+  // ---- forward DIT of the zero-interleaved chunk (2048 points): stage 0 is a copy, rounds do stages (s, s+1), s = 1,3,5,7,9 ----
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int s = 2 * r + 1;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const uint32_t qq = q + t * NT;                          // 512 quads
+      const uint32_t lo = qq & ((1u << s) - 1), hi = qq >> s;
+      const uint32_t i0 = (hi << (s + 2)) | lo, d = 1u << s;
+      uint32_t x0, x1, x2, x3;
+      if (r == 0) { x0 = A[i0 >> 1]; x1 = A[(i0 + d) >> 1]; x2 = A[(i0 + 2 * d) >> 1]; x3 = A[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
+      else { x0 = Bf[i0]; x1 = Bf[i0 + d]; x2 = Bf[i0 + 2 * d]; x3 = Bf[i0 + 3 * d]; }
+      const uint32_t w2 = small_fwd[lo << (Bm - s - 1)];       // w_2048^(lo << (9-s)): twiddle of stage s+1
+      const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_fwd_m);
+      const uint32_t t1 = bb::mont_mul(x1, w1), t3 = bb::mont_mul(x3, w1);
+      const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add(x2, t3), y3 = bb::sub(x2, t3);
+      const uint32_t u2 = bb::mont_mul(y2, w2), u3 = bb::mont_mul(y3, w2i);
+      Bf[i0] = bb::add(y0, u2); Bf[i0 + 2 * d] = bb::sub(y0, u2); Bf[i0 + d] = bb::add(y1, u3); Bf[i0 + 3 * d] = bb::sub(y1, u3);
+    }
+    __syncthreads();
+  }
+  {
+    uint4* dst = reinterpret_cast<uint4*>(y + 2 * base);
+    dst[q] = reinterpret_cast<const uint4*>(Bf)[q];
+    dst[q + NT] = reinterpret_cast<const uint4*>(Bf)[q + NT];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 Merkle
 // ------------------------------------------------------------------------------------------------
@@ -212,6 +282,51 @@ __global__ __launch_bounds__(NT) void compress_kernel(const uint32_t* __restrict
   reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
 }
 
+// Upper part of a Merkle tree in ONE launch: a single workgroup walks the levels from `m` digests down to the root
+// (launch + tail latency of ~12 tiny kernels costs more than the hashing itself).  cur = level of m digests inside the tree buffer.
+__global__ __launch_bounds__(NT) void compress_tail_kernel(uint32_t* __restrict__ cur, uint32_t m) {
+  while (m > 1) {
+    uint32_t* nxt = cur + 4 * (uint64_t)m;
+    for (uint32_t i = threadIdx.x; i < m / 2; i += NT) {
+      const uint4 l = reinterpret_cast<const uint4*>(cur)[2 * i], r = reinterpret_cast<const uint4*>(cur)[2 * i + 1];
+      uint32_t s[p2::T] = {bb::to_mont(l.x), bb::to_mont(l.y), bb::to_mont(l.z), bb::to_mont(l.w), bb::to_mont(r.x), bb::to_mont(r.y), bb::to_mont(r.z), bb::to_mont(r.w), 0, 0, 0, 0};
+      p2::permute(s, d_p2);
+      reinterpret_cast<uint4*>(nxt)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+    }
+    __threadfence_block();
+    __syncthreads();
+    cur = nxt; m >>= 1;
+  }
+}
+
+// ALU roofline probe: every lane runs `iters` rounds of 8 independent Montgomery multiplications (no memory traffic), i.e. the
+// best modmul rate this formulation of mont_mul can reach on the chip.  The Poseidon2 kernels are priced against it.
+__global__ __launch_bounds__(NT) void modmul_peak_kernel(uint32_t* __restrict__ out, uint32_t iters) {
+  uint32_t a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = (threadIdx.x * 2654435761u + blockIdx.x * 40503u + k * 7919u) % bb::P;
+  for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = bb::mont_mul(a[k], a[(k + 1) & 7]);
+  }
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r ^= a[k];
+  if (r == 0xFFFFFFFFu) out[0] = r;                     // never true (values < p); keeps the chain live
+}
+
+// all levels above the leaf digests: wide levels one launch each, the last <= 2048 digests in a single launch
+void launch_tree_levels(uint32_t* leaf_digests, uint64_t n_leaves, hipStream_t s) {
+  uint32_t* cur = leaf_digests;
+  uint64_t m = n_leaves;
+  for (; m > 2048; m >>= 1) {
+    uint32_t* nxt = cur + 4 * m;
+    hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cur, m / 2, nxt);
+    cur = nxt;
+  }
+  if (m > 1) hipLaunchKernelGGL(compress_tail_kernel, dim3(1), dim3(NT), 0, s, cur, (uint32_t)m);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -234,6 +349,25 @@ struct zkir_stark_ctx {
 extern "C" {
 
 uint32_t zkir_main_trace_width(void) { return 89; }
+
+// Diagnostic: measured peak Montgomery-multiplication rate (modmul/s) of the device, used as the ALU roofline of the Poseidon2 kernels.
+double zkir_modmul_peak_per_s(void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* d = nullptr;
+  if (hipMalloc(&d, 256) != hipSuccess) return 0.0;
+  const uint32_t blocks = 256 * 16, iters = 4096;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  hipLaunchKernelGGL(modmul_peak_kernel, dim3(blocks), dim3(NT), 0, s, d, 64u);
+  (void)hipEventRecord(a, s);
+  hipLaunchKernelGGL(modmul_peak_kernel, dim3(blocks), dim3(NT), 0, s, d, iters);
+  (void)hipEventRecord(b, s);
+  (void)hipEventSynchronize(b);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
+  return ms > 0 ? (double)blocks * NT * iters * 8.0 / (ms * 1e-3) : 0.0;
+}
 
 int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** out) {
   if (!out || log_n < 1 || log_n > 26 || log_blowup != 1) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_stark_ctx_create: need 1 <= log_n <= 26 and log_blowup == 1"}); return ZKIR_ERR_ARGUMENT; }
@@ -292,7 +426,13 @@ int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint3
     hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(N >> (B + C), width), dim3(NT), (4u << (B + C)), s, in, (uint64_t)N, L, s0, B, C, c->d_tw_inv, c->d_small_inv, Bm);
     s0 += B;
   }
-  hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, c->d_small_inv, c->d_small_fwd, c->d_g_lo, c->d_g_hi);
+  if (Bm == 10) {
+    static const uint32_t j4_inv_m = bb::to_mont(bb::inv(bb::root_of_unity(2))), j4_fwd_m = bb::to_mont(bb::root_of_unity(2));
+    hipLaunchKernelGGL(lde_middle_r4_kernel, dim3(N >> Bm, width), dim3(NT), 0, s, in, (uint64_t)N, out, (uint64_t)2 * N, L, c->d_small_inv, c->d_small_fwd, c->d_g_lo,
+                       c->d_g_hi, j4_inv_m, j4_fwd_m);
+  } else {
+    hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, c->d_small_inv, c->d_small_fwd, c->d_g_lo, c->d_g_hi);
+  }
   // forward DIT strided stages Bm+1 .. L of the size-2N transform
   const int L2 = L + 1;
   for (int s0 = Bm + 1; s0 < L2;) {
@@ -310,12 +450,7 @@ int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
   hipStream_t s = (hipStream_t)stream;
   if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle: n_leaves must be a power of two"}); return ZKIR_ERR_ARGUMENT; }
   hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, mat, width, n_leaves, n_leaves, tree);
-  uint32_t* cur = tree;
-  for (uint64_t m = n_leaves; m > 1; m >>= 1) {
-    uint32_t* nxt = cur + 4 * m;
-    hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cur, m / 2, nxt);
-    cur = nxt;
-  }
+  launch_tree_levels(tree, n_leaves, s);
   return check_launch("merkle_commit");
 }
 

@@ -345,8 +345,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
       HIP_OK(fri_layers[j + 1].alloc(4 * h * 4));
       uint32_t* tree = fri_trees[j].as<uint32_t>();
       hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(h)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, tree);
-      uint32_t* cur = tree;
-      for (uint64_t q = h; q > 1; q >>= 1) { uint32_t* nxt = cur + 4 * q; hipLaunchKernelGGL(compress_kernel, dim3(grid_for(q / 2)), dim3(NT), 0, s, cur, q / 2, nxt); cur = nxt; }
+      launch_tree_levels(tree, h, s);
       HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * h - 2), 16, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
       ch.observe_n(lroots[j].data(), 4);

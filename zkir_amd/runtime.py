@@ -138,6 +138,8 @@ def lib() -> C.CDLL:
     L.zkir_stark_ctx_free.restype = None
     L.zkir_stark_ctx_free.argtypes = [V]
     L.zkir_main_trace_width.restype = U32
+    L.zkir_modmul_peak_per_s.restype = C.c_double
+    L.zkir_modmul_peak_per_s.argtypes = [V]
     for name, args in [("zkir_main_trace_launch", [C.POINTER(TraceColumnsC), U64, V, V]), ("zkir_lde_launch", [V, V, U32, V, V]),
                        ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V])]:
         f = getattr(L, name)
