@@ -213,14 +213,17 @@ class Machine {
     if (tracing_ && addr != fetch_pc_) log_.mem_events.push(zkir_mem_event{addr, value, (uint32_t)cycle_, (uint8_t)is_write, width, 0});  // Q9
   }
   inline Status misaligned(uint64_t addr, unsigned al) { return {ZKIR_ERR_MISALIGNED, "Misaligned access: address " + hexs(addr) + ", alignment " + std::to_string(al)}; }
-  template <typename T> inline bool load(uint64_t addr, T& out, Status& st) {
-    if (sizeof(T) > 1 && (addr & (sizeof(T) - 1))) { st = misaligned(addr, sizeof(T)); return false; }
+  // Errors are rare: the hot path returns plain bools and the Status (with its message string) is only built on failure.
+  Status err_;
+  inline bool fail(Status s) { err_ = std::move(s); return false; }
+  template <typename T> inline bool load(uint64_t addr, T& out) {
+    if (sizeof(T) > 1 && (addr & (sizeof(T) - 1))) return fail(misaligned(addr, sizeof(T)));
     out = mem_.load<T>(addr);
     note(addr, (uint64_t)out, false, sizeof(T));
     return true;
   }
-  template <typename T> inline bool store(uint64_t addr, T v, Status& st) {
-    if (sizeof(T) > 1 && (addr & (sizeof(T) - 1))) { st = misaligned(addr, sizeof(T)); return false; }
+  template <typename T> inline bool store(uint64_t addr, T v) {
+    if (sizeof(T) > 1 && (addr & (sizeof(T) - 1))) return fail(misaligned(addr, sizeof(T)));
     mem_.store<T>(addr, v);
     note(addr, (uint64_t)v, true, sizeof(T));
     return true;
@@ -248,10 +251,10 @@ class Machine {
   }
   inline void write_accumulated(uint8_t r, const uint64_t l[2]) { if (r) { wr_value(r, l[0] | (l[1] << 30)); wr_state(r, 1); } }  // state.rs:184-192
 
-  Status step(const Decoded& d);
-  Status step_deferred(const Decoded& d);
-  Status syscall();
-  Status hash_syscall(int which);
+  bool step(const Decoded& d);            // false => err_ holds the RuntimeError
+  bool step_deferred(const Decoded& d);
+  bool syscall();
+  bool hash_syscall(int which);
   void flush_range_checks();
 
   const zkir_vm_config cfg_;
@@ -274,8 +277,7 @@ class Machine {
 };
 
 // execute.rs:35-673.  Register fields by position: R/I-type rd=a rs1=b rs2=c; S/B-type rs1=a rs2=b.
-Status Machine::step(const Decoded& d) {
-  Status st;
+bool Machine::step(const Decoded& d) {
   const uint64_t immu = (uint64_t)(int64_t)d.imm;            // `imm as u64` sign-extends (Q4)
   switch (d.op) {
     case 0x00: {  // ADD :43-63
@@ -303,13 +305,13 @@ Status Machine::step(const Decoded& d) {
     }
     case 0x04: case 0x05: {  // DIVU / REMU :134-149, :168-183
       const uint64_t a = rd(d.b), b = rd(d.c);
-      if (b == 0) return {ZKIR_ERR_DIV_ZERO, "Division by zero at PC " + hexs(pc_)};
+      if (b == 0) return fail({ZKIR_ERR_DIV_ZERO, "Division by zero at PC " + hexs(pc_)});
       wr(d.a, d.op == 0x04 ? a / b : a % b, computed(bound_[d.b].max_bits));     // after_div for both (Q2)
       pc_ += 4; break;
     }
     case 0x06: case 0x07: {  // DIV / REM :117-132, :151-166 — raw u64 reinterpreted as i64 (Q2)
       const int64_t a = (int64_t)rd(d.b), b = (int64_t)rd(d.c);
-      if (b == 0) return {ZKIR_ERR_DIV_ZERO, "Division by zero at PC " + hexs(pc_)};
+      if (b == 0) return fail({ZKIR_ERR_DIV_ZERO, "Division by zero at PC " + hexs(pc_)});
       uint64_t r;
       if (a == INT64_MIN && b == -1) r = d.op == 0x06 ? (uint64_t)INT64_MIN : 0;   // wrapping_div / wrapping_rem
       else r = d.op == 0x06 ? (uint64_t)(a / b) : (uint64_t)(a % b);
@@ -354,21 +356,21 @@ Status Machine::step(const Decoded& d) {
       pc_ += 4; break;
     }
     case 0x30: case 0x31: {  // LB / LBU :477-499 (Q1: LB keeps the 64-bit sign extension)
-      uint8_t v; if (!load<uint8_t>(rd(d.b) + immu, v, st)) return st;
+      uint8_t v; if (!load<uint8_t>(rd(d.b) + immu, v)) return false;
       wr(d.a, d.op == 0x30 ? (uint64_t)(int64_t)(int8_t)v : (uint64_t)v, type_width(8));
       pc_ += 4; break;
     }
     case 0x32: case 0x33: {  // LH / LHU :501-523
-      uint16_t v; if (!load<uint16_t>(rd(d.b) + immu, v, st)) return st;
+      uint16_t v; if (!load<uint16_t>(rd(d.b) + immu, v)) return false;
       wr(d.a, d.op == 0x32 ? (uint64_t)(int64_t)(int16_t)v : (uint64_t)v, type_width(16));
       pc_ += 4; break;
     }
-    case 0x34: { uint32_t v; if (!load<uint32_t>(rd(d.b) + immu, v, st)) return st; wr(d.a, v, type_width(32)); pc_ += 4; break; }   // LW :525-535 zero-extends
-    case 0x35: { uint64_t v; if (!load<uint64_t>(rd(d.b) + immu, v, st)) return st; wr(d.a, v, type_width(40)); pc_ += 4; break; }   // LD :537-546
-    case 0x38: if (!store<uint8_t>(rd(d.a) + immu, (uint8_t)rd(d.b), st)) return st; pc_ += 4; break;      // SB :549-554
-    case 0x39: if (!store<uint16_t>(rd(d.a) + immu, (uint16_t)rd(d.b), st)) return st; pc_ += 4; break;    // SH :556-561
-    case 0x3A: if (!store<uint32_t>(rd(d.a) + immu, (uint32_t)rd(d.b), st)) return st; pc_ += 4; break;    // SW :563-568
-    case 0x3B: if (!store<uint64_t>(rd(d.a) + immu, rd(d.b), st)) return st; pc_ += 4; break;              // SD :570-575
+    case 0x34: { uint32_t v; if (!load<uint32_t>(rd(d.b) + immu, v)) return false; wr(d.a, v, type_width(32)); pc_ += 4; break; }   // LW :525-535 zero-extends
+    case 0x35: { uint64_t v; if (!load<uint64_t>(rd(d.b) + immu, v)) return false; wr(d.a, v, type_width(40)); pc_ += 4; break; }   // LD :537-546
+    case 0x38: if (!store<uint8_t>(rd(d.a) + immu, (uint8_t)rd(d.b))) return false; pc_ += 4; break;      // SB :549-554
+    case 0x39: if (!store<uint16_t>(rd(d.a) + immu, (uint16_t)rd(d.b))) return false; pc_ += 4; break;    // SH :556-561
+    case 0x3A: if (!store<uint32_t>(rd(d.a) + immu, (uint32_t)rd(d.b))) return false; pc_ += 4; break;    // SW :563-568
+    case 0x3B: if (!store<uint64_t>(rd(d.a) + immu, rd(d.b))) return false; pc_ += 4; break;              // SD :570-575
     case 0x40: pc_ += (rd(d.a) == rd(d.b)) ? (uint64_t)(int64_t)d.imm : 4; break;                          // BEQ :578-586 raw compare; target = own pc + off (Q7)
     case 0x41: pc_ += (rd(d.a) != rd(d.b)) ? (uint64_t)(int64_t)d.imm : 4; break;                          // BNE :588-596
     case 0x42: pc_ += slt40(rd(d.a) & M40, rd(d.b) & M40) ? (uint64_t)(int64_t)d.imm : 4; break;           // BLT :598-606
@@ -384,11 +386,11 @@ Status Machine::step(const Decoded& d) {
     case 0x50: pc_ += 4; break;                                                                     // ECALL :661-665 (syscall runs afterwards, Q8)
     case 0x51: halted_ = true; halt_kind_ = ZKIR_HALT_EBREAK; break;                                // EBREAK :667-669
   }
-  return st;
+  return true;
 }
 
 // execute.rs:888-1003
-Status Machine::step_deferred(const Decoded& d) {
+bool Machine::step_deferred(const Decoded& d) {
   enum { NONE, ONE, TWO_RI, TWO_SB };
   int kind = NONE;
   switch (d.op) {
@@ -437,34 +439,33 @@ Status Machine::step_deferred(const Decoded& d) {
   } else {
     return step(d);
   }
-  return {};
+  return true;
 }
 
 // syscall.rs:94-177
-Status Machine::syscall() {
+bool Machine::syscall() {
   const uint64_t num = reg_[10];
   switch (num) {
-    case 0: halted_ = true; halt_kind_ = ZKIR_HALT_EXIT; halt_code_ = reg_[11]; return {};
-    case 1: wr_value(10, input_pos_ < n_inputs_ ? inputs_[input_pos_++] : 0); return {};     // READ: bound of R10 untouched (a10)
-    case 2: log_.outputs.push_back(reg_[11]); return {};
+    case 0: halted_ = true; halt_kind_ = ZKIR_HALT_EXIT; halt_code_ = reg_[11]; return true;
+    case 1: wr_value(10, input_pos_ < n_inputs_ ? inputs_[input_pos_++] : 0); return true;   // READ: bound of R10 untouched (a10)
+    case 2: log_.outputs.push_back(reg_[11]); return true;
     case 3: return hash_syscall(0);
-    case 4: return {ZKIR_ERR_OTHER, "Poseidon2 not yet implemented"};                          // crypto.rs:306-315
+    case 4: return fail({ZKIR_ERR_OTHER, "Poseidon2 not yet implemented"});                    // crypto.rs:306-315
     case 5: return hash_syscall(1);
     case 6: return hash_syscall(2);
-    default: return {ZKIR_ERR_INVALID_SYSCALL, "Invalid syscall: " + std::to_string(num)};
+    default: return fail({ZKIR_ERR_INVALID_SYSCALL, "Invalid syscall: " + std::to_string(num)});
   }
 }
 
-Status Machine::hash_syscall(int which) {
+bool Machine::hash_syscall(int which) {
   const uint64_t ip = reg_[11], il = reg_[12], op = reg_[13];
-  if (il > (1ull << 32)) return {ZKIR_ERR_OTHER, "hash input length too large"};   // the reference would abort in Vec::with_capacity
-  Status st;
+  if (il > (1ull << 32)) return fail({ZKIR_ERR_OTHER, "hash input length too large"});   // the reference would abort in Vec::with_capacity
   std::vector<uint8_t> in((size_t)il);
-  for (uint64_t i = 0; i < il; i++) { uint8_t b; load<uint8_t>(ip + i, b, st); in[i] = b; }       // one width-1 Read per byte (crypto.rs:232-235)
+  for (uint64_t i = 0; i < il; i++) { uint8_t b; load<uint8_t>(ip + i, b); in[i] = b; }           // one width-1 Read per byte (crypto.rs:232-235)
   if (which == 0) {
     uint32_t h[8];
     sha256(in.data(), in.size(), h);
-    for (int i = 0; i < 8; i++) if (!store<uint32_t>(op + 4 * (uint64_t)i, h[i], st)) return st;  // crypto.rs:252-255
+    for (int i = 0; i < 8; i++) if (!store<uint32_t>(op + 4 * (uint64_t)i, h[i])) return false;  // crypto.rs:252-255
     wr_value(10, 0);
     wr_bound(14, BoundT{32, ZKIR_BOUND_CRYPTO_OUTPUT, 0});                                        // syscall.rs:135
     if (tracing_ && il < 56) {                                                                    // single-block message -> SHA chip input (crypto.rs:108-139)
@@ -479,10 +480,10 @@ Status Machine::hash_syscall(int which) {
   } else {
     uint8_t dgst[32];
     if (which == 1) keccak256(in.data(), in.size(), dgst); else blake3(in.data(), in.size(), dgst);
-    for (int i = 0; i < 32; i++) store<uint8_t>(op + (uint64_t)i, dgst[i], st);                   // crypto.rs:351-353, :390-392
+    for (int i = 0; i < 32; i++) store<uint8_t>(op + (uint64_t)i, dgst[i]);                       // crypto.rs:351-353, :390-392
     wr_value(10, 0);
   }
-  return {};
+  return true;
 }
 
 void Machine::flush_range_checks() {                      // RangeCheckTracker::checkpoint, range_check.rs:140-168
@@ -524,9 +525,8 @@ Status Machine::run() {
       log_.pc.push(fetch_pc_); log_.inst.push(word);                  // row pre-state is implied by the events so far (vm.rs:245-253)
     }
     dirty_ = 0;
-    st = deferred_ ? step_deferred(d) : step(d);
-    if (!st.ok()) return st;
-    if (d.op == 0x50) { st = syscall(); if (!st.ok()) return st; }    // vm.rs:277-279
+    if (!(deferred_ ? step_deferred(d) : step(d))) return err_;
+    if (d.op == 0x50 && !syscall()) return err_;                      // vm.rs:277-279
     if (tracing_ && dirty_) {
       uint32_t m = dirty_;
       while (m) {
