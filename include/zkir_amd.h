@@ -258,6 +258,10 @@ int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uin
  * leaf digests first, root = last 4 words */
 int zkir_merkle_commit_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* hip_stream);
 
+/* Top of a row-sharded commitment: tree[0..4n) holds n (power of two) digests — the all-gathered subtree roots of the row
+ * shards, in rank order — and the call appends the log2(n) upper levels; root = last 4 words of the 4*(2n-1)-word buffer. */
+int zkir_merkle_cap_launch(const zkir_stark_ctx* ctx, uint32_t* tree, uint64_t n_digests, void* hip_stream);
+
 /* Full proof (execution-trace AIR of DESIGN.md §8.4: cycle counter, R0 = 0, boolean flags, untouched registers keep their
  * limbs/state), blow-up 2, 24 FRI queries, final codeword of 8.  `trace` = K1 output for n_rows = 2^log_n rows.  *proof_out is a
  * malloc'ed array of u32 words (little-endian canonical field elements; layout in oracle/stark_oracle.cpp so::prove), released

@@ -136,6 +136,34 @@ def test_proof_bytes_match_oracle_and_verify(name, log_n):
     ctx.close()
 
 
+def test_row_sharded_commitment_matches_oracle():
+    """BASELINE configs[3] shape on one device: each row shard is filled and committed on its own (own register snapshot, own
+    LDE + Merkle subtree); the shard roots are the leaves of the top levels.  Oracle: same thing on the CPU."""
+    import torch
+    from zkir_amd import pipeline as pl, stark
+    log_n, G = 9, 4
+    n = 1 << log_n
+    blob = spec.sha256_chain_program().to_bytes()
+    log = rt.interpret(blob, config=rt.VMConfig(max_cycles=n * G, enable_execution_trace=True), tile_rows=256)
+    rows = oracle.run(blob, max_cycles=n * G, enable_execution_trace=True).rows
+    ctx = stark.StarkContext(log_n)
+    roots, want_roots = [], []
+    for g in range(G):
+        sh = log.shard(g * n, (g + 1) * n)
+        ddl = pl.upload(sh)
+        tr = pl.DeviceTrace(ddl)
+        pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        root, _, tree = stark.commit_trace(ctx, tr)
+        roots.append(tree[-4:].clone())
+        want_roots.append(so.commit_trace(rows[g * n:(g + 1) * n], 1))
+        assert np.array_equal(root, want_roots[-1]), f"shard {g}"
+        sh.close()
+    top = stark.merkle_cap(ctx, torch.stack(roots)).cpu().numpy().view(np.uint32)
+    want_top = so.compress(so.compress(want_roots[0], want_roots[1]), so.compress(want_roots[2], want_roots[3]))
+    assert np.array_equal(top, want_top)
+    ctx.close(); log.close()
+
+
 def test_proof_2p16_verifies():
     """Larger than the oracle prover comfortably handles: the oracle VERIFIER (cheap) accepts the GPU proof."""
     from zkir_amd import stark

@@ -95,6 +95,26 @@ def test_normalization_events(name):
     assert np.array_equal(pl.normalization_events(log), want.norm_events)
 
 
+def test_execution_result_members_mirror_the_reference():
+    """ExecutionResult.{get_memory_trace, memory_op_count, range_check_witnesses, normalization_witnesses} (vm.rs:54-103)."""
+    blob, inputs, cfg = programs.ALL["deferred_negative_and_overflow"]()
+    cfg = dict(cfg, enable_range_checking=True, enable_execution_trace=True)
+    res = rt.VM(blob, inputs, rt.VMConfig(**cfg)).run()
+    want = oracle.run(blob, inputs, **cfg)
+    assert np.array_equal(res.get_memory_trace(), want.sorted_memops) and res.memory_op_count() == len(want.memops)
+    assert np.array_equal(res.normalization_witnesses, want.norm_events)
+    res.close()
+    blob, inputs, cfg = programs.ALL["rc_many_pending"]()
+    res = rt.VM(blob, inputs, rt.VMConfig(enable_execution_trace=True, **cfg)).run()
+    want = oracle.run(blob, inputs, enable_execution_trace=True, **cfg)
+    w = res.range_check_witnesses
+    assert len(w) == len(want.rc_offsets) - 1 and sum(len(x) for x in w) == len(want.rc_checks)
+    flat = [c for grp in w for c in grp]
+    for got, exp in zip(flat, want.rc_checks):
+        assert got == (int(exp["value"]), [int(x) for x in exp["chunks"]], int(exp["pc"]))
+    res.close()
+
+
 def test_sha256_chip_matches_witness():
     """K3 vs sha256_hash_with_witness (crypto.rs:223-297): all 608 words per block, every single-block length 0..55."""
     from zkir_amd import pipeline as pl

@@ -136,6 +136,106 @@ __global__ __launch_bounds__(NT) void ntt_strided_kernel(uint32_t* __restrict__ 
   for (uint32_t e = threadIdx.x; e < elems; e += NT) x[base + (e >> C) * stride_mid + (e & cmask)] = lds[e];
 }
 
+// Radix-4 strided pass: 2R radix-2 stages (R register-resident radix-4 rounds) over tiles of 2^(2R) x 2^C elements, in place.
+// With R = 5 a single pass covers ten stages (tile 1024 x 16 words = 64 KiB of LDS), so a 2^20-point column needs ONE strided
+// pass on each side of the fused middle kernel instead of two (36 B/element of HBM traffic per column instead of 60).
+// Twiddles per quad: one read of a compact table (root of order <= 1024/2048) times a per-lane running power; the other
+// stage's twiddle is its square and the odd pair's is its product with a 4th root of unity.
+template <bool DIT, int R, int C, int NTH>
+__global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint32_t* __restrict__ data, uint64_t col_stride, int L, int s0, const uint32_t* __restrict__ tw,
+                                                              const uint32_t* __restrict__ small, int log_small, uint32_t j4_m) {
+  constexpr int B = 2 * R;
+  constexpr uint32_t ELEMS = 1u << (B + C), QUADS = ELEMS / 4, CMASK = (1u << C) - 1;
+  static_assert(QUADS % NTH == 0 && NTH % (1 << C) == 0, "tile / thread geometry");
+  extern __shared__ uint32_t lds[];
+  uint32_t* x = data + (uint64_t)blockIdx.y * col_stride;
+  const uint32_t n = 1u << L;
+  const uint32_t stride_mid = DIT ? (1u << s0) : (n >> (s0 + B));
+  const uint32_t lo_tiles = stride_mid >> C;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t hi = tile / lo_tiles, lo0 = (tile % lo_tiles) << C;
+  const uint32_t base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
+  for (uint32_t e = threadIdx.x; e < ELEMS; e += NTH) lds[e] = x[base + (e >> C) * stride_mid + (e & CMASK)];
+  const uint32_t lo = lo0 + (threadIdx.x & CMASK);
+  uint32_t tp[R];                                              // per-lane power used by round r
+  if (DIT) {                                                   // round r needs w^(lo << (L-1-s0-(2r+1))): finest at r = R-1, each earlier round is its 4th power
+    uint32_t u = tw[lo << (L - s0 - B)];
+#pragma unroll
+    for (int r = R - 1; r >= 0; r--) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
+  } else {                                                     // round r needs w^-(lo << (s0+2r))
+    uint32_t u = tw[lo << s0];
+#pragma unroll
+    for (int r = 0; r < R; r++) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int b = 2 * r;
+#pragma unroll
+    for (uint32_t k = 0; k < QUADS / NTH; k++) {
+      const uint32_t q = threadIdx.x + k * NTH;
+      const uint32_t lo_l = q & CMASK, qq = q >> C;
+      if (!DIT) {
+        const int lg = B - 2 - b;                              // log2(h2) in mid units
+        const uint32_t h2 = 1u << lg, mid_lo = qq & (h2 - 1), mid_hi = qq >> lg;
+        const uint32_t i0 = ((((mid_hi << (lg + 2)) | mid_lo)) << C) | lo_l, d = h2 << C;
+        const uint32_t x0 = lds[i0], x1 = lds[i0 + d], x2 = lds[i0 + 2 * d], x3 = lds[i0 + 3 * d];
+        const uint32_t wA = bb::mont_mul(tp[r], small[mid_lo << (log_small - (B - b))]);
+        const uint32_t wB = bb::mont_mul(wA, j4_m), w2 = bb::mont_mul(wA, wA);
+        const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub(x0, x2), wA);
+        const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub(x1, x3), wB);
+        lds[i0] = bb::add(y0, y1); lds[i0 + d] = bb::mont_mul(bb::sub(y0, y1), w2);
+        lds[i0 + 2 * d] = bb::add(y2, y3); lds[i0 + 3 * d] = bb::mont_mul(bb::sub(y2, y3), w2);
+      } else {
+        const uint32_t dm = 1u << b, mid_lo = qq & (dm - 1), mid_hi = qq >> b;
+        const uint32_t i0 = ((((mid_hi << (b + 2)) | mid_lo)) << C) | lo_l, d = dm << C;
+        const uint32_t x0 = lds[i0], x1 = lds[i0 + d], x2 = lds[i0 + 2 * d], x3 = lds[i0 + 3 * d];
+        const uint32_t w2 = bb::mont_mul(tp[r], small[mid_lo << (log_small - (b + 2))]);
+        const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_m);
+        const uint32_t t1 = bb::mont_mul(x1, w1), t3 = bb::mont_mul(x3, w1);
+        const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add(x2, t3), y3 = bb::sub(x2, t3);
+        const uint32_t u2 = bb::mont_mul(y2, w2), u3 = bb::mont_mul(y3, w2i);
+        lds[i0] = bb::add(y0, u2); lds[i0 + 2 * d] = bb::sub(y0, u2); lds[i0 + d] = bb::add(y1, u3); lds[i0 + 3 * d] = bb::sub(y1, u3);
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < ELEMS; e += NTH) x[base + (e >> C) * stride_mid + (e & CMASK)] = lds[e];
+}
+
+template <bool DIT, int R, int C, int NTH>
+void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t width, int L, int s0, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m, hipStream_t s) {
+  constexpr size_t lds = 4u << (2 * R + C);
+  auto k = ntt_strided_r4_kernel<DIT, R, C, NTH>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)(n >> (2 * R + C)), width), dim3(NTH), lds, s, data, n, L, s0, tw, small, log_small, j4_m);
+}
+
+// `stages` radix-2 stages starting at s0, as few passes as possible: radix-4 passes of 10/8/6/4/2 stages + a radix-2 pass for an odd one
+template <bool DIT>
+void run_strided_stages(uint32_t* data, uint64_t n, uint32_t width, int L, int s0, int stages, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m,
+                        hipStream_t s) {
+  while (stages > 0) {
+    int R = stages / 2 > 5 ? 5 : stages / 2;
+    if (stages - 2 * R == 1 && R == 5) R = 4;                  // keep an even remainder (e.g. 11 = 8 + 2 + 1 is avoided: 11 -> 8 + ... )
+    if (R == 0) {                                              // single leftover stage: radix-2 kernel
+      const int C = 6;
+      hipLaunchKernelGGL(ntt_strided_kernel<DIT>, dim3((unsigned)(n >> (1 + C)), width), dim3(NT), (4u << (1 + C)), s, data, n, L, s0, 1, C, tw, small, log_small);
+      s0 += 1; stages -= 1;
+      continue;
+    }
+    switch (R) {
+      case 5: launch_strided_r4<DIT, 5, 4, 1024>(data, n, width, L, s0, tw, small, log_small, j4_m, s); break;
+      case 4: launch_strided_r4<DIT, 4, 6, 1024>(data, n, width, L, s0, tw, small, log_small, j4_m, s); break;
+      case 3: launch_strided_r4<DIT, 3, 6, 256>(data, n, width, L, s0, tw, small, log_small, j4_m, s); break;
+      case 2: launch_strided_r4<DIT, 2, 6, 256>(data, n, width, L, s0, tw, small, log_small, j4_m, s); break;
+      default: launch_strided_r4<DIT, 1, 6, 64>(data, n, width, L, s0, tw, small, log_small, j4_m, s); break;
+    }
+    s0 += 2 * R; stages -= 2 * R;
+  }
+}
+
 // Fused middle: last Bm inverse-DIF stages on a contiguous 2^Bm chunk of the size-N array `in`, scale by g^k / N
 // (k = bit-reversal of the position), zero-interleave, first Bm+1 forward-DIT stages, write the 2^(Bm+1) chunk of `out`.
 //   g_lo[k & 1023] * g_hi[k >> 10] = g^k * N^-1   (two-level power table, Montgomery form)
@@ -419,28 +519,17 @@ int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint3
   const int L = (int)c->log_n;
   const uint32_t N = 1u << L;
   const int Bm = L < 10 ? L : 10;
-  // inverse DIF strided stages 0 .. L-Bm-1
-  for (int s0 = 0; s0 < L - Bm;) {
-    const int B = (L - Bm - s0) < 5 ? (L - Bm - s0) : 5;
-    int C = L - (s0 + B); if (C > 6) C = 6;                   // stride_mid = 2^(L-s0-B) >= 2^Bm
-    hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(N >> (B + C), width), dim3(NT), (4u << (B + C)), s, in, (uint64_t)N, L, s0, B, C, c->d_tw_inv, c->d_small_inv, Bm);
-    s0 += B;
-  }
+  static const uint32_t j4_inv_m = bb::to_mont(bb::inv(bb::root_of_unity(2))), j4_fwd_m = bb::to_mont(bb::root_of_unity(2));
+  // inverse DIF strided stages 0 .. L-Bm-1 (only when L > 10; the compact table then has order 2^Bm = 1024)
+  run_strided_stages<false>(in, N, width, L, 0, L - Bm, c->d_tw_inv, c->d_small_inv, Bm, j4_inv_m, s);
   if (Bm == 10) {
-    static const uint32_t j4_inv_m = bb::to_mont(bb::inv(bb::root_of_unity(2))), j4_fwd_m = bb::to_mont(bb::root_of_unity(2));
     hipLaunchKernelGGL(lde_middle_r4_kernel, dim3(N >> Bm, width), dim3(NT), 0, s, in, (uint64_t)N, out, (uint64_t)2 * N, L, c->d_small_inv, c->d_small_fwd, c->d_g_lo,
                        c->d_g_hi, j4_inv_m, j4_fwd_m);
   } else {
     hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, c->d_small_inv, c->d_small_fwd, c->d_g_lo, c->d_g_hi);
   }
   // forward DIT strided stages Bm+1 .. L of the size-2N transform
-  const int L2 = L + 1;
-  for (int s0 = Bm + 1; s0 < L2;) {
-    const int B = (L2 - s0) < 5 ? (L2 - s0) : 5;
-    int C = s0 < 6 ? s0 : 6;
-    hipLaunchKernelGGL(ntt_strided_kernel<true>, dim3((2 * N) >> (B + C), width), dim3(NT), (4u << (B + C)), s, out, (uint64_t)2 * N, L2, s0, B, C, c->d_tw_fwd, c->d_small_fwd, Bm + 1);
-    s0 += B;
-  }
+  run_strided_stages<true>(out, (uint64_t)2 * N, width, L + 1, Bm + 1, L - Bm, c->d_tw_fwd, c->d_small_fwd, Bm + 1, j4_fwd_m, s);
   return check_launch("lde");
 }
 
@@ -452,6 +541,15 @@ int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
   hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, mat, width, n_leaves, n_leaves, tree);
   launch_tree_levels(tree, n_leaves, s);
   return check_launch("merkle_commit");
+}
+
+// Upper levels over already-computed digests (multi-GPU: the all-gathered subtree roots of the row shards are the leaves of the
+// top log2(G) levels).  tree[0 .. 4n) must hold the n digests; the call fills the remaining 4(n-1) words, root = last 4.
+int zkir_merkle_cap_launch(const zkir_stark_ctx* c, uint32_t* tree, uint64_t n_digests, void* stream) {
+  (void)c;
+  if (n_digests == 0 || (n_digests & (n_digests - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle cap: n_digests must be a power of two"}); return ZKIR_ERR_ARGUMENT; }
+  launch_tree_levels(tree, n_digests, (hipStream_t)stream);
+  return check_launch("merkle_cap");
 }
 
 }  // extern "C"

@@ -26,7 +26,9 @@ def _to_dev(a: np.ndarray, device) -> torch.Tensor:
     flat = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
     if flat.size == 0:
         return torch.empty(0, dtype=torch.uint8, device=device)
-    return torch.from_numpy(flat.copy()).to(device, non_blocking=False)
+    if not flat.flags.writeable:                       # torch.from_numpy wants a writable buffer; the delta-log views are read-only
+        flat = flat.copy()
+    return torch.from_numpy(flat).to(device, non_blocking=False)     # straight from the delta log's host buffer (no staging copy)
 
 
 @dataclass
@@ -49,11 +51,11 @@ def upload(log: rt.DeltaLog, device=None) -> DeviceDeltaLog:
     device = device or torch.device("cuda", torch.cuda.current_device())
     T = log.tile_rows
     cap = (log.n_rows + T - 1) // T * T
-    pc = torch.zeros(cap, dtype=torch.int64, device=device)
-    inst = torch.zeros(cap, dtype=torch.int32, device=device)
+    pc = torch.zeros(cap, dtype=torch.int64, device=device) if cap != log.n_rows else torch.empty(cap, dtype=torch.int64, device=device)
+    inst = torch.zeros(cap, dtype=torch.int32, device=device) if cap != log.n_rows else torch.empty(cap, dtype=torch.int32, device=device)
     if log.n_rows:
-        pc[:log.n_rows] = torch.from_numpy(log.pc.view(np.int64).copy()).to(device)
-        inst[:log.n_rows] = torch.from_numpy(log.inst.view(np.int32).copy()).to(device)
+        pc[:log.n_rows].view(torch.uint8).copy_(_to_dev(log.pc, device))
+        inst[:log.n_rows].view(torch.uint8).copy_(_to_dev(log.inst, device))
     return DeviceDeltaLog(n_rows=log.n_rows, cycle_base=log.cycle_base, tile_rows=T, n_tiles=log.n_tiles, n_events=len(log.reg_events),
                           events=_to_dev(log.reg_events, device), tile_ev_off=_to_dev(log.tile_ev_off, device),
                           tile_snap=_to_dev(log.tile_snap, device), pc=pc, inst=inst)

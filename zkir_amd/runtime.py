@@ -43,6 +43,11 @@ NORM_EVENT_DTYPE = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("raw_value", "<u8
 SHA_BLOCK_DTYPE = np.dtype([("message_block", "<u4", (16,)), ("timestamp", "<u8")])
 assert REG_EVENT_DTYPE.itemsize == 32 and MEM_EVENT_DTYPE.itemsize == 24 and NORM_EVENT_DTYPE.itemsize == 32 and SHA_BLOCK_DTYPE.itemsize == 72
 
+_MEMOP_DTYPE = np.dtype([("address", "<u8"), ("value", "<u8"), ("timestamp", "<u8"), ("is_write", "u1"), ("width", "u1"),
+                         ("bound_bits", "<u4"), ("bound_tag", "u1"), ("bound_payload", "<u8")])
+_NORM_DTYPE = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("reg", "u1"), ("accumulated", "<u8", (2,)), ("normalized", "<u4", (2,)),
+                        ("carries", "<u4", (2,)), ("normalized_bits", "u1"), ("limb_bits", "u1"), ("cause", "u1"), ("opcode", "u1")])
+
 FIELD_CYCLE, FIELD_PC, FIELD_INSTRUCTION, FIELD_REGISTERS, FIELD_BOUND_BITS, FIELD_BOUND_TAG, FIELD_BOUND_PAYLOAD, FIELD_REG_STATE = range(8)
 _FIELD_DTYPE = {0: "<u8", 1: "<u8", 2: "<u4", 3: "<u8", 4: "<u4", 5: "u1", 6: "<u8", 7: "u1"}
 
@@ -141,7 +146,7 @@ def lib() -> C.CDLL:
     L.zkir_modmul_peak_per_s.restype = C.c_double
     L.zkir_modmul_peak_per_s.argtypes = [V]
     for name, args in [("zkir_main_trace_launch", [C.POINTER(TraceColumnsC), U64, V, V]), ("zkir_lde_launch", [V, V, U32, V, V]),
-                       ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V])]:
+                       ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V]), ("zkir_merkle_cap_launch", [V, V, U64, V])]:
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
@@ -310,6 +315,39 @@ class ExecutionResult:
         if not result_handle:
             self.execution_trace._r, self.execution_trace.n_rows, self.execution_trace.columns = None, 0, None
         self.delta_log = log
+
+    # -- the remaining ExecutionResult members (vm.rs:64-103), expanded on the device from the delta log's side logs --
+    def get_memory_trace(self) -> np.ndarray:
+        """ExecutionResult::get_memory_trace (vm.rs:85-94): every data-memory op, stably sorted by (timestamp, address, Read<Write).
+        Returns packed MemoryOp records (address, value, timestamp, is_write, width, bound_*)."""
+        from . import pipeline as pl
+        if self._log.n_rows == 0 or len(self._log.mem_events) == 0:
+            return np.zeros(0, dtype=_MEMOP_DTYPE)
+        return pl.memory_ops(self._log)[2].to_numpy()
+
+    def memory_op_count(self) -> int:
+        """ExecutionResult::memory_op_count (vm.rs:97-102)."""
+        return len(self._log.mem_events)
+
+    @property
+    def range_check_witnesses(self) -> list:
+        """Vec<RangeCheckWitness> (range_check.rs:209-238): one list of (value, chunks[4], pc) per non-empty checkpoint."""
+        from . import pipeline as pl
+        log = self._log
+        if len(log.rc_events) == 0:
+            return []
+        value, pc, chunks, _ = pl.range_checks(log)
+        v, p, c = value.cpu().numpy().view(np.uint64), pc.cpu().numpy().view(np.uint64), chunks.cpu().numpy().view(np.uint16).T
+        offs = log.rc_offsets
+        return [[(int(v[i]), [int(x) for x in c[i]], int(p[i])) for i in range(int(offs[k]), int(offs[k + 1]))] for k in range(len(offs) - 1)]
+
+    @property
+    def normalization_witnesses(self) -> np.ndarray:
+        """Vec<NormalizationEvent> (normalization_witness.rs:129-138) as packed records."""
+        from . import pipeline as pl
+        if len(self._log.norm_events) == 0:
+            return np.zeros(0, dtype=_NORM_DTYPE)
+        return pl.normalization_events(self._log)
 
     def close(self):
         if self._r:

@@ -77,6 +77,15 @@ def merkle_commit(ctx: StarkContext, mat: torch.Tensor, stream=None) -> torch.Te
     return tree
 
 
+def merkle_cap(ctx: StarkContext, digests: torch.Tensor, stream=None) -> torch.Tensor:
+    """Root over n (power of two) digests int32[n][4] — the all-gathered per-GPU subtree roots of a row-sharded commitment."""
+    n = digests.shape[0]
+    tree = torch.empty(4 * (2 * n - 1), dtype=torch.int32, device=digests.device)
+    tree[:4 * n] = digests.reshape(-1)
+    pl._check(rt.lib().zkir_merkle_cap_launch(ctx.handle, tree.data_ptr(), n, _sp(stream)))
+    return tree[-4:]
+
+
 def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None):
     """main trace -> LDE -> Merkle.  Returns (root np.uint32[4], lde matrix tensor, tree tensor)."""
     m = main_trace(trace, stream)
