@@ -24,8 +24,9 @@ constexpr uint32_t GEN = 31u;                // multiplicative generator, LDE co
 constexpr uint32_t ROOT27 = 0x1A427A41u;     // 31^15: primitive 2^27-th root of unity
 constexpr uint32_t W_EXT = 11u;              // X^4 = 11
 
-BB_HD uint32_t add(uint32_t a, uint32_t b) { const uint32_t s = a + b; return s >= P ? s - P : s; }
-BB_HD uint32_t sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
+// add/sub as (op, op, unsigned min): the wrong candidate always wraps around 2^32 and loses the min
+BB_HD uint32_t add(uint32_t a, uint32_t b) { const uint32_t s = a + b, d = s - P; return d < s ? d : s; }
+BB_HD uint32_t sub(uint32_t a, uint32_t b) { const uint32_t d = a - b, e = d + P; return e < d ? e : d; }
 BB_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 BB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
 BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
@@ -34,6 +35,52 @@ BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
   const uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);     // < 2p
   const uint32_t d = u - P;                                       // wraps above u when u < p
   return d < u ? d : u;                                           // min(u, u - p): 32-bit ops only
+}
+// ---- lazy helpers (gfx950: v_add/v_sub issue in ~2.3 cycles per wave, v_min/v_mul*/v_mad_u64 in ~4.2-4.5, measured with
+// scripts/ubench_alu.hip; a modular add is add+add+min = 8.7 cycles, so hot loops skip the reduction where a value only
+// feeds a Montgomery multiplication or a 64-bit accumulation) -------------------------------------------------------
+// mont_mul() accepts ONE operand below 2p when the other is canonical: t + m*p < 2p^2 + 2^32 p < 2^64 and u < 2p still holds.
+BB_HD uint32_t reduce_2p(uint32_t x) { const uint32_t d = x - P; return d < x ? d : x; }       // [0, 2p) -> [0, p)
+// Montgomery product WITHOUT the final conditional subtraction: result < a*b/2^32 + p.  With p/2^32 = 0.46875:
+//   a, b < p            -> result < 1.469 p
+//   a < 1.469 p, b < p  -> result < 1.689 p          (needs a*b + 2^32 p < 2^64 and the result below 2^32 = 2.133 p: both hold)
+BB_HD uint32_t mont_mul_lazy(uint32_t a, uint32_t b) {
+  const uint64_t t = (uint64_t)a * b;
+  const uint32_t m = (uint32_t)t * NEG_PINV;
+  return (uint32_t)((t + (uint64_t)m * P) >> 32);
+}
+// acc + K*x in 64 bits as ONE full-rate instruction on the device (v_mad_u64_u32 with an inline-constant multiplier);
+// takes the 32-bit x as it is, no zero-extended register pair needed
+template <int K>
+BB_HD uint64_t mad_wide(uint64_t acc, uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %2" : "=v"(r) : "v"(x), "v"(acc), "n"(K) : "vcc");
+  return r;
+#else
+  return acc + (uint64_t)K * x;
+#endif
+}
+BB_HD uint64_t acc_add(uint64_t acc, uint32_t x) { return mad_wide<1>(acc, x); }
+// canonical residue of a small multiple of p held in 64 bits: acc < 2^(32+S) and acc < 200 p.  With M = floor(2^(32+S) / p)
+// (34 for S = 4, 136 for S = 6) the estimate q = floor((acc >> S) * M / 2^32) never exceeds Q = floor(acc / p) and falls
+// short of acc / p by less than Q * 0.0039 + 2^-20 < 1, so q is Q or Q - 1: the remainder candidate is below 2p and fits 32 bits.
+// (The device multiply is spelled as an instruction: written in C++, LLVM proves acc >> S fits 32 bits, drops the truncation
+// and then emits a 64 x 32-bit product with a dead high half: two extra instructions per reduction.)
+BB_HD uint32_t mulhi_u32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+#else
+  return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+template <int S>
+BB_HD uint32_t reduce_wide(uint64_t acc) {
+  constexpr uint32_t M = (uint32_t)((1ull << (32 + S)) / P);
+  const uint32_t q = mulhi_u32((uint32_t)(acc >> S), M);
+  return reduce_2p((uint32_t)acc - q * P);
 }
 BB_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2); }
 BB_HD uint32_t from_mont(uint32_t a) { return mont_mul(a, 1u); }

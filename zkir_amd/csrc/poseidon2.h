@@ -19,6 +19,7 @@ struct Consts {              // Montgomery form
   uint32_t ext[RF][T];
   uint32_t in[RP];
   uint32_t diag[T];
+  uint32_t zero[T];
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -32,54 +33,76 @@ inline void generate(Consts& c) {
   auto next = [&]() -> uint32_t { for (;;) { const uint32_t v = (uint32_t)(splitmix64(s) >> 33); if (v < bb::P) return bb::to_mont(v); } };
   for (int r = 0; r < RF; r++) for (int i = 0; i < T; i++) c.ext[r][i] = next();
   for (int r = 0; r < RP; r++) c.in[r] = next();
+  for (int i = 0; i < T; i++) c.zero[i] = 0;
   c.diag[0] = bb::to_mont(bb::P - 2);
   for (int i = 1; i < T; i++) c.diag[i] = bb::to_mont(1u << (i - 1));
 }
 
-BB_HD uint32_t sbox(uint32_t x) { const uint32_t x2 = bb::mont_mul(x, x), x3 = bb::mont_mul(x2, x), x6 = bb::mont_mul(x3, x3); return bb::mont_mul(x6, x); }
+// x^7 for canonical x; only x^3 needs its reduction (it is squared), the other products stay within the lazy bounds of
+// bb::mont_mul_lazy: x2 < 1.469p, x3 < p, x6 < 1.469p, result < 1.689p.
+BB_HD uint32_t sbox_lazy(uint32_t x) {
+  const uint32_t x2 = bb::mont_mul_lazy(x, x), x3 = bb::mont_mul(x2, x), x6 = bb::mont_mul_lazy(x3, x3);
+  return bb::mont_mul_lazy(x6, x);
+}
+BB_HD uint32_t sbox(uint32_t x) { return bb::reduce_2p(sbox_lazy(x)); }
 
-// M4 * (a,b,c,d) with additions only: 5a+7b+c+3d, 4a+6b+c+d, a+3b+5c+7d, a+b+4c+6d
-BB_HD void m4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-  using namespace bb;
-  const uint32_t ab = add(a, b), cd = add(c, d);
-  const uint32_t a2 = dbl(a), b2 = dbl(b), c2 = dbl(c), d2 = dbl(d);
-  const uint32_t a4 = dbl(a2), b4 = dbl(b2), c4 = dbl(c2), d4 = dbl(d2);
-  const uint32_t y0 = add(add(add(a4, ab), add(b4, b2)), add(cd, d2));           // 5a + 7b + c + 3d
-  const uint32_t y1 = add(add(a4, add(b4, b2)), cd);                              // 4a + 6b + c + d
-  const uint32_t y2 = add(add(ab, b2), add(add(c4, cd), add(d4, d2)));            // a + 3b + 5c + 7d
-  const uint32_t y3 = add(ab, add(c4, add(d4, d2)));                              // a + b + 4c + 6d
-  a = y0; b = y1; c = y2; d = y3;
+// M4 * (a,b,c,d) = (5a+7b+c+3d, 4a+6b+c+d, a+3b+5c+7d, a+b+4c+6d) with 8 additions and 4 shifts (the evaluation order of the
+// Poseidon2 paper, appendix B), WITHOUT reductions, in 64 bits (outputs below 16 max(a,b,c,d)): on gfx950 every line is one
+// full-rate v_lshl_add_u64 / v_mad_u64_u32, against three instructions for a modular addition.  Inputs may be lazy.
+BB_HD void m4_wide(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint64_t* y) {
+  const uint64_t t0 = bb::acc_add(a, b), t1 = bb::acc_add(c, d);
+  const uint64_t t2 = bb::mad_wide<2>(t1, b), t3 = bb::mad_wide<2>(t0, d);
+  const uint64_t t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;                        // a + b + 4c + 6d ; 4a + 6b + c + d
+  y[0] = t3 + t5; y[1] = t5; y[2] = t2 + t4; y[3] = t4;
 }
-BB_HD void ext_linear(uint32_t* s) {
-  m4(s[0], s[1], s[2], s[3]); m4(s[4], s[5], s[6], s[7]); m4(s[8], s[9], s[10], s[11]);
-  uint32_t sum[4];
+// External linear layer circ(2*M4, M4, M4) followed by the addition of `rc` (the constants of the round that comes next, or
+// zeros); inputs below 1.689p (sbox_lazy), canonical out.  Every output is below 64 * 1.689p + p < 2^38 before its single reduction.
+BB_HD void ext_linear(uint32_t* s, const uint32_t* rc) {
+  uint64_t y[T];
+  m4_wide(s[0], s[1], s[2], s[3], y); m4_wide(s[4], s[5], s[6], s[7], y + 4); m4_wide(s[8], s[9], s[10], s[11], y + 8);
+  uint64_t sum[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) sum[j] = bb::add(bb::add(s[j], s[4 + j]), s[8 + j]);
+  for (int j = 0; j < 4; j++) sum[j] = y[j] + y[4 + j] + y[8 + j];
 #pragma unroll
-  for (int k = 0; k < T; k++) s[k] = bb::add(s[k], sum[k & 3]);
-}
-BB_HD void int_linear(uint32_t* s, const Consts& c) {
-  uint32_t sum = 0;
-#pragma unroll
-  for (int i = 0; i < T; i++) sum = bb::add(sum, s[i]);
-#pragma unroll
-  for (int i = 0; i < T; i++) s[i] = bb::add(sum, bb::mont_mul(s[i], c.diag[i]));
-}
-BB_HD void permute(uint32_t* s, const Consts& c) {
-  ext_linear(s);
-#pragma unroll 1
-  for (int r = 0; r < RF / 2; r++) {
-#pragma unroll
-    for (int i = 0; i < T; i++) s[i] = sbox(bb::add(s[i], c.ext[r][i]));
-    ext_linear(s);
+  for (int k = 0; k < T; k++) {
+    uint64_t v = y[k] + sum[k & 3];
+    v += rc[k];
+    s[k] = bb::reduce_wide<6>(v);
   }
+}
+// The 22 partial rounds: s[0] <- sbox(s[0] + rc); s[i] <- sum(s) + diag[i] * s[i] with diag = (-2, 1, 2, 4, ..., 1024).
+// s[1..11] stay LAZY (below 2p, unreduced) between rounds: they only feed the 64-bit sum and one Montgomery multiplication
+// by a canonical constant (both fine with a 2p operand), so `sum + product` is a bare 32-bit add.  s[0] is canonical throughout.
+BB_HD void int_rounds(uint32_t* s, const Consts& c) {
 #pragma unroll 1
-  for (int r = 0; r < RP; r++) { s[0] = sbox(bb::add(s[0], c.in[r])); int_linear(s, c); }
-#pragma unroll 1
-  for (int r = RF / 2; r < RF; r++) {
+  for (int r = 0; r < RP; r++) {
+    const uint32_t s0 = sbox(bb::add(s[0], c.in[r]));
+    uint64_t acc = s0;                                         // < p + 11 * 2p < 2^36
 #pragma unroll
-    for (int i = 0; i < T; i++) s[i] = sbox(bb::add(s[i], c.ext[r][i]));
-    ext_linear(s);
+    for (int i = 1; i < T; i++) acc = bb::acc_add(acc, s[i]);
+    const uint32_t sum = bb::reduce_wide<4>(acc);
+    s[0] = bb::sub(sum, bb::dbl(s0));
+    s[1] = sum + bb::reduce_2p(s[1]);
+#pragma unroll
+    for (int i = 2; i < T; i++) s[i] = sum + bb::mont_mul(s[i], c.diag[i]);
+  }
+#pragma unroll
+  for (int i = 1; i < T; i++) s[i] = bb::reduce_2p(s[i]);
+}
+// Each linear layer adds the constants of the round that FOLLOWS it while the values are still wide (one 64-bit add instead
+// of a modular one); the layers closing each half add zeros so that the round loop stays a single code path.
+BB_HD void permute(uint32_t* s, const Consts& c) {
+  ext_linear(s, c.ext[0]);
+#pragma unroll 1
+  for (int r = 0; r < RF; r++) {
+    if (r == RF / 2) {
+      int_rounds(s, c);
+#pragma unroll
+      for (int i = 0; i < T; i++) s[i] = bb::add(s[i], c.ext[RF / 2][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < T; i++) s[i] = sbox_lazy(s[i]);
+    ext_linear(s,(r == RF / 2 - 1 || r == RF - 1) ? c.zero : c.ext[r + 1]);
   }
 }
 
