@@ -26,7 +26,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# Montgomery multiplications in one Poseidon2-12 permutation as implemented (poseidon2.h): 4 per S-box x (8 x 12 + 22) S-boxes
+# + 10 diagonal products x 22 partial rounds (diag entries 1 and the -2 of lane 0 need none)
+MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 10 * 22
 W = 89
+
+
+def _strided_passes(stages: int) -> int:
+    """Number of strided NTT launches zkir::lde_run (ntt.hip, run_strided_stages) makes for `stages` radix-2 stages."""
+    cnt = 0
+    while stages > 0:
+        r = min(5, stages // 2)
+        if stages - 2 * r == 1 and r == 5:
+            r = 4
+        stages -= 2 * r if r else 1
+        cnt += 1
+    return cnt
 
 
 def main():
@@ -164,15 +179,15 @@ def main():
         kernels = {"trace_fill": {"bound": "hbm", "bytes": fill_bytes, "ms": stage_ms["trace_fill"]}}
         if commit:
             #   main_trace: reads the 372 B/row trace once (+ the next-row re-read served by L2), writes 89 u32 columns
-            #   lde: per column 2 strided inverse passes (8 B/elem over N) + fused middle (4N read + 8N written)
-            #        + 2 strided forward passes (8 B/elem over 2N)   [k >= 16; fewer passes below]
+            #   lde: per column `n_inv` strided inverse passes (8 B/elem over N; one radix-4 pass covers up to ten
+            #        stages) + fused middle (4N read + 8N written) + as many strided forward passes (8 B/elem over 2N)
             #   merkle: reads the LDE matrix once, writes 16 B per node; ALU-bound (Poseidon2), bytes given for completeness
-            n_inv = -(-max(k - 10, 0) // 5)
+            n_inv = _strided_passes(max(k - 10, 0))
             kernels["main_trace"] = {"bound": "hbm", "bytes": (372 + 4 * W) * n, "ms": stage_ms["main_trace"]}
             kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
             perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
             modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
-            modmul = perms * 736 / (stage_ms["merkle"] * 1e-3)
+            modmul = perms * MONT_MUL_PER_PERM / (stage_ms["merkle"] * 1e-3)
             kernels["merkle"] = {"bound": "int-alu", "bytes": 4 * W * 2 * n + 16 * (4 * n - 1), "ms": stage_ms["merkle"],
                                  "poseidon2_perms_per_s": perms / (stage_ms["merkle"] * 1e-3),
                                  "mont_mul_per_s": modmul, "mont_mul_peak_per_s_measured": modmul_peak,
@@ -198,8 +213,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernels[dom]["ms"],
                          "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
-                         "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (≈736 Montgomery multiplications per "
-                                  "permutation), not HBM- or MFMA-bound; see roofline_by_stage for its ALU rate and for the HBM-bound stages")
+                         "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (692 Montgomery multiplications + 130 wide reductions per "
+                                  "permutation; VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see roofline_by_stage for its ALU rate and for the HBM-bound stages")
                          if kernels[dom]["bound"] != "hbm" else None},
             "roofline_by_stage": kernels,
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,

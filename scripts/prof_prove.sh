@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the end-to-end prover (scripts/time_prove.py) -> gpurun_out/prof_prove/summary_kernel_stats.txt
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_prove; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o c -- python $R/scripts/time_prove.py ${1:-20} > $OUT/stdout.log 2>&1
+python - <<PY
+import sqlite3, glob
+c = sqlite3.connect(sorted(glob.glob("$OUT/kt/*.db"))[0])
+rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 30").fetchall()
+with open("$OUT/summary_kernel_stats.txt", "w") as f:
+    for name, calls, total, avg, pct in rows:
+        s = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+        line = f"{s:70s} {calls:6d} {total/1e3:12.1f} us {avg/1e3:10.2f} us {pct:6.2f}%"
+        print(line); f.write(line + "\n")
+PY

@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for `python bench.py` (run on the GPU box via gpurun). Usage: profile_bench.sh <round-tag>
+# Counter passes are separate runs with --kernel-trace only (never combined with other trace domains).
 export TMPDIR=/tmp
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT; cd /tmp
@@ -8,5 +9,7 @@ python $R/bench.py --stage trace_fill --steps 200 --warmup 20 --no-cpu-baseline 
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o b -- python $R/bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pf.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pw.log 2>&1
-python $R/scripts/extract_prof.py $OUT $OUT/summary trace_fill main_trace lde_middle ntt_strided leaf_hash compress | cut -c1-150
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_valu -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pv.log 2>&1
+python $R/scripts/extract_prof.py $OUT $OUT/summary trace_fill main_trace lde_middle ntt_strided leaf_hash compress subtree | cut -c1-150
+python $R/scripts/extract_valu.py $OUT/pmc_valu $OUT/summary_valu_busy.txt
 head -c 1500 $OUT/bench.json; echo; tail -3 $OUT/bench.err

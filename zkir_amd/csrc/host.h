@@ -103,4 +103,16 @@ void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
 void blake3(const uint8_t* data, size_t len, uint8_t out[32]);
 
 void set_last_error(const Status& st);
+
+// ntt.hip — coset LDE of `width` columns (device pointers; tables owned by zkir_stark_ctx, all in Montgomery form)
+struct LdeTables {
+  int log_n;
+  const uint32_t* tw_inv;     // w_N^-k, k < N/2
+  const uint32_t* tw_fwd;     // w_{2N}^k, k < N
+  const uint32_t* g_lo;       // g^k / N, k < 1024
+  const uint32_t* g_hi;       // g^(1024 k)
+  const uint32_t* small_inv;  // w_{2^Bm}^-k, k < 2^(Bm-1)      (Bm = min(log_n, 10))
+  const uint32_t* small_fwd;  // w_{2^(Bm+1)}^k, k < 2^Bm
+};
+void lde_run(const LdeTables& t, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);
 }  // namespace zkir
