@@ -49,6 +49,13 @@ BB_HD uint32_t mont_mul_lazy(uint32_t a, uint32_t b) {
   const uint32_t m = (uint32_t)t * NEG_PINV;
   return (uint32_t)((t + (uint64_t)m * P) >> 32);
 }
+// (a*b + c) / R mod p, lazy: the 64-bit multiply-add takes the addend for free, so mont(a, b) + c/R costs the three instructions
+// of the product alone.  a < 2p, b < p, c < 2^32: a*b + c + 2^32 p < 2^64 and the result is below a*b/2^32 + p + 1 (< 2p).
+BB_HD uint32_t mont_mul_add_lazy(uint32_t a, uint32_t b, uint32_t c) {
+  const uint64_t t = (uint64_t)a * b + c;
+  const uint32_t m = (uint32_t)t * NEG_PINV;
+  return (uint32_t)((t + (uint64_t)m * P) >> 32);
+}
 // acc + K*x in 64 bits as ONE full-rate instruction on the device (v_mad_u64_u32 with an inline-constant multiplier);
 // takes the 32-bit x as it is, no zero-extended register pair needed
 template <int K>

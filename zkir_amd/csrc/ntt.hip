@@ -221,22 +221,23 @@ __global__ __launch_bounds__(NT) void lde_middle_kernel(const uint32_t* __restri
 }
 
 // Same computation for Bm = 10, with register-resident radix-4 butterflies: every round does TWO radix-2 stages on 4 values held
-// in registers, so the 10 inverse + 10 forward stages need 10 LDS round trips / barriers instead of 21, each lane has 4-8
-// independent multiplications in flight, and only one twiddle per quad is read (the others are its square and its product with
-// a 4th root of unity).  A = LDS[0,1024): inverse part; Bf = LDS[1024, 3072): forward part (zero-interleaved, stage 0 = copy).
-__global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __restrict__ in, uint64_t in_stride, uint32_t* __restrict__ out, uint64_t out_stride, int L,
-                                                            const uint32_t* __restrict__ small_inv, const uint32_t* __restrict__ small_fwd,
+// in registers, so the 10 inverse + 10 forward stages need 10 LDS round trips / barriers instead of 21, and only one twiddle per
+// quad is read (the others are its square and its product with a 4th root of unity).  A workgroup works on the same chunk of NC
+// columns: the kernel is VALU-bound (rocprofv3: VALUBusy 92 % with one column), and the index arithmetic, twiddles and coset
+// scale factors are the same for every column, so they are computed once per quad and reused NC times.
+// A = inverse part (1024 words per column); Bf = forward part (2048 words per column, zero-interleaved, stage 0 = copy).
+template <int NC>
+__global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __restrict__ in, uint64_t in_stride, uint32_t* __restrict__ out, uint64_t out_stride,
+                                                            uint32_t width, int L, const uint32_t* __restrict__ small_inv, const uint32_t* __restrict__ small_fwd,
                                                             const uint32_t* __restrict__ g_lo, const uint32_t* __restrict__ g_hi, uint32_t j4_inv_m, uint32_t j4_fwd_m) {
   constexpr int Bm = 10;
-  __shared__ uint32_t A[1024];
-  __shared__ uint32_t Bf[2048];
-  const uint32_t* x = in + (uint64_t)blockIdx.y * in_stride;
-  uint32_t* y = out + (uint64_t)blockIdx.y * out_stride;
+  __shared__ uint32_t A[NC][1024];
+  __shared__ uint32_t Bf[NC][2048];
+  const uint32_t col0 = blockIdx.y * NC;
   const uint32_t base = blockIdx.x << Bm, q = threadIdx.x;
-  {
-    const uint4 v = reinterpret_cast<const uint4*>(x + base)[q];
-    reinterpret_cast<uint4*>(A)[q] = v;
-  }
+#pragma unroll
+  for (int c = 0; c < NC; c++)
+    if (col0 + c < width) reinterpret_cast<uint4*>(A[c])[q] = reinterpret_cast<const uint4*>(in + (uint64_t)(col0 + c) * in_stride + base)[q];
   __syncthreads();
   // ---- inverse DIF, rounds r = 0..4: stages (2r, 2r+1), spans h1 = 2^(9-2r), h2 = h1/2 ----
 #pragma unroll
@@ -244,22 +245,26 @@ __global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __res
     const int lg = 8 - 2 * r;                                  // log2(h2)
     const uint32_t h2 = 1u << lg, lo = q & (h2 - 1), hi = q >> lg;
     const uint32_t i0 = (hi << (lg + 2)) | lo;
-    const uint32_t x0 = A[i0], x1 = A[i0 + h2], x2 = A[i0 + 2 * h2], x3 = A[i0 + 3 * h2];
     const uint32_t wA = small_inv[lo << (2 * r)];              // w_1024^-(lo << 2r)
     const uint32_t wB = bb::mont_mul(wA, j4_inv_m), w2 = bb::mont_mul(wA, wA);
-    const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub(x0, x2), wA);
-    const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub(x1, x3), wB);
-    uint32_t z0 = bb::add(y0, y1), z1 = bb::mont_mul(bb::sub(y0, y1), w2);
-    uint32_t z2 = bb::add(y2, y3), z3 = bb::mont_mul(bb::sub(y2, y3), w2);
-    if (r == 4) {                                              // last round (positions 4q..4q+3): fold in the coset scale g^k / N, k = bitrev_L(position)
+    uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    if (r == 4) {                                              // last round (positions 4q..4q+3): the coset scale g^k / N, k = bitrev_L(position)
       const uint32_t p0 = base + i0;
       const uint32_t k0 = bitrev(p0, L), k1 = bitrev(p0 + 1, L), k2 = bitrev(p0 + 2, L), k3 = bitrev(p0 + 3, L);
-      z0 = bb::mont_mul(bb::mont_mul(z0, g_lo[k0 & 1023]), g_hi[k0 >> 10]);
-      z1 = bb::mont_mul(bb::mont_mul(z1, g_lo[k1 & 1023]), g_hi[k1 >> 10]);
-      z2 = bb::mont_mul(bb::mont_mul(z2, g_lo[k2 & 1023]), g_hi[k2 >> 10]);
-      z3 = bb::mont_mul(bb::mont_mul(z3, g_lo[k3 & 1023]), g_hi[k3 >> 10]);
+      g0 = bb::mont_mul(g_lo[k0 & 1023], g_hi[k0 >> 10]); g1 = bb::mont_mul(g_lo[k1 & 1023], g_hi[k1 >> 10]);
+      g2 = bb::mont_mul(g_lo[k2 & 1023], g_hi[k2 >> 10]); g3 = bb::mont_mul(g_lo[k3 & 1023], g_hi[k3 >> 10]);
     }
-    A[i0] = z0; A[i0 + h2] = z1; A[i0 + 2 * h2] = z2; A[i0 + 3 * h2] = z3;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      uint32_t* a = A[c];
+      const uint32_t x0 = a[i0], x1 = a[i0 + h2], x2 = a[i0 + 2 * h2], x3 = a[i0 + 3 * h2];
+      const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub(x0, x2), wA);
+      const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub(x1, x3), wB);
+      uint32_t z0 = bb::add(y0, y1), z1 = bb::mont_mul(bb::sub(y0, y1), w2);
+      uint32_t z2 = bb::add(y2, y3), z3 = bb::mont_mul(bb::sub(y2, y3), w2);
+      if (r == 4) { z0 = bb::mont_mul(z0, g0); z1 = bb::mont_mul(z1, g1); z2 = bb::mont_mul(z2, g2); z3 = bb::mont_mul(z3, g3); }
+      a[i0] = z0; a[i0 + h2] = z1; a[i0 + 2 * h2] = z2; a[i0 + 3 * h2] = z3;
+    }
     __syncthreads();
   }
   // ---- forward DIT of the zero-interleaved chunk (2048 points): stage 0 is a copy, rounds do stages (s, s+1), s = 1,3,5,7,9 ----
@@ -271,22 +276,28 @@ __global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __res
       const uint32_t qq = q + t * NT;                          // 512 quads
       const uint32_t lo = qq & ((1u << s) - 1), hi = qq >> s;
       const uint32_t i0 = (hi << (s + 2)) | lo, d = 1u << s;
-      uint32_t x0, x1, x2, x3;
-      if (r == 0) { x0 = A[i0 >> 1]; x1 = A[(i0 + d) >> 1]; x2 = A[(i0 + 2 * d) >> 1]; x3 = A[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
-      else { x0 = Bf[i0]; x1 = Bf[i0 + d]; x2 = Bf[i0 + 2 * d]; x3 = Bf[i0 + 3 * d]; }
       const uint32_t w2 = small_fwd[lo << (Bm - s - 1)];       // w_2048^(lo << (9-s)): twiddle of stage s+1
       const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_fwd_m);
-      const uint32_t t1 = bb::mont_mul(x1, w1), t3 = bb::mont_mul(x3, w1);
-      const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add(x2, t3), y3 = bb::sub(x2, t3);
-      const uint32_t u2 = bb::mont_mul(y2, w2), u3 = bb::mont_mul(y3, w2i);
-      Bf[i0] = bb::add(y0, u2); Bf[i0 + 2 * d] = bb::sub(y0, u2); Bf[i0 + d] = bb::add(y1, u3); Bf[i0 + 3 * d] = bb::sub(y1, u3);
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        uint32_t* bf = Bf[c];
+        uint32_t x0, x1, x2, x3;
+        if (r == 0) { const uint32_t* a = A[c]; x0 = a[i0 >> 1]; x1 = a[(i0 + d) >> 1]; x2 = a[(i0 + 2 * d) >> 1]; x3 = a[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
+        else { x0 = bf[i0]; x1 = bf[i0 + d]; x2 = bf[i0 + 2 * d]; x3 = bf[i0 + 3 * d]; }
+        const uint32_t t1 = bb::mont_mul(x1, w1), t3 = bb::mont_mul(x3, w1);
+        const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add(x2, t3), y3 = bb::sub(x2, t3);
+        const uint32_t u2 = bb::mont_mul(y2, w2), u3 = bb::mont_mul(y3, w2i);
+        bf[i0] = bb::add(y0, u2); bf[i0 + 2 * d] = bb::sub(y0, u2); bf[i0 + d] = bb::add(y1, u3); bf[i0 + 3 * d] = bb::sub(y1, u3);
+      }
     }
     __syncthreads();
   }
-  {
-    uint4* dst = reinterpret_cast<uint4*>(y + 2 * base);
-    dst[q] = reinterpret_cast<const uint4*>(Bf)[q];
-    dst[q + NT] = reinterpret_cast<const uint4*>(Bf)[q + NT];
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if (col0 + c >= width) break;
+    uint4* dst = reinterpret_cast<uint4*>(out + (uint64_t)(col0 + c) * out_stride + 2 * base);
+    dst[q] = reinterpret_cast<const uint4*>(Bf[c])[q];
+    dst[q + NT] = reinterpret_cast<const uint4*>(Bf[c])[q + NT];
   }
 }
 
@@ -304,8 +315,9 @@ void lde_run(const LdeTables& t, uint32_t* in, uint32_t width, uint32_t* out, vo
   // inverse DIF strided stages 0 .. L-Bm-1 (only when L > 10; the compact table then has order 2^Bm = 1024)
   run_strided_stages<false>(in, N, width, L, 0, L - Bm, t.tw_inv, t.small_inv, Bm, j4_inv_m, s);
   if (Bm == 10) {
-    hipLaunchKernelGGL(lde_middle_r4_kernel, dim3(N >> Bm, width), dim3(NT), 0, s, in, (uint64_t)N, out, (uint64_t)2 * N, L, t.small_inv, t.small_fwd, t.g_lo, t.g_hi,
-                       j4_inv_m, j4_fwd_m);
+    constexpr int NC = 1;
+    hipLaunchKernelGGL(lde_middle_r4_kernel<NC>, dim3(N >> Bm, (width + NC - 1) / NC), dim3(NT), 0, s, in, (uint64_t)N, out, (uint64_t)2 * N, width, L, t.small_inv, t.small_fwd,
+                       t.g_lo, t.g_hi, j4_inv_m, j4_fwd_m);
   } else {
     hipLaunchKernelGGL(lde_middle_kernel, dim3(N >> Bm, width), dim3(NT), (8u << Bm), s, in, (uint64_t)N, out, (uint64_t)2 * N, L, Bm, t.small_inv, t.small_fwd, t.g_lo, t.g_hi);
   }

@@ -7,7 +7,16 @@
 // Round constants: SplitMix64 seeded with the ASCII bytes "ZKIR-P2-", top 31 bits of each output, rejection-sampled below p,
 // 96 external then 22 internal.  A demonstrator instance (rate 8 / capacity 4 => ~62-bit collision resistance), not a vetted one.
 //
-// All state words handled here are in MONTGOMERY form.
+// All state words handled here are in MONTGOMERY form.  The function computed is exactly the textbook permutation (the oracle,
+// oracle/stark_oracle.cpp, implements it naively and every kernel is compared with it bit for bit); what is specific to gfx950
+// is HOW: the hash kernels sit at ~100 % VALU issue utilisation (profiles/*_valu_busy.txt), so the formulation minimises the
+// instruction count —
+//   * linear layers in 64 bits without intermediate reductions (v_lshl_add_u64 / v_mad_u64_u32 are single full-rate
+//     instructions), one Barrett reduction per output;
+//   * Montgomery products without their final conditional subtraction wherever the bounds allow ("lazy", see babybear.h);
+//   * additions folded into the 64-bit addend of a Montgomery product: (a*b + c) / R = mont(a, b) + c / R costs nothing extra.
+//     The partial rounds add the column sum that way, the full rounds add the NEXT round's constants pulled back through the
+//     linear layer (pre[r] = M_ext^-1 * ext[r + 1], computed once by generate()).
 #pragma once
 #include "babybear.h"
 
@@ -15,11 +24,11 @@ namespace p2 {
 
 constexpr int T = 12, RF = 8, RP = 22, RATE = 8, DIGEST = 4;
 
-struct Consts {              // Montgomery form
+struct Consts {              // Montgomery form unless noted
   uint32_t ext[RF][T];
   uint32_t in[RP];
   uint32_t diag[T];
-  uint32_t zero[T];
+  uint32_t pre[RF][T];       // (M_ext^-1 * ext[r + 1]) * R^2 mod p: addend of the last S-box product of full round r; zero for r = 3, 7
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -28,21 +37,54 @@ inline uint64_t splitmix64(uint64_t& s) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+
+// inverse of the external matrix circ(2*M4, M4, M4) over F_p (canonical entries), Gauss-Jordan; cold path
+inline void ext_matrix_inverse(uint32_t inv[T][T]) {
+  static const uint32_t M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+  uint32_t a[T][2 * T];
+  for (int i = 0; i < T; i++)
+    for (int j = 0; j < T; j++) {
+      a[i][j] = M4[i & 3][j & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u);
+      a[i][T + j] = i == j;
+    }
+  for (int col = 0; col < T; col++) {
+    int piv = col;
+    while (a[piv][col] == 0) piv++;                             // the matrix is invertible (MDS-derived), a pivot exists
+    for (int j = 0; j < 2 * T; j++) { const uint32_t t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+    const uint32_t pinv = bb::inv(a[col][col]);
+    for (int j = 0; j < 2 * T; j++) a[col][j] = bb::mul(a[col][j], pinv);
+    for (int i = 0; i < T; i++) {
+      if (i == col || a[i][col] == 0) continue;
+      const uint32_t f = a[i][col];
+      for (int j = 0; j < 2 * T; j++) a[i][j] = bb::sub(a[i][j], bb::mul(f, a[col][j]));
+    }
+  }
+  for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) inv[i][j] = a[i][T + j];
+}
+
 inline void generate(Consts& c) {
   uint64_t s = 0x5A4B49522D50322Dull;
   auto next = [&]() -> uint32_t { for (;;) { const uint32_t v = (uint32_t)(splitmix64(s) >> 33); if (v < bb::P) return bb::to_mont(v); } };
   for (int r = 0; r < RF; r++) for (int i = 0; i < T; i++) c.ext[r][i] = next();
   for (int r = 0; r < RP; r++) c.in[r] = next();
-  for (int i = 0; i < T; i++) c.zero[i] = 0;
   c.diag[0] = bb::to_mont(bb::P - 2);
   for (int i = 1; i < T; i++) c.diag[i] = bb::to_mont(1u << (i - 1));
+  uint32_t minv[T][T];
+  ext_matrix_inverse(minv);
+  for (int r = 0; r < RF; r++)
+    for (int i = 0; i < T; i++) {
+      uint32_t v = 0;
+      if (r != RF / 2 - 1 && r != RF - 1)
+        for (int j = 0; j < T; j++) v = bb::add(v, bb::mul(minv[i][j], bb::from_mont(c.ext[r + 1][j])));
+      c.pre[r][i] = bb::to_mont(bb::to_mont(v));
+    }
 }
 
 // x^7 for canonical x; only x^3 needs its reduction (it is squared), the other products stay within the lazy bounds of
-// bb::mont_mul_lazy: x2 < 1.469p, x3 < p, x6 < 1.469p, result < 1.689p.
-BB_HD uint32_t sbox_lazy(uint32_t x) {
+// bb::mont_mul_lazy: x2 < 1.469p, x3 < p, x6 < 1.469p, result < 1.689p.  `addend` (canonical, = v * R^2) adds v * R for free.
+BB_HD uint32_t sbox_lazy(uint32_t x, uint32_t addend = 0) {
   const uint32_t x2 = bb::mont_mul_lazy(x, x), x3 = bb::mont_mul(x2, x), x6 = bb::mont_mul_lazy(x3, x3);
-  return bb::mont_mul_lazy(x6, x);
+  return bb::mont_mul_add_lazy(x6, x, addend);
 }
 BB_HD uint32_t sbox(uint32_t x) { return bb::reduce_2p(sbox_lazy(x)); }
 
@@ -55,8 +97,9 @@ BB_HD void m4_wide(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint64_t* y) 
   const uint64_t t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;                        // a + b + 4c + 6d ; 4a + 6b + c + d
   y[0] = t3 + t5; y[1] = t5; y[2] = t2 + t4; y[3] = t4;
 }
-// External linear layer circ(2*M4, M4, M4) followed by the addition of `rc` (the constants of the round that comes next, or
-// zeros); inputs below 1.689p (sbox_lazy), canonical out.  Every output is below 64 * 1.689p + p < 2^38 before its single reduction.
+// External linear layer circ(2*M4, M4, M4), optionally followed by the addition of `rc`; inputs below 1.689p + 1 (sbox_lazy),
+// canonical out.  Every output is below 64 * 1.69p + p < 2^38 before its single reduction.
+template <bool ADD_RC>
 BB_HD void ext_linear(uint32_t* s, const uint32_t* rc) {
   uint64_t y[T];
   m4_wide(s[0], s[1], s[2], s[3], y); m4_wide(s[4], s[5], s[6], s[7], y + 4); m4_wide(s[8], s[9], s[10], s[11], y + 8);
@@ -66,13 +109,13 @@ BB_HD void ext_linear(uint32_t* s, const uint32_t* rc) {
 #pragma unroll
   for (int k = 0; k < T; k++) {
     uint64_t v = y[k] + sum[k & 3];
-    v += rc[k];
+    if (ADD_RC) v += rc[k];
     s[k] = bb::reduce_wide<6>(v);
   }
 }
 // The 22 partial rounds: s[0] <- sbox(s[0] + rc); s[i] <- sum(s) + diag[i] * s[i] with diag = (-2, 1, 2, 4, ..., 1024).
 // s[1..11] stay LAZY (below 2p, unreduced) between rounds: they only feed the 64-bit sum and one Montgomery multiplication
-// by a canonical constant (both fine with a 2p operand), so `sum + product` is a bare 32-bit add.  s[0] is canonical throughout.
+// by a canonical constant, and that multiplication adds the sum on its way: (s[i] * diag[i] + sum * R) / R.  s[0] is canonical.
 BB_HD void int_rounds(uint32_t* s, const Consts& c) {
 #pragma unroll 1
   for (int r = 0; r < RP; r++) {
@@ -81,18 +124,16 @@ BB_HD void int_rounds(uint32_t* s, const Consts& c) {
 #pragma unroll
     for (int i = 1; i < T; i++) acc = bb::acc_add(acc, s[i]);
     const uint32_t sum = bb::reduce_wide<4>(acc);
+    const uint32_t sum_r = bb::mont_mul_lazy(sum, bb::R2);     // sum * R mod p, below 1.469p
     s[0] = bb::sub(sum, bb::dbl(s0));
-    s[1] = sum + bb::reduce_2p(s[1]);
 #pragma unroll
-    for (int i = 2; i < T; i++) s[i] = sum + bb::mont_mul(s[i], c.diag[i]);
+    for (int i = 1; i < T; i++) s[i] = bb::mont_mul_add_lazy(s[i], c.diag[i], sum_r);      // < 1.9375p + 1
   }
 #pragma unroll
   for (int i = 1; i < T; i++) s[i] = bb::reduce_2p(s[i]);
 }
-// Each linear layer adds the constants of the round that FOLLOWS it while the values are still wide (one 64-bit add instead
-// of a modular one); the layers closing each half add zeros so that the round loop stays a single code path.
 BB_HD void permute(uint32_t* s, const Consts& c) {
-  ext_linear(s, c.ext[0]);
+  ext_linear<true>(s, c.ext[0]);
 #pragma unroll 1
   for (int r = 0; r < RF; r++) {
     if (r == RF / 2) {
@@ -101,8 +142,8 @@ BB_HD void permute(uint32_t* s, const Consts& c) {
       for (int i = 0; i < T; i++) s[i] = bb::add(s[i], c.ext[RF / 2][i]);
     }
 #pragma unroll
-    for (int i = 0; i < T; i++) s[i] = sbox_lazy(s[i]);
-    ext_linear(s,(r == RF / 2 - 1 || r == RF - 1) ? c.zero : c.ext[r + 1]);
+    for (int i = 0; i < T; i++) s[i] = sbox_lazy(s[i], c.pre[r][i]);
+    ext_linear<false>(s, nullptr);
   }
 }
 
