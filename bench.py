@@ -234,7 +234,7 @@ def main():
                       f"faithful O(N^2) mode (vm.rs:287-298): {nf} rows in {dtf:.2f} s = {nf / dtf:.3g} rows/s")
             cpu_value = nn / dt
             if commit:
-                kc = 14
+                kc = 18                                         # ~15 s of single-core work (oracle NTT + Poseidon2)
                 rows = oracle.run(blob, max_cycles=1 << kc, enable_execution_trace=True).rows
                 t0 = time.perf_counter()
                 so.commit_trace(rows, 1)

@@ -52,7 +52,12 @@ def main():
             if "FillFunctor" in s:
                 cal.append(f"{counter} calibration: {s} reported {avg} KB")
     for s, t in traffic.items():
-        fetch = t.get("FETCH_SIZE_KB_avg", 0.0) * 1024 * 2          # gfx950: FETCH_SIZE counts 128-B requests at 64 B
+        # gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 for wide coalesced reads.  The strided NTT passes read 64-B
+        # runs (16 consecutive words per tile row, C = 4): their requests are counted in full (the raw value equals the
+        # algorithmic 4 B/element exactly), so no correction there.
+        factor = 1 if "ntt_strided" in s else 2
+        t["fetch_correction_factor"] = factor
+        fetch = t.get("FETCH_SIZE_KB_avg", 0.0) * 1024 * factor
         write = t.get("WRITE_SIZE_KB_avg", 0.0) * 1024
         t["hbm_read_bytes_corrected"] = fetch
         t["hbm_write_bytes"] = write

@@ -10,6 +10,6 @@ rows = c.execute("select name,total_calls,total_duration,average,percentage from
 with open("$OUT/summary_kernel_stats.txt", "w") as f:
     for name, calls, total, avg, pct in rows:
         s = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
-        line = f"{s:70s} {calls:6d} {total/1e3:12.1f} us {avg/1e3:10.2f} us {pct:6.2f}%"
+        line = f"{s:70s} {calls:6d} {total:12.1f} us {avg:10.2f} us {pct:6.2f}%"
         print(line); f.write(line + "\n")
 PY
