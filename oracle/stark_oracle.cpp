@@ -212,8 +212,20 @@ static void merkle_build(const std::vector<F>& mat, int width, size_t n, Merkle&
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v0)
 // =================================================================================================
-static const int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 1;   // "ZKPF"
+static const int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103, LOG_ARITY = 3;
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 2;   // "ZKPF"; v2: FRI layers are committed every LOG_ARITY folds
+
+// FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
+// before the next commitment.  Layer 0 (the DEEP codeword) is folded once, so that its leaves are the pairs (q, q + N) the trace
+// and quotient openings determine; every later layer is folded LOG_ARITY times (less at the end, to land on 2^LOG_FINAL values).
+static std::vector<int> fri_schedule(int log_n) {
+  std::vector<int> ks;
+  for (int log_m = log_n + 1; log_m > LOG_FINAL;) {
+    const int k = ks.empty() ? 1 : std::min(LOG_ARITY, log_m - LOG_FINAL);
+    ks.push_back(k); log_m -= k;
+  }
+  return ks;
+}
 
 // ---- duplex challenger over Poseidon2-12 (rate 8): overwrite-absorb, squeeze from the end of the rate ----
 struct Challenger {
@@ -349,23 +361,29 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
   // ---- FRI commit phase ----
   pt.fri.clear(); pt.fri_trees.clear(); pt.betas.clear();
   pt.fri.push_back(cw);
+  const std::vector<int> ks = fri_schedule(log_n);
   F shift = GEN; int log_m = log_n + 1;
-  while (log_m > LOG_FINAL) {
+  for (const int k : ks) {
     const std::vector<E>& c = pt.fri.back();
-    const size_t m = c.size(), h = m / 2;
-    std::vector<F> mat(8 * h);                                            // leaf i = (c[i], c[i+h]) as 8 base elements, column-major [8][h]
-    for (size_t i = 0; i < h; i++) for (int t = 0; t < 4; t++) { mat[(size_t)t * h + i] = c[i].c[t]; mat[(size_t)(4 + t) * h + i] = c[i + h].c[t]; }
-    Merkle tr; merkle_build(mat, 8, h, tr);
+    const size_t m = c.size(), g = m >> k, nv = (size_t)1 << k;              // g leaves of 2^k values: leaf i = (c[i + t g])_t
+    std::vector<F> mat(4 * nv * g);                                         // 4 * 2^k base elements per leaf, column-major [4 * 2^k][g]
+    for (size_t i = 0; i < g; i++) for (size_t t = 0; t < nv; t++) for (int e = 0; e < 4; e++) mat[(t * 4 + e) * g + i] = c[i + t * g].c[e];
+    Merkle tr; merkle_build(mat, (int)(4 * nv), g, tr);
     ch.observe_n(tr.layers.back().data(), 4);
-    const E beta = ch.sample_ext();
+    E beta = ch.sample_ext();
     pt.betas.push_back(beta);
-    std::vector<E> nx(h);
-    const F wm = root_of_unity(log_m);
-    F x = shift;
-    for (size_t i = 0; i < h; i++) { nx[i] = fold_pair(c[i], c[i + h], x, beta); x = fmul(x, wm); }
+    std::vector<E> cur = c;
+    for (int f = 0; f < k; f++) {                                           // binary folds with beta^(2^f); the domain shift squares each time
+      const size_t h = cur.size() / 2;
+      std::vector<E> nx(h);
+      const F wm = root_of_unity(log_m);
+      F x = shift;
+      for (size_t i = 0; i < h; i++) { nx[i] = fold_pair(cur[i], cur[i + h], x, beta); x = fmul(x, wm); }
+      cur.swap(nx);
+      shift = fmul(shift, shift); log_m--; beta = emul(beta, beta);
+    }
     pt.fri_trees.push_back(std::move(tr));
-    pt.fri.push_back(std::move(nx));
-    shift = fmul(shift, shift); log_m--;
+    pt.fri.push_back(std::move(cur));
   }
   const std::vector<E>& fin = pt.fri.back();
   for (const E& e : fin) ch.observe_ext(e);
@@ -388,8 +406,8 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wm; k++) w.push_back(pt.L[(size_t)k * N2 + pos]); merkle_path(pt.trace_tree, pos, w); }
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int i = 0; i < 4; i++) w.push_back(pt.Qc[(size_t)i * N2 + pos]); merkle_path(pt.quot_tree, pos, w); }
     for (size_t j = 0; j < pt.fri_trees.size(); j++) {
-      const size_t h = pt.fri[j].size() / 2, idx = q & (h - 1);
-      put_e(w, pt.fri[j][idx]); put_e(w, pt.fri[j][idx + h]);
+      const size_t g = pt.fri[j].size() >> ks[j], idx = q & (g - 1);
+      for (size_t t = 0; t < ((size_t)1 << ks[j]); t++) put_e(w, pt.fri[j][idx + t * g]);
       merkle_path(pt.fri_trees[j], idx, w);
     }
   }
@@ -419,7 +437,8 @@ static int verify(const uint32_t* w, size_t len) {
   for (int i = 0; i < 4; i++) { q_z[i] = get_e(p); p += 4; }
   if (!need(1)) return 4;
   const int n_layers = w[p++];
-  if (n_layers != log_n + 1 - LOG_FINAL) return 5;
+  const std::vector<int> ks = fri_schedule(log_n);
+  if (n_layers != (int)ks.size()) return 5;
   if (!need((size_t)4 * n_layers + 4 * ((size_t)1 << LOG_FINAL))) return 4;
   std::vector<const F*> lroots(n_layers);
   for (int j = 0; j < n_layers; j++) { lroots[j] = w + p; p += 4; }
@@ -452,7 +471,6 @@ static int verify(const uint32_t* w, size_t len) {
   }
   // 2. final codeword is low degree: interpolate over shift_f * <w_8>, top half of the coefficients must vanish
   {
-    F shift = GEN; for (int j = 0; j < n_layers; j++) shift = fmul(shift, shift);
     const size_t m = fin.size();
     for (int t = 0; t < 4; t++) {
       std::vector<F> ev(m); for (size_t i = 0; i < m; i++) ev[i] = fin[i].c[t];
@@ -497,28 +515,29 @@ static int verify(const uint32_t* w, size_t len) {
       for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wm + i], ql[s2][i]));
       deep[s2] = eadd(emul(esub(A, a0), einv(esub(e_from(x), zeta))), emul(esub(B, b0), einv(esub(e_from(x), zeta_w))));
     }
-    // FRI layers
-    E expect_lo = deep[0], expect_hi = deep[1];
-    bool have_pair = true;                                                 // layer 0: both elements of the leaf are known from the trace/quotient openings
-    E carried = e_from(0); size_t carried_idx = 0;
+    // FRI layers: the leaf of layer j holds the 2^k values that the next k binary folds combine into one
+    E carried = e_from(0); size_t carried_idx = q;                         // value / position carried into the current layer
     F shift = GEN; int log_m = log_n + 1;
-    size_t idx_full = q;                                                   // position of the carried value in the current layer
     for (int j = 0; j < n_layers; j++) {
-      const size_t h = (size_t)1 << (log_m - 1), idx = idx_full & (h - 1);
-      const int depth = log_m - 1;
-      if (!need((size_t)8 + 4 * depth)) return 4;
-      const E lo = get_e(p), hi = get_e(p + 4);
-      F dg[4]; hash_elems(w + p, 8, dg);
-      p += 8;
+      const int k = ks[j], depth = log_m - k;
+      const size_t nv = (size_t)1 << k, g = (size_t)1 << depth, idx = carried_idx & (g - 1), slot = carried_idx >> depth;
+      if (!need(4 * nv + 4 * (size_t)depth)) return 4;
+      std::vector<E> v(nv);
+      for (size_t t = 0; t < nv; t++) v[t] = get_e(p + 4 * t);
+      F dg[4]; hash_elems(w + p, 4 * nv, dg);
+      p += 4 * nv;
       if (!check_path(dg, idx, w + p, depth, lroots[j])) return 23;
-      p += 4 * depth;
-      if (have_pair) { if (!eeq(lo, expect_lo) || !eeq(hi, expect_hi)) return 24; have_pair = false; }
-      else { const E& mine = (carried_idx < h) ? lo : hi; if (!eeq(mine, carried)) return 25; }
-      const F x = fmul(shift, fpow(root_of_unity(log_m), idx));
-      carried = fold_pair(lo, hi, x, betas[j]);
-      carried_idx = idx;                                                   // position in the next layer (size h)
-      idx_full = idx;
-      shift = fmul(shift, shift); log_m--;
+      p += 4 * (size_t)depth;
+      if (j == 0) { if (!eeq(v[0], deep[0]) || !eeq(v[1], deep[1])) return 24; }   // both elements of the first leaf are known from the openings
+      else if (!eeq(v[slot], carried)) return 25;
+      E beta = betas[j];
+      for (int f = 0; f < k; f++) {
+        const size_t half = nv >> (f + 1);
+        const F wm = root_of_unity(log_m);
+        for (size_t t = 0; t < half; t++) v[t] = fold_pair(v[t], v[t + half], fmul(shift, fpow(wm, idx + t * g)), beta);
+        shift = fmul(shift, shift); log_m--; beta = emul(beta, beta);
+      }
+      carried = v[0]; carried_idx = idx;                                   // position in the next layer (size g)
     }
     if (!eeq(fin[carried_idx & (fin.size() - 1)], carried)) return 26;
   }

@@ -167,9 +167,24 @@ def _rows(n, prog="fib", **cfg):
     return oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg).rows
 
 
-@pytest.mark.parametrize("log_n,prog", [(3, "fib"), (4, "fib"), (7, "fib"), (9, "sha"), (10, "fib")])
+def _fri_schedule(log_n, log_final=3, log_arity=3):
+    """Folds per committed FRI layer (oracle/stark_oracle.cpp: fri_schedule): layer 0 once, then 8-to-1, shorter at the end."""
+    ks, log_m = [], log_n + 1
+    while log_m > log_final:
+        k = 1 if not ks else min(log_arity, log_m - log_final)
+        ks.append(k)
+        log_m -= k
+    return ks
+
+
+@pytest.mark.parametrize("log_n,prog", [(3, "fib"), (4, "fib"), (5, "fib"), (7, "fib"), (8, "fib"), (9, "sha"), (10, "fib")])
 def test_prove_verify_roundtrip(log_n, prog):
     pr = so.prove(_rows(1 << log_n, prog))
+    ks = _fri_schedule(log_n)                                                              # [1], [1,1], [1,2], [1,3,1], [1,3,2], [1,3,3], [1,3,3,1]
+    assert pr[1] == 2 and pr[6 + 8 + (2 * 89 + 4) * 4] == len(ks)                          # proof version, number of committed FRI layers
+    depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
+    per_query = 1 + 2 * (89 + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
+    assert len(pr) == 6 + 8 + (2 * 89 + 4) * 4 + 1 + 4 * len(ks) + 4 * 8 + 24 * per_query
     assert pr[0] == 0x46504B5A and pr[2] == log_n and pr[3] == 89 and pr[4] == 24
     assert (pr[6:] < P).all()
     assert so.verify(pr) == 0

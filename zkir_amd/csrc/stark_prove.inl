@@ -16,7 +16,20 @@ struct ProveParams {            // constants of one proof, Montgomery form, uplo
 };
 __constant__ ProveParams d_pp;
 
-constexpr int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103, WM = 89;
+constexpr int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103, WM = 89, LOG_ARITY = 3;
+
+// Folds per committed FRI layer (so::fri_schedule): the DEEP codeword is folded once (its leaves are the pairs (q, q + N) the trace
+// openings determine), later layers 8-to-1 (three binary folds with beta, beta^2, beta^4), the last one as needed to reach 2^LOG_FINAL.
+// A commitment costs ~log2(leaves) SEQUENTIAL Poseidon2 levels (~10 us each once a level is small), so committing every third
+// fold cuts the latency-bound part of FRI from ~200 levels to ~80 at 2^20 rows.
+std::vector<int> fri_schedule(int log_n) {
+  std::vector<int> ks;
+  for (int log_m = log_n + 1; log_m > LOG_FINAL;) {
+    const int k = ks.empty() ? 1 : (LOG_ARITY < log_m - LOG_FINAL ? LOG_ARITY : log_m - LOG_FINAL);
+    ks.push_back(k); log_m -= k;
+  }
+  return ks;
+}
 
 __device__ __forceinline__ E4 e_from_base_m(uint32_t xm) { return E4{{xm, 0, 0, 0}}; }
 __device__ __forceinline__ E4 e_fma_base(const E4& acc, const E4& coef, uint32_t vm) {          // acc + coef * v   (all Montgomery)
@@ -132,14 +145,19 @@ __global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L
   for (int i = 0; i < 4; i++) cw[(uint64_t)i * N2 + j] = f.c[i];
 }
 
-// ---- FRI: leaf i of a layer of size m = (c[i], c[i+m/2]) = 8 base elements = one permutation -------------------------------
-__global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const uint32_t* __restrict__ c, uint64_t m, uint32_t* __restrict__ digests) {
-  const uint64_t h = m >> 1, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= h) return;
+// ---- FRI: leaf i of a layer of size m folded k times = (c[i + t g])_{t < 2^k}, g = m >> k: 4 * 2^k base elements absorbed
+// eight at a time (two extension values per permutation), as so::hash_elems does ------------------------------------------------
+__global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
+  const uint64_t g = m >> k, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= g) return;
   uint32_t s[p2::T];
 #pragma unroll
-  for (int t = 0; t < 4; t++) { s[t] = bb::to_mont(c[(uint64_t)t * m + i]); s[4 + t] = bb::to_mont(c[(uint64_t)t * m + h + i]); s[8 + t] = 0; }
-  p2::permute(s, d_p2);
+  for (int t = 0; t < p2::T; t++) s[t] = 0;
+  for (uint32_t u = 0; u < (1u << k); u += 2) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) { s[t] = bb::to_mont(c[(uint64_t)t * m + i + u * g]); s[4 + t] = bb::to_mont(c[(uint64_t)t * m + i + (u + 1) * g]); }
+    p2::permute(s, d_p2);
+  }
   reinterpret_cast<uint4*>(digests)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
 }
 
@@ -227,7 +245,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   hipStream_t s = (hipStream_t)stream;
   *proof_out = nullptr; *proof_words = 0;
   const int depth0 = (int)log_n + 1;
-  const int n_layers = (int)log_n + 1 - LOG_FINAL;
+  const std::vector<int> ks = fri_schedule((int)log_n);
+  const int n_layers = (int)ks.size();
 
   {                                               // workspace: 12 W (M + L) + 320 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     const size_t want = (size_t)(12 * WM + 400) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
@@ -339,21 +358,30 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   {
     uint32_t shift = bb::GEN;
     int log_m = (int)log_n + 1;
-    for (int j = 0; j < n_layers; j++, log_m--) {
-      const uint64_t m = 1ull << log_m, h = m >> 1;
-      HIP_OK(fri_trees[j].alloc(4 * (2 * h - 1) * 4));
-      HIP_OK(fri_layers[j + 1].alloc(4 * h * 4));
+    for (int j = 0; j < n_layers; j++) {
+      const int k = ks[j];
+      const uint64_t m = 1ull << log_m, g = m >> k;
+      HIP_OK(fri_trees[j].alloc(4 * (2 * g - 1) * 4));
       uint32_t* tree = fri_trees[j].as<uint32_t>();
-      hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(h)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, tree);
-      launch_tree_levels(tree, h, s);
-      HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * h - 2), 16, hipMemcpyDeviceToHost, s));
+      hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, (uint32_t)k, tree);
+      launch_tree_levels(tree, g, s);
+      HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * g - 2), 16, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
       ch.observe_n(lroots[j].data(), 4);
       betas[j] = ch.sample_ext();
-      const uint32_t half_shift_inv_m = bb::to_mont(bb::inv(bb::mul(2, shift)));
-      hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(h)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), (uint32_t)log_m, log_n + 1, c->d_tw_fwd, bb::e_to_mont(betas[j]),
-                         half_shift_inv_m, fri_layers[j + 1].as<uint32_t>());
-      shift = bb::mul(shift, shift);
+      E4 beta = betas[j];
+      const uint32_t* src = fri_layers[j].as<uint32_t>();
+      for (int f = 0; f < k; f++, log_m--) {                                   // k binary folds: beta^(2^f), shift^(2^f)
+        const uint64_t h = (1ull << log_m) >> 1;
+        DevBuf dst;
+        HIP_OK(dst.alloc(4 * h * 4));
+        const uint32_t half_shift_inv_m = bb::to_mont(bb::inv(bb::mul(2, shift)));
+        hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(h)), dim3(NT), 0, s, src, (uint32_t)log_m, log_n + 1, c->d_tw_fwd, bb::e_to_mont(beta), half_shift_inv_m, dst.as<uint32_t>());
+        src = dst.as<uint32_t>();
+        if (f == k - 1) fri_layers[j + 1] = dst;
+        shift = bb::mul(shift, shift);
+        beta = h_e_mul(beta, beta);
+      }
     }
   }
   const uint64_t fin_n = 1ull << LOG_FINAL;
@@ -367,7 +395,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
 
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
   std::vector<uint32_t> head;
-  head.insert(head.end(), {0x46504B5Au, 1u, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL});
+  head.insert(head.end(), {0x46504B5Au, 2u, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL});
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WM; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
   for (int k = 0; k < WM; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);
@@ -388,11 +416,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dL.as<uint32_t>() + pos, N2, (uint32_t)WM, off}); off += WM; path_jobs(dTree.as<uint32_t>(), N2, pos); }
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ.as<uint32_t>() + pos, N2, 4, off}); off += 4; path_jobs(dQTree.as<uint32_t>(), N2, pos); }
     int log_m = (int)log_n + 1;
-    for (int j = 0; j < n_layers; j++, log_m--) {
-      const uint64_t m = 1ull << log_m, h = m >> 1, idx = q & (h - 1);
-      jobs.push_back({fri_layers[j].as<uint32_t>() + idx, m, 4, off}); off += 4;
-      jobs.push_back({fri_layers[j].as<uint32_t>() + idx + h, m, 4, off}); off += 4;
-      path_jobs(fri_trees[j].as<uint32_t>(), h, idx);
+    for (int j = 0; j < n_layers; log_m -= ks[j], j++) {
+      const uint64_t m = 1ull << log_m, g = m >> ks[j], idx = q & (g - 1);
+      for (uint64_t t = 0; t < (1ull << ks[j]); t++) { jobs.push_back({fri_layers[j].as<uint32_t>() + idx + t * g, m, 4, off}); off += 4; }
+      path_jobs(fri_trees[j].as<uint32_t>(), g, idx);
     }
   }
   HIP_OK(dJobs.alloc(jobs.size() * sizeof(GatherJob))); HIP_OK(dOut.alloc((size_t)off * 4));
