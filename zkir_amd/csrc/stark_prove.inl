@@ -37,9 +37,21 @@ __device__ __forceinline__ E4 e_fma_base(const E4& acc, const E4& coef, uint32_t
              bb::add(acc.c[3], bb::mont_mul(coef.c[3], vm))}};
 }
 
+// Lazy accumulation of Σ coef_k * v_k (coef in E, v in F): each product is a Montgomery product WITHOUT its final subtraction
+// (3 instructions, below 1.469p) added into a 64-bit sum (1 instruction); one Barrett reduction per coordinate at the end.
+// Up to 136 terms fit the 200p bound of bb::reduce_wide<7>.
+struct LazyE4 { uint64_t a[4] = {0, 0, 0, 0}; };
+__device__ __forceinline__ void lz_fma(LazyE4& acc, const E4& coef, uint32_t v) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc.a[t] = bb::acc_add(acc.a[t], bb::mont_mul_lazy(coef.c[t], v));
+}
+__device__ __forceinline__ E4 lz_reduce(const LazyE4& acc) {
+  return E4{{bb::reduce_wide<7>(acc.a[0]), bb::reduce_wide<7>(acc.a[1]), bb::reduce_wide<7>(acc.a[2]), bb::reduce_wide<7>(acc.a[3])}};
+}
+
 // ---- quotient: Q(x_j) = (Σ_c alpha^c C_c(x_j)) / Z_H(x_j) on x_j = g w_2N^j;  next row = position j+2 -------------------
 __global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, uint32_t gN_m,
-                                                       uint32_t wn_inv_m, uint32_t* __restrict__ Q) {
+                                                       uint32_t wn_inv_m, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m, uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
@@ -51,95 +63,114 @@ __global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict
   const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
   const uint32_t one = bb::R1;
   const uint32_t zh = bb::sub((j & 1) ? bb::neg(gN_m) : gN_m, one);                                 // x^N - 1
-  // base-field inverses by exponentiation (two per point; negligible next to the 2*W loads)
+  // Z_H takes two values on the coset (x^N = +-g^N): its inverses come from the host; 1/(x - 1) is one exponentiation per point
   auto inv_m = [](uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; };
-  const uint32_t inv_zh = inv_m(zh);
+  const uint32_t inv_zh = (j & 1) ? inv_zh_odd_m : inv_zh_even_m;
   const uint32_t is_first = bb::mont_mul(zh, inv_m(bb::sub(x, one)));
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
-  E4 acc = bb::e_zero();
+  LazyE4 acc;                                                                                        // 103 terms
   int c = 0;
   const uint32_t cyc = ld(0, j);
-  acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(bb::sub(bb::sub(ld(0, jn), cyc), one), is_trans));
-  acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(cyc, is_first));
+  lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(bb::sub(bb::sub(ld(0, jn), cyc), one), is_trans));
+  lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(cyc, is_first));
 #pragma unroll 1
   for (int r = 0; r < 16; r++) {
     const uint32_t st = ld(57 + r, j), ch = ld(73 + r, j);
-    acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(st, bb::sub(st, one)));
-    acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(ch, bb::sub(ch, one)));
+    lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(st, bb::sub(st, one)));
+    lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(ch, bb::sub(ch, one)));
     const uint32_t keep_t = bb::mont_mul(bb::sub(one, ch), is_trans);
 #pragma unroll
-    for (int l = 0; l < 3; l++) acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(9 + 3 * r + l, jn), ld(9 + 3 * r + l, j))));
-    acc = e_fma_base(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(57 + r, jn), st)));
+    for (int l = 0; l < 3; l++) lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(9 + 3 * r + l, jn), ld(9 + 3 * r + l, j))));
+    lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(57 + r, jn), st)));
   }
-  acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(9, j)); acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(10, j)); acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(11, j));
-  acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(57, j)); acc = e_fma_base(acc, d_pp.alpha_pow[c++], ld(73, j));
-  const E4 q = bb::e_from_mont(bb::e_mul_fm(acc, inv_zh));
+  lz_fma(acc, d_pp.alpha_pow[c++], ld(9, j)); lz_fma(acc, d_pp.alpha_pow[c++], ld(10, j)); lz_fma(acc, d_pp.alpha_pow[c++], ld(11, j));
+  lz_fma(acc, d_pp.alpha_pow[c++], ld(57, j)); lz_fma(acc, d_pp.alpha_pow[c++], ld(73, j));
+  const E4 q = bb::e_from_mont(bb::e_mul_fm(lz_reduce(acc), inv_zh));
 #pragma unroll
   for (int i = 0; i < 4; i++) Q[(uint64_t)i * N2 + j] = q.c[i];
 }
 
 // ---- barycentric weights over the LDE coset: e_j = x_j / (zeta - x_j)  (Montgomery E4, AoS) -------------------------------
-__global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const uint32_t* __restrict__ tw_fwd, E4* __restrict__ wts) {
+// and dinv_j = 1 / (zeta - x_j), which the DEEP kernel reuses: 1 / (zeta w - x_j) = w^-1 / (zeta - x_{j-2}) on the 2N coset
+__global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const uint32_t* __restrict__ tw_fwd, E4* __restrict__ wts, E4* __restrict__ dinv) {
   const uint32_t N2 = 2u << log_n, N = N2 >> 1;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
   const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
   const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
   E4 d = d_pp.zeta; d.c[0] = bb::sub(d.c[0], x);
-  wts[j] = bb::e_mul_fm(bb::e_inv_m(d), x);
+  const E4 di = bb::e_inv_m(d);
+  dinv[j] = di;
+  wts[j] = bb::e_mul_fm(di, x);
 }
 
-// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}      (grid: chunks x columns)
-__global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, const E4* __restrict__ wts, E4* __restrict__ partial, uint32_t n_chunks) {
-  __shared__ E4 red[2][NT / 64];
-  const uint32_t col = blockIdx.y, chunk = blockIdx.x;
+// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (CANONICAL E4; grid: chunks x column groups).
+// A workgroup handles CG columns so that the 16-byte weights (the bulk of the traffic when read once per column) are loaded once
+// per CG values; products are accumulated lazily: mont(e, v) without its final subtraction (3 instructions) into a 64-bit sum
+// (1 instruction), reduced once at the end.  v stays canonical: mont(e * R, v) = e * v needs no conversion of the matrix.
+template <int CG>
+__global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, uint32_t width, const E4* __restrict__ wts, E4* __restrict__ partial,
+                                                       uint32_t n_chunks) {
+  __shared__ uint32_t red[NT / 64][CG][2][4];
+  const uint32_t col0 = blockIdx.y * CG, chunk = blockIdx.x;
   const uint64_t per = N2 / n_chunks, lo = (uint64_t)chunk * per;
-  const uint32_t* v = mat + (uint64_t)col * N2;
-  E4 s0 = bb::e_zero(), s1 = bb::e_zero();
-  for (uint64_t j = lo + threadIdx.x; j < lo + per; j += NT) {
-    const uint32_t vm = bb::to_mont(v[j]);
-    s0 = e_fma_base(s0, wts[j], vm);
-    s1 = e_fma_base(s1, wts[(j + N2 - 2) & (N2 - 1)], vm);
-  }
+  const uint32_t* v[CG];
 #pragma unroll
-  for (int t = 0; t < 4; t++) {
-    for (int off = 32; off > 0; off >>= 1) {
-      s0.c[t] = bb::add(s0.c[t], __shfl_down(s0.c[t], off, 64));
-      s1.c[t] = bb::add(s1.c[t], __shfl_down(s1.c[t], off, 64));
+  for (int c = 0; c < CG; c++) v[c] = mat + (uint64_t)(col0 + c < width ? col0 + c : width - 1) * N2;
+  uint64_t a0[CG][4], a1[CG][4];
+#pragma unroll
+  for (int c = 0; c < CG; c++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) a0[c][t] = a1[c][t] = 0;
+  for (uint64_t j = lo + threadIdx.x; j < lo + per; j += NT) {
+    const E4 w0 = wts[j], w1 = wts[(j + N2 - 2) & (N2 - 1)];
+#pragma unroll
+    for (int c = 0; c < CG; c++) {
+      const uint32_t x = v[c][j];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        a0[c][t] = bb::acc_add(a0[c][t], bb::mont_mul_lazy(w0.c[t], x));
+        a1[c][t] = bb::acc_add(a1[c][t], bb::mont_mul_lazy(w1.c[t], x));
+      }
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) { red[0][wv] = s0; red[1][wv] = s1; }
+#pragma unroll
+  for (int c = 0; c < CG; c++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      uint32_t r0 = (uint32_t)(a0[c][t] % bb::P), r1 = (uint32_t)(a1[c][t] % bb::P);
+      for (int off = 32; off > 0; off >>= 1) { r0 = bb::add(r0, __shfl_down(r0, off, 64)); r1 = bb::add(r1, __shfl_down(r1, off, 64)); }
+      if (lane == 0) { red[wv][c][0][t] = r0; red[wv][c][1][t] = r1; }
+    }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    E4 a = red[0][0], b = red[1][0];
-    for (int k = 1; k < NT / 64; k++) { a = bb::e_add(a, red[0][k]); b = bb::e_add(b, red[1][k]); }
-    partial[((uint64_t)col * n_chunks + chunk) * 2] = a;
-    partial[((uint64_t)col * n_chunks + chunk) * 2 + 1] = b;
+  if (threadIdx.x < CG * 8) {
+    const int c = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, t = threadIdx.x & 3;
+    uint32_t r = red[0][c][which][t];
+    for (int k = 1; k < NT / 64; k++) r = bb::add(r, red[k][c][which][t]);
+    if (col0 + c < width) partial[((uint64_t)(col0 + c) * n_chunks + chunk) * 2 + which].c[t] = r;
   }
 }
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
-__global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ Q, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
-                                                   uint32_t* __restrict__ cw) {
-  const uint32_t N2 = 2u << log_n, N = N2 >> 1;
+__global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ Q, uint32_t log_n, const E4* __restrict__ dinv,
+                                                   uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
+  const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
-  E4 A = bb::e_zero(), B = bb::e_zero();
+  LazyE4 A, B;                                                                // 93 and 89 terms; canonical v x Montgomery gamma^k = canonical product
 #pragma unroll 4
   for (int k = 0; k < WM; k++) {
-    const uint32_t vm = bb::to_mont(L[(uint64_t)k * N2 + j]);
-    A = e_fma_base(A, d_pp.gamma_pow[k], vm);
-    B = e_fma_base(B, d_pp.gamma_pow[WM + k], vm);
+    const uint32_t v = L[(uint64_t)k * N2 + j];
+    lz_fma(A, d_pp.gamma_pow[k], v);
+    lz_fma(B, d_pp.gamma_pow[WM + k], v);
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) A = e_fma_base(A, d_pp.gamma_pow[2 * WM + i], bb::to_mont(Q[(uint64_t)i * N2 + j]));
-  const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
-  const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
-  E4 d1 = d_pp.zeta, d2 = d_pp.zeta_w;                                        // x - zeta = -(zeta - x)
-  d1.c[0] = bb::sub(d1.c[0], x); d2.c[0] = bb::sub(d2.c[0], x);
-  const E4 t1 = bb::e_mul_m(bb::e_sub(d_pp.a0, A), bb::e_inv_m(d1));          // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
-  const E4 t2 = bb::e_mul_m(bb::e_sub(d_pp.b0, B), bb::e_inv_m(d2));
+  for (int i = 0; i < 4; i++) lz_fma(A, d_pp.gamma_pow[2 * WM + i], Q[(uint64_t)i * N2 + j]);
+  const E4 Am = bb::e_to_mont(lz_reduce(A)), Bm = bb::e_to_mont(lz_reduce(B));
+  const E4 i1 = dinv[j], i2 = bb::e_mul_fm(dinv[(j + N2 - 2) & (N2 - 1)], wn_inv_m);   // 1/(zeta - x), 1/(zeta w - x)
+  const E4 t1 = bb::e_mul_m(bb::e_sub(d_pp.a0, Am), i1);                      // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
+  const E4 t2 = bb::e_mul_m(bb::e_sub(d_pp.b0, Bm), i2);
   const E4 f = bb::e_from_mont(bb::e_add(t1, t2));
 #pragma unroll
   for (int i = 0; i < 4; i++) cw[(uint64_t)i * N2 + j] = f.c[i];
@@ -249,7 +280,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   const int n_layers = (int)ks.size();
 
   {                                               // workspace: 12 W (M + L) + 320 (trees, quotient, weights, FRI) bytes per row, allocated once per context
-    const size_t want = (size_t)(12 * WM + 400) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
+    const size_t want = (size_t)(12 * WM + 440) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -259,11 +290,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
     c->arena_off = 0;
     g_arena_ctx = c;
   }
-  DevBuf dM, dL, dTree, dQ, dQTree, dW, dPart, dJobs, dOut;
+  DevBuf dM, dL, dTree, dQ, dQTree, dW, dDinv, dPart, dJobs, dOut;
   std::vector<DevBuf> fri_trees(n_layers), fri_layers(n_layers + 1);
   HIP_OK(dM.alloc(WM * N * 4)); HIP_OK(dL.alloc(WM * N2 * 4)); HIP_OK(dTree.alloc(4 * (2 * N2 - 1) * 4));
-  HIP_OK(dQ.alloc(4 * N2 * 4)); HIP_OK(dQTree.alloc(4 * (2 * N2 - 1) * 4)); HIP_OK(dW.alloc(N2 * sizeof(E4)));
-  const uint32_t n_chunks = N2 >= 16 * NT ? 16 : 1;
+  HIP_OK(dQ.alloc(4 * N2 * 4)); HIP_OK(dQTree.alloc(4 * (2 * N2 - 1) * 4)); HIP_OK(dW.alloc(N2 * sizeof(E4))); HIP_OK(dDinv.alloc(N2 * sizeof(E4)));
+  const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
   HIP_OK(dPart.alloc((size_t)(WM + 4) * n_chunks * 2 * sizeof(E4)));
 
   hipEvent_t ev[9];
@@ -294,7 +325,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
     HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp, sizeof(pp.alpha_pow), offsetof(ProveParams, alpha_pow), hipMemcpyHostToDevice, s));
   }
   const uint32_t gN_m = bb::to_mont(bb::pow(bb::GEN, N)), wn_inv_m = bb::to_mont(bb::inv(bb::root_of_unity((int)log_n)));
-  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), log_n, c->d_tw_fwd, gN_m, wn_inv_m, dQ.as<uint32_t>());
+  const uint32_t gN = bb::pow(bb::GEN, N);
+  const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
+  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), log_n, c->d_tw_fwd, gN_m, wn_inv_m, inv_zh_even_m, inv_zh_odd_m, dQ.as<uint32_t>());
   rc = zkir_merkle_commit_launch(c, dQ.as<uint32_t>(), 4, N2, dQTree.as<uint32_t>(), s); if (rc) return rc;
   HIP_OK(hipMemcpyAsync(qroot, dQTree.as<uint32_t>() + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -307,9 +340,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   // ---- 3. openings by barycentric evaluation over the LDE coset ------------------------------------------------------------
   pp.zeta = bb::e_to_mont(zeta); pp.zeta_w = bb::e_to_mont(zeta_w);
   HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.zeta, 2 * sizeof(E4), offsetof(ProveParams, zeta), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dW.as<E4>());
-  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, WM), dim3(NT), 0, s, dL.as<uint32_t>(), N2, dW.as<E4>(), dPart.as<E4>(), n_chunks);
-  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 4), dim3(NT), 0, s, dQ.as<uint32_t>(), N2, dW.as<E4>(), dPart.as<E4>() + (size_t)WM * n_chunks * 2, n_chunks);
+  hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dW.as<E4>(), dDinv.as<E4>());
+  constexpr int CG = 4;
+  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, (WM + CG - 1) / CG), dim3(NT), 0, s, dL.as<uint32_t>(), N2, (uint32_t)WM, dW.as<E4>(), dPart.as<E4>(), n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, 1), dim3(NT), 0, s, dQ.as<uint32_t>(), N2, 4u, dW.as<E4>(), dPart.as<E4>() + (size_t)WM * n_chunks * 2, n_chunks);
   std::vector<E4> part((size_t)(WM + 4) * n_chunks * 2);
   HIP_OK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -324,7 +358,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
     for (int k = 0; k < WM + 4; k++) {
       E4 a = bb::e_zero(), b = bb::e_zero();
       for (uint32_t q = 0; q < n_chunks; q++) { a = bb::e_add(a, part[((size_t)k * n_chunks + q) * 2]); b = bb::e_add(b, part[((size_t)k * n_chunks + q) * 2 + 1]); }
-      const E4 va = bb::e_from_mont(bb::e_mul_m(a, sc_m)), vb = bb::e_from_mont(bb::e_mul_m(b, sc_m));      // partial sums are Montgomery E4
+      const E4 va = bb::e_mul_m(a, sc_m), vb = bb::e_mul_m(b, sc_m);                                          // canonical partial sums x Montgomery scale = canonical
       if (k < WM) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WM] = va;
     }
   }
@@ -349,7 +383,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
     HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.a0, 2 * sizeof(E4), offsetof(ProveParams, a0), hipMemcpyHostToDevice, s));
   }
   HIP_OK(fri_layers[0].alloc(4 * N2 * 4));
-  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), dQ.as<uint32_t>(), log_n, c->d_tw_fwd, fri_layers[0].as<uint32_t>());
+  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), dQ.as<uint32_t>(), log_n, dDinv.as<E4>(), wn_inv_m, fri_layers[0].as<uint32_t>());
   mark(6);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
