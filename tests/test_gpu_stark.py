@@ -164,10 +164,12 @@ def test_row_sharded_commitment_matches_oracle():
     ctx.close(); log.close()
 
 
-def test_proof_2p16_verifies():
-    """Larger than the oracle prover comfortably handles: the oracle VERIFIER (cheap) accepts the GPU proof."""
+@pytest.mark.parametrize("log_n", [16, 18])
+def test_proof_large_verifies(log_n):
+    """Larger than the oracle prover comfortably handles: the oracle VERIFIER (cheap) accepts the GPU proof.  2^18 rows is the
+    smallest size whose FRI schedule has an 8-to-1 layer hashed by the one-permutation-per-lane kernel (> 2^14 leaves), and whose
+    Merkle trees use the per-level kernel, both subtree modes and the quad-lane permutation."""
     from zkir_amd import stark
-    log_n = 16
     log, tr = _device_trace(spec.fib_endless_program().to_bytes(), 1 << log_n)
     ctx = stark.StarkContext(log_n)
     proof = stark.prove(ctx, tr)

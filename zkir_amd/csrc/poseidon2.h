@@ -147,4 +147,65 @@ BB_HD void permute(uint32_t* s, const Consts& c) {
   }
 }
 
+#if defined(__HIPCC__)
+// ---- the same permutation spread over a QUAD of lanes (latency variant) ---------------------------------------------------------
+// A lone wave issues one VALU instruction every ~4 cycles, so one permutation per lane (~4250 instructions) takes ~8 us no matter
+// how few lanes are busy — and the upper Merkle levels / small FRI layers keep only a few lanes busy.  Here lane l of an aligned
+// quad holds state words l, 4 + l, 8 + l (column l of the three M4 blocks): the S-box layer is 3 chains per lane instead of 12, the
+// M4 products take the block's four words through DPP quad broadcasts (row l of M4 as per-lane multipliers), the column sums stay
+// inside a lane, and the partial-round sum is a 2-step quad butterfly.  ~1800 instructions per lane.  All four lanes of a quad must
+// be active.  Same function, same bounds as permute(); which words a lane keeps lazy differs, the canonical results do not.
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ uint64_t quad_perm64(uint64_t v) { return ((uint64_t)quad_perm<CTRL>((uint32_t)(v >> 32)) << 32) | quad_perm<CTRL>((uint32_t)v); }
+
+template <bool ADD_RC>
+__device__ __forceinline__ void ext_linear_quad(uint32_t* s, const uint32_t* m4row, const uint32_t* rc) {
+  uint64_t y[3];
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const uint32_t v0 = quad_perm<0x00>(s[b]), v1 = quad_perm<0x55>(s[b]), v2 = quad_perm<0xAA>(s[b]), v3 = quad_perm<0xFF>(s[b]);
+    y[b] = (uint64_t)v0 * m4row[0] + (uint64_t)v1 * m4row[1] + (uint64_t)v2 * m4row[2] + (uint64_t)v3 * m4row[3];
+  }
+  const uint64_t sum = y[0] + y[1] + y[2];
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    uint64_t v = y[b] + sum;
+    if (ADD_RC) v += rc[b];
+    s[b] = bb::reduce_wide<6>(v);
+  }
+}
+// s[b] = state word 4 b + l of the quad's permutation, l = lane & 3; Montgomery form, canonical in and out
+__device__ __forceinline__ void permute_quad(uint32_t* s, int l, const Consts& c) {
+  const uint32_t packed = l == 0 ? 0x03010705u : l == 1 ? 0x01010604u : l == 2 ? 0x07050301u : 0x06040101u;   // row l of M4, one byte per entry
+  const uint32_t m4row[4] = {packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF, packed >> 24};
+  const uint32_t diag[3] = {c.diag[l], c.diag[4 + l], c.diag[8 + l]};
+  { const uint32_t rc[3] = {c.ext[0][l], c.ext[0][4 + l], c.ext[0][8 + l]}; ext_linear_quad<true>(s, m4row, rc); }
+#pragma unroll 1
+  for (int r = 0; r < RF; r++) {
+    if (r == RF / 2) {
+#pragma unroll 1
+      for (int q = 0; q < RP; q++) {
+        const uint32_t sb = sbox(bb::add(s[0], c.in[q]));                    // meaningful in lane 0 only (word 0)
+        const uint32_t s0 = l == 0 ? sb : s[0];
+        uint64_t acc = bb::acc_add(bb::acc_add((uint64_t)s0, s[1]), s[2]);
+        acc += quad_perm64<0xB1>(acc);                                       // lanes (1,0,3,2)
+        acc += quad_perm64<0x4E>(acc);                                       // lanes (2,3,0,1): every lane now holds the sum of all 12 words
+        const uint32_t sum_r = bb::mont_mul_lazy(bb::reduce_wide<4>(acc), bb::R2);
+        s[0] = bb::reduce_2p(bb::mont_mul_add_lazy(s0, diag[0], sum_r));     // word 0 must be canonical for the next S-box (diag[0] = -2)
+        s[1] = bb::mont_mul_add_lazy(s[1], diag[1], sum_r);
+        s[2] = bb::mont_mul_add_lazy(s[2], diag[2], sum_r);
+      }
+      s[1] = bb::reduce_2p(s[1]); s[2] = bb::reduce_2p(s[2]);
+#pragma unroll
+      for (int b = 0; b < 3; b++) s[b] = bb::add(s[b], c.ext[RF / 2][4 * b + l]);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; b++) s[b] = sbox_lazy(s[b], c.pre[r][4 * b + l]);
+    ext_linear_quad<false>(s, m4row, nullptr);
+  }
+}
+#endif
+
 }  // namespace p2

@@ -192,6 +192,19 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const uint32_t* __res
   reinterpret_cast<uint4*>(digests)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
 }
 
+// the same leaf hash with one permutation per quad of lanes (p2::permute_quad): small layers are latency-bound
+__global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
+  const uint64_t g = m >> k, t = (uint64_t)blockIdx.x * NT + threadIdx.x, i = t >> 2;
+  const int l = (int)(t & 3);
+  if (i >= g) return;                                                         // whole quads leave together
+  uint32_t s[3] = {0, 0, 0};
+  for (uint32_t u = 0; u < (1u << k); u += 2) {
+    s[0] = bb::to_mont(c[(uint64_t)l * m + i + u * g]); s[1] = bb::to_mont(c[(uint64_t)l * m + i + (u + 1) * g]);
+    p2::permute_quad(s, l, d_p2);
+  }
+  digests[4 * i + l] = bb::from_mont(s[0]);
+}
+
 // c'[i] = (c[i] + c[i+h])/2 + beta (c[i] - c[i+h]) / (2 x_i),  x_i = shift * w_m^i
 __global__ __launch_bounds__(NT) void fri_fold_kernel(const uint32_t* __restrict__ c, uint32_t log_m, uint32_t log_2n, const uint32_t* __restrict__ tw_fwd, E4 beta_m,
                                                        uint32_t half_shift_inv_m, uint32_t* __restrict__ out) {
@@ -397,7 +410,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
       const uint64_t m = 1ull << log_m, g = m >> k;
       HIP_OK(fri_trees[j].alloc(4 * (2 * g - 1) * 4));
       uint32_t* tree = fri_trees[j].as<uint32_t>();
-      hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, (uint32_t)k, tree);
+      if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, (uint32_t)k, tree);
+      else hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, (uint32_t)k, tree);
       launch_tree_levels(tree, g, s);
       HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * g - 2), 16, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
