@@ -270,6 +270,9 @@ int zkir_prove(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint6
                float* stage_ms, void* hip_stream);
 void zkir_proof_free(uint32_t* proof);
 uint32_t zkir_proof_num_queries(void);
+/* Host-side Poseidon2-12 permutation of the transcript (canonical words in and out; no device needed): what a verifier or an
+ * integrator re-deriving the Fiat-Shamir challenges calls.  Same code as the device kernels (poseidon2.h), compiled for the host. */
+void zkir_poseidon2_permute(uint32_t state[12]);
 
 /* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
 typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */

@@ -65,3 +65,26 @@ def test_exec_without_gpu_fails_loudly():
     with pytest.raises(rt.RuntimeError) as e:
         rt.VM(spec.fib_program(5), [], rt.VMConfig(enable_execution_trace=True)).run()
     assert e.value.code == rt.ERR_DEVICE
+
+
+def test_host_poseidon2_matches_oracle():
+    """zkir_poseidon2_permute (the product's host build of poseidon2.h: wide linear layers, lazy Montgomery products, constants
+    folded into multiply-adds) against the oracle's textbook permutation, on random states and on the edges of the range."""
+    import numpy as np
+    from oracle import stark_api as so
+    P = so.P
+    rng = np.random.default_rng(12)
+    states = [rng.integers(0, P, 12).astype(np.uint32) for _ in range(300)]
+    states += [np.full(12, P - 1, np.uint32), np.zeros(12, np.uint32), np.ones(12, np.uint32), np.arange(12, dtype=np.uint32),
+               np.array([P - 1, 0] * 6, np.uint32), np.array([0, P - 1] * 6, np.uint32), np.array([(P - 1) // 2] * 12, np.uint32)]
+    for s in states:
+        got = s.copy()
+        rt.lib().zkir_poseidon2_permute(got.ctypes.data)
+        assert np.array_equal(got, so.permute(s)), s
+    # iterate the permutation: 200 dependent applications explore states nobody picked
+    s = np.arange(12, dtype=np.uint32)
+    want = s.copy()
+    for _ in range(200):
+        rt.lib().zkir_poseidon2_permute(s.ctypes.data)
+        want = so.permute(want)
+    assert np.array_equal(s, want)

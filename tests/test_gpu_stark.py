@@ -55,6 +55,30 @@ def test_merkle_matches_oracle(log_n, width):
     ctx.close()
 
 
+@pytest.mark.parametrize("fill", ["p-1", "zero", "one", "alternating"])
+def test_merkle_and_lde_extreme_values(fill):
+    """Worst cases for the lazy (unreduced) arithmetic of the hash and NTT kernels: every input at the top of the range."""
+    import torch
+    from zkir_amd import stark
+    log_n, width = 9, 89
+    n = 1 << log_n
+    mat = np.zeros((width, n), dtype=np.uint32)
+    if fill == "p-1":
+        mat[:] = P - 1
+    elif fill == "one":
+        mat[:] = 1
+    elif fill == "alternating":
+        mat[:, ::2] = P - 1; mat[::2, 1::2] = P - 2
+    ctx = stark.StarkContext(log_n)
+    tree = stark.merkle_commit(ctx, torch.from_numpy(mat.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    root, layers = so.merkle(mat, want_layers=True)
+    assert np.array_equal(tree, layers)
+    got = stark.lde(ctx, torch.from_numpy(mat[:3].copy().view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    for k in range(3):
+        assert np.array_equal(got[k], so.lde(mat[k], 1)[1])
+    ctx.close()
+
+
 @pytest.mark.parametrize("name,log_n", [("fib", 6), ("fib", 10), ("fib", 12), ("sha", 9), ("deferred", 8)])
 def test_main_trace_and_commit_match_oracle(name, log_n):
     from zkir_amd import stark

@@ -208,6 +208,14 @@ extern "C" {
 
 uint32_t zkir_main_trace_width(void) { return 89; }
 
+void zkir_poseidon2_permute(uint32_t state[12]) {
+  static const p2::Consts consts = [] { p2::Consts c; p2::generate(c); return c; }();
+  uint32_t s[p2::T];
+  for (int i = 0; i < p2::T; i++) s[i] = bb::to_mont(state[i] % bb::P);
+  p2::permute(s, consts);
+  for (int i = 0; i < p2::T; i++) state[i] = bb::from_mont(s[i]);
+}
+
 // Diagnostic: measured peak Montgomery-multiplication rate (modmul/s) of the device, used as the ALU roofline of the Poseidon2 kernels.
 double zkir_modmul_peak_per_s(void* stream) {
   hipStream_t s = (hipStream_t)stream;
