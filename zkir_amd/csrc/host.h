@@ -1,6 +1,8 @@
 // host.h — internal host-side types of libzkir_amd (not part of the C ABI).
 #pragma once
 
+#include <sys/mman.h>
+
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +28,13 @@ struct BoundT {            // ValueBound, zkir-spec/src/bound.rs:116-121
   uint64_t payload;
 };
 
+// Recycling of the big log blocks (interp.cpp): a 2^20-row run writes ~50 MB of logs once, front to back, and with 4 KiB pages
+// (no THP in containers) first-touch page faults cost more than the interpretation itself (64 ms sys vs 53 ms user at 2^22 rows).
+// Freed blocks >= 8 MiB are parked (at most 8 blocks / 4 GiB) and handed to the next run already mapped.
+void* block_pool_take(size_t min_bytes, size_t* got_bytes);   // nullptr if nothing suitable is parked
+void block_pool_give(void* p, size_t bytes);                  // takes ownership (may free)
+constexpr size_t BLOCK_POOL_MIN = 8u << 20;
+
 // Growable POD buffer backed by realloc (mremap for large blocks: growth neither copies nor re-faults).
 template <typename T>
 class Buf {
@@ -33,12 +42,19 @@ class Buf {
   Buf() = default;
   Buf(const Buf&) = delete;
   Buf& operator=(const Buf&) = delete;
-  ~Buf() { free(p_); }
+  ~Buf() { if (cap_ * sizeof(T) >= BLOCK_POOL_MIN) block_pool_give(p_, cap_ * sizeof(T)); else free(p_); }
   void reserve(size_t n) {
     if (n <= cap_) return;
+    if (!p_ && n * sizeof(T) >= BLOCK_POOL_MIN) {
+      size_t got = 0;
+      if (void* q = block_pool_take(n * sizeof(T), &got)) { p_ = (T*)q; cap_ = got / sizeof(T); return; }
+    }
     void* q = realloc(p_, n * sizeof(T));
     if (!q) throw std::bad_alloc();
     p_ = (T*)q; cap_ = n;
+    // the trace logs are tens of MB written once, front to back: with 4 KiB pages two thirds of the interpreter's time went to
+    // first-touch page faults (21 ms vs 7 ms without the trace at 2^20 rows); ask for transparent huge pages (THP = madvise here)
+    if (n * sizeof(T) >= (8u << 20)) (void)madvise(q, n * sizeof(T), MADV_HUGEPAGE);
   }
   inline void push(const T& v) {
     if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024);

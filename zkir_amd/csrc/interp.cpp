@@ -28,9 +28,46 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 
 namespace zkir {
+
+// ---- block pool (host.h) --------------------------------------------------------------------------------------------------
+namespace {
+struct Parked { void* p; size_t bytes; };
+std::mutex g_pool_mu;
+std::vector<Parked> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MAX_BLOCKS = 8, POOL_MAX_BYTES = 4ull << 30;
+}  // namespace
+
+void* block_pool_take(size_t min_bytes, size_t* got_bytes) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int best = -1;
+  for (int i = 0; i < (int)g_pool.size(); i++)
+    if (g_pool[i].bytes >= min_bytes && g_pool[i].bytes <= 4 * min_bytes && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+  if (best < 0) return nullptr;
+  const Parked b = g_pool[best];
+  g_pool.erase(g_pool.begin() + best);
+  g_pool_bytes -= b.bytes;
+  *got_bytes = b.bytes;
+  return b.p;
+}
+
+void block_pool_give(void* p, size_t bytes) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (bytes > POOL_MAX_BYTES) { free(p); return; }
+  g_pool.push_back({p, bytes});
+  g_pool_bytes += bytes;
+  while (g_pool.size() > POOL_MAX_BLOCKS || g_pool_bytes > POOL_MAX_BYTES) {    // drop the oldest
+    g_pool_bytes -= g_pool.front().bytes;
+    free(g_pool.front().p);
+    g_pool.erase(g_pool.begin());
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // bounds (bound.rs)
