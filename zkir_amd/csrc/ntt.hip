@@ -139,10 +139,10 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint32_t* __restric
         const uint32_t x0 = lds[i0], x1 = lds[i0 + d], x2 = lds[i0 + 2 * d], x3 = lds[i0 + 3 * d];
         const uint32_t wA = bb::mont_mul(tp[r], small[mid_lo << (log_small - (B - b))]);
         const uint32_t wB = bb::mont_mul(wA, j4_m), w2 = bb::mont_mul(wA, wA);
-        const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub(x0, x2), wA);
-        const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub(x1, x3), wB);
-        lds[i0] = bb::add(y0, y1); lds[i0 + d] = bb::mont_mul(bb::sub(y0, y1), w2);
-        lds[i0 + 2 * d] = bb::add(y2, y3); lds[i0 + 3 * d] = bb::mont_mul(bb::sub(y2, y3), w2);
+        const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub_lazy(x0, x2), wA);      // differences only feed a product: no reduction
+        const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub_lazy(x1, x3), wB);
+        lds[i0] = bb::add(y0, y1); lds[i0 + d] = bb::mont_mul(bb::sub_lazy(y0, y1), w2);
+        lds[i0 + 2 * d] = bb::add(y2, y3); lds[i0 + 3 * d] = bb::mont_mul(bb::sub_lazy(y2, y3), w2);
       } else {
         const uint32_t dm = 1u << b, mid_lo = qq & (dm - 1), mid_hi = qq >> b;
         const uint32_t i0 = ((((mid_hi << (b + 2)) | mid_lo)) << C) | lo_l, d = dm << C;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint32_t* __restric
         const uint32_t w2 = bb::mont_mul(tp[r], small[mid_lo << (log_small - (b + 2))]);
         const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_m);
         const uint32_t t1 = bb::mont_mul(x1, w1), t3 = bb::mont_mul(x3, w1);
-        const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add(x2, t3), y3 = bb::sub(x2, t3);
+        const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add_lazy(x2, t3), y3 = bb::sub_lazy(x2, t3);
         const uint32_t u2 = bb::mont_mul(y2, w2), u3 = bb::mont_mul(y3, w2i);
         lds[i0] = bb::add(y0, u2); lds[i0 + 2 * d] = bb::sub(y0, u2); lds[i0 + d] = bb::add(y1, u3); lds[i0 + 3 * d] = bb::sub(y1, u3);
       }
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __res
     const uint32_t h2 = 1u << lg, lo = q & (h2 - 1), hi = q >> lg;
     const uint32_t i0 = (hi << (lg + 2)) | lo;
     const uint32_t wA = small_inv[lo << (2 * r)];              // w_1024^-(lo << 2r)
+    // (reading wB = table[e + 256] and w2 = table[2e] instead of computing them was tried: 610 -> 747 us, the loads cost more)
     const uint32_t wB = bb::mont_mul(wA, j4_inv_m), w2 = bb::mont_mul(wA, wA);
     uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
     if (r == 4) {                                              // last round (positions 4q..4q+3): the coset scale g^k / N, k = bitrev_L(position)
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __res
     for (int c = 0; c < NC; c++) {
       uint32_t* a = A[c];
       const uint32_t x0 = a[i0], x1 = a[i0 + h2], x2 = a[i0 + 2 * h2], x3 = a[i0 + 3 * h2];
-      const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub(x0, x2), wA);
-      const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub(x1, x3), wB);
-      uint32_t z0 = bb::add(y0, y1), z1 = bb::mont_mul(bb::sub(y0, y1), w2);
-      uint32_t z2 = bb::add(y2, y3), z3 = bb::mont_mul(bb::sub(y2, y3), w2);
+      const uint32_t y0 = bb::add(x0, x2), y2 = bb::mont_mul(bb::sub_lazy(x0, x2), wA);
+      const uint32_t y1 = bb::add(x1, x3), y3 = bb::mont_mul(bb::sub_lazy(x1, x3), wB);
+      uint32_t z0 = bb::add(y0, y1), z1 = bb::mont_mul(bb::sub_lazy(y0, y1), w2);
+      uint32_t z2 = bb::add(y2, y3), z3 = bb::mont_mul(bb::sub_lazy(y2, y3), w2);
       if (r == 4) { z0 = bb::mont_mul(z0, g0); z1 = bb::mont_mul(z1, g1); z2 = bb::mont_mul(z2, g2); z3 = bb::mont_mul(z3, g3); }
       a[i0] = z0; a[i0 + h2] = z1; a[i0 + 2 * h2] = z2; a[i0 + 3 * h2] = z3;
     }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(NT) void lde_middle_r4_kernel(const uint32_t* __res
         if (r == 0) { const uint32_t* a = A[c]; x0 = a[i0 >> 1]; x1 = a[(i0 + d) >> 1]; x2 = a[(i0 + 2 * d) >> 1]; x3 = a[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
         else { x0 = bf[i0]; x1 = bf[i0 + d]; x2 = bf[i0 + 2 * d]; x3 = bf[i0 + 3 * d]; }
         const uint32_t t1 = bb::mont_mul(x1, w1), t3 = bb::mont_mul(x3, w1);
-        const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add(x2, t3), y3 = bb::sub(x2, t3);
+        const uint32_t y0 = bb::add(x0, t1), y1 = bb::sub(x0, t1), y2 = bb::add_lazy(x2, t3), y3 = bb::sub_lazy(x2, t3);
         const uint32_t u2 = bb::mont_mul(y2, w2), u3 = bb::mont_mul(y3, w2i);
         bf[i0] = bb::add(y0, u2); bf[i0 + 2 * d] = bb::sub(y0, u2); bf[i0 + d] = bb::add(y1, u3); bf[i0 + 3 * d] = bb::sub(y1, u3);
       }

@@ -14,6 +14,7 @@
 
 #include <array>
 #include <cstddef>
+#include <mutex>
 #include <vector>
 
 #include "../../include/zkir_amd.h"

@@ -287,6 +287,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
   if (n_rows != N || log_n < (uint32_t)LOG_FINAL) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: n_rows must equal 2^log_n of the context (>= 8)"}); return ZKIR_ERR_ARGUMENT; }
   hipStream_t s = (hipStream_t)stream;
+  // The per-proof challenges live in __constant__ memory (d_pp) and the context's workspace is a single arena: proofs are
+  // serialised per process.  Everything before this entry point (zkir_exec, trace fill, witness kernels, LDE, Merkle) is re-entrant.
+  static std::mutex prove_mu;
+  std::lock_guard<std::mutex> prove_lock(prove_mu);
   *proof_out = nullptr; *proof_words = 0;
   const int depth0 = (int)log_n + 1;
   const std::vector<int> ks = fri_schedule((int)log_n);
