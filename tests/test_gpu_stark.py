@@ -200,3 +200,66 @@ def test_proof_large_verifies(log_n):
     assert so.verify(proof) == 0
     assert proof[2] == log_n and proof[3] == 89
     ctx.close()
+
+
+def _fpow(a, e):
+    """Vectorised a^e mod p on uint64 arrays (products of two 31-bit values fit 62 bits)."""
+    a = a.astype(np.uint64) % np.uint64(P)
+    r = np.ones_like(a)
+    while e:
+        if e & 1:
+            r = r * a % np.uint64(P)
+        a = a * a % np.uint64(P)
+        e >>= 1
+    return r
+
+
+def _bary_eval(values, log_size, shift, z):
+    """f(z) for the polynomial of degree < 2^log_size with f(shift * w^j) = values[j], base-field z outside the domain:
+    f(z) = ((z/shift)^n - 1)/n * sum_j values[j] * x_j / (z - x_j)."""
+    n = 1 << log_size
+    w = pow(31, (P - 1) >> log_size, P)                           # primitive 2^log_size-th root: 31 generates F_p^*, p - 1 = 15 * 2^27
+    x = np.empty(n, dtype=np.uint64)                              # x_j = shift * w^j by doubling
+    x[0] = shift
+    filled, wp = 1, w
+    while filled < n:
+        x[filled:2 * filled] = x[:filled] * np.uint64(wp) % np.uint64(P)
+        wp = wp * wp % P
+        filled *= 2
+    d = (np.uint64(z) + np.uint64(P) - x) % np.uint64(P)
+    terms = values.astype(np.uint64) * (x * _fpow(d, P - 2) % np.uint64(P)) % np.uint64(P)
+    s = int(terms.sum(dtype=np.uint64)) % P                       # at most 2^21 terms below 2^31
+    zs = z * pow(shift, P - 2, P) % P
+    return (pow(zs, n, P) - 1) * pow(n, P - 2, P) % P * s % P
+
+
+def test_full_size_2p20_properties():
+    """BASELINE configs[1] size (2^20 rows), where the oracle's O(N log N) scalar code takes minutes: size-independent properties.
+    * LDE: the column interpolant evaluated at a random point from the N trace values on H equals the one evaluated from the
+      2N LDE values on the coset g<w_2N> (both by the barycentric formula, numpy on the host);
+    * Merkle: random leaves re-hashed with the oracle's sponge and walked up their paths with the oracle's compression reach the root;
+    * proof: the oracle's verifier accepts the GPU proof."""
+    from zkir_amd import stark
+    log_n = 20
+    n = 1 << log_n
+    log, tr = _device_trace(spec.fib_endless_program().to_bytes(), n)
+    ctx = stark.StarkContext(log_n)
+    m = stark.main_trace(tr).cpu().numpy().view(np.uint32)
+    root, L, tree = stark.commit_trace(ctx, tr)
+    Lh, t = L.cpu().numpy().view(np.uint32), tree.cpu().numpy().view(np.uint32)
+    rng = np.random.default_rng(20)
+    for col in (0, 1, 9, 21, 76):                                   # cycle, pc limb, r0 limb (all zero), r4 limb, a changed flag
+        z = int(rng.integers(2, P))
+        assert _bary_eval(m[col], log_n, 1, z) == _bary_eval(Lh[col], log_n + 1, 31, z), col
+    for j in rng.integers(0, 2 * n, 6):
+        j = int(j)
+        node, off, mm = so.hash_elems(Lh[:, j]), 0, 2 * n
+        assert np.array_equal(node, t[4 * j:4 * j + 4])
+        while mm > 1:
+            sib = t[off + 4 * (j ^ 1): off + 4 * (j ^ 1) + 4]
+            node = so.compress(node, sib) if j % 2 == 0 else so.compress(sib, node)
+            off += 4 * mm; mm //= 2; j //= 2
+        assert np.array_equal(node, root)
+    proof = stark.prove(ctx, tr)
+    assert so.verify(proof) == 0
+    ctx.close()
