@@ -1,0 +1,112 @@
+"""Pipelined proving of independent runs on one GPU: host threads interpret (the VM is sequential — one run per thread) and
+upload the delta log on their own HIP streams while the single GPU thread fills the trace and proves the previous run.
+
+This is the caller side of the hot path (SURVEY §8f widening): what a proving service built on the C ABI looks like — one
+process per GPU, a few host cores feeding it, the execution trace never leaving HBM.  `zkir_prove` serialises per process, so
+there is exactly one consumer; the producers overlap with it because the C calls and the copies release the GIL.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import pipeline as pl, runtime as rt, stark
+
+Job = Tuple[bytes, Sequence[int], rt.VMConfig]
+
+
+@dataclass
+class PipelineReport:
+    runs: int = 0
+    rows: int = 0
+    wall_s: float = 0.0
+    interpret_s: float = 0.0          # summed over runs (overlapped across producer threads)
+    upload_s: float = 0.0
+    proofs: List[np.ndarray] = field(default_factory=list)
+
+    @property
+    def ms_per_run(self) -> float:
+        return self.wall_s / max(self.runs, 1) * 1e3
+
+    @property
+    def rows_per_s(self) -> float:
+        return self.rows / self.wall_s if self.wall_s else 0.0
+
+
+def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Optional[stark.StarkContext] = None,
+               keep_proofs: bool = True) -> PipelineReport:
+    """Prove every job (program blob, inputs, VMConfig with enable_execution_trace and max_cycles = 2^log2_rows rows).
+    Proofs come back in job order."""
+    pl._require_gpu()
+    jobs = list(jobs)
+    own_ctx = ctx is None
+    ctx = ctx or stark.StarkContext(log2_rows)
+    ready: "queue.Queue" = queue.Queue(maxsize=max(2, producers))
+    todo = list(enumerate(jobs))[::-1]
+    lock = threading.Lock()
+    errors: List[BaseException] = []
+
+    def producer():
+        s = torch.cuda.Stream()
+        while True:
+            with lock:
+                if not todo or errors:
+                    return
+                idx, (blob, inputs, cfg) = todo.pop()
+            try:
+                t0 = time.perf_counter()
+                log = rt.interpret(blob, list(inputs), cfg)
+                t1 = time.perf_counter()
+                if log.n_rows != 1 << log2_rows:
+                    raise rt.RuntimeError(rt.ERR_ARGUMENT, f"job {idx}: {log.n_rows} trace rows, the context is for 2^{log2_rows}")
+                with torch.cuda.stream(s):
+                    ddl = pl.upload(log)
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+                log.close()
+                ready.put((idx, ddl, ev, t1 - t0, time.perf_counter() - t1))
+            except BaseException as e:                    # surfaced by the consumer
+                errors.append(e)
+                ready.put(None)
+                return
+
+    rep = PipelineReport(runs=len(jobs), rows=len(jobs) << log2_rows)
+    out: List[Optional[np.ndarray]] = [None] * len(jobs)
+    threads = [threading.Thread(target=producer, daemon=True) for _ in range(max(1, producers))]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    try:
+        for _ in range(len(jobs)):
+            item = ready.get()
+            if item is None:
+                raise errors[0]
+            idx, ddl, ev, h, u = item
+            rep.interpret_s += h
+            rep.upload_s += u
+            torch.cuda.current_stream().wait_event(ev)
+            tr = pl.DeviceTrace(ddl)
+            pl.trace_fill(pl.trace_fill_args(ddl, tr))
+            proof = stark.prove(ctx, tr)                  # returns after the proof words are on the host: the run's buffers are idle
+            if keep_proofs:
+                out[idx] = proof
+        torch.cuda.synchronize()
+        rep.wall_s = time.perf_counter() - t0
+    finally:
+        with lock:
+            todo.clear()
+        while any(t.is_alive() for t in threads):         # unblock producers stuck on a full queue
+            try:
+                ready.get_nowait()
+            except queue.Empty:
+                time.sleep(0.001)
+        if own_ctx:
+            ctx.close()
+    rep.proofs = [p for p in out if p is not None]
+    return rep
