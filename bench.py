@@ -66,10 +66,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # Functional test of the N > 1 path on a 1-GPU box: ZKIR_BENCH_BACKEND=gloo ZKIR_BENCH_SHARE_GPU=1 runs every rank on
+    # cuda:0 and stages the 16-byte root exchange through the host.  Production (the driver's launch): nccl = RCCL, one GPU per rank.
+    backend = os.environ.get("ZKIR_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("ZKIR_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     k = args.log2_rows
     n = 1 << k
@@ -112,6 +119,25 @@ def main():
                    ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
                    ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
 
+    # N > 1: the step ends with the only collective of the path — an all-gather of the per-GPU subtree roots (16 B per rank over
+    # RCCL/xGMI) — and every rank hashes the top log2(G) levels over them (zkir_merkle_cap_launch), so `value` is the rate of the
+    # complete G-GPU commitment, not of G unrelated ones.
+    gathered, cap_root = None, [None]
+    if commit and world > 1:
+        gathered = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(world)]
+
+        def exchange():
+            if backend == "nccl":
+                dist.all_gather(gathered, tree[-4:])
+            else:
+                host = [torch.zeros(4, dtype=torch.int32) for _ in range(world)]
+                dist.all_gather(host, tree[-4:].cpu())
+                for dst, src in zip(gathered, host):
+                    dst.copy_(src)
+            if world & (world - 1) == 0:
+                cap_root[0] = stark.merkle_cap(ctx, torch.stack(gathered))
+        stages.append(("allgather_cap", exchange))
+
     def step():
         for _, f in stages:
             f()
@@ -122,8 +148,13 @@ def main():
         torch.cuda.synchronize()
 
     t_pre = time.perf_counter()                       # untimed pre-warm: let the GPU clocks settle (DVFS) before the W warmup steps
-    while time.perf_counter() - t_pre < 0.3:
-        step()
+    if world == 1:
+        while time.perf_counter() - t_pre < 0.3:
+            step()
+            torch.cuda.synchronize()
+    else:                                             # the step contains a collective: every rank must run the same number of them
+        for _ in range(40):
+            step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -138,7 +169,7 @@ def main():
     wall = time.perf_counter() - t0
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
@@ -197,12 +228,10 @@ def main():
         assert np.array_equal(got[r], e["value"][pos]), "bench parity spot-check failed"
     root = tree[-4:].cpu().numpy().view(np.uint32).tolist() if commit else None
     roots = None
-    if commit and world > 1:                          # the only collective of the path: all-gather of per-GPU subtree roots
-        g = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(world)]
-        dist.all_gather(g, tree[-4:].contiguous())
-        roots = [x.cpu().numpy().view(np.uint32).tolist() for x in g]
-        if world & (world - 1) == 0:                  # every rank hashes the top log2(G) levels over the gathered subtree roots
-            root = stark.merkle_cap(ctx, torch.stack(g)).cpu().numpy().view(np.uint32).tolist()
+    if commit and world > 1:
+        roots = [x.cpu().numpy().view(np.uint32).tolist() for x in gathered]
+        if cap_root[0] is not None:
+            root = cap_root[0].cpu().numpy().view(np.uint32).tolist()
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
@@ -253,7 +282,7 @@ def main():
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes,
             "pipelined_end_to_end": pipelined,
-            "merkle_root": root, "merkle_roots_all_ranks": roots,
+            "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,
             "h2d_upload_s": h2d_s,
             "end_to_end_rows_per_s_incl_host_and_pcie": n / (host_s / world + h2d_s + gpu_ms_per_step * 1e-3),
