@@ -40,7 +40,7 @@ BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
 // scripts/ubench_alu.hip; a modular add is add+add+min = 8.7 cycles, so hot loops skip the reduction where a value only
 // feeds a Montgomery multiplication or a 64-bit accumulation) -------------------------------------------------------
 // mont_mul() accepts ONE operand below 2p when the other is canonical: t + m*p < 2p^2 + 2^32 p < 2^64 and u < 2p still holds.
-// unreduced sum / difference of canonical values, below 2p: only as the lazy operand of a Montgomery product
+// add_lazy / sub_lazy: unreduced sum / difference of canonical values, below 2p — only ever that lazy operand of a product.
 BB_HD uint32_t add_lazy(uint32_t a, uint32_t b) { return a + b; }
 BB_HD uint32_t sub_lazy(uint32_t a, uint32_t b) { return a - b + P; }
 BB_HD uint32_t reduce_2p(uint32_t x) { const uint32_t d = x - P; return d < x ? d : x; }       // [0, 2p) -> [0, p)

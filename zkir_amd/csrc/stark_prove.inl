@@ -159,7 +159,6 @@ __global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
   LazyE4 A, B;                                                                // 93 and 89 terms; canonical v x Montgomery gamma^k = canonical product
-#pragma unroll 4
   for (int k = 0; k < WM; k++) {
     const uint32_t v = L[(uint64_t)k * N2 + j];
     lz_fma(A, d_pp.gamma_pow[k], v);
@@ -292,7 +291,6 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   static std::mutex prove_mu;
   std::lock_guard<std::mutex> prove_lock(prove_mu);
   *proof_out = nullptr; *proof_words = 0;
-  const int depth0 = (int)log_n + 1;
   const std::vector<int> ks = fri_schedule((int)log_n);
   const int n_layers = (int)ks.size();
 
