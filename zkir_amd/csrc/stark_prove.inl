@@ -159,7 +159,18 @@ __global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
   LazyE4 A, B;                                                                // 93 and 89 terms; canonical v x Montgomery gamma^k = canonical product
-  for (int k = 0; k < WM; k++) {
+  // eight column loads in flight per lane (the loop body is long and the compiler keeps it rolled: one load at a time otherwise)
+  constexpr int UN = 8;
+  int k = 0;
+#pragma unroll 1
+  for (; k + UN <= WM; k += UN) {
+    uint32_t v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) v[u] = L[(uint64_t)(k + u) * N2 + j];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { lz_fma(A, d_pp.gamma_pow[k + u], v[u]); lz_fma(B, d_pp.gamma_pow[WM + k + u], v[u]); }
+  }
+  for (; k < WM; k++) {
     const uint32_t v = L[(uint64_t)k * N2 + j];
     lz_fma(A, d_pp.gamma_pow[k], v);
     lz_fma(B, d_pp.gamma_pow[WM + k], v);
