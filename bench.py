@@ -159,30 +159,23 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events between the stages INSIDE the timed region, on the stream the kernels are launched on (torch's current stream):
+    # the per-stage durations the rooflines are computed from are those of the timed steps themselves.
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] for _ in range(args.steps)]
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()                                        # every launch goes to torch's current stream
-    ev1.record()
+    for i in range(args.steps):
+        for j, (_, f) in enumerate(stages):
+            marks[i][j].record()
+            f()
+        marks[i][-1].record()
     barrier()
     wall = time.perf_counter() - t0
-    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    gpu_ms_per_step = marks[0][0].elapsed_time(marks[-1][-1]) / args.steps
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-
-    # ---- per-stage kernel times with HIP events on the launch stream (outside the timed region) ----
-    stage_ms = {}
-    for name, f in stages:
-        ts = []
-        for _ in range(10):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); f(); b.record()
-            torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b))
-        stage_ms[name] = float(np.mean(ts))
+    stage_ms = {name: float(np.mean([marks[i][j].elapsed_time(marks[i][j + 1]) for i in range(args.steps)])) for j, (name, _) in enumerate(stages)}
 
     # ---- measured HBM copy bandwidth of this device (report the measured peak next to the nominal 8 TB/s) ----
     src = torch.empty(1 << 28, dtype=torch.int32, device="cuda")          # 1 GiB
