@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--stage", choices=["commit", "trace_fill"], default="commit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prove", action="store_true", help="skip the end-to-end proof / pipelined sections that follow the timed region "
+                    "(profiling runs: keeps the rocprofv3 per-kernel averages to the kernels of the timed steps)")
     args = ap.parse_args()
 
     import numpy as np
@@ -192,7 +194,7 @@ def main():
 
     # ---- end-to-end prove (BASELINE metric's "end-to-end prove ms"): AIR quotient + openings + DEEP + FRI on top of the commit ----
     prove_ms, prove_stage_ms, proof_bytes = None, None, None
-    if commit and world == 1:                         # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
+    if commit and world == 1 and not args.no_prove:   # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
         for _ in range(2):                            # first call allocates the context's workspace
             t0 = time.perf_counter()
             proof, pms = stark.prove(ctx, trace, want_stage_ms=True)
@@ -202,7 +204,7 @@ def main():
 
     # ---- the same proof with the host in the loop: independent runs pipelined through interpret -> H2D -> K1 -> prove ----------
     pipelined = None
-    if commit and world == 1 and k <= 22:
+    if commit and world == 1 and k <= 22 and not args.no_prove:
         from zkir_amd import service
         job = (blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
         service.prove_many([job] * 2, k, producers=1, ctx=ctx, keep_proofs=False)
