@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end prove timing (zkir_prove stage breakdown) on a 2^k-cycle fib trace; verifies the proof with the oracle verifier."""
+"""End-to-end prove timing (zkir_prove stage breakdown) on a 2^k-cycle fib trace.  (The proofs are checked against the oracle in tests/test_gpu_stark.py.)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,6 +19,3 @@ for it in range(3):
 wall, ms = best
 for nm, v in zip(names, ms): print(f"{nm:16s} {v:9.3f} ms")
 print(f"prove wall       {wall:9.3f} ms   (sum of stages {sum(ms):.3f});  host interpret {t_host*1e3:.1f} ms;  proof {len(proof)*4/1024:.1f} KiB")
-if "--verify" in sys.argv:
-    from oracle import stark_api as so
-    t0 = time.perf_counter(); rc = so.verify(proof); print("oracle verify ->", rc, f"({time.perf_counter()-t0:.2f} s)")
