@@ -44,6 +44,17 @@ def _strided_passes(stages: int) -> int:
     return cnt
 
 
+def _profiled_valu_busy(kernel: str):
+    """VALUBusy (0..1) of `kernel` from the committed rocprofv3 counter pass (profiles/r01_bench_commit_valu_busy.txt), or None."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r01_bench_commit_valu_busy.txt")):
+            if line.startswith(kernel):
+                return float(line.split()[-2]) / 100.0
+    except OSError:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,7 +282,13 @@ def main():
                          "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
                          "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (692 Montgomery multiplications + 130 wide reductions per "
                                   "permutation; VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see roofline_by_stage for its ALU rate and for the HBM-bound stages")
-                         if kernels[dom]["bound"] != "hbm" else None},
+                         if kernels[dom]["bound"] != "hbm" else None,
+                         # the roofline that does bound this kernel: vector-ALU issue.  `achieved`/`peak` = Montgomery products per
+                         # second against the device's measured peak of independent products; `valu_busy_profiled` = rocprofv3
+                         # VALUBusy of leaf_hash_kernel in the committed counter pass of this command (profiles/)
+                         "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["mont_mul_per_s"], "peak": kernels[dom]["mont_mul_peak_per_s_measured"],
+                                  "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel")}
+                                 if kernels[dom]["bound"] == "int-alu" else None)},
             "roofline_by_stage": kernels,
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
