@@ -70,6 +70,9 @@ while time.time() < t_end:
             continue                                                # halted early: not a power-of-two trace
         log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
         ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        got_rows = tr.rows()
+        for name in want_rows.dtype.names:                          # K1 (trace fill) against the oracle's rows, all 372 B
+            assert np.array_equal(got_rows[name], want_rows[name]), ("trace", name)
         ctx = ctxs.setdefault(log_n, stark.StarkContext(log_n))
         proof = stark.prove(ctx, tr)
         want = so.prove(want_rows)
@@ -78,4 +81,4 @@ while time.time() < t_end:
         # verifier's verdict must at least be the same for both provers' (identical) words
         n_proof += 1
         log.close()
-print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_proof} proofs identical to the oracle in {budget:.0f} s")
+print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_proof} traces + proofs identical to the oracle in {budget:.0f} s")
