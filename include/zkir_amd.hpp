@@ -1,0 +1,235 @@
+// zkir_amd.hpp — C++ host mirror of the reference's interface for the hot path, above the C ABI of zkir_amd.h.
+//
+// The reference is Rust and its toolchain is absent from the image, so the host side a maintainer would write in
+// `zkir-runtime` is given here in C++ with the reference's names, argument meaning and error behaviour:
+//
+//   zkir_spec::Opcode / encode / Program          zkir-spec/src/opcode.rs:24-144, zkir-assembler/src/encoder.rs:18-151,
+//                                                 zkir-spec/src/program.rs:62-346
+//   zkir_runtime::VMConfig                        zkir-runtime/src/vm.rs:15-50 (same defaults)
+//   zkir_runtime::HaltReason                      zkir-runtime/src/state.rs:8-15
+//   zkir_runtime::RuntimeError                    zkir-runtime/src/error.rs:7-37 (kind + the reference's message text)
+//   zkir_runtime::VM::new(..).run()               zkir-runtime/src/vm.rs:138-358 (`run` consumes the VM)
+//   zkir_runtime::ExecutionResult                 zkir-runtime/src/vm.rs:54-103
+//   zkir_runtime::run(program, inputs)            zkir-runtime/src/lib.rs:59-62
+//
+// Header-only, C++17, no HIP types: link with -lzkir_amd.  With enable_execution_trace the run goes through zkir_exec and the
+// trace stays in HBM (ExecutionTrace copies columns/rows to the host on demand); without it only the host interpreter runs.
+// tests/cpp/reference_tests.cpp re-states a handful of the reference's own tests against this header.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "zkir_amd.h"
+
+namespace zkir_spec {
+
+enum class Opcode : uint8_t {                                   // opcode.rs:24-144
+  ADD = 0x00, SUB = 0x01, MUL = 0x02, MULH = 0x03, DIVU = 0x04, REMU = 0x05, DIV = 0x06, REM = 0x07, ADDI = 0x08,
+  AND = 0x10, OR = 0x11, XOR = 0x12, ANDI = 0x13, ORI = 0x14, XORI = 0x15,
+  SLL = 0x18, SRL = 0x19, SRA = 0x1A, SLLI = 0x1B, SRLI = 0x1C, SRAI = 0x1D,
+  SLTU = 0x20, SGEU = 0x21, SLT = 0x22, SGE = 0x23, SEQ = 0x24, SNE = 0x25, CMOV = 0x26, CMOVZ = 0x27, CMOVNZ = 0x28,
+  LB = 0x30, LBU = 0x31, LH = 0x32, LHU = 0x33, LW = 0x34, LD = 0x35, SB = 0x38, SH = 0x39, SW = 0x3A, SD = 0x3B,
+  BEQ = 0x40, BNE = 0x41, BLT = 0x42, BGE = 0x43, BLTU = 0x44, BGEU = 0x45, JAL = 0x48, JALR = 0x49, ECALL = 0x50, EBREAK = 0x51
+};
+
+// encoder.rs:100-151; immediates are silently masked to 17 bits (quirk Q11), S/B-type keep rs1 in bits 10:7 and rs2 in 14:11
+inline uint32_t enc_r(Opcode op, int rd, int rs1, int rs2) { return (uint32_t)op | (rd & 0xF) << 7 | (rs1 & 0xF) << 11 | (rs2 & 0xF) << 15; }
+inline uint32_t enc_i(Opcode op, int rd, int rs1, int32_t imm) { return (uint32_t)op | (rd & 0xF) << 7 | (rs1 & 0xF) << 11 | ((uint32_t)imm & 0x1FFFF) << 15; }
+inline uint32_t enc_j(Opcode op, int rd, int32_t off) { return (uint32_t)op | (rd & 0xF) << 7 | ((uint32_t)off & 0x1FFFFF) << 11; }
+
+// the reference's `Instruction::X { .. }` vocabulary
+inline uint32_t add(int rd, int rs1, int rs2) { return enc_r(Opcode::ADD, rd, rs1, rs2); }
+inline uint32_t sub(int rd, int rs1, int rs2) { return enc_r(Opcode::SUB, rd, rs1, rs2); }
+inline uint32_t mul(int rd, int rs1, int rs2) { return enc_r(Opcode::MUL, rd, rs1, rs2); }
+inline uint32_t div_(int rd, int rs1, int rs2) { return enc_r(Opcode::DIV, rd, rs1, rs2); }
+inline uint32_t divu(int rd, int rs1, int rs2) { return enc_r(Opcode::DIVU, rd, rs1, rs2); }
+inline uint32_t addi(int rd, int rs1, int32_t imm) { return enc_i(Opcode::ADDI, rd, rs1, imm); }
+inline uint32_t lw(int rd, int rs1, int32_t imm) { return enc_i(Opcode::LW, rd, rs1, imm); }
+inline uint32_t sw(int rs1, int rs2, int32_t imm) { return enc_i(Opcode::SW, rs1, rs2, imm); }     // mem[rs1 + imm] = rs2
+inline uint32_t beq(int rs1, int rs2, int32_t off) { return enc_i(Opcode::BEQ, rs1, rs2, off); }
+inline uint32_t bne(int rs1, int rs2, int32_t off) { return enc_i(Opcode::BNE, rs1, rs2, off); }
+inline uint32_t jal(int rd, int32_t off) { return enc_j(Opcode::JAL, rd, off); }
+inline uint32_t ecall() { return (uint32_t)Opcode::ECALL; }
+inline uint32_t ebreak() { return (uint32_t)Opcode::EBREAK; }
+
+// program.rs:62-346: 32-byte little-endian header + code words + data bytes
+struct Program {
+  uint8_t limb_bits = 20, data_limbs = 2, addr_limbs = 2, flags = 0;
+  uint32_t entry_point = 0x1000, bss_size = 0, stack_size = 1u << 20;
+  std::vector<uint32_t> code;
+  std::vector<uint8_t> data;
+
+  static Program from_code(std::vector<uint32_t> words) { Program p; p.code = std::move(words); return p; }
+
+  std::vector<uint8_t> to_bytes() const {                       // program.rs:300-315
+    std::vector<uint8_t> b(32 + 4 * code.size() + data.size());
+    auto put32 = [&](size_t at, uint32_t v) { for (int i = 0; i < 4; i++) b[at + i] = (uint8_t)(v >> (8 * i)); };
+    put32(0, 0x52494B5Au); put32(4, 0x00030004u);
+    b[8] = limb_bits; b[9] = data_limbs; b[10] = addr_limbs; b[11] = flags;
+    put32(12, entry_point); put32(16, (uint32_t)(4 * code.size())); put32(20, (uint32_t)data.size()); put32(24, bss_size); put32(28, stack_size);
+    for (size_t i = 0; i < code.size(); i++) put32(32 + 4 * i, code[i]);
+    if (!data.empty()) std::memcpy(b.data() + 32 + 4 * code.size(), data.data(), data.size());
+    return b;
+  }
+};
+
+}  // namespace zkir_spec
+
+namespace zkir_runtime {
+
+struct VMConfig {                                               // vm.rs:15-50
+  uint64_t max_cycles = 1000000;
+  bool trace = false, enable_range_checking = false, enable_execution_trace = false, enable_deferred_model = false;
+};
+
+struct HaltReason {                                             // state.rs:8-15
+  enum Kind { Ebreak = ZKIR_HALT_EBREAK, Exit = ZKIR_HALT_EXIT, CycleLimit = ZKIR_HALT_CYCLE_LIMIT } kind;
+  uint64_t code = 0;                                            // Exit(code)
+  bool operator==(const HaltReason& o) const { return kind == o.kind && (kind != Exit || code == o.code); }
+  bool operator!=(const HaltReason& o) const { return !(*this == o); }
+  static HaltReason exit(uint64_t c) { return {Exit, c}; }
+  static HaltReason ebreak() { return {Ebreak, 0}; }
+  static HaltReason cycle_limit() { return {CycleLimit, 0}; }
+};
+
+class RuntimeError : public std::runtime_error {                // error.rs:7-37; what() is the reference's Display text
+ public:
+  enum Kind { MisalignedAccess = ZKIR_ERR_MISALIGNED, InvalidMemoryAccess = ZKIR_ERR_INVALID_MEMORY, DivisionByZero = ZKIR_ERR_DIV_ZERO,
+              InvalidSyscall = ZKIR_ERR_INVALID_SYSCALL, Decode = ZKIR_ERR_DECODE, Other = ZKIR_ERR_OTHER, BadProgram = ZKIR_ERR_BAD_PROGRAM,
+              Device = ZKIR_ERR_DEVICE, Argument = ZKIR_ERR_ARGUMENT };
+  RuntimeError(int code, const std::string& msg) : std::runtime_error(msg), kind((Kind)code) {}
+  Kind kind;
+};
+
+namespace detail {
+[[noreturn]] inline void raise(int rc) { const char* m = zkir_last_error(); throw RuntimeError(rc, m ? m : "zkir_amd error"); }
+}  // namespace detail
+
+struct ValueBound { uint32_t max_bits; uint8_t source_tag; uint64_t source_payload; };   // bound.rs:116-121 (tag = ZKIR_BOUND_*)
+
+struct TraceRow {                                               // trace.rs:24-50 (memory_ops are served by ExecutionResult)
+  uint64_t cycle, pc;
+  uint32_t instruction;
+  std::array<uint64_t, 16> registers;
+  std::array<ValueBound, 16> bounds;
+  std::array<uint8_t, 16> register_states;                      // 0 Normalized, 1 Accumulated
+};
+
+class ExecutionResult;
+
+// Vec<TraceRow> of the reference, resident in HBM as struct-of-arrays (zkir_trace_columns)
+class ExecutionTrace {
+ public:
+  size_t len() const { return n_rows_; }
+  bool is_empty() const { return n_rows_ == 0; }
+  const zkir_trace_columns* device_columns() const { return r_ ? zkir_result_trace(r_) : nullptr; }
+  // field ids of zkir_result_copy_column: 0 cycle, 1 pc, 2 instruction, 3 registers, 4 bound_bits, 5 bound_tag, 6 bound_payload, 7 reg_state
+  template <typename T>
+  std::vector<T> column(int field, int reg = 0) const {
+    std::vector<T> out(n_rows_);
+    if (n_rows_) { const int rc = zkir_result_copy_column(r_, field, reg, out.data()); if (rc != ZKIR_OK) detail::raise(rc); }
+    return out;
+  }
+  std::vector<TraceRow> rows() const {                          // host copy of every row (tests; O(372 B/row) over PCIe)
+    std::vector<TraceRow> out(n_rows_);
+    const auto cyc = column<uint64_t>(0), pc = column<uint64_t>(1);
+    const auto ins = column<uint32_t>(2);
+    for (size_t i = 0; i < n_rows_; i++) { out[i].cycle = cyc[i]; out[i].pc = pc[i]; out[i].instruction = ins[i]; }
+    for (int g = 0; g < 16; g++) {
+      const auto v = column<uint64_t>(3, g), pay = column<uint64_t>(6, g);
+      const auto bits = column<uint32_t>(4, g);
+      const auto tag = column<uint8_t>(5, g), st = column<uint8_t>(7, g);
+      for (size_t i = 0; i < n_rows_; i++) { out[i].registers[g] = v[i]; out[i].bounds[g] = {bits[i], tag[i], pay[i]}; out[i].register_states[g] = st[i]; }
+    }
+    return out;
+  }
+
+ private:
+  friend class ExecutionResult;
+  const zkir_result* r_ = nullptr;
+  size_t n_rows_ = 0;
+};
+
+class ExecutionResult {                                         // vm.rs:54-78
+ public:
+  uint64_t cycles = 0;
+  std::vector<uint64_t> outputs;
+  HaltReason halt_reason{HaltReason::Ebreak, 0};
+  ExecutionTrace execution_trace;
+
+  size_t memory_op_count() const { return zkir_delta_log_n_mem_events(log()); }          // vm.rs:97-102
+  size_t range_check_witness_count() const { return zkir_delta_log_n_rc_witnesses(log()); }
+  size_t normalization_event_count() const { return zkir_delta_log_n_norm_events(log()); }
+  const zkir_delta_log* delta_log() const { return log(); }     // host-side logs for the witness kernels (zkir_memops_*_launch, ...)
+
+  ExecutionResult(ExecutionResult&& o) noexcept { *this = std::move(o); }
+  ExecutionResult& operator=(ExecutionResult&& o) noexcept {
+    if (this != &o) {
+      release();
+      cycles = o.cycles; outputs = std::move(o.outputs); halt_reason = o.halt_reason; execution_trace = o.execution_trace;
+      res_ = o.res_; own_log_ = o.own_log_; o.res_ = nullptr; o.own_log_ = nullptr; o.execution_trace = ExecutionTrace();
+    }
+    return *this;
+  }
+  ExecutionResult(const ExecutionResult&) = delete;
+  ExecutionResult& operator=(const ExecutionResult&) = delete;
+  ~ExecutionResult() { release(); }
+
+ private:
+  friend class VM;
+  ExecutionResult() = default;
+  const zkir_delta_log* log() const { return res_ ? zkir_result_delta_log(res_) : own_log_; }
+  void fill() {
+    const zkir_delta_log* l = log();
+    cycles = zkir_delta_log_cycles(l);
+    const int kind = zkir_delta_log_halt_kind(l);
+    halt_reason = {(HaltReason::Kind)kind, kind == ZKIR_HALT_EXIT ? zkir_delta_log_halt_code(l) : 0};
+    const uint64_t* o = zkir_delta_log_outputs(l);
+    outputs.assign(o, o + zkir_delta_log_n_outputs(l));
+    execution_trace.r_ = res_;
+    execution_trace.n_rows_ = res_ ? (size_t)zkir_delta_log_n_rows(l) : 0;
+  }
+  void release() {
+    if (res_) zkir_result_free(res_);                           // also frees the delta log it owns
+    else if (own_log_) zkir_delta_log_free(own_log_);
+    res_ = nullptr; own_log_ = nullptr;
+  }
+  zkir_result* res_ = nullptr;
+  zkir_delta_log* own_log_ = nullptr;
+};
+
+class VM {                                                      // vm.rs:138-358
+ public:
+  static VM new_(const zkir_spec::Program& program, std::vector<uint64_t> inputs, VMConfig config = {}) { return VM(program.to_bytes(), std::move(inputs), config); }
+  VM(std::vector<uint8_t> program_blob, std::vector<uint64_t> inputs, VMConfig config = {})
+      : blob_(std::move(program_blob)), inputs_(std::move(inputs)), config_(config) {}
+
+  ExecutionResult run() && {                                    // consumes the VM, as in the reference
+    const zkir_vm_config cfg{config_.max_cycles, (uint8_t)config_.trace, (uint8_t)config_.enable_range_checking,
+                             (uint8_t)config_.enable_execution_trace, (uint8_t)config_.enable_deferred_model};
+    ExecutionResult r;
+    int rc;
+    if (config_.enable_execution_trace) rc = zkir_exec(blob_.data(), blob_.size(), inputs_.data(), inputs_.size(), &cfg, &r.res_);
+    else rc = zkir_interpret(blob_.data(), blob_.size(), inputs_.data(), inputs_.size(), &cfg, 0, &r.own_log_);   // nothing to materialise on the device
+    if (rc != ZKIR_OK) detail::raise(rc);
+    r.fill();
+    return r;
+  }
+
+ private:
+  std::vector<uint8_t> blob_;
+  std::vector<uint64_t> inputs_;
+  VMConfig config_;
+};
+
+inline std::vector<uint64_t> run(const zkir_spec::Program& program, std::vector<uint64_t> inputs) {      // lib.rs:59-62
+  return VM::new_(program, std::move(inputs), VMConfig{}).run().outputs;
+}
+
+}  // namespace zkir_runtime

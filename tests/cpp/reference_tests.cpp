@@ -1,0 +1,163 @@
+// reference_tests.cpp — a handful of the reference's own tests re-stated against the C++ host mirror (include/zkir_amd.hpp):
+// same programs, same assertions, the reference file:line next to each.  Expected values are the literals those tests assert
+// (also held as data in tests/golden/reference_kats.json).
+//
+//   ./reference_tests host   — tests that run with VMConfig defaults (no execution trace: host interpreter only, no GPU needed)
+//   ./reference_tests gpu    — the tests that enable the execution trace (zkir_exec: trace materialised in HBM) as well
+//
+// Built and run by tests/test_cpp_mirror.py (g++ -std=c++17 -Iinclude tests/cpp/reference_tests.cpp -Lzkir_amd -lzkir_amd).
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "zkir_amd.hpp"
+
+using namespace zkir_spec;
+using zkir_runtime::ExecutionResult;
+using zkir_runtime::HaltReason;
+using zkir_runtime::RuntimeError;
+using zkir_runtime::VM;
+using zkir_runtime::VMConfig;
+
+static int failures = 0;
+#define CHECK(cond)                                                                           \
+  do { if (!(cond)) { std::printf("    FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+
+static std::vector<uint32_t> cat(std::initializer_list<std::vector<uint32_t>> parts) {
+  std::vector<uint32_t> out;
+  for (auto& p : parts) out.insert(out.end(), p.begin(), p.end());
+  return out;
+}
+static std::vector<uint32_t> write_reg(int r) { return {addi(11, r, 0), addi(10, 0, 2), ecall()}; }       // SYS_WRITE(R11 = r)
+static const std::vector<uint32_t> EXIT0 = {addi(10, 0, 0), addi(11, 0, 0), ecall()};                      // SYS_EXIT(0)
+
+// ---- tests/cross_module.rs ----------------------------------------------------------------------------------------------
+static void test_fibonacci() {                                   // cross_module.rs:140-175: fib(5) = 5, exit code 0
+  auto code = cat({{addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, 4), add(4, 1, 2), addi(1, 2, 0), addi(2, 4, 0), addi(3, 3, -1), bne(3, 0, -16)}, write_reg(2), EXIT0});
+  CHECK(code[3] == 0x00010A00u && code[7] == 0xFFF801C1u);       // the encodings the reference's assembler produces
+  ExecutionResult r = VM::new_(Program::from_code(code), {}).run();
+  CHECK(r.outputs == std::vector<uint64_t>{5});
+  CHECK(r.halt_reason == HaltReason::exit(0));
+}
+static void test_sum_loop() {                                    // cross_module.rs:406-437: 1 + 2 + .. + 5 = 15
+  auto code = cat({{addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, 6), add(1, 1, 2), addi(2, 2, 1), bne(2, 3, -8)}, write_reg(1), EXIT0});
+  CHECK(zkir_runtime::run(Program::from_code(code), {}) == std::vector<uint64_t>{15});
+}
+static void test_arithmetic_chain() {                            // cross_module.rs:60-87: 10 + 20 + 30 = 60
+  auto code = cat({{addi(1, 0, 10), addi(2, 0, 20), addi(3, 0, 30), add(4, 1, 2), add(4, 4, 3)}, write_reg(4), EXIT0});
+  CHECK(zkir_runtime::run(Program::from_code(code), {}) == std::vector<uint64_t>{60});
+}
+static void test_branch_taken_skips() {                          // cross_module.rs:370-403: r3 stays 0
+  auto code = cat({{addi(1, 0, 10), addi(2, 0, 10), beq(1, 2, 8), addi(3, 0, 1), addi(4, 0, 2)}, write_reg(3), EXIT0});
+  CHECK(zkir_runtime::run(Program::from_code(code), {}) == std::vector<uint64_t>{0});
+}
+static void test_store_load_roundtrip() {                        // cross_module.rs:335-363
+  auto code = cat({{addi(1, 0, 42), addi(2, 0, 0x1000), sw(2, 1, 0), lw(3, 2, 0)}, write_reg(3), EXIT0});
+  CHECK(zkir_runtime::run(Program::from_code(code), {}) == std::vector<uint64_t>{42});
+}
+static void test_echo_input() {                                  // cross_module.rs:32-57; vm.rs:489-533
+  auto code = cat({{addi(10, 0, 1), ecall(), addi(11, 10, 0), addi(10, 0, 2), ecall()}, EXIT0});
+  ExecutionResult r = VM::new_(Program::from_code(code), {123}).run();
+  CHECK(r.outputs == std::vector<uint64_t>{123} && r.halt_reason == HaltReason::exit(0));
+}
+// ---- zkir-runtime/src/vm.rs unit tests ----------------------------------------------------------------------------------
+static void test_exit_code() {                                   // vm.rs:464-486: Exit(42) after 3 cycles
+  ExecutionResult r = VM::new_(Program::from_code({addi(10, 0, 0), addi(11, 0, 42), ecall()}), {}).run();
+  CHECK(r.halt_reason == HaltReason::exit(42) && r.cycles == 3);
+}
+static void test_basic_ebreak() {                                // vm.rs:434-461
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 0, 10), addi(2, 0, 20), add(3, 1, 2), ebreak()}), {}).run();
+  CHECK(r.halt_reason == HaltReason::ebreak() && r.cycles == 4);
+}
+static void test_cycle_limit() {                                 // vm.rs:536-552: jal r0, 0 forever, max_cycles = 100
+  VMConfig cfg; cfg.max_cycles = 100;
+  ExecutionResult r = VM::new_(Program::from_code({jal(0, 0)}), {}, cfg).run();
+  CHECK(r.halt_reason == HaltReason::cycle_limit() && r.cycles == 100);
+}
+static void test_trace_disabled_by_default() {                   // vm.rs:866-904
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 0, 0x42), addi(3, 0, 0x1000), sw(3, 1, 0), ebreak()}), {}).run();
+  CHECK(r.execution_trace.is_empty() && r.memory_op_count() == 0);
+}
+// ---- tests/stress_tests.rs ----------------------------------------------------------------------------------------------
+static void test_thousand_instructions() {                       // stress_tests.rs:25-56: 1003 cycles
+  std::vector<uint32_t> code(1000, add(1, 1, 0));
+  code.insert(code.end(), EXIT0.begin(), EXIT0.end());
+  ExecutionResult r = VM::new_(Program::from_code(code), {}).run();
+  CHECK(r.halt_reason == HaltReason::exit(0) && r.cycles == 1003);
+}
+static void test_divu_by_one() {                                 // stress_tests.rs:437-460
+  auto code = cat({{addi(1, 0, 12345), addi(2, 0, 1), divu(3, 1, 2)}, write_reg(3), EXIT0});
+  CHECK(zkir_runtime::run(Program::from_code(code), {}) == std::vector<uint64_t>{12345});
+}
+// ---- error behaviour ----------------------------------------------------------------------------------------------------
+template <typename F>
+static bool throws(RuntimeError::Kind kind, const char* needle, F f) {
+  try { f(); } catch (const RuntimeError& e) { return e.kind == kind && std::strstr(e.what(), needle) != nullptr; }
+  return false;
+}
+static void test_division_by_zero() {                            // execute.rs:849-867: RuntimeError::DivisionByZero { pc }
+  CHECK(throws(RuntimeError::DivisionByZero, "Division by zero", [] { VM::new_(Program::from_code({addi(1, 0, 100), div_(3, 1, 2)}), {}).run(); }));
+}
+static void test_invalid_syscall() {                             // syscall.rs:262-277: InvalidSyscall { syscall: 999 }
+  CHECK(throws(RuntimeError::InvalidSyscall, "999", [] { VM::new_(Program::from_code({addi(10, 0, 999), ecall()}), {}).run(); }));
+}
+static void test_poseidon2_syscall_is_an_error() {               // syscall_integration.rs:401-422; crypto.rs:462-466
+  CHECK(throws(RuntimeError::Other, "", [] { VM::new_(Program::from_code({addi(10, 0, 4), ecall()}), {}).run(); }));
+}
+static void test_run_consumes_the_vm() {                         // vm.rs:208 takes self: in C++ run() is rvalue-qualified
+  VM vm = VM::new_(Program::from_code({ebreak()}), {});
+  ExecutionResult r = std::move(vm).run();
+  CHECK(r.cycles == 1);
+}
+// ---- execution trace (GPU) ----------------------------------------------------------------------------------------------
+static void test_execution_trace_rows() {                        // vm.rs:906-964; cross_module.rs:444-468: 4 rows, cycle = index, pre-state
+  VMConfig cfg; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 0, 100), addi(2, 0, 200), add(3, 1, 2), ebreak()}), {}, cfg).run();
+  CHECK(r.execution_trace.len() == 4);
+  auto rows = r.execution_trace.rows();
+  for (size_t i = 0; i < rows.size(); i++) CHECK(rows[i].cycle == i && rows[i].pc == 0x1000 + 4 * i);
+  CHECK(rows[0].registers[1] == 0 && rows[1].registers[1] == 100 && rows[2].registers[2] == 200 && rows[3].registers[3] == 300);   // state BEFORE each instruction
+  CHECK(rows[3].instruction == ebreak());
+  CHECK(r.halt_reason == HaltReason::ebreak());
+}
+static void test_trace_with_memory_ops() {                       // vm.rs:996-1070: 5 rows, one store and one load recorded
+  VMConfig cfg; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 0, 0x42), addi(3, 0, 0x1000), sw(3, 1, 0), lw(4, 3, 0), ebreak()}), {}, cfg).run();
+  CHECK(r.execution_trace.len() == 5 && r.memory_op_count() == 2);
+  auto rows = r.execution_trace.rows();
+  CHECK(rows[4].registers[4] == 0x42);
+}
+static void test_cycle_limit_trace() {                           // vm.rs:211-214: CycleLimit is a normal halt with exactly max_cycles rows
+  VMConfig cfg; cfg.enable_execution_trace = true; cfg.max_cycles = 1000;
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 1, 1), jal(0, -4)}), {}, cfg).run();
+  CHECK(r.execution_trace.len() == 1000 && r.halt_reason == HaltReason::cycle_limit());
+  auto r1 = r.execution_trace.column<uint64_t>(3, 1);             // registers[1] column straight from HBM
+  CHECK(r1[0] == 0 && r1[2] == 1 && r1[999] == 500);
+}
+
+int main(int argc, char** argv) {
+  const bool gpu = argc > 1 && std::string(argv[1]) == "gpu";
+  struct T { const char* name; std::function<void()> f; bool needs_gpu; };
+  const std::vector<T> tests = {
+      {"test_fibonacci", test_fibonacci, false}, {"test_sum_loop", test_sum_loop, false}, {"test_arithmetic_chain", test_arithmetic_chain, false},
+      {"test_branch_taken_skips", test_branch_taken_skips, false}, {"test_store_load_roundtrip", test_store_load_roundtrip, false},
+      {"test_echo_input", test_echo_input, false}, {"test_exit_code", test_exit_code, false}, {"test_basic_ebreak", test_basic_ebreak, false},
+      {"test_cycle_limit", test_cycle_limit, false}, {"test_trace_disabled_by_default", test_trace_disabled_by_default, false},
+      {"test_thousand_instructions", test_thousand_instructions, false}, {"test_divu_by_one", test_divu_by_one, false},
+      {"test_division_by_zero", test_division_by_zero, false}, {"test_invalid_syscall", test_invalid_syscall, false},
+      {"test_poseidon2_syscall_is_an_error", test_poseidon2_syscall_is_an_error, false}, {"test_run_consumes_the_vm", test_run_consumes_the_vm, false},
+      {"test_execution_trace_rows", test_execution_trace_rows, true}, {"test_trace_with_memory_ops", test_trace_with_memory_ops, true},
+      {"test_cycle_limit_trace", test_cycle_limit_trace, true}};
+  int ran = 0;
+  for (const auto& t : tests) {
+    if (t.needs_gpu && !gpu) continue;
+    const int before = failures;
+    try { t.f(); } catch (const std::exception& e) { std::printf("    EXCEPTION in %s: %s\n", t.name, e.what()); failures++; }
+    std::printf("%s ... %s\n", t.name, failures == before ? "ok" : "FAILED");
+    ran++;
+  }
+  std::printf("%d tests, %d failures\n", ran, failures);
+  return failures ? 1 : 0;
+}
