@@ -233,3 +233,34 @@ inline std::vector<uint64_t> run(const zkir_spec::Program& program, std::vector<
 }
 
 }  // namespace zkir_runtime
+
+// ---- the self-defined prover stages (ABSENT from the reference, parity unpinned) ---------------------------------
+namespace zkir_prover {
+
+class StarkContext {                                            // device tables + workspace for traces of 2^log_n rows
+ public:
+  explicit StarkContext(uint32_t log_n) : log_n_(log_n) { const int rc = zkir_stark_ctx_create(log_n, 1, &h_); if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc); }
+  ~StarkContext() { zkir_stark_ctx_free(h_); }
+  StarkContext(const StarkContext&) = delete;
+  StarkContext& operator=(const StarkContext&) = delete;
+  const zkir_stark_ctx* handle() const { return h_; }
+  uint32_t log_n() const { return log_n_; }
+
+ private:
+  zkir_stark_ctx* h_ = nullptr;
+  uint32_t log_n_;
+};
+
+// Full proof (u32 little-endian words, format v2) of a run whose execution trace has exactly 2^log_n rows and is resident in HBM.
+inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::ExecutionResult& result, void* hip_stream = nullptr) {
+  uint32_t* words = nullptr;
+  uint64_t n = 0;
+  const int rc = zkir_prove(ctx.handle(), result.execution_trace.device_columns(), result.execution_trace.len(), &words, &n, nullptr, hip_stream);
+  if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc);
+  std::vector<uint32_t> out(words, words + n);
+  zkir_proof_free(words);
+  return out;
+}
+
+}  // namespace zkir_prover
+

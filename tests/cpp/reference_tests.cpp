@@ -137,6 +137,18 @@ static void test_cycle_limit_trace() {                           // vm.rs:211-21
   CHECK(r1[0] == 0 && r1[2] == 1 && r1[999] == 500);
 }
 
+// ---- prover stages (no counterpart in the reference: only the shape of the result can be asserted here; the words are compared
+// with the oracle's prover and checked by its verifier in tests/test_gpu_stark.py) ------------------------------------------------
+static void test_prove_power_of_two_trace() {
+  VMConfig cfg; cfg.enable_execution_trace = true; cfg.max_cycles = 1 << 10;
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 1, 1), jal(0, -4)}), {}, cfg).run();
+  zkir_prover::StarkContext ctx(10);
+  const std::vector<uint32_t> proof = zkir_prover::prove(ctx, r);
+  CHECK(proof.size() > 1000 && proof[0] == 0x46504B5Au && proof[1] == 2 && proof[2] == 10 && proof[3] == 89 && proof[4] == zkir_proof_num_queries());
+  CHECK(zkir_prover::prove(ctx, r) == proof);                    // deterministic transcript
+  for (size_t i = 6; i < proof.size(); i++) if (proof[i] >= 2013265921u) { CHECK(!"non-canonical proof word"); break; }
+}
+
 int main(int argc, char** argv) {
   const bool gpu = argc > 1 && std::string(argv[1]) == "gpu";
   struct T { const char* name; std::function<void()> f; bool needs_gpu; };
@@ -149,7 +161,8 @@ int main(int argc, char** argv) {
       {"test_division_by_zero", test_division_by_zero, false}, {"test_invalid_syscall", test_invalid_syscall, false},
       {"test_poseidon2_syscall_is_an_error", test_poseidon2_syscall_is_an_error, false}, {"test_run_consumes_the_vm", test_run_consumes_the_vm, false},
       {"test_execution_trace_rows", test_execution_trace_rows, true}, {"test_trace_with_memory_ops", test_trace_with_memory_ops, true},
-      {"test_cycle_limit_trace", test_cycle_limit_trace, true}};
+      {"test_cycle_limit_trace", test_cycle_limit_trace, true},
+      {"test_prove_power_of_two_trace", test_prove_power_of_two_trace, true}};
   int ran = 0;
   for (const auto& t : tests) {
     if (t.needs_gpu && !gpu) continue;
