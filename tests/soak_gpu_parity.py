@@ -38,7 +38,7 @@ def edge_heavy(shape):
 
 
 t_end = time.time() + budget
-n_merkle = n_lde = n_proof = 0
+n_merkle = n_lde = n_proof = n_wit = 0
 ctxs = {}
 while time.time() < t_end:
     what = rng.integers(0, 10)
@@ -58,6 +58,26 @@ while time.time() < t_end:
         for k in range(width):
             assert np.array_equal(got[k], so.lde(mat[k], 1)[1]), ("lde", log_n, k)
         n_lde += 1
+    elif what == 8:                                                 # witness kernels on a random program (any length, any halt)
+        blob, inputs = programs.random_program(int(rng.integers(0, 1 << 30)), n_instr=int(rng.integers(50, 600)))
+        cfg = dict(max_cycles=int(rng.integers(100, 30000)), enable_execution_trace=True, enable_range_checking=bool(rng.integers(0, 2)),
+                   enable_deferred_model=bool(rng.integers(0, 2)))
+        try:
+            want = oracle.run(blob, inputs, **cfg)
+        except oracle.OracleError:
+            continue
+        log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
+        if len(log.mem_events):
+            rows_c, offsets, srt = pl.memory_ops(log)
+            assert np.array_equal(rows_c.to_numpy(), want.memops) and np.array_equal(srt.to_numpy(), want.sorted_memops), "memops"
+            assert np.array_equal(offsets.cpu().numpy().view(np.uint64), want.row_memop_offsets), "memop offsets"
+        if len(log.rc_events):
+            value, pc, chunks, mult = pl.range_checks(log)
+            assert np.array_equal(value.cpu().numpy().view(np.uint64), want.rc_checks["value"]) and np.array_equal(chunks.cpu().numpy().view(np.uint16).T, want.rc_checks["chunks"]), "rc"
+        if len(log.norm_events):
+            assert np.array_equal(pl.normalization_events(log), want.norm_events), "norm"
+        n_wit += 1
+        log.close()
     else:                                                           # whole proof of a random program
         log_n = int(rng.integers(3, 11))
         blob, inputs = programs.random_program(int(rng.integers(0, 1 << 30)), n_instr=200)
@@ -81,4 +101,4 @@ while time.time() < t_end:
         # verifier's verdict must at least be the same for both provers' (identical) words
         n_proof += 1
         log.close()
-print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_proof} traces + proofs identical to the oracle in {budget:.0f} s")
+print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_wit} witness sets, {n_proof} traces + proofs identical to the oracle in {budget:.0f} s")
