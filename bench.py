@@ -3,15 +3,20 @@
 "2^20-cycle fib trace: BabyBear NTT/LDE + Poseidon2 Merkle on 1 MI355X".
 
 A "step" = one pass of the device hot path over one resident delta log of a 2^k-cycle Fibonacci run:
-    K1 trace_fill (372 B/row SoA trace)  ->  main_trace (89 Baby Bear columns)  ->  LDE (blow-up 2, coset NTT)
+    K1 trace_fill (372 B/row SoA trace)  ->  main_trace (Baby Bear columns)  ->  LDE (blow-up 2, coset NTT)
     ->  Poseidon2-12 Merkle commitment of the 2^(k+1) LDE rows.
 The delta log (register events, tile index, pc/instruction columns) is resident in HBM before the timed region; the
-sequential host interpreter that produced it is timed separately (`host_interpret_rows_per_s`).  `--stage trace_fill`
-times K1 alone.  The trace / LDE / Merkle stages after K1 have no counterpart in the reference (no prover there).
+sequential host interpreter that produced it is timed separately (`host_interpret_rows_per_s`, `zkir_exec_ms`).
+`--stage trace_fill` times K1 alone.  The trace / LDE / Merkle stages after K1 have no counterpart in the reference (no prover there).
 
-N ranks = N row shards of one (N * 2^k)-cycle run (weak scaling): each rank fills and commits its own row range from
-its own register snapshot with no data-path collective; the per-rank Merkle roots are all-gathered over RCCL (32 B... 16 B
-per rank) and rank 0 hashes the top levels.  Launch: `python bench.py` (N=1) or torch.distributed.run with --gpus N.
+The JSON line also carries `by_config`: the other single-GPU BASELINE configs measured in the same run, outside the timed region —
+configs[2] (2^24-cycle fib: commit step + full proof, per-stage rooflines) and configs[4] (2^22-cycle SHA-256 chain: the five
+witness kernels with algorithmic bytes, ms and fraction of the HBM peak).
+
+N ranks = N row shards of one (N * 2^k)-cycle run (weak scaling): each rank fills and commits its own row range from its own
+register snapshot with no data-path collective; the per-rank Merkle roots are all-gathered over RCCL (16 B per rank) and every
+rank hashes the top levels.  N > 1 defaults to BASELINE configs[3]'s per-GPU share, 2^23 rows per GPU (2^26 rows on 8 GPUs).
+Launch: `python bench.py` (N=1) or torch.distributed.run with --gpus N.
 """
 from __future__ import annotations
 
@@ -29,7 +34,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 # Montgomery multiplications in one Poseidon2-12 permutation as implemented (poseidon2.h): 4 per S-box x (8 x 12 + 22) S-boxes
 # + 10 diagonal products x 22 partial rounds (diag entries 1 and the -2 of lane 0 need none)
 MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 10 * 22
-W = 89
+PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
 
 
 def _strided_passes(stages: int) -> int:
@@ -45,14 +50,184 @@ def _strided_passes(stages: int) -> int:
 
 
 def _profiled_valu_busy(kernel: str):
-    """VALUBusy (0..1) of `kernel` from the committed rocprofv3 counter pass (profiles/r01_bench_commit_valu_busy.txt), or None."""
-    try:
-        for line in open(os.path.join(ROOT, "profiles", "r01_bench_commit_valu_busy.txt")):
+    """VALUBusy (0..1) of `kernel` from the newest committed rocprofv3 counter pass (profiles/*_valu_busy.txt), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_commit_valu_busy.txt")), reverse=True):
+        for line in open(path):
             if line.startswith(kernel):
                 return float(line.split()[-2]) / 100.0
+    return None
+
+
+def _host_cpu():
+    model, cores = "unknown", os.cpu_count()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
     except OSError:
         pass
-    return None
+    return {"model": model, "logical_cores": cores}
+
+
+def _hip_time(f, reps=5, warm=2):
+    """Median HIP-event time (ms) of f() on torch's current stream (the stream every launch below is made on)."""
+    import numpy as np
+    import torch
+    for _ in range(warm):
+        f()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); f(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts))
+
+
+def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
+    """Algorithmic bytes, ms and rooflines of the commit stages for 2^k rows."""
+    n = 1 << k
+    kernels = {"trace_fill": {"bound": "hbm", "bytes": fill_bytes, "ms": stage_ms["trace_fill"]}}
+    if "merkle" in stage_ms:
+        #   main_trace: reads the 372 B/row trace once (+ the next-row re-read served by L2), writes W u32 columns
+        #   lde (DESIGN.md §8.3): per column `n_inv` strided inverse passes (8 B/elem over N; one radix-4 pass covers up to ten
+        #        stages) + fused middle (4N read + 8N written) + as many strided forward passes (8 B/elem over 2N)
+        #   merkle: reads the LDE matrix once, writes 16 B per node; ALU-bound (Poseidon2), bytes given for completeness
+        n_inv = _strided_passes(max(k - 10, 0))
+        kernels["main_trace"] = {"bound": "hbm", "bytes": (372 + 4 * W) * n, "ms": stage_ms["main_trace"]}
+        kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
+        perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
+        modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
+        modmul = perms * MONT_MUL_PER_PERM / (stage_ms["merkle"] * 1e-3)
+        kernels["merkle"] = {"bound": "int-alu", "bytes": 4 * W * 2 * n + 16 * (4 * n - 1), "ms": stage_ms["merkle"],
+                             "poseidon2_perms_per_s": perms / (stage_ms["merkle"] * 1e-3),
+                             "mont_mul_per_s": modmul, "mont_mul_peak_per_s_measured": modmul_peak,
+                             "frac_of_alu_peak": modmul / modmul_peak if modmul_peak else None}
+    for v in kernels.values():
+        v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
+    return kernels
+
+
+def _config2_fib_2p24(lib, sp):
+    """BASELINE configs[2]: 2^24-cycle fib on one GPU — commit step stages + full proof, measured with HIP events."""
+    import torch
+    from zkir_amd import pipeline as pl, runtime as rt, spec, stark
+    k = 24
+    n = 1 << k
+    W = stark.W_MAIN
+    blob = spec.fib_endless_program().to_bytes()
+    t0 = time.perf_counter()
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    host_s = time.perf_counter() - t0
+    ddl = pl.upload(log); trace = pl.DeviceTrace(ddl); fa = pl.trace_fill_args(ddl, trace)
+    ctx = stark.StarkContext(k)
+    m = torch.empty((W, n), dtype=torch.int32, device="cuda")
+    L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
+    tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
+    stages = [("trace_fill", lambda: pl.trace_fill(fa)),
+              ("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, m.data_ptr(), sp()))),
+              ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
+              ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
+    for _, f in stages:
+        f()
+    stage_ms = {name: _hip_time(f, reps=3, warm=0) for name, f in stages}
+    root = tree[-4:].cpu().numpy().view("uint32").tolist()
+    kernels = _commit_kernel_table(k, W, pl.trace_fill_bytes(ddl), stage_ms, lib, sp)
+    del m, L, tree
+    torch.cuda.empty_cache()
+    prove_ms, pms, proof = None, None, None
+    for _ in range(2):                                # first call allocates the context's workspace
+        t0 = time.perf_counter()
+        proof, pms = stark.prove(ctx, trace, want_stage_ms=True)
+        prove_ms = (time.perf_counter() - t0) * 1e3
+    step_ms = sum(stage_ms.values())
+    out = {"workload": "fib_endless 2^24 cycles, 1 GPU: trace fill + main trace + LDE + Poseidon2 Merkle (commit step), then the full proof "
+                       "(AIR quotient, openings, DEEP, FRI, queries)",
+           "rows": n, "commit_step_ms": step_ms, "commit_rows_per_s": n / (step_ms * 1e-3), "stage_ms": stage_ms, "roofline_by_stage": kernels,
+           "prove_ms": prove_ms, "prove_stage_ms": dict(zip(PROVE_STAGES, pms)), "prove_rows_per_s": n / (prove_ms * 1e-3),
+           "proof_bytes": int(len(proof) * 4), "merkle_root": root, "proof_trace_root_matches_commit": proof[6:10].tolist() == root,
+           "host_interpret_s": host_s, "hbm_resident_GB": (372 * n + (12 * W + 440) * n) / 1e9}
+    ctx.close(); log.close()
+    del trace, ddl
+    torch.cuda.empty_cache()
+    return out
+
+
+def _config4_sha_2p22(lib, sp):
+    """BASELINE configs[4]: SHA-256 hash-chain program for 2^22 cycles — the syscall-chip trace columns (witness.hip kernels)."""
+    import hashlib
+    import numpy as np
+    import torch
+    from zkir_amd import pipeline as pl, runtime as rt, spec
+    k = 22
+    n = 1 << k
+    dev = torch.device("cuda")
+    t0 = time.perf_counter()
+    log = rt.interpret(spec.sha256_chain_program().to_bytes(), [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    host_s = time.perf_counter() - t0
+    n_ops, n_blk = len(log.mem_events), len(log.sha_blocks)
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); fa = pl.trace_fill_args(ddl, tr)
+    ev = pl._to_dev(log.mem_events, dev)
+    rows_c, sort_c = pl.MemopColumns(n_ops, dev), pl.MemopColumns(n_ops, dev)
+    offs = torch.empty(n + 1, dtype=torch.int64, device=dev); scratch = torch.empty(n, dtype=torch.uint8, device=dev)
+    blk = pl._to_dev(log.sha_blocks, dev)
+    out = torch.empty((608, n_blk), dtype=torch.int32, device=dev); ts = torch.empty(n_blk, dtype=torch.int64, device=dev)
+    kern = {}
+
+    def rec(name, f, nbytes, note=None):
+        ms = _hip_time(f)
+        kern[name] = {"bound": "hbm", "bytes": int(nbytes), "ms": ms, "achieved_GBs": nbytes / (ms * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if note:
+            kern[name]["note"] = note
+    rec("trace_fill", lambda: pl.trace_fill(fa), pl.trace_fill_bytes(ddl))
+    rec("memops_row_offsets", lambda: pl._check(lib.zkir_memops_row_offsets_launch(ev.data_ptr(), n_ops, n, offs.data_ptr(), sp())), 8 * (n + 1),
+        "one binary search per row over the L2-resident event array: latency-bound, small")
+    rec("memops_expand", lambda: pl._check(lib.zkir_memops_expand_launch(ev.data_ptr(), n_ops, 0, C.byref(rows_c.c), sp())), (24 + 39) * n_ops)
+    rec("memops_sort", lambda: pl._check(lib.zkir_memops_sort_launch(ev.data_ptr(), n_ops, n, 0, offs.data_ptr(), scratch.data_ptr(), C.byref(sort_c.c), sp())),
+        (24 * 2 + 39) * n_ops + n, "= ExecutionResult::get_memory_trace(): rank in a two-run merge per row")
+    rec("sha256_chip", lambda: pl._check(lib.zkir_sha256_chip_launch(blk.data_ptr(), n_blk, out.data_ptr(), n_blk, ts.data_ptr(), sp())), (72 + 2432 + 8) * n_blk)
+    o = out[:, [0, n_blk // 2, n_blk - 1]].cpu().numpy().view(np.uint32)       # parity spot-check outside the timings: digests vs hashlib
+    for col, idx in enumerate([0, n_blk // 2, n_blk - 1]):
+        msg = log.sha_blocks[idx]["message_block"].astype(">u4").tobytes()[:32]
+        assert o[600:608, col].astype(">u4").tobytes() == hashlib.sha256(msg).digest(), "bench: SHA chip spot-check failed"
+    res = {"workload": "sha256_chain_program 2^22 cycles, 1 GPU (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427): K1 + memory-op CSR/expand/sort + SHA-256 chip",
+           "rows": n, "memory_ops": n_ops, "sha256_blocks": n_blk, "reg_events": ddl.n_events, "kernels": kern,
+           "witness_ms_total": sum(v["ms"] for v in kern.values()), "host_interpret_s": host_s}
+    log.close()
+    return res
+
+
+def _cpu_baseline(blob, k, commit):
+    """The reference path's own quantity — VM execution-trace rows/s — from the CPU oracle (C++ restatement of VM::run; the Rust
+    reference cannot be built here), one thread, on this box's host cores.  Bounded to ~10-30 s."""
+    from oracle import api as oracle
+    oracle.time_run(blob, 1 << 12)                      # warm the allocator / page cache
+    n_cpu = 1 << min(k, 22)
+    dt, nn = oracle.time_run(blob, n_cpu)
+    kf = 17                                             # faithful mode is O(N^2): 2^17 rows take a few seconds, 2^18 four times that
+    dtf, nf = oracle.time_run(blob, 1 << kf, faithful=True)
+    cpu = _host_cpu()
+    sample = (f"oracle/zkir_oracle.cpp (C++ -O3 restatement of VM::run, vm.rs:208-358) on {nn} rows of the same fib program, linear mode "
+              f"(the reference's per-cycle O(N) memory-trace filter, vm.rs:287-298, replaced by a cursor): {dt:.3f} s = {nn / dt:.3g} rows/s; "
+              f"faithful O(N^2) mode: {nf} rows in {dtf:.2f} s = {nf / dtf:.3g} rows/s (the largest size that finishes in seconds); "
+              f"host CPU: {cpu['model']}, {cpu['logical_cores']} logical cores, 1 used")
+    out = {"value": nn / dt, "unit": "rows/s", "cores": 1, "kind": "port", "sample": sample,
+           "linear_rows_per_s": nn / dt, "faithful_rows_per_s": nf / dtf, "faithful_rows": nf, "host_cpu": cpu}
+    if commit:                                          # self-defined stages: NOT the reference path; a separate, labelled figure
+        from oracle import stark_api as so
+        kc = 16
+        rows = oracle.run(blob, max_cycles=1 << kc, enable_execution_trace=True).rows
+        t0 = time.perf_counter()
+        so.commit_trace(rows, 1)
+        dtc = time.perf_counter() - t0
+        out["commit_stage_self_defined"] = {"rows": 1 << kc, "seconds": dtc, "rows_per_s": (1 << kc) / dtc, "cores": 1,
+                                            "what": "oracle/stark_oracle.cpp main trace + LDE + Poseidon2 Merkle (naive %-arithmetic; stages absent from "
+                                                    "the reference, self-defined): a labelled side figure, never part of `value`"}
+    return out
 
 
 def main():
@@ -60,12 +235,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--log2-rows", type=int, default=20, help="rows per GPU = 2^k (BASELINE configs[1] = 20)")
+    ap.add_argument("--log2-rows", type=int, default=None, help="rows per GPU = 2^k (default: 20 = BASELINE configs[1] at N=1; 23 = configs[3]'s "
+                    "per-GPU share, 2^26 rows over 8 GPUs, at N>1)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--stage", choices=["commit", "trace_fill"], default="commit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the end-to-end proof / pipelined sections that follow the timed region "
                     "(profiling runs: keeps the rocprofv3 per-kernel averages to the kernels of the timed steps)")
+    ap.add_argument("--no-by-config", action="store_true", help="skip the configs[2] / configs[4] sections (profiling runs)")
+    ap.add_argument("--only-config", choices=["2", "4"], default=None, help="run only that by_config section and print it (profiling runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,6 +257,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if world & (world - 1):
+        raise SystemExit(f"bench.py: --gpus {world} is not a power of two: the row-sharded commitment is a binary Merkle tree over the "
+                         "per-GPU subtree roots (zkir_merkle_cap_launch), so the number of row shards must be 1, 2, 4 or 8")
     # Functional test of the N > 1 path on a 1-GPU box: ZKIR_BENCH_BACKEND=gloo ZKIR_BENCH_SHARE_GPU=1 runs every rank on
     # cuda:0 and stages the 16-byte root exchange through the host.  Production (the driver's launch): nccl = RCCL, one GPU per rank.
     backend = os.environ.get("ZKIR_BENCH_BACKEND", "nccl")
@@ -91,11 +272,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    k = args.log2_rows
+    lib = rt.lib()
+    sp = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    if args.only_config:
+        torch.zeros(1 << 20, device="cuda").sum().item()
+        print(json.dumps({"by_config": {f"configs[{args.only_config}]": (_config2_fib_2p24 if args.only_config == "2" else _config4_sha_2p22)(lib, sp)}}))
+        return
+
+    k = args.log2_rows if args.log2_rows is not None else (20 if world == 1 else 23)
     n = 1 << k
     total_rows = n * world
+    W = stark.W_MAIN
     blob = spec.fib_endless_program().to_bytes()
-    lib = rt.lib()
 
     # ---- host stage (untimed for `value`; reported separately) ------------------------------------
     t0 = time.perf_counter()
@@ -104,12 +292,12 @@ def main():
     assert log.n_rows == total_rows and log.halt_reason == rt.HaltReason.CycleLimit()
     # steady state: the log buffers of a finished run are recycled (host.h block pool), so later runs do not page-fault their way
     # through ~50 B/row of fresh memory; time a second run and give its buffers back
-    t0 = time.perf_counter()
-    rt.interpret(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True), tile_rows=args.tile_rows).close()
-    warm = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    rt.interpret(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True), tile_rows=args.tile_rows).close()
-    host_s = min(warm, time.perf_counter() - t0)
+    host_s = host_first_s
+    if world == 1:
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rt.interpret(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True), tile_rows=args.tile_rows).close()
+            host_s = min(host_s, time.perf_counter() - t0)
     shard = log.shard(rank * n, (rank + 1) * n) if world > 1 else log
     torch.zeros(1 << 20, device="cuda").sum().item()   # HIP context / allocator warm-up is not part of the H2D figure
     t0 = time.perf_counter()
@@ -124,7 +312,6 @@ def main():
         m = torch.empty((W, n), dtype=torch.int32, device="cuda")
         L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
         tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
-    sp = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 
     stages = [("trace_fill", lambda: pl.trace_fill(fill_args))]
     if commit:
@@ -147,8 +334,7 @@ def main():
                 dist.all_gather(host, tree[-4:].cpu())
                 for dst, src in zip(gathered, host):
                     dst.copy_(src)
-            if world & (world - 1) == 0:
-                cap_root[0] = stark.merkle_cap(ctx, torch.stack(gathered))
+            cap_root[0] = stark.merkle_cap(ctx, torch.stack(gathered))
         stages.append(("allgather_cap", exchange))
 
     def step():
@@ -166,7 +352,7 @@ def main():
             step()
             torch.cuda.synchronize()
     else:                                             # the step contains a collective: every rank must run the same number of them
-        for _ in range(40):
+        for _ in range(10):
             step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -206,18 +392,18 @@ def main():
     # ---- end-to-end prove (BASELINE metric's "end-to-end prove ms"): AIR quotient + openings + DEEP + FRI on top of the commit ----
     prove_ms, prove_stage_ms, proof_bytes = None, None, None
     if commit and world == 1 and not args.no_prove:   # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
-        for _ in range(2):                            # first call allocates the context's workspace
+        for _ in range(3):                            # first call allocates the context's workspace
             t0 = time.perf_counter()
             proof, pms = stark.prove(ctx, trace, want_stage_ms=True)
             prove_ms = (time.perf_counter() - t0) * 1e3
-        prove_stage_ms = dict(zip(["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "openings", "deep", "fri", "queries"], pms))
+        prove_stage_ms = dict(zip(PROVE_STAGES, pms))
         proof_bytes = int(len(proof) * 4)
 
     # ---- the drop-in entry point itself: zkir_exec = host interpretation + H2D + K1 in one call (VM::new + VM::run, trace left in HBM)
     exec_s = None
     if world == 1 and k <= 24:
         ts = []
-        for _ in range(4):
+        for _ in range(5):
             t0 = time.perf_counter()
             res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run()
             ts.append(time.perf_counter() - t0)
@@ -250,30 +436,23 @@ def main():
         roots = [x.cpu().numpy().view(np.uint32).tolist() for x in gathered]
         if cap_root[0] is not None:
             root = cap_root[0].cpu().numpy().view(np.uint32).tolist()
+    fill_bytes = pl.trace_fill_bytes(ddl)
+    n_events, tile_rows = ddl.n_events, ddl.tile_rows
+
+    # ---- the other single-GPU BASELINE configs, outside the timed region (free the configs[1] buffers first) ----
+    by_config = None
+    if rank == 0 and world == 1 and commit and not args.no_by_config and k == 20:
+        if commit:
+            del m, L, tree
+            ctx.close()
+        del trace, ddl, fill_args
+        torch.cuda.empty_cache()
+        by_config = {"configs[2]": _config2_fib_2p24(lib, sp), "configs[4]": _config4_sha_2p22(lib, sp)}
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
         value = total_rows * args.steps / wall
-        fill_bytes = pl.trace_fill_bytes(ddl)
-        kernels = {"trace_fill": {"bound": "hbm", "bytes": fill_bytes, "ms": stage_ms["trace_fill"]}}
-        if commit:
-            #   main_trace: reads the 372 B/row trace once (+ the next-row re-read served by L2), writes 89 u32 columns
-            #   lde: per column `n_inv` strided inverse passes (8 B/elem over N; one radix-4 pass covers up to ten
-            #        stages) + fused middle (4N read + 8N written) + as many strided forward passes (8 B/elem over 2N)
-            #   merkle: reads the LDE matrix once, writes 16 B per node; ALU-bound (Poseidon2), bytes given for completeness
-            n_inv = _strided_passes(max(k - 10, 0))
-            kernels["main_trace"] = {"bound": "hbm", "bytes": (372 + 4 * W) * n, "ms": stage_ms["main_trace"]}
-            kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
-            perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
-            modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
-            modmul = perms * MONT_MUL_PER_PERM / (stage_ms["merkle"] * 1e-3)
-            kernels["merkle"] = {"bound": "int-alu", "bytes": 4 * W * 2 * n + 16 * (4 * n - 1), "ms": stage_ms["merkle"],
-                                 "poseidon2_perms_per_s": perms / (stage_ms["merkle"] * 1e-3),
-                                 "mont_mul_per_s": modmul, "mont_mul_peak_per_s_measured": modmul_peak,
-                                 "frac_of_alu_peak": modmul / modmul_peak if modmul_peak else None}
-        for v in kernels.values():
-            v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-            v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
+        kernels = _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp)
         dom = max(kernels, key=lambda q: kernels[q]["ms"])
         traffic = None                                 # HBM bytes/launch from the committed rocprofv3 PMC passes of this exact workload
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{dom}_k{k}.json")
@@ -285,9 +464,12 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (Baby Bear, 31-bit modular) / u64 trace words" if commit else "u64", "data": "synthetic",
-            "config": {"workload": f"fib_endless 2^{k} cycles per GPU (v3.4 fib loop of tests/cross_module.rs:145-164, max_cycles halt), "
-                                   f"VMConfig{{enable_execution_trace}}; stages = {'+'.join(s for s, _ in stages)}; blow-up 2, Poseidon2 width 12",
-                       "rows_per_gpu": n, "tile_rows": ddl.tile_rows, "reg_events_per_gpu": ddl.n_events, "main_trace_width": W if commit else None,
+            "config": {"workload": (f"fib_endless 2^{k} cycles per GPU" + (" = BASELINE configs[1]" if k == 20 and world == 1 else "")
+                                    + (f" = BASELINE configs[3] (2^26-cycle fib row-sharded over 8 GPUs)" if k == 23 and world == 8 else
+                                       (f" (configs[3]'s per-GPU share; {world} row shards of one 2^{k + world.bit_length() - 1}-cycle run)" if world > 1 else ""))
+                                    + "; v3.4 fib loop of tests/cross_module.rs:145-164, max_cycles halt, VMConfig{enable_execution_trace}; "
+                                    f"stages = {'+'.join(s for s, _ in stages)}; blow-up 2, Poseidon2 width 12"),
+                       "rows_per_gpu": n, "tile_rows": tile_rows, "reg_events_per_gpu": n_events, "main_trace_width": W if commit else None,
                        "parallelism": f"row-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernels[dom]["ms"],
@@ -302,35 +484,22 @@ def main():
                                   "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel")}
                                  if kernels[dom]["bound"] == "int-alu" else None)},
             "roofline_by_stage": kernels,
+            "by_config": by_config,
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes,
             "pipelined_end_to_end": pipelined,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,
+            "host_interpret_ns_per_instruction": host_s / total_rows * 1e9, "host_interpret_s": host_s,
             "h2d_upload_s": h2d_s,
-            "end_to_end_rows_per_s_incl_host_and_pcie": n / (host_s / world + h2d_s + gpu_ms_per_step * 1e-3),
+            "end_to_end_rows_per_s_incl_host_and_pcie": n / (exec_s + (gpu_ms_per_step - stage_ms["trace_fill"]) * 1e-3) if exec_s else None,
             "zkir_exec_ms": exec_s * 1e3 if exec_s else None,                 # drop-in call: interpret + H2D + trace fill, PCIe-inclusive
             "zkir_exec_rows_per_s": n / exec_s if exec_s else None,
+            "host_cpu": _host_cpu(),
         }
         if not args.no_cpu_baseline and world == 1:
-            from oracle import api as oracle, stark_api as so
-            oracle.time_run(blob, 1 << 12)                      # warm the allocator / page cache
-            n_cpu = min(total_rows, 1 << 22)
-            dt, nn = oracle.time_run(blob, n_cpu)
-            dtf, nf = oracle.time_run(blob, 1 << 14, faithful=True)
-            sample = (f"oracle (C++ restatement of VM::run, linear mode): {nn} rows in {dt:.2f} s = {nn / dt:.3g} rows/s; "
-                      f"faithful O(N^2) mode (vm.rs:287-298): {nf} rows in {dtf:.2f} s = {nf / dtf:.3g} rows/s")
-            cpu_value = nn / dt
-            if commit:
-                kc = 18                                         # ~15 s of single-core work (oracle NTT + Poseidon2)
-                rows = oracle.run(blob, max_cycles=1 << kc, enable_execution_trace=True).rows
-                t0 = time.perf_counter()
-                so.commit_trace(rows, 1)
-                dtc = time.perf_counter() - t0
-                cpu_value = (1 << kc) / (dtc + (1 << kc) / (nn / dt))
-                sample += f"; oracle commit (main trace + LDE + Poseidon2 Merkle) of 2^{kc} rows in {dtc:.2f} s; value = rows/s of trace + commit at 2^{kc} rows"
-            out["cpu_baseline"] = {"value": cpu_value, "unit": "rows/s", "cores": 1, "kind": "port", "sample": sample}
+            out["cpu_baseline"] = _cpu_baseline(blob, k, commit)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

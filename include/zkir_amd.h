@@ -119,7 +119,7 @@ typedef struct zkir_sha_block {
 typedef struct zkir_delta_log zkir_delta_log;   /* opaque, host memory */
 
 /* Run the program on the host interpreter (bit-exact to VM::run, vm.rs:208-358) and record the delta
- * log.  tile_rows (power of two, 256..4096; 0 = default: 256 when max_cycles <= 2^21, else 512) fixes
+ * log.  tile_rows (power of two, 256..2048; 0 = default: 256 when max_cycles <= 2^21, else 512) fixes
  * the granularity of the tile index (one K1 workgroup per tile).
  * Returns ZKIR_OK or an error code (then *out is NULL). No device is touched. */
 int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
@@ -154,6 +154,7 @@ size_t zkir_delta_log_n_rc_events(const zkir_delta_log*);
 const zkir_rc_event* zkir_delta_log_rc_events(const zkir_delta_log*);
 size_t zkir_delta_log_n_rc_witnesses(const zkir_delta_log*);
 const uint64_t* zkir_delta_log_rc_offsets(const zkir_delta_log*);  /* [n_rc_witnesses+1] CSR over rc_events */
+const uint64_t* zkir_delta_log_rc_cycles(const zkir_delta_log*);   /* [n_rc_witnesses] cycle of the checkpoint that produced witness k (vm.rs:316-344) */
 uint32_t zkir_delta_log_rc_chunk_bits(const zkir_delta_log*);      /* header limb_bits / 2 (range_check.rs:29) */
 size_t zkir_delta_log_n_norm_events(const zkir_delta_log*);
 const zkir_norm_event* zkir_delta_log_norm_events(const zkir_delta_log*);
@@ -287,6 +288,51 @@ const zkir_trace_columns* zkir_result_trace(const zkir_result* r);       /* devi
 /* copy one device column to host: field = 0 cycle,1 pc,2 instruction,3 registers,4 bound_bits,5 bound_tag,
  * 6 bound_payload,7 reg_state; reg ignored for fields 0-2.  dst must hold n_rows elements. */
 int zkir_result_copy_column(const zkir_result* r, int field, int reg, void* dst);
+
+
+/* ---- the rest of ExecutionResult (vm.rs:54-103) behind the handle: witness streams as DEVICE columns ---------------------------
+ * Each call expands the corresponding side log of the run on the device the first time it is made (witness.hip kernels), caches
+ * the columns in the handle and returns the same pointers afterwards; they stay valid until zkir_result_free.  Thread-safe. */
+typedef struct zkir_memory_witness {     /* TraceRow.memory_ops of every row + ExecutionResult::get_memory_trace() (vm.rs:85-94) */
+  uint64_t n_ops;                        /* = ExecutionResult::memory_op_count() (vm.rs:97-102) */
+  uint64_t n_rows;
+  zkir_memop_columns row_order;          /* ops in execution order; row r owns ops [row_offsets[r], row_offsets[r+1]) */
+  const uint64_t* row_offsets;           /* device, [n_rows+1] */
+  zkir_memop_columns sorted;             /* stable order by (timestamp, address, Read<Write): trace.rs:210-223 */
+} zkir_memory_witness;
+int zkir_result_memory_trace(zkir_result* r, zkir_memory_witness* out);
+
+typedef struct zkir_range_check_witness { /* ExecutionResult.range_check_witnesses: Vec<RangeCheckWitness> (range_check.rs:209-238) */
+  uint64_t n_checks;                     /* total checks over all witnesses */
+  uint64_t n_witnesses;                  /* non-empty checkpoints (vm.rs:340-342) */
+  const uint64_t* witness_offsets;       /* HOST, [n_witnesses+1]: witness k owns checks [off[k], off[k+1]) */
+  const uint64_t* witness_cycles;        /* HOST, [n_witnesses]: cycle of the checkpoint */
+  const uint64_t* value;                 /* device [n_checks] */
+  const uint64_t* pc;                    /* device [n_checks] */
+  const uint16_t* chunks;                /* device [4][chunk_stride]: chunk c of check i at chunks[c*chunk_stride + i] (range_check.rs:175-192) */
+  uint64_t chunk_stride;
+  uint32_t chunk_bits;
+  const uint32_t* multiplicity;          /* device [2^chunk_bits]: lookup multiplicities of all chunks */
+} zkir_range_check_witness;
+int zkir_result_range_check_witnesses(zkir_result* r, zkir_range_check_witness* out);
+
+typedef struct zkir_normalization_witness { /* ExecutionResult.normalization_witnesses (normalization_witness.rs:129-138) */
+  uint64_t n_events;
+  zkir_norm_columns columns;             /* device */
+} zkir_normalization_witness;
+int zkir_result_normalization_witnesses(zkir_result* r, zkir_normalization_witness* out);
+
+typedef struct zkir_sha256_witness {     /* Sha256Witness per single-block SHA-256 syscall (trace.rs:236-285); never reached from VM::run in the
+                                            reference (syscall.rs:127 passes None) — BASELINE configs[4]'s "syscall-chip trace columns" */
+  uint64_t n_blocks;
+  const uint32_t* columns;               /* device [608][stride], layout of zkir_sha256_chip_launch */
+  uint64_t stride;
+  const uint64_t* timestamps;            /* device [n_blocks] */
+} zkir_sha256_witness;
+int zkir_result_sha256_witnesses(zkir_result* r, zkir_sha256_witness* out);
+
+/* D2H copy for hosts that do not link a HIP runtime themselves (the pointers above are device memory) */
+int zkir_device_to_host(void* host_dst, const void* device_src, size_t bytes);
 
 const char* zkir_last_error(void);
 const char* zkir_version(void);

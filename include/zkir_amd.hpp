@@ -50,6 +50,7 @@ inline uint32_t mul(int rd, int rs1, int rs2) { return enc_r(Opcode::MUL, rd, rs
 inline uint32_t div_(int rd, int rs1, int rs2) { return enc_r(Opcode::DIV, rd, rs1, rs2); }
 inline uint32_t divu(int rd, int rs1, int rs2) { return enc_r(Opcode::DIVU, rd, rs1, rs2); }
 inline uint32_t addi(int rd, int rs1, int32_t imm) { return enc_i(Opcode::ADDI, rd, rs1, imm); }
+inline uint32_t slli(int rd, int rs1, int shamt) { return enc_i(Opcode::SLLI, rd, rs1, shamt); }
 inline uint32_t lw(int rd, int rs1, int32_t imm) { return enc_i(Opcode::LW, rd, rs1, imm); }
 inline uint32_t sw(int rs1, int rs2, int32_t imm) { return enc_i(Opcode::SW, rs1, rs2, imm); }     // mem[rs1 + imm] = rs2
 inline uint32_t beq(int rs1, int rs2, int32_t off) { return enc_i(Opcode::BEQ, rs1, rs2, off); }
@@ -121,6 +122,23 @@ struct TraceRow {                                               // trace.rs:24-5
   std::array<uint8_t, 16> register_states;                      // 0 Normalized, 1 Accumulated
 };
 
+struct MemoryOp {                                               // trace.rs:149-167
+  uint64_t address, value, timestamp;
+  uint8_t op;                                                   // MemOpType: 0 Read, 1 Write
+  uint8_t width;
+  ValueBound bound;
+  bool is_read() const { return op == 0; }
+  bool is_write() const { return op == 1; }
+};
+struct RangeCheck { uint64_t value; std::array<uint16_t, 4> chunks; uint64_t pc; };   // range_check.rs:209-238 (one entry of a RangeCheckWitness)
+using RangeCheckWitness = std::vector<RangeCheck>;
+struct NormalizationEvent {                                     // normalization_witness.rs:19-43, :129-138
+  uint64_t cycle, pc;
+  uint8_t reg, triggering_opcode;
+  std::array<uint64_t, 2> accumulated;
+  std::array<uint32_t, 2> normalized, carries;
+};
+
 class ExecutionResult;
 
 // Vec<TraceRow> of the reference, resident in HBM as struct-of-arrays (zkir_trace_columns)
@@ -164,6 +182,45 @@ class ExecutionResult {                                         // vm.rs:54-78
   ExecutionTrace execution_trace;
 
   size_t memory_op_count() const { return zkir_delta_log_n_mem_events(log()); }          // vm.rs:97-102
+
+  // ExecutionResult::get_memory_trace (vm.rs:85-94): every data-memory op sorted by (timestamp, address, Read<Write); the sort and
+  // the column expansion run on the device behind zkir_result_memory_trace, this copies the result to the host
+  std::vector<MemoryOp> get_memory_trace() const { return memops(true, 0, (uint64_t)-1); }
+  // TraceRow.memory_ops of one row (trace.rs:49)
+  std::vector<MemoryOp> row_memory_ops(uint64_t row) const { return memops(false, row, row + 1); }
+  std::vector<RangeCheckWitness> range_check_witnesses() const {                        // vm.rs:66-69
+    std::vector<RangeCheckWitness> out;
+    if (!res_) return out;
+    zkir_range_check_witness w;
+    int rc = zkir_result_range_check_witnesses(res_, &w);
+    if (rc != ZKIR_OK) detail::raise(rc);
+    std::vector<uint64_t> v(w.n_checks), pc(w.n_checks);
+    std::vector<uint16_t> ch(4 * w.chunk_stride);
+    d2h(v.data(), w.value, 8 * w.n_checks); d2h(pc.data(), w.pc, 8 * w.n_checks); d2h(ch.data(), w.chunks, 2 * ch.size());
+    for (uint64_t k = 0; k < w.n_witnesses; k++) {
+      RangeCheckWitness wit;
+      for (uint64_t i = w.witness_offsets[k]; i < w.witness_offsets[k + 1]; i++)
+        wit.push_back({v[i], {ch[i], ch[w.chunk_stride + i], ch[2 * w.chunk_stride + i], ch[3 * w.chunk_stride + i]}, pc[i]});
+      out.push_back(std::move(wit));
+    }
+    return out;
+  }
+  std::vector<NormalizationEvent> normalization_witnesses() const {                     // vm.rs:75-77
+    std::vector<NormalizationEvent> out;
+    if (!res_) return out;
+    zkir_normalization_witness w;
+    int rc = zkir_result_normalization_witnesses(res_, &w);
+    if (rc != ZKIR_OK) detail::raise(rc);
+    const size_t n = w.n_events;
+    std::vector<uint64_t> cyc(n), pc(n), a0(n), a1(n);
+    std::vector<uint32_t> n0(n), n1(n), c0(n), c1(n);
+    std::vector<uint8_t> reg(n), op(n);
+    d2h(cyc.data(), w.columns.cycle, 8 * n); d2h(pc.data(), w.columns.pc, 8 * n); d2h(a0.data(), w.columns.accumulated0, 8 * n); d2h(a1.data(), w.columns.accumulated1, 8 * n);
+    d2h(n0.data(), w.columns.normalized0, 4 * n); d2h(n1.data(), w.columns.normalized1, 4 * n); d2h(c0.data(), w.columns.carry0, 4 * n); d2h(c1.data(), w.columns.carry1, 4 * n);
+    d2h(reg.data(), w.columns.reg, n); d2h(op.data(), w.columns.opcode, n);
+    for (size_t i = 0; i < n; i++) out.push_back({cyc[i], pc[i], reg[i], op[i], {a0[i], a1[i]}, {n0[i], n1[i]}, {c0[i], c1[i]}});
+    return out;
+  }
   size_t range_check_witness_count() const { return zkir_delta_log_n_rc_witnesses(log()); }
   size_t normalization_event_count() const { return zkir_delta_log_n_norm_events(log()); }
   const zkir_delta_log* delta_log() const { return log(); }     // host-side logs for the witness kernels (zkir_memops_*_launch, ...)
@@ -185,6 +242,25 @@ class ExecutionResult {                                         // vm.rs:54-78
   friend class VM;
   ExecutionResult() = default;
   const zkir_delta_log* log() const { return res_ ? zkir_result_delta_log(res_) : own_log_; }
+  static void d2h(void* dst, const void* src, size_t bytes) { const int rc = zkir_device_to_host(dst, src, bytes); if (rc != ZKIR_OK) detail::raise(rc); }
+  std::vector<MemoryOp> memops(bool sorted, uint64_t row_lo, uint64_t row_hi) const {
+    std::vector<MemoryOp> out;
+    if (!res_) return out;
+    zkir_memory_witness w;
+    const int rc = zkir_result_memory_trace(res_, &w);
+    if (rc != ZKIR_OK) detail::raise(rc);
+    uint64_t lo = 0, hi = w.n_ops;
+    if (!sorted) { uint64_t o[2]; d2h(&o[0], w.row_offsets + row_lo, 8); d2h(&o[1], w.row_offsets + row_hi, 8); lo = o[0]; hi = o[1]; }
+    const zkir_memop_columns& c = sorted ? w.sorted : w.row_order;
+    const size_t n = hi - lo;
+    std::vector<uint64_t> ad(n), va(n), ts(n), pay(n);
+    std::vector<uint32_t> bits(n);
+    std::vector<uint8_t> wr(n), wd(n), tag(n);
+    d2h(ad.data(), c.address + lo, 8 * n); d2h(va.data(), c.value + lo, 8 * n); d2h(ts.data(), c.timestamp + lo, 8 * n); d2h(pay.data(), c.bound_payload + lo, 8 * n);
+    d2h(bits.data(), c.bound_bits + lo, 4 * n); d2h(wr.data(), c.is_write + lo, n); d2h(wd.data(), c.width + lo, n); d2h(tag.data(), c.bound_tag + lo, n);
+    for (size_t i = 0; i < n; i++) out.push_back({ad[i], va[i], ts[i], wr[i], wd[i], {bits[i], tag[i], pay[i]}});
+    return out;
+  }
   void fill() {
     const zkir_delta_log* l = log();
     cycles = zkir_delta_log_cycles(l);

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         L = C.CDLL(_SO)
         L.zo_run.restype = C.c_void_p
         L.zo_run.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(_Cfg), C.c_int]
+        L.zo_run_window.restype = C.c_void_p
+        L.zo_run_window.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(_Cfg), C.c_uint64, C.c_uint64]
         for name, res in [("zo_error_code", C.c_int), ("zo_error_msg", C.c_char_p), ("zo_cycles", C.c_uint64),
                           ("zo_halt_kind", C.c_int), ("zo_halt_code", C.c_uint64), ("zo_n_outputs", C.c_size_t),
                           ("zo_outputs", C.c_void_p), ("zo_n_rows", C.c_size_t), ("zo_rows", C.c_void_p),
@@ -119,12 +121,16 @@ class OracleResult:
 
 def run(program_blob: bytes, inputs=(), max_cycles: int = 1_000_000, enable_range_checking: bool = False,
         enable_execution_trace: bool = False, enable_deferred_model: bool = False, faithful: bool = False,
-        want_sorted: bool = True) -> OracleResult:
-    """VM::new(program, inputs, config).run() of the reference (vm.rs:138-358), restated on the CPU."""
+        want_sorted: bool = True, keep_rows: tuple | None = None) -> OracleResult:
+    """VM::new(program, inputs, config).run() of the reference (vm.rs:138-358), restated on the CPU.
+    keep_rows=(lo, hi): run everything but keep only the rows / memory ops of cycles [lo, hi) (tests at 2^22..2^26 rows)."""
     L = lib()
     cfg = _Cfg(max_cycles, 0, int(enable_range_checking), int(enable_execution_trace), int(enable_deferred_model))
     arr = (C.c_uint64 * max(1, len(inputs)))(*inputs)
-    h = L.zo_run(program_blob, len(program_blob), arr, len(inputs), C.byref(cfg), int(faithful))
+    if keep_rows is not None:
+        h = L.zo_run_window(program_blob, len(program_blob), arr, len(inputs), C.byref(cfg), int(keep_rows[0]), int(keep_rows[1]))
+    else:
+        h = L.zo_run(program_blob, len(program_blob), arr, len(inputs), C.byref(cfg), int(faithful))
     try:
         code = L.zo_error_code(h)
         if code != 0:

@@ -969,7 +969,11 @@ static PackedMemOp pack_memop(const MemOp& o) {
 // ---------------------------------------------------------------------------------------------
 // zkir-runtime/src/vm.rs:138-358
 // ---------------------------------------------------------------------------------------------
-static void vm_run(const Program& prog, const std::vector<uint64_t>& inputs, const VMConfig& cfg, bool faithful, Result& res) {
+// keep_lo/keep_hi (tests at BASELINE sizes): only rows with keep_lo <= cycle < keep_hi and their memory ops are KEPT (the whole
+// program still runs); outside a full run the cumulative memory trace is dropped each cycle so memory stays bounded.
+static void vm_run(const Program& prog, const std::vector<uint64_t>& inputs, const VMConfig& cfg, bool faithful, Result& res,
+                   uint64_t keep_lo = 0, uint64_t keep_hi = ~0ull) {
+  const bool windowed = keep_lo != 0 || keep_hi != ~0ull;
   if (prog.entry_point < 0x1000) {                                                // vm.rs:141-147 (panic in the reference)
     res.err = {E_BAD_PROGRAM, "Program appears to be in debug format (entry_point=" + hex(prog.entry_point) + "). Use release format (zkir-llvm without --debug) for execution."};
     return;
@@ -983,7 +987,7 @@ static void vm_run(const Program& prog, const std::vector<uint64_t>& inputs, con
   RangeCheckTracker* rc = cfg.enable_range_checking ? new RangeCheckTracker(prog.cfg) : nullptr;       // vm.rs:184-188
   if (cfg.enable_execution_trace) mem.trace_enabled = true;                                            // vm.rs:191-193
   IOHandler io; io.inputs = inputs;
-  if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 27)) {   // timing hygiene only (the reference does not reserve):
+  if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 27) && !windowed) {   // timing hygiene only (the reference does not reserve):
     res.rows.reserve(cfg.max_cycles);                                   // keeps realloc+page-fault noise out of the CPU baseline
     res.row_memop_off.reserve(cfg.max_cycles + 1);
     mem.trace.reserve(cfg.max_cycles);
@@ -1026,7 +1030,9 @@ static void vm_run(const Program& prog, const std::vector<uint64_t>& inputs, con
     }
     if (inst.op == ECALL && !handle_syscall(st, mem, io, err)) break;             // :277-279
 
-    if (cfg.enable_execution_trace) {                                             // :282-313
+    if (cfg.enable_execution_trace && windowed && (st.cycles < keep_lo || st.cycles >= keep_hi)) {
+      mem.trace.resize(trace_mark);                                               // windowed test mode: row outside the kept range
+    } else if (cfg.enable_execution_trace) {                                      // :282-313
       if (faithful) {
         for (const MemOp& op : mem.trace)                                         // the O(len(trace)) filter, :291-298
           if (op.timestamp == st.cycles && op.address != fetch_pc) res.memops.push_back(pack_memop(op));
@@ -1076,6 +1082,18 @@ void* zo_run(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_i
   c.enable_execution_trace = cfg->enable_execution_trace; c.enable_deferred_model = cfg->enable_deferred_model;
   std::vector<uint64_t> in(inputs, inputs + n_inputs);
   zo::vm_run(p, in, c, faithful != 0, *r);
+  return r;
+}
+// same run, keeping only the rows (and their memory ops) of cycles [keep_lo, keep_hi): parity tests at 2^22..2^26 rows
+void* zo_run_window(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zo_config* cfg, uint64_t keep_lo, uint64_t keep_hi) {
+  auto* r = new zo::Result();
+  zo::Program p;
+  if (!zo::program_from_bytes(blob, len, p, r->err)) return r;
+  zo::VMConfig c;
+  c.max_cycles = cfg->max_cycles; c.trace = cfg->trace; c.enable_range_checking = cfg->enable_range_checking;
+  c.enable_execution_trace = cfg->enable_execution_trace; c.enable_deferred_model = cfg->enable_deferred_model;
+  std::vector<uint64_t> in(inputs, inputs + n_inputs);
+  zo::vm_run(p, in, c, false, *r, keep_lo, keep_hi);
   return r;
 }
 void zo_free(void* h) { delete (zo::Result*)h; }

@@ -136,6 +136,49 @@ static void test_cycle_limit_trace() {                           // vm.rs:211-21
   auto r1 = r.execution_trace.column<uint64_t>(3, 1);             // registers[1] column straight from HBM
   CHECK(r1[0] == 0 && r1[2] == 1 && r1[999] == 500);
 }
+static void test_trace_timestamp_synchronization() {             // vm.rs:1073-1200: 2 SW + 2 LW; row memory_ops, timestamps = cycles, sorted trace
+  VMConfig cfg; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 0, 0x100), addi(2, 0, 0x1000), sw(2, 1, 0), addi(3, 0, 0x200), sw(2, 3, 4), lw(4, 2, 0), lw(5, 2, 4), ebreak()}), {}, cfg).run();
+  CHECK(r.halt_reason == HaltReason::ebreak());
+  const auto all = r.get_memory_trace();
+  CHECK(all.size() == 4);
+  size_t writes = 0, reads = 0;
+  for (const auto& op : all) { writes += op.is_write(); reads += op.is_read(); }
+  CHECK(writes == 2 && reads == 2);
+  const struct { uint64_t row; bool write; } expect[] = {{2, true}, {4, true}, {5, false}, {6, false}};
+  for (const auto& e : expect) {
+    const auto ops = r.row_memory_ops(e.row);
+    CHECK(ops.size() == 1 && ops[0].is_write() == e.write && ops[0].timestamp == e.row);
+  }
+  for (uint64_t row : {0, 1, 3, 7}) CHECK(r.row_memory_ops(row).empty());
+  for (size_t i = 1; i < all.size(); i++) CHECK(all[i - 1].timestamp <= all[i].timestamp);
+  CHECK(all[2].value == 0x100 && all[3].value == 0x200 && all[0].address == 0x1000 && all[1].address == 0x1004);
+  CHECK(all[0].bound.max_bits == 32 && all[0].bound.source_tag == ZKIR_BOUND_TYPE_WIDTH);          // memory.rs:245
+}
+static void test_bound_propagation_and_deferred_checks() {       // vm.rs:698-752: 30 doublings then SW -> range-check witnesses
+  std::vector<uint32_t> code = {addi(1, 0, (1 << 15) - 1)};
+  for (int i = 0; i < 30; i++) code.push_back(add(1, 1, 1));
+  code.push_back(addi(2, 0, 0x1000)); code.push_back(sw(2, 1, 0)); code.push_back(ebreak());
+  VMConfig cfg; cfg.enable_range_checking = true; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(Program::from_code(code), {}, cfg).run();
+  CHECK(r.halt_reason == HaltReason::ebreak());
+  const auto w = r.range_check_witnesses();
+  CHECK(w.size() > 0 && w.size() == r.range_check_witness_count());
+  for (const auto& wit : w)
+    for (const auto& c : wit) {                                  // range_check.rs:175-192: 10-bit chunks of the two 20-bit limbs
+      const uint32_t l0 = c.value & 0xFFFFF, l1 = (c.value >> 20) & 0xFFFFF;
+      CHECK(c.chunks[0] == (l0 & 1023) && c.chunks[1] == (l0 >> 10) && c.chunks[2] == (l1 & 1023) && c.chunks[3] == (l1 >> 10));
+    }
+}
+static void test_deferred_carry_normalization_event() {          // deferred_integration_test.rs:270-316 through the VM: (2^20 - 10) + 100 -> [90, 1], carry 1
+  // r1 = 2^20 - 10 (slli + addi keep it Normalized), r2 = 100, r3 = r1 + r2 (deferred: Accumulated), then an observation point on r3
+  VMConfig cfg; cfg.enable_deferred_model = true; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(Program::from_code({addi(1, 0, 1), slli(1, 1, 20), addi(1, 1, -10), addi(2, 0, 100), add(3, 1, 2), beq(3, 0, 8), ebreak(), ebreak()}), {}, cfg).run();
+  const auto ev = r.normalization_witnesses();
+  CHECK(ev.size() == r.normalization_event_count() && !ev.empty());
+  const zkir_runtime::NormalizationEvent& e = ev.back();                       // the BEQ's rs1 = r3 (execute.rs:903-916: rs1 only)
+  CHECK(e.reg == 3 && e.triggering_opcode == 0x40 && e.normalized[0] == 90 && e.normalized[1] == 1 && e.carries[0] == 1);
+}
 
 // ---- prover stages (no counterpart in the reference: only the shape of the result can be asserted here; the words are compared
 // with the oracle's prover and checked by its verifier in tests/test_gpu_stark.py) ------------------------------------------------
@@ -162,6 +205,9 @@ int main(int argc, char** argv) {
       {"test_poseidon2_syscall_is_an_error", test_poseidon2_syscall_is_an_error, false}, {"test_run_consumes_the_vm", test_run_consumes_the_vm, false},
       {"test_execution_trace_rows", test_execution_trace_rows, true}, {"test_trace_with_memory_ops", test_trace_with_memory_ops, true},
       {"test_cycle_limit_trace", test_cycle_limit_trace, true},
+      {"test_trace_timestamp_synchronization", test_trace_timestamp_synchronization, true},
+      {"test_bound_propagation_and_deferred_checks", test_bound_propagation_and_deferred_checks, true},
+      {"test_deferred_carry_normalization_event", test_deferred_carry_normalization_event, true},
       {"test_prove_power_of_two_trace", test_prove_power_of_two_trace, true}};
   int ran = 0;
   for (const auto& t : tests) {

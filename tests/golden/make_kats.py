@@ -8,14 +8,39 @@ Run: python tests/golden/make_kats.py   (regenerates the JSON next to this file)
 """
 import json
 import os
-import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-from zkir_amd import spec  # noqa: E402
-from zkir_amd.spec import Opcode as O, encode as E  # noqa: E402
+# A self-contained encoder, written from the reference's bit layout (zkir-spec/src/encoding.rs:23-60, zkir-assembler/src/
+# encoder.rs:100-151): opcode 7 b @0, rd 4 b @7, rs1 4 b @11, rs2 4 b @15 | imm17 @15; S/B-type put rs1 @7, rs2 @11; J: off21 @11.
+# Deliberately NOT imported from the product package: the fixtures must not depend on the code they test.  Opcode bytes:
+# zkir-spec/src/opcode.rs:154-228.
+class O:  # noqa: E742
+    ADD, DIVU, DIV, ADDI, LW, SW, BEQ, BNE, JAL, ECALL, EBREAK = 0x00, 0x04, 0x06, 0x08, 0x34, 0x3A, 0x40, 0x41, 0x48, 0x50, 0x51
 
+
+def E(op, rd=0, rs1=0, rs2=0, imm=0):  # noqa: E743
+    if op in (O.ADD, O.DIVU, O.DIV):
+        return op | (rd & 0xF) << 7 | (rs1 & 0xF) << 11 | (rs2 & 0xF) << 15
+    if op in (O.SW, O.BEQ, O.BNE):
+        return op | (rs1 & 0xF) << 7 | (rs2 & 0xF) << 11 | (imm & 0x1FFFF) << 15
+    if op == O.JAL:
+        return op | (rd & 0xF) << 7 | (imm & 0x1FFFFF) << 11
+    if op in (O.ECALL, O.EBREAK):
+        return op
+    return op | (rd & 0xF) << 7 | (rs1 & 0xF) << 11 | (imm & 0x1FFFF) << 15
+
+
+class spec:  # the handful of constructors the programs below use, in the reference's `Instruction::X {..}` vocabulary
+    add = staticmethod(lambda rd, rs1, rs2: E(O.ADD, rd, rs1, rs2))
+    lw = staticmethod(lambda rd, rs1, imm: E(O.LW, rd, rs1, imm=imm))
+    sw = staticmethod(lambda rs1, rs2, imm: E(O.SW, rs1=rs1, rs2=rs2, imm=imm))
+    beq = staticmethod(lambda rs1, rs2, off: E(O.BEQ, rs1=rs1, rs2=rs2, imm=off))
+    bne = staticmethod(lambda rs1, rs2, off: E(O.BNE, rs1=rs1, rs2=rs2, imm=off))
+    jal = staticmethod(lambda rd, off: E(O.JAL, rd, imm=off))
+
+
+assert E(O.ADD, 4, 1, 2) == 0x00010A00 and E(O.BNE, rs1=3, rs2=0, imm=-16) == 0xFFF801C1   # tests/cross_module.rs:140-175 (fib5 words 3 and 7)
 A = lambda rd, rs1, imm: E(O.ADDI, rd, rs1, imm=imm)  # noqa: E731
-EC, EB = spec.ecall(), spec.ebreak()
+EC, EB = O.ECALL, O.EBREAK
 EXIT0 = [A(10, 0, 0), A(11, 0, 0), EC]
 WRITE = lambda r: [A(11, r, 0), A(10, 0, 2), EC]  # noqa: E731
 

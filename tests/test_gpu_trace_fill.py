@@ -26,7 +26,7 @@ def _check(res, want):
 
 @pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1023, 1024, 1025, 5000, 65536])
 def test_fib_cycle_limit_sizes(n):
-    """Ragged and exact tile multiples (tile = 1024 rows); halt = CycleLimit with exactly n rows (vm.rs:211-214)."""
+    """Ragged and exact tile multiples (default tile = 256 rows); halt = CycleLimit with exactly n rows (vm.rs:211-214)."""
     res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=n)
     assert res.cycles == n
     _check(res, want)

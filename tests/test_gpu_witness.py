@@ -95,6 +95,37 @@ def test_normalization_events(name):
     assert np.array_equal(pl.normalization_events(log), want.norm_events)
 
 
+@pytest.mark.parametrize("name", MEM_PROGRAMS + ["rc_doubling", "rc_many_pending", "rc_config_30bit", "fib_rc", "deferred_fib", "deferred_add_sub_mix"])
+def test_result_handle_witness_streams(name):
+    """The drop-in handle itself (zkir_exec -> zkir_result_memory_trace / _range_check_witnesses / _normalization_witnesses /
+    _sha256_witnesses): device columns behind the C ABI, copied back and compared with the oracle's ExecutionResult."""
+    blob, inputs, cfg = programs.ALL[name]()
+    cfg = dict(cfg, enable_execution_trace=True)
+    res = rt.VM(blob, inputs, rt.VMConfig(**cfg)).run()
+    want = oracle.run(blob, inputs, **cfg)
+    ops, offs = res.row_memory_ops()
+    assert np.array_equal(ops, want.memops) and np.array_equal(offs, want.row_memop_offsets)
+    assert np.array_equal(res.get_memory_trace(), want.sorted_memops) and res.memory_op_count() == len(want.memops)
+    assert np.array_equal(res.get_memory_trace(), want.sorted_memops)                # cached columns: same answer the second time
+    w = res.range_check_witnesses
+    assert [len(x) for x in w] == list(np.diff(want.rc_offsets.astype(np.int64)))
+    flat = [c for grp in w for c in grp]
+    assert flat == [(int(e["value"]), [int(x) for x in e["chunks"]], int(e["pc"])) for e in want.rc_checks]
+    if len(want.rc_checks):
+        rcw = res.range_check_witness()
+        mult = res._d2h(rcw.multiplicity, 1 << rcw.chunk_bits, "<u4")
+        assert np.array_equal(mult, np.bincount(want.rc_checks["chunks"].reshape(-1), minlength=1 << rcw.chunk_bits).astype(np.uint32))
+    assert np.array_equal(res.normalization_witnesses, want.norm_events)
+    cols, stamps = res.sha256_witnesses()
+    blocks = res.delta_log.sha_blocks
+    assert cols.shape[1] == len(blocks) == len(stamps)
+    for k in range(len(blocks)):
+        n_bytes = int(blocks[k]["message_block"][15]) // 8
+        msg = blocks[k]["message_block"].astype(">u4").tobytes()[:n_bytes]
+        assert np.array_equal(cols[:, k], oracle.sha256_witness(msg, int(stamps[k]))["flat"])
+    res.close()
+
+
 def test_execution_result_members_mirror_the_reference():
     """ExecutionResult.{get_memory_trace, memory_op_count, range_check_witnesses, normalization_witnesses} (vm.rs:54-103)."""
     blob, inputs, cfg = programs.ALL["deferred_negative_and_overflow"]()

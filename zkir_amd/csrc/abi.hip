@@ -2,6 +2,8 @@
 // zkir_exec (VM::new + VM::run replacement: host interpreter -> H2D -> K1 trace fill).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/zkir_amd.h"
 #include "host.h"
 
@@ -18,7 +20,23 @@ struct zkir_result {
   void* d_tile_snap = nullptr;
   void* d_block = nullptr;      // one allocation holding every trace column
   uint64_t cap_rows = 0;
+  // witness streams of ExecutionResult (vm.rs:54-103), expanded on the device on first request and cached
+  std::mutex wmu;
+  bool mem_built = false, rc_built = false, norm_built = false, sha_built = false;
+  void* d_mem = nullptr; zkir_memory_witness mem{};
+  void* d_rc = nullptr; zkir_range_check_witness rc{};
+  void* d_norm = nullptr; zkir_normalization_witness norm{};
+  void* d_sha = nullptr; zkir_sha256_witness sha{};
 };
+
+namespace {
+// carve `count` elements of T out of a device block (256-byte aligned pieces)
+struct Carver {
+  unsigned char* p; size_t off = 0;
+  template <typename T> T* take(size_t count) { T* r = (T*)(p + off); off += (count * sizeof(T) + 255) & ~(size_t)255; return r; }
+};
+inline size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+}  // namespace
 
 #define HIP_TRY(expr)                                                                                  \
   do {                                                                                                 \
@@ -64,6 +82,12 @@ int zkir_delta_log_shard(const zkir_delta_log* src, uint64_t row_begin, uint64_t
   d->tile_rows = src->tile_rows; d->rc_chunk_bits = src->rc_chunk_bits;
   d->n_rows = row_end - row_begin; d->cycle_base = row_begin;
   d->rc_offsets.push_back(0);
+  for (size_t k = 0; k < src->rc_cycles.size(); k++) {                            // a witness belongs to the shard that holds its checkpoint cycle (vm.rs:316-344)
+    if (src->rc_cycles[k] < row_begin || src->rc_cycles[k] >= row_end) continue;
+    d->rc_events.append(src->rc_events.data() + src->rc_offsets[k], src->rc_offsets[k + 1] - src->rc_offsets[k]);
+    d->rc_offsets.push_back(d->rc_events.size());
+    d->rc_cycles.push_back(src->rc_cycles[k]);
+  }
   if (d->n_rows == 0) { d->tile_ev_off.push_back(0); *out = d; return ZKIR_OK; }
   const uint64_t t0 = row_begin / T, t1 = (row_end + T - 1) / T;                   // tiles [t0, t1)
   const uint32_t e0 = src->tile_ev_off[t0];
@@ -111,6 +135,7 @@ size_t zkir_delta_log_n_rc_events(const zkir_delta_log* l) { return l->rc_events
 const zkir_rc_event* zkir_delta_log_rc_events(const zkir_delta_log* l) { return l->rc_events.data(); }
 size_t zkir_delta_log_n_rc_witnesses(const zkir_delta_log* l) { return l->rc_offsets.size() - 1; }
 const uint64_t* zkir_delta_log_rc_offsets(const zkir_delta_log* l) { return l->rc_offsets.data(); }
+const uint64_t* zkir_delta_log_rc_cycles(const zkir_delta_log* l) { return l->rc_cycles.data(); }
 uint32_t zkir_delta_log_rc_chunk_bits(const zkir_delta_log* l) { return l->rc_chunk_bits; }
 size_t zkir_delta_log_n_norm_events(const zkir_delta_log* l) { return l->norm_events.size(); }
 const zkir_norm_event* zkir_delta_log_norm_events(const zkir_delta_log* l) { return l->norm_events.data(); }
@@ -186,6 +211,10 @@ void zkir_result_free(zkir_result* r) {
   if (r->d_events) (void)hipFree(r->d_events);
   if (r->d_tile_ev_off) (void)hipFree(r->d_tile_ev_off);
   if (r->d_tile_snap) (void)hipFree(r->d_tile_snap);
+  if (r->d_mem) (void)hipFree(r->d_mem);
+  if (r->d_rc) (void)hipFree(r->d_rc);
+  if (r->d_norm) (void)hipFree(r->d_norm);
+  if (r->d_sha) (void)hipFree(r->d_sha);
   delete r->log;
   delete r;
 }
@@ -209,6 +238,145 @@ int zkir_result_copy_column(const zkir_result* r, int field, int reg, void* dst)
     case 7: src = r->cols.reg_state + off; elt = 1; break;
   }
   hipError_t e = hipMemcpy(dst, src, n * elt, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
+  return ZKIR_OK;
+}
+
+
+// ---- ExecutionResult witness streams (vm.rs:54-103) behind the drop-in handle ---------------------------------------------------
+// Each accessor uploads the compact side log once, runs the witness.hip kernels on the NULL stream, synchronises and caches the
+// device columns in the handle (released by zkir_result_free).  Thread-safe per handle.
+#define HIP_TRYW(expr)                                                                                 \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)});      \
+      if (staging) (void)hipFree(staging);                                                             \
+      return ZKIR_ERR_DEVICE;                                                                          \
+    }                                                                                                  \
+  } while (0)
+
+static void carve_memops(Carver& cv, uint64_t n, zkir_memop_columns& c) {
+  c.address = cv.take<uint64_t>(n); c.value = cv.take<uint64_t>(n); c.timestamp = cv.take<uint64_t>(n); c.bound_payload = cv.take<uint64_t>(n);
+  c.bound_bits = cv.take<uint32_t>(n); c.is_write = cv.take<uint8_t>(n); c.width = cv.take<uint8_t>(n); c.bound_tag = cv.take<uint8_t>(n);
+}
+
+int zkir_result_memory_trace(zkir_result* r, zkir_memory_witness* out) {
+  if (!r || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_result_memory_trace: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(r->wmu);
+  if (!r->mem_built) {
+    const zkir_delta_log* log = r->log;
+    const uint64_t n = log->mem_events.size(), rows = log->n_rows;
+    void* staging = nullptr;
+    r->mem = zkir_memory_witness{};
+    r->mem.n_ops = n; r->mem.n_rows = rows;
+    const size_t per_cols = 4 * padded(n * 8) + padded(n * 4) + 3 * padded(n);
+    const size_t bytes = 2 * per_cols + padded((rows + 1) * 8) + 256;
+    HIP_TRYW(hipMalloc(&r->d_mem, bytes));
+    Carver cv{(unsigned char*)r->d_mem};
+    carve_memops(cv, n, r->mem.row_order); carve_memops(cv, n, r->mem.sorted);
+    uint64_t* offs = cv.take<uint64_t>(rows + 1);
+    r->mem.row_offsets = offs;
+    HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_mem_event) + rows + 256));
+    zkir_mem_event* d_ev = (zkir_mem_event*)staging;
+    uint8_t* scratch = (uint8_t*)staging + ((n * sizeof(zkir_mem_event) + 255) & ~(size_t)255);
+    if (n) HIP_TRYW(hipMemcpyAsync(d_ev, log->mem_events.data(), n * sizeof(zkir_mem_event), hipMemcpyHostToDevice, nullptr));
+    int rc = zkir_memops_row_offsets_launch(d_ev, n, rows, offs, nullptr);
+    if (rc == ZKIR_OK) rc = zkir_memops_expand_launch(d_ev, n, log->cycle_base, &r->mem.row_order, nullptr);
+    if (rc == ZKIR_OK) rc = zkir_memops_sort_launch(d_ev, n, rows, log->cycle_base, offs, scratch, &r->mem.sorted, nullptr);
+    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    HIP_TRYW(hipStreamSynchronize(nullptr));
+    (void)hipFree(staging);
+    r->mem_built = true;
+  }
+  *out = r->mem;
+  return ZKIR_OK;
+}
+
+int zkir_result_range_check_witnesses(zkir_result* r, zkir_range_check_witness* out) {
+  if (!r || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_result_range_check_witnesses: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(r->wmu);
+  if (!r->rc_built) {
+    const zkir_delta_log* log = r->log;
+    const uint64_t n = log->rc_events.size();
+    void* staging = nullptr;
+    r->rc = zkir_range_check_witness{};
+    r->rc.n_checks = n; r->rc.n_witnesses = log->rc_offsets.size() - 1; r->rc.witness_offsets = log->rc_offsets.data();
+    r->rc.witness_cycles = log->rc_cycles.data();
+    r->rc.chunk_bits = log->rc_chunk_bits; r->rc.chunk_stride = (n + 127) & ~(uint64_t)127;
+    const size_t bytes = 2 * padded(n * 8) + padded(4 * r->rc.chunk_stride * 2) + padded(sizeof(uint32_t) << log->rc_chunk_bits) + 256;
+    HIP_TRYW(hipMalloc(&r->d_rc, bytes));
+    Carver cv{(unsigned char*)r->d_rc};
+    uint64_t* value = cv.take<uint64_t>(n); uint64_t* pc = cv.take<uint64_t>(n);
+    uint16_t* chunks = cv.take<uint16_t>(4 * r->rc.chunk_stride); uint32_t* mult = cv.take<uint32_t>((size_t)1 << log->rc_chunk_bits);
+    r->rc.value = value; r->rc.pc = pc; r->rc.chunks = chunks; r->rc.multiplicity = mult;
+    HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_rc_event) + 256));
+    if (n) HIP_TRYW(hipMemcpyAsync(staging, log->rc_events.data(), n * sizeof(zkir_rc_event), hipMemcpyHostToDevice, nullptr));
+    const int rc = zkir_range_check_expand_launch((const zkir_rc_event*)staging, n, log->rc_chunk_bits, value, pc, chunks, r->rc.chunk_stride, mult, nullptr);
+    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    HIP_TRYW(hipStreamSynchronize(nullptr));
+    (void)hipFree(staging);
+    r->rc_built = true;
+  }
+  *out = r->rc;
+  return ZKIR_OK;
+}
+
+int zkir_result_normalization_witnesses(zkir_result* r, zkir_normalization_witness* out) {
+  if (!r || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_result_normalization_witnesses: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(r->wmu);
+  if (!r->norm_built) {
+    const zkir_delta_log* log = r->log;
+    const uint64_t n = log->norm_events.size();
+    void* staging = nullptr;
+    r->norm = zkir_normalization_witness{};
+    r->norm.n_events = n;
+    HIP_TRYW(hipMalloc(&r->d_norm, 4 * padded(n * 8) + 4 * padded(n * 4) + 2 * padded(n) + 256));
+    Carver cv{(unsigned char*)r->d_norm};
+    zkir_norm_columns& c = r->norm.columns;
+    c.cycle = cv.take<uint64_t>(n); c.pc = cv.take<uint64_t>(n); c.accumulated0 = cv.take<uint64_t>(n); c.accumulated1 = cv.take<uint64_t>(n);
+    c.normalized0 = cv.take<uint32_t>(n); c.normalized1 = cv.take<uint32_t>(n); c.carry0 = cv.take<uint32_t>(n); c.carry1 = cv.take<uint32_t>(n);
+    c.reg = cv.take<uint8_t>(n); c.opcode = cv.take<uint8_t>(n);
+    HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_norm_event) + 256));
+    if (n) HIP_TRYW(hipMemcpyAsync(staging, log->norm_events.data(), n * sizeof(zkir_norm_event), hipMemcpyHostToDevice, nullptr));
+    const int rc = zkir_norm_expand_launch((const zkir_norm_event*)staging, n, &c, nullptr);
+    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    HIP_TRYW(hipStreamSynchronize(nullptr));
+    (void)hipFree(staging);
+    r->norm_built = true;
+  }
+  *out = r->norm;
+  return ZKIR_OK;
+}
+
+int zkir_result_sha256_witnesses(zkir_result* r, zkir_sha256_witness* out) {
+  if (!r || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_result_sha256_witnesses: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(r->wmu);
+  if (!r->sha_built) {
+    const zkir_delta_log* log = r->log;
+    const uint64_t n = log->sha_blocks.size();
+    void* staging = nullptr;
+    r->sha = zkir_sha256_witness{};
+    r->sha.n_blocks = n; r->sha.stride = (n + 63) & ~(uint64_t)63;
+    HIP_TRYW(hipMalloc(&r->d_sha, padded(608 * r->sha.stride * 4) + padded(n * 8) + 256));
+    Carver cv{(unsigned char*)r->d_sha};
+    uint32_t* cols = cv.take<uint32_t>(608 * r->sha.stride); uint64_t* ts = cv.take<uint64_t>(n);
+    r->sha.columns = cols; r->sha.timestamps = ts;
+    HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_sha_block) + 256));
+    if (n) HIP_TRYW(hipMemcpyAsync(staging, log->sha_blocks.data(), n * sizeof(zkir_sha_block), hipMemcpyHostToDevice, nullptr));
+    const int rc = zkir_sha256_chip_launch((const zkir_sha_block*)staging, n, cols, r->sha.stride, ts, nullptr);
+    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    HIP_TRYW(hipStreamSynchronize(nullptr));
+    (void)hipFree(staging);
+    r->sha_built = true;
+  }
+  *out = r->sha;
+  return ZKIR_OK;
+}
+
+int zkir_device_to_host(void* host_dst, const void* device_src, size_t bytes) {
+  if (bytes == 0) return ZKIR_OK;
+  const hipError_t e = hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
   return ZKIR_OK;
 }

@@ -5,7 +5,7 @@
 // crypto.rs:346-348) and blake3 1.5 (blake3::hash, crypto.rs:387).  These are the published
 // algorithms (FIPS 180-4; Keccak-f[1600] r=1088 c=512 with pad byte 0x01; BLAKE3 spec, default
 // mode), written block-streaming.  Pinned by the digests the reference's tests hold
-// (crypto.rs:402-546, crypto_edge_cases.rs:36-127) via tests/test_hashes.py.
+// (crypto.rs:402-546, crypto_edge_cases.rs:36-127) via tests/test_oracle_kats.py (the [product_host] parametrisation drives these functions through the interpreter's syscalls).
 #include "host.h"
 
 namespace zkir {

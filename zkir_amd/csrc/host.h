@@ -103,6 +103,7 @@ struct zkir_delta_log {
   zkir::Buf<zkir_mem_event> mem_events;
   zkir::Buf<zkir_rc_event> rc_events;
   std::vector<uint64_t> rc_offsets;
+  std::vector<uint64_t> rc_cycles;   // cycle of the checkpoint that flushed witness k (vm.rs:316-344); row sharding cuts by it
   zkir::Buf<zkir_norm_event> norm_events;
   zkir::Buf<zkir_sha_block> sha_blocks;
 };

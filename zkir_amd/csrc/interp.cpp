@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 
@@ -525,7 +526,7 @@ bool Machine::hash_syscall(int which) {
 
 void Machine::flush_range_checks() {                      // RangeCheckTracker::checkpoint, range_check.rs:140-168
   for (const PendingCheck& p : pending_) log_.rc_events.push(zkir_rc_event{p.value40, p.pc});
-  if (!pending_.empty()) log_.rc_offsets.push_back(log_.rc_events.size());   // vm.rs:340-342: empty witnesses are dropped
+  if (!pending_.empty()) { log_.rc_offsets.push_back(log_.rc_events.size()); log_.rc_cycles.push_back(cycle_); }   // vm.rs:340-342: empty witnesses are dropped
   pending_.clear();
 }
 
@@ -543,7 +544,8 @@ Status Machine::run() {
   Status st;
   while (!halted_) {
     if (cycle_ >= cfg_.max_cycles) { halted_ = true; halt_kind_ = ZKIR_HALT_CYCLE_LIMIT; break; }     // vm.rs:211-214
-    if (tracing_ && cycle_ >= 0xFFFFFFF0ull) return {ZKIR_ERR_OTHER, "trace longer than 2^32-16 rows is not supported"};
+    if (tracing_ && (cycle_ >= 0xFFFFFFF0ull || log_.reg_events.size() >= 0xFFFFFFC0ull))                // event / row indices are 32-bit (tile index, vis)
+      return {ZKIR_ERR_OTHER, "trace longer than 2^32-16 rows or 2^32-64 register events is not supported"};
     fetch_pc_ = pc_;
     if (pc_ & 3) return {ZKIR_ERR_OTHER, "Misaligned PC: " + hexs(pc_)};                              // vm.rs:364-369
     const uint32_t word = mem_.load<uint32_t>(pc_);                                                   // the fetch is never part of a row (vm.rs:295)
@@ -598,13 +600,11 @@ Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t
     return {ZKIR_ERR_BAD_PROGRAM, "Program appears to be in debug format (entry_point=" + hexs(pv.entry_point) + "). Use release format (zkir-llvm without --debug) for execution."};
   }
   if (tile_rows == 0) tile_rows = cfg.max_cycles <= (1ull << 21) ? 256u : 512u;   // measured best on MI355X (profiles/r01_sweep_trace_fill.txt)
-  if (tile_rows < 256 || tile_rows > 4096 || (tile_rows & (tile_rows - 1))) return {ZKIR_ERR_ARGUMENT, "tile_rows must be a power of two in 256..4096"};
+  if (tile_rows < 256 || tile_rows > 2048 || (tile_rows & (tile_rows - 1))) return {ZKIR_ERR_ARGUMENT, "tile_rows must be a power of two in 256..2048"};   // K1 instantiations (trace_fill.hip); 4096 would need 262 KB of LDS
   log.tile_rows = tile_rows;
   if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 28)) { log.pc.reserve(cfg.max_cycles); log.inst.reserve(cfg.max_cycles); log.reg_events.reserve(cfg.max_cycles + 16); }
-  Machine* m = new Machine(pv, inputs, n_inputs, cfg, log);
-  st = m->run();
-  delete m;
-  return st;
+  std::unique_ptr<Machine> m(new Machine(pv, inputs, n_inputs, cfg, log));   // ~170 KB (icache): heap, released on every path
+  return m->run();
 }
 
 }  // namespace zkir

@@ -148,20 +148,23 @@ class MemopColumns:
 
 
 def memory_ops(log: rt.DeltaLog, device=None, stream=None):
-    """Returns (row_order MemopColumns, row_offsets tensor[n_rows+1], sorted MemopColumns = get_memory_trace())."""
+    """Returns (row_order MemopColumns, row_offsets tensor[n_rows+1], sorted MemopColumns = get_memory_trace()).
+    Uploads, allocations and launches all happen on `stream` (default: the current stream), which is synchronised before returning."""
     _require_gpu()
     device = device or torch.device("cuda", torch.cuda.current_device())
     L = rt.lib()
     n, n_rows = len(log.mem_events), log.n_rows
-    ev = _to_dev(log.mem_events, device)
-    sp = _stream_ptr(stream)
-    row_cols, sorted_cols = MemopColumns(n, device), MemopColumns(n, device)
-    offsets = torch.empty(n_rows + 1, dtype=torch.int64, device=device)
-    scratch = torch.empty(max(n_rows, 1), dtype=torch.uint8, device=device)
-    _check(L.zkir_memops_row_offsets_launch(ev.data_ptr(), n, n_rows, offsets.data_ptr(), sp))
-    _check(L.zkir_memops_expand_launch(ev.data_ptr(), n, log.cycle_base, C.byref(row_cols.c), sp))
-    _check(L.zkir_memops_sort_launch(ev.data_ptr(), n, n_rows, log.cycle_base, offsets.data_ptr(), scratch.data_ptr(), C.byref(sorted_cols.c), sp))
-    torch.cuda.current_stream().synchronize()
+    s = stream or torch.cuda.current_stream()
+    with torch.cuda.stream(s):
+        ev = _to_dev(log.mem_events, device)
+        sp = _stream_ptr(s)
+        row_cols, sorted_cols = MemopColumns(n, device), MemopColumns(n, device)
+        offsets = torch.empty(n_rows + 1, dtype=torch.int64, device=device)
+        scratch = torch.empty(max(n_rows, 1), dtype=torch.uint8, device=device)
+        _check(L.zkir_memops_row_offsets_launch(ev.data_ptr(), n, n_rows, offsets.data_ptr(), sp))
+        _check(L.zkir_memops_expand_launch(ev.data_ptr(), n, log.cycle_base, C.byref(row_cols.c), sp))
+        _check(L.zkir_memops_sort_launch(ev.data_ptr(), n, n_rows, log.cycle_base, offsets.data_ptr(), scratch.data_ptr(), C.byref(sorted_cols.c), sp))
+        s.synchronize()
     return row_cols, offsets, sorted_cols
 
 
@@ -170,14 +173,16 @@ def range_checks(log: rt.DeltaLog, device=None, stream=None):
     _require_gpu()
     device = device or torch.device("cuda", torch.cuda.current_device())
     n = len(log.rc_events)
-    ev = _to_dev(log.rc_events, device)
-    value = torch.empty(max(n, 1), dtype=torch.int64, device=device)
-    pc = torch.empty(max(n, 1), dtype=torch.int64, device=device)
-    chunks = torch.empty((4, max(n, 1)), dtype=torch.int16, device=device)
-    mult = torch.empty(1 << log.rc_chunk_bits, dtype=torch.int32, device=device)
-    _check(rt.lib().zkir_range_check_expand_launch(ev.data_ptr(), n, log.rc_chunk_bits, value.data_ptr(), pc.data_ptr(), chunks.data_ptr(),
-                                                    max(n, 1), mult.data_ptr(), _stream_ptr(stream)))
-    torch.cuda.current_stream().synchronize()
+    s = stream or torch.cuda.current_stream()
+    with torch.cuda.stream(s):
+        ev = _to_dev(log.rc_events, device)
+        value = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+        pc = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+        chunks = torch.empty((4, max(n, 1)), dtype=torch.int16, device=device)
+        mult = torch.empty(1 << log.rc_chunk_bits, dtype=torch.int32, device=device)
+        _check(rt.lib().zkir_range_check_expand_launch(ev.data_ptr(), n, log.rc_chunk_bits, value.data_ptr(), pc.data_ptr(), chunks.data_ptr(),
+                                                        max(n, 1), mult.data_ptr(), _stream_ptr(s)))
+        s.synchronize()
     return value[:n], pc[:n], chunks[:, :n], mult
 
 
@@ -186,13 +191,15 @@ def normalization_events(log: rt.DeltaLog, device=None, stream=None) -> np.ndarr
     _require_gpu()
     device = device or torch.device("cuda", torch.cuda.current_device())
     n = len(log.norm_events)
-    ev = _to_dev(log.norm_events, device)
+    s = stream or torch.cuda.current_stream()
     spec_ = (("cycle", torch.int64), ("pc", torch.int64), ("reg", torch.uint8), ("opcode", torch.uint8), ("accumulated0", torch.int64),
              ("accumulated1", torch.int64), ("normalized0", torch.int32), ("normalized1", torch.int32), ("carry0", torch.int32), ("carry1", torch.int32))
-    t = {k: torch.empty(max(n, 1), dtype=dt, device=device) for k, dt in spec_}
-    cols = rt.NormColumnsC(*[t[k].data_ptr() for k, _ in spec_])
-    _check(rt.lib().zkir_norm_expand_launch(ev.data_ptr(), n, C.byref(cols), _stream_ptr(stream)))
-    torch.cuda.current_stream().synchronize()
+    with torch.cuda.stream(s):
+        ev = _to_dev(log.norm_events, device)
+        t = {k: torch.empty(max(n, 1), dtype=dt, device=device) for k, dt in spec_}
+        cols = rt.NormColumnsC(*[t[k].data_ptr() for k, _ in spec_])
+        _check(rt.lib().zkir_norm_expand_launch(ev.data_ptr(), n, C.byref(cols), _stream_ptr(s)))
+        s.synchronize()
     dt = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("reg", "u1"), ("accumulated", "<u8", (2,)), ("normalized", "<u4", (2,)),
                    ("carries", "<u4", (2,)), ("normalized_bits", "u1"), ("limb_bits", "u1"), ("cause", "u1"), ("opcode", "u1")])
     out = np.zeros(n, dtype=dt)
@@ -206,12 +213,15 @@ def normalization_events(log: rt.DeltaLog, device=None, stream=None) -> np.ndarr
 
 
 def sha256_chip(blocks: np.ndarray, device=None, stream=None):
-    """K3: blocks = rt.SHA_BLOCK_DTYPE records -> (columns tensor int32 [608][n], timestamps int64[n])."""
+    """K3: blocks = rt.SHA_BLOCK_DTYPE records -> (columns tensor int32 [608][n], timestamps int64[n]); `stream` is synchronised."""
     _require_gpu()
     device = device or torch.device("cuda", torch.cuda.current_device())
     n = len(blocks)
-    ev = _to_dev(blocks, device)
-    out = torch.empty((608, max(n, 1)), dtype=torch.int32, device=device)
-    ts = torch.empty(max(n, 1), dtype=torch.int64, device=device)
-    _check(rt.lib().zkir_sha256_chip_launch(ev.data_ptr(), n, out.data_ptr(), max(n, 1), ts.data_ptr(), _stream_ptr(stream)))
+    s = stream or torch.cuda.current_stream()
+    with torch.cuda.stream(s):
+        ev = _to_dev(blocks, device)
+        out = torch.empty((608, max(n, 1)), dtype=torch.int32, device=device)
+        ts = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+        _check(rt.lib().zkir_sha256_chip_launch(ev.data_ptr(), n, out.data_ptr(), max(n, 1), ts.data_ptr(), _stream_ptr(s)))
+        s.synchronize()
     return out[:, :n], ts[:n]

@@ -83,6 +83,24 @@ class NormColumnsC(C.Structure):
                                          "carry0", "carry1")]
 
 
+class MemoryWitnessC(C.Structure):            # zkir_memory_witness
+    _fields_ = [("n_ops", C.c_uint64), ("n_rows", C.c_uint64), ("row_order", MemopColumnsC), ("row_offsets", C.c_void_p), ("sorted", MemopColumnsC)]
+
+
+class RangeCheckWitnessC(C.Structure):        # zkir_range_check_witness
+    _fields_ = [("n_checks", C.c_uint64), ("n_witnesses", C.c_uint64), ("witness_offsets", C.c_void_p), ("witness_cycles", C.c_void_p),
+                ("value", C.c_void_p), ("pc", C.c_void_p), ("chunks", C.c_void_p), ("chunk_stride", C.c_uint64), ("chunk_bits", C.c_uint32),
+                ("multiplicity", C.c_void_p)]
+
+
+class NormalizationWitnessC(C.Structure):     # zkir_normalization_witness
+    _fields_ = [("n_events", C.c_uint64), ("columns", NormColumnsC)]
+
+
+class Sha256WitnessC(C.Structure):            # zkir_sha256_witness
+    _fields_ = [("n_blocks", C.c_uint64), ("columns", C.c_void_p), ("stride", C.c_uint64), ("timestamps", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -114,7 +132,7 @@ def lib() -> C.CDLL:
                       ("inst", C.c_void_p), ("n_reg_events", C.c_size_t), ("reg_events", C.c_void_p), ("n_tiles", C.c_size_t),
                       ("tile_ev_off", C.c_void_p), ("tile_snap", C.c_void_p), ("n_mem_events", C.c_size_t),
                       ("mem_events", C.c_void_p), ("n_rc_events", C.c_size_t), ("rc_events", C.c_void_p),
-                      ("n_rc_witnesses", C.c_size_t), ("rc_offsets", C.c_void_p), ("rc_chunk_bits", C.c_uint32),
+                      ("n_rc_witnesses", C.c_size_t), ("rc_offsets", C.c_void_p), ("rc_cycles", C.c_void_p), ("rc_chunk_bits", C.c_uint32),
                       ("n_norm_events", C.c_size_t), ("norm_events", C.c_void_p), ("n_sha_blocks", C.c_size_t),
                       ("sha_blocks", C.c_void_p)]:
         f = getattr(L, "zkir_delta_log_" + name)
@@ -166,6 +184,13 @@ def lib() -> C.CDLL:
     L.zkir_result_trace.argtypes = [C.c_void_p]
     L.zkir_result_copy_column.restype = C.c_int
     L.zkir_result_copy_column.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for name, st in [("memory_trace", MemoryWitnessC), ("range_check_witnesses", RangeCheckWitnessC),
+                     ("normalization_witnesses", NormalizationWitnessC), ("sha256_witnesses", Sha256WitnessC)]:
+        f = getattr(L, "zkir_result_" + name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(st)]
+    L.zkir_device_to_host.restype = C.c_int
+    L.zkir_device_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -232,6 +257,7 @@ class DeltaLog:
         self.mem_events = _view(L.zkir_delta_log_mem_events(h), L.zkir_delta_log_n_mem_events(h), MEM_EVENT_DTYPE)
         self.rc_events = _view(L.zkir_delta_log_rc_events(h), L.zkir_delta_log_n_rc_events(h), RC_EVENT_DTYPE)
         self.rc_offsets = _view(L.zkir_delta_log_rc_offsets(h), L.zkir_delta_log_n_rc_witnesses(h) + 1, "<u8")
+        self.rc_cycles = _view(L.zkir_delta_log_rc_cycles(h), L.zkir_delta_log_n_rc_witnesses(h), "<u8")
         self.rc_chunk_bits = L.zkir_delta_log_rc_chunk_bits(h)
         self.norm_events = _view(L.zkir_delta_log_norm_events(h), L.zkir_delta_log_n_norm_events(h), NORM_EVENT_DTYPE)
         self.sha_blocks = _view(L.zkir_delta_log_sha_blocks(h), L.zkir_delta_log_n_sha_blocks(h), SHA_BLOCK_DTYPE)
@@ -286,10 +312,38 @@ class ExecutionTrace:
                 _raise(rc)
         return out
 
+    _ROW_DTYPE = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("instruction", "<u4"), ("registers", "<u8", (16,)),
+                           ("bound_bits", "<u4", (16,)), ("bound_tag", "u1", (16,)), ("bound_payload", "<u8", (16,)), ("reg_state", "u1", (16,))])
+
+    def rows_window(self, lo: int, hi: int) -> np.ndarray:
+        """Rows [lo, hi) as packed reference-shaped records, copied straight from the device columns (sampled parity checks at
+        sizes where copying whole columns is wasteful)."""
+        assert 0 <= lo <= hi <= self.n_rows
+        n = hi - lo
+        out = np.zeros(n, dtype=self._ROW_DTYPE)
+        if n == 0:
+            return out
+        c, L = self.columns, lib()
+
+        def grab(base, elt, dtype, reg=None):
+            buf = np.empty(n, dtype=dtype)
+            off = (lo if reg is None else reg * c.reg_stride + lo) * elt
+            rc = L.zkir_device_to_host(buf.ctypes.data, base + off, n * elt)
+            if rc != ZKIR_OK:
+                _raise(rc)
+            return buf
+        out["cycle"] = grab(c.cycle, 8, "<u8"); out["pc"] = grab(c.pc, 8, "<u8"); out["instruction"] = grab(c.instruction, 4, "<u4")
+        for r in range(16):
+            out["registers"][:, r] = grab(c.registers, 8, "<u8", r)
+            out["bound_bits"][:, r] = grab(c.bound_bits, 4, "<u4", r)
+            out["bound_tag"][:, r] = grab(c.bound_tag, 1, "u1", r)
+            out["bound_payload"][:, r] = grab(c.bound_payload, 8, "<u8", r)
+            out["reg_state"][:, r] = grab(c.reg_state, 1, "u1", r)
+        return out
+
     def rows(self) -> np.ndarray:
         """All rows as packed reference-shaped records (same dtype as the test oracle's rows)."""
-        dt = np.dtype([("cycle", "<u8"), ("pc", "<u8"), ("instruction", "<u4"), ("registers", "<u8", (16,)),
-                       ("bound_bits", "<u4", (16,)), ("bound_tag", "u1", (16,)), ("bound_payload", "<u8", (16,)), ("reg_state", "u1", (16,))])
+        dt = self._ROW_DTYPE
         out = np.zeros(self.n_rows, dtype=dt)
         out["cycle"] = self.column(FIELD_CYCLE)
         out["pc"] = self.column(FIELD_PC)
@@ -317,38 +371,108 @@ class ExecutionResult:
             self.execution_trace._r, self.execution_trace.n_rows, self.execution_trace.columns = None, 0, None
         self.delta_log = log
 
-    # -- the remaining ExecutionResult members (vm.rs:64-103), expanded on the device from the delta log's side logs --
+    # -- the remaining ExecutionResult members (vm.rs:64-103): device columns behind the C handle (zkir_result_*), copied to the
+    #    host here as reference-shaped records for the tests --
+    def _d2h(self, ptr, n, dtype) -> np.ndarray:
+        out = np.empty(n, dtype=dtype)
+        if n:
+            rc = lib().zkir_device_to_host(out.ctypes.data, ptr, out.nbytes)
+            if rc != ZKIR_OK:
+                _raise(rc)
+        return out
+
+    def _memops(self, cols: MemopColumnsC, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=_MEMOP_DTYPE)
+        for name in _MEMOP_DTYPE.names:
+            out[name] = self._d2h(getattr(cols, name), n, _MEMOP_DTYPE[name])
+        return out
+
+    def memory_witness(self) -> MemoryWitnessC:
+        """zkir_result_memory_trace: device columns (row order, CSR row offsets, sorted)."""
+        w = MemoryWitnessC()
+        rc = lib().zkir_result_memory_trace(self._r, C.byref(w))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        return w
+
     def get_memory_trace(self) -> np.ndarray:
         """ExecutionResult::get_memory_trace (vm.rs:85-94): every data-memory op, stably sorted by (timestamp, address, Read<Write).
         Returns packed MemoryOp records (address, value, timestamp, is_write, width, bound_*)."""
-        from . import pipeline as pl
-        if self._log.n_rows == 0 or len(self._log.mem_events) == 0:
+        if not self._r or self._log.n_rows == 0:
             return np.zeros(0, dtype=_MEMOP_DTYPE)
-        return pl.memory_ops(self._log)[2].to_numpy()
+        w = self.memory_witness()
+        return self._memops(w.sorted, w.n_ops)
+
+    def row_memory_ops(self) -> Tuple[np.ndarray, np.ndarray]:
+        """TraceRow.memory_ops of every row (trace.rs:49): (ops in row order, offsets[n_rows+1])."""
+        if not self._r or self._log.n_rows == 0:
+            return np.zeros(0, dtype=_MEMOP_DTYPE), np.zeros(1, dtype=np.uint64)
+        w = self.memory_witness()
+        return self._memops(w.row_order, w.n_ops), self._d2h(w.row_offsets, w.n_rows + 1, "<u8")
 
     def memory_op_count(self) -> int:
         """ExecutionResult::memory_op_count (vm.rs:97-102)."""
         return len(self._log.mem_events)
 
+    def range_check_witness(self) -> Optional[RangeCheckWitnessC]:
+        if not self._r:
+            return None
+        w = RangeCheckWitnessC()
+        rc = lib().zkir_result_range_check_witnesses(self._r, C.byref(w))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        return w
+
     @property
     def range_check_witnesses(self) -> list:
         """Vec<RangeCheckWitness> (range_check.rs:209-238): one list of (value, chunks[4], pc) per non-empty checkpoint."""
-        from . import pipeline as pl
         log = self._log
         if len(log.rc_events) == 0:
             return []
-        value, pc, chunks, _ = pl.range_checks(log)
-        v, p, c = value.cpu().numpy().view(np.uint64), pc.cpu().numpy().view(np.uint64), chunks.cpu().numpy().view(np.uint16).T
+        if self._r:
+            w = self.range_check_witness()
+            n = w.n_checks
+            v, p = self._d2h(w.value, n, "<u8"), self._d2h(w.pc, n, "<u8")
+            c = self._d2h(w.chunks, 4 * w.chunk_stride, "<u2").reshape(4, -1)[:, :n].T
+        else:                                   # run without an execution trace: no device handle; expand through the layer-2 launch
+            from . import pipeline as pl
+            value, pc, chunks, _ = pl.range_checks(log)
+            v, p, c = value.cpu().numpy().view(np.uint64), pc.cpu().numpy().view(np.uint64), chunks.cpu().numpy().view(np.uint16).T
         offs = log.rc_offsets
         return [[(int(v[i]), [int(x) for x in c[i]], int(p[i])) for i in range(int(offs[k]), int(offs[k + 1]))] for k in range(len(offs) - 1)]
 
     @property
     def normalization_witnesses(self) -> np.ndarray:
         """Vec<NormalizationEvent> (normalization_witness.rs:129-138) as packed records."""
-        from . import pipeline as pl
         if len(self._log.norm_events) == 0:
             return np.zeros(0, dtype=_NORM_DTYPE)
-        return pl.normalization_events(self._log)
+        if not self._r:
+            from . import pipeline as pl
+            return pl.normalization_events(self._log)
+        w = NormalizationWitnessC()
+        rc = lib().zkir_result_normalization_witnesses(self._r, C.byref(w))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        n, c = w.n_events, w.columns
+        out = np.zeros(n, dtype=_NORM_DTYPE)
+        out["cycle"] = self._d2h(c.cycle, n, "<u8"); out["pc"] = self._d2h(c.pc, n, "<u8")
+        out["reg"] = self._d2h(c.reg, n, "u1"); out["opcode"] = self._d2h(c.opcode, n, "u1")
+        out["accumulated"][:, 0] = self._d2h(c.accumulated0, n, "<u8"); out["accumulated"][:, 1] = self._d2h(c.accumulated1, n, "<u8")
+        out["normalized"][:, 0] = self._d2h(c.normalized0, n, "<u4"); out["normalized"][:, 1] = self._d2h(c.normalized1, n, "<u4")
+        out["carries"][:, 0] = self._d2h(c.carry0, n, "<u4"); out["carries"][:, 1] = self._d2h(c.carry1, n, "<u4")
+        out["normalized_bits"] = 20; out["limb_bits"] = 30; out["cause"] = 0
+        return out
+
+    def sha256_witnesses(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Sha256Witness columns of every single-block SHA-256 syscall: (uint32[608][n_blocks], timestamps[n_blocks])."""
+        if not self._r:
+            return np.zeros((608, 0), dtype=np.uint32), np.zeros(0, dtype=np.uint64)
+        w = Sha256WitnessC()
+        rc = lib().zkir_result_sha256_witnesses(self._r, C.byref(w))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        cols = self._d2h(w.columns, 608 * w.stride, "<u4").reshape(608, -1)[:, :w.n_blocks]
+        return cols, self._d2h(w.timestamps, w.n_blocks, "<u8")
 
     def close(self):
         if self._r:
