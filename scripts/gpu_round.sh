@@ -17,7 +17,7 @@ with open(sys.argv[2], "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats: kernel, calls, total us, average us, share\n")
     for name, calls, total, avg, pct in rows:
         s = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:80]
-        f.write(f"{s:80s} {calls:6d} {total/1e3:12.1f} us {avg/1e3:10.2f} us {pct:6.2f}%\n")
+        f.write(f"{s:80s} {calls:6d} {total:12.1f} us {avg:10.2f} us {pct:6.2f}%\n")
 print(open(sys.argv[2]).read())
 PY
 }
