@@ -91,12 +91,12 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
     n = 1 << k
     kernels = {"trace_fill": {"bound": "hbm", "bytes": fill_bytes, "ms": stage_ms["trace_fill"]}}
     if "merkle" in stage_ms:
-        #   main_trace: reads the 372 B/row trace once (+ the next-row re-read served by L2), writes W u32 columns
+        #   main_trace: reads the value / state / cycle / pc / instruction columns (164 B/row; the next-row re-read is served by L2), writes W u32 columns
         #   lde: per column `n_inv` strided inverse passes (8 B/elem over N; one radix-4 pass covers up to ten
         #        stages) + fused middle (4N read + 8N written) + as many strided forward passes (8 B/elem over 2N)
         #   merkle: reads the LDE matrix once, writes 16 B per node; ALU-bound (Poseidon2), bytes given for completeness
         n_inv = _strided_passes(max(k - 10, 0))
-        kernels["main_trace"] = {"bound": "hbm", "bytes": (372 + 4 * W) * n, "ms": stage_ms["main_trace"]}
+        kernels["main_trace"] = {"bound": "hbm", "bytes": (164 + 4 * W) * n, "ms": stage_ms["main_trace"]}
         kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
         perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
         modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
@@ -128,7 +128,7 @@ def _config2_fib_2p24(lib, sp):
     L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
     tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
     stages = [("trace_fill", lambda: pl.trace_fill(fa)),
-              ("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, m.data_ptr(), sp()))),
+              ("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, 0, m.data_ptr(), sp()))),
               ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
               ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
     for _, f in stages:
@@ -141,16 +141,21 @@ def _config2_fib_2p24(lib, sp):
     del m, L, tree
     torch.cuda.empty_cache()
     prove_ms, pms, proof = None, None, None
+    pub = rt.public_inputs(log, blob)
     for _ in range(2):                                # first call allocates the context's workspace
         t0 = time.perf_counter()
-        proof, pms = stark.prove(ctx, trace, want_stage_ms=True)
+        proof, pms = stark.prove(ctx, trace, pub, want_stage_ms=True)
         prove_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    verdict = rt.verify(proof, pub)
+    verify_ms = (time.perf_counter() - t0) * 1e3
+    assert verdict == 0, f"bench: the 2^24-row proof was rejected (check {verdict})"
     step_ms = sum(stage_ms.values())
     out = {"workload": "fib_endless 2^24 cycles, 1 GPU: trace fill + main trace + LDE + Poseidon2 Merkle (commit step), then the full proof "
                        "(AIR quotient, openings, DEEP, FRI, queries)",
            "rows": n, "commit_step_ms": step_ms, "commit_rows_per_s": n / (step_ms * 1e-3), "stage_ms": stage_ms, "roofline_by_stage": kernels,
            "prove_ms": prove_ms, "prove_stage_ms": dict(zip(PROVE_STAGES, pms)), "prove_rows_per_s": n / (prove_ms * 1e-3),
-           "proof_bytes": int(len(proof) * 4), "merkle_root": root, "proof_trace_root_matches_commit": proof[6:10].tolist() == root,
+           "proof_bytes": int(len(proof) * 4), "verify_ms_host": verify_ms, "merkle_root": root, "proof_trace_root_matches_commit": proof[21:25].tolist() == root,
            "host_interpret_s": host_s, "hbm_resident_GB": (372 * n + (12 * W + 440) * n) / 1e9}
     ctx.close(); log.close()
     del trace, ddl
@@ -224,7 +229,7 @@ def _cpu_baseline(blob, k, commit):
         kc = 16
         rows = oracle.run(blob, max_cycles=1 << kc, enable_execution_trace=True).rows
         t0 = time.perf_counter()
-        so.commit_trace(rows, 1)
+        so.commit_trace(rows, 1, pub=so.public_inputs(len(rows), blob))
         dtc = time.perf_counter() - t0
         out["commit_stage_self_defined"] = {"rows": 1 << kc, "seconds": dtc, "rows_per_s": (1 << kc) / dtc, "cores": 1,
                                             "what": "oracle/stark_oracle.cpp main trace + LDE + Poseidon2 Merkle (naive %-arithmetic; stages absent from "
@@ -317,7 +322,7 @@ def main():
 
     stages = [("trace_fill", lambda: pl.trace_fill(fill_args))]
     if commit:
-        stages += [("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, m.data_ptr(), sp()))),
+        stages += [("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, 0, m.data_ptr(), sp()))),
                    ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
                    ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
 
@@ -392,14 +397,18 @@ def main():
     del src, dst
 
     # ---- end-to-end prove (BASELINE metric's "end-to-end prove ms"): AIR quotient + openings + DEEP + FRI on top of the commit ----
-    prove_ms, prove_stage_ms, proof_bytes = None, None, None
+    prove_ms, prove_stage_ms, proof_bytes, verify_ms = None, None, None, None
     if commit and world == 1 and not args.no_prove:   # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
+        pub = rt.public_inputs(log, blob)
         for _ in range(3):                            # first call allocates the context's workspace
             t0 = time.perf_counter()
-            proof, pms = stark.prove(ctx, trace, want_stage_ms=True)
+            proof, pms = stark.prove(ctx, trace, pub, want_stage_ms=True)
             prove_ms = (time.perf_counter() - t0) * 1e3
         prove_stage_ms = dict(zip(PROVE_STAGES, pms))
         proof_bytes = int(len(proof) * 4)
+        t0 = time.perf_counter()
+        assert rt.verify(proof, pub) == 0, "bench: proof rejected by zkir_verify"
+        verify_ms = (time.perf_counter() - t0) * 1e3
 
     # ---- the drop-in entry point itself: zkir_exec = host interpretation + H2D + K1 in one call (VM::new + VM::run, trace left in HBM)
     exec_s = None
@@ -489,7 +498,8 @@ def main():
             "by_config": by_config,
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
-            "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes,
+            "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
+            "prover": "ZKIR-STARK v1 (self-defined; AIR of 152 columns / 259 constraints, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12)",
             "pipelined_end_to_end": pipelined,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,

@@ -239,19 +239,24 @@ int zkir_norm_expand_launch(const zkir_norm_event* events, uint64_t n, const zki
  * timestamps[n] optional. */
 int zkir_sha256_chip_launch(const zkir_sha_block* blocks, uint64_t n, uint32_t* out, uint64_t stride, uint64_t* timestamps, void* hip_stream);
 
-/* ---- prover stages over Baby Bear (stark.hip) ----------------------------------------------------
+/* ---- prover stages over Baby Bear (stark.hip, ntt.hip, verify.cpp) ---------------------------------
  * NOT in the reference (no prove(), no Plonky3: Cargo.toml:67-69) => self-defined
- * ("ZKIR-STARK v0"), parity unpinned; spec = oracle/stark_oracle.cpp.  Field elements are canonical
- * u32 (< p = 2^31 - 2^27 + 1) at rest; matrices are column-major [width][n]. */
-typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, coset powers, Poseidon2 constants) for 2^log_n rows */
+ * ("ZKIR-STARK v1"), parity unpinned; spec = oracle/stark_oracle.cpp, frozen by tests/golden/stark_goldens.json.
+ * Field elements are canonical u32 (< p = 2^31 - 2^27 + 1) at rest; matrices are column-major [width][n].
+ * Demonstrator parameters: blow-up 2, 50 FRI queries + 12 bits of grinding (~62 bits, conjectured), Poseidon2 width 12 with
+ * capacity 4 (~62-bit collisions).  What the AIR does and does not constrain is stated in zkir_amd/csrc/air.h. */
+typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, coset powers, Poseidon2 constants) + workspace for 2^log_n rows.
+                                                     One proof at a time per context; different contexts are independent (no process-wide state). */
 int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup /* must be 1 */, zkir_stark_ctx** out);
 void zkir_stark_ctx_free(zkir_stark_ctx* ctx);
-uint32_t zkir_main_trace_width(void);             /* 89 */
+uint32_t zkir_main_trace_width(void);             /* 152 */
+uint32_t zkir_padded_log_n(uint64_t n_real);      /* log2 of the padded trace length: max(3, ceil(log2(n_real))) */
 /* diagnostic: measured peak rate (per second) of independent Montgomery multiplications on the current device — the integer-ALU
  * roofline the Poseidon2 kernels are priced against (they are ALU-bound, not HBM- or MFMA-bound) */
 double zkir_modmul_peak_per_s(void* hip_stream);
-/* trace columns (K1 output) -> main trace matrix out[89][n_rows] */
-int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_rows, uint32_t* out, void* hip_stream);
+/* trace columns (K1 output, n_real executed rows) -> main trace matrix out[152][N], N = 2^zkir_padded_log_n(n_real): rows past n_real are
+ * padding (class "pad": state of the last executed row, cycle keeps counting).  deferred = VMConfig.enable_deferred_model of the run. */
+int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* hip_stream);
 /* per-column low-degree extension: in[width][N] (evaluations over <w_N>, natural order; CLOBBERED as scratch when N > 1024)
  * -> out[width][2N] = evaluations over the coset 31*<w_2N>, natural order */
 int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);
@@ -263,14 +268,33 @@ int zkir_merkle_commit_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, ui
  * shards, in rank order — and the call appends the log2(n) upper levels; root = last 4 words of the 4*(2n-1)-word buffer. */
 int zkir_merkle_cap_launch(const zkir_stark_ctx* ctx, uint32_t* tree, uint64_t n_digests, void* hip_stream);
 
-/* Full proof (execution-trace AIR of DESIGN.md §8.4: cycle counter, R0 = 0, boolean flags, untouched registers keep their
- * limbs/state), blow-up 2, 24 FRI queries, final codeword of 8.  `trace` = K1 output for n_rows = 2^log_n rows.  *proof_out is a
- * malloc'ed array of u32 words (little-endian canonical field elements; layout in oracle/stark_oracle.cpp so::prove), released
- * with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries. */
-int zkir_prove(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint64_t n_rows, uint32_t** proof_out, uint64_t* proof_words,
+/* Public inputs of a proof: absorbed by the Fiat-Shamir transcript before the first commitment and carried in the proof header. */
+typedef struct zkir_public_inputs {
+  uint64_t n_real;             /* executed rows = ExecutionResult.cycles */
+  uint64_t entry_point;        /* ProgramHeader.entry_point: pc of row 0 (constrained) */
+  uint32_t deferred;           /* VMConfig.enable_deferred_model (the opcode semantics of the AIR are the default mode's) */
+  uint32_t reserved;
+  uint32_t program_digest[4];  /* zkir_digest_bytes(program blob) */
+  uint32_t io_digest[4];       /* zkir_digest_bytes(LE u64 words [n_inputs, inputs.., n_outputs, outputs.., halt kind, halt code, cycles]) */
+} zkir_public_inputs;
+/* Poseidon2 sponge digest of a byte string (host): [len as four 16-bit pieces] ++ [LE 16-bit halfwords] */
+void zkir_digest_bytes(const uint8_t* bytes, size_t len, uint32_t out[4]);
+/* the public inputs of a finished run (host; `log` is the unsharded delta log of the run) */
+int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
+                          uint32_t deferred, zkir_public_inputs* out);
+
+/* Full proof of the execution whose K1 output is `trace` (pub->n_real rows; ctx built for zkir_padded_log_n(pub->n_real)).  *proof_out is a
+ * malloc'ed array of u32 words (little-endian canonical field elements, format v3: layout in oracle/stark_oracle.cpp so::prove),
+ * released with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries. */
+int zkir_prove(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, const zkir_public_inputs* pub, uint32_t** proof_out, uint64_t* proof_words,
                float* stage_ms, void* hip_stream);
 void zkir_proof_free(uint32_t* proof);
 uint32_t zkir_proof_num_queries(void);
+uint32_t zkir_proof_version(void);
+/* Verifier (host only, no device): 0 = accepted, otherwise the number of the failed check (1-5 malformed, 6 public inputs differ
+ * from `expect`, 10 constraints at zeta, 11 final codeword degree, 12 grinding, 20-26 query / Merkle / FRI checks, 30 length).
+ * expect may be NULL: the header's own public inputs are then only checked for internal consistency. */
+int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect);
 /* Host-side Poseidon2-12 permutation of the transcript (canonical words in and out; no device needed): what a verifier or an
  * integrator re-deriving the Fiat-Shamir challenges calls.  Same code as the device kernels (poseidon2.h), compiled for the host. */
 void zkir_poseidon2_permute(uint32_t state[12]);

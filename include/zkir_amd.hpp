@@ -327,16 +327,28 @@ class StarkContext {                                            // device tables
   uint32_t log_n_;
 };
 
-// Full proof (u32 little-endian words, format v2) of a run whose execution trace has exactly 2^log_n rows and is resident in HBM.
-inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::ExecutionResult& result, void* hip_stream = nullptr) {
+// Public inputs of a proof of `result` (row count, mode, entry pc, program digest, io digest)
+inline zkir_public_inputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,
+                                        const zkir_runtime::VMConfig& config = {}) {
+  zkir_public_inputs pub;
+  const std::vector<uint8_t> blob = program.to_bytes();
+  const int rc = zkir_public_inputs_of(result.delta_log(), blob.data(), blob.size(), inputs.data(), inputs.size(), config.enable_deferred_model ? 1u : 0u, &pub);
+  if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc);
+  return pub;
+}
+
+// Full proof (u32 little-endian words, format v3) of a run whose execution trace is resident in HBM; the context must be built for
+// zkir_padded_log_n(rows).  zkir_prover::verify is the host-side check (0 = accepted).
+inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::ExecutionResult& result, const zkir_public_inputs& pub, void* hip_stream = nullptr) {
   uint32_t* words = nullptr;
   uint64_t n = 0;
-  const int rc = zkir_prove(ctx.handle(), result.execution_trace.device_columns(), result.execution_trace.len(), &words, &n, nullptr, hip_stream);
+  const int rc = zkir_prove(ctx.handle(), result.execution_trace.device_columns(), &pub, &words, &n, nullptr, hip_stream);
   if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc);
   std::vector<uint32_t> out(words, words + n);
   zkir_proof_free(words);
   return out;
 }
+inline int verify(const std::vector<uint32_t>& proof, const zkir_public_inputs* expect = nullptr) { return zkir_verify(proof.data(), proof.size(), expect); }
 
 }  // namespace zkir_prover
 

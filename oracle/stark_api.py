@@ -8,7 +8,7 @@ import numpy as np
 from . import api
 
 P = 2013265921
-W_MAIN = 89
+W_MAIN = 152
 _bound = False
 
 
@@ -21,19 +21,57 @@ def lib():
         L.so_fmul.restype = U32; L.so_fmul.argtypes = [U32, U32]
         L.so_finv.restype = U32; L.so_finv.argtypes = [U32]
         L.so_root_of_unity.restype = U32; L.so_root_of_unity.argtypes = [I]
+        PP = C.POINTER(PublicC)
         for name, args in [("so_emul", [V, V, V]), ("so_einv", [V, V]), ("so_poseidon2_permute", [V]), ("so_poseidon2_constants", [V, V, V]),
-                           ("so_hash_elems", [V, SZ, V]), ("so_compress", [V, V, V]), ("so_ntt", [V, SZ, I]), ("so_lde", [V, SZ, I, V, V]),
-                           ("so_main_trace", [V, SZ, V]), ("so_merkle", [V, I, SZ, V, V]), ("so_commit_trace", [V, SZ, I, V, V])]:
+                           ("so_hash_elems", [V, SZ, V]), ("so_compress", [V, V, V]), ("so_digest_bytes", [V, SZ, V]), ("so_ntt", [V, SZ, I]),
+                           ("so_lde", [V, SZ, I, V, V]), ("so_main_trace", [V, PP, V]), ("so_merkle", [V, I, SZ, V, V]),
+                           ("so_commit_trace", [V, PP, I, V, V])]:
             f = getattr(L, name); f.restype = None; f.argtypes = args
         L.so_main_trace_width.restype = I
-        L.so_prove.restype = SZ; L.so_prove.argtypes = [V, SZ, V, SZ]
-        L.so_verify.restype = I; L.so_verify.argtypes = [V, SZ]
+        L.so_padded_log_n.restype = I; L.so_padded_log_n.argtypes = [C.c_uint64]
+        L.so_num_constraints.restype = I
+        L.so_constraints_eval.restype = I; L.so_constraints_eval.argtypes = [V, V, U32, U32, U32, PP, V, V]
+        L.so_prove.restype = SZ; L.so_prove.argtypes = [V, PP, V, SZ]
+        L.so_prove_matrix.restype = SZ; L.so_prove_matrix.argtypes = [V, PP, V, SZ]
+        L.so_verify.restype = I; L.so_verify.argtypes = [V, SZ, PP]
+        L.so_pow_bits.restype = I; L.so_header_words.restype = I
         L.so_last_challenges.restype = None; L.so_last_challenges.argtypes = [V, V, V]
         L.so_last_quotient.restype = None; L.so_last_quotient.argtypes = [V]
         L.so_last_fri_layer.restype = SZ; L.so_last_fri_layer.argtypes = [I, V]
         L.so_num_queries.restype = I; L.so_log_final.restype = I
         _bound = True
     return L
+
+
+class PublicC(C.Structure):
+    """so_public: the public inputs of a proof (observed first by the transcript, carried in the proof header)."""
+    _fields_ = [("n_real", C.c_uint64), ("deferred", C.c_uint32), ("pad", C.c_uint32), ("entry", C.c_uint64), ("prog", C.c_uint32 * 4), ("io", C.c_uint32 * 4)]
+
+
+def digest_bytes(b: bytes) -> np.ndarray:
+    o = np.zeros(4, np.uint32)
+    lib().so_digest_bytes(bytes(b), len(b), o.ctypes.data)
+    return o
+
+
+def io_bytes(inputs, outputs, halt_kind: int, halt_code: int, cycles: int) -> bytes:
+    """What the io digest covers: little-endian u64 words [n_inputs, inputs.., n_outputs, outputs.., halt kind, halt code, cycles]."""
+    words = [len(inputs), *inputs, len(outputs), *outputs, halt_kind, halt_code, cycles]
+    return np.array([int(x) & (2**64 - 1) for x in words], dtype="<u8").tobytes()
+
+
+def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2, 0), deferred: bool = False, entry: int | None = None) -> PublicC:
+    """Public inputs of a run: halt = (kind, code) with kind 0 Ebreak / 1 Exit / 2 CycleLimit; entry defaults to the blob header's."""
+    if entry is None:
+        entry = int.from_bytes(blob[12:16], "little") if len(blob) >= 16 else 0x1000
+    p = PublicC(n_real, int(deferred), 0, entry)
+    p.prog[:] = [int(x) for x in digest_bytes(blob)]
+    p.io[:] = [int(x) for x in digest_bytes(io_bytes(list(inputs), list(outputs), halt[0], halt[1], n_real))]
+    return p
+
+
+def padded_log_n(n_real: int) -> int:
+    return lib().so_padded_log_n(n_real)
 
 
 def _u32(a):
@@ -89,12 +127,24 @@ def lde(evals, log_blowup=1):
     return coeffs, out
 
 
-def main_trace(rows: np.ndarray) -> np.ndarray:
-    """Packed reference rows (api.ROW_DTYPE) -> Baby Bear matrix [W_MAIN][n]."""
+def _pub(rows, pub):
+    return pub if pub is not None else public_inputs(len(rows))
+
+
+def main_trace(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
+    """Packed reference rows (api.ROW_DTYPE) -> Baby Bear matrix [W_MAIN][N], N = the padded power of two."""
     rows = np.ascontiguousarray(rows)
-    out = np.zeros((W_MAIN, len(rows)), np.uint32)
-    lib().so_main_trace(rows.ctypes.data, len(rows), out.ctypes.data)
+    pub = _pub(rows, pub)
+    out = np.zeros((W_MAIN, 1 << padded_log_n(pub.n_real)), np.uint32)
+    lib().so_main_trace(rows.ctypes.data, C.byref(pub), out.ctypes.data)
     return out
+
+
+def constraints_eval(loc, nxt, is_first, is_last, is_trans, pub: PublicC, alpha) -> np.ndarray:
+    """Σ alpha^c C_c(loc, nxt) for base-field rows and the given selector values (E4 result)."""
+    loc, nxt, alpha, o = _u32(loc), _u32(nxt), _u32(alpha), np.zeros(4, np.uint32)
+    lib().so_constraints_eval(loc.ctypes.data, nxt.ctypes.data, int(is_first), int(is_last), int(is_trans), C.byref(pub), alpha.ctypes.data, o.ctypes.data)
+    return o
 
 
 def merkle(mat: np.ndarray, want_layers=False):
@@ -106,31 +156,42 @@ def merkle(mat: np.ndarray, want_layers=False):
     return (root, layers) if want_layers else root
 
 
-def commit_trace(rows: np.ndarray, log_blowup=1, want_lde=False):
+def commit_trace(rows: np.ndarray, log_blowup=1, want_lde=False, pub: PublicC | None = None):
     rows = np.ascontiguousarray(rows)
-    n = len(rows)
+    pub = _pub(rows, pub)
+    n = 1 << padded_log_n(pub.n_real)
     root = np.zeros(4, np.uint32)
     L = np.zeros((W_MAIN, n << log_blowup), np.uint32) if want_lde else None
-    lib().so_commit_trace(rows.ctypes.data, n, log_blowup, root.ctypes.data, L.ctypes.data if want_lde else None)
+    lib().so_commit_trace(rows.ctypes.data, C.byref(pub), log_blowup, root.ctypes.data, L.ctypes.data if want_lde else None)
     return (root, L) if want_lde else root
 
 
 # ---- stage B: prover + verifier ------------------------------------------------------------------
-def prove(rows: np.ndarray) -> np.ndarray:
-    """Full ZKIR-STARK v0 proof (u32 words) for a power-of-two number of packed reference rows."""
+def prove(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
+    """Full ZKIR-STARK v1 proof (u32 words) of the executed rows (any count >= 1; padded to a power of two >= 8)."""
     rows = np.ascontiguousarray(rows)
-    n = len(rows)
-    assert n & (n - 1) == 0 and n >= 8
-    size = lib().so_prove(rows.ctypes.data, n, None, 0)
+    pub = _pub(rows, pub)
+    assert pub.n_real == len(rows) >= 1
+    size = lib().so_prove(rows.ctypes.data, C.byref(pub), None, 0)
     out = np.zeros(size, np.uint32)
-    lib().so_prove(rows.ctypes.data, n, out.ctypes.data, size)
+    lib().so_prove(rows.ctypes.data, C.byref(pub), out.ctypes.data, size)
     return out
 
 
-def verify(proof: np.ndarray) -> int:
-    """0 = accepted; otherwise the code of the first failed check."""
+def prove_matrix(matrix: np.ndarray, pub: PublicC) -> np.ndarray:
+    """Proof of a GIVEN main-trace matrix [W_MAIN][N] (tests: what a cheating prover would submit)."""
+    m = _u32(matrix)
+    assert m.shape == (W_MAIN, 1 << padded_log_n(pub.n_real))
+    size = lib().so_prove_matrix(m.ctypes.data, C.byref(pub), None, 0)
+    out = np.zeros(size, np.uint32)
+    lib().so_prove_matrix(m.ctypes.data, C.byref(pub), out.ctypes.data, size)
+    return out
+
+
+def verify(proof: np.ndarray, expect: PublicC | None = None) -> int:
+    """0 = accepted; otherwise the code of the first failed check (6: the header's public inputs are not the expected ones)."""
     proof = _u32(proof)
-    return lib().so_verify(proof.ctypes.data, len(proof))
+    return lib().so_verify(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None)
 
 
 def last_challenges():

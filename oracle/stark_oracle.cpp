@@ -2,13 +2,14 @@
 //
 // PARITY UNPINNED.  The reference (seceq/zkir) contains no prover: no AIR, NTT/LDE, Merkle tree, FRI or
 // proof format, and its Plonky3 dependency is commented out with no rev (Cargo.toml:67-69).
-// Everything in this file is therefore defined by THIS repository ("ZKIR-STARK v0") following
+// Everything in this file is therefore defined by THIS repository ("ZKIR-STARK v1") following
 // BASELINE.json:north_star literally (Baby Bear, radix-2 NTT/LDE, Poseidon2 width 12, FRI), and is pinned only by
 // algebraic self-checks (tests/test_stark_oracle.py: inverse-NTT round trips, naive DFT, Merkle path checks, a full
 // verifier).  The GPU implementation (zkir_amd/csrc/stark.hip) is checked bit-for-bit against this file.
 //
 // Arithmetic here is deliberately the naive canonical form (u64 products reduced with %), independent of the
 // Montgomery arithmetic used on the device.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -149,43 +150,135 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
   ntt(out, false);
 }
 
+
 // ---------------------------------------------------------------------------------------------
-// main trace matrix: packed 372-byte reference rows -> W = 89 Baby Bear columns
+// main trace matrix of ZKIR-STARK v1: packed 372-byte reference rows -> W = 152 Baby Bear columns, padded to a
+// power of two.  Column map:
+//   0 cycle | 1-3 pc limbs (20/20/24 bits) | 4 op7 | 5 fa (bits 10:7) | 6 fb (14:11) | 7 fc (18:15) | 8 fhi (31:19)
+//   9+3r+l register limbs (20-bit limbs when Normalized, 30-bit when Accumulated; l = 2: the bits above) | 57+r storage state
+//   73+(r-1)  wr[r], r = 1..15: the row's instruction writes register r
+//   88+(r-1)  selb[r]: one-hot of field b          103+(r-1) selc[r]: one-hot of field c (of field a on BNE rows: rs1 sits there)
+//   118-120 xb = limbs of reg[fb]   121-123 xc = limbs of reg[fc | fa]   124-126 y = limbs of the value written to rd
+//   127-133 class one-hot: add, addi, bne, jal, oth (any other executed instruction), halt (last executed row), pad
+//   134-138 decode chain t1 = op(op-8), t2 = (op-0x41)(op-0x48), t3 = t1 t2, inv = 1/t3, t5 = t3 inv (proves op is none of the four)
+//   139 s = bit 31 of the word (sign of imm17 / off21) | 140 se = (tk + k_jal) s
+//   141-142 c0 c1 carries of the value addition | 143-145 d0 d1 d2 carries of pc + delta | 146 dl0 = low limb of the pc increment
+//   147 ne = [xb != xc] | 148-150 iv: inverse witness of the first differing limb | 151 tk = branch taken
 // ---------------------------------------------------------------------------------------------
-static const int W_MAIN = 89;
+static const int W_MAIN = 152;
+enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
+       C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_T = 134, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
+       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151 };
+enum { K_ADD = 0, K_ADDI = 1, K_BNE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6 };
+static const uint32_t OP_ADD = 0x00, OP_ADDI = 0x08, OP_BNE = 0x41, OP_JAL = 0x48;
+
 #pragma pack(push, 1)
 struct PackedRow { uint64_t cycle, pc; uint32_t instruction; uint64_t registers[16]; uint32_t bound_bits[16]; uint8_t bound_tag[16]; uint64_t bound_payload[16]; uint8_t reg_state[16]; };
 #pragma pack(pop)
-// col-major out[W_MAIN][n]; `changed[r]` of row i = 1 iff the triple (value, bound, state) of register r differs... no:
-// iff an instruction at row i wrote register r.  The oracle derives it from consecutive rows of the FULL triple, which is
-// what a write does unless it rewrites identical contents; the product derives it from its event log.  To keep the two
-// definitions identical the flag is defined on contents: changed_r[i] = [triple_r(row i+1) != triple_r(row i)], and 0 for the last row.
-static void main_trace(const PackedRow* rows, size_t n, std::vector<F>& out) {
-  out.assign((size_t)W_MAIN * n, 0);
-  auto col = [&](int k) { return out.data() + (size_t)k * n; };
-  for (size_t i = 0; i < n; i++) {
-    const PackedRow& r = rows[i];
-    col(0)[i] = (F)(r.cycle % P);
-    col(1)[i] = (F)(r.pc & 0xFFFFF); col(2)[i] = (F)((r.pc >> 20) & 0xFFFFF); col(3)[i] = (F)(r.pc >> 40);
-    uint32_t w = r.instruction;
-    col(4)[i] = w & 0x7F; col(5)[i] = (w >> 7) & 0xF; col(6)[i] = (w >> 11) & 0xF; col(7)[i] = (w >> 15) & 0xF; col(8)[i] = w >> 19;
+
+// Public inputs of a proof: observed by the transcript first and carried in the proof header.
+struct Public {
+  uint64_t n_real = 0;       // executed rows (ExecutionResult.cycles); the trace is padded to N = max(8, next power of two)
+  uint32_t deferred = 0;     // VMConfig.enable_deferred_model: the opcode semantics of the AIR are those of the default mode only
+  uint64_t entry = 0x1000;   // header.entry_point: pc of row 0
+  F prog[4] = {0, 0, 0, 0};  // digest of the program blob
+  F io[4] = {0, 0, 0, 0};    // digest of (inputs, outputs, halt reason, cycles)
+};
+static int padded_log_n(uint64_t n_real) { int k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
+
+// digest of a byte string: Poseidon2 sponge over [len as four 16-bit pieces] ++ [little-endian 16-bit halfwords, zero-padded]
+static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
+  std::vector<F> e;
+  for (int i = 0; i < 4; i++) e.push_back((F)(((uint64_t)n >> (16 * i)) & 0xFFFF));
+  for (size_t i = 0; i < n; i += 2) e.push_back((F)b[i] | (i + 1 < n ? (F)b[i + 1] << 8 : 0));
+  hash_elems(e.data(), e.size(), out);
+}
+
+static inline void reg_limbs(uint64_t v, uint8_t st, F out[3]) {
+  const int bits = st ? 30 : 20;
+  const uint64_t mask = (1ull << bits) - 1;
+  out[0] = (F)(v & mask); out[1] = (F)((v >> bits) & mask); out[2] = (F)(v >> (2 * bits));
+}
+
+// col-major out[W_MAIN][N]
+static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out) {
+  const int log_n = padded_log_n(n_real);
+  const size_t N = (size_t)1 << log_n;
+  out.assign((size_t)W_MAIN * N, 0);
+  auto col = [&](int k) { return out.data() + (size_t)k * N; };
+  const bool D = pub.deferred != 0;
+  for (size_t i = 0; i < N; i++) {
+    const bool pad = i >= n_real;
+    const PackedRow& r = rows[pad ? n_real - 1 : i];
+    const bool last = i + 1 >= n_real;                      // the last executed row and every padding row: no successor to describe
+    col(C_CYCLE)[i] = (F)((pad ? (uint64_t)i : r.cycle) % P);
+    const F pc[3] = {(F)(r.pc & 0xFFFFF), (F)((r.pc >> 20) & 0xFFFFF), (F)(r.pc >> 40)};
+    for (int l = 0; l < 3; l++) col(C_PC + l)[i] = pc[l];
+    const uint32_t w = r.instruction;
+    const F op = w & 0x7F, fa = (w >> 7) & 0xF, fb = (w >> 11) & 0xF, fc = (w >> 15) & 0xF, fhi = w >> 19, s = w >> 31;
+    col(C_OP)[i] = op; col(C_FA)[i] = fa; col(C_FB)[i] = fb; col(C_FC)[i] = fc; col(C_FHI)[i] = fhi; col(C_S)[i] = s;
+    F limb[16][3];
     for (int g = 0; g < 16; g++) {
-      uint64_t v = r.registers[g];
-      int bits = r.reg_state[g] ? 30 : 20;
-      uint64_t mask = (1ull << bits) - 1;
-      col(9 + 3 * g)[i] = (F)(v & mask); col(10 + 3 * g)[i] = (F)((v >> bits) & mask); col(11 + 3 * g)[i] = (F)(v >> (2 * bits));
-      col(57 + g)[i] = r.reg_state[g];
-      bool ch = false;
-      if (i + 1 < n) {
-        const PackedRow& q = rows[i + 1];
-        ch = q.registers[g] != v || q.reg_state[g] != r.reg_state[g] || q.bound_bits[g] != r.bound_bits[g] || q.bound_tag[g] != r.bound_tag[g] ||
-             q.bound_payload[g] != r.bound_payload[g];
+      reg_limbs(r.registers[g], r.reg_state[g], limb[g]);
+      for (int l = 0; l < 3; l++) col(C_LIMB + 3 * g + l)[i] = limb[g][l];
+      col(C_STATE + g)[i] = r.reg_state[g];
+    }
+    int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
+    if (cls == K_OTH && !D) cls = op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : op == OP_BNE ? K_BNE : op == OP_JAL ? K_JAL : K_OTH;
+    col(C_K + cls)[i] = 1;
+    const F t1 = fmul(op, fsub(op, 8)), t2 = fmul(fsub(op, OP_BNE), fsub(op, OP_JAL)), t3 = fmul(t1, t2), inv = t3 ? finv(t3) : 0;
+    col(C_T)[i] = t1; col(C_T + 1)[i] = t2; col(C_T + 2)[i] = t3; col(C_T + 3)[i] = inv; col(C_T + 4)[i] = fmul(t3, inv);
+    const uint32_t tc = cls == K_BNE ? fa : fc;             // second operand: rs2 = field c, but BNE has rs1 in field a (rs2 in field b)
+    if (fb) col(C_SELB + fb - 1)[i] = 1;
+    if (tc) col(C_SELC + tc - 1)[i] = 1;
+    const F* xb = limb[fb]; const F* xc = limb[tc];         // register 0 reads as zero limbs: its columns are constrained to zero
+    for (int l = 0; l < 3; l++) { col(C_XB + l)[i] = xb[l]; col(C_XC + l)[i] = xc[l]; }
+    F ne = 0;
+    for (int l = 0; l < 3; l++) if (!ne && xb[l] != xc[l]) { ne = 1; col(C_IV + l)[i] = finv(fsub(xb[l], xc[l])); }
+    col(C_NE)[i] = ne;
+    const F tk = cls == K_BNE ? ne : 0;
+    col(C_TK)[i] = tk;
+    const F imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFF;        // sign-extended imm17 mod 2^40, as two 20-bit limbs
+    const F lo20 = fb + 16 * fc + 256 * fhi - (s << 20);                                           // low 20 bits of off21
+    const F dl0 = cls == K_JAL ? lo20 : tk ? im0 : 4;
+    col(C_DL0)[i] = dl0;
+    const F se = (tk || cls == K_JAL) ? s : 0;
+    col(C_SE)[i] = se;
+    F y[3] = {0, 0, 0}, c0 = 0, c1 = 0;
+    int rd = -1;
+    if (cls == K_ADD || cls == K_ADDI) {
+      const F b0 = cls == K_ADD ? xc[0] : im0, b1 = cls == K_ADD ? xc[1] : im1;
+      const uint64_t v0 = (uint64_t)xb[0] + b0; c0 = (F)(v0 >> 20); y[0] = (F)(v0 & 0xFFFFF);
+      const uint64_t v1 = (uint64_t)xb[1] + b1 + c0; c1 = (F)(v1 >> 20); y[1] = (F)(v1 & 0xFFFFF);
+      rd = fa;
+    } else if (cls == K_JAL) {
+      const uint64_t v0 = (uint64_t)pc[0] + 4; c0 = (F)(v0 >> 20); y[0] = (F)(v0 & 0xFFFFF);
+      const uint64_t v1 = (uint64_t)pc[1] + c0; c1 = (F)(v1 >> 20); y[1] = (F)(v1 & 0xFFFFF);
+      y[2] = pc[2] + c1;
+      rd = fa;
+    }
+    if (rd > 0) col(C_WR + rd - 1)[i] = 1;
+    if (cls == K_OTH) {                                     // any other instruction: what it wrote is read off the next row
+      const PackedRow& q = rows[i + 1];
+      bool first = true;
+      for (int g = 1; g < 16; g++) {
+        F nl[3]; reg_limbs(q.registers[g], q.reg_state[g], nl);
+        if (nl[0] != limb[g][0] || nl[1] != limb[g][1] || nl[2] != limb[g][2] || q.reg_state[g] != r.reg_state[g]) {
+          col(C_WR + g - 1)[i] = 1;
+          if (first && !D) { y[0] = nl[0]; y[1] = nl[1]; y[2] = nl[2]; first = false; }
+        }
       }
-      col(73 + g)[i] = ch;
+    }
+    for (int l = 0; l < 3; l++) col(C_Y + l)[i] = y[l];
+    col(C_C0)[i] = c0; col(C_C1)[i] = c1;
+    if (cls == K_ADD || cls == K_ADDI || cls == K_BNE || cls == K_JAL) {                           // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
+      const uint64_t v0 = (uint64_t)pc[0] + dl0; const F d0 = (F)(v0 >> 20);
+      const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; const F d1 = (F)(v1 >> 20);
+      const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; const F d2 = (F)(v2 >> 24);
+      col(C_D0)[i] = d0; col(C_D1)[i] = d1; col(C_D2)[i] = d2;
     }
   }
 }
-
 // ---------------------------------------------------------------------------------------------
 // Merkle tree over the rows of a column-major matrix (leaf j = hash of column values at position j)
 // ---------------------------------------------------------------------------------------------
@@ -210,10 +303,11 @@ static void merkle_build(const std::vector<F>& mat, int width, size_t n, Merkle&
 
 
 // =================================================================================================
-// Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v0)
+// Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
-static const int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103, LOG_ARITY = 3;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 2;   // "ZKPF"; v2: FRI layers are committed every LOG_ARITY folds
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 3;   // "ZKPF"; v3: AIR v1 (152 columns), public inputs, padding, grinding
+static const int HEADER_WORDS = 21;                                   // words before the trace root (layout in prove())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
 // before the next commitment.  Layer 0 (the DEEP codeword) is folded once, so that its leaves are the pairs (q, q + N) the trace
@@ -238,33 +332,134 @@ struct Challenger {
   F sample() { if (!in.empty() || out.empty()) duplex(); F v = out.back(); out.pop_back(); return v; }
   E sample_ext() { E e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
   uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
+  // proof of work: the transcript is flushed (pending input absorbed), then the nonce is the smallest field element whose
+  // absorption makes the next squeezed element end in POW_BITS zero bits; grind() returns it, check_pow() re-derives the element
+  void flush() { if (!in.empty()) duplex(); out.clear(); }
+  bool check_pow(F nonce) { flush(); observe(nonce); return (sample() & ((1u << POW_BITS) - 1)) == 0; }
+  F grind() {
+    flush();
+    for (F nonce = 0;; nonce++) { Challenger c = *this; if (c.check_pow(nonce)) return nonce; }
+  }
 };
 
-// ---- the AIR: Σ_c alpha^c C_c over one (local, next) row pair; generic over base / extension values ----
-// columns: 0 cycle | 1-3 pc limbs | 4-8 instruction fields | 9+3r.. register limbs | 57+r state | 73+r changed
-// row values as E (base-field rows are lifted); returns Σ alpha^c C_c
-static E constraints_sum(const E* loc, const E* nxt, const E& is_first, const E& is_trans, const E* ap) {
-  E acc = e_from(0); int c = 0;
-  auto push = [&](const E& v) { acc = eadd(acc, emul(ap[c], v)); c++; };
+// ---- the AIR: Σ_c alpha^c C_c over one (local, next) row pair; values as E (base-field rows are lifted) ----
+// is_first = Z_H(x)/(x - 1), is_last = Z_H(x)/(x - w^(n_real-1)) (the last EXECUTED row), is_trans = x - w^-1.
+// Every constraint has degree <= 2 in the columns (x is_trans) or degree 1 (x is_first / is_last): the quotient has degree < N.
+struct AirAcc {
+  const E* ap; E acc; int c;
+  void push(const E& v) { acc = eadd(acc, emul(ap[c], v)); c++; }
+};
+static int constraints_sum(const E* loc, const E* nxt, const E& is_first, const E& is_last, const E& is_trans, const Public& pub, const E* ap, E& result) {
+  AirAcc A{ap, e_from(0), 0};
+  auto push = [&](const E& v) { A.push(v); };
+  auto cst = [](uint64_t v) { return e_from((F)(v % P)); };
   const E one = e_from(1);
-  push(emul(esub(esub(nxt[0], loc[0]), one), is_trans));                 // c0: cycle' = cycle + 1
-  push(emul(loc[0], is_first));                                          // c1: cycle[0] = 0
-  for (int r = 0; r < 16; r++) {
-    const E st = loc[57 + r], ch = loc[73 + r];
-    push(emul(st, esub(st, one)));                                       // state boolean
-    push(emul(ch, esub(ch, one)));                                       // changed boolean
-    const E keep = esub(one, ch);
-    for (int l = 0; l < 3; l++) push(emul(emul(keep, esub(nxt[9 + 3 * r + l], loc[9 + 3 * r + l])), is_trans));   // untouched registers keep their limbs
-    push(emul(emul(keep, esub(nxt[57 + r], st)), is_trans));             // ... and their storage state
+  const E Dm = cst(pub.deferred ? 1 : 0), nD = cst(pub.deferred ? 0 : 1);
+  const E op = loc[C_OP], fa = loc[C_FA], fb = loc[C_FB], fc = loc[C_FC], fhi = loc[C_FHI], s = loc[C_S], se = loc[C_SE];
+  const E* K = loc + C_K;
+  // 1. cycle counter, first row, last executed row
+  push(emul(esub(esub(nxt[C_CYCLE], loc[C_CYCLE]), one), is_trans));
+  push(emul(loc[C_CYCLE], is_first));
+  for (int l = 0; l < 3; l++) push(emul(esub(loc[C_PC + l], cst(l == 0 ? (pub.entry & 0xFFFFF) : l == 1 ? ((pub.entry >> 20) & 0xFFFFF) : (pub.entry >> 40))), is_first));
+  for (int k = C_LIMB; k < C_STATE + 16; k++) push(emul(loc[k], is_first));                        // VMState::new: all registers zero, Normalized (state.rs:55-71)
+  push(emul(esub(K[K_HALT], one), is_last));
+  // 2. R0 is hard-wired zero
+  for (int l = 0; l < 3; l++) push(loc[C_LIMB + l]);
+  push(loc[C_STATE]);
+  // 3. booleans
+  auto boolean = [&](const E& b) { push(emul(b, esub(b, one))); };
+  for (int r = 0; r < 16; r++) boolean(loc[C_STATE + r]);
+  for (int r = 0; r < 15; r++) { boolean(loc[C_WR + r]); boolean(loc[C_SELB + r]); boolean(loc[C_SELC + r]); }
+  for (int k = 0; k < 7; k++) boolean(K[k]);
+  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]);
+  // 4. exactly one class; class <-> opcode; "oth" means none of the four constrained opcodes (default mode)
+  { E sum = e_from(0); for (int k = 0; k < 7; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  push(emul(K[K_ADD], esub(op, cst(OP_ADD)))); push(emul(K[K_ADDI], esub(op, cst(OP_ADDI))));
+  push(emul(K[K_BNE], esub(op, cst(OP_BNE)))); push(emul(K[K_JAL], esub(op, cst(OP_JAL))));
+  push(esub(loc[C_T], emul(op, esub(op, cst(8)))));
+  push(esub(loc[C_T + 1], emul(esub(op, cst(OP_BNE)), esub(op, cst(OP_JAL)))));
+  push(esub(loc[C_T + 2], emul(loc[C_T], loc[C_T + 1])));
+  push(esub(loc[C_T + 4], emul(loc[C_T + 2], loc[C_T + 3])));
+  push(emul(nD, emul(K[K_OTH], esub(loc[C_T + 4], one))));
+  // 5. register selectors: wr (written register = field a for add/addi/jal, none for bne/halt/pad, at most one in default mode),
+  //    selb = one-hot(fb), selc = one-hot(fc), or one-hot(fa) on BNE rows
+  auto moments = [&](int base, E& s0, E& s1, E& s2) {
+    s0 = s1 = s2 = e_from(0);
+    for (int r = 1; r < 16; r++) { const E& v = loc[base + r - 1]; s0 = eadd(s0, v); s1 = eadd(s1, emul_f(v, r)); s2 = eadd(s2, emul_f(v, r * r)); }
+  };
+  E w0, w1, w2, b0, b1, b2, c0s, c1s, c2s;
+  moments(C_WR, w0, w1, w2); moments(C_SELB, b0, b1, b2); moments(C_SELC, c0s, c1s, c2s);
+  push(emul(nD, esub(emul(w1, w1), w2)));
+  push(emul(eadd(eadd(K[K_ADD], K[K_ADDI]), K[K_JAL]), esub(w1, fa)));
+  push(emul(eadd(eadd(K[K_BNE], K[K_HALT]), K[K_PAD]), w0));
+  push(esub(b1, fb)); push(esub(emul(b1, b1), b2));
+  push(esub(c1s, eadd(fc, emul(K[K_BNE], esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));
+  // 6. operand fetch
+  for (int l = 0; l < 3; l++) {
+    E xb = e_from(0), xc = e_from(0);
+    for (int r = 1; r < 16; r++) { xb = eadd(xb, emul(loc[C_SELB + r - 1], loc[C_LIMB + 3 * r + l])); xc = eadd(xc, emul(loc[C_SELC + r - 1], loc[C_LIMB + 3 * r + l])); }
+    push(esub(loc[C_XB + l], xb)); push(esub(loc[C_XC + l], xc));
   }
-  push(loc[9]); push(loc[10]); push(loc[11]); push(loc[57]); push(loc[73]);   // R0 is hard-wired zero, Normalized, never written
-  return acc;
+  // 7. opcode semantics of the value written (execute.rs:43-63 ADD, :185-197 ADDI, :639-647 JAL link), 40-bit wrap as two 20-bit limbs
+  const E two20 = cst(1u << 20), two24 = cst(1u << 24);
+  const E imm17 = eadd(fc, emul_f(fhi, 16));
+  const E im0 = eadd(esub(imm17, emul_f(s, 1u << 17)), emul_f(s, 1u << 20)), im1 = emul_f(s, 0xFFFFF);
+  const E lo20 = esub(eadd(eadd(fb, emul_f(fc, 16)), emul_f(fhi, 256)), emul_f(s, 1u << 20));
+  const E *xb = loc + C_XB, *xc = loc + C_XC, *y = loc + C_Y, *pc = loc + C_PC;
+  const E c0 = loc[C_C0], c1 = loc[C_C1];
+  push(emul(K[K_ADD], eadd(esub(esub(y[0], xb[0]), xc[0]), emul(two20, c0))));
+  push(emul(K[K_ADD], eadd(esub(esub(esub(y[1], xb[1]), xc[1]), c0), emul(two20, c1))));
+  push(emul(K[K_ADD], y[2]));
+  push(emul(K[K_ADDI], eadd(esub(esub(y[0], xb[0]), im0), emul(two20, c0))));
+  push(emul(K[K_ADDI], eadd(esub(esub(esub(y[1], xb[1]), im1), c0), emul(two20, c1))));
+  push(emul(K[K_ADDI], y[2]));
+  push(emul(K[K_JAL], eadd(esub(esub(y[0], pc[0]), cst(4)), emul(two20, c0))));
+  push(emul(K[K_JAL], eadd(esub(esub(y[1], pc[1]), c0), emul(two20, c1))));
+  push(emul(K[K_JAL], esub(esub(y[2], pc[2]), c1)));
+  // 8. BNE compares the raw 64-bit values (execute.rs:588-596): ne = [xb != xc] over all three limbs
+  {
+    E dot = e_from(0);
+    for (int l = 0; l < 3; l++) { const E d = esub(xb[l], xc[l]); dot = eadd(dot, emul(d, loc[C_IV + l])); push(emul(esub(one, loc[C_NE]), d)); }
+    push(esub(loc[C_NE], dot));
+  }
+  push(emul(K[K_BNE], esub(loc[C_TK], loc[C_NE])));
+  push(emul(esub(one, K[K_BNE]), loc[C_TK]));
+  // 9. next pc: pc + 4, pc + imm17 (branch taken) or pc + off21 (JAL), wrapping at 2^64 over (20, 20, 24)-bit limbs (state.rs:131-133)
+  push(esub(loc[C_DL0], eadd(eadd(cst(4), emul(loc[C_TK], esub(im0, cst(4)))), emul(K[K_JAL], esub(lo20, cst(4))))));
+  push(esub(se, emul(eadd(loc[C_TK], K[K_JAL]), s)));
+  const E kc = eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_BNE], K[K_JAL]));
+  const E hp = eadd(K[K_HALT], K[K_PAD]);
+  push(emul(emul(kc, eadd(esub(esub(nxt[C_PC], pc[0]), loc[C_DL0]), emul(two20, loc[C_D0]))), is_trans));
+  push(emul(emul(kc, eadd(esub(esub(esub(nxt[C_PC + 1], pc[1]), emul_f(se, 0xFFFFF)), loc[C_D0]), emul(two20, loc[C_D1]))), is_trans));
+  push(emul(emul(kc, eadd(esub(esub(esub(nxt[C_PC + 2], pc[2]), emul_f(se, 0xFFFFFF)), loc[C_D1]), emul(two24, loc[C_D2]))), is_trans));
+  for (int l = 0; l < 3; l++) push(emul(emul(hp, esub(nxt[C_PC + l], pc[l])), is_trans));
+  // 10. register file update: the written register takes y (default mode) / may change freely (deferred mode), the others keep
+  //     their limbs and storage state; a written register becomes Normalized in default mode
+  for (int r = 1; r < 16; r++) {
+    const E& wr = loc[C_WR + r - 1];
+    for (int l = 0; l < 3; l++) {
+      const E &cur = loc[C_LIMB + 3 * r + l], &nx = nxt[C_LIMB + 3 * r + l];
+      push(emul(esub(esub(nx, cur), emul(wr, esub(eadd(emul(nD, y[l]), emul(Dm, nx)), cur))), is_trans));
+    }
+    const E &cur = loc[C_STATE + r], &nx = nxt[C_STATE + r];
+    push(emul(esub(esub(nx, cur), emul(wr, esub(emul(Dm, nx), cur))), is_trans));
+  }
+  // 11. executed rows, then the halt row, then padding only
+  push(emul(emul(K[K_HALT], esub(one, nxt[C_K + K_PAD])), is_trans));
+  push(emul(emul(K[K_PAD], esub(one, nxt[C_K + K_PAD])), is_trans));
+  push(emul(emul(esub(esub(one, K[K_PAD]), K[K_HALT]), nxt[C_K + K_PAD]), is_trans));
+  result = A.acc;
+  return A.c;
+}
+static int num_constraints() {                                            // by a dry run (the list above is the definition)
+  std::vector<E> z(W_MAIN, e_from(0)), ap(MAX_CONSTRAINTS, e_from(0));
+  E r; Public pub;
+  return constraints_sum(z.data(), z.data(), e_from(0), e_from(0), e_from(0), pub, ap.data(), r);
 }
 
 struct Proof { std::vector<uint32_t> w; };
 static void put_e(std::vector<uint32_t>& w, const E& e) { for (int i = 0; i < 4; i++) w.push_back(e.c[i]); }
 
-struct Tree { Merkle m; };
 static void merkle_path(const Merkle& t, size_t leaf, std::vector<uint32_t>& w) {
   size_t j = leaf;
   for (size_t lv = 0; lv + 1 < t.layers.size(); lv++) { const F* sib = &t.layers[lv][4 * (j ^ 1)]; for (int i = 0; i < 4; i++) w.push_back(sib[i]); j >>= 1; }
@@ -275,19 +470,31 @@ static E fold_pair(const E& a, const E& b, F x, const E& beta) {          // (a+
 }
 static E horner_base(const std::vector<F>& coeffs, const E& z) { E acc = e_from(0); for (size_t k = coeffs.size(); k-- > 0;) acc = eadd(emul(acc, z), e_from(coeffs[k])); return acc; }
 
+// header words 2..20 = everything both sides know before the first commitment; observed by the transcript in this order
+static void header_words(int log_n, const Public& pub, std::vector<uint32_t>& w) {
+  w.clear();
+  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(W_MAIN); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL); w.push_back(POW_BITS);
+  w.push_back((uint32_t)(pub.n_real & 0x3FFFFFFF)); w.push_back((uint32_t)(pub.n_real >> 30)); w.push_back(pub.deferred ? 1u : 0u);
+  w.push_back((uint32_t)(pub.entry & 0xFFFFF)); w.push_back((uint32_t)((pub.entry >> 20) & 0xFFFFF)); w.push_back((uint32_t)(pub.entry >> 40));
+  for (int i = 0; i < 4; i++) w.push_back(pub.prog[i]);
+  for (int i = 0; i < 4; i++) w.push_back(pub.io[i]);
+}
+
 struct ProverTrace {     // everything the oracle keeps for inspection by tests
   std::vector<F> M, L, Qc;            // [W][N], [W][2N], [4][2N]
   Merkle trace_tree, quot_tree;
   std::vector<std::vector<E>> fri;    // codewords per layer (layer 0 = DEEP codeword, size 2N)
   std::vector<Merkle> fri_trees;
-  E alpha, zeta, gamma; std::vector<E> betas; std::vector<uint32_t> queries;
+  E alpha, zeta, gamma; std::vector<E> betas; std::vector<uint32_t> queries; F pow_nonce = 0;
 };
 
-static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt) {
-  int log_n = 0; while (((size_t)1 << log_n) < n) log_n++;
-  const size_t N = n, N2 = 2 * n;
+// matrix_override (tests): prove this main-trace matrix [W][N] instead of the one derived from the rows (a cheating prover)
+static void prove(const PackedRow* rows, const Public& pub, Proof& proof, ProverTrace& pt, const F* matrix_override = nullptr) {
+  const int log_n = padded_log_n(pub.n_real);
+  const size_t N = (size_t)1 << log_n, N2 = 2 * N;
   const int Wm = W_MAIN;
-  main_trace(rows, n, pt.M);
+  if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wm * N);
+  else main_trace(rows, pub.n_real, pub, pt.M);
   pt.L.assign((size_t)Wm * N2, 0);
   std::vector<std::vector<F>> coeffs(Wm);
   for (int k = 0; k < Wm; k++) {
@@ -296,14 +503,18 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
     memcpy(&pt.L[(size_t)k * N2], o.data(), N2 * 4);
   }
   merkle_build(pt.L, Wm, N2, pt.trace_tree);
+  std::vector<uint32_t>& w = proof.w;
+  header_words(log_n, pub, w);
   Challenger ch;
-  ch.observe(log_n); ch.observe(Wm); ch.observe(NUM_QUERIES); ch.observe(LOG_FINAL);
+  ch.observe_n(w.data() + 2, w.size() - 2);
   ch.observe_n(pt.trace_tree.layers.back().data(), 4);
   pt.alpha = ch.sample_ext();
-  std::vector<E> ap(N_CONSTRAINTS); ap[0] = e_from(1); for (int c = 1; c < N_CONSTRAINTS; c++) ap[c] = emul(ap[c - 1], pt.alpha);
+  const int NC = num_constraints();
+  std::vector<E> ap(NC); ap[0] = e_from(1); for (int c = 1; c < NC; c++) ap[c] = emul(ap[c - 1], pt.alpha);
 
   // ---- quotient on the LDE coset: x_j = g * w_2N^j, next row = position j + 2 ----
-  const F w2n = root_of_unity(log_n + 1), wn_inv = finv(root_of_unity(log_n));
+  const F w2n = root_of_unity(log_n + 1), wn = root_of_unity(log_n), wn_inv = finv(wn);
+  const F w_last = fpow(wn, pub.n_real - 1);
   const F gN = fpow(GEN, N);
   pt.Qc.assign(4 * N2, 0);
   {
@@ -314,8 +525,10 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
       const F zh = fsub((j & 1) ? fneg(gN) : gN, 1);                      // x^N - 1, x^N = g^N (-1)^j
       const F inv_zh = finv(zh);
       const E is_first = e_from(fmul(zh, finv(fsub(x, 1))));
+      const E is_last = e_from(fmul(zh, finv(fsub(x, w_last))));
       const E is_trans = e_from(fsub(x, wn_inv));
-      E q = emul_f(constraints_sum(loc.data(), nxt.data(), is_first, is_trans, ap.data()), inv_zh);
+      E sum; constraints_sum(loc.data(), nxt.data(), is_first, is_last, is_trans, pub, ap.data(), sum);
+      E q = emul_f(sum, inv_zh);
       for (int i = 0; i < 4; i++) pt.Qc[(size_t)i * N2 + j] = q.c[i];
       x = fmul(x, w2n);
     }
@@ -323,7 +536,7 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
   merkle_build(pt.Qc, 4, N2, pt.quot_tree);
   ch.observe_n(pt.quot_tree.layers.back().data(), 4);
   pt.zeta = ch.sample_ext();
-  const E zeta_w = emul_f(pt.zeta, root_of_unity(log_n));
+  const E zeta_w = emul_f(pt.zeta, wn);
 
   // ---- openings (oracle: Horner on coefficient vectors) ----
   std::vector<E> t_z(Wm), t_zw(Wm), q_z(4);
@@ -387,12 +600,12 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
   }
   const std::vector<E>& fin = pt.fri.back();
   for (const E& e : fin) ch.observe_ext(e);
+  pt.pow_nonce = ch.grind();
+  const bool pow_ok = ch.check_pow(pt.pow_nonce); (void)pow_ok;
   pt.queries.clear();
   for (int t = 0; t < NUM_QUERIES; t++) pt.queries.push_back(ch.sample_bits(log_n));
 
-  // ---- serialize ----
-  std::vector<uint32_t>& w = proof.w; w.clear();
-  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(Wm); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL);
+  // ---- serialize: [0..21) header | trace root | quotient root | openings | FRI roots | final codeword | pow nonce | queries ----
   for (int i = 0; i < 4; i++) w.push_back(pt.trace_tree.layers.back()[i]);
   for (int i = 0; i < 4; i++) w.push_back(pt.quot_tree.layers.back()[i]);
   for (int k = 0; k < Wm; k++) put_e(w, t_z[k]);
@@ -401,6 +614,7 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
   w.push_back((uint32_t)pt.fri_trees.size());
   for (auto& tr : pt.fri_trees) for (int i = 0; i < 4; i++) w.push_back(tr.layers.back()[i]);
   for (const E& e : fin) put_e(w, e);
+  w.push_back(pt.pow_nonce);
   for (uint32_t q : pt.queries) {
     w.push_back(q);
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wm; k++) w.push_back(pt.L[(size_t)k * N2 + pos]); merkle_path(pt.trace_tree, pos, w); }
@@ -413,20 +627,30 @@ static void prove(const PackedRow* rows, size_t n, Proof& proof, ProverTrace& pt
   }
 }
 
-// ---- verifier (N4): returns 0 if the proof is accepted, otherwise a non-zero code naming the failed check ----
+// ---- verifier (N4): returns 0 if the proof is accepted, otherwise a non-zero code naming the failed check.  `expect` (nullable):
+// the public inputs the caller expects (program / io digests, row count, mode, entry point); a mismatch with the header is code 6 ----
 static bool check_path(const F* leaf_digest, size_t idx, const uint32_t* path, int depth, const F* root) {
   F node[4]; memcpy(node, leaf_digest, 16);
   for (int d = 0; d < depth; d++) { F nx[4]; if (idx & 1) compress(path + 4 * d, node, nx); else compress(node, path + 4 * d, nx); memcpy(node, nx, 16); idx >>= 1; }
   return !memcmp(node, root, 16);
 }
-static int verify(const uint32_t* w, size_t len) {
+static int verify(const uint32_t* w, size_t len, const Public* expect) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
-  if (!need(6) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
-  const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5]; p = 6;
-  if (Wm != W_MAIN || nq != NUM_QUERIES || log_final != LOG_FINAL || log_n < LOG_FINAL || log_n > 26) return 2;
+  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
+  const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5];
+  if (Wm != W_MAIN || nq != NUM_QUERIES || log_final != LOG_FINAL || w[6] != (uint32_t)POW_BITS || log_n < LOG_FINAL || log_n > 26) return 2;
+  Public pub;
+  if (w[7] >= (1u << 30) || w[9] > 1 || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
+  pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
+  pub.entry = (uint64_t)w[10] | ((uint64_t)w[11] << 20) | ((uint64_t)w[12] << 40);
+  memcpy(pub.prog, w + 13, 16); memcpy(pub.io, w + 17, 16);
+  if (pub.n_real == 0 || padded_log_n(pub.n_real) != log_n) return 2;
+  if (expect && (expect->n_real != pub.n_real || (expect->deferred != 0) != (pub.deferred != 0) || expect->entry != pub.entry ||
+                 memcmp(expect->prog, pub.prog, 16) || memcmp(expect->io, pub.io, 16))) return 6;
+  p = HEADER_WORDS;
   const size_t N = (size_t)1 << log_n;
-  for (size_t i = 6; i < len; i++) if (w[i] >= P) return 3;   // every payload word must be canonical (query indices are < N < p)
+  for (size_t i = 2; i < len; i++) if (w[i] >= P) return 3;   // every payload word must be canonical (query indices are < N < p)
   if (!need(8)) return 4;
   const F* troot = w + p; p += 4; const F* qroot = w + p; p += 4;
   auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
@@ -439,14 +663,15 @@ static int verify(const uint32_t* w, size_t len) {
   const int n_layers = w[p++];
   const std::vector<int> ks = fri_schedule(log_n);
   if (n_layers != (int)ks.size()) return 5;
-  if (!need((size_t)4 * n_layers + 4 * ((size_t)1 << LOG_FINAL))) return 4;
+  if (!need((size_t)4 * n_layers + 4 * ((size_t)1 << LOG_FINAL) + 1)) return 4;
   std::vector<const F*> lroots(n_layers);
   for (int j = 0; j < n_layers; j++) { lroots[j] = w + p; p += 4; }
   std::vector<E> fin((size_t)1 << LOG_FINAL);
   for (auto& e : fin) { e = get_e(p); p += 4; }
+  const F pow_nonce = w[p++];
   // transcript
   Challenger ch;
-  ch.observe(log_n); ch.observe(Wm); ch.observe(NUM_QUERIES); ch.observe(LOG_FINAL);
+  ch.observe_n(w + 2, HEADER_WORDS - 2);
   ch.observe_n(troot, 4);
   const E alpha = ch.sample_ext();
   ch.observe_n(qroot, 4);
@@ -458,13 +683,17 @@ static int verify(const uint32_t* w, size_t len) {
   std::vector<E> betas(n_layers);
   for (int j = 0; j < n_layers; j++) { ch.observe_n(lroots[j], 4); betas[j] = ch.sample_ext(); }
   for (const E& e : fin) ch.observe_ext(e);
+  if (!ch.check_pow(pow_nonce)) return 12;
   // 1. constraints at zeta:  Σ alpha^c C_c(zeta) == Q(zeta) * Z_H(zeta)
   {
-    std::vector<E> ap(N_CONSTRAINTS); ap[0] = e_from(1); for (int c = 1; c < N_CONSTRAINTS; c++) ap[c] = emul(ap[c - 1], alpha);
+    const int NC = num_constraints();
+    std::vector<E> ap(NC); ap[0] = e_from(1); for (int c = 1; c < NC; c++) ap[c] = emul(ap[c - 1], alpha);
+    const F wn = root_of_unity(log_n);
     const E zN = epow(zeta, N), zh = esub(zN, e_from(1));
     const E is_first = emul(zh, einv(esub(zeta, e_from(1))));
-    const E is_trans = esub(zeta, e_from(finv(root_of_unity(log_n))));
-    const E lhs = constraints_sum(t_z.data(), t_zw.data(), is_first, is_trans, ap.data());
+    const E is_last = emul(zh, einv(esub(zeta, e_from(fpow(wn, pub.n_real - 1)))));
+    const E is_trans = esub(zeta, e_from(finv(wn)));
+    E lhs; constraints_sum(t_z.data(), t_zw.data(), is_first, is_last, is_trans, pub, ap.data(), lhs);
     E qz = e_from(0);
     for (int i = 0; i < 4; i++) { E basis = e_from(0); basis.c[i] = 1; qz = eadd(qz, emul(basis, q_z[i])); }
     if (!eeq(lhs, emul(qz, zh))) return 10;
@@ -523,7 +752,7 @@ static int verify(const uint32_t* w, size_t len) {
       const size_t nv = (size_t)1 << k, g = (size_t)1 << depth, idx = carried_idx & (g - 1), slot = carried_idx >> depth;
       if (!need(4 * nv + 4 * (size_t)depth)) return 4;
       std::vector<E> v(nv);
-      for (size_t t = 0; t < nv; t++) v[t] = get_e(p + 4 * t);
+      for (size_t t2 = 0; t2 < nv; t2++) v[t2] = get_e(p + 4 * t2);
       F dg[4]; hash_elems(w + p, 4 * nv, dg);
       p += 4 * nv;
       if (!check_path(dg, idx, w + p, depth, lroots[j])) return 23;
@@ -534,7 +763,7 @@ static int verify(const uint32_t* w, size_t len) {
       for (int f = 0; f < k; f++) {
         const size_t half = nv >> (f + 1);
         const F wm = root_of_unity(log_m);
-        for (size_t t = 0; t < half; t++) v[t] = fold_pair(v[t], v[t + half], fmul(shift, fpow(wm, idx + t * g)), beta);
+        for (size_t t2 = 0; t2 < half; t2++) v[t2] = fold_pair(v[t2], v[t2 + half], fmul(shift, fpow(wm, idx + t2 * g)), beta);
         shift = fmul(shift, shift); log_m--; beta = emul(beta, beta);
       }
       carried = v[0]; carried_idx = idx;                                   // position in the next layer (size g)
@@ -550,6 +779,10 @@ static int verify(const uint32_t* w, size_t len) {
 // C API (ctypes)
 // =================================================================================================
 extern "C" {
+struct so_public { uint64_t n_real; uint32_t deferred; uint32_t pad; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; };
+static so::Public to_pub(const so_public* p) {
+  so::Public q; q.n_real = p->n_real; q.deferred = p->deferred; q.entry = p->entry; memcpy(q.prog, p->prog, 16); memcpy(q.io, p->io, 16); return q;
+}
 uint32_t so_p() { return so::P; }
 uint32_t so_fmul(uint32_t a, uint32_t b) { return so::fmul(a, b); }
 uint32_t so_finv(uint32_t a) { return so::finv(a); }
@@ -563,6 +796,7 @@ void so_poseidon2_constants(uint32_t* ext96, uint32_t* in22, uint32_t* diag12) {
 }
 void so_hash_elems(const uint32_t* in, size_t n, uint32_t* out4) { so::hash_elems(in, n, out4); }
 void so_compress(const uint32_t* l, const uint32_t* r, uint32_t* out4) { so::compress(l, r, out4); }
+void so_digest_bytes(const uint8_t* b, size_t n, uint32_t* out4) { so::digest_bytes(b, n, out4); }
 void so_ntt(uint32_t* a, size_t n, int inverse) { std::vector<so::F> v(a, a + n); so::ntt(v, inverse != 0); memcpy(a, v.data(), n * 4); }
 // evals[n] -> coeffs[n], lde[n << log_blowup]
 void so_lde(const uint32_t* evals, size_t n, int log_blowup, uint32_t* coeffs, uint32_t* out) {
@@ -572,8 +806,23 @@ void so_lde(const uint32_t* evals, size_t n, int log_blowup, uint32_t* coeffs, u
   memcpy(out, o.data(), o.size() * 4);
 }
 int so_main_trace_width() { return so::W_MAIN; }
-void so_main_trace(const void* packed_rows, size_t n, uint32_t* out /* [W_MAIN][n] */) {
-  std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, n, m); memcpy(out, m.data(), m.size() * 4);
+int so_padded_log_n(uint64_t n_real) { return so::padded_log_n(n_real); }
+int so_num_constraints() { return so::num_constraints(); }
+void so_main_trace(const void* packed_rows, const so_public* pub, uint32_t* out /* [W_MAIN][N] */) {
+  std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m); memcpy(out, m.data(), m.size() * 4);
+}
+// Σ alpha^c C_c of one (local, next) row pair with base-field values and the given selector values (tests: which constraint fails)
+int so_constraints_eval(const uint32_t* loc, const uint32_t* nxt, uint32_t is_first, uint32_t is_last, uint32_t is_trans, const so_public* pub, const uint32_t* alpha4,
+                        uint32_t* out4) {
+  const int NC = so::num_constraints();
+  so::E a; memcpy(a.c, alpha4, 16);
+  std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
+  std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN);
+  for (int k = 0; k < so::W_MAIN; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
+  so::E r;
+  so::constraints_sum(l.data(), x.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), to_pub(pub), ap.data(), r);
+  memcpy(out4, r.c, 16);
+  return NC;
 }
 // Merkle root (and optionally every layer, concatenated leaf-layer first) of a column-major matrix [width][n]
 void so_merkle(const uint32_t* mat, int width, size_t n, uint32_t* root4, uint32_t* all_layers /* nullable, 4*(2n-1) */) {
@@ -582,9 +831,10 @@ void so_merkle(const uint32_t* mat, int width, size_t n, uint32_t* root4, uint32
   memcpy(root4, t.layers.back().data(), 16);
   if (all_layers) { size_t off = 0; for (auto& l : t.layers) { memcpy(all_layers + off, l.data(), l.size() * 4); off += l.size(); } }
 }
-// commit = main_trace -> per-column LDE -> Merkle over the LDE rows; returns root, optionally the LDE matrix [W][n<<lb]
-void so_commit_trace(const void* packed_rows, size_t n, int log_blowup, uint32_t* root4, uint32_t* lde_out /* nullable */) {
-  std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, n, m);
+// commit = main_trace -> per-column LDE -> Merkle over the LDE rows; returns root, optionally the LDE matrix [W][N<<lb]
+void so_commit_trace(const void* packed_rows, const so_public* pub, int log_blowup, uint32_t* root4, uint32_t* lde_out /* nullable */) {
+  std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m);
+  const size_t n = (size_t)1 << so::padded_log_n(pub->n_real);
   size_t big = n << log_blowup;
   std::vector<so::F> L((size_t)so::W_MAIN * big);
   for (int k = 0; k < so::W_MAIN; k++) {
@@ -599,15 +849,26 @@ void so_commit_trace(const void* packed_rows, size_t n, int log_blowup, uint32_t
 
 // ---- stage B C API ----
 static so::ProverTrace g_pt;   // last prover run (tests inspect intermediate objects)
-size_t so_prove(const void* packed_rows, size_t n, uint32_t* out, size_t cap) {
-  so::Proof pr; so::prove((const so::PackedRow*)packed_rows, n, pr, g_pt);
+size_t so_prove(const void* packed_rows, const so_public* pub, uint32_t* out, size_t cap) {
+  so::Proof pr; so::prove((const so::PackedRow*)packed_rows, to_pub(pub), pr, g_pt);
   if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
   return pr.w.size();
 }
-int so_verify(const uint32_t* proof, size_t len) { return so::verify(proof, len); }
+size_t so_prove_matrix(const uint32_t* matrix, const so_public* pub, uint32_t* out, size_t cap) {
+  so::Proof pr; so::prove(nullptr, to_pub(pub), pr, g_pt, matrix);
+  if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
+  return pr.w.size();
+}
+int so_verify(const uint32_t* proof, size_t len, const so_public* expect) {
+  if (!expect) return so::verify(proof, len, nullptr);
+  const so::Public e = to_pub(expect);
+  return so::verify(proof, len, &e);
+}
 void so_last_challenges(uint32_t* alpha, uint32_t* zeta, uint32_t* gamma) { memcpy(alpha, g_pt.alpha.c, 16); memcpy(zeta, g_pt.zeta.c, 16); memcpy(gamma, g_pt.gamma.c, 16); }
 void so_last_quotient(uint32_t* out /* [4][2N] */) { memcpy(out, g_pt.Qc.data(), g_pt.Qc.size() * 4); }
 size_t so_last_fri_layer(int j, uint32_t* out /* [m][4] */) { if (j < 0 || (size_t)j >= g_pt.fri.size()) return 0; if (out) memcpy(out, g_pt.fri[j].data(), g_pt.fri[j].size() * 16); return g_pt.fri[j].size(); }
 int so_num_queries() { return so::NUM_QUERIES; }
 int so_log_final() { return so::LOG_FINAL; }
+int so_pow_bits() { return so::POW_BITS; }
+int so_header_words() { return so::HEADER_WORDS; }
 }  // extern "C"

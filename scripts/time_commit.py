@@ -10,16 +10,17 @@ n = 1 << k
 log = rt.interpret(spec.fib_endless_program().to_bytes(), [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
 ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); fa = pl.trace_fill_args(ddl, tr)
 ctx = stark.StarkContext(k)
-m = torch.empty((89, n), dtype=torch.int32, device="cuda")
-L = torch.empty((89, 2 * n), dtype=torch.int32, device="cuda")
+W = stark.W_MAIN
+m = torch.empty((W, n), dtype=torch.int32, device="cuda")
+L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
 tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
 import ctypes as C
 lib = rt.lib(); sp = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def stages():
     yield "trace_fill", lambda: pl.trace_fill(fa)
-    yield "main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(tr.c), n, m.data_ptr(), sp()))
-    yield "lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), 89, L.data_ptr(), sp()))
-    yield "merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), 89, 2 * n, tree.data_ptr(), sp()))
+    yield "main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(tr.c), n, 0, m.data_ptr(), sp()))
+    yield "lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))
+    yield "merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp()))
 for _ in range(3):
     for name, f in stages(): f()
 torch.cuda.synchronize()

@@ -180,16 +180,25 @@ static void test_deferred_carry_normalization_event() {          // deferred_int
   CHECK(e.reg == 3 && e.triggering_opcode == 0x40 && e.normalized[0] == 90 && e.normalized[1] == 1 && e.carries[0] == 1);
 }
 
-// ---- prover stages (no counterpart in the reference: only the shape of the result can be asserted here; the words are compared
-// with the oracle's prover and checked by its verifier in tests/test_gpu_stark.py) ------------------------------------------------
-static void test_prove_power_of_two_trace() {
-  VMConfig cfg; cfg.enable_execution_trace = true; cfg.max_cycles = 1 << 10;
-  ExecutionResult r = VM::new_(Program::from_code({addi(1, 1, 1), jal(0, -4)}), {}, cfg).run();
-  zkir_prover::StarkContext ctx(10);
-  const std::vector<uint32_t> proof = zkir_prover::prove(ctx, r);
-  CHECK(proof.size() > 1000 && proof[0] == 0x46504B5Au && proof[1] == 2 && proof[2] == 10 && proof[3] == 89 && proof[4] == zkir_proof_num_queries());
-  CHECK(zkir_prover::prove(ctx, r) == proof);                    // deterministic transcript
-  for (size_t i = 6; i < proof.size(); i++) if (proof[i] >= 2013265921u) { CHECK(!"non-canonical proof word"); break; }
+// ---- prover stages (no counterpart in the reference; the words are compared with the oracle's prover in tests/test_gpu_stark.py) --
+static void test_prove_and_verify() {
+  // a run that halts on its own (Exit after 3 + 5*11 + 6 rows): padded to 2^7, bound to its program / outputs / halt reason
+  auto code = cat({{addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, 11), add(4, 1, 2), addi(1, 2, 0), addi(2, 4, 0), addi(3, 3, -1), bne(3, 0, -16)}, write_reg(2), EXIT0});
+  const Program prog = Program::from_code(code);
+  VMConfig cfg; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(prog, {}, cfg).run();
+  CHECK(r.outputs == std::vector<uint64_t>{144} && r.cycles == 64);
+  const zkir_public_inputs pub = zkir_prover::public_inputs(r, prog, {}, cfg);
+  CHECK(pub.n_real == 64 && pub.entry_point == 0x1000 && pub.deferred == 0);
+  zkir_prover::StarkContext ctx(zkir_padded_log_n(pub.n_real));
+  const std::vector<uint32_t> proof = zkir_prover::prove(ctx, r, pub);
+  CHECK(proof.size() > 1000 && proof[0] == 0x46504B5Au && proof[1] == zkir_proof_version() && proof[2] == 6 && proof[3] == zkir_main_trace_width() && proof[4] == zkir_proof_num_queries());
+  CHECK(zkir_prover::prove(ctx, r, pub) == proof);               // deterministic transcript
+  CHECK(zkir_prover::verify(proof) == 0 && zkir_prover::verify(proof, &pub) == 0);
+  zkir_public_inputs other = pub; other.io_digest[0] ^= 1;       // someone claims other outputs
+  CHECK(zkir_prover::verify(proof, &other) == 6);
+  std::vector<uint32_t> bad = proof; bad[bad.size() / 2] = (bad[bad.size() / 2] + 1) % 2013265921u;
+  CHECK(zkir_prover::verify(bad) != 0);
 }
 
 int main(int argc, char** argv) {
@@ -208,7 +217,7 @@ int main(int argc, char** argv) {
       {"test_trace_timestamp_synchronization", test_trace_timestamp_synchronization, true},
       {"test_bound_propagation_and_deferred_checks", test_bound_propagation_and_deferred_checks, true},
       {"test_deferred_carry_normalization_event", test_deferred_carry_normalization_event, true},
-      {"test_prove_power_of_two_trace", test_prove_power_of_two_trace, true}};
+      {"test_prove_and_verify", test_prove_and_verify, true}};
   int ran = 0;
   for (const auto& t : tests) {
     if (t.needs_gpu && !gpu) continue;

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK v1, proof format v3).
+
+The reference has no prover, so nothing external can pin these stages; this file pins them against DRIFT: the
+commitment roots and a SHA-256 of the full proof words for four small runs, computed by the CPU oracle (oracle/stark_oracle.cpp).
+tests/test_stark_goldens.py checks the oracle (CPU) and the GPU prover (-m gpu) against it, so no change to the field, Poseidon2
+instance, main-trace columns, AIR, transcript, FRI schedule, grinding or serialisation can land without this file changing —
+deliberately, in its own commit.
+
+Does NOT import the product package: the programs are encoded here from the reference's bit layout (zkir-spec/src/encoding.rs:23-60,
+program header zkir-spec/src/program.rs:170-186), like tests/golden/make_kats.py.
+
+Run: python tests/golden/make_stark_goldens.py
+"""
+import hashlib
+import json
+import os
+import struct
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
+
+ADD, ADDI, SLLI, LW, SW, BNE, JAL, ECALL = 0x00, 0x08, 0x1B, 0x34, 0x3A, 0x41, 0x48, 0x50
+
+
+def r_(op, rd, rs1, rs2): return op | rd << 7 | rs1 << 11 | rs2 << 15
+def i_(op, rd, rs1, imm): return op | rd << 7 | rs1 << 11 | (imm & 0x1FFFF) << 15
+def j_(op, rd, off): return op | rd << 7 | (off & 0x1FFFFF) << 11
+
+
+def blob(code, data=b""):
+    hdr = struct.pack("<IIBBBBIIIII", 0x52494B5A, 0x00030004, 20, 2, 2, 0, 0x1000, 4 * len(code), len(data), 0, 1 << 20)
+    return hdr + b"".join(struct.pack("<I", w & 0xFFFFFFFF) for w in code) + data
+
+
+FIB_LOOP = [r_(ADD, 4, 1, 2), i_(ADDI, 1, 2, 0), i_(ADDI, 2, 4, 0), i_(ADDI, 3, 3, -1), i_(BNE, 3, 0, -16)]      # tests/cross_module.rs:145-164
+FIB_ENDLESS = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 1), i_(ADDI, 3, 0, 0)] + FIB_LOOP + [j_(JAL, 0, -20)])
+FIB30 = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 1), i_(ADDI, 3, 0, 29)] + FIB_LOOP +
+             [i_(ADDI, 11, 2, 0), i_(ADDI, 10, 0, 2), ECALL, i_(ADDI, 10, 0, 0), i_(ADDI, 11, 0, 0), ECALL])
+_sha = [i_(ADDI, 5, 0, 0), i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(ADDI, 7, 5, 32),
+        i_(LW, 8, 5, 0), i_(SW, 6, 8, 0), i_(ADDI, 5, 5, 4), i_(ADDI, 6, 6, 4), i_(BNE, 5, 7, -16),
+        i_(ADDI, 11, 0, 0x8000), i_(SLLI, 11, 11, 1), i_(ADDI, 13, 11, 32), i_(ADDI, 12, 0, 32),
+        i_(ADDI, 10, 0, 3), ECALL, i_(ADDI, 9, 11, 0), i_(ADDI, 11, 13, 0), i_(ADDI, 13, 9, 0), j_(JAL, 0, -20)]
+_sha[0] = i_(ADDI, 5, 0, 0x1000 + 4 * len(_sha))
+SHA_CHAIN = blob(_sha, bytes(range(32)))                                                                           # pattern of crypto_edge_cases.rs:405-427
+
+CASES = [
+    dict(name="fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=False),
+    dict(name="sha_2p9", blob=SHA_CHAIN, max_cycles=1 << 9, deferred=False),
+    dict(name="deferred_fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=True),
+    dict(name="fib30_exit_154_rows", blob=FIB30, max_cycles=1_000_000, deferred=False),
+]
+
+
+def golden(case):
+    res = oracle.run(case["blob"], max_cycles=case["max_cycles"], enable_execution_trace=True, enable_deferred_model=case["deferred"])
+    pub = so.public_inputs(len(res.rows), case["blob"], [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=case["deferred"])
+    proof = so.prove(res.rows, pub)
+    assert so.verify(proof, pub) == 0
+    root = so.commit_trace(res.rows, 1, pub=pub)
+    assert list(root) == list(proof[21:25])
+    return dict(name=case["name"], program_blob_hex=case["blob"].hex(), max_cycles=case["max_cycles"], deferred=case["deferred"],
+                n_rows=len(res.rows), outputs=[int(x) for x in res.outputs], halt=[int(res.halt_kind), int(res.halt_code)],
+                program_digest=[int(x) for x in pub.prog], io_digest=[int(x) for x in pub.io],
+                trace_root=[int(x) for x in proof[21:25]], quotient_root=[int(x) for x in proof[25:29]],
+                proof_words=int(len(proof)), proof_sha256=hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest())
+
+
+if __name__ == "__main__":
+    out = {"_about": "frozen outputs of ZKIR-STARK v1 / proof format v3 (self-defined stages; see make_stark_goldens.py)",
+           "proof_version": 3, "main_trace_width": so.W_MAIN, "num_constraints": so.lib().so_num_constraints(),
+           "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
+           "cases": [golden(c) for c in CASES]}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+    for c in out["cases"]:
+        print(f'  {c["name"]:24s} rows {c["n_rows"]:5d}  root {c["trace_root"]}  proof {c["proof_words"]} words  sha256 {c["proof_sha256"][:16]}..')

@@ -81,22 +81,26 @@ while time.time() < t_end:
     else:                                                           # whole proof of a random program
         log_n = int(rng.integers(3, 11))
         blob, inputs = programs.random_program(int(rng.integers(0, 1 << 30)), n_instr=200)
-        cfg = dict(max_cycles=1 << log_n, enable_execution_trace=True, enable_deferred_model=bool(rng.integers(0, 2)))
+        cfg = dict(max_cycles=int(rng.integers((1 << log_n) // 2 + 1, (1 << log_n) + 1)), enable_execution_trace=True, enable_deferred_model=bool(rng.integers(0, 2)))
         try:
-            want_rows = oracle.run(blob, inputs, **cfg).rows
+            res = oracle.run(blob, inputs, **cfg)
         except oracle.OracleError:
             continue
-        if len(want_rows) != 1 << log_n:
-            continue                                                # halted early: not a power-of-two trace
+        want_rows = res.rows
+        if len(want_rows) == 0:
+            continue
+        log_n = so.padded_log_n(len(want_rows))                     # any halt: the trace is padded to a power of two
+        opub = so.public_inputs(len(want_rows), blob, list(inputs), list(res.outputs), (res.halt_kind, res.halt_code), deferred=cfg["enable_deferred_model"])
         log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
         ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
         got_rows = tr.rows()
         for name in want_rows.dtype.names:                          # K1 (trace fill) against the oracle's rows, all 372 B
             assert np.array_equal(got_rows[name], want_rows[name]), ("trace", name)
         ctx = ctxs.setdefault(log_n, stark.StarkContext(log_n))
-        proof = stark.prove(ctx, tr)
-        want = so.prove(want_rows)
+        proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, cfg["enable_deferred_model"]))
+        want = so.prove(want_rows, opub)
         assert np.array_equal(proof, want), ("proof", log_n)
+        assert rt.verify(proof) == so.verify(proof), "verdicts"
         # random programs need not satisfy the AIR (e.g. a write to R0's shadow is impossible, but flags are data-driven): the
         # verifier's verdict must at least be the same for both provers' (identical) words
         n_proof += 1

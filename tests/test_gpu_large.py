@@ -71,7 +71,7 @@ def test_config2_fib_2p24_trace_commit_proof():
     tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib = rt.lib()
-    pl._check(lib.zkir_main_trace_launch(C.byref(trace_c), n, m.data_ptr(), sp))
+    pl._check(lib.zkir_main_trace_launch(C.byref(trace_c), n, 0, m.data_ptr(), sp))
     cols_m = {c: m[c].cpu().numpy().view(np.uint32) for c in (0, 21)}             # cycle, r4 limb 0 (LDE clobbers m)
     pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), stark.W_MAIN, L.data_ptr(), sp))
     pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), stark.W_MAIN, 2 * n, tree.data_ptr(), sp))
@@ -96,14 +96,12 @@ def test_config2_fib_2p24_trace_commit_proof():
     torch.cuda.empty_cache()
 
     # ---- full proof of the 2^24-row run, accepted by the oracle verifier; its trace root is the commitment above ----
-    out, n_words = C.POINTER(C.c_uint32)(), C.c_uint64()
-    pl._check(lib.zkir_prove(ctx.handle, C.byref(trace_c), n, C.byref(out), C.byref(n_words), None, sp))
-    proof = np.ctypeslib.as_array(out, shape=(n_words.value,)).copy()
-    lib.zkir_proof_free(out)
-    assert so.verify(proof) == 0
-    assert proof[2] == k and np.array_equal(proof[6:10], root)
+    pub = res.public_inputs()
+    proof = stark.prove(ctx, trace_c, pub)
+    assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0                   # the product's verifier and the oracle's
+    assert proof[2] == k and proof[7] == n and np.array_equal(proof[21:25], root)
     t = proof.copy(); t[len(t) // 3] = (int(t[len(t) // 3]) + 1) % P
-    assert so.verify(t) != 0
+    assert so.verify(t) != 0 and rt.verify(t) == so.verify(t)
     ctx.close(); res.close()
 
 

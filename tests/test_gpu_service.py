@@ -13,22 +13,25 @@ def test_prove_many_matches_sequential_and_verifies():
     from zkir_amd import pipeline as pl, service, stark
     k = 10
     cfg = rt.VMConfig(max_cycles=1 << k, enable_execution_trace=True)
-    jobs = [(spec.fib_endless_program().to_bytes(), [], cfg), (spec.sha256_chain_program().to_bytes(), [], cfg)] * 4
+    ragged = rt.VMConfig(max_cycles=(1 << k) - 123, enable_execution_trace=True)             # pads to the same 2^k
+    jobs = [(spec.fib_endless_program().to_bytes(), [], cfg), (spec.sha256_chain_program().to_bytes(), [], ragged)] * 4
     rep = service.prove_many(jobs, k, producers=3)
-    assert rep.runs == 8 and len(rep.proofs) == 8 and rep.rows == 8 << k
+    assert rep.runs == 8 and len(rep.proofs) == 8 and rep.rows == 4 * ((2 << k) - 123)
     ctx = stark.StarkContext(k)
     for (blob, inputs, c), proof in zip(jobs[:2], rep.proofs[:2]):
         log = rt.interpret(blob, inputs, c)
         ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
-        assert np.array_equal(stark.prove(ctx, tr), proof)
+        pub = rt.public_inputs(log, blob, inputs)
+        assert np.array_equal(stark.prove(ctx, tr, pub), proof)
+        assert rt.verify(proof, pub) == 0
     ctx.close()
-    assert all(so.verify(p) == 0 for p in rep.proofs)
+    assert all(so.verify(p) == 0 and rt.verify(p) == 0 for p in rep.proofs)
     assert np.array_equal(rep.proofs[0], rep.proofs[2]) and not np.array_equal(rep.proofs[0], rep.proofs[1])     # job order kept
 
 
 def test_prove_many_reports_bad_jobs():
     from zkir_amd import service
     k = 8
-    short = rt.VMConfig(max_cycles=100, enable_execution_trace=True)             # 100 rows, not 2^8
+    short = rt.VMConfig(max_cycles=100, enable_execution_trace=True)             # 100 rows pad to 2^7, the context is for 2^8
     with pytest.raises(rt.RuntimeError):
         service.prove_many([(spec.fib_endless_program().to_bytes(), [], short)], k, producers=1)

@@ -41,7 +41,7 @@ def test_lde_matches_oracle(log_n):
     ctx.close()
 
 
-@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (10, 17)])
+@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 152), (10, 17)])
 def test_merkle_matches_oracle(log_n, width):
     import torch
     from zkir_amd import stark
@@ -60,7 +60,7 @@ def test_merkle_and_lde_extreme_values(fill):
     """Worst cases for the lazy (unreduced) arithmetic of the hash and NTT kernels: every input at the top of the range."""
     import torch
     from zkir_amd import stark
-    log_n, width = 9, 89
+    log_n, width = 9, 152
     n = 1 << log_n
     mat = np.zeros((width, n), dtype=np.uint32)
     if fill == "p-1":
@@ -79,43 +79,56 @@ def test_merkle_and_lde_extreme_values(fill):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,log_n", [("fib", 6), ("fib", 10), ("fib", 12), ("sha", 9), ("deferred", 8)])
-def test_main_trace_and_commit_match_oracle(name, log_n):
+PROGRAMS = {"fib": (spec.fib_endless_program, {}), "sha": (spec.sha256_chain_program, {}), "deferred": (spec.fib_endless_program, {"enable_deferred_model": True}),
+            "fib30": (lambda: spec.fib_program(30), {}), "exit42": (lambda: spec.Program.from_code([spec.addi(10, 0, 0), spec.addi(11, 0, 42), spec.ecall()]), {})}
+
+
+def _case(name, n):
+    """(blob, cfg, device trace, oracle rows, oracle public inputs, product public inputs) of program `name` run for at most n cycles."""
+    from zkir_amd import pipeline as pl
+    mk, cfg = PROGRAMS[name]
+    blob = mk().to_bytes()
+    kw = dict(max_cycles=n) if n else {}
+    log = rt.interpret(blob, [], rt.VMConfig(enable_execution_trace=True, **kw, **cfg))
+    ddl = pl.upload(log)
+    tr = pl.DeviceTrace(ddl)
+    pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    res = oracle.run(blob, enable_execution_trace=True, **kw, **cfg)
+    deferred = bool(cfg.get("enable_deferred_model"))
+    opub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=deferred)
+    return blob, log, tr, res.rows, opub, rt.public_inputs(log, blob, [], deferred)
+
+
+@pytest.mark.parametrize("name,n", [("fib", 64), ("fib", 1024), ("fib", 4096), ("fib", 1000), ("fib", 5), ("sha", 512), ("sha", 700), ("deferred", 256),
+                                    ("fib30", None), ("exit42", None)])
+def test_main_trace_and_commit_match_oracle(name, n):
+    """All 152 columns of the padded main trace, the LDE and the commitment root, for power-of-two and ragged row counts and for
+    programs that halt on their own (Exit / padding rows)."""
     from zkir_amd import stark
-    n = 1 << log_n
-    cfg = {}
-    if name == "fib":
-        blob = spec.fib_endless_program().to_bytes()
-    elif name == "sha":
-        blob = spec.sha256_chain_program().to_bytes()
-    else:
-        blob, cfg = spec.fib_endless_program().to_bytes(), {"enable_deferred_model": True}
-    log, tr = _device_trace(blob, n, **cfg)
-    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg).rows
-    want_m = so.main_trace(rows)
-    got_m = stark.main_trace(tr).cpu().numpy().view(np.uint32)
-    assert np.array_equal(got_m, want_m)
-    ctx = stark.StarkContext(log_n)
-    root, L, tree = stark.commit_trace(ctx, tr)
-    want_root, want_L = so.commit_trace(rows, 1, want_lde=True)
+    blob, log, tr, rows, opub, pub = _case(name, n)
+    assert pub.n_real == len(rows) == opub.n_real
+    want_m = so.main_trace(rows, opub)
+    got_m = stark.main_trace(tr, deferred=bool(opub.deferred)).cpu().numpy().view(np.uint32)
+    assert got_m.shape == want_m.shape
+    for k in range(want_m.shape[0]):
+        assert np.array_equal(got_m[k], want_m[k]), f"main-trace column {k}"
+    ctx = stark.StarkContext(stark.padded_log_n(len(rows)))
+    root, L, tree = stark.commit_trace(ctx, tr, deferred=bool(opub.deferred))
+    want_root, want_L = so.commit_trace(rows, 1, want_lde=True, pub=opub)
     assert np.array_equal(L.cpu().numpy().view(np.uint32), want_L)
     assert np.array_equal(root, want_root)
-    ctx.close()
+    ctx.close(); log.close()
 
 
 def test_commit_2p16_root_and_properties():
-    """A larger size (oracle still finishes in seconds): root equality + LDE agrees with the trace polynomial on H."""
+    """A larger size (oracle still finishes in seconds): root equality + Merkle path of a random leaf recomputed with the oracle's hash."""
     from zkir_amd import stark
-    log_n = 16
+    log_n = 15
     n = 1 << log_n
-    blob = spec.fib_endless_program().to_bytes()
-    log, tr = _device_trace(blob, n)
+    blob, log, tr, rows, opub, pub = _case("fib", n)
     ctx = stark.StarkContext(log_n)
-    m = stark.main_trace(tr)
     root, L, tree = stark.commit_trace(ctx, tr)
-    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
-    assert np.array_equal(root, so.commit_trace(rows, 1))
-    # Merkle path of a random leaf recomputed with the oracle's hash
+    assert np.array_equal(root, so.commit_trace(rows, 1, pub=opub))
     Lh = L.cpu().numpy().view(np.uint32)
     t = tree.cpu().numpy().view(np.uint32)
     j, off, mm = 54321, 0, 2 * n
@@ -126,28 +139,21 @@ def test_commit_2p16_root_and_properties():
         node = so.compress(node, sib) if j % 2 == 0 else so.compress(sib, node)
         off += 4 * mm; mm //= 2; j //= 2
     assert np.array_equal(node, root)
-    ctx.close()
+    ctx.close(); log.close()
 
 
-@pytest.mark.parametrize("name,log_n", [("fib", 3), ("fib", 5), ("fib", 8), ("fib", 11), ("sha", 9), ("deferred", 10), ("fib", 13)])
-def test_proof_bytes_match_oracle_and_verify(name, log_n):
-    """End-to-end proof (quotient, openings, DEEP, FRI, queries): GPU proof words == oracle proof words, and the oracle's
-    verifier accepts them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on coefficients."""
+@pytest.mark.parametrize("name,n", [("fib", 8), ("fib", 5), ("fib", 32), ("fib", 256), ("fib", 2048), ("fib", 1500), ("sha", 512), ("sha", 300), ("deferred", 1024),
+                                    ("fib30", None), ("exit42", None), ("fib", 8192)])
+def test_proof_bytes_match_oracle_and_verify(name, n):
+    """End-to-end proof (quotient over the v1 AIR, openings, DEEP, FRI, grinding, queries): GPU proof words == oracle proof words,
+    and both verifiers accept them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on
+    coefficients; the GPU's constraint list is air.h, the oracle's its own."""
     from zkir_amd import stark
-    n = 1 << log_n
-    cfg = {}
-    if name == "fib":
-        blob = spec.fib_endless_program().to_bytes()
-    elif name == "sha":
-        blob = spec.sha256_chain_program().to_bytes()
-    else:
-        blob, cfg = spec.fib_endless_program().to_bytes(), {"enable_deferred_model": True}
-    log, tr = _device_trace(blob, n, **cfg)
-    ctx = stark.StarkContext(log_n)
-    proof, ms = stark.prove(ctx, tr, want_stage_ms=True)
-    assert so.verify(proof) == 0
-    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg).rows
-    want = so.prove(rows)
+    blob, log, tr, rows, opub, pub = _case(name, n)
+    ctx = stark.StarkContext(stark.padded_log_n(len(rows)))
+    proof, ms = stark.prove(ctx, tr, pub, want_stage_ms=True)
+    assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0
+    want = so.prove(rows, opub)
     assert len(proof) == len(want)
     if not np.array_equal(proof, want):
         bad = np.nonzero(proof != want)[0]
@@ -156,8 +162,70 @@ def test_proof_bytes_match_oracle_and_verify(name, log_n):
     for pos in (8, 30, len(proof) // 2, len(proof) - 1):
         t = proof.copy()
         t[pos] = (int(t[pos]) + 1) % P
-        assert so.verify(t) != 0
-    ctx.close()
+        assert so.verify(t) != 0 and rt.verify(t) == so.verify(t)
+    assert np.array_equal(stark.prove(ctx, tr, pub), proof)                                 # deterministic
+    ctx.close(); log.close()
+
+
+def test_wrong_execution_is_rejected_on_the_gpu_path():
+    """The GPU prover on a device trace whose values do not follow the program (patched in HBM): the proof it emits is rejected by
+    both verifiers at the constraint check — a wrong ADD result, a wrong branch target."""
+    import torch
+    from zkir_amd import stark
+    blob, log, tr, rows, opub, pub = _case("fib", 256)
+    ctx = stark.StarkContext(8)
+    ops = rows["instruction"] & 0x7F
+    k = int(np.nonzero(ops == 0x00)[0][5])
+    nxt = k + 1 + int(np.nonzero(ops[k + 1:] == 0x00)[0][0])
+    saved = tr.registers[4, k + 1:nxt + 1].clone()
+    tr.registers[4, k + 1:nxt + 1] += 1                                                     # the ADD's result, consistently off by one until r4 is rewritten
+    bad = stark.prove(ctx, tr, pub)
+    assert so.verify(bad, opub) == 10 and rt.verify(bad, pub) == 10
+    tr.registers[4, k + 1:nxt + 1] = saved
+    kb = int(np.nonzero(ops == 0x41)[0][3])
+    saved_pc = tr.pc[kb + 1].clone()
+    tr.pc[kb + 1] = tr.pc[kb] + 4                                                           # BNE taken in the run, fall-through claimed
+    bad = stark.prove(ctx, tr, pub)
+    assert so.verify(bad, opub) == 10 and rt.verify(bad, pub) == 10
+    tr.pc[kb + 1] = saved_pc
+    good = stark.prove(ctx, tr, pub)
+    assert rt.verify(good, pub) == 0 and np.array_equal(good, so.prove(rows, opub))
+    ctx.close(); log.close()
+
+
+def test_two_contexts_prove_concurrently():
+    """No process-wide prover state: two threads, two contexts, two streams, different runs — proofs identical to the sequential ones."""
+    import threading
+    import torch
+    from zkir_amd import stark
+    cases = [_case("fib", 4096), _case("sha", 3000)]
+    ctxs = [stark.StarkContext(12), stark.StarkContext(12)]
+    want = [stark.prove(c, cs[2], cs[5]) for c, cs in zip(ctxs, cases)]
+    got = [[None] * 6 for _ in cases]
+    errs = []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            for r in range(6):
+                with torch.cuda.stream(s):
+                    got[i][r] = stark.prove(ctxs[i], cases[i][2], cases[i][5], stream=s)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for r in range(6):
+            assert np.array_equal(got[i][r], want[i]), (i, r)
+        assert rt.verify(want[i], cases[i][5]) == 0
+    for c in ctxs:
+        c.close()
 
 
 def test_row_sharded_commitment_matches_oracle():
@@ -190,16 +258,17 @@ def test_row_sharded_commitment_matches_oracle():
 
 @pytest.mark.parametrize("log_n", [16, 18])
 def test_proof_large_verifies(log_n):
-    """Larger than the oracle prover comfortably handles: the oracle VERIFIER (cheap) accepts the GPU proof.  2^18 rows is the
+    """Larger than the oracle prover comfortably handles: both VERIFIERS (cheap) accept the GPU proof.  2^18 rows is the
     smallest size whose FRI schedule has an 8-to-1 layer hashed by the one-permutation-per-lane kernel (> 2^14 leaves), and whose
-    Merkle trees use the per-level kernel, both subtree modes and the quad-lane permutation."""
+    Merkle trees use the per-level kernel, both subtree modes and the quad-lane permutation.  One row short of the power of two:
+    the last row is padding."""
     from zkir_amd import stark
-    log, tr = _device_trace(spec.fib_endless_program().to_bytes(), 1 << log_n)
+    blob, log, tr, rows, opub, pub = _case("fib", (1 << log_n) - 1)
     ctx = stark.StarkContext(log_n)
-    proof = stark.prove(ctx, tr)
-    assert so.verify(proof) == 0
-    assert proof[2] == log_n and proof[3] == 89
-    ctx.close()
+    proof = stark.prove(ctx, tr, pub)
+    assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0
+    assert proof[2] == log_n and proof[3] == 152 and proof[7] == (1 << log_n) - 1
+    ctx.close(); log.close()
 
 
 def _fpow(a, e):
@@ -238,17 +307,20 @@ def test_full_size_2p20_properties():
     * LDE: the column interpolant evaluated at a random point from the N trace values on H equals the one evaluated from the
       2N LDE values on the coset g<w_2N> (both by the barycentric formula, numpy on the host);
     * Merkle: random leaves re-hashed with the oracle's sponge and walked up their paths with the oracle's compression reach the root;
-    * proof: the oracle's verifier accepts the GPU proof."""
-    from zkir_amd import stark
+    * proof: both verifiers accept the GPU proof."""
+    from zkir_amd import pipeline as pl, stark
     log_n = 20
     n = 1 << log_n
-    log, tr = _device_trace(spec.fib_endless_program().to_bytes(), n)
+    blob = spec.fib_endless_program().to_bytes()
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    pub = rt.public_inputs(log, blob)
     ctx = stark.StarkContext(log_n)
     m = stark.main_trace(tr).cpu().numpy().view(np.uint32)
     root, L, tree = stark.commit_trace(ctx, tr)
     Lh, t = L.cpu().numpy().view(np.uint32), tree.cpu().numpy().view(np.uint32)
     rng = np.random.default_rng(20)
-    for col in (0, 1, 9, 21, 76):                                   # cycle, pc limb, r0 limb (all zero), r4 limb, a changed flag
+    for col in (0, 1, 9, 21, 76, 124, 130):                         # cycle, pc limb, r0 limb (all zero), r4 limb, a write selector, y limb, a class flag
         z = int(rng.integers(2, P))
         assert _bary_eval(m[col], log_n, 1, z) == _bary_eval(Lh[col], log_n + 1, 31, z), col
     for j in rng.integers(0, 2 * n, 6):
@@ -260,6 +332,8 @@ def test_full_size_2p20_properties():
             node = so.compress(node, sib) if j % 2 == 0 else so.compress(sib, node)
             off += 4 * mm; mm //= 2; j //= 2
         assert np.array_equal(node, root)
-    proof = stark.prove(ctx, tr)
-    assert so.verify(proof) == 0
-    ctx.close()
+    del L, tree, Lh, t
+    proof = stark.prove(ctx, tr, pub)
+    assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0
+    assert np.array_equal(proof[21:25], root)
+    ctx.close(); log.close()

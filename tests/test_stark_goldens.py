@@ -1,0 +1,61 @@
+"""Frozen goldens of the self-defined prover stages (tests/golden/stark_goldens.json, written by make_stark_goldens.py without the
+product package): the CPU oracle and — on the GPU box — the HIP prover must reproduce the commitment roots and the SHA-256 of every
+proof word.  A change to the field, the Poseidon2 instance, the main-trace columns, the AIR, the transcript, FRI or the proof layout
+shows up here first, and can only land together with a deliberate regeneration of the JSON."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import api as oracle, stark_api as so
+from zkir_amd import runtime as rt, spec
+
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stark_goldens.json")))
+CASES = {c["name"]: c for c in G["cases"]}
+
+
+def test_goldens_describe_the_shipped_programs():
+    """The fixture's blobs are the workloads the product ships (encoded there independently, from the reference's bit layout)."""
+    assert bytes.fromhex(CASES["fib_2p10"]["program_blob_hex"]) == spec.fib_endless_program().to_bytes()
+    assert bytes.fromhex(CASES["sha_2p9"]["program_blob_hex"]) == spec.sha256_chain_program().to_bytes()
+    assert bytes.fromhex(CASES["fib30_exit_154_rows"]["program_blob_hex"]) == spec.fib_program(30).to_bytes()
+    assert G["proof_version"] == 3 and G["main_trace_width"] == so.W_MAIN == 152 and G["num_constraints"] == so.lib().so_num_constraints()
+    assert [int(x) for x in so.permute(list(range(12)))] == G["poseidon2_of_0_to_11"]
+    st = np.arange(12, dtype=np.uint32)
+    rt.lib().zkir_poseidon2_permute(st.ctypes.data)                                  # the product's host permutation
+    assert [int(x) for x in st] == G["poseidon2_of_0_to_11"]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_goldens(name):
+    c = CASES[name]
+    blob = bytes.fromhex(c["program_blob_hex"])
+    res = oracle.run(blob, max_cycles=c["max_cycles"], enable_execution_trace=True, enable_deferred_model=c["deferred"])
+    assert len(res.rows) == c["n_rows"] and [int(x) for x in res.outputs] == c["outputs"] and [res.halt_kind, res.halt_code] == c["halt"]
+    pub = so.public_inputs(len(res.rows), blob, [], c["outputs"], tuple(c["halt"]), deferred=c["deferred"])
+    assert [int(x) for x in pub.prog] == c["program_digest"] and [int(x) for x in pub.io] == c["io_digest"]
+    proof = so.prove(res.rows, pub)
+    assert [int(x) for x in proof[21:25]] == c["trace_root"] and [int(x) for x in proof[25:29]] == c["quotient_root"]
+    assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
+    assert rt.verify(proof) == 0                                                      # the product's verifier accepts the frozen proofs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_prover_reproduces_goldens(name):
+    from zkir_amd import stark
+    c = CASES[name]
+    blob = bytes.fromhex(c["program_blob_hex"])
+    cfg = rt.VMConfig(max_cycles=c["max_cycles"], enable_execution_trace=True, enable_deferred_model=c["deferred"])
+    res = rt.VM(blob, [], cfg).run()
+    assert res.cycles == c["n_rows"] and list(res.outputs) == c["outputs"]
+    pub = res.public_inputs()
+    assert list(pub.program_digest) == c["program_digest"] and list(pub.io_digest) == c["io_digest"]
+    ctx = stark.StarkContext(stark.padded_log_n(res.cycles))
+    proof = stark.prove(ctx, res.execution_trace.columns, pub)
+    assert [int(x) for x in proof[21:25]] == c["trace_root"] and [int(x) for x in proof[25:29]] == c["quotient_root"]
+    assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
+    assert rt.verify(proof, pub) == 0
+    ctx.close(); res.close()

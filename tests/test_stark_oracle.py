@@ -141,30 +141,77 @@ def test_merkle_layers_and_paths():
     assert np.array_equal(node, root)
 
 
+# column map of the v1 main trace (oracle/stark_oracle.cpp)
+C_PC, C_OP, C_FA, C_LIMB, C_STATE, C_WR, C_SELB, C_SELC, C_XB, C_XC, C_Y, C_K, C_T, C_S, C_C0, C_D0, C_DL0, C_NE, C_IV, C_TK = \
+    1, 4, 5, 9, 57, 73, 88, 103, 118, 121, 124, 127, 134, 139, 141, 143, 146, 147, 148, 151
+K_ADD, K_ADDI, K_BNE, K_JAL, K_OTH, K_HALT, K_PAD = range(7)
+W = so.W_MAIN
+
+
 def test_main_trace_columns_and_commit():
     blob = spec.fib_endless_program().to_bytes()
-    rows = oracle.run(blob, max_cycles=64, enable_execution_trace=True).rows
-    m = so.main_trace(rows)
-    assert m.shape == (89, 64) and (m < P).all()
-    assert list(m[0]) == list(range(64))
-    assert np.array_equal(m[1], rows["pc"] & 0xFFFFF) and not m[3].any()
-    assert np.array_equal(m[4], rows["instruction"] & 0x7F)
-    assert np.array_equal(m[9 + 3 * 4], rows["registers"][:, 4] & 0xFFFFF)
-    # changed flags: content of the register triple differs in the next row
-    ch4 = m[73 + 4]
-    nxt = (rows["registers"][1:, 4] != rows["registers"][:-1, 4]) | (rows["bound_bits"][1:, 4] != rows["bound_bits"][:-1, 4])
-    assert np.array_equal(ch4[:-1].astype(bool), nxt) and ch4[-1] == 0
-    root, L = so.commit_trace(rows, 1, want_lde=True)
-    assert L.shape == (89, 128)
+    n = 50                                                       # not a power of two: 14 padding rows
+    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
+    pub = so.public_inputs(n, blob)
+    m = so.main_trace(rows, pub)
+    assert m.shape == (152, 64) and (m < P).all()
+    assert list(m[0]) == list(range(64))                         # the cycle column keeps counting through the padding
+    assert np.array_equal(m[1][:n], rows["pc"] & 0xFFFFF) and not m[3].any()
+    assert np.array_equal(m[C_OP][:n], rows["instruction"] & 0x7F)
+    assert np.array_equal(m[C_LIMB + 3 * 4][:n], rows["registers"][:, 4] & 0xFFFFF)
+    cls = m[C_K:C_K + 7]
+    assert (cls.sum(axis=0) == 1).all()
+    assert cls[K_PAD][n:].all() and cls[K_HALT][n - 1] == 1 and cls[K_HALT].sum() == 1 and not cls[K_PAD][:n].any()
+    ops = rows["instruction"][:n - 1] & 0x7F
+    for k, code in ((K_ADD, 0x00), (K_ADDI, 0x08), (K_BNE, 0x41), (K_JAL, 0x48)):
+        assert np.array_equal(cls[k][:n - 1].astype(bool), ops == code)
+    assert not cls[K_OTH].any()                                  # the fib loop is made of the four constrained opcodes only
+    # wr = one-hot of rd on writing rows; y = the value the next row shows in rd
+    for i in range(n - 1):
+        w = rows["instruction"][i]
+        rd = (int(w) >> 7) & 0xF
+        wr = m[C_WR:C_WR + 15, i]
+        if cls[K_BNE][i] or rd == 0:
+            assert not wr.any()
+        else:
+            assert wr.sum() == 1 and wr[rd - 1] == 1
+            v = int(rows["registers"][i + 1, rd])
+            assert [int(m[C_Y + l, i]) for l in range(3)] == [v & 0xFFFFF, (v >> 20) & 0xFFFFF, v >> 40]
+    # padding rows repeat the state of the last executed row
+    assert (m[C_LIMB:C_STATE + 16, n:] == m[C_LIMB:C_STATE + 16, n - 1:n]).all() and (m[C_PC:C_PC + 3, n:] == m[C_PC:C_PC + 3, n - 1:n]).all()
+    root, L = so.commit_trace(rows, 1, want_lde=True, pub=pub)
+    assert L.shape == (152, 128)
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
 
 
+def test_air_holds_row_by_row_on_honest_traces():
+    """Every constraint vanishes on every (row, next row) pair of an honest main trace: evaluated here with the row selectors a
+    verifier would use ON the trace domain (is_first = [i == 0], is_last = [i == n_real - 1], is_trans = [i != N - 1])."""
+    for prog, n, cfg in ((spec.fib_endless_program(), 50, {}), (spec.sha256_chain_program(), 200, {}), (spec.fib_program(12), None, {}),
+                         (spec.fib_endless_program(), 40, {"enable_deferred_model": True})):
+        blob = prog.to_bytes()
+        res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
+        rows = res.rows
+        pub = so.public_inputs(len(rows), blob, deferred=bool(cfg))
+        m = so.main_trace(rows, pub)
+        N = m.shape[1]
+        alpha = np.array([7, 11, 13, 17], np.uint32)
+        for i in range(N):
+            out = so.constraints_eval(m[:, i], m[:, (i + 1) % N], int(i == 0), int(i == len(rows) - 1), int(i != N - 1), pub, alpha)
+            assert not out.any(), (i, len(rows))
+
+
 # ---- stage B: prover + verifier ------------------------------------------------------------------------------------
-def _rows(n, prog="fib", **cfg):
+def _run(n, prog="fib", **cfg):
     blob = (spec.fib_endless_program() if prog == "fib" else spec.sha256_chain_program()).to_bytes()
-    return oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg).rows
+    res = oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg)
+    return res.rows, so.public_inputs(len(res.rows), blob, deferred=bool(cfg.get("enable_deferred_model")))
+
+
+def _rows(n, prog="fib", **cfg):
+    return _run(n, prog, **cfg)[0]
 
 
 def _fri_schedule(log_n, log_final=3, log_arity=3):
@@ -177,29 +224,61 @@ def _fri_schedule(log_n, log_final=3, log_arity=3):
     return ks
 
 
-@pytest.mark.parametrize("log_n,prog", [(3, "fib"), (4, "fib"), (5, "fib"), (7, "fib"), (8, "fib"), (9, "sha"), (10, "fib")])
-def test_prove_verify_roundtrip(log_n, prog):
-    pr = so.prove(_rows(1 << log_n, prog))
+HDR = 21          # header words before the trace root
+NQ = 50
+
+
+@pytest.mark.parametrize("n,prog", [(8, "fib"), (16, "fib"), (5, "fib"), (100, "fib"), (256, "fib"), (300, "sha"), (1024, "fib")])
+def test_prove_verify_roundtrip(n, prog):
+    rows, pub = _run(n, prog)
+    pr = so.prove(rows, pub)
+    log_n = so.padded_log_n(n)
     ks = _fri_schedule(log_n)                                                              # [1], [1,1], [1,2], [1,3,1], [1,3,2], [1,3,3], [1,3,3,1]
-    assert pr[1] == 2 and pr[6 + 8 + (2 * 89 + 4) * 4] == len(ks)                          # proof version, number of committed FRI layers
+    assert pr[1] == 3 and pr[HDR + 8 + (2 * W + 4) * 4] == len(ks)                         # proof version, number of committed FRI layers
     depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
-    per_query = 1 + 2 * (89 + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
-    assert len(pr) == 6 + 8 + (2 * 89 + 4) * 4 + 1 + 4 * len(ks) + 4 * 8 + 24 * per_query
-    assert pr[0] == 0x46504B5A and pr[2] == log_n and pr[3] == 89 and pr[4] == 24
-    assert (pr[6:] < P).all()
-    assert so.verify(pr) == 0
+    per_query = 1 + 2 * (W + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
+    assert len(pr) == HDR + 8 + (2 * W + 4) * 4 + 1 + 4 * len(ks) + 4 * 8 + 1 + NQ * per_query
+    assert pr[0] == 0x46504B5A and pr[2] == log_n and pr[3] == W and pr[4] == NQ and pr[6] == 12 and pr[7] == n
+    assert (pr[2:] < P).all()
+    assert so.verify(pr) == 0 and so.verify(pr, pub) == 0
     assert so.verify(pr[:-1]) != 0 and so.verify(np.concatenate([pr, [0]])) != 0           # length is checked
-    rng = np.random.default_rng(log_n)
-    for pos in rng.integers(6, len(pr), 40):                                               # any single-word change is rejected
+    rng = np.random.default_rng(n)
+    for pos in list(range(7, HDR)) + [int(x) for x in rng.integers(HDR, len(pr), 40)]:     # any single-word change is rejected, public inputs included
         t = pr.copy()
         t[pos] = (int(t[pos]) + 1 + int(rng.integers(0, 1000))) % P
         if t[pos] != pr[pos]:
             assert so.verify(t) != 0, pos
 
 
+def test_public_inputs_are_bound():
+    """The header carries (rows, mode, entry pc, program digest, io digest); the transcript absorbs it before anything else, and a
+    verifier that expects other public inputs rejects."""
+    blob = spec.fib_program(12).to_bytes()
+    res = oracle.run(blob, enable_execution_trace=True)
+    pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code))
+    pr = so.prove(res.rows, pub)
+    assert so.verify(pr, pub) == 0
+    other_prog = so.public_inputs(len(res.rows), spec.fib_program(13).to_bytes(), [], list(res.outputs), (res.halt_kind, res.halt_code))
+    other_out = so.public_inputs(len(res.rows), blob, [], [999], (res.halt_kind, res.halt_code))
+    other_halt = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (2, 0))
+    for e in (other_prog, other_out, other_halt):
+        assert so.verify(pr, e) == 6
+    a, b = so.prove(res.rows, pub), so.prove(res.rows, other_out)                          # same trace, other claimed outputs: different challenges throughout
+    assert np.array_equal(a[HDR:HDR + 4], b[HDR:HDR + 4]) and not np.array_equal(a[HDR + 4:HDR + 8], b[HDR + 4:HDR + 8])
+
+
+def test_proof_of_work_nonce():
+    rows, pub = _run(32)
+    pr = so.prove(rows, pub)
+    log_n, ks = 5, _fri_schedule(5)
+    at = HDR + 8 + (2 * W + 4) * 4 + 1 + 4 * len(ks) + 4 * 8
+    t = pr.copy(); t[at] = (int(t[at]) + 1) % P
+    assert so.verify(t) in (12, 20)                              # another nonce: the grinding check (or, if it happens to pass, the query indices) fails
+
+
 def test_quotient_is_low_degree_and_fri_layers_fold():
     n = 64
-    so.prove(_rows(n))
+    so.prove(*_run(n))
     Q = so.last_quotient(n)
     for i in range(4):                                                                     # degree < N: upper half of the coset-coefficients vanish
         c = so.ntt(Q[i], inverse=True)
@@ -213,26 +292,99 @@ def test_quotient_is_low_degree_and_fri_layers_fold():
 
 
 def test_invalid_traces_are_rejected():
-    rows = _rows(64).copy()
-    rows["cycle"][30] = 77                                   # cycle counter must increase by one
-    assert so.verify(so.prove(rows)) == 10
-    rows = _rows(64).copy()
-    rows["registers"][:, 0] = 1                              # R0 is hard-wired zero
-    assert so.verify(so.prove(rows)) == 10
-    rows = _rows(64).copy()
-    rows["reg_state"][10, 3] = 2                             # storage state is boolean
-    assert so.verify(so.prove(rows)) == 10
-    rows = _rows(64).copy()
-    rows["cycle"] += 5                                       # first row must be cycle 0
-    assert so.verify(so.prove(rows)) == 10
+    def rejected(mutate, n=64):
+        rows, pub = _run(n)
+        rows = rows.copy()
+        mutate(rows)
+        return so.verify(so.prove(rows, pub)) == 10
+    assert rejected(lambda r: r["cycle"].__setitem__(30, 77))                  # cycle counter must increase by one
+    assert rejected(lambda r: r["registers"].__setitem__((slice(None), 0), 1))  # R0 is hard-wired zero
+    assert rejected(lambda r: r["reg_state"].__setitem__((10, 3), 2))          # storage state is boolean
+    assert rejected(lambda r: r["cycle"].__iadd__(5))                          # first row must be cycle 0
+    assert rejected(lambda r: r["registers"].__setitem__((0, 5), 3))           # registers start at zero (state.rs:55-71)
+    assert rejected(lambda r: r["pc"].__iadd__(8))                             # row 0 is at the entry point
+
+
+def test_wrong_execution_is_rejected():
+    """What the v0 AIR could not see (VERDICT r1 'missing' 1): a trace whose register VALUES or control flow do not follow the
+    program.  Every mutation keeps the trace internally 'continuous' (the wrong value persists until the next write)."""
+    rows0, pub = _run(64)
+    ops = rows0["instruction"] & 0x7F
+
+    def proof_of(rows):
+        return so.verify(so.prove(rows, pub))
+    # ADD r4, r1, r2 at some row k: its result, visible from row k+1 until r4 is written again, is off by one
+    k = int(np.nonzero(ops == 0x00)[0][2])
+    nxt = k + 1 + int(np.nonzero(ops[k + 1:] == 0x00)[0][0])
+    rows = rows0.copy(); rows["registers"][k + 1:nxt + 1, 4] += 1
+    assert proof_of(rows) == 10
+    # ADDI r3, r3, -1: the counter does not decrement
+    k = int(np.nonzero((ops == 0x08) & (((rows0["instruction"] >> 7) & 0xF) == 3))[0][3])
+    nxt = k + 1 + int(np.nonzero((ops[k + 1:] == 0x08) & (((rows0["instruction"][k + 1:] >> 7) & 0xF) == 3))[0][0])
+    rows = rows0.copy(); rows["registers"][k + 1:nxt + 1, 3] = rows["registers"][k, 3]
+    assert proof_of(rows) == 10
+    # a write lands in the wrong register (r5 instead of rd)
+    k = int(np.nonzero(ops == 0x00)[0][1])
+    rows = rows0.copy(); rows["registers"][k + 1:, 5] = 123
+    assert proof_of(rows) == 10
+    # BNE taken, but the next row continues at pc + 4 (and stays consistent afterwards: every later pc shifted the same way)
+    k = int(np.nonzero(ops == 0x41)[0][1])
+    rows = rows0.copy(); rows["pc"][k + 1] = rows["pc"][k] + 4
+    assert proof_of(rows) == 10
+    # JAL r0, -20 lands somewhere else
+    rows1, pub1 = _run(64, "sha")
+    k = int(np.nonzero((rows1["instruction"] & 0x7F) == 0x48)[0][0])
+    rows = rows1.copy(); rows["pc"][k + 1] += 4
+    assert so.verify(so.prove(rows, pub1)) == 10
+    # one instruction word replaced by another opcode's while the registers still follow the original program
+    k = int(np.nonzero(ops == 0x00)[0][2])
+    rows = rows0.copy(); rows["instruction"][k] = (int(rows["instruction"][k]) & ~0x7F) | 0x01      # ADD -> SUB ("other": unconstrained value, so accepted ...)
+    assert proof_of(rows) == 0                                   # ... which is the documented gap: nothing ties the word at pc to the program yet (DESIGN §8.5)
+
+
+def test_cheating_prover_matrices_are_rejected():
+    """A prover that submits its own main-trace matrix: relabelling a constrained opcode as 'other', freeing the write selector,
+    lying about an operand, or skipping rows by early padding."""
+    rows, pub = _run(40)
+    m0 = so.main_trace(rows, pub)
+    assert so.verify(so.prove_matrix(m0, pub)) == 0
+    ops = rows["instruction"] & 0x7F
+    k = int(np.nonzero(ops == 0x00)[0][2])
+
+    def bad(edit):
+        m = m0.copy(); edit(m)
+        return so.verify(so.prove_matrix(m, pub)) == 10
+
+    def relabel(m):                                              # ADD row claims to be "other" to escape the addition constraint
+        m[C_K + K_ADD, k] = 0; m[C_K + K_OTH, k] = 1
+    assert bad(relabel)
+
+    def relabel_with_t5(m):                                      # ... and forges the non-membership witness as well
+        relabel(m); m[C_T + 4, k] = 1
+    assert bad(relabel_with_t5)
+    assert bad(lambda m: m.__setitem__((C_WR + 6, k), 1))        # a second written register
+    assert bad(lambda m: m.__setitem__((C_XB, k), (int(m[C_XB, k]) + 1) % P))          # operand not the register selected by field b
+    assert bad(lambda m: m.__setitem__((C_SELB + 2, k), 1))      # selector not one-hot
+
+    def wrong_sum(m):                                            # y off by one, and the next rows consistently show the wrong value
+        nxt = k + 1 + int(np.nonzero(ops[k + 1:] == 0x00)[0][0])
+        m[C_Y, k] = (int(m[C_Y, k]) + 1) % P
+        m[C_LIMB + 3 * 4, k + 1:nxt + 1] = (m[C_LIMB + 3 * 4, k + 1:nxt + 1].astype(np.int64) + 1) % P
+    assert bad(wrong_sum)
+
+    def early_pad(m):                                            # stop executing at row 20: halt there, padding afterwards
+        m[C_K:C_K + 7, 20:] = 0; m[C_K + K_HALT, 20] = 1; m[C_K + K_PAD, 21:] = 1
+        m[1:C_K, 21:] = m[1:C_K, 20:21]; m[C_WR:C_WR + 15, 20:] = 0; m[C_Y:C_Y + 3, 20:] = 0; m[C_C0:C_C0 + 5, 20:] = 0; m[C_TK, 20:] = 0
+    assert bad(early_pad)                                        # the public row count pins the halt row (is_last)
 
 
 def test_transcript_binds_everything():
-    a = so.prove(_rows(32))
+    a = so.prove(*_run(32))
     al, ze, ga = so.last_challenges()
-    rows = _rows(32).copy()
+    rows, pub = _run(32)
+    rows = rows.copy()
     rows["pc"][7] ^= 4
-    b = so.prove(rows)
+    b = so.prove(rows, pub)
     al2, ze2, ga2 = so.last_challenges()
     assert not np.array_equal(al, al2) and not np.array_equal(ze, ze2) and not np.array_equal(ga, ga2)
-    assert not np.array_equal(a[6:10], b[6:10])              # trace roots differ
+    assert not np.array_equal(a[HDR:HDR + 4], b[HDR:HDR + 4])    # trace roots differ

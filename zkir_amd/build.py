@@ -13,9 +13,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzkir_amd.so")
 OBJ = os.path.join(HERE, "build")
 
-HOST_SOURCES = ["interp.cpp", "hashes.cpp"]
+HOST_SOURCES = ["interp.cpp", "hashes.cpp", "verify.cpp"]
 HIP_SOURCES = ["trace_fill.hip", "witness.hip", "ntt.hip", "stark.hip", "abi.hip"]
-HEADERS = ["host.h", "babybear.h", "poseidon2.h", "stark_prove.inl", os.path.join("..", "..", "include", "zkir_amd.h")]
+HEADERS = ["host.h", "babybear.h", "poseidon2.h", "air.h", "stark_prove.inl", os.path.join("..", "..", "include", "zkir_amd.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

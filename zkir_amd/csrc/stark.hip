@@ -1,11 +1,12 @@
-// stark.hip — self-defined prover stages over Baby Bear on gfx950 ("ZKIR-STARK v0").
+// stark.hip — self-defined prover stages over Baby Bear on gfx950 ("ZKIR-STARK v1").
 //
 // The reference has none of this (parity unpinned); the spec is oracle/stark_oracle.cpp and every
 // kernel here is checked bit-for-bit against it.  Stage A (this part): main-trace field columns, Poseidon2-12 Merkle commitment
 // (the coset LDE between them lives in ntt.hip).
 //
-//   main_trace_kernel   372 B/row SoA trace -> 89 Baby Bear columns (limbs of pc / instruction fields / registers, state and
-//                       "changed" flags).  HBM-bound: ~744 B read (row + next row, second read L2-hot) + 356 B written per row.
+//   main_trace_kernel   372 B/row SoA trace -> the 152 Baby Bear columns of the v1 AIR (air.h: limbs of pc / instruction fields /
+//                       registers, storage state, write and operand selectors, operands, result, opcode classes, carries),
+//                       padded to a power of two.  HBM-bound: ~170 B read (values + states of the row and the next) + 608 B written per row.
 //   (NTT / coset LDE kernels: ntt.hip)
 //   merkle kernels      Poseidon2 width-12 sponge over the rows of the LDE matrix (one lane per leaf, column reads coalesced
 //                       across lanes) + 2-to-1 compression layers.  ALU-bound (≈740 Montgomery multiplications per permutation);
@@ -14,10 +15,12 @@
 
 #include <array>
 #include <cstddef>
+#include <memory>
 #include <mutex>
 #include <vector>
 
 #include "../../include/zkir_amd.h"
+#include "air.h"
 #include "babybear.h"
 #include "host.h"
 #include "poseidon2.h"
@@ -25,7 +28,6 @@
 namespace {
 
 constexpr int NT = 256;
-__constant__ p2::Consts d_p2;
 
 inline unsigned grid_for(uint64_t n, int per = NT) { return (unsigned)((n + per - 1) / per); }
 int check_launch(const char* what) {
@@ -39,30 +41,105 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits =
 // ------------------------------------------------------------------------------------------------
 // main trace columns (oracle: so::main_trace)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, uint64_t n, uint32_t* __restrict__ out) {
+// Montgomery-free helpers for the witness columns (canonical values in and out)
+__device__ __forceinline__ uint32_t f_inv(uint32_t a) {          // a^(p-2), canonical; 0 -> 0
+  uint32_t r = bb::R1, b = bb::to_mont(a), e = bb::P - 2;
+  while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; }
+  return bb::from_mont(r);
+}
+__device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
+  const int bits = st ? 30 : 20;
+  const uint64_t mask = (1ull << bits) - 1;
+  out[0] = (uint32_t)(v & mask); out[1] = (uint32_t)((v >> bits) & mask); out[2] = (uint32_t)(v >> (2 * bits));
+}
+
+// One thread per (padded) row; every column write is coalesced across lanes.  Rows >= n_real are padding: they repeat the last
+// executed row's state with class "pad" and keep counting cycles.  Mirrors so::main_trace of the oracle word for word.
+__global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t deferred, uint32_t* __restrict__ out) {
+  using namespace air;
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= n) return;
-  auto col = [&](int k) -> uint32_t& { return out[(uint64_t)k * n + i]; };
-  col(0) = (uint32_t)(t.cycle[i] % bb::P);
-  const uint64_t pc = t.pc[i];
-  col(1) = (uint32_t)(pc & 0xFFFFF); col(2) = (uint32_t)((pc >> 20) & 0xFFFFF); col(3) = (uint32_t)(pc >> 40);
-  const uint32_t w = t.instruction[i];
-  col(4) = w & 0x7F; col(5) = (w >> 7) & 0xF; col(6) = (w >> 11) & 0xF; col(7) = (w >> 15) & 0xF; col(8) = w >> 19;
-  const bool last = i + 1 >= n;
+  if (i >= N) return;
+  auto col = [&](int k) -> uint32_t& { return out[(uint64_t)k * N + i]; };
+  const bool pad = i >= n_real, last = i + 1 >= n_real;
+  const uint64_t src = pad ? n_real - 1 : i;
+  col(C_CYCLE) = (uint32_t)((pad ? i : t.cycle[src]) % bb::P);
+  const uint64_t pcv = t.pc[src];
+  const uint32_t pc[3] = {(uint32_t)(pcv & 0xFFFFF), (uint32_t)((pcv >> 20) & 0xFFFFF), (uint32_t)(pcv >> 40)};
+  col(C_PC) = pc[0]; col(C_PC + 1) = pc[1]; col(C_PC + 2) = pc[2];
+  const uint32_t w = t.instruction[src];
+  const uint32_t op = w & 0x7F, fa = (w >> 7) & 0xF, fb = (w >> 11) & 0xF, fc = (w >> 15) & 0xF, fhi = w >> 19, s = w >> 31;
+  col(C_OP) = op; col(C_FA) = fa; col(C_FB) = fb; col(C_FC) = fc; col(C_FHI) = fhi; col(C_S) = s;
+  int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
+  if (cls == K_OTH && !deferred) cls = op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : op == OP_BNE ? K_BNE : op == OP_JAL ? K_JAL : K_OTH;
+#pragma unroll
+  for (int k = 0; k < 7; k++) col(C_K + k) = cls == k;
+  {
+    const uint32_t opm = bb::to_mont(op);
+    const uint32_t t1 = bb::mont_mul(opm, bb::sub(op, 8)), t2 = bb::mont_mul(bb::to_mont(bb::sub(op, OP_BNE)), bb::sub(op, OP_JAL));   // mont(a R, b) = a b
+    const uint32_t t3 = bb::mont_mul(bb::to_mont(t1), t2), inv = f_inv(t3);
+    col(C_T) = t1; col(C_T + 1) = t2; col(C_T + 2) = t3; col(C_T + 3) = inv; col(C_T + 4) = bb::mont_mul(bb::to_mont(t3), inv);
+  }
+  const uint32_t tc = cls == K_BNE ? fa : fc;
+  uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
+  bool first = true;
 #pragma unroll 4
   for (int g = 0; g < 16; g++) {
-    const uint64_t o = (uint64_t)g * t.reg_stride + i;
+    const uint64_t o = (uint64_t)g * t.reg_stride + src;
     const uint64_t v = t.registers[o];
     const uint32_t st = t.reg_state[o];
-    const int bits = st ? 30 : 20;
-    const uint64_t mask = (1ull << bits) - 1;
-    col(9 + 3 * g) = (uint32_t)(v & mask); col(10 + 3 * g) = (uint32_t)((v >> bits) & mask); col(11 + 3 * g) = (uint32_t)(v >> (2 * bits));
-    col(57 + g) = st;
-    uint32_t ch = 0;
-    if (!last) ch = (t.registers[o + 1] != v) | (t.reg_state[o + 1] != st) | (t.bound_bits[o + 1] != t.bound_bits[o]) | (t.bound_tag[o + 1] != t.bound_tag[o]) |
-                    (t.bound_payload[o + 1] != t.bound_payload[o]);
-    col(73 + g) = ch;
+    uint32_t limb[3];
+    reg_limbs(v, st, limb);
+    col(C_LIMB + 3 * g) = limb[0]; col(C_LIMB + 3 * g + 1) = limb[1]; col(C_LIMB + 3 * g + 2) = limb[2];
+    col(C_STATE + g) = st;
+    if (g == 0) continue;
+    col(C_SELB + g - 1) = fb == (uint32_t)g; col(C_SELC + g - 1) = tc == (uint32_t)g;
+    if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
+    if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
+    uint32_t wr = 0;
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL) wr = fa == (uint32_t)g;
+    else if (cls == K_OTH) {                                     // any other instruction: what it wrote is read off the next row
+      uint32_t nl[3];
+      const uint32_t nst = t.reg_state[o + 1];
+      reg_limbs(t.registers[o + 1], nst, nl);
+      if (nl[0] != limb[0] || nl[1] != limb[1] || nl[2] != limb[2] || nst != st) {
+        wr = 1;
+        if (first && !deferred) { y[0] = nl[0]; y[1] = nl[1]; y[2] = nl[2]; first = false; }
+      }
+    }
+    col(C_WR + g - 1) = wr;
   }
+  col(C_XB) = xb[0]; col(C_XB + 1) = xb[1]; col(C_XB + 2) = xb[2];
+  col(C_XC) = xc[0]; col(C_XC + 1) = xc[1]; col(C_XC + 2) = xc[2];
+  uint32_t ne = 0, iv[3] = {0, 0, 0};
+#pragma unroll
+  for (int l = 0; l < 3; l++) if (!ne && xb[l] != xc[l]) { ne = 1; iv[l] = f_inv(bb::sub(xb[l], xc[l])); }
+  col(C_NE) = ne; col(C_IV) = iv[0]; col(C_IV + 1) = iv[1]; col(C_IV + 2) = iv[2];
+  const uint32_t tk = cls == K_BNE ? ne : 0;
+  col(C_TK) = tk;
+  const uint32_t imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFFu;
+  const uint32_t lo20 = fb + 16 * fc + 256 * fhi - (s << 20);
+  const uint32_t dl0 = cls == K_JAL ? lo20 : tk ? im0 : 4u;
+  const uint32_t se = (tk || cls == K_JAL) ? s : 0u;
+  col(C_DL0) = dl0; col(C_SE) = se;
+  uint32_t c0 = 0, c1 = 0;
+  if (cls == K_ADD || cls == K_ADDI) {
+    const uint32_t b0 = cls == K_ADD ? xc[0] : im0, b1 = cls == K_ADD ? xc[1] : im1;
+    const uint64_t v0 = (uint64_t)xb[0] + b0; c0 = (uint32_t)(v0 >> 20); y[0] = (uint32_t)(v0 & 0xFFFFF);
+    const uint64_t v1 = (uint64_t)xb[1] + b1 + c0; c1 = (uint32_t)(v1 >> 20); y[1] = (uint32_t)(v1 & 0xFFFFF);
+  } else if (cls == K_JAL) {
+    const uint64_t v0 = (uint64_t)pc[0] + 4; c0 = (uint32_t)(v0 >> 20); y[0] = (uint32_t)(v0 & 0xFFFFF);
+    const uint64_t v1 = (uint64_t)pc[1] + c0; c1 = (uint32_t)(v1 >> 20); y[1] = (uint32_t)(v1 & 0xFFFFF);
+    y[2] = pc[2] + c1;
+  }
+  col(C_Y) = y[0]; col(C_Y + 1) = y[1]; col(C_Y + 2) = y[2];
+  col(C_C0) = c0; col(C_C1) = c1;
+  uint32_t d0 = 0, d1 = 0, d2 = 0;
+  if (cls == K_ADD || cls == K_ADDI || cls == K_BNE || cls == K_JAL) {
+    const uint64_t v0 = (uint64_t)pc[0] + dl0; d0 = (uint32_t)(v0 >> 20);
+    const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; d1 = (uint32_t)(v1 >> 20);
+    const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; d2 = (uint32_t)(v2 >> 24);
+  }
+  col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -81,7 +158,7 @@ __global__ __launch_bounds__(NT) void powers_kernel(uint32_t w, uint32_t scale_m
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 Merkle
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void leaf_hash_kernel(const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint64_t col_stride, uint32_t* __restrict__ digests) {
+__global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint64_t col_stride, uint32_t* __restrict__ digests) {
   const uint64_t j = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (j >= n) return;
   uint32_t s[p2::T];
@@ -91,19 +168,19 @@ __global__ __launch_bounds__(NT) void leaf_hash_kernel(const uint32_t* __restric
 #pragma unroll
     for (int i = 0; i < p2::RATE; i++)
       if (off + i < width) s[i] = bb::to_mont(mat[(uint64_t)(off + i) * col_stride + j]);
-    p2::permute(s, d_p2);
+    p2::permute(s, *cp);
   }
-  if (width == 0) p2::permute(s, d_p2);
+  if (width == 0) p2::permute(s, *cp);
   uint4 d = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
   reinterpret_cast<uint4*>(digests)[j] = d;
 }
 
-__global__ __launch_bounds__(NT) void compress_kernel(const uint32_t* __restrict__ in, uint64_t n_out, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(NT) void compress_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ in, uint64_t n_out, uint32_t* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n_out) return;
   const uint4 l = reinterpret_cast<const uint4*>(in)[2 * i], r = reinterpret_cast<const uint4*>(in)[2 * i + 1];
   uint32_t s[p2::T] = {bb::to_mont(l.x), bb::to_mont(l.y), bb::to_mont(l.z), bb::to_mont(l.w), bb::to_mont(r.x), bb::to_mont(r.y), bb::to_mont(r.z), bb::to_mont(r.w), 0, 0, 0, 0};
-  p2::permute(s, d_p2);
+  p2::permute(s, *cp);
   reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
 }
 
@@ -112,7 +189,7 @@ __global__ __launch_bounds__(NT) void compress_kernel(const uint32_t* __restrict
 // tree buffer.  Small levels are latency-bound (one Poseidon2 permutation is ~1200 dependent instructions deep), so a launch and
 // a global-memory round trip per level cost more than the hashing; this way a tree of <= 2^18 digests needs two launches.
 constexpr uint32_t SUBTREE = 512;
-__global__ __launch_bounds__(NT) void subtree_kernel(uint32_t* __restrict__ cur, uint64_t m, uint32_t per_wg) {
+__global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restrict__ cp, uint32_t* __restrict__ cur, uint64_t m, uint32_t per_wg) {
   __shared__ uint4 buf[SUBTREE];
   const uint32_t t = threadIdx.x;
   uint64_t pos0 = (uint64_t)blockIdx.x * per_wg;
@@ -133,7 +210,7 @@ __global__ __launch_bounds__(NT) void subtree_kernel(uint32_t* __restrict__ cur,
       }
       __syncthreads();                                         // all inputs read before slot t is overwritten
       if (active) {
-        p2::permute(s, d_p2);
+        p2::permute(s, *cp);
         buf[t] = make_uint4(s[0], s[1], s[2], s[3]);
         reinterpret_cast<uint4*>(cur)[pos0 + t] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
       }
@@ -145,7 +222,7 @@ __global__ __launch_bounds__(NT) void subtree_kernel(uint32_t* __restrict__ cur,
       if (active) { s[0] = words[8 * pi + l]; s[1] = words[8 * pi + 4 + l]; }
       __syncthreads();
       if (active) {
-        p2::permute_quad(s, (int)l, d_p2);
+        p2::permute_quad(s, (int)l, *cp);
         reinterpret_cast<uint32_t*>(buf)[4 * pi + l] = s[0];
         cur[4 * (pos0 + pi) + l] = bb::from_mont(s[0]);
       }
@@ -171,17 +248,17 @@ __global__ __launch_bounds__(NT) void modmul_peak_kernel(uint32_t* __restrict__ 
 }
 
 // all levels above the leaf digests: wide levels (throughput-bound) one launch each, then subtree launches
-void launch_tree_levels(uint32_t* leaf_digests, uint64_t n_leaves, hipStream_t s) {
+void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n_leaves, hipStream_t s) {
   uint32_t* cur = leaf_digests;
   uint64_t m = n_leaves;
   for (; m > (1u << 18); m >>= 1) {
     uint32_t* nxt = cur + 4 * m;
-    hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cur, m / 2, nxt);
+    hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cp, cur, m / 2, nxt);
     cur = nxt;
   }
   while (m > 1) {
     const uint32_t per = m < SUBTREE ? (uint32_t)m : SUBTREE;
-    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT), 0, s, cur, m, per);
+    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT), 0, s, cp, cur, m, per);
     for (uint32_t c = per; c > 1; c >>= 1) { cur += 4 * m; m >>= 1; }
   }
 }
@@ -199,7 +276,9 @@ struct zkir_stark_ctx {
   uint32_t* d_g_hi = nullptr;     // g^(1024 k)
   uint32_t* d_small_inv = nullptr;  // w_{2^Bm}^-k, k < 2^(Bm-1)      (Bm = min(log_n, 10))
   uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
-  p2::Consts consts;
+  p2::Consts consts;              // host copy (transcript, verifier side)
+  p2::Consts* d_p2 = nullptr;     // device copy: every hash kernel takes the pointer (no process-wide __constant__ state)
+  mutable std::mutex mu;          // a context serves one proof at a time (its workspace arena); different contexts are independent
   // prover workspace: one device allocation made on the first zkir_prove and reused (hipMalloc of GBs costs more than the kernels)
   mutable unsigned char* arena = nullptr;
   mutable size_t arena_size = 0, arena_off = 0;
@@ -207,7 +286,7 @@ struct zkir_stark_ctx {
 
 extern "C" {
 
-uint32_t zkir_main_trace_width(void) { return 89; }
+uint32_t zkir_main_trace_width(void) { return air::W; }
 
 void zkir_poseidon2_permute(uint32_t state[12]) {
   static const p2::Consts consts = [] { p2::Consts c; p2::generate(c); return c; }();
@@ -244,7 +323,8 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
   const uint32_t N = 1u << log_n;
   const uint32_t n_inv = N >= 2 ? N / 2 : 1, n_hi = (N >> 10) + 1;
   p2::generate(c->consts);
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_p2), &c->consts, sizeof(p2::Consts));
+  hipError_t e = hipMalloc((void**)&c->d_p2, sizeof(p2::Consts));
+  if (e == hipSuccess) e = hipMemcpy(c->d_p2, &c->consts, sizeof(p2::Consts), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_inv, (size_t)n_inv * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_fwd, (size_t)N * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_lo, 1024 * 4);
@@ -269,14 +349,17 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
 void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
   (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi);
-  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd);
+  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
 
-int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_rows, uint32_t* out, void* stream) {
-  if (n_rows == 0) return ZKIR_OK;
-  hipLaunchKernelGGL(main_trace_kernel, dim3(grid_for(n_rows)), dim3(NT), 0, (hipStream_t)stream, *trace, n_rows, out);
+uint32_t zkir_padded_log_n(uint64_t n_real) { uint32_t k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
+
+int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* stream) {
+  if (!trace || !out || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
+  hipLaunchKernelGGL(main_trace_kernel, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, deferred, out);
   return check_launch("main_trace");
 }
 
@@ -289,20 +372,18 @@ int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint3
 
 // tree = [leaf digests (4*n)] [layer 1 (4*n/2)] ... [root (4)]  = 4*(2n-1) words; n_leaves a power of two
 int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* stream) {
-  (void)c;
   hipStream_t s = (hipStream_t)stream;
-  if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle: n_leaves must be a power of two"}); return ZKIR_ERR_ARGUMENT; }
-  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, mat, width, n_leaves, n_leaves, tree);
-  launch_tree_levels(tree, n_leaves, s);
+  if (!c || n_leaves == 0 || (n_leaves & (n_leaves - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle: null context, or n_leaves not a power of two"}); return ZKIR_ERR_ARGUMENT; }
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, n_leaves, tree);
+  launch_tree_levels(c->d_p2, tree, n_leaves, s);
   return check_launch("merkle_commit");
 }
 
 // Upper levels over already-computed digests (multi-GPU: the all-gathered subtree roots of the row shards are the leaves of the
 // top log2(G) levels).  tree[0 .. 4n) must hold the n digests; the call fills the remaining 4(n-1) words, root = last 4.
 int zkir_merkle_cap_launch(const zkir_stark_ctx* c, uint32_t* tree, uint64_t n_digests, void* stream) {
-  (void)c;
-  if (n_digests == 0 || (n_digests & (n_digests - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle cap: n_digests must be a power of two"}); return ZKIR_ERR_ARGUMENT; }
-  launch_tree_levels(tree, n_digests, (hipStream_t)stream);
+  if (!c || n_digests == 0 || (n_digests & (n_digests - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle cap: null context, or n_digests not a power of two"}); return ZKIR_ERR_ARGUMENT; }
+  launch_tree_levels(c->d_p2, tree, n_digests, (hipStream_t)stream);
   return check_launch("merkle_cap");
 }
 

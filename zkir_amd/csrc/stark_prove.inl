@@ -9,14 +9,17 @@ namespace {
 
 using bb::E4;
 
-struct ProveParams {            // constants of one proof, Montgomery form, uploaded once per phase
-  E4 alpha_pow[103];
-  E4 gamma_pow[2 * 89 + 4];
-  E4 zeta, zeta_w, a0, b0;
-};
-__constant__ ProveParams d_pp;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, HEADER_WORDS = 21;
+constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 3;
 
-constexpr int NUM_QUERIES = 24, LOG_FINAL = 3, N_CONSTRAINTS = 103, WM = 89, LOG_ARITY = 3;
+struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
+  E4 alpha_pow[N_CONSTRAINTS];
+  E4 gamma_pow[2 * WM + 4];
+  E4 zeta, zeta_w, a0, b0;
+  uint32_t entry_m[3];          // public entry pc limbs
+  uint32_t deferred;
+};
 
 // Folds per committed FRI layer (so::fri_schedule): the DEEP codeword is folded once (its leaves are the pairs (q, q + N) the trace
 // openings determine), later layers 8-to-1 (three binary folds with beta, beta^2, beta^4), the last one as needed to reach 2^LOG_FINAL.
@@ -50,55 +53,60 @@ __device__ __forceinline__ E4 lz_reduce(const LazyE4& acc) {
 }
 
 // ---- quotient: Q(x_j) = (Σ_c alpha^c C_c(x_j)) / Z_H(x_j) on x_j = g w_2N^j;  next row = position j+2 -------------------
-__global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, uint32_t gN_m,
-                                                       uint32_t wn_inv_m, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m, uint32_t* __restrict__ Q) {
+// The constraint list is air::eval (air.h), instantiated here on base-field Montgomery values read straight from the LDE matrix.
+struct QuotientOps {
+  using V = uint32_t;
+  const uint32_t* __restrict__ L; uint64_t N2; uint32_t j, jn; const ProveParams* __restrict__ pp;
+  LazyE4 acc; E4 partial; int pending;
+  __device__ __forceinline__ V add(V a, V b) const { return bb::add(a, b); }
+  __device__ __forceinline__ V sub(V a, V b) const { return bb::sub(a, b); }
+  __device__ __forceinline__ V mul(V a, V b) const { return bb::mont_mul(a, b); }
+  __device__ __forceinline__ V mulc(V a, uint32_t cm) const { return bb::mont_mul(a, cm); }
+  __device__ __forceinline__ V cst(uint32_t cm) const { return cm; }
+  __device__ __forceinline__ V loc(int k) const { return bb::to_mont(L[(uint64_t)k * N2 + j]); }
+  __device__ __forceinline__ V nxt(int k) const { return bb::to_mont(L[(uint64_t)k * N2 + jn]); }
+  __device__ __forceinline__ void push(int idx, V v) {
+    lz_fma(acc, pp->alpha_pow[idx], v);
+    if (++pending == 128) { partial = bb::e_add(partial, lz_reduce(acc)); acc = LazyE4(); pending = 0; }     // 136 terms fit the lazy sum
+  }
+};
+__device__ __forceinline__ uint32_t inv_mont(uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; }
+
+__global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp,
+                                                       uint32_t gN_m, uint32_t wn_inv_m, uint32_t w_last_m, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m,
+                                                       uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
-  const uint32_t jn = (j + 2) & (N2 - 1);
-  auto ld = [&](int k, uint32_t pos) { return bb::to_mont(L[(uint64_t)k * N2 + pos]); };
   // x = g * w_2N^j (Montgomery): w^j = tw[j] for j < N, -tw[j-N] otherwise
   const uint32_t N = N2 >> 1;
   const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
   const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
   const uint32_t one = bb::R1;
   const uint32_t zh = bb::sub((j & 1) ? bb::neg(gN_m) : gN_m, one);                                 // x^N - 1
-  // Z_H takes two values on the coset (x^N = +-g^N): its inverses come from the host; 1/(x - 1) is one exponentiation per point
-  auto inv_m = [](uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; };
+  // Z_H takes two values on the coset (x^N = +-g^N): its inverses come from the host; 1/(x - 1) and 1/(x - w^last) are one
+  // exponentiation each per point
   const uint32_t inv_zh = (j & 1) ? inv_zh_odd_m : inv_zh_even_m;
-  const uint32_t is_first = bb::mont_mul(zh, inv_m(bb::sub(x, one)));
+  const uint32_t is_first = bb::mont_mul(zh, inv_mont(bb::sub(x, one)));
+  const uint32_t is_last = bb::mont_mul(zh, inv_mont(bb::sub(x, w_last_m)));
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
-  LazyE4 acc;                                                                                        // 103 terms
-  int c = 0;
-  const uint32_t cyc = ld(0, j);
-  lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(bb::sub(bb::sub(ld(0, jn), cyc), one), is_trans));
-  lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(cyc, is_first));
-#pragma unroll 1
-  for (int r = 0; r < 16; r++) {
-    const uint32_t st = ld(57 + r, j), ch = ld(73 + r, j);
-    lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(st, bb::sub(st, one)));
-    lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(ch, bb::sub(ch, one)));
-    const uint32_t keep_t = bb::mont_mul(bb::sub(one, ch), is_trans);
-#pragma unroll
-    for (int l = 0; l < 3; l++) lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(9 + 3 * r + l, jn), ld(9 + 3 * r + l, j))));
-    lz_fma(acc, d_pp.alpha_pow[c++], bb::mont_mul(keep_t, bb::sub(ld(57 + r, jn), st)));
-  }
-  lz_fma(acc, d_pp.alpha_pow[c++], ld(9, j)); lz_fma(acc, d_pp.alpha_pow[c++], ld(10, j)); lz_fma(acc, d_pp.alpha_pow[c++], ld(11, j));
-  lz_fma(acc, d_pp.alpha_pow[c++], ld(57, j)); lz_fma(acc, d_pp.alpha_pow[c++], ld(73, j));
-  const E4 q = bb::e_from_mont(bb::e_mul_fm(lz_reduce(acc), inv_zh));
+  QuotientOps o{L, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0};
+  air::eval(o, is_first, is_last, is_trans, pp->entry_m, pp->deferred != 0);
+  const E4 total = bb::e_add(o.partial, lz_reduce(o.acc));
+  const E4 q = bb::e_from_mont(bb::e_mul_fm(total, inv_zh));
 #pragma unroll
   for (int i = 0; i < 4; i++) Q[(uint64_t)i * N2 + j] = q.c[i];
 }
 
 // ---- barycentric weights over the LDE coset: e_j = x_j / (zeta - x_j)  (Montgomery E4, AoS) -------------------------------
 // and dinv_j = 1 / (zeta - x_j), which the DEEP kernel reuses: 1 / (zeta w - x_j) = w^-1 / (zeta - x_{j-2}) on the 2N coset
-__global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const uint32_t* __restrict__ tw_fwd, E4* __restrict__ wts, E4* __restrict__ dinv) {
+__global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp, E4* __restrict__ wts, E4* __restrict__ dinv) {
   const uint32_t N2 = 2u << log_n, N = N2 >> 1;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
   const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
   const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
-  E4 d = d_pp.zeta; d.c[0] = bb::sub(d.c[0], x);
+  E4 d = pp->zeta; d.c[0] = bb::sub(d.c[0], x);
   const E4 di = bb::e_inv_m(d);
   dinv[j] = di;
   wts[j] = bb::e_mul_fm(di, x);
@@ -154,33 +162,32 @@ __global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
 __global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ Q, uint32_t log_n, const E4* __restrict__ dinv,
-                                                   uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
+                                                   const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
   const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
-  LazyE4 A, B;                                                                // 93 and 89 terms; canonical v x Montgomery gamma^k = canonical product
+  // canonical v x Montgomery gamma^k = canonical product; 156 and 152 terms: the lazy sums are folded once on the way (136 terms fit)
+  LazyE4 A, B;
+  E4 Ap = bb::e_zero(), Bp = bb::e_zero();
   // eight column loads in flight per lane (the loop body is long and the compiler keeps it rolled: one load at a time otherwise)
   constexpr int UN = 8;
-  int k = 0;
+  constexpr int FOLD = 80;                                                     // lazy sums are folded after 80 terms; 76 more follow
+  static_assert(WM % UN == 0 && FOLD % UN == 0 && FOLD <= 128 && WM + 4 - FOLD <= 128, "column loop");
 #pragma unroll 1
-  for (; k + UN <= WM; k += UN) {
+  for (int k = 0; k < WM; k += UN) {
     uint32_t v[UN];
 #pragma unroll
     for (int u = 0; u < UN; u++) v[u] = L[(uint64_t)(k + u) * N2 + j];
 #pragma unroll
-    for (int u = 0; u < UN; u++) { lz_fma(A, d_pp.gamma_pow[k + u], v[u]); lz_fma(B, d_pp.gamma_pow[WM + k + u], v[u]); }
-  }
-  for (; k < WM; k++) {
-    const uint32_t v = L[(uint64_t)k * N2 + j];
-    lz_fma(A, d_pp.gamma_pow[k], v);
-    lz_fma(B, d_pp.gamma_pow[WM + k], v);
+    for (int u = 0; u < UN; u++) { lz_fma(A, pp->gamma_pow[k + u], v[u]); lz_fma(B, pp->gamma_pow[WM + k + u], v[u]); }
+    if (k + UN == FOLD) { Ap = lz_reduce(A); Bp = lz_reduce(B); A = LazyE4(); B = LazyE4(); }
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) lz_fma(A, d_pp.gamma_pow[2 * WM + i], Q[(uint64_t)i * N2 + j]);
-  const E4 Am = bb::e_to_mont(lz_reduce(A)), Bm = bb::e_to_mont(lz_reduce(B));
+  for (int i = 0; i < 4; i++) lz_fma(A, pp->gamma_pow[2 * WM + i], Q[(uint64_t)i * N2 + j]);
+  const E4 Am = bb::e_to_mont(bb::e_add(Ap, lz_reduce(A))), Bm = bb::e_to_mont(bb::e_add(Bp, lz_reduce(B)));
   const E4 i1 = dinv[j], i2 = bb::e_mul_fm(dinv[(j + N2 - 2) & (N2 - 1)], wn_inv_m);   // 1/(zeta - x), 1/(zeta w - x)
-  const E4 t1 = bb::e_mul_m(bb::e_sub(d_pp.a0, Am), i1);                      // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
-  const E4 t2 = bb::e_mul_m(bb::e_sub(d_pp.b0, Bm), i2);
+  const E4 t1 = bb::e_mul_m(bb::e_sub(pp->a0, Am), i1);                       // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
+  const E4 t2 = bb::e_mul_m(bb::e_sub(pp->b0, Bm), i2);
   const E4 f = bb::e_from_mont(bb::e_add(t1, t2));
 #pragma unroll
   for (int i = 0; i < 4; i++) cw[(uint64_t)i * N2 + j] = f.c[i];
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L
 
 // ---- FRI: leaf i of a layer of size m folded k times = (c[i + t g])_{t < 2^k}, g = m >> k: 4 * 2^k base elements absorbed
 // eight at a time (two extension values per permutation), as so::hash_elems does ------------------------------------------------
-__global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
+__global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
   const uint64_t g = m >> k, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= g) return;
   uint32_t s[p2::T];
@@ -197,20 +204,20 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const uint32_t* __res
   for (uint32_t u = 0; u < (1u << k); u += 2) {
 #pragma unroll
     for (int t = 0; t < 4; t++) { s[t] = bb::to_mont(c[(uint64_t)t * m + i + u * g]); s[4 + t] = bb::to_mont(c[(uint64_t)t * m + i + (u + 1) * g]); }
-    p2::permute(s, d_p2);
+    p2::permute(s, *cp);
   }
   reinterpret_cast<uint4*>(digests)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
 }
 
 // the same leaf hash with one permutation per quad of lanes (p2::permute_quad): small layers are latency-bound
-__global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
+__global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
   const uint64_t g = m >> k, t = (uint64_t)blockIdx.x * NT + threadIdx.x, i = t >> 2;
   const int l = (int)(t & 3);
   if (i >= g) return;                                                         // whole quads leave together
   uint32_t s[3] = {0, 0, 0};
   for (uint32_t u = 0; u < (1u << k); u += 2) {
     s[0] = bb::to_mont(c[(uint64_t)l * m + i + u * g]); s[1] = bb::to_mont(c[(uint64_t)l * m + i + (u + 1) * g]);
-    p2::permute_quad(s, l, d_p2);
+    p2::permute_quad(s, l, *cp);
   }
   digests[4 * i + l] = bb::from_mont(s[0]);
 }
@@ -246,6 +253,18 @@ __global__ void gather_kernel(const GatherJob* __restrict__ jobs, uint32_t n_job
   for (uint32_t k = threadIdx.x; k < g.count; k += blockDim.x) dst[g.dst + k] = g.src[(uint64_t)k * g.stride];
 }
 
+// ---- proof-of-work grinding: one candidate nonce per lane; the smallest hit wins (deterministic) ------------------------------
+__global__ __launch_bounds__(NT) void pow_grind_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ state_m, uint32_t base, uint32_t* __restrict__ best) {
+  const uint32_t nonce = base + blockIdx.x * NT + threadIdx.x;
+  if (nonce >= bb::P) return;
+  uint32_t s[p2::T];
+#pragma unroll
+  for (int i = 0; i < p2::T; i++) s[i] = state_m[i];
+  s[0] = bb::to_mont(nonce);                                                  // overwrite-absorb of the single pending element
+  p2::permute(s, *cp);
+  if ((bb::from_mont(s[p2::RATE - 1]) & ((1u << POW_BITS) - 1)) == 0) atomicMin(best, nonce);   // sample() takes the last rate element
+}
+
 // ---- host-side duplex challenger (Montgomery state; canonical in/out) -------------------------------------------------------
 struct Challenger {
   const p2::Consts& c;
@@ -258,6 +277,8 @@ struct Challenger {
   uint32_t sample() { if (!in.empty() || out.empty()) duplex(); const uint32_t v = out.back(); out.pop_back(); return v; }
   E4 sample_ext() { E4 e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
   uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
+  void flush() { if (!in.empty()) duplex(); out.clear(); }                    // so::Challenger::flush
+  bool check_pow(uint32_t nonce) { flush(); observe(nonce); return (sample() & ((1u << POW_BITS) - 1)) == 0; }
 };
 
 E4 h_e_mul(const E4& a, const E4& b) { return bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(a), bb::e_to_mont(b))); }   // canonical in/out
@@ -266,46 +287,64 @@ E4 h_e_pow(E4 a, uint64_t e) { E4 r{{1, 0, 0, 0}}; while (e) { if (e & 1) r = h_
 #define HIP_OK(expr)                                                                                         \
   do { hipError_t _e = (expr); if (_e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)}); return ZKIR_ERR_DEVICE; } } while (0)
 
-// Bump allocation out of the context's persistent workspace (reset at the start of every zkir_prove).
-thread_local const zkir_stark_ctx* g_arena_ctx = nullptr;
-struct DevBuf {
-  void* p = nullptr;
-  hipError_t alloc(size_t bytes) {
-    const zkir_stark_ctx* c = g_arena_ctx;
-    const size_t need = (bytes + 255) & ~(size_t)255;
-    if (!c || c->arena_off + need > c->arena_size) return hipErrorOutOfMemory;
-    p = c->arena + c->arena_off;
+// Bump allocation out of the context's persistent workspace (reset at the start of every zkir_prove; the context's mutex is held).
+struct Arena {
+  const zkir_stark_ctx* c;
+  template <typename T> hipError_t take(T** out, size_t count) {
+    const size_t need = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (c->arena_off + need > c->arena_size) return hipErrorOutOfMemory;
+    *out = (T*)(c->arena + c->arena_off);
     c->arena_off += need;
     return hipSuccess;
   }
-  template <typename T> T* as() { return (T*)p; }
 };
+struct StageEvents {             // RAII: released on every return path
+  hipEvent_t ev[9]; bool on = false;
+  hipError_t create() { for (auto& e : ev) { const hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; } on = true; return hipSuccess; }
+  ~StageEvents() { if (on) for (auto& e : ev) (void)hipEventDestroy(e); }
+};
+
+// the 21 header words of a v3 proof (so::header_words): everything both sides know before the first commitment
+void header_words(uint32_t log_n, const zkir_public_inputs& pub, std::vector<uint32_t>& w) {
+  w.clear();
+  w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
+  w.insert(w.end(), {(uint32_t)(pub.n_real & 0x3FFFFFFF), (uint32_t)(pub.n_real >> 30), pub.deferred ? 1u : 0u});
+  w.insert(w.end(), {(uint32_t)(pub.entry_point & 0xFFFFF), (uint32_t)((pub.entry_point >> 20) & 0xFFFFF), (uint32_t)(pub.entry_point >> 40)});
+  w.insert(w.end(), pub.program_digest, pub.program_digest + 4);
+  w.insert(w.end(), pub.io_digest, pub.io_digest + 4);
+}
 
 }  // namespace
 
 extern "C" {
 
 uint32_t zkir_proof_num_queries(void) { return NUM_QUERIES; }
+uint32_t zkir_proof_version(void) { return PROOF_VERSION; }
 
 void zkir_proof_free(uint32_t* proof) { free(proof); }
 
-// Full proof for the trace whose main-trace LDE is produced from `trace` (n_rows = 2^ctx.log_n).  Phases are timed with HIP events
-// when stage_ms != NULL: [0] main trace, [1] LDE, [2] trace Merkle, [3] quotient (+Merkle), [4] openings, [5] DEEP, [6] FRI, [7] queries.
-int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_t n_rows, uint32_t** proof_out, uint64_t* proof_words, float* stage_ms, void* stream) {
-  if (!c || !trace || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
+// Full proof of the run whose K1 output is `trace` (pub->n_real executed rows, padded to 2^ctx.log_n).  Phases are timed with HIP events
+// when stage_ms != NULL: [0] main trace, [1] LDE, [2] trace Merkle, [3] quotient (+Merkle), [4] openings, [5] DEEP, [6] FRI (+grinding), [7] queries.
+int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const zkir_public_inputs* pub, uint32_t** proof_out, uint64_t* proof_words, float* stage_ms,
+               void* stream) {
+  if (!c || !trace || !pub || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
   const uint32_t log_n = c->log_n;
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
-  if (n_rows != N || log_n < (uint32_t)LOG_FINAL) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: n_rows must equal 2^log_n of the context (>= 8)"}); return ZKIR_ERR_ARGUMENT; }
+  if (pub->n_real == 0 || zkir_padded_log_n(pub->n_real) != log_n || pub->entry_point >= (1ull << 40)) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the context's log_n must be zkir_padded_log_n(n_real) (n_real >= 1), and entry_point < 2^40"});
+    return ZKIR_ERR_ARGUMENT;
+  }
+  for (int i = 0; i < 4; i++)
+    if (pub->program_digest[i] >= bb::P || pub->io_digest[i] >= bb::P) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: digests must be canonical field elements"}); return ZKIR_ERR_ARGUMENT; }
   hipStream_t s = (hipStream_t)stream;
-  // The per-proof challenges live in __constant__ memory (d_pp) and the context's workspace is a single arena: proofs are
-  // serialised per process.  Everything before this entry point (zkir_exec, trace fill, witness kernels, LDE, Merkle) is re-entrant.
-  static std::mutex prove_mu;
-  std::lock_guard<std::mutex> prove_lock(prove_mu);
+  // One proof at a time per context (its workspace arena); proofs on different contexts run concurrently: the per-proof constants
+  // live in the arena (no __constant__ / static state).
+  std::lock_guard<std::mutex> ctx_lock(c->mu);
   *proof_out = nullptr; *proof_words = 0;
   const std::vector<int> ks = fri_schedule((int)log_n);
   const int n_layers = (int)ks.size();
 
-  {                                               // workspace: 12 W (M + L) + 320 (trees, quotient, weights, FRI) bytes per row, allocated once per context
+  {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     const size_t want = (size_t)(12 * WM + 440) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
@@ -314,69 +353,76 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
       c->arena_size = want;
     }
     c->arena_off = 0;
-    g_arena_ctx = c;
   }
-  DevBuf dM, dL, dTree, dQ, dQTree, dW, dDinv, dPart, dJobs, dOut;
-  std::vector<DevBuf> fri_trees(n_layers), fri_layers(n_layers + 1);
-  HIP_OK(dM.alloc(WM * N * 4)); HIP_OK(dL.alloc(WM * N2 * 4)); HIP_OK(dTree.alloc(4 * (2 * N2 - 1) * 4));
-  HIP_OK(dQ.alloc(4 * N2 * 4)); HIP_OK(dQTree.alloc(4 * (2 * N2 - 1) * 4)); HIP_OK(dW.alloc(N2 * sizeof(E4))); HIP_OK(dDinv.alloc(N2 * sizeof(E4)));
+  Arena ar{c};
+  uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest;
+  E4 *dW, *dDinv, *dPart;
+  ProveParams* dPP;
+  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4));
+  HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
+  HIP_OK(ar.take(&dQ, 4 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
-  HIP_OK(dPart.alloc((size_t)(WM + 4) * n_chunks * 2 * sizeof(E4)));
+  HIP_OK(ar.take(&dPart, (size_t)(WM + 4) * n_chunks * 2));
+  std::vector<uint32_t*> fri_trees(n_layers), fri_layers(n_layers + 1);
 
-  hipEvent_t ev[9];
-  if (stage_ms) for (auto& e : ev) HIP_OK(hipEventCreate(&e));
-  auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(ev[i], s); };
+  StageEvents se;
+  if (stage_ms) HIP_OK(se.create());
+  auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(se.ev[i], s); };
 
   // ---- 1. main trace, LDE, trace commitment ---------------------------------------------------------------------------------
   mark(0);
-  int rc = zkir_main_trace_launch(trace, N, dM.as<uint32_t>(), s); if (rc) return rc;
+  int rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s); if (rc) return rc;
   mark(1);
-  rc = zkir_lde_launch(c, dM.as<uint32_t>(), WM, dL.as<uint32_t>(), s); if (rc) return rc;
+  rc = zkir_lde_launch(c, dM, WM, dL, s); if (rc) return rc;
   mark(2);
-  rc = zkir_merkle_commit_launch(c, dL.as<uint32_t>(), WM, N2, dTree.as<uint32_t>(), s); if (rc) return rc;
+  rc = zkir_merkle_commit_launch(c, dL, WM, N2, dTree, s); if (rc) return rc;
   uint32_t troot[4], qroot[4];
-  HIP_OK(hipMemcpyAsync(troot, dTree.as<uint32_t>() + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   mark(3);
+  std::vector<uint32_t> head;
+  header_words(log_n, *pub, head);
   Challenger ch(c->consts);
-  ch.observe(log_n); ch.observe(WM); ch.observe(NUM_QUERIES); ch.observe(LOG_FINAL);
+  ch.observe_n(head.data() + 2, head.size() - 2);
   ch.observe_n(troot, 4);
   const E4 alpha = ch.sample_ext();
 
   // ---- 2. quotient ------------------------------------------------------------------------------------------------------------
-  static ProveParams pp;                          // host staging (proofs are serialised per process; the ABI is single-proof-at-a-time per ctx)
+  std::unique_ptr<ProveParams> pp(new ProveParams());     // host staging of this proof's constants
   {
     E4 a{{1, 0, 0, 0}};
-    for (int k = 0; k < N_CONSTRAINTS; k++) { pp.alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
-    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp, sizeof(pp.alpha_pow), offsetof(ProveParams, alpha_pow), hipMemcpyHostToDevice, s));
+    for (int k = 0; k < N_CONSTRAINTS; k++) { pp->alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
+    pp->entry_m[0] = bb::to_mont((uint32_t)(pub->entry_point & 0xFFFFF)); pp->entry_m[1] = bb::to_mont((uint32_t)((pub->entry_point >> 20) & 0xFFFFF));
+    pp->entry_m[2] = bb::to_mont((uint32_t)(pub->entry_point >> 40)); pp->deferred = pub->deferred ? 1 : 0;
+    HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
   }
-  const uint32_t gN_m = bb::to_mont(bb::pow(bb::GEN, N)), wn_inv_m = bb::to_mont(bb::inv(bb::root_of_unity((int)log_n)));
-  const uint32_t gN = bb::pow(bb::GEN, N);
+  const uint32_t wn = bb::root_of_unity((int)log_n);
+  const uint32_t gN = bb::pow(bb::GEN, N), gN_m = bb::to_mont(gN), wn_inv_m = bb::to_mont(bb::inv(wn)), w_last_m = bb::to_mont(bb::pow(wn, pub->n_real - 1));
   const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
-  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), log_n, c->d_tw_fwd, gN_m, wn_inv_m, inv_zh_even_m, inv_zh_odd_m, dQ.as<uint32_t>());
-  rc = zkir_merkle_commit_launch(c, dQ.as<uint32_t>(), 4, N2, dQTree.as<uint32_t>(), s); if (rc) return rc;
-  HIP_OK(hipMemcpyAsync(qroot, dQTree.as<uint32_t>() + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, log_n, c->d_tw_fwd, dPP, gN_m, wn_inv_m, w_last_m, inv_zh_even_m, inv_zh_odd_m, dQ);
+  rc = zkir_merkle_commit_launch(c, dQ, 4, N2, dQTree, s); if (rc) return rc;
+  HIP_OK(hipMemcpyAsync(qroot, dQTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   mark(4);
   ch.observe_n(qroot, 4);
   const E4 zeta = ch.sample_ext();
-  const E4 zeta_w = bb::E4{{bb::mul(zeta.c[0], bb::root_of_unity((int)log_n)), bb::mul(zeta.c[1], bb::root_of_unity((int)log_n)),
-                            bb::mul(zeta.c[2], bb::root_of_unity((int)log_n)), bb::mul(zeta.c[3], bb::root_of_unity((int)log_n))}};
+  const E4 zeta_w = bb::E4{{bb::mul(zeta.c[0], wn), bb::mul(zeta.c[1], wn), bb::mul(zeta.c[2], wn), bb::mul(zeta.c[3], wn)}};
 
   // ---- 3. openings by barycentric evaluation over the LDE coset ------------------------------------------------------------
-  pp.zeta = bb::e_to_mont(zeta); pp.zeta_w = bb::e_to_mont(zeta_w);
-  HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.zeta, 2 * sizeof(E4), offsetof(ProveParams, zeta), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dW.as<E4>(), dDinv.as<E4>());
+  pp->zeta = bb::e_to_mont(zeta); pp->zeta_w = bb::e_to_mont(zeta_w);
+  HIP_OK(hipMemcpyAsync(&dPP->zeta, &pp->zeta, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dPP, dW, dDinv);
   constexpr int CG = 4;
-  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, (WM + CG - 1) / CG), dim3(NT), 0, s, dL.as<uint32_t>(), N2, (uint32_t)WM, dW.as<E4>(), dPart.as<E4>(), n_chunks);
-  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, 1), dim3(NT), 0, s, dQ.as<uint32_t>(), N2, 4u, dW.as<E4>(), dPart.as<E4>() + (size_t)WM * n_chunks * 2, n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, (WM + CG - 1) / CG), dim3(NT), 0, s, dL, N2, (uint32_t)WM, dW, dPart, n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks);
   std::vector<E4> part((size_t)(WM + 4) * n_chunks * 2);
-  HIP_OK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(part.data(), dPart, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   std::vector<E4> t_z(WM), t_zw(WM), q_z(4);
   {
     // scale = ((z/g)^2N - 1) / (2N);  for z = zeta*w the factor is the same because w^(2N) = 1
-    const E4 zg = bb::E4{{bb::mul(zeta.c[0], bb::inv(bb::GEN)), bb::mul(zeta.c[1], bb::inv(bb::GEN)), bb::mul(zeta.c[2], bb::inv(bb::GEN)), bb::mul(zeta.c[3], bb::inv(bb::GEN))}};
+    const uint32_t ginv = bb::inv(bb::GEN);
+    const E4 zg = bb::E4{{bb::mul(zeta.c[0], ginv), bb::mul(zeta.c[1], ginv), bb::mul(zeta.c[2], ginv), bb::mul(zeta.c[3], ginv)}};
     E4 sc = h_e_pow(zg, N2); sc.c[0] = bb::sub(sc.c[0], 1);
     const uint32_t inv2n = bb::inv((uint32_t)(N2 % bb::P));
     for (int t = 0; t < 4; t++) sc.c[t] = bb::mul(sc.c[t], inv2n);
@@ -398,18 +444,18 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   {
     E4 g{{1, 0, 0, 0}}, a0 = bb::e_zero(), b0 = bb::e_zero();
     for (int k = 0; k < 2 * WM + 4; k++) {
-      pp.gamma_pow[k] = bb::e_to_mont(g);
+      pp->gamma_pow[k] = bb::e_to_mont(g);
       if (k < WM) a0 = bb::e_add(a0, h_e_mul(g, t_z[k]));
       else if (k < 2 * WM) b0 = bb::e_add(b0, h_e_mul(g, t_zw[k - WM]));
       else a0 = bb::e_add(a0, h_e_mul(g, q_z[k - 2 * WM]));
       g = h_e_mul(g, gamma);
     }
-    pp.a0 = bb::e_to_mont(a0); pp.b0 = bb::e_to_mont(b0);
-    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.gamma_pow, sizeof(pp.gamma_pow), offsetof(ProveParams, gamma_pow), hipMemcpyHostToDevice, s));
-    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_pp), &pp.a0, 2 * sizeof(E4), offsetof(ProveParams, a0), hipMemcpyHostToDevice, s));
+    pp->a0 = bb::e_to_mont(a0); pp->b0 = bb::e_to_mont(b0);
+    HIP_OK(hipMemcpyAsync(dPP->gamma_pow, pp->gamma_pow, sizeof(pp->gamma_pow), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(&dPP->a0, &pp->a0, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   }
-  HIP_OK(fri_layers[0].alloc(4 * N2 * 4));
-  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL.as<uint32_t>(), dQ.as<uint32_t>(), log_n, dDinv.as<E4>(), wn_inv_m, fri_layers[0].as<uint32_t>());
+  HIP_OK(ar.take(&fri_layers[0], 4 * N2));
+  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dQ, log_n, dDinv, dPP, wn_inv_m, fri_layers[0]);
   mark(6);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
@@ -421,24 +467,24 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
     for (int j = 0; j < n_layers; j++) {
       const int k = ks[j];
       const uint64_t m = 1ull << log_m, g = m >> k;
-      HIP_OK(fri_trees[j].alloc(4 * (2 * g - 1) * 4));
-      uint32_t* tree = fri_trees[j].as<uint32_t>();
-      if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, (uint32_t)k, tree);
-      else hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j].as<uint32_t>(), m, (uint32_t)k, tree);
-      launch_tree_levels(tree, g, s);
+      HIP_OK(ar.take(&fri_trees[j], 4 * (2 * g - 1)));
+      uint32_t* tree = fri_trees[j];
+      if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
+      else hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
+      launch_tree_levels(c->d_p2, tree, g, s);
       HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * g - 2), 16, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
       ch.observe_n(lroots[j].data(), 4);
       betas[j] = ch.sample_ext();
       E4 beta = betas[j];
-      const uint32_t* src = fri_layers[j].as<uint32_t>();
+      const uint32_t* src = fri_layers[j];
       for (int f = 0; f < k; f++, log_m--) {                                   // k binary folds: beta^(2^f), shift^(2^f)
         const uint64_t h = (1ull << log_m) >> 1;
-        DevBuf dst;
-        HIP_OK(dst.alloc(4 * h * 4));
+        uint32_t* dst;
+        HIP_OK(ar.take(&dst, 4 * h));
         const uint32_t half_shift_inv_m = bb::to_mont(bb::inv(bb::mul(2, shift)));
-        hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(h)), dim3(NT), 0, s, src, (uint32_t)log_m, log_n + 1, c->d_tw_fwd, bb::e_to_mont(beta), half_shift_inv_m, dst.as<uint32_t>());
-        src = dst.as<uint32_t>();
+        hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(h)), dim3(NT), 0, s, src, (uint32_t)log_m, log_n + 1, c->d_tw_fwd, bb::e_to_mont(beta), half_shift_inv_m, dst);
+        src = dst;
         if (f == k - 1) fri_layers[j + 1] = dst;
         shift = bb::mul(shift, shift);
         beta = h_e_mul(beta, beta);
@@ -447,16 +493,28 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   }
   const uint64_t fin_n = 1ull << LOG_FINAL;
   uint32_t fin_cols[4 * 8];
-  HIP_OK(hipMemcpyAsync(fin_cols, fri_layers[n_layers].p, 4 * fin_n * 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(fin_cols, fri_layers[n_layers], 4 * fin_n * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
-  mark(7);
   for (uint64_t i = 0; i < fin_n; i++) for (int t = 0; t < 4; t++) ch.observe(fin_cols[t * fin_n + i]);
+  // grinding: smallest nonce whose absorption makes the next squeezed element end in POW_BITS zero bits (so::Challenger::grind)
+  uint32_t pow_nonce = 0xFFFFFFFFu;
+  {
+    ch.flush();
+    HIP_OK(hipMemcpyAsync(dState, ch.st, sizeof(ch.st), hipMemcpyHostToDevice, s));
+    const uint32_t batch = 1u << 18;
+    for (uint64_t base = 0; base < bb::P && pow_nonce == 0xFFFFFFFFu; base += batch) {
+      HIP_OK(hipMemsetAsync(dBest, 0xFF, 4, s));
+      hipLaunchKernelGGL(pow_grind_kernel, dim3(batch / NT), dim3(NT), 0, s, c->d_p2, dState, (uint32_t)base, dBest);
+      HIP_OK(hipMemcpyAsync(&pow_nonce, dBest, 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+    }
+    if (pow_nonce == 0xFFFFFFFFu || !ch.check_pow(pow_nonce)) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: proof-of-work search failed"}); return ZKIR_ERR_OTHER; }
+  }
+  mark(7);
   std::vector<uint32_t> queries(NUM_QUERIES);
   for (auto& q : queries) q = ch.sample_bits((int)log_n);
 
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
-  std::vector<uint32_t> head;
-  head.insert(head.end(), {0x46504B5Au, 2u, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL});
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WM; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
   for (int k = 0; k < WM; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);
@@ -464,6 +522,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   head.push_back((uint32_t)n_layers);
   for (auto& r : lroots) head.insert(head.end(), r.begin(), r.end());
   for (uint64_t i = 0; i < fin_n; i++) for (int t = 0; t < 4; t++) head.push_back(fin_cols[t * fin_n + i]);
+  head.push_back(pow_nonce);
 
   std::vector<GatherJob> jobs;
   uint32_t off = 0;                                                           // offsets inside the query section
@@ -474,31 +533,31 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_
   };
   for (uint32_t q : queries) {
     qpos.push_back(off); off += 1;
-    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dL.as<uint32_t>() + pos, N2, (uint32_t)WM, off}); off += WM; path_jobs(dTree.as<uint32_t>(), N2, pos); }
-    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ.as<uint32_t>() + pos, N2, 4, off}); off += 4; path_jobs(dQTree.as<uint32_t>(), N2, pos); }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dL + pos, N2, (uint32_t)WM, off}); off += WM; path_jobs(dTree, N2, pos); }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos, N2, 4, off}); off += 4; path_jobs(dQTree, N2, pos); }
     int log_m = (int)log_n + 1;
     for (int j = 0; j < n_layers; log_m -= ks[j], j++) {
       const uint64_t m = 1ull << log_m, g = m >> ks[j], idx = q & (g - 1);
-      for (uint64_t t = 0; t < (1ull << ks[j]); t++) { jobs.push_back({fri_layers[j].as<uint32_t>() + idx + t * g, m, 4, off}); off += 4; }
-      path_jobs(fri_trees[j].as<uint32_t>(), g, idx);
+      for (uint64_t t = 0; t < (1ull << ks[j]); t++) { jobs.push_back({fri_layers[j] + idx + t * g, m, 4, off}); off += 4; }
+      path_jobs(fri_trees[j], g, idx);
     }
   }
-  HIP_OK(dJobs.alloc(jobs.size() * sizeof(GatherJob))); HIP_OK(dOut.alloc((size_t)off * 4));
-  HIP_OK(hipMemcpyAsync(dJobs.p, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)jobs.size()), dim3(64), 0, s, dJobs.as<GatherJob>(), (uint32_t)jobs.size(), dOut.as<uint32_t>());
+  GatherJob* dJobs; uint32_t* dOut;
+  HIP_OK(ar.take(&dJobs, jobs.size())); HIP_OK(ar.take(&dOut, (size_t)off));
+  HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)jobs.size()), dim3(64), 0, s, dJobs, (uint32_t)jobs.size(), dOut);
   const uint64_t total = head.size() + off;
   uint32_t* out = (uint32_t*)malloc(total * 4);
   if (!out) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: out of host memory"}); return ZKIR_ERR_OTHER; }
   memcpy(out, head.data(), head.size() * 4);
-  hipError_t e = hipMemcpyAsync(out + head.size(), dOut.p, (size_t)off * 4, hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(out + head.size(), dOut, (size_t)off * 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess || check_launch("zkir_prove") != ZKIR_OK) { free(out); if (e != hipSuccess) zkir::set_last_error({ZKIR_ERR_DEVICE, hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
   for (size_t t = 0; t < queries.size(); t++) out[head.size() + qpos[t]] = queries[t];
   mark(8);
   if (stage_ms) {
-    (void)hipEventSynchronize(ev[8]);
-    for (int i = 0; i < 8; i++) { (void)hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]); }
-    for (auto& x : ev) (void)hipEventDestroy(x);
+    (void)hipEventSynchronize(se.ev[8]);
+    for (int i = 0; i < 8; i++) (void)hipEventElapsedTime(&stage_ms[i], se.ev[i], se.ev[i + 1]);
   }
   *proof_out = out; *proof_words = total;
   return ZKIR_OK;

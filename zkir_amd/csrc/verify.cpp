@@ -1,0 +1,275 @@
+// verify.cpp — the product's verifier of ZKIR-STARK v1 proofs (format v3) and the public-input helpers; host only, no device.
+//
+// Self-defined stages (the reference has no prover or verifier: SURVEY.md F1 / a17, N4).  Independent of oracle/: Montgomery
+// arithmetic (babybear.h), the product's Poseidon2 (poseidon2.h) and the product's constraint list (air.h, the same template the
+// quotient kernel instantiates); tests/ compare its verdicts with the oracle's so::verify on valid, tampered and cheating proofs.
+// Transcript and proof layout: see zkir_prove (stark_prove.inl) and DESIGN.md §8.8.
+#include <cstring>
+#include <vector>
+
+#include "../../include/zkir_amd.h"
+#include "air.h"
+#include "babybear.h"
+#include "host.h"
+#include "poseidon2.h"
+
+namespace {
+
+using bb::E4;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, HEADER_WORDS = 21;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 3;
+
+const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
+
+// canonical digests / compressions on top of the Montgomery permutation
+void hash_elems(const uint32_t* in, size_t n, uint32_t out[4]) {          // overwrite-mode sponge, rate 8 (so::hash_elems)
+  uint32_t s[p2::T] = {0};
+  for (size_t off = 0; off < n; off += p2::RATE) {
+    const size_t len = n - off < (size_t)p2::RATE ? n - off : (size_t)p2::RATE;
+    for (size_t i = 0; i < len; i++) s[i] = bb::to_mont(in[off + i]);
+    p2::permute(s, consts());
+  }
+  if (n == 0) p2::permute(s, consts());
+  for (int i = 0; i < 4; i++) out[i] = bb::from_mont(s[i]);
+}
+void compress(const uint32_t* l, const uint32_t* r, uint32_t out[4]) {
+  uint32_t s[p2::T] = {0};
+  for (int i = 0; i < 4; i++) { s[i] = bb::to_mont(l[i]); s[4 + i] = bb::to_mont(r[i]); }
+  p2::permute(s, consts());
+  for (int i = 0; i < 4; i++) out[i] = bb::from_mont(s[i]);
+}
+bool check_path(const uint32_t* leaf, size_t idx, const uint32_t* path, int depth, const uint32_t* root) {
+  uint32_t node[4]; memcpy(node, leaf, 16);
+  for (int d = 0; d < depth; d++) { uint32_t nx[4]; if (idx & 1) compress(path + 4 * d, node, nx); else compress(node, path + 4 * d, nx); memcpy(node, nx, 16); idx >>= 1; }
+  return !memcmp(node, root, 16);
+}
+
+struct Challenger {                                                        // duplex sponge, Montgomery state, canonical in / out
+  uint32_t st[p2::T] = {0};
+  std::vector<uint32_t> in, out;
+  void duplex() { for (size_t i = 0; i < in.size(); i++) st[i] = bb::to_mont(in[i]); in.clear(); p2::permute(st, consts()); out.clear(); for (int i = 0; i < p2::RATE; i++) out.push_back(bb::from_mont(st[i])); }
+  void observe(uint32_t x) { out.clear(); in.push_back(x); if ((int)in.size() == p2::RATE) duplex(); }
+  void observe_n(const uint32_t* x, size_t n) { for (size_t i = 0; i < n; i++) observe(x[i]); }
+  uint32_t sample() { if (!in.empty() || out.empty()) duplex(); const uint32_t v = out.back(); out.pop_back(); return v; }
+  E4 sample_ext() { E4 e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
+  uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
+  bool check_pow(uint32_t nonce) { if (!in.empty()) duplex(); out.clear(); observe(nonce); return (sample() & ((1u << POW_BITS) - 1)) == 0; }
+};
+
+std::vector<int> fri_schedule(int log_n) {
+  std::vector<int> ks;
+  for (int log_m = log_n + 1; log_m > LOG_FINAL;) { const int k = ks.empty() ? 1 : (LOG_ARITY < log_m - LOG_FINAL ? LOG_ARITY : log_m - LOG_FINAL); ks.push_back(k); log_m -= k; }
+  return ks;
+}
+
+// E4 helpers on MONTGOMERY values
+inline E4 m_base(uint32_t xm) { return E4{{xm, 0, 0, 0}}; }
+inline E4 m_pow(E4 a, uint64_t e) { E4 r = bb::e_one_m(); while (e) { if (e & 1) r = bb::e_mul_m(r, a); a = bb::e_mul_m(a, a); e >>= 1; } return r; }
+inline bool e_eq(const E4& a, const E4& b) { return !memcmp(a.c, b.c, 16); }
+
+struct VerifierOps {                                                       // air::eval on the openings at zeta (E4, Montgomery)
+  using V = E4;
+  const E4* l; const E4* n; const E4* ap; E4 acc;
+  V add(const V& a, const V& b) const { return bb::e_add(a, b); }
+  V sub(const V& a, const V& b) const { return bb::e_sub(a, b); }
+  V mul(const V& a, const V& b) const { return bb::e_mul_m(a, b); }
+  V mulc(const V& a, uint32_t cm) const { return bb::e_mul_fm(a, cm); }
+  V cst(uint32_t cm) const { return m_base(cm); }
+  V loc(int k) const { return l[k]; }
+  V nxt(int k) const { return n[k]; }
+  void push(int idx, const V& v) { acc = bb::e_add(acc, bb::e_mul_m(ap[idx], v)); }
+};
+
+// binary fold of one pair, Montgomery: (a + b)/2 + beta (a - b) / (2x)
+inline E4 fold_pair(const E4& a, const E4& b, uint32_t x_m, const E4& beta) {
+  const uint32_t half_m = bb::to_mont((bb::P + 1) / 2), two_m = bb::to_mont(2);
+  uint32_t inv = bb::R1, base = bb::mont_mul(two_m, x_m), e = bb::P - 2;
+  while (e) { if (e & 1) inv = bb::mont_mul(inv, base); base = bb::mont_mul(base, base); e >>= 1; }
+  return bb::e_add(bb::e_mul_fm(bb::e_add(a, b), half_m), bb::e_mul_m(beta, bb::e_mul_fm(bb::e_sub(a, b), inv)));
+}
+
+}  // namespace
+
+extern "C" {
+
+void zkir_digest_bytes(const uint8_t* b, size_t n, uint32_t out[4]) {
+  std::vector<uint32_t> e;
+  e.reserve(4 + (n + 1) / 2);
+  for (int i = 0; i < 4; i++) e.push_back((uint32_t)(((uint64_t)n >> (16 * i)) & 0xFFFF));
+  for (size_t i = 0; i < n; i += 2) e.push_back((uint32_t)b[i] | (i + 1 < n ? (uint32_t)b[i + 1] << 8 : 0u));
+  hash_elems(e.data(), e.size(), out);
+}
+
+int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs, uint32_t deferred,
+                          zkir_public_inputs* out) {
+  if (!log || !out || (!blob && blob_len) || (!inputs && n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  if (log->cycle_base != 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: needs the unsharded log of the run"}); return ZKIR_ERR_ARGUMENT; }
+  memset(out, 0, sizeof *out);
+  out->n_real = log->cycles;
+  out->deferred = deferred ? 1 : 0;
+  uint32_t entry = 0x1000;
+  if (blob_len >= 16) memcpy(&entry, blob + 12, 4);                        // ProgramHeader.entry_point, program.rs:189-213
+  out->entry_point = entry;
+  zkir_digest_bytes(blob, blob_len, out->program_digest);
+  std::vector<uint64_t> io;
+  io.push_back(n_inputs); io.insert(io.end(), inputs, inputs + n_inputs);
+  io.push_back(log->outputs.size()); io.insert(io.end(), log->outputs.begin(), log->outputs.end());
+  io.push_back((uint64_t)log->halt_kind); io.push_back(log->halt_kind == ZKIR_HALT_EXIT ? log->halt_code : 0); io.push_back(log->cycles);
+  zkir_digest_bytes((const uint8_t*)io.data(), io.size() * 8, out->io_digest);
+  return ZKIR_OK;
+}
+
+int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect) {
+  if (!w) return 1;
+  size_t p = 0;
+  auto need = [&](size_t k) { return p + k <= len; };
+  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
+  const int log_n = (int)w[2];
+  if (w[3] != (uint32_t)WM || w[4] != (uint32_t)NUM_QUERIES || w[5] != (uint32_t)LOG_FINAL || w[6] != (uint32_t)POW_BITS || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
+  if (w[7] >= (1u << 30) || w[9] > 1 || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
+  zkir_public_inputs pub;
+  memset(&pub, 0, sizeof pub);
+  pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
+  pub.entry_point = (uint64_t)w[10] | ((uint64_t)w[11] << 20) | ((uint64_t)w[12] << 40);
+  memcpy(pub.program_digest, w + 13, 16); memcpy(pub.io_digest, w + 17, 16);
+  if (pub.n_real == 0 || zkir_padded_log_n(pub.n_real) != (uint32_t)log_n) return 2;
+  if (expect && (expect->n_real != pub.n_real || (expect->deferred != 0) != (pub.deferred != 0) || expect->entry_point != pub.entry_point ||
+                 memcmp(expect->program_digest, pub.program_digest, 16) || memcmp(expect->io_digest, pub.io_digest, 16))) return 6;
+  p = HEADER_WORDS;
+  const size_t N = (size_t)1 << log_n;
+  for (size_t i = 2; i < len; i++) if (w[i] >= bb::P) return 3;
+  if (!need(8)) return 4;
+  const uint32_t* troot = w + p; p += 4; const uint32_t* qroot = w + p; p += 4;
+  auto get_m = [&](size_t at) { E4 e; memcpy(e.c, w + at, 16); return bb::e_to_mont(e); };      // proof word -> Montgomery E4
+  if (!need((size_t)(2 * WM + 4) * 4)) return 4;
+  const size_t at_tz = p, at_tzw = p + 4 * (size_t)WM, at_qz = p + 8 * (size_t)WM;
+  std::vector<E4> t_z(WM), t_zw(WM), q_z(4);
+  for (int k = 0; k < WM; k++) { t_z[k] = get_m(at_tz + 4 * k); t_zw[k] = get_m(at_tzw + 4 * k); }
+  for (int i = 0; i < 4; i++) q_z[i] = get_m(at_qz + 4 * i);
+  p += (size_t)(2 * WM + 4) * 4;
+  if (!need(1)) return 4;
+  const int n_layers = (int)w[p++];
+  const std::vector<int> ks = fri_schedule(log_n);
+  if (n_layers != (int)ks.size()) return 5;
+  if (!need((size_t)4 * n_layers + 4 * ((size_t)1 << LOG_FINAL) + 1)) return 4;
+  std::vector<const uint32_t*> lroots(n_layers);
+  for (int j = 0; j < n_layers; j++) { lroots[j] = w + p; p += 4; }
+  const size_t at_fin = p, n_fin = (size_t)1 << LOG_FINAL;
+  std::vector<E4> fin(n_fin);
+  for (size_t i = 0; i < n_fin; i++) { fin[i] = get_m(p); p += 4; }
+  const uint32_t pow_nonce = w[p++];
+  // ---- transcript ----
+  Challenger ch;
+  ch.observe_n(w + 2, HEADER_WORDS - 2);
+  ch.observe_n(troot, 4);
+  const E4 alpha = bb::e_to_mont(ch.sample_ext());
+  ch.observe_n(qroot, 4);
+  const E4 zeta = bb::e_to_mont(ch.sample_ext());
+  ch.observe_n(w + at_tz, (size_t)(2 * WM + 4) * 4);
+  const E4 gamma = bb::e_to_mont(ch.sample_ext());
+  std::vector<E4> betas(n_layers);
+  for (int j = 0; j < n_layers; j++) { ch.observe_n(lroots[j], 4); betas[j] = bb::e_to_mont(ch.sample_ext()); }
+  ch.observe_n(w + at_fin, 4 * n_fin);
+  if (!ch.check_pow(pow_nonce)) return 12;
+  // ---- 1. constraints at zeta: sum_c alpha^c C_c(zeta) == Q(zeta) Z_H(zeta) ----
+  const uint32_t wn = bb::root_of_unity(log_n), wn_m = bb::to_mont(wn);
+  {
+    std::vector<E4> ap(air::N_CONSTRAINTS);
+    ap[0] = bb::e_one_m();
+    for (int c = 1; c < air::N_CONSTRAINTS; c++) ap[c] = bb::e_mul_m(ap[c - 1], alpha);
+    E4 zh = m_pow(zeta, N); zh.c[0] = bb::sub(zh.c[0], bb::R1);
+    E4 d1 = zeta; d1.c[0] = bb::sub(d1.c[0], bb::R1);
+    E4 dl = zeta; dl.c[0] = bb::sub(dl.c[0], bb::to_mont(bb::pow(wn, pub.n_real - 1)));
+    const E4 is_first = bb::e_mul_m(zh, bb::e_inv_m(d1)), is_last = bb::e_mul_m(zh, bb::e_inv_m(dl));
+    E4 is_trans = zeta; is_trans.c[0] = bb::sub(is_trans.c[0], bb::to_mont(bb::inv(wn)));
+    const uint32_t entry_m[3] = {bb::to_mont(w[10]), bb::to_mont(w[11]), bb::to_mont(w[12])};
+    VerifierOps o{t_z.data(), t_zw.data(), ap.data(), bb::e_zero()};
+    air::eval(o, is_first, is_last, is_trans, entry_m, pub.deferred != 0);
+    E4 qz = bb::e_zero();                                                  // Q(zeta) = sum_i X^i q_i(zeta): basis element X^i times the E4 opening
+    for (int i = 0; i < 4; i++) { E4 basis = bb::e_zero(); basis.c[i] = bb::R1; qz = bb::e_add(qz, bb::e_mul_m(basis, q_z[i])); }
+    if (!e_eq(o.acc, bb::e_mul_m(qz, zh))) return 10;
+  }
+  // ---- 2. final codeword has degree < 4: the four upper coefficients of its interpolant over an order-8 coset vanish (the coset
+  //         shift scales coefficient k by shift^-k and cannot make a non-zero one vanish, so a plain size-8 inverse DFT decides) ----
+  {
+    const uint32_t w8inv_m = bb::to_mont(bb::inv(bb::root_of_unity(LOG_FINAL)));
+    for (size_t k = n_fin / 2; k < n_fin; k++) {
+      E4 c = bb::e_zero();
+      uint32_t tw = bb::R1, step = bb::R1;
+      for (size_t t = 0; t < k; t++) step = bb::mont_mul(step, w8inv_m);  // w^-k
+      for (size_t i = 0; i < n_fin; i++) { c = bb::e_add(c, bb::e_mul_fm(fin[i], tw)); tw = bb::mont_mul(tw, step); }
+      if (c.c[0] | c.c[1] | c.c[2] | c.c[3]) return 11;
+    }
+  }
+  // ---- 3. queries ----
+  std::vector<E4> gp(2 * WM + 4);
+  gp[0] = bb::e_one_m();
+  for (size_t k = 1; k < gp.size(); k++) gp[k] = bb::e_mul_m(gp[k - 1], gamma);
+  E4 a0 = bb::e_zero(), b0 = bb::e_zero();
+  for (int k = 0; k < WM; k++) { a0 = bb::e_add(a0, bb::e_mul_m(gp[k], t_z[k])); b0 = bb::e_add(b0, bb::e_mul_m(gp[WM + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = bb::e_add(a0, bb::e_mul_m(gp[2 * WM + i], q_z[i]));
+  const E4 zeta_w = bb::e_mul_fm(zeta, wn_m);
+  const uint32_t w2n = bb::root_of_unity(log_n + 1);
+  const int depth0 = log_n + 1;
+  for (int t = 0; t < NUM_QUERIES; t++) {
+    const uint32_t q = ch.sample_bits(log_n);
+    if (!need(1) || w[p++] != q) return 20;
+    E4 deep[2];
+    const uint32_t* tl[2]; const uint32_t* ql[2];
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      if (!need((size_t)WM + 4 * depth0)) return 4;
+      tl[s2] = w + p; p += WM;
+      uint32_t dg[4]; hash_elems(tl[s2], WM, dg);
+      if (!check_path(dg, pos, w + p, depth0, troot)) return 21;
+      p += 4 * (size_t)depth0;
+    }
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      if (!need((size_t)4 + 4 * depth0)) return 4;
+      ql[s2] = w + p; p += 4;
+      uint32_t dg[4]; hash_elems(ql[s2], 4, dg);
+      if (!check_path(dg, pos, w + p, depth0, qroot)) return 22;
+      p += 4 * (size_t)depth0;
+    }
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      const uint32_t x_m = bb::to_mont(bb::mul(bb::GEN, bb::pow(w2n, pos)));
+      E4 A = bb::e_zero(), B = bb::e_zero();                               // canonical column value x Montgomery gamma^k = canonical; lifted to Montgomery at the end
+      for (int k = 0; k < WM; k++) { A = bb::e_add(A, bb::e_mul_fm(gp[k], tl[s2][k])); B = bb::e_add(B, bb::e_mul_fm(gp[WM + k], tl[s2][k])); }
+      for (int i = 0; i < 4; i++) A = bb::e_add(A, bb::e_mul_fm(gp[2 * WM + i], ql[s2][i]));
+      A = bb::e_to_mont(A); B = bb::e_to_mont(B);
+      E4 dz = bb::e_zero(); dz.c[0] = x_m; E4 dzw = dz;
+      dz = bb::e_sub(dz, zeta); dzw = bb::e_sub(dzw, zeta_w);
+      deep[s2] = bb::e_add(bb::e_mul_m(bb::e_sub(A, a0), bb::e_inv_m(dz)), bb::e_mul_m(bb::e_sub(B, b0), bb::e_inv_m(dzw)));
+    }
+    E4 carried = bb::e_zero(); size_t carried_idx = q;
+    uint32_t shift = bb::GEN; int log_m = log_n + 1;
+    for (int j = 0; j < n_layers; j++) {
+      const int k = ks[j], depth = log_m - k;
+      const size_t nv = (size_t)1 << k, g = (size_t)1 << depth, idx = carried_idx & (g - 1), slot = carried_idx >> depth;
+      if (!need(4 * nv + 4 * (size_t)depth)) return 4;
+      std::vector<E4> v(nv);
+      for (size_t t2 = 0; t2 < nv; t2++) v[t2] = get_m(p + 4 * t2);
+      uint32_t dg[4]; hash_elems(w + p, 4 * nv, dg);
+      p += 4 * nv;
+      if (!check_path(dg, idx, w + p, depth, lroots[j])) return 23;
+      p += 4 * (size_t)depth;
+      if (j == 0) { if (!e_eq(v[0], deep[0]) || !e_eq(v[1], deep[1])) return 24; }
+      else if (!e_eq(v[slot], carried)) return 25;
+      E4 beta = betas[j];
+      for (int f = 0; f < k; f++) {
+        const size_t half = nv >> (f + 1);
+        const uint32_t wm = bb::root_of_unity(log_m);
+        for (size_t t2 = 0; t2 < half; t2++) v[t2] = fold_pair(v[t2], v[t2 + half], bb::to_mont(bb::mul(shift, bb::pow(wm, idx + t2 * g))), beta);
+        shift = bb::mul(shift, shift); log_m--; beta = bb::e_mul_m(beta, beta);
+      }
+      carried = v[0]; carried_idx = idx;
+    }
+    if (!e_eq(fin[carried_idx & (n_fin - 1)], carried)) return 26;
+  }
+  if (p != len) return 30;
+  return 0;
+}
+
+}  // extern "C"

@@ -83,6 +83,11 @@ class NormColumnsC(C.Structure):
                                          "carry0", "carry1")]
 
 
+class PublicInputsC(C.Structure):             # zkir_public_inputs
+    _fields_ = [("n_real", C.c_uint64), ("entry_point", C.c_uint64), ("deferred", C.c_uint32), ("reserved", C.c_uint32),
+                ("program_digest", C.c_uint32 * 4), ("io_digest", C.c_uint32 * 4)]
+
+
 class MemoryWitnessC(C.Structure):            # zkir_memory_witness
     _fields_ = [("n_ops", C.c_uint64), ("n_rows", C.c_uint64), ("row_order", MemopColumnsC), ("row_offsets", C.c_void_p), ("sorted", MemopColumnsC)]
 
@@ -163,13 +168,22 @@ def lib() -> C.CDLL:
     L.zkir_main_trace_width.restype = U32
     L.zkir_modmul_peak_per_s.restype = C.c_double
     L.zkir_modmul_peak_per_s.argtypes = [V]
-    for name, args in [("zkir_main_trace_launch", [C.POINTER(TraceColumnsC), U64, V, V]), ("zkir_lde_launch", [V, V, U32, V, V]),
+    L.zkir_padded_log_n.restype = U32
+    L.zkir_padded_log_n.argtypes = [U64]
+    for name, args in [("zkir_main_trace_launch", [C.POINTER(TraceColumnsC), U64, U32, V, V]), ("zkir_lde_launch", [V, V, U32, V, V]),
                        ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V]), ("zkir_merkle_cap_launch", [V, V, U64, V])]:
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
     L.zkir_prove.restype = C.c_int
-    L.zkir_prove.argtypes = [V, C.POINTER(TraceColumnsC), U64, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(U64), C.POINTER(C.c_float), V]
+    L.zkir_prove.argtypes = [V, C.POINTER(TraceColumnsC), C.POINTER(PublicInputsC), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(U64), C.POINTER(C.c_float), V]
+    L.zkir_verify.restype = C.c_int
+    L.zkir_verify.argtypes = [V, U64, C.POINTER(PublicInputsC)]
+    L.zkir_digest_bytes.restype = None
+    L.zkir_digest_bytes.argtypes = [C.c_char_p, C.c_size_t, V]
+    L.zkir_public_inputs_of.restype = C.c_int
+    L.zkir_public_inputs_of.argtypes = [V, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, U32, C.POINTER(PublicInputsC)]
+    L.zkir_proof_version.restype = U32
     L.zkir_proof_free.restype = None
     L.zkir_proof_free.argtypes = [C.POINTER(C.c_uint32)]
     L.zkir_proof_num_queries.restype = U32
@@ -282,6 +296,23 @@ class DeltaLog:
             pass
 
 
+def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False) -> PublicInputsC:
+    """zkir_public_inputs_of: what a proof of this run is bound to (row count, mode, entry pc, program digest, io digest)."""
+    blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
+    arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
+    out = PublicInputsC()
+    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), int(deferred), C.byref(out))
+    if rc != ZKIR_OK:
+        _raise(rc)
+    return out
+
+
+def verify(proof: np.ndarray, expect: Optional[PublicInputsC] = None) -> int:
+    """zkir_verify (host only): 0 = accepted, otherwise the number of the failed check."""
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    return lib().zkir_verify(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None)
+
+
 def interpret(program: Program | bytes, inputs: Sequence[int] = (), config: Optional[VMConfig] = None, tile_rows: int = 0) -> DeltaLog:
     """Host stage only (zkir_interpret): run the program, return the delta log.  Never touches a GPU."""
     blob = program if isinstance(program, (bytes, bytearray)) else program.to_bytes()
@@ -360,9 +391,10 @@ class ExecutionTrace:
 class ExecutionResult:
     """vm.rs:54-78."""
 
-    def __init__(self, result_handle: Optional[int], log: DeltaLog):
+    def __init__(self, result_handle: Optional[int], log: DeltaLog, blob: bytes = b"", inputs: Sequence[int] = (), config: Optional[VMConfig] = None):
         self._r = result_handle
         self._log = log
+        self._blob, self._inputs, self._config = blob, list(inputs), config or VMConfig()
         self.cycles: int = log.cycles
         self.outputs: List[int] = log.outputs
         self.halt_reason: HaltReason = log.halt_reason
@@ -474,6 +506,10 @@ class ExecutionResult:
         cols = self._d2h(w.columns, 608 * w.stride, "<u4").reshape(608, -1)[:, :w.n_blocks]
         return cols, self._d2h(w.timestamps, w.n_blocks, "<u8")
 
+    def public_inputs(self) -> PublicInputsC:
+        """Public inputs of a proof of this run (zkir_public_inputs_of)."""
+        return public_inputs(self._log, self._blob, self._inputs, self._config.enable_deferred_model)
+
     def close(self):
         if self._r:
             lib().zkir_result_free(self._r)    # also frees the delta log it owns
@@ -507,13 +543,13 @@ class VM:
         arr = (C.c_uint64 * max(1, len(self._inputs)))(*self._inputs)
         if not self._config.enable_execution_trace:
             # nothing to materialise on the device: host stage only
-            return ExecutionResult(None, interpret(self._blob, self._inputs, self._config))
+            return ExecutionResult(None, interpret(self._blob, self._inputs, self._config), self._blob, self._inputs, self._config)
         out = C.c_void_p()
         rc = L.zkir_exec(self._blob, len(self._blob), arr, len(self._inputs), C.byref(cfg), C.byref(out))
         if rc != ZKIR_OK:
             _raise(rc)
         log = DeltaLog(L.zkir_result_delta_log(out.value), owned=False)
-        return ExecutionResult(out.value, log)
+        return ExecutionResult(out.value, log, self._blob, self._inputs, self._config)
 
 
 def run(program: Program | bytes, inputs: Sequence[int] = ()) -> List[int]:

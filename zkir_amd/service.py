@@ -2,8 +2,8 @@
 upload the delta log on their own HIP streams while the single GPU thread fills the trace and proves the previous run.
 
 This is the caller side of the hot path (SURVEY §8f widening): what a proving service built on the C ABI looks like — one
-process per GPU, a few host cores feeding it, the execution trace never leaving HBM.  `zkir_prove` serialises per process, so
-there is exactly one consumer; the producers overlap with it because the C calls and the copies release the GIL.
+process per GPU, a few host cores feeding it, the execution trace never leaving HBM.  A `zkir_stark_ctx` serves one proof at a time (its
+workspace), so there is one consumer per context; the producers overlap with it because the C calls and the copies release the GIL.
 """
 from __future__ import annotations
 
@@ -41,8 +41,8 @@ class PipelineReport:
 
 def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Optional[stark.StarkContext] = None,
                keep_proofs: bool = True) -> PipelineReport:
-    """Prove every job (program blob, inputs, VMConfig with enable_execution_trace and max_cycles = 2^log2_rows rows).
-    Proofs come back in job order."""
+    """Prove every job (program blob, inputs, VMConfig with enable_execution_trace; the run's row count must pad to 2^log2_rows,
+    i.e. 2^(log2_rows-1) < rows <= 2^log2_rows).  Proofs come back in job order."""
     pl._require_gpu()
     jobs = list(jobs)
     own_ctx = ctx is None
@@ -63,20 +63,21 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                 t0 = time.perf_counter()
                 log = rt.interpret(blob, list(inputs), cfg)
                 t1 = time.perf_counter()
-                if log.n_rows != 1 << log2_rows:
-                    raise rt.RuntimeError(rt.ERR_ARGUMENT, f"job {idx}: {log.n_rows} trace rows, the context is for 2^{log2_rows}")
+                if log.n_rows == 0 or stark.padded_log_n(log.n_rows) != log2_rows:
+                    raise rt.RuntimeError(rt.ERR_ARGUMENT, f"job {idx}: {log.n_rows} trace rows do not pad to the context's 2^{log2_rows}")
+                pub = rt.public_inputs(log, blob, list(inputs), cfg.enable_deferred_model)
                 with torch.cuda.stream(s):
                     ddl = pl.upload(log)
                     ev = torch.cuda.Event()
                     ev.record(s)
                 log.close()
-                ready.put((idx, ddl, ev, t1 - t0, time.perf_counter() - t1))
+                ready.put((idx, ddl, ev, t1 - t0, time.perf_counter() - t1, pub, log.n_rows))
             except BaseException as e:                    # surfaced by the consumer
                 errors.append(e)
                 ready.put(None)
                 return
 
-    rep = PipelineReport(runs=len(jobs), rows=len(jobs) << log2_rows)
+    rep = PipelineReport(runs=len(jobs), rows=0)
     out: List[Optional[np.ndarray]] = [None] * len(jobs)
     threads = [threading.Thread(target=producer, daemon=True) for _ in range(max(1, producers))]
     t0 = time.perf_counter()
@@ -87,13 +88,14 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
             item = ready.get()
             if item is None:
                 raise errors[0]
-            idx, ddl, ev, h, u = item
+            idx, ddl, ev, h, u, pub, n_rows = item
             rep.interpret_s += h
             rep.upload_s += u
+            rep.rows += n_rows
             torch.cuda.current_stream().wait_event(ev)
             tr = pl.DeviceTrace(ddl)
             pl.trace_fill(pl.trace_fill_args(ddl, tr))
-            proof = stark.prove(ctx, tr)                  # returns after the proof words are on the host: the run's buffers are idle
+            proof = stark.prove(ctx, tr, pub)             # returns after the proof words are on the host: the run's buffers are idle
             if keep_proofs:
                 out[idx] = proof
         torch.cuda.synchronize()

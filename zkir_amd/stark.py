@@ -15,7 +15,7 @@ from . import pipeline as pl
 from . import runtime as rt
 
 P = 2013265921
-W_MAIN = 89
+W_MAIN = 152
 
 
 class StarkContext:
@@ -50,11 +50,15 @@ def _sp(stream):
     return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
 
 
-def main_trace(trace: pl.DeviceTrace, stream=None) -> torch.Tensor:
-    """K4: SoA execution trace -> main trace matrix int32[89][n_rows] (canonical Baby Bear values)."""
+def padded_log_n(n_real: int) -> int:
+    return int(rt.lib().zkir_padded_log_n(n_real))
+
+
+def main_trace(trace: pl.DeviceTrace, stream=None, deferred: bool = False) -> torch.Tensor:
+    """K4: SoA execution trace (n_rows executed rows) -> main trace matrix int32[152][N], N = the padded power of two (>= 8)."""
     n = trace.n_rows
-    out = torch.empty((W_MAIN, n), dtype=torch.int32, device=trace.cycle.device)
-    pl._check(rt.lib().zkir_main_trace_launch(C.byref(trace.c), n, out.data_ptr(), _sp(stream)))
+    out = torch.empty((W_MAIN, 1 << padded_log_n(n)), dtype=torch.int32, device=trace.cycle.device)
+    pl._check(rt.lib().zkir_main_trace_launch(C.byref(trace.c), n, int(deferred), out.data_ptr(), _sp(stream)))
     return out
 
 
@@ -86,21 +90,26 @@ def merkle_cap(ctx: StarkContext, digests: torch.Tensor, stream=None) -> torch.T
     return tree[-4:]
 
 
-def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None):
+def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None, deferred: bool = False):
     """main trace -> LDE -> Merkle.  Returns (root np.uint32[4], lde matrix tensor, tree tensor)."""
-    m = main_trace(trace, stream)
+    m = main_trace(trace, stream, deferred)
     L = lde(ctx, m, stream, clobber=True)
     tree = merkle_commit(ctx, L, stream)
     root = tree[-4:].cpu().numpy().view(np.uint32)
     return root, L, tree
 
 
-def prove(ctx: StarkContext, trace: pl.DeviceTrace, stream=None, want_stage_ms: bool = False):
-    """zkir_prove: full ZKIR-STARK v0 proof for a 2^log_n-row device trace.  Returns np.uint32 proof words (and stage ms)."""
+def prove(ctx: StarkContext, trace, pub: rt.PublicInputsC, stream=None, want_stage_ms: bool = False):
+    """zkir_prove: full ZKIR-STARK v1 proof of a device trace (`trace`: pl.DeviceTrace or zkir_trace_columns) bound to the public
+    inputs `pub` (rt.public_inputs / ExecutionResult.public_inputs).  Returns np.uint32 proof words (and stage ms)."""
+    cols = trace.c if hasattr(trace, "c") else trace
     out = C.POINTER(C.c_uint32)()
     n_words = C.c_uint64()
     ms = (C.c_float * 8)()
-    pl._check(rt.lib().zkir_prove(ctx.handle, C.byref(trace.c), trace.n_rows, C.byref(out), C.byref(n_words), ms if want_stage_ms else None, _sp(stream)))
+    pl._check(rt.lib().zkir_prove(ctx.handle, C.byref(cols), C.byref(pub), C.byref(out), C.byref(n_words), ms if want_stage_ms else None, _sp(stream)))
     proof = np.ctypeslib.as_array(out, shape=(n_words.value,)).copy()
     rt.lib().zkir_proof_free(out)
     return (proof, list(ms)) if want_stage_ms else proof
+
+
+verify = rt.verify
