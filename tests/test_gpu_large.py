@@ -153,8 +153,9 @@ def test_config4_sha_chain_2p22_syscall_chip_columns():
     nb = cols.shape[1]
     assert nb == len(res.delta_log.sha_blocks) and nb > 690_000
     assert (np.diff(stamps.astype(np.int64)) > 0).all()
-    # full size: it is a hash CHAIN — the final state of block b is the message of block b+1, padding words are fixed
-    assert np.array_equal(cols[600:608, :-1], cols[0:8, 1:])
+    # full size: it is a hash CHAIN — the digest of block b is the message of block b+1.  The syscall stores the eight big-endian
+    # digest words with little-endian write_u32 (crypto.rs:252-255), so in memory every word is byte-swapped; padding words are fixed
+    assert np.array_equal(cols[600:608, :-1].byteswap(), cols[0:8, 1:])
     assert (cols[8] == 0x80000000).all() and not cols[9:15].any() and (cols[15] == 256).all()
     assert np.array_equal(cols[16:24], np.repeat(np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19],
                                                            dtype=np.uint32)[:, None], nb, axis=1))
@@ -165,7 +166,8 @@ def test_config4_sha_chain_2p22_syscall_chip_columns():
         blk = cols[0:8, b].astype(">u4").tobytes()
         if b < 4:
             assert blk == msg
-            msg = hashlib.sha256(msg).digest()
+            dg = hashlib.sha256(msg).digest()
+            msg = b"".join(dg[4 * i:4 * i + 4][::-1] for i in range(8))       # what the syscall left in memory
         wit = oracle.sha256_witness(blk, int(stamps[b]))
         assert np.array_equal(cols[:, b], wit["flat"])
         assert cols[600:608, b].astype(">u4").tobytes() == hashlib.sha256(blk).digest()
