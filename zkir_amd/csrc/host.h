@@ -60,6 +60,13 @@ class Buf {
     if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024);
     p_[n_++] = v;
   }
+  // bulk producers (the interpreter's hot loop): room for `extra` more elements at the end, written through the returned pointer
+  // and made part of the buffer with commit(); growth is geometric
+  inline T* grow(size_t extra) {
+    if (n_ + extra > cap_) reserve(cap_ * 2 > n_ + extra ? cap_ * 2 : n_ + extra);
+    return p_ + n_;
+  }
+  inline void commit(size_t k) { n_ += k; }
   void append(const T* src, size_t n) {
     if (n == 0) return;
     reserve(n_ + n);

@@ -25,6 +25,8 @@
 
 #include "host.h"
 
+#include <emmintrin.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -234,11 +236,23 @@ class Machine {
     const uint64_t dbase = 0x1000 + 4 * pv.n_code_words;
     for (uint64_t i = 0; i < pv.n_data; i++) mem_.store<uint8_t>(dbase + i, pv.data[i]);
     for (auto& e : icache_) e.pc = ~0ull;
+    code_bytes_ = 4 * pv.n_code_words;
+    words_.resize(pv.n_code_words); dec_.resize(pv.n_code_words);
+    for (uint64_t i = 0; i < pv.n_code_words; i++) decode_slot(i);
   }
 
-  Status run();
+  Status run() {                                                       // the loop is specialised on the three mode flags
+    const int m = (tracing_ ? 4 : 0) | (deferred_ ? 2 : 0) | (range_ ? 1 : 0);
+    switch (m) {
+      case 0: return run_loop<false, false, false>(); case 1: return run_loop<false, false, true>();
+      case 2: return run_loop<false, true, false>(); case 3: return run_loop<false, true, true>();
+      case 4: return run_loop<true, false, false>(); case 5: return run_loop<true, false, true>();
+      case 6: return run_loop<true, true, false>(); default: return run_loop<true, true, true>();
+    }
+  }
 
  private:
+  template <bool TRACING, bool DEFERRED, bool RANGE> Status run_loop();
   // ---- register file with write tracking ----
   inline uint64_t rd(uint8_t r) const { return reg_[r]; }            // reg_[0] is never written, so it reads 0 (state.rs:76-82)
   inline void wr(uint8_t r, uint64_t v, const BoundT& b) { if (r) { reg_[r] = v; bound_[r] = b; dirty_ |= 1u << r; } }   // state.rs:110-113
@@ -263,8 +277,22 @@ class Machine {
   template <typename T> inline bool store(uint64_t addr, T v) {
     if (sizeof(T) > 1 && (addr & (sizeof(T) - 1))) return fail(misaligned(addr, sizeof(T)));
     mem_.store<T>(addr, v);
+    if (__builtin_expect(addr - 0x1000 < code_bytes_, 0)) refresh_code(addr);    // self-modifying code: the pre-decoded image follows memory
     note(addr, (uint64_t)v, true, sizeof(T));
     return true;
+  }
+  // pre-decoded code image: word i of the loaded program (address 0x1000 + 4 i) as fetched from memory and its decoded fields
+  // (op = 0xFF: not a valid opcode).  Kept in step with stores into the code region (aligned accesses never straddle a word
+  // boundary, except SD which covers two).
+  void decode_slot(uint64_t i) {
+    const uint32_t w = mem_.load<uint32_t>(0x1000 + 4 * i);
+    words_[i] = w;
+    if (!decode_word(w, dec_[i])) dec_[i].op = 0xFF;
+  }
+  void refresh_code(uint64_t addr) {
+    const uint64_t i = (addr - 0x1000) >> 2;
+    decode_slot(i);
+    if (i + 1 < words_.size()) decode_slot(i + 1);
   }
 
   // ---- deferred carry model helpers (state.rs:184-220, normalize.rs) ----
@@ -289,7 +317,7 @@ class Machine {
   }
   inline void write_accumulated(uint8_t r, const uint64_t l[2]) { if (r) { wr_value(r, l[0] | (l[1] << 30)); wr_state(r, 1); } }  // state.rs:184-192
 
-  bool step(const Decoded& d);            // false => err_ holds the RuntimeError
+  inline __attribute__((always_inline)) bool step(const Decoded& d);            // false => err_ holds the RuntimeError
   bool step_deferred(const Decoded& d);
   bool syscall();
   bool hash_syscall(int which);
@@ -312,10 +340,13 @@ class Machine {
   ICacheEntry icache_[NICACHE];
 
   std::vector<PendingCheck> pending_;
+  uint64_t code_bytes_ = 0;
+  std::vector<uint32_t> words_;
+  std::vector<Decoded> dec_;
 };
 
 // execute.rs:35-673.  Register fields by position: R/I-type rd=a rs1=b rs2=c; S/B-type rs1=a rs2=b.
-bool Machine::step(const Decoded& d) {
+inline __attribute__((always_inline)) bool Machine::step(const Decoded& d) {
   const uint64_t immu = (uint64_t)(int64_t)d.imm;            // `imm as u64` sign-extends (Q4)
   switch (d.op) {
     case 0x00: {  // ADD :43-63
@@ -530,7 +561,9 @@ void Machine::flush_range_checks() {                      // RangeCheckTracker::
   pending_.clear();
 }
 
-Status Machine::run() {
+template <bool TRACING, bool DEFERRED, bool RANGE>
+Status Machine::run_loop() {
+  constexpr bool tracing_ = TRACING, deferred_ = DEFERRED, range_ = RANGE;   // shadow the members: compile-time in this instantiation
   const uint32_t T = log_.tile_rows;
   // initial snapshot = events 0..15
   uint32_t last_ev[16];
@@ -541,49 +574,81 @@ Status Machine::run() {
     }
   }
   log_.rc_offsets.push_back(0);
-  Status st;
+  const uint64_t max_cycles = cfg_.max_cycles;
+  // The loop runs tile by tile: the per-tile bookkeeping (tile index, output capacity) is done once per T rows and the rows
+  // themselves are written through raw pointers (pc, instruction word, register events), so the per-instruction work is
+  // fetch (pre-decoded image) -> execute -> at most a few 32-byte event stores.
   while (!halted_) {
-    if (cycle_ >= cfg_.max_cycles) { halted_ = true; halt_kind_ = ZKIR_HALT_CYCLE_LIMIT; break; }     // vm.rs:211-214
-    if (tracing_ && (cycle_ >= 0xFFFFFFF0ull || log_.reg_events.size() >= 0xFFFFFFC0ull))                // event / row indices are 32-bit (tile index, vis)
-      return {ZKIR_ERR_OTHER, "trace longer than 2^32-16 rows or 2^32-64 register events is not supported"};
-    fetch_pc_ = pc_;
-    if (pc_ & 3) return {ZKIR_ERR_OTHER, "Misaligned PC: " + hexs(pc_)};                              // vm.rs:364-369
-    const uint32_t word = mem_.load<uint32_t>(pc_);                                                   // the fetch is never part of a row (vm.rs:295)
-    ICacheEntry& ic = icache_[(pc_ >> 2) & (NICACHE - 1)];
-    if (ic.pc != pc_ || ic.word != word) {
-      Decoded d;
-      if (!decode_word(word, d)) { char m[64]; snprintf(m, sizeof m, "Decode error: Unknown opcode: 0x%02X", word & 0x7F); return {ZKIR_ERR_DECODE, m}; }
-      ic.pc = pc_; ic.word = word; ic.d = d;
-    }
-    const Decoded d = ic.d;
+    if (cycle_ >= max_cycles) { halted_ = true; halt_kind_ = ZKIR_HALT_CYCLE_LIMIT; break; }            // vm.rs:211-214
+    uint64_t chunk = T - (cycle_ & (T - 1));
+    if (chunk > max_cycles - cycle_) chunk = max_cycles - cycle_;
+    uint64_t* pc_out = nullptr; uint32_t* inst_out = nullptr; zkir_reg_event* ev_out = nullptr;
+    uint32_t ev_base = 0;
     if (tracing_) {
-      if ((cycle_ & (T - 1)) == 0) {                                  // tile index: events visible at the tile's first row
+      if (cycle_ + chunk >= 0xFFFFFFF0ull || log_.reg_events.size() + 4 * chunk >= 0xFFFFFFC0ull)              // event / row indices are 32-bit (tile index, vis)
+        return {ZKIR_ERR_OTHER, "trace longer than 2^32-16 rows or 2^32-64 register events is not supported"};
+      if ((cycle_ & (T - 1)) == 0) {                                    // tile index: events visible at the tile's first row
         log_.tile_ev_off.push_back((uint32_t)log_.reg_events.size());
         for (int r = 0; r < 16; r++) log_.tile_snap.push_back(last_ev[r]);
       }
-      log_.pc.push(fetch_pc_); log_.inst.push(word);                  // row pre-state is implied by the events so far (vm.rs:245-253)
+      pc_out = log_.pc.grow(chunk); inst_out = log_.inst.grow(chunk);
+      ev_out = log_.reg_events.grow(4 * chunk);                         // at most 3 registers change per instruction (deferred-mode normalisations + rd)
+      ev_base = (uint32_t)log_.reg_events.size();
     }
-    dirty_ = 0;
-    if (!(deferred_ ? step_deferred(d) : step(d))) return err_;
-    if (d.op == 0x50 && !syscall()) return err_;                      // vm.rs:277-279
-    if (tracing_ && dirty_) {
-      uint32_t m = dirty_;
-      while (m) {
-        const int r = __builtin_ctz(m); m &= m - 1;
-        last_ev[r] = (uint32_t)log_.reg_events.size();
-        log_.reg_events.push(zkir_reg_event{reg_[r], bound_[r].payload, bound_[r].max_bits, (uint32_t)(cycle_ + 1), (uint8_t)r, state_[r], bound_[r].tag, {0, 0, 0, 0, 0}});
+    uint64_t rows = 0; uint32_t n_ev = 0;
+    for (; rows < chunk; rows++) {
+      fetch_pc_ = pc_;
+      uint32_t word; Decoded d;
+      const uint64_t off = pc_ - 0x1000;
+      if (__builtin_expect(off < code_bytes_ && !(off & 3), 1)) {       // inside the loaded image: pre-decoded
+        word = words_[off >> 2]; d = dec_[off >> 2];
+        if (__builtin_expect(d.op == 0xFF, 0)) { char m[64]; snprintf(m, sizeof m, "Decode error: Unknown opcode: 0x%02X", word & 0x7F); return {ZKIR_ERR_DECODE, m}; }
+      } else {
+        if (pc_ & 3) return {ZKIR_ERR_OTHER, "Misaligned PC: " + hexs(pc_)};                          // vm.rs:364-369
+        word = mem_.load<uint32_t>(pc_);                                                               // the fetch is never part of a row (vm.rs:295)
+        ICacheEntry& ic = icache_[(pc_ >> 2) & (NICACHE - 1)];
+        if (ic.pc != pc_ || ic.word != word) {
+          Decoded nd;
+          if (!decode_word(word, nd)) { char m[64]; snprintf(m, sizeof m, "Decode error: Unknown opcode: 0x%02X", word & 0x7F); return {ZKIR_ERR_DECODE, m}; }
+          ic.pc = pc_; ic.word = word; ic.d = nd;
+        }
+        d = ic.d;
       }
-    }
-    if (range_) {                                                     // vm.rs:316-344
-      bool cp = (d.op >= 0x38 && d.op <= 0x3B) || (d.op >= 0x40 && d.op <= 0x45) || d.op == 0x48 || d.op == 0x49 || (d.op >= 0x04 && d.op <= 0x07);
-      if (!cp && !pending_.empty()) {                                 // should_checkpoint, range_check.rs:122-135
-        if (pending_.size() >= 16) cp = true;
-        else for (const PendingCheck& p : pending_) if (p.max_bits >= data_bits_ + 4) { cp = true; break; }
+      if (tracing_) {                                                   // row pre-state is implied by the events so far (vm.rs:245-253)
+        // streaming stores: the logs are written once, front to back, and read next by the DMA engine — keeping them out of the
+        // cache hierarchy avoids the read-for-ownership of every line (the traced loop is store-bandwidth-bound otherwise)
+        _mm_stream_si64((long long*)(pc_out + rows), (long long)fetch_pc_);
+        _mm_stream_si32((int*)(inst_out + rows), (int)word);
       }
-      if (cp) flush_range_checks();
+      dirty_ = 0;
+      if (!(deferred_ ? step_deferred(d) : step(d))) return err_;
+      if (d.op == 0x50 && !syscall()) return err_;                      // vm.rs:277-279
+      if (tracing_ && dirty_) {
+        uint32_t m = dirty_;
+        do {
+          const int r = __builtin_ctz(m); m &= m - 1;
+          last_ev[r] = ev_base + n_ev;
+          const zkir_reg_event e{reg_[r], bound_[r].payload, bound_[r].max_bits, (uint32_t)(cycle_ + 1), (uint8_t)r, state_[r], bound_[r].tag, {0, 0, 0, 0, 0}};
+          __m128i lo, hi;
+          memcpy(&lo, &e, 16); memcpy(&hi, (const char*)&e + 16, 16);
+          _mm_stream_si128((__m128i*)(ev_out + n_ev), lo); _mm_stream_si128((__m128i*)(ev_out + n_ev) + 1, hi);   // 32-byte events on 16-byte aligned storage
+          n_ev++;
+        } while (m);
+      }
+      if (range_) {                                                     // vm.rs:316-344
+        bool cp = (d.op >= 0x38 && d.op <= 0x3B) || (d.op >= 0x40 && d.op <= 0x45) || d.op == 0x48 || d.op == 0x49 || (d.op >= 0x04 && d.op <= 0x07);
+        if (!cp && !pending_.empty()) {                                 // should_checkpoint, range_check.rs:122-135
+          if (pending_.size() >= 16) cp = true;
+          else for (const PendingCheck& p : pending_) if (p.max_bits >= data_bits_ + 4) { cp = true; break; }
+        }
+        if (cp) flush_range_checks();
+      }
+      cycle_++;                                                         // vm.rs:347
+      if (halted_) { rows++; break; }
     }
-    cycle_++;                                                         // vm.rs:347
+    if (tracing_) { log_.pc.commit(rows); log_.inst.commit(rows); log_.reg_events.commit(n_ev); }
   }
+  if (tracing_) _mm_sfence();                                           // streaming stores globally visible before the log is handed on
   if (tracing_) log_.tile_ev_off.push_back((uint32_t)log_.reg_events.size());
   log_.cycles = cycle_; log_.halt_kind = halt_kind_; log_.halt_code = halt_code_;
   log_.n_rows = tracing_ ? cycle_ : 0;
