@@ -309,6 +309,9 @@ int zkir_exec(const uint8_t* program_blob, size_t blob_len, const uint64_t* inpu
 void zkir_result_free(zkir_result* r);
 const zkir_delta_log* zkir_result_delta_log(const zkir_result* r);       /* host-side metadata */
 const zkir_trace_columns* zkir_result_trace(const zkir_result* r);       /* device pointers */
+/* wall-clock breakdown of the zkir_exec call that produced r (ms): host interpretation | device allocation | H2D of the delta log |
+ * K1 launch + synchronisation */
+void zkir_result_stage_ms(const zkir_result* r, float out[4]);
 /* copy one device column to host: field = 0 cycle,1 pc,2 instruction,3 registers,4 bound_bits,5 bound_tag,
  * 6 bound_payload,7 reg_state; reg ignored for fields 0-2.  dst must hold n_rows elements. */
 int zkir_result_copy_column(const zkir_result* r, int field, int reg, void* dst);

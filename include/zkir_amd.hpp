@@ -80,6 +80,49 @@ struct Program {
   }
 };
 
+
+// Mersenne31 (zkir-spec/src/field.rs:16-189): the field type the spec crate defines (p = 2^31 - 1), canonical representation.  The
+// runtime never uses it (no caller outside the reference's own tests) — mirrored for completeness of the spec surface,
+// pinned by the reference's unit tests (field.rs:231-321, re-stated in tests/cpp/reference_tests.cpp).
+class Mersenne31 {
+ public:
+  static constexpr uint32_t PRIME = (1u << 31) - 1;
+  constexpr Mersenne31() : v_(0) {}
+  constexpr explicit Mersenne31(uint32_t value) : v_(reduce(value)) {}               // Mersenne31::new (field.rs:33-35)
+  static constexpr Mersenne31 zero() { return Mersenne31(); }
+  static constexpr Mersenne31 one() { return Mersenne31(1); }
+  constexpr uint32_t value() const { return v_; }
+  constexpr bool is_zero() const { return v_ == 0; }
+  constexpr bool is_one() const { return v_ == 1; }
+  constexpr Mersenne31 operator+(Mersenne31 r) const { return raw(reduce(v_ + r.v_)); }                       // field.rs:129-136
+  constexpr Mersenne31 operator-(Mersenne31 r) const { return raw(reduce(v_ + PRIME - r.v_)); }               // field.rs:145-153
+  constexpr Mersenne31 operator*(Mersenne31 r) const { return raw(reduce64((uint64_t)v_ * r.v_)); }           // field.rs:162-169
+  constexpr Mersenne31 operator-() const { return v_ == 0 ? Mersenne31() : raw(PRIME - v_); }                 // field.rs:80-86
+  Mersenne31& operator+=(Mersenne31 r) { return *this = *this + r; }
+  Mersenne31& operator-=(Mersenne31 r) { return *this = *this - r; }
+  Mersenne31& operator*=(Mersenne31 r) { return *this = *this * r; }
+  constexpr bool operator==(Mersenne31 r) const { return v_ == r.v_; }
+  constexpr bool operator!=(Mersenne31 r) const { return v_ != r.v_; }
+  constexpr Mersenne31 pow(uint32_t exp) const {                                                              // field.rs:102-115
+    Mersenne31 base = *this, result = one();
+    while (exp > 0) { if (exp & 1) result = result * base; base = base * base; exp >>= 1; }
+    return result;
+  }
+  Mersenne31 inv() const {                                                                                    // field.rs:92-99 (panics on zero)
+    if (v_ == 0) throw std::domain_error("Division by zero in Mersenne31");
+    return pow(PRIME - 2);
+  }
+
+ private:
+  static constexpr Mersenne31 raw(uint32_t canonical) { Mersenne31 m; m.v_ = canonical; return m; }
+  static constexpr uint32_t reduce(uint32_t x) {                                                              // field.rs:53-67: (x & p) + (x >> 31), one conditional subtraction
+    const uint32_t sum = (x & PRIME) + (x >> 31);
+    return sum >= PRIME ? sum - PRIME : sum;
+  }
+  static constexpr uint32_t reduce64(uint64_t x) { return reduce(((uint32_t)x & PRIME) + (uint32_t)(x >> 31)); }   // field.rs:70-77
+  uint32_t v_;
+};
+
 }  // namespace zkir_spec
 
 namespace zkir_runtime {

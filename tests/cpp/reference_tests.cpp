@@ -91,6 +91,25 @@ static void test_divu_by_one() {                                 // stress_tests
   auto code = cat({{addi(1, 0, 12345), addi(2, 0, 1), divu(3, 1, 2)}, write_reg(3), EXIT0});
   CHECK(zkir_runtime::run(Program::from_code(code), {}) == std::vector<uint64_t>{12345});
 }
+// ---- zkir-spec/src/field.rs: Mersenne31 (field.rs:231-321) -------------------------------------------------------------------
+static void test_mersenne31_field() {
+  using M = zkir_spec::Mersenne31;
+  const uint32_t p = 2147483647u;
+  CHECK(M::PRIME == p && M::zero().value() == 0 && M::one().value() == 1);                                   // test_constants
+  CHECK(M(0).value() == 0 && M(1).value() == 1 && M(p).value() == 0 && M(p + 1).value() == 1 && M(2 * p).value() == 0);   // test_reduce
+  CHECK((M(100) + M(200)).value() == 300 && (M(p - 1) + M(5)).value() == 4);                                 // test_addition
+  CHECK((M(200) - M(100)).value() == 100 && (M(5) - M(10)).value() == p - 5);                                // test_subtraction
+  CHECK((M(100) * M(200)).value() == 20000 && (M(1u << 20) * M(1u << 20)).value() < p);                     // test_multiplication
+  CHECK((M(1u << 20) * M(1u << 20)).value() == 512);                                                         // 2^40 mod (2^31 - 1) = 2^9
+  CHECK((M(100) + -M(100)).value() == 0 && (-M::zero()).value() == 0 && (-M::one()).value() == p - 1);       // test_negation
+  CHECK((M(7) * M(7).inv()).value() == 1 && (M(12345) * M(12345).inv()).value() == 1);                       // test_inversion
+  bool threw = false;
+  try { M::zero().inv(); } catch (const std::domain_error& e) { threw = std::strstr(e.what(), "Division by zero") != nullptr; }   // test_inverse_zero
+  CHECK(threw);
+  CHECK(M(2).pow(0).value() == 1 && M(2).pow(1).value() == 2 && M(2).pow(10).value() == 1024 && M(123).pow(p - 1).value() == 1);   // test_pow
+  M acc(5); acc += M(7); acc *= M(3); acc -= M(40);                                                          // assign forms (field.rs:138-176)
+  CHECK(acc.value() == p - 4);
+}
 // ---- error behaviour ----------------------------------------------------------------------------------------------------
 template <typename F>
 static bool throws(RuntimeError::Kind kind, const char* needle, F f) {
@@ -210,7 +229,7 @@ int main(int argc, char** argv) {
       {"test_echo_input", test_echo_input, false}, {"test_exit_code", test_exit_code, false}, {"test_basic_ebreak", test_basic_ebreak, false},
       {"test_cycle_limit", test_cycle_limit, false}, {"test_trace_disabled_by_default", test_trace_disabled_by_default, false},
       {"test_thousand_instructions", test_thousand_instructions, false}, {"test_divu_by_one", test_divu_by_one, false},
-      {"test_division_by_zero", test_division_by_zero, false}, {"test_invalid_syscall", test_invalid_syscall, false},
+      {"test_mersenne31_field", test_mersenne31_field, false}, {"test_division_by_zero", test_division_by_zero, false}, {"test_invalid_syscall", test_invalid_syscall, false},
       {"test_poseidon2_syscall_is_an_error", test_poseidon2_syscall_is_an_error, false}, {"test_run_consumes_the_vm", test_run_consumes_the_vm, false},
       {"test_execution_trace_rows", test_execution_trace_rows, true}, {"test_trace_with_memory_ops", test_trace_with_memory_ops, true},
       {"test_cycle_limit_trace", test_cycle_limit_trace, true},

@@ -34,11 +34,11 @@ def _run(mode):
 def test_cpp_mirror_host_tests():
     _build()
     out = _run("host")
-    assert "16 tests, 0 failures" in out, out
+    assert "17 tests, 0 failures" in out, out
 
 
 @pytest.mark.gpu
 def test_cpp_mirror_gpu_tests():
     _build()
     out = _run("gpu")
-    assert "23 tests, 0 failures" in out, out
+    assert "24 tests, 0 failures" in out, out

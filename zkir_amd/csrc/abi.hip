@@ -2,6 +2,7 @@
 // zkir_exec (VM::new + VM::run replacement: host interpreter -> H2D -> K1 trace fill).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <mutex>
 
 #include "../../include/zkir_amd.h"
@@ -20,6 +21,7 @@ struct zkir_result {
   void* d_tile_snap = nullptr;
   void* d_block = nullptr;      // one allocation holding every trace column
   uint64_t cap_rows = 0;
+  float stage_ms[4] = {0, 0, 0, 0};   // host interpretation | device allocation | H2D of the delta log | K1 + synchronisation
   // witness streams of ExecutionResult (vm.rs:54-103), expanded on the device on first request and cached
   std::mutex wmu;
   bool mem_built = false, rc_built = false, norm_built = false, sha_built = false;
@@ -153,11 +155,15 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
     zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_exec: no usable HIP device (the product path has no CPU fallback)"});
     return ZKIR_ERR_DEVICE;
   }
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t0) { return std::chrono::duration<float, std::milli>(clk::now() - t0).count(); };
   zkir_delta_log* log = nullptr;
+  auto t0 = clk::now();
   int rc = zkir_interpret(blob, len, inputs, n_inputs, cfg, 0, &log);
   if (rc != ZKIR_OK) return rc;
   zkir_result* r = new zkir_result();
   r->log = log;
+  r->stage_ms[0] = ms_since(t0);
   const uint64_t n = log->n_rows;
   if (n > 0) {
     const uint32_t T = log->tile_rows;
@@ -168,6 +174,7 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
     unsigned char* base = nullptr;
     hipStream_t s = nullptr;
     zkir_trace_fill_args a{};
+    t0 = clk::now();
     HIP_TRY(hipMalloc(&r->d_block, bytes));
     base = (unsigned char*)r->d_block;
     r->cols.cycle = (uint64_t*)base;                   base += cap * 8;
@@ -182,11 +189,13 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
     HIP_TRY(hipMalloc(&r->d_events, log->reg_events.size() * sizeof(zkir_reg_event)));
     HIP_TRY(hipMalloc(&r->d_tile_ev_off, log->tile_ev_off.size() * 4));
     HIP_TRY(hipMalloc(&r->d_tile_snap, log->tile_snap.size() * 4));
+    r->stage_ms[1] = ms_since(t0); t0 = clk::now();
     HIP_TRY(hipMemcpyAsync(r->d_events, log->reg_events.data(), log->reg_events.size() * sizeof(zkir_reg_event), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(r->d_tile_ev_off, log->tile_ev_off.data(), log->tile_ev_off.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(r->d_tile_snap, log->tile_snap.data(), log->tile_snap.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(r->cols.pc, log->pc.data(), n * 8, hipMemcpyHostToDevice, s));           // pc / instruction columns arrive in final form
     HIP_TRY(hipMemcpyAsync(r->cols.instruction, log->inst.data(), n * 4, hipMemcpyHostToDevice, s));
+    r->stage_ms[2] = ms_since(t0); t0 = clk::now();
     a.events = (const zkir_reg_event*)r->d_events;
     a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off;
     a.tile_snap = (const uint32_t*)r->d_tile_snap;
@@ -195,6 +204,7 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
     rc = zkir_trace_fill_launch(&a, s);
     if (rc != ZKIR_OK) goto fail_rc;
     HIP_TRY(hipStreamSynchronize(s));
+    r->stage_ms[3] = ms_since(t0);
   }
   *out = r;
   return ZKIR_OK;
@@ -219,6 +229,7 @@ void zkir_result_free(zkir_result* r) {
   delete r;
 }
 const zkir_delta_log* zkir_result_delta_log(const zkir_result* r) { return r->log; }
+void zkir_result_stage_ms(const zkir_result* r, float out[4]) { for (int i = 0; i < 4; i++) out[i] = r->stage_ms[i]; }
 const zkir_trace_columns* zkir_result_trace(const zkir_result* r) { return &r->cols; }
 
 int zkir_result_copy_column(const zkir_result* r, int field, int reg, void* dst) {

@@ -196,6 +196,8 @@ def lib() -> C.CDLL:
     L.zkir_result_delta_log.argtypes = [C.c_void_p]
     L.zkir_result_trace.restype = C.POINTER(TraceColumnsC)
     L.zkir_result_trace.argtypes = [C.c_void_p]
+    L.zkir_result_stage_ms.restype = None
+    L.zkir_result_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.zkir_result_copy_column.restype = C.c_int
     L.zkir_result_copy_column.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     for name, st in [("memory_trace", MemoryWitnessC), ("range_check_witnesses", RangeCheckWitnessC),
@@ -505,6 +507,13 @@ class ExecutionResult:
             _raise(rc)
         cols = self._d2h(w.columns, 608 * w.stride, "<u4").reshape(608, -1)[:, :w.n_blocks]
         return cols, self._d2h(w.timestamps, w.n_blocks, "<u8")
+
+    def exec_stage_ms(self) -> dict:
+        """Wall-clock breakdown of the zkir_exec call behind this result (zkir_result_stage_ms)."""
+        ms = (C.c_float * 4)()
+        if self._r:
+            lib().zkir_result_stage_ms(self._r, ms)
+        return dict(zip(("interpret", "device_alloc", "h2d", "k1_and_sync"), [float(x) for x in ms]))
 
     def public_inputs(self) -> PublicInputsC:
         """Public inputs of a proof of this run (zkir_public_inputs_of)."""
