@@ -124,8 +124,8 @@ def _config2_fib_2p24(lib, sp):
     host_s = time.perf_counter() - t0
     ddl = pl.upload(log); trace = pl.DeviceTrace(ddl); fa = pl.trace_fill_args(ddl, trace)
     ctx = stark.StarkContext(k)
-    m = torch.empty((W, n), dtype=torch.int32, device="cuda")
-    L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
+    m = torch.empty((W // 8, n, 8), dtype=torch.int32, device="cuda")        # B8 layout (include/zkir_amd.h)
+    L = torch.empty((W // 8, 2 * n, 8), dtype=torch.int32, device="cuda")
     tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
     stages = [("trace_fill", lambda: pl.trace_fill(fa)),
               ("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, 0, m.data_ptr(), sp()))),
@@ -316,8 +316,8 @@ def main():
     commit = args.stage == "commit"
     if commit:
         ctx = stark.StarkContext(k)
-        m = torch.empty((W, n), dtype=torch.int32, device="cuda")
-        L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
+        m = torch.empty((W // 8, n, 8), dtype=torch.int32, device="cuda")    # B8 layout (include/zkir_amd.h)
+        L = torch.empty((W // 8, 2 * n, 8), dtype=torch.int32, device="cuda")
         tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
 
     stages = [("trace_fill", lambda: pl.trace_fill(fill_args))]

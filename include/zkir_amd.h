@@ -242,7 +242,11 @@ int zkir_sha256_chip_launch(const zkir_sha_block* blocks, uint64_t n, uint32_t* 
 /* ---- prover stages over Baby Bear (stark.hip, ntt.hip, verify.cpp) ---------------------------------
  * NOT in the reference (no prove(), no Plonky3: Cargo.toml:67-69) => self-defined
  * ("ZKIR-STARK v1"), parity unpinned; spec = oracle/stark_oracle.cpp, frozen by tests/golden/stark_goldens.json.
- * Field elements are canonical u32 (< p = 2^31 - 2^27 + 1) at rest; matrices are column-major [width][n].
+ * Field elements are canonical u32 (< p = 2^31 - 2^27 + 1) at rest.
+ * Matrix layout "B8": the columns of a matrix with `width` columns and n rows are grouped in ceil(width/8) blocks of 8; block b is
+ * the array [n][8] of u32 (32 contiguous bytes per row position: columns 8b..8b+7), blocks follow each other; element (column k,
+ * row j) is word ((k/8)*n + j)*8 + k%8.  Columns past `width` in the last block are zero.  Every kernel moves 16-byte vectors and
+ * the NTT shares its twiddles across the columns a lane carries; one block is one absorption of the rate-8 Poseidon2 sponge.
  * Demonstrator parameters: blow-up 2, 50 FRI queries + 12 bits of grinding (~62 bits, conjectured), Poseidon2 width 12 with
  * capacity 4 (~62-bit collisions).  What the AIR does and does not constrain is stated in zkir_amd/csrc/air.h. */
 typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, coset powers, Poseidon2 constants) + workspace for 2^log_n rows.
@@ -254,14 +258,14 @@ uint32_t zkir_padded_log_n(uint64_t n_real);      /* log2 of the padded trace le
 /* diagnostic: measured peak rate (per second) of independent Montgomery multiplications on the current device — the integer-ALU
  * roofline the Poseidon2 kernels are priced against (they are ALU-bound, not HBM- or MFMA-bound) */
 double zkir_modmul_peak_per_s(void* hip_stream);
-/* trace columns (K1 output, n_real executed rows) -> main trace matrix out[152][N], N = 2^zkir_padded_log_n(n_real): rows past n_real are
+/* trace columns (K1 output, n_real executed rows) -> main trace matrix (B8: 19 blocks [N][8]), N = 2^zkir_padded_log_n(n_real): rows past n_real are
  * padding (class "pad": state of the last executed row, cycle keeps counting).  deferred = VMConfig.enable_deferred_model of the run. */
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* hip_stream);
-/* per-column low-degree extension: in[width][N] (evaluations over <w_N>, natural order; CLOBBERED as scratch when N > 1024)
- * -> out[width][2N] = evaluations over the coset 31*<w_2N>, natural order */
+/* per-column low-degree extension: in = B8 matrix with N rows (evaluations over <w_N>, natural order; CLOBBERED as scratch when N >= 1024)
+ * -> out = B8 matrix with 2N rows = evaluations over the coset 31*<w_2N>, natural order.  All 8 columns of every block are transformed. */
 int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);
-/* Poseidon2-12 Merkle tree over the n_leaves rows of mat[width][n_leaves]; tree = 4*(2*n_leaves-1) words,
- * leaf digests first, root = last 4 words */
+/* Poseidon2-12 Merkle tree over the n_leaves rows of the B8 matrix `mat` (leaf j = sponge over the `width` real columns of row j);
+ * tree = 4*(2*n_leaves-1) words, leaf digests first, root = last 4 words */
 int zkir_merkle_commit_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* hip_stream);
 
 /* Top of a row-sharded commitment: tree[0..4n) holds n (power of two) digests — the all-gathered subtree roots of the row

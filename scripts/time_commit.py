@@ -11,8 +11,8 @@ log = rt.interpret(spec.fib_endless_program().to_bytes(), [], rt.VMConfig(max_cy
 ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); fa = pl.trace_fill_args(ddl, tr)
 ctx = stark.StarkContext(k)
 W = stark.W_MAIN
-m = torch.empty((W, n), dtype=torch.int32, device="cuda")
-L = torch.empty((W, 2 * n), dtype=torch.int32, device="cuda")
+m = torch.empty((W // 8, n, 8), dtype=torch.int32, device="cuda")
+L = torch.empty((W // 8, 2 * n, 8), dtype=torch.int32, device="cuda")
 tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
 import ctypes as C
 lib = rt.lib(); sp = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)

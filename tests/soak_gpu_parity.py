@@ -46,7 +46,7 @@ while time.time() < t_end:
         log_m, width = int(rng.integers(1, 13)), int(rng.integers(1, 100))
         mat = edge_heavy((width, 1 << log_m))
         ctx = ctxs.setdefault(max(log_m - 1, 1), stark.StarkContext(max(log_m - 1, 1)))
-        tree = stark.merkle_commit(ctx, torch.from_numpy(mat.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+        tree = stark.merkle_commit(ctx, stark.to_b8(torch.from_numpy(mat.view(np.int32)).cuda()), mat.shape[0]).cpu().numpy().view(np.uint32)
         _, layers = so.merkle(mat, want_layers=True)
         assert np.array_equal(tree, layers), ("merkle", log_m, width)
         n_merkle += 1
@@ -54,7 +54,7 @@ while time.time() < t_end:
         log_n, width = int(rng.integers(1, 15)), int(rng.integers(1, 6))
         mat = edge_heavy((width, 1 << log_n))
         ctx = ctxs.setdefault(log_n, stark.StarkContext(log_n))
-        got = stark.lde(ctx, torch.from_numpy(mat.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+        got = stark.from_b8(stark.lde(ctx, stark.to_b8(torch.from_numpy(mat.view(np.int32)).cuda())), mat.shape[0]).cpu().numpy().view(np.uint32)
         for k in range(width):
             assert np.array_equal(got[k], so.lde(mat[k], 1)[1]), ("lde", log_n, k)
         n_lde += 1

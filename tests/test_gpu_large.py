@@ -66,13 +66,14 @@ def test_config2_fib_2p24_trace_commit_proof():
     # ---- commitment over the same device trace ----
     ctx = stark.StarkContext(k)
     trace_c = tr.columns
-    m = torch.empty((stark.W_MAIN, n), dtype=torch.int32, device="cuda")
-    L = torch.empty((stark.W_MAIN, 2 * n), dtype=torch.int32, device="cuda")
+    NB = stark.W_MAIN // 8                                                      # B8 layout: blocks of 8 columns, [rows][8]
+    m = torch.empty((NB, n, 8), dtype=torch.int32, device="cuda")
+    L = torch.empty((NB, 2 * n, 8), dtype=torch.int32, device="cuda")
     tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib = rt.lib()
     pl._check(lib.zkir_main_trace_launch(C.byref(trace_c), n, 0, m.data_ptr(), sp))
-    cols_m = {c: m[c].cpu().numpy().view(np.uint32) for c in (0, 21)}             # cycle, r4 limb 0 (LDE clobbers m)
+    cols_m = {c: m[c // 8, :, c % 8].cpu().numpy().view(np.uint32) for c in (0, 21)}     # cycle, r4 limb 0 (LDE clobbers m)
     pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), stark.W_MAIN, L.data_ptr(), sp))
     pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), stark.W_MAIN, 2 * n, tree.data_ptr(), sp))
     root = tree[-4:].cpu().numpy().view(np.uint32)
@@ -82,9 +83,9 @@ def test_config2_fib_2p24_trace_commit_proof():
     rng = np.random.default_rng(24)
     for c in (0, 21):                                             # the LDE is the extension of the trace column: same value at a random point
         z = int(rng.integers(2, P))
-        assert _bary_eval(cols_m[c], k, 1, z) == _bary_eval(L[c].cpu().numpy().view(np.uint32), k + 1, 31, z), c
+        assert _bary_eval(cols_m[c], k, 1, z) == _bary_eval(L[c // 8, :, c % 8].cpu().numpy().view(np.uint32), k + 1, 31, z), c
     for j in [0, 2 * n - 1] + [int(x) for x in rng.integers(0, 2 * n, 4)]:       # sampled leaves: oracle sponge + oracle compression up to the root
-        node = so.hash_elems(L[:, j].cpu().numpy().view(np.uint32))
+        node = so.hash_elems(L[:, j, :].reshape(-1).cpu().numpy().view(np.uint32))
         off, mm = 0, 2 * n
         assert np.array_equal(node, tree[4 * j:4 * j + 4].cpu().numpy().view(np.uint32))
         while mm > 1:

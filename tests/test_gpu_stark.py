@@ -23,16 +23,18 @@ def _device_trace(blob, n, inputs=(), **cfg):
     return log, tr
 
 
-@pytest.mark.parametrize("log_n", [3, 6, 10, 11, 13])
+@pytest.mark.parametrize("log_n", [3, 6, 9, 10, 11, 12, 13, 14, 15])
 def test_lde_matches_oracle(log_n):
     import torch
     from zkir_amd import stark
-    n, w = 1 << log_n, 5
+    n, w = 1 << log_n, 5 if log_n < 14 else 11                    # ragged last block; every pass structure (direct stage, radix-4 passes of 2..10 stages)
     rng = np.random.default_rng(log_n)
     mat = rng.integers(0, P, (w, n)).astype(np.uint32)
     mat[1] = 0; mat[2] = 1; mat[3] = np.arange(n) % P
     ctx = stark.StarkContext(log_n)
-    got = stark.lde(ctx, torch.from_numpy(mat.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    out = stark.lde(ctx, stark.to_b8(torch.from_numpy(mat.view(np.int32)).cuda()))
+    got = stark.from_b8(out, w).cpu().numpy().view(np.uint32)
+    assert not out[0, :, w:].any()                                 # the zero columns of a ragged block stay zero
     for k in range(w):
         assert np.array_equal(got[k], so.lde(mat[k], 1)[1]), f"column {k}"
     # the extension restricted to even positions of a 2N-NTT of the coefficients is the trace itself on a shifted domain:
@@ -48,7 +50,7 @@ def test_merkle_matches_oracle(log_n, width):
     n = 1 << log_n
     mat = np.random.default_rng(width).integers(0, P, (width, n)).astype(np.uint32)
     ctx = stark.StarkContext(max(log_n - 1, 1))
-    tree = stark.merkle_commit(ctx, torch.from_numpy(mat.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    tree = stark.merkle_commit(ctx, stark.to_b8(torch.from_numpy(mat.view(np.int32)).cuda()), width).cpu().numpy().view(np.uint32)
     root, layers = so.merkle(mat, want_layers=True)
     assert np.array_equal(tree, layers)
     assert np.array_equal(tree[-4:], root)
@@ -70,10 +72,10 @@ def test_merkle_and_lde_extreme_values(fill):
     elif fill == "alternating":
         mat[:, ::2] = P - 1; mat[::2, 1::2] = P - 2
     ctx = stark.StarkContext(log_n)
-    tree = stark.merkle_commit(ctx, torch.from_numpy(mat.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    tree = stark.merkle_commit(ctx, stark.to_b8(torch.from_numpy(mat.view(np.int32)).cuda()), width).cpu().numpy().view(np.uint32)
     root, layers = so.merkle(mat, want_layers=True)
     assert np.array_equal(tree, layers)
-    got = stark.lde(ctx, torch.from_numpy(mat[:3].copy().view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    got = stark.from_b8(stark.lde(ctx, stark.to_b8(torch.from_numpy(mat[:3].copy().view(np.int32)).cuda())), 3).cpu().numpy().view(np.uint32)
     for k in range(3):
         assert np.array_equal(got[k], so.lde(mat[k], 1)[1])
     ctx.close()
@@ -108,14 +110,14 @@ def test_main_trace_and_commit_match_oracle(name, n):
     blob, log, tr, rows, opub, pub = _case(name, n)
     assert pub.n_real == len(rows) == opub.n_real
     want_m = so.main_trace(rows, opub)
-    got_m = stark.main_trace(tr, deferred=bool(opub.deferred)).cpu().numpy().view(np.uint32)
+    got_m = stark.from_b8(stark.main_trace(tr, deferred=bool(opub.deferred)), stark.W_MAIN).cpu().numpy().view(np.uint32)
     assert got_m.shape == want_m.shape
     for k in range(want_m.shape[0]):
         assert np.array_equal(got_m[k], want_m[k]), f"main-trace column {k}"
     ctx = stark.StarkContext(stark.padded_log_n(len(rows)))
     root, L, tree = stark.commit_trace(ctx, tr, deferred=bool(opub.deferred))
     want_root, want_L = so.commit_trace(rows, 1, want_lde=True, pub=opub)
-    assert np.array_equal(L.cpu().numpy().view(np.uint32), want_L)
+    assert np.array_equal(stark.from_b8(L, stark.W_MAIN).cpu().numpy().view(np.uint32), want_L)
     assert np.array_equal(root, want_root)
     ctx.close(); log.close()
 
@@ -129,7 +131,7 @@ def test_commit_2p16_root_and_properties():
     ctx = stark.StarkContext(log_n)
     root, L, tree = stark.commit_trace(ctx, tr)
     assert np.array_equal(root, so.commit_trace(rows, 1, pub=opub))
-    Lh = L.cpu().numpy().view(np.uint32)
+    Lh = stark.from_b8(L, stark.W_MAIN).cpu().numpy().view(np.uint32)
     t = tree.cpu().numpy().view(np.uint32)
     j, off, mm = 54321, 0, 2 * n
     node = so.hash_elems(Lh[:, j])
@@ -316,9 +318,9 @@ def test_full_size_2p20_properties():
     ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
     pub = rt.public_inputs(log, blob)
     ctx = stark.StarkContext(log_n)
-    m = stark.main_trace(tr).cpu().numpy().view(np.uint32)
+    m = stark.from_b8(stark.main_trace(tr), stark.W_MAIN).cpu().numpy().view(np.uint32)
     root, L, tree = stark.commit_trace(ctx, tr)
-    Lh, t = L.cpu().numpy().view(np.uint32), tree.cpu().numpy().view(np.uint32)
+    Lh, t = stark.from_b8(L, stark.W_MAIN).cpu().numpy().view(np.uint32), tree.cpu().numpy().view(np.uint32)
     rng = np.random.default_rng(20)
     for col in (0, 1, 9, 21, 76, 124, 130):                         # cycle, pc limb, r0 limb (all zero), r4 limb, a write selector, y limb, a class flag
         z = int(rng.integers(2, P))

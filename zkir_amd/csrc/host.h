@@ -138,5 +138,5 @@ struct LdeTables {
   const uint32_t* small_inv;  // w_{2^Bm}^-k, k < 2^(Bm-1)      (Bm = min(log_n, 10))
   const uint32_t* small_fwd;  // w_{2^(Bm+1)}^k, k < 2^Bm
 };
-void lde_run(const LdeTables& t, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);
+void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out, void* hip_stream);   // matrices in the B8 layout: n_blocks x [rows][8]
 }  // namespace zkir

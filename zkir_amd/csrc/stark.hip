@@ -6,7 +6,8 @@
 //
 //   main_trace_kernel   372 B/row SoA trace -> the 152 Baby Bear columns of the v1 AIR (air.h: limbs of pc / instruction fields /
 //                       registers, storage state, write and operand selectors, operands, result, opcode classes, carries),
-//                       padded to a power of two.  HBM-bound: ~170 B read (values + states of the row and the next) + 608 B written per row.
+//                       padded to a power of two, written in the B8 layout (blocks of 8 columns, [rows][8]).  HBM-bound: ~170 B
+//                       read (values + states of the row and the next) + 608 B written per row.
 //   (NTT / coset LDE kernels: ntt.hip)
 //   merkle kernels      Poseidon2 width-12 sponge over the rows of the LDE matrix (one lane per leaf, column reads coalesced
 //                       across lanes) + 2-to-1 compression layers.  ALU-bound (≈740 Montgomery multiplications per permutation);
@@ -37,6 +38,8 @@ int check_launch(const char* what) {
 }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits == 0 ? 0u : __brev(x) >> (32 - bits); }
+// B8 matrix layout (include/zkir_amd.h): element (column k, row j) of a matrix with n rows
+__host__ __device__ __forceinline__ uint64_t b8(uint32_t k, uint64_t j, uint64_t n) { return ((uint64_t)(k >> 3) * n + j) * 8 + (k & 7); }
 
 // ------------------------------------------------------------------------------------------------
 // main trace columns (oracle: so::main_trace)
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, ui
   using namespace air;
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
-  auto col = [&](int k) -> uint32_t& { return out[(uint64_t)k * N + i]; };
+  auto col = [&](int k) -> uint32_t& { return out[b8((uint32_t)k, i, N)]; };
   const bool pad = i >= n_real, last = i + 1 >= n_real;
   const uint64_t src = pad ? n_real - 1 : i;
   col(C_CYCLE) = (uint32_t)((pad ? i : t.cycle[src]) % bb::P);
@@ -158,16 +161,20 @@ __global__ __launch_bounds__(NT) void powers_kernel(uint32_t w, uint32_t scale_m
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 Merkle
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint64_t col_stride, uint32_t* __restrict__ digests) {
+// one lane per leaf (= row position); a B8 block is exactly one absorption of the rate-8 sponge: two 16-byte loads per permutation
+__global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint32_t* __restrict__ digests) {
   const uint64_t j = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (j >= n) return;
   uint32_t s[p2::T];
 #pragma unroll
   for (int i = 0; i < p2::T; i++) s[i] = 0;
+  const uint4* m4 = reinterpret_cast<const uint4*>(mat);
   for (uint32_t off = 0; off < width; off += p2::RATE) {
+    const uint4 lo = m4[((uint64_t)(off >> 3) * n + j) * 2], hi = m4[((uint64_t)(off >> 3) * n + j) * 2 + 1];
+    const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int i = 0; i < p2::RATE; i++)
-      if (off + i < width) s[i] = bb::to_mont(mat[(uint64_t)(off + i) * col_stride + j]);
+      if (off + i < width) s[i] = bb::to_mont(v[i]);             // a ragged last block overwrites only its real columns (so::hash_elems)
     p2::permute(s, *cp);
   }
   if (width == 0) p2::permute(s, *cp);
@@ -363,18 +370,18 @@ int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uin
   return check_launch("main_trace");
 }
 
-// in: [width][N] canonical evaluations over H (natural order; used as scratch and overwritten!), out: [width][2N]
+// in: ceil(width/8) blocks [N][8] of canonical evaluations over H (natural order; used as scratch and overwritten!), out: blocks [2N][8]
 int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* out, void* stream) {
   const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
-  zkir::lde_run(t, in, width, out, stream);                    // ntt.hip
+  zkir::lde_run(t, in, (width + 7) / 8, out, stream);          // ntt.hip
   return check_launch("lde");
 }
 
-// tree = [leaf digests (4*n)] [layer 1 (4*n/2)] ... [root (4)]  = 4*(2n-1) words; n_leaves a power of two
+// mat: B8 layout, ceil(width/8) blocks [n_leaves][8]; tree = [leaf digests (4*n)] [layer 1 (4*n/2)] ... [root (4)] = 4*(2n-1) words; n_leaves a power of two
 int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!c || n_leaves == 0 || (n_leaves & (n_leaves - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle: null context, or n_leaves not a power of two"}); return ZKIR_ERR_ARGUMENT; }
-  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, n_leaves, tree);
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, tree);
   launch_tree_levels(c->d_p2, tree, n_leaves, s);
   return check_launch("merkle_commit");
 }

@@ -63,8 +63,8 @@ struct QuotientOps {
   __device__ __forceinline__ V mul(V a, V b) const { return bb::mont_mul(a, b); }
   __device__ __forceinline__ V mulc(V a, uint32_t cm) const { return bb::mont_mul(a, cm); }
   __device__ __forceinline__ V cst(uint32_t cm) const { return cm; }
-  __device__ __forceinline__ V loc(int k) const { return bb::to_mont(L[(uint64_t)k * N2 + j]); }
-  __device__ __forceinline__ V nxt(int k) const { return bb::to_mont(L[(uint64_t)k * N2 + jn]); }
+  __device__ __forceinline__ V loc(int k) const { return bb::to_mont(L[b8((uint32_t)k, j, N2)]); }
+  __device__ __forceinline__ V nxt(int k) const { return bb::to_mont(L[b8((uint32_t)k, jn, N2)]); }
   __device__ __forceinline__ void push(int idx, V v) {
     lz_fma(acc, pp->alpha_pow[idx], v);
     if (++pending == 128) { partial = bb::e_add(partial, lz_reduce(acc)); acc = LazyE4(); pending = 0; }     // 136 terms fit the lazy sum
@@ -94,8 +94,9 @@ __global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict
   air::eval(o, is_first, is_last, is_trans, pp->entry_m, pp->deferred != 0);
   const E4 total = bb::e_add(o.partial, lz_reduce(o.acc));
   const E4 q = bb::e_from_mont(bb::e_mul_fm(total, inv_zh));
-#pragma unroll
-  for (int i = 0; i < 4; i++) Q[(uint64_t)i * N2 + j] = q.c[i];
+  uint4* q4 = reinterpret_cast<uint4*>(Q);                                     // one B8 block: four coordinate columns + four zero columns
+  q4[(uint64_t)j * 2] = make_uint4(q.c[0], q.c[1], q.c[2], q.c[3]);
+  q4[(uint64_t)j * 2 + 1] = make_uint4(0, 0, 0, 0);
 }
 
 // ---- barycentric weights over the LDE coset: e_j = x_j / (zeta - x_j)  (Montgomery E4, AoS) -------------------------------
@@ -112,19 +113,18 @@ __global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const 
   wts[j] = bb::e_mul_fm(di, x);
 }
 
-// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (CANONICAL E4; grid: chunks x column groups).
-// A workgroup handles CG columns so that the 16-byte weights (the bulk of the traffic when read once per column) are loaded once
-// per CG values; products are accumulated lazily: mont(e, v) without its final subtraction (3 instructions) into a 64-bit sum
-// (1 instruction), reduced once at the end.  v stays canonical: mont(e * R, v) = e * v needs no conversion of the matrix.
-template <int CG>
+// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (CANONICAL E4; grid: chunks x half blocks of the B8 matrix).
+// A workgroup handles the FOUR columns of one half block — one 16-byte load brings their values at a position — so that the 16-byte
+// weights (the bulk of the traffic when read once per column) are loaded once per four values; products are accumulated lazily:
+// mont(e, v) without its final subtraction (3 instructions) into a 64-bit sum (1 instruction), reduced once at the end.  v stays
+// canonical: mont(e * R, v) = e * v needs no conversion of the matrix.
 __global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, uint32_t width, const E4* __restrict__ wts, E4* __restrict__ partial,
                                                        uint32_t n_chunks) {
+  constexpr int CG = 4;
   __shared__ uint32_t red[NT / 64][CG][2][4];
   const uint32_t col0 = blockIdx.y * CG, chunk = blockIdx.x;
   const uint64_t per = N2 / n_chunks, lo = (uint64_t)chunk * per;
-  const uint32_t* v[CG];
-#pragma unroll
-  for (int c = 0; c < CG; c++) v[c] = mat + (uint64_t)(col0 + c < width ? col0 + c : width - 1) * N2;
+  const uint4* v4 = reinterpret_cast<const uint4*>(mat) + (uint64_t)(col0 >> 3) * N2 * 2 + ((col0 >> 2) & 1);
   uint64_t a0[CG][4], a1[CG][4];
 #pragma unroll
   for (int c = 0; c < CG; c++)
@@ -132,13 +132,14 @@ __global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict
     for (int t = 0; t < 4; t++) a0[c][t] = a1[c][t] = 0;
   for (uint64_t j = lo + threadIdx.x; j < lo + per; j += NT) {
     const E4 w0 = wts[j], w1 = wts[(j + N2 - 2) & (N2 - 1)];
+    const uint4 xv = v4[j * 2];
+    const uint32_t x[CG] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int c = 0; c < CG; c++) {
-      const uint32_t x = v[c][j];
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        a0[c][t] = bb::acc_add(a0[c][t], bb::mont_mul_lazy(w0.c[t], x));
-        a1[c][t] = bb::acc_add(a1[c][t], bb::mont_mul_lazy(w1.c[t], x));
+        a0[c][t] = bb::acc_add(a0[c][t], bb::mont_mul_lazy(w0.c[t], x[c]));
+        a1[c][t] = bb::acc_add(a1[c][t], bb::mont_mul_lazy(w1.c[t], x[c]));
       }
     }
   }
@@ -169,21 +170,22 @@ __global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L
   // canonical v x Montgomery gamma^k = canonical product; 156 and 152 terms: the lazy sums are folded once on the way (136 terms fit)
   LazyE4 A, B;
   E4 Ap = bb::e_zero(), Bp = bb::e_zero();
-  // eight column loads in flight per lane (the loop body is long and the compiler keeps it rolled: one load at a time otherwise)
   constexpr int UN = 8;
+  const uint4* L4 = reinterpret_cast<const uint4*>(L);
   constexpr int FOLD = 80;                                                     // lazy sums are folded after 80 terms; 76 more follow
   static_assert(WM % UN == 0 && FOLD % UN == 0 && FOLD <= 128 && WM + 4 - FOLD <= 128, "column loop");
 #pragma unroll 1
   for (int k = 0; k < WM; k += UN) {
-    uint32_t v[UN];
-#pragma unroll
-    for (int u = 0; u < UN; u++) v[u] = L[(uint64_t)(k + u) * N2 + j];
+    const uint4 vlo = L4[((uint64_t)(k >> 3) * N2 + j) * 2], vhi = L4[((uint64_t)(k >> 3) * N2 + j) * 2 + 1];   // one B8 block = eight columns
+    const uint32_t v[UN] = {vlo.x, vlo.y, vlo.z, vlo.w, vhi.x, vhi.y, vhi.z, vhi.w};
 #pragma unroll
     for (int u = 0; u < UN; u++) { lz_fma(A, pp->gamma_pow[k + u], v[u]); lz_fma(B, pp->gamma_pow[WM + k + u], v[u]); }
     if (k + UN == FOLD) { Ap = lz_reduce(A); Bp = lz_reduce(B); A = LazyE4(); B = LazyE4(); }
   }
-#pragma unroll
-  for (int i = 0; i < 4; i++) lz_fma(A, pp->gamma_pow[2 * WM + i], Q[(uint64_t)i * N2 + j]);
+  {
+    const uint4 qv = reinterpret_cast<const uint4*>(Q)[(uint64_t)j * 2];
+    lz_fma(A, pp->gamma_pow[2 * WM], qv.x); lz_fma(A, pp->gamma_pow[2 * WM + 1], qv.y); lz_fma(A, pp->gamma_pow[2 * WM + 2], qv.z); lz_fma(A, pp->gamma_pow[2 * WM + 3], qv.w);
+  }
   const E4 Am = bb::e_to_mont(bb::e_add(Ap, lz_reduce(A))), Bm = bb::e_to_mont(bb::e_add(Bp, lz_reduce(B)));
   const E4 i1 = dinv[j], i2 = bb::e_mul_fm(dinv[(j + N2 - 2) & (N2 - 1)], wn_inv_m);   // 1/(zeta - x), 1/(zeta w - x)
   const E4 t1 = bb::e_mul_m(bb::e_sub(pp->a0, Am), i1);                       // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
@@ -345,7 +347,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const int n_layers = (int)ks.size();
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
-    const size_t want = (size_t)(12 * WM + 440) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
+    static_assert(WM % 8 == 0, "the main trace fills whole B8 blocks");
+    const size_t want = (size_t)(12 * WM + 480) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -360,7 +363,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   ProveParams* dPP;
   HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4));
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
-  HIP_OK(ar.take(&dQ, 4 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
+  HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
   HIP_OK(ar.take(&dPart, (size_t)(WM + 4) * n_chunks * 2));
   std::vector<uint32_t*> fri_trees(n_layers), fri_layers(n_layers + 1);
@@ -412,9 +415,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   pp->zeta = bb::e_to_mont(zeta); pp->zeta_w = bb::e_to_mont(zeta_w);
   HIP_OK(hipMemcpyAsync(&dPP->zeta, &pp->zeta, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dPP, dW, dDinv);
-  constexpr int CG = 4;
-  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, (WM + CG - 1) / CG), dim3(NT), 0, s, dL, N2, (uint32_t)WM, dW, dPart, n_chunks);
-  hipLaunchKernelGGL(bary_dot_kernel<CG>, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WM + 3) / 4), dim3(NT), 0, s, dL, N2, (uint32_t)WM, dW, dPart, n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks);
   std::vector<E4> part((size_t)(WM + 4) * n_chunks * 2);
   HIP_OK(hipMemcpyAsync(part.data(), dPart, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -533,8 +535,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   };
   for (uint32_t q : queries) {
     qpos.push_back(off); off += 1;
-    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dL + pos, N2, (uint32_t)WM, off}); off += WM; path_jobs(dTree, N2, pos); }
-    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos, N2, 4, off}); off += 4; path_jobs(dQTree, N2, pos); }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // a trace row = 8 consecutive words out of each of the WM/8 blocks
+      for (uint32_t b = 0; b < (uint32_t)WM / 8; b++) { jobs.push_back({dL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off}); off += 8; }
+      path_jobs(dTree, N2, pos);
+    }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos * 8, 1, 4, off}); off += 4; path_jobs(dQTree, N2, pos); }
     int log_m = (int)log_n + 1;
     for (int j = 0; j < n_layers; log_m -= ks[j], j++) {
       const uint64_t m = 1ull << log_m, g = m >> ks[j], idx = q & (g - 1);

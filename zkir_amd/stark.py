@@ -54,28 +54,46 @@ def padded_log_n(n_real: int) -> int:
     return int(rt.lib().zkir_padded_log_n(n_real))
 
 
+# ---- the B8 matrix layout of the C ABI (include/zkir_amd.h): blocks of 8 columns, block b = [rows][8] -----------------------------
+def to_b8(cols: torch.Tensor) -> torch.Tensor:
+    """Column-major int32[width][n] -> B8 int32[ceil(width/8)][n][8] (missing columns of the last block are zero)."""
+    width, n = cols.shape
+    nb = (width + 7) // 8
+    out = torch.zeros((nb * 8, n), dtype=cols.dtype, device=cols.device)
+    out[:width] = cols
+    return out.view(nb, 8, n).permute(0, 2, 1).contiguous()
+
+
+def from_b8(mat: torch.Tensor, width: int) -> torch.Tensor:
+    """B8 int32[nb][n][8] -> column-major int32[width][n]."""
+    nb, n, _ = mat.shape
+    return mat.permute(0, 2, 1).reshape(nb * 8, n)[:width].contiguous()
+
+
 def main_trace(trace: pl.DeviceTrace, stream=None, deferred: bool = False) -> torch.Tensor:
-    """K4: SoA execution trace (n_rows executed rows) -> main trace matrix int32[152][N], N = the padded power of two (>= 8)."""
+    """K4: SoA execution trace (n_rows executed rows) -> main trace matrix in the B8 layout, int32[19][N][8], N = the padded power of two."""
     n = trace.n_rows
-    out = torch.empty((W_MAIN, 1 << padded_log_n(n)), dtype=torch.int32, device=trace.cycle.device)
+    out = torch.empty((W_MAIN // 8, 1 << padded_log_n(n), 8), dtype=torch.int32, device=trace.cycle.device)
     pl._check(rt.lib().zkir_main_trace_launch(C.byref(trace.c), n, int(deferred), out.data_ptr(), _sp(stream)))
     return out
 
 
 def lde(ctx: StarkContext, mat: torch.Tensor, stream=None, clobber: bool = False) -> torch.Tensor:
-    """Per-column LDE of mat[width][N] to [width][2N] on the coset 31*<w_2N> (natural order)."""
-    width, n = mat.shape
-    assert n == 1 << ctx.log_n and mat.dtype == torch.int32 and mat.is_contiguous()
+    """Per-column LDE of a B8 matrix int32[nb][N][8] to int32[nb][2N][8] on the coset 31*<w_2N> (natural order)."""
+    nb, n, eight = mat.shape
+    assert eight == 8 and n == 1 << ctx.log_n and mat.dtype == torch.int32 and mat.is_contiguous()
     src = mat if clobber else mat.clone()
-    out = torch.empty((width, 2 * n), dtype=torch.int32, device=mat.device)
-    pl._check(rt.lib().zkir_lde_launch(ctx.handle, src.data_ptr(), width, out.data_ptr(), _sp(stream)))
+    out = torch.empty((nb, 2 * n, 8), dtype=torch.int32, device=mat.device)
+    pl._check(rt.lib().zkir_lde_launch(ctx.handle, src.data_ptr(), nb * 8, out.data_ptr(), _sp(stream)))
     return out
 
 
-def merkle_commit(ctx: StarkContext, mat: torch.Tensor, stream=None) -> torch.Tensor:
-    """Poseidon2-12 Merkle tree over the rows (positions) of mat[width][n]; returns the tree int32[4*(2n-1)], root = last 4."""
-    width, n = mat.shape
-    assert mat.dtype == torch.int32 and mat.is_contiguous()
+def merkle_commit(ctx: StarkContext, mat: torch.Tensor, width: Optional[int] = None, stream=None) -> torch.Tensor:
+    """Poseidon2-12 Merkle tree over the rows (positions) of a B8 matrix int32[nb][n][8] with `width` real columns (default all);
+    returns the tree int32[4*(2n-1)], root = last 4."""
+    nb, n, eight = mat.shape
+    assert eight == 8 and mat.dtype == torch.int32 and mat.is_contiguous()
+    width = nb * 8 if width is None else width
     tree = torch.empty(4 * (2 * n - 1), dtype=torch.int32, device=mat.device)
     pl._check(rt.lib().zkir_merkle_commit_launch(ctx.handle, mat.data_ptr(), width, n, tree.data_ptr(), _sp(stream)))
     return tree
@@ -91,10 +109,10 @@ def merkle_cap(ctx: StarkContext, digests: torch.Tensor, stream=None) -> torch.T
 
 
 def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None, deferred: bool = False):
-    """main trace -> LDE -> Merkle.  Returns (root np.uint32[4], lde matrix tensor, tree tensor)."""
+    """main trace -> LDE -> Merkle.  Returns (root np.uint32[4], lde matrix tensor (B8), tree tensor)."""
     m = main_trace(trace, stream, deferred)
     L = lde(ctx, m, stream, clobber=True)
-    tree = merkle_commit(ctx, L, stream)
+    tree = merkle_commit(ctx, L, W_MAIN, stream)
     root = tree[-4:].cpu().numpy().view(np.uint32)
     return root, L, tree
 
