@@ -14,6 +14,8 @@
 // fused in one contiguous-chunk kernel.  HBM traffic per element and column: 8 B per strided pass, 12 B for the fused middle.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/zkir_amd.h"
 #include "babybear.h"
 #include "host.h"
@@ -147,6 +149,8 @@ void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int
   hipLaunchKernelGGL(k, dim3((unsigned)(n >> (2 * R + C)), n_blocks), dim3(NTH), lds, s, (uint4*)data, 2 * n, L, s0, tw, small, log_small, j4_m);
 }
 
+inline int strided_c() { static const int c = getenv("ZKIR_NTT_C") ? atoi(getenv("ZKIR_NTT_C")) : 1; return c; }
+
 // `stages` radix-2 stages starting at s0, as few passes as possible: radix-4 passes of 10/8/6/4/2 stages + one direct stage for an odd count
 template <bool DIT>
 void run_strided_stages(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int s0, int stages, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m,
@@ -160,7 +164,12 @@ void run_strided_stages(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, in
       continue;
     }
     switch (R) {
-      case 5: launch_strided_r4<DIT, 5, 1, 512>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
+      case 5:
+        // tile rows of 4 positions = 128 contiguous bytes (a full cache line; 128 KiB of LDS, one workgroup of 16 waves per CU) or of
+        // 2 positions = 64 bytes (64 KiB, two workgroups of 8 waves): ZKIR_NTT_C picks (benchmarking), default from the measurements
+        if (strided_c() == 2) launch_strided_r4<DIT, 5, 2, 1024>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s);
+        else launch_strided_r4<DIT, 5, 1, 512>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s);
+        break;
       case 4: launch_strided_r4<DIT, 4, 3, 512>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
       case 3: launch_strided_r4<DIT, 3, 4, 256>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
       case 2: launch_strided_r4<DIT, 2, 5, 128>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
