@@ -149,7 +149,7 @@ void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int
   hipLaunchKernelGGL(k, dim3((unsigned)(n >> (2 * R + C)), n_blocks), dim3(NTH), lds, s, (uint4*)data, 2 * n, L, s0, tw, small, log_small, j4_m);
 }
 
-inline int strided_c() { static const int c = getenv("ZKIR_NTT_C") ? atoi(getenv("ZKIR_NTT_C")) : 1; return c; }
+inline int strided_c() { static const int c = getenv("ZKIR_NTT_C") ? atoi(getenv("ZKIR_NTT_C")) : 2; return c; }
 
 // `stages` radix-2 stages starting at s0, as few passes as possible: radix-4 passes of 10/8/6/4/2 stages + one direct stage for an odd count
 template <bool DIT>

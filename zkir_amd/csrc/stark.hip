@@ -58,16 +58,15 @@ __device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[
 
 // One thread per (padded) row; every column write is coalesced across lanes.  Rows >= n_real are padding: they repeat the last
 // executed row's state with class "pad" and keep counting cycles.  Mirrors so::main_trace of the oracle word for word.
-// Output goes through LDS: a lane produces the 152 words of ITS row one by one (column-major in LDS: conflict-free), then the
-// workgroup writes its 64 rows x 19 blocks as 16-byte vectors, consecutive lanes on consecutive addresses (a lane writing its own
-// row directly would scatter 4-byte stores 32 bytes apart).
-constexpr int MT_ROWS = 64;
-__global__ __launch_bounds__(MT_ROWS) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t deferred, uint32_t* __restrict__ out) {
+// A lane builds the 152 words of ITS row in registers (every column index below is a compile-time constant once the register loop
+// is unrolled) and stores them as 38 16-byte vectors; the two halves of a 32-byte block position are written back to back, so the
+// L2 merges them into full sectors.
+__global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t deferred, uint32_t* __restrict__ out) {
   using namespace air;
-  __shared__ uint32_t srow[W * MT_ROWS];
-  const uint64_t i0 = (uint64_t)blockIdx.x * MT_ROWS;
-  const uint64_t i = i0 + threadIdx.x < N ? i0 + threadIdx.x : N - 1;          // lanes past the end recompute the last row (never written out)
-  auto col = [&](int k) -> uint32_t& { return srow[k * MT_ROWS + threadIdx.x]; };
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= N) return;
+  uint32_t rowv[W];
+  auto col = [&](int k) -> uint32_t& { return rowv[k]; };
   const bool pad = i >= n_real, last = i + 1 >= n_real;
   const uint64_t src = pad ? n_real - 1 : i;
   col(C_CYCLE) = (uint32_t)((pad ? i : t.cycle[src]) % bb::P);
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(MT_ROWS) void main_trace_kernel(zkir_trace_columns 
   const uint32_t tc = cls == K_BNE ? fa : fc;
   uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
   bool first = true;
-#pragma unroll 4
+#pragma unroll
   for (int g = 0; g < 16; g++) {
     const uint64_t o = (uint64_t)g * t.reg_stride + src;
     const uint64_t v = t.registers[o];
@@ -148,14 +147,11 @@ __global__ __launch_bounds__(MT_ROWS) void main_trace_kernel(zkir_trace_columns 
     const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; d2 = (uint32_t)(v2 >> 24);
   }
   col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2;
-  __syncthreads();
   uint4* out4 = reinterpret_cast<uint4*>(out);
-  const uint32_t rows = N - i0 < (uint64_t)MT_ROWS ? (uint32_t)(N - i0) : (uint32_t)MT_ROWS;
-  for (uint32_t e = threadIdx.x; e < (uint32_t)(W / 8) * MT_ROWS * 2; e += MT_ROWS) {
-    const uint32_t b = e / (2 * MT_ROWS), rem = e % (2 * MT_ROWS), j = rem >> 1, h = rem & 1;
-    if (j >= rows) continue;
-    const uint32_t* src = srow + (8 * b + 4 * h) * MT_ROWS + j;
-    out4[((uint64_t)b * N + i0 + j) * 2 + h] = make_uint4(src[0], src[MT_ROWS], src[2 * MT_ROWS], src[3 * MT_ROWS]);
+#pragma unroll
+  for (int b = 0; b < W / 8; b++) {
+    out4[((uint64_t)b * N + i) * 2] = make_uint4(rowv[8 * b], rowv[8 * b + 1], rowv[8 * b + 2], rowv[8 * b + 3]);
+    out4[((uint64_t)b * N + i) * 2 + 1] = make_uint4(rowv[8 * b + 4], rowv[8 * b + 5], rowv[8 * b + 6], rowv[8 * b + 7]);
   }
 }
 
@@ -380,7 +376,7 @@ uint32_t zkir_padded_log_n(uint64_t n_real) { uint32_t k = 3; while (((uint64_t)
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* stream) {
   if (!trace || !out || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
-  hipLaunchKernelGGL(main_trace_kernel, dim3(grid_for(N, MT_ROWS)), dim3(MT_ROWS), 0, (hipStream_t)stream, *trace, n_real, N, deferred, out);
+  hipLaunchKernelGGL(main_trace_kernel, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, deferred, out);
   return check_launch("main_trace");
 }
 

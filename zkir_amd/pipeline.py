@@ -61,6 +61,30 @@ def upload(log: rt.DeltaLog, device=None) -> DeviceDeltaLog:
                           tile_snap=_to_dev(log.tile_snap, device), pc=pc, inst=inst)
 
 
+class HostShard:
+    """The part of a (sharded) delta log K1 needs, as plain numpy arrays: what `save_shard` / `load_shard` move between the
+    processes of one node (bench.py --gpus N: rank 0 interprets once, every rank picks up its row range)."""
+    FIELDS = ("pc", "inst", "reg_events", "tile_ev_off", "tile_snap")
+
+    def __init__(self, n_rows, cycle_base, tile_rows, n_tiles, **arrays):
+        self.n_rows, self.cycle_base, self.tile_rows, self.n_tiles = int(n_rows), int(cycle_base), int(tile_rows), int(n_tiles)
+        for k in self.FIELDS:
+            setattr(self, k, arrays[k])
+
+
+def save_shard(shard, path: str) -> None:
+    """Write a delta log (usually `log.shard(a, b)`) to `path` (.npz, uncompressed; /dev/shm keeps it in memory)."""
+    np.savez(path, meta=np.array([shard.n_rows, shard.cycle_base, shard.tile_rows, shard.n_tiles], dtype=np.uint64),
+             **{k: np.ascontiguousarray(getattr(shard, k)) for k in HostShard.FIELDS})
+
+
+def load_shard(path: str) -> HostShard:
+    with np.load(path) as z:
+        meta = z["meta"]
+        return HostShard(meta[0], meta[1], meta[2], meta[3], pc=z["pc"], inst=z["inst"], reg_events=z["reg_events"].view(rt.REG_EVENT_DTYPE).reshape(-1),
+                         tile_ev_off=z["tile_ev_off"], tile_snap=z["tile_snap"].reshape(-1, 16))
+
+
 class DeviceTrace:
     """Wide SoA execution trace in HBM (zkir_trace_columns); columns are torch tensors sharing one allocation pattern."""
 
