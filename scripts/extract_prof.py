@@ -55,7 +55,7 @@ def main():
         # gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 for wide coalesced reads.  The strided NTT passes read 64-B
         # runs (16 consecutive words per tile row, C = 4): their requests are counted in full (the raw value equals the
         # algorithmic 4 B/element exactly), so no correction there.
-        factor = 1 if "ntt_strided" in s else 2
+        factor = 2                       # B8 layout: every kernel reads >= 128-byte runs with 16-byte lanes (the strided NTT tiles are 128-byte rows)
         t["fetch_correction_factor"] = factor
         fetch = t.get("FETCH_SIZE_KB_avg", 0.0) * 1024 * factor
         write = t.get("WRITE_SIZE_KB_avg", 0.0) * 1024
