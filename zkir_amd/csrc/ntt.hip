@@ -72,73 +72,110 @@ __global__ __launch_bounds__(NT) void ntt_stage_kernel(uint4* __restrict__ data,
 // 2048) times a per-lane running power; the other stage's twiddle is its square and the odd pair's is its product with a 4th root.
 // LDS holds the two halves as separate planes so that consecutive lanes touch consecutive 16-byte words.
 template <bool DIT, int R, int C, int NTH>
-__global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__ data, uint64_t blk_u4, int L, int s0, const uint32_t* __restrict__ tw,
-                                                              const uint32_t* __restrict__ small, int log_small, uint32_t j4_m) {
+__global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__ data, uint64_t blk_u4, uint32_t tiles_per_block, uint32_t total, int L, int s0,
+                                                              const uint32_t* __restrict__ tw, const uint32_t* __restrict__ small, int log_small, uint32_t j4_m) {
   constexpr int B = 2 * R;
   constexpr uint32_t POS = 1u << (B + C), QUADS = POS / 4, CMASK = (1u << C) - 1, PLANE = POS + 4;       // +4: the two planes start in different banks
+  constexpr uint32_t MOVES = 2 * POS / NTH;
   static_assert(QUADS % NTH == 0 && NTH % (1 << C) == 0 && (2 * POS) % NTH == 0, "tile / thread geometry");
   extern __shared__ uint4 lds4[];                                              // [2][PLANE]
-  uint4* x = data + (uint64_t)blockIdx.y * blk_u4;
   const uint32_t n = 1u << L;
   const uint32_t stride_mid = DIT ? (1u << s0) : (n >> (s0 + B));
   const uint32_t lo_tiles = stride_mid >> C;
-  const uint32_t tile = blockIdx.x;
-  const uint32_t hi = tile / lo_tiles, lo0 = (tile % lo_tiles) << C;
-  const uint32_t base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
-  // tile rows are 2^C consecutive positions = 2^(C+1) uint4
+  // Persistent workgroups: each walks the (block, tile) work list with a stride of the grid and keeps the NEXT tile's 16-byte loads
+  // in flight (registers) while it runs the radix-4 rounds of the current one — with one or two workgroups per CU (64-128 KiB of LDS
+  // each) nothing else would hide the global-memory latency of a tile load behind arithmetic.
+  auto geometry = [&](uint32_t w, uint4*& x, uint32_t& base, uint32_t& lo0) {
+    const uint32_t tile = w % tiles_per_block;
+    x = data + (uint64_t)(w / tiles_per_block) * blk_u4;
+    const uint32_t hi = tile / lo_tiles;
+    lo0 = (tile % lo_tiles) << C;
+    base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
+  };
+  uint4 pre[MOVES];
+  uint4* x; uint32_t base, lo0;
+  uint32_t w = blockIdx.x;
+  if (w >= total) return;
+  geometry(w, x, base, lo0);
 #pragma unroll
-  for (uint32_t k = 0; k < 2 * POS / NTH; k++) {
+  for (uint32_t k = 0; k < MOVES; k++) {                                       // tile rows are 2^C consecutive positions = 2^(C+1) uint4
     const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-    lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))] = x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv];
+    pre[k] = x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv];
   }
-  const uint32_t lo = lo0 + (threadIdx.x & CMASK);
-  uint32_t tp[R];                                              // per-lane power used by round r
-  if (DIT) {                                                   // round r needs w^(lo << (L-1-s0-(2r+1))): finest at r = R-1, each earlier round is its 4th power
-    uint32_t u = tw[lo << (L - s0 - B)];
+  for (;;) {
 #pragma unroll
-    for (int r = R - 1; r >= 0; r--) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
-  } else {                                                     // round r needs w^-(lo << (s0+2r))
-    uint32_t u = tw[lo << s0];
+    for (uint32_t k = 0; k < MOVES; k++) {
+      const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
+      lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))] = pre[k];
+    }
+    const uint32_t lo = lo0 + (threadIdx.x & CMASK);
+    uint32_t tp[R];                                            // per-lane power used by round r
+    if (DIT) {                                                 // round r needs w^(lo << (L-1-s0-(2r+1))): finest at r = R-1, each earlier round is its 4th power
+      uint32_t u = tw[lo << (L - s0 - B)];
 #pragma unroll
-    for (int r = 0; r < R; r++) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
-  }
-  __syncthreads();
+      for (int r = R - 1; r >= 0; r--) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
+    } else {                                                   // round r needs w^-(lo << (s0+2r))
+      uint32_t u = tw[lo << s0];
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int b = 2 * r;
-#pragma unroll
-    for (uint32_t k = 0; k < QUADS / NTH; k++) {
-      const uint32_t q = threadIdx.x + k * NTH;
-      const uint32_t lo_l = q & CMASK, qq = q >> C;
-      uint32_t i0, d, wa, wb, wc;
-      if (!DIT) {
-        const int lg = B - 2 - b;                              // log2(h2) in row units
-        const uint32_t h2 = 1u << lg, mid_lo = qq & (h2 - 1), mid_hi = qq >> lg;
-        i0 = ((((mid_hi << (lg + 2)) | mid_lo)) << C) | lo_l; d = h2 << C;
-        wa = bb::mont_mul(tp[r], small[mid_lo << (log_small - (B - b))]);
-        wb = bb::mont_mul(wa, j4_m); wc = bb::mont_mul(wa, wa);
-      } else {
-        const uint32_t dm = 1u << b, mid_lo = qq & (dm - 1), mid_hi = qq >> b;
-        i0 = ((((mid_hi << (b + 2)) | mid_lo)) << C) | lo_l; d = dm << C;
-        wb = bb::mont_mul(tp[r], small[mid_lo << (log_small - (b + 2))]);       // w2
-        wa = bb::mont_mul(wb, wb); wc = bb::mont_mul(wb, j4_m);                 // w1, w2i
-      }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        uint4* pl = lds4 + h * PLANE;
-        uint4 x0 = pl[i0], x1 = pl[i0 + d], x2 = pl[i0 + 2 * d], x3 = pl[i0 + 3 * d];
-        if (!DIT) dif4(x0, x1, x2, x3, wa, wb, wc); else dit4(x0, x1, x2, x3, wa, wb, wc);
-        pl[i0] = x0; pl[i0 + d] = x1; pl[i0 + 2 * d] = x2; pl[i0 + 3 * d] = x3;
-      }
+      for (int r = 0; r < R; r++) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
     }
     __syncthreads();
-  }
+    const uint32_t wn = w + gridDim.x;
+    uint4* xn = x; uint32_t base_n = base, lo0_n = lo0;
+    if (wn < total) {                                          // next tile: loads issued now, consumed after this tile's rounds
+      geometry(wn, xn, base_n, lo0_n);
 #pragma unroll
-  for (uint32_t k = 0; k < 2 * POS / NTH; k++) {
-    const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-    x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv] = lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))];
+      for (uint32_t k = 0; k < MOVES; k++) {
+        const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
+        pre[k] = xn[((uint64_t)base_n + (uint64_t)row * stride_mid) * 2 + wv];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int b = 2 * r;
+#pragma unroll
+      for (uint32_t k = 0; k < QUADS / NTH; k++) {
+        const uint32_t q = threadIdx.x + k * NTH;
+        const uint32_t lo_l = q & CMASK, qq = q >> C;
+        uint32_t i0, d, wa, wb, wc;
+        if (!DIT) {
+          const int lg = B - 2 - b;                            // log2(h2) in row units
+          const uint32_t h2 = 1u << lg, mid_lo = qq & (h2 - 1), mid_hi = qq >> lg;
+          i0 = ((((mid_hi << (lg + 2)) | mid_lo)) << C) | lo_l; d = h2 << C;
+          wa = bb::mont_mul(tp[r], small[mid_lo << (log_small - (B - b))]);
+          wb = bb::mont_mul(wa, j4_m); wc = bb::mont_mul(wa, wa);
+        } else {
+          const uint32_t dm = 1u << b, mid_lo = qq & (dm - 1), mid_hi = qq >> b;
+          i0 = ((((mid_hi << (b + 2)) | mid_lo)) << C) | lo_l; d = dm << C;
+          wb = bb::mont_mul(tp[r], small[mid_lo << (log_small - (b + 2))]);     // w2
+          wa = bb::mont_mul(wb, wb); wc = bb::mont_mul(wb, j4_m);               // w1, w2i
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          uint4* pl = lds4 + h * PLANE;
+          uint4 x0 = pl[i0], x1 = pl[i0 + d], x2 = pl[i0 + 2 * d], x3 = pl[i0 + 3 * d];
+          if (!DIT) dif4(x0, x1, x2, x3, wa, wb, wc); else dit4(x0, x1, x2, x3, wa, wb, wc);
+          pl[i0] = x0; pl[i0 + d] = x1; pl[i0 + 2 * d] = x2; pl[i0 + 3 * d] = x3;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < MOVES; k++) {
+      const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
+      x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv] = lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))];
+    }
+    if (wn >= total) break;
+    w = wn; x = xn; base = base_n; lo0 = lo0_n;
+    __syncthreads();                                           // every lane has copied its part of the tile out before LDS is refilled
   }
 }
+
+inline unsigned cu_count() {
+  static const unsigned n = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256u; return (unsigned)p.multiProcessorCount; }();
+  return n;
+}
+inline int persist() { static const int v = getenv("ZKIR_NTT_PERSIST") ? atoi(getenv("ZKIR_NTT_PERSIST")) : 1; return v; }
 
 template <bool DIT, int R, int C, int NTH>
 void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int s0, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m, hipStream_t s) {
@@ -146,7 +183,11 @@ void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int
   auto k = ntt_strided_r4_kernel<DIT, R, C, NTH>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(k, dim3((unsigned)(n >> (2 * R + C)), n_blocks), dim3(NTH), lds, s, (uint4*)data, 2 * n, L, s0, tw, small, log_small, j4_m);
+  const uint32_t tiles = (uint32_t)(n >> (2 * R + C)), total = tiles * n_blocks;
+  const unsigned per_cu = (unsigned)((160u << 10) / lds) > 0 ? (unsigned)((160u << 10) / lds) : 1u;       // workgroups resident per CU (LDS-limited)
+  unsigned grid = persist() ? cu_count() * (per_cu > 8 ? 8 : per_cu) : total;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), lds, s, (uint4*)data, 2 * n, tiles, total, L, s0, tw, small, log_small, j4_m);
 }
 
 inline int strided_c() { static const int c = getenv("ZKIR_NTT_C") ? atoi(getenv("ZKIR_NTT_C")) : 2; return c; }
@@ -231,65 +272,83 @@ __global__ __launch_bounds__(NT) void lde_small_kernel(const uint32_t* __restric
 // carries.  LDS: A = both halves of the chunk (32 KiB), Bf = the forward part of ONE half at a time (32 KiB): 64 KiB per workgroup,
 // two workgroups per CU.
 constexpr int MID_NT = 512;
-__global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int L, const uint32_t* __restrict__ small_inv,
-                                                                const uint32_t* __restrict__ small_fwd, const uint32_t* __restrict__ g_lo, const uint32_t* __restrict__ g_hi,
-                                                                uint32_t j4_inv_m, uint32_t j4_fwd_m) {
+__global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t chunks_per_block, uint32_t total, int L,
+                                                                const uint32_t* __restrict__ small_inv, const uint32_t* __restrict__ small_fwd,
+                                                                const uint32_t* __restrict__ g_lo, const uint32_t* __restrict__ g_hi, uint32_t j4_inv_m, uint32_t j4_fwd_m) {
   constexpr int Bm = 10;
   constexpr uint32_t APL = 1024;
   __shared__ uint4 A[2 * APL];
   __shared__ uint4 Bf[2048];
-  const uint32_t n = 1u << L;
-  const uint4* x = in + (uint64_t)blockIdx.y * n * 2;
-  uint4* y = out + (uint64_t)blockIdx.y * n * 4;
-  const uint32_t base = blockIdx.x << Bm, t = threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; A[(e & 1) * APL + (e >> 1)] = x[(uint64_t)base * 2 + e]; }
-  __syncthreads();
-  // ---- inverse DIF, rounds r = 0..4: stages (2r, 2r+1), spans h1 = 2^(9-2r), h2 = h1/2; lane = (quad q, half h) ----
+  const uint32_t n = 1u << L, t = threadIdx.x;
+  // persistent workgroups with the next chunk's loads in flight during the 15 rounds of the current one (see the strided kernel)
+  uint32_t w = blockIdx.x;
+  if (w >= total) return;
+  uint4 pre[4];
   {
-    const uint32_t q = t & 255;
-    uint4* a = A + (t >> 8) * APL;
+    const uint4* x = in + ((uint64_t)(w / chunks_per_block) * n + ((uint64_t)(w % chunks_per_block) << Bm)) * 2;
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
-      const int lg = 8 - 2 * r;                                // log2(h2)
-      const uint32_t h2 = 1u << lg, lo = q & (h2 - 1), hi = q >> lg;
-      const uint32_t i0 = (hi << (lg + 2)) | lo;
-      const uint32_t wA = small_inv[lo << (2 * r)];            // w_1024^-(lo << 2r)
-      const uint32_t wB = bb::mont_mul(wA, j4_inv_m), w2 = bb::mont_mul(wA, wA);
-      uint4 x0 = a[i0], x1 = a[i0 + h2], x2 = a[i0 + 2 * h2], x3 = a[i0 + 3 * h2];
-      dif4(x0, x1, x2, x3, wA, wB, w2);
-      if (r == 4) {                                            // last round (positions 4q..4q+3): the coset scale g^k / N, k = bitrev_L(position)
-        const uint32_t p0 = base + i0;
-        const uint32_t k0 = bitrev(p0, L), k1 = bitrev(p0 + 1, L), k2 = bitrev(p0 + 2, L), k3 = bitrev(p0 + 3, L);
-        x0 = mul4(x0, bb::mont_mul(g_lo[k0 & 1023], g_hi[k0 >> 10])); x1 = mul4(x1, bb::mont_mul(g_lo[k1 & 1023], g_hi[k1 >> 10]));
-        x2 = mul4(x2, bb::mont_mul(g_lo[k2 & 1023], g_hi[k2 >> 10])); x3 = mul4(x3, bb::mont_mul(g_lo[k3 & 1023], g_hi[k3 >> 10]));
-      }
-      a[i0] = x0; a[i0 + h2] = x1; a[i0 + 2 * h2] = x2; a[i0 + 3 * h2] = x3;
-      __syncthreads();
-    }
+    for (int k = 0; k < 4; k++) pre[k] = x[t + k * MID_NT];
   }
-  // ---- forward DIT of the zero-interleaved chunk (2048 positions), one half of the block at a time: stage 0 is a copy, rounds do
-  //      stages (s, s+1), s = 1,3,5,7,9; lane = quad t of 512 ----
-#pragma unroll 1
-  for (int h = 0; h < 2; h++) {
-    const uint4* a = A + h * APL;
+  for (;;) {
+    const uint32_t base = (w % chunks_per_block) << Bm;
+    uint4* y = out + (uint64_t)(w / chunks_per_block) * n * 4;
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
-      const int s = 2 * r + 1;
-      const uint32_t lo = t & ((1u << s) - 1), hi = t >> s;
-      const uint32_t i0 = (hi << (s + 2)) | lo, d = 1u << s;
-      const uint32_t w2 = small_fwd[lo << (Bm - s - 1)];       // w_2048^(lo << (9-s)): twiddle of stage s+1
-      const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_fwd_m);
-      uint4 x0, x1, x2, x3;
-      if (r == 0) { x0 = a[i0 >> 1]; x1 = a[(i0 + d) >> 1]; x2 = a[(i0 + 2 * d) >> 1]; x3 = a[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
-      else { x0 = Bf[i0]; x1 = Bf[i0 + d]; x2 = Bf[i0 + 2 * d]; x3 = Bf[i0 + 3 * d]; }
-      dit4(x0, x1, x2, x3, w1, w2, w2i);
-      Bf[i0] = x0; Bf[i0 + d] = x1; Bf[i0 + 2 * d] = x2; Bf[i0 + 3 * d] = x3;
+    for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; A[(e & 1) * APL + (e >> 1)] = pre[k]; }
+    __syncthreads();
+    const uint32_t wn = w + gridDim.x;
+    if (wn < total) {
+      const uint4* x = in + ((uint64_t)(wn / chunks_per_block) * n + ((uint64_t)(wn % chunks_per_block) << Bm)) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; k++) pre[k] = x[t + k * MID_NT];
+    }
+    // ---- inverse DIF, rounds r = 0..4: stages (2r, 2r+1), spans h1 = 2^(9-2r), h2 = h1/2; lane = (quad q, half h) ----
+    {
+      const uint32_t q = t & 255;
+      uint4* a = A + (t >> 8) * APL;
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        const int lg = 8 - 2 * r;                              // log2(h2)
+        const uint32_t h2 = 1u << lg, lo = q & (h2 - 1), hi = q >> lg;
+        const uint32_t i0 = (hi << (lg + 2)) | lo;
+        const uint32_t wA = small_inv[lo << (2 * r)];          // w_1024^-(lo << 2r)
+        const uint32_t wB = bb::mont_mul(wA, j4_inv_m), w2 = bb::mont_mul(wA, wA);
+        uint4 x0 = a[i0], x1 = a[i0 + h2], x2 = a[i0 + 2 * h2], x3 = a[i0 + 3 * h2];
+        dif4(x0, x1, x2, x3, wA, wB, w2);
+        if (r == 4) {                                          // last round (positions 4q..4q+3): the coset scale g^k / N, k = bitrev_L(position)
+          const uint32_t p0 = base + i0;
+          const uint32_t k0 = bitrev(p0, L), k1 = bitrev(p0 + 1, L), k2 = bitrev(p0 + 2, L), k3 = bitrev(p0 + 3, L);
+          x0 = mul4(x0, bb::mont_mul(g_lo[k0 & 1023], g_hi[k0 >> 10])); x1 = mul4(x1, bb::mont_mul(g_lo[k1 & 1023], g_hi[k1 >> 10]));
+          x2 = mul4(x2, bb::mont_mul(g_lo[k2 & 1023], g_hi[k2 >> 10])); x3 = mul4(x3, bb::mont_mul(g_lo[k3 & 1023], g_hi[k3 >> 10]));
+        }
+        a[i0] = x0; a[i0 + h2] = x1; a[i0 + 2 * h2] = x2; a[i0 + 3 * h2] = x3;
+        __syncthreads();
+      }
+    }
+    // ---- forward DIT of the zero-interleaved chunk (2048 positions), one half of the block at a time: stage 0 is a copy, rounds do
+    //      stages (s, s+1), s = 1,3,5,7,9; lane = quad t of 512 ----
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const uint4* a = A + h * APL;
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        const int s = 2 * r + 1;
+        const uint32_t lo = t & ((1u << s) - 1), hi = t >> s;
+        const uint32_t i0 = (hi << (s + 2)) | lo, d = 1u << s;
+        const uint32_t w2 = small_fwd[lo << (Bm - s - 1)];     // w_2048^(lo << (9-s)): twiddle of stage s+1
+        const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_fwd_m);
+        uint4 x0, x1, x2, x3;
+        if (r == 0) { x0 = a[i0 >> 1]; x1 = a[(i0 + d) >> 1]; x2 = a[(i0 + 2 * d) >> 1]; x3 = a[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
+        else { x0 = Bf[i0]; x1 = Bf[i0 + d]; x2 = Bf[i0 + 2 * d]; x3 = Bf[i0 + 3 * d]; }
+        dit4(x0, x1, x2, x3, w1, w2, w2i);
+        Bf[i0] = x0; Bf[i0 + d] = x1; Bf[i0 + 2 * d] = x2; Bf[i0 + 3 * d] = x3;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; y[((uint64_t)2 * base + e) * 2 + h] = Bf[e]; }
       __syncthreads();
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; y[((uint64_t)2 * base + e) * 2 + h] = Bf[e]; }
-    __syncthreads();
+    if (wn >= total) break;
+    w = wn;
   }
 }
 
@@ -309,8 +368,13 @@ void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out,
   }
   // inverse DIF strided stages 0 .. L-11 (the compact table then has order 1024)
   run_strided_stages<false>(in, N, n_blocks, L, 0, L - 10, t.tw_inv, t.small_inv, 10, j4_inv_m, s);
-  hipLaunchKernelGGL(lde_middle_r4_kernel, dim3(N >> 10, n_blocks), dim3(MID_NT), 0, s, (const uint4*)in, (uint4*)out, L, t.small_inv, t.small_fwd, t.g_lo, t.g_hi, j4_inv_m,
-                     j4_fwd_m);
+  {
+    const uint32_t chunks = N >> 10, total = chunks * n_blocks;
+    unsigned grid = persist() ? cu_count() * 2 : total;                     // 64 KiB of LDS: two workgroups per CU
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL(lde_middle_r4_kernel, dim3(grid), dim3(MID_NT), 0, s, (const uint4*)in, (uint4*)out, chunks, total, L, t.small_inv, t.small_fwd, t.g_lo, t.g_hi,
+                       j4_inv_m, j4_fwd_m);
+  }
   // forward DIT strided stages 11 .. L of the size-2N transform
   run_strided_stages<true>(out, (uint64_t)2 * N, n_blocks, L + 1, 11, L - 10, t.tw_fwd, t.small_fwd, 11, j4_fwd_m, s);
 }
