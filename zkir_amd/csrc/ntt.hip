@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/zkir_amd.h"
 #include "babybear.h"
@@ -24,6 +25,16 @@ namespace {
 
 constexpr int NT = 256;
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits == 0 ? 0u : __brev(x) >> (32 - bits); }
+
+// compile-time loop: the body sees its index as a constant, so small per-lane arrays stay in registers
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (K < N) { f(std::integral_constant<int, K>{}); static_for<K + 1, N>(f); }
+}
+
+using u32x4 = uint32_t __attribute__((ext_vector_type(4)));          // plain vector for values that only travel (prefetch registers)
+__device__ __forceinline__ u32x4 ld4(const uint4* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st4(uint4* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 // ---- four columns at a time --------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 add4(uint4 a, uint4 b) { return make_uint4(bb::add(a.x, b.x), bb::add(a.y, b.y), bb::add(a.z, b.z), bb::add(a.w, b.w)); }
@@ -92,22 +103,22 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
     lo0 = (tile % lo_tiles) << C;
     base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
   };
-  uint4 pre[MOVES];
+  u32x4 pre[MOVES];
   uint4* x; uint32_t base, lo0;
   uint32_t w = blockIdx.x;
   if (w >= total) return;
   geometry(w, x, base, lo0);
-#pragma unroll
-  for (uint32_t k = 0; k < MOVES; k++) {                                       // tile rows are 2^C consecutive positions = 2^(C+1) uint4
+  static_for<0, (int)MOVES>([&](auto kc) {                                     // tile rows are 2^C consecutive positions = 2^(C+1) uint4
+    constexpr uint32_t k = decltype(kc)::value;
     const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-    pre[k] = x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv];
-  }
+    pre[k] = ld4(&x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv]);
+  });
   for (;;) {
-#pragma unroll
-    for (uint32_t k = 0; k < MOVES; k++) {
+    static_for<0, (int)MOVES>([&](auto kc) {
+      constexpr uint32_t k = decltype(kc)::value;
       const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-      lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))] = pre[k];
-    }
+      st4(&lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))], pre[k]);
+    });
     const uint32_t lo = lo0 + (threadIdx.x & CMASK);
     uint32_t tp[R];                                            // per-lane power used by round r
     if (DIT) {                                                 // round r needs w^(lo << (L-1-s0-(2r+1))): finest at r = R-1, each earlier round is its 4th power
@@ -124,11 +135,11 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
     uint4* xn = x; uint32_t base_n = base, lo0_n = lo0;
     if (wn < total) {                                          // next tile: loads issued now, consumed after this tile's rounds
       geometry(wn, xn, base_n, lo0_n);
-#pragma unroll
-      for (uint32_t k = 0; k < MOVES; k++) {
+      static_for<0, (int)MOVES>([&](auto kc) {
+        constexpr uint32_t k = decltype(kc)::value;
         const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-        pre[k] = xn[((uint64_t)base_n + (uint64_t)row * stride_mid) * 2 + wv];
-      }
+        pre[k] = ld4(&xn[((uint64_t)base_n + (uint64_t)row * stride_mid) * 2 + wv]);
+      });
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -283,23 +294,23 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
   // persistent workgroups with the next chunk's loads in flight during the 15 rounds of the current one (see the strided kernel)
   uint32_t w = blockIdx.x;
   if (w >= total) return;
-  uint4 pre[4];
+  u32x4 pre[4];
   {
     const uint4* x = in + ((uint64_t)(w / chunks_per_block) * n + ((uint64_t)(w % chunks_per_block) << Bm)) * 2;
 #pragma unroll
-    for (int k = 0; k < 4; k++) pre[k] = x[t + k * MID_NT];
+    for (int k = 0; k < 4; k++) pre[k] = ld4(&x[t + k * MID_NT]);
   }
   for (;;) {
     const uint32_t base = (w % chunks_per_block) << Bm;
     uint4* y = out + (uint64_t)(w / chunks_per_block) * n * 4;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; A[(e & 1) * APL + (e >> 1)] = pre[k]; }
+    for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; st4(&A[(e & 1) * APL + (e >> 1)], pre[k]); }
     __syncthreads();
     const uint32_t wn = w + gridDim.x;
     if (wn < total) {
       const uint4* x = in + ((uint64_t)(wn / chunks_per_block) * n + ((uint64_t)(wn % chunks_per_block) << Bm)) * 2;
 #pragma unroll
-      for (int k = 0; k < 4; k++) pre[k] = x[t + k * MID_NT];
+      for (int k = 0; k < 4; k++) pre[k] = ld4(&x[t + k * MID_NT]);
     }
     // ---- inverse DIF, rounds r = 0..4: stages (2r, 2r+1), spans h1 = 2^(9-2r), h2 = h1/2; lane = (quad q, half h) ----
     {
