@@ -226,14 +226,19 @@ def _cpu_baseline(blob, k, commit):
            "linear_rows_per_s": nn / dt, "faithful_rows_per_s": nf / dtf, "faithful_rows": nf, "host_cpu": cpu}
     if commit:                                          # self-defined stages: NOT the reference path; a separate, labelled figure
         from oracle import stark_api as so
-        kc = 16
-        rows = oracle.run(blob, max_cycles=1 << kc, enable_execution_trace=True).rows
+        threads = max(1, min(cpu["logical_cores"] or 1, 64))
+        rows = oracle.run(blob, max_cycles=1 << k, enable_execution_trace=True).rows
         t0 = time.perf_counter()
-        so.commit_trace(rows, 1, pub=so.public_inputs(len(rows), blob))
-        dtc = time.perf_counter() - t0
-        out["commit_stage_self_defined"] = {"rows": 1 << kc, "seconds": dtc, "rows_per_s": (1 << kc) / dtc, "cores": 1,
-                                            "what": "oracle/stark_oracle.cpp main trace + LDE + Poseidon2 Merkle (naive %-arithmetic; stages absent from "
-                                                    "the reference, self-defined): a labelled side figure, never part of `value`"}
+        m = so.main_trace(rows, so.public_inputs(len(rows), blob))
+        t_main = time.perf_counter() - t0
+        del rows
+        root, t_lde, t_merkle = so.commit_port(m, threads)
+        out["commit_stage_self_defined"] = {
+            "rows": 1 << k, "threads": threads, "main_trace_s_1_thread": t_main, "lde_s": t_lde, "merkle_s": t_merkle,
+            "rows_per_s": (1 << k) / (t_lde + t_merkle), "merkle_root": [int(x) for x in root],
+            "what": "the SAME commit stage at the SAME size on this box's host cores: oracle/cpu_commit_port.cpp (Montgomery arithmetic, radix-2 NTTs with "
+                    "twiddle tables, std::thread over columns / leaves); stages absent from the reference (self-defined) — a labelled side figure, "
+                    "never part of `value`; its root must equal the GPU's (checked below)"}
     return out
 
 
@@ -448,12 +453,17 @@ def main():
         exec_s = min(ts[1:])                              # steady state (first call: device allocations, cold block pool)
 
     # ---- the same proof with the host in the loop: independent runs pipelined through interpret -> H2D -> K1 -> prove ----------
-    pipelined = None
+    pipelined = pipelined_commit = None
     if commit and world == 1 and k <= 22 and not args.no_prove:
         from zkir_amd import service
         job = (blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
         service.prove_many([job] * 2, k, producers=1, ctx=ctx, keep_proofs=False)
         rep = service.prove_many([job] * 24, k, producers=3, ctx=ctx, keep_proofs=False)
+        service.prove_many([job] * 2, k, producers=1, ctx=ctx, keep_proofs=False, commit_only=True)
+        rc = service.prove_many([job] * 32, k, producers=3, ctx=ctx, keep_proofs=False, commit_only=True)
+        pipelined_commit = {"runs": rc.runs, "producer_threads": 3, "ms_per_committed_run": rc.ms_per_run, "rows_per_s_committed_end_to_end": rc.rows_per_s,
+                            "note": "host interpretation + H2D + the commit step (trace fill, main trace, LDE, Merkle) of independent runs, host threads overlapped with the "
+                                    "GPU: the rate of the bench step with the host and PCIe in the loop"}
         pipelined = {"runs": rep.runs, "producer_threads": 3, "ms_per_proven_run": rep.ms_per_run, "rows_per_s_proven_end_to_end": rep.rows_per_s,
                      "interpret_ms_per_run": rep.interpret_s / rep.runs * 1e3, "upload_ms_per_run": rep.upload_s / rep.runs * 1e3,
                      "note": "host interpretation + H2D + trace fill + full proof of independent 2^k-row runs, producers overlapped with the GPU (zkir_amd/service.py)"}
@@ -525,7 +535,7 @@ def main():
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
             "prover": "ZKIR-STARK v1 (self-defined; AIR of 152 columns / 259 constraints, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12)",
-            "pipelined_end_to_end": pipelined,
+            "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,
             "host_interpret_ns_per_instruction": host_s / total_rows * 1e9, "host_interpret_s": host_s,
@@ -538,6 +548,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = _cpu_baseline(blob, k, commit)
+            side = out["cpu_baseline"].get("commit_stage_self_defined")
+            if side and root is not None:
+                assert side["merkle_root"] == root, "bench: the CPU port's commitment root differs from the GPU's"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

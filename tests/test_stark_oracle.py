@@ -186,6 +186,17 @@ def test_main_trace_columns_and_commit():
     assert np.array_equal(col, L[0])
 
 
+def test_cpu_commit_port_matches_the_oracle():
+    """oracle/cpu_commit_port.cpp (the multi-threaded Montgomery port bench.py times as the CPU figure of the commit stage) computes
+    the same root as the naive oracle."""
+    for prog, n in ((spec.fib_endless_program(), 300), (spec.sha256_chain_program(), 1024)):
+        blob = prog.to_bytes()
+        rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
+        pub = so.public_inputs(len(rows), blob)
+        root, t_lde, t_merkle = so.commit_port(so.main_trace(rows, pub), 3)
+        assert np.array_equal(root, so.commit_trace(rows, 1, pub=pub)) and t_lde > 0 and t_merkle > 0
+
+
 def test_air_holds_row_by_row_on_honest_traces():
     """Every constraint vanishes on every (row, next row) pair of an honest main trace: evaluated here with the row selectors a
     verifier would use ON the trace domain (is_first = [i == 0], is_last = [i == n_real - 1], is_trans = [i != N - 1])."""

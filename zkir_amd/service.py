@@ -40,9 +40,10 @@ class PipelineReport:
 
 
 def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Optional[stark.StarkContext] = None,
-               keep_proofs: bool = True) -> PipelineReport:
+               keep_proofs: bool = True, commit_only: bool = False) -> PipelineReport:
     """Prove every job (program blob, inputs, VMConfig with enable_execution_trace; the run's row count must pad to 2^log2_rows,
-    i.e. 2^(log2_rows-1) < rows <= 2^log2_rows).  Proofs come back in job order."""
+    i.e. 2^(log2_rows-1) < rows <= 2^log2_rows).  Proofs come back in job order.  commit_only: stop after the trace commitment
+    (trace fill + main trace + LDE + Merkle); `proofs` then holds the 4-word roots."""
     pl._require_gpu()
     jobs = list(jobs)
     own_ctx = ctx is None
@@ -95,7 +96,10 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
             torch.cuda.current_stream().wait_event(ev)
             tr = pl.DeviceTrace(ddl)
             pl.trace_fill(pl.trace_fill_args(ddl, tr))
-            proof = stark.prove(ctx, tr, pub)             # returns after the proof words are on the host: the run's buffers are idle
+            if commit_only:
+                proof = stark.commit_trace(ctx, tr, deferred=bool(pub.deferred))[0]     # root on the host: the run's buffers are idle
+            else:
+                proof = stark.prove(ctx, tr, pub)         # returns after the proof words are on the host: the run's buffers are idle
             if keep_proofs:
                 out[idx] = proof
         torch.cuda.synchronize()
