@@ -192,6 +192,9 @@ typedef struct zkir_trace_fill_args {
 /* K1: expand the register-write log into the SoA trace columns (cycle, registers, bounds, states).
  * Asynchronous on `hip_stream` (a hipStream_t; NULL = default stream). */
 int zkir_trace_fill_launch(const zkir_trace_fill_args* args, void* hip_stream);
+/* The same for tiles [tile_begin, tile_end) only (args describe the whole trace): used to fill the tiles whose log has already been
+ * uploaded while the host interpreter is still producing the rest (zkir_exec does this internally). */
+int zkir_trace_fill_range_launch(const zkir_trace_fill_args* args, uint64_t tile_begin, uint64_t tile_end, void* hip_stream);
 
 /* Algorithmic HBM bytes one zkir_trace_fill_launch moves: 360*n_rows written +
  * 32*n_events + 68*n_tiles read. */
@@ -364,6 +367,9 @@ int zkir_result_sha256_witnesses(zkir_result* r, zkir_sha256_witness* out);
 
 /* D2H copy for hosts that do not link a HIP runtime themselves (the pointers above are device memory) */
 int zkir_device_to_host(void* host_dst, const void* device_src, size_t bytes);
+/* H2D copy of a host-side log array (zkir_delta_log_* pointers) into caller-owned device memory, ordered on `hip_stream`: the copy
+ * path of zkir_exec for callers that drive the stages themselves */
+int zkir_host_to_device(void* device_dst, const void* host_src, size_t bytes, void* hip_stream);
 
 const char* zkir_last_error(void);
 const char* zkir_version(void);

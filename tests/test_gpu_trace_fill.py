@@ -113,3 +113,48 @@ def test_sharded_fill_matches_unsharded():
         sh.close()
     helpers.assert_rows_equal(np.concatenate(parts), want)
     log.close()
+
+
+# ---- zkir_exec's streaming path: runs with max_cycles >= 2^17 upload the finished part of the delta log and fill its tiles from a
+# second host thread while the interpreter is still running --------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1 << 17, (1 << 17) + 5, 300_001])
+def test_streaming_exec_cycle_limit(n):
+    res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=n)
+    assert res.cycles == n
+    _check(res, want)
+    res.close()
+
+
+def test_streaming_exec_program_that_halts_early():
+    """max_cycles = 10^6 (the default), the program exits after 327,684 rows: the device columns were sized for max_cycles."""
+    blob = spec.fib_program(65536).to_bytes()
+    res, want = _run_both(blob)
+    assert res.cycles == 3 + 5 * 65535 + 6 and res.halt_reason == rt.HaltReason.Exit(0)
+    _check(res, want)
+    assert res.exec_stage_ms()["interpret"] > 0
+    res.close()
+
+
+def test_streaming_exec_abandoned_when_the_log_outgrows_its_reservation():
+    """Deferred mode writes more than 1.25 register events per row (normalisations): the interpreter has to grow the event log, the
+    uploader lets go of it and zkir_exec starts over on the plain path — same trace."""
+    res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=1 << 18, enable_deferred_model=True)
+    assert len(res.delta_log.reg_events) > 1.25 * (1 << 18)
+    _check(res, want)
+    res.close()
+
+
+def test_streaming_exec_error_after_streaming_started():
+    from zkir_amd.spec import Opcode as O, encode as E
+    A = programs.A
+    # 60000 iterations of a 4-instruction loop (240k rows), then a division by zero
+    code = [A(3, 0, 30000), E(O.SLLI, 3, 3, imm=1), A(1, 1, 1), A(3, 3, -1), spec.bne(3, 0, -8), E(O.DIV, 2, 1, 0), programs.EB]
+    blob = spec.Program.from_code(code).to_bytes()
+    with pytest.raises(rt.RuntimeError) as e:
+        rt.VM(blob, [], rt.VMConfig(enable_execution_trace=True)).run()
+    assert e.value.code == rt.ERR_DIV_ZERO
+    with pytest.raises(oracle.OracleError):
+        oracle.run(blob, enable_execution_trace=True)
+    res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=1 << 17)        # the library is fine afterwards
+    _check(res, want)
+    res.close()

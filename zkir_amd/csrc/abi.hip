@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #include "../../include/zkir_amd.h"
 #include "host.h"
@@ -147,8 +150,103 @@ const zkir_sha_block* zkir_delta_log_sha_blocks(const zkir_delta_log* l) { retur
 // ---- drop-in layer ------------------------------------------------------------------------------
 static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// Device side of zkir_exec.  The columns, the event array and the tile index are sized for `cap_rows` rows / the given capacities.
+static int alloc_trace(zkir_result* r, uint64_t cap, size_t ev_cap, size_t toff_cap, size_t snap_cap) {
+  // column block: cycle 8 | pc 8 | regs 128 | payload 128 | bits 64 | inst 4 | tag 16 | state 16  = 372 B per (padded) row
+  unsigned char* base = nullptr;
+  r->cap_rows = cap;
+  if (hipMalloc(&r->d_block, cap * 372) != hipSuccess || hipMalloc(&r->d_events, ev_cap * sizeof(zkir_reg_event)) != hipSuccess ||
+      hipMalloc(&r->d_tile_ev_off, toff_cap * 4) != hipSuccess || hipMalloc(&r->d_tile_snap, snap_cap * 4) != hipSuccess) {
+    zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("zkir_exec: hipMalloc: ") + hipGetErrorString(hipGetLastError())});
+    return ZKIR_ERR_DEVICE;
+  }
+  base = (unsigned char*)r->d_block;
+  r->cols.cycle = (uint64_t*)base;                   base += cap * 8;
+  r->cols.pc = (uint64_t*)base;                      base += cap * 8;
+  r->cols.registers = (uint64_t*)base;               base += cap * 128;
+  r->cols.bound_payload = (uint64_t*)base;           base += cap * 128;
+  r->cols.bound_bits = (uint32_t*)base;              base += cap * 64;
+  r->cols.instruction = (uint32_t*)base;             base += cap * 4;
+  r->cols.bound_tag = (uint8_t*)base;                base += cap * 16;
+  r->cols.reg_state = (uint8_t*)base;                base += cap * 16;
+  r->cols.reg_stride = cap;
+  return ZKIR_OK;
+}
+static void free_trace(zkir_result* r) {
+  if (r->d_block) (void)hipFree(r->d_block);
+  if (r->d_events) (void)hipFree(r->d_events);
+  if (r->d_tile_ev_off) (void)hipFree(r->d_tile_ev_off);
+  if (r->d_tile_snap) (void)hipFree(r->d_tile_snap);
+  r->d_block = r->d_events = r->d_tile_ev_off = r->d_tile_snap = nullptr;
+  r->cols = zkir_trace_columns{};
+}
+
+// Uploads what the running interpreter has finished (zkir::Progress) and fills those tiles, on its own thread and stream, so that
+// the H2D copy of the delta log and K1 hide under the interpretation instead of following it.
+struct ExecStreamer {
+  zkir_result* r; const zkir_delta_log* log; zkir::Progress prog; uint64_t max_cycles; int device;
+  std::thread th;
+  hipStream_t stream = nullptr;
+  bool active = false, abandoned = false, failed = false;
+  uint64_t up_rows = 0, up_events = 0, up_tiles = 0, up_toff = 0;
+  std::string error;
+
+  zkir_trace_fill_args args() const {
+    zkir_trace_fill_args a{};
+    a.events = (const zkir_reg_event*)r->d_events; a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off; a.tile_snap = (const uint32_t*)r->d_tile_snap;
+    a.n_rows = r->cap_rows; a.cycle_base = 0; a.tile_rows = log->tile_rows; a.n_events = 0; a.out = r->cols;
+    return a;
+  }
+  // copy rows / events / tile index up to (tiles, rows, events) and fill the new complete tiles
+  bool advance(uint64_t tiles, uint64_t rows, uint64_t events, uint64_t toff_entries) {
+    auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess) { error = std::string(what) + ": " + hipGetErrorString(e); failed = true; } return e == hipSuccess; };
+    if (rows > up_rows) {
+      if (!ok(hipMemcpyAsync(r->cols.pc + up_rows, log->pc.data() + up_rows, (rows - up_rows) * 8, hipMemcpyHostToDevice, stream), "H2D pc")) return false;
+      if (!ok(hipMemcpyAsync(r->cols.instruction + up_rows, log->inst.data() + up_rows, (rows - up_rows) * 4, hipMemcpyHostToDevice, stream), "H2D instruction")) return false;
+    }
+    if (events > up_events && !ok(hipMemcpyAsync((zkir_reg_event*)r->d_events + up_events, log->reg_events.data() + up_events, (events - up_events) * sizeof(zkir_reg_event),
+                                                hipMemcpyHostToDevice, stream), "H2D events")) return false;
+    if (toff_entries > up_toff && !ok(hipMemcpyAsync((uint32_t*)r->d_tile_ev_off + up_toff, log->tile_ev_off.data() + up_toff, (toff_entries - up_toff) * 4, hipMemcpyHostToDevice, stream),
+                                      "H2D tile index")) return false;
+    if (tiles > up_tiles && !ok(hipMemcpyAsync((uint32_t*)r->d_tile_snap + up_tiles * 16, log->tile_snap.data() + up_tiles * 16, (tiles - up_tiles) * 64, hipMemcpyHostToDevice, stream),
+                                "H2D tile snapshots")) return false;
+    const zkir_trace_fill_args a = args();
+    if (tiles > up_tiles && zkir_trace_fill_range_launch(&a, up_tiles, tiles, stream) != ZKIR_OK) { error = zkir_last_error(); failed = true; return false; }
+    up_rows = rows; up_events = events; up_tiles = tiles; up_toff = toff_entries;
+    return true;
+  }
+  void body() {
+    (void)hipSetDevice(device);
+    const uint32_t T = log->tile_rows;
+    for (;;) {
+      const bool fin = prog.finished.load();
+      if (!prog.stable.load()) { abandoned = true; break; }
+      const uint64_t t = prog.tiles.load(std::memory_order_acquire);
+      if (t > up_tiles && t * T >= (1u << 16)) {                           // short runs never start streaming (no device allocation for max_cycles rows)
+        prog.consumer_idle.store(false);
+        if (!prog.stable.load()) { prog.consumer_idle.store(true); abandoned = true; break; }
+        const uint64_t rows = prog.rows.load(std::memory_order_relaxed), events = prog.events.load(std::memory_order_relaxed);
+        if (!active) {
+          const uint64_t cap = (max_cycles + T - 1) / T * T;
+          if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+              alloc_trace(r, cap, log->reg_events.capacity(), log->tile_ev_off.capacity(), log->tile_snap.capacity()) != ZKIR_OK) { failed = true; error = zkir_last_error(); }
+          active = !failed;
+        }
+        if (!failed) advance(t, rows, events, t + 1);
+        prog.consumer_idle.store(true);
+        if (failed) break;
+      } else if (fin) {
+        break;
+      } else {
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+    }
+    prog.consumer_idle.store(true);
+  }
+};
+
 int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, zkir_result** out) {
-  if (!out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_exec: null out"}); return ZKIR_ERR_ARGUMENT; }
+  if (!out || !cfg) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_exec: null argument"}); return ZKIR_ERR_ARGUMENT; }
   *out = nullptr;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
@@ -157,60 +255,79 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
   }
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t0) { return std::chrono::duration<float, std::milli>(clk::now() - t0).count(); };
-  zkir_delta_log* log = nullptr;
-  auto t0 = clk::now();
-  int rc = zkir_interpret(blob, len, inputs, n_inputs, cfg, 0, &log);
-  if (rc != ZKIR_OK) return rc;
   zkir_result* r = new zkir_result();
+  zkir_delta_log* log = new zkir_delta_log();
   r->log = log;
-  r->stage_ms[0] = ms_since(t0);
-  const uint64_t n = log->n_rows;
-  if (n > 0) {
-    const uint32_t T = log->tile_rows;
-    const uint64_t cap = round_up(n, T);
-    r->cap_rows = cap;
-    // column block: cycle 8 | pc 8 | inst 4 | regs 128 | bits 64 | tag 16 | payload 128 | state 16  = 372 B per (padded) row
-    const uint64_t bytes = cap * 372;
-    unsigned char* base = nullptr;
-    hipStream_t s = nullptr;
-    zkir_trace_fill_args a{};
-    t0 = clk::now();
-    HIP_TRY(hipMalloc(&r->d_block, bytes));
-    base = (unsigned char*)r->d_block;
-    r->cols.cycle = (uint64_t*)base;                   base += cap * 8;
-    r->cols.pc = (uint64_t*)base;                      base += cap * 8;
-    r->cols.registers = (uint64_t*)base;               base += cap * 128;
-    r->cols.bound_payload = (uint64_t*)base;           base += cap * 128;
-    r->cols.bound_bits = (uint32_t*)base;              base += cap * 64;
-    r->cols.instruction = (uint32_t*)base;             base += cap * 4;
-    r->cols.bound_tag = (uint8_t*)base;                base += cap * 16;
-    r->cols.reg_state = (uint8_t*)base;                base += cap * 16;
-    r->cols.reg_stride = cap;
-    HIP_TRY(hipMalloc(&r->d_events, log->reg_events.size() * sizeof(zkir_reg_event)));
-    HIP_TRY(hipMalloc(&r->d_tile_ev_off, log->tile_ev_off.size() * 4));
-    HIP_TRY(hipMalloc(&r->d_tile_snap, log->tile_snap.size() * 4));
-    r->stage_ms[1] = ms_since(t0); t0 = clk::now();
-    HIP_TRY(hipMemcpyAsync(r->d_events, log->reg_events.data(), log->reg_events.size() * sizeof(zkir_reg_event), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->d_tile_ev_off, log->tile_ev_off.data(), log->tile_ev_off.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->d_tile_snap, log->tile_snap.data(), log->tile_snap.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->cols.pc, log->pc.data(), n * 8, hipMemcpyHostToDevice, s));           // pc / instruction columns arrive in final form
-    HIP_TRY(hipMemcpyAsync(r->cols.instruction, log->inst.data(), n * 4, hipMemcpyHostToDevice, s));
-    r->stage_ms[2] = ms_since(t0); t0 = clk::now();
-    a.events = (const zkir_reg_event*)r->d_events;
-    a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off;
-    a.tile_snap = (const uint32_t*)r->d_tile_snap;
-    a.n_rows = n; a.cycle_base = 0; a.tile_rows = T; a.n_events = (uint32_t)log->reg_events.size();
-    a.out = r->cols;
-    rc = zkir_trace_fill_launch(&a, s);
-    if (rc != ZKIR_OK) goto fail_rc;
-    HIP_TRY(hipStreamSynchronize(s));
-    r->stage_ms[3] = ms_since(t0);
+  // Long traced runs stream: a second host thread uploads the finished part of the delta log and launches K1 on it while the
+  // interpreter keeps running (ZKIR_EXEC_STREAM=0 turns it off).  Everything else takes the plain path: interpret, upload, fill.
+  static const bool stream_ok = !(getenv("ZKIR_EXEC_STREAM") && atoi(getenv("ZKIR_EXEC_STREAM")) == 0);
+  const bool streaming = stream_ok && cfg->enable_execution_trace && cfg->max_cycles >= (1ull << 17) && cfg->max_cycles <= (1ull << 26);
+  std::unique_ptr<ExecStreamer> st;
+  if (streaming) {
+    st.reset(new ExecStreamer());
+    st->r = r; st->log = log; st->max_cycles = cfg->max_cycles; st->device = 0;
+    (void)hipGetDevice(&st->device);
   }
+  auto t0 = clk::now();
+  zkir::Status status;
+  if (streaming) st->th = std::thread([&] { st->body(); });
+  try {
+    status = zkir::interpret(blob, len, inputs, n_inputs, *cfg, 0, *log, streaming ? &st->prog : nullptr);
+  } catch (const std::bad_alloc&) {
+    status = {ZKIR_ERR_OTHER, "out of host memory while recording the delta log"};
+  }
+  if (streaming) { st->prog.finished.store(true); st->th.join(); }
+  r->stage_ms[0] = ms_since(t0);
+  int rc = ZKIR_OK;
+  hipStream_t s = nullptr;
+  if (!status.ok()) { zkir::set_last_error(status); rc = status.code; goto fail_rc; }
+  if (streaming && st->failed) { zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_exec (streaming): " + st->error}); rc = ZKIR_ERR_DEVICE; goto fail_rc; }
+  {
+    const uint64_t n = log->n_rows;
+    if (n > 0) {
+      const uint32_t T = log->tile_rows;
+      const uint64_t n_tiles = (n + T - 1) / T;
+      if (streaming && st->active && !st->abandoned) {                     // the tail: what the interpreter produced after the last report
+        t0 = clk::now();
+        s = st->stream;
+        if (!st->advance(n_tiles, n, log->reg_events.size(), n_tiles + 1)) { zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_exec (streaming): " + st->error}); rc = ZKIR_ERR_DEVICE; goto fail_rc; }
+        r->stage_ms[2] = ms_since(t0); t0 = clk::now();
+        HIP_TRY(hipStreamSynchronize(s));
+        r->stage_ms[3] = ms_since(t0);
+      } else {
+        if (streaming && st->active) { HIP_TRY(hipStreamSynchronize(st->stream)); free_trace(r); }   // streaming was abandoned (a log buffer had to grow): start over
+        zkir_trace_fill_args a{};
+        t0 = clk::now();
+        rc = alloc_trace(r, round_up(n, T), log->reg_events.size(), log->tile_ev_off.size(), log->tile_snap.size());
+        if (rc != ZKIR_OK) goto fail_rc;
+        r->stage_ms[1] = ms_since(t0); t0 = clk::now();
+        HIP_TRY(hipMemcpyAsync(r->d_events, log->reg_events.data(), log->reg_events.size() * sizeof(zkir_reg_event), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(r->d_tile_ev_off, log->tile_ev_off.data(), log->tile_ev_off.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(r->d_tile_snap, log->tile_snap.data(), log->tile_snap.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(r->cols.pc, log->pc.data(), n * 8, hipMemcpyHostToDevice, s));           // pc / instruction columns arrive in final form
+        HIP_TRY(hipMemcpyAsync(r->cols.instruction, log->inst.data(), n * 4, hipMemcpyHostToDevice, s));
+        r->stage_ms[2] = ms_since(t0); t0 = clk::now();
+        a.events = (const zkir_reg_event*)r->d_events;
+        a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off;
+        a.tile_snap = (const uint32_t*)r->d_tile_snap;
+        a.n_rows = n; a.cycle_base = 0; a.tile_rows = T; a.n_events = (uint32_t)log->reg_events.size();
+        a.out = r->cols;
+        rc = zkir_trace_fill_launch(&a, s);
+        if (rc != ZKIR_OK) goto fail_rc;
+        HIP_TRY(hipStreamSynchronize(s));
+        r->stage_ms[3] = ms_since(t0);
+      }
+    } else if (streaming && st->active) {
+      HIP_TRY(hipStreamSynchronize(st->stream)); free_trace(r);
+    }
+  }
+  if (streaming && st->stream) (void)hipStreamDestroy(st->stream);
   *out = r;
   return ZKIR_OK;
 fail:
   rc = ZKIR_ERR_DEVICE;
 fail_rc:
+  if (streaming && st && st->stream) { (void)hipStreamSynchronize(st->stream); (void)hipStreamDestroy(st->stream); }
   zkir_result_free(r);
   return rc;
 }
@@ -382,6 +499,13 @@ int zkir_result_sha256_witnesses(zkir_result* r, zkir_sha256_witness* out) {
     r->sha_built = true;
   }
   *out = r->sha;
+  return ZKIR_OK;
+}
+
+int zkir_host_to_device(void* device_dst, const void* host_src, size_t bytes, void* stream) {
+  if (bytes == 0) return ZKIR_OK;
+  const hipError_t e = hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("hipMemcpy H2D: ") + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
   return ZKIR_OK;
 }
 

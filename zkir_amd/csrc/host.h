@@ -3,6 +3,7 @@
 
 #include <sys/mman.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,7 @@ class Buf {
     n_ += n;
   }
   size_t size() const { return n_; }
+  size_t capacity() const { return cap_; }
   const T* data() const { return p_; }
   T* data() { return p_; }
   const T& operator[](size_t i) const { return p_[i]; }
@@ -118,8 +120,18 @@ struct zkir_delta_log {
 namespace zkir {
 using DeltaLog = ::zkir_delta_log;
 
+// Progress of a running interpretation, for a consumer on another thread (zkir_exec's uploader).  The interpreter publishes, every
+// few tiles, how many COMPLETE tiles / rows / register events the log holds; nothing it has published is ever moved or rewritten as
+// long as `stable` stays true (buffers are pre-reserved; if one would have to grow, the interpreter clears `stable` and waits for
+// `consumer_idle` before reallocating — the consumer then abandons streaming).
+struct Progress {
+  std::atomic<uint64_t> tiles{0}, rows{0}, events{0};
+  std::atomic<bool> stable{true}, consumer_idle{true}, finished{false};
+};
+
 Status parse_program(const uint8_t* blob, size_t len, ProgramView& pv);
-Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log);
+Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log,
+                 Progress* progress = nullptr);
 
 // hashes.cpp — the digests behind syscalls 3/5/6 (zkir-runtime/src/crypto.rs uses sha2 / sha3::Keccak256 / blake3)
 void sha256(const uint8_t* data, size_t len, uint32_t out_be_words[8]);

@@ -221,8 +221,8 @@ namespace {
 
 class Machine {
  public:
-  Machine(const ProgramView& pv, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, DeltaLog& log)
-      : cfg_(cfg), log_(log), inputs_(inputs), n_inputs_(n_inputs) {
+  Machine(const ProgramView& pv, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, DeltaLog& log, Progress* progress)
+      : cfg_(cfg), log_(log), inputs_(inputs), n_inputs_(n_inputs), progress_(progress) {
     tracing_ = cfg.enable_execution_trace != 0;
     deferred_ = cfg.enable_deferred_model != 0;
     range_ = cfg.enable_range_checking != 0;
@@ -340,6 +340,7 @@ class Machine {
   ICacheEntry icache_[NICACHE];
 
   std::vector<PendingCheck> pending_;
+  Progress* progress_ = nullptr;
   uint64_t code_bytes_ = 0;
   std::vector<uint32_t> words_;
   std::vector<Decoded> dec_;
@@ -588,8 +589,21 @@ Status Machine::run_loop() {
       if (cycle_ + chunk >= 0xFFFFFFF0ull || log_.reg_events.size() + 4 * chunk >= 0xFFFFFFC0ull)              // event / row indices are 32-bit (tile index, vis)
         return {ZKIR_ERR_OTHER, "trace longer than 2^32-16 rows or 2^32-64 register events is not supported"};
       if ((cycle_ & (T - 1)) == 0) {                                    // tile index: events visible at the tile's first row
+        if (progress_ && progress_->stable.load(std::memory_order_relaxed) &&
+            (log_.reg_events.size() + 4 * chunk > log_.reg_events.capacity() || log_.tile_ev_off.size() + 2 > log_.tile_ev_off.capacity() ||
+             log_.pc.size() + chunk > log_.pc.capacity())) {            // a buffer is about to move: the consumer must let go of the log first
+          progress_->stable.store(false);                               // (sequentially consistent: paired with the consumer's idle / stable handshake)
+          while (!progress_->consumer_idle.load()) _mm_pause();
+        }
         log_.tile_ev_off.push_back((uint32_t)log_.reg_events.size());
         for (int r = 0; r < 16; r++) log_.tile_snap.push_back(last_ev[r]);
+        if (progress_ && (log_.tile_ev_off.size() & 31) == 1 && progress_->stable.load(std::memory_order_relaxed)) {   // every 32 tiles
+          _mm_sfence();                                                 // the streaming stores of the finished tiles are visible
+          const uint64_t t = log_.tile_ev_off.size() - 1;
+          progress_->events.store(log_.reg_events.size(), std::memory_order_relaxed);
+          progress_->rows.store(cycle_, std::memory_order_relaxed);
+          progress_->tiles.store(t, std::memory_order_release);
+        }
       }
       pc_out = log_.pc.grow(chunk); inst_out = log_.inst.grow(chunk);
       ev_out = log_.reg_events.grow(4 * chunk);                         // at most 3 registers change per instruction (deferred-mode normalisations + rd)
@@ -657,7 +671,8 @@ Status Machine::run_loop() {
 
 }  // namespace
 
-Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log) {
+Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log,
+                 Progress* progress) {
   ProgramView pv;
   Status st = parse_program(blob, len, pv);
   if (!st.ok()) return st;
@@ -667,8 +682,14 @@ Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t
   if (tile_rows == 0) tile_rows = cfg.max_cycles <= (1ull << 21) ? 256u : 512u;   // measured best on MI355X (profiles/r01_sweep_trace_fill.txt)
   if (tile_rows < 256 || tile_rows > 2048 || (tile_rows & (tile_rows - 1))) return {ZKIR_ERR_ARGUMENT, "tile_rows must be a power of two in 256..2048"};   // K1 instantiations (trace_fill.hip); 4096 would need 262 KB of LDS
   log.tile_rows = tile_rows;
-  if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 28)) { log.pc.reserve(cfg.max_cycles); log.inst.reserve(cfg.max_cycles); log.reg_events.reserve(cfg.max_cycles + 16); }
-  std::unique_ptr<Machine> m(new Machine(pv, inputs, n_inputs, cfg, log));   // ~170 KB (icache): heap, released on every path
+  if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 28)) {
+    log.pc.reserve(cfg.max_cycles); log.inst.reserve(cfg.max_cycles);
+    // with a streaming consumer the event log and the tile index must not move while it reads them: room for 1.25 events per row
+    // (the fib loop writes 0.8) and for every tile; a run that needs more makes the consumer give up streaming (Progress::stable)
+    log.reg_events.reserve(progress ? cfg.max_cycles + cfg.max_cycles / 4 + 4096 : cfg.max_cycles + 16);
+    if (progress) { log.tile_ev_off.reserve(cfg.max_cycles / tile_rows + 4); log.tile_snap.reserve((cfg.max_cycles / tile_rows + 4) * 16); }
+  }
+  std::unique_ptr<Machine> m(new Machine(pv, inputs, n_inputs, cfg, log, progress));   // ~170 KB (icache): heap, released on every path
   return m->run();
 }
 

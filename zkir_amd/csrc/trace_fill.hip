@@ -45,7 +45,7 @@ struct alignas(16) EvLds { uint32_t dw[8]; };
 
 template <int T, int NT, int EVCAP, bool NTS>
 __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __restrict__ events, const uint32_t* __restrict__ tile_ev_off,
-                                                          const uint32_t* __restrict__ tile_snap, uint64_t cycle_base, uint64_t* __restrict__ col_cycle,
+                                                          const uint32_t* __restrict__ tile_snap, uint32_t tile0, uint64_t cycle_base, uint64_t* __restrict__ col_cycle,
                                                           uint64_t* __restrict__ col_reg, uint32_t* __restrict__ col_bits, uint8_t* __restrict__ col_tag,
                                                           uint64_t* __restrict__ col_payload, uint8_t* __restrict__ col_state, uint64_t reg_stride) {
   static_assert(T % 128 == 0 && NT % 64 == 0, "tile geometry");
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = blockIdx.x + tile0;                                     // tile0: first tile of a partial launch (zkir_trace_fill_range_launch)
   const uint64_t row0 = (uint64_t)tile * T;
   const uint32_t ev_lo = tile_ev_off[tile], ev_hi = tile_ev_off[tile + 1];
   const uint32_t m = ev_hi - ev_lo;                                             // events becoming visible at rows row0+1 .. row0+T
@@ -191,13 +191,13 @@ __global__ __launch_bounds__(NT) void trace_fill_kernel(const zkir_reg_event* __
 }
 
 template <int T, int NT, bool NTS>
-int launch_tile(const zkir_trace_fill_args* a, uint32_t n_tiles, hipStream_t stream) {
+int launch_tile(const zkir_trace_fill_args* a, uint32_t tile0, uint32_t n_tiles, hipStream_t stream) {
   constexpr int EVCAP = 16 + T;
   constexpr size_t lds = sizeof(EvLds) * EVCAP + 2 * 16 * T + 16;
   auto k = trace_fill_kernel<T, NT, EVCAP, NTS>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  hipLaunchKernelGGL(k, dim3(n_tiles), dim3(NT), lds, stream, a->events, a->tile_ev_off, a->tile_snap, a->cycle_base, a->out.cycle, a->out.registers,
+  hipLaunchKernelGGL(k, dim3(n_tiles), dim3(NT), lds, stream, a->events, a->tile_ev_off, a->tile_snap, tile0, a->cycle_base, a->out.cycle, a->out.registers,
                      a->out.bound_bits, a->out.bound_tag, a->out.bound_payload, a->out.reg_state, a->out.reg_stride);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("trace_fill launch failed: ") + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
@@ -206,11 +206,21 @@ int launch_tile(const zkir_trace_fill_args* a, uint32_t n_tiles, hipStream_t str
 
 }  // namespace
 
+extern "C" int zkir_trace_fill_range_launch(const zkir_trace_fill_args* a, uint64_t tile_begin, uint64_t tile_end, void* hip_stream);
 extern "C" int zkir_trace_fill_launch(const zkir_trace_fill_args* a, void* hip_stream) {
   if (!a) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_trace_fill_launch: null args"}); return ZKIR_ERR_ARGUMENT; }
-  if (a->n_rows == 0) return ZKIR_OK;
+  return zkir_trace_fill_range_launch(a, 0, (a->n_rows + a->tile_rows - 1) / (a->tile_rows ? a->tile_rows : 1), hip_stream);
+}
+
+// tiles [tile_begin, tile_end) of the trace described by `a` (its arrays and columns are those of the WHOLE trace): what a caller
+// that streams the delta log to the device while the interpreter is still running launches for the tiles it already has
+extern "C" int zkir_trace_fill_range_launch(const zkir_trace_fill_args* a, uint64_t tile_begin, uint64_t tile_end, void* hip_stream) {
+  if (!a) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_trace_fill_launch: null args"}); return ZKIR_ERR_ARGUMENT; }
+  if (a->n_rows == 0 || tile_begin >= tile_end) return ZKIR_OK;
   const uint32_t T = a->tile_rows;
   const uint64_t n_tiles = (a->n_rows + T - 1) / T;
+  if (tile_end > n_tiles) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_trace_fill_range_launch: tile range past the end of the trace"}); return ZKIR_ERR_ARGUMENT; }
+  const uint32_t t0 = (uint32_t)tile_begin, cnt = (uint32_t)(tile_end - tile_begin);
   if (a->out.reg_stride < n_tiles * T || (a->out.reg_stride & 15)) {
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_trace_fill_launch: reg_stride must be a multiple of 16 and >= n_rows rounded up to tile_rows"});
     return ZKIR_ERR_ARGUMENT;
@@ -223,8 +233,8 @@ extern "C" int zkir_trace_fill_launch(const zkir_trace_fill_args* a, void* hip_s
   static const int nts = getenv("ZKIR_TF_NT") ? atoi(getenv("ZKIR_TF_NT")) : 1;
 #define ZKIR_TF_CASE(TT)                                                                          \
   case TT:                                                                                        \
-    if (threads == 512) rc = nts ? launch_tile<TT, 512, true>(a, (uint32_t)n_tiles, s) : launch_tile<TT, 512, false>(a, (uint32_t)n_tiles, s); \
-    else rc = nts ? launch_tile<TT, 256, true>(a, (uint32_t)n_tiles, s) : launch_tile<TT, 256, false>(a, (uint32_t)n_tiles, s);               \
+    if (threads == 512) rc = nts ? launch_tile<TT, 512, true>(a, t0, cnt, s) : launch_tile<TT, 512, false>(a, t0, cnt, s); \
+    else rc = nts ? launch_tile<TT, 256, true>(a, t0, cnt, s) : launch_tile<TT, 256, false>(a, t0, cnt, s);               \
     break;
   switch (T) {
     ZKIR_TF_CASE(256)

@@ -22,13 +22,13 @@ def _require_gpu():
 
 
 def _to_dev(a: np.ndarray, device) -> torch.Tensor:
-    """Upload raw bytes of a (possibly structured) numpy array as a uint8 tensor."""
+    """Upload raw bytes of a (possibly structured) numpy array as a uint8 tensor: one hipMemcpy straight from the delta log's host
+    buffer (zkir_host_to_device, the copy path of zkir_exec), ordered on torch's current stream."""
     flat = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-    if flat.size == 0:
-        return torch.empty(0, dtype=torch.uint8, device=device)
-    if not flat.flags.writeable:                       # torch.from_numpy wants a writable buffer; the delta-log views are read-only
-        flat = flat.copy()
-    return torch.from_numpy(flat).to(device, non_blocking=False)     # straight from the delta log's host buffer (no staging copy)
+    out = torch.empty(flat.size, dtype=torch.uint8, device=device)
+    if flat.size:
+        _check(rt.lib().zkir_host_to_device(out.data_ptr(), flat.ctypes.data, flat.size, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
 
 
 @dataclass

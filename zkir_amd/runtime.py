@@ -205,6 +205,8 @@ def lib() -> C.CDLL:
         f = getattr(L, "zkir_result_" + name)
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.POINTER(st)]
+    L.zkir_host_to_device.restype = C.c_int
+    L.zkir_host_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zkir_device_to_host.restype = C.c_int
     L.zkir_device_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
