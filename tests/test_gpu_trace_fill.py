@@ -136,9 +136,13 @@ def test_streaming_exec_program_that_halts_early():
 
 
 def test_streaming_exec_abandoned_when_the_log_outgrows_its_reservation():
-    """Deferred mode writes more than 1.25 register events per row (normalisations): the interpreter has to grow the event log, the
-    uploader lets go of it and zkir_exec starts over on the plain path — same trace."""
-    res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=1 << 18, enable_deferred_model=True)
+    """A loop whose XORs force a normalisation of both operands each time writes more than the 1.25 register events per row the
+    streaming path reserves: the interpreter has to grow the event log, the uploader lets go of it and zkir_exec starts over on the
+    plain path — same trace."""
+    from zkir_amd.spec import Opcode as O, encode as E
+    code = [spec.addi(1, 0, 5), spec.addi(2, 0, 9), spec.add(1, 1, 0), spec.add(2, 2, 0), E(O.XOR, 3, 1, 2),
+            spec.add(1, 1, 0), spec.add(2, 2, 0), E(O.XOR, 3, 1, 2), spec.jal(0, -24)]
+    res, want = _run_both(spec.Program.from_code(code).to_bytes(), max_cycles=1 << 18, enable_deferred_model=True)
     assert len(res.delta_log.reg_events) > 1.25 * (1 << 18)
     _check(res, want)
     res.close()

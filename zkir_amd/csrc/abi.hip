@@ -183,6 +183,15 @@ static void free_trace(zkir_result* r) {
 
 // Uploads what the running interpreter has finished (zkir::Progress) and fills those tiles, on its own thread and stream, so that
 // the H2D copy of the delta log and K1 hide under the interpretation instead of following it.
+// streams are recycled (creating and destroying one per call costs more than the copies it carries)
+static std::mutex g_stream_mu;
+static std::vector<hipStream_t> g_streams;
+static hipError_t acquire_stream(hipStream_t* s) {
+  { std::lock_guard<std::mutex> lk(g_stream_mu); if (!g_streams.empty()) { *s = g_streams.back(); g_streams.pop_back(); return hipSuccess; } }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+static void release_stream(hipStream_t s) { std::lock_guard<std::mutex> lk(g_stream_mu); g_streams.push_back(s); }
+
 struct ExecStreamer {
   zkir_result* r; const zkir_delta_log* log; zkir::Progress prog; uint64_t max_cycles; int device;
   std::thread th;
@@ -228,7 +237,7 @@ struct ExecStreamer {
         const uint64_t rows = prog.rows.load(std::memory_order_relaxed), events = prog.events.load(std::memory_order_relaxed);
         if (!active) {
           const uint64_t cap = (max_cycles + T - 1) / T * T;
-          if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+          if (acquire_stream(&stream) != hipSuccess ||
               alloc_trace(r, cap, log->reg_events.capacity(), log->tile_ev_off.capacity(), log->tile_snap.capacity()) != ZKIR_OK) { failed = true; error = zkir_last_error(); }
           active = !failed;
         }
@@ -321,13 +330,13 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
       HIP_TRY(hipStreamSynchronize(st->stream)); free_trace(r);
     }
   }
-  if (streaming && st->stream) (void)hipStreamDestroy(st->stream);
+  if (streaming && st->stream) release_stream(st->stream);
   *out = r;
   return ZKIR_OK;
 fail:
   rc = ZKIR_ERR_DEVICE;
 fail_rc:
-  if (streaming && st && st->stream) { (void)hipStreamSynchronize(st->stream); (void)hipStreamDestroy(st->stream); }
+  if (streaming && st && st->stream) { (void)hipStreamSynchronize(st->stream); release_stream(st->stream); }
   zkir_result_free(r);
   return rc;
 }

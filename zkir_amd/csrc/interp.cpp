@@ -597,7 +597,7 @@ Status Machine::run_loop() {
         }
         log_.tile_ev_off.push_back((uint32_t)log_.reg_events.size());
         for (int r = 0; r < 16; r++) log_.tile_snap.push_back(last_ev[r]);
-        if (progress_ && (log_.tile_ev_off.size() & 31) == 1 && progress_->stable.load(std::memory_order_relaxed)) {   // every 32 tiles
+        if (progress_ && (log_.tile_ev_off.size() & 511) == 1 && progress_->stable.load(std::memory_order_relaxed)) {   // every 512 tiles
           _mm_sfence();                                                 // the streaming stores of the finished tiles are visible
           const uint64_t t = log_.tile_ev_off.size() - 1;
           progress_->events.store(log_.reg_events.size(), std::memory_order_relaxed);
