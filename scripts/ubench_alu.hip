@@ -313,6 +313,76 @@ __global__ void k_subrev(uint32_t* out, uint32_t c) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// ---- 64-bit (register pair) operand kernels: double-precision and packed-f32 instructions ----
+#define K64(NAME, ASM) \
+__global__ void NAME(uint32_t* out, uint32_t c) { \
+  double x[8]; \
+  for (int j = 0; j < 8; j++) x[j] = 1.0 + (double)(threadIdx.x + j) * 1e-9; \
+  const double cc = 1.0 + (double)c * 1e-12; \
+  for (int i = 0; i < ITER; i++) { \
+    asm volatile(ASM : "+v"(x[0]) : "v"(cc)); asm volatile(ASM : "+v"(x[1]) : "v"(cc)); asm volatile(ASM : "+v"(x[2]) : "v"(cc)); asm volatile(ASM : "+v"(x[3]) : "v"(cc)); \
+    asm volatile(ASM : "+v"(x[4]) : "v"(cc)); asm volatile(ASM : "+v"(x[5]) : "v"(cc)); asm volatile(ASM : "+v"(x[6]) : "v"(cc)); asm volatile(ASM : "+v"(x[7]) : "v"(cc)); \
+  } \
+  double r = 0; for (int j = 0; j < 8; j++) r += x[j]; \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)__double_as_longlong(r); \
+}
+K64(k_add_f64, "v_add_f64 %0, %0, %1")
+K64(k_mul_f64, "v_mul_f64 %0, %0, %1")
+K64(k_fma_f64, "v_fma_f64 %0, %0, %1, %1")
+K64(k_rndne_f64, "v_rndne_f64 %0, %0")
+K64(k_max_f64, "v_max_f64 %0, %0, %1")
+K64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %1")
+K64(k_pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+K64(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+K64(k_cmp_f64, "v_cmp_lt_f64 vcc, %0, %1")
+K64(k_lshl_add_u64b, "v_lshl_add_u64 %0, %0, 0, %1")
+// conversions: 64 <-> 32 (one side a pair)
+__global__ void k_cvt_f64_u32(uint32_t* out, uint32_t c) {
+  double x[8]; uint32_t a = threadIdx.x + c;
+  for (int j = 0; j < 8; j++) x[j] = 0;
+#define S(j) asm volatile("v_cvt_f64_u32 %0, %1" : "+v"(x[j]) : "v"(a));
+  CHAIN8(S)
+#undef S
+  double r = 0; for (int j = 0; j < 8; j++) r += x[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)__double_as_longlong(r);
+}
+__global__ void k_cvt_f64_i32(uint32_t* out, uint32_t c) {
+  double x[8]; uint32_t a = threadIdx.x + c;
+  for (int j = 0; j < 8; j++) x[j] = 0;
+#define S(j) asm volatile("v_cvt_f64_i32 %0, %1" : "+v"(x[j]) : "v"(a));
+  CHAIN8(S)
+#undef S
+  double r = 0; for (int j = 0; j < 8; j++) r += x[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)__double_as_longlong(r);
+}
+__global__ void k_cvt_u32_f64(uint32_t* out, uint32_t c) {
+  uint32_t x[8]; double a = 3.0 + threadIdx.x + c;
+  for (int j = 0; j < 8; j++) x[j] = 0;
+#define S(j) asm volatile("v_cvt_u32_f64 %0, %1" : "+v"(x[j]) : "v"(a));
+  CHAIN8(S)
+#undef S
+  uint32_t r = 0; for (int j = 0; j < 8; j++) r ^= x[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_cvt_i32_f64(uint32_t* out, uint32_t c) {
+  uint32_t x[8]; double a = 3.0 + threadIdx.x + c;
+  for (int j = 0; j < 8; j++) x[j] = 0;
+#define S(j) asm volatile("v_cvt_i32_f64 %0, %1" : "+v"(x[j]) : "v"(a));
+  CHAIN8(S)
+#undef S
+  uint32_t r = 0; for (int j = 0; j < 8; j++) r ^= x[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_mul_f32(uint32_t* out, uint32_t c) {
+  uint32_t x[8];
+  for (int j = 0; j < 8; j++) x[j] = threadIdx.x + j;
+#define S(j) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[j]) : "v"(c) : "vcc");
+  CHAIN8(S)
+#undef S
+  uint32_t r = 0; for (int j = 0; j < 8; j++) r ^= x[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 template <typename K>
 void run(const char* name, K kernel, uint32_t* d_out, double clk_ghz, int n_simd) {
   const int blocks = 256 * 8, threads = 512;                  // 8 workgroups of 8 waves per CU -> 16 waves per SIMD
@@ -373,6 +443,21 @@ int main() {
   run("v_pk_add_u16", k_pkadd, d_out, clk, n_simd);
   run("v_pk_min_u16", k_pkmin, d_out, clk, n_simd);
   run("v_subrev_u32", k_subrev, d_out, clk, n_simd);
+  run("v_mul_f32", k_mul_f32, d_out, clk, n_simd);
+  run("v_add_f64", k_add_f64, d_out, clk, n_simd);
+  run("v_mul_f64", k_mul_f64, d_out, clk, n_simd);
+  run("v_fma_f64", k_fma_f64, d_out, clk, n_simd);
+  run("v_rndne_f64", k_rndne_f64, d_out, clk, n_simd);
+  run("v_max_f64", k_max_f64, d_out, clk, n_simd);
+  run("v_cmp_lt_f64", k_cmp_f64, d_out, clk, n_simd);
+  run("v_pk_fma_f32", k_pk_fma_f32, d_out, clk, n_simd);
+  run("v_pk_add_f32", k_pk_add_f32, d_out, clk, n_simd);
+  run("v_pk_mul_f32", k_pk_mul_f32, d_out, clk, n_simd);
+  run("v_lshl_add_u64 (acc)", k_lshl_add_u64b, d_out, clk, n_simd);
+  run("v_cvt_f64_u32", k_cvt_f64_u32, d_out, clk, n_simd);
+  run("v_cvt_f64_i32", k_cvt_f64_i32, d_out, clk, n_simd);
+  run("v_cvt_u32_f64", k_cvt_u32_f64, d_out, clk, n_simd);
+  run("v_cvt_i32_f64", k_cvt_i32_f64, d_out, clk, n_simd);
   hipFree(d_out);
   return 0;
 }

@@ -53,8 +53,8 @@ BB_HD uint32_t mont_mul_lazy(uint32_t a, uint32_t b) {
   return (uint32_t)((t + (uint64_t)m * P) >> 32);
 }
 // (a*b + c) / R mod p, lazy: the 64-bit multiply-add takes the addend for free, so mont(a, b) + c/R costs the three instructions
-// of the product alone.  a < 2p, b < p, c < 2^32: a*b + c + 2^32 p < 2^64 and the result is below a*b/2^32 + p + 1 (< 2p).
-BB_HD uint32_t mont_mul_add_lazy(uint32_t a, uint32_t b, uint32_t c) {
+// of the product alone.  a < 2p, b < p, c < 2^34: a*b + c + 2^32 p < 2^64 and the result is below a*b/2^32 + p + 4 (< 2p).
+BB_HD uint32_t mont_mul_add_lazy(uint32_t a, uint32_t b, uint64_t c) {
   const uint64_t t = (uint64_t)a * b + c;
   const uint32_t m = (uint32_t)t * NEG_PINV;
   return (uint32_t)((t + (uint64_t)m * P) >> 32);
@@ -91,6 +91,13 @@ BB_HD uint32_t reduce_wide(uint64_t acc) {
   constexpr uint32_t M = (uint32_t)((1ull << (32 + S)) / P);
   const uint32_t q = mulhi_u32((uint32_t)(acc >> S), M);
   return reduce_2p((uint32_t)acc - q * P);
+}
+// acc / R mod p for a 64-bit acc (Montgomery reduction of a wide sum): two instructions against the six of reduce_wide; the result
+// is below acc / 2^32 + p, i.e. "canonical + a little" for the acc < 2^38 sums of the Poseidon2 linear layers, and carries the factor
+// 1/R, which the caller has to account for.  acc + 2^32 p < 2^64 is all it needs.
+BB_HD uint32_t mont_reduce_wide(uint64_t acc) {
+  const uint32_t m = (uint32_t)acc * NEG_PINV;
+  return (uint32_t)((acc + (uint64_t)m * P) >> 32);
 }
 BB_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2); }
 BB_HD uint32_t from_mont(uint32_t a) { return mont_mul(a, 1u); }

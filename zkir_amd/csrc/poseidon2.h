@@ -29,6 +29,16 @@ struct Consts {              // Montgomery form unless noted
   uint32_t in[RP];
   uint32_t diag[T];
   uint32_t pre[RF][T];       // (M_ext^-1 * ext[r + 1]) * R^2 mod p: addend of the last S-box product of full round r; zero for r = 3, 7
+  // permute_scaled(): the same constants carried by the factor the state has at that point (canonical values)
+  uint32_t ext0_s[T];        // ext[0] * F_IN
+  uint32_t pre_s[RF][T];     // (M_ext^-1 * ext[r + 1]) * h_r * R, h_r = factor of the state after the S-boxes of full round r
+  uint32_t in_scale;         // mont_mul(x, in_scale) = x * F_IN: canonical value -> input word of permute_scaled
+  uint32_t out_scale;        // mont_mul(s, out_scale) = s / F_OUT: output word -> canonical value
+  uint32_t carry;            // mont_mul(s, carry) = s * F_IN / F_OUT: output word -> input word of the next permutation (sponge capacity)
+  uint32_t r3;               // R^3 mod p
+  uint32_t diag0;            // diag[0] = -2 in Montgomery form
+  uint32_t in_r[RP + 1];     // in[r] * R (Montgomery form of the Montgomery form): the NEXT partial round's constant rides the addend of
+                             // word 0's update product; in_r[RP] = 0
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -78,6 +88,35 @@ inline void generate(Consts& c) {
         for (int j = 0; j < T; j++) v = bb::add(v, bb::mul(minv[i][j], bb::from_mont(c.ext[r + 1][j])));
       c.pre[r][i] = bb::to_mont(bb::to_mont(v));
     }
+  // ---- permute_scaled(): factors.  A state word holds f * v for the true value v.  S-boxes in Montgomery arithmetic take the
+  // factor f to f^7 / R^6, a linear layer keeps it, its wide Montgomery reduction divides it by R.  The 22 partial rounds S-box
+  // one word only, so they want the factor that S-boxes preserve, f = R; working backwards from there through full rounds 3..0
+  // and the initial layer fixes F_IN, forwards through rounds 4..7 gives F_OUT.  (x -> x^7 is a bijection: gcd(7, p - 1) = 1.)
+  {
+    constexpr uint64_t INV7 = 1725656503ull;                   // 7^-1 mod (p - 1)
+    const uint32_t R = bb::R1, Rinv = bb::inv(R);
+    const uint32_t R6 = bb::pow(R, 6);
+    uint32_t g[RF + 1], h[RF];                                 // g[r]: factor entering the S-boxes of full round r; h[r]: after them
+    g[RF / 2] = R;
+    for (int r = RF / 2 - 1; r >= 0; r--) { h[r] = bb::mul(g[r + 1], R); g[r] = bb::pow(bb::mul(h[r], R6), INV7); }
+    for (int r = RF / 2; r < RF; r++) { h[r] = bb::mul(bb::pow(g[r], 7), bb::inv(R6)); g[r + 1] = bb::mul(h[r], Rinv); }
+    const uint32_t f_in = bb::mul(g[0], R), f_out = g[RF];
+    for (int i = 0; i < T; i++) c.ext0_s[i] = bb::mul(bb::from_mont(c.ext[0][i]), f_in);
+    for (int r = 0; r < RF; r++)
+      for (int i = 0; i < T; i++) {
+        uint32_t v = 0;
+        if (r != RF / 2 - 1 && r != RF - 1)
+          for (int j = 0; j < T; j++) v = bb::add(v, bb::mul(minv[i][j], bb::from_mont(c.ext[r + 1][j])));
+        c.pre_s[r][i] = bb::mul(bb::mul(v, h[r]), R);
+      }
+    c.in_scale = bb::mul(f_in, R);
+    c.out_scale = bb::mul(R, bb::inv(f_out));
+    c.carry = bb::mul(bb::mul(f_in, R), bb::inv(f_out));
+    c.r3 = bb::pow(R, 3);
+    c.diag0 = c.diag[0];
+    for (int r = 0; r < RP; r++) c.in_r[r] = bb::to_mont(c.in[r]);
+    c.in_r[RP] = 0;
+  }
 }
 
 // x^7 for canonical x; only x^3 needs its reduction (it is squared), the other products stay within the lazy bounds of
@@ -144,6 +183,61 @@ BB_HD void permute(uint32_t* s, const Consts& c) {
 #pragma unroll
     for (int i = 0; i < T; i++) s[i] = sbox_lazy(s[i], c.pre[r][i]);
     ext_linear<false>(s, nullptr);
+  }
+}
+
+// ---- the same permutation with SCALED state words (throughput variant) ------------------------------------------------------------
+// The 108 outputs of the nine external linear layers and the 22 partial-round sums are reduced with bb::mont_reduce_wide (2
+// instructions) instead of the Barrett reduce_wide (6): that divides the state by R each time, so a state word holds f * v with a
+// factor f that changes from layer to layer in a fixed, data-independent way; generate() pre-multiplies every round constant by the
+// factor of the place it is added at and chooses the input factor so that the partial rounds see f = R (plain Montgomery form).
+//   in : s[i] = mont_mul(x_i, c.in_scale) for canonical x_i, or mont_mul_lazy(previous output word, c.carry); below 1.69p
+//   out: s[i] = F_OUT * v_i below p + 64; canonical v_i = mont_mul(s[i], c.out_scale)
+// The function computed on the x_i / v_i is exactly permute()'s (tests/test_stark_oracle.py, test_gpu_stark.py: bit for bit).
+template <bool ADD_RC>
+BB_HD void ext_linear_scaled(uint32_t* s, const uint32_t* rc) {
+  uint64_t y[T];
+  m4_wide(s[0], s[1], s[2], s[3], y); m4_wide(s[4], s[5], s[6], s[7], y + 4); m4_wide(s[8], s[9], s[10], s[11], y + 8);
+  uint64_t sum[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) sum[j] = y[j] + y[4 + j] + y[8 + j];
+#pragma unroll
+  for (int k = 0; k < T; k++) {
+    uint64_t v = y[k] + sum[k & 3];
+    if (ADD_RC) v += rc[k];
+    s[k] = bb::mont_reduce_wide(v);                            // < 2^38 / 2^32 + p
+  }
+}
+BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // state factor R on entry and exit; s[0] canonical, s[1..11] below 2p
+  uint32_t x = bb::add(s[0], c.in[0]);
+#pragma unroll 1
+  for (int r = 0; r < RP; r++) {
+    const uint32_t s0 = sbox_lazy(x);                          // below 1.689p: only feeds the 64-bit sum and a product
+    uint64_t acc = s0;
+#pragma unroll
+    for (int i = 1; i < T; i++) acc = bb::acc_add(acc, s[i]);
+    const uint32_t sum_r = bb::mont_mul_lazy(bb::mont_reduce_wide(acc), c.r3);      // (sum / R) * R^3 / R = sum * R, below 1.469p
+    x = bb::reduce_2p(bb::mont_mul_add_lazy(s0, c.diag0, (uint64_t)sum_r + c.in_r[r + 1]));   // sum - 2 s0 + in[r + 1]: the next S-box input
+#pragma unroll
+    for (int i = 1; i < T; i++) s[i] = bb::mont_mul_add_lazy(s[i], c.diag[i], sum_r);
+  }
+  s[0] = x;
+#pragma unroll
+  for (int i = 1; i < T; i++) s[i] = bb::reduce_2p(s[i]);
+}
+BB_HD void permute_scaled(uint32_t* s, const Consts& c) {
+  ext_linear_scaled<true>(s, c.ext0_s);
+#pragma unroll 1
+  for (int r = 0; r < RF; r++) {
+    if (r == RF / 2) {
+      s[0] = bb::reduce_2p(s[0]);                              // p + 64 -> canonical: the partial rounds add a constant to it first
+      int_rounds_scaled(s, c);
+#pragma unroll
+      for (int i = 0; i < T; i++) s[i] = bb::add(s[i], c.ext[RF / 2][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < T; i++) s[i] = sbox_lazy(s[i], c.pre_s[r][i]);
+    ext_linear_scaled<false>(s, nullptr);
   }
 }
 

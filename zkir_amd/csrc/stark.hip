@@ -179,16 +179,20 @@ __global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restr
 #pragma unroll
   for (int i = 0; i < p2::T; i++) s[i] = 0;
   const uint4* m4 = reinterpret_cast<const uint4*>(mat);
+  // p2::permute_scaled: absorbed values enter with the factor in_scale, words that stay (the capacity; the tail of the rate in a
+  // ragged last block, which so::hash_elems leaves in place) are carried over from the previous output with `carry`
+  const uint32_t in_scale = cp->in_scale, carry = cp->carry, out_scale = cp->out_scale;
   for (uint32_t off = 0; off < width; off += p2::RATE) {
     const uint4 lo = m4[((uint64_t)(off >> 3) * n + j) * 2], hi = m4[((uint64_t)(off >> 3) * n + j) * 2 + 1];
     const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int i = 0; i < p2::RATE; i++)
-      if (off + i < width) s[i] = bb::to_mont(v[i]);             // a ragged last block overwrites only its real columns (so::hash_elems)
-    p2::permute(s, *cp);
+    for (int i = 0; i < p2::RATE; i++) s[i] = off + i < width ? bb::mont_mul(v[i], in_scale) : bb::mont_mul_lazy(s[i], carry);
+#pragma unroll
+    for (int i = p2::RATE; i < p2::T; i++) s[i] = bb::mont_mul_lazy(s[i], carry);
+    p2::permute_scaled(s, *cp);
   }
-  if (width == 0) p2::permute(s, *cp);
-  uint4 d = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+  if (width == 0) p2::permute_scaled(s, *cp);
+  uint4 d = make_uint4(bb::mont_mul(s[0], out_scale), bb::mont_mul(s[1], out_scale), bb::mont_mul(s[2], out_scale), bb::mont_mul(s[3], out_scale));
   reinterpret_cast<uint4*>(digests)[j] = d;
 }
 
@@ -196,9 +200,11 @@ __global__ __launch_bounds__(NT) void compress_kernel(const p2::Consts* __restri
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n_out) return;
   const uint4 l = reinterpret_cast<const uint4*>(in)[2 * i], r = reinterpret_cast<const uint4*>(in)[2 * i + 1];
-  uint32_t s[p2::T] = {bb::to_mont(l.x), bb::to_mont(l.y), bb::to_mont(l.z), bb::to_mont(l.w), bb::to_mont(r.x), bb::to_mont(r.y), bb::to_mont(r.z), bb::to_mont(r.w), 0, 0, 0, 0};
-  p2::permute(s, *cp);
-  reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+  const uint32_t k = cp->in_scale, ko = cp->out_scale;
+  uint32_t s[p2::T] = {bb::mont_mul(l.x, k), bb::mont_mul(l.y, k), bb::mont_mul(l.z, k), bb::mont_mul(l.w, k), bb::mont_mul(r.x, k), bb::mont_mul(r.y, k), bb::mont_mul(r.z, k),
+                       bb::mont_mul(r.w, k), 0, 0, 0, 0};
+  p2::permute_scaled(s, *cp);
+  reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::mont_mul(s[0], ko), bb::mont_mul(s[1], ko), bb::mont_mul(s[2], ko), bb::mont_mul(s[3], ko));
 }
 
 // Subtrees in ONE launch: every workgroup takes `per_wg` (a power of two <= 512) consecutive digests of the level `cur` (m digests)

@@ -203,12 +203,15 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const p2::Consts* __r
   uint32_t s[p2::T];
 #pragma unroll
   for (int t = 0; t < p2::T; t++) s[t] = 0;
+  const uint32_t in_scale = cp->in_scale, carry = cp->carry, ko = cp->out_scale;
   for (uint32_t u = 0; u < (1u << k); u += 2) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) { s[t] = bb::to_mont(c[(uint64_t)t * m + i + u * g]); s[4 + t] = bb::to_mont(c[(uint64_t)t * m + i + (u + 1) * g]); }
-    p2::permute(s, *cp);
+    for (int t = 0; t < 4; t++) { s[t] = bb::mont_mul(c[(uint64_t)t * m + i + u * g], in_scale); s[4 + t] = bb::mont_mul(c[(uint64_t)t * m + i + (u + 1) * g], in_scale); }
+#pragma unroll
+    for (int t = p2::RATE; t < p2::T; t++) s[t] = bb::mont_mul_lazy(s[t], carry);
+    p2::permute_scaled(s, *cp);
   }
-  reinterpret_cast<uint4*>(digests)[i] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+  reinterpret_cast<uint4*>(digests)[i] = make_uint4(bb::mont_mul(s[0], ko), bb::mont_mul(s[1], ko), bb::mont_mul(s[2], ko), bb::mont_mul(s[3], ko));
 }
 
 // the same leaf hash with one permutation per quad of lanes (p2::permute_quad): small layers are latency-bound
