@@ -305,6 +305,9 @@ int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_i
 /* Host-side Poseidon2-12 permutation of the transcript (canonical words in and out; no device needed): what a verifier or an
  * integrator re-deriving the Fiat-Shamir challenges calls.  Same code as the device kernels (poseidon2.h), compiled for the host. */
 void zkir_poseidon2_permute(uint32_t state[12]);
+/* The same permutation in the formulation the hash kernels run (scaled state words, poseidon2.h: permute_scaled), host build:
+ * `rounds` chained applications, canonical words in and out.  Exists so that the formulation can be checked without a device. */
+void zkir_poseidon2_permute_scaled(uint32_t state[12], uint32_t rounds);
 
 /* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
 typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */

@@ -81,10 +81,16 @@ def test_host_poseidon2_matches_oracle():
         got = s.copy()
         rt.lib().zkir_poseidon2_permute(got.ctypes.data)
         assert np.array_equal(got, so.permute(s)), s
+        scaled = s.copy()
+        rt.lib().zkir_poseidon2_permute_scaled(scaled.ctypes.data, 1)               # the formulation the hash kernels run
+        assert np.array_equal(scaled, got), s
     # iterate the permutation: 200 dependent applications explore states nobody picked
     s = np.arange(12, dtype=np.uint32)
     want = s.copy()
+    chained = s.copy()
+    rt.lib().zkir_poseidon2_permute_scaled(chained.ctypes.data, 200)                # with the sponge's carry step in between
     for _ in range(200):
         rt.lib().zkir_poseidon2_permute(s.ctypes.data)
         want = so.permute(want)
     assert np.array_equal(s, want)
+    assert np.array_equal(chained, want)

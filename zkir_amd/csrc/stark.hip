@@ -319,6 +319,20 @@ void zkir_poseidon2_permute(uint32_t state[12]) {
   for (int i = 0; i < p2::T; i++) state[i] = bb::from_mont(s[i]);
 }
 
+// The throughput formulation the hash kernels run (p2::permute_scaled: scaled state words, Montgomery-reduced linear layers),
+// host build, canonical words in and out, `rounds` chained applications with the carry step a sponge performs between them:
+// lets the CPU suite pin it against the oracle without a device.
+void zkir_poseidon2_permute_scaled(uint32_t state[12], uint32_t rounds) {
+  static const p2::Consts consts = [] { p2::Consts c; p2::generate(c); return c; }();
+  uint32_t s[p2::T];
+  for (int i = 0; i < p2::T; i++) s[i] = bb::mont_mul(state[i] % bb::P, consts.in_scale);
+  for (uint32_t r = 0; r < rounds; r++) {
+    if (r) for (int i = 0; i < p2::T; i++) s[i] = bb::mont_mul_lazy(s[i], consts.carry);
+    p2::permute_scaled(s, consts);
+  }
+  for (int i = 0; i < p2::T; i++) state[i] = rounds ? bb::mont_mul(s[i], consts.out_scale) : state[i] % bb::P;
+}
+
 // Diagnostic: measured peak Montgomery-multiplication rate (modmul/s) of the device, used as the ALU roofline of the Poseidon2 kernels.
 double zkir_modmul_peak_per_s(void* stream) {
   hipStream_t s = (hipStream_t)stream;

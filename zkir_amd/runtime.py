@@ -188,6 +188,7 @@ def lib() -> C.CDLL:
     L.zkir_proof_free.argtypes = [C.POINTER(C.c_uint32)]
     L.zkir_proof_num_queries.restype = U32
     L.zkir_poseidon2_permute.restype = None; L.zkir_poseidon2_permute.argtypes = [C.c_void_p]
+    L.zkir_poseidon2_permute_scaled.restype = None; L.zkir_poseidon2_permute_scaled.argtypes = [C.c_void_p, C.c_uint32]
     L.zkir_exec.restype = C.c_int
     L.zkir_exec.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.POINTER(C.c_void_p)]
     L.zkir_result_free.argtypes = [C.c_void_p]
