@@ -31,9 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-# Montgomery multiplications in one Poseidon2-12 permutation as implemented (poseidon2.h): 4 per S-box x (8 x 12 + 22) S-boxes
-# + 10 diagonal products x 22 partial rounds (diag entries 1 and the -2 of lane 0 need none)
-MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 10 * 22
+# Montgomery multiplications in one Poseidon2-12 permutation as the hash kernels run it (poseidon2.h, permute_scaled): 4 per S-box x
+# (8 x 12 + 22) S-boxes + 13 per partial round (11 diagonal products, word 0's update, the sum's change of form) x 22 + the 12
+# products that bring 8 absorbed values and the 4 carried capacity words to the input factor
+MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 13 * 22 + 12
 PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
 
 
@@ -520,12 +521,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernels[dom]["ms"],
                          "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
-                         "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (692 Montgomery multiplications + 130 wide reductions per "
+                         "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (770 Montgomery multiplications + 130 wide Montgomery reductions per "
                                   "permutation; VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see roofline_by_stage for its ALU rate and for the HBM-bound stages")
                          if kernels[dom]["bound"] != "hbm" else None,
                          # the roofline that does bound this kernel: vector-ALU issue.  `achieved`/`peak` = Montgomery products per
-                         # second against the device's measured peak of independent products; `valu_busy_profiled` = rocprofv3
-                         # VALUBusy of leaf_hash_kernel in the committed counter pass of this command (profiles/)
+                         # second against the device's measured peak of independent MINIMAL products (three multiplier-pipe
+                         # instructions each; what the integer multipliers can do at all) — the rest of the kernel's issue slots are
+                         # the additions / 64-bit sums / reductions of the linear layers; `valu_busy_profiled` = rocprofv3 VALUBusy
+                         # of leaf_hash_kernel in the committed counter pass of this command (profiles/): the pipe is never idle
                          "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["mont_mul_per_s"], "peak": kernels[dom]["mont_mul_peak_per_s_measured"],
                                   "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel")}
                                  if kernels[dom]["bound"] == "int-alu" else None)},

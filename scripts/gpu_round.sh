@@ -33,6 +33,7 @@ prof)
   summ $OUT/kt_c4 $OUT/${TAG}_config4_kernel_stats.txt
   rm -rf $OUT/kt_c1 $OUT/kt_c2 $OUT/kt_c4;;
 pmc)
+  export ZKIR_EXEC_STREAM=0   # whole-run K1 launches only: the streaming zkir_exec adds partial-range launches to the per-kernel averages
   for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed 's/_size//'); 
     timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$d -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-prove --no-by-config > $OUT/pmc_$d.log 2>&1; done
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_valu -o b -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-prove --no-by-config > $OUT/pmc_valu.log 2>&1

@@ -254,20 +254,22 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
   }
 }
 
-// ALU roofline probe: every lane runs `iters` rounds of 8 independent Montgomery multiplications (no memory traffic), i.e. the
-// best modmul rate this formulation of mont_mul can reach on the chip.  The Poseidon2 kernels are priced against it.
+// ALU roofline probe: every lane runs `iters` rounds of 8 independent MINIMAL Montgomery products (64-bit multiply, low multiply,
+// 64-bit multiply-add: three multiplier-pipe instructions, no final subtraction, no memory traffic): the rate at which the chip's
+// integer multipliers can turn out 31-bit modular products at all.  The Poseidon2 kernels are priced against it; the share of their
+// time that is NOT such products is the additions, 64-bit accumulations and reductions of the linear layers.
 __global__ __launch_bounds__(NT) void modmul_peak_kernel(uint32_t* __restrict__ out, uint32_t iters) {
-  uint32_t a[8];
+  uint32_t a[8], c[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) a[k] = (threadIdx.x * 2654435761u + blockIdx.x * 40503u + k * 7919u) % bb::P;
+  for (int k = 0; k < 8; k++) { a[k] = (threadIdx.x * 2654435761u + blockIdx.x * 40503u + k * 7919u) % bb::P; c[k] = (a[k] * 31u + 7u) % bb::P; }
   for (uint32_t i = 0; i < iters; i++) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) a[k] = bb::mont_mul(a[k], a[(k + 1) & 7]);
+    for (int k = 0; k < 8; k++) a[k] = bb::mont_mul_lazy(a[k], c[k]);    // the 3-instruction product (stays below 2p), as the hash kernels use it
   }
   uint32_t r = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) r ^= a[k];
-  if (r == 0xFFFFFFFFu) out[0] = r;                     // never true (values < p); keeps the chain live
+  if (r == 0xFFFFFFFFu && iters == 0xFFFFFFFFu) out[0] = r;  // never true; keeps the chain live
 }
 
 // all levels above the leaf digests: wide levels (throughput-bound) one launch each, then subtree launches
