@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/reference_suite_kats.json: the reference's integration-test SUITES for the execution path, re-stated as VM
+programs with the values those tests assert (re-typed by hand; the reference is Rust and cannot run in this image — these are
+transcriptions of the literals and instruction lists in its test code: data, not source).
+
+  zkir-runtime/tests/syscall_integration.rs   (handle_syscall driven through a VMState: here the same register set-up + ECALL)
+  zkir-runtime/tests/memory_subsystem.rs      (Memory::{read,write}_u{8,16,32,64}: here SB/SH/SW/SD + LBU/LHU/LW/LD)
+  zkir-runtime/tests/bounds_propagation.rs, witness_collection_test.rs, deferred_integration_test.rs, range_checking.rs
+  zkir-runtime/tests/crypto_edge_cases.rs     (hash calls on a Memory: here the SHA-256 / Keccak-256 / BLAKE3 syscalls)
+  tests/stress_tests.rs, tests/end_to_end.rs, tests/cross_module.rs (assembly sources kept next to the hand-encoded words)
+
+Every entry cites file:line (paths relative to /root/reference).  An expectation is only ever what the reference test asserts
+(outputs, halt reason, cycle count, witness counts, an error); "ok" = the test only asserts that the run succeeds.
+The encoder below is this script's own (bit layout of zkir-assembler/src/encoder.rs:100-151, opcode bytes of
+zkir-spec/src/opcode.rs:154-228) — the fixtures do not depend on the package they test.
+
+Run: python tests/golden/make_suite_kats.py
+"""
+import json
+import os
+
+OPC = dict(add=0x00, sub=0x01, mul=0x02, mulh=0x03, divu=0x04, remu=0x05, div=0x06, rem=0x07, addi=0x08,
+           and_=0x10, or_=0x11, xor=0x12, andi=0x13, ori=0x14, xori=0x15, sll=0x18, srl=0x19, sra=0x1A, slli=0x1B, srli=0x1C, srai=0x1D,
+           sltu=0x20, sgeu=0x21, slt=0x22, sge=0x23, seq=0x24, sne=0x25, cmov=0x26, cmovz=0x27, cmovnz=0x28,
+           lb=0x30, lbu=0x31, lh=0x32, lhu=0x33, lw=0x34, ld=0x35, sb=0x38, sh=0x39, sw=0x3A, sd=0x3B,
+           beq=0x40, bne=0x41, blt=0x42, bge=0x43, bltu=0x44, bgeu=0x45, jal=0x48, jalr=0x49, ecall=0x50, ebreak=0x51)
+R_TYPE = {"add", "sub", "mul", "mulh", "divu", "remu", "div", "rem", "and_", "or_", "xor", "sll", "srl", "sra", "sltu", "sgeu", "slt", "sge", "seq", "sne",
+          "cmov", "cmovz", "cmovnz"}
+S_TYPE = {"sb", "sh", "sw", "sd", "beq", "bne", "blt", "bge", "bltu", "bgeu"}
+
+
+def I(m, a=0, b=0, c=0):
+    """R: (rd, rs1, rs2)   I / load / shift-imm / jalr: (rd, rs1, imm)   store: (base, value, imm)   branch: (rs1, rs2, offset)   jal: (rd, offset)"""
+    op = OPC[m]
+    if m in R_TYPE:
+        return op | (a & 0xF) << 7 | (b & 0xF) << 11 | (c & 0xF) << 15
+    if m == "jal":
+        return op | (a & 0xF) << 7 | (b & 0x1FFFFF) << 11
+    if m in ("ecall", "ebreak"):
+        return op
+    return op | (a & 0xF) << 7 | (b & 0xF) << 11 | (c & 0x1FFFF) << 15      # I-type and S/B-type share the field positions
+
+
+assert I("add", 4, 1, 2) == 0x00010A00 and I("bne", 3, 0, -16) == 0xFFF801C1       # tests/cross_module.rs:140-175 (fib5 words 3 and 7)
+
+EC, EB = I("ecall"), I("ebreak")
+LI = lambda rd, v: [I("addi", rd, 0, v)]                                            # noqa: E731   -65536 <= v <= 65535
+EXIT = lambda code=0: [I("addi", 10, 0, 0), I("addi", 11, 0, code), EC]             # noqa: E731
+EXIT_ADD = [I("add", 10, 0, 0), EC]                                                 # `add r10, r0, r0; ecall` of tests/end_to_end.rs (R11 is still 0)
+WRITE = lambda r: [I("addi", 11, r, 0), I("addi", 10, 0, 2), EC]                    # noqa: E731   output the value of register r
+READ = [I("addi", 10, 0, 1), EC]                                                    # R10 <- next input (0 when exhausted)
+
+
+def LI32(rd, v):
+    """rd <- 32-bit constant: upper half, shift, OR in the lower half (ADDI immediates are 17-bit signed: encoder.rs:117)."""
+    return [I("addi", rd, 0, (v >> 16) & 0xFFFF), I("slli", rd, rd, 16), I("ori", rd, rd, v & 0xFFFF)] if v > 0xFFFF else LI(rd, v)
+
+
+def BYTES_AT(base_reg, tmp, data):
+    out = []
+    for i, b in enumerate(data):
+        out += [I("addi", tmp, 0, b), I("sb", base_reg, tmp, i)]
+    return out
+
+
+def HASH(sys_no, in_reg, length, out_reg):
+    return [I("addi", 10, 0, sys_no), I("addi", 11, in_reg, 0), I("addi", 12, 0, length), I("addi", 13, out_reg, 0), EC]
+
+
+def WRITE_WORDS(base_reg, tmp, n):                                                  # output n little-endian u32 words read back with LW
+    out = []
+    for i in range(n):
+        out += [I("lw", tmp, base_reg, 4 * i)] + WRITE(tmp)
+    return out
+
+
+SHA_HELLO = [0x2cf24dba, 0x5fb0a30e, 0x26e83b2a, 0xc5b9e29e, 0x1b161e5c, 0x1fa7425e, 0x73043362, 0x938b9824]
+SHA_EMPTY = [0xe3b0c442, 0x98fc1c14, 0x9afbf4c8, 0x996fb924, 0x27ae41e4, 0x649b934c, 0xa495991b, 0x7852b855]
+DATA_BASE_REG = lambda rd: [I("addi", rd, 0, 1), I("slli", rd, rd, 32)]             # noqa: E731   DATA_BASE = 0x1_0000_0000 (zkir-spec/src/lib.rs:58)
+HEAP_BASE_REG = lambda rd: [I("addi", rd, 0, 2), I("slli", rd, rd, 32)]             # noqa: E731   HEAP_BASE = 0x2_0000_0000 (:62)
+
+P = []      # the cases
+
+
+def case(name, cite, code, **kw):
+    assert not any(p["name"] == name for p in P), name
+    P.append(dict(name=name, cite=cite, code=code, **kw))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/tests/syscall_integration.rs
+# ---------------------------------------------------------------------------------------------------------------------------------
+S = "zkir-runtime/tests/syscall_integration.rs"
+# (hash buffers at 0x10000 / 0x20000 rather than the 0x1000 / 0x2000 of the bare-Memory tests: a VM has its code at 0x1000)
+SYS_BUF = LI(1, 0x1000) + [I("slli", 1, 1, 4)] + LI(2, 0x2000) + [I("slli", 2, 2, 4)]
+case("sys_exit_0", f"{S}:17-31", EXIT(0), halt=["Exit", 0])
+case("sys_exit_1", f"{S}:33-47", EXIT(1), halt=["Exit", 1])
+case("sys_exit_255", f"{S}:49-63", EXIT(255), halt=["Exit", 255])
+case("sys_read_single", f"{S}:69-82", READ + WRITE(10) + EXIT(), inputs=[42], outputs=[42])
+case("sys_read_multiple", f"{S}:84-105", (READ + WRITE(10)) * 3 + EXIT(), inputs=[100, 200, 300], outputs=[100, 200, 300])
+case("sys_read_exhausted", f"{S}:107-126", (READ + WRITE(10)) * 2 + EXIT(), inputs=[42], outputs=[42, 0])
+case("sys_read_empty", f"{S}:128-138", READ + WRITE(10) + EXIT(), inputs=[], outputs=[0])
+case("sys_write_single", f"{S}:144-157", LI(1, 123) + WRITE(1) + EXIT(), outputs=[123])
+case("sys_write_multiple", f"{S}:159-174", sum([LI(1, v) + WRITE(1) for v in (10, 20, 30, 40)], []) + EXIT(), outputs=[10, 20, 30, 40])
+case("sys_write_large", f"{S}:176-189", LI32(1, 0xFFFFFFFF) + WRITE(1) + EXIT(), outputs=[0xFFFFFFFF])
+case("sys_read_process_write", f"{S}:195-216", READ + [I("add", 1, 0, 10)] + READ + [I("add", 1, 1, 10)] + READ + [I("add", 1, 1, 10)] + WRITE(1) + EXIT(),
+     inputs=[5, 10, 15], outputs=[30])
+case("sys_echo_five", f"{S}:218-240", (READ + WRITE(10)) * 5 + EXIT(), inputs=[1, 2, 3, 4, 5], outputs=[1, 2, 3, 4, 5])
+case("sys_invalid_999", f"{S}:246-258", LI(10, 999) + [EC], error=4)
+case("sys_invalid_7", f"{S}:260-272", LI(10, 7) + [EC], error=4)
+case("sys_sha256_hello", f"{S}:278-318", SYS_BUF + BYTES_AT(1, 3, b"hello") + HASH(3, 1, 5, 2) + WRITE(10) + WRITE_WORDS(2, 4, 8) + EXIT(),
+     outputs=[0] + SHA_HELLO)                                 # R10 = 0 after the call, then the eight words read back with read_u32
+case("sys_sha256_empty", f"{S}:320-353", SYS_BUF + HASH(3, 1, 0, 2) + WRITE(10) + WRITE_WORDS(2, 4, 8) + EXIT(), outputs=[0] + SHA_EMPTY)
+case("sys_keccak256_hello_returns_0", f"{S}:359-384", SYS_BUF + BYTES_AT(1, 3, b"hello") + HASH(5, 1, 5, 2) + WRITE(10) + EXIT(), outputs=[0])
+case("sys_blake3_hello_returns_0", f"{S}:390-415", SYS_BUF + BYTES_AT(1, 3, b"hello") + HASH(6, 1, 5, 2) + WRITE(10) + EXIT(), outputs=[0])
+case("sys_poseidon2_not_implemented", f"{S}:401-422", SYS_BUF + BYTES_AT(1, 3, bytes([1, 2, 3, 4])) + HASH(4, 1, 4, 2), error=6)
+case("sys_io_read_write_independent", f"{S}:441-457", LI(1, 999) + WRITE(1) + READ + [I("add", 5, 0, 10)] + LI(1, 888) + WRITE(1) + READ + [I("add", 6, 0, 10)] + LI(1, 777) + WRITE(1)
+     + WRITE(5) + WRITE(6) + EXIT(), inputs=[100, 200], outputs=[999, 888, 777, 100, 200])
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/tests/memory_subsystem.rs — the VM switches strict protection off (vm.rs:175), so the region / protection tests are
+# not on the path; the access-width, endianness, alignment, zero-fill, sparse, cross-page, stack and trace tests are.
+# ---------------------------------------------------------------------------------------------------------------------------------
+M = "zkir-runtime/tests/memory_subsystem.rs"
+case("mem_byte_rw", f"{M}:58-76", DATA_BASE_REG(1) + LI(2, 0x42) + [I("sb", 1, 2, 0), I("lbu", 3, 1, 0)] + WRITE(3) + LI(2, 0xFF) + [I("sb", 1, 2, 1), I("lbu", 3, 1, 1)] + WRITE(3)
+     + EXIT(), outputs=[0x42, 0xFF])
+case("mem_byte_rw_256", f"{M}:67-75", DATA_BASE_REG(1) + LI(2, 0) + LI(4, 256) + [I("add", 5, 1, 2), I("sb", 5, 2, 100), I("addi", 2, 2, 1), I("bne", 2, 4, -12)]
+     + LI(2, 0) + [I("add", 5, 1, 2), I("lbu", 6, 5, 100), I("addi", 11, 6, 0), I("addi", 10, 0, 2), EC, I("addi", 2, 2, 1), I("bne", 2, 4, -24)] + EXIT(),
+     outputs=[i & 0xFF for i in range(256)], config={"max_cycles": 100000})
+case("mem_halfword_rw", f"{M}:78-88", DATA_BASE_REG(1) + LI(2, 0x1234) + [I("sh", 1, 2, 0), I("lhu", 3, 1, 0)] + WRITE(3) + LI32(2, 0xABCD) + [I("sh", 1, 2, 2), I("lhu", 3, 1, 2)]
+     + WRITE(3) + EXIT(), outputs=[0x1234, 0xABCD])
+case("mem_word_rw", f"{M}:90-100", DATA_BASE_REG(1) + LI32(2, 0xDEADBEEF) + [I("sw", 1, 2, 0), I("lw", 3, 1, 0)] + WRITE(3) + LI32(2, 0xCAFEBABE) + [I("sw", 1, 2, 4), I("lw", 3, 1, 4)]
+     + WRITE(3) + EXIT(), outputs=[0xDEADBEEF, 0xCAFEBABE])
+case("mem_little_endian", f"{M}:110-121", DATA_BASE_REG(1) + LI32(2, 0x04030201) + [I("sw", 1, 2, 0)] + sum([[I("lbu", 3, 1, i)] + WRITE(3) for i in range(4)], []) + EXIT(),
+     outputs=[1, 2, 3, 4])
+case("mem_misaligned_sh", f"{M}:127-129", DATA_BASE_REG(1) + LI(2, 0x1234) + [I("sh", 1, 2, 1)], error=1)
+case("mem_misaligned_lh", f"{M}:130", DATA_BASE_REG(1) + [I("lhu", 3, 1, 1)], error=1)
+case("mem_misaligned_sw_1", f"{M}:133", DATA_BASE_REG(1) + [I("sw", 1, 2, 1)], error=1)
+case("mem_misaligned_sw_2", f"{M}:134", DATA_BASE_REG(1) + [I("sw", 1, 2, 2)], error=1)
+case("mem_misaligned_sw_3", f"{M}:135", DATA_BASE_REG(1) + [I("sw", 1, 2, 3)], error=1)
+case("mem_misaligned_lw", f"{M}:136", DATA_BASE_REG(1) + [I("lw", 3, 1, 1)], error=1)
+case("mem_misaligned_sd", f"{M}:139", DATA_BASE_REG(1) + [I("sd", 1, 2, 4)], error=1)
+case("mem_misaligned_ld", f"{M}:140", DATA_BASE_REG(1) + [I("ld", 3, 1, 4)], error=1)
+case("mem_uninitialized_reads_zero", f"{M}:143-151", DATA_BASE_REG(1) + LI(2, 1) + [I("slli", 2, 2, 16), I("add", 1, 1, 2)]
+     + sum([[I(op, 3, 1, 0)] + WRITE(3) for op in ("lbu", "lhu", "lw", "ld")], []) + EXIT(), outputs=[0, 0, 0, 0])
+case("mem_sparse", f"{M}:153-169", DATA_BASE_REG(1) + LI32(2, 0xAAAA) + [I("sw", 1, 2, 0)] + LI(4, 1) + [I("slli", 4, 4, 20), I("add", 5, 1, 4)] + LI32(2, 0xBBBB) + [I("sw", 5, 2, 0)]
+     + HEAP_BASE_REG(6) + LI(4, 5) + [I("slli", 4, 4, 20), I("add", 6, 6, 4)] + LI32(2, 0xCCCC) + [I("sw", 6, 2, 0)]
+     + [I("lw", 3, 1, 0)] + WRITE(3) + [I("lw", 3, 5, 0)] + WRITE(3) + [I("lw", 3, 6, 0)] + WRITE(3) + LI(4, 5) + [I("slli", 4, 4, 16), I("add", 7, 1, 4), I("lw", 3, 7, 0)] + WRITE(3)
+     + EXIT(), outputs=[0xAAAA, 0xBBBB, 0xCCCC, 0])
+case("mem_cross_page", f"{M}:291-312", DATA_BASE_REG(1) + LI(4, 0x1000) + [I("add", 1, 1, 4)] + LI32(2, 0x12345678) + [I("sw", 1, 2, -4), I("lw", 3, 1, -4)] + WRITE(3)
+     + LI32(2, 0xAABBCCDD) + [I("sw", 1, 2, 0), I("lw", 3, 1, 0)] + WRITE(3) + sum([[I("lbu", 3, 1, -4 + i)] + WRITE(3) for i in range(4)], []) + EXIT(),
+     outputs=[0x12345678, 0xAABBCCDD, 0x78, 0x56, 0x34, 0x12])
+# STACK_TOP = 0xFF_FFFF_FFFF (zkir-spec/src/lib.rs:65); sp = (STACK_TOP - 8) & !7; ten doublewords below it hold 0..9
+case("mem_stack_ops", f"{M}:266-283", LI(1, -1) + [I("addi", 1, 1, -8), I("andi", 1, 1, -8)] + sum([LI(2, i) + [I("sd", 1, 2, -8 * i)] for i in range(10)], [])
+     + sum([[I("ld", 3, 1, -8 * i)] + WRITE(3) for i in range(10)], []) + EXIT(), outputs=list(range(10)))
+case("mem_trace_write_then_read", f"{M}:219-235", DATA_BASE_REG(1) + LI32(2, 0x12345678) + [I("sw", 1, 2, 0), I("lw", 3, 1, 0), EB],
+     config={"enable_execution_trace": True}, halt=["Ebreak"], n_memops=2,
+     memops=[{"is_write": 1, "address": 0x100000000, "value": 0x12345678}, {"is_write": 0, "address": 0x100000000, "value": 0x12345678}])
+case("mem_trace_bounds", f"{M}:237-249", DATA_BASE_REG(1) + LI(2, -1) + [I("sb", 1, 2, 0), I("sh", 1, 2, 2), I("sw", 1, 2, 4), EB],
+     config={"enable_execution_trace": True}, halt=["Ebreak"], n_memops=3, memops=[{"bound_bits": 8}, {"bound_bits": 16}, {"bound_bits": 32}])
+case("mem_trace_disabled", f"{M}:266-279; zkir-runtime/src/vm.rs:866-904", DATA_BASE_REG(1) + LI(2, 0x1111) + [I("sw", 1, 2, 0), EB], halt=["Ebreak"], n_memops=0, n_rows=0)
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/tests/bounds_propagation.rs
+# ---------------------------------------------------------------------------------------------------------------------------------
+B = "zkir-runtime/tests/bounds_propagation.rs"
+RC = {"enable_range_checking": True}
+case("bp_register_zero_initial_bound", f"{B}:27-48", [I("add", 1, 0, 0), EB], config={"enable_range_checking": True, "enable_execution_trace": True}, halt=["Ebreak"])
+case("bp_immediate_constant_bound", f"{B}:50-72", LI(1, 100) + [EB], config={"enable_range_checking": True, "enable_execution_trace": True}, halt=["Ebreak"], rc_witnesses=0)
+case("bp_add_bound_growth", f"{B}:74-108", LI(1, 100) + LI(2, 200) + [I("add", 3, 1, 2), EB], config=RC, halt=["Ebreak"], rc_witnesses=0)
+case("bp_mul_bound_growth", f"{B}:110-140", LI(1, 1000) + LI(2, 1000) + [I("mul", 3, 1, 2), EB], config=RC, halt=["Ebreak"])
+case("bp_shift_bound_growth", f"{B}:142-166", LI(1, 1) + [I("slli", 2, 1, 10), EB], config=RC, halt=["Ebreak"])
+case("bp_accumulated_bounds_trigger_checks", f"{B}:168-212", LI(1, (1 << 15) - 1) + [I("add", 1, 1, 1)] * 30 + LI(2, 0x1000) + [I("sw", 2, 1, 0), EB], config=RC, halt=["Ebreak"],
+     rc_witnesses_min=1)
+case("bp_and_preserves_bound", f"{B}:214-244", LI(1, 0xFF) + LI(2, 0x0F) + [I("and_", 3, 1, 2), EB], config=RC, halt=["Ebreak"])
+case("bp_srl_reduces_bound", f"{B}:246-270", LI(1, 0xFF00) + [I("srli", 2, 1, 8), EB], config=RC, halt=["Ebreak"])
+case("bp_store_triggers_checkpoint", f"{B}:272-302", LI(1, 42) + LI(2, 0x1000) + [I("sw", 2, 1, 0), EB], config=RC, halt=["Ebreak"])
+case("bp_branch_triggers_checkpoint", f"{B}:304-334", LI(1, 1) + LI(2, 1) + [I("beq", 1, 2, 4), EB], config=RC, halt=["Ebreak"])
+case("bp_division_triggers_checkpoint", f"{B}:336-366", LI(1, 100) + LI(2, 10) + [I("divu", 3, 1, 2), EB], config=RC, halt=["Ebreak"])
+case("bp_execution_trace_records_bounds", f"{B}:368-407", LI(1, 100) + LI(2, 200) + [I("add", 3, 1, 2), EB], config={"enable_execution_trace": True}, halt=["Ebreak"], n_rows=4)
+case("bp_different_limb_config", f"{B}:413-449", LI(1, 1000) + [EB], config=RC, program_config={"limb_bits": 30, "data_limbs": 2, "addr_limbs": 2}, halt=["Ebreak"])
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/tests/witness_collection_test.rs, deferred_integration_test.rs
+# ---------------------------------------------------------------------------------------------------------------------------------
+Wt, D = "zkir-runtime/tests/witness_collection_test.rs", "zkir-runtime/tests/deferred_integration_test.rs"
+WC1 = LI(1, 100) + LI(2, 200) + [I("add", 3, 1, 2)] + LI(4, 300) + [I("beq", 3, 4, 8)] + LI(5, 999) + EXIT()
+case("wc_no_witnesses_without_deferred_model", f"{Wt}:23-87", WC1, halt=["Exit", 0], norm_events=0)
+case("wc_witnesses_with_deferred_model", f"{Wt}:23-113", WC1, config={"enable_deferred_model": True}, halt=["Exit", 0], norm_events_min=1, norm_all_observation=True,
+     norm_all_verify=True)
+# the ADDI immediate (1 << 20) - 10 does not fit 17 bits: the encoder keeps its low 17 bits (encoder.rs:117), i.e. -10 — the word below
+case("wc_carry_propagation", f"{Wt}:115-183", [I("addi", 1, 0, (1 << 20) - 10)] + LI(2, 100) + [I("add", 3, 1, 2)] + [I("addi", 4, 0, 0x10000), I("sw", 4, 3, 0)] + EXIT(),
+     config={"enable_deferred_model": True}, halt=["Exit", 0], norm_events_min=1, norm_all_verify=True,
+     stale="the test also asserts that some event has carries (:171-175); the code gives the SW's event to rs1 = R4, the base (execute.rs:902-915, "
+           "'TEMPORARY: only normalize first source register'), and normalises R3 — the register with the carry — silently, so that assertion cannot "
+           "hold against the reference's own code (same staleness as deferred_integration_test.rs:346, SURVEY.md §8c); not asserted here")
+case("wc_cycle_and_pc_tracking", f"{Wt}:185-215", LI(1, 10) + LI(2, 20) + [I("add", 3, 1, 2), I("beq", 3, 3, 4), EB], config={"enable_deferred_model": True}, halt=["Ebreak"],
+     norm_events_min=1, norm_min_cycle=3, norm_min_pc=0x1000)
+case("di_add_then_branch", f"{D}:20-81", LI(1, 100) + LI(2, 200) + [I("add", 3, 1, 2)] + LI(4, 300) + [I("beq", 3, 4, 8)] + LI(5, 1) + LI(5, 42) + EXIT(), ok=True)
+case("di_arithmetic_chain", f"{D}:83-137", LI(1, 10) + [I("addi", 1, 1, 20), I("addi", 1, 1, 30), I("addi", 1, 1, 40), I("addi", 1, 1, 50), I("sw", 0, 1, 0x10000)] + EXIT(), ok=True)
+case("di_add_sub_mix", f"{D}:139-193", LI(1, 100) + LI(2, 50) + [I("add", 3, 1, 2)] + LI(4, 30) + [I("sub", 5, 3, 4), I("andi", 6, 5, 0xFFFF)] + EXIT(), ok=True)
+# execute_with_deferred on R1 = 1000, R2 = 2000: ADD leaves R3 needing normalisation; normalising gives [3000, 0], carries [0, 0], value 3000
+case("di_manual_deferred_add_3000", f"{D}:195-225", LI(1, 1000) + LI(2, 2000) + [I("add", 3, 1, 2), I("beq", 3, 0, 4)] + WRITE(3) + EXIT(), config={"enable_deferred_model": True},
+     outputs=[3000], norm_event_for={"register": 3, "normalized": [3000, 0], "carries": [0, 0]})
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/tests/crypto_edge_cases.rs
+# ---------------------------------------------------------------------------------------------------------------------------------
+C = "zkir-runtime/tests/crypto_edge_cases.rs"
+# The reference calls the hash functions on a bare Memory with the input at 0x1000 and the digest at 0x2000.  In a VM the program's own
+# code sits at 0x1000 (vm.rs:155), so the re-stated programs keep their buffers at 0x10000 / 0x20000 / 0x30000 instead.
+HEAD = LI(1, 0x1000) + [I("slli", 1, 1, 4)] + LI(2, 0x2000) + [I("slli", 2, 2, 4)]
+OUT3 = LI(7, 0x3000) + [I("slli", 7, 7, 4)]
+case("ce_sha256_empty", f"{C}:25-45", HEAD + HASH(3, 1, 0, 2) + WRITE_WORDS(2, 4, 8) + EXIT(), outputs=SHA_EMPTY)
+case("ce_sha256_single_byte_a", f"{C}:48-63", HEAD + BYTES_AT(1, 3, b"a") + HASH(3, 1, 1, 2) + WRITE_WORDS(2, 4, 1) + EXIT(), outputs=[0xca978112])
+case("ce_sha256_55_bytes", f"{C}:66-79", HEAD + LI(3, 0x61) + LI(4, 0) + LI(5, 55) + [I("add", 6, 1, 4), I("sb", 6, 3, 0), I("addi", 4, 4, 1), I("bne", 4, 5, -12)] + HASH(3, 1, 55, 2) + EXIT(), ok=True)
+case("ce_sha256_64_bytes", f"{C}:82-97", HEAD + LI(3, 0x62) + LI(4, 0) + LI(5, 64) + [I("add", 6, 1, 4), I("sb", 6, 3, 0), I("addi", 4, 4, 1), I("bne", 4, 5, -12)] + HASH(3, 1, 64, 2) + EXIT(), ok=True)
+case("ce_sha256_abc", f"{C}:100-127", HEAD + BYTES_AT(1, 3, b"abc") + HASH(3, 1, 3, 2) + WRITE_WORDS(2, 4, 2) + EXIT(), outputs=[0xba7816bf, 0x8f01cfea])
+case("ce_sha256_hello_two_words", f"{C}:100-127", HEAD + BYTES_AT(1, 3, b"hello") + HASH(3, 1, 5, 2) + WRITE_WORDS(2, 4, 2) + EXIT(), outputs=[0x2cf24dba, 0x5fb0a30e])
+case("ce_keccak256_empty_first_byte", f"{C}:134-147; :167-187", HEAD + HASH(5, 1, 0, 2) + [I("lbu", 4, 2, 0)] + WRITE(4) + EXIT(), outputs=[0xc5])
+case("ce_keccak256_hello_first_byte", f"{C}:167-187", HEAD + BYTES_AT(1, 3, b"hello") + HASH(5, 1, 5, 2) + [I("lbu", 4, 2, 0)] + WRITE(4) + EXIT(), outputs=[0x1c])
+case("ce_keccak256_long_input", f"{C}:190-205", HEAD + LI(4, 0) + LI(5, 1000) + [I("add", 6, 1, 4), I("sb", 6, 4, 0), I("addi", 4, 4, 1), I("bne", 4, 5, -12)] + OUT3 + HASH(5, 1, 1000, 7)
+     + EXIT(), ok=True, config={"max_cycles": 100000})
+case("ce_blake3_empty_first_byte", f"{C}:212-225", HEAD + HASH(6, 1, 0, 2) + [I("lbu", 4, 2, 0)] + WRITE(4) + EXIT(), outputs=[0xaf])
+case("ce_blake3_long_input", f"{C}:241-256", HEAD + LI(4, 0) + LI(5, 1000) + [I("add", 6, 1, 4), I("sb", 6, 4, 0), I("addi", 4, 4, 1), I("bne", 4, 5, -12)] + OUT3 + HASH(6, 1, 1000, 7)
+     + EXIT(), ok=True, config={"max_cycles": 100000})
+case("ce_sha256_unaligned_input", f"{C}:324-335", HEAD + [I("addi", 1, 1, 1)] + BYTES_AT(1, 3, b"a") + HASH(3, 1, 1, 2) + EXIT(), ok=True)
+case("ce_sha256_all_zeros_32", f"{C}:356-368", HEAD + sum([[I("sw", 1, 0, 4 * i)] for i in range(8)], []) + HASH(3, 1, 32, 2) + EXIT(), ok=True)
+case("ce_sha256_all_ones_32", f"{C}:371-383", HEAD + LI(3, -1) + sum([[I("sw", 1, 3, 4 * i)] for i in range(8)], []) + HASH(3, 1, 32, 2) + EXIT(), ok=True)
+case("ce_sequential_crypto_ops", f"{C}:390-402", sum([LI(1, 0x1000 + i * 0x10) + [I("slli", 1, 1, 4)] + LI(2, 0x5000 + i * 0x10) + [I("slli", 2, 2, 4)] + LI(3, i) + [I("sb", 1, 3, 0)]
+                                                      + HASH(3, 1, 1, 2) for i in range(10)], []) + EXIT(), ok=True)
+# hash chain: SHA-256("hello") at 0x2000, its 32 bytes hashed again into 0x3000; the two first words differ
+case("ce_hash_chain", f"{C}:405-427", HEAD + BYTES_AT(1, 3, b"hello") + HASH(3, 1, 5, 2) + OUT3 + HASH(3, 2, 32, 7) + [I("lw", 4, 2, 0), I("lw", 5, 7, 0), I("sne", 6, 4, 5)] + WRITE(4)
+     + WRITE(6) + EXIT(), outputs=[0x2cf24dba, 1])
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/tests/range_checking.rs — the tracker policy seen through the VM (needs_check: bound > 40 bits; checkpoint at stores;
+# chunk decomposition of boundary values).  MUL bounds add (bound.rs), constants have their bit length as bound.
+# ---------------------------------------------------------------------------------------------------------------------------------
+Rg = "zkir-runtime/tests/range_checking.rs"
+# ADDI from R0 gives bound = bits(constant) + 1 (bound.rs: after_add = max + 1): 0x7FFF -> 16; squared -> 32; x 0x7F (8) -> 40 bits: not
+# deferred;  x 0xFF (9) -> 41 bits: deferred, witnessed at the store.  `final_bound` pins the construction itself on the last trace row.
+RCT = {"enable_range_checking": True, "enable_execution_trace": True}
+case("rc_needs_check_40_bits_no", f"{Rg}:58-71", LI(1, 0x7FFF) + [I("mul", 2, 1, 1)] + LI(3, 0x7F) + [I("mul", 4, 2, 3)] + LI(5, 0x1000) + [I("slli", 5, 5, 4), I("sw", 5, 4, 0), EB], config=RCT,
+     halt=["Ebreak"], rc_witnesses=0, final_bound={"reg": 4, "bits": 40})
+case("rc_needs_check_41_bits_yes", f"{Rg}:58-71; :135-149", LI(1, 0x7FFF) + [I("mul", 2, 1, 1)] + LI(3, 0xFF) + [I("mul", 4, 2, 3)] + LI(5, 0x1000) + [I("slli", 5, 5, 4), I("sw", 5, 4, 0), EB], config=RCT,
+     halt=["Ebreak"], rc_witnesses=1, rc_checks_total=1, rc_check_pcs=[0x1000 + 4 * 3], final_bound={"reg": 4, "bits": 41})
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-spec/tests/value_types.rs (Value40 arithmetic seen through ADD / SUB / MUL / SLLI / SRLI) and bounds_and_validation.rs (the
+# bound algebra seen on the bound columns of the trace: operands with TypeWidth(8) / TypeWidth(16) bounds come from LBU / LHU)
+# ---------------------------------------------------------------------------------------------------------------------------------
+V, Bv = "zkir-spec/tests/value_types.rs", "zkir-spec/tests/bounds_and_validation.rs"
+MAX40 = (1 << 40) - 1
+case("vt_overflow_wraps_to_zero", f"{V}:26-33", LI(1, -1) + LI(2, 1) + [I("add", 3, 1, 2)] + WRITE(1) + WRITE(3) + EXIT(), outputs=[MAX40, 0])
+case("vt_underflow_wraps_to_max", f"{V}:43-49", LI(2, 1) + [I("sub", 3, 0, 2)] + WRITE(3) + EXIT(), outputs=[MAX40])
+case("vt_cross_limb_carry", f"{V}:52-61", LI32(1, 0xFFFFF) + LI(2, 1) + [I("add", 3, 1, 2)] + WRITE(3) + EXIT(), outputs=[0x100000])
+case("vt_multiplication_overflow", f"{V}:64-75", LI(1, 1) + [I("slli", 1, 1, 20), I("mul", 3, 1, 1)] + WRITE(3) + LI32(4, 0xFFFFF) + LI(5, 2) + [I("mul", 6, 4, 5)] + WRITE(6) + EXIT(),
+     outputs=[0, 0x1FFFFE])
+case("vt_bitwise_comprehensive", f"{V}:78-97", LI(1, -1) + [I("xori", 2, 0, -1)] + WRITE(2) + [I("xori", 3, 1, -1)] + WRITE(3) + [I("xor", 4, 1, 1)] + WRITE(4) + [I("and_", 5, 1, 0)] + WRITE(5)
+     + [I("or_", 6, 1, 0)] + WRITE(6) + EXIT(), outputs=[MAX40, 0, 0, 0, MAX40])
+case("vt_shift_edge_cases", f"{V}:100-114", LI(1, 1) + [I("slli", 1, 1, 39), I("ori", 1, 1, 1)] + sum([[I(op, 2, 1, sh)] + WRITE(2) for op, sh in (("slli", 0), ("srli", 0), ("slli", 40), ("srli", 40))], [])
+     + EXIT(), outputs=[0x8000000001, 0x8000000001, 0, 0])
+case("bv_bound_propagation", f"{Bv}:63-103", DATA_BASE_REG(15) + [I("lbu", 1, 15, 0), I("lbu", 2, 15, 1), I("lhu", 5, 15, 2), I("add", 3, 1, 2), I("mul", 4, 1, 2), I("and_", 6, 5, 1), I("slli", 7, 1, 4),
+                                                                  I("srli", 8, 1, 4), I("sltu", 9, 1, 2), EB],
+     config={"enable_execution_trace": True}, halt=["Ebreak"], final_bounds={"1": 8, "2": 8, "5": 16, "3": 9, "4": 16, "6": 8, "7": 12, "8": 4, "9": 1})
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# tests/stress_tests.rs, tests/end_to_end.rs, tests/cross_module.rs — assembly sources (assembler aliases: zero = R0, t2 = R10,
+# a0 = R11, zkir-assembler/src/parser.rs:40-43) with the words they must assemble to
+# ---------------------------------------------------------------------------------------------------------------------------------
+T, E2, X = "tests/stress_tests.rs", "tests/end_to_end.rs", "tests/cross_module.rs"
+ASM_EXIT = "addi t2, zero, 0\naddi a0, zero, 0\necall\n"
+case("st_tight_loop_10000", f"{T}:77-101", LI(1, 0) + LI(2, 10000) + [I("addi", 1, 1, 1), I("bne", 1, 2, -4)] + EXIT(),
+     source="addi r1, zero, 0\naddi r2, zero, 10000\nloop:\naddi r1, r1, 1\nbne r1, r2, -4\n" + ASM_EXIT, halt=["Exit", 0], config={"max_cycles": 1000000})
+case("st_nested_loops_100x100", f"{T}:103-136", LI(1, 0) + LI(3, 100) + LI(2, 0) + [I("addi", 2, 2, 1), I("bne", 2, 3, -4), I("addi", 1, 1, 1), I("bne", 1, 3, -16)] + EXIT(),
+     source="addi r1, zero, 0\naddi r3, zero, 100\nouter:\naddi r2, zero, 0\ninner:\naddi r2, r2, 1\nbne r2, r3, -4\naddi r1, r1, 1\nbne r1, r3, -16\n" + ASM_EXIT,
+     halt=["Exit", 0], config={"max_cycles": 100000})
+case("st_cycle_limit_enforcement", f"{T}:142-159", [I("jal", 0, 0)], config={"max_cycles": 100}, halt=["CycleLimit"], cycles=100)
+case("st_many_memory_operations", f"{T}:192-216", LI(1, 0x1000) + LI(2, 1) + sum([[I("sw", 1, 2, 4 * i), I("addi", 2, 2, 1)] for i in range(100)], []) + EXIT(),
+     source="addi r1, zero, 0x1000\naddi r2, zero, 1\n" + "".join(f"sw r2, {4 * i}(r1)\naddi r2, r2, 1\n" for i in range(100)) + ASM_EXIT, halt=["Exit", 0])
+case("st_sparse_memory_access", f"{T}:218-247", LI(1, 42) + LI(2, 0x1000) + [I("sw", 2, 1, 0)] + LI(2, 0x2000) + [I("sw", 2, 1, 0)] + LI(2, 0x3000) + [I("sw", 2, 1, 0)] + EXIT(),
+     source="addi r1, zero, 42\naddi r2, zero, 0x1000\nsw r1, 0(r2)\naddi r2, zero, 0x2000\nsw r1, 0(r2)\naddi r2, zero, 0x3000\nsw r1, 0(r2)\n" + ASM_EXIT, halt=["Exit", 0])
+case("st_repeated_multiplication", f"{T}:253-299", LI(1, 2) + LI(2, 1) + [I("mul", 2, 2, 1)] * 20 + EXIT(), halt=["Exit", 0])
+case("st_all_arithmetic_ops", f"{T}:301-327", LI(1, 100) + LI(2, 7) + [I("add", 3, 1, 2), I("sub", 4, 1, 2), I("mul", 5, 1, 2), I("divu", 6, 1, 2), I("remu", 7, 1, 2)] + EXIT(),
+     source="addi r1, zero, 100\naddi r2, zero, 7\nadd r3, r1, r2\nsub r4, r1, r2\nmul r5, r1, r2\ndivu r6, r1, r2\nremu r7, r1, r2\n" + ASM_EXIT, halt=["Exit", 0])
+case("st_many_branches", f"{T}:333-358", LI(1, 0) + LI(2, 1) + [I("bne", 1, 2, 4), I("add", 1, 1, 1)] * 50 + EXIT(),
+     source="addi r1, zero, 0\naddi r2, zero, 1\n" + "bne r1, r2, 4\nadd r1, r1, r1\n" * 50 + ASM_EXIT, halt=["Exit", 0])
+case("st_alternating_branches", f"{T}:360-390", LI(1, 1) + LI(2, 0) + LI(3, 50) + [I("addi", 4, 1, 0), I("addi", 1, 2, 0), I("addi", 2, 4, 0), I("addi", 3, 3, -1), I("bne", 3, 0, -16)] + EXIT(),
+     source="addi r1, zero, 1\naddi r2, zero, 0\naddi r3, zero, 50\nloop:\naddi r4, r1, 0\naddi r1, r2, 0\naddi r2, r4, 0\naddi r3, r3, -1\nbne r3, zero, -16\n" + ASM_EXIT,
+     halt=["Exit", 0])
+case("st_zero_register_destination", f"{T}:496-519", [I("addi", 0, 0, 100), I("addi", 11, 0, 0), I("addi", 10, 0, 2), EC] + EXIT(),
+     source="addi zero, zero, 100\naddi a0, zero, 0\naddi t2, zero, 2\necall\n" + ASM_EXIT, outputs=[0])
+
+def e2e(name, lines, src, words, **kw):
+    case(name, f"{E2}:{lines}", words, source=src, **kw)
+
+
+e2e("e2e_simple_addition", "21-37", "addi r1, r0, 10\naddi r2, r0, 20\nadd r3, r1, r2\nadd r10, r0, r0\necall\n", LI(1, 10) + LI(2, 20) + [I("add", 3, 1, 2)] + EXIT_ADD, ok=True)
+e2e("e2e_subtraction", "39-54", "addi r1, r0, 50\naddi r2, r0, 30\nsub r3, r1, r2\nadd r10, r0, r0\necall\n", LI(1, 50) + LI(2, 30) + [I("sub", 3, 1, 2)] + EXIT_ADD, ok=True)
+e2e("e2e_multiplication", "56-71", "addi r1, r0, 7\naddi r2, r0, 6\nmul r3, r1, r2\nadd r10, r0, r0\necall\n", LI(1, 7) + LI(2, 6) + [I("mul", 3, 1, 2)] + EXIT_ADD, ok=True)
+e2e("e2e_bitwise_operations", "73-90", "addi r1, r0, 255\naddi r2, r0, 15\nand r3, r1, r2\nor r4, r1, r2\nxor r5, r1, r2\nadd r10, r0, r0\necall\n",
+    LI(1, 255) + LI(2, 15) + [I("and_", 3, 1, 2), I("or_", 4, 1, 2), I("xor", 5, 1, 2)] + EXIT_ADD, ok=True)
+e2e("e2e_shifts", "92-107", "addi r1, r0, 8\nslli r2, r1, 2\nsrli r3, r1, 1\nadd r10, r0, r0\necall\n", LI(1, 8) + [I("slli", 2, 1, 2), I("srli", 3, 1, 1)] + EXIT_ADD, ok=True)
+e2e("e2e_branch_taken", "109-126", "addi r1, r0, 5\naddi r2, r0, 5\nbeq r1, r2, 8\naddi r3, r0, 100\naddi r3, r0, 42\nadd r10, r0, r0\necall\n",
+    LI(1, 5) + LI(2, 5) + [I("beq", 1, 2, 8)] + LI(3, 100) + LI(3, 42) + EXIT_ADD, ok=True)
+e2e("e2e_branch_not_taken", "128-144", "addi r1, r0, 5\naddi r2, r0, 10\nbeq r1, r2, 8\naddi r3, r0, 100\nadd r10, r0, r0\necall\n",
+    LI(1, 5) + LI(2, 10) + [I("beq", 1, 2, 8)] + LI(3, 100) + EXIT_ADD, ok=True)
+e2e("e2e_comparison_slt", "146-162", "addi r1, r0, 5\naddi r2, r0, 10\nslt r3, r1, r2\nslt r4, r2, r1\nadd r10, r0, r0\necall\n",
+    LI(1, 5) + LI(2, 10) + [I("slt", 3, 1, 2), I("slt", 4, 2, 1)] + EXIT_ADD, ok=True)
+e2e("e2e_loop_counting", "164-181", "addi r1, r0, 0\naddi r2, r0, 5\naddi r1, r1, 1\nbne r1, r2, -4\nadd r10, r0, r0\necall\n", LI(1, 0) + LI(2, 5) + [I("addi", 1, 1, 1), I("bne", 1, 2, -4)] + EXIT_ADD,
+    ok=True)
+e2e("e2e_execution_with_trace", "260-279", "addi r1, r0, 1\naddi r2, r0, 2\nadd r3, r1, r2\nadd r10, r0, r0\necall\n", LI(1, 1) + LI(2, 2) + [I("add", 3, 1, 2)] + EXIT_ADD,
+    config={"enable_execution_trace": True}, n_rows_min=4)
+e2e("e2e_execution_cycle_limit", "281-304", "addi r1, r1, 1\njal r0, -4\n", [I("addi", 1, 1, 1), I("jal", 0, -4)], config={"max_cycles": 100}, cycles_min=100)
+e2e("e2e_fibonacci", "310-331", "addi r1, r0, 0\naddi r2, r0, 1\naddi r3, r0, 10\naddi r4, r0, 2\nadd r5, r1, r2\nadd r1, r0, r2\nadd r2, r0, r5\naddi r4, r4, 1\nbne r4, r3, -16\nadd r10, r0, r0\necall\n",
+    LI(1, 0) + LI(2, 1) + LI(3, 10) + LI(4, 2) + [I("add", 5, 1, 2), I("add", 1, 0, 2), I("add", 2, 0, 5), I("addi", 4, 4, 1), I("bne", 4, 3, -16)] + EXIT_ADD, ok=True)
+e2e("e2e_sum_values", "334-353", "addi r1, r0, 0\naddi r2, r0, 1\naddi r3, r0, 2\naddi r4, r0, 3\nadd r1, r1, r2\nadd r1, r1, r3\nadd r1, r1, r4\nadd r10, r0, r0\necall\n",
+    LI(1, 0) + LI(2, 1) + LI(3, 2) + LI(4, 3) + [I("add", 1, 1, 2), I("add", 1, 1, 3), I("add", 1, 1, 4)] + EXIT_ADD, ok=True)
+case("xm_full_roundtrip_simple_ecall", f"{X}:112-126", [EC], source="ecall", halt=["Exit", 0], cycles=1)
+
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_suite_kats.json")
+with open(out, "w") as f:
+    json.dump({"_about": "The reference's integration-test suites re-stated as VM programs; see make_suite_kats.py", "programs": P}, f, indent=1, sort_keys=True)
+print("wrote", out, len(P), "programs")
