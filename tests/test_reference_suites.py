@@ -159,5 +159,12 @@ def test_reference_suite_through_zkir_exec_on_the_gpu():
             assert list(res.outputs) == p["outputs"], p["name"]
         if "halt" in p:
             assert (res.halt_reason.kind, res.halt_reason.code) == (HALT[p["halt"][0]], p["halt"][1] if len(p["halt"]) > 1 else 0), p["name"]
-        helpers.assert_rows_equal(res.execution_trace.to_numpy_rows(), want.rows)
+        helpers.assert_rows_equal(res.execution_trace.rows(), want.rows)
+        # the rest of ExecutionResult, expanded on the device behind the same handle (vm.rs:54-103)
+        ops, offs = res.row_memory_ops()
+        assert np.array_equal(ops, want.memops) and np.array_equal(offs, want.row_memop_offsets), p["name"]
+        assert np.array_equal(res.get_memory_trace(), want.sorted_memops), p["name"]
+        flat = [c for grp in res.range_check_witnesses for c in grp]
+        assert flat == [(int(e["value"]), [int(x) for x in e["chunks"]], int(e["pc"])) for e in want.rc_checks], p["name"]
+        assert np.array_equal(res.normalization_witnesses, want.norm_events), p["name"]
         res.close()
