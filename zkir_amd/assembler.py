@@ -83,6 +83,14 @@ def _reg(tok, line):
     return _REGS[name]
 
 
+def parse_register(name: str) -> int:
+    """zkir_assembler::parse_register (parser.rs:22-49): r0..r15 and the ABI aliases, case-insensitive -> register index."""
+    n = name.lower()
+    if n not in _REGS:
+        raise AssemblerError(0, f"Invalid register: {name}")
+    return _REGS[n]
+
+
 def _num(tok, line):
     if tok[0] != "num":
         raise AssemblerError(line, f"Expected number, got {tok!r}")
