@@ -266,6 +266,24 @@ case("bv_bound_propagation", f"{Bv}:63-103", DATA_BASE_REG(15) + [I("lbu", 1, 15
      config={"enable_execution_trace": True}, halt=["Ebreak"], final_bounds={"1": 8, "2": 8, "5": 16, "3": 9, "4": 16, "6": 8, "7": 12, "8": 4, "9": 1})
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+# zkir-runtime/src/execute.rs unit tests (:676-886): one instruction on a hand-set VMState; here the registers are set with ADDI first
+# ---------------------------------------------------------------------------------------------------------------------------------
+X2 = "zkir-runtime/src/execute.rs"
+case("ex_arithmetic_add", f"{X2}:687-702", LI(1, 100) + LI(2, 50) + [I("add", 3, 1, 2)] + WRITE(3) + EXIT(), outputs=[150])
+case("ex_arithmetic_sub", f"{X2}:704-718", LI(1, 100) + LI(2, 30) + [I("sub", 3, 1, 2)] + WRITE(3) + EXIT(), outputs=[70])
+case("ex_logical_and", f"{X2}:720-734", LI(1, 0b1100) + LI(2, 0b1010) + [I("and_", 3, 1, 2)] + WRITE(3) + EXIT(), outputs=[0b1000])
+case("ex_shift_left", f"{X2}:736-750", LI(1, 0b11) + LI(2, 4) + [I("sll", 3, 1, 2)] + WRITE(3) + EXIT(), outputs=[0b110000])
+case("ex_comparison_slt", f"{X2}:752-766", LI(1, 10) + LI(2, 20) + [I("slt", 3, 1, 2)] + WRITE(3) + EXIT(), outputs=[1])
+case("ex_load_store", f"{X2}:768-790", LI(1, 0x1000) + [I("slli", 1, 1, 4)] + LI32(2, 0x12345678) + [I("sw", 1, 2, 0), I("lw", 3, 1, 0)] + WRITE(3) + EXIT(), outputs=[0x12345678])
+# BEQ taken: pc = own pc + offset (state.pc 0 -> 100 in the unit test); not taken: pc + 4.  Seen through which ADDI runs.
+case("ex_branch_taken", f"{X2}:792-807", LI(1, 10) + LI(2, 10) + [I("beq", 1, 2, 8)] + LI(3, 111) + LI(4, 222) + WRITE(3) + WRITE(4) + EXIT(), outputs=[0, 222])
+case("ex_branch_not_taken", f"{X2}:809-824", LI(1, 10) + LI(2, 20) + [I("beq", 1, 2, 8)] + LI(3, 111) + LI(4, 222) + WRITE(3) + WRITE(4) + EXIT(), outputs=[111, 222])
+# JAL: rd = pc + 4 (the unit test: pc 0 -> R1 = 4, pc = 1000); here the JAL is word 0 at 0x1000 and jumps over one instruction
+case("ex_jal_link_and_target", f"{X2}:826-838", [I("jal", 1, 8)] + LI(3, 111) + WRITE(1) + WRITE(3) + EXIT(), outputs=[0x1004, 0])
+case("ex_ebreak", f"{X2}:840-848", [EB], halt=["Ebreak"], cycles=1)
+case("ex_division_by_zero", f"{X2}:850-867", LI(1, 100) + LI(2, 0) + [I("div", 3, 1, 2)], error=3)
+
+# ---------------------------------------------------------------------------------------------------------------------------------
 # tests/stress_tests.rs, tests/end_to_end.rs, tests/cross_module.rs — assembly sources (assembler aliases: zero = R0, t2 = R10,
 # a0 = R11, zkir-assembler/src/parser.rs:40-43) with the words they must assemble to
 # ---------------------------------------------------------------------------------------------------------------------------------
