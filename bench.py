@@ -317,7 +317,16 @@ def main():
             host_s = min(host_s, time.perf_counter() - t0)
         shard = log
     else:
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        # the shards total ~40 B per row (2.7 GB at 2^26 rows): /dev/shm when it has the room (a container may cap it at 64 MB), else the temp dir
+        import tempfile
+        need = int(total_rows * 48 * 1.1)
+        shm = "/dev/shm"
+        try:
+            st = os.statvfs(shm)
+            if st.f_bavail * st.f_frsize < need:
+                shm = tempfile.gettempdir()
+        except OSError:
+            shm = tempfile.gettempdir()
         path = lambda r: os.path.join(shm, f"zkir_bench_{os.environ.get('MASTER_PORT', '0')}_{r}.npz")  # noqa: E731
         if rank == 0:
             t0 = time.perf_counter()
