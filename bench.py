@@ -327,6 +327,9 @@ def main():
                 shm = tempfile.gettempdir()
         except OSError:
             shm = tempfile.gettempdir()
+        choice = [shm]
+        dist.broadcast_object_list(choice, src=0)           # one decision for the node: rank 0's, taken before anything is written
+        shm = choice[0]
         path = lambda r: os.path.join(shm, f"zkir_bench_{os.environ.get('MASTER_PORT', '0')}_{r}.npz")  # noqa: E731
         if rank == 0:
             t0 = time.perf_counter()
