@@ -473,7 +473,7 @@ def main():
         service.prove_many([job] * 2, k, producers=1, ctx=ctx, keep_proofs=False)
         rep = service.prove_many([job] * 24, k, producers=3, ctx=ctx, keep_proofs=False)
         service.prove_many([job] * 2, k, producers=1, ctx=ctx, keep_proofs=False, commit_only=True)
-        rc = service.prove_many([job] * 32, k, producers=3, ctx=ctx, keep_proofs=False, commit_only=True)
+        rc = service.prove_many([job] * 64, k, producers=3, ctx=ctx, keep_proofs=False, commit_only=True)
         pipelined_commit = {"runs": rc.runs, "producer_threads": 3, "ms_per_committed_run": rc.ms_per_run, "rows_per_s_committed_end_to_end": rc.rows_per_s,
                             "note": "host interpretation + H2D + the commit step (trace fill, main trace, LDE, Merkle) of independent runs, host threads overlapped with the "
                                     "GPU: the rate of the bench step with the host and PCIe in the loop"}

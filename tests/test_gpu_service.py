@@ -35,3 +35,27 @@ def test_prove_many_reports_bad_jobs():
     short = rt.VMConfig(max_cycles=100, enable_execution_trace=True)             # 100 rows pad to 2^7, the context is for 2^8
     with pytest.raises(rt.RuntimeError):
         service.prove_many([(spec.fib_endless_program().to_bytes(), [], short)], k, producers=1)
+
+
+def test_commit_many_roots_match_sequential_and_keep_job_order():
+    """commit_only: the lag-one pipeline (the next run's kernels are queued before the previous root is read back) returns, per job and
+    in job order, the root the sequential commit gives and the oracle's."""
+    from zkir_amd import pipeline as pl, service, stark
+    k = 9
+    cfg = rt.VMConfig(max_cycles=1 << k, enable_execution_trace=True)
+    ragged = rt.VMConfig(max_cycles=(1 << k) - 77, enable_execution_trace=True)
+    jobs = [(spec.fib_endless_program().to_bytes(), [], cfg), (spec.sha256_chain_program().to_bytes(), [], ragged), (spec.fib_endless_program().to_bytes(), [], ragged)] * 3
+    rep = service.prove_many(jobs, k, producers=3, commit_only=True)
+    assert len(rep.proofs) == 9
+    ctx = stark.StarkContext(k)
+    for (blob, inputs, c), root in zip(jobs[:3], rep.proofs[:3]):
+        log = rt.interpret(blob, inputs, c)
+        ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        want = stark.commit_trace(ctx, tr)[0]
+        assert np.array_equal(root, want)
+        r = so.commit_root_of_run(blob, inputs, c.max_cycles) if hasattr(so, "commit_root_of_run") else None
+        assert r is None or np.array_equal(root, r)
+    ctx.close()
+    for i in range(3):
+        assert np.array_equal(rep.proofs[i], rep.proofs[i + 3]) and np.array_equal(rep.proofs[i], rep.proofs[i + 6])
+    assert not np.array_equal(rep.proofs[0], rep.proofs[1]) and not np.array_equal(rep.proofs[0], rep.proofs[2])

@@ -84,6 +84,16 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
     t0 = time.perf_counter()
     for t in threads:
         t.start()
+    pending = None                                        # commit_only: the previous run's (index, pinned root, event, its buffers)
+    roots = [torch.empty(4, dtype=torch.int32, pin_memory=True) for _ in range(2)] if commit_only else []
+    idx_run = 0
+
+    def finish(p):
+        if p is not None:
+            p[2].synchronize()
+            if keep_proofs:
+                out[p[0]] = p[1].numpy().copy().view(np.uint32)
+
     try:
         for _ in range(len(jobs)):
             item = ready.get()
@@ -97,11 +107,24 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
             tr = pl.DeviceTrace(ddl)
             pl.trace_fill(pl.trace_fill_args(ddl, tr))
             if commit_only:
-                proof = stark.commit_trace(ctx, tr, deferred=bool(pub.deferred))[0]     # root on the host: the run's buffers are idle
+                # The commitment needs nothing from the host: queue this run's kernels BEHIND the previous run's, and only then wait
+                # for the previous root (16 bytes into pinned memory) — the GPU goes from one run to the next without a gap.
+                m = stark.main_trace(tr, deferred=bool(pub.deferred))
+                L = stark.lde(ctx, m, clobber=True)
+                tree = stark.merkle_commit(ctx, L, stark.W_MAIN)
+                root = roots[idx_run & 1]                 # two pinned landing buffers, used alternately (pinned allocation is slow)
+                idx_run += 1
+                root.copy_(tree[-4:], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                finish(pending)
+                pending = (idx, root, done, (ddl, tr, m, L, tree))
             else:
                 proof = stark.prove(ctx, tr, pub)         # returns after the proof words are on the host: the run's buffers are idle
-            if keep_proofs:
-                out[idx] = proof
+                if keep_proofs:
+                    out[idx] = proof
+        finish(pending)
+        pending = None
         torch.cuda.synchronize()
         rep.wall_s = time.perf_counter() - t0
     finally:
