@@ -127,7 +127,8 @@ int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t*
 void zkir_delta_log_free(zkir_delta_log* log);
 
 /* Row sharding (multi-GPU): a self-contained delta log for rows [row_begin, row_end) of `log`
- * (row_begin a multiple of tile_rows).  Its first 16 events are the register snapshot at row_begin, event
+ * (any row range; a row_begin that is not a multiple of tile_rows — segment proofs overlap by one row — gets the shard its own
+ * tiling, rebuilt from the events).  Its first 16 events are the register snapshot at row_begin, event
  * `vis`, mem-event rows and the tile index are rebased to the shard, and zkir_delta_log_cycle_base()
  * returns row_begin.  Side logs (range checks, normalizations, SHA blocks) are cut by the same cycle range.
  * Outputs / halt reason / cycles stay those of the whole run. */
@@ -291,17 +292,31 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob
                           uint32_t deferred, zkir_public_inputs* out);
 
 /* Full proof of the execution whose K1 output is `trace` (pub->n_real rows; ctx built for zkir_padded_log_n(pub->n_real)).  *proof_out is a
- * malloc'ed array of u32 words (little-endian canonical field elements, format v3: layout in oracle/stark_oracle.cpp so::prove),
- * released with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries. */
+ * malloc'ed array of u32 words (little-endian canonical field elements, format v4: layout in oracle/stark_oracle.cpp so::prove),
+ * released with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries.
+ * The trace may be that of a whole run or of a SEGMENT of one (the K1 output of a row shard, zkir_delta_log_shard(log, a, b) with
+ * cycle_base = a): the proof header records the 68-word state (cycle, pc limbs, register limbs, storage states) of the first and of
+ * the last row and the AIR pins those rows to it; pub->n_real is then the segment's row count, pub->io_digest the RUN's. */
 int zkir_prove(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, const zkir_public_inputs* pub, uint32_t** proof_out, uint64_t* proof_words,
                float* stage_ms, void* hip_stream);
 void zkir_proof_free(uint32_t* proof);
 uint32_t zkir_proof_num_queries(void);
 uint32_t zkir_proof_version(void);
-/* Verifier (host only, no device): 0 = accepted, otherwise the number of the failed check (1-5 malformed, 6 public inputs differ
- * from `expect`, 10 constraints at zeta, 11 final codeword degree, 12 grinding, 20-26 query / Merkle / FRI checks, 30 length).
+/* Verifier of the proof of a WHOLE run (host only, no device): 0 = accepted, otherwise the number of the failed check (1-5
+ * malformed, 6 public inputs differ from `expect`, 7 the run does not start in the VM's initial state (cycle 0, entry point, zero
+ * registers), 10 constraints at zeta, 11 final codeword degree, 12 grinding, 20-26 query / Merkle / FRI checks, 30 length).
  * expect may be NULL: the header's own public inputs are then only checked for internal consistency. */
 int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect);
+/* A run proven in SEGMENTS (multi-GPU: one row shard per device; consecutive segments overlap by one row — the last row of segment i,
+ * labelled "halt" there, is row 0 of segment i + 1).  zkir_verify_segment: the same checks without check 7; first_state / last_state
+ * (68 words each, nullable) receive the header's boundary states.  zkir_verify_chain: every segment verifies, the first starts in the
+ * initial state, each later one starts in exactly the state its predecessor ended in (the cycle counter is part of the state), mode /
+ * entry point / program digest / io digest agree; expect (nullable) = the RUN's public inputs, n_real = its total rows
+ * = sum(n_i - 1) + 1.  0 = accepted; 40 empty, 41 first state, 42 link, 43 public inputs, 44 row count; 1000 (i + 1) + c = check c
+ * of segment i. */
+int zkir_verify_segment(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect, uint32_t first_state[68], uint32_t last_state[68]);
+int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* proof_words, uint32_t n_segments, const zkir_public_inputs* expect);
+uint32_t zkir_proof_state_words(void);
 /* Host-side Poseidon2-12 permutation of the transcript (canonical words in and out; no device needed): what a verifier or an
  * integrator re-deriving the Fiat-Shamir challenges calls.  Same code as the device kernels (poseidon2.h), compiled for the host. */
 void zkir_poseidon2_permute(uint32_t state[12]);

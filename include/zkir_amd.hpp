@@ -380,7 +380,7 @@ inline zkir_public_inputs public_inputs(const zkir_runtime::ExecutionResult& res
   return pub;
 }
 
-// Full proof (u32 little-endian words, format v3) of a run whose execution trace is resident in HBM; the context must be built for
+// Full proof (u32 little-endian words, format v4) of a run whose execution trace is resident in HBM; the context must be built for
 // zkir_padded_log_n(rows).  zkir_prover::verify is the host-side check (0 = accepted).
 inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::ExecutionResult& result, const zkir_public_inputs& pub, void* hip_stream = nullptr) {
   uint32_t* words = nullptr;
@@ -392,6 +392,16 @@ inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::
   return out;
 }
 inline int verify(const std::vector<uint32_t>& proof, const zkir_public_inputs* expect = nullptr) { return zkir_verify(proof.data(), proof.size(), expect); }
+// A run proven in segments (one row shard per GPU, consecutive segments sharing one row): every segment on its own, and the chain as one run.
+struct BoundaryStates { uint32_t first[68], last[68]; };
+inline int verify_segment(const std::vector<uint32_t>& proof, BoundaryStates* states = nullptr, const zkir_public_inputs* expect = nullptr) {
+  return zkir_verify_segment(proof.data(), proof.size(), expect, states ? states->first : nullptr, states ? states->last : nullptr);
+}
+inline int verify_chain(const std::vector<std::vector<uint32_t>>& proofs, const zkir_public_inputs* expect = nullptr) {
+  std::vector<const uint32_t*> ptrs; std::vector<uint64_t> lens;
+  for (const auto& p : proofs) { ptrs.push_back(p.data()); lens.push_back(p.size()); }
+  return zkir_verify_chain(ptrs.data(), lens.data(), (uint32_t)proofs.size(), expect);
+}
 
 }  // namespace zkir_prover
 

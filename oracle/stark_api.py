@@ -34,7 +34,10 @@ def lib():
         L.so_prove.restype = SZ; L.so_prove.argtypes = [V, PP, V, SZ]
         L.so_prove_matrix.restype = SZ; L.so_prove_matrix.argtypes = [V, PP, V, SZ]
         L.so_verify.restype = I; L.so_verify.argtypes = [V, SZ, PP]
-        L.so_pow_bits.restype = I; L.so_header_words.restype = I
+        L.so_pow_bits.restype = I; L.so_header_words.restype = I; L.so_state_words.restype = I
+        L.so_verify_segment.restype = I; L.so_verify_segment.argtypes = [V, SZ, PP, V]
+        L.so_verify_chain.restype = I; L.so_verify_chain.argtypes = [V, V, I, PP]
+        L.so_constraints_eval_states.restype = I; L.so_constraints_eval_states.argtypes = [V, V, U32, U32, U32, PP, V, V, V, V]
         L.so_commit_port.restype = None; L.so_commit_port.argtypes = [V, I, I, I, V, V]
         L.so_last_challenges.restype = None; L.so_last_challenges.argtypes = [V, V, V]
         L.so_last_quotient.restype = None; L.so_last_quotient.argtypes = [V]
@@ -203,6 +206,33 @@ def verify(proof: np.ndarray, expect: PublicC | None = None) -> int:
     """0 = accepted; otherwise the code of the first failed check (6: the header's public inputs are not the expected ones)."""
     proof = _u32(proof)
     return lib().so_verify(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None)
+
+
+def verify_segment(proof: np.ndarray, expect: PublicC | None = None):
+    """A SEGMENT of a run (no initial-state requirement): (code, first_state[68], last_state[68]) — what verify_chain links."""
+    proof = _u32(proof)
+    st = np.zeros(136, np.uint32)
+    rc = lib().so_verify_segment(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None, st.ctypes.data)
+    return rc, st[:68].copy(), st[68:].copy()
+
+
+def verify_chain(proofs, expect: PublicC | None = None) -> int:
+    """Segments of one run in order (each overlapping its predecessor by one row).  0 = accepted; 40-44 chain checks; 1000 (i+1) + c = check c
+    of segment i.  `expect.n_real` = the run's total executed rows."""
+    ps = [_u32(p) for p in proofs]
+    ptrs = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
+    lens = (C.c_size_t * len(ps))(*[len(p) for p in ps])
+    return lib().so_verify_chain(ptrs, lens, len(ps), C.byref(expect) if expect is not None else None)
+
+
+def constraints_eval_states(loc, nxt, is_first, is_last, is_trans, pub: PublicC, first, last, alpha) -> np.ndarray:
+    loc, nxt, alpha, first, last, o = _u32(loc), _u32(nxt), _u32(alpha), _u32(first), _u32(last), np.zeros(4, np.uint32)
+    lib().so_constraints_eval_states(loc.ctypes.data, nxt.ctypes.data, int(is_first), int(is_last), int(is_trans), C.byref(pub), first.ctypes.data, last.ctypes.data,
+                                     alpha.ctypes.data, o.ctypes.data)
+    return o
+
+
+STATE_COLS = [0, 1, 2, 3] + list(range(9, 73))      # cycle, pc limbs, register limbs, storage states (so::state_col)
 
 
 def last_challenges():

@@ -169,6 +169,8 @@ static const int W_MAIN = 152;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_T = 134, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
        C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151 };
+static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
+
 enum { K_ADD = 0, K_ADDI = 1, K_BNE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6 };
 static const uint32_t OP_ADD = 0x00, OP_ADDI = 0x08, OP_BNE = 0x41, OP_JAL = 0x48;
 
@@ -183,7 +185,13 @@ struct Public {
   uint64_t entry = 0x1000;   // header.entry_point: pc of row 0
   F prog[4] = {0, 0, 0, 0};  // digest of the program blob
   F io[4] = {0, 0, 0, 0};    // digest of (inputs, outputs, halt reason, cycles)
+  // Boundary states (format v4): the 68 state columns (cycle, pc limbs, 48 register limbs, 16 storage states) of row 0 and of row
+  // n_real - 1.  The prover reads them off its main trace and puts them in the header; the AIR pins both rows to them.  A proof of a
+  // WHOLE run must start in the VM's initial state (verify(): check 7); a SEGMENT of a run starts where its predecessor ended
+  // (verify_chain()).
+  F first[68] = {0}, last[68] = {0};
 };
+static const int N_STATE = 68;
 static int padded_log_n(uint64_t n_real) { int k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
 
 // digest of a byte string: Poseidon2 sponge over [len as four 16-bit pieces] ++ [little-endian 16-bit halfwords, zero-padded]
@@ -211,7 +219,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     const bool pad = i >= n_real;
     const PackedRow& r = rows[pad ? n_real - 1 : i];
     const bool last = i + 1 >= n_real;                      // the last executed row and every padding row: no successor to describe
-    col(C_CYCLE)[i] = (F)((pad ? (uint64_t)i : r.cycle) % P);
+    col(C_CYCLE)[i] = (F)((pad ? r.cycle + (i - (n_real - 1)) : r.cycle) % P);      // padding keeps counting
     const F pc[3] = {(F)(r.pc & 0xFFFFF), (F)((r.pc >> 20) & 0xFFFFF), (F)(r.pc >> 40)};
     for (int l = 0; l < 3; l++) col(C_PC + l)[i] = pc[l];
     const uint32_t w = r.instruction;
@@ -306,8 +314,8 @@ static void merkle_build(const std::vector<F>& mat, int width, size_t n, Merkle&
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 3;   // "ZKPF"; v3: AIR v1 (152 columns), public inputs, padding, grinding
-static const int HEADER_WORDS = 21;                                   // words before the trace root (layout in prove())
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 4;   // "ZKPF"; v4: v3 (AIR v1, public inputs, padding, grinding) + boundary states
+static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
 // before the next commitment.  Layer 0 (the DEEP codeword) is folded once, so that its leaves are the pairs (q, q + N) the trace
@@ -359,9 +367,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E& is_first, const 
   const E* K = loc + C_K;
   // 1. cycle counter, first row, last executed row
   push(emul(esub(esub(nxt[C_CYCLE], loc[C_CYCLE]), one), is_trans));
-  push(emul(loc[C_CYCLE], is_first));
-  for (int l = 0; l < 3; l++) push(emul(esub(loc[C_PC + l], cst(l == 0 ? (pub.entry & 0xFFFFF) : l == 1 ? ((pub.entry >> 20) & 0xFFFFF) : (pub.entry >> 40))), is_first));
-  for (int k = C_LIMB; k < C_STATE + 16; k++) push(emul(loc[k], is_first));                        // VMState::new: all registers zero, Normalized (state.rs:55-71)
+  for (int i = 0; i < N_STATE; i++) push(emul(esub(loc[state_col(i)], cst(pub.first[i])), is_first));   // row 0 is in the public first state
   push(emul(esub(K[K_HALT], one), is_last));
   // 2. R0 is hard-wired zero
   for (int l = 0; l < 3; l++) push(loc[C_LIMB + l]);
@@ -448,6 +454,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E& is_first, const 
   push(emul(emul(K[K_HALT], esub(one, nxt[C_K + K_PAD])), is_trans));
   push(emul(emul(K[K_PAD], esub(one, nxt[C_K + K_PAD])), is_trans));
   push(emul(emul(esub(esub(one, K[K_PAD]), K[K_HALT]), nxt[C_K + K_PAD]), is_trans));
+  // 12. (v4) the last executed row is in the public last state: what a following segment starts from
+  for (int i = 0; i < N_STATE; i++) push(emul(esub(loc[state_col(i)], cst(pub.last[i])), is_last));
   result = A.acc;
   return A.c;
 }
@@ -478,6 +486,13 @@ static void header_words(int log_n, const Public& pub, std::vector<uint32_t>& w)
   w.push_back((uint32_t)(pub.entry & 0xFFFFF)); w.push_back((uint32_t)((pub.entry >> 20) & 0xFFFFF)); w.push_back((uint32_t)(pub.entry >> 40));
   for (int i = 0; i < 4; i++) w.push_back(pub.prog[i]);
   for (int i = 0; i < 4; i++) w.push_back(pub.io[i]);
+  for (int i = 0; i < N_STATE; i++) w.push_back(pub.first[i]);
+  for (int i = 0; i < N_STATE; i++) w.push_back(pub.last[i]);
+}
+// the VM's initial state at `entry` (VMState::new, state.rs:55-71): cycle 0, pc = entry, all registers zero and Normalized
+static void initial_state(uint64_t entry, F st[N_STATE]) {
+  memset(st, 0, N_STATE * sizeof(F));
+  st[1] = (F)(entry & 0xFFFFF); st[2] = (F)((entry >> 20) & 0xFFFFF); st[3] = (F)(entry >> 40);
 }
 
 struct ProverTrace {     // everything the oracle keeps for inspection by tests
@@ -489,12 +504,17 @@ struct ProverTrace {     // everything the oracle keeps for inspection by tests
 };
 
 // matrix_override (tests): prove this main-trace matrix [W][N] instead of the one derived from the rows (a cheating prover)
-static void prove(const PackedRow* rows, const Public& pub, Proof& proof, ProverTrace& pt, const F* matrix_override = nullptr) {
+static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, ProverTrace& pt, const F* matrix_override = nullptr) {
+  Public pub = pub_in;
   const int log_n = padded_log_n(pub.n_real);
   const size_t N = (size_t)1 << log_n, N2 = 2 * N;
   const int Wm = W_MAIN;
   if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wm * N);
   else main_trace(rows, pub.n_real, pub, pt.M);
+  for (int i = 0; i < N_STATE; i++) {                                     // boundary states: rows 0 and n_real - 1 of the matrix being proven
+    pub.first[i] = pt.M[(size_t)state_col(i) * N];
+    pub.last[i] = pt.M[(size_t)state_col(i) * N + (pub.n_real - 1)];
+  }
   pt.L.assign((size_t)Wm * N2, 0);
   std::vector<std::vector<F>> coeffs(Wm);
   for (int k = 0; k < Wm; k++) {
@@ -634,7 +654,9 @@ static bool check_path(const F* leaf_digest, size_t idx, const uint32_t* path, i
   for (int d = 0; d < depth; d++) { F nx[4]; if (idx & 1) compress(path + 4 * d, node, nx); else compress(node, path + 4 * d, nx); memcpy(node, nx, 16); idx >>= 1; }
   return !memcmp(node, root, 16);
 }
-static int verify(const uint32_t* w, size_t len, const Public* expect) {
+// whole_run: the proof must start in the VM's initial state (check 7); otherwise it is a segment and `states_out` (nullable, 2 x 68
+// words: first, last) is what verify_chain() links.
+static int verify(const uint32_t* w, size_t len, const Public* expect, bool whole_run = true, F* states_out = nullptr) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
   if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
@@ -645,9 +667,13 @@ static int verify(const uint32_t* w, size_t len, const Public* expect) {
   pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
   pub.entry = (uint64_t)w[10] | ((uint64_t)w[11] << 20) | ((uint64_t)w[12] << 40);
   memcpy(pub.prog, w + 13, 16); memcpy(pub.io, w + 17, 16);
+  memcpy(pub.first, w + 21, N_STATE * 4); memcpy(pub.last, w + 21 + N_STATE, N_STATE * 4);
+  for (int i = 0; i < 2 * N_STATE; i++) if (w[21 + i] >= P) return 3;
   if (pub.n_real == 0 || padded_log_n(pub.n_real) != log_n) return 2;
   if (expect && (expect->n_real != pub.n_real || (expect->deferred != 0) != (pub.deferred != 0) || expect->entry != pub.entry ||
                  memcmp(expect->prog, pub.prog, 16) || memcmp(expect->io, pub.io, 16))) return 6;
+  if (whole_run) { F init[N_STATE]; initial_state(pub.entry, init); if (memcmp(init, pub.first, sizeof init)) return 7; }
+  if (states_out) { memcpy(states_out, pub.first, N_STATE * 4); memcpy(states_out + N_STATE, pub.last, N_STATE * 4); }
   p = HEADER_WORDS;
   const size_t N = (size_t)1 << log_n;
   for (size_t i = 2; i < len; i++) if (w[i] >= P) return 3;   // every payload word must be canonical (query indices are < N < p)
@@ -773,6 +799,36 @@ static int verify(const uint32_t* w, size_t len, const Public* expect) {
   if (p != len) return 30;
   return 0;
 }
+
+// ---- a run proven in SEGMENTS (row ranges that overlap by one row: the last row of segment i is row 0 of segment i + 1, labelled
+// "halt" in the former — its instruction is executed by the latter).  Every proof must verify as a segment; the first starts in the
+// VM's initial state; each later one starts in exactly the state its predecessor ended in (the cycle counter is part of the state);
+// program digest, io digest, mode and entry point are the same everywhere; `expect` (nullable) carries the run's public inputs, its
+// n_real being the run's TOTAL executed rows = sum(n_i - 1) + 1.  0 = accepted; 40-44 = chain checks; 1000 (i + 1) + c = check c of
+// segment i failed.
+static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n, const Public* expect) {
+  if (n < 1) return 40;
+  std::vector<F> st((size_t)n * 2 * N_STATE);
+  uint64_t total = 1;
+  for (int i = 0; i < n; i++) {
+    const int rc = verify(proofs[i], lens[i], nullptr, false, &st[(size_t)i * 2 * N_STATE]);
+    if (rc) return 1000 * (i + 1) + rc;
+    const uint32_t* w = proofs[i];
+    total += ((uint64_t)w[7] | ((uint64_t)w[8] << 30)) - 1;
+    if (memcmp(w + 9, proofs[0] + 9, 12 * 4)) return 43;                 // mode, entry, program digest, io digest
+  }
+  const uint32_t* w0 = proofs[0];
+  const uint64_t entry = (uint64_t)w0[10] | ((uint64_t)w0[11] << 20) | ((uint64_t)w0[12] << 40);
+  F init[N_STATE]; initial_state(entry, init);
+  if (memcmp(init, &st[0], sizeof init)) return 41;
+  for (int i = 1; i < n; i++)
+    if (memcmp(&st[(size_t)i * 2 * N_STATE], &st[(size_t)(i - 1) * 2 * N_STATE + N_STATE], N_STATE * 4)) return 42;
+  if (expect) {
+    if ((expect->deferred != 0) != (w0[9] != 0) || expect->entry != entry || memcmp(expect->prog, w0 + 13, 16) || memcmp(expect->io, w0 + 17, 16)) return 43;
+    if (expect->n_real != total) return 44;
+  }
+  return 0;
+}
 }  // namespace so
 
 // =================================================================================================
@@ -820,7 +876,25 @@ int so_constraints_eval(const uint32_t* loc, const uint32_t* nxt, uint32_t is_fi
   std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN);
   for (int k = 0; k < so::W_MAIN; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
   so::E r;
-  so::constraints_sum(l.data(), x.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), to_pub(pub), ap.data(), r);
+  so::Public q = to_pub(pub);
+  so::initial_state(q.entry, q.first);                                                    // a whole run's first state;
+  if (is_last) for (int i = 0; i < so::N_STATE; i++) q.last[i] = loc[so::state_col(i)];   // the last state is whatever the last row holds
+  so::constraints_sum(l.data(), x.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, ap.data(), r);
+  memcpy(out4, r.c, 16);
+  return NC;
+}
+// the same with explicit boundary states (68 words each): segments
+int so_constraints_eval_states(const uint32_t* loc, const uint32_t* nxt, uint32_t is_first, uint32_t is_last, uint32_t is_trans, const so_public* pub, const uint32_t* first68,
+                               const uint32_t* last68, const uint32_t* alpha4, uint32_t* out4) {
+  const int NC = so::num_constraints();
+  so::E a; memcpy(a.c, alpha4, 16);
+  std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
+  std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN);
+  for (int k = 0; k < so::W_MAIN; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
+  so::Public q = to_pub(pub);
+  memcpy(q.first, first68, sizeof q.first); memcpy(q.last, last68, sizeof q.last);
+  so::E r;
+  so::constraints_sum(l.data(), x.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, ap.data(), r);
   memcpy(out4, r.c, 16);
   return NC;
 }
@@ -864,6 +938,18 @@ int so_verify(const uint32_t* proof, size_t len, const so_public* expect) {
   const so::Public e = to_pub(expect);
   return so::verify(proof, len, &e);
 }
+// segment verification: states136 (nullable) receives the header's first and last state
+int so_verify_segment(const uint32_t* proof, size_t len, const so_public* expect, uint32_t* states136) {
+  if (!expect) return so::verify(proof, len, nullptr, false, states136);
+  const so::Public e = to_pub(expect);
+  return so::verify(proof, len, &e, false, states136);
+}
+int so_verify_chain(const uint32_t* const* proofs, const size_t* lens, int n, const so_public* expect) {
+  if (!expect) return so::verify_chain(proofs, lens, n, nullptr);
+  const so::Public e = to_pub(expect);
+  return so::verify_chain(proofs, lens, n, &e);
+}
+int so_state_words() { return so::N_STATE; }
 void so_last_challenges(uint32_t* alpha, uint32_t* zeta, uint32_t* gamma) { memcpy(alpha, g_pt.alpha.c, 16); memcpy(zeta, g_pt.zeta.c, 16); memcpy(gamma, g_pt.gamma.c, 16); }
 void so_last_quotient(uint32_t* out /* [4][2N] */) { memcpy(out, g_pt.Qc.data(), g_pt.Qc.size() * 4); }
 size_t so_last_fri_layer(int j, uint32_t* out /* [m][4] */) { if (j < 0 || (size_t)j >= g_pt.fri.size()) return 0; if (out) memcpy(out, g_pt.fri[j].data(), g_pt.fri[j].size() * 16); return g_pt.fri[j].size(); }

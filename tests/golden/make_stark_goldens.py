@@ -60,11 +60,11 @@ def golden(case):
     proof = so.prove(res.rows, pub)
     assert so.verify(proof, pub) == 0
     root = so.commit_trace(res.rows, 1, pub=pub)
-    assert list(root) == list(proof[21:25])
+    assert list(root) == list(proof[157:161])
     return dict(name=case["name"], program_blob_hex=case["blob"].hex(), max_cycles=case["max_cycles"], deferred=case["deferred"],
                 n_rows=len(res.rows), outputs=[int(x) for x in res.outputs], halt=[int(res.halt_kind), int(res.halt_code)],
                 program_digest=[int(x) for x in pub.prog], io_digest=[int(x) for x in pub.io],
-                trace_root=[int(x) for x in proof[21:25]], quotient_root=[int(x) for x in proof[25:29]],
+                trace_root=[int(x) for x in proof[157:161]], quotient_root=[int(x) for x in proof[161:165]],
                 proof_words=int(len(proof)), proof_sha256=hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest())
 
 

@@ -49,6 +49,10 @@ def test_two_ranks_sharded_commitment():
     want = [so.commit_trace(rows[g * n:(g + 1) * n], 1) for g in range(world)]
     assert [list(map(int, r)) for r in want] == out["merkle_roots_all_ranks"]
     assert list(map(int, so.compress(want[0], want[1]))) == out["merkle_root"]
+    # the run PROVEN in segments, one per rank (+ the one-row tail), and accepted as one run by zkir_verify_chain on rank 0
+    sp = out["segment_prove"]
+    assert sp and "error" not in sp, sp
+    assert sp["segments"] == world + 1 and sp["verify_chain_code"] == 0 and sp["rows_per_segment"] == n and sp["ms_all_segments_in_parallel"] > 0
 
 
 def test_non_power_of_two_world_is_rejected():

@@ -337,5 +337,40 @@ def test_full_size_2p20_properties():
     del L, tree, Lh, t
     proof = stark.prove(ctx, tr, pub)
     assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0
-    assert np.array_equal(proof[21:25], root)
+    assert np.array_equal(proof[157:161], root)
     ctx.close(); log.close()
+
+
+@pytest.mark.parametrize("name,n_total,seg", [("fib", 1000, 300), ("sha", 700, 256), ("fib", 4096, 1025), ("deferred", 500, 200)])
+def test_a_run_proven_in_segments_on_the_gpu(name, n_total, seg):
+    """Multi-GPU proving, executed here shard after shard on one device: every row shard of the delta log (plus the first row of the
+    next one) goes through K1 and zkir_prove on its own; each segment proof is the oracle's word for word, and the chain verifies as
+    ONE run in both verifiers.  Nothing but 16-byte-aligned row ranges of the host log is shared between the segments."""
+    from zkir_amd import pipeline as pl, stark
+    mk, cfg = PROGRAMS[name]
+    blob = mk().to_bytes()
+    deferred = bool(cfg.get("enable_deferred_model"))
+    log = rt.interpret(blob, [], rt.VMConfig(enable_execution_trace=True, max_cycles=n_total, **cfg))
+    res = oracle.run(blob, enable_execution_trace=True, max_cycles=n_total, **cfg)
+    run_pub = rt.public_inputs(log, blob, [], deferred)
+    run_opub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=deferred)
+    cuts, a = [], 0
+    while a < log.n_rows - 1:
+        b = min(a + seg, log.n_rows)
+        cuts.append((a, b)); a = b - 1
+    proofs = []
+    for a, b in cuts:
+        sh = log.shard(a, b)
+        ddl = pl.upload(sh); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        pub = rt.PublicInputsC.from_buffer_copy(run_pub); pub.n_real = b - a
+        ctx = stark.StarkContext(stark.padded_log_n(b - a))
+        proof = stark.prove(ctx, tr, pub)
+        ctx.close(); sh.close()
+        opub = so.PublicC.from_buffer_copy(run_opub); opub.n_real = b - a
+        want = so.prove(res.rows[a:b], opub)
+        assert np.array_equal(proof, want), f"segment rows [{a}, {b})"
+        proofs.append(proof)
+    assert len(proofs) >= 3
+    assert rt.verify_chain(proofs, run_pub) == 0 and so.verify_chain(proofs, run_opub) == 0
+    assert rt.verify(proofs[1]) == 7 and rt.verify_chain(proofs[1:]) == 41 and rt.verify_chain([proofs[0]] + proofs[2:]) == 42
+    log.close()

@@ -136,8 +136,13 @@ def test_shard_equals_slice():
         sel["row"] -= lo
         assert np.array_equal(sh.mem_events, sel)
         sh.close()
+    sh = log.shard(100, 200)         # not tile-aligned: the shard gets its own tiling (tests/test_shard_logs.py)
+    rows = helpers.expand_delta_log(sh)
+    rows["cycle"] += np.uint64(100)
+    helpers.assert_rows_equal(rows, full[100:200])
+    sh.close()
     with pytest.raises(rt.RuntimeError):
-        log.shard(100, 200)          # not tile-aligned
+        log.shard(200, 100)          # empty-negative range
 
 
 def test_fib_2p16_faithful_equals_linear():

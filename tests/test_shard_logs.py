@@ -53,3 +53,32 @@ def test_shards_concatenate_to_the_whole(name):
     if name == "fib_rc_long":
         assert len(log.rc_events) > 0 and len(log.rc_cycles) == len(log.rc_offsets) - 1
     log.close()
+
+
+@pytest.mark.parametrize("name", sorted(_CASES))
+def test_unaligned_and_overlapping_shards_expand_to_their_rows(name):
+    """Cuts that are not on tile boundaries (segment proofs overlap by one row): the shard's own tiling — snapshot at its first row,
+    tile offsets and tile snapshots rebuilt from the events — expands to exactly rows [a, b) of the run, and its tile index satisfies
+    the invariants K1 relies on."""
+    blob, inputs, cfg = _CASES[name]
+    try:
+        log = rt.interpret(blob, inputs, rt.VMConfig(enable_execution_trace=True, **cfg), tile_rows=256)
+    except rt.RuntimeError:
+        pytest.skip("program errors out")
+    n = log.n_rows
+    whole = helpers.expand_delta_log(log)
+    seg = 300
+    cuts, a = [], 0
+    while a < n - 1:
+        b = min(a + seg, n)
+        cuts.append((a, b)); a = b - 1                       # overlap by one row
+    cuts += [(1, n), (255, 257), (257, 258), (n - 1, n), (777 % n, min(n, 777 % n + 513))]
+    for a, b in cuts:
+        sh = log.shard(a, b)
+        assert sh.n_rows == b - a and sh.cycle_base == a
+        helpers.check_tile_index(sh)
+        rows = helpers.expand_delta_log(sh)
+        rows["cycle"] += np.uint64(a)
+        helpers.assert_rows_equal(rows, whole[a:b])
+        sh.close()
+    log.close()

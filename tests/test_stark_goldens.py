@@ -37,7 +37,7 @@ def test_oracle_reproduces_goldens(name):
     pub = so.public_inputs(len(res.rows), blob, [], c["outputs"], tuple(c["halt"]), deferred=c["deferred"])
     assert [int(x) for x in pub.prog] == c["program_digest"] and [int(x) for x in pub.io] == c["io_digest"]
     proof = so.prove(res.rows, pub)
-    assert [int(x) for x in proof[21:25]] == c["trace_root"] and [int(x) for x in proof[25:29]] == c["quotient_root"]
+    assert [int(x) for x in proof[157:161]] == c["trace_root"] and [int(x) for x in proof[161:165]] == c["quotient_root"]
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof) == 0                                                      # the product's verifier accepts the frozen proofs
 
@@ -55,7 +55,7 @@ def test_gpu_prover_reproduces_goldens(name):
     assert list(pub.program_digest) == c["program_digest"] and list(pub.io_digest) == c["io_digest"]
     ctx = stark.StarkContext(stark.padded_log_n(res.cycles))
     proof = stark.prove(ctx, res.execution_trace.columns, pub)
-    assert [int(x) for x in proof[21:25]] == c["trace_root"] and [int(x) for x in proof[25:29]] == c["quotient_root"]
+    assert [int(x) for x in proof[157:161]] == c["trace_root"] and [int(x) for x in proof[161:165]] == c["quotient_root"]
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof, pub) == 0
     ctx.close(); res.close()

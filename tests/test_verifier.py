@@ -31,7 +31,7 @@ def test_accepts_what_the_oracle_accepts(n, prog, cfg):
     assert so.verify(pr, pub) == 0
     assert rt.verify(pr) == 0 and rt.verify(pr, _pub_c(pub)) == 0
     rng = np.random.default_rng(len(rows))
-    for pos in list(range(2, 21)) + [int(x) for x in rng.integers(21, len(pr), 60)] + [len(pr) - 1]:     # same verdict AND same failing check everywhere
+    for pos in list(range(2, 21)) + [21, 24, 30, 88, 89, 92, 156] + [int(x) for x in rng.integers(157, len(pr), 60)] + [len(pr) - 1]:     # same verdict AND same failing check everywhere
         t = pr.copy()
         t[pos] = (int(t[pos]) + 1 + int(rng.integers(0, 50))) % P
         if t[pos] != pr[pos]:
@@ -81,3 +81,28 @@ def test_rejects_cheating_provers_like_the_oracle():
         r = rows.copy(); mutate(r)
         pr = so.prove(r, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10
+
+
+@pytest.mark.parametrize("n_total,seg,prog", [(100, 40, "fib"), (300, 128, "sha"), (65, 33, "fib")])
+def test_segment_chains_same_verdicts_as_the_oracle(n_total, seg, prog):
+    """zkir_verify_segment / zkir_verify_chain against so::verify / so::verify_chain on a run proven in overlapping segments: accepted
+    chains, and the same code for every way of breaking one (wrong start, gap, order, public inputs, row count, a bad segment)."""
+    from test_stark_oracle import _segments
+    rows, full, cuts, proofs = _segments(n_total, seg, prog)
+    fullc = _pub_c(full)
+    assert so.verify_chain(proofs, full) == 0 and rt.verify_chain(proofs, fullc) == 0 and rt.verify_chain(proofs) == 0
+    for i, pr in enumerate(proofs):
+        rc, f, l = rt.verify_segment(pr)
+        orc, of, ol = so.verify_segment(pr)
+        assert rc == orc == 0 and np.array_equal(f, of) and np.array_equal(l, ol) and int(f[0]) == cuts[i][0] and int(l[0]) == cuts[i][1] - 1
+        assert rt.verify(pr) == so.verify(pr) == (0 if i == 0 else 7)
+    wrong_rows = rt.PublicInputsC.from_buffer_copy(fullc); wrong_rows.n_real += 1
+    wrong_prog = rt.PublicInputsC.from_buffer_copy(fullc); wrong_prog.program_digest[1] ^= 1
+    o_rows = so.PublicC.from_buffer_copy(full); o_rows.n_real += 1
+    o_prog = so.PublicC.from_buffer_copy(full); o_prog.prog[1] ^= 1
+    tampered = proofs[-1].copy(); tampered[300] = (int(tampered[300]) + 1) % P
+    cases = [(proofs[1:], None, None), (proofs[::-1], None, None), ([proofs[0], proofs[0]], None, None), (proofs, wrong_rows, o_rows), (proofs, wrong_prog, o_prog),
+             (proofs[:-1] + [tampered], None, None), ([], None, None)]
+    for chain, e_rt, e_so in cases:
+        want = so.verify_chain(chain, e_so) if chain else 40
+        assert want != 0 and rt.verify_chain(chain, e_rt) == want, (want, rt.verify_chain(chain, e_rt))

@@ -78,8 +78,8 @@ int zkir_delta_log_shard(const zkir_delta_log* src, uint64_t row_begin, uint64_t
   if (!src || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: null argument"}); return ZKIR_ERR_ARGUMENT; }
   *out = nullptr;
   const uint64_t T = src->tile_rows;
-  if (row_begin > row_end || row_end > src->n_rows || row_begin % T != 0 || src->cycle_base != 0) {
-    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: need 0 <= row_begin <= row_end <= n_rows, row_begin % tile_rows == 0, unsharded source"});
+  if (row_begin > row_end || row_end > src->n_rows || src->cycle_base != 0) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: need 0 <= row_begin <= row_end <= n_rows and an unsharded source"});
     return ZKIR_ERR_ARGUMENT;
   }
   zkir_delta_log* d = new zkir_delta_log();
@@ -94,6 +94,44 @@ int zkir_delta_log_shard(const zkir_delta_log* src, uint64_t row_begin, uint64_t
     d->rc_cycles.push_back(src->rc_cycles[k]);
   }
   if (d->n_rows == 0) { d->tile_ev_off.push_back(0); *out = d; return ZKIR_OK; }
+  if (row_begin % T != 0) {
+    // A cut that is not on a tile boundary (segment proofs overlap by ONE row, so their first rows are at g (S - 1)): the shard gets
+    // its own tiling from row_begin.  Snapshot = the source tile's snapshot advanced over the events visible by row_begin; then one
+    // pass over the shard's events rebuilds tile_ev_off (first event with vis > tile start) and tile_snap (last event per register
+    // with vis <= tile start), the conventions of include/zkir_amd.h.
+    const uint64_t ts = row_begin / T, nt = (d->n_rows + T - 1) / T;
+    const zkir_reg_event* ev = src->reg_events.data();
+    const size_t n_ev = src->reg_events.size();
+    uint32_t snap[16];
+    for (int r = 0; r < 16; r++) snap[r] = src->tile_snap[ts * 16 + r];
+    size_t e0 = src->tile_ev_off[ts];
+    while (e0 < n_ev && ev[e0].vis <= row_begin) { snap[ev[e0].reg] = (uint32_t)e0; e0++; }
+    const uint64_t end_vis = row_begin + nt * T;                                  // events up to the end of the shard's last tile
+    size_t e1 = e0;
+    while (e1 < n_ev && ev[e1].vis <= end_vis) e1++;
+    d->pc.append(src->pc.data() + row_begin, d->n_rows);
+    d->inst.append(src->inst.data() + row_begin, d->n_rows);
+    for (int r = 0; r < 16; r++) { zkir_reg_event e = ev[snap[r]]; e.vis = 0; d->reg_events.push(e); }
+    for (size_t k = e0; k < e1; k++) { zkir_reg_event e = ev[k]; e.vis -= (uint32_t)row_begin; d->reg_events.push(e); }
+    uint32_t last[16];
+    for (int r = 0; r < 16; r++) last[r] = (uint32_t)r;
+    size_t k = e0;
+    for (uint64_t j = 0; j < nt; j++) {
+      const uint64_t start = row_begin + j * T;
+      while (k < e1 && ev[k].vis <= start) { last[ev[k].reg] = (uint32_t)(k - e0 + 16); k++; }
+      d->tile_ev_off.push_back((uint32_t)(k - e0 + 16));
+      for (int r = 0; r < 16; r++) d->tile_snap.push_back(last[r]);
+    }
+    d->tile_ev_off.push_back((uint32_t)(e1 - e0 + 16));
+    for (size_t m = 0; m < src->mem_events.size(); m++) {
+      zkir_mem_event me = src->mem_events[m];
+      if (me.row >= row_begin && me.row < row_end) { me.row -= (uint32_t)row_begin; d->mem_events.push(me); }
+    }
+    for (size_t m = 0; m < src->norm_events.size(); m++) if (src->norm_events[m].cycle >= row_begin && src->norm_events[m].cycle < row_end) d->norm_events.push(src->norm_events[m]);
+    for (size_t m = 0; m < src->sha_blocks.size(); m++) if (src->sha_blocks[m].timestamp >= row_begin && src->sha_blocks[m].timestamp < row_end) d->sha_blocks.push(src->sha_blocks[m]);
+    *out = d;
+    return ZKIR_OK;
+  }
   const uint64_t t0 = row_begin / T, t1 = (row_end + T - 1) / T;                   // tiles [t0, t1)
   const uint32_t e0 = src->tile_ev_off[t0];
   // events up to the end of the last tile; for an interior cut that is tile_ev_off[t1], for the run's tail all remaining

@@ -11,8 +11,9 @@
 //   * y = xb + xc, xb + sext(imm17) (mod 2^40, two 20-bit limbs with boolean carries), or pc + 4 — the register selected by wr shows
 //     y in the next row, every other register keeps its limbs and storage state (execute.rs:43-63, :185-197, :639-647);
 //   * pc' = pc + 4 | pc + sext(imm17) if the BNE operands differ in any limb | pc + sext(off21) for JAL, mod 2^64 (state.rs:131-133);
-//   * cycle counts up from 0; row 0 starts at the entry point with zero registers; the row count is public: row n_real - 1 is the
-//     halt row, only padding follows it, padding keeps everything.
+//   * cycle counts up; row 0 is in the public FIRST state and row n_real - 1 in the public LAST state (for a whole run the verifier
+//     requires the first state to be the VM's initial one: cycle 0, entry point, zero registers); the row count is public: row
+//     n_real - 1 is the halt row, only padding follows it, padding keeps everything.
 // Not constrained yet (stated in DESIGN.md §8.5): limb / carry / field RANGES (need the lookup argument the range-check
 // multiplicities of K2 are produced for), the instruction word at pc being the program's (same lookup), the other 46 opcodes'
 // values, and deferred-mode arithmetic (deferred = 1 relaxes the write constraints to "unwritten registers keep their value").
@@ -31,7 +32,11 @@ constexpr uint32_t OP_ADD = 0x00, OP_ADDI = 0x08, OP_BNE = 0x41, OP_JAL = 0x48;
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
 enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 142,
              I_ONE_CLASS = 150, I_CLASS_OP = 151, I_CHAIN = 155, I_OTH = 159, I_WR = 160, I_SELB = 163, I_SELC = 165, I_OPERAND = 167, I_VALUE = 173,
-             I_NE = 182, I_TK = 186, I_DL0 = 188, I_SE = 189, I_PC = 190, I_PC_KEEP = 193, I_REGS = 196, I_TAIL = 256, N_CONSTRAINTS = 259 };
+             I_NE = 182, I_TK = 186, I_DL0 = 188, I_SE = 189, I_PC = 190, I_PC_KEEP = 193, I_REGS = 196, I_TAIL = 256, I_LAST = 259, N_CONSTRAINTS = 327 };
+// Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
+// last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
+constexpr int N_STATE = 68;
+BB_HD constexpr int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }
 
 // canonical constant -> Montgomery form at compile time
 constexpr uint32_t M(uint64_t v) { return (uint32_t)(((v % bb::P) * (uint64_t)bb::R1) % bb::P); }
@@ -41,9 +46,9 @@ constexpr RegConsts make_reg_consts() { RegConsts c{}; for (int i = 0; i < 16; i
 // `Ops` supplies the value type and its arithmetic:
 //   using V;  V add(V,V), sub(V,V), mul(V,V);  V mulc(V, uint32_t montgomery_constant);  V cst(uint32_t montgomery_constant);
 //   V loc(int column), nxt(int column);  void push(int constraint_index, V value)      (values in Montgomery form throughout)
-// is_first / is_last / is_trans: the row selectors at the evaluation point; entry[3]: Montgomery limbs of the public entry pc.
+// is_first / is_last / is_trans: the row selectors at the evaluation point; first_m / last_m: the public boundary states (Montgomery).
 template <class Ops>
-BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typename Ops::V is_trans, const uint32_t entry_m[3], bool deferred) {
+BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typename Ops::V is_trans, const uint32_t* first_m, const uint32_t* last_m, bool deferred) {
   using V = typename Ops::V;
   const V one = o.cst(bb::R1), zero = o.cst(0);
   auto boolean = [&](int idx, V b) { o.push(idx, o.mul(b, o.sub(b, one))); };
@@ -57,9 +62,13 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   // 1. cycle counter, first row, last executed row
   const V cyc = o.loc(C_CYCLE);
   o.push(I_CYCLE, o.mul(o.sub(o.sub(o.nxt(C_CYCLE), cyc), one), is_trans));
-  o.push(I_CYCLE0, o.mul(cyc, is_first));
+  o.push(I_CYCLE0, o.mul(o.sub(cyc, o.cst(first_m[0])), is_first));
+  o.push(I_LAST, o.mul(o.sub(cyc, o.cst(last_m[0])), is_last));
 #pragma unroll
-  for (int l = 0; l < 3; l++) o.push(I_ENTRY + l, o.mul(o.sub(pc[l], o.cst(entry_m[l])), is_first));
+  for (int l = 0; l < 3; l++) {
+    o.push(I_ENTRY + l, o.mul(o.sub(pc[l], o.cst(first_m[1 + l])), is_first));
+    o.push(I_LAST + 1 + l, o.mul(o.sub(pc[l], o.cst(last_m[1 + l])), is_last));
+  }
   o.push(I_HALT, o.mul(o.sub(K[K_HALT], one), is_last));
   // registers: first-row zero, R0, booleans, selector moments, operand sums, update — one pass per register
   V w0 = zero, w1 = zero, w2 = zero, b1 = zero, b2 = zero, c1s = zero, c2s = zero;
@@ -68,9 +77,14 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int r = 0; r < 16; r++) {
     V limb[3];
 #pragma unroll
-    for (int l = 0; l < 3; l++) { limb[l] = o.loc(C_LIMB + 3 * r + l); o.push(I_ZERO0 + 3 * r + l, o.mul(limb[l], is_first)); }
+    for (int l = 0; l < 3; l++) {
+      limb[l] = o.loc(C_LIMB + 3 * r + l);
+      o.push(I_ZERO0 + 3 * r + l, o.mul(o.sub(limb[l], o.cst(first_m[4 + 3 * r + l])), is_first));
+      o.push(I_LAST + 4 + 3 * r + l, o.mul(o.sub(limb[l], o.cst(last_m[4 + 3 * r + l])), is_last));
+    }
     const V st = o.loc(C_STATE + r);
-    o.push(I_ZERO0 + 48 + r, o.mul(st, is_first));
+    o.push(I_ZERO0 + 48 + r, o.mul(o.sub(st, o.cst(first_m[52 + r])), is_first));
+    o.push(I_LAST + 52 + r, o.mul(o.sub(st, o.cst(last_m[52 + r])), is_last));
     boolean(I_BOOL_STATE + r, st);
     if (r == 0) {
 #pragma unroll

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, ui
   auto col = [&](int k) -> uint32_t& { return rowv[k]; };
   const bool pad = i >= n_real, last = i + 1 >= n_real;
   const uint64_t src = pad ? n_real - 1 : i;
-  col(C_CYCLE) = (uint32_t)((pad ? i : t.cycle[src]) % bb::P);
+  col(C_CYCLE) = (uint32_t)((t.cycle[src] + (i - src)) % bb::P);               // padding keeps counting from the last executed row
   const uint64_t pcv = t.pc[src];
   const uint32_t pc[3] = {(uint32_t)(pcv & 0xFFFFF), (uint32_t)((pcv >> 20) & 0xFFFFF), (uint32_t)(pcv >> 40)};
   col(C_PC) = pc[0]; col(C_PC + 1) = pc[1]; col(C_PC + 2) = pc[2];

@@ -9,15 +9,15 @@ namespace {
 
 using bb::E4;
 
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, HEADER_WORDS = 21;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 3;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 4;
 
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
   E4 alpha_pow[N_CONSTRAINTS];
   E4 gamma_pow[2 * WM + 4];
   E4 zeta, zeta_w, a0, b0;
-  uint32_t entry_m[3];          // public entry pc limbs
+  uint32_t first_m[NS], last_m[NS];   // public boundary states: rows 0 and n_real - 1 (Montgomery)
   uint32_t deferred;
 };
 
@@ -91,12 +91,20 @@ __global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict
   const uint32_t is_last = bb::mont_mul(zh, inv_mont(bb::sub(x, w_last_m)));
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
   QuotientOps o{L, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0};
-  air::eval(o, is_first, is_last, is_trans, pp->entry_m, pp->deferred != 0);
+  air::eval(o, is_first, is_last, is_trans, pp->first_m, pp->last_m, pp->deferred != 0);
   const E4 total = bb::e_add(o.partial, lz_reduce(o.acc));
   const E4 q = bb::e_from_mont(bb::e_mul_fm(total, inv_zh));
   uint4* q4 = reinterpret_cast<uint4*>(Q);                                     // one B8 block: four coordinate columns + four zero columns
   q4[(uint64_t)j * 2] = make_uint4(q.c[0], q.c[1], q.c[2], q.c[3]);
   q4[(uint64_t)j * 2 + 1] = make_uint4(0, 0, 0, 0);
+}
+
+// ---- boundary states: the 68 state words of rows 0 and last_row of the main trace (B8 layout) -> out[136] ----------------------------
+__global__ void boundary_states_kernel(const uint32_t* __restrict__ M, uint64_t N, uint64_t last_row, uint32_t* __restrict__ out) {
+  const uint32_t i = threadIdx.x;
+  if (i >= 2 * NS) return;
+  const uint32_t k = (uint32_t)air::state_col((int)(i % NS));
+  out[i] = M[b8(k, i < (uint32_t)NS ? 0 : last_row, N)];
 }
 
 // ---- barycentric weights over the LDE coset: e_j = x_j / (zeta - x_j)  (Montgomery E4, AoS) -------------------------------
@@ -309,14 +317,15 @@ struct StageEvents {             // RAII: released on every return path
   ~StageEvents() { if (on) for (auto& e : ev) (void)hipEventDestroy(e); }
 };
 
-// the 21 header words of a v3 proof (so::header_words): everything both sides know before the first commitment
-void header_words(uint32_t log_n, const zkir_public_inputs& pub, std::vector<uint32_t>& w) {
+// the header words of a v4 proof (so::header_words): parameters, public inputs, the two boundary states read off the main trace
+void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t* states, std::vector<uint32_t>& w) {
   w.clear();
   w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
   w.insert(w.end(), {(uint32_t)(pub.n_real & 0x3FFFFFFF), (uint32_t)(pub.n_real >> 30), pub.deferred ? 1u : 0u});
   w.insert(w.end(), {(uint32_t)(pub.entry_point & 0xFFFFF), (uint32_t)((pub.entry_point >> 20) & 0xFFFFF), (uint32_t)(pub.entry_point >> 40)});
   w.insert(w.end(), pub.program_digest, pub.program_digest + 4);
   w.insert(w.end(), pub.io_digest, pub.io_digest + 4);
+  w.insert(w.end(), states, states + 2 * NS);
 }
 
 }  // namespace
@@ -361,10 +370,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     c->arena_off = 0;
   }
   Arena ar{c};
-  uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest;
+  uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest, *dBound;
   E4 *dW, *dDinv, *dPart;
   ProveParams* dPP;
-  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4));
+  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS));
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
@@ -378,16 +387,18 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 1. main trace, LDE, trace commitment ---------------------------------------------------------------------------------
   mark(0);
   int rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s); if (rc) return rc;
+  hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, dBound);   // before the LDE overwrites dM
   mark(1);
   rc = zkir_lde_launch(c, dM, WM, dL, s); if (rc) return rc;
   mark(2);
   rc = zkir_merkle_commit_launch(c, dL, WM, N2, dTree, s); if (rc) return rc;
-  uint32_t troot[4], qroot[4];
+  uint32_t troot[4], qroot[4], bound[2 * NS];
   HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(bound, dBound, sizeof bound, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   mark(3);
   std::vector<uint32_t> head;
-  header_words(log_n, *pub, head);
+  header_words(log_n, *pub, bound, head);
   Challenger ch(c->consts);
   ch.observe_n(head.data() + 2, head.size() - 2);
   ch.observe_n(troot, 4);
@@ -398,8 +409,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   {
     E4 a{{1, 0, 0, 0}};
     for (int k = 0; k < N_CONSTRAINTS; k++) { pp->alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
-    pp->entry_m[0] = bb::to_mont((uint32_t)(pub->entry_point & 0xFFFFF)); pp->entry_m[1] = bb::to_mont((uint32_t)((pub->entry_point >> 20) & 0xFFFFF));
-    pp->entry_m[2] = bb::to_mont((uint32_t)(pub->entry_point >> 40)); pp->deferred = pub->deferred ? 1 : 0;
+    for (int i = 0; i < NS; i++) { pp->first_m[i] = bb::to_mont(bound[i]); pp->last_m[i] = bb::to_mont(bound[NS + i]); }
+    pp->deferred = pub->deferred ? 1 : 0;
     HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
   }
   const uint32_t wn = bb::root_of_unity((int)log_n);

@@ -1,4 +1,5 @@
-// verify.cpp — the product's verifier of ZKIR-STARK v1 proofs (format v3) and the public-input helpers; host only, no device.
+// verify.cpp — the product's verifier of ZKIR-STARK v1 proofs (format v4: whole runs, segments of a run, chains of segments) and the
+// public-input helpers; host only, no device.
 //
 // Self-defined stages (the reference has no prover or verifier: SURVEY.md F1 / a17, N4).  Independent of oracle/: Montgomery
 // arithmetic (babybear.h), the product's Poseidon2 (poseidon2.h) and the product's constraint list (air.h, the same template the
@@ -16,8 +17,8 @@
 namespace {
 
 using bb::E4;
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, HEADER_WORDS = 21;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 3;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 4;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
 
@@ -88,6 +89,14 @@ inline E4 fold_pair(const E4& a, const E4& b, uint32_t x_m, const E4& beta) {
   return bb::e_add(bb::e_mul_fm(bb::e_add(a, b), half_m), bb::e_mul_m(beta, bb::e_mul_fm(bb::e_sub(a, b), inv)));
 }
 
+// the VM's initial state at `entry` (VMState::new, state.rs:55-71) as a state vector: cycle 0, pc limbs, zero registers, Normalized
+void initial_state(uint64_t entry, uint32_t st[NS]) {
+  memset(st, 0, NS * sizeof(uint32_t));
+  st[1] = (uint32_t)(entry & 0xFFFFF); st[2] = (uint32_t)((entry >> 20) & 0xFFFFF); st[3] = (uint32_t)(entry >> 40);
+}
+
+int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out);
+
 }  // namespace
 
 extern "C" {
@@ -119,7 +128,47 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t
   return ZKIR_OK;
 }
 
-int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect) {
+int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect) { return verify_impl(w, len, expect, true, nullptr); }
+
+int zkir_verify_segment(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, uint32_t first_state[68], uint32_t last_state[68]) {
+  uint32_t st[2 * NS];
+  const int rc = verify_impl(w, len, expect, false, st);
+  if (rc == 0) { if (first_state) memcpy(first_state, st, NS * 4); if (last_state) memcpy(last_state, st + NS, NS * 4); }
+  return rc;
+}
+
+uint32_t zkir_proof_state_words(void) { return NS; }
+
+int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint32_t n, const zkir_public_inputs* expect) {
+  if (!proofs || !lens || n < 1) return 40;
+  std::vector<uint32_t> st((size_t)n * 2 * NS);
+  uint64_t total = 1;
+  for (uint32_t i = 0; i < n; i++) {
+    const int rc = verify_impl(proofs[i], lens[i], nullptr, false, &st[(size_t)i * 2 * NS]);
+    if (rc) return 1000 * (int)(i + 1) + rc;
+    const uint32_t* w = proofs[i];
+    total += ((uint64_t)w[7] | ((uint64_t)w[8] << 30)) - 1;
+    if (memcmp(w + 9, proofs[0] + 9, 12 * 4)) return 43;                   // mode, entry point, program digest, io digest
+  }
+  const uint32_t* w0 = proofs[0];
+  const uint64_t entry = (uint64_t)w0[10] | ((uint64_t)w0[11] << 20) | ((uint64_t)w0[12] << 40);
+  uint32_t init[NS];
+  initial_state(entry, init);
+  if (memcmp(init, &st[0], sizeof init)) return 41;
+  for (uint32_t i = 1; i < n; i++)
+    if (memcmp(&st[(size_t)i * 2 * NS], &st[(size_t)(i - 1) * 2 * NS + NS], NS * 4)) return 42;
+  if (expect) {
+    if ((expect->deferred != 0) != (w0[9] != 0) || expect->entry_point != entry || memcmp(expect->program_digest, w0 + 13, 16) || memcmp(expect->io_digest, w0 + 17, 16)) return 43;
+    if (expect->n_real != total) return 44;
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out) {
   if (!w) return 1;
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
@@ -132,9 +181,13 @@ int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
   pub.entry_point = (uint64_t)w[10] | ((uint64_t)w[11] << 20) | ((uint64_t)w[12] << 40);
   memcpy(pub.program_digest, w + 13, 16); memcpy(pub.io_digest, w + 17, 16);
+  const uint32_t* first = w + 21; const uint32_t* last = w + 21 + NS;       // boundary states: pinned to rows 0 and n_real - 1 by the AIR
+  for (int i = 0; i < 2 * NS; i++) if (first[i] >= bb::P) return 3;
   if (pub.n_real == 0 || zkir_padded_log_n(pub.n_real) != (uint32_t)log_n) return 2;
   if (expect && (expect->n_real != pub.n_real || (expect->deferred != 0) != (pub.deferred != 0) || expect->entry_point != pub.entry_point ||
                  memcmp(expect->program_digest, pub.program_digest, 16) || memcmp(expect->io_digest, pub.io_digest, 16))) return 6;
+  if (whole_run) { uint32_t init[NS]; initial_state(pub.entry_point, init); if (memcmp(init, first, sizeof init)) return 7; }   // a run starts in the VM's initial state
+  if (states_out) memcpy(states_out, first, 2 * NS * 4);
   p = HEADER_WORDS;
   const size_t N = (size_t)1 << log_n;
   for (size_t i = 2; i < len; i++) if (w[i] >= bb::P) return 3;
@@ -182,9 +235,10 @@ int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     E4 dl = zeta; dl.c[0] = bb::sub(dl.c[0], bb::to_mont(bb::pow(wn, pub.n_real - 1)));
     const E4 is_first = bb::e_mul_m(zh, bb::e_inv_m(d1)), is_last = bb::e_mul_m(zh, bb::e_inv_m(dl));
     E4 is_trans = zeta; is_trans.c[0] = bb::sub(is_trans.c[0], bb::to_mont(bb::inv(wn)));
-    const uint32_t entry_m[3] = {bb::to_mont(w[10]), bb::to_mont(w[11]), bb::to_mont(w[12])};
+    uint32_t first_m[NS], last_m[NS];
+    for (int i = 0; i < NS; i++) { first_m[i] = bb::to_mont(first[i]); last_m[i] = bb::to_mont(last[i]); }
     VerifierOps o{t_z.data(), t_zw.data(), ap.data(), bb::e_zero()};
-    air::eval(o, is_first, is_last, is_trans, entry_m, pub.deferred != 0);
+    air::eval(o, is_first, is_last, is_trans, first_m, last_m, pub.deferred != 0);
     E4 qz = bb::e_zero();                                                  // Q(zeta) = sum_i X^i q_i(zeta): basis element X^i times the E4 opening
     for (int i = 0; i < 4; i++) { E4 basis = bb::e_zero(); basis.c[i] = bb::R1; qz = bb::e_add(qz, bb::e_mul_m(basis, q_z[i])); }
     if (!e_eq(o.acc, bb::e_mul_m(qz, zh))) return 10;
@@ -272,4 +326,4 @@ int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   return 0;
 }
 
-}  // extern "C"
+}  // namespace

@@ -179,6 +179,11 @@ def lib() -> C.CDLL:
     L.zkir_prove.argtypes = [V, C.POINTER(TraceColumnsC), C.POINTER(PublicInputsC), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(U64), C.POINTER(C.c_float), V]
     L.zkir_verify.restype = C.c_int
     L.zkir_verify.argtypes = [V, U64, C.POINTER(PublicInputsC)]
+    L.zkir_verify_segment.restype = C.c_int
+    L.zkir_verify_segment.argtypes = [V, U64, C.POINTER(PublicInputsC), V, V]
+    L.zkir_verify_chain.restype = C.c_int
+    L.zkir_verify_chain.argtypes = [V, V, C.c_uint32, C.POINTER(PublicInputsC)]
+    L.zkir_proof_state_words.restype = C.c_uint32
     L.zkir_digest_bytes.restype = None
     L.zkir_digest_bytes.argtypes = [C.c_char_p, C.c_size_t, V]
     L.zkir_public_inputs_of.restype = C.c_int
@@ -310,6 +315,22 @@ def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int]
     if rc != ZKIR_OK:
         _raise(rc)
     return out
+
+
+def verify_segment(proof: np.ndarray, expect: Optional[PublicInputsC] = None):
+    """zkir_verify_segment: a SEGMENT of a run -> (code, first_state u32[68], last_state u32[68])."""
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    first, last = np.zeros(68, np.uint32), np.zeros(68, np.uint32)
+    rc = lib().zkir_verify_segment(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None, first.ctypes.data, last.ctypes.data)
+    return rc, first, last
+
+
+def verify_chain(proofs, expect: Optional[PublicInputsC] = None) -> int:
+    """zkir_verify_chain: the segments of one run, in order; expect.n_real = the run's total executed rows."""
+    ps = [np.ascontiguousarray(p, dtype=np.uint32) for p in proofs]
+    ptrs = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
+    lens = (C.c_uint64 * len(ps))(*[len(p) for p in ps])
+    return lib().zkir_verify_chain(ptrs, lens, len(ps), C.byref(expect) if expect is not None else None)
 
 
 def verify(proof: np.ndarray, expect: Optional[PublicInputsC] = None) -> int:
