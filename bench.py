@@ -50,6 +50,31 @@ def _strided_passes(stages: int) -> int:
     return cnt
 
 
+_STAGE_KERNELS = {"trace_fill": ["trace_fill_kernel"], "main_trace": ["main_trace_kernel"], "lde": ["ntt_strided_r4_kernel<false", "lde_middle", "ntt_strided_r4_kernel<true"],
+                  "merkle": ["leaf_hash_kernel", "compress_kernel", "subtree_kernel"]}
+
+
+def _profiled_traffic(stage: str):
+    """HBM bytes one step's `stage` moves, from the newest committed rocprofv3 counter passes of this exact command (profiles/
+    r*_bench_commit_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE per kernel, corrected as MI355X_MICROARCH.md prescribes, averaged per
+    launch).  A stage is several kernels: each kernel's per-launch bytes times its launches per step (its launch count relative to the
+    stage's first kernel, which runs once per step)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_commit_pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    names = _STAGE_KERNELS.get(stage, [])
+    ref = next((v for kname, v in d.items() if names and kname.startswith(names[0])), None)
+    if not ref or not ref.get("WRITE_SIZE_launches"):
+        return None
+    total = 0.0
+    for kname, v in d.items():
+        if any(kname.startswith(nm) for nm in names):
+            total += v["hbm_bytes_per_launch"] * round(v["WRITE_SIZE_launches"] / ref["WRITE_SIZE_launches"])
+    return total
+
+
 def _profiled_valu_busy(kernel: str):
     """VALUBusy (0..1) of `kernel` from the newest committed rocprofv3 counter pass (profiles/*_valu_busy.txt), or None."""
     import glob
@@ -577,10 +602,7 @@ def main():
         value = total_rows * args.steps / wall
         kernels = _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp)
         dom = max(kernels, key=lambda q: kernels[q]["ms"])
-        traffic = None                                 # HBM bytes/launch from the committed rocprofv3 PMC passes of this exact workload
-        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{dom}_k{k}.json")
-        if os.path.exists(pmc):
-            traffic = next(iter(json.load(open(pmc)).values())).get("hbm_bytes_per_launch")
+        traffic = _profiled_traffic(dom) if (k == 20 and world == 1 and commit) else None
         out = {
             "metric": f"trace rows/sec (2^{k}-cycle fib: execution-trace fill + BabyBear NTT/LDE + Poseidon2 Merkle commitment)"
                       if commit else f"trace rows/sec (2^{k}-cycle fib, execution-trace fill only)",

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(NT) void lde_small_kernel(const uint32_t* __restric
 // scale g^k / N (k = bit-reversal of the position), zero-interleave, and the first 11 forward-DIT stages of the size-2N transform,
 // written as the 2048-position chunk of `out`.  Register-resident radix-4 rounds: 5 + 5 LDS round trips for the 21 stages, one
 // twiddle read per quad (the others are its square and its product with a 4th root of unity), shared by the four columns a lane
-// carries.  LDS: A = both halves of the chunk (32 KiB), Bf = the forward part of ONE half at a time (32 KiB): 64 KiB per workgroup,
-// two workgroups per CU.
+// carries.  LDS: A = both halves of the chunk (32 KiB; later the forward buffer of half 1), Bf = the forward buffer of half 0 (32 KiB):
+// 64 KiB per workgroup, two workgroups per CU.
 constexpr int MID_NT = 512;
 __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t chunks_per_block, uint32_t total, int L,
                                                                 const uint32_t* __restrict__ small_inv, const uint32_t* __restrict__ small_fwd,
@@ -337,9 +337,14 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
     }
     // ---- forward DIT of the zero-interleaved chunk (2048 positions), one half of the block at a time: stage 0 is a copy, rounds do
     //      stages (s, s+1), s = 1,3,5,7,9; lane = quad t of 512 ----
+    // Half 0 runs its forward rounds in Bf; half 1 then runs them in A itself (A is dead once round 0 of half 1 has read it — one
+    // extra barrier between that round's loads and stores), so that both halves of a position are stored TOGETHER: 32 contiguous
+    // bytes per lane whose two 16-byte stores meet in L2.  Stored one half at a time, 10 us apart, every 32-byte sector reached HBM
+    // twice, half-filled: WRITE_SIZE showed 2.40 GB per launch against 1.28 GB algorithmic (profiles/r02i_bench_commit_pmc_traffic.txt).
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {
       const uint4* a = A + h * APL;
+      uint4* F = h == 0 ? Bf : A;
 #pragma unroll
       for (int r = 0; r < 5; r++) {
         const int s = 2 * r + 1;
@@ -348,16 +353,18 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
         const uint32_t w2 = small_fwd[lo << (Bm - s - 1)];     // w_2048^(lo << (9-s)): twiddle of stage s+1
         const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_fwd_m);
         uint4 x0, x1, x2, x3;
-        if (r == 0) { x0 = a[i0 >> 1]; x1 = a[(i0 + d) >> 1]; x2 = a[(i0 + 2 * d) >> 1]; x3 = a[(i0 + 3 * d) >> 1]; }   // after stage 0: Bf[j] = A[j >> 1]
-        else { x0 = Bf[i0]; x1 = Bf[i0 + d]; x2 = Bf[i0 + 2 * d]; x3 = Bf[i0 + 3 * d]; }
+        if (r == 0) {                                          // after stage 0: F[j] = A[j >> 1]
+          x0 = a[i0 >> 1]; x1 = a[(i0 + d) >> 1]; x2 = a[(i0 + 2 * d) >> 1]; x3 = a[(i0 + 3 * d) >> 1];
+          __syncthreads();                                     // half 1 overwrites what it has just read
+        } else { x0 = F[i0]; x1 = F[i0 + d]; x2 = F[i0 + 2 * d]; x3 = F[i0 + 3 * d]; }
         dit4(x0, x1, x2, x3, w1, w2, w2i);
-        Bf[i0] = x0; Bf[i0 + d] = x1; Bf[i0 + 2 * d] = x2; Bf[i0 + 3 * d] = x3;
+        F[i0] = x0; F[i0 + d] = x1; F[i0 + 2 * d] = x2; F[i0 + 3 * d] = x3;
         __syncthreads();
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; y[((uint64_t)2 * base + e) * 2 + h] = Bf[e]; }
-      __syncthreads();
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; y[((uint64_t)2 * base + e) * 2] = Bf[e]; y[((uint64_t)2 * base + e) * 2 + 1] = A[e]; }
+    __syncthreads();
     if (wn >= total) break;
     w = wn;
   }
