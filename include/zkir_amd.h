@@ -331,6 +331,11 @@ typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device
  * on the current HIP device.  Fails with ZKIR_ERR_DEVICE if no GPU is usable (no CPU fallback). */
 int zkir_exec(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
               const zkir_vm_config* cfg, zkir_result** out);
+/* The same handle for a ROW SHARD of a finished interpretation (zkir_interpret): rows [row_begin, row_end) of `log` are cut out
+ * (zkir_delta_log_shard), uploaded to the CURRENT HIP device and filled there.  Multi-GPU: one call per device, each with its row range
+ * (hipSetDevice / one process per GPU); segment proofs: ranges that share one row.  The result owns the shard (zkir_result_delta_log:
+ * cycle_base = row_begin); trace columns hold absolute cycles; the witness accessors describe the shard's rows. */
+int zkir_exec_shard(const zkir_delta_log* log, uint64_t row_begin, uint64_t row_end, zkir_result** out);
 void zkir_result_free(zkir_result* r);
 const zkir_delta_log* zkir_result_delta_log(const zkir_result* r);       /* host-side metadata */
 const zkir_trace_columns* zkir_result_trace(const zkir_result* r);       /* device pointers */

@@ -220,6 +220,46 @@ static void test_prove_and_verify() {
   CHECK(zkir_prover::verify(bad) != 0);
 }
 
+// A run proven in segments through the plain C ABI, as a multi-GPU caller without any HIP code of its own would: one interpretation,
+// zkir_exec_shard per row range (ranges share one row), zkir_prove per shard, zkir_verify_chain over the proofs.
+static void test_segment_proofs_through_the_c_abi() {
+  auto code = cat({{addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, 150), add(4, 1, 2), addi(1, 2, 0), addi(2, 4, 0), addi(3, 3, -1), bne(3, 0, -16)}, write_reg(2), EXIT0});
+  const Program prog = Program::from_code(code);
+  const std::vector<uint8_t> blob = prog.to_bytes();
+  zkir_vm_config cfg{}; cfg.max_cycles = 1000000; cfg.enable_execution_trace = 1;
+  zkir_delta_log* log = nullptr;
+  CHECK(zkir_interpret(blob.data(), blob.size(), nullptr, 0, &cfg, 0, &log) == ZKIR_OK);
+  const uint64_t n = zkir_delta_log_n_rows(log);                 // 3 + 5 * 150 + 6 = 759 rows
+  CHECK(n == 759);
+  zkir_public_inputs run_pub;
+  CHECK(zkir_public_inputs_of(log, blob.data(), blob.size(), nullptr, 0, 0, &run_pub) == ZKIR_OK);
+  const uint64_t S = 256;
+  std::vector<std::vector<uint32_t>> proofs;
+  for (uint64_t a = 0; a + 1 < n; a += S - 1) {
+    const uint64_t b = a + S < n ? a + S : n;
+    zkir_result* r = nullptr;
+    CHECK(zkir_exec_shard(log, a, b, &r) == ZKIR_OK);
+    CHECK(zkir_delta_log_cycle_base(zkir_result_delta_log(r)) == a && zkir_delta_log_n_rows(zkir_result_delta_log(r)) == b - a);
+    zkir_public_inputs pub = run_pub; pub.n_real = b - a;
+    zkir_stark_ctx* ctx = nullptr;
+    CHECK(zkir_stark_ctx_create(zkir_padded_log_n(b - a), 1, &ctx) == ZKIR_OK);
+    uint32_t* words = nullptr; uint64_t nw = 0;
+    CHECK(zkir_prove(ctx, zkir_result_trace(r), &pub, &words, &nw, nullptr, nullptr) == ZKIR_OK);
+    proofs.emplace_back(words, words + nw);
+    zkir_proof_free(words); zkir_stark_ctx_free(ctx); zkir_result_free(r);
+  }
+  CHECK(proofs.size() == 3);
+  CHECK(zkir_prover::verify_chain(proofs, &run_pub) == 0 && zkir_prover::verify_chain(proofs) == 0);
+  zkir_prover::BoundaryStates st0, st1;
+  CHECK(zkir_prover::verify_segment(proofs[0], &st0) == 0 && zkir_prover::verify_segment(proofs[1], &st1) == 0);
+  CHECK(st0.first[0] == 0 && st0.last[0] == S - 1 && st1.first[0] == S - 1 && std::memcmp(st0.last, st1.first, sizeof st0.last) == 0);
+  CHECK(zkir_prover::verify(proofs[0]) == 0 && zkir_prover::verify(proofs[1]) == 7);          // only the first starts in the initial state
+  CHECK(zkir_prover::verify_chain({proofs[0], proofs[2]}) == 42 && zkir_prover::verify_chain({proofs[1], proofs[2]}) == 41);
+  zkir_public_inputs wrong = run_pub; wrong.n_real += 1;
+  CHECK(zkir_prover::verify_chain(proofs, &wrong) == 44);
+  zkir_delta_log_free(log);
+}
+
 int main(int argc, char** argv) {
   const bool gpu = argc > 1 && std::string(argv[1]) == "gpu";
   struct T { const char* name; std::function<void()> f; bool needs_gpu; };
@@ -236,7 +276,7 @@ int main(int argc, char** argv) {
       {"test_trace_timestamp_synchronization", test_trace_timestamp_synchronization, true},
       {"test_bound_propagation_and_deferred_checks", test_bound_propagation_and_deferred_checks, true},
       {"test_deferred_carry_normalization_event", test_deferred_carry_normalization_event, true},
-      {"test_prove_and_verify", test_prove_and_verify, true}};
+      {"test_prove_and_verify", test_prove_and_verify, true}, {"test_segment_proofs_through_the_c_abi", test_segment_proofs_through_the_c_abi, true}};
   int ran = 0;
   for (const auto& t : tests) {
     if (t.needs_gpu && !gpu) continue;

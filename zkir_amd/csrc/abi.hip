@@ -379,6 +379,53 @@ fail_rc:
   return rc;
 }
 
+// The drop-in handle for a ROW SHARD of a finished interpretation (multi-GPU: every device takes one; segment proofs: shards that share
+// one row): cut rows [row_begin, row_end) out of `log` (zkir_delta_log_shard), upload that shard to the current device and fill its
+// trace.  The result owns the shard; its trace columns hold absolute cycles (cycle_base = row_begin), its witness accessors describe the
+// shard's rows.  No host code of the caller needs HIP.
+int zkir_exec_shard(const zkir_delta_log* log, uint64_t row_begin, uint64_t row_end, zkir_result** out) {
+  if (!out || !log) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_exec_shard: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+    zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_exec_shard: no usable HIP device (the product path has no CPU fallback)"});
+    return ZKIR_ERR_DEVICE;
+  }
+  zkir_delta_log* sh = nullptr;
+  int rc = zkir_delta_log_shard(log, row_begin, row_end, &sh);
+  if (rc != ZKIR_OK) return rc;
+  zkir_result* r = new zkir_result();
+  r->log = sh;
+  hipStream_t s = nullptr;
+  const uint64_t n = sh->n_rows;
+  if (n > 0) {
+    const uint32_t T = sh->tile_rows;
+    zkir_trace_fill_args a{};
+    rc = alloc_trace(r, round_up(n, T), sh->reg_events.size(), sh->tile_ev_off.size(), sh->tile_snap.size());
+    if (rc != ZKIR_OK) goto fail_rc;
+    HIP_TRY(hipMemcpyAsync(r->d_events, sh->reg_events.data(), sh->reg_events.size() * sizeof(zkir_reg_event), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r->d_tile_ev_off, sh->tile_ev_off.data(), sh->tile_ev_off.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r->d_tile_snap, sh->tile_snap.data(), sh->tile_snap.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r->cols.pc, sh->pc.data(), n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r->cols.instruction, sh->inst.data(), n * 4, hipMemcpyHostToDevice, s));
+    a.events = (const zkir_reg_event*)r->d_events;
+    a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off;
+    a.tile_snap = (const uint32_t*)r->d_tile_snap;
+    a.n_rows = n; a.cycle_base = sh->cycle_base; a.tile_rows = T; a.n_events = (uint32_t)sh->reg_events.size();
+    a.out = r->cols;
+    rc = zkir_trace_fill_launch(&a, s);
+    if (rc != ZKIR_OK) goto fail_rc;
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  *out = r;
+  return ZKIR_OK;
+fail:
+  rc = ZKIR_ERR_DEVICE;
+fail_rc:
+  zkir_result_free(r);
+  return rc;
+}
+
 void zkir_result_free(zkir_result* r) {
   if (!r) return;
   if (r->d_block) (void)hipFree(r->d_block);
