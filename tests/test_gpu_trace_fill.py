@@ -162,3 +162,20 @@ def test_streaming_exec_error_after_streaming_started():
     res, want = _run_both(spec.fib_endless_program().to_bytes(), max_cycles=1 << 17)        # the library is fine afterwards
     _check(res, want)
     res.close()
+
+
+@pytest.mark.parametrize("a,b", [(0, 700), (699, 1399), (1, 2), (255, 1025), (1398, 2100)])
+def test_exec_shard_rows_and_witnesses_match_the_oracle_slice(a, b):
+    """zkir_exec_shard: any row range of a finished interpretation as its own device trace — rows (absolute cycles), memory ops and
+    SHA witnesses of the shard equal the oracle's for those rows."""
+    blob = spec.sha256_chain_program().to_bytes()
+    cfg = rt.VMConfig(max_cycles=2100, enable_execution_trace=True)
+    log = rt.interpret(blob, [], cfg)
+    want = oracle.run(blob, [], max_cycles=2100, enable_execution_trace=True)
+    res = rt.exec_shard(log, a, b, blob, [], cfg)
+    assert len(res.execution_trace) == b - a and res.delta_log.cycle_base == a
+    helpers.assert_rows_equal(res.execution_trace.rows(), want.rows[a:b])
+    ops, offs = res.row_memory_ops()
+    lo, hi = int(want.row_memop_offsets[a]), int(want.row_memop_offsets[b])
+    assert np.array_equal(ops, want.memops[lo:hi]) and np.array_equal(offs, want.row_memop_offsets[a:b + 1] - want.row_memop_offsets[a])
+    res.close(); log.close()

@@ -585,6 +585,19 @@ class VM:
         return ExecutionResult(out.value, log, self._blob, self._inputs, self._config)
 
 
+def exec_shard(log: "DeltaLog", row_begin: int, row_end: int, blob: bytes = b"", inputs: Sequence[int] = (), config: Optional[VMConfig] = None) -> ExecutionResult:
+    """zkir_exec_shard: the drop-in handle for rows [row_begin, row_end) of a finished interpretation, cut out, uploaded to the current
+    device and filled there (multi-GPU: one call per device; segment proofs: ranges that share one row)."""
+    L = lib()
+    L.zkir_exec_shard.restype = C.c_int
+    L.zkir_exec_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+    out = C.c_void_p()
+    rc = L.zkir_exec_shard(log._h, int(row_begin), int(row_end), C.byref(out))
+    if rc != ZKIR_OK:
+        _raise(rc)
+    return ExecutionResult(out.value, DeltaLog(L.zkir_result_delta_log(out.value), owned=False), blob, inputs, config)
+
+
 def run(program: Program | bytes, inputs: Sequence[int] = ()) -> List[int]:
     """zkir_runtime::run (lib.rs:59-62): default config, outputs only."""
     res = VM(program, inputs, VMConfig()).run()
