@@ -137,11 +137,11 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
     return kernels
 
 
-def _config2_fib_2p24(lib, sp):
-    """BASELINE configs[2]: 2^24-cycle fib on one GPU — commit step stages + full proof, measured with HIP events."""
+def _config2_fib_2p24(lib, sp, k=24):
+    """BASELINE configs[2]: 2^24-cycle fib on one GPU — commit step stages + full proof, measured with HIP events.  k = 26: the 2^26
+    rows of configs[3] (there row-sharded over 8 GPUs) on ONE device — 25 GB of trace, 122 GB of field matrices, all resident in HBM."""
     import torch
     from zkir_amd import pipeline as pl, runtime as rt, spec, stark
-    k = 24
     n = 1 << k
     W = stark.W_MAIN
     blob = spec.fib_endless_program().to_bytes()
@@ -159,7 +159,7 @@ def _config2_fib_2p24(lib, sp):
               ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
     for _, f in stages:
         f()
-    stage_ms = {name: _hip_time(f, reps=3, warm=0) for name, f in stages}
+    stage_ms = {name: _hip_time(f, reps=3 if k <= 24 else 2, warm=0) for name, f in stages}
     for _, f in stages:                               # the LDE uses its input as scratch: one more pass in order, so the root is that of the trace
         f()
     root = tree[-4:].cpu().numpy().view("uint32").tolist()
@@ -175,10 +175,10 @@ def _config2_fib_2p24(lib, sp):
     t0 = time.perf_counter()
     verdict = rt.verify(proof, pub)
     verify_ms = (time.perf_counter() - t0) * 1e3
-    assert verdict == 0, f"bench: the 2^24-row proof was rejected (check {verdict})"
+    assert verdict == 0, f"bench: the 2^{k}-row proof was rejected (check {verdict})"
     step_ms = sum(stage_ms.values())
-    out = {"workload": "fib_endless 2^24 cycles, 1 GPU: trace fill + main trace + LDE + Poseidon2 Merkle (commit step), then the full proof "
-                       "(AIR quotient, openings, DEEP, FRI, queries)",
+    out = {"workload": f"fib_endless 2^{k} cycles, 1 GPU: trace fill + main trace + LDE + Poseidon2 Merkle (commit step), then the full proof "
+                       "(AIR quotient, openings, DEEP, FRI, queries)" + ("; the row count of configs[3] (2^26, there over 8 GPUs) on ONE device" if k == 26 else ""),
            "rows": n, "commit_step_ms": step_ms, "commit_rows_per_s": n / (step_ms * 1e-3), "stage_ms": stage_ms, "roofline_by_stage": kernels,
            "prove_ms": prove_ms, "prove_stage_ms": dict(zip(PROVE_STAGES, pms)), "prove_rows_per_s": n / (prove_ms * 1e-3),
            "proof_bytes": int(len(proof) * 4), "verify_ms_host": verify_ms, "merkle_root": root, "proof_trace_root_matches_commit": proof[157:161].tolist() == root,
@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--no-prove", action="store_true", help="skip the end-to-end proof / pipelined sections that follow the timed region "
                     "(profiling runs: keeps the rocprofv3 per-kernel averages to the kernels of the timed steps)")
     ap.add_argument("--no-by-config", action="store_true", help="skip the configs[2] / configs[4] sections (profiling runs)")
-    ap.add_argument("--only-config", choices=["2", "4"], default=None, help="run only that by_config section and print it (profiling runs)")
+    ap.add_argument("--only-config", choices=["2", "3", "4"], default=None, help="run only that by_config section and print it (profiling runs; 3 = 2^26 rows on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -314,7 +314,8 @@ def main():
     sp = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
     if args.only_config:
         torch.zeros(1 << 20, device="cuda").sum().item()
-        print(json.dumps({"by_config": {f"configs[{args.only_config}]": (_config2_fib_2p24 if args.only_config == "2" else _config4_sha_2p22)(lib, sp)}}))
+        fn = {"2": lambda: _config2_fib_2p24(lib, sp), "3": lambda: _config2_fib_2p24(lib, sp, 26), "4": lambda: _config4_sha_2p22(lib, sp)}[args.only_config]
+        print(json.dumps({"by_config": {("configs[3] on one GPU" if args.only_config == "3" else f"configs[{args.only_config}]"): fn()}}))
         return
 
     k = args.log2_rows if args.log2_rows is not None else (20 if world == 1 else 23)
@@ -596,6 +597,12 @@ def main():
         del trace, ddl, fill_args
         torch.cuda.empty_cache()
         by_config = {"configs[2]": _config2_fib_2p24(lib, sp), "configs[4]": _config4_sha_2p22(lib, sp)}
+        try:                                           # 2^26 rows need ~185 GB of HBM: reported when the device has them, never fatal
+            if torch.cuda.mem_get_info()[1] >= 250 * (1 << 30):
+                by_config["configs[3] on one GPU"] = _config2_fib_2p24(lib, sp, 26)
+        except Exception as e:
+            by_config["configs[3] on one GPU"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3

@@ -29,15 +29,28 @@ def test_config2_fib_2p24_trace_commit_proof():
     """configs[2]: 2^24-cycle fib — trace rows vs the oracle on sampled windows, loop semantics on ALL rows, commitment root
     reproduced from sampled Merkle paths + the LDE checked against the trace polynomial, and the full proof accepted by the
     oracle verifier."""
+    _fib_full_size(24, _windows(1 << 24))
+
+
+def test_config3_row_count_2p26_on_one_gpu():
+    """The 2^26 rows of configs[3] (there row-sharded over 8 GPUs) on ONE device: 25 GB of trace and 122 GB of field matrices resident
+    in HBM; the same checks as at 2^24 (two oracle windows: each costs one 2^26-cycle oracle run)."""
+    import torch
+    if torch.cuda.mem_get_info()[1] < 250 * (1 << 30):
+        pytest.skip("needs ~185 GB of HBM")
+    n = 1 << 26
+    _fib_full_size(26, [(0, 256), (n - 300, n)])
+
+
+def _fib_full_size(k, windows):
     import torch
     from zkir_amd import pipeline as pl, stark
-    k = 24
     n = 1 << k
     blob = spec.fib_endless_program().to_bytes()
     res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run()          # zkir_exec: interpret + H2D + K1
     assert res.cycles == n and res.halt_reason == rt.HaltReason.CycleLimit() and len(res.execution_trace) == n
     tr = res.execution_trace
-    for lo, hi in _windows(n):
+    for lo, hi in windows:
         want = oracle.run(blob, max_cycles=n, enable_execution_trace=True, keep_rows=(lo, hi))
         assert want.cycles == n
         helpers.assert_rows_equal(tr.rows_window(lo, hi), want.rows)
@@ -80,7 +93,7 @@ def test_config2_fib_2p24_trace_commit_proof():
     assert np.array_equal(cols_m[0], np.arange(n, dtype=np.uint64) % P)           # cycle column of the main trace
     assert np.array_equal(cols_m[21], (tr.column(rt.FIELD_REGISTERS, 4) & np.uint64(0xFFFFF)).astype(np.uint32))
     from test_gpu_stark import _bary_eval
-    rng = np.random.default_rng(24)
+    rng = np.random.default_rng(k)
     for c in (0, 21):                                             # the LDE is the extension of the trace column: same value at a random point
         z = int(rng.integers(2, P))
         assert _bary_eval(cols_m[c], k, 1, z) == _bary_eval(L[c // 8, :, c % 8].cpu().numpy().view(np.uint32), k + 1, 31, z), c
@@ -96,7 +109,7 @@ def test_config2_fib_2p24_trace_commit_proof():
     del m, L, tree
     torch.cuda.empty_cache()
 
-    # ---- full proof of the 2^24-row run, accepted by the oracle verifier; its trace root is the commitment above ----
+    # ---- full proof of the 2^k-row run, accepted by the oracle verifier; its trace root is the commitment above ----
     pub = res.public_inputs()
     proof = stark.prove(ctx, trace_c, pub)
     assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0                   # the product's verifier and the oracle's
