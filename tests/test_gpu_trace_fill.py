@@ -179,3 +179,34 @@ def test_exec_shard_rows_and_witnesses_match_the_oracle_slice(a, b):
     lo, hi = int(want.row_memop_offsets[a]), int(want.row_memop_offsets[b])
     assert np.array_equal(ops, want.memops[lo:hi]) and np.array_equal(offs, want.row_memop_offsets[a:b + 1] - want.row_memop_offsets[a])
     res.close(); log.close()
+
+
+def test_concurrent_zkir_exec_calls_from_several_threads():
+    """The ABI is re-entrant: several host threads run zkir_exec at once (each streaming call has its own helper thread and a pooled
+    upload stream; the log blocks come from a shared pool) — every result is the oracle's, bit for bit."""
+    import threading
+    jobs = [(spec.fib_endless_program().to_bytes(), dict(max_cycles=(1 << 17) + 11 * i)) for i in range(4)]
+    jobs += [(spec.sha256_chain_program().to_bytes(), dict(max_cycles=150_000)), (spec.fib_program(2000).to_bytes(), {})]
+    want = [oracle.run(b, [], enable_execution_trace=True, **kw) for b, kw in jobs]
+    got, errs = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            b, kw = jobs[i]
+            for _ in range(3):
+                res = rt.VM(b, [], rt.VMConfig(enable_execution_trace=True, **kw)).run()
+                rows = res.execution_trace.rows()
+                outs, cyc = list(res.outputs), res.cycles
+                res.close()
+            got[i] = (rows, outs, cyc)
+        except BaseException as e:                         # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for (rows, outs, cyc), w in zip(got, want):
+        assert cyc == w.cycles and outs == list(w.outputs)
+        helpers.assert_rows_equal(rows, w.rows)
