@@ -282,8 +282,8 @@ def _cpu_baseline(blob, k, commit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-rows", type=int, default=None, help="rows per GPU = 2^k (default: 20 = BASELINE configs[1] at N=1; 23 = configs[3]'s "
                     "per-GPU share, 2^26 rows over 8 GPUs, at N>1)")
     ap.add_argument("--tile-rows", type=int, default=0)
