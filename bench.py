@@ -218,7 +218,8 @@ def _config4_sha_2p22(lib, sp):
     rows_c, sort_c = pl.MemopColumns(n_ops, dev), pl.MemopColumns(n_ops, dev)
     offs = torch.empty(n + 1, dtype=torch.int64, device=dev); scratch = torch.empty(n, dtype=torch.uint8, device=dev)
     blk = pl._to_dev(log.sha_blocks, dev)
-    out = torch.empty((608, n_blk), dtype=torch.int32, device=dev); ts = torch.empty(n_blk, dtype=torch.int64, device=dev)
+    sha_stride = (n_blk + 63) // 64 * 64                      # a multiple of 4: the 16-byte-store chip kernel
+    out = torch.empty((608, sha_stride), dtype=torch.int32, device=dev); ts = torch.empty(n_blk, dtype=torch.int64, device=dev)
     kern = {}
 
     def rec(name, f, nbytes, note=None):
@@ -233,7 +234,7 @@ def _config4_sha_2p22(lib, sp):
     rec("memops_expand", lambda: pl._check(lib.zkir_memops_expand_launch(ev.data_ptr(), n_ops, 0, C.byref(rows_c.c), sp())), (24 + 39) * n_ops)
     rec("memops_sort", lambda: pl._check(lib.zkir_memops_sort_launch(ev.data_ptr(), n_ops, n, 0, offs.data_ptr(), scratch.data_ptr(), C.byref(sort_c.c), sp())),
         (24 * 2 + 39) * n_ops + n, "= ExecutionResult::get_memory_trace(): rank in a two-run merge per row")
-    rec("sha256_chip", lambda: pl._check(lib.zkir_sha256_chip_launch(blk.data_ptr(), n_blk, out.data_ptr(), n_blk, ts.data_ptr(), sp())), (72 + 2432 + 8) * n_blk)
+    rec("sha256_chip", lambda: pl._check(lib.zkir_sha256_chip_launch(blk.data_ptr(), n_blk, out.data_ptr(), sha_stride, ts.data_ptr(), sp())), (72 + 2432 + 8) * n_blk)
     o = out[:, [0, n_blk // 2, n_blk - 1]].cpu().numpy().view(np.uint32)       # parity spot-check outside the timings: digests vs hashlib
     for col, idx in enumerate([0, n_blk // 2, n_blk - 1]):
         msg = log.sha_blocks[idx]["message_block"].astype(">u4").tobytes()[:32]

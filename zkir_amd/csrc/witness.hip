@@ -11,6 +11,8 @@
 //   sha256_chip   Sha256Witness per single-block message, zkir-runtime/src/crypto.rs:142-207,223-297; trace.rs:236-256
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/zkir_amd.h"
 #include "host.h"
 
@@ -68,9 +70,49 @@ __device__ __forceinline__ bool memop_before(const zkir_mem_event& a, uint64_t i
   return ia < ib;                                                // stable
 }
 
+// One lane per op.  The rank of an op inside its row's segment takes three binary searches over the segment (first write; position
+// of the op's address in the other run): ~11 DEPENDENT loads.  Done on global memory that was the whole cost of the kernel (0.8 ms
+// against 0.3 ms for the same bytes in row order).  A workgroup therefore first copies the keys (address, is_write) of every segment
+// its 256 ops touch into LDS — ops of a row are contiguous, so that is its own 256 ops plus the rest of the first and last segment —
+// and searches there; a range that does not fit (a hash over kilobytes of input) keeps the global path.
+constexpr uint32_t SORT_CAP = 2048;
+struct GlobalKeys {
+  const zkir_mem_event* ev;
+  __device__ __forceinline__ uint64_t address(uint64_t i) const { return ev[i].address; }
+  __device__ __forceinline__ bool is_write(uint64_t i) const { return ev[i].is_write != 0; }
+};
+struct LdsKeys {
+  const uint64_t* addr; const unsigned char* wr; uint64_t base;
+  __device__ __forceinline__ uint64_t address(uint64_t i) const { return addr[i - base]; }
+  __device__ __forceinline__ bool is_write(uint64_t i) const { return wr[i - base] != 0; }
+};
+template <class Keys>
+__device__ __forceinline__ uint64_t merge_rank(const Keys& k, uint64_t i, uint64_t s, uint64_t t, uint64_t address, bool is_write) {
+  uint64_t lo = s, hi = t;                                       // first write in the segment
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (k.is_write(mid)) hi = mid; else lo = mid + 1; }
+  const uint64_t w0 = lo;
+  if (!is_write) {                                               // reads precede writes at equal address: count writes strictly below
+    uint64_t a = w0, b = t;
+    while (a < b) { const uint64_t mid = (a + b) >> 1; if (k.address(mid) < address) a = mid + 1; else b = mid; }
+    return (i - s) + (a - w0);
+  }
+  uint64_t a = s, b = w0;                                        // count reads at or below
+  while (a < b) { const uint64_t mid = (a + b) >> 1; if (k.address(mid) <= address) a = mid + 1; else b = mid; }
+  return (i - w0) + (a - s);
+}
+
 __global__ __launch_bounds__(NT) void memops_sort_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, uint64_t cycle_base,
                                                           const uint64_t* __restrict__ offsets, const unsigned char* __restrict__ seg_bad, zkir_memop_columns c) {
-  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  __shared__ uint64_t s_addr[SORT_CAP];
+  __shared__ unsigned char s_wr[SORT_CAP];
+  const uint64_t b0 = (uint64_t)blockIdx.x * NT, b1 = b0 + NT < n ? b0 + NT : n;        // this workgroup's ops
+  const uint64_t lo = offsets[ev[b0].row], hi = offsets[(uint64_t)ev[b1 - 1].row + 1];    // every segment they belong to (uniform)
+  const bool in_lds = hi - lo <= SORT_CAP;
+  if (in_lds) {
+    for (uint64_t j = lo + threadIdx.x; j < hi; j += NT) { const zkir_mem_event e = ev[j]; s_addr[j - lo] = e.address; s_wr[j - lo] = e.is_write; }
+    __syncthreads();
+  }
+  const uint64_t i = b0 + threadIdx.x;
   if (i >= n) return;
   const zkir_mem_event e = ev[i];
   const uint64_t s = offsets[e.row], t = offsets[(uint64_t)e.row + 1];
@@ -78,18 +120,7 @@ __global__ __launch_bounds__(NT) void memops_sort_kernel(const zkir_mem_event* _
   if (t - s == 1) {
     rank = 0;
   } else if (!seg_bad[e.row]) {
-    uint64_t lo = s, hi = t;                                     // nR: first write in the segment
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ev[mid].is_write) hi = mid; else lo = mid + 1; }
-    const uint64_t w0 = lo;
-    if (!e.is_write) {                                           // reads precede writes at equal address: count writes strictly below
-      uint64_t a = w0, b = t;
-      while (a < b) { const uint64_t mid = (a + b) >> 1; if (ev[mid].address < e.address) a = mid + 1; else b = mid; }
-      rank = (i - s) + (a - w0);
-    } else {                                                     // count reads at or below
-      uint64_t a = s, b = w0;
-      while (a < b) { const uint64_t mid = (a + b) >> 1; if (ev[mid].address <= e.address) a = mid + 1; else b = mid; }
-      rank = (i - w0) + (a - s);
-    }
+    rank = in_lds ? merge_rank(LdsKeys{s_addr, s_wr, lo}, i, s, t, e.address, e.is_write != 0) : merge_rank(GlobalKeys{ev}, i, s, t, e.address, e.is_write != 0);
   } else {
     rank = 0;
     for (uint64_t j = s; j < t; j++) rank += memop_before(ev[j], j, e, i) ? 1 : 0;
@@ -187,6 +218,68 @@ __global__ __launch_bounds__(NT) void sha256_chip_kernel(const zkir_sha_block* _
   o[4 * stride] = H0[4] + e; o[5 * stride] = H0[5] + f; o[6 * stride] = H0[6] + g; o[7 * stride] = H0[7] + h;
 }
 
+template <int K, int N, class F>
+__device__ __forceinline__ void sha_static_for(F&& f) {
+  if constexpr (K < N) { f(std::integral_constant<int, K>{}); sha_static_for<K + 1, N>(f); }
+}
+
+// The same with FOUR consecutive blocks per lane: every column store is one 16-byte non-temporal store per lane (1 KiB per wave
+// instruction instead of 256 B) — the kernel is a pure HBM writer (2432 B out per 72 B in) and 4-byte stores left it at 3-4 TB/s.
+// Needs stride % 4 == 0 and a 16-byte aligned `out`; the last lane of a ragged tail falls back to scalar stores for its blocks.
+__global__ __launch_bounds__(NT) void sha256_chip_x4_kernel(const zkir_sha_block* __restrict__ blocks, uint64_t n, uint32_t* __restrict__ out, uint64_t stride,
+                                                             uint64_t* __restrict__ timestamps) {
+  using v4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * NT + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const int cnt = n - i0 >= 4 ? 4 : (int)(n - i0);
+  auto put = [&](uint64_t col, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    uint32_t* p = out + col * stride + i0;
+    if (cnt == 4) { v4 v = {v0, v1, v2, v3}; __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p)); }
+    else { p[0] = v0; if (cnt > 1) p[1] = v1; if (cnt > 2) p[2] = v2; }
+  };
+  uint32_t w[4][16];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint64_t i = i0 + (q < cnt ? q : 0);                                 // lanes of a ragged tail re-read block i0: values unused
+    const uint2* src = reinterpret_cast<const uint2*>(blocks + i);             // 72-byte records: 8-byte aligned
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint2 v = src[k]; w[q][2 * k] = v.x; w[q][2 * k + 1] = v.y; }
+    if (timestamps && q < cnt) timestamps[i0 + q] = blocks[i0 + q].timestamp;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) put(k, w[0][k], w[1][k], w[2][k], w[3][k]);
+  const uint32_t H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+#pragma unroll
+  for (int k = 0; k < 8; k++) put(16 + k, H0[k], H0[k], H0[k], H0[k]);
+  uint32_t st[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[q][k] = H0[k];
+  sha_static_for<0, 64>([&](auto tc) {                          // compile-time round index: w[][] and st[][] stay in registers
+    constexpr int t = decltype(tc)::value;
+    uint32_t wt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (t < 16) wt[q] = w[q][t];
+      else {
+        const uint32_t w15 = w[q][(t + 1) & 15], w2 = w[q][(t + 14) & 15];
+        wt[q] = (rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10)) + w[q][(t + 9) & 15] + (rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3)) + w[q][t & 15];
+        w[q][t & 15] = wt[q];
+      }
+      const uint32_t a = st[q][0], b = st[q][1], c = st[q][2], d = st[q][3], e = st[q][4], f = st[q][5], g = st[q][6], h = st[q][7];
+      const uint32_t t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[t] + wt[q];
+      const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      st[q][7] = g; st[q][6] = f; st[q][5] = e; st[q][4] = d + t1; st[q][3] = c; st[q][2] = b; st[q][1] = a; st[q][0] = t1 + t2;
+    }
+    put(24 + t, wt[0], wt[1], wt[2], wt[3]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) put(88 + 8 * t + k, st[0][k], st[1][k], st[2][k], st[3][k]);
+  });
+#pragma unroll
+  for (int k = 0; k < 8; k++) put(600 + k, H0[k] + st[0][k], H0[k] + st[1][k], H0[k] + st[2][k], H0[k] + st[3][k]);
+}
+
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
@@ -240,7 +333,10 @@ int zkir_norm_expand_launch(const zkir_norm_event* ev, uint64_t n, const zkir_no
 int zkir_sha256_chip_launch(const zkir_sha_block* blocks, uint64_t n, uint32_t* out, uint64_t stride, uint64_t* timestamps, void* stream) {
   if (n == 0) return ZKIR_OK;
   if (stride < n) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "sha256_chip: stride < n"}); return ZKIR_ERR_ARGUMENT; }
-  hipLaunchKernelGGL(sha256_chip_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, blocks, n, out, stride, timestamps);
+  if (stride % 4 == 0 && ((uintptr_t)out & 15) == 0)           // 16-byte column stores, four blocks per lane
+    hipLaunchKernelGGL(sha256_chip_x4_kernel, dim3(grid_for((n + 3) / 4)), dim3(NT), 0, (hipStream_t)stream, blocks, n, out, stride, timestamps);
+  else
+    hipLaunchKernelGGL(sha256_chip_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, blocks, n, out, stride, timestamps);
   return check_launch("sha256_chip");
 }
 

@@ -244,8 +244,9 @@ def sha256_chip(blocks: np.ndarray, device=None, stream=None):
     s = stream or torch.cuda.current_stream()
     with torch.cuda.stream(s):
         ev = _to_dev(blocks, device)
-        out = torch.empty((608, max(n, 1)), dtype=torch.int32, device=device)
+        stride = (max(n, 1) + 63) // 64 * 64              # a multiple of 4 selects the 16-byte-store kernel
+        out = torch.empty((608, stride), dtype=torch.int32, device=device)
         ts = torch.empty(max(n, 1), dtype=torch.int64, device=device)
-        _check(rt.lib().zkir_sha256_chip_launch(ev.data_ptr(), n, out.data_ptr(), max(n, 1), ts.data_ptr(), _stream_ptr(s)))
+        _check(rt.lib().zkir_sha256_chip_launch(ev.data_ptr(), n, out.data_ptr(), stride, ts.data_ptr(), _stream_ptr(s)))
         s.synchronize()
     return out[:, :n], ts[:n]
