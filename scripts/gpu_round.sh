@@ -40,4 +40,10 @@ pmc)
   python $R/scripts/extract_prof.py $OUT $OUT/${TAG}_bench_commit trace_fill main_trace lde_middle ntt_strided leaf_hash compress subtree | cut -c1-150
   python $R/scripts/extract_valu.py $OUT/pmc_valu $OUT/${TAG}_bench_commit_valu_busy.txt
   rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_valu;;
+pmc4)   # HBM traffic of the configs[4] witness kernels (SHA chain, 2^22 cycles): separate counter passes, --kernel-trace only
+  export ZKIR_EXEC_STREAM=0
+  for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed 's/_size//');
+    timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$d -o b -- python $R/bench.py --only-config 4 > $OUT/pmc4_$d.log 2>&1; done
+  python $R/scripts/extract_prof.py $OUT $OUT/${TAG}_config4 trace_fill memops_expand memops_sort memops_row_offsets memops_segment sha256_chip | cut -c1-150
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write;;
 esac; done
