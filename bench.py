@@ -123,7 +123,12 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
         #   merkle: reads the LDE matrix once, writes 16 B per node; ALU-bound (Poseidon2), bytes given for completeness
         n_inv = _strided_passes(max(k - 10, 0))
         kernels["main_trace"] = {"bound": "hbm", "bytes": (164 + 4 * W) * n, "ms": stage_ms["main_trace"]}
-        kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"]}
+        kernels["lde"] = {"bound": "hbm", "bytes": W * n * (8 * n_inv + 12 + 16 * n_inv), "ms": stage_ms["lde"],
+                          # the other floor under this stage: a radix-2 butterfly of 31-bit Montgomery arithmetic costs ~33 SIMD-cycles
+                          # per wave64 on gfx950 (profiles/r02_ubench_alu.txt); a column of n rows has 30 n butterflies (inverse over n, forward over 2n)
+                          "valu_floor_ms": W * n * 30 * 33.0 / 64 / (1024 * 2.4e9) * 1e3,
+                          "note": "HBM traffic equals the algorithmic bytes (PMC); the stage sits on a VALU-issue floor of 31-bit modular butterflies about as high as its "
+                                  "HBM floor at the 5 TB/s a copy reaches: see valu_floor_ms"}
         perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
         modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
         modmul = perms * MONT_MUL_PER_PERM / (stage_ms["merkle"] * 1e-3)
