@@ -909,8 +909,13 @@ static bool program_from_bytes(const uint8_t* b, size_t len, Program& p, Error& 
   p.entry_point = rd32(b + 12); p.code_size = rd32(b + 16); p.data_size = rd32(b + 20); p.bss_size = rd32(b + 24); p.stack_size = rd32(b + 28);
   if (p.magic != 0x52494B5Au) { snprintf(m, sizeof m, "Invalid program magic: expected 0x5A4B4952, got %#010x", p.magic); err = {E_BAD_PROGRAM, m}; return false; }
   if (p.version != 0x00030004u) { snprintf(m, sizeof m, "Invalid program version: expected 0x00030004, found %#010x", p.version); err = {E_BAD_PROGRAM, m}; return false; }
-  if (p.cfg.limb_bits < 16 || p.cfg.limb_bits > 30 || p.cfg.limb_bits % 2 != 0 || p.cfg.data_limbs < 1 || p.cfg.data_limbs > 4 || p.cfg.addr_limbs < 1 ||
-      p.cfg.addr_limbs > 2) { err = {E_BAD_PROGRAM, "Invalid configuration"}; return false; }                      // config.rs:154-174
+  // Config::validate (config.rs:154-174) in its order; ZkIrError::InvalidConfig displays "Invalid configuration: {ConfigError}" (error.rs:9,
+  // config.rs:215-231)
+  const char* cfg_err = (p.cfg.limb_bits < 16 || p.cfg.limb_bits > 30) ? "limb_bits must be in range [16, 30]"
+                        : (p.cfg.limb_bits % 2 != 0)                  ? "limb_bits must be even"
+                        : (p.cfg.data_limbs < 1 || p.cfg.data_limbs > 4) ? "data_limbs must be in range [1, 4]"
+                        : (p.cfg.addr_limbs < 1 || p.cfg.addr_limbs > 2) ? "addr_limbs must be in range [1, 2]" : nullptr;
+  if (cfg_err) { err = {E_BAD_PROGRAM, std::string("Invalid configuration: ") + cfg_err}; return false; }
   size_t code_end = 32 + (size_t)p.code_size, data_end = code_end + (size_t)p.data_size;
   if (len < data_end) { snprintf(m, sizeof m, "Invalid program size: expected %zu bytes, found %zu bytes", data_end, len); err = {E_BAD_PROGRAM, m}; return false; }
   p.code.clear();

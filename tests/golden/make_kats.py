@@ -174,6 +174,19 @@ kats = {
     "program_blob": {"magic_bytes_hex": "5a4b4952", "version": 0x00030004, "default_limb_bits": 20, "default_data_limbs": 2, "default_addr_limbs": 2,
                      "roundtrip": {"code": [0x12345678, 0xABCDEF01], "data_hex": "01020304"}, "cite": "zkir-spec/src/program.rs:408-457"},
     "edge_immediates": {"min": -65536, "max": 65535, "cite": "tests/cross_module.rs:229-256"},
+    # Program::from_bytes on a default program whose header byte(s) at `offset` are replaced: the Display text of the ZkIrError
+    # (zkir-spec/src/error.rs:9-29 with ConfigError's Display, config.rs:215-231; checks in the order of program.rs:147-167, config.rs:154-174)
+    "blob_errors": [
+        {"offset": 0, "bytes_hex": "00000000", "message": "Invalid program magic: expected 0x5A4B4952, got 0x00000000", "cite": "zkir-spec/src/error.rs:13"},
+        {"offset": 4, "bytes_hex": "03000300", "message": "Invalid program version: expected 0x00030004, found 0x00030003", "cite": "zkir-spec/src/error.rs:16"},
+        {"offset": 8, "bytes_hex": "0f", "message": "Invalid configuration: limb_bits must be in range [16, 30]", "cite": "zkir-spec/src/config.rs:156-158,218-220"},
+        {"offset": 8, "bytes_hex": "20", "message": "Invalid configuration: limb_bits must be in range [16, 30]", "cite": "zkir-spec/src/config.rs:156-158"},
+        {"offset": 8, "bytes_hex": "15", "message": "Invalid configuration: limb_bits must be even", "cite": "zkir-spec/src/config.rs:159-161,221-223"},
+        {"offset": 9, "bytes_hex": "00", "message": "Invalid configuration: data_limbs must be in range [1, 4]", "cite": "zkir-spec/src/config.rs:164-166,224-226"},
+        {"offset": 9, "bytes_hex": "05", "message": "Invalid configuration: data_limbs must be in range [1, 4]", "cite": "zkir-spec/src/config.rs:164-166"},
+        {"offset": 10, "bytes_hex": "03", "message": "Invalid configuration: addr_limbs must be in range [1, 2]", "cite": "zkir-spec/src/config.rs:169-171,227-229"},
+    ],
+    "blob_truncated": {"keep": 31, "message": "Invalid header size: expected 32 bytes, found 31 bytes", "cite": "zkir-spec/src/error.rs:19; program.rs:189-194"},
 }
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")

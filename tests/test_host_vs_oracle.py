@@ -152,3 +152,51 @@ def test_fib_2p16_faithful_equals_linear():
     assert np.array_equal(a.rows, b.rows)
     # bounds never tighten in this loop: max_bits of r1/r2/r4 only grow
     assert (np.diff(b.rows["bound_bits"][8:, 4].astype(np.int64)) >= 0).all() and b.rows["bound_bits"][-1, 4] > 40
+
+
+def test_program_blob_validation_matches_the_oracle_on_mutated_headers():
+    """ProgramHeader::from_bytes / validate and Program::from_bytes (zkir-spec/src/program.rs:147-214, :318-346): every header field
+    pushed off its valid range, every kind of truncation, and 300 random single-byte corruptions of a valid blob — the product's
+    loader gives the oracle's verdict: the same code and the same message, or the same run."""
+    good = bytearray(spec.fib_program(7).to_bytes())
+
+    def same(blob):
+        blob = bytes(blob)
+        try:
+            want = oracle.run(blob, [], max_cycles=2000, enable_execution_trace=True)
+        except oracle.OracleError as e:
+            with pytest.raises(rt.RuntimeError) as ei:
+                rt.interpret(blob, [], rt.VMConfig(max_cycles=2000, enable_execution_trace=True))
+            assert (ei.value.code, ei.value.message) == (e.code, e.msg), (blob[:32].hex(), ei.value.message, e.msg)
+            return e.code
+        log = rt.interpret(blob, [], rt.VMConfig(max_cycles=2000, enable_execution_trace=True))
+        assert log.cycles == want.cycles and list(log.outputs) == list(want.outputs)
+        return 0
+
+    assert same(good) == 0
+    def with_(off, val, width=1):
+        b = bytearray(good); b[off:off + width] = int(val).to_bytes(width, "little"); return b
+    rejected = 0
+    for b in [with_(0, 0x5A4B4953, 4), with_(4, 0x00030003, 4), with_(4, 0x00040000, 4)]:        # magic, version (program.rs:37,40,147-160)
+        rejected += same(b) == 7
+    for limb_bits in (0, 15, 17, 21, 31, 32, 255):                                                # config.rs:154-174
+        rejected += same(with_(8, limb_bits)) == 7
+    for data_limbs in (0, 5, 255):
+        rejected += same(with_(9, data_limbs)) == 7
+    for addr_limbs in (0, 3, 255):
+        rejected += same(with_(10, addr_limbs)) != 0
+    assert rejected >= 15
+    for limb_bits, data_limbs in ((16, 1), (18, 2), (30, 3), (24, 4)):                             # valid non-default configurations run the same on both sides
+        b = with_(8, limb_bits); b[9] = data_limbs
+        same(b)
+    for cut in (0, 1, 4, 31, 32, 33, len(good) - 1, len(good) - 4):                                # truncations
+        same(good[:cut])
+    same(good + b"\\x00" * 7)                                                                       # trailing bytes
+    for off, width in ((12, 4), (16, 4), (20, 4), (24, 4), (28, 4)):                               # entry point and the four section sizes: small and huge values
+        for val in (0, 1, 4, 0x1000, 0x1004, len(good), 0x7FFFFFFF, 0xFFFFFFFF):
+            same(with_(off, val, width))
+    rng = np.random.default_rng(99)
+    for _ in range(300):
+        b = bytearray(good)
+        b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        same(b)

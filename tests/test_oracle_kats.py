@@ -158,6 +158,19 @@ def test_program_blob_kats():
     assert r.code == q.code and r.data == q.data and r.header == q.header
 
 
+def test_blob_error_message_kats():
+    """The text a ZkIrError displays for a malformed blob (error.rs / config.rs literals) — oracle and product loader, word for word."""
+    good = Program().to_bytes()
+    cases = [(good[:k["offset"]] + bytes.fromhex(k["bytes_hex"]) + good[k["offset"] + len(k["bytes_hex"]) // 2:], k["message"]) for k in KATS["blob_errors"]]
+    cases.append((good[:KATS["blob_truncated"]["keep"]], KATS["blob_truncated"]["message"]))
+    for blob, msg in cases:
+        with pytest.raises(oracle.OracleError) as eo:
+            oracle.run(blob)
+        with pytest.raises(rt.RuntimeError) as ep:
+            rt.interpret(blob)
+        assert eo.value.code == ep.value.code == 7 and eo.value.msg == ep.value.message == msg, (eo.value.msg, ep.value.message, msg)
+
+
 def test_normalize_and_range_chunk_kats():
     """Drive the deferred model / range checker so the KAT limbs actually occur in a run."""
     from zkir_amd import spec

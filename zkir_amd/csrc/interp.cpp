@@ -200,10 +200,10 @@ Status parse_program(const uint8_t* b, size_t len, ProgramView& pv) {
   if (magic != 0x52494B5Au) { snprintf(m, sizeof m, "Invalid program magic: expected 0x5A4B4952, got %#010x", magic); return {ZKIR_ERR_BAD_PROGRAM, m}; }
   if (version != 0x00030004u) { snprintf(m, sizeof m, "Invalid program version: expected 0x00030004, found %#010x", version); return {ZKIR_ERR_BAD_PROGRAM, m}; }
   pv.limb_bits = b[8]; pv.data_limbs = b[9]; pv.addr_limbs = b[10];
-  if (pv.limb_bits < 16 || pv.limb_bits > 30) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: limb_bits must be in 16..=30"};
+  if (pv.limb_bits < 16 || pv.limb_bits > 30) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: limb_bits must be in range [16, 30]"};
   if (pv.limb_bits & 1) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: limb_bits must be even"};
-  if (pv.data_limbs < 1 || pv.data_limbs > 4) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: data_limbs must be in 1..=4"};
-  if (pv.addr_limbs < 1 || pv.addr_limbs > 2) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: addr_limbs must be in 1..=2"};
+  if (pv.data_limbs < 1 || pv.data_limbs > 4) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: data_limbs must be in range [1, 4]"};
+  if (pv.addr_limbs < 1 || pv.addr_limbs > 2) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: addr_limbs must be in range [1, 2]"};
   pv.entry_point = le32(b + 12);
   const uint64_t code_size = le32(b + 16), data_size = le32(b + 20);
   const uint64_t need = 32 + code_size + data_size;
