@@ -907,8 +907,8 @@ static bool program_from_bytes(const uint8_t* b, size_t len, Program& p, Error& 
   if (len < 32) { snprintf(m, sizeof m, "Invalid header size: expected 32 bytes, found %zu bytes", len); err = {E_BAD_PROGRAM, m}; return false; }
   p.magic = rd32(b); p.version = rd32(b + 4); p.cfg.limb_bits = b[8]; p.cfg.data_limbs = b[9]; p.cfg.addr_limbs = b[10]; p.flags = b[11];
   p.entry_point = rd32(b + 12); p.code_size = rd32(b + 16); p.data_size = rd32(b + 20); p.bss_size = rd32(b + 24); p.stack_size = rd32(b + 28);
-  if (p.magic != 0x52494B5Au) { snprintf(m, sizeof m, "Invalid program magic: expected 0x5A4B4952, got %#010x", p.magic); err = {E_BAD_PROGRAM, m}; return false; }
-  if (p.version != 0x00030004u) { snprintf(m, sizeof m, "Invalid program version: expected 0x00030004, found %#010x", p.version); err = {E_BAD_PROGRAM, m}; return false; }
+  if (p.magic != 0x52494B5Au) { snprintf(m, sizeof m, "Invalid program magic: expected 0x5A4B4952, got 0x%08x", p.magic); err = {E_BAD_PROGRAM, m}; return false; }
+  if (p.version != 0x00030004u) { snprintf(m, sizeof m, "Invalid program version: expected 0x00030004, found 0x%08x", p.version); err = {E_BAD_PROGRAM, m}; return false; }
   // Config::validate (config.rs:154-174) in its order; ZkIrError::InvalidConfig displays "Invalid configuration: {ConfigError}" (error.rs:9,
   // config.rs:215-231)
   const char* cfg_err = (p.cfg.limb_bits < 16 || p.cfg.limb_bits > 30) ? "limb_bits must be in range [16, 30]"

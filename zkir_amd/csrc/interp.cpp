@@ -197,8 +197,8 @@ Status parse_program(const uint8_t* b, size_t len, ProgramView& pv) {
   char m[160];
   if (len < 32) { snprintf(m, sizeof m, "Invalid header size: expected 32 bytes, found %zu bytes", len); return {ZKIR_ERR_BAD_PROGRAM, m}; }
   const uint32_t magic = le32(b), version = le32(b + 4);
-  if (magic != 0x52494B5Au) { snprintf(m, sizeof m, "Invalid program magic: expected 0x5A4B4952, got %#010x", magic); return {ZKIR_ERR_BAD_PROGRAM, m}; }
-  if (version != 0x00030004u) { snprintf(m, sizeof m, "Invalid program version: expected 0x00030004, found %#010x", version); return {ZKIR_ERR_BAD_PROGRAM, m}; }
+  if (magic != 0x52494B5Au) { snprintf(m, sizeof m, "Invalid program magic: expected 0x5A4B4952, got 0x%08x", magic); return {ZKIR_ERR_BAD_PROGRAM, m}; }
+  if (version != 0x00030004u) { snprintf(m, sizeof m, "Invalid program version: expected 0x00030004, found 0x%08x", version); return {ZKIR_ERR_BAD_PROGRAM, m}; }
   pv.limb_bits = b[8]; pv.data_limbs = b[9]; pv.addr_limbs = b[10];
   if (pv.limb_bits < 16 || pv.limb_bits > 30) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: limb_bits must be in range [16, 30]"};
   if (pv.limb_bits & 1) return {ZKIR_ERR_BAD_PROGRAM, "Invalid configuration: limb_bits must be even"};
