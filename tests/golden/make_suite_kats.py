@@ -106,14 +106,14 @@ case("sys_write_large", f"{S}:176-189", LI32(1, 0xFFFFFFFF) + WRITE(1) + EXIT(),
 case("sys_read_process_write", f"{S}:195-216", READ + [I("add", 1, 0, 10)] + READ + [I("add", 1, 1, 10)] + READ + [I("add", 1, 1, 10)] + WRITE(1) + EXIT(),
      inputs=[5, 10, 15], outputs=[30])
 case("sys_echo_five", f"{S}:218-240", (READ + WRITE(10)) * 5 + EXIT(), inputs=[1, 2, 3, 4, 5], outputs=[1, 2, 3, 4, 5])
-case("sys_invalid_999", f"{S}:246-258", LI(10, 999) + [EC], error=4)
-case("sys_invalid_7", f"{S}:260-272", LI(10, 7) + [EC], error=4)
+case("sys_invalid_999", f"{S}:246-258", LI(10, 999) + [EC], error=4, error_message="Invalid syscall: 999")           # Display: zkir-runtime/src/error.rs:23
+case("sys_invalid_7", f"{S}:260-272", LI(10, 7) + [EC], error=4, error_message="Invalid syscall: 7")
 case("sys_sha256_hello", f"{S}:278-318", SYS_BUF + BYTES_AT(1, 3, b"hello") + HASH(3, 1, 5, 2) + WRITE(10) + WRITE_WORDS(2, 4, 8) + EXIT(),
      outputs=[0] + SHA_HELLO)                                 # R10 = 0 after the call, then the eight words read back with read_u32
 case("sys_sha256_empty", f"{S}:320-353", SYS_BUF + HASH(3, 1, 0, 2) + WRITE(10) + WRITE_WORDS(2, 4, 8) + EXIT(), outputs=[0] + SHA_EMPTY)
 case("sys_keccak256_hello_returns_0", f"{S}:359-384", SYS_BUF + BYTES_AT(1, 3, b"hello") + HASH(5, 1, 5, 2) + WRITE(10) + EXIT(), outputs=[0])
 case("sys_blake3_hello_returns_0", f"{S}:390-415", SYS_BUF + BYTES_AT(1, 3, b"hello") + HASH(6, 1, 5, 2) + WRITE(10) + EXIT(), outputs=[0])
-case("sys_poseidon2_not_implemented", f"{S}:401-422", SYS_BUF + BYTES_AT(1, 3, bytes([1, 2, 3, 4])) + HASH(4, 1, 4, 2), error=6)
+case("sys_poseidon2_not_implemented", f"{S}:401-422", SYS_BUF + BYTES_AT(1, 3, bytes([1, 2, 3, 4])) + HASH(4, 1, 4, 2), error=6, error_message="Poseidon2 not yet implemented")
 case("sys_io_read_write_independent", f"{S}:441-457", LI(1, 999) + WRITE(1) + READ + [I("add", 5, 0, 10)] + LI(1, 888) + WRITE(1) + READ + [I("add", 6, 0, 10)] + LI(1, 777) + WRITE(1)
      + WRITE(5) + WRITE(6) + EXIT(), inputs=[100, 200], outputs=[999, 888, 777, 100, 200])
 
@@ -133,14 +133,15 @@ case("mem_word_rw", f"{M}:90-100", DATA_BASE_REG(1) + LI32(2, 0xDEADBEEF) + [I("
      + WRITE(3) + EXIT(), outputs=[0xDEADBEEF, 0xCAFEBABE])
 case("mem_little_endian", f"{M}:110-121", DATA_BASE_REG(1) + LI32(2, 0x04030201) + [I("sw", 1, 2, 0)] + sum([[I("lbu", 3, 1, i)] + WRITE(3) for i in range(4)], []) + EXIT(),
      outputs=[1, 2, 3, 4])
-case("mem_misaligned_sh", f"{M}:127-129", DATA_BASE_REG(1) + LI(2, 0x1234) + [I("sh", 1, 2, 1)], error=1)
+case("mem_misaligned_sh", f"{M}:127-129", DATA_BASE_REG(1) + LI(2, 0x1234) + [I("sh", 1, 2, 1)], error=1,
+     error_message="Misaligned access: address 0x100000001, alignment 2")                                   # Display: zkir-runtime/src/error.rs:14 ({address:#x})
 case("mem_misaligned_lh", f"{M}:130", DATA_BASE_REG(1) + [I("lhu", 3, 1, 1)], error=1)
 case("mem_misaligned_sw_1", f"{M}:133", DATA_BASE_REG(1) + [I("sw", 1, 2, 1)], error=1)
 case("mem_misaligned_sw_2", f"{M}:134", DATA_BASE_REG(1) + [I("sw", 1, 2, 2)], error=1)
-case("mem_misaligned_sw_3", f"{M}:135", DATA_BASE_REG(1) + [I("sw", 1, 2, 3)], error=1)
+case("mem_misaligned_sw_3", f"{M}:135", DATA_BASE_REG(1) + [I("sw", 1, 2, 3)], error=1, error_message="Misaligned access: address 0x100000003, alignment 4")
 case("mem_misaligned_lw", f"{M}:136", DATA_BASE_REG(1) + [I("lw", 3, 1, 1)], error=1)
 case("mem_misaligned_sd", f"{M}:139", DATA_BASE_REG(1) + [I("sd", 1, 2, 4)], error=1)
-case("mem_misaligned_ld", f"{M}:140", DATA_BASE_REG(1) + [I("ld", 3, 1, 4)], error=1)
+case("mem_misaligned_ld", f"{M}:140", DATA_BASE_REG(1) + [I("ld", 3, 1, 4)], error=1, error_message="Misaligned access: address 0x100000004, alignment 8")
 case("mem_uninitialized_reads_zero", f"{M}:143-151", DATA_BASE_REG(1) + LI(2, 1) + [I("slli", 2, 2, 16), I("add", 1, 1, 2)]
      + sum([[I(op, 3, 1, 0)] + WRITE(3) for op in ("lbu", "lhu", "lw", "ld")], []) + EXIT(), outputs=[0, 0, 0, 0])
 case("mem_sparse", f"{M}:153-169", DATA_BASE_REG(1) + LI32(2, 0xAAAA) + [I("sw", 1, 2, 0)] + LI(4, 1) + [I("slli", 4, 4, 20), I("add", 5, 1, 4)] + LI32(2, 0xBBBB) + [I("sw", 5, 2, 0)]
@@ -281,7 +282,7 @@ case("ex_branch_not_taken", f"{X2}:809-824", LI(1, 10) + LI(2, 20) + [I("beq", 1
 # JAL: rd = pc + 4 (the unit test: pc 0 -> R1 = 4, pc = 1000); here the JAL is word 0 at 0x1000 and jumps over one instruction
 case("ex_jal_link_and_target", f"{X2}:826-838", [I("jal", 1, 8)] + LI(3, 111) + WRITE(1) + WRITE(3) + EXIT(), outputs=[0x1004, 0])
 case("ex_ebreak", f"{X2}:840-848", [EB], halt=["Ebreak"], cycles=1)
-case("ex_division_by_zero", f"{X2}:850-867", LI(1, 100) + LI(2, 0) + [I("div", 3, 1, 2)], error=3)
+case("ex_division_by_zero", f"{X2}:850-867", LI(1, 100) + LI(2, 0) + [I("div", 3, 1, 2)], error=3, error_message="Division by zero at PC 0x1008")   # error.rs:20
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # tests/stress_tests.rs, tests/end_to_end.rs, tests/cross_module.rs — assembly sources (assembler aliases: zero = R0, t2 = R10,

@@ -34,14 +34,14 @@ def _run(p, impl):
         try:
             log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
         except rt.RuntimeError as e:
-            return e.code
+            return e.code, e.message
         return dict(cycles=log.cycles, outputs=list(log.outputs), halt=(log.halt_reason.kind, log.halt_reason.code), n_rows=log.n_rows,
                     memops=helpers.memops_from_log(log), n_rc_w=len(log.rc_offsets) - 1, rc_checks=helpers.rc_from_log(log), norm=helpers.norm_from_log(log),
                     rows=helpers.expand_delta_log(log) if log.n_rows else None)
     try:
         r = oracle.run(blob, inputs, **cfg)
     except oracle.OracleError as e:
-        return e.code
+        return e.code, e.msg
     return dict(cycles=r.cycles, outputs=list(r.outputs), halt=(r.halt_kind, r.halt_code if r.halt_kind == 1 else 0), n_rows=len(r.rows), memops=r.memops,
                 n_rc_w=len(r.rc_offsets) - 1, rc_checks=r.rc_checks, norm=r.norm_events, rows=r.rows)
 
@@ -58,9 +58,11 @@ def _witness_verifies(e):
 
 def _check(p, r):
     if "error" in p:
-        assert r == p["error"], r
+        assert isinstance(r, tuple) and r[0] == p["error"], r
+        if "error_message" in p:                              # the reference's Display text (zkir-runtime/src/error.rs)
+            assert r[1] == p["error_message"], r
         return
-    assert isinstance(r, dict), f"run failed with error code {r}"
+    assert isinstance(r, dict), f"run failed with error {r}"
     if "outputs" in p:
         assert r["outputs"] == p["outputs"]
     if "cycles" in p:
