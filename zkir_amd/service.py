@@ -19,6 +19,8 @@ import torch
 from . import pipeline as pl, runtime as rt, stark
 
 Job = Tuple[bytes, Sequence[int], rt.VMConfig]
+_spare_ctx: dict = {}                                         # log2_rows -> idle StarkContexts of the extra proving threads
+_spare_lock = threading.Lock()
 
 
 @dataclass
@@ -40,10 +42,12 @@ class PipelineReport:
 
 
 def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Optional[stark.StarkContext] = None,
-               keep_proofs: bool = True, commit_only: bool = False) -> PipelineReport:
+               keep_proofs: bool = True, commit_only: bool = False, provers: int = 2) -> PipelineReport:
     """Prove every job (program blob, inputs, VMConfig with enable_execution_trace; the run's row count must pad to 2^log2_rows,
     i.e. 2^(log2_rows-1) < rows <= 2^log2_rows).  Proofs come back in job order.  commit_only: stop after the trace commitment
-    (trace fill + main trace + LDE + Merkle); `proofs` then holds the 4-word roots."""
+    (trace fill + main trace + LDE + Merkle); `proofs` then holds the 4-word roots.
+    provers: a proof makes ~13 host round trips (Fiat-Shamir on the host) during which ITS stream is idle; with two proving threads,
+    each with its own context (workspace) and stream, the GPU works on one proof while the other waits for its transcript."""
     pl._require_gpu()
     jobs = list(jobs)
     own_ctx = ctx is None
@@ -94,15 +98,60 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
             if keep_proofs:
                 out[p[0]] = p[1].numpy().copy().view(np.uint32)
 
+    # ---- extra proving threads (full proofs only): each takes whole jobs off the queue, on its own context and stream ----
+    n_extra = 0 if commit_only else max(0, min(provers, len(jobs)) - 1)
+    claimed = [0]
+
+    def claim() -> bool:
+        with lock:
+            if claimed[0] >= len(jobs) or errors:
+                return False
+            claimed[0] += 1
+            return True
+
+    def prover_thread():
+        try:
+            with _spare_lock:                                 # contexts of the extra threads are kept between calls (tables + workspace)
+                my_ctx = _spare_ctx[log2_rows].pop() if _spare_ctx.get(log2_rows) else None
+            my_ctx = my_ctx or stark.StarkContext(log2_rows)
+            stream = torch.cuda.Stream()
+            try:
+                with torch.cuda.stream(stream):
+                    while claim():
+                        item = ready.get()
+                        if item is None:
+                            ready.put(None)                  # let the others see the failure too
+                            return
+                        idx, ddl, ev, h, u, pub, n_rows = item
+                        stream.wait_event(ev)
+                        tr = pl.DeviceTrace(ddl)
+                        pl.trace_fill(pl.trace_fill_args(ddl, tr))
+                        proof = stark.prove(my_ctx, tr, pub)
+                        with lock:
+                            rep.interpret_s += h; rep.upload_s += u; rep.rows += n_rows
+                            if keep_proofs:
+                                out[idx] = proof
+            finally:
+                with _spare_lock:
+                    _spare_ctx.setdefault(log2_rows, []).append(my_ctx)
+        except BaseException as e:                            # noqa: BLE001
+            with lock:
+                errors.append(e)
+
+    extra = [threading.Thread(target=prover_thread, daemon=True) for _ in range(n_extra)]
+    for t in extra:
+        t.start()
     try:
-        for _ in range(len(jobs)):
+        while claim():
             item = ready.get()
             if item is None:
+                ready.put(None)
                 raise errors[0]
             idx, ddl, ev, h, u, pub, n_rows = item
-            rep.interpret_s += h
-            rep.upload_s += u
-            rep.rows += n_rows
+            with lock:
+                rep.interpret_s += h
+                rep.upload_s += u
+                rep.rows += n_rows
             torch.cuda.current_stream().wait_event(ev)
             tr = pl.DeviceTrace(ddl)
             pl.trace_fill(pl.trace_fill_args(ddl, tr))
@@ -125,6 +174,10 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                     out[idx] = proof
         finish(pending)
         pending = None
+        for t in extra:
+            t.join()
+        if errors:
+            raise errors[0]
         torch.cuda.synchronize()
         rep.wall_s = time.perf_counter() - t0
     finally:
