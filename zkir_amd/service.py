@@ -90,6 +90,7 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
         t.start()
     pending = None                                        # commit_only: the previous run's (index, pinned root, event, its buffers)
     roots = [torch.empty(4, dtype=torch.int32, pin_memory=True) for _ in range(2)] if commit_only else []
+    commit_streams = [torch.cuda.Stream() for _ in range(2)] if commit_only else []
     idx_run = 0
 
     def finish(p):
@@ -152,26 +153,33 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                 rep.interpret_s += h
                 rep.upload_s += u
                 rep.rows += n_rows
+            if commit_only:
+                # The commitment needs nothing from the host: queue this run's kernels BEHIND the previous run's, and only then wait
+                # for the previous root (16 bytes into pinned memory) — the GPU goes from one run to the next without a gap.  Runs
+                # alternate between two streams, so the latency-bound tail of one tree (a few workgroups walking the top levels) shares
+                # the device with the bandwidth-bound head of the next run.
+                cs = commit_streams[idx_run & 1]
+                with torch.cuda.stream(cs):
+                    cs.wait_event(ev)
+                    tr = pl.DeviceTrace(ddl)
+                    pl.trace_fill(pl.trace_fill_args(ddl, tr))
+                    m = stark.main_trace(tr, deferred=bool(pub.deferred))
+                    L = stark.lde(ctx, m, clobber=True)
+                    tree = stark.merkle_commit(ctx, L, stark.W_MAIN)
+                    root = roots[idx_run & 1]             # two pinned landing buffers, used alternately (pinned allocation is slow)
+                    idx_run += 1
+                    root.copy_(tree[-4:], non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(cs)
+                finish(pending)
+                pending = (idx, root, done, (ddl, tr, m, L, tree))
+                continue
             torch.cuda.current_stream().wait_event(ev)
             tr = pl.DeviceTrace(ddl)
             pl.trace_fill(pl.trace_fill_args(ddl, tr))
-            if commit_only:
-                # The commitment needs nothing from the host: queue this run's kernels BEHIND the previous run's, and only then wait
-                # for the previous root (16 bytes into pinned memory) — the GPU goes from one run to the next without a gap.
-                m = stark.main_trace(tr, deferred=bool(pub.deferred))
-                L = stark.lde(ctx, m, clobber=True)
-                tree = stark.merkle_commit(ctx, L, stark.W_MAIN)
-                root = roots[idx_run & 1]                 # two pinned landing buffers, used alternately (pinned allocation is slow)
-                idx_run += 1
-                root.copy_(tree[-4:], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-                finish(pending)
-                pending = (idx, root, done, (ddl, tr, m, L, tree))
-            else:
-                proof = stark.prove(ctx, tr, pub)         # returns after the proof words are on the host: the run's buffers are idle
-                if keep_proofs:
-                    out[idx] = proof
+            proof = stark.prove(ctx, tr, pub)             # returns after the proof words are on the host: the run's buffers are idle
+            if keep_proofs:
+                out[idx] = proof
         finish(pending)
         pending = None
         for t in extra:
