@@ -659,6 +659,9 @@ def main():
                                  if kernels[dom]["bound"] == "int-alu" else None)},
             "roofline_by_stage": kernels,
             "by_config": by_config,
+            # rows per second of ONE GPU over its own stages (everything but the all-gather + cap): at N > 1 the shard is 2^23 rows, not the 2^20 of
+            # N = 1 (a second strided NTT pass per side), so this — not value(1) — is the single-device rate `value` / N is to be held against
+            "per_gpu_local_stage_rows_per_s": n / (sum(v for q, v in stage_ms.items() if q != "allgather_cap") * 1e-3),
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
