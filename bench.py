@@ -39,13 +39,23 @@ PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "ope
 
 
 def _strided_passes(stages: int) -> int:
-    """Number of strided NTT launches zkir::lde_run (ntt.hip, run_strided_stages) makes for `stages` radix-2 stages."""
+    """Number of strided NTT launches zkir::lde_run (ntt.hip, run_strided_stages) makes for `stages` radix-2 stages: LDS radix-4 passes of
+    10 / 8 / 6 / 4 stages, register passes of 3 / 2, a lone stage only for 1."""
     cnt = 0
     while stages > 0:
-        r = min(5, stages // 2)
-        if stages - 2 * r == 1 and r == 5:
-            r = 4
-        stages -= 2 * r if r else 1
+        if stages >= 10 and stages != 11:
+            take = 10
+        elif stages == 11:
+            take = 8
+        elif stages == 9:
+            take = 6
+        elif stages == 7:
+            take = 4
+        elif stages == 5:
+            take = 3
+        else:
+            take = stages
+        stages -= take
         cnt += 1
     return cnt
 

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python $GRAFT_REPO_ROOT/scripts/time_lde.py 20 > /tmp/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python $GRAFT_REPO_ROOT/scripts/time_lde.py ${1:-20} > /tmp/kt.log 2>&1
 python - <<'PY'
 import sqlite3, glob
 c = sqlite3.connect(sorted(glob.glob("/tmp/kt/*.db"))[0])

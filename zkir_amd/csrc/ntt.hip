@@ -182,6 +182,79 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
   }
 }
 
+// ---- register-only pass of S = 2 or 3 stages (radix 4 / 8), no LDS: what is left over once the ten-stage LDS passes are taken
+// (stage counts of 12 = 10 + 2, 13 = 10 + 3, 11 = 8 + 3 ...).  One lane = one (position, half-block) = four columns; it loads its 2^S
+// rows (16 bytes each, consecutive lanes on consecutive 16-byte words), runs the S stages in registers and stores them back: 8 B per
+// element of HBM traffic for S stages, where the tiny-tile LDS pass (2 stages) followed by the single-stage pass moved 16 B for 3.
+// Twiddles: one table read (the finest stage's) and its squares, times the constant 4th / 8th roots.
+template <bool DIT, int S>
+__global__ __launch_bounds__(NT) void ntt_reg_kernel(uint4* __restrict__ data, uint64_t blk_u4, int L, int s0, const uint32_t* __restrict__ tw, uint32_t r4_m, uint32_t r8_m,
+                                                       uint32_t r8_3_m) {
+  constexpr int E = 1 << S;
+  const uint32_t n = 1u << L;
+  uint4* x = data + (uint64_t)blockIdx.y * blk_u4;
+  const uint64_t item = (uint64_t)blockIdx.x * NT + threadIdx.x;               // (group t, half h)
+  if (item >= ((uint64_t)n >> S) * 2) return;
+  const uint32_t t = (uint32_t)(item >> 1), h = (uint32_t)(item & 1);
+  const uint32_t d = DIT ? (1u << s0) : (n >> (s0 + S));                       // row distance between the lane's elements
+  const uint32_t hi = t / d, lo = t % d;
+  const uint64_t base = ((uint64_t)hi * d * E + lo) * 2 + h;
+  uint4 v[E];
+#pragma unroll
+  for (int k = 0; k < E; k++) v[k] = x[base + (uint64_t)k * d * 2];
+  if (!DIT) {
+    // DIF: stage j pairs (k, k + E/2^(j+1)); twiddle of the pair with low index kl = T_j * rho_{2^(S-j)}^kl, T_j = T0^(2^j), T0 = w^-(lo << s0)
+    const uint32_t T0 = tw[lo << s0];
+    const uint32_t T1 = bb::mont_mul(T0, T0);
+    if (S == 3) {
+      const uint32_t T2 = bb::mont_mul(T1, T1);
+      const uint32_t a1 = bb::mont_mul(T0, r8_m), a2 = bb::mont_mul(T0, r4_m), a3 = bb::mont_mul(T0, r8_3_m), b1 = bb::mont_mul(T1, r4_m);
+      const uint32_t w0[4] = {T0, a1, a2, a3};
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint4 a = v[k], b = v[k + 4]; v[k] = add4(a, b); v[k + 4] = mul4(subl4(a, b), w0[k]); }
+#pragma unroll
+      for (int g = 0; g < 8; g += 4) {
+        { const uint4 a = v[g], b = v[g + 2]; v[g] = add4(a, b); v[g + 2] = mul4(subl4(a, b), T1); }
+        { const uint4 a = v[g + 1], b = v[g + 3]; v[g + 1] = add4(a, b); v[g + 3] = mul4(subl4(a, b), b1); }
+      }
+#pragma unroll
+      for (int g = 0; g < 8; g += 2) { const uint4 a = v[g], b = v[g + 1]; v[g] = add4(a, b); v[g + 1] = mul4(subl4(a, b), T2); }
+    } else {
+      const uint32_t a1 = bb::mont_mul(T0, r4_m);
+      { const uint4 a = v[0], b = v[2]; v[0] = add4(a, b); v[2] = mul4(subl4(a, b), T0); }
+      { const uint4 a = v[1], b = v[3]; v[1] = add4(a, b); v[3] = mul4(subl4(a, b), a1); }
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) { const uint4 a = v[g], b = v[g + 1]; v[g] = add4(a, b); v[g + 1] = mul4(subl4(a, b), T1); }
+    }
+  } else {
+    // DIT: stage j pairs (k, k + 2^j); twiddle of the pair with low index kl = U_j * rho_{2^(j+1)}^kl, U_(S-1) = w^(lo << (L - s0 - S)), U_(j-1) = U_j^2
+    const uint32_t Uf = tw[lo << (L - s0 - S)];
+    const uint32_t Um = bb::mont_mul(Uf, Uf);
+    if (S == 3) {
+      const uint32_t U0 = bb::mont_mul(Um, Um);
+      const uint32_t m1 = bb::mont_mul(Um, r4_m), f1 = bb::mont_mul(Uf, r8_m), f2 = bb::mont_mul(Uf, r4_m), f3 = bb::mont_mul(Uf, r8_3_m);
+#pragma unroll
+      for (int g = 0; g < 8; g += 2) { const uint4 tt = mul4(v[g + 1], U0); const uint4 a = v[g]; v[g] = add4(a, tt); v[g + 1] = sub4(a, tt); }
+#pragma unroll
+      for (int g = 0; g < 8; g += 4) {
+        { const uint4 tt = mul4(v[g + 2], Um); const uint4 a = v[g]; v[g] = add4(a, tt); v[g + 2] = sub4(a, tt); }
+        { const uint4 tt = mul4(v[g + 3], m1); const uint4 a = v[g + 1]; v[g + 1] = add4(a, tt); v[g + 3] = sub4(a, tt); }
+      }
+      const uint32_t wf[4] = {Uf, f1, f2, f3};
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint4 tt = mul4(v[k + 4], wf[k]); const uint4 a = v[k]; v[k] = add4(a, tt); v[k + 4] = sub4(a, tt); }
+    } else {
+      const uint32_t f1 = bb::mont_mul(Uf, r4_m);
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) { const uint4 tt = mul4(v[g + 1], Um); const uint4 a = v[g]; v[g] = add4(a, tt); v[g + 1] = sub4(a, tt); }
+      { const uint4 tt = mul4(v[2], Uf); const uint4 a = v[0]; v[0] = add4(a, tt); v[2] = sub4(a, tt); }
+      { const uint4 tt = mul4(v[3], f1); const uint4 a = v[1]; v[1] = add4(a, tt); v[3] = sub4(a, tt); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < E; k++) x[base + (uint64_t)k * d * 2] = v[k];
+}
+
 inline unsigned cu_count() {
   static const unsigned n = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256u; return (unsigned)p.multiProcessorCount; }();
   return n;
@@ -203,31 +276,40 @@ void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int
 
 inline int strided_c() { static const int c = getenv("ZKIR_NTT_C") ? atoi(getenv("ZKIR_NTT_C")) : 2; return c; }
 
-// `stages` radix-2 stages starting at s0, as few passes as possible: radix-4 passes of 10/8/6/4/2 stages + one direct stage for an odd count
+// `stages` radix-2 stages starting at s0 in as few passes over the data as possible: LDS radix-4 passes of 10 / 8 / 6 / 4 stages and
+// register passes of 3 / 2 stages (13 = 10 + 3, 12 = 10 + 2, 11 = 8 + 3, 9 = 6 + 3, 7 = 4 + 3, 5 = 3 + 2); a lone stage only for 1
 template <bool DIT>
 void run_strided_stages(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int s0, int stages, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m,
-                        hipStream_t s) {
+                        uint32_t r8_m, uint32_t r8_3_m, hipStream_t s) {
   while (stages > 0) {
-    int R = stages / 2 > 5 ? 5 : stages / 2;
-    if (stages - 2 * R == 1 && R == 5) R = 4;                  // keep an even remainder (e.g. 11 = 8 + 2 + 1 is avoided: 11 -> 8 + ... )
-    if (R == 0) {                                              // single leftover stage
-      hipLaunchKernelGGL(ntt_stage_kernel<DIT>, dim3((unsigned)((n + NT - 1) / NT), n_blocks), dim3(NT), 0, s, (uint4*)data, 2 * n, L, s0, tw);
-      s0 += 1; stages -= 1;
-      continue;
-    }
-    switch (R) {
-      case 5:
+    int take;
+    if (stages >= 10 && stages != 11) take = 10;
+    else if (stages == 11) take = 8;
+    else if (stages == 9) take = 6;
+    else if (stages == 7) take = 4;
+    else if (stages == 5) take = 3;
+    else take = stages;                                          // 8, 6, 4, 3, 2, 1
+    switch (take) {
+      case 10:
         // tile rows of 4 positions = 128 contiguous bytes (a full cache line; 128 KiB of LDS, one workgroup of 16 waves per CU) or of
         // 2 positions = 64 bytes (64 KiB, two workgroups of 8 waves): ZKIR_NTT_C picks (benchmarking), default from the measurements
         if (strided_c() == 2) launch_strided_r4<DIT, 5, 2, 1024>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s);
         else launch_strided_r4<DIT, 5, 1, 512>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s);
         break;
-      case 4: launch_strided_r4<DIT, 4, 3, 512>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
-      case 3: launch_strided_r4<DIT, 3, 4, 256>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
-      case 2: launch_strided_r4<DIT, 2, 5, 128>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
-      default: launch_strided_r4<DIT, 1, 6, 64>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
+      case 8: launch_strided_r4<DIT, 4, 3, 512>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
+      case 6: launch_strided_r4<DIT, 3, 4, 256>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
+      case 4: launch_strided_r4<DIT, 2, 5, 128>(data, n, n_blocks, L, s0, tw, small, log_small, j4_m, s); break;
+      case 3:
+        hipLaunchKernelGGL((ntt_reg_kernel<DIT, 3>), dim3((unsigned)(((n >> 3) * 2 + NT - 1) / NT), n_blocks), dim3(NT), 0, s, (uint4*)data, 2 * n, L, s0, tw, j4_m, r8_m, r8_3_m);
+        break;
+      case 2:
+        hipLaunchKernelGGL((ntt_reg_kernel<DIT, 2>), dim3((unsigned)(((n >> 2) * 2 + NT - 1) / NT), n_blocks), dim3(NT), 0, s, (uint4*)data, 2 * n, L, s0, tw, j4_m, r8_m, r8_3_m);
+        break;
+      default:
+        hipLaunchKernelGGL(ntt_stage_kernel<DIT>, dim3((unsigned)((n + NT - 1) / NT), n_blocks), dim3(NT), 0, s, (uint4*)data, 2 * n, L, s0, tw);
+        break;
     }
-    s0 += 2 * R; stages -= 2 * R;
+    s0 += take; stages -= take;
   }
 }
 
@@ -380,12 +462,15 @@ void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out,
   const int L = t.log_n;
   const uint32_t N = 1u << L;
   static const uint32_t j4_inv_m = bb::to_mont(bb::inv(bb::root_of_unity(2))), j4_fwd_m = bb::to_mont(bb::root_of_unity(2));
+  static const uint32_t r8_fwd = bb::root_of_unity(3), r8_inv = bb::inv(r8_fwd);
+  static const uint32_t r8_inv_m = bb::to_mont(r8_inv), r8_inv3_m = bb::to_mont(bb::mul(bb::mul(r8_inv, r8_inv), r8_inv));
+  static const uint32_t r8_fwd_m = bb::to_mont(r8_fwd), r8_fwd3_m = bb::to_mont(bb::mul(bb::mul(r8_fwd, r8_fwd), r8_fwd));
   if (L < 10) {
     hipLaunchKernelGGL(lde_small_kernel, dim3(n_blocks), dim3(NT), (8u << L), s, in, out, L, t.small_inv, t.small_fwd, t.g_lo, t.g_hi);
     return;
   }
   // inverse DIF strided stages 0 .. L-11 (the compact table then has order 1024)
-  run_strided_stages<false>(in, N, n_blocks, L, 0, L - 10, t.tw_inv, t.small_inv, 10, j4_inv_m, s);
+  run_strided_stages<false>(in, N, n_blocks, L, 0, L - 10, t.tw_inv, t.small_inv, 10, j4_inv_m, r8_inv_m, r8_inv3_m, s);
   {
     const uint32_t chunks = N >> 10, total = chunks * n_blocks;
     unsigned grid = persist() ? cu_count() * 2 : total;                     // 64 KiB of LDS: two workgroups per CU
@@ -394,7 +479,7 @@ void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out,
                        j4_inv_m, j4_fwd_m);
   }
   // forward DIT strided stages 11 .. L of the size-2N transform
-  run_strided_stages<true>(out, (uint64_t)2 * N, n_blocks, L + 1, 11, L - 10, t.tw_fwd, t.small_fwd, 11, j4_fwd_m, s);
+  run_strided_stages<true>(out, (uint64_t)2 * N, n_blocks, L + 1, 11, L - 10, t.tw_fwd, t.small_fwd, 11, j4_fwd_m, r8_fwd_m, r8_fwd3_m, s);
 }
 
 }  // namespace zkir
