@@ -106,3 +106,33 @@ def test_segment_chains_same_verdicts_as_the_oracle(n_total, seg, prog):
     for chain, e_rt, e_so in cases:
         want = so.verify_chain(chain, e_so) if chain else 40
         assert want != 0 and rt.verify_chain(chain, e_rt) == want, (want, rt.verify_chain(chain, e_rt))
+
+
+def test_verifier_fuzz_never_accepts_and_agrees_with_the_oracle():
+    """1500 random corruptions of a valid proof — single words set to arbitrary 32-bit values (header fields included: sizes, counts,
+    log2 N up to absurd values), random truncations and extensions, swapped regions: the product's verifier never accepts, never
+    reads out of bounds (it would crash here), and names the same failing check as the oracle's."""
+    rows, pub = _run(200)
+    pr = so.prove(rows, pub)
+    rng = np.random.default_rng(2024)
+    special = [0, 1, 2, 3, 7, 8, 26, 27, 31, 32, 50, 64, 152, 153, 255, 256, 1 << 16, (1 << 20) - 1, 1 << 20, (1 << 30) - 1, 1 << 30, P - 1, P, P + 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF]
+    for it in range(1500):
+        t = pr.copy()
+        kind = it % 5
+        if kind == 0:                                             # a header / parameter word
+            t[int(rng.integers(0, 165))] = special[int(rng.integers(0, len(special)))]
+        elif kind == 1:                                           # any word, arbitrary value
+            t[int(rng.integers(0, len(t)))] = int(rng.integers(0, 1 << 32))
+        elif kind == 2:                                           # truncation / extension
+            cut = int(rng.integers(0, len(t) + 40))
+            t = t[:cut] if cut <= len(t) else np.concatenate([t, rng.integers(0, P, cut - len(t)).astype(np.uint32)])
+        elif kind == 3:                                           # two words swapped
+            a, b = (int(x) for x in rng.integers(0, len(t), 2))
+            t[a], t[b] = t[b], t[a]
+        else:                                                     # a run of words zeroed
+            a = int(rng.integers(0, len(t)))
+            t[a:a + int(rng.integers(1, 64))] = 0
+        if len(t) == len(pr) and np.array_equal(t, pr):
+            continue
+        got, want = rt.verify(t), so.verify(t)
+        assert got != 0 and got == want, (it, kind, got, want)
