@@ -136,3 +136,35 @@ def test_verifier_fuzz_never_accepts_and_agrees_with_the_oracle():
             continue
         got, want = rt.verify(t), so.verify(t)
         assert got != 0 and got == want, (it, kind, got, want)
+
+
+def test_chain_verifier_fuzz_agrees_with_the_oracle():
+    """Random damage to a chain of segment proofs — a corrupted word in one segment, segments dropped, repeated or reordered, a
+    truncated segment: zkir_verify_chain never accepts and returns the oracle's code."""
+    from test_stark_oracle import _segments
+    rows, full, cuts, proofs = _segments(200, 60)
+    fullc = _pub_c(full)
+    assert len(proofs) == 4 and rt.verify_chain(proofs, fullc) == 0
+    rng = np.random.default_rng(7)
+    for it in range(300):
+        chain = [p.copy() for p in proofs]
+        kind = it % 4
+        if kind == 0:
+            k = int(rng.integers(0, len(chain))); pos = int(rng.integers(0, len(chain[k])))
+            chain[k][pos] = int(rng.integers(0, 1 << 32))
+        elif kind == 1:
+            order = rng.permutation(len(chain))
+            if (order == np.arange(len(chain))).all():
+                continue
+            chain = [chain[i] for i in order]
+        elif kind == 2:
+            k = int(rng.integers(0, len(chain)))
+            chain = chain[:k] + chain[k + 1:] if rng.integers(0, 2) else chain[:k] + [chain[k]] + chain[k:]
+        else:
+            k = int(rng.integers(0, len(chain)))
+            chain[k] = chain[k][:int(rng.integers(0, len(chain[k])))]
+        same = len(chain) == len(proofs) and all(len(a) == len(b) and np.array_equal(a, b) for a, b in zip(chain, proofs))
+        if same:
+            continue
+        got, want = rt.verify_chain(chain, fullc), (so.verify_chain(chain, full) if chain else 40)
+        assert got != 0 and got == want, (it, kind, got, want)
