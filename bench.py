@@ -16,6 +16,9 @@ witness kernels with algorithmic bytes, ms and fraction of the HBM peak).
 N ranks = N row shards of one (N * 2^k)-cycle run (weak scaling): each rank fills and commits its own row range from its own
 register snapshot with no data-path collective; the per-rank Merkle roots are all-gathered over RCCL (16 B per rank) and every
 rank hashes the top levels.  N > 1 defaults to BASELINE configs[3]'s per-GPU share, 2^23 rows per GPU (2^26 rows on 8 GPUs).
+Host side at N > 1: rank g executes rows [0, g n) of the run untraced on its own core and traces its own n rows
+(zkir_interpret_window) — no shard files, no transport; `multi_gpu_end_to_end` reports the time to root of the sharded run with
+the host in the loop and the aggregate of N independent runs (one interpreter each), next to the resident-input `value`.
 Launch: `python bench.py` (N=1) or torch.distributed.run with --gpus N.
 """
 from __future__ import annotations
@@ -244,11 +247,12 @@ def _config4_sha_2p22(lib, sp):
         if note:
             kern[name]["note"] = note
     rec("trace_fill", lambda: pl.trace_fill(fa), pl.trace_fill_bytes(ddl))
-    rec("memops_row_offsets", lambda: pl._check(lib.zkir_memops_row_offsets_launch(ev.data_ptr(), n_ops, n, offs.data_ptr(), sp())), 8 * (n + 1),
-        "one binary search per row over the L2-resident event array: latency-bound, small")
-    rec("memops_expand", lambda: pl._check(lib.zkir_memops_expand_launch(ev.data_ptr(), n_ops, 0, C.byref(rows_c.c), sp())), (24 + 39) * n_ops)
-    rec("memops_sort", lambda: pl._check(lib.zkir_memops_sort_launch(ev.data_ptr(), n_ops, n, 0, offs.data_ptr(), scratch.data_ptr(), C.byref(sort_c.c), sp())),
-        (24 * 2 + 39) * n_ops + n, "= ExecutionResult::get_memory_trace(): rank in a two-run merge per row")
+    rec("memops_expand_csr", lambda: pl._check(lib.zkir_memops_expand_csr_launch(ev.data_ptr(), n_ops, n, 0, C.byref(rows_c.c), offs.data_ptr(), scratch.data_ptr(), sp())),
+        (24 + 39) * n_ops + 8 * (n + 1) + n,
+        "TraceRow.memory_ops in row order + the CSR row offsets + the per-row shape flags of the sort, ONE pass over the events (round 2: three passes; "
+        "the per-row binary search alone moved 12x its algorithmic bytes)")
+    rec("memops_sort", lambda: pl._check(lib.zkir_memops_sort_prepared_launch(ev.data_ptr(), n_ops, 0, offs.data_ptr(), scratch.data_ptr(), C.byref(sort_c.c), sp())),
+        (24 + 39) * n_ops + n, "= ExecutionResult::get_memory_trace(): rank in a two-run merge per row (keys of the touched segments staged in LDS)")
     rec("sha256_chip", lambda: pl._check(lib.zkir_sha256_chip_launch(blk.data_ptr(), n_blk, out.data_ptr(), sha_stride, ts.data_ptr(), sp())), (72 + 2432 + 8) * n_blk)
     o = out[:, [0, n_blk // 2, n_blk - 1]].cpu().numpy().view(np.uint32)       # parity spot-check outside the timings: digests vs hashlib
     for col, idx in enumerate([0, n_blk // 2, n_blk - 1]):
@@ -285,11 +289,12 @@ def _cpu_baseline(blob, k, commit):
         m = so.main_trace(rows, so.public_inputs(len(rows), blob))
         t_main = time.perf_counter() - t0
         del rows
-        root, t_lde, t_merkle = so.commit_port(m, threads)
+        from bench_cpu import api as cpu_port
+        root, t_lde, t_merkle = cpu_port.commit_port(m, threads)
         out["commit_stage_self_defined"] = {
             "rows": 1 << k, "threads": threads, "main_trace_s_1_thread": t_main, "lde_s": t_lde, "merkle_s": t_merkle,
             "rows_per_s": (1 << k) / (t_lde + t_merkle), "merkle_root": [int(x) for x in root],
-            "what": "the SAME commit stage at the SAME size on this box's host cores: oracle/cpu_commit_port.cpp (Montgomery arithmetic, radix-2 NTTs with "
+            "what": "the SAME commit stage at the SAME size on this box's host cores: bench_cpu/cpu_commit_port.cpp (Montgomery arithmetic, radix-2 NTTs with "
                     "twiddle tables, std::thread over columns / leaves); stages absent from the reference (self-defined) — a labelled side figure, "
                     "never part of `value`; its root must equal the GPU's (checked below)"}
     return out
@@ -355,7 +360,8 @@ def main():
     # Execution is sequential: ONE interpretation per node.  N = 1: in-process.  N > 1: rank 0 interprets the whole (N * 2^k)-row
     # run once and leaves every rank's row shard (own register snapshot, rebased events) in /dev/shm; the other ranks wait and
     # pick theirs up — they never interpret.
-    host_first_s = host_s = shard_io_s = None
+    host_first_s = host_s = None
+    per_rank_host_s = None
     log = None
     if world == 1:
         t0 = time.perf_counter()
@@ -370,61 +376,33 @@ def main():
             host_s = min(host_s, time.perf_counter() - t0)
         shard = log
     else:
-        # the shards total ~40 B per row (2.7 GB at 2^26 rows): /dev/shm when it has the room (a container may cap it at 64 MB), else the temp dir
-        import tempfile
-        need = int(total_rows * 48 * 1.1)
-        shm = "/dev/shm"
-        try:
-            st = os.statvfs(shm)
-            if st.f_bavail * st.f_frsize < need:
-                shm = tempfile.gettempdir()
-        except OSError:
-            shm = tempfile.gettempdir()
-        choice = [shm]
-        dist.broadcast_object_list(choice, src=0)           # one decision for the node: rank 0's, taken before anything is written
-        shm = choice[0]
-        path = lambda r: os.path.join(shm, f"zkir_bench_{os.environ.get('MASTER_PORT', '0')}_{r}.npz")  # noqa: E731
-        seg_path = lambda r: os.path.join(shm, f"zkir_bench_{os.environ.get('MASTER_PORT', '0')}_seg{r}.npz")  # noqa: E731
+        # Execution is sequential (vm.rs:208-358): the state at row g*n exists only once rows [0, g*n) have been executed.  Rank g
+        # executes them itself, UNTRACED (zkir_interpret_window: no log stores, 1.5-2x the traced rate), then traces its own rows —
+        # so GPU g has its shard after g*n*t_untraced + n*t_traced, sooner than a single traced interpreter on rank 0 would reach
+        # those rows, and nothing travels between the processes (round 2 wrote every shard to /dev/shm as .npz and read it back).
+        # The window also covers the segment-proof shard of the rank ([g(n-1), g(n-1)+n): overlaps the previous rank's by one row).
         want_segments = args.stage == "commit" and not args.no_prove
-        run_pub_bytes = [None]
-        if rank == 0:
-            t0 = time.perf_counter()
-            log = rt.interpret(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True), tile_rows=args.tile_rows)
-            host_first_s = host_s = time.perf_counter() - t0
-            assert log.n_rows == total_rows and log.halt_reason == rt.HaltReason.CycleLimit()
-            t0 = time.perf_counter()
-            for r in range(world):
-                sh = log.shard(r * n, (r + 1) * n)
-                pl.save_shard(sh, path(r))
-                sh.close()
-            shard_io_s = time.perf_counter() - t0
-            if want_segments:
-                # SEGMENT proofs: rank r proves rows [r (n - 1), r (n - 1) + n) — 2^k rows, the last one shared with the next
-                # segment — and the G - 1 rows that leaves at the end of the run are one more (tiny) segment, proven by the last rank
-                for r in range(world):
-                    sh = log.shard(r * (n - 1), r * (n - 1) + n)
-                    pl.save_shard(sh, seg_path(r))
-                    sh.close()
-                sh = log.shard(world * (n - 1), total_rows)
-                pl.save_shard(sh, seg_path(world))
-                sh.close()
-                run_pub_bytes[0] = bytes(rt.public_inputs(log, blob))
-            log.close()
+        vm_cfg = rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True)
+        lo = rank * (n - 1) if want_segments else rank * n
         dist.barrier()
-        shard = pl.load_shard(path(rank))
+        t0 = time.perf_counter()
+        win = rt.interpret(blob, [], vm_cfg, tile_rows=args.tile_rows, window=(lo, (rank + 1) * n))
+        host_first_s = host_s = time.perf_counter() - t0                  # this rank: fast-forward + its traced window
+        assert win.n_rows == (rank + 1) * n - lo and win.cycle_base == lo
+        shard = win.shard(rank * n, (rank + 1) * n)
         seg_shards = []
+        run_pub_bytes = [None]
         if want_segments:
-            dist.broadcast_object_list(run_pub_bytes, src=0)
-            seg_shards.append(pl.load_shard(seg_path(rank)))
-            if rank == world - 1:
-                seg_shards.append(pl.load_shard(seg_path(world)))
-        dist.barrier()
-        if rank == 0:
-            for r in range(world + 1):
-                if want_segments and os.path.exists(seg_path(r)):
-                    os.unlink(seg_path(r))
-            for r in range(world):
-                os.unlink(path(r))
+            seg_shards.append(win.shard(rank * (n - 1), rank * (n - 1) + n))
+            if rank == world - 1:                                         # the G rows the G overlapping segments leave at the end of the run
+                seg_shards.append(win.shard(world * (n - 1), total_rows))
+                assert not win.window_open and win.cycles == total_rows and win.halt_reason == rt.HaltReason.CycleLimit()
+                run_pub_bytes[0] = bytes(rt.public_inputs(win, blob))      # the last rank executed the run to its halt: outputs / halt reason / cycles are the run's
+            dist.broadcast_object_list(run_pub_bytes, src=world - 1)
+        per_rank_host_s = [None] * world
+        dist.all_gather_object(per_rank_host_s, host_s)
+        host_first_s = host_s = max(per_rank_host_s)                      # the last rank's: it executes the whole run
+        win.close()
     torch.zeros(1 << 20, device="cuda").sum().item()   # HIP context / allocator warm-up is not part of the H2D figure
     t0 = time.perf_counter()
     ddl = pl.upload(shard)
@@ -570,6 +548,73 @@ def main():
         except Exception as e:                                    # the bench line must not depend on this leg
             segment_prove = {"error": repr(e)}
 
+    # ---- N > 1 with the HOST IN THE LOOP: (a) time to root of ONE run row-sharded over the G GPUs, every rank starting
+    #      from the program blob: zkir_exec_window (rows before the shard executed untraced on the rank's core, its own rows traced
+    #      with upload + K1 streamed underneath) -> main trace -> LDE -> Merkle -> all-gather + cap; (b) G INDEPENDENT runs, one per
+    #      GPU, each interpreted by its own rank: the mode whose aggregate scales with G, since one run is bounded by one core
+    multi_e2e = None
+    if commit and world > 1:
+        try:
+            def commit_from(cols, n_rows):
+                pl._check(lib.zkir_main_trace_launch(C.byref(cols), n_rows, 0, m.data_ptr(), sp()))
+                pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))
+                pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp()))
+
+            def timed(body, reps=3):
+                best = None
+                for _ in range(reps):                             # first repetition: cold block pool / device allocations
+                    barrier()
+                    t0 = time.perf_counter()
+                    parts = body()
+                    barrier()
+                    dt = time.perf_counter() - t0
+                    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    if best is None or float(t.item()) < best[0]:
+                        best = (float(t.item()), parts)
+                return best
+
+            def sharded_run():
+                t0 = time.perf_counter()
+                res = rt.VM(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True)).run_window(rank * n, (rank + 1) * n)
+                t_exec = time.perf_counter() - t0
+                commit_from(res.execution_trace.columns, n)
+                exchange()
+                torch.cuda.synchronize()
+                res.close()
+                return t_exec
+
+            def independent_run():
+                t0 = time.perf_counter()
+                res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run()
+                t_exec = time.perf_counter() - t0
+                commit_from(res.execution_trace.columns, n)
+                torch.cuda.synchronize()
+                res.close()
+                return t_exec
+
+            t_root, t_exec = timed(sharded_run)
+            sharded_root = cap_root[0].cpu().numpy().view(np.uint32).tolist()
+            exec_all = [None] * world
+            dist.all_gather_object(exec_all, t_exec)
+            t_ind, t_exec_i = timed(independent_run)
+            for _ in range(2):                                    # leave `tree` / `gathered` / cap_root holding the sharded run's commitment again
+                step()
+            torch.cuda.synchronize()
+            multi_e2e = {
+                "one_run_row_sharded": {
+                    "rows": total_rows, "time_to_root_s": t_root, "end_to_end_rows_per_s_incl_host": total_rows / t_root,
+                    "zkir_exec_window_s_per_rank": exec_all, "root": sharded_root,
+                    "what": "barrier -> every rank: zkir_exec_window(program, rows [g n, (g+1) n)) = rows [0, g n) executed untraced on the rank's own core, its rows "
+                            "traced with H2D + K1 streamed under the interpreter -> main trace -> LDE -> Merkle -> all-gather of the roots + cap -> barrier; max over ranks",
+                    "bound": "one run is a sequential chain: its time to root cannot drop below (G - 1) n t_untraced + n t_traced + one GPU's commit step, whatever G is"},
+                "independent_runs_one_per_gpu": {
+                    "runs": world, "rows_per_run": n, "wall_s": t_ind, "rows_per_s_end_to_end_incl_host": world * n / t_ind, "zkir_exec_s_rank0": t_exec_i,
+                    "what": "barrier -> every rank: zkir_exec of its OWN 2^k-cycle run (one interpreter thread per run) -> main trace -> LDE -> Merkle -> barrier: "
+                            "G runs need G interpreters, so this is the aggregate that grows with G"}}
+        except Exception as e:                                    # the bench line must not depend on this leg
+            multi_e2e = {"error": repr(e)}
+
     # ---- the drop-in entry point itself: zkir_exec = host interpretation + H2D + K1 in one call (VM::new + VM::run, trace left in HBM)
     exec_s = None
     if world == 1 and k <= 24:
@@ -680,7 +725,12 @@ def main():
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,
             "host_interpret_ns_per_instruction": host_s / total_rows * 1e9, "host_interpret_s": host_s,
-            "host_interpretations_per_node": 1, "shard_distribution_s": shard_io_s,
+            # N = 1: the one interpretation of the run.  N > 1: EVERY rank executes its own prefix (rank g: g n rows untraced + n rows traced, on its own
+            # core: zkir_interpret_window) — G interpreters per node, no shard transport; `host_interpret_s` is then the slowest rank's (the last one's)
+            "host_interpretations_per_node": world, "shard_distribution_s": 0.0,
+            "host_window_s_per_rank": per_rank_host_s if world > 1 else None,
+            "multi_gpu_end_to_end": multi_e2e,
+            "end_to_end_rows_per_s_incl_host": (multi_e2e or {}).get("one_run_row_sharded", {}).get("end_to_end_rows_per_s_incl_host") if world > 1 else None,
             "h2d_upload_s": h2d_s,
             "end_to_end_rows_per_s_incl_host_and_pcie": n / (exec_s + (gpu_ms_per_step - stage_ms["trace_fill"]) * 1e-3) if exec_s else None,
             "zkir_exec_ms": exec_s * 1e3 if exec_s else None,                 # drop-in call: interpret + H2D + trace fill, PCIe-inclusive

@@ -1,6 +1,6 @@
 // cpu_commit_port.cpp — CPU PORT of the commit stage (LDE + Poseidon2 Merkle) for bench.py's `cpu_baseline` leg ONLY.
 //
-// TEST/BENCH INFRASTRUCTURE.  The commit stage has no counterpart in the reference (no prover there), so this is not
+// BENCH INFRASTRUCTURE (kept outside oracle/: it compiles product headers).  The commit stage has no counterpart in the reference (no prover there), so this is not
 // "the reference path": it is the same self-defined computation the GPU step performs, written the way a CPU implementation would
 // be — Montgomery arithmetic (the product's babybear.h / poseidon2.h compiled for the host), iterative radix-2 NTTs with twiddle
 // tables, std::thread over columns and leaves — so that the GPU number has a same-size, same-work CPU figure next to it.  The

@@ -126,7 +126,20 @@ int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t*
                    const zkir_vm_config* cfg, uint32_t tile_rows, zkir_delta_log** out);
 void zkir_delta_log_free(zkir_delta_log* log);
 
-/* Row sharding (multi-GPU): a self-contained delta log for rows [row_begin, row_end) of `log`
+/* Trace WINDOW: the delta log of rows [row_begin, min(row_end, rows of the run)) only (cycle_base = row_begin).  VM::run is a
+ * sequential chain (vm.rs:208-358: cycle c + 1 needs the registers, memory and pc of cycle c), so the state at row_begin exists only
+ * after rows [0, row_begin) have been executed: this call executes them UNTRACED (no log stores; measured 1.5-2x the traced rate),
+ * takes the register snapshot from the live machine, records the window and stops.  Multi-GPU: rank g of G calls it
+ * with its own row range on its own host core — every GPU gets its shard after g * n * t_untraced + n * t_traced, sooner than a
+ * single traced interpreter reaches those rows, with no inter-process transport.  cfg->enable_execution_trace must be set.
+ * zkir_delta_log_cycles / halt / outputs describe the machine where the interpretation stopped; zkir_delta_log_window_open() = 1 if
+ * that was the window's end rather than a halt (the run continues past row_end). */
+int zkir_interpret_window(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg,
+                          uint32_t tile_rows, uint64_t row_begin, uint64_t row_end, zkir_delta_log** out);
+int zkir_delta_log_window_open(const zkir_delta_log*);
+
+/* Row sharding (multi-GPU): a self-contained delta log for rows [row_begin, row_end) of `log` (ABSOLUTE row numbers: a source that
+ * is itself a window or a shard holds rows [cycle_base, cycle_base + n_rows))
  * (any row range; a row_begin that is not a multiple of tile_rows — segment proofs overlap by one row — gets the shard its own
  * tiling, rebuilt from the events).  Its first 16 events are the register snapshot at row_begin, event
  * `vis`, mem-event rows and the tile index are rebased to the shard, and zkir_delta_log_cycle_base()
@@ -217,7 +230,14 @@ typedef struct zkir_memop_columns {
 
 /* TraceRow.memory_ops flattened in row order */
 int zkir_memops_expand_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t cycle_base, const zkir_memop_columns* out, void* hip_stream);
-/* CSR: offsets[r] = number of ops whose row < r, r = 0..n_rows (n_rows+1 entries) */
+/* TraceRow.memory_ops in row order, the CSR row offsets (n_rows + 1 entries) and the per-row shape flags the sort needs (n_rows bytes;
+ * 1 = the row's ops are not [ascending reads][ascending writes]) — all three from ONE pass over the events (24 B read per op) */
+int zkir_memops_expand_csr_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t n_rows, uint64_t cycle_base, const zkir_memop_columns* out,
+                                  uint64_t* row_offsets, uint8_t* seg_flags, void* hip_stream);
+/* ExecutionResult::get_memory_trace() given the offsets and flags of zkir_memops_expand_csr_launch: one more pass over the events */
+int zkir_memops_sort_prepared_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t cycle_base, const uint64_t* row_offsets, const uint8_t* seg_flags,
+                                     const zkir_memop_columns* out, void* hip_stream);
+/* CSR alone: offsets[r] = number of ops whose row < r, r = 0..n_rows (n_rows+1 entries); one binary search per row */
 int zkir_memops_row_offsets_launch(const zkir_mem_event* events, uint64_t n_ops, uint64_t n_rows, uint64_t* offsets, void* hip_stream);
 /* ExecutionResult::get_memory_trace() (vm.rs:85-94): stable order by (timestamp, address, Read<Write).
  * row_offsets from zkir_memops_row_offsets_launch; seg_scratch = n_rows bytes of device scratch. */
@@ -287,7 +307,8 @@ typedef struct zkir_public_inputs {
 } zkir_public_inputs;
 /* Poseidon2 sponge digest of a byte string (host): [len as four 16-bit pieces] ++ [LE 16-bit halfwords] */
 void zkir_digest_bytes(const uint8_t* bytes, size_t len, uint32_t out[4]);
-/* the public inputs of a finished run (host; `log` is the unsharded delta log of the run) */
+/* the public inputs of a finished run (host; `log`: the run's delta log, a shard of it, or the trace window that reached the run's
+ * halt — anything whose cycles / outputs / halt reason are the finished run's; a window with zkir_delta_log_window_open() is refused) */
 int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
                           uint32_t deferred, zkir_public_inputs* out);
 
@@ -331,6 +352,11 @@ typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device
  * on the current HIP device.  Fails with ZKIR_ERR_DEVICE if no GPU is usable (no CPU fallback). */
 int zkir_exec(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
               const zkir_vm_config* cfg, zkir_result** out);
+/* The same call for ONE GPU'S SHARE of a run: rows [0, row_begin) are executed untraced on the calling thread, rows [row_begin,
+ * row_end) are traced, uploaded and filled on the current device while the interpreter runs (zkir_interpret_window + the streaming
+ * of zkir_exec).  The handle's trace columns hold absolute cycles; zkir_result_delta_log(r): cycle_base = row_begin. */
+int zkir_exec_window(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg,
+                     uint64_t row_begin, uint64_t row_end, zkir_result** out);
 /* The same handle for a ROW SHARD of a finished interpretation (zkir_interpret): rows [row_begin, row_end) of `log` are cut out
  * (zkir_delta_log_shard), uploaded to the CURRENT HIP device and filled there.  Multi-GPU: one call per device, each with its row range
  * (hipSetDevice / one process per GPU); segment proofs: ranges that share one row.  The result owns the shard (zkir_result_delta_log:

@@ -229,7 +229,8 @@ class ExecutionResult {                                         // vm.rs:54-78
   // ExecutionResult::get_memory_trace (vm.rs:85-94): every data-memory op sorted by (timestamp, address, Read<Write); the sort and
   // the column expansion run on the device behind zkir_result_memory_trace, this copies the result to the host
   std::vector<MemoryOp> get_memory_trace() const { return memops(true, 0, (uint64_t)-1); }
-  // TraceRow.memory_ops of one row (trace.rs:49)
+  // TraceRow.memory_ops of one row (trace.rs:49).  `row` indexes the rows of THIS handle: for a row shard (zkir_exec_shard) it is
+  // relative to the shard's first row (absolute cycle = row + zkir_delta_log_cycle_base); out of range throws std::out_of_range.
   std::vector<MemoryOp> row_memory_ops(uint64_t row) const { return memops(false, row, row + 1); }
   std::vector<RangeCheckWitness> range_check_witnesses() const {                        // vm.rs:66-69
     std::vector<RangeCheckWitness> out;
@@ -293,6 +294,7 @@ class ExecutionResult {                                         // vm.rs:54-78
     const int rc = zkir_result_memory_trace(res_, &w);
     if (rc != ZKIR_OK) detail::raise(rc);
     uint64_t lo = 0, hi = w.n_ops;
+    if (!sorted && (row_lo >= w.n_rows || row_hi > w.n_rows)) throw std::out_of_range("row_memory_ops: row " + std::to_string(row_lo) + " is past the handle's " + std::to_string(w.n_rows) + " rows");
     if (!sorted) { uint64_t o[2]; d2h(&o[0], w.row_offsets + row_lo, 8); d2h(&o[1], w.row_offsets + row_hi, 8); lo = o[0]; hi = o[1]; }
     const zkir_memop_columns& c = sorted ? w.sorted : w.row_order;
     const size_t n = hi - lo;

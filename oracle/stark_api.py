@@ -38,7 +38,6 @@ def lib():
         L.so_verify_segment.restype = I; L.so_verify_segment.argtypes = [V, SZ, PP, V]
         L.so_verify_chain.restype = I; L.so_verify_chain.argtypes = [V, V, I, PP]
         L.so_constraints_eval_states.restype = I; L.so_constraints_eval_states.argtypes = [V, V, U32, U32, U32, PP, V, V, V, V]
-        L.so_commit_port.restype = None; L.so_commit_port.argtypes = [V, I, I, I, V, V]
         L.so_last_challenges.restype = None; L.so_last_challenges.argtypes = [V, V, V]
         L.so_last_quotient.restype = None; L.so_last_quotient.argtypes = [V]
         L.so_last_fri_layer.restype = SZ; L.so_last_fri_layer.argtypes = [I, V]
@@ -158,16 +157,6 @@ def merkle(mat: np.ndarray, want_layers=False):
     layers = np.zeros(4 * (2 * n - 1), np.uint32) if want_layers else None
     lib().so_merkle(mat.ctypes.data, w, n, root.ctypes.data, layers.ctypes.data if want_layers else None)
     return (root, layers) if want_layers else root
-
-
-def commit_port(matrix: np.ndarray, threads: int):
-    """CPU port of the commit stage (cpu_commit_port.cpp: Montgomery arithmetic, `threads` host threads) over a column-major
-    main-trace matrix [W][N]: returns (root, lde_seconds, merkle_seconds).  bench.py's cpu_baseline leg only."""
-    m = _u32(matrix)
-    w, n = m.shape
-    root, secs = np.zeros(4, np.uint32), np.zeros(2, np.float64)
-    lib().so_commit_port(m.ctypes.data, w, int(n).bit_length() - 1, int(threads), root.ctypes.data, secs.ctypes.data)
-    return root, float(secs[0]), float(secs[1])
 
 
 def commit_trace(rows: np.ndarray, log_blowup=1, want_lde=False, pub: PublicC | None = None):

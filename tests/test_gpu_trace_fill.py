@@ -210,3 +210,35 @@ def test_concurrent_zkir_exec_calls_from_several_threads():
     for (rows, outs, cyc), w in zip(got, want):
         assert cyc == w.cycles and outs == list(w.outputs)
         helpers.assert_rows_equal(rows, w.rows)
+
+
+# ---- zkir_exec_window: one GPU's share of a run executed on this rank (rows before it untraced, its own rows traced; streamed above 2^17 rows) ----
+@pytest.mark.parametrize("a,b", [(0, 3000), (1000, 3000), (1, 2), (2999, 3000), (2500, 9000), (3000, 3001)])
+def test_exec_window_rows_and_witnesses_match_the_oracle_slice(a, b):
+    """The handle of a trace window — rows (absolute cycles), per-row memory ops and SHA witnesses — equals the oracle's rows [a, b) of
+    the whole run; a window past the end of the run is cut at the halt."""
+    blob = spec.sha256_chain_program().to_bytes()
+    n = 3000
+    want = oracle.run(blob, [], max_cycles=n, enable_execution_trace=True)
+    res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run_window(a, b)
+    lo, hi = min(a, n), min(b, n)
+    assert len(res.execution_trace) == hi - lo and res.delta_log.cycle_base == lo and res.delta_log.window_open == (b < n)
+    if hi > lo:
+        helpers.assert_rows_equal(res.execution_trace.rows(), want.rows[lo:hi])
+        ops, offs = res.row_memory_ops()
+        o0, o1 = int(want.row_memop_offsets[lo]), int(want.row_memop_offsets[hi])
+        assert np.array_equal(ops, want.memops[o0:o1]) and np.array_equal(offs, want.row_memop_offsets[lo:hi + 1] - want.row_memop_offsets[lo])
+    res.close()
+
+
+@pytest.mark.parametrize("a,b", [(1 << 17, 1 << 18), ((1 << 17) - 77, (1 << 18) + 1), (300_000, 300_000 + (1 << 17) + 3)])
+def test_streaming_exec_window(a, b):
+    """Windows of 2^17 rows and more take the streaming path (upload + K1 of the finished tiles under the running interpreter), with
+    cycle_base = a: same rows as the oracle's slice of the whole run."""
+    blob = spec.fib_endless_program().to_bytes()
+    n = 300_000 + (1 << 17) + 3
+    want = oracle.run(blob, [], max_cycles=n, enable_execution_trace=True, keep_rows=(a, b))
+    res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run_window(a, b)
+    assert len(res.execution_trace) == b - a and res.delta_log.cycle_base == a
+    helpers.assert_rows_equal(res.execution_trace.rows(), want.rows)
+    res.close()

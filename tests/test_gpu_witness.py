@@ -21,15 +21,43 @@ MEM_PROGRAMS = ["mem_sw_lw", "timestamps", "loads_stores", "q9_access_at_own_pc"
                 "sha256_hello", "deferred_negative_and_overflow", "fib30"]
 
 
+@pytest.mark.parametrize("separate", [False, True], ids=["one_pass_csr", "separate_passes"])
 @pytest.mark.parametrize("name", MEM_PROGRAMS)
-def test_memory_ops_row_order_offsets_and_sorted(name):
+def test_memory_ops_row_order_offsets_and_sorted(name, separate):
+    """Both ways to the same columns: the single-pass expansion that also emits the CSR offsets and the shape flags (what the result
+    handle uses), and the stand-alone entry points (binary-search CSR, expansion, sort with its own check pass)."""
     from zkir_amd import pipeline as pl
     blob, inputs, cfg = programs.ALL[name]()
     log, want = _both(blob, inputs, cfg)
-    rows, offsets, srt = pl.memory_ops(log)
+    rows, offsets, srt = pl.memory_ops(log, separate_passes=separate)
     assert np.array_equal(rows.to_numpy(), want.memops)
     assert np.array_equal(offsets.cpu().numpy().view(np.uint64), want.row_memop_offsets)
     assert np.array_equal(srt.to_numpy(), want.sorted_memops)            # ExecutionResult::get_memory_trace, vm.rs:85-94
+
+
+def test_memory_ops_csr_with_long_gaps_between_ops():
+    """A program that touches memory rarely: thousands of rows without an op between two ops, ops in the first and the last row, a
+    tail of rows after the last op — the single-pass CSR fills every gap (short ones by the lane that sees the boundary, long ones
+    by its workgroup)."""
+    from zkir_amd import pipeline as pl
+    from zkir_amd.spec import Opcode as O, encode as E
+    A = programs.A
+    loop = lambda cnt: [A(3, 0, cnt), A(1, 1, 1), A(3, 3, -1), spec.bne(3, 0, -8)]          # noqa: E731 - 1 + 3 cnt rows without memory ops
+    code = ([E(O.SW, rs1=0, rs2=0, imm=0x4000)] + loop(5) + [A(5, 0, 0x2000), E(O.SW, rs1=5, rs2=1, imm=0)] + loop(3000) + [E(O.LW, 2, 5, imm=0)] + loop(20)
+            + [E(O.SW, rs1=5, rs2=1, imm=4), E(O.LW, 2, 5, imm=4)] + loop(700) + [E(O.LW, 2, 5, imm=0)])
+    for tail in ([programs.EB], loop(9000) + [programs.EB]):
+        blob = spec.Program.from_code(code + tail).to_bytes()
+        log, want = _both(blob, [], {})
+        assert len(want.memops) == 6 and want.memops["timestamp"][0] == 0
+        for separate in (False, True):
+            rows, offsets, srt = pl.memory_ops(log, separate_passes=separate)
+            assert np.array_equal(rows.to_numpy(), want.memops)
+            assert np.array_equal(offsets.cpu().numpy().view(np.uint64), want.row_memop_offsets)
+            assert np.array_equal(srt.to_numpy(), want.sorted_memops)
+    # no memory ops at all: every offset is zero
+    log, want = _both(spec.fib_endless_program().to_bytes(), [], dict(max_cycles=5000))
+    rows, offsets, srt = pl.memory_ops(log)
+    assert len(want.memops) == 0 and np.array_equal(offsets.cpu().numpy().view(np.uint64), want.row_memop_offsets)
 
 
 def test_memory_sort_fallback_on_wrapping_addresses():

@@ -1,6 +1,7 @@
-"""N>1 path on CPU: two gloo ranks shard the rows exactly as bench.py does on GPUs (rank g owns rows
-[g*n/2, (g+1)*n/2) with its own register snapshot, no data-path collective), expand their shard with the
-numpy stand-in for K1, and an all_gather of per-shard digests reproduces the unsharded trace."""
+"""N>1 path on CPU: two gloo ranks shard the rows exactly as bench.py does on GPUs — rank g executes rows [0, g*n/2) of the run
+UNTRACED and traces its own rows [g*n/2, (g+1)*n/2) (zkir_interpret_window: own register snapshot, no transport between the ranks,
+no data-path collective), cuts its commit shard and its overlapping segment shard out of the window, expands them with the numpy
+stand-in for K1, and an all_gather of per-shard digests reproduces the trace of the whole run."""
 import hashlib
 import os
 import socket
@@ -28,18 +29,26 @@ def _free_port():
 def _worker(rank, world, port, blob, out_q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    log = rt.interpret(blob, config=rt.VMConfig(max_cycles=N_ROWS, enable_execution_trace=True), tile_rows=256)
     per = N_ROWS // world
-    sh = log.shard(rank * per, (rank + 1) * per)
+    lo = rank * (per - 1)                                   # the window covers the commit shard and the segment-proof shard (one row earlier per rank)
+    win = rt.interpret(blob, config=rt.VMConfig(max_cycles=N_ROWS, enable_execution_trace=True), tile_rows=256, window=(lo, (rank + 1) * per))
+    assert win.cycle_base == lo and win.n_rows == (rank + 1) * per - lo and win.window_open == (rank < world - 1)
+    sh = win.shard(rank * per, (rank + 1) * per)
+    seg = win.shard(rank * (per - 1), rank * (per - 1) + per)
     rows = helpers.expand_delta_log(sh)
     rows["cycle"] += np.uint64(sh.cycle_base)
+    seg_rows = helpers.expand_delta_log(seg)
+    seg_rows["cycle"] += np.uint64(seg.cycle_base)
     digest = torch.tensor(list(hashlib.sha256(rows.tobytes()).digest()), dtype=torch.uint8)
+    seg_digest = hashlib.sha256(seg_rows.tobytes()).digest()
+    all_seg = [None] * world
+    dist.all_gather_object(all_seg, seg_digest)
     gathered = [torch.zeros(32, dtype=torch.uint8) for _ in range(world)]
     dist.all_gather(gathered, digest)                       # the only collective of the path: 32 bytes per rank
     n_ev = torch.tensor([len(sh.reg_events)], dtype=torch.int64)
     dist.all_reduce(n_ev)
     if rank == 0:
-        out_q.put(([bytes(g.tolist()) for g in gathered], int(n_ev.item())))
+        out_q.put(([bytes(g.tolist()) for g in gathered], int(n_ev.item()), all_seg))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,7 +61,7 @@ def test_two_rank_row_sharding_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, blob, q)) for r in range(2)]
     for p in procs:
         p.start()
-    digests, n_ev = q.get(timeout=120)
+    digests, n_ev, seg_digests = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -61,3 +70,4 @@ def test_two_rank_row_sharding_gloo():
     half = N_ROWS // 2
     assert digests == [hashlib.sha256(full[:half].tobytes()).digest(), hashlib.sha256(full[half:].tobytes()).digest()]
     assert n_ev >= len(log.reg_events)          # each shard carries its own 16 snapshot events
+    assert seg_digests == [hashlib.sha256(full[g * (half - 1):g * (half - 1) + half].tobytes()).digest() for g in range(2)]

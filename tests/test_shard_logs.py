@@ -82,3 +82,64 @@ def test_unaligned_and_overlapping_shards_expand_to_their_rows(name):
         helpers.assert_rows_equal(rows, whole[a:b])
         sh.close()
     log.close()
+
+
+def _same_log(a, b, what):
+    """Two delta logs describe the same rows: every array equal, same base / tiling."""
+    assert a.n_rows == b.n_rows and a.cycle_base == b.cycle_base and a.tile_rows == b.tile_rows, what
+    for name in ("pc", "inst", "reg_events", "tile_ev_off", "tile_snap", "mem_events", "rc_events", "rc_offsets", "rc_cycles", "norm_events", "sha_blocks"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert x.shape == y.shape and np.array_equal(x, y), f"{what}: {name} differs"
+
+
+@pytest.mark.parametrize("name", sorted(_CASES))
+def test_trace_windows_equal_the_shards_of_the_whole_run(name):
+    """zkir_interpret_window (multi-GPU: rank g fast-forwards untraced to its first row, then traces its own rows) records exactly what
+    cutting rows [a, b) out of the whole run's log gives — tile-aligned and unaligned windows, windows that reach past the end of
+    the run, empty ones — and a window can itself be sharded with absolute row numbers (commit shard + overlapping segment shard)."""
+    blob, inputs, cfg = _CASES[name]
+    vmc = rt.VMConfig(enable_execution_trace=True, **cfg)
+    try:
+        log = rt.interpret(blob, inputs, vmc, tile_rows=256)
+    except rt.RuntimeError:
+        pytest.skip("program errors out")
+    n = log.n_rows
+    whole = helpers.expand_delta_log(log)
+    for a, b in [(0, n), (256, 768), (0, 256), (512, n), (512, n + 1000), (300, 811), (n - 1, n), (1, 2), (n, n + 5), (n + 7, n + 9), (255, 257)]:
+        if a > b:
+            continue
+        win = rt.interpret(blob, inputs, vmc, tile_rows=256, window=(a, b))
+        lo, hi = min(a, n), min(b, n)
+        assert win.n_rows == hi - lo and win.cycle_base == lo, (a, b)
+        assert win.window_open == (b < n), (a, b)                 # stopped at the window's end, or at the run's halt
+        if hi > lo:
+            helpers.check_tile_index(win)
+            rows = helpers.expand_delta_log(win)
+            rows["cycle"] += np.uint64(lo)
+            helpers.assert_rows_equal(rows, whole[lo:hi])
+            ref = log.shard(lo, hi)
+            if lo % 256 == 0:                                     # same tiling: the logs are identical array by array
+                _same_log(win, ref, f"window {a}:{b}")
+            else:
+                assert np.array_equal(win.mem_events, ref.mem_events) and np.array_equal(win.rc_events, ref.rc_events) and np.array_equal(win.rc_cycles, ref.rc_cycles)
+                assert np.array_equal(win.norm_events, ref.norm_events) and np.array_equal(win.sha_blocks, ref.sha_blocks)
+            ref.close()
+        if not win.window_open:
+            assert win.cycles == log.cycles and win.halt_reason == log.halt_reason and win.outputs == log.outputs
+        else:
+            assert win.cycles == b
+        win.close()
+    # a window sharded further, absolute rows: what bench.py --gpus N does (commit shard [g n, (g+1) n) and segment shard [g (n-1), g (n-1) + n))
+    a, b = (300, min(n, 1100)) if n > 900 else (n // 4, n - 3)
+    win = rt.interpret(blob, inputs, vmc, tile_rows=256, window=(a, b))
+    for lo, hi in [(a, b), (a + 1, b), (a + 212, min(b, a + 212 + 256)), (min(512, b - 1), b), (a, a + 1)]:
+        sh, ref = win.shard(lo, hi), log.shard(lo, hi)
+        rows = helpers.expand_delta_log(sh)
+        rows["cycle"] += np.uint64(lo)
+        helpers.assert_rows_equal(rows, whole[lo:hi])
+        assert sh.cycle_base == lo and np.array_equal(sh.mem_events, ref.mem_events) and np.array_equal(sh.norm_events, ref.norm_events)
+        assert np.array_equal(sh.sha_blocks, ref.sha_blocks) and np.array_equal(sh.rc_events, ref.rc_events) and np.array_equal(sh.rc_cycles, ref.rc_cycles)
+        sh.close(); ref.close()
+    with pytest.raises(rt.RuntimeError):
+        win.shard(a - 1, b)
+    win.close(); log.close()

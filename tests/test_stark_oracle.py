@@ -5,6 +5,7 @@ structural properties, Merkle recomputation."""
 import numpy as np
 import pytest
 
+from bench_cpu import api as cpu_port
 from oracle import api as oracle, stark_api as so
 from zkir_amd import spec
 
@@ -187,13 +188,13 @@ def test_main_trace_columns_and_commit():
 
 
 def test_cpu_commit_port_matches_the_oracle():
-    """oracle/cpu_commit_port.cpp (the multi-threaded Montgomery port bench.py times as the CPU figure of the commit stage) computes
+    """bench_cpu/cpu_commit_port.cpp (the multi-threaded Montgomery port bench.py times as the CPU figure of the commit stage) computes
     the same root as the naive oracle."""
     for prog, n in ((spec.fib_endless_program(), 300), (spec.sha256_chain_program(), 1024)):
         blob = prog.to_bytes()
         rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
         pub = so.public_inputs(len(rows), blob)
-        root, t_lde, t_merkle = so.commit_port(so.main_trace(rows, pub), 3)
+        root, t_lde, t_merkle = cpu_port.commit_port(so.main_trace(rows, pub), 3)
         assert np.array_equal(root, so.commit_trace(rows, 1, pub=pub)) and t_lde > 0 and t_merkle > 0
 
 

@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -77,13 +78,14 @@ void zkir_delta_log_free(zkir_delta_log* log) { delete log; }
 int zkir_delta_log_shard(const zkir_delta_log* src, uint64_t row_begin, uint64_t row_end, zkir_delta_log** out) {
   if (!src || !out) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: null argument"}); return ZKIR_ERR_ARGUMENT; }
   *out = nullptr;
-  const uint64_t T = src->tile_rows;
-  if (row_begin > row_end || row_end > src->n_rows || src->cycle_base != 0) {
-    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: need 0 <= row_begin <= row_end <= n_rows and an unsharded source"});
+  const uint64_t T = src->tile_rows, B = src->cycle_base;                         // the source may itself be a window / shard: rows are absolute
+  if (row_begin > row_end || row_begin < B || row_end > B + src->n_rows) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_delta_log_shard: need cycle_base <= row_begin <= row_end <= cycle_base + n_rows of the source log"});
     return ZKIR_ERR_ARGUMENT;
   }
+  const uint64_t rb = row_begin - B, re = row_end - B;                            // positions inside the source
   zkir_delta_log* d = new zkir_delta_log();
-  d->cycles = src->cycles; d->halt_kind = src->halt_kind; d->halt_code = src->halt_code; d->outputs = src->outputs;
+  d->cycles = src->cycles; d->halt_kind = src->halt_kind; d->halt_code = src->halt_code; d->outputs = src->outputs; d->window_open = src->window_open;
   d->tile_rows = src->tile_rows; d->rc_chunk_bits = src->rc_chunk_bits;
   d->n_rows = row_end - row_begin; d->cycle_base = row_begin;
   d->rc_offsets.push_back(0);
@@ -94,69 +96,84 @@ int zkir_delta_log_shard(const zkir_delta_log* src, uint64_t row_begin, uint64_t
     d->rc_cycles.push_back(src->rc_cycles[k]);
   }
   if (d->n_rows == 0) { d->tile_ev_off.push_back(0); *out = d; return ZKIR_OK; }
-  if (row_begin % T != 0) {
+  // side logs: mem-event rows are relative to the log they sit in; normalization cycles and SHA timestamps are absolute
+  auto side_logs = [&] {
+    for (size_t m = 0; m < src->mem_events.size(); m++) {
+      zkir_mem_event me = src->mem_events[m];
+      if (me.row >= rb && me.row < re) { me.row -= (uint32_t)rb; d->mem_events.push(me); }
+    }
+    for (size_t m = 0; m < src->norm_events.size(); m++) if (src->norm_events[m].cycle >= row_begin && src->norm_events[m].cycle < row_end) d->norm_events.push(src->norm_events[m]);
+    for (size_t m = 0; m < src->sha_blocks.size(); m++) if (src->sha_blocks[m].timestamp >= row_begin && src->sha_blocks[m].timestamp < row_end) d->sha_blocks.push(src->sha_blocks[m]);
+  };
+  d->pc.append(src->pc.data() + rb, d->n_rows);
+  d->inst.append(src->inst.data() + rb, d->n_rows);
+  if (rb % T != 0) {
     // A cut that is not on a tile boundary (segment proofs overlap by ONE row, so their first rows are at g (S - 1)): the shard gets
     // its own tiling from row_begin.  Snapshot = the source tile's snapshot advanced over the events visible by row_begin; then one
     // pass over the shard's events rebuilds tile_ev_off (first event with vis > tile start) and tile_snap (last event per register
     // with vis <= tile start), the conventions of include/zkir_amd.h.
-    const uint64_t ts = row_begin / T, nt = (d->n_rows + T - 1) / T;
+    const uint64_t ts = rb / T, nt = (d->n_rows + T - 1) / T;
     const zkir_reg_event* ev = src->reg_events.data();
     const size_t n_ev = src->reg_events.size();
     uint32_t snap[16];
     for (int r = 0; r < 16; r++) snap[r] = src->tile_snap[ts * 16 + r];
     size_t e0 = src->tile_ev_off[ts];
-    while (e0 < n_ev && ev[e0].vis <= row_begin) { snap[ev[e0].reg] = (uint32_t)e0; e0++; }
-    const uint64_t end_vis = row_begin + nt * T;                                  // events up to the end of the shard's last tile
+    while (e0 < n_ev && ev[e0].vis <= rb) { snap[ev[e0].reg] = (uint32_t)e0; e0++; }
+    const uint64_t end_vis = rb + nt * T;                                         // events up to the end of the shard's last tile
     size_t e1 = e0;
     while (e1 < n_ev && ev[e1].vis <= end_vis) e1++;
-    d->pc.append(src->pc.data() + row_begin, d->n_rows);
-    d->inst.append(src->inst.data() + row_begin, d->n_rows);
     for (int r = 0; r < 16; r++) { zkir_reg_event e = ev[snap[r]]; e.vis = 0; d->reg_events.push(e); }
-    for (size_t k = e0; k < e1; k++) { zkir_reg_event e = ev[k]; e.vis -= (uint32_t)row_begin; d->reg_events.push(e); }
+    for (size_t k = e0; k < e1; k++) { zkir_reg_event e = ev[k]; e.vis -= (uint32_t)rb; d->reg_events.push(e); }
     uint32_t last[16];
     for (int r = 0; r < 16; r++) last[r] = (uint32_t)r;
     size_t k = e0;
     for (uint64_t j = 0; j < nt; j++) {
-      const uint64_t start = row_begin + j * T;
+      const uint64_t start = rb + j * T;
       while (k < e1 && ev[k].vis <= start) { last[ev[k].reg] = (uint32_t)(k - e0 + 16); k++; }
       d->tile_ev_off.push_back((uint32_t)(k - e0 + 16));
       for (int r = 0; r < 16; r++) d->tile_snap.push_back(last[r]);
     }
     d->tile_ev_off.push_back((uint32_t)(e1 - e0 + 16));
-    for (size_t m = 0; m < src->mem_events.size(); m++) {
-      zkir_mem_event me = src->mem_events[m];
-      if (me.row >= row_begin && me.row < row_end) { me.row -= (uint32_t)row_begin; d->mem_events.push(me); }
-    }
-    for (size_t m = 0; m < src->norm_events.size(); m++) if (src->norm_events[m].cycle >= row_begin && src->norm_events[m].cycle < row_end) d->norm_events.push(src->norm_events[m]);
-    for (size_t m = 0; m < src->sha_blocks.size(); m++) if (src->sha_blocks[m].timestamp >= row_begin && src->sha_blocks[m].timestamp < row_end) d->sha_blocks.push(src->sha_blocks[m]);
+    side_logs();
     *out = d;
     return ZKIR_OK;
   }
-  const uint64_t t0 = row_begin / T, t1 = (row_end + T - 1) / T;                   // tiles [t0, t1)
+  const uint64_t t0 = rb / T, t1 = (re + T - 1) / T;                               // tiles [t0, t1)
   const uint32_t e0 = src->tile_ev_off[t0];
   // events up to the end of the last tile; for an interior cut that is tile_ev_off[t1], for the run's tail all remaining
   const uint32_t e1 = src->tile_ev_off[t1];
-  d->pc.append(src->pc.data() + row_begin, d->n_rows);
-  d->inst.append(src->inst.data() + row_begin, d->n_rows);
   for (int r = 0; r < 16; r++) {                                                   // snapshot at row_begin
     zkir_reg_event e = src->reg_events[src->tile_snap[t0 * 16 + r]];
     e.vis = 0;
     d->reg_events.push(e);
   }
-  for (uint32_t k = e0; k < e1; k++) { zkir_reg_event e = src->reg_events[k]; e.vis -= (uint32_t)row_begin; d->reg_events.push(e); }
+  for (uint32_t k = e0; k < e1; k++) { zkir_reg_event e = src->reg_events[k]; e.vis -= (uint32_t)rb; d->reg_events.push(e); }
   for (uint64_t t = t0; t <= t1; t++) d->tile_ev_off.push_back(src->tile_ev_off[t] - e0 + 16);
   for (uint64_t t = t0; t < t1; t++)
     for (int r = 0; r < 16; r++) { const uint32_t i = src->tile_snap[t * 16 + r]; d->tile_snap.push_back(i < e0 ? (uint32_t)r : i - e0 + 16); }
-  for (size_t k = 0; k < src->mem_events.size(); k++) {
-    zkir_mem_event m = src->mem_events[k];
-    if (m.row >= row_begin && m.row < row_end) { m.row -= (uint32_t)row_begin; d->mem_events.push(m); }
-  }
-  for (size_t k = 0; k < src->norm_events.size(); k++) if (src->norm_events[k].cycle >= row_begin && src->norm_events[k].cycle < row_end) d->norm_events.push(src->norm_events[k]);
-  for (size_t k = 0; k < src->sha_blocks.size(); k++) if (src->sha_blocks[k].timestamp >= row_begin && src->sha_blocks[k].timestamp < row_end) d->sha_blocks.push(src->sha_blocks[k]);
+  side_logs();
   *out = d;
   return ZKIR_OK;
 }
 uint64_t zkir_delta_log_cycle_base(const zkir_delta_log* l) { return l->cycle_base; }
+int zkir_delta_log_window_open(const zkir_delta_log* l) { return l->window_open ? 1 : 0; }
+
+int zkir_interpret_window(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, uint32_t tile_rows,
+                          uint64_t row_begin, uint64_t row_end, zkir_delta_log** out) {
+  if (!out || !cfg || (!blob && len)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_interpret_window: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  *out = nullptr;
+  if (!cfg->enable_execution_trace) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_interpret_window: a trace window needs enable_execution_trace"}); return ZKIR_ERR_ARGUMENT; }
+  zkir_delta_log* log = new zkir_delta_log();
+  zkir::Status st;
+  try {
+    st = zkir::interpret(blob, len, inputs, n_inputs, *cfg, tile_rows, *log, nullptr, row_begin, row_end);
+  } catch (const std::bad_alloc&) {
+    st = {ZKIR_ERR_OTHER, "out of host memory while recording the delta log"};
+  }
+  if (!st.ok()) { zkir::set_last_error(st); delete log; return st.code; }
+  *out = log;
+  return ZKIR_OK;
+}
 
 uint64_t zkir_delta_log_cycles(const zkir_delta_log* l) { return l->cycles; }
 int zkir_delta_log_halt_kind(const zkir_delta_log* l) { return l->halt_kind; }
@@ -222,13 +239,15 @@ static void free_trace(zkir_result* r) {
 // Uploads what the running interpreter has finished (zkir::Progress) and fills those tiles, on its own thread and stream, so that
 // the H2D copy of the delta log and K1 hide under the interpretation instead of following it.
 // streams are recycled (creating and destroying one per call costs more than the copies it carries)
+// The pool is keyed by DEVICE: a hipStream_t belongs to the device that was current when it was created, and one process may drive
+// several GPUs (hipSetDevice + one zkir_exec per device); a stream of device 0 must never carry the copies and K1 of a run on device 1.
 static std::mutex g_stream_mu;
-static std::vector<hipStream_t> g_streams;
-static hipError_t acquire_stream(hipStream_t* s) {
-  { std::lock_guard<std::mutex> lk(g_stream_mu); if (!g_streams.empty()) { *s = g_streams.back(); g_streams.pop_back(); return hipSuccess; } }
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+static std::map<int, std::vector<hipStream_t>> g_streams;
+static hipError_t acquire_stream(int device, hipStream_t* s) {
+  { std::lock_guard<std::mutex> lk(g_stream_mu); auto& v = g_streams[device]; if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; } }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);      // created on the calling thread's current device (= `device`, set by the caller)
 }
-static void release_stream(hipStream_t s) { std::lock_guard<std::mutex> lk(g_stream_mu); g_streams.push_back(s); }
+static void release_stream(int device, hipStream_t s) { std::lock_guard<std::mutex> lk(g_stream_mu); g_streams[device].push_back(s); }
 
 struct ExecStreamer {
   zkir_result* r; const zkir_delta_log* log; zkir::Progress prog; uint64_t max_cycles; int device;
@@ -241,7 +260,7 @@ struct ExecStreamer {
   zkir_trace_fill_args args() const {
     zkir_trace_fill_args a{};
     a.events = (const zkir_reg_event*)r->d_events; a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off; a.tile_snap = (const uint32_t*)r->d_tile_snap;
-    a.n_rows = r->cap_rows; a.cycle_base = 0; a.tile_rows = log->tile_rows; a.n_events = 0; a.out = r->cols;
+    a.n_rows = r->cap_rows; a.cycle_base = log->cycle_base; a.tile_rows = log->tile_rows; a.n_events = 0; a.out = r->cols;
     return a;
   }
   // copy rows / events / tile index up to (tiles, rows, events) and fill the new complete tiles
@@ -275,11 +294,16 @@ struct ExecStreamer {
         const uint64_t rows = prog.rows.load(std::memory_order_relaxed), events = prog.events.load(std::memory_order_relaxed);
         if (!active) {
           const uint64_t cap = (max_cycles + T - 1) / T * T;
-          if (acquire_stream(&stream) != hipSuccess ||
-              alloc_trace(r, cap, log->reg_events.capacity(), log->tile_ev_off.capacity(), log->tile_snap.capacity()) != ZKIR_OK) { failed = true; error = zkir_last_error(); }
-          active = !failed;
+          // The streaming buffers are sized for max_cycles rows (the columns are strided by the capacity, they cannot grow in place):
+          // 372 B/row + 40 B/row of log, 27 GB at 2^26.  If the device cannot give that much — several concurrent calls, a run
+          // that will halt long before max_cycles — streaming is ABANDONED, not failed: zkir_exec then takes the plain path,
+          // which allocates for the rows the run actually produced.
+          if (acquire_stream(device, &stream) != hipSuccess) { stream = nullptr; abandoned = true; }
+          else if (alloc_trace(r, cap, log->reg_events.capacity(), log->tile_ev_off.capacity(), log->tile_snap.capacity()) != ZKIR_OK) { (void)hipGetLastError(); free_trace(r); abandoned = true; }
+          if (abandoned) { prog.consumer_idle.store(true); break; }
+          active = true;
         }
-        if (!failed) advance(t, rows, events, t + 1);
+        advance(t, rows, events, t + 1);
         prog.consumer_idle.store(true);
         if (failed) break;
       } else if (fin) {
@@ -292,9 +316,12 @@ struct ExecStreamer {
   }
 };
 
-int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, zkir_result** out) {
+// zkir_exec and zkir_exec_window: rows [row_begin, row_end) of the run (the whole run for zkir_exec) interpreted, uploaded and filled
+static int exec_impl(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, uint64_t row_begin, uint64_t row_end,
+                     zkir_result** out) {
   if (!out || !cfg) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_exec: null argument"}); return ZKIR_ERR_ARGUMENT; }
   *out = nullptr;
+  if (row_begin > row_end) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_exec_window: row_begin > row_end"}); return ZKIR_ERR_ARGUMENT; }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
     zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_exec: no usable HIP device (the product path has no CPU fallback)"});
@@ -308,18 +335,19 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
   // Long traced runs stream: a second host thread uploads the finished part of the delta log and launches K1 on it while the
   // interpreter keeps running (ZKIR_EXEC_STREAM=0 turns it off).  Everything else takes the plain path: interpret, upload, fill.
   static const bool stream_ok = !(getenv("ZKIR_EXEC_STREAM") && atoi(getenv("ZKIR_EXEC_STREAM")) == 0);
-  const bool streaming = stream_ok && cfg->enable_execution_trace && cfg->max_cycles >= (1ull << 17) && cfg->max_cycles <= (1ull << 26);
+  const uint64_t win_hi = row_end < cfg->max_cycles ? row_end : cfg->max_cycles, win_rows = win_hi > row_begin ? win_hi - row_begin : 0;   // rows the trace can have at most
+  const bool streaming = stream_ok && cfg->enable_execution_trace && win_rows >= (1ull << 17) && win_rows <= (1ull << 26);
   std::unique_ptr<ExecStreamer> st;
   if (streaming) {
     st.reset(new ExecStreamer());
-    st->r = r; st->log = log; st->max_cycles = cfg->max_cycles; st->device = 0;
+    st->r = r; st->log = log; st->max_cycles = win_rows; st->device = 0;
     (void)hipGetDevice(&st->device);
   }
   auto t0 = clk::now();
   zkir::Status status;
   if (streaming) st->th = std::thread([&] { st->body(); });
   try {
-    status = zkir::interpret(blob, len, inputs, n_inputs, *cfg, 0, *log, streaming ? &st->prog : nullptr);
+    status = zkir::interpret(blob, len, inputs, n_inputs, *cfg, 0, *log, streaming ? &st->prog : nullptr, row_begin, row_end);
   } catch (const std::bad_alloc&) {
     status = {ZKIR_ERR_OTHER, "out of host memory while recording the delta log"};
   }
@@ -357,7 +385,7 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
         a.events = (const zkir_reg_event*)r->d_events;
         a.tile_ev_off = (const uint32_t*)r->d_tile_ev_off;
         a.tile_snap = (const uint32_t*)r->d_tile_snap;
-        a.n_rows = n; a.cycle_base = 0; a.tile_rows = T; a.n_events = (uint32_t)log->reg_events.size();
+        a.n_rows = n; a.cycle_base = log->cycle_base; a.tile_rows = T; a.n_events = (uint32_t)log->reg_events.size();
         a.out = r->cols;
         rc = zkir_trace_fill_launch(&a, s);
         if (rc != ZKIR_OK) goto fail_rc;
@@ -368,15 +396,27 @@ int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_
       HIP_TRY(hipStreamSynchronize(st->stream)); free_trace(r);
     }
   }
-  if (streaming && st->stream) release_stream(st->stream);
+  if (streaming && st->stream) release_stream(st->device, st->stream);
   *out = r;
   return ZKIR_OK;
 fail:
   rc = ZKIR_ERR_DEVICE;
 fail_rc:
-  if (streaming && st && st->stream) { (void)hipStreamSynchronize(st->stream); release_stream(st->stream); }
+  if (streaming && st && st->stream) { (void)hipStreamSynchronize(st->stream); release_stream(st->device, st->stream); }
   zkir_result_free(r);
   return rc;
+}
+
+int zkir_exec(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, zkir_result** out) {
+  return exec_impl(blob, len, inputs, n_inputs, cfg, 0, ~0ull, out);
+}
+
+// One GPU's share of a run executed on THIS rank: rows [0, row_begin) are executed untraced (the state at row_begin cannot be had any
+// other way: execution is sequential), rows [row_begin, row_end) are traced, uploaded and filled while the interpreter runs.
+int zkir_exec_window(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, uint64_t row_begin, uint64_t row_end,
+                     zkir_result** out) {
+  if (cfg && !cfg->enable_execution_trace) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_exec_window: a trace window needs enable_execution_trace"}); return ZKIR_ERR_ARGUMENT; }
+  return exec_impl(blob, len, inputs, n_inputs, cfg, row_begin, row_end, out);
 }
 
 // The drop-in handle for a ROW SHARD of a finished interpretation (multi-GPU: every device takes one; segment proofs: shards that share
@@ -474,6 +514,7 @@ int zkir_result_copy_column(const zkir_result* r, int field, int reg, void* dst)
     if (_e != hipSuccess) {                                                                            \
       zkir::set_last_error({ZKIR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)});      \
       if (staging) (void)hipFree(staging);                                                             \
+      if (*owned) { (void)hipFree(*owned); *owned = nullptr; }   /* nothing half-built stays in the handle */ \
       return ZKIR_ERR_DEVICE;                                                                          \
     }                                                                                                  \
   } while (0)
@@ -490,6 +531,7 @@ int zkir_result_memory_trace(zkir_result* r, zkir_memory_witness* out) {
     const zkir_delta_log* log = r->log;
     const uint64_t n = log->mem_events.size(), rows = log->n_rows;
     void* staging = nullptr;
+    void** owned = &r->d_mem;
     r->mem = zkir_memory_witness{};
     r->mem.n_ops = n; r->mem.n_rows = rows;
     const size_t per_cols = 4 * padded(n * 8) + padded(n * 4) + 3 * padded(n);
@@ -503,10 +545,10 @@ int zkir_result_memory_trace(zkir_result* r, zkir_memory_witness* out) {
     zkir_mem_event* d_ev = (zkir_mem_event*)staging;
     uint8_t* scratch = (uint8_t*)staging + ((n * sizeof(zkir_mem_event) + 255) & ~(size_t)255);
     if (n) HIP_TRYW(hipMemcpyAsync(d_ev, log->mem_events.data(), n * sizeof(zkir_mem_event), hipMemcpyHostToDevice, nullptr));
-    int rc = zkir_memops_row_offsets_launch(d_ev, n, rows, offs, nullptr);
-    if (rc == ZKIR_OK) rc = zkir_memops_expand_launch(d_ev, n, log->cycle_base, &r->mem.row_order, nullptr);
-    if (rc == ZKIR_OK) rc = zkir_memops_sort_launch(d_ev, n, rows, log->cycle_base, offs, scratch, &r->mem.sorted, nullptr);
-    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    // two passes over the events: expansion + CSR offsets + shape flags, then the sort by rank
+    int rc = zkir_memops_expand_csr_launch(d_ev, n, rows, log->cycle_base, &r->mem.row_order, offs, scratch, nullptr);
+    if (rc == ZKIR_OK) rc = zkir_memops_sort_prepared_launch(d_ev, n, log->cycle_base, offs, scratch, &r->mem.sorted, nullptr);
+    if (rc != ZKIR_OK) { (void)hipFree(staging); (void)hipFree(*owned); *owned = nullptr; return rc; }
     HIP_TRYW(hipStreamSynchronize(nullptr));
     (void)hipFree(staging);
     r->mem_built = true;
@@ -522,6 +564,7 @@ int zkir_result_range_check_witnesses(zkir_result* r, zkir_range_check_witness* 
     const zkir_delta_log* log = r->log;
     const uint64_t n = log->rc_events.size();
     void* staging = nullptr;
+    void** owned = &r->d_rc;
     r->rc = zkir_range_check_witness{};
     r->rc.n_checks = n; r->rc.n_witnesses = log->rc_offsets.size() - 1; r->rc.witness_offsets = log->rc_offsets.data();
     r->rc.witness_cycles = log->rc_cycles.data();
@@ -535,7 +578,7 @@ int zkir_result_range_check_witnesses(zkir_result* r, zkir_range_check_witness* 
     HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_rc_event) + 256));
     if (n) HIP_TRYW(hipMemcpyAsync(staging, log->rc_events.data(), n * sizeof(zkir_rc_event), hipMemcpyHostToDevice, nullptr));
     const int rc = zkir_range_check_expand_launch((const zkir_rc_event*)staging, n, log->rc_chunk_bits, value, pc, chunks, r->rc.chunk_stride, mult, nullptr);
-    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    if (rc != ZKIR_OK) { (void)hipFree(staging); (void)hipFree(*owned); *owned = nullptr; return rc; }
     HIP_TRYW(hipStreamSynchronize(nullptr));
     (void)hipFree(staging);
     r->rc_built = true;
@@ -551,6 +594,7 @@ int zkir_result_normalization_witnesses(zkir_result* r, zkir_normalization_witne
     const zkir_delta_log* log = r->log;
     const uint64_t n = log->norm_events.size();
     void* staging = nullptr;
+    void** owned = &r->d_norm;
     r->norm = zkir_normalization_witness{};
     r->norm.n_events = n;
     HIP_TRYW(hipMalloc(&r->d_norm, 4 * padded(n * 8) + 4 * padded(n * 4) + 2 * padded(n) + 256));
@@ -562,7 +606,7 @@ int zkir_result_normalization_witnesses(zkir_result* r, zkir_normalization_witne
     HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_norm_event) + 256));
     if (n) HIP_TRYW(hipMemcpyAsync(staging, log->norm_events.data(), n * sizeof(zkir_norm_event), hipMemcpyHostToDevice, nullptr));
     const int rc = zkir_norm_expand_launch((const zkir_norm_event*)staging, n, &c, nullptr);
-    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    if (rc != ZKIR_OK) { (void)hipFree(staging); (void)hipFree(*owned); *owned = nullptr; return rc; }
     HIP_TRYW(hipStreamSynchronize(nullptr));
     (void)hipFree(staging);
     r->norm_built = true;
@@ -578,6 +622,7 @@ int zkir_result_sha256_witnesses(zkir_result* r, zkir_sha256_witness* out) {
     const zkir_delta_log* log = r->log;
     const uint64_t n = log->sha_blocks.size();
     void* staging = nullptr;
+    void** owned = &r->d_sha;
     r->sha = zkir_sha256_witness{};
     r->sha.n_blocks = n; r->sha.stride = (n + 63) & ~(uint64_t)63;
     HIP_TRYW(hipMalloc(&r->d_sha, padded(608 * r->sha.stride * 4) + padded(n * 8) + 256));
@@ -587,7 +632,7 @@ int zkir_result_sha256_witnesses(zkir_result* r, zkir_sha256_witness* out) {
     HIP_TRYW(hipMalloc(&staging, n * sizeof(zkir_sha_block) + 256));
     if (n) HIP_TRYW(hipMemcpyAsync(staging, log->sha_blocks.data(), n * sizeof(zkir_sha_block), hipMemcpyHostToDevice, nullptr));
     const int rc = zkir_sha256_chip_launch((const zkir_sha_block*)staging, n, cols, r->sha.stride, ts, nullptr);
-    if (rc != ZKIR_OK) { (void)hipFree(staging); return rc; }
+    if (rc != ZKIR_OK) { (void)hipFree(staging); (void)hipFree(*owned); *owned = nullptr; return rc; }
     HIP_TRYW(hipStreamSynchronize(nullptr));
     (void)hipFree(staging);
     r->sha_built = true;

@@ -74,6 +74,7 @@ class Buf {
     memcpy(p_ + n_, src, n * sizeof(T));
     n_ += n;
   }
+  void clear() { n_ = 0; }
   size_t size() const { return n_; }
   size_t capacity() const { return cap_; }
   const T* data() const { return p_; }
@@ -100,7 +101,8 @@ struct zkir_delta_log {
   int halt_kind = ZKIR_HALT_EBREAK;
   uint64_t halt_code = 0;
   uint64_t n_rows = 0;
-  uint64_t cycle_base = 0;       // TraceRow.cycle of row 0 (non-zero only for shards)
+  uint64_t cycle_base = 0;       // TraceRow.cycle of row 0 (non-zero only for shards and trace windows)
+  bool window_open = false;      // the interpretation stopped at the end of its trace window, not at a halt (zkir_interpret_window)
   uint32_t tile_rows = ZKIR_DEFAULT_TILE_ROWS;
   uint32_t rc_chunk_bits = 10;
   std::vector<uint64_t> outputs;
@@ -130,8 +132,9 @@ struct Progress {
 };
 
 Status parse_program(const uint8_t* blob, size_t len, ProgramView& pv);
+// win_begin / win_end: trace window in absolute rows (default: the whole run).  Rows before the window are executed untraced.
 Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log,
-                 Progress* progress = nullptr);
+                 Progress* progress = nullptr, uint64_t win_begin = 0, uint64_t win_end = ~0ull);
 
 // hashes.cpp — the digests behind syscalls 3/5/6 (zkir-runtime/src/crypto.rs uses sha2 / sha3::Keccak256 / blake3)
 void sha256(const uint8_t* data, size_t len, uint32_t out_be_words[8]);

@@ -241,7 +241,31 @@ class Machine {
     for (uint64_t i = 0; i < pv.n_code_words; i++) decode_slot(i);
   }
 
+  // Trace WINDOW (multi-GPU row shards, include/zkir_amd.h: zkir_interpret_window): execution is sequential, so the state at row
+  // `begin` is only known by executing rows [0, begin) — which this machine does in the UNTRACED specialisation of the loop (no log
+  // stores at all), then it switches to the traced one with the 16 snapshot events taken from the live registers, records rows
+  // [begin, end) relative to `begin` (cycle_base = begin) and stops.
+  void set_window(uint64_t begin, uint64_t end) { win_begin_ = begin; win_end_ = end; }
+
   Status run() {                                                       // the loop is specialised on the three mode flags
+    if (tracing_ && win_begin_ > 0) {                                  // fast-forward: same semantics, nothing recorded
+      tracing_ = false;
+      stop_at_ = win_begin_;
+      Status st = dispatch();
+      tracing_ = true;
+      if (!st.ok()) return st;
+      // side logs of the skipped rows do not belong to the window
+      log_.rc_events.clear(); log_.rc_offsets.clear(); log_.rc_cycles.clear(); log_.norm_events.clear(); log_.sha_blocks.clear();
+      base_ = cycle_;                                                  // = win_begin_, or the halting cycle if the run ended before the window
+      log_.cycle_base = base_;                                         // known to a streaming consumer before the first tile is published
+      if (halted_) { finish_log(true); log_.rc_offsets.push_back(0); return {}; }
+    }
+    stop_at_ = win_end_;
+    return dispatch();
+  }
+
+ private:
+  Status dispatch() {
     const int m = (tracing_ ? 4 : 0) | (deferred_ ? 2 : 0) | (range_ ? 1 : 0);
     switch (m) {
       case 0: return run_loop<false, false, false>(); case 1: return run_loop<false, false, true>();
@@ -250,8 +274,13 @@ class Machine {
       case 6: return run_loop<true, true, false>(); default: return run_loop<true, true, true>();
     }
   }
+  void finish_log(bool traced) {
+    log_.cycles = cycle_; log_.halt_kind = halt_kind_; log_.halt_code = halt_code_;
+    log_.n_rows = traced ? cycle_ - base_ : 0;
+    log_.cycle_base = base_;
+    log_.window_open = !halted_;                                       // stopped at the window's end, not at a halt
+  }
 
- private:
   template <bool TRACING, bool DEFERRED, bool RANGE> Status run_loop();
   // ---- register file with write tracking ----
   inline uint64_t rd(uint8_t r) const { return reg_[r]; }            // reg_[0] is never written, so it reads 0 (state.rs:76-82)
@@ -262,7 +291,7 @@ class Machine {
 
   // ---- data memory with the architectural-access log (memory.rs:243-253) ----
   inline void note(uint64_t addr, uint64_t value, bool is_write, uint8_t width) {
-    if (tracing_ && addr != fetch_pc_) log_.mem_events.push(zkir_mem_event{addr, value, (uint32_t)cycle_, (uint8_t)is_write, width, 0});  // Q9
+    if (tracing_ && addr != fetch_pc_) log_.mem_events.push(zkir_mem_event{addr, value, (uint32_t)(cycle_ - base_), (uint8_t)is_write, width, 0});  // Q9
   }
   inline Status misaligned(uint64_t addr, unsigned al) { return {ZKIR_ERR_MISALIGNED, "Misaligned access: address " + hexs(addr) + ", alignment " + std::to_string(al)}; }
   // Errors are rare: the hot path returns plain bools and the Status (with its message string) is only built on failure.
@@ -330,6 +359,7 @@ class Machine {
   uint32_t data_bits_;
 
   uint64_t pc_ = 0, fetch_pc_ = 0, cycle_ = 0;
+  uint64_t win_begin_ = 0, win_end_ = ~0ull, stop_at_ = ~0ull, base_ = 0;   // trace window; rows of the log are cycle_ - base_
   uint64_t reg_[16]; BoundT bound_[16]; uint8_t state_[16];
   uint32_t dirty_ = 0;
   bool halted_ = false; int halt_kind_ = ZKIR_HALT_EBREAK; uint64_t halt_code_ = 0;
@@ -574,21 +604,22 @@ Status Machine::run_loop() {
       last_ev[r] = r;
     }
   }
-  log_.rc_offsets.push_back(0);
-  const uint64_t max_cycles = cfg_.max_cycles;
+  if (log_.rc_offsets.empty()) log_.rc_offsets.push_back(0);
+  const uint64_t max_cycles = cfg_.max_cycles, stop_at = stop_at_ < max_cycles ? stop_at_ : max_cycles, base = base_;
   // The loop runs tile by tile: the per-tile bookkeeping (tile index, output capacity) is done once per T rows and the rows
   // themselves are written through raw pointers (pc, instruction word, register events), so the per-instruction work is
   // fetch (pre-decoded image) -> execute -> at most a few 32-byte event stores.
   while (!halted_) {
     if (cycle_ >= max_cycles) { halted_ = true; halt_kind_ = ZKIR_HALT_CYCLE_LIMIT; break; }            // vm.rs:211-214
-    uint64_t chunk = T - (cycle_ & (T - 1));
-    if (chunk > max_cycles - cycle_) chunk = max_cycles - cycle_;
+    if (cycle_ >= stop_at) break;                                       // end of the trace window (or of the fast-forward): not a halt
+    uint64_t chunk = T - ((cycle_ - base) & (T - 1));
+    if (chunk > stop_at - cycle_) chunk = stop_at - cycle_;
     uint64_t* pc_out = nullptr; uint32_t* inst_out = nullptr; zkir_reg_event* ev_out = nullptr;
     uint32_t ev_base = 0;
     if (tracing_) {
-      if (cycle_ + chunk >= 0xFFFFFFF0ull || log_.reg_events.size() + 4 * chunk >= 0xFFFFFFC0ull)              // event / row indices are 32-bit (tile index, vis)
+      if (cycle_ - base + chunk >= 0xFFFFFFF0ull || log_.reg_events.size() + 4 * chunk >= 0xFFFFFFC0ull)       // event / row indices are 32-bit (tile index, vis)
         return {ZKIR_ERR_OTHER, "trace longer than 2^32-16 rows or 2^32-64 register events is not supported"};
-      if ((cycle_ & (T - 1)) == 0) {                                    // tile index: events visible at the tile's first row
+      if (((cycle_ - base) & (T - 1)) == 0) {                           // tile index: events visible at the tile's first row
         if (progress_ && progress_->stable.load(std::memory_order_relaxed) &&
             (log_.reg_events.size() + 4 * chunk > log_.reg_events.capacity() || log_.tile_ev_off.size() + 2 > log_.tile_ev_off.capacity() ||
              log_.pc.size() + chunk > log_.pc.capacity())) {            // a buffer is about to move: the consumer must let go of the log first
@@ -601,7 +632,7 @@ Status Machine::run_loop() {
           _mm_sfence();                                                 // the streaming stores of the finished tiles are visible
           const uint64_t t = log_.tile_ev_off.size() - 1;
           progress_->events.store(log_.reg_events.size(), std::memory_order_relaxed);
-          progress_->rows.store(cycle_, std::memory_order_relaxed);
+          progress_->rows.store(cycle_ - base, std::memory_order_relaxed);
           progress_->tiles.store(t, std::memory_order_release);
         }
       }
@@ -642,7 +673,7 @@ Status Machine::run_loop() {
         do {
           const int r = __builtin_ctz(m); m &= m - 1;
           last_ev[r] = ev_base + n_ev;
-          const zkir_reg_event e{reg_[r], bound_[r].payload, bound_[r].max_bits, (uint32_t)(cycle_ + 1), (uint8_t)r, state_[r], bound_[r].tag, {0, 0, 0, 0, 0}};
+          const zkir_reg_event e{reg_[r], bound_[r].payload, bound_[r].max_bits, (uint32_t)(cycle_ - base + 1), (uint8_t)r, state_[r], bound_[r].tag, {0, 0, 0, 0, 0}};
           __m128i lo, hi;
           memcpy(&lo, &e, 16); memcpy(&hi, (const char*)&e + 16, 16);
           _mm_stream_si128((__m128i*)(ev_out + n_ev), lo); _mm_stream_si128((__m128i*)(ev_out + n_ev) + 1, hi);   // 32-byte events on 16-byte aligned storage
@@ -664,32 +695,35 @@ Status Machine::run_loop() {
   }
   if (tracing_) _mm_sfence();                                           // streaming stores globally visible before the log is handed on
   if (tracing_) log_.tile_ev_off.push_back((uint32_t)log_.reg_events.size());
-  log_.cycles = cycle_; log_.halt_kind = halt_kind_; log_.halt_code = halt_code_;
-  log_.n_rows = tracing_ ? cycle_ : 0;
+  finish_log(tracing_);
   return {};
 }
 
 }  // namespace
 
 Status interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config& cfg, uint32_t tile_rows, DeltaLog& log,
-                 Progress* progress) {
+                 Progress* progress, uint64_t win_begin, uint64_t win_end) {
+  if (win_begin > win_end) return {ZKIR_ERR_ARGUMENT, "trace window: row_begin > row_end"};
   ProgramView pv;
   Status st = parse_program(blob, len, pv);
   if (!st.ok()) return st;
   if (pv.entry_point < 0x1000) {                                      // vm.rs:141-147 panics; reported as an error here
     return {ZKIR_ERR_BAD_PROGRAM, "Program appears to be in debug format (entry_point=" + hexs(pv.entry_point) + "). Use release format (zkir-llvm without --debug) for execution."};
   }
-  if (tile_rows == 0) tile_rows = cfg.max_cycles <= (1ull << 21) ? 256u : 512u;   // measured best on MI355X (profiles/r01_sweep_trace_fill.txt)
+  // rows the log can hold at most: the window, cut by max_cycles
+  const uint64_t hi = win_end < cfg.max_cycles ? win_end : cfg.max_cycles, cap_rows = hi > win_begin ? hi - win_begin : 0;
+  if (tile_rows == 0) tile_rows = cap_rows <= (1ull << 21) ? 256u : 512u;         // measured best on MI355X (profiles/r01_sweep_trace_fill.txt)
   if (tile_rows < 256 || tile_rows > 2048 || (tile_rows & (tile_rows - 1))) return {ZKIR_ERR_ARGUMENT, "tile_rows must be a power of two in 256..2048"};   // K1 instantiations (trace_fill.hip); 4096 would need 262 KB of LDS
   log.tile_rows = tile_rows;
-  if (cfg.enable_execution_trace && cfg.max_cycles <= (1ull << 28)) {
-    log.pc.reserve(cfg.max_cycles); log.inst.reserve(cfg.max_cycles);
+  if (cfg.enable_execution_trace && cap_rows <= (1ull << 28)) {
+    log.pc.reserve(cap_rows); log.inst.reserve(cap_rows);
     // with a streaming consumer the event log and the tile index must not move while it reads them: room for 1.25 events per row
     // (the fib loop writes 0.8) and for every tile; a run that needs more makes the consumer give up streaming (Progress::stable)
-    log.reg_events.reserve(progress ? cfg.max_cycles + cfg.max_cycles / 4 + 4096 : cfg.max_cycles + 16);
-    if (progress) { log.tile_ev_off.reserve(cfg.max_cycles / tile_rows + 4); log.tile_snap.reserve((cfg.max_cycles / tile_rows + 4) * 16); }
+    log.reg_events.reserve(progress ? cap_rows + cap_rows / 4 + 4096 : cap_rows + 16);
+    if (progress) { log.tile_ev_off.reserve(cap_rows / tile_rows + 4); log.tile_snap.reserve((cap_rows / tile_rows + 4) * 16); }
   }
   std::unique_ptr<Machine> m(new Machine(pv, inputs, n_inputs, cfg, log, progress));   // ~170 KB (icache): heap, released on every path
+  m->set_window(win_begin, win_end);
   return m->run();
 }
 

@@ -14,7 +14,9 @@
 // fused in one contiguous-chunk kernel.  HBM traffic per element and column: 8 B per strided pass, 12 B for the fused middle.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/zkir_amd.h"
@@ -255,9 +257,15 @@ __global__ __launch_bounds__(NT) void ntt_reg_kernel(uint4* __restrict__ data, u
   for (int k = 0; k < E; k++) x[base + (uint64_t)k * d * 2] = v[k];
 }
 
+// CUs of the CURRENT device, cached per device id (one process may drive several GPUs)
 inline unsigned cu_count() {
-  static const unsigned n = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256u; return (unsigned)p.multiProcessorCount; }();
-  return n;
+  static std::mutex mu;
+  static unsigned cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cached[dev]) { hipDeviceProp_t p; cached[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? (unsigned)p.multiProcessorCount : 256u; }
+  return cached[dev];
 }
 inline int persist() { static const int v = getenv("ZKIR_NTT_PERSIST") ? atoi(getenv("ZKIR_NTT_PERSIST")) : 1; return v; }
 
@@ -265,8 +273,10 @@ template <bool DIT, int R, int C, int NTH>
 void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int s0, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m, hipStream_t s) {
   constexpr size_t lds = 16u * 2 * ((1u << (2 * R + C)) + 4);
   auto k = ntt_strided_r4_kernel<DIT, R, C, NTH>;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  static std::atomic<uint64_t> attr_done{0};                                   // one bit per device id: the attribute is per (function, device)
+  int dev = 0; (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done.fetch_or(bit); }
   const uint32_t tiles = (uint32_t)(n >> (2 * R + C)), total = tiles * n_blocks;
   const unsigned per_cu = (unsigned)((160u << 10) / lds) > 0 ? (unsigned)((160u << 10) / lds) : 1u;       // workgroups resident per CU (LDS-limited)
   unsigned grid = persist() ? cu_count() * (per_cu > 8 ? 8 : per_cu) : total;

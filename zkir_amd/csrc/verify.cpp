@@ -112,7 +112,9 @@ void zkir_digest_bytes(const uint8_t* b, size_t n, uint32_t out[4]) {
 int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs, uint32_t deferred,
                           zkir_public_inputs* out) {
   if (!log || !out || (!blob && blob_len) || (!inputs && n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: null argument"}); return ZKIR_ERR_ARGUMENT; }
-  if (log->cycle_base != 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: needs the unsharded log of the run"}); return ZKIR_ERR_ARGUMENT; }
+  // cycles / outputs / halt reason must be those of the FINISHED run: the whole log, any shard of it, or the trace window of the
+  // rank that executed the run to its end (multi-GPU: the last rank) — not a window that stopped before the halt
+  if (log->window_open) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: this trace window ended before the run did (its outputs / halt reason are not the run's)"}); return ZKIR_ERR_ARGUMENT; }
   memset(out, 0, sizeof *out);
   out->n_real = log->cycles;
   out->deferred = deferred ? 1 : 0;

@@ -40,6 +40,44 @@ __global__ __launch_bounds__(NT) void memops_expand_kernel(const zkir_mem_event*
   if (i < n) put_memop(c, i, ev[i], cycle_base);
 }
 
+// The same expansion in ONE pass over the events that also produces the CSR row offsets and the per-row shape flags of the sort:
+// ops are ordered by row, so op i is the first op of its row iff ev[i-1].row != ev[i].row, and then offsets[r] = i for every row r in
+// (ev[i-1].row, ev[i].row] (rows without ops in between included); the op after the last one closes the table with offsets = n for
+// the remaining rows.  A lane fills short gaps itself; long ones (a program that touches memory rarely) are queued in LDS and filled by
+// the whole workgroup, so no lane ever loops over more than GAP_INLINE rows alone.  The shape flag (memops_segment_check_kernel's
+// test) needs the same neighbour.  Replaces a binary search per ROW over the event array (12x its algorithmic bytes in HBM traffic,
+// profiles/r02k_config4_pmc_traffic.txt) and a separate check pass that re-read all events.
+constexpr uint32_t GAP_INLINE = 32, GAP_QUEUE = 2 * NT;
+__global__ __launch_bounds__(NT) void memops_expand_csr_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, uint64_t n_rows, uint64_t cycle_base, zkir_memop_columns c,
+                                                                uint64_t* __restrict__ offsets, unsigned char* __restrict__ seg_bad) {
+  __shared__ uint64_t q_lo[GAP_QUEUE], q_hi[GAP_QUEUE], q_val[GAP_QUEUE];
+  __shared__ uint32_t q_n;
+  if (threadIdx.x == 0) q_n = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  auto fill = [&](uint64_t lo, uint64_t hi, uint64_t val) {      // offsets[lo..hi] = val (inclusive)
+    if (hi < lo) return;
+    if (hi - lo < GAP_INLINE) { for (uint64_t r = lo; r <= hi; r++) offsets[r] = val; return; }
+    const uint32_t k = atomicAdd(&q_n, 1u);                       // at most two gaps per lane (the last op also closes the table)
+    q_lo[k] = lo; q_hi[k] = hi; q_val[k] = val;
+  };
+  if (i < n) {
+    const zkir_mem_event e = ev[i];
+    put_memop(c, i, e, cycle_base);
+    if (i == 0) fill(0, e.row, 0);
+    else {
+      const zkir_mem_event p = ev[i - 1];                         // the neighbour's line is in L1/L2: no extra HBM traffic
+      if (p.row != e.row) fill((uint64_t)p.row + 1, e.row, i);
+      else if ((e.is_write < p.is_write) || (e.is_write == p.is_write && e.address < p.address)) seg_bad[e.row] = 1;
+    }
+    if (i == n - 1) fill((uint64_t)e.row + 1, n_rows, n);
+  }
+  __syncthreads();
+  const uint32_t qn = q_n;
+  for (uint32_t k = 0; k < qn; k++)
+    for (uint64_t r = q_lo[k] + threadIdx.x; r <= q_hi[k]; r += NT) offsets[r] = q_val[k];
+}
+
 // offsets[r] = number of ops with row < r  (ops are ordered by row); one thread per row, binary search
 __global__ __launch_bounds__(NT) void memops_row_offsets_kernel(const zkir_mem_event* __restrict__ ev, uint64_t n, uint64_t n_rows, uint64_t* __restrict__ offsets) {
   const uint64_t r = (uint64_t)blockIdx.x * NT + threadIdx.x;
@@ -261,7 +299,7 @@ __global__ __launch_bounds__(NT) void sha256_chip_x4_kernel(const zkir_sha_block
     uint32_t wt[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      if (t < 16) wt[q] = w[q][t];
+      if constexpr (t < 16) wt[q] = w[q][t];
       else {
         const uint32_t w15 = w[q][(t + 1) & 15], w2 = w[q][(t + 14) & 15];
         wt[q] = (rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10)) + w[q][(t + 9) & 15] + (rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3)) + w[q][t & 15];
@@ -294,6 +332,26 @@ int zkir_memops_expand_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t
   if (n_ops == 0) return ZKIR_OK;
   hipLaunchKernelGGL(memops_expand_kernel, dim3(grid_for(n_ops)), dim3(NT), 0, (hipStream_t)stream, ev, n_ops, cycle_base, *out);
   return check_launch("memops_expand");
+}
+
+int zkir_memops_expand_csr_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t n_rows, uint64_t cycle_base, const zkir_memop_columns* out, uint64_t* row_offsets,
+                                  uint8_t* seg_flags, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!row_offsets || !seg_flags || (n_ops && (!ev || !out))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memops_expand_csr_launch: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  if (hipMemsetAsync(seg_flags, 0, n_rows ? n_rows : 1, s) != hipSuccess) return check_launch("memops_expand_csr memset");
+  if (n_ops == 0) {                                              // no ops: every offset is 0
+    if (hipMemsetAsync(row_offsets, 0, (n_rows + 1) * 8, s) != hipSuccess) return check_launch("memops_expand_csr memset");
+    return ZKIR_OK;
+  }
+  hipLaunchKernelGGL(memops_expand_csr_kernel, dim3(grid_for(n_ops)), dim3(NT), 0, s, ev, n_ops, n_rows, cycle_base, *out, row_offsets, seg_flags);
+  return check_launch("memops_expand_csr");
+}
+
+int zkir_memops_sort_prepared_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t cycle_base, const uint64_t* row_offsets, const uint8_t* seg_flags,
+                                     const zkir_memop_columns* out, void* stream) {
+  if (n_ops == 0) return ZKIR_OK;
+  hipLaunchKernelGGL(memops_sort_kernel, dim3(grid_for(n_ops)), dim3(NT), 0, (hipStream_t)stream, ev, n_ops, cycle_base, row_offsets, seg_flags, *out);
+  return check_launch("memops_sort");
 }
 
 int zkir_memops_row_offsets_launch(const zkir_mem_event* ev, uint64_t n_ops, uint64_t n_rows, uint64_t* offsets, void* stream) {

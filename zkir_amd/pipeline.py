@@ -171,9 +171,11 @@ class MemopColumns:
         return out
 
 
-def memory_ops(log: rt.DeltaLog, device=None, stream=None):
+def memory_ops(log: rt.DeltaLog, device=None, stream=None, separate_passes: bool = False):
     """Returns (row_order MemopColumns, row_offsets tensor[n_rows+1], sorted MemopColumns = get_memory_trace()).
-    Uploads, allocations and launches all happen on `stream` (default: the current stream), which is synchronised before returning."""
+    Uploads, allocations and launches all happen on `stream` (default: the current stream), which is synchronised before returning.
+    Default: two passes over the events (zkir_memops_expand_csr_launch: expansion + CSR offsets + shape flags; then the sort);
+    separate_passes=True drives the stand-alone entry points instead (binary-search CSR, expansion, sort with its own check pass)."""
     _require_gpu()
     device = device or torch.device("cuda", torch.cuda.current_device())
     L = rt.lib()
@@ -185,9 +187,13 @@ def memory_ops(log: rt.DeltaLog, device=None, stream=None):
         row_cols, sorted_cols = MemopColumns(n, device), MemopColumns(n, device)
         offsets = torch.empty(n_rows + 1, dtype=torch.int64, device=device)
         scratch = torch.empty(max(n_rows, 1), dtype=torch.uint8, device=device)
-        _check(L.zkir_memops_row_offsets_launch(ev.data_ptr(), n, n_rows, offsets.data_ptr(), sp))
-        _check(L.zkir_memops_expand_launch(ev.data_ptr(), n, log.cycle_base, C.byref(row_cols.c), sp))
-        _check(L.zkir_memops_sort_launch(ev.data_ptr(), n, n_rows, log.cycle_base, offsets.data_ptr(), scratch.data_ptr(), C.byref(sorted_cols.c), sp))
+        if separate_passes:
+            _check(L.zkir_memops_row_offsets_launch(ev.data_ptr(), n, n_rows, offsets.data_ptr(), sp))
+            _check(L.zkir_memops_expand_launch(ev.data_ptr(), n, log.cycle_base, C.byref(row_cols.c), sp))
+            _check(L.zkir_memops_sort_launch(ev.data_ptr(), n, n_rows, log.cycle_base, offsets.data_ptr(), scratch.data_ptr(), C.byref(sorted_cols.c), sp))
+        else:
+            _check(L.zkir_memops_expand_csr_launch(ev.data_ptr(), n, n_rows, log.cycle_base, C.byref(row_cols.c), offsets.data_ptr(), scratch.data_ptr(), sp))
+            _check(L.zkir_memops_sort_prepared_launch(ev.data_ptr(), n, log.cycle_base, offsets.data_ptr(), scratch.data_ptr(), C.byref(sorted_cols.c), sp))
         s.synchronize()
     return row_cols, offsets, sorted_cols
 

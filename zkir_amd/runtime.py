@@ -147,6 +147,15 @@ def lib() -> C.CDLL:
     L.zkir_delta_log_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
     L.zkir_delta_log_cycle_base.restype = C.c_uint64
     L.zkir_delta_log_cycle_base.argtypes = [C.c_void_p]
+    L.zkir_delta_log_window_open.restype = C.c_int
+    L.zkir_delta_log_window_open.argtypes = [C.c_void_p]
+    L.zkir_interpret_window.restype = C.c_int
+    L.zkir_interpret_window.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.c_uint32, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_void_p)]
+    L.zkir_exec_window.restype = C.c_int
+    L.zkir_exec_window.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(VmConfigC), C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.zkir_exec_shard.restype = C.c_int
+    L.zkir_exec_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
     L.zkir_trace_fill_launch.restype = C.c_int
     L.zkir_trace_fill_launch.argtypes = [C.POINTER(TraceFillArgsC), C.c_void_p]
     L.zkir_trace_fill_bytes.restype = C.c_uint64
@@ -154,6 +163,8 @@ def lib() -> C.CDLL:
     V, U64, U32 = C.c_void_p, C.c_uint64, C.c_uint32
     for name, args in [("zkir_memops_expand_launch", [V, U64, U64, C.POINTER(MemopColumnsC), V]),
                        ("zkir_memops_row_offsets_launch", [V, U64, U64, V, V]),
+                       ("zkir_memops_expand_csr_launch", [V, U64, U64, U64, C.POINTER(MemopColumnsC), V, V, V]),
+                       ("zkir_memops_sort_prepared_launch", [V, U64, U64, V, V, C.POINTER(MemopColumnsC), V]),
                        ("zkir_memops_sort_launch", [V, U64, U64, U64, V, V, C.POINTER(MemopColumnsC), V]),
                        ("zkir_range_check_expand_launch", [V, U64, U32, V, V, V, U64, V, V]),
                        ("zkir_norm_expand_launch", [V, U64, C.POINTER(NormColumnsC), V]),
@@ -271,6 +282,7 @@ class DeltaLog:
         self.outputs = _view(L.zkir_delta_log_outputs(h), L.zkir_delta_log_n_outputs(h), "<u8").tolist()
         self.n_rows = L.zkir_delta_log_n_rows(h)
         self.cycle_base = L.zkir_delta_log_cycle_base(h)
+        self.window_open = bool(L.zkir_delta_log_window_open(h))      # a trace window that ended before the run did
         self.tile_rows = L.zkir_delta_log_tile_rows(h)
         self.pc = _view(L.zkir_delta_log_pc(h), self.n_rows, "<u8")
         self.inst = _view(L.zkir_delta_log_inst(h), self.n_rows, "<u4")
@@ -339,13 +351,18 @@ def verify(proof: np.ndarray, expect: Optional[PublicInputsC] = None) -> int:
     return lib().zkir_verify(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None)
 
 
-def interpret(program: Program | bytes, inputs: Sequence[int] = (), config: Optional[VMConfig] = None, tile_rows: int = 0) -> DeltaLog:
-    """Host stage only (zkir_interpret): run the program, return the delta log.  Never touches a GPU."""
+def interpret(program: Program | bytes, inputs: Sequence[int] = (), config: Optional[VMConfig] = None, tile_rows: int = 0,
+              window: Optional[Tuple[int, int]] = None) -> DeltaLog:
+    """Host stage only (zkir_interpret): run the program, return the delta log.  Never touches a GPU.
+    window = (row_begin, row_end): zkir_interpret_window — rows before row_begin are executed untraced, the log holds the window."""
     blob = program if isinstance(program, (bytes, bytearray)) else program.to_bytes()
     cfg = (config or VMConfig())._c()
     arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
     out = C.c_void_p()
-    rc = lib().zkir_interpret(bytes(blob), len(blob), arr, len(inputs), C.byref(cfg), tile_rows, C.byref(out))
+    if window is None:
+        rc = lib().zkir_interpret(bytes(blob), len(blob), arr, len(inputs), C.byref(cfg), tile_rows, C.byref(out))
+    else:
+        rc = lib().zkir_interpret_window(bytes(blob), len(blob), arr, len(inputs), C.byref(cfg), tile_rows, int(window[0]), int(window[1]), C.byref(out))
     if rc != ZKIR_OK:
         _raise(rc)
     return DeltaLog(out.value)
@@ -567,6 +584,22 @@ class VM:
         self._config = config or VMConfig()
         self._consumed = False
 
+    def run_window(self, row_begin: int, row_end: int) -> ExecutionResult:
+        """zkir_exec_window: one GPU's share of the run — rows before row_begin executed untraced on this thread, rows [row_begin,
+        row_end) traced, uploaded and filled on the current device (multi-GPU: every rank calls it with its own range)."""
+        if self._consumed:
+            raise ValueError("VM::run consumes the VM (vm.rs:208)")
+        self._consumed = True
+        L = lib()
+        cfg = self._config._c()
+        arr = (C.c_uint64 * max(1, len(self._inputs)))(*self._inputs)
+        out = C.c_void_p()
+        rc = L.zkir_exec_window(self._blob, len(self._blob), arr, len(self._inputs), C.byref(cfg), int(row_begin), int(row_end), C.byref(out))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        log = DeltaLog(L.zkir_result_delta_log(out.value), owned=False)
+        return ExecutionResult(out.value, log, self._blob, self._inputs, self._config)
+
     def run(self) -> ExecutionResult:
         if self._consumed:
             raise ValueError("VM::run consumes the VM (vm.rs:208)")
@@ -589,8 +622,6 @@ def exec_shard(log: "DeltaLog", row_begin: int, row_end: int, blob: bytes = b"",
     """zkir_exec_shard: the drop-in handle for rows [row_begin, row_end) of a finished interpretation, cut out, uploaded to the current
     device and filled there (multi-GPU: one call per device; segment proofs: ranges that share one row)."""
     L = lib()
-    L.zkir_exec_shard.restype = C.c_int
-    L.zkir_exec_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
     out = C.c_void_p()
     rc = L.zkir_exec_shard(log._h, int(row_begin), int(row_end), C.byref(out))
     if rc != ZKIR_OK:

@@ -21,6 +21,29 @@ from . import pipeline as pl, runtime as rt, stark
 Job = Tuple[bytes, Sequence[int], rt.VMConfig]
 _spare_ctx: dict = {}                                         # log2_rows -> idle StarkContexts of the extra proving threads
 _spare_lock = threading.Lock()
+_SPARE_MAX = 2                                                # contexts kept between calls (each holds tables + a proof workspace of GBs at large sizes)
+
+
+def close_spare_contexts() -> None:
+    """Release the contexts the extra proving threads keep between prove_many calls (device tables + workspace)."""
+    with _spare_lock:
+        for lst in _spare_ctx.values():
+            for c in lst:
+                c.close()
+        _spare_ctx.clear()
+
+
+def _park_ctx(log2_rows: int, c) -> None:
+    with _spare_lock:
+        if sum(len(v) for v in _spare_ctx.values()) >= _SPARE_MAX:      # cap: drop the oldest parked context of another size first
+            for k in list(_spare_ctx):
+                if k != log2_rows and _spare_ctx[k]:
+                    _spare_ctx[k].pop(0).close()
+                    break
+            else:
+                c.close()
+                return
+        _spare_ctx.setdefault(log2_rows, []).append(c)
 
 
 @dataclass
@@ -56,12 +79,22 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
     todo = list(enumerate(jobs))[::-1]
     lock = threading.Lock()
     errors: List[BaseException] = []
+    stop = threading.Event()                                  # set on any failure (main thread included): every helper thread leaves
+
+    def take():
+        """Next ready item, or None once the pipeline is stopping (never blocks forever: a failed consumer stops feeding the queue)."""
+        while not stop.is_set():
+            try:
+                return ready.get(timeout=0.05)
+            except queue.Empty:
+                continue
+        return None
 
     def producer():
         s = torch.cuda.Stream()
         while True:
             with lock:
-                if not todo or errors:
+                if not todo or errors or stop.is_set():
                     return
                 idx, (blob, inputs, cfg) = todo.pop()
             try:
@@ -79,7 +112,7 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                 ready.put((idx, ddl, ev, t1 - t0, time.perf_counter() - t1, pub, log.n_rows))
             except BaseException as e:                    # surfaced by the consumer
                 errors.append(e)
-                ready.put(None)
+                stop.set()
                 return
 
     rep = PipelineReport(runs=len(jobs), rows=0)
@@ -105,7 +138,7 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
 
     def claim() -> bool:
         with lock:
-            if claimed[0] >= len(jobs) or errors:
+            if claimed[0] >= len(jobs) or errors or stop.is_set():
                 return False
             claimed[0] += 1
             return True
@@ -119,9 +152,8 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
             try:
                 with torch.cuda.stream(stream):
                     while claim():
-                        item = ready.get()
+                        item = take()
                         if item is None:
-                            ready.put(None)                  # let the others see the failure too
                             return
                         idx, ddl, ev, h, u, pub, n_rows = item
                         stream.wait_event(ev)
@@ -133,21 +165,20 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                             if keep_proofs:
                                 out[idx] = proof
             finally:
-                with _spare_lock:
-                    _spare_ctx.setdefault(log2_rows, []).append(my_ctx)
+                _park_ctx(log2_rows, my_ctx)
         except BaseException as e:                            # noqa: BLE001
             with lock:
                 errors.append(e)
+            stop.set()
 
     extra = [threading.Thread(target=prover_thread, daemon=True) for _ in range(n_extra)]
     for t in extra:
         t.start()
     try:
         while claim():
-            item = ready.get()
+            item = take()
             if item is None:
-                ready.put(None)
-                raise errors[0]
+                break
             idx, ddl, ev, h, u, pub, n_rows = item
             with lock:
                 rep.interpret_s += h
@@ -188,7 +219,12 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
             raise errors[0]
         torch.cuda.synchronize()
         rep.wall_s = time.perf_counter() - t0
+    except BaseException as e:                            # a failure on THIS thread (e.g. stark.prove) stops the helpers too
+        with lock:
+            errors.append(e)
+        raise
     finally:
+        stop.set()
         with lock:
             todo.clear()
         while any(t.is_alive() for t in threads):         # unblock producers stuck on a full queue
@@ -196,6 +232,8 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                 ready.get_nowait()
             except queue.Empty:
                 time.sleep(0.001)
+        for t in extra:                                   # the proving threads poll `stop`: they hold a context and a stream until they leave
+            t.join()
         if own_ctx:
             ctx.close()
     rep.proofs = [p for p in out if p is not None]
