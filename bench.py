@@ -39,6 +39,51 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 # products that bring 8 absorbed values and the 4 carried capacity words to the input factor
 MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 13 * 22 + 12
 PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
+# The integer-ALU roofline of the Poseidon2 kernels, ANALYTIC (a fixed denominator; VERDICT r2 weak #3): a Montgomery product is three
+# multiplier-class wave instructions (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32), each of which issues in 4.2 SIMD-cycles per wave64 on
+# gfx950 (profiles/r02_ubench_alu.txt: v_mul_lo 4.21, v_mul_hi 4.09, v_mad_u64_u32 4.48); the chip has 256 CUs x 4 SIMDs at 2.4 GHz:
+#     1024 SIMDs x 2.4e9 cycles/s x 64 lanes / (3 instructions x 4.2 cycles) = 1.248e13 products/s
+ALU_PEAK_FORMULA = "1024 SIMDs x 2.4e9 Hz x 64 lanes / (3 multiplier-class instructions x 4.2 SIMD-cycles per wave64 instruction)"
+ALU_PEAK_MONT_MUL_PER_S = 1024 * 2.4e9 * 64 / (3 * 4.2)
+
+
+def _fri_schedule(k):
+    """stark_prove.inl fri_schedule: folds per committed layer (1, then 3 at a time down to 2^3 values)."""
+    ks, log_m = [], k + 1
+    while log_m > 3:
+        f = 1 if not ks else min(3, log_m - 3)
+        ks.append(f)
+        log_m -= f
+    return ks
+
+
+def _prove_stage_table(k, W, pms):
+    """Algorithmic HBM bytes (the minimum: every operand read once, every result written once), ms and fraction of the HBM peak of
+    the prover stages that follow the commitment (VERDICT r2 weak #10).  pms = the 8 stage times of zkir_prove (HIP events)."""
+    n2 = 2 << k
+    tree = 16 * (2 * n2 - 1)
+    fri = 0
+    m = n2
+    for f in _fri_schedule(k):
+        g = m >> f
+        fri += 16 * m + 16 * (2 * g - 1)                      # leaf hash reads the layer, the tree is written
+        for _ in range(f):
+            fri += 16 * m + 8 * m                             # a binary fold reads m extension values, writes m / 2
+            m >>= 1
+    rows = {
+        "quotient_and_merkle": (4 * W * n2 + 32 * n2) + (32 * n2 + tree),   # constraint evaluation reads the LDE once (row j and row j + 2 are the same bytes), writes the Q block; its tree
+        "openings": 4 * W * n2 + 32 * n2 + 2 * 16 * n2 + 2 * 16 * n2,       # weights written (2 x 16 B), matrix + Q read once, weights read once
+        "deep": 4 * W * n2 + 16 * n2 + 2 * 16 * n2 + 16 * n2,               # matrix, Q, two inverse columns read; the codeword written
+        "fri": fri,
+    }
+    out = {}
+    for name, nbytes in rows.items():
+        ms = float(pms[PROVE_STAGES.index(name)])
+        out[name] = {"bytes": int(nbytes), "ms": ms, "achieved_GBs": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                     "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+    out["openings"]["note"] = "the 16-byte weights are re-read once per group of four columns (38 groups); L2 / Infinity Cache absorb most of it"
+    out["fri"]["note"] = "latency-bound: ~80 sequential Poseidon2 tree levels and seven host round trips, not bytes"
+    return out
 
 
 def _strided_passes(stages: int) -> int:
@@ -64,28 +109,29 @@ def _strided_passes(stages: int) -> int:
 
 
 _STAGE_KERNELS = {"trace_fill": ["trace_fill_kernel"], "main_trace": ["main_trace_kernel"], "lde": ["ntt_strided_r4_kernel<false", "lde_middle", "ntt_strided_r4_kernel<true"],
-                  "merkle": ["leaf_hash_kernel", "compress_kernel", "subtree_kernel"]}
+                  "merkle": ["leaf_hash_kernel", "compress_kernel", "subtree_kernel"], "merkle_leaves": ["leaf_hash_kernel"],
+                  "merkle_levels": ["compress_kernel", "subtree_kernel"]}
 
 
 def _profiled_traffic(stage: str):
-    """HBM bytes one step's `stage` moves, from the newest committed rocprofv3 counter passes of this exact command (profiles/
+    """(bytes, file): HBM bytes one step's `stage` moves, from the newest committed rocprofv3 counter passes of this exact command (profiles/
     r*_bench_commit_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE per kernel, corrected as MI355X_MICROARCH.md prescribes, averaged per
     launch).  A stage is several kernels: each kernel's per-launch bytes times its launches per step (its launch count relative to the
     stage's first kernel, which runs once per step)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_commit_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     names = _STAGE_KERNELS.get(stage, [])
     ref = next((v for kname, v in d.items() if names and kname.startswith(names[0])), None)
     if not ref or not ref.get("WRITE_SIZE_launches"):
-        return None
+        return None, None
     total = 0.0
     for kname, v in d.items():
         if any(kname.startswith(nm) for nm in names):
             total += v["hbm_bytes_per_launch"] * round(v["WRITE_SIZE_launches"] / ref["WRITE_SIZE_launches"])
-    return total
+    return total, os.path.relpath(files[-1], ROOT)
 
 
 def _profiled_valu_busy(kernel: str):
@@ -129,7 +175,7 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
     """Algorithmic bytes, ms and rooflines of the commit stages for 2^k rows."""
     n = 1 << k
     kernels = {"trace_fill": {"bound": "hbm", "bytes": fill_bytes, "ms": stage_ms["trace_fill"]}}
-    if "merkle" in stage_ms:
+    if "merkle" in stage_ms or "merkle_leaves" in stage_ms:
         #   main_trace: reads the value / state / cycle / pc / instruction columns (164 B/row; the next-row re-read is served by L2), writes W u32 columns
         #   lde (DESIGN.md §8.3): per column `n_inv` strided inverse passes (8 B/elem over N; one radix-4 pass covers up to ten
         #        stages) + fused middle (4N read + 8N written) + as many strided forward passes (8 B/elem over 2N)
@@ -142,13 +188,19 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
                           "valu_floor_ms": W * n * 30 * 33.0 / 64 / (1024 * 2.4e9) * 1e3,
                           "note": "HBM traffic equals the algorithmic bytes (PMC); the stage sits on a VALU-issue floor of 31-bit modular butterflies about as high as its "
                                   "HBM floor at the 5 TB/s a copy reaches: see valu_floor_ms"}
-        perms = 2 * n * (-(-W // 8)) + (2 * n - 1)
-        modmul_peak = float(lib.zkir_modmul_peak_per_s(sp()))          # measured on this device: independent mont_mul chains, no memory
-        modmul = perms * MONT_MUL_PER_PERM / (stage_ms["merkle"] * 1e-3)
-        kernels["merkle"] = {"bound": "int-alu", "bytes": 4 * W * 2 * n + 16 * (4 * n - 1), "ms": stage_ms["merkle"],
-                             "poseidon2_perms_per_s": perms / (stage_ms["merkle"] * 1e-3),
-                             "mont_mul_per_s": modmul, "mont_mul_peak_per_s_measured": modmul_peak,
-                             "frac_of_alu_peak": modmul / modmul_peak if modmul_peak else None}
+        # Merkle: the leaf layer (leaf_hash_kernel: one rate-8 sponge per LDE row, ceil(W/8) permutations; reads the matrix once, writes 16 B per
+        # leaf) and the 2N - 1 compressions above it (compress_kernel / subtree_kernel), timed separately when the caller split the stage
+        perms_leaf, perms_lvl = 2 * n * (-(-W // 8)), 2 * n - 1
+        bytes_leaf, bytes_lvl = (4 * W + 16) * 2 * n, (32 + 16) * (2 * n - 1)
+        if "merkle_leaves" in stage_ms:
+            parts = [("merkle_leaves", perms_leaf, bytes_leaf, "leaf_hash_kernel"), ("merkle_levels", perms_lvl, bytes_lvl, "compress_kernel + subtree_kernel")]
+        else:
+            parts = [("merkle", perms_leaf + perms_lvl, bytes_leaf + bytes_lvl, "leaf_hash_kernel + compress_kernel + subtree_kernel")]
+        for name, perms, nbytes, kern in parts:
+            ms = stage_ms[name]
+            modmul = perms * MONT_MUL_PER_PERM / (ms * 1e-3)
+            kernels[name] = {"bound": "int-alu", "kernels": kern, "bytes": nbytes, "ms": ms, "poseidon2_perms": perms, "poseidon2_perms_per_s": perms / (ms * 1e-3),
+                             "mont_mul_per_s": modmul, "alu_peak_analytic": ALU_PEAK_MONT_MUL_PER_S, "frac_of_alu_peak": modmul / ALU_PEAK_MONT_MUL_PER_S}
     for v in kernels.values():
         v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
         v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
@@ -174,7 +226,8 @@ def _config2_fib_2p24(lib, sp, k=24):
     stages = [("trace_fill", lambda: pl.trace_fill(fa)),
               ("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, 0, m.data_ptr(), sp()))),
               ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
-              ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
+              ("merkle_leaves", lambda: pl._check(lib.zkir_merkle_leaves_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp()))),   # leaf_hash_kernel alone
+              ("merkle_levels", lambda: pl._check(lib.zkir_merkle_cap_launch(ctx.handle, tree.data_ptr(), 2 * n, sp())))]                           # together = zkir_merkle_commit_launch
     for _, f in stages:
         f()
     stage_ms = {name: _hip_time(f, reps=3 if k <= 24 else 2, warm=0) for name, f in stages}
@@ -209,6 +262,7 @@ def _config2_fib_2p24(lib, sp, k=24):
                        "(AIR quotient, openings, DEEP, FRI, queries)" + ("; the row count of configs[3] (2^26, there over 8 GPUs) on ONE device" if k == 26 else ""),
            "rows": n, "commit_step_ms": step_ms, "commit_rows_per_s": n / (step_ms * 1e-3), "stage_ms": stage_ms, "roofline_by_stage": kernels,
            "prove_ms": prove_ms, "prove_stage_ms": dict(zip(PROVE_STAGES, pms)), "prove_rows_per_s": n / (prove_ms * 1e-3),
+           "prove_stage_roofline": _prove_stage_table(k, W, list(pms)),
            "proof_bytes": int(len(proof) * 4), "verify_ms_host": verify_ms, "merkle_root": root, "proof_trace_root_matches_commit": proof[157:161].tolist() == root,
            "host_interpret_s": host_s, "hbm_resident_GB": (372 * n + (12 * W + 440) * n) / 1e9,
            "zkir_exec_ms": exec_ms, "zkir_exec_rows_per_s": n / (exec_ms * 1e-3) if exec_ms else None}
@@ -280,7 +334,21 @@ def _cpu_baseline(blob, k, commit):
               f"faithful O(N^2) mode: {nf} rows in {dtf:.2f} s = {nf / dtf:.3g} rows/s (the largest size that finishes in seconds); "
               f"host CPU: {cpu['model']}, {cpu['logical_cores']} logical cores, 1 used")
     out = {"value": nn / dt, "unit": "rows/s", "cores": 1, "kind": "port", "sample": sample,
-           "linear_rows_per_s": nn / dt, "faithful_rows_per_s": nf / dtf, "faithful_rows": nf, "host_cpu": cpu}
+           "linear_rows_per_s": nn / dt, "linear_rows": nn, "faithful_rows_per_s": nf / dtf, "faithful_rows": nf, "host_cpu": cpu}
+    if k == 20:
+        # north_star's target is stated at 2^24 cycles: time the linear mode AT that size, ~2-4 s.  The oracle keeps its rows
+        # (372 B each: 6.2 GB, ~9 GB at the peak of the vector's growth); a host without that much free memory builds every row without keeping it.
+        avail = 0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable"):
+                    avail = int(line.split()[1]) * 1024
+        except OSError:
+            pass
+        keep = avail >= (20 << 30)
+        dt24, n24 = oracle.time_run(blob, 1 << 24, build_only=not keep)
+        out["linear_2p24"] = {"rows": n24, "seconds": dt24, "rows_per_s": n24 / dt24, "rows_kept": keep,
+                              "what": "the same oracle, linear mode, one thread, 2^24 cycles of the same fib program" + ("" if keep else " (rows built but not stored: host memory)")}
     if commit:                                          # self-defined stages: NOT the reference path; a separate, labelled figure
         from oracle import stark_api as so
         threads = max(1, min(cpu["logical_cores"] or 1, 64))
@@ -421,7 +489,8 @@ def main():
     if commit:
         stages += [("main_trace", lambda: pl._check(lib.zkir_main_trace_launch(C.byref(trace.c), n, 0, m.data_ptr(), sp()))),
                    ("lde", lambda: pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), W, L.data_ptr(), sp()))),
-                   ("merkle", lambda: pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp())))]
+                   ("merkle_leaves", lambda: pl._check(lib.zkir_merkle_leaves_launch(ctx.handle, L.data_ptr(), W, 2 * n, tree.data_ptr(), sp()))),   # leaf_hash_kernel alone
+                   ("merkle_levels", lambda: pl._check(lib.zkir_merkle_cap_launch(ctx.handle, tree.data_ptr(), 2 * n, sp())))]                           # together = zkir_merkle_commit_launch
 
     # N > 1: the step ends with the only collective of the path — an all-gather of the per-GPU subtree roots (16 B per rank over
     # RCCL/xGMI) — and every rank hashes the top log2(G) levels over them (zkir_merkle_cap_launch), so `value` is the rate of the
@@ -684,7 +753,13 @@ def main():
         value = total_rows * args.steps / wall
         kernels = _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp)
         dom = max(kernels, key=lambda q: kernels[q]["ms"])
-        traffic = _profiled_traffic(dom) if (k == 20 and world == 1 and commit) else None
+        traffic, traffic_source = _profiled_traffic(dom) if (k == 20 and world == 1 and commit) else (None, None)
+        dom_kernel = {"merkle_leaves": "leaf_hash_kernel", "trace_fill": "trace_fill_kernel", "main_trace": "main_trace_kernel"}.get(dom, dom)
+        alu_measured = None
+        if commit:                                        # the measured counterpart of the analytic ALU peak: 7 repetitions, spread reported (it moves with the clock state)
+            reps = sorted(float(lib.zkir_modmul_peak_per_s(sp())) for _ in range(7))
+            alu_measured = {"median": reps[3], "min": reps[0], "max": reps[-1], "reps": 7,
+                            "what": "zkir_modmul_peak_per_s: 8 independent chains of minimal Montgomery products per lane, no memory traffic, 4096 workgroups"}
         out = {
             "metric": f"trace rows/sec (2^{k}-cycle fib: execution-trace fill + BabyBear NTT/LDE + Poseidon2 Merkle commitment)"
                       if commit else f"trace rows/sec (2^{k}-cycle fib, execution-trace fill only)",
@@ -698,20 +773,28 @@ def main():
                                     f"stages = {'+'.join(s for s, _ in stages)}; blow-up 2, Poseidon2 width 12"),
                        "rows_per_gpu": n, "tile_rows": tile_rows, "reg_events_per_gpu": n_events, "main_trace_width": W if commit else None,
                        "parallelism": f"row-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernels[dom]["ms"],
-                         "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
-                         "note": ("dominant stage is the Poseidon2 Merkle commitment, which is integer-ALU-bound (770 Montgomery multiplications + 130 wide Montgomery reductions per "
-                                  "permutation; VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see roofline_by_stage for its ALU rate and for the HBM-bound stages")
+            # the dominant KERNEL of the step (its own launch bracketed by HIP events inside the timed region; at N = 1 / 2^20 rows: leaf_hash_kernel),
+            # priced against the HBM peak as the contract asks — and against the roofline that does bound it (`alu`)
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (a file, NOT a counter read in this run)"
+                                         if traffic is not None else None,
+                         "kernel_ms": kernels[dom]["ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
+                         "note": ("the dominant kernel is the Poseidon2 leaf hash, which is integer-ALU-bound (770 Montgomery multiplications + 130 wide Montgomery reductions per "
+                                  "permutation; VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see `alu` and roofline_by_stage")
                          if kernels[dom]["bound"] != "hbm" else None,
-                         # the roofline that does bound this kernel: vector-ALU issue.  `achieved`/`peak` = Montgomery products per
-                         # second against the device's measured peak of independent MINIMAL products (three multiplier-pipe
-                         # instructions each; what the integer multipliers can do at all) — the rest of the kernel's issue slots are
-                         # the additions / 64-bit sums / reductions of the linear layers; `valu_busy_profiled` = rocprofv3 VALUBusy
-                         # of leaf_hash_kernel in the committed counter pass of this command (profiles/): the pipe is never idle
-                         "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["mont_mul_per_s"], "peak": kernels[dom]["mont_mul_peak_per_s_measured"],
-                                  "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel")}
+                         # the roofline that does bound this kernel: vector-ALU issue.  `peak` is ANALYTIC and fixed (ALU_PEAK_FORMULA); the measured rate of
+                         # independent minimal products on this device, with its spread, is next to it; `valu_busy_profiled` = rocprofv3 VALUBusy of
+                         # leaf_hash_kernel in the committed counter pass of this command (profiles/): the pipe is never idle
+                         "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["mont_mul_per_s"], "peak": ALU_PEAK_MONT_MUL_PER_S, "peak_formula": ALU_PEAK_FORMULA,
+                                  "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "peak_measured": alu_measured,
+                                  "mont_mul_per_permutation": MONT_MUL_PER_PERM, "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel")}
                                  if kernels[dom]["bound"] == "int-alu" else None)},
+            # `value` is rows/s of a commit over W self-chosen columns: the width-independent figures are per column of 2^20 rows
+            "per_column": ({"main_trace_width": W, "rows": n,
+                            "lde_us_per_column_per_2p20_rows": stage_ms["lde"] * 1e3 / W * ((1 << 20) / n),
+                            "merkle_us_per_column_per_2p20_rows": (stage_ms["merkle_leaves"] + stage_ms["merkle_levels"]) * 1e3 / W * ((1 << 20) / n),
+                            "main_trace_us_per_column_per_2p20_rows": stage_ms["main_trace"] * 1e3 / W * ((1 << 20) / n)} if commit else None),
             "roofline_by_stage": kernels,
             "by_config": by_config,
             # rows per second of ONE GPU over its own stages (everything but the all-gather + cap): at N > 1 the shard is 2^23 rows, not the 2^20 of
@@ -720,6 +803,7 @@ def main():
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
+            "prove_stage_roofline": _prove_stage_table(k, W, [prove_stage_ms[q] for q in PROVE_STAGES]) if prove_stage_ms else None,
             "prover": "ZKIR-STARK v1 (self-defined; AIR of 152 columns / 327 constraints, boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12)",
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
@@ -746,10 +830,14 @@ def main():
             if c2.get("zkir_exec_rows_per_s"):
                 # north_star's target, stated on its own terms: the trace path (VM::run -> execution trace, the only stage the reference has) at
                 # 2^24 cycles on one GPU against the CPU restatement of the reference in linear mode (faithful mode cannot finish at 2^24)
-                cpu = out["cpu_baseline"]["linear_rows_per_s"]
+                l24 = out["cpu_baseline"].get("linear_2p24") or {}
+                cpu = l24.get("rows_per_s") or out["cpu_baseline"]["linear_rows_per_s"]
                 out["target_10x_at_2p24"] = {"gpu_path": "zkir_exec at 2^24 cycles (host interpretation + H2D + trace fill, 372 B/row left in HBM)",
-                                             "gpu_path_rows_per_s": c2["zkir_exec_rows_per_s"], "cpu_linear_rows_per_s_at_2p20": cpu,
+                                             "gpu_path_rows_per_s": c2["zkir_exec_rows_per_s"], "cpu_linear_rows_per_s": cpu, "cpu_rows": l24.get("rows") or out["cpu_baseline"]["linear_rows"],
                                              "ratio": c2["zkir_exec_rows_per_s"] / cpu,
+                                             "what_the_ratio_is": "the product's trace path (an optimised host interpreter writing a 44 B/row delta log, with the GPU expanding it to 372 B/row underneath) "
+                                                                  "against the literal single-threaded restatement of VM::run building 372 B rows on the CPU, same size; of the "
+                                                                  "GPU path's time ~97 % is the host interpreter and ~3 % K1 — it is an end-to-end ratio of two trace paths, not a kernel speed-up",
                                              "commit_step_ratio_vs_cpu_commit_port": (c2["commit_rows_per_s"] / side["rows_per_s"]) if side else None}
         print(json.dumps(out))
     if world > 1:

@@ -292,6 +292,11 @@ int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uin
  * tree = 4*(2*n_leaves-1) words, leaf digests first, root = last 4 words */
 int zkir_merkle_commit_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* hip_stream);
 
+/* The two halves of zkir_merkle_commit_launch, for callers that time or schedule them separately: the leaf digests (tree[0..4n), one
+ * sponge per row: leaf_hash_kernel, the dominant kernel of the commit step), then zkir_merkle_cap_launch(ctx, tree, n_leaves) for the
+ * levels above them. */
+int zkir_merkle_leaves_launch(const zkir_stark_ctx* ctx, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* digests, void* hip_stream);
+
 /* Top of a row-sharded commitment: tree[0..4n) holds n (power of two) digests — the all-gathered subtree roots of the row
  * shards, in rank order — and the call appends the log2(n) upper levels; root = last 4 words of the 4*(2n-1)-word buffer. */
 int zkir_merkle_cap_launch(const zkir_stark_ctx* ctx, uint32_t* tree, uint64_t n_digests, void* hip_stream);

@@ -156,16 +156,20 @@ def run(program_blob: bytes, inputs=(), max_cycles: int = 1_000_000, enable_rang
         L.zo_free(h)
 
 
-def time_run(program_blob: bytes, max_cycles: int, faithful: bool = False) -> tuple[float, int]:
-    """Wall time of one trace-generating run (no result copies): (seconds, rows)."""
+def time_run(program_blob: bytes, max_cycles: int, faithful: bool = False, build_only: bool = False) -> tuple[float, int]:
+    """Wall time of one trace-generating run (no result copies): (seconds, rows).  build_only: every row is built (pre-state copy,
+    memory-op filter) but not kept — for sizes whose 372 B/row would not fit the host's memory; returns the cycle count as rows."""
     import time
     L = lib()
     cfg = _Cfg(max_cycles, 0, 0, 1, 0)
     arr = (C.c_uint64 * 1)()
     t0 = time.perf_counter()
-    h = L.zo_run(program_blob, len(program_blob), arr, 0, C.byref(cfg), int(faithful))
+    if build_only:
+        h = L.zo_run_window(program_blob, len(program_blob), arr, 0, C.byref(cfg), max_cycles + 1, max_cycles + 2)
+    else:
+        h = L.zo_run(program_blob, len(program_blob), arr, 0, C.byref(cfg), int(faithful))
     dt = time.perf_counter() - t0
-    n = L.zo_n_rows(h)
+    n = L.zo_cycles(h) if build_only else L.zo_n_rows(h)
     L.zo_free(h)
     return dt, n
 

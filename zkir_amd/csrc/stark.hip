@@ -418,6 +418,15 @@ int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
   return check_launch("merkle_commit");
 }
 
+// The leaf layer alone: digests[0 .. 4n) = sponge over the `width` real columns of every row (leaf_hash_kernel); zkir_merkle_cap_launch
+// on the same buffer then adds the levels above — together they are zkir_merkle_commit_launch.  Exists so that a caller (bench.py)
+// can bracket the dominant kernel of the commit step with its own events.
+int zkir_merkle_leaves_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* digests, void* stream) {
+  if (!c || !mat || !digests || n_leaves == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle leaves: null argument or no leaves"}); return ZKIR_ERR_ARGUMENT; }
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, (hipStream_t)stream, c->d_p2, mat, width, n_leaves, digests);
+  return check_launch("merkle_leaves");
+}
+
 // Upper levels over already-computed digests (multi-GPU: the all-gathered subtree roots of the row shards are the leaves of the
 // top log2(G) levels).  tree[0 .. 4n) must hold the n digests; the call fills the remaining 4(n-1) words, root = last 4.
 int zkir_merkle_cap_launch(const zkir_stark_ctx* c, uint32_t* tree, uint64_t n_digests, void* stream) {

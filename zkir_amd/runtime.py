@@ -182,7 +182,8 @@ def lib() -> C.CDLL:
     L.zkir_padded_log_n.restype = U32
     L.zkir_padded_log_n.argtypes = [U64]
     for name, args in [("zkir_main_trace_launch", [C.POINTER(TraceColumnsC), U64, U32, V, V]), ("zkir_lde_launch", [V, V, U32, V, V]),
-                       ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V]), ("zkir_merkle_cap_launch", [V, V, U64, V])]:
+                       ("zkir_merkle_commit_launch", [V, V, U32, U64, V, V]), ("zkir_merkle_leaves_launch", [V, V, U32, U64, V, V]),
+                       ("zkir_merkle_cap_launch", [V, V, U64, V])]:
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
