@@ -263,7 +263,7 @@ def _config2_fib_2p24(lib, sp, k=24):
            "rows": n, "commit_step_ms": step_ms, "commit_rows_per_s": n / (step_ms * 1e-3), "stage_ms": stage_ms, "roofline_by_stage": kernels,
            "prove_ms": prove_ms, "prove_stage_ms": dict(zip(PROVE_STAGES, pms)), "prove_rows_per_s": n / (prove_ms * 1e-3),
            "prove_stage_roofline": _prove_stage_table(k, W, list(pms)),
-           "proof_bytes": int(len(proof) * 4), "verify_ms_host": verify_ms, "merkle_root": root, "proof_trace_root_matches_commit": proof[157:161].tolist() == root,
+           "proof_bytes": int(len(proof) * 4), "verify_ms_host": verify_ms, "merkle_root": root, "proof_trace_root_matches_commit": stark.trace_root(proof) == root,
            "host_interpret_s": host_s, "hbm_resident_GB": (372 * n + (12 * W + 440) * n) / 1e9,
            "zkir_exec_ms": exec_ms, "zkir_exec_rows_per_s": n / (exec_ms * 1e-3) if exec_ms else None}
     ctx.close(); log.close()
@@ -581,7 +581,7 @@ def main():
     segment_prove = None
     if commit and world > 1 and not args.no_prove:
         try:
-            run_pub = rt.PublicInputsC.from_buffer_copy(run_pub_bytes[0])
+            run_pub = rt.PublicInputsC.from_buffer_copy(run_pub_bytes[0]).with_program(blob)   # the borrowed program pointer of another process means nothing here
             seg_proofs, seg_ms = [], None
             for si, sh in enumerate(seg_shards):
                 ddl2 = pl.upload(sh); tr2 = pl.DeviceTrace(ddl2); pl.trace_fill(pl.trace_fill_args(ddl2, tr2))

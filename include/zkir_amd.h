@@ -309,6 +309,11 @@ typedef struct zkir_public_inputs {
   uint32_t reserved;
   uint32_t program_digest[4];  /* zkir_digest_bytes(program blob) */
   uint32_t io_digest[4];       /* zkir_digest_bytes(LE u64 words [n_inputs, inputs.., n_outputs, outputs.., halt kind, halt code, cycles]) */
+  /* PROVER side only (ignored when the struct is the `expect` of a verifier): the program itself, BORROWED — set by
+   * zkir_public_inputs_of to the caller's blob, which must stay valid while the struct is passed to zkir_prove.  Its code words are
+   * the instruction ROM of the lookup argument; the proof carries the program (format v5), the verifier checks it against program_digest. */
+  const uint8_t* program_blob;
+  uint64_t program_blob_len;
 } zkir_public_inputs;
 /* Poseidon2 sponge digest of a byte string (host): [len as four 16-bit pieces] ++ [LE 16-bit halfwords] */
 void zkir_digest_bytes(const uint8_t* bytes, size_t len, uint32_t out[4]);
@@ -318,7 +323,9 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob
                           uint32_t deferred, zkir_public_inputs* out);
 
 /* Full proof of the execution whose K1 output is `trace` (pub->n_real rows; ctx built for zkir_padded_log_n(pub->n_real)).  *proof_out is a
- * malloc'ed array of u32 words (little-endian canonical field elements, format v4: layout in oracle/stark_oracle.cpp so::prove),
+ * malloc'ed array of u32 words (little-endian canonical field elements, format v5: layout in oracle/stark_oracle.cpp so::prove),
+ * pub->program_blob must be the program that ran: every row's (pc, instruction word) is looked up in its code table, and a run that executes
+ * anything else (self-modified code, a pc outside the code segment) is refused with ZKIR_ERR_ARGUMENT — it has no proof in this AIR.
  * released with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries.
  * The trace may be that of a whole run or of a SEGMENT of one (the K1 output of a row shard, zkir_delta_log_shard(log, a, b) with
  * cycle_base = a): the proof header records the 68-word state (cycle, pc limbs, register limbs, storage states) of the first and of
@@ -330,7 +337,9 @@ uint32_t zkir_proof_num_queries(void);
 uint32_t zkir_proof_version(void);
 /* Verifier of the proof of a WHOLE run (host only, no device): 0 = accepted, otherwise the number of the failed check (1-5
  * malformed, 6 public inputs differ from `expect`, 7 the run does not start in the VM's initial state (cycle 0, entry point, zero
- * registers), 10 constraints at zeta, 11 final codeword degree, 12 grinding, 20-26 query / Merkle / FRI checks, 30 length).
+ * registers), 8 the program carried in the proof is malformed or is not the one program_digest / entry_point name, 10 constraints at
+ * zeta (incl. the lookup argument: the verifier computes the table side from that program and the multiplicities in the proof), 11 final
+ * codeword degree, 12 grinding, 20-27 query / Merkle / FRI checks, 30 length).
  * expect may be NULL: the header's own public inputs are then only checked for internal consistency. */
 int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect);
 /* A run proven in SEGMENTS (multi-GPU: one row shard per device; consecutive segments overlap by one row — the last row of segment i,

@@ -372,17 +372,31 @@ class StarkContext {                                            // device tables
   uint32_t log_n_;
 };
 
-// Public inputs of a proof of `result` (row count, mode, entry pc, program digest, io digest)
-inline zkir_public_inputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,
-                                        const zkir_runtime::VMConfig& config = {}) {
+// Public inputs of a proof of `result` (row count, mode, entry pc, program digest, io digest).  The C struct borrows the program blob (the
+// prover reads the instruction ROM of the lookup argument from it; the proof carries it): this wrapper OWNS the bytes and keeps the
+// struct's pointer on them through copies and moves.
+struct PublicInputs : zkir_public_inputs {
+  PublicInputs() : zkir_public_inputs{} {}
+  PublicInputs(const zkir_public_inputs& c, std::vector<uint8_t> blob) : zkir_public_inputs(c), blob_(std::move(blob)) { repoint(); }
+  PublicInputs(const PublicInputs& o) : zkir_public_inputs(o), blob_(o.blob_) { repoint(); }
+  PublicInputs(PublicInputs&& o) noexcept : zkir_public_inputs(o), blob_(std::move(o.blob_)) { repoint(); }
+  PublicInputs& operator=(PublicInputs o) { static_cast<zkir_public_inputs&>(*this) = o; blob_ = std::move(o.blob_); repoint(); return *this; }
+  const std::vector<uint8_t>& program_bytes() const { return blob_; }
+
+ private:
+  void repoint() { program_blob = blob_.data(); program_blob_len = blob_.size(); }
+  std::vector<uint8_t> blob_;
+};
+inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,
+                                  const zkir_runtime::VMConfig& config = {}) {
   zkir_public_inputs pub;
-  const std::vector<uint8_t> blob = program.to_bytes();
+  std::vector<uint8_t> blob = program.to_bytes();
   const int rc = zkir_public_inputs_of(result.delta_log(), blob.data(), blob.size(), inputs.data(), inputs.size(), config.enable_deferred_model ? 1u : 0u, &pub);
   if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc);
-  return pub;
+  return PublicInputs(pub, std::move(blob));
 }
 
-// Full proof (u32 little-endian words, format v4) of a run whose execution trace is resident in HBM; the context must be built for
+// Full proof (u32 little-endian words, format v5) of a run whose execution trace is resident in HBM; the context must be built for
 // zkir_padded_log_n(rows).  zkir_prover::verify is the host-side check (0 = accepted).
 inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::ExecutionResult& result, const zkir_public_inputs& pub, void* hip_stream = nullptr) {
   uint32_t* words = nullptr;

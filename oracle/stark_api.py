@@ -9,6 +9,10 @@ from . import api
 
 P = 2013265921
 W_MAIN = 152
+W_AUX = 24                  # aux trace of the lookup argument: H0..H3, HR, S as four base columns each
+RC_TABLE = 1024
+N_LK = 52                   # lookup parameters: alpha (4), lambda^0..10 (44), T / N (4)
+HEADER_WORDS = 157
 _bound = False
 
 
@@ -30,14 +34,18 @@ def lib():
         L.so_main_trace_width.restype = I
         L.so_padded_log_n.restype = I; L.so_padded_log_n.argtypes = [C.c_uint64]
         L.so_num_constraints.restype = I
-        L.so_constraints_eval.restype = I; L.so_constraints_eval.argtypes = [V, V, U32, U32, U32, PP, V, V]
+        L.so_constraints_eval.restype = I; L.so_constraints_eval.argtypes = [V, V, V, V, V, U32, U32, U32, PP, V, V]
+        L.so_lookup_setup.restype = SZ; L.so_lookup_setup.argtypes = [V, PP, V, V, V, V, V, V]
+        L.so_aux_width.restype = I; L.so_rc_table.restype = I
+        L.so_last_lookup.restype = None; L.so_last_lookup.argtypes = [V]
+        L.so_last_aux.restype = None; L.so_last_aux.argtypes = [V]
         L.so_prove.restype = SZ; L.so_prove.argtypes = [V, PP, V, SZ]
         L.so_prove_matrix.restype = SZ; L.so_prove_matrix.argtypes = [V, PP, V, SZ]
         L.so_verify.restype = I; L.so_verify.argtypes = [V, SZ, PP]
         L.so_pow_bits.restype = I; L.so_header_words.restype = I; L.so_state_words.restype = I
         L.so_verify_segment.restype = I; L.so_verify_segment.argtypes = [V, SZ, PP, V]
         L.so_verify_chain.restype = I; L.so_verify_chain.argtypes = [V, V, I, PP]
-        L.so_constraints_eval_states.restype = I; L.so_constraints_eval_states.argtypes = [V, V, U32, U32, U32, PP, V, V, V, V]
+        L.so_constraints_eval_states.restype = I; L.so_constraints_eval_states.argtypes = [V, V, V, V, V, U32, U32, U32, PP, V, V, V, V]
         L.so_last_challenges.restype = None; L.so_last_challenges.argtypes = [V, V, V]
         L.so_last_quotient.restype = None; L.so_last_quotient.argtypes = [V]
         L.so_last_fri_layer.restype = SZ; L.so_last_fri_layer.argtypes = [I, V]
@@ -48,7 +56,19 @@ def lib():
 
 class PublicC(C.Structure):
     """so_public: the public inputs of a proof (observed first by the transcript, carried in the proof header)."""
-    _fields_ = [("n_real", C.c_uint64), ("deferred", C.c_uint32), ("pad", C.c_uint32), ("entry", C.c_uint64), ("prog", C.c_uint32 * 4), ("io", C.c_uint32 * 4)]
+    _fields_ = [("n_real", C.c_uint64), ("deferred", C.c_uint32), ("pad", C.c_uint32), ("entry", C.c_uint64), ("prog", C.c_uint32 * 4), ("io", C.c_uint32 * 4),
+                ("blob", C.c_char_p), ("blob_len", C.c_uint64)]     # the program itself (prover side): its code words are the instruction ROM
+
+    def set_blob(self, blob: bytes):
+        self._blob_ref = bytes(blob)            # keeps the bytes alive as long as the struct
+        self.blob = self._blob_ref
+        self.blob_len = len(self._blob_ref)
+        return self
+
+    def clone(self):
+        q = PublicC(self.n_real, self.deferred, 0, self.entry)
+        q.prog[:] = list(self.prog); q.io[:] = list(self.io)
+        return q.set_blob(getattr(self, "_blob_ref", b""))
 
 
 def digest_bytes(b: bytes) -> np.ndarray:
@@ -68,6 +88,7 @@ def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2
     if entry is None:
         entry = int.from_bytes(blob[12:16], "little") if len(blob) >= 16 else 0x1000
     p = PublicC(n_real, int(deferred), 0, entry)
+    p.set_blob(blob)
     p.prog[:] = [int(x) for x in digest_bytes(blob)]
     p.io[:] = [int(x) for x in digest_bytes(io_bytes(list(inputs), list(outputs), halt[0], halt[1], n_real))]
     return p
@@ -143,10 +164,23 @@ def main_trace(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
     return out
 
 
-def constraints_eval(loc, nxt, is_first, is_last, is_trans, pub: PublicC, alpha) -> np.ndarray:
-    """Σ alpha^c C_c(loc, nxt) for base-field rows and the given selector values (E4 result)."""
-    loc, nxt, alpha, o = _u32(loc), _u32(nxt), _u32(alpha), np.zeros(4, np.uint32)
-    lib().so_constraints_eval(loc.ctypes.data, nxt.ctypes.data, int(is_first), int(is_last), int(is_trans), C.byref(pub), alpha.ctypes.data, o.ctypes.data)
+def lookup_setup(matrix: np.ndarray, pub: PublicC, alpha_l, lam):
+    """The lookup side of a main-trace matrix for GIVEN challenges: (aux trace [W_AUX][N], lk[52] = alpha, lambda powers, T / N,
+    ROM multiplicities, range multiplicities)."""
+    m, a, l = _u32(matrix), _u32(alpha_l), _u32(lam)
+    n = m.shape[1]
+    aux, lk, rc = np.zeros((W_AUX, n), np.uint32), np.zeros(N_LK, np.uint32), np.zeros(RC_TABLE, np.uint32)
+    n_rom = lib().so_lookup_setup(m.ctypes.data, C.byref(pub), a.ctypes.data, l.ctypes.data, None, None, None, None)
+    rom = np.zeros(max(n_rom, 1), np.uint32)
+    lib().so_lookup_setup(m.ctypes.data, C.byref(pub), a.ctypes.data, l.ctypes.data, aux.ctypes.data, lk.ctypes.data, rom.ctypes.data, rc.ctypes.data)
+    return aux, lk, rom[:n_rom], rc
+
+
+def constraints_eval(loc, nxt, aloc, anxt, lk, is_first, is_last, is_trans, pub: PublicC, alpha) -> np.ndarray:
+    """Σ alpha^c C_c of one (local, next) row pair — main columns, aux columns, lookup parameters — for the given selector values (E4 result)."""
+    loc, nxt, aloc, anxt, lk, alpha, o = _u32(loc), _u32(nxt), _u32(aloc), _u32(anxt), _u32(lk), _u32(alpha), np.zeros(4, np.uint32)
+    lib().so_constraints_eval(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(is_first), int(is_last), int(is_trans), C.byref(pub),
+                              alpha.ctypes.data, o.ctypes.data)
     return o
 
 
@@ -214,11 +248,30 @@ def verify_chain(proofs, expect: PublicC | None = None) -> int:
     return lib().so_verify_chain(ptrs, lens, len(ps), C.byref(expect) if expect is not None else None)
 
 
-def constraints_eval_states(loc, nxt, is_first, is_last, is_trans, pub: PublicC, first, last, alpha) -> np.ndarray:
-    loc, nxt, alpha, first, last, o = _u32(loc), _u32(nxt), _u32(alpha), _u32(first), _u32(last), np.zeros(4, np.uint32)
-    lib().so_constraints_eval_states(loc.ctypes.data, nxt.ctypes.data, int(is_first), int(is_last), int(is_trans), C.byref(pub), first.ctypes.data, last.ctypes.data,
-                                     alpha.ctypes.data, o.ctypes.data)
+def constraints_eval_states(loc, nxt, aloc, anxt, lk, is_first, is_last, is_trans, pub: PublicC, first, last, alpha) -> np.ndarray:
+    loc, nxt, aloc, anxt, lk, alpha, first, last, o = _u32(loc), _u32(nxt), _u32(aloc), _u32(anxt), _u32(lk), _u32(alpha), _u32(first), _u32(last), np.zeros(4, np.uint32)
+    lib().so_constraints_eval_states(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(is_first), int(is_last), int(is_trans),
+                                     C.byref(pub), first.ctypes.data, last.ctypes.data, alpha.ctypes.data, o.ctypes.data)
     return o
+
+
+def proof_layout(proof: np.ndarray) -> dict:
+    """Word offsets of the parts of a v5 proof that follow the header: program, multiplicities, roots, openings."""
+    blob_len = int(proof[HEADER_WORDS])
+    at = HEADER_WORDS + 1
+    blob_words = (blob_len + 1) // 2
+    blob = bytearray(blob_len)
+    for i in range(0, blob_len, 2):
+        h = int(proof[at + i // 2])
+        blob[i] = h & 0xFF
+        if i + 1 < blob_len:
+            blob[i + 1] = h >> 8
+    n_rom = int.from_bytes(blob[16:20], "little") // 4 if blob_len >= 32 else 0
+    rom_mult = at + blob_words
+    rc_mult = rom_mult + n_rom
+    troot = rc_mult + RC_TABLE
+    return {"blob_len": blob_len, "blob": bytes(blob), "blob_at": at, "n_rom": n_rom, "rom_mult": rom_mult, "rc_mult": rc_mult, "trace_root": troot, "aux_root": troot + 4,
+            "quotient_root": troot + 8, "openings": troot + 12, "t_z": troot + 12, "t_zw": troot + 12 + 4 * (W_MAIN + W_AUX), "q_z": troot + 12 + 8 * (W_MAIN + W_AUX)}
 
 
 STATE_COLS = [0, 1, 2, 3] + list(range(9, 73))      # cycle, pc limbs, register limbs, storage states (so::state_col)

@@ -160,15 +160,25 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //   88+(r-1)  selb[r]: one-hot of field b          103+(r-1) selc[r]: one-hot of field c (of field a on BNE rows: rs1 sits there)
 //   118-120 xb = limbs of reg[fb]   121-123 xc = limbs of reg[fc | fa]   124-126 y = limbs of the value written to rd
 //   127-133 class one-hot: add, addi, bne, jal, oth (any other executed instruction), halt (last executed row), pad
-//   134-138 decode chain t1 = op(op-8), t2 = (op-0x41)(op-0x48), t3 = t1 t2, inv = 1/t3, t5 = t3 inv (proves op is none of the four)
+//   134 opclass of the instruction word (0 add, 1 addi, 2 bne, 3 jal, 4 anything else): part of the instruction-ROM tuple, so the class
+//       one-hot of an executed row is tied to the PROGRAM's word at pc, not to a free witness
+//   135-138 range chunks: y0 = c135 + 1024 c136, y1 = c137 + 1024 c138, each looked up in the 10-bit table (range_check.rs:175-192, config.rs:78-80)
 //   139 s = bit 31 of the word (sign of imm17 / off21) | 140 se = (tk + k_jal) s
 //   141-142 c0 c1 carries of the value addition | 143-145 d0 d1 d2 carries of pc + delta | 146 dl0 = low limb of the pc increment
 //   147 ne = [xb != xc] | 148-150 iv: inverse witness of the first differing limb | 151 tk = branch taken
 // ---------------------------------------------------------------------------------------------
 static const int W_MAIN = 152;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
-       C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_T = 134, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
+       C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
        C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151 };
+// AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 24 base columns = six extension-field columns,
+// coordinate by coordinate: H0..H3 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
+// S = running sum of (H0 + H1 + H2 + H3 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
+// carried in the proof and the multiplicities the prover sends before alpha is drawn.
+static const int W_AUX = 24, W_ALL = W_MAIN + W_AUX;
+enum { A_H = 0, A_HR = 16, A_S = 20 };
+static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the reference's range-check table: 2^(limb_bits/2) entries (range_check.rs:29, config.rs:78-80)
+static const int N_TUPLE = 10;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
 
 enum { K_ADD = 0, K_ADDI = 1, K_BNE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6 };
@@ -185,6 +195,7 @@ struct Public {
   uint64_t entry = 0x1000;   // header.entry_point: pc of row 0
   F prog[4] = {0, 0, 0, 0};  // digest of the program blob
   F io[4] = {0, 0, 0, 0};    // digest of (inputs, outputs, halt reason, cycles)
+  const uint8_t* blob = nullptr; size_t blob_len = 0;   // the program itself (prover side): its code words are the instruction ROM; carried in the proof
   // Boundary states (format v4): the 68 state columns (cycle, pc limbs, 48 register limbs, 16 storage states) of row 0 and of row
   // n_real - 1.  The prover reads them off its main trace and puts them in the header; the AIR pins both rows to them.  A proof of a
   // WHOLE run must start in the VM's initial state (verify(): check 7); a SEGMENT of a run starts where its predecessor ended
@@ -200,6 +211,27 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
   for (int i = 0; i < 4; i++) e.push_back((F)(((uint64_t)n >> (16 * i)) & 0xFFFF));
   for (size_t i = 0; i < n; i += 2) e.push_back((F)b[i] | (i + 1 < n ? (F)b[i + 1] << 8 : 0));
   hash_elems(e.data(), e.size(), out);
+}
+
+static inline F opclass_of(uint32_t op) { return op == OP_ADD ? 0 : op == OP_ADDI ? 1 : op == OP_BNE ? 2 : op == OP_JAL ? 3 : 4; }
+// The instruction ROM of a program blob (Program::to_bytes layout, program.rs:170-214,300-346): code word t sits at pc = 0x1000 + 4 t
+// (VM::new loads the code at CODE_BASE whatever the entry point, vm.rs:153-160); tuple = (pc limbs 20/20/24, op, fa, fb, fc, fhi, s, opclass).
+struct Rom { std::vector<F> rows; size_t n = 0; uint64_t entry = 0; bool ok = false; const F* row(size_t t) const { return &rows[t * N_TUPLE]; } };
+static inline void rom_tuple(uint64_t pc, uint32_t w, F out[N_TUPLE]) {
+  out[0] = (F)(pc & 0xFFFFF); out[1] = (F)((pc >> 20) & 0xFFFFF); out[2] = (F)(pc >> 40);
+  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F);
+}
+static Rom rom_from_blob(const uint8_t* b, size_t n) {
+  Rom r;
+  auto le32 = [&](size_t at) { return (uint32_t)b[at] | ((uint32_t)b[at + 1] << 8) | ((uint32_t)b[at + 2] << 16) | ((uint32_t)b[at + 3] << 24); };
+  if (!b || n < 32) return r;
+  r.entry = le32(12);
+  const uint64_t code_size = le32(16);
+  if (code_size % 4 || 32 + code_size > n) return r;
+  r.n = code_size / 4; r.rows.resize(r.n * N_TUPLE);
+  for (size_t t = 0; t < r.n; t++) rom_tuple(0x1000 + 4 * (uint64_t)t, le32(32 + 4 * t), &r.rows[t * N_TUPLE]);
+  r.ok = true;
+  return r;
 }
 
 static inline void reg_limbs(uint64_t v, uint8_t st, F out[3]) {
@@ -234,8 +266,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
     if (cls == K_OTH && !D) cls = op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : op == OP_BNE ? K_BNE : op == OP_JAL ? K_JAL : K_OTH;
     col(C_K + cls)[i] = 1;
-    const F t1 = fmul(op, fsub(op, 8)), t2 = fmul(fsub(op, OP_BNE), fsub(op, OP_JAL)), t3 = fmul(t1, t2), inv = t3 ? finv(t3) : 0;
-    col(C_T)[i] = t1; col(C_T + 1)[i] = t2; col(C_T + 2)[i] = t3; col(C_T + 3)[i] = inv; col(C_T + 4)[i] = fmul(t3, inv);
+    col(C_OPC)[i] = opclass_of(op);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const uint32_t tc = cls == K_BNE ? fa : fc;             // second operand: rs2 = field c, but BNE has rs1 in field a (rs2 in field b)
     if (fb) col(C_SELB + fb - 1)[i] = 1;
     if (tc) col(C_SELC + tc - 1)[i] = 1;
@@ -278,6 +309,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       }
     }
     for (int l = 0; l < 3; l++) col(C_Y + l)[i] = y[l];
+    col(C_RC)[i] = y[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = y[0] >> RC_BITS; col(C_RC + 2)[i] = y[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = y[1] >> RC_BITS;
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
     if (cls == K_ADD || cls == K_ADDI || cls == K_BNE || cls == K_JAL) {                           // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
       const uint64_t v0 = (uint64_t)pc[0] + dl0; const F d0 = (F)(v0 >> 20);
@@ -310,11 +342,82 @@ static void merkle_build(const std::vector<F>& mat, int width, size_t n, Merkle&
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Lookup argument (LogUp) of AIR v2: what is looked up, the multiplicities, the aux trace
+// ---------------------------------------------------------------------------------------------
+struct LookupParams { E alpha; E lam[N_TUPLE + 1]; E t_over_n; };
+static inline E fingerprint(const F* tuple, const LookupParams& lp) {        // sum_j lambda^j f_j + lambda^10 (the tag keeps ROM entries apart from range values)
+  E fp = lp.lam[N_TUPLE];
+  for (int j = 0; j < N_TUPLE; j++) fp = eadd(fp, emul_f(lp.lam[j], tuple[j]));
+  return fp;
+}
+static inline void row_tuple(const std::vector<F>& M, size_t N, size_t i, F out[N_TUPLE]) {
+  static const int cols[N_TUPLE] = {C_PC, C_PC + 1, C_PC + 2, C_OP, C_FA, C_FB, C_FC, C_FHI, C_S, C_OPC};
+  for (int j = 0; j < N_TUPLE; j++) out[j] = M[(size_t)cols[j] * N + i];
+}
+// Multiplicities of the two tables over ALL N rows of the matrix (padding rows repeat the last executed row's instruction and have
+// y = 0).  A value that is not in its table is simply not counted — the sums then cannot match and the proof is rejected.
+static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& rom, std::vector<F>& rom_mult, std::vector<F>& rc_mult, size_t* first_bad_row = nullptr) {
+  rom_mult.assign(rom.n, 0); rc_mult.assign(RC_TABLE, 0);
+  if (first_bad_row) *first_bad_row = (size_t)-1;
+  for (size_t i = 0; i < N; i++) {
+    for (int k = 0; k < 4; k++) { const F v = M[(size_t)(C_RC + k) * N + i]; if (v < (F)RC_TABLE) rc_mult[v]++; else if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i; }
+    F t[N_TUPLE]; row_tuple(M, N, i, t);
+    const uint64_t pc = (uint64_t)t[0] | ((uint64_t)t[1] << 20) | ((uint64_t)t[2] << 40);
+    const uint64_t u = (pc - 0x1000) / 4;
+    if (t[0] < (1u << 20) && t[1] < (1u << 20) && t[2] < (1u << 24) && pc >= 0x1000 && (pc & 3) == 0 && u < rom.n && !memcmp(rom.row(u), t, sizeof t)) rom_mult[u]++;
+    else if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i;
+  }
+}
+// batch inversion in E (Montgomery's trick): one einv + 3 emul per element
+static void batch_einv(std::vector<E>& v) {
+  const size_t n = v.size();
+  if (!n) return;
+  std::vector<E> pre(n);
+  E acc = e_from(1);
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; acc = emul(acc, v[i]); }
+  E inv = einv(acc);
+  for (size_t i = n; i-- > 0;) { const E t = emul(inv, pre[i]); inv = emul(inv, v[i]); v[i] = t; }
+}
+// T = sum_t m_t / (alpha - t) + sum_u r_u / (alpha - fingerprint(ROM row u)): the table side of the LogUp identity
+static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, const LookupParams& lp) {
+  std::vector<E> d(RC_TABLE + rom.n);
+  for (int t = 0; t < RC_TABLE; t++) d[t] = esub(lp.alpha, e_from((F)t));
+  for (size_t u = 0; u < rom.n; u++) d[RC_TABLE + u] = esub(lp.alpha, fingerprint(rom.row(u), lp));
+  batch_einv(d);
+  E T = e_from(0);
+  for (int t = 0; t < RC_TABLE; t++) T = eadd(T, emul_f(d[t], rc_mult[t]));
+  for (size_t u = 0; u < rom.n; u++) T = eadd(T, emul_f(d[RC_TABLE + u], rom_mult[u]));
+  return T;
+}
+// aux trace [W_AUX][N] of the main-trace matrix M: helper columns of the five lookups of every row and the running sum
+static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp, std::vector<F>& A) {
+  A.assign((size_t)W_AUX * N, 0);
+  std::vector<E> d(5 * N);
+  for (size_t i = 0; i < N; i++) {
+    for (int k = 0; k < 4; k++) d[5 * i + k] = esub(lp.alpha, e_from(M[(size_t)(C_RC + k) * N + i]));
+    F t[N_TUPLE]; row_tuple(M, N, i, t);
+    d[5 * i + 4] = esub(lp.alpha, fingerprint(t, lp));
+  }
+  batch_einv(d);
+  E S = e_from(0);
+  for (size_t i = 0; i < N; i++) {
+    E hs = e_from(0);
+    for (int k = 0; k < 5; k++) {
+      const E& h = d[5 * i + k];
+      for (int c = 0; c < 4; c++) A[(size_t)((k < 4 ? A_H + 4 * k : A_HR) + c) * N + i] = h.c[c];
+      hs = eadd(hs, h);
+    }
+    for (int c = 0; c < 4; c++) A[(size_t)(A_S + c) * N + i] = S.c[c];       // S_i = sum over rows j < i of (hsum_j - T / N); S_0 = 0
+    S = eadd(S, esub(hs, lp.t_over_n));
+  }
+}
+
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 4;   // "ZKPF"; v4: v3 (AIR v1, public inputs, padding, grinding) + boundary states
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 5;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
@@ -357,7 +460,9 @@ struct AirAcc {
   const E* ap; E acc; int c;
   void push(const E& v) { acc = eadd(acc, emul(ap[c], v)); c++; }
 };
-static int constraints_sum(const E* loc, const E* nxt, const E& is_first, const E& is_last, const E& is_trans, const Public& pub, const E* ap, E& result) {
+// aloc / anxt: the aux columns (local / next row), lp: the lookup challenges and T / N.
+static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* anxt, const E& is_first, const E& is_last, const E& is_trans, const Public& pub,
+                           const LookupParams& lp, const E* ap, E& result) {
   AirAcc A{ap, e_from(0), 0};
   auto push = [&](const E& v) { A.push(v); };
   auto cst = [](uint64_t v) { return e_from((F)(v % P)); };
@@ -378,15 +483,15 @@ static int constraints_sum(const E* loc, const E* nxt, const E& is_first, const 
   for (int r = 0; r < 15; r++) { boolean(loc[C_WR + r]); boolean(loc[C_SELB + r]); boolean(loc[C_SELC + r]); }
   for (int k = 0; k < 7; k++) boolean(K[k]);
   boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]);
-  // 4. exactly one class; class <-> opcode; "oth" means none of the four constrained opcodes (default mode)
+  // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
+  //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
   { E sum = e_from(0); for (int k = 0; k < 7; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
-  push(emul(K[K_ADD], esub(op, cst(OP_ADD)))); push(emul(K[K_ADDI], esub(op, cst(OP_ADDI))));
-  push(emul(K[K_BNE], esub(op, cst(OP_BNE)))); push(emul(K[K_JAL], esub(op, cst(OP_JAL))));
-  push(esub(loc[C_T], emul(op, esub(op, cst(8)))));
-  push(esub(loc[C_T + 1], emul(esub(op, cst(OP_BNE)), esub(op, cst(OP_JAL)))));
-  push(esub(loc[C_T + 2], emul(loc[C_T], loc[C_T + 1])));
-  push(esub(loc[C_T + 4], emul(loc[C_T + 2], loc[C_T + 3])));
-  push(emul(nD, emul(K[K_OTH], esub(loc[C_T + 4], one))));
+  {
+    E ks = e_from(0);
+    for (int k = 1; k <= K_OTH; k++) ks = eadd(ks, emul_f(K[k], (F)k));
+    push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
+  }
+  (void)op;
   // 5. register selectors: wr (written register = field a for add/addi/jal, none for bne/halt/pad, at most one in default mode),
   //    selb = one-hot(fb), selc = one-hot(fc), or one-hot(fa) on BNE rows
   auto moments = [&](int base, E& s0, E& s1, E& s2) {
@@ -456,13 +561,55 @@ static int constraints_sum(const E* loc, const E* nxt, const E& is_first, const 
   push(emul(emul(esub(esub(one, K[K_PAD]), K[K_HALT]), nxt[C_K + K_PAD]), is_trans));
   // 12. (v4) the last executed row is in the public last state: what a following segment starts from
   for (int i = 0; i < N_STATE; i++) push(emul(esub(loc[state_col(i)], cst(pub.last[i])), is_last));
+  // ---- AIR v2: the lookup argument.  Extension-field columns are four base columns (coordinates in F[X]/(X^4 - 11)); a constraint
+  //      between extension values is stated coordinate by coordinate, so every polynomial involved stays a base-field polynomial.
+  // product of two extension values given by coordinates: out_k = sum_{i+j=k} h_i d_j + 11 sum_{i+j=k+4} h_i d_j
+  auto ext_mul = [&](const E* h, const E* d, E* out) {
+    for (int k = 0; k < 4; k++) {
+      E lo = e_from(0), hi = e_from(0);
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { if (i + j == k) lo = eadd(lo, emul(h[i], d[j])); else if (i + j == k + 4) hi = eadd(hi, emul(h[i], d[j])); }
+      out[k] = eadd(lo, emul_f(hi, WEXT));
+    }
+  };
+  // 13. the written value's low limbs are two 10-bit chunks each (their range is the lookup below)
+  const E* R = loc + C_RC;
+  push(esub(esub(y[0], R[0]), emul_f(R[1], RC_TABLE)));
+  push(esub(esub(y[1], R[2]), emul_f(R[3], RC_TABLE)));
+  // 14. range helpers: H_i (alpha - R_i) = 1
+  for (int i = 0; i < 4; i++) {
+    E d[4], pr[4];
+    for (int k = 0; k < 4; k++) d[k] = cst(lp.alpha.c[k]);
+    d[0] = esub(d[0], R[i]);
+    ext_mul(aloc + A_H + 4 * i, d, pr);
+    push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
+  }
+  // 15. instruction ROM: HR (alpha - fingerprint(pc limbs, op, fa, fb, fc, fhi, s, opclass)) = 1
+  {
+    static const int cols[N_TUPLE] = {C_PC, C_PC + 1, C_PC + 2, C_OP, C_FA, C_FB, C_FC, C_FHI, C_S, C_OPC};
+    E d[4], pr[4];
+    for (int k = 0; k < 4; k++) {
+      E fp = cst(lp.lam[N_TUPLE].c[k]);
+      for (int j = 0; j < N_TUPLE; j++) fp = eadd(fp, emul_f(loc[cols[j]], lp.lam[j].c[k]));
+      d[k] = esub(cst(lp.alpha.c[k]), fp);
+    }
+    ext_mul(aloc + A_HR, d, pr);
+    push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
+  }
+  // 16. running sum, cyclic over ALL N rows (no selector): S(w x) - S(x) = H0 + H1 + H2 + H3 + HR - T / N.  Summed over the cycle the left
+  //     side telescopes to zero, so the row side of the LogUp identity equals T, the table side the verifier computed.
+  for (int k = 0; k < 4; k++) {
+    E hs = aloc[A_HR + k];
+    for (int i = 0; i < 4; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
+    push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
+  }
   result = A.acc;
   return A.c;
 }
 static int num_constraints() {                                            // by a dry run (the list above is the definition)
   std::vector<E> z(W_MAIN, e_from(0)), ap(MAX_CONSTRAINTS, e_from(0));
-  E r; Public pub;
-  return constraints_sum(z.data(), z.data(), e_from(0), e_from(0), e_from(0), pub, ap.data(), r);
+  E r; Public pub; LookupParams lp;
+  memset(&lp, 0, sizeof lp);
+  return constraints_sum(z.data(), z.data(), z.data(), z.data(), e_from(0), e_from(0), e_from(0), pub, lp, ap.data(), r);
 }
 
 struct Proof { std::vector<uint32_t> w; };
@@ -497,7 +644,10 @@ static void initial_state(uint64_t entry, F st[N_STATE]) {
 
 struct ProverTrace {     // everything the oracle keeps for inspection by tests
   std::vector<F> M, L, Qc;            // [W][N], [W][2N], [4][2N]
-  Merkle trace_tree, quot_tree;
+  std::vector<F> A, AL;               // aux trace [W_AUX][N] and its LDE [W_AUX][2N]
+  std::vector<F> rom_mult, rc_mult;
+  LookupParams lp;
+  Merkle trace_tree, aux_tree, quot_tree;
   std::vector<std::vector<E>> fri;    // codewords per layer (layer 0 = DEEP codeword, size 2N)
   std::vector<Merkle> fri_trees;
   E alpha, zeta, gamma; std::vector<E> betas; std::vector<uint32_t> queries; F pow_nonce = 0;
@@ -528,6 +678,33 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   Challenger ch;
   ch.observe_n(w.data() + 2, w.size() - 2);
   ch.observe_n(pt.trace_tree.layers.back().data(), 4);
+  // ---- the program (its code words are the instruction ROM) and the lookup multiplicities, fixed BEFORE the lookup challenges ----
+  const Rom rom = rom_from_blob(pub.blob, pub.blob_len);
+  w.push_back((uint32_t)pub.blob_len);
+  for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
+  lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult);
+  w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
+  w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
+  ch.observe_n(pt.rom_mult.data(), pt.rom_mult.size());
+  ch.observe_n(pt.rc_mult.data(), pt.rc_mult.size());
+  pt.lp.alpha = ch.sample_ext();
+  {
+    const E lambda = ch.sample_ext();
+    pt.lp.lam[0] = e_from(1);
+    for (int j = 1; j <= N_TUPLE; j++) pt.lp.lam[j] = emul(pt.lp.lam[j - 1], lambda);
+  }
+  pt.lp.t_over_n = emul_f(lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp), finv((F)(N % P)));
+  // ---- aux trace: helper columns + running sum; its own LDE and commitment ----
+  aux_trace(pt.M, N, pt.lp, pt.A);
+  pt.AL.assign((size_t)W_AUX * N2, 0);
+  std::vector<std::vector<F>> acoeffs(W_AUX);
+  for (int k = 0; k < W_AUX; k++) {
+    std::vector<F> e(pt.A.begin() + (size_t)k * N, pt.A.begin() + (size_t)(k + 1) * N), o;
+    lde(e, 1, acoeffs[k], o);
+    memcpy(&pt.AL[(size_t)k * N2], o.data(), N2 * 4);
+  }
+  merkle_build(pt.AL, W_AUX, N2, pt.aux_tree);
+  ch.observe_n(pt.aux_tree.layers.back().data(), 4);
   pt.alpha = ch.sample_ext();
   const int NC = num_constraints();
   std::vector<E> ap(NC); ap[0] = e_from(1); for (int c = 1; c < NC; c++) ap[c] = emul(ap[c - 1], pt.alpha);
@@ -539,15 +716,16 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   pt.Qc.assign(4 * N2, 0);
   {
     F x = GEN;
-    std::vector<E> loc(Wm), nxt(Wm);
+    std::vector<E> loc(Wm), nxt(Wm), aloc(W_AUX), anxt(W_AUX);
     for (size_t j = 0; j < N2; j++) {
       for (int k = 0; k < Wm; k++) { loc[k] = e_from(pt.L[(size_t)k * N2 + j]); nxt[k] = e_from(pt.L[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      for (int k = 0; k < W_AUX; k++) { aloc[k] = e_from(pt.AL[(size_t)k * N2 + j]); anxt[k] = e_from(pt.AL[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
       const F zh = fsub((j & 1) ? fneg(gN) : gN, 1);                      // x^N - 1, x^N = g^N (-1)^j
       const F inv_zh = finv(zh);
       const E is_first = e_from(fmul(zh, finv(fsub(x, 1))));
       const E is_last = e_from(fmul(zh, finv(fsub(x, w_last))));
       const E is_trans = e_from(fsub(x, wn_inv));
-      E sum; constraints_sum(loc.data(), nxt.data(), is_first, is_last, is_trans, pub, ap.data(), sum);
+      E sum; constraints_sum(loc.data(), nxt.data(), aloc.data(), anxt.data(), is_first, is_last, is_trans, pub, pt.lp, ap.data(), sum);
       E q = emul_f(sum, inv_zh);
       for (int i = 0; i < 4; i++) pt.Qc[(size_t)i * N2 + j] = q.c[i];
       x = fmul(x, w2n);
@@ -559,8 +737,11 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   const E zeta_w = emul_f(pt.zeta, wn);
 
   // ---- openings (oracle: Horner on coefficient vectors) ----
-  std::vector<E> t_z(Wm), t_zw(Wm), q_z(4);
+  // column order everywhere below (openings, gamma powers): main columns, then aux columns = W_ALL "trace" columns
+  const int Wt = W_ALL;
+  std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
   for (int k = 0; k < Wm; k++) { t_z[k] = horner_base(coeffs[k], pt.zeta); t_zw[k] = horner_base(coeffs[k], zeta_w); }
+  for (int k = 0; k < W_AUX; k++) { t_z[Wm + k] = horner_base(acoeffs[k], pt.zeta); t_zw[Wm + k] = horner_base(acoeffs[k], zeta_w); }
   for (int i = 0; i < 4; i++) {                                           // quotient columns: interpolate from the coset evaluations
     std::vector<F> ev(pt.Qc.begin() + (size_t)i * N2, pt.Qc.begin() + (size_t)(i + 1) * N2);
     ntt(ev, true);                                                        // coefficients of q_i(g x)
@@ -568,23 +749,24 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
     for (size_t k2 = 0; k2 < N2; k2++) { ev[k2] = fmul(ev[k2], sc); sc = fmul(sc, ginv); }
     q_z[i] = horner_base(ev, pt.zeta);
   }
-  for (int k = 0; k < Wm; k++) ch.observe_ext(t_z[k]);
-  for (int k = 0; k < Wm; k++) ch.observe_ext(t_zw[k]);
+  for (int k = 0; k < Wt; k++) ch.observe_ext(t_z[k]);
+  for (int k = 0; k < Wt; k++) ch.observe_ext(t_zw[k]);
   for (int i = 0; i < 4; i++) ch.observe_ext(q_z[i]);
   pt.gamma = ch.sample_ext();
 
   // ---- DEEP codeword over the LDE coset ----
-  std::vector<E> gp(2 * Wm + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], pt.gamma);
+  std::vector<E> gp(2 * Wt + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], pt.gamma);
   E a0 = e_from(0), b0 = e_from(0);
-  for (int k = 0; k < Wm; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wm + k], t_zw[k])); }
-  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wm + i], q_z[i]));
+  for (int k = 0; k < Wt; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wt + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wt + i], q_z[i]));
   std::vector<E> cw(N2);
   {
     F x = GEN;
     for (size_t j = 0; j < N2; j++) {
       E A = e_from(0), B = e_from(0);
-      for (int k = 0; k < Wm; k++) { const F v = pt.L[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[k], v)); B = eadd(B, emul_f(gp[Wm + k], v)); }
-      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wm + i], pt.Qc[(size_t)i * N2 + j]));
+      for (int k = 0; k < Wm; k++) { const F v = pt.L[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[k], v)); B = eadd(B, emul_f(gp[Wt + k], v)); }
+      for (int k = 0; k < W_AUX; k++) { const F v = pt.AL[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[Wm + k], v)); B = eadd(B, emul_f(gp[Wt + Wm + k], v)); }
+      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wt + i], pt.Qc[(size_t)i * N2 + j]));
       const E d1 = einv(esub(e_from(x), pt.zeta)), d2 = einv(esub(e_from(x), zeta_w));
       cw[j] = eadd(emul(esub(A, a0), d1), emul(esub(B, b0), d2));
       x = fmul(x, w2n);
@@ -625,11 +807,13 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   pt.queries.clear();
   for (int t = 0; t < NUM_QUERIES; t++) pt.queries.push_back(ch.sample_bits(log_n));
 
-  // ---- serialize: [0..21) header | trace root | quotient root | openings | FRI roots | final codeword | pow nonce | queries ----
+  // ---- serialize: header | program (length, halfwords) | ROM multiplicities | range multiplicities (all pushed above) | trace root | aux root |
+  //      quotient root | openings (main + aux at zeta, main + aux at zeta w, quotient) | FRI roots | final codeword | pow nonce | queries ----
   for (int i = 0; i < 4; i++) w.push_back(pt.trace_tree.layers.back()[i]);
+  for (int i = 0; i < 4; i++) w.push_back(pt.aux_tree.layers.back()[i]);
   for (int i = 0; i < 4; i++) w.push_back(pt.quot_tree.layers.back()[i]);
-  for (int k = 0; k < Wm; k++) put_e(w, t_z[k]);
-  for (int k = 0; k < Wm; k++) put_e(w, t_zw[k]);
+  for (int k = 0; k < Wt; k++) put_e(w, t_z[k]);
+  for (int k = 0; k < Wt; k++) put_e(w, t_zw[k]);
   for (int i = 0; i < 4; i++) put_e(w, q_z[i]);
   w.push_back((uint32_t)pt.fri_trees.size());
   for (auto& tr : pt.fri_trees) for (int i = 0; i < 4; i++) w.push_back(tr.layers.back()[i]);
@@ -638,6 +822,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   for (uint32_t q : pt.queries) {
     w.push_back(q);
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wm; k++) w.push_back(pt.L[(size_t)k * N2 + pos]); merkle_path(pt.trace_tree, pos, w); }
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < W_AUX; k++) w.push_back(pt.AL[(size_t)k * N2 + pos]); merkle_path(pt.aux_tree, pos, w); }
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int i = 0; i < 4; i++) w.push_back(pt.Qc[(size_t)i * N2 + pos]); merkle_path(pt.quot_tree, pos, w); }
     for (size_t j = 0; j < pt.fri_trees.size(); j++) {
       const size_t g = pt.fri[j].size() >> ks[j], idx = q & (g - 1);
@@ -677,13 +862,31 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   p = HEADER_WORDS;
   const size_t N = (size_t)1 << log_n;
   for (size_t i = 2; i < len; i++) if (w[i] >= P) return 3;   // every payload word must be canonical (query indices are < N < p)
-  if (!need(8)) return 4;
-  const F* troot = w + p; p += 4; const F* qroot = w + p; p += 4;
+  // the program: [byte length][16-bit halfwords]; its digest must be the header's, its entry point the header's (check 8)
+  if (!need(1)) return 4;
+  const size_t blob_len = w[p++];
+  if (blob_len > ((size_t)1 << 30) || !need((blob_len + 1) / 2)) return 4;
+  std::vector<uint8_t> blob(blob_len);
+  for (size_t i = 0; i < blob_len; i += 2) {
+    const uint32_t h = w[p + i / 2];
+    if (h > 0xFFFF || (i + 1 >= blob_len && h > 0xFF)) return 8;
+    blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8);
+  }
+  p += (blob_len + 1) / 2;
+  { F dg[DIGEST]; digest_bytes(blob.data(), blob_len, dg); if (memcmp(dg, pub.prog, 16)) return 8; }
+  const Rom rom = rom_from_blob(blob.data(), blob_len);
+  if (!rom.ok || rom.entry != pub.entry) return 8;
+  if (!need(rom.n + RC_TABLE)) return 4;
+  const F* rom_mult = w + p; p += rom.n;
+  const F* rc_mult = w + p; p += RC_TABLE;
+  if (!need(12)) return 4;
+  const F* troot = w + p; p += 4; const F* aroot = w + p; p += 4; const F* qroot = w + p; p += 4;
   auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
-  if (!need((size_t)(2 * Wm + 4) * 4)) return 4;
-  std::vector<E> t_z(Wm), t_zw(Wm), q_z(4);
-  for (int k = 0; k < Wm; k++) { t_z[k] = get_e(p); p += 4; }
-  for (int k = 0; k < Wm; k++) { t_zw[k] = get_e(p); p += 4; }
+  const int Wt = W_ALL;
+  if (!need((size_t)(2 * Wt + 4) * 4)) return 4;
+  std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
+  for (int k = 0; k < Wt; k++) { t_z[k] = get_e(p); p += 4; }
+  for (int k = 0; k < Wt; k++) { t_zw[k] = get_e(p); p += 4; }
   for (int i = 0; i < 4; i++) { q_z[i] = get_e(p); p += 4; }
   if (!need(1)) return 4;
   const int n_layers = w[p++];
@@ -699,11 +902,22 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   Challenger ch;
   ch.observe_n(w + 2, HEADER_WORDS - 2);
   ch.observe_n(troot, 4);
+  ch.observe_n(rom_mult, rom.n);
+  ch.observe_n(rc_mult, RC_TABLE);
+  LookupParams lp;
+  lp.alpha = ch.sample_ext();
+  {
+    const E lambda = ch.sample_ext();
+    lp.lam[0] = e_from(1);
+    for (int j = 1; j <= N_TUPLE; j++) lp.lam[j] = emul(lp.lam[j - 1], lambda);
+  }
+  lp.t_over_n = emul_f(lookup_table_sum(rom, rom_mult, rc_mult, lp), finv((F)(N % P)));   // the table side of the lookup identity, computed HERE
+  ch.observe_n(aroot, 4);
   const E alpha = ch.sample_ext();
   ch.observe_n(qroot, 4);
   const E zeta = ch.sample_ext();
-  for (int k = 0; k < Wm; k++) ch.observe_ext(t_z[k]);
-  for (int k = 0; k < Wm; k++) ch.observe_ext(t_zw[k]);
+  for (int k = 0; k < Wt; k++) ch.observe_ext(t_z[k]);
+  for (int k = 0; k < Wt; k++) ch.observe_ext(t_zw[k]);
   for (int i = 0; i < 4; i++) ch.observe_ext(q_z[i]);
   const E gamma = ch.sample_ext();
   std::vector<E> betas(n_layers);
@@ -719,7 +933,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     const E is_first = emul(zh, einv(esub(zeta, e_from(1))));
     const E is_last = emul(zh, einv(esub(zeta, e_from(fpow(wn, pub.n_real - 1)))));
     const E is_trans = esub(zeta, e_from(finv(wn)));
-    E lhs; constraints_sum(t_z.data(), t_zw.data(), is_first, is_last, is_trans, pub, ap.data(), lhs);
+    E lhs; constraints_sum(t_z.data(), t_zw.data(), t_z.data() + Wm, t_zw.data() + Wm, is_first, is_last, is_trans, pub, lp, ap.data(), lhs);
     E qz = e_from(0);
     for (int i = 0; i < 4; i++) { E basis = e_from(0); basis.c[i] = 1; qz = eadd(qz, emul(basis, q_z[i])); }
     if (!eeq(lhs, emul(qz, zh))) return 10;
@@ -734,10 +948,10 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     }
   }
   // 3. queries
-  std::vector<E> gp(2 * Wm + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], gamma);
+  std::vector<E> gp(2 * Wt + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], gamma);
   E a0 = e_from(0), b0 = e_from(0);
-  for (int k = 0; k < Wm; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wm + k], t_zw[k])); }
-  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wm + i], q_z[i]));
+  for (int k = 0; k < Wt; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wt + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wt + i], q_z[i]));
   const E zeta_w = emul_f(zeta, root_of_unity(log_n));
   const F w2n = root_of_unity(log_n + 1);
   const int depth0 = log_n + 1;
@@ -745,13 +959,21 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     const uint32_t q = ch.sample_bits(log_n);
     if (!need(1) || w[p++] != q) return 20;
     E deep[2];
-    const uint32_t* tl[2]; const uint32_t* ql[2];
+    const uint32_t* tl[2]; const uint32_t* al[2]; const uint32_t* ql[2];
     for (int s2 = 0; s2 < 2; s2++) {
       const size_t pos = (size_t)q + (s2 ? N : 0);
       if (!need((size_t)Wm + 4 * depth0)) return 4;
       tl[s2] = w + p; p += Wm;
       F dg[4]; hash_elems(tl[s2], Wm, dg);
       if (!check_path(dg, pos, w + p, depth0, troot)) return 21;
+      p += 4 * depth0;
+    }
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      if (!need((size_t)W_AUX + 4 * depth0)) return 4;
+      al[s2] = w + p; p += W_AUX;
+      F dg[4]; hash_elems(al[s2], W_AUX, dg);
+      if (!check_path(dg, pos, w + p, depth0, aroot)) return 27;
       p += 4 * depth0;
     }
     for (int s2 = 0; s2 < 2; s2++) {
@@ -766,8 +988,9 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
       const size_t pos = (size_t)q + (s2 ? N : 0);
       const F x = fmul(GEN, fpow(w2n, pos));
       E A = e_from(0), B = e_from(0);
-      for (int k = 0; k < Wm; k++) { A = eadd(A, emul_f(gp[k], tl[s2][k])); B = eadd(B, emul_f(gp[Wm + k], tl[s2][k])); }
-      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wm + i], ql[s2][i]));
+      for (int k = 0; k < Wm; k++) { A = eadd(A, emul_f(gp[k], tl[s2][k])); B = eadd(B, emul_f(gp[Wt + k], tl[s2][k])); }
+      for (int k = 0; k < W_AUX; k++) { A = eadd(A, emul_f(gp[Wm + k], al[s2][k])); B = eadd(B, emul_f(gp[Wt + Wm + k], al[s2][k])); }
+      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wt + i], ql[s2][i]));
       deep[s2] = eadd(emul(esub(A, a0), einv(esub(e_from(x), zeta))), emul(esub(B, b0), einv(esub(e_from(x), zeta_w))));
     }
     // FRI layers: the leaf of layer j holds the 2^k values that the next k binary folds combine into one
@@ -835,9 +1058,11 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
 // C API (ctypes)
 // =================================================================================================
 extern "C" {
-struct so_public { uint64_t n_real; uint32_t deferred; uint32_t pad; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; };
+struct so_public { uint64_t n_real; uint32_t deferred; uint32_t pad; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; const uint8_t* blob; uint64_t blob_len; };
 static so::Public to_pub(const so_public* p) {
-  so::Public q; q.n_real = p->n_real; q.deferred = p->deferred; q.entry = p->entry; memcpy(q.prog, p->prog, 16); memcpy(q.io, p->io, 16); return q;
+  so::Public q; q.n_real = p->n_real; q.deferred = p->deferred; q.entry = p->entry; memcpy(q.prog, p->prog, 16); memcpy(q.io, p->io, 16);
+  q.blob = p->blob; q.blob_len = (size_t)p->blob_len;
+  return q;
 }
 uint32_t so_p() { return so::P; }
 uint32_t so_fmul(uint32_t a, uint32_t b) { return so::fmul(a, b); }
@@ -867,34 +1092,73 @@ int so_num_constraints() { return so::num_constraints(); }
 void so_main_trace(const void* packed_rows, const so_public* pub, uint32_t* out /* [W_MAIN][N] */) {
   std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m); memcpy(out, m.data(), m.size() * 4);
 }
+// lookup parameters as 52 words: alpha (4), lambda^0..lambda^10 (44), T / N (4)
+static void lk_pack(const so::LookupParams& lp, uint32_t* out) {
+  memcpy(out, lp.alpha.c, 16);
+  for (int j = 0; j <= so::N_TUPLE; j++) memcpy(out + 4 + 4 * j, lp.lam[j].c, 16);
+  memcpy(out + 4 + 4 * (so::N_TUPLE + 1), lp.t_over_n.c, 16);
+}
+static so::LookupParams lk_unpack(const uint32_t* in) {
+  so::LookupParams lp;
+  memcpy(lp.alpha.c, in, 16);
+  for (int j = 0; j <= so::N_TUPLE; j++) memcpy(lp.lam[j].c, in + 4 + 4 * j, 16);
+  memcpy(lp.t_over_n.c, in + 4 + 4 * (so::N_TUPLE + 1), 16);
+  return lp;
+}
+int so_aux_width() { return so::W_AUX; }
+int so_rc_table() { return so::RC_TABLE; }
+// The lookup side of a main-trace matrix [W_MAIN][N] for GIVEN challenges (tests): multiplicities of both tables, T / N, the aux
+// trace [W_AUX][N].  Returns the number of ROM rows (code words of pub->blob).  rom_mult (nullable) must hold that many words.
+size_t so_lookup_setup(const uint32_t* matrix, const so_public* pub, const uint32_t* alpha4, const uint32_t* lambda4, uint32_t* aux_out, uint32_t* lk52, uint32_t* rom_mult,
+                       uint32_t* rc_mult) {
+  const so::Public q = to_pub(pub);
+  const size_t N = (size_t)1 << so::padded_log_n(q.n_real);
+  const so::Rom rom = so::rom_from_blob(q.blob, q.blob_len);
+  std::vector<so::F> M(matrix, matrix + (size_t)so::W_MAIN * N), rm, cm, A;
+  so::lookup_multiplicities(M, N, rom, rm, cm);
+  so::LookupParams lp;
+  memcpy(lp.alpha.c, alpha4, 16);
+  so::E lambda; memcpy(lambda.c, lambda4, 16);
+  lp.lam[0] = so::e_from(1);
+  for (int j = 1; j <= so::N_TUPLE; j++) lp.lam[j] = so::emul(lp.lam[j - 1], lambda);
+  lp.t_over_n = so::emul_f(so::lookup_table_sum(rom, rm.data(), cm.data(), lp), so::finv((so::F)(N % so::P)));
+  so::aux_trace(M, N, lp, A);
+  if (aux_out) memcpy(aux_out, A.data(), A.size() * 4);
+  if (lk52) lk_pack(lp, lk52);
+  if (rom_mult && rom.n) memcpy(rom_mult, rm.data(), rom.n * 4);
+  if (rc_mult) memcpy(rc_mult, cm.data(), so::RC_TABLE * 4);
+  return rom.n;
+}
 // Σ alpha^c C_c of one (local, next) row pair with base-field values and the given selector values (tests: which constraint fails)
-int so_constraints_eval(const uint32_t* loc, const uint32_t* nxt, uint32_t is_first, uint32_t is_last, uint32_t is_trans, const so_public* pub, const uint32_t* alpha4,
-                        uint32_t* out4) {
+int so_constraints_eval(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk52, uint32_t is_first, uint32_t is_last,
+                        uint32_t is_trans, const so_public* pub, const uint32_t* alpha4, uint32_t* out4) {
   const int NC = so::num_constraints();
   so::E a; memcpy(a.c, alpha4, 16);
   std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
-  std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN);
+  std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN), al(so::W_AUX), ax(so::W_AUX);
   for (int k = 0; k < so::W_MAIN; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
+  for (int k = 0; k < so::W_AUX; k++) { al[k] = so::e_from(aloc[k]); ax[k] = so::e_from(anxt[k]); }
   so::E r;
   so::Public q = to_pub(pub);
   so::initial_state(q.entry, q.first);                                                    // a whole run's first state;
   if (is_last) for (int i = 0; i < so::N_STATE; i++) q.last[i] = loc[so::state_col(i)];   // the last state is whatever the last row holds
-  so::constraints_sum(l.data(), x.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, ap.data(), r);
+  so::constraints_sum(l.data(), x.data(), al.data(), ax.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, lk_unpack(lk52), ap.data(), r);
   memcpy(out4, r.c, 16);
   return NC;
 }
 // the same with explicit boundary states (68 words each): segments
-int so_constraints_eval_states(const uint32_t* loc, const uint32_t* nxt, uint32_t is_first, uint32_t is_last, uint32_t is_trans, const so_public* pub, const uint32_t* first68,
-                               const uint32_t* last68, const uint32_t* alpha4, uint32_t* out4) {
+int so_constraints_eval_states(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk52, uint32_t is_first, uint32_t is_last,
+                               uint32_t is_trans, const so_public* pub, const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t* out4) {
   const int NC = so::num_constraints();
   so::E a; memcpy(a.c, alpha4, 16);
   std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
-  std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN);
+  std::vector<so::E> l(so::W_MAIN), x(so::W_MAIN), al(so::W_AUX), ax(so::W_AUX);
   for (int k = 0; k < so::W_MAIN; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
+  for (int k = 0; k < so::W_AUX; k++) { al[k] = so::e_from(aloc[k]); ax[k] = so::e_from(anxt[k]); }
   so::Public q = to_pub(pub);
   memcpy(q.first, first68, sizeof q.first); memcpy(q.last, last68, sizeof q.last);
   so::E r;
-  so::constraints_sum(l.data(), x.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, ap.data(), r);
+  so::constraints_sum(l.data(), x.data(), al.data(), ax.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, lk_unpack(lk52), ap.data(), r);
   memcpy(out4, r.c, 16);
   return NC;
 }
@@ -953,6 +1217,8 @@ int so_state_words() { return so::N_STATE; }
 void so_last_challenges(uint32_t* alpha, uint32_t* zeta, uint32_t* gamma) { memcpy(alpha, g_pt.alpha.c, 16); memcpy(zeta, g_pt.zeta.c, 16); memcpy(gamma, g_pt.gamma.c, 16); }
 void so_last_quotient(uint32_t* out /* [4][2N] */) { memcpy(out, g_pt.Qc.data(), g_pt.Qc.size() * 4); }
 size_t so_last_fri_layer(int j, uint32_t* out /* [m][4] */) { if (j < 0 || (size_t)j >= g_pt.fri.size()) return 0; if (out) memcpy(out, g_pt.fri[j].data(), g_pt.fri[j].size() * 16); return g_pt.fri[j].size(); }
+void so_last_lookup(uint32_t* lk52) { lk_pack(g_pt.lp, lk52); }
+void so_last_aux(uint32_t* out /* [W_AUX][N] */) { memcpy(out, g_pt.A.data(), g_pt.A.size() * 4); }
 int so_num_queries() { return so::NUM_QUERIES; }
 int so_log_final() { return so::LOG_FINAL; }
 int so_pow_bits() { return so::POW_BITS; }

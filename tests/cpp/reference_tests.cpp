@@ -207,7 +207,7 @@ static void test_prove_and_verify() {
   VMConfig cfg; cfg.enable_execution_trace = true;
   ExecutionResult r = VM::new_(prog, {}, cfg).run();
   CHECK(r.outputs == std::vector<uint64_t>{144} && r.cycles == 64);
-  const zkir_public_inputs pub = zkir_prover::public_inputs(r, prog, {}, cfg);
+  const zkir_prover::PublicInputs pub = zkir_prover::public_inputs(r, prog, {}, cfg);     // owns the program bytes the prover reads the ROM from
   CHECK(pub.n_real == 64 && pub.entry_point == 0x1000 && pub.deferred == 0);
   zkir_prover::StarkContext ctx(zkir_padded_log_n(pub.n_real));
   const std::vector<uint32_t> proof = zkir_prover::prove(ctx, r, pub);

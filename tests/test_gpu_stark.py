@@ -189,12 +189,33 @@ def test_wrong_execution_is_rejected_on_the_gpu_path():
     bad = stark.prove(ctx, tr, pub)
     assert so.verify(bad, opub) == 10 and rt.verify(bad, pub) == 10
     tr.registers[4, k + 1:nxt + 1] = saved
+    # A row whose (pc, instruction word) is not in the program's code table has NO proof in AIR v2 (instruction-ROM lookup): the honest
+    # prover refuses it instead of emitting a proof the verifier would reject — a BNE's fall-through claimed where the run branched
+    # (the word at the claimed pc is another one), an instruction word patched in HBM (ADD -> SUB: the forgery AIR v1 accepted)
     kb = int(np.nonzero(ops == 0x41)[0][3])
     saved_pc = tr.pc[kb + 1].clone()
-    tr.pc[kb + 1] = tr.pc[kb] + 4                                                           # BNE taken in the run, fall-through claimed
-    bad = stark.prove(ctx, tr, pub)
-    assert so.verify(bad, opub) == 10 and rt.verify(bad, pub) == 10
+    tr.pc[kb + 1] = tr.pc[kb] + 4
+    with pytest.raises(rt.RuntimeError) as e:
+        stark.prove(ctx, tr, pub)
+    assert e.value.code == rt.ERR_ARGUMENT and f"row {kb + 1} " in e.value.message and "code table" in e.value.message
     tr.pc[kb + 1] = saved_pc
+    saved_w = tr.instruction[k].clone()
+    tr.instruction[k] = (int(saved_w) & ~0x7F) | 0x01
+    with pytest.raises(rt.RuntimeError) as e:
+        stark.prove(ctx, tr, pub)
+    assert e.value.code == rt.ERR_ARGUMENT and f"row {k} " in e.value.message
+    tr.instruction[k] = saved_w
+    # ... and so has a run of a program that rewrites its own code: the executed word is not the program's
+    from zkir_amd import pipeline as pl
+    import programs
+    sm_blob, sm_in, sm_cfg = programs.ALL["self_modifying"]()
+    sm_log = rt.interpret(sm_blob, sm_in, rt.VMConfig(enable_execution_trace=True, **sm_cfg))
+    sm_ddl = pl.upload(sm_log); sm_tr = pl.DeviceTrace(sm_ddl); pl.trace_fill(pl.trace_fill_args(sm_ddl, sm_tr))
+    sm_ctx = stark.StarkContext(stark.padded_log_n(sm_log.n_rows))
+    with pytest.raises(rt.RuntimeError) as e:
+        stark.prove(sm_ctx, sm_tr, rt.public_inputs(sm_log, sm_blob, sm_in))
+    assert "code table" in e.value.message
+    sm_ctx.close(); sm_log.close()
     good = stark.prove(ctx, tr, pub)
     assert rt.verify(good, pub) == 0 and np.array_equal(good, so.prove(rows, opub))
     ctx.close(); log.close()
@@ -342,7 +363,7 @@ def test_full_size_2p20_properties():
     del L, tree, Lh, t
     proof = stark.prove(ctx, tr, pub)
     assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0
-    assert np.array_equal(proof[157:161], root)
+    assert stark.trace_root(proof) == [int(x) for x in root]
     ctx.close(); log.close()
 
 

@@ -21,7 +21,7 @@ def test_goldens_describe_the_shipped_programs():
     assert bytes.fromhex(CASES["fib_2p10"]["program_blob_hex"]) == spec.fib_endless_program().to_bytes()
     assert bytes.fromhex(CASES["sha_2p9"]["program_blob_hex"]) == spec.sha256_chain_program().to_bytes()
     assert bytes.fromhex(CASES["fib30_exit_154_rows"]["program_blob_hex"]) == spec.fib_program(30).to_bytes()
-    assert G["proof_version"] == 3 and G["main_trace_width"] == so.W_MAIN == 152 and G["num_constraints"] == so.lib().so_num_constraints()
+    assert G["proof_version"] == 5 and G["main_trace_width"] == so.W_MAIN == 152 and G["num_constraints"] == so.lib().so_num_constraints()
     assert [int(x) for x in so.permute(list(range(12)))] == G["poseidon2_of_0_to_11"]
     st = np.arange(12, dtype=np.uint32)
     rt.lib().zkir_poseidon2_permute(st.ctypes.data)                                  # the product's host permutation
@@ -37,7 +37,9 @@ def test_oracle_reproduces_goldens(name):
     pub = so.public_inputs(len(res.rows), blob, [], c["outputs"], tuple(c["halt"]), deferred=c["deferred"])
     assert [int(x) for x in pub.prog] == c["program_digest"] and [int(x) for x in pub.io] == c["io_digest"]
     proof = so.prove(res.rows, pub)
-    assert [int(x) for x in proof[157:161]] == c["trace_root"] and [int(x) for x in proof[161:165]] == c["quotient_root"]
+    t0 = so.proof_layout(proof)["trace_root"]
+    assert int(proof[1]) == 5 and [int(x) for x in proof[t0:t0 + 4]] == c["trace_root"] and [int(x) for x in proof[t0 + 4:t0 + 8]] == c["aux_root"]
+    assert [int(x) for x in proof[t0 + 8:t0 + 12]] == c["quotient_root"]
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof) == 0                                                      # the product's verifier accepts the frozen proofs
 
@@ -55,7 +57,8 @@ def test_gpu_prover_reproduces_goldens(name):
     assert list(pub.program_digest) == c["program_digest"] and list(pub.io_digest) == c["io_digest"]
     ctx = stark.StarkContext(stark.padded_log_n(res.cycles))
     proof = stark.prove(ctx, res.execution_trace.columns, pub)
-    assert [int(x) for x in proof[157:161]] == c["trace_root"] and [int(x) for x in proof[161:165]] == c["quotient_root"]
+    t0 = so.proof_layout(proof)["trace_root"]
+    assert [int(x) for x in proof[t0:t0 + 4]] == c["trace_root"] and [int(x) for x in proof[t0 + 4:t0 + 8]] == c["aux_root"] and [int(x) for x in proof[t0 + 8:t0 + 12]] == c["quotient_root"]
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof, pub) == 0
     ctx.close(); res.close()

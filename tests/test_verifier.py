@@ -67,17 +67,22 @@ def test_rejects_cheating_provers_like_the_oracle():
     m0 = so.main_trace(rows, pub)
     ops = rows["instruction"] & 0x7F
     k = int(np.nonzero(ops == 0x00)[0][2])
-    C_K, C_T, C_WR, C_XB, C_Y = 127, 134, 73, 118, 124
+    C_K, C_OPC, C_RC, C_WR, C_XB, C_Y, C_FA = 127, 134, 135, 73, 118, 124, 5
 
-    def relabel(m):
-        m[C_K + 0, k] = 0; m[C_K + 4, k] = 1; m[C_T + 4, k] = 1
+    def relabel(m):                                               # an ADD row runs as "other", with the word's class forged to match: not a ROM row
+        m[C_K + 0, k] = 0; m[C_K + 4, k] = 1; m[C_OPC, k] = 4
+
+    def chunk_out_of_table(m):                                    # y0 = chunk0 + 1024 chunk1 still holds, but chunk1 is not a table entry
+        m[C_RC, k] = (int(m[C_RC, k]) + 1024) % P; m[C_RC + 1, k] = (int(m[C_RC + 1, k]) - 1) % P
     edits = [relabel, lambda m: m.__setitem__((C_WR + 6, k), 1), lambda m: m.__setitem__((C_XB, k), (int(m[C_XB, k]) + 1) % P),
-             lambda m: m.__setitem__((C_Y, k), (int(m[C_Y, k]) + 1) % P)]
+             lambda m: m.__setitem__((C_Y, k), (int(m[C_Y, k]) + 1) % P), chunk_out_of_table,
+             lambda m: m.__setitem__((C_FA, k), int(m[C_FA, k]) ^ 1)]                     # another rd than the program's word has
     for e in edits:
         m = m0.copy(); e(m)
         pr = so.prove_matrix(m, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10
-    for mutate in (lambda r: r["registers"].__setitem__((slice(k + 1, k + 4), 4), 5), lambda r: r["pc"].__setitem__(k + 1, 0x2000)):
+    for mutate in (lambda r: r["registers"].__setitem__((slice(k + 1, k + 4), 4), 5), lambda r: r["pc"].__setitem__(k + 1, 0x2000),
+                   lambda r: r["instruction"].__setitem__(k, (int(r["instruction"][k]) & ~0x7F) | 0x01)):      # ADD -> SUB: the forged word AIR v1 accepted
         r = rows.copy(); mutate(r)
         pr = so.prove(r, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10

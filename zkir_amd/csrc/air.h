@@ -1,4 +1,5 @@
-// air.h — the AIR of ZKIR-STARK v1: column map of the 152-column main trace and the constraint list, written
+// air.h — the AIR of ZKIR-STARK (v2: v1 + the lookup argument): column map of the 152-column main trace and of the
+// 24-column aux trace, and the constraint list, written
 // ONCE for the two places of the product that evaluate it: the quotient kernel (stark_prove.inl; base-field values at every point
 // of the LDE coset, lazily accumulated) and the host verifier (verify.cpp; extension-field openings at zeta).  The oracle
 // (oracle/stark_oracle.cpp, constraints_sum) states the same list independently in naive arithmetic; constraint c carries the
@@ -14,9 +15,17 @@
 //   * cycle counts up; row 0 is in the public FIRST state and row n_real - 1 in the public LAST state (for a whole run the verifier
 //     requires the first state to be the VM's initial one: cycle 0, entry point, zero registers); the row count is public: row
 //     n_real - 1 is the halt row, only padding follows it, padding keeps everything.
-// Not constrained yet (stated in DESIGN.md §8.5): limb / carry / field RANGES (need the lookup argument the range-check
-// multiplicities of K2 are produced for), the instruction word at pc being the program's (same lookup), the other 46 opcodes'
-// values, and deferred-mode arithmetic (deferred = 1 relaxes the write constraints to "unwritten registers keep their value").
+// AIR v2 adds ONE LogUp lookup argument used twice (aux trace: six extension-field columns committed after the lookup challenges):
+//   * instruction ROM: the tuple (pc limbs, op, fa, fb, fc, fhi, s, opclass) of EVERY row is a row of the program's code table — the
+//     verifier builds that table from the program carried in the proof (its digest is the public program_digest), so the instruction
+//     word at pc is the program's (vm.rs:362-379), its fields are in range, and the class an executed row runs as is the class of that
+//     word (opclass), not a free witness;
+//   * ranges: the two low limbs of the written value y are two 10-bit chunks each, every chunk a row of the 2^10 table
+//     (range_check.rs:175-192, config.rs:78-80), which makes the boolean carries of ADD / ADDI / JAL the only solution;
+//   the prover sends the multiplicities of both tables BEFORE the challenges (alpha, lambda) are drawn; the verifier computes the table
+//   side T = sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u) itself; the running-sum column closes over the cycle of N rows.
+// Not constrained yet: the other 46 opcodes' values (class "other"), memory consistency, deferred-mode arithmetic
+// (deferred = 1 relaxes the write constraints to "unwritten registers keep their value").
 #pragma once
 #include "babybear.h"
 
@@ -24,15 +33,24 @@ namespace air {
 
 constexpr int W = 152;
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
-             C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_T = 134, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
+             C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
              C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151 };
+// aux trace: H0..H3 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
+constexpr int W_AUX = 24, W_ALL = W + W_AUX;
+enum : int { A_H = 0, A_HR = 16, A_S = 20 };
+constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 10;
+// per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^10, T / N
+enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), N_LK = LK_TN + 4 };
+BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : C_OPC; }
+BB_HD constexpr uint32_t opclass_of(uint32_t op) { return op == 0x00 ? 0u : op == 0x08 ? 1u : op == 0x41 ? 2u : op == 0x48 ? 3u : 4u; }
 enum : int { K_ADD = 0, K_ADDI = 1, K_BNE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6 };
 constexpr uint32_t OP_ADD = 0x00, OP_ADDI = 0x08, OP_BNE = 0x41, OP_JAL = 0x48;
 
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
 enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 142,
-             I_ONE_CLASS = 150, I_CLASS_OP = 151, I_CHAIN = 155, I_OTH = 159, I_WR = 160, I_SELB = 163, I_SELC = 165, I_OPERAND = 167, I_VALUE = 173,
-             I_NE = 182, I_TK = 186, I_DL0 = 188, I_SE = 189, I_PC = 190, I_PC_KEEP = 193, I_REGS = 196, I_TAIL = 256, I_LAST = 259, N_CONSTRAINTS = 327 };
+             I_ONE_CLASS = 150, I_OPCLASS = 151, I_WR = 152, I_SELB = 155, I_SELC = 157, I_OPERAND = 159, I_VALUE = 165,
+             I_NE = 174, I_TK = 178, I_DL0 = 180, I_SE = 181, I_PC = 182, I_PC_KEEP = 185, I_REGS = 188, I_TAIL = 248, I_LAST = 251,
+             I_CHUNK = 319, I_RANGE = 321, I_ROM = 337, I_SUM = 341, N_CONSTRAINTS = 345 };
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -45,14 +63,15 @@ constexpr RegConsts make_reg_consts() { RegConsts c{}; for (int i = 0; i < 16; i
 
 // `Ops` supplies the value type and its arithmetic:
 //   using V;  V add(V,V), sub(V,V), mul(V,V);  V mulc(V, uint32_t montgomery_constant);  V cst(uint32_t montgomery_constant);
-//   V loc(int column), nxt(int column);  void push(int constraint_index, V value)      (values in Montgomery form throughout)
+//   V loc(int column), nxt(int column);  V aloc(int aux column), anxt(int aux column);  V par(int lookup parameter: LK_*);
+//   void push(int constraint_index, V value)                                          (values in Montgomery form throughout)
 // is_first / is_last / is_trans: the row selectors at the evaluation point; first_m / last_m: the public boundary states (Montgomery).
 template <class Ops>
 BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typename Ops::V is_trans, const uint32_t* first_m, const uint32_t* last_m, bool deferred) {
   using V = typename Ops::V;
   const V one = o.cst(bb::R1), zero = o.cst(0);
   auto boolean = [&](int idx, V b) { o.push(idx, o.mul(b, o.sub(b, one))); };
-  const V op = o.loc(C_OP), fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI), s = o.loc(C_S), se = o.loc(C_SE);
+  const V fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI), s = o.loc(C_S), se = o.loc(C_SE);
   V K[7];
 #pragma unroll
   for (int k = 0; k < 7; k++) K[k] = o.loc(C_K + k);
@@ -124,16 +143,13 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
     for (int k = 1; k < 7; k++) sum = o.add(sum, K[k]);
     o.push(I_ONE_CLASS, o.sub(sum, one));
   }
-  o.push(I_CLASS_OP, o.mul(K[K_ADD], op));
-  o.push(I_CLASS_OP + 1, o.mul(K[K_ADDI], o.sub(op, o.cst(M(OP_ADDI)))));
-  o.push(I_CLASS_OP + 2, o.mul(K[K_BNE], o.sub(op, o.cst(M(OP_BNE)))));
-  o.push(I_CLASS_OP + 3, o.mul(K[K_JAL], o.sub(op, o.cst(M(OP_JAL)))));
-  const V t1 = o.loc(C_T), t2 = o.loc(C_T + 1), t3 = o.loc(C_T + 2), tinv = o.loc(C_T + 3), t5 = o.loc(C_T + 4);
-  o.push(I_CHAIN, o.sub(t1, o.mul(op, o.sub(op, o.cst(M(8))))));
-  o.push(I_CHAIN + 1, o.sub(t2, o.mul(o.sub(op, o.cst(M(OP_BNE))), o.sub(op, o.cst(M(OP_JAL))))));
-  o.push(I_CHAIN + 2, o.sub(t3, o.mul(t1, t2)));
-  o.push(I_CHAIN + 3, o.sub(t5, o.mul(t3, tinv)));
-  o.push(I_OTH, deferred ? zero : o.mul(K[K_OTH], o.sub(t5, one)));
+  {
+    // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
+    V ks = K[1];
+#pragma unroll
+    for (int k = 2; k <= K_OTH; k++) ks = o.add(ks, o.mulc(K[k], M((uint64_t)k)));
+    o.push(I_OPCLASS, deferred ? zero : o.sub(o.mul(o.sub(one, o.add(K[K_HALT], K[K_PAD])), o.loc(C_OPC)), ks));
+  }
   // 5. selectors
   o.push(I_WR, deferred ? zero : o.sub(o.mul(w1, w1), w2));
   o.push(I_WR + 1, o.mul(o.add(o.add(K[K_ADD], K[K_ADDI]), K[K_JAL]), o.sub(w1, fa)));
@@ -189,6 +205,64 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   o.push(I_TAIL, o.mul(o.mul(K[K_HALT], o.sub(one, npad)), is_trans));
   o.push(I_TAIL + 1, o.mul(o.mul(K[K_PAD], o.sub(one, npad)), is_trans));
   o.push(I_TAIL + 2, o.mul(o.mul(o.sub(o.sub(one, K[K_PAD]), K[K_HALT]), npad), is_trans));
+  // ---- AIR v2: the lookup argument.  An extension-field column is four base columns (coordinates in F[X]/(X^4 - 11)); a relation between
+  //      extension values is stated coordinate by coordinate.  out_k = sum_{i+j=k} h_i d_j + 11 sum_{i+j=k+4} h_i d_j
+  auto ext_mul = [&](const V* h, const V* d, V* out) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      V lo = zero, hi = zero;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { if (i + j == k) lo = o.add(lo, o.mul(h[i], d[j])); else if (i + j == k + 4) hi = o.add(hi, o.mul(h[i], d[j])); }
+      }
+      out[k] = o.add(lo, o.mulc(hi, M(11)));
+    }
+  };
+  // 13. the written value's low limbs are two 10-bit chunks each
+  V R[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
+  o.push(I_CHUNK, o.sub(o.sub(y[0], R[0]), o.mulc(R[1], M(RC_TABLE))));
+  o.push(I_CHUNK + 1, o.sub(o.sub(y[1], R[2]), o.mulc(R[3], M(RC_TABLE))));
+  // 14. range helpers: H_i (alpha - R_i) = 1
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    V h[4], d[4], pr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_H + 4 * i + k); d[k] = o.par(LK_ALPHA + k); }
+    d[0] = o.sub(d[0], R[i]);
+    ext_mul(h, d, pr);
+    o.push(I_RANGE + 4 * i, o.sub(pr[0], one));
+#pragma unroll
+    for (int k = 1; k < 4; k++) o.push(I_RANGE + 4 * i + k, pr[k]);
+  }
+  // 15. instruction ROM: HR (alpha - fingerprint(tuple)) = 1, fingerprint = sum_j lambda^j f_j + lambda^10
+  {
+    V h[4], d[4], pr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_HR + k); d[k] = o.par(LK_LAM + 4 * N_TUPLE + k); }
+#pragma unroll 1
+    for (int j = 0; j < N_TUPLE; j++) {
+      const V f = o.loc(tuple_col(j));
+#pragma unroll
+      for (int k = 0; k < 4; k++) d[k] = o.add(d[k], o.mul(f, o.par(LK_LAM + 4 * j + k)));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] = o.sub(o.par(LK_ALPHA + k), d[k]);
+    ext_mul(h, d, pr);
+    o.push(I_ROM, o.sub(pr[0], one));
+#pragma unroll
+    for (int k = 1; k < 4; k++) o.push(I_ROM + k, pr[k]);
+  }
+  // 16. running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + H1 + H2 + H3 + HR - T / N
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    V hs = o.aloc(A_HR + k);
+#pragma unroll
+    for (int i = 0; i < 4; i++) hs = o.add(hs, o.aloc(A_H + 4 * i + k));
+    o.push(I_SUM + k, o.add(o.sub(o.sub(o.anxt(A_S + k), o.aloc(A_S + k)), hs), o.par(LK_TN + k)));
+  }
 }
 
 }  // namespace air

@@ -4,8 +4,8 @@
 // kernel here is checked bit-for-bit against it.  Stage A (this part): main-trace field columns, Poseidon2-12 Merkle commitment
 // (the coset LDE between them lives in ntt.hip).
 //
-//   main_trace_kernel   372 B/row SoA trace -> the 152 Baby Bear columns of the v1 AIR (air.h: limbs of pc / instruction fields /
-//                       registers, storage state, write and operand selectors, operands, result, opcode classes, carries),
+//   main_trace_kernel   372 B/row SoA trace -> the 152 Baby Bear columns of the AIR (air.h: limbs of pc / instruction fields /
+//                       registers, storage state, write and operand selectors, operands, result, opcode classes, range chunks, carries),
 //                       padded to a power of two, written in the B8 layout (blocks of 8 columns, [rows][8]).  HBM-bound: ~170 B
 //                       read (values + states of the row and the next) + 608 B written per row.
 //   (NTT / coset LDE kernels: ntt.hip)
@@ -80,12 +80,7 @@ __global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, ui
   if (cls == K_OTH && !deferred) cls = op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : op == OP_BNE ? K_BNE : op == OP_JAL ? K_JAL : K_OTH;
 #pragma unroll
   for (int k = 0; k < 7; k++) col(C_K + k) = cls == k;
-  {
-    const uint32_t opm = bb::to_mont(op);
-    const uint32_t t1 = bb::mont_mul(opm, bb::sub(op, 8)), t2 = bb::mont_mul(bb::to_mont(bb::sub(op, OP_BNE)), bb::sub(op, OP_JAL));   // mont(a R, b) = a b
-    const uint32_t t3 = bb::mont_mul(bb::to_mont(t1), t2), inv = f_inv(t3);
-    col(C_T) = t1; col(C_T + 1) = t2; col(C_T + 2) = t3; col(C_T + 3) = inv; col(C_T + 4) = bb::mont_mul(bb::to_mont(t3), inv);
-  }
+  col(C_OPC) = opclass_of(op);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const uint32_t tc = cls == K_BNE ? fa : fc;
   uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
   bool first = true;
@@ -139,6 +134,7 @@ __global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, ui
     y[2] = pc[2] + c1;
   }
   col(C_Y) = y[0]; col(C_Y + 1) = y[1]; col(C_Y + 2) = y[2];
+  col(C_RC) = y[0] & (RC_TABLE - 1); col(C_RC + 1) = y[0] >> RC_BITS; col(C_RC + 2) = y[1] & (RC_TABLE - 1); col(C_RC + 3) = y[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0;
   if (cls == K_ADD || cls == K_ADDI || cls == K_BNE || cls == K_JAL) {

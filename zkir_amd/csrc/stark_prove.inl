@@ -9,16 +9,17 @@ namespace {
 
 using bb::E4;
 
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, WA = air::W_AUX, WT = air::W_ALL, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 4;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 5;
 
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
   E4 alpha_pow[N_CONSTRAINTS];
-  E4 gamma_pow[2 * WM + 4];
+  E4 gamma_pow[2 * WT + 4];     // main columns, aux columns at zeta; the same at zeta w; the quotient
   E4 zeta, zeta_w, a0, b0;
   uint32_t first_m[NS], last_m[NS];   // public boundary states: rows 0 and n_real - 1 (Montgomery)
   uint32_t deferred;
+  uint32_t lk[air::N_LK];       // lookup parameters (air.h LK_*): alpha, lambda powers, T / N — base-field coordinates, Montgomery
 };
 
 // Folds per committed FRI layer (so::fri_schedule): the DEEP codeword is folded once (its leaves are the pairs (q, q + N) the trace
@@ -56,8 +57,11 @@ __device__ __forceinline__ E4 lz_reduce(const LazyE4& acc) {
 // The constraint list is air::eval (air.h), instantiated here on base-field Montgomery values read straight from the LDE matrix.
 struct QuotientOps {
   using V = uint32_t;
-  const uint32_t* __restrict__ L; uint64_t N2; uint32_t j, jn; const ProveParams* __restrict__ pp;
+  const uint32_t* __restrict__ L; const uint32_t* __restrict__ AL; uint64_t N2; uint32_t j, jn; const ProveParams* __restrict__ pp;
   LazyE4 acc; E4 partial; int pending;
+  __device__ __forceinline__ V aloc(int k) const { return bb::to_mont(AL[b8((uint32_t)k, j, N2)]); }
+  __device__ __forceinline__ V anxt(int k) const { return bb::to_mont(AL[b8((uint32_t)k, jn, N2)]); }
+  __device__ __forceinline__ V par(int i) const { return pp->lk[i]; }
   __device__ __forceinline__ V add(V a, V b) const { return bb::add(a, b); }
   __device__ __forceinline__ V sub(V a, V b) const { return bb::sub(a, b); }
   __device__ __forceinline__ V mul(V a, V b) const { return bb::mont_mul(a, b); }
@@ -72,7 +76,7 @@ struct QuotientOps {
 };
 __device__ __forceinline__ uint32_t inv_mont(uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; }
 
-__global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp,
+__global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp,
                                                        uint32_t gN_m, uint32_t wn_inv_m, uint32_t w_last_m, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m,
                                                        uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
@@ -90,13 +94,162 @@ __global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict
   const uint32_t is_first = bb::mont_mul(zh, inv_mont(bb::sub(x, one)));
   const uint32_t is_last = bb::mont_mul(zh, inv_mont(bb::sub(x, w_last_m)));
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
-  QuotientOps o{L, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0};
+  QuotientOps o{L, AL, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0};
   air::eval(o, is_first, is_last, is_trans, pp->first_m, pp->last_m, pp->deferred != 0);
   const E4 total = bb::e_add(o.partial, lz_reduce(o.acc));
   const E4 q = bb::e_from_mont(bb::e_mul_fm(total, inv_zh));
   uint4* q4 = reinterpret_cast<uint4*>(Q);                                     // one B8 block: four coordinate columns + four zero columns
   q4[(uint64_t)j * 2] = make_uint4(q.c[0], q.c[1], q.c[2], q.c[3]);
   q4[(uint64_t)j * 2 + 1] = make_uint4(0, 0, 0, 0);
+}
+
+// ---- lookup argument (AIR v2): per-row table indices + multiplicities, inverse tables, aux trace -------------------------------------
+// The looked-up values of a row live in blocks 0, 1, 16, 17 of the main-trace matrix: tuple (pc limbs, op, fa, fb, fc | fhi | opclass | s)
+// and the four range chunks.  One pass over them, BEFORE the LDE uses the matrix as scratch: side[i] = (chunk 0 | chunk 1 << 16,
+// chunk 2 | chunk 3 << 16, ROM row u, 0), the range-table histogram (LDS-privatised) and the ROM histogram (LDS-privatised for the
+// first ROM_LDS rows of the table — a program's hot code — global atomics beyond).  A row whose tuple is not the program's word at
+// its pc (self-modified code, pc outside the code segment) or whose chunk is out of range has no proof: its index goes to bad_row.
+constexpr uint32_t ROM_LDS = 4096;
+__global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
+                                                           uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row) {
+  __shared__ uint32_t h_rc[air::RC_TABLE];
+  __shared__ uint32_t h_rom[ROM_LDS];
+  const uint32_t rom_lds = n_code < ROM_LDS ? n_code : ROM_LDS;
+  for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) h_rc[k] = 0;
+  for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) h_rom[k] = 0;
+  __syncthreads();
+  const uint4* M4 = reinterpret_cast<const uint4*>(M);
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < N; i += (uint64_t)gridDim.x * NT) {
+    const uint4 b0l = M4[(0 * N + i) * 2], b0h = M4[(0 * N + i) * 2 + 1], b1l = M4[(1 * N + i) * 2];        // cycle pc0 pc1 pc2 | op fa fb fc | fhi ..
+    const uint4 b16h = M4[(16 * N + i) * 2 + 1], b17l = M4[(17 * N + i) * 2];                               // 132 133 opclass chunk0 | chunk1 chunk2 chunk3 s
+    static_assert(air::C_OPC == 134 && air::C_RC == 135 && air::C_S == 139 && air::C_PC == 1 && air::C_OP == 4 && air::C_FHI == 8, "column map");
+    const uint32_t r[4] = {b16h.w, b17l.x, b17l.y, b17l.z};
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
+    const uint64_t pc = (uint64_t)b0l.y | ((uint64_t)b0l.z << 20) | ((uint64_t)b0l.w << 40);
+    const uint64_t u = (pc - 0x1000) >> 2;
+    uint32_t ui = 0;
+    if (b0l.y < (1u << 20) && b0l.z < (1u << 20) && b0l.w < (1u << 24) && pc >= 0x1000 && !(pc & 3) && u < n_code) {
+      const uint32_t w = code[u];
+      ui = (uint32_t)u;
+      if (b0h.x == (w & 0x7F) && b0h.y == ((w >> 7) & 0xF) && b0h.z == ((w >> 11) & 0xF) && b0h.w == ((w >> 15) & 0xF) && b1l.x == (w >> 19) && b17l.w == (w >> 31) &&
+          b16h.z == air::opclass_of(w & 0x7F)) {
+        if (ui < rom_lds) atomicAdd(&h_rom[ui], 1u); else atomicAdd(&rom_mult[ui], 1u);
+      } else ok = false;
+    } else ok = false;
+    if (!ok) atomicMin(bad_row, (unsigned long long)i);
+    side[i] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), ui, 0);
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) if (h_rc[k]) atomicAdd(&rc_mult[k], h_rc[k]);
+  for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) if (h_rom[k]) atomicAdd(&rom_mult[k], h_rom[k]);
+}
+
+// inverse tables for the drawn challenges: inv_rc[t] = 1 / (alpha - t), inv_rom[u] = 1 / (alpha - fingerprint(ROM row u))  (Montgomery E4).
+// Every lookup of the aux trace is then a table read, and the verifier-side sum T = sum m_t inv_rc[t] + sum r_u inv_rom[u] is formed
+// from the same tables on the host.
+__global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __restrict__ code, uint32_t n_code, const ProveParams* __restrict__ pp, E4* __restrict__ inv_rc,
+                                                            E4* __restrict__ inv_rom) {
+  const uint32_t t = blockIdx.x * NT + threadIdx.x;
+  if (t >= (uint32_t)air::RC_TABLE + n_code) return;
+  E4 d;
+#pragma unroll
+  for (int k = 0; k < 4; k++) d.c[k] = pp->lk[air::LK_ALPHA + k];
+  if (t < (uint32_t)air::RC_TABLE) {
+    d.c[0] = bb::sub(d.c[0], bb::to_mont(t));
+    inv_rc[t] = bb::e_inv_m(d);
+    return;
+  }
+  const uint32_t u = t - air::RC_TABLE, w = code[u];
+  const uint64_t pc = 0x1000 + 4ull * u;
+  const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), w & 0x7F, (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF,
+                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F)};
+  // (fingerprint coordinates in Montgomery form: lk holds R * lambda^j_k, mont_mul(R a, to_mont(f)) = R a f)
+  E4 fpm;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t fp = pp->lk[air::LK_LAM + 4 * air::N_TUPLE + k];
+#pragma unroll
+    for (int j = 0; j < air::N_TUPLE; j++) fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 * j + k], bb::to_mont(f[j])));
+    fpm.c[k] = fp;
+  }
+  E4 dd;
+#pragma unroll
+  for (int k = 0; k < 4; k++) dd.c[k] = bb::sub(pp->lk[air::LK_ALPHA + k], fpm.c[k]);
+  inv_rom[u] = bb::e_inv_m(dd);
+}
+
+// aux rows: H0..H3, HR (canonical) into blocks 0..2 of the aux matrix, and in the S slot the row's increment d_i = H0 + .. + HR - T / N
+// (the scan kernels below turn the increments into the running sum S_i = sum_{j < i} d_j)
+__global__ __launch_bounds__(NT) void aux_rows_kernel(const uint4* __restrict__ side, uint64_t N, const E4* __restrict__ inv_rc, const E4* __restrict__ inv_rom,
+                                                       const ProveParams* __restrict__ pp, uint32_t* __restrict__ A) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= N) return;
+  const uint4 sd = side[i];
+  const E4 h0 = inv_rc[sd.x & 0xFFFF], h1 = inv_rc[sd.x >> 16], h2 = inv_rc[sd.y & 0xFFFF], h3 = inv_rc[sd.y >> 16], hr = inv_rom[sd.z];
+  E4 d = bb::e_add(bb::e_add(bb::e_add(h0, h1), bb::e_add(h2, h3)), hr);
+#pragma unroll
+  for (int k = 0; k < 4; k++) d.c[k] = bb::sub(d.c[k], pp->lk[air::LK_TN + k]);
+  uint4* A4 = reinterpret_cast<uint4*>(A);
+  auto put = [&](uint32_t blk, uint32_t half, const E4& e) { const E4 c = bb::e_from_mont(e); A4[((uint64_t)blk * N + i) * 2 + half] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
+  put(0, 0, h0); put(0, 1, h1); put(1, 0, h2); put(1, 1, h3); put(2, 0, hr); put(2, 1, d);
+}
+
+// Exclusive prefix sum (coordinate-wise, mod p) over the S slot of the aux matrix (block 2, second half), three launches:
+//   local: every workgroup scans SCAN_ROWS consecutive rows in place and leaves their total in sums[block]
+//   sums:  one workgroup turns sums[] into exclusive offsets
+//   add:   every row adds its workgroup's offset
+constexpr uint32_t SCAN_PER = 4, SCAN_ROWS = NT * SCAN_PER;
+__device__ __forceinline__ uint4 add4m(uint4 a, uint4 b) { return make_uint4(bb::add(a.x, b.x), bb::add(a.y, b.y), bb::add(a.z, b.z), bb::add(a.w, b.w)); }
+__device__ __forceinline__ uint4 block_exclusive_scan(uint4 v, uint4* lds /* NT */, uint4& total) {    // exclusive scan of one value per thread across the workgroup
+  const uint32_t t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < NT; off <<= 1) {
+    uint4 x = lds[t];
+    if (t >= off) x = add4m(x, lds[t - off]);
+    __syncthreads();
+    lds[t] = x;
+    __syncthreads();
+  }
+  total = lds[NT - 1];
+  const uint4 ex = t ? lds[t - 1] : make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  return ex;
+}
+__global__ __launch_bounds__(NT) void scan_local_kernel(uint32_t* __restrict__ A, uint64_t N, uint4* __restrict__ sums) {
+  __shared__ uint4 lds[NT];
+  uint4* S = reinterpret_cast<uint4*>(A) + (uint64_t)2 * N * 2 + 1;          // element i at S[2 i]
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_ROWS + (uint64_t)threadIdx.x * SCAN_PER;
+  uint4 v[SCAN_PER], run = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER; k++) { v[k] = base + k < N ? S[2 * (base + k)] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER; k++) { const uint4 x = v[k]; v[k] = run; run = add4m(run, x); }     // thread-local exclusive
+  uint4 total;
+  const uint4 ex = block_exclusive_scan(run, lds, total);
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER; k++) if (base + k < N) S[2 * (base + k)] = add4m(v[k], ex);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(NT) void scan_sums_kernel(uint4* __restrict__ sums, uint32_t n) {
+  __shared__ uint4 lds[NT];
+  uint4 carry = make_uint4(0, 0, 0, 0);
+  for (uint32_t b = 0; b < n; b += NT) {
+    const uint32_t i = b + threadIdx.x;
+    const uint4 v = i < n ? sums[i] : make_uint4(0, 0, 0, 0);
+    uint4 total;
+    const uint4 ex = block_exclusive_scan(v, lds, total);
+    if (i < n) sums[i] = add4m(ex, carry);
+    carry = add4m(carry, total);
+  }
+}
+__global__ __launch_bounds__(NT) void scan_add_kernel(uint32_t* __restrict__ A, uint64_t N, const uint4* __restrict__ sums) {
+  uint4* S = reinterpret_cast<uint4*>(A) + (uint64_t)2 * N * 2 + 1;
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= N) return;
+  S[2 * i] = add4m(S[2 * i], sums[i / SCAN_ROWS]);
 }
 
 // ---- boundary states: the 68 state words of rows 0 and last_row of the main trace (B8 layout) -> out[136] ----------------------------
@@ -170,29 +323,32 @@ __global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict
 }
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
-__global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ Q, uint32_t log_n, const E4* __restrict__ dinv,
-                                                   const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
+__global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, const uint32_t* __restrict__ Q, uint32_t log_n,
+                                                   const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
   const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
-  // canonical v x Montgomery gamma^k = canonical product; 156 and 152 terms: the lazy sums are folded once on the way (136 terms fit)
+  // canonical v x Montgomery gamma^k = canonical product; the lazy sums (136 terms fit) are folded into Ap / Bp every FOLD terms
   LazyE4 A, B;
   E4 Ap = bb::e_zero(), Bp = bb::e_zero();
-  constexpr int UN = 8;
-  const uint4* L4 = reinterpret_cast<const uint4*>(L);
-  constexpr int FOLD = 80;                                                     // lazy sums are folded after 80 terms; 76 more follow
-  static_assert(WM % UN == 0 && FOLD % UN == 0 && FOLD <= 128 && WM + 4 - FOLD <= 128, "column loop");
-#pragma unroll 1
-  for (int k = 0; k < WM; k += UN) {
-    const uint4 vlo = L4[((uint64_t)(k >> 3) * N2 + j) * 2], vhi = L4[((uint64_t)(k >> 3) * N2 + j) * 2 + 1];   // one B8 block = eight columns
+  constexpr int UN = 8, FOLD = 80;
+  static_assert(WM % UN == 0 && WA % UN == 0 && FOLD % UN == 0 && FOLD <= 128, "column loop");
+  int pending = 0;
+  auto block = [&](const uint4* M4, int blk, int k0) {                         // one B8 block = eight columns, gamma indices k0 .. k0 + 7 (zeta) and WT + k0 .. (zeta w)
+    const uint4 vlo = M4[((uint64_t)blk * N2 + j) * 2], vhi = M4[((uint64_t)blk * N2 + j) * 2 + 1];
     const uint32_t v[UN] = {vlo.x, vlo.y, vlo.z, vlo.w, vhi.x, vhi.y, vhi.z, vhi.w};
 #pragma unroll
-    for (int u = 0; u < UN; u++) { lz_fma(A, pp->gamma_pow[k + u], v[u]); lz_fma(B, pp->gamma_pow[WM + k + u], v[u]); }
-    if (k + UN == FOLD) { Ap = lz_reduce(A); Bp = lz_reduce(B); A = LazyE4(); B = LazyE4(); }
-  }
+    for (int u = 0; u < UN; u++) { lz_fma(A, pp->gamma_pow[k0 + u], v[u]); lz_fma(B, pp->gamma_pow[WT + k0 + u], v[u]); }
+    pending += UN;
+    if (pending == FOLD) { Ap = bb::e_add(Ap, lz_reduce(A)); Bp = bb::e_add(Bp, lz_reduce(B)); A = LazyE4(); B = LazyE4(); pending = 0; }
+  };
+#pragma unroll 1
+  for (int k = 0; k < WM; k += UN) block(reinterpret_cast<const uint4*>(L), k >> 3, k);
+#pragma unroll 1
+  for (int k = 0; k < WA; k += UN) block(reinterpret_cast<const uint4*>(AL), k >> 3, WM + k);
   {
     const uint4 qv = reinterpret_cast<const uint4*>(Q)[(uint64_t)j * 2];
-    lz_fma(A, pp->gamma_pow[2 * WM], qv.x); lz_fma(A, pp->gamma_pow[2 * WM + 1], qv.y); lz_fma(A, pp->gamma_pow[2 * WM + 2], qv.z); lz_fma(A, pp->gamma_pow[2 * WM + 3], qv.w);
+    lz_fma(A, pp->gamma_pow[2 * WT], qv.x); lz_fma(A, pp->gamma_pow[2 * WT + 1], qv.y); lz_fma(A, pp->gamma_pow[2 * WT + 2], qv.z); lz_fma(A, pp->gamma_pow[2 * WT + 3], qv.w);
   }
   const E4 Am = bb::e_to_mont(bb::e_add(Ap, lz_reduce(A))), Bm = bb::e_to_mont(bb::e_add(Bp, lz_reduce(B)));
   const E4 i1 = dinv[j], i2 = bb::e_mul_fm(dinv[(j + N2 - 2) & (N2 - 1)], wn_inv_m);   // 1/(zeta - x), 1/(zeta w - x)
@@ -350,6 +506,21 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   }
   for (int i = 0; i < 4; i++)
     if (pub->program_digest[i] >= bb::P || pub->io_digest[i] >= bb::P) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: digests must be canonical field elements"}); return ZKIR_ERR_ARGUMENT; }
+  // the program: its code words are the instruction ROM every row is looked up in (Program::to_bytes layout, program.rs:170-214)
+  const uint8_t* blob = pub->program_blob;
+  const uint64_t blob_len = pub->program_blob_len;
+  uint32_t n_code = 0;
+  {
+    auto le32 = [&](size_t at) { return (uint32_t)blob[at] | ((uint32_t)blob[at + 1] << 8) | ((uint32_t)blob[at + 2] << 16) | ((uint32_t)blob[at + 3] << 24); };
+    bool ok = blob && blob_len >= 32 && blob_len <= (1ull << 30);
+    if (ok) { const uint64_t code_size = le32(16); ok = code_size % 4 == 0 && 32 + code_size <= blob_len && le32(12) == pub->entry_point; n_code = (uint32_t)(code_size / 4); }
+    if (ok) { uint32_t dg[4]; zkir_digest_bytes(blob, blob_len, dg); ok = !memcmp(dg, pub->program_digest, 16); }
+    if (!ok) {
+      zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->program_blob must be the program that ran (Program::to_bytes layout; its digest and entry point are the public inputs'): "
+                                               "use zkir_public_inputs_of, and keep the blob alive while proving"});
+      return ZKIR_ERR_ARGUMENT;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   // One proof at a time per context (its workspace arena); proofs on different contexts run concurrently: the per-proof constants
   // live in the arena (no __constant__ / static state).
@@ -360,7 +531,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WM % 8 == 0, "the main trace fills whole B8 blocks");
-    const size_t want = (size_t)(12 * WM + 480) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20);
+    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -370,42 +541,99 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     c->arena_off = 0;
   }
   Arena ar{c};
-  uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest, *dBound;
-  E4 *dW, *dDinv, *dPart;
+  uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest, *dBound, *dA, *dAL, *dATree, *dCode, *dMult;
+  unsigned long long* dBad;
+  uint4 *dSide, *dSums;
+  E4 *dW, *dDinv, *dPart, *dInvRc, *dInvRom;
   ProveParams* dPP;
-  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS));
+  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS)); HIP_OK(ar.take(&dBad, 1));
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
+  HIP_OK(ar.take(&dA, WA * N)); HIP_OK(ar.take(&dAL, WA * N2)); HIP_OK(ar.take(&dATree, 4 * (2 * N2 - 1)));
+  HIP_OK(ar.take(&dSide, N)); HIP_OK(ar.take(&dSums, N / SCAN_ROWS + 1));
+  HIP_OK(ar.take(&dCode, (size_t)n_code + 1)); HIP_OK(ar.take(&dMult, (size_t)n_code + air::RC_TABLE));                   // ROM multiplicities, then range multiplicities
+  HIP_OK(ar.take(&dInvRc, air::RC_TABLE)); HIP_OK(ar.take(&dInvRom, (size_t)n_code + 1));
   HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
-  HIP_OK(ar.take(&dPart, (size_t)(WM + 4) * n_chunks * 2));
+  HIP_OK(ar.take(&dPart, (size_t)(WT + 4) * n_chunks * 2));
   std::vector<uint32_t*> fri_trees(n_layers), fri_layers(n_layers + 1);
 
   StageEvents se;
   if (stage_ms) HIP_OK(se.create());
   auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(se.ev[i], s); };
 
-  // ---- 1. main trace, LDE, trace commitment ---------------------------------------------------------------------------------
+  // ---- 1. main trace, lookup indices + multiplicities, LDE, trace commitment ---------------------------------------------------
   mark(0);
   int rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s); if (rc) return rc;
   hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, dBound);   // before the LDE overwrites dM
+  std::vector<uint32_t> code(n_code);                         // lives to the end of the call: the H2D copy below reads it
+  {
+    for (uint32_t t = 0; t < n_code; t++) memcpy(&code[t], blob + 32 + 4 * (size_t)t, 4);
+    if (n_code) HIP_OK(hipMemcpyAsync(dCode, code.data(), (size_t)n_code * 4, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemsetAsync(dMult, 0, ((size_t)n_code + air::RC_TABLE) * 4, s));
+    HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
+    unsigned g = grid_for(N); if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, dCode, n_code, dSide, dMult + n_code, dMult, dBad);
+  }
   mark(1);
   rc = zkir_lde_launch(c, dM, WM, dL, s); if (rc) return rc;
   mark(2);
   rc = zkir_merkle_commit_launch(c, dL, WM, N2, dTree, s); if (rc) return rc;
-  uint32_t troot[4], qroot[4], bound[2 * NS];
+  uint32_t troot[4], aroot[4], qroot[4], bound[2 * NS];
+  unsigned long long bad_row = ~0ull;
+  std::vector<uint32_t> mult((size_t)n_code + air::RC_TABLE);
   HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(bound, dBound, sizeof bound, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(mult.data(), dMult, mult.size() * 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(&bad_row, dBad, 8, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
-  mark(3);
+  if (bad_row != ~0ull) {
+    char m[256];
+    snprintf(m, sizeof m, "zkir_prove: row %llu of the trace has no proof in this AIR: its (pc, instruction word) is not in the program's code table (self-modified code, "
+                          "a pc outside the code segment) or a written limb is out of range", bad_row);
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, m});
+    return ZKIR_ERR_ARGUMENT;
+  }
   std::vector<uint32_t> head;
   header_words(log_n, *pub, bound, head);
   Challenger ch(c->consts);
   ch.observe_n(head.data() + 2, head.size() - 2);
   ch.observe_n(troot, 4);
+  ch.observe_n(mult.data(), mult.size());                     // ROM multiplicities, range multiplicities: fixed before the lookup challenges
+  std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
+  {
+    // ---- 1b. lookup challenges, inverse tables, T, aux trace (helper columns + running sum), its LDE and commitment ----
+    const E4 alpha_l = ch.sample_ext(), lambda = ch.sample_ext();
+    E4 lam{{1, 0, 0, 0}};
+    for (int k = 0; k < 4; k++) pp->lk[air::LK_ALPHA + k] = bb::to_mont(alpha_l.c[k]);
+    for (int j = 0; j <= air::N_TUPLE; j++) { for (int k = 0; k < 4; k++) pp->lk[air::LK_LAM + 4 * j + k] = bb::to_mont(lam.c[k]); lam = h_e_mul(lam, lambda); }
+    for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = 0;
+    HIP_OK(hipMemcpyAsync(dPP->lk, pp->lk, sizeof(pp->lk), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom);
+    std::vector<E4> inv((size_t)air::RC_TABLE + n_code);
+    HIP_OK(hipMemcpyAsync(inv.data(), dInvRc, (size_t)air::RC_TABLE * sizeof(E4), hipMemcpyDeviceToHost, s));
+    if (n_code) HIP_OK(hipMemcpyAsync(inv.data() + air::RC_TABLE, dInvRom, (size_t)n_code * sizeof(E4), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    E4 T = bb::e_zero();                                      // Montgomery: sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u)
+    for (int t = 0; t < air::RC_TABLE; t++) if (mult[n_code + t]) T = bb::e_add(T, bb::e_mul_fm(inv[t], bb::to_mont(mult[n_code + t] % bb::P)));
+    for (uint32_t u = 0; u < n_code; u++) if (mult[u]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + u], bb::to_mont(mult[u] % bb::P)));
+    const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
+    for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];
+    HIP_OK(hipMemcpyAsync(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(aux_rows_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, N, dInvRc, dInvRom, dPP, dA);
+    const uint32_t n_scan = (uint32_t)((N + SCAN_ROWS - 1) / SCAN_ROWS);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(n_scan), dim3(NT), 0, s, dA, N, dSums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(NT), 0, s, dSums, n_scan);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dA, N, dSums);
+    rc = zkir_lde_launch(c, dA, WA, dAL, s); if (rc) return rc;
+    rc = zkir_merkle_commit_launch(c, dAL, WA, N2, dATree, s); if (rc) return rc;
+    HIP_OK(hipMemcpyAsync(aroot, dATree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    ch.observe_n(aroot, 4);
+  }
+  mark(3);
   const E4 alpha = ch.sample_ext();
 
   // ---- 2. quotient ------------------------------------------------------------------------------------------------------------
-  std::unique_ptr<ProveParams> pp(new ProveParams());     // host staging of this proof's constants
   {
     E4 a{{1, 0, 0, 0}};
     for (int k = 0; k < N_CONSTRAINTS; k++) { pp->alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
@@ -416,7 +644,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const uint32_t wn = bb::root_of_unity((int)log_n);
   const uint32_t gN = bb::pow(bb::GEN, N), gN_m = bb::to_mont(gN), wn_inv_m = bb::to_mont(bb::inv(wn)), w_last_m = bb::to_mont(bb::pow(wn, pub->n_real - 1));
   const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
-  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, log_n, c->d_tw_fwd, dPP, gN_m, wn_inv_m, w_last_m, inv_zh_even_m, inv_zh_odd_m, dQ);
+  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, dPP, gN_m, wn_inv_m, w_last_m, inv_zh_even_m, inv_zh_odd_m, dQ);
   rc = zkir_merkle_commit_launch(c, dQ, 4, N2, dQTree, s); if (rc) return rc;
   HIP_OK(hipMemcpyAsync(qroot, dQTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -429,12 +657,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   pp->zeta = bb::e_to_mont(zeta); pp->zeta_w = bb::e_to_mont(zeta_w);
   HIP_OK(hipMemcpyAsync(&dPP->zeta, &pp->zeta, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dPP, dW, dDinv);
+  // columns in the order used everywhere below: main (WM), aux (WA) = WT "trace" columns, then the quotient's four
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WM + 3) / 4), dim3(NT), 0, s, dL, N2, (uint32_t)WM, dW, dPart, n_chunks);
-  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks);
-  std::vector<E4> part((size_t)(WM + 4) * n_chunks * 2);
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WA + 3) / 4), dim3(NT), 0, s, dAL, N2, (uint32_t)WA, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks);
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WT * n_chunks * 2, n_chunks);
+  std::vector<E4> part((size_t)(WT + 4) * n_chunks * 2);
   HIP_OK(hipMemcpyAsync(part.data(), dPart, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
-  std::vector<E4> t_z(WM), t_zw(WM), q_z(4);
+  std::vector<E4> t_z(WT), t_zw(WT), q_z(4);
   {
     // scale = ((z/g)^2N - 1) / (2N);  for z = zeta*w the factor is the same because w^(2N) = 1
     const uint32_t ginv = bb::inv(bb::GEN);
@@ -443,27 +673,27 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     const uint32_t inv2n = bb::inv((uint32_t)(N2 % bb::P));
     for (int t = 0; t < 4; t++) sc.c[t] = bb::mul(sc.c[t], inv2n);
     const E4 sc_m = bb::e_to_mont(sc);
-    for (int k = 0; k < WM + 4; k++) {
+    for (int k = 0; k < WT + 4; k++) {
       E4 a = bb::e_zero(), b = bb::e_zero();
       for (uint32_t q = 0; q < n_chunks; q++) { a = bb::e_add(a, part[((size_t)k * n_chunks + q) * 2]); b = bb::e_add(b, part[((size_t)k * n_chunks + q) * 2 + 1]); }
       const E4 va = bb::e_mul_m(a, sc_m), vb = bb::e_mul_m(b, sc_m);                                          // canonical partial sums x Montgomery scale = canonical
-      if (k < WM) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WM] = va;
+      if (k < WT) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WT] = va;
     }
   }
   mark(5);
-  for (int k = 0; k < WM; k++) ch.observe_n(t_z[k].c, 4);
-  for (int k = 0; k < WM; k++) ch.observe_n(t_zw[k].c, 4);
+  for (int k = 0; k < WT; k++) ch.observe_n(t_z[k].c, 4);
+  for (int k = 0; k < WT; k++) ch.observe_n(t_zw[k].c, 4);
   for (int i = 0; i < 4; i++) ch.observe_n(q_z[i].c, 4);
   const E4 gamma = ch.sample_ext();
 
   // ---- 4. DEEP codeword ------------------------------------------------------------------------------------------------------
   {
     E4 g{{1, 0, 0, 0}}, a0 = bb::e_zero(), b0 = bb::e_zero();
-    for (int k = 0; k < 2 * WM + 4; k++) {
+    for (int k = 0; k < 2 * WT + 4; k++) {
       pp->gamma_pow[k] = bb::e_to_mont(g);
-      if (k < WM) a0 = bb::e_add(a0, h_e_mul(g, t_z[k]));
-      else if (k < 2 * WM) b0 = bb::e_add(b0, h_e_mul(g, t_zw[k - WM]));
-      else a0 = bb::e_add(a0, h_e_mul(g, q_z[k - 2 * WM]));
+      if (k < WT) a0 = bb::e_add(a0, h_e_mul(g, t_z[k]));
+      else if (k < 2 * WT) b0 = bb::e_add(b0, h_e_mul(g, t_zw[k - WT]));
+      else a0 = bb::e_add(a0, h_e_mul(g, q_z[k - 2 * WT]));
       g = h_e_mul(g, gamma);
     }
     pp->a0 = bb::e_to_mont(a0); pp->b0 = bb::e_to_mont(b0);
@@ -471,7 +701,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemcpyAsync(&dPP->a0, &pp->a0, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   }
   HIP_OK(ar.take(&fri_layers[0], 4 * N2));
-  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dQ, log_n, dDinv, dPP, wn_inv_m, fri_layers[0]);
+  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, fri_layers[0]);
   mark(6);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
@@ -531,9 +761,12 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   for (auto& q : queries) q = ch.sample_bits((int)log_n);
 
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
-  head.insert(head.end(), troot, troot + 4); head.insert(head.end(), qroot, qroot + 4);
-  for (int k = 0; k < WM; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
-  for (int k = 0; k < WM; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);
+  head.push_back((uint32_t)blob_len);                                         // the program: byte length, then 16-bit halfwords
+  for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
+  head.insert(head.end(), mult.begin(), mult.end());                          // ROM multiplicities, range multiplicities
+  head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
+  for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
+  for (int k = 0; k < WT; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);
   for (int i = 0; i < 4; i++) head.insert(head.end(), q_z[i].c, q_z[i].c + 4);
   head.push_back((uint32_t)n_layers);
   for (auto& r : lroots) head.insert(head.end(), r.begin(), r.end());
@@ -552,6 +785,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // a trace row = 8 consecutive words out of each of the WM/8 blocks
       for (uint32_t b = 0; b < (uint32_t)WM / 8; b++) { jobs.push_back({dL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off}); off += 8; }
       path_jobs(dTree, N2, pos);
+    }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // the aux row and its path
+      for (uint32_t b = 0; b < (uint32_t)WA / 8; b++) { jobs.push_back({dAL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off}); off += 8; }
+      path_jobs(dATree, N2, pos);
     }
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos * 8, 1, 4, off}); off += 4; path_jobs(dQTree, N2, pos); }
     int log_m = (int)log_n + 1;

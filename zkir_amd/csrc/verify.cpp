@@ -1,4 +1,4 @@
-// verify.cpp — the product's verifier of ZKIR-STARK v1 proofs (format v4: whole runs, segments of a run, chains of segments) and the
+// verify.cpp — the product's verifier of ZKIR-STARK proofs (format v5: whole runs, segments of a run, chains of segments) and the
 // public-input helpers; host only, no device.
 //
 // Self-defined stages (the reference has no prover or verifier: SURVEY.md F1 / a17, N4).  Independent of oracle/: Montgomery
@@ -17,8 +17,8 @@
 namespace {
 
 using bb::E4;
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 4;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, WA = air::W_AUX, WT = air::W_ALL, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 5;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
 
@@ -70,7 +70,10 @@ inline bool e_eq(const E4& a, const E4& b) { return !memcmp(a.c, b.c, 16); }
 
 struct VerifierOps {                                                       // air::eval on the openings at zeta (E4, Montgomery)
   using V = E4;
-  const E4* l; const E4* n; const E4* ap; E4 acc;
+  const E4* l; const E4* n; const E4* al; const E4* an; const uint32_t* lk_m; const E4* ap; E4 acc;
+  V aloc(int k) const { return al[k]; }
+  V anxt(int k) const { return an[k]; }
+  V par(int i) const { return m_base(lk_m[i]); }
   V add(const V& a, const V& b) const { return bb::e_add(a, b); }
   V sub(const V& a, const V& b) const { return bb::e_sub(a, b); }
   V mul(const V& a, const V& b) const { return bb::e_mul_m(a, b); }
@@ -122,6 +125,7 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t
   if (blob_len >= 16) memcpy(&entry, blob + 12, 4);                        // ProgramHeader.entry_point, program.rs:189-213
   out->entry_point = entry;
   zkir_digest_bytes(blob, blob_len, out->program_digest);
+  out->program_blob = blob; out->program_blob_len = blob_len;              // borrowed: the prover reads the instruction ROM from it
   std::vector<uint64_t> io;
   io.push_back(n_inputs); io.insert(io.end(), inputs, inputs + n_inputs);
   io.push_back(log->outputs.size()); io.insert(io.end(), log->outputs.begin(), log->outputs.end());
@@ -193,15 +197,35 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   p = HEADER_WORDS;
   const size_t N = (size_t)1 << log_n;
   for (size_t i = 2; i < len; i++) if (w[i] >= bb::P) return 3;
-  if (!need(8)) return 4;
-  const uint32_t* troot = w + p; p += 4; const uint32_t* qroot = w + p; p += 4;
+  // ---- the program carried in the proof: [byte length][16-bit halfwords]; it must be the program the header names (check 8) ----
+  if (!need(1)) return 4;
+  const size_t blob_len = w[p++];
+  if (blob_len > ((size_t)1 << 30) || !need((blob_len + 1) / 2)) return 4;
+  std::vector<uint8_t> blob(blob_len);
+  for (size_t i = 0; i < blob_len; i += 2) {
+    const uint32_t h = w[p + i / 2];
+    if (h > 0xFFFF || (i + 1 >= blob_len && h > 0xFF)) return 8;
+    blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8);
+  }
+  p += (blob_len + 1) / 2;
+  { uint32_t dg[4]; zkir_digest_bytes(blob.data(), blob_len, dg); if (memcmp(dg, pub.program_digest, 16)) return 8; }
+  auto le32 = [&](size_t at) { return (uint32_t)blob[at] | ((uint32_t)blob[at + 1] << 8) | ((uint32_t)blob[at + 2] << 16) | ((uint32_t)blob[at + 3] << 24); };
+  if (blob_len < 32) return 8;
+  const uint64_t code_size = le32(16);
+  if (code_size % 4 || 32 + code_size > blob_len || le32(12) != pub.entry_point) return 8;
+  const size_t n_code = (size_t)(code_size / 4);
+  if (!need(n_code + air::RC_TABLE)) return 4;
+  const uint32_t* rom_mult = w + p; p += n_code;
+  const uint32_t* rc_mult = w + p; p += air::RC_TABLE;
+  if (!need(12)) return 4;
+  const uint32_t* troot = w + p; p += 4; const uint32_t* aroot = w + p; p += 4; const uint32_t* qroot = w + p; p += 4;
   auto get_m = [&](size_t at) { E4 e; memcpy(e.c, w + at, 16); return bb::e_to_mont(e); };      // proof word -> Montgomery E4
-  if (!need((size_t)(2 * WM + 4) * 4)) return 4;
-  const size_t at_tz = p, at_tzw = p + 4 * (size_t)WM, at_qz = p + 8 * (size_t)WM;
-  std::vector<E4> t_z(WM), t_zw(WM), q_z(4);
-  for (int k = 0; k < WM; k++) { t_z[k] = get_m(at_tz + 4 * k); t_zw[k] = get_m(at_tzw + 4 * k); }
+  if (!need((size_t)(2 * WT + 4) * 4)) return 4;
+  const size_t at_tz = p, at_tzw = p + 4 * (size_t)WT, at_qz = p + 8 * (size_t)WT;
+  std::vector<E4> t_z(WT), t_zw(WT), q_z(4);                                // main columns, then aux columns
+  for (int k = 0; k < WT; k++) { t_z[k] = get_m(at_tz + 4 * k); t_zw[k] = get_m(at_tzw + 4 * k); }
   for (int i = 0; i < 4; i++) q_z[i] = get_m(at_qz + 4 * i);
-  p += (size_t)(2 * WM + 4) * 4;
+  p += (size_t)(2 * WT + 4) * 4;
   if (!need(1)) return 4;
   const int n_layers = (int)w[p++];
   const std::vector<int> ks = fri_schedule(log_n);
@@ -217,10 +241,49 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   Challenger ch;
   ch.observe_n(w + 2, HEADER_WORDS - 2);
   ch.observe_n(troot, 4);
+  ch.observe_n(rom_mult, n_code);
+  ch.observe_n(rc_mult, air::RC_TABLE);
+  const E4 alpha_l = bb::e_to_mont(ch.sample_ext()), lambda = bb::e_to_mont(ch.sample_ext());
+  // lookup parameters (air.h LK_*), Montgomery: alpha, lambda^0..10, T / N — T is the table side of the lookup identity, computed HERE
+  // from the program in the proof and the multiplicities: sum_t m_t / (alpha - t) + sum_u r_u / (alpha - fingerprint(ROM row u))
+  uint32_t lk_m[air::N_LK];
+  {
+    E4 lam[air::N_TUPLE + 1];
+    lam[0] = bb::e_one_m();
+    for (int j = 1; j <= air::N_TUPLE; j++) lam[j] = bb::e_mul_m(lam[j - 1], lambda);
+    for (int k = 0; k < 4; k++) lk_m[air::LK_ALPHA + k] = alpha_l.c[k];
+    for (int j = 0; j <= air::N_TUPLE; j++) for (int k = 0; k < 4; k++) lk_m[air::LK_LAM + 4 * j + k] = lam[j].c[k];
+    std::vector<E4> d((size_t)air::RC_TABLE + n_code);
+    for (int t = 0; t < air::RC_TABLE; t++) { d[t] = alpha_l; d[t].c[0] = bb::sub(d[t].c[0], bb::to_mont((uint32_t)t)); }
+    for (size_t u = 0; u < n_code; u++) {
+      const uint32_t cw = le32(32 + 4 * u);
+      const uint64_t pc = 0x1000 + 4 * (uint64_t)u;
+      const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), cw & 0x7F, (cw >> 7) & 0xF, (cw >> 11) & 0xF,
+                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F)};
+      E4 fp = lam[air::N_TUPLE];
+      for (int j = 0; j < air::N_TUPLE; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(f[j])));
+      d[air::RC_TABLE + u] = bb::e_sub(alpha_l, fp);
+    }
+    // batch inversion (Montgomery's trick): one e_inv_m, three products per element
+    std::vector<E4> pre(d.size());
+    E4 acc = bb::e_one_m();
+    for (size_t i = 0; i < d.size(); i++) { pre[i] = acc; acc = bb::e_mul_m(acc, d[i]); }
+    E4 inv = bb::e_inv_m(acc);
+    E4 T = bb::e_zero();
+    for (size_t i = d.size(); i-- > 0;) {
+      const E4 di = bb::e_mul_m(inv, pre[i]);
+      inv = bb::e_mul_m(inv, d[i]);
+      const uint32_t m = i < (size_t)air::RC_TABLE ? rc_mult[i] : rom_mult[i - air::RC_TABLE];
+      if (m) T = bb::e_add(T, bb::e_mul_fm(di, bb::to_mont(m)));
+    }
+    const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
+    for (int k = 0; k < 4; k++) lk_m[air::LK_TN + k] = tn.c[k];
+  }
+  ch.observe_n(aroot, 4);
   const E4 alpha = bb::e_to_mont(ch.sample_ext());
   ch.observe_n(qroot, 4);
   const E4 zeta = bb::e_to_mont(ch.sample_ext());
-  ch.observe_n(w + at_tz, (size_t)(2 * WM + 4) * 4);
+  ch.observe_n(w + at_tz, (size_t)(2 * WT + 4) * 4);
   const E4 gamma = bb::e_to_mont(ch.sample_ext());
   std::vector<E4> betas(n_layers);
   for (int j = 0; j < n_layers; j++) { ch.observe_n(lroots[j], 4); betas[j] = bb::e_to_mont(ch.sample_ext()); }
@@ -239,7 +302,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     E4 is_trans = zeta; is_trans.c[0] = bb::sub(is_trans.c[0], bb::to_mont(bb::inv(wn)));
     uint32_t first_m[NS], last_m[NS];
     for (int i = 0; i < NS; i++) { first_m[i] = bb::to_mont(first[i]); last_m[i] = bb::to_mont(last[i]); }
-    VerifierOps o{t_z.data(), t_zw.data(), ap.data(), bb::e_zero()};
+    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero()};
     air::eval(o, is_first, is_last, is_trans, first_m, last_m, pub.deferred != 0);
     E4 qz = bb::e_zero();                                                  // Q(zeta) = sum_i X^i q_i(zeta): basis element X^i times the E4 opening
     for (int i = 0; i < 4; i++) { E4 basis = bb::e_zero(); basis.c[i] = bb::R1; qz = bb::e_add(qz, bb::e_mul_m(basis, q_z[i])); }
@@ -258,12 +321,12 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     }
   }
   // ---- 3. queries ----
-  std::vector<E4> gp(2 * WM + 4);
+  std::vector<E4> gp(2 * WT + 4);
   gp[0] = bb::e_one_m();
   for (size_t k = 1; k < gp.size(); k++) gp[k] = bb::e_mul_m(gp[k - 1], gamma);
   E4 a0 = bb::e_zero(), b0 = bb::e_zero();
-  for (int k = 0; k < WM; k++) { a0 = bb::e_add(a0, bb::e_mul_m(gp[k], t_z[k])); b0 = bb::e_add(b0, bb::e_mul_m(gp[WM + k], t_zw[k])); }
-  for (int i = 0; i < 4; i++) a0 = bb::e_add(a0, bb::e_mul_m(gp[2 * WM + i], q_z[i]));
+  for (int k = 0; k < WT; k++) { a0 = bb::e_add(a0, bb::e_mul_m(gp[k], t_z[k])); b0 = bb::e_add(b0, bb::e_mul_m(gp[WT + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = bb::e_add(a0, bb::e_mul_m(gp[2 * WT + i], q_z[i]));
   const E4 zeta_w = bb::e_mul_fm(zeta, wn_m);
   const uint32_t w2n = bb::root_of_unity(log_n + 1);
   const int depth0 = log_n + 1;
@@ -271,13 +334,21 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     const uint32_t q = ch.sample_bits(log_n);
     if (!need(1) || w[p++] != q) return 20;
     E4 deep[2];
-    const uint32_t* tl[2]; const uint32_t* ql[2];
+    const uint32_t* tl[2]; const uint32_t* al[2]; const uint32_t* ql[2];
     for (int s2 = 0; s2 < 2; s2++) {
       const size_t pos = (size_t)q + (s2 ? N : 0);
       if (!need((size_t)WM + 4 * depth0)) return 4;
       tl[s2] = w + p; p += WM;
       uint32_t dg[4]; hash_elems(tl[s2], WM, dg);
       if (!check_path(dg, pos, w + p, depth0, troot)) return 21;
+      p += 4 * (size_t)depth0;
+    }
+    for (int s2 = 0; s2 < 2; s2++) {
+      const size_t pos = (size_t)q + (s2 ? N : 0);
+      if (!need((size_t)WA + 4 * depth0)) return 4;
+      al[s2] = w + p; p += WA;
+      uint32_t dg[4]; hash_elems(al[s2], WA, dg);
+      if (!check_path(dg, pos, w + p, depth0, aroot)) return 27;
       p += 4 * (size_t)depth0;
     }
     for (int s2 = 0; s2 < 2; s2++) {
@@ -292,8 +363,9 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       const size_t pos = (size_t)q + (s2 ? N : 0);
       const uint32_t x_m = bb::to_mont(bb::mul(bb::GEN, bb::pow(w2n, pos)));
       E4 A = bb::e_zero(), B = bb::e_zero();                               // canonical column value x Montgomery gamma^k = canonical; lifted to Montgomery at the end
-      for (int k = 0; k < WM; k++) { A = bb::e_add(A, bb::e_mul_fm(gp[k], tl[s2][k])); B = bb::e_add(B, bb::e_mul_fm(gp[WM + k], tl[s2][k])); }
-      for (int i = 0; i < 4; i++) A = bb::e_add(A, bb::e_mul_fm(gp[2 * WM + i], ql[s2][i]));
+      for (int k = 0; k < WM; k++) { A = bb::e_add(A, bb::e_mul_fm(gp[k], tl[s2][k])); B = bb::e_add(B, bb::e_mul_fm(gp[WT + k], tl[s2][k])); }
+      for (int k = 0; k < WA; k++) { A = bb::e_add(A, bb::e_mul_fm(gp[WM + k], al[s2][k])); B = bb::e_add(B, bb::e_mul_fm(gp[WT + WM + k], al[s2][k])); }
+      for (int i = 0; i < 4; i++) A = bb::e_add(A, bb::e_mul_fm(gp[2 * WT + i], ql[s2][i]));
       A = bb::e_to_mont(A); B = bb::e_to_mont(B);
       E4 dz = bb::e_zero(); dz.c[0] = x_m; E4 dzw = dz;
       dz = bb::e_sub(dz, zeta); dzw = bb::e_sub(dzw, zeta_w);

@@ -61,14 +61,20 @@ __global__ __launch_bounds__(NT) void memops_expand_csr_kernel(const zkir_mem_ev
     const uint32_t k = atomicAdd(&q_n, 1u);                       // at most two gaps per lane (the last op also closes the table)
     q_lo[k] = lo; q_hi[k] = hi; q_val[k] = val;
   };
+  // the neighbour's key comes from the previous LANE (one shuffle each); only lane 0 of a wave reads ev[i - 1] itself
+  zkir_mem_event e{};
+  if (i < n) e = ev[i];
+  const int lane = threadIdx.x & 63;
+  uint32_t p_row = __shfl_up(e.row, 1, 64);
+  uint32_t p_wr = __shfl_up((uint32_t)e.is_write, 1, 64);
+  uint64_t p_addr = __shfl_up(e.address, 1, 64);
   if (i < n) {
-    const zkir_mem_event e = ev[i];
     put_memop(c, i, e, cycle_base);
     if (i == 0) fill(0, e.row, 0);
     else {
-      const zkir_mem_event p = ev[i - 1];                         // the neighbour's line is in L1/L2: no extra HBM traffic
-      if (p.row != e.row) fill((uint64_t)p.row + 1, e.row, i);
-      else if ((e.is_write < p.is_write) || (e.is_write == p.is_write && e.address < p.address)) seg_bad[e.row] = 1;
+      if (lane == 0) { const zkir_mem_event p = ev[i - 1]; p_row = p.row; p_wr = p.is_write; p_addr = p.address; }
+      if (p_row != e.row) fill((uint64_t)p_row + 1, e.row, i);
+      else if ((e.is_write < p_wr) || (e.is_write == p_wr && e.address < p_addr)) seg_bad[e.row] = 1;
     }
     if (i == n - 1) fill((uint64_t)e.row + 1, n_rows, n);
   }

@@ -85,7 +85,21 @@ class NormColumnsC(C.Structure):
 
 class PublicInputsC(C.Structure):             # zkir_public_inputs
     _fields_ = [("n_real", C.c_uint64), ("entry_point", C.c_uint64), ("deferred", C.c_uint32), ("reserved", C.c_uint32),
-                ("program_digest", C.c_uint32 * 4), ("io_digest", C.c_uint32 * 4)]
+                ("program_digest", C.c_uint32 * 4), ("io_digest", C.c_uint32 * 4),
+                ("program_blob", C.c_void_p), ("program_blob_len", C.c_uint64)]     # borrowed pointer (prover side): see with_program()
+
+    def with_program(self, blob: bytes) -> "PublicInputsC":
+        """Point the struct at `blob` (kept alive by the struct): needed after the struct has been copied byte-wise or sent to another
+        process, where the borrowed pointer means nothing."""
+        self._blob_ref = bytes(blob)
+        self._blob_buf = C.create_string_buffer(self._blob_ref, len(self._blob_ref))
+        self.program_blob = C.cast(self._blob_buf, C.c_void_p).value
+        self.program_blob_len = len(self._blob_ref)
+        return self
+
+    def copy(self) -> "PublicInputsC":
+        q = PublicInputsC.from_buffer_copy(bytes(self))
+        return q.with_program(getattr(self, "_blob_ref", b""))
 
 
 class MemoryWitnessC(C.Structure):            # zkir_memory_witness
@@ -327,7 +341,7 @@ def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int]
     rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), int(deferred), C.byref(out))
     if rc != ZKIR_OK:
         _raise(rc)
-    return out
+    return out.with_program(blob)          # the C call borrowed a temporary: re-point at bytes this struct owns
 
 
 def verify_segment(proof: np.ndarray, expect: Optional[PublicInputsC] = None):

@@ -16,6 +16,28 @@ from . import runtime as rt
 
 P = 2013265921
 W_MAIN = 152
+W_AUX = 24                  # aux trace of the lookup argument (air.h): H0..H3, HR, S as four base columns each
+RC_TABLE = 1024
+HEADER_WORDS = 157
+
+
+def proof_layout(proof) -> dict:
+    """Word offsets inside a format-v5 proof: header | program (byte length, 16-bit halfwords) | ROM multiplicities | range multiplicities |
+    trace root | aux root | quotient root | openings ..."""
+    blob_len = int(proof[HEADER_WORDS])
+    at = HEADER_WORDS + 1
+    half = np.asarray(proof[at:at + (blob_len + 1) // 2], dtype=np.uint32)
+    blob = np.stack([half & 0xFF, half >> 8], axis=1).astype(np.uint8).reshape(-1)[:blob_len].tobytes()
+    n_rom = int.from_bytes(blob[16:20], "little") // 4 if blob_len >= 32 else 0
+    rom_mult = at + (blob_len + 1) // 2
+    troot = rom_mult + n_rom + RC_TABLE
+    return {"blob": blob, "n_rom": n_rom, "rom_mult": rom_mult, "rc_mult": rom_mult + n_rom, "trace_root": troot, "aux_root": troot + 4, "quotient_root": troot + 8,
+            "openings": troot + 12}
+
+
+def trace_root(proof) -> list:
+    t0 = proof_layout(proof)["trace_root"]
+    return [int(x) for x in proof[t0:t0 + 4]]
 
 
 class StarkContext:
