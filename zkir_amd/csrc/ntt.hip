@@ -105,30 +105,43 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
     lo0 = (tile % lo_tiles) << C;
     base = (DIT ? (hi << (s0 + B)) : hi * (n >> s0)) + lo0;
   };
+  static_assert(QUADS == NTH, "one quad per lane and round");
   u32x4 pre[MOVES];
   uint4* x; uint32_t base, lo0;
   uint32_t w = blockIdx.x;
   if (w >= total) return;
+  // vmcnt retires IN ORDER: a table read issued after the next tile's prefetch would make its s_waitcnt drain the whole prefetch
+  // before the first round starts (rocm 7.2 emitted s_waitcnt vmcnt(0) in round 0 for exactly that) — so nothing is read from global
+  // memory between the issue of a prefetch and its use.  The compact-table factors depend on (lane, round) only: read ONCE per
+  // workgroup; the tile-dependent power tw[lo << ..] of the NEXT tile is fetched as the last load of that tile's prefetch.
+  uint32_t sm[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int b = 2 * r;
+    const uint32_t qq = threadIdx.x >> C;
+    if (!DIT) { const int lg = B - 2 - b; sm[r] = small[(qq & ((1u << lg) - 1)) << (log_small - (B - b))]; }
+    else sm[r] = small[(qq & ((1u << b) - 1)) << (log_small - (b + 2))];
+  }
   geometry(w, x, base, lo0);
   static_for<0, (int)MOVES>([&](auto kc) {                                     // tile rows are 2^C consecutive positions = 2^(C+1) uint4
     constexpr uint32_t k = decltype(kc)::value;
     const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
     pre[k] = ld4(&x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv]);
   });
+  uint32_t tw_cur = DIT ? tw[(lo0 + (threadIdx.x & CMASK)) << (L - s0 - B)] : tw[(lo0 + (threadIdx.x & CMASK)) << s0];
   for (;;) {
     static_for<0, (int)MOVES>([&](auto kc) {
       constexpr uint32_t k = decltype(kc)::value;
       const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
       st4(&lds4[(wv & 1) * PLANE + ((row << C) | (wv >> 1))], pre[k]);
     });
-    const uint32_t lo = lo0 + (threadIdx.x & CMASK);
     uint32_t tp[R];                                            // per-lane power used by round r
     if (DIT) {                                                 // round r needs w^(lo << (L-1-s0-(2r+1))): finest at r = R-1, each earlier round is its 4th power
-      uint32_t u = tw[lo << (L - s0 - B)];
+      uint32_t u = tw_cur;
 #pragma unroll
       for (int r = R - 1; r >= 0; r--) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
     } else {                                                   // round r needs w^-(lo << (s0+2r))
-      uint32_t u = tw[lo << s0];
+      uint32_t u = tw_cur;
 #pragma unroll
       for (int r = 0; r < R; r++) { tp[r] = u; u = bb::mont_mul(u, u); u = bb::mont_mul(u, u); }
     }
@@ -142,6 +155,7 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
         const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
         pre[k] = ld4(&xn[((uint64_t)base_n + (uint64_t)row * stride_mid) * 2 + wv]);
       });
+      tw_cur = DIT ? tw[(lo0_n + (threadIdx.x & CMASK)) << (L - s0 - B)] : tw[(lo0_n + (threadIdx.x & CMASK)) << s0];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -155,12 +169,12 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
           const int lg = B - 2 - b;                            // log2(h2) in row units
           const uint32_t h2 = 1u << lg, mid_lo = qq & (h2 - 1), mid_hi = qq >> lg;
           i0 = ((((mid_hi << (lg + 2)) | mid_lo)) << C) | lo_l; d = h2 << C;
-          wa = bb::mont_mul(tp[r], small[mid_lo << (log_small - (B - b))]);
+          wa = bb::mont_mul(tp[r], sm[r]);
           wb = bb::mont_mul(wa, j4_m); wc = bb::mont_mul(wa, wa);
         } else {
           const uint32_t dm = 1u << b, mid_lo = qq & (dm - 1), mid_hi = qq >> b;
           i0 = ((((mid_hi << (b + 2)) | mid_lo)) << C) | lo_l; d = dm << C;
-          wb = bb::mont_mul(tp[r], small[mid_lo << (log_small - (b + 2))]);     // w2
+          wb = bb::mont_mul(tp[r], sm[r]);                                      // w2
           wa = bb::mont_mul(wb, wb); wc = bb::mont_mul(wb, j4_m);               // w1, w2i
         }
 #pragma unroll
@@ -386,24 +400,39 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
   // persistent workgroups with the next chunk's loads in flight during the 15 rounds of the current one (see the strided kernel)
   uint32_t w = blockIdx.x;
   if (w >= total) return;
+  // vmcnt retires in order (see the strided kernel): no global read between the issue of the next chunk's prefetch and its use.
+  // The twiddles of the ten rounds depend on (lane, round) only: read once per workgroup.  The coset scale of the lane's four
+  // positions depends on the chunk: read at the top of the chunk, BEFORE the next prefetch is issued.
+  uint32_t tw_i[5], tw_f[5];
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int lg = 8 - 2 * r;
+    tw_i[r] = small_inv[((t & 255) & ((1u << lg) - 1)) << (2 * r)];           // w_1024^-(lo << 2r)
+    const int sft = 2 * r + 1;
+    tw_f[r] = small_fwd[(t & ((1u << sft) - 1)) << (Bm - sft - 1)];            // w_2048^(lo << (9-s)): twiddle of stage s+1
+  }
   u32x4 pre[4];
-  {
-    const uint4* x = in + ((uint64_t)(w / chunks_per_block) * n + ((uint64_t)(w % chunks_per_block) << Bm)) * 2;
+  uint32_t glo[4], ghi[4];                                     // factors of g^k / N for the lane's four positions 4q .. 4q + 3 of the last inverse round, k = bitrev_L(position)
+  auto fetch = [&](uint32_t ww) {                              // one chunk's loads, in the order they are consumed: the 1024 positions, then the scale factors
+    const uint4* x = in + ((uint64_t)(ww / chunks_per_block) * n + ((uint64_t)(ww % chunks_per_block) << Bm)) * 2;
 #pragma unroll
     for (int k = 0; k < 4; k++) pre[k] = ld4(&x[t + k * MID_NT]);
-  }
+    const uint32_t p0 = ((ww % chunks_per_block) << Bm) + 4 * (t & 255);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const uint32_t k = bitrev(p0 + i, L); glo[i] = g_lo[k & 1023]; ghi[i] = g_hi[k >> 10]; }
+  };
+  fetch(w);
   for (;;) {
     const uint32_t base = (w % chunks_per_block) << Bm;
     uint4* y = out + (uint64_t)(w / chunks_per_block) * n * 4;
 #pragma unroll
     for (int k = 0; k < 4; k++) { const uint32_t e = t + k * MID_NT; st4(&A[(e & 1) * APL + (e >> 1)], pre[k]); }
+    uint32_t gs[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) gs[i] = bb::mont_mul(glo[i], ghi[i]);
     __syncthreads();
     const uint32_t wn = w + gridDim.x;
-    if (wn < total) {
-      const uint4* x = in + ((uint64_t)(wn / chunks_per_block) * n + ((uint64_t)(wn % chunks_per_block) << Bm)) * 2;
-#pragma unroll
-      for (int k = 0; k < 4; k++) pre[k] = ld4(&x[t + k * MID_NT]);
-    }
+    if (wn < total) fetch(wn);
     // ---- inverse DIF, rounds r = 0..4: stages (2r, 2r+1), spans h1 = 2^(9-2r), h2 = h1/2; lane = (quad q, half h) ----
     {
       const uint32_t q = t & 255;
@@ -413,15 +442,12 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
         const int lg = 8 - 2 * r;                              // log2(h2)
         const uint32_t h2 = 1u << lg, lo = q & (h2 - 1), hi = q >> lg;
         const uint32_t i0 = (hi << (lg + 2)) | lo;
-        const uint32_t wA = small_inv[lo << (2 * r)];          // w_1024^-(lo << 2r)
+        const uint32_t wA = tw_i[r];                            // w_1024^-(lo << 2r)
         const uint32_t wB = bb::mont_mul(wA, j4_inv_m), w2 = bb::mont_mul(wA, wA);
         uint4 x0 = a[i0], x1 = a[i0 + h2], x2 = a[i0 + 2 * h2], x3 = a[i0 + 3 * h2];
         dif4(x0, x1, x2, x3, wA, wB, w2);
-        if (r == 4) {                                          // last round (positions 4q..4q+3): the coset scale g^k / N, k = bitrev_L(position)
-          const uint32_t p0 = base + i0;
-          const uint32_t k0 = bitrev(p0, L), k1 = bitrev(p0 + 1, L), k2 = bitrev(p0 + 2, L), k3 = bitrev(p0 + 3, L);
-          x0 = mul4(x0, bb::mont_mul(g_lo[k0 & 1023], g_hi[k0 >> 10])); x1 = mul4(x1, bb::mont_mul(g_lo[k1 & 1023], g_hi[k1 >> 10]));
-          x2 = mul4(x2, bb::mont_mul(g_lo[k2 & 1023], g_hi[k2 >> 10])); x3 = mul4(x3, bb::mont_mul(g_lo[k3 & 1023], g_hi[k3 >> 10]));
+        if (r == 4) {                                          // last round (positions 4q..4q+3, i0 = 4q): the coset scale g^k / N
+          x0 = mul4(x0, gs[0]); x1 = mul4(x1, gs[1]); x2 = mul4(x2, gs[2]); x3 = mul4(x3, gs[3]);
         }
         a[i0] = x0; a[i0 + h2] = x1; a[i0 + 2 * h2] = x2; a[i0 + 3 * h2] = x3;
         __syncthreads();
@@ -442,7 +468,7 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
         const int s = 2 * r + 1;
         const uint32_t lo = t & ((1u << s) - 1), hi = t >> s;
         const uint32_t i0 = (hi << (s + 2)) | lo, d = 1u << s;
-        const uint32_t w2 = small_fwd[lo << (Bm - s - 1)];     // w_2048^(lo << (9-s)): twiddle of stage s+1
+        const uint32_t w2 = tw_f[r];                            // w_2048^(lo << (9-s)): twiddle of stage s+1
         const uint32_t w1 = bb::mont_mul(w2, w2), w2i = bb::mont_mul(w2, j4_fwd_m);
         uint4 x0, x1, x2, x3;
         if (r == 0) {                                          // after stage 0: F[j] = A[j >> 1]
