@@ -38,6 +38,12 @@ using u32x4 = uint32_t __attribute__((ext_vector_type(4)));          // plain ve
 __device__ __forceinline__ u32x4 ld4(const uint4* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st4(uint4* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// LDS hand-off INSIDE a wave: the next round reads only what this wave itself wrote (LDS operations of one wave execute in issue
+// order; the wait makes the writes complete, the clobber keeps the compiler from moving LDS accesses across).  Where it applies it
+// replaces a workgroup barrier: the waves of a workgroup then drift apart, and one wave's LDS latency is covered by another's arithmetic
+// instead of all of them waiting at the same instruction.
+__device__ __forceinline__ void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // ---- four columns at a time --------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 add4(uint4 a, uint4 b) { return make_uint4(bb::add(a.x, b.x), bb::add(a.y, b.y), bb::add(a.z, b.z), bb::add(a.w, b.w)); }
 __device__ __forceinline__ uint4 sub4(uint4 a, uint4 b) { return make_uint4(bb::sub(a.x, b.x), bb::sub(a.y, b.y), bb::sub(a.z, b.z), bb::sub(a.w, b.w)); }
@@ -185,7 +191,10 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
           pl[i0] = x0; pl[i0 + d] = x1; pl[i0 + 2 * d] = x2; pl[i0 + 3 * d] = x3;
         }
       }
-      __syncthreads();
+      // A wave's 64 quads (2^(6-C) values of qq) cover one contiguous "home block" of 4 * 2^(6-C) rows in every round whose quad span
+      // fits it: DIF rounds with log2(h2) <= 6 - C, DIT rounds with b <= 6 - C.  Between two such rounds the data never leaves the wave.
+      const bool wave_local = !DIT ? (r + 1 < R && B - 2 - b <= 6 - C) : (r + 1 < R && b + 2 <= 6 - C);
+      if (wave_local) wave_sync_lds(); else __syncthreads();
     }
 #pragma unroll
     for (uint32_t k = 0; k < MOVES; k++) {
@@ -450,7 +459,8 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
           x0 = mul4(x0, gs[0]); x1 = mul4(x1, gs[1]); x2 = mul4(x2, gs[2]); x3 = mul4(x3, gs[3]);
         }
         a[i0] = x0; a[i0 + h2] = x1; a[i0 + 2 * h2] = x2; a[i0 + 3 * h2] = x3;
-        __syncthreads();
+        // rounds 1..4 stay inside the wave's own 256 positions of its plane (q = 64 v .. 64 v + 63): only round 0 hands data to other waves
+        if (r >= 1 && r < 4) wave_sync_lds(); else __syncthreads();
       }
     }
     // ---- forward DIT of the zero-interleaved chunk (2048 positions), one half of the block at a time: stage 0 is a copy, rounds do
@@ -477,7 +487,8 @@ __global__ __launch_bounds__(MID_NT) void lde_middle_r4_kernel(const uint4* __re
         } else { x0 = F[i0]; x1 = F[i0 + d]; x2 = F[i0 + 2 * d]; x3 = F[i0 + 3 * d]; }
         dit4(x0, x1, x2, x3, w1, w2, w2i);
         F[i0] = x0; F[i0 + d] = x1; F[i0 + 2 * d] = x2; F[i0 + 3 * d] = x3;
-        __syncthreads();
+        // rounds 0..2 (spans up to 128) stay inside the wave's own 256 positions [256 v, 256 v + 256) of F; rounds 3 and 4 cross waves
+        if (r < 2) wave_sync_lds(); else __syncthreads();
       }
     }
 #pragma unroll
