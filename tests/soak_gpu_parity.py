@@ -38,7 +38,7 @@ def edge_heavy(shape):
 
 
 t_end = time.time() + budget
-n_merkle = n_lde = n_proof = n_wit = 0
+n_merkle = n_lde = n_proof = n_wit = n_refused = 0
 ctxs = {}
 while time.time() < t_end:
     what = rng.integers(0, 10)
@@ -97,12 +97,22 @@ while time.time() < t_end:
         for name in want_rows.dtype.names:                          # K1 (trace fill) against the oracle's rows, all 372 B
             assert np.array_equal(got_rows[name], want_rows[name]), ("trace", name)
         ctx = ctxs.setdefault(log_n, stark.StarkContext(log_n))
-        proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, cfg["enable_deferred_model"]))
         want = so.prove(want_rows, opub)
+        try:
+            proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, cfg["enable_deferred_model"]))
+        except rt.RuntimeError as e:
+            # AIR v2: a run that executes a word that is not the program's (a store into the code segment, a pc outside it) has no proof; the
+            # honest GPU prover refuses it — and the proof the oracle's prover emits for the same rows must be one the verifiers reject
+            assert e.code == rt.ERR_ARGUMENT and "code table" in e.message, e.message
+            assert so.verify(want) != 0 and rt.verify(want) == so.verify(want), "refused by the prover but accepted by a verifier"
+            n_refused += 1
+            log.close()
+            continue
         assert np.array_equal(proof, want), ("proof", log_n)
         assert rt.verify(proof) == so.verify(proof), "verdicts"
         # random programs need not satisfy the AIR (e.g. a write to R0's shadow is impossible, but flags are data-driven): the
         # verifier's verdict must at least be the same for both provers' (identical) words
         n_proof += 1
         log.close()
-print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_wit} witness sets, {n_proof} traces + proofs identical to the oracle in {budget:.0f} s")
+print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_wit} witness sets, {n_proof} traces + proofs identical to the oracle, "
+      f"{n_refused} unprovable runs refused by the GPU prover and rejected by both verifiers, in {budget:.0f} s")
