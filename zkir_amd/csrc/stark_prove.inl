@@ -13,6 +13,15 @@ constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, WA = air::W_AUX, WT 
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
 constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 5;
 
+#ifndef DEEP_WAVES
+#define DEEP_WAVES 4
+#endif
+#ifndef BARY_WAVES
+#define BARY_WAVES 4
+#endif
+#ifndef QUOT_WAVES
+#define QUOT_WAVES 4
+#endif
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
   E4 alpha_pow[N_CONSTRAINTS];
   E4 gamma_pow[2 * WT + 4];     // main columns, aux columns at zeta; the same at zeta w; the quotient
@@ -76,7 +85,7 @@ struct QuotientOps {
 };
 __device__ __forceinline__ uint32_t inv_mont(uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; }
 
-__global__ __launch_bounds__(NT) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp,
+__global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp,
                                                        uint32_t gN_m, uint32_t wn_inv_m, uint32_t w_last_m, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m,
                                                        uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const 
 // weights (the bulk of the traffic when read once per column) are loaded once per four values; products are accumulated lazily:
 // mont(e, v) without its final subtraction (3 instructions) into a 64-bit sum (1 instruction), reduced once at the end.  v stays
 // canonical: mont(e * R, v) = e * v needs no conversion of the matrix.
-__global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, uint32_t width, const E4* __restrict__ wts, E4* __restrict__ partial,
+__global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, uint32_t width, const E4* __restrict__ wts, E4* __restrict__ partial,
                                                        uint32_t n_chunks) {
   constexpr int CG = 4;
   __shared__ uint32_t red[NT / 64][CG][2][4];
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(NT) void bary_dot_kernel(const uint32_t* __restrict
 }
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
-__global__ __launch_bounds__(NT) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, const uint32_t* __restrict__ Q, uint32_t log_n,
+__global__ __launch_bounds__(NT, DEEP_WAVES) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, const uint32_t* __restrict__ Q, uint32_t log_n,
                                                    const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
   const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
