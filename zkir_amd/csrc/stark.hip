@@ -61,7 +61,10 @@ __device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[
 // A lane builds the 152 words of ITS row in registers (every column index below is a compile-time constant once the register loop
 // is unrolled) and stores them as 38 16-byte vectors; the two halves of a 32-byte block position are written back to back, so the
 // L2 merges them into full sectors.
-__global__ __launch_bounds__(NT) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t deferred, uint32_t* __restrict__ out) {
+#ifndef MT_WAVES
+#define MT_WAVES 3
+#endif
+__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t deferred, uint32_t* __restrict__ out) {
   using namespace air;
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
