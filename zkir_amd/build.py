@@ -33,6 +33,26 @@ def _newer(src: str, dst: str, deps) -> bool:
     return any(os.path.getmtime(p) > t for p in [src] + list(deps))
 
 
+def build_variant(tag: str, defines, csrc: str = CSRC) -> str:
+    """A second build of the library with extra -D flags (kernel experiments), as zkir_amd/variants/libzkir_amd_<tag>.so; run it
+    with ZKIR_AMD_LIB=<that path>.  `csrc` may point at another checkout's sources (a baseline to time against)."""
+    vdir = os.path.join(HERE, "variants", tag)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for name in HOST_SOURCES + HIP_SOURCES:
+        src = os.path.join(csrc, name)
+        obj = os.path.join(vdir, name + ".o")
+        objs.append(obj)
+        if name.endswith(".hip"):
+            cmd = [HIPCC, f"--offload-arch={ARCH}", *COMMON, *EXTRA.get(name, []), *defines, "-c", src, "-o", obj]
+        else:
+            cmd = [HIPCC, "-x", "c++", *COMMON, "-march=x86-64-v2", *defines, "-c", src, "-o", obj]
+        subprocess.check_call(cmd)
+    out = os.path.join(HERE, "variants", f"libzkir_amd_{tag}.so")
+    subprocess.check_call([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs])
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     deps = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]

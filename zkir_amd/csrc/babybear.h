@@ -99,6 +99,37 @@ BB_HD uint32_t mont_reduce_wide(uint64_t acc) {
   const uint32_t m = (uint32_t)acc * NEG_PINV;
   return (uint32_t)((acc + (uint64_t)m * P) >> 32);
 }
+// ---- SIGNED Montgomery arithmetic (the Poseidon2 throughput kernels) ---------------------------------------------------------
+// Operands are int32 residues in (-p, p).  With m = t * (-p^-1) mod 2^32 read as a SIGNED word, (t + m p) / 2^32 lies within p/2 of
+// t / 2^32, so for |a b| < 2^31 p the product is again in (-p, p) (|r| < |a b| / 2^32 + p / 2 <= 0.469 p + 0.5 p) WITHOUT any
+// conditional subtraction: chains of products (the x^7 S-box) cost their three multiplier instructions each and nothing else.
+// The 64-bit sums are formed modulo 2^64 (no signed overflow in C++); only the high word of the exact multiple of 2^32 is kept.
+BB_HD int32_t smont_mul(int32_t a, int32_t b) {
+  const int64_t t = (int64_t)a * b;
+  const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
+  return (int32_t)(((uint64_t)t + (uint64_t)((int64_t)m * (int64_t)P)) >> 32);
+}
+// (a b + c) / R: c a 64-bit addend (|a b + c| / 2^32 + p / 2 bounds the result; c = p 2^32 + .. biases it into (0, 2p) for unsigned use)
+BB_HD int32_t smont_mul_add(int32_t a, int32_t b, uint64_t c) {
+  const uint64_t t = (uint64_t)((int64_t)a * b) + c;
+  const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
+  return (int32_t)((t + (uint64_t)((int64_t)m * (int64_t)P)) >> 32);
+}
+// acc / R for a signed 64-bit sum: within p / 2 of acc / 2^32
+BB_HD int32_t smont_reduce_wide(int64_t acc) {
+  const int32_t m = (int32_t)((uint32_t)acc * NEG_PINV);
+  return (int32_t)(((uint64_t)acc + (uint64_t)((int64_t)m * (int64_t)P)) >> 32);
+}
+// acc + x with x sign-extended by the instruction (v_mad_i64_i32 with the inline multiplier 1)
+BB_HD int64_t sacc_add(int64_t acc, int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t r;
+  asm("v_mad_i64_i32 %0, vcc, %1, 1, %2" : "=v"(r) : "v"(x), "v"(acc) : "vcc");
+  return r;
+#else
+  return acc + x;
+#endif
+}
 BB_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2); }
 BB_HD uint32_t from_mont(uint32_t a) { return mont_mul(a, 1u); }
 // canonical * canonical -> canonical (two reductions; for cold paths)

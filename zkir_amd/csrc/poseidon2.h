@@ -20,6 +20,9 @@
 #pragma once
 #include "babybear.h"
 
+#ifndef P2_RF_UNROLL
+#define P2_RF_UNROLL 1
+#endif
 namespace p2 {
 
 constexpr int T = 12, RF = 8, RP = 22, RATE = 8, DIGEST = 4;
@@ -31,14 +34,17 @@ struct Consts {              // Montgomery form unless noted
   uint32_t pre[RF][T];       // (M_ext^-1 * ext[r + 1]) * R^2 mod p: addend of the last S-box product of full round r; zero for r = 3, 7
   // permute_scaled(): the same constants carried by the factor the state has at that point (canonical values)
   uint32_t ext0_s[T];        // ext[0] * F_IN
-  uint32_t pre_s[RF][T];     // (M_ext^-1 * ext[r + 1]) * h_r * R, h_r = factor of the state after the S-boxes of full round r
+  uint64_t pre_b[RF][T];     // p * 2^32 + (M_ext^-1 * ext[r + 1]) * h_r * R, h_r = factor of the state after the S-boxes of full round r: the 64-bit
+                             // addend of the last S-box product (constant + the bias that makes the signed result an unsigned word)
   uint32_t in_scale;         // mont_mul(x, in_scale) = x * F_IN: canonical value -> input word of permute_scaled
   uint32_t out_scale;        // mont_mul(s, out_scale) = s / F_OUT: output word -> canonical value
   uint32_t carry;            // mont_mul(s, carry) = s * F_IN / F_OUT: output word -> input word of the next permutation (sponge capacity)
   uint32_t r3;               // R^3 mod p
   uint32_t diag0;            // diag[0] = -2 in Montgomery form
   uint32_t in_r[RP + 1];     // in[r] * R (Montgomery form of the Montgomery form): the NEXT partial round's constant rides the addend of
-                             // word 0's update product; in_r[RP] = 0
+                             // word 0's update product; in_r[RP] = ext[RF/2][0] * R (the constant of the full round that follows)
+  uint32_t ext4_r[T];        // ext[RF/2][i] * R: rides the addends of the LAST partial round's update products
+  int32_t in0_neg;           // in[0] - p (in (-p, 0]): word 0 enters the partial rounds as a signed residue
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -107,7 +113,7 @@ inline void generate(Consts& c) {
         uint32_t v = 0;
         if (r != RF / 2 - 1 && r != RF - 1)
           for (int j = 0; j < T; j++) v = bb::add(v, bb::mul(minv[i][j], bb::from_mont(c.ext[r + 1][j])));
-        c.pre_s[r][i] = bb::mul(bb::mul(v, h[r]), R);
+        c.pre_b[r][i] = ((uint64_t)bb::P << 32) | bb::mul(bb::mul(v, h[r]), R);
       }
     c.in_scale = bb::mul(f_in, R);
     c.out_scale = bb::mul(R, bb::inv(f_out));
@@ -115,7 +121,9 @@ inline void generate(Consts& c) {
     c.r3 = bb::pow(R, 3);
     c.diag0 = c.diag[0];
     for (int r = 0; r < RP; r++) c.in_r[r] = bb::to_mont(c.in[r]);
-    c.in_r[RP] = 0;
+    c.in_r[RP] = bb::to_mont(c.ext[RF / 2][0]);
+    for (int i = 0; i < T; i++) c.ext4_r[i] = bb::to_mont(c.ext[RF / 2][i]);
+    c.in0_neg = (int32_t)c.in[0] - (int32_t)bb::P;
   }
 }
 
@@ -191,7 +199,7 @@ BB_HD void permute(uint32_t* s, const Consts& c) {
 // instructions) instead of the Barrett reduce_wide (6): that divides the state by R each time, so a state word holds f * v with a
 // factor f that changes from layer to layer in a fixed, data-independent way; generate() pre-multiplies every round constant by the
 // factor of the place it is added at and chooses the input factor so that the partial rounds see f = R (plain Montgomery form).
-//   in : s[i] = mont_mul(x_i, c.in_scale) for canonical x_i, or mont_mul_lazy(previous output word, c.carry); below 1.69p
+//   in : s[i] = mont_mul_lazy(x_i, c.in_scale) for canonical x_i, or mont_mul_lazy(previous output word, c.carry); below 1.96p
 //   out: s[i] = F_OUT * v_i below p + 64; canonical v_i = mont_mul(s[i], c.out_scale)
 // The function computed on the x_i / v_i is exactly permute()'s (tests/test_stark_oracle.py, test_gpu_stark.py: bit for bit).
 template <bool ADD_RC>
@@ -208,35 +216,54 @@ BB_HD void ext_linear_scaled(uint32_t* s, const uint32_t* rc) {
     s[k] = bb::mont_reduce_wide(v);                            // < 2^38 / 2^32 + p
   }
 }
-BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // state factor R on entry and exit; s[0] canonical, s[1..11] below 2p
-  uint32_t x = bb::add(s[0], c.in[0]);
+// S-boxes in SIGNED Montgomery arithmetic (bb::smont_mul): inputs are int32 residues with |x| <= p + 128 — the "canonical + a little"
+// outputs of ext_linear_scaled read as signed words, or the (-p, p) words the partial rounds leave — and no product of the chain needs
+// a correction (every intermediate stays within 0.97 p).  The last product takes a 64-bit `addend`: v * R^2 (adds v * R) and, in the
+// full rounds, the bias p * 2^32 (one constant, Consts::pre_b): its result r + p lies in (0.04 p, 1.96 p) and is handed to the 64-bit linear layer as an UNSIGNED word
+// (zero-extension is a register of zeros; a signed word would need a shift per operand).
+BB_HD uint32_t sbox_biased(uint32_t xu, uint64_t addend) {
+  const int32_t x = (int32_t)xu;
+  const int32_t x2 = bb::smont_mul(x, x), x3 = bb::smont_mul(x2, x), x6 = bb::smont_mul(x3, x3);
+  return (uint32_t)bb::smont_mul_add(x6, x, addend);
+}
+BB_HD int32_t sbox_signed(int32_t x) {
+  const int32_t x2 = bb::smont_mul(x, x), x3 = bb::smont_mul(x2, x), x6 = bb::smont_mul(x3, x3);
+  return bb::smont_mul(x6, x);
+}
+// The 22 partial rounds on signed residues in (-p, p): state factor R (plain Montgomery form) on entry and exit, and NOTHING is
+// reduced anywhere — a signed product of a word below p with a constant below p is within 0.97 p again, the 64-bit column sum takes
+// its operands sign-extended by the multiply-add that accumulates them.  The constant of the full round that follows rides the
+// addends of the last round's update products (LAST), so the words leave ready for its S-boxes.
+template <bool LAST>
+BB_HD void int_round_signed(int32_t& x, int32_t* t, const Consts& c, int r) {
+  const int32_t s0 = sbox_signed(x);
+  int64_t acc = s0;
+#pragma unroll
+  for (int i = 1; i < T; i++) acc = bb::sacc_add(acc, t[i]);
+  const int64_t sum_r = bb::smont_mul(bb::smont_reduce_wide(acc), (int32_t)c.r3);                // (sum / R) * R^3 / R = sum * R
+  x = bb::smont_mul_add(s0, (int32_t)c.diag0, (uint64_t)(sum_r + c.in_r[r + 1]));               // sum - 2 s0 + the next constant: the next S-box input
+#pragma unroll
+  for (int i = 1; i < T; i++) t[i] = bb::smont_mul_add(t[i], (int32_t)c.diag[i], (uint64_t)(LAST ? sum_r + c.ext4_r[i] : sum_r));
+}
+BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // in: unsigned words below p + 128; out: signed words in (-p, p), next round's constants added
+  int32_t x = (int32_t)s[0] + c.in0_neg;
+  int32_t t[T];
+#pragma unroll
+  for (int i = 1; i < T; i++) t[i] = (int32_t)s[i];
 #pragma unroll 1
-  for (int r = 0; r < RP; r++) {
-    const uint32_t s0 = sbox_lazy(x);                          // below 1.689p: only feeds the 64-bit sum and a product
-    uint64_t acc = s0;
+  for (int r = 0; r < RP - 1; r++) int_round_signed<false>(x, t, c, r);
+  int_round_signed<true>(x, t, c, RP - 1);
+  s[0] = (uint32_t)x;
 #pragma unroll
-    for (int i = 1; i < T; i++) acc = bb::acc_add(acc, s[i]);
-    const uint32_t sum_r = bb::mont_mul_lazy(bb::mont_reduce_wide(acc), c.r3);      // (sum / R) * R^3 / R = sum * R, below 1.469p
-    x = bb::reduce_2p(bb::mont_mul_add_lazy(s0, c.diag0, (uint64_t)sum_r + c.in_r[r + 1]));   // sum - 2 s0 + in[r + 1]: the next S-box input
-#pragma unroll
-    for (int i = 1; i < T; i++) s[i] = bb::mont_mul_add_lazy(s[i], c.diag[i], sum_r);
-  }
-  s[0] = x;
-#pragma unroll
-  for (int i = 1; i < T; i++) s[i] = bb::reduce_2p(s[i]);
+  for (int i = 1; i < T; i++) s[i] = (uint32_t)t[i];
 }
 BB_HD void permute_scaled(uint32_t* s, const Consts& c) {
   ext_linear_scaled<true>(s, c.ext0_s);
-#pragma unroll 1
+#pragma unroll P2_RF_UNROLL
   for (int r = 0; r < RF; r++) {
-    if (r == RF / 2) {
-      s[0] = bb::reduce_2p(s[0]);                              // p + 64 -> canonical: the partial rounds add a constant to it first
-      int_rounds_scaled(s, c);
+    if (r == RF / 2) int_rounds_scaled(s, c);
 #pragma unroll
-      for (int i = 0; i < T; i++) s[i] = bb::add(s[i], c.ext[RF / 2][i]);
-    }
-#pragma unroll
-    for (int i = 0; i < T; i++) s[i] = sbox_lazy(s[i], c.pre_s[r][i]);
+    for (int i = 0; i < T; i++) s[i] = sbox_biased(s[i], c.pre_b[r][i]);
     ext_linear_scaled<false>(s, nullptr);
   }
 }

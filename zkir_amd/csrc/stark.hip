@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restr
     const uint4 lo = m4[((uint64_t)(off >> 3) * n + j) * 2], hi = m4[((uint64_t)(off >> 3) * n + j) * 2 + 1];
     const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int i = 0; i < p2::RATE; i++) s[i] = off + i < width ? bb::mont_mul(v[i], in_scale) : bb::mont_mul_lazy(s[i], carry);
+    for (int i = 0; i < p2::RATE; i++) s[i] = off + i < width ? bb::mont_mul_lazy(v[i], in_scale) : bb::mont_mul_lazy(s[i], carry);
 #pragma unroll
     for (int i = p2::RATE; i < p2::T; i++) s[i] = bb::mont_mul_lazy(s[i], carry);
     p2::permute_scaled(s, *cp);
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(NT) void compress_kernel(const p2::Consts* __restri
   if (i >= n_out) return;
   const uint4 l = reinterpret_cast<const uint4*>(in)[2 * i], r = reinterpret_cast<const uint4*>(in)[2 * i + 1];
   const uint32_t k = cp->in_scale, ko = cp->out_scale;
-  uint32_t s[p2::T] = {bb::mont_mul(l.x, k), bb::mont_mul(l.y, k), bb::mont_mul(l.z, k), bb::mont_mul(l.w, k), bb::mont_mul(r.x, k), bb::mont_mul(r.y, k), bb::mont_mul(r.z, k),
-                       bb::mont_mul(r.w, k), 0, 0, 0, 0};
+  uint32_t s[p2::T] = {bb::mont_mul_lazy(l.x, k), bb::mont_mul_lazy(l.y, k), bb::mont_mul_lazy(l.z, k), bb::mont_mul_lazy(l.w, k), bb::mont_mul_lazy(r.x, k), bb::mont_mul_lazy(r.y, k),
+                       bb::mont_mul_lazy(r.z, k), bb::mont_mul_lazy(r.w, k), 0, 0, 0, 0};
   p2::permute_scaled(s, *cp);
   reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::mont_mul(s[0], ko), bb::mont_mul(s[1], ko), bb::mont_mul(s[2], ko), bb::mont_mul(s[3], ko));
 }
@@ -326,7 +326,7 @@ void zkir_poseidon2_permute(uint32_t state[12]) {
 void zkir_poseidon2_permute_scaled(uint32_t state[12], uint32_t rounds) {
   static const p2::Consts consts = [] { p2::Consts c; p2::generate(c); return c; }();
   uint32_t s[p2::T];
-  for (int i = 0; i < p2::T; i++) s[i] = bb::mont_mul(state[i] % bb::P, consts.in_scale);
+  for (int i = 0; i < p2::T; i++) s[i] = bb::mont_mul_lazy(state[i] % bb::P, consts.in_scale);
   for (uint32_t r = 0; r < rounds; r++) {
     if (r) for (int i = 0; i < p2::T; i++) s[i] = bb::mont_mul_lazy(s[i], consts.carry);
     p2::permute_scaled(s, consts);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_kernel(const p2::Consts* __r
   const uint32_t in_scale = cp->in_scale, carry = cp->carry, ko = cp->out_scale;
   for (uint32_t u = 0; u < (1u << k); u += 2) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) { s[t] = bb::mont_mul(c[(uint64_t)t * m + i + u * g], in_scale); s[4 + t] = bb::mont_mul(c[(uint64_t)t * m + i + (u + 1) * g], in_scale); }
+    for (int t = 0; t < 4; t++) { s[t] = bb::mont_mul_lazy(c[(uint64_t)t * m + i + u * g], in_scale); s[4 + t] = bb::mont_mul_lazy(c[(uint64_t)t * m + i + (u + 1) * g], in_scale); }
 #pragma unroll
     for (int t = p2::RATE; t < p2::T; t++) s[t] = bb::mont_mul_lazy(s[t], carry);
     p2::permute_scaled(s, *cp);

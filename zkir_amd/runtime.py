@@ -28,7 +28,8 @@ import numpy as np
 from .spec import Program
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libzkir_amd.so")
+# ZKIR_AMD_LIB: another build of the same library (kernel experiments: scripts/build_variant.py); the default is the in-tree build
+_SO = os.environ.get("ZKIR_AMD_LIB") or os.path.join(_HERE, "libzkir_amd.so")
 
 (ZKIR_OK, ERR_MISALIGNED, ERR_INVALID_MEMORY, ERR_DIV_ZERO, ERR_INVALID_SYSCALL, ERR_DECODE, ERR_OTHER, ERR_BAD_PROGRAM,
  ERR_DEVICE, ERR_ARGUMENT) = range(10)
