@@ -8,7 +8,7 @@ import numpy as np
 from . import api
 
 P = 2013265921
-W_MAIN = 152
+W_MAIN = 160
 W_AUX = 24                  # aux trace of the lookup argument: H0..H3, HR, S as four base columns each
 RC_TABLE = 1024
 N_LK = 52                   # lookup parameters: alpha (4), lambda^0..10 (44), T / N (4)

@@ -166,11 +166,19 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //   139 s = bit 31 of the word (sign of imm17 / off21) | 140 se = (tk + k_jal) s
 //   141-142 c0 c1 carries of the value addition | 143-145 d0 d1 d2 carries of pc + delta | 146 dl0 = low limb of the pc increment
 //   147 ne = [xb != xc] | 148-150 iv: inverse witness of the first differing limb | 151 tk = branch taken
+// AIR v3 (opcode FAMILIES: a family is a pair of opcodes that differ in their low bit, the polarity of one comparison):
+//   152-155 class one-hot, continued: sub, bru (BLTU / BGEU), se (SEQ / SNE), su (SLTU / SGEU); column 129 (was "bne") is the family
+//           bre (BEQ / BNE).  Class ids = opclass values: add 0, addi 1, bre 2, jal 3, oth 4, (halt 5, pad 6,) sub 7, bru 8, se 9, su 10
+//   156-157 z = the two RANGE-CHECKED 20-bit limbs of the row (the chunks 135-138 split z): the written value's low limbs on add / addi /
+//           jal / sub / oth rows (y = z there), the 40-bit difference xb - xc on su rows and xc - xb on bru rows (whose borrow c1 is the
+//           unsigned comparison, execute.rs:373-407, :618-636), zero elsewhere
+//   158 flag = the family's comparison: [xb == xc] (raw 64-bit, all three limbs) on bre / se rows, the borrow c1 on bru / su rows, else 0
+//   159 fx = flag XOR (op - the family's even opcode): the branch decision (tk) of bre / bru rows, the value written by se / su rows
 // ---------------------------------------------------------------------------------------------
-static const int W_MAIN = 152;
+static const int W_MAIN = 160;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151 };
+       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159 };
 // AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 24 base columns = six extension-field columns,
 // coordinate by coordinate: H0..H3 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
 // S = running sum of (H0 + H1 + H2 + H3 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
@@ -181,8 +189,12 @@ static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the refere
 static const int N_TUPLE = 10;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
 
-enum { K_ADD = 0, K_ADDI = 1, K_BNE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6 };
-static const uint32_t OP_ADD = 0x00, OP_ADDI = 0x08, OP_BNE = 0x41, OP_JAL = 0x48;
+enum { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, N_CLASS = 11 };
+static inline int kcol(int k) { return k < 7 ? C_K + k : C_K2 + (k - 7); }
+static const uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
+                      OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48;
+// the even opcode of a family (its polarity-0 member); 0 for the classes that are one opcode
+static inline uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLTU : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0; }
 
 #pragma pack(push, 1)
 struct PackedRow { uint64_t cycle, pc; uint32_t instruction; uint64_t registers[16]; uint32_t bound_bits[16]; uint8_t bound_tag[16]; uint64_t bound_payload[16]; uint8_t reg_state[16]; };
@@ -213,7 +225,12 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
   hash_elems(e.data(), e.size(), out);
 }
 
-static inline F opclass_of(uint32_t op) { return op == OP_ADD ? 0 : op == OP_ADDI ? 1 : op == OP_BNE ? 2 : op == OP_JAL ? 3 : 4; }
+static inline F opclass_of(uint32_t op) {
+  switch (op) {
+    case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
+    case OP_BLTU: case OP_BGEU: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE; case OP_SLTU: case OP_SGEU: return K_SU; default: return K_OTH;
+  }
+}
 // The instruction ROM of a program blob (Program::to_bytes layout, program.rs:170-214,300-346): code word t sits at pc = 0x1000 + 4 t
 // (VM::new loads the code at CODE_BASE whatever the entry point, vm.rs:153-160); tuple = (pc limbs 20/20/24, op, fa, fb, fc, fhi, s, opclass).
 struct Rom { std::vector<F> rows; size_t n = 0; uint64_t entry = 0; bool ok = false; const F* row(size_t t) const { return &rows[t * N_TUPLE]; } };
@@ -264,10 +281,11 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       col(C_STATE + g)[i] = r.reg_state[g];
     }
     int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
-    if (cls == K_OTH && !D) cls = op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : op == OP_BNE ? K_BNE : op == OP_JAL ? K_JAL : K_OTH;
-    col(C_K + cls)[i] = 1;
+    if (cls == K_OTH && !D) cls = (int)opclass_of(op);
+    col(kcol(cls))[i] = 1;
     col(C_OPC)[i] = opclass_of(op);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
-    const uint32_t tc = cls == K_BNE ? fa : fc;             // second operand: rs2 = field c, but BNE has rs1 in field a (rs2 in field b)
+    const bool branch = cls == K_BRE || cls == K_BRU;
+    const uint32_t tc = branch ? fa : fc;                   // second operand: rs2 = field c, but B-type words have rs1 in field a (rs2 in field b)
     if (fb) col(C_SELB + fb - 1)[i] = 1;
     if (tc) col(C_SELC + tc - 1)[i] = 1;
     const F* xb = limb[fb]; const F* xc = limb[tc];         // register 0 reads as zero limbs: its columns are constrained to zero
@@ -275,7 +293,18 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     F ne = 0;
     for (int l = 0; l < 3; l++) if (!ne && xb[l] != xc[l]) { ne = 1; col(C_IV + l)[i] = finv(fsub(xb[l], xc[l])); }
     col(C_NE)[i] = ne;
-    const F tk = cls == K_BNE ? ne : 0;
+    // the 40-bit difference of the masked operands and its borrows: xb - xc (SUB, SLTU / SGEU: rs1 = field b), xc - xb (BLTU / BGEU: rs1 = field a)
+    F z[2] = {0, 0}, c0 = 0, c1 = 0;
+    if (cls == K_SUB || cls == K_SU || cls == K_BRU) {
+      const F* a = cls == K_BRU ? xc : xb; const F* b = cls == K_BRU ? xb : xc;
+      const int64_t v0 = (int64_t)a[0] - b[0]; c0 = v0 < 0; z[0] = (F)(v0 + ((int64_t)c0 << 20));
+      const int64_t v1 = (int64_t)a[1] - b[1] - c0; c1 = v1 < 0; z[1] = (F)(v1 + ((int64_t)c1 << 20));
+    }
+    const F flag = (cls == K_BRE || cls == K_SE) ? 1 - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0;
+    const F pol = fsub(op, family_base(cls));               // 0 / 1 inside a family; the opcode itself on every other row (fx is unused there)
+    const F fx = fsub(fadd(flag, pol), fmul(2, fmul(pol, flag)));
+    col(C_FLAG)[i] = flag; col(C_FX)[i] = fx;
+    const F tk = branch ? fx : 0;
     col(C_TK)[i] = tk;
     const F imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFF;        // sign-extended imm17 mod 2^40, as two 20-bit limbs
     const F lo20 = fb + 16 * fc + 256 * fhi - (s << 20);                                           // low 20 bits of off21
@@ -283,7 +312,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     col(C_DL0)[i] = dl0;
     const F se = (tk || cls == K_JAL) ? s : 0;
     col(C_SE)[i] = se;
-    F y[3] = {0, 0, 0}, c0 = 0, c1 = 0;
+    F y[3] = {0, 0, 0};
     int rd = -1;
     if (cls == K_ADD || cls == K_ADDI) {
       const F b0 = cls == K_ADD ? xc[0] : im0, b1 = cls == K_ADD ? xc[1] : im1;
@@ -295,7 +324,8 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       const uint64_t v1 = (uint64_t)pc[1] + c0; c1 = (F)(v1 >> 20); y[1] = (F)(v1 & 0xFFFFF);
       y[2] = pc[2] + c1;
       rd = fa;
-    }
+    } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
+    else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     if (rd > 0) col(C_WR + rd - 1)[i] = 1;
     if (cls == K_OTH) {                                     // any other instruction: what it wrote is read off the next row
       const PackedRow& q = rows[i + 1];
@@ -309,9 +339,11 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       }
     }
     for (int l = 0; l < 3; l++) col(C_Y + l)[i] = y[l];
-    col(C_RC)[i] = y[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = y[0] >> RC_BITS; col(C_RC + 2)[i] = y[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = y[1] >> RC_BITS;
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_OTH) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
+    col(C_Z)[i] = z[0]; col(C_Z + 1)[i] = z[1];
+    col(C_RC)[i] = z[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = z[0] >> RC_BITS; col(C_RC + 2)[i] = z[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = z[1] >> RC_BITS;
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_BNE || cls == K_JAL) {                           // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
+    if (cls != K_OTH && cls != K_HALT && cls != K_PAD) {                                            // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
       const uint64_t v0 = (uint64_t)pc[0] + dl0; const F d0 = (F)(v0 >> 20);
       const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; const F d1 = (F)(v1 >> 20);
       const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; const F d2 = (F)(v2 >> 24);
@@ -417,7 +449,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 5;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2)
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 6;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
@@ -469,7 +501,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E one = e_from(1);
   const E Dm = cst(pub.deferred ? 1 : 0), nD = cst(pub.deferred ? 0 : 1);
   const E op = loc[C_OP], fa = loc[C_FA], fb = loc[C_FB], fc = loc[C_FC], fhi = loc[C_FHI], s = loc[C_S], se = loc[C_SE];
-  const E* K = loc + C_K;
+  E K[N_CLASS];
+  for (int k = 0; k < N_CLASS; k++) K[k] = loc[kcol(k)];
   // 1. cycle counter, first row, last executed row
   push(emul(esub(esub(nxt[C_CYCLE], loc[C_CYCLE]), one), is_trans));
   for (int i = 0; i < N_STATE; i++) push(emul(esub(loc[state_col(i)], cst(pub.first[i])), is_first));   // row 0 is in the public first state
@@ -481,17 +514,18 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   auto boolean = [&](const E& b) { push(emul(b, esub(b, one))); };
   for (int r = 0; r < 16; r++) boolean(loc[C_STATE + r]);
   for (int r = 0; r < 15; r++) { boolean(loc[C_WR + r]); boolean(loc[C_SELB + r]); boolean(loc[C_SELC + r]); }
-  for (int k = 0; k < 7; k++) boolean(K[k]);
+  for (int k = 0; k < N_CLASS; k++) boolean(K[k]);
   boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
-  { E sum = e_from(0); for (int k = 0; k < 7; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  { E sum = e_from(0); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
     E ks = e_from(0);
-    for (int k = 1; k <= K_OTH; k++) ks = eadd(ks, emul_f(K[k], (F)k));
+    for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
-  (void)op;
+  const E Kbr = eadd(K[K_BRE], K[K_BRU]);                                    // B-type rows: rs1 in field a, nothing written, may be taken
+  const E Kcmp = eadd(K[K_SE], K[K_SU]);                                     // comparison rows: the flag is the value written
   // 5. register selectors: wr (written register = field a for add/addi/jal, none for bne/halt/pad, at most one in default mode),
   //    selb = one-hot(fb), selc = one-hot(fc), or one-hot(fa) on BNE rows
   auto moments = [&](int base, E& s0, E& s1, E& s2) {
@@ -501,10 +535,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   E w0, w1, w2, b0, b1, b2, c0s, c1s, c2s;
   moments(C_WR, w0, w1, w2); moments(C_SELB, b0, b1, b2); moments(C_SELC, c0s, c1s, c2s);
   push(emul(nD, esub(emul(w1, w1), w2)));
-  push(emul(eadd(eadd(K[K_ADD], K[K_ADDI]), K[K_JAL]), esub(w1, fa)));
-  push(emul(eadd(eadd(K[K_BNE], K[K_HALT]), K[K_PAD]), w0));
+  push(emul(eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), Kcmp), esub(w1, fa)));
+  push(emul(eadd(eadd(Kbr, K[K_HALT]), K[K_PAD]), w0));
   push(esub(b1, fb)); push(esub(emul(b1, b1), b2));
-  push(esub(c1s, eadd(fc, emul(K[K_BNE], esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));
+  push(esub(c1s, eadd(fc, emul(Kbr, esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));
   // 6. operand fetch
   for (int l = 0; l < 3; l++) {
     E xb = e_from(0), xc = e_from(0);
@@ -516,29 +550,53 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E imm17 = eadd(fc, emul_f(fhi, 16));
   const E im0 = eadd(esub(imm17, emul_f(s, 1u << 17)), emul_f(s, 1u << 20)), im1 = emul_f(s, 0xFFFFF);
   const E lo20 = esub(eadd(eadd(fb, emul_f(fc, 16)), emul_f(fhi, 256)), emul_f(s, 1u << 20));
-  const E *xb = loc + C_XB, *xc = loc + C_XC, *y = loc + C_Y, *pc = loc + C_PC;
+  //    — stated on z, the range-checked pair of limbs (13.); y = z on the rows that write it (and on "other" rows, whose y stays in range)
+  const E *xb = loc + C_XB, *xc = loc + C_XC, *y = loc + C_Y, *pc = loc + C_PC, *z = loc + C_Z;
   const E c0 = loc[C_C0], c1 = loc[C_C1];
-  push(emul(K[K_ADD], eadd(esub(esub(y[0], xb[0]), xc[0]), emul(two20, c0))));
-  push(emul(K[K_ADD], eadd(esub(esub(esub(y[1], xb[1]), xc[1]), c0), emul(two20, c1))));
-  push(emul(K[K_ADD], y[2]));
-  push(emul(K[K_ADDI], eadd(esub(esub(y[0], xb[0]), im0), emul(two20, c0))));
-  push(emul(K[K_ADDI], eadd(esub(esub(esub(y[1], xb[1]), im1), c0), emul(two20, c1))));
+  push(emul(K[K_ADD], eadd(esub(esub(z[0], xb[0]), xc[0]), emul(two20, c0))));
+  push(emul(K[K_ADD], eadd(esub(esub(esub(z[1], xb[1]), xc[1]), c0), emul(two20, c1))));
+  push(emul(eadd(K[K_ADD], K[K_SUB]), y[2]));
+  push(emul(K[K_ADDI], eadd(esub(esub(z[0], xb[0]), im0), emul(two20, c0))));
+  push(emul(K[K_ADDI], eadd(esub(esub(esub(z[1], xb[1]), im1), c0), emul(two20, c1))));
   push(emul(K[K_ADDI], y[2]));
-  push(emul(K[K_JAL], eadd(esub(esub(y[0], pc[0]), cst(4)), emul(two20, c0))));
-  push(emul(K[K_JAL], eadd(esub(esub(y[1], pc[1]), c0), emul(two20, c1))));
+  push(emul(K[K_JAL], eadd(esub(esub(z[0], pc[0]), cst(4)), emul(two20, c0))));
+  push(emul(K[K_JAL], eadd(esub(esub(z[1], pc[1]), c0), emul(two20, c1))));
   push(emul(K[K_JAL], esub(esub(y[2], pc[2]), c1)));
+  // 7b. (v3) differences with borrows: z = xb - xc mod 2^40 on SUB and SLTU / SGEU rows (execute.rs:65-77, :373-407), z = xc - xb on BLTU /
+  //     BGEU rows (:618-636); c1 = 1 exactly when the minuend is the smaller 40-bit value (z's limbs are in range, so the borrows are forced)
+  {
+    const E Ks = eadd(K[K_SUB], K[K_SU]);
+    push(emul(Ks, esub(eadd(esub(z[0], xb[0]), xc[0]), emul(two20, c0))));
+    push(emul(Ks, esub(eadd(eadd(esub(z[1], xb[1]), xc[1]), c0), emul(two20, c1))));
+    push(emul(K[K_BRU], esub(eadd(esub(z[0], xc[0]), xb[0]), emul(two20, c0))));
+    push(emul(K[K_BRU], esub(eadd(eadd(esub(z[1], xc[1]), xb[1]), c0), emul(two20, c1))));
+  }
+  //     the written value: y = z on arithmetic and "other" rows, (fx, 0, 0) on comparison rows
+  {
+    const E Ky = eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), K[K_OTH]);
+    push(emul(Ky, esub(y[0], z[0]))); push(emul(Ky, esub(y[1], z[1])));
+    push(emul(Kcmp, esub(y[0], loc[C_FX]))); push(emul(Kcmp, y[1])); push(emul(Kcmp, y[2]));
+  }
   // 8. BNE compares the raw 64-bit values (execute.rs:588-596): ne = [xb != xc] over all three limbs
   {
     E dot = e_from(0);
     for (int l = 0; l < 3; l++) { const E d = esub(xb[l], xc[l]); dot = eadd(dot, emul(d, loc[C_IV + l])); push(emul(esub(one, loc[C_NE]), d)); }
     push(esub(loc[C_NE], dot));
   }
-  push(emul(K[K_BNE], esub(loc[C_TK], loc[C_NE])));
-  push(emul(esub(one, K[K_BNE]), loc[C_TK]));
+  // 8b. (v3) the family's comparison and its polarity: flag = [xb == xc] on BEQ / BNE / SEQ / SNE rows, the borrow c1 on the unsigned
+  //     comparisons, 0 elsewhere; fx = flag XOR pol, pol = op - (the family's even opcode) — the ROM ties op to the class, so pol is 0 / 1;
+  //     a branch is taken iff fx (execute.rs:578-596, :618-636)
+  push(esub(esub(loc[C_FLAG], emul(eadd(K[K_BRE], K[K_SE]), esub(one, loc[C_NE]))), emul(eadd(K[K_BRU], K[K_SU]), c1)));
+  {
+    E pol = op;
+    for (int k = 0; k < N_CLASS; k++) if (family_base(k)) pol = esub(pol, emul_f(K[k], family_base(k)));
+    push(esub(esub(esub(loc[C_FX], loc[C_FLAG]), pol), emul_f(emul(pol, loc[C_FLAG]), P - 2)));      // fx - flag - pol + 2 pol flag
+  }
+  push(esub(loc[C_TK], emul(Kbr, loc[C_FX])));
   // 9. next pc: pc + 4, pc + imm17 (branch taken) or pc + off21 (JAL), wrapping at 2^64 over (20, 20, 24)-bit limbs (state.rs:131-133)
   push(esub(loc[C_DL0], eadd(eadd(cst(4), emul(loc[C_TK], esub(im0, cst(4)))), emul(K[K_JAL], esub(lo20, cst(4))))));
   push(esub(se, emul(eadd(loc[C_TK], K[K_JAL]), s)));
-  const E kc = eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_BNE], K[K_JAL]));
+  const E kc = esub(esub(esub(one, K[K_OTH]), K[K_HALT]), K[K_PAD]);       // every class whose next pc the AIR derives
   const E hp = eadd(K[K_HALT], K[K_PAD]);
   push(emul(emul(kc, eadd(esub(esub(nxt[C_PC], pc[0]), loc[C_DL0]), emul(two20, loc[C_D0]))), is_trans));
   push(emul(emul(kc, eadd(esub(esub(esub(nxt[C_PC + 1], pc[1]), emul_f(se, 0xFFFFF)), loc[C_D0]), emul(two20, loc[C_D1]))), is_trans));
@@ -571,10 +629,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
       out[k] = eadd(lo, emul_f(hi, WEXT));
     }
   };
-  // 13. the written value's low limbs are two 10-bit chunks each (their range is the lookup below)
+  // 13. the limbs of z are two 10-bit chunks each (their range is the lookup below)
   const E* R = loc + C_RC;
-  push(esub(esub(y[0], R[0]), emul_f(R[1], RC_TABLE)));
-  push(esub(esub(y[1], R[2]), emul_f(R[3], RC_TABLE)));
+  push(esub(esub(z[0], R[0]), emul_f(R[1], RC_TABLE)));
+  push(esub(esub(z[1], R[2]), emul_f(R[3], RC_TABLE)));
   // 14. range helpers: H_i (alpha - R_i) = 1
   for (int i = 0; i < 4; i++) {
     E d[4], pr[4];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v2, proof format v5).
+"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v3, proof format v6).
 
 The reference has no prover, so nothing external can pin these stages; this file FREEZES them — it pins nothing:
 the values are produced by this repository's own oracle, so they guard against DRIFT only: the
@@ -23,7 +23,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
 
-ADD, ADDI, SLLI, LW, SW, BNE, JAL, ECALL = 0x00, 0x08, 0x1B, 0x34, 0x3A, 0x41, 0x48, 0x50
+ADD, SUB, ADDI, SLLI, SLTU, SGEU, SEQ, SNE, LW, SW, BEQ, BNE, BLTU, BGEU, JAL, ECALL = 0x00, 0x01, 0x08, 0x1B, 0x20, 0x21, 0x24, 0x25, 0x34, 0x3A, 0x40, 0x41, 0x44, 0x45, 0x48, 0x50
 
 
 def r_(op, rd, rs1, rs2): return op | rd << 7 | rs1 << 11 | rs2 << 15
@@ -47,11 +47,18 @@ _sha = [i_(ADDI, 5, 0, 0), i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(ADDI, 7
 _sha[0] = i_(ADDI, 5, 0, 0x1000 + 4 * len(_sha))
 SHA_CHAIN = blob(_sha, bytes(range(32)))                                                                           # pattern of crypto_edge_cases.rs:405-427
 
+# every opcode family of AIR v3 besides the fib loop's, every comparison both ways (the product ships it as spec.compare_loop_program)
+CMP_LOOP = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 7), i_(ADDI, 3, 0, 100), i_(ADDI, 10, 0, 1), i_(ADDI, 11, 0, 500),
+                 r_(SUB, 4, 3, 2), r_(SUB, 5, 2, 3), r_(SLTU, 6, 2, 11), r_(SGEU, 7, 2, 11), r_(SEQ, 8, 6, 10), r_(SNE, 9, 6, 10),
+                 r_(ADD, 2, 2, 6), i_(ADDI, 2, 2, 45), i_(BLTU, 2, 3, 8), r_(ADD, 3, 3, 3), i_(BGEU, 2, 11, 8), r_(SUB, 3, 3, 9),
+                 i_(BEQ, 6, 10, 8), i_(ADDI, 1, 1, 1), i_(ADDI, 10, 6, 0), i_(BNE, 1, 0, -60), j_(JAL, 0, -64)])
+
 CASES = [
     dict(name="fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=False),
     dict(name="sha_2p9", blob=SHA_CHAIN, max_cycles=1 << 9, deferred=False),
     dict(name="deferred_fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=True),
     dict(name="fib30_exit_154_rows", blob=FIB30, max_cycles=1_000_000, deferred=False),
+    dict(name="compare_loop_600_rows", blob=CMP_LOOP, max_cycles=600, deferred=False),
 ]
 
 
@@ -73,8 +80,8 @@ def golden(case):
 
 
 if __name__ == "__main__":
-    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v2, proof format v5; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
-           "proof_version": 5, "main_trace_width": so.W_MAIN, "num_constraints": so.lib().so_num_constraints(),
+    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v3, proof format v6; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
+           "proof_version": 6, "main_trace_width": so.W_MAIN, "num_constraints": so.lib().so_num_constraints(),
            "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
            "cases": [golden(c) for c in CASES]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")

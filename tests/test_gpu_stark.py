@@ -48,7 +48,7 @@ def test_lde_matches_oracle(log_n):
     ctx.close()
 
 
-@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 152), (10, 17)])
+@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 160), (10, 17)])
 def test_merkle_matches_oracle(log_n, width):
     import torch
     from zkir_amd import stark
@@ -67,7 +67,7 @@ def test_merkle_and_lde_extreme_values(fill):
     """Worst cases for the lazy (unreduced) arithmetic of the hash and NTT kernels: every input at the top of the range."""
     import torch
     from zkir_amd import stark
-    log_n, width = 9, 152
+    log_n, width = 9, 160
     n = 1 << log_n
     mat = np.zeros((width, n), dtype=np.uint32)
     if fill == "p-1":
@@ -87,6 +87,7 @@ def test_merkle_and_lde_extreme_values(fill):
 
 
 PROGRAMS = {"fib": (spec.fib_endless_program, {}), "sha": (spec.sha256_chain_program, {}), "deferred": (spec.fib_endless_program, {"enable_deferred_model": True}),
+            "cmp": (spec.compare_loop_program, {}), "cmp_deferred": (spec.compare_loop_program, {"enable_deferred_model": True}),
             "fib30": (lambda: spec.fib_program(30), {}), "exit42": (lambda: spec.Program.from_code([spec.addi(10, 0, 0), spec.addi(11, 0, 42), spec.ecall()]), {})}
 
 
@@ -107,9 +108,9 @@ def _case(name, n):
 
 
 @pytest.mark.parametrize("name,n", [("fib", 64), ("fib", 1024), ("fib", 4096), ("fib", 1000), ("fib", 5), ("sha", 512), ("sha", 700), ("deferred", 256),
-                                    ("fib30", None), ("exit42", None)])
+                                    ("fib30", None), ("exit42", None), ("cmp", 600), ("cmp", 5000), ("cmp_deferred", 300)])
 def test_main_trace_and_commit_match_oracle(name, n):
-    """All 152 columns of the padded main trace, the LDE and the commitment root, for power-of-two and ragged row counts and for
+    """All 160 columns of the padded main trace, the LDE and the commitment root, for power-of-two and ragged row counts and for
     programs that halt on their own (Exit / padding rows)."""
     from zkir_amd import stark
     blob, log, tr, rows, opub, pub = _case(name, n)
@@ -150,7 +151,7 @@ def test_commit_2p16_root_and_properties():
 
 
 @pytest.mark.parametrize("name,n", [("fib", 8), ("fib", 5), ("fib", 32), ("fib", 256), ("fib", 2048), ("fib", 1500), ("sha", 512), ("sha", 300), ("deferred", 1024),
-                                    ("fib30", None), ("exit42", None), ("fib", 8192)])
+                                    ("fib30", None), ("exit42", None), ("fib", 8192), ("cmp", 600), ("cmp", 4096), ("cmp_deferred", 300)])
 def test_proof_bytes_match_oracle_and_verify(name, n):
     """End-to-end proof (quotient over the v1 AIR, openings, DEEP, FRI, grinding, queries): GPU proof words == oracle proof words,
     and both verifiers accept them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on
@@ -189,6 +190,20 @@ def test_wrong_execution_is_rejected_on_the_gpu_path():
     bad = stark.prove(ctx, tr, pub)
     assert so.verify(bad, opub) == 10 and rt.verify(bad, pub) == 10
     tr.registers[4, k + 1:nxt + 1] = saved
+    # AIR v3: the comparison families, on a run of spec.compare_loop_program — an SLTU written the wrong way round, a SUB off by one
+    blob3, log3, tr3, rows3, opub3, pub3 = _case("cmp", 600)
+    ctx3 = stark.StarkContext(10)
+    ops3 = rows3["instruction"] & 0x7F
+    for op, rd, edit in ((0x20, 6, lambda v: v ^ 1), (0x01, 4, lambda v: v + 1)):
+        ks = np.nonzero((ops3 == op) & (((rows3["instruction"] >> 7) & 0xF) == rd))[0]
+        k3, nx3 = int(ks[4]), int(ks[5])
+        saved3 = tr3.registers[rd, k3 + 1:nx3 + 1].clone()
+        tr3.registers[rd, k3 + 1:nx3 + 1] = edit(saved3)
+        bad3 = stark.prove(ctx3, tr3, pub3)
+        assert so.verify(bad3, opub3) == 10 and rt.verify(bad3, pub3) == 10, hex(op)
+        tr3.registers[rd, k3 + 1:nx3 + 1] = saved3
+    assert np.array_equal(stark.prove(ctx3, tr3, pub3), so.prove(rows3, opub3))
+    ctx3.close(); log3.close()
     # A row whose (pc, instruction word) is not in the program's code table has NO proof in AIR v2 (instruction-ROM lookup): the honest
     # prover refuses it instead of emitting a proof the verifier would reject — a BNE's fall-through claimed where the run branched
     # (the word at the claimed pc is another one), an instruction word patched in HBM (ADD -> SUB: the forgery AIR v1 accepted)
@@ -295,7 +310,7 @@ def test_proof_large_verifies(log_n):
     ctx = stark.StarkContext(log_n)
     proof = stark.prove(ctx, tr, pub)
     assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0
-    assert proof[2] == log_n and proof[3] == 152 and proof[7] == (1 << log_n) - 1
+    assert proof[2] == log_n and proof[3] == 160 and proof[7] == (1 << log_n) - 1
     ctx.close(); log.close()
 
 

@@ -142,11 +142,15 @@ def test_merkle_layers_and_paths():
     assert np.array_equal(node, root)
 
 
-# column map of the main trace (AIR v2: oracle/stark_oracle.cpp)
+# column map of the main trace (AIR v3: oracle/stark_oracle.cpp)
 C_PC, C_OP, C_FA, C_LIMB, C_STATE, C_WR, C_SELB, C_SELC, C_XB, C_XC, C_Y, C_K, C_OPC, C_RC, C_S, C_C0, C_D0, C_DL0, C_NE, C_IV, C_TK = \
     1, 4, 5, 9, 57, 73, 88, 103, 118, 121, 124, 127, 134, 135, 139, 141, 143, 146, 147, 148, 151
-K_ADD, K_ADDI, K_BNE, K_JAL, K_OTH, K_HALT, K_PAD = range(7)
+C_K2, C_Z, C_FLAG, C_FX = 152, 156, 158, 159
+K_ADD, K_ADDI, K_BRE, K_JAL, K_OTH, K_HALT, K_PAD, K_SUB, K_BRU, K_SE, K_SU = range(11)
+K_BNE = K_BRE                                                    # BEQ / BNE share a class: the family's comparison with either polarity
+KCOL = [C_K + k for k in range(7)] + [C_K2 + k for k in range(4)]
 W = so.W_MAIN
+OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU}
 
 
 def test_main_trace_columns_and_commit():
@@ -155,18 +159,18 @@ def test_main_trace_columns_and_commit():
     rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
     pub = so.public_inputs(n, blob)
     m = so.main_trace(rows, pub)
-    assert m.shape == (152, 64) and (m < P).all()
+    assert m.shape == (160, 64) and (m < P).all()
     assert list(m[0]) == list(range(64))                         # the cycle column keeps counting through the padding
     assert np.array_equal(m[1][:n], rows["pc"] & 0xFFFFF) and not m[3].any()
     assert np.array_equal(m[C_OP][:n], rows["instruction"] & 0x7F)
     assert np.array_equal(m[C_LIMB + 3 * 4][:n], rows["registers"][:, 4] & 0xFFFFF)
-    cls = m[C_K:C_K + 7]
+    cls = m[KCOL]
     assert (cls.sum(axis=0) == 1).all()
     assert cls[K_PAD][n:].all() and cls[K_HALT][n - 1] == 1 and cls[K_HALT].sum() == 1 and not cls[K_PAD][:n].any()
     ops = rows["instruction"][:n - 1] & 0x7F
     for k, code in ((K_ADD, 0x00), (K_ADDI, 0x08), (K_BNE, 0x41), (K_JAL, 0x48)):
         assert np.array_equal(cls[k][:n - 1].astype(bool), ops == code)
-    assert not cls[K_OTH].any()                                  # the fib loop is made of the four constrained opcodes only
+    assert not cls[K_OTH].any() and not cls[K_SUB:].any()       # the fib loop is made of four constrained opcodes only
     # wr = one-hot of rd on writing rows; y = the value the next row shows in rd
     for i in range(n - 1):
         w = rows["instruction"][i]
@@ -179,17 +183,65 @@ def test_main_trace_columns_and_commit():
             v = int(rows["registers"][i + 1, rd])
             assert [int(m[C_Y + l, i]) for l in range(3)] == [v & 0xFFFFF, (v >> 20) & 0xFFFFF, v >> 40]
     # opclass = class of the instruction WORD on every row (halt and padding rows included); the range chunks split y's two low limbs
-    opc = np.select([m[C_OP] == 0x00, m[C_OP] == 0x08, m[C_OP] == 0x41, m[C_OP] == 0x48], [0, 1, 2, 3], 4)
+    opc = np.array([OPCLASS.get(int(o), K_OTH) for o in m[C_OP]])
     assert np.array_equal(m[C_OPC], opc)
     assert (m[C_RC:C_RC + 4] < 1024).all()
-    assert np.array_equal(m[C_RC] + 1024 * m[C_RC + 1], m[C_Y]) and np.array_equal(m[C_RC + 2] + 1024 * m[C_RC + 3], m[C_Y + 1])
+    assert np.array_equal(m[C_RC] + 1024 * m[C_RC + 1], m[C_Z]) and np.array_equal(m[C_RC + 2] + 1024 * m[C_RC + 3], m[C_Z + 1])
+    wrote = cls[K_ADD] | cls[K_ADDI] | cls[K_JAL]
+    assert np.array_equal(m[C_Z][wrote == 1], m[C_Y][wrote == 1]) and not m[C_Z][wrote == 0].any()      # z = the written limbs; zero on BNE / halt / pad rows
     # padding rows repeat the state of the last executed row
     assert (m[C_LIMB:C_STATE + 16, n:] == m[C_LIMB:C_STATE + 16, n - 1:n]).all() and (m[C_PC:C_PC + 3, n:] == m[C_PC:C_PC + 3, n - 1:n]).all()
     root, L = so.commit_trace(rows, 1, want_lde=True, pub=pub)
-    assert L.shape == (152, 128)
+    assert L.shape == (160, 128)
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
+
+
+def test_main_trace_of_the_opcode_families():
+    """AIR v3: SUB, SLTU / SGEU, SEQ / SNE, BEQ / BNE, BLTU / BGEU rows of spec.compare_loop_program: class = the word's family, the
+    difference limbs with their borrows, the comparison flag, its polarity, the value written and the branch decision — against the VM's
+    own rows (next pc, next register value)."""
+    blob = spec.compare_loop_program().to_bytes()
+    n = 600
+    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
+    pub = so.public_inputs(n, blob)
+    m = so.main_trace(rows, pub)
+    cls = m[KCOL]
+    assert (cls.sum(axis=0) == 1).all() and not cls[K_OTH].any()            # every opcode of this program is constrained
+    M40 = (1 << 40) - 1
+    seen = set()
+    for i in range(n - 1):
+        w = int(rows["instruction"][i]); op = w & 0x7F; k = OPCLASS[op]
+        assert cls[k][i] == 1 and m[C_OPC, i] == k
+        fa, fb, fc = (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF
+        reg = [int(v) for v in rows["registers"][i]]
+        z = int(m[C_Z, i]) | (int(m[C_Z + 1, i]) << 20)
+        if k in (K_SUB, K_SU):
+            assert z == (reg[fb] - reg[fc]) & M40 and m[C_C0 + 1, i] == int((reg[fb] & M40) < (reg[fc] & M40))
+        if k == K_BRU:
+            assert z == (reg[fa] - reg[fb]) & M40 and m[C_C0 + 1, i] == int((reg[fa] & M40) < (reg[fb] & M40))
+        if k in (K_BRE, K_SE):
+            a, b = (reg[fa], reg[fb]) if k == K_BRE else (reg[fb], reg[fc])
+            assert m[C_FLAG, i] == int(a == b)
+        if k in (K_BRU, K_SU):
+            assert m[C_FLAG, i] == m[C_C0 + 1, i]
+        if k in (K_BRE, K_BRU, K_SE, K_SU):
+            assert m[C_FX, i] == int(m[C_FLAG, i]) ^ (op & 1)
+        if k in (K_BRE, K_BRU):
+            taken = int(rows["pc"][i + 1]) != int(rows["pc"][i]) + 4
+            assert m[C_TK, i] == int(taken) == m[C_FX, i] and not m[C_WR:C_WR + 15, i].any()
+            seen.add((op, taken))
+        else:
+            assert m[C_TK, i] == 0
+        if k in (K_SE, K_SU):
+            assert [int(m[C_Y + l, i]) for l in range(3)] == [int(m[C_FX, i]), 0, 0] and int(rows["registers"][i + 1, fa]) == m[C_FX, i]
+            seen.add((op, int(m[C_FX, i])))
+        if k == K_SUB:
+            assert int(rows["registers"][i + 1, fa]) == z == int(m[C_Y, i]) | (int(m[C_Y + 1, i]) << 20) and m[C_Y + 2, i] == 0
+            seen.add((op, int(m[C_C0 + 1, i])))
+    # every comparison came out both ways, every branch was both taken and not taken, SUB with and without a borrow out of 40 bits
+    assert seen == {(op, v) for op in (0x01, 0x20, 0x21, 0x24, 0x25, 0x40, 0x41, 0x44, 0x45) for v in (0, 1)}
 
 
 def test_cpu_commit_port_matches_the_oracle():
@@ -207,7 +259,8 @@ def test_air_holds_row_by_row_on_honest_traces():
     """Every constraint vanishes on every (row, next row) pair of an honest main trace: evaluated here with the row selectors a
     verifier would use ON the trace domain (is_first = [i == 0], is_last = [i == n_real - 1], is_trans = [i != N - 1])."""
     for prog, n, cfg in ((spec.fib_endless_program(), 50, {}), (spec.sha256_chain_program(), 200, {}), (spec.fib_program(12), None, {}),
-                         (spec.fib_endless_program(), 40, {"enable_deferred_model": True})):
+                         (spec.fib_endless_program(), 40, {"enable_deferred_model": True}), (spec.compare_loop_program(), 600, {}),
+                         (spec.compare_loop_program(), 100, {"enable_deferred_model": True})):
         blob = prog.to_bytes()
         res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
         rows = res.rows
@@ -232,8 +285,12 @@ def test_air_holds_row_by_row_on_honest_traces():
 
 
 # ---- stage B: prover + verifier ------------------------------------------------------------------------------------
+def _prog(prog):
+    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program}[prog]()
+
+
 def _run(n, prog="fib", **cfg):
-    blob = (spec.fib_endless_program() if prog == "fib" else spec.sha256_chain_program()).to_bytes()
+    blob = _prog(prog).to_bytes()
     res = oracle.run(blob, max_cycles=n, enable_execution_trace=True, **cfg)
     return res.rows, so.public_inputs(len(res.rows), blob, deferred=bool(cfg.get("enable_deferred_model")))
 
@@ -257,17 +314,17 @@ NQ = 50
 WA, WT = so.W_AUX, so.W_MAIN + so.W_AUX
 
 
-@pytest.mark.parametrize("n,prog", [(8, "fib"), (16, "fib"), (5, "fib"), (100, "fib"), (256, "fib"), (300, "sha"), (1024, "fib")])
+@pytest.mark.parametrize("n,prog", [(8, "fib"), (16, "fib"), (5, "fib"), (100, "fib"), (256, "fib"), (300, "sha"), (1024, "fib"), (600, "cmp")])
 def test_prove_verify_roundtrip(n, prog):
     rows, pub = _run(n, prog)
     pr = so.prove(rows, pub)
     log_n = so.padded_log_n(n)
     ks = _fri_schedule(log_n)                                                              # [1], [1,1], [1,2], [1,3,1], [1,3,2], [1,3,3], [1,3,3,1]
     lay = so.proof_layout(pr)
-    blob = (spec.fib_endless_program() if prog == "fib" else spec.sha256_chain_program()).to_bytes()
+    blob = _prog(prog).to_bytes()
     assert lay["blob"] == blob and lay["n_rom"] == int.from_bytes(blob[16:20], "little") // 4 and lay["trace_root"] == HDR + 1 + (len(blob) + 1) // 2 + lay["n_rom"] + 1024
     fixed = lay["trace_root"] + 12 + (2 * WT + 4) * 4                                      # ... roots (trace, aux, quotient), openings of main + aux columns and the quotient
-    assert pr[1] == 5 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
+    assert pr[1] == 6 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
     assert int(pr[lay["rom_mult"]:lay["rc_mult"]].sum()) == 1 << log_n and int(pr[lay["rc_mult"]:lay["trace_root"]].sum()) == 4 << log_n   # multiplicities count every row
     depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
     per_query = 1 + 2 * (W + 4 * (log_n + 1)) + 2 * (WA + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
@@ -464,6 +521,42 @@ def test_wrong_execution_is_rejected():
     assert so.verify(so.prove(r2, so.public_inputs(len(r2), spec.fib_endless_program().to_bytes()))) != 0
 
 
+def test_wrong_execution_of_the_opcode_families_is_rejected():
+    """AIR v3: the same for SUB, the unsigned and the equality comparisons and the four branches they drive: a wrong difference, a
+    comparison written the wrong way round, a branch that goes the other way — each kept consistent afterwards, each rejected."""
+    rows0, pub = _run(600, "cmp")
+    ops = rows0["instruction"] & 0x7F
+    rd_of = (rows0["instruction"] >> 7) & 0xF
+    assert so.verify(so.prove(rows0, pub)) == 0
+
+    def rejected(rows):
+        return so.verify(so.prove(rows, pub)) == 10
+
+    def until_rewritten(k, rd):                                  # rows k+1 .. (the next write of rd): where a forged value of rd shows
+        later = np.nonzero((rd_of[k + 1:] == rd) & ~np.isin(ops[k + 1:], (0x40, 0x41, 0x44, 0x45)))[0]
+        return k + 1, k + 2 + int(later[0]) if len(later) else len(rows0)
+    for op, delta in ((0x01, 1), (0x01, 1 << 20), (0x20, None), (0x21, None), (0x24, None), (0x25, None)):
+        k = int(np.nonzero(ops == op)[0][3]); rd = int(rd_of[k])
+        lo, hi = until_rewritten(k, rd)
+        rows = rows0.copy()
+        if delta is None: rows["registers"][lo:hi, rd] ^= 1      # the comparison written the wrong way round
+        else: rows["registers"][lo:hi, rd] = (rows["registers"][lo:hi, rd] + delta) & ((1 << 40) - 1)
+        assert rejected(rows), hex(op)
+    # SUB that forgets the wrap: a - b below zero written as a 64-bit two's complement (bits above 40 set)
+    k = int(np.nonzero((ops == 0x01) & (rd_of == 5))[0][2]); lo, hi = until_rewritten(k, 5)
+    rows = rows0.copy(); rows["registers"][lo:hi, 5] |= np.uint64(0xFFFFFF << 40)
+    assert rejected(rows)
+    # branches going the other way: the next pc is the other candidate (everything after it shifted along is then a different run: only
+    # the one row is forged here, the ROM lookup and the pc constraint both see it)
+    for op in (0x40, 0x41, 0x44, 0x45):
+        for want_taken in (False, True):
+            ks = [int(k) for k in np.nonzero(ops[:-1] == op)[0] if (int(rows0["pc"][k + 1]) != int(rows0["pc"][k]) + 4) == want_taken]
+            k = ks[len(ks) // 2]
+            w = int(rows0["instruction"][k]); imm = (w >> 15) - (1 << 17 if w >> 31 else 0)
+            rows = rows0.copy(); rows["pc"][k + 1] = int(rows0["pc"][k]) + (4 if want_taken else imm)
+            assert rejected(rows), (hex(op), want_taken)
+
+
 def test_cheating_prover_matrices_are_rejected():
     """A prover that submits its own main-trace matrix: relabelling a constrained opcode as 'other', freeing the write selector,
     lying about an operand, or skipping rows by early padding."""
@@ -494,6 +587,7 @@ def test_cheating_prover_matrices_are_rejected():
         y1 = int(m[C_Y + 1, k]) + d                               # the carry into limb 1 changes with it; stays inside 20 bits here
         assert 0 <= y1 < 1 << 20
         m[C_Y + 1, k] = y1; m[C_RC + 2, k] = y1 & 1023; m[C_RC + 3, k] = y1 >> 10
+        m[C_Z, k] = m[C_Y, k]; m[C_Z + 1, k] = y1                # z = y on an ADD row
         rd = 4                                                    # add r4, r1, r2: the forged limbs are what the register shows until it is written again
         m[C_LIMB + 3 * rd, k + 1:nxt + 1] = m[C_Y, k]; m[C_LIMB + 3 * rd + 1, k + 1:nxt + 1] = m[C_Y + 1, k]
     assert bad(out_of_range_carry)
@@ -507,9 +601,43 @@ def test_cheating_prover_matrices_are_rejected():
         m[C_LIMB + 3 * 4, k + 1:nxt + 1] = (m[C_LIMB + 3 * 4, k + 1:nxt + 1].astype(np.int64) + 1) % P
     assert bad(wrong_sum)
 
+    def wrong_sum_with_z(m):                                     # ... the same with z and its chunks moved along (y = z holds): the addition itself fails
+        wrong_sum(m); m[C_Z, k] = m[C_Y, k]
+        m[C_RC, k] = int(m[C_Z, k]) & 1023; m[C_RC + 1, k] = int(m[C_Z, k]) >> 10
+    assert bad(wrong_sum_with_z)
+
+    # AIR v3: the same on the comparison families (rows of spec.compare_loop_program)
+    rows3, pub3 = _run(600, "cmp")
+    m3 = so.main_trace(rows3, pub3)
+    ops3 = rows3["instruction"] & 0x7F
+
+    def bad3(edit):
+        m = m3.copy(); edit(m)
+        return so.verify(so.prove_matrix(m, pub3)) == 10
+    ku = int(np.nonzero(ops3 == 0x20)[0][5]); kb = int(np.nonzero(ops3 == 0x44)[0][5]); ke = int(np.nonzero(ops3 == 0x40)[0][5]); ks = int(np.nonzero(ops3 == 0x01)[0][5])
+
+    def flip_borrow(m, k):                                       # the borrow that decides an unsigned comparison, flipped with z moved along by 2^20 x 2^20:
+        c1 = int(m[C_C0 + 1, k]); d = 1 - 2 * c1                 # every difference constraint still holds, z1 leaves its range — the chunk lookup refuses it
+        m[C_C0 + 1, k] = 1 - c1
+        z1 = (int(m[C_Z + 1, k]) + d * (1 << 20)) % P
+        m[C_Z + 1, k] = z1; m[C_RC + 3, k] = (int(m[C_RC + 3, k]) + d * 1024) % P
+        m[C_FLAG, k] = 1 - c1; m[C_FX, k] = 1 - int(m[C_FX, k])
+    def sltu_flipped(m):                                          # ... with the written value (and what the register shows afterwards) following the forged flag
+        flip_borrow(m, ku); m[C_Y, ku] = m[C_FX, ku]
+        nxt = ku + 1 + int(np.nonzero(ops3[ku + 1:] == 0x20)[0][0])
+        m[C_LIMB + 3 * 6, ku + 1:nxt + 1] = m[C_FX, ku]
+    assert bad3(sltu_flipped)
+    assert bad3(lambda m: (flip_borrow(m, kb), m.__setitem__((C_TK, kb), m[C_FX, kb])))          # BLTU decided by a forged borrow
+    assert bad3(lambda m: m.__setitem__((C_FLAG, ke), 1 - int(m[C_FLAG, ke])))                    # the equality flag is not [xb == xc]
+    assert bad3(lambda m: m.__setitem__((C_FX, ke), 1 - int(m[C_FX, ke])))                        # the polarity is not the opcode's
+    assert bad3(lambda m: m.__setitem__((C_TK, ke), 1 - int(m[C_TK, ke])))                        # the branch does not follow fx
+    assert bad3(lambda m: (m.__setitem__((C_K2 + 0, ks), 0), m.__setitem__((C_K + K_OTH, ks), 1)))  # a SUB row hiding as "other"
+    assert bad3(lambda m: (m.__setitem__((C_K2 + 0, ks), 0), m.__setitem__((C_K + K_ADD, ks), 1)))  # ... or running as an ADD
+
     def early_pad(m):                                            # stop executing at row 20: halt there, padding afterwards
         m[C_K:C_K + 7, 20:] = 0; m[C_K + K_HALT, 20] = 1; m[C_K + K_PAD, 21:] = 1
         m[1:C_K, 21:] = m[1:C_K, 20:21]; m[C_WR:C_WR + 15, 20:] = 0; m[C_Y:C_Y + 3, 20:] = 0; m[C_C0:C_C0 + 5, 20:] = 0; m[C_TK, 20:] = 0
+        m[C_Z:C_Z + 2, 20:] = 0; m[C_RC:C_RC + 4, 20:] = 0; m[C_FLAG, 20:] = 0; m[C_FX, 20:] = m[C_OP, 20:]
     assert bad(early_pad)                                        # the public row count pins the halt row (is_last)
 
 

@@ -18,13 +18,13 @@ def _pub_c(p: so.PublicC) -> rt.PublicInputsC:
 
 
 def _run(n, prog="fib", **cfg):
-    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12)}[prog]().to_bytes()
+    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program}[prog]().to_bytes()
     res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
     return res.rows, so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=bool(cfg))
 
 
 @pytest.mark.parametrize("n,prog,cfg", [(8, "fib", {}), (5, "fib", {}), (100, "fib", {}), (300, "sha", {}), (None, "fib12", {}), (512, "fib", {}),
-                                         (200, "fib", {"enable_deferred_model": True})])
+                                         (200, "fib", {"enable_deferred_model": True}), (600, "cmp", {}), (150, "cmp", {"enable_deferred_model": True})])
 def test_accepts_what_the_oracle_accepts(n, prog, cfg):
     rows, pub = _run(n, prog, **cfg)
     pr = so.prove(rows, pub)
@@ -86,6 +86,28 @@ def test_rejects_cheating_provers_like_the_oracle():
         r = rows.copy(); mutate(r)
         pr = so.prove(r, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10
+
+
+def test_rejects_forged_opcode_families_like_the_oracle():
+    """AIR v3 (SUB, SLTU / SGEU, SEQ / SNE, BEQ / BNE, BLTU / BGEU): the product verifier's constraint list (air.h) and the oracle's give
+    the same verdict on forged comparison flags, polarities, branch decisions, differences, and on rows relabelled into another class."""
+    rows, pub = _run(600, "cmp")
+    m0 = so.main_trace(rows, pub)
+    ops = rows["instruction"] & 0x7F
+    C_K, C_K2, C_Y, C_C1, C_TK, C_Z, C_FLAG, C_FX = 127, 152, 124, 142, 151, 156, 158, 159
+    at = {op: int(np.nonzero(ops == op)[0][4]) for op in (0x01, 0x20, 0x21, 0x24, 0x25, 0x40, 0x41, 0x44, 0x45)}
+    flip = lambda col, k: (lambda m: m.__setitem__((col, k), 1 - int(m[col, k])))
+    edits = [flip(C_FLAG, at[0x24]), flip(C_FX, at[0x25]), flip(C_TK, at[0x40]), flip(C_TK, at[0x45]), flip(C_FLAG, at[0x44]), flip(C_C1, at[0x20]), flip(C_C1, at[0x44]),
+             flip(C_Y, at[0x21]), lambda m: m.__setitem__((C_Z, at[0x01]), (int(m[C_Z, at[0x01]]) + 1) % P),
+             lambda m: (m.__setitem__((C_K2 + 0, at[0x01]), 0), m.__setitem__((C_K + 4, at[0x01]), 1)),          # SUB as "other"
+             lambda m: (m.__setitem__((C_K2 + 3, at[0x20]), 0), m.__setitem__((C_K2 + 2, at[0x20]), 1)),         # SLTU as the equality family
+             lambda m: (m.__setitem__((C_K2 + 1, at[0x44]), 0), m.__setitem__((C_K + 2, at[0x44]), 1))]          # BLTU as BEQ / BNE
+    for i, e in enumerate(edits):
+        m = m0.copy(); e(m)
+        pr = so.prove_matrix(m, pub)
+        assert so.verify(pr) == 10 and rt.verify(pr) == 10, i
+    pr = so.prove_matrix(m0, pub)
+    assert so.verify(pr) == 0 and rt.verify(pr) == 0
 
 
 @pytest.mark.parametrize("n_total,seg,prog", [(100, 40, "fib"), (300, 128, "sha"), (65, 33, "fib")])

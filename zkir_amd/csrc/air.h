@@ -31,10 +31,10 @@
 
 namespace air {
 
-constexpr int W = 152;
+constexpr int W = 160;
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151 };
+             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159 };
 // aux trace: H0..H3 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
 constexpr int W_AUX = 24, W_ALL = W + W_AUX;
 enum : int { A_H = 0, A_HR = 16, A_S = 20 };
@@ -42,15 +42,23 @@ constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 10;
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^10, T / N
 enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), N_LK = LK_TN + 4 };
 BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : C_OPC; }
-BB_HD constexpr uint32_t opclass_of(uint32_t op) { return op == 0x00 ? 0u : op == 0x08 ? 1u : op == 0x41 ? 2u : op == 0x48 ? 3u : 4u; }
-enum : int { K_ADD = 0, K_ADDI = 1, K_BNE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6 };
-constexpr uint32_t OP_ADD = 0x00, OP_ADDI = 0x08, OP_BNE = 0x41, OP_JAL = 0x48;
+// AIR v3: class ids (= opclass values of the instruction word; halt / pad are row roles, not word classes).  A FAMILY is a pair of opcodes
+// that differ in their low bit, the polarity of one comparison: bre = BEQ / BNE, bru = BLTU / BGEU, se = SEQ / SNE, su = SLTU / SGEU.
+enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, N_CLASS = 11 };
+BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : C_K2 + (k - 7); }
+constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
+                   OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48;
+BB_HD constexpr uint32_t opclass_of(uint32_t op) {
+  return op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+       : (op == OP_BLTU || op == OP_BGEU) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE : (op == OP_SLTU || op == OP_SGEU) ? K_SU : (uint32_t)K_OTH;
+}
+BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLTU : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0u; }   // the even opcode of a family
 
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
-enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 142,
-             I_ONE_CLASS = 150, I_OPCLASS = 151, I_WR = 152, I_SELB = 155, I_SELC = 157, I_OPERAND = 159, I_VALUE = 165,
-             I_NE = 174, I_TK = 178, I_DL0 = 180, I_SE = 181, I_PC = 182, I_PC_KEEP = 185, I_REGS = 188, I_TAIL = 248, I_LAST = 251,
-             I_CHUNK = 319, I_RANGE = 321, I_ROM = 337, I_SUM = 341, N_CONSTRAINTS = 345 };
+enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 146,
+             I_ONE_CLASS = 154, I_OPCLASS = 155, I_WR = 156, I_SELB = 159, I_SELC = 161, I_OPERAND = 163, I_VALUE = 169, I_DIFF = 178, I_WRITTEN = 182,
+             I_NE = 187, I_FLAG = 191, I_FX = 192, I_TK = 193, I_DL0 = 194, I_SE = 195, I_PC = 196, I_PC_KEEP = 199, I_REGS = 202, I_TAIL = 262, I_LAST = 265,
+             I_CHUNK = 333, I_RANGE = 335, I_ROM = 351, I_SUM = 355, N_CONSTRAINTS = 359 };
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -72,10 +80,12 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   const V one = o.cst(bb::R1), zero = o.cst(0);
   auto boolean = [&](int idx, V b) { o.push(idx, o.mul(b, o.sub(b, one))); };
   const V fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI), s = o.loc(C_S), se = o.loc(C_SE);
-  V K[7];
+  V K[N_CLASS];
 #pragma unroll
-  for (int k = 0; k < 7; k++) K[k] = o.loc(C_K + k);
+  for (int k = 0; k < N_CLASS; k++) K[k] = o.loc(kcol(k));
+  const V Kbr = o.add(K[K_BRE], K[K_BRU]), Kcmp = o.add(K[K_SE], K[K_SU]);       // B-type rows; comparison rows (the flag is the value written)
   const V y[3] = {o.loc(C_Y), o.loc(C_Y + 1), o.loc(C_Y + 2)};
+  const V z[2] = {o.loc(C_Z), o.loc(C_Z + 1)};
   const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
   const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
   // 1. cycle counter, first row, last executed row
@@ -132,7 +142,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   }
   // 3. remaining booleans
 #pragma unroll
-  for (int k = 0; k < 7; k++) boolean(I_BOOL_K + k, K[k]);
+  for (int k = 0; k < N_CLASS; k++) boolean(I_BOOL_K + k, K[k]);
   const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), ne = o.loc(C_NE), tk = o.loc(C_TK);
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
   boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk);
@@ -140,22 +150,22 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   {
     V sum = K[0];
 #pragma unroll
-    for (int k = 1; k < 7; k++) sum = o.add(sum, K[k]);
+    for (int k = 1; k < N_CLASS; k++) sum = o.add(sum, K[k]);
     o.push(I_ONE_CLASS, o.sub(sum, one));
   }
   {
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
     V ks = K[1];
 #pragma unroll
-    for (int k = 2; k <= K_OTH; k++) ks = o.add(ks, o.mulc(K[k], M((uint64_t)k)));
+    for (int k = 2; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = o.add(ks, o.mulc(K[k], M((uint64_t)k)));
     o.push(I_OPCLASS, deferred ? zero : o.sub(o.mul(o.sub(one, o.add(K[K_HALT], K[K_PAD])), o.loc(C_OPC)), ks));
   }
   // 5. selectors
   o.push(I_WR, deferred ? zero : o.sub(o.mul(w1, w1), w2));
-  o.push(I_WR + 1, o.mul(o.add(o.add(K[K_ADD], K[K_ADDI]), K[K_JAL]), o.sub(w1, fa)));
-  o.push(I_WR + 2, o.mul(o.add(o.add(K[K_BNE], K[K_HALT]), K[K_PAD]), w0));
+  o.push(I_WR + 1, o.mul(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), Kcmp), o.sub(w1, fa)));
+  o.push(I_WR + 2, o.mul(o.add(o.add(Kbr, K[K_HALT]), K[K_PAD]), w0));
   o.push(I_SELB, o.sub(b1, fb)); o.push(I_SELB + 1, o.sub(o.mul(b1, b1), b2));
-  o.push(I_SELC, o.sub(c1s, o.add(fc, o.mul(K[K_BNE], o.sub(fa, fc))))); o.push(I_SELC + 1, o.sub(o.mul(c1s, c1s), c2s));
+  o.push(I_SELC, o.sub(c1s, o.add(fc, o.mul(Kbr, o.sub(fa, fc))))); o.push(I_SELC + 1, o.sub(o.mul(c1s, c1s), c2s));
   // 6. operands
   V xb[3], xc[3];
 #pragma unroll
@@ -168,15 +178,31 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   const V im0 = o.add(o.sub(imm17, o.mulc(s, M(1u << 17))), o.mulc(s, M(1u << 20))), im1 = o.mulc(s, M(0xFFFFF));
   const V lo20 = o.sub(o.add(o.add(fb, o.mulc(fc, M(16))), o.mulc(fhi, M(256))), o.mulc(s, M(1u << 20)));
   const V c0s20 = o.mulc(c0, M(1u << 20)), c1s20 = o.mulc(c1, M(1u << 20));
-  o.push(I_VALUE, o.mul(K[K_ADD], o.add(o.sub(o.sub(y[0], xb[0]), xc[0]), c0s20)));
-  o.push(I_VALUE + 1, o.mul(K[K_ADD], o.add(o.sub(o.sub(o.sub(y[1], xb[1]), xc[1]), c0), c1s20)));
-  o.push(I_VALUE + 2, o.mul(K[K_ADD], y[2]));
-  o.push(I_VALUE + 3, o.mul(K[K_ADDI], o.add(o.sub(o.sub(y[0], xb[0]), im0), c0s20)));
-  o.push(I_VALUE + 4, o.mul(K[K_ADDI], o.add(o.sub(o.sub(o.sub(y[1], xb[1]), im1), c0), c1s20)));
+  // stated on z, the range-checked pair of limbs (13.); y = z on the rows that write it and on "other" rows (whose y stays in range)
+  o.push(I_VALUE, o.mul(K[K_ADD], o.add(o.sub(o.sub(z[0], xb[0]), xc[0]), c0s20)));
+  o.push(I_VALUE + 1, o.mul(K[K_ADD], o.add(o.sub(o.sub(o.sub(z[1], xb[1]), xc[1]), c0), c1s20)));
+  o.push(I_VALUE + 2, o.mul(o.add(K[K_ADD], K[K_SUB]), y[2]));
+  o.push(I_VALUE + 3, o.mul(K[K_ADDI], o.add(o.sub(o.sub(z[0], xb[0]), im0), c0s20)));
+  o.push(I_VALUE + 4, o.mul(K[K_ADDI], o.add(o.sub(o.sub(o.sub(z[1], xb[1]), im1), c0), c1s20)));
   o.push(I_VALUE + 5, o.mul(K[K_ADDI], y[2]));
-  o.push(I_VALUE + 6, o.mul(K[K_JAL], o.add(o.sub(o.sub(y[0], pc[0]), o.cst(M(4))), c0s20)));
-  o.push(I_VALUE + 7, o.mul(K[K_JAL], o.add(o.sub(o.sub(y[1], pc[1]), c0), c1s20)));
+  o.push(I_VALUE + 6, o.mul(K[K_JAL], o.add(o.sub(o.sub(z[0], pc[0]), o.cst(M(4))), c0s20)));
+  o.push(I_VALUE + 7, o.mul(K[K_JAL], o.add(o.sub(o.sub(z[1], pc[1]), c0), c1s20)));
   o.push(I_VALUE + 8, o.mul(K[K_JAL], o.sub(o.sub(y[2], pc[2]), c1)));
+  // 7b. differences with borrows: z = xb - xc mod 2^40 on SUB and SLTU / SGEU rows (execute.rs:65-77, :373-407), z = xc - xb on BLTU / BGEU
+  //     rows (:618-636): c1 = 1 exactly when the minuend is the smaller 40-bit value
+  {
+    const V Ks = o.add(K[K_SUB], K[K_SU]);
+    o.push(I_DIFF, o.mul(Ks, o.sub(o.add(o.sub(z[0], xb[0]), xc[0]), c0s20)));
+    o.push(I_DIFF + 1, o.mul(Ks, o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20)));
+    o.push(I_DIFF + 2, o.mul(K[K_BRU], o.sub(o.add(o.sub(z[0], xc[0]), xb[0]), c0s20)));
+    o.push(I_DIFF + 3, o.mul(K[K_BRU], o.sub(o.add(o.add(o.sub(z[1], xc[1]), xb[1]), c0), c1s20)));
+  }
+  const V flag = o.loc(C_FLAG), fx = o.loc(C_FX);
+  {
+    const V Ky = o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), K[K_OTH]);
+    o.push(I_WRITTEN, o.mul(Ky, o.sub(y[0], z[0]))); o.push(I_WRITTEN + 1, o.mul(Ky, o.sub(y[1], z[1])));
+    o.push(I_WRITTEN + 2, o.mul(Kcmp, o.sub(y[0], fx))); o.push(I_WRITTEN + 3, o.mul(Kcmp, y[1])); o.push(I_WRITTEN + 4, o.mul(Kcmp, y[2]));
+  }
   // 8. BNE operands differ?
   {
     V dot = zero;
@@ -188,13 +214,21 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
     }
     o.push(I_NE + 3, o.sub(ne, dot));
   }
-  o.push(I_TK, o.mul(K[K_BNE], o.sub(tk, ne)));
-  o.push(I_TK + 1, o.mul(o.sub(one, K[K_BNE]), tk));
+  // 8b. the family's comparison and its polarity: flag = [xb == xc] on BEQ / BNE / SEQ / SNE rows, the borrow c1 on the unsigned comparisons,
+  //     0 elsewhere; fx = flag XOR pol, pol = op - the family's even opcode (0 / 1: the ROM ties op to the class); a branch is taken iff fx
+  o.push(I_FLAG, o.sub(o.sub(flag, o.mul(o.add(K[K_BRE], K[K_SE]), o.sub(one, ne))), o.mul(o.add(K[K_BRU], K[K_SU]), c1)));
+  {
+    V pol = o.loc(C_OP);
+#pragma unroll
+    for (int k = 0; k < N_CLASS; k++) if (family_base(k)) pol = o.sub(pol, o.mulc(K[k], M(family_base(k))));
+    o.push(I_FX, o.add(o.sub(o.sub(fx, flag), pol), o.mulc(o.mul(pol, flag), M(2))));
+  }
+  o.push(I_TK, o.sub(tk, o.mul(Kbr, fx)));
   // 9. next pc
   const V four = o.cst(M(4)), dl0 = o.loc(C_DL0);
   o.push(I_DL0, o.sub(dl0, o.add(o.add(four, o.mul(tk, o.sub(im0, four))), o.mul(K[K_JAL], o.sub(lo20, four)))));
   o.push(I_SE, o.sub(se, o.mul(o.add(tk, K[K_JAL]), s)));
-  const V kc = o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_BNE], K[K_JAL])), hp = o.add(K[K_HALT], K[K_PAD]);
+  const V hp = o.add(K[K_HALT], K[K_PAD]), kc = o.sub(o.sub(one, K[K_OTH]), hp);     // kc: every class whose next pc the AIR derives
   o.push(I_PC, o.mul(o.mul(kc, o.add(o.sub(o.sub(npc[0], pc[0]), dl0), o.mulc(d0, M(1u << 20)))), is_trans));
   o.push(I_PC + 1, o.mul(o.mul(kc, o.add(o.sub(o.sub(o.sub(npc[1], pc[1]), o.mulc(se, M(0xFFFFF))), d0), o.mulc(d1, M(1u << 20)))), is_trans));
   o.push(I_PC + 2, o.mul(o.mul(kc, o.add(o.sub(o.sub(o.sub(npc[2], pc[2]), o.mulc(se, M(0xFFFFFF))), d1), o.mulc(d2, M(1u << 24)))), is_trans));
@@ -219,12 +253,12 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
       out[k] = o.add(lo, o.mulc(hi, M(11)));
     }
   };
-  // 13. the written value's low limbs are two 10-bit chunks each
+  // 13. the limbs of z are two 10-bit chunks each
   V R[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
-  o.push(I_CHUNK, o.sub(o.sub(y[0], R[0]), o.mulc(R[1], M(RC_TABLE))));
-  o.push(I_CHUNK + 1, o.sub(o.sub(y[1], R[2]), o.mulc(R[3], M(RC_TABLE))));
+  o.push(I_CHUNK, o.sub(o.sub(z[0], R[0]), o.mulc(R[1], M(RC_TABLE))));
+  o.push(I_CHUNK + 1, o.sub(o.sub(z[1], R[2]), o.mulc(R[3], M(RC_TABLE))));
   // 14. range helpers: H_i (alpha - R_i) = 1
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {

@@ -80,11 +80,12 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
   const uint32_t op = w & 0x7F, fa = (w >> 7) & 0xF, fb = (w >> 11) & 0xF, fc = (w >> 15) & 0xF, fhi = w >> 19, s = w >> 31;
   col(C_OP) = op; col(C_FA) = fa; col(C_FB) = fb; col(C_FC) = fc; col(C_FHI) = fhi; col(C_S) = s;
   int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
-  if (cls == K_OTH && !deferred) cls = op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : op == OP_BNE ? K_BNE : op == OP_JAL ? K_JAL : K_OTH;
+  if (cls == K_OTH && !deferred) cls = (int)opclass_of(op);
 #pragma unroll
-  for (int k = 0; k < 7; k++) col(C_K + k) = cls == k;
+  for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;
   col(C_OPC) = opclass_of(op);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
-  const uint32_t tc = cls == K_BNE ? fa : fc;
+  const bool branch = cls == K_BRE || cls == K_BRU;
+  const uint32_t tc = branch ? fa : fc;                                         // B-type words have rs1 in field a (rs2 in field b)
   uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
   bool first = true;
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL) wr = fa == (uint32_t)g;
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_SUB || cls == K_SE || cls == K_SU) wr = fa == (uint32_t)g;
     else if (cls == K_OTH) {                                     // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -119,14 +120,24 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
 #pragma unroll
   for (int l = 0; l < 3; l++) if (!ne && xb[l] != xc[l]) { ne = 1; iv[l] = f_inv(bb::sub(xb[l], xc[l])); }
   col(C_NE) = ne; col(C_IV) = iv[0]; col(C_IV + 1) = iv[1]; col(C_IV + 2) = iv[2];
-  const uint32_t tk = cls == K_BNE ? ne : 0;
+  // the 40-bit difference of the masked operands and its borrows: xb - xc (SUB, SLTU / SGEU), xc - xb (BLTU / BGEU: rs1 = field a)
+  uint32_t z[2] = {0, 0}, c0 = 0, c1 = 0;
+  if (cls == K_SUB || cls == K_SU || cls == K_BRU) {
+    const uint32_t* a = cls == K_BRU ? xc : xb; const uint32_t* b = cls == K_BRU ? xb : xc;
+    const int32_t v0 = (int32_t)a[0] - (int32_t)b[0]; c0 = v0 < 0; z[0] = (uint32_t)(v0 + (int32_t)(c0 << 20));
+    const int32_t v1 = (int32_t)a[1] - (int32_t)b[1] - (int32_t)c0; c1 = v1 < 0; z[1] = (uint32_t)(v1 + (int32_t)(c1 << 20));
+  }
+  const uint32_t flag = (cls == K_BRE || cls == K_SE) ? 1u - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0u;
+  const uint32_t pol = op - family_base(cls);                                   // 0 / 1 inside a family; the opcode itself (< 128) on other rows
+  const uint32_t fx = flag ? 1u - pol : pol;                                    // flag XOR pol where it matters (flag = 0 outside the families)
+  col(C_FLAG) = flag; col(C_FX) = fx;
+  const uint32_t tk = branch ? fx : 0;
   col(C_TK) = tk;
   const uint32_t imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFFu;
   const uint32_t lo20 = fb + 16 * fc + 256 * fhi - (s << 20);
   const uint32_t dl0 = cls == K_JAL ? lo20 : tk ? im0 : 4u;
   const uint32_t se = (tk || cls == K_JAL) ? s : 0u;
   col(C_DL0) = dl0; col(C_SE) = se;
-  uint32_t c0 = 0, c1 = 0;
   if (cls == K_ADD || cls == K_ADDI) {
     const uint32_t b0 = cls == K_ADD ? xc[0] : im0, b1 = cls == K_ADD ? xc[1] : im1;
     const uint64_t v0 = (uint64_t)xb[0] + b0; c0 = (uint32_t)(v0 >> 20); y[0] = (uint32_t)(v0 & 0xFFFFF);
@@ -135,12 +146,15 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     const uint64_t v0 = (uint64_t)pc[0] + 4; c0 = (uint32_t)(v0 >> 20); y[0] = (uint32_t)(v0 & 0xFFFFF);
     const uint64_t v1 = (uint64_t)pc[1] + c0; c1 = (uint32_t)(v1 >> 20); y[1] = (uint32_t)(v1 & 0xFFFFF);
     y[2] = pc[2] + c1;
-  }
+  } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; }
+  else if (cls == K_SE || cls == K_SU) y[0] = fx;
   col(C_Y) = y[0]; col(C_Y + 1) = y[1]; col(C_Y + 2) = y[2];
-  col(C_RC) = y[0] & (RC_TABLE - 1); col(C_RC + 1) = y[0] >> RC_BITS; col(C_RC + 2) = y[1] & (RC_TABLE - 1); col(C_RC + 3) = y[1] >> RC_BITS;   // 10-bit chunks, looked up
+  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_OTH) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
+  col(C_Z) = z[0]; col(C_Z + 1) = z[1];
+  col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (cls == K_ADD || cls == K_ADDI || cls == K_BNE || cls == K_JAL) {
+  if (cls != K_OTH && cls != K_HALT && cls != K_PAD) {
     const uint64_t v0 = (uint64_t)pc[0] + dl0; d0 = (uint32_t)(v0 >> 20);
     const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; d1 = (uint32_t)(v1 >> 20);
     const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; d2 = (uint32_t)(v2 >> 24);

@@ -11,7 +11,7 @@ using bb::E4;
 
 constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, WA = air::W_AUX, WT = air::W_ALL, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 5;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 6;
 
 #ifndef DEEP_WAVES
 #define DEEP_WAVES 4

@@ -213,6 +213,32 @@ def fib_endless_program() -> Program:
     ])
 
 
+def compare_loop_program() -> Program:
+    """An endless loop over every opcode family the AIR (v3) constrains besides the fib loop's: SUB (with and without a borrow out of
+    40 bits), SLTU / SGEU, SEQ / SNE, BEQ / BNE, BLTU / BGEU — every comparison comes out both ways and every branch is both taken and
+    not taken (a runs after a doubling b and passes a threshold; the first 600 cycles see all of it).  Run with max_cycles (halt = CycleLimit)."""
+    def r(op, rd, rs1, rs2): return encode(op, rd, rs1, rs2)
+    def b(op, rs1, rs2, off): return encode(op, rs1=rs1, rs2=rs2, imm=off)
+    O = Opcode
+    return Program.from_code([
+        addi(1, 0, 0), addi(2, 0, 7), addi(3, 0, 100), addi(10, 0, 1), addi(11, 0, 500),    # i, a, b, the previous iteration's (a < 500), the threshold
+        # L (pc 0x1014):
+        sub(4, 3, 2), sub(5, 2, 3),                              # b - a, a - b: one of the two wraps below zero (mod 2^40)
+        r(O.SLTU, 6, 2, 11), r(O.SGEU, 7, 2, 11),                # a < 500, a >= 500
+        r(O.SEQ, 8, 6, 10), r(O.SNE, 9, 6, 10),                  # same outcome as last time?
+        add(2, 2, 6), addi(2, 2, 45),                            # a += 45 + (a < 500)
+        b(O.BLTU, 2, 3, 8),                                      # a < b: skip the next instruction
+        add(3, 3, 3),                                            # b *= 2: a needs longer and longer to catch up
+        b(O.BGEU, 2, 11, 8),                                     # a >= 500: skip
+        sub(3, 3, 9),                                            # b -= (outcome changed)
+        b(O.BEQ, 6, 10, 8),                                      # outcome repeated: skip the count
+        addi(1, 1, 1),                                           # i += 1
+        addi(10, 6, 0),
+        b(O.BNE, 1, 0, -60),                                     # i != 0: back to L
+        jal(0, -64),                                             # i still 0: back to L as well
+    ])
+
+
 def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
     """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
     The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).

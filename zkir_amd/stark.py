@@ -15,7 +15,7 @@ from . import pipeline as pl
 from . import runtime as rt
 
 P = 2013265921
-W_MAIN = 152
+W_MAIN = 160
 W_AUX = 24                  # aux trace of the lookup argument (air.h): H0..H3, HR, S as four base columns each
 RC_TABLE = 1024
 HEADER_WORDS = 157
