@@ -256,7 +256,7 @@ def constraints_eval_states(loc, nxt, aloc, anxt, lk, is_first, is_last, is_tran
 
 
 def proof_layout(proof: np.ndarray) -> dict:
-    """Word offsets of the parts of a v5 proof that follow the header: program, multiplicities, roots, openings."""
+    """Word offsets of the parts of a v5 / v6 proof that follow the header: program, multiplicities, roots, openings."""
     blob_len = int(proof[HEADER_WORDS])
     at = HEADER_WORDS + 1
     blob_words = (blob_len + 1) // 2

@@ -152,7 +152,7 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 
 
 // ---------------------------------------------------------------------------------------------
-// main trace matrix of ZKIR-STARK v1: packed 372-byte reference rows -> W = 152 Baby Bear columns, padded to a
+// main trace matrix of ZKIR-STARK: packed 372-byte reference rows -> W = 160 Baby Bear columns, padded to a
 // power of two.  Column map:
 //   0 cycle | 1-3 pc limbs (20/20/24 bits) | 4 op7 | 5 fa (bits 10:7) | 6 fb (14:11) | 7 fc (18:15) | 8 fhi (31:19)
 //   9+3r+l register limbs (20-bit limbs when Normalized, 30-bit when Accumulated; l = 2: the bits above) | 57+r storage state

@@ -1,30 +1,36 @@
-// air.h — the AIR of ZKIR-STARK (v2: v1 + the lookup argument): column map of the 152-column main trace and of the
-// 24-column aux trace, and the constraint list, written
+// air.h — the AIR of ZKIR-STARK (v3: v2 + four comparison families and SUB): column map of the 160-column main trace and of
+// the 24-column aux trace, and the constraint list, written
 // ONCE for the two places of the product that evaluate it: the quotient kernel (stark_prove.inl; base-field values at every point
 // of the LDE coset, lazily accumulated) and the host verifier (verify.cpp; extension-field openings at zeta).  The oracle
 // (oracle/stark_oracle.cpp, constraints_sum) states the same list independently in naive arithmetic; constraint c carries the
 // coefficient alpha^c and the indices below are that list's order.
 //
 // What the constraints say (default VM mode; `deferred` public input = 0):
-//   * the class one-hot follows the opcode: ADD / ADDI / BNE / JAL rows cannot hide as "other" (non-membership witness t5);
-//   * wr = one-hot(rd) on ADD / ADDI / JAL rows, empty on BNE / halt / padding rows, at most one register otherwise;
-//     selb = one-hot(field b), selc = one-hot(field c) (of field a on BNE rows), xb / xc = the selected registers' limbs;
-//   * y = xb + xc, xb + sext(imm17) (mod 2^40, two 20-bit limbs with boolean carries), or pc + 4 — the register selected by wr shows
-//     y in the next row, every other register keeps its limbs and storage state (execute.rs:43-63, :185-197, :639-647);
-//   * pc' = pc + 4 | pc + sext(imm17) if the BNE operands differ in any limb | pc + sext(off21) for JAL, mod 2^64 (state.rs:131-133);
+//   * an executed row runs as the class of ITS PROGRAM WORD (opclass, part of the instruction-ROM tuple): ADD, ADDI, SUB, JAL and the
+//     families (pairs of opcodes that differ in the polarity of one comparison) BEQ / BNE, BLTU / BGEU, SEQ / SNE, SLTU / SGEU — 12 of the
+//     50 opcodes; everything else is class "other";
+//   * wr = one-hot(rd) on rows that write (ADD / ADDI / SUB / JAL / SEQ.. / SLTU..), empty on branch / halt / padding rows, at most one
+//     register otherwise; selb = one-hot(field b), selc = one-hot(field c) (of field a on B-type rows), xb / xc = the selected limbs;
+//   * z = the row's RANGE-CHECKED pair of 20-bit limbs: xb + xc, xb + sext(imm17), pc + 4 (mod 2^40, boolean carries), xb - xc on SUB and
+//     SLTU / SGEU rows, xc - xb on BLTU / BGEU rows (boolean borrows; the borrow out of 40 bits IS the unsigned comparison,
+//     execute.rs:373-407, :618-636); y = the value written: z on arithmetic rows, the comparison (0 / 1) on SEQ.. / SLTU.. rows — the
+//     register selected by wr shows y in the next row, every other register keeps its limbs and storage state;
+//   * flag = [xb == xc] over all three limbs (raw 64-bit compare, execute.rs:409-431, :578-596) on the equality families, the borrow on
+//     the unsigned ones; fx = flag XOR (op - the family's even opcode); a branch is taken iff fx;
+//   * pc' = pc + 4 | pc + sext(imm17) if taken | pc + sext(off21) for JAL, mod 2^64 (state.rs:131-133);
 //   * cycle counts up; row 0 is in the public FIRST state and row n_real - 1 in the public LAST state (for a whole run the verifier
 //     requires the first state to be the VM's initial one: cycle 0, entry point, zero registers); the row count is public: row
 //     n_real - 1 is the halt row, only padding follows it, padding keeps everything.
-// AIR v2 adds ONE LogUp lookup argument used twice (aux trace: six extension-field columns committed after the lookup challenges):
+// ONE LogUp lookup argument used twice (AIR v2; aux trace: six extension-field columns committed after the lookup challenges):
 //   * instruction ROM: the tuple (pc limbs, op, fa, fb, fc, fhi, s, opclass) of EVERY row is a row of the program's code table — the
 //     verifier builds that table from the program carried in the proof (its digest is the public program_digest), so the instruction
 //     word at pc is the program's (vm.rs:362-379), its fields are in range, and the class an executed row runs as is the class of that
 //     word (opclass), not a free witness;
-//   * ranges: the two low limbs of the written value y are two 10-bit chunks each, every chunk a row of the 2^10 table
-//     (range_check.rs:175-192, config.rs:78-80), which makes the boolean carries of ADD / ADDI / JAL the only solution;
+//   * ranges: the limbs of z are two 10-bit chunks each, every chunk a row of the 2^10 table (range_check.rs:175-192, config.rs:78-80),
+//     which makes the boolean carries / borrows the only solution;
 //   the prover sends the multiplicities of both tables BEFORE the challenges (alpha, lambda) are drawn; the verifier computes the table
 //   side T = sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u) itself; the running-sum column closes over the cycle of N rows.
-// Not constrained yet: the other 46 opcodes' values (class "other"), memory consistency, deferred-mode arithmetic
+// Not constrained yet: the other 38 opcodes' values (class "other"), memory consistency, deferred-mode arithmetic
 // (deferred = 1 relaxes the write constraints to "unwritten registers keep their value").
 #pragma once
 #include "babybear.h"

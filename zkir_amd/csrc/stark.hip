@@ -4,7 +4,7 @@
 // kernel here is checked bit-for-bit against it.  Stage A (this part): main-trace field columns, Poseidon2-12 Merkle commitment
 // (the coset LDE between them lives in ntt.hip).
 //
-//   main_trace_kernel   372 B/row SoA trace -> the 152 Baby Bear columns of the AIR (air.h: limbs of pc / instruction fields /
+//   main_trace_kernel   372 B/row SoA trace -> the 160 Baby Bear columns of the AIR (air.h: limbs of pc / instruction fields /
 //                       registers, storage state, write and operand selectors, operands, result, opcode classes, range chunks, carries),
 //                       padded to a power of two, written in the B8 layout (blocks of 8 columns, [rows][8]).  HBM-bound: ~170 B
 //                       read (values + states of the row and the next) + 608 B written per row.
@@ -58,8 +58,8 @@ __device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[
 
 // One thread per (padded) row; every column write is coalesced across lanes.  Rows >= n_real are padding: they repeat the last
 // executed row's state with class "pad" and keep counting cycles.  Mirrors so::main_trace of the oracle word for word.
-// A lane builds the 152 words of ITS row in registers (every column index below is a compile-time constant once the register loop
-// is unrolled) and stores them as 38 16-byte vectors; the two halves of a 32-byte block position are written back to back, so the
+// A lane builds the 160 words of ITS row in registers (every column index below is a compile-time constant once the register loop
+// is unrolled) and stores them as 40 16-byte vectors; the two halves of a 32-byte block position are written back to back, so the
 // L2 merges them into full sectors.
 #ifndef MT_WAVES
 #define MT_WAVES 3

@@ -22,7 +22,7 @@ HEADER_WORDS = 157
 
 
 def proof_layout(proof) -> dict:
-    """Word offsets inside a format-v5 proof: header | program (byte length, 16-bit halfwords) | ROM multiplicities | range multiplicities |
+    """Word offsets inside a format-v6 proof (same layout as v5): header | program (byte length, 16-bit halfwords) | ROM multiplicities | range multiplicities |
     trace root | aux root | quotient root | openings ..."""
     blob_len = int(proof[HEADER_WORDS])
     at = HEADER_WORDS + 1
