@@ -355,7 +355,7 @@ def _cpu_baseline(blob, k, commit):
         threads = max(1, min(cpu["logical_cores"] or 1, 64))
         rows = oracle.run(blob, max_cycles=1 << k, enable_execution_trace=True).rows
         t0 = time.perf_counter()
-        m = so.main_trace(rows, so.public_inputs(len(rows), blob))
+        m = so.to_committed(so.main_trace(rows, so.public_inputs(len(rows), blob)))      # the columns the commit stage works on (default mode: 144)
         t_main = time.perf_counter() - t0
         del rows
         from bench_cpu import api as cpu_port

@@ -8,7 +8,9 @@ import numpy as np
 from . import api
 
 P = 2013265921
-W_MAIN = 160
+W_MAIN = 160                # LOGICAL main-trace columns (what main_trace() returns and the constraints read)
+W_COMMITTED = 144           # columns of the committed matrix in the default VM mode (R0's limbs and the storage states are identically zero there)
+W_COMMITTED_DEFERRED = 160  # deferred mode: only R0's limbs and state are left out
 W_AUX = 24                  # aux trace of the lookup argument: H0..H3, HR, S as four base columns each
 RC_TABLE = 1024
 N_LK = 52                   # lookup parameters: alpha (4), lambda^0..10 (44), T / N (4)
@@ -32,6 +34,8 @@ def lib():
                            ("so_commit_trace", [V, PP, I, V, V])]:
             f = getattr(L, name); f.restype = None; f.argtypes = args
         L.so_main_trace_width.restype = I
+        L.so_committed_width.restype = I; L.so_committed_width.argtypes = [I]
+        L.so_to_committed.restype = None; L.so_to_committed.argtypes = [V, SZ, I, V]
         L.so_padded_log_n.restype = I; L.so_padded_log_n.argtypes = [C.c_uint64]
         L.so_num_constraints.restype = I
         L.so_constraints_eval.restype = I; L.so_constraints_eval.argtypes = [V, V, V, V, V, U32, U32, U32, PP, V, V]
@@ -164,6 +168,18 @@ def main_trace(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
     return out
 
 
+def committed_width(deferred=False) -> int:
+    return W_COMMITTED_DEFERRED if deferred else W_COMMITTED
+
+
+def to_committed(matrix: np.ndarray, deferred=False) -> np.ndarray:
+    """Logical main-trace matrix [W_MAIN][n] -> the committed one [committed_width][n] (so::to_physical)."""
+    m = _u32(matrix)
+    out = np.zeros((committed_width(deferred), m.shape[1]), np.uint32)
+    lib().so_to_committed(m.ctypes.data, m.shape[1], int(bool(deferred)), out.ctypes.data)
+    return out
+
+
 def lookup_setup(matrix: np.ndarray, pub: PublicC, alpha_l, lam):
     """The lookup side of a main-trace matrix for GIVEN challenges: (aux trace [W_AUX][N], lk[52] = alpha, lambda powers, T / N,
     ROM multiplicities, range multiplicities)."""
@@ -198,7 +214,7 @@ def commit_trace(rows: np.ndarray, log_blowup=1, want_lde=False, pub: PublicC | 
     pub = _pub(rows, pub)
     n = 1 << padded_log_n(pub.n_real)
     root = np.zeros(4, np.uint32)
-    L = np.zeros((W_MAIN, n << log_blowup), np.uint32) if want_lde else None
+    L = np.zeros((committed_width(pub.deferred), n << log_blowup), np.uint32) if want_lde else None
     lib().so_commit_trace(rows.ctypes.data, C.byref(pub), log_blowup, root.ctypes.data, L.ctypes.data if want_lde else None)
     return (root, L) if want_lde else root
 
@@ -256,7 +272,8 @@ def constraints_eval_states(loc, nxt, aloc, anxt, lk, is_first, is_last, is_tran
 
 
 def proof_layout(proof: np.ndarray) -> dict:
-    """Word offsets of the parts of a v5 / v6 proof that follow the header: program, multiplicities, roots, openings."""
+    """Word offsets of the parts of a proof (format v5 on) that follow the header: program, multiplicities, roots, openings."""
+    wt = int(proof[3]) + W_AUX                                   # header word 3 = committed main-trace columns
     blob_len = int(proof[HEADER_WORDS])
     at = HEADER_WORDS + 1
     blob_words = (blob_len + 1) // 2
@@ -271,7 +288,7 @@ def proof_layout(proof: np.ndarray) -> dict:
     rc_mult = rom_mult + n_rom
     troot = rc_mult + RC_TABLE
     return {"blob_len": blob_len, "blob": bytes(blob), "blob_at": at, "n_rom": n_rom, "rom_mult": rom_mult, "rc_mult": rc_mult, "trace_root": troot, "aux_root": troot + 4,
-            "quotient_root": troot + 8, "openings": troot + 12, "t_z": troot + 12, "t_zw": troot + 12 + 4 * (W_MAIN + W_AUX), "q_z": troot + 12 + 8 * (W_MAIN + W_AUX)}
+            "quotient_root": troot + 8, "openings": troot + 12, "t_z": troot + 12, "t_zw": troot + 12 + 4 * wt, "q_z": troot + 12 + 8 * wt}
 
 
 STATE_COLS = [0, 1, 2, 3] + list(range(9, 73))      # cycle, pc limbs, register limbs, storage states (so::state_col)

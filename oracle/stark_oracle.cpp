@@ -183,7 +183,26 @@ enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8,
 // coordinate by coordinate: H0..H3 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
 // S = running sum of (H0 + H1 + H2 + H3 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
 // carried in the proof and the multiplicities the prover sends before alpha is drawn.
-static const int W_AUX = 24, W_ALL = W_MAIN + W_AUX;
+// LOGICAL vs COMMITTED columns (proof format v7).  The map above is the LOGICAL main trace: what the AIR talks about.  Some logical columns
+// are identically zero by the AIR's own constraints and are not committed: the three limbs of R0 (hard-wired zero, state.rs:77-85) and its
+// storage state, and — in the default VM mode, where no register is ever Accumulated (the deferred model is off, vm.rs:47) — all 16 storage
+// states.  The committed ("physical") matrix is the logical one with those columns removed, zero-padded to whole blocks of 8:
+// 144 columns in default mode (141 + 3), 160 in deferred mode (156 + 4).  A removed column reads as the constant 0 wherever the
+// constraints, the boundary states or the lookups mention it.
+static const int W_AUX = 24;
+static inline bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
+static inline int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a non-virtual column
+static inline int phys_width(bool deferred) { return deferred ? 160 : 144; }
+// logical [W_MAIN][N] -> committed [phys_width][N]
+static void to_physical(const std::vector<F>& M, size_t N, bool deferred, std::vector<F>& out) {
+  out.assign((size_t)phys_width(deferred) * N, 0);
+  for (int c = 0; c < W_MAIN; c++) if (!is_virtual(c, deferred)) memcpy(&out[(size_t)phys_col(c, deferred) * N], &M[(size_t)c * N], N * sizeof(F));
+}
+// a row of committed values (base field or extension) -> the logical row the constraints read
+template <class V>
+static void to_logical_row(const V* phys, bool deferred, const V& zero, V* logical) {
+  for (int c = 0; c < W_MAIN; c++) logical[c] = is_virtual(c, deferred) ? zero : phys[phys_col(c, deferred)];
+}
 enum { A_H = 0, A_HR = 16, A_S = 20 };
 static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the reference's range-check table: 2^(limb_bits/2) entries (range_check.rs:29, config.rs:78-80)
 static const int N_TUPLE = 10;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass
@@ -449,7 +468,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 6;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns)
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 7;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
@@ -686,7 +705,7 @@ static E horner_base(const std::vector<F>& coeffs, const E& z) { E acc = e_from(
 // header words 2..20 = everything both sides know before the first commitment; observed by the transcript in this order
 static void header_words(int log_n, const Public& pub, std::vector<uint32_t>& w) {
   w.clear();
-  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(W_MAIN); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL); w.push_back(POW_BITS);
+  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(phys_width(pub.deferred != 0)); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL); w.push_back(POW_BITS);
   w.push_back((uint32_t)(pub.n_real & 0x3FFFFFFF)); w.push_back((uint32_t)(pub.n_real >> 30)); w.push_back(pub.deferred ? 1u : 0u);
   w.push_back((uint32_t)(pub.entry & 0xFFFFF)); w.push_back((uint32_t)((pub.entry >> 20) & 0xFFFFF)); w.push_back((uint32_t)(pub.entry >> 40));
   for (int i = 0; i < 4; i++) w.push_back(pub.prog[i]);
@@ -701,7 +720,7 @@ static void initial_state(uint64_t entry, F st[N_STATE]) {
 }
 
 struct ProverTrace {     // everything the oracle keeps for inspection by tests
-  std::vector<F> M, L, Qc;            // [W][N], [W][2N], [4][2N]
+  std::vector<F> M, Mp, L, Qc;        // logical [W_MAIN][N], committed [Wm][N], its LDE [Wm][2N], [4][2N]
   std::vector<F> A, AL;               // aux trace [W_AUX][N] and its LDE [W_AUX][2N]
   std::vector<F> rom_mult, rc_mult;
   LookupParams lp;
@@ -716,9 +735,12 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   Public pub = pub_in;
   const int log_n = padded_log_n(pub.n_real);
   const size_t N = (size_t)1 << log_n, N2 = 2 * N;
-  const int Wm = W_MAIN;
-  if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wm * N);
+  const bool Dm = pub.deferred != 0;
+  const int Wm = phys_width(Dm);
+  if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)W_MAIN * N);     // LOGICAL; whatever it holds in uncommitted columns is dropped
   else main_trace(rows, pub.n_real, pub, pt.M);
+  for (int c = 0; c < W_MAIN; c++) if (is_virtual(c, Dm)) std::fill(pt.M.begin() + (size_t)c * N, pt.M.begin() + (size_t)(c + 1) * N, 0);
+  to_physical(pt.M, N, Dm, pt.Mp);
   for (int i = 0; i < N_STATE; i++) {                                     // boundary states: rows 0 and n_real - 1 of the matrix being proven
     pub.first[i] = pt.M[(size_t)state_col(i) * N];
     pub.last[i] = pt.M[(size_t)state_col(i) * N + (pub.n_real - 1)];
@@ -726,7 +748,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   pt.L.assign((size_t)Wm * N2, 0);
   std::vector<std::vector<F>> coeffs(Wm);
   for (int k = 0; k < Wm; k++) {
-    std::vector<F> e(pt.M.begin() + (size_t)k * N, pt.M.begin() + (size_t)(k + 1) * N), o;
+    std::vector<F> e(pt.Mp.begin() + (size_t)k * N, pt.Mp.begin() + (size_t)(k + 1) * N), o;
     lde(e, 1, coeffs[k], o);
     memcpy(&pt.L[(size_t)k * N2], o.data(), N2 * 4);
   }
@@ -774,9 +796,10 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   pt.Qc.assign(4 * N2, 0);
   {
     F x = GEN;
-    std::vector<E> loc(Wm), nxt(Wm), aloc(W_AUX), anxt(W_AUX);
+    std::vector<E> ploc(Wm), pnxt(Wm), loc(W_MAIN), nxt(W_MAIN), aloc(W_AUX), anxt(W_AUX);
     for (size_t j = 0; j < N2; j++) {
-      for (int k = 0; k < Wm; k++) { loc[k] = e_from(pt.L[(size_t)k * N2 + j]); nxt[k] = e_from(pt.L[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      for (int k = 0; k < Wm; k++) { ploc[k] = e_from(pt.L[(size_t)k * N2 + j]); pnxt[k] = e_from(pt.L[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      to_logical_row(ploc.data(), Dm, e_from(0), loc.data()); to_logical_row(pnxt.data(), Dm, e_from(0), nxt.data());
       for (int k = 0; k < W_AUX; k++) { aloc[k] = e_from(pt.AL[(size_t)k * N2 + j]); anxt[k] = e_from(pt.AL[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
       const F zh = fsub((j & 1) ? fneg(gN) : gN, 1);                      // x^N - 1, x^N = g^N (-1)^j
       const F inv_zh = finv(zh);
@@ -796,7 +819,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
 
   // ---- openings (oracle: Horner on coefficient vectors) ----
   // column order everywhere below (openings, gamma powers): main columns, then aux columns = W_ALL "trace" columns
-  const int Wt = W_ALL;
+  const int Wt = Wm + W_AUX;
   std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
   for (int k = 0; k < Wm; k++) { t_z[k] = horner_base(coeffs[k], pt.zeta); t_zw[k] = horner_base(coeffs[k], zeta_w); }
   for (int k = 0; k < W_AUX; k++) { t_z[Wm + k] = horner_base(acoeffs[k], pt.zeta); t_zw[Wm + k] = horner_base(acoeffs[k], zeta_w); }
@@ -904,9 +927,10 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   auto need = [&](size_t k) { return p + k <= len; };
   if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
   const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5];
-  if (Wm != W_MAIN || nq != NUM_QUERIES || log_final != LOG_FINAL || w[6] != (uint32_t)POW_BITS || log_n < LOG_FINAL || log_n > 26) return 2;
+  if (nq != NUM_QUERIES || log_final != LOG_FINAL || w[6] != (uint32_t)POW_BITS || log_n < LOG_FINAL || log_n > 26) return 2;
   Public pub;
-  if (w[7] >= (1u << 30) || w[9] > 1 || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
+  if (w[9] > 1 || Wm != phys_width(w[9] != 0)) return 2;                 // the committed width is the mode's
+  if (w[7] >= (1u << 30) || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
   pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
   pub.entry = (uint64_t)w[10] | ((uint64_t)w[11] << 20) | ((uint64_t)w[12] << 40);
   memcpy(pub.prog, w + 13, 16); memcpy(pub.io, w + 17, 16);
@@ -940,7 +964,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   if (!need(12)) return 4;
   const F* troot = w + p; p += 4; const F* aroot = w + p; p += 4; const F* qroot = w + p; p += 4;
   auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
-  const int Wt = W_ALL;
+  const int Wt = Wm + W_AUX;
   if (!need((size_t)(2 * Wt + 4) * 4)) return 4;
   std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
   for (int k = 0; k < Wt; k++) { t_z[k] = get_e(p); p += 4; }
@@ -991,7 +1015,9 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     const E is_first = emul(zh, einv(esub(zeta, e_from(1))));
     const E is_last = emul(zh, einv(esub(zeta, e_from(fpow(wn, pub.n_real - 1)))));
     const E is_trans = esub(zeta, e_from(finv(wn)));
-    E lhs; constraints_sum(t_z.data(), t_zw.data(), t_z.data() + Wm, t_zw.data() + Wm, is_first, is_last, is_trans, pub, lp, ap.data(), lhs);
+    std::vector<E> loc(W_MAIN), nxt(W_MAIN);                              // the logical rows at zeta and zeta w: uncommitted columns are the constant 0
+    to_logical_row(t_z.data(), pub.deferred != 0, e_from(0), loc.data()); to_logical_row(t_zw.data(), pub.deferred != 0, e_from(0), nxt.data());
+    E lhs; constraints_sum(loc.data(), nxt.data(), t_z.data() + Wm, t_zw.data() + Wm, is_first, is_last, is_trans, pub, lp, ap.data(), lhs);
     E qz = e_from(0);
     for (int i = 0; i < 4; i++) { E basis = e_from(0); basis.c[i] = 1; qz = eadd(qz, emul(basis, q_z[i])); }
     if (!eeq(lhs, emul(qz, zh))) return 10;
@@ -1144,7 +1170,14 @@ void so_lde(const uint32_t* evals, size_t n, int log_blowup, uint32_t* coeffs, u
   if (coeffs) memcpy(coeffs, c.data(), n * 4);
   memcpy(out, o.data(), o.size() * 4);
 }
-int so_main_trace_width() { return so::W_MAIN; }
+int so_main_trace_width() { return so::W_MAIN; }                                   // LOGICAL columns (what so_main_trace writes and the constraints read)
+int so_committed_width(int deferred) { return so::phys_width(deferred != 0); }     // columns of the committed matrix: 144 (default mode) / 160 (deferred)
+// logical [W_MAIN][n] -> committed [so_committed_width][n]
+void so_to_committed(const uint32_t* logical, size_t n, int deferred, uint32_t* out) {
+  std::vector<so::F> M(logical, logical + (size_t)so::W_MAIN * n), o;
+  so::to_physical(M, n, deferred != 0, o);
+  memcpy(out, o.data(), o.size() * 4);
+}
 int so_padded_log_n(uint64_t n_real) { return so::padded_log_n(n_real); }
 int so_num_constraints() { return so::num_constraints(); }
 void so_main_trace(const void* packed_rows, const so_public* pub, uint32_t* out /* [W_MAIN][N] */) {
@@ -1227,18 +1260,20 @@ void so_merkle(const uint32_t* mat, int width, size_t n, uint32_t* root4, uint32
   memcpy(root4, t.layers.back().data(), 16);
   if (all_layers) { size_t off = 0; for (auto& l : t.layers) { memcpy(all_layers + off, l.data(), l.size() * 4); off += l.size(); } }
 }
-// commit = main_trace -> per-column LDE -> Merkle over the LDE rows; returns root, optionally the LDE matrix [W][N<<lb]
+// commit = main_trace -> committed columns -> per-column LDE -> Merkle over the LDE rows; returns root, optionally the LDE matrix [Wm][N<<lb]
 void so_commit_trace(const void* packed_rows, const so_public* pub, int log_blowup, uint32_t* root4, uint32_t* lde_out /* nullable */) {
   std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m);
   const size_t n = (size_t)1 << so::padded_log_n(pub->n_real);
   size_t big = n << log_blowup;
-  std::vector<so::F> L((size_t)so::W_MAIN * big);
-  for (int k = 0; k < so::W_MAIN; k++) {
-    std::vector<so::F> e(m.begin() + (size_t)k * n, m.begin() + (size_t)(k + 1) * n), c, o;
+  const int Wm = so::phys_width(pub->deferred != 0);
+  std::vector<so::F> mp; so::to_physical(m, n, pub->deferred != 0, mp);
+  std::vector<so::F> L((size_t)Wm * big);
+  for (int k = 0; k < Wm; k++) {
+    std::vector<so::F> e(mp.begin() + (size_t)k * n, mp.begin() + (size_t)(k + 1) * n), c, o;
     so::lde(e, log_blowup, c, o);
     memcpy(&L[(size_t)k * big], o.data(), big * 4);
   }
-  so::Merkle t; so::merkle_build(L, so::W_MAIN, big, t);
+  so::Merkle t; so::merkle_build(L, Wm, big, t);
   memcpy(root4, t.layers.back().data(), 16);
   if (lde_out) memcpy(lde_out, L.data(), L.size() * 4);
 }

@@ -10,7 +10,7 @@ n = 1 << k
 log = rt.interpret(spec.fib_endless_program().to_bytes(), [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
 ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); fa = pl.trace_fill_args(ddl, tr)
 ctx = stark.StarkContext(k)
-W = stark.W_MAIN
+W = int(rt.lib().zkir_main_trace_width())          # the committed width of the library that is loaded (variants differ)
 m = torch.empty((W // 8, n, 8), dtype=torch.int32, device="cuda")
 L = torch.empty((W // 8, 2 * n, 8), dtype=torch.int32, device="cuda")
 tree = torch.empty(4 * (4 * n - 1), dtype=torch.int32, device="cuda")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Time the commit stages with several builds of the library on ONE box (box-to-box spread is ~3 %): scripts/variants_time.sh <tag> <variant> ...
-# (variants: zkir_amd/variants/libzkir_amd_<variant>.so, made by zkir_amd.build.build_variant; "default" = the in-tree build)
+# (variants: zkir_amd/variants/libzkir_amd_<variant>.so, made by zkir_amd.build.build_variant; "default" = the in-tree build;
+#  W=<columns> in the environment overrides the matrix width the script commits, for builds with another main-trace width)
 R=${GRAFT_REPO_ROOT:-$(dirname $(dirname $(readlink -f $0)))}; TAG=$1; shift
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 for rep in 1 2; do for v in "$@"; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v3, proof format v6).
+"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v3, proof format v7).
 
 The reference has no prover, so nothing external can pin these stages; this file FREEZES them — it pins nothing:
 the values are produced by this repository's own oracle, so they guard against DRIFT only: the
@@ -80,8 +80,8 @@ def golden(case):
 
 
 if __name__ == "__main__":
-    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v3, proof format v6; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
-           "proof_version": 6, "main_trace_width": so.W_MAIN, "num_constraints": so.lib().so_num_constraints(),
+    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v3, proof format v7; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
+           "proof_version": 7, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
            "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
            "cases": [golden(c) for c in CASES]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")

@@ -48,7 +48,7 @@ def test_lde_matches_oracle(log_n):
     ctx.close()
 
 
-@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 160), (10, 17)])
+@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 144), (8, 160), (10, 17)])
 def test_merkle_matches_oracle(log_n, width):
     import torch
     from zkir_amd import stark
@@ -110,20 +110,24 @@ def _case(name, n):
 @pytest.mark.parametrize("name,n", [("fib", 64), ("fib", 1024), ("fib", 4096), ("fib", 1000), ("fib", 5), ("sha", 512), ("sha", 700), ("deferred", 256),
                                     ("fib30", None), ("exit42", None), ("cmp", 600), ("cmp", 5000), ("cmp_deferred", 300)])
 def test_main_trace_and_commit_match_oracle(name, n):
-    """All 160 columns of the padded main trace, the LDE and the commitment root, for power-of-two and ragged row counts and for
-    programs that halt on their own (Exit / padding rows)."""
+    """All committed columns of the padded main trace (144 in default mode, 160 deferred: the oracle's 160 logical columns minus the ones
+    that are identically zero), the LDE and the commitment root, for power-of-two and ragged row counts and for programs that halt on
+    their own (Exit / padding rows)."""
     from zkir_amd import stark
     blob, log, tr, rows, opub, pub = _case(name, n)
     assert pub.n_real == len(rows) == opub.n_real
-    want_m = so.main_trace(rows, opub)
-    got_m = stark.from_b8(stark.main_trace(tr, deferred=bool(opub.deferred)), stark.W_MAIN).cpu().numpy().view(np.uint32)
+    deferred = bool(opub.deferred)
+    wm = stark.main_width(deferred)
+    assert wm == so.committed_width(deferred) == rt.lib().zkir_main_trace_width_for(int(deferred)) and stark.W_MAIN == rt.lib().zkir_main_trace_width()
+    want_m = so.to_committed(so.main_trace(rows, opub), deferred)
+    got_m = stark.from_b8(stark.main_trace(tr, deferred=deferred), wm).cpu().numpy().view(np.uint32)
     assert got_m.shape == want_m.shape
     for k in range(want_m.shape[0]):
         assert np.array_equal(got_m[k], want_m[k]), f"main-trace column {k}"
     ctx = stark.StarkContext(stark.padded_log_n(len(rows)))
     root, L, tree = stark.commit_trace(ctx, tr, deferred=bool(opub.deferred))
     want_root, want_L = so.commit_trace(rows, 1, want_lde=True, pub=opub)
-    assert np.array_equal(stark.from_b8(L, stark.W_MAIN).cpu().numpy().view(np.uint32), want_L)
+    assert np.array_equal(stark.from_b8(L, wm).cpu().numpy().view(np.uint32), want_L)
     assert np.array_equal(root, want_root)
     ctx.close(); log.close()
 
@@ -310,7 +314,7 @@ def test_proof_large_verifies(log_n):
     ctx = stark.StarkContext(log_n)
     proof = stark.prove(ctx, tr, pub)
     assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0
-    assert proof[2] == log_n and proof[3] == 160 and proof[7] == (1 << log_n) - 1
+    assert proof[2] == log_n and proof[3] == 144 and proof[7] == (1 << log_n) - 1
     ctx.close(); log.close()
 
 
@@ -363,7 +367,7 @@ def test_full_size_2p20_properties():
     root, L, tree = stark.commit_trace(ctx, tr)
     Lh, t = stark.from_b8(L, stark.W_MAIN).cpu().numpy().view(np.uint32), tree.cpu().numpy().view(np.uint32)
     rng = np.random.default_rng(20)
-    for col in (0, 1, 9, 21, 76, 124, 130):                         # cycle, pc limb, r0 limb (all zero), r4 limb, a write selector, y limb, a class flag
+    for col in (0, 1, 9, 18, 57, 105, 111):                         # committed columns: cycle, pc limb, r1 limb, r4 limb, a write selector, y limb, a class flag
         z = int(rng.integers(2, P))
         assert _bary_eval(m[col], log_n, 1, z) == _bary_eval(Lh[col], log_n + 1, 31, z), col
     for j in rng.integers(0, 2 * n, 6):

@@ -192,10 +192,26 @@ def test_main_trace_columns_and_commit():
     # padding rows repeat the state of the last executed row
     assert (m[C_LIMB:C_STATE + 16, n:] == m[C_LIMB:C_STATE + 16, n - 1:n]).all() and (m[C_PC:C_PC + 3, n:] == m[C_PC:C_PC + 3, n - 1:n]).all()
     root, L = so.commit_trace(rows, 1, want_lde=True, pub=pub)
-    assert L.shape == (160, 128)
+    # what is committed: the logical matrix minus the columns that are identically zero (R0's limbs, the 16 storage states of the default
+    # mode), packed and zero-padded to whole blocks of 8: 141 + 3 columns
+    kept = [c for c in range(160) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16)]
+    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 141
+    mc = so.to_committed(m)
+    assert mc.shape == (144, 64) and np.array_equal(mc[:141], m[kept]) and not mc[141:].any()
+    assert L.shape == (144, 128)
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
+    coeffs, col = so.lde(m[C_WR], 1)
+    assert np.array_equal(col, L[C_WR - 19])
+    # deferred mode keeps the storage states (only R0's limbs and state are left out): 156 + 4 columns
+    rows_d = oracle.run(blob, max_cycles=n, enable_execution_trace=True, enable_deferred_model=True).rows
+    pub_d = so.public_inputs(n, blob, deferred=True)
+    m_d = so.main_trace(rows_d, pub_d)
+    kept_d = [c for c in range(160) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
+    mc_d = so.to_committed(m_d, deferred=True)
+    assert mc_d.shape == (160, 64) and np.array_equal(mc_d[:156], m_d[kept_d]) and not mc_d[156:].any() and m_d[C_STATE + 1:C_STATE + 16].any()
+    assert so.commit_trace(rows_d, 1, want_lde=True, pub=pub_d)[1].shape == (160, 128)
 
 
 def test_main_trace_of_the_opcode_families():
@@ -251,7 +267,7 @@ def test_cpu_commit_port_matches_the_oracle():
         blob = prog.to_bytes()
         rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
         pub = so.public_inputs(len(rows), blob)
-        root, t_lde, t_merkle = cpu_port.commit_port(so.main_trace(rows, pub), 3)
+        root, t_lde, t_merkle = cpu_port.commit_port(so.to_committed(so.main_trace(rows, pub)), 3)
         assert np.array_equal(root, so.commit_trace(rows, 1, pub=pub)) and t_lde > 0 and t_merkle > 0
 
 
@@ -311,7 +327,8 @@ def _fri_schedule(log_n, log_final=3, log_arity=3):
 
 HDR = 21 + 2 * 68   # header words: parameters, public inputs, the two boundary states; then (format v5) the program and the lookup multiplicities
 NQ = 50
-WA, WT = so.W_AUX, so.W_MAIN + so.W_AUX
+WA, WC = so.W_AUX, so.W_COMMITTED                                # aux columns; committed main columns of a default-mode proof
+WT = WC + WA
 
 
 @pytest.mark.parametrize("n,prog", [(8, "fib"), (16, "fib"), (5, "fib"), (100, "fib"), (256, "fib"), (300, "sha"), (1024, "fib"), (600, "cmp")])
@@ -324,12 +341,12 @@ def test_prove_verify_roundtrip(n, prog):
     blob = _prog(prog).to_bytes()
     assert lay["blob"] == blob and lay["n_rom"] == int.from_bytes(blob[16:20], "little") // 4 and lay["trace_root"] == HDR + 1 + (len(blob) + 1) // 2 + lay["n_rom"] + 1024
     fixed = lay["trace_root"] + 12 + (2 * WT + 4) * 4                                      # ... roots (trace, aux, quotient), openings of main + aux columns and the quotient
-    assert pr[1] == 6 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
+    assert pr[1] == 7 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
     assert int(pr[lay["rom_mult"]:lay["rc_mult"]].sum()) == 1 << log_n and int(pr[lay["rc_mult"]:lay["trace_root"]].sum()) == 4 << log_n   # multiplicities count every row
     depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
-    per_query = 1 + 2 * (W + 4 * (log_n + 1)) + 2 * (WA + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
+    per_query = 1 + 2 * (WC + 4 * (log_n + 1)) + 2 * (WA + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
     assert len(pr) == fixed + 1 + 4 * len(ks) + 4 * 8 + 1 + NQ * per_query
-    assert pr[0] == 0x46504B5A and pr[2] == log_n and pr[3] == W and pr[4] == NQ and pr[6] == 12 and pr[7] == n
+    assert pr[0] == 0x46504B5A and pr[2] == log_n and pr[3] == WC and pr[4] == NQ and pr[6] == 12 and pr[7] == n
     assert (pr[2:] < P).all()
     assert so.verify(pr) == 0 and so.verify(pr, pub) == 0
     assert so.verify(pr[:-1]) != 0 and so.verify(np.concatenate([pr, [0]])) != 0           # length is checked
@@ -390,10 +407,14 @@ def test_invalid_traces_are_rejected():
         mutate(rows)
         return so.verify(so.prove(rows, pub))
     assert code(lambda r: r["cycle"].__setitem__(30, 77)) == 10                    # cycle counter must increase by one
-    assert code(lambda r: r["registers"].__setitem__((slice(1, None), 0), 1)) == 10  # R0 is hard-wired zero
-    assert code(lambda r: r["reg_state"].__setitem__((10, 3), 2)) == 10            # storage state is boolean
+    # R0 is hard-wired zero: its limbs are not even committed (format v7) — a trace whose R0 holds 1 has operands the selectors cannot produce
+    assert code(lambda r: r["registers"].__setitem__((slice(1, None), 0), 1)) == 10
+    assert code(lambda r: r["registers"].__setitem__((slice(None), 0), 1)) == 10
+    # default mode: every register is Normalized, the storage states are not committed either — a row that claims another state splits
+    # its limbs differently and breaks the register's continuity
+    assert code(lambda r: r["reg_state"].__setitem__((10, 3), 2)) == 10
+    assert code(lambda r: r["reg_state"].__setitem__((10, 3), 1)) == 10
     # a run that does not START in the VM's initial state: the first state in the header (pinned to row 0 by the AIR) gives it away
-    assert code(lambda r: r["registers"].__setitem__((slice(None), 0), 1)) == 7
     assert code(lambda r: r["cycle"].__iadd__(5)) == 7                             # first row must be cycle 0
     assert code(lambda r: r["registers"].__setitem__((0, 5), 3)) == 7              # registers start at zero (state.rs:55-71)
     assert code(lambda r: r["pc"].__iadd__(8)) == 7                                # row 0 is at the entry point

@@ -41,8 +41,25 @@ constexpr int W = 160;
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
              C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159 };
+// LOGICAL vs COMMITTED columns (proof format v7).  W and the C_* map are the LOGICAL main trace: what the constraints talk about.  Columns
+// that are identically zero by the constraints themselves are not committed: R0's three limbs and its storage state (R0 is hard-wired
+// zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
+// committed matrix is the logical one with those columns removed, zero-padded to whole B8 blocks: 144 columns in default mode (141 + 3),
+// 160 in deferred mode (156 + 4); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
+constexpr int W_COMMITTED_DEFAULT = 144, W_COMMITTED_DEFERRED = 160;
+BB_HD constexpr bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
+BB_HD constexpr int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a committed column
+BB_HD constexpr int committed_width(bool deferred) { return deferred ? W_COMMITTED_DEFERRED : W_COMMITTED_DEFAULT; }
+BB_HD constexpr int committed_used(bool deferred) { return deferred ? W - 4 : W - 19; }      // the rest of the committed width is zero padding
+// the logical column stored at committed position p (p < committed_used)
+BB_HD constexpr int logical_col(int p, bool deferred) {
+  int c = p;
+  if (c >= C_LIMB) c += 3;                                     // R0's limbs
+  if (deferred) { if (c >= C_STATE) c += 1; } else { if (c >= C_STATE) c += 16; }
+  return c;
+}
 // aux trace: H0..H3 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
-constexpr int W_AUX = 24, W_ALL = W + W_AUX;
+constexpr int W_AUX = 24;
 enum : int { A_H = 0, A_HR = 16, A_S = 20 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 10;
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^10, T / N

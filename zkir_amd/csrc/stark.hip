@@ -64,8 +64,11 @@ __device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[
 #ifndef MT_WAVES
 #define MT_WAVES 3
 #endif
-__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t deferred, uint32_t* __restrict__ out) {
+// DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 144 columns by default, 160 deferred.
+template <bool DEF>
+__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out) {
   using namespace air;
+  constexpr uint32_t deferred = DEF ? 1u : 0u;
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   uint32_t rowv[W];
@@ -160,11 +163,13 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; d2 = (uint32_t)(v2 >> 24);
   }
   col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2;
+  // the committed columns, packed: committed position p holds logical column logical_col(p); the tail of the last block is zero padding
   uint4* out4 = reinterpret_cast<uint4*>(out);
+  auto at = [&](int p) -> uint32_t { return p < committed_used(DEF) ? rowv[logical_col(p < committed_used(DEF) ? p : 0, DEF)] : 0u; };
 #pragma unroll
-  for (int b = 0; b < W / 8; b++) {
-    out4[((uint64_t)b * N + i) * 2] = make_uint4(rowv[8 * b], rowv[8 * b + 1], rowv[8 * b + 2], rowv[8 * b + 3]);
-    out4[((uint64_t)b * N + i) * 2 + 1] = make_uint4(rowv[8 * b + 4], rowv[8 * b + 5], rowv[8 * b + 6], rowv[8 * b + 7]);
+  for (int b = 0; b < committed_width(DEF) / 8; b++) {
+    out4[((uint64_t)b * N + i) * 2] = make_uint4(at(8 * b), at(8 * b + 1), at(8 * b + 2), at(8 * b + 3));
+    out4[((uint64_t)b * N + i) * 2 + 1] = make_uint4(at(8 * b + 4), at(8 * b + 5), at(8 * b + 6), at(8 * b + 7));
   }
 }
 
@@ -324,7 +329,8 @@ struct zkir_stark_ctx {
 
 extern "C" {
 
-uint32_t zkir_main_trace_width(void) { return air::W; }
+uint32_t zkir_main_trace_width(void) { return air::committed_width(false); }
+uint32_t zkir_main_trace_width_for(uint32_t deferred) { return air::committed_width(deferred != 0); }
 
 void zkir_poseidon2_permute(uint32_t state[12]) {
   static const p2::Consts consts = [] { p2::Consts c; p2::generate(c); return c; }();
@@ -411,7 +417,8 @@ uint32_t zkir_padded_log_n(uint64_t n_real) { uint32_t k = 3; while (((uint64_t)
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* stream) {
   if (!trace || !out || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
-  hipLaunchKernelGGL(main_trace_kernel, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, deferred, out);
+  if (deferred) hipLaunchKernelGGL(main_trace_kernel<true>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
+  else hipLaunchKernelGGL(main_trace_kernel<false>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
   return check_launch("main_trace");
 }
 

@@ -9,9 +9,10 @@ namespace {
 
 using bb::E4;
 
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, WA = air::W_AUX, WT = air::W_ALL, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+// WMX / WTX: the largest committed width (deferred mode) — array sizes; a proof's own widths are air::committed_width(deferred) and that + WA
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_DEFERRED, WA = air::W_AUX, WTX = WMX + WA, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 6;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 7;
 
 #ifndef DEEP_WAVES
 #define DEEP_WAVES 4
@@ -24,7 +25,7 @@ constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 6;
 #endif
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
   E4 alpha_pow[N_CONSTRAINTS];
-  E4 gamma_pow[2 * WT + 4];     // main columns, aux columns at zeta; the same at zeta w; the quotient
+  E4 gamma_pow[2 * WTX + 4];    // main columns, aux columns at zeta; the same at zeta w; the quotient (2 * (committed width + WA) + 4 used)
   E4 zeta, zeta_w, a0, b0;
   uint32_t first_m[NS], last_m[NS];   // public boundary states: rows 0 and n_real - 1 (Montgomery)
   uint32_t deferred;
@@ -67,7 +68,7 @@ __device__ __forceinline__ E4 lz_reduce(const LazyE4& acc) {
 struct QuotientOps {
   using V = uint32_t;
   const uint32_t* __restrict__ L; const uint32_t* __restrict__ AL; uint64_t N2; uint32_t j, jn; const ProveParams* __restrict__ pp;
-  LazyE4 acc; E4 partial; int pending;
+  LazyE4 acc; E4 partial; int pending; bool deferred;
   __device__ __forceinline__ V aloc(int k) const { return bb::to_mont(AL[b8((uint32_t)k, j, N2)]); }
   __device__ __forceinline__ V anxt(int k) const { return bb::to_mont(AL[b8((uint32_t)k, jn, N2)]); }
   __device__ __forceinline__ V par(int i) const { return pp->lk[i]; }
@@ -76,8 +77,9 @@ struct QuotientOps {
   __device__ __forceinline__ V mul(V a, V b) const { return bb::mont_mul(a, b); }
   __device__ __forceinline__ V mulc(V a, uint32_t cm) const { return bb::mont_mul(a, cm); }
   __device__ __forceinline__ V cst(uint32_t cm) const { return cm; }
-  __device__ __forceinline__ V loc(int k) const { return bb::to_mont(L[b8((uint32_t)k, j, N2)]); }
-  __device__ __forceinline__ V nxt(int k) const { return bb::to_mont(L[b8((uint32_t)k, jn, N2)]); }
+  // logical column k: the constant 0 if it is not committed (air.h: is_virtual), else its committed position
+  __device__ __forceinline__ V loc(int k) const { return air::is_virtual(k, deferred) ? 0u : bb::to_mont(L[b8((uint32_t)air::phys_col(k, deferred), j, N2)]); }
+  __device__ __forceinline__ V nxt(int k) const { return air::is_virtual(k, deferred) ? 0u : bb::to_mont(L[b8((uint32_t)air::phys_col(k, deferred), jn, N2)]); }
   __device__ __forceinline__ void push(int idx, V v) {
     lz_fma(acc, pp->alpha_pow[idx], v);
     if (++pending == 128) { partial = bb::e_add(partial, lz_reduce(acc)); acc = LazyE4(); pending = 0; }     // 136 terms fit the lazy sum
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
   const uint32_t is_first = bb::mont_mul(zh, inv_mont(bb::sub(x, one)));
   const uint32_t is_last = bb::mont_mul(zh, inv_mont(bb::sub(x, w_last_m)));
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
-  QuotientOps o{L, AL, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0};
+  QuotientOps o{L, AL, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0, pp->deferred != 0};
   air::eval(o, is_first, is_last, is_trans, pp->first_m, pp->last_m, pp->deferred != 0);
   const E4 total = bb::e_add(o.partial, lz_reduce(o.acc));
   const E4 q = bb::e_from_mont(bb::e_mul_fm(total, inv_zh));
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
 // first ROM_LDS rows of the table — a program's hot code — global atomics beyond).  A row whose tuple is not the program's word at
 // its pc (self-modified code, pc outside the code segment) or whose chunk is out of range has no proof: its index goes to bad_row.
 constexpr uint32_t ROM_LDS = 4096;
-__global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
+__global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, bool deferred, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
                                                            uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row) {
   __shared__ uint32_t h_rc[air::RC_TABLE];
   __shared__ uint32_t h_rom[ROM_LDS];
@@ -128,11 +130,13 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
   for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) h_rom[k] = 0;
   __syncthreads();
   const uint4* M4 = reinterpret_cast<const uint4*>(M);
+  // committed positions of the columns read here (the instruction tuple's head is the same in both modes; opclass, the chunks and s move)
+  const uint32_t p_opc = (uint32_t)air::phys_col(air::C_OPC, deferred), p_rc = (uint32_t)air::phys_col(air::C_RC, deferred), p_s = (uint32_t)air::phys_col(air::C_S, deferred);
+  static_assert(air::C_PC == 1 && air::C_OP == 4 && air::C_FHI == 8 && air::C_LIMB == 9, "the tuple's head sits before the first uncommitted column");
   for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < N; i += (uint64_t)gridDim.x * NT) {
-    const uint4 b0l = M4[(0 * N + i) * 2], b0h = M4[(0 * N + i) * 2 + 1], b1l = M4[(1 * N + i) * 2];        // cycle pc0 pc1 pc2 | op fa fb fc | fhi ..
-    const uint4 b16h = M4[(16 * N + i) * 2 + 1], b17l = M4[(17 * N + i) * 2];                               // 132 133 opclass chunk0 | chunk1 chunk2 chunk3 s
-    static_assert(air::C_OPC == 134 && air::C_RC == 135 && air::C_S == 139 && air::C_PC == 1 && air::C_OP == 4 && air::C_FHI == 8, "column map");
-    const uint32_t r[4] = {b16h.w, b17l.x, b17l.y, b17l.z};
+    const uint4 b0l = M4[(0 * N + i) * 2], b0h = M4[(0 * N + i) * 2 + 1];                                  // cycle pc0 pc1 pc2 | op fa fb fc
+    const uint32_t fhi_v = M[b8(air::C_FHI, i, N)], opc_v = M[b8(p_opc, i, N)], s_v = M[b8(p_s, i, N)];
+    const uint32_t r[4] = {M[b8(p_rc, i, N)], M[b8(p_rc + 1, i, N)], M[b8(p_rc + 2, i, N)], M[b8(p_rc + 3, i, N)]};
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) { if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
     if (b0l.y < (1u << 20) && b0l.z < (1u << 20) && b0l.w < (1u << 24) && pc >= 0x1000 && !(pc & 3) && u < n_code) {
       const uint32_t w = code[u];
       ui = (uint32_t)u;
-      if (b0h.x == (w & 0x7F) && b0h.y == ((w >> 7) & 0xF) && b0h.z == ((w >> 11) & 0xF) && b0h.w == ((w >> 15) & 0xF) && b1l.x == (w >> 19) && b17l.w == (w >> 31) &&
-          b16h.z == air::opclass_of(w & 0x7F)) {
+      if (b0h.x == (w & 0x7F) && b0h.y == ((w >> 7) & 0xF) && b0h.z == ((w >> 11) & 0xF) && b0h.w == ((w >> 15) & 0xF) && fhi_v == (w >> 19) && s_v == (w >> 31) &&
+          opc_v == air::opclass_of(w & 0x7F)) {
         if (ui < rom_lds) atomicAdd(&h_rom[ui], 1u); else atomicAdd(&rom_mult[ui], 1u);
       } else ok = false;
     } else ok = false;
@@ -262,11 +266,11 @@ __global__ __launch_bounds__(NT) void scan_add_kernel(uint32_t* __restrict__ A, 
 }
 
 // ---- boundary states: the 68 state words of rows 0 and last_row of the main trace (B8 layout) -> out[136] ----------------------------
-__global__ void boundary_states_kernel(const uint32_t* __restrict__ M, uint64_t N, uint64_t last_row, uint32_t* __restrict__ out) {
+__global__ void boundary_states_kernel(const uint32_t* __restrict__ M, uint64_t N, uint64_t last_row, bool deferred, uint32_t* __restrict__ out) {
   const uint32_t i = threadIdx.x;
   if (i >= 2 * NS) return;
-  const uint32_t k = (uint32_t)air::state_col((int)(i % NS));
-  out[i] = M[b8(k, i < (uint32_t)NS ? 0 : last_row, N)];
+  const int k = air::state_col((int)(i % NS));                 // logical column; an uncommitted one (R0's limbs, default-mode storage states) is the constant 0
+  out[i] = air::is_virtual(k, deferred) ? 0u : M[b8((uint32_t)air::phys_col(k, deferred), i < (uint32_t)NS ? 0 : last_row, N)];
 }
 
 // ---- barycentric weights over the LDE coset: e_j = x_j / (zeta - x_j)  (Montgomery E4, AoS) -------------------------------
@@ -333,15 +337,16 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
 __global__ __launch_bounds__(NT, DEEP_WAVES) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, const uint32_t* __restrict__ Q, uint32_t log_n,
-                                                   const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t* __restrict__ cw) {
+                                                   const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, int WM, uint32_t* __restrict__ cw) {
   const uint32_t N2 = 2u << log_n;
+  const int WT = WM + WA;                                      // WM = the proof's committed main-trace width (a multiple of 8)
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
   // canonical v x Montgomery gamma^k = canonical product; the lazy sums (136 terms fit) are folded into Ap / Bp every FOLD terms
   LazyE4 A, B;
   E4 Ap = bb::e_zero(), Bp = bb::e_zero();
   constexpr int UN = 8, FOLD = 80;
-  static_assert(WM % UN == 0 && WA % UN == 0 && FOLD % UN == 0 && FOLD <= 128, "column loop");
+  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && WA % UN == 0 && FOLD % UN == 0 && FOLD <= 128, "column loop");
   int pending = 0;
   auto block = [&](const uint4* M4, int blk, int k0) {                         // one B8 block = eight columns, gamma indices k0 .. k0 + 7 (zeta) and WT + k0 .. (zeta w)
     const uint4 vlo = M4[((uint64_t)blk * N2 + j) * 2], vhi = M4[((uint64_t)blk * N2 + j) * 2 + 1];
@@ -485,7 +490,7 @@ struct StageEvents {             // RAII: released on every return path
 // the header words of a v4 proof (so::header_words): parameters, public inputs, the two boundary states read off the main trace
 void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t* states, std::vector<uint32_t>& w) {
   w.clear();
-  w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)WM, (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
+  w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)air::committed_width(pub.deferred != 0), (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
   w.insert(w.end(), {(uint32_t)(pub.n_real & 0x3FFFFFFF), (uint32_t)(pub.n_real >> 30), pub.deferred ? 1u : 0u});
   w.insert(w.end(), {(uint32_t)(pub.entry_point & 0xFFFFF), (uint32_t)((pub.entry_point >> 20) & 0xFFFFF), (uint32_t)(pub.entry_point >> 40)});
   w.insert(w.end(), pub.program_digest, pub.program_digest + 4);
@@ -509,6 +514,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (!c || !trace || !pub || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
   const uint32_t log_n = c->log_n;
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
+  const bool DEF = pub && pub->deferred != 0;
+  const int WM = air::committed_width(DEF), WT = WM + WA;     // this proof's committed main-trace columns; main + aux
   if (pub->n_real == 0 || zkir_padded_log_n(pub->n_real) != log_n || pub->entry_point >= (1ull << 40)) {
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the context's log_n must be zkir_padded_log_n(n_real) (n_real >= 1), and entry_point < 2^40"});
     return ZKIR_ERR_ARGUMENT;
@@ -539,7 +546,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const int n_layers = (int)ks.size();
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
-    static_assert(WM % 8 == 0, "the main trace fills whole B8 blocks");
+    static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
     const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
@@ -573,7 +580,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 1. main trace, lookup indices + multiplicities, LDE, trace commitment ---------------------------------------------------
   mark(0);
   int rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s); if (rc) return rc;
-  hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, dBound);   // before the LDE overwrites dM
+  hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, DEF, dBound);   // before the LDE overwrites dM
   std::vector<uint32_t> code(n_code);                         // lives to the end of the call: the H2D copy below reads it
   {
     for (uint32_t t = 0; t < n_code; t++) memcpy(&code[t], blob + 32 + 4 * (size_t)t, 4);
@@ -581,7 +588,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemsetAsync(dMult, 0, ((size_t)n_code + air::RC_TABLE) * 4, s));
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, dCode, n_code, dSide, dMult + n_code, dMult, dBad);
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, DEF, dCode, n_code, dSide, dMult + n_code, dMult, dBad);
   }
   mark(1);
   rc = zkir_lde_launch(c, dM, WM, dL, s); if (rc) return rc;
@@ -710,7 +717,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemcpyAsync(&dPP->a0, &pp->a0, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   }
   HIP_OK(ar.take(&fri_layers[0], 4 * N2));
-  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, fri_layers[0]);
+  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, WM, fri_layers[0]);
   mark(6);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------

@@ -17,8 +17,8 @@
 namespace {
 
 using bb::E4;
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WM = air::W, WA = air::W_AUX, WT = air::W_ALL, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 6;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WA = air::W_AUX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 7;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
 
@@ -70,7 +70,7 @@ inline bool e_eq(const E4& a, const E4& b) { return !memcmp(a.c, b.c, 16); }
 
 struct VerifierOps {                                                       // air::eval on the openings at zeta (E4, Montgomery)
   using V = E4;
-  const E4* l; const E4* n; const E4* al; const E4* an; const uint32_t* lk_m; const E4* ap; E4 acc;
+  const E4* l; const E4* n; const E4* al; const E4* an; const uint32_t* lk_m; const E4* ap; E4 acc; bool deferred;
   V aloc(int k) const { return al[k]; }
   V anxt(int k) const { return an[k]; }
   V par(int i) const { return m_base(lk_m[i]); }
@@ -79,8 +79,9 @@ struct VerifierOps {                                                       // ai
   V mul(const V& a, const V& b) const { return bb::e_mul_m(a, b); }
   V mulc(const V& a, uint32_t cm) const { return bb::e_mul_fm(a, cm); }
   V cst(uint32_t cm) const { return m_base(cm); }
-  V loc(int k) const { return l[k]; }
-  V nxt(int k) const { return n[k]; }
+  // logical column k of the AIR: the constant 0 if it is not committed (air.h: is_virtual), else the opening of its committed position
+  V loc(int k) const { return air::is_virtual(k, deferred) ? bb::e_zero() : l[air::phys_col(k, deferred)]; }
+  V nxt(int k) const { return air::is_virtual(k, deferred) ? bb::e_zero() : n[air::phys_col(k, deferred)]; }
   void push(int idx, const V& v) { acc = bb::e_add(acc, bb::e_mul_m(ap[idx], v)); }
 };
 
@@ -180,7 +181,8 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   auto need = [&](size_t k) { return p + k <= len; };
   if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
   const int log_n = (int)w[2];
-  if (w[3] != (uint32_t)WM || w[4] != (uint32_t)NUM_QUERIES || w[5] != (uint32_t)LOG_FINAL || w[6] != (uint32_t)POW_BITS || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
+  const int WM = (int)w[3], WT = WM + WA;                                  // committed main-trace columns (checked against the mode below); main + aux
+  if (w[9] > 1 || w[3] != (uint32_t)air::committed_width(w[9] != 0) || w[4] != (uint32_t)NUM_QUERIES || w[5] != (uint32_t)LOG_FINAL || w[6] != (uint32_t)POW_BITS || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
   if (w[7] >= (1u << 30) || w[9] > 1 || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
   zkir_public_inputs pub;
   memset(&pub, 0, sizeof pub);
@@ -302,7 +304,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     E4 is_trans = zeta; is_trans.c[0] = bb::sub(is_trans.c[0], bb::to_mont(bb::inv(wn)));
     uint32_t first_m[NS], last_m[NS];
     for (int i = 0; i < NS; i++) { first_m[i] = bb::to_mont(first[i]); last_m[i] = bb::to_mont(last[i]); }
-    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero()};
+    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero(), pub.deferred != 0};
     air::eval(o, is_first, is_last, is_trans, first_m, last_m, pub.deferred != 0);
     E4 qz = bb::e_zero();                                                  // Q(zeta) = sum_i X^i q_i(zeta): basis element X^i times the E4 opening
     for (int i = 0; i < 4; i++) { E4 basis = bb::e_zero(); basis.c[i] = bb::R1; qz = bb::e_add(qz, bb::e_mul_m(basis, q_z[i])); }

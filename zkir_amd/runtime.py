@@ -192,6 +192,8 @@ def lib() -> C.CDLL:
     L.zkir_stark_ctx_free.restype = None
     L.zkir_stark_ctx_free.argtypes = [V]
     L.zkir_main_trace_width.restype = U32
+    if hasattr(L, "zkir_main_trace_width_for"):               # absent from older builds loaded through ZKIR_AMD_LIB (kernel experiments)
+        L.zkir_main_trace_width_for.restype = U32; L.zkir_main_trace_width_for.argtypes = [U32]
     L.zkir_modmul_peak_per_s.restype = C.c_double
     L.zkir_modmul_peak_per_s.argtypes = [V]
     L.zkir_padded_log_n.restype = U32

@@ -15,7 +15,8 @@ from . import pipeline as pl
 from . import runtime as rt
 
 P = 2013265921
-W_MAIN = 160
+W_MAIN = 144                 # COMMITTED main-trace columns of a default-mode run (zkir_main_trace_width); the AIR has 160 logical columns (air.h)
+W_MAIN_DEFERRED = 160        # deferred mode: the storage states are committed too
 W_AUX = 24                  # aux trace of the lookup argument (air.h): H0..H3, HR, S as four base columns each
 RC_TABLE = 1024
 HEADER_WORDS = 157
@@ -86,6 +87,11 @@ def to_b8(cols: torch.Tensor) -> torch.Tensor:
     return out.view(nb, 8, n).permute(0, 2, 1).contiguous()
 
 
+def main_width(deferred: bool = False) -> int:
+    """Committed main-trace columns of a run (zkir_main_trace_width_for): 144 in the default VM mode, 160 with the deferred model."""
+    return W_MAIN_DEFERRED if deferred else W_MAIN
+
+
 def from_b8(mat: torch.Tensor, width: int) -> torch.Tensor:
     """B8 int32[nb][n][8] -> column-major int32[width][n]."""
     nb, n, _ = mat.shape
@@ -93,9 +99,10 @@ def from_b8(mat: torch.Tensor, width: int) -> torch.Tensor:
 
 
 def main_trace(trace: pl.DeviceTrace, stream=None, deferred: bool = False) -> torch.Tensor:
-    """K4: SoA execution trace (n_rows executed rows) -> main trace matrix in the B8 layout, int32[19][N][8], N = the padded power of two."""
+    """K4: SoA execution trace (n_rows executed rows) -> the COMMITTED main-trace matrix in the B8 layout, int32[main_width(deferred) / 8][N][8],
+    N = the padded power of two."""
     n = trace.n_rows
-    out = torch.empty((W_MAIN // 8, 1 << padded_log_n(n), 8), dtype=torch.int32, device=trace.cycle.device)
+    out = torch.empty((main_width(deferred) // 8, 1 << padded_log_n(n), 8), dtype=torch.int32, device=trace.cycle.device)
     pl._check(rt.lib().zkir_main_trace_launch(C.byref(trace.c), n, int(deferred), out.data_ptr(), _sp(stream)))
     return out
 
@@ -134,7 +141,7 @@ def commit_trace(ctx: StarkContext, trace: pl.DeviceTrace, stream=None, deferred
     """main trace -> LDE -> Merkle.  Returns (root np.uint32[4], lde matrix tensor (B8), tree tensor)."""
     m = main_trace(trace, stream, deferred)
     L = lde(ctx, m, stream, clobber=True)
-    tree = merkle_commit(ctx, L, W_MAIN, stream)
+    tree = merkle_commit(ctx, L, main_width(deferred), stream)
     root = tree[-4:].cpu().numpy().view(np.uint32)
     return root, L, tree
 
