@@ -174,11 +174,16 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //           unsigned comparison, execute.rs:373-407, :618-636), zero elsewhere
 //   158 flag = the family's comparison: [xb == xc] (raw 64-bit, all three limbs) on bre / se rows, the borrow c1 on bru / su rows, else 0
 //   159 fx = flag XOR (op - the family's even opcode): the branch decision (tk) of bre / bru rows, the value written by se / su rows
+// AIR v4 (control flow of every opcode but the two signed branches):
+//   160-161 class one-hot, continued: jalr (id 11), oj (id 12) = "other, jumps": BLT / BGE, whose comparison the AIR cannot state yet — their
+//           next pc is free, they write nothing.  Class "other" (id 4) is now SEQUENTIAL: pc' = pc + 4 like every instruction that is
+//           not a branch or a jump (loads, stores, the remaining ALU opcodes, ECALL: execute.rs advances pc by 4 in each of them)
+//   162 b0 = the bit JALR clears: next pc + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs mod 2^64 (execute.rs:649-658), carries d0 d1 d2
 // ---------------------------------------------------------------------------------------------
-static const int W_MAIN = 160;
+static const int W_MAIN = 163;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159 };
+       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162 };
 // AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 24 base columns = six extension-field columns,
 // coordinate by coordinate: H0..H3 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
 // S = running sum of (H0 + H1 + H2 + H3 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
@@ -208,10 +213,10 @@ static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the refere
 static const int N_TUPLE = 10;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
 
-enum { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, N_CLASS = 11 };
-static inline int kcol(int k) { return k < 7 ? C_K + k : C_K2 + (k - 7); }
+enum { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, N_CLASS = 13 };
+static inline int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : C_K3 + (k - 11); }
 static const uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
-                      OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48;
+                      OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
 // the even opcode of a family (its polarity-0 member); 0 for the classes that are one opcode
 static inline uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLTU : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0; }
 
@@ -247,7 +252,8 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
 static inline F opclass_of(uint32_t op) {
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
-    case OP_BLTU: case OP_BGEU: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE; case OP_SLTU: case OP_SGEU: return K_SU; default: return K_OTH;
+    case OP_BLTU: case OP_BGEU: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE; case OP_SLTU: case OP_SGEU: return K_SU;
+    case OP_JALR: return K_JALR; case OP_BLT: case OP_BGE: return K_OJ; default: return K_OTH;
   }
 }
 // The instruction ROM of a program blob (Program::to_bytes layout, program.rs:170-214,300-346): code word t sits at pc = 0x1000 + 4 t
@@ -301,6 +307,8 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     }
     int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
     if (cls == K_OTH && !D) cls = (int)opclass_of(op);
+    if (cls == K_OTH && D && opclass_of(op) != K_OTH && opclass_of(op) != K_ADD && opclass_of(op) != K_ADDI && opclass_of(op) != K_SUB && opclass_of(op) != K_SE && opclass_of(op) != K_SU)
+      cls = K_OJ;                                             // deferred mode: no opcode semantics, but "other" is sequential — branches and jumps run as the free-pc class
     col(kcol(cls))[i] = 1;
     col(C_OPC)[i] = opclass_of(op);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
@@ -338,7 +346,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       const uint64_t v0 = (uint64_t)xb[0] + b0; c0 = (F)(v0 >> 20); y[0] = (F)(v0 & 0xFFFFF);
       const uint64_t v1 = (uint64_t)xb[1] + b1 + c0; c1 = (F)(v1 >> 20); y[1] = (F)(v1 & 0xFFFFF);
       rd = fa;
-    } else if (cls == K_JAL) {
+    } else if (cls == K_JAL || cls == K_JALR) {                 // the link pc + 4 (execute.rs:639-658)
       const uint64_t v0 = (uint64_t)pc[0] + 4; c0 = (F)(v0 >> 20); y[0] = (F)(v0 & 0xFFFFF);
       const uint64_t v1 = (uint64_t)pc[1] + c0; c1 = (F)(v1 >> 20); y[1] = (F)(v1 & 0xFFFFF);
       y[2] = pc[2] + c1;
@@ -346,7 +354,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     if (rd > 0) col(C_WR + rd - 1)[i] = 1;
-    if (cls == K_OTH) {                                     // any other instruction: what it wrote is read off the next row
+    if (cls == K_OTH || (cls == K_OJ && D)) {               // any other instruction: what it wrote is read off the next row
       const PackedRow& q = rows[i + 1];
       bool first = true;
       for (int g = 1; g < 16; g++) {
@@ -358,11 +366,16 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       }
     }
     for (int l = 0; l < 3; l++) col(C_Y + l)[i] = y[l];
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_OTH) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
     col(C_Z)[i] = z[0]; col(C_Z + 1)[i] = z[1];
     col(C_RC)[i] = z[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = z[0] >> RC_BITS; col(C_RC + 2)[i] = z[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = z[1] >> RC_BITS;
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
-    if (cls != K_OTH && cls != K_HALT && cls != K_PAD) {                                            // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
+    if (cls == K_JALR) {                                                                            // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
+      const uint64_t v0 = (uint64_t)xb[0] + im0; const F d0 = (F)(v0 >> 20);
+      const uint64_t v1 = (uint64_t)xb[1] + im1 + d0; const F d1 = (F)(v1 >> 20);
+      const uint64_t v2 = (uint64_t)xb[2] + (uint64_t)s * 0xFFFFFF + d1; const F d2 = (F)(v2 >> 24);
+      col(C_D0)[i] = d0; col(C_D1)[i] = d1; col(C_D2)[i] = d2; col(C_B0)[i] = (F)(v0 & 1);
+    } else if (cls != K_OJ && cls != K_HALT && cls != K_PAD) {                                      // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
       const uint64_t v0 = (uint64_t)pc[0] + dl0; const F d0 = (F)(v0 >> 20);
       const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; const F d1 = (F)(v1 >> 20);
       const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; const F d2 = (F)(v2 >> 24);
@@ -468,7 +481,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 7;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode)
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 8;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
@@ -534,7 +547,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   for (int r = 0; r < 16; r++) boolean(loc[C_STATE + r]);
   for (int r = 0; r < 15; r++) { boolean(loc[C_WR + r]); boolean(loc[C_SELB + r]); boolean(loc[C_SELC + r]); }
   for (int k = 0; k < N_CLASS; k++) boolean(K[k]);
-  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]);
+  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
   { E sum = e_from(0); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
@@ -554,8 +567,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   E w0, w1, w2, b0, b1, b2, c0s, c1s, c2s;
   moments(C_WR, w0, w1, w2); moments(C_SELB, b0, b1, b2); moments(C_SELC, c0s, c1s, c2s);
   push(emul(nD, esub(emul(w1, w1), w2)));
-  push(emul(eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), Kcmp), esub(w1, fa)));
-  push(emul(eadd(eadd(Kbr, K[K_HALT]), K[K_PAD]), w0));
+  push(emul(eadd(eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), Kcmp), K[K_JALR]), esub(w1, fa)));
+  push(emul(eadd(eadd(eadd(Kbr, emul(nD, K[K_OJ])), K[K_HALT]), K[K_PAD]), w0));   // branches write nothing (BLT / BGE too: class oj in default mode)
   push(esub(b1, fb)); push(esub(emul(b1, b1), b2));
   push(esub(c1s, eadd(fc, emul(Kbr, esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));
   // 6. operand fetch
@@ -578,9 +591,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   push(emul(K[K_ADDI], eadd(esub(esub(z[0], xb[0]), im0), emul(two20, c0))));
   push(emul(K[K_ADDI], eadd(esub(esub(esub(z[1], xb[1]), im1), c0), emul(two20, c1))));
   push(emul(K[K_ADDI], y[2]));
-  push(emul(K[K_JAL], eadd(esub(esub(z[0], pc[0]), cst(4)), emul(two20, c0))));
-  push(emul(K[K_JAL], eadd(esub(esub(z[1], pc[1]), c0), emul(two20, c1))));
-  push(emul(K[K_JAL], esub(esub(y[2], pc[2]), c1)));
+  const E Kj = eadd(K[K_JAL], K[K_JALR]);                                    // both link pc + 4 (execute.rs:639-658)
+  push(emul(Kj, eadd(esub(esub(z[0], pc[0]), cst(4)), emul(two20, c0))));
+  push(emul(Kj, eadd(esub(esub(z[1], pc[1]), c0), emul(two20, c1))));
+  push(emul(Kj, esub(esub(y[2], pc[2]), c1)));
   // 7b. (v3) differences with borrows: z = xb - xc mod 2^40 on SUB and SLTU / SGEU rows (execute.rs:65-77, :373-407), z = xc - xb on BLTU /
   //     BGEU rows (:618-636); c1 = 1 exactly when the minuend is the smaller 40-bit value (z's limbs are in range, so the borrows are forced)
   {
@@ -592,7 +606,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   }
   //     the written value: y = z on arithmetic and "other" rows, (fx, 0, 0) on comparison rows
   {
-    const E Ky = eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), K[K_OTH]);
+    const E Ky = eadd(eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), eadd(K[K_OTH], K[K_JALR])), emul(Dm, K[K_OJ]));   // (oj writes only in deferred mode)
     push(emul(Ky, esub(y[0], z[0]))); push(emul(Ky, esub(y[1], z[1])));
     push(emul(Kcmp, esub(y[0], loc[C_FX]))); push(emul(Kcmp, y[1])); push(emul(Kcmp, y[2]));
   }
@@ -615,12 +629,18 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   // 9. next pc: pc + 4, pc + imm17 (branch taken) or pc + off21 (JAL), wrapping at 2^64 over (20, 20, 24)-bit limbs (state.rs:131-133)
   push(esub(loc[C_DL0], eadd(eadd(cst(4), emul(loc[C_TK], esub(im0, cst(4)))), emul(K[K_JAL], esub(lo20, cst(4))))));
   push(esub(se, emul(eadd(loc[C_TK], K[K_JAL]), s)));
-  const E kc = esub(esub(esub(one, K[K_OTH]), K[K_HALT]), K[K_PAD]);       // every class whose next pc the AIR derives
+  const E kc = esub(esub(esub(esub(one, K[K_JALR]), K[K_OJ]), K[K_HALT]), K[K_PAD]);   // pc' = pc + delta: every class but jalr (below), oj (free), halt / pad (keep);
+                                                                              // class "other" is in it with delta 4 (tk = 0 there): it is sequential
   const E hp = eadd(K[K_HALT], K[K_PAD]);
   push(emul(emul(kc, eadd(esub(esub(nxt[C_PC], pc[0]), loc[C_DL0]), emul(two20, loc[C_D0]))), is_trans));
   push(emul(emul(kc, eadd(esub(esub(esub(nxt[C_PC + 1], pc[1]), emul_f(se, 0xFFFFF)), loc[C_D0]), emul(two20, loc[C_D1]))), is_trans));
   push(emul(emul(kc, eadd(esub(esub(esub(nxt[C_PC + 2], pc[2]), emul_f(se, 0xFFFFFF)), loc[C_D1]), emul(two24, loc[C_D2]))), is_trans));
   for (int l = 0; l < 3; l++) push(emul(emul(hp, esub(nxt[C_PC + l], pc[l])), is_trans));
+  // 9b. (v4) JALR: pc' + b0 = rs1 + sext(imm17) mod 2^64 over (20, 20, 24)-bit limbs, b0 = the bit that is cleared (execute.rs:649-658); the
+  //     limbs of pc' are a code address (every row's pc is looked up in the ROM), so the carries and b0 are forced
+  push(emul(emul(K[K_JALR], esub(eadd(eadd(nxt[C_PC], loc[C_B0]), emul(two20, loc[C_D0])), eadd(xb[0], im0))), is_trans));
+  push(emul(emul(K[K_JALR], esub(eadd(nxt[C_PC + 1], emul(two20, loc[C_D1])), eadd(eadd(xb[1], im1), loc[C_D0]))), is_trans));
+  push(emul(emul(K[K_JALR], esub(eadd(nxt[C_PC + 2], emul(two24, loc[C_D2])), eadd(eadd(xb[2], emul_f(s, 0xFFFFFF)), loc[C_D1]))), is_trans));
   // 10. register file update: the written register takes y (default mode) / may change freely (deferred mode), the others keep
   //     their limbs and storage state; a written register becomes Normalized in default mode
   for (int r = 1; r < 16; r++) {

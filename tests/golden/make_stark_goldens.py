@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v3, proof format v7).
+"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v4, proof format v8).
 
 The reference has no prover, so nothing external can pin these stages; this file FREEZES them — it pins nothing:
 the values are produced by this repository's own oracle, so they guard against DRIFT only: the
@@ -23,7 +23,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
 
-ADD, SUB, ADDI, SLLI, SLTU, SGEU, SEQ, SNE, LW, SW, BEQ, BNE, BLTU, BGEU, JAL, ECALL = 0x00, 0x01, 0x08, 0x1B, 0x20, 0x21, 0x24, 0x25, 0x34, 0x3A, 0x40, 0x41, 0x44, 0x45, 0x48, 0x50
+ADD, SUB, MUL, ADDI, SLLI, SLTU, SGEU, SEQ, SNE, LW, SW, BEQ, BNE, BLT, BGE, BLTU, BGEU, JAL, JALR, ECALL = \
+    0x00, 0x01, 0x02, 0x08, 0x1B, 0x20, 0x21, 0x24, 0x25, 0x34, 0x3A, 0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x48, 0x49, 0x50
 
 
 def r_(op, rd, rs1, rs2): return op | rd << 7 | rs1 << 11 | rs2 << 15
@@ -53,12 +54,18 @@ CMP_LOOP = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 7), i_(ADDI, 3, 0, 100), i_(A
                  r_(ADD, 2, 2, 6), i_(ADDI, 2, 2, 45), i_(BLTU, 2, 3, 8), r_(ADD, 3, 3, 3), i_(BGEU, 2, 11, 8), r_(SUB, 3, 3, 9),
                  i_(BEQ, 6, 10, 8), i_(ADDI, 1, 1, 1), i_(ADDI, 10, 6, 0), i_(BNE, 1, 0, -60), j_(JAL, 0, -64)])
 
+# a subroutine call loop: JAL / JALR (even and odd return sums, a negative immediate), BLT / BGE, MUL / SLLI (the product ships it as spec.call_loop_program)
+CALL_LOOP = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 5), i_(ADDI, 6, 0, 20),
+                  j_(JAL, 15, 24), i_(ADDI, 1, 1, 1), i_(BLT, 1, 2, 8), i_(ADDI, 2, 2, 7), i_(BGE, 1, 6, -16), j_(JAL, 0, -20),
+                  r_(MUL, 3, 1, 2), i_(SLLI, 4, 3, 2), i_(ADDI, 14, 15, 5), r_(SEQ, 5, 4, 0), i_(BEQ, 5, 0, 8), i_(JALR, 13, 15, 0), i_(JALR, 0, 14, -4)])
+
 CASES = [
     dict(name="fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=False),
     dict(name="sha_2p9", blob=SHA_CHAIN, max_cycles=1 << 9, deferred=False),
     dict(name="deferred_fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=True),
     dict(name="fib30_exit_154_rows", blob=FIB30, max_cycles=1_000_000, deferred=False),
     dict(name="compare_loop_600_rows", blob=CMP_LOOP, max_cycles=600, deferred=False),
+    dict(name="call_loop_500_rows", blob=CALL_LOOP, max_cycles=500, deferred=False),
 ]
 
 
@@ -80,8 +87,8 @@ def golden(case):
 
 
 if __name__ == "__main__":
-    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v3, proof format v7; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
-           "proof_version": 7, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
+    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v4, proof format v8; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
+           "proof_version": 8, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
            "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
            "cases": [golden(c) for c in CASES]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")

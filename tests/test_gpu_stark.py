@@ -88,6 +88,7 @@ def test_merkle_and_lde_extreme_values(fill):
 
 PROGRAMS = {"fib": (spec.fib_endless_program, {}), "sha": (spec.sha256_chain_program, {}), "deferred": (spec.fib_endless_program, {"enable_deferred_model": True}),
             "cmp": (spec.compare_loop_program, {}), "cmp_deferred": (spec.compare_loop_program, {"enable_deferred_model": True}),
+            "call": (spec.call_loop_program, {}), "call_deferred": (spec.call_loop_program, {"enable_deferred_model": True}),
             "fib30": (lambda: spec.fib_program(30), {}), "exit42": (lambda: spec.Program.from_code([spec.addi(10, 0, 0), spec.addi(11, 0, 42), spec.ecall()]), {})}
 
 
@@ -108,7 +109,8 @@ def _case(name, n):
 
 
 @pytest.mark.parametrize("name,n", [("fib", 64), ("fib", 1024), ("fib", 4096), ("fib", 1000), ("fib", 5), ("sha", 512), ("sha", 700), ("deferred", 256),
-                                    ("fib30", None), ("exit42", None), ("cmp", 600), ("cmp", 5000), ("cmp_deferred", 300)])
+                                    ("fib30", None), ("exit42", None), ("cmp", 600), ("cmp", 5000), ("cmp_deferred", 300), ("call", 500), ("call", 3000),
+                                    ("call_deferred", 250)])
 def test_main_trace_and_commit_match_oracle(name, n):
     """All committed columns of the padded main trace (144 in default mode, 160 deferred: the oracle's 160 logical columns minus the ones
     that are identically zero), the LDE and the commitment root, for power-of-two and ragged row counts and for programs that halt on
@@ -155,7 +157,8 @@ def test_commit_2p16_root_and_properties():
 
 
 @pytest.mark.parametrize("name,n", [("fib", 8), ("fib", 5), ("fib", 32), ("fib", 256), ("fib", 2048), ("fib", 1500), ("sha", 512), ("sha", 300), ("deferred", 1024),
-                                    ("fib30", None), ("exit42", None), ("fib", 8192), ("cmp", 600), ("cmp", 4096), ("cmp_deferred", 300)])
+                                    ("fib30", None), ("exit42", None), ("fib", 8192), ("cmp", 600), ("cmp", 4096), ("cmp_deferred", 300), ("call", 500),
+                                    ("call", 2048), ("call_deferred", 250)])
 def test_proof_bytes_match_oracle_and_verify(name, n):
     """End-to-end proof (quotient over the v1 AIR, openings, DEEP, FRI, grinding, queries): GPU proof words == oracle proof words,
     and both verifiers accept them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on
@@ -208,6 +211,19 @@ def test_wrong_execution_is_rejected_on_the_gpu_path():
         tr3.registers[rd, k3 + 1:nx3 + 1] = saved3
     assert np.array_equal(stark.prove(ctx3, tr3, pub3), so.prove(rows3, opub3))
     ctx3.close(); log3.close()
+    # AIR v4: a JALR's link off by 4, a register written "by" a signed branch — on a run of spec.call_loop_program
+    blob4, log4, tr4, rows4, opub4, pub4 = _case("call", 500)
+    ctx4 = stark.StarkContext(9)
+    ops4 = rows4["instruction"] & 0x7F
+    kj = int(np.nonzero((ops4 == 0x49) & (((rows4["instruction"] >> 7) & 0xF) == 13))[0][0]); kb = int(np.nonzero(ops4 == 0x42)[0][3])
+    for reg, lo, edit in ((13, kj + 1, lambda v: v + 4), (9, kb + 1, lambda v: v + 7)):
+        saved4 = tr4.registers[reg, lo:len(rows4)].clone()
+        tr4.registers[reg, lo:len(rows4)] = edit(saved4)
+        bad4 = stark.prove(ctx4, tr4, pub4)
+        assert so.verify(bad4, opub4) == 10 and rt.verify(bad4, pub4) == 10, reg
+        tr4.registers[reg, lo:len(rows4)] = saved4
+    assert np.array_equal(stark.prove(ctx4, tr4, pub4), so.prove(rows4, opub4))
+    ctx4.close(); log4.close()
     # A row whose (pc, instruction word) is not in the program's code table has NO proof in AIR v2 (instruction-ROM lookup): the honest
     # prover refuses it instead of emitting a proof the verifier would reject — a BNE's fall-through claimed where the run branched
     # (the word at the claimed pc is another one), an instruction word patched in HBM (ADD -> SUB: the forgery AIR v1 accepted)

@@ -145,12 +145,12 @@ def test_merkle_layers_and_paths():
 # column map of the main trace (AIR v3: oracle/stark_oracle.cpp)
 C_PC, C_OP, C_FA, C_LIMB, C_STATE, C_WR, C_SELB, C_SELC, C_XB, C_XC, C_Y, C_K, C_OPC, C_RC, C_S, C_C0, C_D0, C_DL0, C_NE, C_IV, C_TK = \
     1, 4, 5, 9, 57, 73, 88, 103, 118, 121, 124, 127, 134, 135, 139, 141, 143, 146, 147, 148, 151
-C_K2, C_Z, C_FLAG, C_FX = 152, 156, 158, 159
-K_ADD, K_ADDI, K_BRE, K_JAL, K_OTH, K_HALT, K_PAD, K_SUB, K_BRU, K_SE, K_SU = range(11)
+C_K2, C_Z, C_FLAG, C_FX, C_K3, C_B0 = 152, 156, 158, 159, 160, 162
+K_ADD, K_ADDI, K_BRE, K_JAL, K_OTH, K_HALT, K_PAD, K_SUB, K_BRU, K_SE, K_SU, K_JALR, K_OJ = range(13)
 K_BNE = K_BRE                                                    # BEQ / BNE share a class: the family's comparison with either polarity
-KCOL = [C_K + k for k in range(7)] + [C_K2 + k for k in range(4)]
+KCOL = [C_K + k for k in range(7)] + [C_K2 + k for k in range(4)] + [C_K3 + k for k in range(2)]
 W = so.W_MAIN
-OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU}
+OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU, 0x49: K_JALR, 0x42: K_OJ, 0x43: K_OJ}
 
 
 def test_main_trace_columns_and_commit():
@@ -159,7 +159,7 @@ def test_main_trace_columns_and_commit():
     rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
     pub = so.public_inputs(n, blob)
     m = so.main_trace(rows, pub)
-    assert m.shape == (160, 64) and (m < P).all()
+    assert m.shape == (163, 64) and (m < P).all()
     assert list(m[0]) == list(range(64))                         # the cycle column keeps counting through the padding
     assert np.array_equal(m[1][:n], rows["pc"] & 0xFFFFF) and not m[3].any()
     assert np.array_equal(m[C_OP][:n], rows["instruction"] & 0x7F)
@@ -193,24 +193,24 @@ def test_main_trace_columns_and_commit():
     assert (m[C_LIMB:C_STATE + 16, n:] == m[C_LIMB:C_STATE + 16, n - 1:n]).all() and (m[C_PC:C_PC + 3, n:] == m[C_PC:C_PC + 3, n - 1:n]).all()
     root, L = so.commit_trace(rows, 1, want_lde=True, pub=pub)
     # what is committed: the logical matrix minus the columns that are identically zero (R0's limbs, the 16 storage states of the default
-    # mode), packed and zero-padded to whole blocks of 8: 141 + 3 columns
-    kept = [c for c in range(160) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16)]
-    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 141
+    # mode), packed: 144 columns, whole blocks of 8
+    kept = [c for c in range(163) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16)]
+    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 144
     mc = so.to_committed(m)
-    assert mc.shape == (144, 64) and np.array_equal(mc[:141], m[kept]) and not mc[141:].any()
+    assert mc.shape == (144, 64) and np.array_equal(mc, m[kept])
     assert L.shape == (144, 128)
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
     coeffs, col = so.lde(m[C_WR], 1)
     assert np.array_equal(col, L[C_WR - 19])
-    # deferred mode keeps the storage states (only R0's limbs and state are left out): 156 + 4 columns
+    # deferred mode keeps the storage states (only R0's limbs and state are left out): 159 columns + 1 of zero padding
     rows_d = oracle.run(blob, max_cycles=n, enable_execution_trace=True, enable_deferred_model=True).rows
     pub_d = so.public_inputs(n, blob, deferred=True)
     m_d = so.main_trace(rows_d, pub_d)
-    kept_d = [c for c in range(160) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
+    kept_d = [c for c in range(163) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
     mc_d = so.to_committed(m_d, deferred=True)
-    assert mc_d.shape == (160, 64) and np.array_equal(mc_d[:156], m_d[kept_d]) and not mc_d[156:].any() and m_d[C_STATE + 1:C_STATE + 16].any()
+    assert mc_d.shape == (160, 64) and np.array_equal(mc_d[:159], m_d[kept_d]) and not mc_d[159:].any() and m_d[C_STATE + 1:C_STATE + 16].any()
     assert so.commit_trace(rows_d, 1, want_lde=True, pub=pub_d)[1].shape == (160, 128)
 
 
@@ -276,7 +276,8 @@ def test_air_holds_row_by_row_on_honest_traces():
     verifier would use ON the trace domain (is_first = [i == 0], is_last = [i == n_real - 1], is_trans = [i != N - 1])."""
     for prog, n, cfg in ((spec.fib_endless_program(), 50, {}), (spec.sha256_chain_program(), 200, {}), (spec.fib_program(12), None, {}),
                          (spec.fib_endless_program(), 40, {"enable_deferred_model": True}), (spec.compare_loop_program(), 600, {}),
-                         (spec.compare_loop_program(), 100, {"enable_deferred_model": True})):
+                         (spec.compare_loop_program(), 100, {"enable_deferred_model": True}), (spec.call_loop_program(), 500, {}),
+                         (spec.call_loop_program(), 120, {"enable_deferred_model": True})):
         blob = prog.to_bytes()
         res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
         rows = res.rows
@@ -302,7 +303,7 @@ def test_air_holds_row_by_row_on_honest_traces():
 
 # ---- stage B: prover + verifier ------------------------------------------------------------------------------------
 def _prog(prog):
-    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program}[prog]()
+    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program, "call": spec.call_loop_program}[prog]()
 
 
 def _run(n, prog="fib", **cfg):
@@ -331,7 +332,7 @@ WA, WC = so.W_AUX, so.W_COMMITTED                                # aux columns; 
 WT = WC + WA
 
 
-@pytest.mark.parametrize("n,prog", [(8, "fib"), (16, "fib"), (5, "fib"), (100, "fib"), (256, "fib"), (300, "sha"), (1024, "fib"), (600, "cmp")])
+@pytest.mark.parametrize("n,prog", [(8, "fib"), (16, "fib"), (5, "fib"), (100, "fib"), (256, "fib"), (300, "sha"), (1024, "fib"), (600, "cmp"), (500, "call")])
 def test_prove_verify_roundtrip(n, prog):
     rows, pub = _run(n, prog)
     pr = so.prove(rows, pub)
@@ -341,7 +342,7 @@ def test_prove_verify_roundtrip(n, prog):
     blob = _prog(prog).to_bytes()
     assert lay["blob"] == blob and lay["n_rom"] == int.from_bytes(blob[16:20], "little") // 4 and lay["trace_root"] == HDR + 1 + (len(blob) + 1) // 2 + lay["n_rom"] + 1024
     fixed = lay["trace_root"] + 12 + (2 * WT + 4) * 4                                      # ... roots (trace, aux, quotient), openings of main + aux columns and the quotient
-    assert pr[1] == 7 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
+    assert pr[1] == 8 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
     assert int(pr[lay["rom_mult"]:lay["rc_mult"]].sum()) == 1 << log_n and int(pr[lay["rc_mult"]:lay["trace_root"]].sum()) == 4 << log_n   # multiplicities count every row
     depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
     per_query = 1 + 2 * (WC + 4 * (log_n + 1)) + 2 * (WA + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
@@ -576,6 +577,69 @@ def test_wrong_execution_of_the_opcode_families_is_rejected():
             w = int(rows0["instruction"][k]); imm = (w >> 15) - (1 << 17 if w >> 31 else 0)
             rows = rows0.copy(); rows["pc"][k + 1] = int(rows0["pc"][k]) + (4 if want_taken else imm)
             assert rejected(rows), (hex(op), want_taken)
+
+
+def test_control_flow_of_every_opcode_but_the_signed_branches():
+    """AIR v4 on spec.call_loop_program: JALR rows (link = pc + 4; next pc + the cleared bit = rs1 + sext(imm), even and odd sums, a
+    negative immediate), class "other" rows (MUL, SLLI: pc + 4 enforced), class "other, jumps" rows (BLT / BGE: free pc, nothing
+    written) — the columns against the VM's rows, and every way of bending the control flow rejected."""
+    rows0, pub = _run(500, "call")
+    m = so.main_trace(rows0, pub)
+    ops = rows0["instruction"] & 0x7F
+    cls = m[KCOL]
+    assert (cls.sum(axis=0) == 1).all()
+    n = len(rows0)
+    seen = set()
+    for i in range(n - 1):
+        op = int(ops[i]); k = OPCLASS.get(op, K_OTH)
+        assert cls[k][i] == 1
+        w = int(rows0["instruction"][i]); fa, fb = (w >> 7) & 0xF, (w >> 11) & 0xF
+        if k == K_JALR:
+            imm = (w >> 15) - (1 << 17 if w >> 31 else 0)
+            t = (int(rows0["registers"][i, fb]) + imm) & ((1 << 64) - 1)
+            assert int(rows0["pc"][i + 1]) == t & ~1 and m[C_B0, i] == t & 1
+            assert [int(m[C_Y + l, i]) for l in range(3)] == [(int(rows0["pc"][i]) + 4) & 0xFFFFF, (int(rows0["pc"][i]) + 4) >> 20 & 0xFFFFF, 0]
+            if fa: assert int(rows0["registers"][i + 1, fa]) == int(rows0["pc"][i]) + 4 and m[C_WR + fa - 1, i] == 1
+            else: assert not m[C_WR:C_WR + 15, i].any()
+            seen.add(("jalr", int(m[C_B0, i]), imm < 0))
+        if k == K_OJ:
+            assert not m[C_WR:C_WR + 15, i].any()
+            seen.add((op, int(rows0["pc"][i + 1]) != int(rows0["pc"][i]) + 4))
+        if k == K_OTH:
+            assert int(rows0["pc"][i + 1]) == int(rows0["pc"][i]) + 4
+            seen.add(op)
+    assert seen >= {("jalr", 0, False), ("jalr", 1, True), (0x42, False), (0x42, True), (0x43, False), (0x43, True), 0x02, 0x1B}
+    assert so.verify(so.prove(rows0, pub)) == 0
+
+    def rejected(rows):
+        return so.verify(so.prove(rows, pub)) == 10
+    kj = int(np.nonzero(ops == 0x49)[0][3]); km = int(np.nonzero(ops == 0x02)[0][3]); kb = int(np.nonzero(ops == 0x42)[0][3])
+    code_pcs = [0x1000 + 4 * t for t in range(len(spec.call_loop_program().code))]
+    # a JALR that returns somewhere else (another valid code address): only that row is forged, the rows after it are the honest ones
+    for other in (int(rows0["pc"][kj + 1]) + 4, int(rows0["pc"][kj + 1]) - 4, code_pcs[0]):
+        rows = rows0.copy(); rows["pc"][kj + 1] = other
+        assert rejected(rows), hex(other)
+    # ... with a wrong link value
+    rows = rows0.copy(); rd = (int(rows0["instruction"][kj]) >> 7) & 0xF
+    kj13 = int(np.nonzero((ops == 0x49) & (((rows0["instruction"] >> 7) & 0xF) == 13))[0][0])
+    rows["registers"][kj13 + 1:, 13] += 4
+    assert rejected(rows)
+    # an "other" row (MUL) that jumps: the next row sits at another code address
+    rows = rows0.copy(); rows["pc"][km + 1] = int(rows0["pc"][km]) + 8
+    assert rejected(rows)
+    # a signed branch may go either way (its comparison is not stated) — but it cannot write a register
+    rows = rows0.copy(); rows["registers"][kb + 1:, 9] = 77
+    assert rejected(rows)
+    m2 = m.copy(); m2[C_WR + 8, kb] = 1; m2[C_LIMB + 27, kb + 1:] = 77       # ... even if the matrix flags the write
+    assert so.verify(so.prove_matrix(m2, pub)) == 10
+    # a JALR row relabelled as the free-pc class: its word's class says otherwise (ROM tuple)
+    m2 = m.copy(); m2[C_K3, kj] = 0; m2[C_K3 + 1, kj] = 1
+    assert so.verify(so.prove_matrix(m2, pub)) == 10
+    m2[C_OPC, kj] = K_OJ
+    assert so.verify(so.prove_matrix(m2, pub)) == 10
+    # the cleared bit forged together with the low pc limb: pc' stops being a code address
+    m2 = m.copy(); m2[C_B0, kj] = 1 - int(m[C_B0, kj]); m2[C_PC, kj + 1] = (int(m[C_PC, kj + 1]) + (1 if m[C_B0, kj] else -1)) % P
+    assert so.verify(so.prove_matrix(m2, pub)) == 10
 
 
 def test_cheating_prover_matrices_are_rejected():

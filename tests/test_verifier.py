@@ -18,13 +18,14 @@ def _pub_c(p: so.PublicC) -> rt.PublicInputsC:
 
 
 def _run(n, prog="fib", **cfg):
-    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program}[prog]().to_bytes()
+    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program, "call": spec.call_loop_program}[prog]().to_bytes()
     res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
     return res.rows, so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=bool(cfg))
 
 
 @pytest.mark.parametrize("n,prog,cfg", [(8, "fib", {}), (5, "fib", {}), (100, "fib", {}), (300, "sha", {}), (None, "fib12", {}), (512, "fib", {}),
-                                         (200, "fib", {"enable_deferred_model": True}), (600, "cmp", {}), (150, "cmp", {"enable_deferred_model": True})])
+                                         (200, "fib", {"enable_deferred_model": True}), (600, "cmp", {}), (150, "cmp", {"enable_deferred_model": True}), (500, "call", {}),
+                                         (200, "call", {"enable_deferred_model": True})])
 def test_accepts_what_the_oracle_accepts(n, prog, cfg):
     rows, pub = _run(n, prog, **cfg)
     pr = so.prove(rows, pub)
@@ -107,6 +108,33 @@ def test_rejects_forged_opcode_families_like_the_oracle():
         pr = so.prove_matrix(m, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10, i
     pr = so.prove_matrix(m0, pub)
+    assert so.verify(pr) == 0 and rt.verify(pr) == 0
+
+
+def test_rejects_bent_control_flow_like_the_oracle():
+    """AIR v4 (JALR, sequential "other" rows, the free-pc class of BLT / BGE): same verdict from the product verifier and the oracle on
+    forged jump targets, links, cleared bits, relabelled rows and writes by a signed branch."""
+    rows, pub = _run(500, "call")
+    m0 = so.main_trace(rows, pub)
+    ops = rows["instruction"] & 0x7F
+    C_PC, C_LIMB, C_WR, C_Y, C_K, C_OPC, C_D0, C_K3, C_B0 = 1, 9, 73, 124, 127, 134, 143, 160, 162
+    kj, km, kb = (int(np.nonzero(ops == op)[0][3]) for op in (0x49, 0x02, 0x42))
+    edits = [lambda m: m.__setitem__((C_B0, kj), 1 - int(m[C_B0, kj])), lambda m: m.__setitem__((C_D0, kj), 1 - int(m[C_D0, kj])),
+             lambda m: m.__setitem__((C_Y, kj), (int(m[C_Y, kj]) + 4) % P),
+             lambda m: (m.__setitem__((C_K3, kj), 0), m.__setitem__((C_K3 + 1, kj), 1)),                   # JALR as the free-pc class
+             lambda m: (m.__setitem__((C_K3, kj), 0), m.__setitem__((C_K3 + 1, kj), 1), m.__setitem__((C_OPC, kj), 12)),
+             lambda m: (m.__setitem__((C_K + 4, km), 0), m.__setitem__((C_K3 + 1, km), 1)),                 # MUL as the free-pc class
+             lambda m: m.__setitem__((C_WR + 8, kb), 1)]                                                     # BLT flags a write
+    for i, e in enumerate(edits):
+        m = m0.copy(); e(m)
+        pr = so.prove_matrix(m, pub)
+        assert so.verify(pr) == 10 and rt.verify(pr) == 10, i
+    for mutate in (lambda r: r["pc"].__setitem__(kj + 1, int(rows["pc"][kj + 1]) + 4), lambda r: r["pc"].__setitem__(km + 1, int(rows["pc"][km]) + 8),
+                   lambda r: r["registers"].__setitem__((slice(kb + 1, None), 9), 5)):
+        r = rows.copy(); mutate(r)
+        pr = so.prove(r, pub)
+        assert so.verify(pr) == 10 and rt.verify(pr) == 10
+    pr = so.prove(rows, pub)
     assert so.verify(pr) == 0 and rt.verify(pr) == 0
 
 

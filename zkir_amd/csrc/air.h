@@ -37,15 +37,15 @@
 
 namespace air {
 
-constexpr int W = 160;
+constexpr int W = 163;
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159 };
+             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162 };
 // LOGICAL vs COMMITTED columns (proof format v7).  W and the C_* map are the LOGICAL main trace: what the constraints talk about.  Columns
 // that are identically zero by the constraints themselves are not committed: R0's three limbs and its storage state (R0 is hard-wired
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
-// committed matrix is the logical one with those columns removed, zero-padded to whole B8 blocks: 144 columns in default mode (141 + 3),
-// 160 in deferred mode (156 + 4); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
+// committed matrix is the logical one with those columns removed, zero-padded to whole B8 blocks: 144 columns in default mode (exactly),
+// 160 in deferred mode (159 + 1); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
 constexpr int W_COMMITTED_DEFAULT = 144, W_COMMITTED_DEFERRED = 160;
 BB_HD constexpr bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
 BB_HD constexpr int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a committed column
@@ -67,21 +67,24 @@ enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), N_LK = LK_
 BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : C_OPC; }
 // AIR v3: class ids (= opclass values of the instruction word; halt / pad are row roles, not word classes).  A FAMILY is a pair of opcodes
 // that differ in their low bit, the polarity of one comparison: bre = BEQ / BNE, bru = BLTU / BGEU, se = SEQ / SNE, su = SLTU / SGEU.
-enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, N_CLASS = 11 };
-BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : C_K2 + (k - 7); }
+// AIR v4: jalr (JALR) and oj = "other, jumps" (BLT / BGE: the signed comparison is not stated yet — free next pc, nothing written); class
+// "other" is SEQUENTIAL (pc + 4) like every instruction that is not a branch or a jump.
+enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, N_CLASS = 13 };
+BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : C_K3 + (k - 11); }
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
-                   OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48;
+                   OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
 BB_HD constexpr uint32_t opclass_of(uint32_t op) {
   return op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
-       : (op == OP_BLTU || op == OP_BGEU) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE : (op == OP_SLTU || op == OP_SGEU) ? K_SU : (uint32_t)K_OTH;
+       : (op == OP_BLTU || op == OP_BGEU) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE : (op == OP_SLTU || op == OP_SGEU) ? K_SU : op == OP_JALR ? K_JALR
+       : (op == OP_BLT || op == OP_BGE) ? K_OJ : (uint32_t)K_OTH;
 }
 BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLTU : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0u; }   // the even opcode of a family
 
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
-enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 146,
-             I_ONE_CLASS = 154, I_OPCLASS = 155, I_WR = 156, I_SELB = 159, I_SELC = 161, I_OPERAND = 163, I_VALUE = 169, I_DIFF = 178, I_WRITTEN = 182,
-             I_NE = 187, I_FLAG = 191, I_FX = 192, I_TK = 193, I_DL0 = 194, I_SE = 195, I_PC = 196, I_PC_KEEP = 199, I_REGS = 202, I_TAIL = 262, I_LAST = 265,
-             I_CHUNK = 333, I_RANGE = 335, I_ROM = 351, I_SUM = 355, N_CONSTRAINTS = 359 };
+enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 148,
+             I_ONE_CLASS = 157, I_OPCLASS = 158, I_WR = 159, I_SELB = 162, I_SELC = 164, I_OPERAND = 166, I_VALUE = 172, I_DIFF = 181, I_WRITTEN = 185,
+             I_NE = 190, I_FLAG = 194, I_FX = 195, I_TK = 196, I_DL0 = 197, I_SE = 198, I_PC = 199, I_PC_KEEP = 202, I_JALR = 205, I_REGS = 208, I_TAIL = 268, I_LAST = 271,
+             I_CHUNK = 339, I_RANGE = 341, I_ROM = 357, I_SUM = 361, N_CONSTRAINTS = 365 };
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -168,7 +171,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int k = 0; k < N_CLASS; k++) boolean(I_BOOL_K + k, K[k]);
   const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), ne = o.loc(C_NE), tk = o.loc(C_TK);
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
-  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk);
+  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0));
   // 4. classes and the opcode
   {
     V sum = K[0];
@@ -185,8 +188,8 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   }
   // 5. selectors
   o.push(I_WR, deferred ? zero : o.sub(o.mul(w1, w1), w2));
-  o.push(I_WR + 1, o.mul(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), Kcmp), o.sub(w1, fa)));
-  o.push(I_WR + 2, o.mul(o.add(o.add(Kbr, K[K_HALT]), K[K_PAD]), w0));
+  o.push(I_WR + 1, o.mul(o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), Kcmp), K[K_JALR]), o.sub(w1, fa)));
+  o.push(I_WR + 2, o.mul(o.add(o.add(o.add(Kbr, deferred ? zero : K[K_OJ]), K[K_HALT]), K[K_PAD]), w0));   // branches write nothing (BLT / BGE too: class oj in default mode)
   o.push(I_SELB, o.sub(b1, fb)); o.push(I_SELB + 1, o.sub(o.mul(b1, b1), b2));
   o.push(I_SELC, o.sub(c1s, o.add(fc, o.mul(Kbr, o.sub(fa, fc))))); o.push(I_SELC + 1, o.sub(o.mul(c1s, c1s), c2s));
   // 6. operands
@@ -208,9 +211,10 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   o.push(I_VALUE + 3, o.mul(K[K_ADDI], o.add(o.sub(o.sub(z[0], xb[0]), im0), c0s20)));
   o.push(I_VALUE + 4, o.mul(K[K_ADDI], o.add(o.sub(o.sub(o.sub(z[1], xb[1]), im1), c0), c1s20)));
   o.push(I_VALUE + 5, o.mul(K[K_ADDI], y[2]));
-  o.push(I_VALUE + 6, o.mul(K[K_JAL], o.add(o.sub(o.sub(z[0], pc[0]), o.cst(M(4))), c0s20)));
-  o.push(I_VALUE + 7, o.mul(K[K_JAL], o.add(o.sub(o.sub(z[1], pc[1]), c0), c1s20)));
-  o.push(I_VALUE + 8, o.mul(K[K_JAL], o.sub(o.sub(y[2], pc[2]), c1)));
+  const V Kj = o.add(K[K_JAL], K[K_JALR]);                                    // both link pc + 4 (execute.rs:639-658)
+  o.push(I_VALUE + 6, o.mul(Kj, o.add(o.sub(o.sub(z[0], pc[0]), o.cst(M(4))), c0s20)));
+  o.push(I_VALUE + 7, o.mul(Kj, o.add(o.sub(o.sub(z[1], pc[1]), c0), c1s20)));
+  o.push(I_VALUE + 8, o.mul(Kj, o.sub(o.sub(y[2], pc[2]), c1)));
   // 7b. differences with borrows: z = xb - xc mod 2^40 on SUB and SLTU / SGEU rows (execute.rs:65-77, :373-407), z = xc - xb on BLTU / BGEU
   //     rows (:618-636): c1 = 1 exactly when the minuend is the smaller 40-bit value
   {
@@ -222,7 +226,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   }
   const V flag = o.loc(C_FLAG), fx = o.loc(C_FX);
   {
-    const V Ky = o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), K[K_OTH]);
+    const V Ky = o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), o.add(K[K_OTH], K[K_JALR])), deferred ? K[K_OJ] : zero);   // (oj writes only in deferred mode)
     o.push(I_WRITTEN, o.mul(Ky, o.sub(y[0], z[0]))); o.push(I_WRITTEN + 1, o.mul(Ky, o.sub(y[1], z[1])));
     o.push(I_WRITTEN + 2, o.mul(Kcmp, o.sub(y[0], fx))); o.push(I_WRITTEN + 3, o.mul(Kcmp, y[1])); o.push(I_WRITTEN + 4, o.mul(Kcmp, y[2]));
   }
@@ -251,12 +255,18 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   const V four = o.cst(M(4)), dl0 = o.loc(C_DL0);
   o.push(I_DL0, o.sub(dl0, o.add(o.add(four, o.mul(tk, o.sub(im0, four))), o.mul(K[K_JAL], o.sub(lo20, four)))));
   o.push(I_SE, o.sub(se, o.mul(o.add(tk, K[K_JAL]), s)));
-  const V hp = o.add(K[K_HALT], K[K_PAD]), kc = o.sub(o.sub(one, K[K_OTH]), hp);     // kc: every class whose next pc the AIR derives
+  // kc: pc' = pc + delta for every class but jalr (9b), oj (free) and halt / pad (keep); class "other" is in it with delta 4 (tk = 0 there): sequential
+  const V hp = o.add(K[K_HALT], K[K_PAD]), kc = o.sub(o.sub(o.sub(one, K[K_JALR]), K[K_OJ]), hp);
   o.push(I_PC, o.mul(o.mul(kc, o.add(o.sub(o.sub(npc[0], pc[0]), dl0), o.mulc(d0, M(1u << 20)))), is_trans));
   o.push(I_PC + 1, o.mul(o.mul(kc, o.add(o.sub(o.sub(o.sub(npc[1], pc[1]), o.mulc(se, M(0xFFFFF))), d0), o.mulc(d1, M(1u << 20)))), is_trans));
   o.push(I_PC + 2, o.mul(o.mul(kc, o.add(o.sub(o.sub(o.sub(npc[2], pc[2]), o.mulc(se, M(0xFFFFFF))), d1), o.mulc(d2, M(1u << 24)))), is_trans));
 #pragma unroll
   for (int l = 0; l < 3; l++) o.push(I_PC_KEEP + l, o.mul(o.mul(hp, o.sub(npc[l], pc[l])), is_trans));
+  // 9b. JALR: pc' + b0 = rs1 + sext(imm17) mod 2^64 over (20, 20, 24)-bit limbs, b0 = the bit that is cleared (execute.rs:649-658); the limbs
+  //     of pc' are a code address (every row's pc is looked up in the ROM), so the carries and b0 are forced
+  o.push(I_JALR, o.mul(o.mul(K[K_JALR], o.sub(o.add(o.add(npc[0], o.loc(C_B0)), o.mulc(d0, M(1u << 20))), o.add(xb[0], im0))), is_trans));
+  o.push(I_JALR + 1, o.mul(o.mul(K[K_JALR], o.sub(o.add(npc[1], o.mulc(d1, M(1u << 20))), o.add(o.add(xb[1], im1), d0))), is_trans));
+  o.push(I_JALR + 2, o.mul(o.mul(K[K_JALR], o.sub(o.add(npc[2], o.mulc(d2, M(1u << 24))), o.add(o.add(xb[2], o.mulc(s, M(0xFFFFFF))), d1))), is_trans));
   // 11. executed rows, the halt row, padding
   const V npad = o.nxt(C_K + K_PAD);
   o.push(I_TAIL, o.mul(o.mul(K[K_HALT], o.sub(one, npad)), is_trans));

@@ -83,7 +83,12 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
   const uint32_t op = w & 0x7F, fa = (w >> 7) & 0xF, fb = (w >> 11) & 0xF, fc = (w >> 15) & 0xF, fhi = w >> 19, s = w >> 31;
   col(C_OP) = op; col(C_FA) = fa; col(C_FB) = fb; col(C_FC) = fc; col(C_FHI) = fhi; col(C_S) = s;
   int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
-  if (cls == K_OTH && !deferred) cls = (int)opclass_of(op);
+  if (cls == K_OTH) {
+    const int wc = (int)opclass_of(op);
+    if (!deferred) cls = wc;
+    else if (wc == K_BRE || wc == K_JAL || wc == K_BRU || wc == K_JALR || wc == K_OJ) cls = K_OJ;     // deferred mode: no opcode semantics, but class "other" is sequential
+  }
+  const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;
   col(C_OPC) = opclass_of(op);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
@@ -105,8 +110,8 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_SUB || cls == K_SE || cls == K_SU) wr = fa == (uint32_t)g;
-    else if (cls == K_OTH) {                                     // any other instruction: what it wrote is read off the next row
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU) wr = fa == (uint32_t)g;
+    else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
       reg_limbs(t.registers[o + 1], nst, nl);
@@ -145,24 +150,28 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     const uint32_t b0 = cls == K_ADD ? xc[0] : im0, b1 = cls == K_ADD ? xc[1] : im1;
     const uint64_t v0 = (uint64_t)xb[0] + b0; c0 = (uint32_t)(v0 >> 20); y[0] = (uint32_t)(v0 & 0xFFFFF);
     const uint64_t v1 = (uint64_t)xb[1] + b1 + c0; c1 = (uint32_t)(v1 >> 20); y[1] = (uint32_t)(v1 & 0xFFFFF);
-  } else if (cls == K_JAL) {
+  } else if (cls == K_JAL || cls == K_JALR) {                      // the link pc + 4
     const uint64_t v0 = (uint64_t)pc[0] + 4; c0 = (uint32_t)(v0 >> 20); y[0] = (uint32_t)(v0 & 0xFFFFF);
     const uint64_t v1 = (uint64_t)pc[1] + c0; c1 = (uint32_t)(v1 >> 20); y[1] = (uint32_t)(v1 & 0xFFFFF);
     y[2] = pc[2] + c1;
   } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; }
   else if (cls == K_SE || cls == K_SU) y[0] = fx;
   col(C_Y) = y[0]; col(C_Y + 1) = y[1]; col(C_Y + 2) = y[2];
-  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_OTH) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
+  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
   col(C_Z) = z[0]; col(C_Z + 1) = z[1];
   col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
-  uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (cls != K_OTH && cls != K_HALT && cls != K_PAD) {
+  uint32_t d0 = 0, d1 = 0, d2 = 0, b0 = 0;
+  if (cls == K_JALR) {                                             // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
+    const uint64_t v0 = (uint64_t)xb[0] + im0; d0 = (uint32_t)(v0 >> 20); b0 = (uint32_t)(v0 & 1);
+    const uint64_t v1 = (uint64_t)xb[1] + im1 + d0; d1 = (uint32_t)(v1 >> 20);
+    const uint64_t v2 = (uint64_t)xb[2] + (uint64_t)s * 0xFFFFFF + d1; d2 = (uint32_t)(v2 >> 24);
+  } else if (cls != K_OJ && cls != K_HALT && cls != K_PAD) {
     const uint64_t v0 = (uint64_t)pc[0] + dl0; d0 = (uint32_t)(v0 >> 20);
     const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; d1 = (uint32_t)(v1 >> 20);
     const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; d2 = (uint32_t)(v2 >> 24);
   }
-  col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2;
+  col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2; col(C_B0) = b0;
   // the committed columns, packed: committed position p holds logical column logical_col(p); the tail of the last block is zero padding
   uint4* out4 = reinterpret_cast<uint4*>(out);
   auto at = [&](int p) -> uint32_t { return p < committed_used(DEF) ? rowv[logical_col(p < committed_used(DEF) ? p : 0, DEF)] : 0u; };

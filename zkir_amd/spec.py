@@ -239,6 +239,31 @@ def compare_loop_program() -> Program:
     ])
 
 
+def call_loop_program() -> Program:
+    """An endless loop around a subroutine call: JAL links, the callee returns through JALR — once with an even target, once with an odd one
+    and a negative immediate (the cleared bit) — with signed branches (BLT / BGE: class "other, jumps" of the AIR, v4) both ways and
+    MUL / SLLI rows in between (class "other": sequential).  Run with max_cycles."""
+    def b(op, rs1, rs2, off): return encode(op, rs1=rs1, rs2=rs2, imm=off)
+    O = Opcode
+    return Program.from_code([
+        addi(1, 0, 0), addi(2, 0, 5), addi(6, 0, 20),            # i, x, a bound
+        # L (0x100C):
+        jal(15, 24),                                             # call F (0x1024), link in r15
+        addi(1, 1, 1),                                           # i += 1
+        b(O.BLT, 1, 2, 8),                                       # i < x (signed): skip the next instruction
+        addi(2, 2, 7),                                           # x += 7
+        b(O.BGE, 1, 6, -16),                                     # i >= 20: back to L this way
+        jal(0, -20),                                             # else that way
+        # F (0x1024):
+        mul(3, 1, 2), slli(4, 3, 2),                             # "other" rows: pc + 4
+        addi(14, 15, 5),                                         # return address + 5
+        encode(O.SEQ, 5, 4, 0),                                  # i * x * 4 == 0 ?  (the first call only)
+        b(O.BEQ, 5, 0, 8),                                       # no: return the odd way
+        encode(O.JALR, 13, 15, imm=0),                           # return to r15, link r13
+        encode(O.JALR, 0, 14, imm=-4),                           # return to (r15 + 5 - 4) & ~1 = r15: negative immediate, odd sum
+    ])
+
+
 def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
     """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
     The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).
