@@ -805,8 +805,8 @@ def main():
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
             "prove_stage_roofline": _prove_stage_table(k, W, [prove_stage_ms[q] for q in PROVE_STAGES]) if prove_stage_ms else None,
-            "prover": "ZKIR-STARK, AIR v3 (self-defined; 160 main + 24 aux columns / 359 constraints: the semantics of 12 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU, SEQ/SNE, BEQ/BNE, BLTU/BGEU, JAL — + a LogUp lookup argument — instruction ROM and 10-bit ranges; "
-                      "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v6 carries the program)",
+            "prover": "ZKIR-STARK, AIR v4 (self-defined; 163 logical main-trace columns, 144 committed in default mode, + 24 aux columns / 365 constraints: the semantics of 13 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU, SEQ/SNE, BEQ/BNE, BLTU/BGEU, JAL, JALR — and the control flow of every opcode but BLT/BGE, + a LogUp lookup argument — instruction ROM and 10-bit ranges; "
+                      "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v8 carries the program)",
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,

@@ -86,15 +86,16 @@ def _fib_full_size(k, windows):
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib = rt.lib()
     pl._check(lib.zkir_main_trace_launch(C.byref(trace_c), n, 0, m.data_ptr(), sp))
-    cols_m = {c: m[c // 8, :, c % 8].cpu().numpy().view(np.uint32) for c in (0, 21)}     # cycle, r4 limb 0 (LDE clobbers m)
+    R4 = 21 - 3                                                                  # logical column 21 (r4 limb 0); R0's three limbs are not committed
+    cols_m = {c: m[c // 8, :, c % 8].cpu().numpy().view(np.uint32) for c in (0, R4)}     # cycle, r4 limb 0 (LDE clobbers m)
     pl._check(lib.zkir_lde_launch(ctx.handle, m.data_ptr(), stark.W_MAIN, L.data_ptr(), sp))
     pl._check(lib.zkir_merkle_commit_launch(ctx.handle, L.data_ptr(), stark.W_MAIN, 2 * n, tree.data_ptr(), sp))
     root = tree[-4:].cpu().numpy().view(np.uint32)
     assert np.array_equal(cols_m[0], np.arange(n, dtype=np.uint64) % P)           # cycle column of the main trace
-    assert np.array_equal(cols_m[21], (tr.column(rt.FIELD_REGISTERS, 4) & np.uint64(0xFFFFF)).astype(np.uint32))
+    assert np.array_equal(cols_m[R4], (tr.column(rt.FIELD_REGISTERS, 4) & np.uint64(0xFFFFF)).astype(np.uint32))
     from test_gpu_stark import _bary_eval
     rng = np.random.default_rng(k)
-    for c in (0, 21):                                             # the LDE is the extension of the trace column: same value at a random point
+    for c in (0, R4):                                             # the LDE is the extension of the trace column: same value at a random point
         z = int(rng.integers(2, P))
         assert _bary_eval(cols_m[c], k, 1, z) == _bary_eval(L[c // 8, :, c % 8].cpu().numpy().view(np.uint32), k + 1, 31, z), c
     for j in [0, 2 * n - 1] + [int(x) for x in rng.integers(0, 2 * n, 4)]:       # sampled leaves: oracle sponge + oracle compression up to the root

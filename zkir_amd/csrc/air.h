@@ -1,4 +1,4 @@
-// air.h — the AIR of ZKIR-STARK (v3: v2 + four comparison families and SUB): column map of the 160-column main trace and of
+// air.h — the AIR of ZKIR-STARK (v4: v2 + SUB, four comparison families, JALR, sequential control flow): column map of the 163 LOGICAL main-trace columns (144 committed in default mode) and of
 // the 24-column aux trace, and the constraint list, written
 // ONCE for the two places of the product that evaluate it: the quotient kernel (stark_prove.inl; base-field values at every point
 // of the LDE coset, lazily accumulated) and the host verifier (verify.cpp; extension-field openings at zeta).  The oracle
@@ -30,7 +30,10 @@
 //     which makes the boolean carries / borrows the only solution;
 //   the prover sends the multiplicities of both tables BEFORE the challenges (alpha, lambda) are drawn; the verifier computes the table
 //   side T = sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u) itself; the running-sum column closes over the cycle of N rows.
-// Not constrained yet: the other 38 opcodes' values (class "other"), memory consistency, deferred-mode arithmetic
+// AIR v4: JALR (link pc + 4; pc' + the cleared bit = rs1 + sext(imm17) mod 2^64), class "other" is SEQUENTIAL (pc + 4 for every opcode that is
+// not a branch or a jump), BLT / BGE run as the free-pc class "oj" and write nothing: control flow is stated for every opcode but those two.
+// Not constrained yet: the other 37 opcodes' VALUES (class "other": y is a free witness), the signed comparisons, memory
+// consistency, deferred-mode arithmetic
 // (deferred = 1 relaxes the write constraints to "unwritten registers keep their value").
 #pragma once
 #include "babybear.h"
