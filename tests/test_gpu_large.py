@@ -169,6 +169,38 @@ def test_opcode_families_2p22_semantics_on_all_rows_and_proof():
     ctx.close(); res.close()
 
 
+def test_call_loop_2p20_control_flow_on_all_rows_and_proof():
+    """AIR v4 at scale: 2^20 cycles of spec.call_loop_program — every JALR lands on (rs1 + imm) & ~1 and links pc + 4, every row that is not a
+    branch or a jump advances the pc by 4 (checked on ALL rows with numpy), and the proof of the run is accepted by both verifiers."""
+    from zkir_amd import stark
+    k = 20
+    n = 1 << k
+    blob = spec.call_loop_program().to_bytes()
+    res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run()
+    assert res.cycles == n
+    tr = res.execution_trace
+    lo, hi = n // 2 - 100, n // 2 + 100
+    helpers.assert_rows_equal(tr.rows_window(lo, hi), oracle.run(blob, max_cycles=n, enable_execution_trace=True, keep_rows=(lo, hi)).rows)
+    pc = tr.column(rt.FIELD_PC); ins = tr.column(rt.FIELD_INSTRUCTION)
+    R = np.stack([tr.column(rt.FIELD_REGISTERS, r) for r in range(16)])
+    op = (ins & 0x7F)[:-1]; fa = ((ins >> 7) & 0xF)[:-1]; fb = ((ins >> 11) & 0xF)[:-1]
+    idx = np.arange(n - 1)
+    imm = ((ins[:-1] >> 15).astype(np.int64) - ((ins[:-1] >> 31).astype(np.int64) << 17))
+    j = op == 0x49
+    assert j.sum() > n // 30
+    assert np.array_equal(pc[1:][j], (R[fb, idx][j].astype(np.int64) + imm[j]).astype(np.uint64) & ~np.uint64(1))
+    w = j & (fa != 0)
+    assert np.array_equal(R[fa, idx + 1][w], pc[:-1][w] + np.uint64(4))
+    seq = ~np.isin(op, [0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x48, 0x49])
+    assert seq.sum() > n // 3 and np.array_equal(pc[1:][seq], pc[:-1][seq] + np.uint64(4))
+    del R
+    ctx = stark.StarkContext(k)
+    pub = res.public_inputs()
+    proof = stark.prove(ctx, tr.columns, pub)
+    assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0 and proof[3] == stark.W_MAIN
+    ctx.close(); res.close()
+
+
 def test_config4_sha_chain_2p22_syscall_chip_columns():
     """configs[4]: SHA-256 hash-chain program for 2^22 cycles — trace rows, memory ops (row order, CSR, sorted), and the SHA-256
     chip columns, all behind the drop-in handle (zkir_result_*), vs the oracle on sampled windows / blocks and through full-size
