@@ -298,8 +298,10 @@ def random_program(seed: int, n_instr: int = 300, range_checking: bool = False):
             body.append(E([O.DIVU, O.REMU, O.DIV, O.REM][ri(0, 4)], reg(), src(), 6 if rng.random() < 0.97 else src()))
         elif k < 0.93:
             body.append(E([O.BEQ, O.BNE, O.BLT, O.BGE, O.BLTU, O.BGEU][ri(0, 6)], rs1=src(), rs2=src(), imm=4 * ri(1, 5)))
-        elif k < 0.95:
+        elif k < 0.94:
             body.append(spec.jal(reg() if rng.random() < 0.5 else 0, 4 * ri(1, 4)))
+        elif k < 0.95:                                               # a computed jump: link the next address, then JALR past 1..3 instructions (even and odd sums)
+            body += [spec.jal(7, 4), E(O.JALR, reg() if rng.random() < 0.5 else 0, 7, imm=4 * ri(1, 5) + ri(0, 2))]
         elif k < 0.97:
             body += [A(11, src(), 0), A(10, 0, 2), EC] if rng.random() < 0.5 else [A(10, 0, 1), EC, A(reg(), 10, 0)]
         else:

@@ -101,7 +101,7 @@ while time.time() < t_end:
         try:
             proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, cfg["enable_deferred_model"]))
         except rt.RuntimeError as e:
-            # AIR v2: a run that executes a word that is not the program's (a store into the code segment, a pc outside it) has no proof; the
+            # a run that executes a word that is not the program's (a store into the code segment, a pc outside it) has no proof; the
             # honest GPU prover refuses it — and the proof the oracle's prover emits for the same rows must be one the verifiers reject
             assert e.code == rt.ERR_ARGUMENT and "code table" in e.message, e.message
             assert so.verify(want) != 0 and rt.verify(want) == so.verify(want), "refused by the prover but accepted by a verifier"
@@ -109,9 +109,11 @@ while time.time() < t_end:
             log.close()
             continue
         assert np.array_equal(proof, want), ("proof", log_n)
-        assert rt.verify(proof) == so.verify(proof), "verdicts"
-        # random programs need not satisfy the AIR (e.g. a write to R0's shadow is impossible, but flags are data-driven): the
-        # verifier's verdict must at least be the same for both provers' (identical) words
+        # COMPLETENESS: an honest execution of ANY program the prover does not refuse satisfies the AIR — every opcode class, every halt, both
+        # modes: both verifiers accept (since AIR v4 class "other" is sequential and JALR / the branches are stated: a random program is
+        # the test that no opcode advances the pc or writes registers in a way the constraints did not foresee)
+        v_o, v_p = so.verify(proof, opub), rt.verify(proof)
+        assert v_o == 0 and v_p == 0, ("an honest run was rejected", v_o, v_p, log_n, cfg)
         n_proof += 1
         log.close()
 print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_wit} witness sets, {n_proof} traces + proofs identical to the oracle, "
