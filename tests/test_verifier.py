@@ -44,6 +44,28 @@ def test_accepts_what_the_oracle_accepts(n, prog, cfg):
     assert rt.verify(t) == so.verify(t) == 3
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_honest_runs_of_random_programs_are_accepted(seed):
+    """Completeness of the AIR: an honest execution of ANY program (every opcode class, data-dependent branches, JALR, syscalls, either
+    mode) that stays inside its code segment satisfies every constraint — class "other" rows really advance the pc by 4 and write at
+    most one register, B-type rows write nothing.  Oracle prover, both verifiers."""
+    import programs
+    blob, inputs = programs.random_program(1000 + seed, n_instr=150)
+    deferred = bool(seed & 1)
+    try:
+        res = oracle.run(blob, inputs, max_cycles=200 + 37 * seed, enable_execution_trace=True, enable_deferred_model=deferred)
+    except oracle.OracleError:
+        pytest.skip("this random program errors out (no trace to prove)")
+    pub = so.public_inputs(len(res.rows), blob, list(inputs), list(res.outputs), (res.halt_kind, res.halt_code), deferred=deferred)
+    pr = so.prove(res.rows, pub)
+    code = so.verify(pr, pub)
+    if code != 0:                                                 # only acceptable reason: the run left its code segment (no ROM row for that pc)
+        in_code = (res.rows["pc"] >= 0x1000) & (res.rows["pc"] < 0x1000 + int.from_bytes(blob[16:20], "little"))
+        assert not in_code.all(), code
+        pytest.skip("this random program jumps out of its code segment: unprovable by design")
+    assert rt.verify(pr) == 0 and rt.verify(pr, _pub_c(pub)) == 0
+
+
 def test_public_inputs_and_digests():
     blob = spec.fib_program(12).to_bytes()
     for data in (b"", b"a", b"hello", blob, bytes(range(256)) * 5):
