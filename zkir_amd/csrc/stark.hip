@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
   col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2; col(C_B0) = b0;
   // the committed columns, packed: committed position p holds logical column logical_col(p); the tail of the last block is zero padding
   uint4* out4 = reinterpret_cast<uint4*>(out);
-  auto at = [&](int p) -> uint32_t { return p < committed_used(DEF) ? rowv[logical_col(p < committed_used(DEF) ? p : 0, DEF)] : 0u; };
+  auto at = [&](int p) -> uint32_t { return p < committed_used(DEF) ? rowv[logical_col(p < committed_used(DEF) ? p : 0, DEF)] : 0u; };   // (inner clamp: the index stays inside rowv for the padding positions too)
 #pragma unroll
   for (int b = 0; b < committed_width(DEF) / 8; b++) {
     out4[((uint64_t)b * N + i) * 2] = make_uint4(at(8 * b), at(8 * b + 1), at(8 * b + 2), at(8 * b + 3));
