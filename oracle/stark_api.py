@@ -8,12 +8,12 @@ import numpy as np
 from . import api
 
 P = 2013265921
-W_MAIN = 163                # LOGICAL main-trace columns (what main_trace() returns and the constraints read)
-W_COMMITTED = 144           # columns of the committed matrix in the default VM mode (R0's limbs and the storage states are identically zero there)
-W_COMMITTED_DEFERRED = 160  # deferred mode: only R0's limbs and state are left out
-W_AUX = 24                  # aux trace of the lookup argument: H0..H3, HR, S as four base columns each
+W_MAIN = 169                # LOGICAL main-trace columns (what main_trace() returns and the constraints read)
+W_COMMITTED = 152           # columns of the committed matrix in the default VM mode (R0's limbs and the storage states are identically zero there)
+W_COMMITTED_DEFERRED = 168  # deferred mode: only R0's limbs and state are left out
+W_AUX = 40                  # aux trace of the lookup argument: H0..H7, HR, S as four base columns each
 RC_TABLE = 1024
-N_LK = 52                   # lookup parameters: alpha (4), lambda^0..10 (44), T / N (4)
+N_LK = 56                   # lookup parameters: alpha (4), lambda^0..11 (48), T / N (4)
 HEADER_WORDS = 157
 _bound = False
 
@@ -181,7 +181,7 @@ def to_committed(matrix: np.ndarray, deferred=False) -> np.ndarray:
 
 
 def lookup_setup(matrix: np.ndarray, pub: PublicC, alpha_l, lam):
-    """The lookup side of a main-trace matrix for GIVEN challenges: (aux trace [W_AUX][N], lk[52] = alpha, lambda powers, T / N,
+    """The lookup side of a main-trace matrix for GIVEN challenges: (aux trace [W_AUX][N], lk[56] = alpha, lambda powers, T / N,
     ROM multiplicities, range multiplicities)."""
     m, a, l = _u32(matrix), _u32(alpha_l), _u32(lam)
     n = m.shape[1]

@@ -180,10 +180,12 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //           not a branch or a jump (loads, stores, the remaining ALU opcodes, ECALL: execute.rs advances pc by 4 in each of them)
 //   162 b0 = the bit JALR clears: next pc + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs mod 2^64 (execute.rs:649-658), carries d0 d1 d2
 // ---------------------------------------------------------------------------------------------
-static const int W_MAIN = 163;
+static const int W_MAIN = 169;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162 };
+       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168 };
+static const int N_RC = 8;                                         // range lookups of a row: the chunks of z (C_RC ..) and of u (C_RC2 ..)
+static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 24 base columns = six extension-field columns,
 // coordinate by coordinate: H0..H3 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
 // S = running sum of (H0 + H1 + H2 + H3 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
@@ -194,10 +196,10 @@ enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8,
 // states.  The committed ("physical") matrix is the logical one with those columns removed, zero-padded to whole blocks of 8:
 // 144 columns in default mode (141 + 3), 160 in deferred mode (156 + 4).  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
-static const int W_AUX = 24;
+static const int W_AUX = 40;
 static inline bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
 static inline int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a non-virtual column
-static inline int phys_width(bool deferred) { return deferred ? 160 : 144; }
+static inline int phys_width(bool deferred) { return deferred ? 168 : 152; }   // 169 - 19 = 150 -> 152, 169 - 4 = 165 -> 168
 // logical [W_MAIN][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, bool deferred, std::vector<F>& out) {
   out.assign((size_t)phys_width(deferred) * N, 0);
@@ -208,9 +210,9 @@ template <class V>
 static void to_logical_row(const V* phys, bool deferred, const V& zero, V* logical) {
   for (int c = 0; c < W_MAIN; c++) logical[c] = is_virtual(c, deferred) ? zero : phys[phys_col(c, deferred)];
 }
-enum { A_H = 0, A_HR = 16, A_S = 20 };
+enum { A_H = 0, A_HR = 32, A_S = 36 };
 static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the reference's range-check table: 2^(limb_bits/2) entries (range_check.rs:29, config.rs:78-80)
-static const int N_TUPLE = 10;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass
+static const int N_TUPLE = 11;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass, g (variant bit)
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
 
 enum { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, N_CLASS = 13 };
@@ -218,7 +220,11 @@ static inline int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7)
 static const uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                       OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
 // the even opcode of a family (its polarity-0 member); 0 for the classes that are one opcode
-static inline uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLTU : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0; }
+static inline uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLT : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0; }
+// AIR v5: the families of ordered comparisons have FOUR members, op = base + 2 g + pol: SLTU SGEU SLT SGE (base 0x20, g = signed) and
+// BLT BGE BLTU BGEU (base 0x42, g = unsigned).  g is the word's VARIANT BIT, part of the ROM tuple (0 for every other opcode).
+static const uint32_t OP_SLT = 0x22, OP_SGE = 0x23;
+static inline uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU) ? 1u : 0u; }
 
 #pragma pack(push, 1)
 struct PackedRow { uint64_t cycle, pc; uint32_t instruction; uint64_t registers[16]; uint32_t bound_bits[16]; uint8_t bound_tag[16]; uint64_t bound_payload[16]; uint8_t reg_state[16]; };
@@ -252,8 +258,9 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
 static inline F opclass_of(uint32_t op) {
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
-    case OP_BLTU: case OP_BGEU: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE; case OP_SLTU: case OP_SGEU: return K_SU;
-    case OP_JALR: return K_JALR; case OP_BLT: case OP_BGE: return K_OJ; default: return K_OTH;
+    case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
+    case OP_SLTU: case OP_SGEU: case OP_SLT: case OP_SGE: return K_SU;
+    case OP_JALR: return K_JALR; default: return K_OTH;
   }
 }
 // The instruction ROM of a program blob (Program::to_bytes layout, program.rs:170-214,300-346): code word t sits at pc = 0x1000 + 4 t
@@ -261,7 +268,7 @@ static inline F opclass_of(uint32_t op) {
 struct Rom { std::vector<F> rows; size_t n = 0; uint64_t entry = 0; bool ok = false; const F* row(size_t t) const { return &rows[t * N_TUPLE]; } };
 static inline void rom_tuple(uint64_t pc, uint32_t w, F out[N_TUPLE]) {
   out[0] = (F)(pc & 0xFFFFF); out[1] = (F)((pc >> 20) & 0xFFFFF); out[2] = (F)(pc >> 40);
-  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F);
+  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F); out[10] = variant_bit(w & 0x7F);
 }
 static Rom rom_from_blob(const uint8_t* b, size_t n) {
   Rom r;
@@ -321,14 +328,25 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     for (int l = 0; l < 3; l++) if (!ne && xb[l] != xc[l]) { ne = 1; col(C_IV + l)[i] = finv(fsub(xb[l], xc[l])); }
     col(C_NE)[i] = ne;
     // the 40-bit difference of the masked operands and its borrows: xb - xc (SUB, SLTU / SGEU: rs1 = field b), xc - xb (BLTU / BGEU: rs1 = field a)
-    F z[2] = {0, 0}, c0 = 0, c1 = 0;
+    //   (v5) ordered comparisons, signed or not: the high limbs enter BIASED, t = limb + 2^19 sgn - 2^20 (sign bit) — the limb of value XOR 2^39
+    //   when the comparison is signed (Value40::signed_lt, value.rs:710-716), the limb itself when it is not; u = (ta, tb) is the row's SECOND
+    //   range-checked pair (chunks C_RC2 ..), which forces the sign bits; the borrow out of the biased difference is the comparison
+    F z[2] = {0, 0}, c0 = 0, c1 = 0, u[2] = {0, 0}, sa = 0, sb = 0;
+    const F g = variant_bit(op);
+    col(C_G)[i] = g;
     if (cls == K_SUB || cls == K_SU || cls == K_BRU) {
       const F* a = cls == K_BRU ? xc : xb; const F* b = cls == K_BRU ? xb : xc;
+      const F sgn = cls == K_SU ? g : cls == K_BRU ? 1 - g : 0;
+      if (sgn) { sa = a[1] >> 19; sb = b[1] >> 19; }
+      const int64_t ta = (int64_t)a[1] + ((int64_t)sgn << 19) - ((int64_t)sa << 20), tb = (int64_t)b[1] + ((int64_t)sgn << 19) - ((int64_t)sb << 20);
       const int64_t v0 = (int64_t)a[0] - b[0]; c0 = v0 < 0; z[0] = (F)(v0 + ((int64_t)c0 << 20));
-      const int64_t v1 = (int64_t)a[1] - b[1] - c0; c1 = v1 < 0; z[1] = (F)(v1 + ((int64_t)c1 << 20));
+      const int64_t v1 = ta - tb - c0; c1 = v1 < 0; z[1] = (F)(v1 + ((int64_t)c1 << 20));
+      if (cls != K_SUB) { u[0] = (F)ta; u[1] = (F)tb; }
     }
+    col(C_SB)[i] = sb;
+    col(C_RC2)[i] = u[0] & (RC_TABLE - 1); col(C_RC2 + 1)[i] = u[0] >> RC_BITS; col(C_RC2 + 2)[i] = u[1] & (RC_TABLE - 1); col(C_RC2 + 3)[i] = u[1] >> RC_BITS;
     const F flag = (cls == K_BRE || cls == K_SE) ? 1 - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0;
-    const F pol = fsub(op, family_base(cls));               // 0 / 1 inside a family; the opcode itself on every other row (fx is unused there)
+    const F pol = fsub(fsub(op, family_base(cls)), 2 * g);  // op = base + 2 g + pol: 0 / 1 inside a family; the opcode itself on every other row (fx is unused there)
     const F fx = fsub(fadd(flag, pol), fmul(2, fmul(pol, flag)));
     col(C_FLAG)[i] = flag; col(C_FX)[i] = fx;
     const F tk = branch ? fx : 0;
@@ -375,7 +393,8 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       const uint64_t v1 = (uint64_t)xb[1] + im1 + d0; const F d1 = (F)(v1 >> 20);
       const uint64_t v2 = (uint64_t)xb[2] + (uint64_t)s * 0xFFFFFF + d1; const F d2 = (F)(v2 >> 24);
       col(C_D0)[i] = d0; col(C_D1)[i] = d1; col(C_D2)[i] = d2; col(C_B0)[i] = (F)(v0 & 1);
-    } else if (cls != K_OJ && cls != K_HALT && cls != K_PAD) {                                      // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
+    } else if (cls != K_OJ && cls != K_HALT && cls != K_PAD) {
+      col(C_B0)[i] = sa;                                                                              // (v5) column b0 doubles as the sign bit of the first operand of an ordered comparison                                      // pc' = pc + delta over (20, 20, 24)-bit limbs, mod 2^64
       const uint64_t v0 = (uint64_t)pc[0] + dl0; const F d0 = (F)(v0 >> 20);
       const uint64_t v1 = (uint64_t)pc[1] + (uint64_t)se * 0xFFFFF + d0; const F d1 = (F)(v1 >> 20);
       const uint64_t v2 = (uint64_t)pc[2] + (uint64_t)se * 0xFFFFFF + d1; const F d2 = (F)(v2 >> 24);
@@ -416,7 +435,7 @@ static inline E fingerprint(const F* tuple, const LookupParams& lp) {        // 
   return fp;
 }
 static inline void row_tuple(const std::vector<F>& M, size_t N, size_t i, F out[N_TUPLE]) {
-  static const int cols[N_TUPLE] = {C_PC, C_PC + 1, C_PC + 2, C_OP, C_FA, C_FB, C_FC, C_FHI, C_S, C_OPC};
+  static const int cols[N_TUPLE] = {C_PC, C_PC + 1, C_PC + 2, C_OP, C_FA, C_FB, C_FC, C_FHI, C_S, C_OPC, C_G};
   for (int j = 0; j < N_TUPLE; j++) out[j] = M[(size_t)cols[j] * N + i];
 }
 // Multiplicities of the two tables over ALL N rows of the matrix (padding rows repeat the last executed row's instruction and have
@@ -425,7 +444,7 @@ static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& 
   rom_mult.assign(rom.n, 0); rc_mult.assign(RC_TABLE, 0);
   if (first_bad_row) *first_bad_row = (size_t)-1;
   for (size_t i = 0; i < N; i++) {
-    for (int k = 0; k < 4; k++) { const F v = M[(size_t)(C_RC + k) * N + i]; if (v < (F)RC_TABLE) rc_mult[v]++; else if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i; }
+    for (int k = 0; k < N_RC; k++) { const F v = M[(size_t)rc_col(k) * N + i]; if (v < (F)RC_TABLE) rc_mult[v]++; else if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i; }
     F t[N_TUPLE]; row_tuple(M, N, i, t);
     const uint64_t pc = (uint64_t)t[0] | ((uint64_t)t[1] << 20) | ((uint64_t)t[2] << 40);
     const uint64_t u = (pc - 0x1000) / 4;
@@ -457,19 +476,20 @@ static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, c
 // aux trace [W_AUX][N] of the main-trace matrix M: helper columns of the five lookups of every row and the running sum
 static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp, std::vector<F>& A) {
   A.assign((size_t)W_AUX * N, 0);
-  std::vector<E> d(5 * N);
+  const int NH = N_RC + 1;
+  std::vector<E> d((size_t)NH * N);
   for (size_t i = 0; i < N; i++) {
-    for (int k = 0; k < 4; k++) d[5 * i + k] = esub(lp.alpha, e_from(M[(size_t)(C_RC + k) * N + i]));
+    for (int k = 0; k < N_RC; k++) d[NH * i + k] = esub(lp.alpha, e_from(M[(size_t)rc_col(k) * N + i]));
     F t[N_TUPLE]; row_tuple(M, N, i, t);
-    d[5 * i + 4] = esub(lp.alpha, fingerprint(t, lp));
+    d[NH * i + N_RC] = esub(lp.alpha, fingerprint(t, lp));
   }
   batch_einv(d);
   E S = e_from(0);
   for (size_t i = 0; i < N; i++) {
     E hs = e_from(0);
-    for (int k = 0; k < 5; k++) {
-      const E& h = d[5 * i + k];
-      for (int c = 0; c < 4; c++) A[(size_t)((k < 4 ? A_H + 4 * k : A_HR) + c) * N + i] = h.c[c];
+    for (int k = 0; k < NH; k++) {
+      const E& h = d[NH * i + k];
+      for (int c = 0; c < 4; c++) A[(size_t)((k < N_RC ? A_H + 4 * k : A_HR) + c) * N + i] = h.c[c];
       hs = eadd(hs, h);
     }
     for (int c = 0; c < 4; c++) A[(size_t)(A_S + c) * N + i] = S.c[c];       // S_i = sum over rows j < i of (hsum_j - T / N); S_0 = 0
@@ -480,8 +500,8 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
-static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 384;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 8;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns)
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 448;
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 9;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
@@ -547,7 +567,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   for (int r = 0; r < 16; r++) boolean(loc[C_STATE + r]);
   for (int r = 0; r < 15; r++) { boolean(loc[C_WR + r]); boolean(loc[C_SELB + r]); boolean(loc[C_SELC + r]); }
   for (int k = 0; k < N_CLASS; k++) boolean(K[k]);
-  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]);
+  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]); boolean(loc[C_SB]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
   { E sum = e_from(0); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
@@ -599,10 +619,22 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   //     BGEU rows (:618-636); c1 = 1 exactly when the minuend is the smaller 40-bit value (z's limbs are in range, so the borrows are forced)
   {
     const E Ks = eadd(K[K_SUB], K[K_SU]);
+    // (v5) ordered comparisons, signed or not (op = base + 2 g + pol; sgn = g on SLTU.. rows, 1 - g on BLT.. rows): the high limbs enter biased,
+    // ta = a1 + 2^19 sgn - 2^20 sa, tb likewise with sb — the limbs of value XOR 2^39 when sgn = 1 (value.rs:710-716) — so ta - tb = a1 - b1 -
+    // 2^20 (sa - sb); u = (ta, tb) is the second range-checked pair of the row, which forces sa / sb to be the sign bits (to be 0 when sgn = 0)
+    const E sab = emul(two20, esub(loc[C_B0], loc[C_SB]));
     push(emul(Ks, esub(eadd(esub(z[0], xb[0]), xc[0]), emul(two20, c0))));
-    push(emul(Ks, esub(eadd(eadd(esub(z[1], xb[1]), xc[1]), c0), emul(two20, c1))));
+    push(emul(K[K_SUB], esub(eadd(eadd(esub(z[1], xb[1]), xc[1]), c0), emul(two20, c1))));
+    push(emul(K[K_SU], eadd(esub(eadd(eadd(esub(z[1], xb[1]), xc[1]), c0), emul(two20, c1)), sab)));
     push(emul(K[K_BRU], esub(eadd(esub(z[0], xc[0]), xb[0]), emul(two20, c0))));
-    push(emul(K[K_BRU], esub(eadd(eadd(esub(z[1], xc[1]), xb[1]), c0), emul(two20, c1))));
+    push(emul(K[K_BRU], eadd(esub(eadd(eadd(esub(z[1], xc[1]), xb[1]), c0), emul(two20, c1)), sab)));
+    const E* R2 = loc + C_RC2;
+    const E u0 = eadd(R2[0], emul_f(R2[1], RC_TABLE)), u1 = eadd(R2[2], emul_f(R2[3], RC_TABLE));
+    const E two19 = cst(1u << 19), gsu = emul(two19, loc[C_G]), gbr = emul(two19, esub(one, loc[C_G]));
+    push(emul(K[K_SU], eadd(esub(esub(u0, xb[1]), gsu), emul(two20, loc[C_B0]))));
+    push(emul(K[K_SU], eadd(esub(esub(u1, xc[1]), gsu), emul(two20, loc[C_SB]))));
+    push(emul(K[K_BRU], eadd(esub(esub(u0, xc[1]), gbr), emul(two20, loc[C_B0]))));
+    push(emul(K[K_BRU], eadd(esub(esub(u1, xb[1]), gbr), emul(two20, loc[C_SB]))));
   }
   //     the written value: y = z on arithmetic and "other" rows, (fx, 0, 0) on comparison rows
   {
@@ -623,6 +655,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   {
     E pol = op;
     for (int k = 0; k < N_CLASS; k++) if (family_base(k)) pol = esub(pol, emul_f(K[k], family_base(k)));
+    pol = esub(pol, emul_f(loc[C_G], 2));                                   // (v5) op = base + 2 g + pol in the four-member families; g = 0 elsewhere
     push(esub(esub(esub(loc[C_FX], loc[C_FLAG]), pol), emul_f(emul(pol, loc[C_FLAG]), P - 2)));      // fx - flag - pol + 2 pol flag
   }
   push(esub(loc[C_TK], emul(Kbr, loc[C_FX])));
@@ -673,16 +706,16 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   push(esub(esub(z[0], R[0]), emul_f(R[1], RC_TABLE)));
   push(esub(esub(z[1], R[2]), emul_f(R[3], RC_TABLE)));
   // 14. range helpers: H_i (alpha - R_i) = 1
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < N_RC; i++) {
     E d[4], pr[4];
     for (int k = 0; k < 4; k++) d[k] = cst(lp.alpha.c[k]);
-    d[0] = esub(d[0], R[i]);
+    d[0] = esub(d[0], loc[rc_col(i)]);
     ext_mul(aloc + A_H + 4 * i, d, pr);
     push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
   }
   // 15. instruction ROM: HR (alpha - fingerprint(pc limbs, op, fa, fb, fc, fhi, s, opclass)) = 1
   {
-    static const int cols[N_TUPLE] = {C_PC, C_PC + 1, C_PC + 2, C_OP, C_FA, C_FB, C_FC, C_FHI, C_S, C_OPC};
+    static const int cols[N_TUPLE] = {C_PC, C_PC + 1, C_PC + 2, C_OP, C_FA, C_FB, C_FC, C_FHI, C_S, C_OPC, C_G};
     E d[4], pr[4];
     for (int k = 0; k < 4; k++) {
       E fp = cst(lp.lam[N_TUPLE].c[k]);
@@ -696,7 +729,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   //     side telescopes to zero, so the row side of the LogUp identity equals T, the table side the verifier computed.
   for (int k = 0; k < 4; k++) {
     E hs = aloc[A_HR + k];
-    for (int i = 0; i < 4; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
+    for (int i = 0; i < N_RC; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
     push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
   }
   result = A.acc;

@@ -145,12 +145,12 @@ def test_merkle_layers_and_paths():
 # column map of the main trace (AIR v3: oracle/stark_oracle.cpp)
 C_PC, C_OP, C_FA, C_LIMB, C_STATE, C_WR, C_SELB, C_SELC, C_XB, C_XC, C_Y, C_K, C_OPC, C_RC, C_S, C_C0, C_D0, C_DL0, C_NE, C_IV, C_TK = \
     1, 4, 5, 9, 57, 73, 88, 103, 118, 121, 124, 127, 134, 135, 139, 141, 143, 146, 147, 148, 151
-C_K2, C_Z, C_FLAG, C_FX, C_K3, C_B0 = 152, 156, 158, 159, 160, 162
+C_K2, C_Z, C_FLAG, C_FX, C_K3, C_B0, C_RC2, C_G, C_SB = 152, 156, 158, 159, 160, 162, 163, 167, 168
 K_ADD, K_ADDI, K_BRE, K_JAL, K_OTH, K_HALT, K_PAD, K_SUB, K_BRU, K_SE, K_SU, K_JALR, K_OJ = range(13)
 K_BNE = K_BRE                                                    # BEQ / BNE share a class: the family's comparison with either polarity
 KCOL = [C_K + k for k in range(7)] + [C_K2 + k for k in range(4)] + [C_K3 + k for k in range(2)]
 W = so.W_MAIN
-OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU, 0x49: K_JALR, 0x42: K_OJ, 0x43: K_OJ}
+OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU, 0x22: K_SU, 0x23: K_SU, 0x49: K_JALR, 0x42: K_BRU, 0x43: K_BRU}
 
 
 def test_main_trace_columns_and_commit():
@@ -159,7 +159,7 @@ def test_main_trace_columns_and_commit():
     rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
     pub = so.public_inputs(n, blob)
     m = so.main_trace(rows, pub)
-    assert m.shape == (163, 64) and (m < P).all()
+    assert m.shape == (169, 64) and (m < P).all()
     assert list(m[0]) == list(range(64))                         # the cycle column keeps counting through the padding
     assert np.array_equal(m[1][:n], rows["pc"] & 0xFFFFF) and not m[3].any()
     assert np.array_equal(m[C_OP][:n], rows["instruction"] & 0x7F)
@@ -185,7 +185,7 @@ def test_main_trace_columns_and_commit():
     # opclass = class of the instruction WORD on every row (halt and padding rows included); the range chunks split y's two low limbs
     opc = np.array([OPCLASS.get(int(o), K_OTH) for o in m[C_OP]])
     assert np.array_equal(m[C_OPC], opc)
-    assert (m[C_RC:C_RC + 4] < 1024).all()
+    assert (m[C_RC:C_RC + 4] < 1024).all() and not m[C_RC2:C_RC2 + 4].any() and not m[C_G].any() and not m[C_SB].any()   # the second range-checked pair serves ordered comparisons only
     assert np.array_equal(m[C_RC] + 1024 * m[C_RC + 1], m[C_Z]) and np.array_equal(m[C_RC + 2] + 1024 * m[C_RC + 3], m[C_Z + 1])
     wrote = cls[K_ADD] | cls[K_ADDI] | cls[K_JAL]
     assert np.array_equal(m[C_Z][wrote == 1], m[C_Y][wrote == 1]) and not m[C_Z][wrote == 0].any()      # z = the written limbs; zero on BNE / halt / pad rows
@@ -193,25 +193,25 @@ def test_main_trace_columns_and_commit():
     assert (m[C_LIMB:C_STATE + 16, n:] == m[C_LIMB:C_STATE + 16, n - 1:n]).all() and (m[C_PC:C_PC + 3, n:] == m[C_PC:C_PC + 3, n - 1:n]).all()
     root, L = so.commit_trace(rows, 1, want_lde=True, pub=pub)
     # what is committed: the logical matrix minus the columns that are identically zero (R0's limbs, the 16 storage states of the default
-    # mode), packed: 144 columns, whole blocks of 8
-    kept = [c for c in range(163) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16)]
-    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 144
+    # mode), packed: 150 columns + 2 of zero padding = 152, whole blocks of 8
+    kept = [c for c in range(169) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16)]
+    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 150
     mc = so.to_committed(m)
-    assert mc.shape == (144, 64) and np.array_equal(mc, m[kept])
-    assert L.shape == (144, 128)
+    assert mc.shape == (152, 64) and np.array_equal(mc[:150], m[kept]) and not mc[150:].any()
+    assert L.shape == (152, 128)
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
     coeffs, col = so.lde(m[C_WR], 1)
     assert np.array_equal(col, L[C_WR - 19])
-    # deferred mode keeps the storage states (only R0's limbs and state are left out): 159 columns + 1 of zero padding
+    # deferred mode keeps the storage states (only R0's limbs and state are left out): 165 columns + 3 of zero padding
     rows_d = oracle.run(blob, max_cycles=n, enable_execution_trace=True, enable_deferred_model=True).rows
     pub_d = so.public_inputs(n, blob, deferred=True)
     m_d = so.main_trace(rows_d, pub_d)
-    kept_d = [c for c in range(163) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
+    kept_d = [c for c in range(169) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
     mc_d = so.to_committed(m_d, deferred=True)
-    assert mc_d.shape == (160, 64) and np.array_equal(mc_d[:159], m_d[kept_d]) and not mc_d[159:].any() and m_d[C_STATE + 1:C_STATE + 16].any()
-    assert so.commit_trace(rows_d, 1, want_lde=True, pub=pub_d)[1].shape == (160, 128)
+    assert mc_d.shape == (168, 64) and np.array_equal(mc_d[:165], m_d[kept_d]) and not mc_d[165:].any() and m_d[C_STATE + 1:C_STATE + 16].any()
+    assert so.commit_trace(rows_d, 1, want_lde=True, pub=pub_d)[1].shape == (168, 128)
 
 
 def test_main_trace_of_the_opcode_families():
@@ -260,6 +260,117 @@ def test_main_trace_of_the_opcode_families():
     assert seen == {(op, v) for op in (0x01, 0x20, 0x21, 0x24, 0x25, 0x40, 0x41, 0x44, 0x45) for v in (0, 1)}
 
 
+def _s40(v):
+    v &= (1 << 40) - 1
+    return v - (1 << 40) if v >> 39 else v
+
+
+def test_main_trace_of_the_signed_comparisons():
+    """AIR v5: SLT / SGE / BLT / BGE rows of spec.signed_loop_program (and SLTU / SGEU / BLTU for contrast): class = the unsigned family's,
+    the word's variant bit g (op = base + 2 g + pol), the sign bits, the biased high limbs as the second range-checked pair u, the borrow of
+    the biased difference = Value40::signed_lt (value.rs:710-716), polarity, the value written / the branch decision — against the VM's rows."""
+    blob = spec.signed_loop_program().to_bytes()
+    n = 700
+    rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
+    pub = so.public_inputs(n, blob)
+    m = so.main_trace(rows, pub)
+    cls = m[KCOL]
+    assert (cls.sum(axis=0) == 1).all()
+    M40 = (1 << 40) - 1
+    seen = set()
+    for i in range(n - 1):
+        w = int(rows["instruction"][i]); op = w & 0x7F; k = OPCLASS.get(op, K_OTH)
+        assert cls[k][i] == 1 and m[C_OPC, i] == k
+        assert m[C_G, i] == int(op in (0x22, 0x23, 0x44, 0x45))
+        if k not in (K_SU, K_BRU):
+            assert not m[C_RC2:C_RC2 + 4, i].any() and m[C_SB, i] == 0
+            continue
+        fa, fb, fc = (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF
+        reg = [int(v) for v in rows["registers"][i]]
+        a, b = (reg[fb] & M40, reg[fc] & M40) if k == K_SU else (reg[fa] & M40, reg[fb] & M40)
+        signed = op in (0x22, 0x23, 0x42, 0x43)
+        sa, sb = (a >> 39, b >> 39) if signed else (0, 0)
+        assert (int(m[C_B0, i]), int(m[C_SB, i])) == (sa, sb)
+        u = [int(m[C_RC2, i]) + 1024 * int(m[C_RC2 + 1, i]), int(m[C_RC2 + 2, i]) + 1024 * int(m[C_RC2 + 3, i])]
+        bias = (1 << 19) if signed else 0
+        assert u == [(a >> 20) + bias - (sa << 20), (b >> 20) + bias - (sb << 20)] and (m[C_RC2:C_RC2 + 4, i] < 1024).all()
+        lt = int(_s40(a) < _s40(b)) if signed else int(a < b)
+        assert m[C_C0 + 1, i] == lt == m[C_FLAG, i] and m[C_FX, i] == lt ^ (op & 1)
+        z = int(m[C_Z, i]) | (int(m[C_Z + 1, i]) << 20)
+        assert z == ((a ^ (bias << 20)) - (b ^ (bias << 20))) & M40                # the difference of the biased values
+        if k == K_BRU:
+            taken = int(rows["pc"][i + 1]) != int(rows["pc"][i]) + 4
+            assert m[C_TK, i] == int(taken) == m[C_FX, i] and not m[C_WR:C_WR + 15, i].any()
+            seen.add((op, taken, sa, sb))
+        else:
+            assert int(rows["registers"][i + 1, fa]) == m[C_FX, i] and [int(m[C_Y + l, i]) for l in range(3)] == [int(m[C_FX, i]), 0, 0]
+            seen.add((op, int(m[C_FX, i]), sa, sb))
+    for op in (0x22, 0x23, 0x42, 0x43):                           # every signed comparison came out both ways, on every combination of operand signs it can
+        assert {(o, v) for (o, v, _, _) in seen if o == op} == {(op, 0), (op, 1)}
+    assert {(x, y) for (o, _, x, y) in seen if o in (0x22, 0x23)} == {(0, 0), (1, 1), (1, 0), (0, 1)}
+    assert {(x, y) for (o, _, x, y) in seen if o in (0x42, 0x43)} == {(0, 0), (1, 1), (1, 0), (0, 1)}
+    assert so.verify(so.prove(rows, pub)) == 0
+
+
+def test_wrong_execution_of_the_signed_comparisons_is_rejected():
+    """AIR v5 on spec.signed_loop_program: a signed comparison written the wrong way round, a signed branch going the other way (taken and
+    not taken), forged sign bits (with the biased limb moved along: it leaves its range), a forged borrow, an unsigned comparison run as a
+    signed one — rejected at the constraint check."""
+    rows0, pub = _run(700, "sgn")
+    ops = rows0["instruction"] & 0x7F
+    rd_of = (rows0["instruction"] >> 7) & 0xF
+    m0 = so.main_trace(rows0, pub)
+
+    def rejected(rows):
+        return so.verify(so.prove(rows, pub)) == 10
+    for op in (0x22, 0x23):
+        for want in (0, 1):
+            ks = [int(k) for k in np.nonzero(ops[:-1] == op)[0] if int(rows0["registers"][k + 1, rd_of[k]]) == want]
+            k = ks[len(ks) // 2]; rd = int(rd_of[k])
+            later = np.nonzero((rd_of[k + 1:] == rd) & ~np.isin(ops[k + 1:], (0x42, 0x43, 0x44, 0x45)))[0]
+            hi = k + 2 + int(later[0]) if len(later) else len(rows0)
+            rows = rows0.copy(); rows["registers"][k + 1:hi, rd] ^= 1
+            assert rejected(rows), (hex(op), want)
+    for op in (0x42, 0x43):
+        for want_taken in (False, True):
+            ks = [int(k) for k in np.nonzero(ops[:-1] == op)[0] if (int(rows0["pc"][k + 1]) != int(rows0["pc"][k]) + 4) == want_taken]
+            k = ks[len(ks) // 2]
+            w = int(rows0["instruction"][k]); imm = (w >> 15) - (1 << 17 if w >> 31 else 0)
+            rows = rows0.copy(); rows["pc"][k + 1] = int(rows0["pc"][k]) + (4 if want_taken else imm)
+            assert rejected(rows), (hex(op), want_taken)
+
+    def bad(edit):
+        m = m0.copy(); edit(m)
+        return so.verify(so.prove_matrix(m, pub)) == 10
+    # rows whose operands have different signs: the sign bits decide
+    ksl = next(int(k) for k in np.nonzero(ops == 0x22)[0] if m0[C_B0, k] != m0[C_SB, k])
+    kbl = next(int(k) for k in np.nonzero(ops == 0x42)[0] if m0[C_B0, k] != m0[C_SB, k])
+
+    def flip_sign(m, k, col, rc):                                # the sign bit flipped, the biased limb following it: u leaves [0, 2^20), a chunk leaves the table
+        sgn = int(m[col, k]); d = (1 if sgn else -1) << 20
+        m[col, k] = 1 - sgn
+        m[rc + 1, k] = (int(m[rc + 1, k]) + d // 1024) % P
+    assert bad(lambda m: flip_sign(m, ksl, C_B0, C_RC2)) and bad(lambda m: flip_sign(m, ksl, C_SB, C_RC2 + 2))
+    assert bad(lambda m: flip_sign(m, kbl, C_B0, C_RC2)) and bad(lambda m: flip_sign(m, kbl, C_SB, C_RC2 + 2))
+
+    def flip_sign_and_borrow(m, k):                              # ... and the borrow with it, so that the difference constraint holds again: the range lookup still refuses u
+        flip_sign(m, k, C_B0, C_RC2)
+        c1 = int(m[C_C0 + 1, k]); m[C_C0 + 1, k] = 1 - c1; m[C_FLAG, k] = 1 - c1; m[C_FX, k] = 1 - int(m[C_FX, k])
+    assert bad(lambda m: flip_sign_and_borrow(m, ksl))
+    # the sign bit flipped with u kept in range: the biased-limb constraint no longer holds
+    assert bad(lambda m: m.__setitem__((C_B0, ksl), 1 - int(m[C_B0, ksl])))
+    assert bad(lambda m: m.__setitem__((C_SB, kbl), 1 - int(m[C_SB, kbl])))
+    # an unsigned comparison claiming sign bits (g says unsigned: the bias is absent, a sign bit of 1 pushes u below zero)
+    ku = next(int(k) for k in np.nonzero(ops == 0x20)[0] if (int(m0[C_XB + 1, k]) >> 19))
+    assert bad(lambda m: flip_sign(m, ku, C_B0, C_RC2))
+    # the variant bit forged (SLT run as SLTU): the ROM tuple is not the program's
+    assert bad(lambda m: m.__setitem__((C_G, ksl), 0))
+    # a forged flag / polarity / decision on a signed row
+    assert bad(lambda m: m.__setitem__((C_FLAG, ksl), 1 - int(m[C_FLAG, ksl])))
+    assert bad(lambda m: m.__setitem__((C_FX, kbl), 1 - int(m[C_FX, kbl])))
+    assert bad(lambda m: m.__setitem__((C_TK, kbl), 1 - int(m[C_TK, kbl])))
+
+
 def test_cpu_commit_port_matches_the_oracle():
     """bench_cpu/cpu_commit_port.cpp (the multi-threaded Montgomery port bench.py times as the CPU figure of the commit stage) computes
     the same root as the naive oracle."""
@@ -288,7 +399,7 @@ def test_air_holds_row_by_row_on_honest_traces():
         # the lookup side for some challenges: aux trace (helper columns, running sum), alpha / lambda powers / T / N; the running sum closes
         # over the cycle (row N - 1 -> row 0) because the row side of the LogUp identity equals the table side T
         aux, lk, rom_mult, rc_mult = so.lookup_setup(m, pub, [5, 6, 7, 8], [9, 10, 11, 12])
-        assert int(rom_mult.sum()) == N and int(rc_mult.sum()) == 4 * N       # every row looks its instruction up once, its four chunks once each
+        assert int(rom_mult.sum()) == N and int(rc_mult.sum()) == 8 * N       # every row looks its instruction up once, its eight chunks once each
         for i in range(N):
             out = so.constraints_eval(m[:, i], m[:, (i + 1) % N], aux[:, i], aux[:, (i + 1) % N], lk, int(i == 0), int(i == len(rows) - 1), int(i != N - 1), pub, alpha)
             assert not out.any(), (i, len(rows))
@@ -296,14 +407,14 @@ def test_air_holds_row_by_row_on_honest_traces():
             # a chunk outside the table, or a row whose tuple is not a ROM row, breaks the identity: the sum no longer closes
             bad = m.copy(); bad[C_RC + 1, 3] = 1024
             aux2, lk2, _, rc2 = so.lookup_setup(bad, pub, [5, 6, 7, 8], [9, 10, 11, 12])
-            assert int(rc2.sum()) == 4 * N - 1
+            assert int(rc2.sum()) == 8 * N - 1
             assert any(so.constraints_eval(bad[:, i], bad[:, (i + 1) % N], aux2[:, i], aux2[:, (i + 1) % N], lk2, int(i == 0), int(i == len(rows) - 1), int(i != N - 1), pub, alpha).any()
                        for i in range(N))
 
 
 # ---- stage B: prover + verifier ------------------------------------------------------------------------------------
 def _prog(prog):
-    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program, "call": spec.call_loop_program}[prog]()
+    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program, "call": spec.call_loop_program, "sgn": spec.signed_loop_program}[prog]()
 
 
 def _run(n, prog="fib", **cfg):
@@ -342,8 +453,8 @@ def test_prove_verify_roundtrip(n, prog):
     blob = _prog(prog).to_bytes()
     assert lay["blob"] == blob and lay["n_rom"] == int.from_bytes(blob[16:20], "little") // 4 and lay["trace_root"] == HDR + 1 + (len(blob) + 1) // 2 + lay["n_rom"] + 1024
     fixed = lay["trace_root"] + 12 + (2 * WT + 4) * 4                                      # ... roots (trace, aux, quotient), openings of main + aux columns and the quotient
-    assert pr[1] == 8 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
-    assert int(pr[lay["rom_mult"]:lay["rc_mult"]].sum()) == 1 << log_n and int(pr[lay["rc_mult"]:lay["trace_root"]].sum()) == 4 << log_n   # multiplicities count every row
+    assert pr[1] == 9 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
+    assert int(pr[lay["rom_mult"]:lay["rc_mult"]].sum()) == 1 << log_n and int(pr[lay["rc_mult"]:lay["trace_root"]].sum()) == 8 << log_n   # multiplicities count every row
     depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
     per_query = 1 + 2 * (WC + 4 * (log_n + 1)) + 2 * (WA + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
     assert len(pr) == fixed + 1 + 4 * len(ks) + 4 * 8 + 1 + NQ * per_query
@@ -579,10 +690,11 @@ def test_wrong_execution_of_the_opcode_families_is_rejected():
             assert rejected(rows), (hex(op), want_taken)
 
 
-def test_control_flow_of_every_opcode_but_the_signed_branches():
-    """AIR v4 on spec.call_loop_program: JALR rows (link = pc + 4; next pc + the cleared bit = rs1 + sext(imm), even and odd sums, a
-    negative immediate), class "other" rows (MUL, SLLI: pc + 4 enforced), class "other, jumps" rows (BLT / BGE: free pc, nothing
-    written) — the columns against the VM's rows, and every way of bending the control flow rejected."""
+def test_control_flow_of_every_opcode():
+    """AIR v4 / v5 on spec.call_loop_program: JALR rows (link = pc + 4; next pc + the cleared bit = rs1 + sext(imm), even and odd sums, a
+    negative immediate), class "other" rows (MUL, SLLI: pc + 4 enforced), signed branches (BLT / BGE: since v5 rows of the ordered-branch
+    class, decided by the signed comparison, nothing written) — the columns against the VM's rows, and every way of bending the control
+    flow rejected."""
     rows0, pub = _run(500, "call")
     m = so.main_trace(rows0, pub)
     ops = rows0["instruction"] & 0x7F
@@ -602,8 +714,8 @@ def test_control_flow_of_every_opcode_but_the_signed_branches():
             if fa: assert int(rows0["registers"][i + 1, fa]) == int(rows0["pc"][i]) + 4 and m[C_WR + fa - 1, i] == 1
             else: assert not m[C_WR:C_WR + 15, i].any()
             seen.add(("jalr", int(m[C_B0, i]), imm < 0))
-        if k == K_OJ:
-            assert not m[C_WR:C_WR + 15, i].any()
+        if k == K_BRU:
+            assert not m[C_WR:C_WR + 15, i].any() and not cls[K_OJ][i]
             seen.add((op, int(rows0["pc"][i + 1]) != int(rows0["pc"][i]) + 4))
         if k == K_OTH:
             assert int(rows0["pc"][i + 1]) == int(rows0["pc"][i]) + 4
@@ -627,7 +739,11 @@ def test_control_flow_of_every_opcode_but_the_signed_branches():
     # an "other" row (MUL) that jumps: the next row sits at another code address
     rows = rows0.copy(); rows["pc"][km + 1] = int(rows0["pc"][km]) + 8
     assert rejected(rows)
-    # a signed branch may go either way (its comparison is not stated) — but it cannot write a register
+    # a signed branch goes the way its comparison says (v5), and it cannot write a register
+    taken = int(rows0["pc"][kb + 1]) != int(rows0["pc"][kb]) + 4
+    wb = int(rows0["instruction"][kb]); immb = (wb >> 15) - (1 << 17 if wb >> 31 else 0)
+    rows = rows0.copy(); rows["pc"][kb + 1] = int(rows0["pc"][kb]) + (4 if taken else immb)
+    assert rejected(rows)
     rows = rows0.copy(); rows["registers"][kb + 1:, 9] = 77
     assert rejected(rows)
     m2 = m.copy(); m2[C_WR + 8, kb] = 1; m2[C_LIMB + 27, kb + 1:] = 77       # ... even if the matrix flags the write
@@ -636,6 +752,8 @@ def test_control_flow_of_every_opcode_but_the_signed_branches():
     m2 = m.copy(); m2[C_K3, kj] = 0; m2[C_K3 + 1, kj] = 1
     assert so.verify(so.prove_matrix(m2, pub)) == 10
     m2[C_OPC, kj] = K_OJ
+    assert so.verify(so.prove_matrix(m2, pub)) == 10
+    m2 = m.copy(); m2[C_K2 + 1, kb] = 0; m2[C_K3 + 1, kb] = 1; m2[C_B0, kb] = 0; m2[C_SB, kb] = 0; m2[C_TK, kb] = 0     # a signed branch relabelled as the free-pc class (deferred mode's)
     assert so.verify(so.prove_matrix(m2, pub)) == 10
     # the cleared bit forged together with the low pc limb: pc' stops being a code address
     m2 = m.copy(); m2[C_B0, kj] = 1 - int(m[C_B0, kj]); m2[C_PC, kj + 1] = (int(m[C_PC, kj + 1]) + (1 if m[C_B0, kj] else -1)) % P

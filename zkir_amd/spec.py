@@ -264,6 +264,41 @@ def call_loop_program() -> Program:
     ])
 
 
+def signed_loop_program() -> Program:
+    """An endless loop over the SIGNED comparisons (AIR v5): SLT / SGE and BLT / BGE on a counter that walks from -6 to 8 and back, against a
+    negative and a positive threshold, the most negative value (2^39) and the largest positive one (2^39 - 1); SLTU / BLTU on the same
+    operands for contrast (a negative value is a huge unsigned one).  Every comparison comes out both ways, every branch is both taken and
+    not taken.  Run with max_cycles (halt = CycleLimit)."""
+    def r(op, rd, rs1, rs2): return encode(op, rd, rs1, rs2)
+    def b(op, rs1, rs2, off): return encode(op, rs1=rs1, rs2=rs2, imm=off)
+    O = Opcode
+    return Program.from_code([
+        addi(1, 0, -6), addi(2, 0, -2), addi(3, 0, 3), addi(13, 0, 8),       # i, a negative and a positive threshold, the loop bound
+        addi(15, 0, 1), slli(15, 15, 39), addi(14, 15, -1),                  # the most negative value 2^39 and the largest positive one 2^39 - 1
+        # L (pc 0x101C):
+        r(O.SLT, 4, 1, 2), r(O.SGE, 5, 1, 2),                                # i < -2, i >= -2
+        r(O.SLT, 6, 3, 1), r(O.SGE, 7, 3, 1),                                # 3 < i, 3 >= i
+        r(O.SLTU, 8, 1, 3), r(O.SGEU, 9, 1, 3),                              # the same operands unsigned: a negative i is huge
+        r(O.SLT, 10, 15, 1), r(O.SGE, 11, 14, 1),                            # min < i (true unless i = min ... always true here), max >= i (always)
+        r(O.SLT, 12, 14, 15),                                                # max < min: never
+        b(O.BLT, 1, 0, 8),                                                   # i < 0: skip the next instruction
+        addi(4, 4, 16),
+        b(O.BGE, 1, 3, 8),                                                   # i >= 3: skip
+        addi(5, 5, 16),
+        b(O.BLT, 2, 1, 8),                                                   # -2 < i: skip
+        addi(6, 6, 16),
+        b(O.BGE, 2, 1, 8),                                                   # -2 >= i: skip
+        addi(7, 7, 16),
+        b(O.BLTU, 1, 3, 8),                                                  # i < 3 unsigned: only for i = 0, 1, 2
+        addi(8, 8, 16),
+        b(O.BLT, 14, 15, 8),                                                 # max < min: never taken
+        addi(1, 1, 1),                                                       # i += 1
+        b(O.BLT, 1, 13, -84),                                                # i < 8: back to L
+        addi(1, 0, -6),                                                      # else start over from -6
+        b(O.BGE, 14, 15, -92),                                               # max >= min: always taken, back to L
+    ])
+
+
 def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
     """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
     The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).
