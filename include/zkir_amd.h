@@ -277,9 +277,9 @@ typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, co
                                                      One proof at a time per context; different contexts are independent (no process-wide state). */
 int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup /* must be 1 */, zkir_stark_ctx** out);
 void zkir_stark_ctx_free(zkir_stark_ctx* ctx);
-uint32_t zkir_main_trace_width(void);             /* 144: COMMITTED main-trace columns of a default-mode run (the AIR's 160 logical columns minus the ones that
+uint32_t zkir_main_trace_width(void);             /* 152: COMMITTED main-trace columns of a default-mode run (the AIR's 169 logical columns minus the ones that
                                                      are identically zero there: R0's limbs and the 16 storage states; zkir_amd/csrc/air.h) */
-uint32_t zkir_main_trace_width_for(uint32_t deferred);   /* 144 (deferred = 0) / 160 (VMConfig.enable_deferred_model: the storage states are committed) */
+uint32_t zkir_main_trace_width_for(uint32_t deferred);   /* 152 (deferred = 0) / 168 (VMConfig.enable_deferred_model: the storage states are committed) */
 uint32_t zkir_padded_log_n(uint64_t n_real);      /* log2 of the padded trace length: max(3, ceil(log2(n_real))) */
 /* diagnostic: measured peak rate (per second) of independent Montgomery multiplications on the current device — the integer-ALU
  * roofline the Poseidon2 kernels are priced against (they are ALU-bound, not HBM- or MFMA-bound) */

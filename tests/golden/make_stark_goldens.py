@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v4, proof format v8).
+"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v5, proof format v9).
 
 The reference has no prover, so nothing external can pin these stages; this file FREEZES them — it pins nothing:
 the values are produced by this repository's own oracle, so they guard against DRIFT only: the
@@ -23,8 +23,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
 
-ADD, SUB, MUL, ADDI, SLLI, SLTU, SGEU, SEQ, SNE, LW, SW, BEQ, BNE, BLT, BGE, BLTU, BGEU, JAL, JALR, ECALL = \
-    0x00, 0x01, 0x02, 0x08, 0x1B, 0x20, 0x21, 0x24, 0x25, 0x34, 0x3A, 0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x48, 0x49, 0x50
+ADD, SUB, MUL, ADDI, SLLI, SLTU, SGEU, SLT, SGE, SEQ, SNE, LW, SW, BEQ, BNE, BLT, BGE, BLTU, BGEU, JAL, JALR, ECALL = \
+    0x00, 0x01, 0x02, 0x08, 0x1B, 0x20, 0x21, 0x22, 0x23, 0x24, 0x25, 0x34, 0x3A, 0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x48, 0x49, 0x50
 
 
 def r_(op, rd, rs1, rs2): return op | rd << 7 | rs1 << 11 | rs2 << 15
@@ -59,6 +59,13 @@ CALL_LOOP = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 5), i_(ADDI, 6, 0, 20),
                   j_(JAL, 15, 24), i_(ADDI, 1, 1, 1), i_(BLT, 1, 2, 8), i_(ADDI, 2, 2, 7), i_(BGE, 1, 6, -16), j_(JAL, 0, -20),
                   r_(MUL, 3, 1, 2), i_(SLLI, 4, 3, 2), i_(ADDI, 14, 15, 5), r_(SEQ, 5, 4, 0), i_(BEQ, 5, 0, 8), i_(JALR, 13, 15, 0), i_(JALR, 0, 14, -4)])
 
+# the signed comparisons of AIR v5 on a counter walking from -6 to 8, against thresholds of both signs and the extreme values (the product ships it as spec.signed_loop_program)
+SIGNED_LOOP = blob([i_(ADDI, 1, 0, -6), i_(ADDI, 2, 0, -2), i_(ADDI, 3, 0, 3), i_(ADDI, 13, 0, 8), i_(ADDI, 15, 0, 1), i_(SLLI, 15, 15, 39), i_(ADDI, 14, 15, -1),
+                    r_(SLT, 4, 1, 2), r_(SGE, 5, 1, 2), r_(SLT, 6, 3, 1), r_(SGE, 7, 3, 1), r_(SLTU, 8, 1, 3), r_(SGEU, 9, 1, 3), r_(SLT, 10, 15, 1), r_(SGE, 11, 14, 1),
+                    r_(SLT, 12, 14, 15), i_(BLT, 1, 0, 8), i_(ADDI, 4, 4, 16), i_(BGE, 1, 3, 8), i_(ADDI, 5, 5, 16), i_(BLT, 2, 1, 8), i_(ADDI, 6, 6, 16),
+                    i_(BGE, 2, 1, 8), i_(ADDI, 7, 7, 16), i_(BLTU, 1, 3, 8), i_(ADDI, 8, 8, 16), i_(BLT, 14, 15, 8), i_(ADDI, 1, 1, 1), i_(BLT, 1, 13, -84),
+                    i_(ADDI, 1, 0, -6), i_(BGE, 14, 15, -92)])
+
 CASES = [
     dict(name="fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=False),
     dict(name="sha_2p9", blob=SHA_CHAIN, max_cycles=1 << 9, deferred=False),
@@ -66,6 +73,7 @@ CASES = [
     dict(name="fib30_exit_154_rows", blob=FIB30, max_cycles=1_000_000, deferred=False),
     dict(name="compare_loop_600_rows", blob=CMP_LOOP, max_cycles=600, deferred=False),
     dict(name="call_loop_500_rows", blob=CALL_LOOP, max_cycles=500, deferred=False),
+    dict(name="signed_loop_700_rows", blob=SIGNED_LOOP, max_cycles=700, deferred=False),
 ]
 
 
@@ -88,7 +96,7 @@ def golden(case):
 
 if __name__ == "__main__":
     out = {"_about": "frozen outputs of ZKIR-STARK (AIR v4, proof format v8; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
-           "proof_version": 8, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
+           "proof_version": 9, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
            "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
            "cases": [golden(c) for c in CASES]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")

@@ -48,7 +48,7 @@ def test_lde_matches_oracle(log_n):
     ctx.close()
 
 
-@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 144), (8, 160), (10, 17)])
+@pytest.mark.parametrize("log_n,width", [(4, 1), (6, 8), (7, 9), (8, 89), (8, 152), (8, 168), (10, 17)])
 def test_merkle_matches_oracle(log_n, width):
     import torch
     from zkir_amd import stark
@@ -67,7 +67,7 @@ def test_merkle_and_lde_extreme_values(fill):
     """Worst cases for the lazy (unreduced) arithmetic of the hash and NTT kernels: every input at the top of the range."""
     import torch
     from zkir_amd import stark
-    log_n, width = 9, 160
+    log_n, width = 9, 168
     n = 1 << log_n
     mat = np.zeros((width, n), dtype=np.uint32)
     if fill == "p-1":
@@ -89,6 +89,7 @@ def test_merkle_and_lde_extreme_values(fill):
 PROGRAMS = {"fib": (spec.fib_endless_program, {}), "sha": (spec.sha256_chain_program, {}), "deferred": (spec.fib_endless_program, {"enable_deferred_model": True}),
             "cmp": (spec.compare_loop_program, {}), "cmp_deferred": (spec.compare_loop_program, {"enable_deferred_model": True}),
             "call": (spec.call_loop_program, {}), "call_deferred": (spec.call_loop_program, {"enable_deferred_model": True}),
+            "sgn": (spec.signed_loop_program, {}), "sgn_deferred": (spec.signed_loop_program, {"enable_deferred_model": True}),
             "fib30": (lambda: spec.fib_program(30), {}), "exit42": (lambda: spec.Program.from_code([spec.addi(10, 0, 0), spec.addi(11, 0, 42), spec.ecall()]), {})}
 
 
@@ -110,9 +111,9 @@ def _case(name, n):
 
 @pytest.mark.parametrize("name,n", [("fib", 64), ("fib", 1024), ("fib", 4096), ("fib", 1000), ("fib", 5), ("sha", 512), ("sha", 700), ("deferred", 256),
                                     ("fib30", None), ("exit42", None), ("cmp", 600), ("cmp", 5000), ("cmp_deferred", 300), ("call", 500), ("call", 3000),
-                                    ("call_deferred", 250)])
+                                    ("call_deferred", 250), ("sgn", 700), ("sgn", 5000), ("sgn_deferred", 300)])
 def test_main_trace_and_commit_match_oracle(name, n):
-    """All committed columns of the padded main trace (144 in default mode, 160 deferred: the oracle's 160 logical columns minus the ones
+    """All committed columns of the padded main trace (152 in default mode, 168 deferred: the oracle's 169 logical columns minus the ones
     that are identically zero), the LDE and the commitment root, for power-of-two and ragged row counts and for programs that halt on
     their own (Exit / padding rows)."""
     from zkir_amd import stark
@@ -158,7 +159,7 @@ def test_commit_2p16_root_and_properties():
 
 @pytest.mark.parametrize("name,n", [("fib", 8), ("fib", 5), ("fib", 32), ("fib", 256), ("fib", 2048), ("fib", 1500), ("sha", 512), ("sha", 300), ("deferred", 1024),
                                     ("fib30", None), ("exit42", None), ("fib", 8192), ("cmp", 600), ("cmp", 4096), ("cmp_deferred", 300), ("call", 500),
-                                    ("call", 2048), ("call_deferred", 250)])
+                                    ("call", 2048), ("call_deferred", 250), ("sgn", 700), ("sgn", 4096), ("sgn_deferred", 300)])
 def test_proof_bytes_match_oracle_and_verify(name, n):
     """End-to-end proof (quotient over the v1 AIR, openings, DEEP, FRI, grinding, queries): GPU proof words == oracle proof words,
     and both verifiers accept them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on
@@ -224,6 +225,21 @@ def test_wrong_execution_is_rejected_on_the_gpu_path():
         tr4.registers[reg, lo:len(rows4)] = saved4
     assert np.array_equal(stark.prove(ctx4, tr4, pub4), so.prove(rows4, opub4))
     ctx4.close(); log4.close()
+    # AIR v5: a signed comparison written the wrong way round, a register that follows a signed branch going the other way — on a run of
+    # spec.signed_loop_program (the r4 += 16 after "blt r1, r0" executed although the branch was taken)
+    blob5, log5, tr5, rows5, opub5, pub5 = _case("sgn", 700)
+    ctx5 = stark.StarkContext(10)
+    ops5 = rows5["instruction"] & 0x7F
+    ks5 = np.nonzero((ops5 == 0x22) & (((rows5["instruction"] >> 7) & 0xF) == 4))[0]
+    k5 = int(ks5[3])
+    nx5 = k5 + 1 + int(np.nonzero(((rows5["instruction"][k5 + 1:] >> 7) & 0xF) == 4)[0][0])
+    saved5 = tr5.registers[4, k5 + 1:nx5 + 1].clone()
+    tr5.registers[4, k5 + 1:nx5 + 1] = saved5 ^ 1
+    bad5 = stark.prove(ctx5, tr5, pub5)
+    assert so.verify(bad5, opub5) == 10 and rt.verify(bad5, pub5) == 10
+    tr5.registers[4, k5 + 1:nx5 + 1] = saved5
+    assert np.array_equal(stark.prove(ctx5, tr5, pub5), so.prove(rows5, opub5))
+    ctx5.close(); log5.close()
     # A row whose (pc, instruction word) is not in the program's code table has NO proof in AIR v2 (instruction-ROM lookup): the honest
     # prover refuses it instead of emitting a proof the verifier would reject — a BNE's fall-through claimed where the run branched
     # (the word at the claimed pc is another one), an instruction word patched in HBM (ADD -> SUB: the forgery AIR v1 accepted)
@@ -330,7 +346,7 @@ def test_proof_large_verifies(log_n):
     ctx = stark.StarkContext(log_n)
     proof = stark.prove(ctx, tr, pub)
     assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0
-    assert proof[2] == log_n and proof[3] == 144 and proof[7] == (1 << log_n) - 1
+    assert proof[2] == log_n and proof[3] == 152 and proof[7] == (1 << log_n) - 1
     ctx.close(); log.close()
 
 

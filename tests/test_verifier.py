@@ -18,14 +18,14 @@ def _pub_c(p: so.PublicC) -> rt.PublicInputsC:
 
 
 def _run(n, prog="fib", **cfg):
-    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program, "call": spec.call_loop_program}[prog]().to_bytes()
+    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program, "call": spec.call_loop_program, "sgn": spec.signed_loop_program}[prog]().to_bytes()
     res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
     return res.rows, so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=bool(cfg))
 
 
 @pytest.mark.parametrize("n,prog,cfg", [(8, "fib", {}), (5, "fib", {}), (100, "fib", {}), (300, "sha", {}), (None, "fib12", {}), (512, "fib", {}),
                                          (200, "fib", {"enable_deferred_model": True}), (600, "cmp", {}), (150, "cmp", {"enable_deferred_model": True}), (500, "call", {}),
-                                         (200, "call", {"enable_deferred_model": True})])
+                                         (200, "call", {"enable_deferred_model": True}), (700, "sgn", {}), (150, "sgn", {"enable_deferred_model": True})])
 def test_accepts_what_the_oracle_accepts(n, prog, cfg):
     rows, pub = _run(n, prog, **cfg)
     pr = so.prove(rows, pub)
@@ -134,7 +134,7 @@ def test_rejects_forged_opcode_families_like_the_oracle():
 
 
 def test_rejects_bent_control_flow_like_the_oracle():
-    """AIR v4 (JALR, sequential "other" rows, the free-pc class of BLT / BGE): same verdict from the product verifier and the oracle on
+    """AIR v4 / v5 (JALR, sequential "other" rows, BLT / BGE): same verdict from the product verifier and the oracle on
     forged jump targets, links, cleared bits, relabelled rows and writes by a signed branch."""
     rows, pub = _run(500, "call")
     m0 = so.main_trace(rows, pub)
@@ -153,6 +153,41 @@ def test_rejects_bent_control_flow_like_the_oracle():
         assert so.verify(pr) == 10 and rt.verify(pr) == 10, i
     for mutate in (lambda r: r["pc"].__setitem__(kj + 1, int(rows["pc"][kj + 1]) + 4), lambda r: r["pc"].__setitem__(km + 1, int(rows["pc"][km]) + 8),
                    lambda r: r["registers"].__setitem__((slice(kb + 1, None), 9), 5)):
+        r = rows.copy(); mutate(r)
+        pr = so.prove(r, pub)
+        assert so.verify(pr) == 10 and rt.verify(pr) == 10
+    pr = so.prove(rows, pub)
+    assert so.verify(pr) == 0 and rt.verify(pr) == 0
+
+
+def test_rejects_forged_signed_comparisons_like_the_oracle():
+    """AIR v5 (SLT / SGE / BLT / BGE: variant bit, sign bits, biased high limbs as the second range-checked pair): same verdict from the
+    product verifier and the oracle on forged sign bits, variant bits, borrows, flags and branch decisions, on signed comparisons written
+    the wrong way round and signed branches going the other way."""
+    rows, pub = _run(700, "sgn")
+    m0 = so.main_trace(rows, pub)
+    ops = rows["instruction"] & 0x7F
+    C_C1, C_TK, C_FLAG, C_FX, C_B0, C_RC2, C_G, C_SB = 142, 151, 158, 159, 162, 163, 167, 168
+    ksl = next(int(k) for k in np.nonzero(ops == 0x22)[0] if m0[C_B0, k] != m0[C_SB, k])
+    kbg = next(int(k) for k in np.nonzero(ops == 0x43)[0] if m0[C_B0, k] != m0[C_SB, k])
+    flip = lambda col, k: (lambda m: m.__setitem__((col, k), 1 - int(m[col, k])))
+
+    def flip_sign(col, rc, k):                                    # the sign bit flipped with the biased limb following it: a chunk leaves the table
+        def e(m):
+            sgn = int(m[col, k]); m[col, k] = 1 - sgn
+            m[rc + 1, k] = (int(m[rc + 1, k]) + (1024 if sgn else -1024)) % P
+        return e
+    edits = [flip(C_B0, ksl), flip(C_SB, ksl), flip(C_B0, kbg), flip(C_SB, kbg), flip_sign(C_B0, C_RC2, ksl), flip_sign(C_SB, C_RC2 + 2, kbg),
+             flip(C_G, ksl), flip(C_G, kbg), flip(C_C1, ksl), flip(C_FLAG, ksl), flip(C_FX, kbg), flip(C_TK, kbg)]
+    for i, e in enumerate(edits):
+        m = m0.copy(); e(m)
+        pr = so.prove_matrix(m, pub)
+        assert so.verify(pr) == 10 and rt.verify(pr) == 10, i
+    rd = (int(rows["instruction"][ksl]) >> 7) & 0xF
+    wb = int(rows["instruction"][kbg]); imm = (wb >> 15) - (1 << 17 if wb >> 31 else 0)
+    taken = int(rows["pc"][kbg + 1]) != int(rows["pc"][kbg]) + 4
+    for mutate in (lambda r: r["registers"].__setitem__((ksl + 1, rd), int(rows["registers"][ksl + 1, rd]) ^ 1),
+                   lambda r: r["pc"].__setitem__(kbg + 1, int(rows["pc"][kbg]) + (4 if taken else imm))):
         r = rows.copy(); mutate(r)
         pr = so.prove(r, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10

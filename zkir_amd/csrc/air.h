@@ -40,16 +40,16 @@
 
 namespace air {
 
-constexpr int W = 163;
+constexpr int W = 169;
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162 };
+             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168 };
 // LOGICAL vs COMMITTED columns (proof format v7).  W and the C_* map are the LOGICAL main trace: what the constraints talk about.  Columns
 // that are identically zero by the constraints themselves are not committed: R0's three limbs and its storage state (R0 is hard-wired
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, zero-padded to whole B8 blocks: 144 columns in default mode (exactly),
 // 160 in deferred mode (159 + 1); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 144, W_COMMITTED_DEFERRED = 160;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168;
 BB_HD constexpr bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
 BB_HD constexpr int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a committed column
 BB_HD constexpr int committed_width(bool deferred) { return deferred ? W_COMMITTED_DEFERRED : W_COMMITTED_DEFAULT; }
@@ -62,32 +62,36 @@ BB_HD constexpr int logical_col(int p, bool deferred) {
   return c;
 }
 // aux trace: H0..H3 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
-constexpr int W_AUX = 24;
-enum : int { A_H = 0, A_HR = 16, A_S = 20 };
-constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 10;
+constexpr int W_AUX = 40;
+enum : int { A_H = 0, A_HR = 32, A_S = 36 };
+constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
+BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^10, T / N
 enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), N_LK = LK_TN + 4 };
-BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : C_OPC; }
+BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : j == 9 ? C_OPC : C_G; }
 // AIR v3: class ids (= opclass values of the instruction word; halt / pad are row roles, not word classes).  A FAMILY is a pair of opcodes
 // that differ in their low bit, the polarity of one comparison: bre = BEQ / BNE, bru = BLTU / BGEU, se = SEQ / SNE, su = SLTU / SGEU.
 // AIR v4: jalr (JALR) and oj = "other, jumps" (BLT / BGE: the signed comparison is not stated yet — free next pc, nothing written); class
 // "other" is SEQUENTIAL (pc + 4) like every instruction that is not a branch or a jump.
 enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, N_CLASS = 13 };
 BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : C_K3 + (k - 11); }
-constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
+constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
 BB_HD constexpr uint32_t opclass_of(uint32_t op) {
   return op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
-       : (op == OP_BLTU || op == OP_BGEU) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE : (op == OP_SLTU || op == OP_SGEU) ? K_SU : op == OP_JALR ? K_JALR
-       : (op == OP_BLT || op == OP_BGE) ? K_OJ : (uint32_t)K_OTH;
+       : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
+       : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (uint32_t)K_OTH;
 }
-BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLTU : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0u; }   // the even opcode of a family
+BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLT : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0u; }   // the lowest opcode of a family
+// AIR v5: the families of ordered comparisons have FOUR members, op = base + 2 g + pol: SLTU SGEU SLT SGE (base 0x20, g = signed) and BLT BGE BLTU
+// BGEU (base 0x42, g = unsigned).  g is the word's VARIANT BIT, the eleventh element of the ROM tuple (0 for every other opcode).
+BB_HD constexpr uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU) ? 1u : 0u; }
 
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
 enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 148,
-             I_ONE_CLASS = 157, I_OPCLASS = 158, I_WR = 159, I_SELB = 162, I_SELC = 164, I_OPERAND = 166, I_VALUE = 172, I_DIFF = 181, I_WRITTEN = 185,
-             I_NE = 190, I_FLAG = 194, I_FX = 195, I_TK = 196, I_DL0 = 197, I_SE = 198, I_PC = 199, I_PC_KEEP = 202, I_JALR = 205, I_REGS = 208, I_TAIL = 268, I_LAST = 271,
-             I_CHUNK = 339, I_RANGE = 341, I_ROM = 357, I_SUM = 361, N_CONSTRAINTS = 365 };
+             I_ONE_CLASS = 158, I_OPCLASS = 159, I_WR = 160, I_SELB = 163, I_SELC = 165, I_OPERAND = 167, I_VALUE = 173, I_DIFF = 182, I_WRITTEN = 191,
+             I_NE = 196, I_FLAG = 200, I_FX = 201, I_TK = 202, I_DL0 = 203, I_SE = 204, I_PC = 205, I_PC_KEEP = 208, I_JALR = 211, I_REGS = 214, I_TAIL = 274, I_LAST = 277,
+             I_CHUNK = 345, I_RANGE = 347, I_ROM = 379, I_SUM = 383, N_CONSTRAINTS = 387 };
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -174,7 +178,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int k = 0; k < N_CLASS; k++) boolean(I_BOOL_K + k, K[k]);
   const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), ne = o.loc(C_NE), tk = o.loc(C_TK);
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
-  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0));
+  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0)); boolean(I_BOOL_MISC + 9, o.loc(C_SB));
   // 4. classes and the opcode
   {
     V sum = K[0];
@@ -222,10 +226,23 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   //     rows (:618-636): c1 = 1 exactly when the minuend is the smaller 40-bit value
   {
     const V Ks = o.add(K[K_SUB], K[K_SU]);
+    // (v5) ordered comparisons, signed or not (op = base + 2 g + pol; sgn = g on SLTU.. rows, 1 - g on BLT.. rows): the high limbs enter BIASED,
+    // ta = a1 + 2^19 sgn - 2^20 sa, tb likewise with sb — the limbs of value XOR 2^39 when sgn = 1 (Value40::signed_lt, value.rs:710-716) — so
+    // ta - tb = a1 - b1 - 2^20 (sa - sb); u = (ta, tb) is the row's second range-checked pair, which forces sa / sb to be the sign bits (0 if sgn = 0)
+    const V sa = o.loc(C_B0), sb = o.loc(C_SB), g = o.loc(C_G);
+    const V sab = o.mulc(o.sub(sa, sb), M(1u << 20));
     o.push(I_DIFF, o.mul(Ks, o.sub(o.add(o.sub(z[0], xb[0]), xc[0]), c0s20)));
-    o.push(I_DIFF + 1, o.mul(Ks, o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20)));
-    o.push(I_DIFF + 2, o.mul(K[K_BRU], o.sub(o.add(o.sub(z[0], xc[0]), xb[0]), c0s20)));
-    o.push(I_DIFF + 3, o.mul(K[K_BRU], o.sub(o.add(o.add(o.sub(z[1], xc[1]), xb[1]), c0), c1s20)));
+    o.push(I_DIFF + 1, o.mul(K[K_SUB], o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20)));
+    o.push(I_DIFF + 2, o.mul(K[K_SU], o.add(o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20), sab)));
+    o.push(I_DIFF + 3, o.mul(K[K_BRU], o.sub(o.add(o.sub(z[0], xc[0]), xb[0]), c0s20)));
+    o.push(I_DIFF + 4, o.mul(K[K_BRU], o.add(o.sub(o.add(o.add(o.sub(z[1], xc[1]), xb[1]), c0), c1s20), sab)));
+    const V u0 = o.add(o.loc(C_RC2), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), u1 = o.add(o.loc(C_RC2 + 2), o.mulc(o.loc(C_RC2 + 3), M(RC_TABLE)));
+    const V gsu = o.mulc(g, M(1u << 19)), gbr = o.mulc(o.sub(one, g), M(1u << 19));
+    const V sa20 = o.mulc(sa, M(1u << 20)), sb20 = o.mulc(sb, M(1u << 20));
+    o.push(I_DIFF + 5, o.mul(K[K_SU], o.add(o.sub(o.sub(u0, xb[1]), gsu), sa20)));
+    o.push(I_DIFF + 6, o.mul(K[K_SU], o.add(o.sub(o.sub(u1, xc[1]), gsu), sb20)));
+    o.push(I_DIFF + 7, o.mul(K[K_BRU], o.add(o.sub(o.sub(u0, xc[1]), gbr), sa20)));
+    o.push(I_DIFF + 8, o.mul(K[K_BRU], o.add(o.sub(o.sub(u1, xb[1]), gbr), sb20)));
   }
   const V flag = o.loc(C_FLAG), fx = o.loc(C_FX);
   {
@@ -251,6 +268,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
     V pol = o.loc(C_OP);
 #pragma unroll
     for (int k = 0; k < N_CLASS; k++) if (family_base(k)) pol = o.sub(pol, o.mulc(K[k], M(family_base(k))));
+    pol = o.sub(pol, o.mulc(o.loc(C_G), M(2)));                                // (v5) op = base + 2 g + pol in the four-member families; g = 0 elsewhere
     o.push(I_FX, o.add(o.sub(o.sub(fx, flag), pol), o.mulc(o.mul(pol, flag), M(2))));
   }
   o.push(I_TK, o.sub(tk, o.mul(Kbr, fx)));
@@ -295,13 +313,13 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
   o.push(I_CHUNK, o.sub(o.sub(z[0], R[0]), o.mulc(R[1], M(RC_TABLE))));
   o.push(I_CHUNK + 1, o.sub(o.sub(z[1], R[2]), o.mulc(R[3], M(RC_TABLE))));
-  // 14. range helpers: H_i (alpha - R_i) = 1
+  // 14. range helpers: H_i (alpha - R_i) = 1, i = 0..7 (the chunks of z, the chunks of u)
 #pragma unroll 1
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < N_RC; i++) {
     V h[4], d[4], pr[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_H + 4 * i + k); d[k] = o.par(LK_ALPHA + k); }
-    d[0] = o.sub(d[0], R[i]);
+    d[0] = o.sub(d[0], o.loc(rc_col(i)));
     ext_mul(h, d, pr);
     o.push(I_RANGE + 4 * i, o.sub(pr[0], one));
 #pragma unroll
@@ -330,7 +348,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int k = 0; k < 4; k++) {
     V hs = o.aloc(A_HR + k);
 #pragma unroll
-    for (int i = 0; i < 4; i++) hs = o.add(hs, o.aloc(A_H + 4 * i + k));
+    for (int i = 0; i < N_RC; i++) hs = o.add(hs, o.aloc(A_H + 4 * i + k));
     o.push(I_SUM + k, o.add(o.sub(o.sub(o.anxt(A_S + k), o.aloc(A_S + k)), hs), o.par(LK_TN + k)));
   }
 }

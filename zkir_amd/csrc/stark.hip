@@ -4,7 +4,7 @@
 // kernel here is checked bit-for-bit against it.  Stage A (this part): main-trace field columns, Poseidon2-12 Merkle commitment
 // (the coset LDE between them lives in ntt.hip).
 //
-//   main_trace_kernel   372 B/row SoA trace -> the 160 Baby Bear columns of the AIR (air.h: limbs of pc / instruction fields /
+//   main_trace_kernel   372 B/row SoA trace -> the 169 logical Baby Bear columns of the AIR (152 committed) (air.h: limbs of pc / instruction fields /
 //                       registers, storage state, write and operand selectors, operands, result, opcode classes, range chunks, carries),
 //                       padded to a power of two, written in the B8 layout (blocks of 8 columns, [rows][8]).  HBM-bound: ~170 B
 //                       read (values + states of the row and the next) + 608 B written per row.
@@ -58,13 +58,13 @@ __device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[
 
 // One thread per (padded) row; every column write is coalesced across lanes.  Rows >= n_real are padding: they repeat the last
 // executed row's state with class "pad" and keep counting cycles.  Mirrors so::main_trace of the oracle word for word.
-// A lane builds the 160 words of ITS row in registers (every column index below is a compile-time constant once the register loop
+// A lane builds the logical words of ITS row in registers (every column index below is a compile-time constant once the register loop
 // is unrolled) and stores them as 40 16-byte vectors; the two halves of a 32-byte block position are written back to back, so the
 // L2 merges them into full sectors.
 #ifndef MT_WAVES
 #define MT_WAVES 3
 #endif
-// DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 144 columns by default, 160 deferred.
+// DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 152 columns by default, 168 deferred.
 template <bool DEF>
 __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out) {
   using namespace air;
@@ -129,12 +129,22 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
   for (int l = 0; l < 3; l++) if (!ne && xb[l] != xc[l]) { ne = 1; iv[l] = f_inv(bb::sub(xb[l], xc[l])); }
   col(C_NE) = ne; col(C_IV) = iv[0]; col(C_IV + 1) = iv[1]; col(C_IV + 2) = iv[2];
   // the 40-bit difference of the masked operands and its borrows: xb - xc (SUB, SLTU / SGEU), xc - xb (BLTU / BGEU: rs1 = field a)
-  uint32_t z[2] = {0, 0}, c0 = 0, c1 = 0;
+  // (v5) ordered comparisons, signed or not: the high limbs enter BIASED, t = limb + 2^19 sgn - 2^20 (sign bit) — the limb of value XOR 2^39 when
+  // the comparison is signed (value.rs:710-716); u = (ta, tb) is the row's second range-checked pair, which forces the sign bits
+  uint32_t z[2] = {0, 0}, c0 = 0, c1 = 0, u[2] = {0, 0}, sa = 0, sb = 0;
+  const uint32_t g = variant_bit(op);
+  col(C_G) = g;
   if (cls == K_SUB || cls == K_SU || cls == K_BRU) {
     const uint32_t* a = cls == K_BRU ? xc : xb; const uint32_t* b = cls == K_BRU ? xb : xc;
+    const uint32_t sgn = cls == K_SU ? g : cls == K_BRU ? 1u - g : 0u;
+    if (sgn) { sa = a[1] >> 19; sb = b[1] >> 19; }
+    const int32_t ta = (int32_t)a[1] + (int32_t)(sgn << 19) - (int32_t)(sa << 20), tb = (int32_t)b[1] + (int32_t)(sgn << 19) - (int32_t)(sb << 20);
     const int32_t v0 = (int32_t)a[0] - (int32_t)b[0]; c0 = v0 < 0; z[0] = (uint32_t)(v0 + (int32_t)(c0 << 20));
-    const int32_t v1 = (int32_t)a[1] - (int32_t)b[1] - (int32_t)c0; c1 = v1 < 0; z[1] = (uint32_t)(v1 + (int32_t)(c1 << 20));
+    const int32_t v1 = ta - tb - (int32_t)c0; c1 = v1 < 0; z[1] = (uint32_t)(v1 + (int32_t)(c1 << 20));
+    if (cls != K_SUB) { u[0] = (uint32_t)ta; u[1] = (uint32_t)tb; }
   }
+  col(C_SB) = sb;
+  col(C_RC2) = u[0] & (RC_TABLE - 1); col(C_RC2 + 1) = u[0] >> RC_BITS; col(C_RC2 + 2) = u[1] & (RC_TABLE - 1); col(C_RC2 + 3) = u[1] >> RC_BITS;
   const uint32_t flag = (cls == K_BRE || cls == K_SE) ? 1u - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0u;
   const uint32_t pol = op - family_base(cls);                                   // 0 / 1 inside a family; the opcode itself (< 128) on other rows
   const uint32_t fx = flag ? 1u - pol : pol;                                    // flag XOR pol where it matters (flag = 0 outside the families)
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
   col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0, b0 = 0;
+  if (cls != K_JALR && cls != K_OJ && cls != K_HALT && cls != K_PAD) b0 = sa;   // (v5) column b0 doubles as the sign bit of the first operand of an ordered comparison
   if (cls == K_JALR) {                                             // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
     const uint64_t v0 = (uint64_t)xb[0] + im0; d0 = (uint32_t)(v0 >> 20); b0 = (uint32_t)(v0 & 1);
     const uint64_t v1 = (uint64_t)xb[1] + im1 + d0; d1 = (uint32_t)(v1 >> 20);

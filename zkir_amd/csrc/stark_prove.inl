@@ -12,7 +12,7 @@ using bb::E4;
 // WMX / WTX: the largest committed width (deferred mode) — array sizes; a proof's own widths are air::committed_width(deferred) and that + WA
 constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_DEFERRED, WA = air::W_AUX, WTX = WMX + WA, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 8;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 9;
 
 #ifndef DEEP_WAVES
 #define DEEP_WAVES 4
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
 // ---- lookup argument (AIR v2): per-row table indices + multiplicities, inverse tables, aux trace -------------------------------------
 // The looked-up values of a row live in blocks 0, 1, 16, 17 of the main-trace matrix: tuple (pc limbs, op, fa, fb, fc | fhi | opclass | s)
 // and the four range chunks.  One pass over them, BEFORE the LDE uses the matrix as scratch: side[i] = (chunk 0 | chunk 1 << 16,
-// chunk 2 | chunk 3 << 16, ROM row u, 0), the range-table histogram (LDS-privatised) and the ROM histogram (LDS-privatised for the
+// chunk 2 | chunk 3 << 16, ROM row u, 0) [v5: eight chunks, three 10-bit chunks per word: (c0 c1 c2, c3 c4 c5, c6 c7, u)], the range-table histogram (LDS-privatised) and the ROM histogram (LDS-privatised for the
 // first ROM_LDS rows of the table — a program's hot code — global atomics beyond).  A row whose tuple is not the program's word at
 // its pc (self-modified code, pc outside the code segment) or whose chunk is out of range has no proof: its index goes to bad_row.
 constexpr uint32_t ROM_LDS = 4096;
@@ -132,14 +132,16 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
   const uint4* M4 = reinterpret_cast<const uint4*>(M);
   // committed positions of the columns read here (the instruction tuple's head is the same in both modes; opclass, the chunks and s move)
   const uint32_t p_opc = (uint32_t)air::phys_col(air::C_OPC, deferred), p_rc = (uint32_t)air::phys_col(air::C_RC, deferred), p_s = (uint32_t)air::phys_col(air::C_S, deferred);
+  const uint32_t p_rc2 = (uint32_t)air::phys_col(air::C_RC2, deferred), p_g = (uint32_t)air::phys_col(air::C_G, deferred);
   static_assert(air::C_PC == 1 && air::C_OP == 4 && air::C_FHI == 8 && air::C_LIMB == 9, "the tuple's head sits before the first uncommitted column");
   for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < N; i += (uint64_t)gridDim.x * NT) {
     const uint4 b0l = M4[(0 * N + i) * 2], b0h = M4[(0 * N + i) * 2 + 1];                                  // cycle pc0 pc1 pc2 | op fa fb fc
-    const uint32_t fhi_v = M[b8(air::C_FHI, i, N)], opc_v = M[b8(p_opc, i, N)], s_v = M[b8(p_s, i, N)];
-    const uint32_t r[4] = {M[b8(p_rc, i, N)], M[b8(p_rc + 1, i, N)], M[b8(p_rc + 2, i, N)], M[b8(p_rc + 3, i, N)]};
+    const uint32_t fhi_v = M[b8(air::C_FHI, i, N)], opc_v = M[b8(p_opc, i, N)], s_v = M[b8(p_s, i, N)], g_v = M[b8(p_g, i, N)];
+    const uint32_t r[air::N_RC] = {M[b8(p_rc, i, N)], M[b8(p_rc + 1, i, N)], M[b8(p_rc + 2, i, N)], M[b8(p_rc + 3, i, N)],
+                                   M[b8(p_rc2, i, N)], M[b8(p_rc2 + 1, i, N)], M[b8(p_rc2 + 2, i, N)], M[b8(p_rc2 + 3, i, N)]};
     bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
+    for (int k = 0; k < air::N_RC; k++) { if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
     const uint64_t pc = (uint64_t)b0l.y | ((uint64_t)b0l.z << 20) | ((uint64_t)b0l.w << 40);
     const uint64_t u = (pc - 0x1000) >> 2;
     uint32_t ui = 0;
@@ -147,12 +149,14 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       const uint32_t w = code[u];
       ui = (uint32_t)u;
       if (b0h.x == (w & 0x7F) && b0h.y == ((w >> 7) & 0xF) && b0h.z == ((w >> 11) & 0xF) && b0h.w == ((w >> 15) & 0xF) && fhi_v == (w >> 19) && s_v == (w >> 31) &&
-          opc_v == air::opclass_of(w & 0x7F)) {
+          opc_v == air::opclass_of(w & 0x7F) && g_v == air::variant_bit(w & 0x7F)) {
         if (ui < rom_lds) atomicAdd(&h_rom[ui], 1u); else atomicAdd(&rom_mult[ui], 1u);
       } else ok = false;
     } else ok = false;
     if (!ok) atomicMin(bad_row, (unsigned long long)i);
-    side[i] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), ui, 0);
+    // (a chunk outside the table has no proof anyway: masked here so that the packed word stays well-formed)
+    auto c10 = [&](int k) { return r[k] & (uint32_t)(air::RC_TABLE - 1); };
+    side[i] = make_uint4(c10(0) | (c10(1) << 10) | (c10(2) << 20), c10(3) | (c10(4) << 10) | (c10(5) << 20), c10(6) | (c10(7) << 10), ui);
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) if (h_rc[k]) atomicAdd(&rc_mult[k], h_rc[k]);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __res
   const uint32_t u = t - air::RC_TABLE, w = code[u];
   const uint64_t pc = 0x1000 + 4ull * u;
   const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), w & 0x7F, (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF,
-                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F)};
+                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F), air::variant_bit(w & 0x7F)};
   // (fingerprint coordinates in Montgomery form: lk holds R * lambda^j_k, mont_mul(R a, to_mont(f)) = R a f)
   E4 fpm;
 #pragma unroll
@@ -193,23 +197,28 @@ __global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __res
   inv_rom[u] = bb::e_inv_m(dd);
 }
 
-// aux rows: H0..H3, HR (canonical) into blocks 0..2 of the aux matrix, and in the S slot the row's increment d_i = H0 + .. + HR - T / N
+// aux rows: H0..H7, HR (canonical) into blocks 0..4 of the aux matrix, and in the S slot (the second half of block 4) the row's increment
+// d_i = H0 + .. + H7 + HR - T / N
 // (the scan kernels below turn the increments into the running sum S_i = sum_{j < i} d_j)
 __global__ __launch_bounds__(NT) void aux_rows_kernel(const uint4* __restrict__ side, uint64_t N, const E4* __restrict__ inv_rc, const E4* __restrict__ inv_rom,
                                                        const ProveParams* __restrict__ pp, uint32_t* __restrict__ A) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   const uint4 sd = side[i];
-  const E4 h0 = inv_rc[sd.x & 0xFFFF], h1 = inv_rc[sd.x >> 16], h2 = inv_rc[sd.y & 0xFFFF], h3 = inv_rc[sd.y >> 16], hr = inv_rom[sd.z];
-  E4 d = bb::e_add(bb::e_add(bb::e_add(h0, h1), bb::e_add(h2, h3)), hr);
-#pragma unroll
-  for (int k = 0; k < 4; k++) d.c[k] = bb::sub(d.c[k], pp->lk[air::LK_TN + k]);
+  const uint32_t ch[air::N_RC] = {sd.x & 1023, (sd.x >> 10) & 1023, sd.x >> 20, sd.y & 1023, (sd.y >> 10) & 1023, sd.y >> 20, sd.z & 1023, sd.z >> 10};
   uint4* A4 = reinterpret_cast<uint4*>(A);
   auto put = [&](uint32_t blk, uint32_t half, const E4& e) { const E4 c = bb::e_from_mont(e); A4[((uint64_t)blk * N + i) * 2 + half] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
-  put(0, 0, h0); put(0, 1, h1); put(1, 0, h2); put(1, 1, h3); put(2, 0, hr); put(2, 1, d);
+  const E4 hr = inv_rom[sd.w];
+  E4 d = hr;
+#pragma unroll
+  for (int k = 0; k < air::N_RC; k++) { const E4 h = inv_rc[ch[k]]; d = bb::e_add(d, h); put((uint32_t)k >> 1, (uint32_t)k & 1, h); }
+#pragma unroll
+  for (int k = 0; k < 4; k++) d.c[k] = bb::sub(d.c[k], pp->lk[air::LK_TN + k]);
+  static_assert(air::A_HR == 4 * air::N_RC && air::A_S == air::A_HR + 4 && air::A_HR % 8 == 0, "aux layout: helpers, then HR | S in one block");
+  put(air::A_HR / 8, 0, hr); put(air::A_HR / 8, 1, d);
 }
 
-// Exclusive prefix sum (coordinate-wise, mod p) over the S slot of the aux matrix (block 2, second half), three launches:
+// Exclusive prefix sum (coordinate-wise, mod p) over the S slot of the aux matrix (block A_S / 8, second half), three launches:
 //   local: every workgroup scans SCAN_ROWS consecutive rows in place and leaves their total in sums[block]
 //   sums:  one workgroup turns sums[] into exclusive offsets
 //   add:   every row adds its workgroup's offset
@@ -233,7 +242,7 @@ __device__ __forceinline__ uint4 block_exclusive_scan(uint4 v, uint4* lds /* NT 
 }
 __global__ __launch_bounds__(NT) void scan_local_kernel(uint32_t* __restrict__ A, uint64_t N, uint4* __restrict__ sums) {
   __shared__ uint4 lds[NT];
-  uint4* S = reinterpret_cast<uint4*>(A) + (uint64_t)2 * N * 2 + 1;          // element i at S[2 i]
+  uint4* S = reinterpret_cast<uint4*>(A) + (uint64_t)(air::A_S / 8) * N * 2 + 1;          // element i at S[2 i]
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_ROWS + (uint64_t)threadIdx.x * SCAN_PER;
   uint4 v[SCAN_PER], run = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(NT) void scan_sums_kernel(uint4* __restrict__ sums,
   }
 }
 __global__ __launch_bounds__(NT) void scan_add_kernel(uint32_t* __restrict__ A, uint64_t N, const uint4* __restrict__ sums) {
-  uint4* S = reinterpret_cast<uint4*>(A) + (uint64_t)2 * N * 2 + 1;
+  uint4* S = reinterpret_cast<uint4*>(A) + (uint64_t)(air::A_S / 8) * N * 2 + 1;
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   S[2 * i] = add4m(S[2 * i], sums[i / SCAN_ROWS]);

@@ -18,7 +18,7 @@ namespace {
 
 using bb::E4;
 constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WA = air::W_AUX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 8;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 9;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
 
@@ -261,7 +261,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       const uint32_t cw = le32(32 + 4 * u);
       const uint64_t pc = 0x1000 + 4 * (uint64_t)u;
       const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), cw & 0x7F, (cw >> 7) & 0xF, (cw >> 11) & 0xF,
-                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F)};
+                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F), air::variant_bit(cw & 0x7F)};
       E4 fp = lam[air::N_TUPLE];
       for (int j = 0; j < air::N_TUPLE; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(f[j])));
       d[air::RC_TABLE + u] = bb::e_sub(alpha_l, fp);

@@ -15,9 +15,9 @@ from . import pipeline as pl
 from . import runtime as rt
 
 P = 2013265921
-W_MAIN = 144                 # COMMITTED main-trace columns of a default-mode run (zkir_main_trace_width); the AIR has 160 logical columns (air.h)
-W_MAIN_DEFERRED = 160        # deferred mode: the storage states are committed too
-W_AUX = 24                  # aux trace of the lookup argument (air.h): H0..H3, HR, S as four base columns each
+W_MAIN = 152                 # COMMITTED main-trace columns of a default-mode run (zkir_main_trace_width); the AIR has 169 logical columns (air.h)
+W_MAIN_DEFERRED = 168        # deferred mode: the storage states are committed too
+W_AUX = 40                  # aux trace of the lookup argument (air.h): H0..H7, HR, S as four base columns each
 RC_TABLE = 1024
 HEADER_WORDS = 157
 
@@ -88,7 +88,7 @@ def to_b8(cols: torch.Tensor) -> torch.Tensor:
 
 
 def main_width(deferred: bool = False) -> int:
-    """Committed main-trace columns of a run (zkir_main_trace_width_for): 144 in the default VM mode, 160 with the deferred model."""
+    """Committed main-trace columns of a run (zkir_main_trace_width_for): 152 in the default VM mode, 168 with the deferred model."""
     return W_MAIN_DEFERRED if deferred else W_MAIN
 
 
