@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
   col(C_SB) = sb;
   col(C_RC2) = u[0] & (RC_TABLE - 1); col(C_RC2 + 1) = u[0] >> RC_BITS; col(C_RC2 + 2) = u[1] & (RC_TABLE - 1); col(C_RC2 + 3) = u[1] >> RC_BITS;
   const uint32_t flag = (cls == K_BRE || cls == K_SE) ? 1u - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0u;
-  const uint32_t pol = op - family_base(cls);                                   // 0 / 1 inside a family; the opcode itself (< 128) on other rows
+  const uint32_t pol = op - family_base(cls) - 2u * g;                          // op = base + 2 g + pol: 0 / 1 inside a family; the opcode itself (minus 2 g) on other rows
   const uint32_t fx = flag ? 1u - pol : pol;                                    // flag XOR pol where it matters (flag = 0 outside the families)
   col(C_FLAG) = flag; col(C_FX) = fx;
   const uint32_t tk = branch ? fx : 0;
