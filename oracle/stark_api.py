@@ -8,7 +8,7 @@ import numpy as np
 from . import api
 
 P = 2013265921
-W_MAIN = 169                # LOGICAL main-trace columns (what main_trace() returns and the constraints read)
+W_MAIN = 172                # LOGICAL main-trace columns (what main_trace() returns and the constraints read)
 W_COMMITTED = 152           # columns of the committed matrix in the default VM mode (R0's limbs and the storage states are identically zero there)
 W_COMMITTED_DEFERRED = 168  # deferred mode: only R0's limbs and state are left out
 W_AUX = 40                  # aux trace of the lookup argument: H0..H7, HR, S as four base columns each

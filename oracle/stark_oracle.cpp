@@ -180,10 +180,11 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //           not a branch or a jump (loads, stores, the remaining ALU opcodes, ECALL: execute.rs advances pc by 4 in each of them)
 //   162 b0 = the bit JALR clears: next pc + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs mod 2^64 (execute.rs:649-658), carries d0 d1 d2
 // ---------------------------------------------------------------------------------------------
-static const int W_MAIN = 169;
+static const int W_MAIN = 172;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168 };
+       C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
+       C_K4 = 169, C_Q = 171 };
 static const int N_RC = 8;                                         // range lookups of a row: the chunks of z (C_RC ..) and of u (C_RC2 ..)
 static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 24 base columns = six extension-field columns,
@@ -197,9 +198,11 @@ static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // 144 columns in default mode (141 + 3), 160 in deferred mode (156 + 4).  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
 static const int W_AUX = 40;
-static inline bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
-static inline int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a non-virtual column
-static inline int phys_width(bool deferred) { return deferred ? 168 : 152; }   // 169 - 19 = 150 -> 152, 169 - 4 = 165 -> 168
+// (AIR v6) the class column "other, jumps" (C_K3 + 1) is identically zero in the default mode too — no opcode's class is oj there (constraint 4) — and is not committed
+static const int C_KOJ = C_K3 + 1;
+static inline bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+static inline int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
+static inline int phys_width(bool deferred) { return deferred ? 168 : 152; }   // 172 - 20 = 152, 172 - 4 = 168: whole blocks of 8, no padding
 // logical [W_MAIN][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, bool deferred, std::vector<F>& out) {
   out.assign((size_t)phys_width(deferred) * N, 0);
@@ -215,15 +218,15 @@ static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the refere
 static const int N_TUPLE = 11;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass, g (variant bit)
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
 
-enum { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, N_CLASS = 13 };
-static inline int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : C_K3 + (k - 11); }
+enum { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, K_CMN = 13, K_CMZ = 14, N_CLASS = 15 };
+static inline int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
 static const uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                       OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
 // the even opcode of a family (its polarity-0 member); 0 for the classes that are one opcode
 static inline uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLT : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0; }
 // AIR v5: the families of ordered comparisons have FOUR members, op = base + 2 g + pol: SLTU SGEU SLT SGE (base 0x20, g = signed) and
 // BLT BGE BLTU BGEU (base 0x42, g = unsigned).  g is the word's VARIANT BIT, part of the ROM tuple (0 for every other opcode).
-static const uint32_t OP_SLT = 0x22, OP_SGE = 0x23;
+static const uint32_t OP_SLT = 0x22, OP_SGE = 0x23, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28;
 static inline uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU) ? 1u : 0u; }
 
 #pragma pack(push, 1)
@@ -260,7 +263,7 @@ static inline F opclass_of(uint32_t op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
     case OP_SLTU: case OP_SGEU: case OP_SLT: case OP_SGE: return K_SU;
-    case OP_JALR: return K_JALR; default: return K_OTH;
+    case OP_JALR: return K_JALR; case OP_CMOV: case OP_CMOVNZ: return K_CMN; case OP_CMOVZ: return K_CMZ; default: return K_OTH;
   }
 }
 // The instruction ROM of a program blob (Program::to_bytes layout, program.rs:170-214,300-346): code word t sits at pc = 0x1000 + 4 t
@@ -314,7 +317,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     }
     int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
     if (cls == K_OTH && !D) cls = (int)opclass_of(op);
-    if (cls == K_OTH && D && opclass_of(op) != K_OTH && opclass_of(op) != K_ADD && opclass_of(op) != K_ADDI && opclass_of(op) != K_SUB && opclass_of(op) != K_SE && opclass_of(op) != K_SU)
+    if (cls == K_OTH && D && (opclass_of(op) == K_BRE || opclass_of(op) == K_BRU || opclass_of(op) == K_JAL || opclass_of(op) == K_JALR))
       cls = K_OJ;                                             // deferred mode: no opcode semantics, but "other" is sequential — branches and jumps run as the free-pc class
     col(kcol(cls))[i] = 1;
     col(C_OPC)[i] = opclass_of(op);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
@@ -344,7 +347,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       if (cls != K_SUB) { u[0] = (F)ta; u[1] = (F)tb; }
     }
     col(C_SB)[i] = sb;
-    col(C_RC2)[i] = u[0] & (RC_TABLE - 1); col(C_RC2 + 1)[i] = u[0] >> RC_BITS; col(C_RC2 + 2)[i] = u[1] & (RC_TABLE - 1); col(C_RC2 + 3)[i] = u[1] >> RC_BITS;
+    F rc2[4] = {u[0] & (RC_TABLE - 1), u[0] >> RC_BITS, u[1] & (RC_TABLE - 1), u[1] >> RC_BITS};
     const F flag = (cls == K_BRE || cls == K_SE) ? 1 - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0;
     const F pol = fsub(fsub(op, family_base(cls)), 2 * g);  // op = base + 2 g + pol: 0 / 1 inside a family; the opcode itself on every other row (fx is unused there)
     const F fx = fsub(fadd(flag, pol), fmul(2, fmul(pol, flag)));
@@ -359,6 +362,12 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     col(C_SE)[i] = se;
     F y[3] = {0, 0, 0};
     int rd = -1;
+    // (v6) nz = [rs2 != 0] over the raw 64 bits, stated for EVERY row on the sum of the three limbs of xc (each limb is in range — the third
+    // one by the range check of every written y2 below — so the sum is zero only if all of them are); q = "a conditional move whose condition holds"
+    const F sx = (F)(((uint64_t)xc[0] + xc[1] + xc[2]) % P), nz = sx != 0;
+    col(C_NZ)[i] = nz; col(C_IVZ)[i] = nz ? finv(sx) : 0;
+    const F q = cls == K_CMN ? nz : cls == K_CMZ ? 1 - nz : 0;
+    col(C_Q)[i] = q;
     if (cls == K_ADD || cls == K_ADDI) {
       const F b0 = cls == K_ADD ? xc[0] : im0, b1 = cls == K_ADD ? xc[1] : im1;
       const uint64_t v0 = (uint64_t)xb[0] + b0; c0 = (F)(v0 >> 20); y[0] = (F)(v0 & 0xFFFFF);
@@ -371,6 +380,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       rd = fa;
     } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
+    else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; if (q) rd = fa; }   // execute.rs:434-472: rd = rs1 (raw) if the condition holds, nothing changes otherwise
     if (rd > 0) col(C_WR + rd - 1)[i] = 1;
     if (cls == K_OTH || (cls == K_OJ && D)) {               // any other instruction: what it wrote is read off the next row
       const PackedRow& q = rows[i + 1];
@@ -384,8 +394,11 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       }
     }
     for (int l = 0; l < 3; l++) col(C_Y + l)[i] = y[l];
+    if (cls == K_OTH) {                                       // (v6) the bits above 40 of what an "other" row writes are range-checked: y2 = R4 + 2^10 R5 + 2^20 R6, R7 = 64 R6 (so R6 < 16: 24 bits)
+      rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64 * rc2[2];
+    }
+    for (int k = 0; k < 4; k++) col(C_RC2 + k)[i] = rc2[k];
     if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
-    col(C_Z)[i] = z[0]; col(C_Z + 1)[i] = z[1];
     col(C_RC)[i] = z[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = z[0] >> RC_BITS; col(C_RC + 2)[i] = z[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = z[1] >> RC_BITS;
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
     if (cls == K_JALR) {                                                                            // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
@@ -501,7 +514,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 448;
-static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 9;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns)
+static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
 // FRI schedule: committed layer j has 2^log_m values and is folded ks[j] times (binary folds with beta, beta^2, beta^4, ...)
@@ -567,7 +580,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   for (int r = 0; r < 16; r++) boolean(loc[C_STATE + r]);
   for (int r = 0; r < 15; r++) { boolean(loc[C_WR + r]); boolean(loc[C_SELB + r]); boolean(loc[C_SELC + r]); }
   for (int k = 0; k < N_CLASS; k++) boolean(K[k]);
-  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]); boolean(loc[C_SB]);
+  boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]); boolean(loc[C_SB]); boolean(loc[C_NZ]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
   { E sum = e_from(0); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
@@ -591,6 +604,12 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   push(emul(eadd(eadd(eadd(Kbr, emul(nD, K[K_OJ])), K[K_HALT]), K[K_PAD]), w0));   // branches write nothing (BLT / BGE too: class oj in default mode)
   push(esub(b1, fb)); push(esub(emul(b1, b1), b2));
   push(esub(c1s, eadd(fc, emul(Kbr, esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));
+  //    (v6) conditional moves CMOV / CMOVNZ (class cmn: the condition is rs2 != 0) and CMOVZ (class cmz: rs2 == 0), execute.rs:434-472:
+  //    q = "this row is a conditional move whose condition holds"; it writes rd = field a exactly then (nothing at all otherwise)
+  const E Kcm = eadd(K[K_CMN], K[K_CMZ]), nz = loc[C_NZ], q = loc[C_Q];
+  push(esub(q, eadd(emul(K[K_CMN], nz), emul(K[K_CMZ], esub(one, nz)))));
+  push(emul(q, esub(w1, fa)));
+  push(emul(esub(Kcm, q), w0));
   // 6. operand fetch
   for (int l = 0; l < 3; l++) {
     E xb = e_from(0), xc = e_from(0);
@@ -603,7 +622,9 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E im0 = eadd(esub(imm17, emul_f(s, 1u << 17)), emul_f(s, 1u << 20)), im1 = emul_f(s, 0xFFFFF);
   const E lo20 = esub(eadd(eadd(fb, emul_f(fc, 16)), emul_f(fhi, 256)), emul_f(s, 1u << 20));
   //    — stated on z, the range-checked pair of limbs (13.); y = z on the rows that write it (and on "other" rows, whose y stays in range)
-  const E *xb = loc + C_XB, *xc = loc + C_XC, *y = loc + C_Y, *pc = loc + C_PC, *z = loc + C_Z;
+  const E *xb = loc + C_XB, *xc = loc + C_XC, *y = loc + C_Y, *pc = loc + C_PC;
+  const E* R = loc + C_RC;
+  const E z[2] = {eadd(R[0], emul_f(R[1], RC_TABLE)), eadd(R[2], emul_f(R[3], RC_TABLE))};   // (v6) z IS its chunks: no columns of its own
   const E c0 = loc[C_C0], c1 = loc[C_C1];
   push(emul(K[K_ADD], eadd(esub(esub(z[0], xb[0]), xc[0]), emul(two20, c0))));
   push(emul(K[K_ADD], eadd(esub(esub(esub(z[1], xb[1]), xc[1]), c0), emul(two20, c1))));
@@ -641,6 +662,18 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     const E Ky = eadd(eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), eadd(K[K_OTH], K[K_JALR])), emul(Dm, K[K_OJ]));   // (oj writes only in deferred mode)
     push(emul(Ky, esub(y[0], z[0]))); push(emul(Ky, esub(y[1], z[1])));
     push(emul(Kcmp, esub(y[0], loc[C_FX]))); push(emul(Kcmp, y[1])); push(emul(Kcmp, y[2]));
+    for (int l = 0; l < 3; l++) push(emul(Kcm, esub(y[l], xb[l])));          // (v6) a conditional move writes rs1's raw value (all three limbs)
+    // (v6) the bits above 40 of what an "other" row writes: y2 = R4 + 2^10 R5 + 2^20 R6 with R7 = 64 R6 — all four in the 10-bit table, so y2 < 2^24.
+    // With it EVERY limb of every register is in range by induction (constrained classes write 0, pc2 + c1 or an operand's limb there)
+    const E* R2 = loc + C_RC2;
+    push(emul(K[K_OTH], esub(esub(esub(y[2], R2[0]), emul_f(R2[1], RC_TABLE)), emul_f(R2[2], RC_TABLE * RC_TABLE))));
+    push(emul(K[K_OTH], esub(R2[3], emul_f(R2[2], 64))));
+  }
+  // 7c. (v6) nz = [xc != 0] on every row, on the sum of xc's limbs (in range, so the sum vanishes only if they all do)
+  {
+    const E sx = eadd(eadd(xc[0], xc[1]), xc[2]);
+    push(emul(esub(one, nz), sx));
+    push(esub(nz, emul(sx, loc[C_IVZ])));
   }
   // 8. BNE compares the raw 64-bit values (execute.rs:588-596): ne = [xb != xc] over all three limbs
   {
@@ -701,10 +734,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
       out[k] = eadd(lo, emul_f(hi, WEXT));
     }
   };
-  // 13. the limbs of z are two 10-bit chunks each (their range is the lookup below)
-  const E* R = loc + C_RC;
-  push(esub(esub(z[0], R[0]), emul_f(R[1], RC_TABLE)));
-  push(esub(esub(z[1], R[2]), emul_f(R[3], RC_TABLE)));
+  // 13. (the limbs of z are two 10-bit chunks each: since v6 z is DEFINED as R0 + 1024 R1, R2 + 1024 R3 — the two constraints that tied the z columns
+  //     to the chunks are gone with the columns)
   // 14. range helpers: H_i (alpha - R_i) = 1
   for (int i = 0; i < N_RC; i++) {
     E d[4], pr[4];

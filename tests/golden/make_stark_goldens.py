@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v5, proof format v9).
+"""Writes tests/golden/stark_goldens.json: frozen outputs of the self-defined prover stages (ZKIR-STARK, AIR v6, proof format v10).
 
 The reference has no prover, so nothing external can pin these stages; this file FREEZES them — it pins nothing:
 the values are produced by this repository's own oracle, so they guard against DRIFT only: the
@@ -23,8 +23,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
 
-ADD, SUB, MUL, ADDI, SLLI, SLTU, SGEU, SLT, SGE, SEQ, SNE, LW, SW, BEQ, BNE, BLT, BGE, BLTU, BGEU, JAL, JALR, ECALL = \
-    0x00, 0x01, 0x02, 0x08, 0x1B, 0x20, 0x21, 0x22, 0x23, 0x24, 0x25, 0x34, 0x3A, 0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x48, 0x49, 0x50
+ADD, SUB, MUL, ADDI, SLLI, SLTU, SGEU, SLT, SGE, SEQ, SNE, CMOV, CMOVZ, CMOVNZ, LB, LW, SW, BEQ, BNE, BLT, BGE, BLTU, BGEU, JAL, JALR, ECALL = \
+    0x00, 0x01, 0x02, 0x08, 0x1B, 0x20, 0x21, 0x22, 0x23, 0x24, 0x25, 0x26, 0x27, 0x28, 0x30, 0x34, 0x3A, 0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x48, 0x49, 0x50
 
 
 def r_(op, rd, rs1, rs2): return op | rd << 7 | rs1 << 11 | rs2 << 15
@@ -66,6 +66,12 @@ SIGNED_LOOP = blob([i_(ADDI, 1, 0, -6), i_(ADDI, 2, 0, -2), i_(ADDI, 3, 0, 3), i
                     i_(BGE, 2, 1, 8), i_(ADDI, 7, 7, 16), i_(BLTU, 1, 3, 8), i_(ADDI, 8, 8, 16), i_(BLT, 14, 15, 8), i_(ADDI, 1, 1, 1), i_(BLT, 1, 13, -84),
                     i_(ADDI, 1, 0, -6), i_(BGE, 14, 15, -92)])
 
+# the conditional moves of AIR v6 with a toggling condition, a raw 64-bit source / condition (sign-extended byte load), rd = r0 (the product ships it as spec.cmov_loop_program)
+CMOV_LOOP = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 7), i_(ADDI, 13, 0, 1), i_(ADDI, 10, 0, 0), i_(ADDI, 5, 0, 0x80), i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(SW, 6, 5, 0),
+                  i_(LB, 7, 6, 0), i_(ADDI, 9, 0, 1), i_(SLLI, 9, 9, 20),
+                  r_(CMOV, 11, 2, 10), r_(CMOVZ, 12, 7, 10), r_(CMOVNZ, 14, 9, 10), r_(CMOV, 0, 2, 13), r_(CMOVZ, 15, 2, 9), r_(CMOVNZ, 15, 7, 7), r_(CMOVZ, 4, 7, 0),
+                  i_(ADDI, 11, 0, 0), i_(ADDI, 12, 0, 0), i_(ADDI, 14, 0, 0), i_(ADDI, 15, 0, 0), i_(ADDI, 4, 0, 0), r_(SUB, 10, 13, 10), i_(ADDI, 1, 1, 1), j_(JAL, 0, -56)])
+
 CASES = [
     dict(name="fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=False),
     dict(name="sha_2p9", blob=SHA_CHAIN, max_cycles=1 << 9, deferred=False),
@@ -74,6 +80,7 @@ CASES = [
     dict(name="compare_loop_600_rows", blob=CMP_LOOP, max_cycles=600, deferred=False),
     dict(name="call_loop_500_rows", blob=CALL_LOOP, max_cycles=500, deferred=False),
     dict(name="signed_loop_700_rows", blob=SIGNED_LOOP, max_cycles=700, deferred=False),
+    dict(name="cmov_loop_400_rows", blob=CMOV_LOOP, max_cycles=400, deferred=False),
 ]
 
 
@@ -96,7 +103,7 @@ def golden(case):
 
 if __name__ == "__main__":
     out = {"_about": "frozen outputs of ZKIR-STARK (AIR v4, proof format v8; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
-           "proof_version": 9, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
+           "proof_version": 10, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
            "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
            "cases": [golden(c) for c in CASES]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")

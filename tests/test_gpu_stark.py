@@ -90,6 +90,7 @@ PROGRAMS = {"fib": (spec.fib_endless_program, {}), "sha": (spec.sha256_chain_pro
             "cmp": (spec.compare_loop_program, {}), "cmp_deferred": (spec.compare_loop_program, {"enable_deferred_model": True}),
             "call": (spec.call_loop_program, {}), "call_deferred": (spec.call_loop_program, {"enable_deferred_model": True}),
             "sgn": (spec.signed_loop_program, {}), "sgn_deferred": (spec.signed_loop_program, {"enable_deferred_model": True}),
+            "cmov": (spec.cmov_loop_program, {}), "cmov_deferred": (spec.cmov_loop_program, {"enable_deferred_model": True}),
             "fib30": (lambda: spec.fib_program(30), {}), "exit42": (lambda: spec.Program.from_code([spec.addi(10, 0, 0), spec.addi(11, 0, 42), spec.ecall()]), {})}
 
 
@@ -111,9 +112,9 @@ def _case(name, n):
 
 @pytest.mark.parametrize("name,n", [("fib", 64), ("fib", 1024), ("fib", 4096), ("fib", 1000), ("fib", 5), ("sha", 512), ("sha", 700), ("deferred", 256),
                                     ("fib30", None), ("exit42", None), ("cmp", 600), ("cmp", 5000), ("cmp_deferred", 300), ("call", 500), ("call", 3000),
-                                    ("call_deferred", 250), ("sgn", 700), ("sgn", 5000), ("sgn_deferred", 300)])
+                                    ("call_deferred", 250), ("sgn", 700), ("sgn", 5000), ("sgn_deferred", 300), ("cmov", 400), ("cmov", 3000), ("cmov_deferred", 300)])
 def test_main_trace_and_commit_match_oracle(name, n):
-    """All committed columns of the padded main trace (152 in default mode, 168 deferred: the oracle's 169 logical columns minus the ones
+    """All committed columns of the padded main trace (152 in default mode, 168 deferred: the oracle's 172 logical columns minus the ones
     that are identically zero), the LDE and the commitment root, for power-of-two and ragged row counts and for programs that halt on
     their own (Exit / padding rows)."""
     from zkir_amd import stark
@@ -159,7 +160,7 @@ def test_commit_2p16_root_and_properties():
 
 @pytest.mark.parametrize("name,n", [("fib", 8), ("fib", 5), ("fib", 32), ("fib", 256), ("fib", 2048), ("fib", 1500), ("sha", 512), ("sha", 300), ("deferred", 1024),
                                     ("fib30", None), ("exit42", None), ("fib", 8192), ("cmp", 600), ("cmp", 4096), ("cmp_deferred", 300), ("call", 500),
-                                    ("call", 2048), ("call_deferred", 250), ("sgn", 700), ("sgn", 4096), ("sgn_deferred", 300)])
+                                    ("call", 2048), ("call_deferred", 250), ("sgn", 700), ("sgn", 4096), ("sgn_deferred", 300), ("cmov", 400), ("cmov", 2048), ("cmov_deferred", 300)])
 def test_proof_bytes_match_oracle_and_verify(name, n):
     """End-to-end proof (quotient over the v1 AIR, openings, DEEP, FRI, grinding, queries): GPU proof words == oracle proof words,
     and both verifiers accept them.  The GPU evaluates openings barycentrically on the LDE coset, the oracle by Horner on

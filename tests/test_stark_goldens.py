@@ -25,7 +25,8 @@ def test_goldens_describe_the_shipped_programs():
     assert G["committed_width"] == so.W_COMMITTED == so.committed_width(False) == 152 and G["committed_width_deferred"] == so.committed_width(True) == 168
     assert bytes.fromhex(CASES["call_loop_500_rows"]["program_blob_hex"]) == spec.call_loop_program().to_bytes()
     assert bytes.fromhex(CASES["signed_loop_700_rows"]["program_blob_hex"]) == spec.signed_loop_program().to_bytes()
-    assert G["proof_version"] == 9 and G["main_trace_width"] == so.W_MAIN == 169 and G["num_constraints"] == so.lib().so_num_constraints()
+    assert bytes.fromhex(CASES["cmov_loop_400_rows"]["program_blob_hex"]) == spec.cmov_loop_program().to_bytes()
+    assert G["proof_version"] == 10 and G["main_trace_width"] == so.W_MAIN == 172 and G["num_constraints"] == so.lib().so_num_constraints()
     assert [int(x) for x in so.permute(list(range(12)))] == G["poseidon2_of_0_to_11"]
     st = np.arange(12, dtype=np.uint32)
     rt.lib().zkir_poseidon2_permute(st.ctypes.data)                                  # the product's host permutation
@@ -42,7 +43,7 @@ def test_oracle_reproduces_goldens(name):
     assert [int(x) for x in pub.prog] == c["program_digest"] and [int(x) for x in pub.io] == c["io_digest"]
     proof = so.prove(res.rows, pub)
     t0 = so.proof_layout(proof)["trace_root"]
-    assert int(proof[1]) == 9 and [int(x) for x in proof[t0:t0 + 4]] == c["trace_root"] and [int(x) for x in proof[t0 + 4:t0 + 8]] == c["aux_root"]
+    assert int(proof[1]) == 10 and [int(x) for x in proof[t0:t0 + 4]] == c["trace_root"] and [int(x) for x in proof[t0 + 4:t0 + 8]] == c["aux_root"]
     assert [int(x) for x in proof[t0 + 8:t0 + 12]] == c["quotient_root"]
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof) == 0                                                      # the product's verifier accepts the frozen proofs

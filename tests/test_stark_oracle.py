@@ -145,12 +145,18 @@ def test_merkle_layers_and_paths():
 # column map of the main trace (AIR v3: oracle/stark_oracle.cpp)
 C_PC, C_OP, C_FA, C_LIMB, C_STATE, C_WR, C_SELB, C_SELC, C_XB, C_XC, C_Y, C_K, C_OPC, C_RC, C_S, C_C0, C_D0, C_DL0, C_NE, C_IV, C_TK = \
     1, 4, 5, 9, 57, 73, 88, 103, 118, 121, 124, 127, 134, 135, 139, 141, 143, 146, 147, 148, 151
-C_K2, C_Z, C_FLAG, C_FX, C_K3, C_B0, C_RC2, C_G, C_SB = 152, 156, 158, 159, 160, 162, 163, 167, 168
-K_ADD, K_ADDI, K_BRE, K_JAL, K_OTH, K_HALT, K_PAD, K_SUB, K_BRU, K_SE, K_SU, K_JALR, K_OJ = range(13)
+C_K2, C_NZ, C_IVZ, C_FLAG, C_FX, C_K3, C_B0, C_RC2, C_G, C_SB, C_K4, C_Q = 152, 156, 157, 158, 159, 160, 162, 163, 167, 168, 169, 171
+
+
+def Z(m, l):
+    """z_l, the row's first range-checked pair of limbs: since AIR v6 it has no columns of its own, it IS its chunks."""
+    return m[C_RC + 2 * l].astype(np.int64) + 1024 * m[C_RC + 2 * l + 1].astype(np.int64)
+
+K_ADD, K_ADDI, K_BRE, K_JAL, K_OTH, K_HALT, K_PAD, K_SUB, K_BRU, K_SE, K_SU, K_JALR, K_OJ, K_CMN, K_CMZ = range(15)
 K_BNE = K_BRE                                                    # BEQ / BNE share a class: the family's comparison with either polarity
-KCOL = [C_K + k for k in range(7)] + [C_K2 + k for k in range(4)] + [C_K3 + k for k in range(2)]
+KCOL = [C_K + k for k in range(7)] + [C_K2 + k for k in range(4)] + [C_K3 + k for k in range(2)] + [C_K4 + k for k in range(2)]
 W = so.W_MAIN
-OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU, 0x22: K_SU, 0x23: K_SU, 0x49: K_JALR, 0x42: K_BRU, 0x43: K_BRU}
+OPCLASS = {0x00: K_ADD, 0x08: K_ADDI, 0x40: K_BRE, 0x41: K_BRE, 0x48: K_JAL, 0x01: K_SUB, 0x44: K_BRU, 0x45: K_BRU, 0x24: K_SE, 0x25: K_SE, 0x20: K_SU, 0x21: K_SU, 0x22: K_SU, 0x23: K_SU, 0x49: K_JALR, 0x42: K_BRU, 0x43: K_BRU, 0x26: K_CMN, 0x28: K_CMN, 0x27: K_CMZ}
 
 
 def test_main_trace_columns_and_commit():
@@ -159,7 +165,7 @@ def test_main_trace_columns_and_commit():
     rows = oracle.run(blob, max_cycles=n, enable_execution_trace=True).rows
     pub = so.public_inputs(n, blob)
     m = so.main_trace(rows, pub)
-    assert m.shape == (169, 64) and (m < P).all()
+    assert m.shape == (172, 64) and (m < P).all()
     assert list(m[0]) == list(range(64))                         # the cycle column keeps counting through the padding
     assert np.array_equal(m[1][:n], rows["pc"] & 0xFFFFF) and not m[3].any()
     assert np.array_equal(m[C_OP][:n], rows["instruction"] & 0x7F)
@@ -185,32 +191,31 @@ def test_main_trace_columns_and_commit():
     # opclass = class of the instruction WORD on every row (halt and padding rows included); the range chunks split y's two low limbs
     opc = np.array([OPCLASS.get(int(o), K_OTH) for o in m[C_OP]])
     assert np.array_equal(m[C_OPC], opc)
-    assert (m[C_RC:C_RC + 4] < 1024).all() and not m[C_RC2:C_RC2 + 4].any() and not m[C_G].any() and not m[C_SB].any()   # the second range-checked pair serves ordered comparisons only
-    assert np.array_equal(m[C_RC] + 1024 * m[C_RC + 1], m[C_Z]) and np.array_equal(m[C_RC + 2] + 1024 * m[C_RC + 3], m[C_Z + 1])
+    assert (m[C_RC:C_RC + 4] < 1024).all() and not m[C_RC2:C_RC2 + 4].any() and not m[C_G].any() and not m[C_SB].any()   # the second range-checked pair serves ordered comparisons (and the high bits of what "other" rows write)
     wrote = cls[K_ADD] | cls[K_ADDI] | cls[K_JAL]
-    assert np.array_equal(m[C_Z][wrote == 1], m[C_Y][wrote == 1]) and not m[C_Z][wrote == 0].any()      # z = the written limbs; zero on BNE / halt / pad rows
+    assert np.array_equal(Z(m, 0)[wrote == 1], m[C_Y][wrote == 1]) and np.array_equal(Z(m, 1)[wrote == 1], m[C_Y + 1][wrote == 1]) and not Z(m, 0)[wrote == 0].any()      # z = the written limbs; zero on BNE / halt / pad rows
     # padding rows repeat the state of the last executed row
     assert (m[C_LIMB:C_STATE + 16, n:] == m[C_LIMB:C_STATE + 16, n - 1:n]).all() and (m[C_PC:C_PC + 3, n:] == m[C_PC:C_PC + 3, n - 1:n]).all()
     root, L = so.commit_trace(rows, 1, want_lde=True, pub=pub)
     # what is committed: the logical matrix minus the columns that are identically zero (R0's limbs, the 16 storage states of the default
-    # mode), packed: 150 columns + 2 of zero padding = 152, whole blocks of 8
-    kept = [c for c in range(169) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16)]
-    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 150
+    # mode, since v6 the class column "other, jumps", which only the deferred mode uses), packed: 152 columns, whole blocks of 8, no padding
+    kept = [c for c in range(172) if not (C_LIMB <= c < C_LIMB + 3 or C_STATE <= c < C_STATE + 16 or c == C_K3 + 1)]
+    assert not m[C_LIMB:C_LIMB + 3].any() and not m[C_STATE:C_STATE + 16].any() and len(kept) == 152 and not m[C_K3 + 1].any()
     mc = so.to_committed(m)
-    assert mc.shape == (152, 64) and np.array_equal(mc[:150], m[kept]) and not mc[150:].any()
+    assert mc.shape == (152, 64) and np.array_equal(mc, m[kept])
     assert L.shape == (152, 128)
     assert np.array_equal(so.merkle(L), root)
     coeffs, col = so.lde(m[0], 1)
     assert np.array_equal(col, L[0])
     coeffs, col = so.lde(m[C_WR], 1)
     assert np.array_equal(col, L[C_WR - 19])
-    # deferred mode keeps the storage states (only R0's limbs and state are left out): 165 columns + 3 of zero padding
+    # deferred mode keeps the storage states (only R0's limbs and state are left out): 168 columns
     rows_d = oracle.run(blob, max_cycles=n, enable_execution_trace=True, enable_deferred_model=True).rows
     pub_d = so.public_inputs(n, blob, deferred=True)
     m_d = so.main_trace(rows_d, pub_d)
-    kept_d = [c for c in range(169) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
+    kept_d = [c for c in range(172) if not (C_LIMB <= c < C_LIMB + 3 or c == C_STATE)]
     mc_d = so.to_committed(m_d, deferred=True)
-    assert mc_d.shape == (168, 64) and np.array_equal(mc_d[:165], m_d[kept_d]) and not mc_d[165:].any() and m_d[C_STATE + 1:C_STATE + 16].any()
+    assert mc_d.shape == (168, 64) and np.array_equal(mc_d, m_d[kept_d]) and m_d[C_STATE + 1:C_STATE + 16].any()
     assert so.commit_trace(rows_d, 1, want_lde=True, pub=pub_d)[1].shape == (168, 128)
 
 
@@ -232,7 +237,7 @@ def test_main_trace_of_the_opcode_families():
         assert cls[k][i] == 1 and m[C_OPC, i] == k
         fa, fb, fc = (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF
         reg = [int(v) for v in rows["registers"][i]]
-        z = int(m[C_Z, i]) | (int(m[C_Z + 1, i]) << 20)
+        z = int(Z(m, 0)[i]) | (int(Z(m, 1)[i]) << 20)
         if k in (K_SUB, K_SU):
             assert z == (reg[fb] - reg[fc]) & M40 and m[C_C0 + 1, i] == int((reg[fb] & M40) < (reg[fc] & M40))
         if k == K_BRU:
@@ -296,7 +301,7 @@ def test_main_trace_of_the_signed_comparisons():
         assert u == [(a >> 20) + bias - (sa << 20), (b >> 20) + bias - (sb << 20)] and (m[C_RC2:C_RC2 + 4, i] < 1024).all()
         lt = int(_s40(a) < _s40(b)) if signed else int(a < b)
         assert m[C_C0 + 1, i] == lt == m[C_FLAG, i] and m[C_FX, i] == lt ^ (op & 1)
-        z = int(m[C_Z, i]) | (int(m[C_Z + 1, i]) << 20)
+        z = int(Z(m, 0)[i]) | (int(Z(m, 1)[i]) << 20)
         assert z == ((a ^ (bias << 20)) - (b ^ (bias << 20))) & M40                # the difference of the biased values
         if k == K_BRU:
             taken = int(rows["pc"][i + 1]) != int(rows["pc"][i]) + 4
@@ -371,6 +376,81 @@ def test_wrong_execution_of_the_signed_comparisons_is_rejected():
     assert bad(lambda m: m.__setitem__((C_TK, kbl), 1 - int(m[C_TK, kbl])))
 
 
+def test_conditional_moves():
+    """AIR v6: CMOV / CMOVNZ / CMOVZ rows of spec.cmov_loop_program — class of the word, nz = [rs2 != 0] over the raw 64 bits (stated on every
+    row), q = the condition holds, the write selector (rd iff q, nothing for rd = r0), y = rs1's raw limbs — against the VM's rows; the range
+    check of the bits above 40 that "other" rows write (the sign-extended byte load); and every way of forging a conditional move rejected."""
+    rows0, pub = _run(400, "cmov")
+    m = so.main_trace(rows0, pub)
+    n = len(rows0)
+    cls = m[KCOL]
+    ops = rows0["instruction"] & 0x7F
+    assert (cls.sum(axis=0) == 1).all()
+    seen = set()
+    for i in range(n - 1):
+        w = int(rows0["instruction"][i]); op = w & 0x7F; k = OPCLASS.get(op, K_OTH)
+        assert cls[k][i] == 1
+        fa, fb, fc = (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF
+        reg = [int(v) for v in rows0["registers"][i]]
+        if op not in (0x40, 0x41, 0x42, 0x43, 0x44, 0x45, 0x38, 0x39, 0x3A, 0x3B):                   # R- / I-type words: xc = reg[field c] (an immediate's bits for I-type: any register)
+            assert m[C_NZ, i] == int(reg[fc] != 0)
+        if k in (K_CMN, K_CMZ):
+            cond = (reg[fc] != 0) == (k == K_CMN)
+            assert m[C_Q, i] == int(cond)
+            assert [int(m[C_Y + l, i]) for l in range(3)] == [reg[fb] & 0xFFFFF, (reg[fb] >> 20) & 0xFFFFF, reg[fb] >> 40]
+            wr = m[C_WR:C_WR + 15, i]
+            if cond and fa: assert wr.sum() == 1 and wr[fa - 1] == 1 and int(rows0["registers"][i + 1, fa]) == reg[fb]
+            else: assert not wr.any() and (rows0["registers"][i + 1] == rows0["registers"][i]).all()
+            seen.add((op, cond, fa == 0, reg[fc] >> 40 != 0, reg[fb] >> 40 != 0))
+        else:
+            assert m[C_Q, i] == 0
+        if k == K_OTH:                                              # the bits above 40 of the written value, as three chunks (the third below 16)
+            y2 = int(m[C_Y + 2, i])
+            assert [int(v) for v in m[C_RC2:C_RC2 + 4, i]] == [y2 & 1023, (y2 >> 10) & 1023, y2 >> 20, 64 * (y2 >> 20)]
+            if op == 0x30: assert y2 == 0xFFFFFF
+    assert {(o, c) for (o, c, _, _, _) in seen} == {(o, c) for o in (0x26, 0x27, 0x28) for c in (False, True)}
+    assert any(z for (_, _, z, _, _) in seen) and any(h for (_, _, _, h, _) in seen) and any(h for (_, _, _, _, h) in seen)
+    assert so.verify(so.prove(rows0, pub)) == 0
+
+    def rejected(rows):
+        return so.verify(so.prove(rows, pub)) == 10
+    rd_of = (rows0["instruction"] >> 7) & 0xF
+    for op in (0x26, 0x27, 0x28):
+        for want in (False, True):                                # a move that happened is undone; one that did not happen is made
+            ks = [int(k) for k in np.nonzero((ops[:-1] == op) & (rd_of[:-1] != 0))[0] if bool(m[C_Q, k]) == want]
+            k = ks[len(ks) // 2]; rd = int(rd_of[k]); src = (int(rows0["instruction"][k]) >> 11) & 0xF
+            later = np.nonzero(rd_of[k + 1:] == rd)[0]
+            hi = k + 2 + int(later[0]) if len(later) else n
+            rows = rows0.copy()
+            rows["registers"][k + 1:hi, rd] = rows0["registers"][k, rd] if want else rows0["registers"][k, src]
+            assert rejected(rows), (hex(op), want)
+    # a move of another value than rs1's (one limb off, the bits above 40 dropped)
+    k = next(int(k) for k in np.nonzero(ops == 0x28)[0] if m[C_Q, k] and m[C_Y + 2, k])
+    rd = int(rd_of[k]); later = np.nonzero(rd_of[k + 1:] == rd)[0]; hi = k + 2 + int(later[0])
+    for edit in (lambda v: v + 1, lambda v: v & ((1 << 40) - 1)):
+        rows = rows0.copy(); rows["registers"][k + 1:hi, rd] = edit(int(rows0["registers"][k + 1, rd]))
+        assert rejected(rows)
+
+    def bad(edit):
+        mm = m.copy(); edit(mm)
+        return so.verify(so.prove_matrix(mm, pub)) == 10
+    kq = next(int(k) for k in np.nonzero((ops == 0x26) & (rd_of == 11))[0] if m[C_Q, k]); kn = next(int(k) for k in np.nonzero((ops == 0x26) & (rd_of == 11))[0] if not m[C_Q, k])
+    assert bad(lambda mm: mm.__setitem__((C_Q, kq), 0)) and bad(lambda mm: mm.__setitem__((C_Q, kn), 1))          # q is not the condition
+    assert bad(lambda mm: mm.__setitem__((C_NZ, kq), 0)) and bad(lambda mm: mm.__setitem__((C_NZ, kn), 1))        # nz is not [rs2 != 0]
+    assert bad(lambda mm: (mm.__setitem__((C_NZ, kn), 1), mm.__setitem__((C_IVZ, kn), 1)))
+    assert bad(lambda mm: (mm.__setitem__((C_WR + 10, kq), 0), mm.__setitem__((C_WR + 11, kq), 1)))               # another register than rd is flagged written
+    assert bad(lambda mm: mm.__setitem__((C_WR + 10, kn), 1))                                                     # a write although the condition fails
+    assert bad(lambda mm: (mm.__setitem__((C_K4, kq), 0), mm.__setitem__((C_K4 + 1, kq), 1)))                     # CMOV run as CMOVZ
+    assert bad(lambda mm: (mm.__setitem__((C_K4, kq), 0), mm.__setitem__((C_K + K_OTH, kq), 1)))                  # ... or hiding as "other"
+    # an "other" row whose written bits above 40 are out of range: the third chunk must be below 16 (64 x it is looked up too)
+    kl = int(np.nonzero(ops == 0x30)[0][0])
+
+    def y2_out_of_range(mm):
+        mm[C_Y + 2, kl] = (int(mm[C_Y + 2, kl]) + (1 << 24)) % P; mm[C_RC2 + 2, kl] = int(mm[C_RC2 + 2, kl]) + 16; mm[C_RC2 + 3, kl] = 64 * int(mm[C_RC2 + 2, kl])
+        mm[C_LIMB + 3 * 7 + 2, kl + 1:] = mm[C_Y + 2, kl]
+    assert bad(y2_out_of_range)
+
+
 def test_cpu_commit_port_matches_the_oracle():
     """bench_cpu/cpu_commit_port.cpp (the multi-threaded Montgomery port bench.py times as the CPU figure of the commit stage) computes
     the same root as the naive oracle."""
@@ -388,7 +468,9 @@ def test_air_holds_row_by_row_on_honest_traces():
     for prog, n, cfg in ((spec.fib_endless_program(), 50, {}), (spec.sha256_chain_program(), 200, {}), (spec.fib_program(12), None, {}),
                          (spec.fib_endless_program(), 40, {"enable_deferred_model": True}), (spec.compare_loop_program(), 600, {}),
                          (spec.compare_loop_program(), 100, {"enable_deferred_model": True}), (spec.call_loop_program(), 500, {}),
-                         (spec.call_loop_program(), 120, {"enable_deferred_model": True})):
+                         (spec.call_loop_program(), 120, {"enable_deferred_model": True}),
+                         (spec.signed_loop_program(), 300, {}), (spec.signed_loop_program(), 100, {"enable_deferred_model": True}), (spec.cmov_loop_program(), 300, {}),
+                         (spec.cmov_loop_program(), 100, {"enable_deferred_model": True})):
         blob = prog.to_bytes()
         res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
         rows = res.rows
@@ -414,7 +496,7 @@ def test_air_holds_row_by_row_on_honest_traces():
 
 # ---- stage B: prover + verifier ------------------------------------------------------------------------------------
 def _prog(prog):
-    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program, "call": spec.call_loop_program, "sgn": spec.signed_loop_program}[prog]()
+    return {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "cmp": spec.compare_loop_program, "call": spec.call_loop_program, "sgn": spec.signed_loop_program, "cmov": spec.cmov_loop_program}[prog]()
 
 
 def _run(n, prog="fib", **cfg):
@@ -453,7 +535,7 @@ def test_prove_verify_roundtrip(n, prog):
     blob = _prog(prog).to_bytes()
     assert lay["blob"] == blob and lay["n_rom"] == int.from_bytes(blob[16:20], "little") // 4 and lay["trace_root"] == HDR + 1 + (len(blob) + 1) // 2 + lay["n_rom"] + 1024
     fixed = lay["trace_root"] + 12 + (2 * WT + 4) * 4                                      # ... roots (trace, aux, quotient), openings of main + aux columns and the quotient
-    assert pr[1] == 9 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
+    assert pr[1] == 10 and pr[fixed] == len(ks)                                             # proof version, number of committed FRI layers
     assert int(pr[lay["rom_mult"]:lay["rc_mult"]].sum()) == 1 << log_n and int(pr[lay["rc_mult"]:lay["trace_root"]].sum()) == 8 << log_n   # multiplicities count every row
     depth = [log_n + 1 - sum(ks[:j + 1]) for j in range(len(ks))]                          # Merkle depth of each FRI tree
     per_query = 1 + 2 * (WC + 4 * (log_n + 1)) + 2 * (WA + 4 * (log_n + 1)) + 2 * (4 + 4 * (log_n + 1)) + sum(4 * (1 << k) + 4 * d for k, d in zip(ks, depth))
@@ -790,7 +872,6 @@ def test_cheating_prover_matrices_are_rejected():
         y1 = int(m[C_Y + 1, k]) + d                               # the carry into limb 1 changes with it; stays inside 20 bits here
         assert 0 <= y1 < 1 << 20
         m[C_Y + 1, k] = y1; m[C_RC + 2, k] = y1 & 1023; m[C_RC + 3, k] = y1 >> 10
-        m[C_Z, k] = m[C_Y, k]; m[C_Z + 1, k] = y1                # z = y on an ADD row
         rd = 4                                                    # add r4, r1, r2: the forged limbs are what the register shows until it is written again
         m[C_LIMB + 3 * rd, k + 1:nxt + 1] = m[C_Y, k]; m[C_LIMB + 3 * rd + 1, k + 1:nxt + 1] = m[C_Y + 1, k]
     assert bad(out_of_range_carry)
@@ -805,8 +886,8 @@ def test_cheating_prover_matrices_are_rejected():
     assert bad(wrong_sum)
 
     def wrong_sum_with_z(m):                                     # ... the same with z and its chunks moved along (y = z holds): the addition itself fails
-        wrong_sum(m); m[C_Z, k] = m[C_Y, k]
-        m[C_RC, k] = int(m[C_Z, k]) & 1023; m[C_RC + 1, k] = int(m[C_Z, k]) >> 10
+        wrong_sum(m)
+        m[C_RC, k] = int(m[C_Y, k]) & 1023; m[C_RC + 1, k] = int(m[C_Y, k]) >> 10
     assert bad(wrong_sum_with_z)
 
     # AIR v3: the same on the comparison families (rows of spec.compare_loop_program)
@@ -822,8 +903,7 @@ def test_cheating_prover_matrices_are_rejected():
     def flip_borrow(m, k):                                       # the borrow that decides an unsigned comparison, flipped with z moved along by 2^20 x 2^20:
         c1 = int(m[C_C0 + 1, k]); d = 1 - 2 * c1                 # every difference constraint still holds, z1 leaves its range — the chunk lookup refuses it
         m[C_C0 + 1, k] = 1 - c1
-        z1 = (int(m[C_Z + 1, k]) + d * (1 << 20)) % P
-        m[C_Z + 1, k] = z1; m[C_RC + 3, k] = (int(m[C_RC + 3, k]) + d * 1024) % P
+        m[C_RC + 3, k] = (int(m[C_RC + 3, k]) + d * 1024) % P
         m[C_FLAG, k] = 1 - c1; m[C_FX, k] = 1 - int(m[C_FX, k])
     def sltu_flipped(m):                                          # ... with the written value (and what the register shows afterwards) following the forged flag
         flip_borrow(m, ku); m[C_Y, ku] = m[C_FX, ku]
@@ -840,7 +920,7 @@ def test_cheating_prover_matrices_are_rejected():
     def early_pad(m):                                            # stop executing at row 20: halt there, padding afterwards
         m[C_K:C_K + 7, 20:] = 0; m[C_K + K_HALT, 20] = 1; m[C_K + K_PAD, 21:] = 1
         m[1:C_K, 21:] = m[1:C_K, 20:21]; m[C_WR:C_WR + 15, 20:] = 0; m[C_Y:C_Y + 3, 20:] = 0; m[C_C0:C_C0 + 5, 20:] = 0; m[C_TK, 20:] = 0
-        m[C_Z:C_Z + 2, 20:] = 0; m[C_RC:C_RC + 4, 20:] = 0; m[C_FLAG, 20:] = 0; m[C_FX, 20:] = m[C_OP, 20:]
+        m[C_RC:C_RC + 4, 20:] = 0; m[C_FLAG, 20:] = 0; m[C_FX, 20:] = m[C_OP, 20:]
     assert bad(early_pad)                                        # the public row count pins the halt row (is_last)
 
 

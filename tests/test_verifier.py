@@ -18,14 +18,14 @@ def _pub_c(p: so.PublicC) -> rt.PublicInputsC:
 
 
 def _run(n, prog="fib", **cfg):
-    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program, "call": spec.call_loop_program, "sgn": spec.signed_loop_program}[prog]().to_bytes()
+    blob = {"fib": spec.fib_endless_program, "sha": spec.sha256_chain_program, "fib12": lambda: spec.fib_program(12), "cmp": spec.compare_loop_program, "call": spec.call_loop_program, "sgn": spec.signed_loop_program, "cmov": spec.cmov_loop_program}[prog]().to_bytes()
     res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, **cfg)
     return res.rows, so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=bool(cfg))
 
 
 @pytest.mark.parametrize("n,prog,cfg", [(8, "fib", {}), (5, "fib", {}), (100, "fib", {}), (300, "sha", {}), (None, "fib12", {}), (512, "fib", {}),
                                          (200, "fib", {"enable_deferred_model": True}), (600, "cmp", {}), (150, "cmp", {"enable_deferred_model": True}), (500, "call", {}),
-                                         (200, "call", {"enable_deferred_model": True}), (700, "sgn", {}), (150, "sgn", {"enable_deferred_model": True})])
+                                         (200, "call", {"enable_deferred_model": True}), (700, "sgn", {}), (150, "sgn", {"enable_deferred_model": True}), (400, "cmov", {}), (150, "cmov", {"enable_deferred_model": True})])
 def test_accepts_what_the_oracle_accepts(n, prog, cfg):
     rows, pub = _run(n, prog, **cfg)
     pr = so.prove(rows, pub)
@@ -117,11 +117,11 @@ def test_rejects_forged_opcode_families_like_the_oracle():
     rows, pub = _run(600, "cmp")
     m0 = so.main_trace(rows, pub)
     ops = rows["instruction"] & 0x7F
-    C_K, C_K2, C_Y, C_C1, C_TK, C_Z, C_FLAG, C_FX = 127, 152, 124, 142, 151, 156, 158, 159
+    C_K, C_K2, C_Y, C_C1, C_TK, C_RC, C_FLAG, C_FX = 127, 152, 124, 142, 151, 135, 158, 159
     at = {op: int(np.nonzero(ops == op)[0][4]) for op in (0x01, 0x20, 0x21, 0x24, 0x25, 0x40, 0x41, 0x44, 0x45)}
     flip = lambda col, k: (lambda m: m.__setitem__((col, k), 1 - int(m[col, k])))
     edits = [flip(C_FLAG, at[0x24]), flip(C_FX, at[0x25]), flip(C_TK, at[0x40]), flip(C_TK, at[0x45]), flip(C_FLAG, at[0x44]), flip(C_C1, at[0x20]), flip(C_C1, at[0x44]),
-             flip(C_Y, at[0x21]), lambda m: m.__setitem__((C_Z, at[0x01]), (int(m[C_Z, at[0x01]]) + 1) % P),
+             flip(C_Y, at[0x21]), lambda m: m.__setitem__((C_RC, at[0x01]), (int(m[C_RC, at[0x01]]) + 1) % 1024),
              lambda m: (m.__setitem__((C_K2 + 0, at[0x01]), 0), m.__setitem__((C_K + 4, at[0x01]), 1)),          # SUB as "other"
              lambda m: (m.__setitem__((C_K2 + 3, at[0x20]), 0), m.__setitem__((C_K2 + 2, at[0x20]), 1)),         # SLTU as the equality family
              lambda m: (m.__setitem__((C_K2 + 1, at[0x44]), 0), m.__setitem__((C_K + 2, at[0x44]), 1))]          # BLTU as BEQ / BNE
@@ -191,6 +191,35 @@ def test_rejects_forged_signed_comparisons_like_the_oracle():
         r = rows.copy(); mutate(r)
         pr = so.prove(r, pub)
         assert so.verify(pr) == 10 and rt.verify(pr) == 10
+    pr = so.prove(rows, pub)
+    assert so.verify(pr) == 0 and rt.verify(pr) == 0
+
+
+def test_rejects_forged_conditional_moves_like_the_oracle():
+    """AIR v6 (CMOV / CMOVNZ / CMOVZ; the range check of the bits above 40 an "other" row writes): same verdict from the product verifier and
+    the oracle on forged conditions, write selectors, classes, moved values and an out-of-range third limb."""
+    rows, pub = _run(400, "cmov")
+    m0 = so.main_trace(rows, pub)
+    ops = rows["instruction"] & 0x7F
+    C_LIMB, C_WR, C_Y, C_K, C_NZ, C_IVZ, C_RC2, C_K4, C_Q = 9, 73, 124, 127, 156, 157, 163, 169, 171
+    kq = next(int(k) for k in np.nonzero((ops == 0x26) & (((rows["instruction"] >> 7) & 0xF) == 11))[0] if m0[C_Q, k]); kn = next(int(k) for k in np.nonzero(ops == 0x27)[0] if not m0[C_Q, k])
+    kl = int(np.nonzero(ops == 0x30)[0][0])
+    flip = lambda col, k: (lambda m: m.__setitem__((col, k), 1 - int(m[col, k])))
+
+    def y2_out_of_range(m):
+        m[C_Y + 2, kl] = (int(m[C_Y + 2, kl]) + (1 << 24)) % P; m[C_RC2 + 2, kl] = int(m[C_RC2 + 2, kl]) + 16; m[C_RC2 + 3, kl] = 64 * int(m[C_RC2 + 2, kl])
+        m[C_LIMB + 3 * 7 + 2, kl + 1:] = m[C_Y + 2, kl]
+    edits = [flip(C_Q, kq), flip(C_Q, kn), flip(C_NZ, kq), flip(C_NZ, kn), flip(C_WR + 10, kq), lambda m: m.__setitem__((C_WR + 11, kn), 1),
+             lambda m: (m.__setitem__((C_K4, kq), 0), m.__setitem__((C_K4 + 1, kq), 1)), lambda m: (m.__setitem__((C_K4, kq), 0), m.__setitem__((C_K + 4, kq), 1)),
+             lambda m: m.__setitem__((C_Y, kq), (int(m[C_Y, kq]) + 1) % P), lambda m: m.__setitem__((C_IVZ, kq), (int(m[C_IVZ, kq]) + 1) % P), y2_out_of_range]
+    for i, e in enumerate(edits):
+        m = m0.copy(); e(m)
+        pr = so.prove_matrix(m, pub)
+        assert so.verify(pr) == 10 and rt.verify(pr) == 10, i
+    rd = (int(rows["instruction"][kq]) >> 7) & 0xF
+    r = rows.copy(); r["registers"][kq + 1, rd] = rows["registers"][kq, rd]              # the move undone
+    pr = so.prove(r, pub)
+    assert so.verify(pr) == 10 and rt.verify(pr) == 10
     pr = so.prove(rows, pub)
     assert so.verify(pr) == 0 and rt.verify(pr) == 0
 

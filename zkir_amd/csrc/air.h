@@ -40,25 +40,29 @@
 
 namespace air {
 
-constexpr int W = 169;
+constexpr int W = 172;
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
-             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_Z = 156, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168 };
+             C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
+             C_K4 = 169, C_Q = 171, C_KOJ = C_K3 + 1 };
 // LOGICAL vs COMMITTED columns (proof format v7).  W and the C_* map are the LOGICAL main trace: what the constraints talk about.  Columns
 // that are identically zero by the constraints themselves are not committed: R0's three limbs and its storage state (R0 is hard-wired
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, zero-padded to whole B8 blocks: 144 columns in default mode (exactly),
 // 160 in deferred mode (159 + 1); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
 constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168;
-BB_HD constexpr bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : (c >= C_STATE && c < C_STATE + 16)); }
-BB_HD constexpr int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0)); }   // of a committed column
+// (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
+// I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
+// 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
+BB_HD constexpr bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+BB_HD constexpr int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
 BB_HD constexpr int committed_width(bool deferred) { return deferred ? W_COMMITTED_DEFERRED : W_COMMITTED_DEFAULT; }
-BB_HD constexpr int committed_used(bool deferred) { return deferred ? W - 4 : W - 19; }      // the rest of the committed width is zero padding
+BB_HD constexpr int committed_used(bool deferred) { return deferred ? W - 4 : W - 20; }      // = the committed width (no padding since v6)
 // the logical column stored at committed position p (p < committed_used)
 BB_HD constexpr int logical_col(int p, bool deferred) {
   int c = p;
   if (c >= C_LIMB) c += 3;                                     // R0's limbs
-  if (deferred) { if (c >= C_STATE) c += 1; } else { if (c >= C_STATE) c += 16; }
+  if (deferred) { if (c >= C_STATE) c += 1; } else { if (c >= C_STATE) c += 16; if (c >= C_KOJ) c += 1; }
   return c;
 }
 // aux trace: H0..H3 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
@@ -73,14 +77,16 @@ BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP :
 // that differ in their low bit, the polarity of one comparison: bre = BEQ / BNE, bru = BLTU / BGEU, se = SEQ / SNE, su = SLTU / SGEU.
 // AIR v4: jalr (JALR) and oj = "other, jumps" (BLT / BGE: the signed comparison is not stated yet — free next pc, nothing written); class
 // "other" is SEQUENTIAL (pc + 4) like every instruction that is not a branch or a jump.
-enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, N_CLASS = 13 };
-BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : C_K3 + (k - 11); }
-constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
+// AIR v6: cmn = CMOV / CMOVNZ (move if rs2 != 0), cmz = CMOVZ (move if rs2 == 0)
+enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, K_CMN = 13, K_CMZ = 14, N_CLASS = 15 };
+BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
+constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
 BB_HD constexpr uint32_t opclass_of(uint32_t op) {
   return op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
-       : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (uint32_t)K_OTH;
+       : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
+       : (uint32_t)K_OTH;
 }
 BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLT : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0u; }   // the lowest opcode of a family
 // AIR v5: the families of ordered comparisons have FOUR members, op = base + 2 g + pol: SLTU SGEU SLT SGE (base 0x20, g = signed) and BLT BGE BLTU
@@ -88,10 +94,10 @@ BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == 
 BB_HD constexpr uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU) ? 1u : 0u; }
 
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
-enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 148,
-             I_ONE_CLASS = 158, I_OPCLASS = 159, I_WR = 160, I_SELB = 163, I_SELC = 165, I_OPERAND = 167, I_VALUE = 173, I_DIFF = 182, I_WRITTEN = 191,
-             I_NE = 196, I_FLAG = 200, I_FX = 201, I_TK = 202, I_DL0 = 203, I_SE = 204, I_PC = 205, I_PC_KEEP = 208, I_JALR = 211, I_REGS = 214, I_TAIL = 274, I_LAST = 277,
-             I_CHUNK = 345, I_RANGE = 347, I_ROM = 379, I_SUM = 383, N_CONSTRAINTS = 387 };
+enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 150,
+             I_ONE_CLASS = 161, I_OPCLASS = 162, I_WR = 163, I_SELB = 166, I_SELC = 168, I_CMOV = 170, I_OPERAND = 173, I_VALUE = 179, I_DIFF = 188, I_WRITTEN = 197,
+             I_CMOV_Y = 202, I_Y2 = 205, I_NZ = 207, I_NE = 209, I_FLAG = 213, I_FX = 214, I_TK = 215, I_DL0 = 216, I_SE = 217, I_PC = 218, I_PC_KEEP = 221, I_JALR = 224, I_REGS = 227,
+             I_TAIL = 287, I_LAST = 290, I_RANGE = 358, I_ROM = 390, I_SUM = 394, N_CONSTRAINTS = 398 };
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -118,7 +124,10 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int k = 0; k < N_CLASS; k++) K[k] = o.loc(kcol(k));
   const V Kbr = o.add(K[K_BRE], K[K_BRU]), Kcmp = o.add(K[K_SE], K[K_SU]);       // B-type rows; comparison rows (the flag is the value written)
   const V y[3] = {o.loc(C_Y), o.loc(C_Y + 1), o.loc(C_Y + 2)};
-  const V z[2] = {o.loc(C_Z), o.loc(C_Z + 1)};
+  V R[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
+  const V z[2] = {o.add(R[0], o.mulc(R[1], M(RC_TABLE))), o.add(R[2], o.mulc(R[3], M(RC_TABLE)))};   // (v6) z IS its chunks: no columns of its own
   const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
   const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
   // 1. cycle counter, first row, last executed row
@@ -178,7 +187,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   for (int k = 0; k < N_CLASS; k++) boolean(I_BOOL_K + k, K[k]);
   const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), ne = o.loc(C_NE), tk = o.loc(C_TK);
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
-  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0)); boolean(I_BOOL_MISC + 9, o.loc(C_SB));
+  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0)); boolean(I_BOOL_MISC + 9, o.loc(C_SB)); boolean(I_BOOL_MISC + 10, o.loc(C_NZ));
   // 4. classes and the opcode
   {
     V sum = K[0];
@@ -199,6 +208,12 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
   o.push(I_WR + 2, o.mul(o.add(o.add(o.add(Kbr, deferred ? zero : K[K_OJ]), K[K_HALT]), K[K_PAD]), w0));   // branches write nothing (BLT / BGE too: class oj in default mode)
   o.push(I_SELB, o.sub(b1, fb)); o.push(I_SELB + 1, o.sub(o.mul(b1, b1), b2));
   o.push(I_SELC, o.sub(c1s, o.add(fc, o.mul(Kbr, o.sub(fa, fc))))); o.push(I_SELC + 1, o.sub(o.mul(c1s, c1s), c2s));
+  // 5b. (v6) conditional moves CMOV / CMOVNZ (class cmn: the condition is rs2 != 0) and CMOVZ (class cmz: rs2 == 0), execute.rs:434-472: q = "this row is a
+  //     conditional move whose condition holds"; it writes rd = field a exactly then (nothing at all otherwise)
+  const V Kcm = o.add(K[K_CMN], K[K_CMZ]), nz = o.loc(C_NZ), q = o.loc(C_Q);
+  o.push(I_CMOV, o.sub(q, o.add(o.mul(K[K_CMN], nz), o.mul(K[K_CMZ], o.sub(one, nz)))));
+  o.push(I_CMOV + 1, o.mul(q, o.sub(w1, fa)));
+  o.push(I_CMOV + 2, o.mul(o.sub(Kcm, q), w0));
   // 6. operands
   V xb[3], xc[3];
 #pragma unroll
@@ -249,6 +264,18 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
     const V Ky = o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), o.add(K[K_OTH], K[K_JALR])), deferred ? K[K_OJ] : zero);   // (oj writes only in deferred mode)
     o.push(I_WRITTEN, o.mul(Ky, o.sub(y[0], z[0]))); o.push(I_WRITTEN + 1, o.mul(Ky, o.sub(y[1], z[1])));
     o.push(I_WRITTEN + 2, o.mul(Kcmp, o.sub(y[0], fx))); o.push(I_WRITTEN + 3, o.mul(Kcmp, y[1])); o.push(I_WRITTEN + 4, o.mul(Kcmp, y[2]));
+#pragma unroll
+    for (int l = 0; l < 3; l++) o.push(I_CMOV_Y + l, o.mul(Kcm, o.sub(y[l], xb[l])));        // (v6) a conditional move writes rs1's raw value (all three limbs)
+    // (v6) the bits above 40 of what an "other" row writes: y2 = R4 + 2^10 R5 + 2^20 R6 with R7 = 64 R6 — all four in the 10-bit table, so y2 < 2^24.  With it
+    // EVERY limb of every register is in range by induction (constrained classes write 0, pc2 + c1 or an operand's limb there)
+    o.push(I_Y2, o.mul(K[K_OTH], o.sub(o.sub(o.sub(y[2], o.loc(C_RC2)), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), o.mulc(o.loc(C_RC2 + 2), M(RC_TABLE * RC_TABLE)))));
+    o.push(I_Y2 + 1, o.mul(K[K_OTH], o.sub(o.loc(C_RC2 + 3), o.mulc(o.loc(C_RC2 + 2), M(64)))));
+  }
+  // 7c. (v6) nz = [xc != 0] on every row, on the sum of xc's limbs (in range, so the sum vanishes only if they all do)
+  {
+    const V sx = o.add(o.add(xc[0], xc[1]), xc[2]);
+    o.push(I_NZ, o.mul(o.sub(one, nz), sx));
+    o.push(I_NZ + 1, o.sub(nz, o.mul(sx, o.loc(C_IVZ))));
   }
   // 8. BNE operands differ?
   {
@@ -307,12 +334,7 @@ BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typen
       out[k] = o.add(lo, o.mulc(hi, M(11)));
     }
   };
-  // 13. the limbs of z are two 10-bit chunks each
-  V R[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
-  o.push(I_CHUNK, o.sub(o.sub(z[0], R[0]), o.mulc(R[1], M(RC_TABLE))));
-  o.push(I_CHUNK + 1, o.sub(o.sub(z[1], R[2]), o.mulc(R[3], M(RC_TABLE))));
+  // 13. (z is defined by its chunks since v6: the two constraints that tied the z columns to them went with the columns)
   // 14. range helpers: H_i (alpha - R_i) = 1, i = 0..7 (the chunks of z, the chunks of u)
 #pragma unroll 1
   for (int i = 0; i < N_RC; i++) {

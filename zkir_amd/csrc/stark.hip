@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU) wr = fa == (uint32_t)g;
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
     else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -144,7 +144,17 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     if (cls != K_SUB) { u[0] = (uint32_t)ta; u[1] = (uint32_t)tb; }
   }
   col(C_SB) = sb;
-  col(C_RC2) = u[0] & (RC_TABLE - 1); col(C_RC2 + 1) = u[0] >> RC_BITS; col(C_RC2 + 2) = u[1] & (RC_TABLE - 1); col(C_RC2 + 3) = u[1] >> RC_BITS;
+  uint32_t rc2[4] = {u[0] & (RC_TABLE - 1), u[0] >> RC_BITS, u[1] & (RC_TABLE - 1), u[1] >> RC_BITS};
+  // (v6) nz = [rs2 != 0] over the raw 64 bits, for EVERY row, on the sum of xc's limbs (each in range, so the sum vanishes only if all do);
+  // q = "a conditional move whose condition holds" (execute.rs:434-472)
+  const uint32_t sx = (uint32_t)(((uint64_t)xc[0] + xc[1] + xc[2]) % bb::P), nz = sx != 0;
+  col(C_NZ) = nz; col(C_IVZ) = nz ? f_inv(sx) : 0u;
+  const uint32_t q = cls == K_CMN ? nz : cls == K_CMZ ? 1u - nz : 0u;
+  col(C_Q) = q;
+  if ((cls == K_CMN || cls == K_CMZ) && !q) {
+#pragma unroll
+    for (int r = 0; r < 15; r++) col(C_WR + r) = 0;
+  }
   const uint32_t flag = (cls == K_BRE || cls == K_SE) ? 1u - ne : (cls == K_BRU || cls == K_SU) ? c1 : 0u;
   const uint32_t pol = op - family_base(cls) - 2u * g;                          // op = base + 2 g + pol: 0 / 1 inside a family; the opcode itself (minus 2 g) on other rows
   const uint32_t fx = flag ? 1u - pol : pol;                                    // flag XOR pol where it matters (flag = 0 outside the families)
@@ -166,9 +176,13 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     y[2] = pc[2] + c1;
   } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; }
   else if (cls == K_SE || cls == K_SU) y[0] = fx;
+  else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; }
   col(C_Y) = y[0]; col(C_Y + 1) = y[1]; col(C_Y + 2) = y[2];
+  if (cls == K_OTH) {                                              // (v6) the bits above 40 of what an "other" row writes are range-checked: y2 = R4 + 2^10 R5 + 2^20 R6, R7 = 64 R6
+    rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64u * rc2[2];
+  }
+  col(C_RC2) = rc2[0]; col(C_RC2 + 1) = rc2[1]; col(C_RC2 + 2) = rc2[2]; col(C_RC2 + 3) = rc2[3];
   if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
-  col(C_Z) = z[0]; col(C_Z + 1) = z[1];
   col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0, b0 = 0;

@@ -12,7 +12,7 @@ using bb::E4;
 // WMX / WTX: the largest committed width (deferred mode) — array sizes; a proof's own widths are air::committed_width(deferred) and that + WA
 constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_DEFERRED, WA = air::W_AUX, WTX = WMX + WA, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 9;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 
 #ifndef DEEP_WAVES
 #define DEEP_WAVES 4

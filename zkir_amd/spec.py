@@ -299,6 +299,30 @@ def signed_loop_program() -> Program:
     ])
 
 
+def cmov_loop_program() -> Program:
+    """An endless loop over the conditional moves (AIR v6): CMOV / CMOVNZ (move if rs2 != 0) and CMOVZ (move if rs2 == 0) with the condition
+    toggling every iteration, a condition that is non-zero only above bit 20, a raw 64-bit source and condition (a sign-extended byte load:
+    bits above 40 set, Q1), and rd = r0.  Run with max_cycles (halt = CycleLimit)."""
+    def r(op, rd, rs1, rs2): return encode(op, rd, rs1, rs2)
+    O = Opcode
+    return Program.from_code([
+        addi(1, 0, 0), addi(2, 0, 7), addi(13, 0, 1), addi(10, 0, 0),         # i, a value to move, the constant 1, the toggling condition
+        addi(5, 0, 0x80), addi(6, 0, 0x8000), slli(6, 6, 1), sw(6, 5, 0),     # mem[0x10000] = 0x80
+        encode(O.LB, 7, 6, imm=0),                                            # r7 = 0xFFFF_FFFF_FFFF_FF80: all three limbs non-zero (execute.rs:477-487)
+        addi(9, 0, 1), slli(9, 9, 20),                                        # r9 = 2^20: non-zero only in the second limb
+        # L (pc 0x102C):
+        r(O.CMOV, 11, 2, 10), r(O.CMOVZ, 12, 7, 10), r(O.CMOVNZ, 14, 9, 10),  # move iff the toggle is 1 / 0 / 1
+        r(O.CMOV, 0, 2, 13),                                                  # condition true, rd = r0: nothing is written
+        r(O.CMOVZ, 15, 2, 9),                                                 # condition 2^20 != 0: not moved
+        r(O.CMOVNZ, 15, 7, 7),                                                # a raw 64-bit condition and source: moved with its bits above 40
+        r(O.CMOVZ, 4, 7, 0),                                                  # condition r0 == 0: always moved
+        addi(11, 0, 0), addi(12, 0, 0), addi(14, 0, 0), addi(15, 0, 0), addi(4, 0, 0),
+        sub(10, 13, 10),                                                      # toggle
+        addi(1, 1, 1),
+        jal(0, -56),                                                          # back to L
+    ])
+
+
 def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
     """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
     The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).
