@@ -805,8 +805,8 @@ def main():
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
             "prove_stage_roofline": _prove_stage_table(k, W, [prove_stage_ms[q] for q in PROVE_STAGES]) if prove_stage_ms else None,
-            "prover": "ZKIR-STARK, AIR v5 (self-defined; 169 logical main-trace columns, 152 committed in default mode, + 40 aux columns / 387 constraints: the semantics of 17 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU/SLT/SGE, SEQ/SNE, BEQ/BNE, BLTU/BGEU/BLT/BGE, JAL, JALR — and the control flow of every opcode, + a LogUp lookup argument — instruction ROM and 10-bit ranges, eight range lookups per row; "
-                      "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v9 carries the program)",
+            "prover": "ZKIR-STARK, AIR v6 (self-defined; 172 logical main-trace columns, 152 committed in default mode, + 40 aux columns / 398 constraints: the semantics of 20 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU/SLT/SGE, SEQ/SNE, CMOV/CMOVZ/CMOVNZ, BEQ/BNE, BLTU/BGEU/BLT/BGE, JAL, JALR — and the control flow of every opcode, + a LogUp lookup argument — instruction ROM and 10-bit ranges, eight range lookups per row; "
+                      "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v10 carries the program)",
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,

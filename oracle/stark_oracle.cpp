@@ -152,7 +152,7 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 
 
 // ---------------------------------------------------------------------------------------------
-// main trace matrix of ZKIR-STARK: packed 372-byte reference rows -> W = 160 Baby Bear columns, padded to a
+// main trace matrix of ZKIR-STARK: packed 372-byte reference rows -> W = 172 LOGICAL Baby Bear columns (AIR v6), padded to a
 // power of two.  Column map:
 //   0 cycle | 1-3 pc limbs (20/20/24 bits) | 4 op7 | 5 fa (bits 10:7) | 6 fb (14:11) | 7 fc (18:15) | 8 fhi (31:19)
 //   9+3r+l register limbs (20-bit limbs when Normalized, 30-bit when Accumulated; l = 2: the bits above) | 57+r storage state
@@ -169,9 +169,9 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 // AIR v3 (opcode FAMILIES: a family is a pair of opcodes that differ in their low bit, the polarity of one comparison):
 //   152-155 class one-hot, continued: sub, bru (BLTU / BGEU), se (SEQ / SNE), su (SLTU / SGEU); column 129 (was "bne") is the family
 //           bre (BEQ / BNE).  Class ids = opclass values: add 0, addi 1, bre 2, jal 3, oth 4, (halt 5, pad 6,) sub 7, bru 8, se 9, su 10
-//   156-157 z = the two RANGE-CHECKED 20-bit limbs of the row (the chunks 135-138 split z): the written value's low limbs on add / addi /
-//           jal / sub / oth rows (y = z there), the 40-bit difference xb - xc on su rows and xc - xb on bru rows (whose borrow c1 is the
-//           unsigned comparison, execute.rs:373-407, :618-636), zero elsewhere
+//   z = (c135 + 1024 c136, c137 + 1024 c138): the two RANGE-CHECKED 20-bit limbs of the row (columns 156-157 until v5; since v6 z has no columns
+//           of its own): the written value's low limbs on add / addi / jal / sub / oth rows (y = z there), the 40-bit difference xb - xc on su
+//           rows and xc - xb on bru rows (whose borrow c1 is the comparison, execute.rs:361-407, :598-636), zero elsewhere
 //   158 flag = the family's comparison: [xb == xc] (raw 64-bit, all three limbs) on bre / se rows, the borrow c1 on bru / su rows, else 0
 //   159 fx = flag XOR (op - the family's even opcode): the branch decision (tk) of bre / bru rows, the value written by se / su rows
 // AIR v4 (control flow of every opcode but the two signed branches):
@@ -179,6 +179,15 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //           next pc is free, they write nothing.  Class "other" (id 4) is now SEQUENTIAL: pc' = pc + 4 like every instruction that is
 //           not a branch or a jump (loads, stores, the remaining ALU opcodes, ECALL: execute.rs advances pc by 4 in each of them)
 //   162 b0 = the bit JALR clears: next pc + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs mod 2^64 (execute.rs:649-658), carries d0 d1 d2
+// AIR v5 (signed comparisons; the control flow of EVERY opcode): the ordered families have four members, op = base + 2 g + pol — SLTU SGEU SLT
+//   SGE (class su, base 0x20, g = signed) and BLT BGE BLTU BGEU (class bru, base 0x42, g = unsigned); class oj is left to the deferred mode
+//   163-166 range chunks of u, the row's SECOND range-checked pair: the BIASED high limbs ta, tb of the operands of an ordered comparison
+//           (t = limb + 2^19 sgn - 2^20 (sign bit): the limb of value XOR 2^39 when the comparison is signed, value.rs:710-716); since v6 also
+//           the bits above 40 of what an "other" row writes (y2 = c163 + 2^10 c164 + 2^20 c165, c166 = 64 c165)
+//   167 g = the word's variant bit (eleventh element of the ROM tuple) | 168 sb = sign bit of the second operand (the first one's is column 162)
+// AIR v6 (conditional moves; every register limb range-checked):
+//   156 nz = [xc != 0] over the raw 64 bits, on every row | 157 ivz = inverse of the sum of xc's limbs
+//   169-170 class one-hot, continued: cmn (id 13: CMOV / CMOVNZ), cmz (id 14: CMOVZ) | 171 q = the row is a conditional move whose condition holds
 // ---------------------------------------------------------------------------------------------
 static const int W_MAIN = 172;
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
@@ -187,15 +196,15 @@ enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8,
        C_K4 = 169, C_Q = 171 };
 static const int N_RC = 8;                                         // range lookups of a row: the chunks of z (C_RC ..) and of u (C_RC2 ..)
 static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
-// AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 24 base columns = six extension-field columns,
-// coordinate by coordinate: H0..H3 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
-// S = running sum of (H0 + H1 + H2 + H3 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
+// AUX trace (committed AFTER the lookup challenges are drawn; AIR v2): 40 base columns = ten extension-field columns (24 = six until v4),
+// coordinate by coordinate: H0..H7 = 1 / (alpha - range chunk i), HR = 1 / (alpha - fingerprint of the row's instruction tuple),
+// S = running sum of (H0 + .. + H7 + HR - T / N) — a LogUp argument whose table side the VERIFIER computes (T) from the program
 // carried in the proof and the multiplicities the prover sends before alpha is drawn.
 // LOGICAL vs COMMITTED columns (proof format v7).  The map above is the LOGICAL main trace: what the AIR talks about.  Some logical columns
 // are identically zero by the AIR's own constraints and are not committed: the three limbs of R0 (hard-wired zero, state.rs:77-85) and its
 // storage state, and — in the default VM mode, where no register is ever Accumulated (the deferred model is off, vm.rs:47) — all 16 storage
-// states.  The committed ("physical") matrix is the logical one with those columns removed, zero-padded to whole blocks of 8:
-// 144 columns in default mode (141 + 3), 160 in deferred mode (156 + 4).  A removed column reads as the constant 0 wherever the
+// states and (v6) the class column "other, jumps".  The committed ("physical") matrix is the logical one with those columns removed:
+// 152 columns in default mode (172 - 20), 168 in deferred mode (172 - 4), whole blocks of 8.  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
 static const int W_AUX = 40;
 // (AIR v6) the class column "other, jumps" (C_K3 + 1) is identically zero in the default mode too — no opcode's class is oj there (constraint 4) — and is not committed

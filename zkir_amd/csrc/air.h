@@ -1,40 +1,48 @@
-// air.h — the AIR of ZKIR-STARK (v4: v2 + SUB, four comparison families, JALR, sequential control flow): column map of the 163 LOGICAL main-trace columns (144 committed in default mode) and of
-// the 24-column aux trace, and the constraint list, written
+// air.h — the AIR of ZKIR-STARK (v6): column map of the 172 LOGICAL main-trace columns (152 committed in default mode, 168 deferred) and of
+// the 40-column aux trace, and the constraint list (398 constraints), written
 // ONCE for the two places of the product that evaluate it: the quotient kernel (stark_prove.inl; base-field values at every point
 // of the LDE coset, lazily accumulated) and the host verifier (verify.cpp; extension-field openings at zeta).  The oracle
 // (oracle/stark_oracle.cpp, constraints_sum) states the same list independently in naive arithmetic; constraint c carries the
-// coefficient alpha^c and the indices below are that list's order.
+// coefficient alpha^c and the indices below are that list's order.  Every constraint has degree <= 2 in the columns (x is_trans, degree 1)
+// or degree 1 (x is_first / is_last): the quotient has degree < N, which is what blow-up 2 affords — no helper column can be inlined.
 //
-// What the constraints say (default VM mode; `deferred` public input = 0):
-//   * an executed row runs as the class of ITS PROGRAM WORD (opclass, part of the instruction-ROM tuple): ADD, ADDI, SUB, JAL and the
-//     families (pairs of opcodes that differ in the polarity of one comparison) BEQ / BNE, BLTU / BGEU, SEQ / SNE, SLTU / SGEU — 12 of the
-//     50 opcodes; everything else is class "other";
-//   * wr = one-hot(rd) on rows that write (ADD / ADDI / SUB / JAL / SEQ.. / SLTU..), empty on branch / halt / padding rows, at most one
-//     register otherwise; selb = one-hot(field b), selc = one-hot(field c) (of field a on B-type rows), xb / xc = the selected limbs;
-//   * z = the row's RANGE-CHECKED pair of 20-bit limbs: xb + xc, xb + sext(imm17), pc + 4 (mod 2^40, boolean carries), xb - xc on SUB and
-//     SLTU / SGEU rows, xc - xb on BLTU / BGEU rows (boolean borrows; the borrow out of 40 bits IS the unsigned comparison,
-//     execute.rs:373-407, :618-636); y = the value written: z on arithmetic rows, the comparison (0 / 1) on SEQ.. / SLTU.. rows — the
-//     register selected by wr shows y in the next row, every other register keeps its limbs and storage state;
+// What the constraints say (default VM mode; `deferred` public input = 0) — the full semantics of 20 of the 50 opcodes, the control flow of all:
+//   * an executed row runs as the class of ITS PROGRAM WORD (opclass, part of the instruction-ROM tuple): ADD, ADDI, SUB, JAL, JALR, the
+//     comparison families BEQ / BNE, SEQ / SNE (pairs: op = base + pol), SLTU / SGEU / SLT / SGE and BLT / BGE / BLTU / BGEU (four members:
+//     op = base + 2 g + pol, g = the word's variant bit, also in the ROM tuple) and the conditional moves CMOV / CMOVNZ (class cmn) and CMOVZ
+//     (class cmz); everything else is class "other";
+//   * wr = one-hot(rd) on rows that write (ADD / ADDI / SUB / JAL / JALR / SEQ.. / SLTU..), on a conditional move exactly when its condition
+//     holds (q), empty on branch / halt / padding rows, at most one register otherwise; selb = one-hot(field b), selc = one-hot(field c) (of
+//     field a on B-type rows), xb / xc = the selected limbs;
+//   * z = R0 + 1024 R1, R2 + 1024 R3: the row's first RANGE-CHECKED pair of 20-bit limbs (no columns of its own since v6): xb + xc, xb + sext(imm17),
+//     pc + 4 (mod 2^40, boolean carries), xb - xc on SUB rows; on ORDERED comparisons (SLTU.. / BLT.. rows) the difference of the operands with
+//     their high limbs BIASED, t = limb + 2^19 sgn - 2^20 (sign bit) — the limbs of value XOR 2^39 when the comparison is signed (sgn = g on SLTU..
+//     rows, 1 - g on BLT.. rows; Value40::signed_lt, value.rs:710-716) — u = (ta, tb) = R4 + 1024 R5, R6 + 1024 R7 being the row's SECOND
+//     range-checked pair, which forces the sign bits (sa = column b0, sb); the borrow out of 40 bits IS the comparison (execute.rs:361-407, :598-636);
+//     y = the value written: z on arithmetic rows, the comparison (0 / 1) on SEQ.. / SLTU.. rows, rs1's raw limbs on conditional moves — the
+//     register selected by wr shows y in the next row, every other register keeps its limbs and storage state; on "other" rows y is a free
+//     witness whose low limbs are z (in range) and whose bits above 40 are range-checked through the second pair: y2 = R4 + 2^10 R5 + 2^20 R6,
+//     R7 = 64 R6 — so every limb of every register is in range by induction;
 //   * flag = [xb == xc] over all three limbs (raw 64-bit compare, execute.rs:409-431, :578-596) on the equality families, the borrow on
-//     the unsigned ones; fx = flag XOR (op - the family's even opcode); a branch is taken iff fx;
-//   * pc' = pc + 4 | pc + sext(imm17) if taken | pc + sext(off21) for JAL, mod 2^64 (state.rs:131-133);
+//     the ordered ones; fx = flag XOR pol; a branch is taken iff fx; nz = [xc != 0] on every row (sum of the in-range limbs), q = K_cmn nz +
+//     K_cmz (1 - nz) (execute.rs:434-472);
+//   * pc' = pc + 4 | pc + sext(imm17) if taken | pc + sext(off21) for JAL | (rs1 + sext(imm17)) & ~1 for JALR, mod 2^64 (state.rs:131-133,
+//     execute.rs:649-658): class "other" is sequential — the control flow of EVERY opcode is constrained;
 //   * cycle counts up; row 0 is in the public FIRST state and row n_real - 1 in the public LAST state (for a whole run the verifier
 //     requires the first state to be the VM's initial one: cycle 0, entry point, zero registers); the row count is public: row
 //     n_real - 1 is the halt row, only padding follows it, padding keeps everything.
-// ONE LogUp lookup argument used twice (AIR v2; aux trace: six extension-field columns committed after the lookup challenges):
-//   * instruction ROM: the tuple (pc limbs, op, fa, fb, fc, fhi, s, opclass) of EVERY row is a row of the program's code table — the
+// ONE LogUp lookup argument used twice (aux trace: ten extension-field columns committed after the lookup challenges: H0..H7, HR, S):
+//   * instruction ROM: the tuple (pc limbs, op, fa, fb, fc, fhi, s, opclass, g) of EVERY row is a row of the program's code table — the
 //     verifier builds that table from the program carried in the proof (its digest is the public program_digest), so the instruction
 //     word at pc is the program's (vm.rs:362-379), its fields are in range, and the class an executed row runs as is the class of that
 //     word (opclass), not a free witness;
-//   * ranges: the limbs of z are two 10-bit chunks each, every chunk a row of the 2^10 table (range_check.rs:175-192, config.rs:78-80),
-//     which makes the boolean carries / borrows the only solution;
+//   * ranges: EIGHT 10-bit chunks per row, every chunk a row of the 2^10 table (range_check.rs:175-192, config.rs:78-80), which makes the
+//     boolean carries / borrows / sign bits the only solution;
 //   the prover sends the multiplicities of both tables BEFORE the challenges (alpha, lambda) are drawn; the verifier computes the table
 //   side T = sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u) itself; the running-sum column closes over the cycle of N rows.
-// AIR v4: JALR (link pc + 4; pc' + the cleared bit = rs1 + sext(imm17) mod 2^64), class "other" is SEQUENTIAL (pc + 4 for every opcode that is
-// not a branch or a jump), BLT / BGE run as the free-pc class "oj" and write nothing: control flow is stated for every opcode but those two.
-// Not constrained yet: the other 37 opcodes' VALUES (class "other": y is a free witness), the signed comparisons, memory
-// consistency, deferred-mode arithmetic
-// (deferred = 1 relaxes the write constraints to "unwritten registers keep their value").
+// Not constrained: the VALUES the other 30 opcodes write (MUL / DIV / logic / shifts / loads / ECALL: class "other", y is a free
+// in-range witness), memory consistency, the SHA-256 chip, deferred-mode arithmetic (deferred = 1 relaxes the write constraints to "unwritten
+// registers keep their value"; branches and jumps run as the free-pc class "oj" there, which no default-mode row can be).
 #pragma once
 #include "babybear.h"
 
