@@ -426,9 +426,8 @@ def main():
     blob = spec.fib_endless_program().to_bytes()
 
     # ---- host stage (untimed for `value`; reported separately) ------------------------------------
-    # Execution is sequential: ONE interpretation per node.  N = 1: in-process.  N > 1: rank 0 interprets the whole (N * 2^k)-row
-    # run once and leaves every rank's row shard (own register snapshot, rebased events) in /dev/shm; the other ranks wait and
-    # pick theirs up — they never interpret.
+    # Execution is sequential.  N = 1: one interpretation, in-process.  N > 1: EVERY rank executes the rows before its shard untraced and
+    # traces its own (zkir_interpret_window, below): no shard files, nothing travels between the processes.
     host_first_s = host_s = None
     per_rank_host_s = None
     log = None
