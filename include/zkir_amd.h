@@ -287,6 +287,10 @@ double zkir_modmul_peak_per_s(void* hip_stream);
 /* trace columns (K1 output, n_real executed rows) -> main trace matrix (B8: zkir_main_trace_width_for(deferred) / 8 blocks [N][8]), N = 2^zkir_padded_log_n(n_real): rows past n_real are
  * padding (class "pad": state of the last executed row, cycle keeps counting).  deferred = VMConfig.enable_deferred_model of the run. */
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* hip_stream);
+/* the same rows computed on the HOST (trace = host pointers, out = host buffer, same B8 layout): the kernel's per-row code is one host + device
+ * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
+ * (there is no CPU fallback). */
+int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out);
 /* per-column low-degree extension: in = B8 matrix with N rows (evaluations over <w_N>, natural order; CLOBBERED as scratch when N >= 1024)
  * -> out = B8 matrix with 2N rows = evaluations over the coset 31*<w_2N>, natural order.  All 8 columns of every block are transformed. */
 int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);

@@ -45,12 +45,12 @@ __host__ __device__ __forceinline__ uint64_t b8(uint32_t k, uint64_t j, uint64_t
 // main trace columns (oracle: so::main_trace)
 // ------------------------------------------------------------------------------------------------
 // Montgomery-free helpers for the witness columns (canonical values in and out)
-__device__ __forceinline__ uint32_t f_inv(uint32_t a) {          // a^(p-2), canonical; 0 -> 0
+BB_HD uint32_t f_inv(uint32_t a) {          // a^(p-2), canonical; 0 -> 0
   uint32_t r = bb::R1, b = bb::to_mont(a), e = bb::P - 2;
   while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; }
   return bb::from_mont(r);
 }
-__device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
+BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
   const int bits = st ? 30 : 20;
   const uint64_t mask = (1ull << bits) - 1;
   out[0] = (uint32_t)(v & mask); out[1] = (uint32_t)((v >> bits) & mask); out[2] = (uint32_t)(v >> (2 * bits));
@@ -65,12 +65,12 @@ __device__ __forceinline__ void reg_limbs(uint64_t v, uint32_t st, uint32_t out[
 #define MT_WAVES 3
 #endif
 // DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 152 columns by default, 168 deferred.
+// The row itself is a host + device function: the kernel below runs it once per lane, zkir_main_trace_host once per row on the CPU — the same
+// code, so the CPU test suite (no GPU) checks it against the oracle column by column (tests/test_abi.py).
 template <bool DEF>
-__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out) {
+BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t N, uint64_t i, uint32_t* __restrict__ out) {
   using namespace air;
   constexpr uint32_t deferred = DEF ? 1u : 0u;
-  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= N) return;
   uint32_t rowv[W];
   auto col = [&](int k) -> uint32_t& { return rowv[k]; };
   const bool pad = i >= n_real, last = i + 1 >= n_real;
@@ -205,6 +205,12 @@ __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_col
     out4[((uint64_t)b * N + i) * 2] = make_uint4(at(8 * b), at(8 * b + 1), at(8 * b + 2), at(8 * b + 3));
     out4[((uint64_t)b * N + i) * 2 + 1] = make_uint4(at(8 * b + 4), at(8 * b + 5), at(8 * b + 6), at(8 * b + 7));
   }
+}
+template <bool DEF>
+__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= N) return;
+  main_trace_row<DEF>(t, n_real, N, i, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -454,6 +460,15 @@ int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uin
   if (deferred) hipLaunchKernelGGL(main_trace_kernel<true>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
   else hipLaunchKernelGGL(main_trace_kernel<false>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
   return check_launch("main_trace");
+}
+// The same rows on the host (trace = HOST pointers, out = host buffer of zkir_main_trace_width_for(deferred) / 8 blocks [N][8]): main_trace_row is one
+// host + device function, so what the kernel computes can be checked without a GPU.  A test / diagnostic entry point, not a fallback: nothing in the
+// product calls it.
+int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out) {
+  if (!trace || !out || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
+  for (uint64_t i = 0; i < N; i++) { if (deferred) main_trace_row<true>(*trace, n_real, N, i, out); else main_trace_row<false>(*trace, n_real, N, i, out); }
+  return ZKIR_OK;
 }
 
 // in: ceil(width/8) blocks [N][8] of canonical evaluations over H (natural order; used as scratch and overwritten!), out: blocks [2N][8]
