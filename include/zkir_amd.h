@@ -329,7 +329,7 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob
                           uint32_t deferred, zkir_public_inputs* out);
 
 /* Full proof of the execution whose K1 output is `trace` (pub->n_real rows; ctx built for zkir_padded_log_n(pub->n_real)).  *proof_out is a
- * malloc'ed array of u32 words (little-endian canonical field elements, format v8: layout in oracle/stark_oracle.cpp so::prove),
+ * malloc'ed array of u32 words (little-endian canonical field elements, format v10: layout in oracle/stark_oracle.cpp so::prove),
  * pub->program_blob must be the program that ran: every row's (pc, instruction word) is looked up in its code table, and a run that executes
  * anything else (self-modified code, a pc outside the code segment) is refused with ZKIR_ERR_ARGUMENT — it has no proof in this AIR.
  * released with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries.

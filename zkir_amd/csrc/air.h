@@ -73,7 +73,7 @@ BB_HD constexpr int logical_col(int p, bool deferred) {
   if (deferred) { if (c >= C_STATE) c += 1; } else { if (c >= C_STATE) c += 16; if (c >= C_KOJ) c += 1; }
   return c;
 }
-// aux trace: H0..H3 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
+// aux trace: H0..H7 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
 constexpr int W_AUX = 40;
 enum : int { A_H = 0, A_HR = 32, A_S = 36 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
 }
 
 // ---- lookup argument (AIR v2): per-row table indices + multiplicities, inverse tables, aux trace -------------------------------------
-// The looked-up values of a row live in blocks 0, 1, 16, 17 of the main-trace matrix: tuple (pc limbs, op, fa, fb, fc | fhi | opclass | s)
+// The looked-up values of a row live in blocks 0, 1 and the last three of the main-trace matrix: tuple (pc limbs, op, fa, fb, fc | fhi | opclass | s | g)
 // and the four range chunks.  One pass over them, BEFORE the LDE uses the matrix as scratch: side[i] = (chunk 0 | chunk 1 << 16,
 // chunk 2 | chunk 3 << 16, ROM row u, 0) [v5: eight chunks, three 10-bit chunks per word: (c0 c1 c2, c3 c4 c5, c6 c7, u)], the range-table histogram (LDS-privatised) and the ROM histogram (LDS-privatised for the
 // first ROM_LDS rows of the table — a program's hot code — global atomics beyond).  A row whose tuple is not the program's word at

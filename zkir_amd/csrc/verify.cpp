@@ -1,4 +1,4 @@
-// verify.cpp — the product's verifier of ZKIR-STARK proofs (format v8: whole runs, segments of a run, chains of segments) and the
+// verify.cpp — the product's verifier of ZKIR-STARK proofs (format v10: whole runs, segments of a run, chains of segments) and the
 // public-input helpers; host only, no device.
 //
 // Self-defined stages (the reference has no prover or verifier: SURVEY.md F1 / a17, N4).  Independent of oracle/: Montgomery
