@@ -201,6 +201,54 @@ def test_call_loop_2p20_control_flow_on_all_rows_and_proof():
     ctx.close(); res.close()
 
 
+def test_signed_comparisons_and_conditional_moves_2p20_semantics_on_all_rows_and_proof():
+    """AIR v5 / v6 at scale: 2^20 cycles of spec.signed_loop_program and 2^18 of spec.cmov_loop_program through zkir_exec — the semantics of SLT / SGE /
+    BLT / BGE (Value40::signed_lt, value.rs:710-716) and of CMOV / CMOVZ / CMOVNZ (execute.rs:434-472) checked on EVERY row with numpy against the
+    next row's register / pc, oracle rows on a window, and the proofs of both runs accepted by both verifiers."""
+    from zkir_amd import stark
+    M40 = np.uint64((1 << 40) - 1); SB = np.uint64(1 << 39)
+    for prog, k in ((spec.signed_loop_program, 20), (spec.cmov_loop_program, 18)):
+        n = 1 << k
+        blob = prog().to_bytes()
+        res = rt.VM(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True)).run()
+        assert res.cycles == n
+        tr = res.execution_trace
+        lo, hi = n // 2 - 100, n // 2 + 100
+        helpers.assert_rows_equal(tr.rows_window(lo, hi), oracle.run(blob, max_cycles=n, enable_execution_trace=True, keep_rows=(lo, hi)).rows)
+        pc = tr.column(rt.FIELD_PC); ins = tr.column(rt.FIELD_INSTRUCTION)
+        R = np.stack([tr.column(rt.FIELD_REGISTERS, r) for r in range(16)])
+        op = (ins & 0x7F)[:-1]; fa = ((ins >> 7) & 0xF)[:-1]; fb = ((ins >> 11) & 0xF)[:-1]; fc = ((ins >> 15) & 0xF)[:-1]
+        idx = np.arange(n - 1)
+        a_, b_, c_ = R[fa, idx], R[fb, idx], R[fc, idx]
+        nxt_rd = R[fa, idx + 1]
+        imm = ((ins[:-1] >> 15).astype(np.int64) - ((ins[:-1] >> 31).astype(np.int64) << 17))
+        seq_pc = pc[:-1] + np.uint64(4); tgt_pc = (pc[:-1].astype(np.int64) + imm).astype(np.uint64)
+        slt = lambda x, y: ((x & M40) ^ SB) < ((y & M40) ^ SB)                           # noqa: E731
+        keep = lambda m: (R[:, idx + 1][:, m] == R[:, idx][:, m]).all()                  # noqa: E731   nothing at all changes
+        checks = {
+            0x22: lambda m: np.array_equal(nxt_rd[m], slt(b_[m], c_[m]).astype(np.uint64)),
+            0x23: lambda m: np.array_equal(nxt_rd[m], (~slt(b_[m], c_[m])).astype(np.uint64)),
+            0x42: lambda m: np.array_equal(pc[1:][m], np.where(slt(a_[m], b_[m]), tgt_pc[m], seq_pc[m])),
+            0x43: lambda m: np.array_equal(pc[1:][m], np.where(~slt(a_[m], b_[m]), tgt_pc[m], seq_pc[m])),
+            0x26: lambda m: np.array_equal(nxt_rd[m & (c_ != 0) & (fa != 0)], b_[m & (c_ != 0) & (fa != 0)]) and keep(m & ((c_ == 0) | (fa == 0))),
+            0x28: lambda m: np.array_equal(nxt_rd[m & (c_ != 0) & (fa != 0)], b_[m & (c_ != 0) & (fa != 0)]) and keep(m & ((c_ == 0) | (fa == 0))),
+            0x27: lambda m: np.array_equal(nxt_rd[m & (c_ == 0) & (fa != 0)], b_[m & (c_ == 0) & (fa != 0)]) and keep(m & ((c_ != 0) | (fa == 0))),
+        }
+        seen = 0
+        for code, ok in checks.items():
+            m = op == code
+            if m.any():
+                assert m.sum() > n // 64 and ok(m), hex(code)
+                seen += 1
+        assert seen == (4 if prog is spec.signed_loop_program else 3)
+        del R, a_, b_, c_, nxt_rd
+        ctx = stark.StarkContext(k)
+        pub = res.public_inputs()
+        proof = stark.prove(ctx, tr.columns, pub)
+        assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0 and proof[3] == stark.W_MAIN
+        ctx.close(); res.close()
+
+
 def test_config4_sha_chain_2p22_syscall_chip_columns():
     """configs[4]: SHA-256 hash-chain program for 2^22 cycles — trace rows, memory ops (row order, CSR, sorted), and the SHA-256
     chip columns, all behind the drop-in handle (zkir_result_*), vs the oracle on sampled windows / blocks and through full-size
