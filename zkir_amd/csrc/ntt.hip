@@ -183,13 +183,14 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
           wb = bb::mont_mul(tp[r], sm[r]);                                      // w2
           wa = bb::mont_mul(wb, wb); wc = bb::mont_mul(wb, j4_m);               // w1, w2i
         }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          uint4* pl = lds4 + h * PLANE;
-          uint4 x0 = pl[i0], x1 = pl[i0 + d], x2 = pl[i0 + 2 * d], x3 = pl[i0 + 3 * d];
-          if (!DIT) dif4(x0, x1, x2, x3, wa, wb, wc); else dit4(x0, x1, x2, x3, wa, wb, wc);
-          pl[i0] = x0; pl[i0 + d] = x1; pl[i0 + 2 * d] = x2; pl[i0 + 3 * d] = x3;
-        }
+        // both halves' eight words are read before either quad is computed: one LDS latency per round instead of two
+        uint4* pl0 = lds4; uint4* pl1 = lds4 + PLANE;
+        uint4 x0 = pl0[i0], x1 = pl0[i0 + d], x2 = pl0[i0 + 2 * d], x3 = pl0[i0 + 3 * d];
+        uint4 y0 = pl1[i0], y1 = pl1[i0 + d], y2 = pl1[i0 + 2 * d], y3 = pl1[i0 + 3 * d];
+        if (!DIT) dif4(x0, x1, x2, x3, wa, wb, wc); else dit4(x0, x1, x2, x3, wa, wb, wc);
+        pl0[i0] = x0; pl0[i0 + d] = x1; pl0[i0 + 2 * d] = x2; pl0[i0 + 3 * d] = x3;
+        if (!DIT) dif4(y0, y1, y2, y3, wa, wb, wc); else dit4(y0, y1, y2, y3, wa, wb, wc);
+        pl1[i0] = y0; pl1[i0 + d] = y1; pl1[i0 + 2 * d] = y2; pl1[i0 + 3 * d] = y3;
       }
       // A wave's 64 quads (2^(6-C) values of qq) cover one contiguous "home block" of 4 * 2^(6-C) rows in every round whose quad span
       // fits it: DIF rounds with log2(h2) <= 6 - C, DIT rounds with b <= 6 - C.  Between two such rounds the data never leaves the wave.
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
     }
     if (wn >= total) break;
     w = wn; x = xn; base = base_n; lo0 = lo0_n;
-    __syncthreads();                                           // every lane has copied its part of the tile out before LDS is refilled
+    // (no barrier here: a lane refills exactly the LDS words it has just copied out — the copy-in and copy-out loops share one slot map —
+    //  and the barrier after the refill orders everything before the first round)
   }
 }
 
