@@ -385,6 +385,10 @@ def main():
     ap.add_argument("--only-config", choices=["2", "3", "4"], default=None, help="run only that by_config section and print it (profiling runs; 3 = 2^26 rows on one GPU)")
     args = ap.parse_args()
 
+    # Read by the HSA runtime when it initialises (the first HIP call of the process), so it has to be in the environment BEFORE torch
+    # touches the device: the host driver only supports dmabuf IPC, and RCCL's intra-node transport needs it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -404,8 +408,11 @@ def main():
     backend = os.environ.get("ZKIR_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("ZKIR_BENCH_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # ZKIR_BENCH_FORCE_DIST=1: take the N > 1 code path at ANY world size — at world 1 (torchrun --nproc-per-node 1, a one-GPU box) that is the
+    # window interpretation, the device all-gather of the root over RCCL, the cap, the f64 all-reduces, the barriers, the object collectives
+    # and the segment proofs + zkir_verify_chain, all on a real `nccl` process group (tests/test_gpu_multirank.py::test_world1_over_rccl)
+    dist_mode = world > 1 or os.environ.get("ZKIR_BENCH_FORCE_DIST") == "1"
+    if dist_mode:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -419,7 +426,7 @@ def main():
         print(json.dumps({"by_config": {("configs[3] on one GPU" if args.only_config == "3" else f"configs[{args.only_config}]"): fn()}}))
         return
 
-    k = args.log2_rows if args.log2_rows is not None else (20 if world == 1 else 23)
+    k = args.log2_rows if args.log2_rows is not None else (20 if not dist_mode else 23)
     n = 1 << k
     total_rows = n * world
     W = stark.W_MAIN
@@ -431,7 +438,7 @@ def main():
     host_first_s = host_s = None
     per_rank_host_s = None
     log = None
-    if world == 1:
+    if not dist_mode:
         t0 = time.perf_counter()
         log = rt.interpret(blob, [], rt.VMConfig(max_cycles=total_rows, enable_execution_trace=True), tile_rows=args.tile_rows)
         host_first_s = host_s = time.perf_counter() - t0
@@ -496,7 +503,7 @@ def main():
     # RCCL/xGMI) — and every rank hashes the top log2(G) levels over them (zkir_merkle_cap_launch), so `value` is the rate of the
     # complete G-GPU commitment, not of G unrelated ones.
     gathered, cap_root = None, [None]
-    if commit and world > 1:
+    if commit and dist_mode:
         gathered = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(world)]
 
         def exchange():
@@ -515,12 +522,12 @@ def main():
             f()
 
     def barrier():
-        if world > 1:
+        if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
     t_pre = time.perf_counter()                       # untimed pre-warm: let the GPU clocks settle (DVFS) before the W warmup steps
-    if world == 1:
+    if not dist_mode:
         while time.perf_counter() - t_pre < 0.3:
             step()
             torch.cuda.synchronize()
@@ -543,7 +550,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     gpu_ms_per_step = marks[0][0].elapsed_time(marks[-1][-1]) / args.steps
-    if world > 1:
+    if dist_mode:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -564,7 +571,7 @@ def main():
 
     # ---- end-to-end prove (BASELINE metric's "end-to-end prove ms"): AIR quotient + openings + DEEP + FRI on top of the commit ----
     prove_ms, prove_stage_ms, proof_bytes, verify_ms = None, None, None, None
-    if commit and world == 1 and not args.no_prove:   # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
+    if commit and not dist_mode and not args.no_prove:   # a proof is for the whole run (its AIR pins cycle[0] = 0): single-GPU only
         pub = rt.public_inputs(log, blob)
         for _ in range(3):                            # first call allocates the context's workspace
             t0 = time.perf_counter()
@@ -579,7 +586,7 @@ def main():
     # ---- N > 1: the run PROVEN, one segment per GPU (no data-path collective: a segment needs its own rows only); the proofs are
     #      gathered on rank 0 and verified there as ONE run (zkir_verify_chain: first state initial, states link, same public inputs)
     segment_prove = None
-    if commit and world > 1 and not args.no_prove:
+    if commit and dist_mode and not args.no_prove:
         try:
             run_pub = rt.PublicInputsC.from_buffer_copy(run_pub_bytes[0]).with_program(blob)   # the borrowed program pointer of another process means nothing here
             seg_proofs, seg_ms = [], None
@@ -622,7 +629,7 @@ def main():
     #      with upload + K1 streamed underneath) -> main trace -> LDE -> Merkle -> all-gather + cap; (b) G INDEPENDENT runs, one per
     #      GPU, each interpreted by its own rank: the mode whose aggregate scales with G, since one run is bounded by one core
     multi_e2e = None
-    if commit and world > 1:
+    if commit and dist_mode:
         try:
             def commit_from(cols, n_rows):
                 pl._check(lib.zkir_main_trace_launch(C.byref(cols), n_rows, 0, m.data_ptr(), sp()))
@@ -686,7 +693,7 @@ def main():
 
     # ---- the drop-in entry point itself: zkir_exec = host interpretation + H2D + K1 in one call (VM::new + VM::run, trace left in HBM)
     exec_s = None
-    if world == 1 and k <= 24:
+    if not dist_mode and k <= 24:
         ts = []
         for _ in range(5):
             t0 = time.perf_counter()
@@ -698,7 +705,7 @@ def main():
 
     # ---- the same proof with the host in the loop: independent runs pipelined through interpret -> H2D -> K1 -> prove ----------
     pipelined = pipelined_commit = None
-    if commit and world == 1 and k <= 22 and not args.no_prove:
+    if commit and not dist_mode and k <= 22 and not args.no_prove:
         from zkir_amd import service
         job = (blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
         service.prove_many([job] * 2, k, producers=1, ctx=ctx, keep_proofs=False)
@@ -725,7 +732,7 @@ def main():
         assert np.array_equal(got[r], e["value"][pos]), "bench parity spot-check failed"
     root = tree[-4:].cpu().numpy().view(np.uint32).tolist() if commit else None
     roots = None
-    if commit and world > 1:
+    if commit and dist_mode:
         roots = [x.cpu().numpy().view(np.uint32).tolist() for x in gathered]
         if cap_root[0] is not None:
             root = cap_root[0].cpu().numpy().view(np.uint32).tolist()
@@ -734,13 +741,16 @@ def main():
 
     # ---- the other single-GPU BASELINE configs, outside the timed region (free the configs[1] buffers first) ----
     by_config = None
-    if rank == 0 and world == 1 and commit and not args.no_by_config and k == 20:
+    if rank == 0 and not dist_mode and commit and not args.no_by_config and k == 20:
         if commit:
             del m, L, tree
             ctx.close()
         del trace, ddl, fill_args
         torch.cuda.empty_cache()
-        by_config = {"configs[2]": _config2_fib_2p24(lib, sp), "configs[4]": _config4_sha_2p22(lib, sp)}
+        by_config = {"configs[2]": _config2_fib_2p24(lib, sp), "configs[4]": _config4_sha_2p22(lib, sp),
+                     # the N = 1 point of the N > 1 lines: they run 2^23 rows per GPU (configs[3]'s share), this line 2^20 — a SCALE curve is to be read
+                     # against THIS rate (a second strided NTT pass per side at 2^23), not against `value`
+                     "2^23 rows on one GPU (the per-GPU problem of the N > 1 lines)": _config2_fib_2p24(lib, sp, 23)}
         try:                                           # 2^26 rows need ~185 GB of HBM: reported when the device has them, never fatal
             if torch.cuda.mem_get_info()[1] >= 250 * (1 << 30):
                 by_config["configs[3] on one GPU"] = _config2_fib_2p24(lib, sp, 26)
@@ -753,7 +763,7 @@ def main():
         value = total_rows * args.steps / wall
         kernels = _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp)
         dom = max(kernels, key=lambda q: kernels[q]["ms"])
-        traffic, traffic_source = _profiled_traffic(dom) if (k == 20 and world == 1 and commit) else (None, None)
+        traffic, traffic_source = _profiled_traffic(dom) if (k == 20 and not dist_mode and commit) else (None, None)
         dom_kernel = {"merkle_leaves": "leaf_hash_kernel", "trace_fill": "trace_fill_kernel", "main_trace": "main_trace_kernel"}.get(dom, dom)
         alu_measured = None
         if commit:                                        # the measured counterpart of the analytic ALU peak: 7 repetitions, spread reported (it moves with the clock state)
@@ -766,9 +776,9 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (Baby Bear, 31-bit modular) / u64 trace words" if commit else "u64", "data": "synthetic",
-            "config": {"workload": (f"fib_endless 2^{k} cycles per GPU" + (" = BASELINE configs[1]" if k == 20 and world == 1 else "")
+            "config": {"workload": (f"fib_endless 2^{k} cycles per GPU" + (" = BASELINE configs[1]" if k == 20 and not dist_mode else "")
                                     + (f" = BASELINE configs[3] (2^26-cycle fib row-sharded over 8 GPUs)" if k == 23 and world == 8 else
-                                       (f" (configs[3]'s per-GPU share; {world} row shards of one 2^{k + world.bit_length() - 1}-cycle run)" if world > 1 else ""))
+                                       (f" (configs[3]'s per-GPU share; {world} row shards of one 2^{k + world.bit_length() - 1}-cycle run)" if dist_mode else ""))
                                     + "; v3.4 fib loop of tests/cross_module.rs:145-164, max_cycles halt, VMConfig{enable_execution_trace}; "
                                     f"stages = {'+'.join(s for s, _ in stages)}; blow-up 2, Poseidon2 width 12"),
                        "rows_per_gpu": n, "tile_rows": tile_rows, "reg_events_per_gpu": n_events, "main_trace_width": W if commit else None,
@@ -800,6 +810,14 @@ def main():
             # rows per second of ONE GPU over its own stages (everything but the all-gather + cap): at N > 1 the shard is 2^23 rows, not the 2^20 of
             # N = 1 (a second strided NTT pass per side), so this — not value(1) — is the single-device rate `value` / N is to be held against
             "per_gpu_local_stage_rows_per_s": n / (sum(v for q, v in stage_ms.items() if q != "allgather_cap") * 1e-3),
+            # N > 1: `value` against N x (rank 0's rate over its own stages at the SAME 2^k rows) — what the all-gather + cap and the barrier cost, with the
+            # size effect (N = 1 runs 2^20 rows, N > 1 runs 2^23 per GPU) taken out; N = 1: the 2^23-row single-GPU rate the N > 1 lines are to be held against
+            "efficiency_vs_same_size_single_gpu": (value / (world * n / (sum(v for q, v in stage_ms.items() if q != "allgather_cap") * 1e-3))) if dist_mode else None,
+            "single_gpu_commit_rows_per_s_by_log2_rows": ({str(k): value, **{str(v["rows"].bit_length() - 1): v["commit_rows_per_s"] for v in (by_config or {}).values()
+                                                                                 if isinstance(v, dict) and "commit_rows_per_s" in v}} if not dist_mode and commit else None),
+            "process_group": ({"backend": backend, "world_size": world, "forced_at_world_1": world == 1,
+                               "collectives_executed": ["barrier", "all_gather(int32[4] root, device)" if backend == "nccl" else "all_gather(int32[4] root, host-staged)",
+                                                        "all_reduce(f64 MAX)", "all_gather_object", "broadcast_object_list", "gather_object"]} if dist_mode else None),
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
             "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
@@ -813,16 +831,16 @@ def main():
             # N = 1: the one interpretation of the run.  N > 1: EVERY rank executes its own prefix (rank g: g n rows untraced + n rows traced, on its own
             # core: zkir_interpret_window) — G interpreters per node, no shard transport; `host_interpret_s` is then the slowest rank's (the last one's)
             "host_interpretations_per_node": world, "shard_distribution_s": 0.0,
-            "host_window_s_per_rank": per_rank_host_s if world > 1 else None,
+            "host_window_s_per_rank": per_rank_host_s if dist_mode else None,
             "multi_gpu_end_to_end": multi_e2e,
-            "end_to_end_rows_per_s_incl_host": (multi_e2e or {}).get("one_run_row_sharded", {}).get("end_to_end_rows_per_s_incl_host") if world > 1 else None,
+            "end_to_end_rows_per_s_incl_host": (multi_e2e or {}).get("one_run_row_sharded", {}).get("end_to_end_rows_per_s_incl_host") if dist_mode else None,
             "h2d_upload_s": h2d_s,
             "end_to_end_rows_per_s_incl_host_and_pcie": n / (exec_s + (gpu_ms_per_step - stage_ms["trace_fill"]) * 1e-3) if exec_s else None,
             "zkir_exec_ms": exec_s * 1e3 if exec_s else None,                 # drop-in call: interpret + H2D + trace fill, PCIe-inclusive
             "zkir_exec_rows_per_s": n / exec_s if exec_s else None,
             "host_cpu": _host_cpu(),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not dist_mode:
             out["cpu_baseline"] = _cpu_baseline(blob, k, commit)
             side = out["cpu_baseline"].get("commit_stage_self_defined")
             if side and root is not None:
@@ -841,7 +859,7 @@ def main():
                                                                   "GPU path's time ~97 % is the host interpreter and ~3 % K1 — it is an end-to-end ratio of two trace paths, not a kernel speed-up",
                                              "commit_step_ratio_vs_cpu_commit_port": (c2["commit_rows_per_s"] / side["rows_per_s"]) if side else None}
         print(json.dumps(out))
-    if world > 1:
+    if dist_mode:
         dist.destroy_process_group()
 
 
