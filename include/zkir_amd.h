@@ -291,6 +291,14 @@ int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uin
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */
 int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out);
+/* Test entry points of the AIR evaluation as the quotient kernel runs it (stark_prove.inl: QuotientOps — lazy 32-bit arithmetic, 96-bit sums, one
+ * accumulator per row selector), host builds of the same code; nothing in the product calls them.
+ * zkir_air_eval_host: sum_c alpha^c C_c (canonical E4 -> out4) of one (row, next row) pair given as LOGICAL columns (172 main, 40 aux; canonical
+ * words), lookup parameters lk[56] (alpha, lambda^0..11, T / N), selector values, the two boundary states and alpha.
+ * zkir_air_check_bounds: the static soundness check of that arithmetic on the constraint list (air.h: BoundOps): 0 = sound, else the broken rule. */
+void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, uint32_t is_first, uint32_t is_last, uint32_t is_trans,
+                        const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t deferred, uint32_t* out4);
+int zkir_air_check_bounds(uint32_t deferred, char* why, size_t why_len);
 /* per-column low-degree extension: in = B8 matrix with N rows (evaluations over <w_N>, natural order; CLOBBERED as scratch when N >= 1024)
  * -> out = B8 matrix with 2N rows = evaluations over the coset 31*<w_2N>, natural order.  All 8 columns of every block are transformed. */
 int zkir_lde_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uint32_t* out, void* hip_stream);

@@ -123,3 +123,45 @@ def test_main_trace_row_code_matches_oracle_on_the_host(prog, n, cfg):
     want = so.to_committed(so.main_trace(rows, so.public_inputs(nr, blob, deferred=deferred)), deferred)
     for k in range(wm):
         assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"
+
+
+def test_quotient_arithmetic_is_sound_on_the_constraint_list():
+    """air::BoundOps runs air::eval on value bounds: every lazy value is reduced before it could overflow, every 96-bit sum stays below 2^73, every
+    constraint index is pushed at most once — in both VM modes."""
+    import ctypes as C
+    L = rt.lib()
+    L.zkir_air_check_bounds.restype = C.c_int
+    L.zkir_air_check_bounds.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    for deferred in (0, 1):
+        why = C.create_string_buffer(256)
+        assert L.zkir_air_check_bounds(deferred, why, 256) == 0, why.value.decode()
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_quotient_evaluation_matches_oracle_constraints(deferred):
+    """The constraint list as the quotient kernel evaluates it (QuotientOps on the host: lazy arithmetic, 96-bit sums, selector-wise accumulators, boundary
+    constants folded out) against the oracle's naive constraints_sum, on random rows (no row of a real trace: every constraint is non-zero), random lookup
+    parameters, selectors, boundary states and alpha — and on rows of all p - 1 (the largest words)."""
+    import ctypes as C
+    import numpy as np
+    from oracle import stark_api as so
+    L = rt.lib()
+    L.zkir_air_eval_host.restype = None
+    L.zkir_air_eval_host.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p]
+    P = so.P
+    rng = np.random.default_rng(2026)
+    virt = [9, 10, 11] + ([57] if deferred else list(range(57, 73)) + [161])       # air.h is_virtual: R0's limbs; the storage states (default: all 16 + class oj)
+    blob = spec.fib_program(5).to_bytes()
+    pub = so.public_inputs(64, blob, deferred=deferred)
+    for trial in range(40):
+        big = trial >= 36
+        def words(n):
+            return np.full(n, P - 1, np.uint32) if big else rng.integers(0, P, n).astype(np.uint32)
+        loc, nxt, aloc, anxt, lk, first, last, alpha = words(172), words(172), words(40), words(40), words(56), words(68), words(68), words(4)
+        loc[virt] = 0; nxt[virt] = 0
+        sel = words(3)
+        want = so.constraints_eval_states(loc, nxt, aloc, anxt, lk, sel[0], sel[1], sel[2], pub, first, last, alpha)
+        got = np.zeros(4, np.uint32)
+        L.zkir_air_eval_host(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]),
+                             first.ctypes.data, last.ctypes.data, alpha.ctypes.data, int(deferred), got.ctypes.data)
+        assert np.array_equal(got, want), (trial, got, want)

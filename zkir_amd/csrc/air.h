@@ -116,271 +116,376 @@ constexpr uint32_t M(uint64_t v) { return (uint32_t)(((v % bb::P) * (uint64_t)bb
 struct RegConsts { uint32_t r[16], r2[16]; };
 constexpr RegConsts make_reg_consts() { RegConsts c{}; for (int i = 0; i < 16; i++) { c.r[i] = M((uint64_t)i); c.r2[i] = M((uint64_t)i * i); } return c; }
 
-// `Ops` supplies the value type and its arithmetic:
-//   using V;  V add(V,V), sub(V,V), mul(V,V);  V mulc(V, uint32_t montgomery_constant);  V cst(uint32_t montgomery_constant);
+// `Ops` supplies the value type and its arithmetic (values in Montgomery form throughout):
+//   using V;  V cst(uint32_t montgomery_constant);  V add(V,V), sub(V,V), mul(V,V);  V mulc(V, uint32_t montgomery_constant);
 //   V loc(int column), nxt(int column);  V aloc(int aux column), anxt(int aux column);  V par(int lookup parameter: LK_*);
-//   void push(int constraint_index, V value)                                          (values in Montgomery form throughout)
-// is_first / is_last / is_trans: the row selectors at the evaluation point; first_m / last_m: the public boundary states (Montgomery).
+//   V loc_r(int column), nxt_r(int column): the same for a column index that is only known at run time (inside a rolled loop), never an uncommitted column;
+//   void end_boundary(): no push_fc / push_lc follows (the quotient kernel folds its two boundary sums and frees their registers); end_trans(): no push_t follows;
+//   LAZY values (round 4; the verifier's Ops treats them as plain values): V lsub(V,V), ladd(V,V) — difference / sum of two REDUCED values left
+//   unreduced (below 2p); V lmul(V a, V b) — product of any 32-bit a with a reduced b, left below 2p.  A lazy value may only be (i) the FIRST
+//   operand of mul / mulc / lmul, (ii) an operand of acc_mul / acc_lin, (iii) pushed.  air::BoundOps (below) runs this very function on value BOUNDS and
+//   fails where a rule is broken (tests/test_abi.py), so the rules are checked, not trusted.
+//   sums of products:  using AccP; AccP accp();  void acc_mul(AccP&, V a, V b)  (any 32-bit words);  V acc_val(const AccP&)  -> reduced
+//   small-constant combinations:  using AccL; AccL accl();  void acc_lin(AccL&, V a, uint32_t k)  (adds k * a; k a small integer, NOT Montgomery);  V accl_val(const AccL&)
+//   constraints (idx = position in the list = power of alpha; the value may be lazy):
+//     push(idx, v)               C = v
+//     push_t(idx, v)             C = v * is_trans
+//     push_fc(idx, v, cm)        C = (v - cm) * is_first          push_lc(idx, v, cm)   C = (v - cm) * is_last       (cm a Montgomery constant: a public boundary word)
+//     push_fc0(idx, cm)          the same for a column that is not committed (v = 0)                                 push_lc0(idx, cm)
+//   The selectors live in the Ops: the quotient kernel keeps one accumulator per selector and multiplies ONCE per point; the boundary words'
+//   share  - sum alpha^idx cm  is a per-proof constant the prover's host side forms (boundary_constant below).
+// first_m / last_m: the public boundary states (Montgomery).
+BB_HD constexpr int first_idx(int i) { return i == 0 ? I_CYCLE0 : i < 4 ? I_ENTRY + (i - 1) : i < 52 ? I_ZERO0 + (i - 4) : I_ZERO0 + 48 + (i - 52); }   // constraint pinning state word i of row 0
+BB_HD constexpr int last_idx(int i) { return I_LAST + i; }                                                                                              // .. of row n_real - 1
+
+// compile-time loop: the body sees its index as a constant (std::integral_constant)
+template <int I> struct air_ic { static constexpr int value = I; };
+template <int K, int N, class F>
+BB_HD void air_static_for(F&& f) {
+  if constexpr (K < N) { f(air_ic<K>{}); air_static_for<K + 1, N>(f); }
+}
+
 template <class Ops>
-BB_HD void eval(Ops& o, typename Ops::V is_first, typename Ops::V is_last, typename Ops::V is_trans, const uint32_t* first_m, const uint32_t* last_m, bool deferred) {
+BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool deferred) {
   using V = typename Ops::V;
+  using AccP = typename Ops::AccP;
+  using AccL = typename Ops::AccL;
   const V one = o.cst(bb::R1), zero = o.cst(0);
-  auto boolean = [&](int idx, V b) { o.push(idx, o.mul(b, o.sub(b, one))); };
-  const V fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI), s = o.loc(C_S), se = o.loc(C_SE);
+  constexpr uint32_t PM1 = bb::P - bb::R1;                     // -1 (Montgomery): b + PM1 is the lazy b - 1
+  auto boolean = [&](int idx, V b) { o.push(idx, o.lmul(o.ladd(b, o.cst(PM1)), b)); };
+  // ---- A. boundary rows: state word i of row 0 / of row n_real - 1 is the public one; the last executed row is the halt row -------------
+  // (unrolled at compile time: the columns are constants, so the quotient kernel reads them as 16-byte vectors, all in flight at once)
+  air_static_for<0, N_STATE>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, col = state_col(i);
+    if (is_virtual(col, deferred)) { o.push_fc0(first_idx(i), first_m[i]); o.push_lc0(last_idx(i), last_m[i]); return; }
+    const V v = o.loc(col);
+    o.push_fc(first_idx(i), v, first_m[i]); o.push_lc(last_idx(i), v, last_m[i]);
+  });
+  o.push_lc(I_HALT, o.loc(kcol(K_HALT)), bb::R1);
+  o.end_boundary();
+  // ---- B. transitions (x is_trans): registers, cycle counter, next pc, the tail of the trace ------------------------------------------------
+  // registers: unwritten ones keep their limbs and storage state, the written one shows y:  nx - cur - wr (tgt - cur);  in the same pass the
+  // selector moments (sums over the registers with small-constant weights) and the selected operands (sums of products).
+  // A ROLLED loop (the quotient kernel's code size), so the columns are run-time indices (loc_r / nxt_r: never an uncommitted column), software-
+  // pipelined: register r + 1's words are requested before register r's are worked on.  It runs BEFORE the row's other columns are read: few values
+  // are live across it.
+  const V y[3] = {o.loc(C_Y), o.loc(C_Y + 1), o.loc(C_Y + 2)};
+  AccL w0 = o.accl(), w1 = o.accl(), w2 = o.accl(), b1 = o.accl(), b2 = o.accl(), c1a = o.accl(), c2a = o.accl();
+  AccP xbs[3] = {o.accp(), o.accp(), o.accp()}, xcs[3] = {o.accp(), o.accp(), o.accp()};
+  struct RegIn { V wr, sb, sc, limb[3], nx[3], st, nst; };
+  auto load_reg = [&](int r) {
+    RegIn g;
+    g.wr = o.loc_r(C_WR + r - 1); g.sb = o.loc_r(C_SELB + r - 1); g.sc = o.loc_r(C_SELC + r - 1);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { g.limb[l] = o.loc_r(C_LIMB + 3 * r + l); g.nx[l] = o.nxt_r(C_LIMB + 3 * r + l); }
+    if (deferred) { g.st = o.loc_r(C_STATE + r); g.nst = o.nxt_r(C_STATE + r); } else { g.st = zero; g.nst = zero; }
+    return g;
+  };
+  RegIn cur = load_reg(1);
+#pragma unroll 1
+  for (int r = 1; r < 16; r++) {
+    const RegIn ahead = load_reg(r + 1 < 16 ? r + 1 : r);
+    const V wr = cur.wr, sb = cur.sb, sc = cur.sc;
+    boolean(I_BOOL_SEL + 3 * (r - 1), wr); boolean(I_BOOL_SEL + 3 * (r - 1) + 1, sb); boolean(I_BOOL_SEL + 3 * (r - 1) + 2, sc);
+    o.acc_lin(w0, wr, 1); o.acc_lin(w1, wr, (uint32_t)r); o.acc_lin(w2, wr, (uint32_t)(r * r));
+    o.acc_lin(b1, sb, (uint32_t)r); o.acc_lin(b2, sb, (uint32_t)(r * r));
+    o.acc_lin(c1a, sc, (uint32_t)r); o.acc_lin(c2a, sc, (uint32_t)(r * r));
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+      const V limb = cur.limb[l], nx = cur.nx[l];
+      o.acc_mul(xbs[l], sb, limb); o.acc_mul(xcs[l], sc, limb);
+      // nx - cur - wr * ((1 - D) y + D nx - cur)
+      const V tgt = deferred ? nx : y[l];
+      o.push_t(I_REGS + 4 * (r - 1) + l, o.lsub(o.sub(nx, limb), o.mul(o.lsub(tgt, limb), wr)));
+    }
+    if (deferred) {                                              // (default mode: no storage-state columns, the constraint is 0 = 0)
+      const V st = cur.st, nst = cur.nst;
+      boolean(I_BOOL_STATE + r, st);
+      o.push_t(I_REGS + 4 * (r - 1) + 3, o.lsub(o.sub(nst, st), o.mul(o.lsub(nst, st), wr)));
+    }
+    cur = ahead;
+  }
   V K[N_CLASS];
 #pragma unroll
-  for (int k = 0; k < N_CLASS; k++) K[k] = o.loc(kcol(k));
+  for (int k = 0; k < N_CLASS; k++) K[k] = is_virtual(kcol(k), deferred) ? zero : o.loc(kcol(k));
+  const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
+  const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
+  const V hp = o.add(K[K_HALT], K[K_PAD]);
+  const V d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), dl0 = o.loc(C_DL0), se = o.loc(C_SE), s = o.loc(C_S);
+  const V fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI);
+  const V imm17 = o.add(fc, o.mulc(fhi, M(16)));
+  const V im0 = o.add(o.sub(imm17, o.mulc(s, M(1u << 17))), o.mulc(s, M(1u << 20))), im1 = o.mulc(s, M(0xFFFFF));
+  V xb[3], xc[3];
+#pragma unroll
+  for (int l = 0; l < 3; l++) { xb[l] = o.loc(C_XB + l); xc[l] = o.loc(C_XC + l); }
+  o.push_t(I_CYCLE, o.lsub(o.sub(o.nxt(C_CYCLE), o.loc(C_CYCLE)), one));
+  // (R0 is hard-wired zero: its limbs and storage state are not committed in either mode — constraints I_R0 .. I_R0 + 3 and I_BOOL_STATE read 0 = 0)
+  static_assert(is_virtual(C_LIMB, false) && is_virtual(C_LIMB + 2, true) && is_virtual(C_STATE, false) && is_virtual(C_STATE, true), "R0's columns are not committed");
+  // next pc.  kc: pc' = pc + delta for every class but jalr, oj (free) and halt / pad (keep); class "other" is in it with delta 4 (tk = 0 there): sequential
+  {
+    const V kc = o.sub(o.sub(o.sub(one, K[K_JALR]), K[K_OJ]), hp);
+    o.push_t(I_PC, o.lmul(o.add(o.sub(o.sub(npc[0], pc[0]), dl0), o.mulc(d0, M(1u << 20))), kc));
+    o.push_t(I_PC + 1, o.lmul(o.add(o.sub(o.sub(o.sub(npc[1], pc[1]), o.mulc(se, M(0xFFFFF))), d0), o.mulc(d1, M(1u << 20))), kc));
+    o.push_t(I_PC + 2, o.lmul(o.add(o.sub(o.sub(o.sub(npc[2], pc[2]), o.mulc(se, M(0xFFFFFF))), d1), o.mulc(d2, M(1u << 24))), kc));
+#pragma unroll
+    for (int l = 0; l < 3; l++) o.push_t(I_PC_KEEP + l, o.lmul(o.lsub(npc[l], pc[l]), hp));
+    // JALR: pc' + b0 = rs1 + sext(imm17) mod 2^64 over (20, 20, 24)-bit limbs, b0 = the bit that is cleared (execute.rs:649-658); the limbs
+    // of pc' are a code address (every row's pc is looked up in the ROM), so the carries and b0 are forced
+    o.push_t(I_JALR, o.lmul(o.lsub(o.add(o.add(npc[0], o.loc(C_B0)), o.mulc(d0, M(1u << 20))), o.add(xb[0], im0)), K[K_JALR]));
+    o.push_t(I_JALR + 1, o.lmul(o.lsub(o.add(npc[1], o.mulc(d1, M(1u << 20))), o.add(o.add(xb[1], im1), d0)), K[K_JALR]));
+    o.push_t(I_JALR + 2, o.lmul(o.lsub(o.add(npc[2], o.mulc(d2, M(1u << 24))), o.add(o.add(xb[2], o.mulc(s, M(0xFFFFFF))), d1)), K[K_JALR]));
+    // executed rows, the halt row, padding
+    const V npad = o.nxt(C_K + K_PAD), one_m_npad = o.sub(one, npad);
+    o.push_t(I_TAIL, o.lmul(one_m_npad, K[K_HALT]));
+    o.push_t(I_TAIL + 1, o.lmul(one_m_npad, K[K_PAD]));
+    o.push_t(I_TAIL + 2, o.lmul(o.sub(o.sub(one, K[K_PAD]), K[K_HALT]), npad));
+  }
+  o.end_trans();
+  // ---- C. row-local constraints -----------------------------------------------------------------------------------------------------------
   const V Kbr = o.add(K[K_BRE], K[K_BRU]), Kcmp = o.add(K[K_SE], K[K_SU]);       // B-type rows; comparison rows (the flag is the value written)
-  const V y[3] = {o.loc(C_Y), o.loc(C_Y + 1), o.loc(C_Y + 2)};
   V R[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
   const V z[2] = {o.add(R[0], o.mulc(R[1], M(RC_TABLE))), o.add(R[2], o.mulc(R[3], M(RC_TABLE)))};   // (v6) z IS its chunks: no columns of its own
-  const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
-  const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
-  // 1. cycle counter, first row, last executed row
-  const V cyc = o.loc(C_CYCLE);
-  o.push(I_CYCLE, o.mul(o.sub(o.sub(o.nxt(C_CYCLE), cyc), one), is_trans));
-  o.push(I_CYCLE0, o.mul(o.sub(cyc, o.cst(first_m[0])), is_first));
-  o.push(I_LAST, o.mul(o.sub(cyc, o.cst(last_m[0])), is_last));
+  // booleans
 #pragma unroll
-  for (int l = 0; l < 3; l++) {
-    o.push(I_ENTRY + l, o.mul(o.sub(pc[l], o.cst(first_m[1 + l])), is_first));
-    o.push(I_LAST + 1 + l, o.mul(o.sub(pc[l], o.cst(last_m[1 + l])), is_last));
-  }
-  o.push(I_HALT, o.mul(o.sub(K[K_HALT], one), is_last));
-  // registers: first-row zero, R0, booleans, selector moments, operand sums, update — one pass per register
-  V w0 = zero, w1 = zero, w2 = zero, b1 = zero, b2 = zero, c1s = zero, c2s = zero;
-  V xbs[3] = {zero, zero, zero}, xcs[3] = {zero, zero, zero};
-#pragma unroll 1
-  for (int r = 0; r < 16; r++) {
-    V limb[3];
-#pragma unroll
-    for (int l = 0; l < 3; l++) {
-      limb[l] = o.loc(C_LIMB + 3 * r + l);
-      o.push(I_ZERO0 + 3 * r + l, o.mul(o.sub(limb[l], o.cst(first_m[4 + 3 * r + l])), is_first));
-      o.push(I_LAST + 4 + 3 * r + l, o.mul(o.sub(limb[l], o.cst(last_m[4 + 3 * r + l])), is_last));
-    }
-    const V st = o.loc(C_STATE + r);
-    o.push(I_ZERO0 + 48 + r, o.mul(o.sub(st, o.cst(first_m[52 + r])), is_first));
-    o.push(I_LAST + 52 + r, o.mul(o.sub(st, o.cst(last_m[52 + r])), is_last));
-    boolean(I_BOOL_STATE + r, st);
-    if (r == 0) {
-#pragma unroll
-      for (int l = 0; l < 3; l++) o.push(I_R0 + l, limb[l]);
-      o.push(I_R0 + 3, st);
-      continue;
-    }
-    const V wr = o.loc(C_WR + r - 1), sb = o.loc(C_SELB + r - 1), sc = o.loc(C_SELC + r - 1);
-    boolean(I_BOOL_SEL + 3 * (r - 1), wr); boolean(I_BOOL_SEL + 3 * (r - 1) + 1, sb); boolean(I_BOOL_SEL + 3 * (r - 1) + 2, sc);
-    constexpr RegConsts RC = make_reg_consts();
-    const uint32_t rm = RC.r[r], r2m = RC.r2[r];
-    w0 = o.add(w0, wr); w1 = o.add(w1, o.mulc(wr, rm)); w2 = o.add(w2, o.mulc(wr, r2m));
-    b1 = o.add(b1, o.mulc(sb, rm)); b2 = o.add(b2, o.mulc(sb, r2m));
-    c1s = o.add(c1s, o.mulc(sc, rm)); c2s = o.add(c2s, o.mulc(sc, r2m));
-#pragma unroll
-    for (int l = 0; l < 3; l++) {
-      xbs[l] = o.add(xbs[l], o.mul(sb, limb[l])); xcs[l] = o.add(xcs[l], o.mul(sc, limb[l]));
-      const V nx = o.nxt(C_LIMB + 3 * r + l);
-      // nx - cur - wr * ((1 - D) y + D nx - cur)
-      const V tgt = deferred ? nx : y[l];
-      o.push(I_REGS + 4 * (r - 1) + l, o.mul(o.sub(o.sub(nx, limb[l]), o.mul(wr, o.sub(tgt, limb[l]))), is_trans));
-    }
-    const V nst = o.nxt(C_STATE + r);
-    const V tgt = deferred ? nst : zero;
-    o.push(I_REGS + 4 * (r - 1) + 3, o.mul(o.sub(o.sub(nst, st), o.mul(wr, o.sub(tgt, st))), is_trans));
-  }
-  // 3. remaining booleans
-#pragma unroll
-  for (int k = 0; k < N_CLASS; k++) boolean(I_BOOL_K + k, K[k]);
-  const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), ne = o.loc(C_NE), tk = o.loc(C_TK);
+  for (int k = 0; k < N_CLASS; k++) { if (!is_virtual(kcol(k), deferred)) boolean(I_BOOL_K + k, K[k]); }
+  const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), ne = o.loc(C_NE), tk = o.loc(C_TK), nz = o.loc(C_NZ), q = o.loc(C_Q);
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
-  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0)); boolean(I_BOOL_MISC + 9, o.loc(C_SB)); boolean(I_BOOL_MISC + 10, o.loc(C_NZ));
-  // 4. classes and the opcode
+  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0)); boolean(I_BOOL_MISC + 9, o.loc(C_SB)); boolean(I_BOOL_MISC + 10, nz);
+  // classes and the opcode
   {
-    V sum = K[0];
+    AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
-    for (int k = 1; k < N_CLASS; k++) sum = o.add(sum, K[k]);
-    o.push(I_ONE_CLASS, o.sub(sum, one));
-  }
-  {
+    for (int k = 0; k < N_CLASS; k++) {
+      if (is_virtual(kcol(k), deferred)) continue;
+      o.acc_lin(sum, K[k], 1);
+      if (k >= 1 && k != K_HALT && k != K_PAD) o.acc_lin(ks, K[k], (uint32_t)k);
+    }
+    o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
-    V ks = K[1];
-#pragma unroll
-    for (int k = 2; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = o.add(ks, o.mulc(K[k], M((uint64_t)k)));
-    o.push(I_OPCLASS, deferred ? zero : o.sub(o.mul(o.sub(one, o.add(K[K_HALT], K[K_PAD])), o.loc(C_OPC)), ks));
+    if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), o.loc(C_OPC)), o.accl_val(ks)));
   }
-  // 5. selectors
-  o.push(I_WR, deferred ? zero : o.sub(o.mul(w1, w1), w2));
-  o.push(I_WR + 1, o.mul(o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), Kcmp), K[K_JALR]), o.sub(w1, fa)));
-  o.push(I_WR + 2, o.mul(o.add(o.add(o.add(Kbr, deferred ? zero : K[K_OJ]), K[K_HALT]), K[K_PAD]), w0));   // branches write nothing (BLT / BGE too: class oj in default mode)
-  o.push(I_SELB, o.sub(b1, fb)); o.push(I_SELB + 1, o.sub(o.mul(b1, b1), b2));
-  o.push(I_SELC, o.sub(c1s, o.add(fc, o.mul(Kbr, o.sub(fa, fc))))); o.push(I_SELC + 1, o.sub(o.mul(c1s, c1s), c2s));
-  // 5b. (v6) conditional moves CMOV / CMOVNZ (class cmn: the condition is rs2 != 0) and CMOVZ (class cmz: rs2 == 0), execute.rs:434-472: q = "this row is a
-  //     conditional move whose condition holds"; it writes rd = field a exactly then (nothing at all otherwise)
-  const V Kcm = o.add(K[K_CMN], K[K_CMZ]), nz = o.loc(C_NZ), q = o.loc(C_Q);
-  o.push(I_CMOV, o.sub(q, o.add(o.mul(K[K_CMN], nz), o.mul(K[K_CMZ], o.sub(one, nz)))));
-  o.push(I_CMOV + 1, o.mul(q, o.sub(w1, fa)));
-  o.push(I_CMOV + 2, o.mul(o.sub(Kcm, q), w0));
-  // 6. operands
-  V xb[3], xc[3];
+  // selectors
+  const V w0v = o.accl_val(w0), w1v = o.accl_val(w1), b1v = o.accl_val(b1), c1v = o.accl_val(c1a);
+  if (!deferred) o.push(I_WR, o.lsub(o.mul(w1v, w1v), o.accl_val(w2)));
+  o.push(I_WR + 1, o.lmul(o.lsub(w1v, fa), o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), Kcmp), K[K_JALR])));
+  o.push(I_WR + 2, o.lmul(w0v, o.add(o.add(o.add(Kbr, deferred ? zero : K[K_OJ]), K[K_HALT]), K[K_PAD])));   // branches write nothing (BLT / BGE too: class oj in default mode)
+  o.push(I_SELB, o.lsub(b1v, fb)); o.push(I_SELB + 1, o.lsub(o.mul(b1v, b1v), o.accl_val(b2)));
+  o.push(I_SELC, o.lsub(c1v, o.add(fc, o.mul(o.lsub(fa, fc), Kbr)))); o.push(I_SELC + 1, o.lsub(o.mul(c1v, c1v), o.accl_val(c2a)));
+  // (v6) conditional moves CMOV / CMOVNZ (class cmn: the condition is rs2 != 0) and CMOVZ (class cmz: rs2 == 0), execute.rs:434-472: q = "this row is a
+  //      conditional move whose condition holds"; it writes rd = field a exactly then (nothing at all otherwise)
+  const V Kcm = o.add(K[K_CMN], K[K_CMZ]);
+  o.push(I_CMOV, o.lsub(q, o.add(o.mul(K[K_CMN], nz), o.mul(K[K_CMZ], o.sub(one, nz)))));
+  o.push(I_CMOV + 1, o.lmul(o.lsub(w1v, fa), q));
+  o.push(I_CMOV + 2, o.lmul(w0v, o.sub(Kcm, q)));
+  // operands
 #pragma unroll
-  for (int l = 0; l < 3; l++) {
-    xb[l] = o.loc(C_XB + l); xc[l] = o.loc(C_XC + l);
-    o.push(I_OPERAND + 2 * l, o.sub(xb[l], xbs[l])); o.push(I_OPERAND + 2 * l + 1, o.sub(xc[l], xcs[l]));
-  }
-  // 7. values written
-  const V imm17 = o.add(fc, o.mulc(fhi, M(16)));
-  const V im0 = o.add(o.sub(imm17, o.mulc(s, M(1u << 17))), o.mulc(s, M(1u << 20))), im1 = o.mulc(s, M(0xFFFFF));
+  for (int l = 0; l < 3; l++) { o.push(I_OPERAND + 2 * l, o.lsub(xb[l], o.acc_val(xbs[l]))); o.push(I_OPERAND + 2 * l + 1, o.lsub(xc[l], o.acc_val(xcs[l]))); }
+  // values written
   const V lo20 = o.sub(o.add(o.add(fb, o.mulc(fc, M(16))), o.mulc(fhi, M(256))), o.mulc(s, M(1u << 20)));
   const V c0s20 = o.mulc(c0, M(1u << 20)), c1s20 = o.mulc(c1, M(1u << 20));
-  // stated on z, the range-checked pair of limbs (13.); y = z on the rows that write it and on "other" rows (whose y stays in range)
-  o.push(I_VALUE, o.mul(K[K_ADD], o.add(o.sub(o.sub(z[0], xb[0]), xc[0]), c0s20)));
-  o.push(I_VALUE + 1, o.mul(K[K_ADD], o.add(o.sub(o.sub(o.sub(z[1], xb[1]), xc[1]), c0), c1s20)));
-  o.push(I_VALUE + 2, o.mul(o.add(K[K_ADD], K[K_SUB]), y[2]));
-  o.push(I_VALUE + 3, o.mul(K[K_ADDI], o.add(o.sub(o.sub(z[0], xb[0]), im0), c0s20)));
-  o.push(I_VALUE + 4, o.mul(K[K_ADDI], o.add(o.sub(o.sub(o.sub(z[1], xb[1]), im1), c0), c1s20)));
-  o.push(I_VALUE + 5, o.mul(K[K_ADDI], y[2]));
+  // stated on z, the range-checked pair of limbs; y = z on the rows that write it and on "other" rows (whose y stays in range)
+  o.push(I_VALUE, o.lmul(o.add(o.sub(o.sub(z[0], xb[0]), xc[0]), c0s20), K[K_ADD]));
+  o.push(I_VALUE + 1, o.lmul(o.add(o.sub(o.sub(o.sub(z[1], xb[1]), xc[1]), c0), c1s20), K[K_ADD]));
+  o.push(I_VALUE + 2, o.lmul(o.ladd(K[K_ADD], K[K_SUB]), y[2]));
+  o.push(I_VALUE + 3, o.lmul(o.add(o.sub(o.sub(z[0], xb[0]), im0), c0s20), K[K_ADDI]));
+  o.push(I_VALUE + 4, o.lmul(o.add(o.sub(o.sub(o.sub(z[1], xb[1]), im1), c0), c1s20), K[K_ADDI]));
+  o.push(I_VALUE + 5, o.lmul(K[K_ADDI], y[2]));
   const V Kj = o.add(K[K_JAL], K[K_JALR]);                                    // both link pc + 4 (execute.rs:639-658)
-  o.push(I_VALUE + 6, o.mul(Kj, o.add(o.sub(o.sub(z[0], pc[0]), o.cst(M(4))), c0s20)));
-  o.push(I_VALUE + 7, o.mul(Kj, o.add(o.sub(o.sub(z[1], pc[1]), c0), c1s20)));
-  o.push(I_VALUE + 8, o.mul(Kj, o.sub(o.sub(y[2], pc[2]), c1)));
-  // 7b. differences with borrows: z = xb - xc mod 2^40 on SUB and SLTU / SGEU rows (execute.rs:65-77, :373-407), z = xc - xb on BLTU / BGEU
-  //     rows (:618-636): c1 = 1 exactly when the minuend is the smaller 40-bit value
+  o.push(I_VALUE + 6, o.lmul(o.add(o.sub(o.sub(z[0], pc[0]), o.cst(M(4))), c0s20), Kj));
+  o.push(I_VALUE + 7, o.lmul(o.add(o.sub(o.sub(z[1], pc[1]), c0), c1s20), Kj));
+  o.push(I_VALUE + 8, o.lmul(o.lsub(o.sub(y[2], pc[2]), c1), Kj));
+  // differences with borrows: z = xb - xc mod 2^40 on SUB and SLTU / SGEU rows (execute.rs:65-77, :373-407), z = xc - xb on BLTU / BGEU
+  // rows (:618-636): c1 = 1 exactly when the minuend is the smaller 40-bit value
   {
     const V Ks = o.add(K[K_SUB], K[K_SU]);
     // (v5) ordered comparisons, signed or not (op = base + 2 g + pol; sgn = g on SLTU.. rows, 1 - g on BLT.. rows): the high limbs enter BIASED,
     // ta = a1 + 2^19 sgn - 2^20 sa, tb likewise with sb — the limbs of value XOR 2^39 when sgn = 1 (Value40::signed_lt, value.rs:710-716) — so
     // ta - tb = a1 - b1 - 2^20 (sa - sb); u = (ta, tb) is the row's second range-checked pair, which forces sa / sb to be the sign bits (0 if sgn = 0)
     const V sa = o.loc(C_B0), sb = o.loc(C_SB), g = o.loc(C_G);
-    const V sab = o.mulc(o.sub(sa, sb), M(1u << 20));
-    o.push(I_DIFF, o.mul(Ks, o.sub(o.add(o.sub(z[0], xb[0]), xc[0]), c0s20)));
-    o.push(I_DIFF + 1, o.mul(K[K_SUB], o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20)));
-    o.push(I_DIFF + 2, o.mul(K[K_SU], o.add(o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20), sab)));
-    o.push(I_DIFF + 3, o.mul(K[K_BRU], o.sub(o.add(o.sub(z[0], xc[0]), xb[0]), c0s20)));
-    o.push(I_DIFF + 4, o.mul(K[K_BRU], o.add(o.sub(o.add(o.add(o.sub(z[1], xc[1]), xb[1]), c0), c1s20), sab)));
+    const V sab = o.mulc(o.lsub(sa, sb), M(1u << 20));
+    o.push(I_DIFF, o.lmul(o.lsub(o.add(o.sub(z[0], xb[0]), xc[0]), c0s20), Ks));
+    const V dsub = o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20);
+    o.push(I_DIFF + 1, o.lmul(dsub, K[K_SUB]));
+    o.push(I_DIFF + 2, o.lmul(o.ladd(dsub, sab), K[K_SU]));
+    o.push(I_DIFF + 3, o.lmul(o.lsub(o.add(o.sub(z[0], xc[0]), xb[0]), c0s20), K[K_BRU]));
+    o.push(I_DIFF + 4, o.lmul(o.ladd(o.sub(o.add(o.add(o.sub(z[1], xc[1]), xb[1]), c0), c1s20), sab), K[K_BRU]));
     const V u0 = o.add(o.loc(C_RC2), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), u1 = o.add(o.loc(C_RC2 + 2), o.mulc(o.loc(C_RC2 + 3), M(RC_TABLE)));
-    const V gsu = o.mulc(g, M(1u << 19)), gbr = o.mulc(o.sub(one, g), M(1u << 19));
+    const V gsu = o.mulc(g, M(1u << 19)), gbr = o.mulc(o.lsub(one, g), M(1u << 19));
     const V sa20 = o.mulc(sa, M(1u << 20)), sb20 = o.mulc(sb, M(1u << 20));
-    o.push(I_DIFF + 5, o.mul(K[K_SU], o.add(o.sub(o.sub(u0, xb[1]), gsu), sa20)));
-    o.push(I_DIFF + 6, o.mul(K[K_SU], o.add(o.sub(o.sub(u1, xc[1]), gsu), sb20)));
-    o.push(I_DIFF + 7, o.mul(K[K_BRU], o.add(o.sub(o.sub(u0, xc[1]), gbr), sa20)));
-    o.push(I_DIFF + 8, o.mul(K[K_BRU], o.add(o.sub(o.sub(u1, xb[1]), gbr), sb20)));
+    o.push(I_DIFF + 5, o.lmul(o.ladd(o.sub(o.sub(u0, xb[1]), gsu), sa20), K[K_SU]));
+    o.push(I_DIFF + 6, o.lmul(o.ladd(o.sub(o.sub(u1, xc[1]), gsu), sb20), K[K_SU]));
+    o.push(I_DIFF + 7, o.lmul(o.ladd(o.sub(o.sub(u0, xc[1]), gbr), sa20), K[K_BRU]));
+    o.push(I_DIFF + 8, o.lmul(o.ladd(o.sub(o.sub(u1, xb[1]), gbr), sb20), K[K_BRU]));
   }
   const V flag = o.loc(C_FLAG), fx = o.loc(C_FX);
   {
     const V Ky = o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), o.add(K[K_OTH], K[K_JALR])), deferred ? K[K_OJ] : zero);   // (oj writes only in deferred mode)
-    o.push(I_WRITTEN, o.mul(Ky, o.sub(y[0], z[0]))); o.push(I_WRITTEN + 1, o.mul(Ky, o.sub(y[1], z[1])));
-    o.push(I_WRITTEN + 2, o.mul(Kcmp, o.sub(y[0], fx))); o.push(I_WRITTEN + 3, o.mul(Kcmp, y[1])); o.push(I_WRITTEN + 4, o.mul(Kcmp, y[2]));
+    o.push(I_WRITTEN, o.lmul(o.lsub(y[0], z[0]), Ky)); o.push(I_WRITTEN + 1, o.lmul(o.lsub(y[1], z[1]), Ky));
+    o.push(I_WRITTEN + 2, o.lmul(o.lsub(y[0], fx), Kcmp)); o.push(I_WRITTEN + 3, o.lmul(Kcmp, y[1])); o.push(I_WRITTEN + 4, o.lmul(Kcmp, y[2]));
 #pragma unroll
-    for (int l = 0; l < 3; l++) o.push(I_CMOV_Y + l, o.mul(Kcm, o.sub(y[l], xb[l])));        // (v6) a conditional move writes rs1's raw value (all three limbs)
+    for (int l = 0; l < 3; l++) o.push(I_CMOV_Y + l, o.lmul(o.lsub(y[l], xb[l]), Kcm));        // (v6) a conditional move writes rs1's raw value (all three limbs)
     // (v6) the bits above 40 of what an "other" row writes: y2 = R4 + 2^10 R5 + 2^20 R6 with R7 = 64 R6 — all four in the 10-bit table, so y2 < 2^24.  With it
     // EVERY limb of every register is in range by induction (constrained classes write 0, pc2 + c1 or an operand's limb there)
-    o.push(I_Y2, o.mul(K[K_OTH], o.sub(o.sub(o.sub(y[2], o.loc(C_RC2)), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), o.mulc(o.loc(C_RC2 + 2), M(RC_TABLE * RC_TABLE)))));
-    o.push(I_Y2 + 1, o.mul(K[K_OTH], o.sub(o.loc(C_RC2 + 3), o.mulc(o.loc(C_RC2 + 2), M(64)))));
+    o.push(I_Y2, o.lmul(o.lsub(o.sub(o.sub(y[2], o.loc(C_RC2)), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), o.mulc(o.loc(C_RC2 + 2), M(RC_TABLE * RC_TABLE))), K[K_OTH]));
+    o.push(I_Y2 + 1, o.lmul(o.lsub(o.loc(C_RC2 + 3), o.mulc(o.loc(C_RC2 + 2), M(64))), K[K_OTH]));
   }
-  // 7c. (v6) nz = [xc != 0] on every row, on the sum of xc's limbs (in range, so the sum vanishes only if they all do)
+  // (v6) nz = [xc != 0] on every row, on the sum of xc's limbs (in range, so the sum vanishes only if they all do)
   {
     const V sx = o.add(o.add(xc[0], xc[1]), xc[2]);
-    o.push(I_NZ, o.mul(o.sub(one, nz), sx));
-    o.push(I_NZ + 1, o.sub(nz, o.mul(sx, o.loc(C_IVZ))));
+    o.push(I_NZ, o.lmul(o.lsub(one, nz), sx));
+    o.push(I_NZ + 1, o.lsub(nz, o.mul(sx, o.loc(C_IVZ))));
   }
-  // 8. BNE operands differ?
+  // BNE operands differ?
   {
-    V dot = zero;
+    AccP dot = o.accp();
 #pragma unroll
     for (int l = 0; l < 3; l++) {
       const V d = o.sub(xb[l], xc[l]);
-      dot = o.add(dot, o.mul(d, o.loc(C_IV + l)));
-      o.push(I_NE + l, o.mul(o.sub(one, ne), d));
+      o.acc_mul(dot, d, o.loc(C_IV + l));
+      o.push(I_NE + l, o.lmul(o.lsub(one, ne), d));
     }
-    o.push(I_NE + 3, o.sub(ne, dot));
+    o.push(I_NE + 3, o.lsub(ne, o.acc_val(dot)));
   }
-  // 8b. the family's comparison and its polarity: flag = [xb == xc] on BEQ / BNE / SEQ / SNE rows, the borrow c1 on the unsigned comparisons,
-  //     0 elsewhere; fx = flag XOR pol, pol = op - the family's even opcode (0 / 1: the ROM ties op to the class); a branch is taken iff fx
-  o.push(I_FLAG, o.sub(o.sub(flag, o.mul(o.add(K[K_BRE], K[K_SE]), o.sub(one, ne))), o.mul(o.add(K[K_BRU], K[K_SU]), c1)));
+  // the family's comparison and its polarity: flag = [xb == xc] on BEQ / BNE / SEQ / SNE rows, the borrow c1 on the unsigned comparisons,
+  // 0 elsewhere; fx = flag XOR pol, pol = op - the family's even opcode (0 / 1: the ROM ties op to the class); a branch is taken iff fx
+  o.push(I_FLAG, o.lsub(o.sub(flag, o.mul(o.lsub(one, ne), o.add(K[K_BRE], K[K_SE]))), o.mul(o.ladd(K[K_BRU], K[K_SU]), c1)));
   {
     V pol = o.loc(C_OP);
 #pragma unroll
     for (int k = 0; k < N_CLASS; k++) if (family_base(k)) pol = o.sub(pol, o.mulc(K[k], M(family_base(k))));
     pol = o.sub(pol, o.mulc(o.loc(C_G), M(2)));                                // (v5) op = base + 2 g + pol in the four-member families; g = 0 elsewhere
-    o.push(I_FX, o.add(o.sub(o.sub(fx, flag), pol), o.mulc(o.mul(pol, flag), M(2))));
+    o.push(I_FX, o.ladd(o.sub(o.sub(fx, flag), pol), o.mulc(o.mul(pol, flag), M(2))));
   }
-  o.push(I_TK, o.sub(tk, o.mul(Kbr, fx)));
-  // 9. next pc
-  const V four = o.cst(M(4)), dl0 = o.loc(C_DL0);
-  o.push(I_DL0, o.sub(dl0, o.add(o.add(four, o.mul(tk, o.sub(im0, four))), o.mul(K[K_JAL], o.sub(lo20, four)))));
-  o.push(I_SE, o.sub(se, o.mul(o.add(tk, K[K_JAL]), s)));
-  // kc: pc' = pc + delta for every class but jalr (9b), oj (free) and halt / pad (keep); class "other" is in it with delta 4 (tk = 0 there): sequential
-  const V hp = o.add(K[K_HALT], K[K_PAD]), kc = o.sub(o.sub(o.sub(one, K[K_JALR]), K[K_OJ]), hp);
-  o.push(I_PC, o.mul(o.mul(kc, o.add(o.sub(o.sub(npc[0], pc[0]), dl0), o.mulc(d0, M(1u << 20)))), is_trans));
-  o.push(I_PC + 1, o.mul(o.mul(kc, o.add(o.sub(o.sub(o.sub(npc[1], pc[1]), o.mulc(se, M(0xFFFFF))), d0), o.mulc(d1, M(1u << 20)))), is_trans));
-  o.push(I_PC + 2, o.mul(o.mul(kc, o.add(o.sub(o.sub(o.sub(npc[2], pc[2]), o.mulc(se, M(0xFFFFFF))), d1), o.mulc(d2, M(1u << 24)))), is_trans));
-#pragma unroll
-  for (int l = 0; l < 3; l++) o.push(I_PC_KEEP + l, o.mul(o.mul(hp, o.sub(npc[l], pc[l])), is_trans));
-  // 9b. JALR: pc' + b0 = rs1 + sext(imm17) mod 2^64 over (20, 20, 24)-bit limbs, b0 = the bit that is cleared (execute.rs:649-658); the limbs
-  //     of pc' are a code address (every row's pc is looked up in the ROM), so the carries and b0 are forced
-  o.push(I_JALR, o.mul(o.mul(K[K_JALR], o.sub(o.add(o.add(npc[0], o.loc(C_B0)), o.mulc(d0, M(1u << 20))), o.add(xb[0], im0))), is_trans));
-  o.push(I_JALR + 1, o.mul(o.mul(K[K_JALR], o.sub(o.add(npc[1], o.mulc(d1, M(1u << 20))), o.add(o.add(xb[1], im1), d0))), is_trans));
-  o.push(I_JALR + 2, o.mul(o.mul(K[K_JALR], o.sub(o.add(npc[2], o.mulc(d2, M(1u << 24))), o.add(o.add(xb[2], o.mulc(s, M(0xFFFFFF))), d1))), is_trans));
-  // 11. executed rows, the halt row, padding
-  const V npad = o.nxt(C_K + K_PAD);
-  o.push(I_TAIL, o.mul(o.mul(K[K_HALT], o.sub(one, npad)), is_trans));
-  o.push(I_TAIL + 1, o.mul(o.mul(K[K_PAD], o.sub(one, npad)), is_trans));
-  o.push(I_TAIL + 2, o.mul(o.mul(o.sub(o.sub(one, K[K_PAD]), K[K_HALT]), npad), is_trans));
-  // ---- AIR v2: the lookup argument.  An extension-field column is four base columns (coordinates in F[X]/(X^4 - 11)); a relation between
-  //      extension values is stated coordinate by coordinate.  out_k = sum_{i+j=k} h_i d_j + 11 sum_{i+j=k+4} h_i d_j
+  o.push(I_TK, o.lsub(tk, o.mul(Kbr, fx)));
+  // next pc: the delta and its sign extension
+  const V four = o.cst(M(4));
+  o.push(I_DL0, o.lsub(dl0, o.add(o.add(four, o.mul(o.lsub(im0, four), tk)), o.mul(o.lsub(lo20, four), K[K_JAL]))));
+  o.push(I_SE, o.lsub(se, o.mul(o.ladd(tk, K[K_JAL]), s)));
+  // ---- the lookup argument.  An extension-field column is four base columns (coordinates in F[X]/(X^4 - 11)); a relation between
+  //      extension values is stated coordinate by coordinate.  out_k = sum_{i+j=k} h_i d_j + 11 sum_{i+j=k+4} h_i d_j  (h11_i = 11 h_i)
   auto ext_mul = [&](const V* h, const V* d, V* out) {
+    V h11[4];
+#pragma unroll
+    for (int i = 1; i < 4; i++) h11[i] = o.mulc(h[i], M(11));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      V lo = zero, hi = zero;
+      AccP a = o.accp();
 #pragma unroll
       for (int i = 0; i < 4; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { if (i + j == k) lo = o.add(lo, o.mul(h[i], d[j])); else if (i + j == k + 4) hi = o.add(hi, o.mul(h[i], d[j])); }
+        for (int j = 0; j < 4; j++) { if (i + j == k) o.acc_mul(a, h[i], d[j]); else if (i + j == k + 4) o.acc_mul(a, h11[i], d[j]); }
       }
-      out[k] = o.add(lo, o.mulc(hi, M(11)));
+      out[k] = o.acc_val(a);
     }
   };
-  // 13. (z is defined by its chunks since v6: the two constraints that tied the z columns to them went with the columns)
-  // 14. range helpers: H_i (alpha - R_i) = 1, i = 0..7 (the chunks of z, the chunks of u)
-#pragma unroll 1
+  // range helpers: H_i (alpha - R_i) = 1, i = 0..7 (the chunks of z, the chunks of u)
+  AccL hs[4] = {o.accl(), o.accl(), o.accl(), o.accl()};                         // H0 + .. + H7 + HR, coordinate by coordinate (the running sum's increment)
+#pragma unroll
   for (int i = 0; i < N_RC; i++) {
     V h[4], d[4], pr[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_H + 4 * i + k); d[k] = o.par(LK_ALPHA + k); }
+    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_H + 4 * i + k); d[k] = o.par(LK_ALPHA + k); o.acc_lin(hs[k], h[k], 1); }
     d[0] = o.sub(d[0], o.loc(rc_col(i)));
     ext_mul(h, d, pr);
-    o.push(I_RANGE + 4 * i, o.sub(pr[0], one));
+    o.push(I_RANGE + 4 * i, o.lsub(pr[0], one));
 #pragma unroll
     for (int k = 1; k < 4; k++) o.push(I_RANGE + 4 * i + k, pr[k]);
   }
-  // 15. instruction ROM: HR (alpha - fingerprint(tuple)) = 1, fingerprint = sum_j lambda^j f_j + lambda^10
+  // instruction ROM: HR (alpha - fingerprint(tuple)) = 1, fingerprint = sum_j lambda^j f_j + lambda^N_TUPLE
   {
     V h[4], d[4], pr[4];
+    AccP fp[4] = {o.accp(), o.accp(), o.accp(), o.accp()};
 #pragma unroll
-    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_HR + k); d[k] = o.par(LK_LAM + 4 * N_TUPLE + k); }
-#pragma unroll 1
+    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_HR + k); o.acc_lin(hs[k], h[k], 1); }
+#pragma unroll
     for (int j = 0; j < N_TUPLE; j++) {
       const V f = o.loc(tuple_col(j));
 #pragma unroll
-      for (int k = 0; k < 4; k++) d[k] = o.add(d[k], o.mul(f, o.par(LK_LAM + 4 * j + k)));
+      for (int k = 0; k < 4; k++) o.acc_mul(fp[k], f, o.par(LK_LAM + 4 * j + k));
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) d[k] = o.sub(o.par(LK_ALPHA + k), d[k]);
+    for (int k = 0; k < 4; k++) d[k] = o.sub(o.sub(o.par(LK_ALPHA + k), o.par(LK_LAM + 4 * N_TUPLE + k)), o.acc_val(fp[k]));
     ext_mul(h, d, pr);
-    o.push(I_ROM, o.sub(pr[0], one));
+    o.push(I_ROM, o.lsub(pr[0], one));
 #pragma unroll
     for (int k = 1; k < 4; k++) o.push(I_ROM + k, pr[k]);
   }
-  // 16. running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + H1 + H2 + H3 + HR - T / N
+  // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR - T / N
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    V hs = o.aloc(A_HR + k);
-#pragma unroll
-    for (int i = 0; i < N_RC; i++) hs = o.add(hs, o.aloc(A_H + 4 * i + k));
-    o.push(I_SUM + k, o.add(o.sub(o.sub(o.anxt(A_S + k), o.aloc(A_S + k)), hs), o.par(LK_TN + k)));
-  }
+  for (int k = 0; k < 4; k++) o.push(I_SUM + k, o.ladd(o.sub(o.sub(o.anxt(A_S + k), o.aloc(A_S + k)), o.accl_val(hs[k])), o.par(LK_TN + k)));
 }
+
+// - sum_i (alpha^first_idx(i) first_m[i]) and the same for the last row: the share of the public boundary words in the two boundary sums — per-proof
+// constants (E4, Montgomery; alpha_pow in Montgomery form) the prover's host side hands the quotient kernel (push_fc / push_lc leave the words out)
+inline void boundary_constants(const bb::E4* alpha_pow_m, const uint32_t* first_m, const uint32_t* last_m, bb::E4& cf, bb::E4& cl) {
+  cf = bb::e_zero(); cl = bb::e_zero();
+  for (int i = 0; i < N_STATE; i++) {
+    cf = bb::e_add(cf, bb::e_mul_fm(alpha_pow_m[first_idx(i)], first_m[i]));
+    cl = bb::e_add(cl, bb::e_mul_fm(alpha_pow_m[last_idx(i)], last_m[i]));
+  }
+  cl = bb::e_add(cl, bb::e_mul_fm(alpha_pow_m[I_HALT], bb::R1));
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// air::eval run on BOUNDS instead of values: every V carries the largest word it can hold under the quotient kernel's arithmetic (QuotientOps,
+// stark_prove.inl), every operation checks the precondition that arithmetic needs (no 32 / 64 / 96-bit overflow, lazy values only where a
+// reduction follows) and every constraint index is pushed at most once.  zkir_air_check_bounds (verify.cpp) runs it; tests/test_abi.py asserts it.
+struct BoundOps {
+  struct V { uint64_t max; };
+  struct AccP { unsigned __int128 max; };
+  struct AccL { uint64_t max; };
+  bool deferred;
+  const char* why = nullptr;
+  unsigned __int128 tot[4] = {0, 0, 0, 0};
+  int seen[N_CONSTRAINTS] = {};
+  static constexpr uint64_t PM = bb::P - 1, U32 = 0xFFFFFFFFull;
+  void need(bool c, const char* w) { if (!c && !why) why = w; }
+  V red() const { return V{PM}; }
+  V loc(int k) { need(k >= 0 && k < W, "loc: column out of range"); return is_virtual(k, deferred) ? V{0} : red(); }
+  V nxt(int k) { return loc(k); }
+  V loc_r(int k) { need(k >= 0 && k < W && !is_virtual(k, deferred), "loc_r: uncommitted column"); return red(); }
+  V nxt_r(int k) { return loc_r(k); }
+  V aloc(int k) { need(k >= 0 && k < W_AUX, "aloc: column out of range"); return red(); }
+  V anxt(int k) { return aloc(k); }
+  V par(int i) { need(i >= 0 && i < N_LK, "par: index out of range"); return red(); }
+  V cst(uint32_t cm) { need(cm < bb::P, "cst: constant not reduced"); return V{cm}; }
+  V add(V a, V b) { need(a.max <= PM && b.max <= PM, "add: lazy operand"); return red(); }
+  V sub(V a, V b) { need(a.max <= PM && b.max <= PM, "sub: lazy operand"); return red(); }
+  V mul(V a, V b) { need(a.max <= U32, "mul: first operand above 32 bits"); need(b.max <= PM, "mul: second operand lazy"); return red(); }
+  V mulc(V a, uint32_t cm) { need(cm < bb::P, "mulc: constant not reduced"); return mul(a, V{cm}); }
+  V lsub(V a, V b) { need(a.max <= PM && b.max <= PM, "lsub: lazy operand"); return V{a.max + bb::P}; }
+  V ladd(V a, V b) { need(a.max <= PM && b.max <= PM, "ladd: lazy operand"); return V{a.max + b.max}; }
+  V lmul(V a, V b) { need(a.max <= U32, "lmul: first operand above 32 bits"); need(b.max <= PM, "lmul: second operand lazy"); return V{((a.max * b.max) >> 32) + bb::P}; }
+  AccP accp() { return AccP{0}; }
+  void acc_mul(AccP& a, V x, V y) { need(x.max <= U32 && y.max <= U32, "acc_mul: operand above 32 bits"); a.max += (unsigned __int128)x.max * y.max; need(a.max < ((unsigned __int128)1 << 73), "acc_mul: sum above 2^73"); }
+  V acc_val(const AccP&) { return red(); }
+  AccL accl() { return AccL{0}; }
+  void acc_lin(AccL& a, V x, uint32_t k) { need(x.max <= PM, "acc_lin: lazy operand"); a.max += (uint64_t)k * x.max; }
+  V accl_val(const AccL& a) { const uint64_t t = (a.max >> 32) * bb::R1 + U32; need(t < (1ull << 38) && t < 200ull * bb::P, "accl_val: sum outside reduce_wide<6>"); return red(); }
+  void end_boundary() {}
+  void end_trans() {}
+  void count(int g, int idx, V v) {
+    need(idx >= 0 && idx < N_CONSTRAINTS, "push: constraint index out of range");
+    if (idx >= 0 && idx < N_CONSTRAINTS) need(seen[idx]++ == 0, "push: constraint index used twice");
+    need(v.max <= U32, "push: value above 32 bits");
+    tot[g] += (unsigned __int128)PM * v.max; need(tot[g] < ((unsigned __int128)1 << 73), "push: sum above 2^73");
+  }
+  void push(int idx, V v) { count(0, idx, v); }
+  void push_t(int idx, V v) { count(1, idx, v); }
+  void push_fc(int idx, V v, uint32_t) { count(2, idx, v); }
+  void push_lc(int idx, V v, uint32_t) { count(3, idx, v); }
+  void push_fc0(int idx, uint32_t) { count(2, idx, V{0}); }
+  void push_lc0(int idx, uint32_t) { count(3, idx, V{0}); }
+};
+// nullptr = the quotient kernel's arithmetic is sound on air::eval; else the first broken rule
+inline const char* check_bounds(bool deferred) {
+  BoundOps o{deferred};
+  uint32_t st[N_STATE] = {};
+  eval(o, st, st, deferred);
+  return o.why;
+}
+#endif
 
 }  // namespace air

@@ -92,6 +92,32 @@ BB_HD uint32_t reduce_wide(uint64_t acc) {
   const uint32_t q = mulhi_u32((uint32_t)(acc >> S), M);
   return reduce_2p((uint32_t)acc - q * P);
 }
+// ---- 96-bit accumulation of plain integer products (round 4: the constraint combination, the DEEP sums, the barycentric dot products) ----
+// A sum of products  x_i * y_i  (x_i, y_i ANY 32-bit words: canonical, lazy, Montgomery ...) is formed as an exact 96-bit integer — one 64-bit
+// multiply-add with carry-out plus one add-with-carry per term (a multiplier-class + a full-rate instruction, ~6.8 SIMD-cycles per wave64 against the
+// ~17 of a lazy Montgomery product added into a 64-bit sum) — and reduced ONCE at the end.  acc96_div_R returns  (sum / 2^32) mod p, canonical: for
+// Montgomery-form operands (x R, y R) that is the Montgomery form R * sum(x y) of the sum.  Up to 2^9 terms (hi < 2^9: the reduction's bound).
+struct Acc96 { uint64_t lo; uint32_t hi; };
+BB_HD Acc96 acc96_zero() { return Acc96{0, 0}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+// x in a scalar register (a per-proof constant: alpha^c, gamma^k), y in a vector register
+__device__ __forceinline__ void mad96_s(Acc96& a, uint32_t x, uint32_t y) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(a.lo), "+v"(a.hi) : "s"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void mad96(Acc96& a, uint32_t x, uint32_t y) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(a.lo), "+v"(a.hi) : "v"(x), "v"(y) : "vcc");
+}
+#else
+inline void mad96(Acc96& a, uint32_t x, uint32_t y) { const uint64_t t = (uint64_t)x * y, s = a.lo + t; a.hi += s < t; a.lo = s; }
+inline void mad96_s(Acc96& a, uint32_t x, uint32_t y) { mad96(a, x, y); }
+#endif
+BB_HD uint32_t acc96_div_R(const Acc96& a) {          // (hi 2^64 + lo) / 2^32 mod p = hi R + lo_hi + lo_lo / R; hi < 2^9
+  const uint32_t l0 = (uint32_t)a.lo, l1 = (uint32_t)(a.lo >> 32);
+  const uint32_t m = l0 * NEG_PINV;
+  const uint32_t r0 = (uint32_t)(((uint64_t)l0 + (uint64_t)m * P) >> 32);      // l0 / R mod p, at most p
+  return reduce_wide<6>((uint64_t)a.hi * R1 + l1 + r0);                         // < 2^37 + 2^33: inside reduce_wide<6>'s bounds (2^38, 200 p)
+}
+
 // acc / R mod p for a 64-bit acc (Montgomery reduction of a wide sum): two instructions against the six of reduce_wide; the result
 // is below acc / 2^32 + p, i.e. "canonical + a little" for the acc < 2^38 sums of the Poseidon2 linear layers, and carries the factor
 // 1/R, which the caller has to account for.  acc + 2^32 p < 2^64 is all it needs.

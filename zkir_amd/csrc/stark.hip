@@ -226,11 +226,35 @@ __global__ __launch_bounds__(NT) void powers_kernel(uint32_t w, uint32_t scale_m
 }
 
 
+// 1 / (x_j - 1) over the LDE coset x_j = g w_2N^j (Montgomery), eight points per lane: one inversion per eight (Montgomery's trick).
+// Depends on log_n only: a table of the context.  x_j = 1 cannot happen (g generates the whole group, so g w^j is never in the 2-power subgroup).
+__global__ __launch_bounds__(NT) void selector_inverse_kernel(uint32_t log_n, const uint32_t* __restrict__ tw_fwd, uint32_t* __restrict__ inv_xm1) {
+  const uint32_t N2 = 2u << log_n, N = N2 >> 1;
+  const uint32_t j0 = (blockIdx.x * NT + threadIdx.x) * 8;
+  if (j0 >= N2) return;
+  uint32_t d[8], pre[8];
+  uint32_t run = bb::R1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t j = j0 + k;
+    const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
+    d[k] = bb::sub(bb::mont_mul(wj, bb::to_mont(bb::GEN)), bb::R1);
+    pre[k] = run; run = bb::mont_mul(run, d[k]);
+  }
+  uint32_t inv = bb::R1, b = run, e = bb::P - 2;
+  while (e) { if (e & 1) inv = bb::mont_mul(inv, b); b = bb::mont_mul(b, b); e >>= 1; }
+#pragma unroll
+  for (int k = 7; k >= 0; k--) { inv_xm1[j0 + k] = bb::mont_mul(inv, pre[k]); inv = bb::mont_mul(inv, d[k]); }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 Merkle
 // ------------------------------------------------------------------------------------------------
 // one lane per leaf (= row position); a B8 block is exactly one absorption of the rate-8 sponge: two 16-byte loads per permutation
-__global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint32_t* __restrict__ digests) {
+// in_scale: cp->in_scale for canonical matrix words; from_mont(cp->in_scale) when the matrix rests in Montgomery form (the prover's LDE matrices): the
+// factor R the words carry is divided out by the multiplication that brings them to the sponge's input scale — same instructions, same digests.
+__global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ mat, uint32_t width, uint64_t n, uint32_t in_scale, uint32_t* __restrict__ digests) {
   const uint64_t j = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (j >= n) return;
   uint32_t s[p2::T];
@@ -239,7 +263,7 @@ __global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restr
   const uint4* m4 = reinterpret_cast<const uint4*>(mat);
   // p2::permute_scaled: absorbed values enter with the factor in_scale, words that stay (the capacity; the tail of the rate in a
   // ragged last block, which so::hash_elems leaves in place) are carried over from the previous output with `carry`
-  const uint32_t in_scale = cp->in_scale, carry = cp->carry, out_scale = cp->out_scale;
+  const uint32_t carry = cp->carry, out_scale = cp->out_scale;
   for (uint32_t off = 0; off < width; off += p2::RATE) {
     const uint4 lo = m4[((uint64_t)(off >> 3) * n + j) * 2], hi = m4[((uint64_t)(off >> 3) * n + j) * 2 + 1];
     const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -356,6 +380,8 @@ struct zkir_stark_ctx {
   uint32_t* d_tw_inv = nullptr;   // w_N^-k, k < N/2
   uint32_t* d_tw_fwd = nullptr;   // w_{2N}^k, k < N
   uint32_t* d_g_lo = nullptr;     // g^k / N, k < 1024
+  uint32_t* d_g_lo_m = nullptr;   // R g^k / N: the same scale with the Montgomery factor folded in — the LDE then leaves its output in Montgomery form (zkir_prove)
+  uint32_t* d_inv_xm1 = nullptr;  // 1 / (x_j - 1), j < 2N, over the LDE coset (Montgomery): the row selectors of the quotient (stark_prove.inl)
   uint32_t* d_g_hi = nullptr;     // g^(1024 k)
   uint32_t* d_small_inv = nullptr;  // w_{2^Bm}^-k, k < 2^(Bm-1)      (Bm = min(log_n, 10))
   uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
@@ -366,6 +392,22 @@ struct zkir_stark_ctx {
   mutable unsigned char* arena = nullptr;
   mutable size_t arena_size = 0, arena_off = 0;
 };
+
+namespace {
+// The LDE with the scale table chosen by the form its output is to rest in: mont_out = the words of `out` carry the Montgomery factor R (the
+// prover's matrices; the scale g^k / N of the fused middle pass comes from the table that has R folded in — same kernels, same instruction count).
+int lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* out, bool mont_out, hipStream_t s) {
+  const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, mont_out ? c->d_g_lo_m : c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
+  zkir::lde_run(t, in, (width + 7) / 8, out, s);               // ntt.hip
+  return check_launch("lde");
+}
+// leaf layer + the levels above it; mont_in = the matrix words carry the Montgomery factor (the digests are those of the canonical words either way)
+int merkle_commit(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, bool mont_in, hipStream_t s) {
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, mont_in ? bb::from_mont(c->consts.in_scale) : c->consts.in_scale, tree);
+  launch_tree_levels(c->d_p2, tree, n_leaves, s);
+  return check_launch("merkle_commit");
+}
+}  // namespace
 
 extern "C" {
 
@@ -427,6 +469,8 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_fwd, (size_t)N * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_lo, 1024 * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_hi, (size_t)n_hi * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_g_lo_m, 1024 * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_inv_xm1, (size_t)2 * N * 4);
   const int Bm = log_n < 10 ? (int)log_n : 10;
   const uint32_t n_si = Bm >= 1 ? (1u << (Bm - 1)) : 1, n_sf = 1u << Bm;
   if (e == hipSuccess) e = hipMalloc(&c->d_small_inv, (size_t)n_si * 4);
@@ -436,7 +480,9 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_inv)), dim3(NT), 0, 0, bb::inv(wN), bb::R1, c->d_tw_inv, n_inv);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(N)), dim3(NT), 0, 0, w2N, bb::R1, c->d_tw_fwd, N);
   hipLaunchKernelGGL(powers_kernel, dim3(4), dim3(NT), 0, 0, bb::GEN, bb::to_mont(bb::inv(N % bb::P)), c->d_g_lo, 1024u);
+  hipLaunchKernelGGL(powers_kernel, dim3(4), dim3(NT), 0, 0, bb::GEN, bb::to_mont(bb::to_mont(bb::inv(N % bb::P))), c->d_g_lo_m, 1024u);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_hi)), dim3(NT), 0, 0, bb::pow(bb::GEN, 1024), bb::R1, c->d_g_hi, n_hi);
+  hipLaunchKernelGGL(selector_inverse_kernel, dim3(grid_for((2ull * N + 7) / 8)), dim3(NT), 0, 0, log_n, c->d_tw_fwd, c->d_inv_xm1);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_si)), dim3(NT), 0, 0, bb::inv(bb::root_of_unity(Bm)), bb::R1, c->d_small_inv, n_si);
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n_sf)), dim3(NT), 0, 0, bb::root_of_unity(Bm + 1), bb::R1, c->d_small_fwd, n_sf);
   if (hipDeviceSynchronize() != hipSuccess || check_launch("stark ctx tables") != ZKIR_OK) { zkir_stark_ctx_free(c); return ZKIR_ERR_DEVICE; }
@@ -446,7 +492,7 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
 
 void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
-  (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi);
+  (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi); (void)hipFree(c->d_g_lo_m); (void)hipFree(c->d_inv_xm1);
   (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
@@ -472,19 +518,13 @@ int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint3
 }
 
 // in: ceil(width/8) blocks [N][8] of canonical evaluations over H (natural order; used as scratch and overwritten!), out: blocks [2N][8]
-int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* out, void* stream) {
-  const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
-  zkir::lde_run(t, in, (width + 7) / 8, out, stream);          // ntt.hip
-  return check_launch("lde");
-}
+int zkir_lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* out, void* stream) { return lde_launch(c, in, width, out, false, (hipStream_t)stream); }
 
 // mat: B8 layout, ceil(width/8) blocks [n_leaves][8]; tree = [leaf digests (4*n)] [layer 1 (4*n/2)] ... [root (4)] = 4*(2n-1) words; n_leaves a power of two
 int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!c || n_leaves == 0 || (n_leaves & (n_leaves - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle: null context, or n_leaves not a power of two"}); return ZKIR_ERR_ARGUMENT; }
-  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, tree);
-  launch_tree_levels(c->d_p2, tree, n_leaves, s);
-  return check_launch("merkle_commit");
+  return merkle_commit(c, mat, width, n_leaves, tree, false, s);
 }
 
 // The leaf layer alone: digests[0 .. 4n) = sponge over the `width` real columns of every row (leaf_hash_kernel); zkir_merkle_cap_launch
@@ -492,7 +532,7 @@ int zkir_merkle_commit_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
 // can bracket the dominant kernel of the commit step with its own events.
 int zkir_merkle_leaves_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* digests, void* stream) {
   if (!c || !mat || !digests || n_leaves == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle leaves: null argument or no leaves"}); return ZKIR_ERR_ARGUMENT; }
-  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, (hipStream_t)stream, c->d_p2, mat, width, n_leaves, digests);
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, (hipStream_t)stream, c->d_p2, mat, width, n_leaves, c->consts.in_scale, digests);
   return check_launch("merkle_leaves");
 }
 

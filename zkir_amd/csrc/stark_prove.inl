@@ -21,13 +21,14 @@ constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 #define BARY_WAVES 4
 #endif
 #ifndef QUOT_WAVES
-#define QUOT_WAVES 4
+#define QUOT_WAVES 3
 #endif
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
   E4 alpha_pow[N_CONSTRAINTS];
   E4 gamma_pow[2 * WTX + 4];    // main columns, aux columns at zeta; the same at zeta w; the quotient (2 * (committed width + WA) + 4 used)
   E4 zeta, zeta_w, a0, b0;
   uint32_t first_m[NS], last_m[NS];   // public boundary states: rows 0 and n_real - 1 (Montgomery)
+  E4 cf, cl;                    // air::boundary_constants: the boundary words' share of the is_first / is_last sums
   uint32_t deferred;
   uint32_t lk[air::N_LK];       // lookup parameters (air.h LK_*): alpha, lambda powers, T / N — base-field coordinates, Montgomery
 };
@@ -64,32 +65,89 @@ __device__ __forceinline__ E4 lz_reduce(const LazyE4& acc) {
 }
 
 // ---- quotient: Q(x_j) = (Σ_c alpha^c C_c(x_j)) / Z_H(x_j) on x_j = g w_2N^j;  next row = position j+2 -------------------
-// The constraint list is air::eval (air.h), instantiated here on base-field Montgomery values read straight from the LDE matrix.
+// The constraint list is air::eval (air.h), instantiated here on base-field Montgomery values read straight from the LDE matrices, which
+// REST in Montgomery form inside a proof (round 4): no conversion on load.  Round 4 also changed HOW the list is evaluated, not what it says:
+//   * the combination Σ alpha^c C_c is four exact 96-bit integer sums (one per extension coordinate) of alpha^c[t] * C_c — a 64-bit multiply-add
+//     with carry-out + an add-with-carry per term (bb::mad96_s) — reduced once per point; round 3 formed a lazy Montgomery product per term
+//     (3 multiplier-class instructions + the 64-bit add);
+//   * one set of sums per row selector (none / is_trans / is_first / is_last): the selector multiplies its sum ONCE per point, and the public
+//     boundary words leave the per-point work altogether (air::boundary_constants);
+//   * 1 / (x_j - 1) comes from a per-context table (zkir_stark_ctx::d_inv_xm1; 1 / (x_j - w^last) is the same table read at j - 2 last, times
+//     w^-last) — round 3 ran two 31-bit exponentiations per point;
+//   * dot products (selected operands, extension-field products) accumulate in 96 bits as well; selector moments in 64;
+//   * column reads are 16-byte loads of (block, row, half): the compiler merges the reads of neighbouring columns (the B8 layout keeps eight
+//     columns of a row in 32 contiguous bytes) — round 3 issued one 4-byte load per column, 64 lanes x 32-byte stride each.
+// Src supplies the words of one row pair: the device source reads the B8 matrices, tests/test_abi.py's host source reads plain arrays.
+template <bool DEF, class Src>
 struct QuotientOps {
   using V = uint32_t;
-  const uint32_t* __restrict__ L; const uint32_t* __restrict__ AL; uint64_t N2; uint32_t j, jn; const ProveParams* __restrict__ pp;
-  LazyE4 acc; E4 partial; int pending; bool deferred;
-  __device__ __forceinline__ V aloc(int k) const { return bb::to_mont(AL[b8((uint32_t)k, j, N2)]); }
-  __device__ __forceinline__ V anxt(int k) const { return bb::to_mont(AL[b8((uint32_t)k, jn, N2)]); }
-  __device__ __forceinline__ V par(int i) const { return pp->lk[i]; }
-  __device__ __forceinline__ V add(V a, V b) const { return bb::add(a, b); }
-  __device__ __forceinline__ V sub(V a, V b) const { return bb::sub(a, b); }
-  __device__ __forceinline__ V mul(V a, V b) const { return bb::mont_mul(a, b); }
-  __device__ __forceinline__ V mulc(V a, uint32_t cm) const { return bb::mont_mul(a, cm); }
-  __device__ __forceinline__ V cst(uint32_t cm) const { return cm; }
-  // logical column k: the constant 0 if it is not committed (air.h: is_virtual), else its committed position
-  __device__ __forceinline__ V loc(int k) const { return air::is_virtual(k, deferred) ? 0u : bb::to_mont(L[b8((uint32_t)air::phys_col(k, deferred), j, N2)]); }
-  __device__ __forceinline__ V nxt(int k) const { return air::is_virtual(k, deferred) ? 0u : bb::to_mont(L[b8((uint32_t)air::phys_col(k, deferred), jn, N2)]); }
-  __device__ __forceinline__ void push(int idx, V v) {
-    lz_fma(acc, pp->alpha_pow[idx], v);
-    if (++pending == 128) { partial = bb::e_add(partial, lz_reduce(acc)); acc = LazyE4(); pending = 0; }     // 136 terms fit the lazy sum
+  using AccP = bb::Acc96;
+  using AccL = uint64_t;
+  Src src;
+  const E4* __restrict__ ap;            // alpha^c, Montgomery
+  const uint32_t* __restrict__ lk;      // lookup parameters, Montgomery
+  bb::Acc96 a0[4], at[4], af[4], al[4]; // Σ alpha^c C_c by selector: none, is_trans, is_first, is_last
+  E4 sf, sl, st;                        // the two boundary sums and the transition sum, reduced as soon as they are complete (their accumulators' registers are then free)
+  BB_HD void end_boundary() { sf = sum_of(af); sl = sum_of(al); }
+  BB_HD void end_trans() { st = sum_of(at); }
+  BB_HD void init() {
+#pragma unroll
+    for (int t = 0; t < 4; t++) a0[t] = at[t] = af[t] = al[t] = bb::acc96_zero();
   }
+  BB_HD V loc(int k) const { return air::is_virtual(k, DEF) ? 0u : src.loc(air::phys_col(k, DEF)); }
+  BB_HD V nxt(int k) const { return air::is_virtual(k, DEF) ? 0u : src.nxt(air::phys_col(k, DEF)); }
+  BB_HD V loc_r(int k) const { return src.loc_r(air::phys_col(k, DEF)); }
+  BB_HD V nxt_r(int k) const { return src.nxt_r(air::phys_col(k, DEF)); }
+  BB_HD V aloc(int k) const { return src.aloc(k); }
+  BB_HD V anxt(int k) const { return src.anxt(k); }
+  BB_HD V par(int i) const { return lk[i]; }
+  BB_HD V cst(uint32_t cm) const { return cm; }
+  BB_HD V add(V a, V b) const { return bb::add(a, b); }
+  BB_HD V sub(V a, V b) const { return bb::sub(a, b); }
+  BB_HD V mul(V a, V b) const { return bb::mont_mul(a, b); }
+  BB_HD V mulc(V a, uint32_t cm) const { return bb::mont_mul(a, cm); }
+  BB_HD V lsub(V a, V b) const { return bb::sub_lazy(a, b); }
+  BB_HD V ladd(V a, V b) const { return bb::add_lazy(a, b); }
+  BB_HD V lmul(V a, V b) const { return bb::mont_mul_lazy(a, b); }
+  BB_HD AccP accp() const { return bb::acc96_zero(); }
+  BB_HD void acc_mul(AccP& a, V x, V y) const { bb::mad96(a, x, y); }
+  BB_HD V acc_val(const AccP& a) const { return bb::acc96_div_R(a); }
+  BB_HD AccL accl() const { return 0; }
+  BB_HD void acc_lin(AccL& a, V x, uint32_t k) const { a += (uint64_t)k * x; }
+  // Σ k x over reduced x with Σ k < 2^11: (acc >> 32) R + (acc mod 2^32) is below 2^38 and 200 p
+  BB_HD V accl_val(const AccL& a) const { return bb::reduce_wide<6>((a >> 32) * bb::R1 + (uint32_t)a); }
+  BB_HD void push_to(bb::Acc96* acc, int idx, V v) {
+    const E4 c = ap[idx];
+    bb::mad96_s(acc[0], c.c[0], v); bb::mad96_s(acc[1], c.c[1], v); bb::mad96_s(acc[2], c.c[2], v); bb::mad96_s(acc[3], c.c[3], v);
+  }
+  BB_HD void push(int idx, V v) { push_to(a0, idx, v); }
+  BB_HD void push_t(int idx, V v) { push_to(at, idx, v); }
+  BB_HD void push_fc(int idx, V v, uint32_t) { push_to(af, idx, v); }
+  BB_HD void push_lc(int idx, V v, uint32_t) { push_to(al, idx, v); }
+  BB_HD void push_fc0(int, uint32_t) {}
+  BB_HD void push_lc0(int, uint32_t) {}
+  // the four sums as extension elements in Montgomery form: alpha^c and C_c both carry the factor R, the reduction divides by R once
+  BB_HD static E4 sum_of(const bb::Acc96* a) { return E4{{bb::acc96_div_R(a[0]), bb::acc96_div_R(a[1]), bb::acc96_div_R(a[2]), bb::acc96_div_R(a[3])}}; }
 };
-__device__ __forceinline__ uint32_t inv_mont(uint32_t a) { uint32_t r = bb::R1, b = a, e = bb::P - 2; while (e) { if (e & 1) r = bb::mont_mul(r, b); b = bb::mont_mul(b, b); e >>= 1; } return r; }
 
-__global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd, const ProveParams* __restrict__ pp,
-                                                       uint32_t gN_m, uint32_t wn_inv_m, uint32_t w_last_m, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m,
-                                                       uint32_t* __restrict__ Q) {
+// one (row, next row) pair of the LDE matrices, B8 layout, 16-byte reads
+struct DeviceRowSrc {
+  const uint4* __restrict__ L4; const uint4* __restrict__ A4; uint64_t N2, j, jn;
+  static __device__ __forceinline__ uint32_t pick(const uint4& q, int c) { return c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w; }
+  __device__ __forceinline__ uint32_t at(const uint4* __restrict__ m, int p, uint64_t row) const { return pick(m[((uint64_t)(p >> 3) * N2 + row) * 2 + ((p >> 2) & 1)], p & 3); }
+  __device__ __forceinline__ uint32_t at_r(const uint4* __restrict__ m, int p, uint64_t row) const { return reinterpret_cast<const uint32_t*>(m)[((uint64_t)(p >> 3) * N2 + row) * 8 + (p & 7)]; }
+  __device__ __forceinline__ uint32_t loc_r(int p) const { return at_r(L4, p, j); }
+  __device__ __forceinline__ uint32_t nxt_r(int p) const { return at_r(L4, p, jn); }
+  __device__ __forceinline__ uint32_t loc(int p) const { return at(L4, p, j); }
+  __device__ __forceinline__ uint32_t nxt(int p) const { return at(L4, p, jn); }
+  __device__ __forceinline__ uint32_t aloc(int p) const { return at(A4, p, j); }
+  __device__ __forceinline__ uint32_t anxt(int p) const { return at(A4, p, jn); }
+};
+
+template <bool DEF>
+__global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
+                                                                  const uint32_t* __restrict__ inv_xm1, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t w_last_inv_m,
+                                                                  uint32_t last_shift, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m, uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
@@ -97,19 +155,18 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
   const uint32_t N = N2 >> 1;
   const uint32_t wj = j < N ? tw_fwd[j] : bb::neg(tw_fwd[j - N]);
   const uint32_t x = bb::mont_mul(wj, bb::to_mont(bb::GEN));
-  const uint32_t one = bb::R1;
-  const uint32_t zh = bb::sub((j & 1) ? bb::neg(gN_m) : gN_m, one);                                 // x^N - 1
-  // Z_H takes two values on the coset (x^N = +-g^N): its inverses come from the host; 1/(x - 1) and 1/(x - w^last) are one
-  // exponentiation each per point
+  // Z_H takes two values on the coset (x^N = +-g^N): its inverses come from the host.  is_first = Z_H / (x - 1), is_last = Z_H / (x - w^last):
+  // Q = (S0 + is_trans St) / Z_H + Sf / (x - 1) + Sl / (x - w^last), and x_j - w^last = w^last (x_(j - 2 last) - 1)
   const uint32_t inv_zh = (j & 1) ? inv_zh_odd_m : inv_zh_even_m;
-  const uint32_t is_first = bb::mont_mul(zh, inv_mont(bb::sub(x, one)));
-  const uint32_t is_last = bb::mont_mul(zh, inv_mont(bb::sub(x, w_last_m)));
+  const uint32_t inv_first = inv_xm1[j], inv_last = bb::mont_mul(inv_xm1[(j + N2 - last_shift) & (N2 - 1)], w_last_inv_m);
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
-  QuotientOps o{L, AL, N2, j, (j + 2) & (N2 - 1), pp, LazyE4(), bb::e_zero(), 0, pp->deferred != 0};
-  air::eval(o, is_first, is_last, is_trans, pp->first_m, pp->last_m, pp->deferred != 0);
-  const E4 total = bb::e_add(o.partial, lz_reduce(o.acc));
-  const E4 q = bb::e_from_mont(bb::e_mul_fm(total, inv_zh));
-  uint4* q4 = reinterpret_cast<uint4*>(Q);                                     // one B8 block: four coordinate columns + four zero columns
+  QuotientOps<DEF, DeviceRowSrc> o{DeviceRowSrc{reinterpret_cast<const uint4*>(L), reinterpret_cast<const uint4*>(AL), N2, j, (j + 2) & (N2 - 1)}, pp->alpha_pow, pp->lk};
+  o.init();
+  air::eval(o, pp->first_m, pp->last_m, DEF);
+  using QO = QuotientOps<DEF, DeviceRowSrc>;
+  const E4 s0 = QO::sum_of(o.a0), st = o.st, sf = bb::e_sub(o.sf, pp->cf), sl = bb::e_sub(o.sl, pp->cl);
+  const E4 q = bb::e_add(bb::e_add(bb::e_mul_fm(bb::e_add(s0, bb::e_mul_fm(st, is_trans)), inv_zh), bb::e_mul_fm(sf, inv_first)), bb::e_mul_fm(sl, inv_last));
+  uint4* q4 = reinterpret_cast<uint4*>(Q);                                     // one B8 block: four coordinate columns (Montgomery, like every matrix of a proof) + four zero columns
   q4[(uint64_t)j * 2] = make_uint4(q.c[0], q.c[1], q.c[2], q.c[3]);
   q4[(uint64_t)j * 2 + 1] = make_uint4(0, 0, 0, 0);
 }
@@ -197,7 +254,7 @@ __global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __res
   inv_rom[u] = bb::e_inv_m(dd);
 }
 
-// aux rows: H0..H7, HR (canonical) into blocks 0..4 of the aux matrix, and in the S slot (the second half of block 4) the row's increment
+// aux rows: H0..H7, HR (Montgomery form) into blocks 0..4 of the aux matrix, and in the S slot (the second half of block 4) the row's increment
 // d_i = H0 + .. + H7 + HR - T / N
 // (the scan kernels below turn the increments into the running sum S_i = sum_{j < i} d_j)
 __global__ __launch_bounds__(NT) void aux_rows_kernel(const uint4* __restrict__ side, uint64_t N, const E4* __restrict__ inv_rc, const E4* __restrict__ inv_rom,
@@ -207,7 +264,8 @@ __global__ __launch_bounds__(NT) void aux_rows_kernel(const uint4* __restrict__ 
   const uint4 sd = side[i];
   const uint32_t ch[air::N_RC] = {sd.x & 1023, (sd.x >> 10) & 1023, sd.x >> 20, sd.y & 1023, (sd.y >> 10) & 1023, sd.y >> 20, sd.z & 1023, sd.z >> 10};
   uint4* A4 = reinterpret_cast<uint4*>(A);
-  auto put = [&](uint32_t blk, uint32_t half, const E4& e) { const E4 c = bb::e_from_mont(e); A4[((uint64_t)blk * N + i) * 2 + half] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
+  // (Montgomery words, as they come out of the inverse tables: the aux matrix rests in Montgomery form like every prover matrix — the LDE is linear)
+  auto put = [&](uint32_t blk, uint32_t half, const E4& c) { A4[((uint64_t)blk * N + i) * 2 + half] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
   const E4 hr = inv_rom[sd.w];
   E4 d = hr;
 #pragma unroll
@@ -296,11 +354,11 @@ __global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const 
   wts[j] = bb::e_mul_fm(di, x);
 }
 
-// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (CANONICAL E4; grid: chunks x half blocks of the B8 matrix).
+// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (MONTGOMERY E4; grid: chunks x half blocks of the B8 matrix).
 // A workgroup handles the FOUR columns of one half block — one 16-byte load brings their values at a position — so that the 16-byte
-// weights (the bulk of the traffic when read once per column) are loaded once per four values; products are accumulated lazily:
-// mont(e, v) without its final subtraction (3 instructions) into a 64-bit sum (1 instruction), reduced once at the end.  v stays
-// canonical: mont(e * R, v) = e * v needs no conversion of the matrix.
+// weights (the bulk of the traffic when read once per column) are loaded once per four values; the products accumulate as exact 96-bit
+// integers (bb::mad96: 2 instructions per term; round 3: a lazy Montgomery product + a 64-bit add, 4 instructions), reduced once per lane.
+// v and e both rest in Montgomery form: the reduction's division by R leaves R * Σ v e.
 __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, uint32_t width, const E4* __restrict__ wts, E4* __restrict__ partial,
                                                        uint32_t n_chunks) {
   constexpr int CG = 4;
@@ -308,11 +366,11 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
   const uint32_t col0 = blockIdx.y * CG, chunk = blockIdx.x;
   const uint64_t per = N2 / n_chunks, lo = (uint64_t)chunk * per;
   const uint4* v4 = reinterpret_cast<const uint4*>(mat) + (uint64_t)(col0 >> 3) * N2 * 2 + ((col0 >> 2) & 1);
-  uint64_t a0[CG][4], a1[CG][4];
+  bb::Acc96 a0[CG][4], a1[CG][4];
 #pragma unroll
   for (int c = 0; c < CG; c++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) a0[c][t] = a1[c][t] = 0;
+    for (int t = 0; t < 4; t++) a0[c][t] = a1[c][t] = bb::acc96_zero();
   for (uint64_t j = lo + threadIdx.x; j < lo + per; j += NT) {
     const E4 w0 = wts[j], w1 = wts[(j + N2 - 2) & (N2 - 1)];
     const uint4 xv = v4[j * 2];
@@ -320,10 +378,7 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
 #pragma unroll
     for (int c = 0; c < CG; c++) {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        a0[c][t] = bb::acc_add(a0[c][t], bb::mont_mul_lazy(w0.c[t], x[c]));
-        a1[c][t] = bb::acc_add(a1[c][t], bb::mont_mul_lazy(w1.c[t], x[c]));
-      }
+      for (int t = 0; t < 4; t++) { bb::mad96(a0[c][t], w0.c[t], x[c]); bb::mad96(a1[c][t], w1.c[t], x[c]); }
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -331,7 +386,7 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
   for (int c = 0; c < CG; c++)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      uint32_t r0 = (uint32_t)(a0[c][t] % bb::P), r1 = (uint32_t)(a1[c][t] % bb::P);
+      uint32_t r0 = bb::acc96_div_R(a0[c][t]), r1 = bb::acc96_div_R(a1[c][t]);
       for (int off = 32; off > 0; off >>= 1) { r0 = bb::add(r0, __shfl_down(r0, off, 64)); r1 = bb::add(r1, __shfl_down(r1, off, 64)); }
       if (lane == 0) { red[wv][c][0][t] = r0; red[wv][c][1][t] = r1; }
     }
@@ -345,25 +400,28 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
 }
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
+// A = Σ gamma^k v_k, B = Σ gamma^(WT + k) v_k over the columns of a position (Montgomery words x Montgomery gamma powers): exact 96-bit sums
+// per extension coordinate (bb::mad96_s, gamma^k in scalar registers), reduced once — the reduction's division by R leaves R A, R B.
 __global__ __launch_bounds__(NT, DEEP_WAVES) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, const uint32_t* __restrict__ Q, uint32_t log_n,
                                                    const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, int WM, uint32_t* __restrict__ cw) {
   const uint32_t N2 = 2u << log_n;
   const int WT = WM + WA;                                      // WM = the proof's committed main-trace width (a multiple of 8)
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
-  // canonical v x Montgomery gamma^k = canonical product; the lazy sums (136 terms fit) are folded into Ap / Bp every FOLD terms
-  LazyE4 A, B;
-  E4 Ap = bb::e_zero(), Bp = bb::e_zero();
-  constexpr int UN = 8, FOLD = 80;
-  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && WA % UN == 0 && FOLD % UN == 0 && FOLD <= 128, "column loop");
-  int pending = 0;
+  bb::Acc96 A[4], B[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) A[t] = B[t] = bb::acc96_zero();
+  constexpr int UN = 8;
+  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && WA % UN == 0 && 2 * (WMX + WA) + 4 < 512, "column loop; 96-bit sums hold 2^9 terms");
   auto block = [&](const uint4* M4, int blk, int k0) {                         // one B8 block = eight columns, gamma indices k0 .. k0 + 7 (zeta) and WT + k0 .. (zeta w)
     const uint4 vlo = M4[((uint64_t)blk * N2 + j) * 2], vhi = M4[((uint64_t)blk * N2 + j) * 2 + 1];
     const uint32_t v[UN] = {vlo.x, vlo.y, vlo.z, vlo.w, vhi.x, vhi.y, vhi.z, vhi.w};
 #pragma unroll
-    for (int u = 0; u < UN; u++) { lz_fma(A, pp->gamma_pow[k0 + u], v[u]); lz_fma(B, pp->gamma_pow[WT + k0 + u], v[u]); }
-    pending += UN;
-    if (pending == FOLD) { Ap = bb::e_add(Ap, lz_reduce(A)); Bp = bb::e_add(Bp, lz_reduce(B)); A = LazyE4(); B = LazyE4(); pending = 0; }
+    for (int u = 0; u < UN; u++) {
+      const E4 ga = pp->gamma_pow[k0 + u], gb = pp->gamma_pow[WT + k0 + u];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { bb::mad96_s(A[t], ga.c[t], v[u]); bb::mad96_s(B[t], gb.c[t], v[u]); }
+    }
   };
 #pragma unroll 1
   for (int k = 0; k < WM; k += UN) block(reinterpret_cast<const uint4*>(L), k >> 3, k);
@@ -371,9 +429,16 @@ __global__ __launch_bounds__(NT, DEEP_WAVES) void deep_kernel(const uint32_t* __
   for (int k = 0; k < WA; k += UN) block(reinterpret_cast<const uint4*>(AL), k >> 3, WM + k);
   {
     const uint4 qv = reinterpret_cast<const uint4*>(Q)[(uint64_t)j * 2];
-    lz_fma(A, pp->gamma_pow[2 * WT], qv.x); lz_fma(A, pp->gamma_pow[2 * WT + 1], qv.y); lz_fma(A, pp->gamma_pow[2 * WT + 2], qv.z); lz_fma(A, pp->gamma_pow[2 * WT + 3], qv.w);
+    const uint32_t v[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const E4 ga = pp->gamma_pow[2 * WT + u];
+#pragma unroll
+      for (int t = 0; t < 4; t++) bb::mad96_s(A[t], ga.c[t], v[u]);
+    }
   }
-  const E4 Am = bb::e_to_mont(bb::e_add(Ap, lz_reduce(A))), Bm = bb::e_to_mont(bb::e_add(Bp, lz_reduce(B)));
+  const E4 Am{{bb::acc96_div_R(A[0]), bb::acc96_div_R(A[1]), bb::acc96_div_R(A[2]), bb::acc96_div_R(A[3])}};
+  const E4 Bm{{bb::acc96_div_R(B[0]), bb::acc96_div_R(B[1]), bb::acc96_div_R(B[2]), bb::acc96_div_R(B[3])}};
   const E4 i1 = dinv[j], i2 = bb::e_mul_fm(dinv[(j + N2 - 2) & (N2 - 1)], wn_inv_m);   // 1/(zeta - x), 1/(zeta w - x)
   const E4 t1 = bb::e_mul_m(bb::e_sub(pp->a0, Am), i1);                       // (A - a0)/(x - zeta) = (a0 - A)/(zeta - x)
   const E4 t2 = bb::e_mul_m(bb::e_sub(pp->b0, Bm), i2);
@@ -437,12 +502,13 @@ __global__ __launch_bounds__(NT) void fri_fold_kernel(const uint32_t* __restrict
 }
 
 // ---- query gathering: job = copy `count` words src[k * stride] -> dst[k] ------------------------------------------------------
-struct GatherJob { const uint32_t* src; uint64_t stride; uint32_t count; uint32_t dst; };
+// (mont: the source words rest in Montgomery form — rows of the LDE matrices — and enter the proof canonical)
+struct GatherJob { const uint32_t* src; uint64_t stride; uint32_t count; uint32_t dst; uint32_t mont; uint32_t pad_; };
 __global__ void gather_kernel(const GatherJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ dst) {
   const uint32_t jb = blockIdx.x;
   if (jb >= n_jobs) return;
   const GatherJob g = jobs[jb];
-  for (uint32_t k = threadIdx.x; k < g.count; k += blockDim.x) dst[g.dst + k] = g.src[(uint64_t)k * g.stride];
+  for (uint32_t k = threadIdx.x; k < g.count; k += blockDim.x) { const uint32_t v = g.src[(uint64_t)k * g.stride]; dst[g.dst + k] = g.mont ? bb::from_mont(v) : v; }
 }
 
 // ---- proof-of-work grinding: one candidate nonce per lane; the smallest hit wins (deterministic) ------------------------------
@@ -507,9 +573,50 @@ void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t*
   w.insert(w.end(), states, states + 2 * NS);
 }
 
+// The quotient kernel's evaluation of the constraint list (QuotientOps: lazy 32-bit arithmetic, 96-bit sums, one accumulator per selector), run on
+// the HOST for one (row, next row) pair given as LOGICAL columns (canonical words): out4 = sum_c alpha^c C_c, canonical — what the oracle's
+// constraints_sum gives for the same inputs (tests/test_abi.py).  A test entry point; nothing in the product calls it.
+struct HostRowSrc {
+  const uint32_t* l; const uint32_t* n; const uint32_t* a; const uint32_t* an;
+  uint32_t loc(int p) const { return l[p]; }
+  uint32_t nxt(int p) const { return n[p]; }
+  uint32_t loc_r(int p) const { return l[p]; }
+  uint32_t nxt_r(int p) const { return n[p]; }
+  uint32_t aloc(int p) const { return a[p]; }
+  uint32_t anxt(int p) const { return an[p]; }
+};
+template <bool DEF>
+static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, const uint32_t* sel3, const uint32_t* first, const uint32_t* last,
+                          const uint32_t* alpha4, uint32_t* out4) {
+  uint32_t l[WMX], n[WMX], a[WA], an[WA], lkm[air::N_LK], fm[NS], lm[NS];
+  for (int p = 0; p < air::committed_used(DEF); p++) { l[p] = bb::to_mont(loc[air::logical_col(p, DEF)]); n[p] = bb::to_mont(nxt[air::logical_col(p, DEF)]); }
+  for (int k = 0; k < WA; k++) { a[k] = bb::to_mont(aloc[k]); an[k] = bb::to_mont(anxt[k]); }
+  for (int i = 0; i < air::N_LK; i++) lkm[i] = bb::to_mont(lk[i]);
+  for (int i = 0; i < NS; i++) { fm[i] = bb::to_mont(first[i]); lm[i] = bb::to_mont(last[i]); }
+  std::vector<E4> ap(N_CONSTRAINTS);
+  E4 al{{alpha4[0], alpha4[1], alpha4[2], alpha4[3]}}, cur{{1, 0, 0, 0}};
+  for (int c = 0; c < N_CONSTRAINTS; c++) { ap[c] = bb::e_to_mont(cur); cur = h_e_mul(cur, al); }
+  QuotientOps<DEF, HostRowSrc> o{HostRowSrc{l, n, a, an}, ap.data(), lkm};
+  o.init();
+  air::eval(o, fm, lm, DEF);
+  E4 cf, cl;
+  air::boundary_constants(ap.data(), fm, lm, cf, cl);
+  using QO = QuotientOps<DEF, HostRowSrc>;
+  const E4 s0 = QO::sum_of(o.a0), st = o.st, sf = bb::e_sub(o.sf, cf), sl = bb::e_sub(o.sl, cl);
+  const E4 tot = bb::e_add(bb::e_add(s0, bb::e_mul_fm(st, bb::to_mont(sel3[2]))), bb::e_add(bb::e_mul_fm(sf, bb::to_mont(sel3[0])), bb::e_mul_fm(sl, bb::to_mont(sel3[1]))));
+  const E4 r = bb::e_from_mont(tot);
+  for (int t = 0; t < 4; t++) out4[t] = r.c[t];
+}
 }  // namespace
 
 extern "C" {
+
+void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, uint32_t is_first, uint32_t is_last, uint32_t is_trans,
+                        const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t deferred, uint32_t* out4) {
+  const uint32_t sel3[3] = {is_first, is_last, is_trans};
+  if (deferred) air_eval_host<true>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, alpha4, out4);
+  else air_eval_host<false>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, alpha4, out4);
+}
 
 uint32_t zkir_proof_num_queries(void) { return NUM_QUERIES; }
 uint32_t zkir_proof_version(void) { return PROOF_VERSION; }
@@ -600,9 +707,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, DEF, dCode, n_code, dSide, dMult + n_code, dMult, dBad);
   }
   mark(1);
-  rc = zkir_lde_launch(c, dM, WM, dL, s); if (rc) return rc;
+  rc = lde_launch(c, dM, WM, dL, /*mont_out=*/true, s); if (rc) return rc;        // canonical evaluations in, MONTGOMERY words out: the matrices of a proof rest in Montgomery form
   mark(2);
-  rc = zkir_merkle_commit_launch(c, dL, WM, N2, dTree, s); if (rc) return rc;
+  rc = merkle_commit(c, dL, WM, N2, dTree, /*mont_in=*/true, s); if (rc) return rc;
   uint32_t troot[4], aroot[4], qroot[4], bound[2 * NS];
   unsigned long long bad_row = ~0ull;
   std::vector<uint32_t> mult((size_t)n_code + air::RC_TABLE);
@@ -649,8 +756,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_scan), dim3(NT), 0, s, dA, N, dSums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(NT), 0, s, dSums, n_scan);
     hipLaunchKernelGGL(scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dA, N, dSums);
-    rc = zkir_lde_launch(c, dA, WA, dAL, s); if (rc) return rc;
-    rc = zkir_merkle_commit_launch(c, dAL, WA, N2, dATree, s); if (rc) return rc;
+    rc = lde_launch(c, dA, WA, dAL, /*mont_out=*/false, s); if (rc) return rc;      // the aux rows are written in Montgomery form already; the extension is linear
+    rc = merkle_commit(c, dAL, WA, N2, dATree, /*mont_in=*/true, s); if (rc) return rc;
     HIP_OK(hipMemcpyAsync(aroot, dATree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     ch.observe_n(aroot, 4);
@@ -663,14 +770,17 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     E4 a{{1, 0, 0, 0}};
     for (int k = 0; k < N_CONSTRAINTS; k++) { pp->alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
     for (int i = 0; i < NS; i++) { pp->first_m[i] = bb::to_mont(bound[i]); pp->last_m[i] = bb::to_mont(bound[NS + i]); }
+    air::boundary_constants(pp->alpha_pow, pp->first_m, pp->last_m, pp->cf, pp->cl);
     pp->deferred = pub->deferred ? 1 : 0;
     HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
   }
   const uint32_t wn = bb::root_of_unity((int)log_n);
-  const uint32_t gN = bb::pow(bb::GEN, N), gN_m = bb::to_mont(gN), wn_inv_m = bb::to_mont(bb::inv(wn)), w_last_m = bb::to_mont(bb::pow(wn, pub->n_real - 1));
+  const uint32_t gN = bb::pow(bb::GEN, N), wn_inv_m = bb::to_mont(bb::inv(wn)), w_last_inv_m = bb::to_mont(bb::inv(bb::pow(wn, pub->n_real - 1)));
   const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
-  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, dPP, gN_m, wn_inv_m, w_last_m, inv_zh_even_m, inv_zh_odd_m, dQ);
-  rc = zkir_merkle_commit_launch(c, dQ, 4, N2, dQTree, s); if (rc) return rc;
+  const uint32_t last_shift = (uint32_t)((2 * (pub->n_real - 1)) & (N2 - 1));   // x_j - w_N^last = w_N^last (x_(j - 2 last) - 1) on the 2N coset
+  if (DEF) hipLaunchKernelGGL(quotient_kernel<true>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  else hipLaunchKernelGGL(quotient_kernel<false>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  rc = merkle_commit(c, dQ, 4, N2, dQTree, /*mont_in=*/true, s); if (rc) return rc;
   HIP_OK(hipMemcpyAsync(qroot, dQTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   mark(4);
@@ -697,11 +807,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     E4 sc = h_e_pow(zg, N2); sc.c[0] = bb::sub(sc.c[0], 1);
     const uint32_t inv2n = bb::inv((uint32_t)(N2 % bb::P));
     for (int t = 0; t < 4; t++) sc.c[t] = bb::mul(sc.c[t], inv2n);
-    const E4 sc_m = bb::e_to_mont(sc);
     for (int k = 0; k < WT + 4; k++) {
       E4 a = bb::e_zero(), b = bb::e_zero();
       for (uint32_t q = 0; q < n_chunks; q++) { a = bb::e_add(a, part[((size_t)k * n_chunks + q) * 2]); b = bb::e_add(b, part[((size_t)k * n_chunks + q) * 2 + 1]); }
-      const E4 va = bb::e_mul_m(a, sc_m), vb = bb::e_mul_m(b, sc_m);                                          // canonical partial sums x Montgomery scale = canonical
+      const E4 va = bb::e_mul_m(a, sc), vb = bb::e_mul_m(b, sc);                                              // Montgomery partial sums x canonical scale = canonical
       if (k < WT) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WT] = va;
     }
   }
@@ -803,23 +912,23 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   std::vector<uint32_t> qpos;                                                 // where each query's index word goes
   auto path_jobs = [&](const uint32_t* tree, uint64_t n_leaves, uint64_t leaf) {
     const uint32_t* layer = tree; uint64_t jdx = leaf;
-    for (uint64_t q = n_leaves; q > 1; q >>= 1) { jobs.push_back({layer + 4 * (jdx ^ 1), 1, 4, off}); off += 4; layer += 4 * q; jdx >>= 1; }
+    for (uint64_t q = n_leaves; q > 1; q >>= 1) { jobs.push_back({layer + 4 * (jdx ^ 1), 1, 4, off, 0u, 0u}); off += 4; layer += 4 * q; jdx >>= 1; }
   };
   for (uint32_t q : queries) {
     qpos.push_back(off); off += 1;
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // a trace row = 8 consecutive words out of each of the WM/8 blocks
-      for (uint32_t b = 0; b < (uint32_t)WM / 8; b++) { jobs.push_back({dL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off}); off += 8; }
+      for (uint32_t b = 0; b < (uint32_t)WM / 8; b++) { jobs.push_back({dL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off, 1u, 0u}); off += 8; }
       path_jobs(dTree, N2, pos);
     }
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // the aux row and its path
-      for (uint32_t b = 0; b < (uint32_t)WA / 8; b++) { jobs.push_back({dAL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off}); off += 8; }
+      for (uint32_t b = 0; b < (uint32_t)WA / 8; b++) { jobs.push_back({dAL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off, 1u, 0u}); off += 8; }
       path_jobs(dATree, N2, pos);
     }
-    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos * 8, 1, 4, off}); off += 4; path_jobs(dQTree, N2, pos); }
+    for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos * 8, 1, 4, off, 1u, 0u}); off += 4; path_jobs(dQTree, N2, pos); }
     int log_m = (int)log_n + 1;
     for (int j = 0; j < n_layers; log_m -= ks[j], j++) {
       const uint64_t m = 1ull << log_m, g = m >> ks[j], idx = q & (g - 1);
-      for (uint64_t t = 0; t < (1ull << ks[j]); t++) { jobs.push_back({fri_layers[j] + idx + t * g, m, 4, off}); off += 4; }
+      for (uint64_t t = 0; t < (1ull << ks[j]); t++) { jobs.push_back({fri_layers[j] + idx + t * g, m, 4, off, 0u, 0u}); off += 4; }
       path_jobs(fri_trees[j], g, idx);
     }
   }

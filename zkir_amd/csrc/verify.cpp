@@ -68,9 +68,12 @@ inline E4 m_base(uint32_t xm) { return E4{{xm, 0, 0, 0}}; }
 inline E4 m_pow(E4 a, uint64_t e) { E4 r = bb::e_one_m(); while (e) { if (e & 1) r = bb::e_mul_m(r, a); a = bb::e_mul_m(a, a); e >>= 1; } return r; }
 inline bool e_eq(const E4& a, const E4& b) { return !memcmp(a.c, b.c, 16); }
 
-struct VerifierOps {                                                       // air::eval on the openings at zeta (E4, Montgomery)
+struct VerifierOps {                                                       // air::eval on the openings at zeta (E4, Montgomery): plain arithmetic, nothing lazy
   using V = E4;
+  using AccP = E4;
+  using AccL = E4;
   const E4* l; const E4* n; const E4* al; const E4* an; const uint32_t* lk_m; const E4* ap; E4 acc; bool deferred;
+  E4 is_first, is_last, is_trans;
   V aloc(int k) const { return al[k]; }
   V anxt(int k) const { return an[k]; }
   V par(int i) const { return m_base(lk_m[i]); }
@@ -79,10 +82,28 @@ struct VerifierOps {                                                       // ai
   V mul(const V& a, const V& b) const { return bb::e_mul_m(a, b); }
   V mulc(const V& a, uint32_t cm) const { return bb::e_mul_fm(a, cm); }
   V cst(uint32_t cm) const { return m_base(cm); }
+  V lsub(const V& a, const V& b) const { return bb::e_sub(a, b); }
+  V ladd(const V& a, const V& b) const { return bb::e_add(a, b); }
+  V lmul(const V& a, const V& b) const { return bb::e_mul_m(a, b); }
+  AccP accp() const { return bb::e_zero(); }
+  void acc_mul(AccP& a, const V& x, const V& y) const { a = bb::e_add(a, bb::e_mul_m(x, y)); }
+  V acc_val(const AccP& a) const { return a; }
+  AccL accl() const { return bb::e_zero(); }
+  void acc_lin(AccL& a, const V& x, uint32_t k) const { a = bb::e_add(a, bb::e_mul_fm(x, bb::to_mont(k))); }
+  V accl_val(const AccL& a) const { return a; }
   // logical column k of the AIR: the constant 0 if it is not committed (air.h: is_virtual), else the opening of its committed position
   V loc(int k) const { return air::is_virtual(k, deferred) ? bb::e_zero() : l[air::phys_col(k, deferred)]; }
   V nxt(int k) const { return air::is_virtual(k, deferred) ? bb::e_zero() : n[air::phys_col(k, deferred)]; }
+  V loc_r(int k) const { return loc(k); }
+  V nxt_r(int k) const { return nxt(k); }
+  void end_boundary() {}
+  void end_trans() {}
   void push(int idx, const V& v) { acc = bb::e_add(acc, bb::e_mul_m(ap[idx], v)); }
+  void push_t(int idx, const V& v) { push(idx, bb::e_mul_m(v, is_trans)); }
+  void push_fc(int idx, const V& v, uint32_t cm) { push(idx, bb::e_mul_m(bb::e_sub(v, m_base(cm)), is_first)); }
+  void push_lc(int idx, const V& v, uint32_t cm) { push(idx, bb::e_mul_m(bb::e_sub(v, m_base(cm)), is_last)); }
+  void push_fc0(int idx, uint32_t cm) { push_fc(idx, bb::e_zero(), cm); }
+  void push_lc0(int idx, uint32_t cm) { push_lc(idx, bb::e_zero(), cm); }
 };
 
 // binary fold of one pair, Montgomery: (a + b)/2 + beta (a - b) / (2x)
@@ -104,6 +125,13 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
 }  // namespace
 
 extern "C" {
+
+// Static check of the quotient kernel's lazy arithmetic on the constraint list (air::BoundOps): 0 = sound; else 1 and the broken rule in `why`.
+int zkir_air_check_bounds(uint32_t deferred, char* why, size_t why_len) {
+  const char* w = air::check_bounds(deferred != 0);
+  if (why && why_len) snprintf(why, why_len, "%s", w ? w : "");
+  return w ? 1 : 0;
+}
 
 void zkir_digest_bytes(const uint8_t* b, size_t n, uint32_t out[4]) {
   std::vector<uint32_t> e;
@@ -304,8 +332,8 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     E4 is_trans = zeta; is_trans.c[0] = bb::sub(is_trans.c[0], bb::to_mont(bb::inv(wn)));
     uint32_t first_m[NS], last_m[NS];
     for (int i = 0; i < NS; i++) { first_m[i] = bb::to_mont(first[i]); last_m[i] = bb::to_mont(last[i]); }
-    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero(), pub.deferred != 0};
-    air::eval(o, is_first, is_last, is_trans, first_m, last_m, pub.deferred != 0);
+    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero(), pub.deferred != 0, is_first, is_last, is_trans};
+    air::eval(o, first_m, last_m, pub.deferred != 0);
     E4 qz = bb::e_zero();                                                  // Q(zeta) = sum_i X^i q_i(zeta): basis element X^i times the E4 opening
     for (int i = 0; i < 4; i++) { E4 basis = bb::e_zero(); basis.c[i] = bb::R1; qz = bb::e_add(qz, bb::e_mul_m(basis, q_z[i])); }
     if (!e_eq(o.acc, bb::e_mul_m(qz, zh))) return 10;
