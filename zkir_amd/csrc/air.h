@@ -155,13 +155,18 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
   auto boolean = [&](int idx, V b) { o.push(idx, o.lmul(o.ladd(b, o.cst(PM1)), b)); };
   // ---- A. boundary rows: state word i of row 0 / of row n_real - 1 is the public one; the last executed row is the halt row -------------
   // (unrolled at compile time: the columns are constants, so the quotient kernel reads them as 16-byte vectors, all in flight at once)
-  air_static_for<0, N_STATE>([&](auto ic) {
-    constexpr int i = decltype(ic)::value, col = state_col(i);
-    if (is_virtual(col, deferred)) { o.push_fc0(first_idx(i), first_m[i]); o.push_lc0(last_idx(i), last_m[i]); return; }
-    const V v = o.loc(col);
-    o.push_fc(first_idx(i), v, first_m[i]); o.push_lc(last_idx(i), v, last_m[i]);
-  });
-  o.push_lc(I_HALT, o.loc(kcol(K_HALT)), bb::R1);
+  // and FIRST in program order, the pushes after them: one memory latency for the phase, not one per column)
+  {
+    V sv[N_STATE];
+    air_static_for<0, N_STATE>([&](auto ic) { constexpr int i = decltype(ic)::value, col = state_col(i); sv[i] = is_virtual(col, deferred) ? zero : o.loc(col); });
+    const V khalt = o.loc(kcol(K_HALT));
+    air_static_for<0, N_STATE>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, col = state_col(i);
+      if (is_virtual(col, deferred)) { o.push_fc0(first_idx(i), first_m[i]); o.push_lc0(last_idx(i), last_m[i]); return; }
+      o.push_fc(first_idx(i), sv[i], first_m[i]); o.push_lc(last_idx(i), sv[i], last_m[i]);
+    });
+    o.push_lc(I_HALT, khalt, bb::R1);
+  }
   o.end_boundary();
   // ---- B. transitions (x is_trans): registers, cycle counter, next pc, the tail of the trace ------------------------------------------------
   // registers: unwritten ones keep their limbs and storage state, the written one shows y:  nx - cur - wr (tgt - cur);  in the same pass the
@@ -205,20 +210,27 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
     }
     cur = ahead;
   }
+  // every other column of the row pair, read HERE — together, before any of them is used (one memory latency)
   V K[N_CLASS];
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) K[k] = is_virtual(kcol(k), deferred) ? zero : o.loc(kcol(k));
   const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
   const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
-  const V hp = o.add(K[K_HALT], K[K_PAD]);
+  const V cyc = o.loc(C_CYCLE), ncyc = o.nxt(C_CYCLE), npad = o.nxt(C_K + K_PAD);
   const V d0 = o.loc(C_D0), d1 = o.loc(C_D1), d2 = o.loc(C_D2), dl0 = o.loc(C_DL0), se = o.loc(C_SE), s = o.loc(C_S);
-  const V fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI);
+  const V op = o.loc(C_OP), fa = o.loc(C_FA), fb = o.loc(C_FB), fc = o.loc(C_FC), fhi = o.loc(C_FHI), opc = o.loc(C_OPC), g = o.loc(C_G);
+  V xb[3], xc[3], iv[3];
+#pragma unroll
+  for (int l = 0; l < 3; l++) { xb[l] = o.loc(C_XB + l); xc[l] = o.loc(C_XC + l); iv[l] = o.loc(C_IV + l); }
+  V R[4], R2[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { R[i] = o.loc(C_RC + i); R2[i] = o.loc(C_RC2 + i); }
+  const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), ne = o.loc(C_NE), tk = o.loc(C_TK), nz = o.loc(C_NZ), q = o.loc(C_Q), sa = o.loc(C_B0), sbit = o.loc(C_SB);
+  const V flag = o.loc(C_FLAG), fx = o.loc(C_FX), ivz = o.loc(C_IVZ);
+  const V hp = o.add(K[K_HALT], K[K_PAD]);
   const V imm17 = o.add(fc, o.mulc(fhi, M(16)));
   const V im0 = o.add(o.sub(imm17, o.mulc(s, M(1u << 17))), o.mulc(s, M(1u << 20))), im1 = o.mulc(s, M(0xFFFFF));
-  V xb[3], xc[3];
-#pragma unroll
-  for (int l = 0; l < 3; l++) { xb[l] = o.loc(C_XB + l); xc[l] = o.loc(C_XC + l); }
-  o.push_t(I_CYCLE, o.lsub(o.sub(o.nxt(C_CYCLE), o.loc(C_CYCLE)), one));
+  o.push_t(I_CYCLE, o.lsub(o.sub(ncyc, cyc), one));
   // (R0 is hard-wired zero: its limbs and storage state are not committed in either mode — constraints I_R0 .. I_R0 + 3 and I_BOOL_STATE read 0 = 0)
   static_assert(is_virtual(C_LIMB, false) && is_virtual(C_LIMB + 2, true) && is_virtual(C_STATE, false) && is_virtual(C_STATE, true), "R0's columns are not committed");
   // next pc.  kc: pc' = pc + delta for every class but jalr, oj (free) and halt / pad (keep); class "other" is in it with delta 4 (tk = 0 there): sequential
@@ -231,11 +243,11 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
     for (int l = 0; l < 3; l++) o.push_t(I_PC_KEEP + l, o.lmul(o.lsub(npc[l], pc[l]), hp));
     // JALR: pc' + b0 = rs1 + sext(imm17) mod 2^64 over (20, 20, 24)-bit limbs, b0 = the bit that is cleared (execute.rs:649-658); the limbs
     // of pc' are a code address (every row's pc is looked up in the ROM), so the carries and b0 are forced
-    o.push_t(I_JALR, o.lmul(o.lsub(o.add(o.add(npc[0], o.loc(C_B0)), o.mulc(d0, M(1u << 20))), o.add(xb[0], im0)), K[K_JALR]));
+    o.push_t(I_JALR, o.lmul(o.lsub(o.add(o.add(npc[0], sa), o.mulc(d0, M(1u << 20))), o.add(xb[0], im0)), K[K_JALR]));
     o.push_t(I_JALR + 1, o.lmul(o.lsub(o.add(npc[1], o.mulc(d1, M(1u << 20))), o.add(o.add(xb[1], im1), d0)), K[K_JALR]));
     o.push_t(I_JALR + 2, o.lmul(o.lsub(o.add(npc[2], o.mulc(d2, M(1u << 24))), o.add(o.add(xb[2], o.mulc(s, M(0xFFFFFF))), d1)), K[K_JALR]));
     // executed rows, the halt row, padding
-    const V npad = o.nxt(C_K + K_PAD), one_m_npad = o.sub(one, npad);
+    const V one_m_npad = o.sub(one, npad);
     o.push_t(I_TAIL, o.lmul(one_m_npad, K[K_HALT]));
     o.push_t(I_TAIL + 1, o.lmul(one_m_npad, K[K_PAD]));
     o.push_t(I_TAIL + 2, o.lmul(o.sub(o.sub(one, K[K_PAD]), K[K_HALT]), npad));
@@ -243,16 +255,12 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
   o.end_trans();
   // ---- C. row-local constraints -----------------------------------------------------------------------------------------------------------
   const V Kbr = o.add(K[K_BRE], K[K_BRU]), Kcmp = o.add(K[K_SE], K[K_SU]);       // B-type rows; comparison rows (the flag is the value written)
-  V R[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) R[i] = o.loc(C_RC + i);
   const V z[2] = {o.add(R[0], o.mulc(R[1], M(RC_TABLE))), o.add(R[2], o.mulc(R[3], M(RC_TABLE)))};   // (v6) z IS its chunks: no columns of its own
   // booleans
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) { if (!is_virtual(kcol(k), deferred)) boolean(I_BOOL_K + k, K[k]); }
-  const V c0 = o.loc(C_C0), c1 = o.loc(C_C1), ne = o.loc(C_NE), tk = o.loc(C_TK), nz = o.loc(C_NZ), q = o.loc(C_Q);
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
-  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, o.loc(C_B0)); boolean(I_BOOL_MISC + 9, o.loc(C_SB)); boolean(I_BOOL_MISC + 10, nz);
+  boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, sa); boolean(I_BOOL_MISC + 9, sbit); boolean(I_BOOL_MISC + 10, nz);
   // classes and the opcode
   {
     AccL sum = o.accl(), ks = o.accl();
@@ -264,7 +272,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
     }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
-    if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), o.loc(C_OPC)), o.accl_val(ks)));
+    if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), opc), o.accl_val(ks)));
   }
   // selectors
   const V w0v = o.accl_val(w0), w1v = o.accl_val(w1), b1v = o.accl_val(b1), c1v = o.accl_val(c1a);
@@ -303,23 +311,21 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
     // (v5) ordered comparisons, signed or not (op = base + 2 g + pol; sgn = g on SLTU.. rows, 1 - g on BLT.. rows): the high limbs enter BIASED,
     // ta = a1 + 2^19 sgn - 2^20 sa, tb likewise with sb — the limbs of value XOR 2^39 when sgn = 1 (Value40::signed_lt, value.rs:710-716) — so
     // ta - tb = a1 - b1 - 2^20 (sa - sb); u = (ta, tb) is the row's second range-checked pair, which forces sa / sb to be the sign bits (0 if sgn = 0)
-    const V sa = o.loc(C_B0), sb = o.loc(C_SB), g = o.loc(C_G);
-    const V sab = o.mulc(o.lsub(sa, sb), M(1u << 20));
+    const V sab = o.mulc(o.lsub(sa, sbit), M(1u << 20));
     o.push(I_DIFF, o.lmul(o.lsub(o.add(o.sub(z[0], xb[0]), xc[0]), c0s20), Ks));
     const V dsub = o.sub(o.add(o.add(o.sub(z[1], xb[1]), xc[1]), c0), c1s20);
     o.push(I_DIFF + 1, o.lmul(dsub, K[K_SUB]));
     o.push(I_DIFF + 2, o.lmul(o.ladd(dsub, sab), K[K_SU]));
     o.push(I_DIFF + 3, o.lmul(o.lsub(o.add(o.sub(z[0], xc[0]), xb[0]), c0s20), K[K_BRU]));
     o.push(I_DIFF + 4, o.lmul(o.ladd(o.sub(o.add(o.add(o.sub(z[1], xc[1]), xb[1]), c0), c1s20), sab), K[K_BRU]));
-    const V u0 = o.add(o.loc(C_RC2), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), u1 = o.add(o.loc(C_RC2 + 2), o.mulc(o.loc(C_RC2 + 3), M(RC_TABLE)));
+    const V u0 = o.add(R2[0], o.mulc(R2[1], M(RC_TABLE))), u1 = o.add(R2[2], o.mulc(R2[3], M(RC_TABLE)));
     const V gsu = o.mulc(g, M(1u << 19)), gbr = o.mulc(o.lsub(one, g), M(1u << 19));
-    const V sa20 = o.mulc(sa, M(1u << 20)), sb20 = o.mulc(sb, M(1u << 20));
+    const V sa20 = o.mulc(sa, M(1u << 20)), sb20 = o.mulc(sbit, M(1u << 20));
     o.push(I_DIFF + 5, o.lmul(o.ladd(o.sub(o.sub(u0, xb[1]), gsu), sa20), K[K_SU]));
     o.push(I_DIFF + 6, o.lmul(o.ladd(o.sub(o.sub(u1, xc[1]), gsu), sb20), K[K_SU]));
     o.push(I_DIFF + 7, o.lmul(o.ladd(o.sub(o.sub(u0, xc[1]), gbr), sa20), K[K_BRU]));
     o.push(I_DIFF + 8, o.lmul(o.ladd(o.sub(o.sub(u1, xb[1]), gbr), sb20), K[K_BRU]));
   }
-  const V flag = o.loc(C_FLAG), fx = o.loc(C_FX);
   {
     const V Ky = o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), o.add(K[K_OTH], K[K_JALR])), deferred ? K[K_OJ] : zero);   // (oj writes only in deferred mode)
     o.push(I_WRITTEN, o.lmul(o.lsub(y[0], z[0]), Ky)); o.push(I_WRITTEN + 1, o.lmul(o.lsub(y[1], z[1]), Ky));
@@ -328,14 +334,14 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
     for (int l = 0; l < 3; l++) o.push(I_CMOV_Y + l, o.lmul(o.lsub(y[l], xb[l]), Kcm));        // (v6) a conditional move writes rs1's raw value (all three limbs)
     // (v6) the bits above 40 of what an "other" row writes: y2 = R4 + 2^10 R5 + 2^20 R6 with R7 = 64 R6 — all four in the 10-bit table, so y2 < 2^24.  With it
     // EVERY limb of every register is in range by induction (constrained classes write 0, pc2 + c1 or an operand's limb there)
-    o.push(I_Y2, o.lmul(o.lsub(o.sub(o.sub(y[2], o.loc(C_RC2)), o.mulc(o.loc(C_RC2 + 1), M(RC_TABLE))), o.mulc(o.loc(C_RC2 + 2), M(RC_TABLE * RC_TABLE))), K[K_OTH]));
-    o.push(I_Y2 + 1, o.lmul(o.lsub(o.loc(C_RC2 + 3), o.mulc(o.loc(C_RC2 + 2), M(64))), K[K_OTH]));
+    o.push(I_Y2, o.lmul(o.lsub(o.sub(o.sub(y[2], R2[0]), o.mulc(R2[1], M(RC_TABLE))), o.mulc(R2[2], M(RC_TABLE * RC_TABLE))), K[K_OTH]));
+    o.push(I_Y2 + 1, o.lmul(o.lsub(R2[3], o.mulc(R2[2], M(64))), K[K_OTH]));
   }
   // (v6) nz = [xc != 0] on every row, on the sum of xc's limbs (in range, so the sum vanishes only if they all do)
   {
     const V sx = o.add(o.add(xc[0], xc[1]), xc[2]);
     o.push(I_NZ, o.lmul(o.lsub(one, nz), sx));
-    o.push(I_NZ + 1, o.lsub(nz, o.mul(sx, o.loc(C_IVZ))));
+    o.push(I_NZ + 1, o.lsub(nz, o.mul(sx, ivz)));
   }
   // BNE operands differ?
   {
@@ -343,7 +349,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
 #pragma unroll
     for (int l = 0; l < 3; l++) {
       const V d = o.sub(xb[l], xc[l]);
-      o.acc_mul(dot, d, o.loc(C_IV + l));
+      o.acc_mul(dot, d, iv[l]);
       o.push(I_NE + l, o.lmul(o.lsub(one, ne), d));
     }
     o.push(I_NE + 3, o.lsub(ne, o.acc_val(dot)));
@@ -352,10 +358,10 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
   // 0 elsewhere; fx = flag XOR pol, pol = op - the family's even opcode (0 / 1: the ROM ties op to the class); a branch is taken iff fx
   o.push(I_FLAG, o.lsub(o.sub(flag, o.mul(o.lsub(one, ne), o.add(K[K_BRE], K[K_SE]))), o.mul(o.ladd(K[K_BRU], K[K_SU]), c1)));
   {
-    V pol = o.loc(C_OP);
+    V pol = op;
 #pragma unroll
     for (int k = 0; k < N_CLASS; k++) if (family_base(k)) pol = o.sub(pol, o.mulc(K[k], M(family_base(k))));
-    pol = o.sub(pol, o.mulc(o.loc(C_G), M(2)));                                // (v5) op = base + 2 g + pol in the four-member families; g = 0 elsewhere
+    pol = o.sub(pol, o.mulc(g, M(2)));                                // (v5) op = base + 2 g + pol in the four-member families; g = 0 elsewhere
     o.push(I_FX, o.ladd(o.sub(o.sub(fx, flag), pol), o.mulc(o.mul(pol, flag), M(2))));
   }
   o.push(I_TK, o.lsub(tk, o.mul(Kbr, fx)));
@@ -380,41 +386,49 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
       out[k] = o.acc_val(a);
     }
   };
+  // the aux row pair and the tuple columns, read together before use
+  V H[N_RC][4], hr[4], S[4], nS[4], tup[N_TUPLE];
+#pragma unroll
+  for (int i = 0; i < N_RC; i++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) H[i][k] = o.aloc(A_H + 4 * i + k);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { hr[k] = o.aloc(A_HR + k); S[k] = o.aloc(A_S + k); nS[k] = o.anxt(A_S + k); }
+  air_static_for<0, N_TUPLE>([&](auto jc) { tup[decltype(jc)::value] = o.loc(tuple_col(decltype(jc)::value)); });
   // range helpers: H_i (alpha - R_i) = 1, i = 0..7 (the chunks of z, the chunks of u)
   AccL hs[4] = {o.accl(), o.accl(), o.accl(), o.accl()};                         // H0 + .. + H7 + HR, coordinate by coordinate (the running sum's increment)
 #pragma unroll
   for (int i = 0; i < N_RC; i++) {
-    V h[4], d[4], pr[4];
+    V d[4], pr[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_H + 4 * i + k); d[k] = o.par(LK_ALPHA + k); o.acc_lin(hs[k], h[k], 1); }
-    d[0] = o.sub(d[0], o.loc(rc_col(i)));
-    ext_mul(h, d, pr);
+    for (int k = 0; k < 4; k++) { d[k] = o.par(LK_ALPHA + k); o.acc_lin(hs[k], H[i][k], 1); }
+    d[0] = o.sub(d[0], i < 4 ? R[i] : R2[i - 4]);
+    ext_mul(H[i], d, pr);
     o.push(I_RANGE + 4 * i, o.lsub(pr[0], one));
 #pragma unroll
     for (int k = 1; k < 4; k++) o.push(I_RANGE + 4 * i + k, pr[k]);
   }
   // instruction ROM: HR (alpha - fingerprint(tuple)) = 1, fingerprint = sum_j lambda^j f_j + lambda^N_TUPLE
   {
-    V h[4], d[4], pr[4];
+    V d[4], pr[4];
     AccP fp[4] = {o.accp(), o.accp(), o.accp(), o.accp()};
 #pragma unroll
-    for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_HR + k); o.acc_lin(hs[k], h[k], 1); }
+    for (int k = 0; k < 4; k++) o.acc_lin(hs[k], hr[k], 1);
 #pragma unroll
     for (int j = 0; j < N_TUPLE; j++) {
-      const V f = o.loc(tuple_col(j));
 #pragma unroll
-      for (int k = 0; k < 4; k++) o.acc_mul(fp[k], f, o.par(LK_LAM + 4 * j + k));
+      for (int k = 0; k < 4; k++) o.acc_mul(fp[k], tup[j], o.par(LK_LAM + 4 * j + k));
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) d[k] = o.sub(o.sub(o.par(LK_ALPHA + k), o.par(LK_LAM + 4 * N_TUPLE + k)), o.acc_val(fp[k]));
-    ext_mul(h, d, pr);
+    ext_mul(hr, d, pr);
     o.push(I_ROM, o.lsub(pr[0], one));
 #pragma unroll
     for (int k = 1; k < 4; k++) o.push(I_ROM + k, pr[k]);
   }
   // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR - T / N
 #pragma unroll
-  for (int k = 0; k < 4; k++) o.push(I_SUM + k, o.ladd(o.sub(o.sub(o.anxt(A_S + k), o.aloc(A_S + k)), o.accl_val(hs[k])), o.par(LK_TN + k)));
+  for (int k = 0; k < 4; k++) o.push(I_SUM + k, o.ladd(o.sub(o.sub(nS[k], S[k]), o.accl_val(hs[k])), o.par(LK_TN + k)));
 }
 
 // - sum_i (alpha^first_idx(i) first_m[i]) and the same for the last row: the share of the public boundary words in the two boundary sums — per-proof
@@ -428,6 +442,32 @@ inline void boundary_constants(const bb::E4* alpha_pow_m, const uint32_t* first_
   cl = bb::e_add(cl, bb::e_mul_fm(alpha_pow_m[I_HALT], bb::R1));
 }
 
+// The ORDER in which air::eval pushes the constraints a quotient kernel consumes (push_fc0 / push_lc0 are not consumed): the kernel reads its
+// coefficients alpha^c from a table laid out in this order, one after the other, each requested while the previous constraint is being accumulated
+// (QuotientOps: a scalar load issued at its point of use costs a scalar-cache round trip per constraint, with nothing to cover it).
+struct OrderOps {
+  struct V {};
+  using AccP = V; using AccL = V;
+  bool deferred;
+  int order[N_CONSTRAINTS]; int n = 0;
+  V loc(int) { return V{}; } V nxt(int) { return V{}; } V loc_r(int) { return V{}; } V nxt_r(int) { return V{}; } V aloc(int) { return V{}; } V anxt(int) { return V{}; }
+  V par(int) { return V{}; } V cst(uint32_t) { return V{}; } V add(V, V) { return V{}; } V sub(V, V) { return V{}; } V mul(V, V) { return V{}; } V mulc(V, uint32_t) { return V{}; }
+  V lsub(V, V) { return V{}; } V ladd(V, V) { return V{}; } V lmul(V, V) { return V{}; }
+  AccP accp() { return V{}; } void acc_mul(AccP&, V, V) {} V acc_val(const AccP&) { return V{}; }
+  AccL accl() { return V{}; } void acc_lin(AccL&, V, uint32_t) {} V accl_val(const AccL&) { return V{}; }
+  void end_boundary() {} void end_trans() {}
+  void rec(int idx) { if (n < N_CONSTRAINTS) order[n] = idx; n++; }
+  void push(int idx, V) { rec(idx); } void push_t(int idx, V) { rec(idx); } void push_fc(int idx, V, uint32_t) { rec(idx); } void push_lc(int idx, V, uint32_t) { rec(idx); }
+  void push_fc0(int, uint32_t) {} void push_lc0(int, uint32_t) {}
+};
+// order[k] = the constraint index of the k-th consumed push; returns their number (<= N_CONSTRAINTS)
+inline int push_order(bool deferred, int* order) {
+  OrderOps o{deferred};
+  uint32_t st[N_STATE] = {};
+  eval(o, st, st, deferred);
+  for (int k = 0; k < o.n && k < N_CONSTRAINTS; k++) order[k] = o.order[k];
+  return o.n;
+}
 #if !defined(__HIP_DEVICE_COMPILE__)
 // air::eval run on BOUNDS instead of values: every V carries the largest word it can hold under the quotient kernel's arithmetic (QuotientOps,
 // stark_prove.inl), every operation checks the precondition that arithmetic needs (no 32 / 64 / 96-bit overflow, lazy values only where a

@@ -104,12 +104,23 @@ BB_HD Acc96 acc96_zero() { return Acc96{0, 0}; }
 __device__ __forceinline__ void mad96_s(Acc96& a, uint32_t x, uint32_t y) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(a.lo), "+v"(a.hi) : "s"(x), "v"(y) : "vcc");
 }
+// four sums at once (the coordinates of an extension-field coefficient times one value): ONE asm statement, so the compiler pads it with hazard
+// nops once, not four times
+__device__ __forceinline__ void mad96x4_s(Acc96* a, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t y) {
+  asm("v_mad_u64_u32 %0, vcc, %8, %12, %0\n\tv_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "v_mad_u64_u32 %1, vcc, %9, %12, %1\n\tv_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %10, %12, %2\n\tv_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_mad_u64_u32 %3, vcc, %11, %12, %3\n\tv_addc_co_u32 %7, vcc, 0, %7, vcc"
+      : "+v"(a[0].lo), "+v"(a[1].lo), "+v"(a[2].lo), "+v"(a[3].lo), "+v"(a[0].hi), "+v"(a[1].hi), "+v"(a[2].hi), "+v"(a[3].hi)
+      : "s"(x0), "s"(x1), "s"(x2), "s"(x3), "v"(y) : "vcc");
+}
 __device__ __forceinline__ void mad96(Acc96& a, uint32_t x, uint32_t y) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(a.lo), "+v"(a.hi) : "v"(x), "v"(y) : "vcc");
 }
 #else
 inline void mad96(Acc96& a, uint32_t x, uint32_t y) { const uint64_t t = (uint64_t)x * y, s = a.lo + t; a.hi += s < t; a.lo = s; }
 inline void mad96_s(Acc96& a, uint32_t x, uint32_t y) { mad96(a, x, y); }
+inline void mad96x4_s(Acc96* a, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t y) { mad96(a[0], x0, y); mad96(a[1], x1, y); mad96(a[2], x2, y); mad96(a[3], x3, y); }
 #endif
 BB_HD uint32_t acc96_div_R(const Acc96& a) {          // (hi 2^64 + lo) / 2^32 mod p = hi R + lo_hi + lo_lo / R; hi < 2^9
   const uint32_t l0 = (uint32_t)a.lo, l1 = (uint32_t)(a.lo >> 32);

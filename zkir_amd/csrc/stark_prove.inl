@@ -24,7 +24,7 @@ constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 #define QUOT_WAVES 3
 #endif
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
-  E4 alpha_pow[N_CONSTRAINTS];
+  E4 alpha_seq[N_CONSTRAINTS + 2];   // alpha^c in the ORDER the quotient kernel consumes them (air::push_order), Montgomery; two spare entries: the kernel requests one ahead
   E4 gamma_pow[2 * WTX + 4];    // main columns, aux columns at zeta; the same at zeta w; the quotient (2 * (committed width + WA) + 4 used)
   E4 zeta, zeta_w, a0, b0;
   uint32_t first_m[NS], last_m[NS];   // public boundary states: rows 0 and n_real - 1 (Montgomery)
@@ -84,7 +84,8 @@ struct QuotientOps {
   using AccP = bb::Acc96;
   using AccL = uint64_t;
   Src src;
-  const E4* __restrict__ ap;            // alpha^c, Montgomery
+  const E4* __restrict__ ap;            // alpha^c (Montgomery) in the order air::eval pushes them (air::push_order): read one after the other
+  E4 pre;                               // the NEXT push's coefficient, requested while the current one is accumulated (scalar registers on the device)
   const uint32_t* __restrict__ lk;      // lookup parameters, Montgomery
   bb::Acc96 a0[4], at[4], af[4], al[4]; // Σ alpha^c C_c by selector: none, is_trans, is_first, is_last
   E4 sf, sl, st;                        // the two boundary sums and the transition sum, reduced as soon as they are complete (their accumulators' registers are then free)
@@ -93,6 +94,7 @@ struct QuotientOps {
   BB_HD void init() {
 #pragma unroll
     for (int t = 0; t < 4; t++) a0[t] = at[t] = af[t] = al[t] = bb::acc96_zero();
+    pre = *ap++;
   }
   BB_HD V loc(int k) const { return air::is_virtual(k, DEF) ? 0u : src.loc(air::phys_col(k, DEF)); }
   BB_HD V nxt(int k) const { return air::is_virtual(k, DEF) ? 0u : src.nxt(air::phys_col(k, DEF)); }
@@ -116,9 +118,10 @@ struct QuotientOps {
   BB_HD void acc_lin(AccL& a, V x, uint32_t k) const { a += (uint64_t)k * x; }
   // Σ k x over reduced x with Σ k < 2^11: (acc >> 32) R + (acc mod 2^32) is below 2^38 and 200 p
   BB_HD V accl_val(const AccL& a) const { return bb::reduce_wide<6>((a >> 32) * bb::R1 + (uint32_t)a); }
-  BB_HD void push_to(bb::Acc96* acc, int idx, V v) {
-    const E4 c = ap[idx];
-    bb::mad96_s(acc[0], c.c[0], v); bb::mad96_s(acc[1], c.c[1], v); bb::mad96_s(acc[2], c.c[2], v); bb::mad96_s(acc[3], c.c[3], v);
+  BB_HD void push_to(bb::Acc96* acc, int, V v) {           // (the constraint's index is implicit: the coefficients come in push order)
+    const E4 c = pre;
+    pre = *ap++;
+    bb::mad96x4_s(acc, c.c[0], c.c[1], c.c[2], c.c[3], v);
   }
   BB_HD void push(int idx, V v) { push_to(a0, idx, v); }
   BB_HD void push_t(int idx, V v) { push_to(at, idx, v); }
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
   const uint32_t inv_zh = (j & 1) ? inv_zh_odd_m : inv_zh_even_m;
   const uint32_t inv_first = inv_xm1[j], inv_last = bb::mont_mul(inv_xm1[(j + N2 - last_shift) & (N2 - 1)], w_last_inv_m);
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
-  QuotientOps<DEF, DeviceRowSrc> o{DeviceRowSrc{reinterpret_cast<const uint4*>(L), reinterpret_cast<const uint4*>(AL), N2, j, (j + 2) & (N2 - 1)}, pp->alpha_pow, pp->lk};
+  QuotientOps<DEF, DeviceRowSrc> o{DeviceRowSrc{reinterpret_cast<const uint4*>(L), reinterpret_cast<const uint4*>(AL), N2, j, (j + 2) & (N2 - 1)}, pp->alpha_seq, {}, pp->lk};
   o.init();
   air::eval(o, pp->first_m, pp->last_m, DEF);
   using QO = QuotientOps<DEF, DeviceRowSrc>;
@@ -596,7 +599,11 @@ static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32
   std::vector<E4> ap(N_CONSTRAINTS);
   E4 al{{alpha4[0], alpha4[1], alpha4[2], alpha4[3]}}, cur{{1, 0, 0, 0}};
   for (int c = 0; c < N_CONSTRAINTS; c++) { ap[c] = bb::e_to_mont(cur); cur = h_e_mul(cur, al); }
-  QuotientOps<DEF, HostRowSrc> o{HostRowSrc{l, n, a, an}, ap.data(), lkm};
+  int order[N_CONSTRAINTS];
+  const int n_push = air::push_order(DEF, order);
+  std::vector<E4> seq((size_t)N_CONSTRAINTS + 2, bb::e_zero());
+  for (int k = 0; k < n_push; k++) seq[k] = ap[order[k]];
+  QuotientOps<DEF, HostRowSrc> o{HostRowSrc{l, n, a, an}, seq.data(), {}, lkm};
   o.init();
   air::eval(o, fm, lm, DEF);
   E4 cf, cl;
@@ -768,9 +775,13 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 2. quotient ------------------------------------------------------------------------------------------------------------
   {
     E4 a{{1, 0, 0, 0}};
-    for (int k = 0; k < N_CONSTRAINTS; k++) { pp->alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
+    std::vector<E4> alpha_pow(N_CONSTRAINTS);
+    for (int k = 0; k < N_CONSTRAINTS; k++) { alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
+    int order[N_CONSTRAINTS];
+    const int n_push = air::push_order(DEF, order);             // the order the quotient kernel consumes the coefficients in
+    for (int k = 0; k < N_CONSTRAINTS + 2; k++) pp->alpha_seq[k] = k < n_push ? alpha_pow[order[k]] : bb::e_zero();
     for (int i = 0; i < NS; i++) { pp->first_m[i] = bb::to_mont(bound[i]); pp->last_m[i] = bb::to_mont(bound[NS + i]); }
-    air::boundary_constants(pp->alpha_pow, pp->first_m, pp->last_m, pp->cf, pp->cl);
+    air::boundary_constants(alpha_pow.data(), pp->first_m, pp->last_m, pp->cf, pp->cl);
     pp->deferred = pub->deferred ? 1 : 0;
     HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
   }
