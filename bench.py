@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 # (8 x 12 + 22) S-boxes + 13 per partial round (11 diagonal products, word 0's update, the sum's change of form) x 22 + the 12
 # products that bring 8 absorbed values and the 4 carried capacity words to the input factor
 MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 13 * 22 + 12
-PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
+PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
 # The integer-ALU roofline of the Poseidon2 kernels, ANALYTIC (a fixed denominator): a Montgomery product is three
 # multiplier-class wave instructions (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32), each of which issues in 4.2 SIMD-cycles per wave64 on
 # gfx950 (profiles/r02_ubench_alu.txt: v_mul_lo 4.21, v_mul_hi 4.09, v_mad_u64_u32 4.48); the chip has 256 CUs x 4 SIMDs at 2.4 GHz:
@@ -59,9 +59,10 @@ def _fri_schedule(k):
 
 def _prove_stage_table(k, W, pms):
     """Algorithmic HBM bytes (the minimum: every operand read once, every result written once), ms and fraction of the HBM peak of
-    the prover stages that follow the commitment (VERDICT r2 weak #10).  pms = the 8 stage times of zkir_prove (HIP events)."""
+    the prover stages that follow the commitment (VERDICT r2 weak #10).  pms = the 9 stage times of zkir_prove (HIP events)."""
     n2 = 2 << k
-    W = W + 24                                                # the quotient, the openings and the DEEP combination read the main matrix AND the 24-column aux matrix of the lookup argument
+    from zkir_amd import stark as _stark
+    W = W + _stark.W_AUX                                      # the quotient, the openings and the DEEP combination read the main matrix AND the aux matrix of the lookup argument (air.h W_AUX)
     tree = 16 * (2 * n2 - 1)
     fri = 0
     m = n2
@@ -143,6 +144,16 @@ def _profiled_valu_busy(kernel: str):
             if line.startswith(kernel):
                 return float(line.split()[-2]) / 100.0
     return None
+
+
+def _root_vs_golden(k, root):
+    """True / False: the commitment root of the 2^k-cycle fib run against tests/golden/config_roots.json (computed by the CPU oracle alone, offline:
+    tests/golden/make_config_roots.py) — BASELINE configs[1]'s "bit-exact root vs CPU"; None when the fixture has no entry for this size."""
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config_roots.json")))["roots"].get(str(k))
+    except OSError:
+        return None
+    return None if gold is None else bool(gold["root"] == root)
 
 
 def _host_cpu():
@@ -826,6 +837,7 @@ def main():
                       "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v10 carries the program)",
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
+            "merkle_root_equals_oracle_golden": _root_vs_golden(k, root) if (commit and not dist_mode) else None,
             "host_interpret_rows_per_s": total_rows / host_s, "host_interpret_first_run_rows_per_s": total_rows / host_first_s,
             "host_interpret_ns_per_instruction": host_s / total_rows * 1e9, "host_interpret_s": host_s,
             # N = 1: the one interpretation of the run.  N > 1: EVERY rank executes its own prefix (rank g: g n rows untraced + n rows traced, on its own

@@ -277,7 +277,7 @@ typedef struct zkir_stark_ctx zkir_stark_ctx;     /* device tables (twiddles, co
                                                      One proof at a time per context; different contexts are independent (no process-wide state). */
 int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup /* must be 1 */, zkir_stark_ctx** out);
 void zkir_stark_ctx_free(zkir_stark_ctx* ctx);
-uint32_t zkir_main_trace_width(void);             /* 152: COMMITTED main-trace columns of a default-mode run (the AIR's 169 logical columns minus the ones that
+uint32_t zkir_main_trace_width(void);             /* 152: COMMITTED main-trace columns of a default-mode run (the AIR's 172 logical columns minus the ones that
                                                      are identically zero there: R0's limbs and the 16 storage states; zkir_amd/csrc/air.h) */
 uint32_t zkir_main_trace_width_for(uint32_t deferred);   /* 152 (deferred = 0) / 168 (VMConfig.enable_deferred_model: the storage states are committed) */
 uint32_t zkir_padded_log_n(uint64_t n_real);      /* log2 of the padded trace length: max(3, ceil(log2(n_real))) */
@@ -325,7 +325,7 @@ typedef struct zkir_public_inputs {
   uint32_t io_digest[4];       /* zkir_digest_bytes(LE u64 words [n_inputs, inputs.., n_outputs, outputs.., halt kind, halt code, cycles]) */
   /* PROVER side only (ignored when the struct is the `expect` of a verifier): the program itself, BORROWED — set by
    * zkir_public_inputs_of to the caller's blob, which must stay valid while the struct is passed to zkir_prove.  Its code words are
-   * the instruction ROM of the lookup argument; the proof carries the program (format v5 on), the verifier checks it against program_digest. */
+   * the instruction ROM of the lookup argument; the proof carries the program (format v5 on; zkir_proof_version() = the current format), the verifier checks it against program_digest. */
   const uint8_t* program_blob;
   uint64_t program_blob_len;
 } zkir_public_inputs;
@@ -340,7 +340,7 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob
  * malloc'ed array of u32 words (little-endian canonical field elements, format v10: layout in oracle/stark_oracle.cpp so::prove),
  * pub->program_blob must be the program that ran: every row's (pc, instruction word) is looked up in its code table, and a run that executes
  * anything else (self-modified code, a pc outside the code segment) is refused with ZKIR_ERR_ARGUMENT — it has no proof in this AIR.
- * released with zkir_proof_free.  stage_ms (8 floats, nullable): main trace, LDE, trace Merkle, quotient, openings, DEEP, FRI, queries.
+ * released with zkir_proof_free.  stage_ms (NINE floats, nullable): main trace, LDE, trace Merkle, lookup argument (aux trace + its LDE and tree), quotient, openings, DEEP, FRI, queries.
  * The trace may be that of a whole run or of a SEGMENT of one (the K1 output of a row shard, zkir_delta_log_shard(log, a, b) with
  * cycle_base = a): the proof header records the 68-word state (cycle, pc limbs, register limbs, storage states) of the first and of
  * the last row and the AIR pins those rows to it; pub->n_real is then the segment's row count, pub->io_digest the RUN's. */

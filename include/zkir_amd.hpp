@@ -396,7 +396,7 @@ inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, c
   return PublicInputs(pub, std::move(blob));
 }
 
-// Full proof (u32 little-endian words, format v5) of a run whose execution trace is resident in HBM; the context must be built for
+// Full proof (u32 little-endian words, format zkir_proof_version()) of a run whose execution trace is resident in HBM; the context must be built for
 // zkir_padded_log_n(rows).  zkir_prover::verify is the host-side check (0 = accepted).
 inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::ExecutionResult& result, const zkir_public_inputs& pub, void* hip_stream = nullptr) {
   uint32_t* words = nullptr;

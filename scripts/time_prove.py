@@ -12,7 +12,7 @@ t_host = time.perf_counter() - t0
 ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr)); torch.cuda.synchronize()
 ctx = stark.StarkContext(k)
 pub = rt.public_inputs(log, spec.fib_endless_program().to_bytes())
-names = ["main_trace", "lde", "trace_merkle", "quotient+merkle", "openings", "deep", "fri", "queries"]
+names = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient+merkle", "openings", "deep", "fri", "queries"]
 best = None
 for it in range(3):
     t0 = time.perf_counter(); proof, ms = stark.prove(ctx, tr, pub, want_stage_ms=True); wall = (time.perf_counter() - t0) * 1e3

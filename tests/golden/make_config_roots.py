@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/config_roots.json: the trace-commitment root of BASELINE configs[1] (2^20-cycle fib, 152 committed columns, blow-up 2) and of
+smaller sizes of the same run, computed by the CPU ORACLE alone (oracle/zkir_oracle.cpp executes, oracle/stark_oracle.cpp commits: textbook
+arithmetic, one thread).  tests/test_gpu_large.py compares the GPU's root with it word for word: "bit-exact root vs CPU" at the size the config names.
+
+What this pins: nothing outside this repository — the commit stage is self-defined (the reference has no prover); the file makes the GPU
+and the independent CPU statement of the same spec agree AT FULL SIZE, where the test suite otherwise samples.
+
+Does not import the product.  Run: python tests/golden/make_config_roots.py [max_log2_rows=20]   (2^20 rows: ~4 minutes, ~3 GB)
+"""
+import json
+import os
+import struct
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
+
+ADD, ADDI, BNE, JAL = 0x00, 0x08, 0x41, 0x48
+
+
+def r_(op, rd, rs1, rs2): return op | rd << 7 | rs1 << 11 | rs2 << 15
+def i_(op, rd, rs1, imm): return op | rd << 7 | rs1 << 11 | (imm & 0x1FFFF) << 15
+def j_(op, rd, off): return op | rd << 7 | (off & 0x1FFFFF) << 11
+
+
+def blob(code):
+    hdr = struct.pack("<IIBBBBIIIII", 0x52494B5A, 0x00030004, 20, 2, 2, 0, 0x1000, 4 * len(code), 0, 0, 1 << 20)
+    return hdr + b"".join(struct.pack("<I", w & 0xFFFFFFFF) for w in code)
+
+
+# the v3.4 fib loop of tests/cross_module.rs:145-164 with a back edge instead of the exit (configs 2-4), halted by max_cycles
+FIB_LOOP = [r_(ADD, 4, 1, 2), i_(ADDI, 1, 2, 0), i_(ADDI, 2, 4, 0), i_(ADDI, 3, 3, -1), i_(BNE, 3, 0, -16)]
+FIB_ENDLESS = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 1), i_(ADDI, 3, 0, 0)] + FIB_LOOP + [j_(JAL, 0, -20)])
+
+
+def main():
+    kmax = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_roots.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    out["_about"] = ("trace-commitment roots (Poseidon2-12 Merkle over the blow-up-2 coset LDE of the 152 committed main-trace columns) of the fib_endless run halted at "
+                     "2^k cycles, written by tests/golden/make_config_roots.py from the CPU oracle alone; self-defined stages: parity UNPINNED vs seceq/zkir "
+                     "(it has no prover) — the file makes GPU == independent CPU statement literal at the size BASELINE configs[1] names")
+    out["program_blob_hex"] = FIB_ENDLESS.hex()
+    roots = out.setdefault("roots", {})
+    for k in sorted(set([12, 16, 18, kmax])):
+        if str(k) in roots:
+            continue
+        t0 = time.time()
+        rows = oracle.run(FIB_ENDLESS, max_cycles=1 << k, enable_execution_trace=True).rows
+        root = so.commit_trace(rows, 1)
+        roots[str(k)] = {"rows": 1 << k, "root": [int(x) for x in root], "oracle_seconds": round(time.time() - t0, 1)}
+        print(k, roots[str(k)], flush=True)
+        json.dump(out, open(path, "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -316,3 +316,48 @@ def test_config4_sha_chain_2p22_syscall_chip_columns():
         assert np.array_equal(cols[:, b], wit["flat"])
         assert cols[600:608, b].astype(">u4").tobytes() == hashlib.sha256(blk).digest()
     res.close()
+
+
+@pytest.mark.parametrize("log_n", [24, 25, 26])
+def test_lde_matches_oracle_at_config_sizes(log_n):
+    """The LDE pass structures of the big configs against the oracle DIRECTLY: 14 / 15 / 16 strided stages on each side of the fused
+    middle = 10 + 4 (2^24), 10 + 3 + 2 (2^25), 10 + 6 (2^26) (ntt.hip: run_strided_stages).  One B8 block, two random columns (the oracle's textbook NTT
+    takes ~1 minute per 2^26-point column), the other six zero — they must come out zero."""
+    import torch
+    from zkir_amd import stark
+    if torch.cuda.mem_get_info()[1] < (28 << log_n) + (4 << 30):
+        pytest.skip("not enough HBM")
+    n = 1 << log_n
+    rng = np.random.default_rng(1000 + log_n)
+    mat = rng.integers(0, P, (2, n)).astype(np.uint32)
+    ctx = stark.StarkContext(log_n)
+    out = stark.lde(ctx, stark.to_b8(torch.from_numpy(mat.view(np.int32)).cuda()), clobber=True)
+    assert not out[0, :, 2:].any()
+    got = stark.from_b8(out, 2).cpu().numpy().view(np.uint32)
+    del out
+    for k in range(2):
+        assert np.array_equal(got[k], so.lde(mat[k], 1)[1]), f"column {k}"
+    ctx.close()
+
+
+@pytest.mark.parametrize("k", [16, 18, 20])
+def test_commitment_root_equals_the_oracles_at_config_size(k):
+    """BASELINE configs[1] says "bit-exact root vs CPU": the GPU's trace-commitment root of the 2^20-cycle fib run (and of two smaller sizes) equals the root
+    the CPU oracle computed for it — tests/golden/config_roots.json, written by tests/golden/make_config_roots.py from the oracle alone (4 minutes of
+    textbook arithmetic at 2^20: too slow to repeat in every test run, which is why it is a fixture)."""
+    import json
+    import os
+    from zkir_amd import pipeline as pl, stark
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_roots.json")))
+    blob = spec.fib_endless_program().to_bytes()
+    assert blob.hex() == gold["program_blob_hex"]
+    n = 1 << k
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    ctx = stark.StarkContext(k)
+    root, _, _ = stark.commit_trace(ctx, tr)
+    assert [int(x) for x in root] == gold["roots"][str(k)]["root"]
+    # the proof of the same run commits to the same trace
+    proof = stark.prove(ctx, tr, rt.public_inputs(log, blob))
+    assert stark.trace_root(proof) == gold["roots"][str(k)]["root"]
+    ctx.close(); log.close()

@@ -56,8 +56,8 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // LOGICAL vs COMMITTED columns (proof format v7).  W and the C_* map are the LOGICAL main trace: what the constraints talk about.  Columns
 // that are identically zero by the constraints themselves are not committed: R0's three limbs and its storage state (R0 is hard-wired
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
-// committed matrix is the logical one with those columns removed, zero-padded to whole B8 blocks: 144 columns in default mode (exactly),
-// 160 in deferred mode (159 + 1); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
+// committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
+// 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
 constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
@@ -78,7 +78,7 @@ constexpr int W_AUX = 40;
 enum : int { A_H = 0, A_HR = 32, A_S = 36 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
 BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
-// per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^10, T / N
+// per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^N_TUPLE (= 11), T / N
 enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), N_LK = LK_TN + 4 };
 BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : j == 9 ? C_OPC : C_G; }
 // AIR v3: class ids (= opclass values of the instruction word; halt / pad are row roles, not word classes).  A FAMILY is a pair of opcodes

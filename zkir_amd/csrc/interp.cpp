@@ -249,10 +249,10 @@ class Machine {
 
   Status run() {                                                       // the loop is specialised on the three mode flags
     if (tracing_ && win_begin_ > 0) {                                  // fast-forward: same semantics, nothing recorded
-      tracing_ = false;
+      tracing_ = false; skipping_ = true;                              // (skipping_: the side logs — range-check witnesses, normalization events — of the skipped rows are not recorded either)
       stop_at_ = win_begin_;
       Status st = dispatch();
-      tracing_ = true;
+      tracing_ = true; skipping_ = false;
       if (!st.ok()) return st;
       // side logs of the skipped rows do not belong to the window
       log_.rc_events.clear(); log_.rc_offsets.clear(); log_.rc_cycles.clear(); log_.norm_events.clear(); log_.sha_blocks.clear();
@@ -341,7 +341,7 @@ class Machine {
   inline void normalize_silent(uint8_t r) { if (r && state_[r]) renormalize(r); }                 // normalize.rs:65-106
   inline void normalize_observed(uint8_t r, uint8_t opcode) {                                     // normalize.rs:121-154 + execute.rs:903-929
     if (!r) return;
-    log_.norm_events.push(zkir_norm_event{cycle_, fetch_pc_, reg_[r], r, state_[r], opcode, {0, 0, 0, 0, 0}});
+    if (!skipping_) log_.norm_events.push(zkir_norm_event{cycle_, fetch_pc_, reg_[r], r, state_[r], opcode, {0, 0, 0, 0, 0}});
     renormalize(r);
   }
   inline void write_accumulated(uint8_t r, const uint64_t l[2]) { if (r) { wr_value(r, l[0] | (l[1] << 30)); wr_state(r, 1); } }  // state.rs:184-192
@@ -355,7 +355,7 @@ class Machine {
   const zkir_vm_config cfg_;
   DeltaLog& log_;
   const uint64_t* inputs_; size_t n_inputs_; size_t input_pos_ = 0;
-  bool tracing_, deferred_, range_;
+  bool tracing_, deferred_, range_, skipping_ = false;
   uint32_t data_bits_;
 
   uint64_t pc_ = 0, fetch_pc_ = 0, cycle_ = 0;
@@ -587,8 +587,10 @@ bool Machine::hash_syscall(int which) {
 }
 
 void Machine::flush_range_checks() {                      // RangeCheckTracker::checkpoint, range_check.rs:140-168
-  for (const PendingCheck& p : pending_) log_.rc_events.push(zkir_rc_event{p.value40, p.pc});
-  if (!pending_.empty()) { log_.rc_offsets.push_back(log_.rc_events.size()); log_.rc_cycles.push_back(cycle_); }   // vm.rs:340-342: empty witnesses are dropped
+  if (!skipping_) {                                       // (a window's fast-forward keeps the tracker's state in step and records nothing)
+    for (const PendingCheck& p : pending_) log_.rc_events.push(zkir_rc_event{p.value40, p.pc});
+    if (!pending_.empty()) { log_.rc_offsets.push_back(log_.rc_events.size()); log_.rc_cycles.push_back(cycle_); }   // vm.rs:340-342: empty witnesses are dropped
+  }
   pending_.clear();
 }
 

@@ -4,7 +4,7 @@
 // kernel here is checked bit-for-bit against it.  Stage A (this part): main-trace field columns, Poseidon2-12 Merkle commitment
 // (the coset LDE between them lives in ntt.hip).
 //
-//   main_trace_kernel   372 B/row SoA trace -> the 169 logical Baby Bear columns of the AIR (152 committed) (air.h: limbs of pc / instruction fields /
+//   main_trace_kernel   372 B/row SoA trace -> the 172 logical Baby Bear columns of the AIR (152 committed by default, 168 deferred) (air.h: limbs of pc / instruction fields /
 //                       registers, storage state, write and operand selectors, operands, result, opcode classes, range chunks, carries),
 //                       padded to a power of two, written in the B8 layout (blocks of 8 columns, [rows][8]).  HBM-bound: ~170 B
 //                       read (values + states of the row and the next) + 608 B written per row.

@@ -560,7 +560,7 @@ struct Arena {
   }
 };
 struct StageEvents {             // RAII: released on every return path
-  hipEvent_t ev[9]; bool on = false;
+  hipEvent_t ev[10]; bool on = false;
   hipError_t create() { for (auto& e : ev) { const hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; } on = true; return hipSuccess; }
   ~StageEvents() { if (on) for (auto& e : ev) (void)hipEventDestroy(e); }
 };
@@ -631,7 +631,8 @@ uint32_t zkir_proof_version(void) { return PROOF_VERSION; }
 void zkir_proof_free(uint32_t* proof) { free(proof); }
 
 // Full proof of the run whose K1 output is `trace` (pub->n_real executed rows, padded to 2^ctx.log_n).  Phases are timed with HIP events
-// when stage_ms != NULL: [0] main trace, [1] LDE, [2] trace Merkle, [3] quotient (+Merkle), [4] openings, [5] DEEP, [6] FRI (+grinding), [7] queries.
+// when stage_ms != NULL (NINE floats): [0] main trace (+ lookup indices), [1] LDE, [2] trace Merkle, [3] lookup argument (inverse tables, aux trace, its LDE and
+// Merkle tree), [4] quotient (+Merkle), [5] openings, [6] DEEP, [7] FRI (+grinding), [8] queries.
 int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const zkir_public_inputs* pub, uint32_t** proof_out, uint64_t* proof_words, float* stage_ms,
                void* stream) {
   if (!c || !trace || !pub || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
@@ -732,6 +733,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, m});
     return ZKIR_ERR_ARGUMENT;
   }
+  mark(3);
   std::vector<uint32_t> head;
   header_words(log_n, *pub, bound, head);
   Challenger ch(c->consts);
@@ -769,7 +771,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipStreamSynchronize(s));
     ch.observe_n(aroot, 4);
   }
-  mark(3);
+  mark(4);
   const E4 alpha = ch.sample_ext();
 
   // ---- 2. quotient ------------------------------------------------------------------------------------------------------------
@@ -794,7 +796,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   rc = merkle_commit(c, dQ, 4, N2, dQTree, /*mont_in=*/true, s); if (rc) return rc;
   HIP_OK(hipMemcpyAsync(qroot, dQTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
-  mark(4);
+  mark(5);
   ch.observe_n(qroot, 4);
   const E4 zeta = ch.sample_ext();
   const E4 zeta_w = bb::E4{{bb::mul(zeta.c[0], wn), bb::mul(zeta.c[1], wn), bb::mul(zeta.c[2], wn), bb::mul(zeta.c[3], wn)}};
@@ -825,7 +827,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       if (k < WT) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WT] = va;
     }
   }
-  mark(5);
+  mark(6);
   for (int k = 0; k < WT; k++) ch.observe_n(t_z[k].c, 4);
   for (int k = 0; k < WT; k++) ch.observe_n(t_zw[k].c, 4);
   for (int i = 0; i < 4; i++) ch.observe_n(q_z[i].c, 4);
@@ -847,7 +849,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   }
   HIP_OK(ar.take(&fri_layers[0], 4 * N2));
   hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, WM, fri_layers[0]);
-  mark(6);
+  mark(7);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
   std::vector<std::array<uint32_t, 4>> lroots(n_layers);
@@ -901,7 +903,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     }
     if (pow_nonce == 0xFFFFFFFFu || !ch.check_pow(pow_nonce)) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: proof-of-work search failed"}); return ZKIR_ERR_OTHER; }
   }
-  mark(7);
+  mark(8);
   std::vector<uint32_t> queries(NUM_QUERIES);
   for (auto& q : queries) q = ch.sample_bits((int)log_n);
 
@@ -955,10 +957,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess || check_launch("zkir_prove") != ZKIR_OK) { free(out); if (e != hipSuccess) zkir::set_last_error({ZKIR_ERR_DEVICE, hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
   for (size_t t = 0; t < queries.size(); t++) out[head.size() + qpos[t]] = queries[t];
-  mark(8);
+  mark(9);
   if (stage_ms) {
-    (void)hipEventSynchronize(se.ev[8]);
-    for (int i = 0; i < 8; i++) (void)hipEventElapsedTime(&stage_ms[i], se.ev[i], se.ev[i + 1]);
+    (void)hipEventSynchronize(se.ev[9]);
+    for (int i = 0; i < 9; i++) (void)hipEventElapsedTime(&stage_ms[i], se.ev[i], se.ev[i + 1]);
   }
   *proof_out = out; *proof_words = total;
   return ZKIR_OK;

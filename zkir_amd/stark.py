@@ -15,7 +15,7 @@ from . import pipeline as pl
 from . import runtime as rt
 
 P = 2013265921
-W_MAIN = 152                 # COMMITTED main-trace columns of a default-mode run (zkir_main_trace_width); the AIR has 169 logical columns (air.h)
+W_MAIN = 152                 # COMMITTED main-trace columns of a default-mode run (zkir_main_trace_width); the AIR has 172 logical columns (air.h: W)
 W_MAIN_DEFERRED = 168        # deferred mode: the storage states are committed too
 W_AUX = 40                  # aux trace of the lookup argument (air.h): H0..H7, HR, S as four base columns each
 RC_TABLE = 1024
@@ -23,7 +23,7 @@ HEADER_WORDS = 157
 
 
 def proof_layout(proof) -> dict:
-    """Word offsets inside a format-v6 proof (same layout as v5): header | program (byte length, 16-bit halfwords) | ROM multiplicities | range multiplicities |
+    """Word offsets inside a proof (format v5 on; the current format is zkir_proof_version()): header | program (byte length, 16-bit halfwords) | ROM multiplicities | range multiplicities |
     trace root | aux root | quotient root | openings ..."""
     blob_len = int(proof[HEADER_WORDS])
     at = HEADER_WORDS + 1
@@ -152,7 +152,7 @@ def prove(ctx: StarkContext, trace, pub: rt.PublicInputsC, stream=None, want_sta
     cols = trace.c if hasattr(trace, "c") else trace
     out = C.POINTER(C.c_uint32)()
     n_words = C.c_uint64()
-    ms = (C.c_float * 8)()
+    ms = (C.c_float * 9)()
     pl._check(rt.lib().zkir_prove(ctx.handle, C.byref(cols), C.byref(pub), C.byref(out), C.byref(n_words), ms if want_stage_ms else None, _sp(stream)))
     proof = np.ctypeslib.as_array(out, shape=(n_words.value,)).copy()
     rt.lib().zkir_proof_free(out)
