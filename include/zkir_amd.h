@@ -291,6 +291,10 @@ int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uin
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */
 int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out);
+/* EXPERIMENT: zkir_main_trace_launch + zkir_lde_launch (default VM mode) with the first two blocks of the main trace never written: the
+ * extension's first inverse pass generates them from the trace.  m = scratch for the main-trace matrix (as zkir_main_trace_launch's out), out = the LDE.
+ * Same output as the two calls; ZKIR_ERR_ARGUMENT where it does not apply (padded log2 rows < 20 or = 21).  Measured in profiles/r04*_fused01*. */
+int zkir_commit_fused01_launch(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* hip_stream);
 /* Test entry points of the AIR evaluation as the quotient kernel runs it (stark_prove.inl: QuotientOps — lazy 32-bit arithmetic, 96-bit sums, one
  * accumulator per row selector), host builds of the same code; nothing in the product calls them.
  * zkir_air_eval_host: sum_c alpha^c C_c (canonical E4 -> out4) of one (row, next row) pair given as LOGICAL columns (172 main, 40 aux; canonical

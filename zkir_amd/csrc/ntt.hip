@@ -84,15 +84,44 @@ __global__ __launch_bounds__(NT) void ntt_stage_kernel(uint4* __restrict__ data,
   else { x[(uint64_t)p * 2 + h] = add4(a, b); x[(uint64_t)(p + stride) * 2 + h] = mul4(subl4(a, b), w); }
 }
 
+// ---- EXPERIMENT (round 4): the first inverse pass GENERATING its input instead of reading it — blocks 0 and 1 of the main trace (cycle, pc limbs,
+// the instruction's fields, the limbs of R1, R2 and R3's first: nothing but loads of the row's own trace words) are computed in the load stage from the
+// 372-B trace, so main_trace_kernel need not write them and this pass need not read them back.  Words as stark.hip: main_trace_row writes them.
+struct TraceSrc01 { zkir_trace_columns t; uint64_t n_real; };
+__device__ __forceinline__ u32x4 trace_quad01(const TraceSrc01& q, uint32_t blk, uint32_t half, uint64_t i) {
+  const bool pad = i >= q.n_real;
+  const uint64_t src = pad ? q.n_real - 1 : i;
+  u32x4 r;
+  if (blk == 0 && half == 0) {
+    const uint64_t pcv = q.t.pc[src];
+    r.x = (uint32_t)((q.t.cycle[src] + (i - src)) % bb::P); r.y = (uint32_t)(pcv & 0xFFFFF); r.z = (uint32_t)((pcv >> 20) & 0xFFFFF); r.w = (uint32_t)(pcv >> 40);
+  } else if (blk == 0) {
+    const uint32_t w = q.t.instruction[src];
+    r.x = w & 0x7F; r.y = (w >> 7) & 0xF; r.z = (w >> 11) & 0xF; r.w = (w >> 15) & 0xF;
+  } else {
+    auto limbs = [&](int g, uint32_t out[3]) {
+      const uint64_t o = (uint64_t)g * q.t.reg_stride + src;
+      const uint64_t v = q.t.registers[o];
+      const int bits = q.t.reg_state[o] ? 30 : 20;
+      const uint64_t mask = (1ull << bits) - 1;
+      out[0] = (uint32_t)(v & mask); out[1] = (uint32_t)((v >> bits) & mask); out[2] = (uint32_t)(v >> (2 * bits));
+    };
+    uint32_t a[3], b[3];
+    if (half == 0) { limbs(1, a); r.x = q.t.instruction[src] >> 19; r.y = a[0]; r.z = a[1]; r.w = a[2]; }
+    else { limbs(2, a); limbs(3, b); r.x = a[0]; r.y = a[1]; r.z = a[2]; r.w = b[0]; }
+  }
+  return r;
+}
+
 // ---- strided radix-4 pass: 2R radix-2 stages (R register-resident radix-4 rounds) over tiles of 2^(2R) rows x 2^C positions, in
 // place, one column block per blockIdx.y.  With R = 5 a single pass covers ten stages (tile 1024 x 2 positions x 32 B = 64 KiB of
 // LDS), so a 2^20-row matrix needs ONE strided pass on each side of the fused middle kernel.  A lane owns one quad of positions and
 // runs it for both halves of the block (eight columns) with one set of twiddles: a read of a compact table (root of order <= 1024 /
 // 2048) times a per-lane running power; the other stage's twiddle is its square and the odd pair's is its product with a 4th root.
 // LDS holds the two halves as separate planes so that consecutive lanes touch consecutive 16-byte words.
-template <bool DIT, int R, int C, int NTH>
+template <bool DIT, int R, int C, int NTH, bool FUSED = false>
 __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__ data, uint64_t blk_u4, uint32_t tiles_per_block, uint32_t total, int L, int s0,
-                                                              const uint32_t* __restrict__ tw, const uint32_t* __restrict__ small, int log_small, uint32_t j4_m) {
+                                                              const uint32_t* __restrict__ tw, const uint32_t* __restrict__ small, int log_small, uint32_t j4_m, TraceSrc01 fsrc = TraceSrc01{}) {
   constexpr int B = 2 * R;
   constexpr uint32_t POS = 1u << (B + C), QUADS = POS / 4, CMASK = (1u << C) - 1, PLANE = POS + 4;       // +4: the two planes start in different banks
   constexpr uint32_t MOVES = 2 * POS / NTH;
@@ -132,7 +161,8 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
   static_for<0, (int)MOVES>([&](auto kc) {                                     // tile rows are 2^C consecutive positions = 2^(C+1) uint4
     constexpr uint32_t k = decltype(kc)::value;
     const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-    pre[k] = ld4(&x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv]);
+    if constexpr (FUSED) pre[k] = trace_quad01(fsrc, w / tiles_per_block, wv & 1, (uint64_t)base + (uint64_t)row * stride_mid + (wv >> 1));
+    else pre[k] = ld4(&x[((uint64_t)base + (uint64_t)row * stride_mid) * 2 + wv]);
   });
   uint32_t tw_cur = DIT ? tw[(lo0 + (threadIdx.x & CMASK)) << (L - s0 - B)] : tw[(lo0 + (threadIdx.x & CMASK)) << s0];
   for (;;) {
@@ -159,7 +189,8 @@ __global__ __launch_bounds__(NTH) void ntt_strided_r4_kernel(uint4* __restrict__
       static_for<0, (int)MOVES>([&](auto kc) {
         constexpr uint32_t k = decltype(kc)::value;
         const uint32_t e = threadIdx.x + k * NTH, row = e >> (C + 1), wv = e & ((2u << C) - 1);
-        pre[k] = ld4(&xn[((uint64_t)base_n + (uint64_t)row * stride_mid) * 2 + wv]);
+        if constexpr (FUSED) pre[k] = trace_quad01(fsrc, wn / tiles_per_block, wv & 1, (uint64_t)base_n + (uint64_t)row * stride_mid + (wv >> 1));
+        else pre[k] = ld4(&xn[((uint64_t)base_n + (uint64_t)row * stride_mid) * 2 + wv]);
       });
       tw_cur = DIT ? tw[(lo0_n + (threadIdx.x & CMASK)) << (L - s0 - B)] : tw[(lo0_n + (threadIdx.x & CMASK)) << s0];
     }
@@ -294,10 +325,11 @@ inline unsigned cu_count() {
 }
 inline int persist() { static const int v = getenv("ZKIR_NTT_PERSIST") ? atoi(getenv("ZKIR_NTT_PERSIST")) : 1; return v; }
 
-template <bool DIT, int R, int C, int NTH>
-void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int s0, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m, hipStream_t s) {
+template <bool DIT, int R, int C, int NTH, bool FUSED = false>
+void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int s0, const uint32_t* tw, const uint32_t* small, int log_small, uint32_t j4_m, hipStream_t s,
+                       const TraceSrc01* fsrc = nullptr) {
   constexpr size_t lds = 16u * 2 * ((1u << (2 * R + C)) + 4);
-  auto k = ntt_strided_r4_kernel<DIT, R, C, NTH>;
+  auto k = ntt_strided_r4_kernel<DIT, R, C, NTH, FUSED>;
   static std::atomic<uint64_t> attr_done{0};                                   // one bit per device id: the attribute is per (function, device)
   int dev = 0; (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
@@ -306,7 +338,7 @@ void launch_strided_r4(uint32_t* data, uint64_t n, uint32_t n_blocks, int L, int
   const unsigned per_cu = (unsigned)((160u << 10) / lds) > 0 ? (unsigned)((160u << 10) / lds) : 1u;       // workgroups resident per CU (LDS-limited)
   unsigned grid = persist() ? cu_count() * (per_cu > 8 ? 8 : per_cu) : total;
   if (grid > total) grid = total;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), lds, s, (uint4*)data, 2 * n, tiles, total, L, s0, tw, small, log_small, j4_m);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), lds, s, (uint4*)data, 2 * n, tiles, total, L, s0, tw, small, log_small, j4_m, fsrc ? *fsrc : TraceSrc01{});
 }
 
 inline int strided_c() { static const int c = getenv("ZKIR_NTT_C") ? atoi(getenv("ZKIR_NTT_C")) : 2; return c; }
@@ -529,6 +561,33 @@ void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out,
   }
   // forward DIT strided stages 11 .. L of the size-2N transform
   run_strided_stages<true>(out, (uint64_t)2 * N, n_blocks, L + 1, 11, L - 10, t.tw_fwd, t.small_fwd, 11, j4_fwd_m, r8_fwd_m, r8_fwd3_m, s);
+}
+
+
+// EXPERIMENT: the same extension with blocks 0 and 1 of `in` NOT read by the first inverse pass — generated from the trace instead (trace_quad01).  Only for
+// traces whose first inverse pass is the ten-stage one (log_n >= 20, log_n != 21); returns false (nothing launched) otherwise.
+bool lde_run_fused01(const LdeTables& t, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* in, uint32_t n_blocks, uint32_t* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int L = t.log_n;
+  if (L < 20 || L == 21 || n_blocks < 3 || strided_c() != 2) return false;
+  const uint32_t N = 1u << L;
+  static const uint32_t j4_inv_m = bb::to_mont(bb::inv(bb::root_of_unity(2))), j4_fwd_m = bb::to_mont(bb::root_of_unity(2));
+  static const uint32_t r8_fwd = bb::root_of_unity(3), r8_inv = bb::inv(r8_fwd);
+  static const uint32_t r8_inv_m = bb::to_mont(r8_inv), r8_inv3_m = bb::to_mont(bb::mul(bb::mul(r8_inv, r8_inv), r8_inv));
+  static const uint32_t r8_fwd_m = bb::to_mont(r8_fwd), r8_fwd3_m = bb::to_mont(bb::mul(bb::mul(r8_fwd, r8_fwd), r8_fwd));
+  const TraceSrc01 src{*trace, n_real};
+  launch_strided_r4<false, 5, 2, 1024, true>(in, N, 2, L, 0, t.tw_inv, t.small_inv, 10, j4_inv_m, s, &src);                         // blocks 0, 1: generated
+  launch_strided_r4<false, 5, 2, 1024>(in + (uint64_t)2 * N * 8, N, n_blocks - 2, L, 0, t.tw_inv, t.small_inv, 10, j4_inv_m, s);     // the others: read
+  if (L - 10 > 10) run_strided_stages<false>(in, N, n_blocks, L, 10, L - 20, t.tw_inv, t.small_inv, 10, j4_inv_m, r8_inv_m, r8_inv3_m, s);
+  {
+    const uint32_t chunks = N >> 10, total = chunks * n_blocks;
+    unsigned grid = persist() ? cu_count() * 2 : total;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL(lde_middle_r4_kernel, dim3(grid), dim3(MID_NT), 0, s, (const uint4*)in, (uint4*)out, chunks, total, L, t.small_inv, t.small_fwd, t.g_lo, t.g_hi,
+                       j4_inv_m, j4_fwd_m);
+  }
+  run_strided_stages<true>(out, (uint64_t)2 * N, n_blocks, L + 1, 11, L - 10, t.tw_fwd, t.small_fwd, 11, j4_fwd_m, r8_fwd_m, r8_fwd3_m, s);
+  return true;
 }
 
 }  // namespace zkir

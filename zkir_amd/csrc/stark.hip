@@ -67,7 +67,8 @@ BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
 // DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 152 columns by default, 168 deferred.
 // The row itself is a host + device function: the kernel below runs it once per lane, zkir_main_trace_host once per row on the CPU — the same
 // code, so the CPU test suite (no GPU) checks it against the oracle column by column (tests/test_abi.py).
-template <bool DEF>
+// SKIP: the first SKIP blocks are not stored (experiment, DESIGN.md §9: the LDE's first pass generates them itself — zkir_lde_fused01_launch)
+template <bool DEF, int SKIP = 0>
 BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t N, uint64_t i, uint32_t* __restrict__ out) {
   using namespace air;
   constexpr uint32_t deferred = DEF ? 1u : 0u;
@@ -201,16 +202,16 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   uint4* out4 = reinterpret_cast<uint4*>(out);
   auto at = [&](int p) -> uint32_t { return p < committed_used(DEF) ? rowv[logical_col(p < committed_used(DEF) ? p : 0, DEF)] : 0u; };   // (inner clamp: the index stays inside rowv for the padding positions too)
 #pragma unroll
-  for (int b = 0; b < committed_width(DEF) / 8; b++) {
+  for (int b = SKIP; b < committed_width(DEF) / 8; b++) {
     out4[((uint64_t)b * N + i) * 2] = make_uint4(at(8 * b), at(8 * b + 1), at(8 * b + 2), at(8 * b + 3));
     out4[((uint64_t)b * N + i) * 2 + 1] = make_uint4(at(8 * b + 4), at(8 * b + 5), at(8 * b + 6), at(8 * b + 7));
   }
 }
-template <bool DEF>
+template <bool DEF, int SKIP = 0>
 __global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
-  main_trace_row<DEF>(t, n_real, N, i, out);
+  main_trace_row<DEF, SKIP>(t, n_real, N, i, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,6 +508,18 @@ int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uin
   else hipLaunchKernelGGL(main_trace_kernel<false>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
   return check_launch("main_trace");
 }
+// EXPERIMENT: main trace without its first two blocks + the extension whose first inverse pass generates them from the trace.
+// Together they are zkir_main_trace_launch + zkir_lde_launch with 128 B/row less HBM traffic; same output.  Returns ZKIR_ERR_ARGUMENT where the fused pass
+// does not apply (log_n < 20 or = 21, deferred mode).
+int zkir_commit_fused01_launch(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* stream) {
+  if (!c || !trace || !m || !out || n_real == 0 || zkir_padded_log_n(n_real) != c->log_n) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_commit_fused01_launch: bad argument"}); return ZKIR_ERR_ARGUMENT; }
+  const uint64_t N = (uint64_t)1 << c->log_n;
+  hipLaunchKernelGGL((main_trace_kernel<false, 2>), dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, m);
+  const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
+  if (!zkir::lde_run_fused01(t, trace, n_real, m, (width + 7) / 8, out, stream)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_commit_fused01_launch: not applicable at this size"}); return ZKIR_ERR_ARGUMENT; }
+  return check_launch("commit_fused01");
+}
+
 // The same rows on the host (trace = HOST pointers, out = host buffer of zkir_main_trace_width_for(deferred) / 8 blocks [N][8]): main_trace_row is one
 // host + device function, so what the kernel computes can be checked without a GPU.  A test / diagnostic entry point, not a fallback: nothing in the
 // product calls it.
