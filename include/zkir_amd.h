@@ -295,6 +295,9 @@ int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint3
  * extension's first inverse pass generates them from the trace.  m = scratch for the main-trace matrix (as zkir_main_trace_launch's out), out = the LDE.
  * Same output as the two calls; ZKIR_ERR_ARGUMENT where it does not apply (padded log2 rows < 20 or = 21).  Measured in profiles/r04*_fused01*. */
 int zkir_commit_fused01_launch(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* hip_stream);
+/* EXPERIMENT: one strided NTT pass (stage 0 of the inverse transform over 2^log_n rows, or stage 11 of the forward one over 2^(log_n + 1)) with tile geometry `variant`
+ * (ntt.hip: strided_variant_run lists them) over `width` columns: for timing the tilings side by side (scripts/time_ntt_tiles.py); the data is left partially transformed. */
+int zkir_ntt_strided_variant_launch(const zkir_stark_ctx* ctx, uint32_t* data, uint32_t width, int variant, int forward, void* hip_stream);
 /* Test entry points of the AIR evaluation as the quotient kernel runs it (stark_prove.inl: QuotientOps — lazy 32-bit arithmetic, 96-bit sums, one
  * accumulator per row selector), host builds of the same code; nothing in the product calls them.
  * zkir_air_eval_host: sum_c alpha^c C_c (canonical E4 -> out4) of one (row, next row) pair given as LOGICAL columns (172 main, 40 aux; canonical

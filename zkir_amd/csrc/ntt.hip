@@ -564,6 +564,34 @@ void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out,
 }
 
 
+// EXPERIMENT (profiles/r04*_lde_tile_variants.txt): ONE strided pass at stage 0 over n_blocks blocks of 2^log_n rows with a chosen tile geometry — the timing of the
+// tilings side by side on the same data (the values are a partial transform: only the time means anything).
+//   0: 10 stages, 1024 rows x 4 positions (128-byte rows), 128 KiB, 1024 lanes: one workgroup per CU   (what lde_run uses)
+//   1: 10 stages, 1024 rows x 2 positions (64-byte rows),   64 KiB,  512 lanes: two per CU
+//   2:  8 stages,  256 rows x 8 positions (256-byte rows),  64 KiB,  512 lanes: two per CU
+//   3:  8 stages,  256 rows x 4 positions (128-byte rows),  32 KiB,  256 lanes: four or five per CU
+//   4:  6 stages,   64 rows x 16 positions,                 32 KiB,  256 lanes
+bool strided_variant_run(const LdeTables& t, uint32_t* data, uint32_t n_blocks, int variant, bool dit, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int L = dit ? t.log_n + 1 : t.log_n;
+  if (t.log_n < 20) return false;
+  const uint64_t n = (uint64_t)1 << L;
+  static const uint32_t j4_inv_m = bb::to_mont(bb::inv(bb::root_of_unity(2))), j4_fwd_m = bb::to_mont(bb::root_of_unity(2));
+  const uint32_t* tw = dit ? t.tw_fwd : t.tw_inv; const uint32_t* sm = dit ? t.small_fwd : t.small_inv;
+  const int ls = dit ? 11 : 10; const uint32_t j4 = dit ? j4_fwd_m : j4_inv_m; const int s0 = dit ? 11 : 0;
+#define ZKIR_VARIANT(R, C, NTH) do { if (dit) launch_strided_r4<true, R, C, NTH>(data, n, n_blocks, L, s0, tw, sm, ls, j4, s); else launch_strided_r4<false, R, C, NTH>(data, n, n_blocks, L, s0, tw, sm, ls, j4, s); } while (0)
+  switch (variant) {
+    case 0: ZKIR_VARIANT(5, 2, 1024); break;
+    case 1: ZKIR_VARIANT(5, 1, 512); break;
+    case 2: ZKIR_VARIANT(4, 3, 512); break;
+    case 3: ZKIR_VARIANT(4, 2, 256); break;
+    case 4: ZKIR_VARIANT(3, 4, 256); break;
+    default: return false;
+  }
+#undef ZKIR_VARIANT
+  return true;
+}
+
 // EXPERIMENT: the same extension with blocks 0 and 1 of `in` NOT read by the first inverse pass — generated from the trace instead (trace_quad01).  Only for
 // traces whose first inverse pass is the ten-stage one (log_n >= 20, log_n != 21); returns false (nothing launched) otherwise.
 bool lde_run_fused01(const LdeTables& t, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* in, uint32_t n_blocks, uint32_t* out, void* stream) {

@@ -520,6 +520,13 @@ int zkir_commit_fused01_launch(const zkir_stark_ctx* c, const zkir_trace_columns
   return check_launch("commit_fused01");
 }
 
+// EXPERIMENT: one strided NTT pass with a chosen tile geometry over `width` columns of 2^log_n (inverse) / 2^(log_n + 1) (forward) rows: timing only (ntt.hip: strided_variant_run)
+int zkir_ntt_strided_variant_launch(const zkir_stark_ctx* c, uint32_t* data, uint32_t width, int variant, int forward, void* stream) {
+  const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
+  if (!zkir::strided_variant_run(t, data, (width + 7) / 8, variant, forward != 0, stream)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_ntt_strided_variant_launch: log_n < 20 or unknown variant"}); return ZKIR_ERR_ARGUMENT; }
+  return check_launch("ntt_strided_variant");
+}
+
 // The same rows on the host (trace = HOST pointers, out = host buffer of zkir_main_trace_width_for(deferred) / 8 blocks [N][8]): main_trace_row is one
 // host + device function, so what the kernel computes can be checked without a GPU.  A test / diagnostic entry point, not a fallback: nothing in the
 // product calls it.
