@@ -136,6 +136,35 @@ def _profiled_traffic(stage: str):
     return total, os.path.relpath(files[-1], ROOT)
 
 
+def _profiled_clock_ghz(kernel: str):
+    """Shader clock (GHz) `kernel` ran at in the newest committed counter pass: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / its duration."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_commit_valu_busy.txt")), reverse=True):
+        for line in open(path):
+            if line.startswith(kernel):
+                f = line.split()
+                try:
+                    return float(f[-3]) / 8 / (float(f[-6]) * 1e-6) / 1e9      # columns: .. avg_us, SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, VALUBusy, ipc
+                except (ValueError, IndexError, ZeroDivisionError):
+                    return None
+    return None
+
+
+def _check_traffic_source_is_fresh(path: str):
+    """The committed counter file `roofline.traffic` is read from must be at least as new as the last commit that touched the kernels it describes: compared
+    through git when the repository is there (it is not on the GPU box: then the check is skipped and says so)."""
+    import subprocess
+    try:
+        t_prof = int(subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--", path], stderr=subprocess.DEVNULL).strip() or 0)
+        t_kern = int(subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--", "zkir_amd/csrc/stark.hip", "zkir_amd/csrc/poseidon2.h", "zkir_amd/csrc/ntt.hip",
+                                              "zkir_amd/csrc/trace_fill.hip"], stderr=subprocess.DEVNULL).strip() or 0)
+    except (OSError, subprocess.CalledProcessError, ValueError):
+        return "unchecked (no git here)"
+    if not t_prof or not t_kern:
+        return "unchecked (no git history for the files)"
+    return "fresh" if t_prof >= t_kern else "STALE: the kernels were committed after this counter pass — re-run scripts/gpu_round.sh <tag> pmc and commit its summaries"
+
+
 def _profiled_valu_busy(kernel: str):
     """VALUBusy (0..1) of `kernel` from the newest committed rocprofv3 counter pass (profiles/*_valu_busy.txt), or None."""
     import glob
@@ -798,6 +827,7 @@ def main():
             # priced against the HBM peak as the contract asks — and against the roofline that does bound it (`alu`)
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_source_freshness": _check_traffic_source_is_fresh(traffic_source) if traffic_source else None,
                          "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (a file, NOT a counter read in this run)"
                                          if traffic is not None else None,
                          "kernel_ms": kernels[dom]["ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
@@ -809,7 +839,10 @@ def main():
                          # leaf_hash_kernel in the committed counter pass of this command (profiles/): the pipe is never idle
                          "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["mont_mul_per_s"], "peak": ALU_PEAK_MONT_MUL_PER_S, "peak_formula": ALU_PEAK_FORMULA,
                                   "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "peak_measured": alu_measured,
-                                  "mont_mul_per_permutation": MONT_MUL_PER_PERM, "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel")}
+                                  "mont_mul_per_permutation": MONT_MUL_PER_PERM, "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel"),
+                                  # the analytic peak assumes 2.4 GHz; under this kernel's load the chip clocks lower (counter pass): the same fraction at THAT clock
+                                  "clock_ghz_profiled": _profiled_clock_ghz("leaf_hash_kernel"),
+                                  "frac_at_measured_clock": (kernels[dom]["frac_of_alu_peak"] * 2.4 / _profiled_clock_ghz("leaf_hash_kernel")) if _profiled_clock_ghz("leaf_hash_kernel") else None}
                                  if kernels[dom]["bound"] == "int-alu" else None)},
             # `value` is rows/s of a commit over W self-chosen columns: the width-independent figures are per column of 2^20 rows
             "per_column": ({"main_trace_width": W, "rows": n,
