@@ -285,7 +285,7 @@ def _config2_fib_2p24(lib, sp, k=24):
         proof, pms = stark.prove(ctx, trace, pub, want_stage_ms=True)
         prove_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
-    verdict = rt.verify(proof, pub)
+    verdict = rt.verify_io(proof, pub, [], log.outputs, log.halt_reason)
     verify_ms = (time.perf_counter() - t0) * 1e3
     assert verdict == 0, f"bench: the 2^{k}-row proof was rejected (check {verdict})"
     step_ms = sum(stage_ms.values())
@@ -620,7 +620,7 @@ def main():
         prove_stage_ms = dict(zip(PROVE_STAGES, pms))
         proof_bytes = int(len(proof) * 4)
         t0 = time.perf_counter()
-        assert rt.verify(proof, pub) == 0, "bench: proof rejected by zkir_verify"
+        assert rt.verify_io(proof, pub, [], log.outputs, log.halt_reason) == 0, "bench: proof (or its I/O / halt claim) rejected by zkir_verify_io"
         verify_ms = (time.perf_counter() - t0) * 1e3
 
     # ---- N > 1: the run PROVEN, one segment per GPU (no data-path collective: a segment needs its own rows only); the proofs are

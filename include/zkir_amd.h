@@ -372,6 +372,14 @@ int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_i
  * of segment i. */
 int zkir_verify_segment(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect, uint32_t first_state[68], uint32_t last_state[68]);
 int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* proof_words, uint32_t n_segments, const zkir_public_inputs* expect);
+/* The run's CLAIM in the clear on top of zkir_verify / zkir_verify_chain (round 4): the I/O tapes and the halt reason (ZKIR_HALT_*, exit code) must hash to the proof's io
+ * digest together with the proof's row count (else 50), and the HALT ROW — the last executed row, pinned to the public last state by the AIR — must be the instruction the
+ * halt reason names, looked up in the program the proof carries: EBREAK for an Ebreak halt, ECALL reading R10 = 0 and R11 = the exit code for Exit(code) (52: another
+ * instruction; 53: another syscall / exit code) — vm.rs:302-347, syscall.rs:101-107.  CycleLimit names no instruction.  The outputs themselves stay unproven (air.h). */
+int zkir_verify_io(const uint32_t* proof, uint64_t words, const zkir_public_inputs* expect, const uint64_t* inputs, size_t n_inputs, const uint64_t* outputs, size_t n_outputs,
+                   int halt_kind, uint64_t halt_code);
+int zkir_verify_chain_io(const uint32_t* const* proofs, const uint64_t* words, uint32_t n_segments, const zkir_public_inputs* expect, const uint64_t* inputs, size_t n_inputs,
+                         const uint64_t* outputs, size_t n_outputs, int halt_kind, uint64_t halt_code);
 uint32_t zkir_proof_state_words(void);
 /* Host-side Poseidon2-12 permutation of the transcript (canonical words in and out; no device needed): what a verifier or an
  * integrator re-deriving the Fiat-Shamir challenges calls.  Same code as the device kernels (poseidon2.h), compiled for the host. */

@@ -255,6 +255,31 @@ def verify_segment(proof: np.ndarray, expect: PublicC | None = None):
     return rc, st[:68].copy(), st[68:].copy()
 
 
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(list(a), dtype=np.uint64))
+
+
+def verify_io(proof: np.ndarray, expect: PublicC | None, inputs, outputs, halt) -> int:
+    """verify + the claim in the clear: (inputs, outputs, halt = (kind, code)) hash to the proof's io digest with its row count (50) and the halt row is the
+    instruction the halt reason names (52) with the claimed exit code (53)."""
+    proof, i, o = _u32(proof), _u64(inputs), _u64(outputs)
+    L = lib()
+    L.so_verify_io.restype = C.c_int
+    L.so_verify_io.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64]
+    return L.so_verify_io(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None, i.ctypes.data, len(i), o.ctypes.data, len(o), int(halt[0]), int(halt[1]))
+
+
+def verify_chain_io(proofs, expect: PublicC | None, inputs, outputs, halt) -> int:
+    ps = [_u32(p) for p in proofs]
+    ptrs = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
+    lens = (C.c_size_t * len(ps))(*[len(p) for p in ps])
+    i, o = _u64(inputs), _u64(outputs)
+    L = lib()
+    L.so_verify_chain_io.restype = C.c_int
+    L.so_verify_chain_io.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64]
+    return L.so_verify_chain_io(ptrs, lens, len(ps), C.byref(expect) if expect is not None else None, i.ctypes.data, len(i), o.ctypes.data, len(o), int(halt[0]), int(halt[1]))
+
+
 def verify_chain(proofs, expect: PublicC | None = None) -> int:
     """Segments of one run in order (each overlapping its predecessor by one row).  0 = accepted; 40-44 chain checks; 1000 (i+1) + c = check c
     of segment i.  `expect.n_real` = the run's total executed rows."""

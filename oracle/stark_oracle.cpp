@@ -1229,6 +1229,56 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
   }
   return 0;
 }
+// ---- the claim in the clear (round 4): I/O tapes + halt reason hash to the io digest, and the halt row is the instruction the halt reason names ----
+// (vm.rs:302-347: Ebreak halts on EBREAK; syscall.rs:101-107: Exit(code) halts on ECALL with R10 = 0, code = R11; vm.rs:211-214: CycleLimit names no instruction)
+static int halt_binding(const uint32_t* w, const F* last, int halt_kind, uint64_t halt_code) {
+  if (halt_kind == 2) return 0;
+  if (halt_kind != 0 && halt_kind != 1) return 52;
+  const size_t blob_len = w[HEADER_WORDS];
+  std::vector<uint8_t> blob(blob_len);
+  for (size_t i = 0; i < blob_len; i += 2) { const uint32_t h = w[HEADER_WORDS + 1 + i / 2]; blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8); }
+  if (blob_len < 32) return 52;
+  const uint32_t code_size = (uint32_t)blob[16] | ((uint32_t)blob[17] << 8) | ((uint32_t)blob[18] << 16) | ((uint32_t)blob[19] << 24);
+  const uint64_t pc = (uint64_t)last[1] | ((uint64_t)last[2] << 20) | ((uint64_t)last[3] << 40);
+  if (pc < 0x1000 || pc % 4 || pc - 0x1000 >= code_size || 32 + (pc - 0x1000) + 4 > blob_len) return 52;
+  const size_t at = 32 + (size_t)(pc - 0x1000);
+  const uint32_t word = (uint32_t)blob[at] | ((uint32_t)blob[at + 1] << 8) | ((uint32_t)blob[at + 2] << 16) | ((uint32_t)blob[at + 3] << 24);
+  if ((word & 0x7F) != (halt_kind == 0 ? 0x51u : 0x50u)) return 52;
+  if (halt_kind == 1) {
+    uint64_t r[2];
+    for (int k = 0; k < 2; k++) {
+      const F* l = last + 4 + 3 * (10 + k); const int bits = last[52 + 10 + k] ? 30 : 20;
+      r[k] = (uint64_t)l[0] | ((uint64_t)l[1] << bits) | ((uint64_t)l[2] << (2 * bits));
+    }
+    if (r[0] != 0 || r[1] != halt_code) return 53;
+  }
+  return 0;
+}
+static bool io_claim_matches(const uint32_t* w, uint64_t cycles, const uint64_t* in, size_t n_in, const uint64_t* out, size_t n_out, int halt_kind, uint64_t halt_code) {
+  std::vector<uint64_t> io;
+  io.push_back(n_in); for (size_t i = 0; i < n_in; i++) io.push_back(in[i]);
+  io.push_back(n_out); for (size_t i = 0; i < n_out; i++) io.push_back(out[i]);
+  io.push_back((uint64_t)halt_kind); io.push_back(halt_kind == 1 ? halt_code : 0); io.push_back(cycles);
+  F dg[DIGEST];
+  digest_bytes((const uint8_t*)io.data(), io.size() * 8, dg);
+  return !memcmp(dg, w + 17, 16);
+}
+static int verify_io(const uint32_t* w, size_t len, const Public* expect, const uint64_t* in, size_t n_in, const uint64_t* out, size_t n_out, int halt_kind, uint64_t halt_code) {
+  F st[2 * N_STATE];
+  const int rc = verify(w, len, expect, true, st);
+  if (rc) return rc;
+  if (!io_claim_matches(w, (uint64_t)w[7] | ((uint64_t)w[8] << 30), in, n_in, out, n_out, halt_kind, halt_code)) return 50;
+  return halt_binding(w, st + N_STATE, halt_kind, halt_code);
+}
+static int verify_chain_io(const uint32_t* const* proofs, const size_t* lens, int n, const Public* expect, const uint64_t* in, size_t n_in, const uint64_t* out, size_t n_out,
+                           int halt_kind, uint64_t halt_code) {
+  const int rc = verify_chain(proofs, lens, n, expect);
+  if (rc) return rc;
+  uint64_t total = 1;
+  for (int i = 0; i < n; i++) total += ((uint64_t)proofs[i][7] | ((uint64_t)proofs[i][8] << 30)) - 1;
+  if (!io_claim_matches(proofs[0], total, in, n_in, out, n_out, halt_kind, halt_code)) return 50;
+  return halt_binding(proofs[n - 1], proofs[n - 1] + 21 + N_STATE, halt_kind, halt_code);
+}
 }  // namespace so
 
 // =================================================================================================
@@ -1398,6 +1448,15 @@ int so_verify_chain(const uint32_t* const* proofs, const size_t* lens, int n, co
   if (!expect) return so::verify_chain(proofs, lens, n, nullptr);
   const so::Public e = to_pub(expect);
   return so::verify_chain(proofs, lens, n, &e);
+}
+int so_verify_io(const uint32_t* proof, size_t len, const so_public* expect, const uint64_t* in, size_t n_in, const uint64_t* out, size_t n_out, int halt_kind, uint64_t halt_code) {
+  so::Public q; if (expect) q = to_pub(expect);
+  return so::verify_io(proof, len, expect ? &q : nullptr, in, n_in, out, n_out, halt_kind, halt_code);
+}
+int so_verify_chain_io(const uint32_t* const* proofs, const size_t* lens, int n, const so_public* expect, const uint64_t* in, size_t n_in, const uint64_t* out, size_t n_out,
+                       int halt_kind, uint64_t halt_code) {
+  so::Public q; if (expect) q = to_pub(expect);
+  return so::verify_chain_io(proofs, lens, n, expect ? &q : nullptr, in, n_in, out, n_out, halt_kind, halt_code);
 }
 int so_state_words() { return so::N_STATE; }
 void so_last_challenges(uint32_t* alpha, uint32_t* zeta, uint32_t* gamma) { memcpy(alpha, g_pt.alpha.c, 16); memcpy(zeta, g_pt.zeta.c, 16); memcpy(gamma, g_pt.gamma.c, 16); }

@@ -340,7 +340,7 @@ def test_lde_matches_oracle_at_config_sizes(log_n):
     ctx.close()
 
 
-@pytest.mark.parametrize("k", [16, 18, 20])
+@pytest.mark.parametrize("k", [16, 18, 20, 22])
 def test_commitment_root_equals_the_oracles_at_config_size(k):
     """BASELINE configs[1] says "bit-exact root vs CPU": the GPU's trace-commitment root of the 2^20-cycle fib run (and of two smaller sizes) equals the root
     the CPU oracle computed for it — tests/golden/config_roots.json, written by tests/golden/make_config_roots.py from the oracle alone (4 minutes of

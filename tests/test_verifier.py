@@ -309,3 +309,95 @@ def test_chain_verifier_fuzz_agrees_with_the_oracle():
             continue
         got, want = rt.verify_chain(chain, fullc), (so.verify_chain(chain, full) if chain else 40)
         assert got != 0 and got == want, (it, kind, got, want)
+
+
+# ---- the claim in the clear: I/O tapes + halt reason (zkir_verify_io / so::verify_io) --------------------------------------------------------------
+def _both_io(pr, pub, inputs, outputs, halt):
+    a = so.verify_io(pr, pub, inputs, outputs, halt)
+    b = rt.verify_io(pr, _pub_c(pub) if pub is not None else None, inputs, outputs, halt)
+    assert a == b, (a, b)
+    return a
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_verify_io_accepts_the_honest_claim_and_rejects_every_other(deferred):
+    """fib(12) exits through ECALL with R10 = 0, R11 = 0 after writing one output (syscall.rs:101-121)."""
+    blob = spec.fib_program(12).to_bytes()
+    res = oracle.run(blob, enable_execution_trace=True, enable_deferred_model=deferred)
+    halt = (res.halt_kind, res.halt_code)
+    assert halt == (1, 0) and list(res.outputs) == [144]
+    pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), halt, deferred=deferred)
+    pr = so.prove(res.rows, pub)
+    assert _both_io(pr, pub, [], [144], halt) == 0
+    assert _both_io(pr, None, [], [144], halt) == 0
+    assert _both_io(pr, pub, [], [145], halt) == 50            # another output: not what the digest was made of
+    assert _both_io(pr, pub, [7], [144], halt) == 50           # another input tape
+    assert _both_io(pr, pub, [], [144], (1, 1)) == 50          # another exit code
+    assert _both_io(pr, pub, [], [144], (0, 0)) == 50          # another halt reason
+    t = pr.copy(); t[30] = (int(t[30]) + 1) % P
+    assert _both_io(t, pub, [], [144], halt) == so.verify(t, pub) != 0     # a proof that does not verify fails with the verifier's own code
+
+
+def test_verify_io_rejects_a_run_cut_short_and_called_an_exit():
+    """The cheat ADVICE r3 describes: the AIR lets ANY row be the last one, so a prover stops fib(12) ten rows early (on an ADDI), hashes the claim 'exited with
+    code 0, output 144' into the io digest and proves that trace.  zkir_verify accepts it — the claim is only bound, not checked — zkir_verify_io looks the halt row's
+    instruction up in the program: 52."""
+    blob = spec.fib_program(12).to_bytes()
+    res = oracle.run(blob, enable_execution_trace=True)
+    k = len(res.rows) - 10
+    claim = dict(inputs=[], outputs=[144], halt=(1, 0))
+    pub = so.public_inputs(k, blob, claim["inputs"], claim["outputs"], claim["halt"])
+    pr = so.prove(res.rows[:k], pub)
+    assert so.verify(pr, pub) == 0 and rt.verify(pr, _pub_c(pub)) == 0
+    assert _both_io(pr, pub, **claim) == 52
+    # stopped ON the final ECALL's row but with another exit code claimed (R11 = 0 there): 53
+    pub2 = so.public_inputs(len(res.rows), blob, [], [144], (1, 5))
+    pr2 = so.prove(res.rows, pub2)
+    assert so.verify(pr2, pub2) == 0
+    assert _both_io(pr2, pub2, [], [144], (1, 5)) == 53
+    # stopped on the WRITE ecall (R10 = 2) and called an exit: an ECALL, but not SYSCALL_EXIT: 53
+    words = np.frombuffer(blob[32:32 + int.from_bytes(blob[16:20], "little")], dtype="<u4")
+    ecall_rows = [i for i, r in enumerate(res.rows) if (int(r["instruction"]) & 0x7F) == 0x50]
+    assert len(ecall_rows) == 2 and words.size
+    k3 = ecall_rows[0] + 1
+    pub3 = so.public_inputs(k3, blob, [], [], (1, 144))         # R11 = 144 on that row: even the 'exit code' matches, the syscall number does not
+    pr3 = so.prove(res.rows[:k3], pub3)
+    assert so.verify(pr3, pub3) == 0 and _both_io(pr3, pub3, [], [], (1, 144)) == 53
+
+
+def test_verify_io_ebreak_and_cycle_limit():
+    prog = spec.Program.from_code([spec.addi(1, 0, 5), spec.addi(2, 1, 7), spec.ebreak()])
+    blob = prog.to_bytes()
+    res = oracle.run(blob, enable_execution_trace=True)
+    assert (res.halt_kind, len(res.rows)) == (0, 3)
+    pub = so.public_inputs(3, blob, [], [], (0, 0))
+    pr = so.prove(res.rows, pub)
+    assert _both_io(pr, pub, [], [], (0, 0)) == 0
+    pub_cut = so.public_inputs(2, blob, [], [], (0, 0))         # cut before the EBREAK, still called an Ebreak halt
+    pr_cut = so.prove(res.rows[:2], pub_cut)
+    assert so.verify(pr_cut, pub_cut) == 0 and _both_io(pr_cut, pub_cut, [], [], (0, 0)) == 52
+    # a CycleLimit halt names no instruction: the claim is the cycle count (vm.rs:211-214)
+    blob2 = spec.fib_endless_program().to_bytes()
+    res2 = oracle.run(blob2, max_cycles=100, enable_execution_trace=True)
+    pub2 = so.public_inputs(100, blob2, [], [], (2, 0))
+    pr2 = so.prove(res2.rows, pub2)
+    assert _both_io(pr2, pub2, [], [], (2, 0)) == 0
+    assert _both_io(pr2, pub2, [], [], (0, 0)) == 50
+
+
+def test_verify_chain_io():
+    """A run proven in two segments: the claim is checked against the LAST segment's last state."""
+    blob = spec.fib_program(12).to_bytes()
+    res = oracle.run(blob, enable_execution_trace=True)
+    n = len(res.rows)
+    halt = (res.halt_kind, res.halt_code)
+    run_pub = so.public_inputs(n, blob, [], list(res.outputs), halt)
+    cut = n // 2
+    segs = []
+    for lo, hi in ((0, cut + 1), (cut, n)):
+        p = so.public_inputs(hi - lo, blob, [], list(res.outputs), halt)
+        p.io[:] = list(run_pub.io)
+        segs.append(so.prove(res.rows[lo:hi], p))
+    assert so.verify_chain(segs, run_pub) == 0
+    assert so.verify_chain_io(segs, run_pub, [], [144], halt) == rt.verify_chain_io(segs, _pub_c(run_pub), [], [144], halt) == 0
+    assert so.verify_chain_io(segs, run_pub, [], [143], halt) == rt.verify_chain_io(segs, _pub_c(run_pub), [], [143], halt) == 50

@@ -40,7 +40,10 @@
 //     boolean carries / borrows / sign bits the only solution;
 //   the prover sends the multiplicities of both tables BEFORE the challenges (alpha, lambda) are drawn; the verifier computes the table
 //   side T = sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u) itself; the running-sum column closes over the cycle of N rows.
-// Not constrained: the VALUES the other 30 opcodes write (MUL / DIV / logic / shifts / loads / ECALL: class "other", y is a free
+// Not constrained IN THE AIR: WHICH instruction the halt row is — I_HALT only forces class "halt" onto the public last row, any row can be it —
+// and the io digest (inputs, outputs, halt reason, cycle count: bound into the transcript, never opened by a constraint).  The halt half is closed OUTSIDE the AIR by
+// zkir_verify_io (verify.cpp): given the claim in the clear it checks the digest and that the public last state sits on the EBREAK / exit-ECALL the claim names; the
+// outputs stay unproven.  Also not constrained: the VALUES the other 30 opcodes write (MUL / DIV / logic / shifts / loads / ECALL: class "other", y is a free
 // in-range witness), memory consistency, the SHA-256 chip, deferred-mode arithmetic (deferred = 1 relaxes the write constraints to "unwritten
 // registers keep their value"; branches and jumps run as the free-pc class "oj" there, which no default-mode row can be).
 #pragma once

@@ -199,6 +199,71 @@ int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint3
   return 0;
 }
 
+// ---- what the run CLAIMS (round 4): its I/O tapes and how it ended -------------------------------------------------------------------
+// The io digest a proof carries is a hash of (inputs, outputs, halt kind, exit code, cycles) that the AIR does not look inside.  These two calls take
+// the claim in the clear and check, on top of zkir_verify / zkir_verify_chain:
+//   50  the claim does not hash to the proof's io digest (or its cycle count is not the proof's row count);
+//   52  the HALT ROW — the last executed row, whose state the AIR pins to the public last state — is not the instruction the claim names: EBREAK for an
+//       Ebreak halt, ECALL for an Exit halt (vm.rs:302-347, syscall.rs:101-107), looked up in the program the proof carries at the last state's pc; a
+//       CycleLimit halt (vm.rs:211-214) names no instruction: the claim is "this many cycles were executed";
+//   53  an Exit halt whose ECALL does not read R10 = 0 (SYSCALL_EXIT) and R11 = the claimed exit code in that state.
+// So a prover can no longer end a run at an arbitrary instruction and call it an exit.  The OUTPUTS stay unproven: they are bound into the
+// transcript, not derived from the trace (air.h: "Not constrained").
+namespace {
+int halt_binding(const uint32_t* w, const uint32_t* last_state, int halt_kind, uint64_t halt_code) {
+  if (halt_kind == ZKIR_HALT_CYCLE_LIMIT) return 0;
+  if (halt_kind != ZKIR_HALT_EBREAK && halt_kind != ZKIR_HALT_EXIT) return 52;
+  const uint64_t blob_len = w[HEADER_WORDS];
+  std::vector<uint8_t> blob(blob_len);
+  for (uint64_t i = 0; i < blob_len; i += 2) { const uint32_t h = w[HEADER_WORDS + 1 + i / 2]; blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8); }
+  if (blob_len < 32) return 52;
+  uint32_t code_size; memcpy(&code_size, blob.data() + 16, 4);
+  const uint64_t pc = (uint64_t)last_state[1] | ((uint64_t)last_state[2] << 20) | ((uint64_t)last_state[3] << 40);
+  if (pc < 0x1000 || (pc & 3) || pc - 0x1000 >= code_size || 32 + (pc - 0x1000) + 4 > blob_len) return 52;
+  uint32_t word; memcpy(&word, blob.data() + 32 + (pc - 0x1000), 4);
+  if ((word & 0x7F) != (halt_kind == ZKIR_HALT_EBREAK ? 0x51u : 0x50u)) return 52;                  // opcode.rs:154-228: ECALL 0x50, EBREAK 0x51
+  if (halt_kind == ZKIR_HALT_EXIT) {
+    auto reg = [&](int r) {                                                                          // raw 64-bit register value from its limbs (30-bit limbs when Accumulated)
+      const uint32_t* l = last_state + 4 + 3 * r; const int bits = last_state[52 + r] ? 30 : 20;
+      return (uint64_t)l[0] | ((uint64_t)l[1] << bits) | ((uint64_t)l[2] << (2 * bits));
+    };
+    if (reg(10) != 0 || reg(11) != halt_code) return 53;
+  }
+  return 0;
+}
+bool io_claim_matches(const uint32_t* w, uint64_t cycles, const uint64_t* inputs, size_t n_in, const uint64_t* outputs, size_t n_out, int halt_kind, uint64_t halt_code) {
+  std::vector<uint64_t> io;
+  io.push_back(n_in); io.insert(io.end(), inputs, inputs + n_in);
+  io.push_back(n_out); io.insert(io.end(), outputs, outputs + n_out);
+  io.push_back((uint64_t)halt_kind); io.push_back(halt_kind == ZKIR_HALT_EXIT ? halt_code : 0); io.push_back(cycles);
+  uint32_t dg[4];
+  zkir_digest_bytes((const uint8_t*)io.data(), io.size() * 8, dg);
+  return !memcmp(dg, w + 17, 16);
+}
+}  // namespace
+
+int zkir_verify_io(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, const uint64_t* inputs, size_t n_in, const uint64_t* outputs, size_t n_out, int halt_kind,
+                   uint64_t halt_code) {
+  if ((!inputs && n_in) || (!outputs && n_out)) return 50;
+  uint32_t st[2 * NS];
+  const int rc = verify_impl(w, len, expect, true, st);
+  if (rc) return rc;
+  const uint64_t n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30);
+  if (!io_claim_matches(w, n_real, inputs, n_in, outputs, n_out, halt_kind, halt_code)) return 50;
+  return halt_binding(w, st + NS, halt_kind, halt_code);
+}
+
+int zkir_verify_chain_io(const uint32_t* const* proofs, const uint64_t* lens, uint32_t n, const zkir_public_inputs* expect, const uint64_t* inputs, size_t n_in,
+                         const uint64_t* outputs, size_t n_out, int halt_kind, uint64_t halt_code) {
+  if ((!inputs && n_in) || (!outputs && n_out)) return 50;
+  const int rc = zkir_verify_chain(proofs, lens, n, expect);
+  if (rc) return rc;
+  uint64_t total = 1;
+  for (uint32_t i = 0; i < n; i++) total += ((uint64_t)proofs[i][7] | ((uint64_t)proofs[i][8] << 30)) - 1;
+  if (!io_claim_matches(proofs[0], total, inputs, n_in, outputs, n_out, halt_kind, halt_code)) return 50;
+  return halt_binding(proofs[n - 1], proofs[n - 1] + 21 + NS, halt_kind, halt_code);                // the last segment's last state (header words 21 + NS ..)
+}
+
 }  // extern "C"
 
 namespace {

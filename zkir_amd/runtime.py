@@ -363,6 +363,34 @@ def verify_chain(proofs, expect: Optional[PublicInputsC] = None) -> int:
     return lib().zkir_verify_chain(ptrs, lens, len(ps), C.byref(expect) if expect is not None else None)
 
 
+def _u64s(a):
+    return np.ascontiguousarray(np.asarray([int(x) & (2**64 - 1) for x in a], dtype=np.uint64))
+
+
+def verify_io(proof: np.ndarray, expect: Optional[PublicInputsC], inputs, outputs, halt) -> int:
+    """zkir_verify_io: zkir_verify + the run's claim in the clear — `inputs`, `outputs` and `halt` (a HaltReason or (kind, code)) must hash to the proof's io digest (50) and
+    the halt row must be the instruction the halt reason names (52: not that instruction; 53: not that exit code)."""
+    proof, i, o = np.ascontiguousarray(proof, dtype=np.uint32), _u64s(inputs), _u64s(outputs)
+    kind, code = (halt.kind, halt.code) if hasattr(halt, "kind") else halt
+    L = lib()
+    L.zkir_verify_io.restype = C.c_int
+    L.zkir_verify_io.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64]
+    return L.zkir_verify_io(proof.ctypes.data, len(proof), C.byref(expect) if expect is not None else None, i.ctypes.data, len(i), o.ctypes.data, len(o), int(kind), int(code or 0))
+
+
+def verify_chain_io(proofs, expect: Optional[PublicInputsC], inputs, outputs, halt) -> int:
+    """zkir_verify_chain_io: the same for a run proven in segments."""
+    ps = [np.ascontiguousarray(p, dtype=np.uint32) for p in proofs]
+    ptrs = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
+    lens = (C.c_uint64 * len(ps))(*[len(p) for p in ps])
+    i, o = _u64s(inputs), _u64s(outputs)
+    kind, code = (halt.kind, halt.code) if hasattr(halt, "kind") else halt
+    L = lib()
+    L.zkir_verify_chain_io.restype = C.c_int
+    L.zkir_verify_chain_io.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64]
+    return L.zkir_verify_chain_io(ptrs, lens, len(ps), C.byref(expect) if expect is not None else None, i.ctypes.data, len(i), o.ctypes.data, len(o), int(kind), int(code or 0))
+
+
 def verify(proof: np.ndarray, expect: Optional[PublicInputsC] = None) -> int:
     """zkir_verify (host only): 0 = accepted, otherwise the number of the failed check."""
     proof = np.ascontiguousarray(proof, dtype=np.uint32)
