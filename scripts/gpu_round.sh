@@ -3,7 +3,7 @@
 # single-GPU BASELINE configs.  Usage: gpu_round.sh <tag> [tests|bench|prof ...]   (default: all three)
 # Counter (PMC) passes are separate runs with --kernel-trace only (never combined with other trace domains).
 export TMPDIR=/tmp
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 WHAT=${@:-tests bench prof}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp
 summ() {  # <db dir> <out file>: top kernels of a rocprofv3 --kernel-trace --stats run
