@@ -408,6 +408,20 @@ inline std::vector<uint32_t> prove(const StarkContext& ctx, const zkir_runtime::
   return out;
 }
 inline int verify(const std::vector<uint32_t>& proof, const zkir_public_inputs* expect = nullptr) { return zkir_verify(proof.data(), proof.size(), expect); }
+// verify + the run's CLAIM in the clear (zkir_verify_io): the I/O tapes and the halt reason must hash to the proof's io digest and the halt row must be the
+// instruction the halt reason names (50 / 52 / 53, include/zkir_amd.h); what a caller who holds an ExecutionResult-shaped claim calls
+inline int verify_io(const std::vector<uint32_t>& proof, const std::vector<uint64_t>& inputs, const std::vector<uint64_t>& outputs, const zkir_runtime::HaltReason& halt,
+                     const zkir_public_inputs* expect = nullptr) {
+  const int kind = (int)halt.kind;                                  // HaltReason::Kind carries the ZKIR_HALT_* values
+  return zkir_verify_io(proof.data(), proof.size(), expect, inputs.data(), inputs.size(), outputs.data(), outputs.size(), kind, halt.code);
+}
+inline int verify_chain_io(const std::vector<std::vector<uint32_t>>& proofs, const std::vector<uint64_t>& inputs, const std::vector<uint64_t>& outputs,
+                           const zkir_runtime::HaltReason& halt, const zkir_public_inputs* expect = nullptr) {
+  std::vector<const uint32_t*> ptrs; std::vector<uint64_t> lens;
+  for (const auto& p : proofs) { ptrs.push_back(p.data()); lens.push_back(p.size()); }
+  const int kind = (int)halt.kind;
+  return zkir_verify_chain_io(ptrs.data(), lens.data(), (uint32_t)proofs.size(), expect, inputs.data(), inputs.size(), outputs.data(), outputs.size(), kind, halt.code);
+}
 // A run proven in segments (one row shard per GPU, consecutive segments sharing one row): every segment on its own, and the chain as one run.
 struct BoundaryStates { uint32_t first[68], last[68]; };
 inline int verify_segment(const std::vector<uint32_t>& proof, BoundaryStates* states = nullptr, const zkir_public_inputs* expect = nullptr) {

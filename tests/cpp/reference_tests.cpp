@@ -214,6 +214,9 @@ static void test_prove_and_verify() {
   CHECK(proof.size() > 1000 && proof[0] == 0x46504B5Au && proof[1] == zkir_proof_version() && proof[2] == 6 && proof[3] == zkir_main_trace_width() && proof[4] == zkir_proof_num_queries());
   CHECK(zkir_prover::prove(ctx, r, pub) == proof);               // deterministic transcript
   CHECK(zkir_prover::verify(proof) == 0 && zkir_prover::verify(proof, &pub) == 0);
+  // the claim in the clear: outputs and halt reason hash to the io digest, the halt row is the exit ECALL with R11 = 0 (zkir_verify_io)
+  CHECK(zkir_prover::verify_io(proof, {}, r.outputs, r.halt_reason, &pub) == 0);
+  CHECK(zkir_prover::verify_io(proof, {}, {145}, r.halt_reason) == 50 && zkir_prover::verify_io(proof, {}, r.outputs, HaltReason::exit(1)) == 50);
   zkir_public_inputs other = pub; other.io_digest[0] ^= 1;       // someone claims other outputs
   CHECK(zkir_prover::verify(proof, &other) == 6);
   std::vector<uint32_t> bad = proof; bad[bad.size() / 2] = (bad[bad.size() / 2] + 1) % 2013265921u;
@@ -254,6 +257,8 @@ static void test_segment_proofs_through_the_c_abi() {
   CHECK(zkir_prover::verify_segment(proofs[0], &st0) == 0 && zkir_prover::verify_segment(proofs[1], &st1) == 0);
   CHECK(st0.first[0] == 0 && st0.last[0] == S - 1 && st1.first[0] == S - 1 && std::memcmp(st0.last, st1.first, sizeof st0.last) == 0);
   CHECK(zkir_prover::verify(proofs[0]) == 0 && zkir_prover::verify(proofs[1]) == 7);          // only the first starts in the initial state
+  CHECK(zkir_prover::verify_chain_io(proofs, {}, std::vector<uint64_t>(zkir_delta_log_outputs(log), zkir_delta_log_outputs(log) + zkir_delta_log_n_outputs(log)), HaltReason::exit(0), &run_pub) == 0);
+  CHECK(zkir_prover::verify_chain_io(proofs, {}, {1}, HaltReason::exit(0)) == 50);
   CHECK(zkir_prover::verify_chain({proofs[0], proofs[2]}) == 42 && zkir_prover::verify_chain({proofs[1], proofs[2]}) == 41);
   zkir_public_inputs wrong = run_pub; wrong.n_real += 1;
   CHECK(zkir_prover::verify_chain(proofs, &wrong) == 44);
