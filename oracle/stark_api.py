@@ -61,7 +61,20 @@ def lib():
 class PublicC(C.Structure):
     """so_public: the public inputs of a proof (observed first by the transcript, carried in the proof header)."""
     _fields_ = [("n_real", C.c_uint64), ("deferred", C.c_uint32), ("pad", C.c_uint32), ("entry", C.c_uint64), ("prog", C.c_uint32 * 4), ("io", C.c_uint32 * 4),
-                ("blob", C.c_char_p), ("blob_len", C.c_uint64)]     # the program itself (prover side): its code words are the instruction ROM
+                ("blob", C.c_char_p), ("blob_len", C.c_uint64),      # the program itself (prover side): its code words are the instruction ROM
+                # mode 2 (`deferred` == 2: the default VM mode WITH the I/O argument): the tapes and the halt reason in the clear, and for a SEGMENT the
+                # WRITE / READ ecalls the run executed before its first row
+                ("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("outputs", C.c_void_p), ("n_outputs", C.c_uint64), ("halt_kind", C.c_uint32), ("pad2", C.c_uint32),
+                ("halt_code", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+
+    def set_io(self, inputs, outputs, halt, writes_before=0, reads_before=0):
+        self._in_ref = np.ascontiguousarray(np.asarray([int(x) & (2**64 - 1) for x in inputs], dtype=np.uint64))
+        self._out_ref = np.ascontiguousarray(np.asarray([int(x) & (2**64 - 1) for x in outputs], dtype=np.uint64))
+        self.inputs, self.n_inputs = (self._in_ref.ctypes.data if len(self._in_ref) else None), len(self._in_ref)
+        self.outputs, self.n_outputs = (self._out_ref.ctypes.data if len(self._out_ref) else None), len(self._out_ref)
+        self.halt_kind, self.halt_code = int(halt[0]), int(halt[1]) if int(halt[0]) == 1 else 0
+        self.writes_before, self.reads_before = int(writes_before), int(reads_before)
+        return self
 
     def set_blob(self, blob: bytes):
         self._blob_ref = bytes(blob)            # keeps the bytes alive as long as the struct
@@ -72,6 +85,8 @@ class PublicC(C.Structure):
     def clone(self):
         q = PublicC(self.n_real, self.deferred, 0, self.entry)
         q.prog[:] = list(self.prog); q.io[:] = list(self.io)
+        if hasattr(self, "_in_ref"):
+            q.set_io(self._in_ref.tolist(), self._out_ref.tolist(), (self.halt_kind, self.halt_code), self.writes_before, self.reads_before)
         return q.set_blob(getattr(self, "_blob_ref", b""))
 
 
@@ -87,12 +102,16 @@ def io_bytes(inputs, outputs, halt_kind: int, halt_code: int, cycles: int) -> by
     return np.array([int(x) & (2**64 - 1) for x in words], dtype="<u8").tobytes()
 
 
-def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2, 0), deferred: bool = False, entry: int | None = None) -> PublicC:
-    """Public inputs of a run: halt = (kind, code) with kind 0 Ebreak / 1 Exit / 2 CycleLimit; entry defaults to the blob header's."""
+def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2, 0), deferred: bool = False, entry: int | None = None, io_mode: bool = False,
+                  writes_before: int = 0, reads_before: int = 0) -> PublicC:
+    """Public inputs of a run: halt = (kind, code) with kind 0 Ebreak / 1 Exit / 2 CycleLimit; entry defaults to the blob header's.
+    io_mode = mode 2: the default VM mode with the I/O argument (the proof carries the tapes; WRITE / READ ecalls are tied to them)."""
     if entry is None:
         entry = int.from_bytes(blob[12:16], "little") if len(blob) >= 16 else 0x1000
-    p = PublicC(n_real, int(deferred), 0, entry)
+    assert not (deferred and io_mode), "the I/O argument is stated for the default VM mode"
+    p = PublicC(n_real, 2 if io_mode else int(deferred), 0, entry)
     p.set_blob(blob)
+    p.set_io(list(inputs), list(outputs), halt, writes_before, reads_before)
     p.prog[:] = [int(x) for x in digest_bytes(blob)]
     p.io[:] = [int(x) for x in digest_bytes(io_bytes(list(inputs), list(outputs), halt[0], halt[1], n_real))]
     return p
@@ -163,20 +182,30 @@ def main_trace(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
     """Packed reference rows (api.ROW_DTYPE) -> Baby Bear matrix [W_MAIN][N], N = the padded power of two."""
     rows = np.ascontiguousarray(rows)
     pub = _pub(rows, pub)
-    out = np.zeros((W_MAIN, 1 << padded_log_n(pub.n_real)), np.uint32)
+    out = np.zeros((logical_width(pub.deferred), 1 << padded_log_n(pub.n_real)), np.uint32)
     lib().so_main_trace(rows.ctypes.data, C.byref(pub), out.ctypes.data)
     return out
 
 
+def logical_width(mode=0) -> int:
+    """Logical main-trace columns of a mode (0 default, 1 deferred, 2 default + I/O): 172 / 172 / 180."""
+    return lib().so_logical_width(int(mode))
+
+
+def aux_width(mode=0) -> int:
+    return lib().so_aux_width_for(int(mode))
+
+
 def committed_width(deferred=False) -> int:
-    return W_COMMITTED_DEFERRED if deferred else W_COMMITTED
+    """Committed columns of a mode (a bool reads as mode 0 / 1; 2 = default + I/O): 152 / 168 / 160."""
+    return lib().so_committed_width(int(deferred))
 
 
 def to_committed(matrix: np.ndarray, deferred=False) -> np.ndarray:
-    """Logical main-trace matrix [W_MAIN][n] -> the committed one [committed_width][n] (so::to_physical)."""
+    """Logical main-trace matrix [logical_width][n] -> the committed one [committed_width][n] (so::to_physical); `deferred` = the mode."""
     m = _u32(matrix)
     out = np.zeros((committed_width(deferred), m.shape[1]), np.uint32)
-    lib().so_to_committed(m.ctypes.data, m.shape[1], int(bool(deferred)), out.ctypes.data)
+    lib().so_to_committed(m.ctypes.data, m.shape[1], int(deferred), out.ctypes.data)
     return out
 
 
@@ -234,7 +263,7 @@ def prove(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
 def prove_matrix(matrix: np.ndarray, pub: PublicC) -> np.ndarray:
     """Proof of a GIVEN main-trace matrix [W_MAIN][N] (tests: what a cheating prover would submit)."""
     m = _u32(matrix)
-    assert m.shape == (W_MAIN, 1 << padded_log_n(pub.n_real))
+    assert m.shape == (logical_width(pub.deferred), 1 << padded_log_n(pub.n_real))
     size = lib().so_prove_matrix(m.ctypes.data, C.byref(pub), None, 0)
     out = np.zeros(size, np.uint32)
     lib().so_prove_matrix(m.ctypes.data, C.byref(pub), out.ctypes.data, size)

@@ -189,7 +189,17 @@ static void lde(const std::vector<F>& evals, int log_blowup, std::vector<F>& coe
 //   156 nz = [xc != 0] over the raw 64 bits, on every row | 157 ivz = inverse of the sum of xc's limbs
 //   169-170 class one-hot, continued: cmn (id 13: CMOV / CMOVNZ), cmz (id 14: CMOVZ) | 171 q = the row is a conditional move whose condition holds
 // ---------------------------------------------------------------------------------------------
-static const int W_MAIN = 172;
+static const int W_MAIN = 172;                                     // logical columns of modes 0 (default) and 1 (deferred)
+// ---- MODE 2 (round 4): the default VM mode WITH the I/O argument.  Eight more logical columns, committed only in this mode (152 + 8 = 160):
+//   172 f2 = the row is a WRITE ecall (R10 = 2) | 173 rl = a READ ecall (R10 = 1) that finds the input tape non-empty | 174 re = a READ ecall on an exhausted tape
+//   175 fh = a hash ecall (R10 = 3..6) | 176-177 h0, h1: R10 - 3 in binary on hash rows | 178 oc = outputs written before this row | 179 ic = inputs consumed before it
+// ECALL is a class of its own there (id 15, no column: Kec = f2 + rl + re + fh); its rows send (oc, R11's limbs) / (ic, the limbs written to R10) into a LogUp relation
+// whose table side the VERIFIER forms from the I/O tapes the proof carries (their digest is the public io digest): syscall.rs:94-177.
+static const int W_MAIN_IO = 180, W_MAX = 180;
+enum { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 177, C_OC = 178, C_IC = 179 };
+static const int K_ECALL = 15;                                     // class id of the ECALL word in mode 2 (the ROM tuple's opclass); modes 0 / 1: "other"
+static const uint32_t OP_ECALL = 0x50;
+static inline int logical_width(int mode) { return mode == 2 ? W_MAIN_IO : W_MAIN; }
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
        C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
@@ -207,22 +217,25 @@ static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // 152 columns in default mode (172 - 20), 168 in deferred mode (172 - 4), whole blocks of 8.  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
 static const int W_AUX = 40;
+static const int W_AUX_IO = 48, W_AUX_MAX = 48;                    // mode 2: + HO (output helper), HI (input helper)
+static inline int aux_width(int mode) { return mode == 2 ? W_AUX_IO : W_AUX; }
 // (AIR v6) the class column "other, jumps" (C_K3 + 1) is identically zero in the default mode too — no opcode's class is oj there (constraint 4) — and is not committed
 static const int C_KOJ = C_K3 + 1;
-static inline bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
-static inline int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
-static inline int phys_width(bool deferred) { return deferred ? 168 : 152; }   // 172 - 20 = 152, 172 - 4 = 168: whole blocks of 8, no padding
-// logical [W_MAIN][N] -> committed [phys_width][N]
-static void to_physical(const std::vector<F>& M, size_t N, bool deferred, std::vector<F>& out) {
-  out.assign((size_t)phys_width(deferred) * N, 0);
-  for (int c = 0; c < W_MAIN; c++) if (!is_virtual(c, deferred)) memcpy(&out[(size_t)phys_col(c, deferred) * N], &M[(size_t)c * N], N * sizeof(F));
+// mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
+static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode != 2) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
+static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
+// logical [logical_width][N] -> committed [phys_width][N]
+static void to_physical(const std::vector<F>& M, size_t N, int mode, std::vector<F>& out) {
+  out.assign((size_t)phys_width(mode) * N, 0);
+  for (int c = 0; c < logical_width(mode); c++) if (!is_virtual(c, mode)) memcpy(&out[(size_t)phys_col(c, mode) * N], &M[(size_t)c * N], N * sizeof(F));
 }
-// a row of committed values (base field or extension) -> the logical row the constraints read
+// a row of committed values (base field or extension) -> the logical row the constraints read (W_MAX entries)
 template <class V>
-static void to_logical_row(const V* phys, bool deferred, const V& zero, V* logical) {
-  for (int c = 0; c < W_MAIN; c++) logical[c] = is_virtual(c, deferred) ? zero : phys[phys_col(c, deferred)];
+static void to_logical_row(const V* phys, int mode, const V& zero, V* logical) {
+  for (int c = 0; c < W_MAX; c++) logical[c] = is_virtual(c, mode) ? zero : phys[phys_col(c, mode)];
 }
-enum { A_H = 0, A_HR = 32, A_S = 36 };
+enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44 };
 static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the reference's range-check table: 2^(limb_bits/2) entries (range_check.rs:29, config.rs:78-80)
 static const int N_TUPLE = 11;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass, g (variant bit)
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
@@ -255,6 +268,14 @@ struct Public {
   // WHOLE run must start in the VM's initial state (verify(): check 7); a SEGMENT of a run starts where its predecessor ended
   // (verify_chain()).
   F first[68] = {0}, last[68] = {0};
+  // ---- mode 2 (deferred == 2): the I/O argument.  The tapes and the halt reason in the clear (the proof carries them; their digest with the run's cycle
+  // count is `io`); for a SEGMENT, the ecalls the run made before its first row (raw counts: the prover's input); cnt_first / cnt_last = (oc, ic) at the
+  // first / last row, read off the main trace by the prover and carried in the header like the boundary states
+  const uint64_t* inputs = nullptr; size_t n_in = 0; const uint64_t* outputs = nullptr; size_t n_out = 0;
+  uint32_t halt_kind = 2; uint64_t halt_code = 0;
+  uint64_t writes_before = 0, reads_before = 0;
+  F cnt_first[2] = {0, 0}, cnt_last[2] = {0, 0};
+  int mode() const { return (int)deferred; }
 };
 static const int N_STATE = 68;
 static int padded_log_n(uint64_t n_real) { int k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
@@ -267,7 +288,8 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
   hash_elems(e.data(), e.size(), out);
 }
 
-static inline F opclass_of(uint32_t op) {
+static inline F opclass_of(uint32_t op, int mode = 0) {
+  if (op == OP_ECALL && mode == 2) return K_ECALL;
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
@@ -278,11 +300,11 @@ static inline F opclass_of(uint32_t op) {
 // The instruction ROM of a program blob (Program::to_bytes layout, program.rs:170-214,300-346): code word t sits at pc = 0x1000 + 4 t
 // (VM::new loads the code at CODE_BASE whatever the entry point, vm.rs:153-160); tuple = (pc limbs 20/20/24, op, fa, fb, fc, fhi, s, opclass).
 struct Rom { std::vector<F> rows; size_t n = 0; uint64_t entry = 0; bool ok = false; const F* row(size_t t) const { return &rows[t * N_TUPLE]; } };
-static inline void rom_tuple(uint64_t pc, uint32_t w, F out[N_TUPLE]) {
+static inline void rom_tuple(uint64_t pc, uint32_t w, F out[N_TUPLE], int mode = 0) {
   out[0] = (F)(pc & 0xFFFFF); out[1] = (F)((pc >> 20) & 0xFFFFF); out[2] = (F)(pc >> 40);
-  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F); out[10] = variant_bit(w & 0x7F);
+  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F, mode); out[10] = variant_bit(w & 0x7F);
 }
-static Rom rom_from_blob(const uint8_t* b, size_t n) {
+static Rom rom_from_blob(const uint8_t* b, size_t n, int mode = 0) {
   Rom r;
   auto le32 = [&](size_t at) { return (uint32_t)b[at] | ((uint32_t)b[at + 1] << 8) | ((uint32_t)b[at + 2] << 16) | ((uint32_t)b[at + 3] << 24); };
   if (!b || n < 32) return r;
@@ -290,7 +312,7 @@ static Rom rom_from_blob(const uint8_t* b, size_t n) {
   const uint64_t code_size = le32(16);
   if (code_size % 4 || 32 + code_size > n) return r;
   r.n = code_size / 4; r.rows.resize(r.n * N_TUPLE);
-  for (size_t t = 0; t < r.n; t++) rom_tuple(0x1000 + 4 * (uint64_t)t, le32(32 + 4 * t), &r.rows[t * N_TUPLE]);
+  for (size_t t = 0; t < r.n; t++) rom_tuple(0x1000 + 4 * (uint64_t)t, le32(32 + 4 * t), &r.rows[t * N_TUPLE], mode);
   r.ok = true;
   return r;
 }
@@ -305,9 +327,11 @@ static inline void reg_limbs(uint64_t v, uint8_t st, F out[3]) {
 static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out) {
   const int log_n = padded_log_n(n_real);
   const size_t N = (size_t)1 << log_n;
-  out.assign((size_t)W_MAIN * N, 0);
+  const int mode = pub.mode();
+  out.assign((size_t)logical_width(mode) * N, 0);
   auto col = [&](int k) { return out.data() + (size_t)k * N; };
-  const bool D = pub.deferred != 0;
+  const bool D = mode == 1, IO = mode == 2;
+  uint64_t oc = pub.writes_before, reads = pub.reads_before;          // mode 2: WRITE / READ ecalls executed so far (syscall.rs:110-121)
   for (size_t i = 0; i < N; i++) {
     const bool pad = i >= n_real;
     const PackedRow& r = rows[pad ? n_real - 1 : i];
@@ -325,11 +349,11 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       col(C_STATE + g)[i] = r.reg_state[g];
     }
     int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
-    if (cls == K_OTH && !D) cls = (int)opclass_of(op);
+    if (cls == K_OTH && !D) cls = (int)opclass_of(op, mode);
     if (cls == K_OTH && D && (opclass_of(op) == K_BRE || opclass_of(op) == K_BRU || opclass_of(op) == K_JAL || opclass_of(op) == K_JALR))
       cls = K_OJ;                                             // deferred mode: no opcode semantics, but "other" is sequential — branches and jumps run as the free-pc class
-    col(kcol(cls))[i] = 1;
-    col(C_OPC)[i] = opclass_of(op);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
+    if (cls != K_ECALL) col(kcol(cls))[i] = 1;                // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
+    col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
     const uint32_t tc = branch ? fa : fc;                   // second operand: rs2 = field c, but B-type words have rs1 in field a (rs2 in field b)
     if (fb) col(C_SELB + fb - 1)[i] = 1;
@@ -390,6 +414,17 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; if (q) rd = fa; }   // execute.rs:434-472: rd = rs1 (raw) if the condition holds, nothing changes otherwise
+    if (IO) {                                                 // the counters every row shows: what happened BEFORE it
+      col(C_OC)[i] = (F)(oc % P); col(C_IC)[i] = (F)((reads < pub.n_in ? reads : pub.n_in) % P);
+    }
+    if (cls == K_ECALL) {                                     // mode 2, an executed ecall: dispatched on R10 (syscall.rs:94-177; 0 = EXIT halts: that row is the halt row)
+      const uint64_t num = r.registers[10];
+      if (num == 2) { col(C_F2)[i] = 1; oc++; }                                                      // WRITE: R11 goes to the output tape, no register changes
+      else if (num == 1) {                                                                           // READ: R10 <- the next input, 0 once the tape is exhausted
+        if (reads < pub.n_in) { col(C_RL)[i] = 1; reg_limbs(pub.inputs[reads], 0, y); } else col(C_RE)[i] = 1;
+        reads++; rd = 10;
+      } else { col(C_FH)[i] = 1; col(C_H0)[i] = (F)((num - 3) & 1); col(C_H1)[i] = (F)(((num - 3) >> 1) & 1); rd = 10; }   // hash syscalls (3..6): R10 <- 0; their memory effect is not stated
+    }
     if (rd > 0) col(C_WR + rd - 1)[i] = 1;
     if (cls == K_OTH || (cls == K_OJ && D)) {               // any other instruction: what it wrote is read off the next row
       const PackedRow& q = rows[i + 1];
@@ -407,7 +442,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64 * rc2[2];
     }
     for (int k = 0; k < 4; k++) col(C_RC2 + k)[i] = rc2[k];
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || cls == K_ECALL || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
     col(C_RC)[i] = z[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = z[0] >> RC_BITS; col(C_RC + 2)[i] = z[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = z[1] >> RC_BITS;
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
     if (cls == K_JALR) {                                                                            // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
@@ -450,7 +485,16 @@ static void merkle_build(const std::vector<F>& mat, int width, size_t n, Merkle&
 // ---------------------------------------------------------------------------------------------
 // Lookup argument (LogUp) of AIR v2: what is looked up, the multiplicities, the aux trace
 // ---------------------------------------------------------------------------------------------
-struct LookupParams { E alpha; E lam[N_TUPLE + 1]; E t_over_n; };
+struct LookupParams { E alpha; E lam[N_TUPLE + 1]; E t_over_n; F n_in = 0; };   // n_in: mode 2, the length of the input tape (public: the proof carries the tape)
+// mode 2: fingerprint of an I/O tuple (index on its tape, the three limbs of the value): sum_j lambda^j g_j + tag lambda^N_TUPLE, tag 2 = output tape, 3 = input tape
+// (the instruction ROM's tuples carry tag 1, range values none: the three tables cannot be confused)
+static inline void io_limbs(uint64_t v, F out[3]) { out[0] = (F)(v & 0xFFFFF); out[1] = (F)((v >> 20) & 0xFFFFF); out[2] = (F)(v >> 40); }
+static inline E io_fingerprint(F idx, const F* limbs, F tag, const LookupParams& lp) {
+  E fp = emul_f(lp.lam[N_TUPLE], tag);
+  fp = eadd(fp, emul_f(lp.lam[0], idx));
+  for (int j = 0; j < 3; j++) fp = eadd(fp, emul_f(lp.lam[1 + j], limbs[j]));
+  return fp;
+}
 static inline E fingerprint(const F* tuple, const LookupParams& lp) {        // sum_j lambda^j f_j + lambda^10 (the tag keeps ROM entries apart from range values)
   E fp = lp.lam[N_TUPLE];
   for (int j = 0; j < N_TUPLE; j++) fp = eadd(fp, emul_f(lp.lam[j], tuple[j]));
@@ -495,9 +539,17 @@ static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, c
   for (size_t u = 0; u < rom.n; u++) T = eadd(T, emul_f(d[RC_TABLE + u], rom_mult[u]));
   return T;
 }
+// (mode 2) the tapes' share of the table side: every output index in [oc_first, oc_last) and every input index in [ic_first, ic_last) exactly once —
+// the indices the segment's counters ran through (a whole run: 0 .. n_out and 0 .. the inputs it consumed)
+static E io_table_sum(const Public& pub, const LookupParams& lp) {
+  E T = e_from(0);
+  for (uint64_t k = pub.cnt_first[0]; k < pub.cnt_last[0] && k < pub.n_out; k++) { F v[3]; io_limbs(pub.outputs[k], v); T = eadd(T, einv(esub(lp.alpha, io_fingerprint((F)k, v, 2, lp)))); }
+  for (uint64_t k = pub.cnt_first[1]; k < pub.cnt_last[1] && k < pub.n_in; k++) { F v[3]; io_limbs(pub.inputs[k], v); T = eadd(T, einv(esub(lp.alpha, io_fingerprint((F)k, v, 3, lp)))); }
+  return T;
+}
 // aux trace [W_AUX][N] of the main-trace matrix M: helper columns of the five lookups of every row and the running sum
-static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp, std::vector<F>& A) {
-  A.assign((size_t)W_AUX * N, 0);
+static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp, std::vector<F>& A, int mode = 0) {
+  A.assign((size_t)aux_width(mode) * N, 0);
   const int NH = N_RC + 1;
   std::vector<E> d((size_t)NH * N);
   for (size_t i = 0; i < N; i++) {
@@ -513,6 +565,21 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
       const E& h = d[NH * i + k];
       for (int c = 0; c < 4; c++) A[(size_t)((k < N_RC ? A_H + 4 * k : A_HR) + c) * N + i] = h.c[c];
       hs = eadd(hs, h);
+    }
+    if (mode == 2) {                                          // the tape helpers: HO = f2 / (alpha - fp(oc, R11)), HI = rl / (alpha - fp(ic, y)); zero on every other row
+      auto at = [&](int c) { return M[(size_t)c * N + i]; };
+      if (at(C_F2)) {
+        const F v[3] = {at(C_LIMB + 33), at(C_LIMB + 34), at(C_LIMB + 35)};
+        const E h = einv(esub(lp.alpha, io_fingerprint(at(C_OC), v, 2, lp)));
+        for (int c = 0; c < 4; c++) A[(size_t)(A_HO + c) * N + i] = h.c[c];
+        hs = eadd(hs, h);
+      }
+      if (at(C_RL)) {
+        const F v[3] = {at(C_Y), at(C_Y + 1), at(C_Y + 2)};
+        const E h = einv(esub(lp.alpha, io_fingerprint(at(C_IC), v, 3, lp)));
+        for (int c = 0; c < 4; c++) A[(size_t)(A_HI + c) * N + i] = h.c[c];
+        hs = eadd(hs, h);
+      }
     }
     for (int c = 0; c < 4; c++) A[(size_t)(A_S + c) * N + i] = S.c[c];       // S_i = sum over rows j < i of (hsum_j - T / N); S_0 = 0
     S = eadd(S, esub(hs, lp.t_over_n));
@@ -573,7 +640,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   auto push = [&](const E& v) { A.push(v); };
   auto cst = [](uint64_t v) { return e_from((F)(v % P)); };
   const E one = e_from(1);
-  const E Dm = cst(pub.deferred ? 1 : 0), nD = cst(pub.deferred ? 0 : 1);
+  const E Dm = cst(pub.mode() == 1 ? 1 : 0), nD = cst(pub.mode() == 1 ? 0 : 1);       // (mode 2 is the DEFAULT VM mode with the I/O argument)
   const E op = loc[C_OP], fa = loc[C_FA], fb = loc[C_FB], fc = loc[C_FC], fhi = loc[C_FHI], s = loc[C_S], se = loc[C_SE];
   E K[N_CLASS];
   for (int k = 0; k < N_CLASS; k++) K[k] = loc[kcol(k)];
@@ -592,9 +659,11 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]); boolean(loc[C_SB]); boolean(loc[C_NZ]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
-  { E sum = e_from(0); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  const bool IO = pub.mode() == 2;
+  const E Kec = IO ? eadd(eadd(loc[C_F2], loc[C_RL]), eadd(loc[C_RE], loc[C_FH])) : e_from(0);   // (mode 2) the ecall class: the sum of its four syscall flags
+  { E sum = Kec; for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
-    E ks = e_from(0);
+    E ks = emul_f(Kec, (F)K_ECALL);
     for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
@@ -770,14 +839,55 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   for (int k = 0; k < 4; k++) {
     E hs = aloc[A_HR + k];
     for (int i = 0; i < N_RC; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
+    if (IO) hs = eadd(hs, eadd(aloc[A_HO + k], aloc[A_HI + k]));
     push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
+  }
+  // ---- 17. (mode 2, round 4) ECALL rows and the I/O tapes (syscall.rs:94-177).  Appended to the list: modes 0 / 1 stop here. ----
+  if (IO) {
+    const E f2 = loc[C_F2], rl = loc[C_RL], re = loc[C_RE], fh = loc[C_FH], h0 = loc[C_H0], h1 = loc[C_H1], oc = loc[C_OC], ic = loc[C_IC];
+    boolean(f2); boolean(rl); boolean(re); boolean(fh); boolean(h0); boolean(h1);
+    push(emul(h0, esub(one, fh))); push(emul(h1, esub(one, fh)));                                   // the two bits of R10 - 3 live on hash rows only
+    // the syscall number: R10 = 1 (READ), 2 (WRITE), 3 + h0 + 2 h1 (hash) — R10 = 0 (EXIT) halts and is no executed row, anything else is a run-time error
+    const E* r10 = loc + C_LIMB + 30; const E* r11 = loc + C_LIMB + 33;
+    push(emul(Kec, r10[1])); push(emul(Kec, r10[2]));
+    push(esub(emul(Kec, r10[0]), eadd(eadd(eadd(rl, re), emul_f(f2, 2)), eadd(emul_f(fh, 3), eadd(h0, emul_f(h1, 2))))));
+    // what an ecall writes: READ and the hashes write R10 (exactly one register: R10), WRITE writes nothing
+    const E wgrp = eadd(eadd(rl, re), fh);
+    push(emul(wgrp, esub(w1, cst(10)))); push(emul(wgrp, esub(w0, one))); push(emul(f2, w0));
+    for (int l = 0; l < 3; l++) push(emul(eadd(fh, re), y[l]));                                     // hashes return 0, so does a READ on an exhausted tape
+    // the counters: oc counts the WRITEs, ic the inputs consumed
+    push(emul(esub(esub(nxt[C_OC], oc), f2), is_trans));
+    push(emul(esub(esub(nxt[C_IC], ic), rl), is_trans));
+    push(emul(re, esub(ic, cst(lp.n_in))));                                                         // "exhausted" means exactly that: every input has been consumed
+    // the two tape lookups: HO (alpha - fp(oc, R11)) = f2, HI (alpha - fp(ic, y)) = rl
+    {
+      E d[4], pr[4];
+      for (int k = 0; k < 4; k++) {
+        E fp = eadd(emul_f(cst(lp.lam[N_TUPLE].c[k]), 2), emul_f(oc, lp.lam[0].c[k]));
+        for (int j = 0; j < 3; j++) fp = eadd(fp, emul_f(r11[j], lp.lam[1 + j].c[k]));
+        d[k] = esub(cst(lp.alpha.c[k]), fp);
+      }
+      ext_mul(aloc + A_HO, d, pr);
+      push(esub(pr[0], f2)); push(pr[1]); push(pr[2]); push(pr[3]);
+      for (int k = 0; k < 4; k++) {
+        E fp = eadd(emul_f(cst(lp.lam[N_TUPLE].c[k]), 3), emul_f(ic, lp.lam[0].c[k]));
+        for (int j = 0; j < 3; j++) fp = eadd(fp, emul_f(y[j], lp.lam[1 + j].c[k]));
+        d[k] = esub(cst(lp.alpha.c[k]), fp);
+      }
+      ext_mul(aloc + A_HI, d, pr);
+      push(esub(pr[0], rl)); push(pr[1]); push(pr[2]); push(pr[3]);
+    }
+    // the counters of the first and of the last executed row are public (header): a whole run starts at (0, 0) and ends with oc = the number of outputs
+    push(emul(esub(oc, cst(pub.cnt_first[0])), is_first)); push(emul(esub(ic, cst(pub.cnt_first[1])), is_first));
+    push(emul(esub(oc, cst(pub.cnt_last[0])), is_last)); push(emul(esub(ic, cst(pub.cnt_last[1])), is_last));
   }
   result = A.acc;
   return A.c;
 }
-static int num_constraints() {                                            // by a dry run (the list above is the definition)
-  std::vector<E> z(W_MAIN, e_from(0)), ap(MAX_CONSTRAINTS, e_from(0));
+static int num_constraints(int mode = 0) {                                // by a dry run (the list above is the definition)
+  std::vector<E> z(W_MAX, e_from(0)), ap(MAX_CONSTRAINTS, e_from(0));
   E r; Public pub; LookupParams lp;
+  pub.deferred = (uint32_t)mode;
   memset(&lp, 0, sizeof lp);
   return constraints_sum(z.data(), z.data(), z.data(), z.data(), e_from(0), e_from(0), e_from(0), pub, lp, ap.data(), r);
 }
@@ -798,13 +908,22 @@ static E horner_base(const std::vector<F>& coeffs, const E& z) { E acc = e_from(
 // header words 2..20 = everything both sides know before the first commitment; observed by the transcript in this order
 static void header_words(int log_n, const Public& pub, std::vector<uint32_t>& w) {
   w.clear();
-  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(phys_width(pub.deferred != 0)); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL); w.push_back(POW_BITS);
-  w.push_back((uint32_t)(pub.n_real & 0x3FFFFFFF)); w.push_back((uint32_t)(pub.n_real >> 30)); w.push_back(pub.deferred ? 1u : 0u);
+  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(phys_width(pub.mode())); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL); w.push_back(POW_BITS);
+  w.push_back((uint32_t)(pub.n_real & 0x3FFFFFFF)); w.push_back((uint32_t)(pub.n_real >> 30)); w.push_back((uint32_t)pub.mode());
   w.push_back((uint32_t)(pub.entry & 0xFFFFF)); w.push_back((uint32_t)((pub.entry >> 20) & 0xFFFFF)); w.push_back((uint32_t)(pub.entry >> 40));
   for (int i = 0; i < 4; i++) w.push_back(pub.prog[i]);
   for (int i = 0; i < 4; i++) w.push_back(pub.io[i]);
   for (int i = 0; i < N_STATE; i++) w.push_back(pub.first[i]);
   for (int i = 0; i < N_STATE; i++) w.push_back(pub.last[i]);
+  if (pub.mode() == 2) { w.push_back(pub.cnt_first[0]); w.push_back(pub.cnt_first[1]); w.push_back(pub.cnt_last[0]); w.push_back(pub.cnt_last[1]); }   // (oc, ic) of the first / last row
+}
+static inline int header_words_of(int mode) { return HEADER_WORDS + (mode == 2 ? 4 : 0); }
+// (mode 2) the I/O section of a proof, after the program: [n_in] [inputs: four 16-bit pieces each] [n_out] [outputs] [halt kind] [halt code: four pieces]
+static void put_u64(std::vector<uint32_t>& w, uint64_t v) { for (int i = 0; i < 4; i++) w.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); }
+static void io_section(const Public& pub, std::vector<uint32_t>& w) {
+  w.push_back((uint32_t)pub.n_in); for (size_t i = 0; i < pub.n_in; i++) put_u64(w, pub.inputs[i]);
+  w.push_back((uint32_t)pub.n_out); for (size_t i = 0; i < pub.n_out; i++) put_u64(w, pub.outputs[i]);
+  w.push_back(pub.halt_kind); put_u64(w, pub.halt_kind == 1 ? pub.halt_code : 0);
 }
 // the VM's initial state at `entry` (VMState::new, state.rs:55-71): cycle 0, pc = entry, all registers zero and Normalized
 static void initial_state(uint64_t entry, F st[N_STATE]) {
@@ -828,16 +947,17 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   Public pub = pub_in;
   const int log_n = padded_log_n(pub.n_real);
   const size_t N = (size_t)1 << log_n, N2 = 2 * N;
-  const bool Dm = pub.deferred != 0;
-  const int Wm = phys_width(Dm);
-  if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)W_MAIN * N);     // LOGICAL; whatever it holds in uncommitted columns is dropped
+  const int Dm = pub.mode();                                              // 0 default, 1 deferred, 2 default + the I/O argument
+  const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
+  if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wl * N);         // LOGICAL; whatever it holds in uncommitted columns is dropped
   else main_trace(rows, pub.n_real, pub, pt.M);
-  for (int c = 0; c < W_MAIN; c++) if (is_virtual(c, Dm)) std::fill(pt.M.begin() + (size_t)c * N, pt.M.begin() + (size_t)(c + 1) * N, 0);
+  for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(pt.M.begin() + (size_t)c * N, pt.M.begin() + (size_t)(c + 1) * N, 0);
   to_physical(pt.M, N, Dm, pt.Mp);
   for (int i = 0; i < N_STATE; i++) {                                     // boundary states: rows 0 and n_real - 1 of the matrix being proven
     pub.first[i] = pt.M[(size_t)state_col(i) * N];
     pub.last[i] = pt.M[(size_t)state_col(i) * N + (pub.n_real - 1)];
   }
+  if (Dm == 2) for (int k = 0; k < 2; k++) { pub.cnt_first[k] = pt.M[(size_t)(C_OC + k) * N]; pub.cnt_last[k] = pt.M[(size_t)(C_OC + k) * N + (pub.n_real - 1)]; }
   pt.L.assign((size_t)Wm * N2, 0);
   std::vector<std::vector<F>> coeffs(Wm);
   for (int k = 0; k < Wm; k++) {
@@ -852,9 +972,10 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   ch.observe_n(w.data() + 2, w.size() - 2);
   ch.observe_n(pt.trace_tree.layers.back().data(), 4);
   // ---- the program (its code words are the instruction ROM) and the lookup multiplicities, fixed BEFORE the lookup challenges ----
-  const Rom rom = rom_from_blob(pub.blob, pub.blob_len);
+  const Rom rom = rom_from_blob(pub.blob, pub.blob_len, Dm);
   w.push_back((uint32_t)pub.blob_len);
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
+  if (Dm == 2) io_section(pub, w);                                         // the tapes and the halt reason: what the io digest is a digest of
   lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
   w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
@@ -866,20 +987,25 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
     pt.lp.lam[0] = e_from(1);
     for (int j = 1; j <= N_TUPLE; j++) pt.lp.lam[j] = emul(pt.lp.lam[j - 1], lambda);
   }
-  pt.lp.t_over_n = emul_f(lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp), finv((F)(N % P)));
+  pt.lp.n_in = (F)(pub.n_in % P);
+  {
+    E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp);
+    if (Dm == 2) T = eadd(T, io_table_sum(pub, pt.lp));
+    pt.lp.t_over_n = emul_f(T, finv((F)(N % P)));
+  }
   // ---- aux trace: helper columns + running sum; its own LDE and commitment ----
-  aux_trace(pt.M, N, pt.lp, pt.A);
-  pt.AL.assign((size_t)W_AUX * N2, 0);
-  std::vector<std::vector<F>> acoeffs(W_AUX);
-  for (int k = 0; k < W_AUX; k++) {
+  aux_trace(pt.M, N, pt.lp, pt.A, Dm);
+  pt.AL.assign((size_t)Wa * N2, 0);
+  std::vector<std::vector<F>> acoeffs(Wa);
+  for (int k = 0; k < Wa; k++) {
     std::vector<F> e(pt.A.begin() + (size_t)k * N, pt.A.begin() + (size_t)(k + 1) * N), o;
     lde(e, 1, acoeffs[k], o);
     memcpy(&pt.AL[(size_t)k * N2], o.data(), N2 * 4);
   }
-  merkle_build(pt.AL, W_AUX, N2, pt.aux_tree);
+  merkle_build(pt.AL, Wa, N2, pt.aux_tree);
   ch.observe_n(pt.aux_tree.layers.back().data(), 4);
   pt.alpha = ch.sample_ext();
-  const int NC = num_constraints();
+  const int NC = num_constraints(Dm);
   std::vector<E> ap(NC); ap[0] = e_from(1); for (int c = 1; c < NC; c++) ap[c] = emul(ap[c - 1], pt.alpha);
 
   // ---- quotient on the LDE coset: x_j = g * w_2N^j, next row = position j + 2 ----
@@ -889,11 +1015,11 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   pt.Qc.assign(4 * N2, 0);
   {
     F x = GEN;
-    std::vector<E> ploc(Wm), pnxt(Wm), loc(W_MAIN), nxt(W_MAIN), aloc(W_AUX), anxt(W_AUX);
+    std::vector<E> ploc(Wm), pnxt(Wm), loc(W_MAX), nxt(W_MAX), aloc(W_AUX_MAX), anxt(W_AUX_MAX);
     for (size_t j = 0; j < N2; j++) {
       for (int k = 0; k < Wm; k++) { ploc[k] = e_from(pt.L[(size_t)k * N2 + j]); pnxt[k] = e_from(pt.L[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
       to_logical_row(ploc.data(), Dm, e_from(0), loc.data()); to_logical_row(pnxt.data(), Dm, e_from(0), nxt.data());
-      for (int k = 0; k < W_AUX; k++) { aloc[k] = e_from(pt.AL[(size_t)k * N2 + j]); anxt[k] = e_from(pt.AL[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      for (int k = 0; k < Wa; k++) { aloc[k] = e_from(pt.AL[(size_t)k * N2 + j]); anxt[k] = e_from(pt.AL[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
       const F zh = fsub((j & 1) ? fneg(gN) : gN, 1);                      // x^N - 1, x^N = g^N (-1)^j
       const F inv_zh = finv(zh);
       const E is_first = e_from(fmul(zh, finv(fsub(x, 1))));
@@ -912,10 +1038,10 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
 
   // ---- openings (oracle: Horner on coefficient vectors) ----
   // column order everywhere below (openings, gamma powers): main columns, then aux columns = W_ALL "trace" columns
-  const int Wt = Wm + W_AUX;
+  const int Wt = Wm + Wa;
   std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
   for (int k = 0; k < Wm; k++) { t_z[k] = horner_base(coeffs[k], pt.zeta); t_zw[k] = horner_base(coeffs[k], zeta_w); }
-  for (int k = 0; k < W_AUX; k++) { t_z[Wm + k] = horner_base(acoeffs[k], pt.zeta); t_zw[Wm + k] = horner_base(acoeffs[k], zeta_w); }
+  for (int k = 0; k < Wa; k++) { t_z[Wm + k] = horner_base(acoeffs[k], pt.zeta); t_zw[Wm + k] = horner_base(acoeffs[k], zeta_w); }
   for (int i = 0; i < 4; i++) {                                           // quotient columns: interpolate from the coset evaluations
     std::vector<F> ev(pt.Qc.begin() + (size_t)i * N2, pt.Qc.begin() + (size_t)(i + 1) * N2);
     ntt(ev, true);                                                        // coefficients of q_i(g x)
@@ -939,7 +1065,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
     for (size_t j = 0; j < N2; j++) {
       E A = e_from(0), B = e_from(0);
       for (int k = 0; k < Wm; k++) { const F v = pt.L[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[k], v)); B = eadd(B, emul_f(gp[Wt + k], v)); }
-      for (int k = 0; k < W_AUX; k++) { const F v = pt.AL[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[Wm + k], v)); B = eadd(B, emul_f(gp[Wt + Wm + k], v)); }
+      for (int k = 0; k < Wa; k++) { const F v = pt.AL[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[Wm + k], v)); B = eadd(B, emul_f(gp[Wt + Wm + k], v)); }
       for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wt + i], pt.Qc[(size_t)i * N2 + j]));
       const E d1 = einv(esub(e_from(x), pt.zeta)), d2 = einv(esub(e_from(x), zeta_w));
       cw[j] = eadd(emul(esub(A, a0), d1), emul(esub(B, b0), d2));
@@ -996,7 +1122,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   for (uint32_t q : pt.queries) {
     w.push_back(q);
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wm; k++) w.push_back(pt.L[(size_t)k * N2 + pos]); merkle_path(pt.trace_tree, pos, w); }
-    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < W_AUX; k++) w.push_back(pt.AL[(size_t)k * N2 + pos]); merkle_path(pt.aux_tree, pos, w); }
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wa; k++) w.push_back(pt.AL[(size_t)k * N2 + pos]); merkle_path(pt.aux_tree, pos, w); }
     for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int i = 0; i < 4; i++) w.push_back(pt.Qc[(size_t)i * N2 + pos]); merkle_path(pt.quot_tree, pos, w); }
     for (size_t j = 0; j < pt.fri_trees.size(); j++) {
       const size_t g = pt.fri[j].size() >> ks[j], idx = q & (g - 1);
@@ -1015,14 +1141,37 @@ static bool check_path(const F* leaf_digest, size_t idx, const uint32_t* path, i
 }
 // whole_run: the proof must start in the VM's initial state (check 7); otherwise it is a segment and `states_out` (nullable, 2 x 68
 // words: first, last) is what verify_chain() links.
-static int verify(const uint32_t* w, size_t len, const Public* expect, bool whole_run = true, F* states_out = nullptr) {
+// (mode 2) the I/O section of a proof -> the tapes and the halt reason; false = malformed
+struct IoSection { std::vector<uint64_t> in, out; uint32_t halt_kind = 2; uint64_t halt_code = 0; size_t words = 0; };
+static bool parse_io_section(const uint32_t* w, size_t avail, IoSection& io) {
+  size_t p = 0;
+  auto u64 = [&](uint64_t& v) { if (p + 4 > avail) return false; v = 0; for (int i = 0; i < 4; i++) { if (w[p + i] > 0xFFFF) return false; v |= (uint64_t)w[p + i] << (16 * i); } p += 4; return true; };
+  for (int tape = 0; tape < 2; tape++) {
+    if (p >= avail) return false;
+    const size_t n = w[p++];
+    if (n > ((size_t)1 << 28) || p + 4 * n > avail) return false;
+    std::vector<uint64_t>& t = tape ? io.out : io.in;
+    t.resize(n);
+    for (size_t k = 0; k < n; k++) if (!u64(t[k])) return false;
+  }
+  if (p >= avail) return false;
+  io.halt_kind = w[p++];
+  if (io.halt_kind > 2 || !u64(io.halt_code)) return false;
+  io.words = p;
+  return true;
+}
+static int halt_binding(const uint32_t* w, const F* last, int halt_kind, uint64_t halt_code);
+static int verify(const uint32_t* w, size_t len, const Public* expect, bool whole_run = true, F* states_out = nullptr, F* counters_out = nullptr) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
   if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
   const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5];
   if (nq != NUM_QUERIES || log_final != LOG_FINAL || w[6] != (uint32_t)POW_BITS || log_n < LOG_FINAL || log_n > 26) return 2;
   Public pub;
-  if (w[9] > 1 || Wm != phys_width(w[9] != 0)) return 2;                 // the committed width is the mode's
+  if (w[9] > 2 || Wm != phys_width((int)w[9])) return 2;                 // the committed width is the mode's (0 default, 1 deferred, 2 default + I/O)
+  const int mode = (int)w[9];
+  const int HW = header_words_of(mode), Wa = aux_width(mode);
+  if (!need(HW)) return 1;
   if (w[7] >= (1u << 30) || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
   pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
   pub.entry = (uint64_t)w[10] | ((uint64_t)w[11] << 20) | ((uint64_t)w[12] << 40);
@@ -1030,11 +1179,13 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   memcpy(pub.first, w + 21, N_STATE * 4); memcpy(pub.last, w + 21 + N_STATE, N_STATE * 4);
   for (int i = 0; i < 2 * N_STATE; i++) if (w[21 + i] >= P) return 3;
   if (pub.n_real == 0 || padded_log_n(pub.n_real) != log_n) return 2;
-  if (expect && (expect->n_real != pub.n_real || (expect->deferred != 0) != (pub.deferred != 0) || expect->entry != pub.entry ||
+  if (mode == 2) { for (int k = 0; k < 4; k++) if (w[HEADER_WORDS + k] >= P) return 3; memcpy(pub.cnt_first, w + HEADER_WORDS, 8); memcpy(pub.cnt_last, w + HEADER_WORDS + 2, 8); }
+  if (counters_out) { memcpy(counters_out, pub.cnt_first, 8); memcpy(counters_out + 2, pub.cnt_last, 8); }
+  if (expect && (expect->n_real != pub.n_real || expect->deferred != pub.deferred || expect->entry != pub.entry ||
                  memcmp(expect->prog, pub.prog, 16) || memcmp(expect->io, pub.io, 16))) return 6;
   if (whole_run) { F init[N_STATE]; initial_state(pub.entry, init); if (memcmp(init, pub.first, sizeof init)) return 7; }
   if (states_out) { memcpy(states_out, pub.first, N_STATE * 4); memcpy(states_out + N_STATE, pub.last, N_STATE * 4); }
-  p = HEADER_WORDS;
+  p = HW;
   const size_t N = (size_t)1 << log_n;
   for (size_t i = 2; i < len; i++) if (w[i] >= P) return 3;   // every payload word must be canonical (query indices are < N < p)
   // the program: [byte length][16-bit halfwords]; its digest must be the header's, its entry point the header's (check 8)
@@ -1049,15 +1200,34 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   }
   p += (blob_len + 1) / 2;
   { F dg[DIGEST]; digest_bytes(blob.data(), blob_len, dg); if (memcmp(dg, pub.prog, 16)) return 8; }
-  const Rom rom = rom_from_blob(blob.data(), blob_len);
+  const Rom rom = rom_from_blob(blob.data(), blob_len, mode);
   if (!rom.ok || rom.entry != pub.entry) return 8;
+  // (mode 2) the tapes and the halt reason the io digest is a digest of (check 50: with the cycle count — a whole run's is its row count; a chain checks the
+  // digest over the total), the counters' ends (51), and the halt row named by the halt reason (52 / 53)
+  IoSection io;
+  if (mode == 2) {
+    if (!parse_io_section(w + p, len - p, io)) return 4;
+    p += io.words;
+    pub.inputs = io.in.data(); pub.n_in = io.in.size(); pub.outputs = io.out.data(); pub.n_out = io.out.size(); pub.halt_kind = io.halt_kind; pub.halt_code = io.halt_code;
+    if (pub.cnt_first[0] > pub.cnt_last[0] || pub.cnt_first[1] > pub.cnt_last[1] || pub.cnt_last[0] > pub.n_out || pub.cnt_last[1] > pub.n_in) return 51;
+    if (whole_run) {
+      std::vector<uint64_t> b;
+      b.push_back(pub.n_in); b.insert(b.end(), io.in.begin(), io.in.end()); b.push_back(pub.n_out); b.insert(b.end(), io.out.begin(), io.out.end());
+      b.push_back(pub.halt_kind); b.push_back(pub.halt_kind == 1 ? pub.halt_code : 0); b.push_back(pub.n_real);
+      F dg[DIGEST]; digest_bytes((const uint8_t*)b.data(), b.size() * 8, dg);
+      if (memcmp(dg, pub.io, 16)) return 50;
+      if (pub.cnt_first[0] || pub.cnt_first[1] || pub.cnt_last[0] != pub.n_out) return 51;              // every output was written, none before the run began
+      const int hb = halt_binding(w, pub.last, (int)pub.halt_kind, pub.halt_code);
+      if (hb) return hb;
+    }
+  }
   if (!need(rom.n + RC_TABLE)) return 4;
   const F* rom_mult = w + p; p += rom.n;
   const F* rc_mult = w + p; p += RC_TABLE;
   if (!need(12)) return 4;
   const F* troot = w + p; p += 4; const F* aroot = w + p; p += 4; const F* qroot = w + p; p += 4;
   auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
-  const int Wt = Wm + W_AUX;
+  const int Wt = Wm + Wa;
   if (!need((size_t)(2 * Wt + 4) * 4)) return 4;
   std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
   for (int k = 0; k < Wt; k++) { t_z[k] = get_e(p); p += 4; }
@@ -1075,7 +1245,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   const F pow_nonce = w[p++];
   // transcript
   Challenger ch;
-  ch.observe_n(w + 2, HEADER_WORDS - 2);
+  ch.observe_n(w + 2, HW - 2);
   ch.observe_n(troot, 4);
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
@@ -1086,7 +1256,12 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     lp.lam[0] = e_from(1);
     for (int j = 1; j <= N_TUPLE; j++) lp.lam[j] = emul(lp.lam[j - 1], lambda);
   }
-  lp.t_over_n = emul_f(lookup_table_sum(rom, rom_mult, rc_mult, lp), finv((F)(N % P)));   // the table side of the lookup identity, computed HERE
+  lp.n_in = (F)(pub.n_in % P);
+  {
+    E T = lookup_table_sum(rom, rom_mult, rc_mult, lp);                    // the table side of the lookup identity, computed HERE
+    if (mode == 2) T = eadd(T, io_table_sum(pub, lp));                     // .. its I/O share from the tapes the proof carries
+    lp.t_over_n = emul_f(T, finv((F)(N % P)));
+  }
   ch.observe_n(aroot, 4);
   const E alpha = ch.sample_ext();
   ch.observe_n(qroot, 4);
@@ -1101,15 +1276,15 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   if (!ch.check_pow(pow_nonce)) return 12;
   // 1. constraints at zeta:  Σ alpha^c C_c(zeta) == Q(zeta) * Z_H(zeta)
   {
-    const int NC = num_constraints();
+    const int NC = num_constraints(mode);
     std::vector<E> ap(NC); ap[0] = e_from(1); for (int c = 1; c < NC; c++) ap[c] = emul(ap[c - 1], alpha);
     const F wn = root_of_unity(log_n);
     const E zN = epow(zeta, N), zh = esub(zN, e_from(1));
     const E is_first = emul(zh, einv(esub(zeta, e_from(1))));
     const E is_last = emul(zh, einv(esub(zeta, e_from(fpow(wn, pub.n_real - 1)))));
     const E is_trans = esub(zeta, e_from(finv(wn)));
-    std::vector<E> loc(W_MAIN), nxt(W_MAIN);                              // the logical rows at zeta and zeta w: uncommitted columns are the constant 0
-    to_logical_row(t_z.data(), pub.deferred != 0, e_from(0), loc.data()); to_logical_row(t_zw.data(), pub.deferred != 0, e_from(0), nxt.data());
+    std::vector<E> loc(W_MAX), nxt(W_MAX);                                // the logical rows at zeta and zeta w: uncommitted columns are the constant 0
+    to_logical_row(t_z.data(), mode, e_from(0), loc.data()); to_logical_row(t_zw.data(), mode, e_from(0), nxt.data());
     E lhs; constraints_sum(loc.data(), nxt.data(), t_z.data() + Wm, t_zw.data() + Wm, is_first, is_last, is_trans, pub, lp, ap.data(), lhs);
     E qz = e_from(0);
     for (int i = 0; i < 4; i++) { E basis = e_from(0); basis.c[i] = 1; qz = eadd(qz, emul(basis, q_z[i])); }
@@ -1147,9 +1322,9 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     }
     for (int s2 = 0; s2 < 2; s2++) {
       const size_t pos = (size_t)q + (s2 ? N : 0);
-      if (!need((size_t)W_AUX + 4 * depth0)) return 4;
-      al[s2] = w + p; p += W_AUX;
-      F dg[4]; hash_elems(al[s2], W_AUX, dg);
+      if (!need((size_t)Wa + 4 * depth0)) return 4;
+      al[s2] = w + p; p += Wa;
+      F dg[4]; hash_elems(al[s2], Wa, dg);
       if (!check_path(dg, pos, w + p, depth0, aroot)) return 27;
       p += 4 * depth0;
     }
@@ -1166,7 +1341,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
       const F x = fmul(GEN, fpow(w2n, pos));
       E A = e_from(0), B = e_from(0);
       for (int k = 0; k < Wm; k++) { A = eadd(A, emul_f(gp[k], tl[s2][k])); B = eadd(B, emul_f(gp[Wt + k], tl[s2][k])); }
-      for (int k = 0; k < W_AUX; k++) { A = eadd(A, emul_f(gp[Wm + k], al[s2][k])); B = eadd(B, emul_f(gp[Wt + Wm + k], al[s2][k])); }
+      for (int k = 0; k < Wa; k++) { A = eadd(A, emul_f(gp[Wm + k], al[s2][k])); B = eadd(B, emul_f(gp[Wt + Wm + k], al[s2][k])); }
       for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wt + i], ql[s2][i]));
       deep[s2] = eadd(emul(esub(A, a0), einv(esub(e_from(x), zeta))), emul(esub(B, b0), einv(esub(e_from(x), zeta_w))));
     }
@@ -1208,10 +1383,10 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
 // segment i failed.
 static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n, const Public* expect) {
   if (n < 1) return 40;
-  std::vector<F> st((size_t)n * 2 * N_STATE);
+  std::vector<F> st((size_t)n * 2 * N_STATE), cnt((size_t)n * 4, 0);
   uint64_t total = 1;
   for (int i = 0; i < n; i++) {
-    const int rc = verify(proofs[i], lens[i], nullptr, false, &st[(size_t)i * 2 * N_STATE]);
+    const int rc = verify(proofs[i], lens[i], nullptr, false, &st[(size_t)i * 2 * N_STATE], &cnt[(size_t)i * 4]);
     if (rc) return 1000 * (i + 1) + rc;
     const uint32_t* w = proofs[i];
     total += ((uint64_t)w[7] | ((uint64_t)w[8] << 30)) - 1;
@@ -1224,8 +1399,27 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
   for (int i = 1; i < n; i++)
     if (memcmp(&st[(size_t)i * 2 * N_STATE], &st[(size_t)(i - 1) * 2 * N_STATE + N_STATE], N_STATE * 4)) return 42;
   if (expect) {
-    if ((expect->deferred != 0) != (w0[9] != 0) || expect->entry != entry || memcmp(expect->prog, w0 + 13, 16) || memcmp(expect->io, w0 + 17, 16)) return 43;
+    if (expect->deferred != w0[9] || expect->entry != entry || memcmp(expect->prog, w0 + 13, 16) || memcmp(expect->io, w0 + 17, 16)) return 43;
     if (expect->n_real != total) return 44;
+  }
+  if (w0[9] == 2) {
+    // (mode 2) the I/O argument across segments: every segment carries the same tapes, the counters start at (0, 0), link up and end with every output written;
+    // the tapes + halt reason + TOTAL cycle count hash to the io digest; the last segment's last row is the instruction the halt reason names
+    const int HW = header_words_of(2);
+    auto io_at = [&](const uint32_t* w) { return HW + 1 + (size_t)(w[HW] + 1) / 2; };
+    IoSection io0;
+    if (!parse_io_section(w0 + io_at(w0), lens[0] - io_at(w0), io0)) return 4;
+    for (int i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
+    if (cnt[0] || cnt[1]) return 51;
+    for (int i = 1; i < n; i++) if (cnt[(size_t)i * 4] != cnt[(size_t)(i - 1) * 4 + 2] || cnt[(size_t)i * 4 + 1] != cnt[(size_t)(i - 1) * 4 + 3]) return 46;
+    if (cnt[(size_t)(n - 1) * 4 + 2] != io0.out.size()) return 51;
+    std::vector<uint64_t> b;
+    b.push_back(io0.in.size()); b.insert(b.end(), io0.in.begin(), io0.in.end()); b.push_back(io0.out.size()); b.insert(b.end(), io0.out.begin(), io0.out.end());
+    b.push_back(io0.halt_kind); b.push_back(io0.halt_kind == 1 ? io0.halt_code : 0); b.push_back(total);
+    F dg[DIGEST]; digest_bytes((const uint8_t*)b.data(), b.size() * 8, dg);
+    if (memcmp(dg, w0 + 17, 16)) return 50;
+    const int hb = halt_binding(proofs[n - 1], proofs[n - 1] + 21 + N_STATE, (int)io0.halt_kind, io0.halt_code);
+    if (hb) return hb;
   }
   return 0;
 }
@@ -1234,9 +1428,10 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
 static int halt_binding(const uint32_t* w, const F* last, int halt_kind, uint64_t halt_code) {
   if (halt_kind == 2) return 0;
   if (halt_kind != 0 && halt_kind != 1) return 52;
-  const size_t blob_len = w[HEADER_WORDS];
+  const int HW = header_words_of((int)w[9]);
+  const size_t blob_len = w[HW];
   std::vector<uint8_t> blob(blob_len);
-  for (size_t i = 0; i < blob_len; i += 2) { const uint32_t h = w[HEADER_WORDS + 1 + i / 2]; blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8); }
+  for (size_t i = 0; i < blob_len; i += 2) { const uint32_t h = w[HW + 1 + i / 2]; blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8); }
   if (blob_len < 32) return 52;
   const uint32_t code_size = (uint32_t)blob[16] | ((uint32_t)blob[17] << 8) | ((uint32_t)blob[18] << 16) | ((uint32_t)blob[19] << 24);
   const uint64_t pc = (uint64_t)last[1] | ((uint64_t)last[2] << 20) | ((uint64_t)last[3] << 40);
@@ -1285,10 +1480,15 @@ static int verify_chain_io(const uint32_t* const* proofs, const size_t* lens, in
 // C API (ctypes)
 // =================================================================================================
 extern "C" {
-struct so_public { uint64_t n_real; uint32_t deferred; uint32_t pad; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; const uint8_t* blob; uint64_t blob_len; };
+struct so_public { uint64_t n_real; uint32_t deferred; uint32_t pad; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; const uint8_t* blob; uint64_t blob_len;
+                   // mode 2 (deferred == 2): the tapes and the halt reason in the clear; for a segment, the WRITE / READ ecalls executed before its first row
+                   const uint64_t* inputs; uint64_t n_inputs; const uint64_t* outputs; uint64_t n_outputs; uint32_t halt_kind; uint32_t pad2; uint64_t halt_code;
+                   uint64_t writes_before, reads_before; };
 static so::Public to_pub(const so_public* p) {
   so::Public q; q.n_real = p->n_real; q.deferred = p->deferred; q.entry = p->entry; memcpy(q.prog, p->prog, 16); memcpy(q.io, p->io, 16);
   q.blob = p->blob; q.blob_len = (size_t)p->blob_len;
+  q.inputs = p->inputs; q.n_in = (size_t)p->n_inputs; q.outputs = p->outputs; q.n_out = (size_t)p->n_outputs; q.halt_kind = p->halt_kind; q.halt_code = p->halt_code;
+  q.writes_before = p->writes_before; q.reads_before = p->reads_before;
   return q;
 }
 uint32_t so_p() { return so::P; }
@@ -1314,11 +1514,14 @@ void so_lde(const uint32_t* evals, size_t n, int log_blowup, uint32_t* coeffs, u
   memcpy(out, o.data(), o.size() * 4);
 }
 int so_main_trace_width() { return so::W_MAIN; }                                   // LOGICAL columns (what so_main_trace writes and the constraints read)
-int so_committed_width(int deferred) { return so::phys_width(deferred != 0); }     // columns of the committed matrix: 144 (default mode) / 160 (deferred)
-// logical [W_MAIN][n] -> committed [so_committed_width][n]
-void so_to_committed(const uint32_t* logical, size_t n, int deferred, uint32_t* out) {
-  std::vector<so::F> M(logical, logical + (size_t)so::W_MAIN * n), o;
-  so::to_physical(M, n, deferred != 0, o);
+int so_committed_width(int mode) { return so::phys_width(mode); }                  // columns of the committed matrix: 152 (mode 0: default) / 168 (1: deferred) / 160 (2: default + I/O)
+int so_logical_width(int mode) { return so::logical_width(mode); }                 // 172 / 172 / 180
+int so_aux_width_for(int mode) { return so::aux_width(mode); }                     // 40 / 40 / 48
+int so_num_constraints_for(int mode) { return so::num_constraints(mode); }         // 398 / 398 / 430
+// logical [so_logical_width][n] -> committed [so_committed_width][n]
+void so_to_committed(const uint32_t* logical, size_t n, int mode, uint32_t* out) {
+  std::vector<so::F> M(logical, logical + (size_t)so::logical_width(mode) * n), o;
+  so::to_physical(M, n, mode, o);
   memcpy(out, o.data(), o.size() * 4);
 }
 int so_padded_log_n(uint64_t n_real) { return so::padded_log_n(n_real); }
@@ -1396,6 +1599,26 @@ int so_constraints_eval_states(const uint32_t* loc, const uint32_t* nxt, const u
   memcpy(out4, r.c, 16);
   return NC;
 }
+// the same in MODE 2: 180 logical columns, 48 aux columns, lk = the 56 words + n_in, cnt4 = (oc, ic) of the first row, (oc, ic) of the last row
+int so_constraints_eval_io(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk57, uint32_t is_first, uint32_t is_last,
+                           uint32_t is_trans, const so_public* pub, const uint32_t* first68, const uint32_t* last68, const uint32_t* cnt4, const uint32_t* alpha4, uint32_t* out4) {
+  const int NC = so::num_constraints(2);
+  so::E a; memcpy(a.c, alpha4, 16);
+  std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
+  std::vector<so::E> l(so::W_MAX), x(so::W_MAX), al(so::W_AUX_MAX), ax(so::W_AUX_MAX);
+  for (int k = 0; k < so::W_MAX; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
+  for (int k = 0; k < so::W_AUX_MAX; k++) { al[k] = so::e_from(aloc[k]); ax[k] = so::e_from(anxt[k]); }
+  so::Public q = to_pub(pub);
+  q.deferred = 2;
+  memcpy(q.first, first68, sizeof q.first); memcpy(q.last, last68, sizeof q.last);
+  memcpy(q.cnt_first, cnt4, 8); memcpy(q.cnt_last, cnt4 + 2, 8);
+  so::LookupParams lp = lk_unpack(lk57);
+  lp.n_in = lk57[56];
+  so::E r;
+  so::constraints_sum(l.data(), x.data(), al.data(), ax.data(), so::e_from(is_first), so::e_from(is_last), so::e_from(is_trans), q, lp, ap.data(), r);
+  memcpy(out4, r.c, 16);
+  return NC;
+}
 // Merkle root (and optionally every layer, concatenated leaf-layer first) of a column-major matrix [width][n]
 void so_merkle(const uint32_t* mat, int width, size_t n, uint32_t* root4, uint32_t* all_layers /* nullable, 4*(2n-1) */) {
   std::vector<so::F> m(mat, mat + (size_t)width * n);
@@ -1408,8 +1631,8 @@ void so_commit_trace(const void* packed_rows, const so_public* pub, int log_blow
   std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m);
   const size_t n = (size_t)1 << so::padded_log_n(pub->n_real);
   size_t big = n << log_blowup;
-  const int Wm = so::phys_width(pub->deferred != 0);
-  std::vector<so::F> mp; so::to_physical(m, n, pub->deferred != 0, mp);
+  const int Wm = so::phys_width((int)pub->deferred);
+  std::vector<so::F> mp; so::to_physical(m, n, (int)pub->deferred, mp);
   std::vector<so::F> L((size_t)Wm * big);
   for (int k = 0; k < Wm; k++) {
     std::vector<so::F> e(mp.begin() + (size_t)k * n, mp.begin() + (size_t)(k + 1) * n), c, o;
