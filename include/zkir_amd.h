@@ -287,6 +287,13 @@ double zkir_modmul_peak_per_s(void* hip_stream);
 /* trace columns (K1 output, n_real executed rows) -> main trace matrix (B8: zkir_main_trace_width_for(deferred) / 8 blocks [N][8]), N = 2^zkir_padded_log_n(n_real): rows past n_real are
  * padding (class "pad": state of the last executed row, cycle keeps counting).  deferred = VMConfig.enable_deferred_model of the run. */
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* hip_stream);
+/* The main trace of MODE 2 (default VM mode + the I/O argument: 160 committed columns): ECALL rows are dispatched on R10, every row shows the counters of the WRITE ecalls /
+ * consumed inputs before it — a prefix count over the rows (scratch: 2 N + 2 (N / 1024 + 2) words of device memory, N = the padded row count).  inputs = the input tape ON
+ * THE DEVICE (a live READ row's written value is looked up against it). */
+typedef struct zkir_io_args { const uint64_t* inputs; uint64_t n_inputs; uint64_t writes_before, reads_before; } zkir_io_args;
+int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* scratch, uint32_t* out, void* hip_stream);
+/* the same on the HOST (host pointers everywhere; no scratch): a test entry point like zkir_main_trace_host */
+int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out);
 /* the same rows computed on the HOST (trace = host pointers, out = host buffer, same B8 layout): the kernel's per-row code is one host + device
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */
@@ -304,7 +311,8 @@ int zkir_ntt_strided_variant_launch(const zkir_stark_ctx* ctx, uint32_t* data, u
  * words), lookup parameters lk[56] (alpha, lambda^0..11, T / N), selector values, the two boundary states and alpha.
  * zkir_air_check_bounds: the static soundness check of that arithmetic on the constraint list (air.h: BoundOps): 0 = sound, else the broken rule. */
 void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, uint32_t is_first, uint32_t is_last, uint32_t is_trans,
-                        const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t deferred, uint32_t* out4);
+                        const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t mode /* 0 default, 1 deferred, 2 default + I/O: 180 / 48 columns, lk[57] */,
+                        const uint32_t* cnt4 /* mode 2: (oc, ic) of the first and of the last row; else NULL */, uint32_t* out4);
 int zkir_air_check_bounds(uint32_t deferred, char* why, size_t why_len);
 /* per-column low-degree extension: in = B8 matrix with N rows (evaluations over <w_N>, natural order; CLOBBERED as scratch when N >= 1024)
  * -> out = B8 matrix with 2N rows = evaluations over the coset 31*<w_2N>, natural order.  All 8 columns of every block are transformed. */
@@ -326,7 +334,7 @@ int zkir_merkle_cap_launch(const zkir_stark_ctx* ctx, uint32_t* tree, uint64_t n
 typedef struct zkir_public_inputs {
   uint64_t n_real;             /* executed rows = ExecutionResult.cycles */
   uint64_t entry_point;        /* ProgramHeader.entry_point: pc of row 0 (constrained) */
-  uint32_t deferred;           /* VMConfig.enable_deferred_model (the opcode semantics of the AIR are the default mode's) */
+  uint32_t deferred;           /* the proof's MODE: 0 = default VM mode, 1 = VMConfig.enable_deferred_model (relaxed AIR), 2 = default mode + the I/O argument (below) */
   uint32_t reserved;
   uint32_t program_digest[4];  /* zkir_digest_bytes(program blob) */
   uint32_t io_digest[4];       /* zkir_digest_bytes(LE u64 words [n_inputs, inputs.., n_outputs, outputs.., halt kind, halt code, cycles]) */
@@ -335,6 +343,18 @@ typedef struct zkir_public_inputs {
    * the instruction ROM of the lookup argument; the proof carries the program (format v5 on; zkir_proof_version() = the current format), the verifier checks it against program_digest. */
   const uint8_t* program_blob;
   uint64_t program_blob_len;
+  /* MODE 2 (`deferred` == 2, round 4): the default VM mode WITH the I/O argument — WRITE / READ ecalls are tied by a lookup to the tapes below, which the proof then
+   * carries (their digest, with the halt reason and the cycle count, is io_digest); the verifier also checks that the run ends on the instruction the halt reason names.
+   * PROVER side (BORROWED pointers, filled by zkir_public_inputs_of; ignored in a verifier's `expect`).  For a SEGMENT of a run the caller sets writes_before /
+   * reads_before: the WRITE / READ ecalls the run executed before the segment's first row. */
+  const uint64_t* inputs;
+  uint64_t n_inputs;
+  const uint64_t* outputs;
+  uint64_t n_outputs;
+  uint32_t halt_kind;          /* ZKIR_HALT_* */
+  uint32_t reserved2;
+  uint64_t halt_code;
+  uint64_t writes_before, reads_before;
 } zkir_public_inputs;
 /* Poseidon2 sponge digest of a byte string (host): [len as four 16-bit pieces] ++ [LE 16-bit halfwords] */
 void zkir_digest_bytes(const uint8_t* bytes, size_t len, uint32_t out[4]);

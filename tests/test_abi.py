@@ -132,9 +132,9 @@ def test_quotient_arithmetic_is_sound_on_the_constraint_list():
     L = rt.lib()
     L.zkir_air_check_bounds.restype = C.c_int
     L.zkir_air_check_bounds.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
-    for deferred in (0, 1):
+    for mode in (0, 1, 2):                                   # default, deferred, default + the I/O argument
         why = C.create_string_buffer(256)
-        assert L.zkir_air_check_bounds(deferred, why, 256) == 0, why.value.decode()
+        assert L.zkir_air_check_bounds(mode, why, 256) == 0, why.value.decode()
 
 
 @pytest.mark.parametrize("deferred", [False, True])
@@ -147,7 +147,7 @@ def test_quotient_evaluation_matches_oracle_constraints(deferred):
     from oracle import stark_api as so
     L = rt.lib()
     L.zkir_air_eval_host.restype = None
-    L.zkir_air_eval_host.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p]
+    L.zkir_air_eval_host.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_void_p]
     P = so.P
     rng = np.random.default_rng(2026)
     virt = [9, 10, 11] + ([57] if deferred else list(range(57, 73)) + [161])       # air.h is_virtual: R0's limbs; the storage states (default: all 16 + class oj)
@@ -163,5 +163,83 @@ def test_quotient_evaluation_matches_oracle_constraints(deferred):
         want = so.constraints_eval_states(loc, nxt, aloc, anxt, lk, sel[0], sel[1], sel[2], pub, first, last, alpha)
         got = np.zeros(4, np.uint32)
         L.zkir_air_eval_host(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]),
-                             first.ctypes.data, last.ctypes.data, alpha.ctypes.data, int(deferred), got.ctypes.data)
+                             first.ctypes.data, last.ctypes.data, alpha.ctypes.data, int(deferred), None, got.ctypes.data)
         assert np.array_equal(got, want), (trial, got, want)
+
+
+def test_quotient_evaluation_matches_oracle_constraints_mode2():
+    """The same in MODE 2 (default VM mode + the I/O argument: 180 logical / 48 aux columns, 430 constraints, the counters' boundary words, n_in among the lookup parameters)."""
+    import ctypes as C
+    import numpy as np
+    from oracle import stark_api as so
+    L = rt.lib()
+    L.zkir_air_eval_host.restype = None
+    L.zkir_air_eval_host.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_void_p]
+    LO = so.lib()
+    LO.so_constraints_eval_io.restype = C.c_int
+    LO.so_constraints_eval_io.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 6
+    P = so.P
+    rng = np.random.default_rng(2027)
+    virt = [9, 10, 11] + list(range(57, 73)) + [161]
+    blob = spec.fib_program(5).to_bytes()
+    pub = so.public_inputs(64, blob, [], [5], (1, 0), io_mode=True)
+    assert LO.so_num_constraints_for(2) == 430
+    for trial in range(40):
+        big = trial >= 36
+        def words(n):
+            return np.full(n, P - 1, np.uint32) if big else rng.integers(0, P, n).astype(np.uint32)
+        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(180), words(180), words(48), words(48), words(57), words(68), words(68), words(4), words(4), words(3)
+        loc[virt] = 0; nxt[virt] = 0
+        want, got = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+        LO.so_constraints_eval_io(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]), C.byref(pub),
+                                  first.ctypes.data, last.ctypes.data, cnt.ctypes.data, alpha.ctypes.data, want.ctypes.data)
+        L.zkir_air_eval_host(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]),
+                             first.ctypes.data, last.ctypes.data, alpha.ctypes.data, 2, cnt.ctypes.data, got.ctypes.data)
+        assert np.array_equal(got, want), (trial, got, want)
+
+
+def _io_program():
+    """READ, READ, WRITE their 40-bit sum, READ on the exhausted tape, WRITE that 0, EXIT(3) (syscall.rs:101-121)."""
+    code = [spec.addi(10, 0, 1), spec.ecall(), spec.addi(5, 10, 0), spec.addi(10, 0, 1), spec.ecall(), spec.add(6, 5, 10), spec.addi(11, 6, 0), spec.addi(10, 0, 2), spec.ecall(),
+            spec.addi(10, 0, 1), spec.ecall(), spec.addi(11, 10, 0), spec.addi(10, 0, 2), spec.ecall(), spec.addi(10, 0, 0), spec.addi(11, 0, 3), spec.ecall()]
+    return spec.Program.from_code(code).to_bytes(), [1000, (1 << 45) + 77]
+
+
+@pytest.mark.parametrize("which", ["io", "fib12", "sha"])
+def test_main_trace_mode2_row_code_matches_oracle_on_the_host(which):
+    """zkir_main_trace_io_host (stark.hip: main_trace_row<2> + the sequential form of the ecall prefix counts) against the oracle's mode-2 main trace: every committed column
+    of every row, on a program that reads, writes and exhausts its tape, on fib(12) (one WRITE, exit) and on the SHA-256 chain (hash ecalls only)."""
+    import numpy as np
+    from oracle import api as oracle, stark_api as so
+    if which == "io":
+        blob, ins = _io_program()
+        res = oracle.run(blob, ins, enable_execution_trace=True)
+    elif which == "fib12":
+        blob, ins = spec.fib_program(12).to_bytes(), []
+        res = oracle.run(blob, enable_execution_trace=True)
+    else:
+        blob, ins = spec.sha256_chain_program().to_bytes(), []
+        res = oracle.run(blob, max_cycles=300, enable_execution_trace=True)
+    rows = res.rows
+    nr = len(rows)
+    cyc, pc, ins_c = (np.ascontiguousarray(rows[f]) for f in ("cycle", "pc", "instruction"))
+    regs, bb_, bt, bp, st = (np.ascontiguousarray(rows[f].T) for f in ("registers", "bound_bits", "bound_tag", "bound_payload", "reg_state"))
+    tc = rt.TraceColumnsC(cyc.ctypes.data, pc.ctypes.data, ins_c.ctypes.data, regs.ctypes.data, bb_.ctypes.data, bt.ctypes.data, bp.ctypes.data, st.ctypes.data, nr)
+    N = 1 << so.padded_log_n(nr)
+    wm = so.committed_width(2)
+    assert wm == 160
+    out = np.zeros((wm // 8, N, 8), np.uint32)
+    tape = np.asarray(ins if ins else [0], dtype=np.uint64)
+
+    class IoArgs(C.Structure):
+        _fields_ = [("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+    io = IoArgs(tape.ctypes.data, len(ins), 0, 0)
+    L = rt.lib()
+    L.zkir_main_trace_io_host.restype = C.c_int
+    L.zkir_main_trace_io_host.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert L.zkir_main_trace_io_host(C.byref(tc), nr, C.byref(io), out.ctypes.data) == 0
+    got = out.transpose(0, 2, 1).reshape(wm, N)
+    pub = so.public_inputs(nr, blob, ins, list(res.outputs), (res.halt_kind, res.halt_code), io_mode=True)
+    want = so.to_committed(so.main_trace(rows, pub), 2)
+    for k in range(wm):
+        assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"

@@ -452,3 +452,76 @@ def test_a_run_proven_in_segments_on_the_gpu(name, n_total, seg):
     assert rt.verify_chain(proofs, run_pub) == 0 and so.verify_chain(proofs, run_opub) == 0
     assert rt.verify(proofs[1]) == 7 and rt.verify_chain(proofs[1:]) == 41 and rt.verify_chain([proofs[0]] + proofs[2:]) == 42
     log.close()
+
+
+# ---- MODE 2 (round 4): the default VM mode with the I/O argument -----------------------------------------------------------------------------------------
+def _io_program():
+    """READ, READ, WRITE their 40-bit sum, READ on the exhausted tape, WRITE that 0, EXIT(3) (syscall.rs:101-121)."""
+    code = [spec.addi(10, 0, 1), spec.ecall(), spec.addi(5, 10, 0), spec.addi(10, 0, 1), spec.ecall(), spec.add(6, 5, 10), spec.addi(11, 6, 0), spec.addi(10, 0, 2), spec.ecall(),
+            spec.addi(10, 0, 1), spec.ecall(), spec.addi(11, 10, 0), spec.addi(10, 0, 2), spec.ecall(), spec.addi(10, 0, 0), spec.addi(11, 0, 3), spec.ecall()]
+    return spec.Program.from_code(code).to_bytes(), [1000, (1 << 45) + 77]
+
+
+def _mode2_case(which):
+    from zkir_amd import pipeline as pl
+    if which == "io":
+        blob, ins = _io_program(); n = None
+    elif which == "fib30":
+        blob, ins, n = spec.fib_program(30).to_bytes(), [], None
+    elif which == "sha":
+        blob, ins, n = spec.sha256_chain_program().to_bytes(), [], 700
+    else:                                                                   # a long loop that WRITEs every iteration and exits: 400 outputs
+        code = [spec.addi(1, 0, 0), spec.addi(3, 0, 400), spec.addi(1, 1, 3), spec.addi(11, 1, 0), spec.addi(10, 0, 2), spec.ecall(), spec.addi(3, 3, -1), spec.bne(3, 0, -20),
+                spec.addi(10, 0, 0), spec.addi(11, 0, 7), spec.ecall()]
+        blob, ins, n = spec.Program.from_code(code).to_bytes(), [], None
+    cfg = dict(max_cycles=n) if n else {}
+    ores = oracle.run(blob, ins, enable_execution_trace=True, **cfg)
+    log = rt.interpret(blob, ins, rt.VMConfig(enable_execution_trace=True, **cfg))
+    assert log.n_rows == len(ores.rows)
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    opub = so.public_inputs(len(ores.rows), blob, ins, list(ores.outputs), (ores.halt_kind, ores.halt_code), io_mode=True)
+    pub = rt.public_inputs(log, blob, ins, io_mode=True)
+    assert pub.deferred == 2 and list(pub.io_digest) == list(opub.io)
+    return blob, ins, ores, log, tr, opub, pub
+
+
+@pytest.mark.parametrize("which", ["io", "fib30", "sha", "writes"])
+def test_mode2_proof_bytes_match_oracle_and_verify(which):
+    """A proof in mode 2 — ECALL rows dispatched on R10, WRITE / READ rows tied to the tapes the proof carries — from the GPU prover equals the oracle's word for word;
+    both verifiers accept it (their zkir_verify now also checks the io digest against the carried tapes and the halt row), zkir_verify_io agrees with the claim."""
+    from zkir_amd import stark
+    blob, ins, ores, log, tr, opub, pub = _mode2_case(which)
+    ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
+    proof = stark.prove(ctx, tr, pub)
+    want = so.prove(ores.rows, opub)
+    assert proof[3] == 160 and proof[9] == 2 and len(proof) == len(want)
+    if not np.array_equal(proof, want):
+        bad = np.nonzero(proof != want)[0]
+        raise AssertionError(f"mode-2 proof differs at word {bad[0]} of {len(want)} ({len(bad)} words differ)")
+    assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0 and rt.verify(proof) == 0
+    assert rt.verify_io(proof, pub, ins, list(ores.outputs), (ores.halt_kind, ores.halt_code)) == 0
+    for pos in (8, 30, 158, 160, len(proof) // 2, len(proof) - 1):
+        t = proof.copy()
+        t[pos] = (int(t[pos]) + 1) % P
+        assert so.verify(t) != 0 and rt.verify(t) == so.verify(t), pos
+    ctx.close(); log.close()
+
+
+def test_mode2_forged_outputs_are_rejected_on_the_gpu_path():
+    """The GPU prover given public inputs that CLAIM other outputs than the trace writes (digest recomputed for the claim): the table side of the tape lookup is formed from the
+    claim, the row side from the trace — the proof it emits fails the constraint check in both verifiers (10); a claim with too few / too many outputs is refused by
+    the prover or fails the counters' check (51)."""
+    from zkir_amd import stark
+    blob, ins, ores, log, tr, opub, pub = _mode2_case("fib30")
+    ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
+    assert list(ores.outputs) == [832040]
+    fake = so.public_inputs(len(ores.rows), blob, ins, [832041], (ores.halt_kind, ores.halt_code), io_mode=True)
+    fpub = pub.copy(); fpub.with_io(ins, [832041]); fpub.io_digest[:] = list(fake.io)
+    proof = stark.prove(ctx, tr, fpub)
+    assert so.verify(proof, fake) == rt.verify(proof, fpub) == 10
+    assert np.array_equal(proof, so.prove(ores.rows, fake))                    # the same (worthless) proof the oracle's prover makes of that claim
+    # the honest claim still verifies, and mode 0 of the same run is what it was (no I/O statement)
+    assert rt.verify(stark.prove(ctx, tr, pub), pub) == 0
+    pub0 = rt.public_inputs(log, blob, ins)
+    assert pub0.deferred == 0 and rt.verify(stark.prove(ctx, tr, pub0), pub0) == 0
+    ctx.close(); log.close()

@@ -51,7 +51,14 @@
 
 namespace air {
 
-constexpr int W = 172;
+constexpr int W = 180;                                         // logical columns of MODE 2; modes 0 / 1 use the first 172 (W_LOGICAL_BASE)
+constexpr int W_LOGICAL_BASE = 172;
+// MODES (the header's word 9, zkir_public_inputs::deferred): 0 = default VM mode, 1 = deferred carry model, 2 (round 4) = default mode WITH the I/O argument:
+// ECALL is a class of its own there (id K_ECALL, no column: Kec = f2 + rl + re + fh), dispatched on R10's limbs — f2 = WRITE (R10 = 2), rl / re = READ (R10 = 1) on a
+// non-empty / exhausted input tape, fh = a hash syscall (R10 = 3 + h0 + 2 h1) — oc / ic count the outputs written / inputs consumed before the row; WRITE rows send
+// (oc, R11's limbs), live READ rows (ic, the limbs written to R10) into a LogUp relation whose table side the VERIFIER forms from the tapes the proof carries
+// (syscall.rs:94-177).  A bool passed where a mode is expected reads as 0 / 1.
+enum : int { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 177, C_OC = 178, C_IC = 179 };
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
              C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
@@ -61,40 +68,43 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
 // 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
-BB_HD constexpr bool is_virtual(int c, bool deferred) { return (c >= C_LIMB && c < C_LIMB + 3) || (deferred ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
-BB_HD constexpr int phys_col(int c, bool deferred) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (deferred ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
-BB_HD constexpr int committed_width(bool deferred) { return deferred ? W_COMMITTED_DEFERRED : W_COMMITTED_DEFAULT; }
-BB_HD constexpr int committed_used(bool deferred) { return deferred ? W - 4 : W - 20; }      // = the committed width (no padding since v6)
+BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode != 2) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+BB_HD constexpr int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
+BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : W_COMMITTED_DEFAULT; }
+BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20)
+BB_HD constexpr int logical_width(int mode) { return mode == 2 ? W : W_LOGICAL_BASE; }
 // the logical column stored at committed position p (p < committed_used)
-BB_HD constexpr int logical_col(int p, bool deferred) {
+BB_HD constexpr int logical_col(int p, int mode) {
   int c = p;
   if (c >= C_LIMB) c += 3;                                     // R0's limbs
-  if (deferred) { if (c >= C_STATE) c += 1; } else { if (c >= C_STATE) c += 16; if (c >= C_KOJ) c += 1; }
+  if (mode == 1) { if (c >= C_STATE) c += 1; } else { if (c >= C_STATE) c += 16; if (c >= C_KOJ) c += 1; }
   return c;
 }
-// aux trace: H0..H7 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each
-constexpr int W_AUX = 40;
-enum : int { A_H = 0, A_HR = 32, A_S = 36 };
+// aux trace: H0..H7 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each; mode 2: + HO (output-tape helper), HI (input-tape helper)
+constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MAX = 48;
+BB_HD constexpr int aux_width(int mode) { return mode == 2 ? W_AUX_IO : W_AUX; }
+enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
 BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^N_TUPLE (= 11), T / N
-enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), N_LK = LK_TN + 4 };
+enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), LK_NIN = LK_TN + 4 /* mode 2: the length of the input tape */, N_LK = LK_NIN + 1 };
 BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : j == 9 ? C_OPC : C_G; }
 // AIR v3: class ids (= opclass values of the instruction word; halt / pad are row roles, not word classes).  A FAMILY is a pair of opcodes
 // that differ in their low bit, the polarity of one comparison: bre = BEQ / BNE, bru = BLTU / BGEU, se = SEQ / SNE, su = SLTU / SGEU.
 // AIR v4: jalr (JALR) and oj = "other, jumps" (BLT / BGE: the signed comparison is not stated yet — free next pc, nothing written); class
 // "other" is SEQUENTIAL (pc + 4) like every instruction that is not a branch or a jump.
 // AIR v6: cmn = CMOV / CMOVNZ (move if rs2 != 0), cmz = CMOVZ (move if rs2 == 0)
-enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, K_CMN = 13, K_CMZ = 14, N_CLASS = 15 };
+enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, K_CMN = 13, K_CMZ = 14, N_CLASS = 15,
+             K_ECALL = 15 /* mode 2 only: the class id of the ECALL word; it has no column */ };
 BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
-                   OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49;
-BB_HD constexpr uint32_t opclass_of(uint32_t op) {
-  return op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+                   OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50;
+BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
+  return (op == OP_ECALL && mode == 2) ? (uint32_t)K_ECALL : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;
@@ -108,7 +118,12 @@ BB_HD constexpr uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op =
 enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 150,
              I_ONE_CLASS = 161, I_OPCLASS = 162, I_WR = 163, I_SELB = 166, I_SELC = 168, I_CMOV = 170, I_OPERAND = 173, I_VALUE = 179, I_DIFF = 188, I_WRITTEN = 197,
              I_CMOV_Y = 202, I_Y2 = 205, I_NZ = 207, I_NE = 209, I_FLAG = 213, I_FX = 214, I_TK = 215, I_DL0 = 216, I_SE = 217, I_PC = 218, I_PC_KEEP = 221, I_JALR = 224, I_REGS = 227,
-             I_TAIL = 287, I_LAST = 290, I_RANGE = 358, I_ROM = 390, I_SUM = 394, N_CONSTRAINTS = 398 };
+             I_TAIL = 287, I_LAST = 290, I_RANGE = 358, I_ROM = 390, I_SUM = 394, N_CONSTRAINTS_BASE = 398,
+             // mode 2 (appended): syscall flags boolean (6), h-bits on hash rows only (2), the syscall number (3), what an ecall writes (3), zero results (3), the counters (2),
+             // "exhausted" (1), the output lookup (4), the input lookup (4), the counters of the first / last row (2 + 2)
+             I_IO_BOOL = 398, I_IO_H = 404, I_IO_R10 = 406, I_IO_WR = 409, I_IO_Y = 412, I_IO_CNT = 415, I_IO_END = 417, I_IO_OUT = 418, I_IO_IN = 422, I_IO_FIRST = 426, I_IO_LAST = 428,
+             N_CONSTRAINTS = 430 };
+BB_HD constexpr int num_constraints(int mode) { return mode == 2 ? N_CONSTRAINTS : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -149,7 +164,8 @@ BB_HD void air_static_for(F&& f) {
 }
 
 template <class Ops>
-BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool deferred) {
+BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mode, const uint32_t* cnt_m = nullptr) {   // cnt_m (mode 2): (oc, ic) of the first row, of the last row (Montgomery)
+  const bool deferred = mode == 1, io = mode == 2;
   using V = typename Ops::V;
   using AccP = typename Ops::AccP;
   using AccL = typename Ops::AccL;
@@ -161,14 +177,19 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
   // and FIRST in program order, the pushes after them: one memory latency for the phase, not one per column)
   {
     V sv[N_STATE];
-    air_static_for<0, N_STATE>([&](auto ic) { constexpr int i = decltype(ic)::value, col = state_col(i); sv[i] = is_virtual(col, deferred) ? zero : o.loc(col); });
+    air_static_for<0, N_STATE>([&](auto ic) { constexpr int i = decltype(ic)::value, col = state_col(i); sv[i] = is_virtual(col, mode) ? zero : o.loc(col); });
     const V khalt = o.loc(kcol(K_HALT));
     air_static_for<0, N_STATE>([&](auto ic) {
       constexpr int i = decltype(ic)::value, col = state_col(i);
-      if (is_virtual(col, deferred)) { o.push_fc0(first_idx(i), first_m[i]); o.push_lc0(last_idx(i), last_m[i]); return; }
+      if (is_virtual(col, mode)) { o.push_fc0(first_idx(i), first_m[i]); o.push_lc0(last_idx(i), last_m[i]); return; }
       o.push_fc(first_idx(i), sv[i], first_m[i]); o.push_lc(last_idx(i), sv[i], last_m[i]);
     });
     o.push_lc(I_HALT, khalt, bb::R1);
+    if (io) {                                                  // (mode 2) the counters of the first and of the last executed row are public too
+      const V oc = o.loc(C_OC), ic = o.loc(C_IC);
+      o.push_fc(I_IO_FIRST, oc, cnt_m[0]); o.push_fc(I_IO_FIRST + 1, ic, cnt_m[1]);
+      o.push_lc(I_IO_LAST, oc, cnt_m[2]); o.push_lc(I_IO_LAST + 1, ic, cnt_m[3]);
+    }
   }
   o.end_boundary();
   // ---- B. transitions (x is_trans): registers, cycle counter, next pc, the tail of the trace ------------------------------------------------
@@ -216,7 +237,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
   // every other column of the row pair, read HERE — together, before any of them is used (one memory latency)
   V K[N_CLASS];
 #pragma unroll
-  for (int k = 0; k < N_CLASS; k++) K[k] = is_virtual(kcol(k), deferred) ? zero : o.loc(kcol(k));
+  for (int k = 0; k < N_CLASS; k++) K[k] = is_virtual(kcol(k), mode) ? zero : o.loc(kcol(k));
   const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
   const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
   const V cyc = o.loc(C_CYCLE), ncyc = o.nxt(C_CYCLE), npad = o.nxt(C_K + K_PAD);
@@ -255,23 +276,33 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
     o.push_t(I_TAIL + 1, o.lmul(one_m_npad, K[K_PAD]));
     o.push_t(I_TAIL + 2, o.lmul(o.sub(o.sub(one, K[K_PAD]), K[K_HALT]), npad));
   }
+  if (io) {                                                    // (mode 2) oc counts the WRITE ecalls, ic the inputs consumed (syscall.rs:110-121)
+    o.push_t(I_IO_CNT, o.lsub(o.sub(o.nxt(C_OC), o.loc(C_OC)), o.loc(C_F2)));
+    o.push_t(I_IO_CNT + 1, o.lsub(o.sub(o.nxt(C_IC), o.loc(C_IC)), o.loc(C_RL)));
+  }
   o.end_trans();
   // ---- C. row-local constraints -----------------------------------------------------------------------------------------------------------
   const V Kbr = o.add(K[K_BRE], K[K_BRU]), Kcmp = o.add(K[K_SE], K[K_SU]);       // B-type rows; comparison rows (the flag is the value written)
   const V z[2] = {o.add(R[0], o.mulc(R[1], M(RC_TABLE))), o.add(R[2], o.mulc(R[3], M(RC_TABLE)))};   // (v6) z IS its chunks: no columns of its own
   // booleans
 #pragma unroll
-  for (int k = 0; k < N_CLASS; k++) { if (!is_virtual(kcol(k), deferred)) boolean(I_BOOL_K + k, K[k]); }
+  for (int k = 0; k < N_CLASS; k++) { if (!is_virtual(kcol(k), mode)) boolean(I_BOOL_K + k, K[k]); }
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
   boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, sa); boolean(I_BOOL_MISC + 9, sbit); boolean(I_BOOL_MISC + 10, nz);
   // classes and the opcode
+  V F2 = zero, RL = zero, RE = zero, FH = zero, H0 = zero, H1 = zero;   // (mode 2) the syscall flags of an ECALL row; Kec = their sum is the row's class
+  if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
     for (int k = 0; k < N_CLASS; k++) {
-      if (is_virtual(kcol(k), deferred)) continue;
+      if (is_virtual(kcol(k), mode)) continue;
       o.acc_lin(sum, K[k], 1);
       if (k >= 1 && k != K_HALT && k != K_PAD) o.acc_lin(ks, K[k], (uint32_t)k);
+    }
+    if (io) {
+      o.acc_lin(sum, F2, 1); o.acc_lin(sum, RL, 1); o.acc_lin(sum, RE, 1); o.acc_lin(sum, FH, 1);
+      o.acc_lin(ks, F2, K_ECALL); o.acc_lin(ks, RL, K_ECALL); o.acc_lin(ks, RE, K_ECALL); o.acc_lin(ks, FH, K_ECALL);
     }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
@@ -429,20 +460,64 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, bool de
 #pragma unroll
     for (int k = 1; k < 4; k++) o.push(I_ROM + k, pr[k]);
   }
-  // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR - T / N
+  // ---- (mode 2, round 4) ECALL rows and the I/O tapes (syscall.rs:94-177): constraints 398.. of the oracle's list ------------------------------------
+  if (io) {
+    const V Kec = o.add(o.add(F2, RL), o.add(RE, FH));
+    boolean(I_IO_BOOL, F2); boolean(I_IO_BOOL + 1, RL); boolean(I_IO_BOOL + 2, RE); boolean(I_IO_BOOL + 3, FH); boolean(I_IO_BOOL + 4, H0); boolean(I_IO_BOOL + 5, H1);
+    const V nfh = o.lsub(one, FH);
+    o.push(I_IO_H, o.lmul(nfh, H0)); o.push(I_IO_H + 1, o.lmul(nfh, H1));             // the two bits of R10 - 3 live on hash rows only
+    // the syscall number: R10 = 1 (READ), 2 (WRITE), 3 + h0 + 2 h1 (hash); 0 (EXIT) halts — that row is the halt row, not an executed ecall
+    const V r10[3] = {o.loc(C_LIMB + 30), o.loc(C_LIMB + 31), o.loc(C_LIMB + 32)}, r11[3] = {o.loc(C_LIMB + 33), o.loc(C_LIMB + 34), o.loc(C_LIMB + 35)};
+    o.push(I_IO_R10, o.lmul(r10[1], Kec)); o.push(I_IO_R10 + 1, o.lmul(r10[2], Kec));
+    {
+      AccL num = o.accl();
+      o.acc_lin(num, RL, 1); o.acc_lin(num, RE, 1); o.acc_lin(num, F2, 2); o.acc_lin(num, FH, 3); o.acc_lin(num, H0, 1); o.acc_lin(num, H1, 2);
+      o.push(I_IO_R10 + 2, o.lsub(o.mul(r10[0], Kec), o.accl_val(num)));
+    }
+    // what an ecall writes: READ and the hashes write R10 and only R10, WRITE writes nothing; hashes and an exhausted READ return 0
+    const V wgrp = o.add(o.add(RL, RE), FH);
+    o.push(I_IO_WR, o.lmul(o.lsub(w1v, o.cst(M(10))), wgrp)); o.push(I_IO_WR + 1, o.lmul(o.lsub(w0v, one), wgrp)); o.push(I_IO_WR + 2, o.lmul(w0v, F2));
+    const V zgrp = o.add(FH, RE);
+#pragma unroll
+    for (int l = 0; l < 3; l++) o.push(I_IO_Y + l, o.lmul(y[l], zgrp));
+    const V oc = o.loc(C_OC), ic = o.loc(C_IC);
+    o.push(I_IO_END, o.lmul(o.lsub(ic, o.par(LK_NIN)), RE));                          // "exhausted": every input has been consumed
+    // the tape lookups: HO (alpha - fp(oc, R11)) = f2, HI (alpha - fp(ic, y)) = rl; fp = sum_j lambda^j g_j + tag lambda^N_TUPLE, tag 2 / 3
+    auto tape = [&](int a_col, int idx0, const V& index, const V* limbs, uint32_t tag, const V& flag) {
+      V h[4], d[4], pr[4];
+      AccP fp[4] = {o.accp(), o.accp(), o.accp(), o.accp()};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        h[k] = o.aloc(a_col + k); o.acc_lin(hs[k], h[k], 1);
+        o.acc_mul(fp[k], index, o.par(LK_LAM + k));
+#pragma unroll
+        for (int j = 0; j < 3; j++) o.acc_mul(fp[k], limbs[j], o.par(LK_LAM + 4 * (1 + j) + k));
+        d[k] = o.sub(o.sub(o.par(LK_ALPHA + k), o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M(tag))), o.acc_val(fp[k]));
+      }
+      ext_mul(h, d, pr);
+      o.push(idx0, o.lsub(pr[0], flag));
+#pragma unroll
+      for (int k = 1; k < 4; k++) o.push(idx0 + k, pr[k]);
+    };
+    tape(A_HO, I_IO_OUT, oc, r11, 2, F2);
+    tape(A_HI, I_IO_IN, ic, y, 3, RL);
+  }
+  // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR (+ HO + HI) - T / N
 #pragma unroll
   for (int k = 0; k < 4; k++) o.push(I_SUM + k, o.ladd(o.sub(o.sub(nS[k], S[k]), o.accl_val(hs[k])), o.par(LK_TN + k)));
 }
 
 // - sum_i (alpha^first_idx(i) first_m[i]) and the same for the last row: the share of the public boundary words in the two boundary sums — per-proof
 // constants (E4, Montgomery; alpha_pow in Montgomery form) the prover's host side hands the quotient kernel (push_fc / push_lc leave the words out)
-inline void boundary_constants(const bb::E4* alpha_pow_m, const uint32_t* first_m, const uint32_t* last_m, bb::E4& cf, bb::E4& cl) {
+inline void boundary_constants(const bb::E4* alpha_pow_m, const uint32_t* first_m, const uint32_t* last_m, bb::E4& cf, bb::E4& cl, const uint32_t* cnt_m = nullptr) {
   cf = bb::e_zero(); cl = bb::e_zero();
   for (int i = 0; i < N_STATE; i++) {
     cf = bb::e_add(cf, bb::e_mul_fm(alpha_pow_m[first_idx(i)], first_m[i]));
     cl = bb::e_add(cl, bb::e_mul_fm(alpha_pow_m[last_idx(i)], last_m[i]));
   }
   cl = bb::e_add(cl, bb::e_mul_fm(alpha_pow_m[I_HALT], bb::R1));
+  if (cnt_m)                                                   // (mode 2) the counters of the first / last row
+    for (int k = 0; k < 2; k++) { cf = bb::e_add(cf, bb::e_mul_fm(alpha_pow_m[I_IO_FIRST + k], cnt_m[k])); cl = bb::e_add(cl, bb::e_mul_fm(alpha_pow_m[I_IO_LAST + k], cnt_m[2 + k])); }
 }
 
 // The ORDER in which air::eval pushes the constraints a quotient kernel consumes (push_fc0 / push_lc0 are not consumed): the kernel reads its
@@ -464,10 +539,10 @@ struct OrderOps {
   void push_fc0(int, uint32_t) {} void push_lc0(int, uint32_t) {}
 };
 // order[k] = the constraint index of the k-th consumed push; returns their number (<= N_CONSTRAINTS)
-inline int push_order(bool deferred, int* order) {
-  OrderOps o{deferred};
-  uint32_t st[N_STATE] = {};
-  eval(o, st, st, deferred);
+inline int push_order(int mode, int* order) {
+  OrderOps o{mode == 1};
+  uint32_t st[N_STATE] = {}, cnt[4] = {};
+  eval(o, st, st, mode, cnt);
   for (int k = 0; k < o.n && k < N_CONSTRAINTS; k++) order[k] = o.order[k];
   return o.n;
 }
@@ -479,7 +554,7 @@ struct BoundOps {
   struct V { uint64_t max; };
   struct AccP { unsigned __int128 max; };
   struct AccL { uint64_t max; };
-  bool deferred;
+  int deferred;                                                // the MODE (0, 1, 2)
   const char* why = nullptr;
   unsigned __int128 tot[4] = {0, 0, 0, 0};
   int seen[N_CONSTRAINTS] = {};
@@ -490,7 +565,7 @@ struct BoundOps {
   V nxt(int k) { return loc(k); }
   V loc_r(int k) { need(k >= 0 && k < W && !is_virtual(k, deferred), "loc_r: uncommitted column"); return red(); }
   V nxt_r(int k) { return loc_r(k); }
-  V aloc(int k) { need(k >= 0 && k < W_AUX, "aloc: column out of range"); return red(); }
+  V aloc(int k) { need(k >= 0 && k < aux_width(deferred), "aloc: column out of range"); return red(); }
   V anxt(int k) { return aloc(k); }
   V par(int i) { need(i >= 0 && i < N_LK, "par: index out of range"); return red(); }
   V cst(uint32_t cm) { need(cm < bb::P, "cst: constant not reduced"); return V{cm}; }
@@ -523,10 +598,10 @@ struct BoundOps {
   void push_lc0(int idx, uint32_t) { count(3, idx, V{0}); }
 };
 // nullptr = the quotient kernel's arithmetic is sound on air::eval; else the first broken rule
-inline const char* check_bounds(bool deferred) {
-  BoundOps o{deferred};
-  uint32_t st[N_STATE] = {};
-  eval(o, st, st, deferred);
+inline const char* check_bounds(int mode) {
+  BoundOps o{mode};
+  uint32_t st[N_STATE] = {}, cnt[4] = {};
+  eval(o, st, st, mode, cnt);
   return o.why;
 }
 #endif

@@ -68,9 +68,13 @@ BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
 // The row itself is a host + device function: the kernel below runs it once per lane, zkir_main_trace_host once per row on the CPU — the same
 // code, so the CPU test suite (no GPU) checks it against the oracle column by column (tests/test_abi.py).
 // SKIP: the first SKIP blocks are not stored (experiment, DESIGN.md §9: the LDE's first pass generates them itself — zkir_lde_fused01_launch)
-template <bool DEF, int SKIP = 0>
-BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t N, uint64_t i, uint32_t* __restrict__ out) {
+// MODE: 0 default, 1 deferred, 2 default + the I/O argument (air.h): there `io` carries the input tape and the ecall counts before the trace, `cnt` the prefix counts
+// (WRITE ecalls, READ ecalls among rows < i of THIS trace) of every row.
+struct IoRowArgs { const uint64_t* inputs; uint64_t n_inputs, writes_before, reads_before; const uint32_t* cnt; /* [N][2] */ };
+template <int MODE, int SKIP = 0>
+BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t N, uint64_t i, uint32_t* __restrict__ out, const IoRowArgs* io = nullptr) {
   using namespace air;
+  constexpr bool DEF = MODE == 1;
   constexpr uint32_t deferred = DEF ? 1u : 0u;
   uint32_t rowv[W];
   auto col = [&](int k) -> uint32_t& { return rowv[k]; };
@@ -85,14 +89,14 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   col(C_OP) = op; col(C_FA) = fa; col(C_FB) = fb; col(C_FC) = fc; col(C_FHI) = fhi; col(C_S) = s;
   int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
   if (cls == K_OTH) {
-    const int wc = (int)opclass_of(op);
+    const int wc = (int)opclass_of(op, MODE);
     if (!deferred) cls = wc;
     else if (wc == K_BRE || wc == K_JAL || wc == K_BRU || wc == K_JALR || wc == K_OJ) cls = K_OJ;     // deferred mode: no opcode semantics, but class "other" is sequential
   }
   const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
-  for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;
-  col(C_OPC) = opclass_of(op);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
+  for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
+  col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
   const uint32_t tc = branch ? fa : fc;                                         // B-type words have rs1 in field a (rs2 in field b)
   uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
@@ -122,6 +126,24 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
       }
     }
     col(C_WR + g - 1) = wr;
+  }
+  if (MODE == 2) {
+    // the counters every row shows — what happened BEFORE it — and, on an executed ecall, the dispatch on R10 (syscall.rs:94-177; R10 = 0 halts: the halt row)
+    const uint64_t writes = io->writes_before + io->cnt[2 * i], reads = io->reads_before + io->cnt[2 * i + 1];
+    col(C_OC) = (uint32_t)(writes % bb::P); col(C_IC) = (uint32_t)((reads < io->n_inputs ? reads : io->n_inputs) % bb::P);
+    col(C_F2) = col(C_RL) = col(C_RE) = col(C_FH) = col(C_H0) = col(C_H1) = 0;
+    if (cls == K_ECALL) {
+      const uint64_t num = t.registers[(uint64_t)10 * t.reg_stride + src];
+      if (num == 2) col(C_F2) = 1;
+      else {
+        if (num == 1) {
+          if (reads < io->n_inputs) { col(C_RL) = 1; const uint64_t v = io->inputs[reads]; y[0] = (uint32_t)(v & 0xFFFFF); y[1] = (uint32_t)((v >> 20) & 0xFFFFF); y[2] = (uint32_t)(v >> 40); }
+          else col(C_RE) = 1;
+        } else { col(C_FH) = 1; col(C_H0) = (uint32_t)((num - 3) & 1); col(C_H1) = (uint32_t)(((num - 3) >> 1) & 1); }
+#pragma unroll
+        for (int r = 0; r < 15; r++) col(C_WR + r) = r == 9;                      // READ and the hash syscalls write R10 (and nothing else)
+      }
+    }
   }
   col(C_XB) = xb[0]; col(C_XB + 1) = xb[1]; col(C_XB + 2) = xb[2];
   col(C_XC) = xc[0]; col(C_XC + 1) = xc[1]; col(C_XC + 2) = xc[2];
@@ -183,7 +205,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64u * rc2[2];
   }
   col(C_RC2) = rc2[0]; col(C_RC2 + 1) = rc2[1]; col(C_RC2 + 2) = rc2[2]; col(C_RC2 + 3) = rc2[3];
-  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
+  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like || (MODE == 2 && cls == K_ECALL)) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
   col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0, b0 = 0;
@@ -200,18 +222,59 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   col(C_D0) = d0; col(C_D1) = d1; col(C_D2) = d2; col(C_B0) = b0;
   // the committed columns, packed: committed position p holds logical column logical_col(p); the tail of the last block is zero padding
   uint4* out4 = reinterpret_cast<uint4*>(out);
-  auto at = [&](int p) -> uint32_t { return p < committed_used(DEF) ? rowv[logical_col(p < committed_used(DEF) ? p : 0, DEF)] : 0u; };   // (inner clamp: the index stays inside rowv for the padding positions too)
+  auto at = [&](int p) -> uint32_t { return p < committed_used(MODE) ? rowv[logical_col(p < committed_used(MODE) ? p : 0, MODE)] : 0u; };   // (inner clamp: the index stays inside rowv for the padding positions too)
 #pragma unroll
-  for (int b = SKIP; b < committed_width(DEF) / 8; b++) {
+  for (int b = SKIP; b < committed_width(MODE) / 8; b++) {
     out4[((uint64_t)b * N + i) * 2] = make_uint4(at(8 * b), at(8 * b + 1), at(8 * b + 2), at(8 * b + 3));
     out4[((uint64_t)b * N + i) * 2 + 1] = make_uint4(at(8 * b + 4), at(8 * b + 5), at(8 * b + 6), at(8 * b + 7));
   }
 }
-template <bool DEF, int SKIP = 0>
-__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out) {
+template <int MODE, int SKIP = 0>
+__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out, IoRowArgs io = IoRowArgs{}) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
-  main_trace_row<DEF, SKIP>(t, n_real, N, i, out);
+  main_trace_row<MODE, SKIP>(t, n_real, N, i, out, &io);
+}
+
+// ---- (mode 2) prefix counts of the WRITE / READ ecalls over the rows: flags -> exclusive scan (three launches: per-block scan, scan of the block totals, add) ----
+BB_HD void io_row_flags(const zkir_trace_columns& t, uint64_t n_real, uint64_t i, uint32_t f[2]) {
+  f[0] = f[1] = 0;
+  if (i + 1 >= n_real) return;                                 // the halt row and the padding execute nothing (an exit ECALL is the halt row)
+  if ((t.instruction[i] & 0x7F) != air::OP_ECALL) return;
+  const uint64_t num = t.registers[(uint64_t)10 * t.reg_stride + i];
+  f[0] = num == 2; f[1] = num == 1;
+}
+constexpr uint32_t IOS_ROWS = 1024;                            // rows per workgroup of the scan (4 per lane)
+__global__ __launch_bounds__(NT) void io_scan_local_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint2* __restrict__ cnt, uint2* __restrict__ sums) {
+  __shared__ uint2 lds[NT];
+  const uint64_t base = (uint64_t)blockIdx.x * IOS_ROWS + (uint64_t)threadIdx.x * 4;
+  uint2 v[4], run = make_uint2(0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { uint32_t f[2] = {0, 0}; if (base + k < N) io_row_flags(t, n_real, base + k, f); v[k] = run; run.x += f[0]; run.y += f[1]; }
+  lds[threadIdx.x] = run;
+  __syncthreads();
+  for (uint32_t off = 1; off < NT; off <<= 1) {
+    uint2 x = lds[threadIdx.x];
+    if (threadIdx.x >= off) { const uint2 y = lds[threadIdx.x - off]; x.x += y.x; x.y += y.y; }
+    __syncthreads();
+    lds[threadIdx.x] = x;
+    __syncthreads();
+  }
+  const uint2 ex = threadIdx.x ? lds[threadIdx.x - 1] : make_uint2(0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (base + k < N) cnt[base + k] = make_uint2(v[k].x + ex.x, v[k].y + ex.y);
+  if (threadIdx.x == NT - 1) sums[blockIdx.x] = lds[NT - 1];
+}
+__global__ void io_scan_sums_kernel(uint2* __restrict__ sums, uint32_t n) {       // one lane: n = N / 1024 block totals (<= 65536)
+  if (threadIdx.x || blockIdx.x) return;
+  uint2 run = make_uint2(0, 0);
+  for (uint32_t b = 0; b < n; b++) { const uint2 v = sums[b]; sums[b] = run; run.x += v.x; run.y += v.y; }
+}
+__global__ __launch_bounds__(NT) void io_scan_add_kernel(uint2* __restrict__ cnt, uint64_t N, const uint2* __restrict__ sums) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= N) return;
+  const uint2 o = sums[i / IOS_ROWS];
+  cnt[i].x += o.x; cnt[i].y += o.y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,7 +476,7 @@ int merkle_commit(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, 
 extern "C" {
 
 uint32_t zkir_main_trace_width(void) { return air::committed_width(false); }
-uint32_t zkir_main_trace_width_for(uint32_t deferred) { return air::committed_width(deferred != 0); }
+uint32_t zkir_main_trace_width_for(uint32_t deferred) { return air::committed_width((int)deferred); }     // `deferred` = the mode: 152 / 168 / 160
 
 void zkir_poseidon2_permute(uint32_t state[12]) {
   static const p2::Consts consts = [] { p2::Consts c; p2::generate(c); return c; }();
@@ -502,11 +565,36 @@ void zkir_stark_ctx_free(zkir_stark_ctx* c) {
 uint32_t zkir_padded_log_n(uint64_t n_real) { uint32_t k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
 
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* stream) {
-  if (!trace || !out || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  if (!trace || !out || n_real == 0 || deferred > 1) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_launch: null argument, empty trace, or a mode other than 0 / 1 (mode 2: zkir_main_trace_io_launch)"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
-  if (deferred) hipLaunchKernelGGL(main_trace_kernel<true>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
-  else hipLaunchKernelGGL(main_trace_kernel<false>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out);
+  if (deferred) hipLaunchKernelGGL(main_trace_kernel<1>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out, IoRowArgs{});
+  else hipLaunchKernelGGL(main_trace_kernel<0>, dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, out, IoRowArgs{});
   return check_launch("main_trace");
+}
+// MODE 2: prefix counts of the WRITE / READ ecalls (three launches over the instruction and R10 columns), then the row kernel
+int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* scratch, uint32_t* out, void* stream) {
+  if (!trace || !out || !io || !scratch || n_real == 0 || (!io->inputs && io->n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_io_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
+  uint2* cnt = reinterpret_cast<uint2*>(scratch);
+  uint2* sums = cnt + N;
+  const uint32_t n_blk = (uint32_t)((N + IOS_ROWS - 1) / IOS_ROWS);
+  hipLaunchKernelGGL(io_scan_local_kernel, dim3(n_blk), dim3(NT), 0, s, *trace, n_real, N, cnt, sums);
+  hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(64), 0, s, sums, n_blk);
+  hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
+  hipLaunchKernelGGL(main_trace_kernel<2>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
+                     IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt)});
+  return check_launch("main_trace_io");
+}
+int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out) {
+  if (!trace || !out || !io || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_io_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
+  std::vector<uint32_t> cnt(2 * N);
+  uint32_t w = 0, r = 0;
+  for (uint64_t i = 0; i < N; i++) { cnt[2 * i] = w; cnt[2 * i + 1] = r; uint32_t f[2] = {0, 0}; if (i < n_real) io_row_flags(*trace, n_real, i, f); w += f[0]; r += f[1]; }
+  const IoRowArgs a{io->inputs, io->n_inputs, io->writes_before, io->reads_before, cnt.data()};
+  for (uint64_t i = 0; i < N; i++) main_trace_row<2>(*trace, n_real, N, i, out, &a);
+  return ZKIR_OK;
 }
 // EXPERIMENT: main trace without its first two blocks + the extension whose first inverse pass generates them from the trace.
 // Together they are zkir_main_trace_launch + zkir_lde_launch with 128 B/row less HBM traffic; same output.  Returns ZKIR_ERR_ARGUMENT where the fused pass
@@ -514,7 +602,7 @@ int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uin
 int zkir_commit_fused01_launch(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* stream) {
   if (!c || !trace || !m || !out || n_real == 0 || zkir_padded_log_n(n_real) != c->log_n) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_commit_fused01_launch: bad argument"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << c->log_n;
-  hipLaunchKernelGGL((main_trace_kernel<false, 2>), dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, m);
+  hipLaunchKernelGGL((main_trace_kernel<0, 2>), dim3(grid_for(N)), dim3(NT), 0, (hipStream_t)stream, *trace, n_real, N, m, IoRowArgs{});
   const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
   if (!zkir::lde_run_fused01(t, trace, n_real, m, (width + 7) / 8, out, stream)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_commit_fused01_launch: not applicable at this size"}); return ZKIR_ERR_ARGUMENT; }
   return check_launch("commit_fused01");
@@ -533,7 +621,7 @@ int zkir_ntt_strided_variant_launch(const zkir_stark_ctx* c, uint32_t* data, uin
 int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out) {
   if (!trace || !out || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
-  for (uint64_t i = 0; i < N; i++) { if (deferred) main_trace_row<true>(*trace, n_real, N, i, out); else main_trace_row<false>(*trace, n_real, N, i, out); }
+  for (uint64_t i = 0; i < N; i++) { if (deferred) main_trace_row<1>(*trace, n_real, N, i, out); else main_trace_row<0>(*trace, n_real, N, i, out); }
   return ZKIR_OK;
 }
 

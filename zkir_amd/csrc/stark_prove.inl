@@ -10,7 +10,7 @@ namespace {
 using bb::E4;
 
 // WMX / WTX: the largest committed width (deferred mode) — array sizes; a proof's own widths are air::committed_width(deferred) and that + WA
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_DEFERRED, WA = air::W_AUX, WTX = WMX + WA, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_DEFERRED, WAX = air::W_AUX_MAX, WTX = WMX + WAX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
 constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 
@@ -28,6 +28,7 @@ struct ProveParams {            // constants of one proof, Montgomery form; live
   E4 gamma_pow[2 * WTX + 4];    // main columns, aux columns at zeta; the same at zeta w; the quotient (2 * (committed width + WA) + 4 used)
   E4 zeta, zeta_w, a0, b0;
   uint32_t first_m[NS], last_m[NS];   // public boundary states: rows 0 and n_real - 1 (Montgomery)
+  uint32_t cnt_m[4];            // (mode 2) the counters (oc, ic) of row 0 and of row n_real - 1 (Montgomery)
   E4 cf, cl;                    // air::boundary_constants: the boundary words' share of the is_first / is_last sums
   uint32_t deferred;
   uint32_t lk[air::N_LK];       // lookup parameters (air.h LK_*): alpha, lambda powers, T / N — base-field coordinates, Montgomery
@@ -78,7 +79,7 @@ __device__ __forceinline__ E4 lz_reduce(const LazyE4& acc) {
 //   * column reads are 16-byte loads of (block, row, half): the compiler merges the reads of neighbouring columns (the B8 layout keeps eight
 //     columns of a row in 32 contiguous bytes) — round 3 issued one 4-byte load per column, 64 lanes x 32-byte stride each.
 // Src supplies the words of one row pair: the device source reads the B8 matrices, tests/test_abi.py's host source reads plain arrays.
-template <bool DEF, class Src>
+template <int DEF /* the MODE: 0 default, 1 deferred, 2 default + I/O */, class Src>
 struct QuotientOps {
   using V = uint32_t;
   using AccP = bb::Acc96;
@@ -147,7 +148,7 @@ struct DeviceRowSrc {
   __device__ __forceinline__ uint32_t anxt(int p) const { return at(A4, p, jn); }
 };
 
-template <bool DEF>
+template <int DEF /* the mode */>
 __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
                                                                   const uint32_t* __restrict__ inv_xm1, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t w_last_inv_m,
                                                                   uint32_t last_shift, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m, uint32_t* __restrict__ Q) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
   const uint32_t is_trans = bb::sub(x, wn_inv_m);
   QuotientOps<DEF, DeviceRowSrc> o{DeviceRowSrc{reinterpret_cast<const uint4*>(L), reinterpret_cast<const uint4*>(AL), N2, j, (j + 2) & (N2 - 1)}, pp->alpha_seq, {}, pp->lk};
   o.init();
-  air::eval(o, pp->first_m, pp->last_m, DEF);
+  air::eval(o, pp->first_m, pp->last_m, DEF, pp->cnt_m);
   using QO = QuotientOps<DEF, DeviceRowSrc>;
   const E4 s0 = QO::sum_of(o.a0), st = o.st, sf = bb::e_sub(o.sf, pp->cf), sl = bb::e_sub(o.sl, pp->cl);
   const E4 q = bb::e_add(bb::e_add(bb::e_mul_fm(bb::e_add(s0, bb::e_mul_fm(st, is_trans)), inv_zh), bb::e_mul_fm(sf, inv_first)), bb::e_mul_fm(sl, inv_last));
@@ -181,8 +182,11 @@ __global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t
 // first ROM_LDS rows of the table — a program's hot code — global atomics beyond).  A row whose tuple is not the program's word at
 // its pc (self-modified code, pc outside the code segment) or whose chunk is out of range has no proof: its index goes to bad_row.
 constexpr uint32_t ROM_LDS = 4096;
-__global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, bool deferred, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
-                                                           uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row) {
+// (mode 2) one entry per WRITE / live READ row: what the row sends into the tape lookup — filled here, turned into helper values once the challenges are drawn
+struct IoEntry { uint32_t row, is_in, idx, v[3], pad[2]; };
+__global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, int deferred /* the mode */, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
+                                                           uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row,
+                                                           IoEntry* __restrict__ io_list, uint32_t* __restrict__ io_count) {
   __shared__ uint32_t h_rc[air::RC_TABLE];
   __shared__ uint32_t h_rom[ROM_LDS];
   const uint32_t rom_lds = n_code < ROM_LDS ? n_code : ROM_LDS;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       const uint32_t w = code[u];
       ui = (uint32_t)u;
       if (b0h.x == (w & 0x7F) && b0h.y == ((w >> 7) & 0xF) && b0h.z == ((w >> 11) & 0xF) && b0h.w == ((w >> 15) & 0xF) && fhi_v == (w >> 19) && s_v == (w >> 31) &&
-          opc_v == air::opclass_of(w & 0x7F) && g_v == air::variant_bit(w & 0x7F)) {
+          opc_v == air::opclass_of(w & 0x7F, deferred) && g_v == air::variant_bit(w & 0x7F)) {
         if (ui < rom_lds) atomicAdd(&h_rom[ui], 1u); else atomicAdd(&rom_mult[ui], 1u);
       } else ok = false;
     } else ok = false;
@@ -217,6 +221,18 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
     // (a chunk outside the table has no proof anyway: masked here so that the packed word stays well-formed)
     auto c10 = [&](int k) { return r[k] & (uint32_t)(air::RC_TABLE - 1); };
     side[i] = make_uint4(c10(0) | (c10(1) << 10) | (c10(2) << 20), c10(3) | (c10(4) << 10) | (c10(5) << 20), c10(6) | (c10(7) << 10), ui);
+    if (deferred == 2) {                                       // the tape lookups of the row (rare: ecall rows only)
+      const uint32_t f2 = M[b8((uint32_t)air::phys_col(air::C_F2, 2), i, N)], rl = M[b8((uint32_t)air::phys_col(air::C_RL, 2), i, N)];
+      if (f2 | rl) {
+        IoEntry e;
+        e.row = (uint32_t)i; e.is_in = rl ? 1u : 0u;
+        e.idx = M[b8((uint32_t)air::phys_col(rl ? air::C_IC : air::C_OC, 2), i, N)];
+        const int v0 = rl ? air::C_Y : air::C_LIMB + 33;       // a live READ sends what it writes to R10 (y), a WRITE sends R11's limbs
+        for (int l = 0; l < 3; l++) e.v[l] = M[b8((uint32_t)air::phys_col(v0 + l, 2), i, N)];
+        e.pad[0] = e.pad[1] = 0;
+        io_list[atomicAdd(io_count, 1u)] = e;
+      }
+    }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) if (h_rc[k]) atomicAdd(&rc_mult[k], h_rc[k]);
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
 // Every lookup of the aux trace is then a table read, and the verifier-side sum T = sum m_t inv_rc[t] + sum r_u inv_rom[u] is formed
 // from the same tables on the host.
 __global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __restrict__ code, uint32_t n_code, const ProveParams* __restrict__ pp, E4* __restrict__ inv_rc,
-                                                            E4* __restrict__ inv_rom) {
+                                                            E4* __restrict__ inv_rom, int mode) {
   const uint32_t t = blockIdx.x * NT + threadIdx.x;
   if (t >= (uint32_t)air::RC_TABLE + n_code) return;
   E4 d;
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __res
   const uint32_t u = t - air::RC_TABLE, w = code[u];
   const uint64_t pc = 0x1000 + 4ull * u;
   const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), w & 0x7F, (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF,
-                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F), air::variant_bit(w & 0x7F)};
+                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F, mode), air::variant_bit(w & 0x7F)};
   // (fingerprint coordinates in Montgomery form: lk holds R * lambda^j_k, mont_mul(R a, to_mont(f)) = R a f)
   E4 fpm;
 #pragma unroll
@@ -277,6 +293,30 @@ __global__ __launch_bounds__(NT) void aux_rows_kernel(const uint4* __restrict__ 
   for (int k = 0; k < 4; k++) d.c[k] = bb::sub(d.c[k], pp->lk[air::LK_TN + k]);
   static_assert(air::A_HR == 4 * air::N_RC && air::A_S == air::A_HR + 4 && air::A_HR % 8 == 0, "aux layout: helpers, then HR | S in one block");
   put(air::A_HR / 8, 0, hr); put(air::A_HR / 8, 1, d);
+}
+
+__device__ __forceinline__ uint4 add4m(uint4 a, uint4 b);
+// (mode 2) the tape helpers of the WRITE / live READ rows: h = 1 / (alpha - fingerprint(index, limbs; tag)) into HO / HI (aux block A_HO / 8: HO | HI) of the row, and added
+// to the row's running-sum increment (the S slot written by aux_rows_kernel); every other row keeps the zeros the block was cleared with
+__global__ __launch_bounds__(NT) void io_aux_kernel(const IoEntry* __restrict__ io_list, uint32_t n_io, uint64_t N, const ProveParams* __restrict__ pp, uint32_t* __restrict__ A) {
+  const uint32_t t = blockIdx.x * NT + threadIdx.x;
+  if (t >= n_io) return;
+  const IoEntry e = io_list[t];
+  const uint32_t g[4] = {bb::to_mont(e.idx), bb::to_mont(e.v[0]), bb::to_mont(e.v[1]), bb::to_mont(e.v[2])};
+  E4 d;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t fp = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + k], bb::to_mont(e.is_in ? 3u : 2u));
+#pragma unroll
+    for (int j = 0; j < 4; j++) fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 * j + k], g[j]));
+    d.c[k] = bb::sub(pp->lk[air::LK_ALPHA + k], fp);
+  }
+  const E4 h = bb::e_inv_m(d);
+  uint4* A4 = reinterpret_cast<uint4*>(A);
+  static_assert(air::A_HO % 8 == 0 && air::A_HI == air::A_HO + 4, "aux layout: HO | HI in one block");
+  A4[((uint64_t)(air::A_HO / 8) * N + e.row) * 2 + (e.is_in ? 1 : 0)] = make_uint4(h.c[0], h.c[1], h.c[2], h.c[3]);
+  uint4* S = A4 + ((uint64_t)(air::A_S / 8) * N + e.row) * 2 + 1;
+  *S = add4m(*S, make_uint4(h.c[0], h.c[1], h.c[2], h.c[3]));
 }
 
 // Exclusive prefix sum (coordinate-wise, mod p) over the S slot of the aux matrix (block A_S / 8, second half), three launches:
@@ -336,8 +376,10 @@ __global__ __launch_bounds__(NT) void scan_add_kernel(uint32_t* __restrict__ A, 
 }
 
 // ---- boundary states: the 68 state words of rows 0 and last_row of the main trace (B8 layout) -> out[136] ----------------------------
-__global__ void boundary_states_kernel(const uint32_t* __restrict__ M, uint64_t N, uint64_t last_row, bool deferred, uint32_t* __restrict__ out) {
+// (mode 2: + the counters (oc, ic) of both rows at out[2 NS .. 2 NS + 4))
+__global__ void boundary_states_kernel(const uint32_t* __restrict__ M, uint64_t N, uint64_t last_row, int deferred /* the mode */, uint32_t* __restrict__ out) {
   const uint32_t i = threadIdx.x;
+  if (deferred == 2 && i >= 2 * NS && i < 2 * NS + 4) { const uint32_t k = i - 2 * NS; out[i] = M[b8((uint32_t)air::phys_col(air::C_OC + (k & 1), 2), k < 2 ? 0 : last_row, N)]; return; }
   if (i >= 2 * NS) return;
   const int k = air::state_col((int)(i % NS));                 // logical column; an uncommitted one (R0's limbs, default-mode storage states) is the constant 0
   out[i] = air::is_virtual(k, deferred) ? 0u : M[b8((uint32_t)air::phys_col(k, deferred), i < (uint32_t)NS ? 0 : last_row, N)];
@@ -406,16 +448,16 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
 // A = Σ gamma^k v_k, B = Σ gamma^(WT + k) v_k over the columns of a position (Montgomery words x Montgomery gamma powers): exact 96-bit sums
 // per extension coordinate (bb::mad96_s, gamma^k in scalar registers), reduced once — the reduction's division by R leaves R A, R B.
 __global__ __launch_bounds__(NT, DEEP_WAVES) void deep_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, const uint32_t* __restrict__ Q, uint32_t log_n,
-                                                   const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, int WM, uint32_t* __restrict__ cw) {
+                                                   const E4* __restrict__ dinv, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, int WM, int WA, uint32_t* __restrict__ cw) {
   const uint32_t N2 = 2u << log_n;
-  const int WT = WM + WA;                                      // WM = the proof's committed main-trace width (a multiple of 8)
+  const int WT = WM + WA;                                      // WM / WA = the proof's committed main-trace / aux widths (multiples of 8)
   const uint32_t j = blockIdx.x * NT + threadIdx.x;
   if (j >= N2) return;
   bb::Acc96 A[4], B[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) A[t] = B[t] = bb::acc96_zero();
   constexpr int UN = 8;
-  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && WA % UN == 0 && 2 * (WMX + WA) + 4 < 512, "column loop; 96-bit sums hold 2^9 terms");
+  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && air::W_COMMITTED_IO % UN == 0 && air::W_AUX % UN == 0 && WAX % UN == 0 && 2 * (WMX + WAX) + 4 < 512, "column loop; 96-bit sums hold 2^9 terms");
   auto block = [&](const uint4* M4, int blk, int k0) {                         // one B8 block = eight columns, gamma indices k0 .. k0 + 7 (zeta) and WT + k0 .. (zeta w)
     const uint4 vlo = M4[((uint64_t)blk * N2 + j) * 2], vhi = M4[((uint64_t)blk * N2 + j) * 2 + 1];
     const uint32_t v[UN] = {vlo.x, vlo.y, vlo.z, vlo.w, vhi.x, vhi.y, vhi.z, vhi.w};
@@ -566,14 +608,14 @@ struct StageEvents {             // RAII: released on every return path
 };
 
 // the header words of a v4 proof (so::header_words): parameters, public inputs, the two boundary states read off the main trace
-void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t* states, std::vector<uint32_t>& w) {
+void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t* states, std::vector<uint32_t>& w) {      // states: 2 NS words (+ 4 counters in mode 2)
   w.clear();
-  w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)air::committed_width(pub.deferred != 0), (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
-  w.insert(w.end(), {(uint32_t)(pub.n_real & 0x3FFFFFFF), (uint32_t)(pub.n_real >> 30), pub.deferred ? 1u : 0u});
+  w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)air::committed_width((int)pub.deferred), (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
+  w.insert(w.end(), {(uint32_t)(pub.n_real & 0x3FFFFFFF), (uint32_t)(pub.n_real >> 30), pub.deferred});
   w.insert(w.end(), {(uint32_t)(pub.entry_point & 0xFFFFF), (uint32_t)((pub.entry_point >> 20) & 0xFFFFF), (uint32_t)(pub.entry_point >> 40)});
   w.insert(w.end(), pub.program_digest, pub.program_digest + 4);
   w.insert(w.end(), pub.io_digest, pub.io_digest + 4);
-  w.insert(w.end(), states, states + 2 * NS);
+  w.insert(w.end(), states, states + 2 * NS + (pub.deferred == 2 ? 4 : 0));
 }
 
 // The quotient kernel's evaluation of the constraint list (QuotientOps: lazy 32-bit arithmetic, 96-bit sums, one accumulator per selector), run on
@@ -588,14 +630,15 @@ struct HostRowSrc {
   uint32_t aloc(int p) const { return a[p]; }
   uint32_t anxt(int p) const { return an[p]; }
 };
-template <bool DEF>
+template <int DEF /* the mode */>
 static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, const uint32_t* sel3, const uint32_t* first, const uint32_t* last,
-                          const uint32_t* alpha4, uint32_t* out4) {
-  uint32_t l[WMX], n[WMX], a[WA], an[WA], lkm[air::N_LK], fm[NS], lm[NS];
+                          const uint32_t* cnt4, const uint32_t* alpha4, uint32_t* out4) {
+  uint32_t l[WMX], n[WMX], a[WAX], an[WAX], lkm[air::N_LK], fm[NS], lm[NS], cm[4] = {0, 0, 0, 0};
   for (int p = 0; p < air::committed_used(DEF); p++) { l[p] = bb::to_mont(loc[air::logical_col(p, DEF)]); n[p] = bb::to_mont(nxt[air::logical_col(p, DEF)]); }
-  for (int k = 0; k < WA; k++) { a[k] = bb::to_mont(aloc[k]); an[k] = bb::to_mont(anxt[k]); }
-  for (int i = 0; i < air::N_LK; i++) lkm[i] = bb::to_mont(lk[i]);
+  for (int k = 0; k < air::aux_width(DEF); k++) { a[k] = bb::to_mont(aloc[k]); an[k] = bb::to_mont(anxt[k]); }
+  for (int i = 0; i < air::N_LK; i++) lkm[i] = (DEF == 2 || i < air::LK_NIN) ? bb::to_mont(lk[i]) : 0u;       // (modes 0 / 1: the caller's lk has 56 words)
   for (int i = 0; i < NS; i++) { fm[i] = bb::to_mont(first[i]); lm[i] = bb::to_mont(last[i]); }
+  if (DEF == 2) for (int k = 0; k < 4; k++) cm[k] = bb::to_mont(cnt4[k]);
   std::vector<E4> ap(N_CONSTRAINTS);
   E4 al{{alpha4[0], alpha4[1], alpha4[2], alpha4[3]}}, cur{{1, 0, 0, 0}};
   for (int c = 0; c < N_CONSTRAINTS; c++) { ap[c] = bb::e_to_mont(cur); cur = h_e_mul(cur, al); }
@@ -605,9 +648,9 @@ static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32
   for (int k = 0; k < n_push; k++) seq[k] = ap[order[k]];
   QuotientOps<DEF, HostRowSrc> o{HostRowSrc{l, n, a, an}, seq.data(), {}, lkm};
   o.init();
-  air::eval(o, fm, lm, DEF);
+  air::eval(o, fm, lm, DEF, cm);
   E4 cf, cl;
-  air::boundary_constants(ap.data(), fm, lm, cf, cl);
+  air::boundary_constants(ap.data(), fm, lm, cf, cl, DEF == 2 ? cm : nullptr);
   using QO = QuotientOps<DEF, HostRowSrc>;
   const E4 s0 = QO::sum_of(o.a0), st = o.st, sf = bb::e_sub(o.sf, cf), sl = bb::e_sub(o.sl, cl);
   const E4 tot = bb::e_add(bb::e_add(s0, bb::e_mul_fm(st, bb::to_mont(sel3[2]))), bb::e_add(bb::e_mul_fm(sf, bb::to_mont(sel3[0])), bb::e_mul_fm(sl, bb::to_mont(sel3[1]))));
@@ -619,10 +662,11 @@ static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32
 extern "C" {
 
 void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, uint32_t is_first, uint32_t is_last, uint32_t is_trans,
-                        const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t deferred, uint32_t* out4) {
+                        const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t mode, const uint32_t* cnt4, uint32_t* out4) {
   const uint32_t sel3[3] = {is_first, is_last, is_trans};
-  if (deferred) air_eval_host<true>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, alpha4, out4);
-  else air_eval_host<false>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, alpha4, out4);
+  if (mode == 2) air_eval_host<2>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
+  else if (mode == 1) air_eval_host<1>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
+  else air_eval_host<0>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
 }
 
 uint32_t zkir_proof_num_queries(void) { return NUM_QUERIES; }
@@ -638,8 +682,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (!c || !trace || !pub || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
   const uint32_t log_n = c->log_n;
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
-  const bool DEF = pub && pub->deferred != 0;
-  const int WM = air::committed_width(DEF), WT = WM + WA;     // this proof's committed main-trace columns; main + aux
+  if (pub->deferred > 2) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument"}); return ZKIR_ERR_ARGUMENT; }
+  const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument (round 4)
+  const bool DEF = MODE == 1;
+  const int WM = air::committed_width(MODE), WA = air::aux_width(MODE), WT = WM + WA;     // this proof's committed main-trace / aux columns
+  if (MODE == 2 && ((!pub->inputs && pub->n_inputs) || (!pub->outputs && pub->n_outputs) || pub->n_inputs >= (1u << 28) || pub->n_outputs >= (1u << 28) || pub->halt_kind > 2)) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: mode 2 needs the I/O tapes and the halt reason in the public inputs (zkir_public_inputs_of fills them)"});
+    return ZKIR_ERR_ARGUMENT;
+  }
   if (pub->n_real == 0 || zkir_padded_log_n(pub->n_real) != log_n || pub->entry_point >= (1ull << 40)) {
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the context's log_n must be zkir_padded_log_n(n_real) (n_real >= 1), and entry_point < 2^40"});
     return ZKIR_ERR_ARGUMENT;
@@ -671,7 +721,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
-    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16);
+    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (MODE == 2 ? 48 : 0)) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
+                        (MODE == 2 ? (size_t)pub->n_inputs * 8 : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -686,7 +737,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   uint4 *dSide, *dSums;
   E4 *dW, *dDinv, *dPart, *dInvRc, *dInvRom;
   ProveParams* dPP;
-  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS)); HIP_OK(ar.take(&dBad, 1));
+  IoEntry* dIo = nullptr; uint32_t* dIoCount = nullptr; uint64_t* dInputs = nullptr; uint32_t* dIoScratch = nullptr;
+  HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS + 4)); HIP_OK(ar.take(&dBad, 1));
+  if (MODE == 2) { HIP_OK(ar.take(&dIo, N)); HIP_OK(ar.take(&dIoCount, 4)); HIP_OK(ar.take(&dInputs, (size_t)pub->n_inputs + 1)); HIP_OK(ar.take(&dIoScratch, 2 * N + 2 * (N / 1024 + 2))); }
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dA, WA * N)); HIP_OK(ar.take(&dAL, WA * N2)); HIP_OK(ar.take(&dATree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dSide, N)); HIP_OK(ar.take(&dSums, N / SCAN_ROWS + 1));
@@ -703,8 +756,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   // ---- 1. main trace, lookup indices + multiplicities, LDE, trace commitment ---------------------------------------------------
   mark(0);
-  int rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s); if (rc) return rc;
-  hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, DEF, dBound);   // before the LDE overwrites dM
+  int rc;
+  if (MODE == 2) {
+    if (pub->n_inputs) HIP_OK(hipMemcpyAsync(dInputs, pub->inputs, (size_t)pub->n_inputs * 8, hipMemcpyHostToDevice, s));
+    const zkir_io_args io{dInputs, pub->n_inputs, pub->writes_before, pub->reads_before};
+    rc = zkir_main_trace_io_launch(trace, pub->n_real, &io, dIoScratch, dM, s);
+  } else rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, MODE, dBound);   // before the LDE overwrites dM
   std::vector<uint32_t> code(n_code);                         // lives to the end of the call: the H2D copy below reads it
   {
     for (uint32_t t = 0; t < n_code; t++) memcpy(&code[t], blob + 32 + 4 * (size_t)t, 4);
@@ -712,17 +771,19 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemsetAsync(dMult, 0, ((size_t)n_code + air::RC_TABLE) * 4, s));
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, DEF, dCode, n_code, dSide, dMult + n_code, dMult, dBad);
+    if (MODE == 2) HIP_OK(hipMemsetAsync(dIoCount, 0, 4, s));
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount);
   }
   mark(1);
   rc = lde_launch(c, dM, WM, dL, /*mont_out=*/true, s); if (rc) return rc;        // canonical evaluations in, MONTGOMERY words out: the matrices of a proof rest in Montgomery form
   mark(2);
   rc = merkle_commit(c, dL, WM, N2, dTree, /*mont_in=*/true, s); if (rc) return rc;
-  uint32_t troot[4], aroot[4], qroot[4], bound[2 * NS];
+  uint32_t troot[4], aroot[4], qroot[4], bound[2 * NS + 4] = {}, n_io = 0;
   unsigned long long bad_row = ~0ull;
   std::vector<uint32_t> mult((size_t)n_code + air::RC_TABLE);
   HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(bound, dBound, sizeof bound, hipMemcpyDeviceToHost, s));
+  if (MODE == 2) HIP_OK(hipMemcpyAsync(&n_io, dIoCount, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(mult.data(), dMult, mult.size() * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(&bad_row, dBad, 8, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -748,8 +809,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int k = 0; k < 4; k++) pp->lk[air::LK_ALPHA + k] = bb::to_mont(alpha_l.c[k]);
     for (int j = 0; j <= air::N_TUPLE; j++) { for (int k = 0; k < 4; k++) pp->lk[air::LK_LAM + 4 * j + k] = bb::to_mont(lam.c[k]); lam = h_e_mul(lam, lambda); }
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = 0;
+    pp->lk[air::LK_NIN] = MODE == 2 ? bb::to_mont((uint32_t)(pub->n_inputs % bb::P)) : 0u;
     HIP_OK(hipMemcpyAsync(dPP->lk, pp->lk, sizeof(pp->lk), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom);
+    hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom, MODE);
     std::vector<E4> inv((size_t)air::RC_TABLE + n_code);
     HIP_OK(hipMemcpyAsync(inv.data(), dInvRc, (size_t)air::RC_TABLE * sizeof(E4), hipMemcpyDeviceToHost, s));
     if (n_code) HIP_OK(hipMemcpyAsync(inv.data() + air::RC_TABLE, dInvRom, (size_t)n_code * sizeof(E4), hipMemcpyDeviceToHost, s));
@@ -757,10 +819,35 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     E4 T = bb::e_zero();                                      // Montgomery: sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u)
     for (int t = 0; t < air::RC_TABLE; t++) if (mult[n_code + t]) T = bb::e_add(T, bb::e_mul_fm(inv[t], bb::to_mont(mult[n_code + t] % bb::P)));
     for (uint32_t u = 0; u < n_code; u++) if (mult[u]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + u], bb::to_mont(mult[u] % bb::P)));
+    if (MODE == 2) {
+      // the tapes' share of the table side, formed like the verifier will form it: every output index in [oc_first, oc_last) and every input index in
+      // [ic_first, ic_last) once (air.h: mode 2; oracle: so::io_table_sum) — if the trace's WRITE / READ rows do not send exactly these, the sums differ and the proof fails
+      auto term = [&](uint64_t k, uint64_t v, uint32_t tag) {
+        const uint32_t gl[4] = {(uint32_t)(k % bb::P), (uint32_t)(v & 0xFFFFF), (uint32_t)((v >> 20) & 0xFFFFF), (uint32_t)(v >> 40)};
+        E4 fp;
+        for (int c4 = 0; c4 < 4; c4++) {
+          uint32_t f = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + c4], bb::to_mont(tag));
+          for (int j = 0; j < 4; j++) f = bb::add(f, bb::mont_mul(pp->lk[air::LK_LAM + 4 * j + c4], bb::to_mont(gl[j])));
+          fp.c[c4] = bb::sub(pp->lk[air::LK_ALPHA + c4], f);
+        }
+        T = bb::e_add(T, bb::e_inv_m(fp));
+      };
+      const uint32_t* cn = bound + 2 * NS;                      // (oc, ic) of the first row, of the last row
+      if (cn[2] > pub->n_outputs || cn[3] > pub->n_inputs || cn[0] > cn[2] || cn[1] > cn[3]) {
+        zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the trace writes more outputs / consumes more inputs than the public inputs' tapes hold (or writes_before / reads_before are wrong)"});
+        return ZKIR_ERR_ARGUMENT;
+      }
+      for (uint64_t k = cn[0]; k < cn[2]; k++) term(k, pub->outputs[k], 2);
+      for (uint64_t k = cn[1]; k < cn[3]; k++) term(k, pub->inputs[k], 3);
+    }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];
     HIP_OK(hipMemcpyAsync(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(aux_rows_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, N, dInvRc, dInvRom, dPP, dA);
+    if (MODE == 2) {                                          // the tape helpers HO | HI: zero but on the WRITE / live READ rows
+      HIP_OK(hipMemsetAsync(dA + (size_t)(air::A_HO / 8) * N * 8, 0, (size_t)N * 32, s));
+      if (n_io) hipLaunchKernelGGL(io_aux_kernel, dim3(grid_for(n_io)), dim3(NT), 0, s, dIo, n_io, N, dPP, dA);
+    }
     const uint32_t n_scan = (uint32_t)((N + SCAN_ROWS - 1) / SCAN_ROWS);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_scan), dim3(NT), 0, s, dA, N, dSums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(NT), 0, s, dSums, n_scan);
@@ -780,10 +867,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     std::vector<E4> alpha_pow(N_CONSTRAINTS);
     for (int k = 0; k < N_CONSTRAINTS; k++) { alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
     int order[N_CONSTRAINTS];
-    const int n_push = air::push_order(DEF, order);             // the order the quotient kernel consumes the coefficients in
+    const int n_push = air::push_order(MODE, order);            // the order the quotient kernel consumes the coefficients in
     for (int k = 0; k < N_CONSTRAINTS + 2; k++) pp->alpha_seq[k] = k < n_push ? alpha_pow[order[k]] : bb::e_zero();
     for (int i = 0; i < NS; i++) { pp->first_m[i] = bb::to_mont(bound[i]); pp->last_m[i] = bb::to_mont(bound[NS + i]); }
-    air::boundary_constants(alpha_pow.data(), pp->first_m, pp->last_m, pp->cf, pp->cl);
+    for (int k = 0; k < 4; k++) pp->cnt_m[k] = bb::to_mont(bound[2 * NS + k]);
+    air::boundary_constants(alpha_pow.data(), pp->first_m, pp->last_m, pp->cf, pp->cl, MODE == 2 ? pp->cnt_m : nullptr);
     pp->deferred = pub->deferred ? 1 : 0;
     HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
   }
@@ -791,8 +879,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const uint32_t gN = bb::pow(bb::GEN, N), wn_inv_m = bb::to_mont(bb::inv(wn)), w_last_inv_m = bb::to_mont(bb::inv(bb::pow(wn, pub->n_real - 1)));
   const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
   const uint32_t last_shift = (uint32_t)((2 * (pub->n_real - 1)) & (N2 - 1));   // x_j - w_N^last = w_N^last (x_(j - 2 last) - 1) on the 2N coset
-  if (DEF) hipLaunchKernelGGL(quotient_kernel<true>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
-  else hipLaunchKernelGGL(quotient_kernel<false>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  if (MODE == 1) hipLaunchKernelGGL(quotient_kernel<1>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  else if (MODE == 2) hipLaunchKernelGGL(quotient_kernel<2>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  else hipLaunchKernelGGL(quotient_kernel<0>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   rc = merkle_commit(c, dQ, 4, N2, dQTree, /*mont_in=*/true, s); if (rc) return rc;
   HIP_OK(hipMemcpyAsync(qroot, dQTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -848,7 +937,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemcpyAsync(&dPP->a0, &pp->a0, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   }
   HIP_OK(ar.take(&fri_layers[0], 4 * N2));
-  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, WM, fri_layers[0]);
+  hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, WM, WA, fri_layers[0]);
   mark(7);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
@@ -910,6 +999,12 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
   head.push_back((uint32_t)blob_len);                                         // the program: byte length, then 16-bit halfwords
   for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
+  if (MODE == 2) {                                                            // the I/O section: the tapes and the halt reason the io digest is a digest of
+    auto put_u64 = [&](uint64_t v) { for (int i = 0; i < 4; i++) head.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); };
+    head.push_back((uint32_t)pub->n_inputs); for (uint64_t i = 0; i < pub->n_inputs; i++) put_u64(pub->inputs[i]);
+    head.push_back((uint32_t)pub->n_outputs); for (uint64_t i = 0; i < pub->n_outputs; i++) put_u64(pub->outputs[i]);
+    head.push_back(pub->halt_kind); put_u64(pub->halt_kind == ZKIR_HALT_EXIT ? pub->halt_code : 0);
+  }
   head.insert(head.end(), mult.begin(), mult.end());                          // ROM multiplicities, range multiplicities
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);

@@ -17,7 +17,7 @@
 namespace {
 
 using bb::E4;
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WA = air::W_AUX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
@@ -72,7 +72,7 @@ struct VerifierOps {                                                       // ai
   using V = E4;
   using AccP = E4;
   using AccL = E4;
-  const E4* l; const E4* n; const E4* al; const E4* an; const uint32_t* lk_m; const E4* ap; E4 acc; bool deferred;
+  const E4* l; const E4* n; const E4* al; const E4* an; const uint32_t* lk_m; const E4* ap; E4 acc; int deferred;   // deferred: the MODE (0, 1, 2)
   E4 is_first, is_last, is_trans;
   V aloc(int k) const { return al[k]; }
   V anxt(int k) const { return an[k]; }
@@ -120,7 +120,37 @@ void initial_state(uint64_t entry, uint32_t st[NS]) {
   st[1] = (uint32_t)(entry & 0xFFFFF); st[2] = (uint32_t)((entry >> 20) & 0xFFFFF); st[3] = (uint32_t)(entry >> 40);
 }
 
-int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out);
+int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out, uint32_t* counters_out = nullptr);
+inline int header_words_of(int mode) { return HEADER_WORDS + (mode == 2 ? 4 : 0); }     // mode 2: + (oc, ic) of the first row, of the last row
+
+// (mode 2) the I/O section of a proof, after the program: [n_in] [inputs: four 16-bit pieces each] [n_out] [outputs] [halt kind] [halt code: four pieces]
+struct IoSection { std::vector<uint64_t> in, out; uint32_t halt_kind = ZKIR_HALT_CYCLE_LIMIT; uint64_t halt_code = 0; size_t words = 0; };
+bool parse_io_section(const uint32_t* w, size_t avail, IoSection& io) {
+  size_t p = 0;
+  auto u64 = [&](uint64_t& v) { if (p + 4 > avail) return false; v = 0; for (int i = 0; i < 4; i++) { if (w[p + i] > 0xFFFF) return false; v |= (uint64_t)w[p + i] << (16 * i); } p += 4; return true; };
+  for (int tape = 0; tape < 2; tape++) {
+    if (p >= avail) return false;
+    const size_t n = w[p++];
+    if (n > ((size_t)1 << 28) || p + 4 * n > avail) return false;
+    std::vector<uint64_t>& t = tape ? io.out : io.in;
+    t.resize(n);
+    for (size_t k = 0; k < n; k++) if (!u64(t[k])) return false;
+  }
+  if (p >= avail) return false;
+  io.halt_kind = w[p++];
+  if (io.halt_kind > 2 || !u64(io.halt_code)) return false;
+  io.words = p;
+  return true;
+}
+bool io_digest_matches(const uint32_t* digest4, const IoSection& io, uint64_t cycles) {
+  std::vector<uint64_t> b;
+  b.push_back(io.in.size()); b.insert(b.end(), io.in.begin(), io.in.end()); b.push_back(io.out.size()); b.insert(b.end(), io.out.begin(), io.out.end());
+  b.push_back(io.halt_kind); b.push_back(io.halt_kind == ZKIR_HALT_EXIT ? io.halt_code : 0); b.push_back(cycles);
+  uint32_t dg[4];
+  zkir_digest_bytes((const uint8_t*)b.data(), b.size() * 8, dg);
+  return !memcmp(dg, digest4, 16);
+}
+int halt_binding(const uint32_t* w, const uint32_t* last_state, int halt_kind, uint64_t halt_code);
 
 }  // namespace
 
@@ -128,7 +158,7 @@ extern "C" {
 
 // Static check of the quotient kernel's lazy arithmetic on the constraint list (air::BoundOps): 0 = sound; else 1 and the broken rule in `why`.
 int zkir_air_check_bounds(uint32_t deferred, char* why, size_t why_len) {
-  const char* w = air::check_bounds(deferred != 0);
+  const char* w = air::check_bounds((int)deferred);                 // `deferred` = the mode: 0, 1 or 2
   if (why && why_len) snprintf(why, why_len, "%s", w ? w : "");
   return w ? 1 : 0;
 }
@@ -149,7 +179,12 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t
   if (log->window_open) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: this trace window ended before the run did (its outputs / halt reason are not the run's)"}); return ZKIR_ERR_ARGUMENT; }
   memset(out, 0, sizeof *out);
   out->n_real = log->cycles;
-  out->deferred = deferred ? 1 : 0;
+  out->deferred = deferred > 2 ? 1 : deferred;                             // the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument
+  // the claim in the clear (mode 2 proofs carry it; BORROWED: the caller's inputs, the log's outputs)
+  out->inputs = inputs; out->n_inputs = n_inputs;
+  out->outputs = log->outputs.data(); out->n_outputs = log->outputs.size();
+  out->halt_kind = (uint32_t)log->halt_kind; out->halt_code = log->halt_kind == ZKIR_HALT_EXIT ? log->halt_code : 0;
+  out->writes_before = out->reads_before = 0;                              // a whole run; the caller of a SEGMENT proof sets them
   uint32_t entry = 0x1000;
   if (blob_len >= 16) memcpy(&entry, blob + 12, 4);                        // ProgramHeader.entry_point, program.rs:189-213
   out->entry_point = entry;
@@ -176,10 +211,10 @@ uint32_t zkir_proof_state_words(void) { return NS; }
 
 int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint32_t n, const zkir_public_inputs* expect) {
   if (!proofs || !lens || n < 1) return 40;
-  std::vector<uint32_t> st((size_t)n * 2 * NS);
+  std::vector<uint32_t> st((size_t)n * 2 * NS), cnt((size_t)n * 4, 0);
   uint64_t total = 1;
   for (uint32_t i = 0; i < n; i++) {
-    const int rc = verify_impl(proofs[i], lens[i], nullptr, false, &st[(size_t)i * 2 * NS]);
+    const int rc = verify_impl(proofs[i], lens[i], nullptr, false, &st[(size_t)i * 2 * NS], &cnt[(size_t)i * 4]);
     if (rc) return 1000 * (int)(i + 1) + rc;
     const uint32_t* w = proofs[i];
     total += ((uint64_t)w[7] | ((uint64_t)w[8] << 30)) - 1;
@@ -193,8 +228,23 @@ int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint3
   for (uint32_t i = 1; i < n; i++)
     if (memcmp(&st[(size_t)i * 2 * NS], &st[(size_t)(i - 1) * 2 * NS + NS], NS * 4)) return 42;
   if (expect) {
-    if ((expect->deferred != 0) != (w0[9] != 0) || expect->entry_point != entry || memcmp(expect->program_digest, w0 + 13, 16) || memcmp(expect->io_digest, w0 + 17, 16)) return 43;
+    if (expect->deferred != w0[9] || expect->entry_point != entry || memcmp(expect->program_digest, w0 + 13, 16) || memcmp(expect->io_digest, w0 + 17, 16)) return 43;
     if (expect->n_real != total) return 44;
+  }
+  if (w0[9] == 2) {
+    // (mode 2) the I/O argument across segments: the same tapes in every segment (45), counters from (0, 0) linking up (46) to "every output written" (51),
+    // tapes + halt reason + TOTAL cycle count hash to the io digest (50), the last segment ends on the instruction the halt reason names (52 / 53)
+    const size_t HW = (size_t)header_words_of(2);
+    auto io_at = [&](const uint32_t* w) { return HW + 1 + ((size_t)w[HW] + 1) / 2; };
+    IoSection io0;
+    if (!parse_io_section(w0 + io_at(w0), (size_t)lens[0] - io_at(w0), io0)) return 4;
+    for (uint32_t i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
+    if (cnt[0] || cnt[1]) return 51;
+    for (uint32_t i = 1; i < n; i++) if (cnt[(size_t)i * 4] != cnt[(size_t)(i - 1) * 4 + 2] || cnt[(size_t)i * 4 + 1] != cnt[(size_t)(i - 1) * 4 + 3]) return 46;
+    if (cnt[(size_t)(n - 1) * 4 + 2] != io0.out.size()) return 51;
+    if (!io_digest_matches(w0 + 17, io0, total)) return 50;
+    const int hb = halt_binding(proofs[n - 1], proofs[n - 1] + 21 + NS, (int)io0.halt_kind, io0.halt_code);
+    if (hb) return hb;
   }
   return 0;
 }
@@ -213,9 +263,10 @@ namespace {
 int halt_binding(const uint32_t* w, const uint32_t* last_state, int halt_kind, uint64_t halt_code) {
   if (halt_kind == ZKIR_HALT_CYCLE_LIMIT) return 0;
   if (halt_kind != ZKIR_HALT_EBREAK && halt_kind != ZKIR_HALT_EXIT) return 52;
-  const uint64_t blob_len = w[HEADER_WORDS];
+  const int HW = header_words_of((int)w[9]);
+  const uint64_t blob_len = w[HW];
   std::vector<uint8_t> blob(blob_len);
-  for (uint64_t i = 0; i < blob_len; i += 2) { const uint32_t h = w[HEADER_WORDS + 1 + i / 2]; blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8); }
+  for (uint64_t i = 0; i < blob_len; i += 2) { const uint32_t h = w[HW + 1 + i / 2]; blob[i] = (uint8_t)(h & 0xFF); if (i + 1 < blob_len) blob[i + 1] = (uint8_t)(h >> 8); }
   if (blob_len < 32) return 52;
   uint32_t code_size; memcpy(&code_size, blob.data() + 16, 4);
   const uint64_t pc = (uint64_t)last_state[1] | ((uint64_t)last_state[2] << 20) | ((uint64_t)last_state[3] << 40);
@@ -268,15 +319,19 @@ int zkir_verify_chain_io(const uint32_t* const* proofs, const uint64_t* lens, ui
 
 namespace {
 
-int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out) {
+int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out, uint32_t* counters_out) {
   if (!w) return 1;
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
   if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
   const int log_n = (int)w[2];
+  if (w[9] > 2) return 2;
+  const int mode = (int)w[9];                                              // 0 default, 1 deferred, 2 default + the I/O argument
+  const int HW = header_words_of(mode), WA = air::aux_width(mode);
+  if (!need(HW)) return 1;
   const int WM = (int)w[3], WT = WM + WA;                                  // committed main-trace columns (checked against the mode below); main + aux
-  if (w[9] > 1 || w[3] != (uint32_t)air::committed_width(w[9] != 0) || w[4] != (uint32_t)NUM_QUERIES || w[5] != (uint32_t)LOG_FINAL || w[6] != (uint32_t)POW_BITS || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
-  if (w[7] >= (1u << 30) || w[9] > 1 || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
+  if (w[3] != (uint32_t)air::committed_width(mode) || w[4] != (uint32_t)NUM_QUERIES || w[5] != (uint32_t)LOG_FINAL || w[6] != (uint32_t)POW_BITS || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
+  if (w[7] >= (1u << 30) || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
   zkir_public_inputs pub;
   memset(&pub, 0, sizeof pub);
   pub.n_real = (uint64_t)w[7] | ((uint64_t)w[8] << 30); pub.deferred = w[9];
@@ -285,11 +340,14 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   const uint32_t* first = w + 21; const uint32_t* last = w + 21 + NS;       // boundary states: pinned to rows 0 and n_real - 1 by the AIR
   for (int i = 0; i < 2 * NS; i++) if (first[i] >= bb::P) return 3;
   if (pub.n_real == 0 || zkir_padded_log_n(pub.n_real) != (uint32_t)log_n) return 2;
-  if (expect && (expect->n_real != pub.n_real || (expect->deferred != 0) != (pub.deferred != 0) || expect->entry_point != pub.entry_point ||
+  uint32_t cnt[4] = {0, 0, 0, 0};                                          // (mode 2) (oc, ic) of the first row, of the last row
+  if (mode == 2) { for (int k = 0; k < 4; k++) { if (w[HEADER_WORDS + k] >= bb::P) return 3; cnt[k] = w[HEADER_WORDS + k]; } }
+  if (counters_out) memcpy(counters_out, cnt, sizeof cnt);
+  if (expect && (expect->n_real != pub.n_real || expect->deferred != pub.deferred || expect->entry_point != pub.entry_point ||
                  memcmp(expect->program_digest, pub.program_digest, 16) || memcmp(expect->io_digest, pub.io_digest, 16))) return 6;
   if (whole_run) { uint32_t init[NS]; initial_state(pub.entry_point, init); if (memcmp(init, first, sizeof init)) return 7; }   // a run starts in the VM's initial state
   if (states_out) memcpy(states_out, first, 2 * NS * 4);
-  p = HEADER_WORDS;
+  p = (size_t)HW;
   const size_t N = (size_t)1 << log_n;
   for (size_t i = 2; i < len; i++) if (w[i] >= bb::P) return 3;
   // ---- the program carried in the proof: [byte length][16-bit halfwords]; it must be the program the header names (check 8) ----
@@ -309,6 +367,20 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   const uint64_t code_size = le32(16);
   if (code_size % 4 || 32 + code_size > blob_len || le32(12) != pub.entry_point) return 8;
   const size_t n_code = (size_t)(code_size / 4);
+  // (mode 2) the tapes and the halt reason the io digest is a digest of: the digest with the cycle count (50; a whole run's is its row count, a chain checks the total),
+  // the counters' ends (51), the halt row named by the halt reason (52 / 53)
+  IoSection io;
+  if (mode == 2) {
+    if (!parse_io_section(w + p, (size_t)len - p, io)) return 4;
+    p += io.words;
+    if (cnt[0] > cnt[2] || cnt[1] > cnt[3] || cnt[2] > io.out.size() || cnt[3] > io.in.size()) return 51;
+    if (whole_run) {
+      if (!io_digest_matches(pub.io_digest, io, pub.n_real)) return 50;
+      if (cnt[0] || cnt[1] || cnt[2] != io.out.size()) return 51;
+      const int hb = halt_binding(w, last, (int)io.halt_kind, io.halt_code);
+      if (hb) return hb;
+    }
+  }
   if (!need(n_code + air::RC_TABLE)) return 4;
   const uint32_t* rom_mult = w + p; p += n_code;
   const uint32_t* rc_mult = w + p; p += air::RC_TABLE;
@@ -334,7 +406,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   const uint32_t pow_nonce = w[p++];
   // ---- transcript ----
   Challenger ch;
-  ch.observe_n(w + 2, HEADER_WORDS - 2);
+  ch.observe_n(w + 2, (size_t)HW - 2);
   ch.observe_n(troot, 4);
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
@@ -354,7 +426,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       const uint32_t cw = le32(32 + 4 * u);
       const uint64_t pc = 0x1000 + 4 * (uint64_t)u;
       const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), cw & 0x7F, (cw >> 7) & 0xF, (cw >> 11) & 0xF,
-                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F), air::variant_bit(cw & 0x7F)};
+                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F, mode), air::variant_bit(cw & 0x7F)};
       E4 fp = lam[air::N_TUPLE];
       for (int j = 0; j < air::N_TUPLE; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(f[j])));
       d[air::RC_TABLE + u] = bb::e_sub(alpha_l, fp);
@@ -370,6 +442,20 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       inv = bb::e_mul_m(inv, d[i]);
       const uint32_t m = i < (size_t)air::RC_TABLE ? rc_mult[i] : rom_mult[i - air::RC_TABLE];
       if (m) T = bb::e_add(T, bb::e_mul_fm(di, bb::to_mont(m)));
+    }
+    lk_m[air::LK_NIN] = 0;
+    if (mode == 2) {
+      // the tapes' share of the table side: every output index in [oc_first, oc_last) and every input index in [ic_first, ic_last) exactly once,
+      // fingerprint = index + lambda v0 + lambda^2 v1 + lambda^3 v2 + tag lambda^N_TUPLE (tag 2 = outputs, 3 = inputs), v = the (20, 20, 24)-bit limbs of the value
+      lk_m[air::LK_NIN] = bb::to_mont((uint32_t)(io.in.size() % bb::P));
+      auto term = [&](uint64_t k, uint64_t v, uint32_t tag) {
+        const uint32_t g[4] = {(uint32_t)(k % bb::P), (uint32_t)(v & 0xFFFFF), (uint32_t)((v >> 20) & 0xFFFFF), (uint32_t)(v >> 40)};
+        E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont(tag));
+        for (int j = 0; j < 4; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(g[j])));
+        T = bb::e_add(T, bb::e_inv_m(bb::e_sub(alpha_l, fp)));
+      };
+      for (uint64_t k = cnt[0]; k < cnt[2]; k++) term(k, io.out[k], 2);
+      for (uint64_t k = cnt[1]; k < cnt[3]; k++) term(k, io.in[k], 3);
     }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) lk_m[air::LK_TN + k] = tn.c[k];
@@ -387,7 +473,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   // ---- 1. constraints at zeta: sum_c alpha^c C_c(zeta) == Q(zeta) Z_H(zeta) ----
   const uint32_t wn = bb::root_of_unity(log_n), wn_m = bb::to_mont(wn);
   {
-    std::vector<E4> ap(air::N_CONSTRAINTS);
+    std::vector<E4> ap(air::N_CONSTRAINTS);                                // (modes 0 / 1 use the first N_CONSTRAINTS_BASE)
     ap[0] = bb::e_one_m();
     for (int c = 1; c < air::N_CONSTRAINTS; c++) ap[c] = bb::e_mul_m(ap[c - 1], alpha);
     E4 zh = m_pow(zeta, N); zh.c[0] = bb::sub(zh.c[0], bb::R1);
@@ -397,8 +483,10 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     E4 is_trans = zeta; is_trans.c[0] = bb::sub(is_trans.c[0], bb::to_mont(bb::inv(wn)));
     uint32_t first_m[NS], last_m[NS];
     for (int i = 0; i < NS; i++) { first_m[i] = bb::to_mont(first[i]); last_m[i] = bb::to_mont(last[i]); }
-    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero(), pub.deferred != 0, is_first, is_last, is_trans};
-    air::eval(o, first_m, last_m, pub.deferred != 0);
+    uint32_t cnt_m[4];
+    for (int k = 0; k < 4; k++) cnt_m[k] = bb::to_mont(cnt[k]);
+    VerifierOps o{t_z.data(), t_zw.data(), t_z.data() + WM, t_zw.data() + WM, lk_m, ap.data(), bb::e_zero(), mode, is_first, is_last, is_trans};
+    air::eval(o, first_m, last_m, mode, cnt_m);
     E4 qz = bb::e_zero();                                                  // Q(zeta) = sum_i X^i q_i(zeta): basis element X^i times the E4 opening
     for (int i = 0; i < 4; i++) { E4 basis = bb::e_zero(); basis.c[i] = bb::R1; qz = bb::e_add(qz, bb::e_mul_m(basis, q_z[i])); }
     if (!e_eq(o.acc, bb::e_mul_m(qz, zh))) return 10;

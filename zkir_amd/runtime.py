@@ -87,7 +87,26 @@ class NormColumnsC(C.Structure):
 class PublicInputsC(C.Structure):             # zkir_public_inputs
     _fields_ = [("n_real", C.c_uint64), ("entry_point", C.c_uint64), ("deferred", C.c_uint32), ("reserved", C.c_uint32),
                 ("program_digest", C.c_uint32 * 4), ("io_digest", C.c_uint32 * 4),
-                ("program_blob", C.c_void_p), ("program_blob_len", C.c_uint64)]     # borrowed pointer (prover side): see with_program()
+                ("program_blob", C.c_void_p), ("program_blob_len", C.c_uint64),      # borrowed pointer (prover side): see with_program()
+                # mode 2 (`deferred` == 2: default VM mode + the I/O argument): the tapes and the halt reason in the clear (borrowed pointers: with_io()); for a SEGMENT
+                # the WRITE / READ ecalls executed before its first row
+                ("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("outputs", C.c_void_p), ("n_outputs", C.c_uint64), ("halt_kind", C.c_uint32), ("reserved2", C.c_uint32),
+                ("halt_code", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+
+    def with_io(self, inputs, outputs, halt=None, writes_before=None, reads_before=None) -> "PublicInputsC":
+        """Point the struct at its own copies of the I/O tapes (kept alive by the struct); halt = a HaltReason or (kind, code)."""
+        self._in_ref = np.ascontiguousarray(np.asarray([int(x) & (2**64 - 1) for x in inputs], dtype=np.uint64))
+        self._out_ref = np.ascontiguousarray(np.asarray([int(x) & (2**64 - 1) for x in outputs], dtype=np.uint64))
+        self.inputs, self.n_inputs = (self._in_ref.ctypes.data if len(self._in_ref) else None), len(self._in_ref)
+        self.outputs, self.n_outputs = (self._out_ref.ctypes.data if len(self._out_ref) else None), len(self._out_ref)
+        if halt is not None:
+            kind, code = (halt.kind, halt.code) if hasattr(halt, "kind") else halt
+            self.halt_kind, self.halt_code = int(kind), int(code or 0) if int(kind) == 1 else 0
+        if writes_before is not None:
+            self.writes_before = int(writes_before)
+        if reads_before is not None:
+            self.reads_before = int(reads_before)
+        return self
 
     def with_program(self, blob: bytes) -> "PublicInputsC":
         """Point the struct at `blob` (kept alive by the struct): needed after the struct has been copied byte-wise or sent to another
@@ -100,6 +119,7 @@ class PublicInputsC(C.Structure):             # zkir_public_inputs
 
     def copy(self) -> "PublicInputsC":
         q = PublicInputsC.from_buffer_copy(bytes(self))
+        q.with_io(getattr(self, "_in_ref", []), getattr(self, "_out_ref", []))
         return q.with_program(getattr(self, "_blob_ref", b""))
 
 
@@ -336,15 +356,18 @@ class DeltaLog:
             pass
 
 
-def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False) -> PublicInputsC:
-    """zkir_public_inputs_of: what a proof of this run is bound to (row count, mode, entry pc, program digest, io digest)."""
+def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False, io_mode: bool = False) -> PublicInputsC:
+    """zkir_public_inputs_of: what a proof of this run is bound to (row count, mode, entry pc, program digest, io digest).  io_mode = mode 2: the default VM mode
+    with the I/O argument (WRITE / READ ecalls tied to the tapes, which the proof then carries)."""
     blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
     arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
     out = PublicInputsC()
-    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), int(deferred), C.byref(out))
+    assert not (deferred and io_mode), "the I/O argument is stated for the default VM mode"
+    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), 2 if io_mode else int(deferred), C.byref(out))
     if rc != ZKIR_OK:
         _raise(rc)
-    return out.with_program(blob)          # the C call borrowed a temporary: re-point at bytes this struct owns
+    out.with_io(list(inputs), list(log.outputs))      # the C call borrowed temporaries: re-point at arrays / bytes this struct owns
+    return out.with_program(blob)
 
 
 def verify_segment(proof: np.ndarray, expect: Optional[PublicInputsC] = None):
