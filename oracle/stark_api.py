@@ -103,13 +103,14 @@ def io_bytes(inputs, outputs, halt_kind: int, halt_code: int, cycles: int) -> by
 
 
 def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2, 0), deferred: bool = False, entry: int | None = None, io_mode: bool = False,
-                  writes_before: int = 0, reads_before: int = 0) -> PublicC:
+                  writes_before: int = 0, reads_before: int = 0, mem_mode: bool = False) -> PublicC:
     """Public inputs of a run: halt = (kind, code) with kind 0 Ebreak / 1 Exit / 2 CycleLimit; entry defaults to the blob header's.
-    io_mode = mode 2: the default VM mode with the I/O argument (the proof carries the tapes; WRITE / READ ecalls are tied to them)."""
+    io_mode = mode 2: the default VM mode with the I/O argument (the proof carries the tapes; WRITE / READ ecalls are tied to them).
+    mem_mode = mode 3: mode 2 with the memory argument (loads and stores constrained, every access tied to a consistent memory; the proof carries the touched cells)."""
     if entry is None:
         entry = int.from_bytes(blob[12:16], "little") if len(blob) >= 16 else 0x1000
-    assert not (deferred and io_mode), "the I/O argument is stated for the default VM mode"
-    p = PublicC(n_real, 2 if io_mode else int(deferred), 0, entry)
+    assert not (deferred and (io_mode or mem_mode)), "the I/O and memory arguments are stated for the default VM mode"
+    p = PublicC(n_real, 3 if mem_mode else 2 if io_mode else int(deferred), 0, entry)
     p.set_blob(blob)
     p.set_io(list(inputs), list(outputs), halt, writes_before, reads_before)
     p.prog[:] = [int(x) for x in digest_bytes(blob)]
@@ -188,7 +189,7 @@ def main_trace(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
 
 
 def logical_width(mode=0) -> int:
-    """Logical main-trace columns of a mode (0 default, 1 deferred, 2 default + I/O): 172 / 172 / 180."""
+    """Logical main-trace columns of a mode (0 default, 1 deferred, 2 default + I/O, 3 default + I/O + memory): 172 / 172 / 180 / 220."""
     return lib().so_logical_width(int(mode))
 
 
@@ -268,6 +269,42 @@ def prove_matrix(matrix: np.ndarray, pub: PublicC) -> np.ndarray:
     out = np.zeros(size, np.uint32)
     lib().so_prove_matrix(m.ctypes.data, C.byref(pub), out.ctypes.data, size)
     return out
+
+
+def mem_cells(rows: np.ndarray, pub: PublicC) -> np.ndarray:
+    """(mode 3) the touched memory cells of a run, [n][7] words as the proof carries them: address limbs (20 + 20 bits), time of the last access, final bytes (4 x 16 bits)."""
+    rows = np.ascontiguousarray(rows)
+    L = lib()
+    L.so_mem_cells.restype = C.c_size_t; L.so_mem_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    n = L.so_mem_cells(rows.ctypes.data, C.byref(pub), None, 0)
+    out = np.zeros((max(n, 1), 7), np.uint32)
+    L.so_mem_cells(rows.ctypes.data, C.byref(pub), out.ctypes.data, n)
+    return out[:n]
+
+
+def prove_matrix_mem(matrix: np.ndarray, pub: PublicC, cells: np.ndarray) -> np.ndarray:
+    """(mode 3) proof of a GIVEN main-trace matrix with a GIVEN list of touched cells (tests: a cheating prover)."""
+    m, c = _u32(matrix), _u32(cells).reshape(-1, 7)
+    assert m.shape == (logical_width(3), 1 << padded_log_n(pub.n_real)) and pub.deferred == 3
+    L = lib()
+    L.so_prove_matrix_mem.restype = C.c_size_t; L.so_prove_matrix_mem.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    size = L.so_prove_matrix_mem(m.ctypes.data, C.byref(pub), c.ctypes.data, len(c), None, 0)
+    out = np.zeros(size, np.uint32)
+    L.so_prove_matrix_mem(m.ctypes.data, C.byref(pub), c.ctypes.data, len(c), out.ctypes.data, size)
+    return out
+
+
+def failing_constraints(matrix: np.ndarray, pub: PublicC, cells=None, alpha_l=(3, 1, 4, 1), lam=(2, 7, 1, 8), cap: int = 64):
+    """(tests) the (constraint index, row) pairs a main-trace matrix violates on the trace domain, with the lookup side set up honestly for the given challenges
+    (any mode; mode 3 takes the touched cells).  The running-sum constraints (the last four of the base list) fail on the wrap-around row exactly when the LogUp sums differ."""
+    m = _u32(matrix)
+    c = _u32(cells if cells is not None else np.zeros((0, 7))).reshape(-1, 7)
+    a, l, out = _u32(alpha_l), _u32(lam), np.zeros((cap, 2), np.uint32)
+    L = lib()
+    L.so_failing_constraints.restype = C.c_size_t
+    L.so_failing_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    n = L.so_failing_constraints(m.ctypes.data, C.byref(pub), c.ctypes.data if len(c) else None, len(c), a.ctypes.data, l.ctypes.data, out.ctypes.data, cap)
+    return n, [tuple(int(x) for x in r) for r in out[:min(n, cap)]]
 
 
 def verify(proof: np.ndarray, expect: PublicC | None = None) -> int:

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
 
 namespace so {
 
@@ -195,11 +196,34 @@ static const int W_MAIN = 172;                                     // logical co
 //   175 fh = a hash ecall (R10 = 3..6) | 176-177 h0, h1: R10 - 3 in binary on hash rows | 178 oc = outputs written before this row | 179 ic = inputs consumed before it
 // ECALL is a class of its own there (id 15, no column: Kec = f2 + rl + re + fh); its rows send (oc, R11's limbs) / (ic, the limbs written to R10) into a LogUp relation
 // whose table side the VERIFIER forms from the I/O tapes the proof carries (their digest is the public io digest): syscall.rs:94-177.
-static const int W_MAIN_IO = 180, W_MAX = 180;
+static const int W_MAIN_IO = 180;
 enum { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 177, C_OC = 178, C_IC = 179 };
-static const int K_ECALL = 15;                                     // class id of the ECALL word in mode 2 (the ROM tuple's opclass); modes 0 / 1: "other"
+static const int K_ECALL = 15;                                     // class id of the ECALL word in modes 2 / 3 (the ROM tuple's opclass); modes 0 / 1: "other"
 static const uint32_t OP_ECALL = 0x50;
-static inline int logical_width(int mode) { return mode == 2 ? W_MAIN_IO : W_MAIN; }
+// ---- MODE 3 (round 4): mode 2 WITH the memory argument — the ten loads and stores (execute.rs:477-575, memory.rs:86-505) are classes of their own (ld = 16, st = 17)
+// and every access is tied to a consistent memory by an offline memory check (Blum et al.) over aligned 8-byte CELLS: a load / store row READS the tuple
+// (cell address, last-access time, the cell's 8 bytes) and WRITES (cell address, its own cycle + 1, the new 8 bytes) — new = old on loads, old with the accessed
+// window replaced by the stored bytes on stores — the time read must be smaller than the time written, and over the whole run {initial cells} + {written} =
+// {read} + {final cells} as multisets (LogUp, one relation).  The VERIFIER supplies the two ends: the proof carries the list of touched cells (strictly increasing
+// canonical addresses, final bytes, final time), the initial bytes are the program image's (code at 0x1000, data behind it, vm.rs:153-170) or zero.
+// 40 more logical columns (180 + 40 = 220, 200 committed):
+//   180 kld, 181 kst: the row is a load / a store | 182-196 e_v: one-hot of the accessed WINDOW v = (width, offset in the cell): v 0-7 one byte at offset v, 8-11 two
+//   bytes at 2 (v - 8), 12-13 four bytes at 4 (v - 12), 14 the whole cell | 197-204 ob_0..7: the cell's bytes BEFORE the access | 205 told: the time of the previous access
+//   206-214 the nine PIECES d0 d1 n0 n1 d3 d4 d5 d6 d7 of the 64-bit window value (bytes, byte 2 as two nibbles n0 + 16 n1: the (20, 20, 24)-bit register limbs are
+//   d0 + 2^8 d1 + 2^16 n0 | n1 + 2^4 d3 + 2^12 d4 | d5 + 2^8 d6 + 2^16 d7): the stored register on stores, the loaded window on loads (zero-extended; on byte / halfword
+//   loads d6 = 2 x the low seven bits of the top byte) | 215 sgb, 216 sgh: the row is LB / LH (sign-extending) | 217 tb: the top bit of the loaded byte / halfword
+//   218 sx = (sgb + sgh) tb | 219 cm2: the carry out of the address's third limb (the address itself must stay below 2^40: addr_limbs = 2, config.rs:30)
+static const int W_MAIN_MEM = 220, W_MAX = 220;
+enum { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219 };
+static const int K_LD = 16, K_ST = 17, N_WIN = 15, N_PIECE = 9;
+static inline int win_width(int v) { return v < 8 ? 1 : v < 12 ? 2 : v < 14 ? 4 : 8; }
+static inline int win_start(int v) { return v < 8 ? v : v < 12 ? 2 * (v - 8) : v < 14 ? 4 * (v - 12) : 0; }
+static inline int win_of(int width, int off) { return width == 1 ? off : width == 2 ? 8 + off / 2 : width == 4 ? 12 + off / 4 : 14; }
+static const uint32_t OP_LB = 0x30, OP_LD = 0x35, OP_SB = 0x38, OP_SD = 0x3B;
+static inline bool is_load(uint32_t op) { return op >= OP_LB && op <= OP_LD; }
+static inline bool is_store(uint32_t op) { return op >= OP_SB && op <= OP_SD; }
+static inline int mem_width(uint32_t op) { return is_store(op) ? 1 << (op - OP_SB) : op <= 0x31 ? 1 : op <= 0x33 ? 2 : op == 0x34 ? 4 : 8; }
+static inline int logical_width(int mode) { return mode == 3 ? W_MAIN_MEM : mode == 2 ? W_MAIN_IO : W_MAIN; }
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
        C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
@@ -217,14 +241,14 @@ static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // 152 columns in default mode (172 - 20), 168 in deferred mode (172 - 4), whole blocks of 8.  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
 static const int W_AUX = 40;
-static const int W_AUX_IO = 48, W_AUX_MAX = 48;                    // mode 2: + HO (output helper), HI (input helper)
-static inline int aux_width(int mode) { return mode == 2 ? W_AUX_IO : W_AUX; }
+static const int W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_MAX = 96;    // mode 2: + HO (output helper), HI (input helper); mode 3: + P0..P8 (piece helpers), HMR, HMW (memory read / write helpers), FPN (fingerprint of the new cell bytes)
+static inline int aux_width(int mode) { return mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
 // (AIR v6) the class column "other, jumps" (C_K3 + 1) is identically zero in the default mode too — no opcode's class is oj there (constraint 4) — and is not committed
 static const int C_KOJ = C_K3 + 1;
 // mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
-static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode != 2) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
-static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
+static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 200 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
 // logical [logical_width][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, int mode, std::vector<F>& out) {
   out.assign((size_t)phys_width(mode) * N, 0);
@@ -235,7 +259,11 @@ template <class V>
 static void to_logical_row(const V* phys, int mode, const V& zero, V* logical) {
   for (int c = 0; c < W_MAX; c++) logical[c] = is_virtual(c, mode) ? zero : phys[phys_col(c, mode)];
 }
-enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44 };
+enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92 };
+// (mode 3) the lookup tables beside the 10-bit range table (no tag) and the ROM (tag 1) / tapes (2, 3): LOW3 = {(v, v & 7)}, v < 2^10 (tag 4: the first range chunk of a
+// memory row is looked up HERE, with the window's offset — the address's low three bits), BYTE = {v < 2^8} (tag 5), NIBBLE = {v < 2^4} (tag 6); memory tuples carry tag 7
+static const int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7;
+static const int PIECE_TAG[9] = {TAG_BYTE, TAG_BYTE, TAG_NIB, TAG_NIB, TAG_BYTE, 0, TAG_BYTE, TAG_BYTE, 0};   // d0 d1 n0 n1 d3 d4 d5 d6 d7 (0: the 10-bit range table)
 static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the reference's range-check table: 2^(limb_bits/2) entries (range_check.rs:29, config.rs:78-80)
 static const int N_TUPLE = 11;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass, g (variant bit)
 static inline int state_col(int i) { return i < 4 ? i : C_LIMB + (i - 4); }    // cycle, pc[3], limbs[48], states[16]: columns 0..3 and 9..72
@@ -275,8 +303,24 @@ struct Public {
   uint32_t halt_kind = 2; uint64_t halt_code = 0;
   uint64_t writes_before = 0, reads_before = 0;
   F cnt_first[2] = {0, 0}, cnt_last[2] = {0, 0};
+  // ---- mode 3: the touched memory cells (aligned 8-byte cells, strictly increasing addresses below 2^40): final bytes (little-endian in `bytes`) and the time of the
+  // last access (cycle + 1).  The prover reads them off its memory replay (main_trace) and the proof carries them; the verifier forms both ends of the memory check.
+  struct Cell { uint64_t addr, bytes; uint32_t t; };
+  std::vector<Cell> cells;
   int mode() const { return (int)deferred; }
+  bool has_io() const { return deferred >= 2; }
+  bool has_mem() const { return deferred == 3; }
 };
+// (mode 3) the bytes of cell `addr` (a multiple of 8) in the VM's INITIAL memory: the code words at 0x1000, the data section right behind them (vm.rs:153-170), zero elsewhere
+static uint64_t image_cell(const uint8_t* blob, size_t n, uint64_t addr) {
+  if (!blob || n < 32) return 0;
+  auto le32 = [&](size_t at) { return (uint64_t)blob[at] | ((uint64_t)blob[at + 1] << 8) | ((uint64_t)blob[at + 2] << 16) | ((uint64_t)blob[at + 3] << 24); };
+  const uint64_t code_size = le32(16), data_size = le32(20);
+  if (32 + code_size + data_size > n) return 0;
+  uint64_t v = 0;
+  for (int k = 0; k < 8; k++) { const uint64_t a = addr + k; if (a >= 0x1000 && a - 0x1000 < code_size + data_size) v |= (uint64_t)blob[32 + (a - 0x1000)] << (8 * k); }
+  return v;
+}
 static const int N_STATE = 68;
 static int padded_log_n(uint64_t n_real) { int k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
 
@@ -289,7 +333,9 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
 }
 
 static inline F opclass_of(uint32_t op, int mode = 0) {
-  if (op == OP_ECALL && mode == 2) return K_ECALL;
+  if (op == OP_ECALL && mode >= 2) return K_ECALL;
+  if (mode == 3 && is_load(op)) return K_LD;
+  if (mode == 3 && is_store(op)) return K_ST;
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
@@ -324,14 +370,15 @@ static inline void reg_limbs(uint64_t v, uint8_t st, F out[3]) {
 }
 
 // col-major out[W_MAIN][N]
-static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out) {
+static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out, std::vector<Public::Cell>* cells_out = nullptr) {
   const int log_n = padded_log_n(n_real);
   const size_t N = (size_t)1 << log_n;
   const int mode = pub.mode();
   out.assign((size_t)logical_width(mode) * N, 0);
   auto col = [&](int k) { return out.data() + (size_t)k * N; };
-  const bool D = mode == 1, IO = mode == 2;
+  const bool D = mode == 1, IO = mode >= 2, MEM = mode == 3;
   uint64_t oc = pub.writes_before, reads = pub.reads_before;          // mode 2: WRITE / READ ecalls executed so far (syscall.rs:110-121)
+  std::map<uint64_t, std::pair<uint64_t, uint32_t>> memory;           // mode 3: the replayed memory, cell address -> (bytes, time of the last access); untouched cells hold the program image
   for (size_t i = 0; i < N; i++) {
     const bool pad = i >= n_real;
     const PackedRow& r = rows[pad ? n_real - 1 : i];
@@ -352,10 +399,12 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     if (cls == K_OTH && !D) cls = (int)opclass_of(op, mode);
     if (cls == K_OTH && D && (opclass_of(op) == K_BRE || opclass_of(op) == K_BRU || opclass_of(op) == K_JAL || opclass_of(op) == K_JALR))
       cls = K_OJ;                                             // deferred mode: no opcode semantics, but "other" is sequential — branches and jumps run as the free-pc class
-    if (cls != K_ECALL) col(kcol(cls))[i] = 1;                // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
+    if (cls == K_LD) col(C_KLD)[i] = 1;                       // (mode 3: loads and stores)
+    else if (cls == K_ST) col(C_KST)[i] = 1;
+    else if (cls != K_ECALL) col(kcol(cls))[i] = 1;           // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
     col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
-    const uint32_t tc = branch ? fa : fc;                   // second operand: rs2 = field c, but B-type words have rs1 in field a (rs2 in field b)
+    const uint32_t tc = (branch || cls == K_ST) ? fa : fc;  // second operand: rs2 = field c, but B-type and S-type words have rs1 in field a (rs2 in field b)
     if (fb) col(C_SELB + fb - 1)[i] = 1;
     if (tc) col(C_SELC + tc - 1)[i] = 1;
     const F* xb = limb[fb]; const F* xc = limb[tc];         // register 0 reads as zero limbs: its columns are constrained to zero
@@ -414,6 +463,47 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; if (q) rd = fa; }   // execute.rs:434-472: rd = rs1 (raw) if the condition holds, nothing changes otherwise
+    bool mem_row = false;
+    F mem_z[2] = {0, 0}, mem_dt = 0;
+    if (cls == K_LD || cls == K_ST) {                         // (mode 3) loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64, which must stay below 2^40
+      mem_row = true;
+      const F* base = cls == K_LD ? xb : xc;                  // loads: rs1 = field b; stores: rs1 = field a (operand c), the stored register rs2 = field b (operand b)
+      const uint64_t v0 = (uint64_t)base[0] + im0; c0 = (F)(v0 >> 20); mem_z[0] = (F)(v0 & 0xFFFFF);
+      const uint64_t v1 = (uint64_t)base[1] + im1 + c0; c1 = (F)(v1 >> 20); mem_z[1] = (F)(v1 & 0xFFFFF);
+      const uint64_t v2 = (uint64_t)base[2] + (uint64_t)s * 0xFFFFFF + c1;
+      col(C_CM2)[i] = (F)(v2 >> 24);                          // (v2 & 0xFFFFFF must be 0: an address of 2^40 or more has no proof in this AIR)
+      const uint64_t ea = (uint64_t)mem_z[0] | ((uint64_t)mem_z[1] << 20);
+      const int width = mem_width(op), off = (int)(ea & 7), v = win_of(width, off - off % width);
+      const uint64_t cell = ea - off, mask = width == 8 ? ~0ull : ((1ull << (8 * width)) - 1);
+      col(C_E + v)[i] = 1;
+      auto it = memory.find(cell);
+      const uint64_t ob = it == memory.end() ? image_cell(pub.blob, pub.blob_len, cell) : it->second.first;
+      const uint32_t told = it == memory.end() ? 0 : it->second.second;
+      for (int k = 0; k < 8; k++) col(C_OB + k)[i] = (F)((ob >> (8 * k)) & 0xFF);
+      col(C_TOLD)[i] = told;
+      mem_dt = (F)(r.cycle - told);                           // time written = cycle + 1 > told
+      uint64_t window, nb = ob;
+      if (cls == K_LD) {
+        window = (ob >> (8 * off)) & mask;
+        uint64_t val = window;
+        const bool sgb = op == 0x30, sgh = op == 0x32;
+        const F tb = width <= 2 ? (F)((window >> (8 * width - 1)) & 1) : 0;
+        if ((sgb || sgh) && tb) val |= ~mask;                 // LB / LH sign-extend to 64 bits (execute.rs:477-511)
+        col(C_SGB)[i] = sgb; col(C_SGH)[i] = sgh; col(C_TB)[i] = tb; col(C_SX)[i] = (sgb || sgh) ? tb : 0;
+        reg_limbs(val, 0, y);
+        rd = fa;
+      } else {
+        window = r.registers[fb];                             // the raw 64-bit register (execute.rs:548-575: value & mask of the width)
+        nb = (ob & ~(mask << (8 * off))) | ((window & mask) << (8 * off));
+        reg_limbs(window & mask, 0, y);                       // (nothing is written: y only satisfies the window equations below)
+      }
+      memory[cell] = std::make_pair(nb, (uint32_t)(r.cycle + 1));
+      // the nine pieces of the window value: the whole stored register on stores, the zero-extended loaded window on loads
+      F pc9[9] = {(F)(window & 0xFF), (F)((window >> 8) & 0xFF), (F)((window >> 16) & 0xF), (F)((window >> 20) & 0xF), (F)((window >> 24) & 0xFF), (F)((window >> 32) & 0xFF),
+                  (F)((window >> 40) & 0xFF), (F)((window >> 48) & 0xFF), (F)((window >> 56) & 0xFF)};
+      if (cls == K_LD && width <= 2) pc9[7] = (F)(2 * ((window >> (8 * (width - 1))) & 0x7F));   // d6 = twice the low seven bits of the top byte: the byte table then says they ARE seven bits
+      for (int k = 0; k < N_PIECE; k++) col(C_PIECE + k)[i] = pc9[k];
+    }
     if (IO) {                                                 // the counters every row shows: what happened BEFORE it
       col(C_OC)[i] = (F)(oc % P); col(C_IC)[i] = (F)((reads < pub.n_in ? reads : pub.n_in) % P);
     }
@@ -441,8 +531,10 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     if (cls == K_OTH) {                                       // (v6) the bits above 40 of what an "other" row writes are range-checked: y2 = R4 + 2^10 R5 + 2^20 R6, R7 = 64 R6 (so R6 < 16: 24 bits)
       rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64 * rc2[2];
     }
+    if (mem_row) { rc2[0] = mem_dt & (RC_TABLE - 1); rc2[1] = (mem_dt >> RC_BITS) & (RC_TABLE - 1); rc2[2] = mem_dt >> (2 * RC_BITS); rc2[3] = 0; }   // (mode 3) cycle - told in three chunks: the time read is smaller than the time written
     for (int k = 0; k < 4; k++) col(C_RC2 + k)[i] = rc2[k];
     if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || cls == K_ECALL || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
+    if (mem_row) { z[0] = mem_z[0]; z[1] = mem_z[1]; }         // (mode 3) the address's two low limbs are the range-checked pair
     col(C_RC)[i] = z[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = z[0] >> RC_BITS; col(C_RC + 2)[i] = z[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = z[1] >> RC_BITS;
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
     if (cls == K_JALR) {                                                                            // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
@@ -458,6 +550,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       col(C_D0)[i] = d0; col(C_D1)[i] = d1; col(C_D2)[i] = d2;
     }
   }
+  if (cells_out) { cells_out->clear(); for (auto& kv : memory) cells_out->push_back(Public::Cell{kv.first, kv.second.first, kv.second.second}); }   // (std::map: increasing addresses)
 }
 // ---------------------------------------------------------------------------------------------
 // Merkle tree over the rows of a column-major matrix (leaf j = hash of column values at position j)
@@ -495,6 +588,12 @@ static inline E io_fingerprint(F idx, const F* limbs, F tag, const LookupParams&
   for (int j = 0; j < 3; j++) fp = eadd(fp, emul_f(lp.lam[1 + j], limbs[j]));
   return fp;
 }
+// (mode 3) fingerprint of a memory tuple (cell address as two 20-bit limbs, time, the cell's eight bytes): a0 + lambda a1 + lambda^2 t + sum_k lambda^(3+k) byte_k + 7 lambda^11
+static inline E mem_bytes_fp(uint64_t bytes, const LookupParams& lp) { E fp = e_from(0); for (int k = 0; k < 8; k++) fp = eadd(fp, emul_f(lp.lam[3 + k], (F)((bytes >> (8 * k)) & 0xFF))); return fp; }
+static inline E mem_fingerprint(F a0, F a1, F t, const E& bytes_fp, const LookupParams& lp) {
+  return eadd(eadd(eadd(emul_f(lp.lam[N_TUPLE], TAG_MEM), e_from(a0)), eadd(emul_f(lp.lam[1], a1), emul_f(lp.lam[2], t))), bytes_fp);
+}
+static inline E tagged(F v, int tag, const LookupParams& lp) { return eadd(e_from(v), emul_f(lp.lam[N_TUPLE], (F)tag)); }   // a one-element tuple of table `tag` (0: the plain range value)
 static inline E fingerprint(const F* tuple, const LookupParams& lp) {        // sum_j lambda^j f_j + lambda^10 (the tag keeps ROM entries apart from range values)
   E fp = lp.lam[N_TUPLE];
   for (int j = 0; j < N_TUPLE; j++) fp = eadd(fp, emul_f(lp.lam[j], tuple[j]));
@@ -506,16 +605,35 @@ static inline void row_tuple(const std::vector<F>& M, size_t N, size_t i, F out[
 }
 // Multiplicities of the two tables over ALL N rows of the matrix (padding rows repeat the last executed row's instruction and have
 // y = 0).  A value that is not in its table is simply not counted — the sums then cannot match and the proof is rejected.
-static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& rom, std::vector<F>& rom_mult, std::vector<F>& rc_mult, size_t* first_bad_row = nullptr) {
+static inline F row_offset(const std::vector<F>& M, size_t N, size_t i) { F off = 0; for (int v = 0; v < N_WIN; v++) off += M[(size_t)(C_E + v) * N + i] * (F)win_start(v); return off; }   // (mode 3) the window's offset in its cell
+static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KLD * N + i] + M[(size_t)C_KST * N + i]; }
+// mem_mult (mode 3): LOW3 (1024) ++ BYTE (256) ++ NIBBLE (16)
+static const int MEM_MULT = RC_TABLE + 256 + 16;
+static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& rom, std::vector<F>& rom_mult, std::vector<F>& rc_mult, size_t* first_bad_row = nullptr, int mode = 0,
+                                  std::vector<F>* mem_mult = nullptr) {
   rom_mult.assign(rom.n, 0); rc_mult.assign(RC_TABLE, 0);
+  const bool MEM = mode == 3 && mem_mult;
+  if (MEM) mem_mult->assign(MEM_MULT, 0);
   if (first_bad_row) *first_bad_row = (size_t)-1;
+  auto bad = [&](size_t i) { if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i; };
   for (size_t i = 0; i < N; i++) {
-    for (int k = 0; k < N_RC; k++) { const F v = M[(size_t)rc_col(k) * N + i]; if (v < (F)RC_TABLE) rc_mult[v]++; else if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i; }
+    for (int k = 0; k < N_RC; k++) {
+      const F v = M[(size_t)rc_col(k) * N + i];
+      if (MEM && k == 0 && row_kmem(M, N, i)) {               // a memory row's first chunk is looked up WITH the window's offset: (v, v & 7)
+        if (v < (F)RC_TABLE && (v & 7) == row_offset(M, N, i)) (*mem_mult)[v]++; else bad(i);
+      } else if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i);
+    }
+    if (MEM) for (int k = 0; k < N_PIECE; k++) {
+      const F v = M[(size_t)(C_PIECE + k) * N + i];
+      if (PIECE_TAG[k] == TAG_BYTE) { if (v < 256) (*mem_mult)[RC_TABLE + v]++; else bad(i); }
+      else if (PIECE_TAG[k] == TAG_NIB) { if (v < 16) (*mem_mult)[RC_TABLE + 256 + v]++; else bad(i); }
+      else { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); }
+    }
     F t[N_TUPLE]; row_tuple(M, N, i, t);
     const uint64_t pc = (uint64_t)t[0] | ((uint64_t)t[1] << 20) | ((uint64_t)t[2] << 40);
     const uint64_t u = (pc - 0x1000) / 4;
     if (t[0] < (1u << 20) && t[1] < (1u << 20) && t[2] < (1u << 24) && pc >= 0x1000 && (pc & 3) == 0 && u < rom.n && !memcmp(rom.row(u), t, sizeof t)) rom_mult[u]++;
-    else if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i;
+    else bad(i);
   }
 }
 // batch inversion in E (Montgomery's trick): one einv + 3 emul per element
@@ -528,15 +646,36 @@ static void batch_einv(std::vector<E>& v) {
   E inv = einv(acc);
   for (size_t i = n; i-- > 0;) { const E t = emul(inv, pre[i]); inv = emul(inv, v[i]); v[i] = t; }
 }
-// T = sum_t m_t / (alpha - t) + sum_u r_u / (alpha - fingerprint(ROM row u)): the table side of the LogUp identity
-static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, const LookupParams& lp) {
-  std::vector<E> d(RC_TABLE + rom.n);
+// T = sum_t m_t / (alpha - t) + sum_u r_u / (alpha - fingerprint(ROM row u)) (+ mode 3: the LOW3, BYTE and NIBBLE tables): the table side of the LogUp identity
+static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, const LookupParams& lp, const F* mem_mult = nullptr) {
+  std::vector<E> d(RC_TABLE + rom.n + (mem_mult ? MEM_MULT : 0));
   for (int t = 0; t < RC_TABLE; t++) d[t] = esub(lp.alpha, e_from((F)t));
   for (size_t u = 0; u < rom.n; u++) d[RC_TABLE + u] = esub(lp.alpha, fingerprint(rom.row(u), lp));
+  if (mem_mult) {
+    E* m = d.data() + RC_TABLE + rom.n;
+    for (int t = 0; t < RC_TABLE; t++) m[t] = esub(lp.alpha, eadd(tagged((F)t, TAG_LOW3, lp), emul_f(lp.lam[1], (F)(t & 7))));
+    for (int t = 0; t < 256; t++) m[RC_TABLE + t] = esub(lp.alpha, tagged((F)t, TAG_BYTE, lp));
+    for (int t = 0; t < 16; t++) m[RC_TABLE + 256 + t] = esub(lp.alpha, tagged((F)t, TAG_NIB, lp));
+  }
   batch_einv(d);
   E T = e_from(0);
   for (int t = 0; t < RC_TABLE; t++) T = eadd(T, emul_f(d[t], rc_mult[t]));
   for (size_t u = 0; u < rom.n; u++) T = eadd(T, emul_f(d[RC_TABLE + u], rom_mult[u]));
+  if (mem_mult) for (int t = 0; t < MEM_MULT; t++) T = eadd(T, emul_f(d[RC_TABLE + rom.n + t], mem_mult[t]));
+  return T;
+}
+// (mode 3) the two ends of the memory check: + 1 / (alpha - fp(cell, time 0, the program image's bytes)) - 1 / (alpha - fp(cell, final time, final bytes)) per touched cell
+static E mem_table_sum(const Public& pub, const LookupParams& lp) {
+  std::vector<E> d(2 * pub.cells.size());
+  for (size_t k = 0; k < pub.cells.size(); k++) {
+    const Public::Cell& c = pub.cells[k];
+    const F a0 = (F)(c.addr & 0xFFFFF), a1 = (F)((c.addr >> 20) & 0xFFFFF);
+    d[2 * k] = esub(lp.alpha, mem_fingerprint(a0, a1, 0, mem_bytes_fp(image_cell(pub.blob, pub.blob_len, c.addr), lp), lp));
+    d[2 * k + 1] = esub(lp.alpha, mem_fingerprint(a0, a1, c.t, mem_bytes_fp(c.bytes, lp), lp));
+  }
+  batch_einv(d);
+  E T = e_from(0);
+  for (size_t k = 0; k < pub.cells.size(); k++) T = eadd(T, esub(d[2 * k], d[2 * k + 1]));
   return T;
 }
 // (mode 2) the tapes' share of the table side: every output index in [oc_first, oc_last) and every input index in [ic_first, ic_last) exactly once —
@@ -551,9 +690,11 @@ static E io_table_sum(const Public& pub, const LookupParams& lp) {
 static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp, std::vector<F>& A, int mode = 0) {
   A.assign((size_t)aux_width(mode) * N, 0);
   const int NH = N_RC + 1;
+  const bool MEM = mode == 3;
   std::vector<E> d((size_t)NH * N);
   for (size_t i = 0; i < N; i++) {
     for (int k = 0; k < N_RC; k++) d[NH * i + k] = esub(lp.alpha, e_from(M[(size_t)rc_col(k) * N + i]));
+    if (MEM && row_kmem(M, N, i)) d[NH * i] = esub(lp.alpha, eadd(tagged(M[(size_t)rc_col(0) * N + i], TAG_LOW3, lp), emul_f(lp.lam[1], row_offset(M, N, i))));   // the LOW3 lookup of a memory row
     F t[N_TUPLE]; row_tuple(M, N, i, t);
     d[NH * i + N_RC] = esub(lp.alpha, fingerprint(t, lp));
   }
@@ -566,8 +707,8 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
       for (int c = 0; c < 4; c++) A[(size_t)((k < N_RC ? A_H + 4 * k : A_HR) + c) * N + i] = h.c[c];
       hs = eadd(hs, h);
     }
-    if (mode == 2) {                                          // the tape helpers: HO = f2 / (alpha - fp(oc, R11)), HI = rl / (alpha - fp(ic, y)); zero on every other row
-      auto at = [&](int c) { return M[(size_t)c * N + i]; };
+    auto at = [&](int c) { return M[(size_t)c * N + i]; };
+    if (mode >= 2) {                                          // the tape helpers: HO = f2 / (alpha - fp(oc, R11)), HI = rl / (alpha - fp(ic, y)); zero on every other row
       if (at(C_F2)) {
         const F v[3] = {at(C_LIMB + 33), at(C_LIMB + 34), at(C_LIMB + 35)};
         const E h = einv(esub(lp.alpha, io_fingerprint(at(C_OC), v, 2, lp)));
@@ -581,6 +722,29 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
         hs = eadd(hs, h);
       }
     }
+    if (MEM) {
+      // the nine piece helpers P_k = 1 / (alpha - piece_k - tag_k lambda^11), on EVERY row (the pieces of a row that is no memory row are zero)
+      for (int k = 0; k < N_PIECE; k++) {
+        const E h = einv(esub(lp.alpha, tagged(at(C_PIECE + k), PIECE_TAG[k], lp)));
+        for (int c = 0; c < 4; c++) A[(size_t)(A_P + 4 * k + c) * N + i] = h.c[c];
+        hs = eadd(hs, h);
+      }
+      // FPN = sum_k lambda^(3+k) (new byte k): the old bytes with the window replaced by the window value's bytes D_j (D_2 = n0 + 16 n1); on EVERY row
+      F ob[8], D[8] = {at(C_PIECE), at(C_PIECE + 1), fadd(at(C_PIECE + 2), fmul(16, at(C_PIECE + 3))), at(C_PIECE + 4), at(C_PIECE + 5), at(C_PIECE + 6), at(C_PIECE + 7), at(C_PIECE + 8)};
+      E obfp = e_from(0);
+      for (int k = 0; k < 8; k++) { ob[k] = at(C_OB + k); obfp = eadd(obfp, emul_f(lp.lam[3 + k], ob[k])); }
+      E fpn = obfp;
+      for (int v = 0; v < N_WIN; v++) if (at(C_E + v)) for (int j = 0; j < win_width(v); j++) fpn = eadd(fpn, emul_f(emul_f(lp.lam[3 + win_start(v) + j], fsub(D[j], ob[win_start(v) + j])), at(C_E + v)));
+      for (int c = 0; c < 4; c++) A[(size_t)(A_FPN + c) * N + i] = fpn.c[c];
+      if (row_kmem(M, N, i)) {                                // HMR = 1 / (alpha - fp(cell, told, old bytes)) is looked up, HMW = 1 / (alpha - fp(cell, cycle + 1, new bytes)) is provided
+        const F z0 = fadd(at(C_RC), fmul(RC_TABLE, at(C_RC + 1))), z1 = fadd(at(C_RC + 2), fmul(RC_TABLE, at(C_RC + 3)));
+        const F a0 = fsub(z0, row_offset(M, N, i));
+        const E hr = einv(esub(lp.alpha, mem_fingerprint(a0, z1, at(C_TOLD), obfp, lp)));
+        const E hw = einv(esub(lp.alpha, mem_fingerprint(a0, z1, fadd(at(C_CYCLE), 1), fpn, lp)));
+        for (int c = 0; c < 4; c++) { A[(size_t)(A_HMR + c) * N + i] = hr.c[c]; A[(size_t)(A_HMW + c) * N + i] = hw.c[c]; }
+        hs = eadd(hs, esub(hr, hw));
+      }
+    }
     for (int c = 0; c < 4; c++) A[(size_t)(A_S + c) * N + i] = S.c[c];       // S_i = sum over rows j < i of (hsum_j - T / N); S_0 = 0
     S = eadd(S, esub(hs, lp.t_over_n));
   }
@@ -589,7 +753,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
-static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 448;
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 576;
 static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns); v9: AIR v5 (eight range lookups, 40 aux columns, the variant bit in the ROM tuple); v10: AIR v6 (172 logical columns, 152 / 168 committed)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
@@ -629,9 +793,10 @@ struct Challenger {
 // ---- the AIR: Σ_c alpha^c C_c over one (local, next) row pair; values as E (base-field rows are lifted) ----
 // is_first = Z_H(x)/(x - 1), is_last = Z_H(x)/(x - w^(n_real-1)) (the last EXECUTED row), is_trans = x - w^-1.
 // Every constraint has degree <= 2 in the columns (x is_trans) or degree 1 (x is_first / is_last): the quotient has degree < N.
+static std::vector<E>* g_air_record = nullptr;   // tests: every constraint value of the NEXT constraints_sum call, in list order
 struct AirAcc {
   const E* ap; E acc; int c;
-  void push(const E& v) { acc = eadd(acc, emul(ap[c], v)); c++; }
+  void push(const E& v) { acc = eadd(acc, emul(ap[c], v)); c++; if (g_air_record) g_air_record->push_back(v); }
 };
 // aloc / anxt: the aux columns (local / next row), lp: the lookup challenges and T / N.
 static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* anxt, const E& is_first, const E& is_last, const E& is_trans, const Public& pub,
@@ -659,11 +824,12 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]); boolean(loc[C_SB]); boolean(loc[C_NZ]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
-  const bool IO = pub.mode() == 2;
+  const bool IO = pub.mode() >= 2, MEM = pub.mode() == 3;
   const E Kec = IO ? eadd(eadd(loc[C_F2], loc[C_RL]), eadd(loc[C_RE], loc[C_FH])) : e_from(0);   // (mode 2) the ecall class: the sum of its four syscall flags
-  { E sum = Kec; for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  const E Kld = MEM ? loc[C_KLD] : e_from(0), Kst = MEM ? loc[C_KST] : e_from(0), Kmem = eadd(Kld, Kst);   // (mode 3) loads, stores
+  { E sum = eadd(Kec, Kmem); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
-    E ks = emul_f(Kec, (F)K_ECALL);
+    E ks = eadd(emul_f(Kec, (F)K_ECALL), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST)));
     for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
@@ -681,7 +847,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   push(emul(eadd(eadd(eadd(eadd(K[K_ADD], K[K_ADDI]), eadd(K[K_JAL], K[K_SUB])), Kcmp), K[K_JALR]), esub(w1, fa)));
   push(emul(eadd(eadd(eadd(Kbr, emul(nD, K[K_OJ])), K[K_HALT]), K[K_PAD]), w0));   // branches write nothing (BLT / BGE too: class oj in default mode)
   push(esub(b1, fb)); push(esub(emul(b1, b1), b2));
-  push(esub(c1s, eadd(fc, emul(Kbr, esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));
+  push(esub(c1s, eadd(fc, emul(eadd(Kbr, Kst), esub(fa, fc))))); push(esub(emul(c1s, c1s), c2s));   // (S-type words: rs1 in field a like B-type ones)
   //    (v6) conditional moves CMOV / CMOVNZ (class cmn: the condition is rs2 != 0) and CMOVZ (class cmz: rs2 == 0), execute.rs:434-472:
   //    q = "this row is a conditional move whose condition holds"; it writes rd = field a exactly then (nothing at all otherwise)
   const E Kcm = eadd(K[K_CMN], K[K_CMZ]), nz = loc[C_NZ], q = loc[C_Q];
@@ -819,6 +985,11 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     E d[4], pr[4];
     for (int k = 0; k < 4; k++) d[k] = cst(lp.alpha.c[k]);
     d[0] = esub(d[0], loc[rc_col(i)]);
+    if (MEM && i == 0) {                                                   // (mode 3) a memory row's first chunk goes to the LOW3 table with the window's offset: alpha - R0 - lambda off - 4 lambda^11 Kmem
+      E off = e_from(0);
+      for (int v = 0; v < N_WIN; v++) off = eadd(off, emul_f(loc[C_E + v], (F)win_start(v)));
+      for (int k = 0; k < 4; k++) d[k] = esub(esub(d[k], emul_f(off, lp.lam[1].c[k])), emul_f(Kmem, fmul(TAG_LOW3, lp.lam[N_TUPLE].c[k])));
+    }
     ext_mul(aloc + A_H + 4 * i, d, pr);
     push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
   }
@@ -840,6 +1011,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     E hs = aloc[A_HR + k];
     for (int i = 0; i < N_RC; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
     if (IO) hs = eadd(hs, eadd(aloc[A_HO + k], aloc[A_HI + k]));
+    if (MEM) { for (int i = 0; i < N_PIECE; i++) hs = eadd(hs, aloc[A_P + 4 * i + k]); hs = eadd(hs, esub(aloc[A_HMR + k], aloc[A_HMW + k])); }   // pieces and the read are looked up, the write is PROVIDED (a table entry)
     push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
   }
   // ---- 17. (mode 2, round 4) ECALL rows and the I/O tapes (syscall.rs:94-177).  Appended to the list: modes 0 / 1 stop here. ----
@@ -881,6 +1053,87 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     push(emul(esub(oc, cst(pub.cnt_first[0])), is_first)); push(emul(esub(ic, cst(pub.cnt_first[1])), is_first));
     push(emul(esub(oc, cst(pub.cnt_last[0])), is_last)); push(emul(esub(ic, cst(pub.cnt_last[1])), is_last));
   }
+  // ---- 18. (mode 3, round 4) loads, stores and the memory check (execute.rs:477-575, memory.rs:86-505).  Appended to the list: mode 2 stops above. ----
+  if (MEM) {
+    const E* Ev = loc + C_E; const E* ob = loc + C_OB; const E* pcs = loc + C_PIECE;
+    const E sgb = loc[C_SGB], sgh = loc[C_SGH], tb = loc[C_TB], sx = loc[C_SX], cm2 = loc[C_CM2];
+    boolean(Kld); boolean(Kst);
+    for (int v = 0; v < N_WIN; v++) boolean(Ev[v]);
+    boolean(sgb); boolean(sgh); boolean(tb); boolean(cm2);
+    E Esum = e_from(0), WB = e_from(0), WH = e_from(0), WW = e_from(0), off = e_from(0);
+    for (int v = 0; v < N_WIN; v++) {
+      Esum = eadd(Esum, Ev[v]); off = eadd(off, emul_f(Ev[v], (F)win_start(v)));
+      if (win_width(v) == 1) WB = eadd(WB, Ev[v]); else if (win_width(v) == 2) WH = eadd(WH, Ev[v]); else if (win_width(v) == 4) WW = eadd(WW, Ev[v]);
+    }
+    const E WD = Ev[14];
+    push(esub(Esum, Kmem));                                                                         // exactly one window on a memory row, none elsewhere
+    push(loc[C_FH]);                                                                                // no hash syscall in this mode: its memory effect is not stated
+    // the opcode names the width (and, for byte / halfword loads, whether the value is sign-extended): LB LBU LH LHU LW LD = 0x30.., SB SH SW SD = 0x38..
+    push(emul(Kld, eadd(esub(esub(esub(esub(esub(op, cst(0x30)), emul_f(WH, 2)), emul_f(WW, 4)), emul_f(WD, 5)), eadd(WB, WH)), eadd(sgb, sgh))));
+    push(emul(Kst, esub(esub(esub(esub(op, cst(0x38)), WH), emul_f(WW, 2)), emul_f(WD, 3))));
+    push(emul(sgb, esub(esub(cst(2), Kld), WB))); push(emul(sgh, esub(esub(cst(2), Kld), WH)));       // sgb only on byte loads, sgh only on halfword loads
+    // what they write: a load rd = field a, a store nothing
+    push(emul(Kld, esub(w1, fa))); push(emul(Kst, w0));
+    // the address rs1 + sext(imm17) mod 2^64 (rs1 = operand b on loads, operand c on stores) = z (two range-checked 20-bit limbs) — its third limb must be zero
+    for (int l = 0; l < 2; l++) {
+      const E cin = l ? c0 : e_from(0), cout = l ? c1 : c0, im = l ? im1 : im0;
+      push(eadd(emul(Kld, eadd(esub(esub(esub(z[l], xb[l]), im), cin), emul(two20, cout))), emul(Kst, eadd(esub(esub(esub(z[l], xc[l]), im), cin), emul(two20, cout)))));
+    }
+    push(eadd(emul(Kld, esub(eadd(eadd(xb[2], emul_f(s, 0xFFFFFF)), c1), emul(two24, cm2))), emul(Kst, esub(eadd(eadd(xc[2], emul_f(s, 0xFFFFFF)), c1), emul(two24, cm2)))));
+    // the time read is smaller than the time written (cycle + 1): cycle - told = R4 + 2^10 R5 + 2^20 R6, three chunks of the second range-checked group
+    const E* R2 = loc + C_RC2;
+    push(emul(Kmem, esub(esub(esub(esub(loc[C_CYCLE], loc[C_TOLD]), R2[0]), emul_f(R2[1], RC_TABLE)), emul_f(R2[2], RC_TABLE * RC_TABLE))));
+    // stores: the pieces are the stored register's (rs2 = operand b), limb by limb — byte and nibble lookups make the decomposition unique
+    const E lim0 = eadd(eadd(pcs[0], emul_f(pcs[1], 1u << 8)), emul_f(pcs[2], 1u << 16)), lim1 = eadd(eadd(pcs[3], emul_f(pcs[4], 1u << 4)), emul_f(pcs[5], 1u << 12)),
+            lim2 = eadd(eadd(pcs[6], emul_f(pcs[7], 1u << 8)), emul_f(pcs[8], 1u << 16));
+    push(emul(Kst, esub(xb[0], lim0))); push(emul(Kst, esub(xb[1], lim1))); push(emul(Kst, esub(xb[2], lim2)));
+    // y = the window value's limbs, zero-extended from the width, sign-extended when sx (on stores nothing is written: y merely satisfies this)
+    const E W48 = eadd(WW, WD);
+    push(esub(emul(Kmem, y[0]), eadd(eadd(eadd(emul(WB, pcs[0]), emul(WH, eadd(pcs[0], emul_f(pcs[1], 1u << 8)))), emul(W48, lim0)),
+                                     emul(sx, esub(esub(two20, emul_f(WB, 1u << 8)), emul_f(WH, 1u << 16))))));
+    push(esub(emul(Kmem, y[1]), eadd(eadd(emul(WW, eadd(pcs[3], emul_f(pcs[4], 1u << 4))), emul(WD, lim1)), emul_f(sx, 0xFFFFF))));
+    push(esub(emul(Kmem, y[2]), eadd(emul(WD, lim2), emul_f(sx, 0xFFFFFF))));
+    // sign extension: sx = (sgb + sgh) tb; on LB rows d0 = 128 tb + d6 / 2, on LH rows d1 = 128 tb + d6 / 2 — d6 is in the byte table, so d6 / 2 has seven bits
+    push(esub(sx, emul(eadd(sgb, sgh), tb)));
+    const E half = cst(finv(2));
+    push(emul(sgb, esub(esub(pcs[0], emul_f(tb, 128)), emul(pcs[7], half))));
+    push(emul(sgh, esub(esub(pcs[1], emul_f(tb, 128)), emul(pcs[7], half))));
+    // the cell's new bytes, as their fingerprint FPN (an aux column: it depends on lambda): the old bytes with the window replaced by the window value's bytes D_j; a load keeps the cell
+    const E D[8] = {pcs[0], pcs[1], eadd(pcs[2], emul_f(pcs[3], 16)), pcs[4], pcs[5], pcs[6], pcs[7], pcs[8]};
+    for (int k = 0; k < 4; k++) {
+      E obfp = e_from(0), fpn;
+      for (int j = 0; j < 8; j++) obfp = eadd(obfp, emul_f(ob[j], lp.lam[3 + j].c[k]));
+      fpn = obfp;
+      for (int v = 0; v < N_WIN; v++) {
+        E dl = e_from(0);
+        for (int j = 0; j < win_width(v); j++) dl = eadd(dl, emul_f(esub(D[j], ob[win_start(v) + j]), lp.lam[3 + win_start(v) + j].c[k]));
+        fpn = eadd(fpn, emul(Ev[v], dl));
+      }
+      push(esub(aloc[A_FPN + k], fpn));
+    }
+    for (int k = 0; k < 4; k++) { E obfp = e_from(0); for (int j = 0; j < 8; j++) obfp = eadd(obfp, emul_f(ob[j], lp.lam[3 + j].c[k])); push(emul(Kld, esub(aloc[A_FPN + k], obfp))); }
+    // the memory check: HMR (alpha - fp(cell, told, old bytes)) = Kmem, HMW (alpha - fp(cell, cycle + 1, new bytes)) = Kmem; cell = (z0 - off, z1)
+    for (int rw = 0; rw < 2; rw++) {
+      E d[4], pr[4];
+      for (int k = 0; k < 4; k++) {
+        E fp = eadd(cst(fmul(TAG_MEM, lp.lam[N_TUPLE].c[k])), emul_f(esub(z[0], off), lp.lam[0].c[k]));
+        fp = eadd(fp, emul_f(z[1], lp.lam[1].c[k]));
+        if (rw == 0) { fp = eadd(fp, emul_f(loc[C_TOLD], lp.lam[2].c[k])); for (int j = 0; j < 8; j++) fp = eadd(fp, emul_f(ob[j], lp.lam[3 + j].c[k])); }
+        else { fp = eadd(fp, emul_f(eadd(loc[C_CYCLE], one), lp.lam[2].c[k])); fp = eadd(fp, aloc[A_FPN + k]); }
+        d[k] = esub(cst(lp.alpha.c[k]), fp);
+      }
+      ext_mul(aloc + (rw ? A_HMW : A_HMR), d, pr);
+      push(esub(pr[0], Kmem)); push(pr[1]); push(pr[2]); push(pr[3]);
+    }
+    // the nine piece lookups: P_k (alpha - piece_k - tag_k lambda^11) = 1
+    for (int i = 0; i < N_PIECE; i++) {
+      E d[4], pr[4];
+      for (int k = 0; k < 4; k++) d[k] = cst(fsub(lp.alpha.c[k], fmul(PIECE_TAG[i], lp.lam[N_TUPLE].c[k])));
+      d[0] = esub(d[0], pcs[i]);
+      ext_mul(aloc + A_P + 4 * i, d, pr);
+      push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
+    }
+  }
   result = A.acc;
   return A.c;
 }
@@ -915,9 +1168,16 @@ static void header_words(int log_n, const Public& pub, std::vector<uint32_t>& w)
   for (int i = 0; i < 4; i++) w.push_back(pub.io[i]);
   for (int i = 0; i < N_STATE; i++) w.push_back(pub.first[i]);
   for (int i = 0; i < N_STATE; i++) w.push_back(pub.last[i]);
-  if (pub.mode() == 2) { w.push_back(pub.cnt_first[0]); w.push_back(pub.cnt_first[1]); w.push_back(pub.cnt_last[0]); w.push_back(pub.cnt_last[1]); }   // (oc, ic) of the first / last row
+  if (pub.mode() >= 2) { w.push_back(pub.cnt_first[0]); w.push_back(pub.cnt_first[1]); w.push_back(pub.cnt_last[0]); w.push_back(pub.cnt_last[1]); }   // (oc, ic) of the first / last row
 }
-static inline int header_words_of(int mode) { return HEADER_WORDS + (mode == 2 ? 4 : 0); }
+static inline int header_words_of(int mode) { return HEADER_WORDS + (mode >= 2 ? 4 : 0); }
+// (mode 3) the memory section of a proof, after the I/O section: [n_cells] then per touched cell [address limb 0 (20 bits, a multiple of 8)] [address limb 1 (20 bits)]
+// [time of the last access] [the final bytes: four 16-bit pieces], by strictly increasing address
+static void put_u64(std::vector<uint32_t>& w, uint64_t v);
+static void mem_section(const Public& pub, std::vector<uint32_t>& w) {
+  w.push_back((uint32_t)pub.cells.size());
+  for (const Public::Cell& c : pub.cells) { w.push_back((uint32_t)(c.addr & 0xFFFFF)); w.push_back((uint32_t)((c.addr >> 20) & 0xFFFFF)); w.push_back(c.t); put_u64(w, c.bytes); }
+}
 // (mode 2) the I/O section of a proof, after the program: [n_in] [inputs: four 16-bit pieces each] [n_out] [outputs] [halt kind] [halt code: four pieces]
 static void put_u64(std::vector<uint32_t>& w, uint64_t v) { for (int i = 0; i < 4; i++) w.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); }
 static void io_section(const Public& pub, std::vector<uint32_t>& w) {
@@ -934,7 +1194,7 @@ static void initial_state(uint64_t entry, F st[N_STATE]) {
 struct ProverTrace {     // everything the oracle keeps for inspection by tests
   std::vector<F> M, Mp, L, Qc;        // logical [W_MAIN][N], committed [Wm][N], its LDE [Wm][2N], [4][2N]
   std::vector<F> A, AL;               // aux trace [W_AUX][N] and its LDE [W_AUX][2N]
-  std::vector<F> rom_mult, rc_mult;
+  std::vector<F> rom_mult, rc_mult, mem_mult;
   LookupParams lp;
   Merkle trace_tree, aux_tree, quot_tree;
   std::vector<std::vector<E>> fri;    // codewords per layer (layer 0 = DEEP codeword, size 2N)
@@ -950,14 +1210,14 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   const int Dm = pub.mode();                                              // 0 default, 1 deferred, 2 default + the I/O argument
   const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
   if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wl * N);         // LOGICAL; whatever it holds in uncommitted columns is dropped
-  else main_trace(rows, pub.n_real, pub, pt.M);
+  else main_trace(rows, pub.n_real, pub, pt.M, &pub.cells);                                   // (mode 3: with the touched cells; an override brings its own in pub_in.cells)
   for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(pt.M.begin() + (size_t)c * N, pt.M.begin() + (size_t)(c + 1) * N, 0);
   to_physical(pt.M, N, Dm, pt.Mp);
   for (int i = 0; i < N_STATE; i++) {                                     // boundary states: rows 0 and n_real - 1 of the matrix being proven
     pub.first[i] = pt.M[(size_t)state_col(i) * N];
     pub.last[i] = pt.M[(size_t)state_col(i) * N + (pub.n_real - 1)];
   }
-  if (Dm == 2) for (int k = 0; k < 2; k++) { pub.cnt_first[k] = pt.M[(size_t)(C_OC + k) * N]; pub.cnt_last[k] = pt.M[(size_t)(C_OC + k) * N + (pub.n_real - 1)]; }
+  if (Dm >= 2) for (int k = 0; k < 2; k++) { pub.cnt_first[k] = pt.M[(size_t)(C_OC + k) * N]; pub.cnt_last[k] = pt.M[(size_t)(C_OC + k) * N + (pub.n_real - 1)]; }
   pt.L.assign((size_t)Wm * N2, 0);
   std::vector<std::vector<F>> coeffs(Wm);
   for (int k = 0; k < Wm; k++) {
@@ -975,12 +1235,14 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   const Rom rom = rom_from_blob(pub.blob, pub.blob_len, Dm);
   w.push_back((uint32_t)pub.blob_len);
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
-  if (Dm == 2) io_section(pub, w);                                         // the tapes and the halt reason: what the io digest is a digest of
-  lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult);
+  if (Dm >= 2) io_section(pub, w);                                         // the tapes and the halt reason: what the io digest is a digest of
+  if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); ch.observe_n(w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
+  lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult, nullptr, Dm, &pt.mem_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
   w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
   ch.observe_n(pt.rom_mult.data(), pt.rom_mult.size());
   ch.observe_n(pt.rc_mult.data(), pt.rc_mult.size());
+  if (Dm == 3) { w.insert(w.end(), pt.mem_mult.begin(), pt.mem_mult.end()); ch.observe_n(pt.mem_mult.data(), pt.mem_mult.size()); }
   pt.lp.alpha = ch.sample_ext();
   {
     const E lambda = ch.sample_ext();
@@ -989,8 +1251,9 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   }
   pt.lp.n_in = (F)(pub.n_in % P);
   {
-    E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp);
-    if (Dm == 2) T = eadd(T, io_table_sum(pub, pt.lp));
+    E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp, Dm == 3 ? pt.mem_mult.data() : nullptr);
+    if (Dm >= 2) T = eadd(T, io_table_sum(pub, pt.lp));
+    if (Dm == 3) T = eadd(T, mem_table_sum(pub, pt.lp));
     pt.lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   // ---- aux trace: helper columns + running sum; its own LDE and commitment ----
@@ -1168,7 +1431,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5];
   if (nq != NUM_QUERIES || log_final != LOG_FINAL || w[6] != (uint32_t)POW_BITS || log_n < LOG_FINAL || log_n > 26) return 2;
   Public pub;
-  if (w[9] > 2 || Wm != phys_width((int)w[9])) return 2;                 // the committed width is the mode's (0 default, 1 deferred, 2 default + I/O)
+  if (w[9] > 3 || Wm != phys_width((int)w[9])) return 2;                 // the committed width is the mode's (0 default, 1 deferred, 2 default + I/O)
   const int mode = (int)w[9];
   const int HW = header_words_of(mode), Wa = aux_width(mode);
   if (!need(HW)) return 1;
@@ -1179,7 +1442,8 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   memcpy(pub.first, w + 21, N_STATE * 4); memcpy(pub.last, w + 21 + N_STATE, N_STATE * 4);
   for (int i = 0; i < 2 * N_STATE; i++) if (w[21 + i] >= P) return 3;
   if (pub.n_real == 0 || padded_log_n(pub.n_real) != log_n) return 2;
-  if (mode == 2) { for (int k = 0; k < 4; k++) if (w[HEADER_WORDS + k] >= P) return 3; memcpy(pub.cnt_first, w + HEADER_WORDS, 8); memcpy(pub.cnt_last, w + HEADER_WORDS + 2, 8); }
+  if (mode == 3 && !whole_run) return 2;                                  // the memory check spans the whole run: a mode-3 proof is never a segment
+  if (mode >= 2) { for (int k = 0; k < 4; k++) if (w[HEADER_WORDS + k] >= P) return 3; memcpy(pub.cnt_first, w + HEADER_WORDS, 8); memcpy(pub.cnt_last, w + HEADER_WORDS + 2, 8); }
   if (counters_out) { memcpy(counters_out, pub.cnt_first, 8); memcpy(counters_out + 2, pub.cnt_last, 8); }
   if (expect && (expect->n_real != pub.n_real || expect->deferred != pub.deferred || expect->entry != pub.entry ||
                  memcmp(expect->prog, pub.prog, 16) || memcmp(expect->io, pub.io, 16))) return 6;
@@ -1205,7 +1469,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   // (mode 2) the tapes and the halt reason the io digest is a digest of (check 50: with the cycle count — a whole run's is its row count; a chain checks the
   // digest over the total), the counters' ends (51), and the halt row named by the halt reason (52 / 53)
   IoSection io;
-  if (mode == 2) {
+  if (mode >= 2) {
     if (!parse_io_section(w + p, len - p, io)) return 4;
     p += io.words;
     pub.inputs = io.in.data(); pub.n_in = io.in.size(); pub.outputs = io.out.data(); pub.n_out = io.out.size(); pub.halt_kind = io.halt_kind; pub.halt_code = io.halt_code;
@@ -1221,9 +1485,30 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
       if (hb) return hb;
     }
   }
-  if (!need(rom.n + RC_TABLE)) return 4;
+  // (mode 3) the touched cells: canonical (20-bit limbs, a multiple of 8), strictly increasing — every cell has ONE initial tuple (check 54)
+  const uint32_t* mem_words = nullptr; size_t mem_len = 0;
+  if (mode == 3) {
+    if (!need(1)) return 4;
+    const size_t nc = w[p];
+    if (nc > ((size_t)1 << 28) || !need(1 + 7 * nc)) return 4;
+    mem_words = w + p; mem_len = 1 + 7 * nc;
+    pub.blob = blob.data(); pub.blob_len = blob_len;
+    pub.cells.resize(nc);
+    for (size_t k = 0; k < nc; k++) {
+      const uint32_t* c = w + p + 1 + 7 * k;
+      if (c[0] >= (1u << 20) || (c[0] & 7) || c[1] >= (1u << 20)) return 54;
+      uint64_t bytes = 0;
+      for (int i = 0; i < 4; i++) { if (c[3 + i] > 0xFFFF) return 54; bytes |= (uint64_t)c[3 + i] << (16 * i); }
+      pub.cells[k] = Public::Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), bytes, c[2]};
+      if (k && pub.cells[k].addr <= pub.cells[k - 1].addr) return 54;
+    }
+    p += mem_len;
+  }
+  if (!need(rom.n + RC_TABLE + (mode == 3 ? MEM_MULT : 0))) return 4;
   const F* rom_mult = w + p; p += rom.n;
   const F* rc_mult = w + p; p += RC_TABLE;
+  const F* mem_mult = nullptr;
+  if (mode == 3) { mem_mult = w + p; p += MEM_MULT; }
   if (!need(12)) return 4;
   const F* troot = w + p; p += 4; const F* aroot = w + p; p += 4; const F* qroot = w + p; p += 4;
   auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
@@ -1247,8 +1532,10 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   Challenger ch;
   ch.observe_n(w + 2, HW - 2);
   ch.observe_n(troot, 4);
+  if (mode == 3) ch.observe_n(mem_words, mem_len);
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
+  if (mode == 3) ch.observe_n(mem_mult, MEM_MULT);
   LookupParams lp;
   lp.alpha = ch.sample_ext();
   {
@@ -1258,8 +1545,9 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   }
   lp.n_in = (F)(pub.n_in % P);
   {
-    E T = lookup_table_sum(rom, rom_mult, rc_mult, lp);                    // the table side of the lookup identity, computed HERE
-    if (mode == 2) T = eadd(T, io_table_sum(pub, lp));                     // .. its I/O share from the tapes the proof carries
+    E T = lookup_table_sum(rom, rom_mult, rc_mult, lp, mem_mult);           // the table side of the lookup identity, computed HERE
+    if (mode >= 2) T = eadd(T, io_table_sum(pub, lp));                     // .. its I/O share from the tapes the proof carries
+    if (mode == 3) T = eadd(T, mem_table_sum(pub, lp));                    // .. and both ends of the memory check from the touched cells it carries
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   ch.observe_n(aroot, 4);
@@ -1655,6 +1943,72 @@ size_t so_prove_matrix(const uint32_t* matrix, const so_public* pub, uint32_t* o
   so::Proof pr; so::prove(nullptr, to_pub(pub), pr, g_pt, matrix);
   if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
   return pr.w.size();
+}
+// (mode 3) the touched cells of a run, 7 words per cell as in the proof's memory section (address limbs, final time, final bytes as four 16-bit pieces); returns the cell count
+size_t so_mem_cells(const void* packed_rows, const so_public* pub, uint32_t* out, size_t cap_cells) {
+  std::vector<so::F> m; std::vector<so::Public::Cell> cells;
+  so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m, &cells);
+  if (out && cells.size() <= cap_cells) for (size_t k = 0; k < cells.size(); k++) {
+    uint32_t* c = out + 7 * k;
+    c[0] = (uint32_t)(cells[k].addr & 0xFFFFF); c[1] = (uint32_t)((cells[k].addr >> 20) & 0xFFFFF); c[2] = cells[k].t;
+    for (int i = 0; i < 4; i++) c[3 + i] = (uint32_t)((cells[k].bytes >> (16 * i)) & 0xFFFF);
+  }
+  return cells.size();
+}
+// (mode 3) proof of a GIVEN matrix with a GIVEN list of touched cells (tests: a cheating prover)
+size_t so_prove_matrix_mem(const uint32_t* matrix, const so_public* pub, const uint32_t* cells7, size_t n_cells, uint32_t* out, size_t cap) {
+  so::Public q = to_pub(pub);
+  for (size_t k = 0; k < n_cells; k++) {
+    const uint32_t* c = cells7 + 7 * k; uint64_t b = 0;
+    for (int i = 0; i < 4; i++) b |= (uint64_t)c[3 + i] << (16 * i);
+    q.cells.push_back(so::Public::Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), b, c[2]});
+  }
+  so::Proof pr; so::prove(nullptr, q, pr, g_pt, matrix);
+  if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
+  return pr.w.size();
+}
+// (tests) which constraints does a main-trace matrix violate ON THE TRACE DOMAIN?  The lookup side is set up honestly for the given challenges (multiplicities, T, aux
+// trace; mode 3: with the given cells); out receives up to cap (constraint index, row) pairs; returns the number of violations.  Boundary states = the matrix's own.
+size_t so_failing_constraints(const uint32_t* matrix, const so_public* pub, const uint32_t* cells7, size_t n_cells, const uint32_t* alpha4, const uint32_t* lambda4, uint32_t* out, size_t cap) {
+  so::Public q = to_pub(pub);
+  const int mode = q.mode(), Wl = so::logical_width(mode), Wa = so::aux_width(mode);
+  const size_t N = (size_t)1 << so::padded_log_n(q.n_real);
+  for (size_t k = 0; k < n_cells; k++) {
+    const uint32_t* c = cells7 + 7 * k; uint64_t b = 0;
+    for (int i = 0; i < 4; i++) b |= (uint64_t)c[3 + i] << (16 * i);
+    q.cells.push_back(so::Public::Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), b, c[2]});
+  }
+  std::vector<so::F> M(matrix, matrix + (size_t)Wl * N), rm, cm, mm, A;
+  for (int c = 0; c < Wl; c++) if (so::is_virtual(c, mode)) std::fill(M.begin() + (size_t)c * N, M.begin() + (size_t)(c + 1) * N, 0);
+  for (int i = 0; i < so::N_STATE; i++) { q.first[i] = M[(size_t)so::state_col(i) * N]; q.last[i] = M[(size_t)so::state_col(i) * N + (q.n_real - 1)]; }
+  if (mode >= 2) for (int k = 0; k < 2; k++) { q.cnt_first[k] = M[(size_t)(so::C_OC + k) * N]; q.cnt_last[k] = M[(size_t)(so::C_OC + k) * N + (q.n_real - 1)]; }
+  const so::Rom rom = so::rom_from_blob(q.blob, q.blob_len, mode);
+  so::lookup_multiplicities(M, N, rom, rm, cm, nullptr, mode, &mm);
+  so::LookupParams lp;
+  memcpy(lp.alpha.c, alpha4, 16);
+  so::E lambda; memcpy(lambda.c, lambda4, 16);
+  lp.lam[0] = so::e_from(1);
+  for (int j = 1; j <= so::N_TUPLE; j++) lp.lam[j] = so::emul(lp.lam[j - 1], lambda);
+  lp.n_in = (so::F)(q.n_in % so::P);
+  so::E T = so::lookup_table_sum(rom, rm.data(), cm.data(), lp, mode == 3 ? mm.data() : nullptr);
+  if (mode >= 2) T = so::eadd(T, so::io_table_sum(q, lp));
+  if (mode == 3) T = so::eadd(T, so::mem_table_sum(q, lp));
+  lp.t_over_n = so::emul_f(T, so::finv((so::F)(N % so::P)));
+  so::aux_trace(M, N, lp, A, mode);
+  const int NC = so::num_constraints(mode);
+  std::vector<so::E> ap(NC, so::e_from(0)), loc(so::W_MAX), nxt(so::W_MAX), al(so::W_AUX_MAX), ax(so::W_AUX_MAX), rec;
+  size_t bad = 0;
+  for (size_t i = 0; i < N; i++) {
+    const size_t j = (i + 1) % N;
+    for (int k = 0; k < so::W_MAX; k++) { loc[k] = so::e_from(k < Wl ? M[(size_t)k * N + i] : 0); nxt[k] = so::e_from(k < Wl ? M[(size_t)k * N + j] : 0); }
+    for (int k = 0; k < so::W_AUX_MAX; k++) { al[k] = so::e_from(k < Wa ? A[(size_t)k * N + i] : 0); ax[k] = so::e_from(k < Wa ? A[(size_t)k * N + j] : 0); }
+    rec.clear(); so::g_air_record = &rec;
+    so::E r;
+    so::constraints_sum(loc.data(), nxt.data(), al.data(), ax.data(), so::e_from(i == 0), so::e_from(i == q.n_real - 1), so::e_from(i + 1 < N), q, lp, ap.data(), r);
+    so::g_air_record = nullptr;
+    for (int c = 0; c < (int)rec.size(); c++) if (!so::eeq(rec[c], so::e_from(0))) { if (out && bad < cap) { out[2 * bad] = (uint32_t)c; out[2 * bad + 1] = (uint32_t)i; } bad++; }
+  }
+  return bad;
 }
 int so_verify(const uint32_t* proof, size_t len, const so_public* expect) {
   if (!expect) return so::verify(proof, len, nullptr);

@@ -269,7 +269,7 @@ _I_OPS = [O.ADDI, O.ANDI, O.ORI, O.XORI]
 _GP = [1, 2, 3, 4, 7, 8, 9, 14, 15]       # r5 = memory base, r6 = non-zero divisor, r10-r13 = syscall scratch
 
 
-def random_program(seed: int, n_instr: int = 300, range_checking: bool = False):
+def random_program(seed: int, n_instr: int = 300, range_checking: bool = False, hashes: bool = True):
     rng = np.random.default_rng(seed)
     ri = lambda lo, hi: int(rng.integers(lo, hi))  # noqa: E731
     reg = lambda: _GP[ri(0, len(_GP))]              # noqa: E731
@@ -304,7 +304,7 @@ def random_program(seed: int, n_instr: int = 300, range_checking: bool = False):
             body += [spec.jal(7, 4), E(O.JALR, reg() if rng.random() < 0.5 else 0, 7, imm=4 * ri(1, 5) + ri(0, 2))]
         elif k < 0.97:
             body += [A(11, src(), 0), A(10, 0, 2), EC] if rng.random() < 0.5 else [A(10, 0, 1), EC, A(reg(), 10, 0)]
-        else:
+        elif hashes:
             num = [3, 5, 6][ri(0, 3)]
             body += [A(11, 5, ri(0, 512)), A(12, 0, ri(0, 200)), A(13, 5, 1024 + 4 * ri(0, 128)), A(10, 0, num), EC, A(reg(), 14, 0)]
     code += body + [EB] * 6

@@ -1,0 +1,114 @@
+"""ZKIR-STARK MODE 3 (round 4): the default VM mode with the I/O argument AND the memory argument — the ten loads and stores (execute.rs:477-575) are constrained and every
+access is tied to a consistent memory by an offline memory check over aligned 8-byte cells.  CPU tests of the ORACLE (prover + verifier); the product's
+verifier and main-trace code are compared with it in tests/test_abi.py, the GPU prover in tests/test_gpu_stark.py.  PARITY UNPINNED (the reference has no prover)."""
+import numpy as np
+import pytest
+
+import programs as pg
+from oracle import api as oracle, stark_api as so
+from zkir_amd import spec
+
+A = pg.A
+C_CYCLE, C_LIMB, C_Y, C_RC2, C_OB, C_TOLD, C_PIECE = 0, 9, 124, 163, 197, 205, 206
+I_SUM = 394                                            # the four running-sum constraints of the base list: they fail on the wrap-around row exactly when the LogUp sums differ
+
+
+def _case(blob, ins=(), **cfg):
+    ores = oracle.run(blob, list(ins), enable_execution_trace=True, **cfg)
+    pub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), mem_mode=True)
+    return ores, pub
+
+
+def test_widths():
+    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (220, 200, 96, 524)
+    assert (so.logical_width(2), so.committed_width(2), so.aux_width(2), so.lib().so_num_constraints_for(2)) == (180, 160, 48, 430)      # mode 2 untouched
+
+
+@pytest.mark.parametrize("name", ["mem_sw_lw", "timestamps", "loads_stores", "alu_all", "q9_access_at_own_pc", "echo5", "fib30", "rc_doubling", "jumps_and_links"])
+def test_honest_runs_are_accepted(name):
+    """Every width (LB LBU LH LHU LW LD / SB SH SW SD), sign extension, loads of untouched cells and of the program image; no constraint is violated on any row."""
+    blob, ins, cfg = getattr(pg, name)()
+    ores, pub = _case(blob, ins, **{k: v for k, v in cfg.items() if k == "max_cycles"})
+    proof = so.prove(ores.rows, pub)
+    assert proof[9] == 3 and proof[3] == 200
+    assert so.verify(proof, pub) == 0
+    assert so.failing_constraints(so.main_trace(ores.rows, pub), pub, so.mem_cells(ores.rows, pub))[0] == 0
+    assert so.verify_segment(proof, pub)[0] == 2                                  # the memory check spans the whole run: never a segment
+
+
+@pytest.mark.parametrize("seed", [1, 3, 4, 5, 6, 8])
+def test_random_programs_are_accepted(seed):
+    blob, ins = pg.random_program(seed, hashes=False)
+    ores, pub = _case(blob, ins)
+    assert sum(1 for w in ores.rows["instruction"] if 0x30 <= (int(w) & 0x7F) <= 0x3B) > 10
+    assert so.verify(so.prove(ores.rows, pub), pub) == 0
+
+
+@pytest.mark.parametrize("name", ["self_modifying", "sha256_hello"])
+def test_runs_outside_the_air_have_no_proof(name):
+    """A store into the code segment changes what is fetched (the ROM is the program's), a hash syscall writes memory the AIR does not state: rejected."""
+    blob, ins, cfg = getattr(pg, name)()
+    ores, pub = _case(blob, ins)
+    assert so.verify(so.prove(ores.rows, pub), pub) == 10
+
+
+def _two_stores_one_load():
+    code = [A(3, 0, 0x4000), A(1, 0, 0x1111), A(2, 0, 0x2222), spec.sw(3, 1, 0), spec.sw(3, 2, 0), spec.lw(4, 3, 0), A(7, 0, 1), pg.EB]
+    blob = pg._p(code)
+    ores, pub = _case(blob)
+    return ores, pub, so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+
+
+def test_a_stale_read_breaks_only_the_memory_check():
+    """SW 0x1111, SW 0x2222, LW: a prover lets the load return the FIRST store's value (old bytes, old time, pieces, y and the register afterwards all consistent).  Every
+    local constraint holds — what fails is the closing of the running sum: the multiset {initial} + {written} != {read} + {final}."""
+    ores, pub, M, cells = _two_stores_one_load()
+    assert [int(x) for x in cells[0]] == [0x4000, 0, 6, 0x2222, 0, 0, 0]
+    assert np.array_equal(so.prove_matrix_mem(M, pub, cells), so.prove(ores.rows, pub))
+    F, i = M.copy(), 5
+    F[C_OB, i] = F[C_OB + 1, i] = 0x11
+    F[C_TOLD, i] = M[C_TOLD, 4]
+    F[C_PIECE, i] = F[C_PIECE + 1, i] = 0x11
+    F[C_Y, i] = 0x1111
+    F[C_LIMB + 3 * 4, i + 1:] = 0x1111
+    dt = int(F[C_CYCLE, i]) - int(F[C_TOLD, i])
+    F[C_RC2, i], F[C_RC2 + 1, i], F[C_RC2 + 2, i] = dt & 1023, (dt >> 10) & 1023, dt >> 20
+    n, bad = so.failing_constraints(F, pub, cells)
+    assert n == 4 and [c for c, _ in bad] == [I_SUM, I_SUM + 1, I_SUM + 2, I_SUM + 3]
+    assert so.verify(so.prove_matrix_mem(F, pub, cells), None) == 10
+    c2 = cells.copy(); c2[0, 3] = 0x1111                                           # .. and no choice of final cell repairs it
+    assert so.verify(so.prove_matrix_mem(F, pub, c2), None) == 10
+    c3 = cells.copy(); c3[0, 2] = 5
+    assert so.verify(so.prove_matrix_mem(F, pub, c3), None) == 10
+
+
+def test_forged_cells_and_values_are_rejected():
+    ores, pub, M, cells = _two_stores_one_load()
+    c = cells.copy(); c[0, 3] ^= 1
+    assert so.verify(so.prove_matrix_mem(M, pub, c), None) == 10                   # forged final bytes
+    assert so.verify(so.prove_matrix_mem(M, pub, cells[:0]), None) == 10           # a touched cell left out
+    assert so.verify(so.prove_matrix_mem(M, pub, np.concatenate([cells, cells])), None) == 54      # a cell listed twice (two initial tuples)
+    c = cells.copy(); c[0, 0] += 4
+    assert so.verify(so.prove_matrix_mem(M, pub, c), None) == 54                   # not a cell address
+    G = M.copy(); G[C_Y, 5] = 0x2223; G[C_LIMB + 12, 6:] = 0x2223                  # the load writes something else than the cell holds
+    assert so.failing_constraints(G, pub, cells)[0] == 1
+    assert so.verify(so.prove_matrix_mem(G, pub, cells), None) == 10
+    proof = so.prove(ores.rows, pub)
+    at = int(np.nonzero(proof == 0x2222)[0][0])                                    # the final bytes in the proof's memory section: bound by the transcript
+    t = proof.copy(); t[at] = 0x2223
+    assert so.verify(t, None) != 0
+
+
+def test_a_write_in_the_future_cannot_be_read():
+    """The time read must be SMALLER than the time written: a load that claims to read what a later store writes violates the range check on cycle - told."""
+    code = [A(3, 0, 0x4000), A(1, 0, 0x77), spec.lw(4, 3, 0), spec.sw(3, 1, 0), A(7, 0, 1), pg.EB]
+    ores, pub = _case(pg._p(code))
+    M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    F = M.copy()
+    # the load (row 2) reads the tuple the store (row 3, time 4) writes; the store reads the initial tuple
+    F[C_OB, 2] = 0x77; F[C_TOLD, 2] = 4; F[C_PIECE, 2] = 0x77; F[C_Y, 2] = 0x77; F[C_LIMB + 12, 3:] = 0x77
+    F[C_OB, 3] = 0; F[C_TOLD, 3] = 0
+    dt = (int(F[C_CYCLE, 2]) - 4) % so.P
+    F[C_RC2, 2], F[C_RC2 + 1, 2], F[C_RC2 + 2, 2] = dt & 1023, (dt >> 10) & 1023, dt >> 20      # not three 10-bit chunks any more
+    c = cells.copy(); c[0, 2] = 3
+    assert so.verify(so.prove_matrix_mem(F, pub, c), None) == 10
