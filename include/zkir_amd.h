@@ -294,6 +294,12 @@ typedef struct zkir_io_args { const uint64_t* inputs; uint64_t n_inputs; uint64_
 int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* scratch, uint32_t* out, void* hip_stream);
 /* the same on the HOST (host pointers everywhere; no scratch): a test entry point like zkir_main_trace_host */
 int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out);
+/* The main trace of MODE 3 (mode 2 + the memory argument: 200 committed columns): load / store rows also show the accessed window, the cell's bytes before the access, the
+ * time of its previous access and the pieces of the value moved.  mem_old / mem_told: [n_real] DEVICE arrays (zkir_memcheck_witness_of computes them on the host: memory is a
+ * sequential chain); scratch as zkir_main_trace_io_launch.  _host: host pointers everywhere, a test entry point. */
+int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
+                               void* hip_stream);
+int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out);
 /* the same rows computed on the HOST (trace = host pointers, out = host buffer, same B8 layout): the kernel's per-row code is one host + device
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */
@@ -355,7 +361,27 @@ typedef struct zkir_public_inputs {
   uint32_t reserved2;
   uint64_t halt_code;
   uint64_t writes_before, reads_before;
+  /* MODE 3 (`deferred` == 3, round 4): mode 2 WITH the memory argument — loads and stores are constrained and every access is tied to a consistent memory (air.h "MODE 3").
+   * PROVER side (BORROWED, set by zkir_public_inputs_set_memory from a zkir_memcheck_witness; ignored in a verifier's `expect`): per ROW the bytes of the accessed 8-byte cell
+   * before the access and the time of the cell's previous access (0 on rows that are no load / store), and the touched cells by increasing address — the proof carries those. */
+  const uint64_t* mem_old;     /* [n_real] */
+  const uint32_t* mem_told;    /* [n_real] */
+  const uint64_t* cell_addr;   /* [n_cells] multiples of 8 below 2^40, strictly increasing */
+  const uint64_t* cell_bytes;  /* [n_cells] the cell's final bytes, little-endian */
+  const uint32_t* cell_time;   /* [n_cells] the time of its last access = that row's cycle + 1 */
+  uint64_t n_cells;
 } zkir_public_inputs;
+/* (mode 3) The memory witness of a WHOLE run (host, sequential like the interpreter: memory is a chain — what a load returns depends on every earlier store): the
+ * log's rows are replayed with their register state (rebuilt from the register events), every load / store looks up its aligned 8-byte cell — the program image at first
+ * (code at 0x1000, data behind it: vm.rs:153-170), zero elsewhere — and records the cell's bytes and the time of its previous access.  Refused (ZKIR_ERR_ARGUMENT): a shard /
+ * window, an address of 2^40 or more (addr_limbs = 2, config.rs:30), an executed hash syscall (its memory effect is not stated by the AIR).  Free with zkir_memcheck_witness_free. */
+typedef struct zkir_memcheck_witness zkir_memcheck_witness;
+int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* program_blob, size_t blob_len, zkir_memcheck_witness** out);
+void zkir_memcheck_witness_free(zkir_memcheck_witness* w);
+uint64_t zkir_memcheck_witness_n_cells(const zkir_memcheck_witness* w);
+uint64_t zkir_memcheck_witness_n_accesses(const zkir_memcheck_witness* w);
+/* points pub's mode-3 fields at the witness (which must outlive the proving call) and sets pub->deferred = 3 */
+void zkir_public_inputs_set_memory(zkir_public_inputs* pub, const zkir_memcheck_witness* w);
 /* Poseidon2 sponge digest of a byte string (host): [len as four 16-bit pieces] ++ [LE 16-bit halfwords] */
 void zkir_digest_bytes(const uint8_t* bytes, size_t len, uint32_t out[4]);
 /* the public inputs of a finished run (host; `log`: the run's delta log, a shard of it, or the trace window that reached the run's

@@ -1887,17 +1887,17 @@ int so_constraints_eval_states(const uint32_t* loc, const uint32_t* nxt, const u
   memcpy(out4, r.c, 16);
   return NC;
 }
-// the same in MODE 2: 180 logical columns, 48 aux columns, lk = the 56 words + n_in, cnt4 = (oc, ic) of the first row, (oc, ic) of the last row
+// the same in MODE 2 / 3 (pub->deferred; anything else reads as 2): 180 / 220 logical columns, 48 / 96 aux columns, lk = the 56 words + n_in, cnt4 = (oc, ic) of the first row, of the last row
 int so_constraints_eval_io(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk57, uint32_t is_first, uint32_t is_last,
                            uint32_t is_trans, const so_public* pub, const uint32_t* first68, const uint32_t* last68, const uint32_t* cnt4, const uint32_t* alpha4, uint32_t* out4) {
-  const int NC = so::num_constraints(2);
+  so::Public q = to_pub(pub);
+  if (q.deferred != 3) q.deferred = 2;
+  const int mode = q.mode(), NC = so::num_constraints(mode), Wl = so::logical_width(mode), Wa = so::aux_width(mode);
   so::E a; memcpy(a.c, alpha4, 16);
   std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
-  std::vector<so::E> l(so::W_MAX), x(so::W_MAX), al(so::W_AUX_MAX), ax(so::W_AUX_MAX);
-  for (int k = 0; k < so::W_MAX; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
-  for (int k = 0; k < so::W_AUX_MAX; k++) { al[k] = so::e_from(aloc[k]); ax[k] = so::e_from(anxt[k]); }
-  so::Public q = to_pub(pub);
-  q.deferred = 2;
+  std::vector<so::E> l(so::W_MAX, so::e_from(0)), x(so::W_MAX, so::e_from(0)), al(so::W_AUX_MAX, so::e_from(0)), ax(so::W_AUX_MAX, so::e_from(0));
+  for (int k = 0; k < Wl; k++) { l[k] = so::e_from(loc[k]); x[k] = so::e_from(nxt[k]); }
+  for (int k = 0; k < Wa; k++) { al[k] = so::e_from(aloc[k]); ax[k] = so::e_from(anxt[k]); }
   memcpy(q.first, first68, sizeof q.first); memcpy(q.last, last68, sizeof q.last);
   memcpy(q.cnt_first, cnt4, 8); memcpy(q.cnt_last, cnt4 + 2, 8);
   so::LookupParams lp = lk_unpack(lk57);

@@ -243,3 +243,120 @@ def test_main_trace_mode2_row_code_matches_oracle_on_the_host(which):
     want = so.to_committed(so.main_trace(rows, pub), 2)
     for k in range(wm):
         assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"
+
+
+# ---- MODE 3 (round 4): mode 2 + the memory argument — the product's host-side pieces against the oracle (no GPU) ------------------------------------------------
+def test_air_bounds_mode3():
+    """The quotient kernel's lazy arithmetic is sound on the mode-3 constraint list too (air::BoundOps on air::eval)."""
+    import ctypes as C
+    L = rt.lib()
+    why = C.create_string_buffer(256)
+    L.zkir_air_check_bounds.restype = C.c_int
+    L.zkir_air_check_bounds.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    assert L.zkir_air_check_bounds(3, why, 256) == 0, why.value.decode()
+
+
+def test_quotient_evaluation_matches_oracle_constraints_mode3():
+    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 3: 220 logical / 96 aux columns, 524 constraints."""
+    import ctypes as C
+    import numpy as np
+    from oracle import stark_api as so
+    L = rt.lib()
+    L.zkir_air_eval_host.restype = None
+    L.zkir_air_eval_host.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_void_p]
+    LO = so.lib()
+    LO.so_constraints_eval_io.restype = C.c_int
+    LO.so_constraints_eval_io.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 6
+    P = so.P
+    rng = np.random.default_rng(2028)
+    virt = [9, 10, 11] + list(range(57, 73)) + [161]
+    blob = spec.fib_program(5).to_bytes()
+    pub = so.public_inputs(64, blob, [], [5], (1, 0), mem_mode=True)
+    assert LO.so_num_constraints_for(3) == 524
+    for trial in range(40):
+        big = trial >= 36
+        def words(n):
+            return np.full(n, P - 1, np.uint32) if big else rng.integers(0, P, n).astype(np.uint32)
+        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(220), words(220), words(96), words(96), words(57), words(68), words(68), words(4), words(4), words(3)
+        loc[virt] = 0; nxt[virt] = 0
+        want, got = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+        LO.so_constraints_eval_io(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]), C.byref(pub),
+                                  first.ctypes.data, last.ctypes.data, cnt.ctypes.data, alpha.ctypes.data, want.ctypes.data)
+        L.zkir_air_eval_host(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]),
+                             first.ctypes.data, last.ctypes.data, alpha.ctypes.data, 3, cnt.ctypes.data, got.ctypes.data)
+        assert np.array_equal(got, want), (trial, got, want)
+
+
+def _mode3_programs():
+    import programs as pg
+    out = {name: getattr(pg, name)() for name in ("mem_sw_lw", "timestamps", "loads_stores", "alu_all", "q9_access_at_own_pc", "echo5")}
+    for seed in (1, 3, 5):
+        blob, ins = pg.random_program(seed, hashes=False)
+        out[f"random{seed}"] = (blob, ins, {})
+    return out
+
+
+@pytest.mark.parametrize("name", ["mem_sw_lw", "timestamps", "loads_stores", "alu_all", "q9_access_at_own_pc", "echo5", "random1", "random3", "random5"])
+def test_memcheck_witness_and_main_trace_mode3_match_oracle_on_the_host(name):
+    """zkir_memcheck_witness_of (the host's sequential memory replay over the delta log) yields the oracle's touched cells, and zkir_main_trace_mem_host (stark.hip:
+    main_trace_row<3>) the oracle's mode-3 main trace: every committed column of every row — all ten loads / stores, sign extension, the program image, Q9's access at its own pc."""
+    import ctypes as C
+    import numpy as np
+    from oracle import api as oracle, stark_api as so
+    blob, ins, cfg = _mode3_programs()[name]
+    cfg = {k: v for k, v in cfg.items() if k == "max_cycles"}
+    res = oracle.run(blob, list(ins), enable_execution_trace=True, **cfg)
+    rows, nr = res.rows, len(res.rows)
+    log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True, **cfg))
+    assert log.n_rows == nr
+    pub = rt.public_inputs(log, blob, list(ins), mem_mode=True)
+    opub = so.public_inputs(nr, blob, list(ins), list(res.outputs), (res.halt_kind, res.halt_code), mem_mode=True)
+    assert pub.deferred == 3 and list(pub.io_digest) == list(opub.io)
+    want_cells = so.mem_cells(rows, opub)
+    assert pub.n_cells == len(want_cells)
+    if pub.n_cells:
+        ca = np.ctypeslib.as_array(C.cast(pub.cell_addr, C.POINTER(C.c_uint64)), (pub.n_cells,))
+        cb = np.ctypeslib.as_array(C.cast(pub.cell_bytes, C.POINTER(C.c_uint64)), (pub.n_cells,))
+        ct = np.ctypeslib.as_array(C.cast(pub.cell_time, C.POINTER(C.c_uint32)), (pub.n_cells,))
+    for k in range(pub.n_cells):
+        w = [int(x) for x in want_cells[k]]
+        assert (int(ca[k]) & 0xFFFFF, int(ca[k]) >> 20, int(ct[k]), [(int(cb[k]) >> (16 * i)) & 0xFFFF for i in range(4)]) == (w[0], w[1], w[2], w[3:])
+    cyc, pc, ins_c = (np.ascontiguousarray(rows[f]) for f in ("cycle", "pc", "instruction"))
+    regs, bb_, bt, bp, st = (np.ascontiguousarray(rows[f].T) for f in ("registers", "bound_bits", "bound_tag", "bound_payload", "reg_state"))
+    tc = rt.TraceColumnsC(cyc.ctypes.data, pc.ctypes.data, ins_c.ctypes.data, regs.ctypes.data, bb_.ctypes.data, bt.ctypes.data, bp.ctypes.data, st.ctypes.data, nr)
+    N = 1 << so.padded_log_n(nr)
+    wm = so.committed_width(3)
+    assert wm == 200
+    out = np.zeros((wm // 8, N, 8), np.uint32)
+    tape = np.asarray(list(ins) if len(ins) else [0], dtype=np.uint64)
+
+    class IoArgs(C.Structure):
+        _fields_ = [("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+    io = IoArgs(tape.ctypes.data, len(ins), 0, 0)
+    L = rt.lib()
+    L.zkir_main_trace_mem_host.restype = C.c_int
+    L.zkir_main_trace_mem_host.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.zkir_main_trace_mem_host(C.byref(tc), nr, C.byref(io), pub.mem_old, pub.mem_told, out.ctypes.data) == 0
+    got = out.transpose(0, 2, 1).reshape(wm, N)
+    want = so.to_committed(so.main_trace(rows, opub), 3)
+    for k in range(wm):
+        assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"
+
+
+def test_memcheck_witness_refuses_runs_outside_the_air():
+    import programs as pg
+    blob, ins, _ = pg.sha256_hello()
+    log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True))
+    with pytest.raises(Exception, match="hash syscall"):
+        rt.public_inputs(log, blob, list(ins), mem_mode=True)
+    O, E = spec.Opcode, spec.encode                                      # LB sign-extends 0x80 to 64 bits (Q1): the next load's address is 0xFFFF_FFFF_FFFF_FF80
+    blob = pg._p([pg.A(5, 0, 0x4000), pg.A(1, 0, 0x80), E(O.SB, rs1=5, rs2=1, imm=0), E(O.LB, 1, 5, imm=0), spec.lw(2, 1, 0), pg.EB])
+    log = rt.interpret(blob, [], rt.VMConfig(enable_execution_trace=True))
+    with pytest.raises(Exception, match="2\\^40"):
+        rt.public_inputs(log, blob, [], mem_mode=True)
+    blob, ins, _ = pg.fib30()
+    log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True))
+    shard = log.shard(10, 20) if hasattr(log, "shard") else None
+    if shard is not None:
+        with pytest.raises(Exception, match="whole run"):
+            rt.MemcheckWitness(shard, blob)

@@ -112,3 +112,50 @@ def test_a_write_in_the_future_cannot_be_read():
     F[C_RC2, 2], F[C_RC2 + 1, 2], F[C_RC2 + 2, 2] = dt & 1023, (dt >> 10) & 1023, dt >> 20      # not three 10-bit chunks any more
     c = cells.copy(); c[0, 2] = 3
     assert so.verify(so.prove_matrix_mem(F, pub, c), None) == 10
+
+
+# ---- the product's verifier (zkir_verify, verify.cpp + air.h) on the oracle's mode-3 proofs: same verdict and same failing check ------------------------------------
+def _pub_c(p):
+    from zkir_amd import runtime as rt
+    out = rt.PublicInputsC(p.n_real, p.entry, p.deferred, 0)
+    out.program_digest[:] = list(p.prog); out.io_digest[:] = list(p.io)
+    return out
+
+
+@pytest.mark.parametrize("name", ["timestamps", "loads_stores", "echo5", "random3"])
+def test_product_verifier_agrees_with_the_oracle(name):
+    from zkir_amd import runtime as rt
+    if name.startswith("random"):
+        blob, ins = pg.random_program(int(name[6:]), hashes=False); cfg = {}
+    else:
+        blob, ins, cfg = getattr(pg, name)()
+    ores, pub = _case(blob, ins)
+    pr = so.prove(ores.rows, pub)
+    assert so.verify(pr, pub) == 0
+    assert rt.verify(pr) == 0 and rt.verify(pr, _pub_c(pub)) == 0
+    assert rt.verify_segment(pr)[0] == 2
+    rng = np.random.default_rng(len(pr))
+    hw = 157 + 4
+    blob_words = (len(blob) + 1) // 2
+    for pos in list(range(2, 21)) + [hw - 1, hw + 3] + [int(x) for x in rng.integers(hw + 1 + blob_words, len(pr), 80)] + [len(pr) - 1]:
+        t = pr.copy()
+        t[pos] = (int(t[pos]) + 1 + int(rng.integers(0, 50))) % so.P
+        if t[pos] != pr[pos]:
+            want = so.verify(t)
+            assert want != 0 and rt.verify(t) == want, (pos, want, rt.verify(t))
+    assert rt.verify(pr[:-1]) == so.verify(pr[:-1]) != 0
+
+
+def test_product_verifier_rejects_what_the_oracle_rejects():
+    """Cheating provers' mode-3 proofs (made by the oracle prover from forged matrices / cells): the product's verifier gives the oracle's verdict."""
+    from zkir_amd import runtime as rt
+    ores, pub, M, cells = _two_stores_one_load()
+    F, i = M.copy(), 5
+    F[C_OB, i] = F[C_OB + 1, i] = 0x11; F[C_TOLD, i] = M[C_TOLD, 4]; F[C_PIECE, i] = F[C_PIECE + 1, i] = 0x11; F[C_Y, i] = 0x1111; F[C_LIMB + 12, i + 1:] = 0x1111
+    dt = int(F[C_CYCLE, i]) - int(F[C_TOLD, i])
+    F[C_RC2, i], F[C_RC2 + 1, i], F[C_RC2 + 2, i] = dt & 1023, (dt >> 10) & 1023, dt >> 20
+    for proof, want in [(so.prove_matrix_mem(F, pub, cells), 10), (so.prove_matrix_mem(M, pub, cells[:0]), 10), (so.prove_matrix_mem(M, pub, np.concatenate([cells, cells])), 54)]:
+        assert so.verify(proof, None) == want and rt.verify(proof) == want
+    c = cells.copy(); c[0, 3] ^= 1
+    proof = so.prove_matrix_mem(M, pub, c)
+    assert so.verify(proof, None) == rt.verify(proof) == 10

@@ -51,14 +51,36 @@
 
 namespace air {
 
-constexpr int W = 180;                                         // logical columns of MODE 2; modes 0 / 1 use the first 172 (W_LOGICAL_BASE)
-constexpr int W_LOGICAL_BASE = 172;
+constexpr int W = 220;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
+constexpr int W_LOGICAL_BASE = 172, W_LOGICAL_IO = 180;
 // MODES (the header's word 9, zkir_public_inputs::deferred): 0 = default VM mode, 1 = deferred carry model, 2 (round 4) = default mode WITH the I/O argument:
 // ECALL is a class of its own there (id K_ECALL, no column: Kec = f2 + rl + re + fh), dispatched on R10's limbs — f2 = WRITE (R10 = 2), rl / re = READ (R10 = 1) on a
 // non-empty / exhausted input tape, fh = a hash syscall (R10 = 3 + h0 + 2 h1) — oc / ic count the outputs written / inputs consumed before the row; WRITE rows send
 // (oc, R11's limbs), live READ rows (ic, the limbs written to R10) into a LogUp relation whose table side the VERIFIER forms from the tapes the proof carries
 // (syscall.rs:94-177).  A bool passed where a mode is expected reads as 0 / 1.
 enum : int { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 177, C_OC = 178, C_IC = 179 };
+// MODE 3 (round 4) = mode 2 WITH the memory argument (oracle/stark_oracle.cpp "MODE 3"): the ten loads and stores (execute.rs:477-575) are classes of their
+// own (ld = 16, st = 17, columns kld / kst) and every access is one step of an offline memory check over aligned 8-byte CELLS — the row READS the tuple (cell address, time of
+// the previous access, the cell's eight bytes) and WRITES (cell address, its own cycle + 1, the new bytes), the time read is smaller than the time written, and the VERIFIER
+// closes the multiset equation with the initial bytes (the program image, zero elsewhere) and the final (bytes, time) of every touched cell, which the proof carries.
+//   e_v: one-hot of the accessed WINDOW v = (width, offset): 0-7 a byte at offset v, 8-11 a halfword at 2 (v - 8), 12-13 a word at 4 (v - 12), 14 the cell
+//   ob_0..7 the cell's bytes before the access, told the time of the previous access (0: never)
+//   pieces d0 d1 n0 n1 d3 d4 d5 d6 d7 of the 64-bit window value (byte 2 = n0 + 16 n1): register limbs d0 + 2^8 d1 + 2^16 n0 | n1 + 2^4 d3 + 2^12 d4 | d5 + 2^8 d6 + 2^16 d7;
+//   the stored register on stores, the loaded window (zero-extended) on loads, where a byte / halfword load also keeps d6 = 2 x (the low seven bits of its top byte)
+//   sgb / sgh: the row is LB / LH; tb: the top bit of what it loads; sx = (sgb + sgh) tb; cm2: the carry out of the address's third limb (the address stays below 2^40)
+enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219 };
+constexpr int K_LD = 16, K_ST = 17, N_WIN = 15, N_PIECE = 9;
+BB_HD constexpr int win_width(int v) { return v < 8 ? 1 : v < 12 ? 2 : v < 14 ? 4 : 8; }
+BB_HD constexpr int win_start(int v) { return v < 8 ? v : v < 12 ? 2 * (v - 8) : v < 14 ? 4 * (v - 12) : 0; }
+BB_HD constexpr int win_of(int width, int off) { return width == 1 ? off : width == 2 ? 8 + off / 2 : width == 4 ? 12 + off / 4 : 14; }
+constexpr uint32_t OP_LB = 0x30, OP_LH = 0x32, OP_LD = 0x35, OP_SB = 0x38, OP_SD = 0x3B;
+BB_HD constexpr bool is_load(uint32_t op) { return op >= OP_LB && op <= OP_LD; }
+BB_HD constexpr bool is_store(uint32_t op) { return op >= OP_SB && op <= OP_SD; }
+BB_HD constexpr int mem_width(uint32_t op) { return is_store(op) ? 1 << (op - OP_SB) : op <= 0x31 ? 1 : op <= 0x33 ? 2 : op == 0x34 ? 4 : 8; }
+// (mode 3) lookup tables beside the 10-bit range table (no tag), the ROM (tag 1) and the tapes (2, 3): LOW3 = {(v, v & 7) : v < 2^10} (tag 4: the FIRST range chunk of a memory
+// row is looked up there, with the window's offset = the address's low three bits), BYTE = {v < 2^8} (5), NIBBLE = {v < 2^4} (6); memory tuples carry tag 7
+constexpr int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, MEM_MULT = 1024 + 256 + 16;
+BB_HD constexpr int piece_tag(int k) { return (k == 2 || k == 3) ? TAG_NIB : (k == 5 || k == 8) ? 0 : TAG_BYTE; }   // d0 d1 n0 n1 d3 d4 d5 d6 d7 (0: the 10-bit range table)
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
              C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
@@ -68,15 +90,15 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
 // 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 200, W_COMMITTED_MAX = 200;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
-BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode != 2) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 BB_HD constexpr int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
-BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : W_COMMITTED_DEFAULT; }
-BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20)
-BB_HD constexpr int logical_width(int mode) { return mode == 2 ? W : W_LOGICAL_BASE; }
+BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : mode == 3 ? W_COMMITTED_MEM : W_COMMITTED_DEFAULT; }
+BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 220 - 20)
+BB_HD constexpr int logical_width(int mode) { return mode == 3 ? W : mode == 2 ? W_LOGICAL_IO : W_LOGICAL_BASE; }
 // the logical column stored at committed position p (p < committed_used)
 BB_HD constexpr int logical_col(int p, int mode) {
   int c = p;
@@ -85,9 +107,10 @@ BB_HD constexpr int logical_col(int p, int mode) {
   return c;
 }
 // aux trace: H0..H7 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each; mode 2: + HO (output-tape helper), HI (input-tape helper)
-constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MAX = 48;
-BB_HD constexpr int aux_width(int mode) { return mode == 2 ? W_AUX_IO : W_AUX; }
-enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44 };
+// mode 3: + P0..P8 (the piece lookups), HMR / HMW (the memory tuple read / written), FPN (the fingerprint of the new cell bytes: an aux column because it depends on lambda)
+constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_MAX = 96;
+BB_HD constexpr int aux_width(int mode) { return mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
+enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
 BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^N_TUPLE (= 11), T / N
@@ -99,12 +122,12 @@ BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP :
 // "other" is SEQUENTIAL (pc + 4) like every instruction that is not a branch or a jump.
 // AIR v6: cmn = CMOV / CMOVNZ (move if rs2 != 0), cmz = CMOVZ (move if rs2 == 0)
 enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, K_CMN = 13, K_CMZ = 14, N_CLASS = 15,
-             K_ECALL = 15 /* mode 2 only: the class id of the ECALL word; it has no column */ };
+             K_ECALL = 15 /* modes 2 / 3: the class id of the ECALL word; it has no column */ };
 BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
-  return (op == OP_ECALL && mode == 2) ? (uint32_t)K_ECALL : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;
@@ -122,8 +145,14 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              // mode 2 (appended): syscall flags boolean (6), h-bits on hash rows only (2), the syscall number (3), what an ecall writes (3), zero results (3), the counters (2),
              // "exhausted" (1), the output lookup (4), the input lookup (4), the counters of the first / last row (2 + 2)
              I_IO_BOOL = 398, I_IO_H = 404, I_IO_R10 = 406, I_IO_WR = 409, I_IO_Y = 412, I_IO_CNT = 415, I_IO_END = 417, I_IO_OUT = 418, I_IO_IN = 422, I_IO_FIRST = 426, I_IO_LAST = 428,
-             N_CONSTRAINTS = 430 };
-BB_HD constexpr int num_constraints(int mode) { return mode == 2 ? N_CONSTRAINTS : N_CONSTRAINTS_BASE; }
+             N_CONSTRAINTS_IO = 430,
+             // mode 3 (appended): booleans (kld, kst, 15 windows, sgb, sgh, tb, cm2: 21), one window (1), no hash syscall (1), the opcode names width and sign (2), sgb / sgh
+             // only on byte / halfword loads (2), what is written (2), the address (3), time order (1), the stored register's pieces (3), y (3), sign extension (3),
+             // FPN (4), a load keeps the cell (4), the tuple read / written (4 + 4), the nine piece lookups (36)
+             I_MEM_BOOL = 430, I_MEM_ONE = 451, I_MEM_NOHASH = 452, I_MEM_OP = 453, I_MEM_SG = 455, I_MEM_WR = 457, I_MEM_EA = 459, I_MEM_DT = 462, I_MEM_ST = 463, I_MEM_Y = 466,
+             I_MEM_SX = 469, I_MEM_FPN = 472, I_MEM_KEEP = 476, I_MEM_RW = 480, I_MEM_PIECE = 488,
+             N_CONSTRAINTS = 524 };
+BB_HD constexpr int num_constraints(int mode) { return mode == 3 ? N_CONSTRAINTS : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -165,7 +194,7 @@ BB_HD void air_static_for(F&& f) {
 
 template <class Ops>
 BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mode, const uint32_t* cnt_m = nullptr) {   // cnt_m (mode 2): (oc, ic) of the first row, of the last row (Montgomery)
-  const bool deferred = mode == 1, io = mode == 2;
+  const bool deferred = mode == 1, io = mode >= 2, mem = mode == 3;
   using V = typename Ops::V;
   using AccP = typename Ops::AccP;
   using AccL = typename Ops::AccL;
@@ -292,6 +321,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   // classes and the opcode
   V F2 = zero, RL = zero, RE = zero, FH = zero, H0 = zero, H1 = zero;   // (mode 2) the syscall flags of an ECALL row; Kec = their sum is the row's class
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
+  V Kld = zero, Kst = zero;                                    // (mode 3) loads, stores
+  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); }
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
@@ -304,6 +335,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.acc_lin(sum, F2, 1); o.acc_lin(sum, RL, 1); o.acc_lin(sum, RE, 1); o.acc_lin(sum, FH, 1);
       o.acc_lin(ks, F2, K_ECALL); o.acc_lin(ks, RL, K_ECALL); o.acc_lin(ks, RE, K_ECALL); o.acc_lin(ks, FH, K_ECALL);
     }
+    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
     if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), opc), o.accl_val(ks)));
@@ -314,7 +346,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   o.push(I_WR + 1, o.lmul(o.lsub(w1v, fa), o.add(o.add(o.add(o.add(K[K_ADD], K[K_ADDI]), o.add(K[K_JAL], K[K_SUB])), Kcmp), K[K_JALR])));
   o.push(I_WR + 2, o.lmul(w0v, o.add(o.add(o.add(Kbr, deferred ? zero : K[K_OJ]), K[K_HALT]), K[K_PAD])));   // branches write nothing (BLT / BGE too: class oj in default mode)
   o.push(I_SELB, o.lsub(b1v, fb)); o.push(I_SELB + 1, o.lsub(o.mul(b1v, b1v), o.accl_val(b2)));
-  o.push(I_SELC, o.lsub(c1v, o.add(fc, o.mul(o.lsub(fa, fc), Kbr)))); o.push(I_SELC + 1, o.lsub(o.mul(c1v, c1v), o.accl_val(c2a)));
+  o.push(I_SELC, o.lsub(c1v, o.add(fc, o.mul(o.lsub(fa, fc), mem ? o.add(Kbr, Kst) : Kbr)))); o.push(I_SELC + 1, o.lsub(o.mul(c1v, c1v), o.accl_val(c2a)));   // (S-type words: rs1 in field a, like B-type ones)
   // (v6) conditional moves CMOV / CMOVNZ (class cmn: the condition is rs2 != 0) and CMOVZ (class cmz: rs2 == 0), execute.rs:434-472: q = "this row is a
   //      conditional move whose condition holds"; it writes rd = field a exactly then (nothing at all otherwise)
   const V Kcm = o.add(K[K_CMN], K[K_CMZ]);
@@ -437,6 +469,18 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
 #pragma unroll
     for (int k = 0; k < 4; k++) { d[k] = o.par(LK_ALPHA + k); o.acc_lin(hs[k], H[i][k], 1); }
     d[0] = o.sub(d[0], i < 4 ? R[i] : R2[i - 4]);
+    if (mem && i == 0) {                                       // (mode 3) a memory row's first chunk goes to the LOW3 table with the window's offset: alpha - R0 - lambda off - 4 lambda^11 Kmem
+      AccL offa = o.accl();
+#pragma unroll
+      for (int v = 1; v < N_WIN; v++) if (win_start(v)) o.acc_lin(offa, o.loc(C_E + v), (uint32_t)win_start(v));
+      const V off = o.accl_val(offa), Kmem = o.add(Kld, Kst);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        AccP t = o.accp();
+        o.acc_mul(t, off, o.par(LK_LAM + 4 + k)); o.acc_mul(t, Kmem, o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M(TAG_LOW3)));
+        d[k] = o.sub(d[k], o.acc_val(t));
+      }
+    }
     ext_mul(H[i], d, pr);
     o.push(I_RANGE + 4 * i, o.lsub(pr[0], one));
 #pragma unroll
@@ -502,9 +546,131 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
     tape(A_HO, I_IO_OUT, oc, r11, 2, F2);
     tape(A_HI, I_IO_IN, ic, y, 3, RL);
   }
+  // ---- (mode 3, round 4) loads, stores and the memory check (execute.rs:477-575, memory.rs:86-505): constraints 430.. of the oracle's list ----------------------------
+  V hmw[4] = {zero, zero, zero, zero};
+  if (mem) {
+    V Ev[N_WIN], ob[8], pcs[N_PIECE];
+#pragma unroll
+    for (int v = 0; v < N_WIN; v++) Ev[v] = o.loc(C_E + v);
+#pragma unroll
+    for (int j = 0; j < 8; j++) ob[j] = o.loc(C_OB + j);
+#pragma unroll
+    for (int j = 0; j < N_PIECE; j++) pcs[j] = o.loc(C_PIECE + j);
+    const V sgb = o.loc(C_SGB), sgh = o.loc(C_SGH), tbit = o.loc(C_TB), sxv = o.loc(C_SX), cm2 = o.loc(C_CM2), told = o.loc(C_TOLD);
+    const V Kmem = o.add(Kld, Kst);
+    boolean(I_MEM_BOOL, Kld); boolean(I_MEM_BOOL + 1, Kst);
+#pragma unroll
+    for (int v = 0; v < N_WIN; v++) boolean(I_MEM_BOOL + 2 + v, Ev[v]);
+    boolean(I_MEM_BOOL + 17, sgb); boolean(I_MEM_BOOL + 18, sgh); boolean(I_MEM_BOOL + 19, tbit); boolean(I_MEM_BOOL + 20, cm2);
+    AccL esum = o.accl(), wba = o.accl(), wha = o.accl(), offa = o.accl();
+#pragma unroll
+    for (int v = 0; v < N_WIN; v++) {
+      o.acc_lin(esum, Ev[v], 1);
+      if (win_start(v)) o.acc_lin(offa, Ev[v], (uint32_t)win_start(v));
+      if (win_width(v) == 1) o.acc_lin(wba, Ev[v], 1); else if (win_width(v) == 2) o.acc_lin(wha, Ev[v], 1);
+    }
+    const V WB = o.accl_val(wba), WH = o.accl_val(wha), WW = o.add(Ev[12], Ev[13]), WD = Ev[14], off = o.accl_val(offa);
+    o.push(I_MEM_ONE, o.lsub(o.accl_val(esum), Kmem));                       // exactly one window on a memory row, none elsewhere
+    o.push(I_MEM_NOHASH, FH);                                                // no hash syscall in this mode: its memory effect is not stated
+    // the opcode names the width (and, for byte / halfword loads, whether the value is sign-extended): LB LBU LH LHU LW LD = 0x30.., SB SH SW SD = 0x38..
+    o.push(I_MEM_OP, o.lmul(o.add(o.sub(o.sub(o.sub(o.sub(o.sub(op, o.cst(M(0x30))), o.mulc(WH, M(3))), o.mulc(WW, M(4))), o.mulc(WD, M(5))), WB), o.add(sgb, sgh)), Kld));
+    o.push(I_MEM_OP + 1, o.lmul(o.sub(o.sub(o.sub(o.sub(op, o.cst(M(0x38))), WH), o.mulc(WW, M(2))), o.mulc(WD, M(3))), Kst));
+    o.push(I_MEM_SG, o.lmul(o.sub(o.sub(o.cst(M(2)), Kld), WB), sgb)); o.push(I_MEM_SG + 1, o.lmul(o.sub(o.sub(o.cst(M(2)), Kld), WH), sgh));
+    // what they write: a load rd = field a, a store nothing
+    o.push(I_MEM_WR, o.lmul(o.lsub(w1v, fa), Kld)); o.push(I_MEM_WR + 1, o.lmul(w0v, Kst));
+    // the address rs1 + sext(imm17) mod 2^64 (rs1 = operand b on loads, operand c on stores) = z, the first range-checked pair; its third limb must vanish
+    o.push(I_MEM_EA, o.ladd(o.mul(o.add(o.sub(o.sub(z[0], xb[0]), im0), c0s20), Kld), o.mul(o.add(o.sub(o.sub(z[0], xc[0]), im0), c0s20), Kst)));
+    o.push(I_MEM_EA + 1, o.ladd(o.mul(o.add(o.sub(o.sub(o.sub(z[1], xb[1]), im1), c0), c1s20), Kld), o.mul(o.add(o.sub(o.sub(o.sub(z[1], xc[1]), im1), c0), c1s20), Kst)));
+    {
+      const V hi = o.sub(o.add(o.mulc(s, M(0xFFFFFF)), c1), o.mulc(cm2, M(1u << 24)));
+      o.push(I_MEM_EA + 2, o.ladd(o.mul(o.add(xb[2], hi), Kld), o.mul(o.add(xc[2], hi), Kst)));
+    }
+    // the time read is smaller than the time written (cycle + 1): cycle - told = R4 + 2^10 R5 + 2^20 R6
+    o.push(I_MEM_DT, o.lmul(o.lsub(o.sub(o.sub(o.sub(cyc, told), R2[0]), o.mulc(R2[1], M(RC_TABLE))), o.mulc(R2[2], M(RC_TABLE * RC_TABLE))), Kmem));
+    // stores: the pieces are the stored register's (rs2 = operand b), limb by limb
+    const V lim0 = o.add(o.add(pcs[0], o.mulc(pcs[1], M(1u << 8))), o.mulc(pcs[2], M(1u << 16))), lim1 = o.add(o.add(pcs[3], o.mulc(pcs[4], M(1u << 4))), o.mulc(pcs[5], M(1u << 12))),
+            lim2 = o.add(o.add(pcs[6], o.mulc(pcs[7], M(1u << 8))), o.mulc(pcs[8], M(1u << 16)));
+    o.push(I_MEM_ST, o.lmul(o.lsub(xb[0], lim0), Kst)); o.push(I_MEM_ST + 1, o.lmul(o.lsub(xb[1], lim1), Kst)); o.push(I_MEM_ST + 2, o.lmul(o.lsub(xb[2], lim2), Kst));
+    // y = the window value's limbs, zero-extended from the width, sign-extended when sx (a store writes nothing: its y merely satisfies this)
+    {
+      AccP a0 = o.accp(), a1 = o.accp();
+      o.acc_mul(a0, WB, pcs[0]); o.acc_mul(a0, WH, o.add(pcs[0], o.mulc(pcs[1], M(1u << 8)))); o.acc_mul(a0, o.add(WW, WD), lim0);
+      o.acc_mul(a0, sxv, o.sub(o.sub(o.cst(M(1u << 20)), o.mulc(WB, M(1u << 8))), o.mulc(WH, M(1u << 16))));
+      o.push(I_MEM_Y, o.lsub(o.mul(y[0], Kmem), o.acc_val(a0)));
+      o.acc_mul(a1, WW, o.add(pcs[3], o.mulc(pcs[4], M(1u << 4)))); o.acc_mul(a1, WD, lim1);
+      o.push(I_MEM_Y + 1, o.lsub(o.mul(y[1], Kmem), o.add(o.acc_val(a1), o.mulc(sxv, M(0xFFFFF)))));
+      o.push(I_MEM_Y + 2, o.lsub(o.mul(y[2], Kmem), o.add(o.mul(WD, lim2), o.mulc(sxv, M(0xFFFFFF)))));
+    }
+    // sign extension: sx = (sgb + sgh) tb; on LB rows d0 = 128 tb + d6 / 2, on LH rows d1 = 128 tb + d6 / 2 — d6 is in the byte table, so d6 / 2 has seven bits
+    o.push(I_MEM_SX, o.lsub(sxv, o.mul(o.add(sgb, sgh), tbit)));
+    {
+      const V low7 = o.add(o.mulc(tbit, M(128)), o.mulc(pcs[7], M((bb::P + 1) / 2)));
+      o.push(I_MEM_SX + 1, o.lmul(o.lsub(pcs[0], low7), sgb)); o.push(I_MEM_SX + 2, o.lmul(o.lsub(pcs[1], low7), sgh));
+    }
+    // the cell's new bytes as their fingerprint FPN (an aux column): the old bytes with the window replaced by the window value's bytes D_j; a load keeps the cell
+    const V D[8] = {pcs[0], pcs[1], o.add(pcs[2], o.mulc(pcs[3], M(16))), pcs[4], pcs[5], pcs[6], pcs[7], pcs[8]};
+    V fpn[4], obfp[4], hmr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { fpn[k] = o.aloc(A_FPN + k); hmr[k] = o.aloc(A_HMR + k); hmw[k] = o.aloc(A_HMW + k); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      AccP a = o.accp(), t = o.accp();
+#pragma unroll
+      for (int j = 0; j < 8; j++) o.acc_mul(a, ob[j], o.par(LK_LAM + 4 * (3 + j) + k));
+      obfp[k] = o.acc_val(a);
+#pragma unroll
+      for (int v = 0; v < N_WIN; v++) {
+        AccP dl = o.accp();
+#pragma unroll
+        for (int j = 0; j < win_width(v); j++) o.acc_mul(dl, o.sub(D[j], ob[win_start(v) + j]), o.par(LK_LAM + 4 * (3 + win_start(v) + j) + k));
+        o.acc_mul(t, Ev[v], o.acc_val(dl));
+      }
+      o.push(I_MEM_FPN + k, o.lsub(o.sub(fpn[k], obfp[k]), o.acc_val(t)));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) o.push(I_MEM_KEEP + k, o.lmul(o.lsub(fpn[k], obfp[k]), Kld));
+    // the memory check: HMR (alpha - fp(cell, told, old bytes)) = Kmem, HMW (alpha - fp(cell, cycle + 1, new bytes)) = Kmem; cell = (z0 - off, z1); fp = a0 + lambda a1 + lambda^2 t + bytes + 7 lambda^11
+    {
+      const V a0 = o.sub(z[0], off), tnew = o.add(cyc, one);
+#pragma unroll
+      for (int rw = 0; rw < 2; rw++) {
+        V d[4], pr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          AccP a = o.accp();
+          o.acc_mul(a, a0, o.par(LK_LAM + k)); o.acc_mul(a, z[1], o.par(LK_LAM + 4 + k)); o.acc_mul(a, rw ? tnew : told, o.par(LK_LAM + 8 + k));
+          d[k] = o.sub(o.sub(o.sub(o.par(LK_ALPHA + k), o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M(TAG_MEM))), o.acc_val(a)), rw ? fpn[k] : obfp[k]);
+        }
+        ext_mul(rw ? hmw : hmr, d, pr);
+        o.push(I_MEM_RW + 4 * rw, o.lsub(pr[0], Kmem));
+#pragma unroll
+        for (int k = 1; k < 4; k++) o.push(I_MEM_RW + 4 * rw + k, pr[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) o.acc_lin(hs[k], hmr[k], 1);
+    }
+    // the nine piece lookups: P_k (alpha - piece_k - tag_k lambda^11) = 1
+#pragma unroll
+    for (int i = 0; i < N_PIECE; i++) {
+      V h[4], d[4], pr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        h[k] = o.aloc(A_P + 4 * i + k); o.acc_lin(hs[k], h[k], 1);
+        d[k] = piece_tag(i) ? o.sub(o.par(LK_ALPHA + k), o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M((uint32_t)piece_tag(i)))) : o.par(LK_ALPHA + k);
+      }
+      d[0] = o.sub(d[0], pcs[i]);
+      ext_mul(h, d, pr);
+      o.push(I_MEM_PIECE + 4 * i, o.lsub(pr[0], one));
+#pragma unroll
+      for (int k = 1; k < 4; k++) o.push(I_MEM_PIECE + 4 * i + k, pr[k]);
+    }
+  }
   // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR (+ HO + HI) - T / N
 #pragma unroll
-  for (int k = 0; k < 4; k++) o.push(I_SUM + k, o.ladd(o.sub(o.sub(nS[k], S[k]), o.accl_val(hs[k])), o.par(LK_TN + k)));
+  for (int k = 0; k < 4; k++) {
+    if (mem) o.push(I_SUM + k, o.ladd(o.add(o.sub(o.sub(nS[k], S[k]), o.accl_val(hs[k])), hmw[k]), o.par(LK_TN + k)));   // .. + P0 + .. + P8 + HMR - HMW: the tuple written is PROVIDED, not looked up
+    else o.push(I_SUM + k, o.ladd(o.sub(o.sub(nS[k], S[k]), o.accl_val(hs[k])), o.par(LK_TN + k)));
+  }
 }
 
 // - sum_i (alpha^first_idx(i) first_m[i]) and the same for the last row: the share of the public boundary words in the two boundary sums — per-proof

@@ -70,7 +70,8 @@ BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
 // SKIP: the first SKIP blocks are not stored (experiment, DESIGN.md §9: the LDE's first pass generates them itself — zkir_lde_fused01_launch)
 // MODE: 0 default, 1 deferred, 2 default + the I/O argument (air.h): there `io` carries the input tape and the ecall counts before the trace, `cnt` the prefix counts
 // (WRITE ecalls, READ ecalls among rows < i of THIS trace) of every row.
-struct IoRowArgs { const uint64_t* inputs; uint64_t n_inputs, writes_before, reads_before; const uint32_t* cnt; /* [N][2] */ };
+// MODE 3 = mode 2 + the memory argument: mem_old / mem_told = per row the bytes of the accessed 8-byte cell before the access and the time of its previous access (zkir_memcheck_witness_of)
+struct IoRowArgs { const uint64_t* inputs; uint64_t n_inputs, writes_before, reads_before; const uint32_t* cnt; /* [N][2] */ const uint64_t* mem_old; const uint32_t* mem_told; /* [n_real] */ };
 template <int MODE, int SKIP = 0>
 BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t N, uint64_t i, uint32_t* __restrict__ out, const IoRowArgs* io = nullptr) {
   using namespace air;
@@ -96,9 +97,10 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
+  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; }
   col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
-  const uint32_t tc = branch ? fa : fc;                                         // B-type words have rs1 in field a (rs2 in field b)
+  const uint32_t tc = (branch || (MODE == 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
   uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
   bool first = true;
 #pragma unroll
@@ -115,7 +117,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && cls == K_LD)) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
     else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -127,7 +129,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     }
     col(C_WR + g - 1) = wr;
   }
-  if (MODE == 2) {
+  if (MODE >= 2) {
     // the counters every row shows — what happened BEFORE it — and, on an executed ecall, the dispatch on R10 (syscall.rs:94-177; R10 = 0 halts: the halt row)
     const uint64_t writes = io->writes_before + io->cnt[2 * i], reads = io->reads_before + io->cnt[2 * i + 1];
     col(C_OC) = (uint32_t)(writes % bb::P); col(C_IC) = (uint32_t)((reads < io->n_inputs ? reads : io->n_inputs) % bb::P);
@@ -186,6 +188,52 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   col(C_TK) = tk;
   const uint32_t imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFFu;
   const uint32_t lo20 = fb + 16 * fc + 256 * fhi - (s << 20);
+  bool mem_row = false;
+  uint32_t mem_z[2] = {0, 0}, mem_dt = 0;
+  if (MODE == 3) {
+    // loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64 — below 2^40, or the run has no proof here — its aligned 8-byte cell's bytes before the
+    // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
+#pragma unroll
+    for (int k = C_E; k < W; k++) col(k) = 0;
+    if (cls == K_LD || cls == K_ST) {
+      mem_row = true;
+      const uint32_t* base = cls == K_LD ? xb : xc;            // loads: rs1 = field b; stores: rs1 = field a (operand c), the stored register rs2 = field b (operand b)
+      const uint64_t v0 = (uint64_t)base[0] + im0; c0 = (uint32_t)(v0 >> 20); mem_z[0] = (uint32_t)(v0 & 0xFFFFF);
+      const uint64_t v1 = (uint64_t)base[1] + im1 + c0; c1 = (uint32_t)(v1 >> 20); mem_z[1] = (uint32_t)(v1 & 0xFFFFF);
+      const uint64_t v2 = (uint64_t)base[2] + (uint64_t)s * 0xFFFFFF + c1;
+      col(C_CM2) = (uint32_t)(v2 >> 24);
+      const uint64_t ea = (uint64_t)mem_z[0] | ((uint64_t)mem_z[1] << 20);
+      const int width = mem_width(op), off = (int)(ea & 7);
+      const uint64_t mask = width == 8 ? ~0ull : ((1ull << (8 * width)) - 1);
+      const int v = win_of(width, off - off % width);
+#pragma unroll
+      for (int k = 0; k < N_WIN; k++) col(C_E + k) = k == v;
+      const uint64_t ob = io->mem_old[src];
+      const uint32_t told = io->mem_told[src];
+#pragma unroll
+      for (int k = 0; k < 8; k++) col(C_OB + k) = (uint32_t)((ob >> (8 * k)) & 0xFF);
+      col(C_TOLD) = told;
+      mem_dt = (uint32_t)(t.cycle[src] - told);                 // the time written, cycle + 1, is larger than the time read
+      uint64_t window;
+      if (cls == K_LD) {
+        window = (ob >> (8 * off)) & mask;
+        uint64_t val = window;
+        const bool sgb = op == OP_LB, sgh = op == OP_LH;
+        const uint32_t tb = width <= 2 ? (uint32_t)((window >> (8 * width - 1)) & 1) : 0u;
+        if ((sgb || sgh) && tb) val |= ~mask;                    // LB / LH sign-extend to 64 bits
+        col(C_SGB) = sgb; col(C_SGH) = sgh; col(C_TB) = tb; col(C_SX) = (sgb || sgh) ? tb : 0u;
+        y[0] = (uint32_t)(val & 0xFFFFF); y[1] = (uint32_t)((val >> 20) & 0xFFFFF); y[2] = (uint32_t)(val >> 40);
+      } else {
+        window = t.registers[(uint64_t)fb * t.reg_stride + src];  // the raw 64-bit register; the store keeps its low `width` bytes
+        const uint64_t val = window & mask;                      // (nothing is written: y only satisfies the window equations)
+        y[0] = (uint32_t)(val & 0xFFFFF); y[1] = (uint32_t)((val >> 20) & 0xFFFFF); y[2] = (uint32_t)(val >> 40);
+      }
+      col(C_PIECE) = (uint32_t)(window & 0xFF); col(C_PIECE + 1) = (uint32_t)((window >> 8) & 0xFF); col(C_PIECE + 2) = (uint32_t)((window >> 16) & 0xF);
+      col(C_PIECE + 3) = (uint32_t)((window >> 20) & 0xF); col(C_PIECE + 4) = (uint32_t)((window >> 24) & 0xFF); col(C_PIECE + 5) = (uint32_t)((window >> 32) & 0xFF);
+      col(C_PIECE + 6) = (uint32_t)((window >> 40) & 0xFF); col(C_PIECE + 7) = (uint32_t)((window >> 48) & 0xFF); col(C_PIECE + 8) = (uint32_t)((window >> 56) & 0xFF);
+      if (cls == K_LD && width <= 2) col(C_PIECE + 7) = (uint32_t)(2 * ((window >> (8 * (width - 1))) & 0x7F));   // d6 = twice the low seven bits of the top byte
+    }
+  }
   const uint32_t dl0 = cls == K_JAL ? lo20 : tk ? im0 : 4u;
   const uint32_t se = (tk || cls == K_JAL) ? s : 0u;
   col(C_DL0) = dl0; col(C_SE) = se;
@@ -204,8 +252,10 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   if (cls == K_OTH) {                                              // (v6) the bits above 40 of what an "other" row writes are range-checked: y2 = R4 + 2^10 R5 + 2^20 R6, R7 = 64 R6
     rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64u * rc2[2];
   }
+  if (mem_row) { rc2[0] = mem_dt & (RC_TABLE - 1); rc2[1] = (mem_dt >> RC_BITS) & (RC_TABLE - 1); rc2[2] = mem_dt >> (2 * RC_BITS); rc2[3] = 0; }   // (mode 3) cycle - told in three chunks
   col(C_RC2) = rc2[0]; col(C_RC2 + 1) = rc2[1]; col(C_RC2 + 2) = rc2[2]; col(C_RC2 + 3) = rc2[3];
-  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like || (MODE == 2 && cls == K_ECALL)) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
+  if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like || (MODE >= 2 && cls == K_ECALL)) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
+  if (mem_row) { z[0] = mem_z[0]; z[1] = mem_z[1]; }             // (mode 3) the address's two low limbs are the range-checked pair
   col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0, b0 = 0;
@@ -585,6 +635,32 @@ int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, 
   hipLaunchKernelGGL(main_trace_kernel<2>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
                      IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt)});
   return check_launch("main_trace_io");
+}
+// MODE 3: the same scan, then the row kernel with the memory witness (device arrays of n_real entries)
+int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
+                               void* stream) {
+  if (!trace || !out || !io || !scratch || !mem_old || !mem_told || n_real == 0 || (!io->inputs && io->n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
+  uint2* cnt = reinterpret_cast<uint2*>(scratch);
+  uint2* sums = cnt + N;
+  const uint32_t n_blk = (uint32_t)((N + IOS_ROWS - 1) / IOS_ROWS);
+  hipLaunchKernelGGL(io_scan_local_kernel, dim3(n_blk), dim3(NT), 0, s, *trace, n_real, N, cnt, sums);
+  hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(64), 0, s, sums, n_blk);
+  hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
+  hipLaunchKernelGGL(main_trace_kernel<3>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
+                     IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt), mem_old, mem_told});
+  return check_launch("main_trace_mem");
+}
+int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
+  if (!trace || !out || !io || !mem_old || !mem_told || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
+  const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
+  std::vector<uint32_t> cnt(2 * N);
+  uint32_t w = 0, r = 0;
+  for (uint64_t i = 0; i < N; i++) { cnt[2 * i] = w; cnt[2 * i + 1] = r; uint32_t f[2] = {0, 0}; if (i < n_real) io_row_flags(*trace, n_real, i, f); w += f[0]; r += f[1]; }
+  const IoRowArgs a{io->inputs, io->n_inputs, io->writes_before, io->reads_before, cnt.data(), mem_old, mem_told};
+  for (uint64_t i = 0; i < N; i++) main_trace_row<3>(*trace, n_real, N, i, out, &a);
+  return ZKIR_OK;
 }
 int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out) {
   if (!trace || !out || !io || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_io_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }

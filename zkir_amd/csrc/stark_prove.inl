@@ -10,7 +10,7 @@ namespace {
 using bb::E4;
 
 // WMX / WTX: the largest committed width (deferred mode) — array sizes; a proof's own widths are air::committed_width(deferred) and that + WA
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_DEFERRED, WAX = air::W_AUX_MAX, WTX = WMX + WAX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_MAX, WAX = air::W_AUX_MAX, WTX = WMX + WAX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
 constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 
@@ -186,9 +186,11 @@ constexpr uint32_t ROM_LDS = 4096;
 struct IoEntry { uint32_t row, is_in, idx, v[3], pad[2]; };
 __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, int deferred /* the mode */, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
                                                            uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row,
-                                                           IoEntry* __restrict__ io_list, uint32_t* __restrict__ io_count) {
+                                                           IoEntry* __restrict__ io_list, uint32_t* __restrict__ io_count, uint32_t* __restrict__ mem_mult, uint4* __restrict__ mem_side) {
   __shared__ uint32_t h_rc[air::RC_TABLE];
   __shared__ uint32_t h_rom[ROM_LDS];
+  __shared__ uint32_t h_mem[air::MEM_MULT];                    // (mode 3) LOW3 | BYTE | NIBBLE
+  if (deferred == 3) for (uint32_t k = threadIdx.x; k < (uint32_t)air::MEM_MULT; k += NT) h_mem[k] = 0;
   const uint32_t rom_lds = n_code < ROM_LDS ? n_code : ROM_LDS;
   for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) h_rc[k] = 0;
   for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) h_rom[k] = 0;
@@ -204,8 +206,35 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
     const uint32_t r[air::N_RC] = {M[b8(p_rc, i, N)], M[b8(p_rc + 1, i, N)], M[b8(p_rc + 2, i, N)], M[b8(p_rc + 3, i, N)],
                                    M[b8(p_rc2, i, N)], M[b8(p_rc2 + 1, i, N)], M[b8(p_rc2 + 2, i, N)], M[b8(p_rc2 + 3, i, N)]};
     bool ok = true;
+    bool mem_row = false;
+    if (deferred == 3) {
+      // (mode 3) the row's memory side, kept for the aux kernels (the LDE overwrites M): pieces, old bytes, old time, window; the piece lookups counted here
+      const uint32_t p_kld = (uint32_t)air::phys_col(air::C_KLD, 3), p_e = (uint32_t)air::phys_col(air::C_E, 3), p_ob = (uint32_t)air::phys_col(air::C_OB, 3),
+                     p_told = (uint32_t)air::phys_col(air::C_TOLD, 3), p_pc = (uint32_t)air::phys_col(air::C_PIECE, 3);
+      const uint32_t kld = M[b8(p_kld, i, N)], kst = M[b8(p_kld + 1, i, N)];
+      mem_row = (kld | kst) != 0;
+      uint32_t win = 15;
+      for (int v = 0; v < air::N_WIN; v++) if (M[b8(p_e + (uint32_t)v, i, N)]) win = (uint32_t)v;
+      uint32_t pc9[air::N_PIECE];
+      for (int k = 0; k < air::N_PIECE; k++) {
+        pc9[k] = M[b8(p_pc + (uint32_t)k, i, N)];
+        const int tag = air::piece_tag(k);
+        if (tag == air::TAG_BYTE) { if (pc9[k] < 256u) atomicAdd(&h_mem[air::RC_TABLE + pc9[k]], 1u); else ok = false; }
+        else if (tag == air::TAG_NIB) { if (pc9[k] < 16u) atomicAdd(&h_mem[air::RC_TABLE + 256 + pc9[k]], 1u); else ok = false; }
+        else { if (pc9[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[pc9[k]], 1u); else ok = false; }
+      }
+      uint32_t obl = 0, obh = 0;
+      for (int k = 0; k < 4; k++) { obl |= (M[b8(p_ob + (uint32_t)k, i, N)] & 0xFF) << (8 * k); obh |= (M[b8(p_ob + 4 + (uint32_t)k, i, N)] & 0xFF) << (8 * k); }
+      mem_side[2 * i] = make_uint4((pc9[0] & 0xFF) | ((pc9[1] & 0xFF) << 8) | ((pc9[4] & 0xFF) << 16) | ((pc9[5] & 0xFF) << 24),
+                                   (pc9[6] & 0xFF) | ((pc9[7] & 0xFF) << 8) | ((pc9[8] & 0xFF) << 16) | ((pc9[2] & 0xF) << 24) | ((pc9[3] & 0xF) << 28), obl, obh);
+      mem_side[2 * i + 1] = make_uint4(M[b8(p_told, i, N)], kld | (kst << 1) | (win << 2), b0l.x /* cycle */, 0u);
+      if (mem_row) {                                             // the first chunk goes to the LOW3 table, with the window's offset
+        const uint32_t off = win < 15 ? (uint32_t)air::win_start((int)win) : 8u;
+        if (r[0] < (uint32_t)air::RC_TABLE && (r[0] & 7) == off) atomicAdd(&h_mem[r[0]], 1u); else ok = false;
+      }
+    }
 #pragma unroll
-    for (int k = 0; k < air::N_RC; k++) { if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
+    for (int k = 0; k < air::N_RC; k++) { if (k == 0 && mem_row) continue; if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
     const uint64_t pc = (uint64_t)b0l.y | ((uint64_t)b0l.z << 20) | ((uint64_t)b0l.w << 40);
     const uint64_t u = (pc - 0x1000) >> 2;
     uint32_t ui = 0;
@@ -221,8 +250,8 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
     // (a chunk outside the table has no proof anyway: masked here so that the packed word stays well-formed)
     auto c10 = [&](int k) { return r[k] & (uint32_t)(air::RC_TABLE - 1); };
     side[i] = make_uint4(c10(0) | (c10(1) << 10) | (c10(2) << 20), c10(3) | (c10(4) << 10) | (c10(5) << 20), c10(6) | (c10(7) << 10), ui);
-    if (deferred == 2) {                                       // the tape lookups of the row (rare: ecall rows only)
-      const uint32_t f2 = M[b8((uint32_t)air::phys_col(air::C_F2, 2), i, N)], rl = M[b8((uint32_t)air::phys_col(air::C_RL, 2), i, N)];
+    if (deferred >= 2) {                                       // the tape lookups of the row (rare: ecall rows only)
+      const uint32_t f2 = M[b8((uint32_t)air::phys_col(air::C_F2, 2), i, N)], rl = M[b8((uint32_t)air::phys_col(air::C_RL, 2), i, N)];     // (the same committed positions in modes 2 and 3)
       if (f2 | rl) {
         IoEntry e;
         e.row = (uint32_t)i; e.is_in = rl ? 1u : 0u;
@@ -237,6 +266,98 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) if (h_rc[k]) atomicAdd(&rc_mult[k], h_rc[k]);
   for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) if (h_rom[k]) atomicAdd(&rom_mult[k], h_rom[k]);
+  if (deferred == 3) for (uint32_t k = threadIdx.x; k < (uint32_t)air::MEM_MULT; k += NT) if (h_mem[k]) atomicAdd(&mem_mult[k], h_mem[k]);
+}
+static_assert(air::phys_col(air::C_F2, 2) == air::phys_col(air::C_F2, 3) && air::phys_col(air::C_IC, 2) == air::phys_col(air::C_IC, 3) && air::phys_col(air::C_Y, 2) == air::phys_col(air::C_Y, 3),
+              "modes 2 and 3 commit the mode-2 columns at the same positions");
+
+__device__ __forceinline__ uint4 add4m(uint4 a, uint4 b);
+// (mode 3) inverse tables of LOW3 | BYTE | NIBBLE for the drawn challenges: 1 / (alpha - v - lambda (v & 7) - 4 lambda^11), 1 / (alpha - v - 5 lambda^11), 1 / (alpha - v - 6 lambda^11)
+__global__ __launch_bounds__(NT) void mem_tables_kernel(const ProveParams* __restrict__ pp, E4* __restrict__ inv_mem) {
+  const uint32_t t = blockIdx.x * NT + threadIdx.x;
+  if (t >= (uint32_t)air::MEM_MULT) return;
+  const uint32_t v = t < (uint32_t)air::RC_TABLE ? t : t < (uint32_t)air::RC_TABLE + 256 ? t - air::RC_TABLE : t - air::RC_TABLE - 256;
+  const uint32_t tag = t < (uint32_t)air::RC_TABLE ? air::TAG_LOW3 : t < (uint32_t)air::RC_TABLE + 256 ? air::TAG_BYTE : air::TAG_NIB;
+  E4 d;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t fp = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + k], bb::to_mont(tag));
+    if (tag == (uint32_t)air::TAG_LOW3) fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 + k], bb::to_mont(v & 7)));
+    d.c[k] = bb::sub(pp->lk[air::LK_ALPHA + k], fp);
+  }
+  d.c[0] = bb::sub(d.c[0], bb::to_mont(v));
+  inv_mem[t] = bb::e_inv_m(d);
+}
+// (mode 3) the memory columns of the aux trace, every row: P0..P8 (table reads), FPN = sum_k lambda^(3+k) (new byte k), and on load / store rows HMR = 1 / (alpha - fp(cell,
+// told, old bytes)), HMW = 1 / (alpha - fp(cell, cycle + 1, new bytes)), H0 re-read from the LOW3 table; the row's running-sum increment (S slot, written by aux_rows_kernel)
+// gains P0 + .. + P8 + HMR - HMW (and H0's correction).  Blocks A_P / 8 ..: P0 | P1, P2 | P3, P4 | P5, P6 | P7, P8 | HMR, HMW | FPN.
+__global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ side, const uint4* __restrict__ mem_side, uint64_t N, const E4* __restrict__ inv_rc, const E4* __restrict__ inv_mem,
+                                                      const ProveParams* __restrict__ pp, uint32_t* __restrict__ A) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= N) return;
+  const uint4 m0 = mem_side[2 * i], m1 = mem_side[2 * i + 1];
+  const uint32_t pc9[air::N_PIECE] = {m0.x & 0xFF, (m0.x >> 8) & 0xFF, (m0.y >> 24) & 0xF, m0.y >> 28, (m0.x >> 16) & 0xFF, m0.x >> 24, m0.y & 0xFF, (m0.y >> 8) & 0xFF, (m0.y >> 16) & 0xFF};
+  uint4* A4 = reinterpret_cast<uint4*>(A);
+  auto put = [&](int col, const E4& c) { A4[((uint64_t)(col >> 3) * N + i) * 2 + ((col >> 2) & 1)] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
+  E4 inc = bb::e_zero();
+#pragma unroll
+  for (int k = 0; k < air::N_PIECE; k++) {
+    const int tag = air::piece_tag(k);
+    const E4 h = tag == air::TAG_BYTE ? inv_mem[air::RC_TABLE + pc9[k]] : tag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + pc9[k]] : inv_rc[pc9[k]];
+    put(air::A_P + 4 * k, h); inc = bb::e_add(inc, h);
+  }
+  const uint32_t kld = m1.y & 1, kst = (m1.y >> 1) & 1, win = m1.y >> 2;
+  const uint64_t ob = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
+  uint64_t nb = ob;
+  int off = 0;
+  if (win < 15) {                                              // the window's bytes replaced by the pieces' (a load's pieces ARE the window's bytes: nb = ob)
+    const uint64_t D = (uint64_t)pc9[0] | ((uint64_t)pc9[1] << 8) | ((uint64_t)(pc9[2] | (pc9[3] << 4)) << 16) | ((uint64_t)pc9[4] << 24) | ((uint64_t)pc9[5] << 32) | ((uint64_t)pc9[6] << 40) |
+                       ((uint64_t)pc9[7] << 48) | ((uint64_t)pc9[8] << 56);
+    const int w = air::win_width((int)win);
+    off = air::win_start((int)win);
+    const uint64_t mask = w == 8 ? ~0ull : ((1ull << (8 * w)) - 1);
+    if (kst) nb = (ob & ~(mask << (8 * off))) | ((D & mask) << (8 * off));
+  }
+  auto bytes_fp = [&](uint64_t b) {
+    E4 f = bb::e_zero();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t bm = bb::to_mont((uint32_t)((b >> (8 * k)) & 0xFF));
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) f.c[c4] = bb::add(f.c[c4], bb::mont_mul(pp->lk[air::LK_LAM + 4 * (3 + k) + c4], bm));
+    }
+    return f;
+  };
+  const E4 fpn = bytes_fp(nb);
+  put(air::A_FPN, fpn);
+  E4 hr = bb::e_zero(), hw = bb::e_zero();
+  if (kld | kst) {
+    const uint4 sd = side[i];
+    const uint32_t c0 = sd.x & 1023, z0 = c0 | (((sd.x >> 10) & 1023) << 10), z1 = (sd.x >> 20) | ((sd.y & 1023) << 10);
+    const uint32_t a0m = bb::to_mont(z0 - (uint32_t)off), a1m = bb::to_mont(z1);
+    auto tuple_inv = [&](uint32_t t, const E4& bfp) {
+      const uint32_t tm = bb::to_mont(t);
+      E4 d;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) {
+        uint32_t fp = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + c4], bb::to_mont((uint32_t)air::TAG_MEM));
+        fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + c4], a0m));
+        fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 + c4], a1m));
+        fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 8 + c4], tm));
+        d.c[c4] = bb::sub(pp->lk[air::LK_ALPHA + c4], bb::add(fp, bfp.c[c4]));
+      }
+      return bb::e_inv_m(d);
+    };
+    hr = tuple_inv(m1.x, bytes_fp(ob));
+    hw = tuple_inv((m1.z + 1) % bb::P, fpn);
+    inc = bb::e_add(inc, bb::e_sub(hr, hw));
+    const E4 h0 = inv_mem[c0];                                  // the first chunk's helper comes from the LOW3 table on a memory row
+    inc = bb::e_add(inc, bb::e_sub(h0, inv_rc[c0]));
+    put(air::A_H, h0);
+  }
+  put(air::A_HMR, hr); put(air::A_HMW, hw);
+  uint4* S = A4 + ((uint64_t)(air::A_S / 8) * N + i) * 2 + 1;
+  *S = add4m(*S, make_uint4(inc.c[0], inc.c[1], inc.c[2], inc.c[3]));
 }
 
 // inverse tables for the drawn challenges: inv_rc[t] = 1 / (alpha - t), inv_rom[u] = 1 / (alpha - fingerprint(ROM row u))  (Montgomery E4).
@@ -379,7 +500,7 @@ __global__ __launch_bounds__(NT) void scan_add_kernel(uint32_t* __restrict__ A, 
 // (mode 2: + the counters (oc, ic) of both rows at out[2 NS .. 2 NS + 4))
 __global__ void boundary_states_kernel(const uint32_t* __restrict__ M, uint64_t N, uint64_t last_row, int deferred /* the mode */, uint32_t* __restrict__ out) {
   const uint32_t i = threadIdx.x;
-  if (deferred == 2 && i >= 2 * NS && i < 2 * NS + 4) { const uint32_t k = i - 2 * NS; out[i] = M[b8((uint32_t)air::phys_col(air::C_OC + (k & 1), 2), k < 2 ? 0 : last_row, N)]; return; }
+  if (deferred >= 2 && i >= 2 * NS && i < 2 * NS + 4) { const uint32_t k = i - 2 * NS; out[i] = M[b8((uint32_t)air::phys_col(air::C_OC + (k & 1), 2), k < 2 ? 0 : last_row, N)]; return; }
   if (i >= 2 * NS) return;
   const int k = air::state_col((int)(i % NS));                 // logical column; an uncommitted one (R0's limbs, default-mode storage states) is the constant 0
   out[i] = air::is_virtual(k, deferred) ? 0u : M[b8((uint32_t)air::phys_col(k, deferred), i < (uint32_t)NS ? 0 : last_row, N)];
@@ -457,7 +578,7 @@ __global__ __launch_bounds__(NT, DEEP_WAVES) void deep_kernel(const uint32_t* __
 #pragma unroll
   for (int t = 0; t < 4; t++) A[t] = B[t] = bb::acc96_zero();
   constexpr int UN = 8;
-  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && air::W_COMMITTED_IO % UN == 0 && air::W_AUX % UN == 0 && WAX % UN == 0 && 2 * (WMX + WAX) + 4 < 512, "column loop; 96-bit sums hold 2^9 terms");
+  static_assert(WMX % UN == 0 && air::W_COMMITTED_DEFAULT % UN == 0 && air::W_COMMITTED_IO % UN == 0 && air::W_AUX % UN == 0 && WAX % UN == 0 && WMX + WAX + 4 < 512, "column loop; each 96-bit sum (A: WT + 4 terms, B: WT) holds 2^9 terms");
   auto block = [&](const uint4* M4, int blk, int k0) {                         // one B8 block = eight columns, gamma indices k0 .. k0 + 7 (zeta) and WT + k0 .. (zeta w)
     const uint4 vlo = M4[((uint64_t)blk * N2 + j) * 2], vhi = M4[((uint64_t)blk * N2 + j) * 2 + 1];
     const uint32_t v[UN] = {vlo.x, vlo.y, vlo.z, vlo.w, vhi.x, vhi.y, vhi.z, vhi.w};
@@ -615,7 +736,7 @@ void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t*
   w.insert(w.end(), {(uint32_t)(pub.entry_point & 0xFFFFF), (uint32_t)((pub.entry_point >> 20) & 0xFFFFF), (uint32_t)(pub.entry_point >> 40)});
   w.insert(w.end(), pub.program_digest, pub.program_digest + 4);
   w.insert(w.end(), pub.io_digest, pub.io_digest + 4);
-  w.insert(w.end(), states, states + 2 * NS + (pub.deferred == 2 ? 4 : 0));
+  w.insert(w.end(), states, states + 2 * NS + (pub.deferred >= 2 ? 4 : 0));
 }
 
 // The quotient kernel's evaluation of the constraint list (QuotientOps: lazy 32-bit arithmetic, 96-bit sums, one accumulator per selector), run on
@@ -636,9 +757,9 @@ static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32
   uint32_t l[WMX], n[WMX], a[WAX], an[WAX], lkm[air::N_LK], fm[NS], lm[NS], cm[4] = {0, 0, 0, 0};
   for (int p = 0; p < air::committed_used(DEF); p++) { l[p] = bb::to_mont(loc[air::logical_col(p, DEF)]); n[p] = bb::to_mont(nxt[air::logical_col(p, DEF)]); }
   for (int k = 0; k < air::aux_width(DEF); k++) { a[k] = bb::to_mont(aloc[k]); an[k] = bb::to_mont(anxt[k]); }
-  for (int i = 0; i < air::N_LK; i++) lkm[i] = (DEF == 2 || i < air::LK_NIN) ? bb::to_mont(lk[i]) : 0u;       // (modes 0 / 1: the caller's lk has 56 words)
+  for (int i = 0; i < air::N_LK; i++) lkm[i] = (DEF >= 2 || i < air::LK_NIN) ? bb::to_mont(lk[i]) : 0u;       // (modes 0 / 1: the caller's lk has 56 words)
   for (int i = 0; i < NS; i++) { fm[i] = bb::to_mont(first[i]); lm[i] = bb::to_mont(last[i]); }
-  if (DEF == 2) for (int k = 0; k < 4; k++) cm[k] = bb::to_mont(cnt4[k]);
+  if (DEF >= 2) for (int k = 0; k < 4; k++) cm[k] = bb::to_mont(cnt4[k]);
   std::vector<E4> ap(N_CONSTRAINTS);
   E4 al{{alpha4[0], alpha4[1], alpha4[2], alpha4[3]}}, cur{{1, 0, 0, 0}};
   for (int c = 0; c < N_CONSTRAINTS; c++) { ap[c] = bb::e_to_mont(cur); cur = h_e_mul(cur, al); }
@@ -650,7 +771,7 @@ static void air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32
   o.init();
   air::eval(o, fm, lm, DEF, cm);
   E4 cf, cl;
-  air::boundary_constants(ap.data(), fm, lm, cf, cl, DEF == 2 ? cm : nullptr);
+  air::boundary_constants(ap.data(), fm, lm, cf, cl, DEF >= 2 ? cm : nullptr);
   using QO = QuotientOps<DEF, HostRowSrc>;
   const E4 s0 = QO::sum_of(o.a0), st = o.st, sf = bb::e_sub(o.sf, cf), sl = bb::e_sub(o.sl, cl);
   const E4 tot = bb::e_add(bb::e_add(s0, bb::e_mul_fm(st, bb::to_mont(sel3[2]))), bb::e_add(bb::e_mul_fm(sf, bb::to_mont(sel3[0])), bb::e_mul_fm(sl, bb::to_mont(sel3[1]))));
@@ -664,7 +785,8 @@ extern "C" {
 void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, uint32_t is_first, uint32_t is_last, uint32_t is_trans,
                         const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t mode, const uint32_t* cnt4, uint32_t* out4) {
   const uint32_t sel3[3] = {is_first, is_last, is_trans};
-  if (mode == 2) air_eval_host<2>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
+  if (mode == 3) air_eval_host<3>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
+  else if (mode == 2) air_eval_host<2>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
   else if (mode == 1) air_eval_host<1>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
   else air_eval_host<0>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
 }
@@ -682,11 +804,16 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (!c || !trace || !pub || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
   const uint32_t log_n = c->log_n;
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
-  if (pub->deferred > 2) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument"}); return ZKIR_ERR_ARGUMENT; }
-  const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument (round 4)
+  if (pub->deferred > 3) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument"}); return ZKIR_ERR_ARGUMENT; }
+  const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument, 3 = 2 + the memory argument (round 4)
+  const bool IO = MODE >= 2, MEM = MODE == 3;
   const bool DEF = MODE == 1;
   const int WM = air::committed_width(MODE), WA = air::aux_width(MODE), WT = WM + WA;     // this proof's committed main-trace / aux columns
-  if (MODE == 2 && ((!pub->inputs && pub->n_inputs) || (!pub->outputs && pub->n_outputs) || pub->n_inputs >= (1u << 28) || pub->n_outputs >= (1u << 28) || pub->halt_kind > 2)) {
+  if (MEM && (!pub->mem_old || !pub->mem_told || (pub->n_cells && (!pub->cell_addr || !pub->cell_bytes || !pub->cell_time)) || pub->n_cells >= (1u << 28) || pub->writes_before || pub->reads_before)) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: mode 3 proves a WHOLE run and needs its memory witness in the public inputs (zkir_memcheck_witness_of + zkir_public_inputs_set_memory)"});
+    return ZKIR_ERR_ARGUMENT;
+  }
+  if (IO && ((!pub->inputs && pub->n_inputs) || (!pub->outputs && pub->n_outputs) || pub->n_inputs >= (1u << 28) || pub->n_outputs >= (1u << 28) || pub->halt_kind > 2)) {
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: mode 2 needs the I/O tapes and the halt reason in the public inputs (zkir_public_inputs_of fills them)"});
     return ZKIR_ERR_ARGUMENT;
   }
@@ -721,8 +848,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
-    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (MODE == 2 ? 48 : 0)) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
-                        (MODE == 2 ? (size_t)pub->n_inputs * 8 : 0);
+    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0)) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
+                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -738,12 +865,15 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   E4 *dW, *dDinv, *dPart, *dInvRc, *dInvRom;
   ProveParams* dPP;
   IoEntry* dIo = nullptr; uint32_t* dIoCount = nullptr; uint64_t* dInputs = nullptr; uint32_t* dIoScratch = nullptr;
+  uint64_t* dMemOld = nullptr; uint32_t* dMemTold = nullptr; uint4* dMemSide = nullptr; E4* dInvMem = nullptr;
   HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS + 4)); HIP_OK(ar.take(&dBad, 1));
-  if (MODE == 2) { HIP_OK(ar.take(&dIo, N)); HIP_OK(ar.take(&dIoCount, 4)); HIP_OK(ar.take(&dInputs, (size_t)pub->n_inputs + 1)); HIP_OK(ar.take(&dIoScratch, 2 * N + 2 * (N / 1024 + 2))); }
+  if (IO) { HIP_OK(ar.take(&dIo, N)); HIP_OK(ar.take(&dIoCount, 4)); HIP_OK(ar.take(&dInputs, (size_t)pub->n_inputs + 1)); HIP_OK(ar.take(&dIoScratch, 2 * N + 2 * (N / 1024 + 2))); }
+  if (MEM) { HIP_OK(ar.take(&dMemOld, N)); HIP_OK(ar.take(&dMemTold, N)); HIP_OK(ar.take(&dMemSide, 2 * N)); HIP_OK(ar.take(&dInvMem, air::MEM_MULT)); }
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dA, WA * N)); HIP_OK(ar.take(&dAL, WA * N2)); HIP_OK(ar.take(&dATree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dSide, N)); HIP_OK(ar.take(&dSums, N / SCAN_ROWS + 1));
-  HIP_OK(ar.take(&dCode, (size_t)n_code + 1)); HIP_OK(ar.take(&dMult, (size_t)n_code + air::RC_TABLE));                   // ROM multiplicities, then range multiplicities
+  const size_t n_mult = (size_t)n_code + air::RC_TABLE + (MEM ? air::MEM_MULT : 0);
+  HIP_OK(ar.take(&dCode, (size_t)n_code + 1)); HIP_OK(ar.take(&dMult, n_mult));                   // ROM multiplicities, then range multiplicities (mode 3: then LOW3 | BYTE | NIBBLE)
   HIP_OK(ar.take(&dInvRc, air::RC_TABLE)); HIP_OK(ar.take(&dInvRom, (size_t)n_code + 1));
   HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
@@ -757,10 +887,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 1. main trace, lookup indices + multiplicities, LDE, trace commitment ---------------------------------------------------
   mark(0);
   int rc;
-  if (MODE == 2) {
+  if (IO) {
     if (pub->n_inputs) HIP_OK(hipMemcpyAsync(dInputs, pub->inputs, (size_t)pub->n_inputs * 8, hipMemcpyHostToDevice, s));
     const zkir_io_args io{dInputs, pub->n_inputs, pub->writes_before, pub->reads_before};
-    rc = zkir_main_trace_io_launch(trace, pub->n_real, &io, dIoScratch, dM, s);
+    if (MEM) {
+      HIP_OK(hipMemcpyAsync(dMemOld, pub->mem_old, (size_t)pub->n_real * 8, hipMemcpyHostToDevice, s));
+      HIP_OK(hipMemcpyAsync(dMemTold, pub->mem_told, (size_t)pub->n_real * 4, hipMemcpyHostToDevice, s));
+      rc = zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
+    } else rc = zkir_main_trace_io_launch(trace, pub->n_real, &io, dIoScratch, dM, s);
   } else rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s);
   if (rc) return rc;
   hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, MODE, dBound);   // before the LDE overwrites dM
@@ -768,11 +902,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   {
     for (uint32_t t = 0; t < n_code; t++) memcpy(&code[t], blob + 32 + 4 * (size_t)t, 4);
     if (n_code) HIP_OK(hipMemcpyAsync(dCode, code.data(), (size_t)n_code * 4, hipMemcpyHostToDevice, s));
-    HIP_OK(hipMemsetAsync(dMult, 0, ((size_t)n_code + air::RC_TABLE) * 4, s));
+    HIP_OK(hipMemsetAsync(dMult, 0, n_mult * 4, s));
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
-    if (MODE == 2) HIP_OK(hipMemsetAsync(dIoCount, 0, 4, s));
-    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount);
+    if (IO) HIP_OK(hipMemsetAsync(dIoCount, 0, 4, s));
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount, dMult + n_code + air::RC_TABLE, dMemSide);
   }
   mark(1);
   rc = lde_launch(c, dM, WM, dL, /*mont_out=*/true, s); if (rc) return rc;        // canonical evaluations in, MONTGOMERY words out: the matrices of a proof rest in Montgomery form
@@ -780,17 +914,17 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   rc = merkle_commit(c, dL, WM, N2, dTree, /*mont_in=*/true, s); if (rc) return rc;
   uint32_t troot[4], aroot[4], qroot[4], bound[2 * NS + 4] = {}, n_io = 0;
   unsigned long long bad_row = ~0ull;
-  std::vector<uint32_t> mult((size_t)n_code + air::RC_TABLE);
+  std::vector<uint32_t> mult(n_mult);
   HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(bound, dBound, sizeof bound, hipMemcpyDeviceToHost, s));
-  if (MODE == 2) HIP_OK(hipMemcpyAsync(&n_io, dIoCount, 4, hipMemcpyDeviceToHost, s));
+  if (IO) HIP_OK(hipMemcpyAsync(&n_io, dIoCount, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(mult.data(), dMult, mult.size() * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(&bad_row, dBad, 8, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   if (bad_row != ~0ull) {
     char m[256];
     snprintf(m, sizeof m, "zkir_prove: row %llu of the trace has no proof in this AIR: its (pc, instruction word) is not in the program's code table (self-modified code, "
-                          "a pc outside the code segment) or a written limb is out of range", bad_row);
+                          "a pc outside the code segment), a written limb is out of range, or (mode 3) its memory witness is not the row's", bad_row);
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, m});
     return ZKIR_ERR_ARGUMENT;
   }
@@ -800,7 +934,18 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   Challenger ch(c->consts);
   ch.observe_n(head.data() + 2, head.size() - 2);
   ch.observe_n(troot, 4);
-  ch.observe_n(mult.data(), mult.size());                     // ROM multiplicities, range multiplicities: fixed before the lookup challenges
+  std::vector<uint32_t> mem_sec;                              // (mode 3) the touched cells as the proof carries them: fixed before the lookup challenges like the multiplicities
+  if (MEM) {
+    mem_sec.push_back((uint32_t)pub->n_cells);
+    for (uint64_t k = 0; k < pub->n_cells; k++) {
+      const uint64_t a = pub->cell_addr[k], b = pub->cell_bytes[k];
+      if ((a & 7) || (a >> 40) || (k && a <= pub->cell_addr[k - 1])) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the touched cells must be multiples of 8 below 2^40 in strictly increasing order"}); return ZKIR_ERR_ARGUMENT; }
+      mem_sec.push_back((uint32_t)(a & 0xFFFFF)); mem_sec.push_back((uint32_t)((a >> 20) & 0xFFFFF)); mem_sec.push_back(pub->cell_time[k]);
+      for (int i = 0; i < 4; i++) mem_sec.push_back((uint32_t)((b >> (16 * i)) & 0xFFFF));
+    }
+    ch.observe_n(mem_sec.data(), mem_sec.size());
+  }
+  ch.observe_n(mult.data(), mult.size());                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
   std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
   {
     // ---- 1b. lookup challenges, inverse tables, T, aux trace (helper columns + running sum), its LDE and commitment ----
@@ -809,17 +954,48 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int k = 0; k < 4; k++) pp->lk[air::LK_ALPHA + k] = bb::to_mont(alpha_l.c[k]);
     for (int j = 0; j <= air::N_TUPLE; j++) { for (int k = 0; k < 4; k++) pp->lk[air::LK_LAM + 4 * j + k] = bb::to_mont(lam.c[k]); lam = h_e_mul(lam, lambda); }
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = 0;
-    pp->lk[air::LK_NIN] = MODE == 2 ? bb::to_mont((uint32_t)(pub->n_inputs % bb::P)) : 0u;
+    pp->lk[air::LK_NIN] = IO ? bb::to_mont((uint32_t)(pub->n_inputs % bb::P)) : 0u;
     HIP_OK(hipMemcpyAsync(dPP->lk, pp->lk, sizeof(pp->lk), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom, MODE);
-    std::vector<E4> inv((size_t)air::RC_TABLE + n_code);
+    if (MEM) hipLaunchKernelGGL(mem_tables_kernel, dim3(grid_for(air::MEM_MULT)), dim3(NT), 0, s, dPP, dInvMem);
+    std::vector<E4> inv((size_t)air::RC_TABLE + n_code + (MEM ? air::MEM_MULT : 0));
     HIP_OK(hipMemcpyAsync(inv.data(), dInvRc, (size_t)air::RC_TABLE * sizeof(E4), hipMemcpyDeviceToHost, s));
     if (n_code) HIP_OK(hipMemcpyAsync(inv.data() + air::RC_TABLE, dInvRom, (size_t)n_code * sizeof(E4), hipMemcpyDeviceToHost, s));
+    if (MEM) HIP_OK(hipMemcpyAsync(inv.data() + air::RC_TABLE + n_code, dInvMem, (size_t)air::MEM_MULT * sizeof(E4), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     E4 T = bb::e_zero();                                      // Montgomery: sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u)
     for (int t = 0; t < air::RC_TABLE; t++) if (mult[n_code + t]) T = bb::e_add(T, bb::e_mul_fm(inv[t], bb::to_mont(mult[n_code + t] % bb::P)));
     for (uint32_t u = 0; u < n_code; u++) if (mult[u]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + u], bb::to_mont(mult[u] % bb::P)));
-    if (MODE == 2) {
+    if (MEM) {
+      // LOW3 | BYTE | NIBBLE, then the two ends of the memory check, formed like the verifier will form them: per touched cell + 1 / (alpha - fp(cell, time 0, the program
+      // image's bytes)) - 1 / (alpha - fp(cell, final time, final bytes)) (oracle: so::mem_table_sum); batch inversion on the host (one e_inv_m, three products per tuple)
+      const size_t m0 = (size_t)n_code + air::RC_TABLE;
+      for (int t = 0; t < air::MEM_MULT; t++) if (mult[m0 + t]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + n_code + t], bb::to_mont(mult[m0 + t] % bb::P)));
+      auto image_cell = [&](uint64_t addr) {
+        uint32_t code_size, data_size; memcpy(&code_size, blob + 16, 4); memcpy(&data_size, blob + 20, 4);
+        uint64_t v = 0;
+        if (32 + (uint64_t)code_size + data_size <= blob_len) for (int k = 0; k < 8; k++) { const uint64_t a = addr + k; if (a >= 0x1000 && a - 0x1000 < (uint64_t)code_size + data_size) v |= (uint64_t)blob[32 + (a - 0x1000)] << (8 * k); }
+        return v;
+      };
+      auto mem_d = [&](uint64_t addr, uint32_t t, uint64_t bytes) {
+        const uint32_t g[11] = {(uint32_t)(addr & 0xFFFFF), (uint32_t)((addr >> 20) & 0xFFFFF), t, (uint32_t)(bytes & 0xFF), (uint32_t)((bytes >> 8) & 0xFF), (uint32_t)((bytes >> 16) & 0xFF),
+                                (uint32_t)((bytes >> 24) & 0xFF), (uint32_t)((bytes >> 32) & 0xFF), (uint32_t)((bytes >> 40) & 0xFF), (uint32_t)((bytes >> 48) & 0xFF), (uint32_t)(bytes >> 56)};
+        E4 d;
+        for (int c4 = 0; c4 < 4; c4++) {
+          uint32_t f = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + c4], bb::to_mont((uint32_t)air::TAG_MEM));
+          for (int j = 0; j < 11; j++) f = bb::add(f, bb::mont_mul(pp->lk[air::LK_LAM + 4 * j + c4], bb::to_mont(g[j])));
+          d.c[c4] = bb::sub(pp->lk[air::LK_ALPHA + c4], f);
+        }
+        return d;
+      };
+      std::vector<E4> d(2 * (size_t)pub->n_cells), pre(2 * (size_t)pub->n_cells);
+      for (uint64_t k = 0; k < pub->n_cells; k++) { d[2 * k] = mem_d(pub->cell_addr[k], 0, image_cell(pub->cell_addr[k])); d[2 * k + 1] = mem_d(pub->cell_addr[k], pub->cell_time[k], pub->cell_bytes[k]); }
+      E4 acc = bb::e_one_m();
+      for (size_t k = 0; k < d.size(); k++) { pre[k] = acc; acc = bb::e_mul_m(acc, d[k]); }
+      E4 iv = d.empty() ? bb::e_one_m() : bb::e_inv_m(acc);
+      for (size_t k = d.size(); k-- > 0;) { const E4 dk = bb::e_mul_m(iv, pre[k]); iv = bb::e_mul_m(iv, d[k]); T = (k & 1) ? bb::e_sub(T, dk) : bb::e_add(T, dk); }
+    }
+    if (IO) {
       // the tapes' share of the table side, formed like the verifier will form it: every output index in [oc_first, oc_last) and every input index in
       // [ic_first, ic_last) once (air.h: mode 2; oracle: so::io_table_sum) — if the trace's WRITE / READ rows do not send exactly these, the sums differ and the proof fails
       auto term = [&](uint64_t k, uint64_t v, uint32_t tag) {
@@ -844,10 +1020,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];
     HIP_OK(hipMemcpyAsync(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(aux_rows_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, N, dInvRc, dInvRom, dPP, dA);
-    if (MODE == 2) {                                          // the tape helpers HO | HI: zero but on the WRITE / live READ rows
+    if (IO) {                                                 // the tape helpers HO | HI: zero but on the WRITE / live READ rows
       HIP_OK(hipMemsetAsync(dA + (size_t)(air::A_HO / 8) * N * 8, 0, (size_t)N * 32, s));
       if (n_io) hipLaunchKernelGGL(io_aux_kernel, dim3(grid_for(n_io)), dim3(NT), 0, s, dIo, n_io, N, dPP, dA);
     }
+    if (MEM) hipLaunchKernelGGL(mem_aux_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, dMemSide, N, dInvRc, dInvMem, dPP, dA);   // P0..P8, HMR, HMW, FPN of every row
     const uint32_t n_scan = (uint32_t)((N + SCAN_ROWS - 1) / SCAN_ROWS);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_scan), dim3(NT), 0, s, dA, N, dSums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(NT), 0, s, dSums, n_scan);
@@ -871,7 +1048,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int k = 0; k < N_CONSTRAINTS + 2; k++) pp->alpha_seq[k] = k < n_push ? alpha_pow[order[k]] : bb::e_zero();
     for (int i = 0; i < NS; i++) { pp->first_m[i] = bb::to_mont(bound[i]); pp->last_m[i] = bb::to_mont(bound[NS + i]); }
     for (int k = 0; k < 4; k++) pp->cnt_m[k] = bb::to_mont(bound[2 * NS + k]);
-    air::boundary_constants(alpha_pow.data(), pp->first_m, pp->last_m, pp->cf, pp->cl, MODE == 2 ? pp->cnt_m : nullptr);
+    air::boundary_constants(alpha_pow.data(), pp->first_m, pp->last_m, pp->cf, pp->cl, IO ? pp->cnt_m : nullptr);
     pp->deferred = pub->deferred ? 1 : 0;
     HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
   }
@@ -880,6 +1057,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
   const uint32_t last_shift = (uint32_t)((2 * (pub->n_real - 1)) & (N2 - 1));   // x_j - w_N^last = w_N^last (x_(j - 2 last) - 1) on the 2N coset
   if (MODE == 1) hipLaunchKernelGGL(quotient_kernel<1>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  else if (MODE == 3) hipLaunchKernelGGL(quotient_kernel<3>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   else if (MODE == 2) hipLaunchKernelGGL(quotient_kernel<2>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   else hipLaunchKernelGGL(quotient_kernel<0>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   rc = merkle_commit(c, dQ, 4, N2, dQTree, /*mont_in=*/true, s); if (rc) return rc;
@@ -999,13 +1177,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
   head.push_back((uint32_t)blob_len);                                         // the program: byte length, then 16-bit halfwords
   for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
-  if (MODE == 2) {                                                            // the I/O section: the tapes and the halt reason the io digest is a digest of
+  if (IO) {                                                                   // the I/O section: the tapes and the halt reason the io digest is a digest of
     auto put_u64 = [&](uint64_t v) { for (int i = 0; i < 4; i++) head.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); };
     head.push_back((uint32_t)pub->n_inputs); for (uint64_t i = 0; i < pub->n_inputs; i++) put_u64(pub->inputs[i]);
     head.push_back((uint32_t)pub->n_outputs); for (uint64_t i = 0; i < pub->n_outputs; i++) put_u64(pub->outputs[i]);
     head.push_back(pub->halt_kind); put_u64(pub->halt_kind == ZKIR_HALT_EXIT ? pub->halt_code : 0);
   }
-  head.insert(head.end(), mult.begin(), mult.end());                          // ROM multiplicities, range multiplicities
+  if (MEM) head.insert(head.end(), mem_sec.begin(), mem_sec.end());           // (mode 3) the touched cells
+  head.insert(head.end(), mult.begin(), mult.end());                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);

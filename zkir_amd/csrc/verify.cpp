@@ -5,7 +5,9 @@
 // arithmetic (babybear.h), the product's Poseidon2 (poseidon2.h) and the product's constraint list (air.h, the same template the
 // quotient kernel instantiates); tests/ compare its verdicts with the oracle's so::verify on valid, tampered and cheating proofs.
 // Transcript and proof layout: see zkir_prove (stark_prove.inl) and DESIGN.md §8.8.
+#include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/zkir_amd.h"
@@ -121,7 +123,16 @@ void initial_state(uint64_t entry, uint32_t st[NS]) {
 }
 
 int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, bool whole_run, uint32_t* states_out, uint32_t* counters_out = nullptr);
-inline int header_words_of(int mode) { return HEADER_WORDS + (mode == 2 ? 4 : 0); }     // mode 2: + (oc, ic) of the first row, of the last row
+inline int header_words_of(int mode) { return HEADER_WORDS + (mode >= 2 ? 4 : 0); }     // modes 2 / 3: + (oc, ic) of the first row, of the last row
+// (mode 3) the bytes of cell `addr` (a multiple of 8) in the VM's INITIAL memory: the code words at 0x1000, the data section right behind them (vm.rs:153-170), zero elsewhere
+uint64_t image_cell(const uint8_t* blob, size_t n, uint64_t addr) {
+  if (!blob || n < 32) return 0;
+  uint32_t code_size, data_size; memcpy(&code_size, blob + 16, 4); memcpy(&data_size, blob + 20, 4);
+  if (32 + (uint64_t)code_size + data_size > n) return 0;
+  uint64_t v = 0;
+  for (int k = 0; k < 8; k++) { const uint64_t a = addr + k; if (a >= 0x1000 && a - 0x1000 < (uint64_t)code_size + data_size) v |= (uint64_t)blob[32 + (a - 0x1000)] << (8 * k); }
+  return v;
+}
 
 // (mode 2) the I/O section of a proof, after the program: [n_in] [inputs: four 16-bit pieces each] [n_out] [outputs] [halt kind] [halt code: four pieces]
 struct IoSection { std::vector<uint64_t> in, out; uint32_t halt_kind = ZKIR_HALT_CYCLE_LIMIT; uint64_t halt_code = 0; size_t words = 0; };
@@ -179,7 +190,7 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t
   if (log->window_open) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: this trace window ended before the run did (its outputs / halt reason are not the run's)"}); return ZKIR_ERR_ARGUMENT; }
   memset(out, 0, sizeof *out);
   out->n_real = log->cycles;
-  out->deferred = deferred > 2 ? 1 : deferred;                             // the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument
+  out->deferred = deferred > 3 ? 1 : deferred;                             // the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument (zkir_memcheck_witness_of)
   // the claim in the clear (mode 2 proofs carry it; BORROWED: the caller's inputs, the log's outputs)
   out->inputs = inputs; out->n_inputs = n_inputs;
   out->outputs = log->outputs.data(); out->n_outputs = log->outputs.size();
@@ -199,6 +210,76 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t
 }
 
 int zkir_verify(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect) { return verify_impl(w, len, expect, true, nullptr); }
+
+// ---- (mode 3) the memory witness: a sequential replay of the run's loads and stores over 8-byte cells (see include/zkir_amd.h) ----
+}  // extern "C"
+struct zkir_memcheck_witness {
+  std::vector<uint64_t> old; std::vector<uint32_t> told;                   // per row
+  std::vector<uint64_t> cell_addr, cell_bytes; std::vector<uint32_t> cell_time;
+  uint64_t n_accesses = 0;
+};
+extern "C" {
+int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* blob, size_t blob_len, zkir_memcheck_witness** out) {
+  if (out) *out = nullptr;
+  auto refuse = [](const std::string& m) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memcheck_witness_of: " + m}); return ZKIR_ERR_ARGUMENT; };
+  if (!log || !out || !blob) return refuse("null argument");
+  if (log->cycle_base != 0 || log->window_open || log->n_rows != log->cycles) return refuse("the memory argument spans a whole run: not a shard, a window or an untraced log");
+  const uint64_t n = log->n_rows;
+  if (n >= (1ull << 30)) return refuse("more than 2^30 rows");
+  auto* w = new zkir_memcheck_witness;
+  w->old.assign(n, 0); w->told.assign(n, 0);
+  // cell -> (bytes, time): open addressing over the touched cells (a run touches far fewer cells than it has rows)
+  struct Slot { uint64_t addr, bytes; uint32_t t; uint32_t used; };
+  size_t cap = 1024; std::vector<Slot> tab(cap, Slot{0, 0, 0, 0}); size_t used = 0;
+  auto find = [&](uint64_t addr) -> Slot& {
+    if (2 * (used + 1) > cap) {
+      std::vector<Slot> nt(cap * 2, Slot{0, 0, 0, 0});
+      for (const Slot& s : tab) if (s.used) { size_t h = (size_t)((s.addr >> 3) * 0x9E3779B97F4A7C15ull >> 20) & (cap * 2 - 1); while (nt[h].used) h = (h + 1) & (cap * 2 - 1); nt[h] = s; }
+      tab.swap(nt); cap *= 2;
+    }
+    size_t h = (size_t)((addr >> 3) * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);
+    while (tab[h].used && tab[h].addr != addr) h = (h + 1) & (cap - 1);
+    if (!tab[h].used) { tab[h] = Slot{addr, image_cell(blob, blob_len, addr), 0, 1}; used++; }
+    return tab[h];
+  };
+  uint64_t reg[16] = {0};
+  const zkir_reg_event* ev = log->reg_events.data(); const size_t n_ev = log->reg_events.size(); size_t e = 0;
+  const uint32_t* inst = log->inst.data();
+  for (uint64_t i = 0; i < n; i++) {
+    while (e < n_ev && ev[e].vis <= i) { reg[ev[e].reg] = ev[e].value; e++; }        // the pre-state of row i
+    if (i + 1 >= n) break;                                                            // the halt row executes nothing the AIR describes
+    const uint32_t word = inst[i], op = word & 0x7F;
+    if (op == air::OP_ECALL) { if (reg[10] >= 3 && reg[10] <= 6) { delete w; return refuse("the run executes a hash syscall (row " + std::to_string(i) + "): its memory effect is not stated by the AIR"); } continue; }
+    if (!air::is_load(op) && !air::is_store(op)) continue;
+    const uint32_t fa = (word >> 7) & 0xF, fb = (word >> 11) & 0xF;
+    const int64_t imm = (int64_t)(int32_t)(word & 0xFFFF8000u) >> 15;                 // imm17, sign-extended
+    const uint64_t ea = reg[air::is_load(op) ? fb : fa] + (uint64_t)imm;              // wrapping u64 add (execute.rs:477-575)
+    if (ea >> 40) { delete w; return refuse("address " + std::to_string(ea) + " at row " + std::to_string(i) + " is not below 2^40"); }
+    const int width = air::mem_width(op), off = (int)(ea & 7);
+    Slot& c = find(ea - off);
+    w->old[i] = c.bytes; w->told[i] = c.t; w->n_accesses++;
+    if (air::is_store(op)) {
+      const uint64_t mask = width == 8 ? ~0ull : ((1ull << (8 * width)) - 1);
+      c.bytes = (c.bytes & ~(mask << (8 * off))) | ((reg[fb] & mask) << (8 * off));
+    }
+    c.t = (uint32_t)(i + 1);
+  }
+  std::vector<const Slot*> order;
+  for (const Slot& s : tab) if (s.used) order.push_back(&s);
+  std::sort(order.begin(), order.end(), [](const Slot* a, const Slot* b) { return a->addr < b->addr; });
+  for (const Slot* s : order) { w->cell_addr.push_back(s->addr); w->cell_bytes.push_back(s->bytes); w->cell_time.push_back(s->t); }
+  *out = w;
+  return ZKIR_OK;
+}
+void zkir_memcheck_witness_free(zkir_memcheck_witness* w) { delete w; }
+uint64_t zkir_memcheck_witness_n_cells(const zkir_memcheck_witness* w) { return w ? w->cell_addr.size() : 0; }
+uint64_t zkir_memcheck_witness_n_accesses(const zkir_memcheck_witness* w) { return w ? w->n_accesses : 0; }
+void zkir_public_inputs_set_memory(zkir_public_inputs* pub, const zkir_memcheck_witness* w) {
+  if (!pub || !w) return;
+  pub->deferred = 3;
+  pub->mem_old = w->old.data(); pub->mem_told = w->told.data();
+  pub->cell_addr = w->cell_addr.data(); pub->cell_bytes = w->cell_bytes.data(); pub->cell_time = w->cell_time.data(); pub->n_cells = w->cell_addr.size();
+}
 
 int zkir_verify_segment(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, uint32_t first_state[68], uint32_t last_state[68]) {
   uint32_t st[2 * NS];
@@ -325,8 +406,9 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   auto need = [&](size_t k) { return p + k <= len; };
   if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
   const int log_n = (int)w[2];
-  if (w[9] > 2) return 2;
-  const int mode = (int)w[9];                                              // 0 default, 1 deferred, 2 default + the I/O argument
+  if (w[9] > 3) return 2;
+  const int mode = (int)w[9];                                              // 0 default, 1 deferred, 2 default + the I/O argument, 3 = 2 + the memory argument
+  if (mode == 3 && !whole_run) return 2;                                   // the memory check spans the whole run: a mode-3 proof is never a segment
   const int HW = header_words_of(mode), WA = air::aux_width(mode);
   if (!need(HW)) return 1;
   const int WM = (int)w[3], WT = WM + WA;                                  // committed main-trace columns (checked against the mode below); main + aux
@@ -341,7 +423,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   for (int i = 0; i < 2 * NS; i++) if (first[i] >= bb::P) return 3;
   if (pub.n_real == 0 || zkir_padded_log_n(pub.n_real) != (uint32_t)log_n) return 2;
   uint32_t cnt[4] = {0, 0, 0, 0};                                          // (mode 2) (oc, ic) of the first row, of the last row
-  if (mode == 2) { for (int k = 0; k < 4; k++) { if (w[HEADER_WORDS + k] >= bb::P) return 3; cnt[k] = w[HEADER_WORDS + k]; } }
+  if (mode >= 2) { for (int k = 0; k < 4; k++) { if (w[HEADER_WORDS + k] >= bb::P) return 3; cnt[k] = w[HEADER_WORDS + k]; } }
   if (counters_out) memcpy(counters_out, cnt, sizeof cnt);
   if (expect && (expect->n_real != pub.n_real || expect->deferred != pub.deferred || expect->entry_point != pub.entry_point ||
                  memcmp(expect->program_digest, pub.program_digest, 16) || memcmp(expect->io_digest, pub.io_digest, 16))) return 6;
@@ -370,7 +452,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   // (mode 2) the tapes and the halt reason the io digest is a digest of: the digest with the cycle count (50; a whole run's is its row count, a chain checks the total),
   // the counters' ends (51), the halt row named by the halt reason (52 / 53)
   IoSection io;
-  if (mode == 2) {
+  if (mode >= 2) {
     if (!parse_io_section(w + p, (size_t)len - p, io)) return 4;
     p += io.words;
     if (cnt[0] > cnt[2] || cnt[1] > cnt[3] || cnt[2] > io.out.size() || cnt[3] > io.in.size()) return 51;
@@ -381,9 +463,32 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       if (hb) return hb;
     }
   }
-  if (!need(n_code + air::RC_TABLE)) return 4;
+  // (mode 3) the touched cells: [n] then per cell [address limb 0 (20 bits, a multiple of 8)] [limb 1 (20 bits)] [time of the last access] [final bytes: four 16-bit pieces],
+  // canonical and by strictly increasing address — every cell has ONE initial tuple (check 54)
+  struct Cell { uint64_t addr, bytes; uint32_t t; };
+  std::vector<Cell> cells;
+  const uint32_t* mem_words = nullptr; size_t mem_len = 0;
+  if (mode == 3) {
+    if (!need(1)) return 4;
+    const size_t nc = w[p];
+    if (nc > ((size_t)1 << 28) || !need(1 + 7 * nc)) return 4;
+    mem_words = w + p; mem_len = 1 + 7 * nc;
+    cells.resize(nc);
+    for (size_t k = 0; k < nc; k++) {
+      const uint32_t* c = w + p + 1 + 7 * k;
+      if (c[0] >= (1u << 20) || (c[0] & 7) || c[1] >= (1u << 20)) return 54;
+      uint64_t bytes = 0;
+      for (int i = 0; i < 4; i++) { if (c[3 + i] > 0xFFFF) return 54; bytes |= (uint64_t)c[3 + i] << (16 * i); }
+      cells[k] = Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), bytes, c[2]};
+      if (k && cells[k].addr <= cells[k - 1].addr) return 54;
+    }
+    p += mem_len;
+  }
+  if (!need(n_code + air::RC_TABLE + (mode == 3 ? air::MEM_MULT : 0))) return 4;
   const uint32_t* rom_mult = w + p; p += n_code;
   const uint32_t* rc_mult = w + p; p += air::RC_TABLE;
+  const uint32_t* mem_mult = nullptr;
+  if (mode == 3) { mem_mult = w + p; p += air::MEM_MULT; }
   if (!need(12)) return 4;
   const uint32_t* troot = w + p; p += 4; const uint32_t* aroot = w + p; p += 4; const uint32_t* qroot = w + p; p += 4;
   auto get_m = [&](size_t at) { E4 e; memcpy(e.c, w + at, 16); return bb::e_to_mont(e); };      // proof word -> Montgomery E4
@@ -408,8 +513,10 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   Challenger ch;
   ch.observe_n(w + 2, (size_t)HW - 2);
   ch.observe_n(troot, 4);
+  if (mode == 3) ch.observe_n(mem_words, mem_len);
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
+  if (mode == 3) ch.observe_n(mem_mult, air::MEM_MULT);
   const E4 alpha_l = bb::e_to_mont(ch.sample_ext()), lambda = bb::e_to_mont(ch.sample_ext());
   // lookup parameters (air.h LK_*), Montgomery: alpha, lambda^0..10, T / N — T is the table side of the lookup identity, computed HERE
   // from the program in the proof and the multiplicities: sum_t m_t / (alpha - t) + sum_u r_u / (alpha - fingerprint(ROM row u))
@@ -420,8 +527,26 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (int j = 1; j <= air::N_TUPLE; j++) lam[j] = bb::e_mul_m(lam[j - 1], lambda);
     for (int k = 0; k < 4; k++) lk_m[air::LK_ALPHA + k] = alpha_l.c[k];
     for (int j = 0; j <= air::N_TUPLE; j++) for (int k = 0; k < 4; k++) lk_m[air::LK_LAM + 4 * j + k] = lam[j].c[k];
-    std::vector<E4> d((size_t)air::RC_TABLE + n_code);
+    const size_t n_tab = (size_t)air::RC_TABLE + n_code;
+    std::vector<E4> d(n_tab + (mode == 3 ? (size_t)air::MEM_MULT + 2 * cells.size() : 0));
     for (int t = 0; t < air::RC_TABLE; t++) { d[t] = alpha_l; d[t].c[0] = bb::sub(d[t].c[0], bb::to_mont((uint32_t)t)); }
+    if (mode == 3) {
+      // the LOW3, BYTE and NIBBLE tables, then the two ends of the memory check: per touched cell the INITIAL tuple (time 0, the program image's bytes) and the FINAL one
+      auto tagged = [&](uint32_t v, int tag) { E4 e = bb::e_sub(alpha_l, bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)tag))); e.c[0] = bb::sub(e.c[0], bb::to_mont(v)); return e; };
+      E4* m = d.data() + n_tab;
+      for (int t = 0; t < air::RC_TABLE; t++) m[t] = bb::e_sub(tagged((uint32_t)t, air::TAG_LOW3), bb::e_mul_fm(lam[1], bb::to_mont((uint32_t)(t & 7))));
+      for (int t = 0; t < 256; t++) m[air::RC_TABLE + t] = tagged((uint32_t)t, air::TAG_BYTE);
+      for (int t = 0; t < 16; t++) m[air::RC_TABLE + 256 + t] = tagged((uint32_t)t, air::TAG_NIB);
+      auto mem_d = [&](const Cell& c, uint32_t t, uint64_t bytes) {
+        E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_MEM));
+        fp.c[0] = bb::add(fp.c[0], bb::to_mont((uint32_t)(c.addr & 0xFFFFF)));
+        fp = bb::e_add(fp, bb::e_mul_fm(lam[1], bb::to_mont((uint32_t)((c.addr >> 20) & 0xFFFFF))));
+        fp = bb::e_add(fp, bb::e_mul_fm(lam[2], bb::to_mont(t)));
+        for (int k = 0; k < 8; k++) fp = bb::e_add(fp, bb::e_mul_fm(lam[3 + k], bb::to_mont((uint32_t)((bytes >> (8 * k)) & 0xFF))));
+        return bb::e_sub(alpha_l, fp);
+      };
+      for (size_t k = 0; k < cells.size(); k++) { m[air::MEM_MULT + 2 * k] = mem_d(cells[k], 0, image_cell(blob.data(), blob_len, cells[k].addr)); m[air::MEM_MULT + 2 * k + 1] = mem_d(cells[k], cells[k].t, cells[k].bytes); }
+    }
     for (size_t u = 0; u < n_code; u++) {
       const uint32_t cw = le32(32 + 4 * u);
       const uint64_t pc = 0x1000 + 4 * (uint64_t)u;
@@ -440,11 +565,12 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (size_t i = d.size(); i-- > 0;) {
       const E4 di = bb::e_mul_m(inv, pre[i]);
       inv = bb::e_mul_m(inv, d[i]);
-      const uint32_t m = i < (size_t)air::RC_TABLE ? rc_mult[i] : rom_mult[i - air::RC_TABLE];
+      if (i >= n_tab + (size_t)air::MEM_MULT) { T = ((i - n_tab - (size_t)air::MEM_MULT) & 1) ? bb::e_sub(T, di) : bb::e_add(T, di); continue; }   // (mode 3) + initial tuple, - final tuple
+      const uint32_t m = i < (size_t)air::RC_TABLE ? rc_mult[i] : i < n_tab ? rom_mult[i - air::RC_TABLE] : mem_mult[i - n_tab];
       if (m) T = bb::e_add(T, bb::e_mul_fm(di, bb::to_mont(m)));
     }
     lk_m[air::LK_NIN] = 0;
-    if (mode == 2) {
+    if (mode >= 2) {
       // the tapes' share of the table side: every output index in [oc_first, oc_last) and every input index in [ic_first, ic_last) exactly once,
       // fingerprint = index + lambda v0 + lambda^2 v1 + lambda^3 v2 + tag lambda^N_TUPLE (tag 2 = outputs, 3 = inputs), v = the (20, 20, 24)-bit limbs of the value
       lk_m[air::LK_NIN] = bb::to_mont((uint32_t)(io.in.size() % bb::P));

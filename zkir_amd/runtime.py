@@ -91,7 +91,15 @@ class PublicInputsC(C.Structure):             # zkir_public_inputs
                 # mode 2 (`deferred` == 2: default VM mode + the I/O argument): the tapes and the halt reason in the clear (borrowed pointers: with_io()); for a SEGMENT
                 # the WRITE / READ ecalls executed before its first row
                 ("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("outputs", C.c_void_p), ("n_outputs", C.c_uint64), ("halt_kind", C.c_uint32), ("reserved2", C.c_uint32),
-                ("halt_code", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+                ("halt_code", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64),
+                # mode 3 (`deferred` == 3: mode 2 + the memory argument): the memory witness of the run (borrowed pointers into a MemcheckWitness: with_memory())
+                ("mem_old", C.c_void_p), ("mem_told", C.c_void_p), ("cell_addr", C.c_void_p), ("cell_bytes", C.c_void_p), ("cell_time", C.c_void_p), ("n_cells", C.c_uint64)]
+
+    def with_memory(self, witness: "MemcheckWitness") -> "PublicInputsC":
+        """zkir_public_inputs_set_memory: mode 3 — point the struct at the run's memory witness (kept alive by the struct)."""
+        self._mem_ref = witness
+        lib().zkir_public_inputs_set_memory(C.byref(self), witness._h)
+        return self
 
     def with_io(self, inputs, outputs, halt=None, writes_before=None, reads_before=None) -> "PublicInputsC":
         """Point the struct at its own copies of the I/O tapes (kept alive by the struct); halt = a HaltReason or (kind, code)."""
@@ -120,7 +128,39 @@ class PublicInputsC(C.Structure):             # zkir_public_inputs
     def copy(self) -> "PublicInputsC":
         q = PublicInputsC.from_buffer_copy(bytes(self))
         q.with_io(getattr(self, "_in_ref", []), getattr(self, "_out_ref", []))
+        if hasattr(self, "_mem_ref"):
+            q.with_memory(self._mem_ref)
         return q.with_program(getattr(self, "_blob_ref", b""))
+
+
+class MemcheckWitness:
+    """zkir_memcheck_witness_of: the memory witness of a whole run (mode 3) — per row the accessed 8-byte cell's bytes before the access and the time of its previous
+    access, and the touched cells; a sequential host replay (memory is a chain).  Refused for shards / windows, addresses of 2^40 or more, executed hash syscalls."""
+
+    def __init__(self, log: "DeltaLog", program):
+        blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
+        L = lib()
+        L.zkir_memcheck_witness_of.restype = C.c_int
+        L.zkir_memcheck_witness_of.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        L.zkir_memcheck_witness_free.restype = None; L.zkir_memcheck_witness_free.argtypes = [C.c_void_p]
+        L.zkir_memcheck_witness_n_cells.restype = C.c_uint64; L.zkir_memcheck_witness_n_cells.argtypes = [C.c_void_p]
+        L.zkir_memcheck_witness_n_accesses.restype = C.c_uint64; L.zkir_memcheck_witness_n_accesses.argtypes = [C.c_void_p]
+        L.zkir_public_inputs_set_memory.restype = None; L.zkir_public_inputs_set_memory.argtypes = [C.c_void_p, C.c_void_p]
+        h = C.c_void_p()
+        rc = L.zkir_memcheck_witness_of(log._h, blob, len(blob), C.byref(h))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        self._h = h
+        self.n_cells = int(L.zkir_memcheck_witness_n_cells(h))
+        self.n_accesses = int(L.zkir_memcheck_witness_n_accesses(h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().zkir_memcheck_witness_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class MemoryWitnessC(C.Structure):            # zkir_memory_witness
@@ -356,17 +396,20 @@ class DeltaLog:
             pass
 
 
-def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False, io_mode: bool = False) -> PublicInputsC:
+def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False, io_mode: bool = False, mem_mode: bool = False) -> PublicInputsC:
     """zkir_public_inputs_of: what a proof of this run is bound to (row count, mode, entry pc, program digest, io digest).  io_mode = mode 2: the default VM mode
-    with the I/O argument (WRITE / READ ecalls tied to the tapes, which the proof then carries)."""
+    with the I/O argument (WRITE / READ ecalls tied to the tapes, which the proof then carries).  mem_mode = mode 3: mode 2 with the memory argument (loads and stores
+    constrained, every access tied to a consistent memory: the run's memory witness is computed here and the proof carries the touched cells)."""
     blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
     arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
     out = PublicInputsC()
-    assert not (deferred and io_mode), "the I/O argument is stated for the default VM mode"
-    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), 2 if io_mode else int(deferred), C.byref(out))
+    assert not (deferred and (io_mode or mem_mode)), "the I/O and memory arguments are stated for the default VM mode"
+    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), 3 if mem_mode else 2 if io_mode else int(deferred), C.byref(out))
     if rc != ZKIR_OK:
         _raise(rc)
     out.with_io(list(inputs), list(log.outputs))      # the C call borrowed temporaries: re-point at arrays / bytes this struct owns
+    if mem_mode:
+        out.with_memory(MemcheckWitness(log, blob))
     return out.with_program(blob)
 
 
