@@ -323,6 +323,22 @@ def cmov_loop_program() -> Program:
     ])
 
 
+def memory_loop_program(n: int) -> Program:
+    """A loop over an array of n 8-byte cells at 0x10000 (AIR mode 3: the memory argument): cell i <- 3 i (SD), then read back as a word, an unsigned halfword at offset 2
+    and a signed byte (LW / LHU / LB: three windows of the cell just written), summed; after n iterations (13 rows each, 4 of them memory accesses) the sum is
+    WRITTEN and the run exits 0.  Run it whole, or with max_cycles for a prefix (halt = CycleLimit)."""
+    assert 1 <= n <= 65535
+    return Program.from_code([
+        addi(6, 0, 0x8000), slli(6, 6, 1), addi(1, 0, 0), addi(3, 0, n), addi(4, 0, 0),
+        # L:
+        add(2, 1, 1), add(2, 2, 1), encode(Opcode.SD, rs1=6, rs2=2, imm=0),
+        lw(7, 6, 0), encode(Opcode.LHU, 8, 6, imm=2), encode(Opcode.LB, 9, 6, imm=0),
+        add(4, 4, 7), add(4, 4, 8), add(4, 4, 9),
+        addi(6, 6, 8), addi(1, 1, 1), addi(3, 3, -1), bne(3, 0, -48),
+        addi(11, 4, 0), addi(10, 0, 2), ecall(), addi(10, 0, 0), addi(11, 0, 0), ecall(),
+    ])
+
+
 def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
     """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
     The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).
