@@ -45,7 +45,25 @@ pub struct ZkirPublicInputs {
     pub io_digest: [u32; 4],
     pub program_blob: *const u8, // borrowed: must outlive zkir_prove
     pub program_blob_len: u64,
+    // mode 2 (deferred == 2: + the I/O argument): the tapes and the halt reason in the clear (borrowed; zkir_public_inputs_of fills them)
+    pub inputs: *const u64,
+    pub n_inputs: u64,
+    pub outputs: *const u64,
+    pub n_outputs: u64,
+    pub halt_kind: u32,
+    pub reserved2: u32,
+    pub halt_code: u64,
+    pub writes_before: u64,
+    pub reads_before: u64,
+    // mode 3 (deferred == 3: + the memory argument): the run's memory witness (borrowed; zkir_public_inputs_set_memory points them at a ZkirMemcheckWitness)
+    pub mem_old: *const u64,
+    pub mem_told: *const u32,
+    pub cell_addr: *const u64,
+    pub cell_bytes: *const u64,
+    pub cell_time: *const u32,
+    pub n_cells: u64,
 }
+pub enum ZkirMemcheckWitness {}
 
 pub enum ZkirResult {}
 pub enum ZkirDeltaLog {}
@@ -68,6 +86,9 @@ extern "C" {
     fn zkir_stark_ctx_free(ctx: *mut ZkirStarkCtx);
     fn zkir_padded_log_n(n_real: u64) -> u32;
     fn zkir_public_inputs_of(log: *const ZkirDeltaLog, blob: *const u8, len: usize, inputs: *const u64, n_inputs: usize, deferred: u32, out: *mut ZkirPublicInputs) -> c_int;
+    fn zkir_memcheck_witness_of(log: *const ZkirDeltaLog, blob: *const u8, len: usize, out: *mut *mut ZkirMemcheckWitness) -> c_int;   // mode 3: the host's sequential memory replay
+    fn zkir_memcheck_witness_free(w: *mut ZkirMemcheckWitness);
+    fn zkir_public_inputs_set_memory(public: *mut ZkirPublicInputs, w: *const ZkirMemcheckWitness);                                      // sets deferred = 3
     fn zkir_prove(ctx: *const ZkirStarkCtx, trace: *const ZkirTraceColumns, public: *const ZkirPublicInputs, proof: *mut *mut u32, words: *mut u64, stage_ms: *mut f32,
                   stream: *mut c_void) -> c_int;
     fn zkir_verify(proof: *const u32, words: u64, expect: *const ZkirPublicInputs) -> c_int;
@@ -115,11 +136,24 @@ impl GpuExecutionResult {
         if rc != 0 { Err(map_error(rc)) } else { Ok(v) }
     }
     /// `prove()` of north_star: the proof words (u32 little-endian, format zkir_proof_version()) and the public inputs it is bound to.
-    pub fn prove(&self) -> Result<(Vec<u32>, ZkirPublicInputs), RuntimeError> {
+    /// Mode 0 (default VM mode) or 1 (the deferred model), as the run was configured.
+    pub fn prove(&self) -> Result<(Vec<u32>, ZkirPublicInputs), RuntimeError> { self.prove_mode(self.deferred as u32) }
+    /// mode 2 = the default VM mode + the I/O argument (the proof says what was read and written), 3 = mode 2 + the memory argument (loads / stores constrained,
+    /// memory consistent; whole runs only; refused for runs that execute a hash syscall or touch an address of 2^40 or more)
+    pub fn prove_mode(&self, mode: u32) -> Result<(Vec<u32>, ZkirPublicInputs), RuntimeError> {
         let mut public = std::mem::MaybeUninit::<ZkirPublicInputs>::uninit();
-        let rc = unsafe { zkir_public_inputs_of(self.log(), self.blob.as_ptr(), self.blob.len(), self.inputs.as_ptr(), self.inputs.len(), self.deferred as u32, public.as_mut_ptr()) };
+        let rc = unsafe { zkir_public_inputs_of(self.log(), self.blob.as_ptr(), self.blob.len(), self.inputs.as_ptr(), self.inputs.len(), mode, public.as_mut_ptr()) };
         if rc != 0 { return Err(map_error(rc)); }
-        let public = unsafe { public.assume_init() };
+        let mut public = unsafe { public.assume_init() };
+        let mut witness: *mut ZkirMemcheckWitness = std::ptr::null_mut();
+        if mode == 3 {
+            let rc = unsafe { zkir_memcheck_witness_of(self.log(), self.blob.as_ptr(), self.blob.len(), &mut witness) };
+            if rc != 0 { return Err(map_error(rc)); }
+            unsafe { zkir_public_inputs_set_memory(&mut public, witness) };
+        }
+        struct FreeWitness(*mut ZkirMemcheckWitness);
+        impl Drop for FreeWitness { fn drop(&mut self) { if !self.0.is_null() { unsafe { zkir_memcheck_witness_free(self.0) } } } }
+        let _free = FreeWitness(witness);                     // the borrowed mode-3 pointers are only read by zkir_prove below
         let mut ctx: *mut ZkirStarkCtx = std::ptr::null_mut();
         let rc = unsafe { zkir_stark_ctx_create(zkir_padded_log_n(public.n_real), 1, &mut ctx) };
         if rc != 0 { return Err(map_error(rc)); }

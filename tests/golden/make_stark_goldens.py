@@ -72,6 +72,20 @@ CMOV_LOOP = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 7), i_(ADDI, 13, 0, 1), i_(A
                   r_(CMOV, 11, 2, 10), r_(CMOVZ, 12, 7, 10), r_(CMOVNZ, 14, 9, 10), r_(CMOV, 0, 2, 13), r_(CMOVZ, 15, 2, 9), r_(CMOVNZ, 15, 7, 7), r_(CMOVZ, 4, 7, 0),
                   i_(ADDI, 11, 0, 0), i_(ADDI, 12, 0, 0), i_(ADDI, 14, 0, 0), i_(ADDI, 15, 0, 0), i_(ADDI, 4, 0, 0), r_(SUB, 10, 13, 10), i_(ADDI, 1, 1, 1), j_(JAL, 0, -56)])
 
+# (modes 2 / 3) an array loop: SD, then LW / LHU / LB windows of the cell just written, summed and WRITTEN (the product ships it as spec.memory_loop_program(40))
+SD, LHU = 0x3B, 0x33
+def s_(op, rs1, rs2, imm): return op | rs1 << 7 | rs2 << 11 | (imm & 0x1FFFF) << 15
+MEM_LOOP = blob([i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(ADDI, 1, 0, 0), i_(ADDI, 3, 0, 40), i_(ADDI, 4, 0, 0),
+                 r_(ADD, 2, 1, 1), r_(ADD, 2, 2, 1), s_(SD, 6, 2, 0), i_(LW, 7, 6, 0), i_(LHU, 8, 6, 2), i_(LB, 9, 6, 0), r_(ADD, 4, 4, 7), r_(ADD, 4, 4, 8), r_(ADD, 4, 4, 9),
+                 i_(ADDI, 6, 6, 8), i_(ADDI, 1, 1, 1), i_(ADDI, 3, 3, -1), i_(BNE, 3, 0, -48),
+                 i_(ADDI, 11, 4, 0), i_(ADDI, 10, 0, 2), ECALL, i_(ADDI, 10, 0, 0), i_(ADDI, 11, 0, 0), ECALL])
+MODE_CASES = [
+    dict(name="mode2_fib30", blob=FIB30, max_cycles=1_000_000, mode=2),
+    dict(name="mode3_fib30", blob=FIB30, max_cycles=1_000_000, mode=3),
+    dict(name="mode2_memory_loop_40", blob=MEM_LOOP, max_cycles=1_000_000, mode=2),
+    dict(name="mode3_memory_loop_40", blob=MEM_LOOP, max_cycles=1_000_000, mode=3),
+]
+
 CASES = [
     dict(name="fib_2p10", blob=FIB_ENDLESS, max_cycles=1 << 10, deferred=False),
     dict(name="sha_2p9", blob=SHA_CHAIN, max_cycles=1 << 9, deferred=False),
@@ -101,14 +115,25 @@ def golden(case):
                 proof_words=int(len(proof)), proof_sha256=hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest())
 
 
+def golden_mode(case):
+    """Modes 2 / 3 (the I/O argument; + the memory argument): the whole proof frozen by its SHA-256, the touched cells (mode 3) by count."""
+    res = oracle.run(case["blob"], max_cycles=case["max_cycles"], enable_execution_trace=True)
+    pub = so.public_inputs(len(res.rows), case["blob"], [], list(res.outputs), (res.halt_kind, res.halt_code), io_mode=case["mode"] == 2, mem_mode=case["mode"] == 3)
+    proof = so.prove(res.rows, pub)
+    assert so.verify(proof, pub) == 0 and int(proof[9]) == case["mode"]
+    return dict(name=case["name"], program_blob_hex=case["blob"].hex(), max_cycles=case["max_cycles"], mode=case["mode"], n_rows=len(res.rows), outputs=[int(x) for x in res.outputs],
+                halt=[int(res.halt_kind), int(res.halt_code)], committed_width=int(proof[3]), n_cells=int(len(so.mem_cells(res.rows, pub))) if case["mode"] == 3 else 0,
+                proof_words=int(len(proof)), proof_sha256=hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest())
+
+
 if __name__ == "__main__":
-    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v4, proof format v8; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
+    out = {"_about": "frozen outputs of ZKIR-STARK (AIR v6 + modes 2 / 3, proof format v10; self-defined stages: these values freeze drift, they pin nothing; see make_stark_goldens.py)",
            "proof_version": 10, "main_trace_width": so.W_MAIN, "committed_width": so.W_COMMITTED, "committed_width_deferred": so.W_COMMITTED_DEFERRED, "num_constraints": so.lib().so_num_constraints(),
            "poseidon2_of_0_to_11": [int(x) for x in so.permute(list(range(12)))],
-           "cases": [golden(c) for c in CASES]}
+           "cases": [golden(c) for c in CASES], "mode_cases": [golden_mode(c) for c in MODE_CASES]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stark_goldens.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)
-    for c in out["cases"]:
-        print(f'  {c["name"]:24s} rows {c["n_rows"]:5d}  root {c["trace_root"]}  proof {c["proof_words"]} words  sha256 {c["proof_sha256"][:16]}..')
+    for c in out["cases"] + out["mode_cases"]:
+        print(f'  {c["name"]:24s} rows {c["n_rows"]:5d}  root {c.get("trace_root", "-")}  proof {c["proof_words"]} words  sha256 {c["proof_sha256"][:16]}..')

@@ -40,12 +40,17 @@
 //     boolean carries / borrows / sign bits the only solution;
 //   the prover sends the multiplicities of both tables BEFORE the challenges (alpha, lambda) are drawn; the verifier computes the table
 //   side T = sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u) itself; the running-sum column closes over the cycle of N rows.
-// Not constrained IN THE AIR: WHICH instruction the halt row is — I_HALT only forces class "halt" onto the public last row, any row can be it —
+// Not constrained IN THE AIR in modes 0 / 1: WHICH instruction the halt row is — I_HALT only forces class "halt" onto the public last row, any row can be it —
 // and the io digest (inputs, outputs, halt reason, cycle count: bound into the transcript, never opened by a constraint).  The halt half is closed OUTSIDE the AIR by
-// zkir_verify_io (verify.cpp): given the claim in the clear it checks the digest and that the public last state sits on the EBREAK / exit-ECALL the claim names; the
-// outputs stay unproven.  Also not constrained: the VALUES the other 30 opcodes write (MUL / DIV / logic / shifts / loads / ECALL: class "other", y is a free
-// in-range witness), memory consistency, the SHA-256 chip, deferred-mode arithmetic (deferred = 1 relaxes the write constraints to "unwritten
-// registers keep their value"; branches and jumps run as the free-pc class "oj" there, which no default-mode row can be).
+// zkir_verify_io (verify.cpp): given the claim in the clear it checks the digest and that the public last state sits on the EBREAK / exit-ECALL the claim names.
+// Also not constrained there: the VALUES the other 30 opcodes write (MUL / DIV / logic / shifts / loads / ECALL: class "other", y is a free in-range witness),
+// memory consistency, the SHA-256 chip, deferred-mode arithmetic (deferred = 1 relaxes the write constraints to "unwritten registers keep their value"; branches and jumps
+// run as the free-pc class "oj" there, which no default-mode row can be).
+// ROUND 4 — two opt-in MODES append columns and constraints to the default-mode list (modes 0 / 1 are unchanged):
+//   MODE 2 = the I/O argument: ECALL's READ / WRITE / EXIT constrained, the outputs and consumed inputs tied to tapes the proof carries, the halt row bound (the verifier does
+//            zkir_verify_io's checks itself);
+//   MODE 3 = mode 2 + the memory argument: the ten loads and stores constrained (30 of 50 opcodes now carry their semantics), every access one step of an offline memory
+//            check over 8-byte cells.  Left free there: MUL / MULH / DIV / REM / logic / shifts (class "other"), hash syscalls (forbidden: fh = 0), the SHA-256 chip.
 #pragma once
 #include "babybear.h"
 
