@@ -163,6 +163,9 @@ impl GpuExecutionResult {
         if rc != 0 { return Err(map_error(rc)); }
         let out = unsafe { std::slice::from_raw_parts(proof, words as usize) }.to_vec();
         unsafe { zkir_proof_free(proof) };
+        // the returned struct is what a verifier's `expect` needs (row count, mode, entry point, digests); the prover-side borrowed pointers end with this call
+        public.mem_old = std::ptr::null(); public.mem_told = std::ptr::null(); public.cell_addr = std::ptr::null(); public.cell_bytes = std::ptr::null();
+        public.cell_time = std::ptr::null(); public.n_cells = 0;
         Ok((out, public))
     }
 }
