@@ -790,6 +790,13 @@ struct Challenger {
   }
 };
 
+// (mode 3) a long section of the proof (the touched cells: seven words per cell) enters the transcript through a two-level sponge: the words are cut into chunks of
+// SECTION_CHUNK, every chunk is hashed on its own (hash_elems: the chunks are independent — the prover hashes them in parallel on the device) and the chunk digests are
+// observed in order.  Binding like observing the words themselves, at 1 / 128 of the sequential permutations.
+static const size_t SECTION_CHUNK = 512;
+static void observe_section(Challenger& ch, const uint32_t* w, size_t n) {
+  for (size_t at = 0; at < n; at += SECTION_CHUNK) { F dg[DIGEST]; hash_elems(w + at, std::min(SECTION_CHUNK, n - at), dg); ch.observe_n(dg, DIGEST); }
+}
 // ---- the AIR: Σ_c alpha^c C_c over one (local, next) row pair; values as E (base-field rows are lifted) ----
 // is_first = Z_H(x)/(x - 1), is_last = Z_H(x)/(x - w^(n_real-1)) (the last EXECUTED row), is_trans = x - w^-1.
 // Every constraint has degree <= 2 in the columns (x is_trans) or degree 1 (x is_first / is_last): the quotient has degree < N.
@@ -1236,7 +1243,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   w.push_back((uint32_t)pub.blob_len);
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
   if (Dm >= 2) io_section(pub, w);                                         // the tapes and the halt reason: what the io digest is a digest of
-  if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); ch.observe_n(w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
+  if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
   lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult, nullptr, Dm, &pt.mem_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
   w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
@@ -1532,7 +1539,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   Challenger ch;
   ch.observe_n(w + 2, HW - 2);
   ch.observe_n(troot, 4);
-  if (mode == 3) ch.observe_n(mem_words, mem_len);
+  if (mode == 3) observe_section(ch, mem_words, mem_len);
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
   if (mode == 3) ch.observe_n(mem_mult, MEM_MULT);

@@ -309,7 +309,7 @@ def test_memcheck_witness_and_main_trace_mode3_match_oracle_on_the_host(name):
     rows, nr = res.rows, len(res.rows)
     log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True, **cfg))
     assert log.n_rows == nr
-    pub = rt.public_inputs(log, blob, list(ins), mem_mode=True)
+    pub = rt.public_inputs(log, blob, list(ins), mem_mode=True, mem_witness="host")
     opub = so.public_inputs(nr, blob, list(ins), list(res.outputs), (res.halt_kind, res.halt_code), mem_mode=True)
     assert pub.deferred == 3 and list(pub.io_digest) == list(opub.io)
     want_cells = so.mem_cells(rows, opub)
@@ -348,12 +348,12 @@ def test_memcheck_witness_refuses_runs_outside_the_air():
     blob, ins, _ = pg.sha256_hello()
     log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True))
     with pytest.raises(Exception, match="hash syscall"):
-        rt.public_inputs(log, blob, list(ins), mem_mode=True)
+        rt.public_inputs(log, blob, list(ins), mem_mode=True, mem_witness="host")
     O, E = spec.Opcode, spec.encode                                      # LB sign-extends 0x80 to 64 bits (Q1): the next load's address is 0xFFFF_FFFF_FFFF_FF80
     blob = pg._p([pg.A(5, 0, 0x4000), pg.A(1, 0, 0x80), E(O.SB, rs1=5, rs2=1, imm=0), E(O.LB, 1, 5, imm=0), spec.lw(2, 1, 0), pg.EB])
     log = rt.interpret(blob, [], rt.VMConfig(enable_execution_trace=True))
     with pytest.raises(Exception, match="2\\^40"):
-        rt.public_inputs(log, blob, [], mem_mode=True)
+        rt.public_inputs(log, blob, [], mem_mode=True, mem_witness="host")
     blob, ins, _ = pg.fib30()
     log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True))
     shard = log.shard(10, 20) if hasattr(log, "shard") else None

@@ -528,7 +528,7 @@ def test_mode2_forged_outputs_are_rejected_on_the_gpu_path():
 
 
 # ---- MODE 3 (round 4): mode 2 + the memory argument ------------------------------------------------------------------------------------------------------------
-def _mode3_case(which):
+def _mode3_case(which, witness="device"):
     from zkir_amd import pipeline as pl
     import programs as pg
     cfg = {}
@@ -544,17 +544,19 @@ def _mode3_case(which):
     assert log.n_rows == len(ores.rows)
     ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
     opub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), mem_mode=True)
-    pub = rt.public_inputs(log, blob, list(ins), mem_mode=True)
+    pub = rt.public_inputs(log, blob, list(ins), mem_mode=True, mem_witness=witness)
     assert pub.deferred == 3 and list(pub.io_digest) == list(opub.io)
     return blob, list(ins), ores, log, tr, opub, pub
 
 
-@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "echo5", "fib30", "random3", "random5", "memloop"])
-def test_mode3_proof_bytes_match_oracle_and_verify(which):
+@pytest.mark.parametrize("witness", ["device", "host"])
+@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "echo5", "fib30", "random3", "random5", "memloop", "q9_access_at_own_pc"])
+def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     """A proof in mode 3 — loads and stores constrained, every access one step of the offline memory check, the touched cells carried — from the GPU prover equals the
-    oracle's word for word; both verifiers accept it and give the same verdict on tampered copies."""
+    oracle's word for word; both verifiers accept it and give the same verdict on tampered copies.  The memory witness comes from the device (memcheck.hip: address-major
+    sort + segmented scan) or from the host's sequential replay: the same proof either way."""
     from zkir_amd import stark
-    blob, ins, ores, log, tr, opub, pub = _mode3_case(which)
+    blob, ins, ores, log, tr, opub, pub = _mode3_case(which, witness)
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
     proof = stark.prove(ctx, tr, pub)
     want = so.prove(ores.rows, opub)
@@ -576,9 +578,12 @@ def test_mode3_forged_memory_is_rejected_on_the_gpu_path():
     the main trace kernel just builds what it is given — but the multiset equation does not close, and both verifiers reject the proof (10).  A forged final cell likewise."""
     import ctypes as C
     from zkir_amd import stark
-    blob, ins, ores, log, tr, opub, pub = _mode3_case("timestamps")          # sw [A] <- 0x100; sw [A + 4] <- 0x200; lw A; lw A + 4: one cell, four accesses (rows 2, 4, 5, 6)
+    blob, ins, ores, log, tr, opub, pub = _mode3_case("timestamps", "host")  # sw [A] <- 0x100; sw [A + 4] <- 0x200; lw A; lw A + 4: one cell, four accesses (rows 2, 4, 5, 6)
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
     assert rt.verify(stark.prove(ctx, tr, pub), pub) == 0
+    with pytest.raises(Exception, match="hash syscall"):                       # the device witness refuses what the host replay refuses
+        b2, i2, o2, l2, t2, op2, p2 = _mode3_case("sha256_hello")
+        stark.prove(stark.StarkContext(stark.padded_log_n(len(o2.rows))), t2, p2)
     n = len(ores.rows)
     old = np.ctypeslib.as_array(C.cast(pub.mem_old, C.POINTER(C.c_uint64)), (n,)).copy()
     told = np.ctypeslib.as_array(C.cast(pub.mem_told, C.POINTER(C.c_uint32)), (n,)).copy()
@@ -608,10 +613,14 @@ def test_mode3_at_scale():
     blob = spec.memory_loop_program(1 << 15).to_bytes()
     log = rt.interpret(blob, [], rt.VMConfig(max_cycles=1 << 18, enable_execution_trace=True))
     ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
-    t0 = time.perf_counter(); pub = rt.public_inputs(log, blob, [], mem_mode=True); t_wit = time.perf_counter() - t0
+    t0 = time.perf_counter(); hpub = rt.public_inputs(log, blob, [], mem_mode=True, mem_witness="host"); t_wit = time.perf_counter() - t0
+    pub = rt.public_inputs(log, blob, [], mem_mode=True)
     ctx = stark.StarkContext(stark.padded_log_n(log.n_rows))
     stark.prove(ctx, tr, pub)
     t0 = time.perf_counter(); proof = stark.prove(ctx, tr, pub); t_prove = time.perf_counter() - t0
-    print(f"mode 3, {log.n_rows} rows, {pub.n_cells} cells: memory witness {t_wit * 1e3:.1f} ms (host), prove {t_prove * 1e3:.1f} ms, proof {len(proof) * 4 / 1024:.0f} KiB")
+    t0 = time.perf_counter(); hproof = stark.prove(ctx, tr, hpub); t_hprove = time.perf_counter() - t0
+    print(f"mode 3, {log.n_rows} rows, {hpub.n_cells} cells: prove {t_prove * 1e3:.1f} ms with the memory witness made on the device; host replay {t_wit * 1e3:.1f} ms + prove {t_hprove * 1e3:.1f} ms; "
+          f"proof {len(proof) * 4 / 1024:.0f} KiB")
+    assert np.array_equal(proof, hproof)
     assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0
     ctx.close(); log.close()

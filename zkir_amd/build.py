@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libzkir_amd.so")
 OBJ = os.path.join(HERE, "build")
 
 HOST_SOURCES = ["interp.cpp", "hashes.cpp", "verify.cpp"]
-HIP_SOURCES = ["trace_fill.hip", "witness.hip", "ntt.hip", "stark.hip", "abi.hip"]
+HIP_SOURCES = ["trace_fill.hip", "witness.hip", "ntt.hip", "stark.hip", "memcheck.hip", "abi.hip"]
 HEADERS = ["host.h", "babybear.h", "poseidon2.h", "air.h", "stark_prove.inl", os.path.join("..", "..", "include", "zkir_amd.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

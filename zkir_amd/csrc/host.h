@@ -143,6 +143,11 @@ void blake3(const uint8_t* data, size_t len, uint8_t out[32]);
 
 void set_last_error(const Status& st);
 
+// memcheck.hip — the memory witness of AIR mode 3 on the device: address-major sort of the accesses + a segmented scan per cell (rocPRIM primitives, this repo's kernels)
+size_t memcheck_scratch_bytes(uint64_t n_real, uint64_t image_len);
+int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint8_t* blob, size_t blob_len, void* scratch, size_t scratch_bytes, uint64_t* mem_old, uint32_t* mem_told,
+                    std::vector<uint64_t>& cell_addr, std::vector<uint64_t>& cell_bytes, std::vector<uint32_t>& cell_time, void* hip_stream);
+
 // ntt.hip — coset LDE of `width` columns (device pointers; tables owned by zkir_stark_ctx, all in Montgomery form)
 struct LdeTables {
   int log_n;

@@ -288,6 +288,58 @@ __global__ __launch_bounds__(NT) void mem_tables_kernel(const ProveParams* __res
   d.c[0] = bb::sub(d.c[0], bb::to_mont(v));
   inv_mem[t] = bb::e_inv_m(d);
 }
+// (mode 3) the chunk digests of a long proof section (so::observe_section: chunks of 512 words, each hashed on its own with the rate-8 overwrite sponge, so::hash_elems): one
+// lane per chunk, 64 sequential permutations each — on the host the touched-cell list of a memory-heavy run (seven words per cell) cost more than the rest of the proof
+constexpr uint32_t SECTION_CHUNK = 512;
+__global__ __launch_bounds__(64) void section_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ w, uint64_t n_words, uint32_t* __restrict__ digests) {
+  const uint64_t c = (uint64_t)blockIdx.x * 64 + threadIdx.x, at = c * SECTION_CHUNK;
+  if (at >= n_words) return;
+  const uint64_t len = n_words - at < SECTION_CHUNK ? n_words - at : SECTION_CHUNK;
+  uint32_t st[p2::T];
+#pragma unroll
+  for (int i = 0; i < p2::T; i++) st[i] = 0;
+  for (uint64_t off = 0; off < len; off += p2::RATE) {
+#pragma unroll
+    for (int i = 0; i < p2::RATE; i++) if (off + i < len) st[i] = bb::to_mont(w[at + off + i]);
+    p2::permute(st, *cp);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[4 * c + i] = bb::from_mont(st[i]);
+}
+// (mode 3) the two ends of the memory check, the VERIFIER's share of the table side, formed on the device: per touched cell + 1 / (alpha - fp(cell, time 0, the program image's
+// bytes)) - 1 / (alpha - fp(cell, final time, final bytes)), summed per workgroup (the host adds the partial sums).  image = the program's code + data bytes (loaded at 0x1000).
+__global__ __launch_bounds__(NT) void mem_cells_sum_kernel(const uint64_t* __restrict__ addr, const uint64_t* __restrict__ bytes, const uint32_t* __restrict__ time, uint32_t n_cells,
+                                                            const uint8_t* __restrict__ image, uint64_t image_len, const ProveParams* __restrict__ pp, E4* __restrict__ partial) {
+  __shared__ E4 red[NT];
+  const uint32_t k = blockIdx.x * NT + threadIdx.x;
+  E4 term = bb::e_zero();
+  if (k < n_cells) {
+    const uint64_t a = addr[k];
+    uint64_t img = 0;
+    for (int b = 0; b < 8; b++) { const uint64_t x = a + b; if (x >= 0x1000 && x - 0x1000 < image_len) img |= (uint64_t)image[x - 0x1000] << (8 * b); }
+    auto tuple_inv = [&](uint32_t t, uint64_t by) {
+      const uint32_t g[11] = {(uint32_t)(a & 0xFFFFF), (uint32_t)((a >> 20) & 0xFFFFF), t, (uint32_t)(by & 0xFF), (uint32_t)((by >> 8) & 0xFF), (uint32_t)((by >> 16) & 0xFF), (uint32_t)((by >> 24) & 0xFF),
+                              (uint32_t)((by >> 32) & 0xFF), (uint32_t)((by >> 40) & 0xFF), (uint32_t)((by >> 48) & 0xFF), (uint32_t)(by >> 56)};
+      E4 d;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) {
+        uint32_t f = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + c4], bb::to_mont((uint32_t)air::TAG_MEM));
+#pragma unroll
+        for (int j = 0; j < 11; j++) f = bb::add(f, bb::mont_mul(pp->lk[air::LK_LAM + 4 * j + c4], bb::to_mont(g[j])));
+        d.c[c4] = bb::sub(pp->lk[air::LK_ALPHA + c4], f);
+      }
+      return bb::e_inv_m(d);
+    };
+    term = bb::e_sub(tuple_inv(0, img), tuple_inv(time[k], bytes[k]));
+  }
+  red[threadIdx.x] = term;
+  __syncthreads();
+  for (uint32_t off = NT / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = bb::e_add(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
 // (mode 3) the memory columns of the aux trace, every row: P0..P8 (table reads), FPN = sum_k lambda^(3+k) (new byte k), and on load / store rows HMR = 1 / (alpha - fp(cell,
 // told, old bytes)), HMW = 1 / (alpha - fp(cell, cycle + 1, new bytes)), H0 re-read from the LOW3 table; the row's running-sum increment (S slot, written by aux_rows_kernel)
 // gains P0 + .. + P8 + HMR - HMW (and H0's correction).  Blocks A_P / 8 ..: P0 | P1, P2 | P3, P4 | P5, P6 | P7, P8 | HMR, HMW | FPN.
@@ -809,8 +861,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const bool IO = MODE >= 2, MEM = MODE == 3;
   const bool DEF = MODE == 1;
   const int WM = air::committed_width(MODE), WA = air::aux_width(MODE), WT = WM + WA;     // this proof's committed main-trace / aux columns
-  if (MEM && (!pub->mem_old || !pub->mem_told || (pub->n_cells && (!pub->cell_addr || !pub->cell_bytes || !pub->cell_time)) || pub->n_cells >= (1u << 28) || pub->writes_before || pub->reads_before)) {
-    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: mode 3 proves a WHOLE run and needs its memory witness in the public inputs (zkir_memcheck_witness_of + zkir_public_inputs_set_memory)"});
+  // (mode 3) the memory witness: computed HERE on the device (memcheck.hip) unless the caller brings one (pub->mem_old != NULL: zkir_memcheck_witness_of's host replay — the
+  // independent implementation the tests compare with — or a forged one)
+  const bool MEM_HOST = MEM && pub->mem_old != nullptr;
+  if (MEM && (pub->writes_before || pub->reads_before || (MEM_HOST && (!pub->mem_told || (pub->n_cells && (!pub->cell_addr || !pub->cell_bytes || !pub->cell_time)) || pub->n_cells >= (1u << 28))))) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: mode 3 proves a WHOLE run; a memory witness passed in the public inputs must be complete (zkir_memcheck_witness_of + zkir_public_inputs_set_memory)"});
     return ZKIR_ERR_ARGUMENT;
   }
   if (IO && ((!pub->inputs && pub->n_inputs) || (!pub->outputs && pub->n_outputs) || pub->n_inputs >= (1u << 28) || pub->n_outputs >= (1u << 28) || pub->halt_kind > 2)) {
@@ -849,7 +904,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
     const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0)) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
-                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 : 0);
+                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)N * 60 + blob_len + (1u << 16) : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -866,9 +921,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   ProveParams* dPP;
   IoEntry* dIo = nullptr; uint32_t* dIoCount = nullptr; uint64_t* dInputs = nullptr; uint32_t* dIoScratch = nullptr;
   uint64_t* dMemOld = nullptr; uint32_t* dMemTold = nullptr; uint4* dMemSide = nullptr; E4* dInvMem = nullptr;
+  uint64_t *dCellAddr = nullptr, *dCellBytes = nullptr; uint32_t* dCellTime = nullptr; uint8_t* dImage = nullptr; E4* dCellPart = nullptr; uint32_t* dSec = nullptr;
   HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS + 4)); HIP_OK(ar.take(&dBad, 1));
   if (IO) { HIP_OK(ar.take(&dIo, N)); HIP_OK(ar.take(&dIoCount, 4)); HIP_OK(ar.take(&dInputs, (size_t)pub->n_inputs + 1)); HIP_OK(ar.take(&dIoScratch, 2 * N + 2 * (N / 1024 + 2))); }
-  if (MEM) { HIP_OK(ar.take(&dMemOld, N)); HIP_OK(ar.take(&dMemTold, N)); HIP_OK(ar.take(&dMemSide, 2 * N)); HIP_OK(ar.take(&dInvMem, air::MEM_MULT)); }
+  if (MEM) {
+    HIP_OK(ar.take(&dMemOld, N)); HIP_OK(ar.take(&dMemTold, N)); HIP_OK(ar.take(&dMemSide, 2 * N)); HIP_OK(ar.take(&dInvMem, air::MEM_MULT));
+    HIP_OK(ar.take(&dCellAddr, N)); HIP_OK(ar.take(&dCellBytes, N)); HIP_OK(ar.take(&dCellTime, N)); HIP_OK(ar.take(&dImage, (size_t)blob_len + 1)); HIP_OK(ar.take(&dCellPart, N / NT + 1));
+    HIP_OK(ar.take(&dSec, 8 * N + 4096));                      // the memory section (seven words per touched cell) and its chunk digests
+  }
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dA, WA * N)); HIP_OK(ar.take(&dAL, WA * N2)); HIP_OK(ar.take(&dATree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dSide, N)); HIP_OK(ar.take(&dSums, N / SCAN_ROWS + 1));
@@ -887,12 +947,22 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 1. main trace, lookup indices + multiplicities, LDE, trace commitment ---------------------------------------------------
   mark(0);
   int rc;
+  std::vector<uint64_t> cell_addr_v, cell_bytes_v; std::vector<uint32_t> cell_time_v;     // (mode 3) the touched cells: the device witness's, or the caller's
   if (IO) {
     if (pub->n_inputs) HIP_OK(hipMemcpyAsync(dInputs, pub->inputs, (size_t)pub->n_inputs * 8, hipMemcpyHostToDevice, s));
     const zkir_io_args io{dInputs, pub->n_inputs, pub->writes_before, pub->reads_before};
     if (MEM) {
-      HIP_OK(hipMemcpyAsync(dMemOld, pub->mem_old, (size_t)pub->n_real * 8, hipMemcpyHostToDevice, s));
-      HIP_OK(hipMemcpyAsync(dMemTold, pub->mem_told, (size_t)pub->n_real * 4, hipMemcpyHostToDevice, s));
+      if (MEM_HOST) {
+        HIP_OK(hipMemcpyAsync(dMemOld, pub->mem_old, (size_t)pub->n_real * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(dMemTold, pub->mem_told, (size_t)pub->n_real * 4, hipMemcpyHostToDevice, s));
+        cell_addr_v.assign(pub->cell_addr, pub->cell_addr + pub->n_cells); cell_bytes_v.assign(pub->cell_bytes, pub->cell_bytes + pub->n_cells); cell_time_v.assign(pub->cell_time, pub->cell_time + pub->n_cells);
+      } else {
+        // scratch = the LDE output buffer, which nothing has written yet (WM * 2N words: 1600 B per row against the ~70 B per row the witness needs)
+        const size_t need = zkir::memcheck_scratch_bytes(pub->n_real, blob_len);
+        if (need > (size_t)WM * N2 * 4) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: memcheck scratch does not fit the LDE buffer"}); return ZKIR_ERR_OTHER; }
+        rc = zkir::memcheck_device(trace, pub->n_real, blob, blob_len, dL, (size_t)WM * N2 * 4, dMemOld, dMemTold, cell_addr_v, cell_bytes_v, cell_time_v, s);
+        if (rc) return rc;
+      }
       rc = zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
     } else rc = zkir_main_trace_io_launch(trace, pub->n_real, &io, dIoScratch, dM, s);
   } else rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s);
@@ -934,16 +1004,26 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   Challenger ch(c->consts);
   ch.observe_n(head.data() + 2, head.size() - 2);
   ch.observe_n(troot, 4);
+  const uint64_t n_cells_v = cell_addr_v.size();
   std::vector<uint32_t> mem_sec;                              // (mode 3) the touched cells as the proof carries them: fixed before the lookup challenges like the multiplicities
   if (MEM) {
-    mem_sec.push_back((uint32_t)pub->n_cells);
-    for (uint64_t k = 0; k < pub->n_cells; k++) {
-      const uint64_t a = pub->cell_addr[k], b = pub->cell_bytes[k];
-      if ((a & 7) || (a >> 40) || (k && a <= pub->cell_addr[k - 1])) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the touched cells must be multiples of 8 below 2^40 in strictly increasing order"}); return ZKIR_ERR_ARGUMENT; }
-      mem_sec.push_back((uint32_t)(a & 0xFFFFF)); mem_sec.push_back((uint32_t)((a >> 20) & 0xFFFFF)); mem_sec.push_back(pub->cell_time[k]);
+    mem_sec.push_back((uint32_t)n_cells_v);
+    for (uint64_t k = 0; k < n_cells_v; k++) {
+      const uint64_t a = cell_addr_v[k], b = cell_bytes_v[k];
+      if ((a & 7) || (a >> 40) || (k && a <= cell_addr_v[k - 1])) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the touched cells must be multiples of 8 below 2^40 in strictly increasing order"}); return ZKIR_ERR_ARGUMENT; }
+      mem_sec.push_back((uint32_t)(a & 0xFFFFF)); mem_sec.push_back((uint32_t)((a >> 20) & 0xFFFFF)); mem_sec.push_back(cell_time_v[k]);
       for (int i = 0; i < 4; i++) mem_sec.push_back((uint32_t)((b >> (16 * i)) & 0xFFFF));
     }
-    ch.observe_n(mem_sec.data(), mem_sec.size());
+    // the section enters the transcript through its chunk digests (so::observe_section), hashed in parallel on the device
+    const size_t n_chunks_sec = (mem_sec.size() + SECTION_CHUNK - 1) / SECTION_CHUNK;
+    if (mem_sec.size() + 4 * n_chunks_sec + 64 > 8 * (size_t)N + 4096) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than the workspace holds"}); return ZKIR_ERR_ARGUMENT; }
+    uint32_t* dSecDg = dSec + ((mem_sec.size() + 63) & ~(size_t)63);
+    HIP_OK(hipMemcpyAsync(dSec, mem_sec.data(), mem_sec.size() * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)mem_sec.size(), dSecDg);
+    std::vector<uint32_t> sec_dg(4 * n_chunks_sec);
+    HIP_OK(hipMemcpyAsync(sec_dg.data(), dSecDg, sec_dg.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    ch.observe_n(sec_dg.data(), sec_dg.size());
   }
   ch.observe_n(mult.data(), mult.size());                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
   std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
@@ -968,32 +1048,24 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (uint32_t u = 0; u < n_code; u++) if (mult[u]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + u], bb::to_mont(mult[u] % bb::P)));
     if (MEM) {
       // LOW3 | BYTE | NIBBLE, then the two ends of the memory check, formed like the verifier will form them: per touched cell + 1 / (alpha - fp(cell, time 0, the program
-      // image's bytes)) - 1 / (alpha - fp(cell, final time, final bytes)) (oracle: so::mem_table_sum); batch inversion on the host (one e_inv_m, three products per tuple)
+      // image's bytes)) - 1 / (alpha - fp(cell, final time, final bytes)) (oracle: so::mem_table_sum) — on the device (mem_cells_sum_kernel), the host adds the partial sums
       const size_t m0 = (size_t)n_code + air::RC_TABLE;
       for (int t = 0; t < air::MEM_MULT; t++) if (mult[m0 + t]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + n_code + t], bb::to_mont(mult[m0 + t] % bb::P)));
-      auto image_cell = [&](uint64_t addr) {
+      if (n_cells_v) {
+        if (n_cells_v > N) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than rows"}); return ZKIR_ERR_ARGUMENT; }
         uint32_t code_size, data_size; memcpy(&code_size, blob + 16, 4); memcpy(&data_size, blob + 20, 4);
-        uint64_t v = 0;
-        if (32 + (uint64_t)code_size + data_size <= blob_len) for (int k = 0; k < 8; k++) { const uint64_t a = addr + k; if (a >= 0x1000 && a - 0x1000 < (uint64_t)code_size + data_size) v |= (uint64_t)blob[32 + (a - 0x1000)] << (8 * k); }
-        return v;
-      };
-      auto mem_d = [&](uint64_t addr, uint32_t t, uint64_t bytes) {
-        const uint32_t g[11] = {(uint32_t)(addr & 0xFFFFF), (uint32_t)((addr >> 20) & 0xFFFFF), t, (uint32_t)(bytes & 0xFF), (uint32_t)((bytes >> 8) & 0xFF), (uint32_t)((bytes >> 16) & 0xFF),
-                                (uint32_t)((bytes >> 24) & 0xFF), (uint32_t)((bytes >> 32) & 0xFF), (uint32_t)((bytes >> 40) & 0xFF), (uint32_t)((bytes >> 48) & 0xFF), (uint32_t)(bytes >> 56)};
-        E4 d;
-        for (int c4 = 0; c4 < 4; c4++) {
-          uint32_t f = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + c4], bb::to_mont((uint32_t)air::TAG_MEM));
-          for (int j = 0; j < 11; j++) f = bb::add(f, bb::mont_mul(pp->lk[air::LK_LAM + 4 * j + c4], bb::to_mont(g[j])));
-          d.c[c4] = bb::sub(pp->lk[air::LK_ALPHA + c4], f);
-        }
-        return d;
-      };
-      std::vector<E4> d(2 * (size_t)pub->n_cells), pre(2 * (size_t)pub->n_cells);
-      for (uint64_t k = 0; k < pub->n_cells; k++) { d[2 * k] = mem_d(pub->cell_addr[k], 0, image_cell(pub->cell_addr[k])); d[2 * k + 1] = mem_d(pub->cell_addr[k], pub->cell_time[k], pub->cell_bytes[k]); }
-      E4 acc = bb::e_one_m();
-      for (size_t k = 0; k < d.size(); k++) { pre[k] = acc; acc = bb::e_mul_m(acc, d[k]); }
-      E4 iv = d.empty() ? bb::e_one_m() : bb::e_inv_m(acc);
-      for (size_t k = d.size(); k-- > 0;) { const E4 dk = bb::e_mul_m(iv, pre[k]); iv = bb::e_mul_m(iv, d[k]); T = (k & 1) ? bb::e_sub(T, dk) : bb::e_add(T, dk); }
+        const uint64_t image_len = 32 + (uint64_t)code_size + data_size <= blob_len ? (uint64_t)code_size + data_size : 0;
+        if (image_len) HIP_OK(hipMemcpyAsync(dImage, blob + 32, image_len, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(dCellAddr, cell_addr_v.data(), n_cells_v * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(dCellBytes, cell_bytes_v.data(), n_cells_v * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(dCellTime, cell_time_v.data(), n_cells_v * 4, hipMemcpyHostToDevice, s));
+        const unsigned nb = grid_for(n_cells_v);
+        hipLaunchKernelGGL(mem_cells_sum_kernel, dim3(nb), dim3(NT), 0, s, dCellAddr, dCellBytes, dCellTime, (uint32_t)n_cells_v, dImage, image_len, dPP, dCellPart);
+        std::vector<E4> part(nb);
+        HIP_OK(hipMemcpyAsync(part.data(), dCellPart, (size_t)nb * sizeof(E4), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        for (const E4& e : part) T = bb::e_add(T, e);
+      }
     }
     if (IO) {
       // the tapes' share of the table side, formed like the verifier will form it: every output index in [oc_first, oc_last) and every input index in

@@ -513,7 +513,8 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   Challenger ch;
   ch.observe_n(w + 2, (size_t)HW - 2);
   ch.observe_n(troot, 4);
-  if (mode == 3) ch.observe_n(mem_words, mem_len);
+  if (mode == 3)                                                           // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section)
+    for (size_t at = 0; at < mem_len; at += 512) { uint32_t dg[4]; hash_elems(mem_words + at, mem_len - at < 512 ? mem_len - at : 512, dg); ch.observe_n(dg, 4); }
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
   if (mode == 3) ch.observe_n(mem_mult, air::MEM_MULT);
