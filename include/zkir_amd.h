@@ -362,8 +362,10 @@ typedef struct zkir_public_inputs {
   uint64_t halt_code;
   uint64_t writes_before, reads_before;
   /* MODE 3 (`deferred` == 3, round 4): mode 2 WITH the memory argument — loads and stores are constrained and every access is tied to a consistent memory (air.h "MODE 3").
-   * PROVER side (BORROWED, set by zkir_public_inputs_set_memory from a zkir_memcheck_witness; ignored in a verifier's `expect`): per ROW the bytes of the accessed 8-byte cell
-   * before the access and the time of the cell's previous access (0 on rows that are no load / store), and the touched cells by increasing address — the proof carries those. */
+   * PROVER side (ignored in a verifier's `expect`).  mem_old == NULL (what zkir_public_inputs_of leaves): zkir_prove computes the run's memory witness ON THE DEVICE
+   * (memcheck.hip: the accesses sorted address-major, a segmented scan per cell).  Otherwise BORROWED pointers set by zkir_public_inputs_set_memory from a zkir_memcheck_witness
+   * (the host's independent replay): per ROW the bytes of the accessed 8-byte cell before the access and the time of the cell's previous access (0 on rows that are no load /
+   * store), and the touched cells by increasing address.  The proof carries the touched cells either way. */
   const uint64_t* mem_old;     /* [n_real] */
   const uint32_t* mem_told;    /* [n_real] */
   const uint64_t* cell_addr;   /* [n_cells] multiples of 8 below 2^40, strictly increasing */
@@ -406,7 +408,8 @@ uint32_t zkir_proof_version(void);
  * malformed, 6 public inputs differ from `expect`, 7 the run does not start in the VM's initial state (cycle 0, entry point, zero
  * registers), 8 the program carried in the proof is malformed or is not the one program_digest / entry_point name, 10 constraints at
  * zeta (incl. the lookup argument: the verifier computes the table side from that program and the multiplicities in the proof), 11 final
- * codeword degree, 12 grinding, 20-27 query / Merkle / FRI checks, 30 length).
+ * codeword degree, 12 grinding, 20-27 query / Merkle / FRI checks, 30 length; modes 2 / 3 also 50-53 = zkir_verify_io's checks on the tapes the proof carries, 51 the
+ * counters' ends; mode 3 also 54 = the touched cells are not canonical 8-byte cell addresses in strictly increasing order; a mode-3 proof is never a segment: 2).
  * expect may be NULL: the header's own public inputs are then only checked for internal consistency. */
 int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect);
 /* A run proven in SEGMENTS (multi-GPU: one row shard per device; consecutive segments overlap by one row — the last row of segment i,
