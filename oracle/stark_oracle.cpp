@@ -213,9 +213,15 @@ static const uint32_t OP_ECALL = 0x50;
 //   d0 + 2^8 d1 + 2^16 n0 | n1 + 2^4 d3 + 2^12 d4 | d5 + 2^8 d6 + 2^16 d7): the stored register on stores, the loaded window on loads (zero-extended; on byte / halfword
 //   loads d6 = 2 x the low seven bits of the top byte) | 215 sgb, 216 sgh: the row is LB / LH (sign-extending) | 217 tb: the top bit of the loaded byte / halfword
 //   218 sx = (sgb + sgh) tb | 219 cm2: the carry out of the address's third limb (the address itself must stay below 2^40: addr_limbs = 2, config.rs:30)
-static const int W_MAIN_MEM = 220, W_MAX = 220;
-enum { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219 };
-static const int K_LD = 16, K_ST = 17, N_WIN = 15, N_PIECE = 9;
+// .. and the six bitwise opcodes AND OR XOR ANDI ORI XORI (execute.rs:199-282: on the 40-bit values, the immediate sign-extended and masked) as class lg = 18, NIBBLE by nibble: the
+// operands and the result are ten nibbles each, nibble k a tuple (a_k, b_k, r_k) looked up in the 256-entry table of the row's operation — in the nine piece slots (a_k = piece k) and,
+// the tenth, in the row's last range slot (a_9 = chunk R7).  24 more logical columns (244, 224 committed):
+//   220 klg | 221 oa, 222 oo: the operation is AND / OR (XOR = klg - oa - oo) | 223 li: the second operand is the immediate | 224-233 b_0..9 | 234-243 r_0..9
+static const int W_MAIN_MEM = 244, W_MAX = 244;
+enum { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219,
+       C_KLG = 220, C_OA = 221, C_OO = 222, C_LI = 223, C_LB = 224, C_LR = 234 };
+static const int K_LD = 16, K_ST = 17, K_LG = 18, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
+static inline bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
 static inline int win_width(int v) { return v < 8 ? 1 : v < 12 ? 2 : v < 14 ? 4 : 8; }
 static inline int win_start(int v) { return v < 8 ? v : v < 12 ? 2 * (v - 8) : v < 14 ? 4 * (v - 12) : 0; }
 static inline int win_of(int width, int off) { return width == 1 ? off : width == 2 ? 8 + off / 2 : width == 4 ? 12 + off / 4 : 14; }
@@ -248,7 +254,7 @@ static const int C_KOJ = C_K3 + 1;
 // mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
 static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
-static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 200 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
+static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 224 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
 // logical [logical_width][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, int mode, std::vector<F>& out) {
   out.assign((size_t)phys_width(mode) * N, 0);
@@ -262,7 +268,7 @@ static void to_logical_row(const V* phys, int mode, const V& zero, V* logical) {
 enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92 };
 // (mode 3) the lookup tables beside the 10-bit range table (no tag) and the ROM (tag 1) / tapes (2, 3): LOW3 = {(v, v & 7)}, v < 2^10 (tag 4: the first range chunk of a
 // memory row is looked up HERE, with the window's offset — the address's low three bits), BYTE = {v < 2^8} (tag 5), NIBBLE = {v < 2^4} (tag 6); memory tuples carry tag 7
-static const int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7;
+static const int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10;   // (8-10: the nibble tables {(a, b, a op b)} of the bitwise opcodes)
 static const int PIECE_TAG[9] = {TAG_BYTE, TAG_BYTE, TAG_NIB, TAG_NIB, TAG_BYTE, 0, TAG_BYTE, TAG_BYTE, 0};   // d0 d1 n0 n1 d3 d4 d5 d6 d7 (0: the 10-bit range table)
 static const int RC_BITS = 10, RC_TABLE = 1 << RC_BITS;            // the reference's range-check table: 2^(limb_bits/2) entries (range_check.rs:29, config.rs:78-80)
 static const int N_TUPLE = 11;                                     // instruction-ROM tuple: pc limbs (3), op, fa, fb, fc, fhi, s, opclass, g (variant bit)
@@ -336,6 +342,7 @@ static inline F opclass_of(uint32_t op, int mode = 0) {
   if (op == OP_ECALL && mode >= 2) return K_ECALL;
   if (mode == 3 && is_load(op)) return K_LD;
   if (mode == 3 && is_store(op)) return K_ST;
+  if (mode == 3 && is_logic(op)) return K_LG;
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
@@ -399,8 +406,9 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     if (cls == K_OTH && !D) cls = (int)opclass_of(op, mode);
     if (cls == K_OTH && D && (opclass_of(op) == K_BRE || opclass_of(op) == K_BRU || opclass_of(op) == K_JAL || opclass_of(op) == K_JALR))
       cls = K_OJ;                                             // deferred mode: no opcode semantics, but "other" is sequential — branches and jumps run as the free-pc class
-    if (cls == K_LD) col(C_KLD)[i] = 1;                       // (mode 3: loads and stores)
+    if (cls == K_LD) col(C_KLD)[i] = 1;                       // (mode 3: loads and stores, the bitwise opcodes)
     else if (cls == K_ST) col(C_KST)[i] = 1;
+    else if (cls == K_LG) col(C_KLG)[i] = 1;
     else if (cls != K_ECALL) col(kcol(cls))[i] = 1;           // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
     col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
@@ -463,6 +471,21 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; if (q) rd = fa; }   // execute.rs:434-472: rd = rs1 (raw) if the condition holds, nothing changes otherwise
+    F lg_a9 = 0; bool lg_row = false;
+    if (cls == K_LG) {                                        // (mode 3) AND OR XOR ANDI ORI XORI on the 40-bit values (execute.rs:199-282), nibble by nibble
+      lg_row = true;
+      const uint32_t which = (op - 0x10) % 3, li = (op - 0x10) / 3;
+      col(C_OA)[i] = which == 0; col(C_OO)[i] = which == 1; col(C_LI)[i] = li;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = li ? ((uint64_t)im0 | ((uint64_t)im1 << 20)) : ((uint64_t)xc[0] | ((uint64_t)xc[1] << 20));
+      const uint64_t rr = which == 0 ? (a & b) : which == 1 ? (a | b) : (a ^ b);
+      for (int k = 0; k < N_NIB; k++) {
+        const F ak = (F)((a >> (4 * k)) & 15);
+        if (k < N_PIECE) col(C_PIECE + k)[i] = ak; else lg_a9 = ak;
+        col(C_LB + k)[i] = (F)((b >> (4 * k)) & 15); col(C_LR + k)[i] = (F)((rr >> (4 * k)) & 15);
+      }
+      y[0] = (F)(rr & 0xFFFFF); y[1] = (F)(rr >> 20); y[2] = 0;
+      rd = fa;
+    }
     bool mem_row = false;
     F mem_z[2] = {0, 0}, mem_dt = 0;
     if (cls == K_LD || cls == K_ST) {                         // (mode 3) loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64, which must stay below 2^40
@@ -532,6 +555,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64 * rc2[2];
     }
     if (mem_row) { rc2[0] = mem_dt & (RC_TABLE - 1); rc2[1] = (mem_dt >> RC_BITS) & (RC_TABLE - 1); rc2[2] = mem_dt >> (2 * RC_BITS); rc2[3] = 0; }   // (mode 3) cycle - told in three chunks: the time read is smaller than the time written
+    if (lg_row) { rc2[0] = rc2[1] = rc2[2] = 0; rc2[3] = lg_a9; }                              // (mode 3) a bitwise row's tenth nibble tuple sits in the last range slot
     for (int k = 0; k < 4; k++) col(C_RC2 + k)[i] = rc2[k];
     if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || cls == K_ECALL || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
     if (mem_row) { z[0] = mem_z[0]; z[1] = mem_z[1]; }         // (mode 3) the address's two low limbs are the range-checked pair
@@ -608,7 +632,9 @@ static inline void row_tuple(const std::vector<F>& M, size_t N, size_t i, F out[
 static inline F row_offset(const std::vector<F>& M, size_t N, size_t i) { F off = 0; for (int v = 0; v < N_WIN; v++) off += M[(size_t)(C_E + v) * N + i] * (F)win_start(v); return off; }   // (mode 3) the window's offset in its cell
 static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KLD * N + i] + M[(size_t)C_KST * N + i]; }
 // mem_mult (mode 3): LOW3 (1024) ++ BYTE (256) ++ NIBBLE (16)
-static const int MEM_MULT = RC_TABLE + 256 + 16;
+static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256, LG_BASE = RC_TABLE + 256 + 16;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR
+static inline int row_logic_op(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KLG * N + i] ? (M[(size_t)C_OA * N + i] ? 0 : M[(size_t)C_OO * N + i] ? 1 : 2) : -1; }   // 0 AND, 1 OR, 2 XOR; -1: not a bitwise row
+static inline F logic_of(int which, F a, F b) { return which == 0 ? (a & b) : which == 1 ? (a | b) : (a ^ b); }
 static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& rom, std::vector<F>& rom_mult, std::vector<F>& rc_mult, size_t* first_bad_row = nullptr, int mode = 0,
                                   std::vector<F>* mem_mult = nullptr) {
   rom_mult.assign(rom.n, 0); rc_mult.assign(RC_TABLE, 0);
@@ -621,10 +647,18 @@ static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& 
       const F v = M[(size_t)rc_col(k) * N + i];
       if (MEM && k == 0 && row_kmem(M, N, i)) {               // a memory row's first chunk is looked up WITH the window's offset: (v, v & 7)
         if (v < (F)RC_TABLE && (v & 7) == row_offset(M, N, i)) (*mem_mult)[v]++; else bad(i);
+      } else if (MEM && k == N_RC - 1 && row_logic_op(M, N, i) >= 0) {   // a bitwise row's tenth nibble tuple (a_9 = this chunk, b_9, r_9)
+        const int which = row_logic_op(M, N, i); const F b = M[(size_t)(C_LB + 9) * N + i], r = M[(size_t)(C_LR + 9) * N + i];
+        if (v < 16 && b < 16 && r == logic_of(which, v, b)) (*mem_mult)[LG_BASE + 256 * which + 16 * v + b]++; else bad(i);
       } else if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i);
     }
     if (MEM) for (int k = 0; k < N_PIECE; k++) {
       const F v = M[(size_t)(C_PIECE + k) * N + i];
+      if (row_logic_op(M, N, i) >= 0) {                       // a bitwise row: every piece slot looks up the nibble tuple (a_k, b_k, r_k) in the operation's table
+        const int which = row_logic_op(M, N, i); const F b = M[(size_t)(C_LB + k) * N + i], r = M[(size_t)(C_LR + k) * N + i];
+        if (v < 16 && b < 16 && r == logic_of(which, v, b)) (*mem_mult)[LG_BASE + 256 * which + 16 * v + b]++; else bad(i);
+        continue;
+      }
       if (PIECE_TAG[k] == TAG_BYTE) { if (v < 256) (*mem_mult)[RC_TABLE + v]++; else bad(i); }
       else if (PIECE_TAG[k] == TAG_NIB) { if (v < 16) (*mem_mult)[RC_TABLE + 256 + v]++; else bad(i); }
       else { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); }
@@ -656,6 +690,8 @@ static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, c
     for (int t = 0; t < RC_TABLE; t++) m[t] = esub(lp.alpha, eadd(tagged((F)t, TAG_LOW3, lp), emul_f(lp.lam[1], (F)(t & 7))));
     for (int t = 0; t < 256; t++) m[RC_TABLE + t] = esub(lp.alpha, tagged((F)t, TAG_BYTE, lp));
     for (int t = 0; t < 16; t++) m[RC_TABLE + 256 + t] = esub(lp.alpha, tagged((F)t, TAG_NIB, lp));
+    for (int which = 0; which < 3; which++) for (int t = 0; t < 256; t++)      // (a, b, a op b): a + lambda b + lambda^2 r + (8 + which) lambda^11
+      m[LG_BASE + 256 * which + t] = esub(lp.alpha, eadd(eadd(tagged((F)(t >> 4), TAG_AND + which, lp), emul_f(lp.lam[1], (F)(t & 15))), emul_f(lp.lam[2], logic_of(which, (F)(t >> 4), (F)(t & 15)))));
   }
   batch_einv(d);
   E T = e_from(0);
@@ -695,6 +731,9 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
   for (size_t i = 0; i < N; i++) {
     for (int k = 0; k < N_RC; k++) d[NH * i + k] = esub(lp.alpha, e_from(M[(size_t)rc_col(k) * N + i]));
     if (MEM && row_kmem(M, N, i)) d[NH * i] = esub(lp.alpha, eadd(tagged(M[(size_t)rc_col(0) * N + i], TAG_LOW3, lp), emul_f(lp.lam[1], row_offset(M, N, i))));   // the LOW3 lookup of a memory row
+    if (MEM && row_logic_op(M, N, i) >= 0)                                                                                                                       // the tenth nibble tuple of a bitwise row
+      d[NH * i + N_RC - 1] = esub(lp.alpha, eadd(eadd(tagged(M[(size_t)rc_col(N_RC - 1) * N + i], TAG_AND + row_logic_op(M, N, i), lp), emul_f(lp.lam[1], M[(size_t)(C_LB + 9) * N + i])),
+                                                emul_f(lp.lam[2], M[(size_t)(C_LR + 9) * N + i])));
     F t[N_TUPLE]; row_tuple(M, N, i, t);
     d[NH * i + N_RC] = esub(lp.alpha, fingerprint(t, lp));
   }
@@ -724,8 +763,10 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
     }
     if (MEM) {
       // the nine piece helpers P_k = 1 / (alpha - piece_k - tag_k lambda^11), on EVERY row (the pieces of a row that is no memory row are zero)
+      const int lgop = row_logic_op(M, N, i);
       for (int k = 0; k < N_PIECE; k++) {
-        const E h = einv(esub(lp.alpha, tagged(at(C_PIECE + k), PIECE_TAG[k], lp)));
+        const E h = lgop >= 0 ? einv(esub(lp.alpha, eadd(eadd(tagged(at(C_PIECE + k), TAG_AND + lgop, lp), emul_f(lp.lam[1], at(C_LB + k))), emul_f(lp.lam[2], at(C_LR + k)))))
+                              : einv(esub(lp.alpha, tagged(at(C_PIECE + k), PIECE_TAG[k], lp)));
         for (int c = 0; c < 4; c++) A[(size_t)(A_P + 4 * k + c) * N + i] = h.c[c];
         hs = eadd(hs, h);
       }
@@ -753,7 +794,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
-static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 576;
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 640;
 static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns); v9: AIR v5 (eight range lookups, 40 aux columns, the variant bit in the ROM tuple); v10: AIR v6 (172 logical columns, 152 / 168 committed)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
@@ -834,9 +875,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const bool IO = pub.mode() >= 2, MEM = pub.mode() == 3;
   const E Kec = IO ? eadd(eadd(loc[C_F2], loc[C_RL]), eadd(loc[C_RE], loc[C_FH])) : e_from(0);   // (mode 2) the ecall class: the sum of its four syscall flags
   const E Kld = MEM ? loc[C_KLD] : e_from(0), Kst = MEM ? loc[C_KST] : e_from(0), Kmem = eadd(Kld, Kst);   // (mode 3) loads, stores
-  { E sum = eadd(Kec, Kmem); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  const E Klg = MEM ? loc[C_KLG] : e_from(0);                                                             // (mode 3) the bitwise opcodes
+  { E sum = eadd(eadd(Kec, Kmem), Klg); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
-    E ks = eadd(emul_f(Kec, (F)K_ECALL), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST)));
+    E ks = eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST)));
     for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
@@ -997,6 +1039,11 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
       for (int v = 0; v < N_WIN; v++) off = eadd(off, emul_f(loc[C_E + v], (F)win_start(v)));
       for (int k = 0; k < 4; k++) d[k] = esub(esub(d[k], emul_f(off, lp.lam[1].c[k])), emul_f(Kmem, fmul(TAG_LOW3, lp.lam[N_TUPLE].c[k])));
     }
+    if (MEM && i == N_RC - 1) {                                            // (mode 3) a bitwise row's tenth nibble tuple: alpha - R7 - lambda b_9 - lambda^2 r_9 - (8 oa + 9 oo + 10 ox) lambda^11
+      const E ox = esub(esub(Klg, loc[C_OA]), loc[C_OO]);
+      const E tg = eadd(eadd(emul_f(loc[C_OA], TAG_AND), emul_f(loc[C_OO], TAG_OR)), emul_f(ox, TAG_XOR));
+      for (int k = 0; k < 4; k++) d[k] = esub(esub(esub(d[k], emul_f(loc[C_LB + 9], lp.lam[1].c[k])), emul_f(loc[C_LR + 9], lp.lam[2].c[k])), emul_f(tg, lp.lam[N_TUPLE].c[k]));
+    }
     ext_mul(aloc + A_H + 4 * i, d, pr);
     push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
   }
@@ -1133,13 +1180,35 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
       push(esub(pr[0], Kmem)); push(pr[1]); push(pr[2]); push(pr[3]);
     }
     // the nine piece lookups: P_k (alpha - piece_k - tag_k lambda^11) = 1
+    // (on a bitwise row the slot looks up the nibble tuple (piece_k, b_k, r_k) in the operation's table instead: tag_k (1 - klg) + 8 oa + 9 oo + 10 ox)
+    const E ox = esub(esub(Klg, loc[C_OA]), loc[C_OO]);
+    const E lgtag = eadd(eadd(emul_f(loc[C_OA], TAG_AND), emul_f(loc[C_OO], TAG_OR)), emul_f(ox, TAG_XOR));
     for (int i = 0; i < N_PIECE; i++) {
       E d[4], pr[4];
-      for (int k = 0; k < 4; k++) d[k] = cst(fsub(lp.alpha.c[k], fmul(PIECE_TAG[i], lp.lam[N_TUPLE].c[k])));
+      const E tg = eadd(emul_f(esub(one, Klg), PIECE_TAG[i]), lgtag);
+      for (int k = 0; k < 4; k++) d[k] = esub(esub(esub(cst(lp.alpha.c[k]), emul_f(tg, lp.lam[N_TUPLE].c[k])), emul_f(loc[C_LB + i], lp.lam[1].c[k])), emul_f(loc[C_LR + i], lp.lam[2].c[k]));
       d[0] = esub(d[0], pcs[i]);
       ext_mul(aloc + A_P + 4 * i, d, pr);
       push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
     }
+    // ---- 19. (mode 3) the bitwise opcodes AND OR XOR ANDI ORI XORI = 0x10 + (0 / 1 / 2) + 3 li (execute.rs:199-282), nibble by nibble ----
+    const E oa = loc[C_OA], oo = loc[C_OO], li = loc[C_LI];
+    boolean(Klg); boolean(oa); boolean(oo); boolean(ox); boolean(li);                            // (ox boolean: exactly one operation on a bitwise row, none elsewhere)
+    push(eadd(eadd(esub(emul_f(li, 3), emul(Klg, esub(op, cst(0x10)))), oo), emul_f(ox, 2)));      // 3 li = klg (op - 0x10) - oo - 2 ox
+    push(emul(li, esub(one, Klg)));
+    push(emul(Klg, esub(w1, fa)));                                                               // rd = field a
+    E a_lo = e_from(0), a_hi = e_from(0), b_lo = e_from(0), b_hi = e_from(0), r_lo = e_from(0), r_hi = e_from(0);
+    for (int k = 0; k < 5; k++) {
+      const F sh = (F)1 << (4 * k);
+      a_lo = eadd(a_lo, emul_f(pcs[k], sh)); a_hi = eadd(a_hi, emul_f(k + 5 < N_PIECE ? pcs[k + 5] : R2[3], sh));        // a_9 = the last range chunk
+      b_lo = eadd(b_lo, emul_f(loc[C_LB + k], sh)); b_hi = eadd(b_hi, emul_f(loc[C_LB + 5 + k], sh));
+      r_lo = eadd(r_lo, emul_f(loc[C_LR + k], sh)); r_hi = eadd(r_hi, emul_f(loc[C_LR + 5 + k], sh));
+    }
+    push(emul(Klg, esub(xb[0], a_lo))); push(emul(Klg, esub(xb[1], a_hi)));                      // rs1's 40 bits
+    push(eadd(emul(esub(Klg, li), esub(xc[0], b_lo)), emul(li, esub(im0, b_lo))));               // rs2's, or the sign-extended immediate's
+    push(eadd(emul(esub(Klg, li), esub(xc[1], b_hi)), emul(li, esub(im1, b_hi))));
+    push(emul(Klg, esub(y[0], r_lo))); push(emul(Klg, esub(y[1], r_hi))); push(emul(Klg, y[2]));   // the result: 40 bits
+    for (int k = 0; k < N_NIB; k++) { push(emul(esub(one, Klg), loc[C_LB + k])); push(emul(esub(one, Klg), loc[C_LR + k])); }   // no second / third tuple element off the bitwise rows
   }
   result = A.acc;
   return A.c;

@@ -1,5 +1,5 @@
 """ZKIR-STARK MODE 3 (round 4): the default VM mode with the I/O argument AND the memory argument — the ten loads and stores (execute.rs:477-575) are constrained and every
-access is tied to a consistent memory by an offline memory check over aligned 8-byte cells.  CPU tests of the ORACLE (prover + verifier); the product's
+access is tied to a consistent memory by an offline memory check over aligned 8-byte cells — AND the six bitwise opcodes (execute.rs:199-282), nibble by nibble.  CPU tests of the ORACLE (prover + verifier); the product's
 verifier and main-trace code are compared with it in tests/test_abi.py, the GPU prover in tests/test_gpu_stark.py.  PARITY UNPINNED (the reference has no prover)."""
 import numpy as np
 import pytest
@@ -20,7 +20,7 @@ def _case(blob, ins=(), **cfg):
 
 
 def test_widths():
-    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (220, 200, 96, 524)
+    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (244, 224, 96, 559)
     assert (so.logical_width(2), so.committed_width(2), so.aux_width(2), so.lib().so_num_constraints_for(2)) == (180, 160, 48, 430)      # mode 2 untouched
 
 
@@ -30,7 +30,7 @@ def test_honest_runs_are_accepted(name):
     blob, ins, cfg = getattr(pg, name)()
     ores, pub = _case(blob, ins, **{k: v for k, v in cfg.items() if k == "max_cycles"})
     proof = so.prove(ores.rows, pub)
-    assert proof[9] == 3 and proof[3] == 200
+    assert proof[9] == 3 and proof[3] == 224
     assert so.verify(proof, pub) == 0
     assert so.failing_constraints(so.main_trace(ores.rows, pub), pub, so.mem_cells(ores.rows, pub))[0] == 0
     assert so.verify_segment(proof, pub)[0] == 2                                  # the memory check spans the whole run: never a segment
@@ -112,6 +112,46 @@ def test_a_write_in_the_future_cannot_be_read():
     F[C_RC2, 2], F[C_RC2 + 1, 2], F[C_RC2 + 2, 2] = dt & 1023, (dt >> 10) & 1023, dt >> 20      # not three 10-bit chunks any more
     c = cells.copy(); c[0, 2] = 3
     assert so.verify(so.prove_matrix_mem(F, pub, c), None) == 10
+
+
+def test_bitwise_opcodes_are_constrained():
+    """AND OR XOR ANDI ORI XORI on 40-bit values with bits above 40 in the registers (masked: Value40::from_u64) and negative immediates (sign-extended, then masked): honest
+    rows satisfy every constraint; a wrong result nibble, a result of the wrong operation, an operand nibble that is not the register's, a tuple smuggled onto another row —
+    each violates a constraint or leaves its table (the multiplicity is then not counted and the running sum does not close)."""
+    O, E = spec.Opcode, spec.encode
+    code = pg.li40(1, 0xF0F0A5C3E1) + pg.li40(2, 0x0FF0FF00FF) + [A(5, 0, 0x4000), A(6, 0, -1), E(O.SD, rs1=5, rs2=6, imm=0), E(O.LB, 7, 5, imm=0)]      # r7 = 0xFFFF..FF (64 bits)
+    code += [E(O.AND, 8, 1, 2), E(O.OR, 9, 1, 2), E(O.XOR, 10, 1, 2), E(O.ANDI, 11, 1, imm=-256), E(O.ORI, 12, 1, imm=0x5555), E(O.XORI, 13, 1, imm=-1),
+             E(O.AND, 14, 7, 1), E(O.XOR, 15, 7, 7), E(O.OR, 0, 1, 2), pg.EB]
+    ores, pub = _case(pg._p(code))
+    M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    ops = ores.rows["instruction"] & 0x7F
+    rows = {int(o): int(np.nonzero(ops == o)[0][-1]) for o in (0x10, 0x11, 0x12, 0x13, 0x14, 0x15)}
+    a, b = 0xF0F0A5C3E1, 0x0FF0FF00FF
+    nxt = ores.rows["registers"]
+    assert int(nxt[rows[0x12] + 1][10]) == a ^ b and int(nxt[rows[0x13] + 1][11]) == a & 0xFFFFFFFF00 and int(nxt[rows[0x15] + 1][13]) == a ^ 0xFFFFFFFFFF
+    assert int(nxt[rows[0x10] + 1][14]) == a                                       # AND with 0xFFFF_FFFF_FFFF_FFFF masked to 40 bits
+    assert so.failing_constraints(M, pub, cells)[0] == 0 and so.verify(so.prove(ores.rows, pub), pub) == 0
+    C_KLG, C_OA, C_OO, C_LB, C_LR, C_PIECE = 220, 221, 222, 224, 234, 206
+
+    def bad(edit):
+        F = M.copy(); edit(F)
+        return so.failing_constraints(F, pub, cells)[0] > 0 and so.verify(so.prove_matrix_mem(F, pub, cells), None) == 10
+    i = rows[0x12]
+    assert bad(lambda F: F.__setitem__((C_LR + 3, i), int(F[C_LR + 3, i]) ^ 1))                                             # a wrong result nibble (y no longer matches)
+    def wrong_nibble_consistent(F):                                                                                          # .. with y and the register following it
+        F[C_LR, i] = int(F[C_LR, i]) ^ 1; F[C_Y, i] = int(F[C_Y, i]) ^ 1; F[C_LIMB + 30, i + 1:] = F[C_Y, i]
+    assert bad(wrong_nibble_consistent)                                                                                     # only the table lookup catches this one
+    def or_as_xor(F):                                                                                                       # an XOR row computing OR: every nibble tuple is in the OR table, not in XOR's
+        v = a | b
+        for k in range(10): F[C_LR + k, i] = (v >> (4 * k)) & 15
+        F[C_Y, i], F[C_Y + 1, i] = v & 0xFFFFF, v >> 20; F[C_LIMB + 30, i + 1:] = v & 0xFFFFF; F[C_LIMB + 31, i + 1:] = v >> 20
+    assert bad(or_as_xor)
+    assert bad(lambda F: (F.__setitem__((C_OA, i), 1)))                                                                     # two operations at once
+    assert bad(lambda F: F.__setitem__((C_PIECE + 2, i), (int(F[C_PIECE + 2, i]) + 1) % 16))                                # an operand nibble that is not rs1's
+    j = rows[0x13]
+    assert bad(lambda F: F.__setitem__((C_LB + 1, j), (int(F[C_LB + 1, j]) + 1) % 16))                                      # .. that is not the immediate's
+    k0 = int(np.nonzero(ops == 0x08)[0][0])
+    assert bad(lambda F: F.__setitem__((C_LB, k0), 3))                                                                      # a tuple element on a row that is no bitwise row
 
 
 # ---- the product's verifier (zkir_verify, verify.cpp + air.h) on the oracle's mode-3 proofs: same verdict and same failing check ------------------------------------
