@@ -550,7 +550,7 @@ def _mode3_case(which, witness="device"):
 
 
 @pytest.mark.parametrize("witness", ["device", "host"])
-@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "echo5", "fib30", "random3", "random5", "memloop", "q9_access_at_own_pc"])
+@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "alu_all", "echo5", "fib30", "random3", "random5", "memloop", "q9_access_at_own_pc"])
 def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     """A proof in mode 3 — loads and stores constrained, every access one step of the offline memory check, the touched cells carried — from the GPU prover equals the
     oracle's word for word; both verifiers accept it and give the same verdict on tampered copies.  The memory witness comes from the device (memcheck.hip: address-major
@@ -560,7 +560,7 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
     proof = stark.prove(ctx, tr, pub)
     want = so.prove(ores.rows, opub)
-    assert proof[3] == 200 and proof[9] == 3 and len(proof) == len(want)
+    assert proof[3] == 224 and proof[9] == 3 and len(proof) == len(want)
     if not np.array_equal(proof, want):
         bad = np.nonzero(proof != want)[0]
         raise AssertionError(f"mode-3 proof differs at word {bad[0]} of {len(want)} ({len(bad)} words differ)")

@@ -56,7 +56,7 @@
 
 namespace air {
 
-constexpr int W = 220;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
+constexpr int W = 244;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
 constexpr int W_LOGICAL_BASE = 172, W_LOGICAL_IO = 180;
 // MODES (the header's word 9, zkir_public_inputs::deferred): 0 = default VM mode, 1 = deferred carry model, 2 (round 4) = default mode WITH the I/O argument:
 // ECALL is a class of its own there (id K_ECALL, no column: Kec = f2 + rl + re + fh), dispatched on R10's limbs — f2 = WRITE (R10 = 2), rl / re = READ (R10 = 1) on a
@@ -73,8 +73,13 @@ enum : int { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 
 //   pieces d0 d1 n0 n1 d3 d4 d5 d6 d7 of the 64-bit window value (byte 2 = n0 + 16 n1): register limbs d0 + 2^8 d1 + 2^16 n0 | n1 + 2^4 d3 + 2^12 d4 | d5 + 2^8 d6 + 2^16 d7;
 //   the stored register on stores, the loaded window (zero-extended) on loads, where a byte / halfword load also keeps d6 = 2 x (the low seven bits of its top byte)
 //   sgb / sgh: the row is LB / LH; tb: the top bit of what it loads; sx = (sgb + sgh) tb; cm2: the carry out of the address's third limb (the address stays below 2^40)
-enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219 };
-constexpr int K_LD = 16, K_ST = 17, N_WIN = 15, N_PIECE = 9;
+// .. and the six BITWISE opcodes AND OR XOR ANDI ORI XORI (execute.rs:199-282: on the 40-bit values, the immediate sign-extended and masked), class lg = 18, nibble by nibble: operands
+// and result are ten nibbles each, nibble k a tuple (a_k, b_k, r_k) looked up in the 256-entry table of the row's operation — in the nine piece slots (a_k = piece k) and, the tenth, in
+// the row's last range slot (a_9 = chunk R7); oa / oo: the operation is AND / OR (XOR = klg - oa - oo), li: the second operand is the immediate
+enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219,
+             C_KLG = 220, C_OA = 221, C_OO = 222, C_LI = 223, C_LB = 224, C_LR = 234 };
+constexpr int K_LD = 16, K_ST = 17, K_LG = 18, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
+BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
 BB_HD constexpr int win_width(int v) { return v < 8 ? 1 : v < 12 ? 2 : v < 14 ? 4 : 8; }
 BB_HD constexpr int win_start(int v) { return v < 8 ? v : v < 12 ? 2 * (v - 8) : v < 14 ? 4 * (v - 12) : 0; }
 BB_HD constexpr int win_of(int width, int off) { return width == 1 ? off : width == 2 ? 8 + off / 2 : width == 4 ? 12 + off / 4 : 14; }
@@ -84,7 +89,9 @@ BB_HD constexpr bool is_store(uint32_t op) { return op >= OP_SB && op <= OP_SD; 
 BB_HD constexpr int mem_width(uint32_t op) { return is_store(op) ? 1 << (op - OP_SB) : op <= 0x31 ? 1 : op <= 0x33 ? 2 : op == 0x34 ? 4 : 8; }
 // (mode 3) lookup tables beside the 10-bit range table (no tag), the ROM (tag 1) and the tapes (2, 3): LOW3 = {(v, v & 7) : v < 2^10} (tag 4: the FIRST range chunk of a memory
 // row is looked up there, with the window's offset = the address's low three bits), BYTE = {v < 2^8} (5), NIBBLE = {v < 2^4} (6); memory tuples carry tag 7
-constexpr int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, MEM_MULT = 1024 + 256 + 16;
+// 8 / 9 / 10: the nibble tables {(a, b, a op b)} of AND / OR / XOR (256 entries each, entry 16 a + b); the multiplicities of LOW3 | BYTE | NIBBLE | AND | OR | XOR travel together
+constexpr int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10, LG_BASE = 1024 + 256 + 16, MEM_MULT = LG_BASE + 3 * 256;
+BB_HD constexpr uint32_t logic_of(int which, uint32_t a, uint32_t b) { return which == 0 ? (a & b) : which == 1 ? (a | b) : (a ^ b); }
 BB_HD constexpr int piece_tag(int k) { return (k == 2 || k == 3) ? TAG_NIB : (k == 5 || k == 8) ? 0 : TAG_BYTE; }   // d0 d1 n0 n1 d3 d4 d5 d6 d7 (0: the 10-bit range table)
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
              C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
@@ -95,14 +102,14 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
 // 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 200, W_COMMITTED_MAX = 200;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 224, W_COMMITTED_MAX = 224;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
 BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 BB_HD constexpr int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
 BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : mode == 3 ? W_COMMITTED_MEM : W_COMMITTED_DEFAULT; }
-BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 220 - 20)
+BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 244 - 20)
 BB_HD constexpr int logical_width(int mode) { return mode == 3 ? W : mode == 2 ? W_LOGICAL_IO : W_LOGICAL_BASE; }
 // the logical column stored at committed position p (p < committed_used)
 BB_HD constexpr int logical_col(int p, int mode) {
@@ -132,7 +139,7 @@ BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
-  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;
@@ -156,7 +163,10 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              // FPN (4), a load keeps the cell (4), the tuple read / written (4 + 4), the nine piece lookups (36)
              I_MEM_BOOL = 430, I_MEM_ONE = 451, I_MEM_NOHASH = 452, I_MEM_OP = 453, I_MEM_SG = 455, I_MEM_WR = 457, I_MEM_EA = 459, I_MEM_DT = 462, I_MEM_ST = 463, I_MEM_Y = 466,
              I_MEM_SX = 469, I_MEM_FPN = 472, I_MEM_KEEP = 476, I_MEM_RW = 480, I_MEM_PIECE = 488,
-             N_CONSTRAINTS = 524 };
+             // the bitwise opcodes (mode 3, appended): booleans klg oa oo ox li (5), the opcode (1), li only on bitwise rows (1), rd (1), rs1's nibbles (2), the second operand's (2),
+             // the result (3), no b_k / r_k off the bitwise rows (20)
+             I_LG_BOOL = 524, I_LG_OP = 529, I_LG_LI = 530, I_LG_WR = 531, I_LG_A = 532, I_LG_B = 534, I_LG_Y = 536, I_LG_ZERO = 539,
+             N_CONSTRAINTS = 559 };
 BB_HD constexpr int num_constraints(int mode) { return mode == 3 ? N_CONSTRAINTS : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
@@ -326,8 +336,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   // classes and the opcode
   V F2 = zero, RL = zero, RE = zero, FH = zero, H0 = zero, H1 = zero;   // (mode 2) the syscall flags of an ECALL row; Kec = their sum is the row's class
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
-  V Kld = zero, Kst = zero;                                    // (mode 3) loads, stores
-  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); }
+  V Kld = zero, Kst = zero, Klg = zero;                        // (mode 3) loads, stores, the bitwise opcodes
+  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); }
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
@@ -340,7 +350,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.acc_lin(sum, F2, 1); o.acc_lin(sum, RL, 1); o.acc_lin(sum, RE, 1); o.acc_lin(sum, FH, 1);
       o.acc_lin(ks, F2, K_ECALL); o.acc_lin(ks, RL, K_ECALL); o.acc_lin(ks, RE, K_ECALL); o.acc_lin(ks, FH, K_ECALL);
     }
-    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); }
+    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(sum, Klg, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); o.acc_lin(ks, Klg, K_LG); }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
     if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), opc), o.accl_val(ks)));
@@ -483,6 +493,17 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       for (int k = 0; k < 4; k++) {
         AccP t = o.accp();
         o.acc_mul(t, off, o.par(LK_LAM + 4 + k)); o.acc_mul(t, Kmem, o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M(TAG_LOW3)));
+        d[k] = o.sub(d[k], o.acc_val(t));
+      }
+    }
+    if (mem && i == N_RC - 1) {                                // (mode 3) a bitwise row's tenth nibble tuple: alpha - R7 - lambda b_9 - lambda^2 r_9 - (8 oa + 9 oo + 10 ox) lambda^11
+      AccL tga = o.accl();
+      o.acc_lin(tga, o.loc(C_OA), TAG_AND); o.acc_lin(tga, o.loc(C_OO), TAG_OR); o.acc_lin(tga, o.sub(o.sub(Klg, o.loc(C_OA)), o.loc(C_OO)), TAG_XOR);
+      const V tg = o.accl_val(tga), b9 = o.loc(C_LB + 9), r9 = o.loc(C_LR + 9);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        AccP t = o.accp();
+        o.acc_mul(t, b9, o.par(LK_LAM + 4 + k)); o.acc_mul(t, r9, o.par(LK_LAM + 8 + k)); o.acc_mul(t, tg, o.par(LK_LAM + 4 * N_TUPLE + k));
         d[k] = o.sub(d[k], o.acc_val(t));
       }
     }
@@ -654,14 +675,24 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
 #pragma unroll
       for (int k = 0; k < 4; k++) o.acc_lin(hs[k], hmr[k], 1);
     }
-    // the nine piece lookups: P_k (alpha - piece_k - tag_k lambda^11) = 1
+    // the nine piece lookups: P_k (alpha - piece_k - tag_k lambda^11) = 1 — on a BITWISE row the slot looks up the nibble tuple (piece_k, b_k, r_k) in the operation's table
+    // instead: P_k (alpha - piece_k - lambda b_k - lambda^2 r_k - (tag_k (1 - klg) + 8 oa + 9 oo + 10 ox) lambda^11) = 1
+    const V oa = o.loc(C_OA), oo = o.loc(C_OO), lii = o.loc(C_LI), ox = o.sub(o.sub(Klg, oa), oo), nlg = o.sub(one, Klg);
+    V lgtag;
+    { AccL a = o.accl(); o.acc_lin(a, oa, TAG_AND); o.acc_lin(a, oo, TAG_OR); o.acc_lin(a, ox, TAG_XOR); lgtag = o.accl_val(a); }
+    V lb[N_NIB], lr[N_NIB];
+#pragma unroll
+    for (int k = 0; k < N_NIB; k++) { lb[k] = o.loc(C_LB + k); lr[k] = o.loc(C_LR + k); }
 #pragma unroll
     for (int i = 0; i < N_PIECE; i++) {
       V h[4], d[4], pr[4];
+      const V tg = piece_tag(i) ? o.add(o.mulc(nlg, M((uint32_t)piece_tag(i))), lgtag) : lgtag;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         h[k] = o.aloc(A_P + 4 * i + k); o.acc_lin(hs[k], h[k], 1);
-        d[k] = piece_tag(i) ? o.sub(o.par(LK_ALPHA + k), o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M((uint32_t)piece_tag(i)))) : o.par(LK_ALPHA + k);
+        AccP t = o.accp();
+        o.acc_mul(t, lb[i], o.par(LK_LAM + 4 + k)); o.acc_mul(t, lr[i], o.par(LK_LAM + 8 + k)); o.acc_mul(t, tg, o.par(LK_LAM + 4 * N_TUPLE + k));
+        d[k] = o.sub(o.par(LK_ALPHA + k), o.acc_val(t));
       }
       d[0] = o.sub(d[0], pcs[i]);
       ext_mul(h, d, pr);
@@ -669,6 +700,27 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
 #pragma unroll
       for (int k = 1; k < 4; k++) o.push(I_MEM_PIECE + 4 * i + k, pr[k]);
     }
+    // ---- the bitwise opcodes AND OR XOR ANDI ORI XORI = 0x10 + (0 / 1 / 2) + 3 li (execute.rs:199-282), nibble by nibble: constraints 524.. ----
+    boolean(I_LG_BOOL, Klg); boolean(I_LG_BOOL + 1, oa); boolean(I_LG_BOOL + 2, oo); boolean(I_LG_BOOL + 3, ox); boolean(I_LG_BOOL + 4, lii);   // (ox boolean: exactly one operation on a bitwise row, none elsewhere)
+    o.push(I_LG_OP, o.ladd(o.add(o.sub(o.mulc(lii, M(3)), o.mul(o.lsub(op, o.cst(M(0x10))), Klg)), oo), o.mulc(ox, M(2))));                   // 3 li = klg (op - 0x10) - oo - 2 ox
+    o.push(I_LG_LI, o.lmul(nlg, lii));
+    o.push(I_LG_WR, o.lmul(o.lsub(w1v, fa), Klg));
+    {
+      // five nibbles -> a 20-bit limb: v0 + 16 v1 + 256 v2 + 4096 v3 + 65536 v4
+      auto limb5 = [&](const V& v0, const V& v1, const V& v2, const V& v3, const V& v4) {
+        return o.add(o.add(o.add(v0, o.mulc(v1, M(16))), o.add(o.mulc(v2, M(256)), o.mulc(v3, M(4096)))), o.mulc(v4, M(65536)));
+      };
+      const V alov = limb5(pcs[0], pcs[1], pcs[2], pcs[3], pcs[4]), ahiv = limb5(pcs[5], pcs[6], pcs[7], pcs[8], R2[3]);        // a_9 = the last range chunk
+      const V blov = limb5(lb[0], lb[1], lb[2], lb[3], lb[4]), bhiv = limb5(lb[5], lb[6], lb[7], lb[8], lb[9]);
+      const V rlov = limb5(lr[0], lr[1], lr[2], lr[3], lr[4]), rhiv = limb5(lr[5], lr[6], lr[7], lr[8], lr[9]);
+      o.push(I_LG_A, o.lmul(o.lsub(xb[0], alov), Klg)); o.push(I_LG_A + 1, o.lmul(o.lsub(xb[1], ahiv), Klg));                          // rs1's 40 bits
+      const V kr = o.sub(Klg, lii);
+      o.push(I_LG_B, o.ladd(o.mul(o.lsub(xc[0], blov), kr), o.mul(o.lsub(im0, blov), lii)));                                              // rs2's, or the sign-extended immediate's
+      o.push(I_LG_B + 1, o.ladd(o.mul(o.lsub(xc[1], bhiv), kr), o.mul(o.lsub(im1, bhiv), lii)));
+      o.push(I_LG_Y, o.lmul(o.lsub(y[0], rlov), Klg)); o.push(I_LG_Y + 1, o.lmul(o.lsub(y[1], rhiv), Klg)); o.push(I_LG_Y + 2, o.lmul(y[2], Klg));   // the result: 40 bits
+    }
+#pragma unroll
+    for (int k = 0; k < N_NIB; k++) { o.push(I_LG_ZERO + 2 * k, o.lmul(lb[k], nlg)); o.push(I_LG_ZERO + 2 * k + 1, o.lmul(lr[k], nlg)); }   // no second / third tuple element off the bitwise rows
   }
   // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR (+ HO + HI) - T / N
 #pragma unroll

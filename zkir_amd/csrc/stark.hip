@@ -97,7 +97,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
-  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; }
+  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; }
   col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
   const uint32_t tc = (branch || (MODE == 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
@@ -117,7 +117,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && cls == K_LD)) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && (cls == K_LD || cls == K_LG))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
     else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -188,13 +188,28 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   col(C_TK) = tk;
   const uint32_t imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFFu;
   const uint32_t lo20 = fb + 16 * fc + 256 * fhi - (s << 20);
-  bool mem_row = false;
-  uint32_t mem_z[2] = {0, 0}, mem_dt = 0;
+  bool mem_row = false, lg_row = false;
+  uint32_t mem_z[2] = {0, 0}, mem_dt = 0, lg_a9 = 0;
   if (MODE == 3) {
     // loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64 — below 2^40, or the run has no proof here — its aligned 8-byte cell's bytes before the
     // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
 #pragma unroll
-    for (int k = C_E; k < W; k++) col(k) = 0;
+    for (int k = C_E; k < W; k++) if (k != C_KLG) col(k) = 0;
+    if (cls == K_LG) {
+      // AND OR XOR ANDI ORI XORI on the 40-bit values (execute.rs:199-282), nibble by nibble: a's nibbles in the piece columns (the tenth in the last range chunk), b's and the result's beside them
+      lg_row = true;
+      const uint32_t which = (op - 0x10) % 3, li = (op - 0x10) / 3;
+      col(C_OA) = which == 0; col(C_OO) = which == 1; col(C_LI) = li;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = li ? ((uint64_t)im0 | ((uint64_t)im1 << 20)) : ((uint64_t)xc[0] | ((uint64_t)xc[1] << 20));
+      const uint64_t rr = which == 0 ? (a & b) : which == 1 ? (a | b) : (a ^ b);
+#pragma unroll
+      for (int k = 0; k < N_NIB; k++) {
+        const uint32_t ak = (uint32_t)((a >> (4 * k)) & 15);
+        if (k < N_PIECE) col(C_PIECE + k) = ak; else lg_a9 = ak;
+        col(C_LB + k) = (uint32_t)((b >> (4 * k)) & 15); col(C_LR + k) = (uint32_t)((rr >> (4 * k)) & 15);
+      }
+      y[0] = (uint32_t)(rr & 0xFFFFF); y[1] = (uint32_t)(rr >> 20); y[2] = 0;
+    }
     if (cls == K_LD || cls == K_ST) {
       mem_row = true;
       const uint32_t* base = cls == K_LD ? xb : xc;            // loads: rs1 = field b; stores: rs1 = field a (operand c), the stored register rs2 = field b (operand b)
@@ -253,6 +268,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     rc2[0] = y[2] & (RC_TABLE - 1); rc2[1] = (y[2] >> RC_BITS) & (RC_TABLE - 1); rc2[2] = y[2] >> (2 * RC_BITS); rc2[3] = 64u * rc2[2];
   }
   if (mem_row) { rc2[0] = mem_dt & (RC_TABLE - 1); rc2[1] = (mem_dt >> RC_BITS) & (RC_TABLE - 1); rc2[2] = mem_dt >> (2 * RC_BITS); rc2[3] = 0; }   // (mode 3) cycle - told in three chunks
+  if (lg_row) { rc2[0] = rc2[1] = rc2[2] = 0; rc2[3] = lg_a9; }   // (mode 3) a bitwise row's tenth nibble tuple sits in the last range slot
   col(C_RC2) = rc2[0]; col(C_RC2 + 1) = rc2[1]; col(C_RC2 + 2) = rc2[2]; col(C_RC2 + 3) = rc2[3];
   if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like || (MODE >= 2 && cls == K_ECALL)) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
   if (mem_row) { z[0] = mem_z[0]; z[1] = mem_z[1]; }             // (mode 3) the address's two low limbs are the range-checked pair

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
                                    M[b8(p_rc2, i, N)], M[b8(p_rc2 + 1, i, N)], M[b8(p_rc2 + 2, i, N)], M[b8(p_rc2 + 3, i, N)]};
     bool ok = true;
     bool mem_row = false;
+    int lg_which = -1;                                           // (mode 3) 0 / 1 / 2: the row is an AND / OR / XOR (immediate or not)
     if (deferred == 3) {
       // (mode 3) the row's memory side, kept for the aux kernels (the LDE overwrites M): pieces, old bytes, old time, window; the piece lookups counted here
       const uint32_t p_kld = (uint32_t)air::phys_col(air::C_KLD, 3), p_e = (uint32_t)air::phys_col(air::C_E, 3), p_ob = (uint32_t)air::phys_col(air::C_OB, 3),
@@ -215,9 +216,19 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       mem_row = (kld | kst) != 0;
       uint32_t win = 15;
       for (int v = 0; v < air::N_WIN; v++) if (M[b8(p_e + (uint32_t)v, i, N)]) win = (uint32_t)v;
+      const uint32_t p_klg = (uint32_t)air::phys_col(air::C_KLG, 3), p_lb = (uint32_t)air::phys_col(air::C_LB, 3), p_lr = (uint32_t)air::phys_col(air::C_LR, 3);
+      const uint32_t klg = M[b8(p_klg, i, N)];
+      lg_which = klg ? (M[b8(p_klg + 1, i, N)] ? 0 : M[b8(p_klg + 2, i, N)] ? 1 : 2) : -1;
+      uint32_t lbits_lo = 0, lbits_hi = 0;                       // b_0..7 | b_8, b_9: kept for the aux kernel
+      auto logic_tuple = [&](uint32_t a, int k) {                // the nibble tuple (a, b_k, r_k) of a bitwise row: in its operation's table?
+        const uint32_t b = M[b8(p_lb + (uint32_t)k, i, N)], r = M[b8(p_lr + (uint32_t)k, i, N)];
+        if (k < 8) lbits_lo |= (b & 15) << (4 * k); else lbits_hi |= (b & 15) << (4 * (k - 8));
+        if (a < 16 && b < 16 && r == air::logic_of(lg_which, a, b)) atomicAdd(&h_mem[air::LG_BASE + 256 * lg_which + 16 * a + b], 1u); else ok = false;
+      };
       uint32_t pc9[air::N_PIECE];
       for (int k = 0; k < air::N_PIECE; k++) {
         pc9[k] = M[b8(p_pc + (uint32_t)k, i, N)];
+        if (lg_which >= 0) { logic_tuple(pc9[k], k); continue; }
         const int tag = air::piece_tag(k);
         if (tag == air::TAG_BYTE) { if (pc9[k] < 256u) atomicAdd(&h_mem[air::RC_TABLE + pc9[k]], 1u); else ok = false; }
         else if (tag == air::TAG_NIB) { if (pc9[k] < 16u) atomicAdd(&h_mem[air::RC_TABLE + 256 + pc9[k]], 1u); else ok = false; }
@@ -227,14 +238,15 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       for (int k = 0; k < 4; k++) { obl |= (M[b8(p_ob + (uint32_t)k, i, N)] & 0xFF) << (8 * k); obh |= (M[b8(p_ob + 4 + (uint32_t)k, i, N)] & 0xFF) << (8 * k); }
       mem_side[2 * i] = make_uint4((pc9[0] & 0xFF) | ((pc9[1] & 0xFF) << 8) | ((pc9[4] & 0xFF) << 16) | ((pc9[5] & 0xFF) << 24),
                                    (pc9[6] & 0xFF) | ((pc9[7] & 0xFF) << 8) | ((pc9[8] & 0xFF) << 16) | ((pc9[2] & 0xF) << 24) | ((pc9[3] & 0xF) << 28), obl, obh);
-      mem_side[2 * i + 1] = make_uint4(M[b8(p_told, i, N)], kld | (kst << 1) | (win << 2), b0l.x /* cycle */, 0u);
+      if (lg_which >= 0) logic_tuple(r[air::N_RC - 1], 9);       // the tenth tuple: a_9 = the last range chunk
+      mem_side[2 * i + 1] = make_uint4(M[b8(p_told, i, N)], kld | (kst << 1) | (win << 2) | ((uint32_t)(lg_which + 1) << 6) | (lbits_hi << 8), b0l.x /* cycle */, lbits_lo);
       if (mem_row) {                                             // the first chunk goes to the LOW3 table, with the window's offset
         const uint32_t off = win < 15 ? (uint32_t)air::win_start((int)win) : 8u;
         if (r[0] < (uint32_t)air::RC_TABLE && (r[0] & 7) == off) atomicAdd(&h_mem[r[0]], 1u); else ok = false;
       }
     }
 #pragma unroll
-    for (int k = 0; k < air::N_RC; k++) { if (k == 0 && mem_row) continue; if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
+    for (int k = 0; k < air::N_RC; k++) { if ((k == 0 && mem_row) || (k == air::N_RC - 1 && lg_which >= 0)) continue; if (r[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[r[k]], 1u); else ok = false; }
     const uint64_t pc = (uint64_t)b0l.y | ((uint64_t)b0l.z << 20) | ((uint64_t)b0l.w << 40);
     const uint64_t u = (pc - 0x1000) >> 2;
     uint32_t ui = 0;
@@ -276,13 +288,16 @@ __device__ __forceinline__ uint4 add4m(uint4 a, uint4 b);
 __global__ __launch_bounds__(NT) void mem_tables_kernel(const ProveParams* __restrict__ pp, E4* __restrict__ inv_mem) {
   const uint32_t t = blockIdx.x * NT + threadIdx.x;
   if (t >= (uint32_t)air::MEM_MULT) return;
-  const uint32_t v = t < (uint32_t)air::RC_TABLE ? t : t < (uint32_t)air::RC_TABLE + 256 ? t - air::RC_TABLE : t - air::RC_TABLE - 256;
-  const uint32_t tag = t < (uint32_t)air::RC_TABLE ? air::TAG_LOW3 : t < (uint32_t)air::RC_TABLE + 256 ? air::TAG_BYTE : air::TAG_NIB;
+  const bool lg = t >= (uint32_t)air::LG_BASE;                  // AND | OR | XOR: entry 16 a + b = the tuple (a, b, a op b)
+  const uint32_t which = lg ? (t - air::LG_BASE) >> 8 : 0, e = (t - air::LG_BASE) & 255;
+  const uint32_t v = lg ? e >> 4 : t < (uint32_t)air::RC_TABLE ? t : t < (uint32_t)air::RC_TABLE + 256 ? t - air::RC_TABLE : t - air::RC_TABLE - 256;
+  const uint32_t tag = lg ? air::TAG_AND + which : t < (uint32_t)air::RC_TABLE ? air::TAG_LOW3 : t < (uint32_t)air::RC_TABLE + 256 ? air::TAG_BYTE : air::TAG_NIB;
   E4 d;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     uint32_t fp = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + k], bb::to_mont(tag));
     if (tag == (uint32_t)air::TAG_LOW3) fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 + k], bb::to_mont(v & 7)));
+    if (lg) fp = bb::add(fp, bb::add(bb::mont_mul(pp->lk[air::LK_LAM + 4 + k], bb::to_mont(e & 15)), bb::mont_mul(pp->lk[air::LK_LAM + 8 + k], bb::to_mont(air::logic_of((int)which, e >> 4, e & 15)))));
     d.c[k] = bb::sub(pp->lk[air::LK_ALPHA + k], fp);
   }
   d.c[0] = bb::sub(d.c[0], bb::to_mont(v));
@@ -352,13 +367,23 @@ __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ s
   uint4* A4 = reinterpret_cast<uint4*>(A);
   auto put = [&](int col, const E4& c) { A4[((uint64_t)(col >> 3) * N + i) * 2 + ((col >> 2) & 1)] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
   E4 inc = bb::e_zero();
+  const int lg_which = (int)((m1.y >> 6) & 3) - 1;              // 0 / 1 / 2: an AND / OR / XOR row — every piece slot then reads its nibble tuple's inverse from the operation's table
+  auto lg_b = [&](int k) { return k < 8 ? (m1.w >> (4 * k)) & 15 : (m1.y >> (8 + 4 * (k - 8))) & 15; };
 #pragma unroll
   for (int k = 0; k < air::N_PIECE; k++) {
     const int tag = air::piece_tag(k);
-    const E4 h = tag == air::TAG_BYTE ? inv_mem[air::RC_TABLE + pc9[k]] : tag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + pc9[k]] : inv_rc[pc9[k]];
+    const E4 h = lg_which >= 0 ? inv_mem[air::LG_BASE + 256 * lg_which + 16 * (pc9[k] & 15) + lg_b(k)]
+               : tag == air::TAG_BYTE ? inv_mem[air::RC_TABLE + pc9[k]] : tag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + pc9[k]] : inv_rc[pc9[k]];
     put(air::A_P + 4 * k, h); inc = bb::e_add(inc, h);
   }
-  const uint32_t kld = m1.y & 1, kst = (m1.y >> 1) & 1, win = m1.y >> 2;
+  if (lg_which >= 0) {                                          // the tenth tuple sits in the last range slot: H7 re-read from the operation's table
+    const uint4 sd = side[i];
+    const uint32_t c7 = sd.z >> 10;
+    const E4 h7 = inv_mem[air::LG_BASE + 256 * lg_which + 16 * (c7 & 15) + lg_b(9)];
+    inc = bb::e_add(inc, bb::e_sub(h7, inv_rc[c7]));
+    put(air::A_H + 4 * (air::N_RC - 1), h7);
+  }
+  const uint32_t kld = m1.y & 1, kst = (m1.y >> 1) & 1, win = (m1.y >> 2) & 15;
   const uint64_t ob = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
   uint64_t nb = ob;
   int off = 0;
