@@ -1500,6 +1500,7 @@ static bool parse_io_section(const uint32_t* w, size_t avail, IoSection& io) {
   return true;
 }
 static int halt_binding(const uint32_t* w, const F* last, int halt_kind, uint64_t halt_code);
+static bool last_row_writes(const uint32_t* w, const F* last, int halt_kind, uint64_t* value);
 static int verify(const uint32_t* w, size_t len, const Public* expect, bool whole_run = true, F* states_out = nullptr, F* counters_out = nullptr) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
@@ -1556,7 +1557,12 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
       b.push_back(pub.halt_kind); b.push_back(pub.halt_kind == 1 ? pub.halt_code : 0); b.push_back(pub.n_real);
       F dg[DIGEST]; digest_bytes((const uint8_t*)b.data(), b.size() * 8, dg);
       if (memcmp(dg, pub.io, 16)) return 50;
-      if (pub.cnt_first[0] || pub.cnt_first[1] || pub.cnt_last[0] != pub.n_out) return 51;              // every output was written, none before the run began
+      // every output was written, none before the run began.  A run that stops at its CYCLE LIMIT has executed its last row too (vm.rs:211-214, :302-347: cycles == rows), and the
+      // AIR's counters describe what happened BEFORE a row: if that row is a WRITE ecall, the last output is the R11 of the public last state and is not counted yet
+      uint64_t tail_value = 0;
+      const bool tail = last_row_writes(w, pub.last, (int)pub.halt_kind, &tail_value);
+      if (pub.cnt_first[0] || pub.cnt_first[1] || pub.cnt_last[0] + (tail ? 1 : 0) != pub.n_out) return 51;
+      if (tail && pub.outputs[pub.n_out - 1] != tail_value) return 51;
       const int hb = halt_binding(w, pub.last, (int)pub.halt_kind, pub.halt_code);
       if (hb) return hb;
     }
@@ -1776,7 +1782,11 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
     for (int i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
     if (cnt[0] || cnt[1]) return 51;
     for (int i = 1; i < n; i++) if (cnt[(size_t)i * 4] != cnt[(size_t)(i - 1) * 4 + 2] || cnt[(size_t)i * 4 + 1] != cnt[(size_t)(i - 1) * 4 + 3]) return 46;
-    if (cnt[(size_t)(n - 1) * 4 + 2] != io0.out.size()) return 51;
+    {
+      uint64_t tail_value = 0;
+      const bool tail = last_row_writes(proofs[n - 1], proofs[n - 1] + 21 + N_STATE, (int)io0.halt_kind, &tail_value);       // (see verify(): the last row of a run cut by its cycle limit)
+      if (cnt[(size_t)(n - 1) * 4 + 2] + (tail ? 1 : 0) != io0.out.size() || (tail && io0.out.back() != tail_value)) return 51;
+    }
     std::vector<uint64_t> b;
     b.push_back(io0.in.size()); b.insert(b.end(), io0.in.begin(), io0.in.end()); b.push_back(io0.out.size()); b.insert(b.end(), io0.out.begin(), io0.out.end());
     b.push_back(io0.halt_kind); b.push_back(io0.halt_kind == 1 ? io0.halt_code : 0); b.push_back(total);
@@ -1812,6 +1822,24 @@ static int halt_binding(const uint32_t* w, const F* last, int halt_kind, uint64_
     if (r[0] != 0 || r[1] != halt_code) return 53;
   }
   return 0;
+}
+// the last executed row of a run that stopped at its cycle limit, if it is a WRITE ecall (R10 = 2): the value it writes (R11 of the public last state)
+static bool last_row_writes(const uint32_t* w, const F* last, int halt_kind, uint64_t* value) {
+  if (halt_kind != 2) return false;
+  const int HW = header_words_of((int)w[9]);
+  const size_t blob_len = w[HW];
+  if (blob_len < 32) return false;
+  auto byte = [&](size_t i) { const uint32_t h = w[HW + 1 + i / 2]; return (uint32_t)((i & 1) ? (h >> 8) : (h & 0xFF)); };
+  const uint32_t code_size = byte(16) | (byte(17) << 8) | (byte(18) << 16) | (byte(19) << 24);
+  const uint64_t pc = (uint64_t)last[1] | ((uint64_t)last[2] << 20) | ((uint64_t)last[3] << 40);
+  if (pc < 0x1000 || pc % 4 || pc - 0x1000 >= code_size || 32 + (pc - 0x1000) + 4 > blob_len) return false;
+  const size_t at = 32 + (size_t)(pc - 0x1000);
+  if ((byte(at) & 0x7F) != 0x50) return false;                                                 // opcode.rs:154-228: ECALL
+  uint64_t r[2];
+  for (int k = 0; k < 2; k++) { const F* l = last + 4 + 3 * (10 + k); const int bits = last[52 + 10 + k] ? 30 : 20; r[k] = (uint64_t)l[0] | ((uint64_t)l[1] << bits) | ((uint64_t)l[2] << (2 * bits)); }
+  if (r[0] != 2) return false;
+  *value = r[1];
+  return true;
 }
 static bool io_claim_matches(const uint32_t* w, uint64_t cycles, const uint64_t* in, size_t n_in, const uint64_t* out, size_t n_out, int halt_kind, uint64_t halt_code) {
   std::vector<uint64_t> io;

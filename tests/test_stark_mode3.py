@@ -199,3 +199,22 @@ def test_product_verifier_rejects_what_the_oracle_rejects():
     c = cells.copy(); c[0, 3] ^= 1
     proof = so.prove_matrix_mem(M, pub, c)
     assert so.verify(proof, None) == rt.verify(proof) == 10
+
+
+def test_a_run_cut_by_its_cycle_limit_on_a_write_is_accepted():
+    """vm.rs:211-214, :302-347: a run that stops at its cycle limit has EXECUTED its last row (cycles == rows).  If that row is a WRITE ecall its output exists, while the AIR's
+    counters say what happened before a row: both verifiers read the last output off the public last state (R10 = 2, R11 = the value) — modes 2 and 3; a forged last output is 51."""
+    from zkir_amd import runtime as rt
+    code = [A(1, 0, 7), A(11, 1, 0), A(10, 0, 2), spec.ecall(), A(1, 1, 1), spec.jal(0, -16)]           # WRITE 7, 8, 9, .. forever
+    blob = pg._p(code)
+    for n, n_out in ((4, 1), (9, 2), (10, 2), (14, 3)):                                                # rows 3, 8, 13 are the WRITEs: n = 4, 9, 14 end ON one
+        ores = oracle.run(blob, [], max_cycles=n, enable_execution_trace=True)
+        assert len(ores.rows) == n and len(ores.outputs) == n_out and ores.halt_kind == 2
+        for kw in (dict(io_mode=True), dict(mem_mode=True)):
+            pub = so.public_inputs(n, blob, [], list(ores.outputs), (2, 0), **kw)
+            pr = so.prove(ores.rows, pub)
+            assert so.verify(pr, pub) == 0 and rt.verify(pr) == 0, (n, kw)
+            if n in (4, 9, 14):
+                fake = so.public_inputs(n, blob, [], list(ores.outputs[:-1]) + [int(ores.outputs[-1]) + 1], (2, 0), **kw)
+                fp = so.prove(ores.rows, fake)
+                assert so.verify(fp, fake) == 51 and rt.verify(fp) == 51

@@ -162,6 +162,7 @@ bool io_digest_matches(const uint32_t* digest4, const IoSection& io, uint64_t cy
   return !memcmp(dg, digest4, 16);
 }
 int halt_binding(const uint32_t* w, const uint32_t* last_state, int halt_kind, uint64_t halt_code);
+bool last_row_writes(const uint32_t* w, const uint32_t* last_state, int halt_kind, uint64_t* value);
 
 }  // namespace
 
@@ -322,7 +323,11 @@ int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint3
     for (uint32_t i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
     if (cnt[0] || cnt[1]) return 51;
     for (uint32_t i = 1; i < n; i++) if (cnt[(size_t)i * 4] != cnt[(size_t)(i - 1) * 4 + 2] || cnt[(size_t)i * 4 + 1] != cnt[(size_t)(i - 1) * 4 + 3]) return 46;
-    if (cnt[(size_t)(n - 1) * 4 + 2] != io0.out.size()) return 51;
+    {
+      uint64_t tail_value = 0;
+      const bool tail = last_row_writes(proofs[n - 1], proofs[n - 1] + 21 + NS, (int)io0.halt_kind, &tail_value);            // (see verify_impl: the last row of a run cut by its cycle limit)
+      if (cnt[(size_t)(n - 1) * 4 + 2] + (tail ? 1 : 0) != io0.out.size() || (tail && io0.out.back() != tail_value)) return 51;
+    }
     if (!io_digest_matches(w0 + 17, io0, total)) return 50;
     const int hb = halt_binding(proofs[n - 1], proofs[n - 1] + 21 + NS, (int)io0.halt_kind, io0.halt_code);
     if (hb) return hb;
@@ -362,6 +367,22 @@ int halt_binding(const uint32_t* w, const uint32_t* last_state, int halt_kind, u
     if (reg(10) != 0 || reg(11) != halt_code) return 53;
   }
   return 0;
+}
+// the last executed row of a run that stopped at its cycle limit, if it is a WRITE ecall (R10 = 2): the value it writes (R11 of the public last state)
+bool last_row_writes(const uint32_t* w, const uint32_t* last, int halt_kind, uint64_t* value) {
+  if (halt_kind != ZKIR_HALT_CYCLE_LIMIT) return false;
+  const int HW = header_words_of((int)w[9]);
+  const uint64_t blob_len = w[HW];
+  if (blob_len < 32) return false;
+  auto byte = [&](uint64_t i) { const uint32_t h = w[HW + 1 + i / 2]; return (uint32_t)((i & 1) ? (h >> 8) : (h & 0xFF)); };
+  const uint32_t code_size = byte(16) | (byte(17) << 8) | (byte(18) << 16) | (byte(19) << 24);
+  const uint64_t pc = (uint64_t)last[1] | ((uint64_t)last[2] << 20) | ((uint64_t)last[3] << 40);
+  if (pc < 0x1000 || (pc & 3) || pc - 0x1000 >= code_size || 32 + (pc - 0x1000) + 4 > blob_len) return false;
+  if ((byte(32 + (pc - 0x1000)) & 0x7F) != 0x50) return false;                                          // opcode.rs:154-228: ECALL
+  auto reg = [&](int r) { const uint32_t* l = last + 4 + 3 * r; const int bits = last[52 + r] ? 30 : 20; return (uint64_t)l[0] | ((uint64_t)l[1] << bits) | ((uint64_t)l[2] << (2 * bits)); };
+  if (reg(10) != 2) return false;
+  *value = reg(11);
+  return true;
 }
 bool io_claim_matches(const uint32_t* w, uint64_t cycles, const uint64_t* inputs, size_t n_in, const uint64_t* outputs, size_t n_out, int halt_kind, uint64_t halt_code) {
   std::vector<uint64_t> io;
@@ -458,7 +479,11 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     if (cnt[0] > cnt[2] || cnt[1] > cnt[3] || cnt[2] > io.out.size() || cnt[3] > io.in.size()) return 51;
     if (whole_run) {
       if (!io_digest_matches(pub.io_digest, io, pub.n_real)) return 50;
-      if (cnt[0] || cnt[1] || cnt[2] != io.out.size()) return 51;
+      // A run that stops at its CYCLE LIMIT has executed its last row too (vm.rs:211-214, :302-347: cycles == rows) while the counters describe what happened BEFORE a row: if
+      // that row is a WRITE ecall, the last output is the R11 of the public last state and is not counted yet
+      uint64_t tail_value = 0;
+      const bool tail = last_row_writes(w, last, (int)io.halt_kind, &tail_value);
+      if (cnt[0] || cnt[1] || cnt[2] + (tail ? 1 : 0) != io.out.size() || (tail && io.out.back() != tail_value)) return 51;
       const int hb = halt_binding(w, last, (int)io.halt_kind, io.halt_code);
       if (hb) return hb;
     }
