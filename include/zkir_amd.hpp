@@ -377,21 +377,47 @@ class StarkContext {                                            // device tables
 // struct's pointer on them through copies and moves.
 struct PublicInputs : zkir_public_inputs {
   PublicInputs() : zkir_public_inputs{} {}
-  PublicInputs(const zkir_public_inputs& c, std::vector<uint8_t> blob) : zkir_public_inputs(c), blob_(std::move(blob)) { repoint(); }
-  PublicInputs(const PublicInputs& o) : zkir_public_inputs(o), blob_(o.blob_) { repoint(); }
-  PublicInputs(PublicInputs&& o) noexcept : zkir_public_inputs(o), blob_(std::move(o.blob_)) { repoint(); }
-  PublicInputs& operator=(PublicInputs o) { static_cast<zkir_public_inputs&>(*this) = o; blob_ = std::move(o.blob_); repoint(); return *this; }
+  PublicInputs(const zkir_public_inputs& c, std::vector<uint8_t> blob) : zkir_public_inputs(c), blob_(std::move(blob)) {
+    if (c.inputs && c.n_inputs) inputs_.assign(c.inputs, c.inputs + c.n_inputs);           // (modes 2 / 3: the tapes travel in the clear — owned here too)
+    if (c.outputs && c.n_outputs) outputs_.assign(c.outputs, c.outputs + c.n_outputs);
+    repoint();
+  }
+  PublicInputs(const PublicInputs& o) : zkir_public_inputs(o), blob_(o.blob_), inputs_(o.inputs_), outputs_(o.outputs_) { repoint(); }
+  PublicInputs(PublicInputs&& o) noexcept : zkir_public_inputs(o), blob_(std::move(o.blob_)), inputs_(std::move(o.inputs_)), outputs_(std::move(o.outputs_)) { repoint(); }
+  PublicInputs& operator=(PublicInputs o) {
+    static_cast<zkir_public_inputs&>(*this) = o; blob_ = std::move(o.blob_); inputs_ = std::move(o.inputs_); outputs_ = std::move(o.outputs_); repoint(); return *this;
+  }
   const std::vector<uint8_t>& program_bytes() const { return blob_; }
 
  private:
-  void repoint() { program_blob = blob_.data(); program_blob_len = blob_.size(); }
+  void repoint() {
+    program_blob = blob_.data(); program_blob_len = blob_.size();
+    inputs = inputs_.empty() ? nullptr : inputs_.data(); n_inputs = inputs_.size();
+    outputs = outputs_.empty() ? nullptr : outputs_.data(); n_outputs = outputs_.size();
+    mem_old = nullptr; mem_told = nullptr; cell_addr = nullptr; cell_bytes = nullptr; cell_time = nullptr; n_cells = 0;   // mode 3: zkir_prove makes the memory witness on the device
+  }
   std::vector<uint8_t> blob_;
+  std::vector<uint64_t> inputs_, outputs_;
+};
+// The proof's MODE: what an accepted proof says beyond the trace's control flow and the 20 opcodes of the default AIR
+enum class ProofMode : uint32_t {
+  Default = 0,    // the default VM mode
+  Deferred = 1,   // VMConfig::enable_deferred_model (relaxed AIR)
+  Io = 2,         // default + the I/O argument: what the run read and wrote, and that it ended on the instruction its halt reason names
+  Memory = 3,     // Io + the memory argument and the bitwise opcodes: loads / stores / AND / OR / XOR constrained, memory consistent (whole runs; no hash syscalls)
 };
 inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,
                                   const zkir_runtime::VMConfig& config = {}) {
   zkir_public_inputs pub;
   std::vector<uint8_t> blob = program.to_bytes();
   const int rc = zkir_public_inputs_of(result.delta_log(), blob.data(), blob.size(), inputs.data(), inputs.size(), config.enable_deferred_model ? 1u : 0u, &pub);
+  if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc);
+  return PublicInputs(pub, std::move(blob));
+}
+inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs, ProofMode mode) {
+  zkir_public_inputs pub;
+  std::vector<uint8_t> blob = program.to_bytes();
+  const int rc = zkir_public_inputs_of(result.delta_log(), blob.data(), blob.size(), inputs.data(), inputs.size(), (uint32_t)mode, &pub);
   if (rc != ZKIR_OK) zkir_runtime::detail::raise(rc);
   return PublicInputs(pub, std::move(blob));
 }

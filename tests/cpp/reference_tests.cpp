@@ -223,6 +223,37 @@ static void test_prove_and_verify() {
   CHECK(zkir_prover::verify(bad) != 0);
 }
 
+// Modes 2 and 3 through the C ABI: the I/O argument, + the memory argument and the bitwise opcodes; the memory witness is made on the device by zkir_prove
+static void test_prove_modes() {
+  // store i * 3 into an array, read it back through LW / LBU, AND / XOR it, WRITE the sum, exit 0
+  auto code = cat({{addi(6, 0, 0x4000), addi(1, 0, 0), addi(3, 0, 9), addi(4, 0, 0),
+                    add(2, 1, 1), add(2, 2, 1), sw(6, 2, 0), lw(7, 6, 0), enc_i(Opcode::LBU, 8, 6, 0),
+                    enc_i(Opcode::ANDI, 7, 7, 0xFF), enc_r(Opcode::XOR, 9, 7, 8), add(4, 4, 7), add(4, 4, 9),
+                    addi(6, 6, 4), addi(1, 1, 1), addi(3, 3, -1), bne(3, 0, -48)}, write_reg(4), EXIT0});
+  const Program prog = Program::from_code(code);
+  VMConfig cfg; cfg.enable_execution_trace = true;
+  ExecutionResult r = VM::new_(prog, {}, cfg).run();
+  CHECK(r.outputs.size() == 1 && r.outputs[0] == 3 * 36);                                 // sum of 3 i, i = 0..8 (the XOR of equal bytes adds 0)
+  zkir_prover::StarkContext ctx(zkir_padded_log_n(r.cycles));
+  for (zkir_prover::ProofMode mode : {zkir_prover::ProofMode::Io, zkir_prover::ProofMode::Memory}) {
+    const zkir_prover::PublicInputs pub = zkir_prover::public_inputs(r, prog, {}, mode);
+    CHECK(pub.deferred == (uint32_t)mode && pub.n_outputs == 1);
+    const std::vector<uint32_t> proof = zkir_prover::prove(ctx, r, pub);
+    CHECK(proof[9] == (uint32_t)mode && proof[3] == (mode == zkir_prover::ProofMode::Io ? 160u : 224u));
+    CHECK(zkir_prover::verify(proof) == 0 && zkir_prover::verify(proof, &pub) == 0);
+    std::vector<uint32_t> bad = proof; bad[bad.size() / 3] = (bad[bad.size() / 3] + 1) % 2013265921u;
+    CHECK(zkir_prover::verify(bad) != 0);
+    // a claim of another output: the prover makes a proof of it, the verifiers reject it (the table side of the tape lookup comes from the claim)
+    zkir_prover::PublicInputs forged = pub;
+    zkir_public_inputs raw = forged;
+    std::vector<uint64_t> outs{r.outputs[0] + 1};
+    raw.outputs = outs.data();
+    const zkir_prover::PublicInputs claim(raw, prog.to_bytes());
+    const std::vector<uint32_t> fproof = zkir_prover::prove(ctx, r, claim);
+    CHECK(zkir_prover::verify(fproof) != 0);
+  }
+}
+
 // A run proven in segments through the plain C ABI, as a multi-GPU caller without any HIP code of its own would: one interpretation,
 // zkir_exec_shard per row range (ranges share one row), zkir_prove per shard, zkir_verify_chain over the proofs.
 static void test_segment_proofs_through_the_c_abi() {
@@ -281,7 +312,7 @@ int main(int argc, char** argv) {
       {"test_trace_timestamp_synchronization", test_trace_timestamp_synchronization, true},
       {"test_bound_propagation_and_deferred_checks", test_bound_propagation_and_deferred_checks, true},
       {"test_deferred_carry_normalization_event", test_deferred_carry_normalization_event, true},
-      {"test_prove_and_verify", test_prove_and_verify, true}, {"test_segment_proofs_through_the_c_abi", test_segment_proofs_through_the_c_abi, true}};
+      {"test_prove_and_verify", test_prove_and_verify, true}, {"test_prove_modes", test_prove_modes, true}, {"test_segment_proofs_through_the_c_abi", test_segment_proofs_through_the_c_abi, true}};
   int ran = 0;
   for (const auto& t : tests) {
     if (t.needs_gpu && !gpu) continue;
