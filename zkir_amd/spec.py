@@ -339,6 +339,25 @@ def memory_loop_program(n: int) -> Program:
     ])
 
 
+def memory_ring_program(log2_cells: int = 15) -> Program:
+    """An ENDLESS walk over a ring of 2^log2_cells 8-byte cells at 0x100000 (AIR mode 3 at any size: run with max_cycles, halt = CycleLimit): per iteration (16 rows) the
+    offset advances by 8 and is wrapped with ANDI, the cell gets the XOR of its old LD value with a counter (SD), is read back as a word, an unsigned halfword and a signed byte
+    (LW / LHU / LB), and the running sum is ORed into a flag register — 5 memory accesses and 3 bitwise opcodes in 16 rows, every cell re-visited after 2^log2_cells iterations."""
+    assert 3 <= log2_cells <= 13 + 3, "the ring mask must fit a positive 17-bit immediate"
+    mask = (8 << log2_cells) - 8
+    assert mask <= 65535
+    return Program.from_code([
+        addi(6, 0, 0x8000), slli(6, 6, 5), addi(1, 0, 0), addi(5, 0, 0), addi(4, 0, 0), addi(12, 0, 0),      # base 0x100000, counter, offset, sum, flags
+        # L:
+        add(7, 6, 5),                                                             # the cell's address
+        encode(Opcode.LD, 2, 7, imm=0), encode(Opcode.XOR, 2, 2, 1), encode(Opcode.SD, rs1=7, rs2=2, imm=0),
+        lw(8, 7, 0), encode(Opcode.LHU, 9, 7, imm=2), encode(Opcode.LB, 10, 7, imm=1),
+        add(4, 4, 8), add(4, 4, 9), add(4, 4, 10), encode(Opcode.OR, 12, 12, 4),
+        addi(5, 5, 8), encode(Opcode.ANDI, 5, 5, imm=mask), addi(1, 1, 1), addi(13, 1, 0),
+        jal(0, -60),
+    ])
+
+
 def sha256_chain_program(seed: bytes = bytes(range(32))) -> Program:
     """SHA-256 hash-chain loop of SURVEY.md §8(d) config 5 (pattern of zkir-runtime/tests/crypto_edge_cases.rs:405-427).
     The 32-byte seed is copied from the data section to 0x10000; then forever: sha256(in, 32, out); swap(in, out).
