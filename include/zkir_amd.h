@@ -382,6 +382,10 @@ int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* program_b
 void zkir_memcheck_witness_free(zkir_memcheck_witness* w);
 uint64_t zkir_memcheck_witness_n_cells(const zkir_memcheck_witness* w);
 uint64_t zkir_memcheck_witness_n_accesses(const zkir_memcheck_witness* w);
+/* The same witness made ON THE DEVICE (memcheck.hip: what zkir_prove runs in mode 3 when the public inputs bring no witness), as a call of its own: trace = the DEVICE columns of
+ * a whole run, the outputs are HOST arrays (mem_old / mem_told: n_real entries, zero where the row is no load / store; the cell arrays: capacity `cap`, *n_cells = the count). */
+int zkir_memcheck_witness_device(const zkir_trace_columns* trace, uint64_t n_real, const uint8_t* program_blob, size_t blob_len, uint64_t* mem_old, uint32_t* mem_told,
+                                 uint64_t* cell_addr, uint64_t* cell_bytes, uint32_t* cell_time, uint64_t cap, uint64_t* n_cells, void* hip_stream);
 /* points pub's mode-3 fields at the witness (which must outlive the proving call) and sets pub->deferred = 3 */
 void zkir_public_inputs_set_memory(zkir_public_inputs* pub, const zkir_memcheck_witness* w);
 /* Poseidon2 sponge digest of a byte string (host): [len as four 16-bit pieces] ++ [LE 16-bit halfwords] */

@@ -624,3 +624,34 @@ def test_mode3_at_scale():
     assert np.array_equal(proof, hproof)
     assert rt.verify(proof, pub) == 0 and so.verify(proof) == 0
     ctx.close(); log.close()
+
+
+@pytest.mark.parametrize("k,log2_cells", [(12, 4), (16, 13), (18, 13), (18, 10), (20, 13)])
+def test_memcheck_witness_device_equals_host_replay(k, log2_cells):
+    """zkir_memcheck_witness_device (memcheck.hip: the accesses sorted by (cell, row), a segmented scan per cell) against zkir_memcheck_witness_of (the host's sequential replay)
+    on spec.memory_ring_program — every cell is RE-VISITED after 2^log2_cells iterations, so each cell's accesses are far apart in time and the sort has real work to do (sizes on
+    both sides of rocPRIM's merge-sort / onesweep switch: sorting on the cell bits alone went wrong in between, scripts/dbg/sort_test.hip): old bytes and old time of every row,
+    and the touched cells, entry for entry."""
+    import ctypes as C
+    import torch
+    from zkir_amd import pipeline as pl
+    n = 1 << k
+    blob = spec.memory_ring_program(log2_cells).to_bytes()
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr)); torch.cuda.synchronize()
+    hw = rt.MemcheckWitness(log, blob)
+    pub = rt.PublicInputsC(); pub.with_memory(hw)
+    nc = hw.n_cells
+    assert nc == min(1 << log2_cells, (n - 6) // 16 + 1)
+    host = [np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), (m,)).copy() for p, t, m in
+            ((pub.mem_old, C.c_uint64, n), (pub.mem_told, C.c_uint32, n), (pub.cell_addr, C.c_uint64, nc), (pub.cell_bytes, C.c_uint64, nc), (pub.cell_time, C.c_uint32, nc))]
+    d_old, d_told = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    d_ca, d_cb, d_ct, dn = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint32), C.c_uint64(0)
+    L = rt.lib()
+    L.zkir_memcheck_witness_device.restype = C.c_int
+    L.zkir_memcheck_witness_device.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t] + [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    assert L.zkir_memcheck_witness_device(C.byref(tr.c), n, blob, len(blob), d_old.ctypes.data, d_told.ctypes.data, d_ca.ctypes.data, d_cb.ctypes.data, d_ct.ctypes.data, n, C.byref(dn), None) == 0
+    assert dn.value == nc
+    for got, want, name in zip((d_old, d_told, d_ca[:nc], d_cb[:nc], d_ct[:nc]), host, ("old bytes", "old time", "cell address", "cell bytes", "cell time")):
+        assert np.array_equal(got, want), f"{name}: first difference at {int(np.nonzero(got != want)[0][0])}"
+    log.close()

@@ -4,7 +4,8 @@
 // What a load returns depends on every earlier store to its cell: a chain per CELL, not per run.  The host replay (verify.cpp: zkir_memcheck_witness_of) walks the run once;
 // here the accesses are put in ADDRESS-MAJOR order — the key order VERDICT r3 asked for, (cell, time) — and each cell's chain becomes a segment of a scan:
 //   1. memkey_kernel     one key per row: (cell index << 26) | row for a load / store (rs1 + sext(imm17), registers read from the trace columns), all-ones otherwise;
-//   2. radix sort        rocPRIM, on the cell bits only: the sort is stable and the input is in row order, so each cell's accesses stay in time order;
+//   2. radix sort        rocPRIM, on the whole key: (cell, row) order, each cell's accesses in time order.  (Sorting on the cell bits alone — begin_bit = 26, relying on
+//                        stability — comes out UNSORTED from rocPRIM 7.2's merge-sort path, 2^17 < n <= 2^21 keys: scripts/dbg/sort_test.hip reproduces it; begin_bit = 0 is right at every size);
 //   3. memelem_kernel    per sorted access: (byte mask, bytes placed at their offset) of a store, nothing for a load; head = first access of its cell;
 //   4. segmented scan    rocPRIM inclusive scan with the "later store overwrites" operator (associative), restarting at heads; it also counts the heads;
 //   5. memout_kernel     old bytes = the program image's (code at 0x1000, data behind it, zero elsewhere: vm.rs:153-170) overlaid with the scan value of the PREVIOUS access of
@@ -122,7 +123,7 @@ namespace zkir {
 // untouched).  cells: host vectors, by increasing address.  Synchronises the stream.
 size_t memcheck_scratch_bytes(uint64_t n_real, uint64_t image_len) {
   size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n_real, ROW_BITS, 64, (hipStream_t)0);
+  (void)rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n_real, 0, 64, (hipStream_t)0);
   (void)rocprim::inclusive_scan(nullptr, t2, (MemElem*)nullptr, (MemElem*)nullptr, (size_t)n_real, OverlayOp(), (hipStream_t)0);
   const size_t tmp = (t1 > t2 ? t1 : t2) + 256;
   return tmp + (size_t)n_real * (8 + 8 + 16 + 16 + 8 + 8 + 4) + ((image_len + 255) & ~(size_t)255) + 4096;
@@ -136,7 +137,7 @@ int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint
   if (32 + image_len > blob_len) image_len = 0;
   if (scratch_bytes < memcheck_scratch_bytes(n_real, image_len)) { set_last_error({ZKIR_ERR_ARGUMENT, "memcheck_device: scratch too small"}); return ZKIR_ERR_ARGUMENT; }
   size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n_real, ROW_BITS, 64, s);
+  (void)rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n_real, 0, 64, s);
   (void)rocprim::inclusive_scan(nullptr, t2, (MemElem*)nullptr, (MemElem*)nullptr, (size_t)n_real, OverlayOp(), s);
   const size_t tmp_bytes = ((t1 > t2 ? t1 : t2) + 255) & ~(size_t)255;
   unsigned char* p = (unsigned char*)scratch;
@@ -150,7 +151,7 @@ int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint
   if (image_len) MC_OK(hipMemcpyAsync(d_img, blob + 32, image_len, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(memkey_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, *trace, n_real, keys, d_flags);
   size_t tb = tmp_bytes;
-  MC_OK(rocprim::radix_sort_keys(tmp, tb, keys, skeys, (size_t)n_real, ROW_BITS, 64, s));
+  MC_OK(rocprim::radix_sort_keys(tmp, tb, keys, skeys, (size_t)n_real, 0, 64, s));
   hipLaunchKernelGGL(memelem_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, *trace, n_real, skeys, el);
   tb = tmp_bytes;
   MC_OK(rocprim::inclusive_scan(tmp, tb, el, sc, (size_t)n_real, OverlayOp(), s));
@@ -173,3 +174,27 @@ int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint
 }
 
 }  // namespace zkir
+
+// The device witness on its own (tests: compared entry for entry with zkir_memcheck_witness_of's host replay).  trace = DEVICE columns of a whole run; mem_old / mem_told: HOST
+// arrays of n_real entries (zero where the row is no load / store); cells: HOST arrays of capacity `cap`; *n_cells receives the count (ZKIR_ERR_ARGUMENT if it exceeds cap).
+extern "C" int zkir_memcheck_witness_device(const zkir_trace_columns* trace, uint64_t n_real, const uint8_t* blob, size_t blob_len, uint64_t* mem_old, uint32_t* mem_told, uint64_t* cell_addr,
+                                            uint64_t* cell_bytes, uint32_t* cell_time, uint64_t cap, uint64_t* n_cells, void* stream) {
+  if (!trace || !blob || !mem_old || !mem_told || !n_cells || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memcheck_witness_device: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  const size_t sb = zkir::memcheck_scratch_bytes(n_real, blob_len);
+  void* scratch = nullptr; uint64_t* d_old = nullptr; uint32_t* d_told = nullptr;
+  if (hipMalloc(&scratch, sb) != hipSuccess || hipMalloc((void**)&d_old, n_real * 8) != hipSuccess || hipMalloc((void**)&d_told, n_real * 4) != hipSuccess) {
+    (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told);
+    zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_memcheck_witness_device: out of device memory"}); return ZKIR_ERR_DEVICE;
+  }
+  (void)hipMemsetAsync(d_old, 0, n_real * 8, (hipStream_t)stream); (void)hipMemsetAsync(d_told, 0, n_real * 4, (hipStream_t)stream);
+  std::vector<uint64_t> ca, cb; std::vector<uint32_t> ct;
+  int rc = zkir::memcheck_device(trace, n_real, blob, blob_len, scratch, sb, d_old, d_told, ca, cb, ct, stream);
+  if (rc == ZKIR_OK) {
+    (void)hipMemcpy(mem_old, d_old, n_real * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(mem_told, d_told, n_real * 4, hipMemcpyDeviceToHost);
+    *n_cells = ca.size();
+    if (ca.size() > cap) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memcheck_witness_device: more cells than the caller's buffers hold"}); rc = ZKIR_ERR_ARGUMENT; }
+    else if (!ca.empty()) { memcpy(cell_addr, ca.data(), ca.size() * 8); memcpy(cell_bytes, cb.data(), cb.size() * 8); memcpy(cell_time, ct.data(), ct.size() * 4); }
+  }
+  (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told);
+  return rc;
+}
