@@ -64,6 +64,9 @@ BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
 #ifndef MT_WAVES
 #define MT_WAVES 3
 #endif
+#ifndef MT_WAVES_MEM
+#define MT_WAVES_MEM 2              // mode 3 builds 244 logical words per row: at three waves per SIMD (168 VGPRs) it spills 392 B / lane
+#endif
 // DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 152 columns by default, 168 deferred.
 // The row itself is a host + device function: the kernel below runs it once per lane, zkir_main_trace_host once per row on the CPU — the same
 // code, so the CPU test suite (no GPU) checks it against the oracle column by column (tests/test_abi.py).
@@ -296,7 +299,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   }
 }
 template <int MODE, int SKIP = 0>
-__global__ __launch_bounds__(NT, MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out, IoRowArgs io = IoRowArgs{}) {
+__global__ __launch_bounds__(NT, MODE == 3 ? MT_WAVES_MEM : MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out, IoRowArgs io = IoRowArgs{}) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   main_trace_row<MODE, SKIP>(t, n_real, N, i, out, &io);

@@ -23,6 +23,9 @@ constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
 #ifndef QUOT_WAVES
 #define QUOT_WAVES 3
 #endif
+#ifndef QUOT_WAVES_MEM
+#define QUOT_WAVES_MEM 2            // mode 3 (224 + 96 columns, 559 constraints): at three waves per SIMD the kernel spills 528 B / lane
+#endif
 struct ProveParams {            // constants of one proof, Montgomery form; lives in the proof's workspace (device), uploaded per phase
   E4 alpha_seq[N_CONSTRAINTS + 2];   // alpha^c in the ORDER the quotient kernel consumes them (air::push_order), Montgomery; two spare entries: the kernel requests one ahead
   E4 gamma_pow[2 * WTX + 4];    // main columns, aux columns at zeta; the same at zeta w; the quotient (2 * (committed width + WA) + 4 used)
@@ -149,7 +152,7 @@ struct DeviceRowSrc {
 };
 
 template <int DEF /* the mode */>
-__global__ __launch_bounds__(NT, QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
+__global__ __launch_bounds__(NT, DEF == 3 ? QUOT_WAVES_MEM : QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
                                                                   const uint32_t* __restrict__ inv_xm1, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t w_last_inv_m,
                                                                   uint32_t last_shift, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m, uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
