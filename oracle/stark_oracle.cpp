@@ -217,7 +217,18 @@ static const uint32_t OP_ECALL = 0x50;
 // operands and the result are ten nibbles each, nibble k a tuple (a_k, b_k, r_k) looked up in the 256-entry table of the row's operation — in the nine piece slots (a_k = piece k) and,
 // the tenth, in the row's last range slot (a_9 = chunk R7).  24 more logical columns (244, 224 committed):
 //   220 klg | 221 oa, 222 oo: the operation is AND / OR (XOR = klg - oa - oo) | 223 li: the second operand is the immediate | 224-233 b_0..9 | 234-243 r_0..9
-static const int W_MAIN_MEM = 244, W_MAX = 244;
+// .. and the six SHIFTS SLL SRL SRA SLLI SRLI SRAI (execute.rs:284-358, value.rs:658-697: on the 40-bit value; the amount is rs2 & 63 or the word's 8-bit shamt; 40 and more
+// shift everything out), class sh = 19, as ONE relation a 2^t = H 2^40 + L: a left shift by sh is L at t = sh, a right shift by sh is H at t = 40 - sh.  a comes in its four 10-bit
+// chunks c_i (the row's second range group), t = 10 u + v by two one-hots: c_i 2^v = lo_i + 2^10 hi_i (both in the 10-bit table: unique), the chunks of a 2^v are m_i = lo_i +
+// hi_(i-1) — no carry: lo_i ends in v zeros, hi_(i-1) < 2^v — and the one-hot of u picks four of them.  SRA adds sign (2^40 - 2^t).  32 more logical columns (276, 256 committed):
+//   244 ksh | 245-249 ul_0..4, 250-254 ur_0..4: the row shifts LEFT / RIGHT with chunk shift u | 255-264 v_0..9: the bit shift | 265 sa: SRA / SRAI | 266 si: the amount is the
+//   word's shamt | 267 sb9: bit 39 of a | 268 sgn = sa sb9 | 269-272 pr_i = c_i 2^v | 273-274 the limbs of 2^40 - 2^t on right shifts | 275 sh: the shift amount
+// shared columns on a shift row: R0..R3 = lo_i, R4..R7 = c_i, pieces 0-3 = hi_i, piece 4 = 2 (c_3 mod 2^9), piece 5 = the bits of rs2's low limb above its first chunk (or of the
+// word's field above the shamt), piece 6 = d (sh beyond what t can say), piece 7 = the shamt's high nibble, piece 8 = rs2's first chunk, looked up with sh in LOW6 = {(v, v & 63)}
+static const int W_MAIN_MEM = 276, W_MAX = 276;
+enum { C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275 };
+static const int K_SH = 19, TAG_LOW6 = 11;
+static inline bool is_shift(uint32_t op) { return op >= 0x18 && op <= 0x1D; }
 enum { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219,
        C_KLG = 220, C_OA = 221, C_OO = 222, C_LI = 223, C_LB = 224, C_LR = 234 };
 static const int K_LD = 16, K_ST = 17, K_LG = 18, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
@@ -254,7 +265,7 @@ static const int C_KOJ = C_K3 + 1;
 // mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
 static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
-static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 224 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
+static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 256 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
 // logical [logical_width][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, int mode, std::vector<F>& out) {
   out.assign((size_t)phys_width(mode) * N, 0);
@@ -343,6 +354,7 @@ static inline F opclass_of(uint32_t op, int mode = 0) {
   if (mode == 3 && is_load(op)) return K_LD;
   if (mode == 3 && is_store(op)) return K_ST;
   if (mode == 3 && is_logic(op)) return K_LG;
+  if (mode == 3 && is_shift(op)) return K_SH;
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
@@ -409,6 +421,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     if (cls == K_LD) col(C_KLD)[i] = 1;                       // (mode 3: loads and stores, the bitwise opcodes)
     else if (cls == K_ST) col(C_KST)[i] = 1;
     else if (cls == K_LG) col(C_KLG)[i] = 1;
+    else if (cls == K_SH) col(C_KSH)[i] = 1;
     else if (cls != K_ECALL) col(kcol(cls))[i] = 1;           // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
     col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
@@ -471,6 +484,40 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     } else if (cls == K_SUB) { y[0] = z[0]; y[1] = z[1]; rd = fa; }                  // execute.rs:65-77: Value40 wrapping_sub
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; if (q) rd = fa; }   // execute.rs:434-472: rd = rs1 (raw) if the condition holds, nothing changes otherwise
+    bool sh_row = false; F sh_lo[4] = {0, 0, 0, 0}, sh_c[4] = {0, 0, 0, 0};
+    if (cls == K_SH) {                                        // (mode 3) SLL SRL SRA SLLI SRLI SRAI = 0x18 + (0 / 1 / 2) + 3 si (execute.rs:284-358)
+      sh_row = true;
+      const uint32_t which = (op - 0x18) % 3, si = (op - 0x18) / 3;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20);
+      const uint32_t amount = si ? ((w >> 15) & 0xFF) : (uint32_t)(xc[0] & 63);
+      col(C_SA)[i] = which == 2; col(C_SI)[i] = si; col(C_SH)[i] = amount;
+      // t = the exponent of a 2^t = H 2^40 + L: sh for a left shift (anything from 40 on shifts everything out: t = 40 says that too), 40 - sh for a right shift (0 from sh = 40 on)
+      const uint32_t t = which == 0 ? (amount < 40 ? amount : 40) : (amount < 40 ? 40 - amount : 0);
+      const uint32_t d = which == 0 ? amount - t : amount - (40 - t);
+      const uint32_t u = t / 10, v = t % 10;
+      col((which == 0 ? C_UL : C_UR) + u)[i] = 1; col(C_V + v)[i] = 1;
+      F hi[4], m[5];
+      for (int k = 0; k < 4; k++) {
+        sh_c[k] = (F)((a >> (10 * k)) & 1023);
+        const uint32_t pr = sh_c[k] << v;
+        col(C_PR + k)[i] = pr; sh_lo[k] = pr & 1023; hi[k] = pr >> 10;
+        col(C_PIECE + k)[i] = hi[k];
+      }
+      const F sb9 = sh_c[3] >> 9, sgn = (which == 2) ? sb9 : 0;
+      col(C_SB9)[i] = sb9; col(C_SGN)[i] = sgn;
+      col(C_PIECE + 4)[i] = 2 * (sh_c[3] & 511);
+      col(C_PIECE + 6)[i] = d;
+      if (si) { const F fhi_v = w >> 19; col(C_PIECE + 7)[i] = fhi_v & 15; col(C_PIECE + 5)[i] = fhi_v >> 4; }
+      else { col(C_PIECE + 8)[i] = xc[0] & 1023; col(C_PIECE + 5)[i] = xc[0] >> 10; col(C_LB + 8)[i] = amount; }
+      m[0] = sh_lo[0]; for (int k = 1; k < 4; k++) m[k] = sh_lo[k] + hi[k - 1]; m[4] = hi[3];
+      uint64_t res = 0;
+      for (int j = 0; j < 4; j++) { const int idx = which == 0 ? j - (int)u : j + 4 - (int)u; if (idx >= 0 && idx <= 4) res |= (uint64_t)m[idx] << (10 * j); }
+      uint64_t ones = 0;
+      if (which != 0) { ones = ((1ull << 40) - 1) & ~((1ull << t) - 1); col(C_ON)[i] = (F)(ones & 0xFFFFF); col(C_ON + 1)[i] = (F)(ones >> 20); }
+      if (sgn) res |= ones;
+      y[0] = (F)(res & 0xFFFFF); y[1] = (F)(res >> 20); y[2] = 0;
+      rd = fa;
+    }
     F lg_a9 = 0; bool lg_row = false;
     if (cls == K_LG) {                                        // (mode 3) AND OR XOR ANDI ORI XORI on the 40-bit values (execute.rs:199-282), nibble by nibble
       lg_row = true;
@@ -556,10 +603,12 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     }
     if (mem_row) { rc2[0] = mem_dt & (RC_TABLE - 1); rc2[1] = (mem_dt >> RC_BITS) & (RC_TABLE - 1); rc2[2] = mem_dt >> (2 * RC_BITS); rc2[3] = 0; }   // (mode 3) cycle - told in three chunks: the time read is smaller than the time written
     if (lg_row) { rc2[0] = rc2[1] = rc2[2] = 0; rc2[3] = lg_a9; }                              // (mode 3) a bitwise row's tenth nibble tuple sits in the last range slot
+    if (sh_row) for (int k = 0; k < 4; k++) rc2[k] = sh_c[k];                                   // (mode 3) a shift row: the chunks of the shifted value
     for (int k = 0; k < 4; k++) col(C_RC2 + k)[i] = rc2[k];
     if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_OTH || cls == K_ECALL || (cls == K_OJ && D)) { z[0] = y[0]; z[1] = y[1]; }   // the written value's low limbs are the range-checked pair
     if (mem_row) { z[0] = mem_z[0]; z[1] = mem_z[1]; }         // (mode 3) the address's two low limbs are the range-checked pair
     col(C_RC)[i] = z[0] & (RC_TABLE - 1); col(C_RC + 1)[i] = z[0] >> RC_BITS; col(C_RC + 2)[i] = z[1] & (RC_TABLE - 1); col(C_RC + 3)[i] = z[1] >> RC_BITS;
+    if (sh_row) for (int k = 0; k < 4; k++) col(C_RC + k)[i] = sh_lo[k];                        // (mode 3) a shift row: the low halves of c_i 2^v
     col(C_C0)[i] = c0; col(C_C1)[i] = c1;
     if (cls == K_JALR) {                                                                            // pc' + b0 = rs1 + sext(imm17) over (20, 20, 24)-bit limbs, mod 2^64
       const uint64_t v0 = (uint64_t)xb[0] + im0; const F d0 = (F)(v0 >> 20);
@@ -632,7 +681,11 @@ static inline void row_tuple(const std::vector<F>& M, size_t N, size_t i, F out[
 static inline F row_offset(const std::vector<F>& M, size_t N, size_t i) { F off = 0; for (int v = 0; v < N_WIN; v++) off += M[(size_t)(C_E + v) * N + i] * (F)win_start(v); return off; }   // (mode 3) the window's offset in its cell
 static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KLD * N + i] + M[(size_t)C_KST * N + i]; }
 // mem_mult (mode 3): LOW3 (1024) ++ BYTE (256) ++ NIBBLE (16)
-static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256, LG_BASE = RC_TABLE + 256 + 16;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR
+static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE, LG_BASE = RC_TABLE + 256 + 16, L6_BASE = LG_BASE + 3 * 256;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR ++ LOW6 (1024: entry v = the tuple (v, v & 63))
+static inline bool row_shift(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0; }
+static inline bool row_shift_reg(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0 && M[(size_t)C_SI * N + i] == 0; }
+// the table a piece slot looks its value up in on a SHIFT row: 0-6 the 10-bit range table, 7 the nibble table, 8 LOW6 (with the amount) when the amount comes from a register
+static inline int shift_piece_tag(int k, bool reg) { return k == 7 ? TAG_NIB : (k == 8 && reg) ? TAG_LOW6 : 0; }
 static inline int row_logic_op(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KLG * N + i] ? (M[(size_t)C_OA * N + i] ? 0 : M[(size_t)C_OO * N + i] ? 1 : 2) : -1; }   // 0 AND, 1 OR, 2 XOR; -1: not a bitwise row
 static inline F logic_of(int which, F a, F b) { return which == 0 ? (a & b) : which == 1 ? (a | b) : (a ^ b); }
 static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& rom, std::vector<F>& rom_mult, std::vector<F>& rc_mult, size_t* first_bad_row = nullptr, int mode = 0,
@@ -657,6 +710,13 @@ static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& 
       if (row_logic_op(M, N, i) >= 0) {                       // a bitwise row: every piece slot looks up the nibble tuple (a_k, b_k, r_k) in the operation's table
         const int which = row_logic_op(M, N, i); const F b = M[(size_t)(C_LB + k) * N + i], r = M[(size_t)(C_LR + k) * N + i];
         if (v < 16 && b < 16 && r == logic_of(which, v, b)) (*mem_mult)[LG_BASE + 256 * which + 16 * v + b]++; else bad(i);
+        continue;
+      }
+      if (row_shift(M, N, i)) {                               // a shift row: the slots are re-typed (shift_piece_tag)
+        const int tag = shift_piece_tag(k, row_shift_reg(M, N, i));
+        if (tag == TAG_LOW6) { if (v < (F)RC_TABLE && M[(size_t)(C_LB + 8) * N + i] == (v & 63)) (*mem_mult)[L6_BASE + v]++; else bad(i); }
+        else if (tag == TAG_NIB) { if (v < 16) (*mem_mult)[RC_TABLE + 256 + v]++; else bad(i); }
+        else { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); }
         continue;
       }
       if (PIECE_TAG[k] == TAG_BYTE) { if (v < 256) (*mem_mult)[RC_TABLE + v]++; else bad(i); }
@@ -692,6 +752,7 @@ static E lookup_table_sum(const Rom& rom, const F* rom_mult, const F* rc_mult, c
     for (int t = 0; t < 16; t++) m[RC_TABLE + 256 + t] = esub(lp.alpha, tagged((F)t, TAG_NIB, lp));
     for (int which = 0; which < 3; which++) for (int t = 0; t < 256; t++)      // (a, b, a op b): a + lambda b + lambda^2 r + (8 + which) lambda^11
       m[LG_BASE + 256 * which + t] = esub(lp.alpha, eadd(eadd(tagged((F)(t >> 4), TAG_AND + which, lp), emul_f(lp.lam[1], (F)(t & 15))), emul_f(lp.lam[2], logic_of(which, (F)(t >> 4), (F)(t & 15)))));
+    for (int t = 0; t < RC_TABLE; t++) m[L6_BASE + t] = esub(lp.alpha, eadd(tagged((F)t, TAG_LOW6, lp), emul_f(lp.lam[1], (F)(t & 63))));
   }
   batch_einv(d);
   E T = e_from(0);
@@ -766,6 +827,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
       const int lgop = row_logic_op(M, N, i);
       for (int k = 0; k < N_PIECE; k++) {
         const E h = lgop >= 0 ? einv(esub(lp.alpha, eadd(eadd(tagged(at(C_PIECE + k), TAG_AND + lgop, lp), emul_f(lp.lam[1], at(C_LB + k))), emul_f(lp.lam[2], at(C_LR + k)))))
+                  : row_shift(M, N, i) ? einv(esub(lp.alpha, eadd(tagged(at(C_PIECE + k), shift_piece_tag(k, row_shift_reg(M, N, i)), lp), emul_f(lp.lam[1], at(C_LB + k)))))
                               : einv(esub(lp.alpha, tagged(at(C_PIECE + k), PIECE_TAG[k], lp)));
         for (int c = 0; c < 4; c++) A[(size_t)(A_P + 4 * k + c) * N + i] = h.c[c];
         hs = eadd(hs, h);
@@ -794,7 +856,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
-static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 640;
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 704;
 static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns); v9: AIR v5 (eight range lookups, 40 aux columns, the variant bit in the ROM tuple); v10: AIR v6 (172 logical columns, 152 / 168 committed)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
@@ -876,9 +938,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E Kec = IO ? eadd(eadd(loc[C_F2], loc[C_RL]), eadd(loc[C_RE], loc[C_FH])) : e_from(0);   // (mode 2) the ecall class: the sum of its four syscall flags
   const E Kld = MEM ? loc[C_KLD] : e_from(0), Kst = MEM ? loc[C_KST] : e_from(0), Kmem = eadd(Kld, Kst);   // (mode 3) loads, stores
   const E Klg = MEM ? loc[C_KLG] : e_from(0);                                                             // (mode 3) the bitwise opcodes
-  { E sum = eadd(eadd(Kec, Kmem), Klg); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  const E Ksh = MEM ? loc[C_KSH] : e_from(0);                                                             // (mode 3) the shifts
+  { E sum = eadd(eadd(eadd(Kec, Kmem), Klg), Ksh); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
-    E ks = eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST)));
+    E ks = eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST)));
     for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
@@ -1185,7 +1248,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     const E lgtag = eadd(eadd(emul_f(loc[C_OA], TAG_AND), emul_f(loc[C_OO], TAG_OR)), emul_f(ox, TAG_XOR));
     for (int i = 0; i < N_PIECE; i++) {
       E d[4], pr[4];
-      const E tg = eadd(emul_f(esub(one, Klg), PIECE_TAG[i]), lgtag);
+      // (.. and on a shift row in the table shift_piece_tag names; piece 8's second element is the amount when it comes from a register)
+      E tg = eadd(emul_f(esub(esub(one, Klg), Ksh), PIECE_TAG[i]), lgtag);
+      if (i == 7) tg = eadd(tg, emul_f(Ksh, TAG_NIB));
+      if (i == 8) tg = eadd(tg, emul_f(esub(Ksh, loc[C_SI]), TAG_LOW6));
       for (int k = 0; k < 4; k++) d[k] = esub(esub(esub(cst(lp.alpha.c[k]), emul_f(tg, lp.lam[N_TUPLE].c[k])), emul_f(loc[C_LB + i], lp.lam[1].c[k])), emul_f(loc[C_LR + i], lp.lam[2].c[k]));
       d[0] = esub(d[0], pcs[i]);
       ext_mul(aloc + A_P + 4 * i, d, pr);
@@ -1208,7 +1274,56 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     push(eadd(emul(esub(Klg, li), esub(xc[0], b_lo)), emul(li, esub(im0, b_lo))));               // rs2's, or the sign-extended immediate's
     push(eadd(emul(esub(Klg, li), esub(xc[1], b_hi)), emul(li, esub(im1, b_hi))));
     push(emul(Klg, esub(y[0], r_lo))); push(emul(Klg, esub(y[1], r_hi))); push(emul(Klg, y[2]));   // the result: 40 bits
-    for (int k = 0; k < N_NIB; k++) { push(emul(esub(one, Klg), loc[C_LB + k])); push(emul(esub(one, Klg), loc[C_LR + k])); }   // no second / third tuple element off the bitwise rows
+    for (int k = 0; k < N_NIB; k++) {                                                             // no second / third tuple element off the bitwise rows (b_8: nor off the register shifts)
+      push(emul(k == 8 ? eadd(esub(esub(one, Klg), Ksh), loc[C_SI]) : esub(one, Klg), loc[C_LB + k])); push(emul(esub(one, Klg), loc[C_LR + k]));
+    }
+    // ---- 20. (mode 3) the shifts SLL SRL SRA SLLI SRLI SRAI = 0x18 + (0 / 1 / 2) + 3 si (execute.rs:284-358): a 2^t = H 2^40 + L, t = 10 u + v ----
+    {
+      const E* UL = loc + C_UL; const E* UR = loc + C_UR; const E* V = loc + C_V; const E* PR = loc + C_PR; const E* Rlo = loc + C_RC; const E* Rc = loc + C_RC2;
+      const E sa = loc[C_SA], si = loc[C_SI], sb9 = loc[C_SB9], sgn = loc[C_SGN], shv = loc[C_SH], dd = pcs[6];
+      boolean(Ksh);
+      for (int u = 0; u < 5; u++) boolean(UL[u]);
+      for (int u = 0; u < 5; u++) boolean(UR[u]);
+      for (int v = 0; v < 10; v++) boolean(V[v]);
+      boolean(sa); boolean(si); boolean(sb9);
+      E sUL = e_from(0), sUR = e_from(0), sV = e_from(0), tt = e_from(0), PV = e_from(0), vsum = e_from(0);
+      for (int u = 0; u < 5; u++) { sUL = eadd(sUL, UL[u]); sUR = eadd(sUR, UR[u]); tt = eadd(tt, emul_f(eadd(UL[u], UR[u]), 10 * u)); }
+      for (int v = 0; v < 10; v++) { sV = eadd(sV, V[v]); tt = eadd(tt, emul_f(V[v], v)); PV = eadd(PV, emul_f(V[v], 1u << v)); if (v) vsum = eadd(vsum, emul_f(V[v], v)); }
+      push(esub(eadd(sUL, sUR), Ksh)); push(esub(sV, Ksh));                                       // one chunk shift (left or right) and one bit shift on a shift row, none elsewhere
+      push(esub(esub(esub(emul(Ksh, esub(op, cst(0x18))), sUR), sa), emul_f(si, 3)));             // the opcode: 0x18 + [right] + [arithmetic] + 3 [immediate]
+      push(emul(sa, esub(one, sUR))); push(emul(si, esub(one, Ksh)));
+      push(emul(Ksh, esub(w1, fa)));                                                              // rd = field a
+      push(emul(Ksh, esub(esub(xb[0], Rc[0]), emul_f(Rc[1], RC_TABLE)))); push(emul(Ksh, esub(esub(xb[1], Rc[2]), emul_f(Rc[3], RC_TABLE))));   // a's four chunks
+      for (int k = 0; k < 4; k++) push(esub(PR[k], emul(Rc[k], PV)));                             // c_k 2^v ..
+      for (int k = 0; k < 4; k++) push(emul(Ksh, esub(esub(PR[k], Rlo[k]), emul_f(pcs[k], RC_TABLE))));   // .. = lo_k + 2^10 hi_k
+      push(emul(Ksh, esub(esub(Rc[3], emul_f(sb9, 512)), emul(pcs[4], cst(finv(2))))));           // bit 39 of a: c_3 = 512 sb9 + piece_4 / 2
+      push(esub(sgn, emul(sa, sb9)));
+      // the amount: rs2's low six bits (its first chunk piece_8 with sh in LOW6, the rest of the limb in piece_5), or the word's shamt fc + 16 (fhi mod 16)
+      push(emul(esub(Ksh, si), esub(esub(xc[0], pcs[8]), emul_f(pcs[5], RC_TABLE))));
+      push(emul(esub(Ksh, si), esub(loc[C_LB + 8], shv)));
+      push(emul(si, esub(esub(fhi, pcs[7]), emul_f(pcs[5], 16))));
+      push(emul(si, esub(esub(shv, fc), emul_f(pcs[7], 16))));
+      push(emul(esub(one, Ksh), shv));
+      // sh = t + d on a left shift, 40 - t + d on a right shift; d (>= 0: a range lookup) only where t cannot say more: t = 40 resp. t = 0
+      push(eadd(emul(sUL, esub(esub(shv, tt), dd)), emul(sUR, esub(eadd(esub(shv, cst(40)), tt), dd))));
+      push(emul(dd, vsum)); push(emul(esub(sUL, UL[4]), dd)); push(emul(esub(sUR, UR[0]), dd));
+      push(emul(UR[4], esub(one, V[0])));                                                        // a right shift keeps at most 40 bits: t <= 40
+      // 2^40 - 2^t in limbs (right shifts): t < 20: (2^20 - 2^t, 2^20 - 1); 20 <= t < 40: (0, 2^20 - 2^(t-20)); t = 40: (0, 0)
+      {
+        const E low = eadd(UR[0], UR[1]);
+        push(esub(loc[C_ON], esub(emul_f(low, 1u << 20), emul(eadd(UR[0], emul_f(UR[1], 1u << 10)), PV))));
+        push(esub(loc[C_ON + 1], esub(esub(esub(emul_f(sUR, 1u << 20), low), emul(eadd(UR[2], emul_f(UR[3], 1u << 10)), PV)), emul_f(UR[4], 1u << 20))));
+      }
+      // the chunks of a 2^v: m_0 = lo_0, m_i = lo_i + hi_(i-1), m_4 = hi_3; result chunk j = m_(j-u) on a left shift, m_(j+4-u) on a right shift
+      E m[5] = {Rlo[0], eadd(Rlo[1], pcs[0]), eadd(Rlo[2], pcs[1]), eadd(Rlo[3], pcs[2]), pcs[3]}, res[4];
+      for (int j = 0; j < 4; j++) {
+        res[j] = e_from(0);
+        for (int u = 0; u < 5; u++) { if (j - u >= 0) res[j] = eadd(res[j], emul(UL[u], m[j - u])); if (j + 4 - u >= 0 && j + 4 - u <= 4) res[j] = eadd(res[j], emul(UR[u], m[j + 4 - u])); }
+      }
+      push(esub(esub(emul(Ksh, y[0]), eadd(res[0], emul_f(res[1], RC_TABLE))), emul(sgn, loc[C_ON])));
+      push(esub(esub(emul(Ksh, y[1]), eadd(res[2], emul_f(res[3], RC_TABLE))), emul(sgn, loc[C_ON + 1])));
+      push(emul(Ksh, y[2]));
+    }
   }
   result = A.acc;
   return A.c;

@@ -560,7 +560,7 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
     proof = stark.prove(ctx, tr, pub)
     want = so.prove(ores.rows, opub)
-    assert proof[3] == 224 and proof[9] == 3 and len(proof) == len(want)
+    assert proof[3] == 256 and proof[9] == 3 and len(proof) == len(want)
     if not np.array_equal(proof, want):
         bad = np.nonzero(proof != want)[0]
         raise AssertionError(f"mode-3 proof differs at word {bad[0]} of {len(want)} ({len(bad)} words differ)")

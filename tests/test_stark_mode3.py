@@ -20,7 +20,7 @@ def _case(blob, ins=(), **cfg):
 
 
 def test_widths():
-    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (244, 224, 96, 559)
+    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (276, 256, 96, 616)
     assert (so.logical_width(2), so.committed_width(2), so.aux_width(2), so.lib().so_num_constraints_for(2)) == (180, 160, 48, 430)      # mode 2 untouched
 
 
@@ -30,7 +30,7 @@ def test_honest_runs_are_accepted(name):
     blob, ins, cfg = getattr(pg, name)()
     ores, pub = _case(blob, ins, **{k: v for k, v in cfg.items() if k == "max_cycles"})
     proof = so.prove(ores.rows, pub)
-    assert proof[9] == 3 and proof[3] == 224
+    assert proof[9] == 3 and proof[3] == 256
     assert so.verify(proof, pub) == 0
     assert so.failing_constraints(so.main_trace(ores.rows, pub), pub, so.mem_cells(ores.rows, pub))[0] == 0
     assert so.verify_segment(proof, pub)[0] == 2                                  # the memory check spans the whole run: never a segment
@@ -152,6 +152,60 @@ def test_bitwise_opcodes_are_constrained():
     assert bad(lambda F: F.__setitem__((C_LB + 1, j), (int(F[C_LB + 1, j]) + 1) % 16))                                      # .. that is not the immediate's
     k0 = int(np.nonzero(ops == 0x08)[0][0])
     assert bad(lambda F: F.__setitem__((C_LB, k0), 3))                                                                      # a tuple element on a row that is no bitwise row
+
+
+def test_shifts_are_constrained():
+    """SLL SRL SRA SLLI SRLI SRAI on 40-bit values (value.rs:658-697): every amount class — 0, inside a chunk, on chunk borders, 39, 40 (everything shifted out), beyond 40 and
+    beyond 49, a register amount with bits above 63 set (masked), an 8-bit shamt of 255 — on a negative and a positive value; honest rows satisfy every constraint; a result off by
+    a bit, a shift by another amount than the register says, a left shift computed as a right shift, a forged sign fill: each is rejected."""
+    O, E = spec.Opcode, spec.encode
+    code = pg.li40(1, 0xF0F0A5C3E1) + pg.li40(2, 0x0312345678)
+    amounts = [0, 1, 9, 10, 11, 19, 20, 29, 30, 39, 40, 41, 49, 50, 63]
+    for n, sh in enumerate(amounts):
+        code += [A(3, 0, sh + (64 if n % 2 else 0)), E(O.SLL, 4, 1, 3), E(O.SRL, 5, 1, 3), E(O.SRA, 6, 1, 3), E(O.SRA, 7, 2, 3)]
+    for sh in amounts + [64, 200, 255]:
+        code += [E(O.SLLI, 8, 1, imm=sh), E(O.SRLI, 9, 1, imm=sh), E(O.SRAI, 10, 1, imm=sh), E(O.SRAI, 11, 2, imm=sh), E(O.SLLI, 0, 2, imm=sh)]
+    ores, pub = _case(pg._p(code + [pg.EB]))
+    M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    regs, ops = ores.rows["registers"], ores.rows["instruction"] & 0x7F
+    a, m40 = 0xF0F0A5C3E1, (1 << 40) - 1
+    for i in np.nonzero((ops >= 0x18) & (ops <= 0x1D))[0]:                                  # the VM's own results are what value.rs says (the oracle is the restated VM)
+        w = int(ores.rows["instruction"][i]); op = w & 0x7F; rd = (w >> 7) & 15; rs1 = (w >> 11) & 15
+        sh = ((w >> 15) & 0xFF) if op >= 0x1B else int(regs[i][(w >> 15) & 15]) & 63
+        v = int(regs[i][rs1]) & m40
+        want = {0: 0 if sh >= 40 else (v << sh) & m40, 1: 0 if sh >= 40 else v >> sh,
+                2: ((m40 if v >> 39 else 0) if sh >= 40 else ((v >> sh) | ((m40 ^ ((1 << (40 - sh)) - 1)) if v >> 39 else 0)))}[(op - 0x18) % 3]
+        if rd:
+            assert int(regs[i + 1][rd]) == want, (hex(op), sh, hex(v))
+    assert so.failing_constraints(M, pub, cells)[0] == 0 and so.verify(so.prove(ores.rows, pub), pub) == 0
+    C_KSH, C_UL, C_UR, C_V, C_SGN, C_PR, C_ON, C_SH = 244, 245, 250, 255, 268, 269, 273, 275
+
+    def bad(edit):
+        F = M.copy(); edit(F)
+        return so.failing_constraints(F, pub, cells)[0] > 0 and so.verify(so.prove_matrix_mem(F, pub, cells), None) == 10
+    nr = len(ops)
+    i = int(np.nonzero((ops == 0x18) & (M[C_SH][:nr] == 11))[0][0])                              # SLL by 11 (u = 1, v = 1)
+    assert M[C_UL + 1, i] == 1 and M[C_V + 1, i] == 1
+
+    def result_off_by_a_bit(F):
+        F[C_Y, i] = int(F[C_Y, i]) ^ 2; F[C_LIMB + 12, i + 1:i + 2] = F[C_Y, i]
+    assert bad(result_off_by_a_bit)
+
+    def other_amount(F):                                                                   # the row shifts by 12 while the register says 11
+        F[C_V + 1, i] = 0; F[C_V + 2, i] = 1
+        a_ = int(regs[i][1]) & m40
+        for k in range(4):
+            pr = ((a_ >> (10 * k)) & 1023) << 2
+            F[C_PR + k, i] = pr; F[135 + k, i] = pr & 1023; F[C_PIECE + k, i] = pr >> 10
+        r = (a_ << 12) & m40
+        F[C_Y, i], F[C_Y + 1, i] = r & 0xFFFFF, r >> 20; F[C_LIMB + 12, i + 1:i + 2] = r & 0xFFFFF; F[C_LIMB + 13, i + 1:i + 2] = r >> 20
+    assert bad(other_amount)
+    assert bad(lambda F: (F.__setitem__((C_UL + 1, i), 0), F.__setitem__((C_UR + 1, i), 1)))   # a left shift run as a right shift (the opcode says left)
+    j = int(np.nonzero((ops == 0x1A) & (M[C_SH][:nr] == 9) & (M[C_SGN][:nr] == 1))[0][0])             # SRA by 9 of a negative value
+    assert bad(lambda F: F.__setitem__((C_SGN, j), 0))                                       # the sign fill dropped
+    assert bad(lambda F: F.__setitem__((C_ON, j), int(F[C_ON, j]) ^ 1))                      # .. or of another width
+    k0 = int(np.nonzero(ops == 0x08)[0][0])
+    assert bad(lambda F: F.__setitem__((C_V + 3, k0), 1))                                    # a bit shift on a row that is no shift
 
 
 # ---- the product's verifier (zkir_verify, verify.cpp + air.h) on the oracle's mode-3 proofs: same verdict and same failing check ------------------------------------

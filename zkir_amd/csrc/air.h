@@ -57,7 +57,7 @@
 
 namespace air {
 
-constexpr int W = 244;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
+constexpr int W = 276;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
 constexpr int W_LOGICAL_BASE = 172, W_LOGICAL_IO = 180;
 // MODES (the header's word 9, zkir_public_inputs::deferred): 0 = default VM mode, 1 = deferred carry model, 2 (round 4) = default mode WITH the I/O argument:
 // ECALL is a class of its own there (id K_ECALL, no column: Kec = f2 + rl + re + fh), dispatched on R10's limbs — f2 = WRITE (R10 = 2), rl / re = READ (R10 = 1) on a
@@ -78,9 +78,18 @@ enum : int { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 
 // and result are ten nibbles each, nibble k a tuple (a_k, b_k, r_k) looked up in the 256-entry table of the row's operation — in the nine piece slots (a_k = piece k) and, the tenth, in
 // the row's last range slot (a_9 = chunk R7); oa / oo: the operation is AND / OR (XOR = klg - oa - oo), li: the second operand is the immediate
 enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PIECE = 206, C_SGB = 215, C_SGH = 216, C_TB = 217, C_SX = 218, C_CM2 = 219,
-             C_KLG = 220, C_OA = 221, C_OO = 222, C_LI = 223, C_LB = 224, C_LR = 234 };
-constexpr int K_LD = 16, K_ST = 17, K_LG = 18, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
+             C_KLG = 220, C_OA = 221, C_OO = 222, C_LI = 223, C_LB = 224, C_LR = 234,
+             // .. and the six SHIFTS SLL SRL SRA SLLI SRLI SRAI (execute.rs:284-358, value.rs:658-697), class sh = 19, as ONE relation a 2^t = H 2^40 + L (a left shift by sh is L at
+             // t = sh, a right shift H at t = 40 - sh; 40 and more shift everything out): a in its four 10-bit chunks c_i (the row's second range group), t = 10 u + v by two
+             // one-hots, c_i 2^v = lo_i + 2^10 hi_i (both range-checked: unique), the chunks of a 2^v are m_i = lo_i + hi_(i-1) — no carry — and the one-hot of u picks four of
+             // them; SRA adds sign (2^40 - 2^t).  ksh | ul_0..4 / ur_0..4: shifts LEFT / RIGHT with chunk shift u | v_0..9: the bit shift | sa: SRA / SRAI | si: the amount is the
+             // word's shamt | sb9: bit 39 of a | sgn = sa sb9 | pr_i = c_i 2^v | on_0, on_1: the limbs of 2^40 - 2^t on right shifts | sh: the amount.  Shared columns on a shift
+             // row: R0..R3 = lo_i, R4..R7 = c_i, pieces 0-3 = hi_i, 4 = 2 (c_3 mod 2^9), 5 = the rest of rs2's low limb / of the word's field, 6 = d (what sh exceeds t's range
+             // by), 7 = the shamt's high nibble, 8 = rs2's first chunk, looked up WITH sh in LOW6 = {(v, v & 63)}
+             C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275 };
+constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
 BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
+BB_HD constexpr bool is_shift(uint32_t op) { return op >= 0x18 && op <= 0x1D; }
 BB_HD constexpr int win_width(int v) { return v < 8 ? 1 : v < 12 ? 2 : v < 14 ? 4 : 8; }
 BB_HD constexpr int win_start(int v) { return v < 8 ? v : v < 12 ? 2 * (v - 8) : v < 14 ? 4 * (v - 12) : 0; }
 BB_HD constexpr int win_of(int width, int off) { return width == 1 ? off : width == 2 ? 8 + off / 2 : width == 4 ? 12 + off / 4 : 14; }
@@ -91,7 +100,10 @@ BB_HD constexpr int mem_width(uint32_t op) { return is_store(op) ? 1 << (op - OP
 // (mode 3) lookup tables beside the 10-bit range table (no tag), the ROM (tag 1) and the tapes (2, 3): LOW3 = {(v, v & 7) : v < 2^10} (tag 4: the FIRST range chunk of a memory
 // row is looked up there, with the window's offset = the address's low three bits), BYTE = {v < 2^8} (5), NIBBLE = {v < 2^4} (6); memory tuples carry tag 7
 // 8 / 9 / 10: the nibble tables {(a, b, a op b)} of AND / OR / XOR (256 entries each, entry 16 a + b); the multiplicities of LOW3 | BYTE | NIBBLE | AND | OR | XOR travel together
-constexpr int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10, LG_BASE = 1024 + 256 + 16, MEM_MULT = LG_BASE + 3 * 256;
+// 11: LOW6 = {(v, v & 63)} (1024 entries): the amount of a register shift
+constexpr int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10, TAG_LOW6 = 11, LG_BASE = 1024 + 256 + 16, L6_BASE = LG_BASE + 3 * 256,
+              MEM_MULT = L6_BASE + 1024;
+BB_HD constexpr int shift_piece_tag(int k, bool reg) { return k == 7 ? TAG_NIB : (k == 8 && reg) ? TAG_LOW6 : 0; }   // the table a piece slot reads on a SHIFT row
 BB_HD constexpr uint32_t logic_of(int which, uint32_t a, uint32_t b) { return which == 0 ? (a & b) : which == 1 ? (a | b) : (a ^ b); }
 BB_HD constexpr int piece_tag(int k) { return (k == 2 || k == 3) ? TAG_NIB : (k == 5 || k == 8) ? 0 : TAG_BYTE; }   // d0 d1 n0 n1 d3 d4 d5 d6 d7 (0: the 10-bit range table)
 enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
@@ -103,14 +115,14 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
 // 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 224, W_COMMITTED_MAX = 224;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 256, W_COMMITTED_MAX = 256;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
 BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 BB_HD constexpr int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
 BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : mode == 3 ? W_COMMITTED_MEM : W_COMMITTED_DEFAULT; }
-BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 244 - 20)
+BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 276 - 20)
 BB_HD constexpr int logical_width(int mode) { return mode == 3 ? W : mode == 2 ? W_LOGICAL_IO : W_LOGICAL_BASE; }
 // the logical column stored at committed position p (p < committed_used)
 BB_HD constexpr int logical_col(int p, int mode) {
@@ -140,7 +152,7 @@ BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
-  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 3 && is_shift(op)) ? (uint32_t)K_SH : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;
@@ -167,7 +179,11 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              // the bitwise opcodes (mode 3, appended): booleans klg oa oo ox li (5), the opcode (1), li only on bitwise rows (1), rd (1), rs1's nibbles (2), the second operand's (2),
              // the result (3), no b_k / r_k off the bitwise rows (20)
              I_LG_BOOL = 524, I_LG_OP = 529, I_LG_LI = 530, I_LG_WR = 531, I_LG_A = 532, I_LG_B = 534, I_LG_Y = 536, I_LG_ZERO = 539,
-             N_CONSTRAINTS = 559 };
+             // the shifts (mode 3, appended): booleans ksh ul ur v sa si sb9 (24), one chunk / bit shift (2), the opcode (3), rd (1), a's chunks (2), c_i 2^v (4) = lo + 2^10 hi (4),
+             // the sign (2), the amount (5), sh vs t (1), d's guards (3), t <= 40 (1), 2^40 - 2^t (2), the result (3)
+             I_SH_BOOL = 559, I_SH_ONE = 583, I_SH_OP = 585, I_SH_WR = 588, I_SH_A = 589, I_SH_PR = 591, I_SH_LOHI = 595, I_SH_SIGN = 599, I_SH_AMT = 601, I_SH_T = 606, I_SH_D = 607,
+             I_SH_T40 = 610, I_SH_ON = 611, I_SH_Y = 613,
+             N_CONSTRAINTS = 616 };
 BB_HD constexpr int num_constraints(int mode) { return mode == 3 ? N_CONSTRAINTS : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
@@ -337,8 +353,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   // classes and the opcode
   V F2 = zero, RL = zero, RE = zero, FH = zero, H0 = zero, H1 = zero;   // (mode 2) the syscall flags of an ECALL row; Kec = their sum is the row's class
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
-  V Kld = zero, Kst = zero, Klg = zero;                        // (mode 3) loads, stores, the bitwise opcodes
-  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); }
+  V Kld = zero, Kst = zero, Klg = zero, Ksh = zero;            // (mode 3) loads, stores, the bitwise opcodes, the shifts
+  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); Ksh = o.loc(C_KSH); }
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
@@ -351,7 +367,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.acc_lin(sum, F2, 1); o.acc_lin(sum, RL, 1); o.acc_lin(sum, RE, 1); o.acc_lin(sum, FH, 1);
       o.acc_lin(ks, F2, K_ECALL); o.acc_lin(ks, RL, K_ECALL); o.acc_lin(ks, RE, K_ECALL); o.acc_lin(ks, FH, K_ECALL);
     }
-    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(sum, Klg, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); o.acc_lin(ks, Klg, K_LG); }
+    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(sum, Klg, 1); o.acc_lin(sum, Ksh, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); o.acc_lin(ks, Klg, K_LG); o.acc_lin(ks, Ksh, K_SH); }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
     if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), opc), o.accl_val(ks)));
@@ -687,7 +703,10 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
 #pragma unroll
     for (int i = 0; i < N_PIECE; i++) {
       V h[4], d[4], pr[4];
-      const V tg = piece_tag(i) ? o.add(o.mulc(nlg, M((uint32_t)piece_tag(i))), lgtag) : lgtag;
+      // (.. and on a SHIFT row in the table shift_piece_tag names; piece 8's second element is then the amount, when it comes from a register)
+      V tg = piece_tag(i) ? o.add(o.mulc(o.sub(nlg, Ksh), M((uint32_t)piece_tag(i))), lgtag) : lgtag;
+      if (i == 7) tg = o.add(tg, o.mulc(Ksh, M((uint32_t)TAG_NIB)));
+      if (i == 8) tg = o.add(tg, o.mulc(o.sub(Ksh, o.loc(C_SI)), M((uint32_t)TAG_LOW6)));
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         h[k] = o.aloc(A_P + 4 * i + k); o.acc_lin(hs[k], h[k], 1);
@@ -721,7 +740,73 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.push(I_LG_Y, o.lmul(o.lsub(y[0], rlov), Klg)); o.push(I_LG_Y + 1, o.lmul(o.lsub(y[1], rhiv), Klg)); o.push(I_LG_Y + 2, o.lmul(y[2], Klg));   // the result: 40 bits
     }
 #pragma unroll
-    for (int k = 0; k < N_NIB; k++) { o.push(I_LG_ZERO + 2 * k, o.lmul(lb[k], nlg)); o.push(I_LG_ZERO + 2 * k + 1, o.lmul(lr[k], nlg)); }   // no second / third tuple element off the bitwise rows
+    for (int k = 0; k < N_NIB; k++) {                          // no second / third tuple element off the bitwise rows (b_8: nor off the register shifts)
+      o.push(I_LG_ZERO + 2 * k, o.lmul(lb[k], k == 8 ? o.add(o.sub(nlg, Ksh), o.loc(C_SI)) : nlg)); o.push(I_LG_ZERO + 2 * k + 1, o.lmul(lr[k], nlg));
+    }
+    // ---- the shifts SLL SRL SRA SLLI SRLI SRAI = 0x18 + (0 / 1 / 2) + 3 si (execute.rs:284-358): a 2^t = H 2^40 + L, t = 10 u + v: constraints 559.. ----
+    {
+      V UL[5], UR[5], Vb[10], PR[4];
+#pragma unroll
+      for (int u = 0; u < 5; u++) { UL[u] = o.loc(C_UL + u); UR[u] = o.loc(C_UR + u); }
+#pragma unroll
+      for (int v = 0; v < 10; v++) Vb[v] = o.loc(C_V + v);
+#pragma unroll
+      for (int k = 0; k < 4; k++) PR[k] = o.loc(C_PR + k);
+      const V sa = o.loc(C_SA), si = o.loc(C_SI), sb9 = o.loc(C_SB9), sgn = o.loc(C_SGN), shv = o.loc(C_SH), dd = pcs[6], on0 = o.loc(C_ON), on1 = o.loc(C_ON + 1);
+      boolean(I_SH_BOOL, Ksh);
+#pragma unroll
+      for (int u = 0; u < 5; u++) { boolean(I_SH_BOOL + 1 + u, UL[u]); boolean(I_SH_BOOL + 6 + u, UR[u]); }
+#pragma unroll
+      for (int v = 0; v < 10; v++) boolean(I_SH_BOOL + 11 + v, Vb[v]);
+      boolean(I_SH_BOOL + 21, sa); boolean(I_SH_BOOL + 22, si); boolean(I_SH_BOOL + 23, sb9);
+      AccL sula = o.accl(), sura = o.accl(), sva = o.accl(), tta = o.accl(), pva = o.accl(), vsa = o.accl();
+#pragma unroll
+      for (int u = 0; u < 5; u++) { o.acc_lin(sula, UL[u], 1); o.acc_lin(sura, UR[u], 1); if (u) { o.acc_lin(tta, UL[u], 10u * u); o.acc_lin(tta, UR[u], 10u * u); } }
+#pragma unroll
+      for (int v = 0; v < 10; v++) { o.acc_lin(sva, Vb[v], 1); o.acc_lin(pva, Vb[v], 1u << v); if (v) { o.acc_lin(tta, Vb[v], (uint32_t)v); o.acc_lin(vsa, Vb[v], (uint32_t)v); } }
+      const V sUL = o.accl_val(sula), sUR = o.accl_val(sura), sV = o.accl_val(sva), tt = o.accl_val(tta), PV = o.accl_val(pva), vsum = o.accl_val(vsa);
+      o.push(I_SH_ONE, o.lsub(o.add(sUL, sUR), Ksh)); o.push(I_SH_ONE + 1, o.lsub(sV, Ksh));      // one chunk shift (left or right) and one bit shift on a shift row, none elsewhere
+      o.push(I_SH_OP, o.lsub(o.sub(o.sub(o.mul(o.lsub(op, o.cst(M(0x18))), Ksh), sUR), sa), o.mulc(si, M(3))));   // the opcode: 0x18 + [right] + [arithmetic] + 3 [immediate]
+      o.push(I_SH_OP + 1, o.lmul(o.lsub(one, sUR), sa)); o.push(I_SH_OP + 2, o.lmul(o.lsub(one, Ksh), si));
+      o.push(I_SH_WR, o.lmul(o.lsub(w1v, fa), Ksh));
+      o.push(I_SH_A, o.lmul(o.lsub(o.sub(xb[0], R2[0]), o.mulc(R2[1], M(RC_TABLE))), Ksh)); o.push(I_SH_A + 1, o.lmul(o.lsub(o.sub(xb[1], R2[2]), o.mulc(R2[3], M(RC_TABLE))), Ksh));   // a's four chunks
+#pragma unroll
+      for (int k = 0; k < 4; k++) o.push(I_SH_PR + k, o.lsub(PR[k], o.mul(R2[k], PV)));           // c_k 2^v ..
+#pragma unroll
+      for (int k = 0; k < 4; k++) o.push(I_SH_LOHI + k, o.lmul(o.lsub(o.sub(PR[k], R[k]), o.mulc(pcs[k], M(RC_TABLE))), Ksh));   // .. = lo_k + 2^10 hi_k
+      o.push(I_SH_SIGN, o.lmul(o.lsub(o.sub(R2[3], o.mulc(sb9, M(512))), o.mulc(pcs[4], M((bb::P + 1) / 2))), Ksh));   // bit 39 of a: c_3 = 512 sb9 + piece_4 / 2
+      o.push(I_SH_SIGN + 1, o.lsub(sgn, o.mul(sa, sb9)));
+      // the amount: rs2's low six bits (its first chunk piece_8 with sh in LOW6, the rest of the limb in piece_5), or the word's shamt fc + 16 (fhi mod 16)
+      const V kreg = o.sub(Ksh, si);
+      o.push(I_SH_AMT, o.lmul(o.lsub(o.sub(xc[0], pcs[8]), o.mulc(pcs[5], M(RC_TABLE))), kreg));
+      o.push(I_SH_AMT + 1, o.lmul(o.lsub(lb[8], shv), kreg));
+      o.push(I_SH_AMT + 2, o.lmul(o.lsub(o.sub(fhi, pcs[7]), o.mulc(pcs[5], M(16))), si));
+      o.push(I_SH_AMT + 3, o.lmul(o.lsub(o.sub(shv, fc), o.mulc(pcs[7], M(16))), si));
+      o.push(I_SH_AMT + 4, o.lmul(shv, o.sub(one, Ksh)));
+      // sh = t + d on a left shift, 40 - t + d on a right shift; d (>= 0: a range lookup) only where t cannot say more: t = 40 resp. t = 0
+      o.push(I_SH_T, o.ladd(o.mul(o.lsub(o.sub(shv, tt), dd), sUL), o.mul(o.lsub(o.add(o.sub(shv, o.cst(M(40))), tt), dd), sUR)));
+      o.push(I_SH_D, o.lmul(dd, vsum)); o.push(I_SH_D + 1, o.lmul(o.lsub(sUL, UL[4]), dd)); o.push(I_SH_D + 2, o.lmul(o.lsub(sUR, UR[0]), dd));
+      o.push(I_SH_T40, o.lmul(o.lsub(one, Vb[0]), UR[4]));                                       // a right shift keeps at most 40 bits: t <= 40
+      // 2^40 - 2^t in limbs (right shifts): t < 20: (2^20 - 2^t, 2^20 - 1); 20 <= t < 40: (0, 2^20 - 2^(t-20)); t = 40: (0, 0)
+      {
+        const V low = o.add(UR[0], UR[1]);
+        o.push(I_SH_ON, o.lsub(on0, o.sub(o.mulc(low, M(1u << 20)), o.mul(o.add(UR[0], o.mulc(UR[1], M(1u << 10))), PV))));
+        o.push(I_SH_ON + 1, o.lsub(on1, o.sub(o.sub(o.sub(o.mulc(sUR, M(1u << 20)), low), o.mul(o.add(UR[2], o.mulc(UR[3], M(1u << 10))), PV)), o.mulc(UR[4], M(1u << 20)))));
+      }
+      // the chunks of a 2^v: m_0 = lo_0, m_i = lo_i + hi_(i-1), m_4 = hi_3; result chunk j = m_(j-u) on a left shift, m_(j+4-u) on a right shift
+      const V m[5] = {R[0], o.add(R[1], pcs[0]), o.add(R[2], pcs[1]), o.add(R[3], pcs[2]), pcs[3]};
+      V res[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        AccP a = o.accp();
+#pragma unroll
+        for (int u = 0; u < 5; u++) { if (j - u >= 0) o.acc_mul(a, UL[u], m[j - u]); if (j + 4 - u >= 0 && j + 4 - u <= 4) o.acc_mul(a, UR[u], m[j + 4 - u]); }
+        res[j] = o.acc_val(a);
+      }
+      o.push(I_SH_Y, o.lsub(o.sub(o.mul(y[0], Ksh), o.add(res[0], o.mulc(res[1], M(RC_TABLE)))), o.mul(sgn, on0)));
+      o.push(I_SH_Y + 1, o.lsub(o.sub(o.mul(y[1], Ksh), o.add(res[2], o.mulc(res[3], M(RC_TABLE)))), o.mul(sgn, on1)));
+      o.push(I_SH_Y + 2, o.lmul(y[2], Ksh));
+    }
   }
   // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR (+ HO + HI) - T / N
 #pragma unroll

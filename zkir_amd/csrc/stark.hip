@@ -100,7 +100,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
-  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; }
+  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; col(C_KSH) = cls == K_SH; }
   col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
   const uint32_t tc = (branch || (MODE == 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
@@ -120,7 +120,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && (cls == K_LD || cls == K_LG))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && (cls == K_LD || cls == K_LG || cls == K_SH))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
     else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -191,13 +191,52 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   col(C_TK) = tk;
   const uint32_t imm17 = fc + 16 * fhi, im0 = imm17 - (s << 17) + (s << 20), im1 = s * 0xFFFFFu;
   const uint32_t lo20 = fb + 16 * fc + 256 * fhi - (s << 20);
-  bool mem_row = false, lg_row = false;
-  uint32_t mem_z[2] = {0, 0}, mem_dt = 0, lg_a9 = 0;
+  bool mem_row = false, lg_row = false, sh_row = false;
+  uint32_t mem_z[2] = {0, 0}, mem_dt = 0, lg_a9 = 0, sh_lo[4] = {0, 0, 0, 0}, sh_c[4] = {0, 0, 0, 0};
   if (MODE == 3) {
     // loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64 — below 2^40, or the run has no proof here — its aligned 8-byte cell's bytes before the
     // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
 #pragma unroll
-    for (int k = C_E; k < W; k++) if (k != C_KLG) col(k) = 0;
+    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH) col(k) = 0;
+    if (cls == K_SH) {
+      // SLL SRL SRA SLLI SRLI SRAI (execute.rs:284-358) as a 2^t = H 2^40 + L: t = sh on a left shift, 40 - sh on a right shift (clamped at 40 / 0: d = the rest), t = 10 u + v
+      sh_row = true;
+      const uint32_t which = (op - 0x18) % 3, si = (op - 0x18) / 3;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20);
+      const uint32_t amount = si ? ((w >> 15) & 0xFF) : (xc[0] & 63);
+      col(C_SA) = which == 2; col(C_SI) = si; col(C_SH) = amount;
+      const uint32_t tt = which == 0 ? (amount < 40 ? amount : 40u) : (amount < 40 ? 40u - amount : 0u);
+      const uint32_t dd = which == 0 ? amount - tt : amount - (40u - tt);
+      const uint32_t u = tt / 10, v = tt % 10;
+#pragma unroll
+      for (int k = 0; k < 5; k++) { col(C_UL + k) = which == 0 && u == (uint32_t)k; col(C_UR + k) = which != 0 && u == (uint32_t)k; }
+#pragma unroll
+      for (int k = 0; k < 10; k++) col(C_V + k) = v == (uint32_t)k;
+      uint32_t hi[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sh_c[k] = (uint32_t)((a >> (10 * k)) & 1023);
+        const uint32_t pr = sh_c[k] << v;
+        col(C_PR + k) = pr; sh_lo[k] = pr & 1023; hi[k] = pr >> 10;
+        col(C_PIECE + k) = hi[k];
+      }
+      const uint32_t sb9 = sh_c[3] >> 9, sgn = which == 2 ? sb9 : 0u;
+      col(C_SB9) = sb9; col(C_SGN) = sgn;
+      col(C_PIECE + 4) = 2 * (sh_c[3] & 511);
+      col(C_PIECE + 6) = dd;
+      if (si) { col(C_PIECE + 7) = fhi & 15; col(C_PIECE + 5) = fhi >> 4; }
+      else { col(C_PIECE + 8) = xc[0] & 1023; col(C_PIECE + 5) = xc[0] >> 10; col(C_LB + 8) = amount; }
+      const uint32_t m[5] = {sh_lo[0], sh_lo[1] + hi[0], sh_lo[2] + hi[1], sh_lo[3] + hi[2], hi[3]};
+      uint64_t res = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const int idx = which == 0 ? j - (int)u : j + 4 - (int)u; if (idx >= 0 && idx <= 4) res |= (uint64_t)m[idx] << (10 * j); }
+      if (which != 0) {
+        const uint64_t ones = ((1ull << 40) - 1) & ~((1ull << tt) - 1);
+        col(C_ON) = (uint32_t)(ones & 0xFFFFF); col(C_ON + 1) = (uint32_t)(ones >> 20);
+        if (sgn) res |= ones;
+      }
+      y[0] = (uint32_t)(res & 0xFFFFF); y[1] = (uint32_t)(res >> 20); y[2] = 0;
+    }
     if (cls == K_LG) {
       // AND OR XOR ANDI ORI XORI on the 40-bit values (execute.rs:199-282), nibble by nibble: a's nibbles in the piece columns (the tenth in the last range chunk), b's and the result's beside them
       lg_row = true;
@@ -272,10 +311,12 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   }
   if (mem_row) { rc2[0] = mem_dt & (RC_TABLE - 1); rc2[1] = (mem_dt >> RC_BITS) & (RC_TABLE - 1); rc2[2] = mem_dt >> (2 * RC_BITS); rc2[3] = 0; }   // (mode 3) cycle - told in three chunks
   if (lg_row) { rc2[0] = rc2[1] = rc2[2] = 0; rc2[3] = lg_a9; }   // (mode 3) a bitwise row's tenth nibble tuple sits in the last range slot
+  if (sh_row) { rc2[0] = sh_c[0]; rc2[1] = sh_c[1]; rc2[2] = sh_c[2]; rc2[3] = sh_c[3]; }   // (mode 3) a shift row: the chunks of the shifted value
   col(C_RC2) = rc2[0]; col(C_RC2 + 1) = rc2[1]; col(C_RC2 + 2) = rc2[2]; col(C_RC2 + 3) = rc2[3];
   if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || oth_like || (MODE >= 2 && cls == K_ECALL)) { z[0] = y[0]; z[1] = y[1]; }     // the written value's low limbs are the range-checked pair
   if (mem_row) { z[0] = mem_z[0]; z[1] = mem_z[1]; }             // (mode 3) the address's two low limbs are the range-checked pair
   col(C_RC) = z[0] & (RC_TABLE - 1); col(C_RC + 1) = z[0] >> RC_BITS; col(C_RC + 2) = z[1] & (RC_TABLE - 1); col(C_RC + 3) = z[1] >> RC_BITS;   // 10-bit chunks, looked up
+  if (sh_row) { col(C_RC) = sh_lo[0]; col(C_RC + 1) = sh_lo[1]; col(C_RC + 2) = sh_lo[2]; col(C_RC + 3) = sh_lo[3]; }                           // (mode 3) a shift row: the low halves of c_i 2^v
   col(C_C0) = c0; col(C_C1) = c1;
   uint32_t d0 = 0, d1 = 0, d2 = 0, b0 = 0;
   if (cls != K_JALR && cls != K_OJ && cls != K_HALT && cls != K_PAD) b0 = sa;   // (v5) column b0 doubles as the sign bit of the first operand of an ordered comparison

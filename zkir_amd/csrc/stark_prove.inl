@@ -228,10 +228,21 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
         if (k < 8) lbits_lo |= (b & 15) << (4 * k); else lbits_hi |= (b & 15) << (4 * (k - 8));
         if (a < 16 && b < 16 && r == air::logic_of(lg_which, a, b)) atomicAdd(&h_mem[air::LG_BASE + 256 * lg_which + 16 * a + b], 1u); else ok = false;
       };
+      const uint32_t ksh = M[b8((uint32_t)air::phys_col(air::C_KSH, 3), i, N)], sh_reg = ksh && !M[b8((uint32_t)air::phys_col(air::C_SI, 3), i, N)];
       uint32_t pc9[air::N_PIECE];
       for (int k = 0; k < air::N_PIECE; k++) {
         pc9[k] = M[b8(p_pc + (uint32_t)k, i, N)];
         if (lg_which >= 0) { logic_tuple(pc9[k], k); continue; }
+        if (ksh) {                                               // a shift row: the slots are re-typed (air::shift_piece_tag); piece 8 of a register shift goes to LOW6 with the amount
+          const int stag = air::shift_piece_tag(k, sh_reg != 0);
+          if (stag == air::TAG_LOW6) {
+            const uint32_t b = M[b8(p_lb + 8, i, N)];
+            lbits_hi = b & 63;                                   // (kept for nothing but symmetry: the aux kernel needs the value only)
+            if (pc9[k] < (uint32_t)air::RC_TABLE && b == (pc9[k] & 63)) atomicAdd(&h_mem[air::L6_BASE + pc9[k]], 1u); else ok = false;
+          } else if (stag == air::TAG_NIB) { if (pc9[k] < 16u) atomicAdd(&h_mem[air::RC_TABLE + 256 + pc9[k]], 1u); else ok = false; }
+          else { if (pc9[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[pc9[k]], 1u); else ok = false; }
+          continue;
+        }
         const int tag = air::piece_tag(k);
         if (tag == air::TAG_BYTE) { if (pc9[k] < 256u) atomicAdd(&h_mem[air::RC_TABLE + pc9[k]], 1u); else ok = false; }
         else if (tag == air::TAG_NIB) { if (pc9[k] < 16u) atomicAdd(&h_mem[air::RC_TABLE + 256 + pc9[k]], 1u); else ok = false; }
@@ -239,10 +250,12 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       }
       uint32_t obl = 0, obh = 0;
       for (int k = 0; k < 4; k++) { obl |= (M[b8(p_ob + (uint32_t)k, i, N)] & 0xFF) << (8 * k); obh |= (M[b8(p_ob + 4 + (uint32_t)k, i, N)] & 0xFF) << (8 * k); }
-      mem_side[2 * i] = make_uint4((pc9[0] & 0xFF) | ((pc9[1] & 0xFF) << 8) | ((pc9[4] & 0xFF) << 16) | ((pc9[5] & 0xFF) << 24),
-                                   (pc9[6] & 0xFF) | ((pc9[7] & 0xFF) << 8) | ((pc9[8] & 0xFF) << 16) | ((pc9[2] & 0xF) << 24) | ((pc9[3] & 0xF) << 28), obl, obh);
+      // side: the nine pieces at ten bits each (a shift row's are chunks), the flags (kld | kst << 1 | window << 2 | (bitwise op + 1) << 6 | b_8, b_9 << 8 | ksh << 16 | register shift << 17)
+      mem_side[2 * i] = make_uint4((pc9[0] & 1023) | ((pc9[1] & 1023) << 10) | ((pc9[2] & 1023) << 20), (pc9[3] & 1023) | ((pc9[4] & 1023) << 10) | ((pc9[5] & 1023) << 20),
+                                   (pc9[6] & 1023) | ((pc9[7] & 1023) << 10) | ((pc9[8] & 1023) << 20), 0u);
       if (lg_which >= 0) logic_tuple(r[air::N_RC - 1], 9);       // the tenth tuple: a_9 = the last range chunk
-      mem_side[2 * i + 1] = make_uint4(M[b8(p_told, i, N)], kld | (kst << 1) | (win << 2) | ((uint32_t)(lg_which + 1) << 6) | (lbits_hi << 8), b0l.x /* cycle */, lbits_lo);
+      mem_side[2 * i].w = kld | (kst << 1) | (win << 2) | ((uint32_t)(lg_which + 1) << 6) | ((lg_which >= 0 ? lbits_hi : 0u) << 8) | (ksh << 16) | (sh_reg << 17);
+      mem_side[2 * i + 1] = make_uint4(obl, obh, M[b8(p_told, i, N)], lbits_lo);      // (the cycle of a whole run's row is its index)
       if (mem_row) {                                             // the first chunk goes to the LOW3 table, with the window's offset
         const uint32_t off = win < 15 ? (uint32_t)air::win_start((int)win) : 8u;
         if (r[0] < (uint32_t)air::RC_TABLE && (r[0] & 7) == off) atomicAdd(&h_mem[r[0]], 1u); else ok = false;
@@ -291,15 +304,17 @@ __device__ __forceinline__ uint4 add4m(uint4 a, uint4 b);
 __global__ __launch_bounds__(NT) void mem_tables_kernel(const ProveParams* __restrict__ pp, E4* __restrict__ inv_mem) {
   const uint32_t t = blockIdx.x * NT + threadIdx.x;
   if (t >= (uint32_t)air::MEM_MULT) return;
-  const bool lg = t >= (uint32_t)air::LG_BASE;                  // AND | OR | XOR: entry 16 a + b = the tuple (a, b, a op b)
+  const bool l6 = t >= (uint32_t)air::L6_BASE;                  // LOW6: entry v = the tuple (v, v & 63)
+  const bool lg = !l6 && t >= (uint32_t)air::LG_BASE;           // AND | OR | XOR: entry 16 a + b = the tuple (a, b, a op b)
   const uint32_t which = lg ? (t - air::LG_BASE) >> 8 : 0, e = (t - air::LG_BASE) & 255;
-  const uint32_t v = lg ? e >> 4 : t < (uint32_t)air::RC_TABLE ? t : t < (uint32_t)air::RC_TABLE + 256 ? t - air::RC_TABLE : t - air::RC_TABLE - 256;
-  const uint32_t tag = lg ? air::TAG_AND + which : t < (uint32_t)air::RC_TABLE ? air::TAG_LOW3 : t < (uint32_t)air::RC_TABLE + 256 ? air::TAG_BYTE : air::TAG_NIB;
+  const uint32_t v = l6 ? t - air::L6_BASE : lg ? e >> 4 : t < (uint32_t)air::RC_TABLE ? t : t < (uint32_t)air::RC_TABLE + 256 ? t - air::RC_TABLE : t - air::RC_TABLE - 256;
+  const uint32_t tag = l6 ? air::TAG_LOW6 : lg ? air::TAG_AND + which : t < (uint32_t)air::RC_TABLE ? air::TAG_LOW3 : t < (uint32_t)air::RC_TABLE + 256 ? air::TAG_BYTE : air::TAG_NIB;
   E4 d;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     uint32_t fp = bb::mont_mul(pp->lk[air::LK_LAM + 4 * air::N_TUPLE + k], bb::to_mont(tag));
     if (tag == (uint32_t)air::TAG_LOW3) fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 + k], bb::to_mont(v & 7)));
+    if (l6) fp = bb::add(fp, bb::mont_mul(pp->lk[air::LK_LAM + 4 + k], bb::to_mont(v & 63)));
     if (lg) fp = bb::add(fp, bb::add(bb::mont_mul(pp->lk[air::LK_LAM + 4 + k], bb::to_mont(e & 15)), bb::mont_mul(pp->lk[air::LK_LAM + 8 + k], bb::to_mont(air::logic_of((int)which, e >> 4, e & 15)))));
     d.c[k] = bb::sub(pp->lk[air::LK_ALPHA + k], fp);
   }
@@ -366,16 +381,20 @@ __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ s
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   const uint4 m0 = mem_side[2 * i], m1 = mem_side[2 * i + 1];
-  const uint32_t pc9[air::N_PIECE] = {m0.x & 0xFF, (m0.x >> 8) & 0xFF, (m0.y >> 24) & 0xF, m0.y >> 28, (m0.x >> 16) & 0xFF, m0.x >> 24, m0.y & 0xFF, (m0.y >> 8) & 0xFF, (m0.y >> 16) & 0xFF};
+  const uint32_t pc9[air::N_PIECE] = {m0.x & 1023, (m0.x >> 10) & 1023, m0.x >> 20, m0.y & 1023, (m0.y >> 10) & 1023, m0.y >> 20, m0.z & 1023, (m0.z >> 10) & 1023, m0.z >> 20};
+  const uint32_t fl = m0.w;                                     // kld | kst << 1 | window << 2 | (bitwise op + 1) << 6 | b_8, b_9 << 8 | ksh << 16 | register shift << 17
   uint4* A4 = reinterpret_cast<uint4*>(A);
   auto put = [&](int col, const E4& c) { A4[((uint64_t)(col >> 3) * N + i) * 2 + ((col >> 2) & 1)] = make_uint4(c.c[0], c.c[1], c.c[2], c.c[3]); };
   E4 inc = bb::e_zero();
-  const int lg_which = (int)((m1.y >> 6) & 3) - 1;              // 0 / 1 / 2: an AND / OR / XOR row — every piece slot then reads its nibble tuple's inverse from the operation's table
-  auto lg_b = [&](int k) { return k < 8 ? (m1.w >> (4 * k)) & 15 : (m1.y >> (8 + 4 * (k - 8))) & 15; };
+  const int lg_which = (int)((fl >> 6) & 3) - 1;                // 0 / 1 / 2: an AND / OR / XOR row — every piece slot then reads its nibble tuple's inverse from the operation's table
+  const bool ksh = (fl >> 16) & 1, sh_reg = (fl >> 17) & 1;     // a shift row: the slots re-typed (air::shift_piece_tag)
+  auto lg_b = [&](int k) { return k < 8 ? (m1.w >> (4 * k)) & 15 : (fl >> (8 + 4 * (k - 8))) & 15; };
 #pragma unroll
   for (int k = 0; k < air::N_PIECE; k++) {
     const int tag = air::piece_tag(k);
+    const int stag = air::shift_piece_tag(k, sh_reg);
     const E4 h = lg_which >= 0 ? inv_mem[air::LG_BASE + 256 * lg_which + 16 * (pc9[k] & 15) + lg_b(k)]
+               : ksh ? (stag == air::TAG_LOW6 ? inv_mem[air::L6_BASE + pc9[k]] : stag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + (pc9[k] & 15)] : inv_rc[pc9[k]])
                : tag == air::TAG_BYTE ? inv_mem[air::RC_TABLE + pc9[k]] : tag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + pc9[k]] : inv_rc[pc9[k]];
     put(air::A_P + 4 * k, h); inc = bb::e_add(inc, h);
   }
@@ -386,8 +405,8 @@ __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ s
     inc = bb::e_add(inc, bb::e_sub(h7, inv_rc[c7]));
     put(air::A_H + 4 * (air::N_RC - 1), h7);
   }
-  const uint32_t kld = m1.y & 1, kst = (m1.y >> 1) & 1, win = (m1.y >> 2) & 15;
-  const uint64_t ob = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
+  const uint32_t kld = fl & 1, kst = (fl >> 1) & 1, win = (fl >> 2) & 15;
+  const uint64_t ob = (uint64_t)m1.x | ((uint64_t)m1.y << 32);
   uint64_t nb = ob;
   int off = 0;
   if (win < 15) {                                              // the window's bytes replaced by the pieces' (a load's pieces ARE the window's bytes: nb = ob)
@@ -428,8 +447,8 @@ __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ s
       }
       return bb::e_inv_m(d);
     };
-    hr = tuple_inv(m1.x, bytes_fp(ob));
-    hw = tuple_inv((m1.z + 1) % bb::P, fpn);
+    hr = tuple_inv(m1.z, bytes_fp(ob));
+    hw = tuple_inv((uint32_t)((i + 1) % bb::P), fpn);            // time written = cycle + 1; a whole run's row i has cycle i
     inc = bb::e_add(inc, bb::e_sub(hr, hw));
     const E4 h0 = inv_mem[c0];                                  // the first chunk's helper comes from the LOW3 table on a memory row
     inc = bb::e_add(inc, bb::e_sub(h0, inv_rc[c0]));

@@ -566,6 +566,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       for (int which = 0; which < 3; which++) for (int t = 0; t < 256; t++)      // the bitwise tables (a, b, a op b): a + lambda b + lambda^2 r + (8 + which) lambda^11
         m[air::LG_BASE + 256 * which + t] = bb::e_sub(bb::e_sub(tagged((uint32_t)(t >> 4), air::TAG_AND + which), bb::e_mul_fm(lam[1], bb::to_mont((uint32_t)(t & 15)))),
                                                       bb::e_mul_fm(lam[2], bb::to_mont(air::logic_of(which, (uint32_t)(t >> 4), (uint32_t)(t & 15)))));
+      for (int t = 0; t < air::RC_TABLE; t++) m[air::L6_BASE + t] = bb::e_sub(tagged((uint32_t)t, air::TAG_LOW6), bb::e_mul_fm(lam[1], bb::to_mont((uint32_t)(t & 63))));   // LOW6: (v, v & 63)
       auto mem_d = [&](const Cell& c, uint32_t t, uint64_t bytes) {
         E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_MEM));
         fp.c[0] = bb::add(fp.c[0], bb::to_mont((uint32_t)(c.addr & 0xFFFFF)));
