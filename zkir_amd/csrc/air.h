@@ -49,9 +49,9 @@
 // ROUND 4 — two opt-in MODES append columns and constraints to the default-mode list (modes 0 / 1 are unchanged):
 //   MODE 2 = the I/O argument: ECALL's READ / WRITE / EXIT constrained, the outputs and consumed inputs tied to tapes the proof carries, the halt row bound (the verifier does
 //            zkir_verify_io's checks itself);
-//   MODE 3 = mode 2 + the memory argument + the bitwise opcodes: the ten loads and stores constrained, every access one step of an offline memory check over 8-byte cells;
-//            AND OR XOR ANDI ORI XORI nibble by nibble through 256-entry tables (36 of 50 opcodes now carry their semantics).  Left free there: MUL / MULH / DIVU / REMU /
-//            DIV / REM and the six shifts (class "other"), hash syscalls (forbidden: fh = 0), the SHA-256 chip.
+//   MODE 3 = mode 2 + the memory argument + the bitwise opcodes + the shifts: the ten loads and stores constrained, every access one step of an offline memory check over
+//            8-byte cells; AND OR XOR ANDI ORI XORI nibble by nibble through 256-entry tables; SLL SRL SRA SLLI SRLI SRAI as a 2^t = H 2^40 + L over 10-bit chunks (42 of 50
+//            opcodes now carry their semantics).  Left free there: MUL / MULH / DIVU / REMU / DIV / REM (class "other"), hash syscalls (forbidden: fh = 0), the SHA-256 chip.
 #pragma once
 #include "babybear.h"
 
