@@ -630,11 +630,13 @@ def main():
         try:
             def timed_prove(tr_, pub_, reps=3):
                 best, pr_, st_ = None, None, None
+                stark.prove(ctx, tr_, pub_)                    # (a wider mode grows the context's workspace on its first call)
                 for _ in range(reps):
                     t0 = time.perf_counter()
-                    pr_, st_ = stark.prove(ctx, tr_, pub_, want_stage_ms=True)
+                    pr, st = stark.prove(ctx, tr_, pub_, want_stage_ms=True)
                     dt = (time.perf_counter() - t0) * 1e3
-                    best = dt if best is None or dt < best else best
+                    if best is None or dt < best:
+                        best, pr_, st_ = dt, pr, st            # the stage times of the run that is reported
                 return best, pr_, st_
             prove_by_mode = {}
             ms2, pr2, _ = timed_prove(trace, rt.public_inputs(log, blob, [], io_mode=True))
