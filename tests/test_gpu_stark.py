@@ -655,3 +655,61 @@ def test_memcheck_witness_device_equals_host_replay(k, log2_cells):
     for got, want, name in zip((d_old, d_told, d_ca[:nc], d_cb[:nc], d_ct[:nc]), host, ("old bytes", "old time", "cell address", "cell bytes", "cell time")):
         assert np.array_equal(got, want), f"{name}: first difference at {int(np.nonzero(got != want)[0][0])}"
     log.close()
+
+
+def test_mode3_wrong_execution_is_rejected_on_the_gpu_path():
+    """Mode 3 on a device trace whose values do not follow the program (patched in HBM, consistently until the register is rewritten): a load that returns another value than
+    the cell holds, an XOR off by a bit, a shift off by a bit, an ANDI with the wrong immediate — each proof the GPU prover emits is rejected by both verifiers; in mode 0 the very
+    same forged traces are ACCEPTED (those opcodes are class "other" there: y is a free witness) — the difference the mode makes."""
+    from zkir_amd import stark
+    blob = spec.memory_ring_program(4).to_bytes()
+    n = 700
+    ores = oracle.run(blob, [], max_cycles=n, enable_execution_trace=True)
+    rows = ores.rows
+    ops, rds = rows["instruction"] & 0x7F, (rows["instruction"] >> 7) & 0xF
+    ctx = stark.StarkContext(stark.padded_log_n(n))
+
+    def fresh():
+        from zkir_amd import pipeline as pl
+        log = rt.interpret(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+        ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        return log, tr
+    log, tr = fresh()
+    pub3, pub0 = rt.public_inputs(log, blob, [], mem_mode=True), rt.public_inputs(log, blob, [])
+    assert rt.verify(stark.prove(ctx, tr, pub3), pub3) == 0
+    for op, rd, what in ((0x34, 8, "LW"), (0x12, 2, "XOR"), (0x13, 5, "ANDI"), (0x11, 12, "OR"), (0x33, 9, "LHU"), (0x30, 10, "LB")):
+        ks = np.nonzero((ops == op) & (rds == rd))[0]
+        k = int(ks[3])
+        later = np.nonzero(rds[k + 1:] == rd)[0]                                            # rows until rd is written again
+        hi = k + 1 + (int(later[0]) if len(later) else n - k - 2)
+        saved = tr.registers[rd, k + 1:hi + 1].clone()
+        tr.registers[rd, k + 1:hi + 1] = saved ^ 2
+        bad3 = stark.prove(ctx, tr, pub3)
+        assert rt.verify(bad3, pub3) != 0 and so.verify(bad3) != 0, what
+        if op in (0x12, 0x11):                                                              # the forged register feeds only rows that are class "other" in mode 0: there the forged trace passes
+            assert rt.verify(stark.prove(ctx, tr, pub0), pub0) == 0, what
+        tr.registers[rd, k + 1:hi + 1] = saved
+    assert rt.verify(stark.prove(ctx, tr, pub3), pub3) == 0
+    ctx.close(); log.close()
+    # the shifts, on tests/programs.py: alu_all
+    import programs as pg
+    blob2, ins2, _ = pg.alu_all()
+    ores2 = oracle.run(blob2, list(ins2), enable_execution_trace=True)
+    from zkir_amd import pipeline as pl
+    log2 = rt.interpret(blob2, list(ins2), rt.VMConfig(enable_execution_trace=True))
+    ddl2 = pl.upload(log2); tr2 = pl.DeviceTrace(ddl2); pl.trace_fill(pl.trace_fill_args(ddl2, tr2))
+    pub2 = rt.public_inputs(log2, blob2, list(ins2), mem_mode=True)
+    ctx2 = stark.StarkContext(stark.padded_log_n(len(ores2.rows)))
+    assert rt.verify(stark.prove(ctx2, tr2, pub2), pub2) == 0
+    ops2, rds2, n2 = ores2.rows["instruction"] & 0x7F, (ores2.rows["instruction"] >> 7) & 0xF, len(ores2.rows)
+    for op in (0x18, 0x19, 0x1A, 0x1B, 0x1C, 0x1D):
+        ks = np.nonzero((ops2 == op) & (rds2 != 0))[0]
+        k = int(ks[len(ks) // 2]); rd = int(rds2[k])
+        later = np.nonzero(rds2[k + 1:] == rd)[0]
+        hi = k + 1 + (int(later[0]) if len(later) else n2 - k - 2)
+        saved = tr2.registers[rd, k + 1:hi + 1].clone()
+        tr2.registers[rd, k + 1:hi + 1] = saved ^ 1
+        bad = stark.prove(ctx2, tr2, pub2)
+        assert rt.verify(bad, pub2) != 0 and so.verify(bad) != 0, hex(op)
+        tr2.registers[rd, k + 1:hi + 1] = saved
+    ctx2.close(); log2.close()
