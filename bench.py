@@ -857,7 +857,11 @@ def main():
                                     + "; v3.4 fib loop of tests/cross_module.rs:145-164, max_cycles halt, VMConfig{enable_execution_trace}; "
                                     f"stages = {'+'.join(s for s, _ in stages)}; blow-up 2, Poseidon2 width 12"),
                        "rows_per_gpu": n, "tile_rows": tile_rows, "reg_events_per_gpu": n_events, "main_trace_width": W if commit else None,
-                       "parallelism": f"row-shard x{world}"},
+                       "parallelism": f"row-shard x{world}",
+                       #  what scales with G and what cannot: said first, not in a nested field
+                       "reading_at_n_gt_1": ("`value` = the GPUs' commit throughput on row shards already in HBM (weak scaling: per-GPU work fixed).  END TO END one run is a sequential chain — "
+                                             "its time to root is bounded by one host core whatever G is (multi_gpu_end_to_end.one_run_row_sharded.bound) — so the figure that grows with G is "
+                                             "the AGGREGATE of G independent runs, one interpreter per GPU: multi_gpu_end_to_end.independent_runs_one_per_gpu.rows_per_s_end_to_end_incl_host") if dist_mode else None},
             # the dominant KERNEL of the step (its own launch bracketed by HIP events inside the timed region; at N = 1 / 2^20 rows: leaf_hash_kernel),
             # priced against the HBM peak as the contract asks — and against the roofline that does bound it (`alu`)
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
