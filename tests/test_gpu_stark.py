@@ -626,6 +626,27 @@ def test_mode3_at_scale():
     ctx.close(); log.close()
 
 
+def test_mode3_prove_wall_time_is_the_stages():
+    """A mode-3 proof's wall time is the sum of its device stages (+ host transcript work), call after call.  Round 4 measured 49 ms of wall for 25 ms of stages from the third
+    call of a process on: the memory section (1.8 MB) crossed as a PAGEABLE copy, the runtime pinned it in place, and free() handing the block back to the kernel evicted the
+    process's queues (host.h: HostPin; profiles/r04w_pageable_copy_stall.txt).  Every block of unbounded size now crosses through the context's pinned staging."""
+    import time
+    from zkir_amd import pipeline as pl, stark
+    blob = spec.memory_loop_program(65535).to_bytes()
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=1 << 20, enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    pub = rt.public_inputs(log, blob, [], mem_mode=True)
+    ctx = stark.StarkContext(stark.padded_log_n(log.n_rows))
+    stark.prove(ctx, tr, pub)
+    gaps = []
+    for _ in range(6):
+        t0 = time.perf_counter(); _, ms = stark.prove(ctx, tr, pub, want_stage_ms=True); wall = (time.perf_counter() - t0) * 1e3
+        gaps.append(wall - float(sum(ms)))
+    print("mode 3, 2^20 rows: wall - stages per call (ms):", [round(g, 2) for g in gaps])
+    assert min(gaps[2:]) < 5.0, gaps                            # (the stall added 17-25 ms to EVERY call from the third on)
+    ctx.close(); log.close()
+
+
 @pytest.mark.parametrize("k,log2_cells", [(12, 4), (16, 13), (18, 13), (18, 10), (20, 13)])
 def test_memcheck_witness_device_equals_host_replay(k, log2_cells):
     """zkir_memcheck_witness_device (memcheck.hip: the accesses sorted by (cell, row), a segmented scan per cell) against zkir_memcheck_witness_of (the host's sequential replay)

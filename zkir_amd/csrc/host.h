@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/zkir_amd.h"
@@ -86,6 +87,23 @@ class Buf {
   size_t n_ = 0, cap_ = 0;
 };
 
+// Pinned host memory for the prover's large host <-> device copies: bump-allocated per call (reset()), the blocks kept by the owner (a stark context) until it goes.
+// WHY (measured, profiles/r04w_pageable_copy_stall.txt): the HIP runtime serves a pageable copy of more than 1 MiB by pinning the caller's pages in place.  When such a block
+// is freed afterwards and glibc hands it back to the kernel (munmap of a large block, or a heap trim), the KFD's MMU notifier evicts the process's queues, and the next
+// submission waits for their restore: +25 ms on every mode-3 proof (its memory section is 1.8 MB at 65536 cells), none on modes 0-2 (nothing above 1 MiB).  So no pageable
+// block that can exceed that size is handed to a copy: it goes through here.  (hip calls inside: defined in memcheck.hip.)
+struct HostPin {
+  std::vector<std::pair<unsigned char*, size_t>> blocks;
+  size_t cur = 0, off = 0;
+  HostPin() = default;
+  HostPin(const HostPin&) = delete;
+  HostPin& operator=(const HostPin&) = delete;
+  ~HostPin();
+  void reset() { cur = 0; off = 0; }
+  void* take(size_t bytes);                                    // 256-byte aligned; nullptr when the host has no more pinned memory to give
+  template <typename T> T* take_n(size_t count) { return (T*)take(count * sizeof(T)); }
+};
+
 struct ProgramView {       // parsed Program blob (zkir-spec/src/program.rs:318-346); points into the caller's bytes
   uint8_t limb_bits = 20, data_limbs = 2, addr_limbs = 2;
   uint32_t entry_point = 0x1000;
@@ -143,10 +161,10 @@ void blake3(const uint8_t* data, size_t len, uint8_t out[32]);
 
 void set_last_error(const Status& st);
 
-// memcheck.hip — the memory witness of AIR mode 3 on the device: address-major sort of the accesses + a segmented scan per cell (rocPRIM primitives, this repo's kernels)
+// memcheck.hip — the memory witness of AIR mode 3 on the device: address-major sort of the accesses (rocPRIM's radix sort) + a segmented scan per cell (this repo's kernels)
 size_t memcheck_scratch_bytes(uint64_t n_real, uint64_t image_len);
 int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint8_t* blob, size_t blob_len, void* scratch, size_t scratch_bytes, uint64_t* mem_old, uint32_t* mem_told,
-                    std::vector<uint64_t>& cell_addr, std::vector<uint64_t>& cell_bytes, std::vector<uint32_t>& cell_time, void* hip_stream);
+                    std::vector<uint64_t>& cell_addr, std::vector<uint64_t>& cell_bytes, std::vector<uint32_t>& cell_time, HostPin& pin, void* hip_stream);
 
 // ntt.hip — coset LDE of `width` columns (device pointers; tables owned by zkir_stark_ctx, all in Montgomery form)
 struct LdeTables {

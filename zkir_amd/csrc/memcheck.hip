@@ -7,18 +7,24 @@
 //   2. radix sort        rocPRIM, on the whole key: (cell, row) order, each cell's accesses in time order.  (Sorting on the cell bits alone — begin_bit = 26, relying on
 //                        stability — comes out UNSORTED from rocPRIM 7.2's merge-sort path, 2^17 < n <= 2^21 keys: scripts/dbg/sort_test.hip reproduces it; begin_bit = 0 is right at every size);
 //   3. memelem_kernel    per sorted access: (byte mask, bytes placed at their offset) of a store, nothing for a load; head = first access of its cell;
-//   4. segmented scan    rocPRIM inclusive scan with the "later store overwrites" operator (associative), restarting at heads; it also counts the heads;
+//   4. segmented scan    an inclusive scan with the "later store overwrites" operator (associative, not commutative), restarting at heads; it also counts the heads.
+//                        Three kernels of this file — tile aggregates, their spine, the tiles again with their prefix — 2 reads + 1 write of 16 B per access;
 //   5. memout_kernel     old bytes = the program image's (code at 0x1000, data behind it, zero elsewhere: vm.rs:153-170) overlaid with the scan value of the PREVIOUS access of
 //                        the cell, old time = that access's row + 1 (0 at a head) -> scattered to the row; the last access of a cell emits the cell's final bytes and time.
-// rocPRIM supplies the two library primitives (a radix sort, a scan) — AMD's own device-wide primitives for gfx950; the kernels around them are this file's.
+// rocPRIM supplies the radix sort — AMD's own device-wide primitive for gfx950; every other kernel is this file's.  (Round 4 used rocprim::inclusive_scan as well: each of its
+// calls, the size query included, runs hipGetDeviceProperties on the host — 3 to 6 ms a call in a process that is not the first on its box, 13-22 ms per proof; ZKIR_PROVE_TIMES
+// showed it.  The radix sort asks for the architecture once per process and caches it.)
 // Refused: an address of 2^40 or more, an executed hash syscall (their memory effect is not stated by the AIR).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-// (only the two primitives used: the umbrella header drags in iterators that do not compile here)
+// (only the primitive used: the umbrella header drags in iterators that do not compile here)
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/zkir_amd.h"
@@ -84,6 +90,62 @@ __global__ __launch_bounds__(NT) void memelem_kernel(zkir_trace_columns t, uint6
   }
   el[j] = e;
 }
+// ---- the segmented scan: tiles of NT * SCAN_IPT consecutive elements, one block each ------------------------------------------------
+constexpr int SCAN_IPT = 8, SCAN_TILE = NT * SCAN_IPT;
+__device__ __forceinline__ MemElem elem_identity() { return MemElem{0, 0, 0, 0, {0, 0}}; }        // op(id, b) = b, op(a, id) = a
+__device__ __forceinline__ MemElem elem_load(const MemElem* __restrict__ p) { const uint4 v = *reinterpret_cast<const uint4*>(p); MemElem e; memcpy(&e, &v, 16); return e; }
+__device__ __forceinline__ void elem_store(MemElem* __restrict__ p, const MemElem& e) { uint4 v; memcpy(&v, &e, 16); *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ MemElem elem_shfl_up(const MemElem& e, int d) {
+  uint32_t w[4]; memcpy(w, &e, 16);
+  for (int k = 0; k < 4; k++) w[k] = __shfl_up(w[k], d, 64);
+  MemElem r; memcpy(&r, w, 16); return r;
+}
+// every thread brings the aggregate of its own (consecutive) elements: returns the aggregate of all the threads BEFORE it, and the block's in *total
+__device__ __forceinline__ MemElem block_exclusive(const MemElem& agg, MemElem* total) {
+  __shared__ MemElem wave_tot[NT / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const OverlayOp op;
+  MemElem inc = agg;
+  for (int d = 1; d < 64; d <<= 1) { const MemElem o = elem_shfl_up(inc, d); if (lane >= d) inc = op(o, inc); }
+  __syncthreads();                                             // (a second call in one kernel: the readers of the first are done)
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  MemElem exc = elem_shfl_up(inc, 1);
+  if (lane == 0) exc = elem_identity();
+  MemElem before = elem_identity(), all = elem_identity();
+  for (int w = 0; w < NT / 64; w++) { if (w == wave) before = all; all = op(all, wave_tot[w]); }
+  *total = all;
+  return op(before, exc);
+}
+__global__ __launch_bounds__(NT) void scan_tiles_kernel(const MemElem* __restrict__ el, uint64_t n, MemElem* __restrict__ part) {
+  const uint64_t j0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+  const OverlayOp op;
+  MemElem agg = elem_identity();
+  for (int k = 0; k < SCAN_IPT; k++) if (j0 + k < n) agg = op(agg, elem_load(el + j0 + k));
+  MemElem tot;
+  (void)block_exclusive(agg, &tot);
+  if (threadIdx.x == 0) elem_store(part + blockIdx.x, tot);
+}
+__global__ __launch_bounds__(NT) void scan_spine_kernel(MemElem* __restrict__ part, uint32_t n_tiles) {      // ONE block: part[i] <- the aggregate of the tiles before i
+  const uint32_t per = (n_tiles + NT - 1) / NT, i0 = threadIdx.x * per;
+  const OverlayOp op;
+  MemElem agg = elem_identity();
+  for (uint32_t k = 0; k < per; k++) if (i0 + k < n_tiles) agg = op(agg, elem_load(part + i0 + k));
+  MemElem tot;
+  MemElem run = block_exclusive(agg, &tot);
+  for (uint32_t k = 0; k < per; k++) if (i0 + k < n_tiles) { const MemElem e = elem_load(part + i0 + k); elem_store(part + i0 + k, run); run = op(run, e); }
+}
+__global__ __launch_bounds__(NT) void scan_apply_kernel(const MemElem* __restrict__ el, uint64_t n, const MemElem* __restrict__ part, MemElem* __restrict__ out) {
+  const uint64_t j0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+  const OverlayOp op;
+  MemElem e[SCAN_IPT], agg = elem_identity();
+  for (int k = 0; k < SCAN_IPT; k++) { e[k] = j0 + k < n ? elem_load(el + j0 + k) : elem_identity(); agg = op(agg, e[k]); }
+  MemElem tot;
+  MemElem run = op(elem_load(part + blockIdx.x), block_exclusive(agg, &tot));
+  for (int k = 0; k < SCAN_IPT; k++) { run = op(run, e[k]); if (j0 + k < n) elem_store(out + j0 + k, run); }
+}
+inline uint32_t scan_tiles_of(uint64_t n) { return (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE); }
+
 __device__ __forceinline__ uint64_t image_cell(const uint8_t* __restrict__ image, uint64_t image_len, uint64_t addr) {
   uint64_t v = 0;
   if (addr + 8 <= 0x1000 || addr - 0x1000 >= image_len) return 0;
@@ -114,62 +176,95 @@ __global__ __launch_bounds__(NT) void memout_kernel(uint64_t n, const uint64_t* 
 
 int dev_fail(const char* what, hipError_t e) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("memcheck: ") + what + ": " + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
 #define MC_OK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) return dev_fail(#x, e_); } while (0)
+size_t sort_tmp_bytes(uint64_t n) { size_t t = 0; (void)rocprim::radix_sort_keys(nullptr, t, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n, 0, 64, (hipStream_t)0); return t; }
 
 }  // namespace
 
 namespace zkir {
 
+HostPin::~HostPin() { for (auto& b : blocks) (void)hipHostFree(b.first); }
+void* HostPin::take(size_t bytes) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  for (; cur < blocks.size(); cur++, off = 0)
+    if (off + need <= blocks[cur].second) { void* p = blocks[cur].first + off; off += need; return p; }
+  size_t total = 0;
+  for (auto& b : blocks) total += b.second;
+  const size_t sz = std::max(need, std::max(total, (size_t)4 << 20));     // geometric: a context settles on a handful of blocks
+  void* p = nullptr;
+  if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+  blocks.push_back({(unsigned char*)p, sz});
+  cur = blocks.size() - 1; off = need;
+  return p;
+}
+
 // scratch: device memory, at least memcheck_scratch_bytes(n_real) bytes, 256-byte aligned.  mem_old / mem_told: device [n_real] (rows that are no load / store are left
-// untouched).  cells: host vectors, by increasing address.  Synchronises the stream.
+// untouched).  cells: host vectors, by increasing address.  pin: staging of the copies (host.h).  Synchronises the stream.
 size_t memcheck_scratch_bytes(uint64_t n_real, uint64_t image_len) {
-  size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n_real, 0, 64, (hipStream_t)0);
-  (void)rocprim::inclusive_scan(nullptr, t2, (MemElem*)nullptr, (MemElem*)nullptr, (size_t)n_real, OverlayOp(), (hipStream_t)0);
-  const size_t tmp = (t1 > t2 ? t1 : t2) + 256;
-  return tmp + (size_t)n_real * (8 + 8 + 16 + 16 + 8 + 8 + 4) + ((image_len + 255) & ~(size_t)255) + 4096;
+  const size_t tmp = sort_tmp_bytes(n_real) + 256;
+  return tmp + (size_t)scan_tiles_of(n_real) * 16 + 256 + (size_t)n_real * (8 + 8 + 16 + 16 + 8 + 8 + 4) + ((image_len + 255) & ~(size_t)255) + 4096;
 }
 int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint8_t* blob, size_t blob_len, void* scratch, size_t scratch_bytes, uint64_t* mem_old, uint32_t* mem_told,
-                    std::vector<uint64_t>& cell_addr, std::vector<uint64_t>& cell_bytes, std::vector<uint32_t>& cell_time, void* stream) {
+                    std::vector<uint64_t>& cell_addr, std::vector<uint64_t>& cell_bytes, std::vector<uint32_t>& cell_time, HostPin& pin, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const bool dbg_t = getenv("ZKIR_PROVE_TIMES") != nullptr;      // diagnostics: host wall time of the phases on stderr
+  const auto t0_ = std::chrono::steady_clock::now();
+  const bool dbg_sync = dbg_t && getenv("ZKIR_PROVE_TIMES")[0] == '2';   // (= 2: a synchronisation at every lap: which phase waits)
+  auto lap = [&](const char* what) { if (dbg_sync) (void)hipStreamSynchronize(s); if (dbg_t) fprintf(stderr, "  memcheck %s: %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count()); };
   if (!trace || !blob || blob_len < 32 || !scratch || !mem_old || !mem_told || n_real == 0 || n_real > (1ull << ROW_BITS)) { set_last_error({ZKIR_ERR_ARGUMENT, "memcheck_device: bad argument"}); return ZKIR_ERR_ARGUMENT; }
   uint32_t code_size, data_size; memcpy(&code_size, blob + 16, 4); memcpy(&data_size, blob + 20, 4);
   uint64_t image_len = (uint64_t)code_size + data_size;
   if (32 + image_len > blob_len) image_len = 0;
   if (scratch_bytes < memcheck_scratch_bytes(n_real, image_len)) { set_last_error({ZKIR_ERR_ARGUMENT, "memcheck_device: scratch too small"}); return ZKIR_ERR_ARGUMENT; }
-  size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n_real, 0, 64, s);
-  (void)rocprim::inclusive_scan(nullptr, t2, (MemElem*)nullptr, (MemElem*)nullptr, (size_t)n_real, OverlayOp(), s);
-  const size_t tmp_bytes = ((t1 > t2 ? t1 : t2) + 255) & ~(size_t)255;
+  lap("entry");
+  const size_t tmp_bytes = (sort_tmp_bytes(n_real) + 255) & ~(size_t)255;
+  const uint32_t n_tiles = scan_tiles_of(n_real);
+  lap("size query");
   unsigned char* p = (unsigned char*)scratch;
   auto take = [&](size_t bytes) { unsigned char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-  void* tmp = take(tmp_bytes);
+  void* tmp = take(tmp_bytes); MemElem* part = (MemElem*)take((size_t)n_tiles * 16);
   uint64_t* keys = (uint64_t*)take(n_real * 8); uint64_t* skeys = (uint64_t*)take(n_real * 8);
   MemElem* el = (MemElem*)take(n_real * 16); MemElem* sc = (MemElem*)take(n_real * 16);
   uint64_t* d_ca = (uint64_t*)take(n_real * 8); uint64_t* d_cb = (uint64_t*)take(n_real * 8); uint32_t* d_ct = (uint32_t*)take(n_real * 4);
   uint8_t* d_img = (uint8_t*)take(image_len + 1); uint32_t* d_flags = (uint32_t*)take(256);      // [0] = refusal flags, [1] = the cell count
   MC_OK(hipMemsetAsync(d_flags, 0, 8, s));
-  if (image_len) MC_OK(hipMemcpyAsync(d_img, blob + 32, image_len, hipMemcpyHostToDevice, s));
+  if (image_len) {
+    void* h = pin.take(image_len);
+    if (!h) return dev_fail("pinned staging", hipErrorOutOfMemory);
+    memcpy(h, blob + 32, image_len);
+    MC_OK(hipMemcpyAsync(d_img, h, image_len, hipMemcpyHostToDevice, s));
+  }
+  lap("image H2D");
   hipLaunchKernelGGL(memkey_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, *trace, n_real, keys, d_flags);
   size_t tb = tmp_bytes;
+  lap("keys");
   MC_OK(rocprim::radix_sort_keys(tmp, tb, keys, skeys, (size_t)n_real, 0, 64, s));
+  lap("sort");
   hipLaunchKernelGGL(memelem_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, *trace, n_real, skeys, el);
-  tb = tmp_bytes;
-  MC_OK(rocprim::inclusive_scan(tmp, tb, el, sc, (size_t)n_real, OverlayOp(), s));
+  lap("elems");
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(NT), 0, s, el, n_real, part);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(NT), 0, s, part, n_tiles);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(n_tiles), dim3(NT), 0, s, el, n_real, part, sc);
+  lap("scan");
   hipLaunchKernelGGL(memout_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, n_real, skeys, sc, d_img, image_len, mem_old, mem_told, d_ca, d_cb, d_ct, d_flags + 1);
   uint32_t flags[2] = {0, 0};
   MC_OK(hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, s));
   MC_OK(hipStreamSynchronize(s));
+  lap("out, synchronised");
   MC_OK(hipGetLastError());
   if (flags[0] & 1) { set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove (mode 3): the run accesses an address of 2^40 or more: it has no proof in this AIR (addr_limbs = 2, config.rs:30)"}); return ZKIR_ERR_ARGUMENT; }
   if (flags[0] & 2) { set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove (mode 3): the run executes a hash syscall: its memory effect is not stated by the AIR"}); return ZKIR_ERR_ARGUMENT; }
   const size_t nc = flags[1];
   cell_addr.resize(nc); cell_bytes.resize(nc); cell_time.resize(nc);
   if (nc) {
-    MC_OK(hipMemcpyAsync(cell_addr.data(), d_ca, nc * 8, hipMemcpyDeviceToHost, s));
-    MC_OK(hipMemcpyAsync(cell_bytes.data(), d_cb, nc * 8, hipMemcpyDeviceToHost, s));
-    MC_OK(hipMemcpyAsync(cell_time.data(), d_ct, nc * 4, hipMemcpyDeviceToHost, s));
+    uint64_t* ha = pin.take_n<uint64_t>(nc); uint64_t* hb = pin.take_n<uint64_t>(nc); uint32_t* ht = pin.take_n<uint32_t>(nc);
+    if (!ha || !hb || !ht) return dev_fail("pinned staging", hipErrorOutOfMemory);
+    MC_OK(hipMemcpyAsync(ha, d_ca, nc * 8, hipMemcpyDeviceToHost, s));
+    MC_OK(hipMemcpyAsync(hb, d_cb, nc * 8, hipMemcpyDeviceToHost, s));
+    MC_OK(hipMemcpyAsync(ht, d_ct, nc * 4, hipMemcpyDeviceToHost, s));
     MC_OK(hipStreamSynchronize(s));
+    memcpy(cell_addr.data(), ha, nc * 8); memcpy(cell_bytes.data(), hb, nc * 8); memcpy(cell_time.data(), ht, nc * 4);
   }
+  lap("cells copied");
   return ZKIR_OK;
 }
 
@@ -188,9 +283,13 @@ extern "C" int zkir_memcheck_witness_device(const zkir_trace_columns* trace, uin
   }
   (void)hipMemsetAsync(d_old, 0, n_real * 8, (hipStream_t)stream); (void)hipMemsetAsync(d_told, 0, n_real * 4, (hipStream_t)stream);
   std::vector<uint64_t> ca, cb; std::vector<uint32_t> ct;
-  int rc = zkir::memcheck_device(trace, n_real, blob, blob_len, scratch, sb, d_old, d_told, ca, cb, ct, stream);
+  zkir::HostPin pin;
+  int rc = zkir::memcheck_device(trace, n_real, blob, blob_len, scratch, sb, d_old, d_told, ca, cb, ct, pin, stream);
   if (rc == ZKIR_OK) {
-    (void)hipMemcpy(mem_old, d_old, n_real * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(mem_told, d_told, n_real * 4, hipMemcpyDeviceToHost);
+    uint64_t* ho = pin.take_n<uint64_t>(n_real); uint32_t* ht = pin.take_n<uint32_t>(n_real);
+    if (!ho || !ht) { (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told); return dev_fail("pinned staging", hipErrorOutOfMemory); }
+    (void)hipMemcpy(ho, d_old, n_real * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(ht, d_told, n_real * 4, hipMemcpyDeviceToHost);
+    memcpy(mem_old, ho, n_real * 8); memcpy(mem_told, ht, n_real * 4);
     *n_cells = ca.size();
     if (ca.size() > cap) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memcheck_witness_device: more cells than the caller's buffers hold"}); rc = ZKIR_ERR_ARGUMENT; }
     else if (!ca.empty()) { memcpy(cell_addr, ca.data(), ca.size() * 8); memcpy(cell_bytes, cb.data(), cb.size() * 8); memcpy(cell_time, ct.data(), ct.size() * 4); }

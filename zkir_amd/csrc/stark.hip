@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <memory>
 #include <mutex>
@@ -565,6 +568,7 @@ struct zkir_stark_ctx {
   // prover workspace: one device allocation made on the first zkir_prove and reused (hipMalloc of GBs costs more than the kernels)
   mutable unsigned char* arena = nullptr;
   mutable size_t arena_size = 0, arena_off = 0;
+  mutable zkir::HostPin pin;      // pinned host staging of the proof's large copies (host.h: why no large pageable block is handed to a copy)
 };
 
 namespace {

@@ -901,12 +901,14 @@ void zkir_proof_free(uint32_t* proof) { free(proof); }
 int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const zkir_public_inputs* pub, uint32_t** proof_out, uint64_t* proof_words, float* stage_ms,
                void* stream) {
   if (!c || !trace || !pub || !proof_out || !proof_words) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  const bool dbg_t = getenv("ZKIR_PROVE_TIMES") != nullptr;      // diagnostics: host wall time of the call's phases on stderr
+  const auto t_entry = std::chrono::steady_clock::now();
+  auto since = [&](const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   const uint32_t log_n = c->log_n;
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
   if (pub->deferred > 3) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument"}); return ZKIR_ERR_ARGUMENT; }
   const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument, 3 = 2 + the memory argument (round 4)
   const bool IO = MODE >= 2, MEM = MODE == 3;
-  const bool DEF = MODE == 1;
   const int WM = air::committed_width(MODE), WA = air::aux_width(MODE), WT = WM + WA;     // this proof's committed main-trace / aux columns
   // (mode 3) the memory witness: computed HERE on the device (memcheck.hip) unless the caller brings one (pub->mem_old != NULL: zkir_memcheck_witness_of's host replay — the
   // independent implementation the tests compare with — or a forged one)
@@ -961,6 +963,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     c->arena_off = 0;
   }
   Arena ar{c};
+  zkir::HostPin& pin = c->pin;                                 // every host block of unbounded size crosses through pinned staging (host.h)
+  pin.reset();
+  auto h2d = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    void* p = pin.take(bytes);
+    if (!p) return hipErrorOutOfMemory;
+    memcpy(p, src, bytes);
+    return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s);
+  };
   uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest, *dBound, *dA, *dAL, *dATree, *dCode, *dMult;
   unsigned long long* dBad;
   uint4 *dSide, *dSums;
@@ -989,25 +999,27 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   StageEvents se;
   if (stage_ms) HIP_OK(se.create());
-  auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(se.ev[i], s); };
+  double host_ms[10] = {0};                                     // (diagnostics) host wall time at every mark
+  auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(se.ev[i], s); if (dbg_t) host_ms[i] = since(t_entry); };
 
   // ---- 1. main trace, lookup indices + multiplicities, LDE, trace commitment ---------------------------------------------------
+  const double t_pre = since(t_entry);
   mark(0);
   int rc;
   std::vector<uint64_t> cell_addr_v, cell_bytes_v; std::vector<uint32_t> cell_time_v;     // (mode 3) the touched cells: the device witness's, or the caller's
   if (IO) {
-    if (pub->n_inputs) HIP_OK(hipMemcpyAsync(dInputs, pub->inputs, (size_t)pub->n_inputs * 8, hipMemcpyHostToDevice, s));
+    if (pub->n_inputs) HIP_OK(h2d(dInputs, pub->inputs, (size_t)pub->n_inputs * 8));
     const zkir_io_args io{dInputs, pub->n_inputs, pub->writes_before, pub->reads_before};
     if (MEM) {
       if (MEM_HOST) {
-        HIP_OK(hipMemcpyAsync(dMemOld, pub->mem_old, (size_t)pub->n_real * 8, hipMemcpyHostToDevice, s));
-        HIP_OK(hipMemcpyAsync(dMemTold, pub->mem_told, (size_t)pub->n_real * 4, hipMemcpyHostToDevice, s));
+        HIP_OK(h2d(dMemOld, pub->mem_old, (size_t)pub->n_real * 8));
+        HIP_OK(h2d(dMemTold, pub->mem_told, (size_t)pub->n_real * 4));
         cell_addr_v.assign(pub->cell_addr, pub->cell_addr + pub->n_cells); cell_bytes_v.assign(pub->cell_bytes, pub->cell_bytes + pub->n_cells); cell_time_v.assign(pub->cell_time, pub->cell_time + pub->n_cells);
       } else {
         // scratch = the LDE output buffer, which nothing has written yet (WM * 2N words: 1600 B per row against the ~70 B per row the witness needs)
         const size_t need = zkir::memcheck_scratch_bytes(pub->n_real, blob_len);
         if (need > (size_t)WM * N2 * 4) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: memcheck scratch does not fit the LDE buffer"}); return ZKIR_ERR_OTHER; }
-        rc = zkir::memcheck_device(trace, pub->n_real, blob, blob_len, dL, (size_t)WM * N2 * 4, dMemOld, dMemTold, cell_addr_v, cell_bytes_v, cell_time_v, s);
+        rc = zkir::memcheck_device(trace, pub->n_real, blob, blob_len, dL, (size_t)WM * N2 * 4, dMemOld, dMemTold, cell_addr_v, cell_bytes_v, cell_time_v, pin, s);
         if (rc) return rc;
       }
       rc = zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
@@ -1015,10 +1027,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   } else rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s);
   if (rc) return rc;
   hipLaunchKernelGGL(boundary_states_kernel, dim3(1), dim3(256), 0, s, dM, N, pub->n_real - 1, MODE, dBound);   // before the LDE overwrites dM
-  std::vector<uint32_t> code(n_code);                         // lives to the end of the call: the H2D copy below reads it
   {
-    for (uint32_t t = 0; t < n_code; t++) memcpy(&code[t], blob + 32 + 4 * (size_t)t, 4);
-    if (n_code) HIP_OK(hipMemcpyAsync(dCode, code.data(), (size_t)n_code * 4, hipMemcpyHostToDevice, s));
+    if (n_code) HIP_OK(h2d(dCode, blob + 32, (size_t)n_code * 4));           // the code words, little-endian as the blob holds them
     HIP_OK(hipMemsetAsync(dMult, 0, n_mult * 4, s));
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
@@ -1031,11 +1041,12 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   rc = merkle_commit(c, dL, WM, N2, dTree, /*mont_in=*/true, s); if (rc) return rc;
   uint32_t troot[4], aroot[4], qroot[4], bound[2 * NS + 4] = {}, n_io = 0;
   unsigned long long bad_row = ~0ull;
-  std::vector<uint32_t> mult(n_mult);
+  uint32_t* mult = pin.take_n<uint32_t>(n_mult);               // (pinned: read back below, and part of the proof)
+  if (!mult) HIP_OK(hipErrorOutOfMemory);
   HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(bound, dBound, sizeof bound, hipMemcpyDeviceToHost, s));
   if (IO) HIP_OK(hipMemcpyAsync(&n_io, dIoCount, 4, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(mult.data(), dMult, mult.size() * 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(mult, dMult, n_mult * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(&bad_row, dBad, 8, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   if (bad_row != ~0ull) {
@@ -1065,14 +1076,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     const size_t n_chunks_sec = (mem_sec.size() + SECTION_CHUNK - 1) / SECTION_CHUNK;
     if (mem_sec.size() + 4 * n_chunks_sec + 64 > 8 * (size_t)N + 4096) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than the workspace holds"}); return ZKIR_ERR_ARGUMENT; }
     uint32_t* dSecDg = dSec + ((mem_sec.size() + 63) & ~(size_t)63);
-    HIP_OK(hipMemcpyAsync(dSec, mem_sec.data(), mem_sec.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_OK(h2d(dSec, mem_sec.data(), mem_sec.size() * 4));
     hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)mem_sec.size(), dSecDg);
     std::vector<uint32_t> sec_dg(4 * n_chunks_sec);
     HIP_OK(hipMemcpyAsync(sec_dg.data(), dSecDg, sec_dg.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     ch.observe_n(sec_dg.data(), sec_dg.size());
   }
-  ch.observe_n(mult.data(), mult.size());                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
+  ch.observe_n(mult, n_mult);                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
   std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
   {
     // ---- 1b. lookup challenges, inverse tables, T, aux trace (helper columns + running sum), its LDE and commitment ----
@@ -1085,10 +1096,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemcpyAsync(dPP->lk, pp->lk, sizeof(pp->lk), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom, MODE);
     if (MEM) hipLaunchKernelGGL(mem_tables_kernel, dim3(grid_for(air::MEM_MULT)), dim3(NT), 0, s, dPP, dInvMem);
-    std::vector<E4> inv((size_t)air::RC_TABLE + n_code + (MEM ? air::MEM_MULT : 0));
-    HIP_OK(hipMemcpyAsync(inv.data(), dInvRc, (size_t)air::RC_TABLE * sizeof(E4), hipMemcpyDeviceToHost, s));
-    if (n_code) HIP_OK(hipMemcpyAsync(inv.data() + air::RC_TABLE, dInvRom, (size_t)n_code * sizeof(E4), hipMemcpyDeviceToHost, s));
-    if (MEM) HIP_OK(hipMemcpyAsync(inv.data() + air::RC_TABLE + n_code, dInvMem, (size_t)air::MEM_MULT * sizeof(E4), hipMemcpyDeviceToHost, s));
+    E4* inv = pin.take_n<E4>((size_t)air::RC_TABLE + n_code + (MEM ? air::MEM_MULT : 0));
+    if (!inv) HIP_OK(hipErrorOutOfMemory);
+    HIP_OK(hipMemcpyAsync(inv, dInvRc, (size_t)air::RC_TABLE * sizeof(E4), hipMemcpyDeviceToHost, s));
+    if (n_code) HIP_OK(hipMemcpyAsync(inv + air::RC_TABLE, dInvRom, (size_t)n_code * sizeof(E4), hipMemcpyDeviceToHost, s));
+    if (MEM) HIP_OK(hipMemcpyAsync(inv + air::RC_TABLE + n_code, dInvMem, (size_t)air::MEM_MULT * sizeof(E4), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     E4 T = bb::e_zero();                                      // Montgomery: sum m_t / (alpha - t) + sum r_u / (alpha - fingerprint_u)
     for (int t = 0; t < air::RC_TABLE; t++) if (mult[n_code + t]) T = bb::e_add(T, bb::e_mul_fm(inv[t], bb::to_mont(mult[n_code + t] % bb::P)));
@@ -1102,10 +1114,10 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
         if (n_cells_v > N) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than rows"}); return ZKIR_ERR_ARGUMENT; }
         uint32_t code_size, data_size; memcpy(&code_size, blob + 16, 4); memcpy(&data_size, blob + 20, 4);
         const uint64_t image_len = 32 + (uint64_t)code_size + data_size <= blob_len ? (uint64_t)code_size + data_size : 0;
-        if (image_len) HIP_OK(hipMemcpyAsync(dImage, blob + 32, image_len, hipMemcpyHostToDevice, s));
-        HIP_OK(hipMemcpyAsync(dCellAddr, cell_addr_v.data(), n_cells_v * 8, hipMemcpyHostToDevice, s));
-        HIP_OK(hipMemcpyAsync(dCellBytes, cell_bytes_v.data(), n_cells_v * 8, hipMemcpyHostToDevice, s));
-        HIP_OK(hipMemcpyAsync(dCellTime, cell_time_v.data(), n_cells_v * 4, hipMemcpyHostToDevice, s));
+        if (image_len) HIP_OK(h2d(dImage, blob + 32, image_len));
+        HIP_OK(h2d(dCellAddr, cell_addr_v.data(), n_cells_v * 8));
+        HIP_OK(h2d(dCellBytes, cell_bytes_v.data(), n_cells_v * 8));
+        HIP_OK(h2d(dCellTime, cell_time_v.data(), n_cells_v * 4));
         const unsigned nb = grid_for(n_cells_v);
         hipLaunchKernelGGL(mem_cells_sum_kernel, dim3(nb), dim3(NT), 0, s, dCellAddr, dCellBytes, dCellTime, (uint32_t)n_cells_v, dImage, image_len, dPP, dCellPart);
         std::vector<E4> part(nb);
@@ -1303,7 +1315,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     head.push_back(pub->halt_kind); put_u64(pub->halt_kind == ZKIR_HALT_EXIT ? pub->halt_code : 0);
   }
   if (MEM) head.insert(head.end(), mem_sec.begin(), mem_sec.end());           // (mode 3) the touched cells
-  head.insert(head.end(), mult.begin(), mult.end());                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
+  head.insert(head.end(), mult, mult + n_mult);                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_zw[k].c, t_zw[k].c + 4);
@@ -1340,20 +1352,28 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   }
   GatherJob* dJobs; uint32_t* dOut;
   HIP_OK(ar.take(&dJobs, jobs.size())); HIP_OK(ar.take(&dOut, (size_t)off));
-  HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, s));
+  HIP_OK(h2d(dJobs, jobs.data(), jobs.size() * sizeof(GatherJob)));
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)jobs.size()), dim3(64), 0, s, dJobs, (uint32_t)jobs.size(), dOut);
   const uint64_t total = head.size() + off;
   uint32_t* out = (uint32_t*)malloc(total * 4);
   if (!out) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: out of host memory"}); return ZKIR_ERR_OTHER; }
   memcpy(out, head.data(), head.size() * 4);
-  hipError_t e = hipMemcpyAsync(out + head.size(), dOut, (size_t)off * 4, hipMemcpyDeviceToHost, s);
+  uint32_t* h_out = pin.take_n<uint32_t>((size_t)off);          // (the proof block is the caller's to free: it is never the target of a copy itself)
+  hipError_t e = h_out ? hipMemcpyAsync(h_out, dOut, (size_t)off * 4, hipMemcpyDeviceToHost, s) : hipErrorOutOfMemory;
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess || check_launch("zkir_prove") != ZKIR_OK) { free(out); if (e != hipSuccess) zkir::set_last_error({ZKIR_ERR_DEVICE, hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
+  memcpy(out + head.size(), h_out, (size_t)off * 4);
   for (size_t t = 0; t < queries.size(); t++) out[head.size() + qpos[t]] = queries[t];
   mark(9);
+  const double t_body = since(t_entry);
   if (stage_ms) {
     (void)hipEventSynchronize(se.ev[9]);
     for (int i = 0; i < 9; i++) (void)hipEventElapsedTime(&stage_ms[i], se.ev[i], se.ev[i + 1]);
+  }
+  if (dbg_t) {
+    fprintf(stderr, "zkir_prove mode %d: %.2f ms before the first stage, %.2f ms to the last mark, %.2f ms at return; host ms per stage:", MODE, t_pre, t_body, since(t_entry));
+    for (int i = 0; i < 9; i++) fprintf(stderr, " %.2f", host_ms[i + 1] - host_ms[i]);
+    fprintf(stderr, "\n");
   }
   *proof_out = out; *proof_words = total;
   return ZKIR_OK;
