@@ -225,7 +225,17 @@ static const uint32_t OP_ECALL = 0x50;
 //   word's shamt | 267 sb9: bit 39 of a | 268 sgn = sa sb9 | 269-272 pr_i = c_i 2^v | 273-274 the limbs of 2^40 - 2^t on right shifts | 275 sh: the shift amount
 // shared columns on a shift row: R0..R3 = lo_i, R4..R7 = c_i, pieces 0-3 = hi_i, piece 4 = 2 (c_3 mod 2^9), piece 5 = the bits of rs2's low limb above its first chunk (or of the
 // word's field above the shamt), piece 6 = d (sh beyond what t can say), piece 7 = the shamt's high nibble, piece 8 = rs2's first chunk, looked up with sh in LOW6 = {(v, v & 63)}
-static const int W_MAIN_MEM = 276, W_MAX = 276;
+// .. and MUL (execute.rs:79-99: the 40-bit values, the product mod 2^40), class mu = 20, as a schoolbook product in 10-bit chunks: a = rs1's low limbs in the row's second range
+// group (R4..R7), b = rs2's in pieces 0-3, the result's chunks r_k = R0..R3 (they ARE z), and for k = 0..3   sum_{i+j=k} a_i b_j + carry_(k-1) = r_k + 2^10 carry_k   with
+// carry_0 = piece 4 (< 2^10), carry_1 = piece 5 + 2^10 e_1 (< 2^11), carry_2 = piece 6 + 2^10 (e_2 + 2 e_3) (< 3 * 2^10 + 4), carry_3 = piece 7 + 2^10 piece 8 (dropped: mod 2^40)
+// — every slot a 10-bit range lookup on such a row, e_1..3 booleans: both sides stay below 2^31 - 2^27, so each equation holds over the integers and the decomposition is unique.
+// The products are of degree 2 already, so the class selector cannot multiply them: ma_i = kmu a_i are columns of their own (zero off MUL rows).  8 more logical columns (284, 264):
+//   276 kmu | 277-280 ma_0..3 | 281-283 e_1..3
+// MULH, DIVU, REMU, DIV, REM stay class "other": they work on the RAW 64-bit registers (Q2, Q3) — 128-bit products, more chunk lookups than a row has slots.
+static const int W_MAIN_MEM = 284, W_MAX = 284;
+enum { C_KMU = 276, C_MA = 277, C_ME = 281 };
+static const int K_MU = 20;
+static const uint32_t OP_MUL = 0x02;
 enum { C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275 };
 static const int K_SH = 19, TAG_LOW6 = 11;
 static inline bool is_shift(uint32_t op) { return op >= 0x18 && op <= 0x1D; }
@@ -265,7 +275,7 @@ static const int C_KOJ = C_K3 + 1;
 // mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
 static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
-static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 256 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
+static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 264 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
 // logical [logical_width][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, int mode, std::vector<F>& out) {
   out.assign((size_t)phys_width(mode) * N, 0);
@@ -355,6 +365,7 @@ static inline F opclass_of(uint32_t op, int mode = 0) {
   if (mode == 3 && is_store(op)) return K_ST;
   if (mode == 3 && is_logic(op)) return K_LG;
   if (mode == 3 && is_shift(op)) return K_SH;
+  if (mode == 3 && op == OP_MUL) return K_MU;
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
@@ -422,6 +433,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     else if (cls == K_ST) col(C_KST)[i] = 1;
     else if (cls == K_LG) col(C_KLG)[i] = 1;
     else if (cls == K_SH) col(C_KSH)[i] = 1;
+    else if (cls == K_MU) col(C_KMU)[i] = 1;
     else if (cls != K_ECALL) col(kcol(cls))[i] = 1;           // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
     col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
@@ -485,6 +497,25 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     else if (cls == K_SE || cls == K_SU) { y[0] = fx; rd = fa; }                      // execute.rs:373-431: the comparison as 0 / 1
     else if (cls == K_CMN || cls == K_CMZ) { y[0] = xb[0]; y[1] = xb[1]; y[2] = xb[2]; if (q) rd = fa; }   // execute.rs:434-472: rd = rs1 (raw) if the condition holds, nothing changes otherwise
     bool sh_row = false; F sh_lo[4] = {0, 0, 0, 0}, sh_c[4] = {0, 0, 0, 0};
+    if (cls == K_MU) {                                        // (mode 3) MUL: Value40::wrapping_mul of the masked operands (execute.rs:79-99), in 10-bit chunks
+      sh_row = true;                                          // (the row's range groups are filled like a shift row's: R0..R3 = the result's chunks, R4..R7 = a's)
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20);
+      F bc[4], carry = 0;
+      for (int k = 0; k < 4; k++) { sh_c[k] = (F)((a >> (10 * k)) & 1023); bc[k] = (F)((b >> (10 * k)) & 1023); col(C_MA + k)[i] = sh_c[k]; col(C_PIECE + k)[i] = bc[k]; }
+      uint64_t res = 0;
+      for (int k = 0; k < 4; k++) {
+        uint64_t t = carry;
+        for (int j = 0; j <= k; j++) t += (uint64_t)sh_c[j] * bc[k - j];
+        sh_lo[k] = (F)(t & 1023); carry = (F)(t >> 10);
+        res |= (uint64_t)sh_lo[k] << (10 * k);
+        col(C_PIECE + 4 + k)[i] = carry & 1023;
+        if (k == 1) col(C_ME)[i] = carry >> 10;
+        if (k == 2) { col(C_ME + 1)[i] = (carry >> 10) & 1; col(C_ME + 2)[i] = carry >> 11; }
+        if (k == 3) col(C_PIECE + 8)[i] = carry >> 10;
+      }
+      y[0] = (F)(res & 0xFFFFF); y[1] = (F)(res >> 20); y[2] = 0;
+      rd = fa;
+    }
     if (cls == K_SH) {                                        // (mode 3) SLL SRL SRA SLLI SRLI SRAI = 0x18 + (0 / 1 / 2) + 3 si (execute.rs:284-358)
       sh_row = true;
       const uint32_t which = (op - 0x18) % 3, si = (op - 0x18) / 3;
@@ -683,6 +714,7 @@ static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M
 // mem_mult (mode 3): LOW3 (1024) ++ BYTE (256) ++ NIBBLE (16)
 static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE, LG_BASE = RC_TABLE + 256 + 16, L6_BASE = LG_BASE + 3 * 256;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR ++ LOW6 (1024: entry v = the tuple (v, v & 63))
 static inline bool row_shift(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0; }
+static inline bool row_mul(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KMU * N + i] != 0; }
 static inline bool row_shift_reg(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0 && M[(size_t)C_SI * N + i] == 0; }
 // the table a piece slot looks its value up in on a SHIFT row: 0-6 the 10-bit range table, 7 the nibble table, 8 LOW6 (with the amount) when the amount comes from a register
 static inline int shift_piece_tag(int k, bool reg) { return k == 7 ? TAG_NIB : (k == 8 && reg) ? TAG_LOW6 : 0; }
@@ -712,6 +744,7 @@ static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& 
         if (v < 16 && b < 16 && r == logic_of(which, v, b)) (*mem_mult)[LG_BASE + 256 * which + 16 * v + b]++; else bad(i);
         continue;
       }
+      if (row_mul(M, N, i)) { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); continue; }   // a MUL row: every piece slot reads the 10-bit range table
       if (row_shift(M, N, i)) {                               // a shift row: the slots are re-typed (shift_piece_tag)
         const int tag = shift_piece_tag(k, row_shift_reg(M, N, i));
         if (tag == TAG_LOW6) { if (v < (F)RC_TABLE && M[(size_t)(C_LB + 8) * N + i] == (v & 63)) (*mem_mult)[L6_BASE + v]++; else bad(i); }
@@ -828,6 +861,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
       for (int k = 0; k < N_PIECE; k++) {
         const E h = lgop >= 0 ? einv(esub(lp.alpha, eadd(eadd(tagged(at(C_PIECE + k), TAG_AND + lgop, lp), emul_f(lp.lam[1], at(C_LB + k))), emul_f(lp.lam[2], at(C_LR + k)))))
                   : row_shift(M, N, i) ? einv(esub(lp.alpha, eadd(tagged(at(C_PIECE + k), shift_piece_tag(k, row_shift_reg(M, N, i)), lp), emul_f(lp.lam[1], at(C_LB + k)))))
+                  : row_mul(M, N, i) ? einv(esub(lp.alpha, tagged(at(C_PIECE + k), 0, lp)))
                               : einv(esub(lp.alpha, tagged(at(C_PIECE + k), PIECE_TAG[k], lp)));
         for (int c = 0; c < 4; c++) A[(size_t)(A_P + 4 * k + c) * N + i] = h.c[c];
         hs = eadd(hs, h);
@@ -938,10 +972,11 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E Kec = IO ? eadd(eadd(loc[C_F2], loc[C_RL]), eadd(loc[C_RE], loc[C_FH])) : e_from(0);   // (mode 2) the ecall class: the sum of its four syscall flags
   const E Kld = MEM ? loc[C_KLD] : e_from(0), Kst = MEM ? loc[C_KST] : e_from(0), Kmem = eadd(Kld, Kst);   // (mode 3) loads, stores
   const E Klg = MEM ? loc[C_KLG] : e_from(0);                                                             // (mode 3) the bitwise opcodes
+  const E Kmu = MEM ? loc[C_KMU] : e_from(0);                                                             // (mode 3) MUL
   const E Ksh = MEM ? loc[C_KSH] : e_from(0);                                                             // (mode 3) the shifts
-  { E sum = eadd(eadd(eadd(Kec, Kmem), Klg), Ksh); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  { E sum = eadd(eadd(eadd(eadd(Kec, Kmem), Klg), Ksh), Kmu); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
-    E ks = eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST)));
+    E ks = eadd(eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST))), emul_f(Kmu, (F)K_MU));
     for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
@@ -1249,7 +1284,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     for (int i = 0; i < N_PIECE; i++) {
       E d[4], pr[4];
       // (.. and on a shift row in the table shift_piece_tag names; piece 8's second element is the amount when it comes from a register)
-      E tg = eadd(emul_f(esub(esub(one, Klg), Ksh), PIECE_TAG[i]), lgtag);
+      E tg = eadd(emul_f(esub(esub(esub(one, Klg), Ksh), Kmu), PIECE_TAG[i]), lgtag);             // (a MUL row: the 10-bit range table in every slot)
       if (i == 7) tg = eadd(tg, emul_f(Ksh, TAG_NIB));
       if (i == 8) tg = eadd(tg, emul_f(esub(Ksh, loc[C_SI]), TAG_LOW6));
       for (int k = 0; k < 4; k++) d[k] = esub(esub(esub(cst(lp.alpha.c[k]), emul_f(tg, lp.lam[N_TUPLE].c[k])), emul_f(loc[C_LB + i], lp.lam[1].c[k])), emul_f(loc[C_LR + i], lp.lam[2].c[k]));
@@ -1323,6 +1358,24 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
       push(esub(esub(emul(Ksh, y[0]), eadd(res[0], emul_f(res[1], RC_TABLE))), emul(sgn, loc[C_ON])));
       push(esub(esub(emul(Ksh, y[1]), eadd(res[2], emul_f(res[3], RC_TABLE))), emul(sgn, loc[C_ON + 1])));
       push(emul(Ksh, y[2]));
+    }
+    // ---- 21. (mode 3) MUL (execute.rs:79-99): the product of the 40-bit operands mod 2^40, schoolbook in 10-bit chunks ----
+    {
+      const E* Rlo = loc + C_RC; const E* Rc = loc + C_RC2; const E* ma = loc + C_MA; const E* me = loc + C_ME;
+      boolean(Kmu); boolean(me[0]); boolean(me[1]); boolean(me[2]);
+      push(emul(Kmu, esub(w1, fa)));                                                              // rd = field a
+      push(emul(Kmu, esub(esub(xb[0], Rc[0]), emul_f(Rc[1], RC_TABLE)))); push(emul(Kmu, esub(esub(xb[1], Rc[2]), emul_f(Rc[3], RC_TABLE))));       // a's four chunks
+      push(emul(Kmu, esub(esub(xc[0], pcs[0]), emul_f(pcs[1], RC_TABLE)))); push(emul(Kmu, esub(esub(xc[1], pcs[2]), emul_f(pcs[3], RC_TABLE))));   // b's
+      for (int k = 0; k < 4; k++) push(esub(ma[k], emul(Kmu, Rc[k])));                            // ma_k = kmu a_k
+      const E carry[4] = {pcs[4], eadd(pcs[5], emul_f(me[0], RC_TABLE)), eadd(pcs[6], emul_f(eadd(me[1], emul_f(me[2], 2)), RC_TABLE)), eadd(pcs[7], emul_f(pcs[8], RC_TABLE))};
+      for (int k = 0; k < 4; k++) {                                                               // sum_{i+j=k} a_i b_j + carry_(k-1) = r_k + 2^10 carry_k
+        E t = e_from(0);
+        for (int j = 0; j <= k; j++) t = eadd(t, emul(ma[j], pcs[k - j]));
+        E lin = eadd(Rlo[k], emul_f(carry[k], RC_TABLE));
+        if (k) lin = esub(lin, carry[k - 1]);
+        push(esub(t, emul(Kmu, lin)));
+      }
+      push(emul(Kmu, esub(y[0], eadd(Rlo[0], emul_f(Rlo[1], RC_TABLE))))); push(emul(Kmu, esub(y[1], eadd(Rlo[2], emul_f(Rlo[3], RC_TABLE))))); push(emul(Kmu, y[2]));
     }
   }
   result = A.acc;

@@ -113,6 +113,20 @@ def alu_all():
     return _p(code + [EB]), [], {}
 
 
+def mul_grid():
+    """MUL (execute.rs:79-99) on a grid of 40-bit operands: zero, one, all ones, the sign bit, every chunk at its extremes (the largest carries), a register with bits above 40
+    set by LB's sign extension (masked: Value40::from_u64), rs1 = rs2 = rd."""
+    vals = [0, 1, 2, 0xFFFFFFFFFF, 0x8000000000, 0xF0F0A5C3E1, 0x0312345678, 1023, 1024, 0xFFFFF, 0x100000, 0x3FF003FF, 0xFFC00FFC00, 0x7FFFFFFFFF]
+    code = [A(5, 0, 0x4000), A(6, 0, 0x80), E(O.SB, rs1=5, rs2=6, imm=0), E(O.LB, 7, 5, imm=0)]           # R7 = 0xFFFF...FF80 (Q1)
+    for a in vals:
+        code += li40(1, a)
+        for b in vals:
+            code += li40(2, b) + [E(O.MUL, 3, 1, 2), E(O.MUL, 4, 2, 1)]
+        code += [E(O.MUL, 8, 1, 7), E(O.MUL, 9, 7, 1), E(O.MUL, 1, 1, 1)]
+    code += [E(O.MUL, 7, 7, 7), E(O.MUL, 0, 1, 2)]
+    return _p(code + [EB]), [], {}
+
+
 def loads_stores():
     code = [A(5, 0, 0x4000)] + li40(1, 0x80F1E2D3C4) + [A(2, 0, -1)]
     code += [E(O.SD, rs1=5, rs2=1, imm=0), E(O.SW, rs1=5, rs2=1, imm=8), E(O.SH, rs1=5, rs2=1, imm=12), E(O.SB, rs1=5, rs2=1, imm=14),

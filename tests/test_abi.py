@@ -257,7 +257,7 @@ def test_air_bounds_mode3():
 
 
 def test_quotient_evaluation_matches_oracle_constraints_mode3():
-    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 3: 276 logical / 96 aux columns, 616 constraints."""
+    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 3: 284 logical / 96 aux columns, 636 constraints."""
     import ctypes as C
     import numpy as np
     from oracle import stark_api as so
@@ -272,12 +272,12 @@ def test_quotient_evaluation_matches_oracle_constraints_mode3():
     virt = [9, 10, 11] + list(range(57, 73)) + [161]
     blob = spec.fib_program(5).to_bytes()
     pub = so.public_inputs(64, blob, [], [5], (1, 0), mem_mode=True)
-    assert LO.so_num_constraints_for(3) == 616
+    assert LO.so_num_constraints_for(3) == 636
     for trial in range(40):
         big = trial >= 36
         def words(n):
             return np.full(n, P - 1, np.uint32) if big else rng.integers(0, P, n).astype(np.uint32)
-        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(276), words(276), words(96), words(96), words(57), words(68), words(68), words(4), words(4), words(3)
+        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(284), words(284), words(96), words(96), words(57), words(68), words(68), words(4), words(4), words(3)
         loc[virt] = 0; nxt[virt] = 0
         want, got = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
         LO.so_constraints_eval_io(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]), C.byref(pub),
@@ -326,7 +326,7 @@ def test_memcheck_witness_and_main_trace_mode3_match_oracle_on_the_host(name):
     tc = rt.TraceColumnsC(cyc.ctypes.data, pc.ctypes.data, ins_c.ctypes.data, regs.ctypes.data, bb_.ctypes.data, bt.ctypes.data, bp.ctypes.data, st.ctypes.data, nr)
     N = 1 << so.padded_log_n(nr)
     wm = so.committed_width(3)
-    assert wm == 256
+    assert wm == 264
     out = np.zeros((wm // 8, N, 8), np.uint32)
     tape = np.asarray(list(ins) if len(ins) else [0], dtype=np.uint64)
 

@@ -550,7 +550,7 @@ def _mode3_case(which, witness="device"):
 
 
 @pytest.mark.parametrize("witness", ["device", "host"])
-@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "alu_all", "echo5", "fib30", "random3", "random5", "memloop", "q9_access_at_own_pc"])
+@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "alu_all", "mul_grid", "echo5", "fib30", "random3", "random5", "memloop", "q9_access_at_own_pc"])
 def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     """A proof in mode 3 — loads and stores constrained, every access one step of the offline memory check, the touched cells carried — from the GPU prover equals the
     oracle's word for word; both verifiers accept it and give the same verdict on tampered copies.  The memory witness comes from the device (memcheck.hip: address-major
@@ -560,7 +560,7 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
     proof = stark.prove(ctx, tr, pub)
     want = so.prove(ores.rows, opub)
-    assert proof[3] == 256 and proof[9] == 3 and len(proof) == len(want)
+    assert proof[3] == 264 and proof[9] == 3 and len(proof) == len(want)
     if not np.array_equal(proof, want):
         bad = np.nonzero(proof != want)[0]
         raise AssertionError(f"mode-3 proof differs at word {bad[0]} of {len(want)} ({len(bad)} words differ)")
@@ -680,7 +680,7 @@ def test_memcheck_witness_device_equals_host_replay(k, log2_cells):
 
 def test_mode3_wrong_execution_is_rejected_on_the_gpu_path():
     """Mode 3 on a device trace whose values do not follow the program (patched in HBM, consistently until the register is rewritten): a load that returns another value than
-    the cell holds, an XOR off by a bit, a shift off by a bit, an ANDI with the wrong immediate — each proof the GPU prover emits is rejected by both verifiers; in mode 0 the very
+    the cell holds, an XOR off by a bit, a shift off by a bit, a product off by one, an ANDI with the wrong immediate — each proof the GPU prover emits is rejected by both verifiers; in mode 0 the very
     same forged traces are ACCEPTED (those opcodes are class "other" there: y is a free witness) — the difference the mode makes."""
     from zkir_amd import stark
     blob = spec.memory_ring_program(4).to_bytes()
@@ -712,7 +712,7 @@ def test_mode3_wrong_execution_is_rejected_on_the_gpu_path():
         tr.registers[rd, k + 1:hi + 1] = saved
     assert rt.verify(stark.prove(ctx, tr, pub3), pub3) == 0
     ctx.close(); log.close()
-    # the shifts, on tests/programs.py: alu_all
+    # the shifts and MUL, on tests/programs.py: alu_all
     import programs as pg
     blob2, ins2, _ = pg.alu_all()
     ores2 = oracle.run(blob2, list(ins2), enable_execution_trace=True)
@@ -723,7 +723,7 @@ def test_mode3_wrong_execution_is_rejected_on_the_gpu_path():
     ctx2 = stark.StarkContext(stark.padded_log_n(len(ores2.rows)))
     assert rt.verify(stark.prove(ctx2, tr2, pub2), pub2) == 0
     ops2, rds2, n2 = ores2.rows["instruction"] & 0x7F, (ores2.rows["instruction"] >> 7) & 0xF, len(ores2.rows)
-    for op in (0x18, 0x19, 0x1A, 0x1B, 0x1C, 0x1D):
+    for op in (0x18, 0x19, 0x1A, 0x1B, 0x1C, 0x1D, 0x02):                                  # .. and MUL
         ks = np.nonzero((ops2 == op) & (rds2 != 0))[0]
         k = int(ks[len(ks) // 2]); rd = int(rds2[k])
         later = np.nonzero(rds2[k + 1:] == rd)[0]

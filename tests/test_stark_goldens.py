@@ -76,7 +76,7 @@ MODE_CASES = {c["name"]: c for c in G["mode_cases"]}
 def test_mode_goldens_describe_the_shipped_programs():
     assert bytes.fromhex(MODE_CASES["mode3_memory_loop_40"]["program_blob_hex"]) == spec.memory_loop_program(40).to_bytes()
     assert bytes.fromhex(MODE_CASES["mode3_fib30"]["program_blob_hex"]) == spec.fib_program(30).to_bytes()
-    assert [MODE_CASES[n]["committed_width"] for n in ("mode2_fib30", "mode3_fib30")] == [so.committed_width(2), so.committed_width(3)] == [160, 256]
+    assert [MODE_CASES[n]["committed_width"] for n in ("mode2_fib30", "mode3_fib30")] == [so.committed_width(2), so.committed_width(3)] == [160, 264]
 
 
 @pytest.mark.parametrize("name", sorted(MODE_CASES))

@@ -20,17 +20,17 @@ def _case(blob, ins=(), **cfg):
 
 
 def test_widths():
-    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (276, 256, 96, 616)
+    assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (284, 264, 96, 636)
     assert (so.logical_width(2), so.committed_width(2), so.aux_width(2), so.lib().so_num_constraints_for(2)) == (180, 160, 48, 430)      # mode 2 untouched
 
 
-@pytest.mark.parametrize("name", ["mem_sw_lw", "timestamps", "loads_stores", "alu_all", "q9_access_at_own_pc", "echo5", "fib30", "rc_doubling", "jumps_and_links"])
+@pytest.mark.parametrize("name", ["mem_sw_lw", "timestamps", "loads_stores", "alu_all", "mul_grid", "q9_access_at_own_pc", "echo5", "fib30", "rc_doubling", "jumps_and_links"])
 def test_honest_runs_are_accepted(name):
     """Every width (LB LBU LH LHU LW LD / SB SH SW SD), sign extension, loads of untouched cells and of the program image; no constraint is violated on any row."""
     blob, ins, cfg = getattr(pg, name)()
     ores, pub = _case(blob, ins, **{k: v for k, v in cfg.items() if k == "max_cycles"})
     proof = so.prove(ores.rows, pub)
-    assert proof[9] == 3 and proof[3] == 256
+    assert proof[9] == 3 and proof[3] == 264
     assert so.verify(proof, pub) == 0
     assert so.failing_constraints(so.main_trace(ores.rows, pub), pub, so.mem_cells(ores.rows, pub))[0] == 0
     assert so.verify_segment(proof, pub)[0] == 2                                  # the memory check spans the whole run: never a segment
@@ -206,6 +206,46 @@ def test_shifts_are_constrained():
     assert bad(lambda F: F.__setitem__((C_ON, j), int(F[C_ON, j]) ^ 1))                      # .. or of another width
     k0 = int(np.nonzero(ops == 0x08)[0][0])
     assert bad(lambda F: F.__setitem__((C_V + 3, k0), 1))                                    # a bit shift on a row that is no shift
+
+
+def test_mul_is_constrained():
+    """MUL = Value40::wrapping_mul of the masked operands (execute.rs:79-99), a schoolbook product in 10-bit chunks: honest rows over a grid of extreme operands satisfy every
+    constraint and the VM's results are the products mod 2^40; a result off by one (consistently carried into the register), a forged carry, a chunk of the wrong operand, a
+    carry bit that is no bit, a MUL run on a row that is none: each is rejected."""
+    blob, ins, _ = pg.mul_grid()
+    ores, pub = _case(blob)
+    M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    regs, words = ores.rows["registers"], ores.rows["instruction"]
+    ops = words & 0x7F
+    m40 = (1 << 40) - 1
+    rows = np.nonzero(ops == 0x02)[0]
+    assert len(rows) > 400
+    for i in rows:
+        w = int(words[i]); rd = (w >> 7) & 15
+        want = ((int(regs[i][(w >> 11) & 15]) & m40) * (int(regs[i][(w >> 15) & 15]) & m40)) & m40
+        if rd:
+            assert int(regs[i + 1][rd]) == want
+    assert so.failing_constraints(M, pub, cells)[0] == 0 and so.verify(so.prove(ores.rows, pub), pub) == 0
+    C_KMU, C_MA, C_ME, C_RC = 276, 277, 281, 135
+    nr = len(ops)
+    assert np.array_equal(M[C_KMU][:nr] != 0, (ops == 0x02) & (np.arange(nr) < nr - 1))
+    assert M[C_ME][rows].max() == 1 and (M[C_ME + 1][rows] + 2 * M[C_ME + 2][rows]).max() == 2 and M[C_PIECE + 8][rows].max() == 3      # the largest carries occur
+
+    def bad(edit):
+        F = M.copy(); edit(F)
+        return so.failing_constraints(F, pub, cells)[0] > 0 and so.verify(so.prove_matrix_mem(F, pub, cells), None) == 10
+    i = int([r for r in rows if ((int(words[r]) >> 7) & 15) == 3 and int(regs[r][1]) == 0xF0F0A5C3E1 and int(regs[r][2]) == 0x0312345678][0])
+
+    def result_off_by_one(F):                                                               # y, its chunk and the register that follows agree with each other — not with the product
+        F[C_Y, i] = int(F[C_Y, i]) ^ 1; F[C_RC, i] = int(F[C_RC, i]) ^ 1; F[C_LIMB + 9, i + 1:i + 2] = F[C_Y, i]
+    assert bad(result_off_by_one)
+    assert bad(lambda F: F.__setitem__((C_PIECE + 5, i), (int(F[C_PIECE + 5, i]) + 1) % 1024))                # a forged carry
+    assert bad(lambda F: F.__setitem__((C_MA + 2, i), (int(F[C_MA + 2, i]) + 1) % 1024))                      # ma_2 is not kmu a_2
+    assert bad(lambda F: (F.__setitem__((C_PIECE + 1, i), (int(F[C_PIECE + 1, i]) + 1) % 1024)))             # a chunk that is not rs2's
+    assert bad(lambda F: F.__setitem__((C_ME, i), 2))                                                        # a carry "bit" of 2
+    k0 = int(np.nonzero(ops == 0x08)[0][0])
+    assert bad(lambda F: F.__setitem__((C_KMU, k0), 1))                                                      # an ADDI run as a MUL
+    assert bad(lambda F: F.__setitem__((C_MA, k0), 5))                                                       # a's chunks off the MUL rows
 
 
 # ---- the product's verifier (zkir_verify, verify.cpp + air.h) on the oracle's mode-3 proofs: same verdict and same failing check ------------------------------------

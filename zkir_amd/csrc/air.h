@@ -50,14 +50,15 @@
 //   MODE 2 = the I/O argument: ECALL's READ / WRITE / EXIT constrained, the outputs and consumed inputs tied to tapes the proof carries, the halt row bound (the verifier does
 //            zkir_verify_io's checks itself);
 //   MODE 3 = mode 2 + the memory argument + the bitwise opcodes + the shifts: the ten loads and stores constrained, every access one step of an offline memory check over
-//            8-byte cells; AND OR XOR ANDI ORI XORI nibble by nibble through 256-entry tables; SLL SRL SRA SLLI SRLI SRAI as a 2^t = H 2^40 + L over 10-bit chunks (42 of 50
-//            opcodes now carry their semantics).  Left free there: MUL / MULH / DIVU / REMU / DIV / REM (class "other"), hash syscalls (forbidden: fh = 0), the SHA-256 chip.
+//            8-byte cells; AND OR XOR ANDI ORI XORI nibble by nibble through 256-entry tables; SLL SRL SRA SLLI SRLI SRAI as a 2^t = H 2^40 + L over 10-bit chunks; MUL
+//            as a schoolbook product of 10-bit chunks (43 of 50 opcodes now carry their semantics).  Left free there: MULH / DIVU / REMU / DIV / REM (class "other": they work
+//            on the raw 64-bit registers), hash syscalls (forbidden: fh = 0), the SHA-256 chip.
 #pragma once
 #include "babybear.h"
 
 namespace air {
 
-constexpr int W = 276;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
+constexpr int W = 284;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
 constexpr int W_LOGICAL_BASE = 172, W_LOGICAL_IO = 180;
 // MODES (the header's word 9, zkir_public_inputs::deferred): 0 = default VM mode, 1 = deferred carry model, 2 (round 4) = default mode WITH the I/O argument:
 // ECALL is a class of its own there (id K_ECALL, no column: Kec = f2 + rl + re + fh), dispatched on R10's limbs — f2 = WRITE (R10 = 2), rl / re = READ (R10 = 1) on a
@@ -86,8 +87,14 @@ enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PI
              // word's shamt | sb9: bit 39 of a | sgn = sa sb9 | pr_i = c_i 2^v | on_0, on_1: the limbs of 2^40 - 2^t on right shifts | sh: the amount.  Shared columns on a shift
              // row: R0..R3 = lo_i, R4..R7 = c_i, pieces 0-3 = hi_i, 4 = 2 (c_3 mod 2^9), 5 = the rest of rs2's low limb / of the word's field, 6 = d (what sh exceeds t's range
              // by), 7 = the shamt's high nibble, 8 = rs2's first chunk, looked up WITH sh in LOW6 = {(v, v & 63)}
-             C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275 };
-constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
+             C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275,
+             // .. and MUL (execute.rs:79-99: Value40::wrapping_mul of the masked operands), class mu = 20, schoolbook in 10-bit chunks: a = rs1's low limbs in R4..R7, b = rs2's in
+             // pieces 0-3, the result's chunks r_k = R0..R3 (= z), and for k = 0..3  sum_{i+j=k} a_i b_j + carry_(k-1) = r_k + 2^10 carry_k  with carry_0 = piece 4, carry_1 =
+             // piece 5 + 2^10 e_1, carry_2 = piece 6 + 2^10 (e_2 + 2 e_3), carry_3 = piece 7 + 2^10 piece 8 (dropped) — every slot a 10-bit range lookup on such a row: both sides
+             // stay below p, the equations hold over the integers.  The products have degree 2 already, so the class cannot gate them: ma_i = kmu a_i are columns (zero elsewhere).
+             C_KMU = 276, C_MA = 277, C_ME = 281 };
+constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
+constexpr uint32_t OP_MUL_ = 0x02;
 BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
 BB_HD constexpr bool is_shift(uint32_t op) { return op >= 0x18 && op <= 0x1D; }
 BB_HD constexpr int win_width(int v) { return v < 8 ? 1 : v < 12 ? 2 : v < 14 ? 4 : 8; }
@@ -115,7 +122,7 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
 // 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 256, W_COMMITTED_MAX = 256;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 264, W_COMMITTED_MAX = 264;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
@@ -152,7 +159,7 @@ BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
-  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 3 && is_shift(op)) ? (uint32_t)K_SH : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 3 && is_shift(op)) ? (uint32_t)K_SH : (mode == 3 && op == OP_MUL_) ? (uint32_t)K_MU : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;
@@ -183,7 +190,9 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              // the sign (2), the amount (5), sh vs t (1), d's guards (3), t <= 40 (1), 2^40 - 2^t (2), the result (3)
              I_SH_BOOL = 559, I_SH_ONE = 583, I_SH_OP = 585, I_SH_WR = 588, I_SH_A = 589, I_SH_PR = 591, I_SH_LOHI = 595, I_SH_SIGN = 599, I_SH_AMT = 601, I_SH_T = 606, I_SH_D = 607,
              I_SH_T40 = 610, I_SH_ON = 611, I_SH_Y = 613,
-             N_CONSTRAINTS = 616 };
+             // MUL (mode 3, appended): booleans kmu e_1..3 (4), rd (1), a's chunks (2), b's (2), ma_k = kmu a_k (4), the four chunk equations (4), the result (3)
+             I_MU_BOOL = 616, I_MU_WR = 620, I_MU_A = 621, I_MU_B = 623, I_MU_MA = 625, I_MU_EQ = 629, I_MU_Y = 633,
+             N_CONSTRAINTS = 636 };
 BB_HD constexpr int num_constraints(int mode) { return mode == 3 ? N_CONSTRAINTS : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
@@ -353,8 +362,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   // classes and the opcode
   V F2 = zero, RL = zero, RE = zero, FH = zero, H0 = zero, H1 = zero;   // (mode 2) the syscall flags of an ECALL row; Kec = their sum is the row's class
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
-  V Kld = zero, Kst = zero, Klg = zero, Ksh = zero;            // (mode 3) loads, stores, the bitwise opcodes, the shifts
-  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); Ksh = o.loc(C_KSH); }
+  V Kld = zero, Kst = zero, Klg = zero, Ksh = zero, Kmu = zero;   // (mode 3) loads, stores, the bitwise opcodes, the shifts, MUL
+  if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); Ksh = o.loc(C_KSH); Kmu = o.loc(C_KMU); }
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
@@ -367,7 +376,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.acc_lin(sum, F2, 1); o.acc_lin(sum, RL, 1); o.acc_lin(sum, RE, 1); o.acc_lin(sum, FH, 1);
       o.acc_lin(ks, F2, K_ECALL); o.acc_lin(ks, RL, K_ECALL); o.acc_lin(ks, RE, K_ECALL); o.acc_lin(ks, FH, K_ECALL);
     }
-    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(sum, Klg, 1); o.acc_lin(sum, Ksh, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); o.acc_lin(ks, Klg, K_LG); o.acc_lin(ks, Ksh, K_SH); }
+    if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(sum, Klg, 1); o.acc_lin(sum, Ksh, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); o.acc_lin(ks, Klg, K_LG); o.acc_lin(ks, Ksh, K_SH); o.acc_lin(sum, Kmu, 1); o.acc_lin(ks, Kmu, K_MU); }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
     if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), opc), o.accl_val(ks)));
@@ -704,7 +713,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
     for (int i = 0; i < N_PIECE; i++) {
       V h[4], d[4], pr[4];
       // (.. and on a SHIFT row in the table shift_piece_tag names; piece 8's second element is then the amount, when it comes from a register)
-      V tg = piece_tag(i) ? o.add(o.mulc(o.sub(nlg, Ksh), M((uint32_t)piece_tag(i))), lgtag) : lgtag;
+      V tg = piece_tag(i) ? o.add(o.mulc(o.sub(o.sub(nlg, Ksh), Kmu), M((uint32_t)piece_tag(i))), lgtag) : lgtag;   // (a MUL row: the 10-bit range table in every slot)
       if (i == 7) tg = o.add(tg, o.mulc(Ksh, M((uint32_t)TAG_NIB)));
       if (i == 8) tg = o.add(tg, o.mulc(o.sub(Ksh, o.loc(C_SI)), M((uint32_t)TAG_LOW6)));
 #pragma unroll
@@ -806,6 +815,31 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.push(I_SH_Y, o.lsub(o.sub(o.mul(y[0], Ksh), o.add(res[0], o.mulc(res[1], M(RC_TABLE)))), o.mul(sgn, on0)));
       o.push(I_SH_Y + 1, o.lsub(o.sub(o.mul(y[1], Ksh), o.add(res[2], o.mulc(res[3], M(RC_TABLE)))), o.mul(sgn, on1)));
       o.push(I_SH_Y + 2, o.lmul(y[2], Ksh));
+    }
+    // ---- MUL (execute.rs:79-99): the product of the 40-bit operands mod 2^40, schoolbook in 10-bit chunks: constraints 616.. ----
+    {
+      V ma[4], me[3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) ma[k] = o.loc(C_MA + k);
+#pragma unroll
+      for (int k = 0; k < 3; k++) me[k] = o.loc(C_ME + k);
+      boolean(I_MU_BOOL, Kmu); boolean(I_MU_BOOL + 1, me[0]); boolean(I_MU_BOOL + 2, me[1]); boolean(I_MU_BOOL + 3, me[2]);
+      o.push(I_MU_WR, o.lmul(o.lsub(w1v, fa), Kmu));
+      o.push(I_MU_A, o.lmul(o.lsub(o.sub(xb[0], R2[0]), o.mulc(R2[1], M(RC_TABLE))), Kmu)); o.push(I_MU_A + 1, o.lmul(o.lsub(o.sub(xb[1], R2[2]), o.mulc(R2[3], M(RC_TABLE))), Kmu));   // a's four chunks
+      o.push(I_MU_B, o.lmul(o.lsub(o.sub(xc[0], pcs[0]), o.mulc(pcs[1], M(RC_TABLE))), Kmu)); o.push(I_MU_B + 1, o.lmul(o.lsub(o.sub(xc[1], pcs[2]), o.mulc(pcs[3], M(RC_TABLE))), Kmu));   // b's
+#pragma unroll
+      for (int k = 0; k < 4; k++) o.push(I_MU_MA + k, o.lsub(ma[k], o.mul(R2[k], Kmu)));            // ma_k = kmu a_k
+      const V carry[4] = {pcs[4], o.add(pcs[5], o.mulc(me[0], M(RC_TABLE))), o.add(pcs[6], o.mulc(o.add(me[1], o.add(me[2], me[2])), M(RC_TABLE))), o.add(pcs[7], o.mulc(pcs[8], M(RC_TABLE)))};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {                                                                // sum_{i+j=k} a_i b_j + carry_(k-1) = r_k + 2^10 carry_k
+        AccP t = o.accp();
+#pragma unroll
+        for (int j = 0; j <= k; j++) o.acc_mul(t, ma[j], pcs[k - j]);
+        V lin = o.add(R[k], o.mulc(carry[k], M(RC_TABLE)));
+        if (k) lin = o.sub(lin, carry[k - 1]);
+        o.push(I_MU_EQ + k, o.lsub(o.acc_val(t), o.mul(lin, Kmu)));
+      }
+      o.push(I_MU_Y, o.lmul(o.lsub(y[0], z[0]), Kmu)); o.push(I_MU_Y + 1, o.lmul(o.lsub(y[1], z[1]), Kmu)); o.push(I_MU_Y + 2, o.lmul(y[2], Kmu));
     }
   }
   // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR (+ HO + HI) - T / N

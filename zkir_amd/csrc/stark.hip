@@ -103,7 +103,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
-  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; col(C_KSH) = cls == K_SH; }
+  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; col(C_KSH) = cls == K_SH; col(C_KMU) = cls == K_MU; }
   col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
   const uint32_t tc = (branch || (MODE == 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
@@ -123,7 +123,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && (cls == K_LD || cls == K_LG || cls == K_SH))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && (cls == K_LD || cls == K_LG || cls == K_SH || cls == K_MU))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
     else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -200,7 +200,30 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     // loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64 — below 2^40, or the run has no proof here — its aligned 8-byte cell's bytes before the
     // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
 #pragma unroll
-    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH) col(k) = 0;
+    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH && k != C_KMU) col(k) = 0;
+    if (cls == K_MU) {
+      // MUL (execute.rs:79-99): the product of the masked operands mod 2^40, schoolbook in 10-bit chunks; the range groups are filled like a shift row's (R0..R3 = the result's
+      // chunks, R4..R7 = a's), b's chunks in pieces 0-3, the carries in pieces 4-8 and e_1..3
+      sh_row = true;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20);
+      uint32_t bc[4], carry = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { sh_c[k] = (uint32_t)((a >> (10 * k)) & 1023); bc[k] = (uint32_t)((b >> (10 * k)) & 1023); col(C_MA + k) = sh_c[k]; col(C_PIECE + k) = bc[k]; }
+      uint64_t res = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t tsum = carry;                                   // < 4 * 2^20 + 2^12
+#pragma unroll
+        for (int j = 0; j <= k; j++) tsum += sh_c[j] * bc[k - j];
+        sh_lo[k] = tsum & 1023; carry = tsum >> 10;
+        res |= (uint64_t)sh_lo[k] << (10 * k);
+        col(C_PIECE + 4 + k) = carry & 1023;
+        if (k == 1) col(C_ME) = carry >> 10;
+        if (k == 2) { col(C_ME + 1) = (carry >> 10) & 1; col(C_ME + 2) = carry >> 11; }
+        if (k == 3) col(C_PIECE + 8) = carry >> 10;
+      }
+      y[0] = (uint32_t)(res & 0xFFFFF); y[1] = (uint32_t)(res >> 20); y[2] = 0;
+    }
     if (cls == K_SH) {
       // SLL SRL SRA SLLI SRLI SRAI (execute.rs:284-358) as a 2^t = H 2^40 + L: t = sh on a left shift, 40 - sh on a right shift (clamped at 40 / 0: d = the rest), t = 10 u + v
       sh_row = true;

@@ -229,10 +229,12 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
         if (a < 16 && b < 16 && r == air::logic_of(lg_which, a, b)) atomicAdd(&h_mem[air::LG_BASE + 256 * lg_which + 16 * a + b], 1u); else ok = false;
       };
       const uint32_t ksh = M[b8((uint32_t)air::phys_col(air::C_KSH, 3), i, N)], sh_reg = ksh && !M[b8((uint32_t)air::phys_col(air::C_SI, 3), i, N)];
+      const uint32_t kmu = M[b8((uint32_t)air::phys_col(air::C_KMU, 3), i, N)];
       uint32_t pc9[air::N_PIECE];
       for (int k = 0; k < air::N_PIECE; k++) {
         pc9[k] = M[b8(p_pc + (uint32_t)k, i, N)];
         if (lg_which >= 0) { logic_tuple(pc9[k], k); continue; }
+        if (kmu) { if (pc9[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[pc9[k]], 1u); else ok = false; continue; }   // a MUL row: every piece slot reads the 10-bit range table
         if (ksh) {                                               // a shift row: the slots are re-typed (air::shift_piece_tag); piece 8 of a register shift goes to LOW6 with the amount
           const int stag = air::shift_piece_tag(k, sh_reg != 0);
           if (stag == air::TAG_LOW6) {
@@ -250,11 +252,11 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       }
       uint32_t obl = 0, obh = 0;
       for (int k = 0; k < 4; k++) { obl |= (M[b8(p_ob + (uint32_t)k, i, N)] & 0xFF) << (8 * k); obh |= (M[b8(p_ob + 4 + (uint32_t)k, i, N)] & 0xFF) << (8 * k); }
-      // side: the nine pieces at ten bits each (a shift row's are chunks), the flags (kld | kst << 1 | window << 2 | (bitwise op + 1) << 6 | b_8, b_9 << 8 | ksh << 16 | register shift << 17)
+      // side: the nine pieces at ten bits each (a shift row's are chunks), the flags (kld | kst << 1 | window << 2 | (bitwise op + 1) << 6 | b_8, b_9 << 8 | ksh << 16 | register shift << 17 | kmu << 18)
       mem_side[2 * i] = make_uint4((pc9[0] & 1023) | ((pc9[1] & 1023) << 10) | ((pc9[2] & 1023) << 20), (pc9[3] & 1023) | ((pc9[4] & 1023) << 10) | ((pc9[5] & 1023) << 20),
                                    (pc9[6] & 1023) | ((pc9[7] & 1023) << 10) | ((pc9[8] & 1023) << 20), 0u);
       if (lg_which >= 0) logic_tuple(r[air::N_RC - 1], 9);       // the tenth tuple: a_9 = the last range chunk
-      mem_side[2 * i].w = kld | (kst << 1) | (win << 2) | ((uint32_t)(lg_which + 1) << 6) | ((lg_which >= 0 ? lbits_hi : 0u) << 8) | (ksh << 16) | (sh_reg << 17);
+      mem_side[2 * i].w = kld | (kst << 1) | (win << 2) | ((uint32_t)(lg_which + 1) << 6) | ((lg_which >= 0 ? lbits_hi : 0u) << 8) | (ksh << 16) | (sh_reg << 17) | (kmu << 18);
       mem_side[2 * i + 1] = make_uint4(obl, obh, M[b8(p_told, i, N)], lbits_lo);      // (the cycle of a whole run's row is its index)
       if (mem_row) {                                             // the first chunk goes to the LOW3 table, with the window's offset
         const uint32_t off = win < 15 ? (uint32_t)air::win_start((int)win) : 8u;
@@ -388,12 +390,14 @@ __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ s
   E4 inc = bb::e_zero();
   const int lg_which = (int)((fl >> 6) & 3) - 1;                // 0 / 1 / 2: an AND / OR / XOR row — every piece slot then reads its nibble tuple's inverse from the operation's table
   const bool ksh = (fl >> 16) & 1, sh_reg = (fl >> 17) & 1;     // a shift row: the slots re-typed (air::shift_piece_tag)
+  const bool kmu = (fl >> 18) & 1;                              // a MUL row: the 10-bit range table in every slot
   auto lg_b = [&](int k) { return k < 8 ? (m1.w >> (4 * k)) & 15 : (fl >> (8 + 4 * (k - 8))) & 15; };
 #pragma unroll
   for (int k = 0; k < air::N_PIECE; k++) {
     const int tag = air::piece_tag(k);
     const int stag = air::shift_piece_tag(k, sh_reg);
     const E4 h = lg_which >= 0 ? inv_mem[air::LG_BASE + 256 * lg_which + 16 * (pc9[k] & 15) + lg_b(k)]
+               : kmu ? inv_rc[pc9[k]]
                : ksh ? (stag == air::TAG_LOW6 ? inv_mem[air::L6_BASE + pc9[k]] : stag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + (pc9[k] & 15)] : inv_rc[pc9[k]])
                : tag == air::TAG_BYTE ? inv_mem[air::RC_TABLE + pc9[k]] : tag == air::TAG_NIB ? inv_mem[air::RC_TABLE + 256 + pc9[k]] : inv_rc[pc9[k]];
     put(air::A_P + 4 * k, h); inc = bb::e_add(inc, h);
