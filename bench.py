@@ -649,7 +649,7 @@ def main():
             mlog = rt.interpret(mblob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
             mddl = pl.upload(mlog); mtr = pl.DeviceTrace(mddl); pl.trace_fill(pl.trace_fill_args(mddl, mtr)); torch.cuda.synchronize()
             base = None
-            for mode, label in ((0, "mode 0 (152 + 40 columns)"), (2, "mode 2 (160 + 48)"), (3, "mode 3 (+ memory argument, bitwise opcodes, shifts: 256 + 96; witness on the device)")):
+            for mode, label in ((0, "mode 0 (152 + 40 columns)"), (2, "mode 2 (160 + 48)"), (3, "mode 3 (+ memory argument, bitwise opcodes, shifts, MUL: 264 + 96; witness on the device)")):
                 mpub = rt.public_inputs(mlog, mblob, [], io_mode=mode == 2, mem_mode=mode == 3)
                 ms, pr, st = timed_prove(mtr, mpub)
                 assert rt.verify(pr, mpub) == 0, f"bench: mode-{mode} proof of the array loop rejected"
@@ -911,7 +911,7 @@ def main():
             "prover": "ZKIR-STARK, AIR v6 (self-defined; 172 logical main-trace columns, 152 committed in default mode, + 40 aux columns / 398 constraints: the semantics of 20 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU/SLT/SGE, SEQ/SNE, CMOV/CMOVZ/CMOVNZ, BEQ/BNE, BLTU/BGEU/BLT/BGE, JAL, JALR — and the control flow of every opcode, + a LogUp lookup argument — instruction ROM and 10-bit ranges, eight range lookups per row; "
                       "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v10 carries the program).  `prove_ms` is MODE 0, the default; "
                       "opt-in modes (round 4, `prove_by_mode`): 2 = + the I/O argument (what the run read / wrote is proven), 3 = + the memory argument, the bitwise opcodes and the shifts "
-                      "(42 of 50 opcodes, memory consistency; 256 + 96 columns, 616 constraints; the memory witness is made on the device)",
+                      "(43 of 50 opcodes, memory consistency; 264 + 96 columns, 636 constraints; the memory witness is made on the device)",
             "prove_by_mode": prove_by_mode,
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),

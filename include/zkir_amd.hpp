@@ -404,7 +404,7 @@ enum class ProofMode : uint32_t {
   Default = 0,    // the default VM mode
   Deferred = 1,   // VMConfig::enable_deferred_model (relaxed AIR)
   Io = 2,         // default + the I/O argument: what the run read and wrote, and that it ended on the instruction its halt reason names
-  Memory = 3,     // Io + the memory argument, the bitwise opcodes and the shifts: 42 of 50 opcodes constrained, memory consistent (whole runs; no hash syscalls)
+  Memory = 3,     // Io + the memory argument, the bitwise opcodes, the shifts and MUL: 43 of 50 opcodes constrained, memory consistent (whole runs; no hash syscalls)
 };
 inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,
                                   const zkir_runtime::VMConfig& config = {}) {

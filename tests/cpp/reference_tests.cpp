@@ -239,7 +239,7 @@ static void test_prove_modes() {
     const zkir_prover::PublicInputs pub = zkir_prover::public_inputs(r, prog, {}, mode);
     CHECK(pub.deferred == (uint32_t)mode && pub.n_outputs == 1);
     const std::vector<uint32_t> proof = zkir_prover::prove(ctx, r, pub);
-    CHECK(proof[9] == (uint32_t)mode && proof[3] == (mode == zkir_prover::ProofMode::Io ? 160u : 256u));
+    CHECK(proof[9] == (uint32_t)mode && proof[3] == zkir_main_trace_width_for((uint32_t)mode));   // 160 / 264 committed columns
     CHECK(zkir_prover::verify(proof) == 0 && zkir_prover::verify(proof, &pub) == 0);
     std::vector<uint32_t> bad = proof; bad[bad.size() / 3] = (bad[bad.size() / 3] + 1) % 2013265921u;
     CHECK(zkir_prover::verify(bad) != 0);
