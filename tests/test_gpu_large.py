@@ -361,3 +361,32 @@ def test_commitment_root_equals_the_oracles_at_config_size(k):
     proof = stark.prove(ctx, tr, rt.public_inputs(log, blob))
     assert stark.trace_root(proof) == gold["roots"][str(k)]["root"]
     ctx.close(); log.close()
+
+
+@pytest.mark.parametrize("k", [12, 16, 18, 20])
+def test_proof_equals_the_oracles_at_config_size(k):
+    """BASELINE's metric is "end-to-end prove ms, 2^20-cycle fib" and north_star asks for bit-identical proof bytes: the GPU prover's COMPLETE proof of that run
+    (and of three smaller sizes) equals the proof the CPU oracle computed for it — tests/golden/config_proofs.json (length, SHA-256 of the words, 257 spaced
+    words), written by tests/golden/make_config_proofs.py from the oracle alone (~13 minutes of textbook arithmetic at 2^20: a fixture, not a per-run
+    computation).  tests/test_gpu_stark.py compares whole proofs word for word up to 2^13 rows; this is the same statement at the headline size."""
+    import hashlib
+    import json
+    import os
+    from zkir_amd import pipeline as pl, stark
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_proofs.json")))
+    blob = spec.fib_endless_program().to_bytes()
+    assert blob.hex() == gold["program_blob_hex"]
+    g = gold["proofs"][str(k)]
+    n = 1 << k
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    ctx = stark.StarkContext(k)
+    pub = rt.public_inputs(log, blob)
+    proof = np.ascontiguousarray(stark.prove(ctx, tr, pub), dtype="<u4")
+    assert len(proof) == g["words"]
+    pos = [int(i * (len(proof) - 1) // (len(g["samples"]) - 1)) for i in range(len(g["samples"]))]
+    bad = [p for p, w in zip(pos, g["samples"]) if int(proof[p]) != w]
+    assert not bad, f"proof differs from the oracle's at sampled words {bad[:8]} (of {len(proof)})"
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+    assert rt.verify(proof, pub) == 0
+    ctx.close(); log.close()

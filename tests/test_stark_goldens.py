@@ -108,3 +108,22 @@ def test_gpu_prover_reproduces_mode_goldens(name):
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof, pub) == 0
     ctx.close(); res.close()
+
+
+def test_config_proof_fixture_is_the_oracles_proof():
+    """tests/golden/config_proofs.json (whole proofs of the fib_endless run at 2^12 .. 2^20 cycles, written by make_config_proofs.py): the smallest entry is
+    recomputed here by the oracle — length, SHA-256 and the spaced words — so the fixture the GPU test compares the 2^20-cycle proof with is known to be made
+    the way its generator says; every entry names the same program, the shipped one."""
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_proofs.json")))
+    blob = bytes.fromhex(gold["program_blob_hex"])
+    assert blob == spec.fib_endless_program().to_bytes()
+    assert {"12", "16", "18", "20"} <= set(gold["proofs"])
+    g = gold["proofs"]["12"]
+    res = oracle.run(blob, max_cycles=1 << 12, enable_execution_trace=True)
+    pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code))
+    proof = np.ascontiguousarray(so.prove(res.rows, pub), dtype="<u4")
+    assert len(proof) == g["words"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+    pos = [int(i * (len(proof) - 1) // (len(g["samples"]) - 1)) for i in range(len(g["samples"]))]
+    assert [int(proof[p]) for p in pos] == g["samples"]
+    for k, e in gold["proofs"].items():
+        assert e["rows"] == 1 << int(k) and len(e["samples"]) == 257 and len(e["sha256"]) == 64
