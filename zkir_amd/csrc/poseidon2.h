@@ -15,8 +15,11 @@
 //     instructions), one Barrett reduction per output;
 //   * Montgomery products without their final conditional subtraction wherever the bounds allow ("lazy", see babybear.h);
 //   * additions folded into the 64-bit addend of a Montgomery product: (a*b + c) / R = mont(a, b) + c / R costs nothing extra.
-//     The partial rounds add the column sum that way, the full rounds add the NEXT round's constants pulled back through the
-//     linear layer (pre[r] = M_ext^-1 * ext[r + 1], computed once by generate()).
+//     The full rounds add the NEXT round's constants pulled back through the linear layer that way (pre[r] = M_ext^-1 * ext[r + 1],
+//     computed once by generate());
+//   * (round 4) the partial rounds' eleven passive words as 64-bit lazy integers, updated by a shift and an add — the diagonal is
+//     (1, 2, 4, .., 1024) — and Montgomery-reduced every third round only (int_rounds_scaled: 173 vector instructions per three rounds
+//     against 207; the leaf hash 3.77 -> 3.48 ms at 152 x 2^21).
 #pragma once
 #include "babybear.h"
 
@@ -39,12 +42,12 @@ struct Consts {              // Montgomery form unless noted
   uint32_t in_scale;         // mont_mul(x, in_scale) = x * F_IN: canonical value -> input word of permute_scaled
   uint32_t out_scale;        // mont_mul(s, out_scale) = s / F_OUT: output word -> canonical value
   uint32_t carry;            // mont_mul(s, carry) = s * F_IN / F_OUT: output word -> input word of the next permutation (sponge capacity)
-  uint32_t r3;               // R^3 mod p
-  uint32_t diag0;            // diag[0] = -2 in Montgomery form
-  uint32_t in_r[RP + 1];     // in[r] * R (Montgomery form of the Montgomery form): the NEXT partial round's constant rides the addend of
-                             // word 0's update product; in_r[RP] = ext[RF/2][0] * R (the constant of the full round that follows)
-  uint32_t ext4_r[T];        // ext[RF/2][i] * R: rides the addends of the LAST partial round's update products
   int32_t in0_neg;           // in[0] - p (in (-p, 0]): word 0 enters the partial rounds as a signed residue
+  // int_rounds_scaled(): the eleven passive words are 64-bit LAZY integers there, reduced (Montgomery: / R) after every third round, so their factor
+  // f_r = R^(1 - floor(r / 3)) drifts; word 0 carries h_r = (f_r R^6)^(1/7), the factor whose S-box output has the factor f_r of the words it is added to
+  int32_t pr_c[RP];          // h_(r+1) R^2 / f_r: what the reduced  sum - 2 s0  of round r is multiplied by on its way to the next S-box (r = RP - 1: towards G = f_(RP-1) / R)
+  uint64_t pr_a[RP];         // h_(r+1) in[r + 1] R: the next round's constant, the addend of that product (r = RP - 1: G ext[RF/2][0] R)
+  uint64_t pr_k[T];          // f_(RP-1) ext[RF/2][i]: the constants of the full round that follows, added to the passive words before their last reduction
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -95,9 +98,11 @@ inline void generate(Consts& c) {
       c.pre[r][i] = bb::to_mont(bb::to_mont(v));
     }
   // ---- permute_scaled(): factors.  A state word holds f * v for the true value v.  S-boxes in Montgomery arithmetic take the
-  // factor f to f^7 / R^6, a linear layer keeps it, its wide Montgomery reduction divides it by R.  The 22 partial rounds S-box
-  // one word only, so they want the factor that S-boxes preserve, f = R; working backwards from there through full rounds 3..0
-  // and the initial layer fixes F_IN, forwards through rounds 4..7 gives F_OUT.  (x -> x^7 is a bijection: gcd(7, p - 1) = 1.)
+  // factor f to f^7 / R^6, a linear layer keeps it, its wide Montgomery reduction divides it by R.  The 22 partial rounds are
+  // ENTERED with the factor that S-boxes preserve, f = R; working backwards from there through full rounds 3..0 and the initial
+  // layer fixes F_IN.  Inside them the passive words' factor drifts by 1 / R per reduction (eight of them) and word 0 follows with
+  // the factor whose S-box output matches (below); they are left with the common factor G = R^-7, and forwards from G through
+  // rounds 4..7 gives F_OUT.  (x -> x^7 is a bijection: gcd(7, p - 1) = 1.)
   {
     constexpr uint64_t INV7 = 1725656503ull;                   // 7^-1 mod (p - 1)
     const uint32_t R = bb::R1, Rinv = bb::inv(R);
@@ -105,6 +110,20 @@ inline void generate(Consts& c) {
     uint32_t g[RF + 1], h[RF];                                 // g[r]: factor entering the S-boxes of full round r; h[r]: after them
     g[RF / 2] = R;
     for (int r = RF / 2 - 1; r >= 0; r--) { h[r] = bb::mul(g[r + 1], R); g[r] = bb::pow(bb::mul(h[r], R6), INV7); }
+    {
+      // the partial rounds (int_rounds_scaled): f[r] the passive words' factor during round r, hx[r] word 0's at its S-box, G the common factor they leave with
+      uint32_t f[RP], hx[RP];
+      for (int r = 0; r < RP; r++) { f[r] = r < 3 ? R : bb::mul(f[r - 3], Rinv); hx[r] = bb::pow(bb::mul(f[r], R6), INV7); }
+      const uint32_t G = bb::mul(f[RP - 1], Rinv), R2c = bb::mul(R, R);
+      for (int r = 0; r < RP; r++) {
+        const uint32_t hn = r + 1 < RP ? hx[r + 1] : G, rcn = bb::from_mont(r + 1 < RP ? c.in[r + 1] : c.ext[RF / 2][0]);
+        c.pr_c[r] = (int32_t)bb::mul(bb::mul(hn, R2c), bb::inv(f[r]));
+        c.pr_a[r] = bb::mul(bb::mul(hn, rcn), R);
+      }
+      c.pr_k[0] = 0;
+      for (int i = 1; i < T; i++) c.pr_k[i] = bb::mul(f[RP - 1], bb::from_mont(c.ext[RF / 2][i]));
+      g[RF / 2] = G;                                           // .. and the second half of the full rounds starts from it
+    }
     for (int r = RF / 2; r < RF; r++) { h[r] = bb::mul(bb::pow(g[r], 7), bb::inv(R6)); g[r + 1] = bb::mul(h[r], Rinv); }
     const uint32_t f_in = bb::mul(g[0], R), f_out = g[RF];
     for (int i = 0; i < T; i++) c.ext0_s[i] = bb::mul(bb::from_mont(c.ext[0][i]), f_in);
@@ -118,11 +137,6 @@ inline void generate(Consts& c) {
     c.in_scale = bb::mul(f_in, R);
     c.out_scale = bb::mul(R, bb::inv(f_out));
     c.carry = bb::mul(bb::mul(f_in, R), bb::inv(f_out));
-    c.r3 = bb::pow(R, 3);
-    c.diag0 = c.diag[0];
-    for (int r = 0; r < RP; r++) c.in_r[r] = bb::to_mont(c.in[r]);
-    c.in_r[RP] = bb::to_mont(c.ext[RF / 2][0]);
-    for (int i = 0; i < T; i++) c.ext4_r[i] = bb::to_mont(c.ext[RF / 2][i]);
     c.in0_neg = (int32_t)c.in[0] - (int32_t)bb::P;
   }
 }
@@ -230,32 +244,67 @@ BB_HD int32_t sbox_signed(int32_t x) {
   const int32_t x2 = bb::smont_mul(x, x), x3 = bb::smont_mul(x2, x), x6 = bb::smont_mul(x3, x3);
   return bb::smont_mul(x6, x);
 }
-// The 22 partial rounds on signed residues in (-p, p): state factor R (plain Montgomery form) on entry and exit, and NOTHING is
-// reduced anywhere — a signed product of a word below p with a constant below p is within 0.97 p again, the 64-bit column sum takes
-// its operands sign-extended by the multiply-add that accumulates them.  The constant of the full round that follows rides the
-// addends of the last round's update products (LAST), so the words leave ready for its S-boxes.
-template <bool LAST>
-BB_HD void int_round_signed(int32_t& x, int32_t* t, const Consts& c, int r) {
-  const int32_t s0 = sbox_signed(x);
-  int64_t acc = s0;
-#pragma unroll
-  for (int i = 1; i < T; i++) acc = bb::sacc_add(acc, t[i]);
-  const int64_t sum_r = bb::smont_mul(bb::smont_reduce_wide(acc), (int32_t)c.r3);                // (sum / R) * R^3 / R = sum * R
-  x = bb::smont_mul_add(s0, (int32_t)c.diag0, (uint64_t)(sum_r + c.in_r[r + 1]));               // sum - 2 s0 + the next constant: the next S-box input
-#pragma unroll
-  for (int i = 1; i < T; i++) t[i] = bb::smont_mul_add(t[i], (int32_t)c.diag[i], (uint64_t)(LAST ? sum_r + c.ext4_r[i] : sum_r));
+// The 22 partial rounds:  s0 = sbox(x);  sum = s0 + Σ t_i;  x <- sum - 2 s0 + next constant;  t_i <- sum + 2^(i-1) t_i   (diag = -2, 1, 2, 4, .., 1024).
+// The update of a passive word is a SHIFT AND AN ADD, so the eleven t_i are kept as 64-bit lazy integers and updated without any multiplication or reduction
+// (round 3 of this repo multiplied each by its diagonal constant — a Montgomery product, three instructions — every round): a word grows by ten bits a round, so
+// after every THIRD round all eleven are Montgomery-reduced (two instructions a word), which divides their common factor f by R.  Word 0 is the only word an S-box
+// sees; it carries the factor h = (f R^6)^(1/7), for which the S-box output x^7 / R^6 has exactly the factor f of the words it is summed with, and the one product
+// on its way to the next S-box (pr_c) moves it from f to the next h while adding the next round constant (pr_a).  Per three rounds: 3 x (12 S-box + 11 sum + 1 + 5)
+// + 11 + 17 + 17 updates (one instruction where the word is still 32 bits or the shift is at most 4, two otherwise) + 22 for the reduction = 154 vector
+// instructions against 3 x 69.  Bounds: |t| < 2^31 after a reduction, < 2^41.1, 2^51.1, 2^61.1 after one, two, three rounds; |sum| < 2^51.5; the reductions take
+// |acc| < 2^62.  The words leave with the common factor G = R^-7 (generate(): the second half of the full rounds starts from it), the constants of full round 4 added.
+template <int K>
+BB_HD int64_t smad(int64_t acc, int32_t x) {                  // acc + K x, x sign-extended by the instruction (v_mad_i64_i32; K an inline constant or a scalar register)
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t r;
+  if constexpr (K >= -16 && K <= 64) asm("v_mad_i64_i32 %0, vcc, %1, %3, %2" : "=v"(r) : "v"(x), "v"(acc), "n"(K) : "vcc");
+  else asm("v_mad_i64_i32 %0, vcc, %1, %3, %2" : "=v"(r) : "v"(x), "v"(acc), "s"(K) : "vcc");
+  return r;
+#else
+  return acc + (int64_t)K * x;
+#endif
 }
-BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // in: unsigned words below p + 128; out: signed words in (-p, p), next round's constants added
+// word 0 of the next round out of  v = f (sum - 2 s0)
+BB_HD int32_t int_next_x(int64_t v, const Consts& c, int r) { return bb::smont_mul_add(bb::smont_reduce_wide(v), c.pr_c[r], c.pr_a[r]); }
+// a round whose passive words are 32-bit (the first after a reduction): they leave as 64-bit integers
+BB_HD void int_round_a(int32_t& x, const int32_t* t, int64_t* w, const Consts& c, int r) {
+  const int32_t s0 = sbox_signed(x);
+  int64_t sum = s0;
+#pragma unroll
+  for (int i = 1; i < T; i++) sum = bb::sacc_add(sum, t[i]);
+  x = int_next_x(smad<-2>(sum, s0), c, r);
+  w[1] = smad<1>(sum, t[1]); w[2] = smad<2>(sum, t[2]); w[3] = smad<4>(sum, t[3]); w[4] = smad<8>(sum, t[4]); w[5] = smad<16>(sum, t[5]); w[6] = smad<32>(sum, t[6]);
+  w[7] = smad<64>(sum, t[7]); w[8] = smad<128>(sum, t[8]); w[9] = smad<256>(sum, t[9]); w[10] = smad<512>(sum, t[10]); w[11] = smad<1024>(sum, t[11]);
+}
+// a round on 64-bit passive words
+BB_HD void int_round_w(int32_t& x, int64_t* w, const Consts& c, int r) {
+  const int32_t s0 = sbox_signed(x);
+  uint64_t acc = (uint64_t)w[1];
+#pragma unroll
+  for (int i = 2; i < T; i++) acc += (uint64_t)w[i];
+  const int64_t sum = bb::sacc_add((int64_t)acc, s0);
+  x = int_next_x(smad<-2>(sum, s0), c, r);
+#pragma unroll
+  for (int i = 1; i < T; i++) w[i] = (int64_t)(((uint64_t)w[i] << (i - 1)) + (uint64_t)sum);
+}
+BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // in: unsigned words below p + 128, factor R; out: signed words in (-p, p), factor G, next round's constants added
   int32_t x = (int32_t)s[0] + c.in0_neg;
   int32_t t[T];
+  int64_t w[T];
 #pragma unroll
   for (int i = 1; i < T; i++) t[i] = (int32_t)s[i];
 #pragma unroll 1
-  for (int r = 0; r < RP - 1; r++) int_round_signed<false>(x, t, c, r);
-  int_round_signed<true>(x, t, c, RP - 1);
+  for (int r = 0; r < RP - 1; r += 3) {
+    int_round_a(x, t, w, c, r);
+    int_round_w(x, w, c, r + 1);
+    int_round_w(x, w, c, r + 2);
+#pragma unroll
+    for (int i = 1; i < T; i++) t[i] = bb::smont_reduce_wide(w[i]);
+  }
+  int_round_a(x, t, w, c, RP - 1);
   s[0] = (uint32_t)x;
 #pragma unroll
-  for (int i = 1; i < T; i++) s[i] = (uint32_t)t[i];
+  for (int i = 1; i < T; i++) s[i] = (uint32_t)bb::smont_reduce_wide((int64_t)((uint64_t)w[i] + c.pr_k[i]));
 }
 BB_HD void permute_scaled(uint32_t* s, const Consts& c) {
   ext_linear_scaled<true>(s, c.ext0_s);
