@@ -35,9 +35,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # Montgomery multiplications in one Poseidon2-12 permutation as the hash kernels run it (poseidon2.h, permute_scaled): 4 per S-box x
-# (8 x 12 + 22) S-boxes + 13 per partial round (11 diagonal products, word 0's update, the sum's change of form) x 22 + the 12
-# products that bring 8 absorbed values and the 4 carried capacity words to the input factor
-MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 13 * 22 + 12
+# (8 x 12 + 22) S-boxes + 1 per partial round (word 0 on its way to the next S-box; round 4: the eleven passive words are updated by a shift and
+# an add, no product — round 3 spent 13 products per partial round) x 22 + the 12 products that bring 8 absorbed values and the 4 carried capacity
+# words to the input factor
+MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 22 + 12
+# vector instructions of one permutation, counted in the ISA of leaf_hash_kernel (absorption included): what the kernel's time is made of
+VALU_INSTR_PER_PERM = 3382
 PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
 # The integer-ALU roofline of the Poseidon2 kernels, ANALYTIC (a fixed denominator): a Montgomery product is three
 # multiplier-class wave instructions (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32), each of which issues in 4.2 SIMD-cycles per wave64 on
@@ -45,6 +48,9 @@ PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient_and
 #     1024 SIMDs x 2.4e9 cycles/s x 64 lanes / (3 instructions x 4.2 cycles) = 1.248e13 products/s
 ALU_PEAK_FORMULA = "1024 SIMDs x 2.4e9 Hz x 64 lanes / (3 multiplier-class instructions x 4.2 SIMD-cycles per wave64 instruction)"
 ALU_PEAK_MONT_MUL_PER_S = 1024 * 2.4e9 * 64 / (3 * 4.2)
+# .. and the same roofline in the unit the kernel's time is really made of since round 4 (fewer products, the rest shifts / 64-bit adds / reductions at the same
+# issue cost): one wave64 vector instruction per 4.2 SIMD-cycles
+ALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.2
 
 
 def _fri_schedule(k):
@@ -74,7 +80,8 @@ def _prove_stage_table(k, W, pms):
             m >>= 1
     rows = {
         "quotient_and_merkle": (4 * W * n2 + 32 * n2) + (32 * n2 + tree),   # constraint evaluation reads the LDE once (row j and row j + 2 are the same bytes), writes the Q block; its tree
-        "openings": 4 * W * n2 + 32 * n2 + 2 * 16 * n2 + 2 * 16 * n2,       # weights written (2 x 16 B), matrix + Q read once, weights read once
+        "openings": 4 * W * (n2 // 2) + 32 * n2 + 2 * 16 * n2 + 2 * 16 * n2,  # weights written (2 x 16 B); the trace matrices read on the EVEN half of the coset (round 4: their degree is < N), Q on all of it; weights read once
+                                                                             # (the rows skipped share their 128-byte lines with the rows read: the HBM traffic is that of the whole matrix)
         "deep": 4 * W * n2 + 16 * n2 + 2 * 16 * n2 + 16 * n2,               # matrix, Q, two inverse columns read; the codeword written
         "fri": fri,
     }
@@ -241,7 +248,10 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
             ms = stage_ms[name]
             modmul = perms * MONT_MUL_PER_PERM / (ms * 1e-3)
             kernels[name] = {"bound": "int-alu", "kernels": kern, "bytes": nbytes, "ms": ms, "poseidon2_perms": perms, "poseidon2_perms_per_s": perms / (ms * 1e-3),
-                             "mont_mul_per_s": modmul, "alu_peak_analytic": ALU_PEAK_MONT_MUL_PER_S, "frac_of_alu_peak": modmul / ALU_PEAK_MONT_MUL_PER_S}
+                             "mont_mul_per_s": modmul, "mont_mul_peak_analytic": ALU_PEAK_MONT_MUL_PER_S, "frac_of_mont_mul_peak": modmul / ALU_PEAK_MONT_MUL_PER_S,
+                             # a wave runs 64 permutations, one per lane: wave instructions per second against one per 4.2 SIMD-cycles on 1024 SIMDs
+                             "valu_wave_instr_per_s": perms / 64 * VALU_INSTR_PER_PERM / (ms * 1e-3), "alu_peak_analytic": ALU_PEAK_WAVE_INSTR_PER_S,
+                             "frac_of_alu_peak": perms / 64 * VALU_INSTR_PER_PERM / (ms * 1e-3) / ALU_PEAK_WAVE_INSTR_PER_S}
     for v in kernels.values():
         v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
         v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
@@ -873,14 +883,20 @@ def main():
                          "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (a file, NOT a counter read in this run)"
                                          if traffic is not None else None,
                          "kernel_ms": kernels[dom]["ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
-                         "note": ("the dominant kernel is the Poseidon2 leaf hash, which is integer-ALU-bound (770 Montgomery multiplications + 130 wide Montgomery reductions per "
-                                  "permutation; VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see `alu` and roofline_by_stage")
+                         "note": ("the dominant kernel is the Poseidon2 leaf hash, which is integer-ALU-bound (3,382 vector instructions per permutation, 506 Montgomery multiplications among them; "
+                                  "VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see `alu` and roofline_by_stage")
                          if kernels[dom]["bound"] != "hbm" else None,
                          # the roofline that does bound this kernel: vector-ALU issue.  `peak` is ANALYTIC and fixed (ALU_PEAK_FORMULA); the measured rate of
                          # independent minimal products on this device, with its spread, is next to it; `valu_busy_profiled` = rocprofv3 VALUBusy of
                          # leaf_hash_kernel in the committed counter pass of this command (profiles/): the pipe is never idle
-                         "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["mont_mul_per_s"], "peak": ALU_PEAK_MONT_MUL_PER_S, "peak_formula": ALU_PEAK_FORMULA,
-                                  "unit": "mont_mul/s", "frac": kernels[dom]["frac_of_alu_peak"], "peak_measured": alu_measured,
+                         "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["valu_wave_instr_per_s"], "peak": ALU_PEAK_WAVE_INSTR_PER_S,
+                                  "peak_formula": "1024 SIMDs x 2.4e9 Hz / 4.2 SIMD-cycles per wave64 vector instruction (profiles/r02_ubench_alu.txt: multiplier-class and 64-bit "
+                                                  "instructions 4.1-4.5, a few 32-bit ones 2.2-2.4: the fraction can exceed 1 by the share of those)",
+                                  "unit": "wave64 VALU instructions/s", "frac": kernels[dom]["frac_of_alu_peak"],
+                                  "valu_instr_per_permutation": VALU_INSTR_PER_PERM,
+                                  # the round-3 way of saying it (products only, three instructions each), kept for comparison: it FELL in round 4 because the kernel does fewer products
+                                  "mont_mul_view": {"achieved": kernels[dom]["mont_mul_per_s"], "peak": ALU_PEAK_MONT_MUL_PER_S, "peak_formula": ALU_PEAK_FORMULA, "unit": "mont_mul/s",
+                                                    "frac": kernels[dom]["frac_of_mont_mul_peak"], "peak_measured": alu_measured},
                                   "mont_mul_per_permutation": MONT_MUL_PER_PERM, "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel"),
                                   # the analytic peak assumes 2.4 GHz; under this kernel's load the chip clocks lower (counter pass): the same fraction at THAT clock
                                   "clock_ghz_profiled": _profiled_clock_ghz("leaf_hash_kernel"),

@@ -309,8 +309,14 @@ BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // in: unsigned w
 BB_HD void permute_scaled(uint32_t* s, const Consts& c) {
   ext_linear_scaled<true>(s, c.ext0_s);
 #pragma unroll P2_RF_UNROLL
-  for (int r = 0; r < RF; r++) {
-    if (r == RF / 2) int_rounds_scaled(s, c);
+  for (int r = 0; r < RF / 2; r++) {
+#pragma unroll
+    for (int i = 0; i < T; i++) s[i] = sbox_biased(s[i], c.pre_b[r][i]);
+    ext_linear_scaled<false>(s, nullptr);
+  }
+  int_rounds_scaled(s, c);
+#pragma unroll P2_RF_UNROLL
+  for (int r = RF / 2; r < RF; r++) {
 #pragma unroll
     for (int i = 0; i < T; i++) s[i] = sbox_biased(s[i], c.pre_b[r][i]);
     ext_linear_scaled<false>(s, nullptr);
