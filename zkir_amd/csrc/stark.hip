@@ -506,18 +506,22 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
   for (uint32_t cnt = per_wg; cnt > 1; cnt >>= 1) {
     cur += 4 * m; m >>= 1; pos0 >>= 1;                         // level written by this iteration
     const uint32_t n_perm = cnt / 2;
-    if (n_perm > NT / 4) {                                     // enough permutations to give every lane its own
-      const bool active = t < n_perm;
+    if (n_perm > NT / 4) {                                     // enough permutations to give every lane its own: the throughput formulation (p2::permute_scaled,
+      const bool active = t < n_perm;                          // a fifth fewer instructions than p2::permute — on a lone wave that is a fifth less latency)
       uint32_t s[p2::T];
       if (active) {
-        const uint4 l = buf[2 * t], r = buf[2 * t + 1];
-        s[0] = l.x; s[1] = l.y; s[2] = l.z; s[3] = l.w; s[4] = r.x; s[5] = r.y; s[6] = r.z; s[7] = r.w; s[8] = s[9] = s[10] = s[11] = 0;
+        const uint4 l = buf[2 * t], r = buf[2 * t + 1];        // Montgomery words R v -> input words F_IN v: one product with F_IN
+        const uint32_t k_in = bb::from_mont(cp->in_scale);
+        s[0] = bb::mont_mul_lazy(l.x, k_in); s[1] = bb::mont_mul_lazy(l.y, k_in); s[2] = bb::mont_mul_lazy(l.z, k_in); s[3] = bb::mont_mul_lazy(l.w, k_in);
+        s[4] = bb::mont_mul_lazy(r.x, k_in); s[5] = bb::mont_mul_lazy(r.y, k_in); s[6] = bb::mont_mul_lazy(r.z, k_in); s[7] = bb::mont_mul_lazy(r.w, k_in);
+        s[8] = s[9] = s[10] = s[11] = 0;
       }
       __syncthreads();                                         // all inputs read before slot t is overwritten
       if (active) {
-        p2::permute(s, *cp);
-        buf[t] = make_uint4(s[0], s[1], s[2], s[3]);
-        reinterpret_cast<uint4*>(cur)[pos0 + t] = make_uint4(bb::from_mont(s[0]), bb::from_mont(s[1]), bb::from_mont(s[2]), bb::from_mont(s[3]));
+        p2::permute_scaled(s, *cp);
+        const uint32_t ko = cp->out_scale, ko_m = bb::to_mont(ko);                     // output words F_OUT v -> canonical v (the tree) and R v (the next level)
+        buf[t] = make_uint4(bb::mont_mul(s[0], ko_m), bb::mont_mul(s[1], ko_m), bb::mont_mul(s[2], ko_m), bb::mont_mul(s[3], ko_m));
+        reinterpret_cast<uint4*>(cur)[pos0 + t] = make_uint4(bb::mont_mul(s[0], ko), bb::mont_mul(s[1], ko), bb::mont_mul(s[2], ko), bb::mont_mul(s[3], ko));
       }
     } else {                                                   // few permutations: one per QUAD of lanes (p2::permute_quad), ~2.4x shorter
       const uint32_t pi = t >> 2, l = t & 3;
