@@ -39,8 +39,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 # an add, no product — round 3 spent 13 products per partial round) x 22 + the 12 products that bring 8 absorbed values and the 4 carried capacity
 # words to the input factor
 MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 22 + 12
-# vector instructions of one permutation, counted in the ISA of leaf_hash_kernel (absorption included): what the kernel's time is made of
-VALU_INSTR_PER_PERM = 3382
+# vector instructions of one permutation in leaf_hash_kernel, absorption included: SQ_INSTS_VALU of a launch / its 622,592 wave-permutations
+# (profiles/r04zz_bench_commit_valu_busy.txt: 3,235.5; round 3: 3,729) — what the kernel's time is made of
+VALU_INSTR_PER_PERM = 3236
 PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
 # The integer-ALU roofline of the Poseidon2 kernels, ANALYTIC (a fixed denominator): a Montgomery product is three
 # multiplier-class wave instructions (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32), each of which issues in 4.2 SIMD-cycles per wave64 on
@@ -883,7 +884,7 @@ def main():
                          "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (a file, NOT a counter read in this run)"
                                          if traffic is not None else None,
                          "kernel_ms": kernels[dom]["ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
-                         "note": ("the dominant kernel is the Poseidon2 leaf hash, which is integer-ALU-bound (3,382 vector instructions per permutation, 506 Montgomery multiplications among them; "
+                         "note": ("the dominant kernel is the Poseidon2 leaf hash, which is integer-ALU-bound (3,236 vector instructions per permutation, 506 Montgomery multiplications among them; "
                                   "VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see `alu` and roofline_by_stage")
                          if kernels[dom]["bound"] != "hbm" else None,
                          # the roofline that does bound this kernel: vector-ALU issue.  `peak` is ANALYTIC and fixed (ALU_PEAK_FORMULA); the measured rate of

@@ -294,7 +294,7 @@ typedef struct zkir_io_args { const uint64_t* inputs; uint64_t n_inputs; uint64_
 int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* scratch, uint32_t* out, void* hip_stream);
 /* the same on the HOST (host pointers everywhere; no scratch): a test entry point like zkir_main_trace_host */
 int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out);
-/* The main trace of MODE 3 (mode 2 + the memory argument, the bitwise opcodes and the shifts: 256 committed columns): load / store rows also show the accessed window, the cell's bytes before the access, the
+/* The main trace of MODE 3 (mode 2 + the memory argument, the bitwise opcodes, the shifts and MUL: 264 committed columns): load / store rows also show the accessed window, the cell's bytes before the access, the
  * time of its previous access and the pieces of the value moved.  mem_old / mem_told: [n_real] DEVICE arrays (zkir_memcheck_witness_of computes them on the host: memory is a
  * sequential chain); scratch as zkir_main_trace_io_launch.  _host: host pointers everywhere, a test entry point. */
 int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,

@@ -287,6 +287,24 @@ BB_HD void int_round_w(int32_t& x, int64_t* w, const Consts& c, int r) {
 #pragma unroll
   for (int i = 1; i < T; i++) w[i] = (int64_t)(((uint64_t)w[i] << (i - 1)) + (uint64_t)sum);
 }
+// The bounds above, computed instead of asserted in prose: interval arithmetic over the eleven words through `rounds` rounds without a reduction, from words of at most
+// `start`; returns the largest magnitude any 64-bit value reaches (a word after its update, the sum, sum - 2 s0).  A Montgomery reduction adds m p with |m| <= 2^31 before
+// it shifts, so it needs |acc| < 2^63 - 2^31 p, for which 2^62 is enough; it returns at most |acc| / 2^32 + p / 2 + 1.
+constexpr uint64_t lazy_rounds_bound(uint64_t start, int rounds) {
+  uint64_t b[T] = {}, top = 0;
+  for (int i = 1; i < T; i++) b[i] = start;
+  for (int r = 0; r < rounds; r++) {
+    uint64_t sum = bb::P;                                      // |s0| < p
+    for (int i = 1; i < T; i++) sum += b[i];
+    if (sum + 2 * (uint64_t)bb::P > top) top = sum + 2 * (uint64_t)bb::P;
+    for (int i = 1; i < T; i++) { b[i] = sum + (b[i] << (i - 1)); if (b[i] > top) top = b[i]; }
+  }
+  return top;
+}
+constexpr uint64_t lazy_reduced_bound(uint64_t acc) { return (acc >> 32) + bb::P / 2 + 2; }
+static_assert(lazy_rounds_bound(1ull << 31, 3) < (1ull << 62), "three partial rounds on words below 2^31 stay inside what a Montgomery reduction takes");
+static_assert(lazy_reduced_bound(lazy_rounds_bound(1ull << 31, 3)) <= (1ull << 31), ".. and their reduction is a word below 2^31 again");
+static_assert(lazy_reduced_bound(lazy_rounds_bound(1ull << 31, 1) + bb::P) < bb::P, "the words leave the last round (one round + the next full round's constant) inside (-p, p)");
 BB_HD void int_rounds_scaled(uint32_t* s, const Consts& c) {   // in: unsigned words below p + 128, factor R; out: signed words in (-p, p), factor G, next round's constants added
   int32_t x = (int32_t)s[0] + c.in0_neg;
   int32_t t[T];
