@@ -7,6 +7,10 @@ words (so that a mismatch says roughly WHERE).  tests/test_gpu_large.py::test_pr
 
 What this pins: nothing outside this repository — the prover is self-defined (the reference has none): parity stays UNPINNED vs seceq/zkir.
 
+Also (`python tests/golden/make_config_proofs.py mode3 [log2_rows ...]`, default 14 16): the MODE-3 proof (memory argument, bitwise opcodes, shifts, MUL: 264 + 96 columns,
+the touched cells carried) of the memory-ring walk halted at 2^k cycles (1024 cells: every cell re-visited 4 / 16 times; 5 memory accesses and 3 bitwise opcodes per 16
+rows) — the large-size counterpart of tests/test_gpu_stark.py's small mode-3 programs; the program is encoded HERE from the reference's bit layout (encoding.rs:23-60).
+
 Does not import the product.  Run: python tests/golden/make_config_proofs.py [log2_rows ...]   (default 16 18 20)
 """
 import hashlib
@@ -20,10 +24,49 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
-from make_config_roots import FIB_ENDLESS  # noqa: E402  (the same program blob, own encoder)
+from make_config_roots import FIB_ENDLESS, blob, i_, j_, r_  # noqa: E402  (the same program blob, own encoder)
 from oracle import api as oracle, stark_api as so  # noqa: E402  (test infrastructure only)
 
 N_SAMPLES = 257
+
+ADD, ADDI, JAL, OR, XOR, ANDI, SLLI, LB, LHU, LW, LD, SD = 0x00, 0x08, 0x48, 0x11, 0x12, 0x13, 0x1B, 0x30, 0x33, 0x34, 0x35, 0x3B
+
+
+def s_(op, rs1, rs2, imm): return op | rs1 << 7 | rs2 << 11 | (imm & 0x1FFFF) << 15      # S-type: rs1 @7, rs2 @11
+def sh_(op, rd, rs1, sh): return op | rd << 7 | rs1 << 11 | (sh & 0xFF) << 15           # shift by immediate: shamt = bits 15..22
+
+
+def ring(log2_cells):
+    """An endless walk over a ring of 2^log2_cells 8-byte cells at 0x100000: LD, XOR with a counter, SD, read back as LW / LHU / LB, sum, OR into a flag register."""
+    mask = (8 << log2_cells) - 8
+    return blob([i_(ADDI, 6, 0, 0x8000), sh_(SLLI, 6, 6, 5), i_(ADDI, 1, 0, 0), i_(ADDI, 5, 0, 0), i_(ADDI, 4, 0, 0), i_(ADDI, 12, 0, 0),
+                 r_(ADD, 7, 6, 5), i_(LD, 2, 7, 0), r_(XOR, 2, 2, 1), s_(SD, 7, 2, 0), i_(LW, 8, 7, 0), i_(LHU, 9, 7, 2), i_(LB, 10, 7, 1),
+                 r_(ADD, 4, 4, 8), r_(ADD, 4, 4, 9), r_(ADD, 4, 4, 10), r_(OR, 12, 12, 4), i_(ADDI, 5, 5, 8), i_(ANDI, 5, 5, mask), i_(ADDI, 1, 1, 1), i_(ADDI, 13, 1, 0),
+                 j_(JAL, 0, -60)])
+
+
+RING = ring(10)
+
+
+def entry(proof, k, t0):
+    pos = sample_positions(len(proof))
+    return {"rows": 1 << k, "words": int(len(proof)), "sha256": hashlib.sha256(proof.tobytes()).hexdigest(), "samples": [int(proof[p]) for p in pos], "oracle_seconds": round(time.time() - t0, 1)}
+
+
+def main_mode3(ks):
+    path = os.path.join(HERE, "config_proofs.json")
+    for k in ks:
+        t0 = time.time()
+        res = oracle.run(RING, max_cycles=1 << k, enable_execution_trace=True)
+        pub = so.public_inputs(len(res.rows), RING, [], list(res.outputs), (res.halt_kind, res.halt_code), mem_mode=True)
+        proof = np.ascontiguousarray(so.prove(res.rows, pub), dtype="<u4")
+        assert so.verify(proof, pub) == 0 and int(proof[9]) == 3
+        e = entry(proof, k, t0)
+        print("mode3", k, e["words"], e["sha256"], e["oracle_seconds"], flush=True)
+        cur = json.load(open(path))
+        cur["ring_program_blob_hex"] = RING.hex()
+        cur.setdefault("mode3_ring_proofs", {})[str(k)] = e
+        json.dump(cur, open(path, "w"), indent=1)
 
 
 def sample_positions(n_words: int):
@@ -31,6 +74,8 @@ def sample_positions(n_words: int):
 
 
 def main():
+    if sys.argv[1:2] == ["mode3"]:
+        return main_mode3([int(a) for a in sys.argv[2:]] or [14, 16])
     ks = [int(a) for a in sys.argv[1:]] or [16, 18, 20]
     path = os.path.join(HERE, "config_proofs.json")
     out = json.load(open(path)) if os.path.exists(path) else {}

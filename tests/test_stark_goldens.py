@@ -125,5 +125,6 @@ def test_config_proof_fixture_is_the_oracles_proof():
     assert len(proof) == g["words"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
     pos = [int(i * (len(proof) - 1) // (len(g["samples"]) - 1)) for i in range(len(g["samples"]))]
     assert [int(proof[p]) for p in pos] == g["samples"]
-    for k, e in gold["proofs"].items():
+    for k, e in list(gold["proofs"].items()) + list(gold["mode3_ring_proofs"].items()):
         assert e["rows"] == 1 << int(k) and len(e["samples"]) == 257 and len(e["sha256"]) == 64
+    assert bytes.fromhex(gold["ring_program_blob_hex"]) == spec.memory_ring_program(10).to_bytes() and {"14", "16", "18"} <= set(gold["mode3_ring_proofs"])
