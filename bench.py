@@ -253,6 +253,9 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
                              # a wave runs 64 permutations, one per lane: wave instructions per second against one per 4.2 SIMD-cycles on 1024 SIMDs
                              "valu_wave_instr_per_s": perms / 64 * VALU_INSTR_PER_PERM / (ms * 1e-3), "alu_peak_analytic": ALU_PEAK_WAVE_INSTR_PER_S,
                              "frac_of_alu_peak": perms / 64 * VALU_INSTR_PER_PERM / (ms * 1e-3) / ALU_PEAK_WAVE_INSTR_PER_S}
+    if "merkle_levels" in kernels:                                # (the per-permutation instruction count is leaf_hash_kernel's: the levels' kernels — compress: the same
+        kernels["merkle_levels"]["alu_note"] = ("valu_wave_instr_per_s / frac_of_alu_peak use leaf_hash_kernel's instruction count per permutation; the upper levels run the "
+                                                "quad-of-lanes formulation (1,912 per lane, four lanes a permutation) and are latency-bound: nominal figures")
     for v in kernels.values():
         v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
         v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
