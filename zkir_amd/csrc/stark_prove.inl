@@ -752,26 +752,41 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const p2::Consts
   digests[4 * i + l] = bb::from_mont(s[0]);
 }
 
-// c'[i] = (c[i] + c[i+h])/2 + beta (c[i] - c[i+h]) / (2 x_i),  x_i = shift * w_m^i
-__global__ __launch_bounds__(NT) void fri_fold_kernel(const uint32_t* __restrict__ c, uint32_t log_m, uint32_t log_2n, const uint32_t* __restrict__ tw_fwd, E4 beta_m,
-                                                       uint32_t half_shift_inv_m, uint32_t* __restrict__ out) {
-  const uint64_t m = 1ull << log_m, h = m >> 1, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= h) return;
-  E4 a, b;
+// one binary fold of a layer of m values: c'[i] = (c[i] + c[i+h])/2 + beta (c[i] - c[i+h]) / (2 x_i),  x_i = shift * w_m^i,  h = m / 2;
+// w_m^-i = w_2N^-(i << (log_2n - log_m)), and w^-k = -w^(N-k) for 0 < k < N (w^N = -1): the table holds w^k for k < N = 2^(log_2n - 1)
+// The K binary folds between two committed layers in ONE launch (round 4: three launches and two intermediate layers before): output i of the last fold depends on the 2^K
+// values c[i + u g], g = m >> K, and fold f pairs v[u] with v[u + 2^(K-f-1)] — exactly the pairs (j, j + h_f) of a binary fold of the size-(m >> f) layer, the same field operations in
+// the same order on every value, so the layer is the one the chain of binary folds leaves.
+struct FoldParams { E4 beta_m[3]; uint32_t half_shift_inv_m[3]; };
+template <int K>
+__global__ __launch_bounds__(NT) void fri_fold_k_kernel(const uint32_t* __restrict__ c, uint32_t log_m, uint32_t log_2n, const uint32_t* __restrict__ tw_fwd, FoldParams fp, uint32_t* __restrict__ out) {
+  const uint64_t m = 1ull << log_m, g = m >> K, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= g) return;
+  E4 v[1 << K];
 #pragma unroll
-  for (int t = 0; t < 4; t++) { a.c[t] = c[(uint64_t)t * m + i]; b.c[t] = c[(uint64_t)t * m + h + i]; }
-  // w_m^-i = w_2N^-(i << (log_2n - log_m)) ; w^-k = -w^(N-k) for 0 < k < N (w^N = -1), table holds w^k for k < N = 2^(log_2n-1)
+  for (int u = 0; u < (1 << K); u++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[u].c[t] = c[(uint64_t)t * m + i + (uint64_t)u * g];
   const uint32_t N = 1u << (log_2n - 1);
-  const uint32_t k = (uint32_t)(i << (log_2n - log_m));
-  const uint32_t winv = k == 0 ? bb::R1 : bb::neg(tw_fwd[N - k]);
-  const uint32_t inv2x = bb::mont_mul(winv, half_shift_inv_m);                 // 1/(2 x_i), Montgomery
   constexpr uint32_t HALF_M = (uint32_t)(((uint64_t)((bb::P + 1) / 2) * bb::R1) % bb::P);
-  const E4 sum = bb::e_mul_fm(bb::e_add(a, b), HALF_M);                        // canonical * mont = canonical
-  const E4 dif = bb::e_mul_fm(bb::e_sub(a, b), inv2x);                         // canonical
-  const E4 prod = bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(dif), beta_m));    // mont(dif) * mont(beta) = mont(dif * beta) -> canonical
-  const E4 res = bb::e_add(sum, prod);
 #pragma unroll
-  for (int t = 0; t < 4; t++) out[(uint64_t)t * h + i] = res.c[t];
+  for (int f = 0; f < K; f++) {
+    const int cnt = 1 << (K - f - 1);
+#pragma unroll
+    for (int u = 0; u < cnt; u++) {
+      const uint64_t j = i + (uint64_t)u * g;                                  // position in the half of the size-(m >> f) domain
+      const uint32_t k = (uint32_t)(j << (log_2n - (log_m - f)));
+      const uint32_t winv = k == 0 ? bb::R1 : bb::neg(tw_fwd[N - k]);
+      const uint32_t inv2x = bb::mont_mul(winv, fp.half_shift_inv_m[f]);
+      const E4 a = v[u], b = v[u + cnt];
+      const E4 sum = bb::e_mul_fm(bb::e_add(a, b), HALF_M);
+      const E4 dif = bb::e_mul_fm(bb::e_sub(a, b), inv2x);
+      const E4 prod = bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(dif), fp.beta_m[f]));
+      v[u] = bb::e_add(sum, prod);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) out[(uint64_t)t * g + i] = v[0].c[t];
 }
 
 // ---- query gathering: job = copy `count` words src[k * stride] -> dst[k] ------------------------------------------------------
@@ -1279,18 +1294,20 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       ch.observe_n(lroots[j].data(), 4);
       betas[j] = ch.sample_ext();
       E4 beta = betas[j];
-      const uint32_t* src = fri_layers[j];
-      for (int f = 0; f < k; f++, log_m--) {                                   // k binary folds: beta^(2^f), shift^(2^f)
-        const uint64_t h = (1ull << log_m) >> 1;
-        uint32_t* dst;
-        HIP_OK(ar.take(&dst, 4 * h));
-        const uint32_t half_shift_inv_m = bb::to_mont(bb::inv(bb::mul(2, shift)));
-        hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(h)), dim3(NT), 0, s, src, (uint32_t)log_m, log_n + 1, c->d_tw_fwd, bb::e_to_mont(beta), half_shift_inv_m, dst);
-        src = dst;
-        if (f == k - 1) fri_layers[j + 1] = dst;
+      FoldParams fp{};                                                         // k binary folds: beta^(2^f), shift^(2^f) — one launch for all of them
+      for (int f = 0; f < k; f++) {
+        fp.beta_m[f] = bb::e_to_mont(beta);
+        fp.half_shift_inv_m[f] = bb::to_mont(bb::inv(bb::mul(2, shift)));
         shift = bb::mul(shift, shift);
         beta = h_e_mul(beta, beta);
       }
+      uint32_t* dst;
+      HIP_OK(ar.take(&dst, 4 * g));
+      if (k == 1) hipLaunchKernelGGL(fri_fold_k_kernel<1>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dst);
+      else if (k == 2) hipLaunchKernelGGL(fri_fold_k_kernel<2>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dst);
+      else hipLaunchKernelGGL(fri_fold_k_kernel<3>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dst);
+      fri_layers[j + 1] = dst;
+      log_m -= k;
     }
   }
   const uint64_t fin_n = 1ull << LOG_FINAL;
