@@ -347,15 +347,19 @@ BB_HD void permute_scaled(uint32_t* s, const Consts& c) {
 // how few lanes are busy — and the upper Merkle levels / small FRI layers keep only a few lanes busy.  Here lane l of an aligned
 // quad holds state words l, 4 + l, 8 + l (column l of the three M4 blocks): the S-box layer is 3 chains per lane instead of 12, the
 // M4 products take the block's four words through DPP quad broadcasts (row l of M4 as per-lane multipliers), the column sums stay
-// inside a lane, and the partial-round sum is a 2-step quad butterfly.  ~1800 instructions per lane.  All four lanes of a quad must
-// be active.  Same function, same bounds as permute(); which words a lane keeps lazy differs, the canonical results do not.
+// inside a lane, and the partial-round sum is a 2-step quad butterfly.  1,585 instructions per lane (round 3, in permute()'s arithmetic: 1,912).  All four lanes of a
+// quad must be active.  Same function as permute() / permute_scaled(); the canonical results do not depend on the formulation.
 template <int CTRL>
 __device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
 template <int CTRL>
 __device__ __forceinline__ uint64_t quad_perm64(uint64_t v) { return ((uint64_t)quad_perm<CTRL>((uint32_t)(v >> 32)) << 32) | quad_perm<CTRL>((uint32_t)v); }
 
+// ---- the quad formulation runs the arithmetic of permute_scaled() (round 4; rounds 2-3 ran permute()'s: 1,912 instructions per lane) — wide Montgomery reductions (2
+// instructions) instead of Barrett ones (6), signed S-boxes without corrections, and the partial rounds' passive words as 64-bit lazy integers reduced every
+// third round (int_rounds_scaled above: here every lane keeps three of them and its own copy of word 0, whose S-box all four lanes run; the sum crosses the quad in two DPP
+// steps).  Same Consts, same factors: words enter with F_IN (mont_mul_lazy(x, in_scale) / mont_mul_lazy(previous output, carry)) and leave with F_OUT.
 template <bool ADD_RC>
-__device__ __forceinline__ void ext_linear_quad(uint32_t* s, const uint32_t* m4row, const uint32_t* rc) {
+__device__ __forceinline__ void ext_linear_quad_scaled(uint32_t* s, const uint32_t* m4row, const uint32_t* rc) {
   uint64_t y[3];
 #pragma unroll
   for (int b = 0; b < 3; b++) {
@@ -367,37 +371,56 @@ __device__ __forceinline__ void ext_linear_quad(uint32_t* s, const uint32_t* m4r
   for (int b = 0; b < 3; b++) {
     uint64_t v = y[b] + sum;
     if (ADD_RC) v += rc[b];
-    s[b] = bb::reduce_wide<6>(v);
+    s[b] = bb::mont_reduce_wide(v);
   }
 }
-// s[b] = state word 4 b + l of the quad's permutation, l = lane & 3; Montgomery form, canonical in and out
-__device__ __forceinline__ void permute_quad(uint32_t* s, int l, const Consts& c) {
+// mask0: all ones, but zero in lane 0 — its first slot is word 0 itself, not a passive word, and stays 0 ((0 << k) + (sum & 0); a select would be a v_cndmask: 20 SIMD-cycles)
+__device__ __forceinline__ void int_round_quad(int32_t& x, int64_t* w, uint64_t mask0, const int* k, const Consts& c, int r) {
+  const int32_t s0 = sbox_signed(x);
+  uint64_t acc = (uint64_t)w[0] + (uint64_t)w[1] + (uint64_t)w[2];
+  acc += quad_perm64<0xB1>(acc);
+  acc += quad_perm64<0x4E>(acc);                                // every lane: the sum of the eleven passive words
+  const int64_t sum = bb::sacc_add((int64_t)acc, s0);
+  x = int_next_x(smad<-2>(sum, s0), c, r);
+  w[0] = (int64_t)(((uint64_t)w[0] << k[0]) + ((uint64_t)sum & mask0));
+  w[1] = (int64_t)(((uint64_t)w[1] << k[1]) + (uint64_t)sum);
+  w[2] = (int64_t)(((uint64_t)w[2] << k[2]) + (uint64_t)sum);
+}
+// s[b] = state word 4 b + l of the quad's permutation, l = lane & 3
+__device__ __forceinline__ void permute_quad_scaled(uint32_t* s, int l, const Consts& c) {
   const uint32_t packed = l == 0 ? 0x03010705u : l == 1 ? 0x01010604u : l == 2 ? 0x07050301u : 0x06040101u;   // row l of M4, one byte per entry
   const uint32_t m4row[4] = {packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF, packed >> 24};
-  const uint32_t diag[3] = {c.diag[l], c.diag[4 + l], c.diag[8 + l]};
-  { const uint32_t rc[3] = {c.ext[0][l], c.ext[0][4 + l], c.ext[0][8 + l]}; ext_linear_quad<true>(s, m4row, rc); }
+  { const uint32_t rc[3] = {c.ext0_s[l], c.ext0_s[4 + l], c.ext0_s[8 + l]}; ext_linear_quad_scaled<true>(s, m4row, rc); }
 #pragma unroll 1
-  for (int r = 0; r < RF; r++) {
-    if (r == RF / 2) {
-#pragma unroll 1
-      for (int q = 0; q < RP; q++) {
-        const uint32_t sb = sbox(bb::add(s[0], c.in[q]));                    // meaningful in lane 0 only (word 0)
-        const uint32_t s0 = l == 0 ? sb : s[0];
-        uint64_t acc = bb::acc_add(bb::acc_add((uint64_t)s0, s[1]), s[2]);
-        acc += quad_perm64<0xB1>(acc);                                       // lanes (1,0,3,2)
-        acc += quad_perm64<0x4E>(acc);                                       // lanes (2,3,0,1): every lane now holds the sum of all 12 words
-        const uint32_t sum_r = bb::mont_mul_lazy(bb::reduce_wide<4>(acc), bb::R2);
-        s[0] = bb::reduce_2p(bb::mont_mul_add_lazy(s0, diag[0], sum_r));     // word 0 must be canonical for the next S-box (diag[0] = -2)
-        s[1] = bb::mont_mul_add_lazy(s[1], diag[1], sum_r);
-        s[2] = bb::mont_mul_add_lazy(s[2], diag[2], sum_r);
-      }
-      s[1] = bb::reduce_2p(s[1]); s[2] = bb::reduce_2p(s[2]);
+  for (int r = 0; r < RF / 2; r++) {
 #pragma unroll
-      for (int b = 0; b < 3; b++) s[b] = bb::add(s[b], c.ext[RF / 2][4 * b + l]);
+    for (int b = 0; b < 3; b++) { uint32_t v = s[b]; asm("" : "+v"(v)); s[b] = sbox_biased(v, c.pre_b[r][4 * b + l]); }   // (opaque: LLVM otherwise proves a sign here and trades v_mad_i64_i32 for an unsigned product + corrections: 108 instructions a round instead of 75)
+    ext_linear_quad_scaled<false>(s, m4row, nullptr);
+  }
+  {
+    int32_t x = (int32_t)quad_perm<0x00>(s[0]) + c.in0_neg;
+    int64_t w[3] = {l == 0 ? 0 : (int64_t)(int32_t)s[0], (int64_t)(int32_t)s[1], (int64_t)(int32_t)s[2]};
+    const int k[3] = {l == 0 ? 0 : l - 1, 3 + l, 7 + l};       // word i is multiplied by 2^(i - 1)
+    uint64_t mask0 = l == 0 ? 0ull : ~0ull;
+    asm("" : "+v"(mask0));                                // (opaque: an AND with a visible 0 / ~0 select comes back as the v_cndmask it is meant to avoid)
+#pragma unroll 1
+    for (int r = 0; r < RP - 1; r += 3) {
+      int_round_quad(x, w, mask0, k, c, r);
+      int_round_quad(x, w, mask0, k, c, r + 1);
+      int_round_quad(x, w, mask0, k, c, r + 2);
+#pragma unroll
+      for (int b = 0; b < 3; b++) w[b] = (int64_t)bb::smont_reduce_wide(w[b]);
     }
+    int_round_quad(x, w, mask0, k, c, RP - 1);
 #pragma unroll
-    for (int b = 0; b < 3; b++) s[b] = sbox_lazy(s[b], c.pre[r][4 * b + l]);
-    ext_linear_quad<false>(s, m4row, nullptr);
+    for (int b = 0; b < 3; b++) s[b] = (uint32_t)bb::smont_reduce_wide((int64_t)((uint64_t)w[b] + c.pr_k[4 * b + l]));
+    if (l == 0) s[0] = (uint32_t)x;
+  }
+#pragma unroll 1
+  for (int r = RF / 2; r < RF; r++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) s[b] = sbox_biased(s[b], c.pre_b[r][4 * b + l]);
+    ext_linear_quad_scaled<false>(s, m4row, nullptr);
   }
 }
 #endif

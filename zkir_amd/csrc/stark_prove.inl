@@ -745,11 +745,13 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const p2::Consts
   const int l = (int)(t & 3);
   if (i >= g) return;                                                         // whole quads leave together
   uint32_t s[3] = {0, 0, 0};
+  const uint32_t k_in = cp->in_scale, carry = cp->carry;
   for (uint32_t u = 0; u < (1u << k); u += 2) {
-    s[0] = bb::to_mont(c[(uint64_t)l * m + i + u * g]); s[1] = bb::to_mont(c[(uint64_t)l * m + i + (u + 1) * g]);
-    p2::permute_quad(s, l, *cp);
+    s[0] = bb::mont_mul_lazy(c[(uint64_t)l * m + i + u * g], k_in); s[1] = bb::mont_mul_lazy(c[(uint64_t)l * m + i + (u + 1) * g], k_in);
+    s[2] = bb::mont_mul_lazy(s[2], carry);                                     // the capacity words stay: output factor -> input factor
+    p2::permute_quad_scaled(s, l, *cp);
   }
-  digests[4 * i + l] = bb::from_mont(s[0]);
+  digests[4 * i + l] = bb::mont_mul(s[0], cp->out_scale);
 }
 
 // one binary fold of a layer of m values: c'[i] = (c[i] + c[i+h])/2 + beta (c[i] - c[i+h]) / (2 x_i),  x_i = shift * w_m^i,  h = m / 2;
