@@ -333,13 +333,16 @@ __global__ __launch_bounds__(64) void section_hash_kernel(const p2::Consts* __re
   uint32_t st[p2::T];
 #pragma unroll
   for (int i = 0; i < p2::T; i++) st[i] = 0;
+  const uint32_t k_in = cp->in_scale, carry = cp->carry, ko = cp->out_scale;    // the throughput formulation (p2::permute_scaled), as leaf_hash_kernel runs the sponge
   for (uint64_t off = 0; off < len; off += p2::RATE) {
 #pragma unroll
-    for (int i = 0; i < p2::RATE; i++) if (off + i < len) st[i] = bb::to_mont(w[at + off + i]);
-    p2::permute(st, *cp);
+    for (int i = 0; i < p2::RATE; i++) st[i] = off + i < len ? bb::mont_mul_lazy(w[at + off + i], k_in) : bb::mont_mul_lazy(st[i], carry);
+#pragma unroll
+    for (int i = p2::RATE; i < p2::T; i++) st[i] = bb::mont_mul_lazy(st[i], carry);
+    p2::permute_scaled(st, *cp);
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) digests[4 * c + i] = bb::from_mont(st[i]);
+  for (int i = 0; i < 4; i++) digests[4 * c + i] = bb::mont_mul(st[i], ko);
 }
 // (mode 3) the two ends of the memory check, the VERIFIER's share of the table side, formed on the device: per touched cell + 1 / (alpha - fp(cell, time 0, the program image's
 // bytes)) - 1 / (alpha - fp(cell, final time, final bytes)), summed per workgroup (the host adds the partial sums).  image = the program's code + data bytes (loaded at 0x1000).
@@ -806,11 +809,12 @@ __global__ __launch_bounds__(NT) void pow_grind_kernel(const p2::Consts* __restr
   const uint32_t nonce = base + blockIdx.x * NT + threadIdx.x;
   if (nonce >= bb::P) return;
   uint32_t s[p2::T];
+  const uint32_t k_in = bb::from_mont(cp->in_scale);                          // Montgomery words R v -> input words F_IN v of the throughput formulation (a fifth fewer instructions)
 #pragma unroll
-  for (int i = 0; i < p2::T; i++) s[i] = state_m[i];
-  s[0] = bb::to_mont(nonce);                                                  // overwrite-absorb of the single pending element
-  p2::permute(s, *cp);
-  if ((bb::from_mont(s[p2::RATE - 1]) & ((1u << POW_BITS) - 1)) == 0) atomicMin(best, nonce);   // sample() takes the last rate element
+  for (int i = 1; i < p2::T; i++) s[i] = bb::mont_mul_lazy(state_m[i], k_in);
+  s[0] = bb::mont_mul_lazy(nonce, cp->in_scale);                              // overwrite-absorb of the single pending element (canonical)
+  p2::permute_scaled(s, *cp);
+  if ((bb::mont_mul(s[p2::RATE - 1], cp->out_scale) & ((1u << POW_BITS) - 1)) == 0) atomicMin(best, nonce);   // sample() takes the last rate element
 }
 
 // ---- host-side duplex challenger (Montgomery state; canonical in/out) -------------------------------------------------------
