@@ -401,10 +401,18 @@ __global__ __launch_bounds__(NT) void io_scan_local_kernel(zkir_trace_columns t,
   for (int k = 0; k < 4; k++) if (base + k < N) cnt[base + k] = make_uint2(v[k].x + ex.x, v[k].y + ex.y);
   if (threadIdx.x == NT - 1) sums[blockIdx.x] = lds[NT - 1];
 }
-__global__ void io_scan_sums_kernel(uint2* __restrict__ sums, uint32_t n) {       // one lane: n = N / 1024 block totals (<= 65536)
-  if (threadIdx.x || blockIdx.x) return;
+// exclusive scan of the n = N / 1024 block totals (<= 65536), one workgroup: every lane sums its contiguous share, takes the totals of the lanes before it from LDS and
+// writes its share's prefixes (one lane walking all of them took 118 us at 2^20 rows: a tenth of a mode-2 proof's main-trace stage)
+__global__ __launch_bounds__(NT) void io_scan_sums_kernel(uint2* __restrict__ sums, uint32_t n) {
+  __shared__ uint2 tot[NT];
+  const uint32_t per = (n + NT - 1) / NT, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint2 a = make_uint2(0, 0);
+  for (uint32_t b = lo; b < hi; b++) { const uint2 v = sums[b]; a.x += v.x; a.y += v.y; }
+  tot[threadIdx.x] = a;
+  __syncthreads();
   uint2 run = make_uint2(0, 0);
-  for (uint32_t b = 0; b < n; b++) { const uint2 v = sums[b]; sums[b] = run; run.x += v.x; run.y += v.y; }
+  for (uint32_t j = 0; j < threadIdx.x; j++) { run.x += tot[j].x; run.y += tot[j].y; }
+  for (uint32_t b = lo; b < hi; b++) { const uint2 v = sums[b]; sums[b] = run; run.x += v.x; run.y += v.y; }
 }
 __global__ __launch_bounds__(NT) void io_scan_add_kernel(uint2* __restrict__ cnt, uint64_t N, const uint2* __restrict__ sums) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
@@ -722,7 +730,7 @@ int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, 
   uint2* sums = cnt + N;
   const uint32_t n_blk = (uint32_t)((N + IOS_ROWS - 1) / IOS_ROWS);
   hipLaunchKernelGGL(io_scan_local_kernel, dim3(n_blk), dim3(NT), 0, s, *trace, n_real, N, cnt, sums);
-  hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(64), 0, s, sums, n_blk);
+  hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(NT), 0, s, sums, n_blk);
   hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
   hipLaunchKernelGGL(main_trace_kernel<2>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
                      IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt)});
@@ -738,7 +746,7 @@ int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real,
   uint2* sums = cnt + N;
   const uint32_t n_blk = (uint32_t)((N + IOS_ROWS - 1) / IOS_ROWS);
   hipLaunchKernelGGL(io_scan_local_kernel, dim3(n_blk), dim3(NT), 0, s, *trace, n_real, N, cnt, sums);
-  hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(64), 0, s, sums, n_blk);
+  hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(NT), 0, s, sums, n_blk);
   hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
   hipLaunchKernelGGL(main_trace_kernel<3>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
                      IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt), mem_old, mem_told});

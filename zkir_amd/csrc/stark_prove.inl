@@ -323,26 +323,25 @@ __global__ __launch_bounds__(NT) void mem_tables_kernel(const ProveParams* __res
   d.c[0] = bb::sub(d.c[0], bb::to_mont(v));
   inv_mem[t] = bb::e_inv_m(d);
 }
-// (mode 3) the chunk digests of a long proof section (so::observe_section: chunks of 512 words, each hashed on its own with the rate-8 overwrite sponge, so::hash_elems): one
-// lane per chunk, 64 sequential permutations each — on the host the touched-cell list of a memory-heavy run (seven words per cell) cost more than the rest of the proof
+// (mode 3) the chunk digests of a long proof section (so::observe_section: chunks of 512 words, each hashed on its own with the rate-8 overwrite sponge, so::hash_elems): a
+// quad of lanes per chunk, 64 sequential permutations each — on the host the touched-cell list of a memory-heavy run (seven words per cell) cost more than the rest of the proof
 constexpr uint32_t SECTION_CHUNK = 512;
 __global__ __launch_bounds__(64) void section_hash_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ w, uint64_t n_words, uint32_t* __restrict__ digests) {
-  const uint64_t c = (uint64_t)blockIdx.x * 64 + threadIdx.x, at = c * SECTION_CHUNK;
-  if (at >= n_words) return;
+  // a QUAD of lanes per chunk (p2::permute_quad_scaled: the 64 permutations of a chunk are sequential and a section has few chunks — latency, not throughput): lane l
+  // holds words l and 4 + l of the rate and capacity word 8 + l
+  const uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x, c = t >> 2, at = c * SECTION_CHUNK;
+  const int l = (int)(t & 3);
+  if (at >= n_words) return;                                                  // whole quads leave together
   const uint64_t len = n_words - at < SECTION_CHUNK ? n_words - at : SECTION_CHUNK;
-  uint32_t st[p2::T];
-#pragma unroll
-  for (int i = 0; i < p2::T; i++) st[i] = 0;
-  const uint32_t k_in = cp->in_scale, carry = cp->carry, ko = cp->out_scale;    // the throughput formulation (p2::permute_scaled), as leaf_hash_kernel runs the sponge
-  for (uint64_t off = 0; off < len; off += p2::RATE) {
-#pragma unroll
-    for (int i = 0; i < p2::RATE; i++) st[i] = off + i < len ? bb::mont_mul_lazy(w[at + off + i], k_in) : bb::mont_mul_lazy(st[i], carry);
-#pragma unroll
-    for (int i = p2::RATE; i < p2::T; i++) st[i] = bb::mont_mul_lazy(st[i], carry);
-    p2::permute_scaled(st, *cp);
+  uint32_t st[3] = {0, 0, 0};
+  const uint32_t k_in = cp->in_scale, carry = cp->carry;
+  for (uint64_t off = 0; off < len; off += p2::RATE) {                        // (a word the ragged last block does not overwrite stays: so::hash_elems)
+    st[0] = off + l < len ? bb::mont_mul_lazy(w[at + off + l], k_in) : bb::mont_mul_lazy(st[0], carry);
+    st[1] = off + 4 + l < len ? bb::mont_mul_lazy(w[at + off + 4 + l], k_in) : bb::mont_mul_lazy(st[1], carry);
+    st[2] = bb::mont_mul_lazy(st[2], carry);
+    p2::permute_quad_scaled(st, l, *cp);
   }
-#pragma unroll
-  for (int i = 0; i < 4; i++) digests[4 * c + i] = bb::mont_mul(st[i], ko);
+  digests[4 * c + l] = bb::mont_mul(st[0], cp->out_scale);
 }
 // (mode 3) the two ends of the memory check, the VERIFIER's share of the table side, formed on the device: per touched cell + 1 / (alpha - fp(cell, time 0, the program image's
 // bytes)) - 1 / (alpha - fp(cell, final time, final bytes)), summed per workgroup (the host adds the partial sums).  image = the program's code + data bytes (loaded at 0x1000).
@@ -1106,7 +1105,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     if (mem_sec.size() + 4 * n_chunks_sec + 64 > 8 * (size_t)N + 4096) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than the workspace holds"}); return ZKIR_ERR_ARGUMENT; }
     uint32_t* dSecDg = dSec + ((mem_sec.size() + 63) & ~(size_t)63);
     HIP_OK(h2d(dSec, mem_sec.data(), mem_sec.size() * 4));
-    hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)mem_sec.size(), dSecDg);
+    hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((4 * n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)mem_sec.size(), dSecDg);
     std::vector<uint32_t> sec_dg(4 * n_chunks_sec);
     HIP_OK(hipMemcpyAsync(sec_dg.data(), dSecDg, sec_dg.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
