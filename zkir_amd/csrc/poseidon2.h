@@ -18,8 +18,8 @@
 //     The full rounds add the NEXT round's constants pulled back through the linear layer that way (pre[r] = M_ext^-1 * ext[r + 1],
 //     computed once by generate());
 //   * (round 4) the partial rounds' eleven passive words as 64-bit lazy integers, updated by a shift and an add — the diagonal is
-//     (1, 2, 4, .., 1024) — and Montgomery-reduced every third round only (int_rounds_scaled: 173 vector instructions per three rounds
-//     against 207; the leaf hash 3.77 -> 3.48 ms at 152 x 2^21).
+//     (1, 2, 4, .., 1024) — and Montgomery-reduced every third round only (int_rounds_scaled: 159 vector instructions per three rounds
+//     against 207; the leaf hash 3.77 -> 3.36 ms at 152 x 2^21).
 #pragma once
 #include "babybear.h"
 
