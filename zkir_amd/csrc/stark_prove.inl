@@ -674,6 +674,15 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
   }
 }
 
+// the chunks' partial sums of a column, added up on the device: 2 (WT + 4) extension elements cross to the host instead of 2 (WT + 4) n_chunks (400 KB at 64 chunks)
+__global__ __launch_bounds__(NT) void bary_sum_kernel(const E4* __restrict__ partial, uint32_t n_cols2, uint32_t n_chunks, E4* __restrict__ out) {
+  const uint32_t idx = blockIdx.x * NT + threadIdx.x;           // 2 k + which
+  if (idx >= n_cols2) return;
+  E4 a = bb::e_zero();
+  for (uint32_t q = 0; q < n_chunks; q++) a = bb::e_add(a, partial[((uint64_t)(idx >> 1) * n_chunks + q) * 2 + (idx & 1)]);
+  out[idx] = a;
+}
+
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
 // A = Σ gamma^k v_k, B = Σ gamma^(WT + k) v_k over the columns of a position (Montgomery words x Montgomery gamma powers): exact 96-bit sums
 // per extension coordinate (bb::mad96_s, gamma^k in scalar registers), reduced once — the reduction's division by R leaves R A, R B.
@@ -1002,7 +1011,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest, *dBound, *dA, *dAL, *dATree, *dCode, *dMult;
   unsigned long long* dBad;
   uint4 *dSide, *dSums;
-  E4 *dW, *dDinv, *dPart, *dInvRc, *dInvRom;
+  E4 *dW, *dDinv, *dPart, *dPartSum, *dInvRc, *dInvRom;
   ProveParams* dPP;
   IoEntry* dIo = nullptr; uint32_t* dIoCount = nullptr; uint64_t* dInputs = nullptr; uint32_t* dIoScratch = nullptr;
   uint64_t* dMemOld = nullptr; uint32_t* dMemTold = nullptr; uint4* dMemSide = nullptr; E4* dInvMem = nullptr;
@@ -1022,7 +1031,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   HIP_OK(ar.take(&dInvRc, air::RC_TABLE)); HIP_OK(ar.take(&dInvRom, (size_t)n_code + 1));
   HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
-  HIP_OK(ar.take(&dPart, (size_t)(WT + 4) * n_chunks * 2));
+  HIP_OK(ar.take(&dPart, (size_t)(WT + 4) * n_chunks * 2)); HIP_OK(ar.take(&dPartSum, (size_t)(WT + 4) * 2));
   std::vector<uint32_t*> fri_trees(n_layers), fri_layers(n_layers + 1);
 
   StageEvents se;
@@ -1235,8 +1244,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WM + 3) / 4), dim3(NT), 0, s, dL, N2, (uint32_t)WM, dW, dPart, n_chunks, 2u);
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WA + 3) / 4), dim3(NT), 0, s, dAL, N2, (uint32_t)WA, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks, 2u);
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WT * n_chunks * 2, n_chunks, 1u);
-  std::vector<E4> part((size_t)(WT + 4) * n_chunks * 2);
-  HIP_OK(hipMemcpyAsync(part.data(), dPart, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(bary_sum_kernel, dim3(grid_for((uint64_t)(WT + 4) * 2)), dim3(NT), 0, s, dPart, (uint32_t)(WT + 4) * 2, n_chunks, dPartSum);
+  std::vector<E4> part((size_t)(WT + 4) * 2);
+  HIP_OK(hipMemcpyAsync(part.data(), dPartSum, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   std::vector<E4> t_z(WT), t_zw(WT), q_z(4);
   {
@@ -1249,8 +1259,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     const uint32_t inv2n = bb::inv((uint32_t)(N2 % bb::P)), invn = bb::inv((uint32_t)((N2 / 2) % bb::P));
     for (int t = 0; t < 4; t++) { sc.c[t] = bb::mul(sc.c[t], inv2n); sc_half.c[t] = bb::mul(sc_half.c[t], invn); }
     for (int k = 0; k < WT + 4; k++) {
-      E4 a = bb::e_zero(), b = bb::e_zero();
-      for (uint32_t q = 0; q < n_chunks; q++) { a = bb::e_add(a, part[((size_t)k * n_chunks + q) * 2]); b = bb::e_add(b, part[((size_t)k * n_chunks + q) * 2 + 1]); }
+      const E4 a = part[2 * (size_t)k], b = part[2 * (size_t)k + 1];
       const E4& sk = k < WT ? sc_half : sc;                                                                   // (trace columns: the even half; the quotient: the whole coset)
       const E4 va = bb::e_mul_m(a, sk), vb = bb::e_mul_m(b, sk);                                              // Montgomery partial sums x canonical scale = canonical
       if (k < WT) { t_z[k] = va; t_zw[k] = vb; } else q_z[k - WT] = va;
@@ -1264,13 +1273,15 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   // ---- 4. DEEP codeword ------------------------------------------------------------------------------------------------------
   {
-    E4 g{{1, 0, 0, 0}}, a0 = bb::e_zero(), b0 = bb::e_zero();
+    // (the powers run in Montgomery form: Montgomery x canonical = canonical, Montgomery x Montgomery = Montgomery — two products a step and no conversions; the GPU waits for this loop)
+    E4 g = bb::e_to_mont(bb::E4{{1, 0, 0, 0}}), a0 = bb::e_zero(), b0 = bb::e_zero();
+    const E4 gamma_m = bb::e_to_mont(gamma);
     for (int k = 0; k < 2 * WT + 4; k++) {
-      pp->gamma_pow[k] = bb::e_to_mont(g);
-      if (k < WT) a0 = bb::e_add(a0, h_e_mul(g, t_z[k]));
-      else if (k < 2 * WT) b0 = bb::e_add(b0, h_e_mul(g, t_zw[k - WT]));
-      else a0 = bb::e_add(a0, h_e_mul(g, q_z[k - 2 * WT]));
-      g = h_e_mul(g, gamma);
+      pp->gamma_pow[k] = g;
+      if (k < WT) a0 = bb::e_add(a0, bb::e_mul_m(g, t_z[k]));
+      else if (k < 2 * WT) b0 = bb::e_add(b0, bb::e_mul_m(g, t_zw[k - WT]));
+      else a0 = bb::e_add(a0, bb::e_mul_m(g, q_z[k - 2 * WT]));
+      g = bb::e_mul_m(g, gamma_m);
     }
     pp->a0 = bb::e_to_mont(a0); pp->b0 = bb::e_to_mont(b0);
     HIP_OK(hipMemcpyAsync(dPP->gamma_pow, pp->gamma_pow, sizeof(pp->gamma_pow), hipMemcpyHostToDevice, s));
