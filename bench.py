@@ -39,19 +39,14 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 # an add, no product — round 3 spent 13 products per partial round) x 22 + the 12 products that bring 8 absorbed values and the 4 carried capacity
 # words to the input factor
 MONT_MUL_PER_PERM = 4 * (8 * 12 + 22) + 22 + 12
-# vector instructions of one permutation in leaf_hash_kernel, absorption included: SQ_INSTS_VALU of a launch / its 622,592 wave-permutations
-# (profiles/r04zz_bench_commit_valu_busy.txt: 3,235.5; round 3: 3,729) — what the kernel's time is made of
-VALU_INSTR_PER_PERM = 3236
 PROVE_STAGES = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient_and_merkle", "openings", "deep", "fri", "queries"]
-# The integer-ALU roofline of the Poseidon2 kernels, ANALYTIC (a fixed denominator): a Montgomery product is three
-# multiplier-class wave instructions (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32), each of which issues in 4.2 SIMD-cycles per wave64 on
-# gfx950 (profiles/r02_ubench_alu.txt: v_mul_lo 4.21, v_mul_hi 4.09, v_mad_u64_u32 4.48); the chip has 256 CUs x 4 SIMDs at 2.4 GHz:
-#     1024 SIMDs x 2.4e9 cycles/s x 64 lanes / (3 instructions x 4.2 cycles) = 1.248e13 products/s
-ALU_PEAK_FORMULA = "1024 SIMDs x 2.4e9 Hz x 64 lanes / (3 multiplier-class instructions x 4.2 SIMD-cycles per wave64 instruction)"
-ALU_PEAK_MONT_MUL_PER_S = 1024 * 2.4e9 * 64 / (3 * 4.2)
-# .. and the same roofline in the unit the kernel's time is really made of since round 4 (fewer products, the rest shifts / 64-bit adds / reductions at the same
-# issue cost): one wave64 vector instruction per 4.2 SIMD-cycles
-ALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.2
+# The integer-ALU bound of the Poseidon2 kernels: sum over instruction classes n_i c_i.  A SIMD has 16 lanes, so a wave64 vector
+# instruction occupies it for c = 4 cycles; the full-rate 32-bit set (v_mov / v_add_u32 / v_and ...: scripts/isa_hist.py FULL_RATE) for c = 2 — the
+# ratios profiles/r02_ubench_alu.txt measured (4.1-4.5 against 2.2-2.4 at a nominal 2.4 GHz).  n_i = the kernel's instruction mix from the committed ISA
+# histogram of the shipped code object (profiles/r*_isa_hist.json, scripts/isa_hist.py) scaled to the DYNAMIC count SQ_INSTS_VALU of the committed
+# counter pass (profiles/r*_bench_commit_valu_busy.txt).  The c_i are lower bounds of every measured cost, so achieved / peak <= 1 by construction.
+SIMDS, PEAK_CLOCK_HZ = 256 * 4, 2.4e9
+MAX_LINE_BYTES = 12_000       # the driver parses ONE line; round 4's grew to 26.8 KB and was not parsed: tests/test_bench_line.py holds this
 
 
 def _fri_schedule(k):
@@ -144,43 +139,69 @@ def _profiled_traffic(stage: str):
     return total, os.path.relpath(files[-1], ROOT)
 
 
-def _profiled_clock_ghz(kernel: str):
-    """Shader clock (GHz) `kernel` ran at in the newest committed counter pass: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / its duration."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_commit_valu_busy.txt")), reverse=True):
-        for line in open(path):
-            if line.startswith(kernel):
-                f = line.split()
-                try:
-                    return float(f[-3]) / 8 / (float(f[-6]) * 1e-6) / 1e9      # columns: .. avg_us, SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, VALUBusy, ipc
-                except (ValueError, IndexError, ZeroDivisionError):
-                    return None
-    return None
-
-
 def _check_traffic_source_is_fresh(path: str):
-    """The committed counter file `roofline.traffic` is read from must be at least as new as the last commit that touched the kernels it describes: compared
-    through git when the repository is there (it is not on the GPU box: then the check is skipped and says so)."""
-    import subprocess
+    """"fresh" when the committed counter file was measured at THIS build's kernel sources: the extract scripts write zkir_amd.build.sources_sha16() into the
+    files they make (no git needed: the GPU box has none)."""
+    from zkir_amd.build import sources_sha16
     try:
-        t_prof = int(subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--", path], stderr=subprocess.DEVNULL).strip() or 0)
-        t_kern = int(subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--", "zkir_amd/csrc/stark.hip", "zkir_amd/csrc/poseidon2.h", "zkir_amd/csrc/ntt.hip",
-                                              "zkir_amd/csrc/trace_fill.hip"], stderr=subprocess.DEVNULL).strip() or 0)
-    except (OSError, subprocess.CalledProcessError, ValueError):
-        return "unchecked (no git here)"
-    if not t_prof or not t_kern:
-        return "unchecked (no git history for the files)"
-    return "fresh" if t_prof >= t_kern else "STALE: the kernels were committed after this counter pass — re-run scripts/gpu_round.sh <tag> pmc and commit its summaries"
+        rec = json.load(open(os.path.join(ROOT, path))).get("_kernels_sha16")
+    except (OSError, ValueError):
+        return "unchecked (file unreadable)"
+    if rec is None:
+        return "unchecked (file carries no kernels_sha16)"
+    return "fresh" if rec == sources_sha16() else "STALE (kernel sources changed since the counter pass)"
 
 
-def _profiled_valu_busy(kernel: str):
-    """VALUBusy (0..1) of `kernel` from the newest committed rocprofv3 counter pass (profiles/*_valu_busy.txt), or None."""
+def _newest_profile(pattern: str):
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_commit_valu_busy.txt")), reverse=True):
-        for line in open(path):
-            if line.startswith(kernel):
-                return float(line.split()[-2]) / 100.0
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=lambda f: (os.path.basename(f).split("_")[0], os.path.getmtime(f)))
+    return files[-1] if files else None
+
+
+def _profiled_counters(kernel: str):
+    """{launch_us, insts_valu, gui_active, valu_busy, clock_ghz, fresh, file} of `kernel` from the newest committed counter pass, or None."""
+    from zkir_amd.build import sources_sha16
+    path = _newest_profile("r*_bench_commit_valu_busy.txt")
+    if not path:
+        return None
+    sha = None
+    for line in open(path):
+        if line.startswith("# kernels_sha16:"):
+            sha = line.split(":", 1)[1].strip()
+        if line.startswith(kernel):
+            f = line[60:].split()                        # the kernel name may contain blanks: the numeric columns start at column 60
+            try:
+                launches, avg_us, insts, act, gui, busy, ipc = (float(x) for x in f[:7])
+            except ValueError:
+                return None
+            return {"launch_us": avg_us, "insts_valu": insts, "valu_busy": busy / 100.0, "clock_ghz": gui / 8 / (avg_us * 1e-6) / 1e9,
+                    "fresh": None if sha is None else sha == sources_sha16(), "file": os.path.relpath(path, ROOT)}
     return None
+
+
+def _alu_roofline(kernel: str, kernel_ms: float):
+    """Instruction-class-weighted VALU bound of `kernel` (see SIMDS above): achieved = its dynamic wave-instruction rate, peak = SIMDS x 2.4 GHz / (sum n_i c_i /
+    sum n_i) with the static mix of the shipped code object.  None when the committed ISA histogram / counter pass are missing."""
+    hist_path = _newest_profile("r*_isa_hist.json")
+    ctr = _profiled_counters(kernel)
+    if not hist_path or not ctr:
+        return None
+    hist = json.load(open(hist_path))
+    h = hist.get(kernel)
+    if not h:
+        return None
+    from zkir_amd.build import sources_sha16
+    c_avg = h["avg_arch_cycles_per_valu"]
+    achieved = ctr["insts_valu"] / (kernel_ms * 1e-3)
+    peak = SIMDS * PEAK_CLOCK_HZ / c_avg
+    cls = h["classes"]
+    return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave64 VALU instr/s", "frac": achieved / peak,
+            "wave_instr_per_launch": ctr["insts_valu"], "avg_issue_cycles": c_avg, "static_valu": h["valu"],
+            "static_mix": {q: cls.get(q, 0) for q in ("multiplier", "add64", "copy", "full_rate_32", "other_valu")},
+            "valu_busy_profiled": ctr["valu_busy"], "clock_ghz_profiled": ctr["clock_ghz"],
+            "frac_at_profiled_clock": achieved / (SIMDS * ctr["clock_ghz"] * 1e9 / c_avg),
+            "isa_hist": os.path.relpath(hist_path, ROOT), "isa_hist_fresh": hist.get("_kernels_sha16") == sources_sha16(),
+            "counters": ctr["file"], "counters_fresh": ctr["fresh"]}
 
 
 def _root_vs_golden(k, root):
@@ -247,15 +268,8 @@ def _commit_kernel_table(k, W, fill_bytes, stage_ms, lib, sp):
             parts = [("merkle", perms_leaf + perms_lvl, bytes_leaf + bytes_lvl, "leaf_hash_kernel + compress_kernel + subtree_kernel")]
         for name, perms, nbytes, kern in parts:
             ms = stage_ms[name]
-            modmul = perms * MONT_MUL_PER_PERM / (ms * 1e-3)
-            kernels[name] = {"bound": "int-alu", "kernels": kern, "bytes": nbytes, "ms": ms, "poseidon2_perms": perms, "poseidon2_perms_per_s": perms / (ms * 1e-3),
-                             "mont_mul_per_s": modmul, "mont_mul_peak_analytic": ALU_PEAK_MONT_MUL_PER_S, "frac_of_mont_mul_peak": modmul / ALU_PEAK_MONT_MUL_PER_S,
-                             # a wave runs 64 permutations, one per lane: wave instructions per second against one per 4.2 SIMD-cycles on 1024 SIMDs
-                             "valu_wave_instr_per_s": perms / 64 * VALU_INSTR_PER_PERM / (ms * 1e-3), "alu_peak_analytic": ALU_PEAK_WAVE_INSTR_PER_S,
-                             "frac_of_alu_peak": perms / 64 * VALU_INSTR_PER_PERM / (ms * 1e-3) / ALU_PEAK_WAVE_INSTR_PER_S}
-    if "merkle_levels" in kernels:                                # (the per-permutation instruction count is leaf_hash_kernel's: the levels' kernels — compress: the same
-        kernels["merkle_levels"]["alu_note"] = ("valu_wave_instr_per_s / frac_of_alu_peak use leaf_hash_kernel's instruction count per permutation; the upper levels run the "
-                                                "quad-of-lanes formulation (1,912 per lane, four lanes a permutation) and are latency-bound: nominal figures")
+            kernels[name] = {"bound": "valu-issue", "kernels": kern, "bytes": nbytes, "ms": ms, "poseidon2_perms": perms, "poseidon2_perms_per_s": perms / (ms * 1e-3),
+                             "mont_mul_per_s": perms * MONT_MUL_PER_PERM / (ms * 1e-3)}
     for v in kernels.values():
         v["achieved_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
         v["frac_of_hbm_peak"] = v["achieved_GBs"] / HBM_PEAK_GBS
@@ -421,6 +435,67 @@ def _cpu_baseline(blob, k, commit):
                     "twiddle tables, std::thread over columns / leaves); stages absent from the reference (self-defined) — a labelled side figure, "
                     "never part of `value`; its root must equal the GPU's (checked below)"}
     return out
+
+
+def _pick(d, *keys):
+    return {q: d[q] for q in keys if isinstance(d, dict) and q in d}
+
+
+def headline(full: dict) -> dict:
+    """The ONE line the driver parses (VERDICT r4 task 1): the contract's keys + roofline + cpu_baseline + the proof figures, numbers only; everything else
+    (by_config, prove_by_mode, roofline_by_stage, pipelined_*, prose) stays in bench_detail.json.  Pure function of the full record: tests/test_bench_line.py."""
+    line = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:300], **_pick(cfg, "rows_per_gpu", "main_trace_width", "parallelism")}
+    rf = dict(full.get("roofline") or {})
+    alu = rf.get("alu")
+    if isinstance(alu, dict):
+        rf["alu"] = _pick(alu, "bound", "achieved", "peak", "unit", "frac", "wave_instr_per_launch", "avg_issue_cycles", "static_mix", "valu_busy_profiled",
+                          "clock_ghz_profiled", "frac_at_profiled_clock", "isa_hist_fresh", "counters_fresh")
+    line["roofline"] = _pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source_freshness", "algorithmic_bytes_per_launch", "kernel_ms", "alu")
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, "value", "unit", "cores", "kind", "linear_rows", "linear_rows_per_s", "faithful_rows", "faithful_rows_per_s")
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        if isinstance(cb.get("linear_2p24"), dict):
+            c["linear_2p24"] = _pick(cb["linear_2p24"], "rows", "seconds", "rows_per_s")
+        c["host_cpu"] = (cb.get("host_cpu") or {}).get("model")
+        line["cpu_baseline"] = c
+    line.update(_pick(full, "prove_ms", "prove_ms_mode2", "prove_ms_100bit", "prove_stage_ms", "proof_bytes", "merkle_root", "merkle_root_equals_oracle_golden",
+                      "gpu_ms_per_step_hip_events", "hbm_copy_GBs_measured", "stage_ms", "zkir_exec_rows_per_s"))
+    t = full.get("target_10x_at_2p24")
+    if isinstance(t, dict):
+        line["target_10x_at_2p24"] = _pick(t, "ratio", "gpu_path_rows_per_s", "cpu_linear_rows_per_s")
+    c2 = (full.get("by_config") or {}).get("configs[2]")
+    if isinstance(c2, dict):
+        line["config2_2p24"] = _pick(c2, "rows", "commit_rows_per_s", "prove_ms", "proof_bytes")
+    if (full.get("n_gpus") or 1) > 1 or full.get("process_group"):
+        line.update(_pick(full, "merkle_roots_all_ranks", "allgather_cap_ms", "per_gpu_local_stage_rows_per_s", "efficiency_vs_same_size_single_gpu",
+                          "end_to_end_rows_per_s_incl_host"))
+        pg = full.get("process_group")
+        if isinstance(pg, dict):
+            line["process_group"] = _pick(pg, "backend", "world_size")
+        sp_ = full.get("segment_prove")
+        if isinstance(sp_, dict):
+            line["segment_prove"] = _pick(sp_, "segments", "ms_all_segments_in_parallel", "rows_per_s_proven", "verify_chain_code", "error")
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def emit(full: dict):
+    """Full record -> bench_detail.json (next to this script; also under gpurun_out/ so it comes back from a GPU box) and stderr; the headline -> ONE stdout line."""
+    detail = json.dumps(full)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(detail + "\n")
+        except OSError:
+            pass
+    print("bench_detail: " + detail, file=sys.stderr, flush=True)
+    text = json.dumps(headline(full))
+    assert len(text) < MAX_LINE_BYTES, f"bench line is {len(text)} bytes (limit {MAX_LINE_BYTES})"
+    print(text, flush=True)
 
 
 def main():
@@ -639,7 +714,7 @@ def main():
 
     # ---- the opt-in proof MODES of round 4 at the same size: the fib run in mode 2 (+ the I/O argument), and the array loop of spec.memory_loop_program
     #      (4 of 13 rows are loads / stores) in modes 0, 2 and 3 (+ the memory argument; the memory witness made on the device) — what saying more costs
-    prove_by_mode = None
+    prove_by_mode = prove_ms_mode2 = None
     if commit and not dist_mode and not args.no_prove and k <= 22:
         try:
             def timed_prove(tr_, pub_, reps=5):
@@ -658,6 +733,7 @@ def main():
             all_ms = []
             ms2, pr2, _ = timed_prove(trace, rt.public_inputs(log, blob, [], io_mode=True))
             assert rt.verify(pr2) == 0
+            prove_ms_mode2 = ms2
             prove_by_mode["fib, mode 2 (+ I/O argument, 160 + 48 columns)"] = {"prove_ms": ms2, "proof_bytes": int(len(pr2) * 4), "vs_mode_0": ms2 / prove_ms}
             mblob = spec.memory_loop_program(min(65535, n // 13)).to_bytes()
             mlog = rt.interpret(mblob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
@@ -857,11 +933,7 @@ def main():
         dom = max(kernels, key=lambda q: kernels[q]["ms"])
         traffic, traffic_source = _profiled_traffic(dom) if (k == 20 and not dist_mode and commit) else (None, None)
         dom_kernel = {"merkle_leaves": "leaf_hash_kernel", "trace_fill": "trace_fill_kernel", "main_trace": "main_trace_kernel"}.get(dom, dom)
-        alu_measured = None
-        if commit:                                        # the measured counterpart of the analytic ALU peak: 7 repetitions, spread reported (it moves with the clock state)
-            reps = sorted(float(lib.zkir_modmul_peak_per_s(sp())) for _ in range(7))
-            alu_measured = {"median": reps[3], "min": reps[0], "max": reps[-1], "reps": 7,
-                            "what": "zkir_modmul_peak_per_s: 8 independent chains of minimal Montgomery products per lane, no memory traffic, 4096 workgroups"}
+        alu = _alu_roofline(dom_kernel, kernels[dom]["ms"]) if (kernels[dom]["bound"] != "hbm" and k == 20 and not dist_mode) else None
         out = {
             "metric": f"trace rows/sec (2^{k}-cycle fib: execution-trace fill + BabyBear NTT/LDE + Poseidon2 Merkle commitment)"
                       if commit else f"trace rows/sec (2^{k}-cycle fib, execution-trace fill only)",
@@ -879,33 +951,13 @@ def main():
                        "reading_at_n_gt_1": ("`value` = the GPUs' commit throughput on row shards already in HBM (weak scaling: per-GPU work fixed).  END TO END one run is a sequential chain — "
                                              "its time to root is bounded by one host core whatever G is (multi_gpu_end_to_end.one_run_row_sharded.bound) — so the figure that grows with G is "
                                              "the AGGREGATE of G independent runs, one interpreter per GPU: multi_gpu_end_to_end.independent_runs_one_per_gpu.rows_per_s_end_to_end_incl_host") if dist_mode else None},
-            # the dominant KERNEL of the step (its own launch bracketed by HIP events inside the timed region; at N = 1 / 2^20 rows: leaf_hash_kernel),
-            # priced against the HBM peak as the contract asks — and against the roofline that does bound it (`alu`)
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source,
+            # the dominant KERNEL of the step (its own launch bracketed by HIP events inside the timed region; at N = 1 / 2^20 rows: leaf_hash_kernel).  `achieved` / `peak` /
+            # `frac` are the HBM figures the contract asks for; `bound` names what the kernel is really bound by, and `alu` prices it against THAT roofline
+            "roofline": {"bound": "valu-issue" if kernels[dom]["bound"] != "hbm" else "hbm", "kernel": dom_kernel, "stage": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_source_freshness": _check_traffic_source_is_fresh(traffic_source) if traffic_source else None,
-                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (a file, NOT a counter read in this run)"
-                                         if traffic is not None else None,
                          "kernel_ms": kernels[dom]["ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
-                         "note": ("the dominant kernel is the Poseidon2 leaf hash, which is integer-ALU-bound (3,236 vector instructions per permutation, 506 Montgomery multiplications among them; "
-                                  "VALU issue slots, see profiles/*_valu_busy.txt), not HBM- or MFMA-bound; see `alu` and roofline_by_stage")
-                         if kernels[dom]["bound"] != "hbm" else None,
-                         # the roofline that does bound this kernel: vector-ALU issue.  `peak` is ANALYTIC and fixed (ALU_PEAK_FORMULA); the measured rate of
-                         # independent minimal products on this device, with its spread, is next to it; `valu_busy_profiled` = rocprofv3 VALUBusy of
-                         # leaf_hash_kernel in the committed counter pass of this command (profiles/): the pipe is never idle
-                         "alu": ({"bound": "valu-issue", "achieved": kernels[dom]["valu_wave_instr_per_s"], "peak": ALU_PEAK_WAVE_INSTR_PER_S,
-                                  "peak_formula": "1024 SIMDs x 2.4e9 Hz / 4.2 SIMD-cycles per wave64 vector instruction (profiles/r02_ubench_alu.txt: multiplier-class and 64-bit "
-                                                  "instructions 4.1-4.5, a few 32-bit ones 2.2-2.4: the fraction can exceed 1 by the share of those)",
-                                  "unit": "wave64 VALU instructions/s", "frac": kernels[dom]["frac_of_alu_peak"],
-                                  "valu_instr_per_permutation": VALU_INSTR_PER_PERM,
-                                  # the round-3 way of saying it (products only, three instructions each), kept for comparison: it FELL in round 4 because the kernel does fewer products
-                                  "mont_mul_view": {"achieved": kernels[dom]["mont_mul_per_s"], "peak": ALU_PEAK_MONT_MUL_PER_S, "peak_formula": ALU_PEAK_FORMULA, "unit": "mont_mul/s",
-                                                    "frac": kernels[dom]["frac_of_mont_mul_peak"], "peak_measured": alu_measured},
-                                  "mont_mul_per_permutation": MONT_MUL_PER_PERM, "valu_busy_profiled": _profiled_valu_busy("leaf_hash_kernel"),
-                                  # the analytic peak assumes 2.4 GHz; under this kernel's load the chip clocks lower (counter pass): the same fraction at THAT clock
-                                  "clock_ghz_profiled": _profiled_clock_ghz("leaf_hash_kernel"),
-                                  "frac_at_measured_clock": (kernels[dom]["frac_of_alu_peak"] * 2.4 / _profiled_clock_ghz("leaf_hash_kernel")) if _profiled_clock_ghz("leaf_hash_kernel") else None}
-                                 if kernels[dom]["bound"] == "int-alu" else None)},
+                         "alu": alu},
             # `value` is rows/s of a commit over W self-chosen columns: the width-independent figures are per column of 2^20 rows
             "per_column": ({"main_trace_width": W, "rows": n,
                             "lde_us_per_column_per_2p20_rows": stage_ms["lde"] * 1e3 / W * ((1 << 20) / n),
@@ -926,7 +978,8 @@ def main():
                                                         "all_reduce(f64 MAX)", "all_gather_object", "broadcast_object_list", "gather_object"]} if dist_mode else None),
             "hbm_copy_GBs_measured": hbm_copy_gbs,         # 1 GiB device-to-device copy, read + write bytes / time
             "gpu_ms_per_step_hip_events": gpu_ms_per_step,
-            "prove_ms": prove_ms, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
+            "prove_ms": prove_ms, "prove_ms_mode2": prove_ms_mode2, "prove_stage_ms": prove_stage_ms, "proof_bytes": proof_bytes, "verify_ms_host": verify_ms,
+            "stage_ms": stage_ms,
             "prove_stage_roofline": _prove_stage_table(k, W, [prove_stage_ms[q] for q in PROVE_STAGES]) if prove_stage_ms else None,
             "prover": "ZKIR-STARK, AIR v6 (self-defined; 172 logical main-trace columns, 152 committed in default mode, + 40 aux columns / 398 constraints: the semantics of 20 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU/SLT/SGE, SEQ/SNE, CMOV/CMOVZ/CMOVNZ, BEQ/BNE, BLTU/BGEU/BLT/BGE, JAL, JALR — and the control flow of every opcode, + a LogUp lookup argument — instruction ROM and 10-bit ranges, eight range lookups per row; "
                       "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v10 carries the program).  `prove_ms` is MODE 0, the default; "
@@ -968,7 +1021,7 @@ def main():
                                                                   "against the literal single-threaded restatement of VM::run building 372 B rows on the CPU, same size; of the "
                                                                   "GPU path's time ~97 % is the host interpreter and ~3 % K1 — it is an end-to-end ratio of two trace paths, not a kernel speed-up",
                                              "commit_step_ratio_vs_cpu_commit_port": (c2["commit_rows_per_s"] / side["rows_per_s"]) if side else None}
-        print(json.dumps(out))
+        emit(out)
     if dist_mode:
         dist.destroy_process_group()
 

@@ -11,8 +11,11 @@ streaming reads, the gfx950 correction the guide prescribes.
 """
 import glob
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def db(path):
@@ -63,9 +66,14 @@ def main():
         t["hbm_write_bytes"] = write
         t["hbm_bytes_per_launch"] = fetch + write
     if traffic:
+        from zkir_amd.build import sources_sha16
+        traffic["_kernels_sha16"] = sources_sha16()
         json.dump(traffic, open(out + "_pmc_traffic.json", "w"), indent=1, sort_keys=True)
         txt = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per launch"] + cal
         for s, t in traffic.items():
+            if s.startswith("_"):
+                txt.append(f"# kernels_sha16: {t}")
+                continue
             txt.append(s)
             for k in sorted(t):
                 txt.append(f"    {k:32s} {t[k]}")

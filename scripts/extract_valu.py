@@ -6,8 +6,11 @@ VALUBusy (rocprof's derived metric) = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM /
 cycles spent executing vector-ALU instructions — the roofline of the integer-ALU-bound Poseidon2 kernels.
 """
 import glob
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 SIMD_NUM = 256 * 4
 XCDS = 8          # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (sum / wall time = 8 x ~2.3 GHz)
@@ -23,7 +26,8 @@ def main():
     for name, ctr, v, n, dur in rows:
         s = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
         per.setdefault(s, {"launches": n, "avg_ns": dur})[ctr] = v
-    lines = ["# kernel, launches, avg_us, SQ_INSTS_VALU (wave instr), SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, VALUBusy % = 100*ACTIVE*4/SIMDs/(GUI_ACTIVE/8 XCDs), VALU instr per SIMD-cycle"]
+    from zkir_amd.build import sources_sha16
+    lines = [f"# kernels_sha16: {sources_sha16()}", "# kernel, launches, avg_us, SQ_INSTS_VALU (wave instr), SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, VALUBusy % = 100*ACTIVE*4/SIMDs/(GUI_ACTIVE/8 XCDs), VALU instr per SIMD-cycle"]
     for s, d in sorted(per.items(), key=lambda kv: -kv[1].get("avg_ns", 0) * kv[1]["launches"]):
         gui, act, insts = d.get("GRBM_GUI_ACTIVE"), d.get("SQ_ACTIVE_INST_VALU"), d.get("SQ_INSTS_VALU")
         busy = 100.0 * act * 4 / SIMD_NUM / (gui / XCDS) if gui and act else float("nan")

@@ -26,6 +26,17 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 EXTRA = {"stark.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
+def sources_sha16() -> str:
+    """sha256 prefix over the kernel / host sources the library is built from: the counter files under profiles/ carry the value they were measured at, so a
+    reader without git (the GPU box) can tell whether they describe THIS build (bench.py roofline.traffic_source_freshness)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(HOST_SOURCES + HIP_SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        h.update(name.encode())
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(src: str, dst: str, deps) -> bool:
     if not os.path.exists(dst):
         return True
