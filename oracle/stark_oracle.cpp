@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include <map>
 
@@ -2202,6 +2203,52 @@ void so_commit_trace(const void* packed_rows, const so_public* pub, int log_blow
   so::Merkle t; so::merkle_build(L, Wm, big, t);
   memcpy(root4, t.layers.back().data(), 16);
   if (lde_out) memcpy(lde_out, L.data(), L.size() * 4);
+}
+
+// The same commitment, COLUMN-BLOCKED (round 5: the root at BASELINE configs[2]'s own size, 2^24 rows): the committed columns are extended eight at a time (one
+// absorption of the rate-8 sponge) and every leaf keeps only its 12-word sponge state, so the 2^25 x 152 LDE matrix (20 GB) never exists: memory = the logical main
+// trace + 8 LDE columns + 48 B per leaf.  Same functions as so_commit_trace (so::lde, so::permute, so::compress), same order of operations per leaf:
+// hash_elems == zero state, for each chunk of 8 { overwrite s[0..8), permute }.  `threads` std::threads share the columns of a block / the leaves: the arithmetic
+// is untouched.  tests/test_stark_oracle.py: equal to so_commit_trace on small sizes, every mode.
+void so_commit_trace_blocked(const void* packed_rows, const so_public* pub, int log_blowup, uint32_t* root4, int threads) {
+  std::vector<so::F> m; so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, to_pub(pub), m);
+  const int mode = (int)pub->deferred, Wm = so::phys_width(mode), Wl = so::logical_width(mode);
+  const size_t n = (size_t)1 << so::padded_log_n(pub->n_real), big = n << log_blowup;
+  std::vector<int> logical_of(Wm, -1);
+  for (int c = 0; c < Wl; c++) if (!so::is_virtual(c, mode)) logical_of[so::phys_col(c, mode)] = c;
+  if (threads < 1) threads = 1;
+  std::vector<so::F> state((size_t)so::T * big, 0);                          // sponge state of leaf j: state[12 j .. 12 j + 12)
+  std::vector<std::vector<so::F>> blk(so::RATE);
+  auto par = [&](size_t count, auto&& body) {                                 // body(lo, hi) over [0, count) split among the threads
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) { size_t lo = count * t / threads, hi = count * (t + 1) / threads; if (lo < hi) th.emplace_back([=, &body] { body(lo, hi); }); }
+    for (auto& x : th) x.join();
+  };
+  for (int k0 = 0; k0 < Wm; k0 += so::RATE) {
+    const int len = std::min(so::RATE, Wm - k0);
+    par((size_t)len, [&](size_t lo, size_t hi) {
+      for (size_t q = lo; q < hi; q++) {
+        const so::F* col = &m[(size_t)logical_of[k0 + (int)q] * n];
+        std::vector<so::F> e(col, col + n), c;
+        so::lde(e, log_blowup, c, blk[q]);
+      }
+    });
+    par(big, [&](size_t lo, size_t hi) {
+      for (size_t j = lo; j < hi; j++) { so::F* s = &state[(size_t)so::T * j]; for (int q = 0; q < len; q++) s[q] = blk[q][j]; so::permute(s); }
+    });
+  }
+  m.clear(); m.shrink_to_fit();
+  for (auto& b : blk) { b.clear(); b.shrink_to_fit(); }
+  std::vector<so::F> cur(4 * big);
+  for (size_t j = 0; j < big; j++) memcpy(&cur[4 * j], &state[(size_t)so::T * j], 16);
+  state.clear(); state.shrink_to_fit();
+  while (cur.size() > 4) {
+    size_t cnt = cur.size() / 8;
+    std::vector<so::F> nxt(4 * cnt);
+    par(cnt, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) so::compress(&cur[8 * i], &cur[8 * i + 4], &nxt[4 * i]); });
+    cur.swap(nxt);
+  }
+  memcpy(root4, cur.data(), 16);
 }
 
 // ---- stage B C API ----

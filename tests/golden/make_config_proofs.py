@@ -11,7 +11,10 @@ Also (`python tests/golden/make_config_proofs.py mode3 [log2_rows ...]`, default
 the touched cells carried) of the memory-ring walk halted at 2^k cycles (1024 cells: every cell re-visited 4 / 16 times; 5 memory accesses and 3 bitwise opcodes per 16
 rows) — the large-size counterpart of tests/test_gpu_stark.py's small mode-3 programs; the program is encoded HERE from the reference's bit layout (encoding.rs:23-60).
 
-Does not import the product.  Run: python tests/golden/make_config_proofs.py [log2_rows ...]   (default 16 18 20)
+Also (`python tests/golden/make_config_proofs.py mode2 [log2_rows ...]`, default 12 16 20; round 5): the MODE-2 proof (the I/O argument) of a fib run that halts by itself and
+WRITES its result — the proof whose output tape says what the run computed.
+
+Does not import the product.  Run: python tests/golden/make_config_proofs.py [log2_rows ...]   (default 16 18 20; 22: ~50 minutes and ~20 GB, one thread)
 """
 import hashlib
 import json
@@ -69,6 +72,42 @@ def main_mode3(ks):
         json.dump(cur, open(path, "w"), indent=1)
 
 
+ADD_, BNE_, ECALL_ = 0x00, 0x41, 0x50
+
+
+def b_(op, rs1, rs2, off): return op | rs1 << 7 | rs2 << 11 | (off & 0x1FFFF) << 15      # B-type: rs1 @7, rs2 @11, offset @15
+
+
+def fib_out(cnt):
+    """The v3.4 fib of tests/cross_module.rs:145-164 with a loop counter beyond the 17-bit immediate (Q11): r3 = hi, doubled twelve times, + lo; `cnt` iterations, then
+    WRITE r2 (syscall 2: the value leaves on the output tape) and EXIT 0.  16 + 5 cnt + 6 rows."""
+    hi, lo = cnt >> 12, cnt & 0xFFF
+    return blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 1), i_(ADDI, 3, 0, hi)] + [r_(ADD_, 3, 3, 3)] * 12 + [i_(ADDI, 3, 3, lo)]
+                + [r_(ADD_, 4, 1, 2), i_(ADDI, 1, 2, 0), i_(ADDI, 2, 4, 0), i_(ADDI, 3, 3, -1), b_(BNE_, 3, 0, -16)]
+                + [i_(ADDI, 11, 2, 0), i_(ADDI, 10, 0, 2), ECALL_, i_(ADDI, 10, 0, 0), i_(ADDI, 11, 0, 0), ECALL_])
+
+
+def main_mode2(ks):
+    """MODE-2 proofs (mode 0 + the I/O argument: the proof says what the run WROTE): fib_out with the largest iteration count whose run fits 2^k rows — the run halts by
+    itself (Exit 0) a few rows short of 2^k, so the padding rows are exercised too; its one output, fib(cnt + 1) mod 2^40, is in the proof's output tape."""
+    path = os.path.join(HERE, "config_proofs.json")
+    for k in ks:
+        cnt = ((1 << k) - 22) // 5
+        prog = fib_out(cnt)
+        t0 = time.time()
+        res = oracle.run(prog, max_cycles=1 << (k + 1), enable_execution_trace=True)
+        assert res.halt_kind == 1 and res.halt_code == 0 and len(res.rows) == 22 + 5 * cnt and len(res.outputs) == 1
+        pub = so.public_inputs(len(res.rows), prog, [], list(res.outputs), (res.halt_kind, res.halt_code), io_mode=True)
+        proof = np.ascontiguousarray(so.prove(res.rows, pub), dtype="<u4")
+        assert so.verify(proof, pub) == 0 and int(proof[9]) == 2
+        e = entry(proof, k, t0)
+        e.update({"rows": len(res.rows), "iterations": cnt, "output": int(res.outputs[0]), "program_blob_hex": prog.hex()})
+        print("mode2", k, e["rows"], e["output"], e["words"], e["sha256"], e["oracle_seconds"], flush=True)
+        cur = json.load(open(path))
+        cur.setdefault("mode2_fib_out_proofs", {})[str(k)] = e
+        json.dump(cur, open(path, "w"), indent=1)
+
+
 def sample_positions(n_words: int):
     return [int(i * (n_words - 1) // (N_SAMPLES - 1)) for i in range(N_SAMPLES)]
 
@@ -76,6 +115,8 @@ def sample_positions(n_words: int):
 def main():
     if sys.argv[1:2] == ["mode3"]:
         return main_mode3([int(a) for a in sys.argv[2:]] or [14, 16])
+    if sys.argv[1:2] == ["mode2"]:
+        return main_mode2([int(a) for a in sys.argv[2:]] or [12, 16, 20])
     ks = [int(a) for a in sys.argv[1:]] or [16, 18, 20]
     path = os.path.join(HERE, "config_proofs.json")
     out = json.load(open(path)) if os.path.exists(path) else {}

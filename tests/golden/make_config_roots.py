@@ -6,7 +6,7 @@ arithmetic, one thread).  tests/test_gpu_large.py compares the GPU's root with i
 What this pins: nothing outside this repository — the commit stage is self-defined (the reference has no prover); the file makes the GPU
 and the independent CPU statement of the same spec agree AT FULL SIZE, where the test suite otherwise samples.
 
-Does not import the product.  Run: python tests/golden/make_config_roots.py [max_log2_rows=20]   (2^20 rows: ~4 minutes, ~3 GB)
+Does not import the product.  Run: python tests/golden/make_config_roots.py [max_log2_rows=20]   (2^20 rows: ~4 minutes, ~3 GB; 2^24 rows, column-blocked on 8 threads: ~15 minutes, ~25 GB)
 """
 import json
 import os
@@ -50,8 +50,14 @@ def main():
             continue
         t0 = time.time()
         rows = oracle.run(FIB_ENDLESS, max_cycles=1 << k, enable_execution_trace=True).rows
-        root = so.commit_trace(rows, 1)
-        roots[str(k)] = {"rows": 1 << k, "root": [int(x) for x in root], "oracle_seconds": round(time.time() - t0, 1)}
+        if k >= 22:       # column-blocked (eight columns at a time, one sponge state per leaf: so_commit_trace_blocked — the same functions in the same order per leaf;
+                          # tests/test_stark_oracle.py holds it equal to commit_trace); threads share columns / leaves, the arithmetic is untouched
+            threads = os.cpu_count() or 1
+            root = so.commit_trace_blocked(rows, 1, threads=threads)
+        else:
+            threads = 1
+            root = so.commit_trace(rows, 1)
+        roots[str(k)] = {"rows": 1 << k, "root": [int(x) for x in root], "oracle_seconds": round(time.time() - t0, 1), "threads": threads}
         print(k, roots[str(k)], flush=True)
         json.dump(out, open(path, "w"), indent=1)
     json.dump(out, open(path, "w"), indent=1)

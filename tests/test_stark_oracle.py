@@ -462,6 +462,20 @@ def test_cpu_commit_port_matches_the_oracle():
         assert np.array_equal(root, so.commit_trace(rows, 1, pub=pub)) and t_lde > 0 and t_merkle > 0
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_column_blocked_commit_is_the_commit(mode):
+    """so_commit_trace_blocked (round 5: the 2^24-row golden root of tests/golden/config_roots.json — eight LDE columns at a time, one 12-word sponge state per leaf, std::threads
+    over columns / leaves) gives the root of so_commit_trace (every LDE column in memory, hash_elems per leaf) in every mode (152 / 168 / 160 / 264 committed columns), ragged row
+    counts, one thread and several."""
+    for prog, n in ((spec.fib_endless_program(), 300), (spec.memory_loop_program(40), 1000), (spec.sha256_chain_program(), 513)):
+        blob = prog.to_bytes()
+        res = oracle.run(blob, max_cycles=n, enable_execution_trace=True, enable_deferred_model=mode == 1)
+        pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3)
+        want = so.commit_trace(res.rows, 1, pub=pub)
+        for threads in (1, 3):
+            assert np.array_equal(so.commit_trace_blocked(res.rows, 1, pub=pub, threads=threads), want), (mode, n, threads)
+
+
 def test_air_holds_row_by_row_on_honest_traces():
     """Every constraint vanishes on every (row, next row) pair of an honest main trace: evaluated here with the row selectors a
     verifier would use ON the trace domain (is_first = [i == 0], is_last = [i == n_real - 1], is_trans = [i != N - 1])."""

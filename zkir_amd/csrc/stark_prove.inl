@@ -625,52 +625,82 @@ __global__ __launch_bounds__(NT) void bary_weights_kernel(uint32_t log_n, const 
   wts[j] = bb::e_mul_fm(di, x);
 }
 
-// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (MONTGOMERY E4; grid: chunks x half blocks of the B8 matrix).
-// A workgroup handles the FOUR columns of one half block — one 16-byte load brings their values at a position — so that the 16-byte
-// weights (the bulk of the traffic when read once per column) are loaded once per four values; the products accumulate as exact 96-bit
-// integers (bb::mad96: 2 instructions per term; round 3: a lazy Montgomery product + a 64-bit add, 4 instructions), reduced once per lane.
-// v and e both rest in Montgomery form: the reduction's division by R leaves R * Σ v e.
-// step = 2 sums over the EVEN positions only: x_(2i) = g w_N^i is the coset g H_N, on which a polynomial of degree < N (every trace column: the LDE of N values) is
-// determined as well, with the same weights x_j / (zeta - x_j) and the scale ((zeta / g)^N - 1) / N — half the multiply-adds (measured: 197 -> 168 us per launch at 2^20 — the rows skipped share their 128-byte lines with the rows read);
-// j - 2 stays even, so the second opening point rides along as before.  The quotient's columns keep step = 1: an HONEST quotient has degree < N too, but the prover must
+// partial[col][chunk][2] = Σ_{j in chunk} v_j * e_j  and  Σ v_j * e_{j-2}  (MONTGOMERY E4).  ONE launch for the three matrices (round 5; round 4: three launches of a
+// kernel that held 4 columns x 4 coordinates x 2 points = 96 accumulator registers per lane, spilled 16 of them at four waves per SIMD, read 16 of every 64 bytes a lane
+// touched and re-read the weights once per four columns): grid = chunks x B8 blocks (main, aux, then the quotient's half block).
+// A QUAD of lanes takes one row of a block: every lane of the quad reads the row's 32 bytes (eight columns — the whole row, so every byte of a fetched line that can be used is)
+// and ONE coordinate t = lane & 3 of the two weights, and keeps 8 columns x 2 points = 16 exact 96-bit sums (bb::mad96: 2 instructions per term) = 48 registers.  The
+// weights are read once per eight columns.  v and e both rest in Montgomery form: the reduction's division by R leaves R * Σ v e.
+// step = 2 (trace matrices) sums over the EVEN positions only: x_(2i) = g w_N^i is the coset g H_N, on which a polynomial of degree < N (every trace column: the LDE of N values) is
+// determined as well, with the same weights x_j / (zeta - x_j) and the scale ((zeta / g)^N - 1) / N — half the multiply-adds (the rows skipped share their 128-byte lines with the rows read:
+// the HBM traffic is the whole matrix); j - 2 stays even, so the second opening point rides along.  The quotient's columns keep step = 1: an HONEST quotient has degree < N too, but the prover must
 // make the same (worthless) proof of a false claim as the oracle does (tests: forged outputs), and there the quotient is whatever the division leaves on the 2 N points.
-__global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t* __restrict__ mat, uint64_t N2, uint32_t width, const E4* __restrict__ wts, E4* __restrict__ partial,
-                                                       uint32_t n_chunks, uint32_t step) {
-  constexpr int CG = 4;
-  __shared__ uint32_t red[NT / 64][CG][2][4];
-  const uint32_t col0 = blockIdx.y * CG, chunk = blockIdx.x;
-  const uint64_t per = N2 / n_chunks, lo = (uint64_t)chunk * per;
-  const uint4* v4 = reinterpret_cast<const uint4*>(mat) + (uint64_t)(col0 >> 3) * N2 * 2 + ((col0 >> 2) & 1);
-  bb::Acc96 a0[CG][4], a1[CG][4];
+constexpr uint32_t BARY_ROWS = NT / 4;                         // rows a workgroup takes per iteration
+constexpr uint64_t BARY_MAX_TERMS = 2048;                      // per 96-bit sum: 2^11 products below p^2 < 2^61.82 keep hi < 2^9, acc96_div_R's bound
+template <int NCOL>
+struct BaryRow { uint4 xa, xb; uint32_t w0, w1; };
+template <int NCOL>
+__device__ __forceinline__ BaryRow<NCOL> bary_load(const uint4* __restrict__ v4, const uint32_t* __restrict__ w32, uint64_t N2, uint64_t j, uint32_t t) {
+  BaryRow<NCOL> r;
+  r.w0 = w32[4 * j + t]; r.w1 = w32[4 * ((j + N2 - 2) & (N2 - 1)) + t];
+  r.xa = v4[j * 2];
+  if (NCOL == 8) r.xb = v4[j * 2 + 1];
+  return r;
+}
+template <int NCOL>
+__device__ __forceinline__ void bary_mads(const BaryRow<NCOL>& r, bb::Acc96 (*a)[2]) {
+  const uint32_t x[8] = {r.xa.x, r.xa.y, r.xa.z, r.xa.w, NCOL == 8 ? r.xb.x : 0, NCOL == 8 ? r.xb.y : 0, NCOL == 8 ? r.xb.z : 0, NCOL == 8 ? r.xb.w : 0};
 #pragma unroll
-  for (int c = 0; c < CG; c++)
-#pragma unroll
-    for (int t = 0; t < 4; t++) a0[c][t] = a1[c][t] = bb::acc96_zero();
-  for (uint64_t j = lo + (uint64_t)step * threadIdx.x; j < lo + per; j += (uint64_t)step * NT) {
-    const E4 w0 = wts[j], w1 = wts[(j + N2 - 2) & (N2 - 1)];
-    const uint4 xv = v4[j * 2];
-    const uint32_t x[CG] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-    for (int c = 0; c < CG; c++) {
-#pragma unroll
-      for (int t = 0; t < 4; t++) { bb::mad96(a0[c][t], w0.c[t], x[c]); bb::mad96(a1[c][t], w1.c[t], x[c]); }
+  for (int c = 0; c < NCOL; c++) { bb::mad96(a[c][0], r.w0, x[c]); bb::mad96(a[c][1], r.w1, x[c]); }
+}
+template <int NCOL>
+__device__ __forceinline__ void bary_block(const uint4* __restrict__ v4, const uint32_t* __restrict__ w32, uint64_t N2, uint64_t lo, uint64_t per, uint32_t step, bb::Acc96 (*a)[2]) {
+  const uint32_t t = threadIdx.x & 3, rq = threadIdx.x >> 2;
+  const uint64_t stride = (uint64_t)step * BARY_ROWS;
+  uint64_t j = lo + (uint64_t)step * rq;
+  if (per >= 2 * stride) {
+    // every lane makes the same per / stride iterations (powers of two): two rows in flight while two are multiplied — the loads of a row are 1-2 us away, its 32
+    // multiply-adds ~130 cycles, and the registers hold five waves per SIMD
+    const uint32_t n_it = (uint32_t)(per / stride);
+    BaryRow<NCOL> r0 = bary_load<NCOL>(v4, w32, N2, j, t), r1 = bary_load<NCOL>(v4, w32, N2, j + stride, t);
+    for (uint32_t it = 0; it < n_it; it += 2) {
+      const uint64_t jn = it + 2 < n_it ? j + 2 * stride : j;          // (the last pair is loaded twice: nothing is read outside the chunk)
+      const BaryRow<NCOL> n0 = bary_load<NCOL>(v4, w32, N2, jn, t), n1 = bary_load<NCOL>(v4, w32, N2, jn + stride, t);
+      bary_mads<NCOL>(r0, a); bary_mads<NCOL>(r1, a);
+      r0 = n0; r1 = n1; j = jn;
     }
+  } else {
+    for (; j < lo + per; j += stride) bary_mads<NCOL>(bary_load<NCOL>(v4, w32, N2, j, t), a);
   }
+}
+__global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t* __restrict__ main_m, const uint32_t* __restrict__ aux_m, const uint32_t* __restrict__ quot_m, uint32_t main_blocks,
+                                                       uint32_t aux_blocks, uint64_t N2, const E4* __restrict__ wts, E4* __restrict__ partial, uint32_t n_chunks, uint32_t log_per) {
+  __shared__ uint32_t red[NT / 64][8][2][4];
+  const uint32_t blk = blockIdx.y, chunk = blockIdx.x;
+  const bool is_q = blk >= main_blocks + aux_blocks;
+  const uint32_t* mat = blk < main_blocks ? main_m + (uint64_t)blk * N2 * 8 : is_q ? quot_m : aux_m + (uint64_t)(blk - main_blocks) * N2 * 8;
+  const uint32_t col0 = blk * 8, ncol = is_q ? 4 : 8;                // columns in the order used everywhere: main, aux, the quotient's four
+  const uint64_t per = 1ull << log_per, lo = (uint64_t)chunk << log_per;             // N2 / n_chunks, a power of two
+  bb::Acc96 a[8][2];
+#pragma unroll
+  for (int c = 0; c < 8; c++) a[c][0] = a[c][1] = bb::acc96_zero();
+  if (is_q) bary_block<4>(reinterpret_cast<const uint4*>(mat), reinterpret_cast<const uint32_t*>(wts), N2, lo, per, 1u, a);
+  else bary_block<8>(reinterpret_cast<const uint4*>(mat), reinterpret_cast<const uint32_t*>(wts), N2, lo, per, 2u, a);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int c = 0; c < CG; c++)
+  for (int c = 0; c < 8; c++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      uint32_t r0 = bb::acc96_div_R(a0[c][t]), r1 = bb::acc96_div_R(a1[c][t]);
-      for (int off = 32; off > 0; off >>= 1) { r0 = bb::add(r0, __shfl_down(r0, off, 64)); r1 = bb::add(r1, __shfl_down(r1, off, 64)); }
-      if (lane == 0) { red[wv][c][0][t] = r0; red[wv][c][1][t] = r1; }
+    for (int which = 0; which < 2; which++) {
+      uint32_t r = bb::acc96_div_R(a[c][which]);
+      for (int off = 32; off >= 4; off >>= 1) r = bb::add(r, __shfl_down(r, off, 64));      // lanes of one coordinate: lane & 3 is kept by every step
+      if (lane < 4) red[wv][c][which][lane] = r;
     }
   __syncthreads();
-  if (threadIdx.x < CG * 8) {
-    const int c = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, t = threadIdx.x & 3;
+  if (threadIdx.x < 64) {
+    const uint32_t c = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, t = threadIdx.x & 3;
     uint32_t r = red[0][c][which][t];
     for (int k = 1; k < NT / 64; k++) r = bb::add(r, red[k][c][which][t]);
-    if (col0 + c < width) partial[((uint64_t)(col0 + c) * n_chunks + chunk) * 2 + which].c[t] = r;
+    if (c < ncol) partial[((uint64_t)(col0 + c) * n_chunks + chunk) * 2 + which].c[t] = r;
   }
 }
 
@@ -1030,7 +1060,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   HIP_OK(ar.take(&dCode, (size_t)n_code + 1)); HIP_OK(ar.take(&dMult, n_mult));                   // ROM multiplicities, then range multiplicities (mode 3: then LOW3 | BYTE | NIBBLE)
   HIP_OK(ar.take(&dInvRc, air::RC_TABLE)); HIP_OK(ar.take(&dInvRom, (size_t)n_code + 1));
   HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
-  const uint32_t n_chunks = N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
+  // chunks of the barycentric sums: enough workgroups to fill the chip (64 x 25 blocks), and few enough terms per 96-bit sum (bary_dot_kernel: BARY_MAX_TERMS)
+  const uint32_t n_chunks = N2 > 64 * BARY_ROWS * BARY_MAX_TERMS ? (uint32_t)(N2 / (BARY_ROWS * BARY_MAX_TERMS)) : N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
   HIP_OK(ar.take(&dPart, (size_t)(WT + 4) * n_chunks * 2)); HIP_OK(ar.take(&dPartSum, (size_t)(WT + 4) * 2));
   std::vector<uint32_t*> fri_trees(n_layers), fri_layers(n_layers + 1);
 
@@ -1241,9 +1272,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   HIP_OK(hipMemcpyAsync(&dPP->zeta, &pp->zeta, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dPP, dW, dDinv);
   // columns in the order used everywhere below: main (WM), aux (WA) = WT "trace" columns, then the quotient's four
-  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WM + 3) / 4), dim3(NT), 0, s, dL, N2, (uint32_t)WM, dW, dPart, n_chunks, 2u);
-  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WA + 3) / 4), dim3(NT), 0, s, dAL, N2, (uint32_t)WA, dW, dPart + (size_t)WM * n_chunks * 2, n_chunks, 2u);
-  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, 1), dim3(NT), 0, s, dQ, N2, 4u, dW, dPart + (size_t)WT * n_chunks * 2, n_chunks, 1u);
+  hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WT + 8) / 8), dim3(NT), 0, s, dL, dAL, dQ, (uint32_t)WM / 8, (uint32_t)WA / 8, (uint64_t)N2, dW, dPart, n_chunks, (uint32_t)__builtin_ctzll(N2 / n_chunks));
   hipLaunchKernelGGL(bary_sum_kernel, dim3(grid_for((uint64_t)(WT + 4) * 2)), dim3(NT), 0, s, dPart, (uint32_t)(WT + 4) * 2, n_chunks, dPartSum);
   std::vector<E4> part((size_t)(WT + 4) * 2);
   HIP_OK(hipMemcpyAsync(part.data(), dPartSum, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
