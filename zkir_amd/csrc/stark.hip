@@ -500,10 +500,12 @@ __global__ __launch_bounds__(NT) void compress_kernel(const p2::Consts* __restri
 // Subtrees in ONE launch: every workgroup takes `per_wg` (a power of two <= 512) consecutive digests of the level `cur` (m digests)
 // and walks log2(per_wg) levels up, keeping the running level in LDS (Montgomery form) and writing every level to its place in the
 // tree buffer.  Small levels are latency-bound (one Poseidon2 permutation is ~1200 dependent instructions deep), so a launch and
-// a global-memory round trip per level cost more than the hashing; this way a tree of <= 2^18 digests needs two launches.
+// a global-memory round trip per level cost more than the hashing.  Round 5: the workgroup that FINISHES LAST (a device-scope counter, left at zero again) goes on with
+// the m / per_wg (<= 512) digests the launch produced, so everything above the last full-occupancy level is one launch (round 4: two, 17 per proof).
 constexpr uint32_t SUBTREE = 512;
-__global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restrict__ cp, uint32_t* __restrict__ cur, uint64_t m, uint32_t per_wg) {
+__global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restrict__ cp, uint32_t* cur, uint64_t m, uint32_t per_wg, uint32_t* counter) {
   __shared__ uint4 buf[SUBTREE];
+  __shared__ uint32_t last_one;
   const uint32_t t = threadIdx.x;
   uint64_t pos0 = (uint64_t)blockIdx.x * per_wg;
   for (uint32_t e = t; e < per_wg; e += NT) {
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
     buf[e] = make_uint4(bb::to_mont(v.x), bb::to_mont(v.y), bb::to_mont(v.z), bb::to_mont(v.w));
   }
   __syncthreads();
+ levels:
   for (uint32_t cnt = per_wg; cnt > 1; cnt >>= 1) {
     cur += 4 * m; m >>= 1; pos0 >>= 1;                         // level written by this iteration
     const uint32_t n_perm = cnt / 2;
@@ -547,6 +550,29 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
     }
     __syncthreads();
   }
+  // `cur` is now the level this launch leaves (m digests, one per workgroup).  The last workgroup to get here takes all of them on.  No fence: a device-scope fence
+  // on gfx950 writes back and invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv; measured here: 512 workgroups doing so took the launch from 94 to 146 us).
+  // Instead the ONE digest a workgroup hands over is re-stored with device-scope atomic stores (write-through), the counter is bumped once those have been
+  // acknowledged (s_waitcnt vmcnt(0) in the same wave), and the workgroup that goes on reads the digests with device-scope atomic loads (past the L2 of its XCD).
+  if (m > 1) {
+    if (t < 4) {
+      const uint32_t v = reinterpret_cast<const uint32_t*>(buf)[t];          // buf[0] = the workgroup's digest in Montgomery form; the tree holds it canonical
+      __hip_atomic_store(&cur[4 * pos0 + t], bb::from_mont(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
+    }
+    if (t == 0) {
+      const uint32_t done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_one = done == (uint32_t)m - 1;
+      if (last_one) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_one) return;
+    per_wg = (uint32_t)m; pos0 = 0;
+    for (uint32_t e = t; e < 4 * per_wg; e += NT)
+      reinterpret_cast<uint32_t*>(buf)[e] = bb::to_mont(__hip_atomic_load(&cur[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    goto levels;
+  }
 }
 
 // ALU roofline probe: every lane runs `iters` rounds of 8 independent MINIMAL Montgomery products (64-bit multiply, low multiply,
@@ -568,7 +594,7 @@ __global__ __launch_bounds__(NT) void modmul_peak_kernel(uint32_t* __restrict__ 
 }
 
 // all levels above the leaf digests: wide levels (throughput-bound) one launch each, then subtree launches
-void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n_leaves, hipStream_t s) {
+void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n_leaves, uint32_t* counter, hipStream_t s) {
   uint32_t* cur = leaf_digests;
   uint64_t m = n_leaves;
   for (; m > (1u << 18); m >>= 1) {
@@ -576,10 +602,9 @@ void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n
     hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cp, cur, m / 2, nxt);
     cur = nxt;
   }
-  while (m > 1) {
+  if (m > 1) {                                                   // m <= 2^18: per <= 512 digests a workgroup, at most 512 workgroups, whose 512 digests the last of them finishes
     const uint32_t per = m < SUBTREE ? (uint32_t)m : SUBTREE;
-    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT), 0, s, cp, cur, m, per);
-    for (uint32_t c = per; c > 1; c >>= 1) { cur += 4 * m; m >>= 1; }
+    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT), 0, s, cp, cur, m, per, counter);
   }
 }
 
@@ -600,6 +625,7 @@ struct zkir_stark_ctx {
   uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
   p2::Consts consts;              // host copy (transcript, verifier side)
   p2::Consts* d_p2 = nullptr;     // device copy: every hash kernel takes the pointer (no process-wide __constant__ state)
+  uint32_t* d_sync = nullptr;     // 64 zeroed words: the "who finishes last" counter of subtree_kernel (left at zero by every launch; launches on one context are stream-ordered)
   mutable std::mutex mu;          // a context serves one proof at a time (its workspace arena); different contexts are independent
   // prover workspace: one device allocation made on the first zkir_prove and reused (hipMalloc of GBs costs more than the kernels)
   mutable unsigned char* arena = nullptr;
@@ -618,7 +644,7 @@ int lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* 
 // leaf layer + the levels above it; mont_in = the matrix words carry the Montgomery factor (the digests are those of the canonical words either way)
 int merkle_commit(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, bool mont_in, hipStream_t s) {
   hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, mont_in ? bb::from_mont(c->consts.in_scale) : c->consts.in_scale, tree);
-  launch_tree_levels(c->d_p2, tree, n_leaves, s);
+  launch_tree_levels(c->d_p2, tree, n_leaves, c->d_sync, s);
   return check_launch("merkle_commit");
 }
 }  // namespace
@@ -679,6 +705,8 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
   p2::generate(c->consts);
   hipError_t e = hipMalloc((void**)&c->d_p2, sizeof(p2::Consts));
   if (e == hipSuccess) e = hipMemcpy(c->d_p2, &c->consts, sizeof(p2::Consts), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&c->d_sync, 256);
+  if (e == hipSuccess) e = hipMemset(c->d_sync, 0, 256);
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_inv, (size_t)n_inv * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_fwd, (size_t)N * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_lo, 1024 * 4);
@@ -707,7 +735,7 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
 void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
   (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi); (void)hipFree(c->d_g_lo_m); (void)hipFree(c->d_inv_xm1);
-  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2);
+  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2); (void)hipFree(c->d_sync);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
@@ -824,7 +852,7 @@ int zkir_merkle_leaves_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
 // top log2(G) levels).  tree[0 .. 4n) must hold the n digests; the call fills the remaining 4(n-1) words, root = last 4.
 int zkir_merkle_cap_launch(const zkir_stark_ctx* c, uint32_t* tree, uint64_t n_digests, void* stream) {
   if (!c || n_digests == 0 || (n_digests & (n_digests - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle cap: null context, or n_digests not a power of two"}); return ZKIR_ERR_ARGUMENT; }
-  launch_tree_levels(c->d_p2, tree, n_digests, (hipStream_t)stream);
+  launch_tree_levels(c->d_p2, tree, n_digests, c->d_sync, (hipStream_t)stream);
   return check_launch("merkle_cap");
 }
 

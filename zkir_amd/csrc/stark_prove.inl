@@ -704,13 +704,17 @@ __global__ __launch_bounds__(NT, BARY_WAVES) void bary_dot_kernel(const uint32_t
   }
 }
 
-// the chunks' partial sums of a column, added up on the device: 2 (WT + 4) extension elements cross to the host instead of 2 (WT + 4) n_chunks (400 KB at 64 chunks)
+// the chunks' partial sums of a column, added up on the device: 2 (WT + 4) extension elements cross to the host instead of 2 (WT + 4) n_chunks.  One wave per sum:
+// lane q takes chunks q, q + 64, .., then the wave adds its lanes up (one thread walking 256 chunks took 87 us).
 __global__ __launch_bounds__(NT) void bary_sum_kernel(const E4* __restrict__ partial, uint32_t n_cols2, uint32_t n_chunks, E4* __restrict__ out) {
-  const uint32_t idx = blockIdx.x * NT + threadIdx.x;           // 2 k + which
+  const uint32_t idx = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;           // idx = 2 k + which
   if (idx >= n_cols2) return;
   E4 a = bb::e_zero();
-  for (uint32_t q = 0; q < n_chunks; q++) a = bb::e_add(a, partial[((uint64_t)(idx >> 1) * n_chunks + q) * 2 + (idx & 1)]);
-  out[idx] = a;
+  for (uint32_t q = lane; q < n_chunks; q += 64) a = bb::e_add(a, partial[((uint64_t)(idx >> 1) * n_chunks + q) * 2 + (idx & 1)]);
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int t = 0; t < 4; t++) a.c[t] = bb::add(a.c[t], __shfl_down(a.c[t], off, 64));
+  if (lane == 0) out[idx] = a;
 }
 
 // ---- DEEP codeword: F(x) = (A(x) - a0)/(x - zeta) + (B(x) - b0)/(x - zeta w) ------------------------------------------------
@@ -800,9 +804,10 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const p2::Consts
 // The K binary folds between two committed layers in ONE launch (round 4: three launches and two intermediate layers before): output i of the last fold depends on the 2^K
 // values c[i + u g], g = m >> K, and fold f pairs v[u] with v[u + 2^(K-f-1)] — exactly the pairs (j, j + h_f) of a binary fold of the size-(m >> f) layer, the same field operations in
 // the same order on every value, so the layer is the one the chain of binary folds leaves.
-struct FoldParams { E4 beta_m[3]; uint32_t half_shift_inv_m[3]; };
+// beta_m: the layer's challenge and its squares, beta^(2^f) (Montgomery), written by fri_transcript_kernel on the device (round 5: no host round trip between the layers)
+struct FoldParams { uint32_t half_shift_inv_m[3]; };
 template <int K>
-__global__ __launch_bounds__(NT) void fri_fold_k_kernel(const uint32_t* __restrict__ c, uint32_t log_m, uint32_t log_2n, const uint32_t* __restrict__ tw_fwd, FoldParams fp, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(NT) void fri_fold_k_kernel(const uint32_t* __restrict__ c, uint32_t log_m, uint32_t log_2n, const uint32_t* __restrict__ tw_fwd, FoldParams fp, const E4* __restrict__ beta_m, uint32_t* __restrict__ out) {
   const uint64_t m = 1ull << log_m, g = m >> K, i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= g) return;
   E4 v[1 << K];
@@ -824,12 +829,36 @@ __global__ __launch_bounds__(NT) void fri_fold_k_kernel(const uint32_t* __restri
       const E4 a = v[u], b = v[u + cnt];
       const E4 sum = bb::e_mul_fm(bb::e_add(a, b), HALF_M);
       const E4 dif = bb::e_mul_fm(bb::e_sub(a, b), inv2x);
-      const E4 prod = bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(dif), fp.beta_m[f]));
+      const E4 prod = bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(dif), beta_m[f]));
       v[u] = bb::e_add(sum, prod);
     }
   }
 #pragma unroll
   for (int t = 0; t < 4; t++) out[(uint64_t)t * g + i] = v[0].c[t];
+}
+
+// ---- the Fiat-Shamir step of one FRI layer ON THE DEVICE: observe the layer's root, sample beta -------------------------------------------
+// Challenger (below; so::Challenger) at this point of the transcript: nothing pending, so  observe(root[0..4)); sample_ext()  is ONE duplex — state words 0..3 overwritten
+// with the root, one permutation, beta = (st[7], st[6], st[5], st[4]) (sample() pops from the back of the eight rate words).  One quad of lanes runs it
+// (p2::permute_quad_scaled: lane l holds words l, 4 + l, 8 + l) on the challenger state the host uploaded (Montgomery words, as Challenger::st), leaves the state for the next
+// layer, and writes  out[0..4) = the root, out[4..16) = beta, beta^2, beta^4 (Montgomery: what fri_fold_k_kernel multiplies by).  The host replays the same steps from
+// the roots once the whole commit phase is enqueued (the proof needs them anyway) and refuses to go on if its betas are not the device's.
+__global__ void fri_transcript_kernel(const p2::Consts* __restrict__ cp, uint32_t* __restrict__ st, const uint32_t* __restrict__ root, uint32_t* __restrict__ out) {
+  __shared__ uint32_t w[p2::T];
+  const uint32_t l = threadIdx.x & 3;
+  const uint32_t k_in = bb::from_mont(cp->in_scale), ko_m = bb::to_mont(cp->out_scale);
+  const uint32_t r = root[l];
+  uint32_t s[3] = {bb::mont_mul_lazy(bb::to_mont(r), k_in), bb::mont_mul_lazy(st[4 + l], k_in), bb::mont_mul_lazy(st[8 + l], k_in)};
+  p2::permute_quad_scaled(s, (int)l, *cp);
+#pragma unroll
+  for (int b = 0; b < 3; b++) { const uint32_t v = bb::mont_mul(s[b], ko_m); st[4 * b + l] = v; w[4 * b + l] = v; }
+  out[l] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    E4 beta{{w[7], w[6], w[5], w[4]}};
+    E4* bo = reinterpret_cast<E4*>(out + 4);
+    for (int f = 0; f < 3; f++) { bo[f] = beta; beta = bb::e_mul_m(beta, beta); }
+  }
 }
 
 // ---- query gathering: job = copy `count` words src[k * stride] -> dst[k] ------------------------------------------------------
@@ -1061,7 +1090,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   HIP_OK(ar.take(&dInvRc, air::RC_TABLE)); HIP_OK(ar.take(&dInvRom, (size_t)n_code + 1));
   HIP_OK(ar.take(&dQ, 8 * N2)); HIP_OK(ar.take(&dQTree, 4 * (2 * N2 - 1))); HIP_OK(ar.take(&dW, N2)); HIP_OK(ar.take(&dDinv, N2));
   // chunks of the barycentric sums: enough workgroups to fill the chip (64 x 25 blocks), and few enough terms per 96-bit sum (bary_dot_kernel: BARY_MAX_TERMS)
-  const uint32_t n_chunks = N2 > 64 * BARY_ROWS * BARY_MAX_TERMS ? (uint32_t)(N2 / (BARY_ROWS * BARY_MAX_TERMS)) : N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
+  const uint32_t n_chunks = N2 > 64 * BARY_ROWS * BARY_MAX_TERMS ? (uint32_t)(N2 / (BARY_ROWS * BARY_MAX_TERMS)) : N2 >= 1024 * NT ? 256 : N2 >= 64 * NT ? 64 : (N2 >= 16 * NT ? 16 : 1);
   HIP_OK(ar.take(&dPart, (size_t)(WT + 4) * n_chunks * 2)); HIP_OK(ar.take(&dPartSum, (size_t)(WT + 4) * 2));
   std::vector<uint32_t*> fri_trees(n_layers), fri_layers(n_layers + 1);
 
@@ -1273,7 +1302,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dPP, dW, dDinv);
   // columns in the order used everywhere below: main (WM), aux (WA) = WT "trace" columns, then the quotient's four
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WT + 8) / 8), dim3(NT), 0, s, dL, dAL, dQ, (uint32_t)WM / 8, (uint32_t)WA / 8, (uint64_t)N2, dW, dPart, n_chunks, (uint32_t)__builtin_ctzll(N2 / n_chunks));
-  hipLaunchKernelGGL(bary_sum_kernel, dim3(grid_for((uint64_t)(WT + 4) * 2)), dim3(NT), 0, s, dPart, (uint32_t)(WT + 4) * 2, n_chunks, dPartSum);
+  hipLaunchKernelGGL(bary_sum_kernel, dim3(((WT + 4) * 2 + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, s, dPart, (uint32_t)(WT + 4) * 2, n_chunks, dPartSum);
   std::vector<E4> part((size_t)(WT + 4) * 2);
   HIP_OK(hipMemcpyAsync(part.data(), dPartSum, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -1321,8 +1350,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   mark(7);
 
   // ---- 5. FRI commit phase ----------------------------------------------------------------------------------------------------
+  // Enqueued as a whole (round 5): per layer  leaf hash -> tree -> fri_transcript_kernel (root -> beta on the device) -> fold;  ONE copy and ONE synchronisation at the
+  // end bring the roots, the betas and the final layer to the host, which replays the transcript (round 4: a root copy, a synchronisation and a parameter upload per layer).
   std::vector<std::array<uint32_t, 4>> lroots(n_layers);
   std::vector<E4> betas(n_layers);
+  uint32_t *dChSt, *dFri;
+  HIP_OK(ar.take(&dChSt, 16)); HIP_OK(ar.take(&dFri, 16 * (size_t)(n_layers + 1)));
+  if (!ch.in.empty()) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: the transcript has pending input at the FRI commit phase"}); return ZKIR_ERR_OTHER; }
+  HIP_OK(hipMemcpyAsync(dChSt, ch.st, sizeof(ch.st), hipMemcpyHostToDevice, s));
   {
     uint32_t shift = bb::GEN;
     int log_m = (int)log_n + 1;
@@ -1333,32 +1368,36 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       uint32_t* tree = fri_trees[j];
       if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
       else hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
-      launch_tree_levels(c->d_p2, tree, g, s);
-      HIP_OK(hipMemcpyAsync(lroots[j].data(), tree + 4 * (2 * g - 2), 16, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipStreamSynchronize(s));
-      ch.observe_n(lroots[j].data(), 4);
-      betas[j] = ch.sample_ext();
-      E4 beta = betas[j];
-      FoldParams fp{};                                                         // k binary folds: beta^(2^f), shift^(2^f) — one launch for all of them
+      launch_tree_levels(c->d_p2, tree, g, c->d_sync, s);
+      hipLaunchKernelGGL(fri_transcript_kernel, dim3(1), dim3(4), 0, s, c->d_p2, dChSt, tree + 4 * (2 * g - 2), dFri + 16 * j);
+      FoldParams fp{};                                                         // k binary folds: beta^(2^f) (device), shift^(2^f) — one launch for all of them
       for (int f = 0; f < k; f++) {
-        fp.beta_m[f] = bb::e_to_mont(beta);
         fp.half_shift_inv_m[f] = bb::to_mont(bb::inv(bb::mul(2, shift)));
         shift = bb::mul(shift, shift);
-        beta = h_e_mul(beta, beta);
       }
       uint32_t* dst;
       HIP_OK(ar.take(&dst, 4 * g));
-      if (k == 1) hipLaunchKernelGGL(fri_fold_k_kernel<1>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dst);
-      else if (k == 2) hipLaunchKernelGGL(fri_fold_k_kernel<2>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dst);
-      else hipLaunchKernelGGL(fri_fold_k_kernel<3>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dst);
+      const E4* dBeta = reinterpret_cast<const E4*>(dFri + 16 * j + 4);
+      if (k == 1) hipLaunchKernelGGL(fri_fold_k_kernel<1>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dBeta, dst);
+      else if (k == 2) hipLaunchKernelGGL(fri_fold_k_kernel<2>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dBeta, dst);
+      else hipLaunchKernelGGL(fri_fold_k_kernel<3>, dim3(grid_for(g)), dim3(NT), 0, s, fri_layers[j], (uint32_t)log_m, log_n + 1, c->d_tw_fwd, fp, dBeta, dst);
       fri_layers[j + 1] = dst;
       log_m -= k;
     }
   }
   const uint64_t fin_n = 1ull << LOG_FINAL;
   uint32_t fin_cols[4 * 8];
+  std::vector<uint32_t> fri_out(16 * (size_t)n_layers);
+  if (n_layers) HIP_OK(hipMemcpyAsync(fri_out.data(), dFri, fri_out.size() * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(fin_cols, fri_layers[n_layers], 4 * fin_n * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
+  for (int j = 0; j < n_layers; j++) {                                       // the host's replay of the device's transcript steps
+    memcpy(lroots[j].data(), &fri_out[16 * (size_t)j], 16);
+    ch.observe_n(lroots[j].data(), 4);
+    betas[j] = ch.sample_ext();
+    const E4 bm = bb::e_to_mont(betas[j]);
+    if (memcmp(bm.c, &fri_out[16 * (size_t)j + 4], 16)) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: the device's FRI transcript diverged from the host's"}); return ZKIR_ERR_OTHER; }
+  }
   for (uint64_t i = 0; i < fin_n; i++) for (int t = 0; t < 4; t++) ch.observe(fin_cols[t * fin_n + i]);
   // grinding: smallest nonce whose absorption makes the next squeezed element end in POW_BITS zero bits (so::Challenger::grind)
   uint32_t pow_nonce = 0xFFFFFFFFu;
