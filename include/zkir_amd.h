@@ -281,9 +281,6 @@ uint32_t zkir_main_trace_width(void);             /* 152: COMMITTED main-trace c
                                                      are identically zero there: R0's limbs and the 16 storage states; zkir_amd/csrc/air.h) */
 uint32_t zkir_main_trace_width_for(uint32_t deferred);   /* 152 (deferred = 0) / 168 (VMConfig.enable_deferred_model: the storage states are committed) */
 uint32_t zkir_padded_log_n(uint64_t n_real);      /* log2 of the padded trace length: max(3, ceil(log2(n_real))) */
-/* diagnostic: measured peak rate (per second) of independent Montgomery multiplications on the current device — the integer-ALU
- * roofline the Poseidon2 kernels are priced against (they are ALU-bound, not HBM- or MFMA-bound) */
-double zkir_modmul_peak_per_s(void* hip_stream);
 /* trace columns (K1 output, n_real executed rows) -> main trace matrix (B8: zkir_main_trace_width_for(deferred) / 8 blocks [N][8]), N = 2^zkir_padded_log_n(n_real): rows past n_real are
  * padding (class "pad": state of the last executed row, cycle keeps counting).  deferred = VMConfig.enable_deferred_model of the run. */
 int zkir_main_trace_launch(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out, void* hip_stream);
@@ -304,13 +301,8 @@ int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, c
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */
 int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint32_t deferred, uint32_t* out);
-/* EXPERIMENT: zkir_main_trace_launch + zkir_lde_launch (default VM mode) with the first two blocks of the main trace never written: the
- * extension's first inverse pass generates them from the trace.  m = scratch for the main-trace matrix (as zkir_main_trace_launch's out), out = the LDE.
- * Same output as the two calls; ZKIR_ERR_ARGUMENT where it does not apply (padded log2 rows < 20 or = 21).  Measured in profiles/r04*_fused01*. */
-int zkir_commit_fused01_launch(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* hip_stream);
-/* EXPERIMENT: one strided NTT pass (stage 0 of the inverse transform over 2^log_n rows, or stage 11 of the forward one over 2^(log_n + 1)) with tile geometry `variant`
- * (ntt.hip: strided_variant_run lists them) over `width` columns: for timing the tilings side by side (scripts/time_ntt_tiles.py); the data is left partially transformed. */
-int zkir_ntt_strided_variant_launch(const zkir_stark_ctx* ctx, uint32_t* data, uint32_t width, int variant, int forward, void* hip_stream);
+/* (the measurement probes and kernel experiments the library also exports — ALU / HBM-copy peaks, the fused first blocks, the strided-pass tilings — are declared in
+ * zkir_amd_experimental.h: not part of the drop-in boundary) */
 /* Test entry points of the AIR evaluation as the quotient kernel runs it (stark_prove.inl: QuotientOps — lazy 32-bit arithmetic, 96-bit sums, one
  * accumulator per row selector), host builds of the same code; nothing in the product calls them.
  * zkir_air_eval_host: sum_c alpha^c C_c (canonical E4 -> out4) of one (row, next row) pair given as LOGICAL columns (172 main, 40 aux; canonical
@@ -340,8 +332,9 @@ int zkir_merkle_cap_launch(const zkir_stark_ctx* ctx, uint32_t* tree, uint64_t n
 typedef struct zkir_public_inputs {
   uint64_t n_real;             /* executed rows = ExecutionResult.cycles */
   uint64_t entry_point;        /* ProgramHeader.entry_point: pc of row 0 (constrained) */
-  uint32_t deferred;           /* the proof's MODE: 0 = default VM mode, 1 = VMConfig.enable_deferred_model (relaxed AIR), 2 = default mode + the I/O argument (below) */
-  uint32_t reserved;
+  uint32_t deferred;           /* the proof's MODE: 0 = default VM mode, 1 = VMConfig.enable_deferred_model (relaxed AIR), 2 = default mode + the I/O argument (below), 3 = 2 + the memory argument */
+  uint32_t fri_params;         /* the prover's parameters: num_queries | pow_bits << 16; 0 = the defaults (50 queries, 12 grinding bits).  Set with zkir_public_inputs_set_params.
+                                * They are header words 4 and 6 of the proof (observed by the transcript); a verifier with an `expect` requires exactly these. */
   uint32_t program_digest[4];  /* zkir_digest_bytes(program blob) */
   uint32_t io_digest[4];       /* zkir_digest_bytes(LE u64 words [n_inputs, inputs.., n_outputs, outputs.., halt kind, halt code, cycles]) */
   /* PROVER side only (ignored when the struct is the `expect` of a verifier): the program itself, BORROWED — set by
@@ -395,6 +388,19 @@ void zkir_digest_bytes(const uint8_t* bytes, size_t len, uint32_t out[4]);
 int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
                           uint32_t deferred, zkir_public_inputs* out);
 
+/* The prover's parameters (zkir_prover_params).  mode: the proof's mode, the same value as zkir_public_inputs.deferred (0 default VM mode, 1 deferred carry model, 2 default +
+ * the I/O argument, 3 = 2 + the memory argument).  num_queries / pow_bits: FRI queries and grinding bits, 0 = the defaults (50, 12); accepted: 50..128 queries, 12..24 bits (a
+ * proof may say more than the defaults, never less).  Conjectured FRI soundness at blow-up 2 is one bit per query + the grinding bits: 50 + 12 = 62, 84 + 16 = 100 — the
+ * capacity-4 Poseidon2 sponge (rate 8, digests of 4 x 31 bits) caps collision resistance at ~62 bits whatever these say (README: a demonstrator instance). */
+typedef struct zkir_result zkir_result;   /* the drop-in layer's handle (zkir_exec, below) */
+typedef struct zkir_prover_params {
+  uint32_t mode;
+  uint32_t num_queries;
+  uint32_t pow_bits;
+} zkir_prover_params;
+/* validates `params` (ZKIR_ERR_ARGUMENT otherwise: the ranges above; params->mode must be pub->deferred) and records the FRI parameters in pub->fri_params */
+int zkir_public_inputs_set_params(zkir_public_inputs* pub, const zkir_prover_params* params);
+
 /* Full proof of the execution whose K1 output is `trace` (pub->n_real rows; ctx built for zkir_padded_log_n(pub->n_real)).  *proof_out is a
  * malloc'ed array of u32 words (little-endian canonical field elements, format v10: layout in oracle/stark_oracle.cpp so::prove),
  * pub->program_blob must be the program that ran: every row's (pc, instruction word) is looked up in its code table, and a run that executes
@@ -406,8 +412,13 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* program_blob
 int zkir_prove(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, const zkir_public_inputs* pub, uint32_t** proof_out, uint64_t* proof_words,
                float* stage_ms, void* hip_stream);
 void zkir_proof_free(uint32_t* proof);
-uint32_t zkir_proof_num_queries(void);
-uint32_t zkir_proof_version(void);
+/* SURVEY 8(b)'s shape of the call: the WHOLE-RUN handle of zkir_exec in (enable_execution_trace), the proof out as bytes (the little-endian u32 words of zkir_prove; free with
+ * zkir_proof_bytes_free).  params may be NULL (mode 0, 50 queries, 12 bits).  Makes and frees a context for the run's size: a caller proving many runs keeps one and uses zkir_prove. */
+int zkir_prove_result(const zkir_result* result, const zkir_prover_params* params, uint8_t** proof, size_t* proof_len);
+void zkir_proof_bytes_free(uint8_t* proof);
+uint32_t zkir_proof_num_queries(void);            /* the default (50) */
+uint32_t zkir_proof_version(void);                /* of modes 0 / 1 (10) */
+uint32_t zkir_proof_version_of_mode(uint32_t mode);   /* modes 2 / 3: 11 (round 5: EBREAK is a class of its own, the I/O section is in the transcript, mode 3 refuses accesses to the code segment) */
 /* Verifier of the proof of a WHOLE run (host only, no device): 0 = accepted, otherwise the number of the failed check (1-5
  * malformed, 6 public inputs differ from `expect`, 7 the run does not start in the VM's initial state (cycle 0, entry point, zero
  * registers), 8 the program carried in the proof is malformed or is not the one program_digest / entry_point name, 10 constraints at
@@ -442,7 +453,7 @@ void zkir_poseidon2_permute(uint32_t state[12]);
 void zkir_poseidon2_permute_scaled(uint32_t state[12], uint32_t rounds);
 
 /* ---- drop-in layer: VM::new + VM::run --------------------------------------------------------- */
-typedef struct zkir_result zkir_result;   /* opaque; owns host metadata + device columns */
+/* (zkir_result: the opaque handle declared above with zkir_prove_result; owns host metadata + device columns) */
 
 /* program_blob is Program::to_bytes() (program.rs:300-315).  On success the trace columns are resident
  * on the current HIP device.  Fails with ZKIR_ERR_DEVICE if no GPU is usable (no CPU fallback). */
@@ -517,6 +528,12 @@ int zkir_device_to_host(void* host_dst, const void* device_src, size_t bytes);
 int zkir_host_to_device(void* device_dst, const void* host_src, size_t bytes, void* hip_stream);
 
 const char* zkir_last_error(void);
+/* The ABI revision of this header: bumped whenever a struct layout, a buffer size or a signature of an EXISTING entry point changes (new entry points alone do not bump it).
+ *   4: zkir_prove's stage_ms is NINE floats (round 4 added the lookup stage: a caller built against eight overflows by 4 bytes)
+ *   5: zkir_public_inputs.reserved became fri_params (same offset; zero = the old behaviour); zkir_verify* compare the proof's FRI parameters with `expect`'s
+ * A binding checks zkir_abi_version() == ZKIR_AMD_ABI_VERSION when it loads the library. */
+#define ZKIR_AMD_ABI_VERSION 5u
+uint32_t zkir_abi_version(void);
 const char* zkir_version(void);
 
 #ifdef __cplusplus

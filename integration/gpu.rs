@@ -40,7 +40,7 @@ pub struct ZkirPublicInputs {
     pub n_real: u64,
     pub entry_point: u64,
     pub deferred: u32,
-    pub reserved: u32,
+    pub fri_params: u32,   // num_queries | pow_bits << 16, 0 = the defaults (zkir_public_inputs_set_params)
     pub program_digest: [u32; 4],
     pub io_digest: [u32; 4],
     pub program_blob: *const u8, // borrowed: must outlive zkir_prove

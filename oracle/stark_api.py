@@ -61,7 +61,7 @@ def lib():
 
 class PublicC(C.Structure):
     """so_public: the public inputs of a proof (observed first by the transcript, carried in the proof header)."""
-    _fields_ = [("n_real", C.c_uint64), ("deferred", C.c_uint32), ("pad", C.c_uint32), ("entry", C.c_uint64), ("prog", C.c_uint32 * 4), ("io", C.c_uint32 * 4),
+    _fields_ = [("n_real", C.c_uint64), ("deferred", C.c_uint32), ("fri", C.c_uint32), ("entry", C.c_uint64), ("prog", C.c_uint32 * 4), ("io", C.c_uint32 * 4),
                 ("blob", C.c_char_p), ("blob_len", C.c_uint64),      # the program itself (prover side): its code words are the instruction ROM
                 # mode 2 (`deferred` == 2: the default VM mode WITH the I/O argument): the tapes and the halt reason in the clear, and for a SEGMENT the
                 # WRITE / READ ecalls the run executed before its first row
@@ -84,7 +84,7 @@ class PublicC(C.Structure):
         return self
 
     def clone(self):
-        q = PublicC(self.n_real, self.deferred, 0, self.entry)
+        q = PublicC(self.n_real, self.deferred, self.fri, self.entry)
         q.prog[:] = list(self.prog); q.io[:] = list(self.io)
         if hasattr(self, "_in_ref"):
             q.set_io(self._in_ref.tolist(), self._out_ref.tolist(), (self.halt_kind, self.halt_code), self.writes_before, self.reads_before)
@@ -104,14 +104,14 @@ def io_bytes(inputs, outputs, halt_kind: int, halt_code: int, cycles: int) -> by
 
 
 def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2, 0), deferred: bool = False, entry: int | None = None, io_mode: bool = False,
-                  writes_before: int = 0, reads_before: int = 0, mem_mode: bool = False) -> PublicC:
+                  writes_before: int = 0, reads_before: int = 0, mem_mode: bool = False, num_queries: int = 0, pow_bits: int = 0) -> PublicC:
     """Public inputs of a run: halt = (kind, code) with kind 0 Ebreak / 1 Exit / 2 CycleLimit; entry defaults to the blob header's.
     io_mode = mode 2: the default VM mode with the I/O argument (the proof carries the tapes; WRITE / READ ecalls are tied to them).
     mem_mode = mode 3: mode 2 with the memory argument (loads and stores constrained, every access tied to a consistent memory; the proof carries the touched cells)."""
     if entry is None:
         entry = int.from_bytes(blob[12:16], "little") if len(blob) >= 16 else 0x1000
     assert not (deferred and (io_mode or mem_mode)), "the I/O and memory arguments are stated for the default VM mode"
-    p = PublicC(n_real, 3 if mem_mode else 2 if io_mode else int(deferred), 0, entry)
+    p = PublicC(n_real, 3 if mem_mode else 2 if io_mode else int(deferred), (int(num_queries) & 0xFFFF) | (int(pow_bits) << 16), entry)      # fri: the prover's parameters, 0 = 50 queries + 12 bits
     p.set_blob(blob)
     p.set_io(list(inputs), list(outputs), halt, writes_before, reads_before)
     p.prog[:] = [int(x) for x in digest_bytes(blob)]

@@ -201,6 +201,10 @@ static const int W_MAIN_IO = 180;
 enum { C_F2 = 172, C_RL = 173, C_RE = 174, C_FH = 175, C_H0 = 176, C_H1 = 177, C_OC = 178, C_IC = 179 };
 static const int K_ECALL = 15;                                     // class id of the ECALL word in modes 2 / 3 (the ROM tuple's opclass); modes 0 / 1: "other"
 static const uint32_t OP_ECALL = 0x50;
+// (round 5, format v11) EBREAK in modes 2 / 3: a class id NO selector carries, so constraint 4 (sum_k k K_k = opclass on an executed row) cannot hold on an EBREAK row — the
+// VM halts there (execute.rs:667): only the halt row, whose class is not the word's, can sit on it.  Modes 0 / 1: "other" (sequential, one free value), as in v10.
+static const int K_EBREAK = 21;
+static const uint32_t OP_EBREAK = 0x51;
 // ---- MODE 3 (round 4): mode 2 WITH the memory argument — the ten loads and stores (execute.rs:477-575, memory.rs:86-505) are classes of their own (ld = 16, st = 17)
 // and every access is tied to a consistent memory by an offline memory check (Blum et al.) over aligned 8-byte CELLS: a load / store row READS the tuple
 // (cell address, last-access time, the cell's 8 bytes) and WRITES (cell address, its own cycle + 1, the new 8 bytes) — new = old on loads, old with the accessed
@@ -335,6 +339,10 @@ struct Public {
   // last access (cycle + 1).  The prover reads them off its memory replay (main_trace) and the proof carries them; the verifier forms both ends of the memory check.
   struct Cell { uint64_t addr, bytes; uint32_t t; };
   std::vector<Cell> cells;
+  // ---- prover parameters (round 5): FRI queries and grinding bits, 0 = the defaults.  Carried in the header (words 4 and 6) and observed by the transcript with it.
+  uint32_t fri = 0;          // num_queries | pow_bits << 16
+  int num_queries() const { return (fri & 0xFFFF) ? (int)(fri & 0xFFFF) : 50; }
+  int pow_bits() const { return (fri >> 16) ? (int)(fri >> 16) : 12; }
   int mode() const { return (int)deferred; }
   bool has_io() const { return deferred >= 2; }
   bool has_mem() const { return deferred == 3; }
@@ -362,6 +370,7 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
 
 static inline F opclass_of(uint32_t op, int mode = 0) {
   if (op == OP_ECALL && mode >= 2) return K_ECALL;
+  if (op == OP_EBREAK && mode >= 2) return K_EBREAK;
   if (mode == 3 && is_load(op)) return K_LD;
   if (mode == 3 && is_store(op)) return K_ST;
   if (mode == 3 && is_logic(op)) return K_LG;
@@ -428,6 +437,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     }
     int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
     if (cls == K_OTH && !D) cls = (int)opclass_of(op, mode);
+    if (cls == K_EBREAK) cls = K_OTH;                         // (an EBREAK that is not the halt row — no honest run has one: the row runs as "other" and constraint 4 fails on it)
     if (cls == K_OTH && D && (opclass_of(op) == K_BRE || opclass_of(op) == K_BRU || opclass_of(op) == K_JAL || opclass_of(op) == K_JALR))
       cls = K_OJ;                                             // deferred mode: no opcode semantics, but "other" is sequential — branches and jumps run as the free-pc class
     if (cls == K_LD) col(C_KLD)[i] = 1;                       // (mode 3: loads and stores, the bitwise opcodes)
@@ -891,7 +901,11 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // =================================================================================================
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
-static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 704;
+// NUM_QUERIES / POW_BITS: the DEFAULT prover parameters (Public::num_queries / pow_bits; the accepted ranges are MIN_.. / MAX_..: a proof may say more, never less)
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 704, MAX_QUERIES = 128, MAX_POW_BITS = 24;
+// modes 0 / 1 keep format v10 word for word; modes 2 / 3 are v11 (round 5): EBREAK is a class of its own there (no row but the halt row can sit on it), mode 3 refuses stores
+// into the code segment, and a mode-2 SEGMENT's tapes enter the transcript
+static inline uint32_t proof_version(int mode) { return mode >= 2 ? 11u : 10u; }
 static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns); v9: AIR v5 (eight range lookups, 40 aux columns, the variant bit in the ROM tuple); v10: AIR v6 (172 logical columns, 152 / 168 committed)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
@@ -921,10 +935,10 @@ struct Challenger {
   // proof of work: the transcript is flushed (pending input absorbed), then the nonce is the smallest field element whose
   // absorption makes the next squeezed element end in POW_BITS zero bits; grind() returns it, check_pow() re-derives the element
   void flush() { if (!in.empty()) duplex(); out.clear(); }
-  bool check_pow(F nonce) { flush(); observe(nonce); return (sample() & ((1u << POW_BITS) - 1)) == 0; }
-  F grind() {
+  bool check_pow(F nonce, int bits = POW_BITS) { flush(); observe(nonce); return (sample() & ((1u << bits) - 1)) == 0; }
+  F grind(int bits = POW_BITS) {
     flush();
-    for (F nonce = 0;; nonce++) { Challenger c = *this; if (c.check_pow(nonce)) return nonce; }
+    for (F nonce = 0;; nonce++) { Challenger c = *this; if (c.check_pow(nonce, bits)) return nonce; }
   }
 };
 
@@ -1406,7 +1420,7 @@ static E horner_base(const std::vector<F>& coeffs, const E& z) { E acc = e_from(
 // header words 2..20 = everything both sides know before the first commitment; observed by the transcript in this order
 static void header_words(int log_n, const Public& pub, std::vector<uint32_t>& w) {
   w.clear();
-  w.push_back(PROOF_MAGIC); w.push_back(PROOF_VERSION); w.push_back(log_n); w.push_back(phys_width(pub.mode())); w.push_back(NUM_QUERIES); w.push_back(LOG_FINAL); w.push_back(POW_BITS);
+  w.push_back(PROOF_MAGIC); w.push_back(proof_version(pub.mode())); w.push_back(log_n); w.push_back(phys_width(pub.mode())); w.push_back((uint32_t)pub.num_queries()); w.push_back(LOG_FINAL); w.push_back((uint32_t)pub.pow_bits());
   w.push_back((uint32_t)(pub.n_real & 0x3FFFFFFF)); w.push_back((uint32_t)(pub.n_real >> 30)); w.push_back((uint32_t)pub.mode());
   w.push_back((uint32_t)(pub.entry & 0xFFFFF)); w.push_back((uint32_t)((pub.entry >> 20) & 0xFFFFF)); w.push_back((uint32_t)(pub.entry >> 40));
   for (int i = 0; i < 4; i++) w.push_back(pub.prog[i]);
@@ -1480,7 +1494,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   const Rom rom = rom_from_blob(pub.blob, pub.blob_len, Dm);
   w.push_back((uint32_t)pub.blob_len);
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
-  if (Dm >= 2) io_section(pub, w);                                         // the tapes and the halt reason: what the io digest is a digest of
+  if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the tapes and the halt reason: what the io digest is a digest of; (v11) fixed BEFORE the lookup challenges — a SEGMENT's tapes too, whose digest only the chain checks
   if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
   lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult, nullptr, Dm, &pt.mem_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
@@ -1610,10 +1624,10 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   }
   const std::vector<E>& fin = pt.fri.back();
   for (const E& e : fin) ch.observe_ext(e);
-  pt.pow_nonce = ch.grind();
-  const bool pow_ok = ch.check_pow(pt.pow_nonce); (void)pow_ok;
+  pt.pow_nonce = ch.grind(pub.pow_bits());
+  const bool pow_ok = ch.check_pow(pt.pow_nonce, pub.pow_bits()); (void)pow_ok;
   pt.queries.clear();
-  for (int t = 0; t < NUM_QUERIES; t++) pt.queries.push_back(ch.sample_bits(log_n));
+  for (int t = 0; t < pub.num_queries(); t++) pt.queries.push_back(ch.sample_bits(log_n));
 
   // ---- serialize: header | program (length, halfwords) | ROM multiplicities | range multiplicities (all pushed above) | trace root | aux root |
   //      quotient root | openings (main + aux at zeta, main + aux at zeta w, quotient) | FRI roots | final codeword | pow nonce | queries ----
@@ -1673,10 +1687,13 @@ static bool last_row_writes(const uint32_t* w, const F* last, int halt_kind, uin
 static int verify(const uint32_t* w, size_t len, const Public* expect, bool whole_run = true, F* states_out = nullptr, F* counters_out = nullptr) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
-  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
-  const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5];
-  if (nq != NUM_QUERIES || log_final != LOG_FINAL || w[6] != (uint32_t)POW_BITS || log_n < LOG_FINAL || log_n > 26) return 2;
+  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[9] > 3 || w[1] != proof_version((int)w[9])) return 1;
+  const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5], pow_bits = (int)w[6];
+  // the prover's parameters: what `expect` names (0 = the defaults) when there is one; otherwise anything from the defaults up (never fewer queries / bits than those)
+  if (expect ? (nq != expect->num_queries() || pow_bits != expect->pow_bits()) : (nq < NUM_QUERIES || pow_bits < POW_BITS)) return 2;
+  if (nq > MAX_QUERIES || pow_bits > MAX_POW_BITS || log_final != LOG_FINAL || log_n < LOG_FINAL || log_n > 26) return 2;
   Public pub;
+  pub.fri = (uint32_t)nq | ((uint32_t)pow_bits << 16);
   if (w[9] > 3 || Wm != phys_width((int)w[9])) return 2;                 // the committed width is the mode's (0 default, 1 deferred, 2 default + I/O)
   const int mode = (int)w[9];
   const int HW = header_words_of(mode), Wa = aux_width(mode);
@@ -1715,6 +1732,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   // (mode 2) the tapes and the halt reason the io digest is a digest of (check 50: with the cycle count — a whole run's is its row count; a chain checks the
   // digest over the total), the counters' ends (51), and the halt row named by the halt reason (52 / 53)
   IoSection io;
+  const uint32_t* io_words = w + p;
   if (mode >= 2) {
     if (!parse_io_section(w + p, len - p, io)) return 4;
     p += io.words;
@@ -1752,6 +1770,10 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
       for (int i = 0; i < 4; i++) { if (c[3 + i] > 0xFFFF) return 54; bytes |= (uint64_t)c[3 + i] << (16 * i); }
       pub.cells[k] = Public::Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), bytes, c[2]};
       if (k && pub.cells[k].addr <= pub.cells[k - 1].addr) return 54;
+      // (v11) no access to the CODE: instruction fetch is tied to the program's words (the ROM), so a store into [0x1000, 0x1000 + code_size) would change what the VM
+      // executes next (vm.rs:175: strict protection is off) but not what the AIR lets through — a mode-3 proof is of a run whose loads and stores stay off the cells
+      // that overlap the code segment, and every accessed cell is in this list (the memory check does not balance otherwise)
+      if (pub.cells[k].addr + 8 > 0x1000 && pub.cells[k].addr < 0x1000 + 4 * (uint64_t)rom.n) return 55;
     }
     p += mem_len;
   }
@@ -1783,6 +1805,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   Challenger ch;
   ch.observe_n(w + 2, HW - 2);
   ch.observe_n(troot, 4);
+  if (mode >= 2) observe_section(ch, io_words, io.words);
   if (mode == 3) observe_section(ch, mem_words, mem_len);
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
@@ -1812,7 +1835,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   std::vector<E> betas(n_layers);
   for (int j = 0; j < n_layers; j++) { ch.observe_n(lroots[j], 4); betas[j] = ch.sample_ext(); }
   for (const E& e : fin) ch.observe_ext(e);
-  if (!ch.check_pow(pow_nonce)) return 12;
+  if (!ch.check_pow(pow_nonce, pow_bits)) return 12;
   // 1. constraints at zeta:  Σ alpha^c C_c(zeta) == Q(zeta) * Z_H(zeta)
   {
     const int NC = num_constraints(mode);
@@ -1922,6 +1945,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
 // segment i failed.
 static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n, const Public* expect) {
   if (n < 1) return 40;
+  if (n == 1 && lens[0] > 9 && proofs[0][9] == 3) return verify(proofs[0], lens[0], expect, true);   // a mode-3 proof is a whole run by itself (never a segment): a "chain" of one
   std::vector<F> st((size_t)n * 2 * N_STATE), cnt((size_t)n * 4, 0);
   uint64_t total = 1;
   for (int i = 0; i < n; i++) {
@@ -1939,6 +1963,7 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
     if (memcmp(&st[(size_t)i * 2 * N_STATE], &st[(size_t)(i - 1) * 2 * N_STATE + N_STATE], N_STATE * 4)) return 42;
   if (expect) {
     if (expect->deferred != w0[9] || expect->entry != entry || memcmp(expect->prog, w0 + 13, 16) || memcmp(expect->io, w0 + 17, 16)) return 43;
+    for (int i = 0; i < n; i++) if (proofs[i][4] != (uint32_t)expect->num_queries() || proofs[i][6] != (uint32_t)expect->pow_bits()) return 43;   // every segment made with the parameters the caller expects
     if (expect->n_real != total) return 44;
   }
   if (w0[9] == 2) {
@@ -1948,7 +1973,7 @@ static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n
     auto io_at = [&](const uint32_t* w) { return HW + 1 + (size_t)(w[HW] + 1) / 2; };
     IoSection io0;
     if (!parse_io_section(w0 + io_at(w0), lens[0] - io_at(w0), io0)) return 4;
-    for (int i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
+    for (int i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || io_at(w) + io0.words > lens[i] || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
     if (cnt[0] || cnt[1]) return 51;
     for (int i = 1; i < n; i++) if (cnt[(size_t)i * 4] != cnt[(size_t)(i - 1) * 4 + 2] || cnt[(size_t)i * 4 + 1] != cnt[(size_t)(i - 1) * 4 + 3]) return 46;
     {
@@ -2041,12 +2066,12 @@ static int verify_chain_io(const uint32_t* const* proofs, const size_t* lens, in
 // C API (ctypes)
 // =================================================================================================
 extern "C" {
-struct so_public { uint64_t n_real; uint32_t deferred; uint32_t pad; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; const uint8_t* blob; uint64_t blob_len;
+struct so_public { uint64_t n_real; uint32_t deferred; uint32_t fri /* prover parameters: num_queries | pow_bits << 16, 0 = the defaults */; uint64_t entry; uint32_t prog[4]; uint32_t io[4]; const uint8_t* blob; uint64_t blob_len;
                    // mode 2 (deferred == 2): the tapes and the halt reason in the clear; for a segment, the WRITE / READ ecalls executed before its first row
                    const uint64_t* inputs; uint64_t n_inputs; const uint64_t* outputs; uint64_t n_outputs; uint32_t halt_kind; uint32_t pad2; uint64_t halt_code;
                    uint64_t writes_before, reads_before; };
 static so::Public to_pub(const so_public* p) {
-  so::Public q; q.n_real = p->n_real; q.deferred = p->deferred; q.entry = p->entry; memcpy(q.prog, p->prog, 16); memcpy(q.io, p->io, 16);
+  so::Public q; q.n_real = p->n_real; q.deferred = p->deferred; q.fri = p->fri; q.entry = p->entry; memcpy(q.prog, p->prog, 16); memcpy(q.io, p->io, 16);
   q.blob = p->blob; q.blob_len = (size_t)p->blob_len;
   q.inputs = p->inputs; q.n_in = (size_t)p->n_inputs; q.outputs = p->outputs; q.n_out = (size_t)p->n_outputs; q.halt_kind = p->halt_kind; q.halt_code = p->halt_code;
   q.writes_before = p->writes_before; q.reads_before = p->reads_before;

@@ -53,12 +53,17 @@ def basic_add_ebreak():             # vm.rs:434-461
     return _p([A(1, 0, 10), A(2, 0, 20), spec.add(3, 1, 2), EB]), [], {}
 
 
-def mem_sw_lw():                    # vm.rs:996-1070
-    return _p([A(1, 0, 0x42), A(3, 0, 0x1000), spec.sw(3, 1, 0), spec.lw(4, 3, 0), EB]), [], {}
+# The reference's own memory tests store at 0x1000 — the FIRST CODE WORD (strict protection is off, vm.rs:175; the word has been executed by then).  `base` moves the data
+# off the code segment: what a mode-3 proof needs (format v11: no touched cell may overlap the code, check 55) — OFF_CODE below.
+OFF_CODE = 0x2000
 
 
-def timestamps():                   # vm.rs:1073-1200
-    return _p([A(1, 0, 0x100), A(2, 0, 0x1000), spec.sw(2, 1, 0), A(3, 0, 0x200), spec.sw(2, 3, 4), spec.lw(4, 2, 0),
+def mem_sw_lw(base=0x1000):         # vm.rs:996-1070
+    return _p([A(1, 0, 0x42), A(3, 0, base), spec.sw(3, 1, 0), spec.lw(4, 3, 0), EB]), [], {}
+
+
+def timestamps(base=0x1000):        # vm.rs:1073-1200
+    return _p([A(1, 0, 0x100), A(2, 0, base), spec.sw(2, 1, 0), A(3, 0, 0x200), spec.sw(2, 3, 4), spec.lw(4, 2, 0),
                spec.lw(5, 2, 4), EB]), [], {}
 
 
@@ -75,8 +80,8 @@ def fib30():
     return spec.fib_program(30).to_bytes(), [], {}
 
 
-def rc_doubling():                  # vm.rs:698-752: 30 doublings then SW -> deferred range checks flushed
-    code = [A(1, 0, (1 << 15) - 1)] + [spec.add(1, 1, 1)] * 30 + [A(2, 0, 0x1000), spec.sw(2, 1, 0), EB]
+def rc_doubling(base=0x1000):       # vm.rs:698-752: 30 doublings then SW -> deferred range checks flushed
+    code = [A(1, 0, (1 << 15) - 1)] + [spec.add(1, 1, 1)] * 30 + [A(2, 0, base), spec.sw(2, 1, 0), EB]
     return _p(code), [], {"enable_range_checking": True}
 
 
@@ -324,3 +329,10 @@ def random_program(seed: int, n_instr: int = 300, range_checking: bool = False, 
     code += body + [EB] * 6
     inputs = [int(x) for x in rng.integers(0, 1 << 62, size=5)]
     return _p(code), inputs
+
+
+def off_code(name):
+    """The program `name` with its data moved off the code segment (mem_sw_lw, timestamps, rc_doubling: the reference's tests store at 0x1000); every other program as it is."""
+    f = globals()[name]
+    import inspect
+    return f(base=OFF_CODE) if "base" in inspect.signature(f).parameters else f()

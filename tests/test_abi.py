@@ -11,8 +11,8 @@ from zkir_amd import runtime as rt, spec
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "zkir_amd.h")).read()
+def _declared_functions(header="zkir_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(zkir_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,6 +23,12 @@ def test_header_symbols_are_exported():
     assert len(names) > 30
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, f"declared in include/zkir_amd.h but not exported: {missing}"
+    # the probes / experiments live in their own header: exported too, and none of them is declared in the drop-in header
+    exp = _declared_functions("zkir_amd_experimental.h")
+    assert {"zkir_modmul_peak_per_s", "zkir_hbm_copy_peak_gbs", "zkir_commit_fused01_launch", "zkir_ntt_strided_variant_launch"} <= set(exp)
+    assert not [n for n in exp if not hasattr(L, n)]
+    assert not set(exp) & set(names)
+    assert {"zkir_prove_result", "zkir_proof_bytes_free", "zkir_public_inputs_set_params", "zkir_proof_version_of_mode"} <= set(names)
 
 
 def test_struct_sizes_match_header():

@@ -536,8 +536,10 @@ def _mode3_case(which, witness="device"):
         blob, ins = pg.random_program(int(which[6:]), hashes=False)
     elif which == "memloop":                                              # a loop that walks an array: store i * 3 at A + 8 i, load it back as bytes / halfwords / words, sum, WRITE the sum
         blob, ins = spec.memory_loop_program(200).to_bytes(), []
+    elif which.endswith("_on_code"):                                      # the reference's test as written: its data at 0x1000, the first code word
+        blob, ins, cfg = getattr(pg, which[:-8])()
     else:
-        blob, ins, cfg = getattr(pg, which)()
+        blob, ins, cfg = pg.off_code(which)                               # (timestamps: the data moved off the code segment — format v11, check 55)
         cfg = {k: v for k, v in cfg.items() if k == "max_cycles"}
     ores = oracle.run(blob, list(ins), enable_execution_trace=True, **cfg)
     log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True, **cfg))
@@ -550,7 +552,7 @@ def _mode3_case(which, witness="device"):
 
 
 @pytest.mark.parametrize("witness", ["device", "host"])
-@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "alu_all", "mul_grid", "echo5", "fib30", "random3", "random5", "memloop", "q9_access_at_own_pc"])
+@pytest.mark.parametrize("which", ["timestamps", "loads_stores", "alu_all", "mul_grid", "echo5", "fib30", "random3", "random5", "memloop", "mem_sw_lw", "rc_doubling"])
 def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     """A proof in mode 3 — loads and stores constrained, every access one step of the offline memory check, the touched cells carried — from the GPU prover equals the
     oracle's word for word; both verifiers accept it and give the same verdict on tampered copies.  The memory witness comes from the device (memcheck.hip: address-major
@@ -570,6 +572,23 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
         t = proof.copy()
         t[pos] = (int(t[pos]) + 1) % P
         assert so.verify(t) != 0 and rt.verify(t) == so.verify(t), pos
+    ctx.close(); log.close()
+
+
+@pytest.mark.parametrize("witness", ["device", "host"])
+@pytest.mark.parametrize("which", ["timestamps_on_code", "mem_sw_lw_on_code", "q9_access_at_own_pc"])
+def test_mode3_refuses_accesses_to_the_code_segment(which, witness):
+    """(format v11) Instruction fetch is tied to the program's words, so a store into the code segment would change what the VM executes (strict protection is off,
+    vm.rs:175) but not what the AIR lets through: the GPU prover refuses a run whose touched cells overlap [0x1000, 0x1000 + code_size) — the reference's own memory tests as
+    written (they store at 0x1000), the Q9 program (an access at its own pc) — and both verifiers reject the oracle's proof of it with check 55."""
+    from zkir_amd import stark
+    blob, ins, ores, log, tr, opub, pub = _mode3_case(which, witness)
+    ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
+    with pytest.raises(rt.RuntimeError) as e:
+        stark.prove(ctx, tr, pub)
+    assert e.value.code == rt.ERR_ARGUMENT and "overlaps the code segment" in e.value.message
+    want = so.prove(ores.rows, opub)
+    assert so.verify(want, opub) == 55 and rt.verify(want) == 55
     ctx.close(); log.close()
 
 

@@ -401,3 +401,33 @@ def test_verify_chain_io():
     assert so.verify_chain(segs, run_pub) == 0
     assert so.verify_chain_io(segs, run_pub, [], [144], halt) == rt.verify_chain_io(segs, _pub_c(run_pub), [], [144], halt) == 0
     assert so.verify_chain_io(segs, run_pub, [], [143], halt) == rt.verify_chain_io(segs, _pub_c(run_pub), [], [143], halt) == 50
+
+
+def test_prover_parameters_are_part_of_the_statement():
+    """zkir_prover_params (round 5): FRI queries and grinding bits are the PROOF's (header words 4 and 6, observed by the transcript).  A verifier with an `expect`
+    requires exactly the expected ones (0 = the defaults, 50 + 12); without one, anything from the defaults up (never fewer).  Oracle and product verifier agree."""
+    from zkir_amd import stark
+    blob = spec.fib_program(30).to_bytes()
+    ores = oracle.run(blob, [], enable_execution_trace=True)
+    args = (len(ores.rows), blob, [], list(ores.outputs), (ores.halt_kind, ores.halt_code))
+    dflt, big = so.public_inputs(*args), so.public_inputs(*args, num_queries=84, pow_bits=16)
+    p0, p1 = so.prove(ores.rows, dflt), so.prove(ores.rows, big)
+    assert (p0[4], p0[6], p1[4], p1[6]) == (50, 12, 84, 16) and len(p1) > len(p0)
+    lay = stark.proof_layout(p1)
+    assert (lay["mode"], lay["num_queries"], lay["pow_bits"]) == (0, 84, 16)
+
+    def c_pub(p, **params):
+        out = rt.PublicInputsC(p.n_real, p.entry, p.deferred, 0)
+        out.program_digest[:] = list(p.prog); out.io_digest[:] = list(p.io)
+        return out.with_params(**params) if params else out
+    for proof, expect_o, expect_c, verdict in ((p0, dflt, c_pub(dflt), 0), (p1, big, c_pub(big, num_queries=84, pow_bits=16), 0), (p1, dflt, c_pub(dflt), 2), (p0, big, c_pub(big, num_queries=84, pow_bits=16), 2),
+                                               (p0, None, None, 0), (p1, None, None, 0)):
+        assert so.verify(proof, expect_o) == verdict and rt.verify(proof, expect_c) == verdict
+    weak = p0.copy(); weak[4] = 49                                        # fewer queries than the defaults: refused whatever else the proof says
+    assert so.verify(weak) == 2 and rt.verify(weak) == 2
+    t = p1.copy(); t[6] = 17                                              # the parameters are observed: another claim about them is another transcript
+    assert so.verify(t) != 0 and rt.verify(t) == so.verify(t)
+    for bad in (dict(num_queries=49), dict(num_queries=129), dict(pow_bits=11), dict(pow_bits=25)):
+        with pytest.raises(rt.RuntimeError) as e:
+            c_pub(dflt, **bad)
+        assert e.value.code == rt.ERR_ARGUMENT

@@ -26,6 +26,9 @@ struct zkir_result {
   void* d_block = nullptr;      // one allocation holding every trace column
   uint64_t cap_rows = 0;
   float stage_ms[4] = {0, 0, 0, 0};   // host interpretation | device allocation | H2D of the delta log | K1 + synchronisation
+  std::vector<uint8_t> program;       // the program and the input tape of the run (zkir_exec / zkir_exec_window keep a copy: zkir_prove_result needs them for the public inputs)
+  std::vector<uint64_t> inputs;
+  bool whole_run = false;             // zkir_exec: rows [0, cycles); a window / shard is a SEGMENT of a run
   // witness streams of ExecutionResult (vm.rs:54-103), expanded on the device on first request and cached
   std::mutex wmu;
   bool mem_built = false, rc_built = false, norm_built = false, sha_built = false;
@@ -57,6 +60,7 @@ extern "C" {
 
 const char* zkir_last_error(void) { return zkir::g_last_error.c_str(); }
 const char* zkir_version(void) { return "zkir_amd 0.1 (ZKIR v3.4, gfx950)"; }
+uint32_t zkir_abi_version(void) { return ZKIR_AMD_ABI_VERSION; }
 
 int zkir_interpret(const uint8_t* blob, size_t len, const uint64_t* inputs, size_t n_inputs, const zkir_vm_config* cfg, uint32_t tile_rows,
                    zkir_delta_log** out) {
@@ -332,6 +336,9 @@ static int exec_impl(const uint8_t* blob, size_t len, const uint64_t* inputs, si
   zkir_result* r = new zkir_result();
   zkir_delta_log* log = new zkir_delta_log();
   r->log = log;
+  if (blob && len) r->program.assign(blob, blob + len);
+  if (inputs && n_inputs) r->inputs.assign(inputs, inputs + n_inputs);
+  r->whole_run = row_begin == 0 && row_end == ~0ull;
   // Long traced runs stream: a second host thread uploads the finished part of the delta log and launches K1 on it while the
   // interpreter keeps running (ZKIR_EXEC_STREAM=0 turns it off).  Everything else takes the plain path: interpret, upload, fill.
   static const bool stream_ok = !(getenv("ZKIR_EXEC_STREAM") && atoi(getenv("ZKIR_EXEC_STREAM")) == 0);
@@ -654,5 +661,37 @@ int zkir_device_to_host(void* host_dst, const void* device_src, size_t bytes) {
   if (e != hipSuccess) { zkir::set_last_error({ZKIR_ERR_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)}); return ZKIR_ERR_DEVICE; }
   return ZKIR_OK;
 }
+
+// ---- prove(result, params) -> proof bytes ------------------------------------------------------------------------------
+// The whole-run handle of zkir_exec goes in, the proof comes out as BYTES (little-endian u32 words, malloc'ed: free with zkir_proof_bytes_free): the context for the
+// run's padded size is made here, the public inputs come from the handle's own log / program / input tape, the mode and the FRI parameters from `params` (NULL =
+// mode 0, 50 queries, 12 grinding bits).  A thin wrapper over zkir_public_inputs_of + zkir_public_inputs_set_params + zkir_prove: callers that prove many runs keep a
+// context and call those (the context's tables and workspace are what a repeated proof reuses).
+int zkir_prove_result(const zkir_result* res, const zkir_prover_params* params, uint8_t** proof, size_t* proof_len) {
+  if (!res || !proof || !proof_len) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove_result: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  *proof = nullptr; *proof_len = 0;
+  if (!res->whole_run || !res->log || res->program.empty() || !res->cols.cycle) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove_result: the handle must be a whole traced run made by zkir_exec (enable_execution_trace; a window / shard is a segment: zkir_prove)"});
+    return ZKIR_ERR_ARGUMENT;
+  }
+  const zkir_prover_params dflt{0, 0, 0};
+  const zkir_prover_params* pr = params ? params : &dflt;
+  zkir_public_inputs pub;
+  int rc = zkir_public_inputs_of(res->log, res->program.data(), res->program.size(), res->inputs.data(), res->inputs.size(), pr->mode, &pub);
+  if (rc != ZKIR_OK) return rc;
+  rc = zkir_public_inputs_set_params(&pub, pr);
+  if (rc != ZKIR_OK) return rc;
+  zkir_stark_ctx* ctx = nullptr;
+  rc = zkir_stark_ctx_create(zkir_padded_log_n(pub.n_real), 1, &ctx);
+  if (rc != ZKIR_OK) return rc;
+  uint32_t* words = nullptr; uint64_t n_words = 0;
+  rc = zkir_prove(ctx, &res->cols, &pub, &words, &n_words, nullptr, nullptr);
+  zkir_stark_ctx_free(ctx);
+  if (rc != ZKIR_OK) return rc;
+  *proof = reinterpret_cast<uint8_t*>(words);                     // x86-64 / gfx950 hosts are little-endian: the words ARE the bytes
+  *proof_len = (size_t)n_words * 4;
+  return ZKIR_OK;
+}
+void zkir_proof_bytes_free(uint8_t* proof) { zkir_proof_free(reinterpret_cast<uint32_t*>(proof)); }
 
 }  // extern "C"

@@ -154,12 +154,24 @@ BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP :
 // "other" is SEQUENTIAL (pc + 4) like every instruction that is not a branch or a jump.
 // AIR v6: cmn = CMOV / CMOVNZ (move if rs2 != 0), cmz = CMOVZ (move if rs2 == 0)
 enum : int { K_ADD = 0, K_ADDI = 1, K_BRE = 2, K_JAL = 3, K_OTH = 4, K_HALT = 5, K_PAD = 6, K_SUB = 7, K_BRU = 8, K_SE = 9, K_SU = 10, K_JALR = 11, K_OJ = 12, K_CMN = 13, K_CMZ = 14, N_CLASS = 15,
-             K_ECALL = 15 /* modes 2 / 3: the class id of the ECALL word; it has no column */ };
+             K_ECALL = 15 /* modes 2 / 3: the class id of the ECALL word; it has no column */,
+             K_EBREAK = 21 /* modes 2 / 3 (format v11): the class id of the EBREAK word — NO selector carries it, so I_OPCLASS cannot hold on an executed EBREAK row: the VM halts there
+                              (execute.rs:667), only the halt row (whose class is not the word's) can sit on it.  Modes 0 / 1: "other", as in v10 */ };
+// ---- prover parameters (round 5; VERDICT r4 task 6): defined ONCE here for the prover (stark_prove.inl) and the verifier (verify.cpp).  DEFAULT_*: what a zero
+// zkir_public_inputs.fri_params means; a proof may say more queries / grinding bits (up to MAX_*), never fewer than the defaults.  Conjectured FRI soundness at blow-up 2:
+// one bit per query + the grinding bits (50 + 12 = 62; 84 + 16 = 100) — the capacity-4 Poseidon2 sponge caps collision resistance at ~62 bits either way (README).
+constexpr int DEFAULT_NUM_QUERIES = 50, DEFAULT_POW_BITS = 12, MAX_NUM_QUERIES = 128, MAX_POW_BITS = 24, LOG_FINAL = 3, LOG_ARITY = 3;
+BB_HD constexpr int num_queries_of(uint32_t fri_params) { return (fri_params & 0xFFFF) ? (int)(fri_params & 0xFFFF) : DEFAULT_NUM_QUERIES; }
+BB_HD constexpr int pow_bits_of(uint32_t fri_params) { return (fri_params >> 16) ? (int)(fri_params >> 16) : DEFAULT_POW_BITS; }
+BB_HD constexpr bool fri_params_ok(uint32_t fri_params) { return num_queries_of(fri_params) >= DEFAULT_NUM_QUERIES && num_queries_of(fri_params) <= MAX_NUM_QUERIES && pow_bits_of(fri_params) >= DEFAULT_POW_BITS && pow_bits_of(fri_params) <= MAX_POW_BITS; }
+// proof format: modes 0 / 1 are v10 word for word; modes 2 / 3 are v11 (EBREAK class, the I/O section in the transcript, no access to the code segment in mode 3)
+BB_HD constexpr uint32_t proof_version(int mode) { return mode >= 2 ? 11u : 10u; }
+constexpr uint64_t CODE_BASE = 0x1000;
 BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
-                   OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50;
+                   OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50, OP_EBREAK = 0x51;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
-  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 3 && is_shift(op)) ? (uint32_t)K_SH : (mode == 3 && op == OP_MUL_) ? (uint32_t)K_MU : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (op == OP_EBREAK && mode >= 2) ? (uint32_t)K_EBREAK : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 3 && is_shift(op)) ? (uint32_t)K_SH : (mode == 3 && op == OP_MUL_) ? (uint32_t)K_MU : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;

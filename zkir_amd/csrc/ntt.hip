@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "../../include/zkir_amd.h"
+#include "../../include/zkir_amd_experimental.h"
 #include "babybear.h"
 #include "host.h"
 

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/zkir_amd.h"
+#include "../../include/zkir_amd_experimental.h"
 #include "air.h"
 #include "babybear.h"
 #include "host.h"
@@ -96,7 +97,8 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   col(C_OP) = op; col(C_FA) = fa; col(C_FB) = fb; col(C_FC) = fc; col(C_FHI) = fhi; col(C_S) = s;
   int cls = pad ? K_PAD : last ? K_HALT : K_OTH;
   if (cls == K_OTH) {
-    const int wc = (int)opclass_of(op, MODE);
+    int wc = (int)opclass_of(op, MODE);
+    if (wc == K_EBREAK) wc = K_OTH;                                               // (an EBREAK that is not the halt row: no honest run has one — the row runs as "other" and I_OPCLASS fails on it)
     if (!deferred) cls = wc;
     else if (wc == K_BRE || wc == K_JAL || wc == K_BRU || wc == K_JALR || wc == K_OJ) cls = K_OJ;     // deferred mode: no opcode semantics, but class "other" is sequential
   }
@@ -677,6 +679,33 @@ void zkir_poseidon2_permute_scaled(uint32_t state[12], uint32_t rounds) {
 }
 
 // Diagnostic: measured peak Montgomery-multiplication rate (modmul/s) of the device, used as the ALU roofline of the Poseidon2 kernels.
+// HBM copy probe: 16 bytes per lane, grid-stride, 8192 workgroups (MI355X_MICROARCH.md's float4 copy: ~6.3 TB/s of the nominal 8)
+namespace { __global__ __launch_bounds__(NT) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) dst[i] = src[i];
+} }
+double zkir_hbm_copy_peak_gbs(uint64_t bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t n = (bytes >> 14) << 10;                      // uint4 elements, a multiple of 1024
+  if (!n) return 0.0;
+  uint4 *a = nullptr, *b = nullptr;
+  if (hipMalloc((void**)&a, n * 16) != hipSuccess) return 0.0;
+  if (hipMalloc((void**)&b, n * 16) != hipSuccess) { (void)hipFree(a); return 0.0; }
+  (void)hipMemsetAsync(a, 1, n * 16, s);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const unsigned blocks = (unsigned)((n / NT) < 8192 ? (n / NT) : 8192);
+  hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(NT), 0, s, a, b, n);
+  const int reps = 10;
+  (void)hipEventRecord(e0, s);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(NT), 0, s, a, b, n);
+  (void)hipEventRecord(e1, s);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+  return ms > 0 ? (double)reps * 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9 : 0.0;
+}
+
 double zkir_modmul_peak_per_s(void* stream) {
   hipStream_t s = (hipStream_t)stream;
   uint32_t* d = nullptr;

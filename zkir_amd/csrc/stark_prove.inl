@@ -10,9 +10,9 @@ namespace {
 using bb::E4;
 
 // WMX / WTX: the largest committed width (deferred mode) — array sizes; a proof's own widths are air::committed_width(deferred) and that + WA
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, WMX = air::W_COMMITTED_MAX, WAX = air::W_AUX_MAX, WTX = WMX + WAX, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
+constexpr int LOG_FINAL = air::LOG_FINAL, WMX = air::W_COMMITTED_MAX, WAX = air::W_AUX_MAX, WTX = WMX + WAX, LOG_ARITY = air::LOG_ARITY, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;   // (queries / grinding bits: air.h, per proof)
 constexpr int N_CONSTRAINTS = air::N_CONSTRAINTS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au;                  // (the version is the mode's: air::proof_version)
 
 #ifndef DEEP_WAVES
 #define DEEP_WAVES 4
@@ -872,7 +872,7 @@ __global__ void gather_kernel(const GatherJob* __restrict__ jobs, uint32_t n_job
 }
 
 // ---- proof-of-work grinding: one candidate nonce per lane; the smallest hit wins (deterministic) ------------------------------
-__global__ __launch_bounds__(NT) void pow_grind_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ state_m, uint32_t base, uint32_t* __restrict__ best) {
+__global__ __launch_bounds__(NT) void pow_grind_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ state_m, uint32_t base, uint32_t pow_bits, uint32_t* __restrict__ best) {
   const uint32_t nonce = base + blockIdx.x * NT + threadIdx.x;
   if (nonce >= bb::P) return;
   uint32_t s[p2::T];
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(NT) void pow_grind_kernel(const p2::Consts* __restr
   for (int i = 1; i < p2::T; i++) s[i] = bb::mont_mul_lazy(state_m[i], k_in);
   s[0] = bb::mont_mul_lazy(nonce, cp->in_scale);                              // overwrite-absorb of the single pending element (canonical)
   p2::permute_scaled(s, *cp);
-  if ((bb::mont_mul(s[p2::RATE - 1], cp->out_scale) & ((1u << POW_BITS) - 1)) == 0) atomicMin(best, nonce);   // sample() takes the last rate element
+  if ((bb::mont_mul(s[p2::RATE - 1], cp->out_scale) & ((1u << pow_bits) - 1)) == 0) atomicMin(best, nonce);   // sample() takes the last rate element
 }
 
 // ---- host-side duplex challenger (Montgomery state; canonical in/out) -------------------------------------------------------
@@ -897,8 +897,20 @@ struct Challenger {
   E4 sample_ext() { E4 e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
   uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
   void flush() { if (!in.empty()) duplex(); out.clear(); }                    // so::Challenger::flush
-  bool check_pow(uint32_t nonce) { flush(); observe(nonce); return (sample() & ((1u << POW_BITS) - 1)) == 0; }
+  bool check_pow(uint32_t nonce, int pow_bits) { flush(); observe(nonce); return (sample() & ((1u << pow_bits) - 1)) == 0; }
 };
+
+// so::hash_elems on the host (the overwrite sponge of the section digests)
+void hash_elems_host(const p2::Consts& c, const uint32_t* in, size_t n, uint32_t out[4]) {
+  uint32_t st[p2::T] = {0};
+  for (size_t off = 0; off < n; off += p2::RATE) {
+    const size_t len = n - off < (size_t)p2::RATE ? n - off : (size_t)p2::RATE;
+    for (size_t i = 0; i < len; i++) st[i] = bb::to_mont(in[off + i]);
+    p2::permute(st, c);
+  }
+  if (n == 0) p2::permute(st, c);
+  for (int i = 0; i < 4; i++) out[i] = bb::from_mont(st[i]);
+}
 
 E4 h_e_mul(const E4& a, const E4& b) { return bb::e_from_mont(bb::e_mul_m(bb::e_to_mont(a), bb::e_to_mont(b))); }   // canonical in/out
 E4 h_e_pow(E4 a, uint64_t e) { E4 r{{1, 0, 0, 0}}; while (e) { if (e & 1) r = h_e_mul(r, a); a = h_e_mul(a, a); e >>= 1; } return r; }
@@ -926,7 +938,8 @@ struct StageEvents {             // RAII: released on every return path
 // the header words of a v4 proof (so::header_words): parameters, public inputs, the two boundary states read off the main trace
 void header_words(uint32_t log_n, const zkir_public_inputs& pub, const uint32_t* states, std::vector<uint32_t>& w) {      // states: 2 NS words (+ 4 counters in mode 2)
   w.clear();
-  w.insert(w.end(), {PROOF_MAGIC, PROOF_VERSION, log_n, (uint32_t)air::committed_width((int)pub.deferred), (uint32_t)NUM_QUERIES, (uint32_t)LOG_FINAL, (uint32_t)POW_BITS});
+  w.insert(w.end(), {PROOF_MAGIC, air::proof_version((int)pub.deferred), log_n, (uint32_t)air::committed_width((int)pub.deferred), (uint32_t)air::num_queries_of(pub.fri_params), (uint32_t)LOG_FINAL,
+                     (uint32_t)air::pow_bits_of(pub.fri_params)});
   w.insert(w.end(), {(uint32_t)(pub.n_real & 0x3FFFFFFF), (uint32_t)(pub.n_real >> 30), pub.deferred});
   w.insert(w.end(), {(uint32_t)(pub.entry_point & 0xFFFFF), (uint32_t)((pub.entry_point >> 20) & 0xFFFFF), (uint32_t)(pub.entry_point >> 40)});
   w.insert(w.end(), pub.program_digest, pub.program_digest + 4);
@@ -986,8 +999,9 @@ void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t
   else air_eval_host<0>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
 }
 
-uint32_t zkir_proof_num_queries(void) { return NUM_QUERIES; }
-uint32_t zkir_proof_version(void) { return PROOF_VERSION; }
+uint32_t zkir_proof_num_queries(void) { return (uint32_t)air::DEFAULT_NUM_QUERIES; }
+uint32_t zkir_proof_version(void) { return air::proof_version(0); }
+uint32_t zkir_proof_version_of_mode(uint32_t mode) { return air::proof_version((int)mode); }
 
 void zkir_proof_free(uint32_t* proof) { free(proof); }
 
@@ -1005,6 +1019,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (pub->deferred > 3) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument"}); return ZKIR_ERR_ARGUMENT; }
   const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument, 3 = 2 + the memory argument (round 4)
   const bool IO = MODE >= 2, MEM = MODE == 3;
+  if (!air::fri_params_ok(pub->fri_params)) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->fri_params (num_queries | pow_bits << 16, 0 = 50 queries + 12 bits) must name 50..128 queries and 12..24 grinding bits (zkir_public_inputs_set_params)"});
+    return ZKIR_ERR_ARGUMENT;
+  }
+  const int NUM_QUERIES = air::num_queries_of(pub->fri_params), POW_BITS = air::pow_bits_of(pub->fri_params);     // this proof's (header words 4 and 6)
   const int WM = air::committed_width(MODE), WA = air::aux_width(MODE), WT = WM + WA;     // this proof's committed main-trace / aux columns
   // (mode 3) the memory witness: computed HERE on the device (memcheck.hip) unless the caller brings one (pub->mem_old != NULL: zkir_memcheck_witness_of's host replay — the
   // independent implementation the tests compare with — or a forged one)
@@ -1048,7 +1067,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
-    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0)) * N + (size_t)NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
+    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0)) * N + (size_t)air::MAX_NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
                         (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)N * 60 + blob_len + (1u << 16) : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
@@ -1159,6 +1178,18 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   Challenger ch(c->consts);
   ch.observe_n(head.data() + 2, head.size() - 2);
   ch.observe_n(troot, 4);
+  std::vector<uint32_t> io_sec;                               // (modes 2 / 3) the tapes and the halt reason as the proof carries them — (v11) in the transcript BEFORE the lookup challenges (a segment's too: its digest only the chain checks)
+  if (IO) {
+    auto put_u64 = [&](uint64_t v) { for (int i = 0; i < 4; i++) io_sec.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); };
+    io_sec.push_back((uint32_t)pub->n_inputs); for (uint64_t i = 0; i < pub->n_inputs; i++) put_u64(pub->inputs[i]);
+    io_sec.push_back((uint32_t)pub->n_outputs); for (uint64_t i = 0; i < pub->n_outputs; i++) put_u64(pub->outputs[i]);
+    io_sec.push_back(pub->halt_kind); put_u64(pub->halt_kind == ZKIR_HALT_EXIT ? pub->halt_code : 0);
+    for (size_t at = 0; at < io_sec.size(); at += SECTION_CHUNK) {          // so::observe_section: chunk digests (host: the tapes are short; a chunk is 64 permutations)
+      uint32_t dg[4];
+      hash_elems_host(c->consts, io_sec.data() + at, std::min((size_t)SECTION_CHUNK, io_sec.size() - at), dg);
+      ch.observe_n(dg, 4);
+    }
+  }
   const uint64_t n_cells_v = cell_addr_v.size();
   std::vector<uint32_t> mem_sec;                              // (mode 3) the touched cells as the proof carries them: fixed before the lookup challenges like the multiplicities
   if (MEM) {
@@ -1166,6 +1197,15 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (uint64_t k = 0; k < n_cells_v; k++) {
       const uint64_t a = cell_addr_v[k], b = cell_bytes_v[k];
       if ((a & 7) || (a >> 40) || (k && a <= cell_addr_v[k - 1])) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the touched cells must be multiples of 8 below 2^40 in strictly increasing order"}); return ZKIR_ERR_ARGUMENT; }
+      if (a + 8 > air::CODE_BASE && a < air::CODE_BASE + 4 * (uint64_t)n_code) {
+        // (v11) instruction fetch is tied to the program's words: a store into the code would change what the VM executes next (vm.rs:175: strict protection is off) but not what
+        // the AIR lets through — mode 3 proves runs whose loads and stores stay off the cells that overlap the code segment, and both verifiers check the list (55)
+        char m[200];
+        snprintf(m, sizeof m, "zkir_prove: the run accesses memory cell 0x%llx, which overlaps the code segment [0x1000, 0x%llx): such a run has no mode-3 proof", (unsigned long long)a,
+                 (unsigned long long)(air::CODE_BASE + 4 * (uint64_t)n_code));
+        zkir::set_last_error({ZKIR_ERR_ARGUMENT, m});
+        return ZKIR_ERR_ARGUMENT;
+      }
       mem_sec.push_back((uint32_t)(a & 0xFFFFF)); mem_sec.push_back((uint32_t)((a >> 20) & 0xFFFFF)); mem_sec.push_back(cell_time_v[k]);
       for (int i = 0; i < 4; i++) mem_sec.push_back((uint32_t)((b >> (16 * i)) & 0xFFFF));
     }
@@ -1407,11 +1447,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     const uint32_t batch = 1u << 18;
     for (uint64_t base = 0; base < bb::P && pow_nonce == 0xFFFFFFFFu; base += batch) {
       HIP_OK(hipMemsetAsync(dBest, 0xFF, 4, s));
-      hipLaunchKernelGGL(pow_grind_kernel, dim3(batch / NT), dim3(NT), 0, s, c->d_p2, dState, (uint32_t)base, dBest);
+      hipLaunchKernelGGL(pow_grind_kernel, dim3(batch / NT), dim3(NT), 0, s, c->d_p2, dState, (uint32_t)base, (uint32_t)POW_BITS, dBest);
       HIP_OK(hipMemcpyAsync(&pow_nonce, dBest, 4, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
     }
-    if (pow_nonce == 0xFFFFFFFFu || !ch.check_pow(pow_nonce)) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: proof-of-work search failed"}); return ZKIR_ERR_OTHER; }
+    if (pow_nonce == 0xFFFFFFFFu || !ch.check_pow(pow_nonce, POW_BITS)) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: proof-of-work search failed"}); return ZKIR_ERR_OTHER; }
   }
   mark(8);
   std::vector<uint32_t> queries(NUM_QUERIES);
@@ -1420,12 +1460,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
   head.push_back((uint32_t)blob_len);                                         // the program: byte length, then 16-bit halfwords
   for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
-  if (IO) {                                                                   // the I/O section: the tapes and the halt reason the io digest is a digest of
-    auto put_u64 = [&](uint64_t v) { for (int i = 0; i < 4; i++) head.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); };
-    head.push_back((uint32_t)pub->n_inputs); for (uint64_t i = 0; i < pub->n_inputs; i++) put_u64(pub->inputs[i]);
-    head.push_back((uint32_t)pub->n_outputs); for (uint64_t i = 0; i < pub->n_outputs; i++) put_u64(pub->outputs[i]);
-    head.push_back(pub->halt_kind); put_u64(pub->halt_kind == ZKIR_HALT_EXIT ? pub->halt_code : 0);
-  }
+  if (IO) head.insert(head.end(), io_sec.begin(), io_sec.end());              // the I/O section: the tapes and the halt reason the io digest is a digest of
   if (MEM) head.insert(head.end(), mem_sec.begin(), mem_sec.end());           // (mode 3) the touched cells
   head.insert(head.end(), mult, mult + n_mult);                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);

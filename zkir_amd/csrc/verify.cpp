@@ -19,8 +19,8 @@
 namespace {
 
 using bb::E4;
-constexpr int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;
-constexpr uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;
+constexpr int LOG_FINAL = air::LOG_FINAL, LOG_ARITY = air::LOG_ARITY, NS = air::N_STATE, HEADER_WORDS = 21 + 2 * NS;   // (queries / grinding bits: the proof's own, air.h; the version: the mode's)
+constexpr uint32_t PROOF_MAGIC = 0x46504B5Au;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
 
@@ -56,7 +56,7 @@ struct Challenger {                                                        // du
   uint32_t sample() { if (!in.empty() || out.empty()) duplex(); const uint32_t v = out.back(); out.pop_back(); return v; }
   E4 sample_ext() { E4 e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
   uint32_t sample_bits(int b) { return sample() & ((1u << b) - 1); }
-  bool check_pow(uint32_t nonce) { if (!in.empty()) duplex(); out.clear(); observe(nonce); return (sample() & ((1u << POW_BITS) - 1)) == 0; }
+  bool check_pow(uint32_t nonce, int pow_bits) { if (!in.empty()) duplex(); out.clear(); observe(nonce); return (sample() & ((1u << pow_bits) - 1)) == 0; }
 };
 
 std::vector<int> fri_schedule(int log_n) {
@@ -275,6 +275,18 @@ int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* blob, siz
 void zkir_memcheck_witness_free(zkir_memcheck_witness* w) { delete w; }
 uint64_t zkir_memcheck_witness_n_cells(const zkir_memcheck_witness* w) { return w ? w->cell_addr.size() : 0; }
 uint64_t zkir_memcheck_witness_n_accesses(const zkir_memcheck_witness* w) { return w ? w->n_accesses : 0; }
+int zkir_public_inputs_set_params(zkir_public_inputs* pub, const zkir_prover_params* params) {
+  if (!pub || !params) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_set_params: null argument"}); return ZKIR_ERR_ARGUMENT; }
+  const uint32_t fp = (params->num_queries & 0xFFFF) | (params->pow_bits << 16);
+  if (params->mode != pub->deferred || params->num_queries > 0xFFFF || params->pow_bits > 0xFFFF || !air::fri_params_ok(fp)) {
+    zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prover_params: mode must be the public inputs' (zkir_public_inputs_of's `deferred`: 0 default, 1 deferred model, 2 + I/O argument, 3 + memory "
+                                             "argument), num_queries 0 (= 50) or 50..128, pow_bits 0 (= 12) or 12..24"});
+    return ZKIR_ERR_ARGUMENT;
+  }
+  pub->fri_params = fp;
+  return ZKIR_OK;
+}
+
 void zkir_public_inputs_set_memory(zkir_public_inputs* pub, const zkir_memcheck_witness* w) {
   if (!pub || !w) return;
   pub->deferred = 3;
@@ -293,6 +305,7 @@ uint32_t zkir_proof_state_words(void) { return NS; }
 
 int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint32_t n, const zkir_public_inputs* expect) {
   if (!proofs || !lens || n < 1) return 40;
+  if (n == 1 && proofs[0] && lens[0] > 9 && proofs[0][9] == 3) return verify_impl(proofs[0], lens[0], expect, true, nullptr, nullptr);   // a mode-3 proof is a whole run by itself (never a segment): a "chain" of one
   std::vector<uint32_t> st((size_t)n * 2 * NS), cnt((size_t)n * 4, 0);
   uint64_t total = 1;
   for (uint32_t i = 0; i < n; i++) {
@@ -311,6 +324,8 @@ int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint3
     if (memcmp(&st[(size_t)i * 2 * NS], &st[(size_t)(i - 1) * 2 * NS + NS], NS * 4)) return 42;
   if (expect) {
     if (expect->deferred != w0[9] || expect->entry_point != entry || memcmp(expect->program_digest, w0 + 13, 16) || memcmp(expect->io_digest, w0 + 17, 16)) return 43;
+    for (uint32_t i = 0; i < n; i++)                                        // every segment made with the parameters the caller expects
+      if (!air::fri_params_ok(expect->fri_params) || proofs[i][4] != (uint32_t)air::num_queries_of(expect->fri_params) || proofs[i][6] != (uint32_t)air::pow_bits_of(expect->fri_params)) return 43;
     if (expect->n_real != total) return 44;
   }
   if (w0[9] == 2) {
@@ -320,7 +335,7 @@ int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint3
     auto io_at = [&](const uint32_t* w) { return HW + 1 + ((size_t)w[HW] + 1) / 2; };
     IoSection io0;
     if (!parse_io_section(w0 + io_at(w0), (size_t)lens[0] - io_at(w0), io0)) return 4;
-    for (uint32_t i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
+    for (uint32_t i = 1; i < n; i++) { const uint32_t* w = proofs[i]; if (io_at(w) != io_at(w0) || io_at(w) + io0.words > (size_t)lens[i] || memcmp(w + io_at(w), w0 + io_at(w0), io0.words * 4)) return 45; }
     if (cnt[0] || cnt[1]) return 51;
     for (uint32_t i = 1; i < n; i++) if (cnt[(size_t)i * 4] != cnt[(size_t)(i - 1) * 4 + 2] || cnt[(size_t)i * 4 + 1] != cnt[(size_t)(i - 1) * 4 + 3]) return 46;
     {
@@ -425,7 +440,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   if (!w) return 1;
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
-  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[1] != PROOF_VERSION) return 1;
+  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[9] > 3 || w[1] != air::proof_version((int)w[9])) return 1;
   const int log_n = (int)w[2];
   if (w[9] > 3) return 2;
   const int mode = (int)w[9];                                              // 0 default, 1 deferred, 2 default + the I/O argument, 3 = 2 + the memory argument
@@ -433,7 +448,12 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   const int HW = header_words_of(mode), WA = air::aux_width(mode);
   if (!need(HW)) return 1;
   const int WM = (int)w[3], WT = WM + WA;                                  // committed main-trace columns (checked against the mode below); main + aux
-  if (w[3] != (uint32_t)air::committed_width(mode) || w[4] != (uint32_t)NUM_QUERIES || w[5] != (uint32_t)LOG_FINAL || w[6] != (uint32_t)POW_BITS || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
+  // the prover's parameters (header words 4 and 6): exactly what `expect` names (0 = the defaults) when there is one; otherwise anything from the defaults up
+  if (w[4] > (uint32_t)air::MAX_NUM_QUERIES || w[6] > (uint32_t)air::MAX_POW_BITS) return 2;
+  const int NUM_QUERIES = (int)w[4], POW_BITS = (int)w[6];
+  if (expect ? (!air::fri_params_ok(expect->fri_params) || NUM_QUERIES != air::num_queries_of(expect->fri_params) || POW_BITS != air::pow_bits_of(expect->fri_params))
+             : (NUM_QUERIES < air::DEFAULT_NUM_QUERIES || POW_BITS < air::DEFAULT_POW_BITS)) return 2;
+  if (w[3] != (uint32_t)air::committed_width(mode) || w[5] != (uint32_t)LOG_FINAL || w[2] < (uint32_t)LOG_FINAL || w[2] > 26) return 2;
   if (w[7] >= (1u << 30) || w[10] >= (1u << 20) || w[11] >= (1u << 20) || w[12] >= (1u << 24)) return 2;
   zkir_public_inputs pub;
   memset(&pub, 0, sizeof pub);
@@ -473,6 +493,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   // (mode 2) the tapes and the halt reason the io digest is a digest of: the digest with the cycle count (50; a whole run's is its row count, a chain checks the total),
   // the counters' ends (51), the halt row named by the halt reason (52 / 53)
   IoSection io;
+  const uint32_t* io_words = w + p;
   if (mode >= 2) {
     if (!parse_io_section(w + p, (size_t)len - p, io)) return 4;
     p += io.words;
@@ -506,6 +527,9 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       for (int i = 0; i < 4; i++) { if (c[3 + i] > 0xFFFF) return 54; bytes |= (uint64_t)c[3 + i] << (16 * i); }
       cells[k] = Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), bytes, c[2]};
       if (k && cells[k].addr <= cells[k - 1].addr) return 54;
+      // (v11, check 55) no access to the CODE: instruction fetch is tied to the program's words, so a store into [0x1000, 0x1000 + code_size) would change what the VM executes
+      // next (vm.rs:175) but not what the AIR lets through — every accessed cell is in this list (the memory check does not balance otherwise), and none may overlap the code
+      if (cells[k].addr + 8 > air::CODE_BASE && cells[k].addr < air::CODE_BASE + 4 * (uint64_t)n_code) return 55;
     }
     p += mem_len;
   }
@@ -538,6 +562,8 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   Challenger ch;
   ch.observe_n(w + 2, (size_t)HW - 2);
   ch.observe_n(troot, 4);
+  if (mode >= 2)                                                           // (v11) the tapes and the halt reason, fixed before the lookup challenges (a segment's too) — so::observe_section
+    for (size_t at = 0; at < io.words; at += 512) { uint32_t dg[4]; hash_elems(io_words + at, io.words - at < 512 ? io.words - at : 512, dg); ch.observe_n(dg, 4); }
   if (mode == 3)                                                           // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section)
     for (size_t at = 0; at < mem_len; at += 512) { uint32_t dg[4]; hash_elems(mem_words + at, mem_len - at < 512 ? mem_len - at : 512, dg); ch.observe_n(dg, 4); }
   ch.observe_n(rom_mult, n_code);
@@ -625,7 +651,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   std::vector<E4> betas(n_layers);
   for (int j = 0; j < n_layers; j++) { ch.observe_n(lroots[j], 4); betas[j] = bb::e_to_mont(ch.sample_ext()); }
   ch.observe_n(w + at_fin, 4 * n_fin);
-  if (!ch.check_pow(pow_nonce)) return 12;
+  if (!ch.check_pow(pow_nonce, POW_BITS)) return 12;
   // ---- 1. constraints at zeta: sum_c alpha^c C_c(zeta) == Q(zeta) Z_H(zeta) ----
   const uint32_t wn = bb::root_of_unity(log_n), wn_m = bb::to_mont(wn);
   {

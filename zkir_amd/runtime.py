@@ -84,8 +84,12 @@ class NormColumnsC(C.Structure):
                                          "carry0", "carry1")]
 
 
+class ProverParamsC(C.Structure):             # zkir_prover_params
+    _fields_ = [("mode", C.c_uint32), ("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
+
+
 class PublicInputsC(C.Structure):             # zkir_public_inputs
-    _fields_ = [("n_real", C.c_uint64), ("entry_point", C.c_uint64), ("deferred", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("n_real", C.c_uint64), ("entry_point", C.c_uint64), ("deferred", C.c_uint32), ("fri_params", C.c_uint32),
                 ("program_digest", C.c_uint32 * 4), ("io_digest", C.c_uint32 * 4),
                 ("program_blob", C.c_void_p), ("program_blob_len", C.c_uint64),      # borrowed pointer (prover side): see with_program()
                 # mode 2 (`deferred` == 2: default VM mode + the I/O argument): the tapes and the halt reason in the clear (borrowed pointers: with_io()); for a SEGMENT
@@ -94,6 +98,18 @@ class PublicInputsC(C.Structure):             # zkir_public_inputs
                 ("halt_code", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64),
                 # mode 3 (`deferred` == 3: mode 2 + the memory argument): the memory witness of the run (borrowed pointers into a MemcheckWitness: with_memory())
                 ("mem_old", C.c_void_p), ("mem_told", C.c_void_p), ("cell_addr", C.c_void_p), ("cell_bytes", C.c_void_p), ("cell_time", C.c_void_p), ("n_cells", C.c_uint64)]
+
+    def with_params(self, num_queries: int = 0, pow_bits: int = 0) -> "PublicInputsC":
+        """zkir_public_inputs_set_params: the prover's FRI parameters (0 = the defaults: 50 queries, 12 grinding bits; accepted 50..128 / 12..24).  A verifier given this
+        struct as `expect` requires exactly them."""
+        pr = ProverParamsC(int(self.deferred), int(num_queries), int(pow_bits))
+        L = lib()
+        L.zkir_public_inputs_set_params.restype = C.c_int
+        L.zkir_public_inputs_set_params.argtypes = [C.c_void_p, C.c_void_p]
+        rc = L.zkir_public_inputs_set_params(C.byref(self), C.byref(pr))
+        if rc != ZKIR_OK:
+            _raise(rc)
+        return self
 
     def with_memory(self, witness: "MemcheckWitness") -> "PublicInputsC":
         """zkir_public_inputs_set_memory: mode 3 — point the struct at the run's memory witness (kept alive by the struct)."""

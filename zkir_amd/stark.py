@@ -22,18 +22,34 @@ RC_TABLE = 1024
 HEADER_WORDS = 157
 
 
+MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE     # (mode 3) LOW3 | BYTE | NIBBLE | AND | OR | XOR | LOW6 multiplicities (air.h MEM_MULT)
+
+
 def proof_layout(proof) -> dict:
-    """Word offsets inside a proof (format v5 on; the current format is zkir_proof_version()): header | program (byte length, 16-bit halfwords) | ROM multiplicities | range multiplicities |
-    trace root | aux root | quotient root | openings ..."""
-    blob_len = int(proof[HEADER_WORDS])
-    at = HEADER_WORDS + 1
+    """Word offsets inside a proof of ANY mode (word 9): header (157 words; modes 2 / 3: + the four counter words) | program (byte length, 16-bit halfwords) | modes 2 / 3: the
+    I/O section (n_in, inputs as four 16-bit pieces each, n_out, outputs, halt kind, halt code) | mode 3: the touched cells (n, 7 words a cell) | ROM multiplicities | range
+    multiplicities | mode 3: the LOW3 .. LOW6 multiplicities | trace root | aux root | quotient root | openings ...  (oracle/stark_oracle.cpp so::prove is the layout's definition)."""
+    mode = int(proof[9])
+    at = HEADER_WORDS + (4 if mode >= 2 else 0)
+    blob_len = int(proof[at])
+    at += 1
     half = np.asarray(proof[at:at + (blob_len + 1) // 2], dtype=np.uint32)
     blob = np.stack([half & 0xFF, half >> 8], axis=1).astype(np.uint8).reshape(-1)[:blob_len].tobytes()
     n_rom = int.from_bytes(blob[16:20], "little") // 4 if blob_len >= 32 else 0
-    rom_mult = at + (blob_len + 1) // 2
-    troot = rom_mult + n_rom + RC_TABLE
-    return {"blob": blob, "n_rom": n_rom, "rom_mult": rom_mult, "rc_mult": rom_mult + n_rom, "trace_root": troot, "aux_root": troot + 4, "quotient_root": troot + 8,
-            "openings": troot + 12}
+    at += (blob_len + 1) // 2
+    io_at = mem_at = None
+    if mode >= 2:
+        io_at = at
+        n_in = int(proof[at]); at += 1 + 4 * n_in
+        n_out = int(proof[at]); at += 1 + 4 * n_out
+        at += 5
+    if mode == 3:
+        mem_at = at
+        at += 1 + 7 * int(proof[at])
+    rom_mult = at
+    troot = rom_mult + n_rom + RC_TABLE + (MEM_MULT if mode == 3 else 0)
+    return {"mode": mode, "num_queries": int(proof[4]), "pow_bits": int(proof[6]), "blob": blob, "n_rom": n_rom, "io_section": io_at, "mem_section": mem_at, "rom_mult": rom_mult,
+            "rc_mult": rom_mult + n_rom, "trace_root": troot, "aux_root": troot + 4, "quotient_root": troot + 8, "openings": troot + 12}
 
 
 def trace_root(proof) -> list:
