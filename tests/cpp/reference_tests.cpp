@@ -254,6 +254,41 @@ static void test_prove_modes() {
   }
 }
 
+// SURVEY 8(b)'s shape of the seam: zkir_exec -> zkir_result, zkir_prove_result(result, params) -> proof bytes; the prover parameters are part of the statement.
+static void test_prove_result_and_parameters() {
+  auto code = cat({{addi(1, 0, 0), addi(2, 0, 1), addi(3, 0, 11), add(4, 1, 2), addi(1, 2, 0), addi(2, 4, 0), addi(3, 3, -1), bne(3, 0, -16)}, write_reg(2), EXIT0});
+  const std::vector<uint8_t> blob = Program::from_code(code).to_bytes();
+  zkir_vm_config cfg{}; cfg.max_cycles = 1000000; cfg.enable_execution_trace = 1;
+  zkir_result* res = nullptr;
+  CHECK(zkir_exec(blob.data(), blob.size(), nullptr, 0, &cfg, &res) == ZKIR_OK);
+  uint8_t* bytes = nullptr; size_t len = 0;
+  CHECK(zkir_prove_result(res, nullptr, &bytes, &len) == ZKIR_OK && len % 4 == 0 && len > 4000);          // defaults: mode 0, 50 queries, 12 bits
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(bytes);
+  CHECK(w[0] == 0x46504B5Au && w[1] == zkir_proof_version() && w[4] == 50 && w[6] == 12 && w[9] == 0);
+  CHECK(zkir_verify(w, len / 4, nullptr) == 0);
+  const size_t len_default = len;
+  zkir_proof_bytes_free(bytes);
+  const zkir_prover_params big{2, 84, 16};                                                                   // mode 2 (the I/O argument), 84 queries + 16 grinding bits
+  CHECK(zkir_prove_result(res, &big, &bytes, &len) == ZKIR_OK && len > len_default);
+  w = reinterpret_cast<const uint32_t*>(bytes);
+  CHECK(w[1] == zkir_proof_version_of_mode(2) && w[4] == 84 && w[6] == 16 && w[9] == 2);
+  CHECK(zkir_verify(w, len / 4, nullptr) == 0);
+  zkir_public_inputs expect;
+  CHECK(zkir_public_inputs_of(zkir_result_delta_log(res), blob.data(), blob.size(), nullptr, 0, 2, &expect) == ZKIR_OK);
+  CHECK(zkir_verify(w, len / 4, &expect) == 2);                                                              // a verifier expecting the defaults refuses other parameters
+  CHECK(zkir_public_inputs_set_params(&expect, &big) == ZKIR_OK && zkir_verify(w, len / 4, &expect) == 0);
+  const uint64_t out144 = 144;
+  CHECK(zkir_verify_io(w, len / 4, &expect, nullptr, 0, &out144, 1, ZKIR_HALT_EXIT, 0) == 0);                 // the mode-2 proof says what the run wrote
+  zkir_proof_bytes_free(bytes);
+  const zkir_prover_params weak{0, 49, 12}, wrong_mode{1, 0, 0};
+  zkir_public_inputs p0;
+  CHECK(zkir_public_inputs_of(zkir_result_delta_log(res), blob.data(), blob.size(), nullptr, 0, 0, &p0) == ZKIR_OK);
+  CHECK(zkir_public_inputs_set_params(&p0, &weak) == ZKIR_ERR_ARGUMENT && zkir_public_inputs_set_params(&p0, &wrong_mode) == ZKIR_ERR_ARGUMENT);
+  CHECK(zkir_prove_result(res, &weak, &bytes, &len) == ZKIR_ERR_ARGUMENT && bytes == nullptr);
+  CHECK(zkir_abi_version() == ZKIR_AMD_ABI_VERSION);
+  zkir_result_free(res);
+}
+
 // A run proven in segments through the plain C ABI, as a multi-GPU caller without any HIP code of its own would: one interpretation,
 // zkir_exec_shard per row range (ranges share one row), zkir_prove per shard, zkir_verify_chain over the proofs.
 static void test_segment_proofs_through_the_c_abi() {
@@ -312,7 +347,7 @@ int main(int argc, char** argv) {
       {"test_trace_timestamp_synchronization", test_trace_timestamp_synchronization, true},
       {"test_bound_propagation_and_deferred_checks", test_bound_propagation_and_deferred_checks, true},
       {"test_deferred_carry_normalization_event", test_deferred_carry_normalization_event, true},
-      {"test_prove_and_verify", test_prove_and_verify, true}, {"test_prove_modes", test_prove_modes, true}, {"test_segment_proofs_through_the_c_abi", test_segment_proofs_through_the_c_abi, true}};
+      {"test_prove_and_verify", test_prove_and_verify, true}, {"test_prove_modes", test_prove_modes, true}, {"test_prove_result_and_parameters", test_prove_result_and_parameters, true}, {"test_segment_proofs_through_the_c_abi", test_segment_proofs_through_the_c_abi, true}};
   int ran = 0;
   for (const auto& t : tests) {
     if (t.needs_gpu && !gpu) continue;

@@ -41,4 +41,4 @@ def test_cpp_mirror_host_tests():
 def test_cpp_mirror_gpu_tests():
     _build()
     out = _run("gpu")
-    assert "26 tests, 0 failures" in out, out
+    assert "27 tests, 0 failures" in out, out

@@ -398,6 +398,34 @@ def test_proof_equals_the_oracles_at_config_size(k):
 
 
 @pytest.mark.parametrize("k", [12, 16, 20])
+def test_proof_at_the_second_parameter_set_equals_the_oracles(k):
+    """zkir_prover_params (round 5): the fib run proven with 84 FRI queries and 16 grinding bits — the GPU prover's complete proof equals the one the CPU oracle computed
+    with the same parameters (tests/golden/config_proofs.json: fib_84q_16b_proofs), says so in header words 4 and 6, and a verifier expecting the defaults refuses it."""
+    import hashlib
+    import json
+    import os
+    from zkir_amd import pipeline as pl, stark
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_proofs.json")))
+    if str(k) not in gold.get("fib_84q_16b_proofs", {}):
+        pytest.skip(f"no oracle proof at the second parameter set for 2^{k} in the fixture")
+    g = gold["fib_84q_16b_proofs"][str(k)]
+    blob = spec.fib_endless_program().to_bytes()
+    assert blob.hex() == gold["program_blob_hex"]
+    log = rt.interpret(blob, [], rt.VMConfig(max_cycles=1 << k, enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    ctx = stark.StarkContext(k)
+    pub = rt.public_inputs(log, blob, num_queries=g["num_queries"], pow_bits=g["pow_bits"])
+    proof = np.ascontiguousarray(stark.prove(ctx, tr, pub), dtype="<u4")
+    assert (int(proof[4]), int(proof[6])) == (84, 16) and len(proof) == g["words"]
+    pos = [int(i * (len(proof) - 1) // (len(g["samples"]) - 1)) for i in range(len(g["samples"]))]
+    bad = [p for p, w in zip(pos, g["samples"]) if int(proof[p]) != w]
+    assert not bad, f"proof differs from the oracle's at sampled words {bad[:8]} (of {len(proof)})"
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+    assert rt.verify(proof, pub) == 0 and rt.verify(proof) == 0 and rt.verify(proof, rt.public_inputs(log, blob)) == 2
+    ctx.close(); log.close()
+
+
+@pytest.mark.parametrize("k", [12, 16, 20])
 def test_mode2_proof_equals_the_oracles_and_says_what_was_output(k):
     """MODE 2 (the I/O argument) at the headline size (VERDICT r4 task 2): a fib run that halts by itself a few rows short of 2^k and WRITES fib(cnt + 1) mod 2^40 —
     the GPU prover's complete mode-2 proof equals the one the CPU oracle computed (tests/golden/config_proofs.json: mode2_fib_out_proofs, written by

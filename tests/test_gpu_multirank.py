@@ -34,8 +34,38 @@ def _launch(world, k, extra_env):
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--log2-rows", str(k), "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
-    return json.loads(line)
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 12_000, "bench.py prints ONE small JSON line (the driver parses it)"
+    head = json.loads(lines[0])
+    detail = json.loads([x for x in p.stderr.splitlines() if x.startswith("bench_detail: ")][-1][len("bench_detail: "):])     # the full record goes to stderr / bench_detail.json
+    for key in ("value", "n_gpus", "ms_per_step", "merkle_root"):
+        assert head[key] == detail[key], key
+    assert head.get("roofline") and head["roofline"].get("frac") is not None
+    return detail
+
+
+def test_world1_over_rccl():
+    """The nccl (= RCCL) process group for real, on a box with ONE GPU: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with
+    ZKIR_BENCH_FORCE_DIST=1 takes bench.py's whole N > 1 code path at world size 1 — init_process_group("nccl", device_id=..), the window
+    interpretation, the DEVICE all-gather of the int32 root, the cap, the f64 all-reduces, the barriers, all_gather_object /
+    broadcast_object_list / gather_object, the segment proofs and zkir_verify_chain.  The capped root of one shard is the shard's own root,
+    and it must equal the oracle's commitment of the run."""
+    k = 14
+    out = _launch(1, k, {"ZKIR_BENCH_FORCE_DIST": "1"})
+    n = 1 << k
+    pg = out["process_group"]
+    assert pg and pg["backend"] == "nccl" and pg["world_size"] == 1 and pg["forced_at_world_1"]
+    assert out["n_gpus"] == 1 and out["config"]["rows_per_gpu"] == n and out["allgather_cap_ms"] is not None
+    rows = oracle.run(spec.fib_endless_program().to_bytes(), max_cycles=n, enable_execution_trace=True).rows
+    want = list(map(int, so.commit_trace(rows, 1)))
+    assert out["merkle_roots_all_ranks"] == [want] and out["merkle_root"] == want
+    e2e = out["multi_gpu_end_to_end"]
+    assert e2e and "error" not in e2e, e2e
+    assert e2e["one_run_row_sharded"]["root"] == want
+    sp = out["segment_prove"]
+    assert sp and "error" not in sp, sp
+    assert sp["segments"] == 2 and sp["verify_chain_code"] == 0                     # rows [0, n) and the one-row tail [n - 1, n)
+    assert 0.5 < out["efficiency_vs_same_size_single_gpu"] <= 1.05
 
 
 def test_two_ranks_sharded_commitment():
@@ -81,27 +111,3 @@ def test_two_ranks_over_rccl():
     want = [so.commit_trace(rows[g * n:(g + 1) * n], 1) for g in range(2)]
     assert list(map(int, so.compress(want[0], want[1]))) == out["merkle_root"]
     assert out["multi_gpu_end_to_end"]["one_run_row_sharded"]["root"] == out["merkle_root"]
-
-
-def test_world1_over_rccl():
-    """The nccl (= RCCL) process group for real, on a box with ONE GPU: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with
-    ZKIR_BENCH_FORCE_DIST=1 takes bench.py's whole N > 1 code path at world size 1 — init_process_group("nccl", device_id=..), the window
-    interpretation, the DEVICE all-gather of the int32 root, the cap, the f64 all-reduces, the barriers, all_gather_object /
-    broadcast_object_list / gather_object, the segment proofs and zkir_verify_chain.  The capped root of one shard is the shard's own root,
-    and it must equal the oracle's commitment of the run."""
-    k = 14
-    out = _launch(1, k, {"ZKIR_BENCH_FORCE_DIST": "1"})
-    n = 1 << k
-    pg = out["process_group"]
-    assert pg and pg["backend"] == "nccl" and pg["world_size"] == 1 and pg["forced_at_world_1"]
-    assert out["n_gpus"] == 1 and out["config"]["rows_per_gpu"] == n and out["allgather_cap_ms"] is not None
-    rows = oracle.run(spec.fib_endless_program().to_bytes(), max_cycles=n, enable_execution_trace=True).rows
-    want = list(map(int, so.commit_trace(rows, 1)))
-    assert out["merkle_roots_all_ranks"] == [want] and out["merkle_root"] == want
-    e2e = out["multi_gpu_end_to_end"]
-    assert e2e and "error" not in e2e, e2e
-    assert e2e["one_run_row_sharded"]["root"] == want
-    sp = out["segment_prove"]
-    assert sp and "error" not in sp, sp
-    assert sp["segments"] == 2 and sp["verify_chain_code"] == 0                     # rows [0, n) and the one-row tail [n - 1, n)
-    assert 0.5 < out["efficiency_vs_same_size_single_gpu"] <= 1.05

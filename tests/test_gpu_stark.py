@@ -308,12 +308,14 @@ def test_two_contexts_prove_concurrently():
         c.close()
 
 
-def test_row_sharded_commitment_matches_oracle():
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_row_sharded_commitment_matches_oracle(G):
     """BASELINE configs[3] shape on one device: each row shard is filled and committed on its own (own register snapshot, own
-    LDE + Merkle subtree); the shard roots are the leaves of the top levels.  Oracle: same thing on the CPU."""
+    LDE + Merkle subtree); the shard roots are the leaves of the top log2(G) levels (zkir_merkle_cap_launch).  G = 8: the three-level cap of the 8-GPU run
+    (VERDICT r4 weak #2).  Oracle: same thing on the CPU."""
     import torch
     from zkir_amd import pipeline as pl, stark
-    log_n, G = 9, 4
+    log_n = 9
     n = 1 << log_n
     blob = spec.sha256_chain_program().to_bytes()
     log = rt.interpret(blob, config=rt.VMConfig(max_cycles=n * G, enable_execution_trace=True), tile_rows=256)
@@ -331,8 +333,10 @@ def test_row_sharded_commitment_matches_oracle():
         assert np.array_equal(root, want_roots[-1]), f"shard {g}"
         sh.close()
     top = stark.merkle_cap(ctx, torch.stack(roots)).cpu().numpy().view(np.uint32)
-    want_top = so.compress(so.compress(want_roots[0], want_roots[1]), so.compress(want_roots[2], want_roots[3]))
-    assert np.array_equal(top, want_top)
+    level = list(want_roots)
+    while len(level) > 1:
+        level = [so.compress(level[i], level[i + 1]) for i in range(0, len(level), 2)]
+    assert np.array_equal(top, level[0])
     ctx.close(); log.close()
 
 

@@ -413,12 +413,12 @@ class DeltaLog:
 
 
 def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False, io_mode: bool = False, mem_mode: bool = False,
-                  mem_witness: str = "device") -> PublicInputsC:
+                  mem_witness: str = "device", num_queries: int = 0, pow_bits: int = 0) -> PublicInputsC:
     """zkir_public_inputs_of: what a proof of this run is bound to (row count, mode, entry pc, program digest, io digest).  io_mode = mode 2: the default VM mode
     with the I/O argument (WRITE / READ ecalls tied to the tapes, which the proof then carries).  mem_mode = mode 3: mode 2 with the memory argument (loads and stores
     constrained, every access tied to a consistent memory; the proof carries the touched cells).  mem_witness = "device": zkir_prove computes the run's memory witness on the
     GPU (memcheck.hip: address-major sort + segmented scan); "host": it is computed here by the host's sequential replay (zkir_memcheck_witness_of — the independent
-    implementation; needs no device) and handed to zkir_prove."""
+    implementation; needs no device) and handed to zkir_prove.  num_queries / pow_bits: the prover's FRI parameters (zkir_prover_params; 0 = the defaults, 50 + 12)."""
     blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
     arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
     out = PublicInputsC()
@@ -429,6 +429,8 @@ def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int]
     out.with_io(list(inputs), list(log.outputs))      # the C call borrowed temporaries: re-point at arrays / bytes this struct owns
     if mem_mode and mem_witness == "host":
         out.with_memory(MemcheckWitness(log, blob))
+    if num_queries or pow_bits:
+        out.with_params(num_queries, pow_bits)
     return out.with_program(blob)
 
 
