@@ -153,7 +153,16 @@ BB_HD uint32_t sbox(uint32_t x) { return bb::reduce_2p(sbox_lazy(x)); }
 // Poseidon2 paper, appendix B), WITHOUT reductions, in 64 bits (outputs below 16 max(a,b,c,d)): on gfx950 every line is one
 // full-rate v_lshl_add_u64 / v_mad_u64_u32, against three instructions for a modular addition.  Inputs may be lazy.
 BB_HD void m4_wide(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint64_t* y) {
+#if defined(P2_ZEXT_MAD) && defined(__HIP_DEVICE_COMPILE__)
+  // EXPERIMENT (profiles/r05_p2_mov_variants.txt): the zero-extension of a / c — a Montgomery result sits in the ODD register of its pair, and a 64-bit operand must be an
+  // even-aligned pair on gfx950, so the compiler copies it next to a register of zeros (v_mov_b32, 2 SIMD-cycles) — made by a multiplier-class instruction instead (x * 1 + 0, 4 cycles)
+  uint64_t za, zc;
+  asm("v_mad_u64_u32 %0, vcc, %1, 1, 0" : "=v"(za) : "v"(a) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, 1, 0" : "=v"(zc) : "v"(c) : "vcc");
+  const uint64_t t0 = bb::mad_wide<1>(za, b), t1 = bb::mad_wide<1>(zc, d);
+#else
   const uint64_t t0 = bb::acc_add(a, b), t1 = bb::acc_add(c, d);
+#endif
   const uint64_t t2 = bb::mad_wide<2>(t1, b), t3 = bb::mad_wide<2>(t0, d);
   const uint64_t t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;                        // a + b + 4c + 6d ; 4a + 6b + c + d
   y[0] = t3 + t5; y[1] = t5; y[2] = t2 + t4; y[3] = t4;

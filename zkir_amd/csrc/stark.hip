@@ -679,31 +679,44 @@ void zkir_poseidon2_permute_scaled(uint32_t state[12], uint32_t rounds) {
 }
 
 // Diagnostic: measured peak Montgomery-multiplication rate (modmul/s) of the device, used as the ALU roofline of the Poseidon2 kernels.
-// HBM copy probe: 16 bytes per lane, grid-stride, 8192 workgroups (MI355X_MICROARCH.md's float4 copy: ~6.3 TB/s of the nominal 8)
-namespace { __global__ __launch_bounds__(NT) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n) {
-  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) dst[i] = src[i];
+// HBM copy probe: 16 bytes per lane (MI355X_MICROARCH.md's float4 copy: ~6.3 TB/s of the nominal 8).  Four loads in flight per lane before the first store; the best of a few
+// grid sizes is reported (the figure is a property of the device, not of one launch geometry).
+namespace { typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(NT) void copy16_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride), c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride); __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
 } }
 double zkir_hbm_copy_peak_gbs(uint64_t bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint64_t n = (bytes >> 14) << 10;                      // uint4 elements, a multiple of 1024
   if (!n) return 0.0;
-  uint4 *a = nullptr, *b = nullptr;
+  u32x4 *a = nullptr, *b = nullptr;
   if (hipMalloc((void**)&a, n * 16) != hipSuccess) return 0.0;
   if (hipMalloc((void**)&b, n * 16) != hipSuccess) { (void)hipFree(a); return 0.0; }
   (void)hipMemsetAsync(a, 1, n * 16, s);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  const unsigned blocks = (unsigned)((n / NT) < 8192 ? (n / NT) : 8192);
-  hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(NT), 0, s, a, b, n);
-  const int reps = 10;
-  (void)hipEventRecord(e0, s);
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(NT), 0, s, a, b, n);
-  (void)hipEventRecord(e1, s);
-  (void)hipEventSynchronize(e1);
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
+  double best = 0.0;
+  for (unsigned want : {1024u, 2048u, 4096u, 16384u, 65536u}) {
+    const unsigned blocks = (unsigned)((n / NT) < want ? (n / NT) : want);
+    hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(NT), 0, s, a, b, n);
+    const int reps = 6;
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(NT), 0, s, a, b, n);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double gbs = ms > 0 ? (double)reps * 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9 : 0.0;
+    if (gbs > best) best = gbs;
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
-  return ms > 0 ? (double)reps * 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9 : 0.0;
+  return best;
 }
 
 double zkir_modmul_peak_per_s(void* stream) {
