@@ -93,7 +93,18 @@ extern "C" {
                   stream: *mut c_void) -> c_int;
     fn zkir_verify(proof: *const u32, words: u64, expect: *const ZkirPublicInputs) -> c_int;
     fn zkir_proof_free(proof: *mut u32);
+    // prove(result, params) -> proof bytes (the handle of zkir_exec keeps the program and the input tape)
+    fn zkir_prove_result(result: *const ZkirResult, params: *const ZkirProverParams, proof: *mut *mut u8, len: *mut usize) -> c_int;
+    fn zkir_proof_bytes_free(proof: *mut u8);
+    fn zkir_abi_version() -> u32;
 }
+
+/// zkir_prover_params: the proof's mode (0 default VM mode, 1 deferred model, 2 + the I/O argument, 3 + the memory argument) and its FRI parameters
+/// (0 = the defaults: 50 queries, 12 grinding bits; accepted 50..128 / 12..24).  They are header words of the proof: a verifier's `expect` must name the same.
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct ZkirProverParams { pub mode: u32, pub num_queries: u32, pub pow_bits: u32 }
+pub const ZKIR_AMD_ABI_VERSION: u32 = 5;
 
 /// include/zkir_amd.h return codes <-> RuntimeError (error.rs:7-37); the message text is the reference's own.
 fn map_error(code: c_int) -> RuntimeError {
@@ -134,6 +145,16 @@ impl GpuExecutionResult {
         let mut v = vec![0u64; self.cycles() as usize];
         let rc = unsafe { zkir_result_copy_column(self.handle, field, reg, v.as_mut_ptr() as *mut c_void) };
         if rc != 0 { Err(map_error(rc)) } else { Ok(v) }
+    }
+    /// `zkir_runtime::prove(&result, &params)` as SURVEY 8(b) writes it: the proof bytes of the whole run behind this handle.
+    pub fn prove_with(&self, params: &ZkirProverParams) -> Result<Vec<u8>, RuntimeError> {
+        assert_eq!(unsafe { zkir_abi_version() }, ZKIR_AMD_ABI_VERSION, "libzkir_amd.so was built from another revision of include/zkir_amd.h");
+        let (mut proof, mut len) = (std::ptr::null_mut::<u8>(), 0usize);
+        let rc = unsafe { zkir_prove_result(self.handle, params, &mut proof, &mut len) };
+        if rc != 0 { return Err(map_error(rc)); }
+        let out = unsafe { std::slice::from_raw_parts(proof, len) }.to_vec();
+        unsafe { zkir_proof_bytes_free(proof) };
+        Ok(out)
     }
     /// `prove()` of north_star: the proof words (u32 little-endian, format zkir_proof_version()) and the public inputs it is bound to.
     /// Mode 0 (default VM mode) or 1 (the deferred model), as the run was configured.

@@ -237,7 +237,7 @@ int memcheck_device(const zkir_trace_columns* trace, uint64_t n_real, const uint
   hipLaunchKernelGGL(memkey_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, *trace, n_real, keys, d_flags);
   size_t tb = tmp_bytes;
   lap("keys");
-  MC_OK(rocprim::radix_sort_keys(tmp, tb, keys, skeys, (size_t)n_real, 0, 64, s));
+  MC_OK(rocprim::radix_sort_keys(tmp, tb, keys, skeys, (size_t)n_real, 0, 63, s));      // the keys are 37 + 26 = 63 bits; the all-ones keys of the rows that are no load / store are the largest on those bits too (one digit pass fewer)
   lap("sort");
   hipLaunchKernelGGL(memelem_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, *trace, n_real, skeys, el);
   lap("elems");

@@ -1320,9 +1320,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   // ---- 2. quotient ------------------------------------------------------------------------------------------------------------
   {
-    E4 a{{1, 0, 0, 0}};
+    // (the powers run in Montgomery form: one extension product a step and no conversions — the GPU waits for this loop)
+    E4 a = bb::e_one_m();
+    const E4 alpha_m = bb::e_to_mont(alpha);
     std::vector<E4> alpha_pow(N_CONSTRAINTS);
-    for (int k = 0; k < N_CONSTRAINTS; k++) { alpha_pow[k] = bb::e_to_mont(a); a = h_e_mul(a, alpha); }
+    for (int k = 0; k < N_CONSTRAINTS; k++) { alpha_pow[k] = a; a = bb::e_mul_m(a, alpha_m); }
     int order[N_CONSTRAINTS];
     const int n_push = air::push_order(MODE, order);            // the order the quotient kernel consumes the coefficients in
     for (int k = 0; k < N_CONSTRAINTS + 2; k++) pp->alpha_seq[k] = k < n_push ? alpha_pow[order[k]] : bb::e_zero();
