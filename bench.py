@@ -174,7 +174,7 @@ def _profiled_counters(kernel: str):
                 launches, avg_us, insts, act, gui, busy, ipc = (float(x) for x in f[:7])
             except ValueError:
                 return None
-            return {"launch_us": avg_us, "insts_valu": insts, "valu_busy": busy / 100.0, "clock_ghz": gui / 8 / (avg_us * 1e-6) / 1e9,
+            return {"launch_us": avg_us, "insts_valu": insts, "gui_active": gui, "valu_busy": busy / 100.0, "clock_ghz": gui / 8 / (avg_us * 1e-6) / 1e9,
                     "fresh": None if sha is None else sha == sources_sha16(), "file": os.path.relpath(path, ROOT)}
     return None
 
@@ -199,7 +199,8 @@ def _alu_roofline(kernel: str, kernel_ms: float):
             "wave_instr_per_launch": ctr["insts_valu"], "avg_issue_cycles": c_avg, "static_valu": h["valu"],
             "static_mix": {q: cls.get(q, 0) for q in ("multiplier", "add64", "copy", "full_rate_32", "other_valu")},
             "valu_busy_profiled": ctr["valu_busy"], "clock_ghz_profiled": ctr["clock_ghz"],
-            "frac_at_profiled_clock": achieved / (SIMDS * ctr["clock_ghz"] * 1e9 / c_avg),
+            # the same fraction INSIDE the committed counter pass (its own instruction count, its own busy cycles: one run, one clock): <= 1 by construction as well
+            "frac_in_counter_pass": ctr["insts_valu"] * c_avg / (SIMDS * ctr["gui_active"] / 8.0),
             "isa_hist": os.path.relpath(hist_path, ROOT), "isa_hist_fresh": hist.get("_kernels_sha16") == sources_sha16(),
             "counters": ctr["file"], "counters_fresh": ctr["fresh"]}
 
@@ -451,7 +452,7 @@ def headline(full: dict) -> dict:
     alu = rf.get("alu")
     if isinstance(alu, dict):
         rf["alu"] = _pick(alu, "bound", "achieved", "peak", "unit", "frac", "wave_instr_per_launch", "avg_issue_cycles", "static_mix", "valu_busy_profiled",
-                          "clock_ghz_profiled", "frac_at_profiled_clock", "isa_hist_fresh", "counters_fresh")
+                          "clock_ghz_profiled", "frac_in_counter_pass", "isa_hist_fresh", "counters_fresh")
     line["roofline"] = _pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source_freshness", "algorithmic_bytes_per_launch", "kernel_ms", "alu")
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):

@@ -77,12 +77,13 @@ def test_emit_prints_one_line_and_writes_the_detail(tmp_path, monkeypatch):
 
 
 def test_alu_bound_is_a_bound():
-    """roofline.alu: sum n_i c_i with architectural issue costs (VERDICT r4 weak #5) — the fraction cannot exceed 1 at the clock the counters were taken at."""
-    alu = bench._alu_roofline("leaf_hash_kernel", None or 1.0)          # any time: only the construction is looked at here
+    """roofline.alu: sum n_i c_i with architectural issue costs.  Inside the committed counter pass (one run: its instruction count against its own busy
+    cycles) the fraction cannot exceed 1; the live `frac` is priced at the 2.4 GHz peak clock, which no box exceeds."""
+    alu = bench._alu_roofline("leaf_hash_kernel", 1.0)          # any time: only the construction is looked at here
     if alu is None:
         pytest.skip("no committed ISA histogram / counter pass under profiles/")
     assert 2.0 <= alu["avg_issue_cycles"] <= 4.0
+    assert 0.5 < alu["frac_in_counter_pass"] <= 1.0, alu
     ctr = bench._profiled_counters("leaf_hash_kernel")
     at_its_own_time = bench._alu_roofline("leaf_hash_kernel", ctr["launch_us"] * 1e-3)
-    assert 0.5 < at_its_own_time["frac_at_profiled_clock"] <= 1.0, at_its_own_time
-    assert at_its_own_time["frac"] <= at_its_own_time["frac_at_profiled_clock"] * 1.1
+    assert at_its_own_time["frac"] <= at_its_own_time["frac_in_counter_pass"] * 1.001          # (the pass ran below 2.4 GHz)

@@ -432,6 +432,71 @@ __device__ __forceinline__ void permute_quad_scaled(uint32_t* s, int l, const Co
     ext_linear_quad_scaled<false>(s, m4row, nullptr);
   }
 }
+// ---- the same permutation spread over a ROW of 16 lanes (round 5: the shortest latency) --------------------------------------------------------
+// Lane l < 12 of an aligned group of 16 holds state word l; lanes 12-15 ride along (their M4 multipliers are zero, their passive word stays zero: nothing they hold reaches
+// a real word).  Same arithmetic, same Consts and factors as permute_quad_scaled; per lane ONE S-box per full round instead of three and ONE passive word instead of
+// three, the sums over the quads / over the row by DPP rotations inside the row (direction-free: every lane adds up all of them).  A lone wave is bound by the chain of dependent
+// multiplier instructions, not by issue: ~33 instructions per full round and ~34 per partial round per lane against 75 and ~50 — about 2 us a permutation instead of
+// 4.5 (the tree tails, the FRI layers and the transcript steps are chains of such permutations: DESIGN.md 8.9b).  All 16 lanes must be active.
+template <int N>
+__device__ __forceinline__ uint64_t row_ror64(uint64_t v) {   // the value of the lane N places away in its row of 16 (rotation)
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, 0x120 + N, 0xF, 0xF, true), hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), 0x120 + N, 0xF, 0xF, true);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <bool ADD_RC>
+__device__ __forceinline__ uint32_t ext_linear_row16_scaled(uint32_t x, const uint32_t* m4row, uint32_t rc) {
+  const uint32_t v0 = quad_perm<0x00>(x), v1 = quad_perm<0x55>(x), v2 = quad_perm<0xAA>(x), v3 = quad_perm<0xFF>(x);
+  const uint64_t y = (uint64_t)v0 * m4row[0] + (uint64_t)v1 * m4row[1] + (uint64_t)v2 * m4row[2] + (uint64_t)v3 * m4row[3];       // M4 on the lane's quad (lanes 12-15: zero multipliers)
+  uint64_t t = y + row_ror64<4>(y);
+  t += row_ror64<8>(t);                                        // the sum over the four quads of the row: the column sums of circ(2 M4, M4, M4)
+  uint64_t v = y + t;
+  if (ADD_RC) v += rc;
+  return bb::mont_reduce_wide(v);
+}
+__device__ __forceinline__ void int_round_row16(int32_t& x, int64_t& w, uint64_t mask, int k, const Consts& c, int r) {
+  const int32_t s0 = sbox_signed(x);
+  uint64_t acc = (uint64_t)w;
+  acc += row_ror64<1>(acc); acc += row_ror64<2>(acc); acc += row_ror64<4>(acc); acc += row_ror64<8>(acc);       // every lane: the sum of the eleven passive words
+  const int64_t sum = bb::sacc_add((int64_t)acc, s0);
+  x = int_next_x(smad<-2>(sum, s0), c, r);
+  w = (int64_t)(((uint64_t)w << k) + ((uint64_t)sum & mask));
+}
+// s = state word l of the row's permutation (l = lane & 15; anything for l >= 12)
+__device__ __forceinline__ uint32_t permute_row16_scaled(uint32_t s, int l, const Consts& c) {
+  // (every loop fully unrolled: a lone wave waits for each round constant it loads inside the chain — ~200 cycles a scalar load, 22 + 8 of them; unrolled, the loads
+  // have static addresses and are issued ahead of the chain)
+  const int q = l & 3, li = l < T ? l : 0;                      // (li: a valid index for the lanes that ride along)
+  const uint32_t packed = l >= T ? 0u : q == 0 ? 0x03010705u : q == 1 ? 0x01010604u : q == 2 ? 0x07050301u : 0x06040101u;   // row q of M4, one byte per entry
+  const uint32_t m4row[4] = {packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF, packed >> 24};
+  s = ext_linear_row16_scaled<true>(s, m4row, c.ext0_s[li]);
+#pragma unroll
+  for (int r = 0; r < RF / 2; r++) {
+    uint32_t v = s; asm("" : "+v"(v));                          // (opaque: see permute_quad_scaled)
+    s = ext_linear_row16_scaled<false>(sbox_biased(v, c.pre_b[r][li]), m4row, 0);
+  }
+  {
+    const uint32_t word0 = (uint32_t)__shfl((int)s, 0, 16);     // every lane its own copy of word 0, whose S-box all of them run
+    int32_t x = (int32_t)word0 + c.in0_neg;
+    const bool passive = l >= 1 && l < T;
+    int64_t w = passive ? (int64_t)(int32_t)s : 0;
+    const int k = passive ? l - 1 : 0;                          // word i is multiplied by 2^(i - 1)
+    uint64_t mask = passive ? ~0ull : 0ull;
+    asm("" : "+v"(mask));                                      // (opaque: see permute_quad_scaled)
+#pragma unroll
+    for (int r = 0; r < RP - 1; r += 3) {
+      int_round_row16(x, w, mask, k, c, r);
+      int_round_row16(x, w, mask, k, c, r + 1);
+      int_round_row16(x, w, mask, k, c, r + 2);
+      w = (int64_t)bb::smont_reduce_wide(w);
+    }
+    int_round_row16(x, w, mask, k, c, RP - 1);
+    s = (uint32_t)bb::smont_reduce_wide((int64_t)((uint64_t)w + c.pr_k[li]));
+    if (l == 0) s = (uint32_t)x;
+  }
+#pragma unroll
+  for (int r = RF / 2; r < RF; r++) s = ext_linear_row16_scaled<false>(sbox_biased(s, c.pre_b[r][li]), m4row, 0);
+  return s;
+}
 #endif
 
 }  // namespace p2

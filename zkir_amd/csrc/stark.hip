@@ -499,18 +499,18 @@ __global__ __launch_bounds__(NT) void compress_kernel(const p2::Consts* __restri
   reinterpret_cast<uint4*>(out)[i] = make_uint4(bb::mont_mul(s[0], ko), bb::mont_mul(s[1], ko), bb::mont_mul(s[2], ko), bb::mont_mul(s[3], ko));
 }
 
-// Subtrees in ONE launch: every workgroup takes `per_wg` (a power of two <= 512) consecutive digests of the level `cur` (m digests)
+// Subtrees in ONE launch: every workgroup takes `per_wg` (a power of two <= 1024) consecutive digests of the level `cur` (m digests)
 // and walks log2(per_wg) levels up, keeping the running level in LDS (Montgomery form) and writing every level to its place in the
 // tree buffer.  Small levels are latency-bound (one Poseidon2 permutation is ~1200 dependent instructions deep), so a launch and
 // a global-memory round trip per level cost more than the hashing.  Round 5: the workgroup that FINISHES LAST (a device-scope counter, left at zero again) goes on with
-// the m / per_wg (<= 512) digests the launch produced, so everything above the last full-occupancy level is one launch (round 4: two, 17 per proof).
-constexpr uint32_t SUBTREE = 512;
-__global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restrict__ cp, uint32_t* cur, uint64_t m, uint32_t per_wg, uint32_t* counter) {
+// the m / per_wg (<= 256) digests the launch produced, so everything above the last full-occupancy level is one launch (round 4: two, 17 per proof).
+constexpr uint32_t SUBTREE = 1024, NT_SUB = 1024;                 // digests / lanes of a workgroup: 64 rows of 16 lanes = 64 permutations a pass in the row formulation
+__global__ __launch_bounds__(NT_SUB) void subtree_kernel(const p2::Consts* __restrict__ cp, uint32_t* cur, uint64_t m, uint32_t per_wg, uint32_t* counter) {
   __shared__ uint4 buf[SUBTREE];
   __shared__ uint32_t last_one;
   const uint32_t t = threadIdx.x;
   uint64_t pos0 = (uint64_t)blockIdx.x * per_wg;
-  for (uint32_t e = t; e < per_wg; e += NT) {
+  for (uint32_t e = t; e < per_wg; e += NT_SUB) {
     const uint4 v = reinterpret_cast<const uint4*>(cur)[pos0 + e];
     buf[e] = make_uint4(bb::to_mont(v.x), bb::to_mont(v.y), bb::to_mont(v.z), bb::to_mont(v.w));
   }
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
   for (uint32_t cnt = per_wg; cnt > 1; cnt >>= 1) {
     cur += 4 * m; m >>= 1; pos0 >>= 1;                         // level written by this iteration
     const uint32_t n_perm = cnt / 2;
-    if (n_perm > NT / 4) {                                     // enough permutations to give every lane its own: the throughput formulation (p2::permute_scaled,
-      const bool active = t < n_perm;                          // a fifth fewer instructions than p2::permute — on a lone wave that is a fifth less latency)
+    if (n_perm > NT_SUB / 16) {                                // more permutations than rows of lanes: one per LANE, the throughput formulation (p2::permute_scaled)
+      const bool active = t < n_perm;
       uint32_t s[p2::T];
       if (active) {
         const uint4 l = buf[2 * t], r = buf[2 * t + 1];        // Montgomery words R v -> input words F_IN v: one product with F_IN
@@ -536,18 +536,20 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
         buf[t] = make_uint4(bb::mont_mul(s[0], ko_m), bb::mont_mul(s[1], ko_m), bb::mont_mul(s[2], ko_m), bb::mont_mul(s[3], ko_m));
         reinterpret_cast<uint4*>(cur)[pos0 + t] = make_uint4(bb::mont_mul(s[0], ko), bb::mont_mul(s[1], ko), bb::mont_mul(s[2], ko), bb::mont_mul(s[3], ko));
       }
-    } else {                                                   // few permutations: one per QUAD of lanes (p2::permute_quad_scaled), ~2.3x shorter
-      const uint32_t pi = t >> 2, l = t & 3;
-      const bool active = pi < n_perm;
+    } else {                                                   // at most 64 permutations: one per ROW of 16 lanes (p2::permute_row16_scaled): the shortest chain — these levels wait for each other
+      const uint32_t pi = t >> 4, l = t & 15;
+      const bool active = pi < n_perm;                         // (whole rows)
       const uint32_t* words = reinterpret_cast<const uint32_t*>(buf);
-      uint32_t s[3] = {0, 0, 0};
-      if (active) { const uint32_t k_in = bb::from_mont(cp->in_scale); s[0] = bb::mont_mul_lazy(words[8 * pi + l], k_in); s[1] = bb::mont_mul_lazy(words[8 * pi + 4 + l], k_in); }
+      uint32_t s = 0;
+      if (active && l < 8) s = bb::mont_mul_lazy(words[8 * pi + l], bb::from_mont(cp->in_scale));       // left digest = words 0-3, right digest = words 4-7, capacity zero
       __syncthreads();
       if (active) {
-        p2::permute_quad_scaled(s, (int)l, *cp);
-        const uint32_t ko = cp->out_scale;
-        reinterpret_cast<uint32_t*>(buf)[4 * pi + l] = bb::mont_mul(s[0], bb::to_mont(ko));
-        cur[4 * (pos0 + pi) + l] = bb::mont_mul(s[0], ko);
+        s = p2::permute_row16_scaled(s, (int)l, *cp);
+        if (l < 4) {
+          const uint32_t ko = cp->out_scale;
+          reinterpret_cast<uint32_t*>(buf)[4 * pi + l] = bb::mont_mul(s, bb::to_mont(ko));
+          cur[4 * (pos0 + pi) + l] = bb::mont_mul(s, ko);
+        }
       }
     }
     __syncthreads();
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(NT) void subtree_kernel(const p2::Consts* __restric
     __syncthreads();
     if (!last_one) return;
     per_wg = (uint32_t)m; pos0 = 0;
-    for (uint32_t e = t; e < 4 * per_wg; e += NT)
+    for (uint32_t e = t; e < 4 * per_wg; e += NT_SUB)
       reinterpret_cast<uint32_t*>(buf)[e] = bb::to_mont(__hip_atomic_load(&cur[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     __syncthreads();
     goto levels;
@@ -604,9 +606,9 @@ void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n
     hipLaunchKernelGGL(compress_kernel, dim3(grid_for(m / 2)), dim3(NT), 0, s, cp, cur, m / 2, nxt);
     cur = nxt;
   }
-  if (m > 1) {                                                   // m <= 2^18: per <= 512 digests a workgroup, at most 512 workgroups, whose 512 digests the last of them finishes
+  if (m > 1) {                                                   // m <= 2^18: per <= 1024 digests a workgroup, at most 256 workgroups, whose digests the last of them finishes
     const uint32_t per = m < SUBTREE ? (uint32_t)m : SUBTREE;
-    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT), 0, s, cp, cur, m, per, counter);
+    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT_SUB), 0, s, cp, cur, m, per, counter);
   }
 }
 

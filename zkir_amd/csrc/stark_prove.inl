@@ -799,6 +799,22 @@ __global__ __launch_bounds__(NT) void fri_leaf_hash_quad_kernel(const p2::Consts
   digests[4 * i + l] = bb::mont_mul(s[0], cp->out_scale);
 }
 
+// .. and with one permutation per ROW of 16 lanes (p2::permute_row16_scaled: the shortest chain) for the smallest layers, whose few leaves wait for each other's 2^k / 2 permutations
+__global__ __launch_bounds__(NT) void fri_leaf_hash_row16_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ c, uint64_t m, uint32_t k, uint32_t* __restrict__ digests) {
+  const uint64_t g = m >> k, t = (uint64_t)blockIdx.x * NT + threadIdx.x, i = t >> 4;
+  const int l = (int)(t & 15);
+  if (i >= g) return;                                                         // whole rows leave together
+  uint32_t s = 0;
+  const uint32_t k_in = cp->in_scale, carry = cp->carry;
+  for (uint32_t u = 0; u < (1u << k); u += 2) {                               // words 0-3: the coordinates of value u, 4-7: of value u + 1, 8-11: the capacity (stays: output factor -> input factor)
+    if (l < 4) s = bb::mont_mul_lazy(c[(uint64_t)l * m + i + u * g], k_in);
+    else if (l < 8) s = bb::mont_mul_lazy(c[(uint64_t)(l - 4) * m + i + (u + 1) * g], k_in);
+    else s = bb::mont_mul_lazy(s, carry);
+    s = p2::permute_row16_scaled(s, l, *cp);
+  }
+  if (l < 4) digests[4 * i + l] = bb::mont_mul(s, cp->out_scale);
+}
+
 // one binary fold of a layer of m values: c'[i] = (c[i] + c[i+h])/2 + beta (c[i] - c[i+h]) / (2 x_i),  x_i = shift * w_m^i,  h = m / 2;
 // w_m^-i = w_2N^-(i << (log_2n - log_m)), and w^-k = -w^(N-k) for 0 < k < N (w^N = -1): the table holds w^k for k < N = 2^(log_2n - 1)
 // The K binary folds between two committed layers in ONE launch (round 4: three launches and two intermediate layers before): output i of the last fold depends on the 2^K
@@ -839,20 +855,19 @@ __global__ __launch_bounds__(NT) void fri_fold_k_kernel(const uint32_t* __restri
 
 // ---- the Fiat-Shamir step of one FRI layer ON THE DEVICE: observe the layer's root, sample beta -------------------------------------------
 // Challenger (below; so::Challenger) at this point of the transcript: nothing pending, so  observe(root[0..4)); sample_ext()  is ONE duplex — state words 0..3 overwritten
-// with the root, one permutation, beta = (st[7], st[6], st[5], st[4]) (sample() pops from the back of the eight rate words).  One quad of lanes runs it
-// (p2::permute_quad_scaled: lane l holds words l, 4 + l, 8 + l) on the challenger state the host uploaded (Montgomery words, as Challenger::st), leaves the state for the next
+// with the root, one permutation, beta = (st[7], st[6], st[5], st[4]) (sample() pops from the back of the eight rate words).  One row of lanes runs it
+// (p2::permute_row16_scaled: one row of 16 lanes, lane l holds word l) on the challenger state the host uploaded (Montgomery words, as Challenger::st), leaves the state for the next
 // layer, and writes  out[0..4) = the root, out[4..16) = beta, beta^2, beta^4 (Montgomery: what fri_fold_k_kernel multiplies by).  The host replays the same steps from
 // the roots once the whole commit phase is enqueued (the proof needs them anyway) and refuses to go on if its betas are not the device's.
 __global__ void fri_transcript_kernel(const p2::Consts* __restrict__ cp, uint32_t* __restrict__ st, const uint32_t* __restrict__ root, uint32_t* __restrict__ out) {
   __shared__ uint32_t w[p2::T];
-  const uint32_t l = threadIdx.x & 3;
+  const int l = (int)(threadIdx.x & 15);                                      // one row of 16 lanes (p2::permute_row16_scaled): lane l < 12 holds state word l
   const uint32_t k_in = bb::from_mont(cp->in_scale), ko_m = bb::to_mont(cp->out_scale);
-  const uint32_t r = root[l];
-  uint32_t s[3] = {bb::mont_mul_lazy(bb::to_mont(r), k_in), bb::mont_mul_lazy(st[4 + l], k_in), bb::mont_mul_lazy(st[8 + l], k_in)};
-  p2::permute_quad_scaled(s, (int)l, *cp);
-#pragma unroll
-  for (int b = 0; b < 3; b++) { const uint32_t v = bb::mont_mul(s[b], ko_m); st[4 * b + l] = v; w[4 * b + l] = v; }
-  out[l] = r;
+  const uint32_t r = l < 4 ? root[l] : 0u;
+  const uint32_t xm = l < 4 ? bb::to_mont(r) : l < p2::T ? st[l] : 0u;          // words 0-3 overwritten with the root, the rest of the state stays
+  uint32_t s = p2::permute_row16_scaled(bb::mont_mul_lazy(xm, k_in), l, *cp);
+  if (l < p2::T) { const uint32_t v = bb::mont_mul(s, ko_m); st[l] = v; w[l] = v; }
+  if (l < 4) out[l] = r;
   __syncthreads();
   if (threadIdx.x == 0) {
     E4 beta{{w[7], w[6], w[5], w[4]}};
@@ -1420,10 +1435,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       const uint64_t m = 1ull << log_m, g = m >> k;
       HIP_OK(ar.take(&fri_trees[j], 4 * (2 * g - 1)));
       uint32_t* tree = fri_trees[j];
-      if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
+      if (g <= (1u << 11)) hipLaunchKernelGGL(fri_leaf_hash_row16_kernel, dim3(grid_for(16 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
+      else if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
       else hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
       launch_tree_levels(c->d_p2, tree, g, c->d_sync, s);
-      hipLaunchKernelGGL(fri_transcript_kernel, dim3(1), dim3(4), 0, s, c->d_p2, dChSt, tree + 4 * (2 * g - 2), dFri + 16 * j);
+      hipLaunchKernelGGL(fri_transcript_kernel, dim3(1), dim3(16), 0, s, c->d_p2, dChSt, tree + 4 * (2 * g - 2), dFri + 16 * j);
       FoldParams fp{};                                                         // k binary folds: beta^(2^f) (device), shift^(2^f) — one launch for all of them
       for (int f = 0; f < k; f++) {
         fp.half_shift_inv_m[f] = bb::to_mont(bb::inv(bb::mul(2, shift)));
