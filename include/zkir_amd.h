@@ -402,7 +402,7 @@ typedef struct zkir_prover_params {
 int zkir_public_inputs_set_params(zkir_public_inputs* pub, const zkir_prover_params* params);
 
 /* Full proof of the execution whose K1 output is `trace` (pub->n_real rows; ctx built for zkir_padded_log_n(pub->n_real)).  *proof_out is a
- * malloc'ed array of u32 words (little-endian canonical field elements, format v10: layout in oracle/stark_oracle.cpp so::prove),
+ * malloc'ed array of u32 words (little-endian canonical field elements; format v10 in modes 0 / 1, v11 in modes 2 / 3 — zkir_proof_version_of_mode; layout in oracle/stark_oracle.cpp so::prove),
  * pub->program_blob must be the program that ran: every row's (pc, instruction word) is looked up in its code table, and a run that executes
  * anything else (self-modified code, a pc outside the code segment) is refused with ZKIR_ERR_ARGUMENT — it has no proof in this AIR.
  * released with zkir_proof_free.  stage_ms (NINE floats, nullable): main trace, LDE, trace Merkle, lookup argument (aux trace + its LDE and tree), quotient, openings, DEEP, FRI, queries.

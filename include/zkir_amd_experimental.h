@@ -13,7 +13,7 @@ double zkir_modmul_peak_per_s(void* hip_stream);
 /* diagnostic: achieved HBM bandwidth (GB/s, read + write bytes) of a 16-byte-per-lane grid-stride device-to-device copy of `bytes` bytes (rounded down to 16 KiB; two scratch
  * buffers are allocated and freed): the measured copy peak the HBM-bound stages are held against next to the nominal 8 TB/s (MI355X_MICROARCH.md: ~6.3 TB/s for this copy) */
 double zkir_hbm_copy_peak_gbs(uint64_t bytes, void* hip_stream);
-/* EXPERIMENT: zkir_main_trace_launch + zkir_lde_launch (default VM mode) with the first two blocks of the main trace never written: the
+/* EXPERIMENT (profiles/HISTORY.md, round 4): zkir_main_trace_launch + zkir_lde_launch (default VM mode) with the first two blocks of the main trace never written: the
  * extension's first inverse pass generates them from the trace.  m = scratch for the main-trace matrix (as zkir_main_trace_launch's out), out = the LDE.
  * Same output as the two calls; ZKIR_ERR_ARGUMENT where it does not apply (padded log2 rows < 20 or = 21).  Measured in profiles/r04*_fused01*. */
 int zkir_commit_fused01_launch(const zkir_stark_ctx* ctx, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* hip_stream);

@@ -178,6 +178,6 @@ struct LdeTables {
 };
 void lde_run(const LdeTables& t, uint32_t* in, uint32_t n_blocks, uint32_t* out, void* hip_stream);   // matrices in the B8 layout: n_blocks x [rows][8]
 bool strided_variant_run(const LdeTables& t, uint32_t* data, uint32_t n_blocks, int variant, bool dit, void* hip_stream);   // experiment: one strided pass, chosen tile geometry (timing only)
-// experiment: blocks 0 and 1 of `in` generated from the trace inside the first inverse pass; false = not applicable at this size (nothing launched)
+// experiment (profiles/HISTORY.md, round 4): blocks 0 and 1 of `in` generated from the trace inside the first inverse pass; false = not applicable at this size (nothing launched)
 bool lde_run_fused01(const LdeTables& t, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* in, uint32_t n_blocks, uint32_t* out, void* hip_stream);
 }  // namespace zkir

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NT) void ntt_stage_kernel(uint4* __restrict__ data,
   else { x[(uint64_t)p * 2 + h] = add4(a, b); x[(uint64_t)(p + stride) * 2 + h] = mul4(subl4(a, b), w); }
 }
 
-// ---- EXPERIMENT (round 4): the first inverse pass GENERATING its input instead of reading it — blocks 0 and 1 of the main trace (cycle, pc limbs,
+// ---- EXPERIMENT (round 4, profiles/HISTORY.md): the first inverse pass GENERATING its input instead of reading it — blocks 0 and 1 of the main trace (cycle, pc limbs,
 // the instruction's fields, the limbs of R1, R2 and R3's first: nothing but loads of the row's own trace words) are computed in the load stage from the
 // 372-B trace, so main_trace_kernel need not write them and this pass need not read them back.  Words as stark.hip: main_trace_row writes them.
 struct TraceSrc01 { zkir_trace_columns t; uint64_t n_real; };

@@ -74,7 +74,7 @@ BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
 // DEF = the deferred VM mode: decides which logical columns are committed (air.h: is_virtual) — 152 columns by default, 168 deferred.
 // The row itself is a host + device function: the kernel below runs it once per lane, zkir_main_trace_host once per row on the CPU — the same
 // code, so the CPU test suite (no GPU) checks it against the oracle column by column (tests/test_abi.py).
-// SKIP: the first SKIP blocks are not stored (experiment, DESIGN.md §9: the LDE's first pass generates them itself — zkir_lde_fused01_launch)
+// SKIP: the first SKIP blocks are not stored (experiment, profiles/HISTORY.md round 4: the LDE's first pass generates them itself — zkir_lde_fused01_launch)
 // MODE: 0 default, 1 deferred, 2 default + the I/O argument (air.h): there `io` carries the input tape and the ecall counts before the trace, `cnt` the prefix counts
 // (WRITE ecalls, READ ecalls among rows < i of THIS trace) of every row.
 // MODE 3 = mode 2 + the memory argument: mem_old / mem_told = per row the bytes of the accessed 8-byte cell before the access and the time of its previous access (zkir_memcheck_witness_of)
@@ -844,7 +844,7 @@ int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, co
   for (uint64_t i = 0; i < N; i++) main_trace_row<2>(*trace, n_real, N, i, out, &a);
   return ZKIR_OK;
 }
-// EXPERIMENT: main trace without its first two blocks + the extension whose first inverse pass generates them from the trace.
+// EXPERIMENT (profiles/HISTORY.md: round 4 against VERDICT r3 #5): main trace without its first two blocks + the extension whose first inverse pass generates them from the trace.
 // Together they are zkir_main_trace_launch + zkir_lde_launch with 128 B/row less HBM traffic; same output.  Returns ZKIR_ERR_ARGUMENT where the fused pass
 // does not apply (log_n < 20 or = 21, deferred mode).
 int zkir_commit_fused01_launch(const zkir_stark_ctx* c, const zkir_trace_columns* trace, uint64_t n_real, uint32_t* m, uint32_t width, uint32_t* out, void* stream) {
