@@ -373,3 +373,22 @@ def test_a_mode2_segment_binds_its_tapes():
         t = s.copy()
         t[at + 1] = (int(t[at + 1]) + 1) & 0xFFFF                        # the first input's low piece
         assert so.verify_segment(t)[0] != 0 and rt.verify_segment(t)[0] == so.verify_segment(t)[0]
+
+
+def test_proof_layout_walks_every_mode():
+    """zkir_amd.stark.proof_layout (it assumed a mode-0 header): on proofs of modes 0, 2 and 3 the trace root it finds is the commitment of the run's trace, the
+    program it finds is the program, and the sections it skips are where the oracle put them."""
+    from zkir_amd import stark
+    blob, ins, cfg = pg.echo5()
+    ores = oracle.run(blob, list(ins), enable_execution_trace=True)
+    for kw, mode in ((dict(), 0), (dict(io_mode=True), 2), (dict(mem_mode=True), 3)):
+        pub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), **kw)
+        pr = so.prove(ores.rows, pub)
+        lay = stark.proof_layout(pr)
+        assert lay["mode"] == mode and lay["blob"] == blob and (lay["num_queries"], lay["pow_bits"]) == (50, 12)
+        assert stark.trace_root(pr) == [int(x) for x in so.commit_trace(ores.rows, 1, pub=pub)]
+        if mode >= 2:
+            at = lay["io_section"]
+            assert int(pr[at]) == len(ins) and int(pr[at + 1 + 4 * len(ins)]) == len(ores.outputs)
+        if mode == 3:
+            assert int(pr[lay["mem_section"]]) == len(so.mem_cells(ores.rows, pub))

@@ -1113,6 +1113,22 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     memcpy(p, src, bytes);
     return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s);
   };
+  // small results the host waits for (roots, boundary states, partial sums ..): copied into PINNED staging — a copy into a pageable block is served synchronously, one
+  // host round trip per copy (the kernel timeline showed 13-29 us between consecutive 16-byte copies) — and handed to their destinations after the ONE synchronisation that follows them
+  struct Staged { void* dst; const void* src; size_t n; };
+  std::vector<Staged> staged;
+  auto d2h = [&](void* dst, const void* dsrc, size_t bytes) -> hipError_t {
+    void* h = pin.take(bytes);
+    if (!h) return hipErrorOutOfMemory;
+    staged.push_back({dst, h, bytes});
+    return hipMemcpyAsync(h, dsrc, bytes, hipMemcpyDeviceToHost, s);
+  };
+  auto sync_d2h = [&]() -> hipError_t {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) for (const Staged& x : staged) memcpy(x.dst, x.src, x.n);
+    staged.clear();
+    return e;
+  };
   uint32_t *dM, *dL, *dTree, *dQ, *dQTree, *dState, *dBest, *dBound, *dA, *dAL, *dATree, *dCode, *dMult;
   unsigned long long* dBad;
   uint4 *dSide, *dSums;
@@ -1186,12 +1202,12 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   unsigned long long bad_row = ~0ull;
   uint32_t* mult = pin.take_n<uint32_t>(n_mult);               // (pinned: read back below, and part of the proof)
   if (!mult) HIP_OK(hipErrorOutOfMemory);
-  HIP_OK(hipMemcpyAsync(troot, dTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(bound, dBound, sizeof bound, hipMemcpyDeviceToHost, s));
-  if (IO) HIP_OK(hipMemcpyAsync(&n_io, dIoCount, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(d2h(troot, dTree + 4 * (2 * N2 - 2), 16));
+  HIP_OK(d2h(bound, dBound, sizeof bound));
+  if (IO) HIP_OK(d2h(&n_io, dIoCount, 4));
   HIP_OK(hipMemcpyAsync(mult, dMult, n_mult * 4, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(&bad_row, dBad, 8, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(d2h(&bad_row, dBad, 8));
+  HIP_OK(sync_d2h());
   if (bad_row != ~0ull) {
     char m[256];
     snprintf(m, sizeof m, "zkir_prove: row %llu of the trace has no proof in this AIR: its (pc, instruction word) is not in the program's code table (self-modified code, "
@@ -1326,8 +1342,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     hipLaunchKernelGGL(scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dA, N, dSums);
     rc = lde_launch(c, dA, WA, dAL, /*mont_out=*/false, s); if (rc) return rc;      // the aux rows are written in Montgomery form already; the extension is linear
     rc = merkle_commit(c, dAL, WA, N2, dATree, /*mont_in=*/true, s); if (rc) return rc;
-    HIP_OK(hipMemcpyAsync(aroot, dATree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(d2h(aroot, dATree + 4 * (2 * N2 - 2), 16));
+    HIP_OK(sync_d2h());
     ch.observe_n(aroot, 4);
   }
   mark(4);
@@ -1358,8 +1374,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   else if (MODE == 2) hipLaunchKernelGGL(quotient_kernel<2>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   else hipLaunchKernelGGL(quotient_kernel<0>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   rc = merkle_commit(c, dQ, 4, N2, dQTree, /*mont_in=*/true, s); if (rc) return rc;
-  HIP_OK(hipMemcpyAsync(qroot, dQTree + 4 * (2 * N2 - 2), 16, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(d2h(qroot, dQTree + 4 * (2 * N2 - 2), 16));
+  HIP_OK(sync_d2h());
   mark(5);
   ch.observe_n(qroot, 4);
   const E4 zeta = ch.sample_ext();
@@ -1373,8 +1389,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WT + 8) / 8), dim3(NT), 0, s, dL, dAL, dQ, (uint32_t)WM / 8, (uint32_t)WA / 8, (uint64_t)N2, dW, dPart, n_chunks, (uint32_t)__builtin_ctzll(N2 / n_chunks));
   hipLaunchKernelGGL(bary_sum_kernel, dim3(((WT + 4) * 2 + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, s, dPart, (uint32_t)(WT + 4) * 2, n_chunks, dPartSum);
   std::vector<E4> part((size_t)(WT + 4) * 2);
-  HIP_OK(hipMemcpyAsync(part.data(), dPartSum, part.size() * sizeof(E4), hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(d2h(part.data(), dPartSum, part.size() * sizeof(E4)));
+  HIP_OK(sync_d2h());
   std::vector<E4> t_z(WT), t_zw(WT), q_z(4);
   {
     // the quotient's columns, over the whole coset g H_2N: scale = ((z/g)^2N - 1) / (2N);  for z = zeta*w the factor is the same because w^(2N) = 1
@@ -1458,9 +1474,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const uint64_t fin_n = 1ull << LOG_FINAL;
   uint32_t fin_cols[4 * 8];
   std::vector<uint32_t> fri_out(16 * (size_t)n_layers);
-  if (n_layers) HIP_OK(hipMemcpyAsync(fri_out.data(), dFri, fri_out.size() * 4, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(fin_cols, fri_layers[n_layers], 4 * fin_n * 4, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  if (n_layers) HIP_OK(d2h(fri_out.data(), dFri, fri_out.size() * 4));
+  HIP_OK(d2h(fin_cols, fri_layers[n_layers], 4 * fin_n * 4));
+  HIP_OK(sync_d2h());
   for (int j = 0; j < n_layers; j++) {                                       // the host's replay of the device's transcript steps
     memcpy(lroots[j].data(), &fri_out[16 * (size_t)j], 16);
     ch.observe_n(lroots[j].data(), 4);
@@ -1478,8 +1494,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (uint64_t base = 0; base < bb::P && pow_nonce == 0xFFFFFFFFu; base += batch) {
       HIP_OK(hipMemsetAsync(dBest, 0xFF, 4, s));
       hipLaunchKernelGGL(pow_grind_kernel, dim3(batch / NT), dim3(NT), 0, s, c->d_p2, dState, (uint32_t)base, (uint32_t)POW_BITS, dBest);
-      HIP_OK(hipMemcpyAsync(&pow_nonce, dBest, 4, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipStreamSynchronize(s));
+      HIP_OK(d2h(&pow_nonce, dBest, 4));
+      HIP_OK(sync_d2h());
     }
     if (pow_nonce == 0xFFFFFFFFu || !ch.check_pow(pow_nonce, POW_BITS)) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: proof-of-work search failed"}); return ZKIR_ERR_OTHER; }
   }
