@@ -876,14 +876,31 @@ __global__ void fri_transcript_kernel(const p2::Consts* __restrict__ cp, uint32_
   }
 }
 
-// ---- query gathering: job = copy `count` words src[k * stride] -> dst[k] ------------------------------------------------------
-// (mont: the source words rest in Montgomery form — rows of the LDE matrices — and enter the proof canonical)
-struct GatherJob { const uint32_t* src; uint64_t stride; uint32_t count; uint32_t dst; uint32_t mont; uint32_t pad_; };
+// ---- query gathering -------------------------------------------------------------------------------------------------------------
+// A job (one workgroup of 64 lanes) is one of three shapes (round 5: ~750 jobs a proof instead of ~15,000 one-line copies — building and uploading that list was 90 us of host time with the GPU idle):
+//   kind 0: `count` words src[k * stride] -> dst[k]                                    (a FRI leaf: the four coordinates of a value, one column apart)
+//   kind 1: `count` ROW PIECES of `width` words, src[b * stride + w] -> dst[b * width + w]  (a matrix row: 8 words out of each B8 block; the quotient's 4)
+//   kind 2: a MERKLE PATH — tree = src, `stride` = its number of leaves, `count` = the leaf index: the sibling digest (4 words) of every level, leaf level first
+// mont: the source words rest in Montgomery form (rows of the LDE matrices) and enter the proof canonical
+struct GatherJob { const uint32_t* src; uint64_t stride; uint32_t count; uint32_t dst; uint32_t mont; uint32_t kind_width; };   // kind_width = kind | width << 8
 __global__ void gather_kernel(const GatherJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ dst) {
   const uint32_t jb = blockIdx.x;
   if (jb >= n_jobs) return;
   const GatherJob g = jobs[jb];
-  for (uint32_t k = threadIdx.x; k < g.count; k += blockDim.x) { const uint32_t v = g.src[(uint64_t)k * g.stride]; dst[g.dst + k] = g.mont ? bb::from_mont(v) : v; }
+  const uint32_t kind = g.kind_width & 0xFF, width = g.kind_width >> 8;
+  if (kind == 0) {
+    for (uint32_t k = threadIdx.x; k < g.count; k += blockDim.x) { const uint32_t v = g.src[(uint64_t)k * g.stride]; dst[g.dst + k] = g.mont ? bb::from_mont(v) : v; }
+  } else if (kind == 1) {
+    for (uint32_t k = threadIdx.x; k < g.count * width; k += blockDim.x) { const uint32_t v = g.src[(uint64_t)(k / width) * g.stride + k % width]; dst[g.dst + k] = g.mont ? bb::from_mont(v) : v; }
+  } else {
+    uint32_t depth = 0;
+    for (uint64_t q = g.stride; q > 1; q >>= 1) depth++;
+    for (uint32_t k = threadIdx.x; k < 4 * depth; k += blockDim.x) {
+      const uint32_t lvl = k >> 2;                                             // level `lvl` starts 4 * (n + n/2 + .. ) = 4 * (2 n - (2 n >> lvl)) words into the tree
+      const uint64_t n = g.stride, at = 4 * (2 * n - ((2 * n) >> lvl)), sib = ((uint64_t)g.count >> lvl) ^ 1;
+      dst[g.dst + k] = g.src[at + 4 * sib + (k & 3)];
+    }
+  }
 }
 
 // ---- proof-of-work grinding: one candidate nonce per lane; the smallest hit wins (deterministic) ------------------------------
@@ -1273,7 +1290,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int j = 0; j <= air::N_TUPLE; j++) { for (int k = 0; k < 4; k++) pp->lk[air::LK_LAM + 4 * j + k] = bb::to_mont(lam.c[k]); lam = h_e_mul(lam, lambda); }
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = 0;
     pp->lk[air::LK_NIN] = IO ? bb::to_mont((uint32_t)(pub->n_inputs % bb::P)) : 0u;
-    HIP_OK(hipMemcpyAsync(dPP->lk, pp->lk, sizeof(pp->lk), hipMemcpyHostToDevice, s));
+    HIP_OK(h2d(dPP->lk, pp->lk, sizeof(pp->lk)));
     hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom, MODE);
     if (MEM) hipLaunchKernelGGL(mem_tables_kernel, dim3(grid_for(air::MEM_MULT)), dim3(NT), 0, s, dPP, dInvMem);
     E4* inv = pin.take_n<E4>((size_t)air::RC_TABLE + n_code + (MEM ? air::MEM_MULT : 0));
@@ -1329,7 +1346,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];
-    HIP_OK(hipMemcpyAsync(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16, hipMemcpyHostToDevice, s));
+    HIP_OK(h2d(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16));
     hipLaunchKernelGGL(aux_rows_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, N, dInvRc, dInvRom, dPP, dA);
     if (IO) {                                                 // the tape helpers HO | HI: zero but on the WRITE / live READ rows
       HIP_OK(hipMemsetAsync(dA + (size_t)(air::A_HO / 8) * N * 8, 0, (size_t)N * 32, s));
@@ -1363,7 +1380,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int k = 0; k < 4; k++) pp->cnt_m[k] = bb::to_mont(bound[2 * NS + k]);
     air::boundary_constants(alpha_pow.data(), pp->first_m, pp->last_m, pp->cf, pp->cl, IO ? pp->cnt_m : nullptr);
     pp->deferred = pub->deferred ? 1 : 0;
-    HIP_OK(hipMemcpyAsync(dPP, pp.get(), sizeof(ProveParams), hipMemcpyHostToDevice, s));
+    HIP_OK(h2d(dPP, pp.get(), sizeof(ProveParams)));
   }
   const uint32_t wn = bb::root_of_unity((int)log_n);
   const uint32_t gN = bb::pow(bb::GEN, N), wn_inv_m = bb::to_mont(bb::inv(wn)), w_last_inv_m = bb::to_mont(bb::inv(bb::pow(wn, pub->n_real - 1)));
@@ -1383,7 +1400,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   // ---- 3. openings by barycentric evaluation over the LDE coset ------------------------------------------------------------
   pp->zeta = bb::e_to_mont(zeta); pp->zeta_w = bb::e_to_mont(zeta_w);
-  HIP_OK(hipMemcpyAsync(&dPP->zeta, &pp->zeta, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
+  HIP_OK(h2d(&dPP->zeta, &pp->zeta, 2 * sizeof(E4)));
   hipLaunchKernelGGL(bary_weights_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, log_n, c->d_tw_fwd, dPP, dW, dDinv);
   // columns in the order used everywhere below: main (WM), aux (WA) = WT "trace" columns, then the quotient's four
   hipLaunchKernelGGL(bary_dot_kernel, dim3(n_chunks, (WT + 8) / 8), dim3(NT), 0, s, dL, dAL, dQ, (uint32_t)WM / 8, (uint32_t)WA / 8, (uint64_t)N2, dW, dPart, n_chunks, (uint32_t)__builtin_ctzll(N2 / n_chunks));
@@ -1427,8 +1444,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       g = bb::e_mul_m(g, gamma_m);
     }
     pp->a0 = bb::e_to_mont(a0); pp->b0 = bb::e_to_mont(b0);
-    HIP_OK(hipMemcpyAsync(dPP->gamma_pow, pp->gamma_pow, sizeof(pp->gamma_pow), hipMemcpyHostToDevice, s));
-    HIP_OK(hipMemcpyAsync(&dPP->a0, &pp->a0, 2 * sizeof(E4), hipMemcpyHostToDevice, s));
+    HIP_OK(h2d(dPP->gamma_pow, pp->gamma_pow, sizeof(pp->gamma_pow)));
+    HIP_OK(h2d(&dPP->a0, &pp->a0, 2 * sizeof(E4)));
   }
   HIP_OK(ar.take(&fri_layers[0], 4 * N2));
   hipLaunchKernelGGL(deep_kernel, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, dQ, log_n, dDinv, dPP, wn_inv_m, WM, WA, fri_layers[0]);
@@ -1442,7 +1459,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   uint32_t *dChSt, *dFri;
   HIP_OK(ar.take(&dChSt, 16)); HIP_OK(ar.take(&dFri, 16 * (size_t)(n_layers + 1)));
   if (!ch.in.empty()) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: the transcript has pending input at the FRI commit phase"}); return ZKIR_ERR_OTHER; }
-  HIP_OK(hipMemcpyAsync(dChSt, ch.st, sizeof(ch.st), hipMemcpyHostToDevice, s));
+  HIP_OK(h2d(dChSt, ch.st, sizeof(ch.st)));
   {
     uint32_t shift = bb::GEN;
     int log_m = (int)log_n + 1;
@@ -1489,7 +1506,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   uint32_t pow_nonce = 0xFFFFFFFFu;
   {
     ch.flush();
-    HIP_OK(hipMemcpyAsync(dState, ch.st, sizeof(ch.st), hipMemcpyHostToDevice, s));
+    HIP_OK(h2d(dState, ch.st, sizeof(ch.st)));
     const uint32_t batch = 1u << 18;
     for (uint64_t base = 0; base < bb::P && pow_nonce == 0xFFFFFFFFu; base += batch) {
       HIP_OK(hipMemsetAsync(dBest, 0xFF, 4, s));
@@ -1522,17 +1539,16 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   uint32_t off = 0;                                                           // offsets inside the query section
   std::vector<uint32_t> qpos;                                                 // where each query's index word goes
   auto path_jobs = [&](const uint32_t* tree, uint64_t n_leaves, uint64_t leaf) {
-    const uint32_t* layer = tree; uint64_t jdx = leaf;
-    for (uint64_t q = n_leaves; q > 1; q >>= 1) { jobs.push_back({layer + 4 * (jdx ^ 1), 1, 4, off, 0u, 0u}); off += 4; layer += 4 * q; jdx >>= 1; }
+    if (n_leaves > 1) { jobs.push_back({tree, n_leaves, (uint32_t)leaf, off, 0u, 2u}); for (uint64_t q = n_leaves; q > 1; q >>= 1) off += 4; }
   };
   for (uint32_t q : queries) {
     qpos.push_back(off); off += 1;
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // a trace row = 8 consecutive words out of each of the WM/8 blocks
-      for (uint32_t b = 0; b < (uint32_t)WM / 8; b++) { jobs.push_back({dL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off, 1u, 0u}); off += 8; }
+      jobs.push_back({dL + pos * 8, N2 * 8, (uint32_t)WM / 8, off, 1u, 1u | (8u << 8)}); off += (uint32_t)WM;
       path_jobs(dTree, N2, pos);
     }
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) {                     // the aux row and its path
-      for (uint32_t b = 0; b < (uint32_t)WA / 8; b++) { jobs.push_back({dAL + ((uint64_t)b * N2 + pos) * 8, 1, 8, off, 1u, 0u}); off += 8; }
+      jobs.push_back({dAL + pos * 8, N2 * 8, (uint32_t)WA / 8, off, 1u, 1u | (8u << 8)}); off += (uint32_t)WA;
       path_jobs(dATree, N2, pos);
     }
     for (uint64_t pos : {(uint64_t)q, (uint64_t)q + N}) { jobs.push_back({dQ + pos * 8, 1, 4, off, 1u, 0u}); off += 4; path_jobs(dQTree, N2, pos); }
