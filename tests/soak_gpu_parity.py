@@ -94,7 +94,8 @@ while time.time() < t_end:
         if len(want_rows) == 0:
             continue
         log_n = so.padded_log_n(len(want_rows))                     # any halt: the trace is padded to a power of two
-        opub = so.public_inputs(len(want_rows), blob, list(inputs), list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3)
+        fri = dict(num_queries=84, pow_bits=16) if rng.integers(0, 4) == 0 else {}                 # (round 5) one proof in four at the second parameter set
+        opub = so.public_inputs(len(want_rows), blob, list(inputs), list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, **fri)
         log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
         ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
         got_rows = tr.rows()
@@ -104,11 +105,11 @@ while time.time() < t_end:
         want = so.prove(want_rows, opub)
         try:
             witness = "host" if (mode == 3 and rng.integers(0, 2)) else "device"          # mode 3: the memory witness from the device (sort + scan) or from the host replay
-            proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, mode == 1, io_mode=mode == 2, mem_mode=mode == 3, mem_witness=witness))
+            proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, mode == 1, io_mode=mode == 2, mem_mode=mode == 3, mem_witness=witness, **fri))
         except rt.RuntimeError as e:
             # a run that executes a word that is not the program's (a store into the code segment, a pc outside it) has no proof; the
             # honest GPU prover refuses it — and the proof the oracle's prover emits for the same rows must be one the verifiers reject
-            assert e.code == rt.ERR_ARGUMENT and ("code table" in e.message or "2^40" in e.message), e.message
+            assert e.code == rt.ERR_ARGUMENT and ("code table" in e.message or "2^40" in e.message or "overlaps the code segment" in e.message), e.message
             assert so.verify(want) != 0 and rt.verify(want) == so.verify(want), "refused by the prover but accepted by a verifier"
             n_refused += 1
             log.close()
