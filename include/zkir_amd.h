@@ -425,7 +425,9 @@ uint32_t zkir_proof_version_of_mode(uint32_t mode);   /* modes 2 / 3: 11 (round 
  * zeta (incl. the lookup argument: the verifier computes the table side from that program and the multiplicities in the proof), 11 final
  * codeword degree, 12 grinding, 20-27 query / Merkle / FRI checks, 30 length; modes 2 / 3 also 50-53 = zkir_verify_io's checks on the tapes the proof carries, 51 the
  * counters' ends; mode 3 also 54 = the touched cells are not canonical 8-byte cell addresses in strictly increasing order; a mode-3 proof is never a segment: 2).
- * expect may be NULL: the header's own public inputs are then only checked for internal consistency. */
+ * expect may be NULL: the header's own public inputs are then only checked for internal consistency.
+ * The queries (independent, ~10,000 Poseidon2 permutations of Merkle paths at 2^20 rows) are checked on up to eight host threads (half the logical cores; ZKIR_VERIFY_THREADS=n
+ * overrides); the verdict is the first failing query's in query order, as a sequential check would give. */
 int zkir_verify(const uint32_t* proof, uint64_t proof_words, const zkir_public_inputs* expect);
 /* A run proven in SEGMENTS (multi-GPU: one row shard per device; consecutive segments overlap by one row — the last row of segment i,
  * labelled "halt" there, is row 0 of segment i + 1).  zkir_verify_segment: the same checks without check 7; first_state / last_state

@@ -27,11 +27,11 @@ EXTRA = {"stark.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def sources_sha16() -> str:
-    """sha256 prefix over the kernel / host sources the library is built from: the counter files under profiles/ carry the value they were measured at, so a
+    """sha256 prefix over the kernel sources the library is built from: the counter files under profiles/ carry the value they were measured at, so a
     reader without git (the GPU box) can tell whether they describe THIS build (bench.py roofline.traffic_source_freshness)."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(HOST_SOURCES + HIP_SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+    for name in sorted(HIP_SOURCES + [x for x in HEADERS if not x.startswith("..")]):      # the KERNEL sources (.hip and what they include): host-only files do not move a counter
         h.update(name.encode())
         h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()[:16]

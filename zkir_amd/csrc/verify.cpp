@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkir_amd.h"
@@ -695,8 +697,18 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   const E4 zeta_w = bb::e_mul_fm(zeta, wn_m);
   const uint32_t w2n = bb::root_of_unity(log_n + 1);
   const int depth0 = log_n + 1;
-  for (int t = 0; t < NUM_QUERIES; t++) {
-    const uint32_t q = ch.sample_bits(log_n);
+  // The queries are independent of each other and all the same size: their indices are drawn first (the transcript is sequential), then they are checked on a few host
+  // threads (round 5: ~10,000 Poseidon2 permutations — the Merkle paths — were 11 of the verifier's 12 ms on one core).  The verdict is the first failing query's, in query
+  // order: exactly what the sequential loop returned.
+  std::vector<uint32_t> qs(NUM_QUERIES);
+  for (auto& q : qs) q = ch.sample_bits(log_n);
+  size_t qsize = 1 + 2 * ((size_t)WM + 4 * depth0) + 2 * ((size_t)WA + 4 * depth0) + 2 * ((size_t)4 + 4 * depth0);
+  { int lm = log_n + 1; for (int j = 0; j < n_layers; j++) { qsize += 4 * ((size_t)1 << ks[j]) + 4 * (size_t)(lm - ks[j]); lm -= ks[j]; } }
+  const size_t p_queries = p;
+  auto check_query = [&](int t) -> int {
+    size_t p = p_queries + (size_t)t * qsize;
+    auto need = [&](size_t k) { return p + k <= len; };
+    const uint32_t q = qs[t];
     if (!need(1) || w[p++] != q) return 20;
     E4 deep[2];
     const uint32_t* tl[2]; const uint32_t* al[2]; const uint32_t* ql[2];
@@ -760,7 +772,22 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       carried = v[0]; carried_idx = idx;
     }
     if (!e_eq(fin[carried_idx & (n_fin - 1)], carried)) return 26;
+    return 0;
+  };
+  std::vector<int> codes(NUM_QUERIES, 0);
+  {
+    unsigned n_thr = std::thread::hardware_concurrency() / 2;               // (half the logical cores, at most eight: SMT siblings and a busy host do not help a 10 ms job)
+    n_thr = n_thr < 1 ? 1 : n_thr > 8 ? 8 : n_thr;
+    if (const char* e = getenv("ZKIR_VERIFY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_thr = (unsigned)v; }
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int t; (t = next.fetch_add(1)) < NUM_QUERIES;) codes[t] = check_query(t); };
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < n_thr; k++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
   }
+  for (int t = 0; t < NUM_QUERIES; t++) if (codes[t]) return codes[t];
+  p = p_queries + (size_t)NUM_QUERIES * qsize;
   if (p != len) return 30;
   return 0;
 }
