@@ -26,21 +26,32 @@ constexpr uint32_t PROOF_MAGIC = 0x46504B5Au;
 
 const p2::Consts& consts() { static const p2::Consts c = [] { p2::Consts k; p2::generate(k); return k; }(); return c; }
 
+// The permutation on a state of Montgomery words (R v, canonical range) in the hash kernels' formulation (p2::permute_scaled: a quarter fewer host instructions than
+// p2::permute; the same function — tests/test_stark_oracle.py compares both with the oracle's textbook permutation)
+inline void permute_m(uint32_t* st) {
+  const p2::Consts& c = consts();
+  const uint32_t k_in = bb::from_mont(c.in_scale), ko_m = bb::to_mont(c.out_scale);
+  uint32_t s[p2::T];
+  for (int i = 0; i < p2::T; i++) s[i] = bb::mont_mul_lazy(st[i], k_in);
+  p2::permute_scaled(s, c);
+  for (int i = 0; i < p2::T; i++) st[i] = bb::mont_mul(s[i], ko_m);
+}
+
 // canonical digests / compressions on top of the Montgomery permutation
 void hash_elems(const uint32_t* in, size_t n, uint32_t out[4]) {          // overwrite-mode sponge, rate 8 (so::hash_elems)
   uint32_t s[p2::T] = {0};
   for (size_t off = 0; off < n; off += p2::RATE) {
     const size_t len = n - off < (size_t)p2::RATE ? n - off : (size_t)p2::RATE;
     for (size_t i = 0; i < len; i++) s[i] = bb::to_mont(in[off + i]);
-    p2::permute(s, consts());
+    permute_m(s);
   }
-  if (n == 0) p2::permute(s, consts());
+  if (n == 0) permute_m(s);
   for (int i = 0; i < 4; i++) out[i] = bb::from_mont(s[i]);
 }
 void compress(const uint32_t* l, const uint32_t* r, uint32_t out[4]) {
   uint32_t s[p2::T] = {0};
   for (int i = 0; i < 4; i++) { s[i] = bb::to_mont(l[i]); s[4 + i] = bb::to_mont(r[i]); }
-  p2::permute(s, consts());
+  permute_m(s);
   for (int i = 0; i < 4; i++) out[i] = bb::from_mont(s[i]);
 }
 bool check_path(const uint32_t* leaf, size_t idx, const uint32_t* path, int depth, const uint32_t* root) {
@@ -52,7 +63,7 @@ bool check_path(const uint32_t* leaf, size_t idx, const uint32_t* path, int dept
 struct Challenger {                                                        // duplex sponge, Montgomery state, canonical in / out
   uint32_t st[p2::T] = {0};
   std::vector<uint32_t> in, out;
-  void duplex() { for (size_t i = 0; i < in.size(); i++) st[i] = bb::to_mont(in[i]); in.clear(); p2::permute(st, consts()); out.clear(); for (int i = 0; i < p2::RATE; i++) out.push_back(bb::from_mont(st[i])); }
+  void duplex() { for (size_t i = 0; i < in.size(); i++) st[i] = bb::to_mont(in[i]); in.clear(); permute_m(st); out.clear(); for (int i = 0; i < p2::RATE; i++) out.push_back(bb::from_mont(st[i])); }
   void observe(uint32_t x) { out.clear(); in.push_back(x); if ((int)in.size() == p2::RATE) duplex(); }
   void observe_n(const uint32_t* x, size_t n) { for (size_t i = 0; i < n; i++) observe(x[i]); }
   uint32_t sample() { if (!in.empty() || out.empty()) duplex(); const uint32_t v = out.back(); out.pop_back(); return v; }
