@@ -14,7 +14,7 @@ rows) — the large-size counterpart of tests/test_gpu_stark.py's small mode-3 p
 Also (`python tests/golden/make_config_proofs.py mode2 [log2_rows ...]`, default 12 16 20; round 5): the MODE-2 proof (the I/O argument) of a fib run that halts by itself and
 WRITES its result — the proof whose output tape says what the run computed.
 
-Does not import the product.  Run: python tests/golden/make_config_proofs.py [log2_rows ...]   (default 16 18 20; 22: ~50 minutes and ~20 GB, one thread)
+Does not import the product.  Run: python tests/golden/make_config_proofs.py [log2_rows ...]   (default 16 18 20; 22: 45 minutes, 23: 104 minutes and ~36 GB, one thread)
 """
 import hashlib
 import json

@@ -366,7 +366,7 @@ def test_commitment_root_equals_the_oracles_at_config_size(k):
     ctx.close(); log.close()
 
 
-@pytest.mark.parametrize("k", [12, 16, 18, 20, 22])
+@pytest.mark.parametrize("k", [12, 16, 18, 20, 22, 23])
 def test_proof_equals_the_oracles_at_config_size(k):
     """BASELINE's metric is "end-to-end prove ms, 2^20-cycle fib" and north_star asks for bit-identical proof bytes: the GPU prover's COMPLETE proof of that run
     (and of three smaller sizes) equals the proof the CPU oracle computed for it — tests/golden/config_proofs.json (length, SHA-256 of the words, 257 spaced
