@@ -87,3 +87,24 @@ def test_alu_bound_is_a_bound():
     ctr = bench._profiled_counters("leaf_hash_kernel")
     at_its_own_time = bench._alu_roofline("leaf_hash_kernel", ctr["launch_us"] * 1e-3)
     assert at_its_own_time["frac"] <= at_its_own_time["frac_in_counter_pass"] * 1.001          # (the pass ran below 2.4 GHz)
+
+
+def test_shipped_code_object_registers_and_spills():
+    """scripts/isa_hist.py on the built library (VERDICT r4 task 4: "llvm-readelf --notes shows zero scratch for bary_dot_kernel"): the kernels the round rewrote keep their accumulators
+    in registers, the throughput hash kernels do not spill, and the committed histogram the bench line's ALU bound reads is that of THIS build."""
+    import subprocess
+    import tempfile
+    so = os.path.join(ROOT, "zkir_amd", "libzkir_amd.so")
+    if not os.path.exists(so) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no built library / no llvm tools here")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "h.json")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "isa_hist.py"), "--json", out, "--kernels", "bary_dot_kernel,leaf_hash_kernel,compress_kernel,subtree_kernel,quotient_kernel<0>"],
+                              stdout=subprocess.DEVNULL)
+        h = json.load(open(out))
+    for k in ("bary_dot_kernel", "leaf_hash_kernel", "compress_kernel", "subtree_kernel"):
+        assert h[k]["regs"]["vgpr_spill"] == 0 and h[k]["regs"]["scratch"] == 0, (k, h[k]["regs"])
+    assert h["bary_dot_kernel"]["regs"]["vgpr"] <= 96                      # 16 exact 96-bit sums (48 registers) + two rows in flight: five waves per SIMD
+    assert h["quotient_kernel<0>"]["regs"]["vgpr_spill"] <= 8             # (three waves per SIMD with a handful of spilled registers beat two waves without: profiles/r05c_p2_variants.txt)
+    committed = json.load(open(bench._newest_profile("r*_isa_hist.json")))
+    assert committed["leaf_hash_kernel"]["classes"] == h["leaf_hash_kernel"]["classes"], "profiles/r*_isa_hist.json is not this build's: re-run scripts/isa_hist.py --json"
