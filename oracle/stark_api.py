@@ -46,6 +46,7 @@ def lib():
         L.so_last_aux.restype = None; L.so_last_aux.argtypes = [V]
         L.so_prove.restype = SZ; L.so_prove.argtypes = [V, PP, V, SZ]
         L.so_prove_matrix.restype = SZ; L.so_prove_matrix.argtypes = [V, PP, V, SZ]
+        L.so_prove_lean.restype = SZ; L.so_prove_lean.argtypes = [V, PP, V, SZ, I]
         L.so_verify.restype = I; L.so_verify.argtypes = [V, SZ, PP]
         L.so_pow_bits.restype = I; L.so_header_words.restype = I; L.so_state_words.restype = I
         L.so_verify_segment.restype = I; L.so_verify_segment.argtypes = [V, SZ, PP, V]
@@ -269,6 +270,18 @@ def prove(rows: np.ndarray, pub: PublicC | None = None) -> np.ndarray:
     out = np.zeros(size, np.uint32)
     lib().so_prove(rows.ctypes.data, C.byref(pub), out.ctypes.data, size)
     return out
+
+
+def prove_lean(rows: np.ndarray, pub: PublicC | None = None, threads: int = 1, cap_words: int = 1 << 22) -> np.ndarray:
+    """The proof of `prove`, by the memory-lean threaded restatement (so::prove_lean: no committed copy, no coefficient vectors, std::threads over columns / leaves / coset
+    points): what makes the whole proof at 2^24 rows fit this container (38 GB against ~70).  One pass: the buffer must hold the proof (a 2^24-row mode-0 proof is ~0.1 M words)."""
+    rows = np.ascontiguousarray(rows)
+    pub = _pub(rows, pub)
+    assert pub.n_real == len(rows) >= 1
+    out = np.zeros(cap_words, np.uint32)
+    size = lib().so_prove_lean(rows.ctypes.data, C.byref(pub), out.ctypes.data, cap_words, int(threads))
+    assert size <= cap_words, f"proof of {size} words does not fit cap_words = {cap_words}"
+    return out[:size].copy()
 
 
 def prove_matrix(matrix: np.ndarray, pub: PublicC) -> np.ndarray:

@@ -1654,6 +1654,243 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   }
 }
 
+// ---- the same proof, MEMORY-LEAN and THREADED (round 6: the whole-proof golden at BASELINE configs[2]'s own size, 2^24 rows) ----
+// `prove` above is the definition; this is the same sequence of the same functions (so::lde, hash_elems, compress, constraints_sum, fold_pair, the same Challenger) with
+//  * nothing kept for inspection: no committed copy of the matrix (a column is extended straight from its logical column), no coefficient vectors (the opening of a column at
+//    zeta / zeta w is Horner on the coefficients RE-DERIVED from the even positions of its LDE: p(g w_N^i) = the LDE at 2 i, an inverse NTT gives the coefficients of p(g x),
+//    times g^-k — field arithmetic is exact, so these are the very words `lde` produced), the logical matrix freed once the aux trace exists;
+//  * `threads` std::threads over independent units: columns (LDE, openings), leaves / tree nodes (Merkle), coset points (quotient, DEEP codeword), fold outputs.
+// What each unit computes is untouched, so the proof is word for word `prove`'s (tests/test_stark_oracle.py::test_lean_prover_equals_the_plain_one: every mode, ragged runs).
+// Peak memory at 2^24 rows, mode 0: the rows (6.2 GB) + the logical matrix (11.5 GB) + the main LDE (20.4 GB) = 38 GB, against ~70 GB for `prove`.
+template <class Body>
+static void par_for(int threads, size_t count, Body&& body) {                // body(lo, hi) over [0, count) split among the threads
+  if (threads <= 1 || count < 2) { if (count) body((size_t)0, count); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) { const size_t lo = count * t / threads, hi = count * (t + 1) / threads; if (lo < hi) th.emplace_back([lo, hi, &body] { body(lo, hi); }); }
+  for (auto& x : th) x.join();
+}
+static void merkle_build_par(const std::vector<F>& mat, int width, size_t n, Merkle& t, int threads) {
+  t.n_leaves = n;
+  t.layers.clear();
+  t.layers.emplace_back(4 * n);
+  par_for(threads, n, [&](size_t lo, size_t hi) {
+    std::vector<F> row(width);
+    for (size_t j = lo; j < hi; j++) { for (int k = 0; k < width; k++) row[k] = mat[(size_t)k * n + j]; hash_elems(row.data(), width, &t.layers[0][4 * j]); }
+  });
+  while (t.layers.back().size() > 4) {
+    const std::vector<F>& prev = t.layers.back();
+    const size_t m = prev.size() / 8;
+    std::vector<F> cur(4 * m);
+    par_for(m >= 1024 ? threads : 1, m, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) compress(&prev[8 * i], &prev[8 * i + 4], &cur[4 * i]); });
+    t.layers.push_back(std::move(cur));
+  }
+}
+// coefficients of the degree < n polynomial behind column `col` of an LDE matrix [.][2n] on GEN <w_2n>, from its even positions
+static void coeffs_from_lde(const F* col, size_t n, std::vector<F>& c) {
+  c.resize(n);
+  for (size_t i = 0; i < n; i++) c[i] = col[2 * i];
+  ntt(c, true);
+  const F ginv = finv(GEN); F sc = 1;
+  for (size_t k = 0; k < n; k++) { c[k] = fmul(c[k], sc); sc = fmul(sc, ginv); }
+}
+static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof, int threads) {
+  Public pub = pub_in;
+  const int log_n = padded_log_n(pub.n_real);
+  const size_t N = (size_t)1 << log_n, N2 = 2 * N;
+  const int Dm = pub.mode();
+  const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
+  if (threads < 1) threads = 1;
+  std::vector<F> M;
+  main_trace(rows, pub.n_real, pub, M, &pub.cells);
+  for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(M.begin() + (size_t)c * N, M.begin() + (size_t)(c + 1) * N, 0);
+  for (int i = 0; i < N_STATE; i++) { pub.first[i] = M[(size_t)state_col(i) * N]; pub.last[i] = M[(size_t)state_col(i) * N + (pub.n_real - 1)]; }
+  if (Dm >= 2) for (int k = 0; k < 2; k++) { pub.cnt_first[k] = M[(size_t)(C_OC + k) * N]; pub.cnt_last[k] = M[(size_t)(C_OC + k) * N + (pub.n_real - 1)]; }
+  std::vector<int> logical_of(Wm, -1);
+  for (int c = 0; c < Wl; c++) if (!is_virtual(c, Dm)) logical_of[phys_col(c, Dm)] = c;
+  std::vector<F> L((size_t)Wm * N2);
+  par_for(threads, (size_t)Wm, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; k++) {
+      const F* col = &M[(size_t)logical_of[k] * N];
+      std::vector<F> e(col, col + N), cf, o;
+      lde(e, 1, cf, o);
+      memcpy(&L[k * N2], o.data(), N2 * 4);
+    }
+  });
+  Merkle trace_tree, aux_tree, quot_tree;
+  merkle_build_par(L, Wm, N2, trace_tree, threads);
+  std::vector<uint32_t>& w = proof.w;
+  header_words(log_n, pub, w);
+  Challenger ch;
+  ch.observe_n(w.data() + 2, w.size() - 2);
+  ch.observe_n(trace_tree.layers.back().data(), 4);
+  const Rom rom = rom_from_blob(pub.blob, pub.blob_len, Dm);
+  w.push_back((uint32_t)pub.blob_len);
+  for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
+  if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
+  if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
+  std::vector<F> rom_mult, rc_mult, mem_mult;
+  lookup_multiplicities(M, N, rom, rom_mult, rc_mult, nullptr, Dm, &mem_mult);
+  w.insert(w.end(), rom_mult.begin(), rom_mult.end());
+  w.insert(w.end(), rc_mult.begin(), rc_mult.end());
+  ch.observe_n(rom_mult.data(), rom_mult.size());
+  ch.observe_n(rc_mult.data(), rc_mult.size());
+  if (Dm == 3) { w.insert(w.end(), mem_mult.begin(), mem_mult.end()); ch.observe_n(mem_mult.data(), mem_mult.size()); }
+  LookupParams lp;
+  lp.alpha = ch.sample_ext();
+  {
+    const E lambda = ch.sample_ext();
+    lp.lam[0] = e_from(1);
+    for (int j = 1; j <= N_TUPLE; j++) lp.lam[j] = emul(lp.lam[j - 1], lambda);
+  }
+  lp.n_in = (F)(pub.n_in % P);
+  {
+    E T = lookup_table_sum(rom, rom_mult.data(), rc_mult.data(), lp, Dm == 3 ? mem_mult.data() : nullptr);
+    if (Dm >= 2) T = eadd(T, io_table_sum(pub, lp));
+    if (Dm == 3) T = eadd(T, mem_table_sum(pub, lp));
+    lp.t_over_n = emul_f(T, finv((F)(N % P)));
+  }
+  std::vector<F> AL((size_t)Wa * N2);
+  {
+    std::vector<F> A;
+    aux_trace(M, N, lp, A, Dm);
+    M.clear(); M.shrink_to_fit();                                           // the logical matrix has done its work
+    par_for(threads, (size_t)Wa, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        std::vector<F> e(A.begin() + k * N, A.begin() + (k + 1) * N), cf, o;
+        lde(e, 1, cf, o);
+        memcpy(&AL[k * N2], o.data(), N2 * 4);
+      }
+    });
+  }
+  merkle_build_par(AL, Wa, N2, aux_tree, threads);
+  ch.observe_n(aux_tree.layers.back().data(), 4);
+  const E alpha = ch.sample_ext();
+  const int NC = num_constraints(Dm);
+  std::vector<E> ap(NC); ap[0] = e_from(1); for (int c = 1; c < NC; c++) ap[c] = emul(ap[c - 1], alpha);
+
+  const F w2n = root_of_unity(log_n + 1), wn = root_of_unity(log_n), wn_inv = finv(wn);
+  const F w_last = fpow(wn, pub.n_real - 1);
+  const F gN = fpow(GEN, N);
+  std::vector<F> Qc(4 * N2);
+  par_for(threads, N2, [&](size_t lo, size_t hi) {
+    F x = fmul(GEN, fpow(w2n, lo));
+    std::vector<E> ploc(Wm), pnxt(Wm), loc(W_MAX), nxt(W_MAX), aloc(W_AUX_MAX), anxt(W_AUX_MAX);
+    for (size_t j = lo; j < hi; j++) {
+      for (int k = 0; k < Wm; k++) { ploc[k] = e_from(L[(size_t)k * N2 + j]); pnxt[k] = e_from(L[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      to_logical_row(ploc.data(), Dm, e_from(0), loc.data()); to_logical_row(pnxt.data(), Dm, e_from(0), nxt.data());
+      for (int k = 0; k < Wa; k++) { aloc[k] = e_from(AL[(size_t)k * N2 + j]); anxt[k] = e_from(AL[(size_t)k * N2 + ((j + 2) & (N2 - 1))]); }
+      const F zh = fsub((j & 1) ? fneg(gN) : gN, 1);
+      const F inv_zh = finv(zh);
+      const E is_first = e_from(fmul(zh, finv(fsub(x, 1))));
+      const E is_last = e_from(fmul(zh, finv(fsub(x, w_last))));
+      const E is_trans = e_from(fsub(x, wn_inv));
+      E sum; constraints_sum(loc.data(), nxt.data(), aloc.data(), anxt.data(), is_first, is_last, is_trans, pub, lp, ap.data(), sum);
+      const E q = emul_f(sum, inv_zh);
+      for (int i = 0; i < 4; i++) Qc[(size_t)i * N2 + j] = q.c[i];
+      x = fmul(x, w2n);
+    }
+  });
+  merkle_build_par(Qc, 4, N2, quot_tree, threads);
+  ch.observe_n(quot_tree.layers.back().data(), 4);
+  const E zeta = ch.sample_ext();
+  const E zeta_w = emul_f(zeta, wn);
+
+  const int Wt = Wm + Wa;
+  std::vector<E> t_z(Wt), t_zw(Wt), q_z(4);
+  par_for(threads, (size_t)Wt, [&](size_t lo, size_t hi) {
+    std::vector<F> cf;
+    for (size_t k = lo; k < hi; k++) {
+      coeffs_from_lde(k < (size_t)Wm ? &L[k * N2] : &AL[(k - Wm) * N2], N, cf);
+      t_z[k] = horner_base(cf, zeta); t_zw[k] = horner_base(cf, zeta_w);
+    }
+  });
+  par_for(std::min(threads, 4), 4, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      std::vector<F> ev(Qc.begin() + i * N2, Qc.begin() + (i + 1) * N2);
+      ntt(ev, true);
+      F ginv = finv(GEN), sc = 1;
+      for (size_t k2 = 0; k2 < N2; k2++) { ev[k2] = fmul(ev[k2], sc); sc = fmul(sc, ginv); }
+      q_z[i] = horner_base(ev, zeta);
+    }
+  });
+  for (int k = 0; k < Wt; k++) ch.observe_ext(t_z[k]);
+  for (int k = 0; k < Wt; k++) ch.observe_ext(t_zw[k]);
+  for (int i = 0; i < 4; i++) ch.observe_ext(q_z[i]);
+  const E gamma = ch.sample_ext();
+
+  std::vector<E> gp(2 * Wt + 4); gp[0] = e_from(1); for (size_t k = 1; k < gp.size(); k++) gp[k] = emul(gp[k - 1], gamma);
+  E a0 = e_from(0), b0 = e_from(0);
+  for (int k = 0; k < Wt; k++) { a0 = eadd(a0, emul(gp[k], t_z[k])); b0 = eadd(b0, emul(gp[Wt + k], t_zw[k])); }
+  for (int i = 0; i < 4; i++) a0 = eadd(a0, emul(gp[2 * Wt + i], q_z[i]));
+  std::vector<std::vector<E>> fri; std::vector<Merkle> fri_trees;
+  fri.emplace_back(N2);
+  par_for(threads, N2, [&](size_t lo, size_t hi) {
+    std::vector<E>& cw = fri[0];
+    F x = fmul(GEN, fpow(w2n, lo));
+    for (size_t j = lo; j < hi; j++) {
+      E A = e_from(0), B = e_from(0);
+      for (int k = 0; k < Wm; k++) { const F v = L[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[k], v)); B = eadd(B, emul_f(gp[Wt + k], v)); }
+      for (int k = 0; k < Wa; k++) { const F v = AL[(size_t)k * N2 + j]; A = eadd(A, emul_f(gp[Wm + k], v)); B = eadd(B, emul_f(gp[Wt + Wm + k], v)); }
+      for (int i = 0; i < 4; i++) A = eadd(A, emul_f(gp[2 * Wt + i], Qc[(size_t)i * N2 + j]));
+      const E d1 = einv(esub(e_from(x), zeta)), d2 = einv(esub(e_from(x), zeta_w));
+      cw[j] = eadd(emul(esub(A, a0), d1), emul(esub(B, b0), d2));
+      x = fmul(x, w2n);
+    }
+  });
+
+  const std::vector<int> ks = fri_schedule(log_n);
+  F shift = GEN; int log_m = log_n + 1;
+  for (const int k : ks) {
+    const std::vector<E>& c = fri.back();
+    const size_t m = c.size(), g = m >> k, nv = (size_t)1 << k;
+    std::vector<F> mat(4 * nv * g);
+    par_for(g >= 4096 ? threads : 1, g, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) for (size_t t = 0; t < nv; t++) for (int e = 0; e < 4; e++) mat[(t * 4 + e) * g + i] = c[i + t * g].c[e]; });
+    Merkle tr; merkle_build_par(mat, (int)(4 * nv), g, tr, g >= 4096 ? threads : 1);
+    mat.clear(); mat.shrink_to_fit();
+    ch.observe_n(tr.layers.back().data(), 4);
+    E beta = ch.sample_ext();
+    std::vector<E> cur = c;
+    for (int f = 0; f < k; f++) {
+      const size_t h = cur.size() / 2;
+      std::vector<E> nx(h);
+      const F wm = root_of_unity(log_m);
+      par_for(h >= 4096 ? threads : 1, h, [&](size_t lo, size_t hi) { F x = fmul(shift, fpow(wm, lo)); for (size_t i = lo; i < hi; i++) { nx[i] = fold_pair(cur[i], cur[i + h], x, beta); x = fmul(x, wm); } });
+      cur.swap(nx);
+      shift = fmul(shift, shift); log_m--; beta = emul(beta, beta);
+    }
+    fri_trees.push_back(std::move(tr));
+    fri.push_back(std::move(cur));
+  }
+  const std::vector<E>& fin = fri.back();
+  for (const E& e : fin) ch.observe_ext(e);
+  const F pow_nonce = ch.grind(pub.pow_bits());
+  (void)ch.check_pow(pow_nonce, pub.pow_bits());
+  std::vector<uint32_t> queries;
+  for (int t = 0; t < pub.num_queries(); t++) queries.push_back(ch.sample_bits(log_n));
+
+  for (int i = 0; i < 4; i++) w.push_back(trace_tree.layers.back()[i]);
+  for (int i = 0; i < 4; i++) w.push_back(aux_tree.layers.back()[i]);
+  for (int i = 0; i < 4; i++) w.push_back(quot_tree.layers.back()[i]);
+  for (int k = 0; k < Wt; k++) put_e(w, t_z[k]);
+  for (int k = 0; k < Wt; k++) put_e(w, t_zw[k]);
+  for (int i = 0; i < 4; i++) put_e(w, q_z[i]);
+  w.push_back((uint32_t)fri_trees.size());
+  for (auto& tr : fri_trees) for (int i = 0; i < 4; i++) w.push_back(tr.layers.back()[i]);
+  for (const E& e : fin) put_e(w, e);
+  w.push_back(pow_nonce);
+  for (uint32_t q : queries) {
+    w.push_back(q);
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wm; k++) w.push_back(L[(size_t)k * N2 + pos]); merkle_path(trace_tree, pos, w); }
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int k = 0; k < Wa; k++) w.push_back(AL[(size_t)k * N2 + pos]); merkle_path(aux_tree, pos, w); }
+    for (size_t pos : {(size_t)q, (size_t)q + N}) { for (int i = 0; i < 4; i++) w.push_back(Qc[(size_t)i * N2 + pos]); merkle_path(quot_tree, pos, w); }
+    for (size_t j = 0; j < fri_trees.size(); j++) {
+      const size_t g = fri[j].size() >> ks[j], idx = q & (g - 1);
+      for (size_t t = 0; t < ((size_t)1 << ks[j]); t++) put_e(w, fri[j][idx + t * g]);
+      merkle_path(fri_trees[j], idx, w);
+    }
+  }
+}
+
 // ---- verifier (N4): returns 0 if the proof is accepted, otherwise a non-zero code naming the failed check.  `expect` (nullable):
 // the public inputs the caller expects (program / io digests, row count, mode, entry point); a mismatch with the header is code 6 ----
 static bool check_path(const F* leaf_digest, size_t idx, const uint32_t* path, int depth, const F* root) {
@@ -2280,6 +2517,12 @@ void so_commit_trace_blocked(const void* packed_rows, const so_public* pub, int 
 static so::ProverTrace g_pt;   // last prover run (tests inspect intermediate objects)
 size_t so_prove(const void* packed_rows, const so_public* pub, uint32_t* out, size_t cap) {
   so::Proof pr; so::prove((const so::PackedRow*)packed_rows, to_pub(pub), pr, g_pt);
+  if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
+  return pr.w.size();
+}
+// the memory-lean threaded restatement of so_prove (so::prove_lean): same proof words; `out` must hold the proof (cap words; the word count is returned either way)
+size_t so_prove_lean(const void* packed_rows, const so_public* pub, uint32_t* out, size_t cap, int threads) {
+  so::Proof pr; so::prove_lean((const so::PackedRow*)packed_rows, to_pub(pub), pr, threads);
   if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
   return pr.w.size();
 }

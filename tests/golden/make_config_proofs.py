@@ -15,6 +15,8 @@ Also (`python tests/golden/make_config_proofs.py mode2 [log2_rows ...]`, default
 WRITES its result — the proof whose output tape says what the run computed.
 
 Does not import the product.  Run: python tests/golden/make_config_proofs.py [log2_rows ...]   (default 16 18 20; 22: 45 minutes, 23: 104 minutes and ~36 GB, one thread)
+2^24 rows (BASELINE configs[2]'s own size; round 6) goes through so::prove_lean — the memory-lean, threaded restatement of so::prove that tests/test_stark_oracle.py holds
+equal to it word for word in every mode (38 GB instead of ~70; ZKIR_ORACLE_THREADS std::threads, default all cores) — and so does any size when ZKIR_ORACLE_LEAN=1.
 """
 import hashlib
 import json
@@ -150,11 +152,15 @@ def main():
         t0 = time.time()
         res = oracle.run(FIB_ENDLESS, max_cycles=1 << k, enable_execution_trace=True)
         pub = so.public_inputs(len(res.rows), FIB_ENDLESS, [], list(res.outputs), (res.halt_kind, res.halt_code))
-        proof = np.ascontiguousarray(so.prove(res.rows, pub), dtype="<u4")
+        lean = k >= 24 or os.environ.get("ZKIR_ORACLE_LEAN") == "1"
+        threads = int(os.environ.get("ZKIR_ORACLE_THREADS", os.cpu_count() or 1)) if lean else 1
+        rows = res.rows
+        del res
+        proof = np.ascontiguousarray(so.prove_lean(rows, pub, threads=threads) if lean else so.prove(rows, pub), dtype="<u4")
         assert so.verify(proof, pub) == 0
         pos = sample_positions(len(proof))
         proofs[str(k)] = {"rows": 1 << k, "words": int(len(proof)), "sha256": hashlib.sha256(proof.tobytes()).hexdigest(),
-                          "samples": [int(proof[p]) for p in pos], "oracle_seconds": round(time.time() - t0, 1)}
+                          "samples": [int(proof[p]) for p in pos], "oracle_seconds": round(time.time() - t0, 1), "threads": threads, "prover": "so::prove_lean" if lean else "so::prove"}
         print(k, proofs[str(k)]["words"], proofs[str(k)]["sha256"], proofs[str(k)]["oracle_seconds"], flush=True)
         cur = json.load(open(path)) if os.path.exists(path) else {}          # (several sizes may be running side by side: merge, do not overwrite)
         cur.update({"_about": out["_about"], "program_blob_hex": out["program_blob_hex"]})

@@ -7,6 +7,9 @@ What this pins: nothing outside this repository — the commit stage is self-def
 and the independent CPU statement of the same spec agree AT FULL SIZE, where the test suite otherwise samples.
 
 Does not import the product.  Run: python tests/golden/make_config_roots.py [max_log2_rows=20]   (2^20 rows: ~4 minutes, ~3 GB; 2^24 rows, column-blocked on 8 threads: ~15 minutes, ~25 GB)
+     python tests/golden/make_config_roots.py sharded 26 8   BASELINE configs[3]'s own workload: the 2^26-cycle run cut into 8 row shards of 2^23, each shard
+                                                             committed on its own (what one GPU of the 8-GPU run commits), the 8 subtree roots capped by three
+                                                             levels of 2-to-1 compressions (what every rank computes after the all-gather) -> roots["26x8"]
 """
 import json
 import os
@@ -36,7 +39,37 @@ FIB_LOOP = [r_(ADD, 4, 1, 2), i_(ADDI, 1, 2, 0), i_(ADDI, 2, 4, 0), i_(ADDI, 3, 
 FIB_ENDLESS = blob([i_(ADDI, 1, 0, 0), i_(ADDI, 2, 0, 1), i_(ADDI, 3, 0, 0)] + FIB_LOOP + [j_(JAL, 0, -20)])
 
 
+def sharded(k, G):
+    """Row shards [g n, (g+1) n), n = 2^k / G, of the 2^k-cycle run: the oracle re-executes the run keeping one shard's rows at a time (window mode),
+    commits the shard exactly as a rank of `bench.py --gpus G` does (its own interpolants over 2^(k - log2 G) rows, its own Merkle subtree) and caps the roots."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_roots.json")
+    out = json.load(open(path))
+    key = f"{k}x{G}"
+    n = (1 << k) // G
+    threads = int(os.environ.get("ZKIR_ORACLE_THREADS", os.cpu_count() or 1))
+    entry = out["roots"].get(key) or {"rows": 1 << k, "shards": G, "rows_per_shard": n, "shard_roots": [], "oracle_seconds": 0.0, "threads": threads}
+    out["roots"][key] = entry
+    for g in range(len(entry["shard_roots"]), G):
+        t0 = time.time()
+        rows = oracle.run(FIB_ENDLESS, max_cycles=1 << k, enable_execution_trace=True, keep_rows=(g * n, (g + 1) * n), want_sorted=False).rows
+        assert len(rows) == n and int(rows["cycle"][0]) == g * n
+        root = so.commit_trace_blocked(rows, 1, threads=threads)
+        del rows
+        entry["shard_roots"].append([int(x) for x in root])
+        entry["oracle_seconds"] = round(entry["oracle_seconds"] + time.time() - t0, 1)
+        print(key, g, entry["shard_roots"][-1], round(time.time() - t0, 1), flush=True)
+        json.dump(out, open(path, "w"), indent=1)
+    level = [[int(x) for x in r] for r in entry["shard_roots"]]
+    while len(level) > 1:
+        level = [[int(x) for x in so.compress(level[i], level[i + 1])] for i in range(0, len(level), 2)]
+    entry["root"] = level[0]
+    print(key, "capped root", entry["root"], flush=True)
+    json.dump(out, open(path, "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sharded":
+        return sharded(int(sys.argv[2]), int(sys.argv[3]))
     kmax = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_roots.json")
     out = json.load(open(path)) if os.path.exists(path) else {}

@@ -62,6 +62,44 @@ def test_merkle_matches_oracle(log_n, width):
     ctx.close()
 
 
+def test_trees_of_one_context_built_on_two_streams_at_once():
+    """subtree_kernel's "who finishes last" counter was one word per context, shared by launches that overlap when a context's trees are built on two
+    streams (service.py's commit_only pipeline; any caller of zkir_merkle_commit_launch / zkir_merkle_cap_launch with its own streams).  Now every launch takes its own slot
+    of a ring.  Here: trees of 2^13 .. 2^17 leaves (8 .. 128 workgroups per subtree launch; narrow matrices, so the leaf layer is short and the launches of the two
+    streams really are in flight together), queued alternately on two streams of ONE context, repeatedly; every tree must equal the one built alone on the default stream."""
+    import torch
+    from zkir_amd import stark
+    ctx = stark.StarkContext(10)
+    rng = np.random.default_rng(7)
+    mats, want = [], []
+    for i, log_n in enumerate([13, 14, 15, 16, 17, 13, 15, 14]):
+        m = stark.to_b8(torch.from_numpy(rng.integers(0, P, (8, 1 << log_n)).astype(np.uint32).view(np.int32)).cuda())
+        mats.append(m)
+        want.append(stark.merkle_commit(ctx, m, 8).cpu().numpy().view(np.uint32))
+        if log_n <= 14:
+            root, layers = so.merkle(stark.from_b8(m, 8).cpu().numpy().view(np.uint32), want_layers=True)
+            assert np.array_equal(want[-1], layers)
+    digs = [m[0, :4096, :4].contiguous() for m in mats]
+    want_caps = [stark.merkle_cap(ctx, d).clone() for d in digs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(20):
+        trees = []
+        for i, m in enumerate(mats):
+            with torch.cuda.stream(streams[i & 1]):
+                trees.append(stark.merkle_commit(ctx, m, 8, stream=streams[i & 1]))
+        caps = []
+        for i in range(8):                                          # the cap launch (zkir_merkle_cap_launch) on the two streams as well: 2^12 digests = 4 workgroups
+            with torch.cuda.stream(streams[i & 1]):
+                caps.append(stark.merkle_cap(ctx, digs[i], stream=streams[i & 1]).clone())
+        torch.cuda.synchronize()
+        for i, t in enumerate(trees):
+            assert np.array_equal(t.cpu().numpy().view(np.uint32), want[i]), f"rep {rep}, tree {i}"
+        for i in range(8):
+            assert torch.equal(caps[i], want_caps[i]), f"rep {rep}, cap {i}"
+    ctx.close()
+
+
 @pytest.mark.parametrize("fill", ["p-1", "zero", "one", "alternating"])
 def test_merkle_and_lde_extreme_values(fill):
     """Worst cases for the lazy (unreduced) arithmetic of the hash and NTT kernels: every input at the top of the range."""

@@ -476,6 +476,24 @@ def test_column_blocked_commit_is_the_commit(mode):
             assert np.array_equal(so.commit_trace_blocked(res.rows, 1, pub=pub, threads=threads), want), (mode, n, threads)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_lean_prover_equals_the_plain_one(mode):
+    """so::prove_lean (round 6: the whole-proof golden at BASELINE configs[2]'s own size, 2^24 rows — no committed copy of the matrix, openings from coefficients re-derived
+    out of the LDE's even positions, std::threads over columns / leaves / coset points) writes the proof of so::prove word for word: every mode (152 / 168 / 160 / 264 committed
+    columns; the I/O and memory sections, the touched cells), ragged row counts, a self-halting run, one thread and several, the second parameter set."""
+    cases = [(spec.fib_endless_program(), 300, {}), (spec.fib_program(12), None, {}), (spec.fib_endless_program(), 2048, {"num_queries": 84, "pow_bits": 16})]
+    if mode != 1:
+        cases.append((spec.memory_loop_program(40), 700, {}))
+    for prog, n, params in cases:
+        blob = prog.to_bytes()
+        res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, enable_deferred_model=mode == 1)
+        pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, **params)
+        want = so.prove(res.rows, pub)
+        assert so.verify(want, pub) == 0
+        for threads in (1, 3):
+            assert np.array_equal(so.prove_lean(res.rows, pub, threads=threads), want), (mode, n, threads)
+
+
 def test_air_holds_row_by_row_on_honest_traces():
     """Every constraint vanishes on every (row, next row) pair of an honest main trace: evaluated here with the row selectors a
     verifier would use ON the trace domain (is_first = [i == 0], is_last = [i == n_real - 1], is_trans = [i != N - 1])."""

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -558,19 +559,30 @@ __global__ __launch_bounds__(NT_SUB) void subtree_kernel(const p2::Consts* __res
   // on gfx950 writes back and invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv; measured here: 512 workgroups doing so took the launch from 94 to 146 us).
   // Instead the ONE digest a workgroup hands over is re-stored with device-scope atomic stores (write-through), the counter is bumped once those have been
   // acknowledged (s_waitcnt vmcnt(0) in the same wave), and the workgroup that goes on reads the digests with device-scope atomic loads (past the L2 of its XCD).
+  // Ordering, spelled out: the hardware side is the gfx9 rule that vmcnt counts stores as well as loads and that the immediate 0x0F70 is vmcnt(0) with every
+  // other counter left alone — both true of gfx950 only, hence the #error below; the compiler side is the pair of `asm volatile("" ::: "memory")` barriers, which keep the
+  // digest stores, the wait and the counter bump (and, on the winner's side, the counter read and the digest loads) in program order.  `counter` is THIS LAUNCH's slot
+  // (launch_tree_levels hands out a fresh one of a ring per launch), so launches that overlap on two streams of one context never see each other's increments.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "subtree_kernel's hand-over relies on the gfx950 (gfx9) s_waitcnt encoding and on vmcnt covering stores"
+#endif
   if (m > 1) {
     if (t < 4) {
       const uint32_t v = reinterpret_cast<const uint32_t*>(buf)[t];          // buf[0] = the workgroup's digest in Montgomery form; the tree holds it canonical
       __hip_atomic_store(&cur[4 * pos0 + t], bb::from_mont(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
+      asm volatile("" ::: "memory");
     }
     if (t == 0) {
       const uint32_t done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::: "memory");
       last_one = done == (uint32_t)m - 1;
-      if (last_one) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last_one) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every increment of this launch has happened: the slot is clean for its next turn of the ring
     }
     __syncthreads();
     if (!last_one) return;
+    asm volatile("" ::: "memory");
     per_wg = (uint32_t)m; pos0 = 0;
     for (uint32_t e = t; e < 4 * per_wg; e += NT_SUB)
       reinterpret_cast<uint32_t*>(buf)[e] = bb::to_mont(__hip_atomic_load(&cur[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -597,8 +609,19 @@ __global__ __launch_bounds__(NT) void modmul_peak_kernel(uint32_t* __restrict__ 
   if (r == 0xFFFFFFFFu && iters == 0xFFFFFFFFu) out[0] = r;  // never true; keeps the chain live
 }
 
+// The "who finishes last" counters of subtree_kernel: a ring of zeroed words, ONE SLOT PER LAUNCH (one counter per context was shared by launches that
+// overlap when a context's trees are built on two streams — service.py's commit_only pipeline, any caller of zkir_merkle_commit_launch / zkir_merkle_cap_launch with streams
+// of its own — and a workgroup could then see "I am last" on another launch's increments).  A slot is left at zero by the launch that used it and comes round again after
+// SYNC_SLOTS further subtree launches on the context; a context never has that many trees in flight (a proof enqueues ten, one after the other).
+constexpr uint32_t SYNC_SLOTS = 1024;
+struct SyncRing {
+  uint32_t* d_slots = nullptr;
+  std::atomic<uint32_t> next{0};
+  uint32_t* take() { return d_slots + (next.fetch_add(1, std::memory_order_relaxed) % SYNC_SLOTS); }
+};
+
 // all levels above the leaf digests: wide levels (throughput-bound) one launch each, then subtree launches
-void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n_leaves, uint32_t* counter, hipStream_t s) {
+void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n_leaves, SyncRing& ring, hipStream_t s) {
   uint32_t* cur = leaf_digests;
   uint64_t m = n_leaves;
   for (; m > (1u << 18); m >>= 1) {
@@ -608,7 +631,7 @@ void launch_tree_levels(const p2::Consts* cp, uint32_t* leaf_digests, uint64_t n
   }
   if (m > 1) {                                                   // m <= 2^18: per <= 1024 digests a workgroup, at most 256 workgroups, whose digests the last of them finishes
     const uint32_t per = m < SUBTREE ? (uint32_t)m : SUBTREE;
-    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT_SUB), 0, s, cp, cur, m, per, counter);
+    hipLaunchKernelGGL(subtree_kernel, dim3((unsigned)(m / per)), dim3(NT_SUB), 0, s, cp, cur, m, per, ring.take());
   }
 }
 
@@ -629,7 +652,7 @@ struct zkir_stark_ctx {
   uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
   p2::Consts consts;              // host copy (transcript, verifier side)
   p2::Consts* d_p2 = nullptr;     // device copy: every hash kernel takes the pointer (no process-wide __constant__ state)
-  uint32_t* d_sync = nullptr;     // 64 zeroed words: the "who finishes last" counter of subtree_kernel (left at zero by every launch; launches on one context are stream-ordered)
+  mutable SyncRing sync;          // subtree_kernel's "who finishes last" counters, one slot per launch (launches of one context may overlap on the caller's streams)
   mutable std::mutex mu;          // a context serves one proof at a time (its workspace arena); different contexts are independent
   // prover workspace: one device allocation made on the first zkir_prove and reused (hipMalloc of GBs costs more than the kernels)
   mutable unsigned char* arena = nullptr;
@@ -648,7 +671,7 @@ int lde_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* 
 // leaf layer + the levels above it; mont_in = the matrix words carry the Montgomery factor (the digests are those of the canonical words either way)
 int merkle_commit(const zkir_stark_ctx* c, const uint32_t* mat, uint32_t width, uint64_t n_leaves, uint32_t* tree, bool mont_in, hipStream_t s) {
   hipLaunchKernelGGL(leaf_hash_kernel, dim3(grid_for(n_leaves)), dim3(NT), 0, s, c->d_p2, mat, width, n_leaves, mont_in ? bb::from_mont(c->consts.in_scale) : c->consts.in_scale, tree);
-  launch_tree_levels(c->d_p2, tree, n_leaves, c->d_sync, s);
+  launch_tree_levels(c->d_p2, tree, n_leaves, c->sync, s);
   return check_launch("merkle_commit");
 }
 }  // namespace
@@ -749,8 +772,8 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
   p2::generate(c->consts);
   hipError_t e = hipMalloc((void**)&c->d_p2, sizeof(p2::Consts));
   if (e == hipSuccess) e = hipMemcpy(c->d_p2, &c->consts, sizeof(p2::Consts), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&c->d_sync, 256);
-  if (e == hipSuccess) e = hipMemset(c->d_sync, 0, 256);
+  if (e == hipSuccess) e = hipMalloc(&c->sync.d_slots, SYNC_SLOTS * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(c->sync.d_slots, 0, SYNC_SLOTS * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_inv, (size_t)n_inv * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_tw_fwd, (size_t)N * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_g_lo, 1024 * 4);
@@ -779,7 +802,7 @@ int zkir_stark_ctx_create(uint32_t log_n, uint32_t log_blowup, zkir_stark_ctx** 
 void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
   (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi); (void)hipFree(c->d_g_lo_m); (void)hipFree(c->d_inv_xm1);
-  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2); (void)hipFree(c->d_sync);
+  (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2); (void)hipFree(c->sync.d_slots);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
@@ -896,7 +919,7 @@ int zkir_merkle_leaves_launch(const zkir_stark_ctx* c, const uint32_t* mat, uint
 // top log2(G) levels).  tree[0 .. 4n) must hold the n digests; the call fills the remaining 4(n-1) words, root = last 4.
 int zkir_merkle_cap_launch(const zkir_stark_ctx* c, uint32_t* tree, uint64_t n_digests, void* stream) {
   if (!c || n_digests == 0 || (n_digests & (n_digests - 1))) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "merkle cap: null context, or n_digests not a power of two"}); return ZKIR_ERR_ARGUMENT; }
-  launch_tree_levels(c->d_p2, tree, n_digests, c->d_sync, (hipStream_t)stream);
+  launch_tree_levels(c->d_p2, tree, n_digests, c->sync, (hipStream_t)stream);
   return check_launch("merkle_cap");
 }
 

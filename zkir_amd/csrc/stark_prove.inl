@@ -1471,7 +1471,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       if (g <= (1u << 11)) hipLaunchKernelGGL(fri_leaf_hash_row16_kernel, dim3(grid_for(16 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
       else if (g <= (1u << 14)) hipLaunchKernelGGL(fri_leaf_hash_quad_kernel, dim3(grid_for(4 * g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
       else hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3(grid_for(g)), dim3(NT), 0, s, c->d_p2, fri_layers[j], m, (uint32_t)k, tree);
-      launch_tree_levels(c->d_p2, tree, g, c->d_sync, s);
+      launch_tree_levels(c->d_p2, tree, g, c->sync, s);
       hipLaunchKernelGGL(fri_transcript_kernel, dim3(1), dim3(16), 0, s, c->d_p2, dChSt, tree + 4 * (2 * g - 2), dFri + 16 * j);
       FoldParams fp{};                                                         // k binary folds: beta^(2^f) (device), shift^(2^f) — one launch for all of them
       for (int f = 0; f < k; f++) {
