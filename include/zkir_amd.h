@@ -121,7 +121,10 @@ typedef struct zkir_delta_log zkir_delta_log;   /* opaque, host memory */
 /* Run the program on the host interpreter (bit-exact to VM::run, vm.rs:208-358) and record the delta
  * log.  tile_rows (power of two, 256..2048; 0 = default: 256 when max_cycles <= 2^21, else 512) fixes
  * the granularity of the tile index (one K1 workgroup per tile).
- * Returns ZKIR_OK or an error code (then *out is NULL). No device is touched. */
+ * Returns ZKIR_OK or an error code (then *out is NULL).  No device WORK is queued; when the process has a device, the log's large
+ * arrays (pc, instruction words, register events: >= 8 MiB) live in PINNED host blocks recycled by a process-wide pool, so that
+ * zkir_host_to_device / hipMemcpyAsync out of them is plain DMA at link rate (ZKIR_PIN_LOG=0: pageable memory).  A caller that
+ * queues asynchronous copies out of a log must let them complete before zkir_delta_log_free hands the blocks back to the pool. */
 int zkir_interpret(const uint8_t* program_blob, size_t blob_len, const uint64_t* inputs, size_t n_inputs,
                    const zkir_vm_config* cfg, uint32_t tile_rows, zkir_delta_log** out);
 void zkir_delta_log_free(zkir_delta_log* log);

@@ -21,6 +21,11 @@ int zkir_commit_fused01_launch(const zkir_stark_ctx* ctx, const zkir_trace_colum
  * (ntt.hip: strided_variant_run lists them) over `width` columns: for timing the tilings side by side (scripts/time_ntt_tiles.py); the data is left partially transformed. */
 int zkir_ntt_strided_variant_launch(const zkir_stark_ctx* ctx, uint32_t* data, uint32_t width, int variant, int forward, void* hip_stream);
 
+/* EXPERIMENT (round 6; profiles/r06_overlap_variants.txt): zkir_lde_launch + zkir_merkle_commit_launch of a canonical matrix with the leaf sponge absorbed block-group-wise on
+ * the context's second stream while the next group of `group` B8 blocks is extended on `hip_stream` (a 12-word sponge state per leaf travels through HBM between groups).
+ * in / out as zkir_lde_launch, tree as zkir_merkle_commit_launch; same output as the two calls. */
+int zkir_commit_overlapped_launch(const zkir_stark_ctx* ctx, uint32_t* in, uint32_t width, uint32_t* out, uint32_t* tree, uint32_t group, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

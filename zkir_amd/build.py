@@ -67,19 +67,24 @@ def build_variant(tag: str, defines, csrc: str = CSRC) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     deps = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    objs = []
+    objs, cmds = [], []
     for name in HOST_SOURCES + HIP_SOURCES:
         src = os.path.join(CSRC, name)
         obj = os.path.join(OBJ, name + ".o")
         objs.append(obj)
         if force or _newer(src, obj, deps):
             if name.endswith(".hip"):
-                cmd = [HIPCC, f"--offload-arch={ARCH}", *COMMON, *EXTRA.get(name, []), "-c", src, "-o", obj]
+                cmds.append([HIPCC, f"--offload-arch={ARCH}", *COMMON, *EXTRA.get(name, []), "-c", src, "-o", obj])
             else:
-                cmd = [HIPCC, "-x", "c++", *COMMON, "-march=x86-64-v2", "-c", src, "-o", obj]
+                cmds.append([HIPCC, "-x", "c++", *COMMON, "-march=x86-64-v2", "-c", src, "-o", obj])
+    if cmds:                                                      # the translation units are independent: compile them side by side (stark.hip alone is two of the 2.5 minutes)
+        from concurrent.futures import ThreadPoolExecutor
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("ZKIR_BUILD_JOBS", "4"))) as ex:
+            list(ex.map(run, cmds))
     if force or any(_newer(o, OUT, []) for o in objs):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT, *objs]
         if verbose:

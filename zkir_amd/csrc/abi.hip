@@ -15,6 +15,17 @@
 namespace zkir {
 static thread_local std::string g_last_error;
 void set_last_error(const Status& st) { g_last_error = st.msg; }
+
+// host.h: the big blocks of the delta log are pinned when the process has a device (asked once; a host-only process — zkir_interpret / zkir_verify on a CPU box — never
+// touches the runtime again after the first "no device").  hipHostMallocPortable: every device of the process may DMA out of the block.
+void* pinned_alloc(size_t bytes) {
+  static const bool have_device = [] { int n = 0; const bool ok = hipGetDeviceCount(&n) == hipSuccess && n > 0; if (!ok) (void)hipGetLastError(); return ok; }();
+  if (!have_device) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 }  // namespace zkir
 
 struct zkir_result {

@@ -33,30 +33,38 @@ struct BoundT {            // ValueBound, zkir-spec/src/bound.rs:116-121
 // Recycling of the big log blocks (interp.cpp): a 2^20-row run writes ~50 MB of logs once, front to back, and with 4 KiB pages
 // (no THP in containers) first-touch page faults cost more than the interpretation itself (64 ms sys vs 53 ms user at 2^22 rows).
 // Freed blocks >= 8 MiB are parked (at most 8 blocks / 4 GiB) and handed to the next run already mapped.
-void* block_pool_take(size_t min_bytes, size_t* got_bytes);   // nullptr if nothing suitable is parked
-void block_pool_give(void* p, size_t bytes);                  // takes ownership (may free)
+// Round 6: the big blocks are PINNED (hipHostMalloc) whenever the process has a device — the delta log is written once by the interpreter and read
+// once by the DMA engine, and a copy out of pageable memory is staged by the runtime through its own pinned bounce buffers at ~4.5 GB/s (10 ms for the 46 MB of a 2^20-row
+// run) where the link moves 50+.  Pinning costs a fraction of a millisecond per MB, ONCE: the pool recycles the blocks.  Without a device (the host-only entry points
+// zkir_interpret / zkir_verify on a CPU box) and with ZKIR_PIN_LOG=0 the blocks are plain malloc memory as before.
+struct Block { void* p = nullptr; size_t bytes = 0; bool pinned = false; };
+Block block_acquire(size_t min_bytes);                        // a parked block of min_bytes .. 4 min_bytes, else a fresh one (pinned if possible); p == nullptr: out of memory
+void block_release(const Block& b);                           // parks the block (or frees it: pool full)
+void* pinned_alloc(size_t bytes);                             // abi.hip: hipHostMalloc; nullptr when there is no device (remembered: asked once) or no pinned memory left
+void pinned_free(void* p);
 constexpr size_t BLOCK_POOL_MIN = 8u << 20;
 
-// Growable POD buffer backed by realloc (mremap for large blocks: growth neither copies nor re-faults).
+// Growable POD buffer: small ones live in realloc memory, big ones (>= BLOCK_POOL_MIN) in pool blocks.
 template <typename T>
 class Buf {
  public:
   Buf() = default;
   Buf(const Buf&) = delete;
   Buf& operator=(const Buf&) = delete;
-  ~Buf() { if (cap_ * sizeof(T) >= BLOCK_POOL_MIN) block_pool_give(p_, cap_ * sizeof(T)); else free(p_); }
+  ~Buf() { if (blk_.p) block_release(blk_); else free(p_); }
   void reserve(size_t n) {
     if (n <= cap_) return;
-    if (!p_ && n * sizeof(T) >= BLOCK_POOL_MIN) {
-      size_t got = 0;
-      if (void* q = block_pool_take(n * sizeof(T), &got)) { p_ = (T*)q; cap_ = got / sizeof(T); return; }
+    if (n * sizeof(T) >= BLOCK_POOL_MIN) {
+      const Block b = block_acquire(n * sizeof(T));
+      if (!b.p) throw std::bad_alloc();
+      if (n_) memcpy(b.p, p_, n_ * sizeof(T));
+      if (blk_.p) block_release(blk_); else free(p_);
+      blk_ = b; p_ = (T*)b.p; cap_ = b.bytes / sizeof(T);
+      return;
     }
     void* q = realloc(p_, n * sizeof(T));
     if (!q) throw std::bad_alloc();
     p_ = (T*)q; cap_ = n;
-    // the trace logs are tens of MB written once, front to back: with 4 KiB pages two thirds of the interpreter's time went to
-    // first-touch page faults (21 ms vs 7 ms without the trace at 2^20 rows); ask for transparent huge pages (THP = madvise here)
-    if (n * sizeof(T) >= (8u << 20)) (void)madvise(q, n * sizeof(T), MADV_HUGEPAGE);
   }
   inline void push(const T& v) {
     if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024);
@@ -78,6 +86,7 @@ class Buf {
   void clear() { n_ = 0; }
   size_t size() const { return n_; }
   size_t capacity() const { return cap_; }
+  bool pinned() const { return blk_.p && blk_.pinned; }
   const T* data() const { return p_; }
   T* data() { return p_; }
   const T& operator[](size_t i) const { return p_[i]; }
@@ -85,6 +94,7 @@ class Buf {
  private:
   T* p_ = nullptr;
   size_t n_ = 0, cap_ = 0;
+  Block blk_;                                                  // set when p_ is a pool block
 };
 
 // Pinned host memory for the prover's large host <-> device copies: bump-allocated per call (reset()), the blocks kept by the owner (a stark context) until it goes.

@@ -489,6 +489,41 @@ __global__ __launch_bounds__(NT) void leaf_hash_kernel(const p2::Consts* __restr
   reinterpret_cast<uint4*>(digests)[j] = d;
 }
 
+// EXPERIMENT (round 6): the leaf sponge BLOCK-WISE — blocks [b0, b1) of the matrix are absorbed into a 12-word sponge state kept per leaf in global memory
+// (three 16-byte vectors per leaf, [3][n] so that a wave's accesses are contiguous), so that the absorption of a group of blocks can run while the NEXT group is still being
+// extended (zkir_commit_overlapped_launch).  Same permutations on the same words in the same order as leaf_hash_kernel: same digests.  first: the state starts at zero;
+// last: the digest is written instead of the state.  The state words are the kernel's scaled post-permutation words (the carry product is applied on the way back in).
+__global__ __launch_bounds__(NT) void leaf_absorb_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ mat, uint32_t width, uint32_t b0, uint32_t b1, uint64_t n, uint32_t in_scale,
+                                                         uint4* __restrict__ state, int first, int last, uint32_t* __restrict__ digests) {
+  const uint64_t j = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (j >= n) return;
+  uint32_t s[p2::T];
+  if (first) {
+#pragma unroll
+    for (int i = 0; i < p2::T; i++) s[i] = 0;
+  } else {
+    const uint4 a = state[j], b = state[n + j], c = state[2 * n + j];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = c.w;
+  }
+  const uint4* m4 = reinterpret_cast<const uint4*>(mat);
+  const uint32_t carry = cp->carry, out_scale = cp->out_scale;
+  for (uint32_t blk = b0; blk < b1; blk++) {
+    const uint32_t off = blk * 8;
+    const uint4 lo = m4[((uint64_t)blk * n + j) * 2], hi = m4[((uint64_t)blk * n + j) * 2 + 1];
+    const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 0; i < p2::RATE; i++) s[i] = off + i < width ? bb::mont_mul_lazy(v[i], in_scale) : bb::mont_mul_lazy(s[i], carry);
+#pragma unroll
+    for (int i = p2::RATE; i < p2::T; i++) s[i] = bb::mont_mul_lazy(s[i], carry);
+    p2::permute_scaled(s, *cp);
+  }
+  if (last) {
+    reinterpret_cast<uint4*>(digests)[j] = make_uint4(bb::mont_mul(s[0], out_scale), bb::mont_mul(s[1], out_scale), bb::mont_mul(s[2], out_scale), bb::mont_mul(s[3], out_scale));
+  } else {
+    state[j] = make_uint4(s[0], s[1], s[2], s[3]); state[n + j] = make_uint4(s[4], s[5], s[6], s[7]); state[2 * n + j] = make_uint4(s[8], s[9], s[10], s[11]);
+  }
+}
+
 __global__ __launch_bounds__(NT) void compress_kernel(const p2::Consts* __restrict__ cp, const uint32_t* __restrict__ in, uint64_t n_out, uint32_t* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n_out) return;
@@ -652,6 +687,8 @@ struct zkir_stark_ctx {
   uint32_t* d_small_fwd = nullptr;  // w_{2^(Bm+1)}^k, k < 2^Bm
   p2::Consts consts;              // host copy (transcript, verifier side)
   p2::Consts* d_p2 = nullptr;     // device copy: every hash kernel takes the pointer (no process-wide __constant__ state)
+  // zkir_commit_overlapped_launch (experiment): a second stream, two events and the per-leaf sponge states, made on first use
+  mutable hipStream_t ov_stream = nullptr; mutable hipEvent_t ov_ev[2] = {nullptr, nullptr}; mutable std::vector<hipEvent_t> ov_group_ev; mutable uint4* d_ov_state = nullptr; mutable size_t ov_state_bytes = 0;
   mutable SyncRing sync;          // subtree_kernel's "who finishes last" counters, one slot per launch (launches of one context may overlap on the caller's streams)
   mutable std::mutex mu;          // a context serves one proof at a time (its workspace arena); different contexts are independent
   // prover workspace: one device allocation made on the first zkir_prove and reused (hipMalloc of GBs costs more than the kernels)
@@ -803,6 +840,10 @@ void zkir_stark_ctx_free(zkir_stark_ctx* c) {
   if (!c) return;
   (void)hipFree(c->d_tw_inv); (void)hipFree(c->d_tw_fwd); (void)hipFree(c->d_g_lo); (void)hipFree(c->d_g_hi); (void)hipFree(c->d_g_lo_m); (void)hipFree(c->d_inv_xm1);
   (void)hipFree(c->d_small_inv); (void)hipFree(c->d_small_fwd); (void)hipFree(c->d_p2); (void)hipFree(c->sync.d_slots);
+  if (c->ov_stream) (void)hipStreamDestroy(c->ov_stream);
+  for (hipEvent_t e : c->ov_ev) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ov_group_ev) (void)hipEventDestroy(e);
+  (void)hipFree(c->d_ov_state);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
@@ -894,6 +935,35 @@ int zkir_main_trace_host(const zkir_trace_columns* trace, uint64_t n_real, uint3
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
   for (uint64_t i = 0; i < N; i++) { if (deferred) main_trace_row<1>(*trace, n_real, N, i, out); else main_trace_row<0>(*trace, n_real, N, i, out); }
   return ZKIR_OK;
+}
+
+// EXPERIMENT (round 6): zkir_lde_launch + zkir_merkle_commit_launch with the leaf sponge overlapped with the extension.  The matrix is extended in
+// groups of `group` B8 blocks on `stream`; each group's absorption (leaf_absorb_kernel: the sponge state of every leaf read and written once per group) runs on the
+// context's second stream behind the group's LDE, so group g + 1 is extended while group g is hashed — the hash leaves ~95 % of HBM idle, the LDE ~30 % of the VALU issue
+// slots.  Same permutations in the same order per leaf: same tree.  Measured in profiles/r06_overlap_variants.txt (scripts/time_overlap.py).
+int zkir_commit_overlapped_launch(const zkir_stark_ctx* c, uint32_t* in, uint32_t width, uint32_t* out, uint32_t* tree, uint32_t group, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!c || !in || !out || !tree || width == 0 || group == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_commit_overlapped_launch: bad argument"}); return ZKIR_ERR_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(c->mu);
+  const uint64_t N = (uint64_t)1 << c->log_n, N2 = N << c->log_blowup;
+  const uint32_t nb = (width + 7) / 8, n_groups = (nb + group - 1) / group;
+  if (!c->ov_stream) {
+    if (hipStreamCreateWithFlags(&c->ov_stream, hipStreamNonBlocking) != hipSuccess) return check_launch("overlap stream");
+    for (auto& e : c->ov_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return check_launch("overlap event");
+  }
+  while (c->ov_group_ev.size() < n_groups) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return check_launch("overlap event"); c->ov_group_ev.push_back(e); }
+  if (c->ov_state_bytes < 48 * N2) { (void)hipFree(c->d_ov_state); c->d_ov_state = nullptr; c->ov_state_bytes = 0; if (hipMalloc(&c->d_ov_state, 48 * N2) != hipSuccess) return check_launch("overlap state"); c->ov_state_bytes = 48 * N2; }
+  const zkir::LdeTables t{(int)c->log_n, c->d_tw_inv, c->d_tw_fwd, c->d_g_lo, c->d_g_hi, c->d_small_inv, c->d_small_fwd};
+  (void)hipEventRecord(c->ov_ev[0], s); (void)hipStreamWaitEvent(c->ov_stream, c->ov_ev[0], 0);              // the second stream starts behind whatever `stream` holds
+  for (uint32_t g = 0; g < n_groups; g++) {
+    const uint32_t b0 = g * group, b1 = std::min(nb, b0 + group);
+    zkir::lde_run(t, in + (uint64_t)b0 * N * 8, b1 - b0, out + (uint64_t)b0 * N2 * 8, s);
+    (void)hipEventRecord(c->ov_group_ev[g], s); (void)hipStreamWaitEvent(c->ov_stream, c->ov_group_ev[g], 0);
+    hipLaunchKernelGGL(leaf_absorb_kernel, dim3(grid_for(N2)), dim3(NT), 0, c->ov_stream, c->d_p2, out, width, b0, b1, N2, c->consts.in_scale, c->d_ov_state, g == 0 ? 1 : 0, g + 1 == n_groups ? 1 : 0, tree);
+  }
+  (void)hipEventRecord(c->ov_ev[1], c->ov_stream); (void)hipStreamWaitEvent(s, c->ov_ev[1], 0);
+  launch_tree_levels(c->d_p2, tree, N2, c->sync, s);
+  return check_launch("commit_overlapped");
 }
 
 // in: ceil(width/8) blocks [N][8] of canonical evaluations over H (natural order; used as scratch and overwritten!), out: blocks [2N][8]

@@ -56,9 +56,16 @@ def upload(log: rt.DeltaLog, device=None) -> DeviceDeltaLog:
     if log.n_rows:
         pc[:log.n_rows].view(torch.uint8).copy_(_to_dev(log.pc, device))
         inst[:log.n_rows].view(torch.uint8).copy_(_to_dev(log.inst, device))
-    return DeviceDeltaLog(n_rows=log.n_rows, cycle_base=log.cycle_base, tile_rows=T, n_tiles=log.n_tiles, n_events=len(log.reg_events),
-                          events=_to_dev(log.reg_events, device), tile_ev_off=_to_dev(log.tile_ev_off, device),
-                          tile_snap=_to_dev(log.tile_snap, device), pc=pc, inst=inst)
+    ddl = DeviceDeltaLog(n_rows=log.n_rows, cycle_base=log.cycle_base, tile_rows=T, n_tiles=log.n_tiles, n_events=len(log.reg_events),
+                         events=_to_dev(log.reg_events, device), tile_ev_off=_to_dev(log.tile_ev_off, device),
+                         tile_snap=_to_dev(log.tile_snap, device), pc=pc, inst=inst)
+    # The log's big buffers are PINNED pool blocks (csrc/host.h), so these copies are asynchronous DMA: the log must not give its blocks back to the pool before the
+    # stream has passed them.  DeltaLog.close() waits for the events recorded here.
+    if hasattr(log, "_uploads"):
+        ev = torch.cuda.Event()
+        ev.record()
+        log._uploads.append(ev)
+    return ddl
 
 
 class HostShard:

@@ -369,6 +369,7 @@ class DeltaLog:
 
     def __init__(self, handle: int, owned: bool = True):
         self._h, self._owned = handle, owned
+        self._uploads = []                                    # events of asynchronous copies out of this log's (pinned) buffers: close() waits for them (pipeline.upload)
         L = lib()
         h = handle
         self.cycles = L.zkir_delta_log_cycles(h)
@@ -401,6 +402,9 @@ class DeltaLog:
         return DeltaLog(out.value)
 
     def close(self):
+        for ev in self._uploads:
+            ev.synchronize()
+        self._uploads = []
         if self._owned and self._h:
             lib().zkir_delta_log_free(self._h)
             self._h = None

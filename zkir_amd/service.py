@@ -105,11 +105,14 @@ def prove_many(jobs: Iterable[Job], log2_rows: int, producers: int = 3, ctx: Opt
                     raise rt.RuntimeError(rt.ERR_ARGUMENT, f"job {idx}: {log.n_rows} trace rows do not pad to the context's 2^{log2_rows}")
                 pub = rt.public_inputs(log, blob, list(inputs), cfg.enable_deferred_model)
                 with torch.cuda.stream(s):
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record(s)
                     ddl = pl.upload(log)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=True)
                     ev.record(s)
-                log.close()
-                ready.put((idx, ddl, ev, t1 - t0, time.perf_counter() - t1, pub, log.n_rows))
+                ev.synchronize()
+                log.close()                                   # (the copies are done: the log's pinned blocks go back to the pool)
+                ready.put((idx, ddl, ev, t1 - t0, ev0.elapsed_time(ev) * 1e-3, pub, log.n_rows))      # upload_s: the copies' time on the copy stream (HIP events), not the wait for a queue slot
             except BaseException as e:                    # surfaced by the consumer
                 errors.append(e)
                 stop.set()
