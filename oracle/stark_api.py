@@ -105,14 +105,15 @@ def io_bytes(inputs, outputs, halt_kind: int, halt_code: int, cycles: int) -> by
 
 
 def public_inputs(n_real: int, blob: bytes = b"", inputs=(), outputs=(), halt=(2, 0), deferred: bool = False, entry: int | None = None, io_mode: bool = False,
-                  writes_before: int = 0, reads_before: int = 0, mem_mode: bool = False, num_queries: int = 0, pow_bits: int = 0) -> PublicC:
+                  writes_before: int = 0, reads_before: int = 0, mem_mode: bool = False, num_queries: int = 0, pow_bits: int = 0, wide_mode: bool = False) -> PublicC:
     """Public inputs of a run: halt = (kind, code) with kind 0 Ebreak / 1 Exit / 2 CycleLimit; entry defaults to the blob header's.
     io_mode = mode 2: the default VM mode with the I/O argument (the proof carries the tapes; WRITE / READ ecalls are tied to them).
-    mem_mode = mode 3: mode 2 with the memory argument (loads and stores constrained, every access tied to a consistent memory; the proof carries the touched cells)."""
+    mem_mode = mode 3: mode 2 with the memory argument (loads and stores constrained, every access tied to a consistent memory; the proof carries the touched cells).
+    wide_mode = mode 4 (round 6): mode 3 with MULH / DIVU / REMU / DIV / REM on operands below 2^40 (six more range slots per row)."""
     if entry is None:
         entry = int.from_bytes(blob[12:16], "little") if len(blob) >= 16 else 0x1000
-    assert not (deferred and (io_mode or mem_mode)), "the I/O and memory arguments are stated for the default VM mode"
-    p = PublicC(n_real, 3 if mem_mode else 2 if io_mode else int(deferred), (int(num_queries) & 0xFFFF) | (int(pow_bits) << 16), entry)      # fri: the prover's parameters, 0 = 50 queries + 12 bits
+    assert not (deferred and (io_mode or mem_mode or wide_mode)), "the I/O and memory arguments are stated for the default VM mode"
+    p = PublicC(n_real, 4 if wide_mode else 3 if mem_mode else 2 if io_mode else int(deferred), (int(num_queries) & 0xFFFF) | (int(pow_bits) << 16), entry)      # fri: the prover's parameters, 0 = 50 queries + 12 bits
     p.set_blob(blob)
     p.set_io(list(inputs), list(outputs), halt, writes_before, reads_before)
     p.prog[:] = [int(x) for x in digest_bytes(blob)]
@@ -308,7 +309,7 @@ def mem_cells(rows: np.ndarray, pub: PublicC) -> np.ndarray:
 def prove_matrix_mem(matrix: np.ndarray, pub: PublicC, cells: np.ndarray) -> np.ndarray:
     """(mode 3) proof of a GIVEN main-trace matrix with a GIVEN list of touched cells (tests: a cheating prover)."""
     m, c = _u32(matrix), _u32(cells).reshape(-1, 7)
-    assert m.shape == (logical_width(3), 1 << padded_log_n(pub.n_real)) and pub.deferred == 3
+    assert m.shape == (logical_width(pub.deferred), 1 << padded_log_n(pub.n_real)) and pub.deferred >= 3
     L = lib()
     L.so_prove_matrix_mem.restype = C.c_size_t; L.so_prove_matrix_mem.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     size = L.so_prove_matrix_mem(m.ctypes.data, C.byref(pub), c.ctypes.data, len(c), None, 0)

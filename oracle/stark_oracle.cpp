@@ -237,8 +237,28 @@ static const uint32_t OP_EBREAK = 0x51;
 // The products are of degree 2 already, so the class selector cannot multiply them: ma_i = kmu a_i are columns of their own (zero off MUL rows).  8 more logical columns (284, 264):
 //   276 kmu | 277-280 ma_0..3 | 281-283 e_1..3
 // MULH, DIVU, REMU, DIV, REM stay class "other": they work on the RAW 64-bit registers (Q2, Q3) — 128-bit products, more chunk lookups than a row has slots.
-static const int W_MAIN_MEM = 284, W_MAX = 284;
+static const int W_MAIN_MEM = 284;
 enum { C_KMU = 276, C_MA = 277, C_ME = 281 };
+// ---- MODE 4 (round 6, proof format v12): mode 3 WITH the "wide arithmetic" class wa = 22 — MULH, DIVU, REMU, DIV, REM (opcodes 3..7; execute.rs:101-183) on operands BELOW 2^40.
+// The reference computes these five on the RAW 64-bit registers (quirks Q2, Q3): MULH = ((a b as u128) >> 40) & (2^40 - 1), DIVU / REMU = a / b, a % b, DIV / REM the same on
+// `as i64` (wrapping).  For registers below 2^40 — everything ADD .. MUL, the logic opcodes, the shifts, the comparisons and LW / LHU / LBU ever write — an i64 is non-negative, so
+// DIV = DIVU, REM = REMU, the 80-bit product's bits above 80 are empty, and all five are ONE relation over 40-bit integers:
+//       F1 F2 + ADD = LO + 2^40 HI        MULH: a b = L + 2^40 y          DIVU / DIV: y b + r = a, r < b          REMU / REM: q b + y = a, y < b
+// A wa row states kwa xb2 = kwa xc2 = 0: a run that feeds one of the five a register with bits above 40 (a sign-extended LB / LH result, an LD, a READ input or a link above
+// 2^40) has NO mode-4 proof — sound, incomplete, and stated; division by zero never is a row (the VM stops: RuntimeError::DivisionByZero).
+// Schoolbook in 10-bit chunks like MUL, but the 80-bit product, the addend and the remainder's range check need 23 lookups where a mode-3 row has 17: the mode adds SIX more
+// 10-bit range slots X0..X5 per row (24 aux columns) and 18 main columns:
+//   284 kwa | 285 om (MULH), 286 od (DIVU / DIV: the quotient is written), 287 orr (REMU / REM: the remainder is), 288 sg (the word is DIV / REM: op = 3 om + 4 od + 5 orr + 2 sg)
+//   289-292 gf_k = kwa F1_k (the products have degree 2 already: gated copies, like MUL's ma_k) | 293-301 e_1..e_9: the bits of the carries above their 10-bit slot | 302-307 X0..X5
+// Slots of a wa row (every one reads the 10-bit table): R0..R3 = LO's chunks, R4..R7 = F1's, pieces 0-3 = F2's (= rs2's), pieces 4-6 = the low parts of carries c0 c1 c2
+// (c1 = p5 + 2^10 e1, c2 = p6 + 2^10 (e2 + 2 e3)), pieces 7, 8 and X0, X1 = G4: HI's chunks (MULH) / ADD's = the remainder's (divisions), X2..X5 = G5: on MULH the carries
+// c3 c4 c5 (c3 = X2 + 2^10 (e4 + 2 e5), c4 = X3 + 2^10 (e6 + 2 e7), c5 = X4 + 2^10 (e8 + 2 e9)), on divisions the chunks of d = b - r - 1 (>= 0: r < b; borrow e4).
+// Position k of the product: sum_{i+j=k} F1_i F2_j + ADD_k + c_(k-1) = LO_k + 2^10 c_k (k <= 3), = HI_(k-4) + 2^10 c_k (k = 4, 5; k = 6: HI_2 + 2^10 HI_3); a division has HI = 0,
+// c3 = 0 and no product above position 3 (q b <= a < 2^40).  Every sum stays below 2^23: the equations hold over the integers and every decomposition is unique.
+static const int W_MAIN_WIDE = 308, W_MAX = 308;
+enum { C_KWA = 284, C_OM = 285, C_OD = 286, C_ORR = 287, C_SG = 288, C_GF = 289, C_WE = 293, C_X = 302 };
+static const int K_WA = 22, N_X = 6, N_WE = 9;
+static inline bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
 static const int K_MU = 20;
 static const uint32_t OP_MUL = 0x02;
 enum { C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275 };
@@ -255,7 +275,7 @@ static const uint32_t OP_LB = 0x30, OP_LD = 0x35, OP_SB = 0x38, OP_SD = 0x3B;
 static inline bool is_load(uint32_t op) { return op >= OP_LB && op <= OP_LD; }
 static inline bool is_store(uint32_t op) { return op >= OP_SB && op <= OP_SD; }
 static inline int mem_width(uint32_t op) { return is_store(op) ? 1 << (op - OP_SB) : op <= 0x31 ? 1 : op <= 0x33 ? 2 : op == 0x34 ? 4 : 8; }
-static inline int logical_width(int mode) { return mode == 3 ? W_MAIN_MEM : mode == 2 ? W_MAIN_IO : W_MAIN; }
+static inline int logical_width(int mode) { return mode == 4 ? W_MAIN_WIDE : mode == 3 ? W_MAIN_MEM : mode == 2 ? W_MAIN_IO : W_MAIN; }
 enum { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FHI = 8, C_LIMB = 9, C_STATE = 57, C_WR = 73, C_SELB = 88, C_SELC = 103,
        C_XB = 118, C_XC = 121, C_Y = 124, C_K = 127, C_OPC = 134, C_RC = 135, C_S = 139, C_SE = 140, C_C0 = 141, C_C1 = 142, C_D0 = 143, C_D1 = 144, C_D2 = 145,
        C_DL0 = 146, C_NE = 147, C_IV = 148, C_TK = 151, C_K2 = 152, C_NZ = 156, C_IVZ = 157, C_FLAG = 158, C_FX = 159, C_K3 = 160, C_B0 = 162, C_RC2 = 163, C_G = 167, C_SB = 168,
@@ -273,14 +293,14 @@ static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // 152 columns in default mode (172 - 20), 168 in deferred mode (172 - 4), whole blocks of 8.  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
 static const int W_AUX = 40;
-static const int W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_MAX = 96;    // mode 2: + HO (output helper), HI (input helper); mode 3: + P0..P8 (piece helpers), HMR, HMW (memory read / write helpers), FPN (fingerprint of the new cell bytes)
-static inline int aux_width(int mode) { return mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
+static const int W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 120, W_AUX_MAX = 120;   // mode 4: + XH0..XH5 (the helpers of the six extra range slots)    // mode 2: + HO (output helper), HI (input helper); mode 3: + P0..P8 (piece helpers), HMR, HMW (memory read / write helpers), FPN (fingerprint of the new cell bytes)
+static inline int aux_width(int mode) { return mode == 4 ? W_AUX_WIDE : mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
 // (AIR v6) the class column "other, jumps" (C_K3 + 1) is identically zero in the default mode too — no opcode's class is oj there (constraint 4) — and is not committed
 static const int C_KOJ = C_K3 + 1;
 // mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
-static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode < 3) || (c >= C_KWA && mode != 4) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
-static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 264 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
+static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 264 : mode == 4 ? 288 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
 // logical [logical_width][N] -> committed [phys_width][N]
 static void to_physical(const std::vector<F>& M, size_t N, int mode, std::vector<F>& out) {
   out.assign((size_t)phys_width(mode) * N, 0);
@@ -291,7 +311,7 @@ template <class V>
 static void to_logical_row(const V* phys, int mode, const V& zero, V* logical) {
   for (int c = 0; c < W_MAX; c++) logical[c] = is_virtual(c, mode) ? zero : phys[phys_col(c, mode)];
 }
-enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92 };
+enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96 };
 // (mode 3) the lookup tables beside the 10-bit range table (no tag) and the ROM (tag 1) / tapes (2, 3): LOW3 = {(v, v & 7)}, v < 2^10 (tag 4: the first range chunk of a
 // memory row is looked up HERE, with the window's offset — the address's low three bits), BYTE = {v < 2^8} (tag 5), NIBBLE = {v < 2^4} (tag 6); memory tuples carry tag 7
 static const int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10;   // (8-10: the nibble tables {(a, b, a op b)} of the bitwise opcodes)
@@ -345,7 +365,8 @@ struct Public {
   int pow_bits() const { return (fri >> 16) ? (int)(fri >> 16) : 12; }
   int mode() const { return (int)deferred; }
   bool has_io() const { return deferred >= 2; }
-  bool has_mem() const { return deferred == 3; }
+  bool has_mem() const { return deferred >= 3; }
+  bool has_wide() const { return deferred == 4; }
 };
 // (mode 3) the bytes of cell `addr` (a multiple of 8) in the VM's INITIAL memory: the code words at 0x1000, the data section right behind them (vm.rs:153-170), zero elsewhere
 static uint64_t image_cell(const uint8_t* blob, size_t n, uint64_t addr) {
@@ -371,11 +392,12 @@ static void digest_bytes(const uint8_t* b, size_t n, F out[DIGEST]) {
 static inline F opclass_of(uint32_t op, int mode = 0) {
   if (op == OP_ECALL && mode >= 2) return K_ECALL;
   if (op == OP_EBREAK && mode >= 2) return K_EBREAK;
-  if (mode == 3 && is_load(op)) return K_LD;
-  if (mode == 3 && is_store(op)) return K_ST;
-  if (mode == 3 && is_logic(op)) return K_LG;
-  if (mode == 3 && is_shift(op)) return K_SH;
-  if (mode == 3 && op == OP_MUL) return K_MU;
+  if (mode >= 3 && is_load(op)) return K_LD;
+  if (mode >= 3 && is_store(op)) return K_ST;
+  if (mode >= 3 && is_logic(op)) return K_LG;
+  if (mode >= 3 && is_shift(op)) return K_SH;
+  if (mode >= 3 && op == OP_MUL) return K_MU;
+  if (mode == 4 && is_wide(op)) return K_WA;
   switch (op) {
     case OP_ADD: return K_ADD; case OP_ADDI: return K_ADDI; case OP_BEQ: case OP_BNE: return K_BRE; case OP_JAL: return K_JAL; case OP_SUB: return K_SUB;
     case OP_BLTU: case OP_BGEU: case OP_BLT: case OP_BGE: return K_BRU; case OP_SEQ: case OP_SNE: return K_SE;
@@ -416,7 +438,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
   const int mode = pub.mode();
   out.assign((size_t)logical_width(mode) * N, 0);
   auto col = [&](int k) { return out.data() + (size_t)k * N; };
-  const bool D = mode == 1, IO = mode >= 2, MEM = mode == 3;
+  const bool D = mode == 1, IO = mode >= 2, MEM = mode >= 3;
   uint64_t oc = pub.writes_before, reads = pub.reads_before;          // mode 2: WRITE / READ ecalls executed so far (syscall.rs:110-121)
   std::map<uint64_t, std::pair<uint64_t, uint32_t>> memory;           // mode 3: the replayed memory, cell address -> (bytes, time of the last access); untouched cells hold the program image
   for (size_t i = 0; i < N; i++) {
@@ -445,6 +467,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     else if (cls == K_LG) col(C_KLG)[i] = 1;
     else if (cls == K_SH) col(C_KSH)[i] = 1;
     else if (cls == K_MU) col(C_KMU)[i] = 1;
+    else if (cls == K_WA) col(C_KWA)[i] = 1;
     else if (cls != K_ECALL) col(kcol(cls))[i] = 1;           // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
     col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
@@ -523,6 +546,39 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
         if (k == 1) col(C_ME)[i] = carry >> 10;
         if (k == 2) { col(C_ME + 1)[i] = (carry >> 10) & 1; col(C_ME + 2)[i] = carry >> 11; }
         if (k == 3) col(C_PIECE + 8)[i] = carry >> 10;
+      }
+      y[0] = (F)(res & 0xFFFFF); y[1] = (F)(res >> 20); y[2] = 0;
+      rd = fa;
+    }
+    if (cls == K_WA) {                                        // (mode 4) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI in 10-bit chunks
+      sh_row = true;                                          // (R0..R3 = LO's chunks, R4..R7 = F1's)
+      const uint64_t M40 = (1ull << 40) - 1;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20);   // (the top limbs must be zero: the constraints say so, a run that breaks it has no proof)
+      const bool mulh = op == 0x03, quot = op == 0x04 || op == 0x06;
+      col(C_OM)[i] = mulh; col(C_OD)[i] = !mulh && quot; col(C_ORR)[i] = !mulh && !quot; col(C_SG)[i] = op >= 0x06;
+      uint64_t f1, add, res;
+      if (mulh) { f1 = a; add = 0; res = (uint64_t)(((unsigned __int128)a * b) >> 40) & M40; }
+      else { const uint64_t qv = b ? a / b : 0, rv = b ? a % b : 0; f1 = qv; add = rv; res = quot ? qv : rv; }       // (b = 0 never is a row: the VM stops with DivisionByZero)
+      F f1c[4], f2c[4], addc[4];
+      for (int k = 0; k < 4; k++) { f1c[k] = (F)((f1 >> (10 * k)) & 1023); f2c[k] = (F)((b >> (10 * k)) & 1023); addc[k] = (F)((add >> (10 * k)) & 1023); sh_c[k] = f1c[k]; col(C_GF + k)[i] = f1c[k]; col(C_PIECE + k)[i] = f2c[k]; }
+      uint64_t carry = 0, cs[7], out[7];
+      for (int k = 0; k < 7; k++) {                           // position k of F1 F2 + ADD
+        uint64_t t = carry + (k < 4 ? addc[k] : 0);
+        for (int j = 0; j < 4; j++) if (k - j >= 0 && k - j < 4) t += (uint64_t)f1c[j] * f2c[k - j];
+        out[k] = t & 1023; carry = t >> 10; cs[k] = carry;
+      }
+      for (int k = 0; k < 4; k++) sh_lo[k] = (F)out[k];      // LO = the product's low 40 bits (MULH) / the dividend (divisions)
+      const F g4[4] = {mulh ? (F)out[4] : addc[0], mulh ? (F)out[5] : addc[1], mulh ? (F)out[6] : addc[2], mulh ? (F)cs[6] : addc[3]};   // HI's chunks (HI_3 = the last carry) / the remainder's
+      col(C_PIECE + 4)[i] = (F)cs[0];
+      col(C_PIECE + 5)[i] = (F)(cs[1] & 1023); col(C_WE)[i] = (F)(cs[1] >> 10);
+      col(C_PIECE + 6)[i] = (F)(cs[2] & 1023); col(C_WE + 1)[i] = (F)((cs[2] >> 10) & 1); col(C_WE + 2)[i] = (F)(cs[2] >> 11);
+      col(C_PIECE + 7)[i] = g4[0]; col(C_PIECE + 8)[i] = g4[1]; col(C_X)[i] = g4[2]; col(C_X + 1)[i] = g4[3];
+      if (mulh) {
+        for (int k = 0; k < 3; k++) { col(C_X + 2 + k)[i] = (F)(cs[3 + k] & 1023); col(C_WE + 3 + 2 * k)[i] = (F)((cs[3 + k] >> 10) & 1); col(C_WE + 4 + 2 * k)[i] = (F)(cs[3 + k] >> 11); }
+      } else {                                                // d = b - r - 1 in chunks, its borrow between the limbs in e4
+        const uint64_t d = (b - add - 1) & M40;
+        for (int k = 0; k < 4; k++) col(C_X + 2 + k)[i] = (F)((d >> (10 * k)) & 1023);
+        col(C_WE + 3)[i] = (F)(((b & 0xFFFFF) < (add & 0xFFFFF) + 1) ? 1 : 0);
       }
       y[0] = (F)(res & 0xFFFFF); y[1] = (F)(res >> 20); y[2] = 0;
       rd = fa;
@@ -726,6 +782,7 @@ static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M
 static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE, LG_BASE = RC_TABLE + 256 + 16, L6_BASE = LG_BASE + 3 * 256;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR ++ LOW6 (1024: entry v = the tuple (v, v & 63))
 static inline bool row_shift(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0; }
 static inline bool row_mul(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KMU * N + i] != 0; }
+static inline bool row_wide(const std::vector<F>& M, size_t N, size_t i, int mode) { return mode == 4 && M[(size_t)C_KWA * N + i] != 0; }
 static inline bool row_shift_reg(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0 && M[(size_t)C_SI * N + i] == 0; }
 // the table a piece slot looks its value up in on a SHIFT row: 0-6 the 10-bit range table, 7 the nibble table, 8 LOW6 (with the amount) when the amount comes from a register
 static inline int shift_piece_tag(int k, bool reg) { return k == 7 ? TAG_NIB : (k == 8 && reg) ? TAG_LOW6 : 0; }
@@ -734,7 +791,7 @@ static inline F logic_of(int which, F a, F b) { return which == 0 ? (a & b) : wh
 static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& rom, std::vector<F>& rom_mult, std::vector<F>& rc_mult, size_t* first_bad_row = nullptr, int mode = 0,
                                   std::vector<F>* mem_mult = nullptr) {
   rom_mult.assign(rom.n, 0); rc_mult.assign(RC_TABLE, 0);
-  const bool MEM = mode == 3 && mem_mult;
+  const bool MEM = mode >= 3 && mem_mult, WIDE = mode == 4;
   if (MEM) mem_mult->assign(MEM_MULT, 0);
   if (first_bad_row) *first_bad_row = (size_t)-1;
   auto bad = [&](size_t i) { if (first_bad_row && *first_bad_row == (size_t)-1) *first_bad_row = i; };
@@ -755,7 +812,7 @@ static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& 
         if (v < 16 && b < 16 && r == logic_of(which, v, b)) (*mem_mult)[LG_BASE + 256 * which + 16 * v + b]++; else bad(i);
         continue;
       }
-      if (row_mul(M, N, i)) { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); continue; }   // a MUL row: every piece slot reads the 10-bit range table
+      if (row_mul(M, N, i) || row_wide(M, N, i, mode)) { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); continue; }   // a MUL row (mode 4: a wide-arithmetic row): every piece slot reads the 10-bit range table
       if (row_shift(M, N, i)) {                               // a shift row: the slots are re-typed (shift_piece_tag)
         const int tag = shift_piece_tag(k, row_shift_reg(M, N, i));
         if (tag == TAG_LOW6) { if (v < (F)RC_TABLE && M[(size_t)(C_LB + 8) * N + i] == (v & 63)) (*mem_mult)[L6_BASE + v]++; else bad(i); }
@@ -767,6 +824,7 @@ static void lookup_multiplicities(const std::vector<F>& M, size_t N, const Rom& 
       else if (PIECE_TAG[k] == TAG_NIB) { if (v < 16) (*mem_mult)[RC_TABLE + 256 + v]++; else bad(i); }
       else { if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); }
     }
+    if (WIDE) for (int k = 0; k < N_X; k++) { const F v = M[(size_t)(C_X + k) * N + i]; if (v < (F)RC_TABLE) rc_mult[v]++; else bad(i); }   // (mode 4) the six extra range slots, on every row
     F t[N_TUPLE]; row_tuple(M, N, i, t);
     const uint64_t pc = (uint64_t)t[0] | ((uint64_t)t[1] << 20) | ((uint64_t)t[2] << 40);
     const uint64_t u = (pc - 0x1000) / 4;
@@ -831,7 +889,7 @@ static E io_table_sum(const Public& pub, const LookupParams& lp) {
 static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp, std::vector<F>& A, int mode = 0) {
   A.assign((size_t)aux_width(mode) * N, 0);
   const int NH = N_RC + 1;
-  const bool MEM = mode == 3;
+  const bool MEM = mode >= 3, WIDE = mode == 4;
   std::vector<E> d((size_t)NH * N);
   for (size_t i = 0; i < N; i++) {
     for (int k = 0; k < N_RC; k++) d[NH * i + k] = esub(lp.alpha, e_from(M[(size_t)rc_col(k) * N + i]));
@@ -872,7 +930,7 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
       for (int k = 0; k < N_PIECE; k++) {
         const E h = lgop >= 0 ? einv(esub(lp.alpha, eadd(eadd(tagged(at(C_PIECE + k), TAG_AND + lgop, lp), emul_f(lp.lam[1], at(C_LB + k))), emul_f(lp.lam[2], at(C_LR + k)))))
                   : row_shift(M, N, i) ? einv(esub(lp.alpha, eadd(tagged(at(C_PIECE + k), shift_piece_tag(k, row_shift_reg(M, N, i)), lp), emul_f(lp.lam[1], at(C_LB + k)))))
-                  : row_mul(M, N, i) ? einv(esub(lp.alpha, tagged(at(C_PIECE + k), 0, lp)))
+                  : (row_mul(M, N, i) || row_wide(M, N, i, mode)) ? einv(esub(lp.alpha, tagged(at(C_PIECE + k), 0, lp)))
                               : einv(esub(lp.alpha, tagged(at(C_PIECE + k), PIECE_TAG[k], lp)));
         for (int c = 0; c < 4; c++) A[(size_t)(A_P + 4 * k + c) * N + i] = h.c[c];
         hs = eadd(hs, h);
@@ -893,6 +951,11 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
         hs = eadd(hs, esub(hr, hw));
       }
     }
+    if (WIDE) for (int k = 0; k < N_X; k++) {                 // (mode 4) XH_k = 1 / (alpha - X_k), on every row
+      const E h = einv(esub(lp.alpha, e_from(at(C_X + k))));
+      for (int c = 0; c < 4; c++) A[(size_t)(A_X + 4 * k + c) * N + i] = h.c[c];
+      hs = eadd(hs, h);
+    }
     for (int c = 0; c < 4; c++) A[(size_t)(A_S + c) * N + i] = S.c[c];       // S_i = sum over rows j < i of (hsum_j - T / N); S_0 = 0
     S = eadd(S, esub(hs, lp.t_over_n));
   }
@@ -902,10 +965,10 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
 // Stage B: AIR quotient, DEEP openings, FRI, proof bytes, verifier  (ZKIR-STARK v1)
 // =================================================================================================
 // NUM_QUERIES / POW_BITS: the DEFAULT prover parameters (Public::num_queries / pow_bits; the accepted ranges are MIN_.. / MAX_..: a proof may say more, never less)
-static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 704, MAX_QUERIES = 128, MAX_POW_BITS = 24;
+static const int NUM_QUERIES = 50, LOG_FINAL = 3, LOG_ARITY = 3, POW_BITS = 12, MAX_CONSTRAINTS = 768, MAX_QUERIES = 128, MAX_POW_BITS = 24;
 // modes 0 / 1 keep format v10 word for word; modes 2 / 3 are v11 (round 5): EBREAK is a class of its own there (no row but the halt row can sit on it), mode 3 refuses stores
 // into the code segment, and a mode-2 SEGMENT's tapes enter the transcript
-static inline uint32_t proof_version(int mode) { return mode >= 2 ? 11u : 10u; }
+static inline uint32_t proof_version(int mode) { return mode == 4 ? 12u : mode >= 2 ? 11u : 10u; }
 static const uint32_t PROOF_MAGIC = 0x46504B5Au, PROOF_VERSION = 10;   // "ZKPF"; v5: v4 (boundary states) + the program, lookup multiplicities and the aux commitment (AIR v2); v6: AIR v3 (160 columns); v7: only the columns that are not identically zero are committed (144 in default mode); v8: AIR v4 (163 logical columns); v9: AIR v5 (eight range lookups, 40 aux columns, the variant bit in the ROM tuple); v10: AIR v6 (172 logical columns, 152 / 168 committed)
 static const int HEADER_WORDS = 21 + 2 * N_STATE;                     // words before the trace root (layout in header_words())
 
@@ -983,15 +1046,16 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   boolean(s); boolean(loc[C_C0]); boolean(loc[C_C1]); boolean(loc[C_D0]); boolean(loc[C_D1]); boolean(loc[C_D2]); boolean(loc[C_NE]); boolean(loc[C_TK]); boolean(loc[C_B0]); boolean(loc[C_SB]); boolean(loc[C_NZ]);
   // 4. exactly one class; an executed row (not halt, not pad) runs as the class of its instruction word: sum_k k K_k = opclass, where
   //    opclass is part of the ROM tuple (constraint 15), i.e. the PROGRAM's word at pc decides it (default mode)
-  const bool IO = pub.mode() >= 2, MEM = pub.mode() == 3;
+  const bool IO = pub.mode() >= 2, MEM = pub.mode() >= 3, WIDE = pub.mode() == 4;
   const E Kec = IO ? eadd(eadd(loc[C_F2], loc[C_RL]), eadd(loc[C_RE], loc[C_FH])) : e_from(0);   // (mode 2) the ecall class: the sum of its four syscall flags
   const E Kld = MEM ? loc[C_KLD] : e_from(0), Kst = MEM ? loc[C_KST] : e_from(0), Kmem = eadd(Kld, Kst);   // (mode 3) loads, stores
   const E Klg = MEM ? loc[C_KLG] : e_from(0);                                                             // (mode 3) the bitwise opcodes
   const E Kmu = MEM ? loc[C_KMU] : e_from(0);                                                             // (mode 3) MUL
   const E Ksh = MEM ? loc[C_KSH] : e_from(0);                                                             // (mode 3) the shifts
-  { E sum = eadd(eadd(eadd(eadd(Kec, Kmem), Klg), Ksh), Kmu); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
+  const E Kwa = WIDE ? loc[C_KWA] : e_from(0);                                                            // (mode 4) MULH DIVU REMU DIV REM
+  { E sum = eadd(eadd(eadd(eadd(eadd(Kec, Kmem), Klg), Ksh), Kmu), Kwa); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
-    E ks = eadd(eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST))), emul_f(Kmu, (F)K_MU));
+    E ks = eadd(eadd(eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST))), emul_f(Kmu, (F)K_MU)), emul_f(Kwa, (F)K_WA));
     for (int k = 1; k < N_CLASS; k++) if (k != K_HALT && k != K_PAD) ks = eadd(ks, emul_f(K[k], (F)k));
     push(emul(nD, esub(emul(esub(one, eadd(K[K_HALT], K[K_PAD])), loc[C_OPC]), ks)));
   }
@@ -1179,6 +1243,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     for (int i = 0; i < N_RC; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
     if (IO) hs = eadd(hs, eadd(aloc[A_HO + k], aloc[A_HI + k]));
     if (MEM) { for (int i = 0; i < N_PIECE; i++) hs = eadd(hs, aloc[A_P + 4 * i + k]); hs = eadd(hs, esub(aloc[A_HMR + k], aloc[A_HMW + k])); }   // pieces and the read are looked up, the write is PROVIDED (a table entry)
+    if (WIDE) for (int i = 0; i < N_X; i++) hs = eadd(hs, aloc[A_X + 4 * i + k]);                  // (mode 4) the six extra range slots
     push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
   }
   // ---- 17. (mode 2, round 4) ECALL rows and the I/O tapes (syscall.rs:94-177).  Appended to the list: modes 0 / 1 stop here. ----
@@ -1299,7 +1364,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     for (int i = 0; i < N_PIECE; i++) {
       E d[4], pr[4];
       // (.. and on a shift row in the table shift_piece_tag names; piece 8's second element is the amount when it comes from a register)
-      E tg = eadd(emul_f(esub(esub(esub(one, Klg), Ksh), Kmu), PIECE_TAG[i]), lgtag);             // (a MUL row: the 10-bit range table in every slot)
+      E tg = eadd(emul_f(esub(esub(esub(esub(one, Klg), Ksh), Kmu), Kwa), PIECE_TAG[i]), lgtag);  // (a MUL row, a wide-arithmetic row: the 10-bit range table in every slot)
       if (i == 7) tg = eadd(tg, emul_f(Ksh, TAG_NIB));
       if (i == 8) tg = eadd(tg, emul_f(esub(Ksh, loc[C_SI]), TAG_LOW6));
       for (int k = 0; k < 4; k++) d[k] = esub(esub(esub(cst(lp.alpha.c[k]), emul_f(tg, lp.lam[N_TUPLE].c[k])), emul_f(loc[C_LB + i], lp.lam[1].c[k])), emul_f(loc[C_LR + i], lp.lam[2].c[k]));
@@ -1391,6 +1456,59 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
         push(esub(t, emul(Kmu, lin)));
       }
       push(emul(Kmu, esub(y[0], eadd(Rlo[0], emul_f(Rlo[1], RC_TABLE))))); push(emul(Kmu, esub(y[1], eadd(Rlo[2], emul_f(Rlo[3], RC_TABLE))))); push(emul(Kmu, y[2]));
+    }
+    // ---- 22. (mode 4, round 6) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI, schoolbook in 10-bit chunks.  Appended: mode 3 stops above. ----
+    if (WIDE) {
+      const E* Rlo = loc + C_RC; const E* Rf = loc + C_RC2; const E* gf = loc + C_GF; const E* we = loc + C_WE; const E* X = loc + C_X;
+      const E om = loc[C_OM], od = loc[C_OD], orr = loc[C_ORR], sg = loc[C_SG], kd = eadd(od, orr);
+      boolean(Kwa); boolean(om); boolean(od); boolean(orr); boolean(sg);
+      for (int k = 0; k < N_WE; k++) boolean(we[k]);
+      push(esub(Kwa, eadd(om, kd)));                                                              // one of the three kinds on a wide row, none elsewhere
+      push(esub(emul(Kwa, op), eadd(eadd(emul_f(om, 3), emul_f(od, 4)), eadd(emul_f(orr, 5), emul_f(sg, 2)))));   // the opcode: MULH 3, DIVU 4, REMU 5, DIV 6, REM 7
+      push(emul(sg, esub(one, kd)));                                                              // the signed variants exist for the divisions only
+      push(emul(Kwa, esub(w1, fa)));                                                              // rd = field a
+      push(emul(Kwa, xb[2])); push(emul(Kwa, xc[2]));                                             // the operands are below 2^40 (what makes DIV = DIVU, REM = REMU, MULH the product's bits 40..79)
+      const E two10 = cst(RC_TABLE);
+      push(emul(Kwa, esub(esub(xc[0], pcs[0]), emul(two10, pcs[1])))); push(emul(Kwa, esub(esub(xc[1], pcs[2]), emul(two10, pcs[3]))));      // F2 = rs2, always
+      push(emul(om, esub(esub(xb[0], Rf[0]), emul(two10, Rf[1])))); push(emul(om, esub(esub(xb[1], Rf[2]), emul(two10, Rf[3]))));            // MULH: F1 = rs1
+      push(emul(kd, esub(esub(xb[0], Rlo[0]), emul(two10, Rlo[1])))); push(emul(kd, esub(esub(xb[1], Rlo[2]), emul(two10, Rlo[3]))));        // divisions: LO = rs1, the dividend
+      for (int k = 0; k < 4; k++) push(esub(gf[k], emul(Kwa, Rf[k])));                            // gf_k = kwa F1_k
+      const E G4[4] = {pcs[7], pcs[8], X[0], X[1]};
+      const E c[6] = {pcs[4], eadd(pcs[5], emul(two10, we[0])), eadd(pcs[6], emul(two10, eadd(we[1], emul_f(we[2], 2)))),
+                      eadd(X[2], emul(two10, eadd(we[3], emul_f(we[4], 2)))), eadd(X[3], emul(two10, eadd(we[5], emul_f(we[6], 2)))), eadd(X[4], emul(two10, eadd(we[7], emul_f(we[8], 2))))};
+      for (int k = 0; k < 7; k++) {
+        E t = e_from(0);
+        for (int j = 0; j < 4; j++) if (k - j >= 0 && k - j < 4) t = eadd(t, emul(gf[j], pcs[k - j]));
+        if (k < 4) {                                                                              // low half: + ADD_k + c_(k-1) = LO_k + 2^10 c_k; the carry OUT of position 3 exists on MULH rows only
+          t = eadd(t, emul(kd, G4[k]));
+          E lin = Rlo[k];
+          if (k < 3) lin = eadd(lin, emul(two10, c[k]));
+          if (k) lin = esub(lin, c[k - 1]);
+          t = esub(t, emul(Kwa, lin));
+          if (k == 3) t = esub(t, emul(om, emul(two10, c[3])));
+        } else {                                                                                  // high half (MULH): + c_(k-1) = HI_(k-4) + 2^10 c_k (k = 6: 2^10 HI_3); a division has nothing there
+          const E hi = k < 6 ? eadd(G4[k - 4], emul(two10, c[k])) : eadd(G4[2], emul(two10, G4[3]));
+          t = eadd(t, emul(om, esub(c[k - 1], hi)));
+        }
+        push(t);
+      }
+      // divisions: the remainder is smaller than the divisor: d = rs2 - r - 1 >= 0 in chunks X2..X5, borrow e4 between the limbs (which also says rs2 != 0)
+      const E r0 = eadd(G4[0], emul(two10, G4[1])), r1 = eadd(G4[2], emul(two10, G4[3])), d0 = eadd(X[2], emul(two10, X[3])), d1 = eadd(X[4], emul(two10, X[5]));
+      push(emul(kd, eadd(esub(esub(esub(xc[0], r0), one), d0), emul(two20, we[3]))));
+      push(emul(kd, esub(esub(esub(xc[1], r1), we[3]), d1)));
+      // what is written: HI (MULH) and the remainder (REMU / REM) sit in G4, the quotient (DIVU / DIV) in F1
+      const E g = eadd(om, orr);
+      push(emul(g, esub(y[0], r0))); push(emul(g, esub(y[1], r1)));
+      push(emul(od, esub(esub(y[0], Rf[0]), emul(two10, Rf[1])))); push(emul(od, esub(esub(y[1], Rf[2]), emul(two10, Rf[3]))));
+      push(emul(Kwa, y[2]));
+      // the six extra range slots: XH_i (alpha - X_i) = 1, on every row
+      for (int i = 0; i < N_X; i++) {
+        E d[4], pr[4];
+        for (int k = 0; k < 4; k++) d[k] = cst(lp.alpha.c[k]);
+        d[0] = esub(d[0], X[i]);
+        ext_mul(aloc + A_X + 4 * i, d, pr);
+        push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
+      }
     }
   }
   result = A.acc;
@@ -1495,13 +1613,13 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   w.push_back((uint32_t)pub.blob_len);
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
   if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the tapes and the halt reason: what the io digest is a digest of; (v11) fixed BEFORE the lookup challenges — a SEGMENT's tapes too, whose digest only the chain checks
-  if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
+  if (Dm >= 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
   lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult, nullptr, Dm, &pt.mem_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
   w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
   ch.observe_n(pt.rom_mult.data(), pt.rom_mult.size());
   ch.observe_n(pt.rc_mult.data(), pt.rc_mult.size());
-  if (Dm == 3) { w.insert(w.end(), pt.mem_mult.begin(), pt.mem_mult.end()); ch.observe_n(pt.mem_mult.data(), pt.mem_mult.size()); }
+  if (Dm >= 3) { w.insert(w.end(), pt.mem_mult.begin(), pt.mem_mult.end()); ch.observe_n(pt.mem_mult.data(), pt.mem_mult.size()); }
   pt.lp.alpha = ch.sample_ext();
   {
     const E lambda = ch.sample_ext();
@@ -1510,9 +1628,9 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   }
   pt.lp.n_in = (F)(pub.n_in % P);
   {
-    E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp, Dm == 3 ? pt.mem_mult.data() : nullptr);
+    E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp, Dm >= 3 ? pt.mem_mult.data() : nullptr);
     if (Dm >= 2) T = eadd(T, io_table_sum(pub, pt.lp));
-    if (Dm == 3) T = eadd(T, mem_table_sum(pub, pt.lp));
+    if (Dm >= 3) T = eadd(T, mem_table_sum(pub, pt.lp));
     pt.lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   // ---- aux trace: helper columns + running sum; its own LDE and commitment ----
@@ -1727,14 +1845,14 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
   w.push_back((uint32_t)pub.blob_len);
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
   if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
-  if (Dm == 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
+  if (Dm >= 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
   std::vector<F> rom_mult, rc_mult, mem_mult;
   lookup_multiplicities(M, N, rom, rom_mult, rc_mult, nullptr, Dm, &mem_mult);
   w.insert(w.end(), rom_mult.begin(), rom_mult.end());
   w.insert(w.end(), rc_mult.begin(), rc_mult.end());
   ch.observe_n(rom_mult.data(), rom_mult.size());
   ch.observe_n(rc_mult.data(), rc_mult.size());
-  if (Dm == 3) { w.insert(w.end(), mem_mult.begin(), mem_mult.end()); ch.observe_n(mem_mult.data(), mem_mult.size()); }
+  if (Dm >= 3) { w.insert(w.end(), mem_mult.begin(), mem_mult.end()); ch.observe_n(mem_mult.data(), mem_mult.size()); }
   LookupParams lp;
   lp.alpha = ch.sample_ext();
   {
@@ -1744,9 +1862,9 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
   }
   lp.n_in = (F)(pub.n_in % P);
   {
-    E T = lookup_table_sum(rom, rom_mult.data(), rc_mult.data(), lp, Dm == 3 ? mem_mult.data() : nullptr);
+    E T = lookup_table_sum(rom, rom_mult.data(), rc_mult.data(), lp, Dm >= 3 ? mem_mult.data() : nullptr);
     if (Dm >= 2) T = eadd(T, io_table_sum(pub, lp));
-    if (Dm == 3) T = eadd(T, mem_table_sum(pub, lp));
+    if (Dm >= 3) T = eadd(T, mem_table_sum(pub, lp));
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   std::vector<F> AL((size_t)Wa * N2);
@@ -1924,14 +2042,14 @@ static bool last_row_writes(const uint32_t* w, const F* last, int halt_kind, uin
 static int verify(const uint32_t* w, size_t len, const Public* expect, bool whole_run = true, F* states_out = nullptr, F* counters_out = nullptr) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
-  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[9] > 3 || w[1] != proof_version((int)w[9])) return 1;
+  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[9] > 4 || w[1] != proof_version((int)w[9])) return 1;
   const int log_n = w[2], Wm = w[3], nq = w[4], log_final = w[5], pow_bits = (int)w[6];
   // the prover's parameters: what `expect` names (0 = the defaults) when there is one; otherwise anything from the defaults up (never fewer queries / bits than those)
   if (expect ? (nq != expect->num_queries() || pow_bits != expect->pow_bits()) : (nq < NUM_QUERIES || pow_bits < POW_BITS)) return 2;
   if (nq > MAX_QUERIES || pow_bits > MAX_POW_BITS || log_final != LOG_FINAL || log_n < LOG_FINAL || log_n > 26) return 2;
   Public pub;
   pub.fri = (uint32_t)nq | ((uint32_t)pow_bits << 16);
-  if (w[9] > 3 || Wm != phys_width((int)w[9])) return 2;                 // the committed width is the mode's (0 default, 1 deferred, 2 default + I/O)
+  if (w[9] > 4 || Wm != phys_width((int)w[9])) return 2;                 // the committed width is the mode's (0 default, 1 deferred, 2 default + I/O)
   const int mode = (int)w[9];
   const int HW = header_words_of(mode), Wa = aux_width(mode);
   if (!need(HW)) return 1;
@@ -1942,7 +2060,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   memcpy(pub.first, w + 21, N_STATE * 4); memcpy(pub.last, w + 21 + N_STATE, N_STATE * 4);
   for (int i = 0; i < 2 * N_STATE; i++) if (w[21 + i] >= P) return 3;
   if (pub.n_real == 0 || padded_log_n(pub.n_real) != log_n) return 2;
-  if (mode == 3 && !whole_run) return 2;                                  // the memory check spans the whole run: a mode-3 proof is never a segment
+  if (mode >= 3 && !whole_run) return 2;                                  // the memory check spans the whole run: a mode-3 proof is never a segment
   if (mode >= 2) { for (int k = 0; k < 4; k++) if (w[HEADER_WORDS + k] >= P) return 3; memcpy(pub.cnt_first, w + HEADER_WORDS, 8); memcpy(pub.cnt_last, w + HEADER_WORDS + 2, 8); }
   if (counters_out) { memcpy(counters_out, pub.cnt_first, 8); memcpy(counters_out + 2, pub.cnt_last, 8); }
   if (expect && (expect->n_real != pub.n_real || expect->deferred != pub.deferred || expect->entry != pub.entry ||
@@ -1993,7 +2111,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   }
   // (mode 3) the touched cells: canonical (20-bit limbs, a multiple of 8), strictly increasing — every cell has ONE initial tuple (check 54)
   const uint32_t* mem_words = nullptr; size_t mem_len = 0;
-  if (mode == 3) {
+  if (mode >= 3) {
     if (!need(1)) return 4;
     const size_t nc = w[p];
     if (nc > ((size_t)1 << 28) || !need(1 + 7 * nc)) return 4;
@@ -2014,11 +2132,11 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     }
     p += mem_len;
   }
-  if (!need(rom.n + RC_TABLE + (mode == 3 ? MEM_MULT : 0))) return 4;
+  if (!need(rom.n + RC_TABLE + (mode >= 3 ? MEM_MULT : 0))) return 4;
   const F* rom_mult = w + p; p += rom.n;
   const F* rc_mult = w + p; p += RC_TABLE;
   const F* mem_mult = nullptr;
-  if (mode == 3) { mem_mult = w + p; p += MEM_MULT; }
+  if (mode >= 3) { mem_mult = w + p; p += MEM_MULT; }
   if (!need(12)) return 4;
   const F* troot = w + p; p += 4; const F* aroot = w + p; p += 4; const F* qroot = w + p; p += 4;
   auto get_e = [&](size_t at) { E e; memcpy(e.c, w + at, 16); return e; };
@@ -2043,10 +2161,10 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   ch.observe_n(w + 2, HW - 2);
   ch.observe_n(troot, 4);
   if (mode >= 2) observe_section(ch, io_words, io.words);
-  if (mode == 3) observe_section(ch, mem_words, mem_len);
+  if (mode >= 3) observe_section(ch, mem_words, mem_len);
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
-  if (mode == 3) ch.observe_n(mem_mult, MEM_MULT);
+  if (mode >= 3) ch.observe_n(mem_mult, MEM_MULT);
   LookupParams lp;
   lp.alpha = ch.sample_ext();
   {
@@ -2058,7 +2176,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   {
     E T = lookup_table_sum(rom, rom_mult, rc_mult, lp, mem_mult);           // the table side of the lookup identity, computed HERE
     if (mode >= 2) T = eadd(T, io_table_sum(pub, lp));                     // .. its I/O share from the tapes the proof carries
-    if (mode == 3) T = eadd(T, mem_table_sum(pub, lp));                    // .. and both ends of the memory check from the touched cells it carries
+    if (mode >= 3) T = eadd(T, mem_table_sum(pub, lp));                    // .. and both ends of the memory check from the touched cells it carries
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   ch.observe_n(aroot, 4);
@@ -2182,7 +2300,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
 // segment i failed.
 static int verify_chain(const uint32_t* const* proofs, const size_t* lens, int n, const Public* expect) {
   if (n < 1) return 40;
-  if (n == 1 && lens[0] > 9 && proofs[0][9] == 3) return verify(proofs[0], lens[0], expect, true);   // a mode-3 proof is a whole run by itself (never a segment): a "chain" of one
+  if (n == 1 && lens[0] > 9 && proofs[0][9] >= 3) return verify(proofs[0], lens[0], expect, true);   // a mode-3 proof is a whole run by itself (never a segment): a "chain" of one
   std::vector<F> st((size_t)n * 2 * N_STATE), cnt((size_t)n * 4, 0);
   uint64_t total = 1;
   for (int i = 0; i < n; i++) {
@@ -2426,7 +2544,7 @@ int so_constraints_eval_states(const uint32_t* loc, const uint32_t* nxt, const u
 int so_constraints_eval_io(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk57, uint32_t is_first, uint32_t is_last,
                            uint32_t is_trans, const so_public* pub, const uint32_t* first68, const uint32_t* last68, const uint32_t* cnt4, const uint32_t* alpha4, uint32_t* out4) {
   so::Public q = to_pub(pub);
-  if (q.deferred != 3) q.deferred = 2;
+  if (q.deferred < 3) q.deferred = 2;
   const int mode = q.mode(), NC = so::num_constraints(mode), Wl = so::logical_width(mode), Wa = so::aux_width(mode);
   so::E a; memcpy(a.c, alpha4, 16);
   std::vector<so::E> ap(NC); ap[0] = so::e_from(1); for (int c = 1; c < NC; c++) ap[c] = so::emul(ap[c - 1], a);
@@ -2577,9 +2695,9 @@ size_t so_failing_constraints(const uint32_t* matrix, const so_public* pub, cons
   lp.lam[0] = so::e_from(1);
   for (int j = 1; j <= so::N_TUPLE; j++) lp.lam[j] = so::emul(lp.lam[j - 1], lambda);
   lp.n_in = (so::F)(q.n_in % so::P);
-  so::E T = so::lookup_table_sum(rom, rm.data(), cm.data(), lp, mode == 3 ? mm.data() : nullptr);
+  so::E T = so::lookup_table_sum(rom, rm.data(), cm.data(), lp, mode >= 3 ? mm.data() : nullptr);
   if (mode >= 2) T = so::eadd(T, so::io_table_sum(q, lp));
-  if (mode == 3) T = so::eadd(T, so::mem_table_sum(q, lp));
+  if (mode >= 3) T = so::eadd(T, so::mem_table_sum(q, lp));
   lp.t_over_n = so::emul_f(T, so::finv((so::F)(N % so::P)));
   so::aux_trace(M, N, lp, A, mode);
   const int NC = so::num_constraints(mode);

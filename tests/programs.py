@@ -132,6 +132,22 @@ def mul_grid():
     return _p(code + [EB]), [], {}
 
 
+def wide_grid():
+    """MULH DIVU REMU DIV REM (execute.rs:101-183) on a grid of operands BELOW 2^40 (AIR mode 4's domain): zero and one, all ones, the sign bit of a 40-bit value (positive as an
+    i64: quirk Q2), every chunk at its extremes (the largest carries of the 80-bit product), dividend < divisor, equal operands, powers of two, rs1 = rs2 = rd, rd = r0."""
+    vals = [0, 1, 2, 0xFFFFFFFFFF, 0x8000000000, 0xF0F0A5C3E1, 0x0312345678, 1023, 1024, 0xFFFFF, 0x100000, 0x3FF003FF, 0xFFC00FFC00, 0x7FFFFFFFFF]
+    code = []
+    for a in vals:
+        code += li40(1, a)
+        for b in vals:
+            code += li40(2, b) + [E(O.MULH, 3, 1, 2), E(O.MULH, 4, 2, 1)]
+            if b:
+                code += [E(O.DIVU, 5, 1, 2), E(O.REMU, 6, 1, 2), E(O.DIV, 7, 1, 2), E(O.REM, 8, 1, 2)]
+        code += [E(O.MULH, 9, 1, 1)] + ([E(O.DIVU, 9, 1, 1), E(O.REM, 0, 1, 1)] if a else [])
+    code += li40(1, 0xFEDCBA9876) + [E(O.REMU, 1, 1, 1)] + li40(1, 0xFEDCBA9876) + [E(O.DIV, 1, 1, 1), E(O.MULH, 1, 1, 1)]
+    return _p(code + [EB]), [], {}
+
+
 def loads_stores():
     code = [A(5, 0, 0x4000)] + li40(1, 0x80F1E2D3C4) + [A(2, 0, -1)]
     code += [E(O.SD, rs1=5, rs2=1, imm=0), E(O.SW, rs1=5, rs2=1, imm=8), E(O.SH, rs1=5, rs2=1, imm=12), E(O.SB, rs1=5, rs2=1, imm=14),
