@@ -366,12 +366,48 @@ def test_commitment_root_equals_the_oracles_at_config_size(k):
     ctx.close(); log.close()
 
 
-@pytest.mark.parametrize("k", [12, 16, 18, 20, 22, 23])
+def test_config3_row_sharded_commitment_equals_the_oracles_at_full_size():
+    """BASELINE configs[3]'s OWN workload on one device: the 2^26-cycle fib run cut into 8 row shards of 2^23 rows; every shard goes through what one rank
+    of `bench.py --gpus 8` runs — zkir_interpret_window (rows before the shard executed untraced, the shard traced), upload, trace fill, main trace, LDE, Merkle subtree — one
+    after the other on this GPU, and the 8 subtree roots are capped by zkir_merkle_cap_launch (what every rank computes after the all-gather).  Every subtree root and the
+    capped root equal tests/golden/config_roots.json["26x8"], which the CPU oracle computed shard by shard (make_config_roots.py sharded 26 8: 47 minutes on 6 threads).
+    With it configs[3]'s data path is bit-exact at full size everywhere except the xGMI hop itself (16 bytes per rank)."""
+    import json
+    import os
+    import torch
+    from zkir_amd import pipeline as pl, stark
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_roots.json")))
+    g = gold["roots"].get("26x8")
+    if not g or "root" not in g:
+        pytest.skip("no oracle answer for the 8 x 2^23 sharded run in the fixture")
+    blob = spec.fib_endless_program().to_bytes()
+    assert blob.hex() == gold["program_blob_hex"]
+    G, n, total = g["shards"], g["rows_per_shard"], g["rows"]
+    ctx = stark.StarkContext(23)
+    roots = []
+    for r in range(G):
+        log = rt.interpret(blob, [], rt.VMConfig(max_cycles=total, enable_execution_trace=True), window=(r * n, (r + 1) * n))
+        assert log.n_rows == n and log.cycle_base == r * n
+        ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+        root, L, tree = stark.commit_trace(ctx, tr)
+        assert [int(x) for x in root] == g["shard_roots"][r], f"shard {r}"
+        roots.append(tree[-4:].clone())
+        del L, tree, tr, ddl
+        log.close()
+        torch.cuda.empty_cache()
+    top = stark.merkle_cap(ctx, torch.stack(roots)).cpu().numpy().view(np.uint32)
+    assert [int(x) for x in top] == g["root"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("k", [12, 16, 18, 20, 22, 23, 24])
 def test_proof_equals_the_oracles_at_config_size(k):
     """BASELINE's metric is "end-to-end prove ms, 2^20-cycle fib" and north_star asks for bit-identical proof bytes: the GPU prover's COMPLETE proof of that run
     (and of three smaller sizes) equals the proof the CPU oracle computed for it — tests/golden/config_proofs.json (length, SHA-256 of the words, 257 spaced
     words), written by tests/golden/make_config_proofs.py from the oracle alone (~13 minutes of textbook arithmetic at 2^20: a fixture, not a per-run
-    computation).  tests/test_gpu_stark.py compares whole proofs word for word up to 2^13 rows; this is the same statement at the headline size."""
+    computation).  tests/test_gpu_stark.py compares whole proofs word for word up to 2^13 rows; this is the same statement at the headline size.
+    k = 24 is BASELINE configs[2] as worded ("2^24-cycle fib ... end-to-end proof bit-exact"; round 6): the golden comes from the oracle's memory-lean threaded prover
+    so::prove_lean, which tests/test_stark_oracle.py::test_lean_prover_equals_the_plain_one holds equal to so::prove word for word in every mode."""
     import hashlib
     import json
     import os
