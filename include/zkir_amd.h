@@ -300,6 +300,11 @@ int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, co
 int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
                                void* hip_stream);
 int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out);
+/* The main trace of MODE 4 (round 6: mode 3 + the wide-arithmetic class — MULH / DIVU / REMU / DIV / REM, execute.rs:101-183, on operands below 2^40: 288 committed columns, six more
+ * 10-bit range values per row); arguments as zkir_main_trace_mem_launch / _host. */
+int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
+                                void* hip_stream);
+int zkir_main_trace_wide_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out);
 /* the same rows computed on the HOST (trace = host pointers, out = host buffer, same B8 layout): the kernel's per-row code is one host + device
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */

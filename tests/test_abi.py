@@ -349,6 +349,88 @@ def test_memcheck_witness_and_main_trace_mode3_match_oracle_on_the_host(name):
         assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"
 
 
+# ---- MODE 4 (round 6): mode 3 + the wide-arithmetic class MULH / DIVU / REMU / DIV / REM — the product's host-side pieces against the oracle (no GPU) ------------------------
+def test_air_bounds_mode4():
+    """The quotient kernel's lazy arithmetic is sound on the mode-4 constraint list (704 constraints) too (air::BoundOps on air::eval)."""
+    import ctypes as C
+    L = rt.lib()
+    why = C.create_string_buffer(256)
+    L.zkir_air_check_bounds.restype = C.c_int
+    L.zkir_air_check_bounds.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    assert L.zkir_air_check_bounds(4, why, 256) == 0, why.value.decode()
+
+
+def test_quotient_evaluation_matches_oracle_constraints_mode4():
+    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 4: 308 logical / 120 aux columns, 704 constraints."""
+    import ctypes as C
+    import numpy as np
+    from oracle import stark_api as so
+    L = rt.lib()
+    L.zkir_air_eval_host.restype = None
+    L.zkir_air_eval_host.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_void_p]
+    LO = so.lib()
+    LO.so_constraints_eval_io.restype = C.c_int
+    LO.so_constraints_eval_io.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 6
+    P = so.P
+    rng = np.random.default_rng(2029)
+    virt = [9, 10, 11] + list(range(57, 73)) + [161]
+    blob = spec.fib_program(5).to_bytes()
+    pub = so.public_inputs(64, blob, [], [5], (1, 0), wide_mode=True)
+    assert LO.so_num_constraints_for(4) == 704 and so.logical_width(4) == 308 and so.aux_width(4) == 120 and so.committed_width(4) == 288
+    for trial in range(40):
+        big = trial >= 36
+        def words(n):
+            return np.full(n, P - 1, np.uint32) if big else rng.integers(0, P, n).astype(np.uint32)
+        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(308), words(308), words(120), words(120), words(57), words(68), words(68), words(4), words(4), words(3)
+        loc[virt] = 0; nxt[virt] = 0
+        want, got = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+        LO.so_constraints_eval_io(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]), C.byref(pub),
+                                  first.ctypes.data, last.ctypes.data, cnt.ctypes.data, alpha.ctypes.data, want.ctypes.data)
+        L.zkir_air_eval_host(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]),
+                             first.ctypes.data, last.ctypes.data, alpha.ctypes.data, 4, cnt.ctypes.data, got.ctypes.data)
+        assert np.array_equal(got, want), (trial, got, want)
+
+
+@pytest.mark.parametrize("name", ["wide_grid", "alu_all", "loads_stores", "random3"])
+def test_main_trace_mode4_matches_oracle_on_the_host(name):
+    """zkir_main_trace_wide_host (stark.hip: main_trace_row<4>) writes the oracle's mode-4 main trace: every committed column of every row — the five wide opcodes over a grid
+    of operands (the largest carries, dividend < divisor, equal operands, rd = r0), and the mode-3 columns unchanged on programs that use none of them."""
+    import ctypes as C
+    import numpy as np
+    import programs as pg
+    from oracle import api as oracle, stark_api as so
+    if name.startswith("random"):
+        blob, ins = pg.random_program(int(name[6:]), hashes=False); cfg = {}
+    else:
+        blob, ins, cfg = getattr(pg, name)()
+    cfg = {k: v for k, v in cfg.items() if k == "max_cycles"}
+    res = oracle.run(blob, list(ins), enable_execution_trace=True, **cfg)
+    rows, nr = res.rows, len(res.rows)
+    log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True, **cfg))
+    pub = rt.public_inputs(log, blob, list(ins), wide_mode=True, mem_witness="host")
+    opub = so.public_inputs(nr, blob, list(ins), list(res.outputs), (res.halt_kind, res.halt_code), wide_mode=True)
+    assert pub.deferred == 4 and list(pub.io_digest) == list(opub.io)
+    cyc, pc, ins_c = (np.ascontiguousarray(rows[f]) for f in ("cycle", "pc", "instruction"))
+    regs, bb_, bt, bp, st = (np.ascontiguousarray(rows[f].T) for f in ("registers", "bound_bits", "bound_tag", "bound_payload", "reg_state"))
+    tc = rt.TraceColumnsC(cyc.ctypes.data, pc.ctypes.data, ins_c.ctypes.data, regs.ctypes.data, bb_.ctypes.data, bt.ctypes.data, bp.ctypes.data, st.ctypes.data, nr)
+    N = 1 << so.padded_log_n(nr)
+    wm = so.committed_width(4)
+    out = np.zeros((wm // 8, N, 8), np.uint32)
+    tape = np.asarray(list(ins) if len(ins) else [0], dtype=np.uint64)
+
+    class IoArgs(C.Structure):
+        _fields_ = [("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+    io = IoArgs(tape.ctypes.data, len(ins), 0, 0)
+    L = rt.lib()
+    L.zkir_main_trace_wide_host.restype = C.c_int
+    L.zkir_main_trace_wide_host.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.zkir_main_trace_wide_host(C.byref(tc), nr, C.byref(io), pub.mem_old, pub.mem_told, out.ctypes.data) == 0
+    got = out.transpose(0, 2, 1).reshape(wm, N)
+    want = so.to_committed(so.main_trace(rows, opub), 4)
+    for k in range(wm):
+        assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"
+
+
 def test_memcheck_witness_refuses_runs_outside_the_air():
     import programs as pg
     blob, ins, _ = pg.sha256_hello()

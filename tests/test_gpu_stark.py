@@ -570,7 +570,7 @@ def test_mode2_forged_outputs_are_rejected_on_the_gpu_path():
 
 
 # ---- MODE 3 (round 4): mode 2 + the memory argument ------------------------------------------------------------------------------------------------------------
-def _mode3_case(which, witness="device"):
+def _mode3_case(which, witness="device", wide=False):
     from zkir_amd import pipeline as pl
     import programs as pg
     cfg = {}
@@ -587,9 +587,9 @@ def _mode3_case(which, witness="device"):
     log = rt.interpret(blob, list(ins), rt.VMConfig(enable_execution_trace=True, **cfg))
     assert log.n_rows == len(ores.rows)
     ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
-    opub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), mem_mode=True)
-    pub = rt.public_inputs(log, blob, list(ins), mem_mode=True, mem_witness=witness)
-    assert pub.deferred == 3 and list(pub.io_digest) == list(opub.io)
+    opub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), mem_mode=not wide, wide_mode=wide)
+    pub = rt.public_inputs(log, blob, list(ins), mem_mode=not wide, wide_mode=wide, mem_witness=witness)
+    assert pub.deferred == (4 if wide else 3) and list(pub.io_digest) == list(opub.io)
     return blob, list(ins), ores, log, tr, opub, pub
 
 
@@ -614,6 +614,55 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
         t = proof.copy()
         t[pos] = (int(t[pos]) + 1) % P
         assert so.verify(t) != 0 and rt.verify(t) == so.verify(t), pos
+    ctx.close(); log.close()
+
+
+# ---- MODE 4 (round 6): mode 3 + MULH / DIVU / REMU / DIV / REM on operands below 2^40 -----------------------------------------------------------------------
+@pytest.mark.parametrize("witness", ["device", "host"])
+@pytest.mark.parametrize("which", ["wide_grid", "alu_all", "timestamps", "mul_grid", "random3", "random5", "memloop", "fib30"])
+def test_mode4_proof_bytes_match_oracle_and_verify(which, witness):
+    """A proof in mode 4 (format v12: 288 + 120 columns, 704 constraints) — the five wide opcodes constrained as F1 F2 + ADD = LO + 2^40 HI over 10-bit chunks, everything of
+    mode 3 beside them — from the GPU prover equals the oracle's word for word; both verifiers accept it and give the same verdict on tampered copies."""
+    from zkir_amd import stark
+    blob, ins, ores, log, tr, opub, pub = _mode3_case(which, witness, wide=True)
+    ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
+    proof = stark.prove(ctx, tr, pub)
+    want = so.prove(ores.rows, opub)
+    assert proof[1] == 12 and proof[3] == 288 and proof[9] == 4 and len(proof) == len(want)
+    if not np.array_equal(proof, want):
+        bad = np.nonzero(proof != want)[0]
+        raise AssertionError(f"mode-4 proof differs at word {bad[0]} of {len(want)} ({len(bad)} words differ)")
+    assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0 and rt.verify(proof) == 0
+    assert rt.verify_io(proof, pub, ins, list(ores.outputs), (ores.halt_kind, ores.halt_code)) == 0
+    for pos in (8, 30, 158, 160, len(proof) // 2, len(proof) - 1):
+        t = proof.copy()
+        t[pos] = (int(t[pos]) + 1) % P
+        assert so.verify(t) != 0 and rt.verify(t) == so.verify(t), pos
+    ctx.close(); log.close()
+
+
+def test_mode4_refuses_wide_operands_above_40_bits():
+    """The five wide opcodes are stated on operands below 2^40 (what makes DIV = DIVU, REM = REMU and MULH the product's bits 40..79: quirks Q2, Q3 on raw 64-bit registers
+    are outside the AIR).  A run that divides a register sign-extended by LB (0xFFFF...FF80) has no mode-4 proof: the GPU prover refuses it naming the row, and both verifiers
+    reject the oracle's proof of it at the constraint check (I_WA_TOP)."""
+    from zkir_amd import pipeline as pl, stark
+    import programs as pg
+    O, E = spec.Opcode, spec.encode
+    blob = pg._p([pg.A(5, 0, 0x4000), pg.A(1, 0, 0x80), E(O.SB, rs1=5, rs2=1, imm=0), E(O.LB, 2, 5, imm=0), pg.A(3, 0, 7), E(O.DIVU, 4, 2, 3), E(O.MULH, 6, 3, 2), pg.EB])
+    ores = oracle.run(blob, [], enable_execution_trace=True)
+    log = rt.interpret(blob, [], rt.VMConfig(enable_execution_trace=True))
+    ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
+    opub = so.public_inputs(len(ores.rows), blob, [], list(ores.outputs), (ores.halt_kind, ores.halt_code), wide_mode=True)
+    pub = rt.public_inputs(log, blob, [], wide_mode=True)
+    ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
+    with pytest.raises(rt.RuntimeError) as e:
+        stark.prove(ctx, tr, pub)
+    assert e.value.code == rt.ERR_ARGUMENT and "row 5" in e.value.message and "bits above 40" in e.value.message
+    want = so.prove(ores.rows, opub)
+    assert so.verify(want, opub) == 10 and rt.verify(want) == 10
+    # the same run in mode 3 (the five opcodes free, class "other") has a proof
+    pub3 = rt.public_inputs(log, blob, [], mem_mode=True)
+    assert rt.verify(stark.prove(ctx, tr, pub3), pub3) == 0
     ctx.close(); log.close()
 
 

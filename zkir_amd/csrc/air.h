@@ -58,8 +58,8 @@
 
 namespace air {
 
-constexpr int W = 284;                                         // logical columns of MODE 3; mode 2 uses the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
-constexpr int W_LOGICAL_BASE = 172, W_LOGICAL_IO = 180;
+constexpr int W = 308;                                         // logical columns of MODE 4; mode 3 uses the first 284 (W_LOGICAL_MEM), mode 2 the first 180 (W_LOGICAL_IO), modes 0 / 1 the first 172 (W_LOGICAL_BASE)
+constexpr int W_LOGICAL_BASE = 172, W_LOGICAL_IO = 180, W_LOGICAL_MEM = 284;
 // MODES (the header's word 9, zkir_public_inputs::deferred): 0 = default VM mode, 1 = deferred carry model, 2 (round 4) = default mode WITH the I/O argument:
 // ECALL is a class of its own there (id K_ECALL, no column: Kec = f2 + rl + re + fh), dispatched on R10's limbs — f2 = WRITE (R10 = 2), rl / re = READ (R10 = 1) on a
 // non-empty / exhausted input tape, fh = a hash syscall (R10 = 3 + h0 + 2 h1) — oc / ic count the outputs written / inputs consumed before the row; WRITE rows send
@@ -92,8 +92,21 @@ enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PI
              // pieces 0-3, the result's chunks r_k = R0..R3 (= z), and for k = 0..3  sum_{i+j=k} a_i b_j + carry_(k-1) = r_k + 2^10 carry_k  with carry_0 = piece 4, carry_1 =
              // piece 5 + 2^10 e_1, carry_2 = piece 6 + 2^10 (e_2 + 2 e_3), carry_3 = piece 7 + 2^10 piece 8 (dropped) — every slot a 10-bit range lookup on such a row: both sides
              // stay below p, the equations hold over the integers.  The products have degree 2 already, so the class cannot gate them: ma_i = kmu a_i are columns (zero elsewhere).
-             C_KMU = 276, C_MA = 277, C_ME = 281 };
-constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, N_WIN = 15, N_PIECE = 9, N_NIB = 10;
+             C_KMU = 276, C_MA = 277, C_ME = 281,
+             // MODE 4 (round 6, proof format v12) = mode 3 WITH the wide-arithmetic class wa = 22: MULH DIVU REMU DIV REM (opcodes 3..7, execute.rs:101-183) on operands BELOW 2^40.
+             // The reference computes the five on the raw 64-bit registers (quirks Q2, Q3); for registers below 2^40 an i64 is non-negative, so DIV = DIVU, REM = REMU, the product has
+             // 80 bits, and all five are ONE relation  F1 F2 + ADD = LO + 2^40 HI  over 40-bit integers (MULH: a b = L + 2^40 y; DIVU / DIV: y b + r = a, r < b; REMU / REM: q b + y =
+             // a, y < b).  A wa row states kwa xb2 = kwa xc2 = 0: a run that feeds one of the five a register with bits above 40 has no mode-4 proof (zkir_prove refuses it).
+             // Schoolbook in 10-bit chunks like MUL; the 80-bit product, the addend and the remainder's range check need 23 lookups where a mode-3 row has 17, so the mode adds SIX
+             // 10-bit range slots X0..X5 per row (24 aux columns XH0..XH5) and 18 main columns:  kwa | om (MULH) od (the quotient is written) orr (the remainder is) | sg (the word
+             // is DIV / REM: op = 3 om + 4 od + 5 orr + 2 sg) | gf_k = kwa F1_k (gated copies: the products have degree 2 already) | e_1..9 (the carries' bits above their slot) | X0..5.
+             // Slots of a wa row (all read the 10-bit table): R0..R3 = LO, R4..R7 = F1, pieces 0-3 = F2 (= rs2), pieces 4-6 = the low parts of c0 c1 c2 (c1 = p5 + 2^10 e1, c2 = p6 +
+             // 2^10 (e2 + 2 e3)), pieces 7, 8, X0, X1 = G4 (HI on MULH, ADD = the remainder on divisions), X2..X5 = G5 (MULH: c3 = X2 + 2^10 (e4 + 2 e5), c4 = X3 + .. (e6, e7), c5 =
+             // X4 + .. (e8, e9); divisions: the chunks of d = rs2 - r - 1 >= 0, borrow e4).  Position k: sum_{i+j=k} F1_i F2_j + ADD_k + c_(k-1) = LO_k + 2^10 c_k (k <= 3), = HI_(k-4) +
+             // 2^10 c_k (k = 4, 5; k = 6: HI_2 + 2^10 HI_3); a division has HI = 0, c3 = 0 and no product above position 3.  Every sum stays below 2^23: integer equations, unique.
+             C_KWA = 284, C_OM = 285, C_OD = 286, C_ORR = 287, C_SG = 288, C_GF = 289, C_WE = 293, C_X = 302 };
+constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, K_WA = 22, N_WIN = 15, N_PIECE = 9, N_NIB = 10, N_X = 6, N_WE = 9;
+BB_HD constexpr bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
 constexpr uint32_t OP_MUL_ = 0x02;
 BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
 BB_HD constexpr bool is_shift(uint32_t op) { return op >= 0x18 && op <= 0x1D; }
@@ -122,15 +135,15 @@ enum : int { C_CYCLE = 0, C_PC = 1, C_OP = 4, C_FA = 5, C_FB = 6, C_FC = 7, C_FH
 // zero, state.rs:77-85) and, in the default VM mode — no register is ever Accumulated there (vm.rs:47) — all 16 storage states.  The
 // committed matrix is the logical one with those columns removed, whole B8 blocks with no padding: 152 columns in default mode,
 // 168 in deferred mode (W_COMMITTED_*); a removed column reads as the constant 0 wherever a constraint, a boundary state or a lookup mentions it.
-constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 264, W_COMMITTED_MAX = 264;
+constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED_IO = 160, W_COMMITTED_MEM = 264, W_COMMITTED_WIDE = 288, W_COMMITTED_MAX = 288;
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
-BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode != 3) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode < 3) || (c >= C_KWA && mode != 4) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 BB_HD constexpr int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
-BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : mode == 3 ? W_COMMITTED_MEM : W_COMMITTED_DEFAULT; }
+BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : mode == 3 ? W_COMMITTED_MEM : mode == 4 ? W_COMMITTED_WIDE : W_COMMITTED_DEFAULT; }
 BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 276 - 20)
-BB_HD constexpr int logical_width(int mode) { return mode == 3 ? W : mode == 2 ? W_LOGICAL_IO : W_LOGICAL_BASE; }
+BB_HD constexpr int logical_width(int mode) { return mode == 4 ? W : mode == 3 ? W_LOGICAL_MEM : mode == 2 ? W_LOGICAL_IO : W_LOGICAL_BASE; }
 // the logical column stored at committed position p (p < committed_used)
 BB_HD constexpr int logical_col(int p, int mode) {
   int c = p;
@@ -140,9 +153,10 @@ BB_HD constexpr int logical_col(int p, int mode) {
 }
 // aux trace: H0..H7 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each; mode 2: + HO (output-tape helper), HI (input-tape helper)
 // mode 3: + P0..P8 (the piece lookups), HMR / HMW (the memory tuple read / written), FPN (the fingerprint of the new cell bytes: an aux column because it depends on lambda)
-constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_MAX = 96;
-BB_HD constexpr int aux_width(int mode) { return mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
-enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92 };
+// mode 4: + XH0..XH5 (the helpers of the six extra range slots)
+constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 120, W_AUX_MAX = 120;
+BB_HD constexpr int aux_width(int mode) { return mode == 4 ? W_AUX_WIDE : mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
+enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
 BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^N_TUPLE (= 11), T / N
@@ -165,13 +179,13 @@ BB_HD constexpr int num_queries_of(uint32_t fri_params) { return (fri_params & 0
 BB_HD constexpr int pow_bits_of(uint32_t fri_params) { return (fri_params >> 16) ? (int)(fri_params >> 16) : DEFAULT_POW_BITS; }
 BB_HD constexpr bool fri_params_ok(uint32_t fri_params) { return num_queries_of(fri_params) >= DEFAULT_NUM_QUERIES && num_queries_of(fri_params) <= MAX_NUM_QUERIES && pow_bits_of(fri_params) >= DEFAULT_POW_BITS && pow_bits_of(fri_params) <= MAX_POW_BITS; }
 // proof format: modes 0 / 1 are v10 word for word; modes 2 / 3 are v11 (EBREAK class, the I/O section in the transcript, no access to the code segment in mode 3)
-BB_HD constexpr uint32_t proof_version(int mode) { return mode >= 2 ? 11u : 10u; }
+BB_HD constexpr uint32_t proof_version(int mode) { return mode == 4 ? 12u : mode >= 2 ? 11u : 10u; }     // (v12 = mode 4: the wide-arithmetic class)
 constexpr uint64_t CODE_BASE = 0x1000;
 BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50, OP_EBREAK = 0x51;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
-  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (op == OP_EBREAK && mode >= 2) ? (uint32_t)K_EBREAK : (mode == 3 && is_load(op)) ? (uint32_t)K_LD : (mode == 3 && is_store(op)) ? (uint32_t)K_ST : (mode == 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 3 && is_shift(op)) ? (uint32_t)K_SH : (mode == 3 && op == OP_MUL_) ? (uint32_t)K_MU : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
+  return (op == OP_ECALL && mode >= 2) ? (uint32_t)K_ECALL : (op == OP_EBREAK && mode >= 2) ? (uint32_t)K_EBREAK : (mode >= 3 && is_load(op)) ? (uint32_t)K_LD : (mode >= 3 && is_store(op)) ? (uint32_t)K_ST : (mode >= 3 && is_logic(op)) ? (uint32_t)K_LG : (mode == 4 && is_wide(op)) ? (uint32_t)K_WA : (mode >= 3 && is_shift(op)) ? (uint32_t)K_SH : (mode >= 3 && op == OP_MUL_) ? (uint32_t)K_MU : op == OP_ADD ? K_ADD : op == OP_ADDI ? K_ADDI : (op == OP_BEQ || op == OP_BNE) ? K_BRE : op == OP_JAL ? K_JAL : op == OP_SUB ? K_SUB
        : (op == OP_BLTU || op == OP_BGEU || op == OP_BLT || op == OP_BGE) ? K_BRU : (op == OP_SEQ || op == OP_SNE) ? K_SE
        : (op == OP_SLTU || op == OP_SGEU || op == OP_SLT || op == OP_SGE) ? K_SU : op == OP_JALR ? K_JALR : (op == OP_CMOV || op == OP_CMOVNZ) ? K_CMN : op == OP_CMOVZ ? K_CMZ
        : (uint32_t)K_OTH;
@@ -204,8 +218,14 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              I_SH_T40 = 610, I_SH_ON = 611, I_SH_Y = 613,
              // MUL (mode 3, appended): booleans kmu e_1..3 (4), rd (1), a's chunks (2), b's (2), ma_k = kmu a_k (4), the four chunk equations (4), the result (3)
              I_MU_BOOL = 616, I_MU_WR = 620, I_MU_A = 621, I_MU_B = 623, I_MU_MA = 625, I_MU_EQ = 629, I_MU_Y = 633,
-             N_CONSTRAINTS = 636 };
-BB_HD constexpr int num_constraints(int mode) { return mode == 3 ? N_CONSTRAINTS : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
+             N_CONSTRAINTS_MEM = 636,
+             // mode 4 (appended): the wide-arithmetic class — booleans kwa om od orr sg e_1..9 (14), one kind (1), the opcode (1), sg on divisions only (1), rd (1), the operands' top
+             // limbs (2), F2 = rs2 (2), F1 = rs1 on MULH (2), LO = rs1 on divisions (2), gf_k = kwa F1_k (4), the seven positions of the product (7), r < rs2 (2), what is written (5),
+             // the six extra range lookups (24)
+             I_WA_BOOL = 636, I_WA_KIND = 650, I_WA_OP = 651, I_WA_SG = 652, I_WA_WR = 653, I_WA_TOP = 654, I_WA_F2 = 656, I_WA_F1 = 658, I_WA_LO = 660, I_WA_GF = 662, I_WA_EQ = 666,
+             I_WA_LT = 673, I_WA_Y = 675, I_WA_X = 680,
+             N_CONSTRAINTS = 704 };
+BB_HD constexpr int num_constraints(int mode) { return mode == 4 ? N_CONSTRAINTS : mode == 3 ? N_CONSTRAINTS_MEM : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
 constexpr int N_STATE = 68;
@@ -247,7 +267,7 @@ BB_HD void air_static_for(F&& f) {
 
 template <class Ops>
 BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mode, const uint32_t* cnt_m = nullptr) {   // cnt_m (mode 2): (oc, ic) of the first row, of the last row (Montgomery)
-  const bool deferred = mode == 1, io = mode >= 2, mem = mode == 3;
+  const bool deferred = mode == 1, io = mode >= 2, mem = mode >= 3, wide = mode == 4;
   using V = typename Ops::V;
   using AccP = typename Ops::AccP;
   using AccL = typename Ops::AccL;
@@ -374,8 +394,9 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   // classes and the opcode
   V F2 = zero, RL = zero, RE = zero, FH = zero, H0 = zero, H1 = zero;   // (mode 2) the syscall flags of an ECALL row; Kec = their sum is the row's class
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
-  V Kld = zero, Kst = zero, Klg = zero, Ksh = zero, Kmu = zero;   // (mode 3) loads, stores, the bitwise opcodes, the shifts, MUL
+  V Kld = zero, Kst = zero, Klg = zero, Ksh = zero, Kmu = zero, Kwa = zero;   // (mode 3) loads, stores, the bitwise opcodes, the shifts, MUL; (mode 4) MULH DIVU REMU DIV REM
   if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); Ksh = o.loc(C_KSH); Kmu = o.loc(C_KMU); }
+  if (wide) Kwa = o.loc(C_KWA);
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
@@ -389,6 +410,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       o.acc_lin(ks, F2, K_ECALL); o.acc_lin(ks, RL, K_ECALL); o.acc_lin(ks, RE, K_ECALL); o.acc_lin(ks, FH, K_ECALL);
     }
     if (mem) { o.acc_lin(sum, Kld, 1); o.acc_lin(sum, Kst, 1); o.acc_lin(sum, Klg, 1); o.acc_lin(sum, Ksh, 1); o.acc_lin(ks, Kld, K_LD); o.acc_lin(ks, Kst, K_ST); o.acc_lin(ks, Klg, K_LG); o.acc_lin(ks, Ksh, K_SH); o.acc_lin(sum, Kmu, 1); o.acc_lin(ks, Kmu, K_MU); }
+    if (wide) { o.acc_lin(sum, Kwa, 1); o.acc_lin(ks, Kwa, K_WA); }
     o.push(I_ONE_CLASS, o.lsub(o.accl_val(sum), one));
     // an executed row runs as the class of its instruction word: (1 - halt - pad) opclass = sum_k k K_k; opclass comes with the ROM tuple
     if (!deferred) o.push(I_OPCLASS, o.lsub(o.mul(o.lsub(one, hp), opc), o.accl_val(ks)));
@@ -725,7 +747,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
     for (int i = 0; i < N_PIECE; i++) {
       V h[4], d[4], pr[4];
       // (.. and on a SHIFT row in the table shift_piece_tag names; piece 8's second element is then the amount, when it comes from a register)
-      V tg = piece_tag(i) ? o.add(o.mulc(o.sub(o.sub(nlg, Ksh), Kmu), M((uint32_t)piece_tag(i))), lgtag) : lgtag;   // (a MUL row: the 10-bit range table in every slot)
+      V tg = piece_tag(i) ? o.add(o.mulc(wide ? o.sub(o.sub(o.sub(nlg, Ksh), Kmu), Kwa) : o.sub(o.sub(nlg, Ksh), Kmu), M((uint32_t)piece_tag(i))), lgtag) : lgtag;   // (a MUL row, a wide-arithmetic row: the 10-bit range table in every slot)
       if (i == 7) tg = o.add(tg, o.mulc(Ksh, M((uint32_t)TAG_NIB)));
       if (i == 8) tg = o.add(tg, o.mulc(o.sub(Ksh, o.loc(C_SI)), M((uint32_t)TAG_LOW6)));
 #pragma unroll
@@ -852,6 +874,73 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
         o.push(I_MU_EQ + k, o.lsub(o.acc_val(t), o.mul(lin, Kmu)));
       }
       o.push(I_MU_Y, o.lmul(o.lsub(y[0], z[0]), Kmu)); o.push(I_MU_Y + 1, o.lmul(o.lsub(y[1], z[1]), Kmu)); o.push(I_MU_Y + 2, o.lmul(y[2], Kmu));
+    }
+    // ---- (mode 4, round 6) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI, schoolbook in 10-bit chunks: constraints 636.. ----
+    if (wide) {
+      V gf[4], we[N_WE], X[N_X];
+#pragma unroll
+      for (int k = 0; k < 4; k++) gf[k] = o.loc(C_GF + k);
+#pragma unroll
+      for (int k = 0; k < N_WE; k++) we[k] = o.loc(C_WE + k);
+#pragma unroll
+      for (int k = 0; k < N_X; k++) X[k] = o.loc(C_X + k);
+      const V om = o.loc(C_OM), od = o.loc(C_OD), orr = o.loc(C_ORR), sg = o.loc(C_SG), kd = o.add(od, orr);
+      boolean(I_WA_BOOL, Kwa); boolean(I_WA_BOOL + 1, om); boolean(I_WA_BOOL + 2, od); boolean(I_WA_BOOL + 3, orr); boolean(I_WA_BOOL + 4, sg);
+#pragma unroll
+      for (int k = 0; k < N_WE; k++) boolean(I_WA_BOOL + 5 + k, we[k]);
+      o.push(I_WA_KIND, o.lsub(Kwa, o.add(om, kd)));                                               // one of the three kinds on a wide row, none elsewhere
+      { AccL a = o.accl(); o.acc_lin(a, om, 3); o.acc_lin(a, od, 4); o.acc_lin(a, orr, 5); o.acc_lin(a, sg, 2); o.push(I_WA_OP, o.lsub(o.mul(op, Kwa), o.accl_val(a))); }   // MULH 3, DIVU 4, REMU 5, DIV 6, REM 7
+      o.push(I_WA_SG, o.lmul(o.lsub(one, kd), sg));                                                // the signed variants exist for the divisions only
+      o.push(I_WA_WR, o.lmul(o.lsub(w1v, fa), Kwa));                                               // rd = field a
+      o.push(I_WA_TOP, o.lmul(xb[2], Kwa)); o.push(I_WA_TOP + 1, o.lmul(xc[2], Kwa));              // the operands are below 2^40
+      constexpr uint32_t T10 = M(RC_TABLE);
+      o.push(I_WA_F2, o.lmul(o.lsub(o.sub(xc[0], pcs[0]), o.mulc(pcs[1], T10)), Kwa)); o.push(I_WA_F2 + 1, o.lmul(o.lsub(o.sub(xc[1], pcs[2]), o.mulc(pcs[3], T10)), Kwa));   // F2 = rs2, always
+      o.push(I_WA_F1, o.lmul(o.lsub(o.sub(xb[0], R2[0]), o.mulc(R2[1], T10)), om)); o.push(I_WA_F1 + 1, o.lmul(o.lsub(o.sub(xb[1], R2[2]), o.mulc(R2[3], T10)), om));         // MULH: F1 = rs1
+      o.push(I_WA_LO, o.lmul(o.lsub(o.sub(xb[0], R[0]), o.mulc(R[1], T10)), kd)); o.push(I_WA_LO + 1, o.lmul(o.lsub(o.sub(xb[1], R[2]), o.mulc(R[3], T10)), kd));             // divisions: LO = rs1
+#pragma unroll
+      for (int k = 0; k < 4; k++) o.push(I_WA_GF + k, o.lsub(gf[k], o.mul(R2[k], Kwa)));           // gf_k = kwa F1_k
+      const V G4[4] = {pcs[7], pcs[8], X[0], X[1]};
+      auto two = [&](const V& a, const V& b) { return o.add(a, o.add(b, b)); };                    // a + 2 b
+      const V cr[6] = {pcs[4], o.add(pcs[5], o.mulc(we[0], T10)), o.add(pcs[6], o.mulc(two(we[1], we[2]), T10)),
+                       o.add(X[2], o.mulc(two(we[3], we[4]), T10)), o.add(X[3], o.mulc(two(we[5], we[6]), T10)), o.add(X[4], o.mulc(two(we[7], we[8]), T10))};
+      air_static_for<0, 7>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        AccP t = o.accp();
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (k - j >= 0 && k - j < 4) o.acc_mul(t, gf[j], pcs[k - j]);
+        if constexpr (k < 4) {                                                                      // low half: + ADD_k + c_(k-1) = LO_k + 2^10 c_k; the carry OUT of position 3 exists on MULH rows only
+          o.acc_mul(t, kd, G4[k]);
+          V lin = R[k];
+          if (k < 3) lin = o.add(lin, o.mulc(cr[k], T10));
+          if (k) lin = o.sub(lin, cr[k - 1]);
+          if constexpr (k == 3) o.push(I_WA_EQ + k, o.lsub(o.sub(o.acc_val(t), o.mul(lin, Kwa)), o.mul(o.mulc(cr[3], T10), om)));
+          else o.push(I_WA_EQ + k, o.lsub(o.acc_val(t), o.mul(lin, Kwa)));
+        } else {                                                                                    // high half (MULH): + c_(k-1) = HI_(k-4) + 2^10 c_k (k = 6: 2^10 HI_3); a division has nothing there
+          const V hi = k < 6 ? o.add(G4[k - 4], o.mulc(cr[k < 6 ? k : 5], T10)) : o.add(G4[2], o.mulc(G4[3], T10));
+          o.push(I_WA_EQ + k, o.ladd(o.acc_val(t), o.mul(o.lsub(cr[k - 1], hi), om)));
+        }
+      });
+      // divisions: the remainder is smaller than the divisor: d = rs2 - r - 1 >= 0 in chunks X2..X5, borrow e4 between the limbs (which also says rs2 != 0)
+      const V r0 = o.add(G4[0], o.mulc(G4[1], T10)), r1 = o.add(G4[2], o.mulc(G4[3], T10)), dd0 = o.add(X[2], o.mulc(X[3], T10)), dd1 = o.add(X[4], o.mulc(X[5], T10));
+      o.push(I_WA_LT, o.lmul(o.ladd(o.sub(o.sub(o.sub(xc[0], r0), one), dd0), o.mulc(we[3], M(1u << 20))), kd));
+      o.push(I_WA_LT + 1, o.lmul(o.lsub(o.sub(o.sub(xc[1], r1), we[3]), dd1), kd));
+      // what is written: HI (MULH) and the remainder (REMU / REM) sit in G4, the quotient (DIVU / DIV) in F1
+      const V gk = o.add(om, orr);
+      o.push(I_WA_Y, o.lmul(o.lsub(y[0], r0), gk)); o.push(I_WA_Y + 1, o.lmul(o.lsub(y[1], r1), gk));
+      o.push(I_WA_Y + 2, o.lmul(o.lsub(o.sub(y[0], R2[0]), o.mulc(R2[1], T10)), od)); o.push(I_WA_Y + 3, o.lmul(o.lsub(o.sub(y[1], R2[2]), o.mulc(R2[3], T10)), od));
+      o.push(I_WA_Y + 4, o.lmul(y[2], Kwa));
+      // the six extra range slots: XH_i (alpha - X_i) = 1, on every row
+#pragma unroll
+      for (int i = 0; i < N_X; i++) {
+        V h[4], d[4], pr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { h[k] = o.aloc(A_X + 4 * i + k); o.acc_lin(hs[k], h[k], 1); d[k] = o.par(LK_ALPHA + k); }
+        d[0] = o.sub(d[0], X[i]);
+        ext_mul(h, d, pr);
+        o.push(I_WA_X + 4 * i, o.lsub(pr[0], one));
+#pragma unroll
+        for (int k = 1; k < 4; k++) o.push(I_WA_X + 4 * i + k, pr[k]);
+      }
     }
   }
   // running sum over the cycle of all N rows (no selector): S(w x) - S(x) = H0 + .. + H7 + HR (+ HO + HI) - T / N

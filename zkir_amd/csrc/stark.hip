@@ -106,10 +106,11 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   const bool oth_like = cls == K_OTH || (cls == K_OJ && deferred);                 // what the row wrote is read off the next row
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
-  if (MODE == 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; col(C_KSH) = cls == K_SH; col(C_KMU) = cls == K_MU; }
+  if (MODE >= 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; col(C_KSH) = cls == K_SH; col(C_KMU) = cls == K_MU; }
+  if (MODE == 4) col(C_KWA) = cls == K_WA;
   col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
-  const uint32_t tc = (branch || (MODE == 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
+  const uint32_t tc = (branch || (MODE >= 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
   uint32_t xb[3] = {0, 0, 0}, xc[3] = {0, 0, 0}, y[3] = {0, 0, 0};
   bool first = true;
 #pragma unroll
@@ -126,7 +127,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     if (fb == (uint32_t)g) { xb[0] = limb[0]; xb[1] = limb[1]; xb[2] = limb[2]; }
     if (tc == (uint32_t)g) { xc[0] = limb[0]; xc[1] = limb[1]; xc[2] = limb[2]; }
     uint32_t wr = 0;
-    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE == 3 && (cls == K_LD || cls == K_LG || cls == K_SH || cls == K_MU))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
+    if (cls == K_ADD || cls == K_ADDI || cls == K_JAL || cls == K_JALR || cls == K_SUB || cls == K_SE || cls == K_SU || cls == K_CMN || cls == K_CMZ || (MODE >= 3 && (cls == K_LD || cls == K_LG || cls == K_SH || cls == K_MU || cls == K_WA))) wr = fa == (uint32_t)g;   // (a conditional move: cleared below if its condition fails)
     else if (oth_like) {                                         // any other instruction: what it wrote is read off the next row
       uint32_t nl[3];
       const uint32_t nst = t.reg_state[o + 1];
@@ -199,11 +200,54 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   const uint32_t lo20 = fb + 16 * fc + 256 * fhi - (s << 20);
   bool mem_row = false, lg_row = false, sh_row = false;
   uint32_t mem_z[2] = {0, 0}, mem_dt = 0, lg_a9 = 0, sh_lo[4] = {0, 0, 0, 0}, sh_c[4] = {0, 0, 0, 0};
-  if (MODE == 3) {
+  if (MODE >= 3) {
     // loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64 — below 2^40, or the run has no proof here — its aligned 8-byte cell's bytes before the
     // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
 #pragma unroll
-    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH && k != C_KMU) col(k) = 0;
+    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH && k != C_KMU && k != C_KWA) col(k) = 0;
+    if (MODE == 4 && cls == K_WA) {
+      // (mode 4) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI in 10-bit chunks (air.h: the slots of a wide-arithmetic row).
+      // The top limbs of the operands must be zero — I_WA_TOP says so; a run that breaks it has no proof (lookup_index_kernel reports the row)
+      sh_row = true;                                             // R0..R3 = LO's chunks, R4..R7 = F1's
+      const uint64_t M40 = (1ull << 40) - 1;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20);
+      const bool mulh = op == 0x03, quot = op == 0x04 || op == 0x06;
+      col(C_OM) = mulh; col(C_OD) = !mulh && quot; col(C_ORR) = !mulh && !quot; col(C_SG) = op >= 0x06;
+      uint64_t f1, addv, res;
+      if (mulh) {                                                // bits 40..79 of the 80-bit product, by 20-bit limbs (no 128-bit type on the device)
+        const uint64_t a0 = a & 0xFFFFF, a1 = a >> 20, b0 = b & 0xFFFFF, b1 = b >> 20;
+        const uint64_t mid = a0 * b1 + a1 * b0 + ((a0 * b0) >> 20);            // < 2^42
+        f1 = a; addv = 0; res = (a1 * b1 + (mid >> 20)) & M40;
+      } else { const uint64_t qv = b ? a / b : 0, rv = b ? a % b : 0; f1 = qv; addv = rv; res = quot ? qv : rv; }     // (rs2 = 0 never is a row: the VM stops with DivisionByZero)
+      uint32_t f1c[4], f2c[4], addc[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { f1c[k] = (uint32_t)((f1 >> (10 * k)) & 1023); f2c[k] = (uint32_t)((b >> (10 * k)) & 1023); addc[k] = (uint32_t)((addv >> (10 * k)) & 1023); sh_c[k] = f1c[k]; col(C_GF + k) = f1c[k]; col(C_PIECE + k) = f2c[k]; }
+      uint32_t carry = 0, cs[7], outc[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {                              // position k of F1 F2 + ADD: below 2^23
+        uint32_t tsum = carry + (k < 4 ? addc[k < 4 ? k : 0] : 0u);
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (k - j >= 0 && k - j < 4) tsum += f1c[j] * f2c[k - j];
+        outc[k] = tsum & 1023; carry = tsum >> 10; cs[k] = carry;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) sh_lo[k] = outc[k];
+      const uint32_t g4[4] = {mulh ? outc[4] : addc[0], mulh ? outc[5] : addc[1], mulh ? outc[6] : addc[2], mulh ? cs[6] : addc[3]};
+      col(C_PIECE + 4) = cs[0];
+      col(C_PIECE + 5) = cs[1] & 1023; col(C_WE) = cs[1] >> 10;
+      col(C_PIECE + 6) = cs[2] & 1023; col(C_WE + 1) = (cs[2] >> 10) & 1; col(C_WE + 2) = cs[2] >> 11;
+      col(C_PIECE + 7) = g4[0]; col(C_PIECE + 8) = g4[1]; col(C_X) = g4[2]; col(C_X + 1) = g4[3];
+      if (mulh) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { col(C_X + 2 + k) = cs[3 + k] & 1023; col(C_WE + 3 + 2 * k) = (cs[3 + k] >> 10) & 1; col(C_WE + 4 + 2 * k) = cs[3 + k] >> 11; }
+      } else {
+        const uint64_t d = (b - addv - 1) & M40;
+#pragma unroll
+        for (int k = 0; k < 4; k++) col(C_X + 2 + k) = (uint32_t)((d >> (10 * k)) & 1023);
+        col(C_WE + 3) = ((b & 0xFFFFF) < (addv & 0xFFFFF) + 1) ? 1u : 0u;
+      }
+      y[0] = (uint32_t)(res & 0xFFFFF); y[1] = (uint32_t)(res >> 20); y[2] = 0;
+    }
     if (cls == K_MU) {
       // MUL (execute.rs:79-99): the product of the masked operands mod 2^40, schoolbook in 10-bit chunks; the range groups are filled like a shift row's (R0..R3 = the result's
       // chunks, R4..R7 = a's), b's chunks in pieces 0-3, the carries in pieces 4-8 and e_1..3
@@ -369,7 +413,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   }
 }
 template <int MODE, int SKIP = 0>
-__global__ __launch_bounds__(NT, MODE == 3 ? MT_WAVES_MEM : MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out, IoRowArgs io = IoRowArgs{}) {
+__global__ __launch_bounds__(NT, MODE >= 3 ? MT_WAVES_MEM : MT_WAVES) void main_trace_kernel(zkir_trace_columns t, uint64_t n_real, uint64_t N, uint32_t* __restrict__ out, IoRowArgs io = IoRowArgs{}) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   main_trace_row<MODE, SKIP>(t, n_real, N, i, out, &io);
@@ -872,9 +916,11 @@ int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, 
                      IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt)});
   return check_launch("main_trace_io");
 }
-// MODE 3: the same scan, then the row kernel with the memory witness (device arrays of n_real entries)
-int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
-                               void* stream) {
+// MODES 3 / 4: the same scan, then the row kernel with the memory witness (device arrays of n_real entries)
+}  // extern "C" (the two helpers are templates)
+namespace {
+template <int MODE>
+int main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out, void* stream) {
   if (!trace || !out || !io || !scratch || !mem_old || !mem_told || n_real == 0 || (!io->inputs && io->n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   hipStream_t s = (hipStream_t)stream;
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
@@ -884,19 +930,33 @@ int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real,
   hipLaunchKernelGGL(io_scan_local_kernel, dim3(n_blk), dim3(NT), 0, s, *trace, n_real, N, cnt, sums);
   hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(NT), 0, s, sums, n_blk);
   hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
-  hipLaunchKernelGGL(main_trace_kernel<3>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
+  hipLaunchKernelGGL(main_trace_kernel<MODE>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
                      IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt), mem_old, mem_told});
   return check_launch("main_trace_mem");
 }
-int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
+template <int MODE>
+int main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
   if (!trace || !out || !io || !mem_old || !mem_told || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
   std::vector<uint32_t> cnt(2 * N);
   uint32_t w = 0, r = 0;
   for (uint64_t i = 0; i < N; i++) { cnt[2 * i] = w; cnt[2 * i + 1] = r; uint32_t f[2] = {0, 0}; if (i < n_real) io_row_flags(*trace, n_real, i, f); w += f[0]; r += f[1]; }
   const IoRowArgs a{io->inputs, io->n_inputs, io->writes_before, io->reads_before, cnt.data(), mem_old, mem_told};
-  for (uint64_t i = 0; i < N; i++) main_trace_row<3>(*trace, n_real, N, i, out, &a);
+  for (uint64_t i = 0; i < N; i++) main_trace_row<MODE>(*trace, n_real, N, i, out, &a);
   return ZKIR_OK;
+}
+}  // namespace
+extern "C" {
+int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
+                               void* stream) { return main_trace_mem_launch<3>(trace, n_real, io, mem_old, mem_told, scratch, out, stream); }
+int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
+  return main_trace_mem_host<3>(trace, n_real, io, mem_old, mem_told, out);
+}
+// MODE 4 (round 6: mode 3 + the wide-arithmetic class MULH / DIVU / REMU / DIV / REM): 288 committed columns
+int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
+                                void* stream) { return main_trace_mem_launch<4>(trace, n_real, io, mem_old, mem_told, scratch, out, stream); }
+int zkir_main_trace_wide_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
+  return main_trace_mem_host<4>(trace, n_real, io, mem_old, mem_told, out);
 }
 int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out) {
   if (!trace || !out || !io || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_io_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }

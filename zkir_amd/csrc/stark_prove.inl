@@ -152,7 +152,7 @@ struct DeviceRowSrc {
 };
 
 template <int DEF /* the mode */>
-__global__ __launch_bounds__(NT, DEF == 3 ? QUOT_WAVES_MEM : QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
+__global__ __launch_bounds__(NT, DEF >= 3 ? QUOT_WAVES_MEM : QUOT_WAVES) void quotient_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ AL, uint32_t log_n, const uint32_t* __restrict__ tw_fwd,
                                                                   const uint32_t* __restrict__ inv_xm1, const ProveParams* __restrict__ pp, uint32_t wn_inv_m, uint32_t w_last_inv_m,
                                                                   uint32_t last_shift, uint32_t inv_zh_even_m, uint32_t inv_zh_odd_m, uint32_t* __restrict__ Q) {
   const uint32_t N2 = 2u << log_n;
@@ -189,11 +189,12 @@ constexpr uint32_t ROM_LDS = 4096;
 struct IoEntry { uint32_t row, is_in, idx, v[3], pad[2]; };
 __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, int deferred /* the mode */, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
                                                            uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row,
-                                                           IoEntry* __restrict__ io_list, uint32_t* __restrict__ io_count, uint32_t* __restrict__ mem_mult, uint4* __restrict__ mem_side) {
+                                                           IoEntry* __restrict__ io_list, uint32_t* __restrict__ io_count, uint32_t* __restrict__ mem_mult, uint4* __restrict__ mem_side,
+                                                           uint2* __restrict__ wide_side /* (mode 4) the six extra range values of every row, ten bits each */) {
   __shared__ uint32_t h_rc[air::RC_TABLE];
   __shared__ uint32_t h_rom[ROM_LDS];
   __shared__ uint32_t h_mem[air::MEM_MULT];                    // (mode 3) LOW3 | BYTE | NIBBLE
-  if (deferred == 3) for (uint32_t k = threadIdx.x; k < (uint32_t)air::MEM_MULT; k += NT) h_mem[k] = 0;
+  if (deferred >= 3) for (uint32_t k = threadIdx.x; k < (uint32_t)air::MEM_MULT; k += NT) h_mem[k] = 0;
   const uint32_t rom_lds = n_code < ROM_LDS ? n_code : ROM_LDS;
   for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) h_rc[k] = 0;
   for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) h_rom[k] = 0;
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
     bool ok = true;
     bool mem_row = false;
     int lg_which = -1;                                           // (mode 3) 0 / 1 / 2: the row is an AND / OR / XOR (immediate or not)
-    if (deferred == 3) {
-      // (mode 3) the row's memory side, kept for the aux kernels (the LDE overwrites M): pieces, old bytes, old time, window; the piece lookups counted here
+    if (deferred >= 3) {
+      // (modes 3 / 4: the mode-3 columns sit at the same committed positions in both) the row's memory side, kept for the aux kernels (the LDE overwrites M): pieces, old bytes, old time, window; the piece lookups counted here
       const uint32_t p_kld = (uint32_t)air::phys_col(air::C_KLD, 3), p_e = (uint32_t)air::phys_col(air::C_E, 3), p_ob = (uint32_t)air::phys_col(air::C_OB, 3),
                      p_told = (uint32_t)air::phys_col(air::C_TOLD, 3), p_pc = (uint32_t)air::phys_col(air::C_PIECE, 3);
       const uint32_t kld = M[b8(p_kld, i, N)], kst = M[b8(p_kld + 1, i, N)];
@@ -229,7 +230,15 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
         if (a < 16 && b < 16 && r == air::logic_of(lg_which, a, b)) atomicAdd(&h_mem[air::LG_BASE + 256 * lg_which + 16 * a + b], 1u); else ok = false;
       };
       const uint32_t ksh = M[b8((uint32_t)air::phys_col(air::C_KSH, 3), i, N)], sh_reg = ksh && !M[b8((uint32_t)air::phys_col(air::C_SI, 3), i, N)];
-      const uint32_t kmu = M[b8((uint32_t)air::phys_col(air::C_KMU, 3), i, N)];
+      uint32_t kmu = M[b8((uint32_t)air::phys_col(air::C_KMU, 3), i, N)];
+      if (deferred == 4) {                                       // (mode 4) a wide-arithmetic row reads the 10-bit table in every piece slot, like a MUL row; its operands must be below 2^40
+        const uint32_t kwa = M[b8((uint32_t)air::phys_col(air::C_KWA, 4), i, N)];
+        if (kwa && (M[b8((uint32_t)air::phys_col(air::C_XB + 2, 4), i, N)] | M[b8((uint32_t)air::phys_col(air::C_XC + 2, 4), i, N)])) ok = false;    // MULH / DIV.. on a register with bits above 40: no proof in this AIR
+        kmu |= kwa;
+        uint32_t xs[air::N_X];
+        for (int k = 0; k < air::N_X; k++) { xs[k] = M[b8((uint32_t)air::phys_col(air::C_X + k, 4), i, N)]; if (xs[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[xs[k]], 1u); else ok = false; }
+        wide_side[i] = make_uint2((xs[0] & 1023) | ((xs[1] & 1023) << 10) | ((xs[2] & 1023) << 20), (xs[3] & 1023) | ((xs[4] & 1023) << 10) | ((xs[5] & 1023) << 20));
+      }
       uint32_t pc9[air::N_PIECE];
       for (int k = 0; k < air::N_PIECE; k++) {
         pc9[k] = M[b8(p_pc + (uint32_t)k, i, N)];
@@ -296,8 +305,9 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < (uint32_t)air::RC_TABLE; k += NT) if (h_rc[k]) atomicAdd(&rc_mult[k], h_rc[k]);
   for (uint32_t k = threadIdx.x; k < rom_lds; k += NT) if (h_rom[k]) atomicAdd(&rom_mult[k], h_rom[k]);
-  if (deferred == 3) for (uint32_t k = threadIdx.x; k < (uint32_t)air::MEM_MULT; k += NT) if (h_mem[k]) atomicAdd(&mem_mult[k], h_mem[k]);
+  if (deferred >= 3) for (uint32_t k = threadIdx.x; k < (uint32_t)air::MEM_MULT; k += NT) if (h_mem[k]) atomicAdd(&mem_mult[k], h_mem[k]);
 }
+static_assert(air::phys_col(air::C_KLD, 3) == air::phys_col(air::C_KLD, 4) && air::phys_col(air::C_KMU, 3) == air::phys_col(air::C_KMU, 4) && air::phys_col(air::C_F2, 2) == air::phys_col(air::C_F2, 4), "mode 4 commits the mode-3 columns at mode 3's positions");
 static_assert(air::phys_col(air::C_F2, 2) == air::phys_col(air::C_F2, 3) && air::phys_col(air::C_IC, 2) == air::phys_col(air::C_IC, 3) && air::phys_col(air::C_Y, 2) == air::phys_col(air::C_Y, 3),
               "modes 2 and 3 commit the mode-2 columns at the same positions");
 
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(NT) void mem_cells_sum_kernel(const uint64_t* __res
 // told, old bytes)), HMW = 1 / (alpha - fp(cell, cycle + 1, new bytes)), H0 re-read from the LOW3 table; the row's running-sum increment (S slot, written by aux_rows_kernel)
 // gains P0 + .. + P8 + HMR - HMW (and H0's correction).  Blocks A_P / 8 ..: P0 | P1, P2 | P3, P4 | P5, P6 | P7, P8 | HMR, HMW | FPN.
 __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ side, const uint4* __restrict__ mem_side, uint64_t N, const E4* __restrict__ inv_rc, const E4* __restrict__ inv_mem,
-                                                      const ProveParams* __restrict__ pp, uint32_t* __restrict__ A) {
+                                                      const ProveParams* __restrict__ pp, uint32_t* __restrict__ A, const uint2* __restrict__ wide_side /* mode 4, else null */) {
   const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
   if (i >= N) return;
   const uint4 m0 = mem_side[2 * i], m1 = mem_side[2 * i + 1];
@@ -461,6 +471,12 @@ __global__ __launch_bounds__(NT) void mem_aux_kernel(const uint4* __restrict__ s
     put(air::A_H, h0);
   }
   put(air::A_HMR, hr); put(air::A_HMW, hw);
+  if (wide_side) {                                             // (mode 4) XH_k = 1 / (alpha - X_k): the six extra range slots, on every row
+    const uint2 xs = wide_side[i];
+    const uint32_t x6[air::N_X] = {xs.x & 1023, (xs.x >> 10) & 1023, xs.x >> 20, xs.y & 1023, (xs.y >> 10) & 1023, xs.y >> 20};
+#pragma unroll
+    for (int k = 0; k < air::N_X; k++) { const E4 h = inv_rc[x6[k]]; put(air::A_X + 4 * k, h); inc = bb::e_add(inc, h); }
+  }
   uint4* S = A4 + ((uint64_t)(air::A_S / 8) * N + i) * 2 + 1;
   *S = add4m(*S, make_uint4(inc.c[0], inc.c[1], inc.c[2], inc.c[3]));
 }
@@ -1037,7 +1053,8 @@ extern "C" {
 void zkir_air_eval_host(const uint32_t* loc, const uint32_t* nxt, const uint32_t* aloc, const uint32_t* anxt, const uint32_t* lk, uint32_t is_first, uint32_t is_last, uint32_t is_trans,
                         const uint32_t* first68, const uint32_t* last68, const uint32_t* alpha4, uint32_t mode, const uint32_t* cnt4, uint32_t* out4) {
   const uint32_t sel3[3] = {is_first, is_last, is_trans};
-  if (mode == 3) air_eval_host<3>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
+  if (mode == 4) air_eval_host<4>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
+  else if (mode == 3) air_eval_host<3>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
   else if (mode == 2) air_eval_host<2>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
   else if (mode == 1) air_eval_host<1>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
   else air_eval_host<0>(loc, nxt, aloc, anxt, lk, sel3, first68, last68, cnt4, alpha4, out4);
@@ -1060,9 +1077,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   auto since = [&](const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   const uint32_t log_n = c->log_n;
   const uint64_t N = 1ull << log_n, N2 = 2 * N;
-  if (pub->deferred > 3) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument"}); return ZKIR_ERR_ARGUMENT; }
-  const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument, 3 = 2 + the memory argument (round 4)
-  const bool IO = MODE >= 2, MEM = MODE == 3;
+  if (pub->deferred > 4) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->deferred is the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument, 4 = 3 + MULH / DIVU / REMU / DIV / REM"}); return ZKIR_ERR_ARGUMENT; }
+  const int MODE = (int)pub->deferred;                         // 0 default, 1 deferred carry model, 2 default + the I/O argument, 3 = 2 + the memory argument (round 4), 4 = 3 + the wide-arithmetic class (round 6)
+  const bool IO = MODE >= 2, MEM = MODE >= 3, WIDE = MODE == 4;
   if (!air::fri_params_ok(pub->fri_params)) {
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: pub->fri_params (num_queries | pow_bits << 16, 0 = 50 queries + 12 bits) must name 50..128 queries and 12..24 grinding bits (zkir_public_inputs_set_params)"});
     return ZKIR_ERR_ARGUMENT;
@@ -1111,7 +1128,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
 
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
-    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0)) * N + (size_t)air::MAX_NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
+    const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0) + (WIDE ? 8 : 0)) * N + (size_t)air::MAX_NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
                         (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)N * 60 + blob_len + (1u << 16) : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
@@ -1152,7 +1169,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   E4 *dW, *dDinv, *dPart, *dPartSum, *dInvRc, *dInvRom;
   ProveParams* dPP;
   IoEntry* dIo = nullptr; uint32_t* dIoCount = nullptr; uint64_t* dInputs = nullptr; uint32_t* dIoScratch = nullptr;
-  uint64_t* dMemOld = nullptr; uint32_t* dMemTold = nullptr; uint4* dMemSide = nullptr; E4* dInvMem = nullptr;
+  uint64_t* dMemOld = nullptr; uint32_t* dMemTold = nullptr; uint4* dMemSide = nullptr; E4* dInvMem = nullptr; uint2* dWideSide = nullptr;
   uint64_t *dCellAddr = nullptr, *dCellBytes = nullptr; uint32_t* dCellTime = nullptr; uint8_t* dImage = nullptr; E4* dCellPart = nullptr; uint32_t* dSec = nullptr;
   HIP_OK(ar.take(&dPP, 1)); HIP_OK(ar.take(&dState, 16)); HIP_OK(ar.take(&dBest, 4)); HIP_OK(ar.take(&dBound, 2 * NS + 4)); HIP_OK(ar.take(&dBad, 1));
   if (IO) { HIP_OK(ar.take(&dIo, N)); HIP_OK(ar.take(&dIoCount, 4)); HIP_OK(ar.take(&dInputs, (size_t)pub->n_inputs + 1)); HIP_OK(ar.take(&dIoScratch, 2 * N + 2 * (N / 1024 + 2))); }
@@ -1160,6 +1177,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(ar.take(&dMemOld, N)); HIP_OK(ar.take(&dMemTold, N)); HIP_OK(ar.take(&dMemSide, 2 * N)); HIP_OK(ar.take(&dInvMem, air::MEM_MULT));
     HIP_OK(ar.take(&dCellAddr, N)); HIP_OK(ar.take(&dCellBytes, N)); HIP_OK(ar.take(&dCellTime, N)); HIP_OK(ar.take(&dImage, (size_t)blob_len + 1)); HIP_OK(ar.take(&dCellPart, N / NT + 1));
     HIP_OK(ar.take(&dSec, 8 * N + 4096));                      // the memory section (seven words per touched cell) and its chunk digests
+    if (WIDE) HIP_OK(ar.take(&dWideSide, N));
   }
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
   HIP_OK(ar.take(&dA, WA * N)); HIP_OK(ar.take(&dAL, WA * N2)); HIP_OK(ar.take(&dATree, 4 * (2 * N2 - 1)));
@@ -1198,7 +1216,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
         rc = zkir::memcheck_device(trace, pub->n_real, blob, blob_len, dL, (size_t)WM * N2 * 4, dMemOld, dMemTold, cell_addr_v, cell_bytes_v, cell_time_v, pin, s);
         if (rc) return rc;
       }
-      rc = zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
+      rc = WIDE ? zkir_main_trace_wide_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s) : zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
     } else rc = zkir_main_trace_io_launch(trace, pub->n_real, &io, dIoScratch, dM, s);
   } else rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s);
   if (rc) return rc;
@@ -1209,7 +1227,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
     if (IO) HIP_OK(hipMemsetAsync(dIoCount, 0, 4, s));
-    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount, dMult + n_code + air::RC_TABLE, dMemSide);
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount, dMult + n_code + air::RC_TABLE, dMemSide, dWideSide);
   }
   mark(1);
   rc = lde_launch(c, dM, WM, dL, /*mont_out=*/true, s); if (rc) return rc;        // canonical evaluations in, MONTGOMERY words out: the matrices of a proof rest in Montgomery form
@@ -1226,9 +1244,9 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   HIP_OK(d2h(&bad_row, dBad, 8));
   HIP_OK(sync_d2h());
   if (bad_row != ~0ull) {
-    char m[256];
+    char m[448];
     snprintf(m, sizeof m, "zkir_prove: row %llu of the trace has no proof in this AIR: its (pc, instruction word) is not in the program's code table (self-modified code, "
-                          "a pc outside the code segment), a written limb is out of range, or (mode 3) its memory witness is not the row's", bad_row);
+                          "a pc outside the code segment), a written limb is out of range, (mode 3) its memory witness is not the row's, or (mode 4) it is a MULH / DIVU / REMU / DIV / REM on a register with bits above 40", bad_row);
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, m});
     return ZKIR_ERR_ARGUMENT;
   }
@@ -1352,7 +1370,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       HIP_OK(hipMemsetAsync(dA + (size_t)(air::A_HO / 8) * N * 8, 0, (size_t)N * 32, s));
       if (n_io) hipLaunchKernelGGL(io_aux_kernel, dim3(grid_for(n_io)), dim3(NT), 0, s, dIo, n_io, N, dPP, dA);
     }
-    if (MEM) hipLaunchKernelGGL(mem_aux_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, dMemSide, N, dInvRc, dInvMem, dPP, dA);   // P0..P8, HMR, HMW, FPN of every row
+    if (MEM) hipLaunchKernelGGL(mem_aux_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, dMemSide, N, dInvRc, dInvMem, dPP, dA, dWideSide);   // P0..P8, HMR, HMW, FPN of every row
     const uint32_t n_scan = (uint32_t)((N + SCAN_ROWS - 1) / SCAN_ROWS);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_scan), dim3(NT), 0, s, dA, N, dSums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(NT), 0, s, dSums, n_scan);
@@ -1387,6 +1405,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const uint32_t inv_zh_even_m = bb::to_mont(bb::inv(bb::sub(gN, 1))), inv_zh_odd_m = bb::to_mont(bb::inv(bb::sub(bb::neg(gN), 1)));
   const uint32_t last_shift = (uint32_t)((2 * (pub->n_real - 1)) & (N2 - 1));   // x_j - w_N^last = w_N^last (x_(j - 2 last) - 1) on the 2N coset
   if (MODE == 1) hipLaunchKernelGGL(quotient_kernel<1>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
+  else if (MODE == 4) hipLaunchKernelGGL(quotient_kernel<4>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   else if (MODE == 3) hipLaunchKernelGGL(quotient_kernel<3>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   else if (MODE == 2) hipLaunchKernelGGL(quotient_kernel<2>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);
   else hipLaunchKernelGGL(quotient_kernel<0>, dim3(grid_for(N2)), dim3(NT), 0, s, dL, dAL, log_n, c->d_tw_fwd, c->d_inv_xm1, dPP, wn_inv_m, w_last_inv_m, last_shift, inv_zh_even_m, inv_zh_odd_m, dQ);

@@ -204,7 +204,7 @@ int zkir_public_inputs_of(const zkir_delta_log* log, const uint8_t* blob, size_t
   if (log->window_open) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_public_inputs_of: this trace window ended before the run did (its outputs / halt reason are not the run's)"}); return ZKIR_ERR_ARGUMENT; }
   memset(out, 0, sizeof *out);
   out->n_real = log->cycles;
-  out->deferred = deferred > 3 ? 1 : deferred;                             // the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument (zkir_memcheck_witness_of)
+  out->deferred = deferred > 4 ? 1 : deferred;                             // the proof's mode: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument (zkir_memcheck_witness_of)
   // the claim in the clear (mode 2 proofs carry it; BORROWED: the caller's inputs, the log's outputs)
   out->inputs = inputs; out->n_inputs = n_inputs;
   out->outputs = log->outputs.data(); out->n_outputs = log->outputs.size();
@@ -302,7 +302,7 @@ int zkir_public_inputs_set_params(zkir_public_inputs* pub, const zkir_prover_par
 
 void zkir_public_inputs_set_memory(zkir_public_inputs* pub, const zkir_memcheck_witness* w) {
   if (!pub || !w) return;
-  pub->deferred = 3;
+  if (pub->deferred < 3) pub->deferred = 3;                               // (a mode-4 proof keeps its mode: the witness is the same)
   pub->mem_old = w->old.data(); pub->mem_told = w->told.data();
   pub->cell_addr = w->cell_addr.data(); pub->cell_bytes = w->cell_bytes.data(); pub->cell_time = w->cell_time.data(); pub->n_cells = w->cell_addr.size();
 }
@@ -318,7 +318,7 @@ uint32_t zkir_proof_state_words(void) { return NS; }
 
 int zkir_verify_chain(const uint32_t* const* proofs, const uint64_t* lens, uint32_t n, const zkir_public_inputs* expect) {
   if (!proofs || !lens || n < 1) return 40;
-  if (n == 1 && proofs[0] && lens[0] > 9 && proofs[0][9] == 3) return verify_impl(proofs[0], lens[0], expect, true, nullptr, nullptr);   // a mode-3 proof is a whole run by itself (never a segment): a "chain" of one
+  if (n == 1 && proofs[0] && lens[0] > 9 && proofs[0][9] >= 3) return verify_impl(proofs[0], lens[0], expect, true, nullptr, nullptr);   // a mode-3 proof is a whole run by itself (never a segment): a "chain" of one
   std::vector<uint32_t> st((size_t)n * 2 * NS), cnt((size_t)n * 4, 0);
   uint64_t total = 1;
   for (uint32_t i = 0; i < n; i++) {
@@ -453,11 +453,11 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   if (!w) return 1;
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= len; };
-  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[9] > 3 || w[1] != air::proof_version((int)w[9])) return 1;
+  if (!need(HEADER_WORDS) || w[0] != PROOF_MAGIC || w[9] > 4 || w[1] != air::proof_version((int)w[9])) return 1;
   const int log_n = (int)w[2];
-  if (w[9] > 3) return 2;
+  if (w[9] > 4) return 2;
   const int mode = (int)w[9];                                              // 0 default, 1 deferred, 2 default + the I/O argument, 3 = 2 + the memory argument
-  if (mode == 3 && !whole_run) return 2;                                   // the memory check spans the whole run: a mode-3 proof is never a segment
+  if (mode >= 3 && !whole_run) return 2;                                   // the memory check spans the whole run: a mode-3 proof is never a segment
   const int HW = header_words_of(mode), WA = air::aux_width(mode);
   if (!need(HW)) return 1;
   const int WM = (int)w[3], WT = WM + WA;                                  // committed main-trace columns (checked against the mode below); main + aux
@@ -527,7 +527,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   struct Cell { uint64_t addr, bytes; uint32_t t; };
   std::vector<Cell> cells;
   const uint32_t* mem_words = nullptr; size_t mem_len = 0;
-  if (mode == 3) {
+  if (mode >= 3) {
     if (!need(1)) return 4;
     const size_t nc = w[p];
     if (nc > ((size_t)1 << 28) || !need(1 + 7 * nc)) return 4;
@@ -546,11 +546,11 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     }
     p += mem_len;
   }
-  if (!need(n_code + air::RC_TABLE + (mode == 3 ? air::MEM_MULT : 0))) return 4;
+  if (!need(n_code + air::RC_TABLE + (mode >= 3 ? air::MEM_MULT : 0))) return 4;
   const uint32_t* rom_mult = w + p; p += n_code;
   const uint32_t* rc_mult = w + p; p += air::RC_TABLE;
   const uint32_t* mem_mult = nullptr;
-  if (mode == 3) { mem_mult = w + p; p += air::MEM_MULT; }
+  if (mode >= 3) { mem_mult = w + p; p += air::MEM_MULT; }
   if (!need(12)) return 4;
   const uint32_t* troot = w + p; p += 4; const uint32_t* aroot = w + p; p += 4; const uint32_t* qroot = w + p; p += 4;
   auto get_m = [&](size_t at) { E4 e; memcpy(e.c, w + at, 16); return bb::e_to_mont(e); };      // proof word -> Montgomery E4
@@ -577,11 +577,11 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   ch.observe_n(troot, 4);
   if (mode >= 2)                                                           // (v11) the tapes and the halt reason, fixed before the lookup challenges (a segment's too) — so::observe_section
     for (size_t at = 0; at < io.words; at += 512) { uint32_t dg[4]; hash_elems(io_words + at, io.words - at < 512 ? io.words - at : 512, dg); ch.observe_n(dg, 4); }
-  if (mode == 3)                                                           // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section)
+  if (mode >= 3)                                                           // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section)
     for (size_t at = 0; at < mem_len; at += 512) { uint32_t dg[4]; hash_elems(mem_words + at, mem_len - at < 512 ? mem_len - at : 512, dg); ch.observe_n(dg, 4); }
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
-  if (mode == 3) ch.observe_n(mem_mult, air::MEM_MULT);
+  if (mode >= 3) ch.observe_n(mem_mult, air::MEM_MULT);
   const E4 alpha_l = bb::e_to_mont(ch.sample_ext()), lambda = bb::e_to_mont(ch.sample_ext());
   // lookup parameters (air.h LK_*), Montgomery: alpha, lambda^0..10, T / N — T is the table side of the lookup identity, computed HERE
   // from the program in the proof and the multiplicities: sum_t m_t / (alpha - t) + sum_u r_u / (alpha - fingerprint(ROM row u))
@@ -593,9 +593,9 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (int k = 0; k < 4; k++) lk_m[air::LK_ALPHA + k] = alpha_l.c[k];
     for (int j = 0; j <= air::N_TUPLE; j++) for (int k = 0; k < 4; k++) lk_m[air::LK_LAM + 4 * j + k] = lam[j].c[k];
     const size_t n_tab = (size_t)air::RC_TABLE + n_code;
-    std::vector<E4> d(n_tab + (mode == 3 ? (size_t)air::MEM_MULT + 2 * cells.size() : 0));
+    std::vector<E4> d(n_tab + (mode >= 3 ? (size_t)air::MEM_MULT + 2 * cells.size() : 0));
     for (int t = 0; t < air::RC_TABLE; t++) { d[t] = alpha_l; d[t].c[0] = bb::sub(d[t].c[0], bb::to_mont((uint32_t)t)); }
-    if (mode == 3) {
+    if (mode >= 3) {
       // the LOW3, BYTE and NIBBLE tables, then the two ends of the memory check: per touched cell the INITIAL tuple (time 0, the program image's bytes) and the FINAL one
       auto tagged = [&](uint32_t v, int tag) { E4 e = bb::e_sub(alpha_l, bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)tag))); e.c[0] = bb::sub(e.c[0], bb::to_mont(v)); return e; };
       E4* m = d.data() + n_tab;

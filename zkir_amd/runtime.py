@@ -417,21 +417,22 @@ class DeltaLog:
 
 
 def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int] = (), deferred: bool = False, io_mode: bool = False, mem_mode: bool = False,
-                  mem_witness: str = "device", num_queries: int = 0, pow_bits: int = 0) -> PublicInputsC:
+                  mem_witness: str = "device", num_queries: int = 0, pow_bits: int = 0, wide_mode: bool = False) -> PublicInputsC:
     """zkir_public_inputs_of: what a proof of this run is bound to (row count, mode, entry pc, program digest, io digest).  io_mode = mode 2: the default VM mode
     with the I/O argument (WRITE / READ ecalls tied to the tapes, which the proof then carries).  mem_mode = mode 3: mode 2 with the memory argument (loads and stores
     constrained, every access tied to a consistent memory; the proof carries the touched cells).  mem_witness = "device": zkir_prove computes the run's memory witness on the
     GPU (memcheck.hip: address-major sort + segmented scan); "host": it is computed here by the host's sequential replay (zkir_memcheck_witness_of — the independent
-    implementation; needs no device) and handed to zkir_prove.  num_queries / pow_bits: the prover's FRI parameters (zkir_prover_params; 0 = the defaults, 50 + 12)."""
+    implementation; needs no device) and handed to zkir_prove.  num_queries / pow_bits: the prover's FRI parameters (zkir_prover_params; 0 = the defaults, 50 + 12).
+    wide_mode = mode 4 (round 6): mode 3 with MULH / DIVU / REMU / DIV / REM constrained on operands below 2^40 (a run that feeds them wider registers has no proof)."""
     blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
     arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
     out = PublicInputsC()
-    assert not (deferred and (io_mode or mem_mode)), "the I/O and memory arguments are stated for the default VM mode"
-    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), 3 if mem_mode else 2 if io_mode else int(deferred), C.byref(out))
+    assert not (deferred and (io_mode or mem_mode or wide_mode)), "the I/O and memory arguments are stated for the default VM mode"
+    rc = lib().zkir_public_inputs_of(log._h, blob, len(blob), arr, len(inputs), 4 if wide_mode else 3 if mem_mode else 2 if io_mode else int(deferred), C.byref(out))
     if rc != ZKIR_OK:
         _raise(rc)
     out.with_io(list(inputs), list(log.outputs))      # the C call borrowed temporaries: re-point at arrays / bytes this struct owns
-    if mem_mode and mem_witness == "host":
+    if (mem_mode or wide_mode) and mem_witness == "host":
         out.with_memory(MemcheckWitness(log, blob))
     if num_queries or pow_bits:
         out.with_params(num_queries, pow_bits)
