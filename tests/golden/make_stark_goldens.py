@@ -79,7 +79,16 @@ MEM_LOOP = blob([i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(ADDI, 1, 0, 0), i
                  r_(ADD, 2, 1, 1), r_(ADD, 2, 2, 1), s_(SD, 6, 2, 0), i_(LW, 7, 6, 0), i_(LHU, 8, 6, 2), i_(LB, 9, 6, 0), r_(ADD, 4, 4, 7), r_(ADD, 4, 4, 8), r_(ADD, 4, 4, 9),
                  i_(ADDI, 6, 6, 8), i_(ADDI, 1, 1, 1), i_(ADDI, 3, 3, -1), i_(BNE, 3, 0, -48),
                  i_(ADDI, 11, 4, 0), i_(ADDI, 10, 0, 2), ECALL, i_(ADDI, 10, 0, 0), i_(ADDI, 11, 0, 0), ECALL])
+# (mode 4) the five wide-arithmetic opcodes on a 40-bit pseudo-random state, with one SD / LD per iteration (the product ships it as spec.wide_loop_program)
+MUL_, MULH, DIVU, REMU, DIV, REM, XOR, SRLI, ORI, LD_ = 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x12, 0x1C, 0x14, 0x35
+WIDE_LOOP = blob([i_(ADDI, 1, 0, 12345), i_(ADDI, 2, 0, 0x2545), i_(SLLI, 2, 2, 4), i_(ADDI, 2, 2, 0xF), i_(ADDI, 12, 0, 0), i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1),
+                  r_(MUL_, 1, 1, 2), i_(ADDI, 1, 1, 0x4057), i_(SRLI, 3, 1, 17), i_(ORI, 3, 3, 1),
+                  r_(MULH, 4, 1, 1), r_(DIVU, 5, 1, 3), r_(REMU, 7, 1, 3), r_(DIV, 8, 4, 3), r_(REM, 9, 4, 3), r_(MULH, 10, 5, 3),
+                  r_(XOR, 12, 12, 4), r_(XOR, 12, 12, 5), r_(XOR, 12, 12, 7), r_(XOR, 12, 12, 8), r_(XOR, 12, 12, 9), r_(XOR, 12, 12, 10),
+                  s_(SD, 6, 12, 0), i_(LD_, 13, 6, 0), j_(JAL, 0, -72)])
 MODE_CASES = [
+    dict(name="mode4_wide_loop_1000", blob=WIDE_LOOP, max_cycles=1000, mode=4),
+    dict(name="mode4_memory_loop_40", blob=MEM_LOOP, max_cycles=1_000_000, mode=4),
     dict(name="mode2_fib30", blob=FIB30, max_cycles=1_000_000, mode=2),
     dict(name="mode3_fib30", blob=FIB30, max_cycles=1_000_000, mode=3),
     dict(name="mode2_memory_loop_40", blob=MEM_LOOP, max_cycles=1_000_000, mode=2),
@@ -116,13 +125,13 @@ def golden(case):
 
 
 def golden_mode(case):
-    """Modes 2 / 3 (the I/O argument; + the memory argument): the whole proof frozen by its SHA-256, the touched cells (mode 3) by count."""
+    """Modes 2 / 3 / 4 (the I/O argument; + the memory argument; + the wide-arithmetic class, format v12): the whole proof frozen by its SHA-256, the touched cells (modes 3 / 4) by count."""
     res = oracle.run(case["blob"], max_cycles=case["max_cycles"], enable_execution_trace=True)
-    pub = so.public_inputs(len(res.rows), case["blob"], [], list(res.outputs), (res.halt_kind, res.halt_code), io_mode=case["mode"] == 2, mem_mode=case["mode"] == 3)
+    pub = so.public_inputs(len(res.rows), case["blob"], [], list(res.outputs), (res.halt_kind, res.halt_code), io_mode=case["mode"] == 2, mem_mode=case["mode"] == 3, wide_mode=case["mode"] == 4)
     proof = so.prove(res.rows, pub)
     assert so.verify(proof, pub) == 0 and int(proof[9]) == case["mode"]
     return dict(name=case["name"], program_blob_hex=case["blob"].hex(), max_cycles=case["max_cycles"], mode=case["mode"], n_rows=len(res.rows), outputs=[int(x) for x in res.outputs],
-                halt=[int(res.halt_kind), int(res.halt_code)], committed_width=int(proof[3]), n_cells=int(len(so.mem_cells(res.rows, pub))) if case["mode"] == 3 else 0,
+                halt=[int(res.halt_kind), int(res.halt_code)], committed_width=int(proof[3]), n_cells=int(len(so.mem_cells(res.rows, pub))) if case["mode"] >= 3 else 0,
                 proof_words=int(len(proof)), proof_sha256=hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest())
 
 

@@ -77,6 +77,7 @@ def test_mode_goldens_describe_the_shipped_programs():
     assert bytes.fromhex(MODE_CASES["mode3_memory_loop_40"]["program_blob_hex"]) == spec.memory_loop_program(40).to_bytes()
     assert bytes.fromhex(MODE_CASES["mode3_fib30"]["program_blob_hex"]) == spec.fib_program(30).to_bytes()
     assert [MODE_CASES[n]["committed_width"] for n in ("mode2_fib30", "mode3_fib30")] == [so.committed_width(2), so.committed_width(3)] == [160, 264]
+    assert bytes.fromhex(MODE_CASES["mode4_wide_loop_1000"]["program_blob_hex"]) == spec.wide_loop_program().to_bytes() and MODE_CASES["mode4_wide_loop_1000"]["committed_width"] == so.committed_width(4) == 288
 
 
 @pytest.mark.parametrize("name", sorted(MODE_CASES))
@@ -85,12 +86,12 @@ def test_oracle_reproduces_mode_goldens(name):
     blob = bytes.fromhex(c["program_blob_hex"])
     res = oracle.run(blob, max_cycles=c["max_cycles"], enable_execution_trace=True)
     assert len(res.rows) == c["n_rows"] and [int(x) for x in res.outputs] == c["outputs"] and [res.halt_kind, res.halt_code] == c["halt"]
-    pub = so.public_inputs(len(res.rows), blob, [], c["outputs"], tuple(c["halt"]), io_mode=c["mode"] == 2, mem_mode=c["mode"] == 3)
+    pub = so.public_inputs(len(res.rows), blob, [], c["outputs"], tuple(c["halt"]), io_mode=c["mode"] == 2, mem_mode=c["mode"] == 3, wide_mode=c["mode"] == 4)
     proof = so.prove(res.rows, pub)
     assert int(proof[9]) == c["mode"] and int(proof[3]) == c["committed_width"]
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]
     assert rt.verify(proof) == 0 and so.verify(proof, pub) == 0
-    if c["mode"] == 3:
+    if c["mode"] >= 3:
         assert len(so.mem_cells(res.rows, pub)) == c["n_cells"]
 
 
@@ -102,7 +103,7 @@ def test_gpu_prover_reproduces_mode_goldens(name):
     blob = bytes.fromhex(c["program_blob_hex"])
     res = rt.VM(blob, [], rt.VMConfig(max_cycles=c["max_cycles"], enable_execution_trace=True)).run()
     assert res.cycles == c["n_rows"] and list(res.outputs) == c["outputs"]
-    pub = rt.public_inputs(res._log, blob, [], io_mode=c["mode"] == 2, mem_mode=c["mode"] == 3)
+    pub = rt.public_inputs(res._log, blob, [], io_mode=c["mode"] == 2, mem_mode=c["mode"] == 3, wide_mode=c["mode"] == 4)
     ctx = stark.StarkContext(stark.padded_log_n(res.cycles))
     proof = stark.prove(ctx, res.execution_trace.columns, pub)
     assert len(proof) == c["proof_words"] and hashlib.sha256(proof.astype("<u4").tobytes()).hexdigest() == c["proof_sha256"]

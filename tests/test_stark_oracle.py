@@ -462,7 +462,7 @@ def test_cpu_commit_port_matches_the_oracle():
         assert np.array_equal(root, so.commit_trace(rows, 1, pub=pub)) and t_lde > 0 and t_merkle > 0
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_column_blocked_commit_is_the_commit(mode):
     """so_commit_trace_blocked (round 5: the 2^24-row golden root of tests/golden/config_roots.json — eight LDE columns at a time, one 12-word sponge state per leaf, std::threads
     over columns / leaves) gives the root of so_commit_trace (every LDE column in memory, hash_elems per leaf) in every mode (152 / 168 / 160 / 264 committed columns), ragged row
@@ -470,13 +470,13 @@ def test_column_blocked_commit_is_the_commit(mode):
     for prog, n in ((spec.fib_endless_program(), 300), (spec.memory_loop_program(40), 1000), (spec.sha256_chain_program(), 513)):
         blob = prog.to_bytes()
         res = oracle.run(blob, max_cycles=n, enable_execution_trace=True, enable_deferred_model=mode == 1)
-        pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3)
+        pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, wide_mode=mode == 4)
         want = so.commit_trace(res.rows, 1, pub=pub)
         for threads in (1, 3):
             assert np.array_equal(so.commit_trace_blocked(res.rows, 1, pub=pub, threads=threads), want), (mode, n, threads)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_lean_prover_equals_the_plain_one(mode):
     """so::prove_lean (round 6: the whole-proof golden at BASELINE configs[2]'s own size, 2^24 rows — no committed copy of the matrix, openings from coefficients re-derived
     out of the LDE's even positions, std::threads over columns / leaves / coset points) writes the proof of so::prove word for word: every mode (152 / 168 / 160 / 264 committed
@@ -484,10 +484,12 @@ def test_lean_prover_equals_the_plain_one(mode):
     cases = [(spec.fib_endless_program(), 300, {}), (spec.fib_program(12), None, {}), (spec.fib_endless_program(), 2048, {"num_queries": 84, "pow_bits": 16})]
     if mode != 1:
         cases.append((spec.memory_loop_program(40), 700, {}))
+    if mode == 4:
+        cases.append((spec.wide_loop_program(), 300, {}))
     for prog, n, params in cases:
         blob = prog.to_bytes()
         res = oracle.run(blob, max_cycles=n or 1_000_000, enable_execution_trace=True, enable_deferred_model=mode == 1)
-        pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, **params)
+        pub = so.public_inputs(len(res.rows), blob, [], list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, wide_mode=mode == 4, **params)
         want = so.prove(res.rows, pub)
         assert so.verify(want, pub) == 0
         for threads in (1, 3):

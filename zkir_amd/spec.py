@@ -339,6 +339,21 @@ def memory_loop_program(n: int) -> Program:
     ])
 
 
+def wide_loop_program() -> Program:
+    """An ENDLESS loop over the five wide-arithmetic opcodes (AIR mode 4: MULH DIVU REMU DIV REM on operands below 2^40; run with max_cycles, halt = CycleLimit): a 40-bit
+    state x <- x * 0x2545F + 0x14057B (MUL / ADDI: wraps mod 2^40), a divisor d = (x >> 17) | 1, then MULH(x, x), DIVU, REMU, DIV, REM of x by d and a MULH of the quotient by
+    the divisor, accumulated with XOR into a checksum that is stored and read back (one SD / LD per iteration): 18 rows per iteration, 6 of them wide, every operand 40 bits."""
+    E, O = encode, Opcode
+    return Program.from_code([
+        addi(1, 0, 12345), addi(2, 0, 0x2545), slli(2, 2, 4), addi(2, 2, 0xF), addi(12, 0, 0), addi(6, 0, 0x8000), slli(6, 6, 1),      # x, the multiplier 0x2545F, checksum, base 0x10000
+        # L:
+        mul(1, 1, 2), addi(1, 1, 0x4057), E(O.SRLI, 3, 1, imm=17), E(O.ORI, 3, 3, imm=1),
+        E(O.MULH, 4, 1, 1), E(O.DIVU, 5, 1, 3), E(O.REMU, 7, 1, 3), E(O.DIV, 8, 4, 3), E(O.REM, 9, 4, 3), E(O.MULH, 10, 5, 3),
+        E(O.XOR, 12, 12, 4), E(O.XOR, 12, 12, 5), E(O.XOR, 12, 12, 7), E(O.XOR, 12, 12, 8), E(O.XOR, 12, 12, 9), E(O.XOR, 12, 12, 10),
+        E(O.SD, rs1=6, rs2=12, imm=0), E(O.LD, 13, 6, imm=0), jal(0, -72),
+    ])
+
+
 def memory_ring_program(log2_cells: int = 15) -> Program:
     """An ENDLESS walk over a ring of 2^log2_cells 8-byte cells at 0x100000 (AIR mode 3 at any size: run with max_cycles, halt = CycleLimit): per iteration (16 rows) the
     offset advances by 8 and is wrapped with ANDI, the cell gets the XOR of its old LD value with a counter (SD), is read back as a word, an unsigned halfword and a signed byte
