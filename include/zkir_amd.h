@@ -300,11 +300,12 @@ int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, co
 int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
                                void* hip_stream);
 int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out);
-/* The main trace of MODE 4 (round 6: mode 3 + the wide-arithmetic class — MULH / DIVU / REMU / DIV / REM, execute.rs:101-183, on operands below 2^40: 288 committed columns, six more
- * 10-bit range values per row); arguments as zkir_main_trace_mem_launch / _host. */
-int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
-                                void* hip_stream);
-int zkir_main_trace_wide_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out);
+/* The main trace of MODE 4 (round 6: mode 3 + the wide-arithmetic class — MULH / DIVU / REMU / DIV / REM, execute.rs:101-183, on operands below 2^40 — + hash syscalls as a
+ * tape + the code segment's boundary cell: 288 committed columns, six more 10-bit range values per row); arguments as zkir_main_trace_mem_launch / _host, plus the program's
+ * code_size (header bytes 16..20): when it is 4 modulo 8 the last code word shares an 8-byte cell with the first data bytes, and stores into that cell's low half have no proof. */
+int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint64_t code_size,
+                                uint32_t* scratch, uint32_t* out, void* hip_stream);
+int zkir_main_trace_wide_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint64_t code_size, uint32_t* out);
 /* the same rows computed on the HOST (trace = host pointers, out = host buffer, same B8 layout): the kernel's per-row code is one host + device
  * function, so the CPU test suite checks it against the oracle without a GPU.  A test / diagnostic entry point — the product never calls it
  * (there is no CPU fallback). */
@@ -373,6 +374,13 @@ typedef struct zkir_public_inputs {
   const uint64_t* cell_bytes;  /* [n_cells] the cell's final bytes, little-endian */
   const uint32_t* cell_time;   /* [n_cells] the time of its last access = that row's cycle + 1 */
   uint64_t n_cells;
+  /* MODE 4 (`deferred` == 4, round 6): mode 3 WITH the wide-arithmetic class (MULH / DIVU / REMU / DIV / REM on operands below 2^40), the code segment's boundary cell, and
+   * HASH SYSCALLS as a tape: the proof carries one record per SHA-256 / Keccak-256 / BLAKE3 call (cycle, pointers, length, kind, and per touched 8-byte cell its bytes before
+   * the call and the time of its previous access) and the verifier computes every digest itself.  PROVER side: hash_section = those records in the proof's own word layout
+   * (csrc/hashcall.h), BORROWED from a zkir_memcheck_witness made with zkir_memcheck_witness_of_mode(.., 4, ..) (zkir_public_inputs_set_memory sets it).  A run that makes
+   * hash calls is proven from that host witness: the device witness (mem_old == NULL) covers loads and stores only, and zkir_prove refuses such a run without the section. */
+  const uint32_t* hash_section;
+  uint64_t hash_section_words;
 } zkir_public_inputs;
 /* (mode 3) The memory witness of a WHOLE run (host, sequential like the interpreter: memory is a chain — what a load returns depends on every earlier store): the
  * log's rows are replayed with their register state (rebuilt from the register events), every load / store looks up its aligned 8-byte cell — the program image at first
@@ -380,6 +388,10 @@ typedef struct zkir_public_inputs {
  * window, an address of 2^40 or more (addr_limbs = 2, config.rs:30), an executed hash syscall (its memory effect is not stated by the AIR).  Free with zkir_memcheck_witness_free. */
 typedef struct zkir_memcheck_witness zkir_memcheck_witness;
 int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* program_blob, size_t blob_len, zkir_memcheck_witness** out);
+/* the same for a given AIR mode: 3 = zkir_memcheck_witness_of; 4 (round 6) also replays the run's hash syscalls (SHA-256 / Keccak-256 / BLAKE3: the message read out of the
+ * replayed memory, the digest computed and laid over the output range) and records them as the proof's hash section (zkir_public_inputs::hash_section) */
+int zkir_memcheck_witness_of_mode(const zkir_delta_log* log, const uint8_t* program_blob, size_t blob_len, uint32_t mode, zkir_memcheck_witness** out);
+uint64_t zkir_memcheck_witness_n_hash_calls(const zkir_memcheck_witness* w);
 void zkir_memcheck_witness_free(zkir_memcheck_witness* w);
 uint64_t zkir_memcheck_witness_n_cells(const zkir_memcheck_witness* w);
 uint64_t zkir_memcheck_witness_n_accesses(const zkir_memcheck_witness* w);

@@ -306,6 +306,28 @@ def mem_cells(rows: np.ndarray, pub: PublicC) -> np.ndarray:
     return out[:n]
 
 
+def hash_section(rows: np.ndarray, pub: PublicC) -> np.ndarray:
+    """(mode 4) the hash calls of a run as the proof carries them (so::hash_section): [n] then per call 8 words + 5 per touched cell."""
+    rows = np.ascontiguousarray(rows)
+    L = lib()
+    L.so_hash_section.restype = C.c_size_t; L.so_hash_section.argtypes = [C.c_void_p, C.POINTER(PublicC), C.c_void_p, C.c_size_t]
+    n = L.so_hash_section(rows.ctypes.data, C.byref(pub), None, 0)
+    out = np.zeros(n, np.uint32)
+    L.so_hash_section(rows.ctypes.data, C.byref(pub), out.ctypes.data, n)
+    return out
+
+
+def set_hash_calls(words=None) -> None:
+    """(tests, mode 4) the hash section prove_matrix_mem / failing_constraints are to use (a matrix brings no rows to replay); None clears."""
+    L = lib()
+    L.so_set_hash_calls.restype = None; L.so_set_hash_calls.argtypes = [C.c_void_p, C.c_size_t]
+    if words is None or len(words) == 0:
+        L.so_set_hash_calls(None, 0)
+    else:
+        w = _u32(words)
+        L.so_set_hash_calls(w.ctypes.data, len(w))
+
+
 def prove_matrix_mem(matrix: np.ndarray, pub: PublicC, cells: np.ndarray) -> np.ndarray:
     """(mode 3) proof of a GIVEN main-trace matrix with a GIVEN list of touched cells (tests: a cheating prover)."""
     m, c = _u32(matrix), _u32(cells).reshape(-1, 7)

@@ -239,7 +239,8 @@ static const uint32_t OP_EBREAK = 0x51;
 // MULH, DIVU, REMU, DIV, REM stay class "other": they work on the RAW 64-bit registers (Q2, Q3) — 128-bit products, more chunk lookups than a row has slots.
 static const int W_MAIN_MEM = 284;
 enum { C_KMU = 276, C_MA = 277, C_ME = 281 };
-// ---- MODE 4 (round 6, proof format v12): mode 3 WITH the "wide arithmetic" class wa = 22 — MULH, DIVU, REMU, DIV, REM (opcodes 3..7; execute.rs:101-183) on operands BELOW 2^40.
+// ---- MODE 4 (round 6, proof format v12) = mode 3 WITH three more things: the WIDE-ARITHMETIC class, HASH SYSCALLS, and the code segment's BOUNDARY CELL. ----
+// (a) class wa = 22: MULH, DIVU, REMU, DIV, REM (opcodes 3..7; execute.rs:101-183) on operands BELOW 2^40.
 // The reference computes these five on the RAW 64-bit registers (quirks Q2, Q3): MULH = ((a b as u128) >> 40) & (2^40 - 1), DIVU / REMU = a / b, a % b, DIV / REM the same on
 // `as i64` (wrapping).  For registers below 2^40 — everything ADD .. MUL, the logic opcodes, the shifts, the comparisons and LW / LHU / LBU ever write — an i64 is non-negative, so
 // DIV = DIVU, REM = REMU, the 80-bit product's bits above 80 are empty, and all five are ONE relation over 40-bit integers:
@@ -247,17 +248,32 @@ enum { C_KMU = 276, C_MA = 277, C_ME = 281 };
 // A wa row states kwa xb2 = kwa xc2 = 0: a run that feeds one of the five a register with bits above 40 (a sign-extended LB / LH result, an LD, a READ input or a link above
 // 2^40) has NO mode-4 proof — sound, incomplete, and stated; division by zero never is a row (the VM stops: RuntimeError::DivisionByZero).
 // Schoolbook in 10-bit chunks like MUL, but the 80-bit product, the addend and the remainder's range check need 23 lookups where a mode-3 row has 17: the mode adds SIX more
-// 10-bit range slots X0..X5 per row (24 aux columns) and 18 main columns:
-//   284 kwa | 285 om (MULH), 286 od (DIVU / DIV: the quotient is written), 287 orr (REMU / REM: the remainder is), 288 sg (the word is DIV / REM: op = 3 om + 4 od + 5 orr + 2 sg)
-//   289-292 gf_k = kwa F1_k (the products have degree 2 already: gated copies, like MUL's ma_k) | 293-301 e_1..e_9: the bits of the carries above their 10-bit slot | 302-307 X0..X5
+// 10-bit range slots X0..X5 per row (24 aux columns) and 22 main columns (kwa = om + od + orr is an expression; the signed variants DIV / REM are the word's VARIANT BIT g, the
+// ROM tuple's eleventh element: op = 3 om + 4 od + 5 orr + 2 g on a wa row):
+//   284 om (MULH), 285 od (DIVU / DIV: the quotient is written), 286 orr (REMU / REM: the remainder is)
+//   287-290 gf_k = kwa F1_k (the products have degree 2 already: gated copies, like MUL's ma_k) | 291-299 e_1..e_9: the bits of the carries above their 10-bit slot | 300-305 X0..X5
 // Slots of a wa row (every one reads the 10-bit table): R0..R3 = LO's chunks, R4..R7 = F1's, pieces 0-3 = F2's (= rs2's), pieces 4-6 = the low parts of carries c0 c1 c2
 // (c1 = p5 + 2^10 e1, c2 = p6 + 2^10 (e2 + 2 e3)), pieces 7, 8 and X0, X1 = G4: HI's chunks (MULH) / ADD's = the remainder's (divisions), X2..X5 = G5: on MULH the carries
 // c3 c4 c5 (c3 = X2 + 2^10 (e4 + 2 e5), c4 = X3 + 2^10 (e6 + 2 e7), c5 = X4 + 2^10 (e8 + 2 e9)), on divisions the chunks of d = b - r - 1 (>= 0: r < b; borrow e4).
 // Position k of the product: sum_{i+j=k} F1_i F2_j + ADD_k + c_(k-1) = LO_k + 2^10 c_k (k <= 3), = HI_(k-4) + 2^10 c_k (k = 4, 5; k = 6: HI_2 + 2^10 HI_3); a division has HI = 0,
 // c3 = 0 and no product above position 3 (q b <= a < 2^40).  Every sum stays below 2^23: the equations hold over the integers and every decomposition is unique.
+// (b) HASH SYSCALLS (syscall.rs:121-171, crypto.rs:223-395: SHA-256 = 3, Keccak-256 = 5, BLAKE3 = 6; Poseidon2 = 4 is an error in the reference: never a row) are a TAPE, like
+// the I/O tapes of mode 2: the proof carries one record per call — (cycle, input pointer, input length, output pointer, kind) and, per aligned 8-byte cell the call touches
+// (the cells under [in, in + len) and [out, out + 32), ascending), the cell's bytes BEFORE the call and the time of its previous access — and the VERIFIER does the rest: it reads
+// the message out of the old bytes, computes the digest ITSELF, lays it over the output range (SHA-256: eight u32 writes of the big-endian-parsed words, crypto.rs:251-254; the
+// other two byte by byte), and adds the call's memory accesses to the table side of the memory check (read (cell, told, old), written (cell, cycle + 1, new); told <= cycle checked
+// in the clear).  The AIR ties the ECALL row to its record with ONE lookup — HH (alpha - fp(cycle, R11's limbs, R12's, R13's, kind) - 12 lambda^11) = fh, four aux columns — and
+// keeps what mode 2 already states about the row (R10 = 3 + h0 + 2 h1, R10 <- 0 and nothing else written).  Mode 3's "no hash syscall" constraint becomes "no syscall 4".  A
+// hash call costs the proof 8 + 5 words per touched cell: the calls are PUBLIC in this design, like the final memory — what it costs NOT to arithmetise SHA-256 (64 rounds x ~20
+// lookups per block: a 2^22-cycle hash chain would need a 2^27-row trace).
+// (c) the BOUNDARY CELL: mode 3 refuses every touched cell that overlaps the code segment (check 55) — sound, but when code_size % 8 == 4 the last code word shares
+// its cell with the first four data bytes (the reference puts the data right behind the code, vm.rs:163-168), and a program that touches them had no proof.  Mode 4 admits THAT
+// cell and states that no store ever writes its low half: 306 iws, 307 nb with nb = delta iws, delta = (cell address - B) as a field element (B = the boundary cell, a public
+// constant of the program; CODE_BASE when there is none), and tl (kst - nb) = 0 with tl = the sum of the windows that touch bytes 0..3 — a store with such a window needs
+// delta != 0.  (Cells with address = B modulo p — 2^9 of the 2^37 cells — are refused with it: stated.)  Loads of the code word stay possible; cells INSIDE the code stay refused.
 static const int W_MAIN_WIDE = 308, W_MAX = 308;
-enum { C_KWA = 284, C_OM = 285, C_OD = 286, C_ORR = 287, C_SG = 288, C_GF = 289, C_WE = 293, C_X = 302 };
-static const int K_WA = 22, N_X = 6, N_WE = 9;
+enum { C_OM = 284, C_OD = 285, C_ORR = 286, C_GF = 287, C_WE = 291, C_X = 300, C_IWS = 306, C_NB = 307 };
+static const int K_WA = 22, N_X = 6, N_WE = 9, TAG_HASH = 12;
 static inline bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
 static const int K_MU = 20;
 static const uint32_t OP_MUL = 0x02;
@@ -293,12 +309,12 @@ static inline int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }
 // 152 columns in default mode (172 - 20), 168 in deferred mode (172 - 4), whole blocks of 8.  A removed column reads as the constant 0 wherever the
 // constraints, the boundary states or the lookups mention it.
 static const int W_AUX = 40;
-static const int W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 120, W_AUX_MAX = 120;   // mode 4: + XH0..XH5 (the helpers of the six extra range slots)    // mode 2: + HO (output helper), HI (input helper); mode 3: + P0..P8 (piece helpers), HMR, HMW (memory read / write helpers), FPN (fingerprint of the new cell bytes)
+static const int W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 128, W_AUX_MAX = 128;   // mode 4: + XH0..XH5 (the helpers of the six extra range slots), HH (the hash-call helper), four columns of zero padding (whole blocks of 8)    // mode 2: + HO (output helper), HI (input helper); mode 3: + P0..P8 (piece helpers), HMR, HMW (memory read / write helpers), FPN (fingerprint of the new cell bytes)
 static inline int aux_width(int mode) { return mode == 4 ? W_AUX_WIDE : mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
 // (AIR v6) the class column "other, jumps" (C_K3 + 1) is identically zero in the default mode too — no opcode's class is oj there (constraint 4) — and is not committed
 static const int C_KOJ = C_K3 + 1;
 // mode: 0 default, 1 deferred, 2 default + I/O argument (a bool passed for `mode` reads as 0 / 1)
-static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode < 3) || (c >= C_KWA && mode != 4) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+static inline bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode < 3) || (c >= C_OM && mode != 4) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 static inline int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a non-virtual column
 static inline int phys_width(int mode) { return mode == 1 ? 168 : mode == 2 ? 160 : mode == 3 ? 264 : mode == 4 ? 288 : 152; }   // 172 - 20 = 152, 172 - 4 = 168, 180 - 20 = 160: whole blocks of 8, no padding
 // logical [logical_width][N] -> committed [phys_width][N]
@@ -311,7 +327,7 @@ template <class V>
 static void to_logical_row(const V* phys, int mode, const V& zero, V* logical) {
   for (int c = 0; c < W_MAX; c++) logical[c] = is_virtual(c, mode) ? zero : phys[phys_col(c, mode)];
 }
-enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96 };
+enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96, A_HH = 120 };
 // (mode 3) the lookup tables beside the 10-bit range table (no tag) and the ROM (tag 1) / tapes (2, 3): LOW3 = {(v, v & 7)}, v < 2^10 (tag 4: the first range chunk of a
 // memory row is looked up HERE, with the window's offset — the address's low three bits), BYTE = {v < 2^8} (tag 5), NIBBLE = {v < 2^4} (tag 6); memory tuples carry tag 7
 static const int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10;   // (8-10: the nibble tables {(a, b, a op b)} of the bitwise opcodes)
@@ -329,7 +345,7 @@ static inline uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_
 // AIR v5: the families of ordered comparisons have FOUR members, op = base + 2 g + pol: SLTU SGEU SLT SGE (base 0x20, g = signed) and
 // BLT BGE BLTU BGEU (base 0x42, g = unsigned).  g is the word's VARIANT BIT, part of the ROM tuple (0 for every other opcode).
 static const uint32_t OP_SLT = 0x22, OP_SGE = 0x23, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28;
-static inline uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU) ? 1u : 0u; }
+static inline uint32_t variant_bit(uint32_t op, int mode = 0) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU || (mode == 4 && (op == 0x06 || op == 0x07))) ? 1u : 0u; }   // (mode 4: DIV / REM are the signed variants of DIVU / REMU)
 
 #pragma pack(push, 1)
 struct PackedRow { uint64_t cycle, pc; uint32_t instruction; uint64_t registers[16]; uint32_t bound_bits[16]; uint8_t bound_tag[16]; uint64_t bound_payload[16]; uint8_t reg_state[16]; };
@@ -359,6 +375,10 @@ struct Public {
   // last access (cycle + 1).  The prover reads them off its memory replay (main_trace) and the proof carries them; the verifier forms both ends of the memory check.
   struct Cell { uint64_t addr, bytes; uint32_t t; };
   std::vector<Cell> cells;
+  // ---- mode 4: the hash syscalls of the run, in order (the proof carries them; the verifier recomputes every digest): per call the cells it touches in increasing address
+  // order, each with its bytes BEFORE the call and the time of its previous access
+  struct HashCall { uint64_t cycle, in_ptr, len, out_ptr; uint32_t kind; std::vector<Cell> cells; };
+  std::vector<HashCall> hcalls;
   // ---- prover parameters (round 5): FRI queries and grinding bits, 0 = the defaults.  Carried in the header (words 4 and 6) and observed by the transcript with it.
   uint32_t fri = 0;          // num_queries | pow_bits << 16
   int num_queries() const { return (fri & 0xFFFF) ? (int)(fri & 0xFFFF) : 50; }
@@ -378,6 +398,46 @@ static uint64_t image_cell(const uint8_t* blob, size_t n, uint64_t addr) {
   for (int k = 0; k < 8; k++) { const uint64_t a = addr + k; if (a >= 0x1000 && a - 0x1000 < code_size + data_size) v |= (uint64_t)blob[32 + (a - 0x1000)] << (8 * k); }
   return v;
 }
+// ---- (mode 4) hash calls: what the verifier recomputes.  The digests are the oracle's own (zkir_oracle.cpp: the functions behind syscalls 3 / 5 / 6, pinned by the reference's KATs).
+extern "C" { void zo_sha256(const uint8_t* d, size_t n, uint32_t out_words[8]); void zo_keccak256(const uint8_t* d, size_t n, uint8_t out[32]); void zo_blake3(const uint8_t* d, size_t n, uint8_t out[32]); }
+static const uint64_t HASH_MAX_LEN = 1u << 20;                  // a proof states hash calls of up to 1 MiB of input (the record's length word is one field element)
+static inline bool hash_call_in_range(uint64_t in_ptr, uint64_t len, uint64_t out_ptr, uint32_t kind) {
+  return (kind == 3 || kind == 5 || kind == 6) && len <= HASH_MAX_LEN && in_ptr < (1ull << 40) && in_ptr + len <= (1ull << 40) && out_ptr < (1ull << 40) && out_ptr + 32 <= (1ull << 40);
+}
+// the aligned 8-byte cells under [in, in + len) and [out, out + 32), ascending, each once
+static void hash_call_cells(uint64_t in_ptr, uint64_t len, uint64_t out_ptr, std::vector<uint64_t>& addrs) {
+  addrs.clear();
+  if (len) for (uint64_t a = in_ptr & ~7ull; a < in_ptr + len; a += 8) addrs.push_back(a);
+  for (uint64_t a = out_ptr & ~7ull; a < out_ptr + 32; a += 8) addrs.push_back(a);
+  std::sort(addrs.begin(), addrs.end());
+  addrs.erase(std::unique(addrs.begin(), addrs.end()), addrs.end());
+}
+// the 32 bytes a hash syscall leaves at out .. out + 32: SHA-256 writes its eight big-endian-parsed words with write_u32 (little-endian), crypto.rs:251-254; Keccak-256 / BLAKE3 the digest's bytes in order
+static void hash_output_bytes(uint32_t kind, const uint8_t* msg, size_t len, uint8_t out[32]) {
+  if (kind == 3) { uint32_t h[8]; zo_sha256(msg, len, h); for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out[4 * i + k] = (uint8_t)(h[i] >> (8 * k)); }
+  else if (kind == 5) zo_keccak256(msg, len, out);
+  else zo_blake3(msg, len, out);
+}
+// the bytes of every touched cell AFTER the call (reads come first, crypto.rs:232-235: the message is read out of the OLD bytes); cells must be hash_call_cells' list
+template <class Call>
+static void hash_call_new_bytes(const Call& c, std::vector<uint64_t>& nb) {
+  auto index_of = [&](uint64_t cell) { size_t lo = 0, hi = c.cells.size(); while (lo + 1 < hi) { const size_t m = (lo + hi) / 2; if (c.cells[m].addr <= cell) lo = m; else hi = m; } return lo; };
+  std::vector<uint8_t> msg((size_t)c.len);
+  for (uint64_t k = 0; k < c.len; k++) { const uint64_t a = c.in_ptr + k; msg[(size_t)k] = (uint8_t)(c.cells[index_of(a & ~7ull)].bytes >> (8 * (a & 7))); }
+  uint8_t d[32];
+  hash_output_bytes(c.kind, msg.data(), msg.size(), d);
+  nb.resize(c.cells.size());
+  for (size_t i = 0; i < c.cells.size(); i++) nb[i] = c.cells[i].bytes;
+  for (int k = 0; k < 32; k++) { const uint64_t a = c.out_ptr + k; const size_t i = index_of(a & ~7ull); const int sh = 8 * (int)(a & 7); nb[i] = (nb[i] & ~(0xFFull << sh)) | ((uint64_t)d[k] << sh); }
+}
+// (mode 4) the code segment's BOUNDARY CELL: when code_size % 8 == 4 the last code word shares its cell with the first four data bytes; CODE_BASE (a cell inside the code:
+// refused anyway) when there is none
+static uint64_t boundary_cell(const uint8_t* blob, size_t n) {
+  if (!blob || n < 32) return 0x1000;
+  const uint64_t code_size = (uint64_t)blob[16] | ((uint64_t)blob[17] << 8) | ((uint64_t)blob[18] << 16) | ((uint64_t)blob[19] << 24);
+  return code_size % 8 == 4 ? 0x1000 + code_size - 4 : 0x1000;
+}
+static inline bool is_low_window(int v) { return v <= 3 || v == 8 || v == 9 || v == 12 || v == 14; }   // the windows that touch bytes 0..3 of their cell
 static const int N_STATE = 68;
 static int padded_log_n(uint64_t n_real) { int k = 3; while (((uint64_t)1 << k) < n_real) k++; return k; }
 
@@ -410,7 +470,7 @@ static inline F opclass_of(uint32_t op, int mode = 0) {
 struct Rom { std::vector<F> rows; size_t n = 0; uint64_t entry = 0; bool ok = false; const F* row(size_t t) const { return &rows[t * N_TUPLE]; } };
 static inline void rom_tuple(uint64_t pc, uint32_t w, F out[N_TUPLE], int mode = 0) {
   out[0] = (F)(pc & 0xFFFFF); out[1] = (F)((pc >> 20) & 0xFFFFF); out[2] = (F)(pc >> 40);
-  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F, mode); out[10] = variant_bit(w & 0x7F);
+  out[3] = w & 0x7F; out[4] = (w >> 7) & 0xF; out[5] = (w >> 11) & 0xF; out[6] = (w >> 15) & 0xF; out[7] = w >> 19; out[8] = w >> 31; out[9] = opclass_of(w & 0x7F, mode); out[10] = variant_bit(w & 0x7F, mode);
 }
 static Rom rom_from_blob(const uint8_t* b, size_t n, int mode = 0) {
   Rom r;
@@ -432,7 +492,7 @@ static inline void reg_limbs(uint64_t v, uint8_t st, F out[3]) {
 }
 
 // col-major out[W_MAIN][N]
-static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out, std::vector<Public::Cell>* cells_out = nullptr) {
+static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out, std::vector<Public::Cell>* cells_out = nullptr, std::vector<Public::HashCall>* hcalls_out = nullptr) {
   const int log_n = padded_log_n(n_real);
   const size_t N = (size_t)1 << log_n;
   const int mode = pub.mode();
@@ -441,6 +501,8 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
   const bool D = mode == 1, IO = mode >= 2, MEM = mode >= 3;
   uint64_t oc = pub.writes_before, reads = pub.reads_before;          // mode 2: WRITE / READ ecalls executed so far (syscall.rs:110-121)
   std::map<uint64_t, std::pair<uint64_t, uint32_t>> memory;           // mode 3: the replayed memory, cell address -> (bytes, time of the last access); untouched cells hold the program image
+  const uint64_t Bcell = boundary_cell(pub.blob, pub.blob_len);       // (mode 4)
+  if (hcalls_out) hcalls_out->clear();
   for (size_t i = 0; i < N; i++) {
     const bool pad = i >= n_real;
     const PackedRow& r = rows[pad ? n_real - 1 : i];
@@ -467,7 +529,6 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     else if (cls == K_LG) col(C_KLG)[i] = 1;
     else if (cls == K_SH) col(C_KSH)[i] = 1;
     else if (cls == K_MU) col(C_KMU)[i] = 1;
-    else if (cls == K_WA) col(C_KWA)[i] = 1;
     else if (cls != K_ECALL) col(kcol(cls))[i] = 1;           // (mode 2: the ecall class has no column — it is the sum of the four syscall flags)
     col(C_OPC)[i] = opclass_of(op, mode);                           // of the WORD, whatever class the row runs as (halt / pad rows, deferred mode)
     const bool branch = cls == K_BRE || cls == K_BRU;
@@ -484,7 +545,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
     //   when the comparison is signed (Value40::signed_lt, value.rs:710-716), the limb itself when it is not; u = (ta, tb) is the row's SECOND
     //   range-checked pair (chunks C_RC2 ..), which forces the sign bits; the borrow out of the biased difference is the comparison
     F z[2] = {0, 0}, c0 = 0, c1 = 0, u[2] = {0, 0}, sa = 0, sb = 0;
-    const F g = variant_bit(op);
+    const F g = variant_bit(op, mode);
     col(C_G)[i] = g;
     if (cls == K_SUB || cls == K_SU || cls == K_BRU) {
       const F* a = cls == K_BRU ? xc : xb; const F* b = cls == K_BRU ? xb : xc;
@@ -555,7 +616,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       const uint64_t M40 = (1ull << 40) - 1;
       const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20);   // (the top limbs must be zero: the constraints say so, a run that breaks it has no proof)
       const bool mulh = op == 0x03, quot = op == 0x04 || op == 0x06;
-      col(C_OM)[i] = mulh; col(C_OD)[i] = !mulh && quot; col(C_ORR)[i] = !mulh && !quot; col(C_SG)[i] = op >= 0x06;
+      col(C_OM)[i] = mulh; col(C_OD)[i] = !mulh && quot; col(C_ORR)[i] = !mulh && !quot;
       uint64_t f1, add, res;
       if (mulh) { f1 = a; add = 0; res = (uint64_t)(((unsigned __int128)a * b) >> 40) & M40; }
       else { const uint64_t qv = b ? a / b : 0, rv = b ? a % b : 0; f1 = qv; add = rv; res = quot ? qv : rv; }       // (b = 0 never is a row: the VM stops with DivisionByZero)
@@ -666,6 +727,10 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
         reg_limbs(window & mask, 0, y);                       // (nothing is written: y only satisfies the window equations below)
       }
       memory[cell] = std::make_pair(nb, (uint32_t)(r.cycle + 1));
+      if (mode == 4 && cls == K_ST && is_low_window(v)) {     // (mode 4) a store into the low half of a cell: not the boundary cell's — nb = delta iws = 1 with delta = cell - B (as a field element) != 0
+        const F delta = fadd(fsub(fsub(mem_z[0], (F)off), (F)(Bcell & 0xFFFFF)), fmul((F)(1u << 20), fsub(mem_z[1], (F)((Bcell >> 20) & 0xFFFFF))));
+        if (delta) { col(C_IWS)[i] = finv(delta); col(C_NB)[i] = 1; }
+      }
       // the nine pieces of the window value: the whole stored register on stores, the zero-extended loaded window on loads
       F pc9[9] = {(F)(window & 0xFF), (F)((window >> 8) & 0xFF), (F)((window >> 16) & 0xF), (F)((window >> 20) & 0xF), (F)((window >> 24) & 0xFF), (F)((window >> 32) & 0xFF),
                   (F)((window >> 40) & 0xFF), (F)((window >> 48) & 0xFF), (F)((window >> 56) & 0xFF)};
@@ -681,7 +746,21 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       else if (num == 1) {                                                                           // READ: R10 <- the next input, 0 once the tape is exhausted
         if (reads < pub.n_in) { col(C_RL)[i] = 1; reg_limbs(pub.inputs[reads], 0, y); } else col(C_RE)[i] = 1;
         reads++; rd = 10;
-      } else { col(C_FH)[i] = 1; col(C_H0)[i] = (F)((num - 3) & 1); col(C_H1)[i] = (F)(((num - 3) >> 1) & 1); rd = 10; }   // hash syscalls (3..6): R10 <- 0; their memory effect is not stated
+      } else {                                                 // hash syscalls (3, 5, 6): R10 <- 0; their memory effect is stated in mode 4 only (the hash tape), a run that makes one has no mode-3 proof
+        col(C_FH)[i] = 1; col(C_H0)[i] = (F)((num - 3) & 1); col(C_H1)[i] = (F)(((num - 3) >> 1) & 1); rd = 10;
+        if (mode == 4 && hash_call_in_range(r.registers[11], r.registers[12], r.registers[13], (uint32_t)num)) {
+          Public::HashCall hc{r.cycle, r.registers[11], r.registers[12], r.registers[13], (uint32_t)num, {}};
+          std::vector<uint64_t> addrs, nbv;
+          hash_call_cells(hc.in_ptr, hc.len, hc.out_ptr, addrs);
+          for (const uint64_t a : addrs) {
+            auto it = memory.find(a);
+            hc.cells.push_back(Public::Cell{a, it == memory.end() ? image_cell(pub.blob, pub.blob_len, a) : it->second.first, it == memory.end() ? 0u : it->second.second});
+          }
+          hash_call_new_bytes(hc, nbv);
+          for (size_t k = 0; k < addrs.size(); k++) memory[addrs[k]] = std::make_pair(nbv[k], (uint32_t)(r.cycle + 1));
+          if (hcalls_out) hcalls_out->push_back(std::move(hc));
+        }
+      }
     }
     if (rd > 0) col(C_WR + rd - 1)[i] = 1;
     if (cls == K_OTH || (cls == K_OJ && D)) {               // any other instruction: what it wrote is read off the next row
@@ -782,7 +861,7 @@ static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M
 static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE, LG_BASE = RC_TABLE + 256 + 16, L6_BASE = LG_BASE + 3 * 256;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR ++ LOW6 (1024: entry v = the tuple (v, v & 63))
 static inline bool row_shift(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0; }
 static inline bool row_mul(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KMU * N + i] != 0; }
-static inline bool row_wide(const std::vector<F>& M, size_t N, size_t i, int mode) { return mode == 4 && M[(size_t)C_KWA * N + i] != 0; }
+static inline bool row_wide(const std::vector<F>& M, size_t N, size_t i, int mode) { return mode == 4 && (M[(size_t)C_OM * N + i] | M[(size_t)C_OD * N + i] | M[(size_t)C_ORR * N + i]) != 0; }
 static inline bool row_shift_reg(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0 && M[(size_t)C_SI * N + i] == 0; }
 // the table a piece slot looks its value up in on a SHIFT row: 0-6 the 10-bit range table, 7 the nibble table, 8 LOW6 (with the amount) when the amount comes from a register
 static inline int shift_piece_tag(int k, bool reg) { return k == 7 ? TAG_NIB : (k == 8 && reg) ? TAG_LOW6 : 0; }
@@ -877,6 +956,41 @@ static E mem_table_sum(const Public& pub, const LookupParams& lp) {
   for (size_t k = 0; k < pub.cells.size(); k++) T = eadd(T, esub(d[2 * k], d[2 * k + 1]));
   return T;
 }
+// (mode 4) a hash call's tuple: (cycle, R11's limbs, R12's limbs, R13's limbs, kind), tag 12
+static inline E hash_fingerprint(const F e[11], const LookupParams& lp) {
+  E fp = emul_f(lp.lam[N_TUPLE], (F)TAG_HASH);
+  for (int j = 0; j < 11; j++) fp = eadd(fp, emul_f(lp.lam[j], e[j]));
+  return fp;
+}
+// (mode 4) the hash calls' share of the table side: + 1 / (alpha - fp(call)) per call (its ECALL row looks it up), and the call's memory accesses, which no row states:
+// - [1 / (alpha - fp(cell, told, old bytes)) - 1 / (alpha - fp(cell, cycle + 1, new bytes))] per touched cell (what a row would have added on the row side as HMR - HMW)
+static E hash_table_sum(const Public& pub, const LookupParams& lp) {
+  std::vector<E> d;
+  std::vector<uint64_t> nb;
+  for (const Public::HashCall& c : pub.hcalls) {
+    F e[11]; F l[3];
+    e[0] = (F)(c.cycle % P);
+    io_limbs(c.in_ptr, l); e[1] = l[0]; e[2] = l[1]; e[3] = l[2];
+    io_limbs(c.len, l); e[4] = l[0]; e[5] = l[1]; e[6] = l[2];
+    io_limbs(c.out_ptr, l); e[7] = l[0]; e[8] = l[1]; e[9] = l[2];
+    e[10] = (F)c.kind;
+    d.push_back(esub(lp.alpha, hash_fingerprint(e, lp)));
+    hash_call_new_bytes(c, nb);
+    for (size_t k = 0; k < c.cells.size(); k++) {
+      const F a0 = (F)(c.cells[k].addr & 0xFFFFF), a1 = (F)((c.cells[k].addr >> 20) & 0xFFFFF);
+      d.push_back(esub(lp.alpha, mem_fingerprint(a0, a1, c.cells[k].t, mem_bytes_fp(c.cells[k].bytes, lp), lp)));
+      d.push_back(esub(lp.alpha, mem_fingerprint(a0, a1, (F)((c.cycle + 1) % P), mem_bytes_fp(nb[k], lp), lp)));
+    }
+  }
+  batch_einv(d);
+  E T = e_from(0);
+  size_t at = 0;
+  for (const Public::HashCall& c : pub.hcalls) {
+    T = eadd(T, d[at++]);
+    for (size_t k = 0; k < c.cells.size(); k++) { T = esub(T, esub(d[at], d[at + 1])); at += 2; }
+  }
+  return T;
+}
 // (mode 2) the tapes' share of the table side: every output index in [oc_first, oc_last) and every input index in [ic_first, ic_last) exactly once —
 // the indices the segment's counters ran through (a whole run: 0 .. n_out and 0 .. the inputs it consumed)
 static E io_table_sum(const Public& pub, const LookupParams& lp) {
@@ -950,6 +1064,14 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
         for (int c = 0; c < 4; c++) { A[(size_t)(A_HMR + c) * N + i] = hr.c[c]; A[(size_t)(A_HMW + c) * N + i] = hw.c[c]; }
         hs = eadd(hs, esub(hr, hw));
       }
+    }
+    if (WIDE && at(C_FH)) {                                   // (mode 4) HH = fh / (alpha - fp(cycle, R11, R12, R13, kind)): the hash call's record is looked up in the tape the proof carries
+      F e[11] = {at(C_CYCLE)};
+      for (int j = 0; j < 9; j++) e[1 + j] = at(C_LIMB + 33 + j);
+      e[10] = (F)(3 + at(C_H0) + 2 * at(C_H1));
+      const E h = einv(esub(lp.alpha, hash_fingerprint(e, lp)));
+      for (int c = 0; c < 4; c++) A[(size_t)(A_HH + c) * N + i] = h.c[c];
+      hs = eadd(hs, h);
     }
     if (WIDE) for (int k = 0; k < N_X; k++) {                 // (mode 4) XH_k = 1 / (alpha - X_k), on every row
       const E h = einv(esub(lp.alpha, e_from(at(C_X + k))));
@@ -1052,7 +1174,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E Klg = MEM ? loc[C_KLG] : e_from(0);                                                             // (mode 3) the bitwise opcodes
   const E Kmu = MEM ? loc[C_KMU] : e_from(0);                                                             // (mode 3) MUL
   const E Ksh = MEM ? loc[C_KSH] : e_from(0);                                                             // (mode 3) the shifts
-  const E Kwa = WIDE ? loc[C_KWA] : e_from(0);                                                            // (mode 4) MULH DIVU REMU DIV REM
+  const E Kwa = WIDE ? eadd(eadd(loc[C_OM], loc[C_OD]), loc[C_ORR]) : e_from(0);                          // (mode 4) MULH DIVU REMU DIV REM: kwa = om + od + orr (no column of its own)
   { E sum = eadd(eadd(eadd(eadd(eadd(Kec, Kmem), Klg), Ksh), Kmu), Kwa); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
     E ks = eadd(eadd(eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST))), emul_f(Kmu, (F)K_MU)), emul_f(Kwa, (F)K_WA));
@@ -1243,7 +1365,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     for (int i = 0; i < N_RC; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
     if (IO) hs = eadd(hs, eadd(aloc[A_HO + k], aloc[A_HI + k]));
     if (MEM) { for (int i = 0; i < N_PIECE; i++) hs = eadd(hs, aloc[A_P + 4 * i + k]); hs = eadd(hs, esub(aloc[A_HMR + k], aloc[A_HMW + k])); }   // pieces and the read are looked up, the write is PROVIDED (a table entry)
-    if (WIDE) for (int i = 0; i < N_X; i++) hs = eadd(hs, aloc[A_X + 4 * i + k]);                  // (mode 4) the six extra range slots
+    if (WIDE) { for (int i = 0; i < N_X; i++) hs = eadd(hs, aloc[A_X + 4 * i + k]); hs = eadd(hs, aloc[A_HH + k]); }   // (mode 4) the six extra range slots, the hash-call lookup
     push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
   }
   // ---- 17. (mode 2, round 4) ECALL rows and the I/O tapes (syscall.rs:94-177).  Appended to the list: modes 0 / 1 stop here. ----
@@ -1299,7 +1421,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     }
     const E WD = Ev[14];
     push(esub(Esum, Kmem));                                                                         // exactly one window on a memory row, none elsewhere
-    push(loc[C_FH]);                                                                                // no hash syscall in this mode: its memory effect is not stated
+    if (WIDE) push(emul(loc[C_H0], esub(one, loc[C_H1])));                                          // (mode 4) hash syscalls are a tape (below); syscall 4 — Poseidon2, an error in the reference — never is a row
+    else push(loc[C_FH]);                                                                           // no hash syscall in this mode: its memory effect is not stated
     // the opcode names the width (and, for byte / halfword loads, whether the value is sign-extended): LB LBU LH LHU LW LD = 0x30.., SB SH SW SD = 0x38..
     push(emul(Kld, eadd(esub(esub(esub(esub(esub(op, cst(0x30)), emul_f(WH, 2)), emul_f(WW, 4)), emul_f(WD, 5)), eadd(WB, WH)), eadd(sgb, sgh))));
     push(emul(Kst, esub(esub(esub(esub(op, cst(0x38)), WH), emul_f(WW, 2)), emul_f(WD, 3))));
@@ -1460,12 +1583,10 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     // ---- 22. (mode 4, round 6) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI, schoolbook in 10-bit chunks.  Appended: mode 3 stops above. ----
     if (WIDE) {
       const E* Rlo = loc + C_RC; const E* Rf = loc + C_RC2; const E* gf = loc + C_GF; const E* we = loc + C_WE; const E* X = loc + C_X;
-      const E om = loc[C_OM], od = loc[C_OD], orr = loc[C_ORR], sg = loc[C_SG], kd = eadd(od, orr);
-      boolean(Kwa); boolean(om); boolean(od); boolean(orr); boolean(sg);
+      const E om = loc[C_OM], od = loc[C_OD], orr = loc[C_ORR], kd = eadd(od, orr);
+      boolean(Kwa); boolean(om); boolean(od); boolean(orr);                                       // (kwa boolean: at most one of the three kinds)
       for (int k = 0; k < N_WE; k++) boolean(we[k]);
-      push(esub(Kwa, eadd(om, kd)));                                                              // one of the three kinds on a wide row, none elsewhere
-      push(esub(emul(Kwa, op), eadd(eadd(emul_f(om, 3), emul_f(od, 4)), eadd(emul_f(orr, 5), emul_f(sg, 2)))));   // the opcode: MULH 3, DIVU 4, REMU 5, DIV 6, REM 7
-      push(emul(sg, esub(one, kd)));                                                              // the signed variants exist for the divisions only
+      push(esub(emul(Kwa, esub(op, emul_f(loc[C_G], 2))), eadd(eadd(emul_f(om, 3), emul_f(od, 4)), emul_f(orr, 5))));   // the opcode: MULH 3, DIVU 4, REMU 5, DIV 6 = 4 + 2 g, REM 7 = 5 + 2 g (g: the word's variant bit, from the ROM)
       push(emul(Kwa, esub(w1, fa)));                                                              // rd = field a
       push(emul(Kwa, xb[2])); push(emul(Kwa, xc[2]));                                             // the operands are below 2^40 (what makes DIV = DIVU, REM = REMU, MULH the product's bits 40..79)
       const E two10 = cst(RC_TABLE);
@@ -1508,6 +1629,28 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
         d[0] = esub(d[0], X[i]);
         ext_mul(aloc + A_X + 4 * i, d, pr);
         push(esub(pr[0], one)); push(pr[1]); push(pr[2]); push(pr[3]);
+      }
+      // ---- 23. (mode 4) the boundary cell: no store writes the low half of cell B — nb = delta iws, delta = the row's cell address minus B as ONE field element; tl (kst - nb) = 0
+      {
+        const uint64_t Bc = boundary_cell(pub.blob, pub.blob_len);
+        E tl = e_from(0);
+        for (int v = 0; v < N_WIN; v++) if (is_low_window(v)) tl = eadd(tl, Ev[v]);
+        const E delta = eadd(esub(esub(z[0], off), cst(Bc & 0xFFFFF)), emul(two20, esub(z[1], cst((Bc >> 20) & 0xFFFFF))));
+        push(esub(loc[C_NB], emul(delta, loc[C_IWS])));
+        push(emul(tl, esub(Kst, loc[C_NB])));
+      }
+      // ---- 24. (mode 4) hash syscalls: HH (alpha - fp(cycle, R11's limbs, R12's, R13's, 3 + h0 + 2 h1) - 12 lambda^11) = fh: the call's record is in the tape the proof carries
+      {
+        E d[4], pr[4];
+        const E kind = eadd(eadd(emul_f(loc[C_FH], 3), loc[C_H0]), emul_f(loc[C_H1], 2));           // (h0 = h1 = 0 off the hash rows, where the helper is zero anyway)
+        for (int k = 0; k < 4; k++) {
+          E fp = eadd(emul_f(cst(lp.lam[N_TUPLE].c[k]), TAG_HASH), emul_f(loc[C_CYCLE], lp.lam[0].c[k]));
+          for (int j = 0; j < 9; j++) fp = eadd(fp, emul_f(loc[C_LIMB + 33 + j], lp.lam[1 + j].c[k]));
+          fp = eadd(fp, emul_f(kind, lp.lam[10].c[k]));
+          d[k] = esub(cst(lp.alpha.c[k]), fp);
+        }
+        ext_mul(aloc + A_HH, d, pr);
+        push(esub(pr[0], loc[C_FH])); push(pr[1]); push(pr[2]); push(pr[3]);
       }
     }
   }
@@ -1556,6 +1699,16 @@ static void mem_section(const Public& pub, std::vector<uint32_t>& w) {
   for (const Public::Cell& c : pub.cells) { w.push_back((uint32_t)(c.addr & 0xFFFFF)); w.push_back((uint32_t)((c.addr >> 20) & 0xFFFFF)); w.push_back(c.t); put_u64(w, c.bytes); }
 }
 // (mode 2) the I/O section of a proof, after the program: [n_in] [inputs: four 16-bit pieces each] [n_out] [outputs] [halt kind] [halt code: four pieces]
+// (mode 4) the hash calls: [n] then per call [cycle] [input pointer: two 20-bit limbs] [input length] [output pointer: two limbs] [kind] [touched cells] and per touched cell
+// (ascending; the addresses follow from the pointers) [time of its previous access] [its bytes before the call: four 16-bit pieces]
+static void hash_section(const Public& pub, std::vector<uint32_t>& w) {
+  w.push_back((uint32_t)pub.hcalls.size());
+  for (const Public::HashCall& c : pub.hcalls) {
+    w.push_back((uint32_t)c.cycle); w.push_back((uint32_t)(c.in_ptr & 0xFFFFF)); w.push_back((uint32_t)(c.in_ptr >> 20)); w.push_back((uint32_t)c.len);
+    w.push_back((uint32_t)(c.out_ptr & 0xFFFFF)); w.push_back((uint32_t)(c.out_ptr >> 20)); w.push_back(c.kind); w.push_back((uint32_t)c.cells.size());
+    for (const Public::Cell& x : c.cells) { w.push_back(x.t); for (int i = 0; i < 4; i++) w.push_back((uint32_t)((x.bytes >> (16 * i)) & 0xFFFF)); }
+  }
+}
 static void put_u64(std::vector<uint32_t>& w, uint64_t v) { for (int i = 0; i < 4; i++) w.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); }
 static void io_section(const Public& pub, std::vector<uint32_t>& w) {
   w.push_back((uint32_t)pub.n_in); for (size_t i = 0; i < pub.n_in; i++) put_u64(w, pub.inputs[i]);
@@ -1587,7 +1740,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   const int Dm = pub.mode();                                              // 0 default, 1 deferred, 2 default + the I/O argument
   const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
   if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wl * N);         // LOGICAL; whatever it holds in uncommitted columns is dropped
-  else main_trace(rows, pub.n_real, pub, pt.M, &pub.cells);                                   // (mode 3: with the touched cells; an override brings its own in pub_in.cells)
+  else main_trace(rows, pub.n_real, pub, pt.M, &pub.cells, &pub.hcalls);                                   // (mode 3: with the touched cells; an override brings its own in pub_in.cells)
   for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(pt.M.begin() + (size_t)c * N, pt.M.begin() + (size_t)(c + 1) * N, 0);
   to_physical(pt.M, N, Dm, pt.Mp);
   for (int i = 0; i < N_STATE; i++) {                                     // boundary states: rows 0 and n_real - 1 of the matrix being proven
@@ -1614,6 +1767,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
   if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the tapes and the halt reason: what the io digest is a digest of; (v11) fixed BEFORE the lookup challenges — a SEGMENT's tapes too, whose digest only the chain checks
   if (Dm >= 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
+  if (Dm == 4) { const size_t at = w.size(); hash_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // (mode 4) the hash calls, likewise
   lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult, nullptr, Dm, &pt.mem_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
   w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
@@ -1631,6 +1785,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
     E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp, Dm >= 3 ? pt.mem_mult.data() : nullptr);
     if (Dm >= 2) T = eadd(T, io_table_sum(pub, pt.lp));
     if (Dm >= 3) T = eadd(T, mem_table_sum(pub, pt.lp));
+    if (Dm == 4) T = eadd(T, hash_table_sum(pub, pt.lp));
     pt.lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   // ---- aux trace: helper columns + running sum; its own LDE and commitment ----
@@ -1819,7 +1974,7 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
   const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
   if (threads < 1) threads = 1;
   std::vector<F> M;
-  main_trace(rows, pub.n_real, pub, M, &pub.cells);
+  main_trace(rows, pub.n_real, pub, M, &pub.cells, &pub.hcalls);
   for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(M.begin() + (size_t)c * N, M.begin() + (size_t)(c + 1) * N, 0);
   for (int i = 0; i < N_STATE; i++) { pub.first[i] = M[(size_t)state_col(i) * N]; pub.last[i] = M[(size_t)state_col(i) * N + (pub.n_real - 1)]; }
   if (Dm >= 2) for (int k = 0; k < 2; k++) { pub.cnt_first[k] = M[(size_t)(C_OC + k) * N]; pub.cnt_last[k] = M[(size_t)(C_OC + k) * N + (pub.n_real - 1)]; }
@@ -1846,6 +2001,7 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
   for (size_t i = 0; i < pub.blob_len; i += 2) w.push_back((uint32_t)pub.blob[i] | (i + 1 < pub.blob_len ? (uint32_t)pub.blob[i + 1] << 8 : 0u));
   if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
   if (Dm >= 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
+  if (Dm == 4) { const size_t at = w.size(); hash_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
   std::vector<F> rom_mult, rc_mult, mem_mult;
   lookup_multiplicities(M, N, rom, rom_mult, rc_mult, nullptr, Dm, &mem_mult);
   w.insert(w.end(), rom_mult.begin(), rom_mult.end());
@@ -1865,6 +2021,7 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
     E T = lookup_table_sum(rom, rom_mult.data(), rc_mult.data(), lp, Dm >= 3 ? mem_mult.data() : nullptr);
     if (Dm >= 2) T = eadd(T, io_table_sum(pub, lp));
     if (Dm >= 3) T = eadd(T, mem_table_sum(pub, lp));
+    if (Dm == 4) T = eadd(T, hash_table_sum(pub, lp));
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   std::vector<F> AL((size_t)Wa * N2);
@@ -2128,9 +2285,44 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
       // (v11) no access to the CODE: instruction fetch is tied to the program's words (the ROM), so a store into [0x1000, 0x1000 + code_size) would change what the VM
       // executes next (vm.rs:175: strict protection is off) but not what the AIR lets through — a mode-3 proof is of a run whose loads and stores stay off the cells
       // that overlap the code segment, and every accessed cell is in this list (the memory check does not balance otherwise)
-      if (pub.cells[k].addr + 8 > 0x1000 && pub.cells[k].addr < 0x1000 + 4 * (uint64_t)rom.n) return 55;
+      // (mode 4) .. except the BOUNDARY cell (code_size % 8 == 4: the last code word and the first four data bytes): the AIR states there that no store writes its low half
+      if (pub.cells[k].addr + 8 > 0x1000 && pub.cells[k].addr < 0x1000 + 4 * (uint64_t)rom.n && !(mode == 4 && (rom.n & 1) && pub.cells[k].addr == boundary_cell(blob.data(), blob_len))) return 55;
     }
     p += mem_len;
+  }
+  // (mode 4) the hash calls: records in increasing cycle order, ranges in the clear, the previous access of every touched cell before the call (the Blum condition: check 56);
+  // the output never lands on code bytes (55)
+  const uint32_t* hash_words = nullptr; size_t hash_len = 0;
+  if (mode == 4) {
+    if (!need(1)) return 4;
+    const size_t nh = w[p];
+    if (nh > pub.n_real) return 56;
+    hash_words = w + p;
+    size_t q = p + 1;
+    pub.hcalls.resize(nh);
+    std::vector<uint64_t> addrs;
+    const uint64_t code_end = 0x1000 + 4 * (uint64_t)rom.n;
+    for (size_t k = 0; k < nh; k++) {
+      if (q + 8 > len) return 4;
+      const uint32_t* c = w + q;
+      Public::HashCall& hc = pub.hcalls[k];
+      if (c[1] >= (1u << 20) || c[2] >= (1u << 20) || c[4] >= (1u << 20) || c[5] >= (1u << 20)) return 56;
+      hc.cycle = c[0]; hc.in_ptr = (uint64_t)c[1] | ((uint64_t)c[2] << 20); hc.len = c[3]; hc.out_ptr = (uint64_t)c[4] | ((uint64_t)c[5] << 20); hc.kind = c[6];
+      if (hc.cycle >= pub.n_real || (k && hc.cycle <= pub.hcalls[k - 1].cycle) || !hash_call_in_range(hc.in_ptr, hc.len, hc.out_ptr, hc.kind)) return 56;
+      if (hc.out_ptr < code_end && hc.out_ptr + 32 > 0x1000) return 55;
+      hash_call_cells(hc.in_ptr, hc.len, hc.out_ptr, addrs);
+      if (c[7] != addrs.size() || q + 8 + 5 * addrs.size() > len) return 56;
+      q += 8;
+      hc.cells.resize(addrs.size());
+      for (size_t j = 0; j < addrs.size(); j++, q += 5) {
+        uint64_t bytes = 0;
+        for (int i = 0; i < 4; i++) { if (w[q + 1 + i] > 0xFFFF) return 56; bytes |= (uint64_t)w[q + 1 + i] << (16 * i); }
+        if (w[q] > hc.cycle) return 56;                                                     // the time read (previous access: its cycle + 1) is smaller than the time written (cycle + 1)
+        hc.cells[j] = Public::Cell{addrs[j], bytes, w[q]};
+      }
+    }
+    hash_len = q - p;
+    p = q;
   }
   if (!need(rom.n + RC_TABLE + (mode >= 3 ? MEM_MULT : 0))) return 4;
   const F* rom_mult = w + p; p += rom.n;
@@ -2162,6 +2354,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   ch.observe_n(troot, 4);
   if (mode >= 2) observe_section(ch, io_words, io.words);
   if (mode >= 3) observe_section(ch, mem_words, mem_len);
+  if (mode == 4) observe_section(ch, hash_words, hash_len);
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
   if (mode >= 3) ch.observe_n(mem_mult, MEM_MULT);
@@ -2177,6 +2370,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     E T = lookup_table_sum(rom, rom_mult, rc_mult, lp, mem_mult);           // the table side of the lookup identity, computed HERE
     if (mode >= 2) T = eadd(T, io_table_sum(pub, lp));                     // .. its I/O share from the tapes the proof carries
     if (mode >= 3) T = eadd(T, mem_table_sum(pub, lp));                    // .. and both ends of the memory check from the touched cells it carries
+    if (mode == 4) T = eadd(T, hash_table_sum(pub, lp));                   // .. (mode 4) and the hash calls: every digest is computed HERE
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   ch.observe_n(aroot, 4);
@@ -2660,6 +2854,33 @@ size_t so_mem_cells(const void* packed_rows, const so_public* pub, uint32_t* out
   }
   return cells.size();
 }
+// (mode 4) the hash calls of a run as the proof's hash section (so::hash_section); returns the word count
+size_t so_hash_section(const void* packed_rows, const so_public* pub, uint32_t* out, size_t cap) {
+  std::vector<so::F> m; so::Public q = to_pub(pub);
+  so::main_trace((const so::PackedRow*)packed_rows, pub->n_real, q, m, &q.cells, &q.hcalls);
+  std::vector<uint32_t> w; so::hash_section(q, w);
+  if (out && w.size() <= cap) memcpy(out, w.data(), w.size() * 4);
+  return w.size();
+}
+// (tests, mode 4) the hash calls so_prove_matrix_mem / so_failing_constraints are to use (a matrix brings no rows to replay): a hash section, possibly forged; n = 0 clears
+static std::vector<so::Public::HashCall> g_hcalls;
+void so_set_hash_calls(const uint32_t* w, size_t n) {
+  g_hcalls.clear();
+  if (!w || !n) return;
+  size_t q = 1;
+  std::vector<uint64_t> addrs;
+  for (uint32_t k = 0; k < w[0] && q + 8 <= n; k++) {
+    so::Public::HashCall hc{w[q], (uint64_t)w[q + 1] | ((uint64_t)w[q + 2] << 20), w[q + 3], (uint64_t)w[q + 4] | ((uint64_t)w[q + 5] << 20), w[q + 6], {}};
+    const size_t nc = w[q + 7];
+    so::hash_call_cells(hc.in_ptr, hc.len, hc.out_ptr, addrs);
+    q += 8;
+    for (size_t j = 0; j < nc && q + 5 <= n; j++, q += 5) {
+      uint64_t b = 0; for (int i = 0; i < 4; i++) b |= (uint64_t)w[q + 1 + i] << (16 * i);
+      hc.cells.push_back(so::Public::Cell{j < addrs.size() ? addrs[j] : 0, b, w[q]});
+    }
+    g_hcalls.push_back(std::move(hc));
+  }
+}
 // (mode 3) proof of a GIVEN matrix with a GIVEN list of touched cells (tests: a cheating prover)
 size_t so_prove_matrix_mem(const uint32_t* matrix, const so_public* pub, const uint32_t* cells7, size_t n_cells, uint32_t* out, size_t cap) {
   so::Public q = to_pub(pub);
@@ -2668,6 +2889,7 @@ size_t so_prove_matrix_mem(const uint32_t* matrix, const so_public* pub, const u
     for (int i = 0; i < 4; i++) b |= (uint64_t)c[3 + i] << (16 * i);
     q.cells.push_back(so::Public::Cell{(uint64_t)c[0] | ((uint64_t)c[1] << 20), b, c[2]});
   }
+  q.hcalls = g_hcalls;
   so::Proof pr; so::prove(nullptr, q, pr, g_pt, matrix);
   if (out && pr.w.size() <= cap) memcpy(out, pr.w.data(), pr.w.size() * 4);
   return pr.w.size();
@@ -2698,6 +2920,7 @@ size_t so_failing_constraints(const uint32_t* matrix, const so_public* pub, cons
   so::E T = so::lookup_table_sum(rom, rm.data(), cm.data(), lp, mode >= 3 ? mm.data() : nullptr);
   if (mode >= 2) T = so::eadd(T, so::io_table_sum(q, lp));
   if (mode >= 3) T = so::eadd(T, so::mem_table_sum(q, lp));
+  if (mode == 4) { q.hcalls = g_hcalls; T = so::eadd(T, so::hash_table_sum(q, lp)); }
   lp.t_over_n = so::emul_f(T, so::finv((so::F)(N % so::P)));
   so::aux_trace(M, N, lp, A, mode);
   const int NC = so::num_constraints(mode);

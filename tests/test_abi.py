@@ -351,7 +351,7 @@ def test_memcheck_witness_and_main_trace_mode3_match_oracle_on_the_host(name):
 
 # ---- MODE 4 (round 6): mode 3 + the wide-arithmetic class MULH / DIVU / REMU / DIV / REM — the product's host-side pieces against the oracle (no GPU) ------------------------
 def test_air_bounds_mode4():
-    """The quotient kernel's lazy arithmetic is sound on the mode-4 constraint list (704 constraints) too (air::BoundOps on air::eval)."""
+    """The quotient kernel's lazy arithmetic is sound on the mode-4 constraint list (707 constraints) too (air::BoundOps on air::eval)."""
     import ctypes as C
     L = rt.lib()
     why = C.create_string_buffer(256)
@@ -361,7 +361,8 @@ def test_air_bounds_mode4():
 
 
 def test_quotient_evaluation_matches_oracle_constraints_mode4():
-    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 4: 308 logical / 120 aux columns, 704 constraints."""
+    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 4: 308 logical / 128 aux columns, 707 constraints (the
+    boundary cell's address enters through two lookup parameters, LK_B0 / LK_B1: the oracle derives it from the program, here fib(5)'s 19 code words: code_size % 8 == 4)."""
     import ctypes as C
     import numpy as np
     from oracle import stark_api as so
@@ -376,13 +377,16 @@ def test_quotient_evaluation_matches_oracle_constraints_mode4():
     virt = [9, 10, 11] + list(range(57, 73)) + [161]
     blob = spec.fib_program(5).to_bytes()
     pub = so.public_inputs(64, blob, [], [5], (1, 0), wide_mode=True)
-    assert LO.so_num_constraints_for(4) == 704 and so.logical_width(4) == 308 and so.aux_width(4) == 120 and so.committed_width(4) == 288
+    assert LO.so_num_constraints_for(4) == 707 and so.logical_width(4) == 308 and so.aux_width(4) == 128 and so.committed_width(4) == 288
+    code_size = int.from_bytes(blob[16:20], "little")
+    bcell = 0x1000 + code_size - 4 if code_size % 8 == 4 else 0x1000
     for trial in range(40):
         big = trial >= 36
         def words(n):
             return np.full(n, P - 1, np.uint32) if big else rng.integers(0, P, n).astype(np.uint32)
-        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(308), words(308), words(120), words(120), words(57), words(68), words(68), words(4), words(4), words(3)
+        loc, nxt, aloc, anxt, lk, first, last, cnt, alpha, sel = words(308), words(308), words(128), words(128), words(59), words(68), words(68), words(4), words(4), words(3)
         loc[virt] = 0; nxt[virt] = 0
+        lk[57], lk[58] = bcell & 0xFFFFF, (bcell >> 20) & 0xFFFFF
         want, got = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
         LO.so_constraints_eval_io(loc.ctypes.data, nxt.ctypes.data, aloc.ctypes.data, anxt.ctypes.data, lk.ctypes.data, int(sel[0]), int(sel[1]), int(sel[2]), C.byref(pub),
                                   first.ctypes.data, last.ctypes.data, cnt.ctypes.data, alpha.ctypes.data, want.ctypes.data)
@@ -391,7 +395,7 @@ def test_quotient_evaluation_matches_oracle_constraints_mode4():
         assert np.array_equal(got, want), (trial, got, want)
 
 
-@pytest.mark.parametrize("name", ["wide_grid", "alu_all", "loads_stores", "random3"])
+@pytest.mark.parametrize("name", ["wide_grid", "alu_all", "loads_stores", "random3", "sha_chain", "sha256_hello"])
 def test_main_trace_mode4_matches_oracle_on_the_host(name):
     """zkir_main_trace_wide_host (stark.hip: main_trace_row<4>) writes the oracle's mode-4 main trace: every committed column of every row — the five wide opcodes over a grid
     of operands (the largest carries, dividend < divisor, equal operands, rd = r0), and the mode-3 columns unchanged on programs that use none of them."""
@@ -401,6 +405,8 @@ def test_main_trace_mode4_matches_oracle_on_the_host(name):
     from oracle import api as oracle, stark_api as so
     if name.startswith("random"):
         blob, ins = pg.random_program(int(name[6:]), hashes=False); cfg = {}
+    elif name == "sha_chain":
+        blob, ins, cfg = spec.sha256_chain_program().to_bytes(), [], {"max_cycles": 600}
     else:
         blob, ins, cfg = getattr(pg, name)()
     cfg = {k: v for k, v in cfg.items() if k == "max_cycles"}
@@ -410,6 +416,11 @@ def test_main_trace_mode4_matches_oracle_on_the_host(name):
     pub = rt.public_inputs(log, blob, list(ins), wide_mode=True, mem_witness="host")
     opub = so.public_inputs(nr, blob, list(ins), list(res.outputs), (res.halt_kind, res.halt_code), wide_mode=True)
     assert pub.deferred == 4 and list(pub.io_digest) == list(opub.io)
+    # the hash tape of the host witness (zkir_memcheck_witness_of_mode, hashcall.h) is the oracle's hash section word for word, the touched cells its touched cells
+    want_hash = so.hash_section(rows, opub)
+    got_hash = np.ctypeslib.as_array(C.cast(pub.hash_section, C.POINTER(C.c_uint32)), (pub.hash_section_words,)) if pub.hash_section_words else np.zeros(1, np.uint32)
+    assert np.array_equal(got_hash, want_hash) and (int(want_hash[0]) > 0) == (name in ("sha_chain", "sha256_hello"))
+    assert pub.n_cells == len(so.mem_cells(rows, opub))
     cyc, pc, ins_c = (np.ascontiguousarray(rows[f]) for f in ("cycle", "pc", "instruction"))
     regs, bb_, bt, bp, st = (np.ascontiguousarray(rows[f].T) for f in ("registers", "bound_bits", "bound_tag", "bound_payload", "reg_state"))
     tc = rt.TraceColumnsC(cyc.ctypes.data, pc.ctypes.data, ins_c.ctypes.data, regs.ctypes.data, bb_.ctypes.data, bt.ctypes.data, bp.ctypes.data, st.ctypes.data, nr)
@@ -423,8 +434,8 @@ def test_main_trace_mode4_matches_oracle_on_the_host(name):
     io = IoArgs(tape.ctypes.data, len(ins), 0, 0)
     L = rt.lib()
     L.zkir_main_trace_wide_host.restype = C.c_int
-    L.zkir_main_trace_wide_host.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    assert L.zkir_main_trace_wide_host(C.byref(tc), nr, C.byref(io), pub.mem_old, pub.mem_told, out.ctypes.data) == 0
+    L.zkir_main_trace_wide_host.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    assert L.zkir_main_trace_wide_host(C.byref(tc), nr, C.byref(io), pub.mem_old, pub.mem_told, int.from_bytes(blob[16:20], "little"), out.ctypes.data) == 0
     got = out.transpose(0, 2, 1).reshape(wm, N)
     want = so.to_committed(so.main_trace(rows, opub), 4)
     for k in range(wm):

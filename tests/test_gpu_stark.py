@@ -619,10 +619,13 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
 
 # ---- MODE 4 (round 6): mode 3 + MULH / DIVU / REMU / DIV / REM on operands below 2^40 -----------------------------------------------------------------------
 @pytest.mark.parametrize("witness", ["device", "host"])
-@pytest.mark.parametrize("which", ["wide_grid", "alu_all", "timestamps", "mul_grid", "random3", "random5", "memloop", "fib30"])
+@pytest.mark.parametrize("which", ["wide_grid", "alu_all", "timestamps", "mul_grid", "random3", "random5", "memloop", "fib30", "sha_chain_small", "sha256_hello", "hashes_all",
+                                   "blake3_multi_chunk"])
 def test_mode4_proof_bytes_match_oracle_and_verify(which, witness):
-    """A proof in mode 4 (format v12: 288 + 120 columns, 704 constraints) — the five wide opcodes constrained as F1 F2 + ADD = LO + 2^40 HI over 10-bit chunks, everything of
-    mode 3 beside them — from the GPU prover equals the oracle's word for word; both verifiers accept it and give the same verdict on tampered copies."""
+    """A proof in mode 4 (format v12: 288 + 128 columns, 707 constraints) — the five wide opcodes constrained as F1 F2 + ADD = LO + 2^40 HI over 10-bit chunks, hash syscalls as
+    a tape whose digests the verifier computes (configs[4]'s SHA-256 chain, the reference's SHA-256 / Keccak-256 / BLAKE3 tests: proven from the host witness — a "device"
+    request is switched over), the boundary cell (the chain program reads its seed from it), everything of mode 3 beside them — from the GPU prover equals the oracle's word
+    for word; both verifiers accept it and give the same verdict on tampered copies."""
     from zkir_amd import stark
     blob, ins, ores, log, tr, opub, pub = _mode3_case(which, witness, wide=True)
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))

@@ -11,7 +11,7 @@ from oracle import api as oracle, stark_api as so
 from zkir_amd import spec
 
 C_LIMB, C_Y, C_RC, C_RC2, C_PIECE = 9, 124, 135, 163, 206
-C_KWA, C_OM, C_OD, C_ORR, C_SG, C_GF, C_WE, C_X = 284, 285, 286, 287, 288, 289, 293, 302
+C_OM, C_OD, C_ORR, C_GF, C_WE, C_X, C_IWS, C_NB, C_G, C_FH, C_KST, C_E = 284, 285, 286, 287, 291, 300, 306, 307, 167, 175, 181, 182
 M40 = (1 << 40) - 1
 
 
@@ -22,7 +22,7 @@ def _case(blob, ins=(), **cfg):
 
 
 def test_widths():
-    assert (so.logical_width(4), so.committed_width(4), so.aux_width(4), so.lib().so_num_constraints_for(4)) == (308, 288, 120, 704)
+    assert (so.logical_width(4), so.committed_width(4), so.aux_width(4), so.lib().so_num_constraints_for(4)) == (308, 288, 128, 707)
     assert (so.logical_width(3), so.committed_width(3), so.aux_width(3), so.lib().so_num_constraints_for(3)) == (284, 264, 96, 636)      # mode 3 untouched
 
 
@@ -75,8 +75,9 @@ def test_wide_arithmetic_is_constrained():
         if rd:
             assert int(regs[i + 1][rd]) == want
     assert so.failing_constraints(M, pub, cells)[0] == 0
-    assert np.array_equal(M[C_KWA][:nr] != 0, (ops >= 3) & (ops <= 7) & (np.arange(nr) < nr - 1))
-    assert np.array_equal(M[C_OM][rows] != 0, ops[rows] == 3) and np.array_equal(M[C_SG][rows] != 0, ops[rows] >= 6)
+    kwa = M[C_OM] + M[C_OD] + M[C_ORR]
+    assert np.array_equal(kwa[:nr] != 0, (ops >= 3) & (ops <= 7) & (np.arange(nr) < nr - 1))
+    assert np.array_equal(M[C_OM][rows] != 0, ops[rows] == 3) and np.array_equal(M[C_G][rows] != 0, ops[rows] >= 6)       # DIV / REM: the word's variant bit
     assert [int(M[C_WE + k][rows].max()) for k in range(8)] == [1] * 8            # every carry bit but the last occurs (c5 = 2048 would need both operands all ones AND c4 maximal)
 
     def bad(edit):
@@ -99,9 +100,10 @@ def test_wide_arithmetic_is_constrained():
     assert bad(remainder_equals_divisor)
     assert bad(lambda F: (F.__setitem__((C_OD, j), 1), F.__setitem__((C_ORR, j), 0)))                        # a REMU word run as a DIVU
     k = int([r for r in rows if int(ops[r]) == 6][3])
-    assert bad(lambda F: (F.__setitem__((C_OM, k), 1), F.__setitem__((C_OD, k), 0), F.__setitem__((C_SG, k), 0)))       # a DIV word run as MULH
+    assert bad(lambda F: (F.__setitem__((C_OM, k), 1), F.__setitem__((C_OD, k), 0)))                          # a DIV word run as MULH
     k0 = int(np.nonzero(ops == 0x08)[0][0])
-    assert bad(lambda F: F.__setitem__((C_KWA, k0), 1))                                                      # an ADDI run as a wide row
+    assert bad(lambda F: F.__setitem__((C_OD, k0), 1))                                                       # an ADDI run as a wide row
+    assert bad(lambda F: (F.__setitem__((C_OD, i), 1), F.__setitem__((C_ORR, i), 1)))                        # two kinds at once
     assert bad(lambda F: F.__setitem__((C_GF, k0), 5))                                                       # F1's gated copies off the wide rows
     assert bad(lambda F: F.__setitem__((C_X + 3, k0), 1024))                                                 # an extra range slot outside the table
 
@@ -133,7 +135,121 @@ def test_product_verifier_agrees_with_the_oracle(name):
         assert so.verify(t) != 0 and rt.verify(t) == so.verify(t), pos
     if name == "wide_grid":
         M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
-        i = int(np.nonzero(M[C_KWA])[0][100])
+        i = int(np.nonzero(M[C_OM] + M[C_OD] + M[C_ORR])[0][100])
         F = M.copy(); F[C_PIECE + 5, i] = (int(F[C_PIECE + 5, i]) + 1) % 1024
         forged = so.prove_matrix_mem(F, pub, cells)
         assert so.verify(forged, None) == rt.verify(forged) == 10
+
+
+# ---- (b) hash syscalls as a tape -------------------------------------------------------------------------------------------------------------------------------
+def _hash_case(name):
+    if name == "sha_chain":
+        blob, ins, cfg = spec.sha256_chain_program().to_bytes(), [], {"max_cycles": 700}
+    else:
+        blob, ins, cfg = getattr(pg, name)()
+        cfg = {k: v for k, v in cfg.items() if k == "max_cycles"}
+    ores, pub = _case(blob, ins, **cfg)
+    return blob, ins, ores, pub
+
+
+HASH_PROGRAMS = ["sha_chain", "sha256_hello", "hashes_all", "blake3_multi_chunk"]
+
+
+@pytest.mark.parametrize("name", HASH_PROGRAMS)
+def test_runs_with_hash_syscalls_have_a_proof(name):
+    """configs[4]'s program (the SHA-256 hash chain) and the reference's hash-syscall tests: the proof carries one record per call, both verifiers recompute every digest
+    and accept; the same run has NO mode-3 proof (check 10: "no hash syscall" is a constraint there)."""
+    from zkir_amd import runtime as rt
+    blob, ins, ores, pub = _hash_case(name)
+    hs = so.hash_section(ores.rows, pub)
+    assert hs[0] >= 1
+    proof = so.prove(ores.rows, pub)
+    assert so.verify(proof, pub) == 0 and rt.verify(proof) == 0 and rt.verify(proof, _pub_c(pub)) == 0
+    so.set_hash_calls(hs)
+    try:
+        assert so.failing_constraints(so.main_trace(ores.rows, pub), pub, so.mem_cells(ores.rows, pub))[0] == 0
+    finally:
+        so.set_hash_calls(None)
+    pub3 = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), mem_mode=True)
+    assert so.verify(so.prove(ores.rows, pub3), pub3) in (10, 55)      # (55: the chain program reads its seed from the cell the last code word shares with the data — mode 4 admits that cell)
+
+
+def test_a_forged_hash_tape_is_rejected():
+    """The tape is the prover's claim; what makes it binding: (1) every digest is the VERIFIER's own computation over the message the record's cells hold — a proof whose memory
+    shows another digest does not balance; (2) the ECALL row looks its (cycle, pointers, length, kind) up in the tape — a record with another pointer, another length, a missing
+    or an extra record breaks the lookup; (3) the cells' previous-access times are checked in the clear (a record that reads a cell "from the future": check 56).  Both
+    verifiers, same verdicts."""
+    from zkir_amd import runtime as rt
+    blob, ins, ores, pub = _hash_case("sha_chain")
+    M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    hs = so.hash_section(ores.rows, pub)
+    n_calls = int(hs[0])
+    assert n_calls > 50
+
+    def verdicts(section):
+        so.set_hash_calls(section)
+        try:
+            pr = so.prove_matrix_mem(M, pub, cells)
+        finally:
+            so.set_hash_calls(None)
+        a, b = so.verify(pr, None), rt.verify(pr)
+        assert a == b, (a, b)
+        return a
+    assert verdicts(hs) == 0                                                      # the honest tape through the same path
+    rec = 1 + 3 * (8 + 5 * int(hs[1 + 7]))                                        # the fourth record (all records of the chain have the same shape: 8 + 5 x 8 words)
+    assert int(hs[rec + 6]) == 3 and int(hs[rec + 7]) == 8
+    t = hs.copy(); t[rec + 8 + 5 * 1 + 1] ^= 1                                    # one bit of the MESSAGE in the record: the verifier hashes another message — the digest in memory is not its digest
+    assert verdicts(t) == 10
+    t = hs.copy(); t[rec + 3] = int(t[rec + 3]) - 1                               # a shorter input length: another tuple than the row's (and another digest)
+    assert verdicts(t) == 10
+    t = hs.copy(); t[rec + 6] = 5                                                 # the call recorded as Keccak-256
+    assert verdicts(t) == 10
+    t = hs.copy(); t[rec + 8] = int(t[rec]) + 1                                   # a cell "last accessed" after the call: the Blum condition, checked in the clear
+    assert verdicts(t) == 56
+    t = hs.copy(); t[rec + 8] = int(t[rec + 8]) - 1                               # .. or at another earlier time than it was: the memory check does not balance
+    assert verdicts(t) == 10
+    drop = np.concatenate([[n_calls - 1], hs[1:rec], hs[rec + 48:]]).astype(np.uint32)      # a record missing: its row's lookup finds nothing
+    assert verdicts(drop) == 10
+    t = hs.copy(); t[rec] = int(t[rec - 48])                                      # records out of cycle order
+    assert verdicts(t) == 56
+
+
+# ---- (c) the boundary cell ---------------------------------------------------------------------------------------------------------------------------------------
+def _boundary_program(store_low: bool, odd: bool = True):
+    """Code of an ODD number of words (code_size % 8 == 4) followed by data: the last code word and the first four data bytes share the cell at 0x1000 + code_size - 4.
+    The program loads the first data word (LW at the boundary cell's upper half), stores into the upper half (SW), loads the code word beside it (LW: the lower half) — and, if
+    asked, stores into the LOWER half, i.e. over its own last instruction."""
+    A, E, O = pg.A, spec.encode, spec.Opcode
+    n_words = 9 if odd else 10
+    data_at = 0x1000 + 4 * n_words
+    code = [A(5, 0, data_at), E(O.LW, 1, 5, imm=0), A(2, 1, 7), E(O.SW, rs1=5, rs2=2, imm=0), E(O.LW, 3, 5, imm=-4), E(O.LBU, 4, 5, imm=1)]
+    code += [E(O.SW, rs1=5, rs2=2, imm=-4)] if store_low else [A(6, 0, 1)]
+    code += [pg.EB] + [A(7, 0, 2)] * (n_words - len(code) - 1)                  # (the words behind the EBREAK are never executed: the store may land on the last one)
+    assert len(code) == n_words
+    return pg._p(code, data=bytes([0x11, 0x22, 0x33, 0x44, 0x55, 0x66, 0x77, 0x88]))
+
+
+def test_the_boundary_cell_between_code_and_data():
+    """with code_size % 8 == 4 the reference's first data word (vm.rs:163-168) shares a cell with the last code word; mode 3 refuses every cell that overlaps
+    the code (check 55), so such a program had no proof.  Mode 4 admits that ONE cell and states that no store writes its low half: loads of either half and stores to the data
+    half are proven; a store over the last instruction has no proof (the constraint I_BC fails: 10) — and cells INSIDE the code stay refused (55)."""
+    from zkir_amd import runtime as rt
+    blob = _boundary_program(store_low=False)
+    ores, pub = _case(blob)
+    assert int(ores.rows["registers"][-1][1]) == 0x44332211 and int(ores.rows["registers"][-1][4]) == 0x22
+    cells = so.mem_cells(ores.rows, pub)
+    assert len(cells) == 1 and int(cells[0][0]) == 0x1000 + 4 * 9 - 4                          # the one touched cell IS the boundary cell
+    proof = so.prove(ores.rows, pub)
+    assert so.verify(proof, pub) == 0 and rt.verify(proof) == 0
+    pub3 = so.public_inputs(len(ores.rows), blob, [], list(ores.outputs), (ores.halt_kind, ores.halt_code), mem_mode=True)
+    assert so.verify(so.prove(ores.rows, pub3), pub3) == 55                                    # mode 3: refused, as before
+    bad = _boundary_program(store_low=True)
+    ores, pub = _case(bad)
+    pr = so.prove(ores.rows, pub)
+    assert so.verify(pr, pub) == 10 and rt.verify(pr) == 10                                    # a store over the last code word
+    M, cl = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    fc = so.failing_constraints(M, pub, cl)
+    assert fc[0] == 1 and int(fc[1][0][0]) == 702                                              # exactly I_BC + 1: tl (kst - nb) on the storing row
+    even = _boundary_program(store_low=False, odd=False)                                      # an even word count: the cell at data_at - 4 .. is all code + the access at -4 touches a code-only cell
+    ores, pub = _case(even)
+    assert so.verify(so.prove(ores.rows, pub), pub) == 55

@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "build")
 
 HOST_SOURCES = ["interp.cpp", "hashes.cpp", "verify.cpp"]
 HIP_SOURCES = ["trace_fill.hip", "witness.hip", "ntt.hip", "stark.hip", "memcheck.hip", "abi.hip"]
-HEADERS = ["host.h", "babybear.h", "poseidon2.h", "air.h", "stark_prove.inl", os.path.join("..", "..", "include", "zkir_amd.h"), os.path.join("..", "..", "include", "zkir_amd_experimental.h")]
+HEADERS = ["host.h", "hashcall.h", "babybear.h", "poseidon2.h", "air.h", "stark_prove.inl", os.path.join("..", "..", "include", "zkir_amd.h"), os.path.join("..", "..", "include", "zkir_amd_experimental.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

@@ -93,19 +93,29 @@ enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PI
              // piece 5 + 2^10 e_1, carry_2 = piece 6 + 2^10 (e_2 + 2 e_3), carry_3 = piece 7 + 2^10 piece 8 (dropped) — every slot a 10-bit range lookup on such a row: both sides
              // stay below p, the equations hold over the integers.  The products have degree 2 already, so the class cannot gate them: ma_i = kmu a_i are columns (zero elsewhere).
              C_KMU = 276, C_MA = 277, C_ME = 281,
-             // MODE 4 (round 6, proof format v12) = mode 3 WITH the wide-arithmetic class wa = 22: MULH DIVU REMU DIV REM (opcodes 3..7, execute.rs:101-183) on operands BELOW 2^40.
-             // The reference computes the five on the raw 64-bit registers (quirks Q2, Q3); for registers below 2^40 an i64 is non-negative, so DIV = DIVU, REM = REMU, the product has
-             // 80 bits, and all five are ONE relation  F1 F2 + ADD = LO + 2^40 HI  over 40-bit integers (MULH: a b = L + 2^40 y; DIVU / DIV: y b + r = a, r < b; REMU / REM: q b + y =
-             // a, y < b).  A wa row states kwa xb2 = kwa xc2 = 0: a run that feeds one of the five a register with bits above 40 has no mode-4 proof (zkir_prove refuses it).
-             // Schoolbook in 10-bit chunks like MUL; the 80-bit product, the addend and the remainder's range check need 23 lookups where a mode-3 row has 17, so the mode adds SIX
-             // 10-bit range slots X0..X5 per row (24 aux columns XH0..XH5) and 18 main columns:  kwa | om (MULH) od (the quotient is written) orr (the remainder is) | sg (the word
-             // is DIV / REM: op = 3 om + 4 od + 5 orr + 2 sg) | gf_k = kwa F1_k (gated copies: the products have degree 2 already) | e_1..9 (the carries' bits above their slot) | X0..5.
-             // Slots of a wa row (all read the 10-bit table): R0..R3 = LO, R4..R7 = F1, pieces 0-3 = F2 (= rs2), pieces 4-6 = the low parts of c0 c1 c2 (c1 = p5 + 2^10 e1, c2 = p6 +
-             // 2^10 (e2 + 2 e3)), pieces 7, 8, X0, X1 = G4 (HI on MULH, ADD = the remainder on divisions), X2..X5 = G5 (MULH: c3 = X2 + 2^10 (e4 + 2 e5), c4 = X3 + .. (e6, e7), c5 =
-             // X4 + .. (e8, e9); divisions: the chunks of d = rs2 - r - 1 >= 0, borrow e4).  Position k: sum_{i+j=k} F1_i F2_j + ADD_k + c_(k-1) = LO_k + 2^10 c_k (k <= 3), = HI_(k-4) +
-             // 2^10 c_k (k = 4, 5; k = 6: HI_2 + 2^10 HI_3); a division has HI = 0, c3 = 0 and no product above position 3.  Every sum stays below 2^23: integer equations, unique.
-             C_KWA = 284, C_OM = 285, C_OD = 286, C_ORR = 287, C_SG = 288, C_GF = 289, C_WE = 293, C_X = 302 };
-constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, K_WA = 22, N_WIN = 15, N_PIECE = 9, N_NIB = 10, N_X = 6, N_WE = 9;
+             // MODE 4 (round 6, proof format v12) = mode 3 WITH (a) the wide-arithmetic class, (b) hash syscalls as a tape, (c) the code segment's boundary cell
+             // (oracle/stark_oracle.cpp "MODE 4").
+             // (a) class wa = 22: MULH DIVU REMU DIV REM (opcodes 3..7, execute.rs:101-183) on operands BELOW 2^40.  The reference computes the five on the raw 64-bit registers
+             // (quirks Q2, Q3); for registers below 2^40 an i64 is non-negative, so DIV = DIVU, REM = REMU, the product has 80 bits, and all five are ONE relation
+             // F1 F2 + ADD = LO + 2^40 HI over 40-bit integers (MULH: a b = L + 2^40 y; DIVU / DIV: y b + r = a, r < b; REMU / REM: q b + y = a, y < b).  A wa row states
+             // kwa xb2 = kwa xc2 = 0: a run that feeds one of the five a register with bits above 40 has no mode-4 proof (zkir_prove refuses it).  Schoolbook in 10-bit chunks like
+             // MUL; the 80-bit product, the addend and the remainder's range check need 23 lookups where a mode-3 row has 17, so the mode adds SIX 10-bit range slots X0..X5 per row
+             // (24 aux columns XH0..XH5) and 22 main columns (kwa = om + od + orr is an expression; DIV / REM are the word's variant bit g, from the ROM: op = 3 om + 4 od + 5 orr
+             // + 2 g):  om (MULH) od (the quotient is written) orr (the remainder is) | gf_k = kwa F1_k (gated copies: the products have degree 2 already) | e_1..9 (the carries'
+             // bits above their slot) | X0..5.  Slots of a wa row (all read the 10-bit table): R0..R3 = LO, R4..R7 = F1, pieces 0-3 = F2 (= rs2), pieces 4-6 = the low parts of c0 c1
+             // c2 (c1 = p5 + 2^10 e1, c2 = p6 + 2^10 (e2 + 2 e3)), pieces 7, 8, X0, X1 = G4 (HI on MULH, ADD = the remainder on divisions), X2..X5 = G5 (MULH: c3 = X2 + 2^10 (e4 + 2
+             // e5), c4 = X3 + .. (e6, e7), c5 = X4 + .. (e8, e9); divisions: the chunks of d = rs2 - r - 1 >= 0, borrow e4).  Position k: sum_{i+j=k} F1_i F2_j + ADD_k + c_(k-1) =
+             // LO_k + 2^10 c_k (k <= 3), = HI_(k-4) + 2^10 c_k (k = 4, 5; k = 6: HI_2 + 2^10 HI_3); a division has HI = 0, c3 = 0 and no product above position 3.
+             // (b) HASH SYSCALLS (SHA-256 = 3, Keccak-256 = 5, BLAKE3 = 6; syscall.rs:121-171) are a TAPE like mode 2's I/O: the proof carries one record per call (cycle, the
+             // pointers, the length, the kind, and per touched 8-byte cell its bytes before the call and the time of its previous access); the VERIFIER computes every digest and
+             // adds the call's memory accesses to the table side of the memory check.  The AIR ties the ECALL row to its record: HH (alpha - fp(cycle, R11, R12, R13, 3 + h0 +
+             // 2 h1) - 12 lambda^11) = fh, four aux columns; mode 3's "no hash syscall" becomes "no syscall 4" (Poseidon2: an error in the reference).
+             // (c) the BOUNDARY CELL (code_size % 8 == 4: the last code word and the first four data bytes share a cell): admitted here, with "no store writes its low half":
+             // iws, nb with nb = delta iws, delta = the row's cell address minus B as ONE field element (B: LK_B0 / LK_B1, a constant of the program), and tl (kst - nb) = 0 with
+             // tl = the windows that touch bytes 0..3.
+             C_OM = 284, C_OD = 285, C_ORR = 286, C_GF = 287, C_WE = 291, C_X = 300, C_IWS = 306, C_NB = 307 };
+constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, K_WA = 22, N_WIN = 15, N_PIECE = 9, N_NIB = 10, N_X = 6, N_WE = 9, TAG_HASH = 12;
+BB_HD constexpr bool is_low_window(int v) { return v <= 3 || v == 8 || v == 9 || v == 12 || v == 14; }   // the windows that touch bytes 0..3 of their cell
 BB_HD constexpr bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
 constexpr uint32_t OP_MUL_ = 0x02;
 BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
@@ -139,7 +149,7 @@ constexpr int W_COMMITTED_DEFAULT = 152, W_COMMITTED_DEFERRED = 168, W_COMMITTED
 // (AIR v6) The class column "other, jumps" (C_KOJ) is identically zero in the default mode as well — no opcode's class is oj there (constraint
 // I_OPCLASS; deferred mode runs its branches and jumps as that class) — and is not committed either: 172 - 20 = 152 columns by default,
 // 172 - 4 = 168 deferred, whole blocks of 8 with no padding.
-BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode < 3) || (c >= C_KWA && mode != 4) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
+BB_HD constexpr bool is_virtual(int c, int mode) { return (c >= C_LIMB && c < C_LIMB + 3) || (c >= C_F2 && mode < 2) || (c >= C_KLD && mode < 3) || (c >= C_OM && mode != 4) || (mode == 1 ? c == C_STATE : ((c >= C_STATE && c < C_STATE + 16) || c == C_KOJ)); }
 BB_HD constexpr int phys_col(int c, int mode) { return c - (c >= C_LIMB + 3 ? 3 : 0) - (mode == 1 ? (c > C_STATE ? 1 : 0) : (c >= C_STATE + 16 ? 16 : 0) + (c > C_KOJ ? 1 : 0)); }   // of a committed column
 BB_HD constexpr int committed_width(int mode) { return mode == 1 ? W_COMMITTED_DEFERRED : mode == 2 ? W_COMMITTED_IO : mode == 3 ? W_COMMITTED_MEM : mode == 4 ? W_COMMITTED_WIDE : W_COMMITTED_DEFAULT; }
 BB_HD constexpr int committed_used(int mode) { return committed_width(mode); }               // (no padding since v6: 172 - 20, 172 - 4, 180 - 20, 276 - 20)
@@ -153,14 +163,17 @@ BB_HD constexpr int logical_col(int p, int mode) {
 }
 // aux trace: H0..H7 (range helpers), HR (ROM helper), S (running sum), four coordinate columns each; mode 2: + HO (output-tape helper), HI (input-tape helper)
 // mode 3: + P0..P8 (the piece lookups), HMR / HMW (the memory tuple read / written), FPN (the fingerprint of the new cell bytes: an aux column because it depends on lambda)
-// mode 4: + XH0..XH5 (the helpers of the six extra range slots)
-constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 120, W_AUX_MAX = 120;
+// mode 4: + XH0..XH5 (the helpers of the six extra range slots), HH (the hash-call helper), four columns of zero padding (whole blocks of 8)
+constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 128, W_AUX_MAX = 128;
 BB_HD constexpr int aux_width(int mode) { return mode == 4 ? W_AUX_WIDE : mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
-enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96 };
+enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96, A_HH = 120 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
 BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^N_TUPLE (= 11), T / N
-enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), LK_NIN = LK_TN + 4 /* mode 2: the length of the input tape */, N_LK = LK_NIN + 1 };
+enum : int { LK_ALPHA = 0, LK_LAM = 4, LK_TN = 4 + 4 * (N_TUPLE + 1), LK_NIN = LK_TN + 4 /* mode 2: the length of the input tape */,
+             LK_B0 = LK_NIN + 1, LK_B1 = LK_B0 + 1 /* mode 4: the two 20-bit limbs of the boundary cell's address (a constant of the program) */, N_LK = LK_B1 + 1 };
+// (mode 4) the code segment's BOUNDARY CELL: when code_size % 8 == 4 the last code word shares its cell with the first four data bytes; CODE_BASE (inside the code: refused anyway) when there is none
+BB_HD constexpr uint64_t boundary_cell(uint64_t code_size) { return code_size % 8 == 4 ? 0x1000 + code_size - 4 : 0x1000; }
 BB_HD constexpr int tuple_col(int j) { return j < 3 ? C_PC + j : j == 3 ? C_OP : j == 4 ? C_FA : j == 5 ? C_FB : j == 6 ? C_FC : j == 7 ? C_FHI : j == 8 ? C_S : j == 9 ? C_OPC : C_G; }
 // AIR v3: class ids (= opclass values of the instruction word; halt / pad are row roles, not word classes).  A FAMILY is a pair of opcodes
 // that differ in their low bit, the polarity of one comparison: bre = BEQ / BNE, bru = BLTU / BGEU, se = SEQ / SNE, su = SLTU / SGEU.
@@ -193,7 +206,7 @@ BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
 BB_HD constexpr uint32_t family_base(int k) { return k == K_BRE ? OP_BEQ : k == K_BRU ? OP_BLT : k == K_SE ? OP_SEQ : k == K_SU ? OP_SLTU : 0u; }   // the lowest opcode of a family
 // AIR v5: the families of ordered comparisons have FOUR members, op = base + 2 g + pol: SLTU SGEU SLT SGE (base 0x20, g = signed) and BLT BGE BLTU
 // BGEU (base 0x42, g = unsigned).  g is the word's VARIANT BIT, the eleventh element of the ROM tuple (0 for every other opcode).
-BB_HD constexpr uint32_t variant_bit(uint32_t op) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU) ? 1u : 0u; }
+BB_HD constexpr uint32_t variant_bit(uint32_t op, int mode = 0) { return (op == OP_SLT || op == OP_SGE || op == OP_BLTU || op == OP_BGEU || (mode == 4 && (op == 0x06 || op == 0x07))) ? 1u : 0u; }   // (mode 4: DIV / REM are the signed variants of DIVU / REMU)
 
 // constraint indices (the order of oracle/stark_oracle.cpp: constraints_sum)
 enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I_R0 = 70, I_BOOL_STATE = 74, I_BOOL_SEL = 90, I_BOOL_K = 135, I_BOOL_MISC = 150,
@@ -219,12 +232,12 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              // MUL (mode 3, appended): booleans kmu e_1..3 (4), rd (1), a's chunks (2), b's (2), ma_k = kmu a_k (4), the four chunk equations (4), the result (3)
              I_MU_BOOL = 616, I_MU_WR = 620, I_MU_A = 621, I_MU_B = 623, I_MU_MA = 625, I_MU_EQ = 629, I_MU_Y = 633,
              N_CONSTRAINTS_MEM = 636,
-             // mode 4 (appended): the wide-arithmetic class — booleans kwa om od orr sg e_1..9 (14), one kind (1), the opcode (1), sg on divisions only (1), rd (1), the operands' top
-             // limbs (2), F2 = rs2 (2), F1 = rs1 on MULH (2), LO = rs1 on divisions (2), gf_k = kwa F1_k (4), the seven positions of the product (7), r < rs2 (2), what is written (5),
-             // the six extra range lookups (24)
-             I_WA_BOOL = 636, I_WA_KIND = 650, I_WA_OP = 651, I_WA_SG = 652, I_WA_WR = 653, I_WA_TOP = 654, I_WA_F2 = 656, I_WA_F1 = 658, I_WA_LO = 660, I_WA_GF = 662, I_WA_EQ = 666,
-             I_WA_LT = 673, I_WA_Y = 675, I_WA_X = 680,
-             N_CONSTRAINTS = 704 };
+             // mode 4 (appended): the wide-arithmetic class — booleans kwa (= om + od + orr) om od orr e_1..9 (13), the opcode (1), rd (1), the operands' top limbs (2), F2 = rs2
+             // (2), F1 = rs1 on MULH (2), LO = rs1 on divisions (2), gf_k = kwa F1_k (4), the seven positions of the product (7), r < rs2 (2), what is written (5), the six extra range
+             // lookups (24); the boundary cell (2); the hash-call lookup (4)
+             I_WA_BOOL = 636, I_WA_OP = 649, I_WA_WR = 650, I_WA_TOP = 651, I_WA_F2 = 653, I_WA_F1 = 655, I_WA_LO = 657, I_WA_GF = 659, I_WA_EQ = 663,
+             I_WA_LT = 670, I_WA_Y = 672, I_WA_X = 677, I_BC = 701, I_HH = 703,
+             N_CONSTRAINTS = 707 };
 BB_HD constexpr int num_constraints(int mode) { return mode == 4 ? N_CONSTRAINTS : mode == 3 ? N_CONSTRAINTS_MEM : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
@@ -396,7 +409,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
   V Kld = zero, Kst = zero, Klg = zero, Ksh = zero, Kmu = zero, Kwa = zero;   // (mode 3) loads, stores, the bitwise opcodes, the shifts, MUL; (mode 4) MULH DIVU REMU DIV REM
   if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); Ksh = o.loc(C_KSH); Kmu = o.loc(C_KMU); }
-  if (wide) Kwa = o.loc(C_KWA);
+  if (wide) Kwa = o.add(o.add(o.loc(C_OM), o.loc(C_OD)), o.loc(C_ORR));   // kwa = om + od + orr (no column of its own)
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
@@ -657,7 +670,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
     }
     const V WB = o.accl_val(wba), WH = o.accl_val(wha), WW = o.add(Ev[12], Ev[13]), WD = Ev[14], off = o.accl_val(offa);
     o.push(I_MEM_ONE, o.lsub(o.accl_val(esum), Kmem));                       // exactly one window on a memory row, none elsewhere
-    o.push(I_MEM_NOHASH, FH);                                                // no hash syscall in this mode: its memory effect is not stated
+    if (wide) o.push(I_MEM_NOHASH, o.lmul(o.lsub(one, H1), H0));             // (mode 4) hash syscalls are a tape (below); syscall 4 — Poseidon2, an error in the reference — never is a row
+    else o.push(I_MEM_NOHASH, FH);                                           // no hash syscall in this mode: its memory effect is not stated
     // the opcode names the width (and, for byte / halfword loads, whether the value is sign-extended): LB LBU LH LHU LW LD = 0x30.., SB SH SW SD = 0x38..
     o.push(I_MEM_OP, o.lmul(o.add(o.sub(o.sub(o.sub(o.sub(o.sub(op, o.cst(M(0x30))), o.mulc(WH, M(3))), o.mulc(WW, M(4))), o.mulc(WD, M(5))), WB), o.add(sgb, sgh)), Kld));
     o.push(I_MEM_OP + 1, o.lmul(o.sub(o.sub(o.sub(o.sub(op, o.cst(M(0x38))), WH), o.mulc(WW, M(2))), o.mulc(WD, M(3))), Kst));
@@ -884,13 +898,11 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       for (int k = 0; k < N_WE; k++) we[k] = o.loc(C_WE + k);
 #pragma unroll
       for (int k = 0; k < N_X; k++) X[k] = o.loc(C_X + k);
-      const V om = o.loc(C_OM), od = o.loc(C_OD), orr = o.loc(C_ORR), sg = o.loc(C_SG), kd = o.add(od, orr);
-      boolean(I_WA_BOOL, Kwa); boolean(I_WA_BOOL + 1, om); boolean(I_WA_BOOL + 2, od); boolean(I_WA_BOOL + 3, orr); boolean(I_WA_BOOL + 4, sg);
+      const V om = o.loc(C_OM), od = o.loc(C_OD), orr = o.loc(C_ORR), kd = o.add(od, orr);
+      boolean(I_WA_BOOL, Kwa); boolean(I_WA_BOOL + 1, om); boolean(I_WA_BOOL + 2, od); boolean(I_WA_BOOL + 3, orr);     // (kwa boolean: at most one of the three kinds)
 #pragma unroll
-      for (int k = 0; k < N_WE; k++) boolean(I_WA_BOOL + 5 + k, we[k]);
-      o.push(I_WA_KIND, o.lsub(Kwa, o.add(om, kd)));                                               // one of the three kinds on a wide row, none elsewhere
-      { AccL a = o.accl(); o.acc_lin(a, om, 3); o.acc_lin(a, od, 4); o.acc_lin(a, orr, 5); o.acc_lin(a, sg, 2); o.push(I_WA_OP, o.lsub(o.mul(op, Kwa), o.accl_val(a))); }   // MULH 3, DIVU 4, REMU 5, DIV 6, REM 7
-      o.push(I_WA_SG, o.lmul(o.lsub(one, kd), sg));                                                // the signed variants exist for the divisions only
+      for (int k = 0; k < N_WE; k++) boolean(I_WA_BOOL + 4 + k, we[k]);
+      { AccL a = o.accl(); o.acc_lin(a, om, 3); o.acc_lin(a, od, 4); o.acc_lin(a, orr, 5); o.push(I_WA_OP, o.lsub(o.mul(o.lsub(op, o.add(g, g)), Kwa), o.accl_val(a))); }   // MULH 3, DIVU 4, REMU 5, DIV 6 = 4 + 2 g, REM 7 = 5 + 2 g
       o.push(I_WA_WR, o.lmul(o.lsub(w1v, fa), Kwa));                                               // rd = field a
       o.push(I_WA_TOP, o.lmul(xb[2], Kwa)); o.push(I_WA_TOP + 1, o.lmul(xc[2], Kwa));              // the operands are below 2^40
       constexpr uint32_t T10 = M(RC_TABLE);
@@ -940,6 +952,39 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
         o.push(I_WA_X + 4 * i, o.lsub(pr[0], one));
 #pragma unroll
         for (int k = 1; k < 4; k++) o.push(I_WA_X + 4 * i + k, pr[k]);
+      }
+      // the boundary cell: no store writes the low half of cell B — nb = delta iws, delta = the row's cell address minus B as ONE field element; tl (kst - nb) = 0
+      {
+        AccL tla = o.accl();
+#pragma unroll
+        for (int v = 0; v < N_WIN; v++) if (is_low_window(v)) o.acc_lin(tla, Ev[v], 1);
+        const V nb = o.loc(C_NB), iws = o.loc(C_IWS);
+        const V delta = o.add(o.sub(o.sub(z[0], off), o.par(LK_B0)), o.mulc(o.sub(z[1], o.par(LK_B1)), M(1u << 20)));
+        o.push(I_BC, o.lsub(nb, o.mul(delta, iws)));
+        o.push(I_BC + 1, o.lmul(o.lsub(Kst, nb), o.accl_val(tla)));
+      }
+      // hash syscalls: HH (alpha - fp(cycle, R11's limbs, R12's, R13's, 3 fh + h0 + 2 h1) - 12 lambda^11) = fh: the call's record is in the tape the proof carries
+      {
+        V h[4], d[4], pr[4], hl[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) hl[j] = o.loc(C_LIMB + 33 + j);
+        AccL ka = o.accl();
+        o.acc_lin(ka, FH, 3); o.acc_lin(ka, H0, 1); o.acc_lin(ka, H1, 2);
+        const V kind = o.accl_val(ka), cycv = o.loc(C_CYCLE);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          h[k] = o.aloc(A_HH + k); o.acc_lin(hs[k], h[k], 1);
+          AccP t = o.accp();
+          o.acc_mul(t, cycv, o.par(LK_LAM + k));
+#pragma unroll
+          for (int j = 0; j < 9; j++) o.acc_mul(t, hl[j], o.par(LK_LAM + 4 * (1 + j) + k));
+          o.acc_mul(t, kind, o.par(LK_LAM + 4 * 10 + k));
+          d[k] = o.sub(o.sub(o.par(LK_ALPHA + k), o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M((uint32_t)TAG_HASH))), o.acc_val(t));
+        }
+        ext_mul(h, d, pr);
+        o.push(I_HH, o.lsub(pr[0], FH));
+#pragma unroll
+        for (int k = 1; k < 4; k++) o.push(I_HH + k, pr[k]);
       }
     }
   }

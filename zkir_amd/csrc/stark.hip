@@ -29,6 +29,7 @@
 #include "air.h"
 #include "babybear.h"
 #include "host.h"
+#include "hashcall.h"
 #include "poseidon2.h"
 
 namespace {
@@ -79,7 +80,8 @@ BB_HD void reg_limbs(uint64_t v, uint32_t st, uint32_t out[3]) {
 // MODE: 0 default, 1 deferred, 2 default + the I/O argument (air.h): there `io` carries the input tape and the ecall counts before the trace, `cnt` the prefix counts
 // (WRITE ecalls, READ ecalls among rows < i of THIS trace) of every row.
 // MODE 3 = mode 2 + the memory argument: mem_old / mem_told = per row the bytes of the accessed 8-byte cell before the access and the time of its previous access (zkir_memcheck_witness_of)
-struct IoRowArgs { const uint64_t* inputs; uint64_t n_inputs, writes_before, reads_before; const uint32_t* cnt; /* [N][2] */ const uint64_t* mem_old; const uint32_t* mem_told; /* [n_real] */ };
+struct IoRowArgs { const uint64_t* inputs; uint64_t n_inputs, writes_before, reads_before; const uint32_t* cnt; /* [N][2] */ const uint64_t* mem_old; const uint32_t* mem_told; /* [n_real] */
+                   uint64_t boundary; /* (mode 4) the boundary cell of the program's code segment (air::boundary_cell) */ };
 template <int MODE, int SKIP = 0>
 BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t N, uint64_t i, uint32_t* __restrict__ out, const IoRowArgs* io = nullptr) {
   using namespace air;
@@ -107,7 +109,6 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
 #pragma unroll
   for (int k = 0; k < N_CLASS; k++) col(kcol(k)) = cls == k;                     // (mode 2: an executed ecall row has none — its class is the sum of its syscall flags)
   if (MODE >= 3) { col(C_KLD) = cls == K_LD; col(C_KST) = cls == K_ST; col(C_KLG) = cls == K_LG; col(C_KSH) = cls == K_SH; col(C_KMU) = cls == K_MU; }
-  if (MODE == 4) col(C_KWA) = cls == K_WA;
   col(C_OPC) = opclass_of(op, MODE);                                                  // of the WORD, whatever class the row runs as: part of the ROM tuple
   const bool branch = cls == K_BRE || cls == K_BRU;
   const uint32_t tc = (branch || (MODE >= 3 && cls == K_ST)) ? fa : fc;         // B-type and S-type words have rs1 in field a (rs2 in field b)
@@ -167,7 +168,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
   // (v5) ordered comparisons, signed or not: the high limbs enter BIASED, t = limb + 2^19 sgn - 2^20 (sign bit) — the limb of value XOR 2^39 when
   // the comparison is signed (value.rs:710-716); u = (ta, tb) is the row's second range-checked pair, which forces the sign bits
   uint32_t z[2] = {0, 0}, c0 = 0, c1 = 0, u[2] = {0, 0}, sa = 0, sb = 0;
-  const uint32_t g = variant_bit(op);
+  const uint32_t g = variant_bit(op, MODE);
   col(C_G) = g;
   if (cls == K_SUB || cls == K_SU || cls == K_BRU) {
     const uint32_t* a = cls == K_BRU ? xc : xb; const uint32_t* b = cls == K_BRU ? xb : xc;
@@ -204,7 +205,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     // loads and stores (execute.rs:477-575): address = rs1 + sext(imm17) mod 2^64 — below 2^40, or the run has no proof here — its aligned 8-byte cell's bytes before the
     // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
 #pragma unroll
-    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH && k != C_KMU && k != C_KWA) col(k) = 0;
+    for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH && k != C_KMU) col(k) = 0;
     if (MODE == 4 && cls == K_WA) {
       // (mode 4) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI in 10-bit chunks (air.h: the slots of a wide-arithmetic row).
       // The top limbs of the operands must be zero — I_WA_TOP says so; a run that breaks it has no proof (lookup_index_kernel reports the row)
@@ -212,7 +213,7 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
       const uint64_t M40 = (1ull << 40) - 1;
       const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20);
       const bool mulh = op == 0x03, quot = op == 0x04 || op == 0x06;
-      col(C_OM) = mulh; col(C_OD) = !mulh && quot; col(C_ORR) = !mulh && !quot; col(C_SG) = op >= 0x06;
+      col(C_OM) = mulh; col(C_OD) = !mulh && quot; col(C_ORR) = !mulh && !quot;
       uint64_t f1, addv, res;
       if (mulh) {                                                // bits 40..79 of the 80-bit product, by 20-bit limbs (no 128-bit type on the device)
         const uint64_t a0 = a & 0xFFFFF, a1 = a >> 20, b0 = b & 0xFFFFF, b1 = b >> 20;
@@ -362,6 +363,11 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
       col(C_PIECE + 3) = (uint32_t)((window >> 20) & 0xF); col(C_PIECE + 4) = (uint32_t)((window >> 24) & 0xFF); col(C_PIECE + 5) = (uint32_t)((window >> 32) & 0xFF);
       col(C_PIECE + 6) = (uint32_t)((window >> 40) & 0xFF); col(C_PIECE + 7) = (uint32_t)((window >> 48) & 0xFF); col(C_PIECE + 8) = (uint32_t)((window >> 56) & 0xFF);
       if (cls == K_LD && width <= 2) col(C_PIECE + 7) = (uint32_t)(2 * ((window >> (8 * (width - 1))) & 0x7F));   // d6 = twice the low seven bits of the top byte
+      if (MODE == 4 && cls == K_ST && is_low_window(v)) {        // (mode 4) a store into the low half of a cell: not the boundary cell's — nb = delta iws = 1, delta = cell - B as a field element != 0
+        const uint64_t Bc = io->boundary;
+        const uint32_t delta = bb::add(bb::sub(bb::sub(mem_z[0], (uint32_t)off), (uint32_t)(Bc & 0xFFFFF)), bb::mul(1u << 20, bb::sub(mem_z[1], (uint32_t)((Bc >> 20) & 0xFFFFF))));
+        if (delta) { col(C_IWS) = f_inv(delta); col(C_NB) = 1; }
+      }
     }
   }
   const uint32_t dl0 = cls == K_JAL ? lo20 : tk ? im0 : 4u;
@@ -920,7 +926,7 @@ int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, 
 }  // extern "C" (the two helpers are templates)
 namespace {
 template <int MODE>
-int main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out, void* stream) {
+int main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out, void* stream, uint64_t boundary = 0x1000) {
   if (!trace || !out || !io || !scratch || !mem_old || !mem_told || n_real == 0 || (!io->inputs && io->n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   hipStream_t s = (hipStream_t)stream;
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
@@ -931,17 +937,17 @@ int main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, cons
   hipLaunchKernelGGL(io_scan_sums_kernel, dim3(1), dim3(NT), 0, s, sums, n_blk);
   hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
   hipLaunchKernelGGL(main_trace_kernel<MODE>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
-                     IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt), mem_old, mem_told});
+                     IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt), mem_old, mem_told, boundary});
   return check_launch("main_trace_mem");
 }
 template <int MODE>
-int main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
+int main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out, uint64_t boundary = 0x1000) {
   if (!trace || !out || !io || !mem_old || !mem_told || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
   const uint64_t N = (uint64_t)1 << zkir_padded_log_n(n_real);
   std::vector<uint32_t> cnt(2 * N);
   uint32_t w = 0, r = 0;
   for (uint64_t i = 0; i < N; i++) { cnt[2 * i] = w; cnt[2 * i + 1] = r; uint32_t f[2] = {0, 0}; if (i < n_real) io_row_flags(*trace, n_real, i, f); w += f[0]; r += f[1]; }
-  const IoRowArgs a{io->inputs, io->n_inputs, io->writes_before, io->reads_before, cnt.data(), mem_old, mem_told};
+  const IoRowArgs a{io->inputs, io->n_inputs, io->writes_before, io->reads_before, cnt.data(), mem_old, mem_told, boundary};
   for (uint64_t i = 0; i < N; i++) main_trace_row<MODE>(*trace, n_real, N, i, out, &a);
   return ZKIR_OK;
 }
@@ -952,11 +958,12 @@ int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real,
 int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
   return main_trace_mem_host<3>(trace, n_real, io, mem_old, mem_told, out);
 }
-// MODE 4 (round 6: mode 3 + the wide-arithmetic class MULH / DIVU / REMU / DIV / REM): 288 committed columns
-int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
-                                void* stream) { return main_trace_mem_launch<4>(trace, n_real, io, mem_old, mem_told, scratch, out, stream); }
-int zkir_main_trace_wide_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out) {
-  return main_trace_mem_host<4>(trace, n_real, io, mem_old, mem_told, out);
+// MODE 4 (round 6: mode 3 + the wide-arithmetic class MULH / DIVU / REMU / DIV / REM, hash syscalls, the boundary cell): 288 committed columns; code_size = the program's (its
+// boundary cell: air::boundary_cell)
+int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint64_t code_size, uint32_t* scratch,
+                                uint32_t* out, void* stream) { return main_trace_mem_launch<4>(trace, n_real, io, mem_old, mem_told, scratch, out, stream, air::boundary_cell(code_size)); }
+int zkir_main_trace_wide_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint64_t code_size, uint32_t* out) {
+  return main_trace_mem_host<4>(trace, n_real, io, mem_old, mem_told, out, air::boundary_cell(code_size));
 }
 int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, uint32_t* out) {
   if (!trace || !out || !io || n_real == 0) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_io_host: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }

@@ -232,7 +232,9 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       const uint32_t ksh = M[b8((uint32_t)air::phys_col(air::C_KSH, 3), i, N)], sh_reg = ksh && !M[b8((uint32_t)air::phys_col(air::C_SI, 3), i, N)];
       uint32_t kmu = M[b8((uint32_t)air::phys_col(air::C_KMU, 3), i, N)];
       if (deferred == 4) {                                       // (mode 4) a wide-arithmetic row reads the 10-bit table in every piece slot, like a MUL row; its operands must be below 2^40
-        const uint32_t kwa = M[b8((uint32_t)air::phys_col(air::C_KWA, 4), i, N)];
+        const uint32_t p_om = (uint32_t)air::phys_col(air::C_OM, 4);
+        const uint32_t kwa = M[b8(p_om, i, N)] | M[b8(p_om + 1, i, N)] | M[b8(p_om + 2, i, N)];            // kwa = om + od + orr
+        if (M[b8((uint32_t)air::phys_col(air::C_FH, 4), i, N)]) atomicAdd(io_count + 1, 1u);                 // a hash syscall row: the proof needs its record (the hash tape)
         if (kwa && (M[b8((uint32_t)air::phys_col(air::C_XB + 2, 4), i, N)] | M[b8((uint32_t)air::phys_col(air::C_XC + 2, 4), i, N)])) ok = false;    // MULH / DIV.. on a register with bits above 40: no proof in this AIR
         kmu |= kwa;
         uint32_t xs[air::N_X];
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       const uint32_t w = code[u];
       ui = (uint32_t)u;
       if (b0h.x == (w & 0x7F) && b0h.y == ((w >> 7) & 0xF) && b0h.z == ((w >> 11) & 0xF) && b0h.w == ((w >> 15) & 0xF) && fhi_v == (w >> 19) && s_v == (w >> 31) &&
-          opc_v == air::opclass_of(w & 0x7F, deferred) && g_v == air::variant_bit(w & 0x7F)) {
+          opc_v == air::opclass_of(w & 0x7F, deferred) && g_v == air::variant_bit(w & 0x7F, deferred)) {
         if (ui < rom_lds) atomicAdd(&h_rom[ui], 1u); else atomicAdd(&rom_mult[ui], 1u);
       } else ok = false;
     } else ok = false;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(NT) void lookup_tables_kernel(const uint32_t* __res
   const uint32_t u = t - air::RC_TABLE, w = code[u];
   const uint64_t pc = 0x1000 + 4ull * u;
   const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), w & 0x7F, (w >> 7) & 0xF, (w >> 11) & 0xF, (w >> 15) & 0xF,
-                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F, mode), air::variant_bit(w & 0x7F)};
+                                    w >> 19, w >> 31, air::opclass_of(w & 0x7F, mode), air::variant_bit(w & 0x7F, mode)};
   // (fingerprint coordinates in Montgomery form: lk holds R * lambda^j_k, mont_mul(R a, to_mont(f)) = R a f)
   E4 fpm;
 #pragma unroll
@@ -567,6 +569,20 @@ __global__ __launch_bounds__(NT) void io_aux_kernel(const IoEntry* __restrict__ 
 //   add:   every row adds its workgroup's offset
 constexpr uint32_t SCAN_PER = 4, SCAN_ROWS = NT * SCAN_PER;
 __device__ __forceinline__ uint4 add4m(uint4 a, uint4 b) { return make_uint4(bb::add(a.x, b.x), bb::add(a.y, b.y), bb::add(a.z, b.z), bb::add(a.w, b.w)); }
+// (mode 4) the hash-call helpers HH = 1 / (alpha - fp(call)) of the hash-syscall rows: computed on the host from the tape's records (the same values the table side is made
+// of), scattered into the row's HH columns and added to its running-sum increment; every other row keeps the zeros the block was cleared with
+struct HashAux { uint32_t row, pad[3]; E4 h; };
+__global__ __launch_bounds__(NT) void hash_aux_kernel(const HashAux* __restrict__ list, uint32_t n, uint64_t N, uint32_t* __restrict__ A) {
+  const uint32_t t = blockIdx.x * NT + threadIdx.x;
+  if (t >= n) return;
+  const HashAux e = list[t];
+  uint4* A4 = reinterpret_cast<uint4*>(A);
+  static_assert(air::A_HH % 8 == 0, "aux layout: HH opens a block");
+  const uint4 h4 = make_uint4(e.h.c[0], e.h.c[1], e.h.c[2], e.h.c[3]);
+  A4[((uint64_t)(air::A_HH / 8) * N + e.row) * 2] = h4;
+  uint4* S = A4 + ((uint64_t)(air::A_S / 8) * N + e.row) * 2 + 1;
+  *S = add4m(*S, h4);
+}
 __device__ __forceinline__ uint4 block_exclusive_scan(uint4 v, uint4* lds /* NT */, uint4& total) {    // exclusive scan of one value per thread across the workgroup
   const uint32_t t = threadIdx.x;
   lds[t] = v;
@@ -1126,10 +1142,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   const std::vector<int> ks = fri_schedule((int)log_n);
   const int n_layers = (int)ks.size();
 
+  // (mode 4) a run with hash calls can touch more cells than it has rows (a 5000-byte BLAKE3 input is 626 cells): the cell arrays and the section buffer are sized by the
+  // caller's witness when it brings one (the device witness sees loads and stores only: at most one cell per row)
+  const uint64_t CELL_CAP = std::max<uint64_t>(N, MEM_HOST ? pub->n_cells + 1 : 0);
+  const size_t SEC_WORDS = 8 * (size_t)CELL_CAP + 4096;
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
     const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0) + (WIDE ? 8 : 0)) * N + (size_t)air::MAX_NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
-                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)N * 60 + blob_len + (1u << 16) : 0);
+                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)CELL_CAP * 60 + blob_len + (1u << 16) : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -1175,8 +1195,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (IO) { HIP_OK(ar.take(&dIo, N)); HIP_OK(ar.take(&dIoCount, 4)); HIP_OK(ar.take(&dInputs, (size_t)pub->n_inputs + 1)); HIP_OK(ar.take(&dIoScratch, 2 * N + 2 * (N / 1024 + 2))); }
   if (MEM) {
     HIP_OK(ar.take(&dMemOld, N)); HIP_OK(ar.take(&dMemTold, N)); HIP_OK(ar.take(&dMemSide, 2 * N)); HIP_OK(ar.take(&dInvMem, air::MEM_MULT));
-    HIP_OK(ar.take(&dCellAddr, N)); HIP_OK(ar.take(&dCellBytes, N)); HIP_OK(ar.take(&dCellTime, N)); HIP_OK(ar.take(&dImage, (size_t)blob_len + 1)); HIP_OK(ar.take(&dCellPart, N / NT + 1));
-    HIP_OK(ar.take(&dSec, 8 * N + 4096));                      // the memory section (seven words per touched cell) and its chunk digests
+    HIP_OK(ar.take(&dCellAddr, CELL_CAP)); HIP_OK(ar.take(&dCellBytes, CELL_CAP)); HIP_OK(ar.take(&dCellTime, CELL_CAP)); HIP_OK(ar.take(&dImage, (size_t)blob_len + 1)); HIP_OK(ar.take(&dCellPart, CELL_CAP / NT + 1));
+    HIP_OK(ar.take(&dSec, SEC_WORDS));                      // the memory section (seven words per touched cell) and its chunk digests
     if (WIDE) HIP_OK(ar.take(&dWideSide, N));
   }
   HIP_OK(ar.take(&dM, WM * N)); HIP_OK(ar.take(&dL, WM * N2)); HIP_OK(ar.take(&dTree, 4 * (2 * N2 - 1)));
@@ -1216,7 +1236,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
         rc = zkir::memcheck_device(trace, pub->n_real, blob, blob_len, dL, (size_t)WM * N2 * 4, dMemOld, dMemTold, cell_addr_v, cell_bytes_v, cell_time_v, pin, s);
         if (rc) return rc;
       }
-      rc = WIDE ? zkir_main_trace_wide_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s) : zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
+      rc = WIDE ? zkir_main_trace_wide_launch(trace, pub->n_real, &io, dMemOld, dMemTold, 4 * (uint64_t)n_code, dIoScratch, dM, s) : zkir_main_trace_mem_launch(trace, pub->n_real, &io, dMemOld, dMemTold, dIoScratch, dM, s);
     } else rc = zkir_main_trace_io_launch(trace, pub->n_real, &io, dIoScratch, dM, s);
   } else rc = zkir_main_trace_launch(trace, pub->n_real, pub->deferred, dM, s);
   if (rc) return rc;
@@ -1226,7 +1246,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemsetAsync(dMult, 0, n_mult * 4, s));
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
-    if (IO) HIP_OK(hipMemsetAsync(dIoCount, 0, 4, s));
+    if (IO) HIP_OK(hipMemsetAsync(dIoCount, 0, 16, s));          // [0] the tape-lookup rows, [1] (mode 4) the hash-syscall rows
     hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount, dMult + n_code + air::RC_TABLE, dMemSide, dWideSide);
   }
   mark(1);
@@ -1239,10 +1259,12 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (!mult) HIP_OK(hipErrorOutOfMemory);
   HIP_OK(d2h(troot, dTree + 4 * (2 * N2 - 2), 16));
   HIP_OK(d2h(bound, dBound, sizeof bound));
-  if (IO) HIP_OK(d2h(&n_io, dIoCount, 4));
+  uint32_t io_counts[4] = {0, 0, 0, 0};
+  if (IO) HIP_OK(d2h(io_counts, dIoCount, 16));
   HIP_OK(hipMemcpyAsync(mult, dMult, n_mult * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(d2h(&bad_row, dBad, 8));
   HIP_OK(sync_d2h());
+  n_io = io_counts[0];
   if (bad_row != ~0ull) {
     char m[448];
     snprintf(m, sizeof m, "zkir_prove: row %llu of the trace has no proof in this AIR: its (pc, instruction word) is not in the program's code table (self-modified code, "
@@ -1275,7 +1297,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (uint64_t k = 0; k < n_cells_v; k++) {
       const uint64_t a = cell_addr_v[k], b = cell_bytes_v[k];
       if ((a & 7) || (a >> 40) || (k && a <= cell_addr_v[k - 1])) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: the touched cells must be multiples of 8 below 2^40 in strictly increasing order"}); return ZKIR_ERR_ARGUMENT; }
-      if (a + 8 > air::CODE_BASE && a < air::CODE_BASE + 4 * (uint64_t)n_code) {
+      if (a + 8 > air::CODE_BASE && a < air::CODE_BASE + 4 * (uint64_t)n_code && !(WIDE && (n_code & 1) && a == air::boundary_cell(4 * (uint64_t)n_code))) {   // (mode 4 admits the boundary cell: I_BC)
         // (v11) instruction fetch is tied to the program's words: a store into the code would change what the VM executes next (vm.rs:175: strict protection is off) but not what
         // the AIR lets through — mode 3 proves runs whose loads and stores stay off the cells that overlap the code segment, and both verifiers check the list (55)
         char m[200];
@@ -1289,7 +1311,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     }
     // the section enters the transcript through its chunk digests (so::observe_section), hashed in parallel on the device
     const size_t n_chunks_sec = (mem_sec.size() + SECTION_CHUNK - 1) / SECTION_CHUNK;
-    if (mem_sec.size() + 4 * n_chunks_sec + 64 > 8 * (size_t)N + 4096) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than the workspace holds"}); return ZKIR_ERR_ARGUMENT; }
+    if (mem_sec.size() + 4 * n_chunks_sec + 64 > SEC_WORDS) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than the workspace holds"}); return ZKIR_ERR_ARGUMENT; }
     uint32_t* dSecDg = dSec + ((mem_sec.size() + 63) & ~(size_t)63);
     HIP_OK(h2d(dSec, mem_sec.data(), mem_sec.size() * 4));
     hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((4 * n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)mem_sec.size(), dSecDg);
@@ -1297,6 +1319,38 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemcpyAsync(sec_dg.data(), dSecDg, sec_dg.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     ch.observe_n(sec_dg.data(), sec_dg.size());
+  }
+  // (mode 4) the hash calls: the tape the proof carries (from the caller's host witness), checked as the verifier will check it, observed like the memory section
+  std::vector<hashcall::Call> hcalls;
+  std::vector<uint32_t> hash_sec;
+  if (WIDE) {
+    if (pub->hash_section && pub->hash_section_words) {
+      size_t used = 0;
+      const int hrc = hashcall::parse_section(pub->hash_section, (size_t)pub->hash_section_words, pub->n_real, air::CODE_BASE + 4 * (uint64_t)n_code, hcalls, &used);
+      if (hrc || used != pub->hash_section_words) {
+        char m[160]; snprintf(m, sizeof m, "zkir_prove: the hash section of the public inputs is malformed (check %d): build it with zkir_memcheck_witness_of_mode(.., 4, ..)", hrc ? hrc : 4);
+        zkir::set_last_error({ZKIR_ERR_ARGUMENT, m}); return ZKIR_ERR_ARGUMENT;
+      }
+      hash_sec.assign(pub->hash_section, pub->hash_section + used);
+    } else hash_sec.push_back(0u);
+    if (hcalls.size() != io_counts[1]) {
+      char m[256];
+      snprintf(m, sizeof m, "zkir_prove: the run makes %u hash syscalls and the public inputs' hash section records %llu: a run with hash syscalls is proven (mode 4) from the host "
+                            "witness (zkir_memcheck_witness_of_mode(.., 4, ..) + zkir_public_inputs_set_memory)", io_counts[1], (unsigned long long)hcalls.size());
+      zkir::set_last_error({ZKIR_ERR_ARGUMENT, m}); return ZKIR_ERR_ARGUMENT;
+    }
+    const size_t n_chunks_sec = (hash_sec.size() + SECTION_CHUNK - 1) / SECTION_CHUNK;
+    if (hash_sec.size() + 4 * n_chunks_sec + 64 <= SEC_WORDS) {           // chunk digests on the device (the buffer of the memory section, free again)
+      uint32_t* dSecDg = dSec + ((hash_sec.size() + 63) & ~(size_t)63);
+      HIP_OK(h2d(dSec, hash_sec.data(), hash_sec.size() * 4));
+      hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((4 * n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)hash_sec.size(), dSecDg);
+      std::vector<uint32_t> sec_dg(4 * n_chunks_sec);
+      HIP_OK(hipMemcpyAsync(sec_dg.data(), dSecDg, sec_dg.size() * 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      ch.observe_n(sec_dg.data(), sec_dg.size());
+    } else {                                                                         // (more records than the workspace holds: the digests on the host)
+      for (size_t at = 0; at < hash_sec.size(); at += SECTION_CHUNK) { uint32_t dg[4]; hash_elems_host(c->consts, hash_sec.data() + at, std::min((size_t)SECTION_CHUNK, hash_sec.size() - at), dg); ch.observe_n(dg, 4); }
+    }
   }
   ch.observe_n(mult, n_mult);                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
   std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
@@ -1308,6 +1362,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     for (int j = 0; j <= air::N_TUPLE; j++) { for (int k = 0; k < 4; k++) pp->lk[air::LK_LAM + 4 * j + k] = bb::to_mont(lam.c[k]); lam = h_e_mul(lam, lambda); }
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = 0;
     pp->lk[air::LK_NIN] = IO ? bb::to_mont((uint32_t)(pub->n_inputs % bb::P)) : 0u;
+    { const uint64_t Bc = air::boundary_cell(4 * (uint64_t)n_code); pp->lk[air::LK_B0] = bb::to_mont((uint32_t)(Bc & 0xFFFFF)); pp->lk[air::LK_B1] = bb::to_mont((uint32_t)((Bc >> 20) & 0xFFFFF)); }   // (mode 4) the boundary cell
     HIP_OK(h2d(dPP->lk, pp->lk, sizeof(pp->lk)));
     hipLaunchKernelGGL(lookup_tables_kernel, dim3(grid_for((uint64_t)air::RC_TABLE + n_code)), dim3(NT), 0, s, dCode, n_code, dPP, dInvRc, dInvRom, MODE);
     if (MEM) hipLaunchKernelGGL(mem_tables_kernel, dim3(grid_for(air::MEM_MULT)), dim3(NT), 0, s, dPP, dInvMem);
@@ -1326,7 +1381,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       const size_t m0 = (size_t)n_code + air::RC_TABLE;
       for (int t = 0; t < air::MEM_MULT; t++) if (mult[m0 + t]) T = bb::e_add(T, bb::e_mul_fm(inv[air::RC_TABLE + n_code + t], bb::to_mont(mult[m0 + t] % bb::P)));
       if (n_cells_v) {
-        if (n_cells_v > N) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than rows"}); return ZKIR_ERR_ARGUMENT; }
+        if (n_cells_v > CELL_CAP) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_prove: more touched cells than the workspace holds"}); return ZKIR_ERR_ARGUMENT; }
         uint32_t code_size, data_size; memcpy(&code_size, blob + 16, 4); memcpy(&data_size, blob + 20, 4);
         const uint64_t image_len = 32 + (uint64_t)code_size + data_size <= blob_len ? (uint64_t)code_size + data_size : 0;
         if (image_len) HIP_OK(h2d(dImage, blob + 32, image_len));
@@ -1362,6 +1417,47 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       for (uint64_t k = cn[0]; k < cn[2]; k++) term(k, pub->outputs[k], 2);
       for (uint64_t k = cn[1]; k < cn[3]; k++) term(k, pub->inputs[k], 3);
     }
+    std::vector<HashAux> hash_aux;                             // (mode 4) the hash rows' helper values HH, to be scattered into the aux trace below
+    if (WIDE && !hcalls.empty()) {
+      // the hash calls' share of the table side, formed like the verifier will form it (verify.cpp; oracle: so::hash_table_sum): + 1 / (alpha - fp(call)) per call, and the call's
+      // memory accesses, which no row states: per touched cell - 1 / (alpha - fp(cell, told, old bytes)) + 1 / (alpha - fp(cell, cycle + 1, new bytes)).  One batch inversion.
+      E4 lamv[air::N_TUPLE + 1];
+      for (int j = 0; j <= air::N_TUPLE; j++) for (int c4 = 0; c4 < 4; c4++) lamv[j].c[c4] = pp->lk[air::LK_LAM + 4 * j + c4];
+      E4 alpha_lm; for (int c4 = 0; c4 < 4; c4++) alpha_lm.c[c4] = pp->lk[air::LK_ALPHA + c4];
+      auto mem_d = [&](uint64_t addr, uint32_t t, uint64_t bytes) {
+        E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_MEM));
+        fp.c[0] = bb::add(fp.c[0], bb::to_mont((uint32_t)(addr & 0xFFFFF)));
+        fp = bb::e_add(fp, bb::e_mul_fm(lamv[1], bb::to_mont((uint32_t)((addr >> 20) & 0xFFFFF))));
+        fp = bb::e_add(fp, bb::e_mul_fm(lamv[2], bb::to_mont(t)));
+        for (int k = 0; k < 8; k++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[3 + k], bb::to_mont((uint32_t)((bytes >> (8 * k)) & 0xFF))));
+        return bb::e_sub(alpha_lm, fp);
+      };
+      std::vector<E4> d; std::vector<int8_t> sign; std::vector<uint64_t> nb;
+      for (const hashcall::Call& hc : hcalls) {
+        const uint32_t e[11] = {(uint32_t)(hc.cycle % bb::P), (uint32_t)(hc.in_ptr & 0xFFFFF), (uint32_t)((hc.in_ptr >> 20) & 0xFFFFF), (uint32_t)(hc.in_ptr >> 40), (uint32_t)(hc.len & 0xFFFFF),
+                                (uint32_t)((hc.len >> 20) & 0xFFFFF), (uint32_t)(hc.len >> 40), (uint32_t)(hc.out_ptr & 0xFFFFF), (uint32_t)((hc.out_ptr >> 20) & 0xFFFFF), (uint32_t)(hc.out_ptr >> 40), hc.kind};
+        E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_HASH));
+        for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[j], bb::to_mont(e[j])));
+        d.push_back(bb::e_sub(alpha_lm, fp)); sign.push_back(2);                                  // (2: a call's own entry — its inverse is also the row's HH)
+        hashcall::new_bytes(hc, nb);
+        for (size_t k = 0; k < hc.cells.size(); k++) {
+          d.push_back(mem_d(hc.cells[k].addr, hc.cells[k].t, hc.cells[k].bytes)); sign.push_back(-1);
+          d.push_back(mem_d(hc.cells[k].addr, (uint32_t)((hc.cycle + 1) % bb::P), nb[k])); sign.push_back(1);
+        }
+      }
+      std::vector<E4> pre(d.size());
+      E4 acc = bb::e_one_m();
+      for (size_t i = 0; i < d.size(); i++) { pre[i] = acc; acc = bb::e_mul_m(acc, d[i]); }
+      E4 inv = bb::e_inv_m(acc);
+      size_t call = hcalls.size();
+      hash_aux.resize(hcalls.size());
+      for (size_t i = d.size(); i-- > 0;) {
+        const E4 di = bb::e_mul_m(inv, pre[i]);
+        inv = bb::e_mul_m(inv, d[i]);
+        if (sign[i] < 0) T = bb::e_sub(T, di); else T = bb::e_add(T, di);
+        if (sign[i] == 2) { call--; hash_aux[call].row = (uint32_t)hcalls[call].cycle; hash_aux[call].pad[0] = hash_aux[call].pad[1] = hash_aux[call].pad[2] = 0; hash_aux[call].h = di; }
+      }
+    }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];
     HIP_OK(h2d(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16));
@@ -1371,6 +1467,15 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       if (n_io) hipLaunchKernelGGL(io_aux_kernel, dim3(grid_for(n_io)), dim3(NT), 0, s, dIo, n_io, N, dPP, dA);
     }
     if (MEM) hipLaunchKernelGGL(mem_aux_kernel, dim3(grid_for(N)), dim3(NT), 0, s, dSide, dMemSide, N, dInvRc, dInvMem, dPP, dA, dWideSide);   // P0..P8, HMR, HMW, FPN of every row
+    if (WIDE) {                                               // the hash-call helpers HH (and the block's four padding columns): zero but on the hash-syscall rows
+      HIP_OK(hipMemsetAsync(dA + (size_t)(air::A_HH / 8) * N * 8, 0, (size_t)N * 32, s));
+      if (!hash_aux.empty()) {
+        if (hash_aux.size() * sizeof(HashAux) > SEC_WORDS * 4) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: more hash calls than the workspace holds"}); return ZKIR_ERR_OTHER; }
+        HashAux* dHashAux = reinterpret_cast<HashAux*>(dSec);   // (the section buffer is free again: 32 N bytes)
+        HIP_OK(h2d(dHashAux, hash_aux.data(), hash_aux.size() * sizeof(HashAux)));
+        hipLaunchKernelGGL(hash_aux_kernel, dim3(grid_for(hash_aux.size())), dim3(NT), 0, s, dHashAux, (uint32_t)hash_aux.size(), N, dA);
+      }
+    }
     const uint32_t n_scan = (uint32_t)((N + SCAN_ROWS - 1) / SCAN_ROWS);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_scan), dim3(NT), 0, s, dA, N, dSums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(NT), 0, s, dSums, n_scan);
@@ -1544,6 +1649,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
   if (IO) head.insert(head.end(), io_sec.begin(), io_sec.end());              // the I/O section: the tapes and the halt reason the io digest is a digest of
   if (MEM) head.insert(head.end(), mem_sec.begin(), mem_sec.end());           // (mode 3) the touched cells
+  if (WIDE) head.insert(head.end(), hash_sec.begin(), hash_sec.end());         // (mode 4) the hash calls
   head.insert(head.end(), mult, mult + n_mult);                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);

@@ -16,6 +16,7 @@
 #include "air.h"
 #include "babybear.h"
 #include "host.h"
+#include "hashcall.h"
 #include "poseidon2.h"
 
 namespace {
@@ -231,9 +232,12 @@ struct zkir_memcheck_witness {
   std::vector<uint64_t> old; std::vector<uint32_t> told;                   // per row
   std::vector<uint64_t> cell_addr, cell_bytes; std::vector<uint32_t> cell_time;
   uint64_t n_accesses = 0;
+  std::vector<uint32_t> hash_words; uint64_t n_hash = 0;                   // (mode 4) the hash calls as the proof's hash section (hashcall.h)
 };
 extern "C" {
-int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* blob, size_t blob_len, zkir_memcheck_witness** out) {
+int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* blob, size_t blob_len, zkir_memcheck_witness** out) { return zkir_memcheck_witness_of_mode(log, blob, blob_len, 3, out); }
+uint64_t zkir_memcheck_witness_n_hash_calls(const zkir_memcheck_witness* w) { return w ? w->n_hash : 0; }
+int zkir_memcheck_witness_of_mode(const zkir_delta_log* log, const uint8_t* blob, size_t blob_len, uint32_t mode, zkir_memcheck_witness** out) {
   if (out) *out = nullptr;
   auto refuse = [](const std::string& m) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memcheck_witness_of: " + m}); return ZKIR_ERR_ARGUMENT; };
   if (!log || !out || !blob) return refuse("null argument");
@@ -257,13 +261,27 @@ int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* blob, siz
     return tab[h];
   };
   uint64_t reg[16] = {0};
+  std::vector<hashcall::Call> hcalls;
   const zkir_reg_event* ev = log->reg_events.data(); const size_t n_ev = log->reg_events.size(); size_t e = 0;
   const uint32_t* inst = log->inst.data();
   for (uint64_t i = 0; i < n; i++) {
     while (e < n_ev && ev[e].vis <= i) { reg[ev[e].reg] = ev[e].value; e++; }        // the pre-state of row i
     if (i + 1 >= n) break;                                                            // the halt row executes nothing the AIR describes
     const uint32_t word = inst[i], op = word & 0x7F;
-    if (op == air::OP_ECALL) { if (reg[10] >= 3 && reg[10] <= 6) { delete w; return refuse("the run executes a hash syscall (row " + std::to_string(i) + "): its memory effect is not stated by the AIR"); } continue; }
+    if (op == air::OP_ECALL) {
+      if (reg[10] < 3 || reg[10] > 6) continue;
+      if (mode != 4) { delete w; return refuse("the run executes a hash syscall (row " + std::to_string(i) + "): its memory effect is not stated by the AIR"); }
+      // (mode 4) a hash call: its record for the tape, its effect on the replayed memory (the message is read out of the OLD bytes; every touched cell gets the call's time)
+      hashcall::Call hc{i, reg[11], reg[12], reg[13], (uint32_t)reg[10], {}};
+      if (!hashcall::in_range(hc.in_ptr, hc.len, hc.out_ptr, hc.kind)) { delete w; return refuse("the hash syscall at row " + std::to_string(i) + " is outside what a proof states (kind 3 / 5 / 6, at most 1 MiB of input, buffers below 2^40)"); }
+      std::vector<uint64_t> addrs, nbv;
+      hashcall::cells_of(hc.in_ptr, hc.len, hc.out_ptr, addrs);
+      for (const uint64_t a : addrs) { const Slot& c = find(a); hc.cells.push_back(hashcall::Cell{a, c.bytes, c.t}); }
+      hashcall::new_bytes(hc, nbv);
+      for (size_t k = 0; k < addrs.size(); k++) { Slot& c = find(addrs[k]); c.bytes = nbv[k]; c.t = (uint32_t)(i + 1); }
+      hcalls.push_back(std::move(hc));
+      continue;
+    }
     if (!air::is_load(op) && !air::is_store(op)) continue;
     const uint32_t fa = (word >> 7) & 0xF, fb = (word >> 11) & 0xF;
     const int64_t imm = (int64_t)(int32_t)(word & 0xFFFF8000u) >> 15;                 // imm17, sign-extended
@@ -282,6 +300,7 @@ int zkir_memcheck_witness_of(const zkir_delta_log* log, const uint8_t* blob, siz
   for (const Slot& s : tab) if (s.used) order.push_back(&s);
   std::sort(order.begin(), order.end(), [](const Slot* a, const Slot* b) { return a->addr < b->addr; });
   for (const Slot* s : order) { w->cell_addr.push_back(s->addr); w->cell_bytes.push_back(s->bytes); w->cell_time.push_back(s->t); }
+  if (mode == 4) { hashcall::put_section(hcalls, w->hash_words); w->n_hash = hcalls.size(); }
   *out = w;
   return ZKIR_OK;
 }
@@ -305,6 +324,7 @@ void zkir_public_inputs_set_memory(zkir_public_inputs* pub, const zkir_memcheck_
   if (pub->deferred < 3) pub->deferred = 3;                               // (a mode-4 proof keeps its mode: the witness is the same)
   pub->mem_old = w->old.data(); pub->mem_told = w->told.data();
   pub->cell_addr = w->cell_addr.data(); pub->cell_bytes = w->cell_bytes.data(); pub->cell_time = w->cell_time.data(); pub->n_cells = w->cell_addr.size();
+  pub->hash_section = w->hash_words.empty() ? nullptr : w->hash_words.data(); pub->hash_section_words = w->hash_words.size();
 }
 
 int zkir_verify_segment(const uint32_t* w, uint64_t len, const zkir_public_inputs* expect, uint32_t first_state[68], uint32_t last_state[68]) {
@@ -542,9 +562,19 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       if (k && cells[k].addr <= cells[k - 1].addr) return 54;
       // (v11, check 55) no access to the CODE: instruction fetch is tied to the program's words, so a store into [0x1000, 0x1000 + code_size) would change what the VM executes
       // next (vm.rs:175) but not what the AIR lets through — every accessed cell is in this list (the memory check does not balance otherwise), and none may overlap the code
-      if (cells[k].addr + 8 > air::CODE_BASE && cells[k].addr < air::CODE_BASE + 4 * (uint64_t)n_code) return 55;
+      // (mode 4) .. except the BOUNDARY cell (code_size % 8 == 4: the last code word and the first four data bytes): the AIR states there that no store writes its low half
+      if (cells[k].addr + 8 > air::CODE_BASE && cells[k].addr < air::CODE_BASE + 4 * (uint64_t)n_code && !(mode == 4 && (n_code & 1) && cells[k].addr == air::boundary_cell(4 * (uint64_t)n_code))) return 55;
     }
     p += mem_len;
+  }
+  // (mode 4) the hash calls: records in increasing cycle order, ranges in the clear, every touched cell's previous access before the call (56); no output on code bytes (55)
+  std::vector<hashcall::Call> hcalls;
+  const uint32_t* hash_words = nullptr; size_t hash_len = 0;
+  if (mode == 4) {
+    hash_words = w + p;
+    const int hrc = hashcall::parse_section(w + p, (size_t)(len - p), pub.n_real, air::CODE_BASE + 4 * (uint64_t)n_code, hcalls, &hash_len);
+    if (hrc) return hrc;
+    p += hash_len;
   }
   if (!need(n_code + air::RC_TABLE + (mode >= 3 ? air::MEM_MULT : 0))) return 4;
   const uint32_t* rom_mult = w + p; p += n_code;
@@ -579,6 +609,8 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (size_t at = 0; at < io.words; at += 512) { uint32_t dg[4]; hash_elems(io_words + at, io.words - at < 512 ? io.words - at : 512, dg); ch.observe_n(dg, 4); }
   if (mode >= 3)                                                           // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section)
     for (size_t at = 0; at < mem_len; at += 512) { uint32_t dg[4]; hash_elems(mem_words + at, mem_len - at < 512 ? mem_len - at : 512, dg); ch.observe_n(dg, 4); }
+  if (mode == 4)                                                           // (mode 4) the hash calls, likewise
+    for (size_t at = 0; at < hash_len; at += 512) { uint32_t dg[4]; hash_elems(hash_words + at, hash_len - at < 512 ? hash_len - at : 512, dg); ch.observe_n(dg, 4); }
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
   if (mode >= 3) ch.observe_n(mem_mult, air::MEM_MULT);
@@ -594,6 +626,8 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (int j = 0; j <= air::N_TUPLE; j++) for (int k = 0; k < 4; k++) lk_m[air::LK_LAM + 4 * j + k] = lam[j].c[k];
     const size_t n_tab = (size_t)air::RC_TABLE + n_code;
     std::vector<E4> d(n_tab + (mode >= 3 ? (size_t)air::MEM_MULT + 2 * cells.size() : 0));
+    const size_t n_fixed = d.size();                                       // (mode 4: the hash calls' entries follow, each with its sign)
+    std::vector<int8_t> hsign;
     for (int t = 0; t < air::RC_TABLE; t++) { d[t] = alpha_l; d[t].c[0] = bb::sub(d[t].c[0], bb::to_mont((uint32_t)t)); }
     if (mode >= 3) {
       // the LOW3, BYTE and NIBBLE tables, then the two ends of the memory check: per touched cell the INITIAL tuple (time 0, the program image's bytes) and the FINAL one
@@ -615,12 +649,30 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
         return bb::e_sub(alpha_l, fp);
       };
       for (size_t k = 0; k < cells.size(); k++) { m[air::MEM_MULT + 2 * k] = mem_d(cells[k], 0, image_cell(blob.data(), blob_len, cells[k].addr)); m[air::MEM_MULT + 2 * k + 1] = mem_d(cells[k], cells[k].t, cells[k].bytes); }
+      // (mode 4) the hash calls: + 1 / (alpha - fp(call)) per call (its ECALL row looks it up) and the call's memory accesses, which no row states: per touched cell
+      // - 1 / (alpha - fp(cell, told, old bytes)) + 1 / (alpha - fp(cell, cycle + 1, new bytes)).  The digest inside the new bytes is computed HERE (hashcall::new_bytes).
+      if (mode == 4) {
+        std::vector<uint64_t> nb;
+        for (const hashcall::Call& c : hcalls) {
+          const uint32_t e[11] = {(uint32_t)(c.cycle % bb::P), (uint32_t)(c.in_ptr & 0xFFFFF), (uint32_t)((c.in_ptr >> 20) & 0xFFFFF), (uint32_t)(c.in_ptr >> 40), (uint32_t)(c.len & 0xFFFFF),
+                                  (uint32_t)((c.len >> 20) & 0xFFFFF), (uint32_t)(c.len >> 40), (uint32_t)(c.out_ptr & 0xFFFFF), (uint32_t)((c.out_ptr >> 20) & 0xFFFFF), (uint32_t)(c.out_ptr >> 40), c.kind};
+          E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_HASH));
+          for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(e[j])));
+          d.push_back(bb::e_sub(alpha_l, fp)); hsign.push_back(1);
+          hashcall::new_bytes(c, nb);
+          for (size_t k = 0; k < c.cells.size(); k++) {
+            const Cell cc{c.cells[k].addr, 0, 0};
+            d.push_back(mem_d(cc, c.cells[k].t, c.cells[k].bytes)); hsign.push_back(-1);
+            d.push_back(mem_d(cc, (uint32_t)((c.cycle + 1) % bb::P), nb[k])); hsign.push_back(1);
+          }
+        }
+      }
     }
     for (size_t u = 0; u < n_code; u++) {
       const uint32_t cw = le32(32 + 4 * u);
       const uint64_t pc = 0x1000 + 4 * (uint64_t)u;
       const uint32_t f[air::N_TUPLE] = {(uint32_t)(pc & 0xFFFFF), (uint32_t)((pc >> 20) & 0xFFFFF), (uint32_t)(pc >> 40), cw & 0x7F, (cw >> 7) & 0xF, (cw >> 11) & 0xF,
-                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F, mode), air::variant_bit(cw & 0x7F)};
+                                        (cw >> 15) & 0xF, cw >> 19, cw >> 31, air::opclass_of(cw & 0x7F, mode), air::variant_bit(cw & 0x7F, mode)};
       E4 fp = lam[air::N_TUPLE];
       for (int j = 0; j < air::N_TUPLE; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(f[j])));
       d[air::RC_TABLE + u] = bb::e_sub(alpha_l, fp);
@@ -634,11 +686,13 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (size_t i = d.size(); i-- > 0;) {
       const E4 di = bb::e_mul_m(inv, pre[i]);
       inv = bb::e_mul_m(inv, d[i]);
+      if (i >= n_fixed) { T = hsign[i - n_fixed] > 0 ? bb::e_add(T, di) : bb::e_sub(T, di); continue; }                                            // (mode 4) the hash calls
       if (i >= n_tab + (size_t)air::MEM_MULT) { T = ((i - n_tab - (size_t)air::MEM_MULT) & 1) ? bb::e_sub(T, di) : bb::e_add(T, di); continue; }   // (mode 3) + initial tuple, - final tuple
       const uint32_t m = i < (size_t)air::RC_TABLE ? rc_mult[i] : i < n_tab ? rom_mult[i - air::RC_TABLE] : mem_mult[i - n_tab];
       if (m) T = bb::e_add(T, bb::e_mul_fm(di, bb::to_mont(m)));
     }
     lk_m[air::LK_NIN] = 0;
+    { const uint64_t Bc = air::boundary_cell(4 * (uint64_t)n_code); lk_m[air::LK_B0] = bb::to_mont((uint32_t)(Bc & 0xFFFFF)); lk_m[air::LK_B1] = bb::to_mont((uint32_t)((Bc >> 20) & 0xFFFFF)); }   // (mode 4) the boundary cell
     if (mode >= 2) {
       // the tapes' share of the table side: every output index in [oc_first, oc_last) and every input index in [ic_first, ic_last) exactly once,
       // fingerprint = index + lambda v0 + lambda^2 v1 + lambda^3 v2 + tag lambda^N_TUPLE (tag 2 = outputs, 3 = inputs), v = the (20, 20, 24)-bit limbs of the value

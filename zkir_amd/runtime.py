@@ -97,7 +97,9 @@ class PublicInputsC(C.Structure):             # zkir_public_inputs
                 ("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("outputs", C.c_void_p), ("n_outputs", C.c_uint64), ("halt_kind", C.c_uint32), ("reserved2", C.c_uint32),
                 ("halt_code", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64),
                 # mode 3 (`deferred` == 3: mode 2 + the memory argument): the memory witness of the run (borrowed pointers into a MemcheckWitness: with_memory())
-                ("mem_old", C.c_void_p), ("mem_told", C.c_void_p), ("cell_addr", C.c_void_p), ("cell_bytes", C.c_void_p), ("cell_time", C.c_void_p), ("n_cells", C.c_uint64)]
+                ("mem_old", C.c_void_p), ("mem_told", C.c_void_p), ("cell_addr", C.c_void_p), ("cell_bytes", C.c_void_p), ("cell_time", C.c_void_p), ("n_cells", C.c_uint64),
+                # mode 4 (`deferred` == 4: mode 3 + the wide-arithmetic class + hash syscalls as a tape): the hash calls as the proof's hash section (borrowed from a MemcheckWitness)
+                ("hash_section", C.c_void_p), ("hash_section_words", C.c_uint64)]
 
     def with_params(self, num_queries: int = 0, pow_bits: int = 0) -> "PublicInputsC":
         """zkir_public_inputs_set_params: the prover's FRI parameters (0 = the defaults: 50 queries, 12 grinding bits; accepted 50..128 / 12..24).  A verifier given this
@@ -153,20 +155,23 @@ class MemcheckWitness:
     """zkir_memcheck_witness_of: the memory witness of a whole run (mode 3) — per row the accessed 8-byte cell's bytes before the access and the time of its previous
     access, and the touched cells; a sequential host replay (memory is a chain).  Refused for shards / windows, addresses of 2^40 or more, executed hash syscalls."""
 
-    def __init__(self, log: "DeltaLog", program):
+    def __init__(self, log: "DeltaLog", program, mode: int = 3):
+        """mode 4 (zkir_memcheck_witness_of_mode): the run's hash syscalls are replayed too and recorded as the proof's hash section (n_hash_calls of them)."""
         blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
         L = lib()
-        L.zkir_memcheck_witness_of.restype = C.c_int
-        L.zkir_memcheck_witness_of.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        L.zkir_memcheck_witness_of_mode.restype = C.c_int
+        L.zkir_memcheck_witness_of_mode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.zkir_memcheck_witness_n_hash_calls.restype = C.c_uint64; L.zkir_memcheck_witness_n_hash_calls.argtypes = [C.c_void_p]
         L.zkir_memcheck_witness_free.restype = None; L.zkir_memcheck_witness_free.argtypes = [C.c_void_p]
         L.zkir_memcheck_witness_n_cells.restype = C.c_uint64; L.zkir_memcheck_witness_n_cells.argtypes = [C.c_void_p]
         L.zkir_memcheck_witness_n_accesses.restype = C.c_uint64; L.zkir_memcheck_witness_n_accesses.argtypes = [C.c_void_p]
         L.zkir_public_inputs_set_memory.restype = None; L.zkir_public_inputs_set_memory.argtypes = [C.c_void_p, C.c_void_p]
         h = C.c_void_p()
-        rc = L.zkir_memcheck_witness_of(log._h, blob, len(blob), C.byref(h))
+        rc = L.zkir_memcheck_witness_of_mode(log._h, blob, len(blob), int(mode), C.byref(h))
         if rc != ZKIR_OK:
             _raise(rc)
         self._h = h
+        self.n_hash_calls = int(L.zkir_memcheck_witness_n_hash_calls(h))
         self.n_cells = int(L.zkir_memcheck_witness_n_cells(h))
         self.n_accesses = int(L.zkir_memcheck_witness_n_accesses(h))
 
@@ -432,8 +437,10 @@ def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int]
     if rc != ZKIR_OK:
         _raise(rc)
     out.with_io(list(inputs), list(log.outputs))      # the C call borrowed temporaries: re-point at arrays / bytes this struct owns
+    if wide_mode and mem_witness == "device" and log.n_rows and int(np.count_nonzero((log.inst & 0x7F) == 0x50)) > (1 if log.halt_reason.kind == HALT_EXIT else 0):
+        mem_witness = "host"                          # a run that may make hash syscalls (an ECALL beside the exit) is proven from the host witness: the hash tape comes with it
     if (mem_mode or wide_mode) and mem_witness == "host":
-        out.with_memory(MemcheckWitness(log, blob))
+        out.with_memory(MemcheckWitness(log, blob, 4 if wide_mode else 3))
     if num_queries or pow_bits:
         out.with_params(num_queries, pow_bits)
     return out.with_program(blob)
