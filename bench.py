@@ -755,6 +755,23 @@ def main():
                 assert rt.verify(pr, mpub) == 0, f"bench: mode-{mode} proof of the array loop rejected"
                 base = ms if base is None else base
                 prove_by_mode[f"array loop ({mlog.n_rows} rows), {label}"] = {"prove_ms": ms, "stage_ms": dict(zip(PROVE_STAGES, st)), "proof_bytes": int(len(pr) * 4), "vs_mode_0": ms / base, "all_ms": list(all_ms)}
+            # (round 6) mode 4 = mode 3 + MULH / DIVU / REMU / DIV / REM + hash syscalls as a tape + the boundary cell: the same array loop (what the wider rows cost a program
+            # that uses none of it), the wide-arithmetic loop, and BASELINE configs[4]'s program — the SHA-256 hash chain — proven with every digest recomputed by the verifier
+            mpub4 = rt.public_inputs(mlog, mblob, [], wide_mode=True, mem_witness="device")
+            ms, pr, st = timed_prove(mtr, mpub4)
+            assert rt.verify(pr, mpub4) == 0
+            prove_by_mode[f"array loop ({mlog.n_rows} rows), mode 4 (288 + 128 columns; witness on the device)"] = {"prove_ms": ms, "stage_ms": dict(zip(PROVE_STAGES, st)), "proof_bytes": int(len(pr) * 4), "vs_mode_0": ms / base}
+            for label, prog in (("wide-arithmetic loop (6 of 18 rows MULH / DIVU / REMU / DIV / REM)", spec.wide_loop_program()), ("SHA-256 hash chain = configs[4]'s program (a hash syscall every 6 rows)", spec.sha256_chain_program())):
+                wblob = prog.to_bytes()
+                wlog = rt.interpret(wblob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
+                wddl = pl.upload(wlog); wtr = pl.DeviceTrace(wddl); pl.trace_fill(pl.trace_fill_args(wddl, wtr)); torch.cuda.synchronize()
+                t0 = time.perf_counter(); wpub = rt.public_inputs(wlog, wblob, [], wide_mode=True, mem_witness="host"); t_wit = (time.perf_counter() - t0) * 1e3
+                ms, pr, st = timed_prove(wtr, wpub)
+                t0 = time.perf_counter(); vrc = rt.verify(pr, wpub); t_ver = (time.perf_counter() - t0) * 1e3
+                assert vrc == 0, f"bench: mode-4 proof of the {label} rejected ({vrc})"
+                prove_by_mode[f"{label}, {wlog.n_rows} rows, mode 4"] = {"prove_ms": ms, "stage_ms": dict(zip(PROVE_STAGES, st)), "proof_bytes": int(len(pr) * 4), "host_witness_ms": t_wit,
+                                                                        "hash_calls": int(wpub._mem_ref.n_hash_calls), "touched_cells": int(wpub._mem_ref.n_cells), "verify_ms_host": t_ver}
+                wlog.close(); del wddl, wtr
             t0 = time.perf_counter(); hw = rt.MemcheckWitness(mlog, mblob); t_host = (time.perf_counter() - t0) * 1e3
             prove_by_mode["array loop: memory witness by the host's sequential replay instead (zkir_memcheck_witness_of)"] = {"ms": t_host, "accesses": hw.n_accesses, "cells": hw.n_cells}
             mlog.close()

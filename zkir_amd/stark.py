@@ -43,12 +43,18 @@ def proof_layout(proof) -> dict:
         n_in = int(proof[at]); at += 1 + 4 * n_in
         n_out = int(proof[at]); at += 1 + 4 * n_out
         at += 5
-    if mode == 3:
+    hash_at = None
+    if mode >= 3:
         mem_at = at
         at += 1 + 7 * int(proof[at])
+    if mode == 4:                                             # (mode 4) the hash calls: [n] then per call 8 words + 5 per touched cell
+        hash_at = at
+        n_calls = int(proof[at]); at += 1
+        for _ in range(n_calls):
+            at += 8 + 5 * int(proof[at + 7])
     rom_mult = at
-    troot = rom_mult + n_rom + RC_TABLE + (MEM_MULT if mode == 3 else 0)
-    return {"mode": mode, "num_queries": int(proof[4]), "pow_bits": int(proof[6]), "blob": blob, "n_rom": n_rom, "io_section": io_at, "mem_section": mem_at, "rom_mult": rom_mult,
+    troot = rom_mult + n_rom + RC_TABLE + (MEM_MULT if mode >= 3 else 0)
+    return {"mode": mode, "num_queries": int(proof[4]), "pow_bits": int(proof[6]), "blob": blob, "n_rom": n_rom, "io_section": io_at, "mem_section": mem_at, "hash_section": hash_at, "rom_mult": rom_mult,
             "rc_mult": rom_mult + n_rom, "trace_root": troot, "aux_root": troot + 4, "quotient_root": troot + 8, "openings": troot + 12}
 
 
