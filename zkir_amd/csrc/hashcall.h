@@ -7,6 +7,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "host.h"
@@ -84,6 +85,27 @@ inline int parse_section(const uint32_t* w, size_t avail, uint64_t n_real, uint6
   }
   *words_used = q;
   return 0;
+}
+
+// The per-call work of the prover's and the verifier's table side (a digest, ~17 fingerprints and their share of a batch inversion per call) split over host threads:
+// fn(part, first_call, last_call) for `parts` contiguous ranges; the caller sums the parts.  A thread that cannot be started runs on the calling thread instead.
+template <class F>
+inline void for_calls(size_t n_calls, unsigned parts, F&& fn) {
+  if (parts <= 1 || n_calls < 2) { fn(0u, (size_t)0, n_calls); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < parts; t++) {
+    const size_t lo = n_calls * t / parts, hi = n_calls * (t + 1) / parts;
+    if (t + 1 == parts) { fn(t, lo, hi); break; }
+    try { th.emplace_back([&fn, t, lo, hi] { fn(t, lo, hi); }); } catch (...) { fn(t, lo, hi); }
+  }
+  for (auto& x : th) x.join();
+}
+inline unsigned parts_for(size_t n_calls) {
+  unsigned hw = std::thread::hardware_concurrency() / 2;
+  if (hw < 1) hw = 1;
+  if (hw > 16) hw = 16;
+  const size_t by_work = n_calls / 512 + 1;                      // (a part should be worth a thread's start)
+  return (unsigned)std::min<size_t>(hw, by_work);
 }
 
 }  // namespace hashcall

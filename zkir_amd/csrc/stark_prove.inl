@@ -1145,11 +1145,11 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // (mode 4) a run with hash calls can touch more cells than it has rows (a 5000-byte BLAKE3 input is 626 cells): the cell arrays and the section buffer are sized by the
   // caller's witness when it brings one (the device witness sees loads and stores only: at most one cell per row)
   const uint64_t CELL_CAP = std::max<uint64_t>(N, MEM_HOST ? pub->n_cells + 1 : 0);
-  const size_t SEC_WORDS = 8 * (size_t)CELL_CAP + 4096;
+  const size_t SEC_WORDS = std::max<size_t>(8 * (size_t)CELL_CAP, WIDE ? (size_t)pub->hash_section_words + (size_t)pub->hash_section_words / 100 : 0) + 4096;   // (the memory section, then the hash section, each with its chunk digests behind it)
   {                                               // workspace: 12 W (M + L) + 440 (trees, quotient, weights, FRI) bytes per row, allocated once per context
     static_assert(WMX % 8 == 0 && air::W_COMMITTED_DEFAULT % 8 == 0, "the main trace fills whole B8 blocks");
     const size_t want = (size_t)(12 * WM + 12 * WA + 16 + 544 + (IO ? 48 : 0) + (MEM ? 48 : 0) + (WIDE ? 8 : 0)) * N + (size_t)air::MAX_NUM_QUERIES * 64 * 1024 + (8u << 20) + (size_t)n_code * 24 + (1u << 16) +
-                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)CELL_CAP * 60 + blob_len + (1u << 16) : 0);
+                        (IO ? (size_t)pub->n_inputs * 8 : 0) + (MEM ? (size_t)air::MEM_MULT * 24 + (size_t)CELL_CAP * 28 + SEC_WORDS * 4 + blob_len + (1u << 16) : 0);
     if (c->arena_size < want) {
       if (c->arena) (void)hipFree(c->arena);
       c->arena = nullptr; c->arena_size = 0;
@@ -1323,6 +1323,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   // (mode 4) the hash calls: the tape the proof carries (from the caller's host witness), checked as the verifier will check it, observed like the memory section
   std::vector<hashcall::Call> hcalls;
   std::vector<uint32_t> hash_sec;
+  const double t_hash0 = since(t_entry);
   if (WIDE) {
     if (pub->hash_section && pub->hash_section_words) {
       size_t used = 0;
@@ -1351,6 +1352,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     } else {                                                                         // (more records than the workspace holds: the digests on the host)
       for (size_t at = 0; at < hash_sec.size(); at += SECTION_CHUNK) { uint32_t dg[4]; hash_elems_host(c->consts, hash_sec.data() + at, std::min((size_t)SECTION_CHUNK, hash_sec.size() - at), dg); ch.observe_n(dg, 4); }
     }
+    if (dbg_t) fprintf(stderr, "zkir_prove mode 4: hash section (%zu calls, %zu words) parsed, hashed and observed in %.2f ms\n", hcalls.size(), hash_sec.size(), since(t_entry) - t_hash0);
   }
   ch.observe_n(mult, n_mult);                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
   std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
@@ -1432,31 +1434,39 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
         for (int k = 0; k < 8; k++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[3 + k], bb::to_mont((uint32_t)((bytes >> (8 * k)) & 0xFF))));
         return bb::e_sub(alpha_lm, fp);
       };
-      std::vector<E4> d; std::vector<int8_t> sign; std::vector<uint64_t> nb;
-      for (const hashcall::Call& hc : hcalls) {
-        const uint32_t e[11] = {(uint32_t)(hc.cycle % bb::P), (uint32_t)(hc.in_ptr & 0xFFFFF), (uint32_t)((hc.in_ptr >> 20) & 0xFFFFF), (uint32_t)(hc.in_ptr >> 40), (uint32_t)(hc.len & 0xFFFFF),
-                                (uint32_t)((hc.len >> 20) & 0xFFFFF), (uint32_t)(hc.len >> 40), (uint32_t)(hc.out_ptr & 0xFFFFF), (uint32_t)((hc.out_ptr >> 20) & 0xFFFFF), (uint32_t)(hc.out_ptr >> 40), hc.kind};
-        E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_HASH));
-        for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[j], bb::to_mont(e[j])));
-        d.push_back(bb::e_sub(alpha_lm, fp)); sign.push_back(2);                                  // (2: a call's own entry — its inverse is also the row's HH)
-        hashcall::new_bytes(hc, nb);
-        for (size_t k = 0; k < hc.cells.size(); k++) {
-          d.push_back(mem_d(hc.cells[k].addr, hc.cells[k].t, hc.cells[k].bytes)); sign.push_back(-1);
-          d.push_back(mem_d(hc.cells[k].addr, (uint32_t)((hc.cycle + 1) % bb::P), nb[k])); sign.push_back(1);
-        }
-      }
-      std::vector<E4> pre(d.size());
-      E4 acc = bb::e_one_m();
-      for (size_t i = 0; i < d.size(); i++) { pre[i] = acc; acc = bb::e_mul_m(acc, d[i]); }
-      E4 inv = bb::e_inv_m(acc);
-      size_t call = hcalls.size();
       hash_aux.resize(hcalls.size());
-      for (size_t i = d.size(); i-- > 0;) {
-        const E4 di = bb::e_mul_m(inv, pre[i]);
-        inv = bb::e_mul_m(inv, d[i]);
-        if (sign[i] < 0) T = bb::e_sub(T, di); else T = bb::e_add(T, di);
-        if (sign[i] == 2) { call--; hash_aux[call].row = (uint32_t)hcalls[call].cycle; hash_aux[call].pad[0] = hash_aux[call].pad[1] = hash_aux[call].pad[2] = 0; hash_aux[call].h = di; }
-      }
+      const unsigned parts = hashcall::parts_for(hcalls.size());
+      std::vector<E4> Tpart(parts, bb::e_zero());
+      hashcall::for_calls(hcalls.size(), parts, [&](unsigned part, size_t lo, size_t hi) {        // (host threads: 175 k calls at 2^20 rows of the SHA chain are ~1 s on one core)
+        std::vector<E4> d; std::vector<int8_t> sign; std::vector<uint64_t> nb;
+        for (size_t ci = lo; ci < hi; ci++) {
+          const hashcall::Call& hc = hcalls[ci];
+          const uint32_t e[11] = {(uint32_t)(hc.cycle % bb::P), (uint32_t)(hc.in_ptr & 0xFFFFF), (uint32_t)((hc.in_ptr >> 20) & 0xFFFFF), (uint32_t)(hc.in_ptr >> 40), (uint32_t)(hc.len & 0xFFFFF),
+                                  (uint32_t)((hc.len >> 20) & 0xFFFFF), (uint32_t)(hc.len >> 40), (uint32_t)(hc.out_ptr & 0xFFFFF), (uint32_t)((hc.out_ptr >> 20) & 0xFFFFF), (uint32_t)(hc.out_ptr >> 40), hc.kind};
+          E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_HASH));
+          for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[j], bb::to_mont(e[j])));
+          d.push_back(bb::e_sub(alpha_lm, fp)); sign.push_back(2);                                // (2: a call's own entry — its inverse is also the row's HH)
+          hashcall::new_bytes(hc, nb);
+          for (size_t k = 0; k < hc.cells.size(); k++) {
+            d.push_back(mem_d(hc.cells[k].addr, hc.cells[k].t, hc.cells[k].bytes)); sign.push_back(-1);
+            d.push_back(mem_d(hc.cells[k].addr, (uint32_t)((hc.cycle + 1) % bb::P), nb[k])); sign.push_back(1);
+          }
+        }
+        std::vector<E4> pre(d.size());
+        E4 acc = bb::e_one_m();
+        for (size_t i = 0; i < d.size(); i++) { pre[i] = acc; acc = bb::e_mul_m(acc, d[i]); }
+        E4 inv = bb::e_inv_m(acc), Tp = bb::e_zero();
+        size_t call = hi;
+        for (size_t i = d.size(); i-- > 0;) {
+          const E4 di = bb::e_mul_m(inv, pre[i]);
+          inv = bb::e_mul_m(inv, d[i]);
+          if (sign[i] < 0) Tp = bb::e_sub(Tp, di); else Tp = bb::e_add(Tp, di);
+          if (sign[i] == 2) { call--; hash_aux[call].row = (uint32_t)hcalls[call].cycle; hash_aux[call].pad[0] = hash_aux[call].pad[1] = hash_aux[call].pad[2] = 0; hash_aux[call].h = di; }
+        }
+        Tpart[part] = Tp;
+      });
+      for (const E4& tp : Tpart) T = bb::e_add(T, tp);
+      if (dbg_t) fprintf(stderr, "zkir_prove mode 4: the hash calls' table side (%u host threads) at %.2f ms\n", parts, since(t_entry));
     }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];

@@ -607,10 +607,18 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
   ch.observe_n(troot, 4);
   if (mode >= 2)                                                           // (v11) the tapes and the halt reason, fixed before the lookup challenges (a segment's too) — so::observe_section
     for (size_t at = 0; at < io.words; at += 512) { uint32_t dg[4]; hash_elems(io_words + at, io.words - at < 512 ? io.words - at : 512, dg); ch.observe_n(dg, 4); }
-  if (mode >= 3)                                                           // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section)
-    for (size_t at = 0; at < mem_len; at += 512) { uint32_t dg[4]; hash_elems(mem_words + at, mem_len - at < 512 ? mem_len - at : 512, dg); ch.observe_n(dg, 4); }
-  if (mode == 4)                                                           // (mode 4) the hash calls, likewise
-    for (size_t at = 0; at < hash_len; at += 512) { uint32_t dg[4]; hash_elems(hash_words + at, hash_len - at < 512 ? hash_len - at : 512, dg); ch.observe_n(dg, 4); }
+  // the touched cells enter through a two-level sponge: chunks of 512 words hashed on their own, the digests observed (so::observe_section); (mode 4) the hash calls likewise.
+  // The chunks are independent: long sections (a 2^22-cycle hash chain's tape is 34 M words = 4 M permutations) are hashed on several host threads.
+  auto observe_section = [&](const uint32_t* sw, size_t sl) {
+    const size_t n_chunks = (sl + 511) / 512;
+    std::vector<uint32_t> dg(4 * n_chunks);
+    hashcall::for_calls(n_chunks, hashcall::parts_for(n_chunks / 8), [&](unsigned, size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) hash_elems(sw + 512 * k, sl - 512 * k < 512 ? sl - 512 * k : 512, dg.data() + 4 * k);
+    });
+    ch.observe_n(dg.data(), dg.size());
+  };
+  if (mode >= 3) observe_section(mem_words, mem_len);
+  if (mode == 4) observe_section(hash_words, hash_len);
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
   if (mode >= 3) ch.observe_n(mem_mult, air::MEM_MULT);
@@ -626,8 +634,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (int j = 0; j <= air::N_TUPLE; j++) for (int k = 0; k < 4; k++) lk_m[air::LK_LAM + 4 * j + k] = lam[j].c[k];
     const size_t n_tab = (size_t)air::RC_TABLE + n_code;
     std::vector<E4> d(n_tab + (mode >= 3 ? (size_t)air::MEM_MULT + 2 * cells.size() : 0));
-    const size_t n_fixed = d.size();                                       // (mode 4: the hash calls' entries follow, each with its sign)
-    std::vector<int8_t> hsign;
+    E4 T_hash = bb::e_zero();                                              // (mode 4) the hash calls' share, summed by its own threads below
     for (int t = 0; t < air::RC_TABLE; t++) { d[t] = alpha_l; d[t].c[0] = bb::sub(d[t].c[0], bb::to_mont((uint32_t)t)); }
     if (mode >= 3) {
       // the LOW3, BYTE and NIBBLE tables, then the two ends of the memory check: per touched cell the INITIAL tuple (time 0, the program image's bytes) and the FINAL one
@@ -651,21 +658,37 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       for (size_t k = 0; k < cells.size(); k++) { m[air::MEM_MULT + 2 * k] = mem_d(cells[k], 0, image_cell(blob.data(), blob_len, cells[k].addr)); m[air::MEM_MULT + 2 * k + 1] = mem_d(cells[k], cells[k].t, cells[k].bytes); }
       // (mode 4) the hash calls: + 1 / (alpha - fp(call)) per call (its ECALL row looks it up) and the call's memory accesses, which no row states: per touched cell
       // - 1 / (alpha - fp(cell, told, old bytes)) + 1 / (alpha - fp(cell, cycle + 1, new bytes)).  The digest inside the new bytes is computed HERE (hashcall::new_bytes).
-      if (mode == 4) {
-        std::vector<uint64_t> nb;
-        for (const hashcall::Call& c : hcalls) {
-          const uint32_t e[11] = {(uint32_t)(c.cycle % bb::P), (uint32_t)(c.in_ptr & 0xFFFFF), (uint32_t)((c.in_ptr >> 20) & 0xFFFFF), (uint32_t)(c.in_ptr >> 40), (uint32_t)(c.len & 0xFFFFF),
-                                  (uint32_t)((c.len >> 20) & 0xFFFFF), (uint32_t)(c.len >> 40), (uint32_t)(c.out_ptr & 0xFFFFF), (uint32_t)((c.out_ptr >> 20) & 0xFFFFF), (uint32_t)(c.out_ptr >> 40), c.kind};
-          E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_HASH));
-          for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(e[j])));
-          d.push_back(bb::e_sub(alpha_l, fp)); hsign.push_back(1);
-          hashcall::new_bytes(c, nb);
-          for (size_t k = 0; k < c.cells.size(); k++) {
-            const Cell cc{c.cells[k].addr, 0, 0};
-            d.push_back(mem_d(cc, c.cells[k].t, c.cells[k].bytes)); hsign.push_back(-1);
-            d.push_back(mem_d(cc, (uint32_t)((c.cycle + 1) % bb::P), nb[k])); hsign.push_back(1);
+      if (mode == 4 && !hcalls.empty()) {
+        const unsigned parts = hashcall::parts_for(hcalls.size());
+        std::vector<E4> Tpart(parts, bb::e_zero());
+        hashcall::for_calls(hcalls.size(), parts, [&](unsigned part, size_t lo, size_t hi) {      // (host threads; each part inverts its own batch)
+          std::vector<E4> hd; std::vector<int8_t> hsign; std::vector<uint64_t> nb;
+          for (size_t ci = lo; ci < hi; ci++) {
+            const hashcall::Call& c = hcalls[ci];
+            const uint32_t e[11] = {(uint32_t)(c.cycle % bb::P), (uint32_t)(c.in_ptr & 0xFFFFF), (uint32_t)((c.in_ptr >> 20) & 0xFFFFF), (uint32_t)(c.in_ptr >> 40), (uint32_t)(c.len & 0xFFFFF),
+                                    (uint32_t)((c.len >> 20) & 0xFFFFF), (uint32_t)(c.len >> 40), (uint32_t)(c.out_ptr & 0xFFFFF), (uint32_t)((c.out_ptr >> 20) & 0xFFFFF), (uint32_t)(c.out_ptr >> 40), c.kind};
+            E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_HASH));
+            for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(e[j])));
+            hd.push_back(bb::e_sub(alpha_l, fp)); hsign.push_back(1);
+            hashcall::new_bytes(c, nb);
+            for (size_t k = 0; k < c.cells.size(); k++) {
+              const Cell cc{c.cells[k].addr, 0, 0};
+              hd.push_back(mem_d(cc, c.cells[k].t, c.cells[k].bytes)); hsign.push_back(-1);
+              hd.push_back(mem_d(cc, (uint32_t)((c.cycle + 1) % bb::P), nb[k])); hsign.push_back(1);
+            }
           }
-        }
+          std::vector<E4> hpre(hd.size());
+          E4 hacc = bb::e_one_m();
+          for (size_t i = 0; i < hd.size(); i++) { hpre[i] = hacc; hacc = bb::e_mul_m(hacc, hd[i]); }
+          E4 hinv = bb::e_inv_m(hacc), Tp = bb::e_zero();
+          for (size_t i = hd.size(); i-- > 0;) {
+            const E4 di = bb::e_mul_m(hinv, hpre[i]);
+            hinv = bb::e_mul_m(hinv, hd[i]);
+            Tp = hsign[i] > 0 ? bb::e_add(Tp, di) : bb::e_sub(Tp, di);
+          }
+          Tpart[part] = Tp;
+        });
+        for (const E4& tp : Tpart) T_hash = bb::e_add(T_hash, tp);
       }
     }
     for (size_t u = 0; u < n_code; u++) {
@@ -686,11 +709,11 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     for (size_t i = d.size(); i-- > 0;) {
       const E4 di = bb::e_mul_m(inv, pre[i]);
       inv = bb::e_mul_m(inv, d[i]);
-      if (i >= n_fixed) { T = hsign[i - n_fixed] > 0 ? bb::e_add(T, di) : bb::e_sub(T, di); continue; }                                            // (mode 4) the hash calls
       if (i >= n_tab + (size_t)air::MEM_MULT) { T = ((i - n_tab - (size_t)air::MEM_MULT) & 1) ? bb::e_sub(T, di) : bb::e_add(T, di); continue; }   // (mode 3) + initial tuple, - final tuple
       const uint32_t m = i < (size_t)air::RC_TABLE ? rc_mult[i] : i < n_tab ? rom_mult[i - air::RC_TABLE] : mem_mult[i - n_tab];
       if (m) T = bb::e_add(T, bb::e_mul_fm(di, bb::to_mont(m)));
     }
+    T = bb::e_add(T, T_hash);
     lk_m[air::LK_NIN] = 0;
     { const uint64_t Bc = air::boundary_cell(4 * (uint64_t)n_code); lk_m[air::LK_B0] = bb::to_mont((uint32_t)(Bc & 0xFFFFF)); lk_m[air::LK_B1] = bb::to_mont((uint32_t)((Bc >> 20) & 0xFFFFF)); }   // (mode 4) the boundary cell
     if (mode >= 2) {
