@@ -152,10 +152,30 @@ def _check_traffic_source_is_fresh(path: str):
     return "fresh" if rec == sources_sha16() else "STALE (kernel sources changed since the counter pass)"
 
 
+def _profile_sha(path: str):
+    """The kernel-source hash a committed profile file says it was measured at (a '# kernels_sha16:' line, or the '_kernels_sha16' key of a JSON file), or None."""
+    try:
+        if path.endswith(".json"):
+            return json.load(open(path)).get("_kernels_sha16")
+        for line in open(path):
+            if line.startswith("# kernels_sha16:"):
+                return line.split(":", 1)[1].strip()
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _newest_profile(pattern: str):
+    """The committed profile file to read: the one measured at THIS build's kernel sources if there is one (mtime means nothing after a checkout), else the
+    highest round tag by NAME — whose figures the caller then marks stale."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=lambda f: (os.path.basename(f).split("_")[0], os.path.getmtime(f)))
-    return files[-1] if files else None
+    from zkir_amd.build import sources_sha16
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=lambda f: os.path.basename(f))
+    if not files:
+        return None
+    cur = sources_sha16()
+    fresh = [f for f in files if _profile_sha(f) == cur]
+    return (fresh or files)[-1]
 
 
 def _profiled_counters(kernel: str):
@@ -195,7 +215,10 @@ def _alu_roofline(kernel: str, kernel_ms: float):
     achieved = ctr["insts_valu"] / (kernel_ms * 1e-3)
     peak = SIMDS * PEAK_CLOCK_HZ / c_avg
     cls = h["classes"]
-    return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "wave64 VALU instr/s", "frac": achieved / peak,
+    fresh = hist.get("_kernels_sha16") == sources_sha16() and ctr["fresh"] is True
+    return {"bound": "valu-issue", "achieved": achieved if fresh else None, "peak": peak, "unit": "wave64 VALU instr/s",
+            "frac": achieved / peak if fresh else None,          #  an instruction count measured at OTHER kernel sources over this run's time is no bound: withheld
+            "frac_if_counters_were_fresh": achieved / peak,
             "wave_instr_per_launch": ctr["insts_valu"], "avg_issue_cycles": c_avg, "static_valu": h["valu"],
             "static_mix": {q: cls.get(q, 0) for q in ("multiplier", "add64", "copy", "full_rate_32", "other_valu")},
             "valu_busy_profiled": ctr["valu_busy"], "clock_ghz_profiled": ctr["clock_ghz"],

@@ -86,7 +86,10 @@ def test_alu_bound_is_a_bound():
     assert 0.5 < alu["frac_in_counter_pass"] <= 1.0, alu
     ctr = bench._profiled_counters("leaf_hash_kernel")
     at_its_own_time = bench._alu_roofline("leaf_hash_kernel", ctr["launch_us"] * 1e-3)
-    assert at_its_own_time["frac"] <= at_its_own_time["frac_in_counter_pass"] * 1.001          # (the pass ran below 2.4 GHz)
+    assert at_its_own_time["frac_if_counters_were_fresh"] <= at_its_own_time["frac_in_counter_pass"] * 1.001          # (the pass ran below 2.4 GHz)
+    #  counters measured at other kernel sources than this build's are no bound on this build's run: `frac` is then withheld, not quoted
+    fresh = at_its_own_time["isa_hist_fresh"] is True and at_its_own_time["counters_fresh"] is True
+    assert (at_its_own_time["frac"] is not None) == fresh and (not fresh or at_its_own_time["frac"] == at_its_own_time["frac_if_counters_were_fresh"])
 
 
 def test_shipped_code_object_registers_and_spills():

@@ -869,8 +869,11 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     if (const char* e = getenv("ZKIR_VERIFY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_thr = (unsigned)v; }
     std::atomic<int> next{0};
     auto work = [&]() { for (int t; (t = next.fetch_add(1)) < NUM_QUERIES;) codes[t] = check_query(t); };
+    if (log_n < 14 && !getenv("ZKIR_VERIFY_THREADS")) n_thr = 1;            // (a small proof is checked faster than threads start)
     std::vector<std::thread> th;
-    for (unsigned k = 1; k < n_thr; k++) th.emplace_back(work);
+    for (unsigned k = 1; k < n_thr; k++) {
+      try { th.emplace_back(work); } catch (...) { break; }                 // (a host that refuses a thread — pids limit, sandbox — must not take the verdict down:
+    }                                                                        //  the queries left over are checked on the calling thread, the threads that did start are joined)
     work();
     for (auto& x : th) x.join();
   }
