@@ -554,7 +554,7 @@ const char* zkir_last_error(void);
  *   4: zkir_prove's stage_ms is NINE floats (round 4 added the lookup stage: a caller built against eight overflows by 4 bytes)
  *   5: zkir_public_inputs.reserved became fri_params (same offset; zero = the old behaviour); zkir_verify* compare the proof's FRI parameters with `expect`'s
  * A binding checks zkir_abi_version() == ZKIR_AMD_ABI_VERSION when it loads the library. */
-#define ZKIR_AMD_ABI_VERSION 5u
+#define ZKIR_AMD_ABI_VERSION 6u   /* 6 (round 6): zkir_public_inputs grew (hash_section), mode 4 entry points, pinned log blocks */
 uint32_t zkir_abi_version(void);
 const char* zkir_version(void);
 

@@ -395,6 +395,7 @@ struct PublicInputs : zkir_public_inputs {
     inputs = inputs_.empty() ? nullptr : inputs_.data(); n_inputs = inputs_.size();
     outputs = outputs_.empty() ? nullptr : outputs_.data(); n_outputs = outputs_.size();
     mem_old = nullptr; mem_told = nullptr; cell_addr = nullptr; cell_bytes = nullptr; cell_time = nullptr; n_cells = 0;   // mode 3: zkir_prove makes the memory witness on the device
+    hash_section = nullptr; hash_section_words = 0;                                                                     // mode 4: a run with hash syscalls brings its tape (zkir_memcheck_witness_of_mode)
   }
   std::vector<uint8_t> blob_;
   std::vector<uint64_t> inputs_, outputs_;
@@ -405,6 +406,8 @@ enum class ProofMode : uint32_t {
   Deferred = 1,   // VMConfig::enable_deferred_model (relaxed AIR)
   Io = 2,         // default + the I/O argument: what the run read and wrote, and that it ended on the instruction its halt reason names
   Memory = 3,     // Io + the memory argument, the bitwise opcodes, the shifts and MUL: 43 of 50 opcodes constrained, memory consistent (whole runs; no hash syscalls)
+  Wide = 4,       // Memory + MULH / DIVU / REMU / DIV / REM on operands below 2^40, the code segment's boundary cell, and — given the host witness with its hash tape
+                  // (zkir_memcheck_witness_of_mode(.., 4, ..) + zkir_public_inputs_set_memory) — hash syscalls, whose digests the verifier computes (round 6)
 };
 inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,
                                   const zkir_runtime::VMConfig& config = {}) {

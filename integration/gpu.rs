@@ -62,6 +62,9 @@ pub struct ZkirPublicInputs {
     pub cell_bytes: *const u64,
     pub cell_time: *const u32,
     pub n_cells: u64,
+    // mode 4 (round 6): the hash calls of the run as the proof's hash section — borrowed from a zkir_memcheck_witness made with zkir_memcheck_witness_of_mode(.., 4, ..)
+    pub hash_section: *const u32,
+    pub hash_section_words: u64,
 }
 pub enum ZkirMemcheckWitness {}
 
@@ -104,7 +107,7 @@ extern "C" {
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct ZkirProverParams { pub mode: u32, pub num_queries: u32, pub pow_bits: u32 }
-pub const ZKIR_AMD_ABI_VERSION: u32 = 5;
+pub const ZKIR_AMD_ABI_VERSION: u32 = 6;
 
 /// include/zkir_amd.h return codes <-> RuntimeError (error.rs:7-37); the message text is the reference's own.
 fn map_error(code: c_int) -> RuntimeError {
@@ -186,7 +189,7 @@ impl GpuExecutionResult {
         unsafe { zkir_proof_free(proof) };
         // the returned struct is what a verifier's `expect` needs (row count, mode, entry point, digests); the prover-side borrowed pointers end with this call
         public.mem_old = std::ptr::null(); public.mem_told = std::ptr::null(); public.cell_addr = std::ptr::null(); public.cell_bytes = std::ptr::null();
-        public.cell_time = std::ptr::null(); public.n_cells = 0;
+        public.cell_time = std::ptr::null(); public.n_cells = 0; public.hash_section = std::ptr::null(); public.hash_section_words = 0;
         Ok((out, public))
     }
 }
