@@ -18,8 +18,8 @@ ctx = stark.StarkContext(k)
 names = ["main_trace", "lde", "trace_merkle", "lookup_aux", "quotient+merkle", "openings", "deep", "fri", "queries"]
 print(f"spec.memory_ring_program({lc}) at 2^{k} rows: host interpret {t_host * 1e3:.1f} ms")
 base = None
-for mode in (0, 2, 3):
-    pub = rt.public_inputs(log, blob, [], io_mode=mode == 2, mem_mode=mode == 3)
+for mode in (0, 2, 3, 4):
+    pub = rt.public_inputs(log, blob, [], io_mode=mode == 2, mem_mode=mode == 3, wide_mode=mode == 4, mem_witness="device")
     best = None
     for it in range(3):
         t0 = time.perf_counter(); proof, ms = stark.prove(ctx, tr, pub, want_stage_ms=True); wall = (time.perf_counter() - t0) * 1e3
