@@ -304,7 +304,9 @@ _I_OPS = [O.ADDI, O.ANDI, O.ORI, O.XORI]
 _GP = [1, 2, 3, 4, 7, 8, 9, 14, 15]       # r5 = memory base, r6 = non-zero divisor, r10-r13 = syscall scratch
 
 
-def random_program(seed: int, n_instr: int = 300, range_checking: bool = False, hashes: bool = True):
+def random_program(seed: int, n_instr: int = 300, range_checking: bool = False, hashes: bool = True, wide_safe: bool = False):
+    """`wide_safe` (proof mode 4): the five wide opcodes read operands cut below 2^40 first (SRLI by >= 24 into the syscall scratch r12 / r13, or r0 / r6), which is
+    what mode 4 states them on; MULH leaves the generic R-type pool for the same reason.  Zero dividends, zero factors and equal operands stay in the draw."""
     rng = np.random.default_rng(seed)
     ri = lambda lo, hi: int(rng.integers(lo, hi))  # noqa: E731
     reg = lambda: _GP[ri(0, len(_GP))]              # noqa: E731
@@ -316,7 +318,10 @@ def random_program(seed: int, n_instr: int = 300, range_checking: bool = False, 
     while len(body) < n_instr:
         k = rng.random()
         if k < 0.40:
-            body.append(E(_R_OPS[ri(0, len(_R_OPS))], reg(), src(), src()))
+            op = _R_OPS[ri(0, len(_R_OPS))]
+            if wide_safe and op == O.MULH:
+                op = O.MUL
+            body.append(E(op, reg(), src(), src()))
         elif k < 0.55:
             body.append(E(_I_OPS[ri(0, len(_I_OPS))], reg(), src(), imm=ri(-65536, 65536)))
         elif k < 0.63:
@@ -329,6 +334,11 @@ def random_program(seed: int, n_instr: int = 300, range_checking: bool = False, 
         elif k < 0.82:
             w = [1, 2, 4, 8][ri(0, 4)]
             body.append(E({1: O.SB, 2: O.SH, 4: O.SW, 8: O.SD}[w], rs1=5, rs2=src(), imm=ri(0, 256) * w))
+        elif k < 0.86 and wide_safe:
+            body += [E(O.SRLI, 12, src(), imm=ri(24, 64)), E(O.SRLI, 13, src(), imm=ri(24, 64)), E(O.ORI, 13, 13, imm=1)]      # r13 != 0: a zero divisor is a VM error
+            op = [O.DIVU, O.REMU, O.DIV, O.REM, O.MULH][ri(0, 5)]
+            b = [13, 12, 6, 0][ri(0, 4)] if op == O.MULH else [13, 13, 6][ri(0, 3)]
+            body.append(E(op, reg(), [12, 12, 12, 13, 6, 0][ri(0, 6)], b))
         elif k < 0.86:
             body.append(E([O.DIVU, O.REMU, O.DIV, O.REM][ri(0, 4)], reg(), src(), 6 if rng.random() < 0.97 else src()))
         elif k < 0.93:

@@ -39,7 +39,7 @@ def edge_heavy(shape):
 
 t_end = time.time() + budget
 n_merkle = n_lde = n_proof = n_wit = n_refused = 0
-n_by_mode = [0, 0, 0, 0]
+n_by_mode = [0, 0, 0, 0, 0]
 ctxs = {}
 while time.time() < t_end:
     what = rng.integers(0, 10)
@@ -83,8 +83,9 @@ while time.time() < t_end:
         log_n = int(rng.integers(3, 11))
         # the proof's MODE: 0 default, 1 deferred model, 2 default + the I/O argument, 3 = 2 + the memory argument (round 4; no hash syscalls there: a run that executes one
         # has no mode-3 proof — the refusal itself is tested in tests/test_gpu_stark.py)
-        mode = int(rng.integers(0, 4))
-        blob, inputs = programs.random_program(int(rng.integers(0, 1 << 30)), n_instr=200, hashes=mode != 3)
+        # (round 6) 4 = 3 + the wide-arithmetic class, the hash tape and the boundary cell: hash syscalls are provable there, the wide opcodes on operands below 2^40
+        mode = int(rng.integers(0, 5))
+        blob, inputs = programs.random_program(int(rng.integers(0, 1 << 30)), n_instr=200, hashes=mode != 3, wide_safe=mode == 4)
         cfg = dict(max_cycles=int(rng.integers((1 << log_n) // 2 + 1, (1 << log_n) + 1)), enable_execution_trace=True, enable_deferred_model=mode == 1)
         try:
             res = oracle.run(blob, inputs, **cfg)
@@ -95,7 +96,7 @@ while time.time() < t_end:
             continue
         log_n = so.padded_log_n(len(want_rows))                     # any halt: the trace is padded to a power of two
         fri = dict(num_queries=84, pow_bits=16) if rng.integers(0, 4) == 0 else {}                 # (round 5) one proof in four at the second parameter set
-        opub = so.public_inputs(len(want_rows), blob, list(inputs), list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, **fri)
+        opub = so.public_inputs(len(want_rows), blob, list(inputs), list(res.outputs), (res.halt_kind, res.halt_code), deferred=mode == 1, io_mode=mode == 2, mem_mode=mode == 3, wide_mode=mode == 4, **fri)
         log = rt.interpret(blob, inputs, rt.VMConfig(**cfg))
         ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
         got_rows = tr.rows()
@@ -104,12 +105,12 @@ while time.time() < t_end:
         ctx = ctxs.setdefault(log_n, stark.StarkContext(log_n))
         want = so.prove(want_rows, opub)
         try:
-            witness = "host" if (mode == 3 and rng.integers(0, 2)) else "device"          # mode 3: the memory witness from the device (sort + scan) or from the host replay
-            proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, mode == 1, io_mode=mode == 2, mem_mode=mode == 3, mem_witness=witness, **fri))
+            witness = "host" if (mode >= 3 and rng.integers(0, 2)) else "device"          # mode 3: the memory witness from the device (sort + scan) or from the host replay
+            proof = stark.prove(ctx, tr, rt.public_inputs(log, blob, inputs, mode == 1, io_mode=mode == 2, mem_mode=mode == 3, wide_mode=mode == 4, mem_witness=witness, **fri))
         except rt.RuntimeError as e:
             # a run that executes a word that is not the program's (a store into the code segment, a pc outside it) has no proof; the
             # honest GPU prover refuses it — and the proof the oracle's prover emits for the same rows must be one the verifiers reject
-            assert e.code == rt.ERR_ARGUMENT and ("code table" in e.message or "2^40" in e.message or "overlaps the code segment" in e.message), e.message
+            assert e.code == rt.ERR_ARGUMENT and ("code table" in e.message or "2^40" in e.message or "bits above 40" in e.message or "overlaps the code segment" in e.message), e.message
             assert so.verify(want) != 0 and rt.verify(want) == so.verify(want), "refused by the prover but accepted by a verifier"
             n_refused += 1
             log.close()
@@ -124,5 +125,5 @@ while time.time() < t_end:
         n_by_mode[mode] += 1
         log.close()
 print(f"soak ok: {n_merkle} Merkle trees, {n_lde} LDEs, {n_wit} witness sets, {n_proof} traces + proofs identical to the oracle, "
-      f"(modes 0 / 1 / 2 / 3: {n_by_mode[0]} / {n_by_mode[1]} / {n_by_mode[2]} / {n_by_mode[3]}), "
+      f"(modes 0 / 1 / 2 / 3 / 4: {n_by_mode[0]} / {n_by_mode[1]} / {n_by_mode[2]} / {n_by_mode[3]} / {n_by_mode[4]}), "
       f"{n_refused} unprovable runs refused by the GPU prover and rejected by both verifiers, in {budget:.0f} s")
