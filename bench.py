@@ -1034,7 +1034,9 @@ def main():
             "prover": "ZKIR-STARK, AIR v6 (self-defined; 172 logical main-trace columns, 152 committed in default mode, + 40 aux columns / 398 constraints: the semantics of 20 of the 50 opcodes — ADD, ADDI, SUB, SLTU/SGEU/SLT/SGE, SEQ/SNE, CMOV/CMOVZ/CMOVNZ, BEQ/BNE, BLTU/BGEU/BLT/BGE, JAL, JALR — and the control flow of every opcode, + a LogUp lookup argument — instruction ROM and 10-bit ranges, eight range lookups per row; "
                       "boundary states for segment proofs, blow-up 2, 50 queries + 12-bit grinding, Poseidon2-12; proof format v10 carries the program).  `prove_ms` is MODE 0, the default; "
                       "opt-in modes (round 4, `prove_by_mode`): 2 = + the I/O argument (what the run read / wrote is proven), 3 = + the memory argument, the bitwise opcodes and the shifts "
-                      "(43 of 50 opcodes, memory consistency; 264 + 96 columns, 636 constraints; the memory witness is made on the device)",
+                      "(43 of 50 opcodes, memory consistency; 264 + 96 columns, 636 constraints; the memory witness is made on the device), 4 (round 6, format v12) = 3 + MULH / DIVU / REMU / DIV / REM on operands "
+                      "below 2^40 (all 50 opcodes carry a statement there; a run that feeds them wider registers has no proof), the hash syscalls through a tape the verifier recomputes "
+                      "(SHA-256 / Keccak / BLAKE3 digests are NOT arithmetised: the verifier hashes the tape's inputs itself), the boundary cell between code and data (288 + 128 columns, 707 constraints)",
             "prove_by_mode": prove_by_mode,
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),

@@ -281,14 +281,17 @@ extern "C" int zkir_memcheck_witness_device(const zkir_trace_columns* trace, uin
     (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told);
     zkir::set_last_error({ZKIR_ERR_DEVICE, "zkir_memcheck_witness_device: out of device memory"}); return ZKIR_ERR_DEVICE;
   }
-  (void)hipMemsetAsync(d_old, 0, n_real * 8, (hipStream_t)stream); (void)hipMemsetAsync(d_told, 0, n_real * 4, (hipStream_t)stream);
+  if (hipMemsetAsync(d_old, 0, n_real * 8, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(d_told, 0, n_real * 4, (hipStream_t)stream) != hipSuccess) {
+    (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told); return dev_fail("clearing the witness columns", hipGetLastError());
+  }
   std::vector<uint64_t> ca, cb; std::vector<uint32_t> ct;
   zkir::HostPin pin;
   int rc = zkir::memcheck_device(trace, n_real, blob, blob_len, scratch, sb, d_old, d_told, ca, cb, ct, pin, stream);
   if (rc == ZKIR_OK) {
     uint64_t* ho = pin.take_n<uint64_t>(n_real); uint32_t* ht = pin.take_n<uint32_t>(n_real);
     if (!ho || !ht) { (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told); return dev_fail("pinned staging", hipErrorOutOfMemory); }
-    (void)hipMemcpy(ho, d_old, n_real * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(ht, d_told, n_real * 4, hipMemcpyDeviceToHost);
+    const hipError_t e1 = hipMemcpy(ho, d_old, n_real * 8, hipMemcpyDeviceToHost), e2 = hipMemcpy(ht, d_told, n_real * 4, hipMemcpyDeviceToHost);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(scratch); (void)hipFree(d_old); (void)hipFree(d_told); return dev_fail("copying the witness back", e1 != hipSuccess ? e1 : e2); }
     memcpy(mem_old, ho, n_real * 8); memcpy(mem_told, ht, n_real * 4);
     *n_cells = ca.size();
     if (ca.size() > cap) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_memcheck_witness_device: more cells than the caller's buffers hold"}); rc = ZKIR_ERR_ARGUMENT; }
