@@ -2299,19 +2299,21 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     if (nh > pub.n_real) return 56;
     hash_words = w + p;
     size_t q = p + 1;
-    pub.hcalls.resize(nh);
+    pub.hcalls.reserve(std::min(nh, (len - p) / 28));                                         // (a record is at least 28 words: a forged count allocates nothing beyond the proof)
     std::vector<uint64_t> addrs;
     const uint64_t code_end = 0x1000 + 4 * (uint64_t)rom.n;
     for (size_t k = 0; k < nh; k++) {
       if (q + 8 > len) return 4;
       const uint32_t* c = w + q;
+      pub.hcalls.emplace_back();
       Public::HashCall& hc = pub.hcalls[k];
       if (c[1] >= (1u << 20) || c[2] >= (1u << 20) || c[4] >= (1u << 20) || c[5] >= (1u << 20)) return 56;
       hc.cycle = c[0]; hc.in_ptr = (uint64_t)c[1] | ((uint64_t)c[2] << 20); hc.len = c[3]; hc.out_ptr = (uint64_t)c[4] | ((uint64_t)c[5] << 20); hc.kind = c[6];
       if (hc.cycle >= pub.n_real || (k && hc.cycle <= pub.hcalls[k - 1].cycle) || !hash_call_in_range(hc.in_ptr, hc.len, hc.out_ptr, hc.kind)) return 56;
       if (hc.out_ptr < code_end && hc.out_ptr + 32 > 0x1000) return 55;
       hash_call_cells(hc.in_ptr, hc.len, hc.out_ptr, addrs);
-      if (c[7] != addrs.size() || q + 8 + 5 * addrs.size() > len) return 56;
+      if (c[7] != addrs.size()) return 56;
+      if (q + 8 + 5 * addrs.size() > len) return 4;                                            // (truncated: like every other section that ends early)
       q += 8;
       hc.cells.resize(addrs.size());
       for (size_t j = 0; j < addrs.size(); j++, q += 5) {

@@ -269,3 +269,37 @@ def test_random_programs_with_wide_ops_and_hash_calls_are_accepted(seed):
     pub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), wide_mode=True)
     proof = so.prove(ores.rows, pub)
     assert so.verify(proof, pub) == 0 and rt.verify(proof) == 0
+
+
+def test_mutated_mode4_proofs_are_rejected_by_both_verifiers_alike():
+    """Robustness of the two verifiers on the format's newest sections: 600 single-word mutations of a mode-4 proof that carries touched cells and a hash tape — a third of them
+    inside the memory / hash sections, with values drawn from the edges (0, 1, 2^16, 2^20, p - 1, 2^32 - 1, the word + 1) — are all rejected, with the same code by
+    `zkir_verify` and by the oracle's verifier, and without either of them reading outside the proof (a forged count cannot make the parser allocate beyond what the proof holds)."""
+    from zkir_amd import runtime as rt, stark
+    blob, ins = pg.random_program(3, n_instr=200, hashes=True, wide_safe=True)
+    ores = oracle.run(blob, ins, max_cycles=600, enable_execution_trace=True)
+    pub = so.public_inputs(len(ores.rows), blob, list(ins), list(ores.outputs), (ores.halt_kind, ores.halt_code), wide_mode=True)
+    proof = so.prove(ores.rows, pub)
+    assert so.verify(proof) == 0 and rt.verify(proof) == 0
+    lay = stark.proof_layout(proof)
+    assert lay["mode"] == 4 and lay["rom_mult"] - lay["hash_section"] > 100                  # the tape is there
+    rng = np.random.default_rng(2026)
+    codes = {}
+    for trial in range(600):
+        where = trial % 3
+        pos = int(rng.integers(lay["mem_section"], lay["rom_mult"])) if where == 0 else int(rng.integers(0, lay["trace_root"])) if where == 1 else int(rng.integers(0, len(proof)))
+        t = proof.copy()
+        old = int(t[pos])
+        new = [0, 1, 1 << 16, 1 << 20, so.P - 1, 0xFFFFFFFF, (old + 1) % so.P, int(rng.integers(0, so.P))][int(rng.integers(0, 8))]
+        if new == old:
+            continue
+        t[pos] = new
+        a, b = so.verify(t), rt.verify(t)
+        assert a != 0 and b != 0, ("a mutated proof was accepted", pos, old, new, a, b)
+        assert a == b, ("the verifiers disagree", pos, old, new, a, b)
+        codes[a] = codes.get(a, 0) + 1
+    assert len(codes) >= 4                                                                     # format, section, constraint and Merkle / FRI rejections were all exercised
+    # truncations: every prefix length around the section boundaries is refused by both, alike
+    for cut in (lay["mem_section"] + 1, lay["hash_section"], lay["hash_section"] + 1, lay["hash_section"] + 9, lay["rom_mult"] - 1, len(proof) - 1):
+        a, b = so.verify(proof[:cut]), rt.verify(proof[:cut])
+        assert a != 0 and a == b, (cut, a, b)

@@ -62,10 +62,11 @@ inline int parse_section(const uint32_t* w, size_t avail, uint64_t n_real, uint6
   if (nh > n_real) return 56;
   size_t q = 1;
   std::vector<uint64_t> addrs;
-  calls.resize(nh);
+  calls.reserve(std::min(nh, avail / 28));                      // (a record is at least 8 + 4 x 5 words: a forged count cannot make the parser allocate beyond what the proof holds)
   for (size_t k = 0; k < nh; k++) {
     if (q + 8 > avail) return 4;
     const uint32_t* c = w + q;
+    calls.emplace_back();
     Call& hc = calls[k];
     if (c[1] >= (1u << 20) || c[2] >= (1u << 20) || c[4] >= (1u << 20) || c[5] >= (1u << 20)) return 56;
     hc.cycle = c[0]; hc.in_ptr = (uint64_t)c[1] | ((uint64_t)c[2] << 20); hc.len = c[3]; hc.out_ptr = (uint64_t)c[4] | ((uint64_t)c[5] << 20); hc.kind = c[6];
