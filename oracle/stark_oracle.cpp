@@ -271,10 +271,28 @@ enum { C_KMU = 276, C_MA = 277, C_ME = 281 };
 // cell and states that no store ever writes its low half: 306 iws, 307 nb with nb = delta iws, delta = (cell address - B) as a field element (B = the boundary cell, a public
 // constant of the program; CODE_BASE when there is none), and tl (kst - nb) = 0 with tl = the sum of the windows that touch bytes 0..3 — a store with such a window needs
 // delta != 0.  (Cells with address = B modulo p — 2^9 of the 2^37 cells — are refused with it: stated.)  Loads of the code word stay possible; cells INSIDE the code stay refused.
+// (d) the WIDE TAPE (round 6, second half): the five wide opcodes on operands with bits ABOVE 40 — the reference computes them on the raw 64-bit registers (`as i64`, 128-bit
+// products: quirks Q2 / Q3; a sign-extended LB result, an LD, a 64-bit input) — are proven like the hash calls: column 131 ot = "this wide row is proven through the tape"
+// (the class is om + od + orr + ot; the chunk relation is gated by om + od + orr alone), the proof carries one record (cycle, rs1's three limbs, rs2's, the opcode) per such row,
+// the VERIFIER computes the result with the reference's own semantics (wide_result below) and the row looks its tuple (cycle, rs1, rs2, rd's new value, opcode) up:
+// WW (alpha - fp - 13 lambda^11) = ot, WW in the four padding columns beside HH.  Any wide row MAY take the tape (sound either way: the verifier recomputes it); the honest
+// prover takes it exactly when an operand has bits above 40, so proofs stay canonical.  With it EVERY run of the VM has a mode-4 statement for every opcode it executes.  The
+// class "other" does not exist in mode 4 — no opcode is left in it — and ITS COLUMN (131) is ot there: no column is added, no committed position moves (308 logical, 288 committed).
 static const int W_MAIN_WIDE = 308, W_MAX = 308;
-enum { C_OM = 284, C_OD = 285, C_ORR = 286, C_GF = 287, C_WE = 291, C_X = 300, C_IWS = 306, C_NB = 307 };
-static const int K_WA = 22, N_X = 6, N_WE = 9, TAG_HASH = 12;
+enum { C_OM = 284, C_OD = 285, C_ORR = 286, C_GF = 287, C_WE = 291, C_X = 300, C_IWS = 306, C_NB = 307, C_OT = 131 /* = C_K + K_OTH: the class column "other", re-used (mode 4 has no such class) */ };
+static const int K_WA = 22, N_X = 6, N_WE = 9, TAG_HASH = 12, TAG_WIDE = 13;
 static inline bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
+// what MULH 3 / DIVU 4 / REMU 5 / DIV 6 / REM 7 write, on the raw 64-bit registers (execute.rs:101-183): MULH = bits 40..79 of the 128-bit product; DIVU / REMU unsigned;
+// DIV / REM on `as i64` with wrapping_div / wrapping_rem (i64::MIN / -1 = i64::MIN, remainder 0).  b = 0 never is a row of a division (the VM stops with DivisionByZero).
+static inline uint64_t wide_result(uint32_t op, uint64_t a, uint64_t b) {
+  if (op == 0x03) return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 40) & ((1ull << 40) - 1);
+  if (b == 0) return 0;
+  if (op == 0x04) return a / b;
+  if (op == 0x05) return a % b;
+  const int64_t sa = (int64_t)a, sb = (int64_t)b;
+  const bool ovf = sa == INT64_MIN && sb == -1;
+  return op == 0x06 ? (ovf ? (uint64_t)INT64_MIN : (uint64_t)(sa / sb)) : (ovf ? 0 : (uint64_t)(sa % sb));
+}
 static const int K_MU = 20;
 static const uint32_t OP_MUL = 0x02;
 enum { C_KSH = 244, C_UL = 245, C_UR = 250, C_V = 255, C_SA = 265, C_SI = 266, C_SB9 = 267, C_SGN = 268, C_PR = 269, C_ON = 273, C_SH = 275 };
@@ -327,7 +345,7 @@ template <class V>
 static void to_logical_row(const V* phys, int mode, const V& zero, V* logical) {
   for (int c = 0; c < W_MAX; c++) logical[c] = is_virtual(c, mode) ? zero : phys[phys_col(c, mode)];
 }
-enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96, A_HH = 120 };
+enum { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96, A_HH = 120, A_WW = 124 };
 // (mode 3) the lookup tables beside the 10-bit range table (no tag) and the ROM (tag 1) / tapes (2, 3): LOW3 = {(v, v & 7)}, v < 2^10 (tag 4: the first range chunk of a
 // memory row is looked up HERE, with the window's offset — the address's low three bits), BYTE = {v < 2^8} (tag 5), NIBBLE = {v < 2^4} (tag 6); memory tuples carry tag 7
 static const int TAG_LOW3 = 4, TAG_BYTE = 5, TAG_NIB = 6, TAG_MEM = 7, TAG_AND = 8, TAG_OR = 9, TAG_XOR = 10;   // (8-10: the nibble tables {(a, b, a op b)} of the bitwise opcodes)
@@ -379,6 +397,9 @@ struct Public {
   // order, each with its bytes BEFORE the call and the time of its previous access
   struct HashCall { uint64_t cycle, in_ptr, len, out_ptr; uint32_t kind; std::vector<Cell> cells; };
   std::vector<HashCall> hcalls;
+  // ---- mode 4: the wide tape — the wide-arithmetic rows whose operands have bits above 40, in order: the row's cycle, rs1, rs2 (raw 64 bits), the opcode 3..7
+  struct WideRec { uint64_t cycle, a, b; uint32_t op; };
+  std::vector<WideRec> wrecs;
   // ---- prover parameters (round 5): FRI queries and grinding bits, 0 = the defaults.  Carried in the header (words 4 and 6) and observed by the transcript with it.
   uint32_t fri = 0;          // num_queries | pow_bits << 16
   int num_queries() const { return (fri & 0xFFFF) ? (int)(fri & 0xFFFF) : 50; }
@@ -492,7 +513,8 @@ static inline void reg_limbs(uint64_t v, uint8_t st, F out[3]) {
 }
 
 // col-major out[W_MAIN][N]
-static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out, std::vector<Public::Cell>* cells_out = nullptr, std::vector<Public::HashCall>* hcalls_out = nullptr) {
+static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, std::vector<F>& out, std::vector<Public::Cell>* cells_out = nullptr, std::vector<Public::HashCall>* hcalls_out = nullptr,
+                       std::vector<Public::WideRec>* wrecs_out = nullptr) {
   const int log_n = padded_log_n(n_real);
   const size_t N = (size_t)1 << log_n;
   const int mode = pub.mode();
@@ -503,6 +525,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
   std::map<uint64_t, std::pair<uint64_t, uint32_t>> memory;           // mode 3: the replayed memory, cell address -> (bytes, time of the last access); untouched cells hold the program image
   const uint64_t Bcell = boundary_cell(pub.blob, pub.blob_len);       // (mode 4)
   if (hcalls_out) hcalls_out->clear();
+  if (wrecs_out) wrecs_out->clear();
   for (size_t i = 0; i < N; i++) {
     const bool pad = i >= n_real;
     const PackedRow& r = rows[pad ? n_real - 1 : i];
@@ -611,6 +634,15 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
       y[0] = (F)(res & 0xFFFFF); y[1] = (F)(res >> 20); y[2] = 0;
       rd = fa;
     }
+    if (cls == K_WA && (xb[2] || xc[2])) {                    // (mode 4 d) an operand with bits above 40: the row is proven through the WIDE TAPE — ot = 1, every chunk column zero,
+      sh_row = true;                                          // the verifier computes what is written from the record (cycle, rs1, rs2, opcode) the proof carries
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20) | ((uint64_t)xb[2] << 40), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20) | ((uint64_t)xc[2] << 40);
+      const uint64_t res = wide_result(op, a, b);
+      col(C_OT)[i] = 1;
+      y[0] = (F)(res & 0xFFFFF); y[1] = (F)((res >> 20) & 0xFFFFF); y[2] = (F)(res >> 40);
+      rd = fa;
+      if (wrecs_out) wrecs_out->push_back(Public::WideRec{r.cycle, a, b, op});
+    } else
     if (cls == K_WA) {                                        // (mode 4) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI in 10-bit chunks
       sh_row = true;                                          // (R0..R3 = LO's chunks, R4..R7 = F1's)
       const uint64_t M40 = (1ull << 40) - 1;
@@ -861,7 +893,7 @@ static inline F row_kmem(const std::vector<F>& M, size_t N, size_t i) { return M
 static const int MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE, LG_BASE = RC_TABLE + 256 + 16, L6_BASE = LG_BASE + 3 * 256;   // .. ++ AND (256: entry 16 a + b) ++ OR ++ XOR ++ LOW6 (1024: entry v = the tuple (v, v & 63))
 static inline bool row_shift(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0; }
 static inline bool row_mul(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KMU * N + i] != 0; }
-static inline bool row_wide(const std::vector<F>& M, size_t N, size_t i, int mode) { return mode == 4 && (M[(size_t)C_OM * N + i] | M[(size_t)C_OD * N + i] | M[(size_t)C_ORR * N + i]) != 0; }
+static inline bool row_wide(const std::vector<F>& M, size_t N, size_t i, int mode) { return mode == 4 && (M[(size_t)C_OM * N + i] | M[(size_t)C_OD * N + i] | M[(size_t)C_ORR * N + i] | M[(size_t)C_OT * N + i]) != 0; }
 static inline bool row_shift_reg(const std::vector<F>& M, size_t N, size_t i) { return M[(size_t)C_KSH * N + i] != 0 && M[(size_t)C_SI * N + i] == 0; }
 // the table a piece slot looks its value up in on a SHIFT row: 0-6 the 10-bit range table, 7 the nibble table, 8 LOW6 (with the amount) when the amount comes from a register
 static inline int shift_piece_tag(int k, bool reg) { return k == 7 ? TAG_NIB : (k == 8 && reg) ? TAG_LOW6 : 0; }
@@ -961,6 +993,29 @@ static inline E hash_fingerprint(const F e[11], const LookupParams& lp) {
   E fp = emul_f(lp.lam[N_TUPLE], (F)TAG_HASH);
   for (int j = 0; j < 11; j++) fp = eadd(fp, emul_f(lp.lam[j], e[j]));
   return fp;
+}
+// (mode 4 d) a wide-tape tuple: (cycle, rs1's limbs, rs2's limbs, the written value's limbs, opcode), tag 13
+static inline E wide_fingerprint(const F e[11], const LookupParams& lp) {
+  E fp = emul_f(lp.lam[N_TUPLE], (F)TAG_WIDE);
+  for (int j = 0; j < 11; j++) fp = eadd(fp, emul_f(lp.lam[j], e[j]));
+  return fp;
+}
+static inline void wide_tuple(const Public::WideRec& c, F e[11]) {
+  F l[3];
+  e[0] = (F)(c.cycle % P);
+  io_limbs(c.a, l); e[1] = l[0]; e[2] = l[1]; e[3] = l[2];
+  io_limbs(c.b, l); e[4] = l[0]; e[5] = l[1]; e[6] = l[2];
+  io_limbs(wide_result(c.op, c.a, c.b), l); e[7] = l[0]; e[8] = l[1]; e[9] = l[2];     // what the reference writes: computed HERE, by whoever forms the table side
+  e[10] = (F)c.op;
+}
+// the wide tape's share of the table side: + 1 / (alpha - fp(record)) per record (its row looks it up)
+static E wide_table_sum(const Public& pub, const LookupParams& lp) {
+  std::vector<E> d;
+  for (const Public::WideRec& c : pub.wrecs) { F e[11]; wide_tuple(c, e); d.push_back(esub(lp.alpha, wide_fingerprint(e, lp))); }
+  batch_einv(d);
+  E T = e_from(0);
+  for (const E& x : d) T = eadd(T, x);
+  return T;
 }
 // (mode 4) the hash calls' share of the table side: + 1 / (alpha - fp(call)) per call (its ECALL row looks it up), and the call's memory accesses, which no row states:
 // - [1 / (alpha - fp(cell, told, old bytes)) - 1 / (alpha - fp(cell, cycle + 1, new bytes))] per touched cell (what a row would have added on the row side as HMR - HMW)
@@ -1073,6 +1128,12 @@ static void aux_trace(const std::vector<F>& M, size_t N, const LookupParams& lp,
       for (int c = 0; c < 4; c++) A[(size_t)(A_HH + c) * N + i] = h.c[c];
       hs = eadd(hs, h);
     }
+    if (WIDE && at(C_OT)) {                                   // (mode 4 d) WW = ot / (alpha - fp(cycle, rs1, rs2, rd's new value, opcode)): the row's record is in the wide tape
+      F e[11] = {at(C_CYCLE), at(C_XB), at(C_XB + 1), at(C_XB + 2), at(C_XC), at(C_XC + 1), at(C_XC + 2), at(C_Y), at(C_Y + 1), at(C_Y + 2), at(C_OP)};
+      const E h = einv(esub(lp.alpha, wide_fingerprint(e, lp)));
+      for (int c = 0; c < 4; c++) A[(size_t)(A_WW + c) * N + i] = h.c[c];
+      hs = eadd(hs, h);
+    }
     if (WIDE) for (int k = 0; k < N_X; k++) {                 // (mode 4) XH_k = 1 / (alpha - X_k), on every row
       const E h = einv(esub(lp.alpha, e_from(at(C_X + k))));
       for (int c = 0; c < 4; c++) A[(size_t)(A_X + 4 * k + c) * N + i] = h.c[c];
@@ -1153,6 +1214,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E op = loc[C_OP], fa = loc[C_FA], fb = loc[C_FB], fc = loc[C_FC], fhi = loc[C_FHI], s = loc[C_S], se = loc[C_SE];
   E K[N_CLASS];
   for (int k = 0; k < N_CLASS; k++) K[k] = loc[kcol(k)];
+  if (pub.has_wide()) K[K_OTH] = e_from(0);                                // (mode 4) no class "other": its column is ot, the wide-tape selector (block 25)
   // 1. cycle counter, first row, last executed row
   push(emul(esub(esub(nxt[C_CYCLE], loc[C_CYCLE]), one), is_trans));
   for (int i = 0; i < N_STATE; i++) push(emul(esub(loc[state_col(i)], cst(pub.first[i])), is_first));   // row 0 is in the public first state
@@ -1174,7 +1236,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
   const E Klg = MEM ? loc[C_KLG] : e_from(0);                                                             // (mode 3) the bitwise opcodes
   const E Kmu = MEM ? loc[C_KMU] : e_from(0);                                                             // (mode 3) MUL
   const E Ksh = MEM ? loc[C_KSH] : e_from(0);                                                             // (mode 3) the shifts
-  const E Kwa = WIDE ? eadd(eadd(loc[C_OM], loc[C_OD]), loc[C_ORR]) : e_from(0);                          // (mode 4) MULH DIVU REMU DIV REM: kwa = om + od + orr (no column of its own)
+  const E Kin = WIDE ? eadd(eadd(loc[C_OM], loc[C_OD]), loc[C_ORR]) : e_from(0);                          // (mode 4) MULH DIVU REMU DIV REM by the chunk relation: om + od + orr
+  const E Kwa = WIDE ? eadd(Kin, loc[C_OT]) : e_from(0);                                                  // .. the class: kwa = om + od + orr + ot (ot: through the wide tape); no column of its own
   { E sum = eadd(eadd(eadd(eadd(eadd(Kec, Kmem), Klg), Ksh), Kmu), Kwa); for (int k = 0; k < N_CLASS; k++) sum = eadd(sum, K[k]); push(esub(sum, one)); }
   {
     E ks = eadd(eadd(eadd(eadd(eadd(emul_f(Kec, (F)K_ECALL), emul_f(Klg, (F)K_LG)), emul_f(Ksh, (F)K_SH)), eadd(emul_f(Kld, (F)K_LD), emul_f(Kst, (F)K_ST))), emul_f(Kmu, (F)K_MU)), emul_f(Kwa, (F)K_WA));
@@ -1365,7 +1428,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     for (int i = 0; i < N_RC; i++) hs = eadd(hs, aloc[A_H + 4 * i + k]);
     if (IO) hs = eadd(hs, eadd(aloc[A_HO + k], aloc[A_HI + k]));
     if (MEM) { for (int i = 0; i < N_PIECE; i++) hs = eadd(hs, aloc[A_P + 4 * i + k]); hs = eadd(hs, esub(aloc[A_HMR + k], aloc[A_HMW + k])); }   // pieces and the read are looked up, the write is PROVIDED (a table entry)
-    if (WIDE) { for (int i = 0; i < N_X; i++) hs = eadd(hs, aloc[A_X + 4 * i + k]); hs = eadd(hs, aloc[A_HH + k]); }   // (mode 4) the six extra range slots, the hash-call lookup
+    if (WIDE) { for (int i = 0; i < N_X; i++) hs = eadd(hs, aloc[A_X + 4 * i + k]); hs = eadd(hs, eadd(aloc[A_HH + k], aloc[A_WW + k])); }   // (mode 4) the six extra range slots, the hash-call lookup
     push(eadd(esub(esub(anxt[A_S + k], aloc[A_S + k]), hs), cst(lp.t_over_n.c[k])));
   }
   // ---- 17. (mode 2, round 4) ECALL rows and the I/O tapes (syscall.rs:94-177).  Appended to the list: modes 0 / 1 stop here. ----
@@ -1584,16 +1647,16 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
     if (WIDE) {
       const E* Rlo = loc + C_RC; const E* Rf = loc + C_RC2; const E* gf = loc + C_GF; const E* we = loc + C_WE; const E* X = loc + C_X;
       const E om = loc[C_OM], od = loc[C_OD], orr = loc[C_ORR], kd = eadd(od, orr);
-      boolean(Kwa); boolean(om); boolean(od); boolean(orr);                                       // (kwa boolean: at most one of the three kinds)
+      boolean(Kwa); boolean(om); boolean(od); boolean(orr);                                       // (kwa boolean: at most one of the four kinds — ot's own boolean is constraint 25)
       for (int k = 0; k < N_WE; k++) boolean(we[k]);
-      push(esub(emul(Kwa, esub(op, emul_f(loc[C_G], 2))), eadd(eadd(emul_f(om, 3), emul_f(od, 4)), emul_f(orr, 5))));   // the opcode: MULH 3, DIVU 4, REMU 5, DIV 6 = 4 + 2 g, REM 7 = 5 + 2 g (g: the word's variant bit, from the ROM)
+      push(esub(emul(Kin, esub(op, emul_f(loc[C_G], 2))), eadd(eadd(emul_f(om, 3), emul_f(od, 4)), emul_f(orr, 5))));   // the opcode: MULH 3, DIVU 4, REMU 5, DIV 6 = 4 + 2 g, REM 7 = 5 + 2 g (g: the word's variant bit, from the ROM)
       push(emul(Kwa, esub(w1, fa)));                                                              // rd = field a
-      push(emul(Kwa, xb[2])); push(emul(Kwa, xc[2]));                                             // the operands are below 2^40 (what makes DIV = DIVU, REM = REMU, MULH the product's bits 40..79)
+      push(emul(Kin, xb[2])); push(emul(Kin, xc[2]));                                             // the chunk relation's operands are below 2^40 (what makes DIV = DIVU, REM = REMU, MULH the product's bits 40..79); wider ones go through the tape (25)
       const E two10 = cst(RC_TABLE);
-      push(emul(Kwa, esub(esub(xc[0], pcs[0]), emul(two10, pcs[1])))); push(emul(Kwa, esub(esub(xc[1], pcs[2]), emul(two10, pcs[3]))));      // F2 = rs2, always
+      push(emul(Kin, esub(esub(xc[0], pcs[0]), emul(two10, pcs[1])))); push(emul(Kin, esub(esub(xc[1], pcs[2]), emul(two10, pcs[3]))));      // F2 = rs2, always
       push(emul(om, esub(esub(xb[0], Rf[0]), emul(two10, Rf[1])))); push(emul(om, esub(esub(xb[1], Rf[2]), emul(two10, Rf[3]))));            // MULH: F1 = rs1
       push(emul(kd, esub(esub(xb[0], Rlo[0]), emul(two10, Rlo[1])))); push(emul(kd, esub(esub(xb[1], Rlo[2]), emul(two10, Rlo[3]))));        // divisions: LO = rs1, the dividend
-      for (int k = 0; k < 4; k++) push(esub(gf[k], emul(Kwa, Rf[k])));                            // gf_k = kwa F1_k
+      for (int k = 0; k < 4; k++) push(esub(gf[k], emul(Kin, Rf[k])));                            // gf_k = (om + od + orr) F1_k
       const E G4[4] = {pcs[7], pcs[8], X[0], X[1]};
       const E c[6] = {pcs[4], eadd(pcs[5], emul(two10, we[0])), eadd(pcs[6], emul(two10, eadd(we[1], emul_f(we[2], 2)))),
                       eadd(X[2], emul(two10, eadd(we[3], emul_f(we[4], 2)))), eadd(X[3], emul(two10, eadd(we[5], emul_f(we[6], 2)))), eadd(X[4], emul(two10, eadd(we[7], emul_f(we[8], 2))))};
@@ -1605,7 +1668,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
           E lin = Rlo[k];
           if (k < 3) lin = eadd(lin, emul(two10, c[k]));
           if (k) lin = esub(lin, c[k - 1]);
-          t = esub(t, emul(Kwa, lin));
+          t = esub(t, emul(Kin, lin));
           if (k == 3) t = esub(t, emul(om, emul(two10, c[3])));
         } else {                                                                                  // high half (MULH): + c_(k-1) = HI_(k-4) + 2^10 c_k (k = 6: 2^10 HI_3); a division has nothing there
           const E hi = k < 6 ? eadd(G4[k - 4], emul(two10, c[k])) : eadd(G4[2], emul(two10, G4[3]));
@@ -1621,7 +1684,7 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
       const E g = eadd(om, orr);
       push(emul(g, esub(y[0], r0))); push(emul(g, esub(y[1], r1)));
       push(emul(od, esub(esub(y[0], Rf[0]), emul(two10, Rf[1])))); push(emul(od, esub(esub(y[1], Rf[2]), emul(two10, Rf[3]))));
-      push(emul(Kwa, y[2]));
+      push(emul(Kin, y[2]));
       // the six extra range slots: XH_i (alpha - X_i) = 1, on every row
       for (int i = 0; i < N_X; i++) {
         E d[4], pr[4];
@@ -1651,6 +1714,21 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
         }
         ext_mul(aloc + A_HH, d, pr);
         push(esub(pr[0], loc[C_FH])); push(pr[1]); push(pr[2]); push(pr[3]);
+      }
+      // ---- 25. (mode 4 d) the wide tape: ot boolean; WW (alpha - fp(cycle, rs1's limbs, rs2's, y's, opcode) - 13 lambda^11) = ot: a wide row outside the chunk relation's domain
+      // writes what the verifier computed from its record
+      {
+        boolean(loc[C_OT]);
+        E d[4], pr[4];
+        const E* tup[10] = {&loc[C_CYCLE], &xb[0], &xb[1], &xb[2], &xc[0], &xc[1], &xc[2], &y[0], &y[1], &y[2]};
+        for (int k = 0; k < 4; k++) {
+          E fp = emul_f(cst(lp.lam[N_TUPLE].c[k]), TAG_WIDE);
+          for (int j = 0; j < 10; j++) fp = eadd(fp, emul_f(*tup[j], lp.lam[j].c[k]));
+          fp = eadd(fp, emul_f(op, lp.lam[10].c[k]));
+          d[k] = esub(cst(lp.alpha.c[k]), fp);
+        }
+        ext_mul(aloc + A_WW, d, pr);
+        push(esub(pr[0], loc[C_OT])); push(pr[1]); push(pr[2]); push(pr[3]);
       }
     }
   }
@@ -1709,6 +1787,16 @@ static void hash_section(const Public& pub, std::vector<uint32_t>& w) {
     for (const Public::Cell& x : c.cells) { w.push_back(x.t); for (int i = 0; i < 4; i++) w.push_back((uint32_t)((x.bytes >> (16 * i)) & 0xFFFF)); }
   }
 }
+// (mode 4 d) the wide tape as a proof section: [n] then per record [cycle] [rs1: limbs of 20, 20, 24 bits] [rs2: likewise] [opcode]
+static void wide_section(const Public& pub, std::vector<uint32_t>& w) {
+  w.push_back((uint32_t)pub.wrecs.size());
+  for (const Public::WideRec& c : pub.wrecs) {
+    w.push_back((uint32_t)c.cycle);
+    w.push_back((uint32_t)(c.a & 0xFFFFF)); w.push_back((uint32_t)((c.a >> 20) & 0xFFFFF)); w.push_back((uint32_t)(c.a >> 40));
+    w.push_back((uint32_t)(c.b & 0xFFFFF)); w.push_back((uint32_t)((c.b >> 20) & 0xFFFFF)); w.push_back((uint32_t)(c.b >> 40));
+    w.push_back(c.op);
+  }
+}
 static void put_u64(std::vector<uint32_t>& w, uint64_t v) { for (int i = 0; i < 4; i++) w.push_back((uint32_t)((v >> (16 * i)) & 0xFFFF)); }
 static void io_section(const Public& pub, std::vector<uint32_t>& w) {
   w.push_back((uint32_t)pub.n_in); for (size_t i = 0; i < pub.n_in; i++) put_u64(w, pub.inputs[i]);
@@ -1740,7 +1828,13 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   const int Dm = pub.mode();                                              // 0 default, 1 deferred, 2 default + the I/O argument
   const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
   if (matrix_override) pt.M.assign(matrix_override, matrix_override + (size_t)Wl * N);         // LOGICAL; whatever it holds in uncommitted columns is dropped
-  else main_trace(rows, pub.n_real, pub, pt.M, &pub.cells, &pub.hcalls);                                   // (mode 3: with the touched cells; an override brings its own in pub_in.cells)
+  else main_trace(rows, pub.n_real, pub, pt.M, &pub.cells, &pub.hcalls, &pub.wrecs);                                   // (mode 3: with the touched cells; an override brings its own in pub_in.cells)
+  if (matrix_override && Dm == 4) {                                       // (the wide tape of an overridden matrix: read off its ot rows — the prover's tape always matches its rows)
+    pub.wrecs.clear();
+    auto m = [&](int c, size_t i) { return (uint64_t)pt.M[(size_t)c * N + i]; };
+    for (size_t i = 0; i < pub.n_real; i++) if (m(C_OT, i))
+      pub.wrecs.push_back(Public::WideRec{m(C_CYCLE, i), m(C_XB, i) | (m(C_XB + 1, i) << 20) | (m(C_XB + 2, i) << 40), m(C_XC, i) | (m(C_XC + 1, i) << 20) | (m(C_XC + 2, i) << 40), (uint32_t)m(C_OP, i)});
+  }
   for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(pt.M.begin() + (size_t)c * N, pt.M.begin() + (size_t)(c + 1) * N, 0);
   to_physical(pt.M, N, Dm, pt.Mp);
   for (int i = 0; i < N_STATE; i++) {                                     // boundary states: rows 0 and n_real - 1 of the matrix being proven
@@ -1768,6 +1862,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
   if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the tapes and the halt reason: what the io digest is a digest of; (v11) fixed BEFORE the lookup challenges — a SEGMENT's tapes too, whose digest only the chain checks
   if (Dm >= 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // the touched cells, fixed BEFORE the lookup challenges like the multiplicities
   if (Dm == 4) { const size_t at = w.size(); hash_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // (mode 4) the hash calls, likewise
+  if (Dm == 4) { const size_t at = w.size(); wide_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }   // .. and the wide tape
   lookup_multiplicities(pt.M, N, rom, pt.rom_mult, pt.rc_mult, nullptr, Dm, &pt.mem_mult);
   w.insert(w.end(), pt.rom_mult.begin(), pt.rom_mult.end());
   w.insert(w.end(), pt.rc_mult.begin(), pt.rc_mult.end());
@@ -1785,7 +1880,7 @@ static void prove(const PackedRow* rows, const Public& pub_in, Proof& proof, Pro
     E T = lookup_table_sum(rom, pt.rom_mult.data(), pt.rc_mult.data(), pt.lp, Dm >= 3 ? pt.mem_mult.data() : nullptr);
     if (Dm >= 2) T = eadd(T, io_table_sum(pub, pt.lp));
     if (Dm >= 3) T = eadd(T, mem_table_sum(pub, pt.lp));
-    if (Dm == 4) T = eadd(T, hash_table_sum(pub, pt.lp));
+    if (Dm == 4) T = eadd(eadd(T, hash_table_sum(pub, pt.lp)), wide_table_sum(pub, pt.lp));
     pt.lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   // ---- aux trace: helper columns + running sum; its own LDE and commitment ----
@@ -1974,7 +2069,7 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
   const int Wm = phys_width(Dm), Wl = logical_width(Dm), Wa = aux_width(Dm);
   if (threads < 1) threads = 1;
   std::vector<F> M;
-  main_trace(rows, pub.n_real, pub, M, &pub.cells, &pub.hcalls);
+  main_trace(rows, pub.n_real, pub, M, &pub.cells, &pub.hcalls, &pub.wrecs);
   for (int c = 0; c < Wl; c++) if (is_virtual(c, Dm)) std::fill(M.begin() + (size_t)c * N, M.begin() + (size_t)(c + 1) * N, 0);
   for (int i = 0; i < N_STATE; i++) { pub.first[i] = M[(size_t)state_col(i) * N]; pub.last[i] = M[(size_t)state_col(i) * N + (pub.n_real - 1)]; }
   if (Dm >= 2) for (int k = 0; k < 2; k++) { pub.cnt_first[k] = M[(size_t)(C_OC + k) * N]; pub.cnt_last[k] = M[(size_t)(C_OC + k) * N + (pub.n_real - 1)]; }
@@ -2002,6 +2097,7 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
   if (Dm >= 2) { const size_t at = w.size(); io_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
   if (Dm >= 3) { const size_t at = w.size(); mem_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
   if (Dm == 4) { const size_t at = w.size(); hash_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
+  if (Dm == 4) { const size_t at = w.size(); wide_section(pub, w); observe_section(ch, w.data() + at, w.size() - at); }
   std::vector<F> rom_mult, rc_mult, mem_mult;
   lookup_multiplicities(M, N, rom, rom_mult, rc_mult, nullptr, Dm, &mem_mult);
   w.insert(w.end(), rom_mult.begin(), rom_mult.end());
@@ -2021,7 +2117,7 @@ static void prove_lean(const PackedRow* rows, const Public& pub_in, Proof& proof
     E T = lookup_table_sum(rom, rom_mult.data(), rc_mult.data(), lp, Dm >= 3 ? mem_mult.data() : nullptr);
     if (Dm >= 2) T = eadd(T, io_table_sum(pub, lp));
     if (Dm >= 3) T = eadd(T, mem_table_sum(pub, lp));
-    if (Dm == 4) T = eadd(T, hash_table_sum(pub, lp));
+    if (Dm == 4) T = eadd(eadd(T, hash_table_sum(pub, lp)), wide_table_sum(pub, lp));
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   std::vector<F> AL((size_t)Wa * N2);
@@ -2326,6 +2422,24 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     hash_len = q - p;
     p = q;
   }
+  // (mode 4 d) the wide tape: records in increasing cycle order, limbs in range, an opcode 3..7, no zero divisor (check 57)
+  const uint32_t* wide_words = nullptr; size_t wide_len = 0;
+  if (mode == 4) {
+    if (!need(1)) return 4;
+    const size_t nw = w[p];
+    if (nw > pub.n_real) return 57;
+    if (!need(1 + 8 * nw)) return 4;
+    wide_words = w + p; wide_len = 1 + 8 * nw;
+    pub.wrecs.resize(nw);
+    for (size_t k = 0; k < nw; k++) {
+      const uint32_t* c = w + p + 1 + 8 * k;
+      if (c[1] >= (1u << 20) || c[2] >= (1u << 20) || c[3] >= (1u << 24) || c[4] >= (1u << 20) || c[5] >= (1u << 20) || c[6] >= (1u << 24) || c[7] < 3 || c[7] > 7) return 57;
+      Public::WideRec& r = pub.wrecs[k];
+      r.cycle = c[0]; r.a = (uint64_t)c[1] | ((uint64_t)c[2] << 20) | ((uint64_t)c[3] << 40); r.b = (uint64_t)c[4] | ((uint64_t)c[5] << 20) | ((uint64_t)c[6] << 40); r.op = c[7];
+      if (r.cycle >= pub.n_real || (k && r.cycle <= pub.wrecs[k - 1].cycle) || (r.op >= 4 && r.b == 0)) return 57;
+    }
+    p += wide_len;
+  }
   if (!need(rom.n + RC_TABLE + (mode >= 3 ? MEM_MULT : 0))) return 4;
   const F* rom_mult = w + p; p += rom.n;
   const F* rc_mult = w + p; p += RC_TABLE;
@@ -2356,7 +2470,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
   ch.observe_n(troot, 4);
   if (mode >= 2) observe_section(ch, io_words, io.words);
   if (mode >= 3) observe_section(ch, mem_words, mem_len);
-  if (mode == 4) observe_section(ch, hash_words, hash_len);
+  if (mode == 4) { observe_section(ch, hash_words, hash_len); observe_section(ch, wide_words, wide_len); }
   ch.observe_n(rom_mult, rom.n);
   ch.observe_n(rc_mult, RC_TABLE);
   if (mode >= 3) ch.observe_n(mem_mult, MEM_MULT);
@@ -2372,7 +2486,7 @@ static int verify(const uint32_t* w, size_t len, const Public* expect, bool whol
     E T = lookup_table_sum(rom, rom_mult, rc_mult, lp, mem_mult);           // the table side of the lookup identity, computed HERE
     if (mode >= 2) T = eadd(T, io_table_sum(pub, lp));                     // .. its I/O share from the tapes the proof carries
     if (mode >= 3) T = eadd(T, mem_table_sum(pub, lp));                    // .. and both ends of the memory check from the touched cells it carries
-    if (mode == 4) T = eadd(T, hash_table_sum(pub, lp));                   // .. (mode 4) and the hash calls: every digest is computed HERE
+    if (mode == 4) T = eadd(eadd(T, hash_table_sum(pub, lp)), wide_table_sum(pub, lp));   // .. (mode 4) and the hash calls: every digest is computed HERE — and the wide tape: every result likewise
     lp.t_over_n = emul_f(T, finv((F)(N % P)));
   }
   ch.observe_n(aroot, 4);
@@ -2922,7 +3036,13 @@ size_t so_failing_constraints(const uint32_t* matrix, const so_public* pub, cons
   so::E T = so::lookup_table_sum(rom, rm.data(), cm.data(), lp, mode >= 3 ? mm.data() : nullptr);
   if (mode >= 2) T = so::eadd(T, so::io_table_sum(q, lp));
   if (mode >= 3) T = so::eadd(T, so::mem_table_sum(q, lp));
-  if (mode == 4) { q.hcalls = g_hcalls; T = so::eadd(T, so::hash_table_sum(q, lp)); }
+  if (mode == 4) {                                                           // (the wide tape: read off the matrix's own ot rows, like so::prove does for an overridden matrix)
+    q.hcalls = g_hcalls; T = so::eadd(T, so::hash_table_sum(q, lp));
+    auto m = [&](int c, size_t i) { return (uint64_t)M[(size_t)c * N + i]; };
+    for (size_t i = 0; i < q.n_real; i++) if (m(so::C_OT, i))
+      q.wrecs.push_back(so::Public::WideRec{m(so::C_CYCLE, i), m(so::C_XB, i) | (m(so::C_XB + 1, i) << 20) | (m(so::C_XB + 2, i) << 40), m(so::C_XC, i) | (m(so::C_XC + 1, i) << 20) | (m(so::C_XC + 2, i) << 40), (uint32_t)m(so::C_OP, i)});
+    T = so::eadd(T, so::wide_table_sum(q, lp));
+  }
   lp.t_over_n = so::emul_f(T, so::finv((so::F)(N % so::P)));
   so::aux_trace(M, N, lp, A, mode);
   const int NC = so::num_constraints(mode);

@@ -86,7 +86,14 @@ WIDE_LOOP = blob([i_(ADDI, 1, 0, 12345), i_(ADDI, 2, 0, 0x2545), i_(SLLI, 2, 2, 
                   r_(MULH, 4, 1, 1), r_(DIVU, 5, 1, 3), r_(REMU, 7, 1, 3), r_(DIV, 8, 4, 3), r_(REM, 9, 4, 3), r_(MULH, 10, 5, 3),
                   r_(XOR, 12, 12, 4), r_(XOR, 12, 12, 5), r_(XOR, 12, 12, 7), r_(XOR, 12, 12, 8), r_(XOR, 12, 12, 9), r_(XOR, 12, 12, 10),
                   s_(SD, 6, 12, 0), i_(LD_, 13, 6, 0), j_(JAL, 0, -72)])
+# (mode 4, the wide tape) the wide opcodes on raw 64-bit registers: a sign-extended byte divided, reduced and multiplied (the product ships it as spec.signed_division_loop_program)
+SB_, LB_, ANDI_ = 0x38, 0x30, 0x13
+TAPE_LOOP = blob([i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(ADDI, 1, 0, 0x95),
+                  s_(SB_, 6, 1, 0), i_(LB_, 2, 6, 0), i_(ANDI_, 3, 1, 0x3F), i_(ADDI, 3, 3, 7),
+                  r_(DIV, 4, 2, 3), r_(REM, 5, 2, 3), r_(DIVU, 7, 2, 3), r_(MULH, 8, 2, 2), r_(REMU, 9, 3, 2), r_(DIV, 10, 3, 2),
+                  i_(ADDI, 1, 1, 3), j_(JAL, 0, -44)])
 MODE_CASES = [
+    dict(name="mode4_signed_division_loop_700", blob=TAPE_LOOP, max_cycles=700, mode=4),
     dict(name="mode4_wide_loop_1000", blob=WIDE_LOOP, max_cycles=1000, mode=4),
     dict(name="mode4_memory_loop_40", blob=MEM_LOOP, max_cycles=1_000_000, mode=4),
     dict(name="mode2_fib30", blob=FIB30, max_cycles=1_000_000, mode=2),

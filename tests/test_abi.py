@@ -351,7 +351,7 @@ def test_memcheck_witness_and_main_trace_mode3_match_oracle_on_the_host(name):
 
 # ---- MODE 4 (round 6): mode 3 + the wide-arithmetic class MULH / DIVU / REMU / DIV / REM — the product's host-side pieces against the oracle (no GPU) ------------------------
 def test_air_bounds_mode4():
-    """The quotient kernel's lazy arithmetic is sound on the mode-4 constraint list (707 constraints) too (air::BoundOps on air::eval)."""
+    """The quotient kernel's lazy arithmetic is sound on the mode-4 constraint list (712 constraints) too (air::BoundOps on air::eval)."""
     import ctypes as C
     L = rt.lib()
     why = C.create_string_buffer(256)
@@ -361,7 +361,7 @@ def test_air_bounds_mode4():
 
 
 def test_quotient_evaluation_matches_oracle_constraints_mode4():
-    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 4: 308 logical / 128 aux columns, 707 constraints (the
+    """air::eval under the quotient kernel's arithmetic (host build) against the oracle's constraints_sum in MODE 4: 308 logical / 128 aux columns, 712 constraints (the
     boundary cell's address enters through two lookup parameters, LK_B0 / LK_B1: the oracle derives it from the program, here fib(5)'s 19 code words: code_size % 8 == 4)."""
     import ctypes as C
     import numpy as np
@@ -377,7 +377,7 @@ def test_quotient_evaluation_matches_oracle_constraints_mode4():
     virt = [9, 10, 11] + list(range(57, 73)) + [161]
     blob = spec.fib_program(5).to_bytes()
     pub = so.public_inputs(64, blob, [], [5], (1, 0), wide_mode=True)
-    assert LO.so_num_constraints_for(4) == 707 and so.logical_width(4) == 308 and so.aux_width(4) == 128 and so.committed_width(4) == 288
+    assert LO.so_num_constraints_for(4) == 712 and so.logical_width(4) == 308 and so.aux_width(4) == 128 and so.committed_width(4) == 288
     code_size = int.from_bytes(blob[16:20], "little")
     bcell = 0x1000 + code_size - 4 if code_size % 8 == 4 else 0x1000
     for trial in range(40):

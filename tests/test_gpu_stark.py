@@ -576,6 +576,8 @@ def _mode3_case(which, witness="device", wide=False):
     cfg = {}
     if which.startswith("random"):
         blob, ins = pg.random_program(int(which[6:]), hashes=False)
+    elif which == "signed_division_loop":                                 # (mode 4) both routes of the wide class: sign-extended bytes (the tape) and small ones (the chunk relation)
+        blob, ins, cfg = spec.signed_division_loop_program().to_bytes(), [], dict(max_cycles=3000)
     elif which == "memloop":                                              # a loop that walks an array: store i * 3 at A + 8 i, load it back as bytes / halfwords / words, sum, WRITE the sum
         blob, ins = spec.memory_loop_program(200).to_bytes(), []
     elif which.endswith("_on_code"):                                      # the reference's test as written: its data at 0x1000, the first code word
@@ -617,12 +619,12 @@ def test_mode3_proof_bytes_match_oracle_and_verify(which, witness):
     ctx.close(); log.close()
 
 
-# ---- MODE 4 (round 6): mode 3 + MULH / DIVU / REMU / DIV / REM on operands below 2^40 -----------------------------------------------------------------------
+# ---- MODE 4 (round 6): mode 3 + MULH / DIVU / REMU / DIV / REM (chunk relation below 2^40, the wide tape above), hash syscalls as a tape, the boundary cell -----------------------------------------------------------------------
 @pytest.mark.parametrize("witness", ["device", "host"])
 @pytest.mark.parametrize("which", ["wide_grid", "alu_all", "timestamps", "mul_grid", "random3", "random5", "memloop", "fib30", "sha_chain_small", "sha256_hello", "hashes_all",
-                                   "blake3_multi_chunk"])
+                                   "blake3_multi_chunk", "loads_stores", "signed_division_loop"])
 def test_mode4_proof_bytes_match_oracle_and_verify(which, witness):
-    """A proof in mode 4 (format v12: 288 + 128 columns, 707 constraints) — the five wide opcodes constrained as F1 F2 + ADD = LO + 2^40 HI over 10-bit chunks, hash syscalls as
+    """A proof in mode 4 (format v12: 288 + 128 columns, 712 constraints) — the five wide opcodes constrained as F1 F2 + ADD = LO + 2^40 HI over 10-bit chunks, hash syscalls as
     a tape whose digests the verifier computes (configs[4]'s SHA-256 chain, the reference's SHA-256 / Keccak-256 / BLAKE3 tests: proven from the host witness — a "device"
     request is switched over), the boundary cell (the chain program reads its seed from it), everything of mode 3 beside them — from the GPU prover equals the oracle's word
     for word; both verifiers accept it and give the same verdict on tampered copies."""
@@ -644,28 +646,37 @@ def test_mode4_proof_bytes_match_oracle_and_verify(which, witness):
     ctx.close(); log.close()
 
 
-def test_mode4_refuses_wide_operands_above_40_bits():
-    """The five wide opcodes are stated on operands below 2^40 (what makes DIV = DIVU, REM = REMU and MULH the product's bits 40..79: quirks Q2, Q3 on raw 64-bit registers
-    are outside the AIR).  A run that divides a register sign-extended by LB (0xFFFF...FF80) has no mode-4 proof: the GPU prover refuses it naming the row, and both verifiers
-    reject the oracle's proof of it at the constraint check (I_WA_TOP)."""
+def test_mode4_wide_tape_raw_64_bit_operands():
+    """The wide tape on the GPU: a run that divides and multiplies RAW 64-bit registers — a byte sign-extended by LB (0xFFFF...FF80), 64-bit inputs that arrive by READ, i64::MIN
+    / -1 — has a mode-4 proof, equal to the oracle's word for word: the row builder marks the rows (ot), lookup_index_kernel appends their records, the host sorts them by
+    cycle, computes the reference's results (air::wide_result) for the table side and scatters the helpers WW.  The tape the proof carries holds exactly those rows; a tampered
+    record is rejected by both verifiers alike."""
     from zkir_amd import pipeline as pl, stark
     import programs as pg
     O, E = spec.Opcode, spec.encode
-    blob = pg._p([pg.A(5, 0, 0x4000), pg.A(1, 0, 0x80), E(O.SB, rs1=5, rs2=1, imm=0), E(O.LB, 2, 5, imm=0), pg.A(3, 0, 7), E(O.DIVU, 4, 2, 3), E(O.MULH, 6, 3, 2), pg.EB])
-    ores = oracle.run(blob, [], enable_execution_trace=True)
-    log = rt.interpret(blob, [], rt.VMConfig(enable_execution_trace=True))
+    vals = [0xFFFFFFFFFFFFFF80, 0x8000000000000000, 0xFFFFFFFFFFFFFFFF, 0x7FFFFFFFFFFFFFFF, 0x0000010000000000, 0x123456789ABCDEF0, 0xFF, 3]
+    regs = [1, 2, 3, 4, 9, 14, 15, 7]
+    code = [pg.A(5, 0, 1)]
+    for r in regs:
+        code += [pg.A(10, 0, 1), pg.EC, E(O.CMOV, r, 10, 5)]                                       # READ leaves the raw 64 bits in r10; CMOV copies them
+    body = [E(op, 8, regs[a], regs[b]) for a in range(8) for b in range(8) for op in (O.MULH, O.DIVU, O.REMU, O.DIV, O.REM)]
+    blob = pg._p(code + body + [pg.EB])
+    ores = oracle.run(blob, vals, enable_execution_trace=True)
+    log = rt.interpret(blob, vals, rt.VMConfig(enable_execution_trace=True))
     ddl = pl.upload(log); tr = pl.DeviceTrace(ddl); pl.trace_fill(pl.trace_fill_args(ddl, tr))
-    opub = so.public_inputs(len(ores.rows), blob, [], list(ores.outputs), (ores.halt_kind, ores.halt_code), wide_mode=True)
-    pub = rt.public_inputs(log, blob, [], wide_mode=True)
+    opub = so.public_inputs(len(ores.rows), blob, vals, list(ores.outputs), (ores.halt_kind, ores.halt_code), wide_mode=True)
+    pub = rt.public_inputs(log, blob, vals, wide_mode=True)
     ctx = stark.StarkContext(stark.padded_log_n(len(ores.rows)))
-    with pytest.raises(rt.RuntimeError) as e:
-        stark.prove(ctx, tr, pub)
-    assert e.value.code == rt.ERR_ARGUMENT and "row 5" in e.value.message and "bits above 40" in e.value.message
+    proof = stark.prove(ctx, tr, pub)
     want = so.prove(ores.rows, opub)
-    assert so.verify(want, opub) == 10 and rt.verify(want) == 10
-    # the same run in mode 3 (the five opcodes free, class "other") has a proof
-    pub3 = rt.public_inputs(log, blob, [], mem_mode=True)
-    assert rt.verify(stark.prove(ctx, tr, pub3), pub3) == 0
+    assert np.array_equal(proof, want)
+    assert so.verify(proof, opub) == 0 and rt.verify(proof, pub) == 0
+    lay = stark.proof_layout(proof)
+    w0 = lay["wide_section"]
+    n = int(proof[w0])
+    assert n >= 5 * 60 and all(int(proof[w0 + 1 + 8 * k]) < int(proof[w0 + 1 + 8 * (k + 1)]) for k in range(n - 1))      # nearly the whole grid, in cycle order
+    t = proof.copy(); t[w0 + 1 + 8 * (n // 2) + 2] ^= 1
+    assert so.verify(t) != 0 and rt.verify(t) == so.verify(t)
     ctx.close(); log.close()
 
 

@@ -78,6 +78,7 @@ def test_mode_goldens_describe_the_shipped_programs():
     assert bytes.fromhex(MODE_CASES["mode3_fib30"]["program_blob_hex"]) == spec.fib_program(30).to_bytes()
     assert [MODE_CASES[n]["committed_width"] for n in ("mode2_fib30", "mode3_fib30")] == [so.committed_width(2), so.committed_width(3)] == [160, 264]
     assert bytes.fromhex(MODE_CASES["mode4_wide_loop_1000"]["program_blob_hex"]) == spec.wide_loop_program().to_bytes() and MODE_CASES["mode4_wide_loop_1000"]["committed_width"] == so.committed_width(4) == 288
+    assert bytes.fromhex(MODE_CASES["mode4_signed_division_loop_700"]["program_blob_hex"]) == spec.signed_division_loop_program().to_bytes()      # (the wide tape: raw 64-bit operands)
 
 
 @pytest.mark.parametrize("name", sorted(MODE_CASES))

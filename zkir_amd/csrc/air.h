@@ -113,10 +113,33 @@ enum : int { C_KLD = 180, C_KST = 181, C_E = 182, C_OB = 197, C_TOLD = 205, C_PI
              // (c) the BOUNDARY CELL (code_size % 8 == 4: the last code word and the first four data bytes share a cell): admitted here, with "no store writes its low half":
              // iws, nb with nb = delta iws, delta = the row's cell address minus B as ONE field element (B: LK_B0 / LK_B1, a constant of the program), and tl (kst - nb) = 0 with
              // tl = the windows that touch bytes 0..3.
-             C_OM = 284, C_OD = 285, C_ORR = 286, C_GF = 287, C_WE = 291, C_X = 300, C_IWS = 306, C_NB = 307 };
-constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, K_WA = 22, N_WIN = 15, N_PIECE = 9, N_NIB = 10, N_X = 6, N_WE = 9, TAG_HASH = 12;
+             // (d) the WIDE TAPE: the five wide opcodes on operands with bits ABOVE 40 (the reference computes them on the raw 64-bit registers: `as i64`, 128-bit products — a
+             // sign-extended LB result, an LD, a 64-bit input) are proven like the hash calls.  ot = "this wide row goes through the tape": the class is om + od + orr + ot, the
+             // chunk relation is gated by om + od + orr alone; the proof carries one record (cycle, rs1's three limbs, rs2's, the opcode) per such row, the VERIFIER computes the
+             // result with the reference's semantics (wide_result) and the row looks (cycle, rs1, rs2, rd's new value, opcode) up: WW (alpha - fp - 13 lambda^11) = ot, WW in the
+             // four padding columns beside HH.  The honest prover takes the tape exactly when an operand has bits above 40 (canonical proofs); any wide row MAY (sound: the
+             // verifier recomputes it).  Class "other" does not exist in mode 4 — no opcode is left in it — and ITS COLUMN is ot there: no column is added, no committed position moves.
+             C_OM = 284, C_OD = 285, C_ORR = 286, C_GF = 287, C_WE = 291, C_X = 300, C_IWS = 306, C_NB = 307, C_OT = 131 /* = kcol(K_OTH), re-used */ };
+constexpr int K_LD = 16, K_ST = 17, K_LG = 18, K_SH = 19, K_MU = 20, K_WA = 22, N_WIN = 15, N_PIECE = 9, N_NIB = 10, N_X = 6, N_WE = 9, TAG_HASH = 12, TAG_WIDE = 13;
 BB_HD constexpr bool is_low_window(int v) { return v <= 3 || v == 8 || v == 9 || v == 12 || v == 14; }   // the windows that touch bytes 0..3 of their cell
 BB_HD constexpr bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
+// what MULH 3 / DIVU 4 / REMU 5 / DIV 6 / REM 7 write, on the raw 64-bit registers (execute.rs:101-183): MULH = bits 40..79 of the 128-bit product; DIVU / REMU unsigned; DIV /
+// REM on `as i64` with wrapping_div / wrapping_rem (i64::MIN / -1 = i64::MIN, remainder 0).  b = 0 never is a row of a division (the VM stops with DivisionByZero).
+BB_HD uint64_t wide_result(uint32_t op, uint64_t a, uint64_t b) {
+  if (op == 0x03) {                                             // (no 128-bit type on the device: the product's bits 40..79 from 32-bit halves)
+    const uint64_t a0 = a & 0xFFFFFFFFull, a1 = a >> 32, b0 = b & 0xFFFFFFFFull, b1 = b >> 32;
+    const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+    const uint64_t mid = (p00 >> 32) + (p01 & 0xFFFFFFFFull) + (p10 & 0xFFFFFFFFull);
+    const uint64_t lo = (p00 & 0xFFFFFFFFull) | (mid << 32), hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+    return ((lo >> 40) | (hi << 24)) & ((1ull << 40) - 1);
+  }
+  if (b == 0) return 0;
+  if (op == 0x04) return a / b;
+  if (op == 0x05) return a % b;
+  const int64_t sa = (int64_t)a, sb = (int64_t)b;
+  const bool ovf = sa == INT64_MIN && sb == -1;
+  return op == 0x06 ? (ovf ? (uint64_t)INT64_MIN : (uint64_t)(sa / sb)) : (ovf ? 0 : (uint64_t)(sa % sb));
+}
 constexpr uint32_t OP_MUL_ = 0x02;
 BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }
 BB_HD constexpr bool is_shift(uint32_t op) { return op >= 0x18 && op <= 0x1D; }
@@ -166,7 +189,7 @@ BB_HD constexpr int logical_col(int p, int mode) {
 // mode 4: + XH0..XH5 (the helpers of the six extra range slots), HH (the hash-call helper), four columns of zero padding (whole blocks of 8)
 constexpr int W_AUX = 40, W_AUX_IO = 48, W_AUX_MEM = 96, W_AUX_WIDE = 128, W_AUX_MAX = 128;
 BB_HD constexpr int aux_width(int mode) { return mode == 4 ? W_AUX_WIDE : mode == 3 ? W_AUX_MEM : mode == 2 ? W_AUX_IO : W_AUX; }
-enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96, A_HH = 120 };
+enum : int { A_H = 0, A_HR = 32, A_S = 36, A_HO = 40, A_HI = 44, A_P = 48, A_HMR = 84, A_HMW = 88, A_FPN = 92, A_X = 96, A_HH = 120, A_WW = 124 };
 constexpr int RC_BITS = 10, RC_TABLE = 1 << RC_BITS, N_TUPLE = 11, N_RC = 8;
 BB_HD constexpr int rc_col(int k) { return k < 4 ? C_RC + k : C_RC2 + (k - 4); }     // the eight range lookups of a row: chunks of z, chunks of u
 // per-proof lookup parameters (base-field words): alpha coordinates, the coordinates of lambda^0 .. lambda^N_TUPLE (= 11), T / N
@@ -195,6 +218,8 @@ BB_HD constexpr bool fri_params_ok(uint32_t fri_params) { return num_queries_of(
 BB_HD constexpr uint32_t proof_version(int mode) { return mode == 4 ? 12u : mode >= 2 ? 11u : 10u; }     // (v12 = mode 4: the wide-arithmetic class)
 constexpr uint64_t CODE_BASE = 0x1000;
 BB_HD constexpr int kcol(int k) { return k < 7 ? C_K + k : k < 11 ? C_K2 + (k - 7) : k < 13 ? C_K3 + (k - 11) : C_K4 + (k - 13); }
+BB_HD constexpr bool class_absent(int k, int mode) { return is_virtual(kcol(k), mode) || (mode == 4 && k == K_OTH); }   // a class no row of the mode has: its selector reads as zero (mode 4: "other" — its column carries ot)
+static_assert(C_OT == kcol(K_OTH), "mode 4 re-uses the class column 'other' as the wide-tape selector");
 constexpr uint32_t OP_ADD = 0x00, OP_SUB = 0x01, OP_ADDI = 0x08, OP_SLTU = 0x20, OP_SGEU = 0x21, OP_SLT = 0x22, OP_SGE = 0x23, OP_SEQ = 0x24, OP_CMOV = 0x26, OP_CMOVZ = 0x27, OP_CMOVNZ = 0x28, OP_SNE = 0x25, OP_BEQ = 0x40, OP_BNE = 0x41,
                    OP_BLT = 0x42, OP_BGE = 0x43, OP_BLTU = 0x44, OP_BGEU = 0x45, OP_JAL = 0x48, OP_JALR = 0x49, OP_ECALL = 0x50, OP_EBREAK = 0x51;
 BB_HD constexpr uint32_t opclass_of(uint32_t op, int mode = 0) {
@@ -237,7 +262,8 @@ enum : int { I_CYCLE = 0, I_CYCLE0 = 1, I_ENTRY = 2, I_ZERO0 = 5, I_HALT = 69, I
              // lookups (24); the boundary cell (2); the hash-call lookup (4)
              I_WA_BOOL = 636, I_WA_OP = 649, I_WA_WR = 650, I_WA_TOP = 651, I_WA_F2 = 653, I_WA_F1 = 655, I_WA_LO = 657, I_WA_GF = 659, I_WA_EQ = 663,
              I_WA_LT = 670, I_WA_Y = 672, I_WA_X = 677, I_BC = 701, I_HH = 703,
-             N_CONSTRAINTS = 707 };
+             I_WT_BOOL = 707, I_WW = 708,                              // the wide tape: ot boolean (1), the record lookup (4)
+             N_CONSTRAINTS = 712 };
 BB_HD constexpr int num_constraints(int mode) { return mode == 4 ? N_CONSTRAINTS : mode == 3 ? N_CONSTRAINTS_MEM : mode == 2 ? N_CONSTRAINTS_IO : N_CONSTRAINTS_BASE; }
 // Boundary states (proof format v4): the 68 state words (cycle, 3 pc limbs, 48 register limbs, 16 storage states) of row 0 and of the
 // last executed row are public; constraint 1 + i pins state word i of row 0, constraint I_LAST + i that of row n_real - 1.
@@ -352,7 +378,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   // every other column of the row pair, read HERE — together, before any of them is used (one memory latency)
   V K[N_CLASS];
 #pragma unroll
-  for (int k = 0; k < N_CLASS; k++) K[k] = is_virtual(kcol(k), mode) ? zero : o.loc(kcol(k));
+  for (int k = 0; k < N_CLASS; k++) K[k] = class_absent(k, mode) ? zero : o.loc(kcol(k));          // (mode 4: no class "other" — its column is ot, the wide-tape selector)
   const V pc[3] = {o.loc(C_PC), o.loc(C_PC + 1), o.loc(C_PC + 2)};
   const V npc[3] = {o.nxt(C_PC), o.nxt(C_PC + 1), o.nxt(C_PC + 2)};
   const V cyc = o.loc(C_CYCLE), ncyc = o.nxt(C_CYCLE), npad = o.nxt(C_K + K_PAD);
@@ -401,7 +427,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   const V z[2] = {o.add(R[0], o.mulc(R[1], M(RC_TABLE))), o.add(R[2], o.mulc(R[3], M(RC_TABLE)))};   // (v6) z IS its chunks: no columns of its own
   // booleans
 #pragma unroll
-  for (int k = 0; k < N_CLASS; k++) { if (!is_virtual(kcol(k), mode)) boolean(I_BOOL_K + k, K[k]); }
+  for (int k = 0; k < N_CLASS; k++) { if (!class_absent(k, mode)) boolean(I_BOOL_K + k, K[k]); }
   boolean(I_BOOL_MISC, s); boolean(I_BOOL_MISC + 1, c0); boolean(I_BOOL_MISC + 2, c1); boolean(I_BOOL_MISC + 3, d0); boolean(I_BOOL_MISC + 4, d1);
   boolean(I_BOOL_MISC + 5, d2); boolean(I_BOOL_MISC + 6, ne); boolean(I_BOOL_MISC + 7, tk); boolean(I_BOOL_MISC + 8, sa); boolean(I_BOOL_MISC + 9, sbit); boolean(I_BOOL_MISC + 10, nz);
   // classes and the opcode
@@ -409,12 +435,13 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
   if (io) { F2 = o.loc(C_F2); RL = o.loc(C_RL); RE = o.loc(C_RE); FH = o.loc(C_FH); H0 = o.loc(C_H0); H1 = o.loc(C_H1); }
   V Kld = zero, Kst = zero, Klg = zero, Ksh = zero, Kmu = zero, Kwa = zero;   // (mode 3) loads, stores, the bitwise opcodes, the shifts, MUL; (mode 4) MULH DIVU REMU DIV REM
   if (mem) { Kld = o.loc(C_KLD); Kst = o.loc(C_KST); Klg = o.loc(C_KLG); Ksh = o.loc(C_KSH); Kmu = o.loc(C_KMU); }
-  if (wide) Kwa = o.add(o.add(o.loc(C_OM), o.loc(C_OD)), o.loc(C_ORR));   // kwa = om + od + orr (no column of its own)
+  V Kin = zero;                                                            // (mode 4) the wide rows proven by the chunk relation: om + od + orr
+  if (wide) { Kin = o.add(o.add(o.loc(C_OM), o.loc(C_OD)), o.loc(C_ORR)); Kwa = o.add(Kin, o.loc(C_OT)); }   // the class: kwa = om + od + orr + ot (ot: through the wide tape); no column of its own
   {
     AccL sum = o.accl(), ks = o.accl();
 #pragma unroll
     for (int k = 0; k < N_CLASS; k++) {
-      if (is_virtual(kcol(k), mode)) continue;
+      if (class_absent(k, mode)) continue;
       o.acc_lin(sum, K[k], 1);
       if (k >= 1 && k != K_HALT && k != K_PAD) o.acc_lin(ks, K[k], (uint32_t)k);
     }
@@ -902,15 +929,15 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       boolean(I_WA_BOOL, Kwa); boolean(I_WA_BOOL + 1, om); boolean(I_WA_BOOL + 2, od); boolean(I_WA_BOOL + 3, orr);     // (kwa boolean: at most one of the three kinds)
 #pragma unroll
       for (int k = 0; k < N_WE; k++) boolean(I_WA_BOOL + 4 + k, we[k]);
-      { AccL a = o.accl(); o.acc_lin(a, om, 3); o.acc_lin(a, od, 4); o.acc_lin(a, orr, 5); o.push(I_WA_OP, o.lsub(o.mul(o.lsub(op, o.add(g, g)), Kwa), o.accl_val(a))); }   // MULH 3, DIVU 4, REMU 5, DIV 6 = 4 + 2 g, REM 7 = 5 + 2 g
+      { AccL a = o.accl(); o.acc_lin(a, om, 3); o.acc_lin(a, od, 4); o.acc_lin(a, orr, 5); o.push(I_WA_OP, o.lsub(o.mul(o.lsub(op, o.add(g, g)), Kin), o.accl_val(a))); }   // MULH 3, DIVU 4, REMU 5, DIV 6 = 4 + 2 g, REM 7 = 5 + 2 g
       o.push(I_WA_WR, o.lmul(o.lsub(w1v, fa), Kwa));                                               // rd = field a
-      o.push(I_WA_TOP, o.lmul(xb[2], Kwa)); o.push(I_WA_TOP + 1, o.lmul(xc[2], Kwa));              // the operands are below 2^40
+      o.push(I_WA_TOP, o.lmul(xb[2], Kin)); o.push(I_WA_TOP + 1, o.lmul(xc[2], Kin));              // the chunk relation's operands are below 2^40 (wider ones: the tape, I_WW)
       constexpr uint32_t T10 = M(RC_TABLE);
-      o.push(I_WA_F2, o.lmul(o.lsub(o.sub(xc[0], pcs[0]), o.mulc(pcs[1], T10)), Kwa)); o.push(I_WA_F2 + 1, o.lmul(o.lsub(o.sub(xc[1], pcs[2]), o.mulc(pcs[3], T10)), Kwa));   // F2 = rs2, always
+      o.push(I_WA_F2, o.lmul(o.lsub(o.sub(xc[0], pcs[0]), o.mulc(pcs[1], T10)), Kin)); o.push(I_WA_F2 + 1, o.lmul(o.lsub(o.sub(xc[1], pcs[2]), o.mulc(pcs[3], T10)), Kin));   // F2 = rs2, always
       o.push(I_WA_F1, o.lmul(o.lsub(o.sub(xb[0], R2[0]), o.mulc(R2[1], T10)), om)); o.push(I_WA_F1 + 1, o.lmul(o.lsub(o.sub(xb[1], R2[2]), o.mulc(R2[3], T10)), om));         // MULH: F1 = rs1
       o.push(I_WA_LO, o.lmul(o.lsub(o.sub(xb[0], R[0]), o.mulc(R[1], T10)), kd)); o.push(I_WA_LO + 1, o.lmul(o.lsub(o.sub(xb[1], R[2]), o.mulc(R[3], T10)), kd));             // divisions: LO = rs1
 #pragma unroll
-      for (int k = 0; k < 4; k++) o.push(I_WA_GF + k, o.lsub(gf[k], o.mul(R2[k], Kwa)));           // gf_k = kwa F1_k
+      for (int k = 0; k < 4; k++) o.push(I_WA_GF + k, o.lsub(gf[k], o.mul(R2[k], Kin)));           // gf_k = (om + od + orr) F1_k
       const V G4[4] = {pcs[7], pcs[8], X[0], X[1]};
       auto two = [&](const V& a, const V& b) { return o.add(a, o.add(b, b)); };                    // a + 2 b
       const V cr[6] = {pcs[4], o.add(pcs[5], o.mulc(we[0], T10)), o.add(pcs[6], o.mulc(two(we[1], we[2]), T10)),
@@ -925,8 +952,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
           V lin = R[k];
           if (k < 3) lin = o.add(lin, o.mulc(cr[k], T10));
           if (k) lin = o.sub(lin, cr[k - 1]);
-          if constexpr (k == 3) o.push(I_WA_EQ + k, o.lsub(o.sub(o.acc_val(t), o.mul(lin, Kwa)), o.mul(o.mulc(cr[3], T10), om)));
-          else o.push(I_WA_EQ + k, o.lsub(o.acc_val(t), o.mul(lin, Kwa)));
+          if constexpr (k == 3) o.push(I_WA_EQ + k, o.lsub(o.sub(o.acc_val(t), o.mul(lin, Kin)), o.mul(o.mulc(cr[3], T10), om)));
+          else o.push(I_WA_EQ + k, o.lsub(o.acc_val(t), o.mul(lin, Kin)));
         } else {                                                                                    // high half (MULH): + c_(k-1) = HI_(k-4) + 2^10 c_k (k = 6: 2^10 HI_3); a division has nothing there
           const V hi = k < 6 ? o.add(G4[k - 4], o.mulc(cr[k < 6 ? k : 5], T10)) : o.add(G4[2], o.mulc(G4[3], T10));
           o.push(I_WA_EQ + k, o.ladd(o.acc_val(t), o.mul(o.lsub(cr[k - 1], hi), om)));
@@ -940,7 +967,7 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
       const V gk = o.add(om, orr);
       o.push(I_WA_Y, o.lmul(o.lsub(y[0], r0), gk)); o.push(I_WA_Y + 1, o.lmul(o.lsub(y[1], r1), gk));
       o.push(I_WA_Y + 2, o.lmul(o.lsub(o.sub(y[0], R2[0]), o.mulc(R2[1], T10)), od)); o.push(I_WA_Y + 3, o.lmul(o.lsub(o.sub(y[1], R2[2]), o.mulc(R2[3], T10)), od));
-      o.push(I_WA_Y + 4, o.lmul(y[2], Kwa));
+      o.push(I_WA_Y + 4, o.lmul(y[2], Kin));
       // the six extra range slots: XH_i (alpha - X_i) = 1, on every row
 #pragma unroll
       for (int i = 0; i < N_X; i++) {
@@ -985,6 +1012,26 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
         o.push(I_HH, o.lsub(pr[0], FH));
 #pragma unroll
         for (int k = 1; k < 4; k++) o.push(I_HH + k, pr[k]);
+      }
+      // the wide tape: ot boolean; WW (alpha - fp(cycle, rs1's limbs, rs2's, y's, opcode) - 13 lambda^11) = ot: the row writes what the verifier computed from its record
+      {
+        const V ot = o.loc(C_OT), cycv = o.loc(C_CYCLE);
+        boolean(I_WT_BOOL, ot);
+        V h[4], d[4], pr[4];
+        const V tup[10] = {cycv, xb[0], xb[1], xb[2], xc[0], xc[1], xc[2], y[0], y[1], y[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          h[k] = o.aloc(A_WW + k); o.acc_lin(hs[k], h[k], 1);
+          AccP t = o.accp();
+#pragma unroll
+          for (int j = 0; j < 10; j++) o.acc_mul(t, tup[j], o.par(LK_LAM + 4 * j + k));
+          o.acc_mul(t, op, o.par(LK_LAM + 4 * 10 + k));
+          d[k] = o.sub(o.sub(o.par(LK_ALPHA + k), o.mulc(o.par(LK_LAM + 4 * N_TUPLE + k), M((uint32_t)TAG_WIDE))), o.acc_val(t));
+        }
+        ext_mul(h, d, pr);
+        o.push(I_WW, o.lsub(pr[0], ot));
+#pragma unroll
+        for (int k = 1; k < 4; k++) o.push(I_WW + k, pr[k]);
       }
     }
   }

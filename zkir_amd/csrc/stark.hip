@@ -206,6 +206,15 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     // access and the time of the cell's previous access come with the row (the host's sequential memory replay); everything else is local
 #pragma unroll
     for (int k = C_E; k < W; k++) if (k != C_KLG && k != C_KSH && k != C_KMU) col(k) = 0;
+    if (MODE == 4 && cls == K_WA && (xb[2] | xc[2])) {
+      // (mode 4 d) an operand with bits above 40: the row goes through the WIDE TAPE (air.h) — ot = 1, every chunk column zero; what is written is the reference's result on the
+      // raw 64-bit registers, which the verifier recomputes from the record (cycle, rs1, rs2, opcode) the proof carries (stark_prove.inl gathers the records from these rows)
+      sh_row = true;
+      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20) | ((uint64_t)xb[2] << 40), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20) | ((uint64_t)xc[2] << 40);
+      const uint64_t res = wide_result(op, a, b);
+      col(C_OT) = 1;
+      y[0] = (uint32_t)(res & 0xFFFFF); y[1] = (uint32_t)((res >> 20) & 0xFFFFF); y[2] = (uint32_t)(res >> 40);
+    } else
     if (MODE == 4 && cls == K_WA) {
       // (mode 4) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI in 10-bit chunks (air.h: the slots of a wide-arithmetic row).
       // The top limbs of the operands must be zero — I_WA_TOP says so; a run that breaks it has no proof (lookup_index_kernel reports the row)

@@ -190,7 +190,8 @@ struct IoEntry { uint32_t row, is_in, idx, v[3], pad[2]; };
 __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __restrict__ M, uint64_t N, int deferred /* the mode */, const uint32_t* __restrict__ code, uint32_t n_code, uint4* __restrict__ side,
                                                            uint32_t* __restrict__ rc_mult, uint32_t* __restrict__ rom_mult, unsigned long long* __restrict__ bad_row,
                                                            IoEntry* __restrict__ io_list, uint32_t* __restrict__ io_count, uint32_t* __restrict__ mem_mult, uint4* __restrict__ mem_side,
-                                                           uint2* __restrict__ wide_side /* (mode 4) the six extra range values of every row, ten bits each */) {
+                                                           uint2* __restrict__ wide_side /* (mode 4) the six extra range values of every row, ten bits each */,
+                                                           uint32_t* __restrict__ wide_tape /* (mode 4) [N][8]: a record (cycle, rs1's limbs, rs2's, opcode) per row with ot = 1, appended in any order */) {
   __shared__ uint32_t h_rc[air::RC_TABLE];
   __shared__ uint32_t h_rom[ROM_LDS];
   __shared__ uint32_t h_mem[air::MEM_MULT];                    // (mode 3) LOW3 | BYTE | NIBBLE
@@ -233,9 +234,15 @@ __global__ __launch_bounds__(NT) void lookup_index_kernel(const uint32_t* __rest
       uint32_t kmu = M[b8((uint32_t)air::phys_col(air::C_KMU, 3), i, N)];
       if (deferred == 4) {                                       // (mode 4) a wide-arithmetic row reads the 10-bit table in every piece slot, like a MUL row; its operands must be below 2^40
         const uint32_t p_om = (uint32_t)air::phys_col(air::C_OM, 4);
-        const uint32_t kwa = M[b8(p_om, i, N)] | M[b8(p_om + 1, i, N)] | M[b8(p_om + 2, i, N)];            // kwa = om + od + orr
+        const uint32_t ot = M[b8((uint32_t)air::phys_col(air::C_OT, 4), i, N)];
+        const uint32_t kwa = M[b8(p_om, i, N)] | M[b8(p_om + 1, i, N)] | M[b8(p_om + 2, i, N)] | ot;       // kwa = om + od + orr + ot
         if (M[b8((uint32_t)air::phys_col(air::C_FH, 4), i, N)]) atomicAdd(io_count + 1, 1u);                 // a hash syscall row: the proof needs its record (the hash tape)
-        if (kwa && (M[b8((uint32_t)air::phys_col(air::C_XB + 2, 4), i, N)] | M[b8((uint32_t)air::phys_col(air::C_XC + 2, 4), i, N)])) ok = false;    // MULH / DIV.. on a register with bits above 40: no proof in this AIR
+        if (ot) {                                                // a wide row with an operand above 2^40: its record goes into the wide tape (the host sorts the records by cycle)
+          uint32_t* r = wide_tape + 8 * (uint64_t)atomicAdd(io_count + 2, 1u);
+          r[0] = M[b8((uint32_t)air::phys_col(air::C_CYCLE, 4), i, N)];
+          for (int k = 0; k < 3; k++) { r[1 + k] = M[b8((uint32_t)air::phys_col(air::C_XB + k, 4), i, N)]; r[4 + k] = M[b8((uint32_t)air::phys_col(air::C_XC + k, 4), i, N)]; }
+          r[7] = M[b8((uint32_t)air::phys_col(air::C_OP, 4), i, N)];
+        }
         kmu |= kwa;
         uint32_t xs[air::N_X];
         for (int k = 0; k < air::N_X; k++) { xs[k] = M[b8((uint32_t)air::phys_col(air::C_X + k, 4), i, N)]; if (xs[k] < (uint32_t)air::RC_TABLE) atomicAdd(&h_rc[xs[k]], 1u); else ok = false; }
@@ -572,14 +579,15 @@ __device__ __forceinline__ uint4 add4m(uint4 a, uint4 b) { return make_uint4(bb:
 // (mode 4) the hash-call helpers HH = 1 / (alpha - fp(call)) of the hash-syscall rows: computed on the host from the tape's records (the same values the table side is made
 // of), scattered into the row's HH columns and added to its running-sum increment; every other row keeps the zeros the block was cleared with
 struct HashAux { uint32_t row, pad[3]; E4 h; };
-__global__ __launch_bounds__(NT) void hash_aux_kernel(const HashAux* __restrict__ list, uint32_t n, uint64_t N, uint32_t* __restrict__ A) {
+// `half` = 0: HH (the hash-call helper), 1: WW (the wide-tape helper, the other half of the same block of eight columns)
+__global__ __launch_bounds__(NT) void hash_aux_kernel(const HashAux* __restrict__ list, uint32_t n, uint64_t N, uint32_t* __restrict__ A, uint32_t half) {
   const uint32_t t = blockIdx.x * NT + threadIdx.x;
   if (t >= n) return;
   const HashAux e = list[t];
   uint4* A4 = reinterpret_cast<uint4*>(A);
-  static_assert(air::A_HH % 8 == 0, "aux layout: HH opens a block");
+  static_assert(air::A_HH % 8 == 0 && air::A_WW == air::A_HH + 4, "aux layout: HH opens a block, WW is its second half");
   const uint4 h4 = make_uint4(e.h.c[0], e.h.c[1], e.h.c[2], e.h.c[3]);
-  A4[((uint64_t)(air::A_HH / 8) * N + e.row) * 2] = h4;
+  A4[((uint64_t)(air::A_HH / 8) * N + e.row) * 2 + half] = h4;
   uint4* S = A4 + ((uint64_t)(air::A_S / 8) * N + e.row) * 2 + 1;
   *S = add4m(*S, h4);
 }
@@ -1247,7 +1255,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
     HIP_OK(hipMemsetAsync(dBad, 0xFF, 8, s));
     unsigned g = grid_for(N); if (g > 2048) g = 2048;
     if (IO) HIP_OK(hipMemsetAsync(dIoCount, 0, 16, s));          // [0] the tape-lookup rows, [1] (mode 4) the hash-syscall rows
-    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount, dMult + n_code + air::RC_TABLE, dMemSide, dWideSide);
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(g), dim3(NT), 0, s, dM, N, MODE, dCode, n_code, dSide, dMult + n_code, dMult, dBad, dIo, dIoCount, dMult + n_code + air::RC_TABLE, dMemSide, dWideSide, dSec);
   }
   mark(1);
   rc = lde_launch(c, dM, WM, dL, /*mont_out=*/true, s); if (rc) return rc;        // canonical evaluations in, MONTGOMERY words out: the matrices of a proof rest in Montgomery form
@@ -1268,9 +1276,20 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   if (bad_row != ~0ull) {
     char m[448];
     snprintf(m, sizeof m, "zkir_prove: row %llu of the trace has no proof in this AIR: its (pc, instruction word) is not in the program's code table (self-modified code, "
-                          "a pc outside the code segment), a written limb is out of range, (mode 3) its memory witness is not the row's, or (mode 4) it is a MULH / DIVU / REMU / DIV / REM on a register with bits above 40", bad_row);
+                          "a pc outside the code segment), a written limb is out of range, (mode 3) its memory witness is not the row's, or (mode 4) a wide-arithmetic chunk is out of range", bad_row);
     zkir::set_last_error({ZKIR_ERR_ARGUMENT, m});
     return ZKIR_ERR_ARGUMENT;
+  }
+  // (mode 4 d) the wide tape: the records of the wide rows that go through it (lookup_index_kernel appended them to the section buffer, which nothing else uses before this point), in cycle order
+  struct WideRec { uint32_t w[8]; };
+  std::vector<WideRec> wrecs;
+  if (WIDE && io_counts[2]) {
+    const uint32_t nw = io_counts[2];
+    if ((size_t)nw * 8 > SEC_WORDS) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: more wide-tape rows than the workspace holds"}); return ZKIR_ERR_OTHER; }
+    wrecs.resize(nw);
+    HIP_OK(hipMemcpyAsync(wrecs.data(), dSec, (size_t)nw * 32, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    std::sort(wrecs.begin(), wrecs.end(), [](const WideRec& x, const WideRec& y) { return x.w[0] < y.w[0]; });
   }
   mark(3);
   std::vector<uint32_t> head;
@@ -1353,6 +1372,33 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       for (size_t at = 0; at < hash_sec.size(); at += SECTION_CHUNK) { uint32_t dg[4]; hash_elems_host(c->consts, hash_sec.data() + at, std::min((size_t)SECTION_CHUNK, hash_sec.size() - at), dg); ch.observe_n(dg, 4); }
     }
     if (dbg_t) fprintf(stderr, "zkir_prove mode 4: hash section (%zu calls, %zu words) parsed, hashed and observed in %.2f ms\n", hcalls.size(), hash_sec.size(), since(t_entry) - t_hash0);
+  }
+  // (mode 4 d) the wide tape as a proof section: [n] then the records, eight words each; checked as the verifier will check it, observed like the hash section
+  std::vector<uint32_t> wide_sec;
+  if (WIDE) {
+    wide_sec.reserve(1 + 8 * wrecs.size());
+    wide_sec.push_back((uint32_t)wrecs.size());
+    for (size_t k = 0; k < wrecs.size(); k++) {
+      const uint32_t* r = wrecs[k].w;
+      const uint64_t b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
+      if (r[0] >= pub->n_real || (k && r[0] <= wrecs[k - 1].w[0]) || r[7] < 3 || r[7] > 7 || (r[7] >= 4 && b == 0)) {
+        char m[160]; snprintf(m, sizeof m, "zkir_prove: the wide-tape record of row %u is not one of an executed MULH / DIVU / REMU / DIV / REM (the trace is not a run of the VM)", r[0]);
+        zkir::set_last_error({ZKIR_ERR_ARGUMENT, m}); return ZKIR_ERR_ARGUMENT;
+      }
+      wide_sec.insert(wide_sec.end(), r, r + 8);
+    }
+    const size_t n_chunks_sec = (wide_sec.size() + SECTION_CHUNK - 1) / SECTION_CHUNK;
+    if (wide_sec.size() > 4 * SECTION_CHUNK && wide_sec.size() + 4 * n_chunks_sec + 64 <= SEC_WORDS) {     // a long tape: the chunk digests on the device
+      uint32_t* dSecDg = dSec + ((wide_sec.size() + 63) & ~(size_t)63);
+      HIP_OK(h2d(dSec, wide_sec.data(), wide_sec.size() * 4));
+      hipLaunchKernelGGL(section_hash_kernel, dim3((unsigned)((4 * n_chunks_sec + 63) / 64)), dim3(64), 0, s, c->d_p2, dSec, (uint64_t)wide_sec.size(), dSecDg);
+      std::vector<uint32_t> sec_dg(4 * n_chunks_sec);
+      HIP_OK(hipMemcpyAsync(sec_dg.data(), dSecDg, sec_dg.size() * 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      ch.observe_n(sec_dg.data(), sec_dg.size());
+    } else {
+      for (size_t at = 0; at < wide_sec.size(); at += SECTION_CHUNK) { uint32_t dg[4]; hash_elems_host(c->consts, wide_sec.data() + at, std::min((size_t)SECTION_CHUNK, wide_sec.size() - at), dg); ch.observe_n(dg, 4); }
+    }
   }
   ch.observe_n(mult, n_mult);                     // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE): fixed before the lookup challenges
   std::unique_ptr<ProveParams> pp(new ProveParams());         // host staging of this proof's constants
@@ -1468,6 +1514,34 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       for (const E4& tp : Tpart) T = bb::e_add(T, tp);
       if (dbg_t) fprintf(stderr, "zkir_prove mode 4: the hash calls' table side (%u host threads) at %.2f ms\n", parts, since(t_entry));
     }
+    std::vector<HashAux> wide_aux;                             // (mode 4 d) the wide-tape rows' helper values WW
+    if (WIDE && !wrecs.empty()) {
+      // the wide tape's share of the table side, formed like the verifier will form it (verify.cpp; oracle: so::wide_table_sum): + 1 / (alpha - fp(cycle, rs1, rs2, the
+      // reference's result, opcode)) per record — the result is computed HERE (air::wide_result); the inverse is also the row's WW.  One batch inversion.
+      E4 lamv[air::N_TUPLE + 1];
+      for (int j = 0; j <= air::N_TUPLE; j++) for (int c4 = 0; c4 < 4; c4++) lamv[j].c[c4] = pp->lk[air::LK_LAM + 4 * j + c4];
+      E4 alpha_lm; for (int c4 = 0; c4 < 4; c4++) alpha_lm.c[c4] = pp->lk[air::LK_ALPHA + c4];
+      std::vector<E4> d(wrecs.size()), pre(wrecs.size());
+      for (size_t k = 0; k < wrecs.size(); k++) {
+        const uint32_t* r = wrecs[k].w;
+        const uint64_t a = (uint64_t)r[1] | ((uint64_t)r[2] << 20) | ((uint64_t)r[3] << 40), b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
+        const uint64_t y = air::wide_result(r[7], a, b);
+        const uint32_t e[11] = {r[0] % bb::P, r[1], r[2], r[3], r[4], r[5], r[6], (uint32_t)(y & 0xFFFFF), (uint32_t)((y >> 20) & 0xFFFFF), (uint32_t)(y >> 40), r[7]};
+        E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_WIDE));
+        for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[j], bb::to_mont(e[j])));
+        d[k] = bb::e_sub(alpha_lm, fp);
+      }
+      E4 acc = bb::e_one_m();
+      for (size_t k = 0; k < d.size(); k++) { pre[k] = acc; acc = bb::e_mul_m(acc, d[k]); }
+      E4 inv = bb::e_inv_m(acc);
+      wide_aux.resize(wrecs.size());
+      for (size_t k = d.size(); k-- > 0;) {
+        const E4 dk = bb::e_mul_m(inv, pre[k]);
+        inv = bb::e_mul_m(inv, d[k]);
+        T = bb::e_add(T, dk);
+        wide_aux[k].row = wrecs[k].w[0]; wide_aux[k].pad[0] = wide_aux[k].pad[1] = wide_aux[k].pad[2] = 0; wide_aux[k].h = dk;
+      }
+    }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];
     HIP_OK(h2d(dPP->lk + air::LK_TN, pp->lk + air::LK_TN, 16));
@@ -1483,7 +1557,14 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
         if (hash_aux.size() * sizeof(HashAux) > SEC_WORDS * 4) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: more hash calls than the workspace holds"}); return ZKIR_ERR_OTHER; }
         HashAux* dHashAux = reinterpret_cast<HashAux*>(dSec);   // (the section buffer is free again: 32 N bytes)
         HIP_OK(h2d(dHashAux, hash_aux.data(), hash_aux.size() * sizeof(HashAux)));
-        hipLaunchKernelGGL(hash_aux_kernel, dim3(grid_for(hash_aux.size())), dim3(NT), 0, s, dHashAux, (uint32_t)hash_aux.size(), N, dA);
+        hipLaunchKernelGGL(hash_aux_kernel, dim3(grid_for(hash_aux.size())), dim3(NT), 0, s, dHashAux, (uint32_t)hash_aux.size(), N, dA, 0u);
+      }
+      if (!wide_aux.empty()) {                                  // WW of the wide-tape rows (behind the hash rows' list in the same buffer: a row is never both)
+        const size_t off = (hash_aux.size() * sizeof(HashAux) + 255) & ~(size_t)255;
+        if (off + wide_aux.size() * sizeof(HashAux) > SEC_WORDS * 4) { zkir::set_last_error({ZKIR_ERR_OTHER, "zkir_prove: more wide-tape rows than the workspace holds"}); return ZKIR_ERR_OTHER; }
+        HashAux* dWideAux = reinterpret_cast<HashAux*>(reinterpret_cast<char*>(dSec) + off);
+        HIP_OK(h2d(dWideAux, wide_aux.data(), wide_aux.size() * sizeof(HashAux)));
+        hipLaunchKernelGGL(hash_aux_kernel, dim3(grid_for(wide_aux.size())), dim3(NT), 0, s, dWideAux, (uint32_t)wide_aux.size(), N, dA, 1u);
       }
     }
     const uint32_t n_scan = (uint32_t)((N + SCAN_ROWS - 1) / SCAN_ROWS);
@@ -1659,7 +1740,7 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
   if (IO) head.insert(head.end(), io_sec.begin(), io_sec.end());              // the I/O section: the tapes and the halt reason the io digest is a digest of
   if (MEM) head.insert(head.end(), mem_sec.begin(), mem_sec.end());           // (mode 3) the touched cells
-  if (WIDE) head.insert(head.end(), hash_sec.begin(), hash_sec.end());         // (mode 4) the hash calls
+  if (WIDE) { head.insert(head.end(), hash_sec.begin(), hash_sec.end()); head.insert(head.end(), wide_sec.begin(), wide_sec.end()); }   // (mode 4) the hash calls, the wide tape
   head.insert(head.end(), mult, mult + n_mult);                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);

@@ -576,6 +576,22 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     if (hrc) return hrc;
     p += hash_len;
   }
+  // (mode 4 d) the wide tape: records in increasing cycle order, limbs in range, an opcode 3..7, no zero divisor (57)
+  struct WideRec { uint32_t w[8]; };
+  const uint32_t* wide_words = nullptr; size_t wide_len = 0, n_wide = 0;
+  if (mode == 4) {
+    if (!need(1)) return 4;
+    n_wide = w[p];
+    if (n_wide > pub.n_real) return 57;
+    if (!need(1 + 8 * n_wide)) return 4;
+    wide_words = w + p; wide_len = 1 + 8 * n_wide;
+    for (size_t k = 0; k < n_wide; k++) {
+      const uint32_t* c = wide_words + 1 + 8 * k;
+      if (c[1] >= (1u << 20) || c[2] >= (1u << 20) || c[3] >= (1u << 24) || c[4] >= (1u << 20) || c[5] >= (1u << 20) || c[6] >= (1u << 24) || c[7] < 3 || c[7] > 7) return 57;
+      if (c[0] >= pub.n_real || (k && c[0] <= c[-8]) || (c[7] >= 4 && !(c[4] | c[5] | c[6]))) return 57;
+    }
+    p += wide_len;
+  }
   if (!need(n_code + air::RC_TABLE + (mode >= 3 ? air::MEM_MULT : 0))) return 4;
   const uint32_t* rom_mult = w + p; p += n_code;
   const uint32_t* rc_mult = w + p; p += air::RC_TABLE;
@@ -618,7 +634,7 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
     ch.observe_n(dg.data(), dg.size());
   };
   if (mode >= 3) observe_section(mem_words, mem_len);
-  if (mode == 4) observe_section(hash_words, hash_len);
+  if (mode == 4) { observe_section(hash_words, hash_len); observe_section(wide_words, wide_len); }
   ch.observe_n(rom_mult, n_code);
   ch.observe_n(rc_mult, air::RC_TABLE);
   if (mode >= 3) ch.observe_n(mem_mult, air::MEM_MULT);
@@ -689,6 +705,23 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
           Tpart[part] = Tp;
         });
         for (const E4& tp : Tpart) T_hash = bb::e_add(T_hash, tp);
+      }
+      // (mode 4 d) the wide tape: + 1 / (alpha - fp(cycle, rs1, rs2, what the reference writes, opcode)) per record — the result is computed HERE (air::wide_result)
+      if (mode == 4 && n_wide) {
+        std::vector<E4> wd(n_wide), wpre(n_wide);
+        for (size_t k = 0; k < n_wide; k++) {
+          const uint32_t* r = wide_words + 1 + 8 * k;
+          const uint64_t a = (uint64_t)r[1] | ((uint64_t)r[2] << 20) | ((uint64_t)r[3] << 40), b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
+          const uint64_t y = air::wide_result(r[7], a, b);
+          const uint32_t e[11] = {r[0] % bb::P, r[1], r[2], r[3], r[4], r[5], r[6], (uint32_t)(y & 0xFFFFF), (uint32_t)((y >> 20) & 0xFFFFF), (uint32_t)(y >> 40), r[7]};
+          E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_WIDE));
+          for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(e[j])));
+          wd[k] = bb::e_sub(alpha_l, fp);
+        }
+        E4 wacc = bb::e_one_m();
+        for (size_t k = 0; k < n_wide; k++) { wpre[k] = wacc; wacc = bb::e_mul_m(wacc, wd[k]); }
+        E4 winv = bb::e_inv_m(wacc);
+        for (size_t k = n_wide; k-- > 0;) { T_hash = bb::e_add(T_hash, bb::e_mul_m(winv, wpre[k])); winv = bb::e_mul_m(winv, wd[k]); }
       }
     }
     for (size_t u = 0; u < n_code; u++) {

@@ -354,6 +354,21 @@ def wide_loop_program() -> Program:
     ])
 
 
+def signed_division_loop_program() -> Program:
+    """An ENDLESS loop over the wide opcodes on RAW 64-bit registers (AIR mode 4's wide tape; run with max_cycles, halt = CycleLimit): a byte b <- b + 3 is stored and loaded
+    back with LB — sign-extended to 64 bits when its top bit is set (execute.rs:477-499) — then divided, reduced and multiplied as the reference does it on `as i64` / u64 /
+    u128 (quirks Q2, Q3): DIV and REM of a negative by a positive, DIVU of the same bits read as unsigned, MULH of two 64-bit values, REMU and DIV with the wide value as the
+    divisor.  Rows whose operands have bits above 40 go through the tape, the others (b < 0x80) through the chunk relation: both routes in one run, 12 rows per iteration."""
+    E, O = encode, Opcode
+    return Program.from_code([
+        addi(6, 0, 0x8000), slli(6, 6, 1), addi(1, 0, 0x95),                                              # base 0x10000, the byte
+        # L:
+        E(O.SB, rs1=6, rs2=1, imm=0), E(O.LB, 2, 6, imm=0), E(O.ANDI, 3, 1, imm=0x3F), addi(3, 3, 7),      # r2 = sext(byte), a divisor 7..70
+        E(O.DIV, 4, 2, 3), E(O.REM, 5, 2, 3), E(O.DIVU, 7, 2, 3), E(O.MULH, 8, 2, 2), E(O.REMU, 9, 3, 2), E(O.DIV, 10, 3, 2),
+        addi(1, 1, 3), jal(0, -44),
+    ])
+
+
 def memory_ring_program(log2_cells: int = 15) -> Program:
     """An ENDLESS walk over a ring of 2^log2_cells 8-byte cells at 0x100000 (AIR mode 3 at any size: run with max_cycles, halt = CycleLimit): per iteration (16 rows) the
     offset advances by 8 and is wrapped with ANDI, the cell gets the XOR of its old LD value with a counter (SD), is read back as a word, an unsigned halfword and a signed byte

@@ -27,7 +27,7 @@ MEM_MULT = RC_TABLE + 256 + 16 + 3 * 256 + RC_TABLE     # (mode 3) LOW3 | BYTE |
 
 def proof_layout(proof) -> dict:
     """Word offsets inside a proof of ANY mode (word 9): header (157 words; modes 2 / 3: + the four counter words) | program (byte length, 16-bit halfwords) | modes 2 / 3: the
-    I/O section (n_in, inputs as four 16-bit pieces each, n_out, outputs, halt kind, halt code) | mode 3: the touched cells (n, 7 words a cell) | ROM multiplicities | range
+    I/O section (n_in, inputs as four 16-bit pieces each, n_out, outputs, halt kind, halt code) | mode 3: the touched cells (n, 7 words a cell) | mode 4: the hash tape, the wide tape | ROM multiplicities | range
     multiplicities | mode 3: the LOW3 .. LOW6 multiplicities | trace root | aux root | quotient root | openings ...  (oracle/stark_oracle.cpp so::prove is the layout's definition)."""
     mode = int(proof[9])
     at = HEADER_WORDS + (4 if mode >= 2 else 0)
@@ -43,7 +43,7 @@ def proof_layout(proof) -> dict:
         n_in = int(proof[at]); at += 1 + 4 * n_in
         n_out = int(proof[at]); at += 1 + 4 * n_out
         at += 5
-    hash_at = None
+    hash_at = wide_at = None
     if mode >= 3:
         mem_at = at
         at += 1 + 7 * int(proof[at])
@@ -52,9 +52,11 @@ def proof_layout(proof) -> dict:
         n_calls = int(proof[at]); at += 1
         for _ in range(n_calls):
             at += 8 + 5 * int(proof[at + 7])
+        wide_at = at                                          # .. then the wide tape: [n] then per record [cycle] [rs1: three limbs] [rs2: three limbs] [opcode]
+        at += 1 + 8 * int(proof[at])
     rom_mult = at
     troot = rom_mult + n_rom + RC_TABLE + (MEM_MULT if mode >= 3 else 0)
-    return {"mode": mode, "num_queries": int(proof[4]), "pow_bits": int(proof[6]), "blob": blob, "n_rom": n_rom, "io_section": io_at, "mem_section": mem_at, "hash_section": hash_at, "rom_mult": rom_mult,
+    return {"mode": mode, "num_queries": int(proof[4]), "pow_bits": int(proof[6]), "blob": blob, "n_rom": n_rom, "io_section": io_at, "mem_section": mem_at, "hash_section": hash_at, "wide_section": wide_at, "rom_mult": rom_mult,
             "rc_mult": rom_mult + n_rom, "trace_root": troot, "aux_root": troot + 4, "quotient_root": troot + 8, "openings": troot + 12}
 
 
