@@ -577,7 +577,7 @@ def _mode3_case(which, witness="device", wide=False):
     if which.startswith("random"):
         blob, ins = pg.random_program(int(which[6:]), hashes=False)
     elif which == "signed_division_loop":                                 # (mode 4) both routes of the wide class: sign-extended bytes (the tape) and small ones (the chunk relation)
-        blob, ins, cfg = spec.signed_division_loop_program().to_bytes(), [], dict(max_cycles=3000)
+        blob, ins, cfg = spec.signed_division_loop_program().to_bytes(), [], dict(max_cycles=1300)      # (the byte reaches 0 — a zero divisor, a VM error — in iteration 121)
     elif which == "memloop":                                              # a loop that walks an array: store i * 3 at A + 8 i, load it back as bytes / halfwords / words, sum, WRITE the sum
         blob, ins = spec.memory_loop_program(200).to_bytes(), []
     elif which.endswith("_on_code"):                                      # the reference's test as written: its data at 0x1000, the first code word

@@ -125,6 +125,17 @@ BB_HD constexpr bool is_low_window(int v) { return v <= 3 || v == 8 || v == 9 ||
 BB_HD constexpr bool is_wide(uint32_t op) { return op >= 0x03 && op <= 0x07; }
 // what MULH 3 / DIVU 4 / REMU 5 / DIV 6 / REM 7 write, on the raw 64-bit registers (execute.rs:101-183): MULH = bits 40..79 of the 128-bit product; DIVU / REMU unsigned; DIV /
 // REM on `as i64` with wrapping_div / wrapping_rem (i64::MIN / -1 = i64::MIN, remainder 0).  b = 0 never is a row of a division (the VM stops with DivisionByZero).
+// (A restoring division, one bit per step, instead of the `/` operator: in the row kernel — 256 registers, a 308-word row partly in scratch — the compiler's inline expansion of
+// four 64-bit divisions left garbage in other columns of the row on gfx950, round 6; 64 short steps on the few rows that take the tape cost nothing.)
+BB_HD void udivmod64(uint64_t a, uint64_t b, uint64_t& q, uint64_t& r) {
+  q = 0; r = 0;
+#pragma unroll 1
+  for (int i = 63; i >= 0; i--) {
+    const uint64_t carry = r >> 63;
+    r = (r << 1) | ((a >> i) & 1);
+    if (carry | (uint64_t)(r >= b)) { r -= b; q |= 1ull << i; }
+  }
+}
 BB_HD uint64_t wide_result(uint32_t op, uint64_t a, uint64_t b) {
   if (op == 0x03) {                                             // (no 128-bit type on the device: the product's bits 40..79 from 32-bit halves)
     const uint64_t a0 = a & 0xFFFFFFFFull, a1 = a >> 32, b0 = b & 0xFFFFFFFFull, b1 = b >> 32;
@@ -134,11 +145,11 @@ BB_HD uint64_t wide_result(uint32_t op, uint64_t a, uint64_t b) {
     return ((lo >> 40) | (hi << 24)) & ((1ull << 40) - 1);
   }
   if (b == 0) return 0;
-  if (op == 0x04) return a / b;
-  if (op == 0x05) return a % b;
-  const int64_t sa = (int64_t)a, sb = (int64_t)b;
-  const bool ovf = sa == INT64_MIN && sb == -1;
-  return op == 0x06 ? (ovf ? (uint64_t)INT64_MIN : (uint64_t)(sa / sb)) : (ovf ? 0 : (uint64_t)(sa % sb));
+  const bool sgn = op >= 0x06, na = sgn && (a >> 63), nb = sgn && (b >> 63);       // DIV / REM: |a| = |q| |b| + |r|, q negative iff the signs differ, r with the dividend's sign
+  uint64_t q, r;
+  udivmod64(na ? 0 - a : a, nb ? 0 - b : b, q, r);                                 // (|i64::MIN| = 2^63 as a u64: i64::MIN / -1 gives |q| = 2^63 = i64::MIN again — wrapping_div — and r = 0)
+  if (op == 0x04 || op == 0x06) return (na != nb) ? 0 - q : q;
+  return na ? 0 - r : r;
 }
 constexpr uint32_t OP_MUL_ = 0x02;
 BB_HD constexpr bool is_logic(uint32_t op) { return op >= 0x10 && op <= 0x15; }

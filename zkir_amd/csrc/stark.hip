@@ -209,11 +209,10 @@ BB_HD void main_trace_row(const zkir_trace_columns& t, uint64_t n_real, uint64_t
     if (MODE == 4 && cls == K_WA && (xb[2] | xc[2])) {
       // (mode 4 d) an operand with bits above 40: the row goes through the WIDE TAPE (air.h) — ot = 1, every chunk column zero; what is written is the reference's result on the
       // raw 64-bit registers, which the verifier recomputes from the record (cycle, rs1, rs2, opcode) the proof carries (stark_prove.inl gathers the records from these rows)
+      // — written by wide_tape_fix_row AFTER this function (its own small kernel: with the 64-bit arithmetic inlined here, hipcc 7.2 at 256 VGPRs + 90 spilled SGPRs built a
+      // row kernel that read registers r6..r9 from wrong addresses on gfx950; round 6, scripts/dbg/diff_mode4.py)
       sh_row = true;
-      const uint64_t a = (uint64_t)xb[0] | ((uint64_t)xb[1] << 20) | ((uint64_t)xb[2] << 40), b = (uint64_t)xc[0] | ((uint64_t)xc[1] << 20) | ((uint64_t)xc[2] << 40);
-      const uint64_t res = wide_result(op, a, b);
       col(C_OT) = 1;
-      y[0] = (uint32_t)(res & 0xFFFFF); y[1] = (uint32_t)((res >> 20) & 0xFFFFF); y[2] = (uint32_t)(res >> 40);
     } else
     if (MODE == 4 && cls == K_WA) {
       // (mode 4) MULH DIVU REMU DIV REM on operands below 2^40 (execute.rs:101-183): F1 F2 + ADD = LO + 2^40 HI in 10-bit chunks (air.h: the slots of a wide-arithmetic row).
@@ -934,6 +933,19 @@ int zkir_main_trace_io_launch(const zkir_trace_columns* trace, uint64_t n_real, 
 // MODES 3 / 4: the same scan, then the row kernel with the memory witness (device arrays of n_real entries)
 }  // extern "C" (the two helpers are templates)
 namespace {
+// (mode 4 d) what a wide-tape row writes: y = the reference's result on the raw 64-bit operands of the row (air::wide_result), filled into the committed matrix in place
+BB_HD void wide_tape_fix_row(uint32_t* __restrict__ out, uint64_t N, uint64_t i) {
+  using namespace air;
+  auto at = [&](int c) -> uint32_t& { return out[b8((uint32_t)phys_col(c, 4), i, N)]; };
+  if (!at(C_OT)) return;
+  const uint64_t a = (uint64_t)at(C_XB) | ((uint64_t)at(C_XB + 1) << 20) | ((uint64_t)at(C_XB + 2) << 40), b = (uint64_t)at(C_XC) | ((uint64_t)at(C_XC + 1) << 20) | ((uint64_t)at(C_XC + 2) << 40);
+  const uint64_t res = wide_result(at(C_OP), a, b);
+  at(C_Y) = (uint32_t)(res & 0xFFFFF); at(C_Y + 1) = (uint32_t)((res >> 20) & 0xFFFFF); at(C_Y + 2) = (uint32_t)(res >> 40);
+}
+__global__ __launch_bounds__(NT) void wide_tape_fix_kernel(uint32_t* __restrict__ out, uint64_t N, uint64_t n_real) {
+  const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+  if (i < n_real) wide_tape_fix_row(out, N, i);
+}
 template <int MODE>
 int main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out, void* stream, uint64_t boundary = 0x1000) {
   if (!trace || !out || !io || !scratch || !mem_old || !mem_told || n_real == 0 || (!io->inputs && io->n_inputs)) { zkir::set_last_error({ZKIR_ERR_ARGUMENT, "zkir_main_trace_mem_launch: null argument or empty trace"}); return ZKIR_ERR_ARGUMENT; }
@@ -947,6 +959,7 @@ int main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, cons
   hipLaunchKernelGGL(io_scan_add_kernel, dim3(grid_for(N)), dim3(NT), 0, s, cnt, N, sums);
   hipLaunchKernelGGL(main_trace_kernel<MODE>, dim3(grid_for(N)), dim3(NT), 0, s, *trace, n_real, N, out,
                      IoRowArgs{io->inputs, io->n_inputs, io->writes_before, io->reads_before, reinterpret_cast<const uint32_t*>(cnt), mem_old, mem_told, boundary});
+  if (MODE == 4) hipLaunchKernelGGL(wide_tape_fix_kernel, dim3(grid_for(n_real)), dim3(NT), 0, s, out, N, n_real);
   return check_launch("main_trace_mem");
 }
 template <int MODE>
@@ -958,6 +971,7 @@ int main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const 
   for (uint64_t i = 0; i < N; i++) { cnt[2 * i] = w; cnt[2 * i + 1] = r; uint32_t f[2] = {0, 0}; if (i < n_real) io_row_flags(*trace, n_real, i, f); w += f[0]; r += f[1]; }
   const IoRowArgs a{io->inputs, io->n_inputs, io->writes_before, io->reads_before, cnt.data(), mem_old, mem_told, boundary};
   for (uint64_t i = 0; i < N; i++) main_trace_row<MODE>(*trace, n_real, N, i, out, &a);
+  if (MODE == 4) for (uint64_t i = 0; i < n_real; i++) wide_tape_fix_row(out, N, i);
   return ZKIR_OK;
 }
 }  // namespace

@@ -358,7 +358,8 @@ def signed_division_loop_program() -> Program:
     """An ENDLESS loop over the wide opcodes on RAW 64-bit registers (AIR mode 4's wide tape; run with max_cycles, halt = CycleLimit): a byte b <- b + 3 is stored and loaded
     back with LB — sign-extended to 64 bits when its top bit is set (execute.rs:477-499) — then divided, reduced and multiplied as the reference does it on `as i64` / u64 /
     u128 (quirks Q2, Q3): DIV and REM of a negative by a positive, DIVU of the same bits read as unsigned, MULH of two 64-bit values, REMU and DIV with the wide value as the
-    divisor.  Rows whose operands have bits above 40 go through the tape, the others (b < 0x80) through the chunk relation: both routes in one run, 12 rows per iteration."""
+    divisor.  Rows whose operands have bits above 40 go through the tape, the others (b < 0x80) through the chunk relation: both routes in one run, 12 rows per iteration.
+    (The byte reaches 0 in iteration 121, row 1455: the VM stops there with DivisionByZero — run it with fewer cycles.)"""
     E, O = encode, Opcode
     return Program.from_code([
         addi(6, 0, 0x8000), slli(6, 6, 1), addi(1, 0, 0x95),                                              # base 0x10000, the byte
