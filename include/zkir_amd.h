@@ -300,7 +300,7 @@ int zkir_main_trace_io_host(const zkir_trace_columns* trace, uint64_t n_real, co
 int zkir_main_trace_mem_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* scratch, uint32_t* out,
                                void* hip_stream);
 int zkir_main_trace_mem_host(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint32_t* out);
-/* The main trace of MODE 4 (round 6: mode 3 + the wide-arithmetic class — MULH / DIVU / REMU / DIV / REM, execute.rs:101-183, on operands below 2^40 — + hash syscalls as a
+/* The main trace of MODE 4 (round 6: mode 3 + the wide-arithmetic class — MULH / DIVU / REMU / DIV / REM, execute.rs:101-183: by a chunk relation on operands below 2^40, through the verifier-recomputed WIDE TAPE on raw 64-bit ones — + hash syscalls as a
  * tape + the code segment's boundary cell: 288 committed columns, six more 10-bit range values per row); arguments as zkir_main_trace_mem_launch / _host, plus the program's
  * code_size (header bytes 16..20): when it is 4 modulo 8 the last code word shares an 8-byte cell with the first data bytes, and stores into that cell's low half have no proof. */
 int zkir_main_trace_wide_launch(const zkir_trace_columns* trace, uint64_t n_real, const zkir_io_args* io, const uint64_t* mem_old, const uint32_t* mem_told, uint64_t code_size,
@@ -374,7 +374,8 @@ typedef struct zkir_public_inputs {
   const uint64_t* cell_bytes;  /* [n_cells] the cell's final bytes, little-endian */
   const uint32_t* cell_time;   /* [n_cells] the time of its last access = that row's cycle + 1 */
   uint64_t n_cells;
-  /* MODE 4 (`deferred` == 4, round 6): mode 3 WITH the wide-arithmetic class (MULH / DIVU / REMU / DIV / REM on operands below 2^40), the code segment's boundary cell, and
+  /* MODE 4 (`deferred` == 4, round 6): mode 3 WITH the wide-arithmetic class (MULH / DIVU / REMU / DIV / REM: constrained by a chunk relation on operands below 2^40; on raw 64-bit operands — `as i64`,
+   * 128-bit products — through the WIDE TAPE: one record (cycle, rs1, rs2, opcode) per such row, gathered by zkir_prove itself, the verifier computes the result), the code segment's boundary cell, and
    * HASH SYSCALLS as a tape: the proof carries one record per SHA-256 / Keccak-256 / BLAKE3 call (cycle, pointers, length, kind, and per touched 8-byte cell its bytes before
    * the call and the time of its previous access) and the verifier computes every digest itself.  PROVER side: hash_section = those records in the proof's own word layout
    * (csrc/hashcall.h), BORROWED from a zkir_memcheck_witness made with zkir_memcheck_witness_of_mode(.., 4, ..) (zkir_public_inputs_set_memory sets it).  A run that makes

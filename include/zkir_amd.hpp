@@ -406,7 +406,7 @@ enum class ProofMode : uint32_t {
   Deferred = 1,   // VMConfig::enable_deferred_model (relaxed AIR)
   Io = 2,         // default + the I/O argument: what the run read and wrote, and that it ended on the instruction its halt reason names
   Memory = 3,     // Io + the memory argument, the bitwise opcodes, the shifts and MUL: 43 of 50 opcodes constrained, memory consistent (whole runs; no hash syscalls)
-  Wide = 4,       // Memory + MULH / DIVU / REMU / DIV / REM on operands below 2^40, the code segment's boundary cell, and — given the host witness with its hash tape
+  Wide = 4,       // Memory + MULH / DIVU / REMU / DIV / REM (a chunk relation below 2^40, the verifier-recomputed wide tape on raw 64-bit operands), the code segment's boundary cell, and — given the host witness with its hash tape
                   // (zkir_memcheck_witness_of_mode(.., 4, ..) + zkir_public_inputs_set_memory) — hash syscalls, whose digests the verifier computes (round 6)
 };
 inline PublicInputs public_inputs(const zkir_runtime::ExecutionResult& result, const zkir_spec::Program& program, const std::vector<uint64_t>& inputs,

@@ -428,7 +428,9 @@ def public_inputs(log: DeltaLog, program: Program | bytes, inputs: Sequence[int]
     constrained, every access tied to a consistent memory; the proof carries the touched cells).  mem_witness = "device": zkir_prove computes the run's memory witness on the
     GPU (memcheck.hip: address-major sort + segmented scan); "host": it is computed here by the host's sequential replay (zkir_memcheck_witness_of — the independent
     implementation; needs no device) and handed to zkir_prove.  num_queries / pow_bits: the prover's FRI parameters (zkir_prover_params; 0 = the defaults, 50 + 12).
-    wide_mode = mode 4 (round 6): mode 3 with MULH / DIVU / REMU / DIV / REM constrained on operands below 2^40 (a run that feeds them wider registers has no proof)."""
+    wide_mode = mode 4 (round 6): mode 3 with MULH / DIVU / REMU / DIV / REM constrained — by a chunk relation on operands below 2^40, through the wide tape (a record per row, the verifier
+    recomputes the result on the raw 64-bit registers) above — hash syscalls as a tape, the code segment's boundary cell: every run of the VM that stays below 2^40 in its addresses and off
+    its own code has a mode-4 proof."""
     blob = bytes(program) if isinstance(program, (bytes, bytearray)) else program.to_bytes()
     arr = (C.c_uint64 * max(1, len(inputs)))(*[int(x) & (2**64 - 1) for x in inputs])
     out = PublicInputsC()
