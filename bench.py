@@ -784,7 +784,9 @@ def main():
             ms, pr, st = timed_prove(mtr, mpub4)
             assert rt.verify(pr, mpub4) == 0
             prove_by_mode[f"array loop ({mlog.n_rows} rows), mode 4 (288 + 128 columns; witness on the device)"] = {"prove_ms": ms, "stage_ms": dict(zip(PROVE_STAGES, st)), "proof_bytes": int(len(pr) * 4), "vs_mode_0": ms / base}
-            for label, prog in (("wide-arithmetic loop (6 of 18 rows MULH / DIVU / REMU / DIV / REM)", spec.wide_loop_program()), ("SHA-256 hash chain = configs[4]'s program (a hash syscall every 6 rows)", spec.sha256_chain_program())):
+            for label, prog in (("wide-arithmetic loop (6 of 18 rows MULH / DIVU / REMU / DIV / REM)", spec.wide_loop_program()),
+                                ("signed-division loop on raw 64-bit registers (6 of 12 rows wide, about half of them through the verifier-recomputed wide tape)", spec.signed_division_loop_program()),
+                                ("SHA-256 hash chain = configs[4]'s program (a hash syscall every 6 rows)", spec.sha256_chain_program())):
                 wblob = prog.to_bytes()
                 wlog = rt.interpret(wblob, [], rt.VMConfig(max_cycles=n, enable_execution_trace=True))
                 wddl = pl.upload(wlog); wtr = pl.DeviceTrace(wddl); pl.trace_fill(pl.trace_fill_args(wddl, wtr)); torch.cuda.synchronize()

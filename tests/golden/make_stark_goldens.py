@@ -91,7 +91,7 @@ SB_, LB_, ANDI_ = 0x38, 0x30, 0x13
 TAPE_LOOP = blob([i_(ADDI, 6, 0, 0x8000), i_(SLLI, 6, 6, 1), i_(ADDI, 1, 0, 0x95),
                   s_(SB_, 6, 1, 0), i_(LB_, 2, 6, 0), i_(ANDI_, 3, 1, 0x3F), i_(ADDI, 3, 3, 7),
                   r_(DIV, 4, 2, 3), r_(REM, 5, 2, 3), r_(DIVU, 7, 2, 3), r_(MULH, 8, 2, 2), r_(REMU, 9, 3, 2), r_(DIV, 10, 3, 2),
-                  i_(ADDI, 1, 1, 3), j_(JAL, 0, -44)])
+                  i_(ADDI, 1, 1, 2), j_(JAL, 0, -44)])
 MODE_CASES = [
     dict(name="mode4_signed_division_loop_700", blob=TAPE_LOOP, max_cycles=700, mode=4),
     dict(name="mode4_wide_loop_1000", blob=WIDE_LOOP, max_cycles=1000, mode=4),

@@ -577,7 +577,7 @@ def _mode3_case(which, witness="device", wide=False):
     if which.startswith("random"):
         blob, ins = pg.random_program(int(which[6:]), hashes=False)
     elif which == "signed_division_loop":                                 # (mode 4) both routes of the wide class: sign-extended bytes (the tape) and small ones (the chunk relation)
-        blob, ins, cfg = spec.signed_division_loop_program().to_bytes(), [], dict(max_cycles=1300)      # (the byte reaches 0 — a zero divisor, a VM error — in iteration 121)
+        blob, ins, cfg = spec.signed_division_loop_program().to_bytes(), [], dict(max_cycles=3000)
     elif which == "memloop":                                              # a loop that walks an array: store i * 3 at A + 8 i, load it back as bytes / halfwords / words, sum, WRITE the sum
         blob, ins = spec.memory_loop_program(200).to_bytes(), []
     elif which.endswith("_on_code"):                                      # the reference's test as written: its data at 0x1000, the first code word
@@ -644,6 +644,36 @@ def test_mode4_proof_bytes_match_oracle_and_verify(which, witness):
         t[pos] = (int(t[pos]) + 1) % P
         assert so.verify(t) != 0 and rt.verify(t) == so.verify(t), pos
     ctx.close(); log.close()
+
+
+@pytest.mark.parametrize("which", ["wide_grid", "loads_stores", "random3", "signed_division_loop", "sha256_hello"])
+def test_mode4_device_main_trace_equals_the_oracles(which):
+    """main_trace_kernel<4> + wide_tape_fix_kernel against the oracle's main trace, every committed column of every row.  The row kernel sits at 256 registers with spilled
+    SGPRs; in round 6 a variant of it with 64-bit division inlined read four registers from wrong addresses on gfx950 — the proofs differed, but this comparison names the column."""
+    import ctypes as C
+    import torch
+    blob, ins, ores, log, tr, opub, pub = _mode3_case(which, "host", wide=True)
+    nr = len(ores.rows)
+    N = 1 << so.padded_log_n(nr); wm = so.committed_width(4)
+    out = torch.zeros((wm // 8, N, 8), dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(2 * N + 2 * (N // 1024 + 2) + 64, dtype=torch.int32, device="cuda")
+    tape = torch.tensor([int(x) - (1 << 64) if int(x) >> 63 else int(x) for x in ins] if len(ins) else [0], dtype=torch.int64, device="cuda")
+
+    class IoArgs(C.Structure):
+        _fields_ = [("inputs", C.c_void_p), ("n_inputs", C.c_uint64), ("writes_before", C.c_uint64), ("reads_before", C.c_uint64)]
+    io = IoArgs(tape.data_ptr(), len(ins), 0, 0)
+    mo = torch.from_numpy(np.ctypeslib.as_array(C.cast(pub.mem_old, C.POINTER(C.c_uint64)), (nr,)).astype(np.int64)).cuda()
+    mt = torch.from_numpy(np.ctypeslib.as_array(C.cast(pub.mem_told, C.POINTER(C.c_uint32)), (nr,)).astype(np.int32)).cuda()
+    L = rt.lib()
+    L.zkir_main_trace_wide_launch.restype = C.c_int
+    L.zkir_main_trace_wide_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.zkir_main_trace_wide_launch(C.byref(tr.c), nr, C.byref(io), mo.data_ptr(), mt.data_ptr(), int.from_bytes(blob[16:20], "little"), scratch.data_ptr(), out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32).transpose(0, 2, 1).reshape(wm, N)
+    want = so.to_committed(so.main_trace(ores.rows, opub), 4)
+    for k in range(wm):
+        assert np.array_equal(got[k], want[k]), f"committed column {k}: first difference at row {int(np.nonzero(got[k] != want[k])[0][0])}"
+    log.close()
 
 
 def test_mode4_wide_tape_raw_64_bit_operands():

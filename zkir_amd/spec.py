@@ -355,18 +355,17 @@ def wide_loop_program() -> Program:
 
 
 def signed_division_loop_program() -> Program:
-    """An ENDLESS loop over the wide opcodes on RAW 64-bit registers (AIR mode 4's wide tape; run with max_cycles, halt = CycleLimit): a byte b <- b + 3 is stored and loaded
+    """An ENDLESS loop over the wide opcodes on RAW 64-bit registers (AIR mode 4's wide tape; run with max_cycles, halt = CycleLimit): an odd byte b <- b + 2 is stored and loaded
     back with LB — sign-extended to 64 bits when its top bit is set (execute.rs:477-499) — then divided, reduced and multiplied as the reference does it on `as i64` / u64 /
     u128 (quirks Q2, Q3): DIV and REM of a negative by a positive, DIVU of the same bits read as unsigned, MULH of two 64-bit values, REMU and DIV with the wide value as the
-    divisor.  Rows whose operands have bits above 40 go through the tape, the others (b < 0x80) through the chunk relation: both routes in one run, 12 rows per iteration.
-    (The byte reaches 0 in iteration 121, row 1455: the VM stops there with DivisionByZero — run it with fewer cycles.)"""
+    divisor.  Rows whose operands have bits above 40 go through the tape, the others (b < 0x80) through the chunk relation: both routes in one run, 12 rows per iteration."""
     E, O = encode, Opcode
     return Program.from_code([
         addi(6, 0, 0x8000), slli(6, 6, 1), addi(1, 0, 0x95),                                              # base 0x10000, the byte
         # L:
         E(O.SB, rs1=6, rs2=1, imm=0), E(O.LB, 2, 6, imm=0), E(O.ANDI, 3, 1, imm=0x3F), addi(3, 3, 7),      # r2 = sext(byte), a divisor 7..70
         E(O.DIV, 4, 2, 3), E(O.REM, 5, 2, 3), E(O.DIVU, 7, 2, 3), E(O.MULH, 8, 2, 2), E(O.REMU, 9, 3, 2), E(O.DIV, 10, 3, 2),
-        addi(1, 1, 3), jal(0, -44),
+        addi(1, 1, 2), jal(0, -44),                                                                      # (the byte stays odd: never a zero divisor)
     ])
 
 
