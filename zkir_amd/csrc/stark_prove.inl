@@ -1521,26 +1521,33 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
       E4 lamv[air::N_TUPLE + 1];
       for (int j = 0; j <= air::N_TUPLE; j++) for (int c4 = 0; c4 < 4; c4++) lamv[j].c[c4] = pp->lk[air::LK_LAM + 4 * j + c4];
       E4 alpha_lm; for (int c4 = 0; c4 < 4; c4++) alpha_lm.c[c4] = pp->lk[air::LK_ALPHA + c4];
-      std::vector<E4> d(wrecs.size()), pre(wrecs.size());
-      for (size_t k = 0; k < wrecs.size(); k++) {
-        const uint32_t* r = wrecs[k].w;
-        const uint64_t a = (uint64_t)r[1] | ((uint64_t)r[2] << 20) | ((uint64_t)r[3] << 40), b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
-        const uint64_t y = air::wide_result(r[7], a, b);
-        const uint32_t e[11] = {r[0] % bb::P, r[1], r[2], r[3], r[4], r[5], r[6], (uint32_t)(y & 0xFFFFF), (uint32_t)((y >> 20) & 0xFFFFF), (uint32_t)(y >> 40), r[7]};
-        E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_WIDE));
-        for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[j], bb::to_mont(e[j])));
-        d[k] = bb::e_sub(alpha_lm, fp);
-      }
-      E4 acc = bb::e_one_m();
-      for (size_t k = 0; k < d.size(); k++) { pre[k] = acc; acc = bb::e_mul_m(acc, d[k]); }
-      E4 inv = bb::e_inv_m(acc);
       wide_aux.resize(wrecs.size());
-      for (size_t k = d.size(); k-- > 0;) {
-        const E4 dk = bb::e_mul_m(inv, pre[k]);
-        inv = bb::e_mul_m(inv, d[k]);
-        T = bb::e_add(T, dk);
-        wide_aux[k].row = wrecs[k].w[0]; wide_aux[k].pad[0] = wide_aux[k].pad[1] = wide_aux[k].pad[2] = 0; wide_aux[k].h = dk;
-      }
+      const unsigned parts = hashcall::parts_for(wrecs.size() / 4);
+      std::vector<E4> Tpart(parts, bb::e_zero());
+      hashcall::for_calls(wrecs.size(), parts, [&](unsigned part, size_t lo, size_t hi) {        // (host threads: a run with 2^18 tape rows is ~50 ms on one core)
+        std::vector<E4> d(hi - lo), pre(hi - lo);
+        for (size_t k = lo; k < hi; k++) {
+          const uint32_t* r = wrecs[k].w;
+          const uint64_t a = (uint64_t)r[1] | ((uint64_t)r[2] << 20) | ((uint64_t)r[3] << 40), b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
+          const uint64_t y = air::wide_result(r[7], a, b);
+          const uint32_t e[11] = {r[0] % bb::P, r[1], r[2], r[3], r[4], r[5], r[6], (uint32_t)(y & 0xFFFFF), (uint32_t)((y >> 20) & 0xFFFFF), (uint32_t)(y >> 40), r[7]};
+          E4 fp = bb::e_mul_fm(lamv[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_WIDE));
+          for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lamv[j], bb::to_mont(e[j])));
+          d[k - lo] = bb::e_sub(alpha_lm, fp);
+        }
+        E4 acc = bb::e_one_m(), Tp = bb::e_zero();
+        for (size_t k = 0; k < d.size(); k++) { pre[k] = acc; acc = bb::e_mul_m(acc, d[k]); }
+        E4 inv = bb::e_inv_m(acc);
+        for (size_t k = d.size(); k-- > 0;) {
+          const E4 dk = bb::e_mul_m(inv, pre[k]);
+          inv = bb::e_mul_m(inv, d[k]);
+          Tp = bb::e_add(Tp, dk);
+          HashAux& x = wide_aux[lo + k];
+          x.row = wrecs[lo + k].w[0]; x.pad[0] = x.pad[1] = x.pad[2] = 0; x.h = dk;
+        }
+        Tpart[part] = Tp;
+      });
+      for (const E4& tp : Tpart) T = bb::e_add(T, tp);
     }
     const E4 tn = bb::e_mul_fm(T, bb::to_mont(bb::inv((uint32_t)(N % bb::P))));
     for (int k = 0; k < 4; k++) pp->lk[air::LK_TN + k] = tn.c[k];

@@ -708,20 +708,26 @@ int verify_impl(const uint32_t* w, uint64_t len, const zkir_public_inputs* expec
       }
       // (mode 4 d) the wide tape: + 1 / (alpha - fp(cycle, rs1, rs2, what the reference writes, opcode)) per record — the result is computed HERE (air::wide_result)
       if (mode == 4 && n_wide) {
-        std::vector<E4> wd(n_wide), wpre(n_wide);
-        for (size_t k = 0; k < n_wide; k++) {
-          const uint32_t* r = wide_words + 1 + 8 * k;
-          const uint64_t a = (uint64_t)r[1] | ((uint64_t)r[2] << 20) | ((uint64_t)r[3] << 40), b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
-          const uint64_t y = air::wide_result(r[7], a, b);
-          const uint32_t e[11] = {r[0] % bb::P, r[1], r[2], r[3], r[4], r[5], r[6], (uint32_t)(y & 0xFFFFF), (uint32_t)((y >> 20) & 0xFFFFF), (uint32_t)(y >> 40), r[7]};
-          E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_WIDE));
-          for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(e[j])));
-          wd[k] = bb::e_sub(alpha_l, fp);
-        }
-        E4 wacc = bb::e_one_m();
-        for (size_t k = 0; k < n_wide; k++) { wpre[k] = wacc; wacc = bb::e_mul_m(wacc, wd[k]); }
-        E4 winv = bb::e_inv_m(wacc);
-        for (size_t k = n_wide; k-- > 0;) { T_hash = bb::e_add(T_hash, bb::e_mul_m(winv, wpre[k])); winv = bb::e_mul_m(winv, wd[k]); }
+        const unsigned parts = hashcall::parts_for(n_wide / 4);
+        std::vector<E4> Tpart(parts, bb::e_zero());
+        hashcall::for_calls(n_wide, parts, [&](unsigned part, size_t lo, size_t hi) {             // (host threads; each part inverts its own batch)
+          std::vector<E4> wd(hi - lo), wpre(hi - lo);
+          for (size_t k = lo; k < hi; k++) {
+            const uint32_t* r = wide_words + 1 + 8 * k;
+            const uint64_t a = (uint64_t)r[1] | ((uint64_t)r[2] << 20) | ((uint64_t)r[3] << 40), b = (uint64_t)r[4] | ((uint64_t)r[5] << 20) | ((uint64_t)r[6] << 40);
+            const uint64_t y = air::wide_result(r[7], a, b);
+            const uint32_t e[11] = {r[0] % bb::P, r[1], r[2], r[3], r[4], r[5], r[6], (uint32_t)(y & 0xFFFFF), (uint32_t)((y >> 20) & 0xFFFFF), (uint32_t)(y >> 40), r[7]};
+            E4 fp = bb::e_mul_fm(lam[air::N_TUPLE], bb::to_mont((uint32_t)air::TAG_WIDE));
+            for (int j = 0; j < 11; j++) fp = bb::e_add(fp, bb::e_mul_fm(lam[j], bb::to_mont(e[j])));
+            wd[k - lo] = bb::e_sub(alpha_l, fp);
+          }
+          E4 wacc = bb::e_one_m(), Tp = bb::e_zero();
+          for (size_t k = 0; k < wd.size(); k++) { wpre[k] = wacc; wacc = bb::e_mul_m(wacc, wd[k]); }
+          E4 winv = bb::e_inv_m(wacc);
+          for (size_t k = wd.size(); k-- > 0;) { Tp = bb::e_add(Tp, bb::e_mul_m(winv, wpre[k])); winv = bb::e_mul_m(winv, wd[k]); }
+          Tpart[part] = Tp;
+        });
+        for (const E4& tp : Tpart) T_hash = bb::e_add(T_hash, tp);
       }
     }
     for (size_t u = 0; u < n_code; u++) {
