@@ -439,13 +439,16 @@ int zkir_prove_result(const zkir_result* result, const zkir_prover_params* param
 void zkir_proof_bytes_free(uint8_t* proof);
 uint32_t zkir_proof_num_queries(void);            /* the default (50) */
 uint32_t zkir_proof_version(void);                /* of modes 0 / 1 (10) */
-uint32_t zkir_proof_version_of_mode(uint32_t mode);   /* modes 2 / 3: 11 (round 5: EBREAK is a class of its own, the I/O section is in the transcript, mode 3 refuses accesses to the code segment) */
+uint32_t zkir_proof_version_of_mode(uint32_t mode);   /* modes 2 / 3: 11 (round 5: EBREAK is a class of its own, the I/O section is in the transcript, mode 3 refuses accesses to the code segment); mode 4: 12 (round 6) */
 /* Verifier of the proof of a WHOLE run (host only, no device): 0 = accepted, otherwise the number of the failed check (1-5
  * malformed, 6 public inputs differ from `expect`, 7 the run does not start in the VM's initial state (cycle 0, entry point, zero
  * registers), 8 the program carried in the proof is malformed or is not the one program_digest / entry_point name, 10 constraints at
  * zeta (incl. the lookup argument: the verifier computes the table side from that program and the multiplicities in the proof), 11 final
  * codeword degree, 12 grinding, 20-27 query / Merkle / FRI checks, 30 length; modes 2 / 3 also 50-53 = zkir_verify_io's checks on the tapes the proof carries, 51 the
- * counters' ends; mode 3 also 54 = the touched cells are not canonical 8-byte cell addresses in strictly increasing order; a mode-3 proof is never a segment: 2).
+ * counters' ends; mode 3 also 54 = the touched cells are not canonical 8-byte cell addresses in strictly increasing order; a mode-3 proof is never a segment: 2;
+ * modes 3 / 4 also 55 = a touched cell / a hash call's output overlaps the code segment (mode 4 admits the boundary cell); mode 4 also 56 = a malformed hash-tape record
+ * (ranges, order, cell count, a previous access that is not before the call), 57 = a malformed wide-tape record (a limb out of range, not an opcode 3..7, a zero divisor, cycles
+ * not increasing); a tape whose records are well-formed but are not the run's fails the lookup argument (10)).
  * expect may be NULL: the header's own public inputs are then only checked for internal consistency.
  * The queries (independent, ~10,000 Poseidon2 permutations of Merkle paths at 2^20 rows) are checked on up to eight host threads (half the logical cores; ZKIR_VERIFY_THREADS=n
  * overrides); the verdict is the first failing query's in query order, as a sequential check would give. */
