@@ -132,10 +132,10 @@ def mul_grid():
     return _p(code + [EB]), [], {}
 
 
-def wide_grid():
+def wide_grid(vals=None):
     """MULH DIVU REMU DIV REM (execute.rs:101-183) on a grid of operands BELOW 2^40 (AIR mode 4's domain): zero and one, all ones, the sign bit of a 40-bit value (positive as an
     i64: quirk Q2), every chunk at its extremes (the largest carries of the 80-bit product), dividend < divisor, equal operands, powers of two, rs1 = rs2 = rd, rd = r0."""
-    vals = [0, 1, 2, 0xFFFFFFFFFF, 0x8000000000, 0xF0F0A5C3E1, 0x0312345678, 1023, 1024, 0xFFFFF, 0x100000, 0x3FF003FF, 0xFFC00FFC00, 0x7FFFFFFFFF]
+    vals = vals or [0, 1, 2, 0xFFFFFFFFFF, 0x8000000000, 0xF0F0A5C3E1, 0x0312345678, 1023, 1024, 0xFFFFF, 0x100000, 0x3FF003FF, 0xFFC00FFC00, 0x7FFFFFFFFF]
     code = []
     for a in vals:
         code += li40(1, a)

@@ -194,6 +194,16 @@ def test_wide_arithmetic_is_constrained():
     assert np.array_equal(M[C_OM][rows] != 0, ops[rows] == 3) and np.array_equal(M[C_G][rows] != 0, ops[rows] >= 6)       # DIV / REM: the word's variant bit
     assert [int(M[C_WE + k][rows].max()) for k in range(8)] == [1] * 8            # every carry bit but the last occurs (c5 = 2048 would need both operands all ones AND c4 maximal)
 
+    # the forgeries on a SMALL grid (the same operand pairs; a quarter of the rows: each forgery is a constraint sweep and a proof)
+    blob, ins, _ = pg.wide_grid([0, 1, 0xF0F0A5C3E1, 0x0312345678, 1024, 0xFFFFFFFFFF])
+    ores, pub = _case(blob)
+    M, cells = so.main_trace(ores.rows, pub), so.mem_cells(ores.rows, pub)
+    regs, words = ores.rows["registers"], ores.rows["instruction"]
+    ops = words & 0x7F
+    nr = len(ops)
+    rows = np.nonzero((ops >= 3) & (ops <= 7) & (np.arange(nr) < nr - 1))[0]
+    assert so.failing_constraints(M, pub, cells)[0] == 0
+
     def bad(edit):
         F = M.copy(); edit(F)
         return so.failing_constraints(F, pub, cells)[0] > 0 and so.verify(so.prove_matrix_mem(F, pub, cells), None) == 10
