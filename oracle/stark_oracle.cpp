@@ -520,7 +520,7 @@ static void main_trace(const PackedRow* rows, size_t n_real, const Public& pub, 
   const int mode = pub.mode();
   out.assign((size_t)logical_width(mode) * N, 0);
   auto col = [&](int k) { return out.data() + (size_t)k * N; };
-  const bool D = mode == 1, IO = mode >= 2, MEM = mode >= 3;
+  const bool D = mode == 1, IO = mode >= 2;
   uint64_t oc = pub.writes_before, reads = pub.reads_before;          // mode 2: WRITE / READ ecalls executed so far (syscall.rs:110-121)
   std::map<uint64_t, std::pair<uint64_t, uint32_t>> memory;           // mode 3: the replayed memory, cell address -> (bytes, time of the last access); untouched cells hold the program image
   const uint64_t Bcell = boundary_cell(pub.blob, pub.blob_len);       // (mode 4)
@@ -1737,9 +1737,8 @@ static int constraints_sum(const E* loc, const E* nxt, const E* aloc, const E* a
 }
 static int num_constraints(int mode = 0) {                                // by a dry run (the list above is the definition)
   std::vector<E> z(W_MAX, e_from(0)), ap(MAX_CONSTRAINTS, e_from(0));
-  E r; Public pub; LookupParams lp;
+  E r; Public pub; LookupParams lp{};
   pub.deferred = (uint32_t)mode;
-  memset(&lp, 0, sizeof lp);
   return constraints_sum(z.data(), z.data(), z.data(), z.data(), e_from(0), e_from(0), e_from(0), pub, lp, ap.data(), r);
 }
 

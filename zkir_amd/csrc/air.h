@@ -961,8 +961,8 @@ BB_HD void eval(Ops& o, const uint32_t* first_m, const uint32_t* last_m, int mod
         if constexpr (k < 4) {                                                                      // low half: + ADD_k + c_(k-1) = LO_k + 2^10 c_k; the carry OUT of position 3 exists on MULH rows only
           o.acc_mul(t, kd, G4[k]);
           V lin = R[k];
-          if (k < 3) lin = o.add(lin, o.mulc(cr[k], T10));
-          if (k) lin = o.sub(lin, cr[k - 1]);
+          if constexpr (k < 3) lin = o.add(lin, o.mulc(cr[k], T10));
+          if constexpr (k > 0) lin = o.sub(lin, cr[k - 1]);
           if constexpr (k == 3) o.push(I_WA_EQ + k, o.lsub(o.sub(o.acc_val(t), o.mul(lin, Kin)), o.mul(o.mulc(cr[3], T10), om)));
           else o.push(I_WA_EQ + k, o.lsub(o.acc_val(t), o.mul(lin, Kin)));
         } else {                                                                                    // high half (MULH): + c_(k-1) = HI_(k-4) + 2^10 c_k (k = 6: 2^10 HI_3); a division has nothing there
