@@ -1038,7 +1038,7 @@ def main():
                       "opt-in modes (round 4, `prove_by_mode`): 2 = + the I/O argument (what the run read / wrote is proven), 3 = + the memory argument, the bitwise opcodes and the shifts "
                       "(43 of 50 opcodes, memory consistency; 264 + 96 columns, 636 constraints; the memory witness is made on the device), 4 (round 6, format v12) = 3 + MULH / DIVU / REMU / DIV / REM on operands "
                       "below 2^40 by a chunk relation and on raw 64-bit operands through a verifier-recomputed wide tape (all 50 opcodes carry a statement), the hash syscalls through a tape the verifier recomputes "
-                      "(SHA-256 / Keccak / BLAKE3 digests are NOT arithmetised: the verifier hashes the tape's inputs itself), the boundary cell between code and data (288 + 128 columns, 707 constraints)",
+                      "(SHA-256 / Keccak / BLAKE3 digests are NOT arithmetised: the verifier hashes the tape's inputs itself), the boundary cell between code and data (288 + 128 columns, 712 constraints)",
             "prove_by_mode": prove_by_mode,
             "pipelined_end_to_end": pipelined, "pipelined_commit_end_to_end": pipelined_commit, "segment_prove": segment_prove,
             "merkle_root": root, "merkle_roots_all_ranks": roots, "allgather_cap_ms": stage_ms.get("allgather_cap"),
