@@ -104,7 +104,7 @@ inline void for_calls(size_t n_calls, unsigned parts, F&& fn) {
 inline unsigned parts_for(size_t n_calls) {
   unsigned hw = std::thread::hardware_concurrency() / 2;
   if (hw < 1) hw = 1;
-  if (hw > 16) hw = 16;
+  if (hw > 32) hw = 32;                                         // (half the logical cores, at most 32: a 2^22-cycle hash chain is 2.4 s of table-side work on one)
   const size_t by_work = n_calls / 512 + 1;                      // (a part should be worth a thread's start)
   return (unsigned)std::min<size_t>(hw, by_work);
 }

@@ -1341,7 +1341,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   }
   // (mode 4) the hash calls: the tape the proof carries (from the caller's host witness), checked as the verifier will check it, observed like the memory section
   std::vector<hashcall::Call> hcalls;
-  std::vector<uint32_t> hash_sec;
+  static const uint32_t no_calls[1] = {0u};
+  struct { const uint32_t* p; size_t n; const uint32_t* data() const { return p; } size_t size() const { return n; } } hash_sec{no_calls, 1};   // a VIEW of the caller's tape (a 2^22-cycle chain: 134 MB — not copied)
   const double t_hash0 = since(t_entry);
   if (WIDE) {
     if (pub->hash_section && pub->hash_section_words) {
@@ -1351,8 +1352,8 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
         char m[160]; snprintf(m, sizeof m, "zkir_prove: the hash section of the public inputs is malformed (check %d): build it with zkir_memcheck_witness_of_mode(.., 4, ..)", hrc ? hrc : 4);
         zkir::set_last_error({ZKIR_ERR_ARGUMENT, m}); return ZKIR_ERR_ARGUMENT;
       }
-      hash_sec.assign(pub->hash_section, pub->hash_section + used);
-    } else hash_sec.push_back(0u);
+      hash_sec.p = pub->hash_section; hash_sec.n = used;
+    }
     if (hcalls.size() != io_counts[1]) {
       char m[256];
       snprintf(m, sizeof m, "zkir_prove: the run makes %u hash syscalls and the public inputs' hash section records %llu: a run with hash syscalls is proven (mode 4) from the host "
@@ -1743,11 +1744,12 @@ int zkir_prove(const zkir_stark_ctx* c, const zkir_trace_columns* trace, const z
   for (auto& q : queries) q = ch.sample_bits((int)log_n);
 
   // ---- 6. serialise: header + openings on the host, query section gathered on the device -----------------------------------
+  head.reserve(head.size() + blob_len / 2 + io_sec.size() + mem_sec.size() + (WIDE ? hash_sec.size() + wide_sec.size() : 0) + n_mult + 8 * (size_t)WT + 4096);   // (one allocation: the tapes of mode 4 can be 100 MB)
   head.push_back((uint32_t)blob_len);                                         // the program: byte length, then 16-bit halfwords
   for (uint64_t i = 0; i < blob_len; i += 2) head.push_back((uint32_t)blob[i] | (i + 1 < blob_len ? (uint32_t)blob[i + 1] << 8 : 0u));
   if (IO) head.insert(head.end(), io_sec.begin(), io_sec.end());              // the I/O section: the tapes and the halt reason the io digest is a digest of
   if (MEM) head.insert(head.end(), mem_sec.begin(), mem_sec.end());           // (mode 3) the touched cells
-  if (WIDE) { head.insert(head.end(), hash_sec.begin(), hash_sec.end()); head.insert(head.end(), wide_sec.begin(), wide_sec.end()); }   // (mode 4) the hash calls, the wide tape
+  if (WIDE) { head.insert(head.end(), hash_sec.data(), hash_sec.data() + hash_sec.size()); head.insert(head.end(), wide_sec.begin(), wide_sec.end()); }   // (mode 4) the hash calls, the wide tape
   head.insert(head.end(), mult, mult + n_mult);                          // ROM multiplicities, range multiplicities (mode 3: LOW3 | BYTE | NIBBLE)
   head.insert(head.end(), troot, troot + 4); head.insert(head.end(), aroot, aroot + 4); head.insert(head.end(), qroot, qroot + 4);
   for (int k = 0; k < WT; k++) head.insert(head.end(), t_z[k].c, t_z[k].c + 4);
